@@ -1,0 +1,87 @@
+"""Model blob reader + per-environment state record packing (layout: include/agx_blob.h)."""
+import json
+import os
+
+import numpy as np
+
+from .model import compiler as L   # layout constant tables only (H, P, R, F, C, G, T, E)
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+
+
+class ModelBlob:
+    def __init__(self, words, meta=None):
+        self.words = np.ascontiguousarray(words, dtype=np.uint32)
+        self.f = self.words.view(np.float32)
+        self.i = self.words.view(np.int32)
+        assert self.i[L.H['MAGIC']] == L.MAGIC and self.i[L.H['VERSION']] == L.VERSION, 'bad model blob'
+        self.meta = meta or {}
+        self.h = {k: int(self.i[v]) for k, v in L.H.items() if k != 'COUNT'}
+        self.ndof, self.nfree, self.nhuman = self.h['NDOF'], self.h['NFREE'], self.h['NHUMAN']
+        self.nfood, self.act_dim, self.obs_dim = self.h['NFOOD'], self.h['ACT_DIM'], self.h['OBS_DIM']
+        self.state_words = self.h['STATE_WORDS']
+
+    @classmethod
+    def load(cls, name='feeding_jaco'):
+        path = os.path.join(DATA_DIR, name + '.agxblob')
+        meta_path = os.path.join(DATA_DIR, name + '.meta.json')
+        meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+        return cls(np.fromfile(path, dtype=np.uint32), meta)
+
+    # ---- sections --------------------------------------------------------------------------
+    def param(self, key):
+        return float(self.f[self.h['OFF_PARAMS'] + L.P[key]])
+
+    def set_param(self, key, value):
+        """Returns a copy of the blob with one PARAMS entry changed (tests, ablations)."""
+        w = self.words.copy()
+        w.view(np.float32)[self.h['OFF_PARAMS'] + L.P[key]] = value
+        return ModelBlob(w, self.meta)
+
+    def robot_f(self, d, key, n=1):
+        o = self.h['OFF_ROBOT'] + d * L.R['STRIDE'] + L.R[key]
+        return self.f[o:o + n].astype(np.float64) if n > 1 else float(self.f[o])
+
+    def robot_i(self, d, key):
+        return int(self.i[self.h['OFF_ROBOT'] + d * L.R['STRIDE'] + L.R[key]])
+
+    def free_f(self, b, key, n=1):
+        o = self.h['OFF_FREE'] + b * L.F['STRIDE'] + L.F[key]
+        return self.f[o:o + n].astype(np.float64) if n > 1 else float(self.f[o])
+
+    def task_f(self, key, n=1):
+        o = self.h['OFF_TASK'] + L.T[key]
+        return self.f[o:o + n].astype(np.float64) if n > 1 else float(self.f[o])
+
+    def task_i(self, key):
+        return int(self.i[self.h['OFF_TASK'] + L.T[key]])
+
+    def collider(self, c):
+        o = self.h['OFF_COLL'] + c * L.C['STRIDE']
+        nv, vo = int(self.i[o + L.C['NVERT']]), int(self.i[o + L.C['VOFF']])
+        v0 = self.h['OFF_VERT'] + 3 * vo
+        return dict(body=int(self.i[o + L.C['BODY']]), radius=float(self.f[o + L.C['RADIUS']]),
+                    friction=float(self.f[o + L.C['FRICTION']]), tag=int(self.i[o + L.C['TAG']]),
+                    verts=self.f[v0:v0 + 3 * nv].reshape(nv, 3).astype(np.float64))
+
+    # ---- state records ------------------------------------------------------------------------
+    def new_state(self, n=1):
+        return np.zeros((n, self.state_words), dtype=np.float32)
+
+    def view(self, state):
+        """Named views into a (n, state_words) float32 array (writes go through)."""
+        h = self.h
+        s = state.reshape(-1, self.state_words)
+        si = s.view(np.int32)
+        e = h['S_ENV']
+        return dict(
+            q=s[:, h['S_Q']:h['S_Q'] + self.ndof], qd=s[:, h['S_QD']:h['S_QD'] + self.ndof],
+            qt=s[:, h['S_QT']:h['S_QT'] + self.ndof],
+            free=s[:, h['S_FREE']:h['S_FREE'] + 13 * self.nfree].reshape(-1, self.nfree, 13),
+            base=s[:, h['S_BASE']:h['S_BASE'] + 7],
+            human=s[:, h['S_HUMAN']:h['S_HUMAN'] + 7 * self.nhuman].reshape(-1, self.nhuman, 7),
+            plane_friction=s[:, e + L.E['PLANE_FRICTION']], gender=si[:, e + L.E['GENDER']],
+            target=s[:, e + L.E['TARGET']:e + L.E['TARGET'] + 3],
+            food_alive=si[:, e + L.E['FOOD_ALIVE']], food_active=si[:, e + L.E['FOOD_ACTIVE']],
+            iteration=si[:, e + L.E['ITERATION']], task_success=si[:, e + L.E['TASK_SUCCESS']],
+            rng=si[:, e + L.E['RNG']:e + L.E['RNG'] + 2], total_food=si[:, e + L.E['TOTAL_FOOD']])

@@ -1,0 +1,485 @@
+"""Model compiler: reference assets + task tables -> flat model blob (include/agx_blob.h).
+
+What PyBullet assembles at ``reset()`` for FeedingJaco-v1 (assistive_gym/envs/feeding.py:114-182)
+is compiled here once into arrays: the Jaco kinematic tree with fixed links merged into their
+parents (assets/jaco/j2s7s300_gym.urdf), the tool / bowl / food free bodies (agents/tool.py:10-47,
+agents/furniture.py:32-34, feeding.py:158-166), convex collision geometry, the static collision
+pair table (filters: tool.py:42-44, jaco.py:17), friction, motor gains (feeding.py:122,
+robot.py:36-37,76-79), the tool constraint (tool.py:46-47, jaco.py:26,31) and the task constants
+(config.ini:15-19,39-46).
+
+Runs where the reference assets exist (this container: /root/reference); the resulting blob is
+committed under assistive_gym_amd/data/ and is what the GPU box loads.
+
+Bullet-internal conventions that cannot be checked here (no Bullet source on the box) are kept
+as explicit parameters and marked [BULLET-UNVERIFIED]:
+  * link inertia = box inertia of the collision AABB in the inertial frame unless
+    URDF_USE_INERTIA_FROM_FILE is passed (only pr2.py:52 passes it);
+  * convex-hull collision margin 0.001 m; default lateral friction 0.5; combined friction =
+    product; ERP 0.2; 50 solver iterations; velocity damping 0.04 per link.
+"""
+import os
+
+import numpy as np
+
+from . import xform as X
+from .human import HumanModel
+from .meshio import load_obj_groups, load_dae_vertices, convex_hull_vertices, reduce_hull
+from .urdf import Urdf
+
+# ---- constants mirrored from include/agx_blob.h (checked by tests/test_blob_layout.py) ----------
+H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT=7, NGROUP=8, NFOOD=9, ACT_DIM=10,
+         OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
+         STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
+         NDIR=29, OFF_DIRS=30, COUNT=40)
+P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
+         LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
+         HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, COUNT=24)
+R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, COM=11, MASS=14, INERTIA=15, LOWER=21, UPPER=22, HAS_LIMIT=23, KP=24, KD=25,
+         MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, STRIDE=32)
+F = dict(MASS=0, INERTIA=1, GRAVITY=4, REFPOS=5, REFQUAT=8, KIND=12, RADIUS=13, STRIDE=16)
+C = dict(BODY=0, NVERT=1, VOFF=2, RADIUS=3, FRICTION=4, TAG=5, AABB_C=6, AABB_H=9, STRIDE=12)
+G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
+T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV=7, SUCCESS_FRAC=8, MOUTH_DIST=9,
+         SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_BODY=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
+         TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COUNT=40)
+E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
+         TOTAL_FOOD=11, COUNT=16)
+BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
+TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8)
+KIND = dict(TOOL=1, BOWL=2, FOOD=3)
+MAGIC, VERSION = 0x31584741, 3
+
+HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
+DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
+
+DEFAULT_ASSETS = '/root/reference/assistive_gym/envs/assets'
+
+
+def box_inertia(mass, lo, hi):
+    l = np.asarray(hi) - np.asarray(lo)
+    return mass / 12.0 * np.array([l[1] ** 2 + l[2] ** 2, l[0] ** 2 + l[2] ** 2, l[0] ** 2 + l[1] ** 2])
+
+
+def box_verts(centre, half):
+    c, h = np.asarray(centre, float), np.asarray(half, float)
+    s = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+    return c + s * h
+
+
+def icosphere42():
+    t = (1 + 5 ** 0.5) / 2
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    d = np.linalg.norm(v[:, None] - v[None], axis=2)
+    edge = d[d > 1e-9].min()
+    mids = []
+    for i in range(12):
+        for j in range(i + 1, 12):
+            if abs(d[i, j] - edge) < 1e-6:
+                m = v[i] + v[j]
+                mids.append(m / np.linalg.norm(m))
+    out = np.concatenate([v, np.array(mids)], axis=0)
+    assert len(out) == 42
+    return out
+
+
+class Scene:
+    """Accumulates colliders / vertices / groups while the scene is assembled."""
+
+    def __init__(self):
+        self.colliders = []   # dict(body, verts, radius, friction, tag)
+        self.ranges = {}
+
+    def begin(self, name):
+        self.ranges[name] = [len(self.colliders), None]
+
+    def end(self, name):
+        self.ranges[name][1] = len(self.colliders)
+
+    def add(self, body, verts, radius, friction, tag):
+        verts = np.atleast_2d(np.asarray(verts, dtype=np.float64))
+        self.colliders.append(dict(body=body, verts=verts, radius=float(radius), friction=float(friction), tag=tag))
+
+
+def link_collision_hulls(link, max_verts, assets_cache):
+    """Convex hull vertex sets of an URDF link's collision shapes, in the link frame.
+    Returns list of (verts, radius)."""
+    out = []
+    for c in link.collisions:
+        if c.kind == 'mesh':
+            key = (c.filename, tuple(c.scale))
+            if key not in assets_cache:
+                if c.filename.lower().endswith('.obj'):
+                    groups = load_obj_groups(c.filename, c.scale)
+                else:
+                    groups = [load_dae_vertices(c.filename) * c.scale]
+                assets_cache[key] = [convex_hull_vertices(g) for g in groups]
+            for hv in assets_cache[key]:
+                hv = reduce_hull(hv, max_verts) if max_verts else hv
+                out.append((X.apply(c.pos, c.quat, hv), HULL_MARGIN))
+        elif c.kind == 'box':
+            if np.all(np.asarray(c.size) <= 0):
+                continue  # zero-size end-effector marker box (j2s7s300_gym.urdf:389-393): no volume
+            out.append((X.apply(c.pos, c.quat, box_verts(np.zeros(3), np.asarray(c.size) / 2)), 0.0))
+        elif c.kind == 'sphere':
+            out.append((np.asarray(c.pos)[None], c.radius))
+        elif c.kind == 'capsule':
+            ends = np.array([[0, 0, -c.length / 2], [0, 0, c.length / 2]])
+            out.append((X.apply(c.pos, c.quat, ends), c.radius))
+        elif c.kind == 'cylinder':
+            # cylinder as a 2x16-gon prism core (no Jaco/feeding asset uses one on the hot path)
+            a = np.linspace(0, 2 * np.pi, 16, endpoint=False)
+            ring = np.stack([c.radius * np.cos(a), c.radius * np.sin(a)], axis=1)
+            pts = np.concatenate([np.c_[ring, np.full(16, -c.length / 2)], np.c_[ring, np.full(16, c.length / 2)]])
+            out.append((X.apply(c.pos, c.quat, pts), 0.0))
+    return out
+
+
+def aabb_inertia_in_inertial_frame(link, hulls):
+    """[BULLET-UNVERIFIED] btCompoundShape::calculateLocalInertia: box inertia of the compound AABB
+    expressed in the link's inertial frame (diagonal there)."""
+    if not hulls:
+        return np.diag(link.inertia).copy() if link.mass > 0 else np.zeros(3)
+    ip, iq = X.invert(link.com_pos, link.com_quat)
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for verts, radius in hulls:
+        v = X.apply(ip, iq, verts)
+        lo = np.minimum(lo, v.min(0) - radius)
+        hi = np.maximum(hi, v.max(0) + radius)
+    return box_inertia(link.mass, lo, hi)
+
+
+def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_gain, motor_force, max_hull_verts):
+    """Jaco: returns (records[ndof][R.STRIDE], per-dof collider lists, base collider list, maps)."""
+    u = Urdf(urdf_path)
+    cache = {}
+    n_pb = len(u.indexed_joints)
+    # world-at-q0 transform of every PyBullet link frame relative to the robot base (root link) frame
+    dof_of_pb = {}       # pb link index -> dof index of the moving link that carries it
+    dof_links = []       # pb index of each moving link
+    for j in u.indexed_joints:
+        if j.type in ('revolute', 'continuous', 'prismatic'):
+            assert j.type != 'prismatic'
+            dof_of_pb[j.index] = len(dof_links)
+            dof_links.append(j.index)
+    # carrier (moving ancestor, or -1 for base) and transform link-frame-in-carrier-frame for every link
+    carrier, rel = {-1: -1}, {-1: (np.zeros(3), np.array([0, 0, 0, 1.0]))}
+    for j in u.indexed_joints:
+        pidx = u.links[j.parent].index
+        if j.index in dof_of_pb:
+            carrier[j.index] = j.index
+            rel[j.index] = (np.zeros(3), np.array([0, 0, 0, 1.0]))
+        else:
+            carrier[j.index] = carrier[pidx]
+            rel[j.index] = X.compose(rel[pidx][0], rel[pidx][1], j.pos, j.quat)
+    rec = np.zeros((len(dof_links), R['STRIDE']), dtype=np.float64)
+    rec_int = {}
+    dof_colliders = [[] for _ in dof_links]
+    base_colliders = []
+    frictions = {}
+    # gather per-link inertial data into carriers
+    acc = {d: [] for d in range(len(dof_links))}
+    for idx in range(-1, n_pb):
+        link = u.link_by_index(idx)
+        hulls = link_collision_hulls(link, max_hull_verts, cache)
+        car = carrier[idx]
+        rp, rq = rel[idx]
+        if car == -1:
+            for verts, radius in hulls:
+                base_colliders.append((X.apply(rp, rq, verts), radius, link.lateral_friction, idx))
+            continue
+        d = dof_of_pb[car]
+        for verts, radius in hulls:
+            dof_colliders[d].append((X.apply(rp, rq, verts), radius, link.lateral_friction, idx))
+        if link.mass > 0:
+            idiag = aabb_inertia_in_inertial_frame(link, hulls)
+            cp, cq = X.compose(rp, rq, link.com_pos, link.com_quat)   # inertial frame in carrier frame
+            Rm = X.quat_to_mat(cq)
+            acc[d].append((link.mass, cp, Rm @ np.diag(idiag) @ Rm.T))
+    for d, pb in enumerate(dof_links):
+        j = u.indexed_joints[pb]
+        pidx = u.links[j.parent].index
+        pcar = carrier[pidx]
+        tp, tq = X.compose(rel[pidx][0], rel[pidx][1], j.pos, j.quat)   # joint frame in the parent carrier frame
+        rec[d, R['TPOS']:R['TPOS'] + 3] = tp
+        rec[d, R['TQUAT']:R['TQUAT'] + 4] = tq
+        rec[d, R['AXIS']:R['AXIS'] + 3] = j.axis / np.linalg.norm(j.axis)
+        m = sum(a[0] for a in acc[d])
+        com = sum(a[0] * a[1] for a in acc[d]) / m
+        I = np.zeros((3, 3))
+        for mi, ci, Ii in acc[d]:
+            r = ci - com
+            I += Ii + mi * ((r @ r) * np.eye(3) - np.outer(r, r))
+        rec[d, R['COM']:R['COM'] + 3] = com
+        rec[d, R['MASS']] = m
+        rec[d, R['INERTIA']:R['INERTIA'] + 6] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+        has_limit = j.type == 'revolute' and j.lower <= j.upper
+        rec[d, R['LOWER']] = j.lower if has_limit else -1e10     # agents/agent.py:223-225
+        rec[d, R['UPPER']] = j.upper if has_limit else 1e10
+        rec[d, R['JDAMP']] = j.damping
+        ints = dict(PARENT=-1 if pcar == -1 else dof_of_pb[pcar], HAS_LIMIT=int(has_limit), ACT=-1, PB_INDEX=pb)
+        if pb in arm_joints:
+            ints['ACT'] = arm_joints.index(pb)
+            rec[d, R['KP']], rec[d, R['KD']], rec[d, R['MAXF']] = motor_gain, 1.0, motor_force
+        elif pb in gripper_joints:
+            # Robot.set_gripper_open_position (agents/robot.py:76-79): kp 0.05, force 500
+            rec[d, R['KP']], rec[d, R['KD']], rec[d, R['MAXF']] = 0.05, 1.0, 500.0
+            rec[d, R['QT0']] = gripper_target
+        else:
+            # [BULLET-UNVERIFIED] default URDF joint motor: velocity target 0, max force = URDF effort
+            rec[d, R['KP']], rec[d, R['KD']], rec[d, R['MAXF']] = 0.0, 1.0, j.effort
+        rec_int[d] = ints
+    return dict(urdf=u, rec=rec, rec_int=rec_int, dof_links=dof_links, dof_of_pb=dof_of_pb, carrier=carrier, rel=rel,
+                dof_colliders=dof_colliders, base_colliders=base_colliders)
+
+
+def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
+    """Returns (blob uint32 array, meta dict)."""
+    sc = Scene()
+    # ------------------------------------------------------------------ robot (agents/jaco.py)
+    arm = [1, 2, 3, 4, 5, 6, 7]
+    grip = [9, 11, 13]
+    rob = compile_robot(os.path.join(assets, 'jaco', 'j2s7s300_gym.urdf'), arm, grip, gripper_target=1.33,
+                        motor_gain=0.025, motor_force=1.0, max_hull_verts=robot_hull_max_verts)
+    ndof = len(rob['dof_links'])
+    gripper_collision = set(range(7, 15))          # jaco.py:17 -> no collision with the tool (tool.py:42-44)
+    sc.begin('robot_arm')                           # links that DO collide with the tool
+    for d in range(ndof):
+        for verts, radius, fr, pb in rob['dof_colliders'][d]:
+            if pb not in gripper_collision:
+                sc.add(d, verts, radius, fr, TAG['ROBOT'])
+    sc.end('robot_arm')
+    sc.begin('robot_gripper')
+    for d in range(ndof):
+        for verts, radius, fr, pb in rob['dof_colliders'][d]:
+            if pb in gripper_collision:
+                sc.add(d, verts, radius, fr, TAG['ROBOT'])
+    sc.end('robot_gripper')
+    sc.begin('robot_base')
+    for verts, radius, fr, pb in rob['base_colliders']:
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'])
+    sc.end('robot_base')
+    # ------------------------------------------------------------------ free bodies
+    free = []
+    # tool: spoon, createMultiBody(baseMass=1) with the 64-hull compound (tool.py:26-34, feeding.py:137)
+    spoon = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'dinnerware', 'spoon_vhacd.obj'), 0.08)]
+    allv = np.concatenate(spoon)
+    free.append(dict(mass=1.0, inertia=box_inertia(1.0, allv.min(0) - HULL_MARGIN, allv.max(0) + HULL_MARGIN), gravity=0.0,
+                     refpos=np.zeros(3), refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0))
+    sc.begin('tool')
+    for hv in spoon:
+        sc.add(BODY_FREE0 + 0, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['TOOL'])
+    sc.end('tool')
+    # bowl (furniture.py:32-34, assets/dinnerware/bowl.urdf)
+    bu = Urdf(os.path.join(assets, 'dinnerware', 'bowl.urdf'))
+    bl = bu.root
+    bowl_hulls = link_collision_hulls(bl, 0, {})
+    ip, iq = X.invert(bl.com_pos, bl.com_quat)
+    bowl_hulls = [(X.apply(ip, iq, v), r) for v, r in bowl_hulls]       # into the COM frame
+    allv = np.concatenate([v for v, _ in bowl_hulls])
+    free.append(dict(mass=bl.mass, inertia=box_inertia(bl.mass, allv.min(0) - HULL_MARGIN, allv.max(0) + HULL_MARGIN),
+                     gravity=-9.81, refpos=ip, refquat=iq, kind=KIND['BOWL'], radius=0.0))
+    sc.begin('bowl')
+    for v, r in bowl_hulls:
+        sc.add(BODY_FREE0 + 1, v, r, bl.lateral_friction, TAG['BOWL'])
+    sc.end('bowl')
+    # food particles (feeding.py:158-166): 8 spheres r=5 mm, m=1 g
+    n_food, food_r, food_m = 8, 0.005, 0.001
+    sc.begin('food')
+    for k in range(n_food):
+        free.append(dict(mass=food_m, inertia=np.full(3, 0.4 * food_m * food_r ** 2), gravity=-9.81, refpos=np.zeros(3),
+                         refquat=np.array([0, 0, 0, 1.0]), kind=KIND['FOOD'], radius=food_r))
+        sc.add(BODY_FREE0 + 2 + k, np.zeros((1, 3)), food_r, DEFAULT_FRICTION, TAG['FOOD'])
+    sc.end('food')
+    # ------------------------------------------------------------------ human (male / female variants)
+    human_bodies = None
+    head_body = None
+    for gender in ('male', 'female'):
+        hm = HumanModel(gender)
+        cols = hm.colliders()
+        links = [c[0] for c in cols]
+        if human_bodies is None:
+            human_bodies = links
+            head_body = links.index(23)
+        assert links == human_bodies
+        sc.begin('human_' + gender)
+        for k, (link, kind, data) in enumerate(cols):
+            body = BODY_HUMAN0 + k
+            if kind == 'capsule':
+                sc.add(body, np.stack([data[0], data[1]]), data[2], DEFAULT_FRICTION, TAG['HUMAN'])
+            elif kind == 'sphere':
+                sc.add(body, data[0][None], data[1], DEFAULT_FRICTION, TAG['HUMAN'])
+            elif kind == 'head':
+                fn, fpos, fquat, scale = data
+                for g in load_obj_groups(os.path.join(assets, fn), scale):
+                    sc.add(body, X.apply(fpos, fquat, convex_hull_vertices(g)), HULL_MARGIN, DEFAULT_FRICTION, TAG['HUMAN'])
+        sc.end('human_' + gender)
+    # ------------------------------------------------------------------ static world
+    sc.begin('table')   # furniture.py:31, assets/table/table_tall.urdf:22-27, lateral friction 1.0
+    sc.add(BODY_WORLD, box_verts(np.array([0.25, -1.0, 0.0]) + [0, 0, 0.7], [0.75, 0.5, 0.025]), 0.0, 1.0, TAG['TABLE'])
+    sc.end('table')
+    sc.begin('plane')   # assets/plane/plane.urdf:21-26 (friction overridden per env, env.py:120)
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    sc.begin('wheelchair')   # furniture.py:16, assets/wheelchair/wheelchair_jaco.urdf:21-26
+    wq = X.quat_from_rpy([np.pi / 2, 0, np.pi])
+    for g in load_obj_groups(os.path.join(assets, 'wheelchair', 'wheelchair_permobil_reduced_compressed_vhacd.obj'), 0.15):
+        hv = X.apply(np.array([0, 0, 0.06]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), wq, convex_hull_vertices(g)))
+        sc.add(BODY_WORLD, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['WHEELCHAIR'])
+    sc.end('wheelchair')
+    # ------------------------------------------------------------------ pair groups
+    rg = sc.ranges
+    groups = []
+
+    def grp(a, b, alt=None, same=False, keep=0):
+        a0, a1 = rg[a]
+        b0, b1 = rg[b]
+        b0f, b1f = rg[alt] if alt else (-1, -1)
+        assert b1 - b0 <= 128 and (b1f - b0f) <= 128, 'B range must fit two wave-wide passes'
+        groups.append([a0, a1, b0, b1, b0f, b1f, 1 if same else 0, keep])
+    # keep=K: a small sphere / hull touching a compound of many convex pieces produces one candidate
+    # per piece inside the 2 cm manifold margin; only the K with the smallest predicted gap become
+    # solver rows (a deliberate bound -- see DESIGN.md "contact budget")
+    grp('food', 'tool', keep=4)
+    grp('food', 'food', same=True)
+    grp('food', 'human_male', alt='human_female', keep=2)
+    grp('food', 'table')
+    grp('food', 'plane')
+    grp('food', 'bowl', keep=4)
+    grp('food', 'wheelchair', keep=2)
+    grp('food', 'robot_arm', keep=2)
+    grp('food', 'robot_gripper', keep=2)
+    grp('tool', 'human_male', alt='human_female', keep=1)
+    grp('robot_arm', 'human_male', alt='human_female', keep=2)
+    grp('robot_gripper', 'human_male', alt='human_female', keep=2)
+    grp('tool', 'table')
+    grp('tool', 'bowl')
+    grp('robot_arm', 'tool')
+    grp('robot_arm', 'table')
+    grp('robot_gripper', 'table')
+    grp('robot_arm', 'bowl')
+    grp('robot_gripper', 'bowl')
+    grp('bowl', 'table')
+    grp('bowl', 'plane')
+    # ------------------------------------------------------------------ pack
+    ncoll = len(sc.colliders)
+    verts = np.concatenate([c['verts'] for c in sc.colliders])
+    voff = np.cumsum([0] + [len(c['verts']) for c in sc.colliders])
+    nfree = len(free)
+    nhuman = len(human_bodies)
+    dirs = icosphere42()
+    off = {}
+    cur = H['COUNT']
+    for name, size in (('PARAMS', P['COUNT']), ('ROBOT', ndof * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
+                       ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
+                       ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT'])):
+        off[name] = cur
+        cur += size
+    nwords = cur
+    f = np.zeros(nwords, dtype=np.float32)
+    i = f.view(np.int32)
+    s_q, s_qd, s_qt = 0, ndof, 2 * ndof
+    s_free = 3 * ndof
+    s_base = s_free + 13 * nfree
+    s_human = s_base + 7
+    s_env = s_human + 7 * nhuman
+    state_words = s_env + E['COUNT']
+    hdr = dict(MAGIC=MAGIC, VERSION=VERSION, NWORDS=nwords, NDOF=ndof, NFREE=nfree, NHUMAN=nhuman, NCOLL=ncoll,
+               NVERT=len(verts), NGROUP=len(groups), NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=25, OFF_PARAMS=off['PARAMS'],
+               OFF_ROBOT=off['ROBOT'], OFF_FREE=off['FREE'], OFF_COLL=off['COLL'], OFF_VERT=off['VERT'],
+               OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
+               S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, FOOD0=2, TOOL_BODY=0, NDIR=len(dirs),
+               OFF_DIRS=off['DIRS'])
+    for k, v in hdr.items():
+        i[H[k]] = v
+    p = f[off['PARAMS']:off['PARAMS'] + P['COUNT']]
+    p[P['DT']] = 0.02
+    p[P['FRAME_SKIP']] = 5
+    p[P['NITER']] = n_iter
+    p[P['ERP']] = 0.2
+    p[P['CONTACT_ERP']] = 0.2
+    p[P['CONTACT_BREAK']] = 0.02
+    p[P['LIN_DAMP']] = 0.04
+    p[P['ANG_DAMP']] = 0.04
+    p[P['FRIC_EPS']] = 1e-7
+    p[P['LIMIT_ACT']] = 0.25
+    p[P['ACTION_SCALE']] = 0.05
+    p[P['GRAVITY_Z']] = -9.81
+    p[P['GJK_TOL']] = 1e-6
+    p[P['GJK_MAXIT']] = 24
+    p[P['MAX_CONTACTS']] = 64
+    p[P['MAX_ROWS']] = 160
+    p[P['ROBOT_GRAVITY_Z']] = 0.0      # feeding.py:150-151
+    p[P['HUMAN_GRAVITY_Z']] = 0.0      # feeding.py:152
+    p[P['CONTACT_SLACK']] = 0.001
+    for d in range(ndof):
+        base = off['ROBOT'] + d * R['STRIDE']
+        f[base:base + R['STRIDE']] = rob['rec'][d]
+        for k, v in rob['rec_int'][d].items():
+            i[base + R[k]] = v
+    for k, b in enumerate(free):
+        base = off['FREE'] + k * F['STRIDE']
+        f[base + F['MASS']] = b['mass']
+        f[base + F['INERTIA']:base + F['INERTIA'] + 3] = b['inertia']
+        f[base + F['GRAVITY']] = b['gravity']
+        f[base + F['REFPOS']:base + F['REFPOS'] + 3] = b['refpos']
+        f[base + F['REFQUAT']:base + F['REFQUAT'] + 4] = b['refquat']
+        i[base + F['KIND']] = b['kind']
+        f[base + F['RADIUS']] = b['radius']
+    v32 = verts.astype(np.float32)
+    f[off['VERT']:off['VERT'] + 3 * len(verts)] = v32.ravel()
+    f[off['DIRS']:off['DIRS'] + 3 * len(dirs)] = dirs.astype(np.float32).ravel()
+    for k, c in enumerate(sc.colliders):
+        base = off['COLL'] + k * C['STRIDE']
+        i[base + C['BODY']] = c['body']
+        i[base + C['NVERT']] = len(c['verts'])
+        i[base + C['VOFF']] = voff[k]
+        f[base + C['RADIUS']] = c['radius']
+        f[base + C['FRICTION']] = c['friction']
+        i[base + C['TAG']] = c['tag']
+        cv = v32[voff[k]:voff[k + 1]].astype(np.float64)
+        lo, hi = cv.min(0), cv.max(0)
+        f[base + C['AABB_C']:base + C['AABB_C'] + 3] = (lo + hi) / 2
+        f[base + C['AABB_H']:base + C['AABB_H'] + 3] = (hi - lo) / 2 * (1 + 1e-6) + 1e-7
+    for k, g in enumerate(groups):
+        base = off['GROUP'] + k * G['STRIDE']
+        i[base:base + G['STRIDE']] = g
+    t = f[off['TASK']:off['TASK'] + T['COUNT']]
+    ti = i[off['TASK']:off['TASK'] + T['COUNT']]
+    t[T['W_DISTANCE']], t[T['W_ACTION']], t[T['W_FOOD']] = 1.0, 0.01, 1.0           # config.ini:15-18
+    t[T['C_V']], t[T['C_F']], t[T['C_HF']], t[T['C_FD']], t[T['C_FDV']] = 0.25, 0.01, 0.05, 1.0, 1.0   # config.ini:40-44
+    t[T['SUCCESS_FRAC']] = 0.75
+    t[T['MOUTH_DIST']], t[T['SPILL_DIST']] = 0.03, 0.1
+    t[T['MOUTH_M']:T['MOUTH_M'] + 3] = [0, -0.11, 0.03]                               # feeding.py:186
+    t[T['MOUTH_F']:T['MOUTH_F'] + 3] = [0, -0.1, 0.03]
+    ti[T['HEAD_BODY']] = head_body
+    # end effector = PyBullet link 8 (jaco.py:11), carried by the moving link of joint 7
+    ee_pb = 8
+    ti[T['EE_LINK']] = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    t[T['EE_POS']:T['EE_POS'] + 3] = rob['rel'][ee_pb][0]
+    t[T['EE_QUAT']:T['EE_QUAT'] + 4] = rob['rel'][ee_pb][1]
+    t[T['TOOL_POS']:T['TOOL_POS'] + 3] = [0.1, -0.0225, 0.03]                          # jaco.py:26
+    t[T['TOOL_QUAT']:T['TOOL_QUAT'] + 4] = X.quat_from_rpy([-0.1, -np.pi / 2.0, 0])    # jaco.py:31
+    t[T['TOOL_MAXF']] = 500.0                                                           # tool.py:47
+    t[T['EPISODE_LEN']] = 200
+    meta = dict(header=hdr, ranges={k: tuple(v) for k, v in sc.ranges.items()}, human_bodies=human_bodies,
+                head_body=head_body, dof_links=rob['dof_links'], n_groups=len(groups), offsets=off,
+                robot_base_pos=[-0.35, -0.3, 0.36], robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist())
+    return f.view(np.uint32).copy(), meta
+
+
+def main():
+    import json
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'data')
+    os.makedirs(out_dir, exist_ok=True)
+    blob, meta = compile_feeding_jaco()
+    blob.tofile(os.path.join(out_dir, 'feeding_jaco.agxblob'))
+    with open(os.path.join(out_dir, 'feeding_jaco.meta.json'), 'w') as fh:
+        json.dump(meta, fh, indent=1, default=lambda o: o.tolist() if hasattr(o, 'tolist') else str(o))
+    print('wrote', len(blob) * 4, 'bytes;', json.dumps(meta['header']))
+
+
+if __name__ == '__main__':
+    main()

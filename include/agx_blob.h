@@ -1,0 +1,159 @@
+/* agx_blob.h -- flat model blob + per-environment state record layout.
+ *
+ * The blob is the compiled form of the scene the reference builds at reset() through PyBullet
+ * (assistive_gym/envs/feeding.py:114-182, envs/env.py:114-134, envs/agents/jaco.py:52-54,
+ * envs/agents/tool.py:10-47, envs/agents/furniture.py:10-40, envs/human_creation.py:58-316):
+ * kinematic tree, inertias, joint limits, motor gains, convex collision geometry, the static
+ * collision-pair table, friction, the tool constraint and the task constants.  It is produced
+ * by assistive_gym_amd/model (Python) and consumed, as DATA only, by libagx (HIP) and by the CPU
+ * oracle.  Everything is 32-bit little-endian words: int32 or IEEE float32.
+ *
+ * This header defines a data format, not an algorithm.
+ */
+#ifndef AGX_BLOB_H
+#define AGX_BLOB_H
+
+#define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
+#define AGX_BLOB_VERSION 3
+
+/* ---- header: int32[AGX_H_COUNT] at word 0 ------------------------------------------------ */
+enum {
+  AGX_H_MAGIC = 0, AGX_H_VERSION, AGX_H_NWORDS,
+  AGX_H_NDOF,      /* robot 1-DoF moving links (fixed links merged into parents)            */
+  AGX_H_NFREE,     /* free rigid bodies (tool, bowl, food particles)                         */
+  AGX_H_NHUMAN,    /* human collision bodies with a per-env world transform                  */
+  AGX_H_NCOLL, AGX_H_NVERT, AGX_H_NGROUP,
+  AGX_H_NFOOD, AGX_H_ACT_DIM, AGX_H_OBS_DIM,
+  AGX_H_OFF_PARAMS, AGX_H_OFF_ROBOT, AGX_H_OFF_FREE, AGX_H_OFF_COLL, AGX_H_OFF_VERT,
+  AGX_H_OFF_GROUP, AGX_H_OFF_TASK,
+  AGX_H_STATE_WORDS,  /* words per environment state record                                  */
+  AGX_H_S_Q, AGX_H_S_QD, AGX_H_S_QT, AGX_H_S_FREE, AGX_H_S_BASE, AGX_H_S_HUMAN, AGX_H_S_ENV,
+  AGX_H_FOOD0,        /* index of the first food particle among the free bodies              */
+  AGX_H_TOOL_BODY,    /* free-body index of the tool                                          */
+  AGX_H_NDIR,         /* number of penetration-sampling directions (stored after the verts)  */
+  AGX_H_OFF_DIRS,
+  AGX_H_COUNT = 40
+};
+
+/* ---- PARAMS: float[AGX_P_COUNT] ----------------------------------------------------------- */
+enum {
+  AGX_P_DT = 0,          /* physics time step, env.py:21 (0.02)                               */
+  AGX_P_FRAME_SKIP,      /* substeps per env step, env.py:21 (5)                              */
+  AGX_P_NITER,           /* PGS sweeps per substep (PyBullet default 50, feeding.py:155)      */
+  AGX_P_ERP,             /* joint / constraint error reduction                                 */
+  AGX_P_CONTACT_ERP,
+  AGX_P_CONTACT_BREAK,   /* contact rows are built for separation < this                      */
+  AGX_P_LIN_DAMP, AGX_P_ANG_DAMP,
+  AGX_P_FRIC_EPS,        /* squared lateral speed above which friction follows the slip dir   */
+  AGX_P_LIMIT_ACT,       /* joint-limit rows are built when the gap is below this             */
+  AGX_P_ACTION_SCALE,    /* env.py:174 action_multiplier (0.05)                               */
+  AGX_P_GRAVITY_Z,       /* env.py:104                                                        */
+  AGX_P_GJK_TOL, AGX_P_GJK_MAXIT,
+  AGX_P_MAX_CONTACTS, AGX_P_MAX_ROWS,
+  AGX_P_ROBOT_GRAVITY_Z, /* per-body gravity of the robot (feeding.py:150-151 sets 0)             */
+  AGX_P_HUMAN_GRAVITY_Z,
+  AGX_P_CONTACT_SLACK,   /* solver rows only for contacts that could close within one substep:
+                            dist + v_n*dt < slack (rows that stay inactive have no effect)         */
+  AGX_P_COUNT = 24
+};
+
+/* ---- ROBOT: one record per moving link, stride AGX_R_STRIDE ------------------------------- */
+enum {
+  AGX_R_PARENT = 0,      /* int: parent moving link, -1 = robot base                          */
+  AGX_R_TPOS = 1,        /* float[3] parent-link frame -> joint frame (q = 0)                 */
+  AGX_R_TQUAT = 4,       /* float[4] (x,y,z,w)                                                */
+  AGX_R_AXIS = 8,        /* float[3] joint axis in the link frame                             */
+  AGX_R_COM = 11,        /* float[3] centre of mass in the link frame                         */
+  AGX_R_MASS = 14,
+  AGX_R_INERTIA = 15,    /* float[6] xx,yy,zz,xy,xz,yz about the COM, link-frame axes         */
+  AGX_R_LOWER = 21, AGX_R_UPPER = 22, AGX_R_HAS_LIMIT = 23, /* int                            */
+  AGX_R_KP = 24, AGX_R_KD = 25, AGX_R_MAXF = 26,
+  AGX_R_ACT = 27,        /* int: action component driving this joint, -1 = none               */
+  AGX_R_QT0 = 28,        /* initial motor target (gripper joints)                             */
+  AGX_R_JDAMP = 29,
+  AGX_R_PB_INDEX = 30,   /* int: PyBullet joint index (jaco.py:8-17), informational           */
+  AGX_R_STRIDE = 32
+};
+
+/* ---- FREE bodies: stride AGX_F_STRIDE ----------------------------------------------------- */
+enum {
+  AGX_F_MASS = 0,
+  AGX_F_INERTIA = 1,     /* float[3] principal moments in the COM frame                       */
+  AGX_F_GRAVITY = 4,     /* per-body gravity z (agent.py:196-197)                             */
+  AGX_F_REFPOS = 5,      /* float[3] base(link) frame expressed in the COM frame              */
+  AGX_F_REFQUAT = 8,     /* float[4]                                                          */
+  AGX_F_KIND = 12,       /* int: AGX_KIND_*                                                   */
+  AGX_F_RADIUS = 13,
+  AGX_F_STRIDE = 16
+};
+enum { AGX_KIND_TOOL = 1, AGX_KIND_BOWL = 2, AGX_KIND_FOOD = 3 };
+
+/* ---- COLLIDERS: convex core (vertex list) + radius, stride AGX_C_STRIDE ------------------- */
+enum {
+  AGX_C_BODY = 0,        /* int: body code, see below                                         */
+  AGX_C_NVERT = 1, AGX_C_VOFF = 2, /* int: vertices are float[3] in the body frame            */
+  AGX_C_RADIUS = 3,      /* sphere/capsule radius, or hull collision margin                   */
+  AGX_C_FRICTION = 4,
+  AGX_C_TAG = 5,         /* int: AGX_TAG_*                                                    */
+  AGX_C_AABB_C = 6,      /* float[3] body-frame AABB centre of the core                       */
+  AGX_C_AABB_H = 9,      /* float[3] half extents                                             */
+  AGX_C_STRIDE = 12
+};
+/* body codes */
+#define AGX_BODY_WORLD (-1)
+#define AGX_BODY_ROBOT_BASE 100
+#define AGX_BODY_FREE0 200
+#define AGX_BODY_HUMAN0 300
+enum { AGX_TAG_ROBOT = 1, AGX_TAG_TOOL = 2, AGX_TAG_HUMAN = 3, AGX_TAG_FOOD = 4, AGX_TAG_BOWL = 5,
+       AGX_TAG_TABLE = 6, AGX_TAG_PLANE = 7, AGX_TAG_WHEELCHAIR = 8 };
+
+/* ---- pair GROUPS (static broadphase table): stride AGX_G_STRIDE --------------------------- */
+enum {
+  AGX_G_A0 = 0, AGX_G_A1 = 1,   /* collider range A [a0,a1)                                   */
+  AGX_G_B0 = 2, AGX_G_B1 = 3,   /* collider range B (male human / default)                    */
+  AGX_G_B0F = 4, AGX_G_B1F = 5, /* collider range B for a female human, -1 = same as default  */
+  AGX_G_FLAGS = 6,              /* bit0: A and B are the same range (i<j only)                */
+  AGX_G_KEEP = 7,               /* per A collider keep only the KEEP contacts with the smallest
+                                   predicted gap (0 = keep all)                               */
+  AGX_G_STRIDE = 8
+};
+
+/* ---- TASK constants: float[AGX_T_COUNT] --------------------------------------------------- */
+enum {
+  AGX_T_W_DISTANCE = 0, AGX_T_W_ACTION, AGX_T_W_FOOD,           /* config.ini:15-18           */
+  AGX_T_C_V, AGX_T_C_F, AGX_T_C_HF, AGX_T_C_FD, AGX_T_C_FDV,   /* config.ini:40-44           */
+  AGX_T_SUCCESS_FRAC,                                           /* config.ini:19              */
+  AGX_T_MOUTH_DIST, AGX_T_SPILL_DIST,                           /* feeding.py:61,71           */
+  AGX_T_MOUTH_M = 11,    /* float[3] mouth offset in the head frame, male (feeding.py:186)    */
+  AGX_T_MOUTH_F = 14,    /* float[3] female                                                   */
+  AGX_T_HEAD_BODY = 17,  /* int: human collision body whose frame is the head link frame      */
+  AGX_T_EE_LINK = 18,    /* int: moving link carrying the end-effector frame                  */
+  AGX_T_EE_POS = 19,     /* float[3] end-effector (PyBullet link 8) frame in that link frame  */
+  AGX_T_EE_QUAT = 22,    /* float[4]                                                          */
+  AGX_T_TOOL_POS = 26,   /* float[3] tool pivot in the end-effector frame (jaco.py:26)        */
+  AGX_T_TOOL_QUAT = 29,  /* float[4] tool frame in the end-effector frame (jaco.py:31)        */
+  AGX_T_TOOL_MAXF = 33,  /* tool.py:47                                                        */
+  AGX_T_EPISODE_LEN = 34,/* feeding.py:37                                                     */
+  AGX_T_COUNT = 40
+};
+
+/* ---- per-env ENV block inside the state record (offset AGX_H_S_ENV) ----------------------- */
+enum {
+  AGX_E_PLANE_FRICTION = 0, /* env.py:120                                                     */
+  AGX_E_GENDER = 1,         /* int 0 male, 1 female (human.py:76-78)                          */
+  AGX_E_TARGET = 2,         /* float[3] mouth target, world (feeding.py:192-196)              */
+  AGX_E_FOOD_ALIVE = 5,     /* int bitmask: particles still in self.foods (feeding.py:50-83)  */
+  AGX_E_FOOD_ACTIVE = 6,    /* int bitmask: particles still in self.foods_active              */
+  AGX_E_ITERATION = 7,      /* int, env.py:185                                                */
+  AGX_E_TASK_SUCCESS = 8,   /* int, feeding.py:64                                             */
+  AGX_E_RNG = 9,            /* uint32[2] per-env counter RNG for the teleport draw            */
+  AGX_E_TOTAL_FOOD = 11,    /* int                                                            */
+  AGX_E_COUNT = 16
+};
+
+/* ---- per-step outputs --------------------------------------------------------------------- */
+enum { AGX_INFO_TOTAL_FORCE = 0, AGX_INFO_TASK_SUCCESS = 1, AGX_INFO_ROBOT_FORCE = 2,
+       AGX_INFO_TOOL_FORCE = 3, AGX_INFO_FOOD_REWARD = 4, AGX_INFO_PREF = 5,
+       AGX_INFO_NCONTACT = 6, AGX_INFO_NROWS = 7, AGX_INFO_COUNT = 8 };
+
+#endif

@@ -1,0 +1,988 @@
+/* agx_oracle.c -- CPU oracle, TEST INFRASTRUCTURE ONLY (see agx_oracle.h; PARITY UNPINNED).
+ *
+ * Plain C, double precision, one environment at a time, no SIMD, no threads.  Every function
+ * names the reference lines it follows; the physics inside p.stepSimulation() (env.py:226) is a
+ * restatement of the published algorithms Bullet's multibody pipeline is built from:
+ *   - forward kinematics + Featherstone articulated-body algorithm (world-frame spatial algebra)
+ *   - convex narrowphase by GJK on (vertex core + radius) shapes, 42-direction penetration sampling
+ *   - velocity-level constraint rows (joint motors, joint limits, 6-row fixed constraint, contact
+ *     normal + one friction direction) solved by projected Gauss-Seidel, fixed sweep count
+ *   - semi-implicit Euler integration.
+ */
+#include "agx_oracle.h"
+#include "../include/agx_blob.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXDOF 16
+#define MAXFREE 16
+#define MAXHUMAN 24
+#define NVMAX (MAXDOF + 6 * MAXFREE)
+#define MAXC 96
+#define MAXROWS 320
+#define MAXV 80 /* max vertices of one collider core */
+#define MAXCOLL 512
+
+typedef struct { double p[3]; double R[9]; } xf_t;
+
+struct agxo_model {
+  uint32_t* w; const float* f; const int32_t* i; size_t nwords;
+  int ndof, nfree, nhuman, ncoll, ngroup, nfood, act_dim, obs_dim, state_words, food0, tool_body, ndir;
+  int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
+  int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
+};
+
+/* ------------------------------------------------------------------------------------ math */
+static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void cross3(const double* a, const double* b, double* o) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void sub3(const double* a, const double* b, double* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static void add3(const double* a, const double* b, double* o) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; }
+static void axpy3(double s, const double* a, double* o) { o[0] += s * a[0]; o[1] += s * a[1]; o[2] += s * a[2]; }
+static void mv3(const double* R, const double* v, double* o) {
+  double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+         z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void mtv3(const double* R, const double* v, double* o) {
+  double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+         z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static void mm3(const double* A, const double* B, double* O) {
+  double t[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) t[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+  memcpy(O, t, sizeof t);
+}
+static void mmt3(const double* A, const double* B, double* O) { /* A * B^T */
+  double t[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) t[3 * r + c] = A[3 * r] * B[3 * c] + A[3 * r + 1] * B[3 * c + 1] + A[3 * r + 2] * B[3 * c + 2];
+  memcpy(O, t, sizeof t);
+}
+static void quat_to_mat(const double* q, double* R) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void mat_to_quat(const double* R, double* q) {
+  double t = R[0] + R[4] + R[8];
+  if (t > 0) { double s = sqrt(t + 1.0) * 2; q[0] = (R[7] - R[5]) / s; q[1] = (R[2] - R[6]) / s; q[2] = (R[3] - R[1]) / s; q[3] = 0.25 * s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = 0.25 * s; q[1] = (R[1] + R[3]) / s; q[2] = (R[2] + R[6]) / s; q[3] = (R[7] - R[5]) / s; }
+  else if (R[4] > R[8]) { double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[1] + R[3]) / s; q[1] = 0.25 * s; q[2] = (R[5] + R[7]) / s; q[3] = (R[2] - R[6]) / s; }
+  else { double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[2] + R[6]) / s; q[1] = (R[5] + R[7]) / s; q[2] = 0.25 * s; q[3] = (R[3] - R[1]) / s; }
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; k++) q[k] /= n;
+}
+static void quat_mul(const double* a, const double* b, double* o) {
+  double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  double y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  double z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+static void axis_angle_mat(const double* a, double th, double* R) {
+  double c = cos(th), s = sin(th), t = 1 - c, x = a[0], y = a[1], z = a[2];
+  R[0] = t * x * x + c; R[1] = t * x * y - s * z; R[2] = t * x * z + s * y;
+  R[3] = t * x * y + s * z; R[4] = t * y * y + c; R[5] = t * y * z - s * x;
+  R[6] = t * x * z - s * y; R[7] = t * y * z + s * x; R[8] = t * z * z + c;
+}
+static void xf_apply(const xf_t* X, const double* v, double* o) { double t[3]; mv3(X->R, v, t); add3(t, X->p, o); }
+
+/* spatial vectors: [angular(3); linear(3)] referred to the world origin */
+static double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+static void crm(const double* v, const double* m, double* o) { /* motion x motion */
+  double a[3], b[3], c[3];
+  cross3(v, m, a); cross3(v, m + 3, b); cross3(v + 3, m, c);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+static void crf(const double* v, const double* f, double* o) { /* motion x* force */
+  double a[3], b[3], c[3];
+  cross3(v, f, a); cross3(v + 3, f + 3, b); cross3(v, f + 3, c);
+  o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+static void mv6(const double* I, const double* v, double* o) {
+  double t[6];
+  for (int r = 0; r < 6; r++) { double s = 0; for (int c = 0; c < 6; c++) s += I[6 * r + c] * v[c]; t[r] = s; }
+  memcpy(o, t, sizeof t);
+}
+/* spatial inertia about the world origin from mass, world COM c, world-axes inertia Ic about the COM */
+static void spatial_inertia(double m, const double* c, const double* Ic, double* I) {
+  double cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+  double cc = dot3(c, c);
+  for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) {
+    I[6 * r + k] = Ic[3 * r + k] + m * ((r == k ? cc : 0.0) - c[r] * c[k]);
+    I[6 * r + 3 + k] = m * cx[3 * r + k];
+    I[6 * (r + 3) + k] = m * cx[3 * k + r];
+    I[6 * (r + 3) + 3 + k] = (r == k) ? m : 0.0;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ model */
+agxo_model* agxo_load(const uint32_t* blob, size_t nwords) {
+  if (nwords < AGX_H_COUNT || blob[AGX_H_MAGIC] != AGX_BLOB_MAGIC || blob[AGX_H_VERSION] != AGX_BLOB_VERSION) return NULL;
+  agxo_model* m = (agxo_model*)calloc(1, sizeof *m);
+  m->w = (uint32_t*)malloc(nwords * 4);
+  memcpy(m->w, blob, nwords * 4);
+  m->f = (const float*)m->w; m->i = (const int32_t*)m->w; m->nwords = nwords;
+  const int32_t* h = m->i;
+  m->ndof = h[AGX_H_NDOF]; m->nfree = h[AGX_H_NFREE]; m->nhuman = h[AGX_H_NHUMAN]; m->ncoll = h[AGX_H_NCOLL];
+  m->ngroup = h[AGX_H_NGROUP]; m->nfood = h[AGX_H_NFOOD]; m->act_dim = h[AGX_H_ACT_DIM]; m->obs_dim = h[AGX_H_OBS_DIM];
+  m->state_words = h[AGX_H_STATE_WORDS]; m->food0 = h[AGX_H_FOOD0]; m->tool_body = h[AGX_H_TOOL_BODY]; m->ndir = h[AGX_H_NDIR];
+  m->o_params = h[AGX_H_OFF_PARAMS]; m->o_robot = h[AGX_H_OFF_ROBOT]; m->o_free = h[AGX_H_OFF_FREE]; m->o_coll = h[AGX_H_OFF_COLL];
+  m->o_vert = h[AGX_H_OFF_VERT]; m->o_group = h[AGX_H_OFF_GROUP]; m->o_task = h[AGX_H_OFF_TASK]; m->o_dirs = h[AGX_H_OFF_DIRS];
+  m->s_q = h[AGX_H_S_Q]; m->s_qd = h[AGX_H_S_QD]; m->s_qt = h[AGX_H_S_QT]; m->s_free = h[AGX_H_S_FREE]; m->s_base = h[AGX_H_S_BASE];
+  m->s_human = h[AGX_H_S_HUMAN]; m->s_env = h[AGX_H_S_ENV];
+  if (m->ndof > MAXDOF || m->nfree > MAXFREE || m->nhuman > MAXHUMAN || m->ncoll > MAXCOLL) { agxo_free(m); return NULL; }
+  return m;
+}
+void agxo_free(agxo_model* m) { if (m) { free(m->w); free(m); } }
+int agxo_state_words(const agxo_model* m) { return m->state_words; }
+int agxo_ndof(const agxo_model* m) { return m->ndof; }
+
+#define PARAM(m, k) ((double)(m)->f[(m)->o_params + (k)])
+#define RF(m, d, k) ((double)(m)->f[(m)->o_robot + (d) * AGX_R_STRIDE + (k)])
+#define RI(m, d, k) ((m)->i[(m)->o_robot + (d) * AGX_R_STRIDE + (k)])
+#define FF(m, b, k) ((double)(m)->f[(m)->o_free + (b) * AGX_F_STRIDE + (k)])
+#define FI(m, b, k) ((m)->i[(m)->o_free + (b) * AGX_F_STRIDE + (k)])
+#define CF(m, c, k) ((double)(m)->f[(m)->o_coll + (c) * AGX_C_STRIDE + (k)])
+#define CI(m, c, k) ((m)->i[(m)->o_coll + (c) * AGX_C_STRIDE + (k)])
+#define GI(m, g, k) ((m)->i[(m)->o_group + (g) * AGX_G_STRIDE + (k)])
+#define TF(m, k) ((double)(m)->f[(m)->o_task + (k)])
+#define TI(m, k) ((m)->i[(m)->o_task + (k)])
+
+/* ------------------------------------------------------------------------------------ sim state */
+typedef struct {
+  int ca, cb;          /* collider indices */
+  int ba, bb;          /* body codes */
+  double pa[3], pb[3], n[3], dist, mu;
+  double lambda_n;     /* solved normal impulse */
+} contact_t;
+
+typedef struct {
+  double J[NVMAX], B[NVMAX];
+  double invD, b, lo, hi, lambda;
+  int fric_of;         /* >=0: friction row bound by mu * lambda of that row */
+  double mu;
+} row_t;
+
+typedef struct {
+  const agxo_model* m;
+  int ndof, nfree, nv;
+  double q[MAXDOF], qd[MAXDOF], qt[MAXDOF];
+  double fpos[MAXFREE][3], fquat[MAXFREE][4], fv[MAXFREE][3], fw[MAXFREE][3];
+  xf_t base, human[MAXHUMAN];
+  double plane_mu, target[3];
+  int gender, alive, active, iteration, success, total_food;
+  uint32_t rng[2];
+  /* derived, per substep */
+  xf_t link[MAXDOF], freex[MAXFREE];
+  double comw[MAXDOF][3], Iw[MAXDOF][9], S[MAXDOF][6], vsp[MAXDOF][6], cvp[MAXDOF][6];
+  double I6[MAXDOF][36], IA[MAXDOF][36], U[MAXDOF][6], Dinv[MAXDOF];
+  double Minv[MAXDOF * MAXDOF];
+  double fIinv[MAXFREE][9];
+  double vel[NVMAX];
+  contact_t con[MAXC]; int ncon;
+  int food_near_human;   /* particles with a (food, human) manifold point: separation < CONTACT_BREAK */
+  int contact_overflow;
+  row_t* rows; int nrows;
+} sim_t;
+
+static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
+  memset(s, 0, sizeof *s);
+  s->m = m; s->ndof = m->ndof; s->nfree = m->nfree; s->nv = m->ndof + 6 * m->nfree;
+  for (int d = 0; d < m->ndof; d++) { s->q[d] = st[m->s_q + d]; s->qd[d] = st[m->s_qd + d]; s->qt[d] = st[m->s_qt + d]; }
+  for (int b = 0; b < m->nfree; b++) {
+    const float* r = st + m->s_free + 13 * b;
+    for (int k = 0; k < 3; k++) { s->fpos[b][k] = r[k]; s->fv[b][k] = r[7 + k]; s->fw[b][k] = r[10 + k]; }
+    for (int k = 0; k < 4; k++) s->fquat[b][k] = r[3 + k];
+  }
+  { const float* r = st + m->s_base; double qd[4] = {r[3], r[4], r[5], r[6]};
+    for (int k = 0; k < 3; k++) s->base.p[k] = r[k]; quat_to_mat(qd, s->base.R); }
+  for (int h = 0; h < m->nhuman; h++) {
+    const float* r = st + m->s_human + 7 * h; double qd[4] = {r[3], r[4], r[5], r[6]};
+    for (int k = 0; k < 3; k++) s->human[h].p[k] = r[k]; quat_to_mat(qd, s->human[h].R);
+  }
+  const float* e = st + m->s_env; const int32_t* ei = (const int32_t*)e;
+  s->plane_mu = e[AGX_E_PLANE_FRICTION]; s->gender = ei[AGX_E_GENDER];
+  for (int k = 0; k < 3; k++) s->target[k] = e[AGX_E_TARGET + k];
+  s->alive = ei[AGX_E_FOOD_ALIVE]; s->active = ei[AGX_E_FOOD_ACTIVE]; s->iteration = ei[AGX_E_ITERATION];
+  s->success = ei[AGX_E_TASK_SUCCESS]; s->total_food = ei[AGX_E_TOTAL_FOOD];
+  s->rng[0] = (uint32_t)ei[AGX_E_RNG]; s->rng[1] = (uint32_t)ei[AGX_E_RNG + 1];
+}
+static void sim_store(const sim_t* s, float* st) {
+  const agxo_model* m = s->m;
+  for (int d = 0; d < m->ndof; d++) { st[m->s_q + d] = (float)s->q[d]; st[m->s_qd + d] = (float)s->qd[d]; st[m->s_qt + d] = (float)s->qt[d]; }
+  for (int b = 0; b < m->nfree; b++) {
+    float* r = st + m->s_free + 13 * b;
+    for (int k = 0; k < 3; k++) { r[k] = (float)s->fpos[b][k]; r[7 + k] = (float)s->fv[b][k]; r[10 + k] = (float)s->fw[b][k]; }
+    for (int k = 0; k < 4; k++) r[3 + k] = (float)s->fquat[b][k];
+  }
+  float* e = st + m->s_env; int32_t* ei = (int32_t*)e;
+  for (int k = 0; k < 3; k++) e[AGX_E_TARGET + k] = (float)s->target[k];
+  ei[AGX_E_FOOD_ALIVE] = s->alive; ei[AGX_E_FOOD_ACTIVE] = s->active; ei[AGX_E_ITERATION] = s->iteration;
+  ei[AGX_E_TASK_SUCCESS] = s->success; ei[AGX_E_RNG] = (int32_t)s->rng[0]; ei[AGX_E_RNG + 1] = (int32_t)s->rng[1];
+}
+
+/* ------------------------------------------------------------------------------------ kinematics
+ * K1 of SURVEY 2.2: what getLinkState(computeForwardKinematics=True) (agent.py:52) reads back. */
+static void kinematics(sim_t* s) {
+  const agxo_model* m = s->m;
+  for (int d = 0; d < s->ndof; d++) {
+    int par = RI(m, d, AGX_R_PARENT);
+    const xf_t* P = par < 0 ? &s->base : &s->link[par];
+    double tp[3] = {RF(m, d, AGX_R_TPOS), RF(m, d, AGX_R_TPOS + 1), RF(m, d, AGX_R_TPOS + 2)};
+    double tq[4] = {RF(m, d, AGX_R_TQUAT), RF(m, d, AGX_R_TQUAT + 1), RF(m, d, AGX_R_TQUAT + 2), RF(m, d, AGX_R_TQUAT + 3)};
+    double ax[3] = {RF(m, d, AGX_R_AXIS), RF(m, d, AGX_R_AXIS + 1), RF(m, d, AGX_R_AXIS + 2)};
+    double Rt[9], Rq[9], R0[9];
+    quat_to_mat(tq, Rt); axis_angle_mat(ax, s->q[d], Rq);
+    mm3(P->R, Rt, R0); mm3(R0, Rq, s->link[d].R);
+    xf_apply(P, tp, s->link[d].p);
+    double com[3] = {RF(m, d, AGX_R_COM), RF(m, d, AGX_R_COM + 1), RF(m, d, AGX_R_COM + 2)};
+    xf_apply(&s->link[d], com, s->comw[d]);
+    double aw[3]; mv3(s->link[d].R, ax, aw);
+    double px[3]; cross3(s->link[d].p, aw, px);
+    for (int k = 0; k < 3; k++) { s->S[d][k] = aw[k]; s->S[d][3 + k] = px[k]; }
+    const double ixx = RF(m, d, AGX_R_INERTIA), iyy = RF(m, d, AGX_R_INERTIA + 1), izz = RF(m, d, AGX_R_INERTIA + 2),
+                 ixy = RF(m, d, AGX_R_INERTIA + 3), ixz = RF(m, d, AGX_R_INERTIA + 4), iyz = RF(m, d, AGX_R_INERTIA + 5);
+    double Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz}, T[9];
+    mm3(s->link[d].R, Il, T); mmt3(T, s->link[d].R, s->Iw[d]);
+    spatial_inertia(RF(m, d, AGX_R_MASS), s->comw[d], s->Iw[d], s->I6[d]);
+    /* spatial velocity */
+    for (int k = 0; k < 6; k++) s->vsp[d][k] = (par < 0 ? 0.0 : s->vsp[par][k]) + s->S[d][k] * s->qd[d];
+    double sq[6]; for (int k = 0; k < 6; k++) sq[k] = s->S[d][k] * s->qd[d];
+    crm(s->vsp[d], sq, s->cvp[d]);
+  }
+  for (int b = 0; b < s->nfree; b++) {
+    memcpy(s->freex[b].p, s->fpos[b], sizeof(double) * 3);
+    quat_to_mat(s->fquat[b], s->freex[b].R);
+    double Ii[9] = {0}; double T[9];
+    for (int k = 0; k < 3; k++) { double I = FF(m, b, AGX_F_INERTIA + k); Ii[4 * k] = I > 0 ? 1.0 / I : 0.0; }
+    mm3(s->freex[b].R, Ii, T); mmt3(T, s->freex[b].R, s->fIinv[b]);
+  }
+}
+
+/* external spatial force on moving link d (gravity + velocity damping), world origin reference.
+ * [BULLET-UNVERIFIED] damping: f = -m v_c (k + k|v_c|), tau = -Ic w (k + k|w|) per link. */
+static void link_external_force(const sim_t* s, int d, int with_damping, double* f6) {
+  const agxo_model* m = s->m;
+  double mass = RF(m, d, AGX_R_MASS);
+  double f[3] = {0, 0, mass * PARAM(m, AGX_P_ROBOT_GRAVITY_Z)}, tau[3] = {0, 0, 0};
+  if (with_damping) {
+    const double* w = s->vsp[d]; double vc[3], t[3];
+    cross3(w, s->comw[d], t); add3(s->vsp[d] + 3, t, vc);
+    double kl = PARAM(m, AGX_P_LIN_DAMP), ka = PARAM(m, AGX_P_ANG_DAMP);
+    double sl = kl + kl * sqrt(dot3(vc, vc)), sa = ka + ka * sqrt(dot3(w, w));
+    axpy3(-mass * sl, vc, f);
+    double Iw[3]; mv3(s->Iw[d], w, Iw); axpy3(-sa, Iw, tau);
+  }
+  double cf[3]; cross3(s->comw[d], f, cf);
+  for (int k = 0; k < 3; k++) { f6[k] = tau[k] + cf[k]; f6[3 + k] = f[k]; }
+}
+
+/* Featherstone ABA, world-frame spatial quantities.  Leaves IA/U/Dinv cached for minv(). */
+static void aba(sim_t* s, const double* tau, int with_damping, double* qdd) {
+  const agxo_model* m = s->m; int n = s->ndof;
+  double pA[MAXDOF][6], u[MAXDOF], a[MAXDOF][6];
+  for (int d = 0; d < n; d++) {
+    memcpy(s->IA[d], s->I6[d], sizeof(double) * 36);
+    double h[6], fe[6]; mv6(s->I6[d], s->vsp[d], h); crf(s->vsp[d], h, pA[d]);
+    link_external_force(s, d, with_damping, fe);
+    for (int k = 0; k < 6; k++) pA[d][k] -= fe[k];
+  }
+  for (int d = n - 1; d >= 0; d--) {
+    mv6(s->IA[d], s->S[d], s->U[d]);
+    double D = dot6(s->S[d], s->U[d]);
+    s->Dinv[d] = D > 1e-300 ? 1.0 / D : 0.0;
+    double t = (tau ? tau[d] : 0.0) - RF(m, d, AGX_R_JDAMP) * s->qd[d];
+    u[d] = t - dot6(s->S[d], pA[d]);
+    int par = RI(m, d, AGX_R_PARENT);
+    if (par >= 0) {
+      double Ia[36];
+      for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Ia[6 * r + c] = s->IA[d][6 * r + c] - s->U[d][r] * s->U[d][c] * s->Dinv[d];
+      double Iac[6]; mv6(Ia, s->cvp[d], Iac);
+      for (int k = 0; k < 36; k++) s->IA[par][k] += Ia[k];
+      for (int k = 0; k < 6; k++) pA[par][k] += pA[d][k] + Iac[k] + s->U[d][k] * (u[d] * s->Dinv[d]);
+    }
+  }
+  for (int d = 0; d < n; d++) {
+    int par = RI(m, d, AGX_R_PARENT);
+    double ap[6];
+    for (int k = 0; k < 6; k++) ap[k] = (par < 0 ? 0.0 : a[par][k]) + s->cvp[d][k];
+    qdd[d] = (u[d] - dot6(s->U[d], ap)) * s->Dinv[d];
+    for (int k = 0; k < 6; k++) a[d][k] = ap[k] + s->S[d][k] * qdd[d];
+  }
+}
+/* M^-1 column by column: ABA response to a unit joint force (what Bullet's
+ * calcAccelerationDeltasMultiDof evaluates per constraint row). Requires aba() caches. */
+static void minv_from_aba(sim_t* s) {
+  const agxo_model* m = s->m; int n = s->ndof;
+  for (int j = 0; j < n; j++) {
+    double pA[MAXDOF][6], u[MAXDOF], a[MAXDOF][6];
+    memset(pA, 0, sizeof pA);
+    for (int d = n - 1; d >= 0; d--) {
+      u[d] = (d == j ? 1.0 : 0.0) - dot6(s->S[d], pA[d]);
+      int par = RI(m, d, AGX_R_PARENT);
+      if (par >= 0) for (int k = 0; k < 6; k++) pA[par][k] += pA[d][k] + s->U[d][k] * (u[d] * s->Dinv[d]);
+    }
+    for (int d = 0; d < n; d++) {
+      int par = RI(m, d, AGX_R_PARENT);
+      double ap[6]; for (int k = 0; k < 6; k++) ap[k] = par < 0 ? 0.0 : a[par][k];
+      double qdd = (u[d] - dot6(s->U[d], ap)) * s->Dinv[d];
+      for (int k = 0; k < 6; k++) a[d][k] = ap[k] + s->S[d][k] * qdd;
+      s->Minv[d * n + j] = qdd;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------ GJK */
+static int support(const double* v, int n, const double* d) {
+  int best = 0; double bd = dot3(v, d);
+  for (int k = 1; k < n; k++) { double t = dot3(v + 3 * k, d); if (t > bd) { bd = t; best = k; } }
+  return best;
+}
+/* closest point to the origin on triangle (a,b,c): barycentric weights out (Ericson, RTCD 5.1.5) */
+static void closest_tri(const double* a, const double* b, const double* c, double* wa, double* wb, double* wc) {
+  double ab[3], ac[3], ap[3], bp[3], cp[3];
+  sub3(b, a, ab); sub3(c, a, ac);
+  for (int k = 0; k < 3; k++) { ap[k] = -a[k]; bp[k] = -b[k]; cp[k] = -c[k]; }
+  double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  if (d1 <= 0 && d2 <= 0) { *wa = 1; *wb = 0; *wc = 0; return; }
+  double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+  if (d3 >= 0 && d4 <= d3) { *wa = 0; *wb = 1; *wc = 0; return; }
+  double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); *wa = 1 - v; *wb = v; *wc = 0; return; }
+  double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+  if (d6 >= 0 && d5 <= d6) { *wa = 0; *wb = 0; *wc = 1; return; }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { double w = d2 / (d2 - d6); *wa = 1 - w; *wb = 0; *wc = w; return; }
+  double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); *wa = 0; *wb = 1 - w; *wc = w; return; }
+  double den = 1.0 / (va + vb + vc);
+  double v = vb * den, w = vc * den;
+  *wa = 1 - v - w; *wb = v; *wc = w;
+}
+/* simplex of n points W (Minkowski difference) -> closest point to origin; compacts the simplex to
+ * the supporting sub-simplex; returns 1 if the origin is enclosed (n==4 case). */
+static int simplex_solve(double W[4][3], double A[4][3], double B[4][3], int* pn, double* lam, double* v) {
+  int n = *pn;
+  double l[4] = {0, 0, 0, 0};
+  if (n == 1) { l[0] = 1; }
+  else if (n == 2) {
+    double d[3]; sub3(W[1], W[0], d);
+    double dd = dot3(d, d), t = dd > 0 ? -dot3(W[0], d) / dd : 0.0;
+    if (t <= 0) { l[0] = 1; } else if (t >= 1) { l[1] = 1; } else { l[0] = 1 - t; l[1] = t; }
+  } else if (n == 3) {
+    closest_tri(W[0], W[1], W[2], &l[0], &l[1], &l[2]);
+  } else {
+    static const int faces[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+    double best = 1e300; int any = 0;
+    for (int f = 0; f < 4; f++) {
+      const double *a = W[faces[f][0]], *b = W[faces[f][1]], *c = W[faces[f][2]], *d = W[faces[f][3]];
+      double ab[3], ac[3], nrm[3], ad[3];
+      sub3(b, a, ab); sub3(c, a, ac); cross3(ab, ac, nrm); sub3(d, a, ad);
+      double sp = -dot3(a, nrm), sd = dot3(ad, nrm);
+      if (sp * sd > 0) continue; /* origin on the same side as the 4th vertex: not outside this face */
+      any = 1;
+      double wa, wb, wc; closest_tri(a, b, c, &wa, &wb, &wc);
+      double p[3]; for (int k = 0; k < 3; k++) p[k] = wa * a[k] + wb * b[k] + wc * c[k];
+      double d2 = dot3(p, p);
+      if (d2 < best) { best = d2; l[0] = l[1] = l[2] = l[3] = 0; l[faces[f][0]] = wa; l[faces[f][1]] = wb; l[faces[f][2]] = wc; }
+    }
+    if (!any) return 1;
+  }
+  int k2 = 0;
+  for (int k = 0; k < n; k++) if (l[k] > 0) {
+    if (k2 != k) { memcpy(W[k2], W[k], 24); memcpy(A[k2], A[k], 24); memcpy(B[k2], B[k], 24); }
+    lam[k2] = l[k]; k2++;
+  }
+  *pn = k2;
+  v[0] = v[1] = v[2] = 0;
+  for (int k = 0; k < k2; k++) axpy3(lam[k], W[k], v);
+  return 0;
+}
+int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int maxit, double* dist, double* pa, double* pb, int* iters) {
+  double W[4][3], A[4][3], B[4][3], lam[4] = {1, 0, 0, 0}, v[3];
+  int n = 0, pen = 0, it;
+  sub3(a, b, v);
+  double vv = dot3(v, v);
+  /* seed simplex with the first vertices so witness points are always defined */
+  memcpy(A[0], a, 24); memcpy(B[0], b, 24); memcpy(W[0], v, 24); n = 1;
+  for (it = 0; it < maxit; it++) {
+    if (vv < 1e-24) { pen = 1; break; }
+    double nv[3] = {-v[0], -v[1], -v[2]};
+    int ia = support(a, na, nv), ib = support(b, nb, v);
+    double w[3]; sub3(a + 3 * ia, b + 3 * ib, w);
+    double vw = dot3(v, w);
+    if (vv - vw <= tol * vv) break;
+    int dup = 0;
+    for (int k = 0; k < n; k++) if (W[k][0] == w[0] && W[k][1] == w[1] && W[k][2] == w[2]) dup = 1;
+    if (dup) break;
+    memcpy(W[n], w, 24); memcpy(A[n], a + 3 * ia, 24); memcpy(B[n], b + 3 * ib, 24); n++;
+    double vn[3];
+    if (simplex_solve(W, A, B, &n, lam, vn)) { pen = 1; break; }
+    double vvn = dot3(vn, vn);
+    memcpy(v, vn, 24);
+    if (vvn >= vv) { vv = vvn; break; }
+    vv = vvn;
+  }
+  if (iters) *iters = it;
+  if (pen) { *dist = 0; return 1; }
+  pa[0] = pa[1] = pa[2] = pb[0] = pb[1] = pb[2] = 0;
+  for (int k = 0; k < n; k++) { axpy3(lam[k], A[k], pa); axpy3(lam[k], B[k], pb); }
+  *dist = sqrt(vv);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ collision */
+static const xf_t XF_IDENT = {{0, 0, 0}, {1, 0, 0, 0, 1, 0, 0, 0, 1}};
+static const xf_t* body_xf(const sim_t* s, int code) {
+  if (code == AGX_BODY_WORLD) return &XF_IDENT;
+  if (code >= AGX_BODY_HUMAN0) return &s->human[code - AGX_BODY_HUMAN0];
+  if (code >= AGX_BODY_FREE0) return &s->freex[code - AGX_BODY_FREE0];
+  if (code == AGX_BODY_ROBOT_BASE) return &s->base;
+  return &s->link[code];
+}
+static void collider_aabb(const sim_t* s, int c, double* lo, double* hi) {
+  const agxo_model* m = s->m; const xf_t* X = body_xf(s, CI(m, c, AGX_C_BODY));
+  double cl[3] = {CF(m, c, AGX_C_AABB_C), CF(m, c, AGX_C_AABB_C + 1), CF(m, c, AGX_C_AABB_C + 2)};
+  double hl[3] = {CF(m, c, AGX_C_AABB_H), CF(m, c, AGX_C_AABB_H + 1), CF(m, c, AGX_C_AABB_H + 2)};
+  double cw[3]; xf_apply(X, cl, cw);
+  double r = CF(m, c, AGX_C_RADIUS);
+  for (int k = 0; k < 3; k++) {
+    double h = fabs(X->R[3 * k]) * hl[0] + fabs(X->R[3 * k + 1]) * hl[1] + fabs(X->R[3 * k + 2]) * hl[2] + r;
+    lo[k] = cw[k] - h; hi[k] = cw[k] + h;
+  }
+}
+static int collider_world_verts(const sim_t* s, int c, const double* shift, double* out) {
+  const agxo_model* m = s->m; const xf_t* X = body_xf(s, CI(m, c, AGX_C_BODY));
+  int n = CI(m, c, AGX_C_NVERT), off = CI(m, c, AGX_C_VOFF);
+  for (int k = 0; k < n; k++) {
+    double v[3] = {m->f[m->o_vert + 3 * (off + k)], m->f[m->o_vert + 3 * (off + k) + 1], m->f[m->o_vert + 3 * (off + k) + 2]};
+    double w[3]; xf_apply(X, v, w); sub3(w, shift, out + 3 * k);
+  }
+  return n;
+}
+/* closest features of two colliders: returns 1 and fills the contact geometry when the separation
+ * (radii included) is below `limit`. */
+static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* out) {
+  const agxo_model* m = s->m;
+  double va[3 * MAXV], vb[3 * MAXV], lo[3], hi[3], shift[3];
+  collider_aabb(s, ca, lo, hi);
+  for (int k = 0; k < 3; k++) shift[k] = 0.5 * (lo[k] + hi[k]);
+  int na = collider_world_verts(s, ca, shift, va), nb = collider_world_verts(s, cb, shift, vb);
+  double ra = CF(m, ca, AGX_C_RADIUS), rb = CF(m, cb, AGX_C_RADIUS);
+  double d, pa[3], pb[3], n[3];
+  int pen = agxo_gjk(va, na, vb, nb, PARAM(m, AGX_P_GJK_TOL), (int)PARAM(m, AGX_P_GJK_MAXIT), &d, pa, pb, NULL);
+  if (!pen) {
+    if (d - ra - rb >= limit) return 0;
+    sub3(pa, pb, n); for (int k = 0; k < 3; k++) n[k] /= d;
+  } else {
+    /* cores overlap: 42-direction penetration sampling (btMinkowskiPenetrationDepthSolver-style) */
+    double best = 1e300; int bi = 0;
+    for (int k = 0; k < m->ndir; k++) {
+      double dir[3] = {m->f[m->o_dirs + 3 * k], m->f[m->o_dirs + 3 * k + 1], m->f[m->o_dirs + 3 * k + 2]};
+      double nd[3] = {-dir[0], -dir[1], -dir[2]};
+      int ia = support(va, na, nd), ib = support(vb, nb, dir);
+      double depth = dot3(vb + 3 * ib, dir) - dot3(va + 3 * ia, dir);
+      if (depth < best) { best = depth; bi = k; }
+    }
+    for (int k = 0; k < 3; k++) n[k] = m->f[m->o_dirs + 3 * bi + k];
+    double nd[3] = {-n[0], -n[1], -n[2]};
+    int ia = support(va, na, nd);
+    memcpy(pa, va + 3 * ia, 24); memcpy(pb, pa, 24); axpy3(best, n, pb);
+    d = -best;
+  }
+  for (int k = 0; k < 3; k++) { out->pa[k] = pa[k] - ra * n[k] + shift[k]; out->pb[k] = pb[k] + rb * n[k] + shift[k]; out->n[k] = n[k]; }
+  out->dist = d - ra - rb; out->ca = ca; out->cb = cb;
+  out->ba = CI(m, ca, AGX_C_BODY); out->bb = CI(m, cb, AGX_C_BODY);
+  double mua = CI(m, ca, AGX_C_TAG) == AGX_TAG_PLANE ? s->plane_mu : CF(m, ca, AGX_C_FRICTION);
+  double mub = CI(m, cb, AGX_C_TAG) == AGX_TAG_PLANE ? s->plane_mu : CF(m, cb, AGX_C_FRICTION);
+  out->mu = mua * mub; /* [BULLET-UNVERIFIED] combined friction = product */
+  out->lambda_n = 0;
+  return 1;
+}
+/* velocity of the material point of body `code` at world point x, from the generalized velocities s->vel */
+static void point_velocity(const sim_t* s, int code, const double* x, double* v) {
+  const agxo_model* m = s->m;
+  v[0] = v[1] = v[2] = 0;
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) {
+    double sv[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = code; d >= 0; d = RI(m, d, AGX_R_PARENT)) for (int k = 0; k < 6; k++) sv[k] += s->S[d][k] * s->vel[d];
+    double wx[3]; cross3(sv, x, wx); add3(sv + 3, wx, v);
+  } else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) {
+    int b = code - AGX_BODY_FREE0, o = s->ndof + 6 * b; double r[3], wr[3];
+    sub3(x, s->fpos[b], r); cross3(s->vel + o + 3, r, wr); add3(s->vel + o, wr, v);
+  }
+}
+/* K2+K3: static pair table -> AABB cull -> GJK; contact order = (group, a, b) enumeration order */
+static void collide(sim_t* s) {
+  const agxo_model* m = s->m;
+  double brk = PARAM(m, AGX_P_CONTACT_BREAK);
+  int maxc = (int)PARAM(m, AGX_P_MAX_CONTACTS); if (maxc > MAXC) maxc = MAXC;
+  double lo[MAXCOLL][3], hi[MAXCOLL][3];
+  for (int c = 0; c < m->ncoll && c < MAXCOLL; c++) collider_aabb(s, c, lo[c], hi[c]);
+  s->ncon = 0; s->food_near_human = 0; s->contact_overflow = 0;
+  double dt = PARAM(m, AGX_P_DT), slack = PARAM(m, AGX_P_CONTACT_SLACK);
+  for (int g = 0; g < m->ngroup; g++) {
+    int a0 = GI(m, g, AGX_G_A0), a1 = GI(m, g, AGX_G_A1), b0 = GI(m, g, AGX_G_B0), b1 = GI(m, g, AGX_G_B1);
+    if (s->gender == 1 && GI(m, g, AGX_G_B0F) >= 0) { b0 = GI(m, g, AGX_G_B0F); b1 = GI(m, g, AGX_G_B1F); }
+    int same = GI(m, g, AGX_G_FLAGS) & 1, keep = GI(m, g, AGX_G_KEEP);
+    for (int a = a0; a < a1; a++) {
+      contact_t cand[128]; double gap[128]; int nc = 0;
+      for (int b = (same ? a + 1 : b0); b < b1; b++) {
+        int sep = 0;
+        for (int k = 0; k < 3; k++) if (lo[a][k] > hi[b][k] + brk || lo[b][k] > hi[a][k] + brk) sep = 1;
+        if (sep) continue;
+        contact_t k;
+        if (!narrowphase(s, a, b, brk, &k)) continue;
+        /* a manifold point exists (what getContactPoints reports, agent.py:100-116) */
+        if (CI(m, a, AGX_C_TAG) == AGX_TAG_FOOD && CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN)
+          s->food_near_human |= 1 << (CI(m, a, AGX_C_BODY) - AGX_BODY_FREE0 - m->food0);
+        /* solver row only if the gap can close within this substep */
+        double va[3], vb[3], vr[3]; point_velocity(s, k.ba, k.pa, va); point_velocity(s, k.bb, k.pb, vb); sub3(va, vb, vr);
+        double pg = k.dist + dot3(vr, k.n) * dt;
+        if (pg >= slack) continue;
+        cand[nc] = k; gap[nc] = pg; nc++;
+      }
+      /* keep the `keep` candidates with the smallest predicted gap (ties: lower B index), emitted in
+       * selection order; keep == 0 keeps all in B order */
+      int nsel = (keep > 0 && keep < nc) ? keep : nc;
+      for (int q = 0; q < nsel; q++) {
+        int bi = q;
+        if (keep > 0) { bi = -1; for (int c = 0; c < nc; c++) if (gap[c] < 1e299 && (bi < 0 || gap[c] < gap[bi])) bi = c; }
+        if (s->ncon >= maxc) { s->contact_overflow++; } else s->con[s->ncon++] = cand[bi];
+        gap[bi] = 1e300;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------ rows */
+/* Jacobian contribution of a unit force `f` (and unit torque `t`) applied on body `code` at world
+ * point x (lever arms about the world origin for links, about the COM for free bodies). */
+static void body_jacobian(const sim_t* s, int code, const double* x, const double* f, const double* t, double sign, double* J) {
+  const agxo_model* m = s->m;
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) {
+    double F[6], xf[3] = {0, 0, 0};
+    if (f) cross3(x, f, xf);
+    for (int k = 0; k < 3; k++) { F[k] = xf[k] + (t ? t[k] : 0.0); F[3 + k] = f ? f[k] : 0.0; }
+    for (int d = code; d >= 0; d = RI(m, d, AGX_R_PARENT)) J[d] += sign * dot6(s->S[d], F);
+  } else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) {
+    int b = code - AGX_BODY_FREE0, o = s->ndof + 6 * b;
+    double r[3], rf[3] = {0, 0, 0};
+    if (f) { sub3(x, s->fpos[b], r); cross3(r, f, rf); }
+    for (int k = 0; k < 3; k++) { J[o + k] += sign * (f ? f[k] : 0.0); J[o + 3 + k] += sign * (rf[k] + (t ? t[k] : 0.0)); }
+  }
+}
+static void finish_row(sim_t* s, row_t* r) {
+  const agxo_model* m = s->m; int n = s->ndof;
+  memset(r->B, 0, sizeof r->B);
+  for (int i = 0; i < n; i++) { double acc = 0; for (int j = 0; j < n; j++) acc += s->Minv[i * n + j] * r->J[j]; r->B[i] = acc; }
+  for (int b = 0; b < s->nfree; b++) {
+    int o = n + 6 * b; double mass = FF(m, b, AGX_F_MASS), im = mass > 0 ? 1.0 / mass : 0.0;
+    for (int k = 0; k < 3; k++) r->B[o + k] = im * r->J[o + k];
+    mv3(s->fIinv[b], r->J + o + 3, r->B + o + 3);
+  }
+  double D = 0; for (int k = 0; k < s->nv; k++) D += r->J[k] * r->B[k];
+  r->invD = D > 1e-12 ? 1.0 / D : 0.0;
+  r->lambda = 0; r->fric_of = -1; r->mu = 0;
+}
+static double row_vel(const sim_t* s, const row_t* r) { double a = 0; for (int k = 0; k < s->nv; k++) a += r->J[k] * s->vel[k]; return a; }
+
+/* rotation matrix -> XYZ Euler angles (small relative rotations of the fixed constraint) */
+static void mat_to_euler_xyz(const double* R, double* e) {
+  double fi = R[2];
+  if (fi < 1.0) { if (fi > -1.0) { e[0] = atan2(-R[5], R[8]); e[1] = asin(R[2]); e[2] = atan2(-R[1], R[0]); }
+    else { e[0] = -atan2(R[3], R[4]); e[1] = -M_PI / 2; e[2] = 0; } }
+  else { e[0] = atan2(R[3], R[4]); e[1] = M_PI / 2; e[2] = 0; }
+}
+static void plane_space(const double* n, double* p) { /* first tangent of btPlaneSpace1 */
+  if (fabs(n[2]) > 0.7071067811865475244) { double a = n[1] * n[1] + n[2] * n[2], k = 1.0 / sqrt(a); p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k; }
+  else { double a = n[0] * n[0] + n[1] * n[1], k = 1.0 / sqrt(a); p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0; }
+}
+static void ee_frame(const sim_t* s, xf_t* ee) {
+  const agxo_model* m = s->m; int L = TI(m, AGX_T_EE_LINK);
+  double p[3] = {TF(m, AGX_T_EE_POS), TF(m, AGX_T_EE_POS + 1), TF(m, AGX_T_EE_POS + 2)};
+  double q[4] = {TF(m, AGX_T_EE_QUAT), TF(m, AGX_T_EE_QUAT + 1), TF(m, AGX_T_EE_QUAT + 2), TF(m, AGX_T_EE_QUAT + 3)}, Rq[9];
+  quat_to_mat(q, Rq); xf_apply(&s->link[L], p, ee->p); mm3(s->link[L].R, Rq, ee->R);
+}
+
+static void build_rows(sim_t* s) {
+  const agxo_model* m = s->m; int n = s->ndof;
+  double dt = PARAM(m, AGX_P_DT), erp = PARAM(m, AGX_P_ERP), cerp = PARAM(m, AGX_P_CONTACT_ERP);
+  int maxrows = (int)PARAM(m, AGX_P_MAX_ROWS); if (maxrows > MAXROWS) maxrows = MAXROWS;
+  s->nrows = 0;
+#define NEWROW() (memset(&s->rows[s->nrows], 0, sizeof(row_t)), &s->rows[s->nrows++])
+  /* joint motors: Agent.control (agent.py:28-33) -> POSITION_CONTROL velocity-level row.
+   * [BULLET-UNVERIFIED] target dv = kp (q*-q)/dt + kd (0 - qd), impulse clamp maxForce*dt */
+  for (int d = 0; d < n; d++) {
+    double maxf = RF(m, d, AGX_R_MAXF); if (maxf <= 0) continue;
+    row_t* r = NEWROW(); r->J[d] = 1.0; finish_row(s, r);
+    r->b = RF(m, d, AGX_R_KP) * (s->qt[d] - s->q[d]) / dt + RF(m, d, AGX_R_KD) * (0.0 - s->vel[d]);
+    r->lo = -maxf * dt; r->hi = maxf * dt;
+  }
+  /* joint limits (URDF lower/upper): unilateral rows, built only when the gap is small */
+  for (int d = 0; d < n; d++) {
+    if (!RI(m, d, AGX_R_HAS_LIMIT)) continue;
+    for (int side = 0; side < 2; side++) {
+      double gap = side == 0 ? s->q[d] - RF(m, d, AGX_R_LOWER) : RF(m, d, AGX_R_UPPER) - s->q[d];
+      if (gap >= PARAM(m, AGX_P_LIMIT_ACT)) continue;
+      row_t* r = NEWROW(); r->J[d] = side == 0 ? 1.0 : -1.0; finish_row(s, r);
+      double rv = row_vel(s, r);
+      r->b = gap > 0 ? (-gap / dt - rv) : (-gap * erp / dt - rv);
+      r->lo = 0; r->hi = 1e30;
+    }
+  }
+  /* tool fixed constraint (tool.py:46-47): 3 linear rows along world axes at the pivots,
+   * 3 angular rows about the parent frame axes; impulse clamp maxForce*dt */
+  {
+    xf_t ee; ee_frame(s, &ee);
+    int L = TI(m, AGX_T_EE_LINK), tb = m->tool_body, code_b = AGX_BODY_FREE0 + tb;
+    double tp[3] = {TF(m, AGX_T_TOOL_POS), TF(m, AGX_T_TOOL_POS + 1), TF(m, AGX_T_TOOL_POS + 2)};
+    double tq[4] = {TF(m, AGX_T_TOOL_QUAT), TF(m, AGX_T_TOOL_QUAT + 1), TF(m, AGX_T_TOOL_QUAT + 2), TF(m, AGX_T_TOOL_QUAT + 3)};
+    double pivA[3], Rt[9], frameA[9];
+    xf_apply(&ee, tp, pivA); quat_to_mat(tq, Rt); mm3(ee.R, Rt, frameA);
+    const double* pivB = s->fpos[tb]; const double* frameB = s->freex[tb].R;
+    double rel[9], At[9];
+    for (int r0 = 0; r0 < 3; r0++) for (int c = 0; c < 3; c++) At[3 * r0 + c] = frameA[3 * c + r0];
+    mm3(At, frameB, rel);
+    double ang[3]; mat_to_euler_xyz(rel, ang);
+    double lim = TF(m, AGX_T_TOOL_MAXF) * dt;
+    for (int k = 0; k < 3; k++) {
+      double nrm[3] = {0, 0, 0}; nrm[k] = 1.0;
+      row_t* r = NEWROW();
+      body_jacobian(s, L, pivA, nrm, NULL, 1.0, r->J); body_jacobian(s, code_b, pivB, nrm, NULL, -1.0, r->J);
+      finish_row(s, r);
+      double perr = pivA[k] - pivB[k];
+      r->b = -perr * erp / dt - row_vel(s, r); r->lo = -lim; r->hi = lim;
+    }
+    for (int k = 0; k < 3; k++) {
+      double axw[3] = {frameA[k], frameA[3 + k], frameA[6 + k]};
+      row_t* r = NEWROW();
+      body_jacobian(s, L, pivA, NULL, axw, 1.0, r->J); body_jacobian(s, code_b, pivB, NULL, axw, -1.0, r->J);
+      finish_row(s, r);
+      r->b = ang[k] * erp / dt - row_vel(s, r); r->lo = -lim; r->hi = lim;
+    }
+  }
+  /* contact normals, then one friction row per contact */
+  int first_normal = s->nrows, nc = s->ncon;
+  if (first_normal + 2 * nc > maxrows) nc = (maxrows - first_normal) / 2;
+  for (int c = 0; c < nc; c++) {
+    contact_t* k = &s->con[c]; row_t* r = NEWROW();
+    body_jacobian(s, k->ba, k->pa, k->n, NULL, 1.0, r->J); body_jacobian(s, k->bb, k->pb, k->n, NULL, -1.0, r->J);
+    finish_row(s, r);
+    double rv = row_vel(s, r);
+    r->b = k->dist > 0 ? (-k->dist / dt - rv) : (-k->dist * cerp / dt - rv);
+    r->lo = 0; r->hi = 1e30;
+  }
+  for (int c = 0; c < nc; c++) {
+    contact_t* k = &s->con[c];
+    /* relative velocity of the contact points, lateral part */
+    row_t tmp; double vr[3];
+    for (int ax = 0; ax < 3; ax++) {
+      double e[3] = {0, 0, 0}; e[ax] = 1.0; memset(tmp.J, 0, sizeof tmp.J);
+      body_jacobian(s, k->ba, k->pa, e, NULL, 1.0, tmp.J); body_jacobian(s, k->bb, k->pb, e, NULL, -1.0, tmp.J);
+      vr[ax] = row_vel(s, &tmp);
+    }
+    double vn = dot3(vr, k->n), t[3] = {vr[0] - vn * k->n[0], vr[1] - vn * k->n[1], vr[2] - vn * k->n[2]};
+    double l2 = dot3(t, t);
+    if (l2 > PARAM(m, AGX_P_FRIC_EPS)) { double il = 1.0 / sqrt(l2); for (int q = 0; q < 3; q++) t[q] *= il; }
+    else plane_space(k->n, t);
+    row_t* r = NEWROW();
+    body_jacobian(s, k->ba, k->pa, t, NULL, 1.0, r->J); body_jacobian(s, k->bb, k->pb, t, NULL, -1.0, r->J);
+    finish_row(s, r);
+    r->b = -row_vel(s, r); r->fric_of = first_normal + c; r->mu = k->mu; r->lo = 0; r->hi = 0;
+  }
+  s->ncon = nc;
+#undef NEWROW
+}
+
+/* K6: projected Gauss-Seidel, fixed number of sweeps, rows in construction order */
+static void pgs(sim_t* s, double* dv) {
+  int iters = (int)PARAM(s->m, AGX_P_NITER);
+  memset(dv, 0, sizeof(double) * NVMAX);
+  for (int it = 0; it < iters; it++) for (int i = 0; i < s->nrows; i++) {
+    row_t* r = &s->rows[i];
+    if (r->invD == 0) continue;
+    double lo = r->lo, hi = r->hi;
+    if (r->fric_of >= 0) { double ln = s->rows[r->fric_of].lambda; hi = r->mu * ln; lo = -hi; }
+    double jdv = 0; for (int k = 0; k < s->nv; k++) jdv += r->J[k] * dv[k];
+    double nl = r->lambda + (r->b - jdv) * r->invD;
+    if (nl < lo) nl = lo; if (nl > hi) nl = hi;
+    double dl = nl - r->lambda; r->lambda = nl;
+    if (dl != 0) for (int k = 0; k < s->nv; k++) dv[k] += r->B[k] * dl;
+  }
+}
+
+/* FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset */
+static void update_target(sim_t* s) {
+  const agxo_model* m = s->m; int hb = TI(m, AGX_T_HEAD_BODY), o = s->gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
+  double mp[3] = {TF(m, o), TF(m, o + 1), TF(m, o + 2)};
+  xf_apply(&s->human[hb], mp, s->target);
+}
+
+/* one p.stepSimulation() (env.py:226) + the post-substep hooks (env.py:227-232) */
+static void substep(sim_t* s) {
+  const agxo_model* m = s->m; int n = s->ndof; double dt = PARAM(m, AGX_P_DT);
+  kinematics(s);
+  double qdd[MAXDOF];
+  aba(s, NULL, 1, qdd); minv_from_aba(s);
+  for (int d = 0; d < n; d++) s->vel[d] = s->qd[d] + dt * qdd[d];
+  for (int b = 0; b < s->nfree; b++) {
+    int o = n + 6 * b; const double *v = s->fv[b], *w = s->fw[b];
+    double kl = PARAM(m, AGX_P_LIN_DAMP), ka = PARAM(m, AGX_P_ANG_DAMP);
+    double sl = kl + kl * sqrt(dot3(v, v)), sa = ka + ka * sqrt(dot3(w, w));
+    double g[3] = {0, 0, FF(m, b, AGX_F_GRAVITY)};
+    for (int k = 0; k < 3; k++) s->vel[o + k] = v[k] + dt * (g[k] - sl * v[k]);
+    /* w' = w + dt * Iinv (-w x (I w)) - dt * sa * w  (world frame; damping torque = -I w sa) */
+    double wl[3], Iwl[3], Iw[3], gy[3], acc[3];
+    mtv3(s->freex[b].R, w, wl);
+    for (int k = 0; k < 3; k++) Iwl[k] = FF(m, b, AGX_F_INERTIA + k) * wl[k];
+    mv3(s->freex[b].R, Iwl, Iw); cross3(w, Iw, gy);
+    double ng[3] = {-gy[0], -gy[1], -gy[2]}; mv3(s->fIinv[b], ng, acc);
+    for (int k = 0; k < 3; k++) s->vel[o + 3 + k] = w[k] + dt * (acc[k] - sa * w[k]);
+  }
+  collide(s);
+  build_rows(s);
+  double dv[NVMAX];
+  pgs(s, dv);
+  for (int c = 0; c < s->ncon; c++) {
+    /* normal rows follow the non-contact rows in construction order */
+    int first_normal = s->nrows - 2 * s->ncon;
+    s->con[c].lambda_n = s->rows[first_normal + c].lambda;
+  }
+  for (int d = 0; d < n; d++) { s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d]; }
+  for (int b = 0; b < s->nfree; b++) {
+    int o = n + 6 * b;
+    for (int k = 0; k < 3; k++) { s->fv[b][k] = s->vel[o + k] + dv[o + k]; s->fw[b][k] = s->vel[o + 3 + k] + dv[o + 3 + k]; s->fpos[b][k] += dt * s->fv[b][k]; }
+    double* w = s->fw[b]; double th = sqrt(dot3(w, w)) * dt, dq[4];
+    if (th > 1e-12) { double sc = sin(th / 2) / (th / dt); dq[0] = w[0] * sc; dq[1] = w[1] * sc; dq[2] = w[2] * sc; dq[3] = cos(th / 2); }
+    else { dq[0] = w[0] * dt / 2; dq[1] = w[1] * dt / 2; dq[2] = w[2] * dt / 2; dq[3] = 1; }
+    double qn[4]; quat_mul(dq, s->fquat[b], qn);
+    double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    for (int k = 0; k < 4; k++) s->fquat[b][k] = qn[k] / nn;
+  }
+  /* Agent.enforce_joint_limits on the human (agent.py:240-250): the human is static here */
+  update_target(s);
+}
+
+/* ------------------------------------------------------------------------------------ task layer */
+static uint32_t rng_next(uint32_t* st) { /* 64-bit LCG in two words, xorshifted output */
+  uint64_t x = ((uint64_t)st[1] << 32) | st[0];
+  x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+  st[0] = (uint32_t)x; st[1] = (uint32_t)(x >> 32);
+  uint32_t o = (uint32_t)(x >> 33) ^ (uint32_t)(x >> 11);
+  return o;
+}
+static void to_base_frame(const sim_t* s, const double* p, const double* R, double* po, double* qo) {
+  /* Agent.convert_to_realworld (agent.py:60-64): invertTransform(base) o (p, R) */
+  double d[3]; sub3(p, s->base.p, d); mtv3(s->base.R, d, po);
+  if (R && qo) { double Bt[9], Rr[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Bt[3 * r + c] = s->base.R[3 * c + r];
+    mm3(Bt, R, Rr); mat_to_quat(Rr, qo); }
+}
+static void tool_base_pose(const sim_t* s, double* p, double* R) {
+  const agxo_model* m = s->m; int tb = m->tool_body;
+  double rp[3] = {FF(m, tb, AGX_F_REFPOS), FF(m, tb, AGX_F_REFPOS + 1), FF(m, tb, AGX_F_REFPOS + 2)};
+  double rq[4] = {FF(m, tb, AGX_F_REFQUAT), FF(m, tb, AGX_F_REFQUAT + 1), FF(m, tb, AGX_F_REFQUAT + 2), FF(m, tb, AGX_F_REFQUAT + 3)}, Rr[9];
+  quat_to_mat(rq, Rr); xf_apply(&s->freex[tb], rp, p); mm3(s->freex[tb].R, Rr, R);
+}
+/* FeedingEnv._get_obs (feeding.py:85-112), robot part */
+static void observe(sim_t* s, double robot_force, double tool_force, float* obs) {
+  const agxo_model* m = s->m; (void)robot_force;
+  double sp[3], sR[9], spr[3], sqr[4], hpr[3], hqr[4], tpr[3];
+  tool_base_pose(s, sp, sR);
+  to_base_frame(s, sp, sR, spr, sqr);
+  int hb = TI(m, AGX_T_HEAD_BODY);
+  to_base_frame(s, s->human[hb].p, s->human[hb].R, hpr, hqr);
+  to_base_frame(s, s->target, NULL, tpr, NULL);
+  int o = 0;
+  for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k];
+  for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k];
+  for (int k = 0; k < 3; k++) obs[o++] = (float)(spr[k] - tpr[k]);
+  for (int d = 0; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+    double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
+  }
+  for (int k = 0; k < 3; k++) obs[o++] = (float)hpr[k];
+  for (int k = 0; k < 4; k++) obs[o++] = (float)hqr[k];
+  obs[o++] = (float)tool_force;
+}
+static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int* food_hit_mask) {
+  const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
+  *robot_f = 0; *tool_f = 0; *food_hit_mask = s->food_near_human;
+  for (int c = 0; c < s->ncon; c++) {
+    const contact_t* k = &s->con[c];
+    int ta = CI(m, k->ca, AGX_C_TAG), tb = CI(m, k->cb, AGX_C_TAG);
+    if (tb == AGX_TAG_HUMAN || ta == AGX_TAG_HUMAN) {
+      int other = ta == AGX_TAG_HUMAN ? tb : ta;
+      if (other == AGX_TAG_ROBOT) *robot_f += k->lambda_n / dt;     /* feeding.py:46 */
+      if (other == AGX_TAG_TOOL) *tool_f += k->lambda_n / dt;       /* feeding.py:47 */
+    }
+  }
+}
+
+void agxo_observe(const agxo_model* m, const float* state, float* obs) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s);
+  observe(s, 0, 0, obs); free(s);
+}
+
+void agxo_settle(const agxo_model* m, float* state, int n_substeps) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
+  s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
+  for (int k = 0; k < n_substeps; k++) substep(s);
+  sim_store(s, state); free(s->rows); free(s);
+}
+
+void agxo_step(const agxo_model* m, float* state, const float* action, float* obs, float* reward, int* done, float* info) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
+  s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
+  int nsub = (int)PARAM(m, AGX_P_FRAME_SKIP);
+  /* take_step (env.py:174-222): clip, scale (float32 arithmetic as numpy does for a float32 action),
+   * 5x accumulate with per-joint limit clamp, set motor targets */
+  s->iteration += 1;
+  double act_norm2 = 0;
+  for (int d = 0; d < s->ndof; d++) {
+    int ai = RI(m, d, AGX_R_ACT); if (ai < 0) continue;
+    float a32 = action[ai]; if (a32 < -1.0f) a32 = -1.0f; if (a32 > 1.0f) a32 = 1.0f;
+    a32 *= (float)PARAM(m, AGX_P_ACTION_SCALE);
+    double a = a32, qa = s->q[d], lo = RF(m, d, AGX_R_LOWER), hi = RF(m, d, AGX_R_UPPER);
+    for (int k = 0; k < nsub; k++) {
+      int below = qa + a < lo, above = qa + a > hi;
+      if (below || above) a = 0;
+      if (below) qa = lo; if (above) qa = hi;
+      qa += a;
+    }
+    s->qt[d] = qa;
+  }
+  for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
+  for (int k = 0; k < nsub; k++) substep(s);
+  kinematics(s); /* poses after the last integration, as the getters in _get_obs see them */
+  double robot_f, tool_f; int hit_mask;
+  contact_forces(s, &robot_f, &tool_f, &hit_mask);
+  observe(s, robot_f, tool_f, obs);
+  double total_f = robot_f + tool_f;
+  /* get_food_rewards (feeding.py:50-83) */
+  double food_reward = 0, food_hit = 0, vel_sum = 0;
+  /* the second loop of get_food_rewards walks foods_active as it was on entry (feeding.py:74-82):
+   * a particle eaten in the first loop is still in it, and getContactPoints still returns the
+   * contacts of the last stepSimulation */
+  const int active_on_entry = s->active;
+  for (int k = 0; k < m->nfood; k++) {
+    if (!(s->alive >> k & 1)) continue;
+    int b = m->food0 + k; double d[3]; sub3(s->target, s->fpos[b], d);
+    if (sqrt(dot3(d, d)) < TF(m, AGX_T_MOUTH_DIST)) {
+      food_reward += 20; s->success += 1; vel_sum += sqrt(dot3(s->fv[b], s->fv[b]));
+      s->alive &= ~(1 << k); s->active &= ~(1 << k);
+      for (int q = 0; q < 3; q++) s->fpos[b][q] = 1000.0 + 1000.0 * (rng_next(s->rng) >> 8) * (1.0 / 16777216.0);
+      s->fquat[b][0] = s->fquat[b][1] = s->fquat[b][2] = 0; s->fquat[b][3] = 1;
+      continue;
+    }
+    /* getClosestPoints(food, tool, distance=0.1) empty?  (agent.py:118-130) */
+    int near = 0;
+    {
+      /* find this particle's collider and test it against every tool collider */
+      int fc = -1;
+      for (int c = 0; c < m->ncoll; c++) if (CI(m, c, AGX_C_BODY) == AGX_BODY_FREE0 + b) { fc = c; break; }
+      for (int c = 0; c < m->ncoll && !near; c++) {
+        if (CI(m, c, AGX_C_TAG) != AGX_TAG_TOOL) continue;
+        double lo1[3], hi1[3], lo2[3], hi2[3]; int sep = 0;
+        collider_aabb(s, fc, lo1, hi1); collider_aabb(s, c, lo2, hi2);
+        for (int q = 0; q < 3; q++) if (lo1[q] > hi2[q] + TF(m, AGX_T_SPILL_DIST) || lo2[q] > hi1[q] + TF(m, AGX_T_SPILL_DIST)) sep = 1;
+        if (sep) continue;
+        contact_t tmp; if (narrowphase(s, fc, c, TF(m, AGX_T_SPILL_DIST), &tmp)) near = 1;
+      }
+    }
+    if (!near) { food_reward -= 5; s->alive &= ~(1 << k); }
+  }
+  for (int k = 0; k < m->nfood; k++) if ((active_on_entry >> k & 1) && (hit_mask >> k & 1)) { food_hit -= 1; s->active &= ~(1 << k); }
+  /* end-effector linear velocity (feeding.py:22, agent.py:69-72) */
+  xf_t ee; ee_frame(s, &ee);
+  int L = TI(m, AGX_T_EE_LINK); double wxp[3], vee[3];
+  cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
+  double ee_speed = sqrt(dot3(vee, vee));
+  /* human_preferences (env.py:237-274), feeding branch */
+  double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_F) * (-total_f) + TF(m, AGX_T_C_HF) * (tool_f < 10 ? 0.0 : -tool_f)
+              + TF(m, AGX_T_C_FD) * food_hit + TF(m, AGX_T_C_FDV) * (-vel_sum);
+  double sp[3], sR[9], dd[3]; tool_base_pose(s, sp, sR); sub3(s->target, sp, dd);
+  double r = TF(m, AGX_T_W_DISTANCE) * (-sqrt(dot3(dd, dd))) + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + TF(m, AGX_T_W_FOOD) * food_reward + pref;
+  *reward = (float)r;
+  *done = s->iteration >= (int)TF(m, AGX_T_EPISODE_LEN);
+  if (info) {
+    info[AGX_INFO_TOTAL_FORCE] = (float)total_f;
+    info[AGX_INFO_TASK_SUCCESS] = (float)(s->success >= s->total_food * TF(m, AGX_T_SUCCESS_FRAC));
+    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)tool_f;
+    info[AGX_INFO_FOOD_REWARD] = (float)food_reward; info[AGX_INFO_PREF] = (float)pref;
+    info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
+  }
+  sim_store(s, state); free(s->rows); free(s);
+}
+
+/* ------------------------------------------------------------------------------------ test hooks */
+void agxo_fk(const agxo_model* m, const float* state, double* pos, double* rot) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s);
+  for (int d = 0; d < m->ndof; d++) { memcpy(pos + 3 * d, s->link[d].p, 24); memcpy(rot + 9 * d, s->link[d].R, 72); }
+  free(s);
+}
+void agxo_ee_pose(const agxo_model* m, const float* state, double* pos3, double* quat4) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s);
+  xf_t ee; ee_frame(s, &ee); memcpy(pos3, ee.p, 24); mat_to_quat(ee.R, quat4); free(s);
+}
+void agxo_crba(const agxo_model* m, const float* state, double* M) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s);
+  int n = m->ndof; double Ic[MAXDOF][36];
+  for (int d = 0; d < n; d++) memcpy(Ic[d], s->I6[d], sizeof Ic[d]);
+  for (int d = n - 1; d >= 0; d--) { int par = RI(m, d, AGX_R_PARENT); if (par >= 0) for (int k = 0; k < 36; k++) Ic[par][k] += Ic[d][k]; }
+  memset(M, 0, sizeof(double) * n * n);
+  for (int i = 0; i < n; i++) {
+    double F[6]; mv6(Ic[i], s->S[i], F);
+    for (int j = i; j >= 0; j = RI(m, j, AGX_R_PARENT)) { double v = dot6(s->S[j], F); M[i * n + j] = v; M[j * n + i] = v; }
+  }
+  free(s);
+}
+void agxo_aba(const agxo_model* m, const float* state, const double* tau, int with_damping, double* qdd) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s); aba(s, tau, with_damping, qdd); free(s);
+}
+void agxo_rnea_bias(const agxo_model* m, const float* state, double* h) {
+  /* recursive Newton-Euler with qdd = 0, world-frame spatial algebra */
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s);
+  int n = m->ndof; double a[MAXDOF][6], f[MAXDOF][6];
+  for (int d = 0; d < n; d++) {
+    int par = RI(m, d, AGX_R_PARENT);
+    for (int k = 0; k < 6; k++) a[d][k] = (par < 0 ? 0.0 : a[par][k]) + s->cvp[d][k];
+    double Ia[6], Iv[6], vIv[6], fe[6];
+    mv6(s->I6[d], a[d], Ia); mv6(s->I6[d], s->vsp[d], Iv); crf(s->vsp[d], Iv, vIv); link_external_force(s, d, 0, fe);
+    for (int k = 0; k < 6; k++) f[d][k] = Ia[k] + vIv[k] - fe[k];
+  }
+  for (int d = n - 1; d >= 0; d--) {
+    h[d] = dot6(s->S[d], f[d]);
+    int par = RI(m, d, AGX_R_PARENT); if (par >= 0) for (int k = 0; k < 6; k++) f[par][k] += f[d][k];
+  }
+  free(s);
+}
+void agxo_minv(const agxo_model* m, const float* state, double* Minv) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s);
+  double qdd[MAXDOF]; aba(s, NULL, 0, qdd); minv_from_aba(s);
+  memcpy(Minv, s->Minv, sizeof(double) * m->ndof * m->ndof); free(s);
+}
+int agxo_collide(const agxo_model* m, const float* state, double* out, int max_out) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s); collide(s);
+  int n = s->ncon < max_out ? s->ncon : max_out;
+  for (int c = 0; c < n; c++) { double* o = out + 12 * c; const contact_t* k = &s->con[c];
+    o[0] = k->ca; o[1] = k->cb; memcpy(o + 2, k->pa, 24); memcpy(o + 5, k->pb, 24); memcpy(o + 8, k->n, 24); o[11] = k->dist; }
+  free(s); return n;
+}
+int agxo_substep_debug(const agxo_model* m, float* state, double* out, int max_out) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
+  s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
+  substep(s);
+  int n = s->ncon < max_out ? s->ncon : max_out;
+  for (int c = 0; c < n; c++) { double* o = out + 13 * c; const contact_t* k = &s->con[c];
+    o[0] = k->ca; o[1] = k->cb; memcpy(o + 2, k->pa, 24); memcpy(o + 5, k->pb, 24); memcpy(o + 8, k->n, 24); o[11] = k->dist; o[12] = k->lambda_n; }
+  sim_store(s, state); free(s->rows); free(s); return n;
+}

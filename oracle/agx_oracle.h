@@ -1,0 +1,64 @@
+/* agx_oracle.h -- CPU oracle (TEST INFRASTRUCTURE ONLY, not part of the product path).
+ *
+ * Double-precision, single-environment, deliberately plain restatement of the FeedingJaco
+ * step():  AssistiveEnv.take_step (assistive_gym/envs/env.py:174-235) + the physics that
+ * p.stepSimulation() performs for this scene + FeedingEnv.step/_get_obs/get_food_rewards
+ * (assistive_gym/envs/feeding.py:12-112,192-196) + human_preferences (env.py:237-274).
+ *
+ * PARITY UNPINNED: the physics half of the reference lives in PyBullet / Bullet3 (Zackory fork,
+ * unpinned, setup.py:21), which is not installable here and whose source is not on this box; the
+ * reference ships no tests or golden vectors for this path.  The Bullet-side conventions restated
+ * here are from the published algorithm descriptions (Featherstone ABA; projected Gauss-Seidel
+ * sequential impulses; GJK) and are marked [BULLET-UNVERIFIED] where a Bullet default is assumed.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
+ */
+#ifndef AGX_ORACLE_H
+#define AGX_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agxo_model agxo_model;
+
+agxo_model* agxo_load(const uint32_t* blob, size_t nwords);
+void agxo_free(agxo_model* m);
+int agxo_state_words(const agxo_model* m);
+int agxo_ndof(const agxo_model* m);
+
+/* one full env step on one environment. state: float32 record (in/out). */
+void agxo_step(const agxo_model* m, float* state, const float* action, float* obs, float* reward,
+               int* done, float* info);
+/* n physics substeps without action processing / rewards (reset-time settling, feeding.py:178-179) */
+void agxo_settle(const agxo_model* m, float* state, int n_substeps);
+/* observation only (reset() return value, feeding.py:182) */
+void agxo_observe(const agxo_model* m, const float* state, float* obs);
+
+/* ---- building blocks exposed for unit tests ------------------------------------------------ */
+/* link world frames: pos[ndof*3], rot[ndof*9] row-major */
+void agxo_fk(const agxo_model* m, const float* state, double* pos, double* rot);
+/* end-effector (PyBullet link 8) world pose */
+void agxo_ee_pose(const agxo_model* m, const float* state, double* pos3, double* quat4);
+/* joint-space mass matrix by CRBA, row-major ndof*ndof */
+void agxo_crba(const agxo_model* m, const float* state, double* M);
+/* unconstrained joint accelerations by ABA with joint torques tau (may be NULL = 0); damping on/off */
+void agxo_aba(const agxo_model* m, const float* state, const double* tau, int with_damping, double* qdd);
+/* bias term h(q,qd) = tau needed for zero acceleration (RNEA), damping excluded */
+void agxo_rnea_bias(const agxo_model* m, const float* state, double* h);
+/* M^-1 by ABA unit-impulse responses, row-major ndof*ndof */
+void agxo_minv(const agxo_model* m, const float* state, double* Minv);
+/* GJK distance between two point sets (cores). returns 0 separated, 1 penetrating */
+int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int maxit,
+             double* dist, double* pa, double* pb, int* iters);
+/* contacts of the current state: out rows of 12 doubles
+ * [colliderA, colliderB, pA(3), pB(3), n(3) (from B to A), distance]; returns count */
+int agxo_collide(const agxo_model* m, const float* state, double* out, int max_out);
+/* one substep returning the solved contact impulses (same row layout + impulse appended = 13) */
+int agxo_substep_debug(const agxo_model* m, float* state, double* contacts_out, int max_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""ctypes binding of the CPU oracle (oracle/libagx_oracle.so) -- test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, 'oracle', 'libagx_oracle.so')
+        src = os.path.join(ROOT, 'oracle', 'agx_oracle.c')
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')], stdout=subprocess.DEVNULL)
+        L = C.CDLL(path)
+        L.agxo_load.restype = C.c_void_p
+        L.agxo_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.agxo_free.argtypes = [C.c_void_p]
+        for name in ('agxo_step', 'agxo_settle', 'agxo_observe', 'agxo_fk', 'agxo_ee_pose', 'agxo_crba', 'agxo_aba',
+                     'agxo_rnea_bias', 'agxo_minv'):
+            getattr(L, name).restype = None
+        L.agxo_gjk.restype = C.c_int
+        L.agxo_collide.restype = C.c_int
+        L.agxo_substep_debug.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, blob):
+        self.blob = blob
+        self.L = lib()
+        self.words = np.ascontiguousarray(blob.words)
+        self.h = self.L.agxo_load(_p(self.words), C.c_size_t(len(self.words)))
+        assert self.h, 'oracle rejected the model blob'
+        self.ndof = blob.ndof
+
+    def __del__(self):
+        try:
+            self.L.agxo_free(C.c_void_p(self.h))
+        except Exception:
+            pass
+
+    def step(self, state, action):
+        """state: float32 (state_words,) updated in place; returns obs, reward, done, info."""
+        obs = np.zeros(self.blob.obs_dim, dtype=np.float32)
+        rew = np.zeros(1, dtype=np.float32)
+        done = np.zeros(1, dtype=np.int32)
+        info = np.zeros(8, dtype=np.float32)
+        action = np.ascontiguousarray(action, dtype=np.float32)
+        self.L.agxo_step(C.c_void_p(self.h), _p(state), _p(action), _p(obs), _p(rew), _p(done), _p(info))
+        return obs, float(rew[0]), bool(done[0]), info
+
+    def settle(self, state, n):
+        self.L.agxo_settle(C.c_void_p(self.h), _p(state), C.c_int(n))
+
+    def observe(self, state):
+        obs = np.zeros(self.blob.obs_dim, dtype=np.float32)
+        self.L.agxo_observe(C.c_void_p(self.h), _p(state), _p(obs))
+        return obs
+
+    def fk(self, state):
+        pos = np.zeros((self.ndof, 3)); rot = np.zeros((self.ndof, 3, 3))
+        self.L.agxo_fk(C.c_void_p(self.h), _p(state), _p(pos), _p(rot))
+        return pos, rot
+
+    def ee_pose(self, state):
+        p = np.zeros(3); q = np.zeros(4)
+        self.L.agxo_ee_pose(C.c_void_p(self.h), _p(state), _p(p), _p(q))
+        return p, q
+
+    def crba(self, state):
+        M = np.zeros((self.ndof, self.ndof))
+        self.L.agxo_crba(C.c_void_p(self.h), _p(state), _p(M))
+        return M
+
+    def aba(self, state, tau=None, damping=False):
+        qdd = np.zeros(self.ndof)
+        tau = None if tau is None else np.ascontiguousarray(tau, dtype=np.float64)
+        self.L.agxo_aba(C.c_void_p(self.h), _p(state), _p(tau), C.c_int(int(damping)), _p(qdd))
+        return qdd
+
+    def rnea_bias(self, state):
+        h = np.zeros(self.ndof)
+        self.L.agxo_rnea_bias(C.c_void_p(self.h), _p(state), _p(h))
+        return h
+
+    def minv(self, state):
+        M = np.zeros((self.ndof, self.ndof))
+        self.L.agxo_minv(C.c_void_p(self.h), _p(state), _p(M))
+        return M
+
+    def gjk(self, a, b, tol=1e-10, maxit=64):
+        a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        d = np.zeros(1); pa = np.zeros(3); pb = np.zeros(3); it = np.zeros(1, dtype=np.int32)
+        pen = self.L.agxo_gjk(_p(a), C.c_int(len(a)), _p(b), C.c_int(len(b)), C.c_double(tol), C.c_int(maxit), _p(d), _p(pa), _p(pb), _p(it))
+        return pen, float(d[0]), pa, pb, int(it[0])
+
+    def collide(self, state, max_out=96):
+        out = np.zeros((max_out, 12))
+        n = self.L.agxo_collide(C.c_void_p(self.h), _p(state), _p(out), C.c_int(max_out))
+        return out[:n]
+
+    def substep_debug(self, state, max_out=96):
+        out = np.zeros((max_out, 13))
+        n = self.L.agxo_substep_debug(C.c_void_p(self.h), _p(state), _p(out), C.c_int(max_out))
+        return out[:n]
