@@ -1,0 +1,232 @@
+// agx_api.hip -- libagx: C ABI (include/agx.h) + kernel launches for gfx950.
+// One workgroup = one wavefront = one environment; 64 threads, LDS_BYTES of dynamic LDS.
+#include "agx_wave.h"
+#include "agx_step.h"
+#include "../../include/agx.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e)); else snprintf(buf, sizeof buf, "%s", what);
+  g_err = buf; return code;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGX_E_HIP, #x, e_); } while (0)
+
+extern "C" __global__ void __launch_bounds__(64)
+agx_step_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* obs, float* reward, uint8_t* done,
+                float* info, float* debug, int n_envs, int sw, int act_dim, int obs_dim, int mode, int nsettle) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  agx::env_step(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr,
+                obs ? obs + (size_t)env * obs_dim : nullptr, reward ? reward + env : nullptr, done ? done + env : nullptr,
+                info ? info + (size_t)env * AGX_INFO_DIM : nullptr, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr,
+                lds, (int)threadIdx.x, mode, nsettle);
+}
+
+// done envs take a fresh record from the pool; coalesced copy, one wave per env
+extern "C" __global__ void __launch_bounds__(64)
+agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* done, int* episode, int n_envs, int sw) {
+  const int env = blockIdx.x;
+  if (env >= n_envs || !done[env]) return;
+  int ep = episode[env] + 1;
+  const float* src = pool + (size_t)((env + 977 * (long long)ep) % pool_n) * sw;
+  for (int k = threadIdx.x; k < sw; k += 64) state[(size_t)env * sw + k] = src[k];
+  if (threadIdx.x == 0) episode[env] = ep;
+}
+
+extern "C" __global__ void __launch_bounds__(64) agx_selftest_kernel(float* out_f, int* out_i, unsigned long long* out_m) {
+  const int lane = wave_lane();
+  float x = (float)(lane * lane % 17) * 0.25f - 1.0f;
+  out_f[lane] = wave_sum(x);
+  out_f[64 + lane] = wave_min(x + (float)((lane * 7) % 5));
+  out_f[128 + lane] = wave_bcast(x, 37);
+  out_f[192 + lane] = wave_shfl(x, (lane * 13 + 5) & 63);
+  out_i[lane] = wave_sum_i(lane % 7);
+  out_i[64 + lane] = wave_scan_excl(lane % 5);
+  unsigned long long m = wave_ballot((lane % 3) == 1);
+  out_m[lane] = m;
+  out_i[128 + lane] = wave_rank(m);
+  out_f[256 + lane] = wave_max(x);
+}
+
+}  // namespace
+
+struct agx_handle_s {
+  int device, n_envs, act_dim, obs_dim, sw;
+  uint32_t* blob_dev;
+  float* state_dev;
+  int* episode_dev;
+  // staging for the *_host convenience calls
+  float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
+  hipEvent_t ev0, ev1;
+};
+
+extern "C" {
+
+const char* agx_version(void) { return "libagx 0.1 (gfx950, wave-per-env FeedingJaco stepper)"; }
+const char* agx_last_error(void) { return g_err.c_str(); }
+int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int agx_lds_bytes_per_env(void) { return agx::LDS_BYTES; }
+int agx_debug_words(void) { return agx::DBG_WORDS; }
+
+int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_handle* out) {
+  if (!blob || !out || n_envs <= 0 || blob_bytes < sizeof(uint32_t) * AGX_H_COUNT) return fail(AGX_E_ARG, "agx_create: bad argument");
+  const uint32_t* w = (const uint32_t*)blob; const int32_t* hi = (const int32_t*)blob;
+  if (w[AGX_H_MAGIC] != AGX_BLOB_MAGIC || w[AGX_H_VERSION] != AGX_BLOB_VERSION || (size_t)hi[AGX_H_NWORDS] * 4 != blob_bytes)
+    return fail(AGX_E_BLOB, "agx_create: not a model blob of this version");
+  if (hi[AGX_H_NDOF] > agx::MAX_DOF || hi[AGX_H_NFREE] > agx::MAX_FREE || hi[AGX_H_NHUMAN] > agx::MAX_HUMAN || hi[AGX_H_NCOLL] > agx::MAX_COLL ||
+      hi[AGX_H_STATE_WORDS] > agx::ST_WORDS || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128)
+    return fail(AGX_E_LIMIT, "agx_create: model exceeds the compiled kernel limits");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AGX_E_NOGPU, "agx_create: no HIP device (libagx has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(AGX_E_ARG, "agx_create: bad device index");
+  HIPCHK(hipSetDevice(device));
+  agx_handle h = new agx_handle_s();
+  memset(h, 0, sizeof *h);
+  h->device = device; h->n_envs = n_envs; h->act_dim = hi[AGX_H_ACT_DIM]; h->obs_dim = hi[AGX_H_OBS_DIM]; h->sw = hi[AGX_H_STATE_WORDS];
+  HIPCHK(hipMalloc(&h->blob_dev, blob_bytes));
+  HIPCHK(hipMemcpy(h->blob_dev, blob, blob_bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&h->state_dev, (size_t)n_envs * h->sw * 4));
+  HIPCHK(hipMemset(h->state_dev, 0, (size_t)n_envs * h->sw * 4));
+  HIPCHK(hipMalloc(&h->episode_dev, (size_t)n_envs * 4));
+  HIPCHK(hipMemset(h->episode_dev, 0, (size_t)n_envs * 4));
+  HIPCHK(hipMalloc(&h->act_dev, (size_t)n_envs * h->act_dim * 4));
+  HIPCHK(hipMalloc(&h->obs_dev, (size_t)n_envs * h->obs_dim * 4));
+  HIPCHK(hipMalloc(&h->rew_dev, (size_t)n_envs * 4));
+  HIPCHK(hipMalloc(&h->info_dev, (size_t)n_envs * AGX_INFO_DIM * 4));
+  HIPCHK(hipMalloc(&h->done_dev, (size_t)n_envs));
+  HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+  HIPCHK(hipFuncSetAttribute((const void*)agx_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
+  *out = h;
+  return AGX_OK;
+}
+
+void agx_destroy(agx_handle h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
+  hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
+  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  delete h;
+}
+
+int agx_dims(agx_handle h, int* n_envs, int* act_dim, int* obs_dim, int* state_words) {
+  if (!h) return fail(AGX_E_ARG, "agx_dims: null handle");
+  if (n_envs) *n_envs = h->n_envs; if (act_dim) *act_dim = h->act_dim; if (obs_dim) *obs_dim = h->obs_dim; if (state_words) *state_words = h->sw;
+  return AGX_OK;
+}
+
+int agx_set_state(agx_handle h, const float* host_states) {
+  if (!h || !host_states) return fail(AGX_E_ARG, "agx_set_state: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(h->state_dev, host_states, (size_t)h->n_envs * h->sw * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(h->episode_dev, 0, (size_t)h->n_envs * 4));
+  return AGX_OK;
+}
+int agx_get_state(agx_handle h, float* host_states) {
+  if (!h || !host_states) return fail(AGX_E_ARG, "agx_get_state: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(host_states, h->state_dev, (size_t)h->n_envs * h->sw * 4, hipMemcpyDeviceToHost));
+  return AGX_OK;
+}
+int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fail(AGX_E_ARG, "agx_state_dev: bad argument"); *out_dev = h->state_dev; return AGX_OK; }
+
+static int launch(agx_handle h, const float* act, float* obs, float* rew, uint8_t* done, float* info, float* dbg, int mode, int nsettle, void* stream) {
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(agx_step_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, (hipStream_t)stream, h->blob_dev, h->state_dev, act, obs, rew,
+                     done, info, dbg, h->n_envs, h->sw, h->act_dim, h->obs_dim, mode, nsettle);
+  HIPCHK(hipGetLastError());
+  return AGX_OK;
+}
+int agx_settle(agx_handle h, int n_substeps, void* stream) {
+  if (!h || n_substeps < 0) return fail(AGX_E_ARG, "agx_settle: bad argument");
+  return launch(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, n_substeps, stream);
+}
+int agx_step(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, void* stream) {
+  if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step: bad argument");
+  return launch(h, a, obs, rew, done, info, nullptr, 0, 0, stream);
+}
+int agx_step_debug(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, float* dbg, void* stream) {
+  if (!h || !a || !obs || !rew || !done || !dbg) return fail(AGX_E_ARG, "agx_step_debug: bad argument");
+  return launch(h, a, obs, rew, done, info, dbg, 0, 0, stream);
+}
+int agx_observe(agx_handle h, float* obs, void* stream) {
+  if (!h || !obs) return fail(AGX_E_ARG, "agx_observe: bad argument");
+  return launch(h, nullptr, obs, nullptr, nullptr, nullptr, nullptr, 2, 0, stream);
+}
+int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {
+  if (!h || !pool_dev || pool_n <= 0 || !done_dev) return fail(AGX_E_ARG, "agx_reset_done: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(agx_reset_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->state_dev, pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->sw);
+  HIPCHK(hipGetLastError());
+  return AGX_OK;
+}
+
+int agx_step_host(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info) {
+  if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step_host: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(h->act_dev, a, (size_t)h->n_envs * h->act_dim * 4, hipMemcpyHostToDevice));
+  int rc = launch(h, h->act_dev, h->obs_dev, h->rew_dev, h->done_dev, h->info_dev, nullptr, 0, 0, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(obs, h->obs_dev, (size_t)h->n_envs * h->obs_dim * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rew, h->rew_dev, (size_t)h->n_envs * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(done, h->done_dev, (size_t)h->n_envs, hipMemcpyDeviceToHost));
+  if (info) HIPCHK(hipMemcpy(info, h->info_dev, (size_t)h->n_envs * AGX_INFO_DIM * 4, hipMemcpyDeviceToHost));
+  return AGX_OK;
+}
+int agx_observe_host(agx_handle h, float* obs) {
+  if (!h || !obs) return fail(AGX_E_ARG, "agx_observe_host: bad argument");
+  int rc = launch(h, nullptr, h->obs_dev, nullptr, nullptr, nullptr, nullptr, 2, 0, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(obs, h->obs_dev, (size_t)h->n_envs * h->obs_dim * 4, hipMemcpyDeviceToHost));
+  return AGX_OK;
+}
+
+int agx_profile_begin(agx_handle h, void* stream) { if (!h) return fail(AGX_E_ARG, "agx_profile_begin: null handle"); HIPCHK(hipSetDevice(h->device)); HIPCHK(hipEventRecord(h->ev0, (hipStream_t)stream)); return AGX_OK; }
+int agx_profile_end(agx_handle h, void* stream, float* ms) {
+  if (!h || !ms) return fail(AGX_E_ARG, "agx_profile_end: bad argument");
+  HIPCHK(hipSetDevice(h->device)); HIPCHK(hipEventRecord(h->ev1, (hipStream_t)stream)); HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return AGX_OK;
+}
+int agx_synchronize(agx_handle h, void* stream) { if (!h) return fail(AGX_E_ARG, "agx_synchronize: null handle"); HIPCHK(hipSetDevice(h->device)); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return AGX_OK; }
+
+int agx_selftest(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AGX_E_NOGPU, "agx_selftest: no HIP device");
+  HIPCHK(hipSetDevice(device));
+  float* of; int* oi; unsigned long long* om;
+  HIPCHK(hipMalloc(&of, 320 * 4)); HIPCHK(hipMalloc(&oi, 192 * 4)); HIPCHK(hipMalloc(&om, 64 * 8));
+  hipLaunchKernelGGL(agx_selftest_kernel, dim3(1), dim3(64), 0, 0, of, oi, om);
+  HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
+  std::vector<float> f(320); std::vector<int> i(192); std::vector<unsigned long long> m(64);
+  HIPCHK(hipMemcpy(f.data(), of, 320 * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(i.data(), oi, 192 * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(m.data(), om, 64 * 8, hipMemcpyDeviceToHost));
+  hipFree(of); hipFree(oi); hipFree(om);
+  float x[64]; double sum = 0; float mn = 1e30f, mx = -1e30f; int isum = 0; unsigned long long bm = 0;
+  for (int l = 0; l < 64; l++) { x[l] = (float)(l * l % 17) * 0.25f - 1.0f; sum += x[l]; float y = x[l] + (float)((l * 7) % 5); if (y < mn) mn = y; if (x[l] > mx) mx = x[l]; isum += l % 7; if (l % 3 == 1) bm |= 1ull << l; }
+  int bad = 0, scan = 0;
+  for (int l = 0; l < 64; l++) {
+    if (fabs(f[l] - (float)sum) > 1e-4f) bad |= 1;
+    if (f[64 + l] != mn) bad |= 2;
+    if (f[128 + l] != x[37]) bad |= 4;
+    if (f[192 + l] != x[(l * 13 + 5) & 63]) bad |= 8;
+    if (i[l] != isum) bad |= 16;
+    if (i[64 + l] != scan) bad |= 32;
+    scan += l % 5;
+    if (m[l] != bm) bad |= 64;
+    if (i[128 + l] != __builtin_popcountll(bm & ((1ull << l) - 1ull))) bad |= 128;
+    if (f[256 + l] != mx) bad |= 256;
+  }
+  if (bad) { char b[96]; snprintf(b, sizeof b, "agx_selftest: wave primitive mismatch, mask 0x%x", bad); return fail(AGX_E_HIP, b); }
+  return AGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,883 @@
+// agx_step.h -- the batched FeedingJaco stepper: ONE WAVEFRONT PER ENVIRONMENT.
+//
+// Replaces, for N lock-stepped environments, what the reference does per env.step():
+//   AssistiveEnv.take_step         assistive_gym/envs/env.py:174-235   (action -> motor targets,
+//                                   5x [p.stepSimulation, human limit clamp, update_targets])
+//   FeedingEnv.step/_get_obs       assistive_gym/envs/feeding.py:12-48,85-112
+//   FeedingEnv.get_food_rewards    assistive_gym/envs/feeding.py:50-83
+//   AssistiveEnv.human_preferences assistive_gym/envs/env.py:237-274
+// and the physics inside p.stepSimulation() for this scene.
+//
+// Layout: the environment's state record (AGX_H_STATE_WORDS floats, contiguous in HBM) is loaded
+// with consecutive lanes reading consecutive words (coalesced), lives in LDS for all frame_skip
+// substeps, and is written back once.  The model blob (tree, inertias, hull vertices, pair table)
+// is shared by every environment and is read through L1/L2.  Generalised velocity deltas of the
+// PGS solve live in registers (lane l owns DoF l and l+64); rows are visited in order, each row's
+// dot product is a DPP wave reduction.
+#pragma once
+#include "agx_math.h"
+#include "agx_gjk.h"
+#include "../../include/agx_blob.h"
+
+namespace agx {
+
+constexpr int MAX_DOF = 12;
+constexpr int MAX_FREE = 10;
+constexpr int MAX_HUMAN = 20;
+constexpr int MAX_CON = 64;
+constexpr int MAX_ROWS = 160;
+constexpr int ST_WORDS = 320;
+constexpr int CON_STRIDE = 16;
+constexpr int HDR_STRIDE = 8;
+constexpr int ARENA_WORDS = 4096;
+
+// ---- LDS layout (float words) -------------------------------------------------------------
+constexpr int L_ST = 0;
+constexpr int L_LINKP = L_ST + ST_WORDS;                 // [MAX_DOF][3] world
+constexpr int L_LINKR = L_LINKP + MAX_DOF * 3;           // [MAX_DOF][9]
+constexpr int L_S = L_LINKR + MAX_DOF * 9;               // [MAX_DOF][6] joint screw about the ref point
+constexpr int L_VEL = L_S + MAX_DOF * 6;                 // [128] generalised velocities v*
+constexpr int L_MINV = L_VEL + 128;                      // [MAX_DOF*MAX_DOF]
+constexpr int L_FREER = L_MINV + MAX_DOF * MAX_DOF;      // [MAX_FREE][9]
+constexpr int L_FIINV = L_FREER + MAX_FREE * 9;          // [MAX_FREE][9]
+constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
+constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
+constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
+constexpr int L_CON = L_MISC + 32;                       // [MAX_CON][CON_STRIDE]
+constexpr int L_LAM = L_CON + MAX_CON * CON_STRIDE;      // [MAX_ROWS]
+constexpr int L_HDR = L_LAM + MAX_ROWS;                  // [MAX_ROWS][HDR_STRIDE]
+constexpr int L_ARENA = L_HDR + MAX_ROWS * HDR_STRIDE;
+constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
+static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
+constexpr int LDS_BYTES = LDS_WORDS * 4;
+// arena, dynamics phase
+constexpr int A_COMW = 0;                                // [MAX_DOF][3] rel. ref
+constexpr int A_IW = A_COMW + MAX_DOF * 3;               // [MAX_DOF][9]
+constexpr int A_VSP = A_IW + MAX_DOF * 9;                // [MAX_DOF][6]
+constexpr int A_CVP = A_VSP + MAX_DOF * 6;
+constexpr int A_IA = A_CVP + MAX_DOF * 6;                // [MAX_DOF][36]
+constexpr int A_U = A_IA + MAX_DOF * 36;
+constexpr int A_PA = A_U + MAX_DOF * 6;
+constexpr int A_ACC = A_PA + MAX_DOF * 6;
+constexpr int A_DINV = A_ACC + MAX_DOF * 6;              // [MAX_DOF]
+constexpr int A_UU = A_DINV + MAX_DOF;
+constexpr int A_QDD = A_UU + MAX_DOF;
+constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_DOF][6] M^-1 column workspace
+constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_DOF * 6;
+static_assert(A_DYN_END <= ARENA_WORDS, "dynamics workspace exceeds the arena");
+// arena, collision phase: world AABBs [ncoll][6]
+constexpr int MAX_COLL = 512;
+static_assert(MAX_COLL * 6 <= ARENA_WORDS, "AABB table exceeds the arena");
+// misc words
+constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
+// contact record
+constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 10, C_DIST = 13, C_MU = 14, C_LAM = 15;
+// row header
+constexpr int DBG_HDR = 16 + MAX_CON * CON_STRIDE + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE, DBG_WORDS = DBG_LAM + MAX_ROWS;
+constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_FRIC = 6, H_MU = 7;
+
+struct Ctx {
+  const float* bf; const int* bi;   // model blob
+  float* lds; int* ldsi;
+  int lane;
+  int ndof, nfree, nhuman, ncoll, ngroup, nfood, nv;
+  int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
+  int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
+  float dt;
+  int ncon, nrows, first_normal, near_mask, overflow;
+  float* dbg;   // optional debug sink (parity tests)
+};
+
+#define PRM(c, k) ((c).bf[(c).o_params + (k)])
+#define RBF(c, d, k) ((c).bf[(c).o_robot + (d) * AGX_R_STRIDE + (k)])
+#define RBI(c, d, k) ((c).bi[(c).o_robot + (d) * AGX_R_STRIDE + (k)])
+#define FBF(c, b, k) ((c).bf[(c).o_free + (b) * AGX_F_STRIDE + (k)])
+#define CLF(c, i, k) ((c).bf[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
+#define CLI(c, i, k) ((c).bi[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
+#define GRI(c, g, k) ((c).bi[(c).o_group + (g) * AGX_G_STRIDE + (k)])
+#define TKF(c, k) ((c).bf[(c).o_task + (k)])
+#define TKI(c, k) ((c).bi[(c).o_task + (k)])
+
+AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
+  c.bf = (const float*)blob; c.bi = (const int*)blob; c.lds = lds; c.ldsi = (int*)lds; c.lane = lane;
+  const int* h = c.bi;
+  c.ndof = h[AGX_H_NDOF]; c.nfree = h[AGX_H_NFREE]; c.nhuman = h[AGX_H_NHUMAN]; c.ncoll = h[AGX_H_NCOLL];
+  c.ngroup = h[AGX_H_NGROUP]; c.nfood = h[AGX_H_NFOOD]; c.nv = c.ndof + 6 * c.nfree;
+  c.o_params = h[AGX_H_OFF_PARAMS]; c.o_robot = h[AGX_H_OFF_ROBOT]; c.o_free = h[AGX_H_OFF_FREE]; c.o_coll = h[AGX_H_OFF_COLL];
+  c.o_vert = h[AGX_H_OFF_VERT]; c.o_group = h[AGX_H_OFF_GROUP]; c.o_task = h[AGX_H_OFF_TASK]; c.o_dirs = h[AGX_H_OFF_DIRS];
+  c.s_q = h[AGX_H_S_Q]; c.s_qd = h[AGX_H_S_QD]; c.s_qt = h[AGX_H_S_QT]; c.s_free = h[AGX_H_S_FREE]; c.s_base = h[AGX_H_S_BASE];
+  c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV];
+  c.dt = PRM(c, AGX_P_DT);
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.dbg = nullptr;
+}
+
+// ---- small helpers ------------------------------------------------------------------------
+AGX_DEV float dot6p(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+// body transform lookup (world rotation + world position) from the LDS tables
+AGX_DEV void body_xf(const Ctx& c, int code, m3& R, v3& p) {
+  const float* L = c.lds;
+  if (code == AGX_BODY_WORLD) { R.a[0] = 1; R.a[1] = 0; R.a[2] = 0; R.a[3] = 0; R.a[4] = 1; R.a[5] = 0; R.a[6] = 0; R.a[7] = 0; R.a[8] = 1; p = mk3(0, 0, 0); }
+  else if (code >= AGX_BODY_HUMAN0) { const float* h = L + L_HUMAN + 12 * (code - AGX_BODY_HUMAN0); p = ld3(h); R = ldm3(h + 3); }
+  else if (code >= AGX_BODY_FREE0) { int b = code - AGX_BODY_FREE0; p = ld3(L + L_ST + c.s_free + 13 * b); R = ldm3(L + L_FREER + 9 * b); }
+  else if (code == AGX_BODY_ROBOT_BASE) { p = ld3(L + L_BASE); R = ldm3(L + L_BASE + 3); }
+  else { p = ld3(L + L_LINKP + 3 * code); R = ldm3(L + L_LINKR + 9 * code); }
+}
+
+// ---- K1: kinematics (agent.py:52 getLinkState(computeForwardKinematics)) ---------------------
+AGX_DEV void kinematics(Ctx& c) {
+  float* L = c.lds; const int lane = c.lane, n = c.ndof;
+  // chain walk: every lane computes the same link frame, lane 0 publishes it
+  for (int d = 0; d < n; d++) {
+    int par = RBI(c, d, AGX_R_PARENT);
+    v3 pp; m3 PR;
+    if (par < 0) { pp = ld3(L + L_BASE); PR = ldm3(L + L_BASE + 3); } else { pp = ld3(L + L_LINKP + 3 * par); PR = ldm3(L + L_LINKR + 9 * par); }
+    v3 tp = mk3(RBF(c, d, AGX_R_TPOS), RBF(c, d, AGX_R_TPOS + 1), RBF(c, d, AGX_R_TPOS + 2));
+    m3 Rt = quat_to_m3(RBF(c, d, AGX_R_TQUAT), RBF(c, d, AGX_R_TQUAT + 1), RBF(c, d, AGX_R_TQUAT + 2), RBF(c, d, AGX_R_TQUAT + 3));
+    v3 ax = mk3(RBF(c, d, AGX_R_AXIS), RBF(c, d, AGX_R_AXIS + 1), RBF(c, d, AGX_R_AXIS + 2));
+    m3 Rq = axis_angle_m3(ax, L[L_ST + c.s_q + d]);
+    m3 R = mul(mul(PR, Rt), Rq);
+    v3 p = mul(PR, tp) + pp;
+    wave_sync();
+    if (lane == 0) { st3(L + L_LINKP + 3 * d, p); stm3(L + L_LINKR + 9 * d, R); }
+    wave_sync();
+  }
+  // end-effector frame and the reference point for the spatial algebra (keeps f32 lever arms short)
+  {
+    int ee = TKI(c, AGX_T_EE_LINK);
+    v3 lp = ld3(L + L_LINKP + 3 * ee); m3 LR = ldm3(L + L_LINKR + 9 * ee);
+    v3 ep = mul(LR, mk3(TKF(c, AGX_T_EE_POS), TKF(c, AGX_T_EE_POS + 1), TKF(c, AGX_T_EE_POS + 2))) + lp;
+    m3 ER = mul(LR, quat_to_m3(TKF(c, AGX_T_EE_QUAT), TKF(c, AGX_T_EE_QUAT + 1), TKF(c, AGX_T_EE_QUAT + 2), TKF(c, AGX_T_EE_QUAT + 3)));
+    if (lane == 0) { st3(L + L_MISC + M_REF, lp); st3(L + L_MISC + M_EEP, ep); stm3(L + L_MISC + M_EER, ER); }
+  }
+  wave_sync();
+  const v3 ref = ld3(L + L_MISC + M_REF);
+  float* A = L + L_ARENA;
+  if (lane < n) {
+    const int d = lane;
+    v3 p = ld3(L + L_LINKP + 3 * d) - ref; m3 R = ldm3(L + L_LINKR + 9 * d);
+    v3 aw = mul(R, mk3(RBF(c, d, AGX_R_AXIS), RBF(c, d, AGX_R_AXIS + 1), RBF(c, d, AGX_R_AXIS + 2)));
+    v3 pxa = cross(p, aw);
+    st3(L + L_S + 6 * d, aw); st3(L + L_S + 6 * d + 3, pxa);
+    v3 cw = mul(R, mk3(RBF(c, d, AGX_R_COM), RBF(c, d, AGX_R_COM + 1), RBF(c, d, AGX_R_COM + 2))) + p;
+    st3(A + A_COMW + 3 * d, cw);
+    m3 Il;
+    Il.a[0] = RBF(c, d, AGX_R_INERTIA); Il.a[4] = RBF(c, d, AGX_R_INERTIA + 1); Il.a[8] = RBF(c, d, AGX_R_INERTIA + 2);
+    Il.a[1] = Il.a[3] = RBF(c, d, AGX_R_INERTIA + 3); Il.a[2] = Il.a[6] = RBF(c, d, AGX_R_INERTIA + 4); Il.a[5] = Il.a[7] = RBF(c, d, AGX_R_INERTIA + 5);
+    stm3(A + A_IW + 9 * d, mul_bt(mul(R, Il), R));
+  }
+  wave_sync();
+  if (lane < n) {
+    const int d = lane;
+    float v[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = d; k >= 0; k = RBI(c, k, AGX_R_PARENT)) { float qd = L[L_ST + c.s_qd + k]; for (int j = 0; j < 6; j++) v[j] += L[L_S + 6 * k + j] * qd; }
+    float qd = L[L_ST + c.s_qd + d];
+    v3 w = mk3(v[0], v[1], v[2]), vo = mk3(v[3], v[4], v[5]);
+    v3 sw = qd * ld3(L + L_S + 6 * d), sv = qd * ld3(L + L_S + 6 * d + 3);
+    v3 ca = cross(w, sw), cl = cross(w, sv) + cross(vo, sw);
+    for (int j = 0; j < 6; j++) A[A_VSP + 6 * d + j] = v[j];
+    st3(A + A_CVP + 6 * d, ca); st3(A + A_CVP + 6 * d + 3, cl);
+  }
+  // free bodies: rotation matrices and world inverse inertia
+  if (lane < c.nfree) {
+    const int b = lane; const float* r = L + L_ST + c.s_free + 13 * b;
+    m3 R = quat_to_m3(r[3], r[4], r[5], r[6]);
+    stm3(L + L_FREER + 9 * b, R);
+    m3 Di; for (int k = 0; k < 9; k++) Di.a[k] = 0;
+    for (int k = 0; k < 3; k++) { float I = FBF(c, b, AGX_F_INERTIA + k); Di.a[4 * k] = I > 0 ? 1.0f / I : 0.0f; }
+    stm3(L + L_FIINV + 9 * b, mul_bt(mul(R, Di), R));
+  }
+  wave_sync();
+}
+
+// ---- K4: articulated-body algorithm, world-frame spatial algebra about the ref point ---------
+AGX_DEV float skewc(v3 c, int i, int j) {   // [c]x entry (i,j)
+  if (i == j) return 0.f;
+  int k = 3 - i - j; float s = ((j - i + 3) % 3 == 1) ? -1.f : 1.f;
+  return s * comp(c, k);
+}
+AGX_DEV void aba_and_minv(Ctx& c) {
+  float* L = c.lds; float* A = L + L_ARENA; const int lane = c.lane, n = c.ndof;
+  const float kl = PRM(c, AGX_P_LIN_DAMP), ka = PRM(c, AGX_P_ANG_DAMP), gz = PRM(c, AGX_P_ROBOT_GRAVITY_Z);
+  // spatial inertias -> IA (lanes = matrix entries), bias forces -> pA (lanes = links)
+  if (lane < 36) {
+    const int r = lane / 6, cc = lane % 6;
+    for (int d = 0; d < n; d++) {
+      float m = RBF(c, d, AGX_R_MASS); v3 cw = ld3(A + A_COMW + 3 * d);
+      float val;
+      if (r < 3 && cc < 3) val = A[A_IW + 9 * d + 3 * r + cc] + m * ((r == cc ? dot(cw, cw) : 0.f) - comp(cw, r) * comp(cw, cc));
+      else if (r < 3) val = m * skewc(cw, r, cc - 3);
+      else if (cc < 3) val = m * skewc(cw, cc, r - 3);
+      else val = (r == cc) ? m : 0.f;
+      A[A_IA + 36 * d + lane] = val;
+    }
+  }
+  if (lane < n) {
+    const int d = lane;
+    float m = RBF(c, d, AGX_R_MASS); v3 cw = ld3(A + A_COMW + 3 * d); m3 Iw = ldm3(A + A_IW + 9 * d);
+    v3 w = ld3(A + A_VSP + 6 * d), vo = ld3(A + A_VSP + 6 * d + 3);
+    v3 vc = vo + cross(w, cw);
+    v3 hl = m * vc, ha = mul(Iw, w) + cross(cw, hl);            // momentum about the ref point
+    v3 pa_ang = cross(w, ha) + cross(vo, hl), pa_lin = cross(w, hl);
+    // external force: gravity + velocity damping [BULLET-UNVERIFIED, see oracle]
+    float sl = kl + kl * sqrtf(dot(vc, vc)), sa = ka + ka * sqrtf(dot(w, w));
+    v3 f = mk3(0, 0, m * gz) - (m * sl) * vc;
+    v3 tau = -(sa * mul(Iw, w));
+    v3 fa = tau + cross(cw, f);
+    st3(A + A_PA + 6 * d, pa_ang - fa); st3(A + A_PA + 6 * d + 3, pa_lin - f);
+  }
+  wave_sync();
+  // pass 2: leaves -> root
+  for (int d = n - 1; d >= 0; d--) {
+    if (lane < 6) { float s = 0; for (int k = 0; k < 6; k++) s += A[A_IA + 36 * d + 6 * lane + k] * L[L_S + 6 * d + k]; A[A_U + 6 * d + lane] = s; }
+    wave_sync();
+    float D = dot6p(L + L_S + 6 * d, A + A_U + 6 * d);
+    float Dinv = D > 1e-30f ? 1.0f / D : 0.0f;
+    float u = -RBF(c, d, AGX_R_JDAMP) * L[L_ST + c.s_qd + d] - dot6p(L + L_S + 6 * d, A + A_PA + 6 * d);
+    if (lane == 0) { A[A_DINV + d] = Dinv; A[A_UU + d] = u; }
+    int par = RBI(c, d, AGX_R_PARENT);
+    if (par >= 0) {
+      float addp = 0.f;
+      if (lane < 6) {
+        float s = 0;
+        for (int j = 0; j < 6; j++) s += (A[A_IA + 36 * d + 6 * lane + j] - A[A_U + 6 * d + lane] * A[A_U + 6 * d + j] * Dinv) * A[A_CVP + 6 * d + j];
+        addp = A[A_PA + 6 * d + lane] + s + A[A_U + 6 * d + lane] * (u * Dinv);
+      }
+      if (lane < 36) { const int r = lane / 6, cc = lane % 6; A[A_IA + 36 * par + lane] += A[A_IA + 36 * d + lane] - A[A_U + 6 * d + r] * A[A_U + 6 * d + cc] * Dinv; }
+      if (lane < 6) A[A_PA + 6 * par + lane] += addp;
+    }
+    wave_sync();
+  }
+  // pass 3: root -> leaves (every lane computes the same chain; lane 0 publishes)
+  for (int d = 0; d < n; d++) {
+    int par = RBI(c, d, AGX_R_PARENT);
+    float ap[6];
+    for (int k = 0; k < 6; k++) ap[k] = (par < 0 ? 0.f : A[A_ACC + 6 * par + k]) + A[A_CVP + 6 * d + k];
+    float qdd = (A[A_UU + d] - dot6p(A + A_U + 6 * d, ap)) * A[A_DINV + d];
+    wave_sync();
+    if (lane == 0) { A[A_QDD + d] = qdd; for (int k = 0; k < 6; k++) A[A_ACC + 6 * d + k] = ap[k] + L[L_S + 6 * d + k] * qdd; }
+    wave_sync();
+  }
+  // M^-1: lane j = response to a unit force on joint j (Bullet: calcAccelerationDeltasMultiDof)
+  if (lane < n) {
+    const int j = lane; float* P = A + A_COLS + j * (MAX_DOF * 6);
+    for (int k = 0; k < n * 6; k++) P[k] = 0.f;
+    float uu[MAX_DOF];
+    for (int d = n - 1; d >= 0; d--) {
+      float u = (d == j ? 1.f : 0.f) - dot6p(L + L_S + 6 * d, P + 6 * d);
+      uu[d] = u;
+      int par = RBI(c, d, AGX_R_PARENT);
+      if (par >= 0) { float s = u * A[A_DINV + d]; for (int k = 0; k < 6; k++) P[6 * par + k] += P[6 * d + k] + A[A_U + 6 * d + k] * s; }
+    }
+    // reuse P as the acceleration workspace
+    for (int d = 0; d < n; d++) {
+      int par = RBI(c, d, AGX_R_PARENT);
+      float ap[6]; for (int k = 0; k < 6; k++) ap[k] = par < 0 ? 0.f : P[6 * par + k];
+      float qdd = (uu[d] - dot6p(A + A_U + 6 * d, ap)) * A[A_DINV + d];
+      for (int k = 0; k < 6; k++) P[6 * d + k] = ap[k] + L[L_S + 6 * d + k] * qdd;
+      L[L_MINV + d * MAX_DOF + j] = qdd;
+    }
+  }
+  wave_sync();
+  if (c.dbg && lane < n) { c.dbg[4 + lane] = A[A_QDD + lane]; }
+}
+
+// ---- unconstrained velocity update -------------------------------------------------------------
+AGX_DEV void predict_velocities(Ctx& c) {
+  float* L = c.lds; float* A = L + L_ARENA; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
+  for (int k = lane; k < 128; k += 64) L[L_VEL + k] = 0.f;
+  wave_sync();
+  if (lane < n) L[L_VEL + lane] = L[L_ST + c.s_qd + lane] + dt * A[A_QDD + lane];
+  if (lane < c.nfree) {
+    const int b = lane, o = n + 6 * b; const float* r = L + L_ST + c.s_free + 13 * b;
+    v3 v = ld3(r + 7), w = ld3(r + 10);
+    float kl = PRM(c, AGX_P_LIN_DAMP), ka = PRM(c, AGX_P_ANG_DAMP);
+    float sl = kl + kl * sqrtf(dot(v, v)), sa = ka + ka * sqrtf(dot(w, w));
+    v3 g = mk3(0, 0, FBF(c, b, AGX_F_GRAVITY));
+    st3(L + L_VEL + o, v + dt * (g - sl * v));
+    m3 R = ldm3(L + L_FREER + 9 * b), Ii = ldm3(L + L_FIINV + 9 * b);
+    v3 wl = tmul(R, w);
+    v3 Iw = mul(R, mk3(FBF(c, b, AGX_F_INERTIA) * wl.x, FBF(c, b, AGX_F_INERTIA + 1) * wl.y, FBF(c, b, AGX_F_INERTIA + 2) * wl.z));
+    v3 acc = mul(Ii, -cross(w, Iw));
+    st3(L + L_VEL + o + 3, w + dt * (acc - sa * w));
+  }
+  wave_sync();
+}
+
+// velocity of the material point of body `code` at world point x from the generalised velocities
+AGX_DEV v3 point_velocity(const Ctx& c, int code, v3 x) {
+  const float* L = c.lds;
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) {
+    float sv[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = code; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { float q = L[L_VEL + d]; for (int k = 0; k < 6; k++) sv[k] += L[L_S + 6 * d + k] * q; }
+    v3 xr = x - ld3(L + L_MISC + M_REF);
+    return mk3(sv[3], sv[4], sv[5]) + cross(mk3(sv[0], sv[1], sv[2]), xr);
+  } else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) {
+    int b = code - AGX_BODY_FREE0, o = c.ndof + 6 * b;
+    v3 r = x - ld3(L + L_ST + c.s_free + 13 * b);
+    return ld3(L + L_VEL + o) + cross(ld3(L + L_VEL + o + 3), r);
+  }
+  return mk3(0, 0, 0);
+}
+
+// ---- K2/K3: collision ----------------------------------------------------------------------------
+struct Cand { v3 pa, pb, n; float dist, gap; };
+
+AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
+  s.n = CLI(c, col, AGX_C_NVERT);
+  s.v = c.bf + c.o_vert + 3 * CLI(c, col, AGX_C_VOFF);
+  v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), s.R, p);
+  s.p = p - shift;
+}
+// closest features of colliders (ca, cb); true if the separation (radii included) is below limit
+AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out) {
+  const float* AB = c.lds + L_ARENA;
+  v3 shift = mk3(0.5f * (AB[6 * ca] + AB[6 * ca + 3]), 0.5f * (AB[6 * ca + 1] + AB[6 * ca + 4]), 0.5f * (AB[6 * ca + 2] + AB[6 * ca + 5]));
+  gjk_shape sa, sb; make_shape(c, ca, shift, sa); make_shape(c, cb, shift, sb);
+  float ra = CLF(c, ca, AGX_C_RADIUS), rb = CLF(c, cb, AGX_C_RADIUS);
+  float d; v3 pa, pb, n;
+  bool pen = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), d, pa, pb);
+  if (!pen) {
+    if (d - ra - rb >= limit) return false;
+    n = (1.0f / d) * (pa - pb);
+  } else {
+    float depth; gjk_penetration(sa, sb, c.bf + c.o_dirs, c.bi[AGX_H_NDIR], depth, n, pa, pb);
+    d = -depth;
+  }
+  out.pa = pa - ra * n + shift; out.pb = pb + rb * n + shift; out.n = n; out.dist = d - ra - rb;
+  return true;
+}
+AGX_DEV float pair_mu(const Ctx& c, int ca, int cb) {
+  float plane_mu = c.lds[L_ST + c.s_env + AGX_E_PLANE_FRICTION];
+  float mua = CLI(c, ca, AGX_C_TAG) == AGX_TAG_PLANE ? plane_mu : CLF(c, ca, AGX_C_FRICTION);
+  float mub = CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE ? plane_mu : CLF(c, cb, AGX_C_FRICTION);
+  return mua * mub;
+}
+AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
+  float* o = c.lds + L_CON + CON_STRIDE * slot; int* oi = (int*)o;
+  oi[C_CA] = ca; oi[C_CB] = cb; oi[C_BA] = CLI(c, ca, AGX_C_BODY); oi[C_BB] = CLI(c, cb, AGX_C_BODY);
+  st3(o + C_PA, k.pa); st3(o + C_PB, k.pb); st3(o + C_N, k.n); o[C_DIST] = k.dist; o[C_MU] = pair_mu(c, ca, cb); o[C_LAM] = 0.f;
+}
+// one candidate test for this lane: AABB cull, GJK, predicted-gap rule.  gap = 3e38 when rejected.
+AGX_DEV void test_pair(Ctx& c, int a, int b, bool valid, float brk, float slack, Cand& k, bool& near_any) {
+  const float* AB = c.lds + L_ARENA;
+  k.gap = 3.0e38f; near_any = false;
+  if (!valid) return;
+  bool sep = false;
+  for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + brk || AB[6 * b + q] > AB[6 * a + 3 + q] + brk) sep = true;
+  if (sep) return;
+  if (!narrowphase(c, a, b, brk, k)) return;
+  near_any = true;
+  v3 vr = point_velocity(c, CLI(c, a, AGX_C_BODY), k.pa) - point_velocity(c, CLI(c, b, AGX_C_BODY), k.pb);
+  float pg = k.dist + dot(vr, k.n) * c.dt;
+  if (pg < slack) k.gap = pg;
+}
+AGX_DEV void collide(Ctx& c) {
+  float* L = c.lds; float* AB = L + L_ARENA; const int lane = c.lane;
+  const float brk = PRM(c, AGX_P_CONTACT_BREAK), slack = PRM(c, AGX_P_CONTACT_SLACK);
+  int maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (maxc > MAX_CON) maxc = MAX_CON;
+  // world AABBs of every collider (lanes over colliders)
+  for (int col = lane; col < c.ncoll; col += 64) {
+    m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
+    v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
+    v3 hl = mk3(CLF(c, col, AGX_C_AABB_H), CLF(c, col, AGX_C_AABB_H + 1), CLF(c, col, AGX_C_AABB_H + 2));
+    v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
+    for (int k = 0; k < 3; k++) {
+      float h = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
+      AB[6 * col + k] = comp(cw, k) - h; AB[6 * col + 3 + k] = comp(cw, k) + h;
+    }
+  }
+  wave_sync();
+  int ncon = 0, near_mask = 0, overflow = 0;
+  const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER];
+  for (int g = 0; g < c.ngroup; g++) {
+    int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
+    if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
+    const bool same = GRI(c, g, AGX_G_FLAGS) & 1; const int keep = GRI(c, g, AGX_G_KEEP);
+    const bool two = (b1 - b0) > 64;
+    for (int a = a0; a < a1; a++) {
+      // lanes over the B range (two passes when it is wider than the wave)
+      Cand k0, k1; bool n0 = false, n1 = false;
+      int bb0 = b0 + lane, bb1 = b0 + 64 + lane;
+      test_pair(c, a, bb0, bb0 < b1 && (!same || bb0 > a), brk, slack, k0, n0);
+      k1.gap = 3.0e38f;
+      if (two) test_pair(c, a, bb1, bb1 < b1 && (!same || bb1 > a), brk, slack, k1, n1);
+      if (CLI(c, a, AGX_C_TAG) == AGX_TAG_FOOD && CLI(c, b0, AGX_C_TAG) == AGX_TAG_HUMAN && wave_any(n0 || n1))
+        near_mask |= 1 << (CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - c.bi[AGX_H_FOOD0]);
+      if (keep > 0) {
+        for (int q = 0; q < keep; q++) {
+          float mg = wave_min(fminf(k0.gap, k1.gap));
+          if (mg > 1.0e38f) break;
+          uint64_t m0 = wave_ballot(k0.gap == mg);
+          int slot1 = 0, win;
+          if (m0) win = ffs64(m0); else { win = ffs64(wave_ballot(k1.gap == mg)); slot1 = 1; }
+          if (ncon < maxc) { if (lane == win) { if (slot1) emit_contact(c, ncon, a, bb1, k1); else emit_contact(c, ncon, a, bb0, k0); } ncon++; }
+          else overflow++;
+          if (lane == win) { if (slot1) k1.gap = 3.0e38f; else k0.gap = 3.0e38f; }
+        }
+      } else {
+        for (int pass = 0; pass < (two ? 2 : 1); pass++) {
+          bool has = (pass ? k1.gap : k0.gap) < 1.0e38f;
+          uint64_t m = wave_ballot(has);
+          int cnt = popc64(m), slot = ncon + wave_rank(m);
+          if (has && slot < maxc) { if (pass) emit_contact(c, slot, a, bb1, k1); else emit_contact(c, slot, a, bb0, k0); }
+          int room = maxc - ncon; if (room < 0) room = 0;
+          if (cnt > room) { overflow += cnt - room; cnt = room; }
+          ncon += cnt;
+        }
+      }
+    }
+  }
+  c.ncon = ncon; c.near_mask = near_mask; c.overflow = overflow;
+  wave_sync();
+}
+
+// ---- K5: constraint rows -----------------------------------------------------------------------------
+// accumulate the Jacobian of a unit force f / unit torque t applied to body `code` at world point x
+AGX_DEV void add_jac(const Ctx& c, int code, v3 x, v3 f, v3 t, float sign, float* Jr, float* Jf) {
+  const float* L = c.lds;
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) {
+    v3 xr = x - ld3(L + L_MISC + M_REF);
+    v3 Fa = cross(xr, f) + t;
+    float F[6] = {Fa.x, Fa.y, Fa.z, f.x, f.y, f.z};
+    const int anc = c.ldsi[L_MISC + M_ANC + code];
+    for (int d = 0; d < c.ndof; d++) if (anc >> d & 1) Jr[d] += sign * dot6p(L + L_S + 6 * d, F);
+  } else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) {
+    int b = code - AGX_BODY_FREE0;
+    v3 r = x - ld3(L + L_ST + c.s_free + 13 * b);
+    v3 ta = cross(r, f) + t;
+    Jf[0] += sign * f.x; Jf[1] += sign * f.y; Jf[2] += sign * f.z; Jf[3] += sign * ta.x; Jf[4] += sign * ta.y; Jf[5] += sign * ta.z;
+  }
+}
+struct RowGeom { float Jr[MAX_DOF]; float Ja[6]; float Jb[6]; int fa, fb; bool robot; };   // fa/fb: free body index or -1
+AGX_DEV void row_clear(RowGeom& r) { for (int k = 0; k < MAX_DOF; k++) r.Jr[k] = 0.f; for (int k = 0; k < 6; k++) { r.Ja[k] = 0.f; r.Jb[k] = 0.f; } r.fa = -1; r.fb = -1; r.robot = false; }
+// force +f (torque +t) on body A at xa, -f (-t) on body B at xb
+AGX_DEV void row_pair(const Ctx& c, RowGeom& r, int codeA, v3 xa, int codeB, v3 xb, v3 f, v3 t) {
+  row_clear(r);
+  if (codeA >= 0 && codeA < AGX_BODY_ROBOT_BASE) r.robot = true;
+  if (codeB >= 0 && codeB < AGX_BODY_ROBOT_BASE) r.robot = true;
+  if (codeA >= AGX_BODY_FREE0 && codeA < AGX_BODY_HUMAN0) r.fa = codeA - AGX_BODY_FREE0;
+  if (codeB >= AGX_BODY_FREE0 && codeB < AGX_BODY_HUMAN0) r.fb = codeB - AGX_BODY_FREE0;
+  add_jac(c, codeA, xa, f, t, 1.f, r.Jr, r.Ja);
+  add_jac(c, codeB, xb, f, t, -1.f, r.Jr, r.Jb);
+}
+AGX_DEV float row_velocity(const Ctx& c, const RowGeom& r) {
+  const float* L = c.lds; float s = 0.f;
+  if (r.robot) for (int d = 0; d < c.ndof; d++) s += r.Jr[d] * L[L_VEL + d];
+  if (r.fa >= 0) for (int k = 0; k < 6; k++) s += r.Ja[k] * L[L_VEL + c.ndof + 6 * r.fa + k];
+  if (r.fb >= 0) for (int k = 0; k < 6; k++) s += r.Jb[k] * L[L_VEL + c.ndof + 6 * r.fb + k];
+  return s;
+}
+AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { return (r.robot ? c.ndof : 0) + (r.fa >= 0 ? 6 : 0) + (r.fb >= 0 ? 6 : 0); }
+// B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
+// A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
+AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float bterm, float lo, float hi, int fric_of, float mu) {
+  float* L = c.lds; float* E = L + L_ARENA + 2 * off; const int n = c.ndof;
+  float D = 0.f; int e = 0;
+  int a0 = 0, na = 0, b0 = 0, nb = 0;
+  if (r.robot) {
+    a0 = 0; na = n;
+    for (int i = 0; i < n; i++) { float acc = 0.f; for (int j = 0; j < n; j++) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j]; E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++; }
+  }
+  for (int side = 0; side < 2; side++) {
+    int fb = side == 0 ? r.fa : r.fb; if (fb < 0) continue;
+    const float* J = side == 0 ? r.Ja : r.Jb;
+    float mass = FBF(c, fb, AGX_F_MASS), im = mass > 0 ? 1.0f / mass : 0.f;
+    v3 Ba = mul(ldm3(L + L_FIINV + 9 * fb), mk3(J[3], J[4], J[5]));
+    float B[6] = {im * J[0], im * J[1], im * J[2], Ba.x, Ba.y, Ba.z};
+    int base = n + 6 * fb;
+    if (na == 0 && nb == 0 && !r.robot) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
+    for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
+  }
+  // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
+  float* H = L + L_HDR + HDR_STRIDE * row; int* Hi = (int*)H;
+  H[H_INVD] = D > 1e-12f ? 1.0f / D : 0.f; H[H_B] = bterm; H[H_LO] = lo; H[H_HI] = hi;
+  Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off; Hi[H_FRIC] = fric_of; H[H_MU] = mu;
+}
+AGX_DEV void plane_space(v3 n, v3& p) {
+  if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
+  else { float a = n.x * n.x + n.y * n.y, k = 1.0f / sqrtf(a); p = mk3(-n.y * k, n.x * k, 0); }
+}
+AGX_DEV void m3_to_euler_xyz(const m3& M, float* e) {
+  const float* R = M.a; float fi = R[2];
+  if (fi < 1.0f) { if (fi > -1.0f) { e[0] = atan2f(-R[5], R[8]); e[1] = asinf(R[2]); e[2] = atan2f(-R[1], R[0]); }
+    else { e[0] = -atan2f(R[3], R[4]); e[1] = -1.57079632679f; e[2] = 0; } }
+  else { e[0] = atan2f(R[3], R[4]); e[1] = 1.57079632679f; e[2] = 0; }
+}
+
+AGX_DEV void build_rows(Ctx& c) {
+  float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
+  const float erp = PRM(c, AGX_P_ERP), cerp = PRM(c, AGX_P_CONTACT_ERP);
+  int maxrows = (int)PRM(c, AGX_P_MAX_ROWS); if (maxrows > MAX_ROWS) maxrows = MAX_ROWS;
+  int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > ARENA_WORDS / 2) maxent = ARENA_WORDS / 2;
+  // --- non-contact rows: lanes 0..15 motors, 16..47 joint limits (dof, side), 48..53 tool constraint
+  RowGeom r; row_clear(r);
+  bool active = false; float bterm = 0.f, lo = 0.f, hi = 0.f;
+  if (lane < 16) {
+    const int d = lane;
+    if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f) {
+      active = true; r.robot = true; r.Jr[d] = 1.f;
+      // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
+      bterm = RBF(c, d, AGX_R_KP) * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
+      float lim = RBF(c, d, AGX_R_MAXF) * dt; lo = -lim; hi = lim;
+    }
+  } else if (lane < 48) {
+    const int d = (lane - 16) >> 1, side = (lane - 16) & 1;
+    if (d < n && RBI(c, d, AGX_R_HAS_LIMIT)) {
+      float q = L[L_ST + c.s_q + d];
+      float gap = side == 0 ? q - RBF(c, d, AGX_R_LOWER) : RBF(c, d, AGX_R_UPPER) - q;
+      if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
+        active = true; r.robot = true; r.Jr[d] = side == 0 ? 1.f : -1.f;
+        float rv = r.Jr[d] * L[L_VEL + d];
+        bterm = gap > 0 ? (-gap / dt - rv) : (-gap * erp / dt - rv);
+        lo = 0.f; hi = 1e30f;
+      }
+    }
+  } else if (lane < 54) {
+    // tool fixed constraint (tool.py:46-47)
+    const int k = lane - 48; active = true;
+    v3 eep = ld3(L + L_MISC + M_EEP); m3 eeR = ldm3(L + L_MISC + M_EER);
+    v3 pivA = mul(eeR, mk3(TKF(c, AGX_T_TOOL_POS), TKF(c, AGX_T_TOOL_POS + 1), TKF(c, AGX_T_TOOL_POS + 2))) + eep;
+    m3 frameA = mul(eeR, quat_to_m3(TKF(c, AGX_T_TOOL_QUAT), TKF(c, AGX_T_TOOL_QUAT + 1), TKF(c, AGX_T_TOOL_QUAT + 2), TKF(c, AGX_T_TOOL_QUAT + 3)));
+    const int tb = c.bi[AGX_H_TOOL_BODY];
+    v3 pivB = ld3(L + L_ST + c.s_free + 13 * tb); m3 frameB = ldm3(L + L_FREER + 9 * tb);
+    float lim = TKF(c, AGX_T_TOOL_MAXF) * dt; lo = -lim; hi = lim;
+    const int link = TKI(c, AGX_T_EE_LINK);
+    if (k < 3) {
+      v3 nrm = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
+      row_pair(c, r, link, pivA, AGX_BODY_FREE0 + tb, pivB, nrm, mk3(0, 0, 0));
+      bterm = -comp(pivA - pivB, k) * erp / dt - row_velocity(c, r);
+    } else {
+      float ang[3]; m3_to_euler_xyz(mul_at(frameA, frameB), ang);
+      const int q = k - 3;
+      v3 axw = mk3(frameA.a[q], frameA.a[3 + q], frameA.a[6 + q]);
+      row_pair(c, r, link, pivA, AGX_BODY_FREE0 + tb, pivB, mk3(0, 0, 0), axw);
+      bterm = ang[q] * erp / dt - row_velocity(c, r);
+    }
+  }
+  int cnt = active ? row_entries(c, r) : 0;
+  uint64_t am = wave_ballot(active);
+  int row = wave_rank(am), off = 1 + wave_scan_excl(cnt);      // entry 0 of the arena is the zero pair
+  int nnc = popc64(am), ent = 1 + wave_sum_i(cnt);
+  wave_sync();
+  if (lane == 0) { L[L_ARENA] = 0.f; L[L_ARENA + 1] = 0.f; }
+  // contacts are needed below but live outside the arena; AABBs (arena) are dead from here on
+  if (active) row_store(c, r, row, off, bterm, lo, hi, -1, 0.f);
+  // --- contact rows: lane = contact; normal rows first, then one friction row per contact
+  int nc = c.ncon;
+  const bool has = lane < nc;
+  int ba = 0, bb = 0; v3 pa = mk3(0, 0, 0), pb = pa, nn = pa; float dist = 0.f, mu = 0.f;
+  RowGeom rn; row_clear(rn);
+  if (has) {
+    const float* k = L + L_CON + CON_STRIDE * lane; const int* ki = (const int*)k;
+    ba = ki[C_BA]; bb = ki[C_BB]; pa = ld3(k + C_PA); pb = ld3(k + C_PB); nn = ld3(k + C_N); dist = k[C_DIST]; mu = k[C_MU];
+    row_pair(c, rn, ba, pa, bb, pb, nn, mk3(0, 0, 0));
+  }
+  int ccnt = has ? row_entries(c, rn) : 0;
+  int cincl = wave_scan_excl(ccnt) + ccnt;
+  // largest prefix of the contact list that fits the row and coefficient budgets
+  bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent);
+  nc = popc64(wave_ballot(fits));
+  const int tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0);
+  const int entN = ent, entF = ent + (nc > 0 ? tot : 0);
+  if (lane < nc) {
+    float rv = row_velocity(c, rn);
+    float bn = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv);
+    row_store(c, rn, nnc + lane, entN + cincl - ccnt, bn, 0.f, 1e30f, -1, 0.f);
+    // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
+    v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);
+    v3 t = vr - dot(vr, nn) * nn;
+    float l2 = dot(t, t);
+    if (l2 > PRM(c, AGX_P_FRIC_EPS)) t = (1.0f / sqrtf(l2)) * t; else plane_space(nn, t);
+    RowGeom rf; row_pair(c, rf, ba, pa, bb, pb, t, mk3(0, 0, 0));
+    row_store(c, rf, nnc + nc + lane, entF + cincl - ccnt, -row_velocity(c, rf), 0.f, 0.f, nnc + lane, mu);
+  }
+  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc;
+  wave_sync();
+}
+
+// ---- K6: projected Gauss-Seidel --------------------------------------------------------------------------
+// Rows are visited in construction order (Gauss-Seidel is order dependent).  Per row: every lane
+// multiplies its (at most two) Jacobian coefficients with the velocity deltas it owns, one DPP
+// reduction gives J.dv, the impulse update is wave-uniform, every lane applies B*dlambda to its
+// DoFs.  Accumulated impulses live in registers: lane (r & 63) owns row r of slot (r >> 6).
+AGX_DEV float lam_pick(int slot, float l0, float l1, float l2) { return slot == 0 ? l0 : (slot == 1 ? l1 : l2); }
+AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
+  float* L = c.lds; const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER), nrows = c.nrows;
+  const float* E = L + L_ARENA;
+  dv0 = 0.f; dv1 = 0.f;
+  float lam0 = 0.f, lam1 = 0.f, lam2 = 0.f;
+  static_assert(MAX_ROWS <= 192, "three impulse registers per lane");
+  const int dof0 = lane, dof1 = lane + 64;
+  for (int it = 0; it < iters; it++) {
+    for (int r = 0; r < nrows; r++) {
+      const float* H = L + L_HDR + HDR_STRIDE * r; const int* Hi = (const int*)H;
+      const float invD = H[H_INVD];
+      if (invD == 0.f) continue;
+      const int pack = Hi[H_PACK], off = Hi[H_OFF], fr = Hi[H_FRIC];
+      const int a0 = pack & 255, na = (pack >> 8) & 255, b0 = (pack >> 16) & 255, nb = (pack >> 24) & 255;
+      float lo = H[H_LO], hi = H[H_HI];
+      if (fr >= 0) { hi = H[H_MU] * wave_bcast(lam_pick(fr >> 6, lam0, lam1, lam2), fr & 63); lo = -hi; }
+      // this lane's coefficients: entry 0 of the arena holds (0,0)
+      unsigned ia = (unsigned)(dof0 - a0), ib = (unsigned)(dof0 - b0);
+      int e0 = ia < (unsigned)na ? off + (int)ia : (ib < (unsigned)nb ? off + na + (int)ib : 0);
+      ia = (unsigned)(dof1 - a0); ib = (unsigned)(dof1 - b0);
+      int e1 = ia < (unsigned)na ? off + (int)ia : (ib < (unsigned)nb ? off + na + (int)ib : 0);
+      const float j0 = E[2 * e0], c0 = E[2 * e0 + 1], j1 = E[2 * e1], c1 = E[2 * e1 + 1];
+      const float lam = wave_bcast(lam_pick(r >> 6, lam0, lam1, lam2), r & 63);
+      const float jdv = wave_sum(j0 * dv0 + j1 * dv1);
+      float nl = lam + (H[H_B] - jdv) * invD;
+      nl = fminf(fmaxf(nl, lo), hi);
+      const float dl = nl - lam;
+      if (lane == (r & 63)) { const int slot = r >> 6; if (slot == 0) lam0 = nl; else if (slot == 1) lam1 = nl; else lam2 = nl; }
+      dv0 += c0 * dl; dv1 += c1 * dl;
+    }
+  }
+  wave_sync();
+  L[L_LAM + lane] = lam0; L[L_LAM + 64 + lane] = lam1; if (128 + lane < MAX_ROWS) L[L_LAM + 128 + lane] = lam2;
+  wave_sync();
+}
+
+// ---- K7 + post-substep hooks -----------------------------------------------------------------------------
+AGX_DEV void integrate(Ctx& c, float dv0, float dv1) {
+  float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
+  if (lane < c.nv) L[L_VEL + lane] += dv0;
+  if (lane + 64 < c.nv) L[L_VEL + lane + 64] += dv1;
+  // contact impulses of this substep (what getContactPoints reports until the next step)
+  if (lane < c.ncon) L[L_CON + CON_STRIDE * lane + C_LAM] = L[L_LAM + c.first_normal + lane];
+  wave_sync();
+  if (lane < n) { float qd = L[L_VEL + lane]; L[L_ST + c.s_qd + lane] = qd; L[L_ST + c.s_q + lane] += dt * qd; }
+  if (lane < c.nfree) {
+    const int b = lane, o = n + 6 * b; float* r = L + L_ST + c.s_free + 13 * b;
+    v3 v = ld3(L + L_VEL + o), w = ld3(L + L_VEL + o + 3);
+    st3(r + 7, v); st3(r + 10, w); st3(r, ld3(r) + dt * v);
+    float wn = sqrtf(dot(w, w)), th = wn * dt; float dq[4];
+    if (th > 1e-12f) { float sc = sinf(0.5f * th) / wn; dq[0] = w.x * sc; dq[1] = w.y * sc; dq[2] = w.z * sc; dq[3] = cosf(0.5f * th); }
+    else { dq[0] = 0.5f * dt * w.x; dq[1] = 0.5f * dt * w.y; dq[2] = 0.5f * dt * w.z; dq[3] = 1.f; }
+    const float ax = dq[0], ay = dq[1], az = dq[2], aw = dq[3], bx = r[3], by = r[4], bz = r[5], bw = r[6];
+    float x = aw * bx + ax * bw + ay * bz - az * by, y = aw * by - ax * bz + ay * bw + az * bx;
+    float z = aw * bz + ax * by - ay * bx + az * bw, w2 = aw * bw - ax * bx - ay * by - az * bz;
+    float nn = 1.0f / sqrtf(x * x + y * y + z * z + w2 * w2);
+    r[3] = x * nn; r[4] = y * nn; r[5] = z * nn; r[6] = w2 * nn;
+  }
+  // FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset
+  if (lane == 0) {
+    const int hb = TKI(c, AGX_T_HEAD_BODY), o = c.ldsi[L_ST + c.s_env + AGX_E_GENDER] == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
+    const float* h = L + L_HUMAN + 12 * hb;
+    st3(L + L_ST + c.s_env + AGX_E_TARGET, mul(ldm3(h + 3), mk3(TKF(c, o), TKF(c, o + 1), TKF(c, o + 2))) + ld3(h));
+  }
+  wave_sync();
+}
+
+// one p.stepSimulation() (env.py:226) plus env.py:227-232
+AGX_DEV void substep(Ctx& c) {
+  kinematics(c);
+  aba_and_minv(c);
+  predict_velocities(c);
+  collide(c);
+  build_rows(c);
+  float dv0, dv1;
+  pgs(c, dv0, dv1);
+  integrate(c, dv0, dv1);
+}
+
+// ---- state load / store ---------------------------------------------------------------------------------
+AGX_DEV void load_env(Ctx& c, const float* gstate, int sw) {
+  float* L = c.lds; const int lane = c.lane;
+  for (int k = lane; k < sw; k += 64) L[L_ST + k] = gstate[k];
+  wave_sync();
+  if (lane == 0) { const float* r = L + L_ST + c.s_base; st3(L + L_BASE, ld3(r)); stm3(L + L_BASE + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
+  if (lane < c.nhuman) { const float* r = L + L_ST + c.s_human + 7 * lane; float* h = L + L_HUMAN + 12 * lane; st3(h, ld3(r)); stm3(h + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
+  if (lane < c.ndof) { int m = 0; for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) m |= 1 << d; c.ldsi[L_MISC + M_ANC + lane] = m; }
+  wave_sync();
+}
+AGX_DEV void store_env(Ctx& c, float* gstate, int sw) {
+  wave_sync();
+  for (int k = c.lane; k < sw; k += 64) gstate[k] = c.lds[L_ST + k];
+}
+
+// ---- task layer ------------------------------------------------------------------------------------------
+AGX_DEV uint32_t rng_next(uint32_t& s0, uint32_t& s1) {
+  uint64_t x = ((uint64_t)s1 << 32) | s0;
+  x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+  s0 = (uint32_t)x; s1 = (uint32_t)(x >> 32);
+  return (uint32_t)(x >> 33) ^ (uint32_t)(x >> 11);
+}
+AGX_DEV void tool_base_pose(const Ctx& c, v3& p, m3& R) {
+  const float* L = c.lds; const int tb = c.bi[AGX_H_TOOL_BODY];
+  m3 FR = ldm3(L + L_FREER + 9 * tb); v3 fp = ld3(L + L_ST + c.s_free + 13 * tb);
+  p = mul(FR, mk3(FBF(c, tb, AGX_F_REFPOS), FBF(c, tb, AGX_F_REFPOS + 1), FBF(c, tb, AGX_F_REFPOS + 2))) + fp;
+  R = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
+}
+// FeedingEnv._get_obs (feeding.py:85-112), robot part; every lane computes, lane 0 writes
+AGX_DEV void observe(const Ctx& c, float tool_force, float* gobs) {
+  const float* L = c.lds;
+  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
+  const float* h = L + L_HUMAN + 12 * TKI(c, AGX_T_HEAD_BODY);
+  v3 hpr = tmul(BR, ld3(h) - bp); q4 hq = m3_to_quat(mul_at(BR, ldm3(h + 3)));
+  v3 tpr = tmul(BR, ld3(L + L_ST + c.s_env + AGX_E_TARGET) - bp);
+  if (c.lane == 0) {
+    int o = 0;
+    gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z;
+    gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
+    gobs[o++] = spr.x - tpr.x; gobs[o++] = spr.y - tpr.y; gobs[o++] = spr.z - tpr.z;
+    for (int d = 0; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+      float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
+      gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
+    }
+    gobs[o++] = hpr.x; gobs[o++] = hpr.y; gobs[o++] = hpr.z;
+    gobs[o++] = hq.x; gobs[o++] = hq.y; gobs[o++] = hq.z; gobs[o++] = hq.w;
+    gobs[o++] = tool_force;
+  }
+}
+
+// mode 0: full env.step(); mode 1: `nsettle` physics substeps only (feeding.py:178-179); mode 2: observation only
+AGX_DEV void env_step(const uint32_t* blob, float* gstate, const float* gaction, float* gobs, float* greward, uint8_t* gdone,
+                      float* ginfo, float* gdebug, float* lds, int lane, int mode, int nsettle) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS];
+  load_env(c, gstate, sw);
+  if (mode == 2) { kinematics(c); observe(c, 0.f, gobs); return; }
+  if (mode == 1) { for (int k = 0; k < nsettle; k++) substep(c); store_env(c, gstate, sw); return; }
+  const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP), act_dim = c.bi[AGX_H_ACT_DIM];
+  // take_step (env.py:174-222): clip, scale, 5x accumulate against the joint limits -> motor targets
+  if (lane == 0) Li[L_ST + c.s_env + AGX_E_ITERATION] += 1;
+  if (lane < c.ndof) {
+    const int d = lane, ai = RBI(c, d, AGX_R_ACT);
+    if (ai >= 0) {
+      float a = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
+      float qa = L[L_ST + c.s_q + d]; const float lo = RBF(c, d, AGX_R_LOWER), hi = RBF(c, d, AGX_R_UPPER);
+      for (int k = 0; k < nsub; k++) {
+        bool below = qa + a < lo, above = qa + a > hi;
+        if (below || above) a = 0.f;
+        if (below) qa = lo; if (above) qa = hi;
+        qa += a;
+      }
+      L[L_ST + c.s_qt + d] = qa;
+    }
+  }
+  float an2 = 0.f;
+  for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
+  wave_sync();
+  for (int k = 0; k < nsub; k++) {
+    c.dbg = (k == 0) ? gdebug : nullptr;
+    substep(c);
+    if (gdebug && k == 0) {   // first-substep internals for the parity tests
+      if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // [4..4+ndof) = qdd of the first ABA
+      for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = L[L_CON + q];
+      for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[16 + MAX_CON * CON_STRIDE + q] = L[L_MINV + q];
+      for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = L[L_HDR + q];
+      for (int q = lane; q < MAX_ROWS; q += 64) gdebug[DBG_LAM + q] = L[L_LAM + q];
+    }
+  }
+  kinematics(c);   // poses as the getters of _get_obs see them after the last stepSimulation
+  // get_total_force (feeding.py:45-48) from the last substep's contact impulses
+  float rf = 0.f, tf = 0.f;
+  if (lane < c.ncon) {
+    const float* k = L + L_CON + CON_STRIDE * lane; const int* ki = (const int*)k;
+    int ta = CLI(c, ki[C_CA], AGX_C_TAG), tb = CLI(c, ki[C_CB], AGX_C_TAG);
+    if (ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN) {
+      int other = ta == AGX_TAG_HUMAN ? tb : ta; float f = k[C_LAM] / c.dt;
+      if (other == AGX_TAG_ROBOT) rf = f;
+      if (other == AGX_TAG_TOOL) tf = f;
+    }
+  }
+  const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), total_f = robot_f + tool_f;
+  observe(c, tool_f, gobs);
+  // get_food_rewards (feeding.py:50-83)
+  float food_reward = 0.f, food_hit = 0.f, vel_sum = 0.f;
+  int alive = Li[L_ST + c.s_env + AGX_E_FOOD_ALIVE], active = Li[L_ST + c.s_env + AGX_E_FOOD_ACTIVE];
+  int success = Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS];
+  uint32_t r0 = (uint32_t)Li[L_ST + c.s_env + AGX_E_RNG], r1 = (uint32_t)Li[L_ST + c.s_env + AGX_E_RNG + 1];
+  const int active_on_entry = active, hit_mask = c.near_mask, food0 = c.bi[AGX_H_FOOD0];
+  const v3 target = ld3(L + L_ST + c.s_env + AGX_E_TARGET);
+  // world AABBs of the tool colliders + particles for the 0.1 m closest-point query (agent.py:118-130)
+  {
+    float* AB = L + L_ARENA;
+    for (int col = lane; col < c.ncoll; col += 64) {
+      int tag = CLI(c, col, AGX_C_TAG);
+      if (tag != AGX_TAG_TOOL && tag != AGX_TAG_FOOD) continue;
+      m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
+      v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
+      v3 hl = mk3(CLF(c, col, AGX_C_AABB_H), CLF(c, col, AGX_C_AABB_H + 1), CLF(c, col, AGX_C_AABB_H + 2));
+      v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
+      for (int k = 0; k < 3; k++) {
+        float hh = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
+        AB[6 * col + k] = comp(cw, k) - hh; AB[6 * col + 3 + k] = comp(cw, k) + hh;
+      }
+    }
+    wave_sync();
+  }
+  int tool0 = -1, tool1 = -1, foodc0 = -1;
+  for (int g = 0; g < c.ngroup; g++) {   // the (food, tool) group carries both collider ranges
+    int a0 = GRI(c, g, AGX_G_A0), b0 = GRI(c, g, AGX_G_B0);
+    if (CLI(c, a0, AGX_C_TAG) == AGX_TAG_FOOD && CLI(c, b0, AGX_C_TAG) == AGX_TAG_TOOL) { foodc0 = a0; tool0 = b0; tool1 = GRI(c, g, AGX_G_B1); break; }
+  }
+  const float spill = TKF(c, AGX_T_SPILL_DIST);
+  for (int k = 0; k < c.nfood; k++) {
+    if (!(alive >> k & 1)) continue;
+    const int b = food0 + k; float* r = L + L_ST + c.s_free + 13 * b;
+    v3 d = target - ld3(r);
+    if (sqrtf(dot(d, d)) < TKF(c, AGX_T_MOUTH_DIST)) {
+      food_reward += 20.f; success += 1; vel_sum += sqrtf(dot(ld3(r + 7), ld3(r + 7)));
+      alive &= ~(1 << k); active &= ~(1 << k);
+      float px = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      float py = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      float pz = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      wave_sync();
+      if (lane == 0) { r[0] = px; r[1] = py; r[2] = pz; r[3] = 0.f; r[4] = 0.f; r[5] = 0.f; r[6] = 1.f; }
+      wave_sync();
+      continue;
+    }
+    bool near = false;
+    {
+      const int fc = foodc0 + k; const float* AB = L + L_ARENA;
+      for (int base = tool0; base < tool1; base += 64) {
+        const int tc = base + lane; bool hitl = false;
+        if (tc < tool1) {
+          bool sep = false;
+          for (int q = 0; q < 3; q++) if (AB[6 * fc + q] > AB[6 * tc + 3 + q] + spill || AB[6 * tc + q] > AB[6 * fc + 3 + q] + spill) sep = true;
+          Cand tmp; if (!sep) hitl = narrowphase(c, fc, tc, spill, tmp);
+        }
+        if (wave_any(hitl)) near = true;
+      }
+    }
+    if (!near) { food_reward -= 5.f; alive &= ~(1 << k); }
+  }
+  for (int k = 0; k < c.nfood; k++) if ((active_on_entry >> k & 1) && (hit_mask >> k & 1)) { food_hit -= 1.f; active &= ~(1 << k); }
+  // end-effector speed (feeding.py:22), human_preferences (env.py:237-274, feeding branch), reward
+  const float* A = L + L_ARENA; (void)A;
+  float ee_speed;
+  {
+    const int ee = TKI(c, AGX_T_EE_LINK);
+    float sv[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = ee; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { float qd = L[L_ST + c.s_qd + d]; for (int j = 0; j < 6; j++) sv[j] += L[L_S + 6 * d + j] * qd; }
+    v3 xr = ld3(L + L_MISC + M_EEP) - ld3(L + L_MISC + M_REF);
+    v3 v = mk3(sv[3], sv[4], sv[5]) + cross(mk3(sv[0], sv[1], sv[2]), xr);
+    ee_speed = sqrtf(dot(v, v));
+  }
+  float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-total_f) + TKF(c, AGX_T_C_HF) * (tool_f < 10.f ? 0.f : -tool_f)
+             + TKF(c, AGX_T_C_FD) * food_hit + TKF(c, AGX_T_C_FDV) * (-vel_sum);
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  v3 dd = target - sp;
+  float reward = TKF(c, AGX_T_W_DISTANCE) * (-sqrtf(dot(dd, dd))) + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + TKF(c, AGX_T_W_FOOD) * food_reward + pref;
+  const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];
+  wave_sync();
+  if (lane == 0) {
+    Li[L_ST + c.s_env + AGX_E_FOOD_ALIVE] = alive; Li[L_ST + c.s_env + AGX_E_FOOD_ACTIVE] = active;
+    Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS] = success; Li[L_ST + c.s_env + AGX_E_RNG] = (int)r0; Li[L_ST + c.s_env + AGX_E_RNG + 1] = (int)r1;
+    *greward = reward;
+    *gdone = (uint8_t)(iteration >= (int)TKF(c, AGX_T_EPISODE_LEN));
+    if (ginfo) {
+      ginfo[AGX_INFO_TOTAL_FORCE] = total_f;
+      ginfo[AGX_INFO_TASK_SUCCESS] = (float)(success >= Li[L_ST + c.s_env + AGX_E_TOTAL_FOOD] * TKF(c, AGX_T_SUCCESS_FRAC));
+      ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = tool_f; ginfo[AGX_INFO_FOOD_REWARD] = food_reward;
+      ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
+    }
+  }
+  store_env(c, gstate, sw);
+}
+
+}  // namespace agx

@@ -1,0 +1,82 @@
+// agx_wave.h -- wave64 primitives for gfx950 (CDNA4).  One wavefront = one environment.
+//
+// Everything cross-lane in the stepper goes through this header: DPP reductions (no LDS
+// traffic), ballots, uniform broadcasts.  Workgroups are a single wavefront, so wave_sync() is a
+// plain LDS fence for the wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AGX_DEV __device__ __forceinline__
+#define AGX_DEV_NOINLINE __device__ __noinline__
+#define AGX_WAVE 64
+
+AGX_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
+AGX_DEV void wave_sync() { __syncthreads(); }
+
+// DPP controls (cdna4 ISA: DPP_CTRL)
+#define AGX_DPP_QUAD_1032 0xb1
+#define AGX_DPP_QUAD_2301 0x4e
+#define AGX_DPP_ROW_SHR4 0x114
+#define AGX_DPP_ROW_SHR8 0x118
+#define AGX_DPP_ROW_BCAST15 0x142
+#define AGX_DPP_ROW_BCAST31 0x143
+
+template <int CTRL>
+AGX_DEV float dpp_mov(float identity, float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+AGX_DEV int dpp_mov_i(int identity, int x) { return __builtin_amdgcn_update_dpp(identity, x, CTRL, 0xf, 0xf, false); }
+
+// sum over the 64 lanes, result uniform in every lane
+AGX_DEV float wave_sum(float x) {
+  x += dpp_mov<AGX_DPP_QUAD_1032>(0.f, x);
+  x += dpp_mov<AGX_DPP_QUAD_2301>(0.f, x);
+  x += dpp_mov<AGX_DPP_ROW_SHR4>(0.f, x);
+  x += dpp_mov<AGX_DPP_ROW_SHR8>(0.f, x);
+  x += dpp_mov<AGX_DPP_ROW_BCAST15>(0.f, x);
+  x += dpp_mov<AGX_DPP_ROW_BCAST31>(0.f, x);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+AGX_DEV float wave_min(float x) {
+  const float id = 3.0e38f;
+  x = fminf(x, dpp_mov<AGX_DPP_QUAD_1032>(id, x));
+  x = fminf(x, dpp_mov<AGX_DPP_QUAD_2301>(id, x));
+  x = fminf(x, dpp_mov<AGX_DPP_ROW_SHR4>(id, x));
+  x = fminf(x, dpp_mov<AGX_DPP_ROW_SHR8>(id, x));
+  x = fminf(x, dpp_mov<AGX_DPP_ROW_BCAST15>(id, x));
+  x = fminf(x, dpp_mov<AGX_DPP_ROW_BCAST31>(id, x));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+AGX_DEV float wave_max(float x) { return -wave_min(-x); }
+AGX_DEV int wave_sum_i(int x) {
+  x += dpp_mov_i<AGX_DPP_QUAD_1032>(0, x);
+  x += dpp_mov_i<AGX_DPP_QUAD_2301>(0, x);
+  x += dpp_mov_i<AGX_DPP_ROW_SHR4>(0, x);
+  x += dpp_mov_i<AGX_DPP_ROW_SHR8>(0, x);
+  x += dpp_mov_i<AGX_DPP_ROW_BCAST15>(0, x);
+  x += dpp_mov_i<AGX_DPP_ROW_BCAST31>(0, x);
+  return __builtin_amdgcn_readlane(x, 63);
+}
+AGX_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
+AGX_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
+// value of lane `src` (src may differ per lane)
+AGX_DEV float wave_shfl(float x, int src) { return __shfl(x, src, 64); }
+AGX_DEV int wave_shfl_i(int x, int src) { return __shfl(x, src, 64); }
+// value of lane `src`, src wave-uniform
+AGX_DEV float wave_bcast(float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); }
+AGX_DEV int wave_bcast_i(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
+// number of set bits of `mask` strictly below this lane
+AGX_DEV int wave_rank(uint64_t mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+AGX_DEV int popc64(uint64_t m) { return __popcll(m); }
+AGX_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+// exclusive prefix sum over lanes (Hillis-Steele on ds_bpermute; used a few times per substep only)
+AGX_DEV int wave_scan_excl(int x) {
+  const int lane = wave_lane();
+  int incl = x;
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+  return incl - x;
+}

@@ -1,0 +1,126 @@
+"""ctypes binding of libagx (include/agx.h).  There is no CPU fallback: if the HIP library is
+missing or no GPU is visible, constructing a stepper raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libagx.so')
+_LIB = None
+
+EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
+           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_debug_words',
+           'agx_observe', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
+           'agx_synchronize', 'agx_selftest']
+
+
+class AgxError(RuntimeError):
+    pass
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise AgxError('libagx.so is not built (%s); run `python -m assistive_gym_amd.build` -- there is no CPU path' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.agx_version.restype = C.c_char_p
+        L.agx_last_error.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise AgxError('%s failed (%d): %s' % (what, rc, load().agx_last_error().decode()))
+
+
+def _ptr(x):
+    """device pointer of a torch tensor / raw int, or None"""
+    if x is None:
+        return None
+    if hasattr(x, 'data_ptr'):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+class Stepper:
+    """Thin owner of one agx_handle: N lock-stepped environments on one GPU."""
+
+    def __init__(self, blob, n_envs, device=0):
+        self.L = load()
+        self.blob = blob
+        words = np.ascontiguousarray(blob.words)
+        h = C.c_void_p()
+        check(self.L.agx_create(words.ctypes.data_as(C.c_void_p), C.c_size_t(words.nbytes), C.c_int(n_envs), C.c_int(device), C.byref(h)), 'agx_create')
+        self.h = h
+        self.n_envs, self.device = n_envs, device
+        self.act_dim, self.obs_dim, self.state_words = blob.act_dim, blob.obs_dim, blob.state_words
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.agx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, states):
+        states = np.ascontiguousarray(states, dtype=np.float32)
+        assert states.shape == (self.n_envs, self.state_words)
+        check(self.L.agx_set_state(self.h, states.ctypes.data_as(C.c_void_p)), 'agx_set_state')
+
+    def get_state(self):
+        out = np.zeros((self.n_envs, self.state_words), dtype=np.float32)
+        check(self.L.agx_get_state(self.h, out.ctypes.data_as(C.c_void_p)), 'agx_get_state')
+        return out
+
+    def state_dev(self):
+        p = C.c_void_p()
+        check(self.L.agx_state_dev(self.h, C.byref(p)), 'agx_state_dev')
+        return p.value
+
+    def settle(self, n_substeps, stream=0):
+        check(self.L.agx_settle(self.h, C.c_int(n_substeps), C.c_void_p(stream)), 'agx_settle')
+
+    def step_dev(self, actions, obs, reward, done, info=None, stream=0, debug=None):
+        if debug is not None:
+            check(self.L.agx_step_debug(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), _ptr(debug), C.c_void_p(stream)), 'agx_step_debug')
+        else:
+            check(self.L.agx_step(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), C.c_void_p(stream)), 'agx_step')
+
+    def observe_dev(self, obs, stream=0):
+        check(self.L.agx_observe(self.h, _ptr(obs), C.c_void_p(stream)), 'agx_observe')
+
+    def reset_done(self, pool, pool_n, done, stream=0):
+        check(self.L.agx_reset_done(self.h, _ptr(pool), C.c_int(pool_n), _ptr(done), C.c_void_p(stream)), 'agx_reset_done')
+
+    def step_host(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, self.act_dim)
+        obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
+        rew = np.zeros(self.n_envs, dtype=np.float32)
+        done = np.zeros(self.n_envs, dtype=np.uint8)
+        info = np.zeros((self.n_envs, 8), dtype=np.float32)
+        check(self.L.agx_step_host(self.h, a.ctypes.data_as(C.c_void_p), obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p),
+                                   done.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p)), 'agx_step_host')
+        return obs, rew, done.astype(bool), info
+
+    def observe_host(self):
+        obs = np.zeros((self.n_envs, self.obs_dim), dtype=np.float32)
+        check(self.L.agx_observe_host(self.h, obs.ctypes.data_as(C.c_void_p)), 'agx_observe_host')
+        return obs
+
+    def profile_begin(self, stream=0):
+        check(self.L.agx_profile_begin(self.h, C.c_void_p(stream)), 'agx_profile_begin')
+
+    def profile_end(self, stream=0):
+        ms = C.c_float()
+        check(self.L.agx_profile_end(self.h, C.c_void_p(stream), C.byref(ms)), 'agx_profile_end')
+        return ms.value
+
+    def synchronize(self, stream=0):
+        check(self.L.agx_synchronize(self.h, C.c_void_p(stream)), 'agx_synchronize')

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched FeedingJaco-v1 stepper (BASELINE.json metric).
+
+One "step" = one env.step() of every one of the 4096 lock-stepped environments of a GPU
+(5 physics substeps of dt 0.02 + observation + reward), plus the auto-reset of
+finished episodes from a device-resident pool.  Actions are a pre-generated random tape already in
+HBM (random-policy rollout, the env_viewer loop of the reference).  With --gpus N every rank steps
+its own 4096 environments (weak scaling) and the per-step observation all-gather over RCCL is
+inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def cpu_baseline(blob, states, n_envs, n_steps):
+    """The CPU oracle (oracle/, plain C, f64, one thread) timed on a bounded sample of the same
+    workload on this box's host cores.  kind = "port": a restatement, NOT PyBullet."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle_lib import Oracle
+    o = Oracle(blob)
+    rng = np.random.RandomState(0)
+    st = states[:n_envs].copy()
+    t0 = time.perf_counter()
+    for k in range(n_steps):
+        a = rng.uniform(-1, 1, (n_envs, blob.act_dim)).astype(np.float32)
+        for i in range(n_envs):
+            o.step(st[i], a[i])
+    dt = time.perf_counter() - t0
+    return dict(value=n_envs * n_steps / dt, unit='env-steps/s', cores=1, kind='port',
+                sample='%d envs x %d steps of the same FeedingJaco workload, C f64 oracle, 1 thread (not PyBullet)' % (n_envs, n_steps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--pool', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: libagx has no CPU path')
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    n = args.envs_per_gpu
+    blob = ModelBlob.load('feeding_jaco')
+    env = FeedingJacoVecEnv(n, device=local_rank, seed=1001, pool_size=args.pool)
+    env.reset(env_offset=rank * n)
+    K, W = args.steps, args.warmup
+    g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
+    tape = torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1
+    gathered = torch.empty((world * n, blob.obs_dim), device='cuda') if distributed else None
+
+    def one(k):
+        obs, rew, done, info = env.step(tape[k])
+        if distributed:
+            dist.all_gather_into_tensor(gathered, obs)
+
+    for k in range(W):
+        one(k)
+    stream = torch.cuda.current_stream().cuda_stream
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    env.stepper.profile_begin(stream)
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        one(k)
+    kernel_ms = env.stepper.profile_end(stream)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        total_steps = world * n * K
+        value = total_steps / elapsed
+        sw = blob.state_words
+        # algorithmic HBM bytes per env-step: state record read + written once, action read, obs /
+        # reward / done / info written (DESIGN.md "bytes per env-step")
+        bytes_per_env_step = 2 * sw * 4 + blob.act_dim * 4 + blob.obs_dim * 4 + 4 + 1 + 8 * 4
+        launch_s = kernel_ms * 1e-3 / K
+        achieved = bytes_per_env_step * n / launch_s / 1e9
+        out = {
+            'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'FeedingJaco-v1, %d lockstep envs per MI355X, random-policy rollout, 5 substeps/step, 50 PGS sweeps' % n,
+                       'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': args.pool, 'parallelism': 'env-sharded x%d' % world,
+                       'obs_allgather': bool(distributed)},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel': 'agx_step_kernel', 'kernel_ms_per_launch': kernel_ms / K,
+                         'algorithmic_bytes_per_env_step': bytes_per_env_step,
+                         'note': 'latency/VALU-bound solver; HBM fraction reported as the contract requires (SURVEY 8d)'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host, 16, 40)
+        print(json.dumps(out))
+    env.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

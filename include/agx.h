@@ -1,0 +1,84 @@
+/* agx.h -- C ABI of libagx: the MI355X-native batched stepper behind Assistive Gym's
+ * env.step() hot path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference repo):
+ *
+ *   agx_create        p.connect(p.DIRECT) + the world build of reset()
+ *                     (assistive_gym/envs/env.py:34,91-134; envs/feeding.py:114-172), for N envs.
+ *                     The world is handed over as a compiled model blob (include/agx_blob.h).
+ *   agx_set_state /   no reference equivalent (the reference has no p.saveState/restoreState,
+ *   agx_get_state     SURVEY section 5): state injection for parity tests, checkpoints, reset pools.
+ *   agx_settle        the settle loop `for _ in range(25): p.stepSimulation()` (feeding.py:178-179).
+ *   agx_step          FeedingEnv.step(action) for every env: AssistiveEnv.take_step
+ *                     (envs/env.py:174-235) incl. 5x p.stepSimulation() (env.py:226), _get_obs
+ *                     (feeding.py:85-112), get_food_rewards (feeding.py:50-83), human_preferences
+ *                     (env.py:237-274), reward / done / info (feeding.py:25-37).
+ *   agx_observe       the `return self._get_obs()` of reset() (feeding.py:182).
+ *   agx_reset_done    gym's TimeLimit/auto-reset on done (assistive_gym/__init__.py:11), drawing
+ *                     the new post-reset state from a caller-provided pool.
+ *
+ * All `*_dev` pointers are DEVICE pointers (HBM) owned by the caller; `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  Calls on one handle must come from one thread at a
+ * time; handles are independent.  Every function returns 0 on success or a negative AGX_E_* code
+ * and never calls exit(); agx_last_error() describes the last failure of the calling thread.
+ */
+#ifndef AGX_H
+#define AGX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agx_handle_s* agx_handle;
+
+enum { AGX_OK = 0, AGX_E_ARG = -1, AGX_E_BLOB = -2, AGX_E_HIP = -3, AGX_E_NOGPU = -4, AGX_E_LIMIT = -5 };
+
+#define AGX_INFO_DIM 8   /* see AGX_INFO_* in agx_blob.h */
+
+/* library / build information */
+const char* agx_version(void);
+const char* agx_last_error(void);
+int agx_device_count(void);
+int agx_lds_bytes_per_env(void);
+
+int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_handle* out);
+void agx_destroy(agx_handle h);
+int agx_dims(agx_handle h, int* n_envs, int* act_dim, int* obs_dim, int* state_words);
+
+/* host <-> device copies of the per-env state records, [n_envs][state_words] float32 */
+int agx_set_state(agx_handle h, const float* host_states);
+int agx_get_state(agx_handle h, float* host_states);
+/* device address of the state records (e.g. to fill them from a device-resident pool) */
+int agx_state_dev(agx_handle h, float** out_dev);
+
+int agx_settle(agx_handle h, int n_substeps, void* stream);
+int agx_step(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
+             uint8_t* done_dev, float* info_dev, void* stream);
+/* same as agx_step, additionally dumping first-substep internals ([n_envs][agx_debug_words()]) */
+int agx_step_debug(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
+                   uint8_t* done_dev, float* info_dev, float* debug_dev, void* stream);
+int agx_debug_words(void);
+int agx_observe(agx_handle h, float* obs_dev, void* stream);
+/* envs with done != 0 get a fresh state from pool_dev ([pool_n][state_words]); the pool entry is
+ * (env_index + 977 * episode_count) mod pool_n, so results do not depend on GPU placement */
+int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream);
+
+/* convenience wrappers with HOST buffers (copies included; not the timed path) */
+int agx_step_host(agx_handle h, const float* actions, float* obs, float* reward, uint8_t* done, float* info);
+int agx_observe_host(agx_handle h, float* obs);
+
+/* HIP-event timing of the kernels launched between begin and end on `stream` */
+int agx_profile_begin(agx_handle h, void* stream);
+int agx_profile_end(agx_handle h, void* stream, float* elapsed_ms);
+
+int agx_synchronize(agx_handle h, void* stream);
+
+/* wave-primitive self test (DPP reductions, ballots, scans): returns 0 if the device matches the
+ * host-computed expectations */
+int agx_selftest(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

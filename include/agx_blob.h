@@ -54,6 +54,7 @@ enum {
   AGX_P_HUMAN_GRAVITY_Z,
   AGX_P_CONTACT_SLACK,   /* solver rows only for contacts that could close within one substep:
                             dist + v_n*dt < slack (rows that stay inactive have no effect)         */
+  AGX_P_MAX_ENTRIES,     /* cap on the summed (J,B) coefficient pairs of all rows of a substep    */
   AGX_P_COUNT = 24
 };
 

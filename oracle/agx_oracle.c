@@ -414,7 +414,7 @@ int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int m
   /* seed simplex with the first vertices so witness points are always defined */
   memcpy(A[0], a, 24); memcpy(B[0], b, 24); memcpy(W[0], v, 24); n = 1;
   for (it = 0; it < maxit; it++) {
-    if (vv < 1e-24) { pen = 1; break; }
+    if (vv < 1e-12) { pen = 1; break; }   /* cores closer than 1 micron: treat as overlapping */
     double nv[3] = {-v[0], -v[1], -v[2]};
     int ia = support(a, na, nv), ib = support(b, nb, v);
     double w[3]; sub3(a + 3 * ia, b + 3 * ib, w);
@@ -670,9 +670,24 @@ static void build_rows(sim_t* s) {
       r->b = ang[k] * erp / dt - row_vel(s, r); r->lo = -lim; r->hi = lim;
     }
   }
-  /* contact normals, then one friction row per contact */
-  int first_normal = s->nrows, nc = s->ncon;
-  if (first_normal + 2 * nc > maxrows) nc = (maxrows - first_normal) / 2;
+  /* contact normals, then one friction row per contact.  The contact list is truncated to the
+   * longest prefix that fits the row budget and the (J,B) coefficient budget: a row stores one
+   * pair per DoF of each dynamic body it touches (all robot DoFs, 6 per free body). */
+  int first_normal = s->nrows, nc = 0;
+  {
+    int ent = 1, maxent = (int)PARAM(m, AGX_P_MAX_ENTRIES);
+    /* non-contact rows: motors and limits address the robot; the 6 tool rows (last) robot + tool */
+    for (int r0 = 0; r0 < first_normal; r0++) ent += n + (r0 >= first_normal - 6 ? 6 : 0);
+    int acc = 0;
+    for (int c = 0; c < s->ncon; c++) {
+      const contact_t* k = &s->con[c];
+      int robot = (k->ba >= 0 && k->ba < AGX_BODY_ROBOT_BASE) || (k->bb >= 0 && k->bb < AGX_BODY_ROBOT_BASE);
+      int e = (robot ? n : 0) + ((k->ba >= AGX_BODY_FREE0 && k->ba < AGX_BODY_HUMAN0) ? 6 : 0) + ((k->bb >= AGX_BODY_FREE0 && k->bb < AGX_BODY_HUMAN0) ? 6 : 0);
+      acc += e;
+      if (first_normal + 2 * (c + 1) > maxrows || ent + 2 * acc > maxent) break;
+      nc = c + 1;
+    }
+  }
   for (int c = 0; c < nc; c++) {
     contact_t* k = &s->con[c]; row_t* r = NEWROW();
     body_jacobian(s, k->ba, k->pa, k->n, NULL, 1.0, r->J); body_jacobian(s, k->bb, k->pb, k->n, NULL, -1.0, r->J);
@@ -976,6 +991,15 @@ int agxo_collide(const agxo_model* m, const float* state, double* out, int max_o
   for (int c = 0; c < n; c++) { double* o = out + 12 * c; const contact_t* k = &s->con[c];
     o[0] = k->ca; o[1] = k->cb; memcpy(o + 2, k->pa, 24); memcpy(o + 5, k->pb, 24); memcpy(o + 8, k->n, 24); o[11] = k->dist; }
   free(s); return n;
+}
+/* rows of one substep: [b, lo, hi, invD, lambda] per row; returns the row count */
+int agxo_rows_debug(const agxo_model* m, float* state, double* out, int max_out) {
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
+  s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
+  substep(s);
+  int n = s->nrows < max_out ? s->nrows : max_out;
+  for (int r = 0; r < n; r++) { double* o = out + 5 * r; o[0] = s->rows[r].b; o[1] = s->rows[r].lo; o[2] = s->rows[r].hi; o[3] = s->rows[r].invD; o[4] = s->rows[r].lambda; }
+  sim_store(s, state); free(s->rows); free(s); return n;
 }
 int agxo_substep_debug(const agxo_model* m, float* state, double* out, int max_out) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);

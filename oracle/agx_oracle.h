@@ -56,6 +56,7 @@ int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int m
  * [colliderA, colliderB, pA(3), pB(3), n(3) (from B to A), distance]; returns count */
 int agxo_collide(const agxo_model* m, const float* state, double* out, int max_out);
 /* one substep returning the solved contact impulses (same row layout + impulse appended = 13) */
+int agxo_rows_debug(const agxo_model* m, float* state, double* out, int max_out);
 int agxo_substep_debug(const agxo_model* m, float* state, double* contacts_out, int max_out);
 
 #ifdef __cplusplus

@@ -26,6 +26,7 @@ def lib():
         L.agxo_gjk.restype = C.c_int
         L.agxo_collide.restype = C.c_int
         L.agxo_substep_debug.restype = C.c_int
+        L.agxo_rows_debug.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -112,4 +113,9 @@ class Oracle:
     def substep_debug(self, state, max_out=96):
         out = np.zeros((max_out, 13))
         n = self.L.agxo_substep_debug(C.c_void_p(self.h), _p(state), _p(out), C.c_int(max_out))
+        return out[:n]
+
+    def rows_debug(self, state, max_out=320):
+        out = np.zeros((max_out, 5))
+        n = self.L.agxo_rows_debug(C.c_void_p(self.h), _p(state), _p(out), C.c_int(max_out))
         return out[:n]
