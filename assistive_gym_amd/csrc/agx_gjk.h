@@ -9,9 +9,25 @@ struct gjk_shape {
   int n;
   m3 R;             // body rotation (world)
   v3 p;             // body position minus the pair's shift point
+  bool box;         // axis-aligned world box given by lo/hi (shifted frame) instead of vertices
+  v3 lo, hi;
 };
 
+AGX_DEV v3 gjk_vertex0(const gjk_shape& s) {
+  if (s.box) return s.lo;
+  return mul(s.R, mk3(s.v[0], s.v[1], s.v[2])) + s.p;
+}
 AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
+  if (s.box) {
+    // vertex order of the 8-corner enumeration (x major): first maximum wins, like the vertex scan
+    v3 best = s.lo; float bd = dot(s.lo, d);
+    for (int q = 1; q < 8; q++) {
+      v3 c = mk3((q & 4) ? s.hi.x : s.lo.x, (q & 2) ? s.hi.y : s.lo.y, (q & 1) ? s.hi.z : s.lo.z);
+      float t = dot(c, d);
+      if (t > bd) { bd = t; best = c; }
+    }
+    return best;
+  }
   v3 dl = tmul(s.R, d);
   int best = 0;
   float bd = s.v[0] * dl.x + s.v[1] * dl.y + s.v[2] * dl.z;
@@ -86,7 +102,7 @@ AGX_DEV bool gjk_solve(gjk_simplex& s, v3& v) {
 // returns true when the cores overlap; otherwise dist / witness points (shifted frame)
 AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, int maxit, float& dist, v3& pa, v3& pb) {
   gjk_simplex s;
-  v3 a0 = mul(sa.R, mk3(sa.v[0], sa.v[1], sa.v[2])) + sa.p, b0 = mul(sb.R, mk3(sb.v[0], sb.v[1], sb.v[2])) + sb.p;
+  v3 a0 = gjk_vertex0(sa), b0 = gjk_vertex0(sb);
   v3 v = a0 - b0;
   float vv = dot(v, v);
   s.A[0] = a0; s.B[0] = b0; s.W[0] = v; s.n = 1; s.lam[0] = 1; s.lam[1] = s.lam[2] = s.lam[3] = 0;

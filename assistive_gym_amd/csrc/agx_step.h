@@ -73,7 +73,7 @@ constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
 // contact record
 constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 10, C_DIST = 13, C_MU = 14, C_LAM = 15;
 // row header
-constexpr int DBG_HDR = 16 + MAX_CON * CON_STRIDE + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE, DBG_WORDS = DBG_LAM + MAX_ROWS;
+constexpr int DBG_HDR = 16 + MAX_CON * CON_STRIDE + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE, DBG_TIME = DBG_LAM + MAX_ROWS, DBG_WORDS = DBG_TIME + 16;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_FRIC = 6, H_MU = 7;
 
 struct Ctx {
@@ -86,6 +86,7 @@ struct Ctx {
   float dt;
   int ncon, nrows, first_normal, near_mask, overflow;
   float* dbg;   // optional debug sink (parity tests)
+  long long tm[8]; bool timing;   // per-phase shader-clock totals (debug path only)
 };
 
 #define PRM(c, k) ((c).bf[(c).o_params + (k)])
@@ -109,6 +110,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV];
   c.dt = PRM(c, AGX_P_DT);
   c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.dbg = nullptr;
+  c.timing = false; for (int k = 0; k < 8; k++) c.tm[k] = 0;
 }
 
 // ---- small helpers ------------------------------------------------------------------------
@@ -326,13 +328,23 @@ AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
   s.n = CLI(c, col, AGX_C_NVERT);
   s.v = c.bf + c.o_vert + 3 * CLI(c, col, AGX_C_VOFF);
   v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), s.R, p);
-  s.p = p - shift;
+  s.p = p - shift; s.box = false;
 }
 // closest features of colliders (ca, cb); true if the separation (radii included) is below limit
 AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out) {
   const float* AB = c.lds + L_ARENA;
   v3 shift = mk3(0.5f * (AB[6 * ca] + AB[6 * ca + 3]), 0.5f * (AB[6 * ca + 1] + AB[6 * ca + 4]), 0.5f * (AB[6 * ca + 2] + AB[6 * ca + 5]));
   gjk_shape sa, sb; make_shape(c, ca, shift, sa); make_shape(c, cb, shift, sb);
+  // large static world boxes (table top, ground): clip to the neighbourhood of A (see oracle)
+  if (CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && sb.n == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
+    sb.box = true;
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+      lo[k] = fmaxf(AB[6 * cb + k], AB[6 * ca + k] - AGX_BOX_CLIP); hi[k] = fminf(AB[6 * cb + 3 + k], AB[6 * ca + 3 + k] + AGX_BOX_CLIP);
+      if (hi[k] < lo[k]) return false;
+    }
+    sb.lo = mk3(lo[0], lo[1], lo[2]) - shift; sb.hi = mk3(hi[0], hi[1], hi[2]) - shift;
+  }
   float ra = CLF(c, ca, AGX_C_RADIUS), rb = CLF(c, cb, AGX_C_RADIUS);
   float d; v3 pa, pb, n;
   bool pen = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), d, pa, pb);
@@ -670,14 +682,17 @@ AGX_DEV void integrate(Ctx& c, float dv0, float dv1) {
 
 // one p.stepSimulation() (env.py:226) plus env.py:227-232
 AGX_DEV void substep(Ctx& c) {
-  kinematics(c);
-  aba_and_minv(c);
-  predict_velocities(c);
-  collide(c);
-  build_rows(c);
+  long long t0 = c.timing ? wave_clock() : 0, t1;
+#define AGX_TICK(k) if (c.timing) { t1 = wave_clock(); c.tm[k] += t1 - t0; t0 = t1; }
+  kinematics(c); AGX_TICK(0)
+  aba_and_minv(c); AGX_TICK(1)
+  predict_velocities(c); AGX_TICK(2)
+  collide(c); AGX_TICK(3)
+  build_rows(c); AGX_TICK(4)
   float dv0, dv1;
-  pgs(c, dv0, dv1);
-  integrate(c, dv0, dv1);
+  pgs(c, dv0, dv1); AGX_TICK(5)
+  integrate(c, dv0, dv1); AGX_TICK(6)
+#undef AGX_TICK
 }
 
 // ---- state load / store ---------------------------------------------------------------------------------
@@ -736,6 +751,8 @@ AGX_DEV void observe(const Ctx& c, float tool_force, float* gobs) {
 AGX_DEV void env_step(const uint32_t* blob, float* gstate, const float* gaction, float* gobs, float* greward, uint8_t* gdone,
                       float* ginfo, float* gdebug, float* lds, int lane, int mode, int nsettle) {
   Ctx c; ctx_init(c, blob, lds, lane);
+  c.timing = gdebug != nullptr;
+  const long long t_begin = c.timing ? wave_clock() : 0;
   float* L = c.lds; int* Li = c.ldsi;
   const int sw = c.bi[AGX_H_STATE_WORDS];
   load_env(c, gstate, sw);
@@ -878,6 +895,7 @@ AGX_DEV void env_step(const uint32_t* blob, float* gstate, const float* gaction,
     }
   }
   store_env(c, gstate, sw);
+  if (gdebug && lane == 0) { for (int k = 0; k < 7; k++) gdebug[DBG_TIME + k] = (float)c.tm[k]; gdebug[DBG_TIME + 7] = (float)(wave_clock() - t_begin); }
 }
 
 }  // namespace agx

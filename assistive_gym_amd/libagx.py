@@ -4,6 +4,8 @@ import ctypes as C
 import os
 
 import numpy as np
+import torch  # noqa: F401  -- imported BEFORE libagx.so is opened: torch ships its own libamdhip64 and the
+#                process must end up with ONE HIP runtime (libagx binds to the already loaded one by soname)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libagx.so')

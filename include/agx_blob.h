@@ -15,6 +15,7 @@
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
 #define AGX_BLOB_VERSION 3
+#define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
 
 /* ---- header: int32[AGX_H_COUNT] at word 0 ------------------------------------------------ */
 enum {

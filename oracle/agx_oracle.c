@@ -476,6 +476,19 @@ static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* 
   collider_aabb(s, ca, lo, hi);
   for (int k = 0; k < 3; k++) shift[k] = 0.5 * (lo[k] + hi[k]);
   int na = collider_world_verts(s, ca, shift, va), nb = collider_world_verts(s, cb, shift, vb);
+  /* a large static world box (table top, ground) is replaced by its intersection with the other
+   * collider's AABB grown by BOX_CLIP: same closest points (they lie within `limit` of A), but all
+   * vertices stay near A so that single-precision GJK remains well conditioned */
+  if (CI(m, cb, AGX_C_BODY) == AGX_BODY_WORLD && nb == 8 && (CI(m, cb, AGX_C_TAG) == AGX_TAG_TABLE || CI(m, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
+    double blo[3], bhi[3], alo[3], ahi[3];
+    collider_aabb(s, cb, blo, bhi); collider_aabb(s, ca, alo, ahi);
+    for (int k = 0; k < 3; k++) {
+      double lo2 = alo[k] - AGX_BOX_CLIP, hi2 = ahi[k] + AGX_BOX_CLIP;
+      if (lo2 > blo[k]) blo[k] = lo2; if (hi2 < bhi[k]) bhi[k] = hi2;
+      if (bhi[k] < blo[k]) return 0;
+    }
+    for (int q = 0; q < 8; q++) for (int k = 0; k < 3; k++) vb[3 * q + k] = ((q >> (2 - k)) & 1 ? bhi[k] : blo[k]) - shift[k];
+  }
   double ra = CF(m, ca, AGX_C_RADIUS), rb = CF(m, cb, AGX_C_RADIUS);
   double d, pa[3], pb[3], n[3];
   int pen = agxo_gjk(va, na, vb, nb, PARAM(m, AGX_P_GJK_TOL), (int)PARAM(m, AGX_P_GJK_MAXIT), &d, pa, pb, NULL);

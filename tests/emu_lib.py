@@ -32,7 +32,8 @@ def _p(a):
 class Emu:
     DBG_HDR = 16 + 64 * 16 + 144
     DBG_LAM = DBG_HDR + 160 * 8
-    DEBUG_WORDS = DBG_LAM + 160
+    DBG_TIME = DBG_LAM + 160
+    DEBUG_WORDS = DBG_TIME + 16
 
     def __init__(self, blob):
         self.blob = blob

@@ -1,0 +1,60 @@
+"""Diagnostic (GPU box): first-substep contacts / rows of the HIP stepper vs the CPU oracle."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import torch
+from assistive_gym_amd.blob import ModelBlob
+from assistive_gym_amd.libagx import Stepper, load
+from assistive_gym_amd.vec_env import build_reset_pool
+from oracle_lib import Oracle
+
+np.set_printoptions(precision=7, suppress=True, linewidth=200)
+blob = ModelBlob.load()
+o = Oracle(blob)
+n = 32
+states = build_reset_pool(blob, n, 5001)
+st = Stepper(blob, n)
+st.set_state(states)
+rng = np.random.RandomState(7)
+actions = rng.uniform(-1, 1, (n, blob.act_dim)).astype(np.float32)
+dev = torch.device('cuda', 0)
+act = torch.from_numpy(actions).to(dev)
+obs = torch.zeros((n, blob.obs_dim), device=dev); rew = torch.zeros(n, device=dev)
+done = torch.zeros(n, dtype=torch.uint8, device=dev); info = torch.zeros((n, 8), device=dev)
+dw = load().agx_debug_words()
+dbg = torch.zeros((n, dw), device=dev)
+st.step_dev(act, obs, rew, done, info, debug=dbg)
+torch.cuda.synchronize()
+dbg = dbg.cpu().numpy(); info = info.cpu().numpy()
+nbad = 0
+for i in range(n):
+    ref = states[i].copy()
+    # replicate the action -> target step on the oracle side by running a full step with debug of substep 0:
+    # the oracle has no such hook, so compare against a 1-substep blob instead
+    b1 = blob.set_param('FRAME_SKIP', 1)
+    o1 = Oracle(b1)
+    ref1 = states[i].copy()
+    # targets: emulate take_step with frame_skip 5 for the targets is not possible with FRAME_SKIP=1; so use zero action rows only
+    con = o.substep_debug(ref)   # zero-action substep (targets = state qt)
+    nc = int(dbg[i, 0])
+    ce = dbg[i, 16:16 + 64 * 16].reshape(64, 16)[:nc]; cei = ce.view(np.int32)
+    same = nc == len(con) and np.array_equal(cei[:, 0], con[:, 0].astype(np.int32)) and np.array_equal(cei[:, 1], con[:, 1].astype(np.int32))
+    if not same:
+        nbad += 1
+        if nbad <= 3:
+            print('env', i, 'gpu ncon', nc, 'oracle ncon', len(con))
+            gp = [(int(cei[k, 0]), int(cei[k, 1])) for k in range(nc)]
+            op = [(int(con[k, 0]), int(con[k, 1])) for k in range(len(con))]
+            print(' only gpu   :', [(p, float(ce[gp.index(p), 13])) for p in gp if p not in op])
+            print(' only oracle:', [(p, float(con[op.index(p), 11])) for p in op if p not in gp])
+print('envs with differing first-substep contact sets: %d / %d' % (nbad, n))
+
+T0 = dw - 16
+tm = dbg[:, T0:T0 + 8]
+names = ['kinematics', 'aba+minv', 'predict', 'collide', 'rows', 'pgs', 'integrate', 'TOTAL env_step']
+print('shader-clock cycles per env.step (mean over %d envs; 5 substeps):' % n)
+for k, nm in enumerate(names):
+    print('  %-16s %12.0f  (%.1f%%)' % (nm, tm[:, k].mean(), 100 * tm[:, k].mean() / tm[:, 7].mean()))
+print('ncon mean %.1f rows mean %.1f' % (info[:, 6].mean(), info[:, 7].mean()))
