@@ -10,6 +10,7 @@ import torch
 from .blob import ModelBlob
 from .host.reset import make_states
 from .libagx import Stepper
+from .shard import pool_indices
 
 SETTLE_STEPS = 25   # feeding.py:178-179
 
@@ -50,7 +51,7 @@ class FeedingJacoVecEnv:
         if self.pool is None:
             self.pool_host = build_reset_pool(self.blob, self.pool_size, self.seed, self.device_index, self.impairment)
             self.pool = torch.from_numpy(self.pool_host).to(self.device)
-        idx = (np.arange(self.n_envs) + env_offset) % self.pool_size
+        idx = pool_indices(env_offset, self.n_envs, self.pool_size)
         self.stepper.set_state(self.pool_host[idx])
         self.stepper.observe_dev(self.obs, self._stream())
         return self.obs

@@ -57,6 +57,7 @@ def main():
     import torch.distributed as dist
     from assistive_gym_amd.blob import ModelBlob
     from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+    from assistive_gym_amd.shard import gather_observations
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -79,7 +80,7 @@ def main():
     def one(k):
         obs, rew, done, info = env.step(tape[k])
         if distributed:
-            dist.all_gather_into_tensor(gathered, obs)
+            gather_observations(obs, world, gathered)
 
     for k in range(W):
         one(k)

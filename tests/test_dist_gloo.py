@@ -1,0 +1,50 @@
+"""world_size-2 gloo test of the env sharding and the observation all-gather."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from assistive_gym_amd.shard import gather_observations, pool_indices, shard_range
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, obs_dim, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = shard_range(rank, world, world * n)
+    obs = torch.arange(lo * obs_dim, hi * obs_dim, dtype=torch.float32).reshape(n, obs_dim)   # row i = global env i
+    full = gather_observations(obs, world)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    q.put((rank, full.numpy().copy(), float(t.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_is_in_global_env_order():
+    world, n, obs_dim = 2, 8, 25
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n, obs_dim, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(timeout=60) for p in ps]
+    want = np.arange(world * n * obs_dim, dtype=np.float32).reshape(world * n, obs_dim)
+    for rank, full, tmax in res:
+        np.testing.assert_array_equal(full, want)
+        assert tmax == 2.0           # max-over-ranks timing reduction used by bench.py
+
+
+def test_initial_state_is_placement_independent():
+    pool, n_global = 256, 16384
+    one = pool_indices(0, n_global, pool)
+    for world in (1, 2, 4, 8):
+        parts = [pool_indices(shard_range(r, world, n_global)[0], n_global // world, pool) for r in range(world)]
+        np.testing.assert_array_equal(np.concatenate(parts), one)

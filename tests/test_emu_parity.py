@@ -1,0 +1,44 @@
+"""The PRODUCT kernel sources (assistive_gym_amd/csrc/agx_step.h, f32) compiled for the CPU wave
+emulator (tests/emu/) against the f64 oracle: catches logic errors and non-uniform collectives
+without a GPU.  The GPU run of the same comparison is tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from assistive_gym_amd.host.reset import make_states
+
+
+@pytest.fixture(scope='module')
+def emu(blob):
+    from emu_lib import Emu
+    return Emu(blob.set_param('NITER', 12))
+
+
+@pytest.fixture(scope='module')
+def oracle12(blob):
+    from oracle_lib import Oracle
+    return Oracle(blob.set_param('NITER', 12))
+
+
+def test_settle_and_step_match(blob, emu, oracle12):
+    st, _ = make_states(blob, 2, seed=3001)
+    rng = np.random.RandomState(2)
+    for i in range(2):
+        so, se = st[i].copy(), st[i].copy()
+        oracle12.settle(so, 4); emu.settle(se, 4)
+        assert np.abs(blob.view(so)['q'] - blob.view(se)['q']).max() < 1e-5
+        assert np.abs(blob.view(so)['free'][0, :, :3] - blob.view(se)['free'][0, :, :3]).max() < 1e-4
+        s = so
+        for k in range(2):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            s1, s2 = s.copy(), s.copy()
+            o_obs, o_rew, o_done, o_info = oracle12.step(s1, a)
+            e_obs, e_rew, e_done, e_info, dbg = emu.step(s2, a, debug=True)
+            assert o_info[6] == e_info[6] and o_info[7] == e_info[7]          # same contacts, same rows
+            assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4
+            assert np.abs(blob.view(s1)['q'] - blob.view(s2)['q']).max() < 1e-5
+            s = s1
+
+
+def test_observe_matches(blob, emu, oracle12):
+    st, _ = make_states(blob, 1, seed=3005)
+    assert np.abs(emu.observe(st[0].copy()) - oracle12.observe(st[0].copy())).max() < 1e-5

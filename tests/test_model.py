@@ -1,0 +1,56 @@
+"""Model data against numbers read from the reference files."""
+import numpy as np
+import pytest
+
+from assistive_gym_amd.model.human import HumanModel
+
+
+def test_jaco_tree(blob):
+    # arm chain 1..7, fingers 9/11/13 hang off link 7 (agents/jaco.py:8-17)
+    assert blob.meta['dof_links'] == [1, 2, 3, 4, 5, 6, 7, 9, 11, 13]
+    parents = [blob.robot_i(d, 'PARENT') for d in range(blob.ndof)]
+    assert parents == [-1, 0, 1, 2, 3, 4, 5, 6, 6, 6]
+    masses = [blob.robot_f(d, 'MASS') for d in range(blob.ndof)]
+    # j2s7s300_gym.urdf link masses; link 7 carries the 1 g end-effector link, fingers carry their tips
+    np.testing.assert_allclose(masses, [0.7477, 0.8447, 0.8447, 0.6763, 0.463, 0.463, 0.991, 0.02, 0.02, 0.02], rtol=1e-6)
+    lo = [blob.robot_f(d, 'LOWER') for d in range(7)]
+    assert lo[1] == pytest.approx(0.820304748437) and lo[3] == pytest.approx(0.523598775598) and lo[5] == pytest.approx(1.1344640138)
+    assert lo[0] < -1e9 and lo[2] < -1e9 and lo[4] < -1e9 and lo[6] < -1e9       # continuous joints, agent.py:223-225
+    assert [blob.robot_i(d, 'ACT') for d in range(10)] == [0, 1, 2, 3, 4, 5, 6, -1, -1, -1]
+    assert [blob.robot_f(d, 'KP') for d in range(10)] == pytest.approx([0.025] * 7 + [0.05] * 3)      # feeding.py:122, robot.py:77
+    assert [blob.robot_f(d, 'MAXF') for d in range(10)] == pytest.approx([1.0] * 7 + [500.0] * 3)
+
+
+def test_collider_ranges(blob):
+    r = blob.meta['ranges']
+    assert r['tool'][1] - r['tool'][0] == 64           # spoon_vhacd.obj groups
+    assert r['bowl'][1] - r['bowl'][0] == 70
+    assert r['wheelchair'][1] - r['wheelchair'][0] == 44
+    assert r['food'][1] - r['food'][0] == 8
+    assert r['human_male'][1] - r['human_male'][0] == 18 + 8       # 18 capsules/spheres + 8 head hulls
+    assert r['human_female'][1] - r['human_female'][0] == 18 + 9
+    food = blob.collider(r['food'][0])
+    assert food['radius'] == pytest.approx(0.005) and len(food['verts']) == 1
+
+
+@pytest.mark.parametrize('gender,total', [('male', 78.4), ('female', 62.5)])
+def test_human_table(gender, total):
+    hm = HumanModel(gender)
+    assert hm.n == 42
+    # PyBullet depth-first numbering: the legend of human_creation.py:5-46
+    assert hm.parent[0] == -1 and hm.parent[10] == -1 and hm.parent[20] == -1 and hm.parent[24] == -1
+    assert hm.parent[3] == 2 and hm.parent[13] == 12 and hm.parent[28] == 27 and hm.parent[35] == 27
+    assert hm.jtype[24] == 'f'
+    assert hm.mass.sum() == pytest.approx(0.9 * total)        # + 0.1 m base = total (human_creation.py:189-280)
+    assert hm.shape[23] == 'head' and hm.shape[9] == 'hand' and hm.shape[34] == 'foot' and hm.shape[27] == 'hips'
+    np.testing.assert_allclose(hm.lower[6], np.deg2rad(-128)); np.testing.assert_allclose(hm.upper[6], 0)
+    q = hm.clamp(np.zeros(42))
+    assert q[3] == pytest.approx(np.deg2rad(5)) and q[13] == pytest.approx(np.deg2rad(-5))   # limits that exclude 0
+
+
+def test_human_fk_straight_pose():
+    hm = HumanModel('male')
+    pos, quat = hm.fk(np.array([0, 0, 1.0]), np.array([0, 0, 0, 1.0]), np.zeros(42))
+    assert pos[23, 2] == pytest.approx(1.0 + 0.1515 + 0.137)          # neck + head offsets
+    assert pos[9, 2] == pytest.approx(1.0 + 2 * 0.07075 - 0.279 - 0.29)   # two pecs offsets (human_creation.py:191), upper arm, forearm
+    assert pos[9, 0] == pytest.approx(-0.179)
