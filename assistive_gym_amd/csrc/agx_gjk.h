@@ -58,7 +58,34 @@ AGX_DEV void gjk_closest_tri(v3 a, v3 b, v3 c, float& wa, float& wb, float& wc) 
   wa = 1 - v - w; wb = v; wc = w;
 }
 
-struct gjk_simplex { v3 W[4], A[4], B[4]; float lam[4]; int n; };
+// The simplex lives in registers: every access below uses compile-time indices (new vertices are
+// appended with a switch on the current size, the reduction to the supporting sub-simplex is a
+// chain of selects), so nothing is spilled to scratch.  Vertex order matches the oracle's
+// (append at the end, order-preserving compaction): ties are broken identically.
+struct gjk_pt { v3 w, a, b; };
+struct gjk_simplex { gjk_pt p0, p1, p2, p3; float l0, l1, l2, l3; int n; };
+
+AGX_DEV gjk_pt gjk_sel(int i, const gjk_pt& a, const gjk_pt& b, const gjk_pt& c, const gjk_pt& d) {
+  gjk_pt r;
+#define AGX_SEL3(f) r.f.x = i == 0 ? a.f.x : (i == 1 ? b.f.x : (i == 2 ? c.f.x : d.f.x)); r.f.y = i == 0 ? a.f.y : (i == 1 ? b.f.y : (i == 2 ? c.f.y : d.f.y)); r.f.z = i == 0 ? a.f.z : (i == 1 ? b.f.z : (i == 2 ? c.f.z : d.f.z));
+  AGX_SEL3(w) AGX_SEL3(a) AGX_SEL3(b)
+#undef AGX_SEL3
+  return r;
+}
+AGX_DEV float gjk_self(int i, float a, float b, float c, float d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
+
+template <int A, int B, int C, int D>
+AGX_DEV void gjk_face(const v3 (&W)[4], float& best, bool& any, float (&l)[4]) {
+  const v3 a = W[A], b = W[B], c = W[C], d = W[D];
+  v3 nrm = cross(b - a, c - a);
+  float sp = -dot(a, nrm), sd = dot(d - a, nrm);
+  if (sp * sd > 0) return;
+  any = true;
+  float wa, wb, wc; gjk_closest_tri(a, b, c, wa, wb, wc);
+  v3 p = wa * a + wb * b + wc * c;
+  float d2 = dot(p, p);
+  if (d2 < best) { best = d2; l[0] = 0; l[1] = 0; l[2] = 0; l[3] = 0; l[A] = wa; l[B] = wb; l[C] = wc; }
+}
 
 // closest point of the simplex to the origin; compacts to the supporting sub-simplex.
 // returns true if the origin is enclosed (tetrahedron case).
@@ -67,35 +94,35 @@ AGX_DEV bool gjk_solve(gjk_simplex& s, v3& v) {
   const int n = s.n;
   if (n == 1) { l[0] = 1; }
   else if (n == 2) {
-    v3 d = s.W[1] - s.W[0];
-    float dd = dot(d, d), t = dd > 0 ? -dot(s.W[0], d) / dd : 0.0f;
+    v3 d = s.p1.w - s.p0.w;
+    float dd = dot(d, d), t = dd > 0 ? -dot(s.p0.w, d) / dd : 0.0f;
     if (t <= 0) l[0] = 1; else if (t >= 1) l[1] = 1; else { l[0] = 1 - t; l[1] = t; }
   } else if (n == 3) {
-    gjk_closest_tri(s.W[0], s.W[1], s.W[2], l[0], l[1], l[2]);
+    gjk_closest_tri(s.p0.w, s.p1.w, s.p2.w, l[0], l[1], l[2]);
   } else {
-    const int faces[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+    const v3 W[4] = {s.p0.w, s.p1.w, s.p2.w, s.p3.w};
     float best = 3.0e38f; bool any = false;
-    for (int f = 0; f < 4; f++) {
-      v3 a = s.W[faces[f][0]], b = s.W[faces[f][1]], c = s.W[faces[f][2]], d = s.W[faces[f][3]];
-      v3 nrm = cross(b - a, c - a);
-      float sp = -dot(a, nrm), sd = dot(d - a, nrm);
-      if (sp * sd > 0) continue;
-      any = true;
-      float wa, wb, wc; gjk_closest_tri(a, b, c, wa, wb, wc);
-      v3 p = wa * a + wb * b + wc * c;
-      float d2 = dot(p, p);
-      if (d2 < best) { best = d2; l[0] = l[1] = l[2] = l[3] = 0; l[faces[f][0]] = wa; l[faces[f][1]] = wb; l[faces[f][2]] = wc; }
-    }
+    gjk_face<0, 1, 2, 3>(W, best, any, l);
+    gjk_face<0, 2, 3, 1>(W, best, any, l);
+    gjk_face<0, 3, 1, 2>(W, best, any, l);
+    gjk_face<1, 3, 2, 0>(W, best, any, l);
     if (!any) return true;
   }
-  int k2 = 0;
-  for (int k = 0; k < n; k++) if (l[k] > 0) {
-    if (k2 != k) { s.W[k2] = s.W[k]; s.A[k2] = s.A[k]; s.B[k2] = s.B[k]; }
-    s.lam[k2] = l[k]; k2++;
-  }
-  s.n = k2;
-  v = mk3(0, 0, 0);
-  for (int k = 0; k < k2; k++) v = v + s.lam[k] * s.W[k];
+  // order-preserving compaction: position j takes the j-th vertex with a positive weight
+  const bool k0 = l[0] > 0, k1 = l[1] > 0, k2 = l[2] > 0, k3 = l[3] > 0;
+  const int c0 = k0 ? 1 : 0, c1 = c0 + (k1 ? 1 : 0), c2 = c1 + (k2 ? 1 : 0), cnt = c2 + (k3 ? 1 : 0);
+  // index of the j-th kept vertex
+  const int i0 = k0 ? 0 : (k1 ? 1 : (k2 ? 2 : 3));
+  const int i1 = (k1 && c1 == 2) ? 1 : ((k2 && c2 == 2) ? 2 : 3);
+  const int i2 = (k2 && c2 == 3) ? 2 : 3;
+  const gjk_pt q0 = gjk_sel(i0, s.p0, s.p1, s.p2, s.p3), q1 = gjk_sel(i1, s.p0, s.p1, s.p2, s.p3), q2 = gjk_sel(i2, s.p0, s.p1, s.p2, s.p3);
+  const float m0 = gjk_self(i0, l[0], l[1], l[2], l[3]), m1 = gjk_self(i1, l[0], l[1], l[2], l[3]), m2 = gjk_self(i2, l[0], l[1], l[2], l[3]);
+  s.p0 = q0; s.p1 = q1; s.p2 = q2;
+  s.l0 = m0; s.l1 = cnt > 1 ? m1 : 0.f; s.l2 = cnt > 2 ? m2 : 0.f; s.l3 = 0.f;
+  s.n = cnt;   // cnt <= 3 whenever the origin is not enclosed
+  v = s.l0 * s.p0.w;
+  if (cnt > 1) v = v + s.l1 * s.p1.w;
+  if (cnt > 2) v = v + s.l2 * s.p2.w;
   return false;
 }
 
@@ -105,17 +132,21 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
   v3 a0 = gjk_vertex0(sa), b0 = gjk_vertex0(sb);
   v3 v = a0 - b0;
   float vv = dot(v, v);
-  s.A[0] = a0; s.B[0] = b0; s.W[0] = v; s.n = 1; s.lam[0] = 1; s.lam[1] = s.lam[2] = s.lam[3] = 0;
+  s.p0.a = a0; s.p0.b = b0; s.p0.w = v; s.p1 = s.p0; s.p2 = s.p0; s.p3 = s.p0;
+  s.n = 1; s.l0 = 1; s.l1 = 0; s.l2 = 0; s.l3 = 0;
   bool pen = false;
   for (int it = 0; it < maxit; it++) {
     if (vv < 1e-12f) { pen = true; break; }   /* cores closer than 1 micron: treat as overlapping */
     v3 wa = gjk_support(sa, -v), wb = gjk_support(sb, v), w = wa - wb;
     float vw = dot(v, w);
     if (vv - vw <= tol * vv) break;
-    bool dup = false;
-    for (int k = 0; k < s.n; k++) if (s.W[k].x == w.x && s.W[k].y == w.y && s.W[k].z == w.z) dup = true;
-    if (dup) break;
-    s.W[s.n] = w; s.A[s.n] = wa; s.B[s.n] = wb; s.n++;
+    const bool e0 = s.p0.w.x == w.x && s.p0.w.y == w.y && s.p0.w.z == w.z;
+    const bool e1 = s.n > 1 && s.p1.w.x == w.x && s.p1.w.y == w.y && s.p1.w.z == w.z;
+    const bool e2 = s.n > 2 && s.p2.w.x == w.x && s.p2.w.y == w.y && s.p2.w.z == w.z;
+    if (e0 || e1 || e2) break;
+    gjk_pt np; np.w = w; np.a = wa; np.b = wb;
+    if (s.n == 1) s.p1 = np; else if (s.n == 2) s.p2 = np; else s.p3 = np;
+    s.n++;
     v3 vn;
     if (gjk_solve(s, vn)) { pen = true; break; }
     float vvn = dot(vn, vn);
@@ -124,8 +155,9 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
     vv = vvn;
   }
   if (pen) { dist = 0; return true; }
-  pa = mk3(0, 0, 0); pb = mk3(0, 0, 0);
-  for (int k = 0; k < s.n; k++) { pa = pa + s.lam[k] * s.A[k]; pb = pb + s.lam[k] * s.B[k]; }
+  pa = s.l0 * s.p0.a; pb = s.l0 * s.p0.b;
+  if (s.n > 1) { pa = pa + s.l1 * s.p1.a; pb = pb + s.l1 * s.p1.b; }
+  if (s.n > 2) { pa = pa + s.l2 * s.p2.a; pb = pb + s.l2 * s.p2.b; }
   dist = sqrtf(vv);
   return false;
 }

@@ -66,7 +66,7 @@ constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_
 constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_DOF * 6;
 static_assert(A_DYN_END <= ARENA_WORDS, "dynamics workspace exceeds the arena");
 // arena, collision phase: world AABBs [ncoll][6]
-constexpr int MAX_COLL = 512;
+constexpr int MAX_COLL = 256;
 static_assert(MAX_COLL * 6 <= ARENA_WORDS, "AABB table exceeds the arena");
 // misc words
 constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
@@ -369,25 +369,36 @@ AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
   oi[C_CA] = ca; oi[C_CB] = cb; oi[C_BA] = CLI(c, ca, AGX_C_BODY); oi[C_BB] = CLI(c, cb, AGX_C_BODY);
   st3(o + C_PA, k.pa); st3(o + C_PB, k.pb); st3(o + C_N, k.n); o[C_DIST] = k.dist; o[C_MU] = pair_mu(c, ca, cb); o[C_LAM] = 0.f;
 }
-// one candidate test for this lane: AABB cull, GJK, predicted-gap rule.  gap = 3e38 when rejected.
-AGX_DEV void test_pair(Ctx& c, int a, int b, bool valid, float brk, float slack, Cand& k, bool& near_any) {
+// Collision pipeline per substep (K2 + K3), all inside the wave:
+//   1. world AABB of every collider (lanes over colliders) -> LDS table
+//   2. per static pair group: body-level cull (union AABBs), then a lane-parallel sweep over the
+//      |A|x|B| pair grid appends the overlapping pairs to an LDS worklist IN ENUMERATION ORDER
+//   3. narrowphase over the worklist, 64 pairs per pass, every lane running its own GJK
+//   4. selection: per A collider the `keep` candidates with the smallest predicted gap (or all of
+//      them, in order) become contacts.
+// The contact order (group, a, selection order) is what the oracle produces, so the solver rows
+// are identical.
+constexpr int WL_MAX = 192, CAND_STRIDE = 12;
+constexpr int A_WL = 6 * MAX_COLL;                      // int[WL_MAX]: a | b << 16
+constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, pb, n, dist
+static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
+
+AGX_DEV void range_aabb(const Ctx& c, int r0, int r1, float* lo, float* hi) {
   const float* AB = c.lds + L_ARENA;
-  k.gap = 3.0e38f; near_any = false;
-  if (!valid) return;
-  bool sep = false;
-  for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + brk || AB[6 * b + q] > AB[6 * a + 3 + q] + brk) sep = true;
-  if (sep) return;
-  if (!narrowphase(c, a, b, brk, k)) return;
-  near_any = true;
-  v3 vr = point_velocity(c, CLI(c, a, AGX_C_BODY), k.pa) - point_velocity(c, CLI(c, b, AGX_C_BODY), k.pb);
-  float pg = k.dist + dot(vr, k.n) * c.dt;
-  if (pg < slack) k.gap = pg;
+  float l[3] = {3.0e38f, 3.0e38f, 3.0e38f}, h[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = r0 + c.lane; i < r1; i += 64) for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], AB[6 * i + k]); h[k] = fmaxf(h[k], AB[6 * i + 3 + k]); }
+  for (int k = 0; k < 3; k++) { lo[k] = wave_min(l[k]); hi[k] = wave_max(h[k]); }
+}
+AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
+  const float* L = c.lds; const int pr = c.ldsi[L_ARENA + A_WL + idx]; const float* cd = L + L_ARENA + A_CAND + CAND_STRIDE * idx;
+  Cand k; k.gap = cd[0]; k.pa = ld3(cd + 1); k.pb = ld3(cd + 4); k.n = ld3(cd + 7); k.dist = cd[10];
+  emit_contact(c, slot, pr & 0xffff, pr >> 16, k);
 }
 AGX_DEV void collide(Ctx& c) {
-  float* L = c.lds; float* AB = L + L_ARENA; const int lane = c.lane;
+  float* L = c.lds; float* AB = L + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; float* CD = L + L_ARENA + A_CAND; const int lane = c.lane;
   const float brk = PRM(c, AGX_P_CONTACT_BREAK), slack = PRM(c, AGX_P_CONTACT_SLACK);
   int maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (maxc > MAX_CON) maxc = MAX_CON;
-  // world AABBs of every collider (lanes over colliders)
+  // 1. world AABBs
   for (int col = lane; col < c.ncoll; col += 64) {
     m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
     v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
@@ -400,44 +411,94 @@ AGX_DEV void collide(Ctx& c) {
   }
   wave_sync();
   int ncon = 0, near_mask = 0, overflow = 0;
-  const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER];
+  const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER], food0 = c.bi[AGX_H_FOOD0];
   for (int g = 0; g < c.ngroup; g++) {
     int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
     if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
     const bool same = GRI(c, g, AGX_G_FLAGS) & 1; const int keep = GRI(c, g, AGX_G_KEEP);
-    const bool two = (b1 - b0) > 64;
-    for (int a = a0; a < a1; a++) {
-      // lanes over the B range (two passes when it is wider than the wave)
-      Cand k0, k1; bool n0 = false, n1 = false;
-      int bb0 = b0 + lane, bb1 = b0 + 64 + lane;
-      test_pair(c, a, bb0, bb0 < b1 && (!same || bb0 > a), brk, slack, k0, n0);
-      k1.gap = 3.0e38f;
-      if (two) test_pair(c, a, bb1, bb1 < b1 && (!same || bb1 > a), brk, slack, k1, n1);
-      if (CLI(c, a, AGX_C_TAG) == AGX_TAG_FOOD && CLI(c, b0, AGX_C_TAG) == AGX_TAG_HUMAN && wave_any(n0 || n1))
-        near_mask |= 1 << (CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - c.bi[AGX_H_FOOD0]);
-      if (keep > 0) {
-        for (int q = 0; q < keep; q++) {
-          float mg = wave_min(fminf(k0.gap, k1.gap));
-          if (mg > 1.0e38f) break;
-          uint64_t m0 = wave_ballot(k0.gap == mg);
-          int slot1 = 0, win;
-          if (m0) win = ffs64(m0); else { win = ffs64(wave_ballot(k1.gap == mg)); slot1 = 1; }
-          if (ncon < maxc) { if (lane == win) { if (slot1) emit_contact(c, ncon, a, bb1, k1); else emit_contact(c, ncon, a, bb0, k0); } ncon++; }
-          else overflow++;
-          if (lane == win) { if (slot1) k1.gap = 3.0e38f; else k0.gap = 3.0e38f; }
+    const int na = a1 - a0, nb = b1 - b0, npairs = na * nb;
+    if (npairs <= 0) continue;
+    // body-level cull
+    {
+      float alo[3], ahi[3], blo[3], bhi[3];
+      range_aabb(c, a0, a1, alo, ahi); range_aabb(c, b0, b1, blo, bhi);
+      bool sep = false;
+      for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + brk || blo[k] > ahi[k] + brk) sep = true;
+      if (sep) continue;
+    }
+    // the group is processed in batches of whole A colliders that cannot overflow the worklist
+    const int abatch = WL_MAX / nb > 0 ? WL_MAX / nb : 1;
+    for (int ab = a0; ab < a1; ab += abatch) {
+    const int bpairs = ((a1 - ab < abatch) ? a1 - ab : abatch) * nb;
+    // 2. broadphase sweep -> worklist
+    int wn = 0;
+    for (int base = 0; base < bpairs; base += 64) {
+      const int p = base + lane; bool ok = p < bpairs;
+      const int ai = ok ? p / nb : 0; const int a = ab + ai, b = b0 + (p - ai * nb);
+      ok = ok && (!same || b > a);
+      if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + brk || AB[6 * b + q] > AB[6 * a + 3 + q] + brk) ok = false;
+      const uint64_t m = wave_ballot(ok);
+      const int slot = wn + wave_rank(m);
+      if (ok && slot < WL_MAX) WL[slot] = a | (b << 16);
+      wn += popc64(m);
+    }
+    if (wn > WL_MAX) { overflow += wn - WL_MAX; wn = WL_MAX; }
+    if (wn == 0) continue;
+    wave_sync();
+    // 3. narrowphase
+    const bool food_human = CLI(c, a0, AGX_C_TAG) == AGX_TAG_FOOD && CLI(c, b0, AGX_C_TAG) == AGX_TAG_HUMAN;
+    for (int base = 0; base < wn; base += 64) {
+      const int i = base + lane; const bool has = i < wn;
+      Cand k; k.gap = 3.0e38f; bool near = false; int a = 0;
+      if (has) {
+        const int pr = WL[i]; a = pr & 0xffff; const int b = pr >> 16;
+        if (narrowphase(c, a, b, brk, k)) {
+          near = true;
+          v3 vr = point_velocity(c, CLI(c, a, AGX_C_BODY), k.pa) - point_velocity(c, CLI(c, b, AGX_C_BODY), k.pb);
+          float pg = k.dist + dot(vr, k.n) * c.dt;
+          if (pg < slack) k.gap = pg;
         }
-      } else {
-        for (int pass = 0; pass < (two ? 2 : 1); pass++) {
-          bool has = (pass ? k1.gap : k0.gap) < 1.0e38f;
-          uint64_t m = wave_ballot(has);
-          int cnt = popc64(m), slot = ncon + wave_rank(m);
-          if (has && slot < maxc) { if (pass) emit_contact(c, slot, a, bb1, k1); else emit_contact(c, slot, a, bb0, k0); }
-          int room = maxc - ncon; if (room < 0) room = 0;
-          if (cnt > room) { overflow += cnt - room; cnt = room; }
-          ncon += cnt;
-        }
+        float* cd = CD + CAND_STRIDE * i;
+        cd[0] = k.gap; st3(cd + 1, k.pa); st3(cd + 4, k.pb); st3(cd + 7, k.n); cd[10] = k.dist;
+      }
+      if (food_human) {   // a manifold point exists: what getContactPoints(food, human) reports (agent.py:100-116)
+        for (int f = 0; f < c.nfood; f++) if (wave_any(near && CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - food0 == f)) near_mask |= 1 << f;
       }
     }
+    wave_sync();
+    // 4. selection
+    if (keep == 0) {
+      for (int base = 0; base < wn; base += 64) {
+        const int i = base + lane; const bool has = i < wn && CD[CAND_STRIDE * i] < 1.0e38f;
+        const uint64_t m = wave_ballot(has);
+        int cnt = popc64(m); const int slot = ncon + wave_rank(m);
+        if (has && slot < maxc) emit_from_cand(c, slot, i);
+        int room = maxc - ncon; if (room < 0) room = 0;
+        if (cnt > room) { overflow += cnt - room; cnt = room; }
+        ncon += cnt;
+      }
+    } else {
+      int cur = 0;
+      while (cur < wn) {
+        const int a = WL[cur] & 0xffff;
+        const int i0 = cur + lane, i1 = cur + 64 + lane;
+        const bool s0 = i0 < wn && (WL[i0 < wn ? i0 : 0] & 0xffff) == a, s1 = i1 < wn && (WL[i1 < wn ? i1 : 0] & 0xffff) == a;
+        const int len = popc64(wave_ballot(s0)) + popc64(wave_ballot(s1));
+        float g0 = s0 ? CD[CAND_STRIDE * i0] : 3.0e38f, g1 = s1 ? CD[CAND_STRIDE * i1] : 3.0e38f;
+        for (int q = 0; q < keep; q++) {
+          const float mg = wave_min(fminf(g0, g1));
+          if (mg > 1.0e38f) break;
+          const uint64_t m0 = wave_ballot(g0 == mg);
+          int slot1 = 0, win;
+          if (m0) win = ffs64(m0); else { win = ffs64(wave_ballot(g1 == mg)); slot1 = 1; }
+          if (ncon < maxc) { if (lane == win) emit_from_cand(c, ncon, slot1 ? i1 : i0); ncon++; } else overflow++;
+          if (lane == win) { if (slot1) g1 = 3.0e38f; else g0 = 3.0e38f; }
+        }
+        cur += len;
+      }
+    }
+    wave_sync();
+    }   // A batches
   }
   c.ncon = ncon; c.near_mask = near_mask; c.overflow = overflow;
   wave_sync();
@@ -608,44 +669,75 @@ AGX_DEV void build_rows(Ctx& c) {
 }
 
 // ---- K6: projected Gauss-Seidel --------------------------------------------------------------------------
-// Rows are visited in construction order (Gauss-Seidel is order dependent).  Per row: every lane
-// multiplies its (at most two) Jacobian coefficients with the velocity deltas it owns, one DPP
-// reduction gives J.dv, the impulse update is wave-uniform, every lane applies B*dlambda to its
-// DoFs.  Accumulated impulses live in registers: lane (r & 63) owns row r of slot (r >> 6).
-AGX_DEV float lam_pick(int slot, float l0, float l1, float l2) { return slot == 0 ? l0 : (slot == 1 ? l1 : l2); }
+// Rows are visited in construction order (Gauss-Seidel is order dependent).  Row headers and the
+// accumulated impulses live in registers, distributed over the lanes (lane r&63 owns row r of slot
+// r>>6) and are broadcast with v_readlane (wave-uniform -> SGPRs, scalar control flow).  Per row
+// every lane fetches its (J,B) pair from the LDS arena (lanes outside the row's two DoF ranges read
+// nothing), one DPP reduction gives J.dv, the impulse update is uniform, every lane applies
+// B*dlambda to the DoFs it owns.  The fetch of row r+1 is issued before the reduction of row r.
+struct PgsRegs { float invD[3], b[3], lo[3], hi[3], mu[3], lam[3]; int pack[3], off[3], fric[3]; };
+
+AGX_DEV void pgs_fetch(const float* E, int lane, int pack, int off, float& j0, float& c0, float& j1, float& c1) {
+  const int a0 = pack & 255, na = (pack >> 8) & 255, b0 = (pack >> 16) & 255, nb = (pack >> 24) & 255;
+  j0 = 0.f; c0 = 0.f; j1 = 0.f; c1 = 0.f;
+  unsigned ia = (unsigned)(lane - a0), ib = (unsigned)(lane - b0);
+  if (ia < (unsigned)na) { j0 = E[2 * (off + (int)ia)]; c0 = E[2 * (off + (int)ia) + 1]; }
+  else if (ib < (unsigned)nb) { j0 = E[2 * (off + na + (int)ib)]; c0 = E[2 * (off + na + (int)ib) + 1]; }
+  if (a0 + na > 64 || b0 + nb > 64) {   // wave-uniform: only rows touching DoFs 64.. need the second slot
+    ia = (unsigned)(lane + 64 - a0); ib = (unsigned)(lane + 64 - b0);
+    if (ia < (unsigned)na) { j1 = E[2 * (off + (int)ia)]; c1 = E[2 * (off + (int)ia) + 1]; }
+    else if (ib < (unsigned)nb) { j1 = E[2 * (off + na + (int)ib)]; c1 = E[2 * (off + na + (int)ib) + 1]; }
+  }
+}
+template <int SLOT>
+AGX_DEV void pgs_sweep_slot(PgsRegs& R, const float* E, int lane, int nrows, float& dv0, float& dv1) {
+  const int n = nrows - 64 * SLOT < 64 ? nrows - 64 * SLOT : 64;
+  if (n <= 0) return;
+  float pj0, pc0, pj1, pc1;
+  pgs_fetch(E, lane, wave_bcast_i(R.pack[SLOT], 0), wave_bcast_i(R.off[SLOT], 0), pj0, pc0, pj1, pc1);
+  for (int rl = 0; rl < n; rl++) {
+    const float j0 = pj0, c0 = pc0, j1 = pj1, c1 = pc1;
+    if (rl + 1 < n) pgs_fetch(E, lane, wave_bcast_i(R.pack[SLOT], rl + 1), wave_bcast_i(R.off[SLOT], rl + 1), pj0, pc0, pj1, pc1);
+    const float invD = wave_bcast(R.invD[SLOT], rl), b = wave_bcast(R.b[SLOT], rl);
+    float lo = wave_bcast(R.lo[SLOT], rl), hi = wave_bcast(R.hi[SLOT], rl);
+    const int fr = wave_bcast_i(R.fric[SLOT], rl);
+    if (fr >= 0) {
+      const int fs = fr >> 6;
+      const float ln = wave_bcast(fs == 0 ? R.lam[0] : (fs == 1 ? R.lam[1] : R.lam[2]), fr & 63);
+      hi = wave_bcast(R.mu[SLOT], rl) * ln; lo = -hi;
+    }
+    const float lam = wave_bcast(R.lam[SLOT], rl);
+    const float jdv = wave_sum(j0 * dv0 + j1 * dv1);
+    float nl = lam + (b - jdv) * invD;
+    nl = fminf(fmaxf(nl, lo), hi);
+    const float dl = nl - lam;
+    R.lam[SLOT] = (lane == rl) ? nl : R.lam[SLOT];
+    dv0 += c0 * dl; dv1 += c1 * dl;
+  }
+}
 AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   float* L = c.lds; const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER), nrows = c.nrows;
   const float* E = L + L_ARENA;
+  static_assert(MAX_ROWS <= 192, "three header/impulse register slots per lane");
+  PgsRegs R;
+  for (int s = 0; s < 3; s++) {
+    const int r = 64 * s + lane;
+    const bool ok = r < nrows && r < MAX_ROWS;
+    const float* H = L + L_HDR + HDR_STRIDE * (ok ? r : 0); const int* Hi = (const int*)H;
+    const float invD = ok ? H[H_INVD] : 0.f;
+    R.invD[s] = invD; R.b[s] = ok ? H[H_B] : 0.f; R.mu[s] = ok ? H[H_MU] : 0.f; R.lam[s] = 0.f;
+    // a row without effective mass (static-static, degenerate) is kept but pinned at zero impulse
+    R.lo[s] = (ok && invD != 0.f) ? H[H_LO] : 0.f; R.hi[s] = (ok && invD != 0.f) ? H[H_HI] : 0.f;
+    R.pack[s] = ok ? Hi[H_PACK] : 0; R.off[s] = ok ? Hi[H_OFF] : 0; R.fric[s] = (ok && invD != 0.f) ? Hi[H_FRIC] : -1;
+  }
   dv0 = 0.f; dv1 = 0.f;
-  float lam0 = 0.f, lam1 = 0.f, lam2 = 0.f;
-  static_assert(MAX_ROWS <= 192, "three impulse registers per lane");
-  const int dof0 = lane, dof1 = lane + 64;
   for (int it = 0; it < iters; it++) {
-    for (int r = 0; r < nrows; r++) {
-      const float* H = L + L_HDR + HDR_STRIDE * r; const int* Hi = (const int*)H;
-      const float invD = H[H_INVD];
-      if (invD == 0.f) continue;
-      const int pack = Hi[H_PACK], off = Hi[H_OFF], fr = Hi[H_FRIC];
-      const int a0 = pack & 255, na = (pack >> 8) & 255, b0 = (pack >> 16) & 255, nb = (pack >> 24) & 255;
-      float lo = H[H_LO], hi = H[H_HI];
-      if (fr >= 0) { hi = H[H_MU] * wave_bcast(lam_pick(fr >> 6, lam0, lam1, lam2), fr & 63); lo = -hi; }
-      // this lane's coefficients: entry 0 of the arena holds (0,0)
-      unsigned ia = (unsigned)(dof0 - a0), ib = (unsigned)(dof0 - b0);
-      int e0 = ia < (unsigned)na ? off + (int)ia : (ib < (unsigned)nb ? off + na + (int)ib : 0);
-      ia = (unsigned)(dof1 - a0); ib = (unsigned)(dof1 - b0);
-      int e1 = ia < (unsigned)na ? off + (int)ia : (ib < (unsigned)nb ? off + na + (int)ib : 0);
-      const float j0 = E[2 * e0], c0 = E[2 * e0 + 1], j1 = E[2 * e1], c1 = E[2 * e1 + 1];
-      const float lam = wave_bcast(lam_pick(r >> 6, lam0, lam1, lam2), r & 63);
-      const float jdv = wave_sum(j0 * dv0 + j1 * dv1);
-      float nl = lam + (H[H_B] - jdv) * invD;
-      nl = fminf(fmaxf(nl, lo), hi);
-      const float dl = nl - lam;
-      if (lane == (r & 63)) { const int slot = r >> 6; if (slot == 0) lam0 = nl; else if (slot == 1) lam1 = nl; else lam2 = nl; }
-      dv0 += c0 * dl; dv1 += c1 * dl;
-    }
+    pgs_sweep_slot<0>(R, E, lane, nrows, dv0, dv1);
+    pgs_sweep_slot<1>(R, E, lane, nrows, dv0, dv1);
+    pgs_sweep_slot<2>(R, E, lane, nrows, dv0, dv1);
   }
   wave_sync();
-  L[L_LAM + lane] = lam0; L[L_LAM + 64 + lane] = lam1; if (128 + lane < MAX_ROWS) L[L_LAM + 128 + lane] = lam2;
+  L[L_LAM + lane] = R.lam[0]; L[L_LAM + 64 + lane] = R.lam[1]; if (128 + lane < MAX_ROWS) L[L_LAM + 128 + lane] = R.lam[2];
   wave_sync();
 }
 
