@@ -19,7 +19,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGX_E_HIP, #x, e_); } while (0)
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 2)
 agx_step_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* obs, float* reward, uint8_t* done,
                 float* info, float* debug, int n_envs, int sw, int act_dim, int obs_dim, int mode, int nsettle) {
   extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -44,8 +44,7 @@ constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
 constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
 constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
 constexpr int L_CON = L_MISC + 32;                       // [MAX_CON][CON_STRIDE]
-constexpr int L_LAM = L_CON + MAX_CON * CON_STRIDE;      // [MAX_ROWS]
-constexpr int L_HDR = L_LAM + MAX_ROWS;                  // [MAX_ROWS][HDR_STRIDE]
+constexpr int L_HDR = L_CON + MAX_CON * CON_STRIDE;      // [MAX_ROWS][HDR_STRIDE]
 constexpr int L_ARENA = L_HDR + MAX_ROWS * HDR_STRIDE;
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
 static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
@@ -86,7 +85,7 @@ struct Ctx {
   float dt;
   int ncon, nrows, first_normal, near_mask, overflow;
   float* dbg;   // optional debug sink (parity tests)
-  long long tm[8]; bool timing;   // per-phase shader-clock totals (debug path only)
+  long long tm[16]; bool timing;   // per-phase shader-clock totals (debug path only)
 };
 
 #define PRM(c, k) ((c).bf[(c).o_params + (k)])
@@ -110,7 +109,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV];
   c.dt = PRM(c, AGX_P_DT);
   c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.dbg = nullptr;
-  c.timing = false; for (int k = 0; k < 8; k++) c.tm[k] = 0;
+  c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 
 // ---- small helpers ------------------------------------------------------------------------
@@ -326,7 +325,7 @@ struct Cand { v3 pa, pb, n; float dist, gap; };
 
 AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
   s.n = CLI(c, col, AGX_C_NVERT);
-  s.v = c.bf + c.o_vert + 3 * CLI(c, col, AGX_C_VOFF);
+  s.v = c.bf + c.bi[AGX_H_OFF_VERT4] + 4 * CLI(c, col, AGX_C_VOFF);
   v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), s.R, p);
   s.p = p - shift; s.box = false;
 }
@@ -398,6 +397,8 @@ AGX_DEV void collide(Ctx& c) {
   float* L = c.lds; float* AB = L + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; float* CD = L + L_ARENA + A_CAND; const int lane = c.lane;
   const float brk = PRM(c, AGX_P_CONTACT_BREAK), slack = PRM(c, AGX_P_CONTACT_SLACK);
   int maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (maxc > MAX_CON) maxc = MAX_CON;
+  long long ct0 = c.timing ? wave_clock() : 0, ct1;
+#define AGX_CTICK(k) if (c.timing) { ct1 = wave_clock(); c.tm[k] += ct1 - ct0; ct0 = ct1; }
   // 1. world AABBs
   for (int col = lane; col < c.ncoll; col += 64) {
     m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
@@ -410,6 +411,7 @@ AGX_DEV void collide(Ctx& c) {
     }
   }
   wave_sync();
+  AGX_CTICK(8)
   int ncon = 0, near_mask = 0, overflow = 0;
   const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER], food0 = c.bi[AGX_H_FOOD0];
   for (int g = 0; g < c.ngroup; g++) {
@@ -424,6 +426,7 @@ AGX_DEV void collide(Ctx& c) {
       range_aabb(c, a0, a1, alo, ahi); range_aabb(c, b0, b1, blo, bhi);
       bool sep = false;
       for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + brk || blo[k] > ahi[k] + brk) sep = true;
+      AGX_CTICK(9)
       if (sep) continue;
     }
     // the group is processed in batches of whole A colliders that cannot overflow the worklist
@@ -443,6 +446,7 @@ AGX_DEV void collide(Ctx& c) {
       wn += popc64(m);
     }
     if (wn > WL_MAX) { overflow += wn - WL_MAX; wn = WL_MAX; }
+    AGX_CTICK(10)
     if (wn == 0) continue;
     wave_sync();
     // 3. narrowphase
@@ -466,6 +470,7 @@ AGX_DEV void collide(Ctx& c) {
       }
     }
     wave_sync();
+    AGX_CTICK(11)
     // 4. selection
     if (keep == 0) {
       for (int base = 0; base < wn; base += 64) {
@@ -498,10 +503,12 @@ AGX_DEV void collide(Ctx& c) {
       }
     }
     wave_sync();
+    AGX_CTICK(12)
     }   // A batches
   }
   c.ncon = ncon; c.near_mask = near_mask; c.overflow = overflow;
   wave_sync();
+#undef AGX_CTICK
 }
 
 // ---- K5: constraint rows -----------------------------------------------------------------------------
@@ -675,69 +682,82 @@ AGX_DEV void build_rows(Ctx& c) {
 // every lane fetches its (J,B) pair from the LDS arena (lanes outside the row's two DoF ranges read
 // nothing), one DPP reduction gives J.dv, the impulse update is uniform, every lane applies
 // B*dlambda to the DoFs it owns.  The fetch of row r+1 is issued before the reduction of row r.
-struct PgsRegs { float invD[3], b[3], lo[3], hi[3], mu[3], lam[3]; int pack[3], off[3], fric[3]; };
+// Register sets: A0/A1 hold rows 0..127 of the non-contact + normal block (lane r&63 of set r>>6),
+// B0/B1 hold the friction rows, placed in the SAME lane as the normal row of their contact so the
+// friction bound mu*lambda_n is a lane-local product.  The impulse update is evaluated in every
+// lane on its own row registers; only the owner lane's result is kept and its delta broadcast.
+struct PgsSet { float invD, b, lo, hi, lam; int pack, off; };   // one row per lane (hi = mu for friction sets)
 
+// (J,B) pair of this lane for a row: lanes outside the row's two DoF ranges read arena entry 0 = (0,0)
 AGX_DEV void pgs_fetch(const float* E, int lane, int pack, int off, float& j0, float& c0, float& j1, float& c1) {
   const int a0 = pack & 255, na = (pack >> 8) & 255, b0 = (pack >> 16) & 255, nb = (pack >> 24) & 255;
-  j0 = 0.f; c0 = 0.f; j1 = 0.f; c1 = 0.f;
   unsigned ia = (unsigned)(lane - a0), ib = (unsigned)(lane - b0);
-  if (ia < (unsigned)na) { j0 = E[2 * (off + (int)ia)]; c0 = E[2 * (off + (int)ia) + 1]; }
-  else if (ib < (unsigned)nb) { j0 = E[2 * (off + na + (int)ib)]; c0 = E[2 * (off + na + (int)ib) + 1]; }
+  int e = ib < (unsigned)nb ? off + na + (int)ib : 0;
+  e = ia < (unsigned)na ? off + (int)ia : e;
+  j0 = E[2 * e]; c0 = E[2 * e + 1];
+  j1 = 0.f; c1 = 0.f;
   if (a0 + na > 64 || b0 + nb > 64) {   // wave-uniform: only rows touching DoFs 64.. need the second slot
     ia = (unsigned)(lane + 64 - a0); ib = (unsigned)(lane + 64 - b0);
-    if (ia < (unsigned)na) { j1 = E[2 * (off + (int)ia)]; c1 = E[2 * (off + (int)ia) + 1]; }
-    else if (ib < (unsigned)nb) { j1 = E[2 * (off + na + (int)ib)]; c1 = E[2 * (off + na + (int)ib) + 1]; }
+    e = ib < (unsigned)nb ? off + na + (int)ib : 0;
+    e = ia < (unsigned)na ? off + (int)ia : e;
+    j1 = E[2 * e]; c1 = E[2 * e + 1];
   }
 }
-template <int SLOT>
-AGX_DEV void pgs_sweep_slot(PgsRegs& R, const float* E, int lane, int nrows, float& dv0, float& dv1) {
-  const int n = nrows - 64 * SLOT < 64 ? nrows - 64 * SLOT : 64;
-  if (n <= 0) return;
+// one Gauss-Seidel pass over the rows held in lanes [l0, l1) of one register set
+template <bool FRICTION>
+AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int lane, int l0, int l1, float& dv0, float& dv1) {
+  if (l1 <= l0) return;
   float pj0, pc0, pj1, pc1;
-  pgs_fetch(E, lane, wave_bcast_i(R.pack[SLOT], 0), wave_bcast_i(R.off[SLOT], 0), pj0, pc0, pj1, pc1);
-  for (int rl = 0; rl < n; rl++) {
+  pgs_fetch(E, lane, wave_bcast_i(S.pack, l0), wave_bcast_i(S.off, l0), pj0, pc0, pj1, pc1);
+  for (int rl = l0; rl < l1; rl++) {
     const float j0 = pj0, c0 = pc0, j1 = pj1, c1 = pc1;
-    if (rl + 1 < n) pgs_fetch(E, lane, wave_bcast_i(R.pack[SLOT], rl + 1), wave_bcast_i(R.off[SLOT], rl + 1), pj0, pc0, pj1, pc1);
-    const float invD = wave_bcast(R.invD[SLOT], rl), b = wave_bcast(R.b[SLOT], rl);
-    float lo = wave_bcast(R.lo[SLOT], rl), hi = wave_bcast(R.hi[SLOT], rl);
-    const int fr = wave_bcast_i(R.fric[SLOT], rl);
-    if (fr >= 0) {
-      const int fs = fr >> 6;
-      const float ln = wave_bcast(fs == 0 ? R.lam[0] : (fs == 1 ? R.lam[1] : R.lam[2]), fr & 63);
-      hi = wave_bcast(R.mu[SLOT], rl) * ln; lo = -hi;
-    }
-    const float lam = wave_bcast(R.lam[SLOT], rl);
+    if (rl + 1 < l1) pgs_fetch(E, lane, wave_bcast_i(S.pack, rl + 1), wave_bcast_i(S.off, rl + 1), pj0, pc0, pj1, pc1);
     const float jdv = wave_sum(j0 * dv0 + j1 * dv1);
-    float nl = lam + (b - jdv) * invD;
-    nl = fminf(fmaxf(nl, lo), hi);
-    const float dl = nl - lam;
-    R.lam[SLOT] = (lane == rl) ? nl : R.lam[SLOT];
+    const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
+    const float nl = wave_clamp(S.lam + (S.b - jdv) * S.invD, lo, hi);
+    const float dlo = nl - S.lam;
+    S.lam = (lane == rl) ? nl : S.lam;
+    const float dl = wave_bcast(dlo, rl);
     dv0 += c0 * dl; dv1 += c1 * dl;
   }
 }
+AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet& S) {
+  const float* L = c.lds;
+  ok = ok && row < MAX_ROWS;
+  const float* H = L + L_HDR + HDR_STRIDE * (ok ? row : 0); const int* Hi = (const int*)H;
+  const float invD = ok ? H[H_INVD] : 0.f;
+  // a row without effective mass (static-static, degenerate) is kept but pinned at zero impulse
+  const bool live = ok && invD != 0.f;
+  S.invD = invD; S.b = ok ? H[H_B] : 0.f; S.lam = 0.f;
+  S.lo = live ? H[H_LO] : 0.f; S.hi = live ? (friction ? H[H_MU] : H[H_HI]) : 0.f;
+  S.pack = ok ? Hi[H_PACK] : 0; S.off = ok ? Hi[H_OFF] : 0;
+}
 AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
-  float* L = c.lds; const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER), nrows = c.nrows;
+  float* L = c.lds; const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER);
   const float* E = L + L_ARENA;
-  static_assert(MAX_ROWS <= 192, "three header/impulse register slots per lane");
-  PgsRegs R;
-  for (int s = 0; s < 3; s++) {
-    const int r = 64 * s + lane;
-    const bool ok = r < nrows && r < MAX_ROWS;
-    const float* H = L + L_HDR + HDR_STRIDE * (ok ? r : 0); const int* Hi = (const int*)H;
-    const float invD = ok ? H[H_INVD] : 0.f;
-    R.invD[s] = invD; R.b[s] = ok ? H[H_B] : 0.f; R.mu[s] = ok ? H[H_MU] : 0.f; R.lam[s] = 0.f;
-    // a row without effective mass (static-static, degenerate) is kept but pinned at zero impulse
-    R.lo[s] = (ok && invD != 0.f) ? H[H_LO] : 0.f; R.hi[s] = (ok && invD != 0.f) ? H[H_HI] : 0.f;
-    R.pack[s] = ok ? Hi[H_PACK] : 0; R.off[s] = ok ? Hi[H_OFF] : 0; R.fric[s] = (ok && invD != 0.f) ? Hi[H_FRIC] : -1;
-  }
+  const int nnc = c.first_normal, nc = c.ncon, nA = nnc + nc;      // rows: [0,nnc) non-contact, [nnc,nA) normals, [nA,nA+nc) friction
+  static_assert(MAX_ROWS <= 256 && MAX_CON <= 64, "two register sets per block");
+  PgsSet A0, A1, B0, B1;
+  pgs_load_set(c, lane, lane < nA, false, A0);
+  pgs_load_set(c, 64 + lane, 64 + lane < nA, false, A1);
+  { const int c0 = lane - nnc, c1 = 64 + lane - nnc;
+    pgs_load_set(c, nA + c0, c0 >= 0 && c0 < nc, true, B0);
+    pgs_load_set(c, nA + c1, c1 >= 0 && c1 < nc, true, B1); }
+  const int a0n = nA < 64 ? nA : 64, a1n = nA - 64;
+  const int f0a = nnc < 64 ? nnc : 64, f0b = nA < 64 ? nA : 64;          // friction rows in B0: lanes [nnc, min(nA,64))
+  const int f1a = nnc > 64 ? nnc - 64 : 0, f1b = nA - 64;                // friction rows in B1: lanes [max(nnc-64,0), nA-64)
   dv0 = 0.f; dv1 = 0.f;
   for (int it = 0; it < iters; it++) {
-    pgs_sweep_slot<0>(R, E, lane, nrows, dv0, dv1);
-    pgs_sweep_slot<1>(R, E, lane, nrows, dv0, dv1);
-    pgs_sweep_slot<2>(R, E, lane, nrows, dv0, dv1);
+    pgs_sweep<false>(A0, A0.lam, E, lane, 0, a0n, dv0, dv1);
+    pgs_sweep<false>(A1, A1.lam, E, lane, 0, a1n, dv0, dv1);
+    pgs_sweep<true>(B0, A0.lam, E, lane, f0a, f0b, dv0, dv1);
+    pgs_sweep<true>(B1, A1.lam, E, lane, f1a, f1b, dv0, dv1);
   }
+  // solved normal impulses -> contact records (what getContactPoints reports until the next step)
   wave_sync();
-  L[L_LAM + lane] = R.lam[0]; L[L_LAM + 64 + lane] = R.lam[1]; if (128 + lane < MAX_ROWS) L[L_LAM + 128 + lane] = R.lam[2];
+  { const int r0 = lane, r1 = 64 + lane;
+    if (r0 >= nnc && r0 < nA) L[L_CON + CON_STRIDE * (r0 - nnc) + C_LAM] = A0.lam;
+    if (r1 >= nnc && r1 < nA) L[L_CON + CON_STRIDE * (r1 - nnc) + C_LAM] = A1.lam; }
   wave_sync();
 }
 
@@ -746,8 +766,6 @@ AGX_DEV void integrate(Ctx& c, float dv0, float dv1) {
   float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
   if (lane < c.nv) L[L_VEL + lane] += dv0;
   if (lane + 64 < c.nv) L[L_VEL + lane + 64] += dv1;
-  // contact impulses of this substep (what getContactPoints reports until the next step)
-  if (lane < c.ncon) L[L_CON + CON_STRIDE * lane + C_LAM] = L[L_LAM + c.first_normal + lane];
   wave_sync();
   if (lane < n) { float qd = L[L_VEL + lane]; L[L_ST + c.s_qd + lane] = qd; L[L_ST + c.s_q + lane] += dt * qd; }
   if (lane < c.nfree) {
@@ -878,7 +896,6 @@ AGX_DEV void env_step(const uint32_t* blob, float* gstate, const float* gaction,
       for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = L[L_CON + q];
       for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[16 + MAX_CON * CON_STRIDE + q] = L[L_MINV + q];
       for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = L[L_HDR + q];
-      for (int q = lane; q < MAX_ROWS; q += 64) gdebug[DBG_LAM + q] = L[L_LAM + q];
     }
   }
   kinematics(c);   // poses as the getters of _get_obs see them after the last stepSimulation
@@ -987,7 +1004,7 @@ AGX_DEV void env_step(const uint32_t* blob, float* gstate, const float* gaction,
     }
   }
   store_env(c, gstate, sw);
-  if (gdebug && lane == 0) { for (int k = 0; k < 7; k++) gdebug[DBG_TIME + k] = (float)c.tm[k]; gdebug[DBG_TIME + 7] = (float)(wave_clock() - t_begin); }
+  if (gdebug && lane == 0) { for (int k = 0; k < 7; k++) gdebug[DBG_TIME + k] = (float)c.tm[k]; gdebug[DBG_TIME + 7] = (float)(wave_clock() - t_begin); for (int k = 8; k < 16; k++) gdebug[DBG_TIME + k] = (float)c.tm[k]; }
 }
 
 }  // namespace agx

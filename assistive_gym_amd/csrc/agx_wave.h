@@ -82,3 +82,5 @@ AGX_DEV int wave_scan_excl(int x) {
 }
 // shader clock (s_memtime), for the per-phase cycle counters of the debug path
 AGX_DEV long long wave_clock() { return (long long)__builtin_readcyclecounter(); }
+// clamp to [lo, hi] (lo <= hi) in one v_med3_f32
+AGX_DEV float wave_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }

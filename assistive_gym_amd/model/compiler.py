@@ -31,7 +31,7 @@ from .urdf import Urdf
 H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT=7, NGROUP=8, NFOOD=9, ACT_DIM=10,
          OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
          STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
-         NDIR=29, OFF_DIRS=30, COUNT=40)
+         NDIR=29, OFF_DIRS=30, OFF_VERT4=31, COUNT=40)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
          HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, COUNT=24)
@@ -48,7 +48,7 @@ E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITER
 BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8)
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 3
+MAGIC, VERSION = 0x31584741, 4
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -374,7 +374,9 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     cur = H['COUNT']
     for name, size in (('PARAMS', P['COUNT']), ('ROBOT', ndof * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
                        ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
-                       ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT'])):
+                       ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('VERT4', 4 * len(verts))):
+        if name == 'VERT4':
+            cur = (cur + 3) // 4 * 4          # 16-byte aligned
         off[name] = cur
         cur += size
     nwords = cur
@@ -391,7 +393,7 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
                OFF_ROBOT=off['ROBOT'], OFF_FREE=off['FREE'], OFF_COLL=off['COLL'], OFF_VERT=off['VERT'],
                OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
                S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, FOOD0=2, TOOL_BODY=0, NDIR=len(dirs),
-               OFF_DIRS=off['DIRS'])
+               OFF_DIRS=off['DIRS'], OFF_VERT4=off['VERT4'])
     for k, v in hdr.items():
         i[H[k]] = v
     p = f[off['PARAMS']:off['PARAMS'] + P['COUNT']]
@@ -432,6 +434,7 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     v32 = verts.astype(np.float32)
     f[off['VERT']:off['VERT'] + 3 * len(verts)] = v32.ravel()
     f[off['DIRS']:off['DIRS'] + 3 * len(dirs)] = dirs.astype(np.float32).ravel()
+    f[off['VERT4']:off['VERT4'] + 4 * len(verts)] = np.concatenate([v32, np.zeros((len(verts), 1), np.float32)], axis=1).ravel()
     for k, c in enumerate(sc.colliders):
         base = off['COLL'] + k * C['STRIDE']
         i[base + C['BODY']] = c['body']

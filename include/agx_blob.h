@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 3
+#define AGX_BLOB_VERSION 4
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
 
 /* ---- header: int32[AGX_H_COUNT] at word 0 ------------------------------------------------ */
@@ -33,6 +33,7 @@ enum {
   AGX_H_TOOL_BODY,    /* free-body index of the tool                                          */
   AGX_H_NDIR,         /* number of penetration-sampling directions (stored after the verts)  */
   AGX_H_OFF_DIRS,
+  AGX_H_OFF_VERT4,    /* the same vertices padded to float[4] (16-byte aligned) for 128-bit loads        */
   AGX_H_COUNT = 40
 };
 
