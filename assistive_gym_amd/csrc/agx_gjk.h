@@ -4,10 +4,8 @@
 // resident, shared by all environments) in the body frame and transformed on the fly.
 #pragma once
 
-struct __attribute__((aligned(16))) agx_f4 { float x, y, z, w; };
-
 struct gjk_shape {
-  const float* v;   // body-frame vertices, padded (x,y,z,0)*n, 16-byte aligned, in the model blob
+  const float* v;   // body-frame vertices (x,y,z)*n in the model blob
   int n;
   m3 R;             // body rotation (world)
   v3 p;             // body position minus the pair's shift point
@@ -17,8 +15,7 @@ struct gjk_shape {
 
 AGX_DEV v3 gjk_vertex0(const gjk_shape& s) {
   if (s.box) return s.lo;
-  const agx_f4 q = *(const agx_f4*)s.v;
-  return mul(s.R, mk3(q.x, q.y, q.z)) + s.p;
+  return mul(s.R, mk3(s.v[0], s.v[1], s.v[2])) + s.p;
 }
 AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
   if (s.box) {
@@ -32,22 +29,24 @@ AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
     return best;
   }
   v3 dl = tmul(s.R, d);
-  // 4 vertices per round, 128-bit loads all issued before the first use (indices clamped to n-1:
-  // a repeated vertex never wins the strict comparison, so the first maximum is still returned)
-  const agx_f4* V = (const agx_f4*)s.v;
-  agx_f4 bv = V[0];
-  float bd = bv.x * dl.x + bv.y * dl.y + bv.z * dl.z;
+  // 4 vertices per round, all loads issued before the first use (indices clamped to n-1: a
+  // repeated vertex never wins the strict comparison, so the first maximum is still returned)
+  const float* V = s.v;
+  int best = 0;
+  float bd = V[0] * dl.x + V[1] * dl.y + V[2] * dl.z;
   const int last = s.n - 1;
   for (int k = 1; k < s.n; k += 4) {
-    const agx_f4 q0 = V[k], q1 = V[k + 1 < last ? k + 1 : last], q2 = V[k + 2 < last ? k + 2 : last], q3 = V[k + 3 < last ? k + 3 : last];
-    const float t0 = q0.x * dl.x + q0.y * dl.y + q0.z * dl.z, t1 = q1.x * dl.x + q1.y * dl.y + q1.z * dl.z;
-    const float t2 = q2.x * dl.x + q2.y * dl.y + q2.z * dl.z, t3 = q3.x * dl.x + q3.y * dl.y + q3.z * dl.z;
-    if (t0 > bd) { bd = t0; bv = q0; }
-    if (t1 > bd) { bd = t1; bv = q1; }
-    if (t2 > bd) { bd = t2; bv = q2; }
-    if (t3 > bd) { bd = t3; bv = q3; }
+    const int k1 = k + 1 < last ? k + 1 : last, k2 = k + 2 < last ? k + 2 : last, k3 = k + 3 < last ? k + 3 : last;
+    const float x0 = V[3 * k], y0 = V[3 * k + 1], z0 = V[3 * k + 2], x1 = V[3 * k1], y1 = V[3 * k1 + 1], z1 = V[3 * k1 + 2];
+    const float x2 = V[3 * k2], y2 = V[3 * k2 + 1], z2 = V[3 * k2 + 2], x3 = V[3 * k3], y3 = V[3 * k3 + 1], z3 = V[3 * k3 + 2];
+    const float t0 = x0 * dl.x + y0 * dl.y + z0 * dl.z, t1 = x1 * dl.x + y1 * dl.y + z1 * dl.z;
+    const float t2 = x2 * dl.x + y2 * dl.y + z2 * dl.z, t3 = x3 * dl.x + y3 * dl.y + z3 * dl.z;
+    if (t0 > bd) { bd = t0; best = k; }
+    if (t1 > bd) { bd = t1; best = k1; }
+    if (t2 > bd) { bd = t2; best = k2; }
+    if (t3 > bd) { bd = t3; best = k3; }
   }
-  return mul(s.R, mk3(bv.x, bv.y, bv.z)) + s.p;
+  return mul(s.R, mk3(V[3 * best], V[3 * best + 1], V[3 * best + 2])) + s.p;
 }
 
 // closest point to the origin on triangle (a,b,c): barycentric weights

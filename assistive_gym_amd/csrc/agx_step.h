@@ -325,7 +325,7 @@ struct Cand { v3 pa, pb, n; float dist, gap; };
 
 AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
   s.n = CLI(c, col, AGX_C_NVERT);
-  s.v = c.bf + c.bi[AGX_H_OFF_VERT4] + 4 * CLI(c, col, AGX_C_VOFF);
+  s.v = c.bf + c.o_vert + 3 * CLI(c, col, AGX_C_VOFF);
   v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), s.R, p);
   s.p = p - shift; s.box = false;
 }
