@@ -1,0 +1,160 @@
+"""gym.Env surface of the reference for the FeedingJaco-v1 hot path.
+
+Mirrors, by name and behaviour, what assistive_gym/learn.py and env_viewer.py touch
+(SURVEY 8b): class ``FeedingJacoEnv`` (assistive_gym/envs/feeding_envs.py:29-31) with
+``reset() -> obs``, ``step(a) -> (obs, reward, done, info)`` (feeding.py:12-43), ``seed``
+(env.py:78-80), ``set_seed``, ``disconnect``, ``render`` (no-op: rendering is out of scope),
+``action_space`` / ``observation_space`` (+ ``_robot`` / ``_human`` variants, env.py:42-49),
+``action_robot_len`` ..., and the ``info`` keys of feeding.py:36.
+
+Each scalar env is slot 0 of its own 1-environment stepper handle; the batched form is
+assistive_gym_amd.vec_env.FeedingJacoVecEnv.  Physics always runs in libagx on the GPU: there is no
+CPU fallback, constructing the env without a GPU raises.
+"""
+import numpy as np
+
+from .blob import ModelBlob
+from .host.reset import FeedingJacoReset
+
+try:                                     # gym is optional here (not installed in the build image)
+    import gym
+    from gym import spaces
+    from gym.utils import seeding
+    _Base = gym.Env
+except Exception:                        # minimal stand-ins with the attributes the callers read
+    gym = None
+
+    class _Box:
+        def __init__(self, low, high, dtype=np.float32):
+            self.low, self.high, self.dtype = np.asarray(low, dtype=dtype), np.asarray(high, dtype=dtype), dtype
+            self.shape = self.low.shape
+            self._rng = np.random.RandomState()
+
+        def seed(self, seed=None):
+            self._rng = np.random.RandomState(seed)
+
+        def sample(self):
+            return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and np.all(x >= self.low) and np.all(x <= self.high)
+
+    class spaces:                        # noqa: N801
+        Box = _Box
+
+    class seeding:                       # noqa: N801
+        @staticmethod
+        def np_random(seed=None):
+            if seed is None:
+                seed = np.random.SeedSequence().entropy % (2 ** 31)
+            return np.random.RandomState(int(seed) % (2 ** 32)), seed
+
+    class _Base:
+        metadata = {}
+
+SETTLE_STEPS = 25       # feeding.py:178-179
+
+
+class FeedingJacoEnv(_Base):
+    """FeedingJaco-v1: Jaco arm on a wheelchair feeds a static (non-cooperating) human."""
+
+    def __init__(self, device=0):
+        self.task = 'feeding'
+        self.time_step, self.frame_skip = 0.02, 5                                    # env.py:21
+        self.blob = ModelBlob.load('feeding_jaco')
+        self.device = device
+        self.action_robot_len, self.action_human_len = self.blob.act_dim, 0          # env.py:40-41
+        self.obs_robot_len, self.obs_human_len = self.blob.obs_dim, 0                # feeding.py:10, env.py:44
+        one = np.ones(self.action_robot_len, dtype=np.float32)
+        big = np.ones(self.obs_robot_len, dtype=np.float32) * 1000000000.0
+        self.action_space = spaces.Box(low=-one, high=one, dtype=np.float32)          # env.py:42
+        self.observation_space = spaces.Box(low=-big, high=big, dtype=np.float32)     # env.py:45
+        self.action_space_robot = spaces.Box(low=-one, high=one, dtype=np.float32)
+        self.observation_space_robot = spaces.Box(low=-big, high=big, dtype=np.float32)
+        self.action_space_human = spaces.Box(low=np.zeros(0, np.float32), high=np.zeros(0, np.float32), dtype=np.float32)
+        self.observation_space_human = spaces.Box(low=np.zeros(0, np.float32), high=np.zeros(0, np.float32), dtype=np.float32)
+        self.gui = False
+        self.iteration = 0
+        self.task_success = 0
+        self.total_force_on_human = 0.0
+        self._stepper = None
+        self._reset_helper = FeedingJacoReset(self.blob)
+        self._episode = 0
+        self.seed(1001)                                                               # env.py:21,30
+
+    # ---- gym API ------------------------------------------------------------------------------
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def set_seed(self, seed=1000):
+        self.np_random.seed(seed)
+
+    def _ensure_stepper(self):
+        if self._stepper is None:
+            from .libagx import Stepper          # raises without the HIP library / a GPU
+            self._stepper = Stepper(self.blob, 1, self.device)
+        return self._stepper
+
+    def reset(self):
+        st = self._ensure_stepper()
+        state = self.blob.new_state(1)
+        self._episode += 1
+        self.reset_info = {}
+        self._reset_helper.sample(self.np_random, state, env_seed=self._episode, info=self.reset_info, impairment='no_tremor')
+        st.set_state(state)
+        st.settle(SETTLE_STEPS)
+        self.iteration, self.task_success = 0, 0
+        return st.observe_host()[0].astype(np.float64)
+
+    def step(self, action):
+        action = np.asarray(action, dtype=np.float32)
+        if action.shape != (self.action_robot_len,):
+            # the reference prints and exit()s (env.py:198-200); a library must not kill the process
+            raise ValueError('Received agent actions of length %d does not match expected action length of %d'
+                             % (action.size, self.action_robot_len))
+        obs, rew, done, info = self._ensure_stepper().step_host(action[None])
+        self.iteration += 1
+        self.total_force_on_human = float(info[0, 0])
+        out_info = {'total_force_on_human': float(info[0, 0]), 'task_success': int(info[0, 1]),
+                    'action_robot_len': self.action_robot_len, 'action_human_len': self.action_human_len,
+                    'obs_robot_len': self.obs_robot_len, 'obs_human_len': self.obs_human_len}      # feeding.py:36
+        return obs[0].astype(np.float64), float(rew[0]), bool(done[0]), out_info
+
+    def render(self, mode='human'):
+        return None          # GUI / EGL rendering is outside the hot path
+
+    def disconnect(self):
+        if self._stepper is not None:
+            self._stepper.close()
+            self._stepper = None
+
+    close = disconnect
+
+    # ---- state injection (no reference equivalent; parity protocol of SURVEY 8c) ----------------
+    def get_state(self):
+        return self._ensure_stepper().get_state()[0]
+
+    def set_state(self, state):
+        self._ensure_stepper().set_state(np.asarray(state, dtype=np.float32).reshape(1, -1))
+
+
+ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv}
+
+
+def make(env_id):
+    """`gym.make('assistive_gym:FeedingJaco-v1')` equivalent, with the TimeLimit of 200 steps folded
+    into the env itself (done = iteration >= 200, feeding.py:37; assistive_gym/__init__.py:11)."""
+    name = env_id.split(':')[-1]
+    if name not in ENV_IDS:
+        raise KeyError('%s is not built yet (hot-path scope: %s)' % (env_id, sorted(ENV_IDS)))
+    return ENV_IDS[name]()
+
+
+if gym is not None:       # same ids the reference registers (assistive_gym/__init__.py:6-12)
+    try:
+        from gym.envs.registration import register
+        register(id='FeedingJaco-v1', entry_point='assistive_gym_amd.envs:FeedingJacoEnv', max_episode_steps=200)
+    except Exception:
+        pass

@@ -1,0 +1,18 @@
+"""The gym surface exists without a GPU; physics calls fail loudly (no CPU fallback)."""
+import numpy as np
+import pytest
+
+
+def test_spaces_and_no_fallback():
+    import torch
+    from assistive_gym_amd.envs import FeedingJacoEnv
+    from assistive_gym_amd.libagx import AgxError
+    env = FeedingJacoEnv()
+    assert env.action_space.shape == (7,) and env.observation_space.shape == (25,)
+    assert env.action_space.low.min() == -1 and env.action_space.high.max() == 1
+    assert env.action_robot_len == 7 and env.action_human_len == 0 and env.obs_robot_len == 25 and env.obs_human_len == 0
+    assert env.seed(5) == [5]
+    assert env.action_space.contains(env.action_space.sample())
+    if not torch.cuda.is_available():
+        with pytest.raises(AgxError):
+            env.reset()
