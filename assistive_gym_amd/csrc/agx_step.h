@@ -62,7 +62,7 @@ constexpr int A_DINV = A_ACC + MAX_DOF * 6;              // [MAX_DOF]
 constexpr int A_UU = A_DINV + MAX_DOF;
 constexpr int A_QDD = A_UU + MAX_DOF;
 constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_DOF][6] M^-1 column workspace
-constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_DOF * 6;
+constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_DOF * 6 + MAX_DOF * MAX_DOF;
 static_assert(A_DYN_END <= ARENA_WORDS, "dynamics workspace exceeds the arena");
 // arena, collision phase: world AABBs [ncoll][6]
 constexpr int MAX_COLL = 256;
@@ -262,10 +262,10 @@ AGX_DEV void aba_and_minv(Ctx& c) {
   if (lane < n) {
     const int j = lane; float* P = A + A_COLS + j * (MAX_DOF * 6);
     for (int k = 0; k < n * 6; k++) P[k] = 0.f;
-    float uu[MAX_DOF];
+    float* UU = A + A_COLS + MAX_DOF * MAX_DOF * 6 + j * MAX_DOF;   // per-lane u[] next to the column workspaces
     for (int d = n - 1; d >= 0; d--) {
       float u = (d == j ? 1.f : 0.f) - dot6p(L + L_S + 6 * d, P + 6 * d);
-      uu[d] = u;
+      UU[d] = u;
       int par = RBI(c, d, AGX_R_PARENT);
       if (par >= 0) { float s = u * A[A_DINV + d]; for (int k = 0; k < 6; k++) P[6 * par + k] += P[6 * d + k] + A[A_U + 6 * d + k] * s; }
     }
@@ -273,7 +273,7 @@ AGX_DEV void aba_and_minv(Ctx& c) {
     for (int d = 0; d < n; d++) {
       int par = RBI(c, d, AGX_R_PARENT);
       float ap[6]; for (int k = 0; k < 6; k++) ap[k] = par < 0 ? 0.f : P[6 * par + k];
-      float qdd = (uu[d] - dot6p(A + A_U + 6 * d, ap)) * A[A_DINV + d];
+      float qdd = (UU[d] - dot6p(A + A_U + 6 * d, ap)) * A[A_DINV + d];
       for (int k = 0; k < 6; k++) P[6 * d + k] = ap[k] + L[L_S + 6 * d + k] * qdd;
       L[L_MINV + d * MAX_DOF + j] = qdd;
     }
@@ -520,7 +520,7 @@ AGX_DEV void add_jac(const Ctx& c, int code, v3 x, v3 f, v3 t, float sign, float
     v3 Fa = cross(xr, f) + t;
     float F[6] = {Fa.x, Fa.y, Fa.z, f.x, f.y, f.z};
     const int anc = c.ldsi[L_MISC + M_ANC + code];
-    for (int d = 0; d < c.ndof; d++) if (anc >> d & 1) Jr[d] += sign * dot6p(L + L_S + 6 * d, F);
+    _Pragma("unroll") for (int d = 0; d < MAX_DOF; d++) if (d < c.ndof && (anc >> d & 1)) Jr[d] += sign * dot6p(L + L_S + 6 * d, F);
   } else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) {
     int b = code - AGX_BODY_FREE0;
     v3 r = x - ld3(L + L_ST + c.s_free + 13 * b);
@@ -542,7 +542,7 @@ AGX_DEV void row_pair(const Ctx& c, RowGeom& r, int codeA, v3 xa, int codeB, v3 
 }
 AGX_DEV float row_velocity(const Ctx& c, const RowGeom& r) {
   const float* L = c.lds; float s = 0.f;
-  if (r.robot) for (int d = 0; d < c.ndof; d++) s += r.Jr[d] * L[L_VEL + d];
+  if (r.robot) { _Pragma("unroll") for (int d = 0; d < MAX_DOF; d++) if (d < c.ndof) s += r.Jr[d] * L[L_VEL + d]; }
   if (r.fa >= 0) for (int k = 0; k < 6; k++) s += r.Ja[k] * L[L_VEL + c.ndof + 6 * r.fa + k];
   if (r.fb >= 0) for (int k = 0; k < 6; k++) s += r.Jb[k] * L[L_VEL + c.ndof + 6 * r.fb + k];
   return s;
@@ -556,7 +556,11 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
   int a0 = 0, na = 0, b0 = 0, nb = 0;
   if (r.robot) {
     a0 = 0; na = n;
-    for (int i = 0; i < n; i++) { float acc = 0.f; for (int j = 0; j < n; j++) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j]; E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++; }
+    _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i < n) {
+      float acc = 0.f;
+      _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j < n) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
+      E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
+    }
   }
   for (int side = 0; side < 2; side++) {
     int fb = side == 0 ? r.fa : r.fb; if (fb < 0) continue;
@@ -595,7 +599,8 @@ AGX_DEV void build_rows(Ctx& c) {
   if (lane < 16) {
     const int d = lane;
     if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f) {
-      active = true; r.robot = true; r.Jr[d] = 1.f;
+      active = true; r.robot = true;
+      _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? 1.f : 0.f;
       // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
       bterm = RBF(c, d, AGX_R_KP) * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
       float lim = RBF(c, d, AGX_R_MAXF) * dt; lo = -lim; hi = lim;
@@ -606,8 +611,10 @@ AGX_DEV void build_rows(Ctx& c) {
       float q = L[L_ST + c.s_q + d];
       float gap = side == 0 ? q - RBF(c, d, AGX_R_LOWER) : RBF(c, d, AGX_R_UPPER) - q;
       if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
-        active = true; r.robot = true; r.Jr[d] = side == 0 ? 1.f : -1.f;
-        float rv = r.Jr[d] * L[L_VEL + d];
+        active = true; r.robot = true;
+        const float sg = side == 0 ? 1.f : -1.f;
+        _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? sg : 0.f;
+        float rv = sg * L[L_VEL + d];
         bterm = gap > 0 ? (-gap / dt - rv) : (-gap * erp / dt - rv);
         lo = 0.f; hi = 1e30f;
       }

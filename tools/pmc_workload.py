@@ -1,0 +1,19 @@
+"""Workload for the PMC passes: 6 observation-only launches (known traffic: one state record read,
+one observation written per env) followed by 6 full env.step launches, 4096 envs."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+n = 4096
+env = FeedingJacoVecEnv(n, pool_size=64, seed=1001, auto_reset=False)
+env.reset()
+torch.cuda.synchronize()
+for _ in range(6):
+    env.stepper.observe_dev(env.obs)
+torch.cuda.synchronize()
+g = torch.Generator(device='cuda'); g.manual_seed(1)
+for _ in range(6):
+    a = torch.rand((n, 7), device='cuda', generator=g) * 2 - 1
+    env.step(a)
+torch.cuda.synchronize()
