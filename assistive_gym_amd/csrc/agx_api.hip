@@ -1,5 +1,6 @@
 // agx_api.hip -- libagx: C ABI (include/agx.h) + kernel launches for gfx950.
-// One workgroup = one wavefront = one environment; 64 threads, LDS_BYTES of dynamic LDS.
+// One workgroup = one wavefront = one environment (64 threads); an env.step() is
+// frame_skip x [agx_build_kernel, agx_solve_kernel] + agx_finish_kernel on one stream.
 #include "agx_wave.h"
 #include "agx_step.h"
 #include "../../include/agx.h"
@@ -19,16 +20,39 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGX_E_HIP, #x, e_); } while (0)
 
+// build: kinematics, ABA, collision, constraint rows -> scratch.  Register- and LDS-heavy.
 extern "C" __global__ void __launch_bounds__(64, 2)
-agx_step_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* obs, float* reward, uint8_t* done,
-                float* info, float* debug, int n_envs, int sw, int act_dim, int obs_dim, int mode, int nsettle) {
+agx_build_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int n_envs, int sw, int act_dim) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x;
   if (env >= n_envs) return;
-  agx::env_step(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr,
-                obs ? obs + (size_t)env * obs_dim : nullptr, reward ? reward + env : nullptr, done ? done + env : nullptr,
-                info ? info + (size_t)env * AGX_INFO_DIM : nullptr, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr,
-                lds, (int)threadIdx.x, mode, nsettle);
+  agx::env_build(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
+                 debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
+}
+// solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
+extern "C" __global__ void __launch_bounds__(64, 4)
+agx_solve_kernel(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int n_envs, int sw) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
+}
+// finish: forces, observation, food state machine, reward, done, info
+extern "C" __global__ void __launch_bounds__(64, 2)
+agx_finish_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
+                  float* info, int n_envs, int sw, int act_dim, int obs_dim) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  agx::env_finish(blob, state + (size_t)env * sw, actions + (size_t)env * act_dim, scratch + (size_t)env * agx::SCR_WORDS, obs + (size_t)env * obs_dim,
+                  reward + env, done + env, info ? info + (size_t)env * AGX_INFO_DIM : nullptr, lds, (int)threadIdx.x);
+}
+extern "C" __global__ void __launch_bounds__(64, 2)
+agx_observe_kernel(const uint32_t* __restrict__ blob, float* state, float* obs, int n_envs, int sw, int obs_dim) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  agx::env_observe(blob, state + (size_t)env * sw, obs + (size_t)env * obs_dim, lds, (int)threadIdx.x);
 }
 
 // done envs take a fresh record from the pool; coalesced copy, one wave per env
@@ -63,7 +87,9 @@ struct agx_handle_s {
   int device, n_envs, act_dim, obs_dim, sw;
   uint32_t* blob_dev;
   float* state_dev;
+  float* scratch_dev;   // [n_envs][SCR_WORDS]: rows, predicted velocities, contacts handed between the kernels
   int* episode_dev;
+  int frame_skip;
   // staging for the *_host convenience calls
   float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
   hipEvent_t ev0, ev1;
@@ -96,6 +122,9 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   HIPCHK(hipMemcpy(h->blob_dev, blob, blob_bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->state_dev, (size_t)n_envs * h->sw * 4));
   HIPCHK(hipMemset(h->state_dev, 0, (size_t)n_envs * h->sw * 4));
+  HIPCHK(hipMalloc(&h->scratch_dev, (size_t)n_envs * agx::SCR_WORDS * 4));
+  HIPCHK(hipMemset(h->scratch_dev, 0, (size_t)n_envs * agx::SCR_WORDS * 4));
+  h->frame_skip = (int)((const float*)blob)[hi[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   HIPCHK(hipMalloc(&h->episode_dev, (size_t)n_envs * 4));
   HIPCHK(hipMemset(h->episode_dev, 0, (size_t)n_envs * 4));
   HIPCHK(hipMalloc(&h->act_dev, (size_t)n_envs * h->act_dim * 4));
@@ -104,7 +133,9 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   HIPCHK(hipMalloc(&h->info_dev, (size_t)n_envs * AGX_INFO_DIM * 4));
   HIPCHK(hipMalloc(&h->done_dev, (size_t)n_envs));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
-  HIPCHK(hipFuncSetAttribute((const void*)agx_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void*)agx_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void*)agx_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void*)agx_observe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
   *out = h;
   return AGX_OK;
 }
@@ -112,7 +143,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
 void agx_destroy(agx_handle h) {
   if (!h) return;
   hipSetDevice(h->device);
-  hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
+  hipFree(h->scratch_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
   hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   delete h;
@@ -139,28 +170,43 @@ int agx_get_state(agx_handle h, float* host_states) {
 }
 int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fail(AGX_E_ARG, "agx_state_dev: bad argument"); *out_dev = h->state_dev; return AGX_OK; }
 
-static int launch(agx_handle h, const float* act, float* obs, float* rew, uint8_t* done, float* info, float* dbg, int mode, int nsettle, void* stream) {
+// one p.stepSimulation() for every environment: build + solve
+static int launch_substep(agx_handle h, const float* act, float* dbg, hipStream_t st) {
+  hipLaunchKernelGGL(agx_build_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, h->n_envs, h->sw, h->act_dim);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(agx_solve_kernel, dim3(h->n_envs), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, dbg, h->n_envs, h->sw);
+  HIPCHK(hipGetLastError());
+  return AGX_OK;
+}
+static int launch_step(agx_handle h, const float* act, float* obs, float* rew, uint8_t* done, float* info, float* dbg, void* stream) {
   HIPCHK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(agx_step_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, (hipStream_t)stream, h->blob_dev, h->state_dev, act, obs, rew,
-                     done, info, dbg, h->n_envs, h->sw, h->act_dim, h->obs_dim, mode, nsettle);
+  hipStream_t st = (hipStream_t)stream;
+  for (int k = 0; k < h->frame_skip; k++) { int rc = launch_substep(h, k == 0 ? act : nullptr, k == 0 ? dbg : nullptr, st); if (rc) return rc; }
+  hipLaunchKernelGGL(agx_finish_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info,
+                     h->n_envs, h->sw, h->act_dim, h->obs_dim);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
 int agx_settle(agx_handle h, int n_substeps, void* stream) {
   if (!h || n_substeps < 0) return fail(AGX_E_ARG, "agx_settle: bad argument");
-  return launch(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, n_substeps, stream);
+  HIPCHK(hipSetDevice(h->device));
+  for (int k = 0; k < n_substeps; k++) { int rc = launch_substep(h, nullptr, nullptr, (hipStream_t)stream); if (rc) return rc; }
+  return AGX_OK;
 }
 int agx_step(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, void* stream) {
   if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step: bad argument");
-  return launch(h, a, obs, rew, done, info, nullptr, 0, 0, stream);
+  return launch_step(h, a, obs, rew, done, info, nullptr, stream);
 }
 int agx_step_debug(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, float* dbg, void* stream) {
   if (!h || !a || !obs || !rew || !done || !dbg) return fail(AGX_E_ARG, "agx_step_debug: bad argument");
-  return launch(h, a, obs, rew, done, info, dbg, 0, 0, stream);
+  return launch_step(h, a, obs, rew, done, info, dbg, stream);
 }
 int agx_observe(agx_handle h, float* obs, void* stream) {
   if (!h || !obs) return fail(AGX_E_ARG, "agx_observe: bad argument");
-  return launch(h, nullptr, obs, nullptr, nullptr, nullptr, nullptr, 2, 0, stream);
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(agx_observe_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, (hipStream_t)stream, h->blob_dev, h->state_dev, obs, h->n_envs, h->sw, h->obs_dim);
+  HIPCHK(hipGetLastError());
+  return AGX_OK;
 }
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {
   if (!h || !pool_dev || pool_n <= 0 || !done_dev) return fail(AGX_E_ARG, "agx_reset_done: bad argument");
@@ -174,7 +220,7 @@ int agx_step_host(agx_handle h, const float* a, float* obs, float* rew, uint8_t*
   if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step_host: bad argument");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpy(h->act_dev, a, (size_t)h->n_envs * h->act_dim * 4, hipMemcpyHostToDevice));
-  int rc = launch(h, h->act_dev, h->obs_dev, h->rew_dev, h->done_dev, h->info_dev, nullptr, 0, 0, nullptr);
+  int rc = launch_step(h, h->act_dev, h->obs_dev, h->rew_dev, h->done_dev, h->info_dev, nullptr, nullptr);
   if (rc) return rc;
   HIPCHK(hipMemcpy(obs, h->obs_dev, (size_t)h->n_envs * h->obs_dim * 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(rew, h->rew_dev, (size_t)h->n_envs * 4, hipMemcpyDeviceToHost));
@@ -184,7 +230,7 @@ int agx_step_host(agx_handle h, const float* a, float* obs, float* rew, uint8_t*
 }
 int agx_observe_host(agx_handle h, float* obs) {
   if (!h || !obs) return fail(AGX_E_ARG, "agx_observe_host: bad argument");
-  int rc = launch(h, nullptr, h->obs_dev, nullptr, nullptr, nullptr, nullptr, 2, 0, nullptr);
+  int rc = agx_observe(h, h->obs_dev, nullptr);
   if (rc) return rc;
   HIPCHK(hipMemcpy(obs, h->obs_dev, (size_t)h->n_envs * h->obs_dim * 4, hipMemcpyDeviceToHost));
   return AGX_OK;

@@ -44,11 +44,12 @@ constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
 constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
 constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
 constexpr int L_CON = L_MISC + 32;                       // [MAX_CON][CON_STRIDE]
-constexpr int L_HDR = L_CON + MAX_CON * CON_STRIDE;      // [MAX_ROWS][HDR_STRIDE]
-constexpr int L_ARENA = L_HDR + MAX_ROWS * HDR_STRIDE;
+constexpr int L_ARENA = L_CON + MAX_CON * CON_STRIDE;
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
 static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
 constexpr int LDS_BYTES = LDS_WORDS * 4;
+constexpr int LDS_SOLVE_WORDS = L_CON;                  // the solve kernel only needs the state copy and the frame tables
+constexpr int LDS_SOLVE_BYTES = LDS_SOLVE_WORDS * 4;
 // arena, dynamics phase
 constexpr int A_COMW = 0;                                // [MAX_DOF][3] rel. ref
 constexpr int A_IW = A_COMW + MAX_DOF * 3;               // [MAX_DOF][9]
@@ -73,6 +74,11 @@ constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
 constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 10, C_DIST = 13, C_MU = 14, C_LAM = 15;
 // row header
 constexpr int DBG_HDR = 16 + MAX_CON * CON_STRIDE + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE, DBG_TIME = DBG_LAM + MAX_ROWS, DBG_WORDS = DBG_TIME + 16;
+// per-environment scratch record in HBM (L2-resident while its environment is being solved)
+constexpr int SCR_ENT = 4096, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
+constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
+constexpr int SCR_WORDS = SCR_O_META + SCR_META;
+constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_FRIC = 6, H_MU = 7;
 
 struct Ctx {
@@ -85,6 +91,8 @@ struct Ctx {
   float dt;
   int ncon, nrows, first_normal, near_mask, overflow;
   float* dbg;   // optional debug sink (parity tests)
+  float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
+  float* gcon;          // contact records handed from the build kernel to the solve / finish kernels
   long long tm[16]; bool timing;   // per-phase shader-clock totals (debug path only)
 };
 
@@ -108,7 +116,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_q = h[AGX_H_S_Q]; c.s_qd = h[AGX_H_S_QD]; c.s_qt = h[AGX_H_S_QT]; c.s_free = h[AGX_H_S_FREE]; c.s_base = h[AGX_H_S_BASE];
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV];
   c.dt = PRM(c, AGX_P_DT);
-  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.dbg = nullptr;
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 
@@ -551,7 +559,7 @@ AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { return (r.robot ? c.nd
 // B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
 // A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
 AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float bterm, float lo, float hi, int fric_of, float mu) {
-  float* L = c.lds; float* E = L + L_ARENA + 2 * off; const int n = c.ndof;
+  float* L = c.lds; float* E = c.E + 2 * off; const int n = c.ndof;
   float D = 0.f; int e = 0;
   int a0 = 0, na = 0, b0 = 0, nb = 0;
   if (r.robot) {
@@ -573,7 +581,7 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
   }
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
-  float* H = L + L_HDR + HDR_STRIDE * row; int* Hi = (int*)H;
+  float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
   H[H_INVD] = D > 1e-12f ? 1.0f / D : 0.f; H[H_B] = bterm; H[H_LO] = lo; H[H_HI] = hi;
   Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off; Hi[H_FRIC] = fric_of; H[H_MU] = mu;
 }
@@ -592,7 +600,7 @@ AGX_DEV void build_rows(Ctx& c) {
   float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
   const float erp = PRM(c, AGX_P_ERP), cerp = PRM(c, AGX_P_CONTACT_ERP);
   int maxrows = (int)PRM(c, AGX_P_MAX_ROWS); if (maxrows > MAX_ROWS) maxrows = MAX_ROWS;
-  int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > ARENA_WORDS / 2) maxent = ARENA_WORDS / 2;
+  int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > SCR_ENT / 2) maxent = SCR_ENT / 2;
   // --- non-contact rows: lanes 0..15 motors, 16..47 joint limits (dof, side), 48..53 tool constraint
   RowGeom r; row_clear(r);
   bool active = false; float bterm = 0.f, lo = 0.f, hi = 0.f;
@@ -646,7 +654,7 @@ AGX_DEV void build_rows(Ctx& c) {
   int row = wave_rank(am), off = 1 + wave_scan_excl(cnt);      // entry 0 of the arena is the zero pair
   int nnc = popc64(am), ent = 1 + wave_sum_i(cnt);
   wave_sync();
-  if (lane == 0) { L[L_ARENA] = 0.f; L[L_ARENA + 1] = 0.f; }
+  if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }
   // contacts are needed below but live outside the arena; AABBs (arena) are dead from here on
   if (active) row_store(c, r, row, off, bterm, lo, hi, -1, 0.f);
   // --- contact rows: lane = contact; normal rows first, then one friction row per contact
@@ -710,15 +718,19 @@ AGX_DEV void pgs_fetch(const float* E, int lane, int pack, int off, float& j0, f
     j1 = E[2 * e]; c1 = E[2 * e + 1];
   }
 }
-// one Gauss-Seidel pass over the rows held in lanes [l0, l1) of one register set
+// one Gauss-Seidel pass over the rows held in lanes [l0, l1) of one register set.  The (J,B) pairs
+// stream from the per-env scratch (L2); the loads for rows r+1 and r+2 are in flight while row r is
+// reduced.
 template <bool FRICTION>
 AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int lane, int l0, int l1, float& dv0, float& dv1) {
   if (l1 <= l0) return;
-  float pj0, pc0, pj1, pc1;
-  pgs_fetch(E, lane, wave_bcast_i(S.pack, l0), wave_bcast_i(S.off, l0), pj0, pc0, pj1, pc1);
+  float aj0, ac0, aj1, ac1, bj0 = 0.f, bc0 = 0.f, bj1 = 0.f, bc1 = 0.f;
+  pgs_fetch(E, lane, wave_bcast_i(S.pack, l0), wave_bcast_i(S.off, l0), aj0, ac0, aj1, ac1);
+  if (l0 + 1 < l1) pgs_fetch(E, lane, wave_bcast_i(S.pack, l0 + 1), wave_bcast_i(S.off, l0 + 1), bj0, bc0, bj1, bc1);
   for (int rl = l0; rl < l1; rl++) {
-    const float j0 = pj0, c0 = pc0, j1 = pj1, c1 = pc1;
-    if (rl + 1 < l1) pgs_fetch(E, lane, wave_bcast_i(S.pack, rl + 1), wave_bcast_i(S.off, rl + 1), pj0, pc0, pj1, pc1);
+    const float j0 = aj0, c0 = ac0, j1 = aj1, c1 = ac1;
+    aj0 = bj0; ac0 = bc0; aj1 = bj1; ac1 = bc1;
+    if (rl + 2 < l1) pgs_fetch(E, lane, wave_bcast_i(S.pack, rl + 2), wave_bcast_i(S.off, rl + 2), bj0, bc0, bj1, bc1);
     const float jdv = wave_sum(j0 * dv0 + j1 * dv1);
     const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
     const float nl = wave_clamp(S.lam + (S.b - jdv) * S.invD, lo, hi);
@@ -729,9 +741,8 @@ AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int l
   }
 }
 AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet& S) {
-  const float* L = c.lds;
   ok = ok && row < MAX_ROWS;
-  const float* H = L + L_HDR + HDR_STRIDE * (ok ? row : 0); const int* Hi = (const int*)H;
+  const float* H = c.H + HDR_STRIDE * (ok ? row : 0); const int* Hi = (const int*)H;
   const float invD = ok ? H[H_INVD] : 0.f;
   // a row without effective mass (static-static, degenerate) is kept but pinned at zero impulse
   const bool live = ok && invD != 0.f;
@@ -740,8 +751,8 @@ AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet&
   S.pack = ok ? Hi[H_PACK] : 0; S.off = ok ? Hi[H_OFF] : 0;
 }
 AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
-  float* L = c.lds; const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER);
-  const float* E = L + L_ARENA;
+  const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER);
+  const float* E = c.E;
   const int nnc = c.first_normal, nc = c.ncon, nA = nnc + nc;      // rows: [0,nnc) non-contact, [nnc,nA) normals, [nA,nA+nc) friction
   static_assert(MAX_ROWS <= 256 && MAX_CON <= 64, "two register sets per block");
   PgsSet A0, A1, B0, B1;
@@ -761,18 +772,16 @@ AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
     pgs_sweep<true>(B1, A1.lam, E, lane, f1a, f1b, dv0, dv1);
   }
   // solved normal impulses -> contact records (what getContactPoints reports until the next step)
-  wave_sync();
   { const int r0 = lane, r1 = 64 + lane;
-    if (r0 >= nnc && r0 < nA) L[L_CON + CON_STRIDE * (r0 - nnc) + C_LAM] = A0.lam;
-    if (r1 >= nnc && r1 < nA) L[L_CON + CON_STRIDE * (r1 - nnc) + C_LAM] = A1.lam; }
-  wave_sync();
+    if (r0 >= nnc && r0 < nA) c.gcon[CON_STRIDE * (r0 - nnc) + C_LAM] = A0.lam;
+    if (r1 >= nnc && r1 < nA) c.gcon[CON_STRIDE * (r1 - nnc) + C_LAM] = A1.lam; }
 }
 
 // ---- K7 + post-substep hooks -----------------------------------------------------------------------------
-AGX_DEV void integrate(Ctx& c, float dv0, float dv1) {
+AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
   float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
-  if (lane < c.nv) L[L_VEL + lane] += dv0;
-  if (lane + 64 < c.nv) L[L_VEL + lane + 64] += dv1;
+  L[L_VEL + lane] = gvel[lane] + dv0;
+  L[L_VEL + lane + 64] = gvel[lane + 64] + dv1;
   wave_sync();
   if (lane < n) { float qd = L[L_VEL + lane]; L[L_ST + c.s_qd + lane] = qd; L[L_ST + c.s_q + lane] += dt * qd; }
   if (lane < c.nfree) {
@@ -795,21 +804,6 @@ AGX_DEV void integrate(Ctx& c, float dv0, float dv1) {
     st3(L + L_ST + c.s_env + AGX_E_TARGET, mul(ldm3(h + 3), mk3(TKF(c, o), TKF(c, o + 1), TKF(c, o + 2))) + ld3(h));
   }
   wave_sync();
-}
-
-// one p.stepSimulation() (env.py:226) plus env.py:227-232
-AGX_DEV void substep(Ctx& c) {
-  long long t0 = c.timing ? wave_clock() : 0, t1;
-#define AGX_TICK(k) if (c.timing) { t1 = wave_clock(); c.tm[k] += t1 - t0; t0 = t1; }
-  kinematics(c); AGX_TICK(0)
-  aba_and_minv(c); AGX_TICK(1)
-  predict_velocities(c); AGX_TICK(2)
-  collide(c); AGX_TICK(3)
-  build_rows(c); AGX_TICK(4)
-  float dv0, dv1;
-  pgs(c, dv0, dv1); AGX_TICK(5)
-  integrate(c, dv0, dv1); AGX_TICK(6)
-#undef AGX_TICK
 }
 
 // ---- state load / store ---------------------------------------------------------------------------------
@@ -864,47 +858,107 @@ AGX_DEV void observe(const Ctx& c, float tool_force, float* gobs) {
   }
 }
 
-// mode 0: full env.step(); mode 1: `nsettle` physics substeps only (feeding.py:178-179); mode 2: observation only
-AGX_DEV void env_step(const uint32_t* blob, float* gstate, const float* gaction, float* gobs, float* greward, uint8_t* gdone,
-                      float* ginfo, float* gdebug, float* lds, int lane, int mode, int nsettle) {
+// ============================================================================================
+// Kernel bodies.  One env.step() = frame_skip x [build, solve] + finish:
+//   build  (register/LDS heavy, ~1/3 of the time): state -> kinematics, ABA + M^-1, predicted
+//          velocities, collision, constraint rows -> per-env scratch record (rows, v*, contacts)
+//   solve  (lean: ~64 VGPRs, 5 KB LDS -> many waves per SIMD): 50 PGS sweeps streaming the rows
+//          from L2, integration, mouth-target update -> state
+//   finish (once per step): forces, observation, food state machine, preferences, reward, done.
+// ============================================================================================
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; };
+AGX_DEV Scratch scratch_of(float* base) {
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META);
+  return s;
+}
+
+// build: `gaction` non-null on the first substep of an env.step() (take_step, env.py:174-222)
+AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gdebug, float* lds, int lane) {
   Ctx c; ctx_init(c, blob, lds, lane);
-  c.timing = gdebug != nullptr;
-  const long long t_begin = c.timing ? wave_clock() : 0;
+  c.timing = gdebug != nullptr; c.dbg = gdebug;
   float* L = c.lds; int* Li = c.ldsi;
   const int sw = c.bi[AGX_H_STATE_WORDS];
+  Scratch scr = scratch_of(gscratch);
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
   load_env(c, gstate, sw);
-  if (mode == 2) { kinematics(c); observe(c, 0.f, gobs); return; }
-  if (mode == 1) { for (int k = 0; k < nsettle; k++) substep(c); store_env(c, gstate, sw); return; }
-  const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP), act_dim = c.bi[AGX_H_ACT_DIM];
-  // take_step (env.py:174-222): clip, scale, 5x accumulate against the joint limits -> motor targets
-  if (lane == 0) Li[L_ST + c.s_env + AGX_E_ITERATION] += 1;
-  if (lane < c.ndof) {
-    const int d = lane, ai = RBI(c, d, AGX_R_ACT);
-    if (ai >= 0) {
-      float a = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
-      float qa = L[L_ST + c.s_q + d]; const float lo = RBF(c, d, AGX_R_LOWER), hi = RBF(c, d, AGX_R_UPPER);
-      for (int k = 0; k < nsub; k++) {
-        bool below = qa + a < lo, above = qa + a > hi;
-        if (below || above) a = 0.f;
-        if (below) qa = lo; if (above) qa = hi;
-        qa += a;
+  if (gaction) {
+    const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP);
+    // clip, scale, 5x accumulate against the joint limits -> motor targets (kept in the state record)
+    if (lane == 0) { Li[L_ST + c.s_env + AGX_E_ITERATION] += 1; ((int*)gstate)[c.s_env + AGX_E_ITERATION] = Li[L_ST + c.s_env + AGX_E_ITERATION]; }
+    if (lane < c.ndof) {
+      const int d = lane, ai = RBI(c, d, AGX_R_ACT);
+      if (ai >= 0) {
+        float a = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
+        float qa = L[L_ST + c.s_q + d]; const float lo = RBF(c, d, AGX_R_LOWER), hi = RBF(c, d, AGX_R_UPPER);
+        for (int k = 0; k < nsub; k++) {
+          bool below = qa + a < lo, above = qa + a > hi;
+          if (below || above) a = 0.f;
+          if (below) qa = lo; if (above) qa = hi;
+          qa += a;
+        }
+        L[L_ST + c.s_qt + d] = qa; gstate[c.s_qt + d] = qa;
       }
-      L[L_ST + c.s_qt + d] = qa;
     }
+    wave_sync();
   }
+  long long t0 = c.timing ? wave_clock() : 0, t1;
+#define AGX_TICK(k) if (c.timing) { t1 = wave_clock(); c.tm[k] += t1 - t0; t0 = t1; }
+  kinematics(c); AGX_TICK(0)
+  aba_and_minv(c); AGX_TICK(1)
+  predict_velocities(c); AGX_TICK(2)
+  collide(c); AGX_TICK(3)
+  build_rows(c); AGX_TICK(4)
+#undef AGX_TICK
+  // hand-over to the solve kernel
+  for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
+  for (int k = lane; k < c.ncon * CON_STRIDE; k += 64) scr.con[k] = L[L_CON + k];
+  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; }
+  if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
+    if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // [4..4+ndof) = qdd
+    for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = L[L_CON + q];
+    for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[16 + MAX_CON * CON_STRIDE + q] = L[L_MINV + q];
+    wave_sync();
+    for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = scr.hdr[q];
+    if (lane == 0) { for (int k = 0; k < 16; k++) if (k != 5 && k != 6 && k != 7) gdebug[DBG_TIME + k] = (float)c.tm[k]; }
+  }
+}
+
+// solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
+AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  const int sw = c.bi[AGX_H_STATE_WORDS];
+  Scratch scr = scratch_of(gscratch);
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC];
+  load_env(c, gstate, sw);
+  const long long t0 = gdebug ? wave_clock() : 0;
+  float dv0, dv1;
+  pgs(c, dv0, dv1);
+  const long long t1 = gdebug ? wave_clock() : 0;
+  integrate(c, scr.vel, dv0, dv1);
+  store_env(c, gstate, sw);
+  if (gdebug && lane == 0) { gdebug[DBG_TIME + 5] = (float)(t1 - t0); gdebug[DBG_TIME + 6] = (float)(wave_clock() - t1); }
+}
+
+AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  load_env(c, gstate, c.bi[AGX_H_STATE_WORDS]);
+  kinematics(c); observe(c, 0.f, gobs);
+}
+
+// finish: everything FeedingEnv.step does after take_step (feeding.py:17-43)
+AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+                        float* ginfo, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS], act_dim = c.bi[AGX_H_ACT_DIM];
+  Scratch scr = scratch_of(gscratch);
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.near_mask = scr.meta[META_NEAR];
+  load_env(c, gstate, sw);
+  for (int k = lane; k < c.ncon * CON_STRIDE; k += 64) L[L_CON + k] = scr.con[k];
   float an2 = 0.f;
   for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
   wave_sync();
-  for (int k = 0; k < nsub; k++) {
-    c.dbg = (k == 0) ? gdebug : nullptr;
-    substep(c);
-    if (gdebug && k == 0) {   // first-substep internals for the parity tests
-      if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // [4..4+ndof) = qdd of the first ABA
-      for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = L[L_CON + q];
-      for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[16 + MAX_CON * CON_STRIDE + q] = L[L_MINV + q];
-      for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = L[L_HDR + q];
-    }
-  }
   kinematics(c);   // poses as the getters of _get_obs see them after the last stepSimulation
   // get_total_force (feeding.py:45-48) from the last substep's contact impulses
   float rf = 0.f, tf = 0.f;
@@ -1011,7 +1065,6 @@ AGX_DEV void env_step(const uint32_t* blob, float* gstate, const float* gaction,
     }
   }
   store_env(c, gstate, sw);
-  if (gdebug && lane == 0) { for (int k = 0; k < 7; k++) gdebug[DBG_TIME + k] = (float)c.tm[k]; gdebug[DBG_TIME + 7] = (float)(wave_clock() - t_begin); for (int k = 8; k < 16; k++) gdebug[DBG_TIME + k] = (float)c.tm[k]; }
 }
 
 }  // namespace agx

@@ -1,29 +1,26 @@
-// Host harness that runs the product kernel source (csrc/agx_step.h) for ONE environment on the
+// Host harness that runs the product kernel sources (csrc/agx_step.h) for ONE environment on the
 // CPU wave emulator.  Built by tests/emu_lib.py into tests/emu/libagx_emu.so.  Test-only.
 #include "agx_wave.h"
 #include "agx_step.h"
+#include <functional>
 
 namespace emu { Wave* W = nullptr; }
 
-struct Args { const uint32_t* blob; float* state; const float* action; float* obs; float* reward; uint8_t* done; float* info; float* debug; float* lds; int mode, nsettle; };
-static Args g_args;
-
+static std::function<void(int)> g_body;
 static void fiber_entry() {
   const int lane = emu::W->cur;
-  agx::env_step(g_args.blob, g_args.state, g_args.action, g_args.obs, g_args.reward, g_args.done, g_args.info, g_args.debug, g_args.lds, lane, g_args.mode, g_args.nsettle);
+  g_body(lane);
   emu::W->done[lane] = true;
-  // a finished lane still has to take part in nothing: env_step ends uniformly for all lanes
   swapcontext(&emu::W->ctx[lane], &emu::W->main_ctx);
 }
-
-extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
-                           float* info, float* debug, int mode, int nsettle) {
+// one "kernel launch" of one workgroup: 64 fresh fibers, LDS filled with garbage (the GPU does not
+// clear LDS between workgroups, and nothing may rely on it)
+static int run_wave(float* lds, size_t lds_words, std::function<void(int)> body) {
   static emu::Wave wave;
   emu::W = &wave;
   memset(&wave, 0, sizeof wave);
-  static float lds[agx::LDS_WORDS];
-  memset(lds, 0, sizeof lds);
-  g_args = Args{blob, state, action, obs, reward, done, info, debug, lds, mode, nsettle};
+  for (size_t k = 0; k < lds_words; k++) { uint32_t g = 0x7fc00000u | (uint32_t)(k * 2654435761u >> 10); memcpy(&lds[k], &g, 4); }
+  g_body = body;
   const size_t STK = 1 << 20;
   for (int l = 0; l < 64; l++) {
     wave.stacks[l] = (char*)malloc(STK);
@@ -36,15 +33,30 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
     int remaining = 0; unsigned gen_before = wave.gen; int arrived_before = wave.arrived;
     for (int l = 0; l < 64; l++) if (!wave.done[l]) { remaining++; wave.cur = l; swapcontext(&wave.main_ctx, &wave.ctx[l]); }
     if (!remaining) break;
-    // progress check: a full sweep that neither completed a rendezvous nor finished a lane nor
-    // changed the arrival count means the lanes disagree on a collective (non-uniform control flow)
     int rem2 = 0; for (int l = 0; l < 64; l++) if (!wave.done[l]) rem2++;
-    if (wave.gen == gen_before && wave.arrived == arrived_before && rem2 == remaining && rem2 != 64 - 0 && wave.arrived != 0 && spins > 4) {
-      bool mixed = rem2 != 64 && rem2 != 0;
-      if (mixed) { fprintf(stderr, "agx_emu: lanes diverged around a collective (%d lanes finished early)\n", 64 - rem2); rc = -1; break; }
+    // a sweep without progress while some lanes have finished: the lanes disagree on a collective
+    if (wave.gen == gen_before && wave.arrived == arrived_before && rem2 == remaining && rem2 != 64 && spins > 4) {
+      fprintf(stderr, "agx_emu: lanes diverged around a collective (%d lanes finished early)\n", 64 - rem2); rc = -1; break;
     }
   }
   for (int l = 0; l < 64; l++) free(wave.stacks[l]);
+  return rc;
+}
+
+extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
+                           float* info, float* debug, int mode, int nsettle) {
+  static float lds[agx::LDS_WORDS];
+  static float scratch[agx::SCR_WORDS];
+  const int frame_skip = (int)((const float*)blob)[((const int*)blob)[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
+  int rc = 0;
+  if (mode == 2) return run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_observe(blob, state, obs, lds, lane); });
+  const int nsub = mode == 1 ? nsettle : frame_skip;
+  for (int k = 0; k < nsub && !rc; k++) {
+    const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (mode == 0 && k == 0) ? debug : nullptr;
+    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, dbg, lds, lane); });
+    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane); });
+  }
+  if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
   return rc;
 }
 extern "C" int agx_emu_lds_bytes() { return agx::LDS_BYTES; }
