@@ -407,15 +407,21 @@ AGX_DEV void collide(Ctx& c) {
   int maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (maxc > MAX_CON) maxc = MAX_CON;
   long long ct0 = c.timing ? wave_clock() : 0, ct1;
 #define AGX_CTICK(k) if (c.timing) { ct1 = wave_clock(); c.tm[k] += ct1 - ct0; ct0 = ct1; }
-  // 1. world AABBs
+  // 1. world AABBs, grown by the distance the collider can travel in this substep (speculative):
+  //    the broadphase margin then only has to cover the solver slack
   for (int col = lane; col < c.ncoll; col += 64) {
-    m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
+    const int code = CLI(c, col, AGX_C_BODY);
+    m3 R; v3 p; body_xf(c, code, R, p);
     v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
     v3 hl = mk3(CLF(c, col, AGX_C_AABB_H), CLF(c, col, AGX_C_AABB_H + 1), CLF(c, col, AGX_C_AABB_H + 2));
     v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
+    v3 vc = point_velocity(c, code, cw), w = mk3(0, 0, 0);
+    if (code >= 0 && code < AGX_BODY_ROBOT_BASE) { for (int d = code; d >= 0; d = RBI(c, d, AGX_R_PARENT)) w = w + L[L_VEL + d] * ld3(L + L_S + 6 * d); }
+    else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) w = ld3(L + L_VEL + c.ndof + 6 * (code - AGX_BODY_FREE0) + 3);
+    const float grow = (sqrtf(dot(vc, vc)) + sqrtf(dot(w, w)) * (sqrtf(dot(hl, hl)) + r)) * c.dt;
     for (int k = 0; k < 3; k++) {
       float h = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
-      AB[6 * col + k] = comp(cw, k) - h; AB[6 * col + 3 + k] = comp(cw, k) + h;
+      AB[6 * col + k] = comp(cw, k) - h - grow; AB[6 * col + 3 + k] = comp(cw, k) + h + grow;
     }
   }
   wave_sync();
@@ -426,6 +432,7 @@ AGX_DEV void collide(Ctx& c) {
     int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
     if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
     const bool same = GRI(c, g, AGX_G_FLAGS) & 1; const int keep = GRI(c, g, AGX_G_KEEP);
+    const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
     const int na = a1 - a0, nb = b1 - b0, npairs = na * nb;
     if (npairs <= 0) continue;
     // body-level cull
@@ -433,7 +440,7 @@ AGX_DEV void collide(Ctx& c) {
       float alo[3], ahi[3], blo[3], bhi[3];
       range_aabb(c, a0, a1, alo, ahi); range_aabb(c, b0, b1, blo, bhi);
       bool sep = false;
-      for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + brk || blo[k] > ahi[k] + brk) sep = true;
+      for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + mg || blo[k] > ahi[k] + mg) sep = true;
       AGX_CTICK(9)
       if (sep) continue;
     }
@@ -447,7 +454,7 @@ AGX_DEV void collide(Ctx& c) {
       const int p = base + lane; bool ok = p < bpairs;
       const int ai = ok ? p / nb : 0; const int a = ab + ai, b = b0 + (p - ai * nb);
       ok = ok && (!same || b > a);
-      if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + brk || AB[6 * b + q] > AB[6 * a + 3 + q] + brk) ok = false;
+      if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + mg || AB[6 * b + q] > AB[6 * a + 3 + q] + mg) ok = false;
       const uint64_t m = wave_ballot(ok);
       const int slot = wn + wave_rank(m);
       if (ok && slot < WL_MAX) WL[slot] = a | (b << 16);

@@ -333,18 +333,18 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     rg = sc.ranges
     groups = []
 
-    def grp(a, b, alt=None, same=False, keep=0):
+    def grp(a, b, alt=None, same=False, keep=0, manifold=False):
         a0, a1 = rg[a]
         b0, b1 = rg[b]
         b0f, b1f = rg[alt] if alt else (-1, -1)
         assert b1 - b0 <= 128 and (b1f - b0f) <= 128, 'B range must fit two wave-wide passes'
-        groups.append([a0, a1, b0, b1, b0f, b1f, 1 if same else 0, keep])
+        groups.append([a0, a1, b0, b1, b0f, b1f, (1 if same else 0) | (2 if manifold else 0), keep])
     # keep=K: a small sphere / hull touching a compound of many convex pieces produces one candidate
     # per piece inside the 2 cm manifold margin; only the K with the smallest predicted gap become
     # solver rows (a deliberate bound -- see DESIGN.md "contact budget")
     grp('food', 'tool', keep=4)
     grp('food', 'food', same=True)
-    grp('food', 'human_male', alt='human_female', keep=2)
+    grp('food', 'human_male', alt='human_female', keep=2, manifold=True)   # feeding.py:77 asks whether a manifold point exists
     grp('food', 'table')
     grp('food', 'plane')
     grp('food', 'bowl', keep=4)

@@ -115,7 +115,8 @@ enum {
   AGX_G_A0 = 0, AGX_G_A1 = 1,   /* collider range A [a0,a1)                                   */
   AGX_G_B0 = 2, AGX_G_B1 = 3,   /* collider range B (male human / default)                    */
   AGX_G_B0F = 4, AGX_G_B1F = 5, /* collider range B for a female human, -1 = same as default  */
-  AGX_G_FLAGS = 6,              /* bit0: A and B are the same range (i<j only)                */
+  AGX_G_FLAGS = 6,              /* bit0: A and B are the same range (i<j only); bit1: the task asks
+                                   whether a manifold point exists (broadphase margin = CONTACT_BREAK) */
   AGX_G_KEEP = 7,               /* per A collider keep only the KEEP contacts with the smallest
                                    predicted gap (0 = keep all)                               */
   AGX_G_STRIDE = 8

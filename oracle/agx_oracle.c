@@ -470,10 +470,10 @@ static int collider_world_verts(const sim_t* s, int c, const double* shift, doub
 }
 /* closest features of two colliders: returns 1 and fills the contact geometry when the separation
  * (radii included) is below `limit`. */
-static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* out) {
+static int narrowphase_ab(const sim_t* s, int ca, int cb, double limit, contact_t* out, const double* alo_in, const double* ahi_in) {
   const agxo_model* m = s->m;
   double va[3 * MAXV], vb[3 * MAXV], lo[3], hi[3], shift[3];
-  collider_aabb(s, ca, lo, hi);
+  if (alo_in) { memcpy(lo, alo_in, 24); memcpy(hi, ahi_in, 24); } else collider_aabb(s, ca, lo, hi);
   for (int k = 0; k < 3; k++) shift[k] = 0.5 * (lo[k] + hi[k]);
   int na = collider_world_verts(s, ca, shift, va), nb = collider_world_verts(s, cb, shift, vb);
   /* a large static world box (table top, ground) is replaced by its intersection with the other
@@ -481,7 +481,7 @@ static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* 
    * vertices stay near A so that single-precision GJK remains well conditioned */
   if (CI(m, cb, AGX_C_BODY) == AGX_BODY_WORLD && nb == 8 && (CI(m, cb, AGX_C_TAG) == AGX_TAG_TABLE || CI(m, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
     double blo[3], bhi[3], alo[3], ahi[3];
-    collider_aabb(s, cb, blo, bhi); collider_aabb(s, ca, alo, ahi);
+    collider_aabb(s, cb, blo, bhi); memcpy(alo, lo, 24); memcpy(ahi, hi, 24);
     for (int k = 0; k < 3; k++) {
       double lo2 = alo[k] - AGX_BOX_CLIP, hi2 = ahi[k] + AGX_BOX_CLIP;
       if (lo2 > blo[k]) blo[k] = lo2; if (hi2 < bhi[k]) bhi[k] = hi2;
@@ -520,6 +520,7 @@ static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* 
   out->lambda_n = 0;
   return 1;
 }
+static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* out);
 /* velocity of the material point of body `code` at world point x, from the generalized velocities s->vel */
 static void point_velocity(const sim_t* s, int code, const double* x, double* v) {
   const agxo_model* m = s->m;
@@ -533,27 +534,48 @@ static void point_velocity(const sim_t* s, int code, const double* x, double* v)
     sub3(x, s->fpos[b], r); cross3(s->vel + o + 3, r, wr); add3(s->vel + o, wr, v);
   }
 }
+static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* out) { return narrowphase_ab(s, ca, cb, limit, out, NULL, NULL); }
+/* speed bound of any material point of collider c under the predicted velocities: |v(centre)| + |w| * rho */
+static double collider_speed(const sim_t* s, int c) {
+  const agxo_model* m = s->m; int code = CI(m, c, AGX_C_BODY);
+  const xf_t* X = body_xf(s, code);
+  double cl[3] = {CF(m, c, AGX_C_AABB_C), CF(m, c, AGX_C_AABB_C + 1), CF(m, c, AGX_C_AABB_C + 2)};
+  double hl[3] = {CF(m, c, AGX_C_AABB_H), CF(m, c, AGX_C_AABB_H + 1), CF(m, c, AGX_C_AABB_H + 2)};
+  double cw[3], v[3], w[3] = {0, 0, 0}; xf_apply(X, cl, cw); point_velocity(s, code, cw, v);
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) { for (int d = code; d >= 0; d = RI(m, d, AGX_R_PARENT)) for (int k = 0; k < 3; k++) w[k] += s->S[d][k] * s->vel[d]; }
+  else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) { int b = code - AGX_BODY_FREE0; memcpy(w, s->vel + s->ndof + 6 * b + 3, 24); }
+  double rho = sqrt(dot3(hl, hl)) + CF(m, c, AGX_C_RADIUS);
+  return sqrt(dot3(v, v)) + sqrt(dot3(w, w)) * rho;
+}
 /* K2+K3: static pair table -> AABB cull -> GJK; contact order = (group, a, b) enumeration order */
 static void collide(sim_t* s) {
   const agxo_model* m = s->m;
   double brk = PARAM(m, AGX_P_CONTACT_BREAK);
   int maxc = (int)PARAM(m, AGX_P_MAX_CONTACTS); if (maxc > MAXC) maxc = MAXC;
   double lo[MAXCOLL][3], hi[MAXCOLL][3];
-  for (int c = 0; c < m->ncoll && c < MAXCOLL; c++) collider_aabb(s, c, lo[c], hi[c]);
+  double dt0 = PARAM(m, AGX_P_DT);
+  for (int c = 0; c < m->ncoll && c < MAXCOLL; c++) {
+    /* speculative AABB: grown by the distance the collider can travel in this substep, so the
+     * broadphase margin only has to cover the solver slack (pairs farther apart cannot yield a row) */
+    collider_aabb(s, c, lo[c], hi[c]);
+    double g = collider_speed(s, c) * dt0;
+    for (int k = 0; k < 3; k++) { lo[c][k] -= g; hi[c][k] += g; }
+  }
   s->ncon = 0; s->food_near_human = 0; s->contact_overflow = 0;
   double dt = PARAM(m, AGX_P_DT), slack = PARAM(m, AGX_P_CONTACT_SLACK);
   for (int g = 0; g < m->ngroup; g++) {
     int a0 = GI(m, g, AGX_G_A0), a1 = GI(m, g, AGX_G_A1), b0 = GI(m, g, AGX_G_B0), b1 = GI(m, g, AGX_G_B1);
     if (s->gender == 1 && GI(m, g, AGX_G_B0F) >= 0) { b0 = GI(m, g, AGX_G_B0F); b1 = GI(m, g, AGX_G_B1F); }
     int same = GI(m, g, AGX_G_FLAGS) & 1, keep = GI(m, g, AGX_G_KEEP);
+    const double mg = (GI(m, g, AGX_G_FLAGS) & 2) ? brk : slack;   /* bit1: getContactPoints-style existence query */
     for (int a = a0; a < a1; a++) {
       contact_t cand[128]; double gap[128]; int nc = 0;
       for (int b = (same ? a + 1 : b0); b < b1; b++) {
         int sep = 0;
-        for (int k = 0; k < 3; k++) if (lo[a][k] > hi[b][k] + brk || lo[b][k] > hi[a][k] + brk) sep = 1;
+        for (int k = 0; k < 3; k++) if (lo[a][k] > hi[b][k] + mg || lo[b][k] > hi[a][k] + mg) sep = 1;
         if (sep) continue;
         contact_t k;
-        if (!narrowphase(s, a, b, brk, &k)) continue;
+        if (!narrowphase_ab(s, a, b, brk, &k, lo[a], hi[a])) continue;
         /* a manifold point exists (what getContactPoints reports, agent.py:100-116) */
         if (CI(m, a, AGX_C_TAG) == AGX_TAG_FOOD && CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN)
           s->food_near_human |= 1 << (CI(m, a, AGX_C_BODY) - AGX_BODY_FREE0 - m->food0);
