@@ -6,6 +6,7 @@
 #include "../../include/agx.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -22,27 +23,27 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 // build: kinematics, ABA, collision, constraint rows -> scratch.  Register- and LDS-heavy.
 extern "C" __global__ void __launch_bounds__(64, 2)
-agx_build_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int n_envs, int sw, int act_dim) {
+agx_build_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int env0, int n_envs, int sw, int act_dim) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x;
+  const int env = env0 + blockIdx.x;
   if (env >= n_envs) return;
   agx::env_build(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
                  debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
 }
 // solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
 extern "C" __global__ void __launch_bounds__(64, 4)
-agx_solve_kernel(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int n_envs, int sw) {
+agx_solve_kernel(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x;
+  const int env = env0 + blockIdx.x;
   if (env >= n_envs) return;
   agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
 }
 // finish: forces, observation, food state machine, reward, done, info
 extern "C" __global__ void __launch_bounds__(64, 2)
 agx_finish_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
-                  float* info, int n_envs, int sw, int act_dim, int obs_dim) {
+                  float* info, int env0, int n_envs, int sw, int act_dim, int obs_dim) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x;
+  const int env = env0 + blockIdx.x;
   if (env >= n_envs) return;
   agx::env_finish(blob, state + (size_t)env * sw, actions + (size_t)env * act_dim, scratch + (size_t)env * agx::SCR_WORDS, obs + (size_t)env * obs_dim,
                   reward + env, done + env, info ? info + (size_t)env * AGX_INFO_DIM : nullptr, lds, (int)threadIdx.x);
@@ -93,6 +94,10 @@ struct agx_handle_s {
   // staging for the *_host convenience calls
   float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
   hipEvent_t ev0, ev1;
+  // The environments are stepped in AGX_CHUNKS independent chunks on internal streams: while one
+  // chunk is in its (latency-bound, lean) solve kernel another is in its (LDS/register-heavy) build
+  // kernel, so the two kernel types share the CUs instead of alternating.
+  int n_chunks; hipStream_t cs[8]; hipEvent_t fork_ev, join_ev[8];
 };
 
 extern "C" {
@@ -133,6 +138,13 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   HIPCHK(hipMalloc(&h->info_dev, (size_t)n_envs * AGX_INFO_DIM * 4));
   HIPCHK(hipMalloc(&h->done_dev, (size_t)n_envs));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+  {
+    const char* e = getenv("AGX_CHUNKS");
+    int nc = e ? atoi(e) : 1; if (nc < 1) nc = 1; if (nc > 8) nc = 8; if (n_envs < 64 * nc) nc = 1;
+    h->n_chunks = nc;
+    HIPCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    for (int k = 0; k < nc; k++) { HIPCHK(hipStreamCreateWithFlags(&h->cs[k], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming)); }
+  }
   HIPCHK(hipFuncSetAttribute((const void*)agx_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void*)agx_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void*)agx_observe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
@@ -146,6 +158,7 @@ void agx_destroy(agx_handle h) {
   hipFree(h->scratch_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
   hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  hipEventDestroy(h->fork_ev); for (int k = 0; k < h->n_chunks; k++) { hipStreamDestroy(h->cs[k]); hipEventDestroy(h->join_ev[k]); }
   delete h;
 }
 
@@ -170,28 +183,42 @@ int agx_get_state(agx_handle h, float* host_states) {
 }
 int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fail(AGX_E_ARG, "agx_state_dev: bad argument"); *out_dev = h->state_dev; return AGX_OK; }
 
-// one p.stepSimulation() for every environment: build + solve
-static int launch_substep(agx_handle h, const float* act, float* dbg, hipStream_t st) {
-  hipLaunchKernelGGL(agx_build_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, h->n_envs, h->sw, h->act_dim);
+// one p.stepSimulation() for the environments [e0, e0+ne): build + solve
+static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st) {
+  hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(agx_solve_kernel, dim3(h->n_envs), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, dbg, h->n_envs, h->sw);
+  hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw);
   HIPCHK(hipGetLastError());
+  return AGX_OK;
+}
+// fork the caller's stream into the chunk streams, run `n_substeps` (and optionally the finish
+// kernel) per chunk, join back.  Work of one chunk is ordered; chunks are independent.
+static int launch_chunked(agx_handle h, int n_substeps, const float* act, float* obs, float* rew, uint8_t* done, float* info, float* dbg, bool finish, void* stream) {
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t user = (hipStream_t)stream;
+  const int nc = h->n_chunks, per = (h->n_envs + nc - 1) / nc;
+  HIPCHK(hipEventRecord(h->fork_ev, user));
+  for (int c = 0; c < nc; c++) {
+    const int e0 = c * per, ne = (e0 + per <= h->n_envs ? per : h->n_envs - e0);
+    if (ne <= 0) continue;
+    hipStream_t st = nc == 1 ? user : h->cs[c];
+    if (nc > 1) HIPCHK(hipStreamWaitEvent(st, h->fork_ev, 0));
+    for (int k = 0; k < n_substeps; k++) { int rc = launch_substep(h, (k == 0) ? act : nullptr, (k == 0) ? dbg : nullptr, e0, ne, st); if (rc) return rc; }
+    if (finish) {
+      hipLaunchKernelGGL(agx_finish_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info,
+                         e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
+      HIPCHK(hipGetLastError());
+    }
+    if (nc > 1) { HIPCHK(hipEventRecord(h->join_ev[c], st)); HIPCHK(hipStreamWaitEvent(user, h->join_ev[c], 0)); }
+  }
   return AGX_OK;
 }
 static int launch_step(agx_handle h, const float* act, float* obs, float* rew, uint8_t* done, float* info, float* dbg, void* stream) {
-  HIPCHK(hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)stream;
-  for (int k = 0; k < h->frame_skip; k++) { int rc = launch_substep(h, k == 0 ? act : nullptr, k == 0 ? dbg : nullptr, st); if (rc) return rc; }
-  hipLaunchKernelGGL(agx_finish_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info,
-                     h->n_envs, h->sw, h->act_dim, h->obs_dim);
-  HIPCHK(hipGetLastError());
-  return AGX_OK;
+  return launch_chunked(h, h->frame_skip, act, obs, rew, done, info, dbg, true, stream);
 }
 int agx_settle(agx_handle h, int n_substeps, void* stream) {
   if (!h || n_substeps < 0) return fail(AGX_E_ARG, "agx_settle: bad argument");
-  HIPCHK(hipSetDevice(h->device));
-  for (int k = 0; k < n_substeps; k++) { int rc = launch_substep(h, nullptr, nullptr, (hipStream_t)stream); if (rc) return rc; }
-  return AGX_OK;
+  return launch_chunked(h, n_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
 }
 int agx_step(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, void* stream) {
   if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step: bad argument");

@@ -385,10 +385,11 @@ AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
 //      them, in order) become contacts.
 // The contact order (group, a, selection order) is what the oracle produces, so the solver rows
 // are identical.
-constexpr int WL_MAX = 192, CAND_STRIDE = 12;
-constexpr int A_WL = 6 * MAX_COLL;                      // int[WL_MAX]: a | b << 16
-constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, pb, n, dist
+constexpr int WL_MAX = 280, CAND_STRIDE = 8;
+constexpr int A_WL = 6 * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18
+constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, n, dist (pb = pa - dist n)
 static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
+static_assert(MAX_COLL <= 512, "collider indices are packed in 9 bits");
 
 AGX_DEV void range_aabb(const Ctx& c, int r0, int r1, float* lo, float* hi) {
   const float* AB = c.lds + L_ARENA;
@@ -398,13 +399,106 @@ AGX_DEV void range_aabb(const Ctx& c, int r0, int r1, float* lo, float* hi) {
 }
 AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
   const float* L = c.lds; const int pr = c.ldsi[L_ARENA + A_WL + idx]; const float* cd = L + L_ARENA + A_CAND + CAND_STRIDE * idx;
-  Cand k; k.gap = cd[0]; k.pa = ld3(cd + 1); k.pb = ld3(cd + 4); k.n = ld3(cd + 7); k.dist = cd[10];
-  emit_contact(c, slot, pr & 0xffff, pr >> 16, k);
+  Cand k; k.gap = cd[0]; k.pa = ld3(cd + 1); k.n = ld3(cd + 4); k.dist = cd[7]; k.pb = k.pa - k.dist * k.n;
+  emit_contact(c, slot, pr & 511, (pr >> 9) & 511, k);
 }
+struct CollideState { int ncon, near_mask, overflow, maxc; };
+
+// narrowphase + selection over the current worklist (entries of one or several whole groups, in
+// enumeration order); appends the resulting contacts
+AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float slack, int gender) {
+  float* L = c.lds; int* WL = c.ldsi + L_ARENA + A_WL; float* CD = L + L_ARENA + A_CAND; const int lane = c.lane;
+  const int food0 = c.bi[AGX_H_FOOD0];
+  if (wn == 0) return;
+  wave_sync();
+  long long ct0 = c.timing ? wave_clock() : 0;
+  if (c.timing) { c.tm[13] += wn; c.tm[14] += (wn + 63) / 64; }   // debug: narrowphase pairs / passes
+  // 3. narrowphase, 64 pairs per pass
+  bool any_manifold_query = false;
+  for (int base = 0; base < wn; base += 64) {
+    const int i = base + lane; const bool has = i < wn;
+    Cand k; k.gap = 3.0e38f; bool near = false; int a = 0, g = 0;
+    if (has) {
+      const int pr = WL[i]; a = pr & 511; const int b = (pr >> 9) & 511; g = pr >> 18;
+      if (narrowphase(c, a, b, brk, k)) {
+        near = true;
+        v3 vr = point_velocity(c, CLI(c, a, AGX_C_BODY), k.pa) - point_velocity(c, CLI(c, b, AGX_C_BODY), k.pb);
+        float pg = k.dist + dot(vr, k.n) * c.dt;
+        if (pg < slack) k.gap = pg;
+      }
+      float* cd = CD + CAND_STRIDE * i;
+      cd[0] = k.gap; st3(cd + 1, k.pa); st3(cd + 4, k.n); cd[7] = k.dist;
+    }
+    // a manifold point exists: what getContactPoints(food, human) reports (agent.py:100-116)
+    const bool mq = has && near && (GRI(c, g, AGX_G_FLAGS) & 2) && CLI(c, a, AGX_C_TAG) == AGX_TAG_FOOD;
+    if (wave_any(mq)) { any_manifold_query = true; for (int f = 0; f < c.nfood; f++) if (wave_any(mq && CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - food0 == f)) cs.near_mask |= 1 << f; }
+  }
+  (void)any_manifold_query;
+  wave_sync();
+  if (c.timing) { long long t = wave_clock(); c.tm[11] += t - ct0; ct0 = t; }
+  // 4. selection, one (group, A collider) segment at a time
+  int cur = 0;
+  while (cur < wn) {
+    const int key = WL[cur] & ~(511 << 9);            // group and A collider
+    const int g = key >> 18, keep = GRI(c, g, AGX_G_KEEP);
+    const int i0 = cur + lane, i1 = cur + 64 + lane;
+    const bool s0 = i0 < wn && (WL[i0 < wn ? i0 : 0] & ~(511 << 9)) == key, s1 = i1 < wn && (WL[i1 < wn ? i1 : 0] & ~(511 << 9)) == key;
+    const uint64_t b0 = wave_ballot(s0), b1 = wave_ballot(s1);
+    // segments are contiguous: the run of matching entries starting at cur
+    const int len0 = (~b0) ? ffs64(~b0) : 64;
+    const int len = len0 < 64 ? len0 : 64 + ((~b1) ? ffs64(~b1) : 64);
+    const bool in0 = lane < len, in1 = 64 + lane < len;
+    float g0 = in0 ? CD[CAND_STRIDE * i0] : 3.0e38f, g1 = in1 ? CD[CAND_STRIDE * i1] : 3.0e38f;
+    if (keep == 0) {   // keep everything, in enumeration order
+      for (int pass = 0; pass < 2; pass++) {
+        const bool has = (pass ? g1 : g0) < 1.0e38f;
+        const uint64_t m = wave_ballot(has);
+        int cnt = popc64(m); const int slot = cs.ncon + wave_rank(m);
+        if (has && slot < cs.maxc) emit_from_cand(c, slot, pass ? i1 : i0);
+        int room = cs.maxc - cs.ncon; if (room < 0) room = 0;
+        if (cnt > room) { cs.overflow += cnt - room; cnt = room; }
+        cs.ncon += cnt;
+      }
+    } else {           // the `keep` smallest predicted gaps, in selection order
+      for (int q = 0; q < keep; q++) {
+        const float mg = wave_min(fminf(g0, g1));
+        if (mg > 1.0e38f) break;
+        const uint64_t m0 = wave_ballot(g0 == mg);
+        int slot1 = 0, win;
+        if (m0) win = ffs64(m0); else { win = ffs64(wave_ballot(g1 == mg)); slot1 = 1; }
+        if (cs.ncon < cs.maxc) { if (lane == win) emit_from_cand(c, cs.ncon, slot1 ? i1 : i0); cs.ncon++; } else cs.overflow++;
+        if (lane == win) { if (slot1) g1 = 3.0e38f; else g0 = 3.0e38f; }
+      }
+    }
+    cur += len;
+  }
+  wave_sync();
+  if (c.timing) { long long t = wave_clock(); c.tm[12] += t - ct0; }
+}
+
+// broadphase sweep of A colliders [aa, ab) x B range of group g, appended to the worklist at wn.
+// returns the new count (may exceed WL_MAX: entries beyond it are not stored)
+AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool same, float mg, int wn) {
+  const float* AB = c.lds + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; const int lane = c.lane;
+  const int nb = b1 - b0, npairs = (ab - aa) * nb;
+  for (int base = 0; base < npairs; base += 64) {
+    const int p = base + lane; bool ok = p < npairs;
+    const int ai = ok ? p / nb : 0; const int a = aa + ai, b = b0 + (p - ai * nb);
+    ok = ok && (!same || b > a);
+    if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + mg || AB[6 * b + q] > AB[6 * a + 3 + q] + mg) ok = false;
+    const uint64_t m = wave_ballot(ok);
+    const int slot = wn + wave_rank(m);
+    if (ok && slot < WL_MAX) WL[slot] = a | (b << 9) | (g << 18);
+    wn += popc64(m);
+  }
+  return wn;
+}
+
 AGX_DEV void collide(Ctx& c) {
-  float* L = c.lds; float* AB = L + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; float* CD = L + L_ARENA + A_CAND; const int lane = c.lane;
+  float* L = c.lds; float* AB = L + L_ARENA; const int lane = c.lane;
   const float brk = PRM(c, AGX_P_CONTACT_BREAK), slack = PRM(c, AGX_P_CONTACT_SLACK);
-  int maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (maxc > MAX_CON) maxc = MAX_CON;
+  CollideState cs; cs.ncon = 0; cs.near_mask = 0; cs.overflow = 0;
+  cs.maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (cs.maxc > MAX_CON) cs.maxc = MAX_CON;
   long long ct0 = c.timing ? wave_clock() : 0, ct1;
 #define AGX_CTICK(k) if (c.timing) { ct1 = wave_clock(); c.tm[k] += ct1 - ct0; ct0 = ct1; }
   // 1. world AABBs, grown by the distance the collider can travel in this substep (speculative):
@@ -426,17 +520,16 @@ AGX_DEV void collide(Ctx& c) {
   }
   wave_sync();
   AGX_CTICK(8)
-  int ncon = 0, near_mask = 0, overflow = 0;
-  const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER], food0 = c.bi[AGX_H_FOOD0];
+  const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER];
+  int wn = 0;    // worklist fill; whole groups are accumulated and flushed together
   for (int g = 0; g < c.ngroup; g++) {
     int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
     if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
-    const bool same = GRI(c, g, AGX_G_FLAGS) & 1; const int keep = GRI(c, g, AGX_G_KEEP);
+    const bool same = GRI(c, g, AGX_G_FLAGS) & 1;
     const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
-    const int na = a1 - a0, nb = b1 - b0, npairs = na * nb;
-    if (npairs <= 0) continue;
-    // body-level cull
-    {
+    const int nb = b1 - b0;
+    if ((a1 - a0) * nb <= 0) continue;
+    {   // body-level cull
       float alo[3], ahi[3], blo[3], bhi[3];
       range_aabb(c, a0, a1, alo, ahi); range_aabb(c, b0, b1, blo, bhi);
       bool sep = false;
@@ -444,84 +537,32 @@ AGX_DEV void collide(Ctx& c) {
       AGX_CTICK(9)
       if (sep) continue;
     }
-    // the group is processed in batches of whole A colliders that cannot overflow the worklist
-    const int abatch = WL_MAX / nb > 0 ? WL_MAX / nb : 1;
-    for (int ab = a0; ab < a1; ab += abatch) {
-    const int bpairs = ((a1 - ab < abatch) ? a1 - ab : abatch) * nb;
-    // 2. broadphase sweep -> worklist
-    int wn = 0;
-    for (int base = 0; base < bpairs; base += 64) {
-      const int p = base + lane; bool ok = p < bpairs;
-      const int ai = ok ? p / nb : 0; const int a = ab + ai, b = b0 + (p - ai * nb);
-      ok = ok && (!same || b > a);
-      if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + mg || AB[6 * b + q] > AB[6 * a + 3 + q] + mg) ok = false;
-      const uint64_t m = wave_ballot(ok);
-      const int slot = wn + wave_rank(m);
-      if (ok && slot < WL_MAX) WL[slot] = a | (b << 16);
-      wn += popc64(m);
+    // 2. broadphase sweep of the whole group into the shared worklist
+    int wn2 = collide_sweep(c, g, a0, a1, b0, b1, same, mg, wn);
+    if (wn2 > WL_MAX) {
+      // does not fit behind the pending groups: flush them, then take this group alone, if necessary
+      // in batches of whole A colliders (a batch of WL_MAX / nb colliders cannot overflow)
+      AGX_CTICK(10)
+      collide_flush(c, wn, cs, brk, slack, gender); wn = 0;
+      ct0 = c.timing ? wave_clock() : 0;
+      wn2 = collide_sweep(c, g, a0, a1, b0, b1, same, mg, 0);
+      if (wn2 > WL_MAX) {
+        const int abatch = WL_MAX / nb > 0 ? WL_MAX / nb : 1;
+        for (int ab = a0; ab < a1; ab += abatch) {
+          int w3 = collide_sweep(c, g, ab, ab + abatch < a1 ? ab + abatch : a1, b0, b1, same, mg, 0);
+          if (w3 > WL_MAX) { cs.overflow += w3 - WL_MAX; w3 = WL_MAX; }
+          AGX_CTICK(10)
+          collide_flush(c, w3, cs, brk, slack, gender);
+          ct0 = c.timing ? wave_clock() : 0;
+        }
+        wn2 = 0;
+      }
     }
-    if (wn > WL_MAX) { overflow += wn - WL_MAX; wn = WL_MAX; }
+    wn = wn2;
     AGX_CTICK(10)
-    if (wn == 0) continue;
-    wave_sync();
-    // 3. narrowphase
-    const bool food_human = CLI(c, a0, AGX_C_TAG) == AGX_TAG_FOOD && CLI(c, b0, AGX_C_TAG) == AGX_TAG_HUMAN;
-    for (int base = 0; base < wn; base += 64) {
-      const int i = base + lane; const bool has = i < wn;
-      Cand k; k.gap = 3.0e38f; bool near = false; int a = 0;
-      if (has) {
-        const int pr = WL[i]; a = pr & 0xffff; const int b = pr >> 16;
-        if (narrowphase(c, a, b, brk, k)) {
-          near = true;
-          v3 vr = point_velocity(c, CLI(c, a, AGX_C_BODY), k.pa) - point_velocity(c, CLI(c, b, AGX_C_BODY), k.pb);
-          float pg = k.dist + dot(vr, k.n) * c.dt;
-          if (pg < slack) k.gap = pg;
-        }
-        float* cd = CD + CAND_STRIDE * i;
-        cd[0] = k.gap; st3(cd + 1, k.pa); st3(cd + 4, k.pb); st3(cd + 7, k.n); cd[10] = k.dist;
-      }
-      if (food_human) {   // a manifold point exists: what getContactPoints(food, human) reports (agent.py:100-116)
-        for (int f = 0; f < c.nfood; f++) if (wave_any(near && CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - food0 == f)) near_mask |= 1 << f;
-      }
-    }
-    wave_sync();
-    AGX_CTICK(11)
-    // 4. selection
-    if (keep == 0) {
-      for (int base = 0; base < wn; base += 64) {
-        const int i = base + lane; const bool has = i < wn && CD[CAND_STRIDE * i] < 1.0e38f;
-        const uint64_t m = wave_ballot(has);
-        int cnt = popc64(m); const int slot = ncon + wave_rank(m);
-        if (has && slot < maxc) emit_from_cand(c, slot, i);
-        int room = maxc - ncon; if (room < 0) room = 0;
-        if (cnt > room) { overflow += cnt - room; cnt = room; }
-        ncon += cnt;
-      }
-    } else {
-      int cur = 0;
-      while (cur < wn) {
-        const int a = WL[cur] & 0xffff;
-        const int i0 = cur + lane, i1 = cur + 64 + lane;
-        const bool s0 = i0 < wn && (WL[i0 < wn ? i0 : 0] & 0xffff) == a, s1 = i1 < wn && (WL[i1 < wn ? i1 : 0] & 0xffff) == a;
-        const int len = popc64(wave_ballot(s0)) + popc64(wave_ballot(s1));
-        float g0 = s0 ? CD[CAND_STRIDE * i0] : 3.0e38f, g1 = s1 ? CD[CAND_STRIDE * i1] : 3.0e38f;
-        for (int q = 0; q < keep; q++) {
-          const float mg = wave_min(fminf(g0, g1));
-          if (mg > 1.0e38f) break;
-          const uint64_t m0 = wave_ballot(g0 == mg);
-          int slot1 = 0, win;
-          if (m0) win = ffs64(m0); else { win = ffs64(wave_ballot(g1 == mg)); slot1 = 1; }
-          if (ncon < maxc) { if (lane == win) emit_from_cand(c, ncon, slot1 ? i1 : i0); ncon++; } else overflow++;
-          if (lane == win) { if (slot1) g1 = 3.0e38f; else g0 = 3.0e38f; }
-        }
-        cur += len;
-      }
-    }
-    wave_sync();
-    AGX_CTICK(12)
-    }   // A batches
   }
-  c.ncon = ncon; c.near_mask = near_mask; c.overflow = overflow;
+  collide_flush(c, wn, cs, brk, slack, gender);
+  c.ncon = cs.ncon; c.near_mask = cs.near_mask; c.overflow = cs.overflow;
   wave_sync();
 #undef AGX_CTICK
 }
@@ -895,15 +936,18 @@ AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction
     if (lane < c.ndof) {
       const int d = lane, ai = RBI(c, d, AGX_R_ACT);
       if (ai >= 0) {
-        float a = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
-        float qa = L[L_ST + c.s_q + d]; const float lo = RBF(c, d, AGX_R_LOWER), hi = RBF(c, d, AGX_R_UPPER);
+        // the limit test of take_step is discontinuous (an action that would cross a limit is zeroed,
+        // env.py:206-211); it is evaluated in double like the reference's numpy code so that a joint
+        // resting exactly on a limit takes the same branch
+        const float a32 = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
+        double a = (double)a32, qa = (double)L[L_ST + c.s_q + d]; const double lo = (double)RBF(c, d, AGX_R_LOWER), hi = (double)RBF(c, d, AGX_R_UPPER);
         for (int k = 0; k < nsub; k++) {
           bool below = qa + a < lo, above = qa + a > hi;
-          if (below || above) a = 0.f;
+          if (below || above) a = 0.0;
           if (below) qa = lo; if (above) qa = hi;
           qa += a;
         }
-        L[L_ST + c.s_qt + d] = qa; gstate[c.s_qt + d] = qa;
+        L[L_ST + c.s_qt + d] = (float)qa; gstate[c.s_qt + d] = (float)qa;
       }
     }
     wave_sync();

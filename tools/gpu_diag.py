@@ -61,4 +61,5 @@ for k, nm in enumerate(names):
     print('  %-16s %12.0f  (%.1f%%)' % (nm, tm[:, k].mean(), 100 * tm[:, k].mean() / tot))
 for k, nm in zip(range(8, 13), ['  collide: aabbs', '  collide: group cull', '  collide: broadphase sweep', '  collide: narrowphase (GJK)', '  collide: selection']):
     print('  %-28s %12.0f' % (nm, tm16[:, k].mean()))
+print('  narrowphase pairs per substep %.1f in %.1f passes' % (tm16[:, 13].mean(), tm16[:, 14].mean()))
 print('ncon mean %.1f rows mean %.1f' % (info[:, 6].mean(), info[:, 7].mean()))
