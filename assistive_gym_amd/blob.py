@@ -20,6 +20,7 @@ class ModelBlob:
         self.ndof, self.nfree, self.nhuman = self.h['NDOF'], self.h['NFREE'], self.h['NHUMAN']
         self.nfood, self.act_dim, self.obs_dim = self.h['NFOOD'], self.h['ACT_DIM'], self.h['OBS_DIM']
         self.state_words = self.h['STATE_WORDS']
+        self.nrobot, self.nhdof = self.h['NROBOT'], self.h['NHDOF']
 
     @classmethod
     def load(cls, name='feeding_jaco'):
@@ -38,12 +39,16 @@ class ModelBlob:
         w.view(np.float32)[self.h['OFF_PARAMS'] + L.P[key]] = value
         return ModelBlob(w, self.meta)
 
-    def robot_f(self, d, key, n=1):
-        o = self.h['OFF_ROBOT'] + d * L.R['STRIDE'] + L.R[key]
+    def rec(self, d, gender=0):
+        """link record index of DoF d (human DoFs have one record per gender)"""
+        return d if d < self.nrobot else d + gender * self.nhdof
+
+    def robot_f(self, d, key, n=1, gender=0):
+        o = self.h['OFF_ROBOT'] + self.rec(d, gender) * L.R['STRIDE'] + L.R[key]
         return self.f[o:o + n].astype(np.float64) if n > 1 else float(self.f[o])
 
-    def robot_i(self, d, key):
-        return int(self.i[self.h['OFF_ROBOT'] + d * L.R['STRIDE'] + L.R[key]])
+    def robot_i(self, d, key, gender=0):
+        return int(self.i[self.h['OFF_ROBOT'] + self.rec(d, gender) * L.R['STRIDE'] + L.R[key]])
 
     def free_f(self, b, key, n=1):
         o = self.h['OFF_FREE'] + b * L.F['STRIDE'] + L.F[key]
@@ -84,4 +89,7 @@ class ModelBlob:
             target=s[:, e + L.E['TARGET']:e + L.E['TARGET'] + 3],
             food_alive=si[:, e + L.E['FOOD_ALIVE']], food_active=si[:, e + L.E['FOOD_ACTIVE']],
             iteration=si[:, e + L.E['ITERATION']], task_success=si[:, e + L.E['TASK_SUCCESS']],
-            rng=si[:, e + L.E['RNG']:e + L.E['RNG'] + 2], total_food=si[:, e + L.E['TOTAL_FOOD']])
+            rng=si[:, e + L.E['RNG']:e + L.E['RNG'] + 2], total_food=si[:, e + L.E['TOTAL_FOOD']],
+            frozen=si[:, e + L.E['FROZEN']],
+            tremor=s[:, h['S_TREMOR']:h['S_TREMOR'] + self.nhdof],
+            tremor_target=s[:, h['S_TREMOR'] + self.nhdof:h['S_TREMOR'] + 2 * self.nhdof])

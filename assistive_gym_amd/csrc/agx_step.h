@@ -21,12 +21,12 @@
 
 namespace agx {
 
-constexpr int MAX_DOF = 12;
+constexpr int MAX_DOF = 16;
 constexpr int MAX_FREE = 10;
 constexpr int MAX_HUMAN = 20;
 constexpr int MAX_CON = 64;
 constexpr int MAX_ROWS = 160;
-constexpr int ST_WORDS = 320;
+constexpr int ST_WORDS = 336;
 constexpr int CON_STRIDE = 16;
 constexpr int HDR_STRIDE = 8;
 constexpr int ARENA_WORDS = 4096;
@@ -86,6 +86,7 @@ struct Ctx {
   float* lds; int* ldsi;
   int lane;
   int ndof, nfree, nhuman, ncoll, ngroup, nfood, nv;
+  int nrobot, nhdof, gender, frozen, s_tremor;   // articulated set: robot DoFs [0,nrobot), human DoFs [nrobot,ndof)
   int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
   int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
   float dt;
@@ -97,8 +98,10 @@ struct Ctx {
 };
 
 #define PRM(c, k) ((c).bf[(c).o_params + (k)])
-#define RBF(c, d, k) ((c).bf[(c).o_robot + (d) * AGX_R_STRIDE + (k)])
-#define RBI(c, d, k) ((c).bi[(c).o_robot + (d) * AGX_R_STRIDE + (k)])
+// link record of DoF d: human DoFs have one record per gender
+#define RREC(c, d) ((d) < (c).nrobot ? (d) : (d) + (c).gender * (c).nhdof)
+#define RBF(c, d, k) ((c).bf[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
+#define RBI(c, d, k) ((c).bi[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
 #define FBF(c, b, k) ((c).bf[(c).o_free + (b) * AGX_F_STRIDE + (k)])
 #define CLF(c, i, k) ((c).bf[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
 #define CLI(c, i, k) ((c).bi[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
@@ -114,7 +117,8 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.o_params = h[AGX_H_OFF_PARAMS]; c.o_robot = h[AGX_H_OFF_ROBOT]; c.o_free = h[AGX_H_OFF_FREE]; c.o_coll = h[AGX_H_OFF_COLL];
   c.o_vert = h[AGX_H_OFF_VERT]; c.o_group = h[AGX_H_OFF_GROUP]; c.o_task = h[AGX_H_OFF_TASK]; c.o_dirs = h[AGX_H_OFF_DIRS];
   c.s_q = h[AGX_H_S_Q]; c.s_qd = h[AGX_H_S_QD]; c.s_qt = h[AGX_H_S_QT]; c.s_free = h[AGX_H_S_FREE]; c.s_base = h[AGX_H_S_BASE];
-  c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV];
+  c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
+  c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0;
   c.dt = PRM(c, AGX_P_DT);
   c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
@@ -139,7 +143,8 @@ AGX_DEV void kinematics(Ctx& c) {
   for (int d = 0; d < n; d++) {
     int par = RBI(c, d, AGX_R_PARENT);
     v3 pp; m3 PR;
-    if (par < 0) { pp = ld3(L + L_BASE); PR = ldm3(L + L_BASE + 3); } else { pp = ld3(L + L_LINKP + 3 * par); PR = ldm3(L + L_LINKR + 9 * par); }
+    if (par == AGX_PARENT_HUMAN_BASE) { pp = ld3(L + L_HUMAN); PR = ldm3(L + L_HUMAN + 3); }
+    else if (par < 0) { pp = ld3(L + L_BASE); PR = ldm3(L + L_BASE + 3); } else { pp = ld3(L + L_LINKP + 3 * par); PR = ldm3(L + L_LINKR + 9 * par); }
     v3 tp = mk3(RBF(c, d, AGX_R_TPOS), RBF(c, d, AGX_R_TPOS + 1), RBF(c, d, AGX_R_TPOS + 2));
     m3 Rt = quat_to_m3(RBF(c, d, AGX_R_TQUAT), RBF(c, d, AGX_R_TQUAT + 1), RBF(c, d, AGX_R_TQUAT + 2), RBF(c, d, AGX_R_TQUAT + 3));
     v3 ax = mk3(RBF(c, d, AGX_R_AXIS), RBF(c, d, AGX_R_AXIS + 1), RBF(c, d, AGX_R_AXIS + 2));
@@ -206,7 +211,7 @@ AGX_DEV float skewc(v3 c, int i, int j) {   // [c]x entry (i,j)
 }
 AGX_DEV void aba_and_minv(Ctx& c) {
   float* L = c.lds; float* A = L + L_ARENA; const int lane = c.lane, n = c.ndof;
-  const float kl = PRM(c, AGX_P_LIN_DAMP), ka = PRM(c, AGX_P_ANG_DAMP), gz = PRM(c, AGX_P_ROBOT_GRAVITY_Z);
+  const float kl = PRM(c, AGX_P_LIN_DAMP), ka = PRM(c, AGX_P_ANG_DAMP);
   // spatial inertias -> IA (lanes = matrix entries), bias forces -> pA (lanes = links)
   if (lane < 36) {
     const int r = lane / 6, cc = lane % 6;
@@ -229,6 +234,7 @@ AGX_DEV void aba_and_minv(Ctx& c) {
     v3 pa_ang = cross(w, ha) + cross(vo, hl), pa_lin = cross(w, hl);
     // external force: gravity + velocity damping [BULLET-UNVERIFIED, see oracle]
     float sl = kl + kl * sqrtf(dot(vc, vc)), sa = ka + ka * sqrtf(dot(w, w));
+    const float gz = PRM(c, RBI(c, d, AGX_R_KIND) == 1 ? AGX_P_HUMAN_GRAVITY_Z : AGX_P_ROBOT_GRAVITY_Z);
     v3 f = mk3(0, 0, m * gz) - (m * sl) * vc;
     v3 tau = -(sa * mul(Iw, w));
     v3 fa = tau + cross(cw, f);
@@ -240,7 +246,7 @@ AGX_DEV void aba_and_minv(Ctx& c) {
     if (lane < 6) { float s = 0; for (int k = 0; k < 6; k++) s += A[A_IA + 36 * d + 6 * lane + k] * L[L_S + 6 * d + k]; A[A_U + 6 * d + lane] = s; }
     wave_sync();
     float D = dot6p(L + L_S + 6 * d, A + A_U + 6 * d);
-    float Dinv = D > 1e-30f ? 1.0f / D : 0.0f;
+    float Dinv = (D > 1e-30f && !(c.frozen >> d & 1)) ? 1.0f / D : 0.0f;   // frozen DoF: static link (mass 0, human.py:104-110)
     float u = -RBF(c, d, AGX_R_JDAMP) * L[L_ST + c.s_qd + d] - dot6p(L + L_S + 6 * d, A + A_PA + 6 * d);
     if (lane == 0) { A[A_DINV + d] = Dinv; A[A_UU + d] = u; }
     int par = RBI(c, d, AGX_R_PARENT);
@@ -480,11 +486,17 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
 // returns the new count (may exceed WL_MAX: entries beyond it are not stored)
 AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool same, float mg, int wn) {
   const float* AB = c.lds + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; const int lane = c.lane;
+  const bool no_adjacent = GRI(c, g, AGX_G_FLAGS) & 4;   // self-collision: not the same link, not parent and child
   const int nb = b1 - b0, npairs = (ab - aa) * nb;
   for (int base = 0; base < npairs; base += 64) {
     const int p = base + lane; bool ok = p < npairs;
     const int ai = ok ? p / nb : 0; const int a = aa + ai, b = b0 + (p - ai * nb);
     ok = ok && (!same || b > a);
+    if (ok && no_adjacent) {
+      const int la = CLI(c, a, AGX_C_BODY), lb = CLI(c, b, AGX_C_BODY);
+      if (la == lb) ok = false;
+      else if (la >= 0 && la < AGX_BODY_ROBOT_BASE && lb >= 0 && lb < AGX_BODY_ROBOT_BASE && (RBI(c, la, AGX_R_PARENT) == lb || RBI(c, lb, AGX_R_PARENT) == la)) ok = false;
+    }
     if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + mg || AB[6 * b + q] > AB[6 * a + 3 + q] + mg) ok = false;
     const uint64_t m = wave_ballot(ok);
     const int slot = wn + wave_rank(m);
@@ -584,13 +596,13 @@ AGX_DEV void add_jac(const Ctx& c, int code, v3 x, v3 f, v3 t, float sign, float
     Jf[0] += sign * f.x; Jf[1] += sign * f.y; Jf[2] += sign * f.z; Jf[3] += sign * ta.x; Jf[4] += sign * ta.y; Jf[5] += sign * ta.z;
   }
 }
-struct RowGeom { float Jr[MAX_DOF]; float Ja[6]; float Jb[6]; int fa, fb; bool robot; };   // fa/fb: free body index or -1
-AGX_DEV void row_clear(RowGeom& r) { for (int k = 0; k < MAX_DOF; k++) r.Jr[k] = 0.f; for (int k = 0; k < 6; k++) { r.Ja[k] = 0.f; r.Jb[k] = 0.f; } r.fa = -1; r.fb = -1; r.robot = false; }
+struct RowGeom { float Jr[MAX_DOF]; float Ja[6]; float Jb[6]; int fa, fb; bool robot, human; };   // fa/fb: free body index or -1; robot/human: articulated blocks touched
+AGX_DEV void row_clear(RowGeom& r) { for (int k = 0; k < MAX_DOF; k++) r.Jr[k] = 0.f; for (int k = 0; k < 6; k++) { r.Ja[k] = 0.f; r.Jb[k] = 0.f; } r.fa = -1; r.fb = -1; r.robot = false; r.human = false; }
 // force +f (torque +t) on body A at xa, -f (-t) on body B at xb
 AGX_DEV void row_pair(const Ctx& c, RowGeom& r, int codeA, v3 xa, int codeB, v3 xb, v3 f, v3 t) {
   row_clear(r);
-  if (codeA >= 0 && codeA < AGX_BODY_ROBOT_BASE) r.robot = true;
-  if (codeB >= 0 && codeB < AGX_BODY_ROBOT_BASE) r.robot = true;
+  if (codeA >= 0 && codeA < AGX_BODY_ROBOT_BASE) { if (codeA < c.nrobot) r.robot = true; else r.human = true; }
+  if (codeB >= 0 && codeB < AGX_BODY_ROBOT_BASE) { if (codeB < c.nrobot) r.robot = true; else r.human = true; }
   if (codeA >= AGX_BODY_FREE0 && codeA < AGX_BODY_HUMAN0) r.fa = codeA - AGX_BODY_FREE0;
   if (codeB >= AGX_BODY_FREE0 && codeB < AGX_BODY_HUMAN0) r.fb = codeB - AGX_BODY_FREE0;
   add_jac(c, codeA, xa, f, t, 1.f, r.Jr, r.Ja);
@@ -598,23 +610,30 @@ AGX_DEV void row_pair(const Ctx& c, RowGeom& r, int codeA, v3 xa, int codeB, v3 
 }
 AGX_DEV float row_velocity(const Ctx& c, const RowGeom& r) {
   const float* L = c.lds; float s = 0.f;
-  if (r.robot) { _Pragma("unroll") for (int d = 0; d < MAX_DOF; d++) if (d < c.ndof) s += r.Jr[d] * L[L_VEL + d]; }
+  if (r.robot || r.human) { _Pragma("unroll") for (int d = 0; d < MAX_DOF; d++) if (d < c.ndof) s += r.Jr[d] * L[L_VEL + d]; }
   if (r.fa >= 0) for (int k = 0; k < 6; k++) s += r.Ja[k] * L[L_VEL + c.ndof + 6 * r.fa + k];
   if (r.fb >= 0) for (int k = 0; k < 6; k++) s += r.Jb[k] * L[L_VEL + c.ndof + 6 * r.fb + k];
   return s;
 }
-AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { return (r.robot ? c.ndof : 0) + (r.fa >= 0 ? 6 : 0) + (r.fb >= 0 ? 6 : 0); }
+// articulated DoF range a row stores: the robot block, the human block, or both (contiguous)
+AGX_DEV void row_art_range(const Ctx& c, const RowGeom& r, int& lo, int& n) {
+  lo = r.robot ? 0 : c.nrobot;
+  n = (r.robot && r.human) ? c.ndof : (r.robot ? c.nrobot : (r.human ? c.nhdof : 0));
+}
+AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return n + (r.fa >= 0 ? 6 : 0) + (r.fb >= 0 ? 6 : 0); }
 // B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
 // A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
 AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float bterm, float lo, float hi, int fric_of, float mu) {
   float* L = c.lds; float* E = c.E + 2 * off; const int n = c.ndof;
   float D = 0.f; int e = 0;
   int a0 = 0, na = 0, b0 = 0, nb = 0;
-  if (r.robot) {
-    a0 = 0; na = n;
-    _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i < n) {
+  int alo, an; row_art_range(c, r, alo, an);
+  const bool art = an > 0;
+  if (art) {
+    a0 = alo; na = an;
+    _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i >= alo && i < alo + an) {
       float acc = 0.f;
-      _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j < n) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
+      _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
       E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
     }
   }
@@ -625,7 +644,7 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
     v3 Ba = mul(ldm3(L + L_FIINV + 9 * fb), mk3(J[3], J[4], J[5]));
     float B[6] = {im * J[0], im * J[1], im * J[2], Ba.x, Ba.y, Ba.z};
     int base = n + 6 * fb;
-    if (na == 0 && nb == 0 && !r.robot) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
+    if (na == 0 && nb == 0 && !art) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
   }
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
@@ -654,8 +673,8 @@ AGX_DEV void build_rows(Ctx& c) {
   bool active = false; float bterm = 0.f, lo = 0.f, hi = 0.f;
   if (lane < 16) {
     const int d = lane;
-    if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f) {
-      active = true; r.robot = true;
+    if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f && !(c.frozen >> d & 1)) {
+      active = true; if (d < c.nrobot) r.robot = true; else r.human = true;
       _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? 1.f : 0.f;
       // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
       bterm = RBF(c, d, AGX_R_KP) * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
@@ -663,11 +682,11 @@ AGX_DEV void build_rows(Ctx& c) {
     }
   } else if (lane < 48) {
     const int d = (lane - 16) >> 1, side = (lane - 16) & 1;
-    if (d < n && RBI(c, d, AGX_R_HAS_LIMIT)) {
+    if (d < n && RBI(c, d, AGX_R_HAS_LIMIT) && !(c.frozen >> d & 1)) {
       float q = L[L_ST + c.s_q + d];
       float gap = side == 0 ? q - RBF(c, d, AGX_R_LOWER) : RBF(c, d, AGX_R_UPPER) - q;
       if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
-        active = true; r.robot = true;
+        active = true; if (d < c.nrobot) r.robot = true; else r.human = true;
         const float sg = side == 0 ? 1.f : -1.f;
         _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? sg : 0.f;
         float rv = sg * L[L_VEL + d];
@@ -831,7 +850,16 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
   L[L_VEL + lane] = gvel[lane] + dv0;
   L[L_VEL + lane + 64] = gvel[lane + 64] + dv1;
   wave_sync();
-  if (lane < n) { float qd = L[L_VEL + lane]; L[L_ST + c.s_qd + lane] = qd; L[L_ST + c.s_q + lane] += dt * qd; }
+  if (lane < n) {
+    const int d = lane;
+    float qd = L[L_VEL + d], q = L[L_ST + c.s_q + d] + dt * qd;
+    // Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250)
+    if (RBI(c, d, AGX_R_KIND) == 1 && !(c.frozen >> d & 1)) {
+      const float lo = RBF(c, d, AGX_R_LOWER), hi = RBF(c, d, AGX_R_UPPER);
+      if (q < lo) { q = lo; qd = 0.f; } else if (q > hi) { q = hi; qd = 0.f; }
+    }
+    L[L_ST + c.s_qd + d] = qd; L[L_ST + c.s_q + d] = q;
+  }
   if (lane < c.nfree) {
     const int b = lane, o = n + 6 * b; float* r = L + L_ST + c.s_free + 13 * b;
     v3 v = ld3(L + L_VEL + o), w = ld3(L + L_VEL + o + 3);
@@ -845,11 +873,16 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
     float nn = 1.0f / sqrtf(x * x + y * y + z * z + w2 * w2);
     r[3] = x * nn; r[4] = y * nn; r[5] = z * nn; r[6] = w2 * nn;
   }
-  // FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset
-  if (lane == 0) {
-    const int hb = TKI(c, AGX_T_HEAD_BODY), o = c.ldsi[L_ST + c.s_env + AGX_E_GENDER] == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
-    const float* h = L + L_HUMAN + 12 * hb;
-    st3(L + L_ST + c.s_env + AGX_E_TARGET, mul(ldm3(h + 3), mk3(TKF(c, o), TKF(c, o + 1), TKF(c, o + 2))) + ld3(h));
+  wave_sync();
+}
+// FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset.  Needs the link
+// frames of a preceding kinematics(); the target is only consumed by the observation / reward code.
+AGX_DEV void update_target(Ctx& c) {
+  float* L = c.lds;
+  wave_sync();
+  if (c.lane == 0) {
+    const int hl = TKI(c, AGX_T_HEAD_LINK), o = c.gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
+    st3(L + L_ST + c.s_env + AGX_E_TARGET, mul(ldm3(L + L_LINKR + 9 * hl), mk3(TKF(c, o), TKF(c, o + 1), TKF(c, o + 2))) + ld3(L + L_LINKP + 3 * hl));
   }
   wave_sync();
 }
@@ -859,6 +892,7 @@ AGX_DEV void load_env(Ctx& c, const float* gstate, int sw) {
   float* L = c.lds; const int lane = c.lane;
   for (int k = lane; k < sw; k += 64) L[L_ST + k] = gstate[k];
   wave_sync();
+  c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
   if (lane == 0) { const float* r = L + L_ST + c.s_base; st3(L + L_BASE, ld3(r)); stm3(L + L_BASE + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
   if (lane < c.nhuman) { const float* r = L + L_ST + c.s_human + 7 * lane; float* h = L + L_HUMAN + 12 * lane; st3(h, ld3(r)); stm3(h + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
   if (lane < c.ndof) { int m = 0; for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) m |= 1 << d; c.ldsi[L_MISC + M_ANC + lane] = m; }
@@ -888,8 +922,8 @@ AGX_DEV void observe(const Ctx& c, float tool_force, float* gobs) {
   v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
   v3 sp; m3 sR; tool_base_pose(c, sp, sR);
   v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
-  const float* h = L + L_HUMAN + 12 * TKI(c, AGX_T_HEAD_BODY);
-  v3 hpr = tmul(BR, ld3(h) - bp); q4 hq = m3_to_quat(mul_at(BR, ldm3(h + 3)));
+  const int hl = TKI(c, AGX_T_HEAD_LINK);
+  v3 hpr = tmul(BR, ld3(L + L_LINKP + 3 * hl) - bp); q4 hq = m3_to_quat(mul_at(BR, ldm3(L + L_LINKR + 9 * hl)));
   v3 tpr = tmul(BR, ld3(L + L_ST + c.s_env + AGX_E_TARGET) - bp);
   if (c.lane == 0) {
     int o = 0;
@@ -932,7 +966,9 @@ AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction
   if (gaction) {
     const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP);
     // clip, scale, 5x accumulate against the joint limits -> motor targets (kept in the state record)
-    if (lane == 0) { Li[L_ST + c.s_env + AGX_E_ITERATION] += 1; ((int*)gstate)[c.s_env + AGX_E_ITERATION] = Li[L_ST + c.s_env + AGX_E_ITERATION]; }
+    const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION] + 1;       // env.py:185
+    wave_sync();
+    if (lane == 0) { Li[L_ST + c.s_env + AGX_E_ITERATION] = iteration; ((int*)gstate)[c.s_env + AGX_E_ITERATION] = iteration; }
     if (lane < c.ndof) {
       const int d = lane, ai = RBI(c, d, AGX_R_ACT);
       if (ai >= 0) {
@@ -948,6 +984,11 @@ AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction
           qa += a;
         }
         L[L_ST + c.s_qt + d] = (float)qa; gstate[c.s_qt + d] = (float)qa;
+      }
+      if (d >= c.nrobot) {   // tremor (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd)
+        const int k = d - c.nrobot;
+        const float qt = L[L_ST + c.s_tremor + c.nhdof + k] + L[L_ST + c.s_tremor + k] * ((iteration % 2 == 0) ? 1.f : -1.f);
+        L[L_ST + c.s_qt + d] = qt; gstate[c.s_qt + d] = qt;
       }
     }
     wave_sync();
@@ -994,7 +1035,7 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
 AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float* lds, int lane) {
   Ctx c; ctx_init(c, blob, lds, lane);
   load_env(c, gstate, c.bi[AGX_H_STATE_WORDS]);
-  kinematics(c); observe(c, 0.f, gobs);
+  kinematics(c); update_target(c); observe(c, 0.f, gobs);
 }
 
 // finish: everything FeedingEnv.step does after take_step (feeding.py:17-43)
@@ -1011,6 +1052,7 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
   for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
   wave_sync();
   kinematics(c);   // poses as the getters of _get_obs see them after the last stepSimulation
+  update_target(c);
   // get_total_force (feeding.py:45-48) from the last substep's contact impulses
   float rf = 0.f, tf = 0.f;
   if (lane < c.ncon) {

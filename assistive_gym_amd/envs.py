@@ -102,7 +102,7 @@ class FeedingJacoEnv(_Base):
         state = self.blob.new_state(1)
         self._episode += 1
         self.reset_info = {}
-        self._reset_helper.sample(self.np_random, state, env_seed=self._episode, info=self.reset_info, impairment='no_tremor')
+        self._reset_helper.sample(self.np_random, state, env_seed=self._episode, info=self.reset_info, impairment='random')
         st.set_state(state)
         st.settle(SETTLE_STEPS)
         self.iteration, self.task_success = 0, 0

@@ -11,7 +11,7 @@ from ..model import xform as X
 class RobotKin:
     def __init__(self, blob):
         self.blob = blob
-        n = blob.ndof
+        n = blob.nrobot          # the robot's DoFs only (the human head chain is not part of the IK)
         self.n = n
         self.parent = [blob.robot_i(d, 'PARENT') for d in range(n)]
         self.tpos = [blob.robot_f(d, 'TPOS', 3) for d in range(n)]

@@ -30,6 +30,7 @@ class FeedingJacoReset:
         self.base_pos = np.array(blob.meta.get('robot_base_pos', [-0.35, -0.3, 0.36]), dtype=np.float64)
         self.base_quat = np.array(blob.meta.get('robot_base_quat', X.quat_from_rpy([0, 0, -np.pi / 2]).tolist()))
         self.human_bodies = blob.meta.get('human_bodies')
+        self.human_dyn = blob.meta.get('human_dynamic_joints', [20, 21, 22, 23])
         self.toc_ee_orient = X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0])     # jaco.py:43
         self._hm_cache = {}
 
@@ -72,10 +73,8 @@ class FeedingJacoReset:
                 v['human'][0, k, :3], v['human'][0, k, 3:] = hbase, [0, 0, 0, 1]
             else:
                 v['human'][0, k, :3], v['human'][0, k, 3:] = hpos[link], hquat[link]
-        head_k = b.task_i('HEAD_BODY')
         mouth = b.task_f('MOUTH_M' if gender == 'male' else 'MOUTH_F', 3)
-        target, _ = X.compose(v['human'][0, head_k, :3].astype(np.float64), v['human'][0, head_k, 3:].astype(np.float64),
-                              mouth, np.array([0, 0, 0, 1.0]))                     # feeding.py:184-196
+        target, _ = X.compose(hpos[23], hquat[23], mouth, np.array([0, 0, 0, 1.0]))   # feeding.py:184-196
         # robot start pose: IK with random restarts towards a point in front of the person
         target_ee_pos = np.array([-0.15, -0.65, 1.15]) + rng.uniform(-0.05, 0.05, size=3)      # feeding.py:139
         q = np.clip(np.zeros(kin.n), kin.lower, kin.upper)                         # Agent.init -> enforce_joint_limits
@@ -104,9 +103,17 @@ class FeedingJacoReset:
         for d in range(kin.n):                                                     # gripper, feeding.py:144 (set instantly)
             if kin.act[d] < 0:
                 q[d] = min(max(b.robot_f(d, 'QT0'), kin.lower[d]), kin.upper[d])
-        v['q'][0] = q
+        nr = b.nrobot
+        v['q'][0, :nr] = q
         v['qd'][0] = 0
-        v['qt'][0] = q            # motors hold the start pose until the first action (see module docstring)
+        v['qt'][0, :nr] = q       # motors hold the start pose until the first action (see module docstring)
+        # human head joints: dynamic links, frozen (mass 0, human.py:104-110) unless the impairment is tremor
+        hq_dyn = np.array([hq[j] for j in self.human_dyn])
+        v['q'][0, nr:] = hq_dyn
+        v['qt'][0, nr:] = hq_dyn
+        v['tremor'][0] = tremors
+        v['tremor_target'][0] = hq_dyn                                             # human.py:123 target_joint_angles
+        v['frozen'][0] = 0 if impairment == 'tremor' else (((1 << b.nhdof) - 1) << nr)
         v['base'][0, :3], v['base'][0, 3:] = self.base_pos, self.base_quat
         # tool in the gripper (tool.py:49-62)
         tp, tq = kin.tool_pose(self.base_pos, self.base_quat, q)
@@ -143,7 +150,7 @@ class FeedingJacoReset:
         return state_row
 
 
-def make_states(blob, n, seed=1001, impairment='no_tremor', **kw):
+def make_states(blob, n, seed=1001, impairment='random', **kw):
     """n independent post-reset (pre-settle) states; env i uses RandomState(seed + i)."""
     rs = FeedingJacoReset(blob)
     st = blob.new_state(n)

@@ -31,24 +31,26 @@ from .urdf import Urdf
 H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT=7, NGROUP=8, NFOOD=9, ACT_DIM=10,
          OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
          STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
-         NDIR=29, OFF_DIRS=30, OFF_VERT4=31, COUNT=40)
+         NDIR=29, OFF_DIRS=30, OFF_VERT4=31, NROBOT=32, NHDOF=33, S_TREMOR=34, COUNT=40)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
          HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, COUNT=24)
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, COM=11, MASS=14, INERTIA=15, LOWER=21, UPPER=22, HAS_LIMIT=23, KP=24, KD=25,
-         MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, STRIDE=32)
+         MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, STRIDE=32)
 F = dict(MASS=0, INERTIA=1, GRAVITY=4, REFPOS=5, REFQUAT=8, KIND=12, RADIUS=13, STRIDE=16)
 C = dict(BODY=0, NVERT=1, VOFF=2, RADIUS=3, FRICTION=4, TAG=5, AABB_C=6, AABB_H=9, STRIDE=12)
 G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
 T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV=7, SUCCESS_FRAC=8, MOUTH_DIST=9,
-         SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_BODY=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
+         SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
          TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COUNT=40)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
-         TOTAL_FOOD=11, COUNT=16)
+         TOTAL_FOOD=11, FROZEN=12, COUNT=16)
 BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
+PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
+HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8)
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 4
+MAGIC, VERSION = 0x31584741, 5
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -294,28 +296,62 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
         sc.add(BODY_FREE0 + 2 + k, np.zeros((1, 3)), food_r, DEFAULT_FRICTION, TAG['FOOD'])
     sc.end('food')
     # ------------------------------------------------------------------ human (male / female variants)
+    # Links of the head joints (human.head_joints = 20..23, agents/human.py:9) are moving links of the
+    # articulated set (DoFs ndof_robot..ndof_robot+3): they are dynamic when the impairment is tremor
+    # (human.py:108: every other link gets mass 0) and frozen per environment otherwise.  All other
+    # human links are static collision bodies with a per-env world transform.
+    nrobot = ndof
+    hd = HUMAN_DYNAMIC_JOINTS
+    nhdof = len(hd)
     human_bodies = None
-    head_body = None
+    human_link_rec = {}
     for gender in ('male', 'female'):
         hm = HumanModel(gender)
         cols = hm.colliders()
-        links = [c[0] for c in cols]
+        static_links = [c[0] for c in cols if c[0] not in hd]
+        static_links = sorted(set(static_links), key=lambda l: (l != -1, l))
         if human_bodies is None:
-            human_bodies = links
-            head_body = links.index(23)
-        assert links == human_bodies
+            human_bodies = static_links
+        assert static_links == human_bodies
         sc.begin('human_' + gender)
-        for k, (link, kind, data) in enumerate(cols):
-            body = BODY_HUMAN0 + k
+        link_hulls = {j: [] for j in hd}
+        for (link, kind, data) in cols:
+            body = nrobot + hd.index(link) if link in hd else BODY_HUMAN0 + human_bodies.index(link)
+            shapes = []
             if kind == 'capsule':
-                sc.add(body, np.stack([data[0], data[1]]), data[2], DEFAULT_FRICTION, TAG['HUMAN'])
+                shapes.append((np.stack([data[0], data[1]]), data[2]))
             elif kind == 'sphere':
-                sc.add(body, data[0][None], data[1], DEFAULT_FRICTION, TAG['HUMAN'])
+                shapes.append((data[0][None], data[1]))
             elif kind == 'head':
                 fn, fpos, fquat, scale = data
                 for g in load_obj_groups(os.path.join(assets, fn), scale):
-                    sc.add(body, X.apply(fpos, fquat, convex_hull_vertices(g)), HULL_MARGIN, DEFAULT_FRICTION, TAG['HUMAN'])
+                    shapes.append((X.apply(fpos, fquat, convex_hull_vertices(g)), HULL_MARGIN))
+            for verts, radius in shapes:
+                sc.add(body, verts, radius, DEFAULT_FRICTION, TAG['HUMAN'])
+                if link in hd:
+                    link_hulls[link].append((verts, radius))
         sc.end('human_' + gender)
+        # link records of the dynamic joints (createMultiBody: link frame = joint frame = inertial frame,
+        # human_creation.py:193-195); inertia = box inertia of the collision AABB [BULLET-UNVERIFIED]
+        recs = np.zeros((nhdof, R['STRIDE']))
+        ints = []
+        for k, j in enumerate(hd):
+            par = hm.parent[j]
+            recs[k, R['TPOS']:R['TPOS'] + 3] = hm.offset[j]
+            recs[k, R['TQUAT']:R['TQUAT'] + 4] = [0, 0, 0, 1]
+            recs[k, R['AXIS']:R['AXIS'] + 3] = hm.axis[j]
+            recs[k, R['MASS']] = hm.mass[j]
+            if link_hulls[j] and hm.mass[j] > 0:
+                lo = np.min([v.min(0) - r for v, r in link_hulls[j]], axis=0)
+                hi = np.max([v.max(0) + r for v, r in link_hulls[j]], axis=0)
+                recs[k, R['INERTIA']:R['INERTIA'] + 3] = box_inertia(hm.mass[j], lo, hi)
+            recs[k, R['LOWER']], recs[k, R['UPPER']] = hm.lower[j], hm.upper[j]
+            recs[k, R['KP']], recs[k, R['KD']], recs[k, R['MAXF']] = 0.025, 1.0, 1.0      # feeding.py:122, human.py:69
+            ints.append(dict(PARENT=PARENT_HUMAN_BASE if par < 0 else nrobot + hd.index(par), HAS_LIMIT=1, ACT=-1, PB_INDEX=j, KIND=1))
+            assert par < 0 or par in hd
+        human_link_rec[gender] = (recs, ints)
+    ndof = nrobot + nhdof
+    head_link = nrobot + hd.index(23)
     # ------------------------------------------------------------------ static world
     sc.begin('table')   # furniture.py:31, assets/table/table_tall.urdf:22-27, lateral friction 1.0
     sc.add(BODY_WORLD, box_verts(np.array([0.25, -1.0, 0.0]) + [0, 0, 0.7], [0.75, 0.5, 0.025]), 0.0, 1.0, TAG['TABLE'])
@@ -330,15 +366,15 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
         sc.add(BODY_WORLD, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['WHEELCHAIR'])
     sc.end('wheelchair')
     # ------------------------------------------------------------------ pair groups
-    rg = sc.ranges
+    rg = dict(sc.ranges)
     groups = []
 
-    def grp(a, b, alt=None, same=False, keep=0, manifold=False):
+    def grp(a, b, alt=None, same=False, keep=0, manifold=False, no_adjacent=False):
         a0, a1 = rg[a]
         b0, b1 = rg[b]
         b0f, b1f = rg[alt] if alt else (-1, -1)
         assert b1 - b0 <= 128 and (b1f - b0f) <= 128, 'B range must fit two wave-wide passes'
-        groups.append([a0, a1, b0, b1, b0f, b1f, (1 if same else 0) | (2 if manifold else 0), keep])
+        groups.append([a0, a1, b0, b1, b0f, b1f, (1 if same else 0) | (2 if manifold else 0) | (4 if no_adjacent else 0), keep])
     # keep=K: a small sphere / hull touching a compound of many convex pieces produces one candidate
     # per piece inside the 2 cm manifold margin; only the K with the smallest predicted gap become
     # solver rows (a deliberate bound -- see DESIGN.md "contact budget")
@@ -363,6 +399,17 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     grp('robot_gripper', 'bowl')
     grp('bowl', 'table')
     grp('bowl', 'plane')
+    # URDF_USE_SELF_COLLISION (jaco.py:53): every robot link pair except same link / parent-child
+    rg['robot_links'] = (rg['robot_arm'][0], rg['robot_gripper'][1])
+    grp('robot_links', 'robot_links', same=True, no_adjacent=True)
+    grp('robot_arm', 'wheelchair')
+    grp('robot_gripper', 'wheelchair')
+    grp('robot_arm', 'plane')
+    grp('robot_gripper', 'plane')
+    grp('tool', 'wheelchair')
+    grp('tool', 'plane')
+    grp('bowl', 'human_male', alt='human_female', keep=1)
+    grp('bowl', 'wheelchair')
     # ------------------------------------------------------------------ pack
     ncoll = len(sc.colliders)
     verts = np.concatenate([c['verts'] for c in sc.colliders])
@@ -372,7 +419,8 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     dirs = icosphere42()
     off = {}
     cur = H['COUNT']
-    for name, size in (('PARAMS', P['COUNT']), ('ROBOT', ndof * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
+    nrec = nrobot + 2 * nhdof
+    for name, size in (('PARAMS', P['COUNT']), ('ROBOT', nrec * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
                        ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
                        ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('VERT4', 4 * len(verts))):
         if name == 'VERT4':
@@ -386,14 +434,15 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     s_free = 3 * ndof
     s_base = s_free + 13 * nfree
     s_human = s_base + 7
-    s_env = s_human + 7 * nhuman
+    s_tremor = s_human + 7 * nhuman
+    s_env = s_tremor + 2 * nhdof
     state_words = s_env + E['COUNT']
     hdr = dict(MAGIC=MAGIC, VERSION=VERSION, NWORDS=nwords, NDOF=ndof, NFREE=nfree, NHUMAN=nhuman, NCOLL=ncoll,
                NVERT=len(verts), NGROUP=len(groups), NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=25, OFF_PARAMS=off['PARAMS'],
                OFF_ROBOT=off['ROBOT'], OFF_FREE=off['FREE'], OFF_COLL=off['COLL'], OFF_VERT=off['VERT'],
                OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
                S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, FOOD0=2, TOOL_BODY=0, NDIR=len(dirs),
-               OFF_DIRS=off['DIRS'], OFF_VERT4=off['VERT4'])
+               OFF_DIRS=off['DIRS'], OFF_VERT4=off['VERT4'], NROBOT=nrobot, NHDOF=nhdof, S_TREMOR=s_tremor)
     for k, v in hdr.items():
         i[H[k]] = v
     p = f[off['PARAMS']:off['PARAMS'] + P['COUNT']]
@@ -417,11 +466,19 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     p[P['HUMAN_GRAVITY_Z']] = 0.0      # feeding.py:152
     p[P['CONTACT_SLACK']] = 0.001
     p[P['MAX_ENTRIES']] = 2040
-    for d in range(ndof):
+    for d in range(nrobot):
         base = off['ROBOT'] + d * R['STRIDE']
         f[base:base + R['STRIDE']] = rob['rec'][d]
         for k, v in rob['rec_int'][d].items():
             i[base + R[k]] = v
+        i[base + R['KIND']] = 0
+    for gi, gender in enumerate(('male', 'female')):
+        recs, ints = human_link_rec[gender]
+        for k in range(nhdof):
+            base = off['ROBOT'] + (nrobot + gi * nhdof + k) * R['STRIDE']
+            f[base:base + R['STRIDE']] = recs[k]
+            for key, v in ints[k].items():
+                i[base + R[key]] = v
     for k, b in enumerate(free):
         base = off['FREE'] + k * F['STRIDE']
         f[base + F['MASS']] = b['mass']
@@ -458,10 +515,11 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     t[T['MOUTH_DIST']], t[T['SPILL_DIST']] = 0.03, 0.1
     t[T['MOUTH_M']:T['MOUTH_M'] + 3] = [0, -0.11, 0.03]                               # feeding.py:186
     t[T['MOUTH_F']:T['MOUTH_F'] + 3] = [0, -0.1, 0.03]
-    ti[T['HEAD_BODY']] = head_body
+    ti[T['HEAD_LINK']] = head_link
     # end effector = PyBullet link 8 (jaco.py:11), carried by the moving link of joint 7
     ee_pb = 8
     ti[T['EE_LINK']] = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    assert ti[T['EE_LINK']] < nrobot
     t[T['EE_POS']:T['EE_POS'] + 3] = rob['rel'][ee_pb][0]
     t[T['EE_QUAT']:T['EE_QUAT'] + 4] = rob['rel'][ee_pb][1]
     t[T['TOOL_POS']:T['TOOL_POS'] + 3] = [0.1, -0.0225, 0.03]                          # jaco.py:26
@@ -469,7 +527,7 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     t[T['TOOL_MAXF']] = 500.0                                                           # tool.py:47
     t[T['EPISODE_LEN']] = 200
     meta = dict(header=hdr, ranges={k: tuple(v) for k, v in sc.ranges.items()}, human_bodies=human_bodies,
-                head_body=head_body, dof_links=rob['dof_links'], n_groups=len(groups), offsets=off,
+                head_link=int(head_link), human_dynamic_joints=hd, nrobot=nrobot, dof_links=rob['dof_links'], n_groups=len(groups), offsets=off,
                 robot_base_pos=[-0.35, -0.3, 0.36], robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist())
     return f.view(np.uint32).copy(), meta
 

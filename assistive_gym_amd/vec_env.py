@@ -15,7 +15,7 @@ from .shard import pool_indices
 SETTLE_STEPS = 25   # feeding.py:178-179
 
 
-def build_reset_pool(blob, pool_size, seed, device=0, impairment='no_tremor'):
+def build_reset_pool(blob, pool_size, seed, device=0, impairment='random'):
     """pool_size post-reset states: host-side sampling + IK (host/reset.py), then the 25 settle
     steps of feeding.py:178-179 on the device.  Returns a float32 (pool_size, state_words) array."""
     states, _ = make_states(blob, pool_size, seed=seed, impairment=impairment)
@@ -29,7 +29,7 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='no_tremor'):
 
 
 class FeedingJacoVecEnv:
-    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='no_tremor', auto_reset=True):
+    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True):
         self.blob = blob or ModelBlob.load('feeding_jaco')
         self.n_envs, self.device_index, self.seed = n_envs, device, seed
         self.device = torch.device('cuda', device)

@@ -14,13 +14,14 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 4
+#define AGX_BLOB_VERSION 5
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
 
 /* ---- header: int32[AGX_H_COUNT] at word 0 ------------------------------------------------ */
 enum {
   AGX_H_MAGIC = 0, AGX_H_VERSION, AGX_H_NWORDS,
-  AGX_H_NDOF,      /* robot 1-DoF moving links (fixed links merged into parents)            */
+  AGX_H_NDOF,      /* 1-DoF moving links of all articulated bodies: robot (fixed links merged into
+                      their parents) followed by the human joints that can be dynamic              */
   AGX_H_NFREE,     /* free rigid bodies (tool, bowl, food particles)                         */
   AGX_H_NHUMAN,    /* human collision bodies with a per-env world transform                  */
   AGX_H_NCOLL, AGX_H_NVERT, AGX_H_NGROUP,
@@ -34,6 +35,9 @@ enum {
   AGX_H_NDIR,         /* number of penetration-sampling directions (stored after the verts)  */
   AGX_H_OFF_DIRS,
   AGX_H_OFF_VERT4,    /* the same vertices padded to float[4] (16-byte aligned) for 128-bit loads        */
+  AGX_H_NROBOT,       /* DoFs [0, NROBOT) belong to the robot, [NROBOT, NDOF) to the human                */
+  AGX_H_NHDOF,        /* human DoFs; their link records exist per gender: record = dof + gender * NHDOF   */
+  AGX_H_S_TREMOR,     /* state: float[NHDOF] tremor amplitude, float[NHDOF] tremor-free target (human.py:89-92) */
   AGX_H_COUNT = 40
 };
 
@@ -62,7 +66,7 @@ enum {
 
 /* ---- ROBOT: one record per moving link, stride AGX_R_STRIDE ------------------------------- */
 enum {
-  AGX_R_PARENT = 0,      /* int: parent moving link, -1 = robot base                          */
+  AGX_R_PARENT = 0,      /* int: parent moving link, -1 = robot base, -2 = human base (chest)    */
   AGX_R_TPOS = 1,        /* float[3] parent-link frame -> joint frame (q = 0)                 */
   AGX_R_TQUAT = 4,       /* float[4] (x,y,z,w)                                                */
   AGX_R_AXIS = 8,        /* float[3] joint axis in the link frame                             */
@@ -74,7 +78,8 @@ enum {
   AGX_R_ACT = 27,        /* int: action component driving this joint, -1 = none               */
   AGX_R_QT0 = 28,        /* initial motor target (gripper joints)                             */
   AGX_R_JDAMP = 29,
-  AGX_R_PB_INDEX = 30,   /* int: PyBullet joint index (jaco.py:8-17), informational           */
+  AGX_R_PB_INDEX = 30,   /* int: PyBullet joint index (jaco.py:8-17, human.py:5-58)              */
+  AGX_R_KIND = 31,       /* int: 0 robot, 1 human (hard limit clamp after each substep, agent.py:240-250) */
   AGX_R_STRIDE = 32
 };
 
@@ -104,6 +109,8 @@ enum {
 };
 /* body codes */
 #define AGX_BODY_WORLD (-1)
+#define AGX_PARENT_ROBOT_BASE (-1)
+#define AGX_PARENT_HUMAN_BASE (-2)
 #define AGX_BODY_ROBOT_BASE 100
 #define AGX_BODY_FREE0 200
 #define AGX_BODY_HUMAN0 300
@@ -116,7 +123,9 @@ enum {
   AGX_G_B0 = 2, AGX_G_B1 = 3,   /* collider range B (male human / default)                    */
   AGX_G_B0F = 4, AGX_G_B1F = 5, /* collider range B for a female human, -1 = same as default  */
   AGX_G_FLAGS = 6,              /* bit0: A and B are the same range (i<j only); bit1: the task asks
-                                   whether a manifold point exists (broadphase margin = CONTACT_BREAK) */
+                                   whether a manifold point exists (broadphase margin = CONTACT_BREAK);
+                                   bit2: skip pairs on the same link or on parent/child links
+                                   (URDF_USE_SELF_COLLISION semantics, jaco.py:53)                    */
   AGX_G_KEEP = 7,               /* per A collider keep only the KEEP contacts with the smallest
                                    predicted gap (0 = keep all)                               */
   AGX_G_STRIDE = 8
@@ -130,7 +139,7 @@ enum {
   AGX_T_MOUTH_DIST, AGX_T_SPILL_DIST,                           /* feeding.py:61,71           */
   AGX_T_MOUTH_M = 11,    /* float[3] mouth offset in the head frame, male (feeding.py:186)    */
   AGX_T_MOUTH_F = 14,    /* float[3] female                                                   */
-  AGX_T_HEAD_BODY = 17,  /* int: human collision body whose frame is the head link frame      */
+  AGX_T_HEAD_LINK = 17,  /* int: moving link that is the human head (human.head = 23)         */
   AGX_T_EE_LINK = 18,    /* int: moving link carrying the end-effector frame                  */
   AGX_T_EE_POS = 19,     /* float[3] end-effector (PyBullet link 8) frame in that link frame  */
   AGX_T_EE_QUAT = 22,    /* float[4]                                                          */
@@ -152,6 +161,7 @@ enum {
   AGX_E_TASK_SUCCESS = 8,   /* int, feeding.py:64                                             */
   AGX_E_RNG = 9,            /* uint32[2] per-env counter RNG for the teleport draw            */
   AGX_E_TOTAL_FOOD = 11,    /* int                                                            */
+  AGX_E_FROZEN = 12,        /* int bitmask of DoFs made static (mass 0 links, human.py:104-110) */
   AGX_E_COUNT = 16
 };
 

@@ -31,7 +31,8 @@ struct agxo_model {
   uint32_t* w; const float* f; const int32_t* i; size_t nwords;
   int ndof, nfree, nhuman, ncoll, ngroup, nfood, act_dim, obs_dim, state_words, food0, tool_body, ndir;
   int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
-  int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
+  int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env, s_tremor;
+  int nrobot, nhdof;
 };
 
 /* ------------------------------------------------------------------------------------ math */
@@ -137,7 +138,8 @@ agxo_model* agxo_load(const uint32_t* blob, size_t nwords) {
   m->o_params = h[AGX_H_OFF_PARAMS]; m->o_robot = h[AGX_H_OFF_ROBOT]; m->o_free = h[AGX_H_OFF_FREE]; m->o_coll = h[AGX_H_OFF_COLL];
   m->o_vert = h[AGX_H_OFF_VERT]; m->o_group = h[AGX_H_OFF_GROUP]; m->o_task = h[AGX_H_OFF_TASK]; m->o_dirs = h[AGX_H_OFF_DIRS];
   m->s_q = h[AGX_H_S_Q]; m->s_qd = h[AGX_H_S_QD]; m->s_qt = h[AGX_H_S_QT]; m->s_free = h[AGX_H_S_FREE]; m->s_base = h[AGX_H_S_BASE];
-  m->s_human = h[AGX_H_S_HUMAN]; m->s_env = h[AGX_H_S_ENV];
+  m->s_human = h[AGX_H_S_HUMAN]; m->s_env = h[AGX_H_S_ENV]; m->s_tremor = h[AGX_H_S_TREMOR];
+  m->nrobot = h[AGX_H_NROBOT]; m->nhdof = h[AGX_H_NHDOF];
   if (m->ndof > MAXDOF || m->nfree > MAXFREE || m->nhuman > MAXHUMAN || m->ncoll > MAXCOLL) { agxo_free(m); return NULL; }
   return m;
 }
@@ -146,8 +148,11 @@ int agxo_state_words(const agxo_model* m) { return m->state_words; }
 int agxo_ndof(const agxo_model* m) { return m->ndof; }
 
 #define PARAM(m, k) ((double)(m)->f[(m)->o_params + (k)])
-#define RF(m, d, k) ((double)(m)->f[(m)->o_robot + (d) * AGX_R_STRIDE + (k)])
-#define RI(m, d, k) ((m)->i[(m)->o_robot + (d) * AGX_R_STRIDE + (k)])
+/* link record of DoF d: human DoFs have one record per gender (agx_blob.h AGX_H_NHDOF) */
+static int g_gender = 0; /* gender of the environment currently being stepped (the oracle is single threaded per process; see sim_load) */
+#define REC(m, d) ((d) < (m)->nrobot ? (d) : (d) + g_gender * (m)->nhdof)
+#define RF(m, d, k) ((double)(m)->f[(m)->o_robot + REC(m, d) * AGX_R_STRIDE + (k)])
+#define RI(m, d, k) ((m)->i[(m)->o_robot + REC(m, d) * AGX_R_STRIDE + (k)])
 #define FF(m, b, k) ((double)(m)->f[(m)->o_free + (b) * AGX_F_STRIDE + (k)])
 #define FI(m, b, k) ((m)->i[(m)->o_free + (b) * AGX_F_STRIDE + (k)])
 #define CF(m, c, k) ((double)(m)->f[(m)->o_coll + (c) * AGX_C_STRIDE + (k)])
@@ -178,7 +183,8 @@ typedef struct {
   double fpos[MAXFREE][3], fquat[MAXFREE][4], fv[MAXFREE][3], fw[MAXFREE][3];
   xf_t base, human[MAXHUMAN];
   double plane_mu, target[3];
-  int gender, alive, active, iteration, success, total_food;
+  int gender, alive, active, iteration, success, total_food, frozen;
+  double tremor[MAXDOF], tremor_target[MAXDOF];
   uint32_t rng[2];
   /* derived, per substep */
   xf_t link[MAXDOF], freex[MAXFREE];
@@ -209,7 +215,9 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
     for (int k = 0; k < 3; k++) s->human[h].p[k] = r[k]; quat_to_mat(qd, s->human[h].R);
   }
   const float* e = st + m->s_env; const int32_t* ei = (const int32_t*)e;
-  s->plane_mu = e[AGX_E_PLANE_FRICTION]; s->gender = ei[AGX_E_GENDER];
+  s->plane_mu = e[AGX_E_PLANE_FRICTION]; s->gender = ei[AGX_E_GENDER]; g_gender = s->gender;
+  s->frozen = ei[AGX_E_FROZEN];
+  for (int k = 0; k < m->nhdof; k++) { s->tremor[k] = st[m->s_tremor + k]; s->tremor_target[k] = st[m->s_tremor + m->nhdof + k]; }
   for (int k = 0; k < 3; k++) s->target[k] = e[AGX_E_TARGET + k];
   s->alive = ei[AGX_E_FOOD_ALIVE]; s->active = ei[AGX_E_FOOD_ACTIVE]; s->iteration = ei[AGX_E_ITERATION];
   s->success = ei[AGX_E_TASK_SUCCESS]; s->total_food = ei[AGX_E_TOTAL_FOOD];
@@ -235,7 +243,7 @@ static void kinematics(sim_t* s) {
   const agxo_model* m = s->m;
   for (int d = 0; d < s->ndof; d++) {
     int par = RI(m, d, AGX_R_PARENT);
-    const xf_t* P = par < 0 ? &s->base : &s->link[par];
+    const xf_t* P = par == AGX_PARENT_HUMAN_BASE ? &s->human[0] : (par < 0 ? &s->base : &s->link[par]);
     double tp[3] = {RF(m, d, AGX_R_TPOS), RF(m, d, AGX_R_TPOS + 1), RF(m, d, AGX_R_TPOS + 2)};
     double tq[4] = {RF(m, d, AGX_R_TQUAT), RF(m, d, AGX_R_TQUAT + 1), RF(m, d, AGX_R_TQUAT + 2), RF(m, d, AGX_R_TQUAT + 3)};
     double ax[3] = {RF(m, d, AGX_R_AXIS), RF(m, d, AGX_R_AXIS + 1), RF(m, d, AGX_R_AXIS + 2)};
@@ -272,7 +280,7 @@ static void kinematics(sim_t* s) {
 static void link_external_force(const sim_t* s, int d, int with_damping, double* f6) {
   const agxo_model* m = s->m;
   double mass = RF(m, d, AGX_R_MASS);
-  double f[3] = {0, 0, mass * PARAM(m, AGX_P_ROBOT_GRAVITY_Z)}, tau[3] = {0, 0, 0};
+  double f[3] = {0, 0, mass * PARAM(m, RI(m, d, AGX_R_KIND) == 1 ? AGX_P_HUMAN_GRAVITY_Z : AGX_P_ROBOT_GRAVITY_Z)}, tau[3] = {0, 0, 0};
   if (with_damping) {
     const double* w = s->vsp[d]; double vc[3], t[3];
     cross3(w, s->comw[d], t); add3(s->vsp[d] + 3, t, vc);
@@ -298,7 +306,7 @@ static void aba(sim_t* s, const double* tau, int with_damping, double* qdd) {
   for (int d = n - 1; d >= 0; d--) {
     mv6(s->IA[d], s->S[d], s->U[d]);
     double D = dot6(s->S[d], s->U[d]);
-    s->Dinv[d] = D > 1e-300 ? 1.0 / D : 0.0;
+    s->Dinv[d] = (D > 1e-300 && !(s->frozen >> d & 1)) ? 1.0 / D : 0.0;   /* frozen DoF: static link (mass 0, human.py:104-110) */
     double t = (tau ? tau[d] : 0.0) - RF(m, d, AGX_R_JDAMP) * s->qd[d];
     u[d] = t - dot6(s->S[d], pA[d]);
     int par = RI(m, d, AGX_R_PARENT);
@@ -571,6 +579,10 @@ static void collide(sim_t* s) {
     for (int a = a0; a < a1; a++) {
       contact_t cand[128]; double gap[128]; int nc = 0;
       for (int b = (same ? a + 1 : b0); b < b1; b++) {
+        if (GI(m, g, AGX_G_FLAGS) & 4) {   /* self-collision: not the same link, not parent and child */
+          int la = CI(m, a, AGX_C_BODY), lb = CI(m, b, AGX_C_BODY);
+          if (la == lb || (la >= 0 && la < AGX_BODY_ROBOT_BASE && lb >= 0 && lb < AGX_BODY_ROBOT_BASE && (RI(m, la, AGX_R_PARENT) == lb || RI(m, lb, AGX_R_PARENT) == la))) continue;
+        }
         int sep = 0;
         for (int k = 0; k < 3; k++) if (lo[a][k] > hi[b][k] + mg || lo[b][k] > hi[a][k] + mg) sep = 1;
         if (sep) continue;
@@ -648,6 +660,23 @@ static void ee_frame(const sim_t* s, xf_t* ee) {
   quat_to_mat(q, Rq); xf_apply(&s->link[L], p, ee->p); mm3(s->link[L].R, Rq, ee->R);
 }
 
+/* number of articulated DoF entries a row stores: the robot block, the human block, or both */
+static int art_entries_of(const sim_t* s, int has_robot, int has_human) {
+  const agxo_model* m = s->m;
+  if (has_robot && has_human) return m->ndof; if (has_robot) return m->nrobot; if (has_human) return m->nhdof; return 0;
+}
+static int art_range_entries(const sim_t* s, int ba, int bb) {
+  const agxo_model* m = s->m; int r = 0, h = 0;
+  if (ba >= 0 && ba < AGX_BODY_ROBOT_BASE) { if (ba < m->nrobot) r = 1; else h = 1; }
+  if (bb >= 0 && bb < AGX_BODY_ROBOT_BASE) { if (bb < m->nrobot) r = 1; else h = 1; }
+  return art_entries_of(s, r, h);
+}
+static int row_art_entries(const sim_t* s, const row_t* r) {
+  const agxo_model* m = s->m; int rr = 0, hh = 0;
+  for (int d = 0; d < m->nrobot; d++) if (r->J[d] != 0) rr = 1;
+  for (int d = m->nrobot; d < m->ndof; d++) if (r->J[d] != 0) hh = 1;
+  return art_entries_of(s, rr, hh);
+}
 static void build_rows(sim_t* s) {
   const agxo_model* m = s->m; int n = s->ndof;
   double dt = PARAM(m, AGX_P_DT), erp = PARAM(m, AGX_P_ERP), cerp = PARAM(m, AGX_P_CONTACT_ERP);
@@ -657,14 +686,14 @@ static void build_rows(sim_t* s) {
   /* joint motors: Agent.control (agent.py:28-33) -> POSITION_CONTROL velocity-level row.
    * [BULLET-UNVERIFIED] target dv = kp (q*-q)/dt + kd (0 - qd), impulse clamp maxForce*dt */
   for (int d = 0; d < n; d++) {
-    double maxf = RF(m, d, AGX_R_MAXF); if (maxf <= 0) continue;
+    double maxf = RF(m, d, AGX_R_MAXF); if (maxf <= 0 || (s->frozen >> d & 1)) continue;
     row_t* r = NEWROW(); r->J[d] = 1.0; finish_row(s, r);
     r->b = RF(m, d, AGX_R_KP) * (s->qt[d] - s->q[d]) / dt + RF(m, d, AGX_R_KD) * (0.0 - s->vel[d]);
     r->lo = -maxf * dt; r->hi = maxf * dt;
   }
   /* joint limits (URDF lower/upper): unilateral rows, built only when the gap is small */
   for (int d = 0; d < n; d++) {
-    if (!RI(m, d, AGX_R_HAS_LIMIT)) continue;
+    if (!RI(m, d, AGX_R_HAS_LIMIT) || (s->frozen >> d & 1)) continue;
     for (int side = 0; side < 2; side++) {
       double gap = side == 0 ? s->q[d] - RF(m, d, AGX_R_LOWER) : RF(m, d, AGX_R_UPPER) - s->q[d];
       if (gap >= PARAM(m, AGX_P_LIMIT_ACT)) continue;
@@ -712,12 +741,11 @@ static void build_rows(sim_t* s) {
   {
     int ent = 1, maxent = (int)PARAM(m, AGX_P_MAX_ENTRIES);
     /* non-contact rows: motors and limits address the robot; the 6 tool rows (last) robot + tool */
-    for (int r0 = 0; r0 < first_normal; r0++) ent += n + (r0 >= first_normal - 6 ? 6 : 0);
+    for (int r0 = 0; r0 < first_normal; r0++) ent += row_art_entries(s, &s->rows[r0]) + (r0 >= first_normal - 6 ? 6 : 0);
     int acc = 0;
     for (int c = 0; c < s->ncon; c++) {
       const contact_t* k = &s->con[c];
-      int robot = (k->ba >= 0 && k->ba < AGX_BODY_ROBOT_BASE) || (k->bb >= 0 && k->bb < AGX_BODY_ROBOT_BASE);
-      int e = (robot ? n : 0) + ((k->ba >= AGX_BODY_FREE0 && k->ba < AGX_BODY_HUMAN0) ? 6 : 0) + ((k->bb >= AGX_BODY_FREE0 && k->bb < AGX_BODY_HUMAN0) ? 6 : 0);
+      int e = art_range_entries(s, k->ba, k->bb) + ((k->ba >= AGX_BODY_FREE0 && k->ba < AGX_BODY_HUMAN0) ? 6 : 0) + ((k->bb >= AGX_BODY_FREE0 && k->bb < AGX_BODY_HUMAN0) ? 6 : 0);
       acc += e;
       if (first_normal + 2 * (c + 1) > maxrows || ent + 2 * acc > maxent) break;
       nc = c + 1;
@@ -772,9 +800,9 @@ static void pgs(sim_t* s, double* dv) {
 
 /* FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset */
 static void update_target(sim_t* s) {
-  const agxo_model* m = s->m; int hb = TI(m, AGX_T_HEAD_BODY), o = s->gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
+  const agxo_model* m = s->m; int hl = TI(m, AGX_T_HEAD_LINK), o = s->gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
   double mp[3] = {TF(m, o), TF(m, o + 1), TF(m, o + 2)};
-  xf_apply(&s->human[hb], mp, s->target);
+  xf_apply(&s->link[hl], mp, s->target);   /* link frames of the CURRENT kinematics() call */
 }
 
 /* one p.stepSimulation() (env.py:226) + the post-substep hooks (env.py:227-232) */
@@ -807,7 +835,14 @@ static void substep(sim_t* s) {
     int first_normal = s->nrows - 2 * s->ncon;
     s->con[c].lambda_n = s->rows[first_normal + c].lambda;
   }
-  for (int d = 0; d < n; d++) { s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d]; }
+  for (int d = 0; d < n; d++) {
+    s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d];
+    /* Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250) */
+    if (RI(m, d, AGX_R_KIND) == 1 && !(s->frozen >> d & 1)) {
+      if (s->q[d] < RF(m, d, AGX_R_LOWER)) { s->q[d] = RF(m, d, AGX_R_LOWER); s->qd[d] = 0; }
+      else if (s->q[d] > RF(m, d, AGX_R_UPPER)) { s->q[d] = RF(m, d, AGX_R_UPPER); s->qd[d] = 0; }
+    }
+  }
   for (int b = 0; b < s->nfree; b++) {
     int o = n + 6 * b;
     for (int k = 0; k < 3; k++) { s->fv[b][k] = s->vel[o + k] + dv[o + k]; s->fw[b][k] = s->vel[o + 3 + k] + dv[o + 3 + k]; s->fpos[b][k] += dt * s->fv[b][k]; }
@@ -818,8 +853,6 @@ static void substep(sim_t* s) {
     double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     for (int k = 0; k < 4; k++) s->fquat[b][k] = qn[k] / nn;
   }
-  /* Agent.enforce_joint_limits on the human (agent.py:240-250): the human is static here */
-  update_target(s);
 }
 
 /* ------------------------------------------------------------------------------------ task layer */
@@ -849,8 +882,8 @@ static void observe(sim_t* s, double robot_force, double tool_force, float* obs)
   double sp[3], sR[9], spr[3], sqr[4], hpr[3], hqr[4], tpr[3];
   tool_base_pose(s, sp, sR);
   to_base_frame(s, sp, sR, spr, sqr);
-  int hb = TI(m, AGX_T_HEAD_BODY);
-  to_base_frame(s, s->human[hb].p, s->human[hb].R, hpr, hqr);
+  int hl = TI(m, AGX_T_HEAD_LINK);
+  to_base_frame(s, s->link[hl].p, s->link[hl].R, hpr, hqr);
   to_base_frame(s, s->target, NULL, tpr, NULL);
   int o = 0;
   for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k];
@@ -878,7 +911,7 @@ static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int*
 }
 
 void agxo_observe(const agxo_model* m, const float* state, float* obs) {
-  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s);
+  sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s); update_target(s);
   observe(s, 0, 0, obs); free(s);
 }
 
@@ -886,6 +919,7 @@ void agxo_settle(const agxo_model* m, float* state, int n_substeps) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
   s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
   for (int k = 0; k < n_substeps; k++) substep(s);
+  kinematics(s); update_target(s);
   sim_store(s, state); free(s->rows); free(s);
 }
 
@@ -910,9 +944,12 @@ void agxo_step(const agxo_model* m, float* state, const float* action, float* ob
     }
     s->qt[d] = qa;
   }
+  /* tremor (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd) */
+  for (int k = 0; k < m->nhdof; k++) s->qt[m->nrobot + k] = s->tremor_target[k] + s->tremor[k] * ((s->iteration % 2 == 0) ? 1.0 : -1.0);
   for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
   for (int k = 0; k < nsub; k++) substep(s);
   kinematics(s); /* poses after the last integration, as the getters in _get_obs see them */
+  update_target(s); /* FeedingEnv.update_targets (feeding.py:192-196) */
   double robot_f, tool_f; int hit_mask;
   contact_forces(s, &robot_f, &tool_f, &hit_mask);
   observe(s, robot_f, tool_f, obs);

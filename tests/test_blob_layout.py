@@ -46,6 +46,6 @@ def test_layout_tables_match_header():
 
 
 def test_blob_header(blob):
-    assert blob.ndof == 10 and blob.nfree == 10 and blob.nfood == 8 and blob.act_dim == 7 and blob.obs_dim == 25
+    assert blob.ndof == 14 and blob.nrobot == 10 and blob.nhdof == 4 and blob.nfree == 10 and blob.nfood == 8 and blob.act_dim == 7 and blob.obs_dim == 25
     assert blob.h['NWORDS'] == len(blob.words)
-    assert blob.state_words == 3 * blob.ndof + 13 * blob.nfree + 7 + 7 * blob.nhuman + L.E['COUNT']
+    assert blob.state_words == 3 * blob.ndof + 13 * blob.nfree + 7 + 7 * blob.nhuman + 2 * blob.nhdof + L.E['COUNT']

@@ -42,3 +42,25 @@ def test_settle_and_step_match(blob, emu, oracle12):
 def test_observe_matches(blob, emu, oracle12):
     st, _ = make_states(blob, 1, seed=3005)
     assert np.abs(emu.observe(st[0].copy()) - oracle12.observe(st[0].copy())).max() < 1e-5
+
+
+def test_tremor_step_matches(blob, emu, oracle12):
+    """Dynamic head chain (tremor impairment): second articulated body, per-gender link records."""
+    st, infos = make_states(blob, 2, seed=3101, impairment='tremor')
+    rng = np.random.RandomState(4)
+    for i in range(2):
+        so, se = st[i].copy(), st[i].copy()
+        oracle12.settle(so, 3); emu.settle(se, 3)
+        assert np.abs(blob.view(so)['q'] - blob.view(se)['q']).max() < 1e-5
+        for k in range(2):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            s1, s2 = so.copy(), so.copy()
+            o_obs, o_rew, o_done, o_info = oracle12.step(s1, a)
+            e_obs, e_rew, e_done, e_info, _ = emu.step(s2, a)
+            # the particle pile is chaotic at 12 sweeps: the last-substep contact set may differ by a few
+            # near-tied candidates; robot, head and reward must still agree
+            assert abs(o_info[6] - e_info[6]) <= 4
+            assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4
+            assert np.abs(blob.view(s1)['q'] - blob.view(s2)['q']).max() < 1e-5
+            assert np.abs(blob.view(s1)['qt'] - blob.view(s2)['qt']).max() < 1e-6
+            so = s1

@@ -9,14 +9,14 @@ def test_jaco_tree(blob):
     # arm chain 1..7, fingers 9/11/13 hang off link 7 (agents/jaco.py:8-17)
     assert blob.meta['dof_links'] == [1, 2, 3, 4, 5, 6, 7, 9, 11, 13]
     parents = [blob.robot_i(d, 'PARENT') for d in range(blob.ndof)]
-    assert parents == [-1, 0, 1, 2, 3, 4, 5, 6, 6, 6]
-    masses = [blob.robot_f(d, 'MASS') for d in range(blob.ndof)]
+    assert parents == [-1, 0, 1, 2, 3, 4, 5, 6, 6, 6, -2, 10, 11, 12]      # robot tree, then the human head chain on the chest
+    masses = [blob.robot_f(d, 'MASS') for d in range(blob.nrobot)]
     # j2s7s300_gym.urdf link masses; link 7 carries the 1 g end-effector link, fingers carry their tips
     np.testing.assert_allclose(masses, [0.7477, 0.8447, 0.8447, 0.6763, 0.463, 0.463, 0.991, 0.02, 0.02, 0.02], rtol=1e-6)
     lo = [blob.robot_f(d, 'LOWER') for d in range(7)]
     assert lo[1] == pytest.approx(0.820304748437) and lo[3] == pytest.approx(0.523598775598) and lo[5] == pytest.approx(1.1344640138)
     assert lo[0] < -1e9 and lo[2] < -1e9 and lo[4] < -1e9 and lo[6] < -1e9       # continuous joints, agent.py:223-225
-    assert [blob.robot_i(d, 'ACT') for d in range(10)] == [0, 1, 2, 3, 4, 5, 6, -1, -1, -1]
+    assert [blob.robot_i(d, 'ACT') for d in range(14)] == [0, 1, 2, 3, 4, 5, 6, -1, -1, -1, -1, -1, -1, -1]
     assert [blob.robot_f(d, 'KP') for d in range(10)] == pytest.approx([0.025] * 7 + [0.05] * 3)      # feeding.py:122, robot.py:77
     assert [blob.robot_f(d, 'MAXF') for d in range(10)] == pytest.approx([1.0] * 7 + [500.0] * 3)
 
@@ -54,3 +54,17 @@ def test_human_fk_straight_pose():
     assert pos[23, 2] == pytest.approx(1.0 + 0.1515 + 0.137)          # neck + head offsets
     assert pos[9, 2] == pytest.approx(1.0 + 2 * 0.07075 - 0.279 - 0.29)   # two pecs offsets (human_creation.py:191), upper arm, forearm
     assert pos[9, 0] == pytest.approx(-0.179)
+
+
+def test_human_head_chain_records(blob):
+    """DoFs 10..13 = human joints 20..23 (human.head_joints), one record per gender (human_creation.py:188-200)."""
+    assert blob.meta['human_dynamic_joints'] == [20, 21, 22, 23] and blob.task_i('HEAD_LINK') == 13
+    for g, total in ((0, 78.4), (1, 62.5)):
+        m = [blob.robot_f(d, 'MASS', gender=g) for d in range(10, 14)]
+        np.testing.assert_allclose(m, [0.01 * total, 0, 0, 0.07 * total], rtol=1e-6)
+        assert [blob.robot_i(d, 'KIND', gender=g) for d in range(10, 14)] == [1, 1, 1, 1]
+        assert [blob.robot_i(d, 'PB_INDEX', gender=g) for d in range(10, 14)] == [20, 21, 22, 23]
+        lo = [blob.robot_f(d, 'LOWER', gender=g) for d in range(10, 14)]
+        np.testing.assert_allclose(lo, np.deg2rad([-10, -50, -34, -70]), rtol=1e-6)
+    assert blob.robot_f(10, 'TPOS', 3)[2] == pytest.approx(0.1515) and blob.robot_f(10, 'TPOS', 3, gender=1)[2] == pytest.approx(0.132)
+    assert blob.nhuman == 17          # static collision bodies: chest + 16 limb links (neck and head are moving links)
