@@ -114,7 +114,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   if (w[AGX_H_MAGIC] != AGX_BLOB_MAGIC || w[AGX_H_VERSION] != AGX_BLOB_VERSION || (size_t)hi[AGX_H_NWORDS] * 4 != blob_bytes)
     return fail(AGX_E_BLOB, "agx_create: not a model blob of this version");
   if (hi[AGX_H_NDOF] > agx::MAX_DOF || hi[AGX_H_NFREE] > agx::MAX_FREE || hi[AGX_H_NHUMAN] > agx::MAX_HUMAN || hi[AGX_H_NCOLL] > agx::MAX_COLL ||
-      hi[AGX_H_STATE_WORDS] > agx::ST_WORDS || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128 || hi[AGX_H_NGROUP] > 8000)
+      hi[AGX_H_STATE_WORDS] > agx::ST_WORDS || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128 || hi[AGX_H_NGROUP] > 64)
     return fail(AGX_E_LIMIT, "agx_create: model exceeds the compiled kernel limits");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AGX_E_NOGPU, "agx_create: no HIP device (libagx has no CPU path)");

@@ -396,6 +396,7 @@ constexpr int A_WL = 6 * MAX_COLL;                      // int[WL_MAX]: a | b <<
 constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, n, dist (pb = pa - dist n)
 static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
 static_assert(MAX_COLL <= 512, "collider indices are packed in 9 bits");
+constexpr int WL_CAP = WL_MAX - 16;   // the candidate words of the last 16 entries (128 ints) hold the A-collider list of a sweep
 
 AGX_DEV void range_aabb(const Ctx& c, int r0, int r1, float* lo, float* hi) {
   const float* AB = c.lds + L_ARENA;
@@ -487,10 +488,25 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
 AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool same, float mg, int wn) {
   const float* AB = c.lds + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; const int lane = c.lane;
   const bool no_adjacent = GRI(c, g, AGX_G_FLAGS) & 4;   // self-collision: not the same link, not parent and child
-  const int nb = b1 - b0, npairs = (ab - aa) * nb;
+  const int nb = b1 - b0;
+  // level 1: A colliders whose box reaches the union of the B range (lanes over A), compacted into
+  // the tail of the candidate area (unused until the flush)
+  float blo[3], bhi[3]; range_aabb(c, b0, b1, blo, bhi);
+  int* ALIST = c.ldsi + L_ARENA + A_CAND + CAND_STRIDE * WL_CAP;
+  int na_live = 0;
+  for (int base = aa; base < ab; base += 64) {
+    const int a = base + lane; bool ok = a < ab;
+    if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > bhi[q] + mg || blo[q] > AB[6 * a + 3 + q] + mg) ok = false;
+    const uint64_t m = wave_ballot(ok);
+    if (ok) ALIST[na_live + wave_rank(m)] = a;
+    na_live += popc64(m);
+  }
+  wave_sync();
+  // level 2: the pair grid of the surviving A colliders, in enumeration order
+  const int npairs = na_live * nb;
   for (int base = 0; base < npairs; base += 64) {
     const int p = base + lane; bool ok = p < npairs;
-    const int ai = ok ? p / nb : 0; const int a = aa + ai, b = b0 + (p - ai * nb);
+    const int ai = ok ? p / nb : 0; const int a = ALIST[ai], b = b0 + (p - ai * nb);
     ok = ok && (!same || b > a);
     if (ok && no_adjacent) {
       const int la = CLI(c, a, AGX_C_BODY), lb = CLI(c, b, AGX_C_BODY);
@@ -500,9 +516,10 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool sa
     if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + mg || AB[6 * b + q] > AB[6 * a + 3 + q] + mg) ok = false;
     const uint64_t m = wave_ballot(ok);
     const int slot = wn + wave_rank(m);
-    if (ok && slot < WL_MAX) WL[slot] = a | (b << 9) | (g << 18);
+    if (ok && slot < WL_CAP) WL[slot] = a | (b << 9) | (g << 18);
     wn += popc64(m);
   }
+  wave_sync();
   return wn;
 }
 
@@ -533,36 +550,47 @@ AGX_DEV void collide(Ctx& c) {
   wave_sync();
   AGX_CTICK(8)
   const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER];
+  // body-level cull of every group at once: lane g scans both collider ranges of group g
+  uint64_t live_groups = 0;
+  {
+    const int g = lane; bool live = false;
+    if (g < c.ngroup) {
+      int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
+      if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
+      const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;
+      if (a1 > a0 && b1 > b0) {
+        float alo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ahi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int i = a0; i < a1; i++) for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], AB[6 * i + k]); ahi[k] = fmaxf(ahi[k], AB[6 * i + 3 + k]); }
+        for (int i = b0; i < b1; i++) for (int k = 0; k < 3; k++) { blo[k] = fminf(blo[k], AB[6 * i + k]); bhi[k] = fmaxf(bhi[k], AB[6 * i + 3 + k]); }
+        live = true;
+        for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + mg || blo[k] > ahi[k] + mg) live = false;
+      }
+    }
+    live_groups = wave_ballot(live);   // the pair table has at most 64 groups (checked in agx_create)
+  }
+  AGX_CTICK(9)
   int wn = 0;    // worklist fill; whole groups are accumulated and flushed together
   for (int g = 0; g < c.ngroup; g++) {
+    if (!(live_groups >> g & 1)) continue;
     int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
     if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
     const bool same = GRI(c, g, AGX_G_FLAGS) & 1;
     const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
     const int nb = b1 - b0;
-    if ((a1 - a0) * nb <= 0) continue;
-    {   // body-level cull
-      float alo[3], ahi[3], blo[3], bhi[3];
-      range_aabb(c, a0, a1, alo, ahi); range_aabb(c, b0, b1, blo, bhi);
-      bool sep = false;
-      for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + mg || blo[k] > ahi[k] + mg) sep = true;
-      AGX_CTICK(9)
-      if (sep) continue;
-    }
     // 2. broadphase sweep of the whole group into the shared worklist
     int wn2 = collide_sweep(c, g, a0, a1, b0, b1, same, mg, wn);
-    if (wn2 > WL_MAX) {
+    if (wn2 > WL_CAP) {
       // does not fit behind the pending groups: flush them, then take this group alone, if necessary
-      // in batches of whole A colliders (a batch of WL_MAX / nb colliders cannot overflow)
+      // in batches of whole A colliders (a batch of WL_CAP / nb colliders cannot overflow)
       AGX_CTICK(10)
       collide_flush(c, wn, cs, brk, slack, gender); wn = 0;
       ct0 = c.timing ? wave_clock() : 0;
       wn2 = collide_sweep(c, g, a0, a1, b0, b1, same, mg, 0);
-      if (wn2 > WL_MAX) {
-        const int abatch = WL_MAX / nb > 0 ? WL_MAX / nb : 1;
+      if (wn2 > WL_CAP) {
+        const int abatch = WL_CAP / nb > 0 ? WL_CAP / nb : 1;
         for (int ab = a0; ab < a1; ab += abatch) {
           int w3 = collide_sweep(c, g, ab, ab + abatch < a1 ? ab + abatch : a1, b0, b1, same, mg, 0);
-          if (w3 > WL_MAX) { cs.overflow += w3 - WL_MAX; w3 = WL_MAX; }
+          if (w3 > WL_CAP) { cs.overflow += w3 - WL_CAP; w3 = WL_CAP; }
           AGX_CTICK(10)
           collide_flush(c, w3, cs, brk, slack, gender);
           ct0 = c.timing ? wave_clock() : 0;
