@@ -94,6 +94,7 @@ struct agx_handle_s {
   // staging for the *_host convenience calls
   float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
   hipEvent_t ev0, ev1;
+  hipEvent_t kev[24];   // agx_step_timed: boundaries of the launches of one step
   // The environments are stepped in AGX_CHUNKS independent chunks on internal streams: while one
   // chunk is in its (latency-bound, lean) solve kernel another is in its (LDS/register-heavy) build
   // kernel, so the two kernel types share the CUs instead of alternating.
@@ -138,6 +139,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   HIPCHK(hipMalloc(&h->info_dev, (size_t)n_envs * AGX_INFO_DIM * 4));
   HIPCHK(hipMalloc(&h->done_dev, (size_t)n_envs));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+  for (int k = 0; k < 24; k++) HIPCHK(hipEventCreate(&h->kev[k]));
   {
     const char* e = getenv("AGX_CHUNKS");
     int nc = e ? atoi(e) : 1; if (nc < 1) nc = 1; if (nc > 8) nc = 8; if (n_envs < 64 * nc) nc = 1;
@@ -158,6 +160,7 @@ void agx_destroy(agx_handle h) {
   hipFree(h->scratch_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
   hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  for (int k = 0; k < 24; k++) hipEventDestroy(h->kev[k]);
   hipEventDestroy(h->fork_ev); for (int k = 0; k < h->n_chunks; k++) { hipStreamDestroy(h->cs[k]); hipEventDestroy(h->join_ev[k]); }
   delete h;
 }
@@ -227,6 +230,31 @@ int agx_step(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done
 int agx_step_debug(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, float* dbg, void* stream) {
   if (!h || !a || !obs || !rew || !done || !dbg) return fail(AGX_E_ARG, "agx_step_debug: bad argument");
   return launch_step(h, a, obs, rew, done, info, dbg, stream);
+}
+int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, void* stream, float* ms3) {
+  if (!h || !a || !obs || !rew || !done || !ms3) return fail(AGX_E_ARG, "agx_step_timed: bad argument");
+  if (2 * h->frame_skip + 2 > 24) return fail(AGX_E_LIMIT, "agx_step_timed: frame_skip too large");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int ne = h->n_envs;
+  int e = 0;
+  HIPCHK(hipEventRecord(h->kev[e++], st));
+  for (int k = 0; k < h->frame_skip; k++) {
+    hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, 0, ne, h->sw, h->act_dim);
+    HIPCHK(hipEventRecord(h->kev[e++], st));
+    hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, 0, ne, h->sw);
+    HIPCHK(hipEventRecord(h->kev[e++], st));
+  }
+  hipLaunchKernelGGL(agx_finish_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, 0, ne, h->sw, h->act_dim, h->obs_dim);
+  HIPCHK(hipEventRecord(h->kev[e++], st));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventSynchronize(h->kev[e - 1]));
+  ms3[0] = ms3[1] = ms3[2] = 0.f;
+  for (int k = 0; k + 1 < e; k++) {
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->kev[k], h->kev[k + 1]));
+    ms3[k == e - 2 ? 2 : (k & 1)] += ms;
+  }
+  return AGX_OK;
 }
 int agx_observe(agx_handle h, float* obs, void* stream) {
   if (!h || !obs) return fail(AGX_E_ARG, "agx_observe: bad argument");

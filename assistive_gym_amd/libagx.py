@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libagx.so')
 _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
-           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_debug_words',
+           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest']
 
@@ -94,6 +94,12 @@ class Stepper:
             check(self.L.agx_step_debug(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), _ptr(debug), C.c_void_p(stream)), 'agx_step_debug')
         else:
             check(self.L.agx_step(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), C.c_void_p(stream)), 'agx_step')
+
+    def step_timed(self, actions, obs, reward, done, info=None, stream=0):
+        """one step with HIP events between the launches; returns ms of (build, solve, finish) kernels"""
+        ms = (C.c_float * 3)()
+        check(self.L.agx_step_timed(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), C.c_void_p(stream), ms), 'agx_step_timed')
+        return [ms[0], ms[1], ms[2]]
 
     def observe_dev(self, obs, stream=0):
         check(self.L.agx_observe(self.h, _ptr(obs), C.c_void_p(stream)), 'agx_observe')

@@ -46,8 +46,8 @@ def cpu_baseline(blob, states, n_envs, n_steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--pool', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -101,15 +101,35 @@ def main():
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # per-kernel durations (HIP events between the launches, on the launch stream), measured after
+    # the timed region so that `value` is not perturbed by the extra events / host syncs
+    NT = 20
+    kms = np.zeros(3)
+    for k in range(NT):
+        kms += np.array(env.stepper.step_timed(tape[(W + k) % (W + K)], env.obs, env.reward, env.done, env.info, stream))
+    kms /= NT
     if rank == 0:
         total_steps = world * n * K
         value = total_steps / elapsed
         sw = blob.state_words
+        fs = int(blob.param('FRAME_SKIP'))
         # algorithmic HBM bytes per env-step: state record read + written once, action read, obs /
         # reward / done / info written (DESIGN.md "bytes per env-step")
         bytes_per_env_step = 2 * sw * 4 + blob.act_dim * 4 + blob.obs_dim * 4 + 4 + 1 + 8 * 4
-        launch_s = kernel_ms * 1e-3 / K
-        achieved = bytes_per_env_step * n / launch_s / 1e9
+        names = ['agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel']
+        launches = [fs, fs, 1]
+        dom = int(np.argmax(kms))
+        # one launch of the dominant kernel advances every env by 1/frame_skip of an env-step
+        launch_ms = kms[dom] / launches[dom]
+        units = n / launches[dom]
+        achieved = bytes_per_env_step * units / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tpath):       # PMC passes of tools/pmc_workload.py (separate rocprofv3 runs)
+            tj = json.load(open(tpath))
+            if tj.get('envs') == n and names[dom] in tj.get('kernels', {}):
+                traffic = tj['kernels'][names[dom]]['hbm_bytes_per_launch']
+                traffic_src = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s)' % tj.get('correction', '')
         out = {
             'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
@@ -118,8 +138,12 @@ def main():
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': args.pool, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'agx_step_kernel', 'kernel_ms_per_launch': kernel_ms / K,
-                         'algorithmic_bytes_per_env_step': bytes_per_env_step,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': names[dom], 'kernel_ms_per_launch': launch_ms, 'launches_per_step': launches[dom],
+                         'algorithmic_bytes_per_env_step': bytes_per_env_step, 'algorithmic_bytes_per_launch': bytes_per_env_step * units,
+                         'kernels_ms_per_step': dict(zip(names, [float(x) for x in kms])),
+                         'all_kernels_ms_per_step': float(kms.sum()), 'stream_ms_per_step': kernel_ms / K,
+                         'step_level_achieved': bytes_per_env_step * n / (kms.sum() * 1e-3) / 1e9,
                          'note': 'latency/VALU-bound solver; HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:

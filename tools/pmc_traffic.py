@@ -1,0 +1,50 @@
+"""Reduce the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of
+tools/pmc_workload.py, as /opt/skills/guides/MI355X_MICROARCH.md "HBM" prescribes) to per-launch
+HBM bytes per kernel -> profiles/r01_traffic.json (read by bench.py for roofline.traffic).
+
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [envs]
+
+Units / corrections: both counters are in KiB.  On gfx950 FETCH_SIZE tallies 128-B requests at
+64 B, so it is doubled (guide); WRITE_SIZE is used as reported.  The observation-only launches of
+the workload have a known byte count (one state record read, one observation written per env)
+and are reported beside the corrected counters as a calibration check."""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter and r['Kernel_Name'].startswith('agx_'):
+            acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']) * 1024.0)
+    return acc
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+    envs = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+    sys.path.insert(0, ROOT)
+    from assistive_gym_amd.blob import ModelBlob
+    blob = ModelBlob.load('feeding_jaco')
+    out = {'envs': envs, 'correction': 'FETCH_SIZE x2 (gfx950, guide), WRITE_SIZE as reported', 'kernels': {}}
+    for k in sorted(set(fetch) | set(write)):
+        f = sum(fetch[k]) / max(1, len(fetch[k]))
+        w = sum(write[k]) / max(1, len(write[k]))
+        out['kernels'][k] = {'launches_sampled': len(fetch[k]), 'fetch_raw_bytes': f, 'write_raw_bytes': w,
+                             'hbm_bytes_per_launch': 2.0 * f + w, 'hbm_bytes_per_env_launch': (2.0 * f + w) / envs}
+    if 'agx_observe_kernel' in out['kernels']:
+        o = out['kernels']['agx_observe_kernel']
+        known_r, known_w = envs * blob.state_words * 4, envs * blob.obs_dim * 4
+        out['calibration'] = {'kernel': 'agx_observe_kernel', 'known_read_bytes': known_r, 'known_write_bytes': known_w,
+                              'fetch_x2_over_known': 2.0 * o['fetch_raw_bytes'] / known_r, 'write_over_known': o['write_raw_bytes'] / known_w}
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'), 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
