@@ -5,6 +5,7 @@
 struct v3 { float x, y, z; };
 struct m3 { float a[9]; };   // row-major
 struct q4 { float x, y, z, w; };
+struct alignas(8) f2 { float x, y; };   // one 8-byte load
 
 AGX_DEV v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 AGX_DEV v3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }

@@ -29,7 +29,8 @@ constexpr int MAX_ROWS = 160;
 constexpr int ST_WORDS = 336;
 constexpr int CON_STRIDE = 16;
 constexpr int HDR_STRIDE = 8;
-constexpr int ARENA_WORDS = 4096;
+constexpr int ARENA_WORDS = 4352;
+constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
 
 // ---- LDS layout (float words) -------------------------------------------------------------
 constexpr int L_ST = 0;
@@ -346,14 +347,14 @@ AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
 // closest features of colliders (ca, cb); true if the separation (radii included) is below limit
 AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out) {
   const float* AB = c.lds + L_ARENA;
-  v3 shift = mk3(0.5f * (AB[6 * ca] + AB[6 * ca + 3]), 0.5f * (AB[6 * ca + 1] + AB[6 * ca + 4]), 0.5f * (AB[6 * ca + 2] + AB[6 * ca + 5]));
+  v3 shift = mk3(0.5f * (AB[ABS * ca] + AB[ABS * ca + 3]), 0.5f * (AB[ABS * ca + 1] + AB[ABS * ca + 4]), 0.5f * (AB[ABS * ca + 2] + AB[ABS * ca + 5]));
   gjk_shape sa, sb; make_shape(c, ca, shift, sa); make_shape(c, cb, shift, sb);
   // large static world boxes (table top, ground): clip to the neighbourhood of A (see oracle)
   if (CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && sb.n == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
     sb.box = true;
     float lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
-      lo[k] = fmaxf(AB[6 * cb + k], AB[6 * ca + k] - AGX_BOX_CLIP); hi[k] = fminf(AB[6 * cb + 3 + k], AB[6 * ca + 3 + k] + AGX_BOX_CLIP);
+      lo[k] = fmaxf(AB[ABS * cb + k], AB[ABS * ca + k] - AGX_BOX_CLIP); hi[k] = fminf(AB[ABS * cb + 3 + k], AB[ABS * ca + 3 + k] + AGX_BOX_CLIP);
       if (hi[k] < lo[k]) return false;
     }
     sb.lo = mk3(lo[0], lo[1], lo[2]) - shift; sb.hi = mk3(hi[0], hi[1], hi[2]) - shift;
@@ -392,7 +393,7 @@ AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
 // The contact order (group, a, selection order) is what the oracle produces, so the solver rows
 // are identical.
 constexpr int WL_MAX = 280, CAND_STRIDE = 8;
-constexpr int A_WL = 6 * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18
+constexpr int A_WL = ABS * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18
 constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, n, dist (pb = pa - dist n)
 static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
 static_assert(MAX_COLL <= 512, "collider indices are packed in 9 bits");
@@ -401,7 +402,7 @@ constexpr int WL_CAP = WL_MAX - 16;   // the candidate words of the last 16 entr
 AGX_DEV void range_aabb(const Ctx& c, int r0, int r1, float* lo, float* hi) {
   const float* AB = c.lds + L_ARENA;
   float l[3] = {3.0e38f, 3.0e38f, 3.0e38f}, h[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int i = r0 + c.lane; i < r1; i += 64) for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], AB[6 * i + k]); h[k] = fmaxf(h[k], AB[6 * i + 3 + k]); }
+  for (int i = r0 + c.lane; i < r1; i += 64) for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], AB[ABS * i + k]); h[k] = fmaxf(h[k], AB[ABS * i + 3 + k]); }
   for (int k = 0; k < 3; k++) { lo[k] = wave_min(l[k]); hi[k] = wave_max(h[k]); }
 }
 AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
@@ -410,6 +411,21 @@ AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
   emit_contact(c, slot, pr & 511, (pr >> 9) & 511, k);
 }
 struct CollideState { int ncon, near_mask, overflow, maxc; };
+// conservative separation test: every point of collider x lies within |half extents| + radius of
+// the centre of its box; collider y lies within its body-frame box inflated by its radius.  True if
+// the two are certainly further apart than `reach`.
+AGX_DEV bool sphere_box_apart(const Ctx& c, int x, int y, float reach) {
+  const float* AB = c.lds + L_ARENA;
+  const v3 cx = mk3(0.5f * (AB[ABS * x] + AB[ABS * x + 3]), 0.5f * (AB[ABS * x + 1] + AB[ABS * x + 4]), 0.5f * (AB[ABS * x + 2] + AB[ABS * x + 5]));
+  const v3 hx = mk3(CLF(c, x, AGX_C_AABB_H), CLF(c, x, AGX_C_AABB_H + 1), CLF(c, x, AGX_C_AABB_H + 2));
+  const float rx = sqrtf(dot(hx, hx)) + CLF(c, x, AGX_C_RADIUS);
+  m3 R; v3 p; body_xf(c, CLI(c, y, AGX_C_BODY), R, p);
+  const v3 pl = tmul(R, cx - p) - mk3(CLF(c, y, AGX_C_AABB_C), CLF(c, y, AGX_C_AABB_C + 1), CLF(c, y, AGX_C_AABB_C + 2));
+  const float dx = fmaxf(fabsf(pl.x) - CLF(c, y, AGX_C_AABB_H), 0.f), dy = fmaxf(fabsf(pl.y) - CLF(c, y, AGX_C_AABB_H + 1), 0.f),
+              dz = fmaxf(fabsf(pl.z) - CLF(c, y, AGX_C_AABB_H + 2), 0.f);
+  const float lb = sqrtf(dx * dx + dy * dy + dz * dz) - rx - CLF(c, y, AGX_C_RADIUS);
+  return lb > reach;
+}
 
 // narrowphase + selection over the current worklist (entries of one or several whole groups, in
 // enumeration order); appends the resulting contacts
@@ -420,6 +436,9 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   wave_sync();
   long long ct0 = c.timing ? wave_clock() : 0;
   if (c.timing) { c.tm[13] += wn; c.tm[14] += (wn + 63) / 64; }   // debug: narrowphase pairs / passes
+#ifdef AGX_EMU_TRACE
+  if (c.timing && lane == 0) { for (int i = 0; i < wn; i++) printf("WL %d %d %d\n", WL[i] >> 18, WL[i] & 511, (WL[i] >> 9) & 511); }
+#endif
   // 3. narrowphase, 64 pairs per pass
   bool any_manifold_query = false;
   for (int base = 0; base < wn; base += 64) {
@@ -496,7 +515,7 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool sa
   int na_live = 0;
   for (int base = aa; base < ab; base += 64) {
     const int a = base + lane; bool ok = a < ab;
-    if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > bhi[q] + mg || blo[q] > AB[6 * a + 3 + q] + mg) ok = false;
+    if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * a + q] > bhi[q] + mg || blo[q] > AB[ABS * a + 3 + q] + mg) ok = false;
     const uint64_t m = wave_ballot(ok);
     if (ok) ALIST[na_live + wave_rank(m)] = a;
     na_live += popc64(m);
@@ -513,7 +532,11 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool sa
       if (la == lb) ok = false;
       else if (la >= 0 && la < AGX_BODY_ROBOT_BASE && lb >= 0 && lb < AGX_BODY_ROBOT_BASE && (RBI(c, la, AGX_R_PARENT) == lb || RBI(c, lb, AGX_R_PARENT) == la)) ok = false;
     }
-    if (ok) for (int q = 0; q < 3; q++) if (AB[6 * a + q] > AB[6 * b + 3 + q] + mg || AB[6 * b + q] > AB[6 * a + 3 + q] + mg) ok = false;
+    if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * a + q] > AB[ABS * b + 3 + q] + mg || AB[ABS * b + q] > AB[ABS * a + 3 + q] + mg) ok = false;
+    // level 3: bounding sphere of one collider against the body-frame box of the other, both ways
+#ifndef AGX_NO_OBB
+    if (ok) { const float reach = mg + AB[ABS * a + 6] + AB[ABS * b + 6] + 1e-5f; ok = !sphere_box_apart(c, a, b, reach) && !sphere_box_apart(c, b, a, reach); }
+#endif
     const uint64_t m = wave_ballot(ok);
     const int slot = wn + wave_rank(m);
     if (ok && slot < WL_CAP) WL[slot] = a | (b << 9) | (g << 18);
@@ -544,8 +567,9 @@ AGX_DEV void collide(Ctx& c) {
     const float grow = (sqrtf(dot(vc, vc)) + sqrtf(dot(w, w)) * (sqrtf(dot(hl, hl)) + r)) * c.dt;
     for (int k = 0; k < 3; k++) {
       float h = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
-      AB[6 * col + k] = comp(cw, k) - h - grow; AB[6 * col + 3 + k] = comp(cw, k) + h + grow;
+      AB[ABS * col + k] = comp(cw, k) - h - grow; AB[ABS * col + 3 + k] = comp(cw, k) + h + grow;
     }
+    AB[ABS * col + 6] = grow;
   }
   wave_sync();
   AGX_CTICK(8)
@@ -560,8 +584,8 @@ AGX_DEV void collide(Ctx& c) {
       const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;
       if (a1 > a0 && b1 > b0) {
         float alo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ahi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        for (int i = a0; i < a1; i++) for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], AB[6 * i + k]); ahi[k] = fmaxf(ahi[k], AB[6 * i + 3 + k]); }
-        for (int i = b0; i < b1; i++) for (int k = 0; k < 3; k++) { blo[k] = fminf(blo[k], AB[6 * i + k]); bhi[k] = fmaxf(bhi[k], AB[6 * i + 3 + k]); }
+        for (int i = a0; i < a1; i++) for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], AB[ABS * i + k]); ahi[k] = fmaxf(ahi[k], AB[ABS * i + 3 + k]); }
+        for (int i = b0; i < b1; i++) for (int k = 0; k < 3; k++) { blo[k] = fminf(blo[k], AB[ABS * i + k]); bhi[k] = fmaxf(bhi[k], AB[ABS * i + 3 + k]); }
         live = true;
         for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + mg || blo[k] > ahi[k] + mg) live = false;
       }
@@ -798,42 +822,179 @@ AGX_DEV void build_rows(Ctx& c) {
 // lane on its own row registers; only the owner lane's result is kept and its delta broadcast.
 struct PgsSet { float invD, b, lo, hi, lam; int pack, off; };   // one row per lane (hi = mu for friction sets)
 
-// (J,B) pair of this lane for a row: lanes outside the row's two DoF ranges read arena entry 0 = (0,0)
-AGX_DEV void pgs_fetch(const float* E, int lane, int pack, int off, float& j0, float& c0, float& j1, float& c1) {
-  const int a0 = pack & 255, na = (pack >> 8) & 255, b0 = (pack >> 16) & 255, nb = (pack >> 24) & 255;
-  unsigned ia = (unsigned)(lane - a0), ib = (unsigned)(lane - b0);
-  int e = ib < (unsigned)nb ? off + na + (int)ib : 0;
-  e = ia < (unsigned)na ? off + (int)ia : e;
-  j0 = E[2 * e]; c0 = E[2 * e + 1];
-  j1 = 0.f; c1 = 0.f;
-  if (a0 + na > 64 || b0 + nb > 64) {   // wave-uniform: only rows touching DoFs 64.. need the second slot
-    ia = (unsigned)(lane + 64 - a0); ib = (unsigned)(lane + 64 - b0);
-    e = ib < (unsigned)nb ? off + na + (int)ib : 0;
-    e = ia < (unsigned)na ? off + (int)ia : e;
-    j1 = E[2 * e]; c1 = E[2 * e + 1];
+// (J,B) pair of this lane for a row: lanes outside the row's two DoF ranges read arena entry 0 = (0,0).
+// Addresses are 32-bit byte offsets from the (wave-uniform) entry base, so the loads use the
+// SGPR-base + VGPR-offset form and need no 64-bit address arithmetic.
+struct PgsBuf { float j0, c0, j1, c1; };
+AGX_DEV void pgs_fetch(const float* E, int lane, int pack, int off, PgsBuf& X) {
+  const unsigned a0 = pack & 255, na = (pack >> 8) & 255, b0 = (pack >> 16) & 255, nb = (unsigned)pack >> 24;
+  const unsigned oa = 8u * (unsigned)off, ob = 8u * ((unsigned)off + na);
+  const char* Eb = (const char*)E;
+  unsigned ia = (unsigned)lane - a0, ib = (unsigned)lane - b0;
+  unsigned e = ib < nb ? ob + 8u * ib : 0u;
+  e = ia < na ? oa + 8u * ia : e;
+  unsigned e1 = 0u;
+  if (a0 + na > 64 || b0 + nb > 64) {   // wave-uniform: only rows touching DoFs 64.. have entries in the second slot
+    ia = (unsigned)lane + 64u - a0; ib = (unsigned)lane + 64u - b0;
+    e1 = ib < nb ? ob + 8u * ib : 0u;
+    e1 = ia < na ? oa + 8u * ia : e1;
   }
+  // both loads are always issued (the second one degenerates to a broadcast of the zero pair): the
+  // number of loads in flight is then the same on every path and the waits can be exact
+  const f2 p = *(const f2*)(Eb + e);
+  const f2 q = *(const f2*)(Eb + e1);
+  X.j0 = p.x; X.c0 = p.y; X.j1 = q.x; X.c1 = q.y;
 }
 // one Gauss-Seidel pass over the rows held in lanes [l0, l1) of one register set.  The (J,B) pairs
-// stream from the per-env scratch (L2); the loads for rows r+1 and r+2 are in flight while row r is
-// reduced.
+// stream from the per-env scratch (L2).  Three named buffers rotate through the roles "in use",
+// "next" and "being fetched" (the loop is unrolled by three so that no register moves are needed and
+// the loads of rows r+1 and r+2 stay in flight while row r is reduced).  Prefetches past the end
+// re-read the last row instead of being skipped, again to keep the number of loads in flight fixed.
+template <bool FRICTION>
+AGX_DEV void pgs_row(PgsSet& S, const float& lam_normal, const PgsBuf& X, int lane, int rl, float& dv0, float& dv1) {
+  const float jdv = wave_sum(X.j0 * dv0 + X.j1 * dv1);
+  const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
+  const float nl = wave_clamp(S.lam + (S.b - jdv) * S.invD, lo, hi);
+  const float dlo = nl - S.lam;
+  S.lam = (lane == rl) ? nl : S.lam;
+  const float dl = wave_bcast(dlo, rl);
+  dv0 += X.c0 * dl;
+  wave_opaque(dv0);       // keeps the two updates scalar: a packed FMA would need (c0, c1) in adjacent registers
+  dv1 += X.c1 * dl;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- the Gauss-Seidel sweep in gfx950 assembly ------------------------------------------------------
+// The compiler's schedule of the loop above is poor in exactly the places that matter: it rotates
+// the prefetch buffers with register moves and, because the number of loads in flight differs between
+// paths, falls back to s_waitcnt vmcnt(0) right after issuing a prefetch.  Here the row loop is written
+// out by hand: four register buffers W,X,Y,Z rotate through "in use / +1 / +2 / being fetched"
+// (unrolled by four, no moves), every row issues exactly two global_load_dwordx2 (rows that do not
+// reach DoFs 64.. load the zero pair for the second slot), so s_waitcnt vmcnt(6) is exact, and the
+// prefetch index is clamped to the last row of the sweep instead of being skipped.
+// Hazards (gfx940 family; the assembler inserts nothing in inline asm): VALU-written VGPR -> DPP 2
+// wait states, VALU-written SGPR/VCC -> VALU read 2, -> v_readlane lane select 4; spacing below
+// keeps to these with independent instructions or s_nop.
+// Register map: v64..v79 buffers, v80..v88 temporaries, s80..s93 scalars.
+#define AGX_PGS_FETCH(IDX, Z0, Z1) \
+  "v_readlane_b32 s81, %[pack], " IDX "\n" \
+  "v_readlane_b32 s82, %[off], " IDX "\n" \
+  "s_nop 0\n" \
+  "s_and_b32 s83, s81, 0xff\n" \
+  "s_bfe_u32 s84, s81, 0x80008\n" \
+  "s_bfe_u32 s85, s81, 0x80010\n" \
+  "s_lshr_b32 s86, s81, 24\n" \
+  "s_add_i32 s87, s82, s84\n" \
+  "v_subrev_u32_e32 v81, s83, %[lane]\n" \
+  "v_subrev_u32_e32 v82, s85, %[lane]\n" \
+  "v_add_lshl_u32 v83, v81, s82, 3\n" \
+  "v_add_lshl_u32 v84, v82, s87, 3\n" \
+  "v_cmp_gt_u32_e32 vcc, s86, v82\n" \
+  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
+  "s_add_i32 s90, s83, s84\n" \
+  "s_add_i32 s91, s85, s86\n" \
+  "v_cndmask_b32_e32 v85, 0, v84, vcc\n" \
+  "s_max_u32 s90, s90, s91\n" \
+  "v_cndmask_b32_e64 v85, v85, v83, s[88:89]\n" \
+  "global_load_dwordx2 " Z0 ", v85, %[E]\n" \
+  "s_cmpk_lt_u32 s90, 0x41\n" \
+  "s_cbranch_scc1 1f\n" \
+  "v_subrev_u32_e32 v81, s83, %[lane64]\n" \
+  "v_subrev_u32_e32 v82, s85, %[lane64]\n" \
+  "v_add_lshl_u32 v83, v81, s82, 3\n" \
+  "v_add_lshl_u32 v84, v82, s87, 3\n" \
+  "v_cmp_gt_u32_e32 vcc, s86, v82\n" \
+  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
+  "s_nop 1\n" \
+  "v_cndmask_b32_e32 v86, 0, v84, vcc\n" \
+  "s_nop 0\n" \
+  "v_cndmask_b32_e64 v86, v86, v83, s[88:89]\n" \
+  "global_load_dwordx2 " Z1 ", v86, %[E]\n" \
+  "s_branch 2f\n" \
+  "1:\n" \
+  "global_load_dwordx2 " Z1 ", v88, %[E]\n" \
+  "2:\n"
+#define AGX_PGS_DPP(CTRL) "s_nop 1\nv_add_f32_dpp v80, v80, v80 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define AGX_PGS_STEP(XJ0, XC0, XJ1, XC1, Z0, Z1) \
+  "s_add_i32 s80, %[r], 3\n" \
+  "s_min_i32 s80, s80, %[last]\n" \
+  AGX_PGS_FETCH("s80", Z0, Z1) \
+  "s_waitcnt vmcnt(6)\n" \
+  "v_mul_f32_e32 v80, " XJ0 ", %[dv0]\n" \
+  "v_fmac_f32_e32 v80, " XJ1 ", %[dv1]\n" \
+  AGX_PGS_DPP("quad_perm:[1,0,3,2]") AGX_PGS_DPP("quad_perm:[2,3,0,1]") AGX_PGS_DPP("row_shr:4") \
+  AGX_PGS_DPP("row_shr:8") AGX_PGS_DPP("row_bcast:15") AGX_PGS_DPP("row_bcast:31") \
+  "s_nop 1\n" \
+  "v_readlane_b32 s92, v80, 63\n" \
+  "v_cmp_eq_u32_e32 vcc, %[r], %[lane]\n" \
+  "s_nop 1\n" \
+  "v_subrev_f32_e32 v80, s92, %[b]\n" \
+  "v_fma_f32 v80, %[invD], v80, %[lam]\n" \
+  "v_med3_f32 v80, v80, %[lo], %[hi]\n" \
+  "v_sub_f32_e32 v87, v80, %[lam]\n" \
+  "v_cndmask_b32_e32 %[lam], %[lam], v80, vcc\n" \
+  "s_nop 0\n" \
+  "v_readlane_b32 s93, v87, %[r]\n" \
+  "s_add_i32 %[r], %[r], 1\n" \
+  "s_cmp_ge_i32 %[r], %[l1]\n" \
+  "s_nop 0\n" \
+  "v_fmac_f32_e32 %[dv0], s93, " XC0 "\n" \
+  "v_fmac_f32_e32 %[dv1], s93, " XC1 "\n" \
+  "s_cbranch_scc1 9f\n"
+// lo/hi are the per-lane bounds of this sweep (for friction sets already scaled by the normal impulses)
+AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int lane, int l0, int l1, float& dv0, float& dv1) {
+  if (l1 <= l0) return;
+  int r = l0; const int last = l1 - 1, lane64 = lane + 64;
+  asm volatile(
+    "v_mov_b32_e32 v88, 0\n"
+    "s_min_i32 s80, %[r], %[last]\n"
+    AGX_PGS_FETCH("s80", "v[64:65]", "v[66:67]")
+    "s_add_i32 s80, %[r], 1\n"
+    "s_min_i32 s80, s80, %[last]\n"
+    AGX_PGS_FETCH("s80", "v[68:69]", "v[70:71]")
+    "s_add_i32 s80, %[r], 2\n"
+    "s_min_i32 s80, s80, %[last]\n"
+    AGX_PGS_FETCH("s80", "v[72:73]", "v[74:75]")
+    "8:\n"
+    AGX_PGS_STEP("v64", "v65", "v66", "v67", "v[76:77]", "v[78:79]")
+    AGX_PGS_STEP("v68", "v69", "v70", "v71", "v[64:65]", "v[66:67]")
+    AGX_PGS_STEP("v72", "v73", "v74", "v75", "v[68:69]", "v[70:71]")
+    AGX_PGS_STEP("v76", "v77", "v78", "v79", "v[72:73]", "v[74:75]")
+    "s_branch 8b\n"
+    "9:\n"
+    "s_waitcnt vmcnt(0)\n"
+    : [lam] "+v"(S.lam), [dv0] "+v"(dv0), [dv1] "+v"(dv1), [r] "+s"(r)
+    : [pack] "v"(S.pack), [off] "v"(S.off), [invD] "v"(S.invD), [b] "v"(S.b), [lo] "v"(lo), [hi] "v"(hi),
+      [lane] "v"(lane), [lane64] "v"(lane64), [E] "s"(E), [l1] "s"(l1), [last] "s"(last)
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+      "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88",
+      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "vcc", "scc", "memory");
+}
+#endif
 template <bool FRICTION>
 AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int lane, int l0, int l1, float& dv0, float& dv1) {
   if (l1 <= l0) return;
-  float aj0, ac0, aj1, ac1, bj0 = 0.f, bc0 = 0.f, bj1 = 0.f, bc1 = 0.f;
-  pgs_fetch(E, lane, wave_bcast_i(S.pack, l0), wave_bcast_i(S.off, l0), aj0, ac0, aj1, ac1);
-  if (l0 + 1 < l1) pgs_fetch(E, lane, wave_bcast_i(S.pack, l0 + 1), wave_bcast_i(S.off, l0 + 1), bj0, bc0, bj1, bc1);
-  for (int rl = l0; rl < l1; rl++) {
-    const float j0 = aj0, c0 = ac0, j1 = aj1, c1 = ac1;
-    aj0 = bj0; ac0 = bc0; aj1 = bj1; ac1 = bc1;
-    if (rl + 2 < l1) pgs_fetch(E, lane, wave_bcast_i(S.pack, rl + 2), wave_bcast_i(S.off, rl + 2), bj0, bc0, bj1, bc1);
-    const float jdv = wave_sum(j0 * dv0 + j1 * dv1);
-    const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
-    const float nl = wave_clamp(S.lam + (S.b - jdv) * S.invD, lo, hi);
-    const float dlo = nl - S.lam;
-    S.lam = (lane == rl) ? nl : S.lam;
-    const float dl = wave_bcast(dlo, rl);
-    dv0 += c0 * dl; dv1 += c1 * dl;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
+  pgs_sweep_asm(S, lo, hi, E, lane, l0, l1, dv0, dv1);
+#else
+  PgsBuf A, B, C;
+  const int last = l1 - 1;
+#define AGX_PGS_FETCH_C(X, r) { const int rr_ = (r) < last ? (r) : last; pgs_fetch(E, lane, wave_bcast_i(S.pack, rr_), wave_bcast_i(S.off, rr_), X); }
+  AGX_PGS_FETCH_C(A, l0);
+  AGX_PGS_FETCH_C(B, l0 + 1);
+  for (int rl = l0;; rl += 3) {
+    AGX_PGS_FETCH_C(C, rl + 2);
+    pgs_row<FRICTION>(S, lam_normal, A, lane, rl, dv0, dv1);
+    if (rl + 1 >= l1) break;
+    AGX_PGS_FETCH_C(A, rl + 3);
+    pgs_row<FRICTION>(S, lam_normal, B, lane, rl + 1, dv0, dv1);
+    if (rl + 2 >= l1) break;
+    AGX_PGS_FETCH_C(B, rl + 4);
+    pgs_row<FRICTION>(S, lam_normal, C, lane, rl + 2, dv0, dv1);
+    if (rl + 3 >= l1) break;
   }
+#undef AGX_PGS_FETCH_C
+#endif
 }
 AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet& S) {
   ok = ok && row < MAX_ROWS;

@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- imported BEFORE libagx.so is opened: torch ships 
 #                process must end up with ONE HIP runtime (libagx binds to the already loaded one by soname)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libagx.so')
+LIB_PATH = os.environ.get('AGX_LIB', os.path.join(HERE, 'lib', 'libagx.so'))   # AGX_LIB: A/B builds of the same library
 _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',

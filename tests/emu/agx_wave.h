@@ -62,3 +62,4 @@ AGX_DEV int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 AGX_DEV int wave_scan_excl(int x) { const uint32_t* s = emu::exchange((uint32_t)x); int t = 0; for (int i = 0; i < emu::W->cur; i++) t += (int)s[i]; return t; }
 AGX_DEV long long wave_clock() { return 0; }
 AGX_DEV float wave_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+AGX_DEV void wave_opaque(float&) {}
