@@ -29,7 +29,7 @@ constexpr int MAX_ROWS = 160;
 constexpr int ST_WORDS = 336;
 constexpr int CON_STRIDE = 16;
 constexpr int HDR_STRIDE = 8;
-constexpr int ARENA_WORDS = 4352;
+constexpr int ARENA_WORDS = 3520;
 constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
 
 // ---- LDS layout (float words) -------------------------------------------------------------
@@ -44,12 +44,11 @@ constexpr int L_FIINV = L_FREER + MAX_FREE * 9;          // [MAX_FREE][9]
 constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
 constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
 constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
-constexpr int L_CON = L_MISC + 32;                       // [MAX_CON][CON_STRIDE]
-constexpr int L_ARENA = L_CON + MAX_CON * CON_STRIDE;
+constexpr int L_ARENA = L_MISC + 32;                     // contact records live in the per-env global scratch, not in LDS
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
 static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
 constexpr int LDS_BYTES = LDS_WORDS * 4;
-constexpr int LDS_SOLVE_WORDS = L_CON;                  // the solve kernel only needs the state copy and the frame tables
+constexpr int LDS_SOLVE_WORDS = L_ARENA;                 // the solve kernel only needs the state copy and the frame tables
 constexpr int LDS_SOLVE_BYTES = LDS_SOLVE_WORDS * 4;
 // arena, dynamics phase
 constexpr int A_COMW = 0;                                // [MAX_DOF][3] rel. ref
@@ -349,6 +348,9 @@ AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out) {
   const float* AB = c.lds + L_ARENA;
   v3 shift = mk3(0.5f * (AB[ABS * ca] + AB[ABS * ca + 3]), 0.5f * (AB[ABS * ca + 1] + AB[ABS * ca + 4]), 0.5f * (AB[ABS * ca + 2] + AB[ABS * ca + 5]));
   gjk_shape sa, sb; make_shape(c, ca, shift, sa); make_shape(c, cb, shift, sb);
+#ifdef AGX_EMU_TRACE
+  if (!(sa.p.x == sa.p.x) || !(sb.p.x == sb.p.x) || !(sb.R.a[0] == sb.R.a[0])) printf("NANPAIR ca %d cb %d shift %g sa.p %g sb.p %g sbR %g\n", ca, cb, shift.x, sa.p.x, sb.p.x, sb.R.a[0]);
+#endif
   // large static world boxes (table top, ground): clip to the neighbourhood of A (see oracle)
   if (CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && sb.n == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
     sb.box = true;
@@ -379,7 +381,7 @@ AGX_DEV float pair_mu(const Ctx& c, int ca, int cb) {
   return mua * mub;
 }
 AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
-  float* o = c.lds + L_CON + CON_STRIDE * slot; int* oi = (int*)o;
+  float* o = c.gcon + CON_STRIDE * slot; int* oi = (int*)o;
   oi[C_CA] = ca; oi[C_CB] = cb; oi[C_BA] = CLI(c, ca, AGX_C_BODY); oi[C_BB] = CLI(c, cb, AGX_C_BODY);
   st3(o + C_PA, k.pa); st3(o + C_PB, k.pb); st3(o + C_N, k.n); o[C_DIST] = k.dist; o[C_MU] = pair_mu(c, ca, cb); o[C_LAM] = 0.f;
 }
@@ -392,7 +394,7 @@ AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
 //      them, in order) become contacts.
 // The contact order (group, a, selection order) is what the oracle produces, so the solver rows
 // are identical.
-constexpr int WL_MAX = 280, CAND_STRIDE = 8;
+constexpr int WL_MAX = 192, CAND_STRIDE = 8;
 constexpr int A_WL = ABS * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18
 constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, n, dist (pb = pa - dist n)
 static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
@@ -782,7 +784,7 @@ AGX_DEV void build_rows(Ctx& c) {
   int ba = 0, bb = 0; v3 pa = mk3(0, 0, 0), pb = pa, nn = pa; float dist = 0.f, mu = 0.f;
   RowGeom rn; row_clear(rn);
   if (has) {
-    const float* k = L + L_CON + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const float* k = c.gcon + CON_STRIDE * lane; const int* ki = (const int*)k;
     ba = ki[C_BA]; bb = ki[C_BB]; pa = ld3(k + C_PA); pb = ld3(k + C_PB); nn = ld3(k + C_N); dist = k[C_DIST]; mu = k[C_MU];
     row_pair(c, rn, ba, pa, bb, pb, nn, mk3(0, 0, 0));
   }
@@ -1192,11 +1194,10 @@ AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction
 #undef AGX_TICK
   // hand-over to the solve kernel
   for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
-  for (int k = lane; k < c.ncon * CON_STRIDE; k += 64) scr.con[k] = L[L_CON + k];
   if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; }
   if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
     if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // [4..4+ndof) = qdd
-    for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = L[L_CON + q];
+    for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = scr.con[q];
     for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[16 + MAX_CON * CON_STRIDE + q] = L[L_MINV + q];
     wave_sync();
     for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = scr.hdr[q];
@@ -1236,7 +1237,6 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
   Scratch scr = scratch_of(gscratch);
   c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.near_mask = scr.meta[META_NEAR];
   load_env(c, gstate, sw);
-  for (int k = lane; k < c.ncon * CON_STRIDE; k += 64) L[L_CON + k] = scr.con[k];
   float an2 = 0.f;
   for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
   wave_sync();
@@ -1245,7 +1245,7 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
   // get_total_force (feeding.py:45-48) from the last substep's contact impulses
   float rf = 0.f, tf = 0.f;
   if (lane < c.ncon) {
-    const float* k = L + L_CON + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const float* k = scr.con + CON_STRIDE * lane; const int* ki = (const int*)k;
     int ta = CLI(c, ki[C_CA], AGX_C_TAG), tb = CLI(c, ki[C_CB], AGX_C_TAG);
     if (ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN) {
       int other = ta == AGX_TAG_HUMAN ? tb : ta; float f = k[C_LAM] / c.dt;
@@ -1274,7 +1274,7 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
       v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
       for (int k = 0; k < 3; k++) {
         float hh = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
-        AB[6 * col + k] = comp(cw, k) - hh; AB[6 * col + 3 + k] = comp(cw, k) + hh;
+        AB[ABS * col + k] = comp(cw, k) - hh; AB[ABS * col + 3 + k] = comp(cw, k) + hh;
       }
     }
     wave_sync();
@@ -1307,7 +1307,7 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
         const int tc = base + lane; bool hitl = false;
         if (tc < tool1) {
           bool sep = false;
-          for (int q = 0; q < 3; q++) if (AB[6 * fc + q] > AB[6 * tc + 3 + q] + spill || AB[6 * tc + q] > AB[6 * fc + 3 + q] + spill) sep = true;
+          for (int q = 0; q < 3; q++) if (AB[ABS * fc + q] > AB[ABS * tc + 3 + q] + spill || AB[ABS * tc + q] > AB[ABS * fc + 3 + q] + spill) sep = true;
           Cand tmp; if (!sep) hitl = narrowphase(c, fc, tc, spill, tmp);
         }
         if (wave_any(hitl)) near = true;

@@ -64,3 +64,32 @@ def test_tremor_step_matches(blob, emu, oracle12):
             assert np.abs(blob.view(s1)['q'] - blob.view(s2)['q']).max() < 1e-5
             assert np.abs(blob.view(s1)['qt'] - blob.view(s2)['qt']).max() < 1e-6
             so = s1
+
+
+def test_food_events_match(blob, emu, oracle12):
+    """Finish kernel state machine (feeding.py:50-83): a particle teleported away from the spoon is
+    a spill (-5, no longer alive), one placed at the mouth target is eaten (+20, task_success)."""
+    st, _ = make_states(blob, 1, seed=3201)
+    s0 = st[0].copy()
+    oracle12.settle(s0, 3)
+    v = blob.view(s0)
+    food0 = blob.h['FOOD0']
+    # displaced diagonally: every per-axis box gap to the spoon stays below the 0.1 m query distance but
+    # the true distance exceeds it, so the spill decision rests on the narrowphase, not on the box test
+    v['free'][0, food0 + 0, :3] += np.array([-0.095, -0.095, 0.095], dtype=np.float32)
+    v['free'][0, food0 + 0, 7:13] = 0.0
+    # released 4.5 cm above the mouth target with zero velocity: after the 0.1 s of free fall of one
+    # env.step it is within the 3 cm mouth radius
+    v['free'][0, food0 + 1, :3] = v['target'][0] + np.array([0.0, 0.0, 0.045], dtype=np.float32)
+    v['free'][0, food0 + 1, 7:13] = 0.0
+    a = np.zeros(blob.act_dim, dtype=np.float32)
+    s1, s2 = s0.copy(), s0.copy()
+    o_obs, o_rew, o_done, o_info = oracle12.step(s1, a)
+    e_obs, e_rew, e_done, e_info, _ = emu.step(s2, a)
+    v1, v2 = blob.view(s1), blob.view(s2)
+    assert int(v1['food_alive'][0]) == int(v2['food_alive'][0]) and int(v1['food_active'][0]) == int(v2['food_active'][0])
+    assert int(v1['food_alive'][0]) & 3 == 0                   # both particles left the alive set
+    assert int(v1['task_success'][0]) == int(v2['task_success'][0]) == 1
+    assert abs(o_rew - e_rew) < 1e-3 and np.abs(o_obs - e_obs).max() < 1e-4
+    # the remaining particles are still on the spoon in both
+    assert bin(int(v2['food_alive'][0])).count('1') == blob.nfood - 2
