@@ -145,17 +145,12 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
   float vv = dot(v, v);
   s.p0.a = a0; s.p0.b = b0; s.p0.w = v; s.p1 = s.p0; s.p2 = s.p0; s.p3 = s.p0;
   s.n = 1; s.l0 = 1; s.l1 = 0; s.l2 = 0; s.l3 = 0;
+  pa = a0; pb = b0;
   bool pen = false;
   for (int it = 0; it < maxit; it++) {
-#ifdef AGX_EMU_TRACE
-    printf("GJKIT %d\n", it);
-#endif
     if (vv < 1e-12f) { pen = true; break; }   /* cores closer than 1 micron: treat as overlapping */
     v3 wa = gjk_support(sa, -v), wb = gjk_support(sb, v), w = wa - wb;
     float vw = dot(v, w);
-#ifdef AGX_EMU_TRACE
-    printf("GJKV na %d nb %d it %d n %d vv %.9g vw %.9g\n", sa.n, sb.box ? -8 : sb.n, it, s.n, vv, vw);
-#endif
     if (vv - vw <= tol * vv) break;
     const bool e0 = s.p0.w.x == w.x && s.p0.w.y == w.y && s.p0.w.z == w.z;
     const bool e1 = s.n > 1 && s.p1.w.x == w.x && s.p1.w.y == w.y && s.p1.w.z == w.z;
@@ -167,17 +162,14 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
     v3 vn;
     if (gjk_solve(s, vn)) { pen = true; break; }
     float vvn = dot(vn, vn);
-    v = vn;
-    if (vvn >= vv) { vv = vvn; break; }
-    vv = vvn;
+    // no progress (a degenerate sub-simplex solve can even move away): keep the closest points found so far
+    if (vvn >= vv) break;
+    v = vn; vv = vvn;
+    pa = s.l0 * s.p0.a; pb = s.l0 * s.p0.b;
+    if (s.n > 1) { pa = pa + s.l1 * s.p1.a; pb = pb + s.l1 * s.p1.b; }
+    if (s.n > 2) { pa = pa + s.l2 * s.p2.a; pb = pb + s.l2 * s.p2.b; }
   }
-#ifdef AGX_EMU_TRACE
-  printf("GJK na %d nb %d pen %d n %d\n", sa.n, sb.box ? -8 : sb.n, (int)pen, s.n);
-#endif
   if (pen) { dist = 0; return true; }
-  pa = s.l0 * s.p0.a; pb = s.l0 * s.p0.b;
-  if (s.n > 1) { pa = pa + s.l1 * s.p1.a; pb = pb + s.l1 * s.p1.b; }
-  if (s.n > 2) { pa = pa + s.l2 * s.p2.a; pb = pb + s.l2 * s.p2.b; }
   dist = sqrtf(vv);
   return false;
 }

@@ -34,11 +34,11 @@ constexpr int ABS = 7;                                   // collider table strid
 
 // ---- LDS layout (float words) -------------------------------------------------------------
 constexpr int L_ST = 0;
-constexpr int L_LINKP = L_ST + ST_WORDS;                 // [MAX_DOF][3] world
+constexpr int L_VEL = L_ST + ST_WORDS;                   // [128] generalised velocities v*
+constexpr int L_LINKP = L_VEL + 128;                     // [MAX_DOF][3] world
 constexpr int L_LINKR = L_LINKP + MAX_DOF * 3;           // [MAX_DOF][9]
 constexpr int L_S = L_LINKR + MAX_DOF * 9;               // [MAX_DOF][6] joint screw about the ref point
-constexpr int L_VEL = L_S + MAX_DOF * 6;                 // [128] generalised velocities v*
-constexpr int L_MINV = L_VEL + 128;                      // [MAX_DOF*MAX_DOF]
+constexpr int L_MINV = L_S + MAX_DOF * 6;                // [MAX_DOF*MAX_DOF]
 constexpr int L_FREER = L_MINV + MAX_DOF * MAX_DOF;      // [MAX_FREE][9]
 constexpr int L_FIINV = L_FREER + MAX_FREE * 9;          // [MAX_FREE][9]
 constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
@@ -48,7 +48,13 @@ constexpr int L_ARENA = L_MISC + 32;                     // contact records live
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
 static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
 constexpr int LDS_BYTES = LDS_WORDS * 4;
-constexpr int LDS_SOLVE_WORDS = L_ARENA;                 // the solve kernel only needs the state copy and the frame tables
+// the solve kernel keeps the state copy, the velocity vector and a window of the first
+// SOLVE_LDS_PAIRS (J,B) pairs of the environment's rows in LDS (16 waves x 9.5 KB fill a CU's 160 KB);
+// rows beyond the window stream from the global scratch (L2)
+constexpr int L_SOLVE_ENT = L_VEL + 128;
+constexpr int SOLVE_LDS_PAIRS = 960;
+static_assert(L_SOLVE_ENT % 2 == 0, "(J,B) pairs are read as 8-byte words");
+constexpr int LDS_SOLVE_WORDS = L_SOLVE_ENT + 2 * SOLVE_LDS_PAIRS;
 constexpr int LDS_SOLVE_BYTES = LDS_SOLVE_WORDS * 4;
 // arena, dynamics phase
 constexpr int A_COMW = 0;                                // [MAX_DOF][3] rel. ref
@@ -78,7 +84,7 @@ constexpr int DBG_HDR = 16 + MAX_CON * CON_STRIDE + MAX_DOF * MAX_DOF, DBG_LAM =
 constexpr int SCR_ENT = 4096, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
 constexpr int SCR_WORDS = SCR_O_META + SCR_META;
-constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4;
+constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_FRIC = 6, H_MU = 7;
 
 struct Ctx {
@@ -93,6 +99,7 @@ struct Ctx {
   int ncon, nrows, first_normal, near_mask, overflow;
   float* dbg;   // optional debug sink (parity tests)
   float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
+  int nent;             // (J,B) pairs written by build_rows (entry 0 is the zero pair)
   float* gcon;          // contact records handed from the build kernel to the solve / finish kernels
   long long tm[16]; bool timing;   // per-phase shader-clock totals (debug path only)
 };
@@ -120,7 +127,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
   c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0;
   c.dt = PRM(c, AGX_P_DT);
-  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr;
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 
@@ -348,9 +355,6 @@ AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out) {
   const float* AB = c.lds + L_ARENA;
   v3 shift = mk3(0.5f * (AB[ABS * ca] + AB[ABS * ca + 3]), 0.5f * (AB[ABS * ca + 1] + AB[ABS * ca + 4]), 0.5f * (AB[ABS * ca + 2] + AB[ABS * ca + 5]));
   gjk_shape sa, sb; make_shape(c, ca, shift, sa); make_shape(c, cb, shift, sb);
-#ifdef AGX_EMU_TRACE
-  if (!(sa.p.x == sa.p.x) || !(sb.p.x == sb.p.x) || !(sb.R.a[0] == sb.R.a[0])) printf("NANPAIR ca %d cb %d shift %g sa.p %g sb.p %g sbR %g\n", ca, cb, shift.x, sa.p.x, sb.p.x, sb.R.a[0]);
-#endif
   // large static world boxes (table top, ground): clip to the neighbourhood of A (see oracle)
   if (CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && sb.n == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
     sb.box = true;
@@ -438,9 +442,6 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   wave_sync();
   long long ct0 = c.timing ? wave_clock() : 0;
   if (c.timing) { c.tm[13] += wn; c.tm[14] += (wn + 63) / 64; }   // debug: narrowphase pairs / passes
-#ifdef AGX_EMU_TRACE
-  if (c.timing && lane == 0) { for (int i = 0; i < wn; i++) printf("WL %d %d %d\n", WL[i] >> 18, WL[i] & 511, (WL[i] >> 9) & 511); }
-#endif
   // 3. narrowphase, 64 pairs per pass
   bool any_manifold_query = false;
   for (int base = 0; base < wn; base += 64) {
@@ -807,7 +808,7 @@ AGX_DEV void build_rows(Ctx& c) {
     RowGeom rf; row_pair(c, rf, ba, pa, bb, pb, t, mk3(0, 0, 0));
     row_store(c, rf, nnc + nc + lane, entF + cincl - ccnt, -row_velocity(c, rf), 0.f, 0.f, nnc + lane, mu);
   }
-  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc;
+  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0);
   wave_sync();
 }
 
@@ -864,7 +865,7 @@ AGX_DEV void pgs_row(PgsSet& S, const float& lam_normal, const PgsBuf& X, int la
   wave_opaque(dv0);       // keeps the two updates scalar: a packed FMA would need (c0, c1) in adjacent registers
   dv1 += X.c1 * dl;
 }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_PGS_CPP)
 // ---- the Gauss-Seidel sweep in gfx950 assembly ------------------------------------------------------
 // The compiler's schedule of the loop above is poor in exactly the places that matter: it rotates
 // the prefetch buffers with register moves and, because the number of loads in flight differs between
@@ -876,8 +877,17 @@ AGX_DEV void pgs_row(PgsSet& S, const float& lam_normal, const PgsBuf& X, int la
 // Hazards (gfx940 family; the assembler inserts nothing in inline asm): VALU-written VGPR -> DPP 2
 // wait states, VALU-written SGPR/VCC -> VALU read 2, -> v_readlane lane select 4; spacing below
 // keeps to these with independent instructions or s_nop.
-// Register map: v64..v79 buffers, v80..v88 temporaries, s80..s93 scalars.
-#define AGX_PGS_FETCH(IDX, Z0, Z1) \
+// Register map: v64..v79 buffers, v80..v88 temporaries, s80..s95 scalars.
+#define AGX_STR2(x) #x
+#define AGX_STR(x) AGX_STR2(x)
+#define AGX_SOLVE_ENT_BYTES 1856
+static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row window used by the assembly");
+// the two sources of a row's pairs: the global scratch (vmcnt) or the LDS window (lgkmcnt)
+#define AGX_LOAD_G(DST, ADDR) "global_load_dwordx2 " DST ", " ADDR ", %[E]\n"
+#define AGX_LOAD_L(DST, ADDR) "ds_read_b64 " DST ", " ADDR " offset:" AGX_STR(AGX_SOLVE_ENT_BYTES) "\n"
+#define AGX_WAIT_G(N) "s_waitcnt vmcnt(" N ")\n"
+#define AGX_WAIT_L(N) "s_waitcnt lgkmcnt(" N ")\n"
+#define AGX_PGS_FETCH(LOAD, IDX, Z0, Z1) \
   "v_readlane_b32 s81, %[pack], " IDX "\n" \
   "v_readlane_b32 s82, %[off], " IDX "\n" \
   "s_nop 0\n" \
@@ -897,7 +907,7 @@ AGX_DEV void pgs_row(PgsSet& S, const float& lam_normal, const PgsBuf& X, int la
   "v_cndmask_b32_e32 v85, 0, v84, vcc\n" \
   "s_max_u32 s90, s90, s91\n" \
   "v_cndmask_b32_e64 v85, v85, v83, s[88:89]\n" \
-  "global_load_dwordx2 " Z0 ", v85, %[E]\n" \
+  LOAD(Z0, "v85") \
   "s_cmpk_lt_u32 s90, 0x41\n" \
   "s_cbranch_scc1 1f\n" \
   "v_subrev_u32_e32 v81, s83, %[lane64]\n" \
@@ -910,75 +920,122 @@ AGX_DEV void pgs_row(PgsSet& S, const float& lam_normal, const PgsBuf& X, int la
   "v_cndmask_b32_e32 v86, 0, v84, vcc\n" \
   "s_nop 0\n" \
   "v_cndmask_b32_e64 v86, v86, v83, s[88:89]\n" \
-  "global_load_dwordx2 " Z1 ", v86, %[E]\n" \
+  LOAD(Z1, "v86") \
   "s_branch 2f\n" \
   "1:\n" \
-  "global_load_dwordx2 " Z1 ", v88, %[E]\n" \
+  LOAD(Z1, "v88") \
   "2:\n"
-#define AGX_PGS_DPP(CTRL) "s_nop 1\nv_add_f32_dpp v80, v80, v80 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-#define AGX_PGS_STEP(XJ0, XC0, XJ1, XC1, Z0, Z1) \
+#define AGX_PGS_DPP(CTRL) "v_add_f32_dpp v80, v80, v80 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// One row: the dependent chain (dot product, 6-step DPP reduction, impulse update, broadcast) with the
+// address arithmetic of the prefetch for row r+3 woven into its wait states.
+#define AGX_PGS_STEP(LOAD, WAIT, XJ0, XC0, XJ1, XC1, Z0, Z1) \
   "s_add_i32 s80, %[r], 3\n" \
   "s_min_i32 s80, s80, %[last]\n" \
-  AGX_PGS_FETCH("s80", Z0, Z1) \
-  "s_waitcnt vmcnt(6)\n" \
+  WAIT("4") \
   "v_mul_f32_e32 v80, " XJ0 ", %[dv0]\n" \
   "v_fmac_f32_e32 v80, " XJ1 ", %[dv1]\n" \
-  AGX_PGS_DPP("quad_perm:[1,0,3,2]") AGX_PGS_DPP("quad_perm:[2,3,0,1]") AGX_PGS_DPP("row_shr:4") \
-  AGX_PGS_DPP("row_shr:8") AGX_PGS_DPP("row_bcast:15") AGX_PGS_DPP("row_bcast:31") \
-  "s_nop 1\n" \
+  "v_readlane_b32 s81, %[pack], s80\n" \
+  "v_readlane_b32 s82, %[off], s80\n" \
+  AGX_PGS_DPP("quad_perm:[1,0,3,2]") \
+  "s_and_b32 s83, s81, 0xff\n" \
+  "s_bfe_u32 s84, s81, 0x80008\n" \
+  AGX_PGS_DPP("quad_perm:[2,3,0,1]") \
+  "s_bfe_u32 s85, s81, 0x80010\n" \
+  "s_lshr_b32 s86, s81, 24\n" \
+  AGX_PGS_DPP("row_shr:4") \
+  "s_add_i32 s87, s82, s84\n" \
+  "v_subrev_u32_e32 v81, s83, %[lane]\n" \
+  AGX_PGS_DPP("row_shr:8") \
+  "v_subrev_u32_e32 v82, s85, %[lane]\n" \
+  "v_add_lshl_u32 v83, v81, s82, 3\n" \
+  AGX_PGS_DPP("row_bcast:15") \
+  "v_add_lshl_u32 v84, v82, s87, 3\n" \
+  "v_cmp_gt_u32_e64 s[94:95], s86, v82\n" \
+  AGX_PGS_DPP("row_bcast:31") \
+  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
+  "s_add_i32 s90, s83, s84\n" \
   "v_readlane_b32 s92, v80, 63\n" \
+  "s_add_i32 s91, s85, s86\n" \
+  "v_cndmask_b32_e64 v85, 0, v84, s[94:95]\n" \
   "v_cmp_eq_u32_e32 vcc, %[r], %[lane]\n" \
-  "s_nop 1\n" \
   "v_subrev_f32_e32 v80, s92, %[b]\n" \
+  "s_max_u32 s90, s90, s91\n" \
+  "v_cndmask_b32_e64 v85, v85, v83, s[88:89]\n" \
   "v_fma_f32 v80, %[invD], v80, %[lam]\n" \
+  LOAD(Z0, "v85") \
   "v_med3_f32 v80, v80, %[lo], %[hi]\n" \
+  "s_cmpk_lt_u32 s90, 0x41\n" \
   "v_sub_f32_e32 v87, v80, %[lam]\n" \
   "v_cndmask_b32_e32 %[lam], %[lam], v80, vcc\n" \
+  "s_cbranch_scc1 1f\n" \
+  "v_subrev_u32_e32 v81, s83, %[lane64]\n" \
+  "v_subrev_u32_e32 v82, s85, %[lane64]\n" \
+  "v_add_lshl_u32 v83, v81, s82, 3\n" \
+  "v_add_lshl_u32 v84, v82, s87, 3\n" \
+  "v_cmp_gt_u32_e64 s[94:95], s86, v82\n" \
+  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
   "s_nop 0\n" \
+  "v_cndmask_b32_e64 v86, 0, v84, s[94:95]\n" \
+  "s_nop 0\n" \
+  "v_cndmask_b32_e64 v86, v86, v83, s[88:89]\n" \
+  LOAD(Z1, "v86") \
+  "s_branch 2f\n" \
+  "1:\n" \
+  LOAD(Z1, "v88") \
+  "2:\n" \
   "v_readlane_b32 s93, v87, %[r]\n" \
   "s_add_i32 %[r], %[r], 1\n" \
   "s_cmp_ge_i32 %[r], %[l1]\n" \
-  "s_nop 0\n" \
   "v_fmac_f32_e32 %[dv0], s93, " XC0 "\n" \
   "v_fmac_f32_e32 %[dv1], s93, " XC1 "\n" \
   "s_cbranch_scc1 9f\n"
-// lo/hi are the per-lane bounds of this sweep (for friction sets already scaled by the normal impulses)
-AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int lane, int l0, int l1, float& dv0, float& dv1) {
-  if (l1 <= l0) return;
-  int r = l0; const int last = l1 - 1, lane64 = lane + 64;
-  asm volatile(
-    "v_mov_b32_e32 v88, 0\n"
-    "s_min_i32 s80, %[r], %[last]\n"
-    AGX_PGS_FETCH("s80", "v[64:65]", "v[66:67]")
-    "s_add_i32 s80, %[r], 1\n"
-    "s_min_i32 s80, s80, %[last]\n"
-    AGX_PGS_FETCH("s80", "v[68:69]", "v[70:71]")
-    "s_add_i32 s80, %[r], 2\n"
-    "s_min_i32 s80, s80, %[last]\n"
-    AGX_PGS_FETCH("s80", "v[72:73]", "v[74:75]")
-    "8:\n"
-    AGX_PGS_STEP("v64", "v65", "v66", "v67", "v[76:77]", "v[78:79]")
-    AGX_PGS_STEP("v68", "v69", "v70", "v71", "v[64:65]", "v[66:67]")
-    AGX_PGS_STEP("v72", "v73", "v74", "v75", "v[68:69]", "v[70:71]")
-    AGX_PGS_STEP("v76", "v77", "v78", "v79", "v[72:73]", "v[74:75]")
-    "s_branch 8b\n"
-    "9:\n"
-    "s_waitcnt vmcnt(0)\n"
-    : [lam] "+v"(S.lam), [dv0] "+v"(dv0), [dv1] "+v"(dv1), [r] "+s"(r)
-    : [pack] "v"(S.pack), [off] "v"(S.off), [invD] "v"(S.invD), [b] "v"(S.b), [lo] "v"(lo), [hi] "v"(hi),
-      [lane] "v"(lane), [lane64] "v"(lane64), [E] "s"(E), [l1] "s"(l1), [last] "s"(last)
-    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
-      "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88",
-      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "vcc", "scc", "memory");
+#define AGX_PGS_BODY(LOAD, WAIT) \
+    "v_mov_b32_e32 v88, 0\n" \
+    "s_min_i32 s80, %[r], %[last]\n" \
+    AGX_PGS_FETCH(LOAD, "s80", "v[64:65]", "v[66:67]") \
+    "s_add_i32 s80, %[r], 1\n" \
+    "s_min_i32 s80, s80, %[last]\n" \
+    AGX_PGS_FETCH(LOAD, "s80", "v[68:69]", "v[70:71]") \
+    "s_add_i32 s80, %[r], 2\n" \
+    "s_min_i32 s80, s80, %[last]\n" \
+    AGX_PGS_FETCH(LOAD, "s80", "v[72:73]", "v[74:75]") \
+    "8:\n" \
+    AGX_PGS_STEP(LOAD, WAIT, "v64", "v65", "v66", "v67", "v[76:77]", "v[78:79]") \
+    AGX_PGS_STEP(LOAD, WAIT, "v68", "v69", "v70", "v71", "v[64:65]", "v[66:67]") \
+    AGX_PGS_STEP(LOAD, WAIT, "v72", "v73", "v74", "v75", "v[68:69]", "v[70:71]") \
+    AGX_PGS_STEP(LOAD, WAIT, "v76", "v77", "v78", "v79", "v[72:73]", "v[74:75]") \
+    "s_branch 8b\n" \
+    "9:\n" \
+    WAIT("0")
+#define AGX_PGS_OPERANDS \
+    : [lam] "+v"(S.lam), [dv0] "+v"(dv0), [dv1] "+v"(dv1), [r] "+s"(r) \
+    : [pack] "v"(S.pack), [off] "v"(S.off), [invD] "v"(S.invD), [b] "v"(S.b), [lo] "v"(lo), [hi] "v"(hi), \
+      [lane] "v"(lane), [lane64] "v"(lane64), [E] "s"(E), [l1] "s"(l1), [last] "s"(last) \
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", \
+      "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", \
+      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc", "memory"
+// lo/hi are the per-lane bounds of this sweep (for friction sets already scaled by the normal
+// impulses).  Rows [l0, ls) have all their pairs inside the LDS window, rows [ls, l1) stream from global.
+AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int lane, int l0, int ls, int l1, float& dv0, float& dv1) {
+  const int lane64 = lane + 64;
+  if (ls > l0) {
+    int r = l0; const int l1 = ls, last = ls - 1;
+    asm volatile(AGX_PGS_BODY(AGX_LOAD_L, AGX_WAIT_L) AGX_PGS_OPERANDS);
+  }
+  if (l1 > ls) {
+    int r = ls; const int last = l1 - 1;
+    asm volatile(AGX_PGS_BODY(AGX_LOAD_G, AGX_WAIT_G) AGX_PGS_OPERANDS);
+  }
 }
 #endif
 template <bool FRICTION>
-AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int lane, int l0, int l1, float& dv0, float& dv1) {
+AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int lane, int l0, int ls, int l1, float& dv0, float& dv1) {
   if (l1 <= l0) return;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_PGS_CPP)
   const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
-  pgs_sweep_asm(S, lo, hi, E, lane, l0, l1, dv0, dv1);
+  pgs_sweep_asm(S, lo, hi, E, lane, l0, ls, l1, dv0, dv1);
 #else
+  (void)ls;
   PgsBuf A, B, C;
   const int last = l1 - 1;
 #define AGX_PGS_FETCH_C(X, r) { const int rr_ = (r) < last ? (r) : last; pgs_fetch(E, lane, wave_bcast_i(S.pack, rr_), wave_bcast_i(S.off, rr_), X); }
@@ -1008,6 +1065,16 @@ AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet&
   S.lo = live ? H[H_LO] : 0.f; S.hi = live ? (friction ? H[H_MU] : H[H_HI]) : 0.f;
   S.pack = ok ? Hi[H_PACK] : 0; S.off = ok ? Hi[H_OFF] : 0;
 }
+// first lane of [l0, l1) whose row reaches beyond the LDS window of (J,B) pairs (l1 if none)
+AGX_DEV int pgs_lds_split(const PgsSet& S, int lane, int l0, int l1) {
+  if (l1 <= l0) return l0;
+#ifdef AGX_NO_LDS_ROWS
+  return l0;
+#endif
+  const int end = S.off + ((S.pack >> 8) & 255) + (int)((unsigned)S.pack >> 24);
+  const uint64_t m = wave_ballot(lane >= l0 && lane < l1 && end > SOLVE_LDS_PAIRS);
+  return wave_uniform(m ? ffs64(m) : l1);
+}
 AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER);
   const float* E = c.E;
@@ -1023,11 +1090,15 @@ AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   const int f0a = nnc < 64 ? nnc : 64, f0b = nA < 64 ? nA : 64;          // friction rows in B0: lanes [nnc, min(nA,64))
   const int f1a = nnc > 64 ? nnc - 64 : 0, f1b = nA - 64;                // friction rows in B1: lanes [max(nnc-64,0), nA-64)
   dv0 = 0.f; dv1 = 0.f;
+  // rows whose pairs lie inside the LDS window (offsets grow with the row index, so per register set
+  // this is a prefix of its lane range)
+  const int s0 = pgs_lds_split(A0, lane, 0, a0n), s1 = pgs_lds_split(A1, lane, 0, a1n);
+  const int t0 = pgs_lds_split(B0, lane, f0a, f0b), t1 = pgs_lds_split(B1, lane, f1a, f1b);
   for (int it = 0; it < iters; it++) {
-    pgs_sweep<false>(A0, A0.lam, E, lane, 0, a0n, dv0, dv1);
-    pgs_sweep<false>(A1, A1.lam, E, lane, 0, a1n, dv0, dv1);
-    pgs_sweep<true>(B0, A0.lam, E, lane, f0a, f0b, dv0, dv1);
-    pgs_sweep<true>(B1, A1.lam, E, lane, f1a, f1b, dv0, dv1);
+    pgs_sweep<false>(A0, A0.lam, E, lane, 0, s0, a0n, dv0, dv1);
+    pgs_sweep<false>(A1, A1.lam, E, lane, 0, s1, a1n, dv0, dv1);
+    pgs_sweep<true>(B0, A0.lam, E, lane, f0a, t0, f0b, dv0, dv1);
+    pgs_sweep<true>(B1, A1.lam, E, lane, f1a, t1, f1b, dv0, dv1);
   }
   // solved normal impulses -> contact records (what getContactPoints reports until the next step)
   { const int r0 = lane, r1 = 64 + lane;
@@ -1194,7 +1265,7 @@ AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction
 #undef AGX_TICK
   // hand-over to the solve kernel
   for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
-  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; }
+  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; }
   if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
     if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // [4..4+ndof) = qdd
     for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = scr.con[q];
@@ -1211,8 +1282,14 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
   c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
-  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC];
-  load_env(c, gstate, sw);
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nent = scr.meta[META_NENT];
+  // state copy only (the frame tables of load_env are not needed here and their LDS is the row window)
+  for (int k = lane; k < sw; k += 64) lds[L_ST + k] = gstate[k];
+  { const int np = c.nent < SOLVE_LDS_PAIRS ? c.nent : SOLVE_LDS_PAIRS;
+    const f2* src = (const f2*)scr.ent; f2* dst = (f2*)(lds + L_SOLVE_ENT);
+    for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
+  wave_sync();
+  c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0, dv1;
   pgs(c, dv0, dv1);

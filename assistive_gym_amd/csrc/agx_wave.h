@@ -84,5 +84,7 @@ AGX_DEV int wave_scan_excl(int x) {
 AGX_DEV long long wave_clock() { return (long long)__builtin_readcyclecounter(); }
 // clamp to [lo, hi] (lo <= hi) in one v_med3_f32
 AGX_DEV float wave_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+// a value known to be the same in every lane, moved to a scalar register
+AGX_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // optimisation barrier on one register value (no instruction is emitted)
 AGX_DEV void wave_opaque(float& x) { asm volatile("" : "+v"(x)); }

@@ -421,6 +421,7 @@ int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int m
   double vv = dot3(v, v);
   /* seed simplex with the first vertices so witness points are always defined */
   memcpy(A[0], a, 24); memcpy(B[0], b, 24); memcpy(W[0], v, 24); n = 1;
+  memcpy(pa, a, 24); memcpy(pb, b, 24);
   for (it = 0; it < maxit; it++) {
     if (vv < 1e-12) { pen = 1; break; }   /* cores closer than 1 micron: treat as overlapping */
     double nv[3] = {-v[0], -v[1], -v[2]};
@@ -435,14 +436,14 @@ int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int m
     double vn[3];
     if (simplex_solve(W, A, B, &n, lam, vn)) { pen = 1; break; }
     double vvn = dot3(vn, vn);
-    memcpy(v, vn, 24);
-    if (vvn >= vv) { vv = vvn; break; }
-    vv = vvn;
+    /* no progress (a degenerate sub-simplex solve can even move away): keep the closest points found so far */
+    if (vvn >= vv) break;
+    memcpy(v, vn, 24); vv = vvn;
+    pa[0] = pa[1] = pa[2] = pb[0] = pb[1] = pb[2] = 0;
+    for (int k = 0; k < n; k++) { axpy3(lam[k], A[k], pa); axpy3(lam[k], B[k], pb); }
   }
   if (iters) *iters = it;
   if (pen) { *dist = 0; return 1; }
-  pa[0] = pa[1] = pa[2] = pb[0] = pb[1] = pb[2] = 0;
-  for (int k = 0; k < n; k++) { axpy3(lam[k], A[k], pa); axpy3(lam[k], B[k], pb); }
   *dist = sqrt(vv);
   return 0;
 }

@@ -63,3 +63,4 @@ AGX_DEV int wave_scan_excl(int x) { const uint32_t* s = emu::exchange((uint32_t)
 AGX_DEV long long wave_clock() { return 0; }
 AGX_DEV float wave_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 AGX_DEV void wave_opaque(float&) {}
+AGX_DEV int wave_uniform(int x) { return x; }

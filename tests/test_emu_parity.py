@@ -93,3 +93,25 @@ def test_food_events_match(blob, emu, oracle12):
     assert abs(o_rew - e_rew) < 1e-3 and np.abs(o_obs - e_obs).max() < 1e-4
     # the remaining particles are still on the spoon in both
     assert bin(int(v2['food_alive'][0])).count('1') == blob.nfood - 2
+
+
+def test_edge_contact_is_not_lost(blob):
+    """Regression: robot link resting on the table EDGE (tests/golden/edge_contact_state.npy, captured
+    from a rollout).  The f32 GJK used to accept a degenerate last sub-simplex solve that moved away
+    from the closest point and so dropped the contact; no-progress iterations now keep the best point."""
+    import os
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    s = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'edge_contact_state.npy'))
+    b1 = blob.set_param('FRAME_SKIP', 1)
+    con = Oracle(blob).substep_debug(s.copy())
+    pairs_o = [(int(c[0]), int(c[1])) for c in con]
+    dbg = Emu(b1).step(s.copy(), np.zeros(blob.act_dim, dtype=np.float32), debug=True)[4]
+    nc = int(dbg[0])
+    ce = dbg[16:16 + 1024].reshape(64, 16)[:nc]
+    pairs_e = [(int(x), int(y)) for x, y in ce.view(np.int32)[:, :2]]
+    robot_o = [p for p in pairs_o if p[0] < 13]
+    assert robot_o, 'fixture must contain a robot contact'
+    assert pairs_e == pairs_o
+    k = pairs_o.index(robot_o[0])
+    assert abs(ce[k, 13] - con[k][11]) < 1e-5 and np.abs(ce[k, 10:13] - np.array(con[k][8:11])).max() < 1e-3

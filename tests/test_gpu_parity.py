@@ -72,7 +72,8 @@ def test_step_matches_oracle(gpu_lib, blob, oracle):
             flips += int(info[i, 6] != o_info[6])
     print('worst deviations', worst, 'contact-count flips', flips, 'of', n * steps)
     assert flips <= 0.03 * n * steps
-    assert worst['obs'] < 1e-3 and worst['reward'] < 1e-3 and worst['force'] < 1e-3 and worst['q'] < 5e-4
+    # measured on MI355X: obs / q deviations of ~1e-6 (f32 device vs f64 oracle); the bounds leave a 50x margin
+    assert worst['obs'] < 1e-4 and worst['reward'] < 1e-4 and worst['force'] < 1e-3 and worst['q'] < 5e-5
 
 
 def test_debug_internals_match_oracle(gpu_lib, blob, oracle):
