@@ -76,9 +76,18 @@ AGX_DEV void gjk_closest_tri(v3 a, v3 b, v3 c, float& wa, float& wb, float& wc) 
 struct gjk_pt { v3 w, a, b; };
 struct gjk_simplex { gjk_pt p0, p1, p2, p3; float l0, l1, l2, l3; int n; };
 
+// i-th of four values as a chain of register selects.  The operands are first pinned to registers:
+// a conditional expression over struct members is an lvalue, which the optimiser turns into a select of
+// ADDRESSES and so forces the whole simplex into scratch memory with dynamically indexed loads.
+AGX_DEV float gjk_pick(int i, float a, float b, float c, float d) {
+  wave_opaque(a); wave_opaque(b); wave_opaque(c); wave_opaque(d);
+  float r = d;
+  r = i == 2 ? c : r; r = i == 1 ? b : r; r = i == 0 ? a : r;
+  return r;
+}
 AGX_DEV gjk_pt gjk_sel(int i, const gjk_pt& a, const gjk_pt& b, const gjk_pt& c, const gjk_pt& d) {
   gjk_pt r;
-#define AGX_SEL3(f) r.f.x = i == 0 ? a.f.x : (i == 1 ? b.f.x : (i == 2 ? c.f.x : d.f.x)); r.f.y = i == 0 ? a.f.y : (i == 1 ? b.f.y : (i == 2 ? c.f.y : d.f.y)); r.f.z = i == 0 ? a.f.z : (i == 1 ? b.f.z : (i == 2 ? c.f.z : d.f.z));
+#define AGX_SEL3(f) r.f.x = gjk_pick(i, a.f.x, b.f.x, c.f.x, d.f.x); r.f.y = gjk_pick(i, a.f.y, b.f.y, c.f.y, d.f.y); r.f.z = gjk_pick(i, a.f.z, b.f.z, c.f.z, d.f.z);
   AGX_SEL3(w) AGX_SEL3(a) AGX_SEL3(b)
 #undef AGX_SEL3
   return r;
