@@ -596,39 +596,43 @@ AGX_DEV void collide(Ctx& c) {
     live_groups = wave_ballot(live);   // the pair table has at most 64 groups (checked in agx_create)
   }
   AGX_CTICK(9)
-  int wn = 0;    // worklist fill; whole groups are accumulated and flushed together
-  for (int g = 0; g < c.ngroup; g++) {
-    if (!(live_groups >> g & 1)) continue;
-    int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
-    if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
-    const bool same = GRI(c, g, AGX_G_FLAGS) & 1;
-    const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
-    const int nb = b1 - b0;
-    // 2. broadphase sweep of the whole group into the shared worklist
-    int wn2 = collide_sweep(c, g, a0, a1, b0, b1, same, mg, wn);
-    if (wn2 > WL_CAP) {
-      // does not fit behind the pending groups: flush them, then take this group alone, if necessary
-      // in batches of whole A colliders (a batch of WL_CAP / nb colliders cannot overflow)
+  // 2.-4. The work is a sequence of units (group, range of its A colliders), normally one unit per
+  // live group.  Units are swept into the shared worklist until one does not fit behind the pending
+  // entries; then the pending entries are flushed (narrowphase + selection) and the unit is retried
+  // on the empty list, split into batches of whole A colliders if it still does not fit.  One sweep
+  // and one flush call site keep the kernel's code size down.
+  int wn = 0, g = 0, ab = -1, abatch = 0;
+  while (true) {
+    while (g < c.ngroup && !(live_groups >> g & 1)) g++;
+    if (g >= c.ngroup) {
+      if (wn == 0) break;
+    } else {
+      const int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1);
+      int b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
+      if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
+      const bool same = GRI(c, g, AGX_G_FLAGS) & 1;
+      const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
+      const int nb = b1 - b0;
+      if (ab < 0) { ab = a0; abatch = a1 - a0; }
+      const int ae = ab + abatch < a1 ? ab + abatch : a1;
+      int wn2 = collide_sweep(c, g, ab, ae, b0, b1, same, mg, wn);
       AGX_CTICK(10)
-      collide_flush(c, wn, cs, brk, slack, gender); wn = 0;
-      ct0 = c.timing ? wave_clock() : 0;
-      wn2 = collide_sweep(c, g, a0, a1, b0, b1, same, mg, 0);
-      if (wn2 > WL_CAP) {
-        const int abatch = WL_CAP / nb > 0 ? WL_CAP / nb : 1;
-        for (int ab = a0; ab < a1; ab += abatch) {
-          int w3 = collide_sweep(c, g, ab, ab + abatch < a1 ? ab + abatch : a1, b0, b1, same, mg, 0);
-          if (w3 > WL_CAP) { cs.overflow += w3 - WL_CAP; w3 = WL_CAP; }
-          AGX_CTICK(10)
-          collide_flush(c, w3, cs, brk, slack, gender);
-          ct0 = c.timing ? wave_clock() : 0;
-        }
-        wn2 = 0;
+      bool fits = wn2 <= WL_CAP;
+      if (!fits && wn == 0) {
+        const int small = WL_CAP / nb > 0 ? WL_CAP / nb : 1;   // a batch of WL_CAP / nb colliders cannot overflow
+        if (abatch > small) { abatch = small; continue; }       // retry this unit in smaller batches
+        cs.overflow += wn2 - WL_CAP; wn2 = WL_CAP; fits = true;  // a single A collider with more than WL_CAP partners
+      }
+      if (fits) {
+        wn = wn2; ab = ae;
+        if (ab >= a1) { g++; ab = -1; }
+        // a unit that was split is flushed batch by batch; whole groups keep accumulating
+        if (ab < 0) continue;
       }
     }
-    wn = wn2;
-    AGX_CTICK(10)
+    collide_flush(c, wn, cs, brk, slack, gender); wn = 0;
+    ct0 = c.timing ? wave_clock() : 0;
   }
-  collide_flush(c, wn, cs, brk, slack, gender);
   c.ncon = cs.ncon; c.near_mask = cs.near_mask; c.overflow = cs.overflow;
   wave_sync();
 #undef AGX_CTICK
@@ -777,8 +781,6 @@ AGX_DEV void build_rows(Ctx& c) {
   int nnc = popc64(am), ent = 1 + wave_sum_i(cnt);
   wave_sync();
   if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }
-  // contacts are needed below but live outside the arena; AABBs (arena) are dead from here on
-  if (active) row_store(c, r, row, off, bterm, lo, hi, -1, 0.f);
   // --- contact rows: lane = contact; normal rows first, then one friction row per contact
   int nc = c.ncon;
   const bool has = lane < nc;
@@ -796,17 +798,29 @@ AGX_DEV void build_rows(Ctx& c) {
   nc = popc64(wave_ballot(fits));
   const int tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0);
   const int entN = ent, entF = ent + (nc > 0 ? tot : 0);
-  if (lane < nc) {
-    float rv = row_velocity(c, rn);
-    float bn = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv);
-    row_store(c, rn, nnc + lane, entN + cincl - ccnt, bn, 0.f, 1e30f, -1, 0.f);
-    // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
-    v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);
-    v3 t = vr - dot(vr, nn) * nn;
-    float l2 = dot(t, t);
-    if (l2 > PRM(c, AGX_P_FRIC_EPS)) t = (1.0f / sqrtf(l2)) * t; else plane_space(nn, t);
-    RowGeom rf; row_pair(c, rf, ba, pa, bb, pb, t, mk3(0, 0, 0));
-    row_store(c, rf, nnc + nc + lane, entF + cincl - ccnt, -row_velocity(c, rf), 0.f, 0.f, nnc + lane, mu);
+  // the three row kinds go through ONE row_store call site (its M^-1 J^T product is the bulk of this
+  // phase's code): kind 0 non-contact, 1 contact normal, 2 contact friction
+  _Pragma("nounroll") for (int kind = 0; kind < 3; kind++) {
+    RowGeom R; int rrow = 0, roff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
+    if (kind == 0) {
+      R = r; go = active; rrow = row; roff = off; rb = bterm; rlo = lo; rhi = hi;
+    } else if (kind == 1) {
+      R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rlo = 0.f; rhi = 1e30f;
+      if (go) { const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv); }
+    } else {
+      go = lane < nc; rrow = nnc + nc + lane; roff = entF + cincl - ccnt; rfric = nnc + lane; rmu = mu;
+      row_clear(R);
+      if (go) {
+        // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
+        v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);
+        v3 t = vr - dot(vr, nn) * nn;
+        float l2 = dot(t, t);
+        if (l2 > PRM(c, AGX_P_FRIC_EPS)) t = (1.0f / sqrtf(l2)) * t; else plane_space(nn, t);
+        row_pair(c, R, ba, pa, bb, pb, t, mk3(0, 0, 0));
+        rb = -row_velocity(c, R);
+      }
+    }
+    if (go) row_store(c, R, rrow, roff, rb, rlo, rhi, rfric, rmu);
   }
   c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0);
   wave_sync();
