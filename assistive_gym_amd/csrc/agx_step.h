@@ -28,7 +28,7 @@ constexpr int MAX_CON = 64;
 constexpr int MAX_ROWS = 160;
 constexpr int ST_WORDS = 336;
 constexpr int CON_STRIDE = 16;
-constexpr int HDR_STRIDE = 8;
+constexpr int HDR_STRIDE = 10;
 constexpr int ARENA_WORDS = 3520;
 constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
 
@@ -85,7 +85,8 @@ constexpr int SCR_ENT = 4096, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SC
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
 constexpr int SCR_WORDS = SCR_O_META + SCR_META;
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5;
-constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_FRIC = 6, H_MU = 7;
+constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
+constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)
 
 struct Ctx {
   const float* bf; const int* bi;   // model blob
@@ -696,7 +697,11 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
       E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
     }
   }
-  for (int side = 0; side < 2; side++) {
+  // free bodies in ascending DoF order, so that the pairs of a row are stored in lane order (the
+  // solver addresses them by the rank of the lane inside the row's lane mask)
+  const int first = (r.fa >= 0 && r.fb >= 0 && r.fb < r.fa) ? 1 : 0;
+  for (int s2 = 0; s2 < 2; s2++) {
+    const int side = s2 ^ first;
     int fb = side == 0 ? r.fa : r.fb; if (fb < 0) continue;
     const float* J = side == 0 ? r.Ja : r.Jb;
     float mass = FBF(c, fb, AGX_F_MASS), im = mass > 0 ? 1.0f / mass : 0.f;
@@ -709,7 +714,14 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
   float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
   H[H_INVD] = D > 1e-12f ? 1.0f / D : 0.f; H[H_B] = bterm; H[H_LO] = lo; H[H_HI] = hi;
-  Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off; Hi[H_FRIC] = fric_of; H[H_MU] = mu;
+  // lane masks of the two DoF ranges: bits 0..63 (first lane slot) and 64.. (second slot)
+  const uint64_t ra = na > 0 ? ((~0ull >> (64 - na)) ) : 0ull, rb = nb > 0 ? ((~0ull >> (64 - nb))) : 0ull;
+  uint64_t mlo = 0ull, mhi = 0ull;
+  if (na > 0) { if (a0 < 64) mlo |= ra << a0; if (a0 + na > 64) mhi |= a0 >= 64 ? ra << (a0 - 64) : ra >> (64 - a0); }
+  if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
+  Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
+  Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
+  (void)fric_of;
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
   if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
@@ -837,7 +849,7 @@ AGX_DEV void build_rows(Ctx& c) {
 // B0/B1 hold the friction rows, placed in the SAME lane as the normal row of their contact so the
 // friction bound mu*lambda_n is a lane-local product.  The impulse update is evaluated in every
 // lane on its own row registers; only the owner lane's result is kept and its delta broadcast.
-struct PgsSet { float invD, b, lo, hi, lam; int pack, off; };   // one row per lane (hi = mu for friction sets)
+struct PgsSet { float invD, b, lo, hi, lam; int pack, off, mlo, mhi, m2; };   // one row per lane (hi = mu for friction sets); off carries OFF_TWO_BIT
 
 // (J,B) pair of this lane for a row: lanes outside the row's two DoF ranges read arena entry 0 = (0,0).
 // Addresses are 32-bit byte offsets from the (wave-uniform) entry base, so the loads use the
@@ -901,39 +913,28 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
 #define AGX_LOAD_L(DST, ADDR) "ds_read_b64 " DST ", " ADDR " offset:" AGX_STR(AGX_SOLVE_ENT_BYTES) "\n"
 #define AGX_WAIT_G(N) "s_waitcnt vmcnt(" N ")\n"
 #define AGX_WAIT_L(N) "s_waitcnt lgkmcnt(" N ")\n"
+// pairs of row IDX -> buffer (Z0: lanes 0..63, Z1: lanes 64..).  The row's lane mask (precomputed by
+// row_store) turns the address into "offset + rank of this lane among the row's lanes": 2 x v_mbcnt,
+// 1 add-shift, 1 select with the mask itself as the condition.
 #define AGX_PGS_FETCH(LOAD, IDX, Z0, Z1) \
-  "v_readlane_b32 s81, %[pack], " IDX "\n" \
-  "v_readlane_b32 s82, %[off], " IDX "\n" \
-  "s_nop 0\n" \
-  "s_and_b32 s83, s81, 0xff\n" \
-  "s_bfe_u32 s84, s81, 0x80008\n" \
-  "s_bfe_u32 s85, s81, 0x80010\n" \
-  "s_lshr_b32 s86, s81, 24\n" \
-  "s_add_i32 s87, s82, s84\n" \
-  "v_subrev_u32_e32 v81, s83, %[lane]\n" \
-  "v_subrev_u32_e32 v82, s85, %[lane]\n" \
-  "v_add_lshl_u32 v83, v81, s82, 3\n" \
-  "v_add_lshl_u32 v84, v82, s87, 3\n" \
-  "v_cmp_gt_u32_e32 vcc, s86, v82\n" \
-  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
-  "s_add_i32 s90, s83, s84\n" \
-  "s_add_i32 s91, s85, s86\n" \
-  "v_cndmask_b32_e32 v85, 0, v84, vcc\n" \
-  "s_max_u32 s90, s90, s91\n" \
-  "v_cndmask_b32_e64 v85, v85, v83, s[88:89]\n" \
+  "v_readlane_b32 s84, %[off], " IDX "\n" \
+  "v_readlane_b32 s82, %[mlo], " IDX "\n" \
+  "v_readlane_b32 s83, %[mhi], " IDX "\n" \
+  "s_bitcmp1_b32 s84, 31\n" \
+  "s_bitset0_b32 s84, 31\n" \
+  "v_mbcnt_lo_u32_b32 v81, s82, 0\n" \
+  "v_mbcnt_hi_u32_b32 v81, s83, v81\n" \
+  "v_add_lshl_u32 v85, v81, s84, 3\n" \
+  "v_cndmask_b32_e64 v85, 0, v85, s[82:83]\n" \
   LOAD(Z0, "v85") \
-  "s_cmpk_lt_u32 s90, 0x41\n" \
-  "s_cbranch_scc1 1f\n" \
-  "v_subrev_u32_e32 v81, s83, %[lane64]\n" \
-  "v_subrev_u32_e32 v82, s85, %[lane64]\n" \
-  "v_add_lshl_u32 v83, v81, s82, 3\n" \
-  "v_add_lshl_u32 v84, v82, s87, 3\n" \
-  "v_cmp_gt_u32_e32 vcc, s86, v82\n" \
-  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
-  "s_nop 1\n" \
-  "v_cndmask_b32_e32 v86, 0, v84, vcc\n" \
-  "s_nop 0\n" \
-  "v_cndmask_b32_e64 v86, v86, v83, s[88:89]\n" \
+  "s_cbranch_scc0 1f\n" \
+  "v_readlane_b32 s86, %[m2], " IDX "\n" \
+  "s_bcnt1_i32_b64 s85, s[82:83]\n" \
+  "s_mov_b32 s87, 0\n" \
+  "s_add_i32 s85, s85, s84\n" \
+  "v_mbcnt_lo_u32_b32 v82, s86, 0\n" \
+  "v_add_lshl_u32 v86, v82, s85, 3\n" \
+  "v_cndmask_b32_e64 v86, 0, v86, s[86:87]\n" \
   LOAD(Z1, "v86") \
   "s_branch 2f\n" \
   "1:\n" \
@@ -948,50 +949,42 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   WAIT("4") \
   "v_mul_f32_e32 v80, " XJ0 ", %[dv0]\n" \
   "v_fmac_f32_e32 v80, " XJ1 ", %[dv1]\n" \
-  "v_readlane_b32 s81, %[pack], s80\n" \
-  "v_readlane_b32 s82, %[off], s80\n" \
+  "v_readlane_b32 s84, %[off], s80\n" \
+  "v_readlane_b32 s82, %[mlo], s80\n" \
   AGX_PGS_DPP("quad_perm:[1,0,3,2]") \
-  "s_and_b32 s83, s81, 0xff\n" \
-  "s_bfe_u32 s84, s81, 0x80008\n" \
+  "v_readlane_b32 s83, %[mhi], s80\n" \
+  "s_bitcmp1_b32 s84, 31\n" \
   AGX_PGS_DPP("quad_perm:[2,3,0,1]") \
-  "s_bfe_u32 s85, s81, 0x80010\n" \
-  "s_lshr_b32 s86, s81, 24\n" \
+  "s_cselect_b32 s90, 1, 0\n" \
+  "s_bitset0_b32 s84, 31\n" \
   AGX_PGS_DPP("row_shr:4") \
-  "s_add_i32 s87, s82, s84\n" \
-  "v_subrev_u32_e32 v81, s83, %[lane]\n" \
-  AGX_PGS_DPP("row_shr:8") \
-  "v_subrev_u32_e32 v82, s85, %[lane]\n" \
-  "v_add_lshl_u32 v83, v81, s82, 3\n" \
-  AGX_PGS_DPP("row_bcast:15") \
-  "v_add_lshl_u32 v84, v82, s87, 3\n" \
-  "v_cmp_gt_u32_e64 s[94:95], s86, v82\n" \
-  AGX_PGS_DPP("row_bcast:31") \
-  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
-  "s_add_i32 s90, s83, s84\n" \
-  "v_readlane_b32 s92, v80, 63\n" \
-  "s_add_i32 s91, s85, s86\n" \
-  "v_cndmask_b32_e64 v85, 0, v84, s[94:95]\n" \
+  "v_mbcnt_lo_u32_b32 v81, s82, 0\n" \
   "v_cmp_eq_u32_e32 vcc, %[r], %[lane]\n" \
-  "v_subrev_f32_e32 v80, s92, %[b]\n" \
-  "s_max_u32 s90, s90, s91\n" \
-  "v_cndmask_b32_e64 v85, v85, v83, s[88:89]\n" \
-  "v_fma_f32 v80, %[invD], v80, %[lam]\n" \
+  AGX_PGS_DPP("row_shr:8") \
+  "v_mbcnt_hi_u32_b32 v81, s83, v81\n" \
+  "s_nop 0\n" \
+  AGX_PGS_DPP("row_bcast:15") \
+  "v_add_lshl_u32 v85, v81, s84, 3\n" \
+  "s_nop 0\n" \
+  AGX_PGS_DPP("row_bcast:31") \
+  "v_cndmask_b32_e64 v85, 0, v85, s[82:83]\n" \
+  "s_cmp_lg_u32 s90, 0\n" \
+  "v_readlane_b32 s92, v80, 63\n" \
   LOAD(Z0, "v85") \
+  "s_nop 0\n" \
+  "v_subrev_f32_e32 v80, s92, %[b]\n" \
+  "v_fma_f32 v80, %[invD], v80, %[lam]\n" \
   "v_med3_f32 v80, v80, %[lo], %[hi]\n" \
-  "s_cmpk_lt_u32 s90, 0x41\n" \
   "v_sub_f32_e32 v87, v80, %[lam]\n" \
   "v_cndmask_b32_e32 %[lam], %[lam], v80, vcc\n" \
-  "s_cbranch_scc1 1f\n" \
-  "v_subrev_u32_e32 v81, s83, %[lane64]\n" \
-  "v_subrev_u32_e32 v82, s85, %[lane64]\n" \
-  "v_add_lshl_u32 v83, v81, s82, 3\n" \
-  "v_add_lshl_u32 v84, v82, s87, 3\n" \
-  "v_cmp_gt_u32_e64 s[94:95], s86, v82\n" \
-  "v_cmp_gt_u32_e64 s[88:89], s84, v81\n" \
-  "s_nop 0\n" \
-  "v_cndmask_b32_e64 v86, 0, v84, s[94:95]\n" \
-  "s_nop 0\n" \
-  "v_cndmask_b32_e64 v86, v86, v83, s[88:89]\n" \
+  "s_cbranch_scc0 1f\n" \
+  "v_readlane_b32 s86, %[m2], s80\n" \
+  "s_bcnt1_i32_b64 s85, s[82:83]\n" \
+  "s_mov_b32 s87, 0\n" \
+  "s_add_i32 s85, s85, s84\n" \
+  "v_mbcnt_lo_u32_b32 v82, s86, 0\n" \
+  "v_add_lshl_u32 v86, v82, s85, 3\n" \
+  "v_cndmask_b32_e64 v86, 0, v86, s[86:87]\n" \
   LOAD(Z1, "v86") \
   "s_branch 2f\n" \
   "1:\n" \
@@ -1023,15 +1016,14 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
     WAIT("0")
 #define AGX_PGS_OPERANDS \
     : [lam] "+v"(S.lam), [dv0] "+v"(dv0), [dv1] "+v"(dv1), [r] "+s"(r) \
-    : [pack] "v"(S.pack), [off] "v"(S.off), [invD] "v"(S.invD), [b] "v"(S.b), [lo] "v"(lo), [hi] "v"(hi), \
-      [lane] "v"(lane), [lane64] "v"(lane64), [E] "s"(E), [l1] "s"(l1), [last] "s"(last) \
+    : [off] "v"(S.off), [mlo] "v"(S.mlo), [mhi] "v"(S.mhi), [m2] "v"(S.m2), [invD] "v"(S.invD), [b] "v"(S.b), [lo] "v"(lo), [hi] "v"(hi), \
+      [lane] "v"(lane), [E] "s"(E), [l1] "s"(l1), [last] "s"(last) \
     : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", \
       "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", \
       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc", "memory"
 // lo/hi are the per-lane bounds of this sweep (for friction sets already scaled by the normal
 // impulses).  Rows [l0, ls) have all their pairs inside the LDS window, rows [ls, l1) stream from global.
 AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int lane, int l0, int ls, int l1, float& dv0, float& dv1) {
-  const int lane64 = lane + 64;
   if (ls > l0) {
     int r = l0; const int l1 = ls, last = ls - 1;
     asm volatile(AGX_PGS_BODY(AGX_LOAD_L, AGX_WAIT_L) AGX_PGS_OPERANDS);
@@ -1052,7 +1044,7 @@ AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int l
   (void)ls;
   PgsBuf A, B, C;
   const int last = l1 - 1;
-#define AGX_PGS_FETCH_C(X, r) { const int rr_ = (r) < last ? (r) : last; pgs_fetch(E, lane, wave_bcast_i(S.pack, rr_), wave_bcast_i(S.off, rr_), X); }
+#define AGX_PGS_FETCH_C(X, r) { const int rr_ = (r) < last ? (r) : last; pgs_fetch(E, lane, wave_bcast_i(S.pack, rr_), wave_bcast_i(S.off, rr_) & 0x7fffffff, X); }
   AGX_PGS_FETCH_C(A, l0);
   AGX_PGS_FETCH_C(B, l0 + 1);
   for (int rl = l0;; rl += 3) {
@@ -1078,6 +1070,7 @@ AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet&
   S.invD = invD; S.b = ok ? H[H_B] : 0.f; S.lam = 0.f;
   S.lo = live ? H[H_LO] : 0.f; S.hi = live ? (friction ? H[H_MU] : H[H_HI]) : 0.f;
   S.pack = ok ? Hi[H_PACK] : 0; S.off = ok ? Hi[H_OFF] : 0;
+  S.mlo = ok ? Hi[H_MLO] : 0; S.mhi = ok ? Hi[H_MHI] : 0; S.m2 = ok ? Hi[H_M2] : 0;
 }
 // first lane of [l0, l1) whose row reaches beyond the LDS window of (J,B) pairs (l1 if none)
 AGX_DEV int pgs_lds_split(const PgsSet& S, int lane, int l0, int l1) {
@@ -1085,7 +1078,7 @@ AGX_DEV int pgs_lds_split(const PgsSet& S, int lane, int l0, int l1) {
 #ifdef AGX_NO_LDS_ROWS
   return l0;
 #endif
-  const int end = S.off + ((S.pack >> 8) & 255) + (int)((unsigned)S.pack >> 24);
+  const int end = (S.off & 0x7fffffff) + ((S.pack >> 8) & 255) + (int)((unsigned)S.pack >> 24);
   const uint64_t m = wave_ballot(lane >= l0 && lane < l1 && end > SOLVE_LDS_PAIRS);
   return wave_uniform(m ? ffs64(m) : l1);
 }

@@ -31,7 +31,7 @@ def _p(a):
 
 class Emu:
     DBG_HDR = 16 + 64 * 16 + 256
-    DBG_LAM = DBG_HDR + 160 * 8
+    DBG_LAM = DBG_HDR + 160 * 10
     DBG_TIME = DBG_LAM + 160
     DEBUG_WORDS = DBG_TIME + 16
 
