@@ -913,7 +913,8 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
 #define AGX_LOAD_L(DST, ADDR) "ds_read_b64 " DST ", " ADDR " offset:" AGX_STR(AGX_SOLVE_ENT_BYTES) "\n"
 #define AGX_WAIT_G(N) "s_waitcnt vmcnt(" N ")\n"
 #define AGX_WAIT_L(N) "s_waitcnt lgkmcnt(" N ")\n"
-// pairs of row IDX -> buffer (Z0: lanes 0..63, Z1: lanes 64..).  The row's lane mask (precomputed by
+// pairs of row IDX -> buffer (Z0: lanes 0..63, Z1: lanes 64..).  Bit 31 of the offset word (second-slot
+// flag) needs no masking: the shift by 3 of the address arithmetic discards it.  The row's lane mask (precomputed by
 // row_store) turns the address into "offset + rank of this lane among the row's lanes": 2 x v_mbcnt,
 // 1 add-shift, 1 select with the mask itself as the condition.
 #define AGX_PGS_FETCH(LOAD, IDX, Z0, Z1) \
@@ -921,7 +922,6 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   "v_readlane_b32 s82, %[mlo], " IDX "\n" \
   "v_readlane_b32 s83, %[mhi], " IDX "\n" \
   "s_bitcmp1_b32 s84, 31\n" \
-  "s_bitset0_b32 s84, 31\n" \
   "v_mbcnt_lo_u32_b32 v81, s82, 0\n" \
   "v_mbcnt_hi_u32_b32 v81, s83, v81\n" \
   "v_add_lshl_u32 v85, v81, s84, 3\n" \
@@ -945,7 +945,6 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
 // address arithmetic of the prefetch for row r+3 woven into its wait states.
 #define AGX_PGS_STEP(LOAD, WAIT, XJ0, XC0, XJ1, XC1, Z0, Z1) \
   "s_add_i32 s80, %[r], 3\n" \
-  "s_min_i32 s80, s80, %[last]\n" \
   WAIT("4") \
   "v_mul_f32_e32 v80, " XJ0 ", %[dv0]\n" \
   "v_fmac_f32_e32 v80, " XJ1 ", %[dv1]\n" \
@@ -955,23 +954,20 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   "v_readlane_b32 s83, %[mhi], s80\n" \
   "s_bitcmp1_b32 s84, 31\n" \
   AGX_PGS_DPP("quad_perm:[2,3,0,1]") \
-  "s_cselect_b32 s90, 1, 0\n" \
-  "s_bitset0_b32 s84, 31\n" \
-  AGX_PGS_DPP("row_shr:4") \
   "v_mbcnt_lo_u32_b32 v81, s82, 0\n" \
   "v_cmp_eq_u32_e32 vcc, %[r], %[lane]\n" \
-  AGX_PGS_DPP("row_shr:8") \
+  AGX_PGS_DPP("row_shr:4") \
   "v_mbcnt_hi_u32_b32 v81, s83, v81\n" \
-  "s_nop 0\n" \
-  AGX_PGS_DPP("row_bcast:15") \
   "v_add_lshl_u32 v85, v81, s84, 3\n" \
-  "s_nop 0\n" \
-  AGX_PGS_DPP("row_bcast:31") \
+  AGX_PGS_DPP("row_shr:8") \
   "v_cndmask_b32_e64 v85, 0, v85, s[82:83]\n" \
-  "s_cmp_lg_u32 s90, 0\n" \
-  "v_readlane_b32 s92, v80, 63\n" \
   LOAD(Z0, "v85") \
+  AGX_PGS_DPP("row_bcast:15") \
+  "s_nop 1\n" \
+  AGX_PGS_DPP("row_bcast:31") \
   "s_nop 0\n" \
+  "v_readlane_b32 s92, v80, 63\n" \
+  "s_nop 1\n" \
   "v_subrev_f32_e32 v80, s92, %[b]\n" \
   "v_fma_f32 v80, %[invD], v80, %[lam]\n" \
   "v_med3_f32 v80, v80, %[lo], %[hi]\n" \
