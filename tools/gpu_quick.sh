@@ -1,3 +1,2 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 600 python -m pytest tests -m gpu -x -q -s 2>&1 | grep "worst\|passed\|failed"
-STEPS=200 bash tools/ab_run.sh
+for v in assistive_gym_amd/lib/variants/*.so; do AGX_LIB=$PWD/$v timeout 300 python tools/micro_solve.py 2>&1 | tail -1; done
