@@ -25,25 +25,73 @@ ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def cpu_baseline(blob, states, n_envs, n_steps):
-    """The CPU oracle (oracle/, plain C, f64, one thread) timed on a bounded sample of the same
-    workload on this box's host cores.  kind = "port": a restatement, NOT PyBullet."""
+def _cpu_worker(path, seed, n_steps):
+    """`bench.py --cpu-worker`: one host process stepping its share of the sample with the C oracle;
+    prints "<env-steps> <seconds>"."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle_lib import Oracle
+    from assistive_gym_amd.blob import ModelBlob
+    blob = ModelBlob.load('feeding_jaco')
     o = Oracle(blob)
-    rng = np.random.RandomState(0)
-    st = states[:n_envs].copy()
+    st = np.load(path)
+    rng = np.random.RandomState(seed)
     t0 = time.perf_counter()
     for k in range(n_steps):
-        a = rng.uniform(-1, 1, (n_envs, blob.act_dim)).astype(np.float32)
-        for i in range(n_envs):
+        a = rng.uniform(-1, 1, (len(st), blob.act_dim)).astype(np.float32)
+        for i in range(len(st)):
             o.step(st[i], a[i])
-    dt = time.perf_counter() - t0
-    return dict(value=n_envs * n_steps / dt, unit='env-steps/s', cores=1, kind='port',
-                sample='%d envs x %d steps of the same FeedingJaco workload, C f64 oracle, 1 thread (not PyBullet)' % (n_envs, n_steps))
+    print(len(st) * n_steps, time.perf_counter() - t0)
+
+
+def _usable_cores():
+    """host cores this process may really use: the affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:                                             # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:                                         # cgroup v1
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(blob, states, envs_per_core, n_steps):
+    """The CPU oracle (oracle/, plain C, f64) timed on a bounded sample of the same workload on ALL host
+    cores of this box (one process per core, each stepping its own environments -- the reference's own
+    scaling model, learn.py:26).  kind = "port": a restatement, NOT PyBullet."""
+    import subprocess
+    import tempfile
+    cores = _usable_cores()
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for c in range(cores):
+            path = os.path.join(tmp, 'cpu_%d.npy' % c)
+            np.save(path, states[(c * envs_per_core + np.arange(envs_per_core)) % len(states)])
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', path, str(c), str(n_steps)],
+                                          stdout=subprocess.PIPE, text=True))
+        res = []
+        for pr in procs:
+            out, _ = pr.communicate()
+            steps, secs = out.split()[-2:]
+            res.append((int(steps), float(secs)))
+    wall = time.perf_counter() - t0
+    total = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)                       # slowest worker, excludes interpreter start-up
+    single = np.mean([r[0] / r[1] for r in res])
+    return dict(value=total / busy, unit='env-steps/s', cores=cores, kind='port',
+                sample='%d processes x %d envs x %d steps of the same FeedingJaco workload, C f64 oracle (not PyBullet); '
+                       'per process %.0f env-steps/s; wall incl. start-up %.1f s' % (cores, envs_per_core, n_steps, single, wall))
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
+        return _cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=400)
@@ -147,7 +195,7 @@ def main():
                          'note': 'latency/VALU-bound solver; HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host, 16, 40)
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host, 8, 1000)
         print(json.dumps(out))
     env.close()
     if distributed:

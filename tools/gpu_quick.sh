@@ -1,2 +1,8 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for v in assistive_gym_amd/lib/variants/*.so; do AGX_LIB=$PWD/$v timeout 300 python tools/micro_solve.py 2>&1 | tail -1; done
+cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us 2>/dev/null
+python -c "
+import sys; sys.path.insert(0,'.')
+import bench; print('usable cores', bench._usable_cores())"
+timeout 600 python bench.py --steps 100 --warmup 20 | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print(round(j['value']), j['cpu_baseline'])"
