@@ -137,6 +137,71 @@ def test_vec_env_rollout_properties(gpu_lib, blob):
     env.close()
 
 
+def test_full_episode_invariants_at_bench_size(gpu_lib, blob):
+    """BASELINE config 2 at full size (4096 envs, a whole 200-step episode + auto-reset): properties that
+    do not need the oracle -- finite outputs, done exactly at step 200, unit quaternions, robot joints
+    inside their limits, the tool still attached to the end effector, particle bookkeeping, and bitwise
+    run-to-run determinism."""
+    import torch
+    from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+    from assistive_gym_amd.host.kin import RobotKin
+    n, T = 4096, 200
+
+    def rollout():
+        env = FeedingJacoVecEnv(n, pool_size=64, seed=1001)
+        env.reset()
+        g = torch.Generator(device='cuda'); g.manual_seed(11)
+        ok = torch.ones((), dtype=torch.bool, device='cuda')
+        early_done = torch.zeros((), dtype=torch.int64, device='cuda')
+        ret = torch.zeros(n, device='cuda')
+        env.auto_reset = False
+        for k in range(T):
+            a = torch.rand((n, blob.act_dim), device='cuda', generator=g) * 2 - 1
+            obs, rew, done, info = env.step(a)
+            ok &= torch.isfinite(obs).all() & torch.isfinite(rew).all() & torch.isfinite(info).all()
+            if k < T - 1:
+                early_done += done.sum()
+            ret += rew
+        torch.cuda.synchronize()
+        final = env.stepper.get_state()
+        out = (bool(ok), int(early_done), done.clone(), obs.clone(), ret.clone(), info.clone(), final)
+        # auto-reset: every finished env takes a pool record and starts a new episode
+        env.auto_reset = True
+        env.stepper.reset_done(env.pool, env.pool_size, env.done)
+        obs2, rew2, done2, info2 = env.step(torch.zeros((n, blob.act_dim), device='cuda'))
+        torch.cuda.synchronize()
+        after = env.stepper.get_state()
+        env.close()
+        return out, (done2.clone(), after)
+
+    (ok, early, done, obs, ret, info, final), (done2, after) = rollout()
+    assert ok and early == 0 and bool(done.all())                      # feeding.py:37: done = iteration >= 200
+    v = blob.view(final)
+    assert int(v['iteration'].min()) == T and int(v['iteration'].max()) == T
+    qn = np.linalg.norm(v['free'][:, :, 3:7], axis=2)
+    alive = v['food_alive'][:, None] >> np.arange(blob.nfood)[None] & 1
+    body_ok = np.ones_like(qn, dtype=bool); body_ok[:, blob.h['FOOD0']:blob.h['FOOD0'] + blob.nfood] = alive.astype(bool)
+    assert np.abs(qn - 1.0)[body_ok].max() < 1e-3
+    kin = RobotKin(blob)
+    q = v['q'][:, :blob.nrobot].astype(np.float64)
+    lim = [d for d in range(blob.nrobot) if blob.robot_i(d, 'HAS_LIMIT')]
+    assert (q[:, lim] > kin.lower[lim] - 0.02).all() and (q[:, lim] < kin.upper[lim] + 0.02).all()
+    # tool.py:46-47: the spoon is held by a fixed constraint of 500 N; sampled envs keep it within 1.5 cm
+    tb = blob.h['TOOL_BODY']
+    for i in range(0, n, 257):
+        tp, _ = kin.tool_pose(v['base'][i, :3].astype(np.float64), v['base'][i, 3:7].astype(np.float64), v['q'][i].astype(np.float64))
+        assert np.linalg.norm(tp - v['free'][i, tb, :3]) < 0.015
+    # particle bookkeeping (feeding.py:50-83): eaten + still alive <= total, success counter = eaten particles
+    assert (v['task_success'] >= 0).all() and (v['task_success'] + alive.sum(1) <= blob.nfood).all()
+    assert np.isfinite(ret.cpu().numpy()).all() and float(info[:, 0].min()) >= 0.0
+    # a new episode has started everywhere
+    va = blob.view(after)
+    assert int(va['iteration'].max()) == 1 and not bool(done2.any())
+    # determinism: the same rollout again is bit-identical
+    (ok_b, early_b, done_b, obs_b, ret_b, info_b, final_b), _ = rollout()
+    assert torch.equal(obs, obs_b) and torch.equal(ret, ret_b) and np.array_equal(final, final_b)
+
+
 def test_scalar_env_facade(gpu_lib, blob, oracle):
     """FeedingJacoEnv: the reference's gym surface (feeding_envs.py:29-31) on top of a 1-env handle."""
     from assistive_gym_amd.envs import FeedingJacoEnv, make
