@@ -943,8 +943,10 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
 #define AGX_PGS_DPP(CTRL) "v_add_f32_dpp v80, v80, v80 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 // One row: the dependent chain (dot product, 6-step DPP reduction, impulse update, broadcast) with the
 // address arithmetic of the prefetch for row r+3 woven into its wait states.
+#define AGX_PGS_NEXT(IDX, MASK) "s_ff1_i32_b64 " IDX ", " MASK "\n" "s_bitset0_b64 " MASK ", " IDX "\n"
 #define AGX_PGS_STEP(LOAD, WAIT, XJ0, XC0, XJ1, XC1, Z0, Z1) \
-  "s_add_i32 s80, %[r], 3\n" \
+  AGX_PGS_NEXT("s94", "%[mask]") \
+  AGX_PGS_NEXT("s80", "s[100:101]") \
   WAIT("4") \
   "v_mul_f32_e32 v80, " XJ0 ", %[dv0]\n" \
   "v_fmac_f32_e32 v80, " XJ1 ", %[dv1]\n" \
@@ -955,7 +957,7 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   "s_bitcmp1_b32 s84, 31\n" \
   AGX_PGS_DPP("quad_perm:[2,3,0,1]") \
   "v_mbcnt_lo_u32_b32 v81, s82, 0\n" \
-  "v_cmp_eq_u32_e32 vcc, %[r], %[lane]\n" \
+  "v_cmp_eq_u32_e32 vcc, s94, %[lane]\n" \
   AGX_PGS_DPP("row_shr:4") \
   "v_mbcnt_hi_u32_b32 v81, s83, v81\n" \
   "v_add_lshl_u32 v85, v81, s84, 3\n" \
@@ -986,21 +988,23 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   "1:\n" \
   LOAD(Z1, "v88") \
   "2:\n" \
-  "v_readlane_b32 s93, v87, %[r]\n" \
-  "s_add_i32 %[r], %[r], 1\n" \
-  "s_cmp_ge_i32 %[r], %[l1]\n" \
+  "v_readlane_b32 s93, v87, s94\n" \
+  "s_cmp_eq_u64 %[mask], 0\n" \
+  "s_nop 0\n" \
   "v_fmac_f32_e32 %[dv0], s93, " XC0 "\n" \
   "v_fmac_f32_e32 %[dv1], s93, " XC1 "\n" \
   "s_cbranch_scc1 9f\n"
+// The rows to visit are the set bits of %[mask] (lane = row slot), taken in ascending order with
+// s_ff1 / s_bitset0; a second cursor s[100:101] runs three rows ahead for the prefetch (when it runs
+// dry its index is -1, i.e. lane 63: a harmless extra fetch).
 #define AGX_PGS_BODY(LOAD, WAIT) \
     "v_mov_b32_e32 v88, 0\n" \
-    "s_min_i32 s80, %[r], %[last]\n" \
+    "s_mov_b64 s[100:101], %[mask]\n" \
+    AGX_PGS_NEXT("s80", "s[100:101]") \
     AGX_PGS_FETCH(LOAD, "s80", "v[64:65]", "v[66:67]") \
-    "s_add_i32 s80, %[r], 1\n" \
-    "s_min_i32 s80, s80, %[last]\n" \
+    AGX_PGS_NEXT("s80", "s[100:101]") \
     AGX_PGS_FETCH(LOAD, "s80", "v[68:69]", "v[70:71]") \
-    "s_add_i32 s80, %[r], 2\n" \
-    "s_min_i32 s80, s80, %[last]\n" \
+    AGX_PGS_NEXT("s80", "s[100:101]") \
     AGX_PGS_FETCH(LOAD, "s80", "v[72:73]", "v[74:75]") \
     "8:\n" \
     AGX_PGS_STEP(LOAD, WAIT, "v64", "v65", "v66", "v67", "v[76:77]", "v[78:79]") \
@@ -1011,21 +1015,27 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
     "9:\n" \
     WAIT("0")
 #define AGX_PGS_OPERANDS \
-    : [lam] "+v"(S.lam), [dv0] "+v"(dv0), [dv1] "+v"(dv1), [r] "+s"(r) \
+    : [lam] "+v"(S.lam), [dv0] "+v"(dv0), [dv1] "+v"(dv1), [mask] "+s"(mask) \
     : [off] "v"(S.off), [mlo] "v"(S.mlo), [mhi] "v"(S.mhi), [m2] "v"(S.m2), [invD] "v"(S.invD), [b] "v"(S.b), [lo] "v"(lo), [hi] "v"(hi), \
-      [lane] "v"(lane), [E] "s"(E), [l1] "s"(l1), [last] "s"(last) \
+      [lane] "v"(lane), [E] "s"(E) \
     : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", \
       "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", \
-      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc", "memory"
+      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s100", "s101", "vcc", "scc", "memory"
 // lo/hi are the per-lane bounds of this sweep (for friction sets already scaled by the normal
-// impulses).  Rows [l0, ls) have all their pairs inside the LDS window, rows [ls, l1) stream from global.
-AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int lane, int l0, int ls, int l1, float& dv0, float& dv1) {
-  if (ls > l0) {
-    int r = l0; const int l1 = ls, last = ls - 1;
+// impulses).  `rows` has one bit per row slot to visit; rows below slot `ls` have all their pairs inside
+// the LDS window, the others stream from global.
+AGX_DEV uint64_t pgs_range_mask(int l0, int l1) {
+  const uint64_t hi = l1 >= 64 ? ~0ull : ((1ull << l1) - 1ull), lo = l0 >= 64 ? ~0ull : ((1ull << l0) - 1ull);
+  return hi & ~lo;
+}
+AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int lane, uint64_t rows, int ls, float& dv0, float& dv1) {
+  const uint64_t in_lds = rows & pgs_range_mask(0, ls), in_glb = rows & ~pgs_range_mask(0, ls);
+  if (in_lds) {
+    uint64_t mask = in_lds;
     asm volatile(AGX_PGS_BODY(AGX_LOAD_L, AGX_WAIT_L) AGX_PGS_OPERANDS);
   }
-  if (l1 > ls) {
-    int r = ls; const int last = l1 - 1;
+  if (in_glb) {
+    uint64_t mask = in_glb;
     asm volatile(AGX_PGS_BODY(AGX_LOAD_G, AGX_WAIT_G) AGX_PGS_OPERANDS);
   }
 }
@@ -1035,7 +1045,13 @@ AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int l
   if (l1 <= l0) return;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_PGS_CPP)
   const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
-  pgs_sweep_asm(S, lo, hi, E, lane, l0, ls, l1, dv0, dv1);
+  uint64_t rows = pgs_range_mask(l0, l1);
+  // A friction row whose normal impulse is zero has the bounds [0, 0]; if its own impulse is zero as
+  // well its update is exactly "no change", so the visit is skipped.  The normal impulses do not
+  // change during a friction sweep and a friction impulse only changes at its own visit, so the set
+  // of rows to visit is known up front.  (More than half of the contacts are speculative and inactive.)
+  if (FRICTION) rows &= wave_ballot(lam_normal != 0.f || S.lam != 0.f);
+  pgs_sweep_asm(S, lo, hi, E, lane, rows, ls, dv0, dv1);
 #else
   (void)ls;
   PgsBuf A, B, C;
