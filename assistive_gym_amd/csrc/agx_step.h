@@ -44,7 +44,9 @@ constexpr int L_FIINV = L_FREER + MAX_FREE * 9;          // [MAX_FREE][9]
 constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
 constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
 constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
-constexpr int L_ARENA = L_MISC + 32;                     // contact records live in the per-env global scratch, not in LDS
+constexpr int L_WMAG = L_MISC + 32;                      // |angular velocity| per moving body: links [MAX_DOF], free bodies [MAX_FREE]
+constexpr int L_ARENA = L_WMAG + 32;                     // contact records live in the per-env global scratch, not in LDS
+static_assert(MAX_DOF + MAX_FREE <= 32, "angular speed table");
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
 static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
 constexpr int LDS_BYTES = LDS_WORDS * 4;
@@ -418,6 +420,13 @@ AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
   emit_contact(c, slot, pr & 511, (pr >> 9) & 511, k);
 }
 struct CollideState { int ncon, near_mask, overflow, maxc; };
+// |angular velocity| of the body a collider is attached to (0 for the static ones), from the table
+// filled at the start of collide()
+AGX_DEV float body_wmag(const Ctx& c, int code) {
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) return c.lds[L_WMAG + code];
+  if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) return c.lds[L_WMAG + MAX_DOF + (code - AGX_BODY_FREE0)];
+  return 0.f;
+}
 // conservative separation test: every point of collider x lies within |half extents| + radius of
 // the centre of its box; collider y lies within its body-frame box inflated by its radius.  True if
 // the two are certainly further apart than `reach`.
@@ -538,9 +547,7 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool sa
     }
     if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * a + q] > AB[ABS * b + 3 + q] + mg || AB[ABS * b + q] > AB[ABS * a + 3 + q] + mg) ok = false;
     // level 3: bounding sphere of one collider against the body-frame box of the other, both ways
-#ifndef AGX_NO_OBB
     if (ok) { const float reach = mg + AB[ABS * a + 6] + AB[ABS * b + 6] + 1e-5f; ok = !sphere_box_apart(c, a, b, reach) && !sphere_box_apart(c, b, a, reach); }
-#endif
     const uint64_t m = wave_ballot(ok);
     const int slot = wn + wave_rank(m);
     if (ok && slot < WL_CAP) WL[slot] = a | (b << 9) | (g << 18);
@@ -559,16 +566,22 @@ AGX_DEV void collide(Ctx& c) {
 #define AGX_CTICK(k) if (c.timing) { ct1 = wave_clock(); c.tm[k] += ct1 - ct0; ct0 = ct1; }
   // 1. world AABBs, grown by the distance the collider can travel in this substep (speculative):
   //    the broadphase margin then only has to cover the solver slack
+  if (lane < MAX_DOF + MAX_FREE) {     // angular speed of every moving body, once (the chain walk is per body, not per collider)
+    v3 w = mk3(0, 0, 0);
+    if (lane < MAX_DOF) { if (lane < c.ndof) for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) w = w + L[L_VEL + d] * ld3(L + L_S + 6 * d); }
+    else if (lane - MAX_DOF < c.nfree) w = ld3(L + L_VEL + c.ndof + 6 * (lane - MAX_DOF) + 3);
+    L[L_WMAG + lane] = sqrtf(dot(w, w));
+  }
+  wave_sync();
   for (int col = lane; col < c.ncoll; col += 64) {
     const int code = CLI(c, col, AGX_C_BODY);
     m3 R; v3 p; body_xf(c, code, R, p);
     v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
     v3 hl = mk3(CLF(c, col, AGX_C_AABB_H), CLF(c, col, AGX_C_AABB_H + 1), CLF(c, col, AGX_C_AABB_H + 2));
     v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
-    v3 vc = point_velocity(c, code, cw), w = mk3(0, 0, 0);
-    if (code >= 0 && code < AGX_BODY_ROBOT_BASE) { for (int d = code; d >= 0; d = RBI(c, d, AGX_R_PARENT)) w = w + L[L_VEL + d] * ld3(L + L_S + 6 * d); }
-    else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) w = ld3(L + L_VEL + c.ndof + 6 * (code - AGX_BODY_FREE0) + 3);
-    const float grow = (sqrtf(dot(vc, vc)) + sqrtf(dot(w, w)) * (sqrtf(dot(hl, hl)) + r)) * c.dt;
+    v3 vc = point_velocity(c, code, cw);
+    const float wmag = body_wmag(c, code);
+    const float grow = (sqrtf(dot(vc, vc)) + wmag * (sqrtf(dot(hl, hl)) + r)) * c.dt;
     for (int k = 0; k < 3; k++) {
       float h = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
       AB[ABS * col + k] = comp(cw, k) - h - grow; AB[ABS * col + 3 + k] = comp(cw, k) + h + grow;
@@ -946,7 +959,7 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
 #define AGX_PGS_NEXT(IDX, MASK) "s_ff1_i32_b64 " IDX ", " MASK "\n" "s_bitset0_b64 " MASK ", " IDX "\n"
 #define AGX_PGS_STEP(LOAD, WAIT, XJ0, XC0, XJ1, XC1, Z0, Z1) \
   AGX_PGS_NEXT("s94", "%[mask]") \
-  AGX_PGS_NEXT("s80", "s[100:101]") \
+  AGX_PGS_NEXT("s80", "s[96:97]") \
   WAIT("4") \
   "v_mul_f32_e32 v80, " XJ0 ", %[dv0]\n" \
   "v_fmac_f32_e32 v80, " XJ1 ", %[dv1]\n" \
@@ -995,16 +1008,16 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   "v_fmac_f32_e32 %[dv1], s93, " XC1 "\n" \
   "s_cbranch_scc1 9f\n"
 // The rows to visit are the set bits of %[mask] (lane = row slot), taken in ascending order with
-// s_ff1 / s_bitset0; a second cursor s[100:101] runs three rows ahead for the prefetch (when it runs
+// s_ff1 / s_bitset0; a second cursor (s[96:97]) runs three rows ahead for the prefetch (when it runs
 // dry its index is -1, i.e. lane 63: a harmless extra fetch).
 #define AGX_PGS_BODY(LOAD, WAIT) \
     "v_mov_b32_e32 v88, 0\n" \
-    "s_mov_b64 s[100:101], %[mask]\n" \
-    AGX_PGS_NEXT("s80", "s[100:101]") \
+    "s_mov_b64 s[96:97], %[mask]\n" \
+    AGX_PGS_NEXT("s80", "s[96:97]") \
     AGX_PGS_FETCH(LOAD, "s80", "v[64:65]", "v[66:67]") \
-    AGX_PGS_NEXT("s80", "s[100:101]") \
+    AGX_PGS_NEXT("s80", "s[96:97]") \
     AGX_PGS_FETCH(LOAD, "s80", "v[68:69]", "v[70:71]") \
-    AGX_PGS_NEXT("s80", "s[100:101]") \
+    AGX_PGS_NEXT("s80", "s[96:97]") \
     AGX_PGS_FETCH(LOAD, "s80", "v[72:73]", "v[74:75]") \
     "8:\n" \
     AGX_PGS_STEP(LOAD, WAIT, "v64", "v65", "v66", "v67", "v[76:77]", "v[78:79]") \
@@ -1020,7 +1033,7 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
       [lane] "v"(lane), [E] "s"(E) \
     : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", \
       "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", \
-      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s100", "s101", "vcc", "scc", "memory"
+      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "vcc", "scc", "memory"
 // lo/hi are the per-lane bounds of this sweep (for friction sets already scaled by the normal
 // impulses).  `rows` has one bit per row slot to visit; rows below slot `ls` have all their pairs inside
 // the LDS window, the others stream from global.
