@@ -420,6 +420,9 @@ AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
   emit_contact(c, slot, pr & 511, (pr >> 9) & 511, k);
 }
 struct CollideState { int ncon, near_mask, overflow, maxc; };
+// the pair-group table, one group per lane (lane g = group g): read from the blob once per substep and
+// broadcast with v_readlane where a group's parameters are needed (a dependent blob load costs an L2 trip)
+struct GroupRegs { int a0, a1, b0, b1, flags, keep; };
 // |angular velocity| of the body a collider is attached to (0 for the static ones), from the table
 // filled at the start of collide()
 AGX_DEV float body_wmag(const Ctx& c, int code) {
@@ -445,7 +448,7 @@ AGX_DEV bool sphere_box_apart(const Ctx& c, int x, int y, float reach) {
 
 // narrowphase + selection over the current worklist (entries of one or several whole groups, in
 // enumeration order); appends the resulting contacts
-AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float slack, int gender) {
+AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float slack, const GroupRegs& G) {
   float* L = c.lds; int* WL = c.ldsi + L_ARENA + A_WL; float* CD = L + L_ARENA + A_CAND; const int lane = c.lane;
   const int food0 = c.bi[AGX_H_FOOD0];
   if (wn == 0) return;
@@ -479,7 +482,7 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   int cur = 0;
   while (cur < wn) {
     const int key = WL[cur] & ~(511 << 9);            // group and A collider
-    const int g = key >> 18, keep = GRI(c, g, AGX_G_KEEP);
+    const int g = key >> 18, keep = wave_bcast_i(G.keep, g);
     const int i0 = cur + lane, i1 = cur + 64 + lane;
     const bool s0 = i0 < wn && (WL[i0 < wn ? i0 : 0] & ~(511 << 9)) == key, s1 = i1 < wn && (WL[i1 < wn ? i1 : 0] & ~(511 << 9)) == key;
     const uint64_t b0 = wave_ballot(s0), b1 = wave_ballot(s1);
@@ -517,9 +520,9 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
 
 // broadphase sweep of A colliders [aa, ab) x B range of group g, appended to the worklist at wn.
 // returns the new count (may exceed WL_MAX: entries beyond it are not stored)
-AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, bool same, float mg, int wn) {
+AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gflags, float mg, int wn) {
   const float* AB = c.lds + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; const int lane = c.lane;
-  const bool no_adjacent = GRI(c, g, AGX_G_FLAGS) & 4;   // self-collision: not the same link, not parent and child
+  const bool same = gflags & 1, no_adjacent = gflags & 4;   // bit2, self-collision: not the same link, not parent and child
   const int nb = b1 - b0;
   // level 1: A colliders whose box reaches the union of the B range (lanes over A), compacted into
   // the tail of the candidate area (unused until the flush)
@@ -593,12 +596,15 @@ AGX_DEV void collide(Ctx& c) {
   const int gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER];
   // body-level cull of every group at once: lane g scans both collider ranges of group g
   uint64_t live_groups = 0;
+  GroupRegs G; G.a0 = 0; G.a1 = 0; G.b0 = 0; G.b1 = 0; G.flags = 0; G.keep = 0;
   {
     const int g = lane; bool live = false;
     if (g < c.ngroup) {
-      int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1), b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
-      if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
-      const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;
+      G.a0 = GRI(c, g, AGX_G_A0); G.a1 = GRI(c, g, AGX_G_A1); G.b0 = GRI(c, g, AGX_G_B0); G.b1 = GRI(c, g, AGX_G_B1);
+      if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { G.b0 = GRI(c, g, AGX_G_B0F); G.b1 = GRI(c, g, AGX_G_B1F); }
+      G.flags = GRI(c, g, AGX_G_FLAGS); G.keep = GRI(c, g, AGX_G_KEEP);
+      const int a0 = G.a0, a1 = G.a1, b0 = G.b0, b1 = G.b1;
+      const float mg = (G.flags & 2) ? brk : slack;
       if (a1 > a0 && b1 > b0) {
         float alo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ahi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         for (int i = a0; i < a1; i++) for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], AB[ABS * i + k]); ahi[k] = fmaxf(ahi[k], AB[ABS * i + 3 + k]); }
@@ -621,15 +627,13 @@ AGX_DEV void collide(Ctx& c) {
     if (g >= c.ngroup) {
       if (wn == 0) break;
     } else {
-      const int a0 = GRI(c, g, AGX_G_A0), a1 = GRI(c, g, AGX_G_A1);
-      int b0 = GRI(c, g, AGX_G_B0), b1 = GRI(c, g, AGX_G_B1);
-      if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { b0 = GRI(c, g, AGX_G_B0F); b1 = GRI(c, g, AGX_G_B1F); }
-      const bool same = GRI(c, g, AGX_G_FLAGS) & 1;
-      const float mg = (GRI(c, g, AGX_G_FLAGS) & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
+      const int a0 = wave_bcast_i(G.a0, g), a1 = wave_bcast_i(G.a1, g), b0 = wave_bcast_i(G.b0, g), b1 = wave_bcast_i(G.b1, g);
+      const int gflags = wave_bcast_i(G.flags, g);
+      const float mg = (gflags & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
       const int nb = b1 - b0;
       if (ab < 0) { ab = a0; abatch = a1 - a0; }
       const int ae = ab + abatch < a1 ? ab + abatch : a1;
-      int wn2 = collide_sweep(c, g, ab, ae, b0, b1, same, mg, wn);
+      int wn2 = collide_sweep(c, g, ab, ae, b0, b1, gflags, mg, wn);
       AGX_CTICK(10)
       bool fits = wn2 <= WL_CAP;
       if (!fits && wn == 0) {
@@ -644,7 +648,7 @@ AGX_DEV void collide(Ctx& c) {
         if (ab < 0) continue;
       }
     }
-    collide_flush(c, wn, cs, brk, slack, gender); wn = 0;
+    collide_flush(c, wn, cs, brk, slack, G); wn = 0;
     ct0 = c.timing ? wave_clock() : 0;
   }
   c.ncon = cs.ncon; c.near_mask = cs.near_mask; c.overflow = cs.overflow;

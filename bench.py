@@ -94,7 +94,7 @@ def main():
         return _cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--pool', type=int, default=256)

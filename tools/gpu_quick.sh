@@ -1,5 +1,4 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 timeout 600 python -m pytest tests -m gpu -x -q -s 2>&1 | grep "worst\|passed\|failed"
-timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline | python -c "
-import json,sys
-j=json.loads(sys.stdin.read()); print(round(j['value']), j['roofline']['kernels_ms_per_step'])"
+STEPS=200 bash tools/ab_run.sh
+AGX_LIB=$PWD/assistive_gym_amd/lib/variants/b_greg.so timeout 300 python tools/gpu_diag.py 2>&1 | grep "narrowphase\|selection\|sweep\|collide  \|cull\|aabbs"
