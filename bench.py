@@ -33,10 +33,13 @@ def _cpu_worker(path, seed, n_steps):
     from assistive_gym_amd.blob import ModelBlob
     blob = ModelBlob.load('feeding_jaco')
     o = Oracle(blob)
-    st = np.load(path)
+    init = np.load(path)
+    st = init.copy()
     rng = np.random.RandomState(seed)
     t0 = time.perf_counter()
     for k in range(n_steps):
+        if k and k % 200 == 0:
+            st[:] = init            # episode end: back to a post-reset state, like the device-side auto-reset
         a = rng.uniform(-1, 1, (len(st), blob.act_dim)).astype(np.float32)
         for i in range(len(st)):
             o.step(st[i], a[i])
