@@ -29,7 +29,7 @@ constexpr int MAX_ROWS = 160;
 constexpr int ST_WORDS = 336;
 constexpr int CON_STRIDE = 16;
 constexpr int HDR_STRIDE = 10;
-constexpr int ARENA_WORDS = 3520;
+constexpr int ARENA_WORDS = 3592;
 constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
 
 // ---- LDS layout (float words) -------------------------------------------------------------
@@ -401,7 +401,7 @@ AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
 //      them, in order) become contacts.
 // The contact order (group, a, selection order) is what the oracle produces, so the solver rows
 // are identical.
-constexpr int WL_MAX = 192, CAND_STRIDE = 8;
+constexpr int WL_MAX = 200, CAND_STRIDE = 8;
 constexpr int A_WL = ABS * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18
 constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, n, dist (pb = pa - dist n)
 static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
