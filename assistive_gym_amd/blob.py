@@ -39,6 +39,30 @@ class ModelBlob:
         w.view(np.float32)[self.h['OFF_PARAMS'] + L.P[key]] = value
         return ModelBlob(w, self.meta)
 
+    def coop(self):
+        """Returns the co-op flavour of this blob (<Task><Robot>HumanEnv, feeding_envs.py:64-67): the human's
+        controllable joints (head, ACT indices after the robot's) take actions and the observation is
+        followed by the human's (feeding.py:102-111)."""
+        w = self.words.copy()
+        wi = w.view(np.int32)
+        n_h = sum(1 for d in range(self.nrobot, self.ndof) if self.robot_i(d, 'ACT') >= 0)
+        wi[L.H['ACT_DIM']] = self.act_dim_robot + n_h
+        wi[L.H['OBS_DIM']] = self.obs_dim_robot + 19 + n_h
+        wi[self.h['OFF_TASK'] + L.T['COOP']] = 1
+        return ModelBlob(w, self.meta)
+
+    @property
+    def is_coop(self):
+        return self.task_i('COOP') == 1
+
+    @property
+    def act_dim_robot(self):
+        return sum(1 for d in range(self.nrobot) if self.robot_i(d, 'ACT') >= 0)
+
+    @property
+    def obs_dim_robot(self):
+        return 18 + self.act_dim_robot
+
     def rec(self, d, gender=0):
         """link record index of DoF d (human DoFs have one record per gender)"""
         return d if d < self.nrobot else d + gender * self.nhdof
@@ -90,6 +114,6 @@ class ModelBlob:
             food_alive=si[:, e + L.E['FOOD_ALIVE']], food_active=si[:, e + L.E['FOOD_ACTIVE']],
             iteration=si[:, e + L.E['ITERATION']], task_success=si[:, e + L.E['TASK_SUCCESS']],
             rng=si[:, e + L.E['RNG']:e + L.E['RNG'] + 2], total_food=si[:, e + L.E['TOTAL_FOOD']],
-            frozen=si[:, e + L.E['FROZEN']],
+            frozen=si[:, e + L.E['FROZEN']], limit_scale=s[:, e + L.E['LIMIT_SCALE']],
             tremor=s[:, h['S_TREMOR']:h['S_TREMOR'] + self.nhdof],
             tremor_target=s[:, h['S_TREMOR'] + self.nhdof:h['S_TREMOR'] + 2 * self.nhdof])

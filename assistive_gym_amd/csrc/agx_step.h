@@ -96,6 +96,8 @@ struct Ctx {
   int lane;
   int ndof, nfree, nhuman, ncoll, ngroup, nfood, nv;
   int nrobot, nhdof, gender, frozen, s_tremor;   // articulated set: robot DoFs [0,nrobot), human DoFs [nrobot,ndof)
+  float limit_scale;    // scale of the human joint limits of this environment (impairment 'limits')
+  bool coop;            // the human is controllable (TASK.COOP)
   int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
   int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
   float dt;
@@ -112,6 +114,9 @@ struct Ctx {
 #define RREC(c, d) ((d) < (c).nrobot ? (d) : (d) + (c).gender * (c).nhdof)
 #define RBF(c, d, k) ((c).bf[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
 #define RBI(c, d, k) ((c).bi[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
+// joint limits of DoF d; the human's are scaled per environment (human_creation.py:199-200)
+#define DLO(c, d) (RBF(c, d, AGX_R_LOWER) * (RBI(c, d, AGX_R_KIND) == 1 ? (c).limit_scale : 1.f))
+#define DHI(c, d) (RBF(c, d, AGX_R_UPPER) * (RBI(c, d, AGX_R_KIND) == 1 ? (c).limit_scale : 1.f))
 #define FBF(c, b, k) ((c).bf[(c).o_free + (b) * AGX_F_STRIDE + (k)])
 #define CLF(c, i, k) ((c).bf[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
 #define CLI(c, i, k) ((c).bi[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
@@ -128,7 +133,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.o_vert = h[AGX_H_OFF_VERT]; c.o_group = h[AGX_H_OFF_GROUP]; c.o_task = h[AGX_H_OFF_TASK]; c.o_dirs = h[AGX_H_OFF_DIRS];
   c.s_q = h[AGX_H_S_Q]; c.s_qd = h[AGX_H_S_QD]; c.s_qt = h[AGX_H_S_QT]; c.s_free = h[AGX_H_S_FREE]; c.s_base = h[AGX_H_S_BASE];
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
-  c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0;
+  c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
   c.dt = PRM(c, AGX_P_DT);
   c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
@@ -772,7 +777,7 @@ AGX_DEV void build_rows(Ctx& c) {
     const int d = (lane - 16) >> 1, side = (lane - 16) & 1;
     if (d < n && RBI(c, d, AGX_R_HAS_LIMIT) && !(c.frozen >> d & 1)) {
       float q = L[L_ST + c.s_q + d];
-      float gap = side == 0 ? q - RBF(c, d, AGX_R_LOWER) : RBF(c, d, AGX_R_UPPER) - q;
+      float gap = side == 0 ? q - DLO(c, d) : DHI(c, d) - q;
       if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
         active = true; if (d < c.nrobot) r.robot = true; else r.human = true;
         const float sg = side == 0 ? 1.f : -1.f;
@@ -1153,7 +1158,7 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
     float qd = L[L_VEL + d], q = L[L_ST + c.s_q + d] + dt * qd;
     // Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250)
     if (RBI(c, d, AGX_R_KIND) == 1 && !(c.frozen >> d & 1)) {
-      const float lo = RBF(c, d, AGX_R_LOWER), hi = RBF(c, d, AGX_R_UPPER);
+      const float lo = DLO(c, d), hi = DHI(c, d);
       if (q < lo) { q = lo; qd = 0.f; } else if (q > hi) { q = hi; qd = 0.f; }
     }
     L[L_ST + c.s_qd + d] = qd; L[L_ST + c.s_q + d] = q;
@@ -1191,6 +1196,8 @@ AGX_DEV void load_env(Ctx& c, const float* gstate, int sw) {
   for (int k = lane; k < sw; k += 64) L[L_ST + k] = gstate[k];
   wave_sync();
   c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
+  { const float ls = c.lds[L_ST + c.s_env + AGX_E_LIMIT_SCALE]; c.limit_scale = ls > 0.f ? ls : 1.f; }   // records written before v6 carry 0
+  c.coop = TKI(c, AGX_T_COOP) == 1;
   if (lane == 0) { const float* r = L + L_ST + c.s_base; st3(L + L_BASE, ld3(r)); stm3(L + L_BASE + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
   if (lane < c.nhuman) { const float* r = L + L_ST + c.s_human + 7 * lane; float* h = L + L_HUMAN + 12 * lane; st3(h, ld3(r)); stm3(h + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
   if (lane < c.ndof) { int m = 0; for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) m |= 1 << d; c.ldsi[L_MISC + M_ANC + lane] = m; }
@@ -1215,7 +1222,7 @@ AGX_DEV void tool_base_pose(const Ctx& c, v3& p, m3& R) {
   R = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
 }
 // FeedingEnv._get_obs (feeding.py:85-112), robot part; every lane computes, lane 0 writes
-AGX_DEV void observe(const Ctx& c, float tool_force, float* gobs) {
+AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* gobs) {
   const float* L = c.lds;
   v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
   v3 sp; m3 sR; tool_base_pose(c, sp, sR);
@@ -1228,13 +1235,26 @@ AGX_DEV void observe(const Ctx& c, float tool_force, float* gobs) {
     gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z;
     gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
     gobs[o++] = spr.x - tpr.x; gobs[o++] = spr.y - tpr.y; gobs[o++] = spr.z - tpr.z;
-    for (int d = 0; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
       float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
       gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
     }
     gobs[o++] = hpr.x; gobs[o++] = hpr.y; gobs[o++] = hpr.z;
     gobs[o++] = hq.x; gobs[o++] = hq.y; gobs[o++] = hq.z; gobs[o++] = hq.w;
     gobs[o++] = tool_force;
+    if (c.coop) {   // human_obs (feeding.py:102-108): the same quantities in the frame of the human's base (collision body 0)
+      const v3 hb = ld3(L + L_HUMAN); const m3 HR = ldm3(L + L_HUMAN + 3);
+      const v3 sph = tmul(HR, sp - hb); const q4 sqh = m3_to_quat(mul_at(HR, sR));
+      const v3 hph = tmul(HR, ld3(L + L_LINKP + 3 * hl) - hb); const q4 hqh = m3_to_quat(mul_at(HR, ldm3(L + L_LINKR + 9 * hl)));
+      const v3 tph = tmul(HR, ld3(L + L_ST + c.s_env + AGX_E_TARGET) - hb);
+      gobs[o++] = sph.x; gobs[o++] = sph.y; gobs[o++] = sph.z;
+      gobs[o++] = sqh.x; gobs[o++] = sqh.y; gobs[o++] = sqh.z; gobs[o++] = sqh.w;
+      gobs[o++] = sph.x - tph.x; gobs[o++] = sph.y - tph.y; gobs[o++] = sph.z - tph.z;
+      for (int d = c.nrobot; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) gobs[o++] = L[L_ST + c.s_q + d];
+      gobs[o++] = hph.x; gobs[o++] = hph.y; gobs[o++] = hph.z;
+      gobs[o++] = hqh.x; gobs[o++] = hqh.y; gobs[o++] = hqh.z; gobs[o++] = hqh.w;
+      gobs[o++] = robot_force; gobs[o++] = tool_force;
+    }
   }
 }
 
@@ -1269,23 +1289,30 @@ AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction
     if (lane == 0) { Li[L_ST + c.s_env + AGX_E_ITERATION] = iteration; ((int*)gstate)[c.s_env + AGX_E_ITERATION] = iteration; }
     if (lane < c.ndof) {
       const int d = lane, ai = RBI(c, d, AGX_R_ACT);
-      if (ai >= 0) {
+      const bool is_human = d >= c.nrobot;
+      const int k2 = is_human ? d - c.nrobot : 0;
+      const float tsign = (iteration % 2 == 0) ? 1.f : -1.f;
+      bool tremor_on = false;                         // impairment == 'tremor'
+      for (int k = 0; k < c.nhdof; k++) if (L[L_ST + c.s_tremor + k] != 0.f) tremor_on = true;
+      if (ai >= 0 && (!is_human || c.coop)) {
         // the limit test of take_step is discontinuous (an action that would cross a limit is zeroed,
         // env.py:206-211); it is evaluated in double like the reference's numpy code so that a joint
         // resting exactly on a limit takes the same branch
         const float a32 = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
-        double a = (double)a32, qa = (double)L[L_ST + c.s_q + d]; const double lo = (double)RBF(c, d, AGX_R_LOWER), hi = (double)RBF(c, d, AGX_R_UPPER);
+        double a = (double)a32, qa = (double)L[L_ST + c.s_q + d]; const double lo = (double)DLO(c, d), hi = (double)DHI(c, d);
+        double tt = (double)L[L_ST + c.s_tremor + c.nhdof + k2];
         for (int k = 0; k < nsub; k++) {
           bool below = qa + a < lo, above = qa + a > hi;
           if (below || above) a = 0.0;
           if (below) qa = lo; if (above) qa = hi;
-          qa += a;
+          if (is_human && tremor_on) { tt += a; qa = tt + (double)(L[L_ST + c.s_tremor + k2] * tsign); }   // env.py:212-215
+          else qa += a;
         }
         L[L_ST + c.s_qt + d] = (float)qa; gstate[c.s_qt + d] = (float)qa;
+        if (is_human && tremor_on) { L[L_ST + c.s_tremor + c.nhdof + k2] = (float)tt; gstate[c.s_tremor + c.nhdof + k2] = (float)tt; }
       }
-      if (d >= c.nrobot) {   // tremor (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd)
-        const int k = d - c.nrobot;
-        const float qt = L[L_ST + c.s_tremor + c.nhdof + k] + L[L_ST + c.s_tremor + k] * ((iteration % 2 == 0) ? 1.f : -1.f);
+      if (is_human && !c.coop) {   // tremor without control (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd)
+        const float qt = L[L_ST + c.s_tremor + c.nhdof + k2] + L[L_ST + c.s_tremor + k2] * tsign;
         L[L_ST + c.s_qt + d] = qt; gstate[c.s_qt + d] = qt;
       }
     }
@@ -1326,6 +1353,8 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
     for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
   wave_sync();
   c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
+  { const float ls = c.lds[L_ST + c.s_env + AGX_E_LIMIT_SCALE]; c.limit_scale = ls > 0.f ? ls : 1.f; }   // records written before v6 carry 0
+  c.coop = TKI(c, AGX_T_COOP) == 1;
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0, dv1;
   pgs(c, dv0, dv1);
@@ -1338,7 +1367,7 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
 AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float* lds, int lane) {
   Ctx c; ctx_init(c, blob, lds, lane);
   load_env(c, gstate, c.bi[AGX_H_STATE_WORDS]);
-  kinematics(c); update_target(c); observe(c, 0.f, gobs);
+  kinematics(c); update_target(c); observe(c, 0.f, 0.f, gobs);
 }
 
 // finish: everything FeedingEnv.step does after take_step (feeding.py:17-43)
@@ -1367,7 +1396,7 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
     }
   }
   const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), total_f = robot_f + tool_f;
-  observe(c, tool_f, gobs);
+  observe(c, robot_f, tool_f, gobs);
   // get_food_rewards (feeding.py:50-83)
   float food_reward = 0.f, food_hit = 0.f, vel_sum = 0.f;
   int alive = Li[L_ST + c.s_env + AGX_E_FOOD_ALIVE], active = Li[L_ST + c.s_env + AGX_E_FOOD_ACTIVE];

@@ -56,24 +56,28 @@ except Exception:                        # minimal stand-ins with the attributes
 SETTLE_STEPS = 25       # feeding.py:178-179
 
 
+def _box(n, bound):
+    v = np.ones(n, dtype=np.float32) * bound
+    return spaces.Box(low=-v, high=v, dtype=np.float32)
+
+
 class FeedingJacoEnv(_Base):
     """FeedingJaco-v1: Jaco arm on a wheelchair feeds a static (non-cooperating) human."""
+    coop = False
 
     def __init__(self, device=0):
         self.task = 'feeding'
         self.time_step, self.frame_skip = 0.02, 5                                    # env.py:21
-        self.blob = ModelBlob.load('feeding_jaco')
+        base = ModelBlob.load('feeding_jaco')
+        self.blob = base.coop() if self.coop else base
         self.device = device
-        self.action_robot_len, self.action_human_len = self.blob.act_dim, 0          # env.py:40-41
-        self.obs_robot_len, self.obs_human_len = self.blob.obs_dim, 0                # feeding.py:10, env.py:44
-        one = np.ones(self.action_robot_len, dtype=np.float32)
-        big = np.ones(self.obs_robot_len, dtype=np.float32) * 1000000000.0
-        self.action_space = spaces.Box(low=-one, high=one, dtype=np.float32)          # env.py:42
-        self.observation_space = spaces.Box(low=-big, high=big, dtype=np.float32)     # env.py:45
-        self.action_space_robot = spaces.Box(low=-one, high=one, dtype=np.float32)
-        self.observation_space_robot = spaces.Box(low=-big, high=big, dtype=np.float32)
-        self.action_space_human = spaces.Box(low=np.zeros(0, np.float32), high=np.zeros(0, np.float32), dtype=np.float32)
-        self.observation_space_human = spaces.Box(low=np.zeros(0, np.float32), high=np.zeros(0, np.float32), dtype=np.float32)
+        self.action_robot_len, self.obs_robot_len = base.act_dim, base.obs_dim       # env.py:40-44, feeding.py:10
+        self.action_human_len = self.blob.act_dim - base.act_dim                     # controllable human joints (feeding_envs.py:11)
+        self.obs_human_len = self.blob.obs_dim - base.obs_dim                        # feeding.py:10: 23 in co-op
+        self.action_space = _box(self.action_robot_len + self.action_human_len, 1.0)               # env.py:42
+        self.observation_space = _box(self.obs_robot_len + self.obs_human_len, 1000000000.0)       # env.py:45
+        self.action_space_robot, self.observation_space_robot = _box(self.action_robot_len, 1.0), _box(self.obs_robot_len, 1000000000.0)
+        self.action_space_human, self.observation_space_human = _box(self.action_human_len, 1.0), _box(self.obs_human_len, 1000000000.0)
         self.gui = False
         self.iteration = 0
         self.task_success = 0
@@ -106,21 +110,32 @@ class FeedingJacoEnv(_Base):
         st.set_state(state)
         st.settle(SETTLE_STEPS)
         self.iteration, self.task_success = 0, 0
-        return st.observe_host()[0].astype(np.float64)
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+    def _split_obs(self, obs):
+        if not self.coop:
+            return obs
+        return {'robot': obs[:self.obs_robot_len], 'human': obs[self.obs_robot_len:]}              # feeding.py:110-111
 
     def step(self, action):
+        if self.coop and isinstance(action, dict):                                                 # feeding.py:13-14
+            action = np.concatenate([action['robot'], action['human']])
         action = np.asarray(action, dtype=np.float32)
-        if action.shape != (self.action_robot_len,):
+        n_act = self.action_robot_len + self.action_human_len
+        if action.shape != (n_act,):
             # the reference prints and exit()s (env.py:198-200); a library must not kill the process
-            raise ValueError('Received agent actions of length %d does not match expected action length of %d'
-                             % (action.size, self.action_robot_len))
+            raise ValueError('Received agent actions of length %d does not match expected action length of %d' % (action.size, n_act))
         obs, rew, done, info = self._ensure_stepper().step_host(action[None])
         self.iteration += 1
         self.total_force_on_human = float(info[0, 0])
         out_info = {'total_force_on_human': float(info[0, 0]), 'task_success': int(info[0, 1]),
                     'action_robot_len': self.action_robot_len, 'action_human_len': self.action_human_len,
                     'obs_robot_len': self.obs_robot_len, 'obs_human_len': self.obs_human_len}      # feeding.py:36
-        return obs[0].astype(np.float64), float(rew[0]), bool(done[0]), out_info
+        o, r, d = self._split_obs(obs[0].astype(np.float64)), float(rew[0]), bool(done[0])
+        if not self.coop:
+            return o, r, d, out_info
+        # co-optimisation: per-agent dictionaries (feeding.py:41-43)
+        return o, {'robot': r, 'human': r}, {'robot': d, 'human': d, '__all__': d}, {'robot': out_info, 'human': out_info}
 
     def render(self, mode='human'):
         return None          # GUI / EGL rendering is outside the hot path
@@ -140,7 +155,13 @@ class FeedingJacoEnv(_Base):
         self._ensure_stepper().set_state(np.asarray(state, dtype=np.float32).reshape(1, -1))
 
 
-ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv}
+class FeedingJacoHumanEnv(FeedingJacoEnv):
+    """FeedingJacoHuman-v1 (feeding_envs.py:64-67): the human's head joints are controllable; actions,
+    observations, rewards, dones and infos are per-agent dictionaries as RLlib's MultiAgentEnv expects."""
+    coop = True
+
+
+ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv}
 
 
 def make(env_id):

@@ -113,7 +113,9 @@ class FeedingJacoReset:
         v['qt'][0, nr:] = hq_dyn
         v['tremor'][0] = tremors
         v['tremor_target'][0] = hq_dyn                                             # human.py:123 target_joint_angles
-        v['frozen'][0] = 0 if impairment == 'tremor' else (((1 << b.nhdof) - 1) << nr)
+        # a controllable human keeps its controllable joints dynamic (human.py:108)
+        v['frozen'][0] = 0 if (impairment == 'tremor' or b.is_coop) else (((1 << b.nhdof) - 1) << nr)
+        v['limit_scale'][0] = limit_scale
         v['base'][0, :3], v['base'][0, 3:] = self.base_pos, self.base_quat
         # tool in the gripper (tool.py:49-62)
         tp, tq = kin.tool_pose(self.base_pos, self.base_quat, q)

@@ -42,15 +42,15 @@ C = dict(BODY=0, NVERT=1, VOFF=2, RADIUS=3, FRICTION=4, TAG=5, AABB_C=6, AABB_H=
 G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
 T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV=7, SUCCESS_FRAC=8, MOUTH_DIST=9,
          SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
-         TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COUNT=40)
+         TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, COUNT=40)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
-         TOTAL_FOOD=11, FROZEN=12, COUNT=16)
+         TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, COUNT=16)
 BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
 PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
 HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8)
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 5
+MAGIC, VERSION = 0x31584741, 6
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -347,7 +347,9 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
                 recs[k, R['INERTIA']:R['INERTIA'] + 3] = box_inertia(hm.mass[j], lo, hi)
             recs[k, R['LOWER']], recs[k, R['UPPER']] = hm.lower[j], hm.upper[j]
             recs[k, R['KP']], recs[k, R['KD']], recs[k, R['MAXF']] = 0.025, 1.0, 1.0      # feeding.py:122, human.py:69
-            ints.append(dict(PARENT=PARENT_HUMAN_BASE if par < 0 else nrobot + hd.index(par), HAS_LIMIT=1, ACT=-1, PB_INDEX=j, KIND=1))
+            # ACT: index of this joint in the co-op action vector (robot actions first, then the human's
+            # controllable joints = head joints, feeding_envs.py:11); ignored unless TASK.COOP is set
+            ints.append(dict(PARENT=PARENT_HUMAN_BASE if par < 0 else nrobot + hd.index(par), HAS_LIMIT=1, ACT=len(arm) + k, PB_INDEX=j, KIND=1))
             assert par < 0 or par in hd
         human_link_rec[gender] = (recs, ints)
     ndof = nrobot + nhdof

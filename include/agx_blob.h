@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 5
+#define AGX_BLOB_VERSION 6
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
 
 /* ---- header: int32[AGX_H_COUNT] at word 0 ------------------------------------------------ */
@@ -147,6 +147,8 @@ enum {
   AGX_T_TOOL_QUAT = 29,  /* float[4] tool frame in the end-effector frame (jaco.py:31)        */
   AGX_T_TOOL_MAXF = 33,  /* tool.py:47                                                        */
   AGX_T_EPISODE_LEN = 34,/* feeding.py:37                                                     */
+  AGX_T_COOP = 35,       /* int: 1 = the human is controllable (<Task><Robot>HumanEnv, feeding_envs.py:44-69):
+                          * ACT_DIM / OBS_DIM of the header include the human's action and observation    */
   AGX_T_COUNT = 40
 };
 
@@ -162,6 +164,8 @@ enum {
   AGX_E_RNG = 9,            /* uint32[2] per-env counter RNG for the teleport draw            */
   AGX_E_TOTAL_FOOD = 11,    /* int                                                            */
   AGX_E_FROZEN = 12,        /* int bitmask of DoFs made static (mass 0 links, human.py:104-110) */
+  AGX_E_LIMIT_SCALE = 13,   /* scale of the human joint limits (impairment 'limits', human.py:85,
+                             * human_creation.py:199-200)                                          */
   AGX_E_COUNT = 16
 };
 

@@ -185,6 +185,8 @@ typedef struct {
   double plane_mu, target[3];
   int gender, alive, active, iteration, success, total_food, frozen;
   double tremor[MAXDOF], tremor_target[MAXDOF];
+  double limit_scale;    /* scale of the human joint limits (impairment 'limits') */
+  int coop;              /* the human is controllable (TASK.COOP) */
   uint32_t rng[2];
   /* derived, per substep */
   xf_t link[MAXDOF], freex[MAXFREE];
@@ -217,6 +219,8 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
   const float* e = st + m->s_env; const int32_t* ei = (const int32_t*)e;
   s->plane_mu = e[AGX_E_PLANE_FRICTION]; s->gender = ei[AGX_E_GENDER]; g_gender = s->gender;
   s->frozen = ei[AGX_E_FROZEN];
+  s->limit_scale = e[AGX_E_LIMIT_SCALE] > 0 ? e[AGX_E_LIMIT_SCALE] : 1.0;   /* records written before v6 carry 0 */
+  s->coop = TI(m, AGX_T_COOP) == 1;
   for (int k = 0; k < m->nhdof; k++) { s->tremor[k] = st[m->s_tremor + k]; s->tremor_target[k] = st[m->s_tremor + m->nhdof + k]; }
   for (int k = 0; k < 3; k++) s->target[k] = e[AGX_E_TARGET + k];
   s->alive = ei[AGX_E_FOOD_ALIVE]; s->active = ei[AGX_E_FOOD_ACTIVE]; s->iteration = ei[AGX_E_ITERATION];
@@ -231,11 +235,16 @@ static void sim_store(const sim_t* s, float* st) {
     for (int k = 0; k < 3; k++) { r[k] = (float)s->fpos[b][k]; r[7 + k] = (float)s->fv[b][k]; r[10 + k] = (float)s->fw[b][k]; }
     for (int k = 0; k < 4; k++) r[3 + k] = (float)s->fquat[b][k];
   }
+  for (int k = 0; k < m->nhdof; k++) st[m->s_tremor + m->nhdof + k] = (float)s->tremor_target[k];
   float* e = st + m->s_env; int32_t* ei = (int32_t*)e;
   for (int k = 0; k < 3; k++) e[AGX_E_TARGET + k] = (float)s->target[k];
   ei[AGX_E_FOOD_ALIVE] = s->alive; ei[AGX_E_FOOD_ACTIVE] = s->active; ei[AGX_E_ITERATION] = s->iteration;
   ei[AGX_E_TASK_SUCCESS] = s->success; ei[AGX_E_RNG] = (int32_t)s->rng[0]; ei[AGX_E_RNG + 1] = (int32_t)s->rng[1];
 }
+
+/* joint limits of DoF d; the human's are scaled per environment (human_creation.py:199-200) */
+static double dof_lower(const sim_t* s, int d) { return RF(s->m, d, AGX_R_LOWER) * (RI(s->m, d, AGX_R_KIND) == 1 ? s->limit_scale : 1.0); }
+static double dof_upper(const sim_t* s, int d) { return RF(s->m, d, AGX_R_UPPER) * (RI(s->m, d, AGX_R_KIND) == 1 ? s->limit_scale : 1.0); }
 
 /* ------------------------------------------------------------------------------------ kinematics
  * K1 of SURVEY 2.2: what getLinkState(computeForwardKinematics=True) (agent.py:52) reads back. */
@@ -696,7 +705,7 @@ static void build_rows(sim_t* s) {
   for (int d = 0; d < n; d++) {
     if (!RI(m, d, AGX_R_HAS_LIMIT) || (s->frozen >> d & 1)) continue;
     for (int side = 0; side < 2; side++) {
-      double gap = side == 0 ? s->q[d] - RF(m, d, AGX_R_LOWER) : RF(m, d, AGX_R_UPPER) - s->q[d];
+      double gap = side == 0 ? s->q[d] - dof_lower(s, d) : dof_upper(s, d) - s->q[d];
       if (gap >= PARAM(m, AGX_P_LIMIT_ACT)) continue;
       row_t* r = NEWROW(); r->J[d] = side == 0 ? 1.0 : -1.0; finish_row(s, r);
       double rv = row_vel(s, r);
@@ -840,8 +849,8 @@ static void substep(sim_t* s) {
     s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d];
     /* Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250) */
     if (RI(m, d, AGX_R_KIND) == 1 && !(s->frozen >> d & 1)) {
-      if (s->q[d] < RF(m, d, AGX_R_LOWER)) { s->q[d] = RF(m, d, AGX_R_LOWER); s->qd[d] = 0; }
-      else if (s->q[d] > RF(m, d, AGX_R_UPPER)) { s->q[d] = RF(m, d, AGX_R_UPPER); s->qd[d] = 0; }
+      if (s->q[d] < dof_lower(s, d)) { s->q[d] = dof_lower(s, d); s->qd[d] = 0; }
+      else if (s->q[d] > dof_upper(s, d)) { s->q[d] = dof_upper(s, d); s->qd[d] = 0; }
     }
   }
   for (int b = 0; b < s->nfree; b++) {
@@ -877,9 +886,17 @@ static void tool_base_pose(const sim_t* s, double* p, double* R) {
   double rq[4] = {FF(m, tb, AGX_F_REFQUAT), FF(m, tb, AGX_F_REFQUAT + 1), FF(m, tb, AGX_F_REFQUAT + 2), FF(m, tb, AGX_F_REFQUAT + 3)}, Rr[9];
   quat_to_mat(rq, Rr); xf_apply(&s->freex[tb], rp, p); mm3(s->freex[tb].R, Rr, R);
 }
-/* FeedingEnv._get_obs (feeding.py:85-112), robot part */
+static void to_human_frame(const sim_t* s, const double* p, const double* R, double* po, double* qo) {
+  /* human.convert_to_realworld: the human's base is collision body 0 (link -1) */
+  const xf_t* B = &s->human[0];
+  double d[3]; sub3(p, B->p, d); mtv3(B->R, d, po);
+  if (R && qo) { double Bt[9], Rr[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Bt[3 * r + c] = B->R[3 * c + r];
+    mm3(Bt, R, Rr); mat_to_quat(Rr, qo); }
+}
+/* FeedingEnv._get_obs (feeding.py:85-112): robot part, followed by the human part in co-op */
 static void observe(sim_t* s, double robot_force, double tool_force, float* obs) {
-  const agxo_model* m = s->m; (void)robot_force;
+  const agxo_model* m = s->m;
   double sp[3], sR[9], spr[3], sqr[4], hpr[3], hqr[4], tpr[3];
   tool_base_pose(s, sp, sR);
   to_base_frame(s, sp, sR, spr, sqr);
@@ -890,12 +907,25 @@ static void observe(sim_t* s, double robot_force, double tool_force, float* obs)
   for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k];
   for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k];
   for (int k = 0; k < 3; k++) obs[o++] = (float)(spr[k] - tpr[k]);
-  for (int d = 0; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
     double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
   }
   for (int k = 0; k < 3; k++) obs[o++] = (float)hpr[k];
   for (int k = 0; k < 4; k++) obs[o++] = (float)hqr[k];
   obs[o++] = (float)tool_force;
+  if (s->coop) {   /* human_obs, feeding.py:102-108 */
+    double sph[3], sqh[4], hph[3], hqh[4], tph[3];
+    to_human_frame(s, sp, sR, sph, sqh);
+    to_human_frame(s, s->link[hl].p, s->link[hl].R, hph, hqh);
+    to_human_frame(s, s->target, NULL, tph, NULL);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)sph[k];
+    for (int k = 0; k < 4; k++) obs[o++] = (float)sqh[k];
+    for (int k = 0; k < 3; k++) obs[o++] = (float)(sph[k] - tph[k]);
+    for (int d = m->nrobot; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) obs[o++] = (float)s->q[d];
+    for (int k = 0; k < 3; k++) obs[o++] = (float)hph[k];
+    for (int k = 0; k < 4; k++) obs[o++] = (float)hqh[k];
+    obs[o++] = (float)robot_force; obs[o++] = (float)tool_force;
+  }
 }
 static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int* food_hit_mask) {
   const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
@@ -932,21 +962,28 @@ void agxo_step(const agxo_model* m, float* state, const float* action, float* ob
    * 5x accumulate with per-joint limit clamp, set motor targets */
   s->iteration += 1;
   double act_norm2 = 0;
+  int tremor_on = 0;
+  for (int k = 0; k < m->nhdof; k++) if (s->tremor[k] != 0) tremor_on = 1;          /* impairment == 'tremor' */
+  const double tsign = (s->iteration % 2 == 0) ? 1.0 : -1.0;
   for (int d = 0; d < s->ndof; d++) {
     int ai = RI(m, d, AGX_R_ACT); if (ai < 0) continue;
+    const int is_human = d >= m->nrobot;
+    if (is_human && !s->coop) continue;                /* the human only takes actions when controllable */
     float a32 = action[ai]; if (a32 < -1.0f) a32 = -1.0f; if (a32 > 1.0f) a32 = 1.0f;
     a32 *= (float)PARAM(m, AGX_P_ACTION_SCALE);
-    double a = a32, qa = s->q[d], lo = RF(m, d, AGX_R_LOWER), hi = RF(m, d, AGX_R_UPPER);
+    double a = a32, qa = s->q[d], lo = dof_lower(s, d), hi = dof_upper(s, d);
+    const int k2 = d - m->nrobot;
     for (int k = 0; k < nsub; k++) {
       int below = qa + a < lo, above = qa + a > hi;
       if (below || above) a = 0;
       if (below) qa = lo; if (above) qa = hi;
-      qa += a;
+      if (is_human && tremor_on) { s->tremor_target[k2] += a; qa = s->tremor_target[k2] + s->tremor[k2] * tsign; }   /* env.py:212-215 */
+      else qa += a;
     }
     s->qt[d] = qa;
   }
-  /* tremor (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd) */
-  for (int k = 0; k < m->nhdof; k++) s->qt[m->nrobot + k] = s->tremor_target[k] + s->tremor[k] * ((s->iteration % 2 == 0) ? 1.0 : -1.0);
+  /* tremor without control (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd) */
+  if (!s->coop) for (int k = 0; k < m->nhdof; k++) s->qt[m->nrobot + k] = s->tremor_target[k] + s->tremor[k] * tsign;
   for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
   for (int k = 0; k < nsub; k++) substep(s);
   kinematics(s); /* poses after the last integration, as the getters in _get_obs see them */

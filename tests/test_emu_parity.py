@@ -115,3 +115,41 @@ def test_edge_contact_is_not_lost(blob):
     assert pairs_e == pairs_o
     k = pairs_o.index(robot_o[0])
     assert abs(ce[k, 13] - con[k][11]) < 1e-5 and np.abs(ce[k, 10:13] - np.array(con[k][8:11])).max() < 1e-3
+
+
+@pytest.mark.parametrize('impairment', ['limits', 'tremor'])
+def test_coop_step_matches(blob, impairment):
+    """Co-op flavour (FeedingJacoHumanEnv, feeding_envs.py:64-67): the human's head joints take actions
+    (env.py:201-215, with the tremor branch), their limits are scaled per environment, and the
+    observation carries the human's 23 values (feeding.py:102-108)."""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    co = blob.coop().set_param('NITER', 12)
+    assert co.is_coop and co.act_dim == 11 and co.obs_dim == 48
+    emu, orc = Emu(co), Oracle(co)
+    st, infos = make_states(co, 1, seed=3301, impairment=impairment)
+    v = co.view(st[0])
+    assert int(v['frozen'][0]) == 0                                   # controllable joints are dynamic
+    assert (float(v['limit_scale'][0]) < 1.0) == (impairment == 'limits')
+    rng = np.random.RandomState(6)
+    so, se = st[0].copy(), st[0].copy()
+    orc.settle(so, 3); emu.settle(se, 3)
+    moved = 0.0
+    for k in range(3):
+        a = rng.uniform(-1, 1, co.act_dim).astype(np.float32)
+        a[7:] = np.sign(a[7:])                                        # drive the head joints hard, into their limits
+        s1, s2 = so.copy(), so.copy()
+        o_obs, o_rew, o_done, o_info = orc.step(s1, a)
+        e_obs, e_rew, e_done, e_info, _ = emu.step(s2, a)
+        assert o_obs.shape == (48,) and np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4
+        v1, v2 = co.view(s1), co.view(s2)
+        assert np.abs(v1['q'] - v2['q']).max() < 1e-5 and np.abs(v1['qt'] - v2['qt']).max() < 1e-6
+        assert np.abs(v1['tremor_target'] - v2['tremor_target']).max() < 1e-6
+        moved = max(moved, np.abs(v1['q'][0, co.nrobot:] - co.view(so)['q'][0, co.nrobot:]).max())
+        # human joint angles appear raw in the human observation (feeding.py:103,108)
+        assert np.abs(o_obs[25 + 10:25 + 14] - v1['q'][0, co.nrobot:]).max() < 1e-6
+        lo = np.array([co.robot_f(d, 'LOWER', gender=int(v1['gender'][0])) for d in range(co.nrobot, co.ndof)]) * float(v1['limit_scale'][0])
+        hi = np.array([co.robot_f(d, 'UPPER', gender=int(v1['gender'][0])) for d in range(co.nrobot, co.ndof)]) * float(v1['limit_scale'][0])
+        assert (v1['q'][0, co.nrobot:] >= lo - 1e-6).all() and (v1['q'][0, co.nrobot:] <= hi + 1e-6).all()
+        so = s1
+    assert moved > 1e-3                                               # the head really is actuated

@@ -16,3 +16,15 @@ def test_spaces_and_no_fallback():
     if not torch.cuda.is_available():
         with pytest.raises(AgxError):
             env.reset()
+
+
+def test_coop_spaces():
+    """FeedingJacoHumanEnv (feeding_envs.py:64-67): 7 robot + 4 human actions, 25 + 23 observations."""
+    from assistive_gym_amd.envs import FeedingJacoHumanEnv, ENV_IDS
+    assert ENV_IDS['FeedingJacoHuman-v1'] is FeedingJacoHumanEnv
+    env = FeedingJacoHumanEnv()
+    assert env.action_space.shape == (11,) and env.observation_space.shape == (48,)
+    assert env.action_space_robot.shape == (7,) and env.action_space_human.shape == (4,)
+    assert env.observation_space_robot.shape == (25,) and env.observation_space_human.shape == (23,)
+    assert (env.action_robot_len, env.action_human_len, env.obs_robot_len, env.obs_human_len) == (7, 4, 25, 23)
+    assert env.blob.is_coop

@@ -284,3 +284,43 @@ def test_food_events_match_oracle(gpu_lib, blob, oracle):
         spilled += 1 - (int(vr['food_alive'][0]) & 1)
     # the scenario exercises both events (spoon pose differs per env, so not necessarily in every env)
     assert eaten >= 1 and spilled >= 1
+
+
+def test_coop_matches_oracle(gpu_lib, blob):
+    """Co-op flavour (FeedingJacoHumanEnv): 11 actions, 48 observations, controllable head joints with
+    per-environment limit scale and the tremor branch of take_step (env.py:201-215); single-step parity
+    with the oracle over random impairments, then the dictionary surface of the scalar env."""
+    from assistive_gym_amd.libagx import Stepper
+    from assistive_gym_amd.vec_env import build_reset_pool
+    from oracle_lib import Oracle
+    co = blob.coop()
+    orc = Oracle(co)
+    n, steps = 16, 4
+    states = build_reset_pool(co, n, 5201)
+    assert (co.view(states)['frozen'] == 0).all()
+    st = Stepper(co, n)
+    rng = np.random.RandomState(9)
+    ref = states.copy()
+    worst = dict(obs=0.0, reward=0.0, q=0.0)
+    for k in range(steps):
+        st.set_state(ref)
+        a = rng.uniform(-1, 1, (n, co.act_dim)).astype(np.float32)
+        obs, rew, done, info = st.step_host(a)
+        got = st.get_state()
+        for i in range(n):
+            o_obs, o_rew, o_done, o_info = orc.step(ref[i], a[i])
+            worst['obs'] = max(worst['obs'], np.abs(obs[i] - o_obs).max())
+            worst['reward'] = max(worst['reward'], abs(rew[i] - o_rew) / max(1.0, abs(o_rew)))
+            worst['q'] = max(worst['q'], np.abs(co.view(got[i])['q'] - co.view(ref[i])['q']).max())
+            assert np.abs(co.view(got[i])['tremor_target'] - co.view(ref[i])['tremor_target']).max() < 1e-6
+    print('co-op worst deviations', worst)
+    assert obs.shape == (n, 48) and worst['obs'] < 1e-4 and worst['reward'] < 1e-4 and worst['q'] < 5e-5
+    st.close()
+    from assistive_gym_amd.envs import make
+    env = make('assistive_gym:FeedingJacoHuman-v1')
+    o = env.reset()
+    assert set(o) == {'robot', 'human'} and o['robot'].shape == (25,) and o['human'].shape == (23,)
+    o, r, d, info = env.step({'robot': env.action_space_robot.sample(), 'human': env.action_space_human.sample()})
+    assert set(r) == {'robot', 'human'} and r['robot'] == r['human'] and set(d) == {'robot', 'human', '__all__'}
+    assert info['robot']['action_human_len'] == 4 and info['human']['obs_human_len'] == 23
+    env.disconnect()

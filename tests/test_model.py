@@ -16,7 +16,11 @@ def test_jaco_tree(blob):
     lo = [blob.robot_f(d, 'LOWER') for d in range(7)]
     assert lo[1] == pytest.approx(0.820304748437) and lo[3] == pytest.approx(0.523598775598) and lo[5] == pytest.approx(1.1344640138)
     assert lo[0] < -1e9 and lo[2] < -1e9 and lo[4] < -1e9 and lo[6] < -1e9       # continuous joints, agent.py:223-225
-    assert [blob.robot_i(d, 'ACT') for d in range(14)] == [0, 1, 2, 3, 4, 5, 6, -1, -1, -1, -1, -1, -1, -1]
+    # action slots: the arm, then (only used by the co-op flavour) the human's head joints
+    assert [blob.robot_i(d, 'ACT') for d in range(14)] == [0, 1, 2, 3, 4, 5, 6, -1, -1, -1, 7, 8, 9, 10]
+    assert (blob.act_dim, blob.obs_dim, blob.is_coop) == (7, 25, False)
+    co = blob.coop()
+    assert (co.act_dim, co.obs_dim, co.is_coop) == (11, 48, True)          # feeding.py:102-111: 23 more observations
     assert [blob.robot_f(d, 'KP') for d in range(10)] == pytest.approx([0.025] * 7 + [0.05] * 3)      # feeding.py:122, robot.py:77
     assert [blob.robot_f(d, 'MAXF') for d in range(10)] == pytest.approx([1.0] * 7 + [500.0] * 3)
 
