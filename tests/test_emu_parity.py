@@ -153,3 +153,42 @@ def test_coop_step_matches(blob, impairment):
         assert (v1['q'][0, co.nrobot:] >= lo - 1e-6).all() and (v1['q'][0, co.nrobot:] <= hi + 1e-6).all()
         so = s1
     assert moved > 1e-3                                               # the head really is actuated
+
+
+@pytest.mark.parametrize('param,value', [('MAX_CONTACTS', 12), ('MAX_ROWS', 60), ('MAX_ENTRIES', 500)])
+def test_budget_truncation_matches(blob, param, value):
+    """Edge case: the contact / row / coefficient budgets are exhausted.  Both implementations keep the
+    same prefix of the contact list (collide: first MAX_CONTACTS selections; build_rows: largest prefix that
+    fits MAX_ROWS and MAX_ENTRIES) and report the overflow."""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    b = blob.set_param('NITER', 8).set_param(param, value)
+    emu, orc = Emu(b), Oracle(b)
+    st, _ = make_states(b, 1, seed=3401)
+    so, se = st[0].copy(), st[0].copy()
+    orc.settle(so, 2); emu.settle(se, 2)
+    a = np.random.RandomState(8).uniform(-1, 1, b.act_dim).astype(np.float32)
+    o_obs, o_rew, o_done, o_info = orc.step(so, a)
+    e_obs, e_rew, e_done, e_info, _ = emu.step(se, a)
+    assert o_info[6] == e_info[6] and o_info[7] == e_info[7]                 # contacts and rows after truncation
+    if param == 'MAX_CONTACTS':
+        assert o_info[6] <= value
+    if param == 'MAX_ROWS':
+        assert o_info[7] <= value
+    assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-3
+    assert np.abs(b.view(so)['q'] - b.view(se)['q']).max() < 1e-5
+
+
+def test_action_clipping_and_zero_action(blob, emu, oracle12):
+    """take_step clips to the action space before scaling (env.py:187-188): +5 behaves like +1, and a zero
+    action keeps the targets where the joints are."""
+    st, _ = make_states(blob, 1, seed=3402)
+    s0 = st[0].copy(); oracle12.settle(s0, 2)
+    big, one = np.full(blob.act_dim, 5.0, np.float32), np.ones(blob.act_dim, np.float32)
+    sa, sb = s0.copy(), s0.copy()
+    ra = emu.step(sa, big); rb = emu.step(sb, one)
+    assert np.array_equal(blob.view(sa)['qt'], blob.view(sb)['qt']) and np.array_equal(blob.view(sa)['q'], blob.view(sb)['q'])
+    assert ra[1] < rb[1]                                                     # only the action penalty differs (feeding.py:27)
+    sz = s0.copy(); emu.step(sz, np.zeros(blob.act_dim, np.float32))
+    arm = [d for d in range(blob.nrobot) if blob.robot_i(d, 'ACT') >= 0]
+    assert np.abs(blob.view(sz)['qt'][0, arm] - blob.view(s0)['q'][0, arm]).max() < 1e-6
