@@ -1,0 +1,26 @@
+"""Soak run (GPU box): 4096 envs x N steps with auto-reset, checks every 50 steps that all outputs are finite and
+reports return statistics per episode (random policy)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+n, N = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 1200
+env = FeedingJacoVecEnv(n, pool_size=256, seed=7)
+env.reset()
+g = torch.Generator(device='cuda'); g.manual_seed(0)
+ret = torch.zeros(n, device='cuda'); ep_returns = []
+bad = 0
+t0 = time.time()
+for k in range(N):
+    a = torch.rand((n, 7), device='cuda', generator=g) * 2 - 1
+    obs, rew, done, info = env.step(a)
+    ret += rew
+    if bool(done.any()):
+        ep_returns.append(ret[done.bool()].clone()); ret[done.bool()] = 0
+    if k % 50 == 49:
+        bad += int((~torch.isfinite(obs)).sum()) + int((~torch.isfinite(rew)).sum()) + int((~torch.isfinite(info)).sum())
+torch.cuda.synchronize()
+r = torch.cat(ep_returns)
+print('steps', N, 'episodes', len(r), 'non-finite values', bad, 'return mean %.2f std %.2f min %.2f max %.2f' % (r.mean(), r.std(), r.min(), r.max()),
+      'max |obs| %.2f' % float(obs.abs().max()), 'env-steps/s %.0f' % (n * N / (time.time() - t0)))
