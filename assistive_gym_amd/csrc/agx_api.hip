@@ -117,6 +117,11 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   if (hi[AGX_H_NDOF] > agx::MAX_DOF || hi[AGX_H_NFREE] > agx::MAX_FREE || hi[AGX_H_NHUMAN] > agx::MAX_HUMAN || hi[AGX_H_NCOLL] > agx::MAX_COLL ||
       hi[AGX_H_STATE_WORDS] > agx::ST_WORDS || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128 || hi[AGX_H_NGROUP] > 64)
     return fail(AGX_E_LIMIT, "agx_create: model exceeds the compiled kernel limits");
+  for (int g = 0; g < hi[AGX_H_NGROUP]; g++) {   // the broadphase compacts each collider range of a pair group into a 128-entry list
+    const int32_t* G = hi + hi[AGX_H_OFF_GROUP] + g * AGX_G_STRIDE;
+    if (G[AGX_G_A1] - G[AGX_G_A0] > 128 || G[AGX_G_B1] - G[AGX_G_B0] > 128 || (G[AGX_G_B0F] >= 0 && G[AGX_G_B1F] - G[AGX_G_B0F] > 128))
+      return fail(AGX_E_LIMIT, "agx_create: a pair group has a collider range of more than 128 colliders");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AGX_E_NOGPU, "agx_create: no HIP device (libagx has no CPU path)");
   if (device < 0 || device >= ndev) return fail(AGX_E_ARG, "agx_create: bad device index");

@@ -413,12 +413,6 @@ static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace
 static_assert(MAX_COLL <= 512, "collider indices are packed in 9 bits");
 constexpr int WL_CAP = WL_MAX - 16;   // the candidate words of the last 16 entries (128 ints) hold the A-collider list of a sweep
 
-AGX_DEV void range_aabb(const Ctx& c, int r0, int r1, float* lo, float* hi) {
-  const float* AB = c.lds + L_ARENA;
-  float l[3] = {3.0e38f, 3.0e38f, 3.0e38f}, h[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int i = r0 + c.lane; i < r1; i += 64) for (int k = 0; k < 3; k++) { l[k] = fminf(l[k], AB[ABS * i + k]); h[k] = fmaxf(h[k], AB[ABS * i + 3 + k]); }
-  for (int k = 0; k < 3; k++) { lo[k] = wave_min(l[k]); hi[k] = wave_max(h[k]); }
-}
 AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
   const float* L = c.lds; const int pr = c.ldsi[L_ARENA + A_WL + idx]; const float* cd = L + L_ARENA + A_CAND + CAND_STRIDE * idx;
   Cand k; k.gap = cd[0]; k.pa = ld3(cd + 1); k.n = ld3(cd + 4); k.dist = cd[7]; k.pb = k.pa - k.dist * k.n;
@@ -427,7 +421,7 @@ AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
 struct CollideState { int ncon, near_mask, overflow, maxc; };
 // the pair-group table, one group per lane (lane g = group g): read from the blob once per substep and
 // broadcast with v_readlane where a group's parameters are needed (a dependent blob load costs an L2 trip)
-struct GroupRegs { int a0, a1, b0, b1, flags, keep; };
+struct GroupRegs { int a0, a1, b0, b1, flags, keep; float alo[3], ahi[3], blo[3], bhi[3]; };   // + union boxes of the two collider ranges
 // |angular velocity| of the body a collider is attached to (0 for the static ones), from the table
 // filled at the start of collide()
 AGX_DEV float body_wmag(const Ctx& c, int code) {
@@ -525,28 +519,34 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
 
 // broadphase sweep of A colliders [aa, ab) x B range of group g, appended to the worklist at wn.
 // returns the new count (may exceed WL_MAX: entries beyond it are not stored)
-AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gflags, float mg, int wn) {
+AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gflags, float mg, int wn, const GroupRegs& G) {
   const float* AB = c.lds + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; const int lane = c.lane;
   const bool same = gflags & 1, no_adjacent = gflags & 4;   // bit2, self-collision: not the same link, not parent and child
-  const int nb = b1 - b0;
-  // level 1: A colliders whose box reaches the union of the B range (lanes over A), compacted into
-  // the tail of the candidate area (unused until the flush)
-  float blo[3], bhi[3]; range_aabb(c, b0, b1, blo, bhi);
-  int* ALIST = c.ldsi + L_ARENA + A_CAND + CAND_STRIDE * WL_CAP;
-  int na_live = 0;
-  for (int base = aa; base < ab; base += 64) {
-    const int a = base + lane; bool ok = a < ab;
-    if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * a + q] > bhi[q] + mg || blo[q] > AB[ABS * a + 3 + q] + mg) ok = false;
-    const uint64_t m = wave_ballot(ok);
-    if (ok) ALIST[na_live + wave_rank(m)] = a;
-    na_live += popc64(m);
+  // level 1: the A colliders whose box reaches the union box of the B range and vice versa (the union
+  // boxes were computed by the group cull, lane g holds them), compacted in ascending order into two
+  // 16-bit lists in the tail of the candidate area (unused until the flush).  Filtering both sides
+  // matters for pairs of compounds (64 spoon pieces x 44 wheelchair pieces: a handful of each are close).
+  float ulo[2][3], uhi[2][3];
+  for (int q = 0; q < 3; q++) { ulo[0][q] = wave_bcast(G.blo[q], g); uhi[0][q] = wave_bcast(G.bhi[q], g); ulo[1][q] = wave_bcast(G.alo[q], g); uhi[1][q] = wave_bcast(G.ahi[q], g); }
+  unsigned short* LIST = (unsigned short*)(c.ldsi + L_ARENA + A_CAND + CAND_STRIDE * WL_CAP);   // [0,128): A side, [128,256): B side
+  int nlive[2] = {0, 0};
+  for (int side = 0; side < 2; side++) {
+    const int r0 = side == 0 ? aa : b0, r1 = side == 0 ? ab : b1;
+    for (int base = r0; base < r1; base += 64) {
+      const int x = base + lane; bool ok = x < r1;
+      if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * x + q] > uhi[side][q] + mg || ulo[side][q] > AB[ABS * x + 3 + q] + mg) ok = false;
+      const uint64_t m = wave_ballot(ok);
+      if (ok) LIST[128 * side + nlive[side] + wave_rank(m)] = (unsigned short)x;
+      nlive[side] += popc64(m);
+    }
   }
+  const int na_live = nlive[0], nb = nlive[1];
   wave_sync();
   // level 2: the pair grid of the surviving A colliders, in enumeration order
   const int npairs = na_live * nb;
   for (int base = 0; base < npairs; base += 64) {
     const int p = base + lane; bool ok = p < npairs;
-    const int ai = ok ? p / nb : 0; const int a = ALIST[ai], b = b0 + (p - ai * nb);
+    const int ai = ok ? p / nb : 0; const int a = LIST[ai], b = LIST[128 + (ok ? p - ai * nb : 0)];
     ok = ok && (!same || b > a);
     if (ok && no_adjacent) {
       const int la = CLI(c, a, AGX_C_BODY), lb = CLI(c, b, AGX_C_BODY);
@@ -602,6 +602,7 @@ AGX_DEV void collide(Ctx& c) {
   // body-level cull of every group at once: lane g scans both collider ranges of group g
   uint64_t live_groups = 0;
   GroupRegs G; G.a0 = 0; G.a1 = 0; G.b0 = 0; G.b1 = 0; G.flags = 0; G.keep = 0;
+  for (int k = 0; k < 3; k++) { G.alo[k] = 0.f; G.ahi[k] = 0.f; G.blo[k] = 0.f; G.bhi[k] = 0.f; }
   {
     const int g = lane; bool live = false;
     if (g < c.ngroup) {
@@ -616,6 +617,7 @@ AGX_DEV void collide(Ctx& c) {
         for (int i = b0; i < b1; i++) for (int k = 0; k < 3; k++) { blo[k] = fminf(blo[k], AB[ABS * i + k]); bhi[k] = fmaxf(bhi[k], AB[ABS * i + 3 + k]); }
         live = true;
         for (int k = 0; k < 3; k++) if (alo[k] > bhi[k] + mg || blo[k] > ahi[k] + mg) live = false;
+        for (int k = 0; k < 3; k++) { G.alo[k] = alo[k]; G.ahi[k] = ahi[k]; G.blo[k] = blo[k]; G.bhi[k] = bhi[k]; }
       }
     }
     live_groups = wave_ballot(live);   // the pair table has at most 64 groups (checked in agx_create)
@@ -638,7 +640,7 @@ AGX_DEV void collide(Ctx& c) {
       const int nb = b1 - b0;
       if (ab < 0) { ab = a0; abatch = a1 - a0; }
       const int ae = ab + abatch < a1 ? ab + abatch : a1;
-      int wn2 = collide_sweep(c, g, ab, ae, b0, b1, gflags, mg, wn);
+      int wn2 = collide_sweep(c, g, ab, ae, b0, b1, gflags, mg, wn, G);
       AGX_CTICK(10)
       bool fits = wn2 <= WL_CAP;
       if (!fits && wn == 0) {
