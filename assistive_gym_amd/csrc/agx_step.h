@@ -477,7 +477,11 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   (void)any_manifold_query;
   wave_sync();
   if (c.timing) { long long t = wave_clock(); c.tm[11] += t - ct0; ct0 = t; }
-  // 4. selection, one (group, A collider) segment at a time
+  // 4. selection, one (group, A collider) segment at a time.  The loop only decides which candidate
+  // becomes which contact slot (SEL[]); the contact records are then written by one lane per contact, so
+  // that their blob reads (bodies, friction) overlap instead of queueing up behind each other.
+  int* SEL = c.ldsi + L_ARENA + A_CAND + CAND_STRIDE * WL_CAP;      // the sweep's lists are dead by now
+  const int ncon0 = cs.ncon;
   int cur = 0;
   while (cur < wn) {
     const int key = WL[cur] & ~(511 << 9);            // group and A collider
@@ -495,7 +499,7 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
         const bool has = (pass ? g1 : g0) < 1.0e38f;
         const uint64_t m = wave_ballot(has);
         int cnt = popc64(m); const int slot = cs.ncon + wave_rank(m);
-        if (has && slot < cs.maxc) emit_from_cand(c, slot, pass ? i1 : i0);
+        if (has && slot < cs.maxc) SEL[slot - ncon0] = pass ? i1 : i0;
         int room = cs.maxc - cs.ncon; if (room < 0) room = 0;
         if (cnt > room) { cs.overflow += cnt - room; cnt = room; }
         cs.ncon += cnt;
@@ -507,12 +511,14 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
         const uint64_t m0 = wave_ballot(g0 == mg);
         int slot1 = 0, win;
         if (m0) win = ffs64(m0); else { win = ffs64(wave_ballot(g1 == mg)); slot1 = 1; }
-        if (cs.ncon < cs.maxc) { if (lane == win) emit_from_cand(c, cs.ncon, slot1 ? i1 : i0); cs.ncon++; } else cs.overflow++;
+        if (cs.ncon < cs.maxc) { if (lane == win) SEL[cs.ncon - ncon0] = slot1 ? i1 : i0; cs.ncon++; } else cs.overflow++;
         if (lane == win) { if (slot1) g1 = 3.0e38f; else g0 = 3.0e38f; }
       }
     }
     cur += len;
   }
+  wave_sync();
+  if (ncon0 + lane < cs.ncon) emit_from_cand(c, ncon0 + lane, SEL[lane]);      // at most MAX_CON = 64 new contacts
   wave_sync();
   if (c.timing) { long long t = wave_clock(); c.tm[12] += t - ct0; }
 }
