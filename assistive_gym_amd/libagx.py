@@ -96,10 +96,10 @@ class Stepper:
             check(self.L.agx_step(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), C.c_void_p(stream)), 'agx_step')
 
     def step_timed(self, actions, obs, reward, done, info=None, stream=0):
-        """one step with HIP events between the launches; returns ms of (build, solve, finish) kernels"""
-        ms = (C.c_float * 3)()
-        check(self.L.agx_step_timed(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), C.c_void_p(stream), ms), 'agx_step_timed')
-        return [ms[0], ms[1], ms[2]]
+        """one step with HIP events after the launches; returns (summed ms, launch counts) of the build, solve, finish kernels"""
+        ms, cnt = (C.c_float * 3)(), (C.c_int * 3)()
+        check(self.L.agx_step_timed(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), C.c_void_p(stream), ms, cnt), 'agx_step_timed')
+        return [ms[0], ms[1], ms[2]], [cnt[0], cnt[1], cnt[2]]
 
     def observe_dev(self, obs, stream=0):
         check(self.L.agx_observe(self.h, _ptr(obs), C.c_void_p(stream)), 'agx_observe')

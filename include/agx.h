@@ -59,10 +59,11 @@ int agx_step(agx_handle h, const float* actions_dev, float* obs_dev, float* rewa
 int agx_step_debug(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
                    uint8_t* done_dev, float* info_dev, float* debug_dev, void* stream);
 int agx_debug_words(void);
-/* same as agx_step with a HIP event between every kernel launch; blocks until the step is done and
- * returns the summed durations of one step in ms3 = {build kernels, solve kernels, finish kernel} */
+/* same as agx_step (same chunk streams) with a HIP event after every kernel launch; blocks until the step
+ * is done and returns the summed launch durations of one step in ms3 = {build, solve, finish kernels} and
+ * the number of launches of each in launches3 (may be NULL) */
 int agx_step_timed(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
-                   uint8_t* done_dev, float* info_dev, void* stream, float* ms3);
+                   uint8_t* done_dev, float* info_dev, void* stream, float* ms3, int* launches3);
 int agx_observe(agx_handle h, float* obs_dev, void* stream);
 /* envs with done != 0 get a fresh state from pool_dev ([pool_n][state_words]); the pool entry is
  * (env_index + 977 * episode_count) mod pool_n, so results do not depend on GPU placement */

@@ -18,10 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_kernel(path, counter):
-    acc = defaultdict(list)
+    """kernel -> [sum of bytes, sum of environments (= workgroups), launches]; launches of a step come in
+    chunks of different sizes, so traffic is normalised per environment"""
+    acc = defaultdict(lambda: [0.0, 0, 0])
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] == counter and r['Kernel_Name'].startswith('agx_'):
-            acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']) * 1024.0)
+            a = acc[r['Kernel_Name'].split('(')[0]]
+            a[0] += float(r['Counter_Value']) * 1024.0; a[1] += int(r['Grid_Size']) // int(r['Workgroup_Size']); a[2] += 1
     return acc
 
 
@@ -31,17 +34,17 @@ def main():
     sys.path.insert(0, ROOT)
     from assistive_gym_amd.blob import ModelBlob
     blob = ModelBlob.load('feeding_jaco')
-    out = {'envs': envs, 'correction': 'FETCH_SIZE x2 (gfx950, guide), WRITE_SIZE as reported', 'kernels': {}}
+    out = {'envs': envs, 'note': 'hbm_bytes_per_launch is for a launch over all `envs` environments; a step issues chunks of them', 'correction': 'FETCH_SIZE x2 (gfx950, guide), WRITE_SIZE as reported', 'kernels': {}}
     for k in sorted(set(fetch) | set(write)):
-        f = sum(fetch[k]) / max(1, len(fetch[k]))
-        w = sum(write[k]) / max(1, len(write[k]))
-        out['kernels'][k] = {'launches_sampled': len(fetch[k]), 'fetch_raw_bytes': f, 'write_raw_bytes': w,
-                             'hbm_bytes_per_launch': 2.0 * f + w, 'hbm_bytes_per_env_launch': (2.0 * f + w) / envs}
+        f = fetch[k][0] / max(1, fetch[k][1])           # raw bytes per environment of a launch
+        w = write[k][0] / max(1, write[k][1])
+        out['kernels'][k] = {'launches_sampled': fetch[k][2], 'fetch_raw_bytes_per_env': f, 'write_raw_bytes_per_env': w,
+                             'hbm_bytes_per_env_launch': 2.0 * f + w, 'hbm_bytes_per_launch': (2.0 * f + w) * envs}
     if 'agx_observe_kernel' in out['kernels']:
         o = out['kernels']['agx_observe_kernel']
-        known_r, known_w = envs * blob.state_words * 4, envs * blob.obs_dim * 4
-        out['calibration'] = {'kernel': 'agx_observe_kernel', 'known_read_bytes': known_r, 'known_write_bytes': known_w,
-                              'fetch_x2_over_known': 2.0 * o['fetch_raw_bytes'] / known_r, 'write_over_known': o['write_raw_bytes'] / known_w}
+        known_r, known_w = blob.state_words * 4, blob.obs_dim * 4
+        out['calibration'] = {'kernel': 'agx_observe_kernel', 'known_read_bytes_per_env': known_r, 'known_write_bytes_per_env': known_w,
+                              'fetch_x2_over_known': 2.0 * o['fetch_raw_bytes_per_env'] / known_r, 'write_over_known': o['write_raw_bytes_per_env'] / known_w}
     json.dump(out, open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
