@@ -54,7 +54,10 @@ constexpr int LDS_BYTES = LDS_WORDS * 4;
 // SOLVE_LDS_PAIRS (J,B) pairs of the environment's rows in LDS (16 waves x 9.5 KB fill a CU's 160 KB);
 // rows beyond the window stream from the global scratch (L2)
 constexpr int L_SOLVE_ENT = L_VEL + 128;
-constexpr int SOLVE_LDS_PAIRS = 960;
+#ifndef AGX_SOLVE_LDS_PAIRS
+#define AGX_SOLVE_LDS_PAIRS 960
+#endif
+constexpr int SOLVE_LDS_PAIRS = AGX_SOLVE_LDS_PAIRS;
 static_assert(L_SOLVE_ENT % 2 == 0, "(J,B) pairs are read as 8-byte words");
 constexpr int LDS_SOLVE_WORDS = L_SOLVE_ENT + 2 * SOLVE_LDS_PAIRS;
 constexpr int LDS_SOLVE_BYTES = LDS_SOLVE_WORDS * 4;
