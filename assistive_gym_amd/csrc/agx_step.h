@@ -54,6 +54,8 @@ constexpr int LDS_BYTES = LDS_WORDS * 4;
 // SOLVE_LDS_PAIRS (J,B) pairs of the environment's rows in LDS (16 waves x 9.5 KB fill a CU's 160 KB);
 // rows beyond the window stream from the global scratch (L2)
 constexpr int L_SOLVE_ENT = L_VEL + 128;
+// Build-time knobs for same-box A/B runs (tools/ab_build.sh): -DAGX_SOLVE_LDS_PAIRS=n (size of the solve kernel's
+// LDS row window), -DAGX_NO_LDS_ROWS (all rows from global memory), -DAGX_PGS_CPP (the C++ twin of the assembly sweep).
 #ifndef AGX_SOLVE_LDS_PAIRS
 #define AGX_SOLVE_LDS_PAIRS 960
 #endif
