@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'agx_api.hip')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in ('agx_api.hip', 'agx_step.h', 'agx_gjk.h', 'agx_math.h', 'agx_wave.h')] + \
+DEPS = [os.path.join(HERE, 'csrc', f) for f in sorted(f for f in os.listdir(os.path.join(HERE, 'csrc')) if f.endswith(('.h', '.hip')))] + \
        [os.path.join(os.path.dirname(HERE), 'include', f) for f in ('agx.h', 'agx_blob.h')]
 OUT = os.path.join(HERE, 'lib', 'libagx.so')
 

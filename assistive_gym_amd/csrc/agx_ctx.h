@@ -1,0 +1,142 @@
+// agx_ctx.h -- compile-time limits, the LDS / scratch layouts, the per-lane context and blob accessors.
+// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+#pragma once
+
+namespace agx {
+
+constexpr int MAX_DOF = 16;
+constexpr int MAX_FREE = 10;
+constexpr int MAX_HUMAN = 20;
+constexpr int MAX_CON = 64;
+constexpr int MAX_ROWS = 160;
+constexpr int ST_WORDS = 336;
+constexpr int CON_STRIDE = 16;
+constexpr int HDR_STRIDE = 10;
+constexpr int ARENA_WORDS = 3592;
+constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
+
+// ---- LDS layout (float words) -------------------------------------------------------------
+constexpr int L_ST = 0;
+constexpr int L_VEL = L_ST + ST_WORDS;                   // [128] generalised velocities v*
+constexpr int L_LINKP = L_VEL + 128;                     // [MAX_DOF][3] world
+constexpr int L_LINKR = L_LINKP + MAX_DOF * 3;           // [MAX_DOF][9]
+constexpr int L_S = L_LINKR + MAX_DOF * 9;               // [MAX_DOF][6] joint screw about the ref point
+constexpr int L_MINV = L_S + MAX_DOF * 6;                // [MAX_DOF*MAX_DOF]
+constexpr int L_FREER = L_MINV + MAX_DOF * MAX_DOF;      // [MAX_FREE][9]
+constexpr int L_FIINV = L_FREER + MAX_FREE * 9;          // [MAX_FREE][9]
+constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
+constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
+constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
+constexpr int L_WMAG = L_MISC + 32;                      // |angular velocity| per moving body: links [MAX_DOF], free bodies [MAX_FREE]
+constexpr int L_ARENA = L_WMAG + 32;                     // contact records live in the per-env global scratch, not in LDS
+static_assert(MAX_DOF + MAX_FREE <= 32, "angular speed table");
+constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
+static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
+constexpr int LDS_BYTES = LDS_WORDS * 4;
+// the solve kernel keeps the state copy, the velocity vector and a window of the first
+// SOLVE_LDS_PAIRS (J,B) pairs of the environment's rows in LDS (16 waves x 9.5 KB fill a CU's 160 KB);
+// rows beyond the window stream from the global scratch (L2)
+constexpr int L_SOLVE_ENT = L_VEL + 128;
+// Build-time knobs for same-box A/B runs (tools/ab_build.sh): -DAGX_SOLVE_LDS_PAIRS=n (size of the solve kernel's
+// LDS row window), -DAGX_NO_LDS_ROWS (all rows from global memory), -DAGX_PGS_CPP (the C++ twin of the assembly sweep).
+#ifndef AGX_SOLVE_LDS_PAIRS
+#define AGX_SOLVE_LDS_PAIRS 960
+#endif
+constexpr int SOLVE_LDS_PAIRS = AGX_SOLVE_LDS_PAIRS;
+static_assert(L_SOLVE_ENT % 2 == 0, "(J,B) pairs are read as 8-byte words");
+constexpr int LDS_SOLVE_WORDS = L_SOLVE_ENT + 2 * SOLVE_LDS_PAIRS;
+constexpr int LDS_SOLVE_BYTES = LDS_SOLVE_WORDS * 4;
+// arena, dynamics phase
+constexpr int A_COMW = 0;                                // [MAX_DOF][3] rel. ref
+constexpr int A_IW = A_COMW + MAX_DOF * 3;               // [MAX_DOF][9]
+constexpr int A_VSP = A_IW + MAX_DOF * 9;                // [MAX_DOF][6]
+constexpr int A_CVP = A_VSP + MAX_DOF * 6;
+constexpr int A_IA = A_CVP + MAX_DOF * 6;                // [MAX_DOF][36]
+constexpr int A_U = A_IA + MAX_DOF * 36;
+constexpr int A_PA = A_U + MAX_DOF * 6;
+constexpr int A_ACC = A_PA + MAX_DOF * 6;
+constexpr int A_DINV = A_ACC + MAX_DOF * 6;              // [MAX_DOF]
+constexpr int A_UU = A_DINV + MAX_DOF;
+constexpr int A_QDD = A_UU + MAX_DOF;
+constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_DOF][6] M^-1 column workspace
+constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_DOF * 6 + MAX_DOF * MAX_DOF;
+static_assert(A_DYN_END <= ARENA_WORDS, "dynamics workspace exceeds the arena");
+// arena, collision phase: world AABBs [ncoll][6]
+constexpr int MAX_COLL = 256;
+static_assert(MAX_COLL * 6 <= ARENA_WORDS, "AABB table exceeds the arena");
+// misc words
+constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
+// contact record
+constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 10, C_DIST = 13, C_MU = 14, C_LAM = 15;
+// row header
+constexpr int DBG_HDR = 16 + MAX_CON * CON_STRIDE + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE, DBG_TIME = DBG_LAM + MAX_ROWS, DBG_WORDS = DBG_TIME + 16;
+// per-environment scratch record in HBM (L2-resident while its environment is being solved)
+constexpr int SCR_ENT = 4096, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
+constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
+constexpr int SCR_WORDS = SCR_O_META + SCR_META;
+constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5;
+constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
+constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)
+
+struct Ctx {
+  const float* bf; const int* bi;   // model blob
+  float* lds; int* ldsi;
+  int lane;
+  int ndof, nfree, nhuman, ncoll, ngroup, nfood, nv;
+  int nrobot, nhdof, gender, frozen, s_tremor;   // articulated set: robot DoFs [0,nrobot), human DoFs [nrobot,ndof)
+  float limit_scale;    // scale of the human joint limits of this environment (impairment 'limits')
+  bool coop;            // the human is controllable (TASK.COOP)
+  int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
+  int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
+  float dt;
+  int ncon, nrows, first_normal, near_mask, overflow;
+  float* dbg;   // optional debug sink (parity tests)
+  float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
+  int nent;             // (J,B) pairs written by build_rows (entry 0 is the zero pair)
+  float* gcon;          // contact records handed from the build kernel to the solve / finish kernels
+  long long tm[16]; bool timing;   // per-phase shader-clock totals (debug path only)
+};
+
+#define PRM(c, k) ((c).bf[(c).o_params + (k)])
+// link record of DoF d: human DoFs have one record per gender
+#define RREC(c, d) ((d) < (c).nrobot ? (d) : (d) + (c).gender * (c).nhdof)
+#define RBF(c, d, k) ((c).bf[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
+#define RBI(c, d, k) ((c).bi[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
+// joint limits of DoF d; the human's are scaled per environment (human_creation.py:199-200)
+#define DLO(c, d) (RBF(c, d, AGX_R_LOWER) * (RBI(c, d, AGX_R_KIND) == 1 ? (c).limit_scale : 1.f))
+#define DHI(c, d) (RBF(c, d, AGX_R_UPPER) * (RBI(c, d, AGX_R_KIND) == 1 ? (c).limit_scale : 1.f))
+#define FBF(c, b, k) ((c).bf[(c).o_free + (b) * AGX_F_STRIDE + (k)])
+#define CLF(c, i, k) ((c).bf[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
+#define CLI(c, i, k) ((c).bi[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
+#define GRI(c, g, k) ((c).bi[(c).o_group + (g) * AGX_G_STRIDE + (k)])
+#define TKF(c, k) ((c).bf[(c).o_task + (k)])
+#define TKI(c, k) ((c).bi[(c).o_task + (k)])
+
+AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
+  c.bf = (const float*)blob; c.bi = (const int*)blob; c.lds = lds; c.ldsi = (int*)lds; c.lane = lane;
+  const int* h = c.bi;
+  c.ndof = h[AGX_H_NDOF]; c.nfree = h[AGX_H_NFREE]; c.nhuman = h[AGX_H_NHUMAN]; c.ncoll = h[AGX_H_NCOLL];
+  c.ngroup = h[AGX_H_NGROUP]; c.nfood = h[AGX_H_NFOOD]; c.nv = c.ndof + 6 * c.nfree;
+  c.o_params = h[AGX_H_OFF_PARAMS]; c.o_robot = h[AGX_H_OFF_ROBOT]; c.o_free = h[AGX_H_OFF_FREE]; c.o_coll = h[AGX_H_OFF_COLL];
+  c.o_vert = h[AGX_H_OFF_VERT]; c.o_group = h[AGX_H_OFF_GROUP]; c.o_task = h[AGX_H_OFF_TASK]; c.o_dirs = h[AGX_H_OFF_DIRS];
+  c.s_q = h[AGX_H_S_Q]; c.s_qd = h[AGX_H_S_QD]; c.s_qt = h[AGX_H_S_QT]; c.s_free = h[AGX_H_S_FREE]; c.s_base = h[AGX_H_S_BASE];
+  c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
+  c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
+  c.dt = PRM(c, AGX_P_DT);
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr;
+  c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
+}
+
+// ---- small helpers ------------------------------------------------------------------------
+AGX_DEV float dot6p(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+// body transform lookup (world rotation + world position) from the LDS tables
+AGX_DEV void body_xf(const Ctx& c, int code, m3& R, v3& p) {
+  const float* L = c.lds;
+  if (code == AGX_BODY_WORLD) { R.a[0] = 1; R.a[1] = 0; R.a[2] = 0; R.a[3] = 0; R.a[4] = 1; R.a[5] = 0; R.a[6] = 0; R.a[7] = 0; R.a[8] = 1; p = mk3(0, 0, 0); }
+  else if (code >= AGX_BODY_HUMAN0) { const float* h = L + L_HUMAN + 12 * (code - AGX_BODY_HUMAN0); p = ld3(h); R = ldm3(h + 3); }
+  else if (code >= AGX_BODY_FREE0) { int b = code - AGX_BODY_FREE0; p = ld3(L + L_ST + c.s_free + 13 * b); R = ldm3(L + L_FREER + 9 * b); }
+  else if (code == AGX_BODY_ROBOT_BASE) { p = ld3(L + L_BASE); R = ldm3(L + L_BASE + 3); }
+  else { p = ld3(L + L_LINKP + 3 * code); R = ldm3(L + L_LINKR + 9 * code); }
+}
+
+}  // namespace agx

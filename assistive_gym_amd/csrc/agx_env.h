@@ -1,0 +1,351 @@
+// agx_env.h -- K7 integration and hooks, state load / store, the task layer (observation, food state machine, reward) and the kernel bodies.
+// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+#pragma once
+
+namespace agx {
+
+// ---- K7 + post-substep hooks -----------------------------------------------------------------------------
+AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
+  float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
+  L[L_VEL + lane] = gvel[lane] + dv0;
+  L[L_VEL + lane + 64] = gvel[lane + 64] + dv1;
+  wave_sync();
+  if (lane < n) {
+    const int d = lane;
+    float qd = L[L_VEL + d], q = L[L_ST + c.s_q + d] + dt * qd;
+    // Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250)
+    if (RBI(c, d, AGX_R_KIND) == 1 && !(c.frozen >> d & 1)) {
+      const float lo = DLO(c, d), hi = DHI(c, d);
+      if (q < lo) { q = lo; qd = 0.f; } else if (q > hi) { q = hi; qd = 0.f; }
+    }
+    L[L_ST + c.s_qd + d] = qd; L[L_ST + c.s_q + d] = q;
+  }
+  if (lane < c.nfree) {
+    const int b = lane, o = n + 6 * b; float* r = L + L_ST + c.s_free + 13 * b;
+    v3 v = ld3(L + L_VEL + o), w = ld3(L + L_VEL + o + 3);
+    st3(r + 7, v); st3(r + 10, w); st3(r, ld3(r) + dt * v);
+    float wn = sqrtf(dot(w, w)), th = wn * dt; float dq[4];
+    if (th > 1e-12f) { float sc = sinf(0.5f * th) / wn; dq[0] = w.x * sc; dq[1] = w.y * sc; dq[2] = w.z * sc; dq[3] = cosf(0.5f * th); }
+    else { dq[0] = 0.5f * dt * w.x; dq[1] = 0.5f * dt * w.y; dq[2] = 0.5f * dt * w.z; dq[3] = 1.f; }
+    const float ax = dq[0], ay = dq[1], az = dq[2], aw = dq[3], bx = r[3], by = r[4], bz = r[5], bw = r[6];
+    float x = aw * bx + ax * bw + ay * bz - az * by, y = aw * by - ax * bz + ay * bw + az * bx;
+    float z = aw * bz + ax * by - ay * bx + az * bw, w2 = aw * bw - ax * bx - ay * by - az * bz;
+    float nn = 1.0f / sqrtf(x * x + y * y + z * z + w2 * w2);
+    r[3] = x * nn; r[4] = y * nn; r[5] = z * nn; r[6] = w2 * nn;
+  }
+  wave_sync();
+}
+// FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset.  Needs the link
+// frames of a preceding kinematics(); the target is only consumed by the observation / reward code.
+AGX_DEV void update_target(Ctx& c) {
+  float* L = c.lds;
+  wave_sync();
+  if (c.lane == 0) {
+    const int hl = TKI(c, AGX_T_HEAD_LINK), o = c.gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
+    st3(L + L_ST + c.s_env + AGX_E_TARGET, mul(ldm3(L + L_LINKR + 9 * hl), mk3(TKF(c, o), TKF(c, o + 1), TKF(c, o + 2))) + ld3(L + L_LINKP + 3 * hl));
+  }
+  wave_sync();
+}
+
+// ---- state load / store ---------------------------------------------------------------------------------
+AGX_DEV void load_env(Ctx& c, const float* gstate, int sw) {
+  float* L = c.lds; const int lane = c.lane;
+  for (int k = lane; k < sw; k += 64) L[L_ST + k] = gstate[k];
+  wave_sync();
+  c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
+  { const float ls = c.lds[L_ST + c.s_env + AGX_E_LIMIT_SCALE]; c.limit_scale = ls > 0.f ? ls : 1.f; }   // records written before v6 carry 0
+  c.coop = TKI(c, AGX_T_COOP) == 1;
+  if (lane == 0) { const float* r = L + L_ST + c.s_base; st3(L + L_BASE, ld3(r)); stm3(L + L_BASE + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
+  if (lane < c.nhuman) { const float* r = L + L_ST + c.s_human + 7 * lane; float* h = L + L_HUMAN + 12 * lane; st3(h, ld3(r)); stm3(h + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
+  if (lane < c.ndof) { int m = 0; for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) m |= 1 << d; c.ldsi[L_MISC + M_ANC + lane] = m; }
+  wave_sync();
+}
+AGX_DEV void store_env(Ctx& c, float* gstate, int sw) {
+  wave_sync();
+  for (int k = c.lane; k < sw; k += 64) gstate[k] = c.lds[L_ST + k];
+}
+
+// ---- task layer ------------------------------------------------------------------------------------------
+AGX_DEV uint32_t rng_next(uint32_t& s0, uint32_t& s1) {
+  uint64_t x = ((uint64_t)s1 << 32) | s0;
+  x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+  s0 = (uint32_t)x; s1 = (uint32_t)(x >> 32);
+  return (uint32_t)(x >> 33) ^ (uint32_t)(x >> 11);
+}
+AGX_DEV void tool_base_pose(const Ctx& c, v3& p, m3& R) {
+  const float* L = c.lds; const int tb = c.bi[AGX_H_TOOL_BODY];
+  m3 FR = ldm3(L + L_FREER + 9 * tb); v3 fp = ld3(L + L_ST + c.s_free + 13 * tb);
+  p = mul(FR, mk3(FBF(c, tb, AGX_F_REFPOS), FBF(c, tb, AGX_F_REFPOS + 1), FBF(c, tb, AGX_F_REFPOS + 2))) + fp;
+  R = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
+}
+// FeedingEnv._get_obs (feeding.py:85-112), robot part; every lane computes, lane 0 writes
+AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* gobs) {
+  const float* L = c.lds;
+  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
+  const int hl = TKI(c, AGX_T_HEAD_LINK);
+  v3 hpr = tmul(BR, ld3(L + L_LINKP + 3 * hl) - bp); q4 hq = m3_to_quat(mul_at(BR, ldm3(L + L_LINKR + 9 * hl)));
+  v3 tpr = tmul(BR, ld3(L + L_ST + c.s_env + AGX_E_TARGET) - bp);
+  if (c.lane == 0) {
+    int o = 0;
+    gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z;
+    gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
+    gobs[o++] = spr.x - tpr.x; gobs[o++] = spr.y - tpr.y; gobs[o++] = spr.z - tpr.z;
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+      float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
+      gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
+    }
+    gobs[o++] = hpr.x; gobs[o++] = hpr.y; gobs[o++] = hpr.z;
+    gobs[o++] = hq.x; gobs[o++] = hq.y; gobs[o++] = hq.z; gobs[o++] = hq.w;
+    gobs[o++] = tool_force;
+    if (c.coop) {   // human_obs (feeding.py:102-108): the same quantities in the frame of the human's base (collision body 0)
+      const v3 hb = ld3(L + L_HUMAN); const m3 HR = ldm3(L + L_HUMAN + 3);
+      const v3 sph = tmul(HR, sp - hb); const q4 sqh = m3_to_quat(mul_at(HR, sR));
+      const v3 hph = tmul(HR, ld3(L + L_LINKP + 3 * hl) - hb); const q4 hqh = m3_to_quat(mul_at(HR, ldm3(L + L_LINKR + 9 * hl)));
+      const v3 tph = tmul(HR, ld3(L + L_ST + c.s_env + AGX_E_TARGET) - hb);
+      gobs[o++] = sph.x; gobs[o++] = sph.y; gobs[o++] = sph.z;
+      gobs[o++] = sqh.x; gobs[o++] = sqh.y; gobs[o++] = sqh.z; gobs[o++] = sqh.w;
+      gobs[o++] = sph.x - tph.x; gobs[o++] = sph.y - tph.y; gobs[o++] = sph.z - tph.z;
+      for (int d = c.nrobot; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) gobs[o++] = L[L_ST + c.s_q + d];
+      gobs[o++] = hph.x; gobs[o++] = hph.y; gobs[o++] = hph.z;
+      gobs[o++] = hqh.x; gobs[o++] = hqh.y; gobs[o++] = hqh.z; gobs[o++] = hqh.w;
+      gobs[o++] = robot_force; gobs[o++] = tool_force;
+    }
+  }
+}
+
+// ============================================================================================
+// Kernel bodies.  One env.step() = frame_skip x [build, solve] + finish:
+//   build  (register/LDS heavy, ~1/3 of the time): state -> kinematics, ABA + M^-1, predicted
+//          velocities, collision, constraint rows -> per-env scratch record (rows, v*, contacts)
+//   solve  (lean: ~64 VGPRs, 5 KB LDS -> many waves per SIMD): 50 PGS sweeps streaming the rows
+//          from L2, integration, mouth-target update -> state
+//   finish (once per step): forces, observation, food state machine, preferences, reward, done.
+// ============================================================================================
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; };
+AGX_DEV Scratch scratch_of(float* base) {
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META);
+  return s;
+}
+
+// build: `gaction` non-null on the first substep of an env.step() (take_step, env.py:174-222)
+AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gdebug, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  c.timing = gdebug != nullptr; c.dbg = gdebug;
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS];
+  Scratch scr = scratch_of(gscratch);
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
+  load_env(c, gstate, sw);
+  if (gaction) {
+    const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP);
+    // clip, scale, 5x accumulate against the joint limits -> motor targets (kept in the state record)
+    const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION] + 1;       // env.py:185
+    wave_sync();
+    if (lane == 0) { Li[L_ST + c.s_env + AGX_E_ITERATION] = iteration; ((int*)gstate)[c.s_env + AGX_E_ITERATION] = iteration; }
+    if (lane < c.ndof) {
+      const int d = lane, ai = RBI(c, d, AGX_R_ACT);
+      const bool is_human = d >= c.nrobot;
+      const int k2 = is_human ? d - c.nrobot : 0;
+      const float tsign = (iteration % 2 == 0) ? 1.f : -1.f;
+      bool tremor_on = false;                         // impairment == 'tremor'
+      for (int k = 0; k < c.nhdof; k++) if (L[L_ST + c.s_tremor + k] != 0.f) tremor_on = true;
+      if (ai >= 0 && (!is_human || c.coop)) {
+        // the limit test of take_step is discontinuous (an action that would cross a limit is zeroed,
+        // env.py:206-211); it is evaluated in double like the reference's numpy code so that a joint
+        // resting exactly on a limit takes the same branch
+        const float a32 = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
+        double a = (double)a32, qa = (double)L[L_ST + c.s_q + d]; const double lo = (double)DLO(c, d), hi = (double)DHI(c, d);
+        double tt = (double)L[L_ST + c.s_tremor + c.nhdof + k2];
+        for (int k = 0; k < nsub; k++) {
+          bool below = qa + a < lo, above = qa + a > hi;
+          if (below || above) a = 0.0;
+          if (below) qa = lo; if (above) qa = hi;
+          if (is_human && tremor_on) { tt += a; qa = tt + (double)(L[L_ST + c.s_tremor + k2] * tsign); }   // env.py:212-215
+          else qa += a;
+        }
+        L[L_ST + c.s_qt + d] = (float)qa; gstate[c.s_qt + d] = (float)qa;
+        if (is_human && tremor_on) { L[L_ST + c.s_tremor + c.nhdof + k2] = (float)tt; gstate[c.s_tremor + c.nhdof + k2] = (float)tt; }
+      }
+      if (is_human && !c.coop) {   // tremor without control (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd)
+        const float qt = L[L_ST + c.s_tremor + c.nhdof + k2] + L[L_ST + c.s_tremor + k2] * tsign;
+        L[L_ST + c.s_qt + d] = qt; gstate[c.s_qt + d] = qt;
+      }
+    }
+    wave_sync();
+  }
+  long long t0 = c.timing ? wave_clock() : 0, t1;
+#define AGX_TICK(k) if (c.timing) { t1 = wave_clock(); c.tm[k] += t1 - t0; t0 = t1; }
+  kinematics(c); AGX_TICK(0)
+  aba_and_minv(c); AGX_TICK(1)
+  predict_velocities(c); AGX_TICK(2)
+  collide(c); AGX_TICK(3)
+  build_rows(c); AGX_TICK(4)
+#undef AGX_TICK
+  // hand-over to the solve kernel
+  for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
+  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; }
+  if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
+    if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // [4..4+ndof) = qdd
+    for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = scr.con[q];
+    for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[16 + MAX_CON * CON_STRIDE + q] = L[L_MINV + q];
+    wave_sync();
+    for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = scr.hdr[q];
+    if (lane == 0) { for (int k = 0; k < 16; k++) if (k != 5 && k != 6 && k != 7) gdebug[DBG_TIME + k] = (float)c.tm[k]; }
+  }
+}
+
+// solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
+AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  const int sw = c.bi[AGX_H_STATE_WORDS];
+  Scratch scr = scratch_of(gscratch);
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nent = scr.meta[META_NENT];
+  // state copy only (the frame tables of load_env are not needed here and their LDS is the row window)
+  for (int k = lane; k < sw; k += 64) lds[L_ST + k] = gstate[k];
+  { const int np = c.nent < SOLVE_LDS_PAIRS ? c.nent : SOLVE_LDS_PAIRS;
+    const f2* src = (const f2*)scr.ent; f2* dst = (f2*)(lds + L_SOLVE_ENT);
+    for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
+  wave_sync();
+  c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
+  { const float ls = c.lds[L_ST + c.s_env + AGX_E_LIMIT_SCALE]; c.limit_scale = ls > 0.f ? ls : 1.f; }   // records written before v6 carry 0
+  c.coop = TKI(c, AGX_T_COOP) == 1;
+  const long long t0 = gdebug ? wave_clock() : 0;
+  float dv0, dv1;
+  pgs(c, dv0, dv1);
+  const long long t1 = gdebug ? wave_clock() : 0;
+  integrate(c, scr.vel, dv0, dv1);
+  store_env(c, gstate, sw);
+  if (gdebug && lane == 0) { gdebug[DBG_TIME + 5] = (float)(t1 - t0); gdebug[DBG_TIME + 6] = (float)(wave_clock() - t1); }
+}
+
+AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  load_env(c, gstate, c.bi[AGX_H_STATE_WORDS]);
+  kinematics(c); update_target(c); observe(c, 0.f, 0.f, gobs);
+}
+
+// finish: everything FeedingEnv.step does after take_step (feeding.py:17-43)
+AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+                        float* ginfo, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS], act_dim = c.bi[AGX_H_ACT_DIM];
+  Scratch scr = scratch_of(gscratch);
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.near_mask = scr.meta[META_NEAR];
+  load_env(c, gstate, sw);
+  float an2 = 0.f;
+  for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
+  wave_sync();
+  kinematics(c);   // poses as the getters of _get_obs see them after the last stepSimulation
+  update_target(c);
+  // get_total_force (feeding.py:45-48) from the last substep's contact impulses
+  float rf = 0.f, tf = 0.f;
+  if (lane < c.ncon) {
+    const float* k = scr.con + CON_STRIDE * lane; const int* ki = (const int*)k;
+    int ta = CLI(c, ki[C_CA], AGX_C_TAG), tb = CLI(c, ki[C_CB], AGX_C_TAG);
+    if (ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN) {
+      int other = ta == AGX_TAG_HUMAN ? tb : ta; float f = k[C_LAM] / c.dt;
+      if (other == AGX_TAG_ROBOT) rf = f;
+      if (other == AGX_TAG_TOOL) tf = f;
+    }
+  }
+  const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), total_f = robot_f + tool_f;
+  observe(c, robot_f, tool_f, gobs);
+  // get_food_rewards (feeding.py:50-83)
+  float food_reward = 0.f, food_hit = 0.f, vel_sum = 0.f;
+  int alive = Li[L_ST + c.s_env + AGX_E_FOOD_ALIVE], active = Li[L_ST + c.s_env + AGX_E_FOOD_ACTIVE];
+  int success = Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS];
+  uint32_t r0 = (uint32_t)Li[L_ST + c.s_env + AGX_E_RNG], r1 = (uint32_t)Li[L_ST + c.s_env + AGX_E_RNG + 1];
+  const int active_on_entry = active, hit_mask = c.near_mask, food0 = c.bi[AGX_H_FOOD0];
+  const v3 target = ld3(L + L_ST + c.s_env + AGX_E_TARGET);
+  // world AABBs of the tool colliders + particles for the 0.1 m closest-point query (agent.py:118-130)
+  {
+    float* AB = L + L_ARENA;
+    for (int col = lane; col < c.ncoll; col += 64) {
+      int tag = CLI(c, col, AGX_C_TAG);
+      if (tag != AGX_TAG_TOOL && tag != AGX_TAG_FOOD) continue;
+      m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
+      v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
+      v3 hl = mk3(CLF(c, col, AGX_C_AABB_H), CLF(c, col, AGX_C_AABB_H + 1), CLF(c, col, AGX_C_AABB_H + 2));
+      v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
+      for (int k = 0; k < 3; k++) {
+        float hh = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
+        AB[ABS * col + k] = comp(cw, k) - hh; AB[ABS * col + 3 + k] = comp(cw, k) + hh;
+      }
+    }
+    wave_sync();
+  }
+  int tool0 = -1, tool1 = -1, foodc0 = -1;
+  for (int g = 0; g < c.ngroup; g++) {   // the (food, tool) group carries both collider ranges
+    int a0 = GRI(c, g, AGX_G_A0), b0 = GRI(c, g, AGX_G_B0);
+    if (CLI(c, a0, AGX_C_TAG) == AGX_TAG_FOOD && CLI(c, b0, AGX_C_TAG) == AGX_TAG_TOOL) { foodc0 = a0; tool0 = b0; tool1 = GRI(c, g, AGX_G_B1); break; }
+  }
+  const float spill = TKF(c, AGX_T_SPILL_DIST);
+  for (int k = 0; k < c.nfood; k++) {
+    if (!(alive >> k & 1)) continue;
+    const int b = food0 + k; float* r = L + L_ST + c.s_free + 13 * b;
+    v3 d = target - ld3(r);
+    if (sqrtf(dot(d, d)) < TKF(c, AGX_T_MOUTH_DIST)) {
+      food_reward += 20.f; success += 1; vel_sum += sqrtf(dot(ld3(r + 7), ld3(r + 7)));
+      alive &= ~(1 << k); active &= ~(1 << k);
+      float px = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      float py = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      float pz = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      wave_sync();
+      if (lane == 0) { r[0] = px; r[1] = py; r[2] = pz; r[3] = 0.f; r[4] = 0.f; r[5] = 0.f; r[6] = 1.f; }
+      wave_sync();
+      continue;
+    }
+    bool near = false;
+    {
+      const int fc = foodc0 + k; const float* AB = L + L_ARENA;
+      for (int base = tool0; base < tool1; base += 64) {
+        const int tc = base + lane; bool hitl = false;
+        if (tc < tool1) {
+          bool sep = false;
+          for (int q = 0; q < 3; q++) if (AB[ABS * fc + q] > AB[ABS * tc + 3 + q] + spill || AB[ABS * tc + q] > AB[ABS * fc + 3 + q] + spill) sep = true;
+          Cand tmp; if (!sep) hitl = narrowphase(c, fc, tc, spill, tmp);
+        }
+        if (wave_any(hitl)) near = true;
+      }
+    }
+    if (!near) { food_reward -= 5.f; alive &= ~(1 << k); }
+  }
+  for (int k = 0; k < c.nfood; k++) if ((active_on_entry >> k & 1) && (hit_mask >> k & 1)) { food_hit -= 1.f; active &= ~(1 << k); }
+  // end-effector speed (feeding.py:22), human_preferences (env.py:237-274, feeding branch), reward
+  const float* A = L + L_ARENA; (void)A;
+  float ee_speed;
+  {
+    const int ee = TKI(c, AGX_T_EE_LINK);
+    float sv[6] = {0, 0, 0, 0, 0, 0};
+    for (int d = ee; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { float qd = L[L_ST + c.s_qd + d]; for (int j = 0; j < 6; j++) sv[j] += L[L_S + 6 * d + j] * qd; }
+    v3 xr = ld3(L + L_MISC + M_EEP) - ld3(L + L_MISC + M_REF);
+    v3 v = mk3(sv[3], sv[4], sv[5]) + cross(mk3(sv[0], sv[1], sv[2]), xr);
+    ee_speed = sqrtf(dot(v, v));
+  }
+  float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-total_f) + TKF(c, AGX_T_C_HF) * (tool_f < 10.f ? 0.f : -tool_f)
+             + TKF(c, AGX_T_C_FD) * food_hit + TKF(c, AGX_T_C_FDV) * (-vel_sum);
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  v3 dd = target - sp;
+  float reward = TKF(c, AGX_T_W_DISTANCE) * (-sqrtf(dot(dd, dd))) + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + TKF(c, AGX_T_W_FOOD) * food_reward + pref;
+  const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];
+  wave_sync();
+  if (lane == 0) {
+    Li[L_ST + c.s_env + AGX_E_FOOD_ALIVE] = alive; Li[L_ST + c.s_env + AGX_E_FOOD_ACTIVE] = active;
+    Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS] = success; Li[L_ST + c.s_env + AGX_E_RNG] = (int)r0; Li[L_ST + c.s_env + AGX_E_RNG + 1] = (int)r1;
+    *greward = reward;
+    *gdone = (uint8_t)(iteration >= (int)TKF(c, AGX_T_EPISODE_LEN));
+    if (ginfo) {
+      ginfo[AGX_INFO_TOTAL_FORCE] = total_f;
+      ginfo[AGX_INFO_TASK_SUCCESS] = (float)(success >= Li[L_ST + c.s_env + AGX_E_TOTAL_FOOD] * TKF(c, AGX_T_SUCCESS_FRAC));
+      ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = tool_f; ginfo[AGX_INFO_FOOD_REWARD] = food_reward;
+      ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
+    }
+  }
+  store_env(c, gstate, sw);
+}
+
+}  // namespace agx

@@ -1,0 +1,206 @@
+// agx_rows.h -- K5 constraint rows: motors, joint limits, tool constraint, contact normal + friction; B = M^-1 J^T.
+// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+#pragma once
+
+namespace agx {
+
+// ---- K5: constraint rows -----------------------------------------------------------------------------
+// accumulate the Jacobian of a unit force f / unit torque t applied to body `code` at world point x
+AGX_DEV void add_jac(const Ctx& c, int code, v3 x, v3 f, v3 t, float sign, float* Jr, float* Jf) {
+  const float* L = c.lds;
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) {
+    v3 xr = x - ld3(L + L_MISC + M_REF);
+    v3 Fa = cross(xr, f) + t;
+    float F[6] = {Fa.x, Fa.y, Fa.z, f.x, f.y, f.z};
+    const int anc = c.ldsi[L_MISC + M_ANC + code];
+    _Pragma("unroll") for (int d = 0; d < MAX_DOF; d++) if (d < c.ndof && (anc >> d & 1)) Jr[d] += sign * dot6p(L + L_S + 6 * d, F);
+  } else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) {
+    int b = code - AGX_BODY_FREE0;
+    v3 r = x - ld3(L + L_ST + c.s_free + 13 * b);
+    v3 ta = cross(r, f) + t;
+    Jf[0] += sign * f.x; Jf[1] += sign * f.y; Jf[2] += sign * f.z; Jf[3] += sign * ta.x; Jf[4] += sign * ta.y; Jf[5] += sign * ta.z;
+  }
+}
+struct RowGeom { float Jr[MAX_DOF]; float Ja[6]; float Jb[6]; int fa, fb; bool robot, human; };   // fa/fb: free body index or -1; robot/human: articulated blocks touched
+AGX_DEV void row_clear(RowGeom& r) { for (int k = 0; k < MAX_DOF; k++) r.Jr[k] = 0.f; for (int k = 0; k < 6; k++) { r.Ja[k] = 0.f; r.Jb[k] = 0.f; } r.fa = -1; r.fb = -1; r.robot = false; r.human = false; }
+// force +f (torque +t) on body A at xa, -f (-t) on body B at xb
+AGX_DEV void row_pair(const Ctx& c, RowGeom& r, int codeA, v3 xa, int codeB, v3 xb, v3 f, v3 t) {
+  row_clear(r);
+  if (codeA >= 0 && codeA < AGX_BODY_ROBOT_BASE) { if (codeA < c.nrobot) r.robot = true; else r.human = true; }
+  if (codeB >= 0 && codeB < AGX_BODY_ROBOT_BASE) { if (codeB < c.nrobot) r.robot = true; else r.human = true; }
+  if (codeA >= AGX_BODY_FREE0 && codeA < AGX_BODY_HUMAN0) r.fa = codeA - AGX_BODY_FREE0;
+  if (codeB >= AGX_BODY_FREE0 && codeB < AGX_BODY_HUMAN0) r.fb = codeB - AGX_BODY_FREE0;
+  add_jac(c, codeA, xa, f, t, 1.f, r.Jr, r.Ja);
+  add_jac(c, codeB, xb, f, t, -1.f, r.Jr, r.Jb);
+}
+AGX_DEV float row_velocity(const Ctx& c, const RowGeom& r) {
+  const float* L = c.lds; float s = 0.f;
+  if (r.robot || r.human) { _Pragma("unroll") for (int d = 0; d < MAX_DOF; d++) if (d < c.ndof) s += r.Jr[d] * L[L_VEL + d]; }
+  if (r.fa >= 0) for (int k = 0; k < 6; k++) s += r.Ja[k] * L[L_VEL + c.ndof + 6 * r.fa + k];
+  if (r.fb >= 0) for (int k = 0; k < 6; k++) s += r.Jb[k] * L[L_VEL + c.ndof + 6 * r.fb + k];
+  return s;
+}
+// articulated DoF range a row stores: the robot block, the human block, or both (contiguous)
+AGX_DEV void row_art_range(const Ctx& c, const RowGeom& r, int& lo, int& n) {
+  lo = r.robot ? 0 : c.nrobot;
+  n = (r.robot && r.human) ? c.ndof : (r.robot ? c.nrobot : (r.human ? c.nhdof : 0));
+}
+AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return n + (r.fa >= 0 ? 6 : 0) + (r.fb >= 0 ? 6 : 0); }
+// B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
+// A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
+AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float bterm, float lo, float hi, int fric_of, float mu) {
+  float* L = c.lds; float* E = c.E + 2 * off; const int n = c.ndof;
+  float D = 0.f; int e = 0;
+  int a0 = 0, na = 0, b0 = 0, nb = 0;
+  int alo, an; row_art_range(c, r, alo, an);
+  const bool art = an > 0;
+  if (art) {
+    a0 = alo; na = an;
+    _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i >= alo && i < alo + an) {
+      float acc = 0.f;
+      _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
+      E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
+    }
+  }
+  // free bodies in ascending DoF order, so that the pairs of a row are stored in lane order (the
+  // solver addresses them by the rank of the lane inside the row's lane mask)
+  const int first = (r.fa >= 0 && r.fb >= 0 && r.fb < r.fa) ? 1 : 0;
+  for (int s2 = 0; s2 < 2; s2++) {
+    const int side = s2 ^ first;
+    int fb = side == 0 ? r.fa : r.fb; if (fb < 0) continue;
+    const float* J = side == 0 ? r.Ja : r.Jb;
+    float mass = FBF(c, fb, AGX_F_MASS), im = mass > 0 ? 1.0f / mass : 0.f;
+    v3 Ba = mul(ldm3(L + L_FIINV + 9 * fb), mk3(J[3], J[4], J[5]));
+    float B[6] = {im * J[0], im * J[1], im * J[2], Ba.x, Ba.y, Ba.z};
+    int base = n + 6 * fb;
+    if (na == 0 && nb == 0 && !art) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
+    for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
+  }
+  // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
+  float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
+  H[H_INVD] = D > 1e-12f ? 1.0f / D : 0.f; H[H_B] = bterm; H[H_LO] = lo; H[H_HI] = hi;
+  // lane masks of the two DoF ranges: bits 0..63 (first lane slot) and 64.. (second slot)
+  const uint64_t ra = na > 0 ? ((~0ull >> (64 - na)) ) : 0ull, rb = nb > 0 ? ((~0ull >> (64 - nb))) : 0ull;
+  uint64_t mlo = 0ull, mhi = 0ull;
+  if (na > 0) { if (a0 < 64) mlo |= ra << a0; if (a0 + na > 64) mhi |= a0 >= 64 ? ra << (a0 - 64) : ra >> (64 - a0); }
+  if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
+  Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
+  Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
+  (void)fric_of;
+}
+AGX_DEV void plane_space(v3 n, v3& p) {
+  if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
+  else { float a = n.x * n.x + n.y * n.y, k = 1.0f / sqrtf(a); p = mk3(-n.y * k, n.x * k, 0); }
+}
+AGX_DEV void m3_to_euler_xyz(const m3& M, float* e) {
+  const float* R = M.a; float fi = R[2];
+  if (fi < 1.0f) { if (fi > -1.0f) { e[0] = atan2f(-R[5], R[8]); e[1] = asinf(R[2]); e[2] = atan2f(-R[1], R[0]); }
+    else { e[0] = -atan2f(R[3], R[4]); e[1] = -1.57079632679f; e[2] = 0; } }
+  else { e[0] = atan2f(R[3], R[4]); e[1] = 1.57079632679f; e[2] = 0; }
+}
+
+AGX_DEV void build_rows(Ctx& c) {
+  float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
+  const float erp = PRM(c, AGX_P_ERP), cerp = PRM(c, AGX_P_CONTACT_ERP);
+  int maxrows = (int)PRM(c, AGX_P_MAX_ROWS); if (maxrows > MAX_ROWS) maxrows = MAX_ROWS;
+  int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > SCR_ENT / 2) maxent = SCR_ENT / 2;
+  // --- non-contact rows: lanes 0..15 motors, 16..47 joint limits (dof, side), 48..53 tool constraint
+  RowGeom r; row_clear(r);
+  bool active = false; float bterm = 0.f, lo = 0.f, hi = 0.f;
+  if (lane < 16) {
+    const int d = lane;
+    if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f && !(c.frozen >> d & 1)) {
+      active = true; if (d < c.nrobot) r.robot = true; else r.human = true;
+      _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? 1.f : 0.f;
+      // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
+      bterm = RBF(c, d, AGX_R_KP) * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
+      float lim = RBF(c, d, AGX_R_MAXF) * dt; lo = -lim; hi = lim;
+    }
+  } else if (lane < 48) {
+    const int d = (lane - 16) >> 1, side = (lane - 16) & 1;
+    if (d < n && RBI(c, d, AGX_R_HAS_LIMIT) && !(c.frozen >> d & 1)) {
+      float q = L[L_ST + c.s_q + d];
+      float gap = side == 0 ? q - DLO(c, d) : DHI(c, d) - q;
+      if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
+        active = true; if (d < c.nrobot) r.robot = true; else r.human = true;
+        const float sg = side == 0 ? 1.f : -1.f;
+        _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? sg : 0.f;
+        float rv = sg * L[L_VEL + d];
+        bterm = gap > 0 ? (-gap / dt - rv) : (-gap * erp / dt - rv);
+        lo = 0.f; hi = 1e30f;
+      }
+    }
+  } else if (lane < 54) {
+    // tool fixed constraint (tool.py:46-47)
+    const int k = lane - 48; active = true;
+    v3 eep = ld3(L + L_MISC + M_EEP); m3 eeR = ldm3(L + L_MISC + M_EER);
+    v3 pivA = mul(eeR, mk3(TKF(c, AGX_T_TOOL_POS), TKF(c, AGX_T_TOOL_POS + 1), TKF(c, AGX_T_TOOL_POS + 2))) + eep;
+    m3 frameA = mul(eeR, quat_to_m3(TKF(c, AGX_T_TOOL_QUAT), TKF(c, AGX_T_TOOL_QUAT + 1), TKF(c, AGX_T_TOOL_QUAT + 2), TKF(c, AGX_T_TOOL_QUAT + 3)));
+    const int tb = c.bi[AGX_H_TOOL_BODY];
+    v3 pivB = ld3(L + L_ST + c.s_free + 13 * tb); m3 frameB = ldm3(L + L_FREER + 9 * tb);
+    float lim = TKF(c, AGX_T_TOOL_MAXF) * dt; lo = -lim; hi = lim;
+    const int link = TKI(c, AGX_T_EE_LINK);
+    if (k < 3) {
+      v3 nrm = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
+      row_pair(c, r, link, pivA, AGX_BODY_FREE0 + tb, pivB, nrm, mk3(0, 0, 0));
+      bterm = -comp(pivA - pivB, k) * erp / dt - row_velocity(c, r);
+    } else {
+      float ang[3]; m3_to_euler_xyz(mul_at(frameA, frameB), ang);
+      const int q = k - 3;
+      v3 axw = mk3(frameA.a[q], frameA.a[3 + q], frameA.a[6 + q]);
+      row_pair(c, r, link, pivA, AGX_BODY_FREE0 + tb, pivB, mk3(0, 0, 0), axw);
+      bterm = ang[q] * erp / dt - row_velocity(c, r);
+    }
+  }
+  int cnt = active ? row_entries(c, r) : 0;
+  uint64_t am = wave_ballot(active);
+  int row = wave_rank(am), off = 1 + wave_scan_excl(cnt);      // entry 0 of the arena is the zero pair
+  int nnc = popc64(am), ent = 1 + wave_sum_i(cnt);
+  wave_sync();
+  if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }
+  // --- contact rows: lane = contact; normal rows first, then one friction row per contact
+  int nc = c.ncon;
+  const bool has = lane < nc;
+  int ba = 0, bb = 0; v3 pa = mk3(0, 0, 0), pb = pa, nn = pa; float dist = 0.f, mu = 0.f;
+  RowGeom rn; row_clear(rn);
+  if (has) {
+    const float* k = c.gcon + CON_STRIDE * lane; const int* ki = (const int*)k;
+    ba = ki[C_BA]; bb = ki[C_BB]; pa = ld3(k + C_PA); pb = ld3(k + C_PB); nn = ld3(k + C_N); dist = k[C_DIST]; mu = k[C_MU];
+    row_pair(c, rn, ba, pa, bb, pb, nn, mk3(0, 0, 0));
+  }
+  int ccnt = has ? row_entries(c, rn) : 0;
+  int cincl = wave_scan_excl(ccnt) + ccnt;
+  // largest prefix of the contact list that fits the row and coefficient budgets
+  bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent);
+  nc = popc64(wave_ballot(fits));
+  const int tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0);
+  const int entN = ent, entF = ent + (nc > 0 ? tot : 0);
+  // the three row kinds go through ONE row_store call site (its M^-1 J^T product is the bulk of this
+  // phase's code): kind 0 non-contact, 1 contact normal, 2 contact friction
+  _Pragma("nounroll") for (int kind = 0; kind < 3; kind++) {
+    RowGeom R; int rrow = 0, roff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
+    if (kind == 0) {
+      R = r; go = active; rrow = row; roff = off; rb = bterm; rlo = lo; rhi = hi;
+    } else if (kind == 1) {
+      R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rlo = 0.f; rhi = 1e30f;
+      if (go) { const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv); }
+    } else {
+      go = lane < nc; rrow = nnc + nc + lane; roff = entF + cincl - ccnt; rfric = nnc + lane; rmu = mu;
+      row_clear(R);
+      if (go) {
+        // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
+        v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);
+        v3 t = vr - dot(vr, nn) * nn;
+        float l2 = dot(t, t);
+        if (l2 > PRM(c, AGX_P_FRIC_EPS)) t = (1.0f / sqrtf(l2)) * t; else plane_space(nn, t);
+        row_pair(c, R, ba, pa, bb, pb, t, mk3(0, 0, 0));
+        rb = -row_velocity(c, R);
+      }
+    }
+    if (go) row_store(c, R, rrow, roff, rb, rlo, rhi, rfric, rmu);
+  }
+  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0);
+  wave_sync();
+}
+
+}  // namespace agx

@@ -16,7 +16,7 @@ def lib():
     if _LIB is None:
         so = os.path.join(EMU, 'libagx_emu.so')
         deps = [os.path.join(EMU, f) for f in ('emu_main.cpp', 'agx_wave.h')] + \
-               [os.path.join(CSRC, f) for f in ('agx_step.h', 'agx_gjk.h', 'agx_math.h')] + [os.path.join(ROOT, 'include', 'agx_blob.h')]
+               [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'agx_blob.h')]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
             subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-I' + EMU, '-I' + CSRC, '-o', so,
                                    os.path.join(EMU, 'emu_main.cpp')])
