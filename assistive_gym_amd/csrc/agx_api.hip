@@ -67,6 +67,16 @@ agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* don
   if (threadIdx.x == 0) episode[env] = ep;
 }
 
+// reset generator: FeedingEnv.reset's sampling incl. the IK restarts (64 per round, one per lane), float64
+extern "C" __global__ void __launch_bounds__(64)
+agx_sample_kernel(const uint32_t* __restrict__ blob, float* state, unsigned long long seed0, int impairment_mode, int gender_mode, float* info4, int n_envs, int sw) {
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  const unsigned long long seed = seed0 + (unsigned long long)env;
+  agx::env_sample(blob, state + (size_t)env * sw, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4 ? info4 + (size_t)env * 4 : nullptr,
+                  (int)threadIdx.x);
+}
+
 extern "C" __global__ void __launch_bounds__(64) agx_selftest_kernel(float* out_f, int* out_i, unsigned long long* out_m) {
   const int lane = wave_lane();
   float x = (float)(lane * lane % 17) * 0.25f - 1.0f;
@@ -91,6 +101,7 @@ struct agx_handle_s {
   float* scratch_dev;   // [n_envs][SCR_WORDS]: rows, predicted velocities, contacts handed between the kernels
   int* episode_dev;
   int frame_skip;
+  bool can_sample;      // the blob fits the compiled reset generator (agx_reset.h)
   // staging for the *_host convenience calls
   float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
   hipEvent_t ev0, ev1;
@@ -123,12 +134,23 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     if (G[AGX_G_A1] - G[AGX_G_A0] > 128 || G[AGX_G_B1] - G[AGX_G_B0] > 128 || (G[AGX_G_B0F] >= 0 && G[AGX_G_B1F] - G[AGX_G_B0F] > 128))
       return fail(AGX_E_LIMIT, "agx_create: a pair group has a collider range of more than 128 colliders");
   }
+  bool can_sample = true;   // the reset generator's IK is compiled for a serial 7-DoF arm carrying the end effector
+  {
+    const int32_t* X = hi + hi[AGX_H_OFF_RESET];
+    const int32_t* T = hi + hi[AGX_H_OFF_TASK];
+    if (X[AGX_X_NARM] != agx::RS_NARM || T[AGX_T_EE_LINK] != agx::RS_NARM - 1 || hi[AGX_H_NROBOT] < agx::RS_NARM || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64) can_sample = false;
+    for (int d = 0; can_sample && d < agx::RS_NARM; d++) {
+      const int32_t* R = hi + hi[AGX_H_OFF_ROBOT] + d * AGX_R_STRIDE;
+      if (R[AGX_R_PARENT] != d - 1 || R[AGX_R_ACT] != d) can_sample = false;
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AGX_E_NOGPU, "agx_create: no HIP device (libagx has no CPU path)");
   if (device < 0 || device >= ndev) return fail(AGX_E_ARG, "agx_create: bad device index");
   HIPCHK(hipSetDevice(device));
   agx_handle h = new agx_handle_s();
   memset(h, 0, sizeof *h);
+  h->can_sample = can_sample;
   h->device = device; h->n_envs = n_envs; h->act_dim = hi[AGX_H_ACT_DIM]; h->obs_dim = hi[AGX_H_OBS_DIM]; h->sw = hi[AGX_H_STATE_WORDS];
   HIPCHK(hipMalloc(&h->blob_dev, blob_bytes));
   HIPCHK(hipMemcpy(h->blob_dev, blob, blob_bytes, hipMemcpyHostToDevice));
@@ -283,6 +305,16 @@ int agx_observe(agx_handle h, float* obs, void* stream) {
   HIPCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(agx_observe_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, (hipStream_t)stream, h->blob_dev, h->state_dev, obs, h->n_envs, h->sw, h->obs_dim);
   HIPCHK(hipGetLastError());
+  return AGX_OK;
+}
+int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {
+  if (!h || impairment_mode < -2 || impairment_mode > 3 || gender_mode < -1 || gender_mode > 1) return fail(AGX_E_ARG, "agx_sample_reset: bad argument");
+  if (!h->can_sample) return fail(AGX_E_LIMIT, "agx_sample_reset: the reset generator needs a serial 7-DoF arm carrying the end effector");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(agx_sample_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->blob_dev, h->state_dev, (unsigned long long)seed, impairment_mode,
+                     gender_mode, ik_info_dev, h->n_envs, h->sw);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(h->episode_dev, 0, (size_t)h->n_envs * 4, (hipStream_t)stream));
   return AGX_OK;
 }
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {

@@ -1,0 +1,386 @@
+// agx_reset.h -- device-side reset generator: FeedingEnv.reset's sampling for one environment per wavefront.
+//
+// What it replaces (reference paths): FeedingEnv.reset up to the settle loop (assistive_gym/envs/feeding.py:114-177):
+// plane friction (envs/env.py:120), Human.init draws (agents/human.py:72-92), the posed static human
+// (feeding.py:124-126, human.py:104-127, tree of human_creation.py:188-278), the mouth target (feeding.py:184-196),
+// init_robot_pose -> Robot.ik_random_restarts (env.py:276-310, agents/robot.py:84-121), gripper / tool / bowl / food
+// placement (feeding.py:143-166, tool.py:49-62, furniture.py:32-34).  The 25 settle substeps (feeding.py:178-179)
+// are the stepper's own kernels (agx_settle).
+//
+// Mapping to the wavefront:
+//   * the scalar draws and the human pose are cheap and computed redundantly / one body per lane;
+//   * the IK restarts of robot.py:88-99 -- a sequential loop in the reference -- run 64 AT A TIME, one restart
+//     per lane, each lane iterating its own damped-least-squares problem in registers.  Every random number has
+//     a fixed (stream, slot) address in a counter-based generator (Philox4x32-10 keyed by the env seed), so
+//     "the first successful restart" is simply the lowest lane of the first round whose ballot is non-empty;
+//   * all of it in float64: it runs once per episode, MI355X has full-rate FP64 vector units, and the result is
+//     then independent of evaluation order to ~1e-13, which is what makes it checkable against the numpy
+//     restatement (oracle/reset_oracle.py) through the discontinuous accept / reject decisions.
+// Bullet's own IK is not reproduced; the acceptance test of ik_random_restarts is.
+#pragma once
+
+namespace agx {
+
+struct d3 { double x, y, z; };
+struct dq { double x, y, z, w; };
+
+AGX_DEV d3 dmk(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+AGX_DEV d3 operator+(d3 a, d3 b) { return dmk(a.x + b.x, a.y + b.y, a.z + b.z); }
+AGX_DEV d3 operator-(d3 a, d3 b) { return dmk(a.x - b.x, a.y - b.y, a.z - b.z); }
+AGX_DEV double ddot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+AGX_DEV d3 dcross(d3 a, d3 b) { return dmk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+AGX_DEV d3 dld3(const float* p) { return dmk((double)p[0], (double)p[1], (double)p[2]); }
+AGX_DEV dq dld4(const float* p) { dq q; q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3]; return q; }
+AGX_DEV dq dq_ident() { dq q; q.x = 0; q.y = 0; q.z = 0; q.w = 1; return q; }
+AGX_DEV dq dqmul(dq a, dq b) {
+  dq r;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  return r;
+}
+AGX_DEV d3 dqrot(dq q0, d3 v) {
+  const double n = 1.0 / sqrt(q0.x * q0.x + q0.y * q0.y + q0.z * q0.z + q0.w * q0.w);
+  const double x = q0.x * n, y = q0.y * n, z = q0.z * n, w = q0.w * n;
+  return dmk((1 - 2 * (y * y + z * z)) * v.x + 2 * (x * y - z * w) * v.y + 2 * (x * z + y * w) * v.z,
+             2 * (x * y + z * w) * v.x + (1 - 2 * (x * x + z * z)) * v.y + 2 * (y * z - x * w) * v.z,
+             2 * (x * z - y * w) * v.x + 2 * (y * z + x * w) * v.y + (1 - 2 * (x * x + y * y)) * v.z);
+}
+AGX_DEV dq dq_axis_angle(d3 a, double th) {
+  const double n = sqrt(ddot(a, a));
+  if (n < 1e-12) return dq_ident();
+  const double s = sin(0.5 * th) / n;
+  dq q; q.x = a.x * s; q.y = a.y * s; q.z = a.z * s; q.w = cos(0.5 * th);
+  return q;
+}
+// (pa, qa) o (pb, qb)
+AGX_DEV void dcompose(d3 pa, dq qa, d3 pb, dq qb, d3& p, dq& q) { p = pa + dqrot(qa, pb); q = dqmul(qa, qb); }
+
+AGX_DEV double wave_bcast_d(double x, int src) {
+  int w[2]; __builtin_memcpy(w, &x, 8);
+  w[0] = wave_bcast_i(w[0], src); w[1] = wave_bcast_i(w[1], src);
+  double r; __builtin_memcpy(&r, w, 8); return r;
+}
+
+// ---- counter-based random numbers: Philox4x32-10, counter (slot, stream, 0, 0), key = env seed ----------
+AGX_DEV double rs_u01(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t slot) {
+  uint32_t c0 = slot, c1 = stream, c2 = 0u, c3 = 0u;
+  for (int r = 0; r < 10; r++) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (double)((((uint64_t)(c0 >> 5)) << 26) | (uint64_t)(c1 >> 6)) * (1.0 / 9007199254740992.0);
+}
+// stream 0 slots, restart-stream slots (+ DoF)
+enum { RS_FRICTION = 0, RS_GENDER = 1, RS_IMPAIRMENT = 2, RS_LIMIT = 3, RS_STRENGTH = 4, RS_HEAD = 8, RS_EE = 12, RS_BOWL = 16,
+       RS_TREMOR = 32, RS_R_REST = 0, RS_R_LO = 16, RS_R_HI = 32 };
+enum { RS_IMP_NONE = 0, RS_IMP_LIMITS = 1, RS_IMP_WEAKNESS = 2, RS_IMP_TREMOR = 3, RS_MODE_RANDOM = -1, RS_MODE_NO_TREMOR = -2 };
+constexpr int RS_NARM = 7;   // arm DoFs solved by the IK; agx_create checks the blob (a serial chain 0..6 carrying the end effector)
+
+struct ResetCtx {
+  const float* bf; const int* bi;
+  const float* xf; const int* xi;     // reset section
+  const float* rob; const float* task;
+  int nj, gender;
+  double ls;                          // limit scale of the sampled human
+  double head[3];                     // head joint angle draws
+};
+#define XF(c, k) ((double)(c).xf[(k)])
+#define XI(c, k) ((c).xi[(k)])
+
+// joint angle of human joint j: task preset (+ head draw), clamped to the limits (agent.py:240-250)
+AGX_DEV double rs_joint_angle(const ResetCtx& c, int j) {
+  const int base = XI(c, AGX_X_OFF_JOINTS) + (c.gender * c.nj + j) * AGX_XJ_STRIDE;
+  const int flags = c.xi[base + AGX_XJ_FLAGS];
+  if (!(flags & 1)) return 0.0;
+  double a = (double)c.xf[base + AGX_XJ_PRESET];
+  const int k = c.xi[base + AGX_XJ_DRAW];
+  if (k >= 0) a += (k == 0 ? c.head[0] : (k == 1 ? c.head[1] : c.head[2]));
+  const double s = (flags & 2) ? c.ls : 1.0;
+  return fmin(fmax(a, (double)c.xf[base + AGX_XJ_LOWER] * s), (double)c.xf[base + AGX_XJ_UPPER] * s);
+}
+// world pose of a human link frame (-1 = base): from the link up to the base, then the base transform
+AGX_DEV void rs_link_pose(const ResetCtx& c, int link, d3& p, dq& q) {
+  p = dmk(0, 0, 0); q = dq_ident();
+  for (int j = link; j >= 0;) {
+    const int base = XI(c, AGX_X_OFF_JOINTS) + (c.gender * c.nj + j) * AGX_XJ_STRIDE;
+    const dq jq = dq_axis_angle(dld3(c.xf + base + AGX_XJ_AXIS), rs_joint_angle(c, j));
+    dcompose(dld3(c.xf + base + AGX_XJ_OFF), jq, p, q, p, q);
+    j = c.xi[base + AGX_XJ_PARENT];
+  }
+  dcompose(dld3(c.xf + (c.gender ? AGX_X_HBASE_F : AGX_X_HBASE_M)), dq_ident(), p, q, p, q);
+}
+
+// arm forward kinematics: joint origins, world joint axes, end-effector pose
+AGX_DEV void rs_arm_fk(const ResetCtx& c, const double* q, d3* pos, d3* axw, d3& pe, dq& oe) {
+  d3 pp = dld3(c.xf + AGX_X_BASE_POS); dq pq = dld4(c.xf + AGX_X_BASE_QUAT);
+#pragma unroll
+  for (int d = 0; d < RS_NARM; d++) {
+    const float* r = c.rob + d * AGX_R_STRIDE;
+    d3 jp; dq jq;
+    dcompose(pp, pq, dld3(r + AGX_R_TPOS), dld4(r + AGX_R_TQUAT), jp, jq);
+    const d3 ax = dld3(r + AGX_R_AXIS);
+    pq = dqmul(jq, dq_axis_angle(ax, q[d]));
+    pp = jp;
+    pos[d] = jp; axw[d] = dqrot(pq, ax);
+  }
+  dcompose(pp, pq, dld3(c.task + AGX_T_EE_POS), dld4(c.task + AGX_T_EE_QUAT), pe, oe);
+}
+
+// damped least squares from q (in place), joint box [lo, hi]
+AGX_DEV void rs_ik(const ResetCtx& c, double* q, const double* lo, const double* hi, d3 tpos, dq tquat) {
+  const double lam2 = XF(c, AGX_X_IK_DAMP) * XF(c, AGX_X_IK_DAMP), tol = XF(c, AGX_X_IK_TOL), maxstep = XF(c, AGX_X_IK_MAXSTEP);
+  const int iters = XI(c, AGX_X_IK_ITERS);
+  for (int it = 0; it < iters; it++) {
+    d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
+    rs_arm_fk(c, q, pos, axw, pe, oe);
+    const d3 ep = tpos - pe;
+    dq oc; oc.x = -oe.x; oc.y = -oe.y; oc.z = -oe.z; oc.w = oe.w;
+    dq qe = dqmul(tquat, oc);
+    if (qe.w < 0) { qe.x = -qe.x; qe.y = -qe.y; qe.z = -qe.z; }
+    const d3 er = dmk(2.0 * qe.x, 2.0 * qe.y, 2.0 * qe.z);
+    if (sqrt(ddot(ep, ep)) < tol && sqrt(ddot(er, er)) < tol) break;
+    // columns of the 6 x NARM Jacobian: [axis x (pe - origin); axis]
+    double J[6][RS_NARM];
+#pragma unroll
+    for (int d = 0; d < RS_NARM; d++) {
+      const d3 l = dcross(axw[d], pe - pos[d]);
+      J[0][d] = l.x; J[1][d] = l.y; J[2][d] = l.z; J[3][d] = axw[d].x; J[4][d] = axw[d].y; J[5][d] = axw[d].z;
+    }
+    // A = J J^T + lam^2 I, Cholesky A = L L^T, solve A y = e
+    double A[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double s = (i == j) ? lam2 : 0.0;
+#pragma unroll
+        for (int d = 0; d < RS_NARM; d++) s += J[i][d] * J[j][d];
+        A[i][j] = s;
+      }
+    }
+    double y[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double s = A[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
+      const double ljj = sqrt(s), inv = 1.0 / ljj;
+      A[j][j] = ljj;
+#pragma unroll
+      for (int i = j + 1; i < 6; i++) {
+        double t = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
+        A[i][j] = t * inv;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double t = y[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) t -= A[i][k] * y[k];
+      y[i] = t / A[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+      double t = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) t -= A[k][i] * y[k];
+      y[i] = t / A[i][i];
+    }
+    double dqv[RS_NARM], step = 0.0;
+#pragma unroll
+    for (int d = 0; d < RS_NARM; d++) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) s += J[i][d] * y[i];
+      dqv[d] = s; step = fmax(step, fabs(s));
+    }
+    const double scale = step > maxstep ? maxstep / step : 1.0;
+#pragma unroll
+    for (int d = 0; d < RS_NARM; d++) q[d] = fmin(fmax(q[d] + (step > maxstep ? dqv[d] * scale : dqv[d]), lo[d]), hi[d]);
+  }
+}
+
+// One environment.  gstate: this env's state record (fully overwritten).  ginfo (may be null): float[4] =
+// {IK succeeded, restarts used, end-effector position error, impairment index}.
+AGX_DEV void env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gstate, uint32_t seed_lo, uint32_t seed_hi,
+                        int impairment_mode, int gender_mode, float* __restrict__ ginfo, int lane) {
+  ResetCtx c;
+  c.bf = (const float*)blob; c.bi = (const int*)blob;
+  c.xf = c.bf + c.bi[AGX_H_OFF_RESET]; c.xi = c.bi + c.bi[AGX_H_OFF_RESET];
+  c.rob = c.bf + c.bi[AGX_H_OFF_ROBOT]; c.task = c.bf + c.bi[AGX_H_OFF_TASK];
+  c.nj = XI(c, AGX_X_NJOINT);
+  const int ndof = c.bi[AGX_H_NDOF], nrobot = c.bi[AGX_H_NROBOT], nhdof = c.bi[AGX_H_NHDOF], nfree = c.bi[AGX_H_NFREE];
+  const int nhuman = c.bi[AGX_H_NHUMAN], nfood = c.bi[AGX_H_NFOOD], state_words = c.bi[AGX_H_STATE_WORDS];
+  const int sQ = c.bi[AGX_H_S_Q], sQT = c.bi[AGX_H_S_QT], sFREE = c.bi[AGX_H_S_FREE], sBASE = c.bi[AGX_H_S_BASE];
+  const int sHUMAN = c.bi[AGX_H_S_HUMAN], sENV = c.bi[AGX_H_S_ENV], sTREMOR = c.bi[AGX_H_S_TREMOR];
+  int* gstate_i = (int*)gstate;
+
+  // ---- scalar draws (every lane computes the same values) ------------------------------------------
+  const double friction = XF(c, AGX_X_FRIC_LO) + (XF(c, AGX_X_FRIC_HI) - XF(c, AGX_X_FRIC_LO)) * rs_u01(seed_lo, seed_hi, 0, RS_FRICTION);
+  c.gender = gender_mode >= 0 ? gender_mode : (rs_u01(seed_lo, seed_hi, 0, RS_GENDER) < 0.5 ? 0 : 1);     // human.py:76-78
+  int imp = impairment_mode;
+  if (imp < 0) {                                                                                             // human.py:80-81
+    const int nchoice = impairment_mode == RS_MODE_RANDOM ? 4 : 3;
+    imp = (int)(rs_u01(seed_lo, seed_hi, 0, RS_IMPAIRMENT) * nchoice);
+    if (imp > nchoice - 1) imp = nchoice - 1;
+  }
+  c.ls = imp != RS_IMP_LIMITS ? 1.0 : XF(c, AGX_X_LIMIT_LO) + (1.0 - XF(c, AGX_X_LIMIT_LO)) * rs_u01(seed_lo, seed_hi, 0, RS_LIMIT);   // human.py:85
+  for (int k = 0; k < 3; k++) c.head[k] = (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_HEAD + k) - 1.0) * XF(c, AGX_X_HEAD_RANGE);          // feeding.py:125
+
+  for (int w = lane; w < state_words; w += AGX_WAVE) gstate[w] = 0.f;
+  wave_sync();
+
+  // ---- posed human: one static collision body per lane, lane NHUMAN the head (mouth target) --------
+  if (lane <= nhuman) {
+    const int link = lane < nhuman ? c.xi[XI(c, AGX_X_OFF_BODIES) + lane]
+                                   : c.xi[XI(c, AGX_X_OFF_DYN) + ((const int*)c.task)[AGX_T_HEAD_LINK] - nrobot];
+    d3 p; dq q;
+    rs_link_pose(c, link, p, q);
+    if (lane < nhuman) {
+      float* o = gstate + sHUMAN + 7 * lane;
+      o[0] = (float)p.x; o[1] = (float)p.y; o[2] = (float)p.z; o[3] = (float)q.x; o[4] = (float)q.y; o[5] = (float)q.z; o[6] = (float)q.w;
+    } else {                                                                                                 // feeding.py:184-196
+      const d3 t = p + dqrot(q, dld3(c.task + (c.gender ? AGX_T_MOUTH_F : AGX_T_MOUTH_M)));
+      float* o = gstate + sENV + AGX_E_TARGET;
+      o[0] = (float)t.x; o[1] = (float)t.y; o[2] = (float)t.z;
+    }
+  }
+
+  // ---- robot start pose: IK restarts, 64 per round (robot.py:84-121) -------------------------------
+  d3 tpos = dld3(c.xf + AGX_X_EE_TARGET);                                                                    // feeding.py:139
+  tpos.x += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_EE + 0) - 1.0) * XF(c, AGX_X_EE_RANGE);
+  tpos.y += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_EE + 1) - 1.0) * XF(c, AGX_X_EE_RANGE);
+  tpos.z += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_EE + 2) - 1.0) * XF(c, AGX_X_EE_RANGE);
+  const dq tquat = dld4(c.xf + AGX_X_EE_QUAT);
+  const int max_restarts = XI(c, AGX_X_IK_RESTARTS), randlim_from = XI(c, AGX_X_IK_RANDLIM_FROM);
+  const double thresh = XF(c, AGX_X_IK_THRESH);
+  double best_q[RS_NARM], best_d = 1e300;
+  int best_r = 0x7fffffff, restarts = max_restarts, ok = 0;
+#pragma unroll
+  for (int d = 0; d < RS_NARM; d++) best_q[d] = 0.0;
+  for (int r0 = 0; r0 < max_restarts && !ok; r0 += AGX_WAVE) {
+    const int r = r0 + lane;
+    const bool active = r < max_restarts;
+    double q[RS_NARM], dpos = 1e300, dor = 1e300;
+#pragma unroll
+    for (int d = 0; d < RS_NARM; d++) q[d] = 0.0;
+    if (active) {
+      double lo[RS_NARM], hi[RS_NARM];
+#pragma unroll
+      for (int d = 0; d < RS_NARM; d++) {
+        const double lower = (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER];
+        double l = lower < -1e9 ? -6.283185307179586 : lower, h = upper > 1e9 ? 6.283185307179586 : upper;       // agent.py:223-231
+        if (r >= randlim_from) {                                                                                 // robot.py:91
+          l *= rs_u01(seed_lo, seed_hi, 1u + (uint32_t)r, RS_R_LO + d);
+          h *= rs_u01(seed_lo, seed_hi, 1u + (uint32_t)r, RS_R_HI + d);
+        }
+        q[d] = l + (h - l) * rs_u01(seed_lo, seed_hi, 1u + (uint32_t)r, RS_R_REST + d);                            // agent.py:263
+        lo[d] = fmin(l, h); hi[d] = fmax(l, h);
+      }
+      rs_ik(c, q, lo, hi, tpos, tquat);
+#pragma unroll
+      for (int d = 0; d < RS_NARM; d++)                                                                          // set_joint_angles(use_limits=True)
+        q[d] = fmin(fmax(q[d], (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER]), (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER]);
+      d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
+      rs_arm_fk(c, q, pos, axw, pe, oe);
+      dpos = sqrt(ddot(tpos - pe, tpos - pe));
+      const double mx = tquat.x - oe.x, my = tquat.y - oe.y, mz = tquat.z - oe.z, mw = tquat.w - oe.w;
+      const double px = tquat.x + oe.x, py = tquat.y + oe.y, pz = tquat.z + oe.z, pw = tquat.w + oe.w;
+      dor = fmin(sqrt(mx * mx + my * my + mz * mz + mw * mw), sqrt(px * px + py * py + pz * pz + pw * pw));
+      if (dpos < best_d) {
+        best_d = dpos; best_r = r;
+#pragma unroll
+        for (int d = 0; d < RS_NARM; d++) best_q[d] = q[d];
+      }
+    }
+    const uint64_t hit = wave_ballot(active && dpos < thresh && dor < thresh);                                  // robot.py:97
+    if (hit) {
+      const int l = ffs64(hit);
+      ok = 1; restarts = r0 + l + 1;
+      best_d = wave_bcast_d(dpos, l);
+#pragma unroll
+      for (int d = 0; d < RS_NARM; d++) best_q[d] = wave_bcast_d(q[d], l);
+    }
+  }
+  if (!ok) {   // no restart met the thresholds: the one with the smallest position error, earliest on ties (robot.py:100-103)
+    double md = 1e300; int mr = 0x7fffffff, ml = 0;
+    for (int l = 0; l < AGX_WAVE; l++) {
+      const double dl = wave_bcast_d(best_d, l); const int rl = wave_bcast_i(best_r, l);
+      if (dl < md || (dl == md && rl < mr)) { md = dl; mr = rl; ml = l; }
+    }
+    best_d = md;
+#pragma unroll
+    for (int d = 0; d < RS_NARM; d++) best_q[d] = wave_bcast_d(best_q[d], ml);
+  }
+
+  // ---- write the record (every lane now holds the chosen arm pose) ---------------------------------
+  d3 pos[RS_NARM], axw[RS_NARM], pe, tp; dq oe, tq;
+  rs_arm_fk(c, best_q, pos, axw, pe, oe);
+  dcompose(pe, oe, dld3(c.task + AGX_T_TOOL_POS), dld4(c.task + AGX_T_TOOL_QUAT), tp, tq);                   // tool.py:49-62
+  if (lane < ndof) {
+    double qv;
+    if (lane < RS_NARM) {
+      qv = best_q[0];
+#pragma unroll
+      for (int d = 1; d < RS_NARM; d++) qv = lane == d ? best_q[d] : qv;
+    } else if (lane < nrobot) {                                                                              // gripper, feeding.py:143-144
+      const float* r = c.rob + lane * AGX_R_STRIDE;
+      qv = fmin(fmax((double)r[AGX_R_QT0], (double)r[AGX_R_LOWER]), (double)r[AGX_R_UPPER]);
+    } else {
+      const int k = lane - nrobot;
+      qv = rs_joint_angle(c, c.xi[XI(c, AGX_X_OFF_DYN) + k]);
+      gstate[sTREMOR + k] = imp == RS_IMP_TREMOR ? (float)((2.0 * rs_u01(seed_lo, seed_hi, 0, RS_TREMOR + k) - 1.0) * XF(c, AGX_X_TREMOR_RANGE)) : 0.f;   // human.py:89-90
+      gstate[sTREMOR + nhdof + k] = (float)qv;                                                               // human.py:123
+    }
+    gstate[sQ + lane] = (float)qv;
+    gstate[sQT + lane] = (float)qv;
+  }
+  if (lane < nfree) {
+    float* o = gstate + sFREE + 13 * lane;
+    const int tool_body = c.bi[AGX_H_TOOL_BODY], bowl_body = XI(c, AGX_X_BOWL_BODY), food0 = c.bi[AGX_H_FOOD0];
+    d3 p = dmk(0, 0, 0); dq q = dq_ident();
+    if (lane == tool_body) { p = tp; q = tq; }
+    else if (lane == bowl_body) {                                                                            // furniture.py:32-34
+      const double br = XF(c, AGX_X_BOWL_RANGE);
+      d3 b = dld3(c.xf + AGX_X_BOWL_POS);
+      b.x += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_BOWL + 0) - 1.0) * br;
+      b.y += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_BOWL + 1) - 1.0) * br;
+      const float* fb = c.bf + c.bi[AGX_H_OFF_FREE] + lane * AGX_F_STRIDE;
+      dq qi = dld4(fb + AGX_F_REFQUAT); qi.x = -qi.x; qi.y = -qi.y; qi.z = -qi.z;
+      const d3 ip = dqrot(qi, dld3(fb + AGX_F_REFPOS));
+      dcompose(b, dq_ident(), dmk(-ip.x, -ip.y, -ip.z), qi, p, q);
+    } else if (lane >= food0 && lane < food0 + nfood) {                                                      // feeding.py:158-166
+      const int k = lane - food0;
+      const double two_r = 2.0 * XF(c, AGX_X_FOOD_R);
+      p = dmk((double)(k >> 2 & 1) * two_r, (double)(k >> 1 & 1) * two_r, (double)(k & 1) * two_r) + dld3(c.xf + AGX_X_FOOD_OFF) + tp;
+    }
+    o[0] = (float)p.x; o[1] = (float)p.y; o[2] = (float)p.z; o[3] = (float)q.x; o[4] = (float)q.y; o[5] = (float)q.z; o[6] = (float)q.w;
+  }
+  if (lane < 7) gstate[sBASE + lane] = c.xf[AGX_X_BASE_POS + lane];      // BASE_POS[3] and BASE_QUAT[4] are adjacent
+  if (lane == 0) {
+    float* e = gstate + sENV; int* ei = gstate_i + sENV;
+    const uint64_t seed = ((uint64_t)seed_hi << 32) | seed_lo;
+    e[AGX_E_PLANE_FRICTION] = (float)friction;
+    ei[AGX_E_GENDER] = c.gender;
+    ei[AGX_E_FOOD_ALIVE] = (1 << nfood) - 1; ei[AGX_E_FOOD_ACTIVE] = (1 << nfood) - 1;
+    ei[AGX_E_ITERATION] = 0; ei[AGX_E_TASK_SUCCESS] = 0;
+    ei[AGX_E_RNG] = (int)((seed * 2654435761ull + 12345ull) & 0x7FFFFFFFull);
+    ei[AGX_E_RNG + 1] = (int)((seed ^ 0x5bd1e995ull) & 0x7FFFFFFFull);
+    ei[AGX_E_TOTAL_FOOD] = nfood;
+    const bool coop = ((const int*)c.task)[AGX_T_COOP] == 1;
+    ei[AGX_E_FROZEN] = (imp == RS_IMP_TREMOR || coop) ? 0 : (((1 << nhdof) - 1) << nrobot);                  // human.py:104-110
+    e[AGX_E_LIMIT_SCALE] = (float)c.ls;
+    if (ginfo) { ginfo[0] = (float)ok; ginfo[1] = (float)restarts; ginfo[2] = (float)best_d; ginfo[3] = (float)imp; }
+  }
+}
+
+#undef XF
+#undef XI
+
+}  // namespace agx

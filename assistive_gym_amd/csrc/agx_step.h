@@ -17,7 +17,8 @@
 //
 // Files: agx_ctx.h (limits, LDS / scratch layouts, per-lane context), agx_dyn.h (kinematics, ABA, M^-1),
 // agx_collide.h (broadphase, GJK narrowphase, contact selection), agx_rows.h (constraint rows),
-// agx_pgs.h (Gauss-Seidel sweeps, gfx950 assembly), agx_env.h (integration, task layer, kernel bodies).
+// agx_pgs.h (Gauss-Seidel sweeps, gfx950 assembly), agx_env.h (integration, task layer, kernel bodies),
+// agx_reset.h (device-side reset generator: sampling + IK restarts, float64).
 #pragma once
 #include "agx_math.h"
 #include "agx_gjk.h"
@@ -28,3 +29,4 @@
 #include "agx_rows.h"
 #include "agx_pgs.h"
 #include "agx_env.h"
+#include "agx_reset.h"

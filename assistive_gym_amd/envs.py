@@ -14,7 +14,6 @@ CPU fallback, constructing the env without a GPU raises.
 import numpy as np
 
 from .blob import ModelBlob
-from .host.reset import FeedingJacoReset
 
 try:                                     # gym is optional here (not installed in the build image)
     import gym
@@ -83,8 +82,6 @@ class FeedingJacoEnv(_Base):
         self.task_success = 0
         self.total_force_on_human = 0.0
         self._stepper = None
-        self._reset_helper = FeedingJacoReset(self.blob)
-        self._episode = 0
         self.seed(1001)                                                               # env.py:21,30
 
     # ---- gym API ------------------------------------------------------------------------------
@@ -101,13 +98,18 @@ class FeedingJacoEnv(_Base):
             self._stepper = Stepper(self.blob, 1, self.device)
         return self._stepper
 
+    def _draw_seed(self):
+        """62 bits from the gym-seeded generator: the key of the device-side reset generator's counter RNG"""
+        r = self.np_random
+        draw = r.integers if hasattr(r, 'integers') else r.randint
+        return (int(draw(0, 2 ** 31 - 1)) << 31) | int(draw(0, 2 ** 31 - 1))
+
     def reset(self):
+        """FeedingEnv.reset (feeding.py:114-182): sampled on the device (agx_sample_reset: human, IK with random
+        restarts, tool / bowl / food), settled for 25 substeps, observed."""
         st = self._ensure_stepper()
-        state = self.blob.new_state(1)
-        self._episode += 1
-        self.reset_info = {}
-        self._reset_helper.sample(self.np_random, state, env_seed=self._episode, info=self.reset_info, impairment='random')
-        st.set_state(state)
+        self.reset_seed = self._draw_seed()
+        st.sample_reset(self.reset_seed, impairment='random')
         st.settle(SETTLE_STEPS)
         self.iteration, self.task_success = 0, 0
         return self._split_obs(st.observe_host()[0].astype(np.float64))

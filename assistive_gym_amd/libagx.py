@@ -13,7 +13,7 @@ _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
-           'agx_observe', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
+           'agx_observe', 'agx_sample_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest']
 
 
@@ -103,6 +103,14 @@ class Stepper:
 
     def observe_dev(self, obs, stream=0):
         check(self.L.agx_observe(self.h, _ptr(obs), C.c_void_p(stream)), 'agx_observe')
+
+    IMPAIRMENT_MODES = {'random': -1, 'no_tremor': -2, 'none': 0, 'limits': 1, 'weakness': 2, 'tremor': 3}
+    GENDER_MODES = {'random': -1, 'male': 0, 'female': 1}
+
+    def sample_reset(self, seed, impairment='random', gender='random', ik_info=None, stream=0):
+        """device-side FeedingEnv.reset sampling of every env (env i from seed + i); follow with settle(25)"""
+        check(self.L.agx_sample_reset(self.h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(self.IMPAIRMENT_MODES[impairment]),
+                                      C.c_int(self.GENDER_MODES[gender]), _ptr(ik_info), C.c_void_p(stream)), 'agx_sample_reset')
 
     def reset_done(self, pool, pool_n, done, stream=0):
         check(self.L.agx_reset_done(self.h, _ptr(pool), C.c_int(pool_n), _ptr(done), C.c_void_p(stream)), 'agx_reset_done')

@@ -31,7 +31,7 @@ from .urdf import Urdf
 H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT=7, NGROUP=8, NFOOD=9, ACT_DIM=10,
          OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
          STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
-         NDIR=29, OFF_DIRS=30, OFF_VERT4=31, NROBOT=32, NHDOF=33, S_TREMOR=34, COUNT=40)
+         NDIR=29, OFF_DIRS=30, OFF_RESET=31, NROBOT=32, NHDOF=33, S_TREMOR=34, COUNT=40)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
          HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, COUNT=24)
@@ -43,6 +43,12 @@ G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
 T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV=7, SUCCESS_FRAC=8, MOUTH_DIST=9,
          SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
          TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, COUNT=40)
+# reset section (sampling ranges of FeedingEnv.reset + the posed-human kinematic tree), see agx_blob.h
+X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
+          HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
+          IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
+          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COUNT=48)
+XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
          TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, COUNT=16)
 BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
@@ -50,7 +56,7 @@ PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
 HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8)
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 6
+MAGIC, VERSION = 0x31584741, 7
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -424,9 +430,8 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     nrec = nrobot + 2 * nhdof
     for name, size in (('PARAMS', P['COUNT']), ('ROBOT', nrec * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
                        ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
-                       ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('VERT4', 4 * len(verts))):
-        if name == 'VERT4':
-            cur = (cur + 3) // 4 * 4          # 16-byte aligned
+                       ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']),
+                       ('RESET', X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof)):
         off[name] = cur
         cur += size
     nwords = cur
@@ -444,7 +449,7 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
                OFF_ROBOT=off['ROBOT'], OFF_FREE=off['FREE'], OFF_COLL=off['COLL'], OFF_VERT=off['VERT'],
                OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
                S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, FOOD0=2, TOOL_BODY=0, NDIR=len(dirs),
-               OFF_DIRS=off['DIRS'], OFF_VERT4=off['VERT4'], NROBOT=nrobot, NHDOF=nhdof, S_TREMOR=s_tremor)
+               OFF_DIRS=off['DIRS'], OFF_RESET=off['RESET'], NROBOT=nrobot, NHDOF=nhdof, S_TREMOR=s_tremor)
     for k, v in hdr.items():
         i[H[k]] = v
     p = f[off['PARAMS']:off['PARAMS'] + P['COUNT']]
@@ -493,7 +498,45 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     v32 = verts.astype(np.float32)
     f[off['VERT']:off['VERT'] + 3 * len(verts)] = v32.ravel()
     f[off['DIRS']:off['DIRS'] + 3 * len(dirs)] = dirs.astype(np.float32).ravel()
-    f[off['VERT4']:off['VERT4'] + 4 * len(verts)] = np.concatenate([v32, np.zeros((len(verts), 1), np.float32)], axis=1).ravel()
+    # ---- reset section: what FeedingEnv.reset samples (feeding.py:114-172) + the posed-human tree
+    x0 = off['RESET']
+    xf, xi = f[x0:], i[x0:]
+    xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
+    xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = [-0.35, -0.3, 0.36]                          # jaco.py:47 toc_base_pos_offset
+    xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])      # feeding.py:136
+    xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0])  # jaco.py:43 toc_ee_orient_rpy
+    xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.15, -0.65, 1.15], 0.05   # feeding.py:139
+    xf[X_['BOWL_POS']:X_['BOWL_POS'] + 3], xf[X_['BOWL_RANGE']] = [-0.15, -0.65, 0.75], 0.05    # furniture.py:33
+    xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [0, 0.03, 0.89], [0, 0.03, 0.86]   # human.py:102
+    xf[X_['FOOD_R']] = 0.005                                                             # feeding.py:158
+    xf[X_['FOOD_OFF']:X_['FOOD_OFF'] + 3] = [-0.005, 0, 0.01]                            # feeding.py:162
+    xf[X_['HEAD_RANGE']] = np.deg2rad(30.0)                                              # feeding.py:125
+    xi[X_['IK_ITERS']], xf[X_['IK_DAMP']], xf[X_['IK_MAXSTEP']], xf[X_['IK_TOL']] = 200, 0.05, 0.5, 1e-4   # host/kin.py (not Bullet's IK)
+    xf[X_['IK_THRESH']], xi[X_['IK_RESTARTS']], xi[X_['IK_RANDLIM_FROM']] = 0.01, 1000, 10   # robot.py:84-97
+    xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5                                    # env.py:120
+    xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(20.0)   # human.py:85-90
+    xi[X_['BOWL_BODY']] = 1
+    oj = X_['COUNT']
+    ob = oj + 2 * 42 * XJ['STRIDE']
+    od = ob + nhuman
+    xi[X_['OFF_JOINTS']], xi[X_['OFF_BODIES']], xi[X_['OFF_DYN']] = oj, ob, od
+    preset = {6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}                         # feeding.py:124
+    draw = {21: 0, 22: 1, 23: 2}                                                         # feeding.py:125
+    for g, gender in enumerate(('male', 'female')):
+        hm1, hm2 = HumanModel(gender, 1.0), HumanModel(gender, 0.5)
+        assert hm1.n == 42
+        for j in range(42):
+            b0 = oj + (g * 42 + j) * XJ['STRIDE']
+            xi[b0 + XJ['PARENT']] = hm1.parent[j]
+            xf[b0 + XJ['OFF']:b0 + XJ['OFF'] + 3] = hm1.offset[j]
+            xf[b0 + XJ['AXIS']:b0 + XJ['AXIS'] + 3] = hm1.axis[j]
+            xf[b0 + XJ['LOWER']], xf[b0 + XJ['UPPER']] = hm1.lower[j], hm1.upper[j]
+            scaled = hm1.lower[j] != hm2.lower[j] or hm1.upper[j] != hm2.upper[j]
+            xi[b0 + XJ['FLAGS']] = (1 if hm1.jtype[j] == 'r' else 0) | (2 if scaled else 0)
+            xf[b0 + XJ['PRESET']] = np.deg2rad(preset.get(j, 0.0))
+            xi[b0 + XJ['DRAW']] = draw.get(j, -1)
+    xi[ob:ob + nhuman] = human_bodies
+    xi[od:od + nhdof] = hd
     for k, c in enumerate(sc.colliders):
         base = off['COLL'] + k * C['STRIDE']
         i[base + C['BODY']] = c['body']

@@ -15,12 +15,18 @@ from .shard import pool_indices
 SETTLE_STEPS = 25   # feeding.py:178-179
 
 
-def build_reset_pool(blob, pool_size, seed, device=0, impairment='random'):
-    """pool_size post-reset states: host-side sampling + IK (host/reset.py), then the 25 settle
-    steps of feeding.py:178-179 on the device.  Returns a float32 (pool_size, state_words) array."""
-    states, _ = make_states(blob, pool_size, seed=seed, impairment=impairment)
+def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device'):
+    """pool_size post-reset states: FeedingEnv.reset's sampling (sampler 'device': agx_sample_reset on the GPU;
+    'host': the numpy path of host/reset.py), then the 25 settle steps of feeding.py:178-179 on the device.
+    Returns a float32 (pool_size, state_words) array."""
     st = Stepper(blob, pool_size, device)
-    st.set_state(states)
+    if sampler == 'device':
+        st.sample_reset(seed, impairment=impairment)
+    elif sampler == 'host':
+        states, _ = make_states(blob, pool_size, seed=seed, impairment=impairment)
+        st.set_state(states)
+    else:
+        raise ValueError("sampler must be 'device' or 'host'")
     st.settle(SETTLE_STEPS)
     st.synchronize()
     out = st.get_state()
@@ -29,11 +35,20 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random'):
 
 
 class FeedingJacoVecEnv:
-    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True):
+    """reset modes (all sampled and settled on the GPU unless 'host'):
+      'pool'    -- a fixed pool of pool_size post-reset states generated once; done envs draw from it
+                   (BASELINE config 2: "auto-reset from pool", SURVEY 8d);
+      'device'  -- every episode of every env starts from a NEWLY sampled state, as in the reference where each
+                   reset() redraws the human, the IK start pose, the bowl ... (feeding.py:114-182); the generator
+                   runs when the lock-stepped batch reaches the end of its 200-step episode;
+      'host'    -- 'pool' with the numpy sampler (host/reset.py)."""
+
+    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool'):
+        assert reset in ('pool', 'device', 'host')
         self.blob = blob or ModelBlob.load('feeding_jaco')
         self.n_envs, self.device_index, self.seed = n_envs, device, seed
         self.device = torch.device('cuda', device)
-        self.pool_size, self.impairment, self.auto_reset = pool_size, impairment, auto_reset
+        self.pool_size, self.impairment, self.auto_reset, self.reset_mode = pool_size, impairment, auto_reset, reset
         self.stepper = Stepper(self.blob, n_envs, device)
         self.act_dim, self.obs_dim = self.blob.act_dim, self.blob.obs_dim
         self.obs = torch.zeros((n_envs, self.obs_dim), dtype=torch.float32, device=self.device)
@@ -41,28 +56,54 @@ class FeedingJacoVecEnv:
         self.done = torch.zeros(n_envs, dtype=torch.uint8, device=self.device)
         self.info = torch.zeros((n_envs, 8), dtype=torch.float32, device=self.device)
         self.pool = None
+        self.generator = Stepper(self.blob, n_envs, device) if reset == 'device' else None
+        self.episode_len = int(self.blob.task_f('EPISODE_LEN'))
+        self.env_offset, self._t, self._episode = 0, 0, 0
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _generate(self, s):
+        """fresh post-reset states for the whole batch in the generator handle: env i of episode e is a function of
+        (seed, e, env_offset + i) only, i.e. independent of the number of GPUs the batch is spread over"""
+        g = self.generator
+        g.sample_reset(self.seed + (self._episode << 32) + self.env_offset, impairment=self.impairment, stream=s)
+        g.settle(SETTLE_STEPS, s)
+        self._episode += 1
+
     def reset(self, env_offset=0):
         """env_offset: global index of this shard's first env (multi-GPU sharding keeps the
         env -> initial state mapping independent of the GPU count)."""
-        if self.pool is None:
-            self.pool_host = build_reset_pool(self.blob, self.pool_size, self.seed, self.device_index, self.impairment)
-            self.pool = torch.from_numpy(self.pool_host).to(self.device)
-        idx = pool_indices(env_offset, self.n_envs, self.pool_size)
-        self.stepper.set_state(self.pool_host[idx])
-        self.stepper.observe_dev(self.obs, self._stream())
+        self.env_offset, self._t = env_offset, 0
+        s = self._stream()
+        if self.reset_mode == 'device':
+            self._generate(s)
+            self.stepper.synchronize(s)
+            self.stepper.set_state(self.generator.get_state())
+        else:
+            if self.pool is None:
+                self.pool_host = build_reset_pool(self.blob, self.pool_size, self.seed, self.device_index, self.impairment,
+                                                  sampler='host' if self.reset_mode == 'host' else 'device')
+                self.pool = torch.from_numpy(self.pool_host).to(self.device)
+            idx = pool_indices(env_offset, self.n_envs, self.pool_size)
+            self.stepper.set_state(self.pool_host[idx])
+        self.stepper.observe_dev(self.obs, s)
         return self.obs
 
     def step(self, actions):
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.shape == (self.n_envs, self.act_dim) and actions.is_contiguous()
         s = self._stream()
         self.stepper.step_dev(actions, self.obs, self.reward, self.done, self.info, s)
+        self._t += 1
         if self.auto_reset:
-            self.stepper.reset_done(self.pool, self.pool_size, self.done, s)
+            if self.reset_mode != 'device':
+                self.stepper.reset_done(self.pool, self.pool_size, self.done, s)
+            elif self._t % self.episode_len == 0:       # lock-stepped batch: every env is done (feeding.py:37)
+                self._generate(s)
+                self.stepper.reset_done(self.generator.state_dev(), self.n_envs, self.done, s)
         return self.obs, self.reward, self.done, self.info
 
     def close(self):
         self.stepper.close()
+        if self.generator is not None:
+            self.generator.close()

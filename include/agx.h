@@ -14,6 +14,10 @@
  *                     (feeding.py:85-112), get_food_rewards (feeding.py:50-83), human_preferences
  *                     (env.py:237-274), reward / done / info (feeding.py:25-37).
  *   agx_observe       the `return self._get_obs()` of reset() (feeding.py:182).
+ *   agx_sample_reset  FeedingEnv.reset() up to its settle loop (feeding.py:114-177) for every env, on the device:
+ *                     Human.init draws (agents/human.py:72-92), the posed human (feeding.py:124-126), the mouth
+ *                     target (feeding.py:184-196), init_robot_pose -> Robot.ik_random_restarts (env.py:276-310,
+ *                     agents/robot.py:84-121), tool / bowl / food placement (feeding.py:143-166).
  *   agx_reset_done    gym's TimeLimit/auto-reset on done (assistive_gym/__init__.py:11), drawing
  *                     the new post-reset state from a caller-provided pool.
  *
@@ -65,6 +69,14 @@ int agx_debug_words(void);
 int agx_step_timed(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
                    uint8_t* done_dev, float* info_dev, void* stream, float* ms3, int* launches3);
 int agx_observe(agx_handle h, float* obs_dev, void* stream);
+/* Overwrites the state record of EVERY env of the handle with a freshly sampled pre-settle reset state; env i
+ * is a pure function of (seed + i) (counter-based Philox4x32-10 draws, so the result does not depend on
+ * how envs are spread over handles or GPUs).  impairment_mode: -1 = random over none/limits/weakness/tremor
+ * (human.py:80), -2 = random without tremor, 0..3 = fixed; gender_mode: -1 random, 0 male, 1 female.
+ * ik_info_dev (may be NULL): [n_envs][4] float = {IK met the thresholds, restarts used, position error,
+ * impairment drawn}.  Follow with agx_settle(h, 25, stream) (feeding.py:178-179) and agx_observe.
+ * Also zeroes the handle's episode counters. */
+int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream);
 /* envs with done != 0 get a fresh state from pool_dev ([pool_n][state_words]); the pool entry is
  * (env_index + 977 * episode_count) mod pool_n, so results do not depend on GPU placement */
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream);

@@ -1,0 +1,307 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy float64 restatement of the device-side reset generator
+(assistive_gym_amd/csrc/agx_reset.h).  Only tests/ may import this file; the product never does.
+
+What it restates, in the order of FeedingEnv.reset (assistive_gym/envs/feeding.py:114-182):
+  plane friction U(0.025, 0.5)                         envs/env.py:120
+  gender, impairment, limit scale, strength, tremors   envs/agents/human.py:72-92
+  human pose: presets + head angles U(-30, 30) deg     feeding.py:124-125, human.py:104-127 (clamped to the limits,
+                                                       agents/agent.py:240-250), tree of human_creation.py:188-278
+  mouth target                                         feeding.py:184-196
+  end-effector start position + IK with random restarts  feeding.py:139, env.py:276-310, robot.py:84-121
+  gripper, tool in the hand, bowl offset, food grid    feeding.py:143-166, tool.py:49-62, furniture.py:32-34
+
+PARITY UNPINNED with respect to PyBullet: the IK is this repository's damped least squares (Bullet's
+calculateInverseKinematics is not reproducible) and the random stream is a counter-based
+Philox4x32-10 instead of numpy's MT19937 (the reference's draw COUNT depends on Bullet's IK results), so
+this file pins the DEVICE KERNEL to an independent restatement, not to the reference's seeds.
+
+Random numbers: u(stream, idx) = Philox4x32-10(counter = (idx, stream, 0, 0), key = 64-bit env seed), first two
+output words -> 53-bit double in [0, 1).  Stream 0 holds the scalar draws of one reset (slots below), stream
+1 + r the draws of IK restart r.  Every draw has a fixed slot, so restarts can be evaluated in any order
+(the device evaluates 64 at a time, one per lane) and "the first successful restart" stays well defined.
+"""
+import numpy as np
+
+M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+MASK = 0xFFFFFFFF
+# stream 0 slots
+S_FRICTION, S_GENDER, S_IMPAIRMENT, S_LIMIT, S_STRENGTH, S_HEAD, S_EE, S_BOWL, S_TREMOR = 0, 1, 2, 3, 4, 8, 12, 16, 32
+# restart stream slots (+ DoF index)
+R_REST, R_LO, R_HI = 0, 16, 32
+IMPAIRMENTS = ('none', 'limits', 'weakness', 'tremor')       # human.py:80
+MODE_RANDOM, MODE_NO_TREMOR = -1, -2
+
+# layout tables of the reset section (include/agx_blob.h AGX_X_*, AGX_XJ_*); restated here so that the
+# oracle does not depend on the product's Python package
+X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
+          HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
+          IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
+          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COUNT=48)
+XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
+H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK = 31, 13, 14, 18
+R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, STRIDE=32)
+F = dict(REFPOS=5, REFQUAT=8, STRIDE=16)
+T = dict(MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35)
+
+
+def philox4x32(counter, key):
+    c0, c1, c2, c3 = counter
+    k0, k1 = key
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & MASK, p1 & MASK, ((p0 >> 32) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return c0, c1, c2, c3
+
+
+def u01(seed, stream, idx):
+    c = philox4x32((idx & MASK, stream & MASK, 0, 0), (seed & MASK, (seed >> 32) & MASK))
+    return (((c[0] >> 5) << 26) | (c[1] >> 6)) / 9007199254740992.0
+
+
+# ---- float64 rigid transforms, (x, y, z, w) quaternions ------------------------------------------------
+def qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def qrot(q, v):
+    x, y, z, w = q / np.sqrt(np.dot(q, q))
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return Rm @ v
+
+
+def q_axis_angle(axis, angle):
+    n = np.sqrt(np.dot(axis, axis))
+    if n < 1e-12:
+        return np.array([0, 0, 0, 1.0])
+    s = np.sin(0.5 * angle) / n
+    return np.array([axis[0] * s, axis[1] * s, axis[2] * s, np.cos(0.5 * angle)])
+
+
+def compose(pa, qa, pb, qb):
+    return pa + qrot(qa, pb), qmul(qa, qb)
+
+
+class ResetOracle:
+    def __init__(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        self.f = w.view(np.float32).astype(np.float64)          # every constant is the blob's float32 value, widened
+        self.i = w.view(np.int32)
+        self.x0 = int(self.i[H_OFF_RESET])
+        self.nrobot, self.nhdof, self.ndof = int(self.i[32]), int(self.i[33]), int(self.i[3])
+        self.nfree, self.nhuman, self.nfood, self.food0, self.tool_body = int(self.i[4]), int(self.i[5]), int(self.i[9]), int(self.i[27]), int(self.i[28])
+        self.state_words = int(self.i[19])
+        self.S = {k: int(self.i[v]) for k, v in dict(Q=20, QD=21, QT=22, FREE=23, BASE=24, HUMAN=25, ENV=26, TREMOR=34).items()}
+
+    # -- accessors ---------------------------------------------------------------------------------
+    def xf(self, key, n=1):
+        o = self.x0 + X_[key]
+        return self.f[o:o + n].copy() if n > 1 else float(self.f[o])
+
+    def xi(self, key):
+        return int(self.i[self.x0 + X_[key]])
+
+    def jf(self, g, j, key, n=1):
+        o = self.x0 + self.xi('OFF_JOINTS') + (g * self.xi('NJOINT') + j) * XJ['STRIDE'] + XJ[key]
+        return self.f[o:o + n].copy() if n > 1 else float(self.f[o])
+
+    def ji(self, g, j, key):
+        return int(self.i[self.x0 + self.xi('OFF_JOINTS') + (g * self.xi('NJOINT') + j) * XJ['STRIDE'] + XJ[key]])
+
+    def rf(self, d, key, n=1):
+        o = int(self.i[H_OFF_ROBOT]) + d * R['STRIDE'] + R[key]
+        return self.f[o:o + n].copy() if n > 1 else float(self.f[o])
+
+    def ri(self, d, key):
+        return int(self.i[int(self.i[H_OFF_ROBOT]) + d * R['STRIDE'] + R[key]])
+
+    def tf(self, key, n=1):
+        o = int(self.i[H_OFF_TASK]) + T[key]
+        return self.f[o:o + n].copy() if n > 1 else float(self.f[o])
+
+    def ti(self, key):
+        return int(self.i[int(self.i[H_OFF_TASK]) + T[key]])
+
+    # -- human --------------------------------------------------------------------------------------
+    def joint_angle(self, g, j, ls, head):
+        """task preset (+ head draw), clamped to the joint limits (agent.py:240-250); fixed joints are 0"""
+        flags = self.ji(g, j, 'FLAGS')
+        if not flags & 1:
+            return 0.0
+        a = self.jf(g, j, 'PRESET')
+        k = self.ji(g, j, 'DRAW')
+        if k >= 0:
+            a = a + head[k]
+        s = ls if flags & 2 else 1.0
+        return min(max(a, self.jf(g, j, 'LOWER') * s), self.jf(g, j, 'UPPER') * s)
+
+    def link_pose(self, g, link, ls, head):
+        """world pose of a human link frame: walk from the link to the base, then the base transform"""
+        p, q = np.zeros(3), np.array([0, 0, 0, 1.0])
+        j = link
+        while j >= 0:
+            jq = q_axis_angle(self.jf(g, j, 'AXIS', 3), self.joint_angle(g, j, ls, head))
+            p, q = compose(self.jf(g, j, 'OFF', 3), jq, p, q)
+            j = self.ji(g, j, 'PARENT')
+        return compose(self.xf('HBASE_F' if g else 'HBASE_M', 3), np.array([0, 0, 0, 1.0]), p, q)
+
+    # -- robot --------------------------------------------------------------------------------------
+    def arm_fk(self, q):
+        narm = self.xi('NARM')
+        pp, pq = self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4)
+        pos, axw = [], []
+        for d in range(narm):
+            assert self.ri(d, 'PARENT') == d - 1 and self.ri(d, 'ACT') == d
+            jp, jq = compose(pp, pq, self.rf(d, 'TPOS', 3), self.rf(d, 'TQUAT', 4))
+            ax = self.rf(d, 'AXIS', 3)
+            pq = qmul(jq, q_axis_angle(ax, q[d]))
+            pp = jp
+            pos.append(jp)
+            axw.append(qrot(pq, ax))
+        assert self.ti('EE_LINK') == narm - 1
+        pe, oe = compose(pp, pq, self.tf('EE_POS', 3), self.tf('EE_QUAT', 4))
+        return pe, oe, pos, axw
+
+    def ik(self, q0, lo, hi, target_pos, target_quat):
+        narm = self.xi('NARM')
+        q = np.array(q0, dtype=np.float64)
+        lam2 = self.xf('IK_DAMP') ** 2
+        tol, maxstep = self.xf('IK_TOL'), self.xf('IK_MAXSTEP')
+        for _ in range(self.xi('IK_ITERS')):
+            pe, oe, pos, axw = self.arm_fk(q)
+            ep = target_pos - pe
+            qe = qmul(target_quat, np.array([-oe[0], -oe[1], -oe[2], oe[3]]))
+            if qe[3] < 0:
+                qe = -qe
+            er = 2.0 * qe[:3]
+            if np.sqrt(ep @ ep) < tol and np.sqrt(er @ er) < tol:
+                break
+            J = np.zeros((6, narm))
+            for d in range(narm):
+                J[:3, d] = np.cross(axw[d], pe - pos[d])
+                J[3:, d] = axw[d]
+            y = np.linalg.solve(J @ J.T + lam2 * np.eye(6), np.concatenate([ep, er]))
+            dq = J.T @ y
+            step = np.max(np.abs(dq))
+            if step > maxstep:
+                dq = dq * (maxstep / step)
+            q = np.minimum(np.maximum(q + dq, lo), hi)
+        return q
+
+    def restart(self, seed, r, target_pos, target_quat):
+        """IK restart r (robot.py:88-99): returns (q, position error, orientation error)"""
+        narm = self.xi('NARM')
+        lower = np.array([self.rf(d, 'LOWER') for d in range(narm)])
+        upper = np.array([self.rf(d, 'UPPER') for d in range(narm)])
+        ik_lo = np.where(lower < -1e9, -2 * np.pi, lower)                 # agent.py:223-231
+        ik_hi = np.where(upper > 1e9, 2 * np.pi, upper)
+        lo, hi = ik_lo, ik_hi
+        if r >= self.xi('IK_RANDLIM_FROM'):                               # robot.py:91 randomize_limits
+            lo = np.array([u01(seed, 1 + r, R_LO + d) for d in range(narm)]) * ik_lo
+            hi = np.array([u01(seed, 1 + r, R_HI + d) for d in range(narm)]) * ik_hi
+        rest = lo + (hi - lo) * np.array([u01(seed, 1 + r, R_REST + d) for d in range(narm)])     # agent.py:263
+        q = self.ik(rest, np.minimum(lo, hi), np.maximum(lo, hi), target_pos, target_quat)
+        q = np.minimum(np.maximum(q, lower), upper)                       # set_joint_angles(use_limits=True)
+        pe, oe, _, _ = self.arm_fk(q)
+        dpos = np.sqrt((target_pos - pe) @ (target_pos - pe))
+        dm, dp = target_quat - oe, target_quat + oe
+        return q, dpos, min(np.sqrt(dm @ dm), np.sqrt(dp @ dp))
+
+    # -- one reset ----------------------------------------------------------------------------------
+    def sample(self, seed, impairment_mode=MODE_RANDOM, gender_mode=-1, max_restarts=None):
+        """-> (state record float32[state_words], info dict)"""
+        u = lambda idx: u01(seed, 0, idx)
+        friction = self.xf('FRIC_LO') + (self.xf('FRIC_HI') - self.xf('FRIC_LO')) * u(S_FRICTION)
+        g = gender_mode if gender_mode >= 0 else (0 if u(S_GENDER) < 0.5 else 1)
+        if impairment_mode >= 0:
+            imp = impairment_mode
+        else:
+            nchoice = 4 if impairment_mode == MODE_RANDOM else 3
+            imp = min(int(u(S_IMPAIRMENT) * nchoice), nchoice - 1)
+        ls = 1.0 if imp != 1 else self.xf('LIMIT_LO') + (1.0 - self.xf('LIMIT_LO')) * u(S_LIMIT)
+        strength = 1.0 if imp != 2 else self.xf('STRENGTH_LO') + (1.0 - self.xf('STRENGTH_LO')) * u(S_STRENGTH)
+        tr = self.xf('TREMOR_RANGE')
+        tremors = np.array([(2 * u(S_TREMOR + k) - 1) * tr if imp == 3 else 0.0 for k in range(self.nhdof)])
+        hr = self.xf('HEAD_RANGE')
+        head = [(2 * u(S_HEAD + k) - 1) * hr for k in range(3)]
+
+        st = np.zeros(self.state_words, dtype=np.float32)
+        si = st.view(np.int32)
+        S = self.S
+        bodies = [int(self.i[self.x0 + self.xi('OFF_BODIES') + k]) for k in range(self.nhuman)]
+        dyn = [int(self.i[self.x0 + self.xi('OFF_DYN') + k]) for k in range(self.nhdof)]
+        for k, link in enumerate(bodies):
+            p, q = self.link_pose(g, link, ls, head)
+            st[S['HUMAN'] + 7 * k:S['HUMAN'] + 7 * k + 3], st[S['HUMAN'] + 7 * k + 3:S['HUMAN'] + 7 * k + 7] = p, q
+        hp, hq = self.link_pose(g, dyn[self.ti('HEAD_LINK') - self.nrobot], ls, head)
+        target, _ = compose(hp, hq, self.tf('MOUTH_F' if g else 'MOUTH_M', 3), np.array([0, 0, 0, 1.0]))
+
+        er = self.xf('EE_RANGE')
+        target_ee = self.xf('EE_TARGET', 3) + np.array([(2 * u(S_EE + k) - 1) * er for k in range(3)])
+        toc = self.xf('EE_QUAT', 4)
+        n_max = self.xi('IK_RESTARTS') if max_restarts is None else max_restarts
+        thr = self.xf('IK_THRESH')
+        best, best_d, ok, restarts = None, np.inf, False, 0
+        for r in range(n_max):
+            restarts = r + 1
+            q, dpos, dor = self.restart(seed, r, target_ee, toc)
+            if dpos < best_d:
+                best, best_d = q, dpos
+            if dpos < thr and dor < thr:                                   # robot.py:97
+                best, best_d, ok = q, dpos, True
+                break
+        nr, narm = self.nrobot, self.xi('NARM')
+        qfull = np.zeros(self.ndof)
+        qfull[:narm] = best
+        for d in range(narm, nr):                                          # gripper opened instantly, feeding.py:143-144
+            qfull[d] = min(max(self.rf(d, 'QT0'), self.rf(d, 'LOWER')), self.rf(d, 'UPPER'))
+        for k, j in enumerate(dyn):
+            qfull[nr + k] = self.joint_angle(g, j, ls, head)
+        st[S['Q']:S['Q'] + self.ndof] = qfull
+        st[S['QT']:S['QT'] + self.ndof] = qfull
+        st[S['TREMOR']:S['TREMOR'] + self.nhdof] = tremors
+        st[S['TREMOR'] + self.nhdof:S['TREMOR'] + 2 * self.nhdof] = qfull[nr:]
+        st[S['BASE']:S['BASE'] + 3], st[S['BASE'] + 3:S['BASE'] + 7] = self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4)
+        # tool in the hand (tool.py:49-62)
+        pe, oe, _, _ = self.arm_fk(best)
+        tp, tq = compose(pe, oe, self.tf('TOOL_POS', 3), self.tf('TOOL_QUAT', 4))
+        fr = lambda b: S['FREE'] + 13 * b
+        for b in range(self.nfree):
+            st[fr(b) + 6] = 1.0
+        st[fr(self.tool_body):fr(self.tool_body) + 3], st[fr(self.tool_body) + 3:fr(self.tool_body) + 7] = tp, tq
+        # bowl (furniture.py:32-34): base frame -> COM frame
+        bb = self.xi('BOWL_BODY')
+        br = self.xf('BOWL_RANGE')
+        bowl = self.xf('BOWL_POS', 3) + np.array([(2 * u(S_BOWL) - 1) * br, (2 * u(S_BOWL + 1) - 1) * br, 0.0])
+        fo = int(self.i[H_OFF_FREE]) + bb * F['STRIDE']
+        refp, refq = self.f[fo + F['REFPOS']:fo + F['REFPOS'] + 3], self.f[fo + F['REFQUAT']:fo + F['REFQUAT'] + 4]
+        qi = np.array([-refq[0], -refq[1], -refq[2], refq[3]])
+        cp, cq = compose(bowl, np.array([0, 0, 0, 1.0]), -qrot(qi, refp), qi)
+        st[fr(bb):fr(bb) + 3], st[fr(bb) + 3:fr(bb) + 7] = cp, cq
+        # food grid above the spoon (feeding.py:158-166)
+        rf_, fo3 = self.xf('FOOD_R'), self.xf('FOOD_OFF', 3)
+        k = 0
+        for a in range(2):
+            for b in range(2):
+                for c in range(2):
+                    st[fr(self.food0 + k):fr(self.food0 + k) + 3] = np.array([a * 2 * rf_, b * 2 * rf_, c * 2 * rf_]) + fo3 + tp
+                    k += 1
+        e = S['ENV']
+        st[e + 0] = friction
+        si[e + 1] = g
+        st[e + 2:e + 5] = target
+        si[e + 5] = si[e + 6] = (1 << self.nfood) - 1
+        si[e + 7] = si[e + 8] = 0
+        si[e + 9] = (seed * 2654435761 + 12345) & 0x7FFFFFFF
+        si[e + 10] = (seed ^ 0x5bd1e995) & 0x7FFFFFFF
+        si[e + 11] = self.nfood
+        coop = self.ti('COOP') == 1
+        si[e + 12] = 0 if (imp == 3 or coop) else (((1 << self.nhdof) - 1) << nr)     # human.py:104-110
+        st[e + 13] = ls
+        return st, dict(gender=g, impairment=imp, limit_scale=ls, strength=strength, tremors=tremors, ik_ok=ok,
+                        ik_restarts=restarts, ik_pos_err=best_d, target_ee=target_ee, head=head)

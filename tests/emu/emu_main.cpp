@@ -59,4 +59,8 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
   if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
   return rc;
 }
+extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed, int impairment_mode, int gender_mode, float* info4) {
+  static float lds[64];
+  return run_wave(lds, 64, [&](int lane) { agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane); });
+}
 extern "C" int agx_emu_lds_bytes() { return agx::LDS_BYTES; }

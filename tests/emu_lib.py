@@ -57,5 +57,13 @@ class Emu:
     def settle(self, state, n):
         self._run(state, None, 1, n)
 
+    def sample(self, seed, impairment_mode=-1, gender_mode=-1):
+        """device-side reset generator (csrc/agx_reset.h) for one env -> (state record, info[4])"""
+        st = np.zeros(self.blob.state_words, dtype=np.float32)
+        info = np.zeros(4, dtype=np.float32)
+        rc = self.L.agx_emu_sample(_p(self.words), _p(st), C.c_uint64(seed), C.c_int(impairment_mode), C.c_int(gender_mode), _p(info))
+        assert rc == 0, 'wave emulator reported divergent control flow'
+        return st, info
+
     def observe(self, state):
         return self._run(state, None, 2, 0)[0]

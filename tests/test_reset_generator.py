@@ -1,0 +1,243 @@
+"""Device-side reset generator (csrc/agx_reset.h: FeedingEnv.reset's sampling, feeding.py:114-177, with
+Robot.ik_random_restarts, robot.py:84-121, 64 restarts per round) against its numpy float64 restatement
+(oracle/reset_oracle.py).  CPU part: the product kernel source on the wave emulator; GPU part: agx_sample_reset
+through the C ABI.  Both sides evaluate in float64 from the same blob constants and the same Philox4x32-10
+slots, so the float32 state records must agree to rounding (1e-6) INCLUDING the accept / reject decisions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import reset_oracle as ro                      # noqa: E402  (test infrastructure)
+from assistive_gym_amd.blob import ModelBlob   # noqa: E402
+from assistive_gym_amd.model import compiler as L   # noqa: E402
+from assistive_gym_amd.model.human import HumanModel   # noqa: E402
+
+TOL = 1e-6
+
+
+def with_reset_params(blob, **kw):
+    """copy of the blob with entries of the reset section changed (ints for IK_ITERS / IK_RESTARTS / IK_RANDLIM_FROM)"""
+    w = blob.words.copy()
+    for k, v in kw.items():
+        o = blob.h['OFF_RESET'] + L.X_[k]
+        if k in ('IK_ITERS', 'IK_RESTARTS', 'IK_RANDLIM_FROM'):
+            w.view(np.int32)[o] = v
+        else:
+            w.view(np.float32)[o] = v
+    return ModelBlob(w, blob.meta)
+
+
+def assert_same_record(blob, a, b, what=''):
+    e = blob.h['S_ENV']
+    ints = [e + L.E[k] for k in ('GENDER', 'FOOD_ALIVE', 'FOOD_ACTIVE', 'ITERATION', 'TASK_SUCCESS', 'RNG', 'TOTAL_FOOD', 'FROZEN')] + [e + L.E['RNG'] + 1]
+    ai, bi = a.view(np.int32), b.view(np.int32)
+    for k in ints:
+        assert ai[k] == bi[k], (what, 'int word', k - e, ai[k], bi[k])
+    fl = np.ones(len(a), bool); fl[ints] = False
+    d = np.abs(a[fl] - b[fl])
+    assert np.all(np.isfinite(a)) and d.max() <= TOL, (what, 'max deviation %.3e at word %d' % (d.max(), np.flatnonzero(fl)[d.argmax()]))
+
+
+def test_philox_known_answers():
+    # Random123 known-answer vectors of philox4x32-10
+    assert ro.philox4x32((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert ro.philox4x32((0xffffffff,) * 4, (0xffffffff,) * 2) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert ro.philox4x32((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+    u = [ro.u01(12345, 0, k) for k in range(2000)]
+    assert 0 <= min(u) and max(u) < 1 and abs(np.mean(u) - 0.5) < 0.02
+
+
+def test_oracle_human_pose_matches_the_compile_time_model(blob):
+    """independent check of the oracle's link walk + the blob's joint table against model/human.py's root-down FK"""
+    o = ro.ResetOracle(blob.words)
+    D = np.deg2rad
+    for g, gender in enumerate(('male', 'female')):
+        for ls in (1.0, 0.6):
+            hm = HumanModel(gender, ls)
+            head = [D(12.0), D(-25.0), D(29.0)]
+            q = np.zeros(hm.n)
+            for j, a in ((6, -90), (16, -90), (28, -90), (31, 80), (35, -90), (38, 80)):      # feeding.py:124
+                q[j] = D(a)
+            q[21], q[22], q[23] = head
+            q = hm.clamp(q)
+            base = np.array([0, 0.03, 0.89 if gender == 'male' else 0.86])
+            pos, quat = hm.fk(base, np.array([0, 0, 0, 1.0]), q)
+            for link in (2, 9, 19, 23, 27, 34, 41):
+                p, qq = o.link_pose(g, link, ls, head)
+                np.testing.assert_allclose(p, pos[link], atol=2e-7)
+                assert min(np.abs(qq - quat[link]).max(), np.abs(qq + quat[link]).max()) < 2e-7
+            assert o.joint_angle(g, 6, ls, head) == pytest.approx(max(D(-90), D(-128) * ls), abs=1e-7)     # elbow preset vs scaled limit
+
+
+@pytest.fixture(scope='module')
+def emu(blob):
+    from emu_lib import Emu
+    return Emu(blob)
+
+
+@pytest.mark.parametrize('seed', [1001, 1002, 1003, 77, (1 << 40) + 5, (1 << 63) + 12345])
+def test_emulated_kernel_matches_oracle(blob, emu, seed):
+    o = ro.ResetOracle(blob.words)
+    st, info = o.sample(seed)
+    se, ie = emu.sample(seed)
+    assert_same_record(blob, st, se, 'seed %d' % seed)
+    assert bool(ie[0]) == info['ik_ok'] and int(ie[1]) == info['ik_restarts'] and int(ie[3]) == info['impairment']
+    assert ie[2] == pytest.approx(info['ik_pos_err'], rel=1e-4)
+    assert info['ik_ok'] and info['ik_pos_err'] < 0.01
+
+
+@pytest.mark.parametrize('impairment,gender', [(0, 0), (1, 1), (2, 0), (3, 1), (-2, -1)])
+def test_fixed_modes(blob, emu, impairment, gender):
+    o = ro.ResetOracle(blob.words)
+    for seed in (31, 32, 33):
+        st, info = o.sample(seed, impairment, gender)
+        se, ie = emu.sample(seed, impairment, gender)
+        assert_same_record(blob, st, se)
+        v = blob.view(se[None])
+        if gender >= 0:
+            assert v['gender'][0] == gender
+        if impairment >= 0:
+            assert int(ie[3]) == impairment
+        else:
+            assert int(ie[3]) in (0, 1, 2)
+        nr = blob.nrobot
+        if int(ie[3]) == 3:       # tremor: head joints dynamic, amplitudes within +-20 deg (human.py:89-90, :108)
+            assert v['frozen'][0] == 0 and np.all(np.abs(v['tremor'][0]) <= np.deg2rad(20) + 1e-6) and np.any(v['tremor'][0] != 0)
+        else:
+            assert v['frozen'][0] == ((1 << blob.nhdof) - 1) << nr and np.all(v['tremor'][0] == 0)
+        assert (v['limit_scale'][0] < 1.0) == (int(ie[3]) == 1)
+        np.testing.assert_array_equal(v['tremor_target'][0], v['q'][0, nr:])
+
+
+def test_restart_rounds_and_randomised_limits(blob):
+    """IK crippled to 3 iterations: most restarts miss the thresholds, so the first success lies beyond the
+    first lanes -- often beyond restart 10 (randomised limits, robot.py:91) or in a later 64-restart round."""
+    from emu_lib import Emu
+    hard = with_reset_params(blob, IK_ITERS=3, IK_RESTARTS=200, IK_THRESH=0.05)
+    o, e = ro.ResetOracle(hard.words), Emu(hard)
+    seen = []
+    for seed in range(400, 412):
+        st, info = o.sample(seed)
+        se, ie = e.sample(seed)
+        assert_same_record(hard, st, se, 'seed %d' % seed)
+        assert bool(ie[0]) == info['ik_ok'] and int(ie[1]) == info['ik_restarts']
+        seen.append(info['ik_restarts'] if info['ik_ok'] else -1)
+    assert any(r > 10 for r in seen), seen
+    assert any(r > 64 or r == -1 for r in seen), seen
+
+
+def test_no_restart_succeeds_keeps_the_best(blob):
+    """thresholds nobody meets: the pose with the smallest position error over ALL restarts is kept (robot.py:100-103)"""
+    from emu_lib import Emu
+    hard = with_reset_params(blob, IK_ITERS=2, IK_RESTARTS=70, IK_THRESH=1e-9)
+    o, e = ro.ResetOracle(hard.words), Emu(hard)
+    for seed in (501, 502, 503):
+        st, info = o.sample(seed)
+        se, ie = e.sample(seed)
+        assert not info['ik_ok'] and not bool(ie[0]) and int(ie[1]) == 70
+        assert_same_record(hard, st, se)
+        assert ie[2] == pytest.approx(info['ik_pos_err'], rel=1e-5)
+
+
+def test_sampled_world_is_consistent(blob, emu, oracle):
+    """the sampled record is a valid world: spoon in the hand, food above the spoon, bowl on the table, mouth
+    target in front of the head; it survives the settle steps and a policy step (feeding.py:178-182)"""
+    for seed in (9001, 9002):
+        st, ie = emu.sample(seed)
+        v = blob.view(st[None])
+        assert 0.025 <= v['plane_friction'][0] <= 0.5
+        tool = v['free'][0, blob.h['TOOL_BODY'], :3]
+        ee, _ = oracle.ee_pose(st)
+        assert np.linalg.norm(np.asarray(ee) - tool) < 0.12                    # tool offset from the end effector (jaco.py:26)
+        assert np.linalg.norm(np.asarray(ee) - (np.array([-0.15, -0.65, 1.15]))) < 0.05 * np.sqrt(3) + 0.011
+        food = v['free'][0, blob.h['FOOD0']:blob.h['FOOD0'] + blob.nfood, :3]
+        assert np.all(food[:, 2] > tool[2]) and np.all(np.abs(food - tool).max(axis=1) < 0.03)
+        bowl = v['free'][0, 1, :3]
+        assert abs(bowl[0] + 0.15) <= 0.08 and abs(bowl[1] + 0.65) <= 0.08
+        head = v['human'][0]                                                   # static bodies; the target sits near the head height
+        assert 0.9 < v['target'][0, 2] < 1.4 and np.all(np.isfinite(head))
+        s1 = st.copy()
+        emu.settle(s1, 25)
+        obs, rew, done, info, _ = emu.step(s1, np.zeros(blob.act_dim, np.float32))
+        assert np.all(np.isfinite(obs)) and np.isfinite(rew) and not done
+        assert int(info[1]) == 0 and blob.view(s1[None])['food_alive'][0] == (1 << blob.nfood) - 1     # nothing spilled while settling
+
+
+def test_draw_statistics(blob, emu):
+    """marginals of the draws over 240 seeds (human.py:76-90, env.py:120, feeding.py:125)"""
+    g, imp, fr, ls = [], [], [], []
+    for seed in range(20000, 20240):
+        st, ie = emu.sample(seed)
+        v = blob.view(st[None])
+        g.append(int(v['gender'][0])); imp.append(int(ie[3])); fr.append(float(v['plane_friction'][0])); ls.append(float(v['limit_scale'][0]))
+        assert bool(ie[0])
+    assert 0.35 < np.mean(g) < 0.65
+    counts = np.bincount(imp, minlength=4)
+    assert counts.min() > 35, counts
+    assert 0.025 <= min(fr) and max(fr) <= 0.5 and 0.2 < np.mean(fr) < 0.32
+    scaled = [x for x, i in zip(ls, imp) if i == 1]
+    assert all(0.5 <= x <= 1.0 for x in scaled) and all(x == 1.0 for x, i in zip(ls, imp) if i != 1)
+
+
+# ---- GPU: the same comparison through the C ABI ---------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_sample_reset_matches_oracle(blob):
+    import torch
+    from assistive_gym_amd.libagx import Stepper
+    n, seed0 = 48, (1 << 33) + 4242
+    st = Stepper(blob, n)
+    info = torch.zeros((n, 4), dtype=torch.float32, device='cuda')
+    st.sample_reset(seed0, ik_info=info)
+    st.synchronize()
+    got, gi = st.get_state(), info.cpu().numpy()
+    o = ro.ResetOracle(blob.words)
+    for i in list(range(12)) + [n - 1]:
+        want, winfo = o.sample(seed0 + i)
+        assert_same_record(blob, want, got[i], 'env %d' % i)
+        assert bool(gi[i, 0]) == winfo['ik_ok'] and int(gi[i, 1]) == winfo['ik_restarts'] and int(gi[i, 3]) == winfo['impairment']
+    # env i depends on seed + i only: a differently sized handle with a shifted seed reproduces the records
+    st2 = Stepper(blob, 8)
+    st2.sample_reset(seed0 + 20)
+    st2.synchronize()
+    np.testing.assert_array_equal(st2.get_state(), got[20:28])
+    st.close(); st2.close()
+
+
+@pytest.mark.gpu
+def test_gpu_hard_ik_matches_oracle(blob):
+    from assistive_gym_amd.libagx import Stepper
+    hard = with_reset_params(blob, IK_ITERS=3, IK_RESTARTS=200, IK_THRESH=0.05)
+    st = Stepper(hard, 12)
+    st.sample_reset(400)
+    st.synchronize()
+    got = st.get_state()
+    o = ro.ResetOracle(hard.words)
+    for i in range(12):
+        want, _ = o.sample(400 + i)
+        assert_same_record(hard, want, got[i], 'env %d' % i)
+    st.close()
+
+
+@pytest.mark.gpu
+def test_gpu_fresh_resets_every_episode(blob):
+    """FeedingJacoVecEnv(reset='device'): every episode starts from newly sampled + settled states"""
+    import torch
+    from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+    env = FeedingJacoVecEnv(64, seed=7, reset='device')
+    obs0 = env.reset().clone()
+    assert torch.isfinite(obs0).all()
+    first = env.stepper.get_state().copy()
+    a = torch.zeros((64, env.act_dim), device='cuda')
+    for k in range(200):
+        obs, rew, done, info = env.step(a)
+    assert bool(done.all())
+    second = env.stepper.get_state()
+    v1, v2 = blob.view(first), blob.view(second)
+    assert np.all(v2['iteration'] == 0) and np.all(v2['food_alive'] == (1 << blob.nfood) - 1)
+    assert np.mean(np.abs(v1['plane_friction'] - v2['plane_friction']) > 1e-4) > 0.9      # new draws, not the old episode's
+    assert torch.isfinite(obs).all()
+    env.close()
