@@ -39,7 +39,7 @@ def assert_same_record(blob, a, b, what=''):
         assert ai[k] == bi[k], (what, 'int word', k - e, ai[k], bi[k])
     fl = np.ones(len(a), bool); fl[ints] = False
     d = np.abs(a[fl] - b[fl])
-    assert np.all(np.isfinite(a)) and d.max() <= TOL, (what, 'max deviation %.3e at word %d' % (d.max(), np.flatnonzero(fl)[d.argmax()]))
+    assert np.all(np.isfinite(a[fl])) and np.all(np.isfinite(b[fl])) and d.max() <= TOL, (what, 'max deviation %.3e at word %d' % (d.max(), np.flatnonzero(fl)[d.argmax()]))
 
 
 def test_philox_known_answers():
