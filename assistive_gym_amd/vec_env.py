@@ -59,6 +59,8 @@ class FeedingJacoVecEnv:
         self.generator = Stepper(self.blob, n_envs, device) if reset == 'device' else None
         self.episode_len = int(self.blob.task_f('EPISODE_LEN'))
         self.env_offset, self._t, self._episode = 0, 0, 0
+        self._side, self._ahead = None, None
+        self.terminal_obs = None
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -71,15 +73,27 @@ class FeedingJacoVecEnv:
         g.settle(SETTLE_STEPS, s)
         self._episode += 1
 
+    def _generate_ahead(self):
+        """the NEXT episode's states, on a side stream: the generator's kernels (1 sample + 25 substeps) fill the
+        gaps of the 200 steps of the running episode instead of stalling the batch at the episode boundary"""
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))      # the previous batch has been handed over
+        self._generate(self._side.cuda_stream)
+        self._ahead = self._side.record_event()
+
     def reset(self, env_offset=0):
         """env_offset: global index of this shard's first env (multi-GPU sharding keeps the
         env -> initial state mapping independent of the GPU count)."""
         self.env_offset, self._t = env_offset, 0
         s = self._stream()
         if self.reset_mode == 'device':
+            if self._ahead is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._ahead)
             self._generate(s)
             self.stepper.synchronize(s)
             self.stepper.set_state(self.generator.get_state())
+            self._generate_ahead()
         else:
             if self.pool is None:
                 self.pool_host = build_reset_pool(self.blob, self.pool_size, self.seed, self.device_index, self.impairment,
@@ -96,11 +110,18 @@ class FeedingJacoVecEnv:
         self.stepper.step_dev(actions, self.obs, self.reward, self.done, self.info, s)
         self._t += 1
         if self.auto_reset:
+            boundary = self._t % self.episode_len == 0      # lock-stepped batch: every env is done (feeding.py:37)
             if self.reset_mode != 'device':
                 self.stepper.reset_done(self.pool, self.pool_size, self.done, s)
-            elif self._t % self.episode_len == 0:       # lock-stepped batch: every env is done (feeding.py:37)
-                self._generate(s)
+            elif boundary:
+                torch.cuda.current_stream(self.device).wait_event(self._ahead)
                 self.stepper.reset_done(self.generator.state_dev(), self.n_envs, self.done, s)
+                self._generate_ahead()
+            if boundary:
+                # vector-env convention: the observation returned with done is the first one of the new episode
+                # (`return self._get_obs()` of reset(), feeding.py:182); the last one of the old episode is kept aside
+                self.terminal_obs = self.obs.clone()
+                self.stepper.observe_dev(self.obs, s)
         return self.obs, self.reward, self.done, self.info
 
     def close(self):

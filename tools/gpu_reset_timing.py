@@ -21,18 +21,29 @@ torch.cuda.synchronize()
 out['sample_ms'] = ev[0].elapsed_time(ev[1]); out['settle25_ms'] = ev[1].elapsed_time(ev[2])
 out['ik_ok_frac'] = float(info[:, 0].mean()); out['ik_restarts_mean'] = float(info[:, 1].mean()); out['ik_restarts_max'] = float(info[:, 1].max())
 st.close()
-for mode in ('pool', 'device'):
+for mode in ('pool', 'device', 'pool', 'device'):
     env = FeedingJacoVecEnv(n, seed=1001, reset=mode)
     env.reset()
     g = torch.Generator(device='cuda'); g.manual_seed(1)
     K = 600
     tape = torch.rand((50, n, 7), device='cuda', generator=g) * 2 - 1
     for k in range(50): env.step(tape[k % 50])
-    env._t = 0 if mode == 'device' else env._t
     torch.cuda.synchronize(); t0 = time.time()
     for k in range(K): env.step(tape[k % 50])
     torch.cuda.synchronize(); dt = time.time() - t0
-    out['env_steps_per_s_' + mode] = n * K / dt
+    out.setdefault('env_steps_per_s_' + mode, []).append(n * K / dt)
     out['mean_reward_' + mode] = float(env.reward.mean())
     env.close()
+from assistive_gym_amd.rollout import GaussianMLPPolicy, collect, gae
+env = FeedingJacoVecEnv(n, seed=1001, reset='device')
+env.reset()
+pi = GaussianMLPPolicy(env.obs_dim, env.act_dim).to(env.device)
+collect(env, pi, 20)
+torch.cuda.synchronize(); t0 = time.time()
+T = 400
+buf = collect(env, pi, T)
+adv, ret = gae(buf['rewards'], buf['values'], buf['dones'])
+torch.cuda.synchronize(); dt = time.time() - t0
+out['rollout_env_steps_per_s_policy_in_loop_fresh_resets'] = n * T / dt
+env.close()
 print(json.dumps(out))
