@@ -23,19 +23,20 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 // build: kinematics, ABA, collision, constraint rows -> scratch.  Register- and LDS-heavy.
 extern "C" __global__ void __launch_bounds__(64, 2)
-agx_build_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int env0, int n_envs, int sw, int act_dim) {
+agx_build_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int env0, int n_envs, int sw, int act_dim,
+                 const uint8_t* __restrict__ active) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = env0 + blockIdx.x;
-  if (env >= n_envs) return;
+  if (env >= n_envs || (active && !active[env])) return;   // `active`: masked settle of agx_reset, null on the step path
   agx::env_build(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
                  debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
 }
 // solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
 extern "C" __global__ void __launch_bounds__(64, 4)
-agx_solve_kernel(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw) {
+agx_solve_kernel(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = env0 + blockIdx.x;
-  if (env >= n_envs) return;
+  if (env >= n_envs || (active && !active[env])) return;
   agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
 }
 // finish: forces, observation, food state machine, reward, done, info
@@ -69,10 +70,12 @@ agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* don
 
 // reset generator: FeedingEnv.reset's sampling incl. the IK restarts (64 per round, one per lane), float64
 extern "C" __global__ void __launch_bounds__(64)
-agx_sample_kernel(const uint32_t* __restrict__ blob, float* state, unsigned long long seed0, int impairment_mode, int gender_mode, float* info4, int n_envs, int sw) {
+agx_sample_kernel(const uint32_t* __restrict__ blob, float* state, unsigned long long seed0, const unsigned long long* __restrict__ seeds, const uint8_t* __restrict__ mask,
+                  int impairment_mode, int gender_mode, float* info4, int* episode, int n_envs, int sw) {
   const int env = blockIdx.x;
-  if (env >= n_envs) return;
-  const unsigned long long seed = seed0 + (unsigned long long)env;
+  if (env >= n_envs || (mask && !mask[env])) return;
+  const unsigned long long seed = seeds ? seeds[env] : seed0 + (unsigned long long)env;
+  if (threadIdx.x == 0) episode[env] = 0;
   agx::env_sample(blob, state + (size_t)env * sw, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4 ? info4 + (size_t)env * 4 : nullptr,
                   (int)threadIdx.x);
 }
@@ -102,6 +105,7 @@ struct agx_handle_s {
   int* episode_dev;
   int frame_skip;
   bool can_sample;      // the blob fits the compiled reset generator (agx_reset.h)
+  const uint8_t* active;// per-env mask honoured by the build / solve launches (agx_reset's masked settle), normally null
   // staging for the *_host convenience calls
   float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
   hipEvent_t ev0, ev1;
@@ -218,9 +222,9 @@ int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fa
 
 // one p.stepSimulation() for the environments [e0, e0+ne): build + solve
 static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st) {
-  hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim);
+  hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw);
+  hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -278,9 +282,9 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
     int e = 0;
     HIPCHK(hipEventRecord(h->kev[c][e++], st));
     for (int k = 0; k < h->frame_skip; k++) {
-      hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim);
+      hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
-      hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw);
+      hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
     }
     hipLaunchKernelGGL(agx_finish_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
@@ -307,15 +311,27 @@ int agx_observe(agx_handle h, float* obs, void* stream) {
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
-int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {
-  if (!h || impairment_mode < -2 || impairment_mode > 3 || gender_mode < -1 || gender_mode > 1) return fail(AGX_E_ARG, "agx_sample_reset: bad argument");
-  if (!h->can_sample) return fail(AGX_E_LIMIT, "agx_sample_reset: the reset generator needs a serial 7-DoF arm carrying the end effector");
+static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev, const uint8_t* mask_dev, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {
+  if (impairment_mode < -2 || impairment_mode > 3 || gender_mode < -1 || gender_mode > 1) return fail(AGX_E_ARG, "reset: bad impairment / gender mode");
+  if (!h->can_sample) return fail(AGX_E_LIMIT, "reset: the reset generator needs a serial 7-DoF arm carrying the end effector");
   HIPCHK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(agx_sample_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->blob_dev, h->state_dev, (unsigned long long)seed, impairment_mode,
-                     gender_mode, ik_info_dev, h->n_envs, h->sw);
+  hipLaunchKernelGGL(agx_sample_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->blob_dev, h->state_dev, (unsigned long long)seed,
+                     (const unsigned long long*)seeds_dev, mask_dev, impairment_mode, gender_mode, ik_info_dev, h->episode_dev, h->n_envs, h->sw);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(h->episode_dev, 0, (size_t)h->n_envs * 4, (hipStream_t)stream));
   return AGX_OK;
+}
+int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {
+  if (!h) return fail(AGX_E_ARG, "agx_sample_reset: null handle");
+  return launch_sample(h, seed, nullptr, nullptr, impairment_mode, gender_mode, ik_info_dev, stream);
+}
+int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, uint64_t seed, int impairment_mode, int gender_mode, int settle_substeps, void* stream) {
+  if (!h || settle_substeps < 0) return fail(AGX_E_ARG, "agx_reset: bad argument");
+  int rc = launch_sample(h, seed, seeds_dev, mask_dev, impairment_mode, gender_mode, nullptr, stream);
+  if (rc) return rc;
+  h->active = mask_dev;   // the settle substeps touch the masked environments only
+  rc = launch_chunked(h, settle_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
+  h->active = nullptr;
+  return rc;
 }
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {
   if (!h || !pool_dev || pool_n <= 0 || !done_dev) return fail(AGX_E_ARG, "agx_reset_done: bad argument");

@@ -13,7 +13,7 @@ _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
-           'agx_observe', 'agx_sample_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
+           'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest']
 
 
@@ -111,6 +111,12 @@ class Stepper:
         """device-side FeedingEnv.reset sampling of every env (env i from seed + i); follow with settle(25)"""
         check(self.L.agx_sample_reset(self.h, C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(self.IMPAIRMENT_MODES[impairment]),
                                       C.c_int(self.GENDER_MODES[gender]), _ptr(ik_info), C.c_void_p(stream)), 'agx_sample_reset')
+
+    def reset(self, mask=None, seeds=None, seed=0, impairment='random', gender='random', settle_substeps=25, stream=0):
+        """reset() of the envs selected by `mask` (uint8 device tensor, None = all): device-side sampling from
+        `seeds` (uint64/int64 device tensor) or seed + env index, then the settle substeps on those envs only"""
+        check(self.L.agx_reset(self.h, _ptr(mask), _ptr(seeds), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(self.IMPAIRMENT_MODES[impairment]),
+                               C.c_int(self.GENDER_MODES[gender]), C.c_int(settle_substeps), C.c_void_p(stream)), 'agx_reset')
 
     def reset_done(self, pool, pool_n, done, stream=0):
         check(self.L.agx_reset_done(self.h, _ptr(pool), C.c_int(pool_n), _ptr(done), C.c_void_p(stream)), 'agx_reset_done')

@@ -18,6 +18,8 @@
  *                     Human.init draws (agents/human.py:72-92), the posed human (feeding.py:124-126), the mouth
  *                     target (feeding.py:184-196), init_robot_pose -> Robot.ik_random_restarts (env.py:276-310,
  *                     agents/robot.py:84-121), tool / bowl / food placement (feeding.py:143-166).
+ *   agx_reset         the same followed by the settle loop, for the envs selected by a mask (a caller resetting
+ *                     the envs that are done), per-env seeds optional.
  *   agx_reset_done    gym's TimeLimit/auto-reset on done (assistive_gym/__init__.py:11), drawing
  *                     the new post-reset state from a caller-provided pool.
  *
@@ -77,6 +79,12 @@ int agx_observe(agx_handle h, float* obs_dev, void* stream);
  * impairment drawn}.  Follow with agx_settle(h, 25, stream) (feeding.py:178-179) and agx_observe.
  * Also zeroes the handle's episode counters. */
 int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream);
+/* reset() of a SUBSET of the envs (gym semantics: the caller resets the envs that are done): envs with
+ * mask_dev[i] != 0 (NULL = all) are re-sampled as by agx_sample_reset -- from seeds_dev[i] if seeds_dev is
+ * given, else from seed + i -- and then run `settle_substeps` substeps (25 in feeding.py:178-179) while all
+ * other envs are left untouched.  Their episode counters restart at 0. */
+int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, uint64_t seed, int impairment_mode,
+              int gender_mode, int settle_substeps, void* stream);
 /* envs with done != 0 get a fresh state from pool_dev ([pool_n][state_words]); the pool entry is
  * (env_index + 977 * episode_count) mod pool_n, so results do not depend on GPU placement */
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream);

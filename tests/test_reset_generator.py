@@ -241,3 +241,42 @@ def test_gpu_fresh_resets_every_episode(blob):
     assert np.mean(np.abs(v1['plane_friction'] - v2['plane_friction']) > 1e-4) > 0.9      # new draws, not the old episode's
     assert torch.isfinite(obs).all()
     env.close()
+
+
+@pytest.mark.gpu
+def test_gpu_masked_reset_leaves_other_envs_alone(blob):
+    """agx_reset(mask, seeds): the selected envs are re-sampled from their own seeds and settled, bit-identical to
+    a whole-batch sample + settle of the same seeds; every other env keeps its state bit for bit"""
+    import torch
+    from assistive_gym_amd.libagx import Stepper
+    n = 96
+    st = Stepper(blob, n)
+    st.sample_reset(100)
+    st.settle(25)
+    a = torch.zeros((n, blob.act_dim), device='cuda')
+    obs = torch.zeros((n, blob.obs_dim), device='cuda'); rew = torch.zeros(n, device='cuda'); done = torch.zeros(n, dtype=torch.uint8, device='cuda')
+    for k in range(3):
+        st.step_dev(a, obs, rew, done)
+    st.synchronize()
+    before = st.get_state()
+    mask = torch.zeros(n, dtype=torch.uint8, device='cuda'); mask[5] = 1; mask[40:50] = 1; mask[95] = 1
+    seeds = torch.arange(n, dtype=torch.int64, device='cuda') * 7 + 123456789
+    st.reset(mask, seeds)
+    st.synchronize()
+    after = st.get_state()
+    m = mask.cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(after[~m], before[~m])
+    # reference: every env sampled from the same per-env seeds and settled as a whole batch
+    ref = Stepper(blob, n)
+    ref.reset(None, seeds)
+    ref.synchronize()
+    want = ref.get_state()
+    np.testing.assert_array_equal(after[m], want[m])
+    assert np.all(blob.view(after[m])['iteration'] == 0) and np.all(blob.view(after[~m])['iteration'] == 3)
+    o = ro.ResetOracle(blob.words)
+    pre, _ = o.sample(int(seeds[5]))
+    st2 = Stepper(blob, n)
+    st2.reset(mask, seeds, settle_substeps=0)
+    st2.synchronize()
+    assert_same_record(blob, pre, st2.get_state()[5], 'masked env 5, before settling')
+    st.close(); ref.close(); st2.close()
