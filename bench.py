@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--pool', type=int, default=256)
+    ap.add_argument('--reset', choices=['pool', 'device', 'host'], default='pool',
+                    help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -121,7 +123,7 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     n = args.envs_per_gpu
     blob = ModelBlob.load('feeding_jaco')
-    env = FeedingJacoVecEnv(n, device=local_rank, seed=1001, pool_size=args.pool)
+    env = FeedingJacoVecEnv(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset)
     env.reset(env_offset=rank * n)
     K, W = args.steps, args.warmup
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
@@ -190,7 +192,7 @@ def main():
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': 'FeedingJaco-v1, %d lockstep envs per MI355X, random-policy rollout, 5 substeps/step, 50 PGS sweeps' % n,
-                       'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': args.pool, 'parallelism': 'env-sharded x%d' % world,
+                       'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': args.pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src,
@@ -203,7 +205,7 @@ def main():
                          'note': 'latency/VALU-bound solver; HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host, 8, 1000)
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.generator.get_state(), 8, 1000)
         print(json.dumps(out))
     env.close()
     if distributed:

@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 import torch
 from assistive_gym_amd.vec_env import FeedingJacoVecEnv
 n, N = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 1200
-env = FeedingJacoVecEnv(n, pool_size=256, seed=7)
+mode = sys.argv[2] if len(sys.argv) > 2 else 'pool'
+env = FeedingJacoVecEnv(n, pool_size=256, seed=7, reset=mode)
 env.reset()
 g = torch.Generator(device='cuda'); g.manual_seed(0)
 ret = torch.zeros(n, device='cuda'); ep_returns = []
@@ -22,5 +23,5 @@ for k in range(N):
         bad += int((~torch.isfinite(obs)).sum()) + int((~torch.isfinite(rew)).sum()) + int((~torch.isfinite(info)).sum())
 torch.cuda.synchronize()
 r = torch.cat(ep_returns)
-print('steps', N, 'episodes', len(r), 'non-finite values', bad, 'return mean %.2f std %.2f min %.2f max %.2f' % (r.mean(), r.std(), r.min(), r.max()),
-      'max |obs| %.2f' % float(obs.abs().max()), 'env-steps/s %.0f' % (n * N / (time.time() - t0)))
+print('reset mode', mode, 'steps', N, 'episodes', len(r), 'non-finite values', bad, 'return mean %.2f std %.2f min %.2f max %.2f' % (r.mean(), r.std(), r.min(), r.max()),
+      'max |obs| %.2f' % float(obs.abs().max()), 'task_success mean %.3f' % float(info[:, 1].mean()), 'env-steps/s %.0f' % (n * N / (time.time() - t0)))
