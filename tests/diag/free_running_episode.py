@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): free-running 200-step episodes, HIP stepper vs oracle from identical states and action tapes
 (no re-synchronisation): how far do trajectories drift, do episode returns / food events agree?"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from assistive_gym_amd.blob import ModelBlob

@@ -2,7 +2,7 @@
 NOT reference/PyBullet data -- the reference cannot run in this environment)."""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from assistive_gym_amd.blob import ModelBlob

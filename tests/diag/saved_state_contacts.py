@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): first-substep contacts of the HIP stepper vs the oracle for one saved state."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from assistive_gym_amd.blob import ModelBlob

@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): per-env single-step deviations of the HIP stepper from the oracle (same protocol as
 tests/test_gpu_parity.py::test_step_matches_oracle), printing the environments that exceed the tolerance."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from assistive_gym_amd.blob import ModelBlob
