@@ -17,6 +17,12 @@ def pool_indices(env_offset, n, pool_size):
     return (np.arange(n) + env_offset) % pool_size
 
 
+def episode_seed(seed, episode, env_offset):
+    """Seed handed to the device-side reset generator for the first env of a shard: env i of episode e is sampled from
+    seed + e * 2^32 + (env_offset + i), a function of the GLOBAL env index and the episode only."""
+    return (int(seed) + (int(episode) << 32) + int(env_offset)) & 0xFFFFFFFFFFFFFFFF
+
+
 def gather_observations(obs_local, world, out=None):
     """[n, obs_dim] per rank -> [world*n, obs_dim] in rank order on every rank."""
     import torch

@@ -10,7 +10,7 @@ import torch
 from .blob import ModelBlob
 from .host.reset import make_states
 from .libagx import Stepper
-from .shard import pool_indices
+from .shard import episode_seed, pool_indices
 
 SETTLE_STEPS = 25   # feeding.py:178-179
 
@@ -39,8 +39,8 @@ class FeedingJacoVecEnv:
       'pool'    -- a fixed pool of pool_size post-reset states generated once; done envs draw from it
                    (BASELINE config 2: "auto-reset from pool", SURVEY 8d);
       'device'  -- every episode of every env starts from a NEWLY sampled state, as in the reference where each
-                   reset() redraws the human, the IK start pose, the bowl ... (feeding.py:114-182); the generator
-                   runs when the lock-stepped batch reaches the end of its 200-step episode;
+                   reset() redraws the human, the IK start pose, the bowl ... (feeding.py:114-182): agx_reset
+                   (sampling + settle, in place) when the lock-stepped batch reaches the end of its 200-step episode;
       'host'    -- 'pool' with the numpy sampler (host/reset.py)."""
 
     def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool'):
@@ -56,31 +56,20 @@ class FeedingJacoVecEnv:
         self.done = torch.zeros(n_envs, dtype=torch.uint8, device=self.device)
         self.info = torch.zeros((n_envs, 8), dtype=torch.float32, device=self.device)
         self.pool = None
-        self.generator = Stepper(self.blob, n_envs, device) if reset == 'device' else None
         self.episode_len = int(self.blob.task_f('EPISODE_LEN'))
         self.env_offset, self._t, self._episode = 0, 0, 0
-        self._side, self._ahead = None, None
         self.terminal_obs = None
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _generate(self, s):
-        """fresh post-reset states for the whole batch in the generator handle: env i of episode e is a function of
-        (seed, e, env_offset + i) only, i.e. independent of the number of GPUs the batch is spread over"""
-        g = self.generator
-        g.sample_reset(self.seed + (self._episode << 32) + self.env_offset, impairment=self.impairment, stream=s)
-        g.settle(SETTLE_STEPS, s)
+    def _fresh_reset(self, mask, s):
+        """FeedingEnv.reset for the envs selected by mask (None = all), in place on the device: env i of episode e is
+        sampled from episode_seed(seed, e, env_offset) + i -- a function of the GLOBAL env index and the episode only,
+        i.e. independent of the number of GPUs the batch is spread over -- and settled for 25 substeps"""
+        self.stepper.reset(mask, None, episode_seed(self.seed, self._episode, self.env_offset), impairment=self.impairment,
+                           settle_substeps=SETTLE_STEPS, stream=s)
         self._episode += 1
-
-    def _generate_ahead(self):
-        """the NEXT episode's states, on a side stream: the generator's kernels (1 sample + 25 substeps) fill the
-        gaps of the 200 steps of the running episode instead of stalling the batch at the episode boundary"""
-        if self._side is None:
-            self._side = torch.cuda.Stream(self.device)
-        self._side.wait_stream(torch.cuda.current_stream(self.device))      # the previous batch has been handed over
-        self._generate(self._side.cuda_stream)
-        self._ahead = self._side.record_event()
 
     def reset(self, env_offset=0):
         """env_offset: global index of this shard's first env (multi-GPU sharding keeps the
@@ -88,12 +77,7 @@ class FeedingJacoVecEnv:
         self.env_offset, self._t = env_offset, 0
         s = self._stream()
         if self.reset_mode == 'device':
-            if self._ahead is not None:
-                torch.cuda.current_stream(self.device).wait_event(self._ahead)
-            self._generate(s)
-            self.stepper.synchronize(s)
-            self.stepper.set_state(self.generator.get_state())
-            self._generate_ahead()
+            self._fresh_reset(None, s)
         else:
             if self.pool is None:
                 self.pool_host = build_reset_pool(self.blob, self.pool_size, self.seed, self.device_index, self.impairment,
@@ -114,9 +98,7 @@ class FeedingJacoVecEnv:
             if self.reset_mode != 'device':
                 self.stepper.reset_done(self.pool, self.pool_size, self.done, s)
             elif boundary:
-                torch.cuda.current_stream(self.device).wait_event(self._ahead)
-                self.stepper.reset_done(self.generator.state_dev(), self.n_envs, self.done, s)
-                self._generate_ahead()
+                self._fresh_reset(self.done, s)
             if boundary:
                 # vector-env convention: the observation returned with done is the first one of the new episode
                 # (`return self._get_obs()` of reset(), feeding.py:182); the last one of the old episode is kept aside
@@ -126,5 +108,3 @@ class FeedingJacoVecEnv:
 
     def close(self):
         self.stepper.close()
-        if self.generator is not None:
-            self.generator.close()

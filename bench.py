@@ -205,7 +205,7 @@ def main():
                          'note': 'latency/VALU-bound solver; HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.generator.get_state(), 8, 1000)
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8, 1000)
         print(json.dumps(out))
     env.close()
     if distributed:

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from assistive_gym_amd.shard import gather_observations, pool_indices, shard_range
+from assistive_gym_amd.shard import episode_seed, gather_observations, pool_indices, shard_range
 
 
 def _free_port():
@@ -48,3 +48,16 @@ def test_initial_state_is_placement_independent():
     for world in (1, 2, 4, 8):
         parts = [pool_indices(shard_range(r, world, n_global)[0], n_global // world, pool) for r in range(world)]
         np.testing.assert_array_equal(np.concatenate(parts), one)
+
+
+def test_fresh_reset_seeds_are_placement_independent():
+    """reset='device': the generator samples env i of a shard from episode_seed(...) + i, so the per-env seeds of
+    the whole job are the same however many GPUs it is spread over, and never repeat across episodes"""
+    n_global, seed = 16384, 1001
+    for episode in (0, 1, 7):
+        one = episode_seed(seed, episode, 0) + np.arange(n_global, dtype=np.uint64)
+        for world in (2, 4, 8):
+            parts = [np.uint64(episode_seed(seed, episode, shard_range(r, world, n_global)[0])) + np.arange(n_global // world, dtype=np.uint64)
+                     for r in range(world)]
+            np.testing.assert_array_equal(np.concatenate(parts), one)
+    assert episode_seed(seed, 1, 0) - episode_seed(seed, 0, n_global - 1) > 1 << 31

@@ -241,6 +241,15 @@ def test_gpu_fresh_resets_every_episode(blob):
     assert np.mean(np.abs(v1['plane_friction'] - v2['plane_friction']) > 1e-4) > 0.9      # new draws, not the old episode's
     assert torch.isfinite(obs).all()
     env.close()
+    # placement independence: the upper half of the batch on its own handle (another GPU's shard) sees the same episodes
+    half = FeedingJacoVecEnv(32, seed=7, reset='device')
+    half.reset(env_offset=32)
+    np.testing.assert_array_equal(half.stepper.get_state(), first[32:])
+    a = torch.zeros((32, half.act_dim), device='cuda')
+    for k in range(200):
+        half.step(a)
+    np.testing.assert_array_equal(half.stepper.get_state(), second[32:])
+    half.close()
 
 
 @pytest.mark.gpu
