@@ -6,6 +6,7 @@ namespace agx {
 
 // ---- K2/K3: collision ----------------------------------------------------------------------------
 struct Cand { v3 pa, pb, n; float dist, gap; };
+constexpr float GJK_FAR_MARGIN = 1e-4f;   // the separating-axis early-out of gjk_distance only fires this far beyond the contact limit
 
 AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
   s.n = CLI(c, col, AGX_C_NVERT);
@@ -13,24 +14,33 @@ AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
   v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), s.R, p);
   s.p = p - shift; s.box = false;
 }
-// closest features of colliders (ca, cb); true if the separation (radii included) is below limit
-AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out) {
+// closest features of colliders (ca, cb); true if the separation (radii included) is below limit.
+// Wave-uniform: every lane calls it, lanes without a pair pass has = false.
+AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, bool has) {
   const float* AB = c.lds + L_ARENA;
-  v3 shift = mk3(0.5f * (AB[ABS * ca] + AB[ABS * ca + 3]), 0.5f * (AB[ABS * ca + 1] + AB[ABS * ca + 4]), 0.5f * (AB[ABS * ca + 2] + AB[ABS * ca + 5]));
-  gjk_shape sa, sb; make_shape(c, ca, shift, sa); make_shape(c, cb, shift, sb);
-  // large static world boxes (table top, ground): clip to the neighbourhood of A (see oracle)
-  if (CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && sb.n == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
-    sb.box = true;
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; k++) {
-      lo[k] = fmaxf(AB[ABS * cb + k], AB[ABS * ca + k] - AGX_BOX_CLIP); hi[k] = fminf(AB[ABS * cb + 3 + k], AB[ABS * ca + 3 + k] + AGX_BOX_CLIP);
-      if (hi[k] < lo[k]) return false;
+  gjk_shape sa, sb;
+  sa.v = nullptr; sa.n = 0; sa.box = false; sb.v = nullptr; sb.n = 0; sb.box = false;
+  v3 shift = mk3(0.f, 0.f, 0.f);
+  float ra = 0.f, rb = 0.f;
+  bool ok = has;
+  if (has) {
+    shift = mk3(0.5f * (AB[ABS * ca] + AB[ABS * ca + 3]), 0.5f * (AB[ABS * ca + 1] + AB[ABS * ca + 4]), 0.5f * (AB[ABS * ca + 2] + AB[ABS * ca + 5]));
+    make_shape(c, ca, shift, sa); make_shape(c, cb, shift, sb);
+    // large static world boxes (table top, ground): clip to the neighbourhood of A (see oracle)
+    if (CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && sb.n == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
+      sb.box = true;
+      float lo[3], hi[3];
+      for (int k = 0; k < 3; k++) {
+        lo[k] = fmaxf(AB[ABS * cb + k], AB[ABS * ca + k] - AGX_BOX_CLIP); hi[k] = fminf(AB[ABS * cb + 3 + k], AB[ABS * ca + 3 + k] + AGX_BOX_CLIP);
+        if (hi[k] < lo[k]) ok = false;
+      }
+      sb.lo = mk3(lo[0], lo[1], lo[2]) - shift; sb.hi = mk3(hi[0], hi[1], hi[2]) - shift;
     }
-    sb.lo = mk3(lo[0], lo[1], lo[2]) - shift; sb.hi = mk3(hi[0], hi[1], hi[2]) - shift;
+    ra = CLF(c, ca, AGX_C_RADIUS); rb = CLF(c, cb, AGX_C_RADIUS);
   }
-  float ra = CLF(c, ca, AGX_C_RADIUS), rb = CLF(c, cb, AGX_C_RADIUS);
   float d; v3 pa, pb, n;
-  bool pen = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), d, pa, pb);
+  const bool pen = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), limit + ra + rb + GJK_FAR_MARGIN, ok, d, pa, pb);
+  if (!ok) return false;
   if (!pen) {
     if (d - ra - rb >= limit) return false;
     n = (1.0f / d) * (pa - pb);
@@ -104,6 +114,7 @@ AGX_DEV bool sphere_box_apart(const Ctx& c, int x, int y, float reach) {
 // enumeration order); appends the resulting contacts
 AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float slack, const GroupRegs& G) {
   float* L = c.lds; int* WL = c.ldsi + L_ARENA + A_WL; float* CD = L + L_ARENA + A_CAND; const int lane = c.lane;
+  const float* AB = L + L_ARENA;
   const int food0 = c.bi[AGX_H_FOOD0];
   if (wn == 0) return;
   wave_sync();
@@ -114,9 +125,19 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   for (int base = 0; base < wn; base += 64) {
     const int i = base + lane; const bool has = i < wn;
     Cand k; k.gap = 3.0e38f; bool near = false; int a = 0, g = 0;
+    int b = 0;
+    float lim = brk;
     if (has) {
-      const int pr = WL[i]; a = pr & 511; const int b = (pr >> 9) & 511; g = pr >> 18;
-      if (narrowphase(c, a, b, brk, k)) {
+      const int pr = WL[i]; a = pr & 511; b = (pr >> 9) & 511; g = pr >> 18;
+      // A row is only built for predicted gap = dist + v_n dt < slack, and |v_n| dt is bounded by the travel distances
+      // the AABBs were grown by.  Unless the task asks whether a manifold point exists (group flag bit 1), a pair
+      // further apart than that is of no interest and its GJK may stop at the first separating axis that proves it
+      // (pairs such as two idle fingers 4 mm apart otherwise run to full convergence every substep).
+      if (!(GRI(c, g, AGX_G_FLAGS) & 2)) lim = fminf(brk, slack + AB[ABS * a + 6] + AB[ABS * b + 6] + 1e-5f);
+    }
+    const bool hit = narrowphase(c, a, b, lim, k, has);
+    if (has) {
+      if (hit) {
         near = true;
         v3 vr = point_velocity(c, CLI(c, a, AGX_C_BODY), k.pa) - point_velocity(c, CLI(c, b, AGX_C_BODY), k.pb);
         float pg = k.dist + dot(vr, k.n) * c.dt;

@@ -303,12 +303,11 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
     {
       const int fc = foodc0 + k; const float* AB = L + L_ARENA;
       for (int base = tool0; base < tool1; base += 64) {
-        const int tc = base + lane; bool hitl = false;
-        if (tc < tool1) {
-          bool sep = false;
-          for (int q = 0; q < 3; q++) if (AB[ABS * fc + q] > AB[ABS * tc + 3 + q] + spill || AB[ABS * tc + q] > AB[ABS * fc + 3 + q] + spill) sep = true;
-          Cand tmp; if (!sep) hitl = narrowphase(c, fc, tc, spill, tmp);
-        }
+        const int tc = base + lane;
+        bool query = tc < tool1;
+        if (query) for (int q = 0; q < 3; q++) if (AB[ABS * fc + q] > AB[ABS * tc + 3 + q] + spill || AB[ABS * tc + q] > AB[ABS * fc + 3 + q] + spill) query = false;
+        Cand tmp;
+        const bool hitl = narrowphase(c, fc, query ? tc : tool0, spill, tmp, query);
         if (wave_any(hitl)) near = true;
       }
     }

@@ -2,6 +2,8 @@
 // colliders, with a fixed-direction penetration sampler when the cores overlap.
 // Each lane works on its own collider pair; vertices are read from the model blob (L1/L2
 // resident, shared by all environments) in the body frame and transformed on the fly.
+// The GJK iteration itself is wave-uniform (lanes that are done are predicated off), so that the
+// support scan of the few pairs with large hulls can be served by the whole wave (gjk_support_wave).
 #pragma once
 
 struct gjk_shape {
@@ -13,6 +15,13 @@ struct gjk_shape {
   v3 lo, hi;
 };
 
+// vertex . direction with a fixed rounding sequence, so that the per-lane scan and the wave-wide scan of
+// gjk_support_wave rank the vertices identically
+AGX_DEV float gjk_dot3(float x, float y, float z, v3 d) { return fmaf(z, d.z, fmaf(y, d.y, x * d.x)); }
+// R^T d, the search direction in the body frame, same remark
+AGX_DEV v3 gjk_local_dir(const m3& R, v3 d) {
+  return mk3(fmaf(R.a[6], d.z, fmaf(R.a[3], d.y, R.a[0] * d.x)), fmaf(R.a[7], d.z, fmaf(R.a[4], d.y, R.a[1] * d.x)), fmaf(R.a[8], d.z, fmaf(R.a[5], d.y, R.a[2] * d.x)));
+}
 AGX_DEV v3 gjk_vertex0(const gjk_shape& s) {
   if (s.box) return s.lo;
   return mul(s.R, mk3(s.v[0], s.v[1], s.v[2])) + s.p;
@@ -28,25 +37,62 @@ AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
     }
     return best;
   }
-  v3 dl = tmul(s.R, d);
+  const v3 dl = gjk_local_dir(s.R, d);
   // 4 vertices per round, all loads issued before the first use (indices clamped to n-1: a
   // repeated vertex never wins the strict comparison, so the first maximum is still returned)
   const float* V = s.v;
   int best = 0;
-  float bd = V[0] * dl.x + V[1] * dl.y + V[2] * dl.z;
+  float bd = gjk_dot3(V[0], V[1], V[2], dl);
   const int last = s.n - 1;
   for (int k = 1; k < s.n; k += 4) {
     const int k1 = k + 1 < last ? k + 1 : last, k2 = k + 2 < last ? k + 2 : last, k3 = k + 3 < last ? k + 3 : last;
     const float x0 = V[3 * k], y0 = V[3 * k + 1], z0 = V[3 * k + 2], x1 = V[3 * k1], y1 = V[3 * k1 + 1], z1 = V[3 * k1 + 2];
     const float x2 = V[3 * k2], y2 = V[3 * k2 + 1], z2 = V[3 * k2 + 2], x3 = V[3 * k3], y3 = V[3 * k3 + 1], z3 = V[3 * k3 + 2];
-    const float t0 = x0 * dl.x + y0 * dl.y + z0 * dl.z, t1 = x1 * dl.x + y1 * dl.y + z1 * dl.z;
-    const float t2 = x2 * dl.x + y2 * dl.y + z2 * dl.z, t3 = x3 * dl.x + y3 * dl.y + z3 * dl.z;
+    const float t0 = gjk_dot3(x0, y0, z0, dl), t1 = gjk_dot3(x1, y1, z1, dl), t2 = gjk_dot3(x2, y2, z2, dl), t3 = gjk_dot3(x3, y3, z3, dl);
     if (t0 > bd) { bd = t0; best = k; }
     if (t1 > bd) { bd = t1; best = k1; }
     if (t2 > bd) { bd = t2; best = k2; }
     if (t3 > bd) { bd = t3; best = k3; }
   }
   return mul(s.R, mk3(V[3 * best], V[3 * best + 1], V[3 * best + 2])) + s.p;
+}
+
+// Support points for all lanes of the wave at once.  Lanes with a small hull (or a box) scan their own
+// vertices; a lane whose hull has more than GJK_COOP_MIN vertices would make the whole wave wait for its
+// scan, so -- when there are only a few of them -- the wave serves those lanes one at a time: 64 vertices per
+// step, one per lane, argmax by wave_max + ballot.  The lowest index among equal maxima wins, like the
+// sequential scan's strict comparison, so both paths return the same vertex.
+#ifdef AGX_GJK_NO_COOP   // build-time knob for A/B runs: every lane scans its own hull
+constexpr int GJK_COOP_MIN = 32, GJK_COOP_MAX_LANES = 0;
+#else
+constexpr int GJK_COOP_MIN = 32, GJK_COOP_MAX_LANES = 16;
+#endif
+AGX_DEV v3 gjk_support_wave(const gjk_shape& s, v3 d, bool active) {
+  const bool big = active && !s.box && s.n > GJK_COOP_MIN;
+  uint64_t hm = wave_ballot(big);
+  const bool coop = hm != 0ull && popc64(hm) <= GJK_COOP_MAX_LANES;
+  v3 out = mk3(0.f, 0.f, 0.f);
+  if (active && !(coop && big)) out = gjk_support(s, d);
+  if (!coop) return out;
+  const v3 dl = gjk_local_dir(s.R, d);
+  const int lane = wave_lane();
+  int lo32, hi32;
+  { const unsigned long long a = (unsigned long long)(uintptr_t)s.v; lo32 = (int)(unsigned)(a & 0xffffffffull); hi32 = (int)(unsigned)(a >> 32); }
+  while (hm) {
+    const int h = ffs64(hm); hm &= hm - 1ull;
+    const float dx = wave_bcast(dl.x, h), dy = wave_bcast(dl.y, h), dz = wave_bcast(dl.z, h);
+    const int n = wave_bcast_i(s.n, h);
+    const float* V = (const float*)(uintptr_t)(((unsigned long long)(unsigned)wave_bcast_i(hi32, h) << 32) | (unsigned long long)(unsigned)wave_bcast_i(lo32, h));
+    int best = 0; float bd = -3.0e38f;
+    for (int base = 0; base < n; base += AGX_WAVE) {
+      const int k = base + lane;
+      const float t = k < n ? gjk_dot3(V[3 * k], V[3 * k + 1], V[3 * k + 2], mk3(dx, dy, dz)) : -3.0e38f;
+      const float m = wave_max(t);
+      if (m > bd) { bd = m; best = base + ffs64(wave_ballot(t == m)); }
+    }
+    if (lane == h) out = mul(s.R, mk3(V[3 * best], V[3 * best + 1], V[3 * best + 2])) + s.p;
+  }
+  return out;
 }
 
 // closest point to the origin on triangle (a,b,c): barycentric weights
@@ -146,40 +192,57 @@ AGX_DEV bool gjk_solve(gjk_simplex& s, v3& v) {
   return false;
 }
 
-// returns true when the cores overlap; otherwise dist / witness points (shifted frame)
-AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, int maxit, float& dist, v3& pa, v3& pb) {
+// returns true when the cores overlap; otherwise dist / witness points (shifted frame).  Called by ALL lanes of the
+// wave; lanes with `has` false only take part in the collectives.
+// `far`: core distance beyond which the caller discards the pair.  Every support point w yields the lower bound
+// v.w / |v| on the distance (w is the extreme point of A - B along -v); once that bound exceeds `far` the iteration
+// stops and the bound is returned as dist (> far, witness points meaningless).  The caller adds a margin to `far` that
+// dwarfs the rounding error of the bound, so accept / reject decisions are those of the converged distance.
+AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, int maxit, float far, bool has, float& dist, v3& pa, v3& pb) {
   gjk_simplex s;
-  v3 a0 = gjk_vertex0(sa), b0 = gjk_vertex0(sb);
+  v3 a0 = mk3(0.f, 0.f, 0.f), b0 = a0;
+  if (has) { a0 = gjk_vertex0(sa); b0 = gjk_vertex0(sb); }
   v3 v = a0 - b0;
   float vv = dot(v, v);
   s.p0.a = a0; s.p0.b = b0; s.p0.w = v; s.p1 = s.p0; s.p2 = s.p0; s.p3 = s.p0;
   s.n = 1; s.l0 = 1; s.l1 = 0; s.l2 = 0; s.l3 = 0;
   pa = a0; pb = b0;
-  bool pen = false;
+  bool pen = false, far_out = false, active = has;
+  float lb = 0.f;
   for (int it = 0; it < maxit; it++) {
-    if (vv < 1e-12f) { pen = true; break; }   /* cores closer than 1 micron: treat as overlapping */
-    v3 wa = gjk_support(sa, -v), wb = gjk_support(sb, v), w = wa - wb;
-    float vw = dot(v, w);
-    if (vv - vw <= tol * vv) break;
-    const bool e0 = s.p0.w.x == w.x && s.p0.w.y == w.y && s.p0.w.z == w.z;
-    const bool e1 = s.n > 1 && s.p1.w.x == w.x && s.p1.w.y == w.y && s.p1.w.z == w.z;
-    const bool e2 = s.n > 2 && s.p2.w.x == w.x && s.p2.w.y == w.y && s.p2.w.z == w.z;
-    if (e0 || e1 || e2) break;
-    gjk_pt np; np.w = w; np.a = wa; np.b = wb;
-    if (s.n == 1) s.p1 = np; else if (s.n == 2) s.p2 = np; else s.p3 = np;
-    s.n++;
-    v3 vn;
-    if (gjk_solve(s, vn)) { pen = true; break; }
-    float vvn = dot(vn, vn);
-    // no progress (a degenerate sub-simplex solve can even move away): keep the closest points found so far
-    if (vvn >= vv) break;
-    v = vn; vv = vvn;
-    pa = s.l0 * s.p0.a; pb = s.l0 * s.p0.b;
-    if (s.n > 1) { pa = pa + s.l1 * s.p1.a; pb = pb + s.l1 * s.p1.b; }
-    if (s.n > 2) { pa = pa + s.l2 * s.p2.a; pb = pb + s.l2 * s.p2.b; }
+    if (active && vv < 1e-12f) { pen = true; active = false; }   /* cores closer than 1 micron: treat as overlapping */
+    if (!wave_any(active)) break;
+    const v3 wa = gjk_support_wave(sa, -v, active), wb = gjk_support_wave(sb, v, active);
+    if (active) {
+      const v3 w = wa - wb;
+      const float vw = dot(v, w);
+      const bool e0 = s.p0.w.x == w.x && s.p0.w.y == w.y && s.p0.w.z == w.z;
+      const bool e1 = s.n > 1 && s.p1.w.x == w.x && s.p1.w.y == w.y && s.p1.w.z == w.z;
+      const bool e2 = s.n > 2 && s.p2.w.x == w.x && s.p2.w.y == w.y && s.p2.w.z == w.z;
+      if (vw > 0.f && vw * vw > far * far * vv) { far_out = true; lb = vw / sqrtf(vv); active = false; }
+      else if (vv - vw <= tol * vv || e0 || e1 || e2) active = false;
+      else {
+        gjk_pt np; np.w = w; np.a = wa; np.b = wb;
+        if (s.n == 1) s.p1 = np; else if (s.n == 2) s.p2 = np; else s.p3 = np;
+        s.n++;
+        v3 vn;
+        if (gjk_solve(s, vn)) { pen = true; active = false; }
+        else {
+          const float vvn = dot(vn, vn);
+          // no progress (a degenerate sub-simplex solve can even move away): keep the closest points found so far
+          if (vvn >= vv) active = false;
+          else {
+            v = vn; vv = vvn;
+            pa = s.l0 * s.p0.a; pb = s.l0 * s.p0.b;
+            if (s.n > 1) { pa = pa + s.l1 * s.p1.a; pb = pb + s.l1 * s.p1.b; }
+            if (s.n > 2) { pa = pa + s.l2 * s.p2.a; pb = pb + s.l2 * s.p2.b; }
+          }
+        }
+      }
+    }
   }
   if (pen) { dist = 0; return true; }
-  dist = sqrtf(vv);
+  dist = far_out ? lb : sqrtf(vv);
   return false;
 }
 
