@@ -93,6 +93,7 @@ def capture_state(env, blob, meta, foods, p):
     v['rng'][0] = [12345, 6789]                 # device RNG of the teleport positions; not compared
     tremor = env.human.impairment == 'tremor'
     v['frozen'][0] = 0 if tremor else (((1 << blob.nhdof) - 1) << nrobot)                         # human.py:108-112
+    v['limit_scale'][0] = env.human.limit_scale                                                    # human.py:85 (scales the head joint limits)
     if tremor:                                  # env.py:212-215: target + tremors * (+1 / -1 by iteration parity)
         ctrl = list(env.human.controllable_joint_indices)
         for k, j in enumerate(meta['human_dynamic_joints']):
