@@ -72,7 +72,8 @@ AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
 // The contact order (group, a, selection order) is what the oracle produces, so the solver rows
 // are identical.
 constexpr int WL_MAX = 200, CAND_STRIDE = 8;
-constexpr int A_WL = ABS * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18
+constexpr int A_WL = ABS * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18 | face-manifold point << 24
+constexpr int WL_KEY_MASK = ~((511 << 9) | (3 << 24));    // (group, A collider) of a worklist entry
 constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, n, dist (pb = pa - dist n)
 static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
 static_assert(MAX_COLL <= 512, "collider indices are packed in 9 bits");
@@ -82,6 +83,48 @@ AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
   const float* L = c.lds; const int pr = c.ldsi[L_ARENA + A_WL + idx]; const float* cd = L + L_ARENA + A_CAND + CAND_STRIDE * idx;
   Cand k; k.gap = cd[0]; k.pa = ld3(cd + 1); k.n = ld3(cd + 4); k.dist = cd[7]; k.pb = k.pa - k.dist * k.n;
   emit_contact(c, slot, pr & 511, (pr >> 9) & 511, k);
+}
+// Face manifold (see face_manifold in oracle/agx_oracle.c and AGX_FACE_* in agx_blob.h): a collider resting on the top
+// face of a static world box touches it along a face or an edge, where GJK's closest point is not unique and a single
+// contact point makes the body rock.  Such a pair occupies 1 + AGX_FACE_EXTRA consecutive worklist entries: entry 0
+// is the GJK contact, entry e the e-th additional vertex contact -- among the vertices of A above the box's footprint
+// and within AGX_FACE_BAND of the lowest one, the one farthest (horizontally) from the points chosen before it, if
+// that is at least AGX_FACE_SPREAD.
+AGX_DEV bool face_box(const Ctx& c, int cb) {
+  return CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && CLI(c, cb, AGX_C_NVERT) == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE);
+}
+// the e-th (1-based) extra contact of pair (ca, cb) whose GJK contact point on A is p0; false if there is none
+AGX_DEV bool face_point(const Ctx& c, int ca, int cb, int e, v3 p0, Cand& out) {
+  const float* AB = c.lds + L_ARENA;
+  const int n = CLI(c, ca, AGX_C_NVERT);
+  const float* V = c.bf + c.o_vert + 3 * CLI(c, ca, AGX_C_VOFF);
+  m3 R; v3 p; body_xf(c, CLI(c, ca, AGX_C_BODY), R, p);
+  const float x0 = AB[ABS * cb], y0 = AB[ABS * cb + 1], x1 = AB[ABS * cb + 3], y1 = AB[ABS * cb + 4], top = AB[ABS * cb + 5];   // radius included
+  float zmin = 3.0e38f;
+  for (int v = 0; v < n; v++) { const v3 w = mul(R, mk3(V[3 * v], V[3 * v + 1], V[3 * v + 2])) + p; if (w.x >= x0 && w.x <= x1 && w.y >= y0 && w.y <= y1 && w.z < zmin) zmin = w.z; }
+  float cx[1 + AGX_FACE_EXTRA], cy[1 + AGX_FACE_EXTRA];
+  cx[0] = p0.x; cy[0] = p0.y;
+#pragma unroll
+  for (int q = 1; q <= AGX_FACE_EXTRA; q++) { cx[q] = 0.f; cy[q] = 0.f; }
+  v3 pick = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 1; q <= AGX_FACE_EXTRA; q++) {
+    if (q > e) break;
+    int bi = -1; float bd = AGX_FACE_SPREAD * AGX_FACE_SPREAD; v3 bw = mk3(0.f, 0.f, 0.f);
+    for (int v = 0; v < n; v++) {
+      const v3 w = mul(R, mk3(V[3 * v], V[3 * v + 1], V[3 * v + 2])) + p;
+      if (!(w.x >= x0 && w.x <= x1 && w.y >= y0 && w.y <= y1) || w.z > zmin + AGX_FACE_BAND) continue;
+      float dmin = 3.0e38f;
+#pragma unroll
+      for (int k = 0; k <= AGX_FACE_EXTRA; k++) if (k < q) { const float dx = w.x - cx[k], dy = w.y - cy[k]; dmin = fminf(dmin, dx * dx + dy * dy); }
+      if (dmin > bd) { bd = dmin; bi = v; bw = w; }
+    }
+    if (bi < 0) return false;
+    cx[q] = bw.x; cy[q] = bw.y; pick = bw;
+  }
+  const float ra = CLF(c, ca, AGX_C_RADIUS);
+  out.n = mk3(0.f, 0.f, 1.f); out.pa = mk3(pick.x, pick.y, pick.z - ra); out.pb = mk3(pick.x, pick.y, top); out.dist = pick.z - ra - top;
+  return true;
 }
 struct CollideState { int ncon, near_mask, overflow, maxc; };
 // the pair-group table, one group per lane (lane g = group g): read from the blob once per substep and
@@ -125,17 +168,26 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   for (int base = 0; base < wn; base += 64) {
     const int i = base + lane; const bool has = i < wn;
     Cand k; k.gap = 3.0e38f; bool near = false; int a = 0, g = 0;
-    int b = 0;
+    int b = 0, sub = 0;
     float lim = brk;
     if (has) {
-      const int pr = WL[i]; a = pr & 511; b = (pr >> 9) & 511; g = pr >> 18;
+      const int pr = WL[i]; a = pr & 511; b = (pr >> 9) & 511; g = (pr >> 18) & 63; sub = (pr >> 24) & 3;
       // A row is only built for predicted gap = dist + v_n dt < slack, and |v_n| dt is bounded by the travel distances
       // the AABBs were grown by.  Unless the task asks whether a manifold point exists (group flag bit 1), a pair
       // further apart than that is of no interest and its GJK may stop at the first separating axis that proves it
       // (pairs such as two idle fingers 4 mm apart otherwise run to full convergence every substep).
       if (!(GRI(c, g, AGX_G_FLAGS) & 2)) lim = fminf(brk, slack + AB[ABS * a + 6] + AB[ABS * b + 6] + 1e-5f);
     }
-    const bool hit = narrowphase(c, a, b, lim, k, has);
+    k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.dist = 0.f;
+    bool hit = narrowphase(c, a, b, lim, k, has && sub == 0);
+    if (wave_any(has && sub > 0)) {   // face-manifold entries: the GJK contact of the pair is `sub` entries back
+      if (has && sub == 0) { float* cd = CD + CAND_STRIDE * i; st3(cd + 1, k.pa); st3(cd + 4, k.n); }
+      wave_sync();
+      if (has && sub > 0) {
+        const float* sd = CD + CAND_STRIDE * (i - sub);
+        hit = sd[6] > 0.999f && face_point(c, a, b, sub, ld3(sd + 1), k) && k.dist < brk;
+      }
+    }
     if (has) {
       if (hit) {
         near = true;
@@ -160,10 +212,10 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   const int ncon0 = cs.ncon;
   int cur = 0;
   while (cur < wn) {
-    const int key = WL[cur] & ~(511 << 9);            // group and A collider
-    const int g = key >> 18, keep = wave_bcast_i(G.keep, g);
+    const int key = WL[cur] & WL_KEY_MASK;            // group and A collider
+    const int g = (key >> 18) & 63, keep = wave_bcast_i(G.keep, g);
     const int i0 = cur + lane, i1 = cur + 64 + lane;
-    const bool s0 = i0 < wn && (WL[i0 < wn ? i0 : 0] & ~(511 << 9)) == key, s1 = i1 < wn && (WL[i1 < wn ? i1 : 0] & ~(511 << 9)) == key;
+    const bool s0 = i0 < wn && (WL[i0 < wn ? i0 : 0] & WL_KEY_MASK) == key, s1 = i1 < wn && (WL[i1 < wn ? i1 : 0] & WL_KEY_MASK) == key;
     const uint64_t b0 = wave_ballot(s0), b1 = wave_ballot(s1);
     // segments are contiguous: the run of matching entries starting at cur
     const int len0 = (~b0) ? ffs64(~b0) : 64;
@@ -201,7 +253,7 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
 
 // broadphase sweep of A colliders [aa, ab) x B range of group g, appended to the worklist at wn.
 // returns the new count (may exceed WL_MAX: entries beyond it are not stored)
-AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gflags, float mg, int wn, const GroupRegs& G) {
+AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gflags, float mg, int wn, int rep, const GroupRegs& G) {
   const float* AB = c.lds + L_ARENA; int* WL = c.ldsi + L_ARENA + A_WL; const int lane = c.lane;
   const bool same = gflags & 1, no_adjacent = gflags & 4;   // bit2, self-collision: not the same link, not parent and child
   // level 1: the A colliders whose box reaches the union box of the B range and vice versa (the union
@@ -225,11 +277,14 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gfl
   const int na_live = nlive[0], nb = nlive[1];
   wave_sync();
   // level 2: the pair grid of the surviving A colliders, in enumeration order
-  const int npairs = na_live * nb;
+  // (groups against static world boxes: every pair is enumerated rep = 1 + AGX_FACE_EXTRA times, entry `sub` > 0
+  // standing for the sub-th extra point of the face manifold)
+  const int npairs = na_live * nb * rep;
   for (int base = 0; base < npairs; base += 64) {
     const int p = base + lane; bool ok = p < npairs;
-    const int ai = ok ? p / nb : 0; const int a = LIST[ai], b = LIST[128 + (ok ? p - ai * nb : 0)];
-    ok = ok && (!same || b > a);
+    const int pq = ok ? p / rep : 0, sub = ok ? p - pq * rep : 0;
+    const int ai = pq / nb; const int a = LIST[ai], b = LIST[128 + pq - ai * nb];
+    ok = ok && (!same || b > a) && (sub == 0 || (face_box(c, b) && CLI(c, a, AGX_C_NVERT) >= 2));
     if (ok && no_adjacent) {
       const int la = CLI(c, a, AGX_C_BODY), lb = CLI(c, b, AGX_C_BODY);
       if (la == lb) ok = false;
@@ -240,7 +295,7 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gfl
     if (ok) { const float reach = mg + AB[ABS * a + 6] + AB[ABS * b + 6] + 1e-5f; ok = !sphere_box_apart(c, a, b, reach) && !sphere_box_apart(c, b, a, reach); }
     const uint64_t m = wave_ballot(ok);
     const int slot = wn + wave_rank(m);
-    if (ok && slot < WL_CAP) WL[slot] = a | (b << 9) | (g << 18);
+    if (ok && slot < WL_CAP) WL[slot] = a | (b << 9) | (g << 18) | (sub << 24);
     wn += popc64(m);
   }
   wave_sync();
@@ -319,10 +374,11 @@ AGX_DEV void collide(Ctx& c) {
       const int a0 = wave_bcast_i(G.a0, g), a1 = wave_bcast_i(G.a1, g), b0 = wave_bcast_i(G.b0, g), b1 = wave_bcast_i(G.b1, g);
       const int gflags = wave_bcast_i(G.flags, g);
       const float mg = (gflags & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
-      const int nb = b1 - b0;
+      const int rep = face_box(c, b0) ? 1 + AGX_FACE_EXTRA : 1;   // B ranges are homogeneous (table boxes, the ground plane, ...)
+      const int nb = (b1 - b0) * rep;
       if (ab < 0) { ab = a0; abatch = a1 - a0; }
       const int ae = ab + abatch < a1 ? ab + abatch : a1;
-      int wn2 = collide_sweep(c, g, ab, ae, b0, b1, gflags, mg, wn, G);
+      int wn2 = collide_sweep(c, g, ab, ae, b0, b1, gflags, mg, wn, rep, G);
       AGX_CTICK(10)
       bool fits = wn2 <= WL_CAP;
       if (!fits && wn == 0) {

@@ -16,6 +16,12 @@
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
 #define AGX_BLOB_VERSION 7
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
+/* face manifold on static world boxes (table top, ground): besides the closest point, up to AGX_FACE_EXTRA more
+ * vertices of the other collider become contact candidates -- those within AGX_FACE_BAND of its lowest vertex,
+ * each at least AGX_FACE_SPREAD (horizontally) away from the points already chosen, farthest first */
+#define AGX_FACE_EXTRA 3
+#define AGX_FACE_BAND 0.0001f
+#define AGX_FACE_SPREAD 0.01f
 
 /* ---- header: int32[AGX_H_COUNT] at word 0 ------------------------------------------------ */
 enum {

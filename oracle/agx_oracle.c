@@ -553,6 +553,43 @@ static void point_velocity(const sim_t* s, int code, const double* x, double* v)
   }
 }
 static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* out) { return narrowphase_ab(s, ca, cb, limit, out, NULL, NULL); }
+/* Face manifold: a collider resting on the top face of a static world box (table, ground) touches it along a face or
+ * an edge, where the closest point of GJK is not unique and a single contact point makes the body rock.  Bullet
+ * accumulates up to 4 points per pair in its persistent manifold (btPersistentManifold [BULLET-UNVERIFIED]); without
+ * per-pair state the same support polygon is rebuilt every substep from the vertices of A: among the vertices above
+ * the box's footprint and within AGX_FACE_BAND of the lowest one, the one farthest (horizontally) from the points
+ * chosen so far is added, as long as it is at least AGX_FACE_SPREAD away; up to AGX_FACE_EXTRA times.  The band makes
+ * the choice insensitive to which of several (nearly) coplanar vertices is the lowest by a rounding error.
+ * k: the GJK contact of the pair (normal +z); returns the number of extra contacts written to out[]. */
+static int face_manifold(const sim_t* s, int ca, int cb, const contact_t* k, const double* blo, const double* bhi, contact_t* out) {
+  const agxo_model* m = s->m;
+  if (!(CI(m, cb, AGX_C_BODY) == AGX_BODY_WORLD && CI(m, cb, AGX_C_NVERT) == 8 && (CI(m, cb, AGX_C_TAG) == AGX_TAG_TABLE || CI(m, cb, AGX_C_TAG) == AGX_TAG_PLANE))) return 0;
+  int na = CI(m, ca, AGX_C_NVERT);
+  if (na < 2 || k->n[2] <= 0.999) return 0;
+  double zero[3] = {0, 0, 0}, va[3 * MAXV]; collider_world_verts(s, ca, zero, va);
+  double ra = CF(m, ca, AGX_C_RADIUS), top = bhi[2];        /* bhi: the box's AABB, radius included */
+  double zmin = 1e300;
+  for (int v = 0; v < na; v++) { const double* p = va + 3 * v; if (p[0] >= blo[0] && p[0] <= bhi[0] && p[1] >= blo[1] && p[1] <= bhi[1] && p[2] < zmin) zmin = p[2]; }
+  double cx[1 + AGX_FACE_EXTRA], cy[1 + AGX_FACE_EXTRA]; int nch = 1, nout = 0;
+  cx[0] = k->pa[0]; cy[0] = k->pa[1];
+  for (int e = 0; e < AGX_FACE_EXTRA; e++) {
+    int bi = -1; double bd = (double)AGX_FACE_SPREAD * (double)AGX_FACE_SPREAD;
+    for (int v = 0; v < na; v++) {
+      const double* p = va + 3 * v;
+      if (!(p[0] >= blo[0] && p[0] <= bhi[0] && p[1] >= blo[1] && p[1] <= bhi[1]) || p[2] > zmin + (double)AGX_FACE_BAND) continue;
+      double dmin = 1e300;
+      for (int c = 0; c < nch; c++) { double dx = p[0] - cx[c], dy = p[1] - cy[c], d2 = dx * dx + dy * dy; if (d2 < dmin) dmin = d2; }
+      if (dmin > bd) { bd = dmin; bi = v; }   /* strictly farther: the lowest index wins ties */
+    }
+    if (bi < 0) break;
+    const double* p = va + 3 * bi;
+    contact_t* o = &out[nout++]; *o = *k;
+    o->pa[0] = p[0]; o->pa[1] = p[1]; o->pa[2] = p[2] - ra; o->pb[0] = p[0]; o->pb[1] = p[1]; o->pb[2] = top;
+    o->n[0] = 0; o->n[1] = 0; o->n[2] = 1; o->dist = p[2] - ra - top; o->lambda_n = 0;
+    cx[nch] = p[0]; cy[nch] = p[1]; nch++;
+  }
+  return nout;
+}
 /* speed bound of any material point of collider c under the predicted velocities: |v(centre)| + |w| * rho */
 static double collider_speed(const sim_t* s, int c) {
   const agxo_model* m = s->m; int code = CI(m, c, AGX_C_BODY);
@@ -604,8 +641,15 @@ static void collide(sim_t* s) {
         /* solver row only if the gap can close within this substep */
         double va[3], vb[3], vr[3]; point_velocity(s, k.ba, k.pa, va); point_velocity(s, k.bb, k.pb, vb); sub3(va, vb, vr);
         double pg = k.dist + dot3(vr, k.n) * dt;
-        if (pg >= slack) continue;
-        cand[nc] = k; gap[nc] = pg; nc++;
+        if (pg < slack) { cand[nc] = k; gap[nc] = pg; nc++; }
+        contact_t extra[AGX_FACE_EXTRA];
+        int ne = face_manifold(s, a, b, &k, lo[b], hi[b], extra);
+        for (int e = 0; e < ne; e++) {
+          if (extra[e].dist >= brk) continue;
+          point_velocity(s, extra[e].ba, extra[e].pa, va); point_velocity(s, extra[e].bb, extra[e].pb, vb); sub3(va, vb, vr);
+          double pg2 = extra[e].dist + dot3(vr, extra[e].n) * dt;
+          if (pg2 < slack && nc < 128) { cand[nc] = extra[e]; gap[nc] = pg2; nc++; }
+        }
       }
       /* keep the `keep` candidates with the smallest predicted gap (ties: lower B index), emitted in
        * selection order; keep == 0 keeps all in B order */
