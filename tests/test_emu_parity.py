@@ -192,3 +192,28 @@ def test_action_clipping_and_zero_action(blob, emu, oracle12):
     sz = s0.copy(); emu.step(sz, np.zeros(blob.act_dim, np.float32))
     arm = [d for d in range(blob.nrobot) if blob.robot_i(d, 'ACT') >= 0]
     assert np.abs(blob.view(sz)['qt'][0, arm] - blob.view(s0)['q'][0, arm]).max() < 1e-6
+
+
+def test_resting_bowl_face_manifold(blob, oracle):
+    """A bowl at rest on the table is the tie-prone case of the face manifold (several coplanar lowest vertices per hull
+    piece): the device code (f32) and the oracle (f64) must pick the same support points -- bowl pose / velocity after a
+    step agree, and the bowl stays at rest."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import reset_oracle as ro
+    from emu_lib import Emu
+    e = Emu(blob)
+    st, _ = ro.ResetOracle(blob.words).sample(41)
+    oracle.settle(st, 25)
+    rng = np.random.RandomState(3)
+    for k in range(30):
+        oracle.step(st, rng.uniform(-1, 1, blob.act_dim).astype(np.float32))
+    so, se = st.copy(), st.copy()
+    a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+    o_obs = oracle.step(so, a)[0]
+    e_obs, _, _, e_info, _ = e.step(se, a)
+    vo, ve = blob.view(so[None]), blob.view(se[None])
+    assert np.abs(o_obs - e_obs).max() < 1e-5
+    assert np.abs(vo['free'][0, 1, :7] - ve['free'][0, 1, :7]).max() < 1e-5
+    assert np.abs(vo['free'][0, 1, 7:] - ve['free'][0, 1, 7:]).max() < 5e-4
+    assert np.linalg.norm(ve['free'][0, 1, 10:13]) < 0.02 and np.linalg.norm(vo['free'][0, 1, 10:13]) < 0.02
