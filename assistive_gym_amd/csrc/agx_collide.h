@@ -13,13 +13,14 @@ AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
   s.v = c.bf + c.o_vert + 3 * CLI(c, col, AGX_C_VOFF);
   v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), s.R, p);
   s.p = p - shift; s.box = false;
+  s.c = mul(s.R, mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2))) + s.p;
 }
 // closest features of colliders (ca, cb); true if the separation (radii included) is below limit.
 // Wave-uniform: every lane calls it, lanes without a pair pass has = false.
 AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, bool has) {
   const float* AB = c.lds + L_ARENA;
   gjk_shape sa, sb;
-  sa.v = nullptr; sa.n = 0; sa.box = false; sb.v = nullptr; sb.n = 0; sb.box = false;
+  sa.v = nullptr; sa.n = 0; sa.box = false; sa.c = mk3(0.f, 0.f, 0.f); sb.v = nullptr; sb.n = 0; sb.box = false; sb.c = sa.c;
   v3 shift = mk3(0.f, 0.f, 0.f);
   float ra = 0.f, rb = 0.f;
   bool ok = has;
@@ -34,7 +35,7 @@ AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, b
         lo[k] = fmaxf(AB[ABS * cb + k], AB[ABS * ca + k] - AGX_BOX_CLIP); hi[k] = fminf(AB[ABS * cb + 3 + k], AB[ABS * ca + 3 + k] + AGX_BOX_CLIP);
         if (hi[k] < lo[k]) ok = false;
       }
-      sb.lo = mk3(lo[0], lo[1], lo[2]) - shift; sb.hi = mk3(hi[0], hi[1], hi[2]) - shift;
+      sb.lo = mk3(lo[0], lo[1], lo[2]) - shift; sb.hi = mk3(hi[0], hi[1], hi[2]) - shift; sb.c = 0.5f * (sb.lo + sb.hi);
     }
     ra = CLF(c, ca, AGX_C_RADIUS); rb = CLF(c, cb, AGX_C_RADIUS);
   }

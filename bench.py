@@ -77,10 +77,12 @@ def cpu_baseline(blob, states, envs_per_core, n_steps):
             path = os.path.join(tmp, 'cpu_%d.npy' % c)
             np.save(path, states[(c * envs_per_core + np.arange(envs_per_core)) % len(states)])
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', path, str(c), str(n_steps)],
-                                          stdout=subprocess.PIPE, text=True))
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         res = []
         for pr in procs:
-            out, _ = pr.communicate()
+            out, err = pr.communicate()
+            if pr.returncode != 0 or len(out.split()) < 2:
+                raise RuntimeError('cpu_baseline worker failed (rc %s): %s' % (pr.returncode, err.strip()[-400:]))
             steps, secs = out.split()[-2:]
             res.append((int(steps), float(secs)))
     wall = time.perf_counter() - t0

@@ -423,14 +423,23 @@ static int simplex_solve(double W[4][3], double A[4][3], double B[4][3], int* pn
   for (int k = 0; k < k2; k++) axpy3(lam[k], W[k], v);
   return 0;
 }
-int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int maxit, double* dist, double* pa, double* pb, int* iters) {
+/* d0 (may be NULL): a vector from B towards A, typically centre(A) - centre(B).  The first simplex point is the
+ * support point of A - B along -d0 (a point of the Minkowski difference that already faces the origin) instead of
+ * the difference of the first vertices; it saves about one iteration per pair. */
+static int gjk_core(const double* a, int na, const double* b, int nb, double tol, int maxit, const double* d0, double* dist, double* pa, double* pb, int* iters) {
   double W[4][3], A[4][3], B[4][3], lam[4] = {1, 0, 0, 0}, v[3];
-  int n = 0, pen = 0, it;
-  sub3(a, b, v);
+  int n = 0, pen = 0, it, ia0 = 0, ib0 = 0;
+  if (d0) {
+    double d[3] = {d0[0], d0[1], d0[2]};
+    if (dot3(d, d) < 1e-12) { d[0] = 1; d[1] = 0; d[2] = 0; }
+    double nd[3] = {-d[0], -d[1], -d[2]};
+    ia0 = support(a, na, nd); ib0 = support(b, nb, d);
+  }
+  sub3(a + 3 * ia0, b + 3 * ib0, v);
   double vv = dot3(v, v);
-  /* seed simplex with the first vertices so witness points are always defined */
-  memcpy(A[0], a, 24); memcpy(B[0], b, 24); memcpy(W[0], v, 24); n = 1;
-  memcpy(pa, a, 24); memcpy(pb, b, 24);
+  /* seed simplex so witness points are always defined */
+  memcpy(A[0], a + 3 * ia0, 24); memcpy(B[0], b + 3 * ib0, 24); memcpy(W[0], v, 24); n = 1;
+  memcpy(pa, a + 3 * ia0, 24); memcpy(pb, b + 3 * ib0, 24);
   for (it = 0; it < maxit; it++) {
     if (vv < 1e-12) { pen = 1; break; }   /* cores closer than 1 micron: treat as overlapping */
     double nv[3] = {-v[0], -v[1], -v[2]};
@@ -455,6 +464,9 @@ int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int m
   if (pen) { *dist = 0; return 1; }
   *dist = sqrt(vv);
   return 0;
+}
+int agxo_gjk(const double* a, int na, const double* b, int nb, double tol, int maxit, double* dist, double* pa, double* pb, int* iters) {
+  return gjk_core(a, na, b, nb, tol, maxit, NULL, dist, pa, pb, iters);
 }
 
 /* ------------------------------------------------------------------------------------ collision */
@@ -497,8 +509,10 @@ static int narrowphase_ab(const sim_t* s, int ca, int cb, double limit, contact_
   /* a large static world box (table top, ground) is replaced by its intersection with the other
    * collider's AABB grown by BOX_CLIP: same closest points (they lie within `limit` of A), but all
    * vertices stay near A so that single-precision GJK remains well conditioned */
+  int clipped = 0;
   if (CI(m, cb, AGX_C_BODY) == AGX_BODY_WORLD && nb == 8 && (CI(m, cb, AGX_C_TAG) == AGX_TAG_TABLE || CI(m, cb, AGX_C_TAG) == AGX_TAG_PLANE)) {
     double blo[3], bhi[3], alo[3], ahi[3];
+    clipped = 1;
     collider_aabb(s, cb, blo, bhi); memcpy(alo, lo, 24); memcpy(ahi, hi, 24);
     for (int k = 0; k < 3; k++) {
       double lo2 = alo[k] - AGX_BOX_CLIP, hi2 = ahi[k] + AGX_BOX_CLIP;
@@ -509,7 +523,16 @@ static int narrowphase_ab(const sim_t* s, int ca, int cb, double limit, contact_
   }
   double ra = CF(m, ca, AGX_C_RADIUS), rb = CF(m, cb, AGX_C_RADIUS);
   double d, pa[3], pb[3], n[3];
-  int pen = agxo_gjk(va, na, vb, nb, PARAM(m, AGX_P_GJK_TOL), (int)PARAM(m, AGX_P_GJK_MAXIT), &d, pa, pb, NULL);
+  /* GJK starts along centre(A) - centre(B): body-frame AABB centres of the cores (the clipped box's own centre) */
+  double cen[2][3], d0[3];
+  for (int q = 0; q < 2; q++) {
+    int cc = q ? cb : ca; const xf_t* X = body_xf(s, CI(m, cc, AGX_C_BODY));
+    double cl[3] = {CF(m, cc, AGX_C_AABB_C), CF(m, cc, AGX_C_AABB_C + 1), CF(m, cc, AGX_C_AABB_C + 2)};
+    xf_apply(X, cl, cen[q]); for (int k = 0; k < 3; k++) cen[q][k] -= shift[k];
+  }
+  if (clipped) for (int k = 0; k < 3; k++) cen[1][k] = 0.5 * (vb[k] + vb[3 * 7 + k]);
+  sub3(cen[0], cen[1], d0);
+  int pen = gjk_core(va, na, vb, nb, PARAM(m, AGX_P_GJK_TOL), (int)PARAM(m, AGX_P_GJK_MAXIT), d0, &d, pa, pb, NULL);
   if (!pen) {
     if (d - ra - rb >= limit) return 0;
     sub3(pa, pb, n); for (int k = 0; k < 3; k++) n[k] /= d;

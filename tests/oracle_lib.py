@@ -14,8 +14,12 @@ def lib():
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libagx_oracle.so')
         src = os.path.join(ROOT, 'oracle', 'agx_oracle.c')
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')], stdout=subprocess.DEVNULL)
+        deps = [src, os.path.join(ROOT, 'oracle', 'agx_oracle.h'), os.path.join(ROOT, 'include', 'agx_blob.h')]
+        if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(d) for d in deps):
+            import fcntl
+            with open(os.path.join(ROOT, 'oracle', '.build.lock'), 'w') as lock:     # bench.py starts one process per core
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle')], stdout=subprocess.DEVNULL)
         L = C.CDLL(path)
         L.agxo_load.restype = C.c_void_p
         L.agxo_load.argtypes = [C.c_void_p, C.c_size_t]

