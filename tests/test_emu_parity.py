@@ -220,3 +220,38 @@ def test_resting_bowl_face_manifold(blob, oracle):
     assert np.abs(vo['free'][0, 1, :7] - ve['free'][0, 1, :7]).max() < 1e-5
     assert np.abs(vo['free'][0, 1, 7:] - ve['free'][0, 1, 7:]).max() < 5e-4
     assert np.linalg.norm(ve['free'][0, 1, 10:13]) < 0.02 and np.linalg.norm(vo['free'][0, 1, 10:13]) < 0.02
+
+
+def test_analytic_scenarios_on_the_device_code(blob, oracle):
+    """The constructed cases of tests/test_oracle.py (free flight, head-on collision of two spheres, a sliding sphere
+    that starts rolling) run through the kernel sources: same particle states as the oracle, which is itself checked
+    against the closed forms there."""
+    from emu_lib import Emu
+    e = Emu(blob)
+    st, _ = make_states(blob, 1, seed=2001)
+    f0 = blob.h['FOOD0']; r = blob.free_f(f0, 'RADIUS')
+
+    def scenario(setup, n):
+        s = st[0].copy(); setup(blob.view(s))
+        so, se = s.copy(), s.copy()
+        oracle.settle(so, n); e.settle(se, n)
+        fo, fe = blob.view(so)['free'][0, f0:f0 + 2], blob.view(se)['free'][0, f0:f0 + 2]
+        assert np.abs(fo[:, :3] - fe[:, :3]).max() < 2e-6 and np.abs(fo[:, 7:10] - fe[:, 7:10]).max() < 2e-5, (fo, fe)
+        assert np.abs(fo[:, 10:13] - fe[:, 10:13]).max() < 5e-3 * max(1.0, np.abs(fo[:, 10:13]).max())
+        return fe
+
+    def flight(v):
+        v['free'][0, f0, :3], v['free'][0, f0, 7:13] = [1.5, 1.5, 2.5], [0.3, -0.2, 0.5, 0, 0, 0]
+    scenario(flight, 4)
+
+    def collide(v):
+        c = np.array([1.5, 1.5, 2.5])
+        v['free'][0, f0, :3], v['free'][0, f0 + 1, :3] = c - [0.02, 0, 0], c + [0.02, 0, 0]
+        v['free'][0, f0, 7:13], v['free'][0, f0 + 1, 7:13] = [0.5, 0, 0, 0, 0, 0], [-0.5, 0, 0, 0, 0, 0]
+    fe = scenario(collide, 3)
+    assert abs(fe[0, 7]) < 1e-4 and abs(fe[1, 7]) < 1e-4 and abs(np.linalg.norm(fe[1, :3] - fe[0, :3]) - 2 * r) < 1e-5
+
+    def slide(v):
+        v['free'][0, f0, :3], v['free'][0, f0, 7:13] = [0.25, -1.0, 0.725 + r], [0.2, 0, 0, 0, 0, 0]
+    fe = scenario(slide, 2)
+    assert fe[0, 11] == pytest.approx(fe[0, 7] / r, rel=1e-2)             # rolling without slipping
