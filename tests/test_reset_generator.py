@@ -338,3 +338,35 @@ def test_gpu_sampled_batch_invariants_at_bench_size(blob):
     with pytest.raises(AgxError):
         bad.sample_reset(1)
     bad.close()
+
+
+# ---- committed fixture (tests/golden/reset_generator.npz, written by tests/diag/make_reset_golden.py) ----------
+def _golden():
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'reset_generator.npz'))
+    return g, [int(s) for s in g['seeds']], [int(x) for x in g['impairment_mode']], [int(x) for x in g['gender_mode']]
+
+
+def test_golden_fixture_oracle_and_emulator(blob, emu):
+    g, seeds, imps, gens = _golden()
+    assert int(g['blob_version']) == blob.h['VERSION']
+    o = ro.ResetOracle(blob.words)
+    for k, (s, imp, gen) in enumerate(zip(seeds, imps, gens)):
+        st, info = o.sample(s, imp, gen)
+        np.testing.assert_array_equal(st.view(np.int32), g['states'][k].view(np.int32))           # the oracle is deterministic
+        se, ie = emu.sample(s, imp, gen)
+        assert_same_record(blob, g['states'][k], se, 'golden record %d' % k)
+        assert [bool(ie[0]), int(ie[1]), int(ie[3])] == [bool(g['info'][k, 0]), int(g['info'][k, 1]), int(g['info'][k, 3])]
+
+
+@pytest.mark.gpu
+def test_gpu_golden_fixture(blob):
+    from assistive_gym_amd.libagx import Stepper
+    g, seeds, imps, gens = _golden()
+    names_i = {v: k for k, v in Stepper.IMPAIRMENT_MODES.items()}
+    names_g = {v: k for k, v in Stepper.GENDER_MODES.items()}
+    st = Stepper(blob, 1)
+    for k, (s, imp, gen) in enumerate(zip(seeds, imps, gens)):
+        st.sample_reset(s, impairment=names_i[imp], gender=names_g[gen])
+        st.synchronize()
+        assert_same_record(blob, g['states'][k], st.get_state()[0], 'golden record %d' % k)
+    st.close()
