@@ -22,5 +22,5 @@ for a in actions:
     ob, r, d, info = o.step(s, a)
     obs.append(ob); rew.append(r)
 np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'feeding_jaco_oracle_traj.npz'), state0=state0, actions=actions,
-                    obs=np.array(obs), reward=np.array(rew, dtype=np.float64))
+                    obs=np.array(obs), reward=np.array(rew, dtype=np.float64), state_end=s)
 print('wrote golden trajectory, return', sum(rew))
