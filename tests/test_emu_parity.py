@@ -255,3 +255,19 @@ def test_analytic_scenarios_on_the_device_code(blob, oracle):
         v['free'][0, f0, :3], v['free'][0, f0, 7:13] = [0.25, -1.0, 0.725 + r], [0.2, 0, 0, 0, 0, 0]
     fe = scenario(slide, 2)
     assert fe[0, 11] == pytest.approx(fe[0, 7] / r, rel=1e-2)             # rolling without slipping
+
+
+def test_golden_trajectory_replay(blob):
+    """The committed oracle trajectory (tests/golden/feeding_jaco_oracle_traj.npz: settled state, 20 actions, the oracle's
+    observations / rewards / final state) replayed FREE-RUNNING through the kernel sources."""
+    import os
+    from emu_lib import Emu
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'feeding_jaco_oracle_traj.npz'))
+    e = Emu(blob)
+    s = g['state0'].copy()
+    for k in range(len(g['actions'])):
+        obs, rew, done, info, _ = e.step(s, g['actions'][k])
+        assert np.abs(obs - g['obs'][k]).max() < 2e-4 and abs(rew - float(g['reward'][k])) < 2e-4, k
+    v, w = blob.view(s[None]), blob.view(g['state_end'][None].copy())
+    assert np.abs(v['q'] - w['q']).max() < 1e-4 and np.abs(v['free'][0, :, :3] - w['free'][0, :, :3]).max() < 3e-3   # the particles jostle on the spoon: mm-level after 20 free-running steps
+    assert v['food_alive'][0] == w['food_alive'][0] and v['iteration'][0] == w['iteration'][0]
