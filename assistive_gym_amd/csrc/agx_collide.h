@@ -108,6 +108,14 @@ AGX_DEV bool face_point(const Ctx& c, int ca, int cb, int e, v3 p0, Cand& out) {
 #pragma unroll
   for (int q = 1; q <= AGX_FACE_EXTRA; q++) { cx[q] = 0.f; cy[q] = 0.f; }
   v3 pick = mk3(0.f, 0.f, 0.f);
+  if (e == 0) {   // the pair's first contact, re-anchored at the first vertex (model order) inside the band
+    bool found = false;
+    for (int v = 0; v < n && !found; v++) {
+      const v3 w = mul(R, mk3(V[3 * v], V[3 * v + 1], V[3 * v + 2])) + p;
+      if (w.x >= x0 && w.x <= x1 && w.y >= y0 && w.y <= y1 && w.z <= zmin + AGX_FACE_BAND) { pick = w; found = true; }
+    }
+    if (!found) return false;
+  }
 #pragma unroll
   for (int q = 1; q <= AGX_FACE_EXTRA; q++) {
     if (q > e) break;
@@ -181,6 +189,9 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
     }
     k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.dist = 0.f;
     bool hit = narrowphase(c, a, b, lim, k, has && sub == 0);
+    // on a face GJK's closest point is an arbitrary point of the face: the first contact of a pair resting on a static
+    // world box is re-anchored at a vertex as well (oracle: face_manifold)
+    if (has && sub == 0 && hit && k.n.z > 0.999f && face_box(c, b) && CLI(c, a, AGX_C_NVERT) >= 2) { Cand k0; k0.gap = k.gap; if (face_point(c, a, b, 0, k.pa, k0)) k = k0; }
     if (wave_any(has && sub > 0)) {   // face-manifold entries: the GJK contact of the pair is `sub` entries back
       if (has && sub == 0) { float* cd = CD + CAND_STRIDE * i; st3(cd + 1, k.pa); st3(cd + 4, k.n); }
       wave_sync();

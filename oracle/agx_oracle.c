@@ -584,7 +584,7 @@ static int narrowphase(const sim_t* s, int ca, int cb, double limit, contact_t* 
  * chosen so far is added, as long as it is at least AGX_FACE_SPREAD away; up to AGX_FACE_EXTRA times.  The band makes
  * the choice insensitive to which of several (nearly) coplanar vertices is the lowest by a rounding error.
  * k: the GJK contact of the pair (normal +z); returns the number of extra contacts written to out[]. */
-static int face_manifold(const sim_t* s, int ca, int cb, const contact_t* k, const double* blo, const double* bhi, contact_t* out) {
+static int face_manifold(const sim_t* s, int ca, int cb, contact_t* k, const double* blo, const double* bhi, contact_t* out) {
   const agxo_model* m = s->m;
   if (!(CI(m, cb, AGX_C_BODY) == AGX_BODY_WORLD && CI(m, cb, AGX_C_NVERT) == 8 && (CI(m, cb, AGX_C_TAG) == AGX_TAG_TABLE || CI(m, cb, AGX_C_TAG) == AGX_TAG_PLANE))) return 0;
   int na = CI(m, ca, AGX_C_NVERT);
@@ -593,6 +593,17 @@ static int face_manifold(const sim_t* s, int ca, int cb, const contact_t* k, con
   double ra = CF(m, ca, AGX_C_RADIUS), top = bhi[2];        /* bhi: the box's AABB, radius included */
   double zmin = 1e300;
   for (int v = 0; v < na; v++) { const double* p = va + 3 * v; if (p[0] >= blo[0] && p[0] <= bhi[0] && p[1] >= blo[1] && p[1] <= bhi[1] && p[2] < zmin) zmin = p[2]; }
+  if (zmin > 1e299) return 0;                               /* no vertex above the footprint: keep the GJK contact */
+  /* On a face the closest point of GJK is an arbitrary point of the face (it differs between f32 and f64 and from
+   * substep to substep); the pair's first contact is therefore re-anchored at a vertex too: the first vertex (in
+   * model order) inside the band.  For a vertex or edge contact that is GJK's own witness point. */
+  for (int v = 0; v < na; v++) {
+    const double* p = va + 3 * v;
+    if (!(p[0] >= blo[0] && p[0] <= bhi[0] && p[1] >= blo[1] && p[1] <= bhi[1]) || p[2] > zmin + (double)AGX_FACE_BAND) continue;
+    k->pa[0] = p[0]; k->pa[1] = p[1]; k->pa[2] = p[2] - ra; k->pb[0] = p[0]; k->pb[1] = p[1]; k->pb[2] = top;
+    k->n[0] = 0; k->n[1] = 0; k->n[2] = 1; k->dist = p[2] - ra - top;
+    break;
+  }
   double cx[1 + AGX_FACE_EXTRA], cy[1 + AGX_FACE_EXTRA]; int nch = 1, nout = 0;
   cx[0] = k->pa[0]; cy[0] = k->pa[1];
   for (int e = 0; e < AGX_FACE_EXTRA; e++) {
@@ -661,12 +672,13 @@ static void collide(sim_t* s) {
         /* a manifold point exists (what getContactPoints reports, agent.py:100-116) */
         if (CI(m, a, AGX_C_TAG) == AGX_TAG_FOOD && CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN)
           s->food_near_human |= 1 << (CI(m, a, AGX_C_BODY) - AGX_BODY_FREE0 - m->food0);
+        /* resting on a static world box: vertex contacts (re-anchors k, adds up to AGX_FACE_EXTRA more) */
+        contact_t extra[AGX_FACE_EXTRA];
+        int ne = face_manifold(s, a, b, &k, lo[b], hi[b], extra);
         /* solver row only if the gap can close within this substep */
         double va[3], vb[3], vr[3]; point_velocity(s, k.ba, k.pa, va); point_velocity(s, k.bb, k.pb, vb); sub3(va, vb, vr);
         double pg = k.dist + dot3(vr, k.n) * dt;
         if (pg < slack) { cand[nc] = k; gap[nc] = pg; nc++; }
-        contact_t extra[AGX_FACE_EXTRA];
-        int ne = face_manifold(s, a, b, &k, lo[b], hi[b], extra);
         for (int e = 0; e < ne; e++) {
           if (extra[e].dist >= brk) continue;
           point_velocity(s, extra[e].ba, extra[e].pa, va); point_velocity(s, extra[e].bb, extra[e].pb, vb); sub3(va, vb, vr);
