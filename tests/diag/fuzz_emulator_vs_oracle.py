@@ -1,0 +1,46 @@
+"""Randomised emulator-vs-oracle campaign (CPU only, test infrastructure): natural states reached by random-policy
+rollouts of random length (co-op and impairments included), then perturbed (bowl thrown, a particle dropped into the
+bowl, joint velocity kicks), one env.step() through the kernel sources on the wave emulator and through the oracle;
+prints every case whose observation / reward / joint angles / free-body positions / contact counts disagree.
+
+    for w in $(seq 0 13); do python tests/diag/fuzz_emulator_vs_oracle.py $w 12 & done; wait
+
+Two campaigns of 168 cases each were clean at the end of round 1 (the first one had found the face-contact
+non-uniqueness fixed by re-anchoring the first contact of a face pair at a vertex)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+from emu_lib import Emu
+from oracle_lib import Oracle
+import reset_oracle as ro
+from assistive_gym_amd.blob import ModelBlob
+w=int(sys.argv[1]); N=int(sys.argv[2])
+base=ModelBlob.load()
+rng=np.random.RandomState(5000+w)
+bad=0
+for t in range(N):
+    coop = rng.rand()<0.25
+    b = base.coop() if coop else base
+    o=Oracle(b); e=Emu(b); R=ro.ResetOracle(b.words)
+    seed=int(rng.randint(1,1<<30)); imp=int(rng.choice([-1,3,1]))
+    st,_=R.sample(seed, imp); o.settle(st,25)
+    nsteps=int(rng.randint(0,60))
+    scale=rng.choice([1.0,1.0,3.0])      # beyond-limit actions are clipped by take_step
+    for k in range(nsteps): o.step(st, (rng.uniform(-1,1,b.act_dim)*scale).astype(np.float32))
+    # occasionally perturb: drop a particle / push the bowl
+    v=b.view(st[None])
+    if rng.rand()<0.5: v['free'][0,1,7:13]+=rng.uniform(-0.6,0.6,6)
+    if rng.rand()<0.3: v['free'][0,2+rng.randint(8),:3]=v['free'][0,1,:3]+[0,0,0.05]
+    if rng.rand()<0.3: v['qd'][0,:7]+=rng.uniform(-1,1,7)
+    if rng.rand()<0.3: v['free'][0,2+rng.randint(8),7:10]+=rng.uniform(-0.5,0.5,3)
+    a=(rng.uniform(-1,1,b.act_dim)*scale).astype(np.float32)
+    so,se=st.copy(),st.copy()
+    oo=o.step(so,a); eo=e.step(se,a)
+    vo,ve=b.view(so[None]),b.view(se[None])
+    dev=dict(obs=np.abs(oo[0]-eo[0]).max(), rew=abs(oo[1]-eo[1]), q=np.abs(vo['q']-ve['q']).max(), pos=np.abs(vo['free'][0,:,:3]-ve['free'][0,:,:3]).max(), ncon=abs(oo[3][6]-eo[3][6]), nrow=abs(oo[3][7]-eo[3][7]), alive=int(vo['food_alive'][0]!=ve['food_alive'][0]))
+    flag = dev['obs']>1e-4 or dev['rew']>1e-3 or dev['q']>5e-5 or dev['pos']>2e-4 or dev['ncon']>0 or dev['alive']
+    if flag:
+        bad+=1; print('MISMATCH worker',w,'case',t,'seed',seed,'imp',imp,'coop',coop,'nsteps',nsteps,'scale',scale,{k:float(x) for k,x in dev.items()}, flush=True)
+        np.save('/tmp/fuzz_bad_%d_%d.npy'%(w,t), np.concatenate([st, a, [float(coop)]]))
+print('worker',w,'done',N,'cases, mismatches',bad, flush=True)
