@@ -88,13 +88,16 @@ AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
 // Face manifold (see face_manifold in oracle/agx_oracle.c and AGX_FACE_* in agx_blob.h): a collider resting on the top
 // face of a static world box touches it along a face or an edge, where GJK's closest point is not unique and a single
 // contact point makes the body rock.  Such a pair occupies 1 + AGX_FACE_EXTRA consecutive worklist entries: entry 0
-// is the GJK contact, entry e the e-th additional vertex contact -- among the vertices of A above the box's footprint
-// and within AGX_FACE_BAND of the lowest one, the one farthest (horizontally) from the points chosen before it, if
-// that is at least AGX_FACE_SPREAD.
+// is the pair's first contact (GJK decides whether the pair is in contact and gives the normal; the point itself is
+// re-anchored at the first vertex, in model order, within AGX_FACE_BAND of the lowest one, because GJK's witness point
+// on a flat face is arbitrary), entry e the e-th additional vertex contact -- among the vertices of A above the box's
+// footprint and inside the band, the one farthest (horizontally) from the points chosen before it, if that is at
+// least AGX_FACE_SPREAD.
 AGX_DEV bool face_box(const Ctx& c, int cb) {
   return CLI(c, cb, AGX_C_BODY) == AGX_BODY_WORLD && CLI(c, cb, AGX_C_NVERT) == 8 && (CLI(c, cb, AGX_C_TAG) == AGX_TAG_TABLE || CLI(c, cb, AGX_C_TAG) == AGX_TAG_PLANE);
 }
-// the e-th (1-based) extra contact of pair (ca, cb) whose GJK contact point on A is p0; false if there is none
+// contact e of the face manifold of pair (ca, cb): e = 0 the re-anchored first contact, e >= 1 the e-th extra one given
+// the first contact point p0; false if there is none
 AGX_DEV bool face_point(const Ctx& c, int ca, int cb, int e, v3 p0, Cand& out) {
   const float* AB = c.lds + L_ARENA;
   const int n = CLI(c, ca, AGX_C_NVERT);
