@@ -21,6 +21,7 @@ class ModelBlob:
         self.nfood, self.act_dim, self.obs_dim = self.h['NFOOD'], self.h['ACT_DIM'], self.h['OBS_DIM']
         self.state_words = self.h['STATE_WORDS']
         self.nrobot, self.nhdof = self.h['NROBOT'], self.h['NHDOF']
+        self.task_kind = self.h['TASK_KIND']
 
     @classmethod
     def load(cls, name='feeding_jaco'):
@@ -47,7 +48,8 @@ class ModelBlob:
         wi = w.view(np.int32)
         n_h = sum(1 for d in range(self.nrobot, self.ndof) if self.robot_i(d, 'ACT') >= 0)
         wi[L.H['ACT_DIM']] = self.act_dim_robot + n_h
-        wi[L.H['OBS_DIM']] = self.obs_dim_robot + 19 + n_h
+        # obs_human_len: 19 + joints in feeding.py:10, 18 + joints in bed_bathing.py:10
+        wi[L.H['OBS_DIM']] = self.obs_dim_robot + (18 if self.task_kind == L.TASK_BED_BATHING else 19) + n_h
         wi[self.h['OFF_TASK'] + L.T['COOP']] = 1
         return ModelBlob(w, self.meta)
 
@@ -61,7 +63,7 @@ class ModelBlob:
 
     @property
     def obs_dim_robot(self):
-        return 18 + self.act_dim_robot
+        return (17 if self.task_kind == L.TASK_BED_BATHING else 18) + self.act_dim_robot       # bed_bathing.py:10 / feeding.py:10
 
     def rec(self, d, gender=0):
         """link record index of DoF d (human DoFs have one record per gender)"""
@@ -90,7 +92,7 @@ class ModelBlob:
         nv, vo = int(self.i[o + L.C['NVERT']]), int(self.i[o + L.C['VOFF']])
         v0 = self.h['OFF_VERT'] + 3 * vo
         return dict(body=int(self.i[o + L.C['BODY']]), radius=float(self.f[o + L.C['RADIUS']]),
-                    friction=float(self.f[o + L.C['FRICTION']]), tag=int(self.i[o + L.C['TAG']]),
+                    friction=float(self.f[o + L.C['FRICTION']]), tag=int(self.i[o + L.C['TAG']]), link=int(self.i[o + L.C['LINK']]),
                     verts=self.f[v0:v0 + 3 * nv].reshape(nv, 3).astype(np.float64))
 
     # ---- state records ------------------------------------------------------------------------
@@ -115,5 +117,6 @@ class ModelBlob:
             iteration=si[:, e + L.E['ITERATION']], task_success=si[:, e + L.E['TASK_SUCCESS']],
             rng=si[:, e + L.E['RNG']:e + L.E['RNG'] + 2], total_food=si[:, e + L.E['TOTAL_FOOD']],
             frozen=si[:, e + L.E['FROZEN']], limit_scale=s[:, e + L.E['LIMIT_SCALE']],
+            task=si[:, h['S_TASK']:h['S_TASK'] + h['TASK_WORDS']],
             tremor=s[:, h['S_TREMOR']:h['S_TREMOR'] + self.nhdof],
             tremor_target=s[:, h['S_TREMOR'] + self.nhdof:h['S_TREMOR'] + 2 * self.nhdof])

@@ -1,24 +1,36 @@
-"""Build libagx.so (HIP, gfx950) in-tree.  `python -m assistive_gym_amd.build`."""
+"""Build libagx.so (HIP, gfx950) in-tree.  `python -m assistive_gym_amd.build`.
+
+The kernels are compiled once per variant (limits + task layer, csrc/agx_kernels.hip) and linked with the handle /
+C-ABI code (csrc/agx_api.hip)."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, 'csrc', 'agx_api.hip')
-DEPS = [os.path.join(HERE, 'csrc', f) for f in sorted(f for f in os.listdir(os.path.join(HERE, 'csrc')) if f.endswith(('.h', '.hip')))] + \
+CSRC = os.path.join(HERE, 'csrc')
+DEPS = [os.path.join(CSRC, f) for f in sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip')))] + \
        [os.path.join(os.path.dirname(HERE), 'include', f) for f in ('agx.h', 'agx_blob.h')]
 OUT = os.path.join(HERE, 'lib', 'libagx.so')
+VARIANTS = ['FEEDING', 'BED_BATHING']
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra=()):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value', '-o', OUT, SRC]
+    base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + list(extra)
     if verbose:
-        cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
-    subprocess.check_call(cmd)
+        base.append('-Rpass-analysis=kernel-resource-usage')
+    objdir = os.path.join(HERE, 'lib', 'obj')
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(os.path.join(objdir, 'agx_api.o'), base + ['-c', os.path.join(CSRC, 'agx_api.hip')])]
+    for v in VARIANTS:
+        jobs.append((os.path.join(objdir, 'agx_kernels_%s.o' % v.lower()), base + ['-DAGX_VARIANT_' + v, '-c', os.path.join(CSRC, 'agx_kernels.hip')]))
+    with ThreadPoolExecutor(len(jobs)) as ex:
+        list(ex.map(lambda j: subprocess.check_call(j[1] + ['-o', j[0]]), jobs))
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + [j[0] for j in jobs])
     return OUT
 
 

@@ -1,8 +1,10 @@
-// agx_api.hip -- libagx: C ABI (include/agx.h) + kernel launches for gfx950.
-// One workgroup = one wavefront = one environment (64 threads); an env.step() is
-// frame_skip x [agx_build_kernel, agx_solve_kernel] + agx_finish_kernel on one stream.
+// agx_api.hip -- libagx: C ABI (include/agx.h), handles, streams and launch sequencing for gfx950.
+// The kernels are compiled per variant (limits + task layer) in agx_kernels.hip; agx_create picks the variant whose
+// task and limits fit the model blob.  One workgroup = one wavefront = one environment (64 threads); an env.step() is
+// frame_skip x [build kernel, solve kernel] + finish kernel per chunk of environments.
 #include "agx_wave.h"
-#include "agx_step.h"
+#include "agx_variant.h"
+#include "../../include/agx_blob.h"
 #include "../../include/agx.h"
 
 #include <stdio.h>
@@ -21,63 +23,16 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGX_E_HIP, #x, e_); } while (0)
 
-// build: kinematics, ABA, collision, constraint rows -> scratch.  Register- and LDS-heavy.
-extern "C" __global__ void __launch_bounds__(64, 2)
-agx_build_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int env0, int n_envs, int sw, int act_dim,
-                 const uint8_t* __restrict__ active) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = env0 + blockIdx.x;
-  if (env >= n_envs || (active && !active[env])) return;   // `active`: masked settle of agx_reset, null on the step path
-  agx::env_build(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
-                 debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
-}
-// solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
-extern "C" __global__ void __launch_bounds__(64, 4)
-agx_solve_kernel(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = env0 + blockIdx.x;
-  if (env >= n_envs || (active && !active[env])) return;
-  agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
-}
-// finish: forces, observation, food state machine, reward, done, info
-extern "C" __global__ void __launch_bounds__(64, 2)
-agx_finish_kernel(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
-                  float* info, int env0, int n_envs, int sw, int act_dim, int obs_dim) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = env0 + blockIdx.x;
-  if (env >= n_envs) return;
-  agx::env_finish(blob, state + (size_t)env * sw, actions + (size_t)env * act_dim, scratch + (size_t)env * agx::SCR_WORDS, obs + (size_t)env * obs_dim,
-                  reward + env, done + env, info ? info + (size_t)env * AGX_INFO_DIM : nullptr, lds, (int)threadIdx.x);
-}
-extern "C" __global__ void __launch_bounds__(64, 2)
-agx_observe_kernel(const uint32_t* __restrict__ blob, float* state, float* obs, int n_envs, int sw, int obs_dim) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int env = blockIdx.x;
-  if (env >= n_envs) return;
-  agx::env_observe(blob, state + (size_t)env * sw, obs + (size_t)env * obs_dim, lds, (int)threadIdx.x);
-}
-
 // done envs take a fresh record from the pool; coalesced copy, one wave per env
 extern "C" __global__ void __launch_bounds__(64)
-agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* done, int* episode, int n_envs, int sw) {
+agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* done, int* episode, int n_envs, int sw, long long env_offset) {
   const int env = blockIdx.x;
   if (env >= n_envs || !done[env]) return;
   int ep = episode[env] + 1;
-  const float* src = pool + (size_t)((env + 977 * (long long)ep) % pool_n) * sw;
+  // the pool entry is a function of the GLOBAL environment index: the same env draws the same states on any GPU count
+  const float* src = pool + (size_t)((env_offset + env + 977 * (long long)ep) % pool_n) * sw;
   for (int k = threadIdx.x; k < sw; k += 64) state[(size_t)env * sw + k] = src[k];
   if (threadIdx.x == 0) episode[env] = ep;
-}
-
-// reset generator: FeedingEnv.reset's sampling incl. the IK restarts (64 per round, one per lane), float64
-extern "C" __global__ void __launch_bounds__(64)
-agx_sample_kernel(const uint32_t* __restrict__ blob, float* state, unsigned long long seed0, const unsigned long long* __restrict__ seeds, const uint8_t* __restrict__ mask,
-                  int impairment_mode, int gender_mode, float* info4, int* episode, int n_envs, int sw) {
-  const int env = blockIdx.x;
-  if (env >= n_envs || (mask && !mask[env])) return;
-  const unsigned long long seed = seeds ? seeds[env] : seed0 + (unsigned long long)env;
-  if (threadIdx.x == 0) episode[env] = 0;
-  agx::env_sample(blob, state + (size_t)env * sw, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4 ? info4 + (size_t)env * 4 : nullptr,
-                  (int)threadIdx.x);
 }
 
 extern "C" __global__ void __launch_bounds__(64) agx_selftest_kernel(float* out_f, int* out_i, unsigned long long* out_m) {
@@ -98,13 +53,16 @@ extern "C" __global__ void __launch_bounds__(64) agx_selftest_kernel(float* out_
 }  // namespace
 
 struct agx_handle_s {
+  const agx_variant* V;   // the compiled kernel variant serving this model
+  int* overflow_dev;      // contacts dropped by a budget since creation (all envs)
+  long long env_offset;   // global index of env 0 of this handle (multi-GPU sharding), see agx_set_env_offset
   int device, n_envs, act_dim, obs_dim, sw;
   uint32_t* blob_dev;
   float* state_dev;
   float* scratch_dev;   // [n_envs][SCR_WORDS]: rows, predicted velocities, contacts handed between the kernels
   int* episode_dev;
   int frame_skip;
-  bool can_sample;      // the blob fits the compiled reset generator (agx_reset.h)
+  bool can_sample;      // the variant has a reset generator (agx_reset.h) and the blob fits it
   const uint8_t* active;// per-env mask honoured by the build / solve launches (agx_reset's masked settle), normally null
   // staging for the *_host convenience calls
   float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
@@ -119,31 +77,38 @@ struct agx_handle_s {
 
 extern "C" {
 
-const char* agx_version(void) { return "libagx 0.1 (gfx950, wave-per-env FeedingJaco stepper)"; }
+const char* agx_version(void) { return "libagx 0.2 (gfx950, wave-per-env stepper; variants: feeding, bed_bathing)"; }
 const char* agx_last_error(void) { return g_err.c_str(); }
 int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
-int agx_lds_bytes_per_env(void) { return agx::LDS_BYTES; }
-int agx_debug_words(void) { return agx::DBG_WORDS; }
+int agx_lds_bytes_per_env(void) { return agx_variant_feeding()->lds_bytes; }
+int agx_debug_words(void) { return agx_variant_feeding()->dbg_words; }   // FeedingJaco variant; agx_debug_layout(h) for a handle
 
 int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_handle* out) {
   if (!blob || !out || n_envs <= 0 || blob_bytes < sizeof(uint32_t) * AGX_H_COUNT) return fail(AGX_E_ARG, "agx_create: bad argument");
   const uint32_t* w = (const uint32_t*)blob; const int32_t* hi = (const int32_t*)blob;
   if (w[AGX_H_MAGIC] != AGX_BLOB_MAGIC || w[AGX_H_VERSION] != AGX_BLOB_VERSION || (size_t)hi[AGX_H_NWORDS] * 4 != blob_bytes)
     return fail(AGX_E_BLOB, "agx_create: not a model blob of this version");
-  if (hi[AGX_H_NDOF] > agx::MAX_DOF || hi[AGX_H_NFREE] > agx::MAX_FREE || hi[AGX_H_NHUMAN] > agx::MAX_HUMAN || hi[AGX_H_NCOLL] > agx::MAX_COLL ||
-      hi[AGX_H_STATE_WORDS] > agx::ST_WORDS || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128 || hi[AGX_H_NGROUP] > 64)
-    return fail(AGX_E_LIMIT, "agx_create: model exceeds the compiled kernel limits");
+  const agx_variant* V = nullptr;
+  {
+    const agx_variant* all[2] = {agx_variant_feeding(), agx_variant_bed_bathing()};
+    for (const agx_variant* v : all) if (v->task_kind == hi[AGX_H_TASK_KIND]) V = v;
+    if (!V) return fail(AGX_E_LIMIT, "agx_create: no kernel variant is compiled for the task of this model");
+  }
+  if (hi[AGX_H_NDOF] > V->max_dof || hi[AGX_H_NFREE] > V->max_free || hi[AGX_H_NHUMAN] > V->max_human || hi[AGX_H_NCOLL] > V->max_coll ||
+      hi[AGX_H_STATE_WORDS] > V->st_words || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128 || hi[AGX_H_NGROUP] > 64 ||
+      hi[AGX_H_NROBOT] > V->max_block || hi[AGX_H_NHDOF] > V->max_block || hi[AGX_H_NDOF] > 32)
+    return fail(AGX_E_LIMIT, "agx_create: model exceeds the limits of the compiled kernel variant");
   for (int g = 0; g < hi[AGX_H_NGROUP]; g++) {   // the broadphase compacts each collider range of a pair group into a 128-entry list
     const int32_t* G = hi + hi[AGX_H_OFF_GROUP] + g * AGX_G_STRIDE;
     if (G[AGX_G_A1] - G[AGX_G_A0] > 128 || G[AGX_G_B1] - G[AGX_G_B0] > 128 || (G[AGX_G_B0F] >= 0 && G[AGX_G_B1F] - G[AGX_G_B0F] > 128))
       return fail(AGX_E_LIMIT, "agx_create: a pair group has a collider range of more than 128 colliders");
   }
-  bool can_sample = true;   // the reset generator's IK is compiled for a serial 7-DoF arm carrying the end effector
-  {
+  bool can_sample = V->sample != nullptr;   // the reset generator's IK is compiled for a serial 7-DoF arm carrying the end effector
+  if (can_sample) {
     const int32_t* X = hi + hi[AGX_H_OFF_RESET];
     const int32_t* T = hi + hi[AGX_H_OFF_TASK];
-    if (X[AGX_X_NARM] != agx::RS_NARM || T[AGX_T_EE_LINK] != agx::RS_NARM - 1 || hi[AGX_H_NROBOT] < agx::RS_NARM || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64) can_sample = false;
-    for (int d = 0; can_sample && d < agx::RS_NARM; d++) {
+    if (X[AGX_X_NARM] != V->rs_narm || T[AGX_T_EE_LINK] != V->rs_narm - 1 || hi[AGX_H_NROBOT] < V->rs_narm || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64) can_sample = false;
+    for (int d = 0; can_sample && d < V->rs_narm; d++) {
       const int32_t* R = hi + hi[AGX_H_OFF_ROBOT] + d * AGX_R_STRIDE;
       if (R[AGX_R_PARENT] != d - 1 || R[AGX_R_ACT] != d) can_sample = false;
     }
@@ -154,14 +119,16 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   HIPCHK(hipSetDevice(device));
   agx_handle h = new agx_handle_s();
   memset(h, 0, sizeof *h);
-  h->can_sample = can_sample;
+  h->can_sample = can_sample; h->V = V;
   h->device = device; h->n_envs = n_envs; h->act_dim = hi[AGX_H_ACT_DIM]; h->obs_dim = hi[AGX_H_OBS_DIM]; h->sw = hi[AGX_H_STATE_WORDS];
   HIPCHK(hipMalloc(&h->blob_dev, blob_bytes));
   HIPCHK(hipMemcpy(h->blob_dev, blob, blob_bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&h->state_dev, (size_t)n_envs * h->sw * 4));
   HIPCHK(hipMemset(h->state_dev, 0, (size_t)n_envs * h->sw * 4));
-  HIPCHK(hipMalloc(&h->scratch_dev, (size_t)n_envs * agx::SCR_WORDS * 4));
-  HIPCHK(hipMemset(h->scratch_dev, 0, (size_t)n_envs * agx::SCR_WORDS * 4));
+  HIPCHK(hipMalloc(&h->scratch_dev, (size_t)n_envs * V->scr_words * 4));
+  HIPCHK(hipMemset(h->scratch_dev, 0, (size_t)n_envs * V->scr_words * 4));
+  HIPCHK(hipMalloc(&h->overflow_dev, 4));
+  HIPCHK(hipMemset(h->overflow_dev, 0, 4));
   h->frame_skip = (int)((const float*)blob)[hi[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   HIPCHK(hipMalloc(&h->episode_dev, (size_t)n_envs * 4));
   HIPCHK(hipMemset(h->episode_dev, 0, (size_t)n_envs * 4));
@@ -181,9 +148,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     HIPCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     for (int k = 0; k < nc; k++) { HIPCHK(hipStreamCreateWithFlags(&h->cs[k], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming)); }
   }
-  HIPCHK(hipFuncSetAttribute((const void*)agx_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
-  HIPCHK(hipFuncSetAttribute((const void*)agx_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
-  HIPCHK(hipFuncSetAttribute((const void*)agx_observe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES));
+  HIPCHK(V->init());
   *out = h;
   return AGX_OK;
 }
@@ -191,7 +156,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
 void agx_destroy(agx_handle h) {
   if (!h) return;
   hipSetDevice(h->device);
-  hipFree(h->scratch_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
+  hipFree(h->scratch_dev); hipFree(h->overflow_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
   hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   for (int c = 0; c < 8; c++) for (int k = 0; k < 16; k++) hipEventDestroy(h->kev[c][k]);
@@ -222,9 +187,9 @@ int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fa
 
 // one p.stepSimulation() for the environments [e0, e0+ne): build + solve
 static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st) {
-  hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active);
+  h->V->build(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active, h->overflow_dev);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active);
+  h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -242,8 +207,7 @@ static int launch_chunked(agx_handle h, int n_substeps, const float* act, float*
     if (nc > 1) HIPCHK(hipStreamWaitEvent(st, h->fork_ev, 0));
     for (int k = 0; k < n_substeps; k++) { int rc = launch_substep(h, (k == 0) ? act : nullptr, (k == 0) ? dbg : nullptr, e0, ne, st); if (rc) return rc; }
     if (finish) {
-      hipLaunchKernelGGL(agx_finish_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info,
-                         e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
+      h->V->finish(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
       HIPCHK(hipGetLastError());
     }
     if (nc > 1) { HIPCHK(hipEventRecord(h->join_ev[c], st)); HIPCHK(hipStreamWaitEvent(user, h->join_ev[c], 0)); }
@@ -282,12 +246,12 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
     int e = 0;
     HIPCHK(hipEventRecord(h->kev[c][e++], st));
     for (int k = 0; k < h->frame_skip; k++) {
-      hipLaunchKernelGGL(agx_build_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr);
+      h->V->build(st, ne, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr, h->overflow_dev);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
-      hipLaunchKernelGGL(agx_solve_kernel, dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr);
+      h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
     }
-    hipLaunchKernelGGL(agx_finish_kernel, dim3(ne), dim3(64), agx::LDS_BYTES, st, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
+    h->V->finish(st, ne, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
     HIPCHK(hipEventRecord(h->kev[c][e++], st));
     HIPCHK(hipGetLastError());
     nev[c] = e;
@@ -307,16 +271,17 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
 int agx_observe(agx_handle h, float* obs, void* stream) {
   if (!h || !obs) return fail(AGX_E_ARG, "agx_observe: bad argument");
   HIPCHK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(agx_observe_kernel, dim3(h->n_envs), dim3(64), agx::LDS_BYTES, (hipStream_t)stream, h->blob_dev, h->state_dev, obs, h->n_envs, h->sw, h->obs_dim);
+  h->V->observe((hipStream_t)stream, h->n_envs, h->blob_dev, h->state_dev, obs, h->sw, h->obs_dim);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
 static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev, const uint8_t* mask_dev, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {
   if (impairment_mode < -2 || impairment_mode > 3 || gender_mode < -1 || gender_mode > 1) return fail(AGX_E_ARG, "reset: bad impairment / gender mode");
-  if (!h->can_sample) return fail(AGX_E_LIMIT, "reset: the reset generator needs a serial 7-DoF arm carrying the end effector");
+  if (!h->can_sample) return fail(AGX_E_LIMIT, "reset: no device-side reset generator for this model (FeedingJaco-type scenes with a serial 7-DoF arm only); "
+                                               "provide post-reset states with agx_set_state / a pool for agx_reset_done");
   HIPCHK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(agx_sample_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->blob_dev, h->state_dev, (unsigned long long)seed,
-                     (const unsigned long long*)seeds_dev, mask_dev, impairment_mode, gender_mode, ik_info_dev, h->episode_dev, h->n_envs, h->sw);
+  h->V->sample((hipStream_t)stream, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
+               gender_mode, ik_info_dev, h->episode_dev, h->sw);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -336,10 +301,28 @@ int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, 
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {
   if (!h || !pool_dev || pool_n <= 0 || !done_dev) return fail(AGX_E_ARG, "agx_reset_done: bad argument");
   HIPCHK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(agx_reset_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->state_dev, pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->sw);
+  hipLaunchKernelGGL(agx_reset_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->state_dev, pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->sw, h->env_offset);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
+
+int agx_set_env_offset(agx_handle h, long long env_offset) {
+  if (!h || env_offset < 0) return fail(AGX_E_ARG, "agx_set_env_offset: bad argument");
+  h->env_offset = env_offset; return AGX_OK;
+}
+int agx_overflow_count(agx_handle h, int* out) {
+  if (!h || !out) return fail(AGX_E_ARG, "agx_overflow_count: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(out, h->overflow_dev, 4, hipMemcpyDeviceToHost));
+  return AGX_OK;
+}
+int agx_debug_layout(agx_handle h, int* out8) {
+  if (!h || !out8) return fail(AGX_E_ARG, "agx_debug_layout: bad argument");
+  const agx_variant* V = h->V;
+  out8[0] = V->dbg_words; out8[1] = V->dbg_con; out8[2] = V->dbg_minv; out8[3] = V->max_dof; out8[4] = V->dbg_hdr; out8[5] = V->dbg_lam; out8[6] = V->dbg_time; out8[7] = V->dbg_qdd;
+  return AGX_OK;
+}
+const char* agx_variant_name(agx_handle h) { return h ? h->V->name : ""; }
 
 int agx_step_host(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info) {
   if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step_host: bad argument");

@@ -1,5 +1,5 @@
 // agx_collide.h -- K2/K3 collision: speculative AABBs, pair-group broadphase, per-lane GJK narrowphase, contact selection.
-// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+// Part of the stepper (see agx_step.h for the overview); included by agx_step.h only.
 #pragma once
 
 namespace agx {
@@ -138,7 +138,7 @@ AGX_DEV bool face_point(const Ctx& c, int ca, int cb, int e, v3 p0, Cand& out) {
   out.n = mk3(0.f, 0.f, 1.f); out.pa = mk3(pick.x, pick.y, pick.z - ra); out.pb = mk3(pick.x, pick.y, top); out.dist = pick.z - ra - top;
   return true;
 }
-struct CollideState { int ncon, near_mask, overflow, maxc; };
+struct CollideState { int ncon, near_mask, overflow, maxc, nqpt; };
 // the pair-group table, one group per lane (lane g = group g): read from the blob once per substep and
 // broadcast with v_readlane where a group's parameters are needed (a dependent blob load costs an L2 trip)
 struct GroupRegs { int a0, a1, b0, b1, flags, keep; float alo[3], ahi[3], blo[3], bhi[3]; };   // + union boxes of the two collider ranges
@@ -214,8 +214,20 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
       cd[0] = k.gap; st3(cd + 1, k.pa); st3(cd + 4, k.n); cd[7] = k.dist;
     }
     // a manifold point exists: what getContactPoints(food, human) reports (agent.py:100-116)
-    const bool mq = has && near && (GRI(c, g, AGX_G_FLAGS) & 2) && CLI(c, a, AGX_C_TAG) == AGX_TAG_FOOD;
-    if (wave_any(mq)) { any_manifold_query = true; for (int f = 0; f < c.nfood; f++) if (wave_any(mq && CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - food0 == f)) cs.near_mask |= 1 << f; }
+    if constexpr (TASK == AGX_TASK_FEEDING) {
+      const bool mq = has && near && (GRI(c, g, AGX_G_FLAGS) & 2) && CLI(c, a, AGX_C_TAG) == AGX_TAG_FOOD;
+      if (wave_any(mq)) { any_manifold_query = true; for (int f = 0; f < c.nfood; f++) if (wave_any(mq && CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - food0 == f)) cs.near_mask |= 1 << f; }
+    }
+    if constexpr (TASK == AGX_TASK_BED_BATHING) {
+      // manifold points of the wiping pad on the human: what tool.get_contact_points(human) reports for linkA == 1,
+      // whether or not they carry force (bed_bathing.py:47-58); the point on the human and the human's link go to the finish kernel
+      const bool qp = has && near && (GRI(c, g, AGX_G_FLAGS) & 2) && CLI(c, a, AGX_C_TAG) == AGX_TAG_TOOL && CLI(c, a, AGX_C_LINK) == TKI(c, AGX_T_PAD_LINK) &&
+                      CLI(c, b, AGX_C_TAG) == AGX_TAG_HUMAN;
+      const uint64_t qm = wave_ballot(qp);
+      const int slot = cs.nqpt + wave_rank(qm);
+      if (qp && slot < MAX_QPT) { float* o = c.gqpt + QPT_STRIDE * slot; st3(o, k.pb); ((int*)o)[3] = CLI(c, b, AGX_C_LINK); }
+      cs.nqpt += popc64(qm);
+    }
   }
   (void)any_manifold_query;
   wave_sync();
@@ -320,7 +332,7 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gfl
 AGX_DEV void collide(Ctx& c) {
   float* L = c.lds; float* AB = L + L_ARENA; const int lane = c.lane;
   const float brk = PRM(c, AGX_P_CONTACT_BREAK), slack = PRM(c, AGX_P_CONTACT_SLACK);
-  CollideState cs; cs.ncon = 0; cs.near_mask = 0; cs.overflow = 0;
+  CollideState cs; cs.ncon = 0; cs.near_mask = 0; cs.overflow = 0; cs.nqpt = 0;
   cs.maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (cs.maxc > MAX_CON) cs.maxc = MAX_CON;
   long long ct0 = c.timing ? wave_clock() : 0, ct1;
 #define AGX_CTICK(k) if (c.timing) { ct1 = wave_clock(); c.tm[k] += ct1 - ct0; ct0 = ct1; }
@@ -363,7 +375,10 @@ AGX_DEV void collide(Ctx& c) {
       G.flags = GRI(c, g, AGX_G_FLAGS); G.keep = GRI(c, g, AGX_G_KEEP);
       const int a0 = G.a0, a1 = G.a1, b0 = G.b0, b1 = G.b1;
       const float mg = (G.flags & 2) ? brk : slack;
-      if (a1 > a0 && b1 > b0) {
+      // bit3 / bit4: male / female only; bit5: only while some human DoF is dynamic
+      const bool wanted = !((G.flags & 8) && gender != 0) && !((G.flags & 16) && gender != 1) &&
+                          !((G.flags & 32) && ((~c.frozen >> c.nrobot) & ((1 << c.nhdof) - 1)) == 0);
+      if (a1 > a0 && b1 > b0 && wanted) {
         float alo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ahi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         for (int i = a0; i < a1; i++) for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], AB[ABS * i + k]); ahi[k] = fmaxf(ahi[k], AB[ABS * i + 3 + k]); }
         for (int i = b0; i < b1; i++) for (int k = 0; k < 3; k++) { blo[k] = fminf(blo[k], AB[ABS * i + k]); bhi[k] = fmaxf(bhi[k], AB[ABS * i + 3 + k]); }
@@ -411,7 +426,7 @@ AGX_DEV void collide(Ctx& c) {
     collide_flush(c, wn, cs, brk, slack, G); wn = 0;
     ct0 = c.timing ? wave_clock() : 0;
   }
-  c.ncon = cs.ncon; c.near_mask = cs.near_mask; c.overflow = cs.overflow;
+  c.ncon = cs.ncon; c.near_mask = cs.near_mask; c.overflow = cs.overflow; c.nqpt = cs.nqpt < MAX_QPT ? cs.nqpt : MAX_QPT;
   wave_sync();
 #undef AGX_CTICK
 }

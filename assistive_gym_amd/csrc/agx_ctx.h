@@ -1,11 +1,28 @@
 // agx_ctx.h -- compile-time limits, the LDS / scratch layouts, the per-lane context and blob accessors.
-// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+// Part of the stepper (see agx_step.h for the overview); included by agx_step.h only.
 #pragma once
 
 namespace agx {
 
-constexpr int MAX_DOF = 16;
-constexpr int MAX_FREE = 10;
+// A variant of the kernels is compiled per task (agx_kernels.hip is built once per variant); the limits below size
+// its LDS / register footprint.  Defaults = FeedingJaco (10 robot + 4 head DoFs, tool + bowl + 8 particles).
+#ifndef AGX_MAX_DOF
+#define AGX_MAX_DOF 16
+#endif
+#ifndef AGX_MAX_FREE
+#define AGX_MAX_FREE 10
+#endif
+#ifndef AGX_MAX_BLOCK      // DoFs of the largest articulated body (robot or human chain): M^-1 is block diagonal
+#define AGX_MAX_BLOCK 10
+#endif
+#ifndef AGX_TASK           // AGX_TASK_* of include/agx_blob.h: the task layer compiled into the finish / observe kernels
+#define AGX_TASK 0
+#endif
+#define AGX_HAS_SAMPLER (AGX_TASK == 0)   // the device-side reset generator (agx_reset.h) exists for FeedingJaco only
+constexpr int MAX_DOF = AGX_MAX_DOF;
+constexpr int MAX_FREE = AGX_MAX_FREE;
+constexpr int MAX_BLOCK = AGX_MAX_BLOCK;
+constexpr int TASK = AGX_TASK;
 constexpr int MAX_HUMAN = 20;
 constexpr int MAX_CON = 64;
 constexpr int MAX_ROWS = 160;
@@ -13,6 +30,7 @@ constexpr int ST_WORDS = 336;
 constexpr int CON_STRIDE = 16;
 constexpr int HDR_STRIDE = 10;
 constexpr int ARENA_WORDS = 3592;
+constexpr int MAX_QPT = 16;                              // manifold points of the (wiping pad, human) pairs handed to the finish kernel
 constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
 
 // ---- LDS layout (float words) -------------------------------------------------------------
@@ -27,7 +45,8 @@ constexpr int L_FIINV = L_FREER + MAX_FREE * 9;          // [MAX_FREE][9]
 constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
 constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
 constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
-constexpr int L_WMAG = L_MISC + 32;                      // |angular velocity| per moving body: links [MAX_DOF], free bodies [MAX_FREE]
+constexpr int MISC_WORDS = (15 + MAX_DOF + 7) / 8 * 8;
+constexpr int L_WMAG = L_MISC + MISC_WORDS;                      // |angular velocity| per moving body: links [MAX_DOF], free bodies [MAX_FREE]
 constexpr int L_ARENA = L_WMAG + 32;                     // contact records live in the per-env global scratch, not in LDS
 static_assert(MAX_DOF + MAX_FREE <= 32, "angular speed table");
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
@@ -58,8 +77,8 @@ constexpr int A_ACC = A_PA + MAX_DOF * 6;
 constexpr int A_DINV = A_ACC + MAX_DOF * 6;              // [MAX_DOF]
 constexpr int A_UU = A_DINV + MAX_DOF;
 constexpr int A_QDD = A_UU + MAX_DOF;
-constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_DOF][6] M^-1 column workspace
-constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_DOF * 6 + MAX_DOF * MAX_DOF;
+constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_BLOCK][6] M^-1 column workspace (links of the lane's own articulated body)
+constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_BLOCK * 6 + MAX_DOF * MAX_BLOCK;
 static_assert(A_DYN_END <= ARENA_WORDS, "dynamics workspace exceeds the arena");
 // arena, collision phase: world AABBs [ncoll][6]
 constexpr int MAX_COLL = 256;
@@ -69,12 +88,16 @@ constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
 // contact record
 constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 10, C_DIST = 13, C_MU = 14, C_LAM = 15;
 // row header
-constexpr int DBG_HDR = 16 + MAX_CON * CON_STRIDE + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE, DBG_TIME = DBG_LAM + MAX_ROWS, DBG_WORDS = DBG_TIME + 16;
+constexpr int DBG_CON = 16, DBG_MINV = DBG_CON + MAX_CON * CON_STRIDE, DBG_HDR = DBG_MINV + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE,
+              DBG_TIME = DBG_LAM + MAX_ROWS, DBG_QDD = DBG_TIME + 16, DBG_WORDS = DBG_QDD + MAX_DOF;
 // per-environment scratch record in HBM (L2-resident while its environment is being solved)
 constexpr int SCR_ENT = 4096, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
+constexpr int QPT_STRIDE = 4;                            // manifold query point: position on the human (3), PyBullet link of the human collider (int)
+constexpr int SCR_QPT = TASK == AGX_TASK_BED_BATHING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
-constexpr int SCR_WORDS = SCR_O_META + SCR_META;
-constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5;
+constexpr int SCR_O_QPT = SCR_O_META + SCR_META;
+constexpr int SCR_WORDS = SCR_O_QPT + SCR_QPT;
+constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
 constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)
 
@@ -90,6 +113,7 @@ struct Ctx {
   int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
   float dt;
   int ncon, nrows, first_normal, near_mask, overflow;
+  float* gqpt; int nqpt;   // bed bathing: manifold points of the (wiping pad, human) pairs (bed_bathing.py:47-58), per-env scratch
   float* dbg;   // optional debug sink (parity tests)
   float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
   int nent;             // (J,B) pairs written by build_rows (entry 0 is the zero pair)
@@ -123,7 +147,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
   c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
   c.dt = PRM(c, AGX_P_DT);
-  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr;
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 

@@ -1,5 +1,5 @@
 // agx_dyn.h -- K1 kinematics, K4 articulated-body algorithm + M^-1, unconstrained velocity update.
-// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+// Part of the stepper (see agx_step.h for the overview); included by agx_step.h only.
 #pragma once
 
 namespace agx {
@@ -16,9 +16,11 @@ AGX_DEV void kinematics(Ctx& c) {
     v3 tp = mk3(RBF(c, d, AGX_R_TPOS), RBF(c, d, AGX_R_TPOS + 1), RBF(c, d, AGX_R_TPOS + 2));
     m3 Rt = quat_to_m3(RBF(c, d, AGX_R_TQUAT), RBF(c, d, AGX_R_TQUAT + 1), RBF(c, d, AGX_R_TQUAT + 2), RBF(c, d, AGX_R_TQUAT + 3));
     v3 ax = mk3(RBF(c, d, AGX_R_AXIS), RBF(c, d, AGX_R_AXIS + 1), RBF(c, d, AGX_R_AXIS + 2));
-    m3 Rq = axis_angle_m3(ax, L[L_ST + c.s_q + d]);
-    m3 R = mul(mul(PR, Rt), Rq);
+    const bool prismatic = RBI(c, d, AGX_R_JTYPE) == 1;
+    const float qj = L[L_ST + c.s_q + d];
+    m3 R = mul(PR, Rt);
     v3 p = mul(PR, tp) + pp;
+    if (prismatic) p = p + qj * mul(R, ax); else R = mul(R, axis_angle_m3(ax, qj));
     wave_sync();
     if (lane == 0) { st3(L + L_LINKP + 3 * d, p); stm3(L + L_LINKR + 9 * d, R); }
     wave_sync();
@@ -38,8 +40,9 @@ AGX_DEV void kinematics(Ctx& c) {
     const int d = lane;
     v3 p = ld3(L + L_LINKP + 3 * d) - ref; m3 R = ldm3(L + L_LINKR + 9 * d);
     v3 aw = mul(R, mk3(RBF(c, d, AGX_R_AXIS), RBF(c, d, AGX_R_AXIS + 1), RBF(c, d, AGX_R_AXIS + 2)));
-    v3 pxa = cross(p, aw);
-    st3(L + L_S + 6 * d, aw); st3(L + L_S + 6 * d + 3, pxa);
+    // joint screw (angular; linear at the ref point): revolute (a, p x a), prismatic (0, a)
+    if (RBI(c, d, AGX_R_JTYPE) == 1) { st3(L + L_S + 6 * d, mk3(0.f, 0.f, 0.f)); st3(L + L_S + 6 * d + 3, aw); }
+    else { st3(L + L_S + 6 * d, aw); st3(L + L_S + 6 * d + 3, cross(p, aw)); }
     v3 cw = mul(R, mk3(RBF(c, d, AGX_R_COM), RBF(c, d, AGX_R_COM + 1), RBF(c, d, AGX_R_COM + 2))) + p;
     st3(A + A_COMW + 3 * d, cw);
     m3 Il;
@@ -140,28 +143,31 @@ AGX_DEV void aba_and_minv(Ctx& c) {
     if (lane == 0) { A[A_QDD + d] = qdd; for (int k = 0; k < 6; k++) A[A_ACC + 6 * d + k] = ap[k] + L[L_S + 6 * d + k] * qdd; }
     wave_sync();
   }
-  // M^-1: lane j = response to a unit force on joint j (Bullet: calcAccelerationDeltasMultiDof)
+  // M^-1: lane j = response to a unit force on joint j (Bullet: calcAccelerationDeltasMultiDof).  M^-1 is block diagonal
+  // (robot, human chain): a lane walks the links of its own articulated body only; cross-block entries are zero.
   if (lane < n) {
-    const int j = lane; float* P = A + A_COLS + j * (MAX_DOF * 6);
-    for (int k = 0; k < n * 6; k++) P[k] = 0.f;
-    float* UU = A + A_COLS + MAX_DOF * MAX_DOF * 6 + j * MAX_DOF;   // per-lane u[] next to the column workspaces
-    for (int d = n - 1; d >= 0; d--) {
-      float u = (d == j ? 1.f : 0.f) - dot6p(L + L_S + 6 * d, P + 6 * d);
-      UU[d] = u;
+    const int j = lane, b0 = j < c.nrobot ? 0 : c.nrobot, b1 = j < c.nrobot ? c.nrobot : n;
+    float* P = A + A_COLS + j * (MAX_BLOCK * 6);
+    for (int k = 0; k < (b1 - b0) * 6; k++) P[k] = 0.f;
+    float* UU = A + A_COLS + MAX_DOF * MAX_BLOCK * 6 + j * MAX_BLOCK;   // per-lane u[] next to the column workspaces
+    for (int d = b1 - 1; d >= b0; d--) {
+      float u = (d == j ? 1.f : 0.f) - dot6p(L + L_S + 6 * d, P + 6 * (d - b0));
+      UU[d - b0] = u;
       int par = RBI(c, d, AGX_R_PARENT);
-      if (par >= 0) { float s = u * A[A_DINV + d]; for (int k = 0; k < 6; k++) P[6 * par + k] += P[6 * d + k] + A[A_U + 6 * d + k] * s; }
+      if (par >= 0) { float s = u * A[A_DINV + d]; for (int k = 0; k < 6; k++) P[6 * (par - b0) + k] += P[6 * (d - b0) + k] + A[A_U + 6 * d + k] * s; }
     }
     // reuse P as the acceleration workspace
-    for (int d = 0; d < n; d++) {
+    for (int d = b0; d < b1; d++) {
       int par = RBI(c, d, AGX_R_PARENT);
-      float ap[6]; for (int k = 0; k < 6; k++) ap[k] = par < 0 ? 0.f : P[6 * par + k];
-      float qdd = (UU[d] - dot6p(A + A_U + 6 * d, ap)) * A[A_DINV + d];
-      for (int k = 0; k < 6; k++) P[6 * d + k] = ap[k] + L[L_S + 6 * d + k] * qdd;
+      float ap[6]; for (int k = 0; k < 6; k++) ap[k] = par < 0 ? 0.f : P[6 * (par - b0) + k];
+      float qdd = (UU[d - b0] - dot6p(A + A_U + 6 * d, ap)) * A[A_DINV + d];
+      for (int k = 0; k < 6; k++) P[6 * (d - b0) + k] = ap[k] + L[L_S + 6 * d + k] * qdd;
       L[L_MINV + d * MAX_DOF + j] = qdd;
     }
+    for (int d = 0; d < n; d++) if (d < b0 || d >= b1) L[L_MINV + d * MAX_DOF + j] = 0.f;
   }
   wave_sync();
-  if (c.dbg && lane < n) { c.dbg[4 + lane] = A[A_QDD + lane]; }
+  if (c.dbg && lane < n) { c.dbg[DBG_QDD + lane] = A[A_QDD + lane]; }
 }
 
 // ---- unconstrained velocity update -------------------------------------------------------------

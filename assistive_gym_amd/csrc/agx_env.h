@@ -1,5 +1,5 @@
 // agx_env.h -- K7 integration and hooks, state load / store, the task layer (observation, food state machine, reward) and the kernel bodies.
-// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+// Part of the stepper (see agx_step.h for the overview); included by agx_step.h only.
 #pragma once
 
 namespace agx {
@@ -40,7 +40,7 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
 AGX_DEV void update_target(Ctx& c) {
   float* L = c.lds;
   wave_sync();
-  if (c.lane == 0) {
+  if (TASK == AGX_TASK_FEEDING && c.lane == 0) {
     const int hl = TKI(c, AGX_T_HEAD_LINK), o = c.gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
     st3(L + L_ST + c.s_env + AGX_E_TARGET, mul(ldm3(L + L_LINKR + 9 * hl), mk3(TKF(c, o), TKF(c, o + 1), TKF(c, o + 2))) + ld3(L + L_LINKP + 3 * hl));
   }
@@ -72,11 +72,46 @@ AGX_DEV uint32_t rng_next(uint32_t& s0, uint32_t& s1) {
   s0 = (uint32_t)x; s1 = (uint32_t)(x >> 32);
   return (uint32_t)(x >> 33) ^ (uint32_t)(x >> 11);
 }
+// pose of the tool frame the task reads: the base frame of the spoon (feeding.py:86), link 1 of the wiper (bed_bathing.py:81)
 AGX_DEV void tool_base_pose(const Ctx& c, v3& p, m3& R) {
   const float* L = c.lds; const int tb = c.bi[AGX_H_TOOL_BODY];
   m3 FR = ldm3(L + L_FREER + 9 * tb); v3 fp = ld3(L + L_ST + c.s_free + 13 * tb);
   p = mul(FR, mk3(FBF(c, tb, AGX_F_REFPOS), FBF(c, tb, AGX_F_REFPOS + 1), FBF(c, tb, AGX_F_REFPOS + 2))) + fp;
   R = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
+  if constexpr (TASK != AGX_TASK_FEEDING) {
+    p = mul(R, mk3(TKF(c, AGX_T_TOOL_OBS_POS), TKF(c, AGX_T_TOOL_OBS_POS + 1), TKF(c, AGX_T_TOOL_OBS_POS + 2))) + p;
+    R = mul(R, quat_to_m3(TKF(c, AGX_T_TOOL_OBS_QUAT), TKF(c, AGX_T_TOOL_OBS_QUAT + 1), TKF(c, AGX_T_TOOL_OBS_QUAT + 2), TKF(c, AGX_T_TOOL_OBS_QUAT + 3)));
+  }
+}
+// BedBathingEnv._get_obs (bed_bathing.py:80-110); every lane computes, lane 0 writes.
+// tool_force = all contacts of the tool, total_force = total_force_on_human, pad_force = tool_force_on_human
+AGX_DEV void observe_bed(const Ctx& c, float tool_force, float total_force, float pad_force, float* gobs) {
+  const float* L = c.lds;
+  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
+  v3 jp[3], jpr[3];
+  for (int k = 0; k < 3; k++) { jp[k] = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + k)); jpr[k] = tmul(BR, jp[k] - bp); }
+  if (c.lane == 0) {
+    int o = 0;
+    gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z;
+    gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+      float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
+      gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
+    }
+    for (int k = 0; k < 3; k++) { gobs[o++] = jpr[k].x; gobs[o++] = jpr[k].y; gobs[o++] = jpr[k].z; }
+    gobs[o++] = tool_force;
+    if (c.coop) {   // human_obs (bed_bathing.py:101-106), in the frame of the human's base (collision body 0)
+      const v3 hb = ld3(L + L_HUMAN); const m3 HR = ldm3(L + L_HUMAN + 3);
+      const v3 sph = tmul(HR, sp - hb); const q4 sqh = m3_to_quat(mul_at(HR, sR));
+      gobs[o++] = sph.x; gobs[o++] = sph.y; gobs[o++] = sph.z;
+      gobs[o++] = sqh.x; gobs[o++] = sqh.y; gobs[o++] = sqh.z; gobs[o++] = sqh.w;
+      for (int d = c.nrobot; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) gobs[o++] = L[L_ST + c.s_q + d];
+      for (int k = 0; k < 3; k++) { const v3 h = tmul(HR, jp[k] - hb); gobs[o++] = h.x; gobs[o++] = h.y; gobs[o++] = h.z; }
+      gobs[o++] = total_force; gobs[o++] = pad_force;
+    }
+  }
 }
 // FeedingEnv._get_obs (feeding.py:85-112), robot part; every lane computes, lane 0 writes
 AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* gobs) {
@@ -123,20 +158,21 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
 //          from L2, integration, mouth-target update -> state
 //   finish (once per step): forces, observation, food state machine, preferences, reward, done.
 // ============================================================================================
-struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; };
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; };
 AGX_DEV Scratch scratch_of(float* base) {
-  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META);
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT;
   return s;
 }
 
 // build: `gaction` non-null on the first substep of an env.step() (take_step, env.py:174-222)
-AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gdebug, float* lds, int lane) {
+// returns the number of contacts dropped by a budget (contact, row or coefficient cap)
+AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gdebug, float* lds, int lane) {
   Ctx c; ctx_init(c, blob, lds, lane);
   c.timing = gdebug != nullptr; c.dbg = gdebug;
   float* L = c.lds; int* Li = c.ldsi;
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
-  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.gqpt = scr.qpt;
   load_env(c, gstate, sw);
   if (gaction) {
     const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP);
@@ -185,15 +221,16 @@ AGX_DEV void env_build(const uint32_t* blob, float* gstate, const float* gaction
 #undef AGX_TICK
   // hand-over to the solve kernel
   for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
-  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; }
+  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; scr.meta[META_NQPT] = c.nqpt; }
   if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
-    if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // [4..4+ndof) = qdd
-    for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[16 + q] = scr.con[q];
-    for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[16 + MAX_CON * CON_STRIDE + q] = L[L_MINV + q];
+    if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // qdd at DBG_QDD
+    for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[DBG_CON + q] = scr.con[q];
+    for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[DBG_MINV + q] = L[L_MINV + q];
     wave_sync();
     for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = scr.hdr[q];
     if (lane == 0) { for (int k = 0; k < 16; k++) if (k != 5 && k != 6 && k != 7) gdebug[DBG_TIME + k] = (float)c.tm[k]; }
   }
+  return c.overflow;
 }
 
 // solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
@@ -224,11 +261,134 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
 AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float* lds, int lane) {
   Ctx c; ctx_init(c, blob, lds, lane);
   load_env(c, gstate, c.bi[AGX_H_STATE_WORDS]);
-  kinematics(c); update_target(c); observe(c, 0.f, 0.f, gobs);
+  kinematics(c); update_target(c);
+  if constexpr (TASK == AGX_TASK_BED_BATHING) observe_bed(c, 0.f, 0.f, 0.f, gobs); else observe(c, 0.f, 0.f, gobs);
+}
+
+// end-effector speed: norm of getLinkState(ee, computeLinkVelocity)[6] (feeding.py:22, bed_bathing.py:19)
+AGX_DEV float ee_speed_of(const Ctx& c) {
+  const float* L = c.lds; const int ee = TKI(c, AGX_T_EE_LINK);
+  float sv[6] = {0, 0, 0, 0, 0, 0};
+  for (int d = ee; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { float qd = L[L_ST + c.s_qd + d]; for (int j = 0; j < 6; j++) sv[j] += L[L_S + 6 * d + j] * qd; }
+  v3 xr = ld3(L + L_MISC + M_EEP) - ld3(L + L_MISC + M_REF);
+  v3 v = mk3(sv[3], sv[4], sv[5]) + cross(mk3(sv[0], sv[1], sv[2]), xr);
+  return sqrtf(dot(v, v));
+}
+
+// finish, bed bathing: everything BedBathingEnv.step does after take_step (bed_bathing.py:15-39)
+AGX_DEV void env_finish_bed(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+                            float* ginfo, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS], act_dim = c.bi[AGX_H_ACT_DIM];
+  Scratch scr = scratch_of(gscratch);
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nqpt = scr.meta[META_NQPT];
+  load_env(c, gstate, sw);
+  float an2 = 0.f;
+  for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
+  wave_sync();
+  kinematics(c);   // poses as the getters of _get_obs see them after the last stepSimulation
+  // get_total_force (bed_bathing.py:41-78) from the last substep's contact impulses:
+  //   total_force_on_human = robot-human + tool-human, tool_force = every contact of the tool,
+  //   tool_force_on_human = (tool link 1, human)
+  float rf = 0.f, tf = 0.f, thf = 0.f, pf = 0.f;
+  if (lane < c.ncon) {
+    const float* k = scr.con + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const int ca = ki[C_CA], cb = ki[C_CB], ta = CLI(c, ca, AGX_C_TAG), tb = CLI(c, cb, AGX_C_TAG);
+    const float f = k[C_LAM] / c.dt;
+    const bool human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
+    if (tool) tf = f;
+    if (human && robot) rf = f;
+    if (human && tool) { thf = f; const int tc = ta == AGX_TAG_TOOL ? ca : cb; if (CLI(c, tc, AGX_C_LINK) == TKI(c, AGX_T_PAD_LINK)) pf = f; }
+  }
+  const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), pad_f = wave_sum(pf), total_f = robot_f + wave_sum(thf);
+  observe_bed(c, tool_f, total_f, pad_f, gobs);
+  // targets wiped by the manifold points of the pad on the human's links (not its base, bed_bathing.py:52-53): lane = target
+  int success = Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS];
+  const int s_task = c.bi[AGX_H_S_TASK];
+  int new_points = 0;
+  {
+    const int g = c.gender, nt = TKI(c, AGX_T_NT + 2 * g) + TKI(c, AGX_T_NT + 2 * g + 1);
+    const float* TT = c.bf + c.bi[AGX_H_OFF_TARGETS] + 4 * g * TKI(c, AGX_T_NT_MAX);
+    const float r2 = TKF(c, AGX_T_TARGET_RADIUS) * TKF(c, AGX_T_TARGET_RADIUS);
+    for (int base = 0; base < nt; base += 64) {
+      const int t = base + lane; bool hit = false;
+      const uint32_t w0 = (uint32_t)Li[L_ST + s_task + AGX_BB_ALIVE + (base >> 5)], w1 = (uint32_t)Li[L_ST + s_task + AGX_BB_ALIVE + (base >> 5) + 1];
+      const uint64_t alive = (uint64_t)w0 | ((uint64_t)w1 << 32);
+      if (t < nt && (alive >> lane & 1)) {
+        const int link = TKI(c, AGX_T_ARM_LINK + ((const int*)TT)[4 * t + 3]);
+        const v3 w = mul(ldm3(L + L_LINKR + 9 * link), ld3(TT + 4 * t)) + ld3(L + L_LINKP + 3 * link);   // update_targets (bed_bathing.py:190-203)
+        for (int q = 0; q < c.nqpt; q++) {
+          const float* o = scr.qpt + QPT_STRIDE * q; const int lb = ((const int*)o)[3];
+          if (lb < 0) continue;
+          const v3 d = ld3(o) - w;
+          if (dot(d, d) < r2) hit = true;
+        }
+      }
+      const uint64_t hm = wave_ballot(hit);
+      new_points += popc64(hm);
+      wave_sync();
+      if (lane == 0) { const uint64_t na = alive & ~hm; Li[L_ST + s_task + AGX_BB_ALIVE + (base >> 5)] = (int)(uint32_t)na; Li[L_ST + s_task + AGX_BB_ALIVE + (base >> 5) + 1] = (int)(uint32_t)(na >> 32); }
+      wave_sync();
+    }
+  }
+  success += new_points;
+  // reward_distance = -min distance tool <-> human within CLOSEST_DIST (bed_bathing.py:23): lane = (tool collider, human collider)
+  float dmin = TKF(c, AGX_T_CLOSEST_DIST);
+  {
+    int t0 = -1, t1 = -1, h0 = -1, h1 = -1;
+    for (int g = 0; g < c.ngroup; g++) {   // the (tool, human) group carries both collider ranges
+      const int a0 = GRI(c, g, AGX_G_A0), b0 = GRI(c, g, AGX_G_B0);
+      if (CLI(c, a0, AGX_C_TAG) == AGX_TAG_TOOL && CLI(c, b0, AGX_C_TAG) == AGX_TAG_HUMAN) {
+        t0 = a0; t1 = GRI(c, g, AGX_G_A1); h0 = b0; h1 = GRI(c, g, AGX_G_B1);
+        if (c.gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { h0 = GRI(c, g, AGX_G_B0F); h1 = GRI(c, g, AGX_G_B1F); }
+        break;
+      }
+    }
+    float* AB = L + L_ARENA;
+    for (int col = t0 + lane; col < t1; col += 64) {   // world AABBs of the tool colliders (narrowphase centres its arithmetic there)
+      m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
+      v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
+      v3 hl = mk3(CLF(c, col, AGX_C_AABB_H), CLF(c, col, AGX_C_AABB_H + 1), CLF(c, col, AGX_C_AABB_H + 2));
+      v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
+      for (int k = 0; k < 3; k++) {
+        float hh = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
+        AB[ABS * col + k] = comp(cw, k) - hh; AB[ABS * col + 3 + k] = comp(cw, k) + hh;
+      }
+    }
+    wave_sync();
+    const int nh = h1 - h0, np = (t1 - t0) * nh;
+    const float lim = dmin;
+    for (int base = 0; base < np; base += 64) {
+      const int p = base + lane; const bool has = p < np;
+      const int ti = has ? p / nh : 0, hi = has ? p - ti * nh : 0;
+      Cand k; k.dist = lim; k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.gap = 0.f;
+      const bool hit = narrowphase(c, t0 + ti, h0 + hi, lim, k, has);
+      dmin = fminf(dmin, wave_min(hit ? k.dist : lim));
+    }
+  }
+  // human_preferences (env.py:237-274), non-feeding branch: forces away from the target area, high forces at the target
+  const float ee_speed = ee_speed_of(c);
+  const float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-(total_f - pad_f)) + TKF(c, AGX_T_C_HF) * (pad_f < 10.f ? 0.f : -pad_f);
+  const float reward = TKF(c, AGX_T_W_DISTANCE) * (-dmin) + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + TKF(c, AGX_T_W_WIPE) * (float)new_points + pref;
+  const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];
+  wave_sync();
+  if (lane == 0) {
+    Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS] = success;
+    *greward = reward;
+    *gdone = (uint8_t)(iteration >= (int)TKF(c, AGX_T_EPISODE_LEN));
+    if (ginfo) {
+      ginfo[AGX_INFO_TOTAL_FORCE] = total_f;
+      ginfo[AGX_INFO_TASK_SUCCESS] = (float)(success >= Li[L_ST + c.s_env + AGX_E_TOTAL_FOOD] * TKF(c, AGX_T_SUCCESS_FRAC));
+      ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = pad_f; ginfo[AGX_INFO_FOOD_REWARD] = (float)new_points;
+      ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
+    }
+  }
+  store_env(c, gstate, sw);
 }
 
 // finish: everything FeedingEnv.step does after take_step (feeding.py:17-43)
-AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
                         float* ginfo, float* lds, int lane) {
   Ctx c; ctx_init(c, blob, lds, lane);
   float* L = c.lds; int* Li = c.ldsi;
@@ -315,16 +475,7 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
   }
   for (int k = 0; k < c.nfood; k++) if ((active_on_entry >> k & 1) && (hit_mask >> k & 1)) { food_hit -= 1.f; active &= ~(1 << k); }
   // end-effector speed (feeding.py:22), human_preferences (env.py:237-274, feeding branch), reward
-  const float* A = L + L_ARENA; (void)A;
-  float ee_speed;
-  {
-    const int ee = TKI(c, AGX_T_EE_LINK);
-    float sv[6] = {0, 0, 0, 0, 0, 0};
-    for (int d = ee; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { float qd = L[L_ST + c.s_qd + d]; for (int j = 0; j < 6; j++) sv[j] += L[L_S + 6 * d + j] * qd; }
-    v3 xr = ld3(L + L_MISC + M_EEP) - ld3(L + L_MISC + M_REF);
-    v3 v = mk3(sv[3], sv[4], sv[5]) + cross(mk3(sv[0], sv[1], sv[2]), xr);
-    ee_speed = sqrtf(dot(v, v));
-  }
+  const float ee_speed = ee_speed_of(c);
   float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-total_f) + TKF(c, AGX_T_C_HF) * (tool_f < 10.f ? 0.f : -tool_f)
              + TKF(c, AGX_T_C_FD) * food_hit + TKF(c, AGX_T_C_FDV) * (-vel_sum);
   v3 sp; m3 sR; tool_base_pose(c, sp, sR);
@@ -345,6 +496,12 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
     }
   }
   store_env(c, gstate, sw);
+}
+
+AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+                        float* ginfo, float* lds, int lane) {
+  if constexpr (TASK == AGX_TASK_BED_BATHING) env_finish_bed(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
+  else env_finish_feeding(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
 }
 
 }  // namespace agx

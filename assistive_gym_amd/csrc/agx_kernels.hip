@@ -1,0 +1,128 @@
+// agx_kernels.hip -- the kernels of ONE variant of the stepper for gfx950.  Built once per variant by
+// assistive_gym_amd/build.py (-DAGX_VARIANT_FEEDING / -DAGX_VARIANT_BED_BATHING select the limits and the task layer);
+// agx_api.hip picks the variant whose task and limits fit the model blob.
+// One workgroup = one wavefront = one environment (64 threads); an env.step() is
+// frame_skip x [build kernel, solve kernel] + finish kernel on one stream.
+#if defined(AGX_VARIANT_BED_BATHING)
+// BedBathingSawyer: 10 Sawyer DoFs + the 10 joints of the human's right arm (dynamic when the impairment is tremor), one free body (wiper)
+#define AGX_MAX_DOF 20
+#define AGX_MAX_FREE 2
+#define AGX_MAX_BLOCK 10
+#define AGX_TASK 1
+#define AGX_VNAME bed_bathing
+#define AGX_K(name) name##_bb
+#elif defined(AGX_VARIANT_FEEDING)
+#define AGX_VNAME feeding
+#define AGX_K(name) name
+#else
+#error "build with -DAGX_VARIANT_FEEDING or -DAGX_VARIANT_BED_BATHING"
+#endif
+
+#include "agx_wave.h"
+#include "agx_step.h"
+#include "agx_variant.h"
+
+namespace {
+
+// build: kinematics, ABA, collision, constraint rows -> scratch.  Register- and LDS-heavy.
+extern "C" __global__ void __launch_bounds__(64, 2)
+AGX_K(agx_build_kernel)(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int env0, int n_envs, int sw, int act_dim,
+                        const uint8_t* __restrict__ active, int* overflow_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = env0 + blockIdx.x;
+  if (env >= n_envs || (active && !active[env])) return;   // `active`: masked settle of agx_reset, null on the step path
+  const int dropped = agx::env_build(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
+                                     debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
+  if (dropped > 0 && threadIdx.x == 0) atomicAdd(overflow_total, dropped);   // contacts dropped by a budget (rare; agx_overflow_count)
+}
+// solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
+extern "C" __global__ void __launch_bounds__(64, 4)
+AGX_K(agx_solve_kernel)(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = env0 + blockIdx.x;
+  if (env >= n_envs || (active && !active[env])) return;
+  agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
+}
+// finish: forces, observation, task state machine, reward, done, info
+extern "C" __global__ void __launch_bounds__(64, 2)
+AGX_K(agx_finish_kernel)(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
+                         float* info, int env0, int n_envs, int sw, int act_dim, int obs_dim) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = env0 + blockIdx.x;
+  if (env >= n_envs) return;
+  agx::env_finish(blob, state + (size_t)env * sw, actions + (size_t)env * act_dim, scratch + (size_t)env * agx::SCR_WORDS, obs + (size_t)env * obs_dim,
+                  reward + env, done + env, info ? info + (size_t)env * AGX_INFO_COUNT : nullptr, lds, (int)threadIdx.x);
+}
+extern "C" __global__ void __launch_bounds__(64, 2)
+AGX_K(agx_observe_kernel)(const uint32_t* __restrict__ blob, float* state, float* obs, int n_envs, int sw, int obs_dim) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  agx::env_observe(blob, state + (size_t)env * sw, obs + (size_t)env * obs_dim, lds, (int)threadIdx.x);
+}
+#if AGX_HAS_SAMPLER
+// reset generator: FeedingEnv.reset's sampling incl. the IK restarts (64 per round, one per lane), float64
+extern "C" __global__ void __launch_bounds__(64)
+AGX_K(agx_sample_kernel)(const uint32_t* __restrict__ blob, float* state, unsigned long long seed0, const unsigned long long* __restrict__ seeds, const uint8_t* __restrict__ mask,
+                         int impairment_mode, int gender_mode, float* info4, int* episode, int n_envs, int sw) {
+  const int env = blockIdx.x;
+  if (env >= n_envs || (mask && !mask[env])) return;
+  const unsigned long long seed = seeds ? seeds[env] : seed0 + (unsigned long long)env;
+  if (threadIdx.x == 0) episode[env] = 0;
+  agx::env_sample(blob, state + (size_t)env * sw, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4 ? info4 + (size_t)env * 4 : nullptr,
+                  (int)threadIdx.x);
+}
+#endif
+
+hipError_t v_init(void) {
+  hipError_t e = hipFuncSetAttribute((const void*)AGX_K(agx_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
+  return e;
+}
+void v_build(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* debug, int e0, int n_envs, int sw, int act_dim,
+             const uint8_t* active, int* overflow_total) {
+  hipLaunchKernelGGL(AGX_K(agx_build_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, debug, e0, n_envs, sw, act_dim, active, overflow_total);
+}
+void v_solve(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active) {
+  hipLaunchKernelGGL(AGX_K(agx_solve_kernel), dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, blob, state, scratch, debug, e0, n_envs, sw, active);
+}
+void v_finish(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done, float* info,
+              int e0, int n_envs, int sw, int act_dim, int obs_dim) {
+  hipLaunchKernelGGL(AGX_K(agx_finish_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, obs, reward, done, info, e0, n_envs, sw, act_dim, obs_dim);
+}
+void v_observe(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim) {
+  hipLaunchKernelGGL(AGX_K(agx_observe_kernel), dim3(n_envs), dim3(64), agx::LDS_BYTES, st, blob, state, obs, n_envs, sw, obs_dim);
+}
+#if AGX_HAS_SAMPLER
+void v_sample(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
+              int impairment_mode, int gender_mode, float* info4, int* episode, int sw) {
+  hipLaunchKernelGGL(AGX_K(agx_sample_kernel), dim3(n_envs), dim3(64), 0, st, blob, state, seed0, seeds, mask, impairment_mode, gender_mode, info4, episode, n_envs, sw);
+}
+#endif
+
+#define AGX_STR2_(x) #x
+#define AGX_STR_(x) AGX_STR2_(x)
+const agx_variant g_variant = {
+  AGX_STR_(AGX_VNAME), agx::TASK,
+  agx::MAX_DOF, agx::MAX_FREE, agx::MAX_BLOCK, agx::MAX_HUMAN, agx::MAX_COLL, agx::ST_WORDS, agx::MAX_CON, agx::MAX_ROWS,
+  agx::LDS_BYTES, agx::LDS_SOLVE_BYTES, agx::SCR_WORDS, agx::DBG_WORDS,
+  agx::DBG_CON, agx::DBG_MINV, agx::DBG_HDR, agx::DBG_LAM, agx::DBG_TIME, agx::DBG_QDD,
+#if AGX_HAS_SAMPLER
+  agx::RS_NARM,
+#else
+  0,
+#endif
+  v_init, v_build, v_solve, v_finish, v_observe,
+#if AGX_HAS_SAMPLER
+  v_sample
+#else
+  nullptr
+#endif
+};
+
+}  // namespace
+
+#define AGX_CAT2_(a, b) a##b
+#define AGX_CAT_(a, b) AGX_CAT2_(a, b)
+extern "C" const agx_variant* AGX_CAT_(agx_variant_, AGX_VNAME)(void) { return &g_variant; }

@@ -1,5 +1,5 @@
 // agx_rows.h -- K5 constraint rows: motors, joint limits, tool constraint, contact normal + friction; B = M^-1 J^T.
-// Part of the FeedingJaco stepper (see agx_step.h for the overview); included by agx_step.h only.
+// Part of the stepper (see agx_step.h for the overview); included by agx_step.h only.
 #pragma once
 
 namespace agx {
@@ -99,94 +99,99 @@ AGX_DEV void m3_to_euler_xyz(const m3& M, float* e) {
   else { e[0] = atan2f(R[3], R[4]); e[1] = 1.57079632679f; e[2] = 0; }
 }
 
+// Non-contact row slots, in row order (the oracle builds them in the same order): motors of DoF 0..MAX_DOF-1, joint limits
+// (DoF, side), the 6 rows of the tool constraint.  One lane per slot, NC_PASSES passes of 64 slots.
+constexpr int NC_SLOTS = 3 * MAX_DOF + 6, NC_PASSES = (NC_SLOTS + 63) / 64;
 AGX_DEV void build_rows(Ctx& c) {
   float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
   const float erp = PRM(c, AGX_P_ERP), cerp = PRM(c, AGX_P_CONTACT_ERP);
   int maxrows = (int)PRM(c, AGX_P_MAX_ROWS); if (maxrows > MAX_ROWS) maxrows = MAX_ROWS;
   int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > SCR_ENT / 2) maxent = SCR_ENT / 2;
-  // --- non-contact rows: lanes 0..15 motors, 16..47 joint limits (dof, side), 48..53 tool constraint
-  RowGeom r; row_clear(r);
-  bool active = false; float bterm = 0.f, lo = 0.f, hi = 0.f;
-  if (lane < 16) {
-    const int d = lane;
-    if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f && !(c.frozen >> d & 1)) {
-      active = true; if (d < c.nrobot) r.robot = true; else r.human = true;
-      _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? 1.f : 0.f;
-      // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
-      bterm = RBF(c, d, AGX_R_KP) * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
-      float lim = RBF(c, d, AGX_R_MAXF) * dt; lo = -lim; hi = lim;
-    }
-  } else if (lane < 48) {
-    const int d = (lane - 16) >> 1, side = (lane - 16) & 1;
-    if (d < n && RBI(c, d, AGX_R_HAS_LIMIT) && !(c.frozen >> d & 1)) {
-      float q = L[L_ST + c.s_q + d];
-      float gap = side == 0 ? q - DLO(c, d) : DHI(c, d) - q;
-      if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
-        active = true; if (d < c.nrobot) r.robot = true; else r.human = true;
-        const float sg = side == 0 ? 1.f : -1.f;
-        _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) r.Jr[q] = (q == d) ? sg : 0.f;
-        float rv = sg * L[L_VEL + d];
-        bterm = gap > 0 ? (-gap / dt - rv) : (-gap * erp / dt - rv);
-        lo = 0.f; hi = 1e30f;
-      }
-    }
-  } else if (lane < 54) {
-    // tool fixed constraint (tool.py:46-47)
-    const int k = lane - 48; active = true;
-    v3 eep = ld3(L + L_MISC + M_EEP); m3 eeR = ldm3(L + L_MISC + M_EER);
-    v3 pivA = mul(eeR, mk3(TKF(c, AGX_T_TOOL_POS), TKF(c, AGX_T_TOOL_POS + 1), TKF(c, AGX_T_TOOL_POS + 2))) + eep;
-    m3 frameA = mul(eeR, quat_to_m3(TKF(c, AGX_T_TOOL_QUAT), TKF(c, AGX_T_TOOL_QUAT + 1), TKF(c, AGX_T_TOOL_QUAT + 2), TKF(c, AGX_T_TOOL_QUAT + 3)));
-    const int tb = c.bi[AGX_H_TOOL_BODY];
-    v3 pivB = ld3(L + L_ST + c.s_free + 13 * tb); m3 frameB = ldm3(L + L_FREER + 9 * tb);
-    float lim = TKF(c, AGX_T_TOOL_MAXF) * dt; lo = -lim; hi = lim;
-    const int link = TKI(c, AGX_T_EE_LINK);
-    if (k < 3) {
-      v3 nrm = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
-      row_pair(c, r, link, pivA, AGX_BODY_FREE0 + tb, pivB, nrm, mk3(0, 0, 0));
-      bterm = -comp(pivA - pivB, k) * erp / dt - row_velocity(c, r);
-    } else {
-      float ang[3]; m3_to_euler_xyz(mul_at(frameA, frameB), ang);
-      const int q = k - 3;
-      v3 axw = mk3(frameA.a[q], frameA.a[3 + q], frameA.a[6 + q]);
-      row_pair(c, r, link, pivA, AGX_BODY_FREE0 + tb, pivB, mk3(0, 0, 0), axw);
-      bterm = ang[q] * erp / dt - row_velocity(c, r);
-    }
-  }
-  int cnt = active ? row_entries(c, r) : 0;
-  uint64_t am = wave_ballot(active);
-  int row = wave_rank(am), off = 1 + wave_scan_excl(cnt);      // entry 0 of the arena is the zero pair
-  int nnc = popc64(am), ent = 1 + wave_sum_i(cnt);
-  wave_sync();
-  if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }
-  // --- contact rows: lane = contact; normal rows first, then one friction row per contact
-  int nc = c.ncon;
-  const bool has = lane < nc;
+  if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }               // entry 0 of the arena is the zero pair
+  int nnc = 0, ent = 1;                                         // non-contact rows / coefficient pairs so far
+  // contact rows: lane = contact; normal rows first, then one friction row per contact
+  int nc = c.ncon, ccnt = 0, cincl = 0, tot = 0, entN = 0, entF = 0;
   int ba = 0, bb = 0; v3 pa = mk3(0, 0, 0), pb = pa, nn = pa; float dist = 0.f, mu = 0.f;
   RowGeom rn; row_clear(rn);
-  if (has) {
-    const float* k = c.gcon + CON_STRIDE * lane; const int* ki = (const int*)k;
-    ba = ki[C_BA]; bb = ki[C_BB]; pa = ld3(k + C_PA); pb = ld3(k + C_PB); nn = ld3(k + C_N); dist = k[C_DIST]; mu = k[C_MU];
-    row_pair(c, rn, ba, pa, bb, pb, nn, mk3(0, 0, 0));
-  }
-  int ccnt = has ? row_entries(c, rn) : 0;
-  int cincl = wave_scan_excl(ccnt) + ccnt;
-  // largest prefix of the contact list that fits the row and coefficient budgets
-  bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent);
-  nc = popc64(wave_ballot(fits));
-  const int tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0);
-  const int entN = ent, entF = ent + (nc > 0 ? tot : 0);
-  // the three row kinds go through ONE row_store call site (its M^-1 J^T product is the bulk of this
-  // phase's code): kind 0 non-contact, 1 contact normal, 2 contact friction
-  _Pragma("nounroll") for (int kind = 0; kind < 3; kind++) {
-    RowGeom R; int rrow = 0, roff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
-    if (kind == 0) {
-      R = r; go = active; rrow = row; roff = off; rb = bterm; rlo = lo; rhi = hi;
-    } else if (kind == 1) {
+  // the row kinds go through ONE row_store call site (its M^-1 J^T product is the bulk of this phase's code):
+  // phases [0, NC_PASSES) non-contact slots, NC_PASSES contact normals, NC_PASSES + 1 contact friction
+  _Pragma("nounroll") for (int ph = 0; ph < NC_PASSES + 2; ph++) {
+    RowGeom R; row_clear(R);
+    int rrow = 0, roff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
+    if (ph < NC_PASSES) {
+      const int slot = 64 * ph + lane;
+      if (slot < MAX_DOF) {
+        const int d = slot;
+        if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f && !(c.frozen >> d & 1)) {
+          go = true; if (d < c.nrobot) R.robot = true; else R.human = true;
+          _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) R.Jr[q] = (q == d) ? 1.f : 0.f;
+          // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
+          rb = RBF(c, d, AGX_R_KP) * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
+          float lim = RBF(c, d, AGX_R_MAXF) * dt; rlo = -lim; rhi = lim;
+        }
+      } else if (slot < 3 * MAX_DOF) {
+        const int d = (slot - MAX_DOF) >> 1, side = (slot - MAX_DOF) & 1;
+        if (d < n && RBI(c, d, AGX_R_HAS_LIMIT) && !(c.frozen >> d & 1)) {
+          float q = L[L_ST + c.s_q + d];
+          float gap = side == 0 ? q - DLO(c, d) : DHI(c, d) - q;
+          if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
+            go = true; if (d < c.nrobot) R.robot = true; else R.human = true;
+            const float sg = side == 0 ? 1.f : -1.f;
+            _Pragma("unroll") for (int q2 = 0; q2 < MAX_DOF; q2++) R.Jr[q2] = (q2 == d) ? sg : 0.f;
+            float rv = sg * L[L_VEL + d];
+            rb = gap > 0 ? (-gap / dt - rv) : (-gap * erp / dt - rv);
+            rlo = 0.f; rhi = 1e30f;
+          }
+        }
+      } else if (slot < NC_SLOTS) {
+        // tool fixed constraint (tool.py:46-47): parent frame = end-effector frame o tool offset, child frame = the tool's
+        // base (URDF root link) frame
+        const int k = slot - 3 * MAX_DOF; go = true;
+        v3 eep = ld3(L + L_MISC + M_EEP); m3 eeR = ldm3(L + L_MISC + M_EER);
+        v3 pivA = mul(eeR, mk3(TKF(c, AGX_T_TOOL_POS), TKF(c, AGX_T_TOOL_POS + 1), TKF(c, AGX_T_TOOL_POS + 2))) + eep;
+        m3 frameA = mul(eeR, quat_to_m3(TKF(c, AGX_T_TOOL_QUAT), TKF(c, AGX_T_TOOL_QUAT + 1), TKF(c, AGX_T_TOOL_QUAT + 2), TKF(c, AGX_T_TOOL_QUAT + 3)));
+        const int tb = c.bi[AGX_H_TOOL_BODY];
+        const m3 FR = ldm3(L + L_FREER + 9 * tb);
+        v3 pivB = mul(FR, mk3(FBF(c, tb, AGX_F_REFPOS), FBF(c, tb, AGX_F_REFPOS + 1), FBF(c, tb, AGX_F_REFPOS + 2))) + ld3(L + L_ST + c.s_free + 13 * tb);
+        m3 frameB = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
+        float lim = TKF(c, AGX_T_TOOL_MAXF) * dt; rlo = -lim; rhi = lim;
+        const int link = TKI(c, AGX_T_EE_LINK);
+        if (k < 3) {
+          v3 nrm = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
+          row_pair(c, R, link, pivA, AGX_BODY_FREE0 + tb, pivB, nrm, mk3(0, 0, 0));
+          rb = -comp(pivA - pivB, k) * erp / dt - row_velocity(c, R);
+        } else {
+          float ang[3]; m3_to_euler_xyz(mul_at(frameA, frameB), ang);
+          const int q = k - 3;
+          v3 axw = mk3(frameA.a[q], frameA.a[3 + q], frameA.a[6 + q]);
+          row_pair(c, R, link, pivA, AGX_BODY_FREE0 + tb, pivB, mk3(0, 0, 0), axw);
+          rb = ang[q] * erp / dt - row_velocity(c, R);
+        }
+      }
+      const int cnt = go ? row_entries(c, R) : 0;
+      const uint64_t am = wave_ballot(go);
+      rrow = nnc + wave_rank(am); roff = ent + wave_scan_excl(cnt);
+      nnc += popc64(am); ent += wave_sum_i(cnt);
+    } else if (ph == NC_PASSES) {
+      const bool has = lane < nc;
+      if (has) {
+        const float* k = c.gcon + CON_STRIDE * lane; const int* ki = (const int*)k;
+        ba = ki[C_BA]; bb = ki[C_BB]; pa = ld3(k + C_PA); pb = ld3(k + C_PB); nn = ld3(k + C_N); dist = k[C_DIST]; mu = k[C_MU];
+        row_pair(c, rn, ba, pa, bb, pb, nn, mk3(0, 0, 0));
+      }
+      ccnt = has ? row_entries(c, rn) : 0;
+      cincl = wave_scan_excl(ccnt) + ccnt;
+      // largest prefix of the contact list that fits the row and coefficient budgets; the contacts beyond it are
+      // dropped and counted as overflow
+      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent);
+      const int kept = popc64(wave_ballot(fits));
+      c.overflow += nc - kept; nc = kept;
+      tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0);
+      entN = ent; entF = ent + (nc > 0 ? tot : 0);
       R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rlo = 0.f; rhi = 1e30f;
       if (go) { const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv); }
     } else {
       go = lane < nc; rrow = nnc + nc + lane; roff = entF + cincl - ccnt; rfric = nnc + lane; rmu = mu;
-      row_clear(R);
       if (go) {
         // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
         v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);

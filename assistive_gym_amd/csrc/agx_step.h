@@ -1,4 +1,5 @@
-// agx_step.h -- the batched FeedingJaco stepper: ONE WAVEFRONT PER ENVIRONMENT.
+// agx_step.h -- the batched stepper: ONE WAVEFRONT PER ENVIRONMENT.  (Compiled once per variant: limits + task layer, see
+// agx_kernels.hip; the citations below are for the FeedingJaco variant, bed_bathing.py has the same structure.)
 //
 // Replaces, for N lock-stepped environments, what the reference does per env.step():
 //   AssistiveEnv.take_step         assistive_gym/envs/env.py:174-235   (action -> motor targets,
@@ -29,4 +30,6 @@
 #include "agx_rows.h"
 #include "agx_pgs.h"
 #include "agx_env.h"
+#if AGX_HAS_SAMPLER
 #include "agx_reset.h"
+#endif

@@ -1,0 +1,28 @@
+// agx_variant.h -- what one compiled variant of the kernels (agx_kernels.hip built with one set of limits and one task
+// layer) exposes to the handle code of agx_api.hip: its limits, its LDS / scratch / debug layout and its launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct agx_variant {
+  const char* name;
+  int task_kind;                         // AGX_TASK_* the finish / observe kernels are compiled for
+  int max_dof, max_free, max_block, max_human, max_coll, st_words, max_con, max_rows;
+  int lds_bytes, lds_solve_bytes, scr_words, dbg_words;
+  int dbg_con, dbg_minv, dbg_hdr, dbg_lam, dbg_time, dbg_qdd;     // debug record layout (agx_debug_layout)
+  int rs_narm;                           // arm DoFs the reset generator's IK is compiled for, 0 = no reset generator in this variant
+  // one-time kernel attribute set-up (dynamic LDS sizes)
+  hipError_t (*init)(void);
+  // launchers: grid = ne workgroups of one wavefront, environments [e0, e0 + ne)
+  void (*build)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* debug, int e0, int n_envs, int sw,
+                int act_dim, const uint8_t* active, int* overflow_total);
+  void (*solve)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active);
+  void (*finish)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
+                 float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim);
+  void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim);
+  void (*sample)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
+                 int impairment_mode, int gender_mode, float* info4, int* episode, int sw);   // null without a reset generator
+};
+
+extern "C" const agx_variant* agx_variant_feeding(void);
+extern "C" const agx_variant* agx_variant_bed_bathing(void);

@@ -14,7 +14,7 @@ _LIB = None
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
-           'agx_synchronize', 'agx_selftest']
+           'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset']
 
 
 class AgxError(RuntimeError):
@@ -29,6 +29,7 @@ def load():
         L = C.CDLL(LIB_PATH)
         L.agx_version.restype = C.c_char_p
         L.agx_last_error.restype = C.c_char_p
+        L.agx_variant_name.restype = C.c_char_p
         _LIB = L
     return _LIB
 
@@ -70,6 +71,25 @@ class Stepper:
             self.close()
         except Exception:
             pass
+
+    def debug_layout(self):
+        """[words per env, contacts offset, M^-1 offset, M^-1 row stride, row headers, impulses, phase timers, qdd] of the debug record"""
+        out = (C.c_int * 8)()
+        check(self.L.agx_debug_layout(self.h, out), 'agx_debug_layout')
+        return list(out)
+
+    def variant(self):
+        return self.L.agx_variant_name(self.h).decode()
+
+    def overflow_count(self):
+        """contacts dropped by a budget since the stepper was created (0 in a healthy run)"""
+        out = C.c_int()
+        check(self.L.agx_overflow_count(self.h, C.byref(out)), 'agx_overflow_count')
+        return out.value
+
+    def set_env_offset(self, env_offset):
+        """global index of this stepper's first env (multi-GPU sharding): keeps agx_reset_done's pool draw placement independent"""
+        check(self.L.agx_set_env_offset(self.h, C.c_longlong(int(env_offset))), 'agx_set_env_offset')
 
     def set_state(self, states):
         states = np.ascontiguousarray(states, dtype=np.float32)

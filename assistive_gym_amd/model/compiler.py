@@ -31,18 +31,20 @@ from .urdf import Urdf
 H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT=7, NGROUP=8, NFOOD=9, ACT_DIM=10,
          OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
          STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
-         NDIR=29, OFF_DIRS=30, OFF_RESET=31, NROBOT=32, NHDOF=33, S_TREMOR=34, COUNT=40)
+         NDIR=29, OFF_DIRS=30, OFF_RESET=31, NROBOT=32, NHDOF=33, S_TREMOR=34, TASK_KIND=35, S_TASK=36, TASK_WORDS=37,
+         OFF_TARGETS=38, COUNT=40)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
          HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, COUNT=24)
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, COM=11, MASS=14, INERTIA=15, LOWER=21, UPPER=22, HAS_LIMIT=23, KP=24, KD=25,
-         MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, STRIDE=32)
+         MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, JTYPE=32, STRIDE=36)
 F = dict(MASS=0, INERTIA=1, GRAVITY=4, REFPOS=5, REFQUAT=8, KIND=12, RADIUS=13, STRIDE=16)
-C = dict(BODY=0, NVERT=1, VOFF=2, RADIUS=3, FRICTION=4, TAG=5, AABB_C=6, AABB_H=9, STRIDE=12)
+C = dict(BODY=0, NVERT=1, VOFF=2, RADIUS=3, FRICTION=4, TAG=5, AABB_C=6, AABB_H=9, LINK=12, STRIDE=16)
 G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
 T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV=7, SUCCESS_FRAC=8, MOUTH_DIST=9,
          SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
-         TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, COUNT=40)
+         TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, TOOL_OBS_POS=36, TOOL_OBS_QUAT=39, W_WIPE=43, TARGET_RADIUS=44,
+         CLOSEST_DIST=45, PAD_LINK=46, ARM_LINK=47, OBS_LINK=49, NT=52, NT_MAX=56, COUNT=64)
 # reset section (sampling ranges of FeedingEnv.reset + the posed-human kinematic tree), see agx_blob.h
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
@@ -54,9 +56,13 @@ E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITER
 BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
 PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
 HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
-TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8)
+TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8, BED=9)
+TASK_FEEDING, TASK_BED_BATHING = 0, 1
+BB = dict(ALIVE=0, ALIVE_WORDS=6, WORDS=6)      # bed bathing task words of the state record (AGX_BB_*)
+# pair-group flags (AGX_G_FLAGS)
+GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC = 1, 2, 4, 8, 16, 32
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 7
+MAGIC, VERSION = 0x31584741, 8
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -106,9 +112,9 @@ class Scene:
     def end(self, name):
         self.ranges[name][1] = len(self.colliders)
 
-    def add(self, body, verts, radius, friction, tag):
+    def add(self, body, verts, radius, friction, tag, link=-1):
         verts = np.atleast_2d(np.asarray(verts, dtype=np.float64))
-        self.colliders.append(dict(body=body, verts=verts, radius=float(radius), friction=float(friction), tag=tag))
+        self.colliders.append(dict(body=body, verts=verts, radius=float(radius), friction=float(friction), tag=tag, link=int(link)))
 
 
 def link_collision_hulls(link, max_verts, assets_cache):
@@ -169,7 +175,6 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
     dof_links = []       # pb index of each moving link
     for j in u.indexed_joints:
         if j.type in ('revolute', 'continuous', 'prismatic'):
-            assert j.type != 'prismatic'
             dof_of_pb[j.index] = len(dof_links)
             dof_links.append(j.index)
     # carrier (moving ancestor, or -1 for base) and transform link-frame-in-carrier-frame for every link
@@ -223,18 +228,18 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
         rec[d, R['COM']:R['COM'] + 3] = com
         rec[d, R['MASS']] = m
         rec[d, R['INERTIA']:R['INERTIA'] + 6] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
-        has_limit = j.type == 'revolute' and j.lower <= j.upper
+        has_limit = j.type in ('revolute', 'prismatic') and j.lower <= j.upper
         rec[d, R['LOWER']] = j.lower if has_limit else -1e10     # agents/agent.py:223-225
         rec[d, R['UPPER']] = j.upper if has_limit else 1e10
         rec[d, R['JDAMP']] = j.damping
-        ints = dict(PARENT=-1 if pcar == -1 else dof_of_pb[pcar], HAS_LIMIT=int(has_limit), ACT=-1, PB_INDEX=pb)
+        ints = dict(PARENT=-1 if pcar == -1 else dof_of_pb[pcar], HAS_LIMIT=int(has_limit), ACT=-1, PB_INDEX=pb, JTYPE=1 if j.type == 'prismatic' else 0)
         if pb in arm_joints:
             ints['ACT'] = arm_joints.index(pb)
             rec[d, R['KP']], rec[d, R['KD']], rec[d, R['MAXF']] = motor_gain, 1.0, motor_force
         elif pb in gripper_joints:
             # Robot.set_gripper_open_position (agents/robot.py:76-79): kp 0.05, force 500
             rec[d, R['KP']], rec[d, R['KD']], rec[d, R['MAXF']] = 0.05, 1.0, 500.0
-            rec[d, R['QT0']] = gripper_target
+            rec[d, R['QT0']] = gripper_target[gripper_joints.index(pb)] if np.ndim(gripper_target) else gripper_target
         else:
             # [BULLET-UNVERIFIED] default URDF joint motor: velocity target 0, max force = URDF effort
             rec[d, R['KP']], rec[d, R['KD']], rec[d, R['MAXF']] = 0.0, 1.0, j.effort
@@ -243,31 +248,230 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
                 dof_colliders=dof_colliders, base_colliders=base_colliders)
 
 
+def add_robot_colliders(sc, rob, name, pb_pred):
+    """colliders of the robot's moving links whose PyBullet link index satisfies pb_pred, as the range `name`"""
+    sc.begin(name)
+    for d in range(len(rob['dof_links'])):
+        for verts, radius, fr, pb in rob['dof_colliders'][d]:
+            if pb_pred(pb):
+                sc.add(d, verts, radius, fr, TAG['ROBOT'], link=pb)
+    sc.end(name)
+
+
+def add_human(sc, assets, nrobot, hd, kp, maxf, act0, split=None):
+    """Both genders of the capsule human (human_creation.py:58-316).  Links of the joints `hd` (a serial chain off the base,
+    in PyBullet numbering) are moving links of the articulated set (DoFs nrobot..nrobot+len(hd)-1): dynamic when they are
+    controllable or the impairment is tremor (human.py:108: every other link gets mass 0) and frozen per environment
+    otherwise.  All other links are static collision bodies with a per-env world transform.
+    split: optional function link -> sub-range name; the colliders of a gender are then emitted grouped by sub-range
+    (ranges 'human_<gender>_<name>') inside the gender's range 'human_<gender>'.
+    Returns (human_bodies, {gender: (link records, int fields)})."""
+    nhdof = len(hd)
+    human_bodies, human_link_rec = None, {}
+    for gender in ('male', 'female'):
+        hm = HumanModel(gender)
+        cols = hm.colliders()
+        static_links = sorted(set(c[0] for c in cols if c[0] not in hd), key=lambda l: (l != -1, l))
+        if human_bodies is None:
+            human_bodies = static_links
+        assert static_links == human_bodies
+        link_hulls = {j: [] for j in hd}
+        names = [None] if split is None else sorted(set(split(c[0]) for c in cols), key=lambda n: min(c[0] for c in cols if split(c[0]) == n) if n != 'rest' else 1000)
+        sc.begin('human_' + gender)
+        for name in names:
+            if name is not None:
+                sc.begin('human_%s_%s' % (gender, name))
+            for (link, kind, data) in cols:
+                if name is not None and split(link) != name:
+                    continue
+                body = nrobot + hd.index(link) if link in hd else BODY_HUMAN0 + human_bodies.index(link)
+                shapes = []
+                if kind == 'capsule':
+                    shapes.append((np.stack([data[0], data[1]]), data[2]))
+                elif kind == 'sphere':
+                    shapes.append((data[0][None], data[1]))
+                elif kind == 'head':
+                    fn, fpos, fquat, scale = data
+                    for g in load_obj_groups(os.path.join(assets, fn), scale):
+                        shapes.append((X.apply(fpos, fquat, convex_hull_vertices(g)), HULL_MARGIN))
+                for verts, radius in shapes:
+                    sc.add(body, verts, radius, DEFAULT_FRICTION, TAG['HUMAN'], link=link)
+                    if link in hd:
+                        link_hulls[link].append((verts, radius))
+            if name is not None:
+                sc.end('human_%s_%s' % (gender, name))
+        sc.end('human_' + gender)
+        # link records of the dynamic joints (createMultiBody: link frame = joint frame = inertial frame,
+        # human_creation.py:193-195); inertia = box inertia of the collision AABB [BULLET-UNVERIFIED]
+        recs = np.zeros((nhdof, R['STRIDE']))
+        ints = []
+        for k, j in enumerate(hd):
+            par = hm.parent[j]
+            recs[k, R['TPOS']:R['TPOS'] + 3] = hm.offset[j]
+            recs[k, R['TQUAT']:R['TQUAT'] + 4] = [0, 0, 0, 1]
+            recs[k, R['AXIS']:R['AXIS'] + 3] = hm.axis[j]
+            recs[k, R['MASS']] = hm.mass[j]
+            if link_hulls[j] and hm.mass[j] > 0:
+                lo = np.min([v.min(0) - r for v, r in link_hulls[j]], axis=0)
+                hi = np.max([v.max(0) + r for v, r in link_hulls[j]], axis=0)
+                recs[k, R['INERTIA']:R['INERTIA'] + 3] = box_inertia(hm.mass[j], lo, hi)
+            recs[k, R['LOWER']], recs[k, R['UPPER']] = hm.lower[j], hm.upper[j]
+            recs[k, R['KP']], recs[k, R['KD']], recs[k, R['MAXF']] = kp, 1.0, maxf
+            # ACT: index of this joint in the co-op action vector (robot actions first, then the human's
+            # controllable joints); ignored unless TASK.COOP is set
+            ints.append(dict(PARENT=PARENT_HUMAN_BASE if par < 0 else nrobot + hd.index(par), HAS_LIMIT=1, ACT=act0 + k, PB_INDEX=j, KIND=1, JTYPE=0))
+            assert par < 0 or par in hd
+        human_link_rec[gender] = (recs, ints)
+    return human_bodies, human_link_rec
+
+
+def default_params(n_iter):
+    return dict(DT=0.02, FRAME_SKIP=5, NITER=n_iter, ERP=0.2, CONTACT_ERP=0.2, CONTACT_BREAK=0.02, LIN_DAMP=0.04, ANG_DAMP=0.04,
+                FRIC_EPS=1e-7, LIMIT_ACT=0.25, ACTION_SCALE=0.05, GRAVITY_Z=-9.81, GJK_TOL=1e-6, GJK_MAXIT=24, MAX_CONTACTS=64,
+                MAX_ROWS=160, ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=0.0, CONTACT_SLACK=0.001, MAX_ENTRIES=2040)
+
+
+def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i, hdr_extra, reset_fill, reset_words,
+         targets=None, task_words=0, meta_extra=None):
+    """Lays the assembled scene out as the flat blob of include/agx_blob.h.  Returns (uint32 array, meta)."""
+    nrobot = len(rob['dof_links'])
+    nhdof = len(hd)
+    ndof = nrobot + nhdof
+    ncoll = len(sc.colliders)
+    verts = np.concatenate([c['verts'] for c in sc.colliders])
+    voff = np.cumsum([0] + [len(c['verts']) for c in sc.colliders])
+    nfree = len(free)
+    nhuman = len(human_bodies)
+    dirs = icosphere42()
+    nt_max = 0 if targets is None else max(len(targets['male']), len(targets['female']))
+    off = {}
+    cur = H['COUNT']
+    nrec = nrobot + 2 * nhdof
+    for name, size in (('PARAMS', P['COUNT']), ('ROBOT', nrec * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
+                       ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
+                       ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('RESET', reset_words(nhuman, nhdof)),
+                       ('TARGETS', 2 * nt_max * 4)):
+        off[name] = cur
+        cur += size
+    nwords = cur
+    f = np.zeros(nwords, dtype=np.float32)
+    i = f.view(np.int32)
+    s_q, s_qd, s_qt = 0, ndof, 2 * ndof
+    s_free = 3 * ndof
+    s_base = s_free + 13 * nfree
+    s_human = s_base + 7
+    s_tremor = s_human + 7 * nhuman
+    s_env = s_tremor + 2 * nhdof
+    s_task = s_env + E['COUNT']
+    state_words = s_task + task_words
+    hdr = dict(MAGIC=MAGIC, VERSION=VERSION, NWORDS=nwords, NDOF=ndof, NFREE=nfree, NHUMAN=nhuman, NCOLL=ncoll,
+               NVERT=len(verts), NGROUP=len(groups), OFF_PARAMS=off['PARAMS'],
+               OFF_ROBOT=off['ROBOT'], OFF_FREE=off['FREE'], OFF_COLL=off['COLL'], OFF_VERT=off['VERT'],
+               OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
+               S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, NDIR=len(dirs),
+               OFF_DIRS=off['DIRS'], OFF_RESET=off['RESET'], NROBOT=nrobot, NHDOF=nhdof, S_TREMOR=s_tremor,
+               S_TASK=s_task, TASK_WORDS=task_words, OFF_TARGETS=off['TARGETS'])
+    hdr.update(hdr_extra)
+    for k, v in hdr.items():
+        i[H[k]] = v
+    pv = f[off['PARAMS']:off['PARAMS'] + P['COUNT']]
+    for k, v in params.items():
+        pv[P[k]] = v
+    for d in range(nrobot):
+        base = off['ROBOT'] + d * R['STRIDE']
+        f[base:base + R['STRIDE']] = rob['rec'][d]
+        for k, v in rob['rec_int'][d].items():
+            i[base + R[k]] = v
+        i[base + R['KIND']] = 0
+    for gi, gender in enumerate(('male', 'female')):
+        recs, ints = human_link_rec[gender]
+        for k in range(nhdof):
+            base = off['ROBOT'] + (nrobot + gi * nhdof + k) * R['STRIDE']
+            f[base:base + R['STRIDE']] = recs[k]
+            for key, v in ints[k].items():
+                i[base + R[key]] = v
+    for k, b in enumerate(free):
+        base = off['FREE'] + k * F['STRIDE']
+        f[base + F['MASS']] = b['mass']
+        f[base + F['INERTIA']:base + F['INERTIA'] + 3] = b['inertia']
+        f[base + F['GRAVITY']] = b['gravity']
+        f[base + F['REFPOS']:base + F['REFPOS'] + 3] = b['refpos']
+        f[base + F['REFQUAT']:base + F['REFQUAT'] + 4] = b['refquat']
+        i[base + F['KIND']] = b['kind']
+        f[base + F['RADIUS']] = b['radius']
+    v32 = verts.astype(np.float32)
+    f[off['VERT']:off['VERT'] + 3 * len(verts)] = v32.ravel()
+    f[off['DIRS']:off['DIRS'] + 3 * len(dirs)] = dirs.astype(np.float32).ravel()
+    reset_fill(f[off['RESET']:], i[off['RESET']:], nhuman, nhdof, human_bodies, hd)
+    for k, c in enumerate(sc.colliders):
+        base = off['COLL'] + k * C['STRIDE']
+        i[base + C['BODY']] = c['body']
+        i[base + C['NVERT']] = len(c['verts'])
+        i[base + C['VOFF']] = voff[k]
+        f[base + C['RADIUS']] = c['radius']
+        f[base + C['FRICTION']] = c['friction']
+        i[base + C['TAG']] = c['tag']
+        i[base + C['LINK']] = c['link']
+        cv = v32[voff[k]:voff[k + 1]].astype(np.float64)
+        lo, hi = cv.min(0), cv.max(0)
+        f[base + C['AABB_C']:base + C['AABB_C'] + 3] = (lo + hi) / 2
+        f[base + C['AABB_H']:base + C['AABB_H'] + 3] = (hi - lo) / 2 * (1 + 1e-6) + 1e-7
+    for k, g in enumerate(groups):
+        base = off['GROUP'] + k * G['STRIDE']
+        i[base:base + G['STRIDE']] = g
+    t = f[off['TASK']:off['TASK'] + T['COUNT']]
+    ti = i[off['TASK']:off['TASK'] + T['COUNT']]
+    t[T['TOOL_OBS_QUAT'] + 3] = 1.0
+    for k, v in task_f.items():
+        v = np.atleast_1d(np.asarray(v, dtype=np.float64))
+        t[T[k]:T[k] + len(v)] = v
+    for k, v in task_i.items():
+        v = np.atleast_1d(np.asarray(v, dtype=np.int64))
+        ti[T[k]:T[k] + len(v)] = v
+    if targets is not None:
+        ti[T['NT_MAX']] = nt_max
+        for gi, gender in enumerate(('male', 'female')):
+            for k, (pos, arm) in enumerate(targets[gender]):
+                base = off['TARGETS'] + 4 * (gi * nt_max + k)
+                f[base:base + 3] = pos
+                i[base + 3] = arm
+    meta = dict(header=hdr, ranges={k: tuple(v) for k, v in sc.ranges.items()}, human_bodies=human_bodies,
+                human_dynamic_joints=hd, nrobot=nrobot, dof_links=rob['dof_links'], n_groups=len(groups), offsets=off)
+    meta.update(meta_extra or {})
+    return f.view(np.uint32).copy(), meta
+
+
+class Groups:
+    """Static pair-group table (broadphase level 0): which collider ranges may touch."""
+
+    def __init__(self, ranges):
+        self.rg = dict(ranges)
+        self.rows = []
+
+    def add(self, a, b, alt=None, same=False, keep=0, manifold=False, no_adjacent=False, flags=0):
+        a0, a1 = self.rg[a]
+        b0, b1 = self.rg[b]
+        b0f, b1f = self.rg[alt] if alt else (-1, -1)
+        assert b1 - b0 <= 128 and (b1f - b0f) <= 128 and a1 - a0 <= 128, 'a collider range must fit two wave-wide passes'
+        if a1 > a0 and b1 > b0:
+            self.rows.append([a0, a1, b0, b1, b0f, b1f, (GF_SAME if same else 0) | (GF_MANIFOLD if manifold else 0) | (GF_NO_ADJACENT if no_adjacent else 0) | flags, keep])
+
+
 def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
-    """Returns (blob uint32 array, meta dict)."""
+    """FeedingJaco-v1 (feeding_envs.py:29-31).  Returns (blob uint32 array, meta dict)."""
     sc = Scene()
     # ------------------------------------------------------------------ robot (agents/jaco.py)
     arm = [1, 2, 3, 4, 5, 6, 7]
     grip = [9, 11, 13]
     rob = compile_robot(os.path.join(assets, 'jaco', 'j2s7s300_gym.urdf'), arm, grip, gripper_target=1.33,
                         motor_gain=0.025, motor_force=1.0, max_hull_verts=robot_hull_max_verts)
-    ndof = len(rob['dof_links'])
+    nrobot = len(rob['dof_links'])
     gripper_collision = set(range(7, 15))          # jaco.py:17 -> no collision with the tool (tool.py:42-44)
-    sc.begin('robot_arm')                           # links that DO collide with the tool
-    for d in range(ndof):
-        for verts, radius, fr, pb in rob['dof_colliders'][d]:
-            if pb not in gripper_collision:
-                sc.add(d, verts, radius, fr, TAG['ROBOT'])
-    sc.end('robot_arm')
-    sc.begin('robot_gripper')
-    for d in range(ndof):
-        for verts, radius, fr, pb in rob['dof_colliders'][d]:
-            if pb in gripper_collision:
-                sc.add(d, verts, radius, fr, TAG['ROBOT'])
-    sc.end('robot_gripper')
+    add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)     # links that DO collide with the tool
+    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
     sc.begin('robot_base')
     for verts, radius, fr, pb in rob['base_colliders']:
-        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'])
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
     sc.end('robot_base')
     # ------------------------------------------------------------------ free bodies
     free = []
@@ -301,64 +505,9 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
                          refquat=np.array([0, 0, 0, 1.0]), kind=KIND['FOOD'], radius=food_r))
         sc.add(BODY_FREE0 + 2 + k, np.zeros((1, 3)), food_r, DEFAULT_FRICTION, TAG['FOOD'])
     sc.end('food')
-    # ------------------------------------------------------------------ human (male / female variants)
-    # Links of the head joints (human.head_joints = 20..23, agents/human.py:9) are moving links of the
-    # articulated set (DoFs ndof_robot..ndof_robot+3): they are dynamic when the impairment is tremor
-    # (human.py:108: every other link gets mass 0) and frozen per environment otherwise.  All other
-    # human links are static collision bodies with a per-env world transform.
-    nrobot = ndof
+    # ------------------------------------------------------------------ human: head joints dynamic-capable (human.head_joints, human.py:9)
     hd = HUMAN_DYNAMIC_JOINTS
-    nhdof = len(hd)
-    human_bodies = None
-    human_link_rec = {}
-    for gender in ('male', 'female'):
-        hm = HumanModel(gender)
-        cols = hm.colliders()
-        static_links = [c[0] for c in cols if c[0] not in hd]
-        static_links = sorted(set(static_links), key=lambda l: (l != -1, l))
-        if human_bodies is None:
-            human_bodies = static_links
-        assert static_links == human_bodies
-        sc.begin('human_' + gender)
-        link_hulls = {j: [] for j in hd}
-        for (link, kind, data) in cols:
-            body = nrobot + hd.index(link) if link in hd else BODY_HUMAN0 + human_bodies.index(link)
-            shapes = []
-            if kind == 'capsule':
-                shapes.append((np.stack([data[0], data[1]]), data[2]))
-            elif kind == 'sphere':
-                shapes.append((data[0][None], data[1]))
-            elif kind == 'head':
-                fn, fpos, fquat, scale = data
-                for g in load_obj_groups(os.path.join(assets, fn), scale):
-                    shapes.append((X.apply(fpos, fquat, convex_hull_vertices(g)), HULL_MARGIN))
-            for verts, radius in shapes:
-                sc.add(body, verts, radius, DEFAULT_FRICTION, TAG['HUMAN'])
-                if link in hd:
-                    link_hulls[link].append((verts, radius))
-        sc.end('human_' + gender)
-        # link records of the dynamic joints (createMultiBody: link frame = joint frame = inertial frame,
-        # human_creation.py:193-195); inertia = box inertia of the collision AABB [BULLET-UNVERIFIED]
-        recs = np.zeros((nhdof, R['STRIDE']))
-        ints = []
-        for k, j in enumerate(hd):
-            par = hm.parent[j]
-            recs[k, R['TPOS']:R['TPOS'] + 3] = hm.offset[j]
-            recs[k, R['TQUAT']:R['TQUAT'] + 4] = [0, 0, 0, 1]
-            recs[k, R['AXIS']:R['AXIS'] + 3] = hm.axis[j]
-            recs[k, R['MASS']] = hm.mass[j]
-            if link_hulls[j] and hm.mass[j] > 0:
-                lo = np.min([v.min(0) - r for v, r in link_hulls[j]], axis=0)
-                hi = np.max([v.max(0) + r for v, r in link_hulls[j]], axis=0)
-                recs[k, R['INERTIA']:R['INERTIA'] + 3] = box_inertia(hm.mass[j], lo, hi)
-            recs[k, R['LOWER']], recs[k, R['UPPER']] = hm.lower[j], hm.upper[j]
-            recs[k, R['KP']], recs[k, R['KD']], recs[k, R['MAXF']] = 0.025, 1.0, 1.0      # feeding.py:122, human.py:69
-            # ACT: index of this joint in the co-op action vector (robot actions first, then the human's
-            # controllable joints = head joints, feeding_envs.py:11); ignored unless TASK.COOP is set
-            ints.append(dict(PARENT=PARENT_HUMAN_BASE if par < 0 else nrobot + hd.index(par), HAS_LIMIT=1, ACT=len(arm) + k, PB_INDEX=j, KIND=1))
-            assert par < 0 or par in hd
-        human_link_rec[gender] = (recs, ints)
-    ndof = nrobot + nhdof
+    human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.025, maxf=1.0, act0=len(arm))   # feeding.py:122, human.py:69
     head_link = nrobot + hd.index(23)
     # ------------------------------------------------------------------ static world
     sc.begin('table')   # furniture.py:31, assets/table/table_tall.urdf:22-27, lateral friction 1.0
@@ -374,15 +523,8 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
         sc.add(BODY_WORLD, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['WHEELCHAIR'])
     sc.end('wheelchair')
     # ------------------------------------------------------------------ pair groups
-    rg = dict(sc.ranges)
-    groups = []
-
-    def grp(a, b, alt=None, same=False, keep=0, manifold=False, no_adjacent=False):
-        a0, a1 = rg[a]
-        b0, b1 = rg[b]
-        b0f, b1f = rg[alt] if alt else (-1, -1)
-        assert b1 - b0 <= 128 and (b1f - b0f) <= 128, 'B range must fit two wave-wide passes'
-        groups.append([a0, a1, b0, b1, b0f, b1f, (1 if same else 0) | (2 if manifold else 0) | (4 if no_adjacent else 0), keep])
+    G_ = Groups(sc.ranges)
+    grp = G_.add
     # keep=K: a small sphere / hull touching a compound of many convex pieces produces one candidate
     # per piece inside the 2 cm manifold margin; only the K with the smallest predicted gap become
     # solver rows (a deliberate bound -- see DESIGN.md "contact budget")
@@ -408,7 +550,7 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     grp('bowl', 'table')
     grp('bowl', 'plane')
     # URDF_USE_SELF_COLLISION (jaco.py:53): every robot link pair except same link / parent-child
-    rg['robot_links'] = (rg['robot_arm'][0], rg['robot_gripper'][1])
+    G_.rg['robot_links'] = (G_.rg['robot_arm'][0], G_.rg['robot_gripper'][1])
     grp('robot_links', 'robot_links', same=True, no_adjacent=True)
     grp('robot_arm', 'wheelchair')
     grp('robot_gripper', 'wheelchair')
@@ -418,175 +560,236 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
     grp('tool', 'plane')
     grp('bowl', 'human_male', alt='human_female', keep=1)
     grp('bowl', 'wheelchair')
-    # ------------------------------------------------------------------ pack
-    ncoll = len(sc.colliders)
-    verts = np.concatenate([c['verts'] for c in sc.colliders])
-    voff = np.cumsum([0] + [len(c['verts']) for c in sc.colliders])
-    nfree = len(free)
-    nhuman = len(human_bodies)
-    dirs = icosphere42()
-    off = {}
-    cur = H['COUNT']
-    nrec = nrobot + 2 * nhdof
-    for name, size in (('PARAMS', P['COUNT']), ('ROBOT', nrec * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
-                       ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
-                       ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']),
-                       ('RESET', X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof)):
-        off[name] = cur
-        cur += size
-    nwords = cur
-    f = np.zeros(nwords, dtype=np.float32)
-    i = f.view(np.int32)
-    s_q, s_qd, s_qt = 0, ndof, 2 * ndof
-    s_free = 3 * ndof
-    s_base = s_free + 13 * nfree
-    s_human = s_base + 7
-    s_tremor = s_human + 7 * nhuman
-    s_env = s_tremor + 2 * nhdof
-    state_words = s_env + E['COUNT']
-    hdr = dict(MAGIC=MAGIC, VERSION=VERSION, NWORDS=nwords, NDOF=ndof, NFREE=nfree, NHUMAN=nhuman, NCOLL=ncoll,
-               NVERT=len(verts), NGROUP=len(groups), NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=25, OFF_PARAMS=off['PARAMS'],
-               OFF_ROBOT=off['ROBOT'], OFF_FREE=off['FREE'], OFF_COLL=off['COLL'], OFF_VERT=off['VERT'],
-               OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
-               S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, FOOD0=2, TOOL_BODY=0, NDIR=len(dirs),
-               OFF_DIRS=off['DIRS'], OFF_RESET=off['RESET'], NROBOT=nrobot, NHDOF=nhdof, S_TREMOR=s_tremor)
-    for k, v in hdr.items():
-        i[H[k]] = v
-    p = f[off['PARAMS']:off['PARAMS'] + P['COUNT']]
-    p[P['DT']] = 0.02
-    p[P['FRAME_SKIP']] = 5
-    p[P['NITER']] = n_iter
-    p[P['ERP']] = 0.2
-    p[P['CONTACT_ERP']] = 0.2
-    p[P['CONTACT_BREAK']] = 0.02
-    p[P['LIN_DAMP']] = 0.04
-    p[P['ANG_DAMP']] = 0.04
-    p[P['FRIC_EPS']] = 1e-7
-    p[P['LIMIT_ACT']] = 0.25
-    p[P['ACTION_SCALE']] = 0.05
-    p[P['GRAVITY_Z']] = -9.81
-    p[P['GJK_TOL']] = 1e-6
-    p[P['GJK_MAXIT']] = 24
-    p[P['MAX_CONTACTS']] = 64
-    p[P['MAX_ROWS']] = 160
-    p[P['ROBOT_GRAVITY_Z']] = 0.0      # feeding.py:150-151
-    p[P['HUMAN_GRAVITY_Z']] = 0.0      # feeding.py:152
-    p[P['CONTACT_SLACK']] = 0.001
-    p[P['MAX_ENTRIES']] = 2040
-    for d in range(nrobot):
-        base = off['ROBOT'] + d * R['STRIDE']
-        f[base:base + R['STRIDE']] = rob['rec'][d]
-        for k, v in rob['rec_int'][d].items():
-            i[base + R[k]] = v
-        i[base + R['KIND']] = 0
-    for gi, gender in enumerate(('male', 'female')):
-        recs, ints = human_link_rec[gender]
-        for k in range(nhdof):
-            base = off['ROBOT'] + (nrobot + gi * nhdof + k) * R['STRIDE']
-            f[base:base + R['STRIDE']] = recs[k]
-            for key, v in ints[k].items():
-                i[base + R[key]] = v
-    for k, b in enumerate(free):
-        base = off['FREE'] + k * F['STRIDE']
-        f[base + F['MASS']] = b['mass']
-        f[base + F['INERTIA']:base + F['INERTIA'] + 3] = b['inertia']
-        f[base + F['GRAVITY']] = b['gravity']
-        f[base + F['REFPOS']:base + F['REFPOS'] + 3] = b['refpos']
-        f[base + F['REFQUAT']:base + F['REFQUAT'] + 4] = b['refquat']
-        i[base + F['KIND']] = b['kind']
-        f[base + F['RADIUS']] = b['radius']
-    v32 = verts.astype(np.float32)
-    f[off['VERT']:off['VERT'] + 3 * len(verts)] = v32.ravel()
-    f[off['DIRS']:off['DIRS'] + 3 * len(dirs)] = dirs.astype(np.float32).ravel()
-    # ---- reset section: what FeedingEnv.reset samples (feeding.py:114-172) + the posed-human tree
-    x0 = off['RESET']
-    xf, xi = f[x0:], i[x0:]
-    xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
-    xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = [-0.35, -0.3, 0.36]                          # jaco.py:47 toc_base_pos_offset
-    xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])      # feeding.py:136
-    xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0])  # jaco.py:43 toc_ee_orient_rpy
-    xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.15, -0.65, 1.15], 0.05   # feeding.py:139
-    xf[X_['BOWL_POS']:X_['BOWL_POS'] + 3], xf[X_['BOWL_RANGE']] = [-0.15, -0.65, 0.75], 0.05    # furniture.py:33
-    xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [0, 0.03, 0.89], [0, 0.03, 0.86]   # human.py:102
-    xf[X_['FOOD_R']] = 0.005                                                             # feeding.py:158
-    xf[X_['FOOD_OFF']:X_['FOOD_OFF'] + 3] = [-0.005, 0, 0.01]                            # feeding.py:162
-    xf[X_['HEAD_RANGE']] = np.deg2rad(30.0)                                              # feeding.py:125
-    xi[X_['IK_ITERS']], xf[X_['IK_DAMP']], xf[X_['IK_MAXSTEP']], xf[X_['IK_TOL']] = 200, 0.05, 0.5, 1e-4   # host/kin.py (not Bullet's IK)
-    xf[X_['IK_THRESH']], xi[X_['IK_RESTARTS']], xi[X_['IK_RANDLIM_FROM']] = 0.01, 1000, 10   # robot.py:84-97
-    xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5                                    # env.py:120
-    xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(20.0)   # human.py:85-90
-    xi[X_['BOWL_BODY']] = 1
-    oj = X_['COUNT']
-    ob = oj + 2 * 42 * XJ['STRIDE']
-    od = ob + nhuman
-    xi[X_['OFF_JOINTS']], xi[X_['OFF_BODIES']], xi[X_['OFF_DYN']] = oj, ob, od
-    preset = {6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}                         # feeding.py:124
-    draw = {21: 0, 22: 1, 23: 2}                                                         # feeding.py:125
-    for g, gender in enumerate(('male', 'female')):
-        hm1, hm2 = HumanModel(gender, 1.0), HumanModel(gender, 0.5)
-        assert hm1.n == 42
-        for j in range(42):
-            b0 = oj + (g * 42 + j) * XJ['STRIDE']
-            xi[b0 + XJ['PARENT']] = hm1.parent[j]
-            xf[b0 + XJ['OFF']:b0 + XJ['OFF'] + 3] = hm1.offset[j]
-            xf[b0 + XJ['AXIS']:b0 + XJ['AXIS'] + 3] = hm1.axis[j]
-            xf[b0 + XJ['LOWER']], xf[b0 + XJ['UPPER']] = hm1.lower[j], hm1.upper[j]
-            scaled = hm1.lower[j] != hm2.lower[j] or hm1.upper[j] != hm2.upper[j]
-            xi[b0 + XJ['FLAGS']] = (1 if hm1.jtype[j] == 'r' else 0) | (2 if scaled else 0)
-            xf[b0 + XJ['PRESET']] = np.deg2rad(preset.get(j, 0.0))
-            xi[b0 + XJ['DRAW']] = draw.get(j, -1)
-    xi[ob:ob + nhuman] = human_bodies
-    xi[od:od + nhdof] = hd
-    for k, c in enumerate(sc.colliders):
-        base = off['COLL'] + k * C['STRIDE']
-        i[base + C['BODY']] = c['body']
-        i[base + C['NVERT']] = len(c['verts'])
-        i[base + C['VOFF']] = voff[k]
-        f[base + C['RADIUS']] = c['radius']
-        f[base + C['FRICTION']] = c['friction']
-        i[base + C['TAG']] = c['tag']
-        cv = v32[voff[k]:voff[k + 1]].astype(np.float64)
-        lo, hi = cv.min(0), cv.max(0)
-        f[base + C['AABB_C']:base + C['AABB_C'] + 3] = (lo + hi) / 2
-        f[base + C['AABB_H']:base + C['AABB_H'] + 3] = (hi - lo) / 2 * (1 + 1e-6) + 1e-7
-    for k, g in enumerate(groups):
-        base = off['GROUP'] + k * G['STRIDE']
-        i[base:base + G['STRIDE']] = g
-    t = f[off['TASK']:off['TASK'] + T['COUNT']]
-    ti = i[off['TASK']:off['TASK'] + T['COUNT']]
-    t[T['W_DISTANCE']], t[T['W_ACTION']], t[T['W_FOOD']] = 1.0, 0.01, 1.0           # config.ini:15-18
-    t[T['C_V']], t[T['C_F']], t[T['C_HF']], t[T['C_FD']], t[T['C_FDV']] = 0.25, 0.01, 0.05, 1.0, 1.0   # config.ini:40-44
-    t[T['SUCCESS_FRAC']] = 0.75
-    t[T['MOUTH_DIST']], t[T['SPILL_DIST']] = 0.03, 0.1
-    t[T['MOUTH_M']:T['MOUTH_M'] + 3] = [0, -0.11, 0.03]                               # feeding.py:186
-    t[T['MOUTH_F']:T['MOUTH_F'] + 3] = [0, -0.1, 0.03]
-    ti[T['HEAD_LINK']] = head_link
+    groups = G_.rows
+    # ------------------------------------------------------------------ reset section: what FeedingEnv.reset samples (feeding.py:114-172) + the posed-human tree
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
+        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = [-0.35, -0.3, 0.36]                          # jaco.py:47 toc_base_pos_offset
+        xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])      # feeding.py:136
+        xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0])  # jaco.py:43 toc_ee_orient_rpy
+        xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.15, -0.65, 1.15], 0.05   # feeding.py:139
+        xf[X_['BOWL_POS']:X_['BOWL_POS'] + 3], xf[X_['BOWL_RANGE']] = [-0.15, -0.65, 0.75], 0.05    # furniture.py:33
+        xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [0, 0.03, 0.89], [0, 0.03, 0.86]   # human.py:102
+        xf[X_['FOOD_R']] = 0.005                                                             # feeding.py:158
+        xf[X_['FOOD_OFF']:X_['FOOD_OFF'] + 3] = [-0.005, 0, 0.01]                            # feeding.py:162
+        xf[X_['HEAD_RANGE']] = np.deg2rad(30.0)                                              # feeding.py:125
+        xi[X_['IK_ITERS']], xf[X_['IK_DAMP']], xf[X_['IK_MAXSTEP']], xf[X_['IK_TOL']] = 200, 0.05, 0.5, 1e-4   # host/kin.py (not Bullet's IK)
+        xf[X_['IK_THRESH']], xi[X_['IK_RESTARTS']], xi[X_['IK_RANDLIM_FROM']] = 0.01, 1000, 10   # robot.py:84-97
+        xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5                                    # env.py:120
+        xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(20.0)   # human.py:85-90
+        xi[X_['BOWL_BODY']] = 1
+        oj = X_['COUNT']
+        ob = oj + 2 * 42 * XJ['STRIDE']
+        od = ob + nhuman
+        xi[X_['OFF_JOINTS']], xi[X_['OFF_BODIES']], xi[X_['OFF_DYN']] = oj, ob, od
+        preset = {6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}                         # feeding.py:124
+        draw = {21: 0, 22: 1, 23: 2}                                                         # feeding.py:125
+        for g, gender in enumerate(('male', 'female')):
+            hm1, hm2 = HumanModel(gender, 1.0), HumanModel(gender, 0.5)
+            assert hm1.n == 42
+            for j in range(42):
+                b0 = oj + (g * 42 + j) * XJ['STRIDE']
+                xi[b0 + XJ['PARENT']] = hm1.parent[j]
+                xf[b0 + XJ['OFF']:b0 + XJ['OFF'] + 3] = hm1.offset[j]
+                xf[b0 + XJ['AXIS']:b0 + XJ['AXIS'] + 3] = hm1.axis[j]
+                xf[b0 + XJ['LOWER']], xf[b0 + XJ['UPPER']] = hm1.lower[j], hm1.upper[j]
+                scaled = hm1.lower[j] != hm2.lower[j] or hm1.upper[j] != hm2.upper[j]
+                xi[b0 + XJ['FLAGS']] = (1 if hm1.jtype[j] == 'r' else 0) | (2 if scaled else 0)
+                xf[b0 + XJ['PRESET']] = np.deg2rad(preset.get(j, 0.0))
+                xi[b0 + XJ['DRAW']] = draw.get(j, -1)
+        xi[ob:ob + nhuman] = human_bodies
+        xi[od:od + nhdof] = hd
     # end effector = PyBullet link 8 (jaco.py:11), carried by the moving link of joint 7
     ee_pb = 8
-    ti[T['EE_LINK']] = rob['dof_of_pb'][rob['carrier'][ee_pb]]
-    assert ti[T['EE_LINK']] < nrobot
-    t[T['EE_POS']:T['EE_POS'] + 3] = rob['rel'][ee_pb][0]
-    t[T['EE_QUAT']:T['EE_QUAT'] + 4] = rob['rel'][ee_pb][1]
-    t[T['TOOL_POS']:T['TOOL_POS'] + 3] = [0.1, -0.0225, 0.03]                          # jaco.py:26
-    t[T['TOOL_QUAT']:T['TOOL_QUAT'] + 4] = X.quat_from_rpy([-0.1, -np.pi / 2.0, 0])    # jaco.py:31
-    t[T['TOOL_MAXF']] = 500.0                                                           # tool.py:47
-    t[T['EPISODE_LEN']] = 200
-    meta = dict(header=hdr, ranges={k: tuple(v) for k, v in sc.ranges.items()}, human_bodies=human_bodies,
-                head_link=int(head_link), human_dynamic_joints=hd, nrobot=nrobot, dof_links=rob['dof_links'], n_groups=len(groups), offsets=off,
-                robot_base_pos=[-0.35, -0.3, 0.36], robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist())
-    return f.view(np.uint32).copy(), meta
+    ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    assert ee_link < nrobot
+    task_f = dict(W_DISTANCE=1.0, W_ACTION=0.01, W_FOOD=1.0,                               # config.ini:15-18
+                  C_V=0.25, C_F=0.01, C_HF=0.05, C_FD=1.0, C_FDV=1.0,                      # config.ini:40-44
+                  SUCCESS_FRAC=0.75, MOUTH_DIST=0.03, SPILL_DIST=0.1,
+                  MOUTH_M=[0, -0.11, 0.03], MOUTH_F=[0, -0.1, 0.03],                        # feeding.py:186
+                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1],
+                  TOOL_POS=[0.1, -0.0225, 0.03], TOOL_QUAT=X.quat_from_rpy([-0.1, -np.pi / 2.0, 0]),   # jaco.py:26,31
+                  TOOL_MAXF=500.0, EPISODE_LEN=200)                                        # tool.py:47
+    task_i = dict(HEAD_LINK=head_link, EE_LINK=ee_link)
+    params = default_params(n_iter)                                                        # robot / human gravity 0: feeding.py:150-152
+    return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
+                dict(NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=25, FOOD0=2, TOOL_BODY=0, TASK_KIND=TASK_FEEDING), reset_fill, reset_words,
+                meta_extra=dict(head_link=int(head_link), robot_base_pos=[-0.35, -0.3, 0.36],
+                                robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist()))
 
 
-def main():
+def capsule_points(p1, p2, radius, distance_between_points):
+    """Util.capsule_points (assistive_gym/envs/util.py:80-113): rings of points around a capsule's cylinder."""
+    p1, p2 = np.array(p1, dtype=np.float64), np.array(p2, dtype=np.float64)
+    axis_vector = (p2 - p1) / np.linalg.norm(p2 - p1)
+    m = np.argmax(np.abs(axis_vector))                       # Util.orthogonal_vector (util.py:115-123)
+    y = np.zeros(3)
+    y[(m + 1) % 3] = 1
+    ortho = np.cross(axis_vector, y)
+    ortho /= np.linalg.norm(ortho)
+    normal = np.cross(axis_vector, ortho)
+    sections = int(np.linalg.norm(p2 - p1) / distance_between_points)
+    pts = []
+    for i in range(sections):
+        section_pos = (p2 - p1) / (sections + 1) * (i + 1)
+        theta_dist = distance_between_points / radius
+        for j in range(int(2 * np.pi * radius / distance_between_points)):
+            th = theta_dist * j
+            pts.append(p1 + section_pos + radius * np.cos(th) * ortho + radius * np.sin(th) * normal)
+    return pts
+
+
+def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
+    """BedBathingSawyer-v1 (bed_bathing_envs.py:23-25): Sawyer (agents/sawyer.py), the wiper (assets/bed_bathing/wiper.urdf,
+    tool.py:22-23), the human lying on the bed (bed_bathing.py:112-137; its right arm joints 0..9 are the controllable joints,
+    bed_bathing_envs.py:12 -- dynamic when the impairment is tremor, human.py:108), the bed (furniture.py:17-18, friction 5,
+    bed_bathing.py:116) and the ground."""
+    sc = Scene()
+    # ------------------------------------------------------------------ robot (agents/sawyer.py:8-17)
+    arm = [3, 8, 9, 10, 11, 13, 16]
+    grip = [20, 22]
+    rob = compile_robot(os.path.join(assets, 'sawyer', 'sawyer.urdf'), arm, grip, gripper_target=[0.0125, -0.0125],    # sawyer.py:21
+                        motor_gain=0.05, motor_force=1.0, max_hull_verts=0)                                            # robot.py:36-37
+    nrobot = len(rob['dof_links'])
+    gripper_collision = {18, 20, 21, 22, 23}           # sawyer.py:17 -> no collision with the tool (tool.py:42-44)
+    # Sawyer.init (sawyer.py:52-61): URDF_USE_SELF_COLLISION, then every pair among links 3..23 and every pair of links
+    # 0..2 with links 0..8 is switched off: what remains is {base, 0, 1, 2} x {9..23}
+    add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
+    add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
+    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+    sc.begin('robot_base')                              # base link and the links fixed to it (torso, pedestal, arm mount: links -1..2)
+    for verts, radius, fr, pb in rob['base_colliders']:
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    sc.end('robot_base')
+    # ------------------------------------------------------------------ tool: wiper.urdf, three links welded by fixed joints = one rigid body
+    wu = Urdf(os.path.join(assets, 'bed_bathing', 'wiper.urdf'))
+    parts = []                                          # (pb link, frame in the base frame, hulls in the link frame, mass, inertia diag in the inertial frame)
+    frames = {-1: (np.zeros(3), np.array([0, 0, 0, 1.0]))}
+    for j in wu.indexed_joints:
+        assert j.type == 'fixed'
+        frames[j.index] = X.compose(*frames[wu.links[j.parent].index], j.pos, j.quat)
+    tot_m, com = 0.0, np.zeros(3)
+    for idx in range(-1, len(wu.indexed_joints)):
+        lk = wu.link_by_index(idx)
+        hulls = link_collision_hulls(lk, 0, {})
+        cp, cq = X.compose(*frames[idx], lk.com_pos, lk.com_quat)
+        parts.append((idx, frames[idx], hulls, lk.mass, aabb_inertia_in_inertial_frame(lk, hulls), cp, cq, lk.lateral_friction))
+        tot_m += lk.mass
+        com += lk.mass * cp
+    com /= tot_m
+    Ic = np.zeros((3, 3))
+    for idx, fr, hulls, mass, idiag, cp, cq, _ in parts:
+        Rm = X.quat_to_mat(cq)
+        r = cp - com
+        Ic += Rm @ np.diag(idiag) @ Rm.T + mass * ((r @ r) * np.eye(3) - np.outer(r, r))
+    assert np.allclose(Ic, np.diag(np.diag(Ic)), atol=1e-12), 'the wiper is symmetric: principal axes = base frame axes'
+    free = [dict(mass=tot_m, inertia=np.diag(Ic), gravity=0.0, refpos=-com, refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0)]   # bed_bathing.py:165
+    sc.begin('tool')
+    for idx, fr, hulls, mass, idiag, cp, cq, lf in parts:
+        for verts, radius in hulls:
+            sc.add(BODY_FREE0 + 0, X.apply(fr[0], fr[1], verts) - com, radius, lf, TAG['TOOL'], link=idx)
+    sc.end('tool')
+    pad_link = 1
+    # ------------------------------------------------------------------ human: right arm joints dynamic-capable (bed_bathing_envs.py:12)
+    hd = list(range(10))
+
+    def split(link):
+        return 'pecs' if link == 2 else ('arm' if 3 <= link <= 9 else 'rest')
+    human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.05, maxf=1.0, act0=len(arm), split=split)    # human.py:69-70
+    # ------------------------------------------------------------------ static world
+    sc.begin('bed')     # furniture.py:17-18, assets/bed/bed.urdf; friction 5 (bed_bathing.py:116)
+    bq = X.quat_from_rpy([np.pi / 2, 0, 0])
+    for g in load_obj_groups(os.path.join(assets, 'bed', 'bed_single_reduced_vhacd.obj'), 1.1):
+        sc.add(BODY_WORLD, X.apply(np.array([-0.1, 0, 0.0]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), bq, convex_hull_vertices(g))), HULL_MARGIN, 5.0, TAG['BED'])
+    sc.end('bed')
+    sc.begin('plane')   # assets/plane/plane.urdf:21-26 (friction overridden per env, env.py:120)
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    # ------------------------------------------------------------------ pair groups
+    G_ = Groups(sc.ranges)
+    grp = G_.add
+    G_.rg['robot_arm'] = (G_.rg['robot_lower'][0], G_.rg['robot_upper'][1])          # links that DO collide with the tool
+    G_.rg['robot_links'] = (G_.rg['robot_lower'][0], G_.rg['robot_gripper'][1])
+    G_.rg['robot_top'] = (G_.rg['robot_upper'][0], G_.rg['robot_gripper'][1])        # links 9..23
+    grp('tool', 'human_male', alt='human_female', manifold=True)     # bed_bathing.py:47-58 reads every manifold point of the pair
+    grp('robot_links', 'human_male', alt='human_female', keep=2)
+    grp('robot_base', 'human_male', alt='human_female', keep=2, flags=GF_HUMAN_DYNAMIC)   # static pedestal: only the dynamic arm matters
+    grp('tool', 'bed', keep=2)
+    grp('robot_links', 'bed', keep=2)
+    grp('robot_arm', 'tool')
+    grp('robot_base', 'tool')
+    grp('robot_base', 'robot_top')                                    # the self-collision pairs Sawyer.init leaves enabled
+    grp('robot_links', 'plane')
+    grp('tool', 'plane')
+    # the human's own right arm (dynamic when the impairment is tremor): arm links 3..9 against the base and links 10.. of the
+    # body (human_creation.py:288-290), pecs + arm against the bed and the ground
+    for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
+        G_.rg['harm_' + gender] = (G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][1])
+        grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)
+        grp('harm_' + gender, 'bed', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
+    groups = G_.rows
+    # ------------------------------------------------------------------ task
+    ee_pb, tool_pb = 19, 18                             # sawyer.py:11,15
+    ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    assert rob['carrier'][tool_pb] == rob['carrier'][ee_pb]
+    # Tool.get_transform / createConstraint (tool.py:46-56): centre-of-mass frame of the tool joint's link o (pos_offset, orient_offset),
+    # expressed here in the end-effector frame
+    tl = wu  # noqa: F841
+    tool_link = rob['urdf'].link_by_index(tool_pb)
+    cpos, cquat = X.compose(*rob['rel'][tool_pb], tool_link.com_pos, tool_link.com_quat)
+    apos, aquat = X.compose(cpos, cquat, np.array([0, 0.1175, 0]), X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0]))    # sawyer.py:27,33
+    iep, ieq = X.invert(*rob['rel'][ee_pb])
+    tpos, tquat = X.compose(iep, ieq, apos, aquat)
+    targets, nts = {}, []
+    for gender in ('male', 'female'):
+        hm = HumanModel(gender)
+        ul, ur = hm.dims['upperarm'][1], hm.dims['upperarm'][0]          # bed_bathing.py:175-180
+        fl, fr_ = hm.dims['forearm'][1], hm.dims['forearm'][0]
+        up = capsule_points([0, 0, 0], [0, 0, -ul], ur, 0.03)           # bed_bathing.py:182-183
+        fo = capsule_points([0, 0, 0], [0, 0, -fl], fr_, 0.03)
+        targets[gender] = [(p_, 0) for p_ in up] + [(p_, 1) for p_ in fo]
+        nts += [len(up), len(fo)]
+    assert nts == [81, 48, 56, 35], nts                                 # SURVEY 3.3: 129 / 91 targets
+    task_f = dict(W_DISTANCE=1.0, W_ACTION=0.01, W_WIPE=5.0, SUCCESS_FRAC=0.3,             # config.ini:9-13
+                  C_V=0.25, C_F=0.01, C_HF=0.05,                                           # config.ini:40-42
+                  TARGET_RADIUS=0.025, CLOSEST_DIST=5.0,                                   # bed_bathing.py:57,23
+                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=tpos, TOOL_QUAT=tquat,
+                  TOOL_OBS_POS=frames[pad_link][0], TOOL_OBS_QUAT=frames[pad_link][1],    # tool.get_pos_orient(1), bed_bathing.py:81
+                  TOOL_MAXF=500.0, EPISODE_LEN=200)                                        # tool.py:47, bed_bathing.py:31
+    task_i = dict(EE_LINK=ee_link, PAD_LINK=pad_link, ARM_LINK=[nrobot + 5, nrobot + 7],   # human.right_shoulder / right_elbow (human.py:23-24)
+                  OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], NT=nts, HEAD_LINK=-1)     # shoulder, elbow, wrist (bed_bathing.py:89-91)
+    params = default_params(n_iter)
+    params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-1.0)                               # bed_bathing.py:162-164
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT']
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        pass        # no device-side reset generator for this scene: the pool comes from assistive_gym_amd/host/reset_bed.py
+    return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_BED_BATHING), reset_fill, reset_words,
+                targets=targets, task_words=BB['WORDS'], meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
+
+
+COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer)
+
+
+def main(names=None):
     import json
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'data')
     os.makedirs(out_dir, exist_ok=True)
-    blob, meta = compile_feeding_jaco()
-    blob.tofile(os.path.join(out_dir, 'feeding_jaco.agxblob'))
-    with open(os.path.join(out_dir, 'feeding_jaco.meta.json'), 'w') as fh:
-        json.dump(meta, fh, indent=1, default=lambda o: o.tolist() if hasattr(o, 'tolist') else str(o))
-    print('wrote', len(blob) * 4, 'bytes;', json.dumps(meta['header']))
+    for name in (names or sorted(COMPILERS)):
+        blob, meta = COMPILERS[name]()
+        blob.tofile(os.path.join(out_dir, name + '.agxblob'))
+        with open(os.path.join(out_dir, name + '.meta.json'), 'w') as fh:
+            json.dump(meta, fh, indent=1, default=lambda o: o.tolist() if hasattr(o, 'tolist') else str(o))
+        print('wrote', name, len(blob) * 4, 'bytes;', json.dumps(meta['header']))
 
 
 if __name__ == '__main__':
-    main()
+    import sys
+    main(sys.argv[1:] or None)

@@ -9,6 +9,9 @@
  *   agx_set_state /   no reference equivalent (the reference has no p.saveState/restoreState,
  *   agx_get_state     SURVEY section 5): state injection for parity tests, checkpoints, reset pools.
  *   agx_settle        the settle loop `for _ in range(25): p.stepSimulation()` (feeding.py:178-179).
+ *   (the citations are those of the FeedingJaco model; a BedBathingSawyer blob is served by the bed_bathing kernel
+ *    variant, whose task layer replaces BedBathingEnv.step/_get_obs/get_total_force/update_targets,
+ *    assistive_gym/envs/bed_bathing.py:12-110,190-203, and the non-feeding branch of human_preferences, env.py:244-247)
  *   agx_step          FeedingEnv.step(action) for every env: AssistiveEnv.take_step
  *                     (envs/env.py:174-235) incl. 5x p.stepSimulation() (env.py:226), _get_obs
  *                     (feeding.py:85-112), get_food_rewards (feeding.py:50-83), human_preferences
@@ -64,7 +67,15 @@ int agx_step(agx_handle h, const float* actions_dev, float* obs_dev, float* rewa
 /* same as agx_step, additionally dumping first-substep internals ([n_envs][agx_debug_words()]) */
 int agx_step_debug(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
                    uint8_t* done_dev, float* info_dev, float* debug_dev, void* stream);
-int agx_debug_words(void);
+int agx_debug_words(void);   /* of the FeedingJaco kernel variant; agx_debug_layout for the variant serving a handle */
+/* layout of the debug record of the kernel variant serving this handle: out8 = {words per env, contacts offset, M^-1 offset,
+ * M^-1 row stride, row headers offset, impulses offset, phase timers offset, qdd offset} */
+int agx_debug_layout(agx_handle h, int* out8);
+/* name of the compiled kernel variant (limits + task layer) that serves this handle: "feeding", "bed_bathing" */
+const char* agx_variant_name(agx_handle h);
+/* contacts dropped since agx_create because a budget was exceeded (contact, row or coefficient cap), summed over all envs:
+ * they are missing from the dynamics and from total_force_on_human; 0 in a healthy run */
+int agx_overflow_count(agx_handle h, int* out);
 /* same as agx_step (same chunk streams) with a HIP event after every kernel launch; blocks until the step
  * is done and returns the summed launch durations of one step in ms3 = {build, solve, finish kernels} and
  * the number of launches of each in launches3 (may be NULL) */
@@ -86,8 +97,10 @@ int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gende
 int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, uint64_t seed, int impairment_mode,
               int gender_mode, int settle_substeps, void* stream);
 /* envs with done != 0 get a fresh state from pool_dev ([pool_n][state_words]); the pool entry is
- * (env_index + 977 * episode_count) mod pool_n, so results do not depend on GPU placement */
+ * (env_offset + env_index + 977 * episode_count) mod pool_n with env_offset = the global index of this handle's first env
+ * (agx_set_env_offset, default 0), so results do not depend on how the envs are spread over GPUs */
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream);
+int agx_set_env_offset(agx_handle h, long long env_offset);
 
 /* convenience wrappers with HOST buffers (copies included; not the timed path) */
 int agx_step_host(agx_handle h, const float* actions, float* obs, float* reward, uint8_t* done, float* info);

@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 7
+#define AGX_BLOB_VERSION 8
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
 /* face manifold on static world boxes (table top, ground): besides the closest point, up to AGX_FACE_EXTRA more
  * vertices of the other collider become contact candidates -- those within AGX_FACE_BAND of its lowest vertex,
@@ -44,8 +44,15 @@ enum {
   AGX_H_NROBOT,       /* DoFs [0, NROBOT) belong to the robot, [NROBOT, NDOF) to the human                */
   AGX_H_NHDOF,        /* human DoFs; their link records exist per gender: record = dof + gender * NHDOF   */
   AGX_H_S_TREMOR,     /* state: float[NHDOF] tremor amplitude, float[NHDOF] tremor-free target (human.py:89-92) */
+  AGX_H_TASK_KIND,    /* AGX_TASK_*: which task layer (observation, reward, force bookkeeping) the blob is compiled for */
+  AGX_H_S_TASK,       /* state: task-specific words after the ENV block (bed bathing: bitmask of the targets not wiped yet) */
+  AGX_H_TASK_WORDS,
+  AGX_H_OFF_TARGETS,  /* bed bathing: float[2 genders][NT_MAX][4] = target position in its arm link frame + arm (0 upper, 1 fore) */
   AGX_H_COUNT = 40
 };
+
+enum { AGX_TASK_FEEDING = 0,      /* assistive_gym/envs/feeding.py     */
+       AGX_TASK_BED_BATHING = 1 };/* assistive_gym/envs/bed_bathing.py */
 
 /* ---- PARAMS: float[AGX_P_COUNT] ----------------------------------------------------------- */
 enum {
@@ -86,7 +93,8 @@ enum {
   AGX_R_JDAMP = 29,
   AGX_R_PB_INDEX = 30,   /* int: PyBullet joint index (jaco.py:8-17, human.py:5-58)              */
   AGX_R_KIND = 31,       /* int: 0 robot, 1 human (hard limit clamp after each substep, agent.py:240-250) */
-  AGX_R_STRIDE = 32
+  AGX_R_JTYPE = 32,      /* int: 0 revolute, 1 prismatic (Sawyer gripper fingers, assets/sawyer/sawyer.urdf)  */
+  AGX_R_STRIDE = 36
 };
 
 /* ---- FREE bodies: stride AGX_F_STRIDE ----------------------------------------------------- */
@@ -111,7 +119,9 @@ enum {
   AGX_C_TAG = 5,         /* int: AGX_TAG_*                                                    */
   AGX_C_AABB_C = 6,      /* float[3] body-frame AABB centre of the core                       */
   AGX_C_AABB_H = 9,      /* float[3] half extents                                             */
-  AGX_C_STRIDE = 12
+  AGX_C_LINK = 12,       /* int: PyBullet link index of the collider on its body (-1 = base), what getContactPoints
+                          * reports as linkIndexA/B (agent.py:100-116; bed_bathing.py:48,51)     */
+  AGX_C_STRIDE = 16
 };
 /* body codes */
 #define AGX_BODY_WORLD (-1)
@@ -121,7 +131,7 @@ enum {
 #define AGX_BODY_FREE0 200
 #define AGX_BODY_HUMAN0 300
 enum { AGX_TAG_ROBOT = 1, AGX_TAG_TOOL = 2, AGX_TAG_HUMAN = 3, AGX_TAG_FOOD = 4, AGX_TAG_BOWL = 5,
-       AGX_TAG_TABLE = 6, AGX_TAG_PLANE = 7, AGX_TAG_WHEELCHAIR = 8 };
+       AGX_TAG_TABLE = 6, AGX_TAG_PLANE = 7, AGX_TAG_WHEELCHAIR = 8, AGX_TAG_BED = 9 };
 
 /* ---- pair GROUPS (static broadphase table): stride AGX_G_STRIDE --------------------------- */
 enum {
@@ -131,7 +141,10 @@ enum {
   AGX_G_FLAGS = 6,              /* bit0: A and B are the same range (i<j only); bit1: the task asks
                                    whether a manifold point exists (broadphase margin = CONTACT_BREAK);
                                    bit2: skip pairs on the same link or on parent/child links
-                                   (URDF_USE_SELF_COLLISION semantics, jaco.py:53)                    */
+                                   (URDF_USE_SELF_COLLISION semantics, jaco.py:53);
+                                   bit3 / bit4: the group exists for a male / female human only (both collider ranges
+                                   are gender specific, e.g. the human's arm against the rest of its body);
+                                   bit5: the group is skipped while every human DoF is frozen (both sides static)   */
   AGX_G_KEEP = 7,               /* per A collider keep only the KEEP contacts with the smallest
                                    predicted gap (0 = keep all)                               */
   AGX_G_STRIDE = 8
@@ -155,7 +168,19 @@ enum {
   AGX_T_EPISODE_LEN = 34,/* feeding.py:37                                                     */
   AGX_T_COOP = 35,       /* int: 1 = the human is controllable (<Task><Robot>HumanEnv, feeding_envs.py:44-69):
                           * ACT_DIM / OBS_DIM of the header include the human's action and observation    */
-  AGX_T_COUNT = 40
+  AGX_T_TOOL_OBS_POS = 36, /* float[3] frame whose pose the observation reports, in the tool base frame: identity for the
+                            * spoon (feeding.py:86), link 1 of the wiper (bed_bathing.py:81)                        */
+  AGX_T_TOOL_OBS_QUAT = 39,/* float[4]                                                                              */
+  /* ---- bed bathing (assistive_gym/envs/bed_bathing.py, config.ini:9-13) ---- */
+  AGX_T_W_WIPE = 43,       /* wiping_reward_weight                                                                  */
+  AGX_T_TARGET_RADIUS = 44,/* a target is wiped when a (tool link 1, human) contact lies within this (bed_bathing.py:57) */
+  AGX_T_CLOSEST_DIST = 45, /* range of the tool <-> human closest-point query (bed_bathing.py:23)                   */
+  AGX_T_PAD_LINK = 46,     /* int: tool link whose contacts wipe (bed_bathing.py:51)                                */
+  AGX_T_ARM_LINK = 47,     /* int[2]: moving links carrying the upper-arm / forearm targets (human.right_shoulder, right_elbow) */
+  AGX_T_OBS_LINK = 49,     /* int[3]: moving links whose positions the observation reports (shoulder, elbow, wrist) */
+  AGX_T_NT = 52,           /* int[2 genders][2 arms]: number of targets (bed_bathing.py:173-188)                    */
+  AGX_T_NT_MAX = 56,       /* int: row count of the per-gender target table                                         */
+  AGX_T_COUNT = 64
 };
 
 /* ---- RESET section (offset AGX_H_OFF_RESET): what FeedingEnv.reset samples (feeding.py:114-172, human.py:72-102,
@@ -220,10 +245,18 @@ enum {
                              * human_creation.py:199-200)                                          */
   AGX_E_COUNT = 16
 };
+/* bed bathing reuses AGX_E_TASK_SUCCESS (targets wiped, bed_bathing.py:60) and AGX_E_TOTAL_FOOD (total_target_count,
+ * bed_bathing.py:187); AGX_E_TARGET / FOOD_* / RNG are unused.  Its task words (offset AGX_H_S_TASK): */
+enum { AGX_BB_ALIVE = 0,        /* int[AGX_BB_ALIVE_WORDS] bitmask of the targets not wiped yet, upper-arm targets first */
+       AGX_BB_ALIVE_WORDS = 6,
+       AGX_BB_WORDS = 6 };
 
 /* ---- per-step outputs --------------------------------------------------------------------- */
 enum { AGX_INFO_TOTAL_FORCE = 0, AGX_INFO_TASK_SUCCESS = 1, AGX_INFO_ROBOT_FORCE = 2,
-       AGX_INFO_TOOL_FORCE = 3, AGX_INFO_FOOD_REWARD = 4, AGX_INFO_PREF = 5,
-       AGX_INFO_NCONTACT = 6, AGX_INFO_NROWS = 7, AGX_INFO_COUNT = 8 };
+       AGX_INFO_TOOL_FORCE = 3,  /* feeding: spoon force on the human; bed bathing: tool_force_on_human (link 1) */
+       AGX_INFO_FOOD_REWARD = 4, /* feeding: food reward; bed bathing: new_contact_points of this step          */
+       AGX_INFO_PREF = 5,
+       AGX_INFO_NCONTACT = 6,    /* solver contacts of the last substep + 1000 * contacts dropped by a budget (overflow) */
+       AGX_INFO_NROWS = 7, AGX_INFO_COUNT = 8 };
 
 #endif

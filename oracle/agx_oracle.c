@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXDOF 16
+#define MAXDOF 32
 #define MAXFREE 16
 #define MAXHUMAN 24
 #define NVMAX (MAXDOF + 6 * MAXFREE)
@@ -24,6 +24,7 @@
 #define MAXROWS 320
 #define MAXV 80 /* max vertices of one collider core */
 #define MAXCOLL 512
+#define MAXQPT 16
 
 typedef struct { double p[3]; double R[9]; } xf_t;
 
@@ -33,6 +34,7 @@ struct agxo_model {
   int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
   int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env, s_tremor;
   int nrobot, nhdof;
+  int task_kind, s_task, o_targets;
 };
 
 /* ------------------------------------------------------------------------------------ math */
@@ -140,6 +142,7 @@ agxo_model* agxo_load(const uint32_t* blob, size_t nwords) {
   m->s_q = h[AGX_H_S_Q]; m->s_qd = h[AGX_H_S_QD]; m->s_qt = h[AGX_H_S_QT]; m->s_free = h[AGX_H_S_FREE]; m->s_base = h[AGX_H_S_BASE];
   m->s_human = h[AGX_H_S_HUMAN]; m->s_env = h[AGX_H_S_ENV]; m->s_tremor = h[AGX_H_S_TREMOR];
   m->nrobot = h[AGX_H_NROBOT]; m->nhdof = h[AGX_H_NHDOF];
+  m->task_kind = h[AGX_H_TASK_KIND]; m->s_task = h[AGX_H_S_TASK]; m->o_targets = h[AGX_H_OFF_TARGETS];
   if (m->ndof > MAXDOF || m->nfree > MAXFREE || m->nhuman > MAXHUMAN || m->ncoll > MAXCOLL) { agxo_free(m); return NULL; }
   return m;
 }
@@ -197,6 +200,8 @@ typedef struct {
   double vel[NVMAX];
   contact_t con[MAXC]; int ncon;
   int food_near_human;   /* particles with a (food, human) manifold point: separation < CONTACT_BREAK */
+  double qpt[MAXQPT][3]; int qpt_link[MAXQPT]; int nqpt;   /* bed bathing: manifold points of the wiping pad on the human (bed_bathing.py:47-58) */
+  uint32_t bb_alive[AGX_BB_ALIVE_WORDS];                  /* bed bathing: targets not wiped yet */
   int contact_overflow;
   row_t* rows; int nrows;
 } sim_t;
@@ -226,6 +231,7 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
   s->alive = ei[AGX_E_FOOD_ALIVE]; s->active = ei[AGX_E_FOOD_ACTIVE]; s->iteration = ei[AGX_E_ITERATION];
   s->success = ei[AGX_E_TASK_SUCCESS]; s->total_food = ei[AGX_E_TOTAL_FOOD];
   s->rng[0] = (uint32_t)ei[AGX_E_RNG]; s->rng[1] = (uint32_t)ei[AGX_E_RNG + 1];
+  if (m->task_kind == AGX_TASK_BED_BATHING) for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) s->bb_alive[k] = (uint32_t)((const int32_t*)st)[m->s_task + AGX_BB_ALIVE + k];
 }
 static void sim_store(const sim_t* s, float* st) {
   const agxo_model* m = s->m;
@@ -240,6 +246,7 @@ static void sim_store(const sim_t* s, float* st) {
   for (int k = 0; k < 3; k++) e[AGX_E_TARGET + k] = (float)s->target[k];
   ei[AGX_E_FOOD_ALIVE] = s->alive; ei[AGX_E_FOOD_ACTIVE] = s->active; ei[AGX_E_ITERATION] = s->iteration;
   ei[AGX_E_TASK_SUCCESS] = s->success; ei[AGX_E_RNG] = (int32_t)s->rng[0]; ei[AGX_E_RNG + 1] = (int32_t)s->rng[1];
+  if (m->task_kind == AGX_TASK_BED_BATHING) for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) ((int32_t*)st)[m->s_task + AGX_BB_ALIVE + k] = (int32_t)s->bb_alive[k];
 }
 
 /* joint limits of DoF d; the human's are scaled per environment (human_creation.py:199-200) */
@@ -257,14 +264,17 @@ static void kinematics(sim_t* s) {
     double tq[4] = {RF(m, d, AGX_R_TQUAT), RF(m, d, AGX_R_TQUAT + 1), RF(m, d, AGX_R_TQUAT + 2), RF(m, d, AGX_R_TQUAT + 3)};
     double ax[3] = {RF(m, d, AGX_R_AXIS), RF(m, d, AGX_R_AXIS + 1), RF(m, d, AGX_R_AXIS + 2)};
     double Rt[9], Rq[9], R0[9];
-    quat_to_mat(tq, Rt); axis_angle_mat(ax, s->q[d], Rq);
-    mm3(P->R, Rt, R0); mm3(R0, Rq, s->link[d].R);
+    const int prismatic = RI(m, d, AGX_R_JTYPE) == 1;   /* Sawyer gripper fingers (assets/sawyer/sawyer.urdf) */
+    quat_to_mat(tq, Rt); mm3(P->R, Rt, R0);
     xf_apply(P, tp, s->link[d].p);
+    if (prismatic) { memcpy(s->link[d].R, R0, sizeof R0); double aw0[3]; mv3(R0, ax, aw0); axpy3(s->q[d], aw0, s->link[d].p); }
+    else { axis_angle_mat(ax, s->q[d], Rq); mm3(R0, Rq, s->link[d].R); }
     double com[3] = {RF(m, d, AGX_R_COM), RF(m, d, AGX_R_COM + 1), RF(m, d, AGX_R_COM + 2)};
     xf_apply(&s->link[d], com, s->comw[d]);
     double aw[3]; mv3(s->link[d].R, ax, aw);
     double px[3]; cross3(s->link[d].p, aw, px);
-    for (int k = 0; k < 3; k++) { s->S[d][k] = aw[k]; s->S[d][3 + k] = px[k]; }
+    /* joint screw (angular; linear at the world origin): revolute (a, p x a), prismatic (0, a) */
+    for (int k = 0; k < 3; k++) { s->S[d][k] = prismatic ? 0.0 : aw[k]; s->S[d][3 + k] = prismatic ? aw[k] : px[k]; }
     const double ixx = RF(m, d, AGX_R_INERTIA), iyy = RF(m, d, AGX_R_INERTIA + 1), izz = RF(m, d, AGX_R_INERTIA + 2),
                  ixy = RF(m, d, AGX_R_INERTIA + 3), ixz = RF(m, d, AGX_R_INERTIA + 4), iyz = RF(m, d, AGX_R_INERTIA + 5);
     double Il[9] = {ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz}, T[9];
@@ -650,12 +660,17 @@ static void collide(sim_t* s) {
     double g = collider_speed(s, c) * dt0;
     for (int k = 0; k < 3; k++) { lo[c][k] -= g; hi[c][k] += g; }
   }
-  s->ncon = 0; s->food_near_human = 0; s->contact_overflow = 0;
+  s->ncon = 0; s->food_near_human = 0; s->contact_overflow = 0; s->nqpt = 0;
   double dt = PARAM(m, AGX_P_DT), slack = PARAM(m, AGX_P_CONTACT_SLACK);
   for (int g = 0; g < m->ngroup; g++) {
     int a0 = GI(m, g, AGX_G_A0), a1 = GI(m, g, AGX_G_A1), b0 = GI(m, g, AGX_G_B0), b1 = GI(m, g, AGX_G_B1);
     if (s->gender == 1 && GI(m, g, AGX_G_B0F) >= 0) { b0 = GI(m, g, AGX_G_B0F); b1 = GI(m, g, AGX_G_B1F); }
     int same = GI(m, g, AGX_G_FLAGS) & 1, keep = GI(m, g, AGX_G_KEEP);
+    {   /* bit3 / bit4: male / female only; bit5: only while some human DoF is dynamic */
+      const int fl = GI(m, g, AGX_G_FLAGS);
+      if (((fl & 8) && s->gender != 0) || ((fl & 16) && s->gender != 1)) continue;
+      if ((fl & 32) && ((~s->frozen >> m->nrobot) & ((1 << m->nhdof) - 1)) == 0) continue;
+    }
     const double mg = (GI(m, g, AGX_G_FLAGS) & 2) ? brk : slack;   /* bit1: getContactPoints-style existence query */
     for (int a = a0; a < a1; a++) {
       contact_t cand[128]; double gap[128]; int nc = 0;
@@ -670,8 +685,13 @@ static void collide(sim_t* s) {
         contact_t k;
         if (!narrowphase_ab(s, a, b, brk, &k, lo[a], hi[a])) continue;
         /* a manifold point exists (what getContactPoints reports, agent.py:100-116) */
-        if (CI(m, a, AGX_C_TAG) == AGX_TAG_FOOD && CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN)
+        if (m->task_kind == AGX_TASK_FEEDING && CI(m, a, AGX_C_TAG) == AGX_TAG_FOOD && CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN)
           s->food_near_human |= 1 << (CI(m, a, AGX_C_BODY) - AGX_BODY_FREE0 - m->food0);
+        /* bed bathing: manifold points of tool link 1 on the human, with or without force (bed_bathing.py:47-58) */
+        if (m->task_kind == AGX_TASK_BED_BATHING && (GI(m, g, AGX_G_FLAGS) & 2) && CI(m, a, AGX_C_TAG) == AGX_TAG_TOOL && CI(m, a, AGX_C_LINK) == TI(m, AGX_T_PAD_LINK) &&
+            CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN && s->nqpt < MAXQPT) {
+          memcpy(s->qpt[s->nqpt], k.pb, 24); s->qpt_link[s->nqpt] = CI(m, b, AGX_C_LINK); s->nqpt++;
+        }
         /* resting on a static world box: vertex contacts (re-anchors k, adds up to AGX_FACE_EXTRA more) */
         contact_t extra[AGX_FACE_EXTRA];
         int ne = face_manifold(s, a, b, &k, lo[b], hi[b], extra);
@@ -801,7 +821,11 @@ static void build_rows(sim_t* s) {
     double tq[4] = {TF(m, AGX_T_TOOL_QUAT), TF(m, AGX_T_TOOL_QUAT + 1), TF(m, AGX_T_TOOL_QUAT + 2), TF(m, AGX_T_TOOL_QUAT + 3)};
     double pivA[3], Rt[9], frameA[9];
     xf_apply(&ee, tp, pivA); quat_to_mat(tq, Rt); mm3(ee.R, Rt, frameA);
-    const double* pivB = s->fpos[tb]; const double* frameB = s->freex[tb].R;
+    /* child frame = the tool's base (URDF root link) frame: COM frame o REF */
+    double pivB[3], frameB[9];
+    { double rp[3] = {FF(m, tb, AGX_F_REFPOS), FF(m, tb, AGX_F_REFPOS + 1), FF(m, tb, AGX_F_REFPOS + 2)};
+      double rq[4] = {FF(m, tb, AGX_F_REFQUAT), FF(m, tb, AGX_F_REFQUAT + 1), FF(m, tb, AGX_F_REFQUAT + 2), FF(m, tb, AGX_F_REFQUAT + 3)}, Rr[9];
+      quat_to_mat(rq, Rr); xf_apply(&s->freex[tb], rp, pivB); mm3(s->freex[tb].R, Rr, frameB); }
     double rel[9], At[9];
     for (int r0 = 0; r0 < 3; r0++) for (int c = 0; c < 3; c++) At[3 * r0 + c] = frameA[3 * c + r0];
     mm3(At, frameB, rel);
@@ -866,6 +890,7 @@ static void build_rows(sim_t* s) {
     finish_row(s, r);
     r->b = -row_vel(s, r); r->fric_of = first_normal + c; r->mu = k->mu; r->lo = 0; r->hi = 0;
   }
+  s->contact_overflow += s->ncon - nc;   /* dropped by the row / coefficient budgets */
   s->ncon = nc;
 #undef NEWROW
 }
@@ -889,7 +914,8 @@ static void pgs(sim_t* s, double* dv) {
 
 /* FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset */
 static void update_target(sim_t* s) {
-  const agxo_model* m = s->m; int hl = TI(m, AGX_T_HEAD_LINK), o = s->gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
+  const agxo_model* m = s->m; if (m->task_kind != AGX_TASK_FEEDING) return;
+  int hl = TI(m, AGX_T_HEAD_LINK), o = s->gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
   double mp[3] = {TF(m, o), TF(m, o + 1), TF(m, o + 2)};
   xf_apply(&s->link[hl], mp, s->target);   /* link frames of the CURRENT kinematics() call */
 }
@@ -964,6 +990,11 @@ static void tool_base_pose(const sim_t* s, double* p, double* R) {
   double rp[3] = {FF(m, tb, AGX_F_REFPOS), FF(m, tb, AGX_F_REFPOS + 1), FF(m, tb, AGX_F_REFPOS + 2)};
   double rq[4] = {FF(m, tb, AGX_F_REFQUAT), FF(m, tb, AGX_F_REFQUAT + 1), FF(m, tb, AGX_F_REFQUAT + 2), FF(m, tb, AGX_F_REFQUAT + 3)}, Rr[9];
   quat_to_mat(rq, Rr); xf_apply(&s->freex[tb], rp, p); mm3(s->freex[tb].R, Rr, R);
+  if (m->task_kind != AGX_TASK_FEEDING) {   /* the frame the task reads: link 1 of the wiper (bed_bathing.py:81) */
+    double op[3] = {TF(m, AGX_T_TOOL_OBS_POS), TF(m, AGX_T_TOOL_OBS_POS + 1), TF(m, AGX_T_TOOL_OBS_POS + 2)};
+    double oq[4] = {TF(m, AGX_T_TOOL_OBS_QUAT), TF(m, AGX_T_TOOL_OBS_QUAT + 1), TF(m, AGX_T_TOOL_OBS_QUAT + 2), TF(m, AGX_T_TOOL_OBS_QUAT + 3)}, Ro[9], R2[9], t[3];
+    mv3(R, op, t); add3(p, t, p); quat_to_mat(oq, Ro); mm3(R, Ro, R2); memcpy(R, R2, sizeof R2);
+  }
 }
 static void to_human_frame(const sim_t* s, const double* p, const double* R, double* po, double* qo) {
   /* human.convert_to_realworld: the human's base is collision body 0 (link -1) */
@@ -1006,6 +1037,105 @@ static void observe(sim_t* s, double robot_force, double tool_force, float* obs)
     obs[o++] = (float)robot_force; obs[o++] = (float)tool_force;
   }
 }
+/* BedBathingEnv._get_obs (bed_bathing.py:80-110): robot part, followed by the human part in co-op */
+static void observe_bed(sim_t* s, double tool_force, double total_force, double pad_force, float* obs) {
+  const agxo_model* m = s->m;
+  double sp[3], sR[9], spr[3], sqr[4];
+  tool_base_pose(s, sp, sR);                 /* tool.get_pos_orient(1) */
+  to_base_frame(s, sp, sR, spr, sqr);
+  int o = 0;
+  for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k];
+  for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k];
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+    double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
+  }
+  for (int j = 0; j < 3; j++) {              /* shoulder, elbow, wrist positions (bed_bathing.py:89-94) */
+    double pr[3]; to_base_frame(s, s->link[TI(m, AGX_T_OBS_LINK + j)].p, NULL, pr, NULL);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)pr[k];
+  }
+  obs[o++] = (float)tool_force;
+  if (s->coop) {                             /* human_obs, bed_bathing.py:100-106 */
+    double sph[3], sqh[4];
+    to_human_frame(s, sp, sR, sph, sqh);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)sph[k];
+    for (int k = 0; k < 4; k++) obs[o++] = (float)sqh[k];
+    for (int d = m->nrobot; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) obs[o++] = (float)s->q[d];
+    for (int j = 0; j < 3; j++) {
+      double ph[3]; to_human_frame(s, s->link[TI(m, AGX_T_OBS_LINK + j)].p, NULL, ph, NULL);
+      for (int k = 0; k < 3; k++) obs[o++] = (float)ph[k];
+    }
+    obs[o++] = (float)total_force; obs[o++] = (float)pad_force;
+  }
+}
+/* everything BedBathingEnv.step does after take_step (bed_bathing.py:15-39) */
+static void finish_bed(sim_t* s, const float* action, float* obs, float* reward, int* done, float* info) {
+  const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
+  /* get_total_force (bed_bathing.py:41-78) */
+  double robot_f = 0, tool_f = 0, tool_human_f = 0, pad_f = 0;
+  for (int c = 0; c < s->ncon; c++) {
+    const contact_t* k = &s->con[c];
+    int ta = CI(m, k->ca, AGX_C_TAG), tb = CI(m, k->cb, AGX_C_TAG);
+    int human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
+    double f = k->lambda_n / dt;
+    if (tool) tool_f += f;                                   /* :43 every contact of the tool */
+    if (human && robot) robot_f += f;                        /* :42 */
+    if (human && tool) { tool_human_f += f;                  /* :47-48 */
+      int tc = ta == AGX_TAG_TOOL ? k->ca : k->cb; if (CI(m, tc, AGX_C_LINK) == TI(m, AGX_T_PAD_LINK)) pad_f += f; }   /* :49-50 */
+  }
+  double total_f = robot_f + tool_human_f;
+  observe_bed(s, tool_f, total_f, pad_f, obs);
+  /* targets within TARGET_RADIUS of a manifold point of the pad on a link of the human (:52-74); world positions as
+   * update_targets leaves them after the last substep (:190-203) */
+  int g = s->gender, nt = TI(m, AGX_T_NT + 2 * g) + TI(m, AGX_T_NT + 2 * g + 1), new_points = 0;
+  const float* TT = m->f + m->o_targets + 4 * g * TI(m, AGX_T_NT_MAX);
+  double r2 = TF(m, AGX_T_TARGET_RADIUS) * TF(m, AGX_T_TARGET_RADIUS);
+  for (int t = 0; t < nt; t++) {
+    if (!(s->bb_alive[t >> 5] >> (t & 31) & 1)) continue;
+    int link = TI(m, AGX_T_ARM_LINK + ((const int32_t*)TT)[4 * t + 3]);
+    double tl[3] = {TT[4 * t], TT[4 * t + 1], TT[4 * t + 2]}, w[3]; xf_apply(&s->link[link], tl, w);
+    int hit = 0;
+    for (int q = 0; q < s->nqpt && !hit; q++) {
+      if (s->qpt_link[q] < 0) continue;                      /* not the human's base link (:52) */
+      double d[3]; sub3(s->qpt[q], w, d); if (dot3(d, d) < r2) hit = 1;
+    }
+    if (hit) { new_points++; s->bb_alive[t >> 5] &= ~(1u << (t & 31)); }
+  }
+  s->success += new_points;
+  /* reward_distance = -min(closest distance tool <-> human within 5 m) (:23) */
+  double dmin = TF(m, AGX_T_CLOSEST_DIST);
+  {
+    int t0 = -1, t1 = -1, h0 = -1, h1 = -1;
+    for (int gg = 0; gg < m->ngroup; gg++) {
+      int a0 = GI(m, gg, AGX_G_A0), b0 = GI(m, gg, AGX_G_B0);
+      if (CI(m, a0, AGX_C_TAG) == AGX_TAG_TOOL && CI(m, b0, AGX_C_TAG) == AGX_TAG_HUMAN) {
+        t0 = a0; t1 = GI(m, gg, AGX_G_A1); h0 = b0; h1 = GI(m, gg, AGX_G_B1);
+        if (s->gender == 1 && GI(m, gg, AGX_G_B0F) >= 0) { h0 = GI(m, gg, AGX_G_B0F); h1 = GI(m, gg, AGX_G_B1F); }
+        break;
+      }
+    }
+    const double lim = dmin;
+    for (int a = t0; a < t1; a++) for (int b = h0; b < h1; b++) {
+      contact_t k; if (narrowphase(s, a, b, lim, &k) && k.dist < dmin) dmin = k.dist;
+    }
+  }
+  double act_norm2 = 0; for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
+  xf_t ee; ee_frame(s, &ee);
+  int L = TI(m, AGX_T_EE_LINK); double wxp[3], vee[3];
+  cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
+  double ee_speed = sqrt(dot3(vee, vee));
+  /* human_preferences (env.py:237-274), non-feeding branch (:244-247) */
+  double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_F) * (-(total_f - pad_f)) + TF(m, AGX_T_C_HF) * (pad_f < 10 ? 0.0 : -pad_f);
+  double r = TF(m, AGX_T_W_DISTANCE) * (-dmin) + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + TF(m, AGX_T_W_WIPE) * new_points + pref;
+  *reward = (float)r;
+  *done = s->iteration >= (int)TF(m, AGX_T_EPISODE_LEN);
+  if (info) {
+    info[AGX_INFO_TOTAL_FORCE] = (float)total_f;
+    info[AGX_INFO_TASK_SUCCESS] = (float)(s->success >= s->total_food * TF(m, AGX_T_SUCCESS_FRAC));
+    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)pad_f;
+    info[AGX_INFO_FOOD_REWARD] = (float)new_points; info[AGX_INFO_PREF] = (float)pref;
+    info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
+  }
+}
 static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int* food_hit_mask) {
   const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
   *robot_f = 0; *tool_f = 0; *food_hit_mask = s->food_near_human;
@@ -1022,7 +1152,8 @@ static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int*
 
 void agxo_observe(const agxo_model* m, const float* state, float* obs) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s); update_target(s);
-  observe(s, 0, 0, obs); free(s);
+  if (m->task_kind == AGX_TASK_BED_BATHING) observe_bed(s, 0, 0, 0, obs); else observe(s, 0, 0, obs);
+  free(s);
 }
 
 void agxo_settle(const agxo_model* m, float* state, int n_substeps) {
@@ -1066,6 +1197,7 @@ void agxo_step(const agxo_model* m, float* state, const float* action, float* ob
   for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
   for (int k = 0; k < nsub; k++) substep(s);
   kinematics(s); /* poses after the last integration, as the getters in _get_obs see them */
+  if (m->task_kind == AGX_TASK_BED_BATHING) { finish_bed(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   update_target(s); /* FeedingEnv.update_targets (feeding.py:192-196) */
   double robot_f, tool_f; int hit_mask;
   contact_forces(s, &robot_f, &tool_f, &hit_mask);

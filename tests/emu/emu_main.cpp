@@ -59,8 +59,15 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
   if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
   return rc;
 }
+#if AGX_HAS_SAMPLER
 extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed, int impairment_mode, int gender_mode, float* info4) {
   static float lds[64];
   return run_wave(lds, 64, [&](int lane) { agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane); });
 }
+#endif
 extern "C" int agx_emu_lds_bytes() { return agx::LDS_BYTES; }
+// debug record layout of this variant (same order as agx_debug_layout of the product library)
+extern "C" void agx_emu_debug_layout(int* out8) {
+  out8[0] = agx::DBG_WORDS; out8[1] = agx::DBG_CON; out8[2] = agx::DBG_MINV; out8[3] = agx::MAX_DOF; out8[4] = agx::DBG_HDR; out8[5] = agx::DBG_LAM;
+  out8[6] = agx::DBG_TIME; out8[7] = agx::DBG_QDD;
+}

@@ -8,21 +8,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, 'tests', 'emu')
 CSRC = os.path.join(ROOT, 'assistive_gym_amd', 'csrc')
-_LIB = None
+_LIBS = {}
+# kernel variants (limits + task layer), the same -D sets as csrc/agx_kernels.hip
+VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=1']}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        so = os.path.join(EMU, 'libagx_emu.so')
+def lib(task_kind=0):
+    if task_kind not in _LIBS:
+        so = os.path.join(EMU, 'libagx_emu_%d.so' % task_kind)
         deps = [os.path.join(EMU, f) for f in ('emu_main.cpp', 'agx_wave.h')] + \
                [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'agx_blob.h')]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-I' + EMU, '-I' + CSRC, '-o', so,
-                                   os.path.join(EMU, 'emu_main.cpp')])
-        _LIB = C.CDLL(so)
-        _LIB.agx_emu_run.restype = C.c_int
-    return _LIB
+            subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-I' + EMU, '-I' + CSRC] + VARIANT_DEFS[task_kind] +
+                                  ['-o', so, os.path.join(EMU, 'emu_main.cpp')])
+        L = C.CDLL(so)
+        L.agx_emu_run.restype = C.c_int
+        _LIBS[task_kind] = L
+    return _LIBS[task_kind]
 
 
 def _p(a):
@@ -30,15 +32,13 @@ def _p(a):
 
 
 class Emu:
-    DBG_HDR = 16 + 64 * 16 + 256
-    DBG_LAM = DBG_HDR + 160 * 10
-    DBG_TIME = DBG_LAM + 160
-    DEBUG_WORDS = DBG_TIME + 16
-
     def __init__(self, blob):
         self.blob = blob
-        self.L = lib()
+        self.L = lib(blob.task_kind)
         self.words = np.ascontiguousarray(blob.words)
+        lay = (C.c_int * 8)()
+        self.L.agx_emu_debug_layout(lay)
+        self.DEBUG_WORDS, self.DBG_CON, self.DBG_MINV, self.MINV_STRIDE, self.DBG_HDR, self.DBG_LAM, self.DBG_TIME, self.DBG_QDD = list(lay)
 
     def _run(self, state, action, mode, nsettle, debug=False):
         obs = np.zeros(self.blob.obs_dim, dtype=np.float32)

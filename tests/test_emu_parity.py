@@ -109,9 +109,10 @@ def test_edge_contact_is_not_lost(blob):
     b1 = blob.set_param('FRAME_SKIP', 1)
     con = Oracle(blob).substep_debug(s.copy())
     pairs_o = [(int(c[0]), int(c[1])) for c in con]
-    dbg = Emu(b1).step(s.copy(), np.zeros(blob.act_dim, dtype=np.float32), debug=True)[4]
+    emu = Emu(b1)
+    dbg = emu.step(s.copy(), np.zeros(blob.act_dim, dtype=np.float32), debug=True)[4]
     nc = int(dbg[0])
-    ce = dbg[16:16 + 1024].reshape(64, 16)[:nc]
+    ce = dbg[emu.DBG_CON:emu.DBG_CON + 1024].reshape(64, 16)[:nc]
     pairs_e = [(int(x), int(y)) for x, y in ce.view(np.int32)[:, :2]]
     robot_o = [p for p in pairs_o if p[0] < 13]
     assert robot_o, 'fixture must contain a robot contact'

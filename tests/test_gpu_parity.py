@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 def gpu_lib():
     from assistive_gym_amd import libagx
     L = libagx.load()
-    assert L.agx_device_count() > 0, 'no GPU visible'
+    if L.agx_device_count() <= 0:
+        pytest.skip('no GPU visible')
     return L
 
 
@@ -88,7 +89,7 @@ def test_debug_internals_match_oracle(gpu_lib, blob, oracle):
     act = torch.zeros((n, blob.act_dim), device=dev)
     obs = torch.zeros((n, blob.obs_dim), device=dev); rew = torch.zeros(n, device=dev)
     done = torch.zeros(n, dtype=torch.uint8, device=dev); info = torch.zeros((n, 8), device=dev)
-    dw = load().agx_debug_words()
+    dw, o_con, o_minv, md = st.debug_layout()[:4]
     dbg = torch.zeros((n, dw), device=dev)
     st.step_dev(act, obs, rew, done, info, debug=dbg)
     torch.cuda.synchronize()
@@ -98,11 +99,11 @@ def test_debug_internals_match_oracle(gpu_lib, blob, oracle):
         con = oracle.substep_debug(ref)
         nc = int(dbg[i, 0])
         assert nc == len(con)
-        ce = dbg[i, 16:16 + 64 * 16].reshape(64, 16)[:nc]
+        ce = dbg[i, o_con:o_con + 64 * 16].reshape(64, 16)[:nc]
         cei = ce.view(np.int32)
         assert np.array_equal(cei[:, 0], con[:, 0].astype(np.int32)) and np.array_equal(cei[:, 1], con[:, 1].astype(np.int32))
         assert np.abs(ce[:, 13] - con[:, 11]).max() < 1e-5
-        Minv = dbg[i, 16 + 1024:16 + 1024 + 256].reshape(16, 16)[:blob.ndof, :blob.ndof]
+        Minv = dbg[i, o_minv:o_minv + md * md].reshape(md, md)[:blob.ndof, :blob.ndof]
         Mo = oracle.minv(states[i].copy())
         nr = blob.nrobot
         assert np.abs(Minv[:nr, :nr] - Mo[:nr, :nr]).max() / np.abs(Mo[:nr, :nr]).max() < 1e-4
