@@ -87,6 +87,10 @@ class ModelBlob:
     def task_i(self, key):
         return int(self.i[self.h['OFF_TASK'] + L.T[key]])
 
+    def task_i_n(self, key, n):
+        o = self.h['OFF_TASK'] + L.T[key]
+        return [int(x) for x in self.i[o:o + n]]
+
     def collider(self, c):
         o = self.h['OFF_COLL'] + c * L.C['STRIDE']
         nv, vo = int(self.i[o + L.C['NVERT']]), int(self.i[o + L.C['VOFF']])

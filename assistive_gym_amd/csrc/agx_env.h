@@ -16,7 +16,7 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
     // Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250)
     if (RBI(c, d, AGX_R_KIND) == 1 && !(c.frozen >> d & 1)) {
       const float lo = DLO(c, d), hi = DHI(c, d);
-      if (q < lo) { q = lo; qd = 0.f; } else if (q > hi) { q = hi; qd = 0.f; }
+      if (q < lo - AGX_LIMIT_EPS) { q = lo; qd = 0.f; } else if (q > hi + AGX_LIMIT_EPS) { q = hi; qd = 0.f; }
     }
     L[L_ST + c.s_qd + d] = qd; L[L_ST + c.s_q + d] = q;
   }

@@ -1,7 +1,8 @@
-"""gym.Env surface of the reference for the FeedingJaco-v1 hot path.
+"""gym.Env surface of the reference for the built hot paths (FeedingJaco-v1, BedBathingSawyer-v1 and their co-op flavours).
 
 Mirrors, by name and behaviour, what assistive_gym/learn.py and env_viewer.py touch
-(SURVEY 8b): class ``FeedingJacoEnv`` (assistive_gym/envs/feeding_envs.py:29-31) with
+(SURVEY 8b): classes ``FeedingJacoEnv`` (assistive_gym/envs/feeding_envs.py:29-31) and ``BedBathingSawyerEnv``
+(assistive_gym/envs/bed_bathing_envs.py:23-25) with
 ``reset() -> obs``, ``step(a) -> (obs, reward, done, info)`` (feeding.py:12-43), ``seed``
 (env.py:78-80), ``set_seed``, ``disconnect``, ``render`` (no-op: rendering is out of scope),
 ``action_space`` / ``observation_space`` (+ ``_robot`` / ``_human`` variants, env.py:42-49),
@@ -60,14 +61,23 @@ def _box(n, bound):
     return spaces.Box(low=-v, high=v, dtype=np.float32)
 
 
-class FeedingJacoEnv(_Base):
-    """FeedingJaco-v1: Jaco arm on a wheelchair feeds a static (non-cooperating) human."""
+class _Agent:
+    """The attributes of the reference's Robot / Human / Tool objects that learn.py, env_viewer.py and user scripts read
+    (controllable_joint_indices, agent.py:21; Robot tables, robot.py:6-39).  Physics calls on them do not exist here."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class AssistiveEnv(_Base):
+    """Common part of the scalar envs (AssistiveEnv, assistive_gym/envs/env.py:21-67)."""
     coop = False
+    model = None            # blob name
+    task = None
 
     def __init__(self, device=0):
-        self.task = 'feeding'
         self.time_step, self.frame_skip = 0.02, 5                                    # env.py:21
-        base = ModelBlob.load('feeding_jaco')
+        base = ModelBlob.load(self.model)
         self.blob = base.coop() if self.coop else base
         self.device = device
         self.action_robot_len, self.obs_robot_len = base.act_dim, base.obs_dim       # env.py:40-44, feeding.py:10
@@ -82,6 +92,12 @@ class FeedingJacoEnv(_Base):
         self.task_success = 0
         self.total_force_on_human = 0.0
         self._stepper = None
+        arm_pb = [base.robot_i(d, 'PB_INDEX') for d in sorted((d for d in range(base.nrobot) if base.robot_i(d, 'ACT') >= 0), key=lambda d: base.robot_i(d, 'ACT'))]
+        hum_pb = [self.blob.robot_i(d, 'PB_INDEX') for d in range(base.nrobot, base.ndof)] if self.coop else []
+        self.robot = _Agent(controllable_joint_indices=arm_pb, mobile=False, motor_gains=base.robot_f(0, 'KP'), motor_forces=base.robot_f(0, 'MAXF'))
+        self.human = _Agent(controllable_joint_indices=hum_pb, controllable=self.coop)
+        self.tool = _Agent()
+        self.camera_width, self.camera_height, self.view_matrix, self.projection_matrix = None, None, None, None
         self.seed(1001)                                                               # env.py:21,30
 
     # ---- gym API ------------------------------------------------------------------------------
@@ -105,14 +121,7 @@ class FeedingJacoEnv(_Base):
         return (int(draw(0, 2 ** 31 - 1)) << 31) | int(draw(0, 2 ** 31 - 1))
 
     def reset(self):
-        """FeedingEnv.reset (feeding.py:114-182): sampled on the device (agx_sample_reset: human, IK with random
-        restarts, tool / bowl / food), settled for 25 substeps, observed."""
-        st = self._ensure_stepper()
-        self.reset_seed = self._draw_seed()
-        st.sample_reset(self.reset_seed, impairment='random')
-        st.settle(SETTLE_STEPS)
-        self.iteration, self.task_success = 0, 0
-        return self._split_obs(st.observe_host()[0].astype(np.float64))
+        raise NotImplementedError('Implement reset')                                              # env.py:69-70
 
     def _split_obs(self, obs):
         if not self.coop:
@@ -142,6 +151,16 @@ class FeedingJacoEnv(_Base):
     def render(self, mode='human'):
         return None          # GUI / EGL rendering is outside the hot path
 
+    def setup_camera(self, camera_eye=(0.5, -0.75, 1.5), camera_target=(-0.2, 0, 0.75), fov=60, camera_width=1920 // 4, camera_height=1080 // 4):
+        """env.py:336-340: remembered only; there is no renderer behind it"""
+        self.camera_width, self.camera_height = camera_width, camera_height
+        self.view_matrix, self.projection_matrix = (tuple(camera_eye), tuple(camera_target)), fov
+
+    def get_camera_image_depth(self, *a, **kw):
+        assert self.view_matrix is not None, 'You must call env.setup_camera() or env.setup_camera_rpy() before getting a camera image'   # env.py:355
+        # rendering is out of scope: a blank frame of the requested size keeps learn.render_policy's loop (learn.py:96-131) running
+        return np.zeros((self.camera_height, self.camera_width, 4), dtype=np.uint8), np.ones((self.camera_height, self.camera_width), dtype=np.float32)
+
     def disconnect(self):
         if self._stepper is not None:
             self._stepper.close()
@@ -157,13 +176,47 @@ class FeedingJacoEnv(_Base):
         self._ensure_stepper().set_state(np.asarray(state, dtype=np.float32).reshape(1, -1))
 
 
+class FeedingJacoEnv(AssistiveEnv):
+    """FeedingJaco-v1: Jaco arm on a wheelchair feeds a static (non-cooperating) human."""
+    model, task = 'feeding_jaco', 'feeding'
+
+    def reset(self):
+        """FeedingEnv.reset (feeding.py:114-182): sampled on the device (agx_sample_reset: human, IK with random
+        restarts, tool / bowl / food), settled for 25 substeps, observed."""
+        st = self._ensure_stepper()
+        self.reset_seed = self._draw_seed()
+        st.sample_reset(self.reset_seed, impairment='random')
+        st.settle(SETTLE_STEPS)
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+
 class FeedingJacoHumanEnv(FeedingJacoEnv):
     """FeedingJacoHuman-v1 (feeding_envs.py:64-67): the human's head joints are controllable; actions,
     observations, rewards, dones and infos are per-agent dictionaries as RLlib's MultiAgentEnv expects."""
     coop = True
 
 
-ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv}
+class BedBathingSawyerEnv(AssistiveEnv):
+    """BedBathingSawyer-v1 (bed_bathing_envs.py:23-25): Sawyer wipes the right arm of a human lying on a bed."""
+    model, task = 'bed_bathing_sawyer', 'bed_bathing'
+
+    def reset(self):
+        """BedBathingEnv.reset (bed_bathing.py:112-171), restated on the host (host/reset_bed.py: human draws, lying pose,
+        TOC base pose search, IK); its result is injected into the stepper."""
+        from .host.reset_bed import BedBathingSawyerReset
+        st = self._ensure_stepper()
+        if not hasattr(self, '_sampler'):
+            self._sampler = BedBathingSawyerReset(self.blob)
+        self.reset_seed = self._draw_seed()
+        rec = self.blob.new_state(1)
+        self._sampler.sample(np.random.RandomState(self.reset_seed % (2 ** 32)), rec, env_seed=self.reset_seed % (2 ** 31))
+        st.set_state(rec)
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+
+ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv}
 
 
 def make(env_id):
@@ -179,5 +232,6 @@ if gym is not None:       # same ids the reference registers (assistive_gym/__in
     try:
         from gym.envs.registration import register
         register(id='FeedingJaco-v1', entry_point='assistive_gym_amd.envs:FeedingJacoEnv', max_episode_steps=200)
+        register(id='BedBathingSawyer-v1', entry_point='assistive_gym_amd.envs:BedBathingSawyerEnv', max_episode_steps=200)
     except Exception:
         pass

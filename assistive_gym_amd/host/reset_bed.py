@@ -1,0 +1,295 @@
+"""Host-side reset for BedBathingSawyer-v1: produces post-reset state records (the stepper's input).
+
+Follows the order of BedBathingEnv.reset (assistive_gym/envs/bed_bathing.py:112-171) and what it calls:
+build_assistive_env('bed', fixed_human_base=False) (envs/env.py:114-134: plane friction, Human.init draws,
+agents/human.py:72-102), the human posed in the air and its joints perturbed by U(-0.1, 0.1) (bed_bathing.py:119-127),
+the settle onto the bed (bed_bathing.py:129-137), the target end-effector pose (bed_bathing.py:147-148),
+init_robot_pose -> Robot.position_robot_toc (env.py:276-310, robot.py:123-215: 50 random base poses scored by goals
+reached and joint-limit-weighted kinematic isotropy), the gripper (bed_bathing.py:156), generate_targets
+(bed_bathing.py:173-188) and the per-body gravities (bed_bathing.py:160-165, compiled into the blob).
+
+Reset is outside the kernel scope; only its RESULT feeds the stepper.  What is NOT the reference's:
+  * Bullet's IK is replaced by damped least squares (as in host/kin.py); the TOC search keeps the reference's structure
+    (50 attempts, start pose + 3 position-only goals, success threshold 0.03, JLWKI score);
+  * the 100-step rag-doll settle of the 47-DoF floating human (bed_bathing.py:129-131) is produced by `settle`:
+    'drop' (default here) lowers the posed human rigidly until its first collider touches the mattress -- a kinematic
+    stand-in that keeps the perturbed joint angles but lets limbs float above the bed by the difference of their radii;
+  * the collision rejection loop of init_robot_pose (env.py:299-308) is not run.
+"""
+import numpy as np
+
+from ..model import compiler as L
+from ..model import xform as X
+from ..model.human import HumanModel
+
+D = np.deg2rad
+
+
+class ArmChain:
+    """Batched (numpy) kinematics of the serial chain base -> end-effector link of the compiled robot."""
+
+    def __init__(self, blob):
+        self.blob = blob
+        ee = blob.task_i('EE_LINK')
+        chain = []
+        d = ee
+        while d >= 0:
+            chain.append(d)
+            d = blob.robot_i(d, 'PARENT')
+        self.chain = chain[::-1]                                  # root -> ee
+        assert all(blob.robot_i(d, 'JTYPE') == 0 for d in self.chain)
+        self.tpos = np.array([blob.robot_f(d, 'TPOS', 3) for d in self.chain])
+        self.tR = np.array([X.quat_to_mat(blob.robot_f(d, 'TQUAT', 4)) for d in self.chain])
+        self.axis = np.array([blob.robot_f(d, 'AXIS', 3) for d in self.chain])
+        self.lower = np.array([blob.robot_f(d, 'LOWER') for d in self.chain])
+        self.upper = np.array([blob.robot_f(d, 'UPPER') for d in self.chain])
+        self.act = [blob.robot_i(d, 'ACT') for d in self.chain]
+        assert all(a >= 0 for a in self.act), 'every joint between the base and the end effector is an arm joint'
+        self.ee_pos = blob.task_f('EE_POS', 3)
+        self.ee_R = X.quat_to_mat(blob.task_f('EE_QUAT', 4))
+        self.n = len(self.chain)
+
+    @staticmethod
+    def _rot(axis, ang):
+        """Rodrigues, batched over ang (B,) for one axis (3,) -> (B, 3, 3)"""
+        a = axis / np.linalg.norm(axis)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        s, c = np.sin(ang)[:, None, None], np.cos(ang)[:, None, None]
+        return np.eye(3)[None] + s * K[None] + (1 - c) * (K @ K)[None]
+
+    def fk(self, base_pos, base_R, q):
+        """base_pos (B,3), base_R (B,3,3), q (B,n) -> ee pos (B,3), ee R (B,3,3), joint origins (B,n,3), joint axes in world (B,n,3)"""
+        B = q.shape[0]
+        p, R = base_pos.copy(), base_R.copy()
+        orig, axw = np.zeros((B, self.n, 3)), np.zeros((B, self.n, 3))
+        for k in range(self.n):
+            p = p + np.einsum('bij,j->bi', R, self.tpos[k])
+            R = R @ self.tR[k][None]
+            orig[:, k] = p
+            axw[:, k] = np.einsum('bij,j->bi', R, self.axis[k])
+            R = R @ self._rot(self.axis[k], q[:, k])
+        pe = p + np.einsum('bij,j->bi', R, self.ee_pos)
+        return pe, R @ self.ee_R[None], orig, axw
+
+    def jacobian(self, pe, orig, axw):
+        Jl = np.cross(axw, pe[:, None, :] - orig)                 # (B,n,3)
+        return np.concatenate([Jl.transpose(0, 2, 1), axw.transpose(0, 2, 1)], axis=1)    # (B,6,n)
+
+    def ik(self, base_pos, base_R, q0, target_pos, target_R=None, iters=100, damping=0.05, maxstep=0.5):
+        """Damped least squares, batched; target_R None = position only.  Returns q (B,n)."""
+        q = q0.copy()
+        for _ in range(iters):
+            pe, Re, orig, axw = self.fk(base_pos, base_R, q)
+            J = self.jacobian(pe, orig, axw)
+            e = target_pos - pe
+            if target_R is not None:
+                Rerr = target_R @ Re.transpose(0, 2, 1)
+                w = 0.5 * np.stack([Rerr[:, 2, 1] - Rerr[:, 1, 2], Rerr[:, 0, 2] - Rerr[:, 2, 0], Rerr[:, 1, 0] - Rerr[:, 0, 1]], axis=1)
+                e = np.concatenate([e, w], axis=1)
+            else:
+                J = J[:, :3]
+            A = J @ J.transpose(0, 2, 1) + damping ** 2 * np.eye(J.shape[1])[None]
+            dq = np.einsum('bji,bj->bi', J, np.linalg.solve(A, e[..., None])[..., 0])
+            step = np.abs(dq).max(axis=1, keepdims=True)
+            dq = np.where(step > maxstep, dq * (maxstep / np.maximum(step, 1e-30)), dq)
+            q = np.clip(q + dq, self.lower[None], self.upper[None])
+        return q
+
+
+def mat_to_quat_batch(R):
+    return np.array([X.mat_to_quat(r) for r in R])
+
+
+def joint_limited_weighting(q, lower, upper):
+    """Robot.joint_limited_weighting (robot.py:217-228), batched over q (B,n) -> diagonal weights (B,n)"""
+    phi, lam = 0.5, 0.05
+    qr = 0.5 * (upper - lower)
+    w = 1.0 - np.power(phi, (qr - np.abs(qr - q + lower)) / (lam * qr) + 1)
+    return np.maximum(w, 0.001)
+
+
+class BedBathingSawyerReset:
+    def __init__(self, blob, settle='drop'):
+        assert blob.task_kind == L.TASK_BED_BATHING
+        self.blob = blob
+        self.arm = ArmChain(blob)
+        self.human_bodies = blob.meta['human_bodies']
+        self.human_dyn = blob.meta['human_dynamic_joints']
+        self.settle = settle
+        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array([-0.2, 0, 0.975])          # robot.py:142 + sawyer.py:37
+        self.ee_R = X.quat_to_mat(X.quat_from_rpy([0, np.pi / 2.0, 0]))                     # sawyer.py:43 toc_ee_orient_rpy
+        r = blob.meta['ranges']
+        self._bed = [blob.collider(c)['verts'] for c in range(*r['bed'])]
+        self._bed_box = np.array([[v.min(0), v.max(0)] for v in self._bed])
+        self._hm = {}
+
+    def _human(self, gender, limit_scale):
+        key = (gender, round(float(limit_scale), 9))
+        if key not in self._hm:
+            if len(self._hm) > 64:
+                self._hm.clear()
+            self._hm[key] = HumanModel(gender, limit_scale)
+        return self._hm[key]
+
+    # ---- the lying human --------------------------------------------------------------------------------
+    def _bed_top(self, x, y):
+        """height of the bed's collision geometry under (x, y): top of the hulls whose footprint box contains the point"""
+        b = self._bed_box
+        inside = (b[:, 0, 0] <= x) & (x <= b[:, 1, 0]) & (b[:, 0, 1] <= y) & (y <= b[:, 1, 1]) & (b[:, 1, 2] < 0.9)   # not the head / foot boards
+        return float(b[inside, 1, 2].max()) + L.HULL_MARGIN if inside.any() else 0.0
+
+    def _drop(self, hm, base_pos, base_quat, hq):
+        """lowers the rigidly posed human until its first collider rests on the bed"""
+        pos, quat = hm.fk(base_pos, base_quat, hq)
+        dz = -np.inf
+        for link, kind, data in hm.colliders():
+            lp, lq = (base_pos, base_quat) if link < 0 else (pos[link], quat[link])
+            if kind == 'capsule':
+                pts, r = X.apply(lp, lq, np.stack([data[0], data[1]])), data[2]
+            elif kind == 'sphere':
+                pts, r = X.apply(lp, lq, data[0][None]), data[1]
+            else:
+                continue            # the head mesh: it rests on the pillow region, the neck / chest decide
+            for p in pts:
+                dz = max(dz, self._bed_top(p[0], p[1]) + r - p[2])
+        return base_pos + np.array([0, 0, dz])
+
+    # ---- TOC base pose search (robot.py:123-215) ---------------------------------------------------------
+    def _toc(self, rng, start_pos, goals, attempts=50):
+        arm = self.arm
+        A = attempts
+        rp = np.stack([rng.uniform(-0.5, 0, size=A), rng.uniform(-0.5, 0.5, size=A), np.zeros(A)], axis=1)     # right_side=True, random_position 0.5
+        yaw = D(rng.uniform(-30, 30, size=A))                                                                 # random_rotation 30
+        # the reference draws position and yaw alternately per attempt; the draws here are made in two blocks (not stream compatible anyway)
+        base_pos = self.toc_base[None] + rp
+        base_R = np.array([X.quat_to_mat(X.quat_from_rpy([0, 0, y])) for y in yaw])
+        ng = 1 + len(goals)
+        lo = np.where(arm.lower < -1e9, -2 * np.pi, arm.lower)
+        hi = np.where(arm.upper > 1e9, 2 * np.pi, arm.upper)
+        q0 = rng.uniform(lo, hi, size=(A, ng, arm.n))                                                         # agent.py:263 rest poses
+        reached = np.zeros((A, ng), dtype=bool)
+        jl = np.zeros((A, ng))
+        qsol = np.zeros((A, ng, arm.n))
+        for g in range(ng):
+            tp = np.repeat((start_pos if g == 0 else goals[g - 1])[None], A, axis=0)
+            tR = np.repeat(self.ee_R[None], A, axis=0) if g == 0 else None
+            q = arm.ik(base_pos, base_R, q0[:, g], tp, tR, iters=100)                                        # max_ik_iterations=100
+            pe, Re, orig, axw = arm.fk(base_pos, base_R, q)
+            ok = np.linalg.norm(tp - pe, axis=1) < 0.03                                                      # robot.py:97 success_threshold
+            if tR is not None:
+                qe, qt = mat_to_quat_batch(Re), X.mat_to_quat(self.ee_R)
+                dq = np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1))
+                ok &= dq < 0.03
+            J = arm.jacobian(pe, orig, axw)
+            W = joint_limited_weighting(q, arm.lower, arm.upper)
+            M = np.einsum('bij,bj,bkj->bik', J, W, J)
+            det = np.maximum(np.linalg.det(M), 0)
+            jl[:, g] = np.power(det, 1.0 / 6) / (np.trace(M, axis1=1, axis2=2) / 6)                          # robot.py:189-191
+            reached[:, g] = ok
+            qsol[:, g] = q
+        valid = reached[:, 0]                                   # the start goal must be reachable (robot.py:196-200)
+        ngoal = np.where(valid, reached.sum(1), -1)
+        manip = np.where(valid, (jl * reached).sum(1), -np.inf)
+        best = max(range(A), key=lambda a: (ngoal[a], manip[a]))   # first of equals = the earliest attempt, as the strict > of robot.py:204
+        if ngoal[best] <= 0:
+            return None
+        return base_pos[best], X.mat_to_quat(base_R[best]), qsol[best, 0], int(ngoal[best]), float(manip[best])
+
+    def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None):
+        """Fill one state record (float32 view of length state_words) in place."""
+        b = self.blob
+        v = b.view(state_row)
+        nr, nh = b.nrobot, b.nhdof
+        plane_friction = rng.uniform(0.025, 0.5)                                   # env.py:120
+        if gender not in ('male', 'female'):
+            gender = rng.choice(['male', 'female'])                                # human.py:76-77
+        if impairment == 'random':
+            impairment = rng.choice(['none', 'limits', 'weakness', 'tremor'])      # human.py:80-81
+        elif impairment == 'no_tremor':
+            impairment = rng.choice(['none', 'limits', 'weakness'])
+        limit_scale = 1.0 if impairment != 'limits' else rng.uniform(0.5, 1.0)     # human.py:85
+        strength = 1.0 if impairment != 'weakness' else rng.uniform(0.25, 1.0)     # human.py:86
+        tremors = np.zeros(nh)
+        if impairment == 'tremor':
+            tremors = rng.uniform(D(-10), D(10), size=nh)                          # human.py:91-92 (the head is not controllable)
+        rng.uniform(0.4, 0.8)                                                      # skin colour, human_creation.py:63
+        hm = self._human(gender, limit_scale)
+        # bed_bathing.py:119-127: pose in the air, every motor joint ~ U(-0.1, 0.1) (this overwrites the 30 degree shoulder preset), limits enforced
+        hq = np.zeros(hm.n)
+        movable = [j for j in range(hm.n) if hm.jtype[j] == 'r']
+        hq[movable] = rng.uniform(-0.1, 0.1, size=len(movable))
+        for j, a in (human_q_override or {}).items():          # tests only: e.g. an abducted arm
+            hq[j] = a
+        hq = hm.clamp(hq)
+        base_pos, base_quat = np.array([-0.15, 0.2, 0.95]), X.quat_from_rpy([-np.pi / 2.0, 0, 0])
+        base_pos = self._drop(hm, base_pos, base_quat, hq)                         # stand-in for the settle, see module docstring
+        hpos, hquat = hm.fk(base_pos, base_quat, hq)
+        for k, link in enumerate(self.human_bodies):
+            if link < 0:
+                v['human'][0, k, :3], v['human'][0, k, 3:] = base_pos, base_quat
+            else:
+                v['human'][0, k, :3], v['human'][0, k, 3:] = hpos[link], hquat[link]
+        shoulder, elbow, wrist = hpos[5], hpos[7], hpos[9]                         # bed_bathing.py:139-141
+        target_ee_pos = np.array([-0.6, 0.2, 1]) + rng.uniform(-0.05, 0.05, size=3)    # bed_bathing.py:147
+        toc = None
+        for _ in range(4):
+            toc = self._toc(rng, target_ee_pos, [shoulder, elbow, wrist])
+            if toc is not None:
+                break
+        assert toc is not None, 'no reachable base pose found'
+        rb_pos, rb_quat, q_arm, ngoal, manip = toc
+        q = np.zeros(nr)
+        for k, d in enumerate(self.arm.chain):
+            q[d] = q_arm[k]
+        for d in range(nr):                                                        # gripper open position, set instantly (bed_bathing.py:156)
+            if b.robot_i(d, 'ACT') < 0:
+                q[d] = min(max(b.robot_f(d, 'QT0'), b.robot_f(d, 'LOWER')), b.robot_f(d, 'UPPER'))
+        v['q'][0, :nr] = q
+        v['qd'][0] = 0
+        v['qt'][0, :nr] = q
+        hq_dyn = np.array([hq[j] for j in self.human_dyn])
+        v['q'][0, nr:] = hq_dyn
+        v['qt'][0, nr:] = hq_dyn
+        v['tremor'][0] = tremors
+        v['tremor_target'][0] = hq_dyn                                             # human.py:123 target_joint_angles
+        # human.setup_joints(use_static_joints=True) after the settle (bed_bathing.py:134): every link static unless the impairment is tremor
+        v['frozen'][0] = 0 if (impairment == 'tremor' or b.is_coop) else (((1 << nh) - 1) << nr)
+        v['limit_scale'][0] = limit_scale
+        v['base'][0, :3], v['base'][0, 3:] = rb_pos, rb_quat
+        # tool in the gripper (tool.py:49-62): base frame = end-effector frame o TOOL; the record holds the COM frame
+        pe, Re, _, _ = self.arm.fk(rb_pos[None], X.quat_to_mat(rb_quat)[None], q_arm[None])
+        tp, tq = X.compose(pe[0], X.mat_to_quat(Re[0]), b.task_f('TOOL_POS', 3), b.task_f('TOOL_QUAT', 4))
+        ip, iq = X.invert(b.free_f(0, 'REFPOS', 3), b.free_f(0, 'REFQUAT', 4))
+        cp, cq = X.compose(tp, tq, ip, iq)
+        free = v['free'][0]
+        free[:] = 0
+        free[0, :3], free[0, 3:7] = cp, cq
+        g = 0 if gender == 'male' else 1
+        nt = b.task_i_n('NT', 4)[2 * g] + b.task_i_n('NT', 4)[2 * g + 1]
+        v['plane_friction'][0] = plane_friction
+        v['gender'][0] = g
+        v['iteration'][0] = 0
+        v['task_success'][0] = 0
+        v['total_food'][0] = nt                                                    # total_target_count (bed_bathing.py:187)
+        alive = np.zeros(L.BB['ALIVE_WORDS'], dtype=np.uint32)
+        for t in range(nt):
+            alive[t >> 5] |= np.uint32(1 << (t & 31))
+        v['task'][0, L.BB['ALIVE']:L.BB['ALIVE'] + L.BB['ALIVE_WORDS']] = alive.view(np.int32)
+        v['rng'][0, 0] = (env_seed * 2654435761 + 12345) & 0x7FFFFFFF
+        v['rng'][0, 1] = (env_seed ^ 0x5bd1e995) & 0x7FFFFFFF
+        if info is not None:
+            info.update(gender=gender, impairment=impairment, limit_scale=limit_scale, strength=strength, tremors=tremors,
+                        toc_goals=ngoal, toc_manipulability=manip, target_ee_pos=target_ee_pos, human_q=hq, human_base=(base_pos, base_quat))
+        return state_row
+
+
+def make_states(blob, n, seed=1001, impairment='random', **kw):
+    """n independent post-reset states; env i uses RandomState(seed + i)."""
+    rs = BedBathingSawyerReset(blob)
+    st = blob.new_state(n)
+    infos = []
+    for i in range(n):
+        info = {}
+        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], env_seed=seed + i, impairment=impairment, info=info, **kw)
+        infos.append(info)
+    return st, infos

@@ -1,8 +1,8 @@
-"""Batched FeedingJaco-v1 environments on one GPU (torch tensors in / out, state resident in HBM).
+"""Batched environments on one GPU (torch tensors in / out, state resident in HBM).
 
 The scalar gym.Env facade with the reference's class names lives in assistive_gym_amd/envs.py;
-this is the data-parallel form: N lock-stepped copies of FeedingJacoEnv
-(assistive_gym/envs/feeding_envs.py:29-31), stepped by one kernel launch per env.step().
+this is the data-parallel form: N lock-stepped copies of FeedingJacoEnv (assistive_gym/envs/feeding_envs.py:29-31)
+or BedBathingSawyerEnv (assistive_gym/envs/bed_bathing_envs.py:23-25), stepped by a few kernel launches per env.step().
 """
 import numpy as np
 import torch
@@ -18,7 +18,12 @@ SETTLE_STEPS = 25   # feeding.py:178-179
 def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device'):
     """pool_size post-reset states: FeedingEnv.reset's sampling (sampler 'device': agx_sample_reset on the GPU;
     'host': the numpy path of host/reset.py), then the 25 settle steps of feeding.py:178-179 on the device.
+    BedBathingSawyer: BedBathingEnv.reset restated on the host (host/reset_bed.py; its reset ends without settle steps).
     Returns a float32 (pool_size, state_words) array."""
+    from .model import compiler as L
+    if blob.task_kind == L.TASK_BED_BATHING:
+        from .host.reset_bed import make_states as make_bed_states
+        return make_bed_states(blob, pool_size, seed=seed, impairment=impairment)[0]
     st = Stepper(blob, pool_size, device)
     if sampler == 'device':
         st.sample_reset(seed, impairment=impairment)
@@ -34,8 +39,9 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     return out
 
 
-class FeedingJacoVecEnv:
-    """reset modes (all sampled and settled on the GPU unless 'host'):
+class AssistiveVecEnv:
+    """N lock-stepped environments of one compiled model (`model` = blob name: 'feeding_jaco', 'bed_bathing_sawyer').
+    reset modes (all sampled and settled on the GPU unless 'host'):
       'pool'    -- a fixed pool of pool_size post-reset states generated once; done envs draw from it
                    (BASELINE config 2: "auto-reset from pool", SURVEY 8d);
       'device'  -- every episode of every env starts from a NEWLY sampled state, as in the reference where each
@@ -43,9 +49,11 @@ class FeedingJacoVecEnv:
                    (sampling + settle, in place) when the lock-stepped batch reaches the end of its 200-step episode;
       'host'    -- 'pool' with the numpy sampler (host/reset.py)."""
 
-    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool'):
+    model = 'feeding_jaco'
+
+    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool', model=None):
         assert reset in ('pool', 'device', 'host')
-        self.blob = blob or ModelBlob.load('feeding_jaco')
+        self.blob = blob or ModelBlob.load(model or self.model)
         self.n_envs, self.device_index, self.seed = n_envs, device, seed
         self.device = torch.device('cuda', device)
         self.pool_size, self.impairment, self.auto_reset, self.reset_mode = pool_size, impairment, auto_reset, reset
@@ -85,6 +93,7 @@ class FeedingJacoVecEnv:
                 self.pool = torch.from_numpy(self.pool_host).to(self.device)
             idx = pool_indices(env_offset, self.n_envs, self.pool_size)
             self.stepper.set_state(self.pool_host[idx])
+            self.stepper.set_env_offset(env_offset)       # later episodes draw from the pool by GLOBAL env index too
         self.stepper.observe_dev(self.obs, s)
         return self.obs
 
@@ -108,3 +117,17 @@ class FeedingJacoVecEnv:
 
     def close(self):
         self.stepper.close()
+
+
+class FeedingJacoVecEnv(AssistiveVecEnv):
+    model = 'feeding_jaco'
+
+
+class BedBathingSawyerVecEnv(AssistiveVecEnv):
+    """BASELINE config 3.  Resets come from a pool of host-sampled post-reset states (reset='pool' / 'host')."""
+    model = 'bed_bathing_sawyer'
+
+    def __init__(self, n_envs, **kw):
+        kw.setdefault('reset', 'pool')
+        assert kw['reset'] != 'device', 'no device-side reset generator for BedBathingSawyer: use a pool'
+        super().__init__(n_envs, **kw)

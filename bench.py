@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/sec of the batched FeedingJaco-v1 stepper (BASELINE.json metric).
+"""bench.py -- env-steps/sec of the batched stepper (BASELINE.json metric: FeedingJaco-v1, 4096 envs per MI355X;
+`--task bedbathing` = BASELINE config 3, BedBathingSawyer-v1).
 
 One "step" = one env.step() of every one of the 4096 lock-stepped environments of a GPU
 (5 physics substeps of dt 0.02 + observation + reward), plus the auto-reset of
@@ -23,15 +24,21 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+SHADER_CLOCK_HZ = 2.4e9   # same guide: max clock 2400 MHz; 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles
+N_SIMD = 1024
+TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the compiled variant, workload description)
+    'feeding': ('feeding_jaco', 'FeedingJacoVecEnv', '', 'FeedingJaco-v1'),
+    'bedbathing': ('bed_bathing_sawyer', 'BedBathingSawyerVecEnv', '_bb', 'BedBathingSawyer-v1'),
+}
 
 
-def _cpu_worker(path, seed, n_steps):
+def _cpu_worker(path, seed, n_steps, model='feeding_jaco'):
     """`bench.py --cpu-worker`: one host process stepping its share of the sample with the C oracle;
     prints "<env-steps> <seconds>"."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle_lib import Oracle
     from assistive_gym_amd.blob import ModelBlob
-    blob = ModelBlob.load('feeding_jaco')
+    blob = ModelBlob.load(model)
     o = Oracle(blob)
     init = np.load(path)
     st = init.copy()
@@ -63,7 +70,7 @@ def _usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(blob, states, envs_per_core, n_steps):
+def cpu_baseline(blob, states, envs_per_core, n_steps, model='feeding_jaco', workload='FeedingJaco'):
     """The CPU oracle (oracle/, plain C, f64) timed on a bounded sample of the same workload on ALL host
     cores of this box (one process per core, each stepping its own environments -- the reference's own
     scaling model, learn.py:26).  kind = "port": a restatement, NOT PyBullet."""
@@ -76,7 +83,7 @@ def cpu_baseline(blob, states, envs_per_core, n_steps):
         for c in range(cores):
             path = os.path.join(tmp, 'cpu_%d.npy' % c)
             np.save(path, states[(c * envs_per_core + np.arange(envs_per_core)) % len(states)])
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', path, str(c), str(n_steps)],
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', path, str(c), str(n_steps), model],
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         res = []
         for pr in procs:
@@ -90,13 +97,13 @@ def cpu_baseline(blob, states, envs_per_core, n_steps):
     busy = max(r[1] for r in res)                       # slowest worker, excludes interpreter start-up
     single = np.mean([r[0] / r[1] for r in res])
     return dict(value=total / busy, unit='env-steps/s', cores=cores, kind='port',
-                sample='%d processes x %d envs x %d steps of the same FeedingJaco workload, C f64 oracle (not PyBullet); '
-                       'per process %.0f env-steps/s; wall incl. start-up %.1f s' % (cores, envs_per_core, n_steps, single, wall))
+                sample='%d processes x %d envs x %d steps of the same %s workload, C f64 oracle (not PyBullet); '
+                       'per process %.0f env-steps/s; wall incl. start-up %.1f s' % (cores, envs_per_core, n_steps, workload, single, wall))
 
 
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
-        return _cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        return _cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), *(sys.argv[5:6]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
@@ -106,12 +113,14 @@ def main():
     ap.add_argument('--reset', choices=['pool', 'device', 'host'], default='pool',
                     help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--task', choices=sorted(TASKS), default='feeding', help="'feeding' = the BASELINE metric (config 2); 'bedbathing' = config 3")
     args = ap.parse_args()
+    model, env_cls, ksuffix, env_id = TASKS[args.task]
 
     import torch
     import torch.distributed as dist
     from assistive_gym_amd.blob import ModelBlob
-    from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+    from assistive_gym_amd import vec_env
     from assistive_gym_amd.shard import gather_observations
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -124,8 +133,8 @@ def main():
     if distributed:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     n = args.envs_per_gpu
-    blob = ModelBlob.load('feeding_jaco')
-    env = FeedingJacoVecEnv(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset)
+    blob = ModelBlob.load(model)
+    env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset)
     env.reset(env_offset=rank * n)
     K, W = args.steps, args.warmup
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
@@ -175,39 +184,51 @@ def main():
         # algorithmic HBM bytes per env-step: state record read + written once, action read, obs /
         # reward / done / info written (DESIGN.md "bytes per env-step")
         bytes_per_env_step = 2 * sw * 4 + blob.act_dim * 4 + blob.obs_dim * 4 + 4 + 1 + 8 * 4
-        names = ['agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel']
+        names = [k + ksuffix for k in ('agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel')]
         dom = int(np.argmax(kms))
         # one launch of the dominant kernel advances the environments of one chunk by 1/frame_skip of an env-step
         launches = [int(round(x)) for x in kcnt]
+        chunks = launches[2]
+        envs_per_launch = n / chunks
         launch_ms = kms[dom] / launches[dom]
-        units = n / launches[dom]            # env-steps advanced by one launch (all launches of a kind together: n)
+        units = n / launches[dom]            # env-steps advanced by one launch (= envs_per_launch / frame_skip for build / solve)
         achieved = bytes_per_env_step * units / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.exists(tpath):       # PMC passes of tools/pmc_workload.py (separate rocprofv3 runs)
-            tj = json.load(open(tpath))
-            if tj.get('envs') == n and names[dom] in tj.get('kernels', {}):
-                traffic = tj['kernels'][names[dom]]['hbm_bytes_per_launch']
-                traffic_src = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s)' % tj.get('correction', '')
+        # HBM traffic and VALU instruction counts of the same kernel from separate rocprofv3 --pmc passes (tools/pmc_workload.py,
+        # reduced by tools/pmc_traffic.py to per-environment figures), scaled to the SAME launch size as the algorithmic bytes
+        traffic, traffic_src, valu_frac = None, None, None
+        for cand in ('r02_traffic_%s.json' % args.task, 'r01_traffic.json' if args.task == 'feeding' else None):
+            tpath = cand and os.path.join(ROOT, 'profiles', cand)
+            if tpath and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                kj = tj.get('kernels', {}).get(names[dom])
+                if kj:
+                    traffic = kj['hbm_bytes_per_env_launch'] * envs_per_launch
+                    traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s), per environment x %d environments per launch' % (cand, tj.get('correction', ''), envs_per_launch)
+                    if 'valu_insts_per_env_launch' in kj:
+                        # wave64 VALU instruction = 2 issue cycles on a SIMD-32 (guide, "Wave scheduling"); 1024 SIMDs
+                        valu_frac = kj['valu_insts_per_env_launch'] * envs_per_launch * 2.0 / (launch_ms * 1e-3 * SHADER_CLOCK_HZ * N_SIMD)
+                    break
         out = {
             'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'FeedingJaco-v1, %d lockstep envs per MI355X, random-policy rollout, 5 substeps/step, 50 PGS sweeps' % n,
+            'config': {'workload': '%s, %d lockstep envs per MI355X, random-policy rollout, 5 substeps/step, 50 PGS sweeps' % (env_id, n),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': args.pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': names[dom], 'kernel_ms_per_launch': launch_ms, 'launches_per_step': launches[dom],
-                         'chunks': launches[2], 'envs_per_launch': n / launches[2],
+                         'chunks': chunks, 'envs_per_launch': envs_per_launch,
                          'algorithmic_bytes_per_env_step': bytes_per_env_step, 'algorithmic_bytes_per_launch': bytes_per_env_step * units,
+                         'traffic_over_algorithmic': (traffic / (bytes_per_env_step * units)) if traffic else None,
+                         'valu_issue_frac': valu_frac,
                          'kernels_ms_per_step_summed_over_overlapping_launches': dict(zip(names, [float(x) for x in kms])),
                          'stream_ms_per_step': kernel_ms / K,
                          'step_level_achieved': bytes_per_env_step * n / (elapsed / K) / 1e9,
-                         'note': 'latency/VALU-bound solver; HBM fraction reported as the contract requires (SURVEY 8d)'},
+                         'note': 'dependent-chain latency bound solver (VALU issue ~0.3 of peak); HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8, 1000)
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8, 1000, model, env_id)
         print(json.dumps(out))
     env.close()
     if distributed:

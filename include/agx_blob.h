@@ -15,6 +15,10 @@
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
 #define AGX_BLOB_VERSION 8
+/* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
+ * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
+ * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
+#define AGX_LIMIT_EPS 1e-6f
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
 /* face manifold on static world boxes (table top, ground): besides the closest point, up to AGX_FACE_EXTRA more
  * vertices of the other collider become contact candidates -- those within AGX_FACE_BAND of its lowest vertex,

@@ -954,8 +954,8 @@ static void substep(sim_t* s) {
     s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d];
     /* Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250) */
     if (RI(m, d, AGX_R_KIND) == 1 && !(s->frozen >> d & 1)) {
-      if (s->q[d] < dof_lower(s, d)) { s->q[d] = dof_lower(s, d); s->qd[d] = 0; }
-      else if (s->q[d] > dof_upper(s, d)) { s->q[d] = dof_upper(s, d); s->qd[d] = 0; }
+      if (s->q[d] < dof_lower(s, d) - (double)AGX_LIMIT_EPS) { s->q[d] = dof_lower(s, d); s->qd[d] = 0; }
+      else if (s->q[d] > dof_upper(s, d) + (double)AGX_LIMIT_EPS) { s->q[d] = dof_upper(s, d); s->qd[d] = 0; }
     }
   }
   for (int b = 0; b < s->nfree; b++) {

@@ -1,12 +1,17 @@
 """Workload for the PMC passes: 6 observation-only launches (known traffic: one state record read,
-one observation written per env) followed by 6 full env.step launches, 4096 envs."""
+one observation written per env) followed by 6 full env.step launches, 4096 envs, unchunked
+(AGX_CHUNKS=1: every launch covers all environments, so per-launch counters are per 4096 environments).
+  python tools/pmc_workload.py [feeding|bedbathing]"""
 import os, sys
+os.environ.setdefault('AGX_CHUNKS', '1')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+from assistive_gym_amd import vec_env
+task = sys.argv[1] if len(sys.argv) > 1 else 'feeding'
+cls = {'feeding': 'FeedingJacoVecEnv', 'bedbathing': 'BedBathingSawyerVecEnv'}[task]
 n = 4096
-env = FeedingJacoVecEnv(n, pool_size=64, seed=1001, auto_reset=False)
+env = getattr(vec_env, cls)(n, pool_size=64, seed=1001, auto_reset=False)
 env.reset()
 torch.cuda.synchronize()
 for _ in range(6):
@@ -14,6 +19,6 @@ for _ in range(6):
 torch.cuda.synchronize()
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 for _ in range(6):
-    a = torch.rand((n, 7), device='cuda', generator=g) * 2 - 1
+    a = torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1
     env.step(a)
 torch.cuda.synchronize()
