@@ -51,6 +51,9 @@ class ModelBlob:
         # obs_human_len: 19 + joints in feeding.py:10, 18 + joints in bed_bathing.py:10
         wi[L.H['OBS_DIM']] = self.obs_dim_robot + (18 if self.task_kind == L.TASK_BED_BATHING else 19) + n_h
         wi[self.h['OFF_TASK'] + L.T['COOP']] = 1
+        # pose-dependent arm limits (human.py:134-152) run when a shoulder joint is controllable (human.py:136-137)
+        if self.h['OFF_MLP'] and any(self.robot_i(d, 'ACT') >= 0 for d in self.task_i_n('ARM_LIMIT_DOF', 1)):
+            wi[self.h['OFF_TASK'] + L.T['ARM_LIMIT_ON']] = 1
         return ModelBlob(w, self.meta)
 
     @property

@@ -35,6 +35,49 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
   }
   wave_sync();
 }
+// Human.enforce_realistic_joint_limits (human.py:134-152) after Agent.enforce_joint_limits (env.py:229-231): the four arm angles,
+// remapped as the training data was (human.py:142-145), go through the Keras classifier Dense(4->64, tanh) x3 -> Dense(64->1,
+// sigmoid) (assets/realistic_arm_limits_model.h5, weights in the blob's MLP section).  Class 1 (sigma > 0.5 <=> logit > 0): the pose
+// is remembered; class 0: the four joints are put back to the last valid pose with zero velocity (set_joint_angles, agent.py:154-156).
+// lane = hidden unit; the activations of a layer are exchanged through 64 words of LDS (`X`, dead storage of the caller).
+AGX_DEV void arm_limits(Ctx& c, float* X) {
+  if (!TKI(c, AGX_T_ARM_LIMIT_ON)) return;
+  float* L = c.lds; int* Li = c.ldsi; const int lane = c.lane;
+  const float* W1 = c.bf + c.bi[AGX_H_OFF_MLP]; const float* W2 = W1 + 4 * 64 + 64; const float* W3 = W2 + 64 * 64 + 64; const float* W4 = W3 + 64 * 64 + 64;
+  const int s_task = c.bi[AGX_H_S_TASK];
+  const float sg = TKF(c, AGX_T_ARM_LIMIT_SIGN), TWO_PI = 6.28318530717959f;
+  int dof[4]; float a[4];
+  for (int k = 0; k < 4; k++) {
+    dof[k] = TKI(c, AGX_T_ARM_LIMIT_DOF + k);
+    // the reference reads the angles after its strict limit reset; here the reset has the tolerance AGX_LIMIT_EPS, so clamp what is read
+    a[k] = wave_clamp(L[L_ST + c.s_q + dof[k]], DLO(c, dof[k]), DHI(c, dof[k]));
+  }
+  const float x0 = sg * a[0] + TWO_PI, x1 = a[1] + TWO_PI, x2 = sg * a[2], x3 = -a[3] + TWO_PI;
+  const float in0 = x0 - TWO_PI * floorf(x0 / TWO_PI), in1 = x1 - TWO_PI * floorf(x1 / TWO_PI), in3 = x3 - TWO_PI * floorf(x3 / TWO_PI);
+  float h = W1[256 + lane] + in0 * W1[lane] + in1 * W1[64 + lane] + x2 * W1[128 + lane] + in3 * W1[192 + lane];
+  h = tanhf(h);
+  for (int layer = 0; layer < 2; layer++) {
+    const float* W = layer == 0 ? W2 : W3;
+    wave_sync(); X[lane] = h; wave_sync();
+    float acc = W[4096 + lane];
+    for (int k = 0; k < 64; k++) acc += X[k] * W[64 * k + lane];
+    h = tanhf(acc);
+  }
+  const float z = wave_sum(h * W4[lane]) + W4[64];
+  wave_sync();
+  if (lane == 0) {
+    if (z > 0.f) {
+      for (int k = 0; k < 4; k++) L[L_ST + s_task + AGX_BB_PREV + k] = L[L_ST + c.s_q + dof[k]];
+      Li[L_ST + s_task + AGX_BB_HAS_PREV] = 1;
+    } else if (Li[L_ST + s_task + AGX_BB_HAS_PREV]) {
+      for (int k = 0; k < 4; k++) {
+        L[L_ST + c.s_q + dof[k]] = wave_clamp(L[L_ST + s_task + AGX_BB_PREV + k], DLO(c, dof[k]), DHI(c, dof[k]));
+        L[L_ST + c.s_qd + dof[k]] = 0.f;
+      }
+    }
+  }
+  wave_sync();
+}
 // FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset.  Needs the link
 // frames of a preceding kinematics(); the target is only consumed by the observation / reward code.
 AGX_DEV void update_target(Ctx& c) {
@@ -254,6 +297,7 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   pgs(c, dv0, dv1);
   const long long t1 = gdebug ? wave_clock() : 0;
   integrate(c, scr.vel, dv0, dv1);
+  if constexpr (TASK == AGX_TASK_BED_BATHING) arm_limits(c, lds + L_VEL);   // the velocity vector is dead after the integration
   store_env(c, gstate, sw);
   if (gdebug && lane == 0) { gdebug[DBG_TIME + 5] = (float)(t1 - t0); gdebug[DBG_TIME + 6] = (float)(wave_clock() - t1); }
 }

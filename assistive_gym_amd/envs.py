@@ -216,7 +216,14 @@ class BedBathingSawyerEnv(AssistiveEnv):
         return self._split_obs(st.observe_host()[0].astype(np.float64))
 
 
-ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv}
+class BedBathingSawyerHumanEnv(BedBathingSawyerEnv):
+    """BedBathingSawyerHuman-v1 (bed_bathing_envs.py:57-61): the human's right arm (10 joints) is controllable; the pose-dependent
+    arm limits (human.py:134-152, the Keras classifier) run after every substep; per-agent dictionaries as in the reference."""
+    coop = True
+
+
+ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
+           'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
 
 
 def make(env_id):

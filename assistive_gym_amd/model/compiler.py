@@ -32,7 +32,7 @@ H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT
          OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
          STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
          NDIR=29, OFF_DIRS=30, OFF_RESET=31, NROBOT=32, NHDOF=33, S_TREMOR=34, TASK_KIND=35, S_TASK=36, TASK_WORDS=37,
-         OFF_TARGETS=38, COUNT=40)
+         OFF_TARGETS=38, OFF_MLP=39, COUNT=40)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
          HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, COUNT=24)
@@ -44,7 +44,7 @@ G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
 T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV=7, SUCCESS_FRAC=8, MOUTH_DIST=9,
          SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
          TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, TOOL_OBS_POS=36, TOOL_OBS_QUAT=39, W_WIPE=43, TARGET_RADIUS=44,
-         CLOSEST_DIST=45, PAD_LINK=46, ARM_LINK=47, OBS_LINK=49, NT=52, NT_MAX=56, COUNT=64)
+         CLOSEST_DIST=45, PAD_LINK=46, ARM_LINK=47, OBS_LINK=49, NT=52, NT_MAX=56, ARM_LIMIT_ON=57, ARM_LIMIT_DOF=58, ARM_LIMIT_SIGN=62, COUNT=64)
 # reset section (sampling ranges of FeedingEnv.reset + the posed-human kinematic tree), see agx_blob.h
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
@@ -58,7 +58,8 @@ PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
 HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8, BED=9)
 TASK_FEEDING, TASK_BED_BATHING = 0, 1
-BB = dict(ALIVE=0, ALIVE_WORDS=6, WORDS=6)      # bed bathing task words of the state record (AGX_BB_*)
+BB = dict(ALIVE=0, ALIVE_WORDS=6, PREV=6, HAS_PREV=10, WORDS=12)
+MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathing task words of the state record (AGX_BB_*)
 # pair-group flags (AGX_G_FLAGS)
 GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC = 1, 2, 4, 8, 16, 32
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
@@ -332,7 +333,7 @@ def default_params(n_iter):
 
 
 def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i, hdr_extra, reset_fill, reset_words,
-         targets=None, task_words=0, meta_extra=None):
+         targets=None, task_words=0, meta_extra=None, mlp=None):
     """Lays the assembled scene out as the flat blob of include/agx_blob.h.  Returns (uint32 array, meta)."""
     nrobot = len(rob['dof_links'])
     nhdof = len(hd)
@@ -350,7 +351,7 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
     for name, size in (('PARAMS', P['COUNT']), ('ROBOT', nrec * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
                        ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
                        ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('RESET', reset_words(nhuman, nhdof)),
-                       ('TARGETS', 2 * nt_max * 4)):
+                       ('TARGETS', 2 * nt_max * 4), ('MLP', MLP_WORDS if mlp is not None else 0)):
         off[name] = cur
         cur += size
     nwords = cur
@@ -370,7 +371,7 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
                OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
                S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, NDIR=len(dirs),
                OFF_DIRS=off['DIRS'], OFF_RESET=off['RESET'], NROBOT=nrobot, NHDOF=nhdof, S_TREMOR=s_tremor,
-               S_TASK=s_task, TASK_WORDS=task_words, OFF_TARGETS=off['TARGETS'])
+               S_TASK=s_task, TASK_WORDS=task_words, OFF_TARGETS=off['TARGETS'], OFF_MLP=off['MLP'] if mlp is not None else 0)
     hdr.update(hdr_extra)
     for k, v in hdr.items():
         i[H[k]] = v
@@ -435,6 +436,12 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
                 base = off['TARGETS'] + 4 * (gi * nt_max + k)
                 f[base:base + 3] = pos
                 i[base + 3] = arm
+    if mlp is not None:
+        # Sequential[Dense(4->64, tanh), Dense(64->64, tanh), Dense(64->64, tanh), Dense(64->1, sigmoid)]
+        assert [k.shape for k, _ in mlp] == [(4, 64), (64, 64), (64, 64), (64, 1)]
+        flat = np.concatenate([np.concatenate([k.ravel(), b_.ravel()]) for k, b_ in mlp]).astype(np.float32)
+        assert len(flat) == MLP_WORDS
+        f[off['MLP']:off['MLP'] + MLP_WORDS] = flat
     meta = dict(header=hdr, ranges={k: tuple(v) for k, v in sc.ranges.items()}, human_bodies=human_bodies,
                 human_dynamic_joints=hd, nrobot=nrobot, dof_links=rob['dof_links'], n_groups=len(groups), offsets=off)
     meta.update(meta_extra or {})
@@ -761,7 +768,11 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
                   TOOL_OBS_POS=frames[pad_link][0], TOOL_OBS_QUAT=frames[pad_link][1],    # tool.get_pos_orient(1), bed_bathing.py:81
                   TOOL_MAXF=500.0, EPISODE_LEN=200)                                        # tool.py:47, bed_bathing.py:31
     task_i = dict(EE_LINK=ee_link, PAD_LINK=pad_link, ARM_LINK=[nrobot + 5, nrobot + 7],   # human.right_shoulder / right_elbow (human.py:23-24)
-                  OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], NT=nts, HEAD_LINK=-1)     # shoulder, elbow, wrist (bed_bathing.py:89-91)
+                  OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], NT=nts, HEAD_LINK=-1,     # shoulder, elbow, wrist (bed_bathing.py:89-91)
+                  ARM_LIMIT_DOF=[nrobot + 3, nrobot + 4, nrobot + 5, nrobot + 6], ARM_LIMIT_ON=0)   # j_right_shoulder_x/y/z, j_right_elbow (human.py:139); ON in co-op
+    task_f['ARM_LIMIT_SIGN'] = -1.0                                                        # right arm (human.py:142-145)
+    from .h5lite import load_keras_dense_stack
+    mlp = load_keras_dense_stack(os.path.join(assets, 'realistic_arm_limits_model.h5'))    # env.py:39
     params = default_params(n_iter)
     params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-1.0)                               # bed_bathing.py:162-164
 
@@ -772,7 +783,7 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
         pass        # no device-side reset generator for this scene: the pool comes from assistive_gym_amd/host/reset_bed.py
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_BED_BATHING), reset_fill, reset_words,
-                targets=targets, task_words=BB['WORDS'], meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
+                targets=targets, task_words=BB['WORDS'], mlp=mlp, meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
 
 
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer)

@@ -52,6 +52,8 @@ enum {
   AGX_H_S_TASK,       /* state: task-specific words after the ENV block (bed bathing: bitmask of the targets not wiped yet) */
   AGX_H_TASK_WORDS,
   AGX_H_OFF_TARGETS,  /* bed bathing: float[2 genders][NT_MAX][4] = target position in its arm link frame + arm (0 upper, 1 fore) */
+  AGX_H_OFF_MLP,      /* arm-limit classifier of Human.enforce_realistic_joint_limits (human.py:134-152): float W1[4][64], b1[64],
+                         W2[64][64], b2[64], W3[64][64], b3[64], W4[64], b4[1] (assets/realistic_arm_limits_model.h5); 0 = none */
   AGX_H_COUNT = 40
 };
 
@@ -184,6 +186,10 @@ enum {
   AGX_T_OBS_LINK = 49,     /* int[3]: moving links whose positions the observation reports (shoulder, elbow, wrist) */
   AGX_T_NT = 52,           /* int[2 genders][2 arms]: number of targets (bed_bathing.py:173-188)                    */
   AGX_T_NT_MAX = 56,       /* int: row count of the per-gender target table                                         */
+  /* ---- pose-dependent arm limits (human.py:134-152), active in co-op envs whose controllable joints contain a shoulder ---- */
+  AGX_T_ARM_LIMIT_ON = 57, /* int: 1 = run the classifier after every substep (env.py:230-231)                      */
+  AGX_T_ARM_LIMIT_DOF = 58,/* int[4]: DoFs of shoulder x, y, z and elbow of the movable arm (human.py:139)          */
+  AGX_T_ARM_LIMIT_SIGN = 62,/* float: -1 right arm, +1 left arm (human.py:142-145)                                   */
   AGX_T_COUNT = 64
 };
 
@@ -253,7 +259,11 @@ enum {
  * bed_bathing.py:187); AGX_E_TARGET / FOOD_* / RNG are unused.  Its task words (offset AGX_H_S_TASK): */
 enum { AGX_BB_ALIVE = 0,        /* int[AGX_BB_ALIVE_WORDS] bitmask of the targets not wiped yet, upper-arm targets first */
        AGX_BB_ALIVE_WORDS = 6,
-       AGX_BB_WORDS = 6 };
+       AGX_BB_PREV = 6,         /* float[4] arm_previous_valid_pose (human.py:147-149): shoulder x, y, z, elbow          */
+       AGX_BB_HAS_PREV = 10,    /* int: a valid pose has been seen (arm_previous_valid_pose is not None)                 */
+       AGX_BB_WORDS = 12 };
+#define AGX_MLP_HIDDEN 64
+#define AGX_MLP_WORDS (4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1)
 
 /* ---- per-step outputs --------------------------------------------------------------------- */
 enum { AGX_INFO_TOTAL_FORCE = 0, AGX_INFO_TASK_SUCCESS = 1, AGX_INFO_ROBOT_FORCE = 2,

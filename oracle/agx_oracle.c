@@ -202,6 +202,7 @@ typedef struct {
   int food_near_human;   /* particles with a (food, human) manifold point: separation < CONTACT_BREAK */
   double qpt[MAXQPT][3]; int qpt_link[MAXQPT]; int nqpt;   /* bed bathing: manifold points of the wiping pad on the human (bed_bathing.py:47-58) */
   uint32_t bb_alive[AGX_BB_ALIVE_WORDS];                  /* bed bathing: targets not wiped yet */
+  double arm_prev[4]; int arm_has_prev;                    /* arm_previous_valid_pose (human.py:147-149) */
   int contact_overflow;
   row_t* rows; int nrows;
 } sim_t;
@@ -231,7 +232,11 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
   s->alive = ei[AGX_E_FOOD_ALIVE]; s->active = ei[AGX_E_FOOD_ACTIVE]; s->iteration = ei[AGX_E_ITERATION];
   s->success = ei[AGX_E_TASK_SUCCESS]; s->total_food = ei[AGX_E_TOTAL_FOOD];
   s->rng[0] = (uint32_t)ei[AGX_E_RNG]; s->rng[1] = (uint32_t)ei[AGX_E_RNG + 1];
-  if (m->task_kind == AGX_TASK_BED_BATHING) for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) s->bb_alive[k] = (uint32_t)((const int32_t*)st)[m->s_task + AGX_BB_ALIVE + k];
+  if (m->task_kind == AGX_TASK_BED_BATHING) {
+    for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) s->bb_alive[k] = (uint32_t)((const int32_t*)st)[m->s_task + AGX_BB_ALIVE + k];
+    for (int k = 0; k < 4; k++) s->arm_prev[k] = st[m->s_task + AGX_BB_PREV + k];
+    s->arm_has_prev = ((const int32_t*)st)[m->s_task + AGX_BB_HAS_PREV];
+  }
 }
 static void sim_store(const sim_t* s, float* st) {
   const agxo_model* m = s->m;
@@ -246,7 +251,11 @@ static void sim_store(const sim_t* s, float* st) {
   for (int k = 0; k < 3; k++) e[AGX_E_TARGET + k] = (float)s->target[k];
   ei[AGX_E_FOOD_ALIVE] = s->alive; ei[AGX_E_FOOD_ACTIVE] = s->active; ei[AGX_E_ITERATION] = s->iteration;
   ei[AGX_E_TASK_SUCCESS] = s->success; ei[AGX_E_RNG] = (int32_t)s->rng[0]; ei[AGX_E_RNG + 1] = (int32_t)s->rng[1];
-  if (m->task_kind == AGX_TASK_BED_BATHING) for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) ((int32_t*)st)[m->s_task + AGX_BB_ALIVE + k] = (int32_t)s->bb_alive[k];
+  if (m->task_kind == AGX_TASK_BED_BATHING) {
+    for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) ((int32_t*)st)[m->s_task + AGX_BB_ALIVE + k] = (int32_t)s->bb_alive[k];
+    for (int k = 0; k < 4; k++) st[m->s_task + AGX_BB_PREV + k] = (float)s->arm_prev[k];
+    ((int32_t*)st)[m->s_task + AGX_BB_HAS_PREV] = s->arm_has_prev;
+  }
 }
 
 /* joint limits of DoF d; the human's are scaled per environment (human_creation.py:199-200) */
@@ -920,6 +929,39 @@ static void update_target(sim_t* s) {
   xf_apply(&s->link[hl], mp, s->target);   /* link frames of the CURRENT kinematics() call */
 }
 
+/* Human.enforce_realistic_joint_limits (human.py:134-152): Keras Sequential[Dense(4->64,tanh) x3, Dense(64->1,sigmoid)]
+ * (assets/realistic_arm_limits_model.h5; weights = the blob's MLP section) on the remapped arm angles (human.py:142-145);
+ * class 1 remembers the pose, class 0 puts the four joints back to the last valid pose with zero velocity. */
+static double wrap_2pi(double x) { return x - 2 * M_PI * floor(x / (2 * M_PI)); }   /* Python's % for a positive modulus */
+double agxo_arm_limit_logit(const agxo_model* m, const double* in4) {
+  const float* W1 = m->f + m->i[AGX_H_OFF_MLP]; const float* W2 = W1 + 4 * 64 + 64; const float* W3 = W2 + 64 * 64 + 64; const float* W4 = W3 + 64 * 64 + 64;
+  double h[64], g[64];
+  for (int j = 0; j < 64; j++) { double a = W1[256 + j]; for (int k = 0; k < 4; k++) a += in4[k] * W1[64 * k + j]; h[j] = tanh(a); }
+  for (int layer = 0; layer < 2; layer++) {
+    const float* W = layer == 0 ? W2 : W3;
+    for (int j = 0; j < 64; j++) { double a = W[4096 + j]; for (int k = 0; k < 64; k++) a += h[k] * W[64 * k + j]; g[j] = tanh(a); }
+    memcpy(h, g, sizeof h);
+  }
+  double z = W4[64]; for (int k = 0; k < 64; k++) z += h[k] * W4[k];
+  return z;   /* class = sigmoid(z) > 0.5 <=> z > 0 */
+}
+static void arm_limits(sim_t* s) {
+  const agxo_model* m = s->m;
+  if (m->task_kind != AGX_TASK_BED_BATHING || !TI(m, AGX_T_ARM_LIMIT_ON)) return;
+  double sg = TF(m, AGX_T_ARM_LIMIT_SIGN), a[4]; int dof[4];
+  for (int k = 0; k < 4; k++) {
+    dof[k] = TI(m, AGX_T_ARM_LIMIT_DOF + k); a[k] = s->q[dof[k]];
+    /* read as the reference's strict limit reset leaves them (the reset here has the tolerance AGX_LIMIT_EPS) */
+    if (a[k] < dof_lower(s, dof[k])) a[k] = dof_lower(s, dof[k]); if (a[k] > dof_upper(s, dof[k])) a[k] = dof_upper(s, dof[k]);
+  }
+  double in4[4] = {wrap_2pi(sg * a[0] + 2 * M_PI), wrap_2pi(a[1] + 2 * M_PI), sg * a[2], wrap_2pi(-a[3] + 2 * M_PI)};   /* human.py:142-145 */
+  if (agxo_arm_limit_logit(m, in4) > 0) { for (int k = 0; k < 4; k++) s->arm_prev[k] = s->q[dof[k]]; s->arm_has_prev = 1; }
+  else if (s->arm_has_prev) for (int k = 0; k < 4; k++) {
+    double v = s->arm_prev[k]; if (v < dof_lower(s, dof[k])) v = dof_lower(s, dof[k]); if (v > dof_upper(s, dof[k])) v = dof_upper(s, dof[k]);
+    s->q[dof[k]] = v; s->qd[dof[k]] = 0;
+  }
+}
+
 /* one p.stepSimulation() (env.py:226) + the post-substep hooks (env.py:227-232) */
 static void substep(sim_t* s) {
   const agxo_model* m = s->m; int n = s->ndof; double dt = PARAM(m, AGX_P_DT);
@@ -968,6 +1010,7 @@ static void substep(sim_t* s) {
     double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     for (int k = 0; k < 4; k++) s->fquat[b][k] = qn[k] / nn;
   }
+  arm_limits(s);   /* env.py:230-231, after the limit reset above */
 }
 
 /* ------------------------------------------------------------------------------------ task layer */

@@ -36,6 +36,9 @@ void agxo_settle(const agxo_model* m, float* state, int n_substeps);
 /* observation only (reset() return value, feeding.py:182) */
 void agxo_observe(const agxo_model* m, const float* state, float* obs);
 
+/* logit of the arm-limit classifier for the four remapped angles (class 1 <=> logit > 0), human.py:146 */
+double agxo_arm_limit_logit(const agxo_model* m, const double* in4);
+
 /* ---- building blocks exposed for unit tests ------------------------------------------------ */
 /* link world frames: pos[ndof*3], rot[ndof*9] row-major */
 void agxo_fk(const agxo_model* m, const float* state, double* pos, double* rot);

@@ -210,3 +210,114 @@ def test_emulator_tremor_arm_is_dynamic(bed, bed_oracle, bed_emu):
 def test_emulator_observe(bed, bed_oracle, bed_emu):
     st, _ = _states(bed, 1, 1005)
     assert np.abs(bed_oracle.observe(st[0]) - bed_emu.observe(st[0])).max() < 1e-5
+
+
+# ---- pose-dependent arm limits (human.py:134-152) and the co-op flavour ----------------------------------------------------
+def _mlp_numpy(bed, x):
+    """the Keras model restated in numpy float64 from the blob's weights"""
+    W = bed.f[bed.h['OFF_MLP']:bed.h['OFF_MLP'] + 8705].astype(np.float64)
+    W1, b1, W2, b2 = W[:256].reshape(4, 64), W[256:320], W[320:4416].reshape(64, 64), W[4416:4480]
+    W3, b3, W4, b4 = W[4480:8576].reshape(64, 64), W[8576:8640], W[8640:8704], W[8704]
+    return np.tanh(np.tanh(np.tanh(x @ W1 + b1) @ W2 + b2) @ W3 + b3) @ W4 + b4
+
+
+def _remap(a):
+    """human.py:142-145 for the right arm"""
+    tz, tx, ty, qe = a
+    return np.array([(-tz + 2 * np.pi) % (2 * np.pi), (tx + 2 * np.pi) % (2 * np.pi), -ty, (-qe + 2 * np.pi) % (2 * np.pi)])
+
+
+def test_h5_reader_and_blob_weights(bed):
+    """assets/realistic_arm_limits_model.h5 read without h5py: 8,705 parameters, tanh x3 + sigmoid; the blob carries them"""
+    import os
+    from assistive_gym_amd.model.h5lite import H5File, load_keras_dense_stack
+    path = '/root/reference/assistive_gym/envs/assets/realistic_arm_limits_model.h5'
+    if not os.path.exists(path):
+        pytest.skip('reference assets not on this box')
+    ds = H5File(path).datasets()
+    assert ds['/model_weights/dense_1/dense_1/kernel:0'].shape == (4, 64) and ds['/optimizer_weights/Adam/iterations:0'] == 425200
+    stack = load_keras_dense_stack(path)
+    assert [k.shape for k, _ in stack] == [(4, 64), (64, 64), (64, 64), (64, 1)] and sum(k.size + b.size for k, b in stack) == 8705
+    flat = np.concatenate([np.concatenate([k.ravel(), b.ravel()]) for k, b in stack])
+    assert np.array_equal(flat, bed.f[bed.h['OFF_MLP']:bed.h['OFF_MLP'] + 8705])
+    raw = open(path, 'rb').read()
+    assert raw.count(b'"activation": "tanh"') == 3 and raw.count(b'"activation": "sigmoid"') == 1
+
+
+def test_oracle_classifier_matches_numpy(bed, bed_oracle):
+    import ctypes as C
+    from oracle_lib import lib
+    L = lib(); L.agxo_arm_limit_logit.restype = C.c_double
+    rng = np.random.RandomState(0)
+    cls = []
+    for k in range(500):
+        x = np.array([rng.uniform(0, 2 * np.pi), rng.uniform(0, 2 * np.pi), rng.uniform(-1.6, 1.6), rng.uniform(0, 2.3)])
+        z = L.agxo_arm_limit_logit(C.c_void_p(bed_oracle.h), x.ctypes.data_as(C.c_void_p))
+        assert abs(z - _mlp_numpy(bed, x)) < 1e-9
+        cls.append(z > 0)
+    assert 0.1 < np.mean(cls) < 0.9                                           # both verdict classes occur
+
+
+def _invalid_arm_pose(bed, rng):
+    """an arm pose inside the joint limits that the classifier rejects, with a clear margin"""
+    lo = np.array([bed.robot_f(bed.nrobot + j, 'LOWER') for j in (3, 4, 5, 6)]); hi = np.array([bed.robot_f(bed.nrobot + j, 'UPPER') for j in (3, 4, 5, 6)])
+    for _ in range(10000):
+        a = rng.uniform(lo, hi)
+        if _mlp_numpy(bed, _remap(a)) < -2.0:
+            return a
+    raise AssertionError('no invalid pose found')
+
+
+def test_coop_arm_limit_rollback(bed, bed_oracle, bed_emu):
+    """co-op env (human arm controllable): an invalid arm pose is rolled back to the last valid one with zero velocity, on the
+    oracle and on the device code alike; a valid pose is remembered"""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    coop = bed.coop()
+    assert coop.is_coop and coop.task_i('ARM_LIMIT_ON') == 1 and (coop.act_dim, coop.obs_dim) == (17, 24 + 28)    # bed_bathing.py:10
+    assert bed.task_i('ARM_LIMIT_ON') == 0
+    o1, e1 = Oracle(coop.set_param('FRAME_SKIP', 1)), Emu(coop.set_param('FRAME_SKIP', 1))
+    st, _ = _states(coop, 1, 7001, impairment='none')
+    s = st[0].copy()
+    v = coop.view(s.reshape(1, -1))
+    nr = coop.nrobot
+    assert v['frozen'][0] == 0                                                 # a controllable human stays dynamic (human.py:108)
+    valid = v['q'][0, nr + 3:nr + 7].copy()
+    assert _mlp_numpy(coop, _remap(valid.astype(np.float64))) > 0
+    # first substep: the sampled pose is valid -> remembered
+    a0 = np.zeros(17, dtype=np.float32)
+    so, se = s.copy(), s.copy()
+    o1.step(so, a0); e1.step(se, a0)
+    for x in (so, se):
+        vx = coop.view(x.reshape(1, -1))
+        assert vx['task'][0, 10] == 1 and np.abs(vx['task'][0, 6:10].view(np.float32) - vx['q'][0, nr + 3:nr + 7]).max() == 0
+    # teleport the arm into a rejected pose: the next substep rolls the four joints back
+    bad = _invalid_arm_pose(coop, np.random.RandomState(3))
+    for x in (so, se):
+        vx = coop.view(x.reshape(1, -1))
+        prev = vx['task'][0, 6:10].view(np.float32).copy()
+        vx['q'][0, nr + 3:nr + 7] = bad; vx['qt'][0, nr + 3:nr + 7] = bad; vx['qd'][0, nr:] = 0
+    oo, _, _, _ = o1.step(so, a0); eo, _, _, _, _ = e1.step(se, a0)
+    for x in (so, se):
+        vx = coop.view(x.reshape(1, -1))
+        assert np.abs(vx['q'][0, nr + 3:nr + 7] - prev).max() < 1e-6 and np.abs(vx['qd'][0, nr + 3:nr + 7]).max() == 0
+    assert np.abs(oo - eo).max() < 1e-4
+
+
+def test_emulator_coop_episode(bed, bed_oracle, bed_emu):
+    """17 actions (7 robot + 10 human arm joints), 24 + 28 observations; device code vs oracle with the classifier in the loop"""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    coop = bed.coop()
+    o, e = Oracle(coop), Emu(coop)
+    st, _ = _states(coop, 1, 7101)
+    so, se = st[0].copy(), st[0].copy()
+    for k in range(4):
+        a = np.random.RandomState(50 + k).uniform(-1, 1, 17).astype(np.float32)
+        oo, orr, od, oi = o.step(so, a)
+        eo, er, ed, ei, _ = e.step(se, a)
+        assert oo.shape == (52,) and np.abs(oo - eo).max() < 2e-5 and abs(orr - er) < 2e-5
+        vo, ve = coop.view(so.reshape(1, -1)), coop.view(se.reshape(1, -1))
+        assert np.abs(vo['q'] - ve['q']).max() < 2e-5 and np.array_equal(vo['task'][0, 10], ve['task'][0, 10])
+    # the human part of the observation: joint angles of the 10 arm joints, then shoulder / elbow / wrist in the human's frame
+    assert np.abs(oo[24 + 7:24 + 17] - vo['q'][0, coop.nrobot:]).max() < 1e-6

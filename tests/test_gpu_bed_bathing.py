@@ -167,3 +167,46 @@ def test_scalar_env_surface(bed):
     p, _ = pad_pose(bed, env.get_state())
     assert np.isfinite(p).all()
     env.disconnect()
+
+
+def test_coop_with_arm_limit_classifier_matches_oracle(bed):
+    """BedBathingSawyerHumanEnv: 17 actions, 52 observations, the arm-limit MLP after every substep (human.py:134-152)"""
+    from assistive_gym_amd.libagx import Stepper
+    from oracle_lib import Oracle
+    coop = bed.coop()
+    o = Oracle(coop)
+    states, _ = _states(coop, 8, 5401)
+    # two envs start in an arm pose the classifier rejects, with a remembered valid pose: they are rolled back in the first substep
+    from test_bed_bathing import _invalid_arm_pose
+    v = coop.view(states)
+    nr = coop.nrobot
+    for i in (6, 7):
+        v['task'][i, 6:10] = v['q'][i, nr + 3:nr + 7].view(np.int32); v['task'][i, 10] = 1
+        bad = _invalid_arm_pose(coop, np.random.RandomState(i)).astype(np.float32)
+        v['q'][i, nr + 3:nr + 7] = bad; v['qt'][i, nr + 3:nr + 7] = bad
+    st = Stepper(coop, 8)
+    st.set_state(states)
+    ref = states.copy()
+    worst = 0.0
+    for k in range(5):
+        act = np.random.RandomState(400 + k).uniform(-1, 1, (8, 17)).astype(np.float32)
+        obs, rew, done, info = st.step_host(act)
+        got = st.get_state()
+        for i in range(8):
+            o_obs, o_rew, _, o_info = o.step(ref[i], act[i])
+            worst = max(worst, float(np.abs(obs[i] - o_obs).max()), abs(float(rew[i]) - o_rew))
+            vg, vo = coop.view(got[i].reshape(1, -1)), coop.view(ref[i].reshape(1, -1))
+            assert vg['task'][0, 10] == vo['task'][0, 10] == 1
+    st.close()
+    assert obs.shape == (8, 52) and worst < 2e-4, worst
+
+
+def test_coop_scalar_env_dicts(bed):
+    from assistive_gym_amd.envs import make
+    env = make('assistive_gym:BedBathingSawyerHuman-v1')
+    obs = env.reset()
+    assert set(obs) == {'robot', 'human'} and obs['robot'].shape == (24,) and obs['human'].shape == (28,)
+    a = {'robot': env.action_space_robot.sample(), 'human': env.action_space_human.sample()}
+    obs, rew, done, info = env.step(a)
+    assert set(done) == {'robot', 'human', '__all__'} and rew['robot'] == rew['human'] and info['human']['action_human_len'] == 10
+    env.disconnect()
