@@ -1,0 +1,60 @@
+"""RLlib adapter: the batched stepper as ONE `ray.rllib.env.VectorEnv`, so that a rollout worker steps thousands of
+environments with a few kernel launches instead of `num_workers = cpu_count()` processes with one PyBullet client each
+(assistive_gym/learn.py:9-37,71-94).  Usage with the reference's training script left unchanged:
+
+    from ray.tune.registry import register_env
+    register_env('assistive_gym:FeedingJaco-v1', lambda cfg: AgxVectorEnv('FeedingJaco-v1', cfg.get('num_envs', 1024)))
+
+RLlib's VectorEnv contract (ray 1.x): vector_reset() -> [obs], reset_at(i) -> obs, vector_step(actions) ->
+([obs], [reward], [done], [info]), get_unwrapped() -> [envs].  Episodes of the lock-stepped batch all end at step 200
+(done = iteration >= 200 in every task's step()); the batch is then reset on the device and reset_at(i) returns the
+first observation of env i's new episode.  ray is optional at import time."""
+import numpy as np
+
+try:
+    from ray.rllib.env.vector_env import VectorEnv as _VectorEnv
+except Exception:
+    class _VectorEnv:                    # the attributes RLlib reads
+        def __init__(self, observation_space, action_space, num_envs):
+            self.observation_space, self.action_space, self.num_envs = observation_space, action_space, num_envs
+
+MODELS = {'FeedingJaco-v1': 'feeding_jaco', 'BedBathingSawyer-v1': 'bed_bathing_sawyer'}
+
+
+class AgxVectorEnv(_VectorEnv):
+    def __init__(self, env_id, num_envs, device=0, seed=1001, **vec_kwargs):
+        from . import envs
+        from .vec_env import AssistiveVecEnv
+        name = env_id.split(':')[-1]
+        proto = envs.ENV_IDS[name]()                     # spaces and info keys of the scalar env
+        assert not proto.coop, 'co-op (multi-agent) envs go through RLlib MultiAgentEnv, not VectorEnv'
+        super().__init__(proto.observation_space, proto.action_space, num_envs)
+        self._info_static = {'action_robot_len': proto.action_robot_len, 'action_human_len': proto.action_human_len,
+                             'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
+        self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=MODELS[name], **vec_kwargs)
+        self._obs = None
+
+    def vector_reset(self):
+        self._obs = self.vec.reset().cpu().numpy().astype(np.float64)
+        return list(self._obs)
+
+    def reset_at(self, index):
+        return self._obs[index]                          # the batch was reset on the device at the episode boundary
+
+    def vector_step(self, actions):
+        import torch
+        a = torch.as_tensor(np.asarray(actions, dtype=np.float32), device=self.vec.device).contiguous()
+        obs, rew, done, info = self.vec.step(a)
+        boundary = bool(done[0].item())
+        # at the boundary vec.obs already holds the first observation of the new episode; RLlib wants the terminal one here
+        last = (self.vec.terminal_obs if boundary else obs).cpu().numpy().astype(np.float64)
+        self._obs = obs.cpu().numpy().astype(np.float64)
+        info_h = info.cpu().numpy()
+        infos = [dict(self._info_static, total_force_on_human=float(info_h[i, 0]), task_success=int(info_h[i, 1])) for i in range(self.num_envs)]
+        return list(last), list(rew.cpu().numpy().astype(np.float64)), [bool(d) for d in done.cpu().numpy()], infos
+
+    def get_unwrapped(self):
+        return []
+
+    def close(self):
+        self.vec.close()

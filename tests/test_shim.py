@@ -1,0 +1,141 @@
+"""`learn.py` drops in unchanged: the reference's own make_env (assistive_gym/learn.py:61-69) is executed against
+the drop-in `assistive_gym` package with stub `gym` / `ray` modules (neither is installed here).  The reference source is
+read from /root/reference at test time (never copied into the repo); the test skips where the reference is absent."""
+import ast
+import importlib
+import os
+import sys
+import types
+
+import pytest
+
+REF_LEARN = '/root/reference/assistive_gym/learn.py'
+
+
+class _TimeLimit:
+    """what gym.make wraps a registered env in when max_episode_steps is given"""
+
+    def __init__(self, env, max_episode_steps):
+        self.env, self._max_episode_steps = env, max_episode_steps
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+
+def _stub_gym():
+    gym = types.ModuleType('gym')
+    reg = {}
+
+    def register(id, entry_point, max_episode_steps=None, **kw):
+        if id in reg:
+            raise RuntimeError('Cannot re-register id: ' + id)
+        reg[id] = (entry_point, max_episode_steps)
+
+    def make(name):
+        if ':' in name:                                  # gym imports the module before the colon, then looks the id up
+            mod, name = name.split(':')
+            importlib.import_module(mod)
+        if name not in reg:
+            raise KeyError('No registered env with id: ' + name)
+        entry, steps = reg[name]
+        mod, cls = entry.split(':')
+        return _TimeLimit(getattr(importlib.import_module(mod), cls)(), steps)
+    gym.make, gym.registry = make, reg
+    envs = types.ModuleType('gym.envs'); registration = types.ModuleType('gym.envs.registration')
+    registration.register = register
+    envs.registration = registration; gym.envs = envs
+    return gym, {'gym': gym, 'gym.envs': envs, 'gym.envs.registration': registration}
+
+
+def _stub_ray():
+    ray = types.ModuleType('ray'); tune = types.ModuleType('ray.tune'); registry = types.ModuleType('ray.tune.registry')
+    creators = {}
+    registry.register_env = lambda name, creator: creators.__setitem__(name, creator)
+    ray.tune, tune.registry = tune, registry
+    return creators, {'ray': ray, 'ray.tune': tune, 'ray.tune.registry': registry}
+
+
+@pytest.fixture()
+def shimmed(monkeypatch):
+    from assistive_gym_amd import shim
+    for m in [k for k in sys.modules if k == 'assistive_gym' or k.startswith('assistive_gym.')]:
+        monkeypatch.delitem(sys.modules, m)
+    gym, gmods = _stub_gym()
+    creators, rmods = _stub_ray()
+    for k, v in {**gmods, **rmods}.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    monkeypatch.syspath_prepend(shim.install())
+    yield gym, creators
+    for m in [k for k in sys.modules if k == 'assistive_gym' or k.startswith('assistive_gym.')]:
+        sys.modules.pop(m, None)
+
+
+def _reference_make_env(gym):
+    if not os.path.exists(REF_LEARN):
+        pytest.skip('reference not on this box')
+    tree = ast.parse(open(REF_LEARN).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'make_env'][0]
+    ns = {'gym': gym, 'importlib': importlib}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), REF_LEARN, 'exec'), ns)
+    return ns['make_env']
+
+
+@pytest.mark.parametrize('env_name', ['FeedingJaco-v1', 'BedBathingSawyer-v1'])
+def test_reference_make_env_single_agent(shimmed, env_name):
+    gym, _ = shimmed
+    make_env = _reference_make_env(gym)
+    env = make_env(env_name, coop=False, seed=7)
+    assert type(env.env).__name__ == env_name.split('-')[0] + 'Env' and env._max_episode_steps == 200
+    assert env.action_space.shape == (7,) and env.observation_space.shape[0] in (24, 25)
+    assert env.action_robot_len == 7 and len(env.robot.controllable_joint_indices) == 7      # what learn.py / env_viewer.py read
+    env.disconnect()
+
+
+@pytest.mark.parametrize('env_name', ['FeedingJacoHuman-v1', 'BedBathingSawyerHuman-v1'])
+def test_reference_make_env_coop(shimmed, env_name):
+    gym, creators = shimmed
+    make_env = _reference_make_env(gym)
+    env = make_env(env_name, coop=True, seed=7)
+    assert type(env).__name__ == env_name.split('-')[0] + 'Env' and env.human.controllable
+    # setup_config (learn.py:31-36) reads these four spaces to build the two policies
+    assert env.observation_space_robot.shape[0] + env.observation_space_human.shape[0] == env.observation_space.shape[0]
+    assert env.action_space_robot.shape[0] + env.action_space_human.shape[0] == env.action_space.shape[0]
+    # and RLlib finds the env under the id the reference registers it with (feeding_envs.py:67, bed_bathing_envs.py:61)
+    assert 'assistive_gym:' + env_name in creators
+    assert type(creators['assistive_gym:' + env_name]({})).__name__ == type(env).__name__
+    env.disconnect()
+
+
+def test_unbuilt_env_id_fails_like_gym(shimmed):
+    gym, _ = shimmed
+    with pytest.raises(KeyError):
+        gym.make('assistive_gym:DressingBaxter-v1')
+
+
+def test_vector_env_adapter_surface():
+    """the RLlib VectorEnv adapter imports without ray and exposes the contract's methods"""
+    from assistive_gym_amd.rllib import AgxVectorEnv
+    for m in ('vector_reset', 'reset_at', 'vector_step', 'get_unwrapped'):
+        assert callable(getattr(AgxVectorEnv, m))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env_id', ['FeedingJaco-v1', 'assistive_gym:BedBathingSawyer-v1'])
+def test_vector_env_adapter_steps_on_the_gpu(env_id):
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU visible')
+    from assistive_gym_amd.rllib import AgxVectorEnv
+    n = 32
+    env = AgxVectorEnv(env_id, n, pool_size=8)
+    obs = env.vector_reset()
+    assert len(obs) == n and obs[0].shape == env.observation_space.shape
+    rng = np.random.RandomState(0)
+    for k in range(200):
+        obs, rew, done, infos = env.vector_step([rng.uniform(-1, 1, 7) for _ in range(n)])
+        assert len(obs) == len(rew) == len(done) == len(infos) == n and all(d == (k == 199) for d in done)
+    assert set(infos[0]) == {'total_force_on_human', 'task_success', 'action_robot_len', 'action_human_len', 'obs_robot_len', 'obs_human_len'}
+    first = env.reset_at(3)                               # first observation of the next episode, already on the host
+    assert first.shape == env.observation_space.shape and np.isfinite(first).all() and not np.array_equal(first, obs[3])
+    env.close()
