@@ -55,6 +55,8 @@ extern "C" __global__ void __launch_bounds__(64) agx_selftest_kernel(float* out_
 struct agx_handle_s {
   const agx_variant* V;   // the compiled kernel variant serving this model
   int* overflow_dev;      // contacts dropped by a budget since creation (all envs)
+  int collision_tries;    // reset generator: successful IK restarts that may be rejected for a collision (AGX_X_COLLISION_TRIES)
+  int *first_restart_dev, *chosen_dev; uint8_t* work_dev;   // reset generator: per-env retry bookkeeping
   long long env_offset;   // global index of env 0 of this handle (multi-GPU sharding), see agx_set_env_offset
   int device, n_envs, act_dim, obs_dim, sw;
   uint32_t* blob_dev;
@@ -129,6 +131,8 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   HIPCHK(hipMemset(h->scratch_dev, 0, (size_t)n_envs * V->scr_words * 4));
   HIPCHK(hipMalloc(&h->overflow_dev, 4));
   HIPCHK(hipMemset(h->overflow_dev, 0, 4));
+  h->collision_tries = can_sample ? hi[hi[AGX_H_OFF_RESET] + AGX_X_COLLISION_TRIES] : 0;
+  HIPCHK(hipMalloc(&h->first_restart_dev, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&h->chosen_dev, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&h->work_dev, (size_t)n_envs));
   h->frame_skip = (int)((const float*)blob)[hi[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   HIPCHK(hipMalloc(&h->episode_dev, (size_t)n_envs * 4));
   HIPCHK(hipMemset(h->episode_dev, 0, (size_t)n_envs * 4));
@@ -156,7 +160,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
 void agx_destroy(agx_handle h) {
   if (!h) return;
   hipSetDevice(h->device);
-  hipFree(h->scratch_dev); hipFree(h->overflow_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
+  hipFree(h->scratch_dev); hipFree(h->overflow_dev); hipFree(h->first_restart_dev); hipFree(h->chosen_dev); hipFree(h->work_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
   hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   for (int c = 0; c < 8; c++) for (int k = 0; k < 16; k++) hipEventDestroy(h->kev[c][k]);
@@ -280,9 +284,23 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
   if (!h->can_sample) return fail(AGX_E_LIMIT, "reset: no device-side reset generator for this model (FeedingJaco-type scenes with a serial 7-DoF arm only); "
                                                "provide post-reset states with agx_set_state / a pool for agx_reset_done");
   HIPCHK(hipSetDevice(h->device));
-  h->V->sample((hipStream_t)stream, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
-               gender_mode, ik_info_dev, h->episode_dev, h->sw);
+  hipStream_t st = (hipStream_t)stream;
+  h->V->sample(st, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
+               gender_mode, ik_info_dev, h->episode_dev, h->sw, nullptr, h->chosen_dev);
   HIPCHK(hipGetLastError());
+  // collision rejection (robot.py:105-112, env.py:299-308): the contacts of the sampled state come from the stepper's own build kernel;
+  // a state whose arm / tool touches the human, the table or the wheelchair is re-sampled from the next IK restart.  Fixed schedule
+  // of `collision_tries` rounds (no host round trip): the kernels of a round exit at once for the environments that are settled.
+  for (int t = 0; t < h->collision_tries; t++) {
+    const uint8_t* active = t == 0 ? mask_dev : h->work_dev;
+    h->V->build(st, h->n_envs, h->blob_dev, h->state_dev, nullptr, h->scratch_dev, nullptr, 0, h->n_envs, h->sw, h->act_dim, active, h->overflow_dev);
+    HIPCHK(hipGetLastError());
+    h->V->verdict(st, h->n_envs, h->blob_dev, h->scratch_dev, active, h->work_dev, h->first_restart_dev, h->chosen_dev);
+    HIPCHK(hipGetLastError());
+    h->V->sample(st, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, h->work_dev, impairment_mode,
+                 gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev);
+    HIPCHK(hipGetLastError());
+  }
   return AGX_OK;
 }
 int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {

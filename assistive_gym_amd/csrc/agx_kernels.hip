@@ -64,13 +64,25 @@ AGX_K(agx_observe_kernel)(const uint32_t* __restrict__ blob, float* state, float
 // reset generator: FeedingEnv.reset's sampling incl. the IK restarts (64 per round, one per lane), float64
 extern "C" __global__ void __launch_bounds__(64)
 AGX_K(agx_sample_kernel)(const uint32_t* __restrict__ blob, float* state, unsigned long long seed0, const unsigned long long* __restrict__ seeds, const uint8_t* __restrict__ mask,
-                         int impairment_mode, int gender_mode, float* info4, int* episode, int n_envs, int sw) {
+                         int impairment_mode, int gender_mode, float* info4, int* episode, int n_envs, int sw, const int* __restrict__ first_restart, int* chosen) {
   const int env = blockIdx.x;
   if (env >= n_envs || (mask && !mask[env])) return;
   const unsigned long long seed = seeds ? seeds[env] : seed0 + (unsigned long long)env;
   if (threadIdx.x == 0) episode[env] = 0;
-  agx::env_sample(blob, state + (size_t)env * sw, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4 ? info4 + (size_t)env * 4 : nullptr,
-                  (int)threadIdx.x);
+  const int r = agx::env_sample(blob, state + (size_t)env * sw, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode,
+                                info4 ? info4 + (size_t)env * 4 : nullptr, (int)threadIdx.x, first_restart ? first_restart[env] : 0);
+  if (chosen && threadIdx.x == 0) chosen[env] = r;
+}
+// after a build-kernel pass over the freshly sampled states: which of them start in collision (and have a restart left to try)?
+// work[env] = 1 and first_restart[env] = chosen + 1 for those, work[env] = 0 for the others
+extern "C" __global__ void __launch_bounds__(64)
+AGX_K(agx_reset_verdict_kernel)(const uint32_t* __restrict__ blob, const float* __restrict__ scratch, const uint8_t* __restrict__ active, uint8_t* work,
+                                int* first_restart, const int* __restrict__ chosen, int n_envs) {
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  bool again = false;
+  if ((!active || active[env]) && chosen[env] >= 0) again = agx::reset_collides(blob, scratch + (size_t)env * agx::SCR_WORDS, (int)threadIdx.x);
+  if (threadIdx.x == 0) { work[env] = again ? 1 : 0; if (again) first_restart[env] = chosen[env] + 1; }
 }
 #endif
 
@@ -96,8 +108,12 @@ void v_observe(hipStream_t st, int n_envs, const uint32_t* blob, float* state, f
 }
 #if AGX_HAS_SAMPLER
 void v_sample(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
-              int impairment_mode, int gender_mode, float* info4, int* episode, int sw) {
-  hipLaunchKernelGGL(AGX_K(agx_sample_kernel), dim3(n_envs), dim3(64), 0, st, blob, state, seed0, seeds, mask, impairment_mode, gender_mode, info4, episode, n_envs, sw);
+              int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen) {
+  hipLaunchKernelGGL(AGX_K(agx_sample_kernel), dim3(n_envs), dim3(64), 0, st, blob, state, seed0, seeds, mask, impairment_mode, gender_mode, info4, episode, n_envs, sw,
+                     first_restart, chosen);
+}
+void v_verdict(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, const uint8_t* active, uint8_t* work, int* first_restart, const int* chosen) {
+  hipLaunchKernelGGL(AGX_K(agx_reset_verdict_kernel), dim3(n_envs), dim3(64), 0, st, blob, scratch, active, work, first_restart, chosen, n_envs);
 }
 #endif
 
@@ -115,9 +131,9 @@ const agx_variant g_variant = {
 #endif
   v_init, v_build, v_solve, v_finish, v_observe,
 #if AGX_HAS_SAMPLER
-  v_sample
+  v_sample, v_verdict
 #else
-  nullptr
+  nullptr, nullptr
 #endif
 };
 

@@ -16,7 +16,11 @@
 //   * all of it in float64: it runs once per episode, MI355X has full-rate FP64 vector units, and the result is
 //     then independent of evaluation order to ~1e-13, which is what makes it checkable against the numpy
 //     restatement (oracle/reset_oracle.py) through the discontinuous accept / reject decisions.
-// Bullet's own IK is not reproduced; the acceptance test of ik_random_restarts is.
+// Bullet's own IK is not reproduced; the acceptance test of ik_random_restarts is: position / orientation
+// thresholds (robot.py:97) AND the collision rejection (robot.py:105-112: a solution whose arm touches the human, the table or the
+// wheelchair is skipped; env.py:299-308: so is one whose tool does).  The contacts of a sampled state come from the stepper's own
+// build kernel (libagx launch_sample: sample -> [build, verdict, re-sample from the next restart] x AGX_X_COLLISION_TRIES); the
+// reference's outer loop re-draws all restarts up to 3 times instead of continuing with the next restart.
 #pragma once
 
 namespace agx {
@@ -208,8 +212,11 @@ AGX_DEV void rs_ik(const ResetCtx& c, double* q, const double* lo, const double*
 
 // One environment.  gstate: this env's state record (fully overwritten).  ginfo (may be null): float[4] =
 // {IK succeeded, restarts used, end-effector position error, impairment index}.
-AGX_DEV void env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gstate, uint32_t seed_lo, uint32_t seed_hi,
-                        int impairment_mode, int gender_mode, float* __restrict__ ginfo, int lane) {
+// first_restart: successful IK restarts below this index were rejected because the arm / tool touched the human, the table or the
+// wheelchair there (robot.py:105-112 `continue`s to the next restart); they neither succeed again nor count as the closest attempt.
+// Returns the index of the accepted restart, -1 if no restart met the thresholds (the closest attempt is used, robot.py:114-117).
+AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gstate, uint32_t seed_lo, uint32_t seed_hi,
+                       int impairment_mode, int gender_mode, float* __restrict__ ginfo, int lane, int first_restart = 0) {
   ResetCtx c;
   c.bf = (const float*)blob; c.bi = (const int*)blob;
   c.xf = c.bf + c.bi[AGX_H_OFF_RESET]; c.xi = c.bi + c.bi[AGX_H_OFF_RESET];
@@ -293,13 +300,14 @@ AGX_DEV void env_sample(const uint32_t* __restrict__ blob, float* __restrict__ g
       const double mx = tquat.x - oe.x, my = tquat.y - oe.y, mz = tquat.z - oe.z, mw = tquat.w - oe.w;
       const double px = tquat.x + oe.x, py = tquat.y + oe.y, pz = tquat.z + oe.z, pw = tquat.w + oe.w;
       dor = fmin(sqrt(mx * mx + my * my + mz * mz + mw * mw), sqrt(px * px + py * py + pz * pz + pw * pw));
-      if (dpos < best_d) {
+      const bool rejected = r < first_restart && dpos < thresh && dor < thresh;      // met the thresholds earlier, collided
+      if (dpos < best_d && !rejected) {
         best_d = dpos; best_r = r;
 #pragma unroll
         for (int d = 0; d < RS_NARM; d++) best_q[d] = q[d];
       }
     }
-    const uint64_t hit = wave_ballot(active && dpos < thresh && dor < thresh);                                  // robot.py:97
+    const uint64_t hit = wave_ballot(active && r >= first_restart && dpos < thresh && dor < thresh);            // robot.py:97
     if (hit) {
       const int l = ffs64(hit);
       ok = 1; restarts = r0 + l + 1;
@@ -378,6 +386,25 @@ AGX_DEV void env_sample(const uint32_t* __restrict__ blob, float* __restrict__ g
     e[AGX_E_LIMIT_SCALE] = (float)c.ls;
     if (ginfo) { ginfo[0] = (float)ok; ginfo[1] = (float)restarts; ginfo[2] = (float)best_d; ginfo[3] = (float)imp; }
   }
+  return ok ? restarts - 1 : -1;
+}
+
+// Collision verdict on a freshly sampled state whose contacts the build kernel has just written to the per-env scratch record:
+// does a robot link (robot.py:105-112: get_closest_points(obj, distance=0)) or the tool (env.py:300-304) touch one of
+// collision_objects = [human, table, wheelchair] (feeding.py:141)?  Wave-uniform result.
+AGX_DEV bool reset_collides(const uint32_t* __restrict__ blob, const float* __restrict__ gscratch, int lane) {
+  const int* bi = (const int*)blob;
+  const int* meta = (const int*)(gscratch + SCR_O_META);
+  const int ncon = meta[META_NCON];
+  bool bad = false;
+  if (lane < ncon) {
+    const float* k = gscratch + SCR_O_CON + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const int ta = bi[bi[AGX_H_OFF_COLL] + ki[C_CA] * AGX_C_STRIDE + AGX_C_TAG], tb = bi[bi[AGX_H_OFF_COLL] + ki[C_CB] * AGX_C_STRIDE + AGX_C_TAG];
+    const bool ra = ta == AGX_TAG_ROBOT || ta == AGX_TAG_TOOL, rb = tb == AGX_TAG_ROBOT || tb == AGX_TAG_TOOL;
+    const bool oa = ta == AGX_TAG_HUMAN || ta == AGX_TAG_TABLE || ta == AGX_TAG_WHEELCHAIR, ob = tb == AGX_TAG_HUMAN || tb == AGX_TAG_TABLE || tb == AGX_TAG_WHEELCHAIR;
+    bad = ((ra && ob) || (rb && oa)) && k[C_DIST] <= 0.f;
+  }
+  return wave_any(bad);
 }
 
 #undef XF

@@ -21,7 +21,9 @@ struct agx_variant {
                  float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim);
   void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim);
   void (*sample)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
-                 int impairment_mode, int gender_mode, float* info4, int* episode, int sw);   // null without a reset generator
+                 int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen);   // null without a reset generator
+  // collision verdict on freshly sampled states after a build pass (see agx_reset.h reset_collides)
+  void (*verdict)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, const uint8_t* active, uint8_t* work, int* first_restart, const int* chosen);
 };
 
 extern "C" const agx_variant* agx_variant_feeding(void);

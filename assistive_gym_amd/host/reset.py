@@ -13,6 +13,10 @@ parity with the reference through reset() is not attainable (the number of RNG d
 Bullet's IK); the draw ORDER up to the IK call is kept.
 
 The 25 settle steps of feeding.py:178-179 are run by the caller on the device (agx_settle).
+
+Unlike the device-side generator (csrc/agx_reset.h, the default everywhere), this numpy sampler does NOT run the collision
+rejection of robot.py:105-112 / env.py:299-308: it has no narrowphase of its own.  It is kept as an explicit alternative
+(`reset='host'`) for tests and for seeds drawn in the reference's MT19937 order.
 """
 import numpy as np
 

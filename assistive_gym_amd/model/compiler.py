@@ -49,7 +49,7 @@ T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
           IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
-          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COUNT=48)
+          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48, COUNT=52)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
          TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, COUNT=16)
@@ -589,6 +589,7 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
         xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5                                    # env.py:120
         xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(20.0)   # human.py:85-90
         xi[X_['BOWL_BODY']] = 1
+        xi[X_['COLLISION_TRIES']] = 3                                                        # env.py:276 max_iterations
         oj = X_['COUNT']
         ob = oj + 2 * 42 * XJ['STRIDE']
         od = ob + nhuman

@@ -20,7 +20,8 @@
  *   agx_sample_reset  FeedingEnv.reset() up to its settle loop (feeding.py:114-177) for every env, on the device:
  *                     Human.init draws (agents/human.py:72-92), the posed human (feeding.py:124-126), the mouth
  *                     target (feeding.py:184-196), init_robot_pose -> Robot.ik_random_restarts (env.py:276-310,
- *                     agents/robot.py:84-121), tool / bowl / food placement (feeding.py:143-166).
+ *                     agents/robot.py:84-121, incl. the rejection of IK solutions that touch the human / table / wheelchair,
+ *                     robot.py:105-112, env.py:299-308), tool / bowl / food placement (feeding.py:143-166).
  *   agx_reset         the same followed by the settle loop, for the envs selected by a mask (a caller resetting
  *                     the envs that are done), per-env seeds optional.
  *   agx_reset_done    gym's TimeLimit/auto-reset on done (assistive_gym/__init__.py:11), drawing

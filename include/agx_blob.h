@@ -226,7 +226,9 @@ enum {
   AGX_X_OFF_DYN = 43,    /* int: int[NHDOF] human joint behind every human DoF                  */
   AGX_X_STRENGTH_LO = 44,/* impairment 'weakness': strength ~ U(lo, 1) (human.py:86; unused by Feeding) */
   AGX_X_FOOD_OFF = 45,   /* float[3] offset of the food grid from the tool position (feeding.py:162) */
-  AGX_X_COUNT = 48
+  AGX_X_COLLISION_TRIES = 48, /* int: how many successful IK restarts may be rejected because the robot / tool touches the human,
+                          * the table or the wheelchair (robot.py:105-112, env.py:299-308) before one is accepted unchecked */
+  AGX_X_COUNT = 52
 };
 enum {
   AGX_XJ_PARENT = 0,     /* int: parent joint (PyBullet link numbering), -1 = base              */

@@ -36,12 +36,48 @@ MODE_RANDOM, MODE_NO_TREMOR = -1, -2
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
           IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
-          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COUNT=48)
+          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48, COUNT=52)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK = 31, 13, 14, 18
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, STRIDE=36)
 F = dict(REFPOS=5, REFQUAT=8, STRIDE=16)
 T = dict(MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35)
+
+
+def contacts_collide(blob_words, contacts):
+    """The verdict of reset_collides (csrc/agx_reset.h) on the C oracle's contact rows [colliderA, colliderB, pA, pB, n, distance, ...]:
+    a robot link or the tool touching (distance <= 0) the human, the table or the wheelchair."""
+    i = np.ascontiguousarray(blob_words, dtype=np.uint32).view(np.int32)
+    off, stride, tag = int(i[15]), 16, 5                                   # AGX_H_OFF_COLL, AGX_C_STRIDE, AGX_C_TAG
+    for c in contacts:
+        ta, tb = int(i[off + int(c[0]) * stride + tag]), int(i[off + int(c[1]) * stride + tag])
+        ra, rb = ta in (1, 2), tb in (1, 2)                                # AGX_TAG_ROBOT, AGX_TAG_TOOL
+        oa, ob = ta in (3, 6, 8), tb in (3, 6, 8)                          # AGX_TAG_HUMAN, AGX_TAG_TABLE, AGX_TAG_WHEELCHAIR
+        if ((ra and ob) or (rb and oa)) and c[11] <= 0:
+            return True
+    return False
+
+
+def with_collision_check(blob_words):
+    """ResetOracle whose collision verdict comes from the contact list of the C oracle (oracle/agx_oracle.c) for the sampled state"""
+    import ctypes as C
+    import os
+    w = np.ascontiguousarray(blob_words, dtype=np.uint32)
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libagx_oracle.so'))
+    lib.agxo_load.restype = C.c_void_p
+    lib.agxo_load.argtypes = [C.c_void_p, C.c_size_t]
+    lib.agxo_substep_debug.restype = C.c_int
+    h = lib.agxo_load(w.ctypes.data_as(C.c_void_p), C.c_size_t(len(w)))
+    assert h, 'oracle rejected the model blob'
+
+    def collides(st):
+        out = np.zeros((96, 13))
+        s = np.ascontiguousarray(st, dtype=np.float32).copy()
+        n = lib.agxo_substep_debug(C.c_void_p(h), s.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int(96))
+        return contacts_collide(w, out[:n])
+    o = ResetOracle(w, collides)
+    o._keep = (lib, w)
+    return o
 
 
 def philox4x32(counter, key):
@@ -88,7 +124,9 @@ def compose(pa, qa, pb, qb):
 
 
 class ResetOracle:
-    def __init__(self, words):
+    def __init__(self, words, collides=None):
+        """collides: optional callback state record -> bool, see contacts_collide() (the C oracle's contact list)"""
+        self.collides = collides
         w = np.ascontiguousarray(words, dtype=np.uint32)
         self.f = w.view(np.float32).astype(np.float64)          # every constant is the blob's float32 value, widened
         self.i = w.view(np.int32)
@@ -214,7 +252,21 @@ class ResetOracle:
 
     # -- one reset ----------------------------------------------------------------------------------
     def sample(self, seed, impairment_mode=MODE_RANDOM, gender_mode=-1, max_restarts=None):
-        """-> (state record float32[state_words], info dict)"""
+        """-> (state record float32[state_words], info dict).  With a `collides` callback (state record -> bool: does the arm /
+        tool touch the human, the table or the wheelchair?) a successful IK restart that collides is rejected and the search
+        goes on from the next restart (robot.py:105-112, env.py:299-308), at most COLLISION_TRIES times."""
+        first, rejected = 0, []
+        tries = self.xi('COLLISION_TRIES') if self.collides is not None else 0
+        for t in range(tries + 1):
+            st, info = self._sample_from(seed, impairment_mode, gender_mode, max_restarts, first)
+            if t == tries or not info['ik_ok'] or not self.collides(st):
+                break
+            rejected.append(info['ik_restarts'] - 1)
+            first = info['ik_restarts']
+        info['rejected_restarts'] = rejected
+        return st, info
+
+    def _sample_from(self, seed, impairment_mode, gender_mode, max_restarts, first_restart):
         u = lambda idx: u01(seed, 0, idx)
         friction = self.xf('FRIC_LO') + (self.xf('FRIC_HI') - self.xf('FRIC_LO')) * u(S_FRICTION)
         g = gender_mode if gender_mode >= 0 else (0 if u(S_GENDER) < 0.5 else 1)
@@ -250,9 +302,12 @@ class ResetOracle:
         for r in range(n_max):
             restarts = r + 1
             q, dpos, dor = self.restart(seed, r, target_ee, toc)
+            met = dpos < thr and dor < thr                                 # robot.py:97
+            if met and r < first_restart:                                  # collided there: `continue` (robot.py:110-112)
+                continue
             if dpos < best_d:
                 best, best_d = q, dpos
-            if dpos < thr and dor < thr:                                   # robot.py:97
+            if met:
                 best, best_d, ok = q, dpos, True
                 break
         nr, narm = self.nrobot, self.xi('NARM')

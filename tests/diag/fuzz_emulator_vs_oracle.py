@@ -23,7 +23,7 @@ bad=0
 for t in range(N):
     coop = rng.rand()<0.25
     b = base.coop() if coop else base
-    o=Oracle(b); e=Emu(b); R=ro.ResetOracle(b.words)
+    o=Oracle(b); e=Emu(b); R=ro.with_collision_check(b.words)
     seed=int(rng.randint(1,1<<30)); imp=int(rng.choice([-1,3,1]))
     st,_=R.sample(seed, imp); o.settle(st,25)
     nsteps=int(rng.randint(0,60))

@@ -9,7 +9,7 @@ import reset_oracle as ro
 from assistive_gym_amd.blob import ModelBlob
 
 blob = ModelBlob.load()
-o = ro.ResetOracle(blob.words)
+o = ro.with_collision_check(blob.words)
 seeds = np.array([1001, 1002, 1003, 1004, (1 << 40) + 5, (1 << 63) + 12345], dtype=np.uint64)
 modes = [(-1, -1)] * len(seeds) + [(3, 1), (1, 0)]
 all_seeds = [int(s) for s in seeds] + [31, 32]

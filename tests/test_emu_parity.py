@@ -207,7 +207,7 @@ def test_resting_bowl_face_manifold(blob, oracle):
     import reset_oracle as ro
     from emu_lib import Emu
     e = Emu(blob)
-    st, _ = ro.ResetOracle(blob.words).sample(41)
+    st, _ = ro.with_collision_check(blob.words).sample(41)
     oracle.settle(st, 25)
     rng = np.random.RandomState(3)
     for k in range(30):
@@ -286,7 +286,7 @@ def test_pushed_bowl_and_particles(blob, oracle, case):
     from emu_lib import Emu
     rng = np.random.RandomState(77 + case)
     e = Emu(blob)
-    st, _ = ro.ResetOracle(blob.words).sample(int(rng.randint(1, 1 << 30)))
+    st, _ = ro.with_collision_check(blob.words).sample(int(rng.randint(1, 1 << 30)))
     oracle.settle(st, 25)
     for k in range(int(rng.randint(5, 30))):
         oracle.step(st, rng.uniform(-1, 1, blob.act_dim).astype(np.float32))

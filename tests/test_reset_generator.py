@@ -53,7 +53,7 @@ def test_philox_known_answers():
 
 def test_oracle_human_pose_matches_the_compile_time_model(blob):
     """independent check of the oracle's link walk + the blob's joint table against model/human.py's root-down FK"""
-    o = ro.ResetOracle(blob.words)
+    o = ro.with_collision_check(blob.words)
     D = np.deg2rad
     for g, gender in enumerate(('male', 'female')):
         for ls in (1.0, 0.6):
@@ -81,7 +81,7 @@ def emu(blob):
 
 @pytest.mark.parametrize('seed', [1001, 1002, 1003, 77, (1 << 40) + 5, (1 << 63) + 12345])
 def test_emulated_kernel_matches_oracle(blob, emu, seed):
-    o = ro.ResetOracle(blob.words)
+    o = ro.with_collision_check(blob.words)
     st, info = o.sample(seed)
     se, ie = emu.sample(seed)
     assert_same_record(blob, st, se, 'seed %d' % seed)
@@ -92,7 +92,7 @@ def test_emulated_kernel_matches_oracle(blob, emu, seed):
 
 @pytest.mark.parametrize('impairment,gender', [(0, 0), (1, 1), (2, 0), (3, 1), (-2, -1)])
 def test_fixed_modes(blob, emu, impairment, gender):
-    o = ro.ResetOracle(blob.words)
+    o = ro.with_collision_check(blob.words)
     for seed in (31, 32, 33):
         st, info = o.sample(seed, impairment, gender)
         se, ie = emu.sample(seed, impairment, gender)
@@ -118,7 +118,7 @@ def test_restart_rounds_and_randomised_limits(blob):
     first lanes -- often beyond restart 10 (randomised limits, robot.py:91) or in a later 64-restart round."""
     from emu_lib import Emu
     hard = with_reset_params(blob, IK_ITERS=3, IK_RESTARTS=200, IK_THRESH=0.05)
-    o, e = ro.ResetOracle(hard.words), Emu(hard)
+    o, e = ro.with_collision_check(hard.words), Emu(hard)
     seen = []
     for seed in range(400, 412):
         st, info = o.sample(seed)
@@ -134,7 +134,7 @@ def test_no_restart_succeeds_keeps_the_best(blob):
     """thresholds nobody meets: the pose with the smallest position error over ALL restarts is kept (robot.py:100-103)"""
     from emu_lib import Emu
     hard = with_reset_params(blob, IK_ITERS=2, IK_RESTARTS=70, IK_THRESH=1e-9)
-    o, e = ro.ResetOracle(hard.words), Emu(hard)
+    o, e = ro.with_collision_check(hard.words), Emu(hard)
     for seed in (501, 502, 503):
         st, info = o.sample(seed)
         se, ie = e.sample(seed)
@@ -194,7 +194,7 @@ def test_gpu_sample_reset_matches_oracle(blob):
     st.sample_reset(seed0, ik_info=info)
     st.synchronize()
     got, gi = st.get_state(), info.cpu().numpy()
-    o = ro.ResetOracle(blob.words)
+    o = ro.with_collision_check(blob.words)
     for i in list(range(12)) + [n - 1]:
         want, winfo = o.sample(seed0 + i)
         assert_same_record(blob, want, got[i], 'env %d' % i)
@@ -215,7 +215,7 @@ def test_gpu_hard_ik_matches_oracle(blob):
     st.sample_reset(400)
     st.synchronize()
     got = st.get_state()
-    o = ro.ResetOracle(hard.words)
+    o = ro.with_collision_check(hard.words)
     for i in range(12):
         want, _ = o.sample(400 + i)
         assert_same_record(hard, want, got[i], 'env %d' % i)
@@ -282,7 +282,7 @@ def test_gpu_masked_reset_leaves_other_envs_alone(blob):
     want = ref.get_state()
     np.testing.assert_array_equal(after[m], want[m])
     assert np.all(blob.view(after[m])['iteration'] == 0) and np.all(blob.view(after[~m])['iteration'] == 3)
-    o = ro.ResetOracle(blob.words)
+    o = ro.with_collision_check(blob.words)
     pre, _ = o.sample(int(seeds[5]))
     st2 = Stepper(blob, n)
     st2.reset(mask, seeds, settle_substeps=0)
@@ -349,7 +349,7 @@ def _golden():
 def test_golden_fixture_oracle_and_emulator(blob, emu):
     g, seeds, imps, gens = _golden()
     assert int(g['blob_version']) == blob.h['VERSION']
-    o = ro.ResetOracle(blob.words)
+    o = ro.with_collision_check(blob.words)
     for k, (s, imp, gen) in enumerate(zip(seeds, imps, gens)):
         st, info = o.sample(s, imp, gen)
         np.testing.assert_array_equal(st.view(np.int32), g['states'][k].view(np.int32))           # the oracle is deterministic
@@ -369,4 +369,60 @@ def test_gpu_golden_fixture(blob):
         st.sample_reset(s, impairment=names_i[imp], gender=names_g[gen])
         st.synchronize()
         assert_same_record(blob, g['states'][k], st.get_state()[0], 'golden record %d' % k)
+    st.close()
+
+
+# ---- collision rejection (robot.py:105-112, env.py:299-308) ------------------------------------------------------------
+COLLIDING_SEEDS = [1004, 1030, 1036]      # the first IK restart that meets the thresholds puts the elbow through the table top
+
+
+def _forbidden_contacts(blob, oracle, st):
+    return ro.contacts_collide(blob.words, oracle.substep_debug(st.copy()))
+
+
+def test_colliding_start_poses_are_rejected(blob, oracle, emu):
+    plain, checked = ro.ResetOracle(blob.words), ro.with_collision_check(blob.words)
+    for s in COLLIDING_SEEDS:
+        st0, i0 = plain.sample(s)
+        assert i0['ik_ok'] and _forbidden_contacts(blob, oracle, st0), 'the unchecked sampler accepts a colliding pose for this seed'
+        st1, i1 = checked.sample(s)
+        assert i1['ik_ok'] and i1['rejected_restarts'] and i1['rejected_restarts'][0] == i0['ik_restarts'] - 1
+        assert i1['ik_restarts'] > i0['ik_restarts'] and not _forbidden_contacts(blob, oracle, st1)
+        se, ie = emu.sample(s)                                   # the device code takes the same decisions
+        assert_same_record(blob, st1, se, 'seed %d' % s)
+        assert int(ie[1]) == i1['ik_restarts']
+    # everything but the arm pose (and what hangs on it) is unchanged by the rejection: same human, same bowl
+    v0, v1 = blob.view(st0.reshape(1, -1)), blob.view(st1.reshape(1, -1))
+    assert np.array_equal(v0['human'], v1['human']) and np.array_equal(v0['free'][0, 1], v1['free'][0, 1]) and not np.array_equal(v0['q'], v1['q'])
+
+
+def test_collision_tries_zero_restores_the_unchecked_sampler(blob, emu):
+    from emu_lib import Emu
+    w = blob.words.copy(); w.view(np.int32)[blob.h['OFF_RESET'] + L.X_['COLLISION_TRIES']] = 0
+    b0 = ModelBlob(w, blob.meta)
+    st0, _ = ro.ResetOracle(b0.words).sample(COLLIDING_SEEDS[0])
+    assert_same_record(b0, st0, Emu(b0).sample(COLLIDING_SEEDS[0])[0])
+    assert_same_record(b0, st0, ro.with_collision_check(b0.words).sample(COLLIDING_SEEDS[0])[0])
+
+
+@pytest.mark.gpu
+def test_gpu_colliding_start_poses_are_rejected(blob, oracle):
+    import torch
+    from assistive_gym_amd.libagx import Stepper
+    checked = ro.with_collision_check(blob.words)
+    n = 64
+    st = Stepper(blob, n)
+    info = torch.zeros((n, 4), device='cuda')
+    st.sample_reset(1001, ik_info=info)
+    st.synchronize()
+    got, info = st.get_state(), info.cpu().numpy()
+    nrej = 0
+    for i in range(n):
+        so, io = checked.sample(1001 + i)
+        assert_same_record(blob, so, got[i], 'env %d' % i)
+        assert int(info[i, 1]) == io['ik_restarts']
+        nrej += len(io['rejected_restarts'])
+        if io['ik_ok'] and len(io['rejected_restarts']) < 3:
+            assert not _forbidden_contacts(blob, oracle, got[i])
+    assert nrej >= 5                                            # seeds 1004, 1015, 1027, ... are among them
     st.close()
