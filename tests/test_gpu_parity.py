@@ -266,7 +266,9 @@ def test_food_events_match_oracle(gpu_lib, blob, oracle):
     food0 = blob.h['FOOD0']
     for i in range(n):
         v = blob.view(states[i])
-        v['free'][0, food0 + 0, :3] += np.array([-0.095, -0.095, 0.095], dtype=np.float32)
+        # even envs: diagonally away (near the edge of the 0.1 m query: spill or not depends on the spoon pose); odd envs: 0.25 m
+        # straight above the spoon (it falls 5 cm during the step): no part of the spoon within 0.1 m
+        v['free'][0, food0 + 0, :3] += np.array([-0.095, -0.095, 0.095] if i % 2 == 0 else [0.0, 0.0, 0.25], dtype=np.float32)
         v['free'][0, food0 + 0, 7:13] = 0.0
         v['free'][0, food0 + 1, :3] = v['target'][0] + np.array([0.0, 0.0, 0.045], dtype=np.float32)
         v['free'][0, food0 + 1, 7:13] = 0.0
