@@ -7,6 +7,7 @@
 #include "../../include/agx_blob.h"
 #include "../../include/agx.h"
 
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -341,6 +342,76 @@ int agx_debug_layout(agx_handle h, int* out8) {
   return AGX_OK;
 }
 const char* agx_variant_name(agx_handle h) { return h ? h->V->name : ""; }
+
+// ---- observation all-gather over RCCL: the only exchange the sharded path has -------------------------------
+// RCCL is bound at run time (dlopen), so a process that never gathers does not need it; a library instance that is already
+// loaded (e.g. the one PyTorch ships) is preferred so that the process ends up with ONE RCCL.
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // ncclUniqueId is passed by value: 128 bytes, see call site
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+struct agx_unique_id { char bytes[128]; };   // layout of ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+RcclApi g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return AGX_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
+  for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // already in the process?
+  for (const char* n : names) { if (lib) break; lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+  if (!lib) return fail(AGX_E_HIP, "agx_allgather: librccl.so not found");
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, const void*, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+  g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) return fail(AGX_E_HIP, "agx_allgather: RCCL symbols missing");
+  g_rccl.lib = lib;
+  return AGX_OK;
+}
+int rccl_fail(const char* what, int rc) {
+  char buf[256]; snprintf(buf, sizeof buf, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+  return fail(AGX_E_HIP, buf);
+}
+}  // namespace
+
+int agx_comm_unique_id(void* out128) {
+  if (!out128) return fail(AGX_E_ARG, "agx_comm_unique_id: null");
+  int rc = rccl_load(); if (rc) return rc;
+  rc = g_rccl.GetUniqueId(out128);
+  return rc ? rccl_fail("ncclGetUniqueId", rc) : AGX_OK;
+}
+int agx_comm_init_rank(int device, int rank, int world, const void* unique_id128, void** comm_out) {
+  if (!unique_id128 || !comm_out || rank < 0 || rank >= world) return fail(AGX_E_ARG, "agx_comm_init_rank: bad argument");
+  int rc = rccl_load(); if (rc) return rc;
+  HIPCHK(hipSetDevice(device));
+  // ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank): the id is a 128-byte struct passed by value
+  typedef int (*init_fn)(void**, int, agx_unique_id, int);
+  agx_unique_id id; memcpy(id.bytes, unique_id128, sizeof id.bytes);
+  rc = ((init_fn)(void*)g_rccl.CommInitRank)(comm_out, world, id, rank);
+  return rc ? rccl_fail("ncclCommInitRank", rc) : AGX_OK;
+}
+int agx_comm_destroy(void* comm) {
+  if (!comm) return AGX_OK;
+  int rc = rccl_load(); if (rc) return rc;
+  rc = g_rccl.CommDestroy(comm);
+  return rc ? rccl_fail("ncclCommDestroy", rc) : AGX_OK;
+}
+int agx_allgather(agx_handle h, const float* local_dev, float* gathered_dev, size_t floats_per_rank, void* comm, void* stream) {
+  if (!h || !local_dev || !gathered_dev) return fail(AGX_E_ARG, "agx_allgather: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (!comm) {   // a single rank: the gathered batch is the local shard
+    if (gathered_dev != local_dev) HIPCHK(hipMemcpyAsync(gathered_dev, local_dev, floats_per_rank * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AGX_OK;
+  }
+  int rc = rccl_load(); if (rc) return rc;
+  rc = g_rccl.AllGather(local_dev, gathered_dev, floats_per_rank, 7 /* ncclFloat32 */, comm, (hipStream_t)stream);
+  return rc ? rccl_fail("ncclAllGather", rc) : AGX_OK;
+}
 
 int agx_step_host(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info) {
   if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step_host: bad argument");

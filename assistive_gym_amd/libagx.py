@@ -14,7 +14,8 @@ _LIB = None
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
-           'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset']
+           'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset',
+           'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather']
 
 
 class AgxError(RuntimeError):
@@ -90,6 +91,10 @@ class Stepper:
     def set_env_offset(self, env_offset):
         """global index of this stepper's first env (multi-GPU sharding): keeps agx_reset_done's pool draw placement independent"""
         check(self.L.agx_set_env_offset(self.h, C.c_longlong(int(env_offset))), 'agx_set_env_offset')
+
+    def allgather(self, local, gathered, comm=None, stream=0):
+        """agx_allgather of a float32 device tensor (comm None = single rank)"""
+        check(self.L.agx_allgather(self.h, _ptr(local), _ptr(gathered), C.c_size_t(local.numel()), C.c_void_p(comm), C.c_void_p(stream)), 'agx_allgather')
 
     def set_state(self, states):
         states = np.ascontiguousarray(states, dtype=np.float32)

@@ -97,9 +97,14 @@ class AssistiveVecEnv:
         self.stepper.observe_dev(self.obs, s)
         return self.obs
 
-    def step(self, actions):
+    def step(self, actions, obs_out=None):
+        """obs_out: optional [n_envs, obs_dim] float32 device tensor that receives the observations instead of self.obs (double
+        buffering for an overlapped all-gather, shard.ObsGatherer); it becomes self.obs"""
         assert actions.is_cuda and actions.dtype == torch.float32 and actions.shape == (self.n_envs, self.act_dim) and actions.is_contiguous()
         s = self._stream()
+        if obs_out is not None:
+            assert obs_out.is_cuda and obs_out.dtype == torch.float32 and obs_out.shape == (self.n_envs, self.obs_dim) and obs_out.is_contiguous()
+            self.obs = obs_out
         self.stepper.step_dev(actions, self.obs, self.reward, self.done, self.info, s)
         self._t += 1
         if self.auto_reset:

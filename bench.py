@@ -121,7 +121,7 @@ def main():
     import torch.distributed as dist
     from assistive_gym_amd.blob import ModelBlob
     from assistive_gym_amd import vec_env
-    from assistive_gym_amd.shard import gather_observations
+    from assistive_gym_amd.shard import ObsGatherer
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -139,15 +139,20 @@ def main():
     K, W = args.steps, args.warmup
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
     tape = torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1
-    gathered = torch.empty((world * n, blob.obs_dim), device='cuda') if distributed else None
+    # whole-batch observation collation: RCCL all-gather on a side stream, overlapped with the next step (two buffers alternate)
+    gatherer = ObsGatherer(n, blob.obs_dim, world, device=torch.device('cuda', local_rank)) if distributed else None
 
     def one(k):
-        obs, rew, done, info = env.step(tape[k])
         if distributed:
-            gather_observations(obs, world, gathered)
+            env.step(tape[k], obs_out=gatherer.buffer(k & 1))
+            gatherer.submit(k & 1)
+        else:
+            env.step(tape[k])
 
     for k in range(W):
         one(k)
+    if distributed:
+        gatherer.wait()
     stream = torch.cuda.current_stream().cuda_stream
     if distributed:
         dist.barrier()
@@ -158,6 +163,7 @@ def main():
         one(k)
     kernel_ms = env.stepper.profile_end(stream)
     if distributed:
+        gatherer.wait()                  # the last gathers are inside the timed region
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

@@ -103,6 +103,17 @@ int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, 
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream);
 int agx_set_env_offset(agx_handle h, long long env_offset);
 
+/* ---- whole-batch observation collation across GPUs: environments are sharded by contiguous index ranges, one
+ * process per GPU; the only exchange is an all-gather of the [n_envs, obs_dim] shards over RCCL / xGMI, and only when one
+ * consumer wants the whole batch.  RCCL is bound at run time (an instance already loaded into the process is reused).
+ * agx_comm_unique_id: rank 0 obtains the 128-byte id and hands it to the other ranks by the host's own means (MPI, TCP, file);
+ * agx_comm_init_rank: collective over all ranks; agx_allgather: gathered_dev[rank * floats_per_rank ...] = the shard of `rank`,
+ * enqueued on `stream` (use a side stream and an event after agx_step to overlap it with the next step); comm == NULL = one rank. */
+int agx_comm_unique_id(void* out128);
+int agx_comm_init_rank(int device, int rank, int world, const void* unique_id128, void** comm_out);
+int agx_comm_destroy(void* comm);
+int agx_allgather(agx_handle h, const float* local_dev, float* gathered_dev, size_t floats_per_rank, void* comm, void* stream);
+
 /* convenience wrappers with HOST buffers (copies included; not the timed path) */
 int agx_step_host(agx_handle h, const float* actions, float* obs, float* reward, uint8_t* done, float* info);
 int agx_observe_host(agx_handle h, float* obs);

@@ -61,3 +61,35 @@ def test_fresh_reset_seeds_are_placement_independent():
                      for r in range(world)]
             np.testing.assert_array_equal(np.concatenate(parts), one)
     assert episode_seed(seed, 1, 0) - episode_seed(seed, 0, n_global - 1) > 1 << 31
+
+
+def _gather_worker(rank, world, port, n, obs_dim, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from assistive_gym_amd.shard import ObsGatherer
+    g = ObsGatherer(n, obs_dim, world)                  # CPU tensors: the synchronous path of the same protocol
+    outs = []
+    for k in range(4):
+        buf = g.buffer(k & 1)
+        buf[:] = torch.arange(n * obs_dim, dtype=torch.float32).reshape(n, obs_dim) + 1000 * k + 100 * rank
+        full = g.submit(k & 1)
+        g.wait(k & 1)
+        outs.append(full.numpy().copy())
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_obs_gatherer_double_buffer_protocol():
+    world, n, obs_dim = 2, 4, 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gather_worker, args=(r, world, port, n, obs_dim, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(timeout=60) for p in ps]
+    base = np.arange(n * obs_dim, dtype=np.float32).reshape(n, obs_dim)
+    for rank, outs in res:
+        for k, full in enumerate(outs):
+            np.testing.assert_array_equal(full, np.concatenate([base + 1000 * k, base + 1000 * k + 100]))
