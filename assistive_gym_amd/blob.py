@@ -49,7 +49,7 @@ class ModelBlob:
         n_h = sum(1 for d in range(self.nrobot, self.ndof) if self.robot_i(d, 'ACT') >= 0)
         wi[L.H['ACT_DIM']] = self.act_dim_robot + n_h
         # obs_human_len: 19 + joints in feeding.py:10, 18 + joints in bed_bathing.py:10
-        wi[L.H['OBS_DIM']] = self.obs_dim_robot + (18 if self.task_kind == L.TASK_BED_BATHING else 19) + n_h
+        wi[L.H['OBS_DIM']] = self.obs_dim_robot + {L.TASK_BED_BATHING: 18, L.TASK_SCRATCH_ITCH: 24}.get(self.task_kind, 19) + n_h    # scratch_itch.py:8
         wi[self.h['OFF_TASK'] + L.T['COOP']] = 1
         # pose-dependent arm limits (human.py:134-152) run when a shoulder joint is controllable (human.py:136-137)
         if self.h['OFF_MLP'] and any(self.robot_i(d, 'ACT') >= 0 for d in self.task_i_n('ARM_LIMIT_DOF', 1)):
@@ -66,7 +66,7 @@ class ModelBlob:
 
     @property
     def obs_dim_robot(self):
-        return (17 if self.task_kind == L.TASK_BED_BATHING else 18) + self.act_dim_robot       # bed_bathing.py:10 / feeding.py:10
+        return {L.TASK_BED_BATHING: 17, L.TASK_SCRATCH_ITCH: 23}.get(self.task_kind, 18) + self.act_dim_robot       # bed_bathing.py:10 / scratch_itch.py:8 / feeding.py:10
 
     def rec(self, d, gender=0):
         """link record index of DoF d (human DoFs have one record per gender)"""
@@ -124,6 +124,7 @@ class ModelBlob:
             iteration=si[:, e + L.E['ITERATION']], task_success=si[:, e + L.E['TASK_SUCCESS']],
             rng=si[:, e + L.E['RNG']:e + L.E['RNG'] + 2], total_food=si[:, e + L.E['TOTAL_FOOD']],
             frozen=si[:, e + L.E['FROZEN']], limit_scale=s[:, e + L.E['LIMIT_SCALE']],
+            human_kp=s[:, e + L.E['HUMAN_KP']], human_maxf=s[:, e + L.E['HUMAN_MAXF']],
             task=si[:, h['S_TASK']:h['S_TASK'] + h['TASK_WORDS']],
             tremor=s[:, h['S_TREMOR']:h['S_TREMOR'] + self.nhdof],
             tremor_target=s[:, h['S_TREMOR'] + self.nhdof:h['S_TREMOR'] + 2 * self.nhdof])

@@ -80,7 +80,7 @@ struct agx_handle_s {
 
 extern "C" {
 
-const char* agx_version(void) { return "libagx 0.2 (gfx950, wave-per-env stepper; variants: feeding, bed_bathing)"; }
+const char* agx_version(void) { return "libagx 0.2 (gfx950, wave-per-env stepper; variants: feeding, bed_bathing, scratch_itch)"; }
 const char* agx_last_error(void) { return g_err.c_str(); }
 int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int agx_lds_bytes_per_env(void) { return agx_variant_feeding()->lds_bytes; }
@@ -93,7 +93,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     return fail(AGX_E_BLOB, "agx_create: not a model blob of this version");
   const agx_variant* V = nullptr;
   {
-    const agx_variant* all[2] = {agx_variant_feeding(), agx_variant_bed_bathing()};
+    const agx_variant* all[3] = {agx_variant_feeding(), agx_variant_bed_bathing(), agx_variant_scratch_itch()};
     for (const agx_variant* v : all) if (v->task_kind == hi[AGX_H_TASK_KIND]) V = v;
     if (!V) return fail(AGX_E_LIMIT, "agx_create: no kernel variant is compiled for the task of this model");
   }

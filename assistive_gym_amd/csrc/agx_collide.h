@@ -218,10 +218,11 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
       const bool mq = has && near && (GRI(c, g, AGX_G_FLAGS) & 2) && CLI(c, a, AGX_C_TAG) == AGX_TAG_FOOD;
       if (wave_any(mq)) { any_manifold_query = true; for (int f = 0; f < c.nfood; f++) if (wave_any(mq && CLI(c, a, AGX_C_BODY) - AGX_BODY_FREE0 - food0 == f)) cs.near_mask |= 1 << f; }
     }
-    if constexpr (TASK == AGX_TASK_BED_BATHING) {
-      // manifold points of the wiping pad on the human: what tool.get_contact_points(human) reports for linkA == 1,
-      // whether or not they carry force (bed_bathing.py:47-58); the point on the human and the human's link go to the finish kernel
-      const bool qp = has && near && (GRI(c, g, AGX_G_FLAGS) & 2) && CLI(c, a, AGX_C_TAG) == AGX_TAG_TOOL && CLI(c, a, AGX_C_LINK) == TKI(c, AGX_T_PAD_LINK) &&
+    if constexpr (TASK != AGX_TASK_FEEDING) {
+      // manifold points of the wiping pad / the scratcher's tool links on the human: what tool.get_contact_points(human) reports for
+      // those linkA, whether or not they carry force (bed_bathing.py:47-58, scratch_itch.py:51-57); the point on the human and the
+      // human's link go to the finish kernel
+      const bool qp = has && near && (GRI(c, g, AGX_G_FLAGS) & 2) && CLI(c, a, AGX_C_TAG) == AGX_TAG_TOOL && (TKI(c, AGX_T_PAD_LINK) >> (CLI(c, a, AGX_C_LINK) + 1) & 1) &&
                       CLI(c, b, AGX_C_TAG) == AGX_TAG_HUMAN;
       const uint64_t qm = wave_ballot(qp);
       const int slot = cs.nqpt + wave_rank(qm);

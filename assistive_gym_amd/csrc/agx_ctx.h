@@ -29,7 +29,10 @@ constexpr int MAX_ROWS = 160;
 constexpr int ST_WORDS = 336;
 constexpr int CON_STRIDE = 16;
 constexpr int HDR_STRIDE = 10;
-constexpr int ARENA_WORDS = 3592;
+#ifndef AGX_ARENA_WORDS   // LDS arena reused per phase: dynamics workspace, then collider AABB table + worklist + candidates
+#define AGX_ARENA_WORDS 3592
+#endif
+constexpr int ARENA_WORDS = AGX_ARENA_WORDS;
 constexpr int MAX_QPT = 16;                              // manifold points of the (wiping pad, human) pairs handed to the finish kernel
 constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
 
@@ -93,7 +96,7 @@ constexpr int DBG_CON = 16, DBG_MINV = DBG_CON + MAX_CON * CON_STRIDE, DBG_HDR =
 // per-environment scratch record in HBM (L2-resident while its environment is being solved)
 constexpr int SCR_ENT = 4096, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
 constexpr int QPT_STRIDE = 4;                            // manifold query point: position on the human (3), PyBullet link of the human collider (int)
-constexpr int SCR_QPT = TASK == AGX_TASK_BED_BATHING ? MAX_QPT * QPT_STRIDE : 0;
+constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
 constexpr int SCR_O_QPT = SCR_O_META + SCR_META;
 constexpr int SCR_WORDS = SCR_O_QPT + SCR_QPT;

@@ -156,6 +156,47 @@ AGX_DEV void observe_bed(const Ctx& c, float tool_force, float total_force, floa
     }
   }
 }
+// world position of the scratch-itch target: limb frame o target_on_arm (scratch_itch.py:148-152)
+AGX_DEV v3 scratch_target(const Ctx& c) {
+  const float* L = c.lds; const int s_task = c.bi[AGX_H_S_TASK];
+  const int link = TKI(c, AGX_T_ARM_LINK + c.ldsi[L_ST + s_task + AGX_SI_LIMB]);
+  return mul(ldm3(L + L_LINKR + 9 * link), ld3(L + L_ST + s_task + AGX_SI_TARGET)) + ld3(L + L_LINKP + 3 * link);
+}
+// ScratchItchEnv._get_obs (scratch_itch.py:59-91); every lane computes, lane 0 writes.
+// tool_force = all contacts of the tool, total_force = total_force_on_human, target_force = tool_force_at_target
+AGX_DEV void observe_scratch(const Ctx& c, float tool_force, float total_force, float target_force, float* gobs) {
+  const float* L = c.lds;
+  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);                       // tool.get_pos_orient(1)
+  v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
+  const v3 tg = scratch_target(c), tgr = tmul(BR, tg - bp);
+  v3 jp[3], jpr[3];
+  for (int k = 0; k < 3; k++) { jp[k] = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + k)); jpr[k] = tmul(BR, jp[k] - bp); }
+  if (c.lane == 0) {
+    int o = 0;
+    gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z;
+    gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
+    gobs[o++] = spr.x - tgr.x; gobs[o++] = spr.y - tgr.y; gobs[o++] = spr.z - tgr.z;
+    gobs[o++] = tgr.x; gobs[o++] = tgr.y; gobs[o++] = tgr.z;
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+      float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
+      gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
+    }
+    for (int k = 0; k < 3; k++) { gobs[o++] = jpr[k].x; gobs[o++] = jpr[k].y; gobs[o++] = jpr[k].z; }
+    gobs[o++] = tool_force;
+    if (c.coop) {   // human_obs (scratch_itch.py:79-88), in the frame of the human's base (collision body 0)
+      const v3 hb = ld3(L + L_HUMAN); const m3 HR = ldm3(L + L_HUMAN + 3);
+      const v3 sph = tmul(HR, sp - hb); const q4 sqh = m3_to_quat(mul_at(HR, sR)); const v3 tgh = tmul(HR, tg - hb);
+      gobs[o++] = sph.x; gobs[o++] = sph.y; gobs[o++] = sph.z;
+      gobs[o++] = sqh.x; gobs[o++] = sqh.y; gobs[o++] = sqh.z; gobs[o++] = sqh.w;
+      gobs[o++] = sph.x - tgh.x; gobs[o++] = sph.y - tgh.y; gobs[o++] = sph.z - tgh.z;
+      gobs[o++] = tgh.x; gobs[o++] = tgh.y; gobs[o++] = tgh.z;
+      for (int d = c.nrobot; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) gobs[o++] = L[L_ST + c.s_q + d];
+      for (int k = 0; k < 3; k++) { const v3 h = tmul(HR, jp[k] - hb); gobs[o++] = h.x; gobs[o++] = h.y; gobs[o++] = h.z; }
+      gobs[o++] = total_force; gobs[o++] = target_force;
+    }
+  }
+}
 // FeedingEnv._get_obs (feeding.py:85-112), robot part; every lane computes, lane 0 writes
 AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* gobs) {
   const float* L = c.lds;
@@ -297,7 +338,7 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   pgs(c, dv0, dv1);
   const long long t1 = gdebug ? wave_clock() : 0;
   integrate(c, scr.vel, dv0, dv1);
-  if constexpr (TASK == AGX_TASK_BED_BATHING) arm_limits(c, lds + L_VEL);   // the velocity vector is dead after the integration
+  if constexpr (TASK != AGX_TASK_FEEDING) arm_limits(c, lds + L_VEL);   // the velocity vector is dead after the integration
   store_env(c, gstate, sw);
   if (gdebug && lane == 0) { gdebug[DBG_TIME + 5] = (float)(t1 - t0); gdebug[DBG_TIME + 6] = (float)(wave_clock() - t1); }
 }
@@ -306,7 +347,9 @@ AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float
   Ctx c; ctx_init(c, blob, lds, lane);
   load_env(c, gstate, c.bi[AGX_H_STATE_WORDS]);
   kinematics(c); update_target(c);
-  if constexpr (TASK == AGX_TASK_BED_BATHING) observe_bed(c, 0.f, 0.f, 0.f, gobs); else observe(c, 0.f, 0.f, gobs);
+  if constexpr (TASK == AGX_TASK_BED_BATHING) observe_bed(c, 0.f, 0.f, 0.f, gobs);
+  else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) observe_scratch(c, 0.f, 0.f, 0.f, gobs);
+  else observe(c, 0.f, 0.f, gobs);
 }
 
 // end-effector speed: norm of getLinkState(ee, computeLinkVelocity)[6] (feeding.py:22, bed_bathing.py:19)
@@ -343,7 +386,7 @@ AGX_DEV void env_finish_bed(const uint32_t* blob, float* gstate, const float* ga
     const bool human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
     if (tool) tf = f;
     if (human && robot) rf = f;
-    if (human && tool) { thf = f; const int tc = ta == AGX_TAG_TOOL ? ca : cb; if (CLI(c, tc, AGX_C_LINK) == TKI(c, AGX_T_PAD_LINK)) pf = f; }
+    if (human && tool) { thf = f; const int tc = ta == AGX_TAG_TOOL ? ca : cb; if (TKI(c, AGX_T_PAD_LINK) >> (CLI(c, tc, AGX_C_LINK) + 1) & 1) pf = f; }
   }
   const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), pad_f = wave_sum(pf), total_f = robot_f + wave_sum(thf);
   observe_bed(c, tool_f, total_f, pad_f, gobs);
@@ -425,6 +468,78 @@ AGX_DEV void env_finish_bed(const uint32_t* blob, float* gstate, const float* ga
       ginfo[AGX_INFO_TOTAL_FORCE] = total_f;
       ginfo[AGX_INFO_TASK_SUCCESS] = (float)(success >= Li[L_ST + c.s_env + AGX_E_TOTAL_FOOD] * TKF(c, AGX_T_SUCCESS_FRAC));
       ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = pad_f; ginfo[AGX_INFO_FOOD_REWARD] = (float)new_points;
+      ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
+    }
+  }
+  store_env(c, gstate, sw);
+}
+
+// finish, scratch itch: everything ScratchItchEnv.step does after take_step (scratch_itch.py:14-44)
+AGX_DEV void env_finish_scratch(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+                                float* ginfo, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS], act_dim = c.bi[AGX_H_ACT_DIM];
+  Scratch scr = scratch_of(gscratch);
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nqpt = scr.meta[META_NQPT];
+  load_env(c, gstate, sw);
+  float an2 = 0.f;
+  for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
+  wave_sync();
+  kinematics(c);   // poses as the getters of _get_obs see them after the last stepSimulation
+  const v3 target = scratch_target(c);                            // update_targets after the last substep
+  const float r2 = TKF(c, AGX_T_TARGET_RADIUS) * TKF(c, AGX_T_TARGET_RADIUS);
+  // get_total_force (scratch_itch.py:46-57) from the last substep's contact impulses
+  float rf = 0.f, tf = 0.f, thf = 0.f, gf = 0.f;
+  if (lane < c.ncon) {
+    const float* k = scr.con + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const int ca = ki[C_CA], cb = ki[C_CB], ta = CLI(c, ca, AGX_C_TAG), tb = CLI(c, cb, AGX_C_TAG);
+    const float f = k[C_LAM] / c.dt;
+    const bool human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
+    if (tool) tf = f;
+    if (human && robot) rf = f;
+    if (human && tool) {
+      thf = f;
+      const bool tool_is_a = ta == AGX_TAG_TOOL; const int tc = tool_is_a ? ca : cb;
+      const v3 on_human = ld3(k + (tool_is_a ? C_PB : C_PA)), d = on_human - target;
+      if ((TKI(c, AGX_T_PAD_LINK) >> (CLI(c, tc, AGX_C_LINK) + 1) & 1) && dot(d, d) < r2) gf = f;      // close to the target (:54)
+    }
+  }
+  const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), target_f = wave_sum(gf), total_f = robot_f + wave_sum(thf);
+  observe_scratch(c, tool_f, total_f, target_f, gobs);
+  // target_contact_pos: the LAST manifold point of the tool's links 0 / 1 on the human within TARGET_RADIUS of the target (:52-56)
+  bool near = false; v3 qp = mk3(0.f, 0.f, 0.f);
+  if (lane < c.nqpt) { qp = ld3(scr.qpt + QPT_STRIDE * lane); const v3 d = qp - target; near = dot(d, d) < r2; }
+  const uint64_t nm = wave_ballot(near);
+  const int s_task = c.bi[AGX_H_S_TASK];
+  int success = Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS];
+  float scratch_reward = 0.f;
+  if (nm) {
+    const int last = 63 - __builtin_clzll((unsigned long long)nm);
+    const v3 cp = mk3(wave_bcast(qp.x, last), wave_bcast(qp.y, last), wave_bcast(qp.z, last));
+    const v3 dp = cp - ld3(L + L_ST + s_task + AGX_SI_PREV_CONTACT);
+    if (sqrtf(dot(dp, dp)) > 0.01f && target_f < 10.f) {         // the tool moved along the skin and does not press too hard (:28-32)
+      scratch_reward = 5.f; success += 1;
+      wave_sync();
+      if (lane == 0) st3(L + L_ST + s_task + AGX_SI_PREV_CONTACT, cp);
+      wave_sync();
+    }
+  }
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  const v3 dd = target - sp;
+  const float ee_speed = ee_speed_of(c);
+  const float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-(total_f - target_f)) + TKF(c, AGX_T_C_HF) * (target_f < 10.f ? 0.f : -target_f);
+  const float reward = TKF(c, AGX_T_W_DISTANCE) * (-sqrtf(dot(dd, dd))) + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + TKF(c, AGX_T_W_WIPE) * scratch_reward + pref;
+  const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];
+  wave_sync();
+  if (lane == 0) {
+    Li[L_ST + c.s_env + AGX_E_TASK_SUCCESS] = success;
+    *greward = reward;
+    *gdone = (uint8_t)(iteration >= (int)TKF(c, AGX_T_EPISODE_LEN));
+    if (ginfo) {
+      ginfo[AGX_INFO_TOTAL_FORCE] = total_f;
+      ginfo[AGX_INFO_TASK_SUCCESS] = (float)(success >= Li[L_ST + c.s_env + AGX_E_TOTAL_FOOD] * TKF(c, AGX_T_SUCCESS_FRAC));
+      ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = target_f; ginfo[AGX_INFO_FOOD_REWARD] = scratch_reward;
       ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
     }
   }
@@ -545,6 +660,7 @@ AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float
 AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
                         float* ginfo, float* lds, int lane) {
   if constexpr (TASK == AGX_TASK_BED_BATHING) env_finish_bed(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
+  else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) env_finish_scratch(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else env_finish_feeding(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
 }
 

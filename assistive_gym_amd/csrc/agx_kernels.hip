@@ -11,11 +11,21 @@
 #define AGX_TASK 1
 #define AGX_VNAME bed_bathing
 #define AGX_K(name) name##_bb
+#elif defined(AGX_VARIANT_SCRATCH_ITCH)
+// ScratchItchPR2: the PR2's left arm branch (7 arm joints + 4 finger joints; its other branches start at rest with zero gravity and are
+// compiled as static) + the 10 joints of the human's right arm, one free body (scratcher)
+#define AGX_MAX_DOF 24
+#define AGX_MAX_FREE 2
+#define AGX_MAX_BLOCK 12
+#define AGX_ARENA_WORDS 4096
+#define AGX_TASK 2
+#define AGX_VNAME scratch_itch
+#define AGX_K(name) name##_si
 #elif defined(AGX_VARIANT_FEEDING)
 #define AGX_VNAME feeding
 #define AGX_K(name) name
 #else
-#error "build with -DAGX_VARIANT_FEEDING or -DAGX_VARIANT_BED_BATHING"
+#error "build with -DAGX_VARIANT_FEEDING, -DAGX_VARIANT_BED_BATHING or -DAGX_VARIANT_SCRATCH_ITCH"
 #endif
 
 #include "agx_wave.h"

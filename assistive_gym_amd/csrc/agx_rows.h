@@ -126,8 +126,11 @@ AGX_DEV void build_rows(Ctx& c) {
           go = true; if (d < c.nrobot) R.robot = true; else R.human = true;
           _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) R.Jr[q] = (q == d) ? 1.f : 0.f;
           // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
-          rb = RBF(c, d, AGX_R_KP) * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
-          float lim = RBF(c, d, AGX_R_MAXF) * dt; rlo = -lim; rhi = lim;
+          // a human that is not an agent holds its pose with the per-env reactive gain / force (human.py:124-127), if there is one
+          float kp = RBF(c, d, AGX_R_KP), maxf = RBF(c, d, AGX_R_MAXF);
+          if (d >= c.nrobot && L[L_ST + c.s_env + AGX_E_HUMAN_KP] > 0.f) { kp = L[L_ST + c.s_env + AGX_E_HUMAN_KP]; maxf = L[L_ST + c.s_env + AGX_E_HUMAN_MAXF]; }
+          rb = kp * (L[L_ST + c.s_qt + d] - L[L_ST + c.s_q + d]) / dt + RBF(c, d, AGX_R_KD) * (0.f - L[L_VEL + d]);
+          float lim = maxf * dt; rlo = -lim; rhi = lim;
         }
       } else if (slot < 3 * MAX_DOF) {
         const int d = (slot - MAX_DOF) >> 1, side = (slot - MAX_DOF) & 1;

@@ -222,7 +222,31 @@ class BedBathingSawyerHumanEnv(BedBathingSawyerEnv):
     coop = True
 
 
-ENV_IDS = {'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
+class ScratchItchPR2Env(AssistiveEnv):
+    """ScratchItchPR2-v1 (scratch_itch_envs.py:17-19): the PR2's left arm scratches a target on the seated human's right arm."""
+    model, task = 'scratch_itch_pr2', 'scratch_itch'
+
+    def reset(self):
+        """ScratchItchEnv.reset (scratch_itch.py:93-132), restated on the host (host/reset_scratch.py); its result is injected."""
+        from .host.reset_scratch import ScratchItchPR2Reset
+        st = self._ensure_stepper()
+        if not hasattr(self, '_sampler'):
+            self._sampler = ScratchItchPR2Reset(self.blob)
+        self.reset_seed = self._draw_seed()
+        rec = self.blob.new_state(1)
+        self._sampler.sample(np.random.RandomState(self.reset_seed % (2 ** 32)), rec, env_seed=self.reset_seed % (2 ** 31))
+        st.set_state(rec)
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+
+class ScratchItchPR2HumanEnv(ScratchItchPR2Env):
+    """ScratchItchPR2Human-v1 (scratch_itch_envs.py:41-44; BASELINE config 4): the human's right arm (10 joints) is controllable,
+    the pose-dependent arm limits run after every substep; actions {'robot': a[7], 'human': a[10]}, observations 30 + 34."""
+    coop = True
+
+
+ENV_IDS = {'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
            'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
 
 
@@ -240,5 +264,6 @@ if gym is not None:       # same ids the reference registers (assistive_gym/__in
         from gym.envs.registration import register
         register(id='FeedingJaco-v1', entry_point='assistive_gym_amd.envs:FeedingJacoEnv', max_episode_steps=200)
         register(id='BedBathingSawyer-v1', entry_point='assistive_gym_amd.envs:BedBathingSawyerEnv', max_episode_steps=200)
+        register(id='ScratchItchPR2-v1', entry_point='assistive_gym_amd.envs:ScratchItchPR2Env', max_episode_steps=200)
     except Exception:
         pass

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import xform as X
 from .human import HumanModel
-from .meshio import load_obj_groups, load_dae_vertices, convex_hull_vertices, reduce_hull
+from .meshio import load_obj_groups, load_dae_vertices, load_stl_vertices, convex_hull_vertices, reduce_hull
 from .urdf import Urdf
 
 # ---- constants mirrored from include/agx_blob.h (checked by tests/test_blob_layout.py) ----------
@@ -52,12 +52,13 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48, COUNT=52)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
-         TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, COUNT=16)
+         TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, HUMAN_KP=14, HUMAN_MAXF=15, COUNT=16)
 BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
 PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
 HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8, BED=9)
-TASK_FEEDING, TASK_BED_BATHING = 0, 1
+TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH = 0, 1, 2
+SI = dict(TARGET=0, LIMB=3, PREV_CONTACT=12, WORDS=16)   # scratch itch task words (AGX_SI_*); the arm-limit words sit where BB has them
 BB = dict(ALIVE=0, ALIVE_WORDS=6, PREV=6, HAS_PREV=10, WORDS=12)
 MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathing task words of the state record (AGX_BB_*)
 # pair-group flags (AGX_G_FLAGS)
@@ -128,6 +129,8 @@ def link_collision_hulls(link, max_verts, assets_cache):
             if key not in assets_cache:
                 if c.filename.lower().endswith('.obj'):
                     groups = load_obj_groups(c.filename, c.scale)
+                elif c.filename.lower().endswith('.stl'):
+                    groups = [load_stl_vertices(c.filename) * c.scale]
                 else:
                     groups = [load_dae_vertices(c.filename) * c.scale]
                 assets_cache[key] = [convex_hull_vertices(g) for g in groups]
@@ -166,16 +169,19 @@ def aabb_inertia_in_inertial_frame(link, hulls):
     return box_inertia(link.mass, lo, hi)
 
 
-def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_gain, motor_force, max_hull_verts):
-    """Jaco: returns (records[ndof][R.STRIDE], per-dof collider lists, base collider list, maps)."""
+def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_gain, motor_force, max_hull_verts, frozen=None, use_file_inertia=False):
+    """Returns (records[ndof][R.STRIDE], per-dof collider lists, base collider list, maps).
+    frozen: {PyBullet joint index: position} -- movable joints compiled as fixed at that position (their links merge into the
+    carrier of their parent); use_file_inertia: URDF_USE_INERTIA_FROM_FILE (pr2.py:52)."""
     u = Urdf(urdf_path)
+    frozen = frozen or {}
     cache = {}
     n_pb = len(u.indexed_joints)
     # world-at-q0 transform of every PyBullet link frame relative to the robot base (root link) frame
     dof_of_pb = {}       # pb link index -> dof index of the moving link that carries it
     dof_links = []       # pb index of each moving link
     for j in u.indexed_joints:
-        if j.type in ('revolute', 'continuous', 'prismatic'):
+        if j.type in ('revolute', 'continuous', 'prismatic') and j.index not in frozen:
             dof_of_pb[j.index] = len(dof_links)
             dof_links.append(j.index)
     # carrier (moving ancestor, or -1 for base) and transform link-frame-in-carrier-frame for every link
@@ -187,7 +193,14 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
             rel[j.index] = (np.zeros(3), np.array([0, 0, 0, 1.0]))
         else:
             carrier[j.index] = carrier[pidx]
-            rel[j.index] = X.compose(rel[pidx][0], rel[pidx][1], j.pos, j.quat)
+            jp, jq = j.pos, j.quat
+            if j.index in frozen and j.type != 'fixed':           # a movable joint held at a fixed position
+                ax = j.axis / np.linalg.norm(j.axis)
+                if j.type == 'prismatic':
+                    jp = jp + X.quat_rotate(jq, ax) * frozen[j.index]
+                else:
+                    jq = X.quat_mul(jq, X.quat_from_axis_angle(ax, frozen[j.index]))
+            rel[j.index] = X.compose(rel[pidx][0], rel[pidx][1], jp, jq)
     rec = np.zeros((len(dof_links), R['STRIDE']), dtype=np.float64)
     rec_int = {}
     dof_colliders = [[] for _ in dof_links]
@@ -208,10 +221,10 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
         for verts, radius in hulls:
             dof_colliders[d].append((X.apply(rp, rq, verts), radius, link.lateral_friction, idx))
         if link.mass > 0:
-            idiag = aabb_inertia_in_inertial_frame(link, hulls)
+            Iin = link.inertia if use_file_inertia else np.diag(aabb_inertia_in_inertial_frame(link, hulls))
             cp, cq = X.compose(rp, rq, link.com_pos, link.com_quat)   # inertial frame in carrier frame
             Rm = X.quat_to_mat(cq)
-            acc[d].append((link.mass, cp, Rm @ np.diag(idiag) @ Rm.T))
+            acc[d].append((link.mass, cp, Rm @ Iin @ Rm.T))
     for d, pb in enumerate(dof_links):
         j = u.indexed_joints[pb]
         pidx = u.links[j.parent].index
@@ -651,6 +664,52 @@ def capsule_points(p1, p2, radius, distance_between_points):
     return pts
 
 
+def add_welded_tool(sc, urdf_path):
+    """A tool URDF whose links are welded by fixed joints (wiper.urdf, tool_scratch.urdf) = ONE rigid free body: composite mass,
+    centre of mass and inertia (per link: box inertia of its collision AABB [BULLET-UNVERIFIED], as for every body loaded without
+    URDF_USE_INERTIA_FROM_FILE); colliders keep their PyBullet link index (what getContactPoints reports as linkIndexA).
+    Returns ([free-body record], {link: frame in the base frame}, centre of mass in the base frame)."""
+    wu = Urdf(urdf_path)
+    parts = []
+    frames = {-1: (np.zeros(3), np.array([0, 0, 0, 1.0]))}
+    for j in wu.indexed_joints:
+        assert j.type == 'fixed'
+        frames[j.index] = X.compose(*frames[wu.links[j.parent].index], j.pos, j.quat)
+    tot_m, com = 0.0, np.zeros(3)
+    for idx in range(-1, len(wu.indexed_joints)):
+        lk = wu.link_by_index(idx)
+        hulls = link_collision_hulls(lk, 0, {})
+        cp, cq = X.compose(*frames[idx], lk.com_pos, lk.com_quat)
+        parts.append((idx, frames[idx], hulls, lk.mass, aabb_inertia_in_inertial_frame(lk, hulls), cp, cq, lk.lateral_friction))
+        tot_m += lk.mass
+        com += lk.mass * cp
+    com /= tot_m
+    Ic = np.zeros((3, 3))
+    for idx, fr, hulls, mass, idiag, cp, cq, _ in parts:
+        Rm = X.quat_to_mat(cq)
+        r = cp - com
+        Ic += Rm @ np.diag(idiag) @ Rm.T + mass * ((r @ r) * np.eye(3) - np.outer(r, r))
+    assert np.allclose(Ic, np.diag(np.diag(Ic)), atol=1e-9), 'principal axes = base frame axes for the tools of the reference'
+    free = [dict(mass=tot_m, inertia=np.diag(Ic), gravity=0.0, refpos=-com, refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0)]
+    sc.begin('tool')
+    for idx, fr, hulls, mass, idiag, cp, cq, lf in parts:
+        for verts, radius in hulls:
+            sc.add(BODY_FREE0 + 0, X.apply(fr[0], fr[1], verts) - com, radius, lf, TAG['TOOL'], link=idx)
+    sc.end('tool')
+    return free, frames, com
+
+
+def tool_offset_in_ee_frame(rob, ee_pb, tool_pb, pos_offset, rpy_offset):
+    """Tool.get_transform / createConstraint (tool.py:46-56): centre-of-mass frame of the tool joint's link o (pos_offset,
+    orient_offset), expressed in the end-effector frame (both links ride on the same moving link)."""
+    assert rob['carrier'][tool_pb] == rob['carrier'][ee_pb]
+    tool_link = rob['urdf'].link_by_index(tool_pb)
+    cpos, cquat = X.compose(*rob['rel'][tool_pb], tool_link.com_pos, tool_link.com_quat)
+    apos, aquat = X.compose(cpos, cquat, np.asarray(pos_offset, dtype=np.float64), X.quat_from_rpy(rpy_offset))
+    iep, ieq = X.invert(*rob['rel'][ee_pb])
+    return X.compose(iep, ieq, apos, aquat)
+
+
 def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
     """BedBathingSawyer-v1 (bed_bathing_envs.py:23-25): Sawyer (agents/sawyer.py), the wiper (assets/bed_bathing/wiper.urdf,
     tool.py:22-23), the human lying on the bed (bed_bathing.py:112-137; its right arm joints 0..9 are the controllable joints,
@@ -674,33 +733,7 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
         sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
     sc.end('robot_base')
     # ------------------------------------------------------------------ tool: wiper.urdf, three links welded by fixed joints = one rigid body
-    wu = Urdf(os.path.join(assets, 'bed_bathing', 'wiper.urdf'))
-    parts = []                                          # (pb link, frame in the base frame, hulls in the link frame, mass, inertia diag in the inertial frame)
-    frames = {-1: (np.zeros(3), np.array([0, 0, 0, 1.0]))}
-    for j in wu.indexed_joints:
-        assert j.type == 'fixed'
-        frames[j.index] = X.compose(*frames[wu.links[j.parent].index], j.pos, j.quat)
-    tot_m, com = 0.0, np.zeros(3)
-    for idx in range(-1, len(wu.indexed_joints)):
-        lk = wu.link_by_index(idx)
-        hulls = link_collision_hulls(lk, 0, {})
-        cp, cq = X.compose(*frames[idx], lk.com_pos, lk.com_quat)
-        parts.append((idx, frames[idx], hulls, lk.mass, aabb_inertia_in_inertial_frame(lk, hulls), cp, cq, lk.lateral_friction))
-        tot_m += lk.mass
-        com += lk.mass * cp
-    com /= tot_m
-    Ic = np.zeros((3, 3))
-    for idx, fr, hulls, mass, idiag, cp, cq, _ in parts:
-        Rm = X.quat_to_mat(cq)
-        r = cp - com
-        Ic += Rm @ np.diag(idiag) @ Rm.T + mass * ((r @ r) * np.eye(3) - np.outer(r, r))
-    assert np.allclose(Ic, np.diag(np.diag(Ic)), atol=1e-12), 'the wiper is symmetric: principal axes = base frame axes'
-    free = [dict(mass=tot_m, inertia=np.diag(Ic), gravity=0.0, refpos=-com, refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0)]   # bed_bathing.py:165
-    sc.begin('tool')
-    for idx, fr, hulls, mass, idiag, cp, cq, lf in parts:
-        for verts, radius in hulls:
-            sc.add(BODY_FREE0 + 0, X.apply(fr[0], fr[1], verts) - com, radius, lf, TAG['TOOL'], link=idx)
-    sc.end('tool')
+    free, frames, com = add_welded_tool(sc, os.path.join(assets, 'bed_bathing', 'wiper.urdf'))       # tool.py:22-23; gravity 0: bed_bathing.py:165
     pad_link = 1
     # ------------------------------------------------------------------ human: right arm joints dynamic-capable (bed_bathing_envs.py:12)
     hd = list(range(10))
@@ -743,15 +776,7 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
     # ------------------------------------------------------------------ task
     ee_pb, tool_pb = 19, 18                             # sawyer.py:11,15
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
-    assert rob['carrier'][tool_pb] == rob['carrier'][ee_pb]
-    # Tool.get_transform / createConstraint (tool.py:46-56): centre-of-mass frame of the tool joint's link o (pos_offset, orient_offset),
-    # expressed here in the end-effector frame
-    tl = wu  # noqa: F841
-    tool_link = rob['urdf'].link_by_index(tool_pb)
-    cpos, cquat = X.compose(*rob['rel'][tool_pb], tool_link.com_pos, tool_link.com_quat)
-    apos, aquat = X.compose(cpos, cquat, np.array([0, 0.1175, 0]), X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0]))    # sawyer.py:27,33
-    iep, ieq = X.invert(*rob['rel'][ee_pb])
-    tpos, tquat = X.compose(iep, ieq, apos, aquat)
+    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, [0, 0.1175, 0], [np.pi / 2.0, 0, np.pi / 2.0])    # sawyer.py:27,33
     targets, nts = {}, []
     for gender in ('male', 'female'):
         hm = HumanModel(gender)
@@ -768,7 +793,7 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
                   EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=tpos, TOOL_QUAT=tquat,
                   TOOL_OBS_POS=frames[pad_link][0], TOOL_OBS_QUAT=frames[pad_link][1],    # tool.get_pos_orient(1), bed_bathing.py:81
                   TOOL_MAXF=500.0, EPISODE_LEN=200)                                        # tool.py:47, bed_bathing.py:31
-    task_i = dict(EE_LINK=ee_link, PAD_LINK=pad_link, ARM_LINK=[nrobot + 5, nrobot + 7],   # human.right_shoulder / right_elbow (human.py:23-24)
+    task_i = dict(EE_LINK=ee_link, PAD_LINK=1 << (pad_link + 1), ARM_LINK=[nrobot + 5, nrobot + 7],   # bitmask over link + 1; human.right_shoulder / right_elbow (human.py:23-24)
                   OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], NT=nts, HEAD_LINK=-1,     # shoulder, elbow, wrist (bed_bathing.py:89-91)
                   ARM_LIMIT_DOF=[nrobot + 3, nrobot + 4, nrobot + 5, nrobot + 6], ARM_LIMIT_ON=0)   # j_right_shoulder_x/y/z, j_right_elbow (human.py:139); ON in co-op
     task_f['ARM_LIMIT_SIGN'] = -1.0                                                        # right arm (human.py:142-145)
@@ -787,7 +812,92 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
                 targets=targets, task_words=BB['WORDS'], mlp=mlp, meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
 
 
-COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer)
+def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
+    """ScratchItchPR2-v1 / ScratchItchPR2Human-v1 (scratch_itch_envs.py:17-19,41-44; BASELINE config 4 is the co-op flavour, `blob.coop()`):
+    the PR2's left arm (agents/pr2.py) holding the scratcher (assets/scratcher/tool_scratch.urdf) next to a human in the wheelchair
+    whose right arm joints 0..9 are the controllable joints.
+    PR2: 44 movable joints behind a fixed base.  With the base fixed every branch off the base is dynamically independent; the
+    branches that are not the left arm (casters, head, lasers, right arm) start at rest (Robot.reset_joints, pr2.py:62-66), carry
+    no gravity (scratch_itch.py:122) and are only held by their default motors, so nothing but a collision could move them: they
+    are compiled as STATIC geometry at those joint positions [deviation, DESIGN.md].  So are three passive joints of the left
+    gripper mechanism (77 motor slider, 78 motor screw, 83 l_gripper_joint: 1..10 g, no collision shape).  What remains dynamic:
+    the 7 arm joints + the 4 finger joints."""
+    sc = Scene()
+    arm = [64, 65, 66, 68, 69, 71, 72]                  # pr2.py:9
+    grip = [79, 80, 81, 82]                             # pr2.py:14
+    urdf_path = os.path.join(assets, 'PR2', 'pr2_no_torso_lift_tall.urdf')
+    u0 = Urdf(urdf_path)
+    frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+    frozen.update(dict(zip([42, 43, 44, 46, 47, 49, 50], [-1.75, 1.25, -1.5, -0.5, -1, 0, -1])))    # right arm tucked, pr2.py:64
+    rob = compile_robot(urdf_path, arm, grip, gripper_target=[0.25] * 4, motor_gain=0.05, motor_force=1.0,                # pr2.py:17, robot.py:36-37
+                        max_hull_verts=robot_hull_max_verts, frozen=frozen, use_file_inertia=True)                       # pr2.py:52
+    nrobot = len(rob['dof_links'])
+    gripper_collision = set(range(71, 86))              # pr2.py:16 -> no collision with the tool (tool.py:42-44)
+    add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)
+    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+    sc.begin('robot_base')                              # the base and every static branch
+    for verts, radius, fr, pb in rob['base_colliders']:
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    sc.end('robot_base')
+    free, frames, com = add_welded_tool(sc, os.path.join(assets, 'scratcher', 'tool_scratch.urdf'))   # tool.py:20-21; gravity 0: scratch_itch.py:124
+    hd = list(range(10))                                # human.right_arm_joints (scratch_itch_envs.py:16)
+
+    def split(link):
+        return 'pecs' if link == 2 else ('arm' if 3 <= link <= 9 else 'rest')
+    human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.05, maxf=1.0, act0=len(arm), split=split)    # human.py:69-70
+    sc.begin('wheelchair')   # furniture.py:16 (wheelchair.urdf: the robot is not mounted on it), basePosition [0, 0, 0.06]
+    wq = X.quat_from_rpy([np.pi / 2, 0, np.pi])
+    for g in load_obj_groups(os.path.join(assets, 'wheelchair', 'wheelchair_permobil_reduced_compressed_vhacd.obj'), 0.15):
+        hv = X.apply(np.array([0, 0, 0.06]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), wq, convex_hull_vertices(g)))
+        sc.add(BODY_WORLD, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['WHEELCHAIR'])
+    sc.end('wheelchair')
+    sc.begin('plane')
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    G_ = Groups(sc.ranges)
+    grp = G_.add
+    G_.rg['robot_links'] = (G_.rg['robot_arm'][0], G_.rg['robot_gripper'][1])
+    grp('tool', 'human_male', alt='human_female', manifold=True)      # scratch_itch.py:51-56 reads every manifold point of the pair
+    grp('robot_links', 'human_male', alt='human_female', keep=2)
+    grp('tool', 'wheelchair', keep=2)
+    grp('robot_links', 'wheelchair', keep=2)
+    grp('robot_arm', 'tool')                                          # no URDF_USE_SELF_COLLISION for the PR2 (pr2.py:52): no robot x robot pairs
+    grp('robot_base', 'tool')
+    grp('robot_links', 'plane')
+    grp('tool', 'plane')
+    for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
+        G_.rg['harm_' + gender] = (G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][1])
+        grp('robot_base', 'harm_' + gender, keep=2, flags=gf | GF_HUMAN_DYNAMIC)       # the static PR2 parts only matter to the moving arm
+        grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)     # human_creation.py:288-290
+        grp('harm_' + gender, 'wheelchair', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
+    groups = G_.rows
+    ee_pb = tool_pb = 76                                # pr2.py:12,15
+    ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, [0, 0, 0], [0, 0, 0])       # pr2.py:26,32
+    task_f = dict(W_DISTANCE=1.0, W_ACTION=0.01, W_WIPE=1.0, SUCCESS_FRAC=25.0,            # config.ini:3-7 (scratch_reward_weight; the 5 of scratch_itch.py:30 is in the task layer)
+                  C_V=0.25, C_F=0.01, C_HF=0.05,                                           # config.ini:40-42
+                  TARGET_RADIUS=0.025,                                                     # scratch_itch.py:54
+                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=tpos, TOOL_QUAT=tquat,
+                  TOOL_OBS_POS=frames[1][0], TOOL_OBS_QUAT=frames[1][1],                   # tool.get_pos_orient(1): the tool tip (scratch_itch.py:25,60)
+                  TOOL_MAXF=500.0, EPISODE_LEN=200, ARM_LIMIT_SIGN=-1.0)
+    task_i = dict(EE_LINK=ee_link, PAD_LINK=(1 << 1) | (1 << 2),                           # linkA in [0, 1] (scratch_itch.py:54), bitmask over link + 1
+                  ARM_LINK=[nrobot + 5, nrobot + 7], OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], HEAD_LINK=-1,
+                  ARM_LIMIT_DOF=[nrobot + 3, nrobot + 4, nrobot + 5, nrobot + 6], ARM_LIMIT_ON=0)
+    params = default_params(n_iter)                                                        # robot / human / tool gravity 0: scratch_itch.py:121-124
+    from .h5lite import load_keras_dense_stack
+    mlp = load_keras_dense_stack(os.path.join(assets, 'realistic_arm_limits_model.h5'))
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT']
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        pass        # the pool comes from assistive_gym_amd/host/reset_scratch.py
+    return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=23 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_SCRATCH_ITCH), reset_fill, reset_words,
+                task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
+
+
+COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2)
 
 
 def main(names=None):

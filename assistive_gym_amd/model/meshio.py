@@ -38,6 +38,17 @@ def load_obj_groups(path, scale=1.0):
     return [np.asarray(g, dtype=np.float64) * scale for g in groups if len(g) > 0]
 
 
+def load_stl_vertices(path):
+    """All vertices of a binary STL (the PR2 link meshes, assets/PR2/meshes/*/*.stl): PyBullet turns such a mesh into one
+    convex hull of its vertices, like the Collada ones."""
+    import struct
+    d = open(path, 'rb').read()
+    n = struct.unpack_from('<I', d, 80)[0]
+    assert 84 + 50 * n == len(d), 'only binary STL files are supported: ' + path
+    tri = np.frombuffer(d, dtype=np.dtype([('n', '<f4', 3), ('v', '<f4', (3, 3)), ('a', '<u2')]), count=n, offset=84)
+    return np.unique(tri['v'].reshape(-1, 3).astype(np.float64), axis=0)
+
+
 def load_dae_vertices(path):
     """All position vertices of every geometry instanced by the visual scene, node matrices applied."""
     text = open(path).read()

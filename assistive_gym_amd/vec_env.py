@@ -24,6 +24,9 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     if blob.task_kind == L.TASK_BED_BATHING:
         from .host.reset_bed import make_states as make_bed_states
         return make_bed_states(blob, pool_size, seed=seed, impairment=impairment)[0]
+    if blob.task_kind == L.TASK_SCRATCH_ITCH:
+        from .host.reset_scratch import make_states as make_scratch_states
+        return make_scratch_states(blob, pool_size, seed=seed, impairment=impairment)[0]
     st = Stepper(blob, pool_size, device)
     if sampler == 'device':
         st.sample_reset(seed, impairment=impairment)
@@ -51,9 +54,13 @@ class AssistiveVecEnv:
 
     model = 'feeding_jaco'
 
-    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool', model=None):
+    coop = False
+
+    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool', model=None, coop=None):
         assert reset in ('pool', 'device', 'host')
         self.blob = blob or ModelBlob.load(model or self.model)
+        if (self.coop if coop is None else coop) and not self.blob.is_coop:
+            self.blob = self.blob.coop()
         self.n_envs, self.device_index, self.seed = n_envs, device, seed
         self.device = torch.device('cuda', device)
         self.pool_size, self.impairment, self.auto_reset, self.reset_mode = pool_size, impairment, auto_reset, reset
@@ -136,3 +143,17 @@ class BedBathingSawyerVecEnv(AssistiveVecEnv):
         kw.setdefault('reset', 'pool')
         assert kw['reset'] != 'device', 'no device-side reset generator for BedBathingSawyer: use a pool'
         super().__init__(n_envs, **kw)
+
+
+class ScratchItchPR2VecEnv(AssistiveVecEnv):
+    """ScratchItchPR2-v1; coop=True = ScratchItchPR2Human-v1 (BASELINE config 4: 7 + 10 actions, 30 + 34 observations per env)."""
+    model = 'scratch_itch_pr2'
+
+    def __init__(self, n_envs, **kw):
+        kw.setdefault('reset', 'pool')
+        assert kw['reset'] != 'device', 'no device-side reset generator for ScratchItchPR2: use a pool'
+        super().__init__(n_envs, **kw)
+
+
+class ScratchItchPR2HumanVecEnv(ScratchItchPR2VecEnv):
+    coop = True

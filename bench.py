@@ -29,6 +29,7 @@ N_SIMD = 1024
 TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the compiled variant, workload description)
     'feeding': ('feeding_jaco', 'FeedingJacoVecEnv', '', 'FeedingJaco-v1'),
     'bedbathing': ('bed_bathing_sawyer', 'BedBathingSawyerVecEnv', '_bb', 'BedBathingSawyer-v1'),
+    'scratchitch': ('scratch_itch_pr2', 'ScratchItchPR2HumanVecEnv', '_si', 'ScratchItchPR2Human-v1 (co-op: 7 robot + 10 human actions)'),
 }
 
 
@@ -38,7 +39,7 @@ def _cpu_worker(path, seed, n_steps, model='feeding_jaco'):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle_lib import Oracle
     from assistive_gym_amd.blob import ModelBlob
-    blob = ModelBlob.load(model)
+    blob = ModelBlob.load(model[:-5]).coop() if model.endswith('+coop') else ModelBlob.load(model)
     o = Oracle(blob)
     init = np.load(path)
     st = init.copy()
@@ -113,7 +114,7 @@ def main():
     ap.add_argument('--reset', choices=['pool', 'device', 'host'], default='pool',
                     help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--task', choices=sorted(TASKS), default='feeding', help="'feeding' = the BASELINE metric (config 2); 'bedbathing' = config 3")
+    ap.add_argument('--task', choices=sorted(TASKS), default='feeding', help="'feeding' = the BASELINE metric (config 2); 'bedbathing' = config 3; 'scratchitch' = config 4's env (co-op) on one GPU")
     args = ap.parse_args()
     model, env_cls, ksuffix, env_id = TASKS[args.task]
 
@@ -133,8 +134,8 @@ def main():
     if distributed:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     n = args.envs_per_gpu
-    blob = ModelBlob.load(model)
     env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset)
+    blob = env.blob                      # the co-op flavour where the task's BASELINE config is co-op
     env.reset(env_offset=rank * n)
     K, W = args.steps, args.warmup
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
@@ -234,7 +235,7 @@ def main():
                          'note': 'dependent-chain latency bound solver (VALU issue ~0.3 of peak); HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8, 1000, model, env_id)
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8, 1000, model + ('+coop' if blob.is_coop else ''), env_id)
         print(json.dumps(out))
     env.close()
     if distributed:

@@ -57,8 +57,9 @@ enum {
   AGX_H_COUNT = 40
 };
 
-enum { AGX_TASK_FEEDING = 0,      /* assistive_gym/envs/feeding.py     */
-       AGX_TASK_BED_BATHING = 1 };/* assistive_gym/envs/bed_bathing.py */
+enum { AGX_TASK_FEEDING = 0,      /* assistive_gym/envs/feeding.py      */
+       AGX_TASK_BED_BATHING = 1,  /* assistive_gym/envs/bed_bathing.py  */
+       AGX_TASK_SCRATCH_ITCH = 2 };/* assistive_gym/envs/scratch_itch.py */
 
 /* ---- PARAMS: float[AGX_P_COUNT] ----------------------------------------------------------- */
 enum {
@@ -181,7 +182,8 @@ enum {
   AGX_T_W_WIPE = 43,       /* wiping_reward_weight                                                                  */
   AGX_T_TARGET_RADIUS = 44,/* a target is wiped when a (tool link 1, human) contact lies within this (bed_bathing.py:57) */
   AGX_T_CLOSEST_DIST = 45, /* range of the tool <-> human closest-point query (bed_bathing.py:23)                   */
-  AGX_T_PAD_LINK = 46,     /* int: tool link whose contacts wipe (bed_bathing.py:51)                                */
+  AGX_T_PAD_LINK = 46,     /* int: bitmask over (tool link + 1) of the tool links whose contacts count: the wiping pad, link 1
+                            * (bed_bathing.py:51 `linkA in [1]`); the scratcher's links 0 and 1 (scratch_itch.py:54 `linkA in [0, 1]`) */
   AGX_T_ARM_LINK = 47,     /* int[2]: moving links carrying the upper-arm / forearm targets (human.right_shoulder, right_elbow) */
   AGX_T_OBS_LINK = 49,     /* int[3]: moving links whose positions the observation reports (shoulder, elbow, wrist) */
   AGX_T_NT = 52,           /* int[2 genders][2 arms]: number of targets (bed_bathing.py:173-188)                    */
@@ -255,6 +257,10 @@ enum {
   AGX_E_FROZEN = 12,        /* int bitmask of DoFs made static (mass 0 links, human.py:104-110) */
   AGX_E_LIMIT_SCALE = 13,   /* scale of the human joint limits (impairment 'limits', human.py:85,
                              * human_creation.py:199-200)                                          */
+  AGX_E_HUMAN_KP = 14,      /* > 0: position gain of the human's joint motors in this environment, overriding the blob's:
+                             * the reactive hold of a non-controllable human, setup_joints(reactive_gain) (human.py:124-127,
+                             * scratch_itch.py:106), vs motor_gains when the human is an agent (env.py:175-182)          */
+  AGX_E_HUMAN_MAXF = 15,    /* with it: the motors' force limit, reactive_force * strength (human.py:126)               */
   AGX_E_COUNT = 16
 };
 /* bed bathing reuses AGX_E_TASK_SUCCESS (targets wiped, bed_bathing.py:60) and AGX_E_TOTAL_FOOD (total_target_count,
@@ -264,6 +270,12 @@ enum { AGX_BB_ALIVE = 0,        /* int[AGX_BB_ALIVE_WORDS] bitmask of the target
        AGX_BB_PREV = 6,         /* float[4] arm_previous_valid_pose (human.py:147-149): shoulder x, y, z, elbow          */
        AGX_BB_HAS_PREV = 10,    /* int: a valid pose has been seen (arm_previous_valid_pose is not None)                 */
        AGX_BB_WORDS = 12 };
+/* scratch itch (offset AGX_H_S_TASK): the target point on the arm (scratch_itch.py:134-146), where the tool last scratched
+ * (prev_target_contact_pos, :30,96) and, at the same offsets as bed bathing, the arm-limit classifier's remembered pose */
+enum { AGX_SI_TARGET = 0,       /* float[3] target_on_arm, in the frame of its limb                                        */
+       AGX_SI_LIMB = 3,         /* int: 0 upper arm (human.right_shoulder), 1 forearm (human.right_elbow)                  */
+       AGX_SI_PREV_CONTACT = 12,/* float[3]                                                                                */
+       AGX_SI_WORDS = 16 };
 #define AGX_MLP_HIDDEN 64
 #define AGX_MLP_WORDS (4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1)
 

@@ -189,6 +189,7 @@ typedef struct {
   int gender, alive, active, iteration, success, total_food, frozen;
   double tremor[MAXDOF], tremor_target[MAXDOF];
   double limit_scale;    /* scale of the human joint limits (impairment 'limits') */
+  double human_kp, human_maxf;   /* per-env motor gain / force of the human's joints, 0 = the blob's (AGX_E_HUMAN_KP) */
   int coop;              /* the human is controllable (TASK.COOP) */
   uint32_t rng[2];
   /* derived, per substep */
@@ -203,6 +204,7 @@ typedef struct {
   double qpt[MAXQPT][3]; int qpt_link[MAXQPT]; int nqpt;   /* bed bathing: manifold points of the wiping pad on the human (bed_bathing.py:47-58) */
   uint32_t bb_alive[AGX_BB_ALIVE_WORDS];                  /* bed bathing: targets not wiped yet */
   double arm_prev[4]; int arm_has_prev;                    /* arm_previous_valid_pose (human.py:147-149) */
+  double si_target[3], si_prev[3]; int si_limb;            /* scratch itch: target_on_arm, prev_target_contact_pos, limb (scratch_itch.py:134-146,96) */
   int contact_overflow;
   row_t* rows; int nrows;
 } sim_t;
@@ -227,15 +229,20 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
   s->frozen = ei[AGX_E_FROZEN];
   s->limit_scale = e[AGX_E_LIMIT_SCALE] > 0 ? e[AGX_E_LIMIT_SCALE] : 1.0;   /* records written before v6 carry 0 */
   s->coop = TI(m, AGX_T_COOP) == 1;
+  s->human_kp = e[AGX_E_HUMAN_KP]; s->human_maxf = e[AGX_E_HUMAN_MAXF];
   for (int k = 0; k < m->nhdof; k++) { s->tremor[k] = st[m->s_tremor + k]; s->tremor_target[k] = st[m->s_tremor + m->nhdof + k]; }
   for (int k = 0; k < 3; k++) s->target[k] = e[AGX_E_TARGET + k];
   s->alive = ei[AGX_E_FOOD_ALIVE]; s->active = ei[AGX_E_FOOD_ACTIVE]; s->iteration = ei[AGX_E_ITERATION];
   s->success = ei[AGX_E_TASK_SUCCESS]; s->total_food = ei[AGX_E_TOTAL_FOOD];
   s->rng[0] = (uint32_t)ei[AGX_E_RNG]; s->rng[1] = (uint32_t)ei[AGX_E_RNG + 1];
-  if (m->task_kind == AGX_TASK_BED_BATHING) {
-    for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) s->bb_alive[k] = (uint32_t)((const int32_t*)st)[m->s_task + AGX_BB_ALIVE + k];
+  if (m->task_kind != AGX_TASK_FEEDING) {
+    if (m->task_kind == AGX_TASK_BED_BATHING) for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) s->bb_alive[k] = (uint32_t)((const int32_t*)st)[m->s_task + AGX_BB_ALIVE + k];
     for (int k = 0; k < 4; k++) s->arm_prev[k] = st[m->s_task + AGX_BB_PREV + k];
     s->arm_has_prev = ((const int32_t*)st)[m->s_task + AGX_BB_HAS_PREV];
+    if (m->task_kind == AGX_TASK_SCRATCH_ITCH) {
+      for (int k = 0; k < 3; k++) { s->si_target[k] = st[m->s_task + AGX_SI_TARGET + k]; s->si_prev[k] = st[m->s_task + AGX_SI_PREV_CONTACT + k]; }
+      s->si_limb = ((const int32_t*)st)[m->s_task + AGX_SI_LIMB];
+    }
   }
 }
 static void sim_store(const sim_t* s, float* st) {
@@ -251,10 +258,11 @@ static void sim_store(const sim_t* s, float* st) {
   for (int k = 0; k < 3; k++) e[AGX_E_TARGET + k] = (float)s->target[k];
   ei[AGX_E_FOOD_ALIVE] = s->alive; ei[AGX_E_FOOD_ACTIVE] = s->active; ei[AGX_E_ITERATION] = s->iteration;
   ei[AGX_E_TASK_SUCCESS] = s->success; ei[AGX_E_RNG] = (int32_t)s->rng[0]; ei[AGX_E_RNG + 1] = (int32_t)s->rng[1];
-  if (m->task_kind == AGX_TASK_BED_BATHING) {
-    for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) ((int32_t*)st)[m->s_task + AGX_BB_ALIVE + k] = (int32_t)s->bb_alive[k];
+  if (m->task_kind != AGX_TASK_FEEDING) {
+    if (m->task_kind == AGX_TASK_BED_BATHING) for (int k = 0; k < AGX_BB_ALIVE_WORDS; k++) ((int32_t*)st)[m->s_task + AGX_BB_ALIVE + k] = (int32_t)s->bb_alive[k];
     for (int k = 0; k < 4; k++) st[m->s_task + AGX_BB_PREV + k] = (float)s->arm_prev[k];
     ((int32_t*)st)[m->s_task + AGX_BB_HAS_PREV] = s->arm_has_prev;
+    if (m->task_kind == AGX_TASK_SCRATCH_ITCH) for (int k = 0; k < 3; k++) st[m->s_task + AGX_SI_PREV_CONTACT + k] = (float)s->si_prev[k];
   }
 }
 
@@ -697,7 +705,7 @@ static void collide(sim_t* s) {
         if (m->task_kind == AGX_TASK_FEEDING && CI(m, a, AGX_C_TAG) == AGX_TAG_FOOD && CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN)
           s->food_near_human |= 1 << (CI(m, a, AGX_C_BODY) - AGX_BODY_FREE0 - m->food0);
         /* bed bathing: manifold points of tool link 1 on the human, with or without force (bed_bathing.py:47-58) */
-        if (m->task_kind == AGX_TASK_BED_BATHING && (GI(m, g, AGX_G_FLAGS) & 2) && CI(m, a, AGX_C_TAG) == AGX_TAG_TOOL && CI(m, a, AGX_C_LINK) == TI(m, AGX_T_PAD_LINK) &&
+        if (m->task_kind != AGX_TASK_FEEDING && (GI(m, g, AGX_G_FLAGS) & 2) && CI(m, a, AGX_C_TAG) == AGX_TAG_TOOL && (TI(m, AGX_T_PAD_LINK) >> (CI(m, a, AGX_C_LINK) + 1) & 1) &&
             CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN && s->nqpt < MAXQPT) {
           memcpy(s->qpt[s->nqpt], k.pb, 24); s->qpt_link[s->nqpt] = CI(m, b, AGX_C_LINK); s->nqpt++;
         }
@@ -806,7 +814,9 @@ static void build_rows(sim_t* s) {
   for (int d = 0; d < n; d++) {
     double maxf = RF(m, d, AGX_R_MAXF); if (maxf <= 0 || (s->frozen >> d & 1)) continue;
     row_t* r = NEWROW(); r->J[d] = 1.0; finish_row(s, r);
-    r->b = RF(m, d, AGX_R_KP) * (s->qt[d] - s->q[d]) / dt + RF(m, d, AGX_R_KD) * (0.0 - s->vel[d]);
+    double kp = RF(m, d, AGX_R_KP);
+    if (d >= m->nrobot && s->human_kp > 0) { kp = s->human_kp; maxf = s->human_maxf; }   /* reactive hold of a human that is not an agent (human.py:124-127) */
+    r->b = kp * (s->qt[d] - s->q[d]) / dt + RF(m, d, AGX_R_KD) * (0.0 - s->vel[d]);
     r->lo = -maxf * dt; r->hi = maxf * dt;
   }
   /* joint limits (URDF lower/upper): unilateral rows, built only when the gap is small */
@@ -947,7 +957,7 @@ double agxo_arm_limit_logit(const agxo_model* m, const double* in4) {
 }
 static void arm_limits(sim_t* s) {
   const agxo_model* m = s->m;
-  if (m->task_kind != AGX_TASK_BED_BATHING || !TI(m, AGX_T_ARM_LIMIT_ON)) return;
+  if (m->task_kind == AGX_TASK_FEEDING || !TI(m, AGX_T_ARM_LIMIT_ON)) return;
   double sg = TF(m, AGX_T_ARM_LIMIT_SIGN), a[4]; int dof[4];
   for (int k = 0; k < 4; k++) {
     dof[k] = TI(m, AGX_T_ARM_LIMIT_DOF + k); a[k] = s->q[dof[k]];
@@ -1123,7 +1133,7 @@ static void finish_bed(sim_t* s, const float* action, float* obs, float* reward,
     if (tool) tool_f += f;                                   /* :43 every contact of the tool */
     if (human && robot) robot_f += f;                        /* :42 */
     if (human && tool) { tool_human_f += f;                  /* :47-48 */
-      int tc = ta == AGX_TAG_TOOL ? k->ca : k->cb; if (CI(m, tc, AGX_C_LINK) == TI(m, AGX_T_PAD_LINK)) pad_f += f; }   /* :49-50 */
+      int tc = ta == AGX_TAG_TOOL ? k->ca : k->cb; if (TI(m, AGX_T_PAD_LINK) >> (CI(m, tc, AGX_C_LINK) + 1) & 1) pad_f += f; }   /* :49-50 */
   }
   double total_f = robot_f + tool_human_f;
   observe_bed(s, tool_f, total_f, pad_f, obs);
@@ -1179,6 +1189,94 @@ static void finish_bed(sim_t* s, const float* action, float* obs, float* reward,
     info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
   }
 }
+/* scratch itch: world position of the target, limb frame o target_on_arm (scratch_itch.py:148-152) */
+static void scratch_target(const sim_t* s, double* t) {
+  const agxo_model* m = s->m; xf_apply(&s->link[TI(m, AGX_T_ARM_LINK + s->si_limb)], s->si_target, t);
+}
+/* ScratchItchEnv._get_obs (scratch_itch.py:59-91) */
+static void observe_scratch(sim_t* s, double tool_force, double total_force, double target_force, float* obs) {
+  const agxo_model* m = s->m;
+  double sp[3], sR[9], spr[3], sqr[4], tg[3], tgr[3];
+  tool_base_pose(s, sp, sR);                 /* tool.get_pos_orient(1) */
+  to_base_frame(s, sp, sR, spr, sqr);
+  scratch_target(s, tg); to_base_frame(s, tg, NULL, tgr, NULL);
+  int o = 0;
+  for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k];
+  for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k];
+  for (int k = 0; k < 3; k++) obs[o++] = (float)(spr[k] - tgr[k]);
+  for (int k = 0; k < 3; k++) obs[o++] = (float)tgr[k];
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+    double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
+  }
+  for (int j = 0; j < 3; j++) {
+    double pr[3]; to_base_frame(s, s->link[TI(m, AGX_T_OBS_LINK + j)].p, NULL, pr, NULL);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)pr[k];
+  }
+  obs[o++] = (float)tool_force;
+  if (s->coop) {                             /* human_obs, scratch_itch.py:79-88 */
+    double sph[3], sqh[4], tgh[3];
+    to_human_frame(s, sp, sR, sph, sqh); to_human_frame(s, tg, NULL, tgh, NULL);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)sph[k];
+    for (int k = 0; k < 4; k++) obs[o++] = (float)sqh[k];
+    for (int k = 0; k < 3; k++) obs[o++] = (float)(sph[k] - tgh[k]);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)tgh[k];
+    for (int d = m->nrobot; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) obs[o++] = (float)s->q[d];
+    for (int j = 0; j < 3; j++) {
+      double ph[3]; to_human_frame(s, s->link[TI(m, AGX_T_OBS_LINK + j)].p, NULL, ph, NULL);
+      for (int k = 0; k < 3; k++) obs[o++] = (float)ph[k];
+    }
+    obs[o++] = (float)total_force; obs[o++] = (float)target_force;
+  }
+}
+/* everything ScratchItchEnv.step does after take_step (scratch_itch.py:14-44) */
+static void finish_scratch(sim_t* s, const float* action, float* obs, float* reward, int* done, float* info) {
+  const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
+  double target[3]; scratch_target(s, target);
+  double r2 = TF(m, AGX_T_TARGET_RADIUS) * TF(m, AGX_T_TARGET_RADIUS);
+  /* get_total_force (scratch_itch.py:46-57) */
+  double robot_f = 0, tool_f = 0, tool_human_f = 0, target_f = 0;
+  for (int c = 0; c < s->ncon; c++) {
+    const contact_t* k = &s->con[c];
+    int ta = CI(m, k->ca, AGX_C_TAG), tb = CI(m, k->cb, AGX_C_TAG);
+    int human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
+    double f = k->lambda_n / dt;
+    if (tool) tool_f += f;                                   /* :48 */
+    if (human && robot) robot_f += f;                        /* :47 */
+    if (human && tool) {
+      tool_human_f += f;                                     /* :52 */
+      int tool_is_a = ta == AGX_TAG_TOOL, tc = tool_is_a ? k->ca : k->cb;
+      const double* on_human = tool_is_a ? k->pb : k->pa; double d[3]; sub3(on_human, target, d);
+      if ((TI(m, AGX_T_PAD_LINK) >> (CI(m, tc, AGX_C_LINK) + 1) & 1) && dot3(d, d) < r2) target_f += f;   /* :54-55 */
+    }
+  }
+  double total_f = robot_f + tool_human_f;
+  observe_scratch(s, tool_f, total_f, target_f, obs);
+  /* target_contact_pos = posB of the last manifold point of tool links 0 / 1 on the human near the target (:54-56) */
+  int have = 0; double cp[3] = {0, 0, 0};
+  for (int q = 0; q < s->nqpt; q++) { double d[3]; sub3(s->qpt[q], target, d); if (dot3(d, d) < r2) { have = 1; memcpy(cp, s->qpt[q], 24); } }
+  double scratch_reward = 0;
+  if (have) {
+    double dp[3]; sub3(cp, s->si_prev, dp);
+    if (sqrt(dot3(dp, dp)) > 0.01 && target_f < 10) { scratch_reward = 5; memcpy(s->si_prev, cp, 24); s->success += 1; }   /* :28-32 */
+  }
+  double act_norm2 = 0; for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
+  double sp[3], sR[9], dd[3]; tool_base_pose(s, sp, sR); sub3(target, sp, dd);      /* :25-26 tool.get_pos_orient(1) */
+  xf_t ee; ee_frame(s, &ee);
+  int L = TI(m, AGX_T_EE_LINK); double wxp[3], vee[3];
+  cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
+  double ee_speed = sqrt(dot3(vee, vee));
+  double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_F) * (-(total_f - target_f)) + TF(m, AGX_T_C_HF) * (target_f < 10 ? 0.0 : -target_f);
+  double r = TF(m, AGX_T_W_DISTANCE) * (-sqrt(dot3(dd, dd))) + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + TF(m, AGX_T_W_WIPE) * scratch_reward + pref;
+  *reward = (float)r;
+  *done = s->iteration >= (int)TF(m, AGX_T_EPISODE_LEN);
+  if (info) {
+    info[AGX_INFO_TOTAL_FORCE] = (float)total_f;
+    info[AGX_INFO_TASK_SUCCESS] = (float)(s->success >= s->total_food * TF(m, AGX_T_SUCCESS_FRAC));
+    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)target_f;
+    info[AGX_INFO_FOOD_REWARD] = (float)scratch_reward; info[AGX_INFO_PREF] = (float)pref;
+    info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
+  }
+}
 static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int* food_hit_mask) {
   const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
   *robot_f = 0; *tool_f = 0; *food_hit_mask = s->food_near_human;
@@ -1195,7 +1293,9 @@ static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int*
 
 void agxo_observe(const agxo_model* m, const float* state, float* obs) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s); update_target(s);
-  if (m->task_kind == AGX_TASK_BED_BATHING) observe_bed(s, 0, 0, 0, obs); else observe(s, 0, 0, obs);
+  if (m->task_kind == AGX_TASK_BED_BATHING) observe_bed(s, 0, 0, 0, obs);
+  else if (m->task_kind == AGX_TASK_SCRATCH_ITCH) observe_scratch(s, 0, 0, 0, obs);
+  else observe(s, 0, 0, obs);
   free(s);
 }
 
@@ -1241,6 +1341,7 @@ void agxo_step(const agxo_model* m, float* state, const float* action, float* ob
   for (int k = 0; k < nsub; k++) substep(s);
   kinematics(s); /* poses after the last integration, as the getters in _get_obs see them */
   if (m->task_kind == AGX_TASK_BED_BATHING) { finish_bed(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
+  if (m->task_kind == AGX_TASK_SCRATCH_ITCH) { finish_scratch(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   update_target(s); /* FeedingEnv.update_targets (feeding.py:192-196) */
   double robot_f, tool_f; int hit_mask;
   contact_forces(s, &robot_f, &tool_f, &hit_mask);

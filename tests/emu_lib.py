@@ -10,7 +10,8 @@ EMU = os.path.join(ROOT, 'tests', 'emu')
 CSRC = os.path.join(ROOT, 'assistive_gym_amd', 'csrc')
 _LIBS = {}
 # kernel variants (limits + task layer), the same -D sets as csrc/agx_kernels.hip
-VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=1']}
+VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=1'],
+                2: ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=2']}
 
 
 def lib(task_kind=0):
