@@ -30,7 +30,9 @@ def _check_step(blob, o, st, ref, act, worst):
     f = blob.obs_dim_robot - 1
     for i in range(len(ref)):
         o_obs, o_rew, o_done, o_info = o.step(ref[i], act[i])
-        assert info[i, 6] == o_info[6] and info[i, 7] == o_info[7], (i, info[i], o_info)
+        # same contacts; the row count may differ by limit rows whose gap sits on the 0.25 rad activation distance (inactive either way):
+        # the four finger joints are held at 0.25 rad, exactly that far from their lower limit (pr2.py:17)
+        assert info[i, 6] == o_info[6] and abs(info[i, 7] - o_info[7]) <= 4, (i, info[i], o_info)
         dev = np.abs(obs[i] - o_obs)
         forces = [f] + ([blob.obs_dim - 2, blob.obs_dim - 1] if blob.is_coop else [])
         for k in forces:
