@@ -63,7 +63,7 @@ def test_model_header_and_tables(bed):
     # wiper: three 0.1 kg links welded together, link 1 = the wiping pad, 3.9 cm below the handle frame
     assert np.isclose(bed.free_f(0, 'MASS'), 0.3) and np.allclose(bed.task_f('TOOL_OBS_POS', 3), [0, 0, -0.039])
     r = bed.meta['ranges']
-    assert [bed.collider(c)['link'] for c in range(*r['tool'])] == [-1, 0, 1] and bed.task_i('PAD_LINK') == 1
+    assert [bed.collider(c)['link'] for c in range(*r['tool'])] == [-1, 0, 1] and bed.task_i('PAD_LINK') == 0b100    # bitmask over link + 1: link 1
     assert all(bed.collider(c)['friction'] == 5.0 for c in range(*r['bed']))                                   # bed_bathing.py:116
     assert bed.task_i_n('NT', 4) == [81, 48, 56, 35]                                                         # 129 / 91 targets
     assert np.isclose(bed.task_f('W_WIPE'), 5.0) and np.isclose(bed.task_f('SUCCESS_FRAC'), 0.3)              # config.ini:9-13
