@@ -80,7 +80,7 @@ struct agx_handle_s {
 
 extern "C" {
 
-const char* agx_version(void) { return "libagx 0.2 (gfx950, wave-per-env stepper; variants: feeding, bed_bathing, scratch_itch)"; }
+const char* agx_version(void) { return "libagx 0.2 (gfx950, wave-per-env stepper; variants: feeding, bed_bathing, scratch_itch, bed_settle)"; }
 const char* agx_last_error(void) { return g_err.c_str(); }
 int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int agx_lds_bytes_per_env(void) { return agx_variant_feeding()->lds_bytes; }
@@ -93,14 +93,20 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     return fail(AGX_E_BLOB, "agx_create: not a model blob of this version");
   const agx_variant* V = nullptr;
   {
-    const agx_variant* all[3] = {agx_variant_feeding(), agx_variant_bed_bathing(), agx_variant_scratch_itch()};
-    for (const agx_variant* v : all) if (v->task_kind == hi[AGX_H_TASK_KIND]) V = v;
-    if (!V) return fail(AGX_E_LIMIT, "agx_create: no kernel variant is compiled for the task of this model");
+    // the first (smallest) variant with the model's task layer whose limits hold the model
+    const agx_variant* all[4] = {agx_variant_feeding(), agx_variant_bed_bathing(), agx_variant_scratch_itch(), agx_variant_bed_settle()};
+    bool task_seen = false;
+    for (const agx_variant* v : all) {
+      if (v->task_kind != hi[AGX_H_TASK_KIND]) continue;
+      task_seen = true;
+      if (hi[AGX_H_NDOF] > v->max_dof || hi[AGX_H_NFREE] > v->max_free || hi[AGX_H_NHUMAN] > v->max_human || hi[AGX_H_NCOLL] > v->max_coll ||
+          hi[AGX_H_STATE_WORDS] > v->st_words || hi[AGX_H_NROBOT] > v->max_block || hi[AGX_H_NHDOF] > v->max_block) continue;
+      V = v; break;
+    }
+    if (!task_seen) return fail(AGX_E_LIMIT, "agx_create: no kernel variant is compiled for the task of this model");
+    if (!V || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128 || hi[AGX_H_NGROUP] > 64 || hi[AGX_H_NDOF] > 64)
+      return fail(AGX_E_LIMIT, "agx_create: model exceeds the limits of the compiled kernel variants");
   }
-  if (hi[AGX_H_NDOF] > V->max_dof || hi[AGX_H_NFREE] > V->max_free || hi[AGX_H_NHUMAN] > V->max_human || hi[AGX_H_NCOLL] > V->max_coll ||
-      hi[AGX_H_STATE_WORDS] > V->st_words || hi[AGX_H_NDOF] + 6 * hi[AGX_H_NFREE] > 128 || hi[AGX_H_NGROUP] > 64 ||
-      hi[AGX_H_NROBOT] > V->max_block || hi[AGX_H_NHDOF] > V->max_block || hi[AGX_H_NDOF] > 32)
-    return fail(AGX_E_LIMIT, "agx_create: model exceeds the limits of the compiled kernel variant");
   for (int g = 0; g < hi[AGX_H_NGROUP]; g++) {   // the broadphase compacts each collider range of a pair group into a 128-entry list
     const int32_t* G = hi + hi[AGX_H_OFF_GROUP] + g * AGX_G_STRIDE;
     if (G[AGX_G_A1] - G[AGX_G_A0] > 128 || G[AGX_G_B1] - G[AGX_G_B0] > 128 || (G[AGX_G_B0F] >= 0 && G[AGX_G_B1F] - G[AGX_G_B0F] > 128))

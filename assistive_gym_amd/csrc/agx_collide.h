@@ -378,7 +378,7 @@ AGX_DEV void collide(Ctx& c) {
       const float mg = (G.flags & 2) ? brk : slack;
       // bit3 / bit4: male / female only; bit5: only while some human DoF is dynamic
       const bool wanted = !((G.flags & 8) && gender != 0) && !((G.flags & 16) && gender != 1) &&
-                          !((G.flags & 32) && ((~c.frozen >> c.nrobot) & ((1 << c.nhdof) - 1)) == 0);
+                          !((G.flags & 32) && c.nrobot + c.nhdof <= 32 && ((~c.frozen >> c.nrobot) & ((1u << c.nhdof) - 1u)) == 0);
       if (a1 > a0 && b1 > b0 && wanted) {
         float alo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ahi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         for (int i = a0; i < a1; i++) for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], AB[ABS * i + k]); ahi[k] = fmaxf(ahi[k], AB[ABS * i + 3 + k]); }

@@ -48,10 +48,11 @@ constexpr int L_FIINV = L_FREER + MAX_FREE * 9;          // [MAX_FREE][9]
 constexpr int L_BASE = L_FIINV + MAX_FREE * 9;           // p(3) R(9)
 constexpr int L_HUMAN = L_BASE + 12;                     // [MAX_HUMAN][12] p(3) R(9)
 constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee R(9), anc masks (MAX_DOF ints)
-constexpr int MISC_WORDS = (15 + MAX_DOF + 7) / 8 * 8;
+constexpr int ANC_WORDS = MAX_DOF > 32 ? 2 : 1;            // ancestor bitmask of a moving link: 1 or 2 ints
+constexpr int MISC_WORDS = (15 + ANC_WORDS * MAX_DOF + 7) / 8 * 8;
 constexpr int L_WMAG = L_MISC + MISC_WORDS;                      // |angular velocity| per moving body: links [MAX_DOF], free bodies [MAX_FREE]
 constexpr int L_ARENA = L_WMAG + 32;                     // contact records live in the per-env global scratch, not in LDS
-static_assert(MAX_DOF + MAX_FREE <= 32, "angular speed table");
+static_assert(MAX_DOF + MAX_FREE <= 64, "angular speed table: one lane per moving body");
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
 static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");
 constexpr int LDS_BYTES = LDS_WORDS * 4;
@@ -94,7 +95,10 @@ constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 
 constexpr int DBG_CON = 16, DBG_MINV = DBG_CON + MAX_CON * CON_STRIDE, DBG_HDR = DBG_MINV + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE,
               DBG_TIME = DBG_LAM + MAX_ROWS, DBG_QDD = DBG_TIME + 16, DBG_WORDS = DBG_QDD + MAX_DOF;
 // per-environment scratch record in HBM (L2-resident while its environment is being solved)
-constexpr int SCR_ENT = 4096, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
+#ifndef AGX_SCR_ENT        // floats of the per-env (J,B) coefficient store: a row keeps one pair per DoF of each articulated block it touches
+#define AGX_SCR_ENT 4096
+#endif
+constexpr int SCR_ENT = AGX_SCR_ENT, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
 constexpr int QPT_STRIDE = 4;                            // manifold query point: position on the human (3), PyBullet link of the human collider (int)
 constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
@@ -130,8 +134,10 @@ struct Ctx {
 #define RBF(c, d, k) ((c).bf[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
 #define RBI(c, d, k) ((c).bi[(c).o_robot + RREC(c, d) * AGX_R_STRIDE + (k)])
 // joint limits of DoF d; the human's are scaled per environment (human_creation.py:199-200)
-#define DLO(c, d) (RBF(c, d, AGX_R_LOWER) * (RBI(c, d, AGX_R_KIND) == 1 ? (c).limit_scale : 1.f))
-#define DHI(c, d) (RBF(c, d, AGX_R_UPPER) * (RBI(c, d, AGX_R_KIND) == 1 ? (c).limit_scale : 1.f))
+#define DLO(c, d) (RBF(c, d, AGX_R_LOWER) * ((RBI(c, d, AGX_R_KIND) & 3) == 1 ? (c).limit_scale : 1.f))
+#define DHI(c, d) (RBF(c, d, AGX_R_UPPER) * ((RBI(c, d, AGX_R_KIND) & 3) == 1 ? (c).limit_scale : 1.f))
+// DoF d made static for this environment (mass-0 links, human.py:104-110): a 32-bit mask, DoFs 32.. are never frozen
+#define FROZEN(c, d) ((d) < 32 && (((c).frozen >> (d)) & 1))
 #define FBF(c, b, k) ((c).bf[(c).o_free + (b) * AGX_F_STRIDE + (k)])
 #define CLF(c, i, k) ((c).bf[(c).o_coll + (i) * AGX_C_STRIDE + (k)])
 #define CLI(c, i, k) ((c).bi[(c).o_coll + (i) * AGX_C_STRIDE + (k)])

@@ -105,7 +105,7 @@ AGX_DEV void aba_and_minv(Ctx& c) {
     v3 pa_ang = cross(w, ha) + cross(vo, hl), pa_lin = cross(w, hl);
     // external force: gravity + velocity damping [BULLET-UNVERIFIED, see oracle]
     float sl = kl + kl * sqrtf(dot(vc, vc)), sa = ka + ka * sqrtf(dot(w, w));
-    const float gz = PRM(c, RBI(c, d, AGX_R_KIND) == 1 ? AGX_P_HUMAN_GRAVITY_Z : AGX_P_ROBOT_GRAVITY_Z);
+    const float gz = PRM(c, (RBI(c, d, AGX_R_KIND) & 1) ? AGX_P_HUMAN_GRAVITY_Z : AGX_P_ROBOT_GRAVITY_Z);
     v3 f = mk3(0, 0, m * gz) - (m * sl) * vc;
     v3 tau = -(sa * mul(Iw, w));
     v3 fa = tau + cross(cw, f);
@@ -117,7 +117,7 @@ AGX_DEV void aba_and_minv(Ctx& c) {
     if (lane < 6) { float s = 0; for (int k = 0; k < 6; k++) s += A[A_IA + 36 * d + 6 * lane + k] * L[L_S + 6 * d + k]; A[A_U + 6 * d + lane] = s; }
     wave_sync();
     float D = dot6p(L + L_S + 6 * d, A + A_U + 6 * d);
-    float Dinv = (D > 1e-30f && !(c.frozen >> d & 1)) ? 1.0f / D : 0.0f;   // frozen DoF: static link (mass 0, human.py:104-110)
+    float Dinv = (D > 1e-30f && !FROZEN(c, d)) ? 1.0f / D : 0.0f;   // frozen DoF: static link (mass 0, human.py:104-110)
     float u = -RBF(c, d, AGX_R_JDAMP) * L[L_ST + c.s_qd + d] - dot6p(L + L_S + 6 * d, A + A_PA + 6 * d);
     if (lane == 0) { A[A_DINV + d] = Dinv; A[A_UU + d] = u; }
     int par = RBI(c, d, AGX_R_PARENT);

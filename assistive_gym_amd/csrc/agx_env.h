@@ -14,7 +14,7 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
     const int d = lane;
     float qd = L[L_VEL + d], q = L[L_ST + c.s_q + d] + dt * qd;
     // Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250)
-    if (RBI(c, d, AGX_R_KIND) == 1 && !(c.frozen >> d & 1)) {
+    if ((RBI(c, d, AGX_R_KIND) & 5) == 1 && !FROZEN(c, d)) {
       const float lo = DLO(c, d), hi = DHI(c, d);
       if (q < lo - AGX_LIMIT_EPS) { q = lo; qd = 0.f; } else if (q > hi + AGX_LIMIT_EPS) { q = hi; qd = 0.f; }
     }
@@ -100,7 +100,11 @@ AGX_DEV void load_env(Ctx& c, const float* gstate, int sw) {
   c.coop = TKI(c, AGX_T_COOP) == 1;
   if (lane == 0) { const float* r = L + L_ST + c.s_base; st3(L + L_BASE, ld3(r)); stm3(L + L_BASE + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
   if (lane < c.nhuman) { const float* r = L + L_ST + c.s_human + 7 * lane; float* h = L + L_HUMAN + 12 * lane; st3(h, ld3(r)); stm3(h + 3, quat_to_m3(r[3], r[4], r[5], r[6])); }
-  if (lane < c.ndof) { int m = 0; for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) m |= 1 << d; c.ldsi[L_MISC + M_ANC + lane] = m; }
+  if (lane < c.ndof) {
+    uint64_t m = 0; for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) m |= 1ull << d;
+    c.ldsi[L_MISC + M_ANC + ANC_WORDS * lane] = (int)(uint32_t)m;
+    if (ANC_WORDS == 2) c.ldsi[L_MISC + M_ANC + 2 * lane + 1] = (int)(uint32_t)(m >> 32);
+  }
   wave_sync();
 }
 AGX_DEV void store_env(Ctx& c, float* gstate, int sw) {

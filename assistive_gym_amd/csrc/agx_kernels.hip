@@ -11,6 +11,17 @@
 #define AGX_TASK 1
 #define AGX_VNAME bed_bathing
 #define AGX_K(name) name##_bb
+#elif defined(AGX_VARIANT_BED_SETTLE)
+// the rag-doll settle of BedBathingEnv.reset (bed_bathing.py:119-137): the whole human as ONE articulated body of 47 DoFs (6 for the
+// floating base + 41 joints) falling onto the bed; reset time only (one wave per SIMD at most: 97 KB of LDS per environment)
+#define AGX_MAX_DOF 48
+#define AGX_MAX_FREE 1
+#define AGX_MAX_BLOCK 48
+#define AGX_ARENA_WORDS 20224
+#define AGX_SCR_ENT 16384
+#define AGX_TASK 1
+#define AGX_VNAME bed_settle
+#define AGX_K(name) name##_bs
 #elif defined(AGX_VARIANT_SCRATCH_ITCH)
 // ScratchItchPR2: the PR2's left arm branch (7 arm joints + 4 finger joints; its other branches start at rest with zero gravity and are
 // compiled as static) + the 10 joints of the human's right arm, one free body (scratcher)

@@ -12,7 +12,8 @@ AGX_DEV void add_jac(const Ctx& c, int code, v3 x, v3 f, v3 t, float sign, float
     v3 xr = x - ld3(L + L_MISC + M_REF);
     v3 Fa = cross(xr, f) + t;
     float F[6] = {Fa.x, Fa.y, Fa.z, f.x, f.y, f.z};
-    const int anc = c.ldsi[L_MISC + M_ANC + code];
+    uint64_t anc = (uint32_t)c.ldsi[L_MISC + M_ANC + ANC_WORDS * code];
+    if (ANC_WORDS == 2) anc |= (uint64_t)(uint32_t)c.ldsi[L_MISC + M_ANC + 2 * code + 1] << 32;
     _Pragma("unroll") for (int d = 0; d < MAX_DOF; d++) if (d < c.ndof && (anc >> d & 1)) Jr[d] += sign * dot6p(L + L_S + 6 * d, F);
   } else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) {
     int b = code - AGX_BODY_FREE0;
@@ -122,7 +123,7 @@ AGX_DEV void build_rows(Ctx& c) {
       const int slot = 64 * ph + lane;
       if (slot < MAX_DOF) {
         const int d = slot;
-        if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f && !(c.frozen >> d & 1)) {
+        if (d < n && RBF(c, d, AGX_R_MAXF) > 0.f && !FROZEN(c, d)) {
           go = true; if (d < c.nrobot) R.robot = true; else R.human = true;
           _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) R.Jr[q] = (q == d) ? 1.f : 0.f;
           // Agent.control (agent.py:28-33): POSITION_CONTROL motor, target dv = kp (q*-q)/dt + kd (0 - qd)
@@ -134,7 +135,7 @@ AGX_DEV void build_rows(Ctx& c) {
         }
       } else if (slot < 3 * MAX_DOF) {
         const int d = (slot - MAX_DOF) >> 1, side = (slot - MAX_DOF) & 1;
-        if (d < n && RBI(c, d, AGX_R_HAS_LIMIT) && !(c.frozen >> d & 1)) {
+        if (d < n && RBI(c, d, AGX_R_HAS_LIMIT) && !FROZEN(c, d)) {
           float q = L[L_ST + c.s_q + d];
           float gap = side == 0 ? q - DLO(c, d) : DHI(c, d) - q;
           if (gap < PRM(c, AGX_P_LIMIT_ACT)) {
@@ -146,7 +147,7 @@ AGX_DEV void build_rows(Ctx& c) {
             rlo = 0.f; rhi = 1e30f;
           }
         }
-      } else if (slot < NC_SLOTS) {
+      } else if (slot < NC_SLOTS && c.nfree > 0) {
         // tool fixed constraint (tool.py:46-47): parent frame = end-effector frame o tool offset, child frame = the tool's
         // base (URDF root link) frame
         const int k = slot - 3 * MAX_DOF; go = true;

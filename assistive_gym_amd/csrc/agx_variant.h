@@ -29,3 +29,4 @@ struct agx_variant {
 extern "C" const agx_variant* agx_variant_feeding(void);
 extern "C" const agx_variant* agx_variant_bed_bathing(void);
 extern "C" const agx_variant* agx_variant_scratch_itch(void);
+extern "C" const agx_variant* agx_variant_bed_settle(void);

@@ -99,7 +99,9 @@ enum {
   AGX_R_QT0 = 28,        /* initial motor target (gripper joints)                             */
   AGX_R_JDAMP = 29,
   AGX_R_PB_INDEX = 30,   /* int: PyBullet joint index (jaco.py:8-17, human.py:5-58)              */
-  AGX_R_KIND = 31,       /* int: 0 robot, 1 human (hard limit clamp after each substep, agent.py:240-250) */
+  AGX_R_KIND = 31,       /* int bits: bit0 human link (human gravity; hard limit reset after each substep, agent.py:240-250; limits scaled
+                          * by the impairment), bit1 limits NOT scaled (legs, waist: human_creation.py:249-278), bit2 no hard limit
+                          * reset (the rag-doll settle of bed_bathing.py:129-131 is plain stepSimulation) */
   AGX_R_JTYPE = 32,      /* int: 0 revolute, 1 prismatic (Sawyer gripper fingers, assets/sawyer/sawyer.urdf)  */
   AGX_R_STRIDE = 36
 };

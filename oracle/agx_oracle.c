@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXDOF 32
+#define MAXDOF 64
 #define MAXFREE 16
 #define MAXHUMAN 24
 #define NVMAX (MAXDOF + 6 * MAXFREE)
@@ -151,6 +151,8 @@ int agxo_state_words(const agxo_model* m) { return m->state_words; }
 int agxo_ndof(const agxo_model* m) { return m->ndof; }
 
 #define PARAM(m, k) ((double)(m)->f[(m)->o_params + (k)])
+/* DoF d made static for this environment: a 32-bit mask, DoFs 32.. are never frozen */
+#define FROZEN(s, d) ((d) < 32 && (((s)->frozen >> (d)) & 1))
 /* link record of DoF d: human DoFs have one record per gender (agx_blob.h AGX_H_NHDOF) */
 static int g_gender = 0; /* gender of the environment currently being stepped (the oracle is single threaded per process; see sim_load) */
 #define REC(m, d) ((d) < (m)->nrobot ? (d) : (d) + g_gender * (m)->nhdof)
@@ -267,8 +269,8 @@ static void sim_store(const sim_t* s, float* st) {
 }
 
 /* joint limits of DoF d; the human's are scaled per environment (human_creation.py:199-200) */
-static double dof_lower(const sim_t* s, int d) { return RF(s->m, d, AGX_R_LOWER) * (RI(s->m, d, AGX_R_KIND) == 1 ? s->limit_scale : 1.0); }
-static double dof_upper(const sim_t* s, int d) { return RF(s->m, d, AGX_R_UPPER) * (RI(s->m, d, AGX_R_KIND) == 1 ? s->limit_scale : 1.0); }
+static double dof_lower(const sim_t* s, int d) { return RF(s->m, d, AGX_R_LOWER) * ((RI(s->m, d, AGX_R_KIND) & 3) == 1 ? s->limit_scale : 1.0); }
+static double dof_upper(const sim_t* s, int d) { return RF(s->m, d, AGX_R_UPPER) * ((RI(s->m, d, AGX_R_KIND) & 3) == 1 ? s->limit_scale : 1.0); }
 
 /* ------------------------------------------------------------------------------------ kinematics
  * K1 of SURVEY 2.2: what getLinkState(computeForwardKinematics=True) (agent.py:52) reads back. */
@@ -316,7 +318,7 @@ static void kinematics(sim_t* s) {
 static void link_external_force(const sim_t* s, int d, int with_damping, double* f6) {
   const agxo_model* m = s->m;
   double mass = RF(m, d, AGX_R_MASS);
-  double f[3] = {0, 0, mass * PARAM(m, RI(m, d, AGX_R_KIND) == 1 ? AGX_P_HUMAN_GRAVITY_Z : AGX_P_ROBOT_GRAVITY_Z)}, tau[3] = {0, 0, 0};
+  double f[3] = {0, 0, mass * PARAM(m, (RI(m, d, AGX_R_KIND) & 1) ? AGX_P_HUMAN_GRAVITY_Z : AGX_P_ROBOT_GRAVITY_Z)}, tau[3] = {0, 0, 0};
   if (with_damping) {
     const double* w = s->vsp[d]; double vc[3], t[3];
     cross3(w, s->comw[d], t); add3(s->vsp[d] + 3, t, vc);
@@ -342,7 +344,7 @@ static void aba(sim_t* s, const double* tau, int with_damping, double* qdd) {
   for (int d = n - 1; d >= 0; d--) {
     mv6(s->IA[d], s->S[d], s->U[d]);
     double D = dot6(s->S[d], s->U[d]);
-    s->Dinv[d] = (D > 1e-300 && !(s->frozen >> d & 1)) ? 1.0 / D : 0.0;   /* frozen DoF: static link (mass 0, human.py:104-110) */
+    s->Dinv[d] = (D > 1e-300 && !FROZEN(s, d)) ? 1.0 / D : 0.0;   /* frozen DoF: static link (mass 0, human.py:104-110) */
     double t = (tau ? tau[d] : 0.0) - RF(m, d, AGX_R_JDAMP) * s->qd[d];
     u[d] = t - dot6(s->S[d], pA[d]);
     int par = RI(m, d, AGX_R_PARENT);
@@ -686,7 +688,7 @@ static void collide(sim_t* s) {
     {   /* bit3 / bit4: male / female only; bit5: only while some human DoF is dynamic */
       const int fl = GI(m, g, AGX_G_FLAGS);
       if (((fl & 8) && s->gender != 0) || ((fl & 16) && s->gender != 1)) continue;
-      if ((fl & 32) && ((~s->frozen >> m->nrobot) & ((1 << m->nhdof) - 1)) == 0) continue;
+      if ((fl & 32) && m->ndof <= 32 && ((~s->frozen >> m->nrobot) & ((1u << m->nhdof) - 1u)) == 0) continue;
     }
     const double mg = (GI(m, g, AGX_G_FLAGS) & 2) ? brk : slack;   /* bit1: getContactPoints-style existence query */
     for (int a = a0; a < a1; a++) {
@@ -812,7 +814,7 @@ static void build_rows(sim_t* s) {
   /* joint motors: Agent.control (agent.py:28-33) -> POSITION_CONTROL velocity-level row.
    * [BULLET-UNVERIFIED] target dv = kp (q*-q)/dt + kd (0 - qd), impulse clamp maxForce*dt */
   for (int d = 0; d < n; d++) {
-    double maxf = RF(m, d, AGX_R_MAXF); if (maxf <= 0 || (s->frozen >> d & 1)) continue;
+    double maxf = RF(m, d, AGX_R_MAXF); if (maxf <= 0 || FROZEN(s, d)) continue;
     row_t* r = NEWROW(); r->J[d] = 1.0; finish_row(s, r);
     double kp = RF(m, d, AGX_R_KP);
     if (d >= m->nrobot && s->human_kp > 0) { kp = s->human_kp; maxf = s->human_maxf; }   /* reactive hold of a human that is not an agent (human.py:124-127) */
@@ -821,7 +823,7 @@ static void build_rows(sim_t* s) {
   }
   /* joint limits (URDF lower/upper): unilateral rows, built only when the gap is small */
   for (int d = 0; d < n; d++) {
-    if (!RI(m, d, AGX_R_HAS_LIMIT) || (s->frozen >> d & 1)) continue;
+    if (!RI(m, d, AGX_R_HAS_LIMIT) || FROZEN(s, d)) continue;
     for (int side = 0; side < 2; side++) {
       double gap = side == 0 ? s->q[d] - dof_lower(s, d) : dof_upper(s, d) - s->q[d];
       if (gap >= PARAM(m, AGX_P_LIMIT_ACT)) continue;
@@ -833,7 +835,8 @@ static void build_rows(sim_t* s) {
   }
   /* tool fixed constraint (tool.py:46-47): 3 linear rows along world axes at the pivots,
    * 3 angular rows about the parent frame axes; impulse clamp maxForce*dt */
-  {
+  const int has_tool = m->nfree > 0;
+  if (has_tool) {
     xf_t ee; ee_frame(s, &ee);
     int L = TI(m, AGX_T_EE_LINK), tb = m->tool_body, code_b = AGX_BODY_FREE0 + tb;
     double tp[3] = {TF(m, AGX_T_TOOL_POS), TF(m, AGX_T_TOOL_POS + 1), TF(m, AGX_T_TOOL_POS + 2)};
@@ -873,7 +876,7 @@ static void build_rows(sim_t* s) {
   {
     int ent = 1, maxent = (int)PARAM(m, AGX_P_MAX_ENTRIES);
     /* non-contact rows: motors and limits address the robot; the 6 tool rows (last) robot + tool */
-    for (int r0 = 0; r0 < first_normal; r0++) ent += row_art_entries(s, &s->rows[r0]) + (r0 >= first_normal - 6 ? 6 : 0);
+    for (int r0 = 0; r0 < first_normal; r0++) ent += row_art_entries(s, &s->rows[r0]) + (has_tool && r0 >= first_normal - 6 ? 6 : 0);
     int acc = 0;
     for (int c = 0; c < s->ncon; c++) {
       const contact_t* k = &s->con[c];
@@ -1005,7 +1008,7 @@ static void substep(sim_t* s) {
   for (int d = 0; d < n; d++) {
     s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d];
     /* Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250) */
-    if (RI(m, d, AGX_R_KIND) == 1 && !(s->frozen >> d & 1)) {
+    if ((RI(m, d, AGX_R_KIND) & 5) == 1 && !FROZEN(s, d)) {
       if (s->q[d] < dof_lower(s, d) - (double)AGX_LIMIT_EPS) { s->q[d] = dof_lower(s, d); s->qd[d] = 0; }
       else if (s->q[d] > dof_upper(s, d) + (double)AGX_LIMIT_EPS) { s->q[d] = dof_upper(s, d); s->qd[d] = 0; }
     }

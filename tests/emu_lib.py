@@ -14,9 +14,12 @@ VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BL
                 2: ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=2']}
 
 
+VARIANT_DEFS['settle'] = ['-DAGX_MAX_DOF=48', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=48', '-DAGX_ARENA_WORDS=20224', '-DAGX_SCR_ENT=16384', '-DAGX_TASK=1']
+
+
 def lib(task_kind=0):
     if task_kind not in _LIBS:
-        so = os.path.join(EMU, 'libagx_emu_%d.so' % task_kind)
+        so = os.path.join(EMU, 'libagx_emu_%s.so' % task_kind)
         deps = [os.path.join(EMU, f) for f in ('emu_main.cpp', 'agx_wave.h')] + \
                [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'agx_blob.h')]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
@@ -35,7 +38,7 @@ def _p(a):
 class Emu:
     def __init__(self, blob):
         self.blob = blob
-        self.L = lib(blob.task_kind)
+        self.L = lib('settle' if blob.ndof > 32 else blob.task_kind)
         self.words = np.ascontiguousarray(blob.words)
         lay = (C.c_int * 8)()
         self.L.agx_emu_debug_layout(lay)
