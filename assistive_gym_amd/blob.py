@@ -115,7 +115,7 @@ class ModelBlob:
         return dict(
             q=s[:, h['S_Q']:h['S_Q'] + self.ndof], qd=s[:, h['S_QD']:h['S_QD'] + self.ndof],
             qt=s[:, h['S_QT']:h['S_QT'] + self.ndof],
-            free=s[:, h['S_FREE']:h['S_FREE'] + 13 * self.nfree].reshape(-1, self.nfree, 13),
+            free=s[:, h['S_FREE']:h['S_FREE'] + 13 * self.nfree].reshape(len(s), self.nfree, 13),
             base=s[:, h['S_BASE']:h['S_BASE'] + 7],
             human=s[:, h['S_HUMAN']:h['S_HUMAN'] + 7 * self.nhuman].reshape(-1, self.nhuman, 7),
             plane_friction=s[:, e + L.E['PLANE_FRICTION']], gender=si[:, e + L.E['GENDER']],

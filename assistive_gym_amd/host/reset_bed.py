@@ -12,8 +12,11 @@ Reset is outside the kernel scope; only its RESULT feeds the steppe
   * Bullet's IK is replaced by damped least squares (as in host/kin.py); the TOC search keeps the reference's structure
     (50 attempts, start pose + 3 position-only goals, success threshold 0.03, JLWKI score);
   * the 100-step rag-doll settle of the 47-DoF floating human (bed_bathing.py:129-131) is produced by `settle`:
-    'drop' (default here) lowers the posed human rigidly until its first collider touches the mattress -- a kinematic
-    stand-in that keeps the perturbed joint angles but lets limbs float above the bed by the difference of their radii;
+    'ragdoll' runs it: the bed_settle model (compiler.compile_bed_settle: the human as one floating articulated body, its own
+    kernel variant) is stepped 100 times by a `settler` (RagdollSettler: the device, through agx_settle) and the resting base
+    pose and joint angles are read back; 'drop' (the default without a device) lowers the posed human rigidly until its first
+    collider touches the mattress -- a kinematic stand-in that keeps the perturbed joint angles but lets limbs float above
+    the bed by the difference of their radii;
   * the collision rejection loop of init_robot_pose (env.py:299-308) is not run.
 """
 import numpy as np
@@ -108,6 +111,55 @@ def joint_limited_weighting(q, lower, upper):
     return np.maximum(w, 0.001)
 
 
+def settle_record(sblob, row, gender, limit_scale, base_pos, base_rpy, hq, plane_friction):
+    """state record of the bed_settle model: the posed human in the air (bed_bathing.py:121,127), at rest"""
+    v = sblob.view(row)
+    row[:] = 0
+    joints = sblob.meta['settle_joints']
+    q = np.concatenate([base_pos, [base_rpy[2], base_rpy[1], base_rpy[0]], [hq[j] for j in joints]])
+    v['q'][0] = q
+    v['qt'][0] = q
+    v['human'][0, 0, 3:] = [0, 0, 0, 1]                       # the world anchor of the virtual root joints
+    v['base'][0, 3:] = [0, 0, 0, 1]
+    v['limit_scale'][0] = limit_scale
+    v['plane_friction'][0] = plane_friction
+    v['gender'][0] = 0 if gender == 'male' else 1
+    return row
+
+
+def settled_pose(sblob, row, hm):
+    """(base_pos, base_quat, hq[hm.n]) of a settle record"""
+    v = sblob.view(row)
+    q = v['q'][0].astype(np.float64)
+    hq = np.zeros(hm.n)
+    for k, j in enumerate(sblob.meta['settle_joints']):
+        hq[j] = q[6 + k]
+    return q[:3].copy(), X.quat_from_rpy([q[5], q[4], q[3]]), hq
+
+
+class RagdollSettler:
+    """Runs the rag-doll settle on the device: an agx context on the bed_settle model, agx_settle for 100 simulation steps
+    (bed_bathing.py:130-131).  Fails loudly without a GPU (the product path has no CPU fallback)."""
+
+    def __init__(self, n_envs, device=0, steps=100):
+        from ..blob import ModelBlob
+        from ..libagx import Stepper
+        self.blob = ModelBlob.load('bed_settle')
+        self.ctx = Stepper(self.blob, n_envs, device)
+        self.n, self.steps = n_envs, steps
+
+    def __call__(self, states):
+        n = len(states)
+        assert n <= self.n
+        buf = self.blob.new_state(self.n)
+        buf[:n] = states
+        buf[n:] = states[:1]
+        self.ctx.set_state(buf)
+        self.ctx.settle(self.steps)
+        self.ctx.L.agx_synchronize(self.ctx.h, None)
+        return self.ctx.get_state()[:n]
+
+
 class BedBathingSawyerReset:
     def __init__(self, blob, settle='drop'):
         assert blob.task_kind == L.TASK_BED_BATHING
@@ -196,10 +248,14 @@ class BedBathingSawyerReset:
         return base_pos[best], X.mat_to_quat(base_R[best]), qsol[best, 0], int(ngoal[best]), float(manip[best])
 
     def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None):
-        """Fill one state record (float32 view of length state_words) in place."""
-        b = self.blob
-        v = b.view(state_row)
-        nr, nh = b.nrobot, b.nhdof
+        """Fill one state record (float32 view of length state_words) in place, with the 'drop' stand-in for the settle."""
+        pre = self.pre_settle(rng, impairment, gender, human_q_override)
+        pre['base_pos'] = self._drop(pre['hm'], pre['base_pos'], pre['base_quat'], pre['hq'])
+        return self.post_settle(rng, state_row, pre, env_seed, info)
+
+    def pre_settle(self, rng, impairment='random', gender='random', human_q_override=None):
+        """the draws of build_assistive_env and the posed human in the air (bed_bathing.py:114-127)"""
+        nh = self.blob.nhdof
         plane_friction = rng.uniform(0.025, 0.5)                                   # env.py:120
         if gender not in ('male', 'female'):
             gender = rng.choice(['male', 'female'])                                # human.py:76-77
@@ -221,8 +277,17 @@ class BedBathingSawyerReset:
         for j, a in (human_q_override or {}).items():          # tests only: e.g. an abducted arm
             hq[j] = a
         hq = hm.clamp(hq)
-        base_pos, base_quat = np.array([-0.15, 0.2, 0.95]), X.quat_from_rpy([-np.pi / 2.0, 0, 0])
-        base_pos = self._drop(hm, base_pos, base_quat, hq)                         # stand-in for the settle, see module docstring
+        base_rpy = np.array([-np.pi / 2.0, 0, 0])
+        return dict(plane_friction=plane_friction, gender=gender, impairment=impairment, limit_scale=limit_scale, strength=strength,
+                    tremors=tremors, hm=hm, hq=hq, base_pos=np.array([-0.15, 0.2, 0.95]), base_rpy=base_rpy, base_quat=X.quat_from_rpy(base_rpy))
+
+    def post_settle(self, rng, state_row, pre, env_seed=0, info=None):
+        """everything after the settle (bed_bathing.py:133-171), from the resting pose in `pre`"""
+        b = self.blob
+        v = b.view(state_row)
+        nr, nh = b.nrobot, b.nhdof
+        plane_friction, gender, impairment, limit_scale, strength, tremors = (pre[k] for k in ('plane_friction', 'gender', 'impairment', 'limit_scale', 'strength', 'tremors'))
+        hm, hq, base_pos, base_quat = pre['hm'], pre['hq'], pre['base_pos'], pre['base_quat']
         hpos, hquat = hm.fk(base_pos, base_quat, hq)
         for k, link in enumerate(self.human_bodies):
             if link < 0:
@@ -283,13 +348,26 @@ class BedBathingSawyerReset:
         return state_row
 
 
-def make_states(blob, n, seed=1001, impairment='random', **kw):
-    """n independent post-reset states; env i uses RandomState(seed + i)."""
-    rs = BedBathingSawyerReset(blob)
+def make_states(blob, n, seed=1001, impairment='random', settler=None, **kw):
+    """n independent post-reset states; env i uses RandomState(seed + i).  With a `settler` (a callable advancing bed_settle
+    state records by the 100 simulation steps of bed_bathing.py:130-131, e.g. RagdollSettler) the human is settled as a rag
+    doll, all environments in one batch; without one the rigid 'drop' stand-in is used."""
+    rs = BedBathingSawyerReset(blob, settle='drop' if settler is None else 'ragdoll')
     st = blob.new_state(n)
-    infos = []
-    for i in range(n):
-        info = {}
-        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], env_seed=seed + i, impairment=impairment, info=info, **kw)
-        infos.append(info)
+    infos = [{} for _ in range(n)]
+    rngs = [np.random.RandomState(seed + i) for i in range(n)]
+    if settler is None:
+        for i in range(n):
+            rs.sample(rngs[i], st[i:i + 1], env_seed=seed + i, impairment=impairment, info=infos[i], **kw)
+        return st, infos
+    from ..blob import ModelBlob
+    sblob = settler.blob if hasattr(settler, 'blob') else ModelBlob.load('bed_settle')
+    pres = [rs.pre_settle(rngs[i], impairment=impairment, **kw) for i in range(n)]
+    ss = sblob.new_state(n)
+    for i, p in enumerate(pres):
+        settle_record(sblob, ss[i:i + 1], p['gender'], p['limit_scale'], p['base_pos'], p['base_rpy'], p['hq'], p['plane_friction'])
+    ss = settler(ss)
+    for i, p in enumerate(pres):
+        p['base_pos'], p['base_quat'], p['hq'] = settled_pose(sblob, ss[i:i + 1], p['hm'])
+        rs.post_settle(rngs[i], st[i:i + 1], p, env_seed=seed + i, info=infos[i])
     return st, infos

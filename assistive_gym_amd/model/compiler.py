@@ -812,6 +812,127 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
                 targets=targets, task_words=BB['WORDS'], mlp=mlp, meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
 
 
+RAGDOLL_PARTS = (('base', -1, -1), ('rpec', 0, 2), ('rarm', 3, 9), ('lpec', 10, 12), ('larm', 13, 19), ('head', 20, 23), ('waist', 24, 27),
+                 ('rleg', 28, 34), ('lleg', 35, 41))
+
+
+def compile_bed_settle(assets=DEFAULT_ASSETS, n_iter=50):
+    """The scene of the rag-doll settle inside BedBathingEnv.reset (bed_bathing.py:119-131): the WHOLE human as one floating
+    articulated body falling onto the bed under gravity -1 for 100 simulation steps, no motors (setup_joints(...,
+    reactive_force=None), human.py:104-117), joint limits as constraints only.  Not an environment: the blob exists so that
+    host/reset_bed.py can run the settle on the device (agx_settle) and read the resting pose back.
+
+    DoFs: 0..2 prismatic x, y, z and 3..5 revolute z, y, x (massless virtual links; the last one IS the chest, so the base
+    orientation is Rz Ry Rx = PyBullet's rpy), then the 41 revolute joints in PyBullet order (the fixed waist joint 24 is
+    merged into the chest).  Self collision as human_creation.py:282-295 leaves it: arms and legs against the rest."""
+    sc = Scene()
+    rob = dict(dof_links=[], rec=[], rec_int=[], dof_colliders=[], base_colliders=[])
+    VR = 6
+    hm0 = HumanModel('male')
+    joints = [j for j in range(hm0.n) if hm0.jtype[j] == 'r']
+    assert len(joints) == 41 and [j for j in range(hm0.n) if hm0.jtype[j] != 'r'] == [24] and hm0.parent[24] == -1
+    dof_of = {-1: VR - 1, 24: VR - 1}
+    dof_of.update({j: VR + k for k, j in enumerate(joints)})
+    nhdof = VR + len(joints)
+    human_link_rec = {}
+    part_of = lambda link: next(n for n, a, b in RAGDOLL_PARTS if a <= link <= b)
+    for gender in ('male', 'female'):
+        hm, hm_half = HumanModel(gender), HumanModel(gender, 0.5)
+        cols = hm.colliders()
+        link_hulls = {}
+        sc.begin('human_' + gender)
+        for name, a, b in RAGDOLL_PARTS:
+            sc.begin('human_%s_%s' % (gender, name))
+            for (link, kind, data) in cols:
+                if not a <= link <= b:
+                    continue
+                shift = hm.offset[24] if link == 24 else np.zeros(3)
+                shapes = []
+                if kind == 'capsule':
+                    shapes.append((np.stack([data[0], data[1]]) + shift, data[2]))
+                elif kind == 'sphere':
+                    shapes.append((data[0][None] + shift, data[1]))
+                elif kind == 'head':
+                    fn, fpos, fquat, scale = data
+                    for g in load_obj_groups(os.path.join(assets, fn), scale):
+                        shapes.append((X.apply(fpos, fquat, convex_hull_vertices(g)) + shift, HULL_MARGIN))
+                for verts, radius in shapes:
+                    sc.add(dof_of[link], verts, radius, DEFAULT_FRICTION, TAG['HUMAN'], link=link)
+                    link_hulls.setdefault(link, []).append((verts, radius))
+            sc.end('human_%s_%s' % (gender, name))
+        sc.end('human_' + gender)
+        recs = np.zeros((nhdof, R['STRIDE']))
+        ints = []
+        vaxes = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 0, 1], [0, 1, 0], [1, 0, 0]]
+        for k in range(VR):
+            recs[k, R['TQUAT'] + 3] = 1.0
+            recs[k, R['AXIS']:R['AXIS'] + 3] = vaxes[k]
+            recs[k, R['LOWER']], recs[k, R['UPPER']] = -1e10, 1e10
+            # bit 0: the human's gravity and impairments; bit 1: limits not scaled by the impairment; bit 2: no clamp after the step
+            ints.append(dict(PARENT=PARENT_HUMAN_BASE if k == 0 else k - 1, HAS_LIMIT=0, ACT=-1, PB_INDEX=-1, KIND=7, JTYPE=1 if k < 3 else 0))
+        def body_inertia(link, mass):
+            if mass <= 0 or link not in link_hulls:
+                return np.zeros(3)                          # a massive link without a shape (joint 26): point mass [BULLET-UNVERIFIED]
+            lo = np.min([v.min(0) - r for v, r in link_hulls[link]], axis=0)
+            hi = np.max([v.max(0) + r for v, r in link_hulls[link]], axis=0)
+            return box_inertia(mass, lo, hi)
+        recs[VR - 1, R['MASS']] = 0.1 * hm.total_mass       # human_creation.py:280 baseMass; the fixed waist link is massless
+        assert hm.mass[24] == 0
+        recs[VR - 1, R['INERTIA']:R['INERTIA'] + 3] = body_inertia(-1, 0.1 * hm.total_mass)
+        for j in joints:
+            k = dof_of[j]
+            par = hm.parent[j]
+            recs[k, R['TPOS']:R['TPOS'] + 3] = hm.offset[j] + (hm.offset[24] if par == 24 else 0)
+            recs[k, R['TQUAT'] + 3] = 1.0
+            recs[k, R['AXIS']:R['AXIS'] + 3] = hm.axis[j]
+            recs[k, R['MASS']] = hm.mass[j]
+            recs[k, R['INERTIA']:R['INERTIA'] + 3] = body_inertia(j, hm.mass[j])
+            recs[k, R['LOWER']], recs[k, R['UPPER']] = hm.lower[j], hm.upper[j]
+            scaled = abs(hm_half.lower[j] - hm.lower[j]) > 1e-12 or abs(hm_half.upper[j] - hm.upper[j]) > 1e-12
+            if scaled:
+                assert np.isclose(hm_half.lower[j], 0.5 * hm.lower[j]) and np.isclose(hm_half.upper[j], 0.5 * hm.upper[j])
+            recs[k, R['KD']] = 1.0
+            ints.append(dict(PARENT=dof_of[par], HAS_LIMIT=1, ACT=-1, PB_INDEX=j, KIND=5 if scaled else 7, JTYPE=0))
+        human_link_rec[gender] = (recs, ints)
+    sc.begin('bed')     # furniture.py:17-18; friction 5 (bed_bathing.py:116)
+    bq = X.quat_from_rpy([np.pi / 2, 0, 0])
+    for g in load_obj_groups(os.path.join(assets, 'bed', 'bed_single_reduced_vhacd.obj'), 1.1):
+        sc.add(BODY_WORLD, X.apply(np.array([-0.1, 0, 0.0]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), bq, convex_hull_vertices(g))), HULL_MARGIN, 5.0, TAG['BED'])
+    sc.end('bed')
+    sc.begin('plane')
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    G_ = Groups(sc.ranges)
+    for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
+        rg = lambda a, b: (G_.rg['human_%s_%s' % (gender, a)][0], G_.rg['human_%s_%s' % (gender, b)][1])
+        for name, (a, b) in dict(rarm=('rarm', 'rarm'), larm=('larm', 'larm'), rleg=('rleg', 'rleg'), lleg=('lleg', 'lleg'), base=('base', 'base'),
+                                 lpec=('lpec', 'lpec'), head=('head', 'head'), lpec_lleg=('lpec', 'lleg'), base_rpec=('base', 'rpec'),
+                                 head_lleg=('head', 'lleg')).items():
+            G_.rg['%s_%s' % (gender, name)] = rg(a, b)
+        G_.add('human_' + gender, 'bed', keep=2, flags=gf)
+        G_.add('human_' + gender, 'plane', keep=1, flags=gf)
+        # human_creation.py:282-295, each unordered pair of parts once
+        for a, b in (('rarm', 'base'), ('rarm', 'lpec_lleg'), ('larm', 'base_rpec'), ('larm', 'head_lleg'),
+                     ('rleg', 'base_rpec'), ('rleg', 'lpec'), ('rleg', 'head'), ('rleg', 'lleg'),
+                     ('lleg', 'base_rpec'), ('lleg', 'lpec'), ('lleg', 'head')):
+            G_.add('%s_%s' % (gender, a), '%s_%s' % (gender, b), flags=gf)
+    params = default_params(n_iter)
+    params.update(HUMAN_GRAVITY_Z=-1.0, MAX_ENTRIES=8000)                               # bed_bathing.py:123
+    task_f = dict(EE_QUAT=[0, 0, 0, 1.0], TOOL_QUAT=[0, 0, 0, 1.0], EPISODE_LEN=1 << 20)
+    task_i = dict(EE_LINK=VR - 1, PAD_LINK=0, ARM_LINK=[VR - 1, VR - 1], OBS_LINK=[VR - 1, VR - 1, VR - 1], NT=[0, 0, 0, 0], HEAD_LINK=-1, ARM_LIMIT_ON=0)
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT']
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        pass
+    rob_empty = dict(dof_links=[], rec=[], rec_int=[])
+    # one "static human body": the world anchor the first virtual joint hangs off (identity pose in the state record)
+    return pack(sc, G_.rows, rob_empty, [-1], human_link_rec, list(range(nhdof)), [], params, task_f, task_i,
+                dict(NFOOD=0, ACT_DIM=0, OBS_DIM=1, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_BED_BATHING), reset_fill, reset_words,
+                task_words=BB['WORDS'], meta_extra=dict(settle_joints=joints, virtual_dofs=VR))
+
+
 def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
     """ScratchItchPR2-v1 / ScratchItchPR2Human-v1 (scratch_itch_envs.py:17-19,41-44; BASELINE config 4 is the co-op flavour, `blob.coop()`):
     the PR2's left arm (agents/pr2.py) holding the scratcher (assets/scratcher/tool_scratch.urdf) next to a human in the wheelchair
@@ -897,7 +1018,8 @@ def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ve
                 task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
 
 
-COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2)
+COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
+                 bed_settle=compile_bed_settle)
 
 
 def main(names=None):

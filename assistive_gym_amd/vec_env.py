@@ -18,12 +18,13 @@ SETTLE_STEPS = 25   # feeding.py:178-179
 def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device'):
     """pool_size post-reset states: FeedingEnv.reset's sampling (sampler 'device': agx_sample_reset on the GPU;
     'host': the numpy path of host/reset.py), then the 25 settle steps of feeding.py:178-179 on the device.
-    BedBathingSawyer: BedBathingEnv.reset restated on the host (host/reset_bed.py; its reset ends without settle steps).
+    BedBathingSawyer: BedBathingEnv.reset restated on the host (host/reset_bed.py) around the rag-doll settle on the device.
     Returns a float32 (pool_size, state_words) array."""
     from .model import compiler as L
     if blob.task_kind == L.TASK_BED_BATHING:
-        from .host.reset_bed import make_states as make_bed_states
-        return make_bed_states(blob, pool_size, seed=seed, impairment=impairment)[0]
+        from .host.reset_bed import make_states as make_bed_states, RagdollSettler
+        # the rag-doll settle of BedBathingEnv.reset runs on the device (bed_settle kernel variant), the rest on the host
+        return make_bed_states(blob, pool_size, seed=seed, impairment=impairment, settler=RagdollSettler(pool_size, device))[0]
     if blob.task_kind == L.TASK_SCRATCH_ITCH:
         from .host.reset_scratch import make_states as make_scratch_states
         return make_scratch_states(blob, pool_size, seed=seed, impairment=impairment)[0]

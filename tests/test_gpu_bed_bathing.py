@@ -225,3 +225,78 @@ def test_coop_scalar_env_dicts(bed):
     obs, rew, done, info = env.step(a)
     assert set(done) == {'robot', 'human', '__all__'} and rew['robot'] == rew['human'] and info['human']['action_human_len'] == 10
     env.disconnect()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the rag-doll settle of BedBathingEnv.reset (bed_bathing.py:119-137) on the device: bed_settle kernel variant
+def _posed_batch(n, seed):
+    from assistive_gym_amd.blob import ModelBlob
+    from test_bed_settle import posed
+    sb, bb = ModelBlob.load('bed_settle'), ModelBlob.load('bed_bathing_sawyer')
+    rows, pres = zip(*[posed(sb, bb, seed + i) for i in range(n)])
+    return sb, np.array(rows), pres
+
+
+def test_ragdoll_settle_matches_oracle(bed):
+    from assistive_gym_amd.libagx import Stepper
+    from oracle_lib import Oracle
+    sb, states, pres = _posed_batch(8, 7001)
+    o = Oracle(sb)
+    st = Stepper(sb, 8)
+    assert st.variant() == 'bed_settle'
+    # (1) the fall, the arms pushed out of the torso, the first bed contacts: step for step against the f64 oracle
+    st.set_state(states)
+    ref = states.copy()
+    st.settle(24)
+    got = st.get_state()
+    for i in range(8):
+        o.settle(ref[i], 24)
+    assert np.abs(got[:, :47] - ref[:, :47]).max() < 5e-4 and np.abs(got[:, 47:94] - ref[:, 47:94]).max() < 2e-2
+    # (2) single steps from the oracle's own trajectory through the settle: no chaotic drift in the comparison
+    for k in range(6):
+        for i in range(8):
+            o.settle(ref[i], 10)
+        st.set_state(ref)
+        st.settle(1)
+        got = st.get_state()
+        nxt = ref.copy()
+        for i in range(8):
+            o.settle(nxt[i], 1)
+        assert np.abs(got[:, :47] - nxt[:, :47]).max() < 5e-5, k
+        assert np.abs(got[:, 47:94] - nxt[:, 47:94]).max() < 5e-3, k
+    assert st.overflow_count() == 0
+    st.close()
+
+
+def test_ragdoll_settler_rests_the_human_on_the_bed(bed):
+    from assistive_gym_amd.host import reset_bed as rb
+    from oracle_lib import Oracle
+    sb, states, pres = _posed_batch(6, 7101)
+    settler = rb.RagdollSettler(6)
+    out = settler(states)
+    o = Oracle(sb)
+    bed0 = sb.meta['ranges']['bed'][0]
+    for i in range(6):
+        v = sb.view(out[i:i + 1])
+        assert np.isfinite(out[i]).all()
+        assert np.abs(v['qd'][0]).max() < 3.0 and np.abs(v['qd'][0, :3]).max() < 0.08
+        bp, bq, hq = rb.settled_pose(sb, out[i:i + 1], pres[i]['hm'])
+        assert 0.8 < bp[2] < 0.92 and abs(bp[0] + 0.15) < 0.1 and abs(bp[1] - 0.2) < 0.1
+        assert np.max(np.maximum(pres[i]['hm'].lower - hq, hq - pres[i]['hm'].upper)) < 1e-2
+        con = o.collide(out[i])                                  # the oracle's narrow phase on the DEVICE's resting state
+        on_bed = con[con[:, 1] >= bed0]
+        assert len(on_bed) >= 8 and on_bed[:, 11].min() > -8e-3
+
+
+def test_bed_vec_env_pool_is_settled(bed):
+    """BedBathingSawyerVecEnv's reset pool goes through the device settle; the stepper then runs from it"""
+    import torch
+    from assistive_gym_amd.vec_env import BedBathingSawyerVecEnv
+    env = BedBathingSawyerVecEnv(8, pool_size=8, seed=4242)
+    obs = env.reset()
+    v = bed.view(env.pool_host)
+    k = bed.meta['human_bodies'].index(-1)
+    assert (v['human'][:, k, 2] > 0.8).all() and (v['human'][:, k, 2] < 0.92).all()      # the chest a chest radius above the mattress
+    for _ in range(3):
+        obs, rew, done, info = env.step(torch.zeros(8, 7, device=obs.device))
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
