@@ -232,6 +232,10 @@ int agx_settle(agx_handle h, int n_substeps, void* stream) {
   if (!h || n_substeps < 0) return fail(AGX_E_ARG, "agx_settle: bad argument");
   return launch_chunked(h, n_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
 }
+int agx_settle_debug(agx_handle h, int n_substeps, float* dbg, void* stream) {
+  if (!h || n_substeps < 1 || !dbg) return fail(AGX_E_ARG, "agx_settle_debug: bad argument");
+  return launch_chunked(h, n_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, dbg, false, stream);
+}
 int agx_step(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, void* stream) {
   if (!h || !a || !obs || !rew || !done) return fail(AGX_E_ARG, "agx_step: bad argument");
   return launch_step(h, a, obs, rew, done, info, nullptr, stream);

@@ -51,7 +51,8 @@ constexpr int L_MISC = L_HUMAN + MAX_HUMAN * 12;         // ref(3), ee p(3), ee 
 constexpr int ANC_WORDS = MAX_DOF > 32 ? 2 : 1;            // ancestor bitmask of a moving link: 1 or 2 ints
 constexpr int MISC_WORDS = (15 + ANC_WORDS * MAX_DOF + 7) / 8 * 8;
 constexpr int L_WMAG = L_MISC + MISC_WORDS;                      // |angular velocity| per moving body: links [MAX_DOF], free bodies [MAX_FREE]
-constexpr int L_ARENA = L_WMAG + 32;                     // contact records live in the per-env global scratch, not in LDS
+constexpr int WMAG_WORDS = MAX_DOF + MAX_FREE > 32 ? (MAX_DOF + MAX_FREE + 7) / 8 * 8 : 32;
+constexpr int L_ARENA = L_WMAG + WMAG_WORDS;                     // contact records live in the per-env global scratch, not in LDS
 static_assert(MAX_DOF + MAX_FREE <= 64, "angular speed table: one lane per moving body");
 constexpr int LDS_WORDS = L_ARENA + ARENA_WORDS;
 static_assert(L_ARENA % 2 == 0, "(J,B) pairs are read as 8-byte words");

@@ -233,7 +233,11 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
         if (s.n == 1) s.p1 = np; else if (s.n == 2) s.p2 = np; else s.p3 = np;
         s.n++;
         v3 vn;
-        if (gjk_solve(s, vn)) { pen = true; active = false; }
+        // An enclosed origin contradicts a separating plane: v.w > 0 proves that every point x of A - B has v.x >= v.w > 0.  A flat
+        // tetrahedron (four nearly coplanar support points: a capsule's segment along a hull facet) can pass the four side tests
+        // by rounding alone -- seen on the device, with its contracted multiply-adds, for a forearm lying along the mattress
+        // edge, 4 cm clear of it.  Then the closest points found so far stand, as in the no-progress case below.
+        if (gjk_solve(s, vn)) { pen = !(vw > 0.f); active = false; }
         else {
           const float vvn = dot(vn, vn);
           // no progress (a degenerate sub-simplex solve can even move away): keep the closest points found so far

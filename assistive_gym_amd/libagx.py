@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('AGX_LIB', os.path.join(HERE, 'lib', 'libagx.so'))   #
 _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
-           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
+           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset',
            'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather']
@@ -113,6 +113,9 @@ class Stepper:
 
     def settle(self, n_substeps, stream=0):
         check(self.L.agx_settle(self.h, C.c_int(n_substeps), C.c_void_p(stream)), 'agx_settle')
+
+    def settle_debug(self, n_substeps, debug, stream=0):
+        check(self.L.agx_settle_debug(self.h, C.c_int(n_substeps), _ptr(debug), C.c_void_p(stream)), 'agx_settle_debug')
 
     def step_dev(self, actions, obs, reward, done, info=None, stream=0, debug=None):
         if debug is not None:

@@ -68,6 +68,8 @@ int agx_step(agx_handle h, const float* actions_dev, float* obs_dev, float* rewa
 /* same as agx_step, additionally dumping first-substep internals ([n_envs][agx_debug_words()]) */
 int agx_step_debug(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
                    uint8_t* done_dev, float* info_dev, float* debug_dev, void* stream);
+/* agx_settle, additionally dumping first-substep internals (models without a task layer to finish a step with, e.g. bed_settle) */
+int agx_settle_debug(agx_handle h, int n_substeps, float* debug_dev, void* stream);
 int agx_debug_words(void);   /* of the FeedingJaco kernel variant; agx_debug_layout for the variant serving a handle */
 /* layout of the debug record of the kernel variant serving this handle: out8 = {words per env, contacts offset, M^-1 offset,
  * M^-1 row stride, row headers offset, impulses offset, phase timers offset, qdd offset} */

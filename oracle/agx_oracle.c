@@ -481,7 +481,9 @@ static int gjk_core(const double* a, int na, const double* b, int nb, double tol
     if (dup) break;
     memcpy(W[n], w, 24); memcpy(A[n], a + 3 * ia, 24); memcpy(B[n], b + 3 * ib, 24); n++;
     double vn[3];
-    if (simplex_solve(W, A, B, &n, lam, vn)) { pen = 1; break; }
+    /* an enclosed origin contradicts a separating plane (v.w > 0: every point x of A - B has v.x >= v.w > 0): a flat
+     * tetrahedron passed the side tests by rounding; the closest points found so far stand (same rule as the device code) */
+    if (simplex_solve(W, A, B, &n, lam, vn)) { pen = !(vw > 0); break; }
     double vvn = dot3(vn, vn);
     /* no progress (a degenerate sub-simplex solve can even move away): keep the closest points found so far */
     if (vvn >= vv) break;

@@ -52,7 +52,7 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
   if (mode == 2) return run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_observe(blob, state, obs, lds, lane); });
   const int nsub = mode == 1 ? nsettle : frame_skip;
   for (int k = 0; k < nsub && !rc; k++) {
-    const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (mode == 0 && k == 0) ? debug : nullptr;
+    const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (k == 0) ? debug : nullptr;
     rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, dbg, lds, lane); });
     if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane); });
   }

@@ -58,8 +58,8 @@ class Emu:
     def step(self, state, action, debug=False):
         return self._run(state, action, 0, 0, debug)
 
-    def settle(self, state, n):
-        self._run(state, None, 1, n)
+    def settle(self, state, n, debug=False):
+        return self._run(state, None, 1, n, debug)[4]
 
     def sample(self, seed, impairment_mode=-1, gender_mode=-1):
         """device-side reset generator (csrc/agx_reset.h) for one env -> (state record, info[4])"""

@@ -240,30 +240,50 @@ def _posed_batch(n, seed):
 def test_ragdoll_settle_matches_oracle(bed):
     from assistive_gym_amd.libagx import Stepper
     from oracle_lib import Oracle
-    sb, states, pres = _posed_batch(8, 7001)
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.model import compiler as L
+    sb_full, states, pres = _posed_batch(8, 7001)
+    # With the bed's friction of 5 (bed_bathing.py:116; mu = 2.5 against skin) the friction bounds -+mu*lambda_n make the 50 projected
+    # Gauss-Seidel sweeps non-contractive once the body lies on the mattress: oracle and device BOTH wander with the sweep count
+    # (measured: 50 -> 200 -> 800 sweeps move the f64 result by 0.05 .. 0.1 rad/s) and rounding differences are amplified.  The
+    # step-by-step comparison therefore runs on the same scene with bed friction 1 (contractive: identical results at 50 / 800 sweeps);
+    # the reference's friction is used for the resting-place check below.
+    w = sb_full.words.copy()
+    for c in range(*sb_full.meta['ranges']['bed']):
+        w.view(np.float32)[sb_full.h['OFF_COLL'] + c * L.C['STRIDE'] + L.C['FRICTION']] = 1.0
+    sb = ModelBlob(w, sb_full.meta)
     o = Oracle(sb)
     st = Stepper(sb, 8)
     assert st.variant() == 'bed_settle'
-    # (1) the fall, the arms pushed out of the torso, the first bed contacts: step for step against the f64 oracle
-    st.set_state(states)
+    # single simulation steps from the f64 oracle's own trajectory -- in the air with the arms pushed out of the torso, at the
+    # impact (around step 20), through the settle: compared step by step the f32 / f64 trajectories cannot drift apart chaotically
     ref = states.copy()
-    st.settle(24)
-    got = st.get_state()
-    for i in range(8):
-        o.settle(ref[i], 24)
-    assert np.abs(got[:, :47] - ref[:, :47]).max() < 5e-4 and np.abs(got[:, 47:94] - ref[:, 47:94]).max() < 2e-2
-    # (2) single steps from the oracle's own trajectory through the settle: no chaotic drift in the comparison
-    for k in range(6):
+    worst = []
+    for k, advance in enumerate((0, 6, 6, 6, 2, 2, 2, 6, 10, 20, 30)):
         for i in range(8):
-            o.settle(ref[i], 10)
+            o.settle(ref[i], advance)
         st.set_state(ref)
         st.settle(1)
         got = st.get_state()
         nxt = ref.copy()
         for i in range(8):
             o.settle(nxt[i], 1)
-        assert np.abs(got[:, :47] - nxt[:, :47]).max() < 5e-5, k
-        assert np.abs(got[:, 47:94] - nxt[:, 47:94]).max() < 5e-3, k
+        dq, dqd = np.abs(got[:, :47] - nxt[:, :47]).max(), np.abs(got[:, 47:94] - nxt[:, 47:94]).max()
+        worst.append((float(dq), float(dqd)))
+        assert dq < 5e-5 and dqd < 2.5e-3, (k, worst)          # dq = dt * dqd
+    print('ragdoll single-step worst (dq, dqd):', max(w[0] for w in worst), max(w[1] for w in worst))
+    # the whole 100-step settle from the start with the reference's friction: same resting place, loosely (the trajectories are chaotic)
+    assert st.overflow_count() == 0
+    st.close()
+    o = Oracle(sb_full)
+    st = Stepper(sb_full, 8)
+    st.set_state(states)
+    st.settle(100)
+    got = st.get_state()
+    ref = states.copy()
+    for i in range(8):
+        o.settle(ref[i], 100)
+    assert np.abs(got[:, :3] - ref[:, :3]).max() < 0.02 and np.abs(got[:, 3:6] - ref[:, 3:6]).max() < 0.1
     assert st.overflow_count() == 0
     st.close()
 
@@ -300,3 +320,38 @@ def test_bed_vec_env_pool_is_settled(bed):
     for _ in range(3):
         obs, rew, done, info = env.step(torch.zeros(8, 7, device=obs.device))
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+
+
+def test_gjk_flat_tetrahedron_regression(bed):
+    """tests/golden/settle_forearm_on_mattress_edge.npy (bed friction 1, captured by tools/gpu_settle_diag.py): the forearm lies along
+    the mattress edge, 4 cm clear of that hull's core.  The device's GJK used to report an enclosed origin for the flat tetrahedron of
+    that pair (side tests decided by the rounding of contracted multiply-adds; the CPU emulator did not reproduce it) and the pair came
+    out 3.8 cm deep with normal +z.  An enclosure is now rejected while a separating plane is known."""
+    import os
+    import torch
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.libagx import Stepper
+    from assistive_gym_amd.model import compiler as L
+    from oracle_lib import Oracle
+    sb0 = ModelBlob.load('bed_settle')
+    w = sb0.words.copy()
+    for c in range(*sb0.meta['ranges']['bed']):
+        w.view(np.float32)[sb0.h['OFF_COLL'] + c * L.C['STRIDE'] + L.C['FRICTION']] = 1.0
+    sb = ModelBlob(w, sb0.meta)
+    s = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'settle_forearm_on_mattress_edge.npy'))
+    st = Stepper(sb, 2)
+    lay = st.debug_layout()
+    dbg = torch.zeros(2, lay[0], device='cuda')
+    st.set_state(np.stack([s, s]))
+    st.settle_debug(1, dbg)
+    torch.cuda.synchronize()
+    got = st.get_state()[0]
+    D = dbg.cpu().numpy()[0]
+    nc = int(D[0])
+    ce = D[lay[1]:lay[1] + 1024].reshape(64, 16)[:nc]
+    ref = s.copy()
+    con = Oracle(sb).substep_debug(ref)
+    assert [(int(x), int(y)) for x, y in ce.view(np.int32)[:, :2]] == [(int(c[0]), int(c[1])) for c in con]
+    assert (3, 97) in [(int(c[0]), int(c[1])) for c in con]
+    assert np.abs(ce[:, 13] - con[:, 11]).max() < 1e-5 and np.abs(ce[:, 10:13] - con[:, 8:11]).max() < 1e-3
+    assert np.abs(got[:47] - ref[:47]).max() < 2e-5
