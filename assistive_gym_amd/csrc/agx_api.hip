@@ -36,6 +36,15 @@ agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* don
   if (threadIdx.x == 0) episode[env] = ep;
 }
 
+// ... and, for models with a cloth, the garment that belongs to that pool record (launched after agx_reset_kernel: episode[] is already advanced)
+extern "C" __global__ void __launch_bounds__(256)
+agx_reset_cloth_kernel(float* cloth, const float* pool, int pool_n, const uint8_t* done, const int* episode, int n_envs, int cw, long long env_offset) {
+  const int env = blockIdx.x;
+  if (env >= n_envs || !done[env]) return;
+  const float* src = pool + (size_t)((env_offset + env + 977 * (long long)episode[env]) % pool_n) * cw;
+  for (int k = threadIdx.x; k < cw; k += 256) cloth[(size_t)env * cw + k] = src[k];
+}
+
 extern "C" __global__ void __launch_bounds__(64) agx_selftest_kernel(float* out_f, int* out_i, unsigned long long* out_m) {
   const int lane = wave_lane();
   float x = (float)(lane * lane % 17) * 0.25f - 1.0f;
@@ -65,6 +74,11 @@ struct agx_handle_s {
   float* scratch_dev;   // [n_envs][SCR_WORDS]: rows, predicted velocities, contacts handed between the kernels
   int* episode_dev;
   int frame_skip;
+  int sim_sub;          // internal substeps per p.stepSimulation() (AGX_H_SIM_SUBSTEPS)
+  // models with a cloth section (DressingBaxter): garments [n_envs][2][NN][3], the link frames of every substep of an env step for the
+  // cloth kernel, its report to the finish kernel, and the garments of the reset pool (agx_set_cloth_pool)
+  int cloth_nn, cloth_words, trace_words, report_words, cloth_lds;
+  float *cloth_dev, *trace_dev, *report_dev; const float* cloth_pool_dev;
   bool can_sample;      // the variant has a reset generator (agx_reset.h) and the blob fits it
   const uint8_t* active;// per-env mask honoured by the build / solve launches (agx_reset's masked settle), normally null
   // staging for the *_host convenience calls
@@ -80,7 +94,7 @@ struct agx_handle_s {
 
 extern "C" {
 
-const char* agx_version(void) { return "libagx 0.2 (gfx950, wave-per-env stepper; variants: feeding, bed_bathing, scratch_itch, bed_settle)"; }
+const char* agx_version(void) { return "libagx 0.2 (gfx950, wave-per-env stepper; variants: feeding, bed_bathing, scratch_itch, bed_settle, dressing)"; }
 const char* agx_last_error(void) { return g_err.c_str(); }
 int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int agx_lds_bytes_per_env(void) { return agx_variant_feeding()->lds_bytes; }
@@ -94,7 +108,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   const agx_variant* V = nullptr;
   {
     // the first (smallest) variant with the model's task layer whose limits hold the model
-    const agx_variant* all[4] = {agx_variant_feeding(), agx_variant_bed_bathing(), agx_variant_scratch_itch(), agx_variant_bed_settle()};
+    const agx_variant* all[5] = {agx_variant_feeding(), agx_variant_bed_bathing(), agx_variant_scratch_itch(), agx_variant_bed_settle(), agx_variant_dressing()};
     bool task_seen = false;
     for (const agx_variant* v : all) {
       if (v->task_kind != hi[AGX_H_TASK_KIND]) continue;
@@ -141,6 +155,20 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   h->collision_tries = can_sample ? hi[hi[AGX_H_OFF_RESET] + AGX_X_COLLISION_TRIES] : 0;
   HIPCHK(hipMalloc(&h->first_restart_dev, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&h->chosen_dev, (size_t)n_envs * 4)); HIPCHK(hipMalloc(&h->work_dev, (size_t)n_envs));
   h->frame_skip = (int)((const float*)blob)[hi[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
+  h->sim_sub = hi[AGX_H_SIM_SUBSTEPS] > 1 ? hi[AGX_H_SIM_SUBSTEPS] : 1;
+  if (hi[AGX_H_OFF_CLOTH]) {
+    if (!V->cloth) { delete h; return fail(AGX_E_LIMIT, "agx_create: the model has a cloth but the kernel variant of its task has no cloth kernel"); }
+    const int32_t* cl = hi + hi[AGX_H_OFF_CLOTH];
+    h->cloth_nn = cl[AGX_CL_NN];
+    h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn);
+    h->trace_words = h->frame_skip * h->sim_sub * hi[AGX_H_NDOF] * 12;
+    h->cloth_lds = 4 * (6 * h->cloth_nn + 12 * 64 + 6 * 192 + 192 + 4 + 6 * (AGX_CLOTH_THREADS / 64) + 4);   // agxc::lds_words
+    if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4 * AGX_CLOTH_THREADS || cl[AGX_CL_NCOLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_MAX_LINKS_PER_COLOR] > AGX_CLOTH_THREADS ||
+        cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + 2 > 64 || cl[AGX_CL_NN] > 65535 || hi[AGX_H_NFREE] != 0) { delete h; return fail(AGX_E_LIMIT, "agx_create: cloth exceeds the limits of the cloth kernel"); }
+    HIPCHK(hipMalloc(&h->cloth_dev, (size_t)n_envs * h->cloth_words * 4)); HIPCHK(hipMemset(h->cloth_dev, 0, (size_t)n_envs * h->cloth_words * 4));
+    HIPCHK(hipMalloc(&h->trace_dev, (size_t)n_envs * h->trace_words * 4)); HIPCHK(hipMemset(h->trace_dev, 0, (size_t)n_envs * h->trace_words * 4));
+    HIPCHK(hipMalloc(&h->report_dev, (size_t)n_envs * h->report_words * 4)); HIPCHK(hipMemset(h->report_dev, 0, (size_t)n_envs * h->report_words * 4));
+  }
   HIPCHK(hipMalloc(&h->episode_dev, (size_t)n_envs * 4));
   HIPCHK(hipMemset(h->episode_dev, 0, (size_t)n_envs * 4));
   HIPCHK(hipMalloc(&h->act_dev, (size_t)n_envs * h->act_dim * 4));
@@ -169,6 +197,7 @@ void agx_destroy(agx_handle h) {
   hipSetDevice(h->device);
   hipFree(h->scratch_dev); hipFree(h->overflow_dev); hipFree(h->first_restart_dev); hipFree(h->chosen_dev); hipFree(h->work_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
   hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
+  if (h->cloth_dev) { hipFree(h->cloth_dev); hipFree(h->trace_dev); hipFree(h->report_dev); }
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   for (int c = 0; c < 8; c++) for (int k = 0; k < 16; k++) hipEventDestroy(h->kev[c][k]);
   hipEventDestroy(h->fork_ev); for (int k = 0; k < h->n_chunks; k++) { hipStreamDestroy(h->cs[k]); hipEventDestroy(h->join_ev[k]); }
@@ -197,10 +226,10 @@ int agx_get_state(agx_handle h, float* host_states) {
 int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fail(AGX_E_ARG, "agx_state_dev: bad argument"); *out_dev = h->state_dev; return AGX_OK; }
 
 // one p.stepSimulation() for the environments [e0, e0+ne): build + solve
-static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st) {
-  h->V->build(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active, h->overflow_dev);
+static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st, int phase) {
+  h->V->build(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active, h->overflow_dev, h->trace_dev, h->trace_words, phase);
   HIPCHK(hipGetLastError());
-  h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active);
+  h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active, phase);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -216,9 +245,19 @@ static int launch_chunked(agx_handle h, int n_substeps, const float* act, float*
     if (ne <= 0) continue;
     hipStream_t st = nc == 1 ? user : h->cs[c];
     if (nc > 1) HIPCHK(hipStreamWaitEvent(st, h->fork_ev, 0));
-    for (int k = 0; k < n_substeps; k++) { int rc = launch_substep(h, (k == 0) ? act : nullptr, (k == 0) ? dbg : nullptr, e0, ne, st); if (rc) return rc; }
+    // n_substeps counts p.stepSimulation() calls, each sim_sub internal substeps long.  With a cloth, the rigid substeps of up to frame_skip
+    // calls run first (leaving their link frames in the trace), then one cloth launch replays them (one-way coupling, agx_cloth.h).
+    for (int g0 = 0; g0 < n_substeps; g0 += h->frame_skip) {
+      const int gs = n_substeps - g0 < h->frame_skip ? n_substeps - g0 : h->frame_skip, nsub = gs * h->sim_sub;
+      for (int k = 0; k < nsub; k++) { const bool first = g0 == 0 && k == 0; int rc = launch_substep(h, first ? act : nullptr, first ? dbg : nullptr, e0, ne, st, k); if (rc) return rc; }
+      if (h->cloth_dev) {
+        h->V->cloth(st, ne, h->blob_dev, h->state_dev, h->trace_dev, h->cloth_dev, h->report_dev, e0, h->n_envs, h->sw, h->trace_words, h->cloth_words, h->report_words, nsub,
+                    h->active, h->cloth_lds);
+        HIPCHK(hipGetLastError());
+      }
+    }
     if (finish) {
-      h->V->finish(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
+      h->V->finish(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, h->report_dev, h->report_words);
       HIPCHK(hipGetLastError());
     }
     if (nc > 1) { HIPCHK(hipEventRecord(h->join_ev[c], st)); HIPCHK(hipStreamWaitEvent(user, h->join_ev[c], 0)); }
@@ -246,7 +285,7 @@ int agx_step_debug(agx_handle h, const float* a, float* obs, float* rew, uint8_t
 }
 int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t* done, float* info, void* stream, float* ms3, int* launches3) {
   if (!h || !a || !obs || !rew || !done || !ms3) return fail(AGX_E_ARG, "agx_step_timed: bad argument");
-  if (2 * h->frame_skip + 2 > 16) return fail(AGX_E_LIMIT, "agx_step_timed: frame_skip too large");
+  if (2 * h->frame_skip * h->sim_sub + 2 > 16 || h->cloth_dev) return fail(AGX_E_LIMIT, "agx_step_timed: too many launches per step for the event table (frame_skip x substeps), or a model with a cloth");
   HIPCHK(hipSetDevice(h->device));
   // the same chunked launch sequence as agx_step, with an event after every launch on its chunk stream
   hipStream_t user = (hipStream_t)stream;
@@ -261,12 +300,12 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
     int e = 0;
     HIPCHK(hipEventRecord(h->kev[c][e++], st));
     for (int k = 0; k < h->frame_skip; k++) {
-      h->V->build(st, ne, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr, h->overflow_dev);
+      h->V->build(st, ne, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr, h->overflow_dev, nullptr, 0, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
-      h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr);
+      h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
     }
-    h->V->finish(st, ne, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim);
+    h->V->finish(st, ne, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, nullptr, 0);
     HIPCHK(hipEventRecord(h->kev[c][e++], st));
     HIPCHK(hipGetLastError());
     nev[c] = e;
@@ -304,7 +343,7 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
   // of `collision_tries` rounds (no host round trip): the kernels of a round exit at once for the environments that are settled.
   for (int t = 0; t < h->collision_tries; t++) {
     const uint8_t* active = t == 0 ? mask_dev : h->work_dev;
-    h->V->build(st, h->n_envs, h->blob_dev, h->state_dev, nullptr, h->scratch_dev, nullptr, 0, h->n_envs, h->sw, h->act_dim, active, h->overflow_dev);
+    h->V->build(st, h->n_envs, h->blob_dev, h->state_dev, nullptr, h->scratch_dev, nullptr, 0, h->n_envs, h->sw, h->act_dim, active, h->overflow_dev, nullptr, 0, 0);
     HIPCHK(hipGetLastError());
     h->V->verdict(st, h->n_envs, h->blob_dev, h->scratch_dev, active, h->work_dev, h->first_restart_dev, h->chosen_dev);
     HIPCHK(hipGetLastError());
@@ -330,9 +369,33 @@ int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, 
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {
   if (!h || !pool_dev || pool_n <= 0 || !done_dev) return fail(AGX_E_ARG, "agx_reset_done: bad argument");
   HIPCHK(hipSetDevice(h->device));
+  if (h->cloth_dev && !h->cloth_pool_dev) return fail(AGX_E_ARG, "agx_reset_done: the model has a cloth; give the garments of the pool with agx_set_cloth_pool first");
   hipLaunchKernelGGL(agx_reset_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->state_dev, pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->sw, h->env_offset);
   HIPCHK(hipGetLastError());
+  if (h->cloth_dev) {
+    hipLaunchKernelGGL(agx_reset_cloth_kernel, dim3(h->n_envs), dim3(256), 0, (hipStream_t)stream, h->cloth_dev, h->cloth_pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->cloth_words, h->env_offset);
+    HIPCHK(hipGetLastError());
+  }
   return AGX_OK;
+}
+// ---- garments of models with a cloth section: float[n_envs][2][NN][3], node positions then node velocities
+int agx_cloth_nodes(agx_handle h, int* nodes) { if (!h || !nodes) return fail(AGX_E_ARG, "agx_cloth_nodes: bad argument"); *nodes = h->cloth_nn; return AGX_OK; }
+int agx_set_cloth(agx_handle h, const float* host_cloth) {
+  if (!h || !host_cloth || !h->cloth_dev) return fail(AGX_E_ARG, "agx_set_cloth: bad argument or a model without a cloth");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(h->cloth_dev, host_cloth, (size_t)h->n_envs * h->cloth_words * 4, hipMemcpyHostToDevice));
+  return AGX_OK;
+}
+int agx_get_cloth(agx_handle h, float* host_cloth) {
+  if (!h || !host_cloth || !h->cloth_dev) return fail(AGX_E_ARG, "agx_get_cloth: bad argument or a model without a cloth");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemcpy(host_cloth, h->cloth_dev, (size_t)h->n_envs * h->cloth_words * 4, hipMemcpyDeviceToHost));
+  return AGX_OK;
+}
+int agx_cloth_dev(agx_handle h, float** out_dev) { if (!h || !out_dev || !h->cloth_dev) return fail(AGX_E_ARG, "agx_cloth_dev: bad argument or a model without a cloth"); *out_dev = h->cloth_dev; return AGX_OK; }
+int agx_set_cloth_pool(agx_handle h, const float* pool_cloth_dev) {
+  if (!h || !h->cloth_dev) return fail(AGX_E_ARG, "agx_set_cloth_pool: bad argument or a model without a cloth");
+  h->cloth_pool_dev = pool_cloth_dev; return AGX_OK;
 }
 
 int agx_set_env_offset(agx_handle h, long long env_offset) {

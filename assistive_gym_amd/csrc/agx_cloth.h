@@ -1,0 +1,284 @@
+// agx_cloth.h -- the garment of DressingEnv (dressing.py:149-157,184): one WORKGROUP of AGX_CLOTH_THREADS threads per environment,
+// node positions x and start-of-substep positions q of all 3,966 nodes resident in LDS (95 KB: one workgroup per CU) for ALL
+// internal substeps of an env step; the velocities are implicit between substeps (v = (x - q)(1 - kDP) / dt).
+//
+// Coupling is one way (see oracle/agx_oracle.c, cloth_substep, which this file follows step for step): the cloth sees the rigid
+// bodies where each substep starts -- the build kernel leaves the world frames of the moving links of every substep in the
+// per-environment trace -- and the rigid bodies do not feel the cloth.  The rigid substeps of an env step therefore all run
+// first, then this kernel replays their poses: x and q are read from and written to HBM once per env step (95 KB each way)
+// instead of once per substep.
+//
+// Per substep: (a) body frames, shape boxes (world AABB grown by the margin) and the attachment point into LDS; the shapes whose
+// box meets the cloth's bounding box form the candidate list, in shape order; (b) per node: normal from the incident faces,
+// gravity, clamped aerodynamic drag, q = x, x += v dt; (c) per node: contacts with the candidate shapes (capsule / sphere cores
+// exactly, hulls through their face planes), at most AGX_CLOTH_NODE_CONTACTS per node, kept in registers -- a node's contacts
+// only move that node; (d) piterations x [anchors, rigid contacts, links colour class by colour class] with a workgroup barrier
+// between phases.  A thread owns nodes tid, tid + T, tid + 2T, ... and, per colour class, link number tid of that class (its
+// two node indices and rest length squared stay in registers for the whole launch).
+#pragma once
+#include "../../include/agx_blob.h"
+
+namespace agxc {
+
+constexpr int T = AGX_CLOTH_THREADS;
+constexpr int NPT = 4;                    // nodes per thread: ceil(3966 / 1024)
+constexpr int NODE_CONTACTS = 2;          // AGX_CLOTH_NODE_CONTACTS: contacts kept per node (the first ones in shape order)
+constexpr int MAX_BODIES = 64, MAX_SHAPES = 192;
+constexpr float EPS = 1.1920929e-7f;      // SIMD_EPSILON
+
+struct f3 { float x, y, z; };
+__device__ inline f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ inline f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ inline f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ inline f3 operator*(float s, f3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ inline float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ inline f3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ inline void st(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+// R (row major, 9 floats) times v, and R^T times v
+__device__ inline f3 rot(const float* R, f3 v) { return mk(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z); }
+__device__ inline f3 rot_t(const float* R, f3 v) { return mk(R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z); }
+__device__ inline void quat_to_mat(const float* q, float* R) {
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// LDS layout (floats)
+struct Lds {
+  float* x; float* q;            // [NN][3] each
+  float* body;                   // [MAX_BODIES][12]: p(3), R(9); index: moving link d, ndof = robot base, ndof + 1 + h = human body h, last = world
+  float* box;                    // [MAX_SHAPES][6] world AABB of the shape grown by the margin
+  int* cand; int* ncand;         // candidate shapes of this substep, in shape order
+  float* red;                    // [16 waves][6] bounding-box reduction
+  float* anchor;                 // [3]
+};
+constexpr int lds_words(int nn) { return 6 * nn + 12 * MAX_BODIES + 6 * MAX_SHAPES + MAX_SHAPES + 4 + 6 * (T / 64) + 4; }
+
+__device__ inline int body_slot(int code, int ndof, int nhuman) {
+  if (code == AGX_BODY_WORLD) return ndof + 1 + nhuman;
+  if (code >= AGX_BODY_HUMAN0) return ndof + 1 + (code - AGX_BODY_HUMAN0);
+  if (code == AGX_BODY_ROBOT_BASE) return ndof;
+  return code;                   // moving link (the dressing scene has no free bodies)
+}
+
+// signed distance of world point x to the surface of shape `sh` (negative inside) and the outward normal, world frame
+__device__ inline float shape_distance(const int* bi, const float* bf, const int* cl, const float* clf, const Lds& S, int sh, f3 x, int ndof, int nhuman, f3& nw) {
+  const int o_coll = bi[AGX_H_OFF_COLL], o_vert = bi[AGX_H_OFF_VERT];
+  const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * sh;
+  const int c = rec[0], p0 = rec[1], np = rec[2];
+  const int* ci = bi + o_coll + c * AGX_C_STRIDE; const float* cf = bf + o_coll + c * AGX_C_STRIDE;
+  const float* B = S.body + 12 * body_slot(ci[AGX_C_BODY], ndof, nhuman);
+  const f3 xl = rot_t(B + 3, x - ld(B));
+  const float rad = cf[AGX_C_RADIUS];
+  f3 nl; float dist;
+  if (np == 0) {
+    const float* v = bf + o_vert + 3 * ci[AGX_C_VOFF];
+    const f3 a = ld(v); f3 cp = a;
+    if (ci[AGX_C_NVERT] == 2) {
+      const f3 ab = ld(v + 3) - a, ax = xl - a; const float l2 = dot(ab, ab);
+      float t = l2 > 0.f ? dot(ax, ab) / l2 : 0.f; t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+      cp = a + t * ab;
+    }
+    nl = xl - cp; const float len = sqrtf(dot(nl, nl));
+    if (len > 1e-12f) nl = (1.0f / len) * nl; else nl = mk(0.f, 0.f, 1.f);
+    dist = len - rad;
+  } else {
+    const float* P = clf + cl[AGX_CL_OFF_PLANE] + 4 * p0;
+    int best = 0; float bd = -3.0e38f;
+    for (int k = 0; k < np; k++) { const float t = P[4 * k] * xl.x + P[4 * k + 1] * xl.y + P[4 * k + 2] * xl.z - P[4 * k + 3]; if (t > bd) { bd = t; best = k; } }
+    nl = mk(P[4 * best], P[4 * best + 1], P[4 * best + 2]);
+    dist = bd - rad;
+  }
+  nw = rot(B + 3, nl);
+  return dist;
+}
+
+struct Contact { f3 n; float offset, c3; f3 imp; };
+
+// one env step of the garment: `nsub` internal substeps, substep k reading the link frames of trace slot k.
+// gcloth: float[2][NN][3] positions then velocities (in/out); greport: see agx_blob.h AGX_CLOTH_REPORT (written after the last substep)
+__device__ inline void cloth_env(const uint32_t* blob, const float* gstate, const float* gtrace, float* gcloth, float* greport, int nsub, float* lds) {
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int oc = bi[AGX_H_OFF_CLOTH]; const int* cl = bi + oc; const float* clf = bf + oc;
+  const int NN = cl[AGX_CL_NN], NCOL = cl[AGX_CL_NCOLOR], NA = cl[AGX_CL_NANCHOR], NS = cl[AGX_CL_NSHAPE];
+  const int ndof = bi[AGX_H_NDOF], nhuman = bi[AGX_H_NHUMAN], S_ = bi[AGX_H_SIM_SUBSTEPS] > 1 ? bi[AGX_H_SIM_SUBSTEPS] : 1;
+  const float* par = clf + cl[AGX_CL_OFF_PARAM];
+  const float dt = bf[bi[AGX_H_OFF_PARAMS] + AGX_P_DT] / (float)S_;
+  const float kLST = par[AGX_CP_KLST], kDP = par[AGX_CP_KDP], kDG = par[AGX_CP_KDG], kDF = par[AGX_CP_KDF], kCHR = par[AGX_CP_KCHR], kAHR = par[AGX_CP_KAHR];
+  const float mrg = par[AGX_CP_MARGIN], im = par[AGX_CP_NODE_IM], rho = par[AGX_CP_AIR_DENSITY]; const int piter = (int)par[AGX_CP_PITER];
+  const int s_env = bi[AGX_H_S_ENV], s_task = bi[AGX_H_S_TASK];
+  const int gender = ((const int*)gstate)[s_env + AGX_E_GENDER];
+  const float grav = gstate[s_task + AGX_DR_CLOTH_GRAVITY];
+  Lds S; S.x = lds; S.q = S.x + 3 * NN; S.body = S.q + 3 * NN; S.box = S.body + 12 * MAX_BODIES; S.cand = (int*)(S.box + 6 * MAX_SHAPES);
+  S.ncand = S.cand + MAX_SHAPES; S.red = (float*)(S.ncand + 4); S.anchor = S.red + 6 * (T / 64);
+  const int* nodei = cl + cl[AGX_CL_OFF_NODE]; const float* nodef = clf + cl[AGX_CL_OFF_NODE];
+  const int* face = cl + cl[AGX_CL_OFF_FACE];
+  const int* anci = cl + cl[AGX_CL_OFF_ANCHOR]; const float* ancf = clf + cl[AGX_CL_OFF_ANCHOR];
+  const int* color = cl + cl[AGX_CL_OFF_COLOR];
+  // this thread's link of every colour class (registers)
+  int lk[AGX_CLOTH_MAX_COLORS]; float lrest[AGX_CLOTH_MAX_COLORS];
+#pragma unroll
+  for (int c = 0; c < AGX_CLOTH_MAX_COLORS; c++) {
+    lk[c] = -1; lrest[c] = 0.f;
+    if (c < NCOL) { const int l = color[c] + tid; if (l < color[c + 1]) { lk[c] = cl[cl[AGX_CL_OFF_LINK] + 2 * l]; lrest[c] = clf[cl[AGX_CL_OFF_LINK] + 2 * l + 1]; } }
+  }
+  // static frames: robot base, human bodies, world; load x, and q := x - v dt / (1 - kDP) so that the implicit velocity of the first substep is v
+  if (tid == 0) {
+    float* B = S.body + 12 * ndof; const float* r = gstate + bi[AGX_H_S_BASE]; st(B, ld(r)); quat_to_mat(r + 3, B + 3);
+    float* W = S.body + 12 * (ndof + 1 + nhuman); st(W, mk(0.f, 0.f, 0.f)); W[3] = 1; W[4] = 0; W[5] = 0; W[6] = 0; W[7] = 1; W[8] = 0; W[9] = 0; W[10] = 0; W[11] = 1;
+  }
+  if (tid >= 64 && tid < 64 + nhuman) { const int h = tid - 64; float* B = S.body + 12 * (ndof + 1 + h); const float* r = gstate + bi[AGX_H_S_HUMAN] + 7 * h; st(B, ld(r)); quat_to_mat(r + 3, B + 3); }
+  const float vscale = dt / (1.0f - kDP);
+  for (int k = tid; k < 3 * NN; k += T) { const float xv = gcloth[k]; S.x[k] = xv; S.q[k] = xv - gcloth[3 * NN + k] * vscale; }
+  bool attached[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; j++) { const int i = tid + j * T; attached[j] = false; for (int a = 0; a < NA; a++) if (anci[4 * a] == i) attached[j] = true; }
+  Contact con[NPT][NODE_CONTACTS]; int ncon[NPT];
+  __syncthreads();
+  for (int sub = 0; sub < nsub; sub++) {
+    // (a) frames of the moving links at the start of this substep; attachment point at the start of the current stepSimulation call
+    const float* tr = gtrace + (size_t)sub * ndof * 12;
+    for (int k = tid; k < 12 * ndof; k += T) S.body[k] = tr[k];
+    __syncthreads();
+    if (sub % S_ == 0 && tid == 0) {     // end-effector frame origin = link frame * EE_POS (dressing.py:200-210)
+      const int ot = bi[AGX_H_OFF_TASK]; const float* B = S.body + 12 * bi[ot + AGX_T_EE_LINK];
+      st(S.anchor, ld(B) + rot(B + 3, ld(bf + ot + AGX_T_EE_POS)));
+    }
+    // cloth bounding box
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int j = 0; j < NPT; j++) { const int i = tid + j * T; if (i < NN) for (int a = 0; a < 3; a++) { const float v = S.x[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); } }
+    for (int a = 0; a < 3; a++) for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+    if (lane == 0) for (int a = 0; a < 3; a++) { S.red[6 * wave + a] = lo[a]; S.red[6 * wave + 3 + a] = hi[a]; }
+    // shape boxes: world AABB of the collider (core box rotated + radius) grown by the margin
+    if (tid < NS) {
+      const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * tid; const int c = rec[0];
+      const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
+      const float* B = S.body + 12 * body_slot(ci[AGX_C_BODY], ndof, nhuman);
+      const f3 cw = ld(B) + rot(B + 3, ld(cf + AGX_C_AABB_C)); const f3 h = ld(cf + AGX_C_AABB_H); const float r = cf[AGX_C_RADIUS] + mrg + 1e-6f;
+      const float* R = B + 3;
+      const float hx = fabsf(R[0]) * h.x + fabsf(R[1]) * h.y + fabsf(R[2]) * h.z + r, hy = fabsf(R[3]) * h.x + fabsf(R[4]) * h.y + fabsf(R[5]) * h.z + r,
+                  hz = fabsf(R[6]) * h.x + fabsf(R[7]) * h.y + fabsf(R[8]) * h.z + r;
+      float* bx = S.box + 6 * tid; bx[0] = cw.x - hx; bx[1] = cw.y - hy; bx[2] = cw.z - hz; bx[3] = cw.x + hx; bx[4] = cw.y + hy; bx[5] = cw.z + hz;
+    }
+    __syncthreads();
+    if (wave == 0) {                     // candidate list: shapes of this gender whose box meets the cloth's, in shape order
+      float clo[3], chi[3];
+      for (int a = 0; a < 3; a++) { clo[a] = S.red[a]; chi[a] = S.red[3 + a]; for (int w = 1; w < T / 64; w++) { clo[a] = fminf(clo[a], S.red[6 * w + a]); chi[a] = fmaxf(chi[a], S.red[6 * w + 3 + a]); } }
+      int n = 0;
+      for (int base = 0; base < NS; base += 64) {
+        const int sh = base + lane; bool ok = sh < NS;
+        if (ok) { const int only = cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh + 3]; if (only && only != gender + 1) ok = false; }
+        if (ok) { const float* bx = S.box + 6 * sh; for (int a = 0; a < 3; a++) if (bx[a] > chi[a] || bx[3 + a] < clo[a]) ok = false; }
+        const unsigned long long m = __ballot(ok);
+        if (ok) S.cand[n + __popcll(m & ((1ull << lane) - 1ull))] = sh;
+        n += __popcll(m);
+      }
+      if (lane == 0) *S.ncand = n;
+    }
+    // (b) forces and prediction (normals read every node's position before any is moved: two passes with a barrier)
+    f3 vnew[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+      const int i = tid + j * T; vnew[j] = mk(0.f, 0.f, 0.f);
+      if (i < NN) {
+        const f3 xi = ld(S.x + 3 * i);
+        f3 nrm = mk(0.f, 0.f, 0.f);
+        for (int e = nodei[2 * i]; e < nodei[2 * i + 2]; e++) { const int fe = face[e]; nrm = nrm + cross(ld(S.x + 3 * (fe & 0xffff)) - xi, ld(S.x + 3 * ((fe >> 16) & 0xffff)) - xi); }
+        const float nl = sqrtf(dot(nrm, nrm)); if (nl > EPS) nrm = (1.0f / nl) * nrm;
+        f3 v = ((1.0f - kDP) / dt) * (xi - ld(S.q + 3 * i));
+        v.z += grav * dt;
+        const float v2 = dot(v, v);
+        if (kDG > 0.f && v2 > EPS) {
+          const float dvn = dot(v, nrm);
+          if (dvn > 0.f) {
+            const float fmag = nodef[2 * i + 1] * dvn * v2 * 0.5f * rho * kDG, dtim = dt * im;
+            if (fmag * dtim * fmag * dtim > v2) v = mk(0.f, 0.f, 0.f); else v = v - (fmag * dtim / sqrtf(v2)) * v;
+          }
+        }
+        vnew[j] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPT; j++) { const int i = tid + j * T; if (i < NN) { const f3 xi = ld(S.x + 3 * i); st(S.q + 3 * i, xi); st(S.x + 3 * i, xi + dt * vnew[j]); } }
+    __syncthreads();
+    // (c) contacts of this thread's nodes (CollideSDF_RS::DoNode)
+    const int ncand = *S.ncand;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+      const int i = tid + j * T; ncon[j] = 0;
+      if (i < NN && !attached[j]) {
+        const f3 xi = ld(S.x + 3 * i), qi = ld(S.q + 3 * i);
+        for (int k = 0; k < ncand && ncon[j] < NODE_CONTACTS; k++) {
+          const int sh = S.cand[k]; const float* bx = S.box + 6 * sh;
+          if (xi.x < bx[0] || xi.y < bx[1] || xi.z < bx[2] || xi.x > bx[3] || xi.y > bx[4] || xi.z > bx[5]) continue;
+          f3 nw; const float dst = shape_distance(bi, bf, cl, clf, S, sh, xi, ndof, nhuman, nw) - mrg;
+          if (dst >= 0.f) continue;
+          Contact& c = con[j][ncon[j] == 0 ? 0 : 1]; ncon[j]++;
+          c.n = nw; c.offset = -dot(nw, xi) + dst; c.imp = mk(0.f, 0.f, 0.f);
+          const f3 vr = xi - qi; const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
+          const float fc = kDF * bf[bi[AGX_H_OFF_COLL] + cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh] * AGX_C_STRIDE + AGX_C_FRICTION];
+          c.c3 = dot(fv, fv) < (dn * fc * dn * fc) ? 0.f : 1.f - fc;
+        }
+      }
+    }
+    // (d) position solver
+    for (int it = 0; it < piter; it++) {
+      if (tid < NA) {                     // PSolve_Anchors
+        const int i = anci[4 * tid]; const f3 wa = ld(S.anchor) + ld(ancf + 4 * tid + 1), xi = ld(S.x + 3 * i), qi = ld(S.q + 3 * i);
+        st(S.x + 3 * i, xi + (-1.0f) * (xi - qi) + kAHR * (wa - xi));
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NPT; j++) {     // PSolve_RContacts
+        const int i = tid + j * T;
+        if (i < NN && ncon[j] > 0) {
+          f3 xi = ld(S.x + 3 * i); const f3 qi = ld(S.q + 3 * i);
+#pragma unroll
+          for (int cc = 0; cc < NODE_CONTACTS; cc++) if (cc < ncon[j]) {
+            Contact& c = con[j][cc];
+            const f3 vr = xi - qi; const float dn = dot(vr, c.n);
+            if (dn <= EPS) {
+              float dp = dot(xi, c.n) + c.offset; if (dp > mrg) dp = mrg;
+              const f3 fv = vr - dn * c.n, corr = vr - c.c3 * fv + (dp * kCHR) * c.n;
+              xi = xi - corr; c.imp = c.imp + (1.0f / (dt * im)) * corr;
+            }
+          }
+          st(S.x + 3 * i, xi);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < AGX_CLOTH_MAX_COLORS; c++) {   // PSolve_Links, one colour class at a time
+        if (c < NCOL) {
+          if (lk[c] >= 0) {
+            const int a = lk[c] & 0xffff, b = (lk[c] >> 16) & 0xffff;
+            const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = lrest[c];
+            if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+  // write back: positions, velocities of the last substep; report for the finish kernel
+  const float vc = (1.0f - kDP) / dt;
+  for (int k = tid; k < 3 * NN; k += T) { gcloth[k] = S.x[k]; gcloth[3 * NN + k] = (S.x[k] - S.q[k]) * vc; }
+  if (greport) {
+    if (tid < 6) st(greport + 3 * tid, ld(S.x + 3 * cl[AGX_CL_TRI + tid]));
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+      const int i = tid + j * T;
+      if (i < NN) for (int cc = 0; cc < NODE_CONTACTS; cc++) {
+        float* o = greport + 20 + 2 * (NODE_CONTACTS * i + cc);
+        if (nsub > 0 && cc < ncon[j]) { const f3 f = (1.0f / dt) * con[j][cc].imp; o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
+      }
+    }
+  }
+}
+
+}  // namespace agxc

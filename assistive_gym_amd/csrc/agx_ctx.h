@@ -119,7 +119,8 @@ struct Ctx {
   bool coop;            // the human is controllable (TASK.COOP)
   int o_params, o_robot, o_free, o_coll, o_vert, o_group, o_task, o_dirs;
   int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env;
-  float dt;
+  float dt;             // one internal substep: DT / SIM_SUBSTEPS
+  bool hooks;           // this substep ends a p.stepSimulation() call: the limit reset and the arm-limit classifier run (env.py:226-232)
   int ncon, nrows, first_normal, near_mask, overflow;
   float* gqpt; int nqpt;   // bed bathing: manifold points of the (wiping pad, human) pairs (bed_bathing.py:47-58), per-env scratch
   float* dbg;   // optional debug sink (parity tests)
@@ -156,7 +157,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_q = h[AGX_H_S_Q]; c.s_qd = h[AGX_H_S_QD]; c.s_qt = h[AGX_H_S_QT]; c.s_free = h[AGX_H_S_FREE]; c.s_base = h[AGX_H_S_BASE];
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
   c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
-  c.dt = PRM(c, AGX_P_DT);
+  c.dt = PRM(c, AGX_P_DT) / (float)(h[AGX_H_SIM_SUBSTEPS] > 1 ? h[AGX_H_SIM_SUBSTEPS] : 1); c.hooks = true;
   c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }

@@ -14,7 +14,7 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
     const int d = lane;
     float qd = L[L_VEL + d], q = L[L_ST + c.s_q + d] + dt * qd;
     // Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250)
-    if ((RBI(c, d, AGX_R_KIND) & 5) == 1 && !FROZEN(c, d)) {
+    if (c.hooks && (RBI(c, d, AGX_R_KIND) & 5) == 1 && !FROZEN(c, d)) {
       const float lo = DLO(c, d), hi = DHI(c, d);
       if (q < lo - AGX_LIMIT_EPS) { q = lo; qd = 0.f; } else if (q > hi + AGX_LIMIT_EPS) { q = hi; qd = 0.f; }
     }
@@ -41,7 +41,7 @@ AGX_DEV void integrate(Ctx& c, const float* gvel, float dv0, float dv1) {
 // is remembered; class 0: the four joints are put back to the last valid pose with zero velocity (set_joint_angles, agent.py:154-156).
 // lane = hidden unit; the activations of a layer are exchanged through 64 words of LDS (`X`, dead storage of the caller).
 AGX_DEV void arm_limits(Ctx& c, float* X) {
-  if (!TKI(c, AGX_T_ARM_LIMIT_ON)) return;
+  if (!TKI(c, AGX_T_ARM_LIMIT_ON) || !c.hooks) return;
   float* L = c.lds; int* Li = c.ldsi; const int lane = c.lane;
   const float* W1 = c.bf + c.bi[AGX_H_OFF_MLP]; const float* W2 = W1 + 4 * 64 + 64; const float* W3 = W2 + 64 * 64 + 64; const float* W4 = W3 + 64 * 64 + 64;
   const int s_task = c.bi[AGX_H_S_TASK];
@@ -254,7 +254,7 @@ AGX_DEV Scratch scratch_of(float* base) {
 
 // build: `gaction` non-null on the first substep of an env.step() (take_step, env.py:174-222)
 // returns the number of contacts dropped by a budget (contact, row or coefficient cap)
-AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gdebug, float* lds, int lane) {
+AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gdebug, float* lds, int lane, float* gtrace = nullptr) {
   Ctx c; ctx_init(c, blob, lds, lane);
   c.timing = gdebug != nullptr; c.dbg = gdebug;
   float* L = c.lds; int* Li = c.ldsi;
@@ -302,6 +302,8 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   long long t0 = c.timing ? wave_clock() : 0, t1;
 #define AGX_TICK(k) if (c.timing) { t1 = wave_clock(); c.tm[k] += t1 - t0; t0 = t1; }
   kinematics(c); AGX_TICK(0)
+  // models with a cloth: the world frames of the moving links where this substep starts, for the cloth kernel (one-way coupling)
+  if (gtrace) { for (int k = lane; k < 3 * c.ndof; k += 64) gtrace[12 * (k / 3) + k % 3] = L[L_LINKP + k]; for (int k = lane; k < 9 * c.ndof; k += 64) gtrace[12 * (k / 9) + 3 + k % 9] = L[L_LINKR + k]; }
   aba_and_minv(c); AGX_TICK(1)
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
@@ -322,8 +324,9 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
 }
 
 // solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
-AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane) {
+AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane, int phase = 0) {
   Ctx c; ctx_init(c, blob, lds, lane);
+  { const int S = c.bi[AGX_H_SIM_SUBSTEPS]; c.hooks = S <= 1 || (phase + 1) % S == 0; }   // phase: index of this substep within the env step
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
   c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
@@ -347,12 +350,14 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   if (gdebug && lane == 0) { gdebug[DBG_TIME + 5] = (float)(t1 - t0); gdebug[DBG_TIME + 6] = (float)(wave_clock() - t1); }
 }
 
+AGX_DEV void observe_dressing(const Ctx& c, float cloth_force_sum, float robot_force, float* gobs);
 AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float* lds, int lane) {
   Ctx c; ctx_init(c, blob, lds, lane);
   load_env(c, gstate, c.bi[AGX_H_STATE_WORDS]);
   kinematics(c); update_target(c);
   if constexpr (TASK == AGX_TASK_BED_BATHING) observe_bed(c, 0.f, 0.f, 0.f, gobs);
   else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) observe_scratch(c, 0.f, 0.f, 0.f, gobs);
+  else if constexpr (TASK == AGX_TASK_DRESSING) observe_dressing(c, c.lds[L_ST + c.bi[AGX_H_S_TASK] + AGX_DR_FORCE_SUM], 0.f, gobs);
   else observe(c, 0.f, 0.f, gobs);
 }
 
@@ -550,6 +555,129 @@ AGX_DEV void env_finish_scratch(const uint32_t* blob, float* gstate, const float
   store_env(c, gstate, sw);
 }
 
+
+// DressingEnv._get_obs (dressing.py:78-110); every lane computes, lane 0 writes
+AGX_DEV void observe_dressing(const Ctx& c, float cloth_force_sum, float robot_force, float* gobs) {
+  const float* L = c.lds;
+  const v3 bp = ld3(L + L_BASE); const m3 BR = ldm3(L + L_BASE + 3);
+  const v3 ep = ld3(L + L_MISC + M_EEP); const m3 eR = ldm3(L + L_MISC + M_EER);
+  const v3 epr = tmul(BR, ep - bp); const q4 eq = m3_to_quat(mul_at(BR, eR));
+  v3 jp[3], jpr[3];
+  for (int k = 0; k < 3; k++) { jp[k] = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + k)); jpr[k] = tmul(BR, jp[k] - bp); }
+  if (c.lane == 0) {
+    int o = 0;
+    gobs[o++] = epr.x; gobs[o++] = epr.y; gobs[o++] = epr.z;
+    gobs[o++] = eq.x; gobs[o++] = eq.y; gobs[o++] = eq.z; gobs[o++] = eq.w;
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+      float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
+      gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
+    }
+    for (int k = 0; k < 3; k++) { gobs[o++] = jpr[k].x; gobs[o++] = jpr[k].y; gobs[o++] = jpr[k].z; }
+    gobs[o++] = cloth_force_sum;
+    if (c.coop) {   // human_obs (dressing.py:100-106), in the frame of the human's base
+      const v3 hb = ld3(L + L_HUMAN); const m3 HR = ldm3(L + L_HUMAN + 3);
+      const v3 eph = tmul(HR, ep - hb); const q4 eqh = m3_to_quat(mul_at(HR, eR));
+      gobs[o++] = eph.x; gobs[o++] = eph.y; gobs[o++] = eph.z;
+      gobs[o++] = eqh.x; gobs[o++] = eqh.y; gobs[o++] = eqh.z; gobs[o++] = eqh.w;
+      for (int d = c.nrobot; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) gobs[o++] = L[L_ST + c.s_q + d];
+      for (int k = 0; k < 3; k++) { const v3 h = tmul(HR, jp[k] - hb); gobs[o++] = h.x; gobs[o++] = h.y; gobs[o++] = h.z; }
+      gobs[o++] = cloth_force_sum; gobs[o++] = robot_force;
+    }
+  }
+}
+AGX_DEV float signed_volume6(v3 a, v3 b, v3 c, v3 d) { return dot(cross(b - a, c - a), d - a); }   // 6 x the signed volume: only its sign is used
+AGX_DEV int sgnf(float x) { return (x > 0.f) - (x < 0.f); }
+// Util.line_intersects_triangle (util.py:125-132)
+AGX_DEV bool line_intersects_triangle(v3 p0, v3 p1, v3 p2, v3 q0, v3 q1) {
+  if (sgnf(signed_volume6(q0, p0, p1, p2)) == sgnf(signed_volume6(q1, p0, p1, p2))) return false;
+  const int a = sgnf(signed_volume6(q0, q1, p0, p1)), b = sgnf(signed_volume6(q0, q1, p1, p2)), cc = sgnf(signed_volume6(q0, q1, p2, p0));
+  return a == b && b == cc;
+}
+// do the six sleeve vertices straddle both planes through `origin` that contain the arm axis (util.py:144-171)?
+AGX_DEV bool points_around_axis(const v3* pts, v3 from, v3 to, v3 origin) {
+  v3 nrm = to - from; nrm = (1.0f / sqrtf(dot(nrm, nrm))) * nrm;
+  v3 tan = cross(mk3(1.f, 1.f, 0.f), nrm); tan = (1.0f / sqrtf(dot(tan, tan))) * tan;
+  v3 bin = cross(tan, nrm); bin = (1.0f / sqrtf(dot(bin, bin))) * bin;
+  bool tp = false, tn = false, bp = false, bn = false;
+  for (int i = 0; i < 6; i++) { const v3 d = pts[i] - origin; const float t = dot(tan, d), b = dot(bin, d); tp |= t > 0.f; tn |= t < 0.f; bp |= b > 0.f; bn |= b < 0.f; }
+  return tp && tn && bp && bn;
+}
+// finish, dressing: everything DressingEnv.step does after take_step (dressing.py:20-76).  greport: what the cloth kernel left for
+// this environment -- the six sleeve vertices and, per node and contact slot, {height, |force|} of the node-vs-rigid contacts of the last substep
+AGX_DEV void env_finish_dressing(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+                                 float* ginfo, float* lds, int lane, const float* greport) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS], act_dim = c.bi[AGX_H_ACT_DIM];
+  Scratch scr = scratch_of(gscratch);
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC];
+  load_env(c, gstate, sw);
+  float an2 = 0.f;
+  for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
+  wave_sync();
+  kinematics(c);
+  const int* cl = c.bi + c.bi[AGX_H_OFF_CLOTH]; const float* clp = c.bf + c.bi[AGX_H_OFF_CLOTH] + cl[AGX_CL_OFF_PARAM];
+  const v3 shoulder = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK)), elbow = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + 1)), wrist = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + 2));
+  v3 pts[6];
+  for (int k = 0; k < 6; k++) pts[k] = greport ? ld3(greport + 3 * k) : mk3(0.f, 0.f, 0.f);
+  // Util.sleeve_on_arm_reward (util.py:134-202)
+  const float rad = TKF(c, AGX_T_ARM_RADIUS + c.gender);
+  const v3 we = wrist - elbow, es = shoulder - elbow; const float lwe = sqrtf(dot(we, we)), les = sqrtf(dot(es, es));
+  const v3 hand_end = wrist + (rad * 2.f / lwe) * we, elbow_end = elbow - (rad / lwe) * we, shoulder_end = shoulder + (rad / les) * es;
+  const bool around_fore = points_around_axis(pts, elbow_end, hand_end, hand_end), around_upper = points_around_axis(pts, shoulder_end, elbow_end, shoulder_end);
+  const bool f1 = line_intersects_triangle(pts[0], pts[1], pts[2], hand_end, elbow_end), f2 = line_intersects_triangle(pts[3], pts[4], pts[5], hand_end, elbow_end);
+  const bool u1 = line_intersects_triangle(pts[0], pts[1], pts[2], elbow_end, shoulder_end), u2 = line_intersects_triangle(pts[3], pts[4], pts[5], elbow_end, shoulder_end);
+  v3 centre = mk3(0.f, 0.f, 0.f); for (int k = 0; k < 6; k++) centre = centre + (1.0f / 6.0f) * pts[k];
+  const v3 dh = hand_end - centre, de = centre - elbow, dfl = hand_end - elbow_end;
+  const float distance_to_hand = sqrtf(dot(dh, dh)), distance_along_forearm = distance_to_hand, distance_along_upperarm = sqrtf(dot(de, de));
+  const float forearm_length = sqrtf(dot(dfl, dfl)), upperarm_length = les;
+  const bool forearm_in = around_fore && (f1 || f2), upperarm_in = around_upper && (u1 || u2);
+  // cloth forces (dressing.py:34-46): x 10, only below the end effector and below 20
+  const v3 ep = ld3(L + L_MISC + M_EEP);
+  float fs = 0.f;
+  if (greport) {
+    const int entries = 2 * cl[AGX_CL_NN];   // AGX_CLOTH_NODE_CONTACTS slots per node
+    const float scale = clp[AGX_CP_FORCE_SCALE], fmax = clp[AGX_CP_FORCE_MAX], below = clp[AGX_CP_EE_BELOW];
+    for (int k = lane; k < entries; k += 64) {
+      const float z = greport[20 + 2 * k], f = greport[20 + 2 * k + 1] * scale;
+      if (f >= 0.f && z < ep.z - below && f < fmax) fs += f;
+    }
+  }
+  const float cloth_force_sum = wave_sum(fs);
+  const float ee_speed = ee_speed_of(c);
+  const float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_D) * (-cloth_force_sum);   // human_preferences(end_effector_velocity, dressing_forces)
+  float reward_dressing;
+  if (upperarm_in) { reward_dressing = forearm_length; if (distance_along_upperarm < upperarm_length) reward_dressing += distance_along_upperarm; }
+  else if (forearm_in && distance_along_forearm < forearm_length) reward_dressing = distance_along_forearm;
+  else reward_dressing = -distance_to_hand;
+  const float reward = TKF(c, AGX_T_W_WIPE) * reward_dressing + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + pref;
+  float rf = 0.f;
+  if (lane < c.ncon) {
+    const float* k = scr.con + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const int ta = CLI(c, ki[C_CA], AGX_C_TAG), tb = CLI(c, ki[C_CB], AGX_C_TAG);
+    if ((ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN) && (ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT)) rf = k[C_LAM] / c.dt;
+  }
+  const float robot_f = wave_sum(rf);
+  observe_dressing(c, cloth_force_sum, robot_f, gobs);
+  const int s_task = c.bi[AGX_H_S_TASK];
+  const float best0 = L[L_ST + s_task + AGX_DR_BEST], best = reward_dressing > best0 ? reward_dressing : best0;
+  const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];
+  wave_sync();
+  if (lane == 0) {
+    L[L_ST + s_task + AGX_DR_BEST] = best; L[L_ST + s_task + AGX_DR_FORCE_SUM] = cloth_force_sum;
+    *greward = reward;
+    *gdone = (uint8_t)(iteration >= (int)TKF(c, AGX_T_EPISODE_LEN));
+    if (ginfo) {
+      ginfo[AGX_INFO_TOTAL_FORCE] = robot_f + cloth_force_sum;
+      ginfo[AGX_INFO_TASK_SUCCESS] = (float)(best >= TKF(c, AGX_T_SUCCESS_FRAC));
+      ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = cloth_force_sum; ginfo[AGX_INFO_FOOD_REWARD] = reward_dressing;
+      ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
+    }
+  }
+  wave_sync();
+  store_env(c, gstate, sw);
+}
+
 // finish: everything FeedingEnv.step does after take_step (feeding.py:17-43)
 AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
                         float* ginfo, float* lds, int lane) {
@@ -662,8 +790,9 @@ AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float
 }
 
 AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
-                        float* ginfo, float* lds, int lane) {
-  if constexpr (TASK == AGX_TASK_BED_BATHING) env_finish_bed(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
+                        float* ginfo, float* lds, int lane, const float* greport = nullptr) {
+  if constexpr (TASK == AGX_TASK_DRESSING) env_finish_dressing(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane, greport);
+  else if constexpr (TASK == AGX_TASK_BED_BATHING) env_finish_bed(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) env_finish_scratch(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else env_finish_feeding(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
 }

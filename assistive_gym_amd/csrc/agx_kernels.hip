@@ -32,6 +32,15 @@
 #define AGX_TASK 2
 #define AGX_VNAME scratch_itch
 #define AGX_K(name) name##_si
+#elif defined(AGX_VARIANT_DRESSING)
+// DressingBaxter: Baxter's left arm (7 arm joints + 2 finger joints; the rest of the robot static) + the 10 joints of the human's left
+// arm, no free body; plus the cloth kernel (agx_cloth.h)
+#define AGX_MAX_DOF 20
+#define AGX_MAX_FREE 1
+#define AGX_MAX_BLOCK 10
+#define AGX_TASK 3
+#define AGX_VNAME dressing
+#define AGX_K(name) name##_dr
 #elif defined(AGX_VARIANT_FEEDING)
 #define AGX_VNAME feeding
 #define AGX_K(name) name
@@ -42,38 +51,54 @@
 #include "agx_wave.h"
 #include "agx_step.h"
 #include "agx_variant.h"
+#if AGX_TASK == 3
+#include "agx_cloth.h"
+#endif
 
 namespace {
 
 // build: kinematics, ABA, collision, constraint rows -> scratch.  Register- and LDS-heavy.
 extern "C" __global__ void __launch_bounds__(64, 2)
 AGX_K(agx_build_kernel)(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int env0, int n_envs, int sw, int act_dim,
-                        const uint8_t* __restrict__ active, int* overflow_total) {
+                        const uint8_t* __restrict__ active, int* overflow_total, float* trace, int trace_words, int phase) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = env0 + blockIdx.x;
   if (env >= n_envs || (active && !active[env])) return;   // `active`: masked settle of agx_reset, null on the step path
   const int dropped = agx::env_build(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
-                                     debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
+                                     debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x,
+                                     trace ? trace + (size_t)env * trace_words + (size_t)phase * 12 * ((const int*)blob)[AGX_H_NDOF] : nullptr);
   if (dropped > 0 && threadIdx.x == 0) atomicAdd(overflow_total, dropped);   // contacts dropped by a budget (rare; agx_overflow_count)
 }
 // solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
 extern "C" __global__ void __launch_bounds__(64, 4)
-AGX_K(agx_solve_kernel)(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active) {
+AGX_K(agx_solve_kernel)(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active, int phase) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = env0 + blockIdx.x;
   if (env >= n_envs || (active && !active[env])) return;
-  agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x);
+  agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x, phase);
 }
 // finish: forces, observation, task state machine, reward, done, info
 extern "C" __global__ void __launch_bounds__(64, 2)
 AGX_K(agx_finish_kernel)(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
-                         float* info, int env0, int n_envs, int sw, int act_dim, int obs_dim) {
+                         float* info, int env0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = env0 + blockIdx.x;
   if (env >= n_envs) return;
   agx::env_finish(blob, state + (size_t)env * sw, actions + (size_t)env * act_dim, scratch + (size_t)env * agx::SCR_WORDS, obs + (size_t)env * obs_dim,
-                  reward + env, done + env, info ? info + (size_t)env * AGX_INFO_COUNT : nullptr, lds, (int)threadIdx.x);
+                  reward + env, done + env, info ? info + (size_t)env * AGX_INFO_COUNT : nullptr, lds, (int)threadIdx.x,
+                  report ? report + (size_t)env * report_words : nullptr);
 }
+#if AGX_TASK == 3
+// the garment: one workgroup of AGX_CLOTH_THREADS threads per environment, positions resident in LDS for all substeps of the launch
+extern "C" __global__ void __launch_bounds__(AGX_CLOTH_THREADS)
+AGX_K(agx_cloth_kernel)(const uint32_t* __restrict__ blob, const float* __restrict__ state, const float* __restrict__ trace, float* cloth, float* report, int env0, int n_envs,
+                        int sw, int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* __restrict__ active) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = env0 + blockIdx.x;
+  if (env >= n_envs || (active && !active[env])) return;
+  agxc::cloth_env(blob, state + (size_t)env * sw, trace + (size_t)env * trace_words, cloth + (size_t)env * cloth_words, report ? report + (size_t)env * report_words : nullptr, nsub, lds);
+}
+#endif
 extern "C" __global__ void __launch_bounds__(64, 2)
 AGX_K(agx_observe_kernel)(const uint32_t* __restrict__ blob, float* state, float* obs, int n_envs, int sw, int obs_dim) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -111,19 +136,31 @@ hipError_t v_init(void) {
   hipError_t e = hipFuncSetAttribute((const void*)AGX_K(agx_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
+#if AGX_TASK == 3
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_cloth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
   return e;
 }
 void v_build(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* debug, int e0, int n_envs, int sw, int act_dim,
-             const uint8_t* active, int* overflow_total) {
-  hipLaunchKernelGGL(AGX_K(agx_build_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, debug, e0, n_envs, sw, act_dim, active, overflow_total);
+             const uint8_t* active, int* overflow_total, float* trace, int trace_words, int phase) {
+  hipLaunchKernelGGL(AGX_K(agx_build_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, debug, e0, n_envs, sw, act_dim, active, overflow_total,
+                     trace, trace_words, phase);
 }
-void v_solve(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active) {
-  hipLaunchKernelGGL(AGX_K(agx_solve_kernel), dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, blob, state, scratch, debug, e0, n_envs, sw, active);
+void v_solve(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase) {
+  hipLaunchKernelGGL(AGX_K(agx_solve_kernel), dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, blob, state, scratch, debug, e0, n_envs, sw, active, phase);
 }
 void v_finish(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done, float* info,
-              int e0, int n_envs, int sw, int act_dim, int obs_dim) {
-  hipLaunchKernelGGL(AGX_K(agx_finish_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, obs, reward, done, info, e0, n_envs, sw, act_dim, obs_dim);
+              int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words) {
+  hipLaunchKernelGGL(AGX_K(agx_finish_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, obs, reward, done, info, e0, n_envs, sw, act_dim, obs_dim,
+                     report, report_words);
 }
+#if AGX_TASK == 3
+void v_cloth(hipStream_t st, int ne, const uint32_t* blob, const float* state, const float* trace, float* cloth, float* report, int e0, int n_envs, int sw,
+             int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* active, int lds_bytes) {
+  hipLaunchKernelGGL(AGX_K(agx_cloth_kernel), dim3(ne), dim3(AGX_CLOTH_THREADS), lds_bytes, st, blob, state, trace, cloth, report, e0, n_envs, sw, trace_words, cloth_words,
+                     report_words, nsub, active);
+}
+#endif
 void v_observe(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim) {
   hipLaunchKernelGGL(AGX_K(agx_observe_kernel), dim3(n_envs), dim3(64), agx::LDS_BYTES, st, blob, state, obs, n_envs, sw, obs_dim);
 }
@@ -152,9 +189,19 @@ const agx_variant g_variant = {
 #endif
   v_init, v_build, v_solve, v_finish, v_observe,
 #if AGX_HAS_SAMPLER
-  v_sample, v_verdict
+  v_sample,
 #else
-  nullptr, nullptr
+  nullptr,
+#endif
+#if AGX_TASK == 3
+  v_cloth,
+#else
+  nullptr,
+#endif
+#if AGX_HAS_SAMPLER
+  v_verdict
+#else
+  nullptr
 #endif
 };
 

@@ -14,14 +14,19 @@ struct agx_variant {
   // one-time kernel attribute set-up (dynamic LDS sizes)
   hipError_t (*init)(void);
   // launchers: grid = ne workgroups of one wavefront, environments [e0, e0 + ne)
+  // phase: index of the substep within the env step (hooks after every SIM_SUBSTEPS-th, slot of the link-frame trace);
+  // trace: [n_envs][trace_words] link frames per substep for the cloth kernel, null for models without a cloth
   void (*build)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* debug, int e0, int n_envs, int sw,
-                int act_dim, const uint8_t* active, int* overflow_total);
-  void (*solve)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active);
+                int act_dim, const uint8_t* active, int* overflow_total, float* trace, int trace_words, int phase);
+  void (*solve)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase);
   void (*finish)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
-                 float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim);
+                 float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words);
   void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim);
   void (*sample)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
                  int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen);   // null without a reset generator
+  // the garment (agx_cloth.h): nsub substeps replaying the trace; null in variants without a cloth
+  void (*cloth)(hipStream_t st, int ne, const uint32_t* blob, const float* state, const float* trace, float* cloth, float* report, int e0, int n_envs, int sw,
+                int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* active, int lds_bytes);
   // collision verdict on freshly sampled states after a build pass (see agx_reset.h reset_collides)
   void (*verdict)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, const uint8_t* active, uint8_t* work, int* first_restart, const int* chosen);
 };
@@ -30,3 +35,4 @@ extern "C" const agx_variant* agx_variant_feeding(void);
 extern "C" const agx_variant* agx_variant_bed_bathing(void);
 extern "C" const agx_variant* agx_variant_scratch_itch(void);
 extern "C" const agx_variant* agx_variant_bed_settle(void);
+extern "C" const agx_variant* agx_variant_dressing(void);

@@ -202,15 +202,15 @@ class BedBathingSawyerEnv(AssistiveEnv):
     model, task = 'bed_bathing_sawyer', 'bed_bathing'
 
     def reset(self):
-        """BedBathingEnv.reset (bed_bathing.py:112-171), restated on the host (host/reset_bed.py: human draws, lying pose,
-        TOC base pose search, IK); its result is injected into the stepper."""
-        from .host.reset_bed import BedBathingSawyerReset
+        """BedBathingEnv.reset (bed_bathing.py:112-171): the draws, the TOC base pose search and the IK restated on the host
+        (host/reset_bed.py) around the rag-doll settle of the human, which runs on the device (bed_settle model); the result is
+        injected into the stepper."""
+        from .host.reset_bed import make_states, RagdollSettler
         st = self._ensure_stepper()
-        if not hasattr(self, '_sampler'):
-            self._sampler = BedBathingSawyerReset(self.blob)
+        if not hasattr(self, '_settler'):
+            self._settler = RagdollSettler(1, self.device)
         self.reset_seed = self._draw_seed()
-        rec = self.blob.new_state(1)
-        self._sampler.sample(np.random.RandomState(self.reset_seed % (2 ** 32)), rec, env_seed=self.reset_seed % (2 ** 31))
+        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler)
         st.set_state(rec)
         self.iteration, self.task_success = 0, 0
         return self._split_obs(st.observe_host()[0].astype(np.float64))

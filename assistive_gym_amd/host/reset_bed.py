@@ -207,11 +207,13 @@ class BedBathingSawyerReset:
         return base_pos + np.array([0, 0, dz])
 
     # ---- TOC base pose search (robot.py:123-215) ---------------------------------------------------------
-    def _toc(self, rng, start_pos, goals, attempts=50):
+    def _toc(self, rng, start_pos, goals, attempts=50, goal_Rs=None, right_side=True):
+        """goal_Rs: optional end-effector orientation (3x3) per goal, None = position only; right_side=False: the base is drawn on the
+        human's left and turned by pi (env.py:298 base_euler_orient, robot.py:143)"""
         arm = self.arm
         A = attempts
-        rp = np.stack([rng.uniform(-0.5, 0, size=A), rng.uniform(-0.5, 0.5, size=A), np.zeros(A)], axis=1)     # right_side=True, random_position 0.5
-        yaw = D(rng.uniform(-30, 30, size=A))                                                                 # random_rotation 30
+        rp = np.stack([rng.uniform(-0.5, 0, size=A) if right_side else rng.uniform(0, 0.5, size=A), rng.uniform(-0.5, 0.5, size=A), np.zeros(A)], axis=1)     # random_position 0.5
+        yaw = (0.0 if right_side else np.pi) + D(rng.uniform(-30, 30, size=A))                              # random_rotation 30
         # the reference draws position and yaw alternately per attempt; the draws here are made in two blocks (not stream compatible anyway)
         base_pos = self.toc_base[None] + rp
         base_R = np.array([X.quat_to_mat(X.quat_from_rpy([0, 0, y])) for y in yaw])
@@ -224,12 +226,13 @@ class BedBathingSawyerReset:
         qsol = np.zeros((A, ng, arm.n))
         for g in range(ng):
             tp = np.repeat((start_pos if g == 0 else goals[g - 1])[None], A, axis=0)
-            tR = np.repeat(self.ee_R[None], A, axis=0) if g == 0 else None
+            gR = self.ee_R if g == 0 else (goal_Rs[g - 1] if goal_Rs is not None else None)
+            tR = np.repeat(gR[None], A, axis=0) if gR is not None else None
             q = arm.ik(base_pos, base_R, q0[:, g], tp, tR, iters=100)                                        # max_ik_iterations=100
             pe, Re, orig, axw = arm.fk(base_pos, base_R, q)
             ok = np.linalg.norm(tp - pe, axis=1) < 0.03                                                      # robot.py:97 success_threshold
             if tR is not None:
-                qe, qt = mat_to_quat_batch(Re), X.mat_to_quat(self.ee_R)
+                qe, qt = mat_to_quat_batch(Re), X.mat_to_quat(gR)
                 dq = np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1))
                 ok &= dq < 0.03
             J = arm.jacobian(pe, orig, axw)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('AGX_LIB', os.path.join(HERE, 'lib', 'libagx.so'))   #
 _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
-           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
+           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_cloth_nodes', 'agx_set_cloth', 'agx_get_cloth', 'agx_cloth_dev', 'agx_set_cloth_pool', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset',
            'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather']
@@ -105,6 +105,26 @@ class Stepper:
         out = np.zeros((self.n_envs, self.state_words), dtype=np.float32)
         check(self.L.agx_get_state(self.h, out.ctypes.data_as(C.c_void_p)), 'agx_get_state')
         return out
+
+    # ---- models with a cloth section: the garments, float32 [n_envs, 2, nodes, 3] (positions, velocities)
+    def cloth_nodes(self):
+        n = C.c_int()
+        check(self.L.agx_cloth_nodes(self.h, C.byref(n)), 'agx_cloth_nodes')
+        return n.value
+
+    def set_cloth(self, cloth):
+        cloth = np.ascontiguousarray(cloth, dtype=np.float32)
+        assert cloth.shape == (self.n_envs, 2, self.cloth_nodes(), 3)
+        check(self.L.agx_set_cloth(self.h, cloth.ctypes.data_as(C.c_void_p)), 'agx_set_cloth')
+
+    def get_cloth(self):
+        out = np.zeros((self.n_envs, 2, self.cloth_nodes(), 3), dtype=np.float32)
+        check(self.L.agx_get_cloth(self.h, out.ctypes.data_as(C.c_void_p)), 'agx_get_cloth')
+        return out
+
+    def set_cloth_pool(self, pool_cloth):
+        """pool_cloth: float32 device tensor [pool_n, 2, nodes, 3]; the caller keeps it alive"""
+        check(self.L.agx_set_cloth_pool(self.h, _ptr(pool_cloth)), 'agx_set_cloth_pool')
 
     def state_dev(self):
         p = C.c_void_p()

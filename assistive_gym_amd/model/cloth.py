@@ -1,0 +1,158 @@
+"""Cloth section of the model blob (include/agx_blob.h, AGX_CL_*): the garment DressingEnv.reset loads
+(assistive_gym/envs/dressing.py:149-157: p.loadCloth(hospitalgown_reduced.obj, scale 1.4, mass 0.16, position, orientation,
+anchors, collisionMargin 0.04) + p.clothParams(...)).
+
+The fork's cloth API is Bullet's btSoftBody behind two extra PyBullet calls [BULLET-UNVERIFIED]; what this module fixes:
+  * node order = the OBJ's vertices in order of first appearance in its face list (tinyobj re-indexes (v, vn) pairs that way).
+    Check: with that order the four anchor nodes 2086, 2087, 2088, 2041 lie within 2 cm of each other and 1.2 cm from
+    `cloth_orig_pos` (dressing.py:148) under world = scale * (R v + position); in file order they are 75 cm apart;
+  * links = the unique edges of the triangles, in order of first appearance (btSoftBodyHelpers::CreateFromTriMesh), no
+    bending links; here they are additionally sorted into colour classes (links of a class share no node) so that a class
+    can be relaxed in parallel -- a different Gauss-Seidel order than Bullet's plain list order;
+  * node mass = total mass / node count (btSoftBody::setTotalMass(mass, fromfaces=false));
+  * node area = mean rest area of the incident faces (btSoftBody::updateArea).
+"""
+import numpy as np
+
+from . import xform as X
+from .compiler import CL, CP, CLOTH_MAX_COLORS, CLOTH_THREADS
+
+
+def load_obj_first_appearance(path):
+    """vertices re-indexed in order of first appearance in the face list; faces in file order"""
+    V, F = [], []
+    for line in open(path):
+        if line.startswith('v '):
+            V.append([float(t) for t in line.split()[1:4]])
+        elif line.startswith('f '):
+            F.append([int(t.split('/')[0]) - 1 for t in line.split()[1:4]])
+    V, F = np.array(V), np.array(F)
+    new_of, order = {}, []
+    for f in F:
+        for a in f:
+            if a not in new_of:
+                new_of[a] = len(order)
+                order.append(a)
+    return V[order], np.array([[new_of[a] for a in f] for f in F])
+
+
+def mesh_links(faces):
+    """unique edges in order of first appearance: (0,1), (1,2), (2,0) of every face (CreateFromTriMesh)"""
+    seen, links = set(), []
+    for f in faces:
+        for a, b in ((f[0], f[1]), (f[1], f[2]), (f[2], f[0])):
+            key = (min(a, b), max(a, b))
+            if key not in seen:
+                seen.add(key)
+                links.append((int(a), int(b)))
+    return links
+
+
+def colour_links(links, n_nodes, cap):
+    """greedy colouring in list order: the smallest class that holds neither node and has room"""
+    used = []                      # per class: set of nodes
+    cls = []
+    for a, b in links:
+        for c, u in enumerate(used):
+            if a not in u and b not in u and len(u) < 2 * cap:
+                break
+        else:
+            used.append(set())
+            c = len(used) - 1
+        used[c].update((a, b))
+        cls.append(c)
+    return np.array(cls), len(used)
+
+
+def hull_planes(verts):
+    """outward unit normals and offsets (n.x = off on the face) of the convex hull of the vertices, coplanar facets merged"""
+    from scipy.spatial import ConvexHull
+    v = np.asarray(verts, dtype=np.float64)
+    try:
+        eq = ConvexHull(v).equations
+    except Exception:
+        lo, hi = v.min(0), v.max(0)            # a flat or degenerate set: its bounding box
+        return np.array([[1, 0, 0, hi[0]], [-1, 0, 0, -lo[0]], [0, 1, 0, hi[1]], [0, -1, 0, -lo[1]], [0, 0, 1, hi[2]], [0, 0, -1, -lo[2]]], dtype=np.float64)
+    out, keys = [], set()
+    for n0, n1, n2, d in eq:
+        key = (round(n0, 5), round(n1, 5), round(n2, 5), round(-d, 6))
+        if key not in keys:
+            keys.add(key)
+            out.append([n0, n1, n2, -d])
+    return np.array(out)
+
+
+def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1, tri2, params, colliders, shape_ids, gender_of=lambda ci: 0):
+    """uint32 words of the cloth section.  colliders: Scene.colliders; shape_ids: the colliders the cloth is tested against;
+    gender_of(collider) = 0 always present, 1 male human only, 2 female human only."""
+    v, faces = load_obj_first_appearance(obj_path)
+    R = X.quat_to_mat(X.quat_from_rpy(rpy))
+    x0 = scale * (v @ R.T + np.asarray(position))                    # see module docstring
+    nn = len(x0)
+    links = mesh_links(faces)
+    cls, ncolor = colour_links(links, nn, CLOTH_THREADS)
+    assert ncolor <= CLOTH_MAX_COLORS, ncolor
+    order = np.argsort(cls, kind='stable')
+    links = [links[k] for k in order]
+    cls = cls[order]
+    color_off = [int(np.searchsorted(cls, c)) for c in range(ncolor)] + [len(links)]
+    max_per = max(color_off[c + 1] - color_off[c] for c in range(ncolor))
+    assert max_per <= CLOTH_THREADS
+    rest2 = np.array([np.sum((x0[a] - x0[b]) ** 2) for a, b in links])
+    # incident faces per node, in face order, rotated so that the node comes first (same cross product)
+    inc = [[] for _ in range(nn)]
+    area_sum, cnt = np.zeros(nn), np.zeros(nn)
+    for f in faces:
+        a, b, c = (int(t) for t in f)
+        ra = 0.5 * np.linalg.norm(np.cross(x0[b] - x0[a], x0[c] - x0[a]))
+        for i, j, k in ((a, b, c), (b, c, a), (c, a, b)):
+            inc[i].append(j | (k << 16))
+            area_sum[i] += ra
+            cnt[i] += 1
+    area = np.where(cnt > 0, area_sum / np.maximum(cnt, 1), 0.0)
+    node_first = np.concatenate([[0], np.cumsum([len(t) for t in inc])]).astype(np.int64)
+    face_entries = np.array([e for t in inc for e in t], dtype=np.int64)
+    # rigid shapes: capsule / sphere cores are evaluated exactly, hulls through their face planes
+    planes, shapes = [], []
+    for ci in shape_ids:
+        c = colliders[ci]
+        if len(c['verts']) <= 2:
+            shapes.append([ci, 0, 0, gender_of(ci)])
+        else:
+            pl = hull_planes(c['verts'])
+            shapes.append([ci, len(planes), len(pl), gender_of(ci)])
+            planes.extend(pl.tolist())
+    planes = np.array(planes, dtype=np.float64).reshape(-1, 4)
+    off, cur = {}, CL['HDR']
+    for name, size in (('COLOR', ncolor + 1), ('LINK', 2 * len(links)), ('NODE', 2 * (nn + 1)), ('FACE', len(face_entries)), ('X0', 3 * nn),
+                       ('ANCHOR', 4 * len(anchors)), ('SHAPE', 4 * len(shapes)), ('PLANE', 4 * len(planes)), ('PARAM', CP['COUNT'])):
+        off[name] = cur
+        cur += size
+    f = np.zeros(cur, dtype=np.float32)
+    i = f.view(np.int32)
+    i[CL['NN']], i[CL['NL']], i[CL['NCOLOR']], i[CL['NANCHOR']], i[CL['NSHAPE']] = nn, len(links), ncolor, len(anchors), len(shapes)
+    for name in ('COLOR', 'LINK', 'NODE', 'FACE', 'X0', 'ANCHOR', 'SHAPE', 'PLANE', 'PARAM'):
+        i[CL['OFF_' + name]] = off[name]
+    i[CL['TRI']:CL['TRI'] + 6] = list(tri1) + list(tri2)
+    i[CL['MAX_LINKS_PER_COLOR']] = max_per
+    i[off['COLOR']:off['COLOR'] + ncolor + 1] = color_off
+    for k, (a, b) in enumerate(links):
+        i[off['LINK'] + 2 * k] = a | (b << 16)
+        f[off['LINK'] + 2 * k + 1] = rest2[k]
+    for n in range(nn + 1):
+        i[off['NODE'] + 2 * n] = node_first[n]
+        f[off['NODE'] + 2 * n + 1] = area[n] if n < nn else 0.0
+    i[off['FACE']:off['FACE'] + len(face_entries)] = face_entries
+    f[off['X0']:off['X0'] + 3 * nn] = x0.astype(np.float32).ravel()
+    for k, n in enumerate(anchors):
+        i[off['ANCHOR'] + 4 * k] = n
+        f[off['ANCHOR'] + 4 * k + 1:off['ANCHOR'] + 4 * k + 4] = x0[n] - np.asarray(anchor_body_pos)
+    i[off['SHAPE']:off['SHAPE'] + 4 * len(shapes)] = np.array(shapes, dtype=np.int64).ravel() if shapes else []
+    f[off['PLANE']:off['PLANE'] + 4 * len(planes)] = planes.astype(np.float32).ravel()
+    pv = f[off['PARAM']:off['PARAM'] + CP['COUNT']]
+    for k, val in params.items():
+        if k != 'MASS':
+            pv[CP[k]] = val
+    pv[CP['NODE_IM']] = nn / params['MASS']                          # setTotalMass(mass, fromfaces=false): equal node masses
+    meta = dict(nodes=nn, links=len(links), colors=ncolor, faces=len(faces), shapes=len(shapes), planes=len(planes), max_links_per_color=max_per)
+    return f.view(np.uint32).copy(), meta

@@ -32,7 +32,7 @@ H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT
          OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
          STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
          NDIR=29, OFF_DIRS=30, OFF_RESET=31, NROBOT=32, NHDOF=33, S_TREMOR=34, TASK_KIND=35, S_TASK=36, TASK_WORDS=37,
-         OFF_TARGETS=38, OFF_MLP=39, COUNT=40)
+         OFF_TARGETS=38, OFF_MLP=39, OFF_CLOTH=40, SIM_SUBSTEPS=41, COUNT=48)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
          HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, COUNT=24)
@@ -44,7 +44,8 @@ G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
 T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV=7, SUCCESS_FRAC=8, MOUTH_DIST=9,
          SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
          TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, TOOL_OBS_POS=36, TOOL_OBS_QUAT=39, W_WIPE=43, TARGET_RADIUS=44,
-         CLOSEST_DIST=45, PAD_LINK=46, ARM_LINK=47, OBS_LINK=49, NT=52, NT_MAX=56, ARM_LIMIT_ON=57, ARM_LIMIT_DOF=58, ARM_LIMIT_SIGN=62, COUNT=64)
+         CLOSEST_DIST=45, PAD_LINK=46, ARM_LINK=47, OBS_LINK=49, NT=52, NT_MAX=56, ARM_LIMIT_ON=57, ARM_LIMIT_DOF=58, ARM_LIMIT_SIGN=62, C_D=64,
+         ARM_RADIUS=65, COUNT=72)
 # reset section (sampling ranges of FeedingEnv.reset + the posed-human kinematic tree), see agx_blob.h
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
@@ -57,14 +58,21 @@ BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
 PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
 HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8, BED=9)
-TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH = 0, 1, 2
+TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH, TASK_DRESSING = 0, 1, 2, 3
+DR = dict(CLOTH_GRAVITY=0, FORCE_SUM=1, BEST=2, WORDS=12)   # dressing task words (AGX_DR_*)
+# cloth section (AGX_CL_*, AGX_CP_*)
+CL = dict(NN=0, NL=1, NCOLOR=2, NANCHOR=3, NSHAPE=4, OFF_COLOR=5, OFF_LINK=6, OFF_NODE=7, OFF_FACE=8, OFF_X0=9, OFF_ANCHOR=10, OFF_SHAPE=11,
+          OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, HDR=24)
+CP = dict(KLST=0, KDP=1, KDG=2, KDF=3, KCHR=4, KKHR=5, KAHR=6, PITER=7, MARGIN=8, NODE_IM=9, AIR_DENSITY=10, FORCE_SCALE=11, FORCE_MAX=12,
+          EE_BELOW=13, COUNT=16)
+CLOTH_MAX_COLORS, CLOTH_THREADS, CLOTH_NODE_CONTACTS = 16, 1024, 2
 SI = dict(TARGET=0, LIMB=3, PREV_CONTACT=12, WORDS=16)   # scratch itch task words (AGX_SI_*); the arm-limit words sit where BB has them
 BB = dict(ALIVE=0, ALIVE_WORDS=6, PREV=6, HAS_PREV=10, WORDS=12)
 MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathing task words of the state record (AGX_BB_*)
 # pair-group flags (AGX_G_FLAGS)
 GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC = 1, 2, 4, 8, 16, 32
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 8
+MAGIC, VERSION = 0x31584741, 9
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -272,7 +280,7 @@ def add_robot_colliders(sc, rob, name, pb_pred):
     sc.end(name)
 
 
-def add_human(sc, assets, nrobot, hd, kp, maxf, act0, split=None):
+def add_human(sc, assets, nrobot, hd, kp, maxf, act0, split=None, cloth=False):
     """Both genders of the capsule human (human_creation.py:58-316).  Links of the joints `hd` (a serial chain off the base,
     in PyBullet numbering) are moving links of the articulated set (DoFs nrobot..nrobot+len(hd)-1): dynamic when they are
     controllable or the impairment is tremor (human.py:108: every other link gets mass 0) and frozen per environment
@@ -283,7 +291,7 @@ def add_human(sc, assets, nrobot, hd, kp, maxf, act0, split=None):
     nhdof = len(hd)
     human_bodies, human_link_rec = None, {}
     for gender in ('male', 'female'):
-        hm = HumanModel(gender)
+        hm = HumanModel(gender, cloth=cloth)         # cloth: extra spheres on the shoulder / elbow / wrist joints (human_creation.py:96-101)
         cols = hm.colliders()
         static_links = sorted(set(c[0] for c in cols if c[0] not in hd), key=lambda l: (l != -1, l))
         if human_bodies is None:
@@ -346,7 +354,7 @@ def default_params(n_iter):
 
 
 def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i, hdr_extra, reset_fill, reset_words,
-         targets=None, task_words=0, meta_extra=None, mlp=None):
+         targets=None, task_words=0, meta_extra=None, mlp=None, cloth=None, sim_substeps=1):
     """Lays the assembled scene out as the flat blob of include/agx_blob.h.  Returns (uint32 array, meta)."""
     nrobot = len(rob['dof_links'])
     nhdof = len(hd)
@@ -364,7 +372,7 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
     for name, size in (('PARAMS', P['COUNT']), ('ROBOT', nrec * R['STRIDE']), ('FREE', nfree * F['STRIDE']),
                        ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
                        ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('RESET', reset_words(nhuman, nhdof)),
-                       ('TARGETS', 2 * nt_max * 4), ('MLP', MLP_WORDS if mlp is not None else 0)):
+                       ('TARGETS', 2 * nt_max * 4), ('MLP', MLP_WORDS if mlp is not None else 0), ('CLOTH', len(cloth) if cloth is not None else 0)):
         off[name] = cur
         cur += size
     nwords = cur
@@ -384,7 +392,8 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
                OFF_GROUP=off['GROUP'], OFF_TASK=off['TASK'], STATE_WORDS=state_words, S_Q=s_q, S_QD=s_qd, S_QT=s_qt,
                S_FREE=s_free, S_BASE=s_base, S_HUMAN=s_human, S_ENV=s_env, NDIR=len(dirs),
                OFF_DIRS=off['DIRS'], OFF_RESET=off['RESET'], NROBOT=nrobot, NHDOF=nhdof, S_TREMOR=s_tremor,
-               S_TASK=s_task, TASK_WORDS=task_words, OFF_TARGETS=off['TARGETS'], OFF_MLP=off['MLP'] if mlp is not None else 0)
+               S_TASK=s_task, TASK_WORDS=task_words, OFF_TARGETS=off['TARGETS'], OFF_MLP=off['MLP'] if mlp is not None else 0,
+               OFF_CLOTH=off['CLOTH'] if cloth is not None else 0, SIM_SUBSTEPS=sim_substeps)
     hdr.update(hdr_extra)
     for k, v in hdr.items():
         i[H[k]] = v
@@ -455,6 +464,8 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
         flat = np.concatenate([np.concatenate([k.ravel(), b_.ravel()]) for k, b_ in mlp]).astype(np.float32)
         assert len(flat) == MLP_WORDS
         f[off['MLP']:off['MLP'] + MLP_WORDS] = flat
+    if cloth is not None:
+        f.view(np.uint32)[off['CLOTH']:off['CLOTH'] + len(cloth)] = cloth
     meta = dict(header=hdr, ranges={k: tuple(v) for k, v in sc.ranges.items()}, human_bodies=human_bodies,
                 human_dynamic_joints=hd, nrobot=nrobot, dof_links=rob['dof_links'], n_groups=len(groups), offsets=off)
     meta.update(meta_extra or {})
@@ -1018,8 +1029,91 @@ def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ve
                 task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
 
 
+def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
+    """DressingBaxter-v1 (dressing_envs.py:19-21; BASELINE config 5): Baxter's left arm (agents/baxter.py) pulls the sleeve of a
+    hospital gown (assets/clothing/hospitalgown_reduced.obj, the cloth section, model/cloth.py) over the left arm of a human
+    sitting in the wheelchair (dressing.py:112-198).  numSubSteps = 8 (dressing.py:184): a stepSimulation is eight internal
+    substeps of 2.5 ms.  Baxter's other joints (head pan, right arm, right gripper) start at rest without gravity and are held by
+    their default motors: static geometry at the poses of Robot.reset_joints / Baxter.reset_joints (baxter.py:63-67), as for the
+    PR2 [deviation, DESIGN.md]."""
+    from .cloth import compile_cloth
+    sc = Scene()
+    arm = [34, 35, 36, 37, 38, 40, 41]                  # baxter.py:9 left_arm_joint_indices
+    grip = [49, 51]                                     # baxter.py:14
+    urdf_path = os.path.join(assets, 'baxter', 'baxter_custom.urdf')
+    u0 = Urdf(urdf_path)
+    frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+    frozen.update(dict(zip([12, 13, 14, 15, 16, 18, 19], [-0.75, 1, -0.5, 0.5, -1, -0.5, 0])))      # baxter.py:66
+    rob = compile_robot(urdf_path, arm, grip, gripper_target=[0.0, 0.0], motor_gain=0.01, motor_force=1.0,          # baxter.py:20, dressing.py:121
+                        max_hull_verts=robot_hull_max_verts, frozen=frozen)
+    nrobot = len(rob['dof_links'])
+    add_robot_colliders(sc, rob, 'robot_links', lambda pb: True)
+    sc.begin('robot_base')
+    for verts, radius, fr, pb in rob['base_colliders']:
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    sc.end('robot_base')
+    hd = list(range(10, 20))                            # human.left_arm_joints (dressing_envs.py:11)
+
+    def split(link):
+        return 'pecs' if link == 12 else ('arm' if 13 <= link <= 19 else 'rest')
+    human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.01, maxf=1.0, act0=len(arm), split=split, cloth=True)   # dressing.py:121, env.py:38
+    sc.begin('wheelchair')   # furniture.py:12-16 ('wheelchair_left' is the plain wheelchair unless the robot is mounted on it)
+    wq = X.quat_from_rpy([np.pi / 2, 0, np.pi])
+    for g in load_obj_groups(os.path.join(assets, 'wheelchair', 'wheelchair_permobil_reduced_compressed_vhacd.obj'), 0.15):
+        hv = X.apply(np.array([0, 0, 0.06]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), wq, convex_hull_vertices(g)))
+        sc.add(BODY_WORLD, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['WHEELCHAIR'])
+    sc.end('wheelchair')
+    sc.begin('plane')
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    G_ = Groups(sc.ranges)
+    grp = G_.add
+    grp('robot_links', 'human_male', alt='human_female', keep=2)
+    grp('robot_links', 'wheelchair', keep=2)
+    grp('robot_links', 'plane')
+    for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
+        G_.rg['harm_' + gender] = (min(G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][0]), max(G_.rg['human_%s_pecs' % gender][1], G_.rg['human_%s_arm' % gender][1]))
+        grp('robot_base', 'harm_' + gender, keep=2, flags=gf | GF_HUMAN_DYNAMIC)
+        grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)     # human_creation.py:291-293
+        grp('harm_' + gender, 'wheelchair', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
+    groups = G_.rows
+    ee_pb = 48                                          # baxter.py:12 left_end_effector
+    ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    radii = [0.043, 0.0355]                             # hand_radius = elbow_radius = shoulder_radius, male / female (human_creation.py:89,140)
+    task_f = dict(W_WIPE=1.0, W_ACTION=0.01, SUCCESS_FRAC=0.4,                             # config.ini:28-31
+                  C_V=0.25, C_F=0.01, C_HF=0.05, C_D=0.01, ARM_RADIUS=radii,              # config.ini:40-45
+                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_QUAT=[0, 0, 0, 1.0],
+                  EPISODE_LEN=200, ARM_LIMIT_SIGN=1.0)                                     # left arm (human.py:142-145)
+    task_i = dict(EE_LINK=ee_link, PAD_LINK=0, ARM_LINK=[nrobot + 5, nrobot + 7], OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], HEAD_LINK=-1,   # left shoulder, elbow, wrist (human.py:25-27)
+                  ARM_LIMIT_DOF=[nrobot + 3, nrobot + 4, nrobot + 5, nrobot + 6], ARM_LIMIT_ON=0)
+    params = default_params(n_iter)
+    params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-1.0)                               # dressing.py:179-181
+    from .h5lite import load_keras_dense_stack
+    mlp = load_keras_dense_stack(os.path.join(assets, 'realistic_arm_limits_model.h5'))
+    # the cloth is tested against the human, the robot and the wheelchair (not the ground: the gown never reaches it in an episode)
+    r = sc.ranges
+    shape_ids = [c for name in ('robot_links', 'robot_base', 'human_male', 'human_female', 'wheelchair') for c in range(*r[name])]
+    cloth_orig_pos = np.array([0.34658437, -0.30296362, 1.20023387])                       # dressing.py:148
+    cloth, cmeta = compile_cloth(os.path.join(assets, 'clothing', 'hospitalgown_reduced.obj'), 1.4, [0.02, -0.38, 0.84], [0, 0, np.pi],
+                                 [2086, 2087, 2088, 2041], cloth_orig_pos, [1180, 2819, 30], [1322, 13, 696],              # dressing.py:153,156-157
+                                 dict(KLST=0.055, KDP=0.01, KDG=10.0, KDF=0.39, KCHR=1.0, KKHR=1.0, KAHR=1.0, PITER=5,    # dressing.py:154
+                                      MARGIN=0.04, MASS=0.16, AIR_DENSITY=1.2, FORCE_SCALE=10.0, FORCE_MAX=20.0, EE_BELOW=0.05),   # dressing.py:153,35,42
+                                 sc.colliders, shape_ids,
+                                 gender_of=lambda ci: 1 if r['human_male'][0] <= ci < r['human_male'][1] else (2 if r['human_female'][0] <= ci < r['human_female'][1] else 0))
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT']
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        pass        # the pool comes from assistive_gym_amd/host/reset_dressing.py
+    return pack(sc, groups, rob, human_bodies, human_link_rec, hd, [], params, task_f, task_i,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRESSING), reset_fill, reset_words,
+                task_words=DR['WORDS'], mlp=mlp, cloth=cloth, sim_substeps=8,
+                meta_extra=dict(arm_joints=arm, gripper_joints=grip, cloth=cmeta, cloth_orig_pos=cloth_orig_pos.tolist()))
+
+
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
-                 bed_settle=compile_bed_settle)
+                 bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter)
 
 
 def main(names=None):

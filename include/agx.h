@@ -62,6 +62,7 @@ int agx_get_state(agx_handle h, float* host_states);
 /* device address of the state records (e.g. to fill them from a device-resident pool) */
 int agx_state_dev(agx_handle h, float** out_dev);
 
+/* n_substeps p.stepSimulation() calls (each AGX_H_SIM_SUBSTEPS internal substeps) without actions, task layer or hooks of env.step */
 int agx_settle(agx_handle h, int n_substeps, void* stream);
 int agx_step(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
              uint8_t* done_dev, float* info_dev, void* stream);
@@ -70,6 +71,15 @@ int agx_step_debug(agx_handle h, const float* actions_dev, float* obs_dev, float
                    uint8_t* done_dev, float* info_dev, float* debug_dev, void* stream);
 /* agx_settle, additionally dumping first-substep internals (models without a task layer to finish a step with, e.g. bed_settle) */
 int agx_settle_debug(agx_handle h, int n_substeps, float* debug_dev, void* stream);
+/* models with a cloth section (DressingBaxter; assistive_gym/envs/dressing.py:149-157, p.loadCloth / p.getSoftBodyData): the garment of
+ * every environment is a float[2][nodes][3] record next to its state record -- node positions, node velocities.  agx_step / agx_settle
+ * advance it; agx_reset_done also replaces the garment of a finished environment, from the device array [pool_n][2][nodes][3] given once
+ * with agx_set_cloth_pool (same pool index as the state record). */
+int agx_cloth_nodes(agx_handle h, int* nodes);   /* 0 for models without a cloth */
+int agx_set_cloth(agx_handle h, const float* host_cloth);
+int agx_get_cloth(agx_handle h, float* host_cloth);
+int agx_cloth_dev(agx_handle h, float** out_dev);
+int agx_set_cloth_pool(agx_handle h, const float* pool_cloth_dev);
 int agx_debug_words(void);   /* of the FeedingJaco kernel variant; agx_debug_layout for the variant serving a handle */
 /* layout of the debug record of the kernel variant serving this handle: out8 = {words per env, contacts offset, M^-1 offset,
  * M^-1 row stride, row headers offset, impulses offset, phase timers offset, qdd offset} */

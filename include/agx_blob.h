@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 8
+#define AGX_BLOB_VERSION 9
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -54,12 +54,18 @@ enum {
   AGX_H_OFF_TARGETS,  /* bed bathing: float[2 genders][NT_MAX][4] = target position in its arm link frame + arm (0 upper, 1 fore) */
   AGX_H_OFF_MLP,      /* arm-limit classifier of Human.enforce_realistic_joint_limits (human.py:134-152): float W1[4][64], b1[64],
                          W2[64][64], b2[64], W3[64][64], b3[64], W4[64], b4[1] (assets/realistic_arm_limits_model.h5); 0 = none */
-  AGX_H_COUNT = 40
+  AGX_H_OFF_CLOTH,    /* cloth section (AGX_CL_*), 0 = the scene has no cloth (dressing.py:153-154)                              */
+  AGX_H_SIM_SUBSTEPS, /* internal substeps per p.stepSimulation(): numSubSteps of setPhysicsEngineParameter (dressing.py:184), else 1.
+                         The stepper's substep is then DT / SIM_SUBSTEPS long, an env step has FRAME_SKIP * SIM_SUBSTEPS of them, and
+                         what the reference does between two stepSimulation calls (limit reset, arm-limit classifier, env.py:226-232)
+                         runs after every SIM_SUBSTEPS-th substep                                                                    */
+  AGX_H_COUNT = 48
 };
 
 enum { AGX_TASK_FEEDING = 0,      /* assistive_gym/envs/feeding.py      */
        AGX_TASK_BED_BATHING = 1,  /* assistive_gym/envs/bed_bathing.py  */
-       AGX_TASK_SCRATCH_ITCH = 2 };/* assistive_gym/envs/scratch_itch.py */
+       AGX_TASK_SCRATCH_ITCH = 2, /* assistive_gym/envs/scratch_itch.py */
+       AGX_TASK_DRESSING = 3 };   /* assistive_gym/envs/dressing.py     */
 
 /* ---- PARAMS: float[AGX_P_COUNT] ----------------------------------------------------------- */
 enum {
@@ -194,7 +200,10 @@ enum {
   AGX_T_ARM_LIMIT_ON = 57, /* int: 1 = run the classifier after every substep (env.py:230-231)                      */
   AGX_T_ARM_LIMIT_DOF = 58,/* int[4]: DoFs of shoulder x, y, z and elbow of the movable arm (human.py:139)          */
   AGX_T_ARM_LIMIT_SIGN = 62,/* float: -1 right arm, +1 left arm (human.py:142-145)                                   */
-  AGX_T_COUNT = 64
+  /* ---- dressing (assistive_gym/envs/dressing.py, config.ini:28-31; W_WIPE = dressing_reward_weight, SUCCESS_FRAC = task_success_threshold) ---- */
+  AGX_T_C_D = 64,           /* dressing_force_weight (config.ini:45)                                                 */
+  AGX_T_ARM_RADIUS = 65,    /* float[2 genders]: hand_radius = elbow_radius = shoulder_radius (human_creation.py:89,140; util.py:134-138) */
+  AGX_T_COUNT = 72
 };
 
 /* ---- RESET section (offset AGX_H_OFF_RESET): what FeedingEnv.reset samples (feeding.py:114-172, human.py:72-102,
@@ -278,6 +287,60 @@ enum { AGX_SI_TARGET = 0,       /* float[3] target_on_arm, in the frame of its l
        AGX_SI_LIMB = 3,         /* int: 0 upper arm (human.right_shoulder), 1 forearm (human.right_elbow)                  */
        AGX_SI_PREV_CONTACT = 12,/* float[3]                                                                                */
        AGX_SI_WORDS = 16 };
+/* dressing (offset AGX_H_S_TASK): at AGX_BB_PREV / AGX_BB_HAS_PREV the arm-limit classifier's remembered pose, like the others */
+enum { AGX_DR_CLOTH_GRAVITY = 0, /* float: world gravity z acting on the cloth: -9.81 / 2 while it settles in reset, then -9.81 (dressing.py:178,195) */
+       AGX_DR_FORCE_SUM = 1,     /* float: cloth_force_sum of the last step (dressing.py:96), an observation input                                */
+       AGX_DR_BEST = 2,          /* float: self.task_success, the best reward_dressing so far (dressing.py:62-63)                                 */
+       AGX_DR_WORDS = 12 };
+
+/* ---- CLOTH section (offset AGX_H_OFF_CLOTH): the garment of DressingEnv.reset (dressing.py:153-154: p.loadCloth of
+ * assets/clothing/hospitalgown_reduced.obj, scale 1.4, mass 0.16, collisionMargin 0.04, four anchor nodes; p.clothParams).
+ * The fork's cloth API is Bullet's btSoftBody [BULLET-UNVERIFIED]; what is restated is its position-based solver:
+ * nodes, links (one per mesh edge), node normals / areas for the aerodynamic drag, anchors, node-vs-rigid contacts.
+ * int32 header [AGX_CL_HDR], then the arrays at the section-relative word offsets it names. ------------------------ */
+enum {
+  AGX_CL_NN = 0,         /* nodes: the OBJ's vertices in order of first appearance in its face list (tinyobj re-indexing)   */
+  AGX_CL_NL = 1,         /* links = unique mesh edges, sorted by colour                                                     */
+  AGX_CL_NCOLOR = 2,     /* colour classes: links of one class share no node and are relaxed in parallel; classes in order   */
+  AGX_CL_NANCHOR = 3,
+  AGX_CL_NSHAPE = 4,     /* rigid colliders the cloth is tested against                                                      */
+  AGX_CL_OFF_COLOR = 5,  /* int[NCOLOR + 1] first link of every class                                                        */
+  AGX_CL_OFF_LINK = 6,   /* {int a | b << 16, float rest length squared}[NL]                                                  */
+  AGX_CL_OFF_NODE = 7,   /* {int first incident face entry, float area}[NN] (+ one terminating entry): node area = mean rest
+                            area of the incident faces (btSoftBody::updateArea)                                             */
+  AGX_CL_OFF_FACE = 8,   /* int[entries] j | k << 16: the other two vertices of each incident face, in the face's winding      */
+  AGX_CL_OFF_X0 = 9,     /* float[NN][3] node positions of the loaded garment for cloth_offset = 0 (dressing.py:149-153)       */
+  AGX_CL_OFF_ANCHOR = 10,/* {int node, float[3] offset from the attachment body}[NANCHOR]                                     */
+  AGX_CL_OFF_SHAPE = 11, /* int[NSHAPE][4]: collider index, first plane, plane count (0: capsule / sphere core + radius), gender
+                            (0 always present, 1 / 2: part of the male / female human only)                                    */
+  AGX_CL_OFF_PLANE = 12, /* float[planes][4]: outward unit normal and offset of the hull's faces in the body frame             */
+  AGX_CL_TRI = 13,       /* int[6]: the two vertex triples around the opening of the left sleeve (dressing.py:156-157)         */
+  AGX_CL_OFF_PARAM = 19, /* float[AGX_CP_COUNT]                                                                                */
+  AGX_CL_MAX_LINKS_PER_COLOR = 20, /* int: size of the largest class (<= the cloth kernel's thread count)                       */
+  AGX_CL_HDR = 24
+};
+enum {
+  AGX_CP_KLST = 0,       /* material linear stiffness (clothParams kLST)                                                      */
+  AGX_CP_KDP = 1,        /* damping                                                                                           */
+  AGX_CP_KDG = 2,        /* drag                                                                                              */
+  AGX_CP_KDF = 3,        /* dynamic friction                                                                                  */
+  AGX_CP_KCHR = 4, AGX_CP_KKHR = 5, AGX_CP_KAHR = 6,   /* rigid / kinetic contact hardness, anchor hardness                   */
+  AGX_CP_PITER = 7,      /* position solver iterations                                                                        */
+  AGX_CP_MARGIN = 8,     /* collisionMargin                                                                                   */
+  AGX_CP_NODE_IM = 9,    /* inverse mass of a node (total mass / NN each)                                                     */
+  AGX_CP_AIR_DENSITY = 10,/* btSoftBodyWorldInfo::air_density (1.2)                                                           */
+  AGX_CP_FORCE_SCALE = 11,/* dressing.py:35: forces * 10                                                                      */
+  AGX_CP_FORCE_MAX = 12, /* dressing.py:42: only forces below 20 count                                                        */
+  AGX_CP_EE_BELOW = 13,  /* dressing.py:42: only contacts more than 0.05 below the end effector count                         */
+  AGX_CP_COUNT = 16
+};
+#define AGX_CLOTH_MAX_COLORS 16
+#define AGX_CLOTH_THREADS 1024
+#define AGX_CLOTH_NODE_CONTACTS 2   /* node-vs-rigid contacts kept per node and substep: the first ones in shape order */
+/* per-environment cloth report written by the cloth kernel for the finish kernel: float[18] the six sleeve vertices, 2 unused,
+ * then per node and contact slot {height of the node, |force|} of the last substep's contacts (|force| = -1: empty slot) */
+#define AGX_CLOTH_REPORT_WORDS(nn) (20 + 2 * AGX_CLOTH_NODE_CONTACTS * (nn))
+
 #define AGX_MLP_HIDDEN 64
 #define AGX_MLP_WORDS (4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1)
 

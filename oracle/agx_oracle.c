@@ -13,6 +13,7 @@
 #include "../include/agx_blob.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -35,6 +36,8 @@ struct agxo_model {
   int s_q, s_qd, s_qt, s_free, s_base, s_human, s_env, s_tremor;
   int nrobot, nhdof;
   int task_kind, s_task, o_targets;
+  int o_cloth, sim_sub;      /* cloth section (0 = none); internal substeps per stepSimulation (numSubSteps) */
+  double dt;                 /* length of one internal substep: DT / sim_sub */
 };
 
 /* ------------------------------------------------------------------------------------ math */
@@ -143,6 +146,8 @@ agxo_model* agxo_load(const uint32_t* blob, size_t nwords) {
   m->s_human = h[AGX_H_S_HUMAN]; m->s_env = h[AGX_H_S_ENV]; m->s_tremor = h[AGX_H_S_TREMOR];
   m->nrobot = h[AGX_H_NROBOT]; m->nhdof = h[AGX_H_NHDOF];
   m->task_kind = h[AGX_H_TASK_KIND]; m->s_task = h[AGX_H_S_TASK]; m->o_targets = h[AGX_H_OFF_TARGETS];
+  m->o_cloth = h[AGX_H_OFF_CLOTH]; m->sim_sub = h[AGX_H_SIM_SUBSTEPS] > 1 ? h[AGX_H_SIM_SUBSTEPS] : 1;
+  m->dt = (double)m->f[m->o_params + AGX_P_DT] / m->sim_sub;
   if (m->ndof > MAXDOF || m->nfree > MAXFREE || m->nhuman > MAXHUMAN || m->ncoll > MAXCOLL) { agxo_free(m); return NULL; }
   return m;
 }
@@ -209,6 +214,11 @@ typedef struct {
   double si_target[3], si_prev[3]; int si_limb;            /* scratch itch: target_on_arm, prev_target_contact_pos, limb (scratch_itch.py:134-146,96) */
   int contact_overflow;
   row_t* rows; int nrows;
+  /* dressing: the cloth (node positions / velocities live with the caller), its attachment point and the contacts of the last substep */
+  double dr_gravity, dr_force_sum, dr_best;
+  double* cx; double* cv; double* cq;                      /* [NN][3] each; NULL = no cloth attached to this call */
+  double anchor[3]; int anchor_set;
+  double* ccon; int nccon;                                 /* {x, y, z, fx, fy, fz} per node-vs-rigid contact */
 } sim_t;
 
 static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
@@ -245,6 +255,7 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
       for (int k = 0; k < 3; k++) { s->si_target[k] = st[m->s_task + AGX_SI_TARGET + k]; s->si_prev[k] = st[m->s_task + AGX_SI_PREV_CONTACT + k]; }
       s->si_limb = ((const int32_t*)st)[m->s_task + AGX_SI_LIMB];
     }
+    if (m->task_kind == AGX_TASK_DRESSING) { s->dr_gravity = st[m->s_task + AGX_DR_CLOTH_GRAVITY]; s->dr_force_sum = st[m->s_task + AGX_DR_FORCE_SUM]; s->dr_best = st[m->s_task + AGX_DR_BEST]; }
   }
 }
 static void sim_store(const sim_t* s, float* st) {
@@ -265,6 +276,7 @@ static void sim_store(const sim_t* s, float* st) {
     for (int k = 0; k < 4; k++) st[m->s_task + AGX_BB_PREV + k] = (float)s->arm_prev[k];
     ((int32_t*)st)[m->s_task + AGX_BB_HAS_PREV] = s->arm_has_prev;
     if (m->task_kind == AGX_TASK_SCRATCH_ITCH) for (int k = 0; k < 3; k++) st[m->s_task + AGX_SI_PREV_CONTACT + k] = (float)s->si_prev[k];
+    if (m->task_kind == AGX_TASK_DRESSING) { st[m->s_task + AGX_DR_FORCE_SUM] = (float)s->dr_force_sum; st[m->s_task + AGX_DR_BEST] = (float)s->dr_best; }
   }
 }
 
@@ -673,7 +685,7 @@ static void collide(sim_t* s) {
   double brk = PARAM(m, AGX_P_CONTACT_BREAK);
   int maxc = (int)PARAM(m, AGX_P_MAX_CONTACTS); if (maxc > MAXC) maxc = MAXC;
   double lo[MAXCOLL][3], hi[MAXCOLL][3];
-  double dt0 = PARAM(m, AGX_P_DT);
+  double dt0 = m->dt;
   for (int c = 0; c < m->ncoll && c < MAXCOLL; c++) {
     /* speculative AABB: grown by the distance the collider can travel in this substep, so the
      * broadphase margin only has to cover the solver slack (pairs farther apart cannot yield a row) */
@@ -682,7 +694,7 @@ static void collide(sim_t* s) {
     for (int k = 0; k < 3; k++) { lo[c][k] -= g; hi[c][k] += g; }
   }
   s->ncon = 0; s->food_near_human = 0; s->contact_overflow = 0; s->nqpt = 0;
-  double dt = PARAM(m, AGX_P_DT), slack = PARAM(m, AGX_P_CONTACT_SLACK);
+  double dt = m->dt, slack = PARAM(m, AGX_P_CONTACT_SLACK);
   for (int g = 0; g < m->ngroup; g++) {
     int a0 = GI(m, g, AGX_G_A0), a1 = GI(m, g, AGX_G_A1), b0 = GI(m, g, AGX_G_B0), b1 = GI(m, g, AGX_G_B1);
     if (s->gender == 1 && GI(m, g, AGX_G_B0F) >= 0) { b0 = GI(m, g, AGX_G_B0F); b1 = GI(m, g, AGX_G_B1F); }
@@ -809,7 +821,7 @@ static int row_art_entries(const sim_t* s, const row_t* r) {
 }
 static void build_rows(sim_t* s) {
   const agxo_model* m = s->m; int n = s->ndof;
-  double dt = PARAM(m, AGX_P_DT), erp = PARAM(m, AGX_P_ERP), cerp = PARAM(m, AGX_P_CONTACT_ERP);
+  double dt = m->dt, erp = PARAM(m, AGX_P_ERP), cerp = PARAM(m, AGX_P_CONTACT_ERP);
   int maxrows = (int)PARAM(m, AGX_P_MAX_ROWS); if (maxrows > MAXROWS) maxrows = MAXROWS;
   s->nrows = 0;
 #define NEWROW() (memset(&s->rows[s->nrows], 0, sizeof(row_t)), &s->rows[s->nrows++])
@@ -978,9 +990,168 @@ static void arm_limits(sim_t* s) {
 }
 
 /* one p.stepSimulation() (env.py:226) + the post-substep hooks (env.py:227-232) */
-static void substep(sim_t* s) {
-  const agxo_model* m = s->m; int n = s->ndof; double dt = PARAM(m, AGX_P_DT);
+
+/* ------------------------------------------------------------------------------------ cloth (dressing.py:149-157,184; model/cloth.py)
+ * One internal substep of the garment: Bullet's btSoftBody position-based step [BULLET-UNVERIFIED, restated from the published
+ * source layout: btSoftBody::predictMotion / solveConstraints / PSolve_Anchors / PSolve_RContacts / PSolve_Links]:
+ *   1. v += g dt; aerodynamic drag (aero model V_Point: only while a node moves along its normal), clamped so that it cannot
+ *      reverse the node; q = x; x += v dt
+ *   2. node-vs-rigid contacts: every node within the collision margin of a shape (anchored nodes excepted) gets a contact
+ *      plane at the margin surface; friction state c3 from the displacement of this substep
+ *   3. piterations x [anchors, rigid contacts, links]; links class by class (classes share no node)
+ *   4. v = (x - q) / dt (1 - kDP)
+ * The rigid bodies do not feel the cloth: the human and the robot are multibodies, which btSoftBody's rigid-contact and anchor
+ * solvers do not push (their impulses go to btRigidBody only), and the attachment sphere has no mass. */
+#define CLH(m, k) ((m)->i[(m)->o_cloth + (k)])
+#define CLPAR(m, k) ((double)(m)->f[(m)->o_cloth + CLH(m, AGX_CL_OFF_PARAM) + (k)])
+#define CLOTH_NODE_CONTACTS AGX_CLOTH_NODE_CONTACTS
+typedef struct { double n[3], offset, c3, imp[3]; } ccontact_t;
+
+/* signed distance of world point x to the surface of shape sh (negative inside) and the outward normal, world frame */
+static double cloth_shape_distance(const sim_t* s, int sh, const double* x, double* nw) {
+  const agxo_model* m = s->m; const int32_t* S = m->i + m->o_cloth + CLH(m, AGX_CL_OFF_SHAPE) + 4 * sh;
+  const int c = S[0], p0 = S[1], np = S[2];
+  const xf_t* X = body_xf(s, CI(m, c, AGX_C_BODY));
+  double d[3], xl[3]; sub3(x, X->p, d); mtv3(X->R, d, xl);
+  const double rad = CF(m, c, AGX_C_RADIUS);
+  double nl[3], dist;
+  if (np == 0) {           /* sphere / capsule: distance to the core point or segment */
+    const float* v = m->f + m->o_vert + 3 * CI(m, c, AGX_C_VOFF);
+    double a[3] = {v[0], v[1], v[2]}, cp[3] = {a[0], a[1], a[2]};
+    if (CI(m, c, AGX_C_NVERT) == 2) {
+      double b[3] = {v[3], v[4], v[5]}, ab[3], ax[3]; sub3(b, a, ab); sub3(xl, a, ax);
+      double t = dot3(ab, ab) > 0 ? dot3(ax, ab) / dot3(ab, ab) : 0; t = t < 0 ? 0 : (t > 1 ? 1 : t);
+      for (int k = 0; k < 3; k++) cp[k] = a[k] + t * ab[k];
+    }
+    sub3(xl, cp, nl); double len = sqrt(dot3(nl, nl));
+    if (len > 1e-12) { for (int k = 0; k < 3; k++) nl[k] /= len; } else { nl[0] = 0; nl[1] = 0; nl[2] = 1; }
+    dist = len - rad;
+  } else {                 /* hull: the largest face-plane distance (exact inside and in front of a face) */
+    const float* P = m->f + m->o_cloth + CLH(m, AGX_CL_OFF_PLANE) + 4 * p0;
+    int best = 0; double bd = -1e300;
+    for (int k = 0; k < np; k++) { double t = P[4 * k] * xl[0] + P[4 * k + 1] * xl[1] + P[4 * k + 2] * xl[2] - P[4 * k + 3]; if (t > bd) { bd = t; best = k; } }
+    nl[0] = P[4 * best]; nl[1] = P[4 * best + 1]; nl[2] = P[4 * best + 2];
+    dist = bd - rad;
+  }
+  mv3(X->R, nl, nw);
+  return dist;
+}
+
+static void cloth_substep(sim_t* s) {
+  const agxo_model* m = s->m; const int oc = m->o_cloth;
+  const int NN = CLH(m, AGX_CL_NN), NCOL = CLH(m, AGX_CL_NCOLOR), NA = CLH(m, AGX_CL_NANCHOR), NS = CLH(m, AGX_CL_NSHAPE);
+  const int32_t* color = m->i + oc + CLH(m, AGX_CL_OFF_COLOR);
+  const int32_t* linki = m->i + oc + CLH(m, AGX_CL_OFF_LINK); const float* linkf = m->f + oc + CLH(m, AGX_CL_OFF_LINK);
+  const int32_t* nodei = m->i + oc + CLH(m, AGX_CL_OFF_NODE); const float* nodef = m->f + oc + CLH(m, AGX_CL_OFF_NODE);
+  const int32_t* face = m->i + oc + CLH(m, AGX_CL_OFF_FACE);
+  const int32_t* anci = m->i + oc + CLH(m, AGX_CL_OFF_ANCHOR); const float* ancf = m->f + oc + CLH(m, AGX_CL_OFF_ANCHOR);
+  const double dt = m->dt, kLST = CLPAR(m, AGX_CP_KLST), kDP = CLPAR(m, AGX_CP_KDP), kDG = CLPAR(m, AGX_CP_KDG), kDF = CLPAR(m, AGX_CP_KDF);
+  const double kCHR = CLPAR(m, AGX_CP_KCHR), kAHR = CLPAR(m, AGX_CP_KAHR), mrg = CLPAR(m, AGX_CP_MARGIN), im = CLPAR(m, AGX_CP_NODE_IM);
+  const double rho = CLPAR(m, AGX_CP_AIR_DENSITY); const int piter = (int)CLPAR(m, AGX_CP_PITER);
+  double (*x)[3] = (double (*)[3])s->cx, (*v)[3] = (double (*)[3])s->cv, (*q)[3] = (double (*)[3])s->cq;
+  /* the attachment sphere sits where the end effector was when the current stepSimulation call began (dressing.py:200-210) */
+  if (!s->anchor_set) { xf_t ee; ee_frame(s, &ee); memcpy(s->anchor, ee.p, 24); s->anchor_set = 1; }
+  /* world AABB of every shape, grown by the margin: nodes outside cannot be in contact */
+  double (*slo)[3] = (double (*)[3])malloc(sizeof(double) * 3 * NS), (*shi)[3] = (double (*)[3])malloc(sizeof(double) * 3 * NS);
+  for (int sh = 0; sh < NS; sh++) {
+    const int c = m->i[oc + CLH(m, AGX_CL_OFF_SHAPE) + 4 * sh];
+    /* the core's body-frame box rotated into the world, grown by radius + margin (the same conservative box as the device code: a
+     * hull's face-plane distance can accept points beyond any box, so both sides must cull alike) */
+    const xf_t* X = body_xf(s, CI(m, c, AGX_C_BODY));
+    double cl_[3] = {CF(m, c, AGX_C_AABB_C), CF(m, c, AGX_C_AABB_C + 1), CF(m, c, AGX_C_AABB_C + 2)}, cw[3];
+    xf_apply(X, cl_, cw);
+    const double r = (double)(float)((float)CF(m, c, AGX_C_RADIUS) + (float)mrg + 1e-6f);
+    for (int k = 0; k < 3; k++) {
+      const double h = fabs(X->R[3 * k]) * CF(m, c, AGX_C_AABB_H) + fabs(X->R[3 * k + 1]) * CF(m, c, AGX_C_AABB_H + 1) + fabs(X->R[3 * k + 2]) * CF(m, c, AGX_C_AABB_H + 2) + r;
+      slo[sh][k] = cw[k] - h; shi[sh][k] = cw[k] + h;
+    }
+  }
+  uint8_t* attached = (uint8_t*)calloc(NN, 1);
+  for (int a = 0; a < NA; a++) attached[anci[4 * a]] = 1;
+  ccontact_t* con = (ccontact_t*)malloc(sizeof(ccontact_t) * CLOTH_NODE_CONTACTS * NN);
+  int* ncon = (int*)calloc(NN, sizeof(int));
+  /* 1. forces and prediction */
+  for (int i = 0; i < NN; i++) {
+    double nrm[3] = {0, 0, 0};
+    for (int e = nodei[2 * i]; e < nodei[2 * i + 2]; e++) {
+      const int j = face[e] & 0xffff, k = (face[e] >> 16) & 0xffff; double a[3], b[3], cr[3];
+      sub3(x[j], x[i], a); sub3(x[k], x[i], b); cross3(a, b, cr); add3(nrm, cr, nrm);
+    }
+    double nl = sqrt(dot3(nrm, nrm)); if (nl > 1.1920929e-7) for (int k = 0; k < 3; k++) nrm[k] /= nl;   /* btSoftBody::updateNormals */
+    double vi[3] = {v[i][0], v[i][1], v[i][2] + s->dr_gravity * dt};
+    const double v2 = dot3(vi, vi);
+    if (kDG > 0 && v2 > 1.1920929e-7) {
+      const double dvn = dot3(vi, nrm);
+      if (dvn > 0) {
+        const double vl = sqrt(v2), c1 = nodef[2 * i + 1] * dvn * v2 / 2 * rho, fmag = c1 * kDG;   /* force = -v/|v| * fmag */
+        const double dtim = dt * im;
+        if (fmag * dtim * fmag * dtim > v2) { vi[0] = 0; vi[1] = 0; vi[2] = 0; }                 /* ApplyClampedForce: it may stop the node, not reverse it */
+        else for (int k = 0; k < 3; k++) vi[k] -= vi[k] / vl * fmag * dtim;
+      }
+    }
+    for (int k = 0; k < 3; k++) { q[i][k] = x[i][k]; v[i][k] = vi[k]; }
+  }
+  for (int i = 0; i < NN; i++) for (int k = 0; k < 3; k++) x[i][k] = q[i][k] + v[i][k] * dt;
+  /* 2. contacts with the rigid shapes (CollideSDF_RS::DoNode) */
+  for (int i = 0; i < NN; i++) {
+    if (attached[i]) continue;
+    for (int sh = 0; sh < NS && ncon[i] < CLOTH_NODE_CONTACTS; sh++) {
+      const int c = m->i[oc + CLH(m, AGX_CL_OFF_SHAPE) + 4 * sh];
+      const int only = m->i[oc + CLH(m, AGX_CL_OFF_SHAPE) + 4 * sh + 3];
+      if (only && only != s->gender + 1) continue;        /* the other gender's colliders are not in the world */
+      int out = 0; for (int k = 0; k < 3; k++) if (x[i][k] < slo[sh][k] || x[i][k] > shi[sh][k]) out = 1;
+      if (out) continue;
+      double nw[3]; const double dst = cloth_shape_distance(s, sh, x[i], nw) - mrg;
+      if (dst >= 0) continue;
+      if (getenv("AGXO_TRACE_NODE") && atoi(getenv("AGXO_TRACE_NODE")) == i) fprintf(stderr, "node %d shape %d collider %d tag %d body %d dst %g n %g %g %g x %g %g %g\n", i, sh, c, CI(m, c, AGX_C_TAG), CI(m, c, AGX_C_BODY), dst, nw[0], nw[1], nw[2], x[i][0], x[i][1], x[i][2]);
+      ccontact_t* k = &con[CLOTH_NODE_CONTACTS * i + ncon[i]++];
+      memcpy(k->n, nw, 24); k->offset = -dot3(nw, x[i]) + dst; k->imp[0] = k->imp[1] = k->imp[2] = 0;
+      double vr[3]; sub3(x[i], q[i], vr); const double dn = dot3(vr, nw); double fv[3] = {vr[0] - nw[0] * dn, vr[1] - nw[1] * dn, vr[2] - nw[2] * dn};
+      const double fc = kDF * CF(m, c, AGX_C_FRICTION);
+      k->c3 = dot3(fv, fv) < (dn * fc * dn * fc) ? 0 : 1 - fc;
+    }
+  }
+  /* 3. position solver */
+  for (int it = 0; it < piter; it++) {
+    for (int a = 0; a < NA; a++) {                       /* PSolve_Anchors: x += -(x - q) + (target - x) kAHR  (static attachment body) */
+      const int i = anci[4 * a];
+      for (int k = 0; k < 3; k++) { const double wa = s->anchor[k] + ancf[4 * a + 1 + k]; x[i][k] += -(x[i][k] - q[i][k]) + (wa - x[i][k]) * kAHR; }
+    }
+    for (int i = 0; i < NN; i++) for (int cc = 0; cc < ncon[i]; cc++) {   /* PSolve_RContacts */
+      ccontact_t* k = &con[CLOTH_NODE_CONTACTS * i + cc];
+      double vr[3]; sub3(x[i], q[i], vr); const double dn = dot3(vr, k->n);
+      if (dn <= 1.1920929e-7) {
+        double dp = dot3(x[i], k->n) + k->offset; if (dp > mrg) dp = mrg;
+        for (int a = 0; a < 3; a++) {
+          const double fva = vr[a] - k->n[a] * dn, corr = vr[a] - fva * k->c3 + k->n[a] * dp * kCHR;
+          x[i][a] -= corr; k->imp[a] += corr / (dt * im);                /* impulse = c0 * corr, c0 = 1 / (dt im) for a static partner */
+        }
+      }
+    }
+    for (int c = 0; c < NCOL; c++) for (int l = color[c]; l < color[c + 1]; l++) {   /* PSolve_Links */
+      const int a = linki[2 * l] & 0xffff, b = (linki[2 * l] >> 16) & 0xffff; const double c1 = linkf[2 * l + 1];
+      double del[3]; sub3(x[b], x[a], del); const double len = dot3(del, del);
+      if (c1 + len > 1.1920929e-7) {
+        const double k = (c1 - len) / (c1 + len) * kLST * 0.5;           /* ((c1 - len) / (c0 (c1 + len))) * im with c0 = 2 im / kLST */
+        for (int t = 0; t < 3; t++) { x[a][t] -= del[t] * k; x[b][t] += del[t] * k; }
+      }
+    }
+  }
+  /* 4. velocities; contact report (position of the node, force = summed impulse / dt) */
+  for (int i = 0; i < NN; i++) for (int k = 0; k < 3; k++) v[i][k] = (x[i][k] - q[i][k]) / dt * (1 - kDP);
+  s->nccon = 0;
+  for (int i = 0; i < NN; i++) for (int cc = 0; cc < ncon[i]; cc++) {
+    const ccontact_t* k = &con[CLOTH_NODE_CONTACTS * i + cc]; double* o = s->ccon + 6 * s->nccon++;
+    for (int a = 0; a < 3; a++) { o[a] = x[i][a]; o[3 + a] = k->imp[a] / dt; }
+  }
+  free(slo); free(shi); free(attached); free(con); free(ncon);
+}
+/* one internal substep; `hooks`: this substep ends a p.stepSimulation() call, after which the reference enforces the human's joint
+ * limits and the pose-dependent arm limits (env.py:226-232) */
+static void substep_h(sim_t* s, int hooks) {
+  const agxo_model* m = s->m; int n = s->ndof; double dt = m->dt;
   kinematics(s);
+  if (s->cx) cloth_substep(s);   /* one-way coupling: the cloth sees the rigid bodies where this substep starts (btSoftBody::predictMotion precedes the rigid solve) */
   double qdd[MAXDOF];
   aba(s, NULL, 1, qdd); minv_from_aba(s);
   for (int d = 0; d < n; d++) s->vel[d] = s->qd[d] + dt * qdd[d];
@@ -1010,7 +1181,7 @@ static void substep(sim_t* s) {
   for (int d = 0; d < n; d++) {
     s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d];
     /* Agent.enforce_joint_limits on the human after every stepSimulation (env.py:229, agent.py:240-250) */
-    if ((RI(m, d, AGX_R_KIND) & 5) == 1 && !FROZEN(s, d)) {
+    if (hooks && (RI(m, d, AGX_R_KIND) & 5) == 1 && !FROZEN(s, d)) {
       if (s->q[d] < dof_lower(s, d) - (double)AGX_LIMIT_EPS) { s->q[d] = dof_lower(s, d); s->qd[d] = 0; }
       else if (s->q[d] > dof_upper(s, d) + (double)AGX_LIMIT_EPS) { s->q[d] = dof_upper(s, d); s->qd[d] = 0; }
     }
@@ -1025,7 +1196,13 @@ static void substep(sim_t* s) {
     double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     for (int k = 0; k < 4; k++) s->fquat[b][k] = qn[k] / nn;
   }
-  arm_limits(s);   /* env.py:230-231, after the limit reset above */
+  if (hooks) arm_limits(s);   /* env.py:230-231, after the limit reset above */
+}
+static void substep(sim_t* s) { substep_h(s, 1); }
+/* one p.stepSimulation(): sim_sub internal substeps (numSubSteps, dressing.py:184), the hooks after the last one */
+static void sim_step(sim_t* s) {
+  s->anchor_set = 0;   /* DressingEnv.update_targets after the previous call moved the cloth's attachment to the end effector (dressing.py:200-210) */
+  for (int k = 0; k < s->m->sim_sub; k++) substep_h(s, k == s->m->sim_sub - 1);
 }
 
 /* ------------------------------------------------------------------------------------ task layer */
@@ -1127,7 +1304,7 @@ static void observe_bed(sim_t* s, double tool_force, double total_force, double 
 }
 /* everything BedBathingEnv.step does after take_step (bed_bathing.py:15-39) */
 static void finish_bed(sim_t* s, const float* action, float* obs, float* reward, int* done, float* info) {
-  const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
+  const agxo_model* m = s->m; double dt = m->dt;
   /* get_total_force (bed_bathing.py:41-78) */
   double robot_f = 0, tool_f = 0, tool_human_f = 0, pad_f = 0;
   for (int c = 0; c < s->ncon; c++) {
@@ -1235,7 +1412,7 @@ static void observe_scratch(sim_t* s, double tool_force, double total_force, dou
 }
 /* everything ScratchItchEnv.step does after take_step (scratch_itch.py:14-44) */
 static void finish_scratch(sim_t* s, const float* action, float* obs, float* reward, int* done, float* info) {
-  const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
+  const agxo_model* m = s->m; double dt = m->dt;
   double target[3]; scratch_target(s, target);
   double r2 = TF(m, AGX_T_TARGET_RADIUS) * TF(m, AGX_T_TARGET_RADIUS);
   /* get_total_force (scratch_itch.py:46-57) */
@@ -1282,8 +1459,121 @@ static void finish_scratch(sim_t* s, const float* action, float* obs, float* rew
     info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
   }
 }
+
+/* ---- dressing (assistive_gym/envs/dressing.py) ---- */
+/* _get_obs (dressing.py:78-110) */
+static void observe_dressing(sim_t* s, double cloth_force_sum, double robot_force, float* obs) {
+  const agxo_model* m = s->m;
+  xf_t ee; ee_frame(s, &ee);
+  double pr[3], qr[4]; to_base_frame(s, ee.p, ee.R, pr, qr);
+  int o = 0;
+  for (int k = 0; k < 3; k++) obs[o++] = (float)pr[k];
+  for (int k = 0; k < 4; k++) obs[o++] = (float)qr[k];
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+    double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);   /* :84 */
+  }
+  for (int j = 0; j < 3; j++) {
+    double p[3]; to_base_frame(s, s->link[TI(m, AGX_T_OBS_LINK + j)].p, NULL, p, NULL);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)p[k];
+  }
+  obs[o++] = (float)cloth_force_sum;
+  if (s->coop) {                             /* human_obs, :100-106 */
+    double ph[3], qh[4]; to_human_frame(s, ee.p, ee.R, ph, qh);
+    for (int k = 0; k < 3; k++) obs[o++] = (float)ph[k];
+    for (int k = 0; k < 4; k++) obs[o++] = (float)qh[k];
+    for (int d = m->nrobot; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) obs[o++] = (float)s->q[d];
+    for (int j = 0; j < 3; j++) {
+      double p[3]; to_human_frame(s, s->link[TI(m, AGX_T_OBS_LINK + j)].p, NULL, p, NULL);
+      for (int k = 0; k < 3; k++) obs[o++] = (float)p[k];
+    }
+    obs[o++] = (float)cloth_force_sum; obs[o++] = (float)robot_force;
+  }
+}
+static double signed_volume(const double* a, const double* b, const double* c, const double* d) {
+  double ba[3], ca[3], da[3], cr[3]; sub3(b, a, ba); sub3(c, a, ca); sub3(d, a, da); cross3(ba, ca, cr); return dot3(cr, da) / 6.0;
+}
+static int sgn(double x) { return (x > 0) - (x < 0); }   /* np.sign */
+/* Util.line_intersects_triangle (util.py:125-132) */
+static int line_intersects_triangle(const double* p0, const double* p1, const double* p2, const double* q0, const double* q1) {
+  if (sgn(signed_volume(q0, p0, p1, p2)) != sgn(signed_volume(q1, p0, p1, p2))) {
+    int a = sgn(signed_volume(q0, q1, p0, p1)), b = sgn(signed_volume(q0, q1, p1, p2)), c = sgn(signed_volume(q0, q1, p2, p0));
+    if (a == b && b == c) return 1;
+  }
+  return 0;
+}
+/* does the point set straddle both planes through `origin` spanned by the arm axis and one of two perpendiculars (util.py:144-160)? */
+static int points_around_axis(const double (*pts)[3], int n, const double* axis_from, const double* axis_to, const double* origin) {
+  double nrm[3], tan[3], bin[3], c110[3] = {1, 1, 0};
+  sub3(axis_to, axis_from, nrm); double l = sqrt(dot3(nrm, nrm)); for (int k = 0; k < 3; k++) nrm[k] /= l;
+  cross3(c110, nrm, tan); l = sqrt(dot3(tan, tan)); for (int k = 0; k < 3; k++) tan[k] /= l;
+  cross3(tan, nrm, bin); l = sqrt(dot3(bin, bin)); for (int k = 0; k < 3; k++) bin[k] /= l;
+  int tp = 0, tn = 0, bp = 0, bn = 0;
+  for (int i = 0; i < n; i++) { double d[3]; sub3(pts[i], origin, d); double t = dot3(tan, d), b = dot3(bin, d); tp |= t > 0; tn |= t < 0; bp |= b > 0; bn |= b < 0; }
+  return tp && tn && bp && bn;
+}
+/* everything DressingEnv.step does after take_step (dressing.py:20-76) */
+static void finish_dressing(sim_t* s, const float* action, float* obs, float* reward, int* done, float* info) {
+  const agxo_model* m = s->m; const double dt = m->dt;
+  const double* shoulder = s->link[TI(m, AGX_T_OBS_LINK)].p; const double* elbow = s->link[TI(m, AGX_T_OBS_LINK + 1)].p; const double* wrist = s->link[TI(m, AGX_T_OBS_LINK + 2)].p;
+  double pts[6][3] = {{0}};
+  if (s->cx) for (int k = 0; k < 6; k++) memcpy(pts[k], s->cx + 3 * m->i[m->o_cloth + AGX_CL_TRI + k], 24);
+  /* Util.sleeve_on_arm_reward (util.py:134-202) */
+  const double rad = TF(m, AGX_T_ARM_RADIUS + s->gender);     /* hand_radius = elbow_radius = shoulder_radius */
+  double we[3], es[3]; sub3(wrist, elbow, we); sub3(shoulder, elbow, es);
+  const double lwe = sqrt(dot3(we, we)), les = sqrt(dot3(es, es));
+  double hand_end[3], elbow_end[3], shoulder_end[3];
+  for (int k = 0; k < 3; k++) { hand_end[k] = wrist[k] + we[k] / lwe * rad * 2; elbow_end[k] = elbow[k] - we[k] / lwe * rad; shoulder_end[k] = shoulder[k] + es[k] / les * rad; }
+  const int around_fore = points_around_axis(pts, 6, elbow_end, hand_end, hand_end);              /* :144-160 */
+  const int around_upper = points_around_axis(pts, 6, shoulder_end, elbow_end, shoulder_end);    /* :162-171 */
+  const int f1 = line_intersects_triangle(pts[0], pts[1], pts[2], hand_end, elbow_end), f2 = line_intersects_triangle(pts[3], pts[4], pts[5], hand_end, elbow_end);
+  const int u1 = line_intersects_triangle(pts[0], pts[1], pts[2], elbow_end, shoulder_end), u2 = line_intersects_triangle(pts[3], pts[4], pts[5], elbow_end, shoulder_end);
+  double centre[3] = {0, 0, 0}; for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) centre[k] += pts[i][k] / 6.0;
+  double d[3];
+  sub3(hand_end, centre, d); const double distance_to_hand = sqrt(dot3(d, d)), distance_along_forearm = distance_to_hand;   /* :181,189 */
+  sub3(centre, elbow, d); const double distance_along_upperarm = sqrt(dot3(d, d));                                          /* :190 */
+  sub3(hand_end, elbow_end, d); const double forearm_length = sqrt(dot3(d, d));
+  const double upperarm_length = les;                                                                                        /* |elbow_pos - shoulder_pos| */
+  const int forearm_in = around_fore && (f1 || f2), upperarm_in = around_upper && (u1 || u2);
+  /* cloth forces (:34-46): x 10, only below the end effector and below 20 */
+  xf_t ee; ee_frame(s, &ee);
+  double cloth_force_sum = 0;
+  for (int c = 0; c < s->nccon; c++) {
+    const double* k = s->ccon + 6 * c; double f[3] = {k[3] * CLPAR(m, AGX_CP_FORCE_SCALE), k[4] * CLPAR(m, AGX_CP_FORCE_SCALE), k[5] * CLPAR(m, AGX_CP_FORCE_SCALE)};
+    const double fn = sqrt(dot3(f, f));
+    if (k[2] < ee.p[2] - CLPAR(m, AGX_CP_EE_BELOW) && fn < CLPAR(m, AGX_CP_FORCE_MAX)) cloth_force_sum += fn;
+  }
+  int L = TI(m, AGX_T_EE_LINK); double wxp[3], vee[3];
+  cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
+  const double ee_speed = sqrt(dot3(vee, vee));
+  /* human_preferences(end_effector_velocity, dressing_forces) (env.py:237-274): the force terms see their defaults, 0 */
+  const double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_D) * (-cloth_force_sum);
+  double act_norm2 = 0; for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
+  double reward_dressing;
+  if (upperarm_in) { reward_dressing = forearm_length; if (distance_along_upperarm < upperarm_length) reward_dressing += distance_along_upperarm; }
+  else if (forearm_in && distance_along_forearm < forearm_length) reward_dressing = distance_along_forearm;
+  else reward_dressing = -distance_to_hand;
+  const double r = TF(m, AGX_T_W_WIPE) * reward_dressing + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + pref;
+  /* _get_obs (:95-96): robot_force_on_human from the contacts of the last substep */
+  double robot_f = 0;
+  for (int c = 0; c < s->ncon; c++) {
+    const contact_t* k = &s->con[c]; int ta = CI(m, k->ca, AGX_C_TAG), tb = CI(m, k->cb, AGX_C_TAG);
+    if ((ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN) && (ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT)) robot_f += k->lambda_n / dt;
+  }
+  s->dr_force_sum = cloth_force_sum;
+  observe_dressing(s, cloth_force_sum, robot_f, obs);
+  if (reward_dressing > s->dr_best) s->dr_best = reward_dressing;                 /* :62-63 */
+  *reward = (float)r;
+  *done = s->iteration >= (int)TF(m, AGX_T_EPISODE_LEN);
+  if (info) {
+    info[AGX_INFO_TOTAL_FORCE] = (float)(robot_f + cloth_force_sum);
+    info[AGX_INFO_TASK_SUCCESS] = (float)(s->dr_best >= TF(m, AGX_T_SUCCESS_FRAC));
+    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)cloth_force_sum;
+    info[AGX_INFO_FOOD_REWARD] = (float)reward_dressing; info[AGX_INFO_PREF] = (float)pref;
+    info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
+  }
+}
 static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int* food_hit_mask) {
-  const agxo_model* m = s->m; double dt = PARAM(m, AGX_P_DT);
+  const agxo_model* m = s->m; double dt = m->dt;
   *robot_f = 0; *tool_f = 0; *food_hit_mask = s->food_near_human;
   for (int c = 0; c < s->ncon; c++) {
     const contact_t* k = &s->con[c];
@@ -1300,21 +1590,47 @@ void agxo_observe(const agxo_model* m, const float* state, float* obs) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s); update_target(s);
   if (m->task_kind == AGX_TASK_BED_BATHING) observe_bed(s, 0, 0, 0, obs);
   else if (m->task_kind == AGX_TASK_SCRATCH_ITCH) observe_scratch(s, 0, 0, 0, obs);
+  else if (m->task_kind == AGX_TASK_DRESSING) observe_dressing(s, s->dr_force_sum, 0, obs);
   else observe(s, 0, 0, obs);
   free(s);
 }
 
-void agxo_settle(const agxo_model* m, float* state, int n_substeps) {
+/* the cloth travels next to the state record: float[2][NN][3], node positions then node velocities */
+int agxo_cloth_nodes(const agxo_model* m) { return m->o_cloth ? m->i[m->o_cloth + AGX_CL_NN] : 0; }
+static void cloth_attach(sim_t* s, const float* cloth) {
+  if (!cloth || !s->m->o_cloth) return;
+  const int n3 = 3 * agxo_cloth_nodes(s->m);
+  s->cx = (double*)malloc(sizeof(double) * n3); s->cv = (double*)malloc(sizeof(double) * n3); s->cq = (double*)malloc(sizeof(double) * n3);
+  s->ccon = (double*)malloc(sizeof(double) * 6 * CLOTH_NODE_CONTACTS * (n3 / 3));
+  for (int k = 0; k < n3; k++) { s->cx[k] = cloth[k]; s->cv[k] = cloth[n3 + k]; }
+}
+static void cloth_detach(sim_t* s, float* cloth) {
+  if (!s->cx) return;
+  const int n3 = 3 * agxo_cloth_nodes(s->m);
+  for (int k = 0; k < n3; k++) { cloth[k] = (float)s->cx[k]; cloth[n3 + k] = (float)s->cv[k]; }
+  free(s->cx); free(s->cv); free(s->cq); free(s->ccon); s->cx = NULL;
+}
+void agxo_settle_cloth(const agxo_model* m, float* state, float* cloth, int n_sim_steps) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
   s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
-  for (int k = 0; k < n_substeps; k++) substep(s);
+  cloth_attach(s, cloth);
+  for (int k = 0; k < n_sim_steps; k++) sim_step(s);
   kinematics(s); update_target(s);
+  cloth_detach(s, cloth);
   sim_store(s, state); free(s->rows); free(s);
 }
+void agxo_settle(const agxo_model* m, float* state, int n_substeps) { agxo_settle_cloth(m, state, NULL, n_substeps); }
+/* contacts of the cloth with the rigid shapes in the last substep of the last call: {x, y, z, fx, fy, fz} each (tests) */
+static double g_ccon[6 * 4096]; static int g_nccon = 0;
+int agxo_cloth_contacts(double* out, int max_out) { int n = g_nccon < max_out ? g_nccon : max_out; memcpy(out, g_ccon, sizeof(double) * 6 * n); return g_nccon; }
 
 void agxo_step(const agxo_model* m, float* state, const float* action, float* obs, float* reward, int* done, float* info) {
+  agxo_step_cloth(m, state, NULL, action, obs, reward, done, info);
+}
+void agxo_step_cloth(const agxo_model* m, float* state, float* cloth, const float* action, float* obs, float* reward, int* done, float* info) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
   s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
+  cloth_attach(s, cloth);
   int nsub = (int)PARAM(m, AGX_P_FRAME_SKIP);
   /* take_step (env.py:174-222): clip, scale (float32 arithmetic as numpy does for a float32 action),
    * 5x accumulate with per-joint limit clamp, set motor targets */
@@ -1343,8 +1659,13 @@ void agxo_step(const agxo_model* m, float* state, const float* action, float* ob
   /* tremor without control (env.py:212-215): target + tremors * (+1 on even iterations, -1 on odd) */
   if (!s->coop) for (int k = 0; k < m->nhdof; k++) s->qt[m->nrobot + k] = s->tremor_target[k] + s->tremor[k] * tsign;
   for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
-  for (int k = 0; k < nsub; k++) substep(s);
+  for (int k = 0; k < nsub; k++) sim_step(s);
   kinematics(s); /* poses after the last integration, as the getters in _get_obs see them */
+  if (m->task_kind == AGX_TASK_DRESSING) {
+    finish_dressing(s, action, obs, reward, done, info);
+    g_nccon = s->cx ? (s->nccon < 4096 ? s->nccon : 4096) : 0; if (g_nccon) memcpy(g_ccon, s->ccon, sizeof(double) * 6 * g_nccon);
+    cloth_detach(s, cloth); sim_store(s, state); free(s->rows); free(s); return;
+  }
   if (m->task_kind == AGX_TASK_BED_BATHING) { finish_bed(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   if (m->task_kind == AGX_TASK_SCRATCH_ITCH) { finish_scratch(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   update_target(s); /* FeedingEnv.update_targets (feeding.py:192-196) */

@@ -33,6 +33,13 @@ void agxo_step(const agxo_model* m, float* state, const float* action, float* ob
                int* done, float* info);
 /* n physics substeps without action processing / rewards (reset-time settling, feeding.py:178-179) */
 void agxo_settle(const agxo_model* m, float* state, int n_substeps);
+/* models with a cloth section (DressingBaxter): the garment travels next to the state record as float[2][NN][3] (node positions,
+ * node velocities); n_sim_steps counts p.stepSimulation() calls (SIM_SUBSTEPS internal substeps each).  cloth may be NULL: the
+ * rigid scene alone is stepped */
+int agxo_cloth_nodes(const agxo_model* m);
+void agxo_step_cloth(const agxo_model* m, float* state, float* cloth, const float* action, float* obs, float* reward, int* done, float* info);
+void agxo_settle_cloth(const agxo_model* m, float* state, float* cloth, int n_sim_steps);
+int agxo_cloth_contacts(double* out, int max_out);
 /* observation only (reset() return value, feeding.py:182) */
 void agxo_observe(const agxo_model* m, const float* state, float* obs);
 

@@ -28,6 +28,10 @@ def lib():
                      'agxo_rnea_bias', 'agxo_minv'):
             getattr(L, name).restype = None
         L.agxo_gjk.restype = C.c_int
+        for name in ('agxo_step_cloth', 'agxo_settle_cloth'):
+            getattr(L, name).restype = None
+        L.agxo_cloth_nodes.restype = C.c_int
+        L.agxo_cloth_contacts.restype = C.c_int
         L.agxo_collide.restype = C.c_int
         L.agxo_substep_debug.restype = C.c_int
         L.agxo_rows_debug.restype = C.c_int
@@ -63,6 +67,26 @@ class Oracle:
         action = np.ascontiguousarray(action, dtype=np.float32)
         self.L.agxo_step(C.c_void_p(self.h), _p(state), _p(action), _p(obs), _p(rew), _p(done), _p(info))
         return obs, float(rew[0]), bool(done[0]), info
+
+    # ---- models with a cloth section: the garment is a float32 [2, NN, 3] array (positions, velocities) next to the state record
+    def step_cloth(self, state, cloth, action):
+        obs = np.zeros(self.blob.obs_dim, dtype=np.float32)
+        rew = np.zeros(1, dtype=np.float32)
+        done = np.zeros(1, dtype=np.int32)
+        info = np.zeros(8, dtype=np.float32)
+        action = np.ascontiguousarray(action, dtype=np.float32)
+        assert cloth.dtype == np.float32 and cloth.flags['C_CONTIGUOUS']
+        self.L.agxo_step_cloth(C.c_void_p(self.h), _p(state), _p(cloth), _p(action), _p(obs), _p(rew), _p(done), _p(info))
+        return obs, float(rew[0]), bool(done[0]), info
+
+    def settle_cloth(self, state, cloth, n_sim_steps):
+        assert cloth.dtype == np.float32 and cloth.flags['C_CONTIGUOUS']
+        self.L.agxo_settle_cloth(C.c_void_p(self.h), _p(state), _p(cloth), C.c_int(n_sim_steps))
+
+    def cloth_contacts(self, max_out=4096):
+        out = np.zeros((max_out, 6))
+        n = self.L.agxo_cloth_contacts(_p(out), C.c_int(max_out))
+        return out[:min(n, max_out)]
 
     def settle(self, state, n):
         self.L.agxo_settle(C.c_void_p(self.h), _p(state), C.c_int(n))

@@ -34,13 +34,14 @@ def parse_enums():
 def test_layout_tables_match_header():
     v = parse_enums()
     for prefix, table in (('AGX_H_', L.H), ('AGX_P_', L.P), ('AGX_R_', L.R), ('AGX_F_', L.F), ('AGX_C_', L.C), ('AGX_G_', L.G),
-                          ('AGX_T_', L.T), ('AGX_E_', L.E), ('AGX_X_', L.X_), ('AGX_XJ_', L.XJ)):
+                          ('AGX_T_', L.T), ('AGX_E_', L.E), ('AGX_X_', L.X_), ('AGX_XJ_', L.XJ), ('AGX_CL_', L.CL), ('AGX_CP_', L.CP), ('AGX_DR_', L.DR)):
         for k, val in table.items():
             assert v[prefix + k] == val, (prefix + k, v[prefix + k], val)
     assert v['AGX_BLOB_MAGIC'] == L.MAGIC and v['AGX_BLOB_VERSION'] == L.VERSION
     assert v['AGX_BODY_ROBOT_BASE'] == L.BODY_ROBOT_BASE and v['AGX_BODY_FREE0'] == L.BODY_FREE0 and v['AGX_BODY_HUMAN0'] == L.BODY_HUMAN0
     for k, val in L.TAG.items():
         assert v['AGX_TAG_' + k] == val
+    assert (v['AGX_CLOTH_MAX_COLORS'], v['AGX_CLOTH_THREADS'], v['AGX_CLOTH_NODE_CONTACTS']) == (L.CLOTH_MAX_COLORS, L.CLOTH_THREADS, L.CLOTH_NODE_CONTACTS)
     for k, val in L.KIND.items():
         assert v['AGX_KIND_' + k] == val
 
