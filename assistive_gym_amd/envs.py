@@ -246,7 +246,33 @@ class ScratchItchPR2HumanEnv(ScratchItchPR2Env):
     coop = True
 
 
-ENV_IDS = {'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
+class DressingBaxterEnv(AssistiveEnv):
+    """DressingBaxter-v1 (dressing_envs.py:19-21; BASELINE config 5): Baxter's left arm pulls the sleeve of a hospital gown over the left
+    arm of the seated human.  The garment (3,966 nodes) lives next to the state record on the device."""
+    model, task = 'dressing_baxter', 'dressing'
+
+    def reset(self):
+        """DressingEnv.reset (dressing.py:112-198): the draws, the TOC base pose search and the IK restated on the host
+        (host/reset_dressing.py); the garment is loaded relative to the end effector and settles for 50 steps on the device."""
+        from .host.reset_dressing import make_states, ClothSettler
+        st = self._ensure_stepper()
+        if not hasattr(self, '_settler'):
+            self._settler = ClothSettler(self.blob, 1, self.device)
+        self.reset_seed = self._draw_seed()
+        rec, cloth, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler)
+        st.set_state(rec)
+        st.set_cloth(cloth)
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+
+class DressingBaxterHumanEnv(DressingBaxterEnv):
+    """DressingBaxterHuman-v1 (dressing_envs.py:51-55): the human's left arm (10 joints) is controllable, the pose-dependent arm limits
+    run after every stepSimulation; actions {'robot': a[7], 'human': a[10]}, observations 24 + 28."""
+    coop = True
+
+
+ENV_IDS = {'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
            'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
 
 

@@ -28,6 +28,12 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     if blob.task_kind == L.TASK_SCRATCH_ITCH:
         from .host.reset_scratch import make_states as make_scratch_states
         return make_scratch_states(blob, pool_size, seed=seed, impairment=impairment)[0]
+    if blob.task_kind == L.TASK_DRESSING:
+        # DressingEnv.reset restated on the host (host/reset_dressing.py) around the 50-step cloth settle on the device;
+        # returns (states, garments): the garment of a pool entry travels with its state record
+        from .host.reset_dressing import make_states as make_dressing_states, ClothSettler
+        st, cloth, _ = make_dressing_states(blob, pool_size, seed=seed, impairment=impairment, settler=ClothSettler(blob, pool_size, device))
+        return st, cloth
     st = Stepper(blob, pool_size, device)
     if sampler == 'device':
         st.sample_reset(seed, impairment=impairment)
@@ -98,9 +104,15 @@ class AssistiveVecEnv:
             if self.pool is None:
                 self.pool_host = build_reset_pool(self.blob, self.pool_size, self.seed, self.device_index, self.impairment,
                                                   sampler='host' if self.reset_mode == 'host' else 'device')
+                if isinstance(self.pool_host, tuple):         # models with a cloth: (states, garments)
+                    self.pool_host, self.cloth_pool_host = self.pool_host
+                    self.cloth_pool = torch.from_numpy(self.cloth_pool_host).to(self.device)
+                    self.stepper.set_cloth_pool(self.cloth_pool)
                 self.pool = torch.from_numpy(self.pool_host).to(self.device)
             idx = pool_indices(env_offset, self.n_envs, self.pool_size)
             self.stepper.set_state(self.pool_host[idx])
+            if getattr(self, 'cloth_pool_host', None) is not None:
+                self.stepper.set_cloth(self.cloth_pool_host[idx])
             self.stepper.set_env_offset(env_offset)       # later episodes draw from the pool by GLOBAL env index too
         self.stepper.observe_dev(self.obs, s)
         return self.obs
@@ -157,4 +169,20 @@ class ScratchItchPR2VecEnv(AssistiveVecEnv):
 
 
 class ScratchItchPR2HumanVecEnv(ScratchItchPR2VecEnv):
+    coop = True
+
+
+class DressingBaxterVecEnv(AssistiveVecEnv):
+    """BASELINE config 5: DressingBaxter-v1 (dressing_envs.py:19-21).  Every environment carries a garment of 3,966 nodes next to its
+    state record; resets come from a pool of (state, settled garment) pairs built once (host/reset_dressing.py + the device settle)."""
+    model = 'dressing_baxter'
+
+    def __init__(self, n_envs, **kw):
+        kw.setdefault('reset', 'pool')
+        kw.setdefault('pool_size', 64)
+        assert kw['reset'] != 'device', 'no device-side reset generator for DressingBaxter: use a pool'
+        super().__init__(n_envs, **kw)
+
+
+class DressingBaxterHumanVecEnv(DressingBaxterVecEnv):
     coop = True
