@@ -15,15 +15,17 @@ OUT = os.path.join(HERE, 'lib', 'libagx.so')
 VARIANTS = ['FEEDING', 'BED_BATHING', 'SCRATCH_ITCH', 'BED_SETTLE', 'DRESSING']
 
 
-def build(force=False, verbose=False, extra=()):
+def build(force=False, verbose=False, extra=(), out=None):
+    """out / extra: an A/B build of the same library with extra compiler flags (same-box comparisons: AGX_LIB=<out> python bench.py)"""
+    OUT = out or globals()['OUT']
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    if not force and not out and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value'] + list(extra)
     if verbose:
         base.append('-Rpass-analysis=kernel-resource-usage')
-    objdir = os.path.join(HERE, 'lib', 'obj')
+    objdir = os.path.join(HERE, 'lib', 'obj' if not out else 'obj_' + os.path.splitext(os.path.basename(out))[0])
     os.makedirs(objdir, exist_ok=True)
     jobs = [(os.path.join(objdir, 'agx_api.o'), base + ['-c', os.path.join(CSRC, 'agx_api.hip')])]
     for v in VARIANTS:
@@ -35,4 +37,7 @@ def build(force=False, verbose=False, extra=()):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))
+    a = sys.argv
+    out = a[a.index('--out') + 1] if '--out' in a else None
+    extra = a[a.index('--extra') + 1].split() if '--extra' in a else ()
+    print(build(force='--force' in a, verbose='-v' in a, extra=extra, out=out))

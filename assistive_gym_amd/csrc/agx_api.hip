@@ -162,8 +162,8 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     h->cloth_nn = cl[AGX_CL_NN];
     h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn);
     h->trace_words = h->frame_skip * h->sim_sub * hi[AGX_H_NDOF] * 12;
-    h->cloth_lds = 4 * (6 * h->cloth_nn + 12 * 64 + 6 * 192 + 192 + 4 + 6 * (AGX_CLOTH_THREADS / 64) + 4);   // agxc::lds_words
-    if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4 * AGX_CLOTH_THREADS || cl[AGX_CL_NCOLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_MAX_LINKS_PER_COLOR] > AGX_CLOTH_THREADS ||
+    h->cloth_lds = 4 * (6 * h->cloth_nn + 12 * 64 + 6 * 192 + 192 + 4 + 6 * (AGX_CLOTH_THREADS / 64) + 4 + 12 * 192 + 3 * 3584 + 4);   // agxc::lds_words
+    if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4096 || cl[AGX_CL_NCOLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_MAX_LINKS_PER_COLOR] > 1024 ||
         cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + 2 > 64 || cl[AGX_CL_NN] > 65535 || hi[AGX_H_NFREE] != 0) { delete h; return fail(AGX_E_LIMIT, "agx_create: cloth exceeds the limits of the cloth kernel"); }
     HIPCHK(hipMalloc(&h->cloth_dev, (size_t)n_envs * h->cloth_words * 4)); HIPCHK(hipMemset(h->cloth_dev, 0, (size_t)n_envs * h->cloth_words * 4));
     HIPCHK(hipMalloc(&h->trace_dev, (size_t)n_envs * h->trace_words * 4)); HIPCHK(hipMemset(h->trace_dev, 0, (size_t)n_envs * h->trace_words * 4));

@@ -21,7 +21,9 @@
 namespace agxc {
 
 constexpr int T = AGX_CLOTH_THREADS;
-constexpr int NPT = 4;                    // nodes per thread: ceil(3966 / 1024)
+constexpr int NPT = 4096 / T;              // nodes per thread (garments of up to 4,096 nodes)
+constexpr int LPT = 1024 / T;              // links per thread and colour class (classes hold at most 1,024 links)
+constexpr int IMP_SLOTS = 3584;           // contacts of the last substep whose impulses are summed for the report (LDS)
 constexpr int NODE_CONTACTS = 2;          // AGX_CLOTH_NODE_CONTACTS: contacts kept per node (the first ones in shape order)
 constexpr int MAX_BODIES = 64, MAX_SHAPES = 192;
 constexpr float EPS = 1.1920929e-7f;      // SIMD_EPSILON
@@ -53,8 +55,11 @@ struct Lds {
   int* cand; int* ncand;         // candidate shapes of this substep, in shape order
   float* red;                    // [16 waves][6] bounding-box reduction
   float* anchor;                 // [3]
+  float* imp; int* nimp;         // [IMP_SLOTS][3] summed contact impulses of the last substep, allocation counter
+  float* shape;                  // [MAX_SHAPES][12]: body slot (int), face planes (int count, int first), radius, core vertex 0 (3), core vertex 1 (3), kDF x friction, unused
 };
-constexpr int lds_words(int nn) { return 6 * nn + 12 * MAX_BODIES + 6 * MAX_SHAPES + MAX_SHAPES + 4 + 6 * (T / 64) + 4; }
+constexpr int SHAPE_WORDS = 12;
+constexpr int lds_words(int nn) { return 6 * nn + 12 * MAX_BODIES + 6 * MAX_SHAPES + MAX_SHAPES + 4 + 6 * (T / 64) + 4 + SHAPE_WORDS * MAX_SHAPES + 3 * IMP_SLOTS + 4; }
 
 __device__ inline int body_slot(int code, int ndof, int nhuman) {
   if (code == AGX_BODY_WORLD) return ndof + 1 + nhuman;
@@ -63,39 +68,31 @@ __device__ inline int body_slot(int code, int ndof, int nhuman) {
   return code;                   // moving link (the dressing scene has no free bodies)
 }
 
-// signed distance of world point x to the surface of shape `sh` (negative inside) and the outward normal, world frame
-__device__ inline float shape_distance(const int* bi, const float* bf, const int* cl, const float* clf, const Lds& S, int sh, f3 x, int ndof, int nhuman, f3& nw) {
-  const int o_coll = bi[AGX_H_OFF_COLL], o_vert = bi[AGX_H_OFF_VERT];
-  const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * sh;
-  const int c = rec[0], p0 = rec[1], np = rec[2];
-  const int* ci = bi + o_coll + c * AGX_C_STRIDE; const float* cf = bf + o_coll + c * AGX_C_STRIDE;
-  const float* B = S.body + 12 * body_slot(ci[AGX_C_BODY], ndof, nhuman);
+// signed distance of world point x to the surface of shape `sh` (negative inside) and the outward normal, world frame; the shape's
+// record comes from the LDS table filled once per launch, only the face planes of hulls are read from the blob (L2)
+__device__ inline float shape_distance(const float* clf, const int* cl, const Lds& S, int sh, f3 x, f3& nw) {
+  const float* rec = S.shape + SHAPE_WORDS * sh; const int* reci = (const int*)rec;
+  const float* B = S.body + 12 * reci[0];
   const f3 xl = rot_t(B + 3, x - ld(B));
-  const float rad = cf[AGX_C_RADIUS];
+  const int np = reci[1]; const float rad = rec[3];
   f3 nl; float dist;
   if (np == 0) {
-    const float* v = bf + o_vert + 3 * ci[AGX_C_VOFF];
-    const f3 a = ld(v); f3 cp = a;
-    if (ci[AGX_C_NVERT] == 2) {
-      const f3 ab = ld(v + 3) - a, ax = xl - a; const float l2 = dot(ab, ab);
-      float t = l2 > 0.f ? dot(ax, ab) / l2 : 0.f; t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
-      cp = a + t * ab;
-    }
-    nl = xl - cp; const float len = sqrtf(dot(nl, nl));
+    const f3 a = ld(rec + 4), ab = ld(rec + 7) - a, ax = xl - a; const float l2 = dot(ab, ab);
+    float t = l2 > 0.f ? dot(ax, ab) / l2 : 0.f; t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+    nl = xl - (a + t * ab); const float len = sqrtf(dot(nl, nl));
     if (len > 1e-12f) nl = (1.0f / len) * nl; else nl = mk(0.f, 0.f, 1.f);
     dist = len - rad;
   } else {
-    const float* P = clf + cl[AGX_CL_OFF_PLANE] + 4 * p0;
-    int best = 0; float bd = -3.0e38f;
-    for (int k = 0; k < np; k++) { const float t = P[4 * k] * xl.x + P[4 * k + 1] * xl.y + P[4 * k + 2] * xl.z - P[4 * k + 3]; if (t > bd) { bd = t; best = k; } }
-    nl = mk(P[4 * best], P[4 * best + 1], P[4 * best + 2]);
+    const float4* P = (const float4*)(clf + cl[AGX_CL_OFF_PLANE]) + reci[2];   // 16-byte aligned by the model compiler
+    float bd = -3.0e38f; nl = mk(0.f, 0.f, 1.f);
+    for (int k = 0; k < np; k++) { const float4 pl = P[k]; const float t = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w; if (t > bd) { bd = t; nl = mk(pl.x, pl.y, pl.z); } }
     dist = bd - rad;
   }
   nw = rot(B + 3, nl);
   return dist;
 }
 
-struct Contact { f3 n; float offset, c3; f3 imp; };
+struct Contact { f3 n; float offset, c3; int slot; };   // slot: impulse accumulator in LDS (last substep only), -1 = none
 
 // one env step of the garment: `nsub` internal substeps, substep k reading the link frames of trace slot k.
 // gcloth: float[2][NN][3] positions then velocities (in/out); greport: see agx_blob.h AGX_CLOTH_REPORT (written after the last substep)
@@ -113,29 +110,34 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   const int gender = ((const int*)gstate)[s_env + AGX_E_GENDER];
   const float grav = gstate[s_task + AGX_DR_CLOTH_GRAVITY];
   Lds S; S.x = lds; S.q = S.x + 3 * NN; S.body = S.q + 3 * NN; S.box = S.body + 12 * MAX_BODIES; S.cand = (int*)(S.box + 6 * MAX_SHAPES);
-  S.ncand = S.cand + MAX_SHAPES; S.red = (float*)(S.ncand + 4); S.anchor = S.red + 6 * (T / 64);
+  S.ncand = S.cand + MAX_SHAPES; S.red = (float*)(S.ncand + 4); S.anchor = S.red + 6 * (T / 64); S.shape = S.anchor + 4; S.imp = S.shape + SHAPE_WORDS * MAX_SHAPES; S.nimp = (int*)(S.imp + 3 * IMP_SLOTS);
   const int* nodei = cl + cl[AGX_CL_OFF_NODE]; const float* nodef = clf + cl[AGX_CL_OFF_NODE];
   const int* face = cl + cl[AGX_CL_OFF_FACE];
   const int* anci = cl + cl[AGX_CL_OFF_ANCHOR]; const float* ancf = clf + cl[AGX_CL_OFF_ANCHOR];
   const int* color = cl + cl[AGX_CL_OFF_COLOR];
-  // this thread's link of every colour class (registers)
-  int lk[AGX_CLOTH_MAX_COLORS]; float lrest[AGX_CLOTH_MAX_COLORS];
-#pragma unroll
-  for (int c = 0; c < AGX_CLOTH_MAX_COLORS; c++) {
-    lk[c] = -1; lrest[c] = 0.f;
-    if (c < NCOL) { const int l = color[c] + tid; if (l < color[c + 1]) { lk[c] = cl[cl[AGX_CL_OFF_LINK] + 2 * l]; lrest[c] = clf[cl[AGX_CL_OFF_LINK] + 2 * l + 1]; } }
-  }
+  // links: thread tid relaxes link number tid (+ T, ...) of every colour class.  The link table (93 KB, shared by all environments: L2)
+  // is streamed, one class ahead of its use, instead of being held in registers (30 VGPRs that the contact phase needs).
+  const int2* links = (const int2*)(cl + cl[AGX_CL_OFF_LINK]);
   // static frames: robot base, human bodies, world; load x, and q := x - v dt / (1 - kDP) so that the implicit velocity of the first substep is v
   if (tid == 0) {
     float* B = S.body + 12 * ndof; const float* r = gstate + bi[AGX_H_S_BASE]; st(B, ld(r)); quat_to_mat(r + 3, B + 3);
     float* W = S.body + 12 * (ndof + 1 + nhuman); st(W, mk(0.f, 0.f, 0.f)); W[3] = 1; W[4] = 0; W[5] = 0; W[6] = 0; W[7] = 1; W[8] = 0; W[9] = 0; W[10] = 0; W[11] = 1;
   }
   if (tid >= 64 && tid < 64 + nhuman) { const int h = tid - 64; float* B = S.body + 12 * (ndof + 1 + h); const float* r = gstate + bi[AGX_H_S_HUMAN] + 7 * h; st(B, ld(r)); quat_to_mat(r + 3, B + 3); }
+  if (tid >= 128 && tid < 128 + NS) {     // shape table
+    const int sh = tid - 128; const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * sh; const int c = rec[0];
+    const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
+    float* o = S.shape + SHAPE_WORDS * sh; int* oi = (int*)o;
+    oi[0] = body_slot(ci[AGX_C_BODY], ndof, nhuman); oi[1] = rec[2]; oi[2] = rec[1]; o[3] = cf[AGX_C_RADIUS];
+    const float* v = bf + bi[AGX_H_OFF_VERT] + 3 * ci[AGX_C_VOFF];
+    st(o + 4, ld(v)); st(o + 7, ci[AGX_C_NVERT] == 2 ? ld(v + 3) : ld(v)); o[10] = kDF * cf[AGX_C_FRICTION]; o[11] = 0.f;
+  }
   const float vscale = dt / (1.0f - kDP);
   for (int k = tid; k < 3 * NN; k += T) { const float xv = gcloth[k]; S.x[k] = xv; S.q[k] = xv - gcloth[3 * NN + k] * vscale; }
-  bool attached[NPT];
+  // ownership: slot tid + j T of the Morton-ordered node list (-1: none); the 64 nodes of a wave and a j lie close together
+  int own[NPT]; bool attached[NPT];
 #pragma unroll
-  for (int j = 0; j < NPT; j++) { const int i = tid + j * T; attached[j] = false; for (int a = 0; a < NA; a++) if (anci[4 * a] == i) attached[j] = true; }
+  for (int j = 0; j < NPT; j++) { const int i = cl[cl[AGX_CL_OFF_PERM] + tid + j * T]; own[j] = i; attached[j] = false; for (int a = 0; a < NA; a++) if (anci[4 * a] == i) attached[j] = true; }
   Contact con[NPT][NODE_CONTACTS]; int ncon[NPT];
   __syncthreads();
   for (int sub = 0; sub < nsub; sub++) {
@@ -143,6 +145,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     const float* tr = gtrace + (size_t)sub * ndof * 12;
     for (int k = tid; k < 12 * ndof; k += T) S.body[k] = tr[k];
     __syncthreads();
+    if (tid == 0) *S.nimp = 0;
     if (sub % S_ == 0 && tid == 0) {     // end-effector frame origin = link frame * EE_POS (dressing.py:200-210)
       const int ot = bi[AGX_H_OFF_TASK]; const float* B = S.body + 12 * bi[ot + AGX_T_EE_LINK];
       st(S.anchor, ld(B) + rot(B + 3, ld(bf + ot + AGX_T_EE_POS)));
@@ -150,14 +153,14 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     // cloth bounding box
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
-    for (int j = 0; j < NPT; j++) { const int i = tid + j * T; if (i < NN) for (int a = 0; a < 3; a++) { const float v = S.x[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); } }
+    for (int j = 0; j < NPT; j++) { const int i = own[j]; if (i >= 0) for (int a = 0; a < 3; a++) { const float v = S.x[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); } }
     for (int a = 0; a < 3; a++) for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
     if (lane == 0) for (int a = 0; a < 3; a++) { S.red[6 * wave + a] = lo[a]; S.red[6 * wave + 3 + a] = hi[a]; }
     // shape boxes: world AABB of the collider (core box rotated + radius) grown by the margin
     if (tid < NS) {
       const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * tid; const int c = rec[0];
-      const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
-      const float* B = S.body + 12 * body_slot(ci[AGX_C_BODY], ndof, nhuman);
+      const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
+      const float* B = S.body + 12 * ((const int*)S.shape)[SHAPE_WORDS * tid];
       const f3 cw = ld(B) + rot(B + 3, ld(cf + AGX_C_AABB_C)); const f3 h = ld(cf + AGX_C_AABB_H); const float r = cf[AGX_C_RADIUS] + mrg + 1e-6f;
       const float* R = B + 3;
       const float hx = fabsf(R[0]) * h.x + fabsf(R[1]) * h.y + fabsf(R[2]) * h.z + r, hy = fabsf(R[3]) * h.x + fabsf(R[4]) * h.y + fabsf(R[5]) * h.z + r,
@@ -183,11 +186,13 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     f3 vnew[NPT];
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
-      const int i = tid + j * T; vnew[j] = mk(0.f, 0.f, 0.f);
-      if (i < NN) {
+      const int i = own[j]; vnew[j] = mk(0.f, 0.f, 0.f);
+      if (i >= 0) {
         const f3 xi = ld(S.x + 3 * i);
         f3 nrm = mk(0.f, 0.f, 0.f);
+#ifndef AGXC_NO_NORMALS
         for (int e = nodei[2 * i]; e < nodei[2 * i + 2]; e++) { const int fe = face[e]; nrm = nrm + cross(ld(S.x + 3 * (fe & 0xffff)) - xi, ld(S.x + 3 * ((fe >> 16) & 0xffff)) - xi); }
+#endif
         const float nl = sqrtf(dot(nrm, nrm)); if (nl > EPS) nrm = (1.0f / nl) * nrm;
         f3 v = ((1.0f - kDP) / dt) * (xi - ld(S.q + 3 * i));
         v.z += grav * dt;
@@ -204,26 +209,54 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NPT; j++) { const int i = tid + j * T; if (i < NN) { const f3 xi = ld(S.x + 3 * i); st(S.q + 3 * i, xi); st(S.x + 3 * i, xi + dt * vnew[j]); } }
+    for (int j = 0; j < NPT; j++) { const int i = own[j]; if (i >= 0) { const f3 xi = ld(S.x + 3 * i); st(S.q + 3 * i, xi); st(S.x + 3 * i, xi + dt * vnew[j]); } }
     __syncthreads();
     // (c) contacts of this thread's nodes (CollideSDF_RS::DoNode)
+#ifdef AGXC_NO_CONTACTS
+    const int ncand = 0;
+#else
     const int ncand = *S.ncand;
+#endif
+    // candidates outermost (their boxes are read once per thread, the next one while the current one is tested), this thread's nodes
+    // innermost.  A shape whose box misses the box of the wave's 64 nodes of slot j (wave uniform, kept in scalar registers) is skipped
+    // for all of them with one test: the nodes of a wave are neighbours on the garment (Morton ownership order).
+    f3 xs[NPT], qs[NPT]; bool mine[NPT];
+    float wlo[NPT][3], whi[NPT][3];
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
-      const int i = tid + j * T; ncon[j] = 0;
-      if (i < NN && !attached[j]) {
-        const f3 xi = ld(S.x + 3 * i), qi = ld(S.q + 3 * i);
-        for (int k = 0; k < ncand && ncon[j] < NODE_CONTACTS; k++) {
-          const int sh = S.cand[k]; const float* bx = S.box + 6 * sh;
-          if (xi.x < bx[0] || xi.y < bx[1] || xi.z < bx[2] || xi.x > bx[3] || xi.y > bx[4] || xi.z > bx[5]) continue;
-          f3 nw; const float dst = shape_distance(bi, bf, cl, clf, S, sh, xi, ndof, nhuman, nw) - mrg;
-          if (dst >= 0.f) continue;
-          Contact& c = con[j][ncon[j] == 0 ? 0 : 1]; ncon[j]++;
-          c.n = nw; c.offset = -dot(nw, xi) + dst; c.imp = mk(0.f, 0.f, 0.f);
-          const f3 vr = xi - qi; const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
-          const float fc = kDF * bf[bi[AGX_H_OFF_COLL] + cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh] * AGX_C_STRIDE + AGX_C_FRICTION];
-          c.c3 = dot(fv, fv) < (dn * fc * dn * fc) ? 0.f : 1.f - fc;
-        }
+      const int i = own[j]; ncon[j] = 0; mine[j] = i >= 0 && !attached[j];
+      xs[j] = mine[j] ? ld(S.x + 3 * i) : mk(0.f, 0.f, 0.f); qs[j] = mine[j] ? ld(S.q + 3 * i) : mk(0.f, 0.f, 0.f);
+      float l3[3] = {mine[j] ? xs[j].x : 3.0e38f, mine[j] ? xs[j].y : 3.0e38f, mine[j] ? xs[j].z : 3.0e38f}, h3[3] = {mine[j] ? xs[j].x : -3.0e38f, mine[j] ? xs[j].y : -3.0e38f, mine[j] ? xs[j].z : -3.0e38f};
+      for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) { l3[a] = fminf(l3[a], __shfl_xor(l3[a], o)); h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], o)); }
+        wlo[j][a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, l3[a])));
+        whi[j][a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, h3[a])));
+      }
+    }
+    int shn = ncand > 0 ? S.cand[0] : 0;
+    float nb[6]; for (int a = 0; a < 6; a++) nb[a] = S.box[6 * shn + a];
+    for (int k = 0; k < ncand; k++) {
+      const int sh = shn; float bx[6]; for (int a = 0; a < 6; a++) bx[a] = nb[a];
+      if (k + 1 < ncand) { shn = S.cand[k + 1]; for (int a = 0; a < 6; a++) nb[a] = S.box[6 * shn + a]; }
+#ifdef AGXC_NO_HULLS
+      if (((const int*)S.shape)[SHAPE_WORDS * sh + 1] > 0) continue;
+#endif
+#pragma unroll
+      for (int j = 0; j < NPT; j++) {
+        if (wlo[j][0] > bx[3] || wlo[j][1] > bx[4] || wlo[j][2] > bx[5] || whi[j][0] < bx[0] || whi[j][1] < bx[1] || whi[j][2] < bx[2]) continue;   // wave uniform
+        const f3 xi = xs[j];
+        if (!mine[j] || ncon[j] >= NODE_CONTACTS) continue;
+        if (xi.x < bx[0] || xi.y < bx[1] || xi.z < bx[2] || xi.x > bx[3] || xi.y > bx[4] || xi.z > bx[5]) continue;
+        f3 nw; const float dst = shape_distance(clf, cl, S, sh, xi, nw) - mrg;
+        if (dst >= 0.f) continue;
+        Contact c;
+        c.n = nw; c.offset = -dot(nw, xi) + dst; c.slot = -1;
+        if (sub == nsub - 1) { const int sl = atomicAdd(S.nimp, 1); if (sl < IMP_SLOTS) { c.slot = sl; st(S.imp + 3 * sl, mk(0.f, 0.f, 0.f)); } }
+        const f3 vr = xi - qs[j]; const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
+        const float fc = S.shape[SHAPE_WORDS * sh + 10];
+        c.c3 = dot(fv, fv) < (dn * fc * dn * fc) ? 0.f : 1.f - fc;
+        if (ncon[j] == 0) con[j][0] = c; else con[j][1] = c;      // no dynamic index: the contacts stay in registers
+        ncon[j]++;
       }
     }
     // (d) position solver
@@ -235,8 +268,8 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < NPT; j++) {     // PSolve_RContacts
-        const int i = tid + j * T;
-        if (i < NN && ncon[j] > 0) {
+        const int i = own[j];
+        if (i >= 0 && ncon[j] > 0) {
           f3 xi = ld(S.x + 3 * i); const f3 qi = ld(S.q + 3 * i);
 #pragma unroll
           for (int cc = 0; cc < NODE_CONTACTS; cc++) if (cc < ncon[j]) {
@@ -245,23 +278,32 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
             if (dn <= EPS) {
               float dp = dot(xi, c.n) + c.offset; if (dp > mrg) dp = mrg;
               const f3 fv = vr - dn * c.n, corr = vr - c.c3 * fv + (dp * kCHR) * c.n;
-              xi = xi - corr; c.imp = c.imp + (1.0f / (dt * im)) * corr;
+              xi = xi - corr;
+              if (c.slot >= 0) { float* o = S.imp + 3 * c.slot; const float w = 1.0f / (dt * im); o[0] += w * corr.x; o[1] += w * corr.y; o[2] += w * corr.z; }
             }
           }
           st(S.x + 3 * i, xi);
         }
       }
       __syncthreads();
+      // PSolve_Links, one colour class at a time
+      int2 nxt[LPT];
 #pragma unroll
-      for (int c = 0; c < AGX_CLOTH_MAX_COLORS; c++) {   // PSolve_Links, one colour class at a time
-        if (c < NCOL) {
-          if (lk[c] >= 0) {
-            const int a = lk[c] & 0xffff, b = (lk[c] >> 16) & 0xffff;
-            const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = lrest[c];
-            if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
-          }
-          __syncthreads();
+      for (int u = 0; u < LPT; u++) { const int l = color[0] + tid + u * T; nxt[u] = l < color[1] ? links[l] : make_int2(-1, 0); }
+      for (int c = 0; c < NCOL; c++) {
+#ifdef AGXC_NO_LINKS
+        break;
+#endif
+        int2 cur[LPT];
+#pragma unroll
+        for (int u = 0; u < LPT; u++) { cur[u] = nxt[u]; if (c + 1 < NCOL) { const int l = color[c + 1] + tid + u * T; nxt[u] = l < color[c + 2] ? links[l] : make_int2(-1, 0); } }
+#pragma unroll
+        for (int u = 0; u < LPT; u++) if (cur[u].x >= 0) {
+          const int a = cur[u].x & 0xffff, b = (cur[u].x >> 16) & 0xffff;
+          const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur[u].y);
+          if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
         }
+        __syncthreads();
       }
     }
   }
@@ -272,10 +314,12 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     if (tid < 6) st(greport + 3 * tid, ld(S.x + 3 * cl[AGX_CL_TRI + tid]));
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
-      const int i = tid + j * T;
-      if (i < NN) for (int cc = 0; cc < NODE_CONTACTS; cc++) {
+      const int i = own[j];
+      if (i >= 0)
+#pragma unroll
+      for (int cc = 0; cc < NODE_CONTACTS; cc++) {
         float* o = greport + 20 + 2 * (NODE_CONTACTS * i + cc);
-        if (nsub > 0 && cc < ncon[j]) { const f3 f = (1.0f / dt) * con[j][cc].imp; o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
+        if (nsub > 0 && cc < ncon[j] && con[j][cc].slot >= 0) { const f3 f = (1.0f / dt) * ld(S.imp + 3 * con[j][cc].slot); o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
       }
     }
   }

@@ -73,6 +73,13 @@ class Stepper:
         except Exception:
             pass
 
+    def n_chunks(self):
+        """independent chunks of environments a step is issued as (AGX_CHUNKS, default 3 from 2048 environments on)"""
+        e = os.environ.get('AGX_CHUNKS')
+        nc = int(e) if e else (3 if self.n_envs >= 2048 else 1)
+        nc = min(max(nc, 1), 8)
+        return 1 if self.n_envs < 64 * nc else nc
+
     def debug_layout(self):
         """[words per env, contacts offset, M^-1 offset, M^-1 row stride, row headers, impulses, phase timers, qdd] of the debug record"""
         out = (C.c_int * 8)()

@@ -90,14 +90,17 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
     x0 = scale * (v @ R.T + np.asarray(position))                    # see module docstring
     nn = len(x0)
     links = mesh_links(faces)
-    cls, ncolor = colour_links(links, nn, CLOTH_THREADS)
+    cls, ncolor = colour_links(links, nn, 1024)                  # the cloth kernel holds 1,024 links of a class (1024 / threads per thread)
     assert ncolor <= CLOTH_MAX_COLORS, ncolor
-    order = np.argsort(cls, kind='stable')
+    # within a class the order is free (no two links share a node): ascending first node, so that the lanes of a wave read LDS addresses
+    # that increase from lane to lane (few bank conflicts)
+    links = [(min(a, b), max(a, b)) for a, b in links]
+    order = np.lexsort((np.array([l[0] for l in links]), cls))
     links = [links[k] for k in order]
     cls = cls[order]
     color_off = [int(np.searchsorted(cls, c)) for c in range(ncolor)] + [len(links)]
     max_per = max(color_off[c + 1] - color_off[c] for c in range(ncolor))
-    assert max_per <= CLOTH_THREADS
+    assert max_per <= 1024
     rest2 = np.array([np.sum((x0[a] - x0[b]) ** 2) for a, b in links])
     # incident faces per node, in face order, rotated so that the node comes first (same cross product)
     inc = [[] for _ in range(nn)]
@@ -112,6 +115,18 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
     area = np.where(cnt > 0, area_sum / np.maximum(cnt, 1), 0.0)
     node_first = np.concatenate([[0], np.cumsum([len(t) for t in inc])]).astype(np.int64)
     face_entries = np.array([e for t in inc for e in t], dtype=np.int64)
+    # ownership order of the cloth kernel: Morton order of the rest positions (10 bits per axis)
+    g = np.floor((x0 - x0.min(0)) / (np.ptp(x0, axis=0).max() + 1e-9) * 1023).astype(np.int64)
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(10):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+    morton = spread(g[:, 0]) | (spread(g[:, 1]) << 1) | (spread(g[:, 2]) << 2)
+    perm = np.full(4096, -1, dtype=np.int64)
+    perm[:nn] = np.argsort(morton, kind='stable')
+    assert nn <= 4096
     # rigid shapes: capsule / sphere cores are evaluated exactly, hulls through their face planes
     planes, shapes = [], []
     for ci in shape_ids:
@@ -124,17 +139,21 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
             planes.extend(pl.tolist())
     planes = np.array(planes, dtype=np.float64).reshape(-1, 4)
     off, cur = {}, CL['HDR']
+    cur += (-cur) % 4      # (the PLANE array is read as 16-byte words: the section itself starts on a 16-byte boundary, see pack())
     for name, size in (('COLOR', ncolor + 1), ('LINK', 2 * len(links)), ('NODE', 2 * (nn + 1)), ('FACE', len(face_entries)), ('X0', 3 * nn),
-                       ('ANCHOR', 4 * len(anchors)), ('SHAPE', 4 * len(shapes)), ('PLANE', 4 * len(planes)), ('PARAM', CP['COUNT'])):
+                       ('ANCHOR', 4 * len(anchors)), ('SHAPE', 4 * len(shapes)), ('PLANE', 4 * len(planes)), ('PARAM', CP['COUNT']), ('PERM', 4096)):
+        if name == 'PLANE':
+            cur += (-cur) % 4
         off[name] = cur
         cur += size
     f = np.zeros(cur, dtype=np.float32)
     i = f.view(np.int32)
     i[CL['NN']], i[CL['NL']], i[CL['NCOLOR']], i[CL['NANCHOR']], i[CL['NSHAPE']] = nn, len(links), ncolor, len(anchors), len(shapes)
-    for name in ('COLOR', 'LINK', 'NODE', 'FACE', 'X0', 'ANCHOR', 'SHAPE', 'PLANE', 'PARAM'):
+    for name in ('COLOR', 'LINK', 'NODE', 'FACE', 'X0', 'ANCHOR', 'SHAPE', 'PLANE', 'PARAM', 'PERM'):
         i[CL['OFF_' + name]] = off[name]
     i[CL['TRI']:CL['TRI'] + 6] = list(tri1) + list(tri2)
     i[CL['MAX_LINKS_PER_COLOR']] = max_per
+    i[off['PERM']:off['PERM'] + 4096] = perm
     i[off['COLOR']:off['COLOR'] + ncolor + 1] = color_off
     for k, (a, b) in enumerate(links):
         i[off['LINK'] + 2 * k] = a | (b << 16)

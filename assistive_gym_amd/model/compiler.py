@@ -62,7 +62,7 @@ TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH, TASK_DRESSING = 0, 1, 2, 3
 DR = dict(CLOTH_GRAVITY=0, FORCE_SUM=1, BEST=2, WORDS=12)   # dressing task words (AGX_DR_*)
 # cloth section (AGX_CL_*, AGX_CP_*)
 CL = dict(NN=0, NL=1, NCOLOR=2, NANCHOR=3, NSHAPE=4, OFF_COLOR=5, OFF_LINK=6, OFF_NODE=7, OFF_FACE=8, OFF_X0=9, OFF_ANCHOR=10, OFF_SHAPE=11,
-          OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, HDR=24)
+          OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, OFF_PERM=21, HDR=24)
 CP = dict(KLST=0, KDP=1, KDG=2, KDF=3, KCHR=4, KKHR=5, KAHR=6, PITER=7, MARGIN=8, NODE_IM=9, AIR_DENSITY=10, FORCE_SCALE=11, FORCE_MAX=12,
           EE_BELOW=13, COUNT=16)
 CLOTH_MAX_COLORS, CLOTH_THREADS, CLOTH_NODE_CONTACTS = 16, 1024, 2
@@ -373,6 +373,8 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
                        ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
                        ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('RESET', reset_words(nhuman, nhdof)),
                        ('TARGETS', 2 * nt_max * 4), ('MLP', MLP_WORDS if mlp is not None else 0), ('CLOTH', len(cloth) if cloth is not None else 0)):
+        if name == 'CLOTH':
+            cur += (-cur) % 4          # 16-byte aligned: the cloth kernel reads face planes as float4
         off[name] = cur
         cur += size
     nwords = cur

@@ -30,6 +30,7 @@ TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the com
     'feeding': ('feeding_jaco', 'FeedingJacoVecEnv', '', 'FeedingJaco-v1'),
     'bedbathing': ('bed_bathing_sawyer', 'BedBathingSawyerVecEnv', '_bb', 'BedBathingSawyer-v1'),
     'scratchitch': ('scratch_itch_pr2', 'ScratchItchPR2HumanVecEnv', '_si', 'ScratchItchPR2Human-v1 (co-op: 7 robot + 10 human actions)'),
+    'dressing': ('dressing_baxter', 'DressingBaxterVecEnv', '_dr', 'DressingBaxter-v1 (cloth of 3,966 nodes per env, numSubSteps 8: 40 internal substeps per step)'),
 }
 
 
@@ -43,14 +44,21 @@ def _cpu_worker(path, seed, n_steps, model='feeding_jaco'):
     o = Oracle(blob)
     init = np.load(path)
     st = init.copy()
+    cloth0 = np.load(path[:-4] + '_cloth.npy') if os.path.exists(path[:-4] + '_cloth.npy') else None      # models with a garment
+    cloth = cloth0.copy() if cloth0 is not None else None
     rng = np.random.RandomState(seed)
     t0 = time.perf_counter()
     for k in range(n_steps):
         if k and k % 200 == 0:
             st[:] = init            # episode end: back to a post-reset state, like the device-side auto-reset
+            if cloth is not None:
+                cloth[:] = cloth0
         a = rng.uniform(-1, 1, (len(st), blob.act_dim)).astype(np.float32)
         for i in range(len(st)):
-            o.step(st[i], a[i])
+            if cloth is not None:
+                o.step_cloth(st[i], cloth[i], a[i])
+            else:
+                o.step(st[i], a[i])
     print(len(st) * n_steps, time.perf_counter() - t0)
 
 
@@ -71,7 +79,7 @@ def _usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(blob, states, envs_per_core, n_steps, model='feeding_jaco', workload='FeedingJaco'):
+def cpu_baseline(blob, states, envs_per_core, n_steps, model='feeding_jaco', workload='FeedingJaco', cloth=None):
     """The CPU oracle (oracle/, plain C, f64) timed on a bounded sample of the same workload on ALL host
     cores of this box (one process per core, each stepping its own environments -- the reference's own
     scaling model, learn.py:26).  kind = "port": a restatement, NOT PyBullet."""
@@ -84,6 +92,8 @@ def cpu_baseline(blob, states, envs_per_core, n_steps, model='feeding_jaco', wor
         for c in range(cores):
             path = os.path.join(tmp, 'cpu_%d.npy' % c)
             np.save(path, states[(c * envs_per_core + np.arange(envs_per_core)) % len(states)])
+            if cloth is not None:
+                np.save(path[:-4] + '_cloth.npy', cloth[(c * envs_per_core + np.arange(envs_per_core)) % len(states)])
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', path, str(c), str(n_steps), model],
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         res = []
@@ -110,13 +120,15 @@ def main():
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
-    ap.add_argument('--pool', type=int, default=256)
+    ap.add_argument('--pool', type=int, default=None, help='reset pool size (default 256; 64 for dressing, whose pool entries carry a garment and a 50-step device settle)')
     ap.add_argument('--reset', choices=['pool', 'device', 'host'], default='pool',
                     help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--task', choices=sorted(TASKS), default='feeding', help="'feeding' = the BASELINE metric (config 2); 'bedbathing' = config 3; 'scratchitch' = config 4's env (co-op) on one GPU")
     args = ap.parse_args()
     model, env_cls, ksuffix, env_id = TASKS[args.task]
+    if args.pool is None:
+        args.pool = 64 if args.task == 'dressing' else 256
 
     import torch
     import torch.distributed as dist
@@ -179,10 +191,16 @@ def main():
     # kernel trace (rocprofv3 --kernel-trace) of this command reports.
     NT = 20
     kms, kcnt = np.zeros(3), np.zeros(3)
-    for k in range(NT):
-        ms, cnt = env.stepper.step_timed(tape[(W + k) % (W + K)], env.obs, env.reward, env.done, env.info, stream)
-        kms += np.array(ms); kcnt += np.array(cnt)
-    kms /= NT; kcnt /= NT
+    has_cloth = getattr(env, 'cloth_pool_host', None) is not None
+    if has_cloth:
+        # 40 build / solve pairs + the cloth kernel + finish per step: too many launches for the per-launch event table; the split by
+        # kernel comes from the rocprofv3 kernel trace (profiles/); here the whole step is the unit
+        kms[:] = [0, 0, kernel_ms / K]; kcnt[:] = [0, 0, env.stepper.n_chunks() if hasattr(env.stepper, 'n_chunks') else 1]
+    else:
+        for k in range(NT):
+            ms, cnt = env.stepper.step_timed(tape[(W + k) % (W + K)], env.obs, env.reward, env.done, env.info, stream)
+            kms += np.array(ms); kcnt += np.array(cnt)
+        kms /= NT; kcnt /= NT
     if rank == 0:
         total_steps = world * n * K
         value = total_steps / elapsed
@@ -191,11 +209,15 @@ def main():
         # algorithmic HBM bytes per env-step: state record read + written once, action read, obs /
         # reward / done / info written (DESIGN.md "bytes per env-step")
         bytes_per_env_step = 2 * sw * 4 + blob.act_dim * 4 + blob.obs_dim * 4 + 4 + 1 + 8 * 4
+        if has_cloth:                        # + the garment read and written once per env step: node positions and velocities
+            bytes_per_env_step += 2 * env.cloth_pool_host[0].size * 4
         names = [k + ksuffix for k in ('agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel')]
+        if has_cloth:
+            names[2] = 'whole step (40 x [agx_build_kernel%s, agx_solve_kernel%s] + agx_cloth_kernel%s + agx_finish_kernel%s)' % ((ksuffix,) * 4)
         dom = int(np.argmax(kms))
         # one launch of the dominant kernel advances the environments of one chunk by 1/frame_skip of an env-step
         launches = [int(round(x)) for x in kcnt]
-        chunks = launches[2]
+        chunks = max(1, launches[2])
         envs_per_launch = n / chunks
         launch_ms = kms[dom] / launches[dom]
         units = n / launches[dom]            # env-steps advanced by one launch (= envs_per_launch / frame_skip for build / solve)
@@ -219,7 +241,7 @@ def main():
             'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s, %d lockstep envs per MI355X, random-policy rollout, 5 substeps/step, 50 PGS sweeps' % (env_id, n),
+            'config': {'workload': '%s, %d lockstep envs per MI355X, random-policy rollout, 5 simulation steps per env step, 50 PGS sweeps' % (env_id, n),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': args.pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -235,7 +257,8 @@ def main():
                          'note': 'dependent-chain latency bound solver (VALU issue ~0.3 of peak); HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8, 1000, model + ('+coop' if blob.is_coop else ''), env_id)
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8 if not has_cloth else 2, 1000 if not has_cloth else 40,
+                                               model + ('+coop' if blob.is_coop else ''), env_id, cloth=env.cloth_pool_host if has_cloth else None)
         print(json.dumps(out))
     env.close()
     if distributed:

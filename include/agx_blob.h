@@ -316,7 +316,9 @@ enum {
   AGX_CL_OFF_PLANE = 12, /* float[planes][4]: outward unit normal and offset of the hull's faces in the body frame             */
   AGX_CL_TRI = 13,       /* int[6]: the two vertex triples around the opening of the left sleeve (dressing.py:156-157)         */
   AGX_CL_OFF_PARAM = 19, /* float[AGX_CP_COUNT]                                                                                */
-  AGX_CL_MAX_LINKS_PER_COLOR = 20, /* int: size of the largest class (<= the cloth kernel's thread count)                       */
+  AGX_CL_MAX_LINKS_PER_COLOR = 20, /* int: size of the largest class (<= 1,024: the cloth kernel keeps 1024 / threads links per thread)   */
+  AGX_CL_OFF_PERM = 21,  /* int[4096]: node owned by slot t of the cloth kernel (thread t % threads, t / threads-th node of that thread), -1 = none:
+                            the nodes in Morton order of their rest positions, so that the 64 nodes of a wave lie close together    */
   AGX_CL_HDR = 24
 };
 enum {

@@ -3,7 +3,7 @@
 cd $(dirname $0)/..
 mkdir -p assistive_gym_amd/lib/variants
 while [ $# -ge 2 ]; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $2 -o assistive_gym_amd/lib/variants/$1.so assistive_gym_amd/csrc/agx_api.hip &
+  python -m assistive_gym_amd.build --out assistive_gym_amd/lib/variants/$1.so --extra "$2" &
   shift 2
 done
 wait

@@ -1,0 +1,26 @@
+"""GPU: time of the dressing model's kernels on a small batch (one garment per CU): python tools/gpu_cloth_bench.py [n_envs] [sim_steps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from assistive_gym_amd.blob import ModelBlob
+from assistive_gym_amd.libagx import Stepper
+from assistive_gym_amd.host import reset_dressing as rd
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+b = ModelBlob.load('dressing_baxter')
+cache = os.path.join(ROOT, 'gpurun_out', 'cloth_bench_states.npz')
+if os.path.exists(cache):
+    z = np.load(cache); st, cl = z['st'], z['cl']
+else:
+    st, cl, _ = rd.make_states(b, 8, seed=5, settler=rd.ClothSettler(b, 8))
+    os.makedirs(os.path.dirname(cache), exist_ok=True); np.savez(cache, st=st, cl=cl)
+dev = Stepper(b, n)
+idx = np.arange(n) % len(st)
+dev.set_state(st[idx]); dev.set_cloth(cl[idx])
+dev.settle(steps); dev.synchronize()
+ts = []
+for rep in range(3):
+    dev.set_state(st[idx]); dev.set_cloth(cl[idx]); dev.synchronize()
+    t = time.perf_counter(); dev.settle(steps); dev.synchronize(); ts.append(time.perf_counter() - t)
+print(os.environ.get('AGX_LIB', 'default').split('/')[-1], 'n_envs', n, 'sim steps', steps, 'ms per sim step (8 substeps): %.3f' % (min(ts) / steps * 1e3), 'finite', np.isfinite(dev.get_cloth()).all())
