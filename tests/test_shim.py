@@ -80,7 +80,7 @@ def _reference_make_env(gym):
     return ns['make_env']
 
 
-@pytest.mark.parametrize('env_name', ['FeedingJaco-v1', 'BedBathingSawyer-v1', 'ScratchItchPR2-v1'])
+@pytest.mark.parametrize('env_name', ['FeedingJaco-v1', 'BedBathingSawyer-v1', 'ScratchItchPR2-v1', 'DressingBaxter-v1'])
 def test_reference_make_env_single_agent(shimmed, env_name):
     gym, _ = shimmed
     make_env = _reference_make_env(gym)
@@ -91,7 +91,7 @@ def test_reference_make_env_single_agent(shimmed, env_name):
     env.disconnect()
 
 
-@pytest.mark.parametrize('env_name', ['FeedingJacoHuman-v1', 'BedBathingSawyerHuman-v1', 'ScratchItchPR2Human-v1'])
+@pytest.mark.parametrize('env_name', ['FeedingJacoHuman-v1', 'BedBathingSawyerHuman-v1', 'ScratchItchPR2Human-v1', 'DressingBaxterHuman-v1'])
 def test_reference_make_env_coop(shimmed, env_name):
     gym, creators = shimmed
     make_env = _reference_make_env(gym)
@@ -109,7 +109,7 @@ def test_reference_make_env_coop(shimmed, env_name):
 def test_unbuilt_env_id_fails_like_gym(shimmed):
     gym, _ = shimmed
     with pytest.raises(KeyError):
-        gym.make('assistive_gym:DressingBaxter-v1')
+        gym.make('assistive_gym:DrinkingPanda-v1')
 
 
 def test_vector_env_adapter_surface():
