@@ -250,7 +250,8 @@ def main():
                          'chunks': chunks, 'envs_per_launch': envs_per_launch,
                          'algorithmic_bytes_per_env_step': bytes_per_env_step, 'algorithmic_bytes_per_launch': bytes_per_env_step * units,
                          'traffic_over_algorithmic': (traffic / (bytes_per_env_step * units)) if traffic else None,
-                         'valu_issue_frac': valu_frac,
+                         'valu_issue_frac': valu_frac,      # of ONE launch (one chunk of environments); `chunks` such launches share the GPU
+                         'valu_issue_frac_all_chunks': (valu_frac * chunks) if valu_frac else None,
                          'kernels_ms_per_step_summed_over_overlapping_launches': dict(zip(names, [float(x) for x in kms])),
                          'stream_ms_per_step': kernel_ms / K,
                          'step_level_achieved': bytes_per_env_step * n / (elapsed / K) / 1e9,
