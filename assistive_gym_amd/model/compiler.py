@@ -373,7 +373,7 @@ def pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f
                        ('COLL', ncoll * C['STRIDE']), ('VERT', 3 * len(verts)), ('DIRS', 3 * len(dirs)),
                        ('GROUP', len(groups) * G['STRIDE']), ('TASK', T['COUNT']), ('RESET', reset_words(nhuman, nhdof)),
                        ('TARGETS', 2 * nt_max * 4), ('MLP', MLP_WORDS if mlp is not None else 0), ('CLOTH', len(cloth) if cloth is not None else 0)):
-        if name == 'CLOTH':
+        if name == 'CLOTH' and cloth is not None:
             cur += (-cur) % 4          # 16-byte aligned: the cloth kernel reads face planes as float4
         off[name] = cur
         cur += size

@@ -1,20 +1,22 @@
-"""Soak run (GPU box): 4096 envs x N steps with auto-reset, checks every 50 steps that all outputs are finite and
-reports return statistics per episode (random policy)."""
+"""Soak run (GPU box): n envs x N steps with auto-reset, checks every 50 steps that all outputs are finite and
+reports return statistics per episode (random policy).  python tools/gpu_soak.py [steps] [pool|device|host] [VecEnv class] [n_envs]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from assistive_gym_amd.vec_env import FeedingJacoVecEnv
-n, N = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 1200
+from assistive_gym_amd import vec_env
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 mode = sys.argv[2] if len(sys.argv) > 2 else 'pool'
-env = FeedingJacoVecEnv(n, pool_size=256, seed=7, reset=mode)
+cls = sys.argv[3] if len(sys.argv) > 3 else 'FeedingJacoVecEnv'
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+env = getattr(vec_env, cls)(n, pool_size=256 if n >= 1024 else 32, seed=7, reset=mode)
 env.reset()
 g = torch.Generator(device='cuda'); g.manual_seed(0)
 ret = torch.zeros(n, device='cuda'); ep_returns = []
 bad = 0
 t0 = time.time()
 for k in range(N):
-    a = torch.rand((n, 7), device='cuda', generator=g) * 2 - 1
+    a = torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1
     obs, rew, done, info = env.step(a)
     ret += rew
     if bool(done.any()):
