@@ -68,7 +68,12 @@ constexpr int L_SOLVE_ENT = L_VEL + 128;
 #endif
 constexpr int SOLVE_LDS_PAIRS = AGX_SOLVE_LDS_PAIRS;
 static_assert(L_SOLVE_ENT % 2 == 0, "(J,B) pairs are read as 8-byte words");
-constexpr int LDS_SOLVE_WORDS = L_SOLVE_ENT + 2 * SOLVE_LDS_PAIRS;
+// Row-space solve (agx_pgs.h pgs_rowspace; the variants other than FeedingJaco, whose environments have few solver rows): the dense
+// Jacobians of up to RS_MAX_ROWS rows and their coupling matrix A = J M^-1 J^T replace the (J,B) window in LDS
+constexpr int RS_MAX_ROWS = TASK != AGX_TASK_FEEDING && MAX_DOF <= 32 ? 56 : 0, RS_NVP = (MAX_DOF + 6 * MAX_FREE) | 1;     // row stride of the dense Jacobian: odd = conflict free
+// layout of the work area behind the (J,B) window, which the row-space path fills with ALL pairs of the environment (it bails out otherwise)
+constexpr int RS_J = 2 * SOLVE_LDS_PAIRS, RS_A = RS_J + RS_MAX_ROWS * RS_NVP, RS_ROW = RS_A + RS_MAX_ROWS * RS_MAX_ROWS, RS_LAM = RS_ROW + 64, RS_WORDS = RS_MAX_ROWS ? RS_LAM + 64 : 0;
+constexpr int LDS_SOLVE_WORDS = L_SOLVE_ENT + (2 * SOLVE_LDS_PAIRS > RS_WORDS ? 2 * SOLVE_LDS_PAIRS : RS_WORDS);
 constexpr int LDS_SOLVE_BYTES = LDS_SOLVE_WORDS * 4;
 // arena, dynamics phase
 constexpr int A_COMW = 0;                                // [MAX_DOF][3] rel. ref

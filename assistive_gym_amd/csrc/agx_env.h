@@ -333,6 +333,9 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nent = scr.meta[META_NENT];
   // state copy only (the frame tables of load_env are not needed here and their LDS is the row window)
   for (int k = lane; k < sw; k += 64) lds[L_ST + k] = gstate[k];
+  // environments with few rows take the row-space sweep (its work area replaces the (J,B) window)
+  // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)
+  const bool rowspace = RS_MAX_ROWS > 0 && c.nrows <= RS_MAX_ROWS && c.nv <= 64 && c.nv <= RS_NVP && c.nrows > 0 && c.nent <= SOLVE_LDS_PAIRS;
   { const int np = c.nent < SOLVE_LDS_PAIRS ? c.nent : SOLVE_LDS_PAIRS;
     const f2* src = (const f2*)scr.ent; f2* dst = (f2*)(lds + L_SOLVE_ENT);
     for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
@@ -342,7 +345,7 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   c.coop = TKI(c, AGX_T_COOP) == 1;
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0, dv1;
-  pgs(c, dv0, dv1);
+  if (!(rowspace && pgs_rowspace(c, lds + L_SOLVE_ENT, dv0, dv1))) pgs(c, dv0, dv1);
   const long long t1 = gdebug ? wave_clock() : 0;
   integrate(c, scr.vel, dv0, dv1);
   if constexpr (TASK != AGX_TASK_FEEDING) arm_limits(c, lds + L_VEL);   // the velocity vector is dead after the integration

@@ -260,6 +260,76 @@ AGX_DEV int pgs_lds_split(const PgsSet& S, int lane, int l0, int l1) {
   const uint64_t m = wave_ballot(lane >= l0 && lane < l1 && end > SOLVE_LDS_PAIRS);
   return wave_uniform(m ? ffs64(m) : l1);
 }
+
+// ---- row-space sweep for environments with few rows -----------------------------------------------------
+// The velocity-space sweep above pays a 6-step cross-lane reduction (J.dv) inside the dependent chain of every row visit.
+// With at most RS_MAX_ROWS rows the coupling matrix A[i][j] = J_j . B_i (how much an impulse on row i changes the velocity
+// row j measures) fits LDS next to the state: lane j then carries w_j = J_j . dv incrementally -- a visit of row i is
+// "new impulse from (b_i - w_i), broadcast its change, w += A[i][:] * change": no reduction, one broadcast.  Measured on MI355X
+// (tools/gpu_pgs_cycles.py): ~145 cycles per row visit instead of ~740, but the work area (30 KB) allows 5 environments per CU
+// instead of 16, so the solve launch of BedBathingSawyer only went from 0.57 to 0.50 ms and its step rate from 890 k to 995 k.  Same rows, same order, same clamps as the velocity-space sweep; the results differ by rounding only
+// (sums are associated differently).  dv = sum_i B_i lambda_i is formed once at the end.
+// Returns false (nothing done) if the environment has more rows than fit or touches DoFs beyond lane 63.
+AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
+  if constexpr (RS_MAX_ROWS == 0) { (void)c; (void)W; (void)dv0; (void)dv1; return false; }
+  else {
+    const int lane = c.lane, iters = (int)PRM(c, AGX_P_NITER);
+    const int nnc = c.first_normal, nc = c.ncon, nA = nnc + nc, R = nA + nc, nv = c.nv;
+    if (R > RS_MAX_ROWS || nv > 64 || nv > RS_NVP || R == 0 || c.nent > SOLVE_LDS_PAIRS) return false;
+    const float* E = W;                                            // the (J,B) window holds every pair of this environment (env_solve copied them)
+    PgsSet S; pgs_load_set(c, lane, lane < R, lane >= nA, S);      // lane r owns row r; friction rows: S.hi = mu
+    float* LJ = W + RS_J; float* A = W + RS_A; float* ROW = W + RS_ROW; float* LAM = W + RS_LAM;
+    // dense Jacobians: J[r][d]
+    for (int r = 0; r < R; r++) {
+      PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(S.pack, r), wave_bcast_i(S.off, r) & 0x7fffffff, X);
+      if (lane < nv) LJ[RS_NVP * r + lane] = X.j0;
+    }
+    wave_sync();
+    // A[i][j] = sum_d J_j[d] B_i[d]: row i's B goes through a one-row LDS buffer (every lane needs all of it)
+    for (int i = 0; i < R; i++) {
+      PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(S.pack, i), wave_bcast_i(S.off, i) & 0x7fffffff, X);
+      wave_sync(); ROW[lane] = X.c0; wave_sync();
+      float a = 0.f;
+      if (lane < R) for (int d = 0; d < nv; d++) a += LJ[RS_NVP * lane + d] * ROW[d];
+      A[RS_MAX_ROWS * i + lane] = a;
+    }
+    wave_sync();
+    float w = 0.f;                                                  // J_r . dv of this lane's row
+    const int fn = lane - nc;                                       // normal row of this lane's friction row
+    for (int it = 0; it < iters; it++) {
+      for (int r = 0; r < nA; r++) {                                // non-contact rows and contact normals
+        const float arow = A[RS_MAX_ROWS * r + lane];
+        const float nl = wave_clamp(S.lam + (S.b - w) * S.invD, S.lo, S.hi);
+        const float dl = wave_bcast(nl - S.lam, r);
+        if (lane == r) S.lam = nl;
+        w += arow * dl;
+      }
+      if (nc > 0) {
+        wave_sync(); LAM[lane] = S.lam; wave_sync();
+        const float ln = (lane >= nA && lane < R) ? LAM[fn] : 0.f;  // the normal impulses do not change during the friction pass
+        const float hi = S.hi * ln, lo = -hi;
+        // a friction row whose normal impulse and own impulse are both zero is an exact no-op (as in the velocity-space sweep)
+        uint64_t todo = wave_ballot(lane >= nA && lane < R && (ln != 0.f || S.lam != 0.f));
+        while (todo) {
+          const int r = ffs64(todo); todo &= todo - 1ull;
+          const float arow = A[RS_MAX_ROWS * r + lane];
+          const float nl = wave_clamp(S.lam + (S.b - w) * S.invD, lo, hi);
+          const float dl = wave_bcast(nl - S.lam, r);
+          if (lane == r) S.lam = nl;
+          w += arow * dl;
+        }
+      }
+    }
+    // dv = sum_r B_r lambda_r, in row order
+    dv0 = 0.f; dv1 = 0.f;
+    for (int r = 0; r < R; r++) {
+      PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(S.pack, r), wave_bcast_i(S.off, r) & 0x7fffffff, X);
+      dv0 += X.c0 * wave_bcast(S.lam, r);
+    }
+    if (lane >= nnc && lane < nA) c.gcon[CON_STRIDE * (lane - nnc) + C_LAM] = S.lam;
+    return true;
+  }
+}
 AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   const int lane = c.lane; const int iters = (int)PRM(c, AGX_P_NITER);
   const float* E = c.E;

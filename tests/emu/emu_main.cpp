@@ -45,16 +45,17 @@ static int run_wave(float* lds, size_t lds_words, std::function<void(int)> body)
 
 extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
                            float* info, float* debug, int mode, int nsettle) {
-  static float lds[agx::LDS_WORDS];
+  static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
   static float scratch[agx::SCR_WORDS];
   const int frame_skip = (int)((const float*)blob)[((const int*)blob)[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   int rc = 0;
   if (mode == 2) return run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_observe(blob, state, obs, lds, lane); });
-  const int nsub = mode == 1 ? nsettle : frame_skip;
+  const int sim_sub = ((const int*)blob)[AGX_H_SIM_SUBSTEPS] > 1 ? ((const int*)blob)[AGX_H_SIM_SUBSTEPS] : 1;   // internal substeps per stepSimulation
+  const int nsub = (mode == 1 ? nsettle : frame_skip) * sim_sub;
   for (int k = 0; k < nsub && !rc; k++) {
     const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (k == 0) ? debug : nullptr;
     rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, dbg, lds, lane); });
-    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane); });
+    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, k); });
   }
   if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
   return rc;
@@ -62,7 +63,7 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
 #if AGX_HAS_SAMPLER
 extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed, int impairment_mode, int gender_mode, float* info4) {
   // the same schedule as libagx's launch_sample: sample, then AGX_X_COLLISION_TRIES rounds of [build, verdict, re-sample from the next restart]
-  static float lds[agx::LDS_WORDS];
+  static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
   static float scratch[agx::SCR_WORDS];
   int chosen = -1, first = 0;
   int rc = run_wave(lds, 64, [&](int lane) { int r = agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane, 0); if (lane == 0) chosen = r; });

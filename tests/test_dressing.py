@@ -265,3 +265,20 @@ def test_internal_substeps_and_hooks(dr, dr_oracle):
     dq = np.abs(v1['q'][0, :7] - dr.view(st[0:1])['q'][0, :7])
     assert dq.max() > 0.01                                       # the arm follows its targets
     assert int(v1['iteration'][0]) == 1
+
+
+def test_emulator_matches_oracle_on_the_rigid_scene(dr, dr_oracle):
+    """the device code of the `dressing` variant (40 internal substeps, hooks after every 8th, the row-space solve, the dressing task layer
+    without a garment attached) on the CPU wave emulator"""
+    from emu_lib import Emu
+    e = Emu(dr)
+    st, cloth, infos = _states(dr, 2, 67, impairment='tremor')
+    rng = np.random.RandomState(2)
+    for i in range(2):
+        so, se = st[i].copy(), st[i].copy()
+        for k in range(2):
+            a = rng.uniform(-1, 1, 7).astype(np.float32)
+            o_obs, o_rew, o_done, o_info = dr_oracle.step(so, a)
+            e_obs, e_rew, e_done, e_info, _ = e.step(se, a)
+            assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4 and o_done == e_done
+            assert np.abs(dr.view(so.reshape(1, -1))['q'] - dr.view(se.reshape(1, -1))['q']).max() < 2e-5
