@@ -106,6 +106,24 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   "1:\n" \
   LOAD(Z1, "v88") \
   "2:\n"
+// The address arithmetic of the row-ahead fetch, woven into the wait states of the reduction.  -DAGX_PGS_NO_ADDR (timing ablation, results
+// meaningless: the fetch reads the zero pair): solve kernel 1.51 -> 1.11 ms per 4096 FeedingJaco environments -- these 3 v_readlane and
+// 4 vector instructions cost 26 %.  Tried instead (round 2, correct on the GPU, slower): per-row fetch headers read with scalar loads and
+// the pairs of a row's two contiguous DoF ranges loaded under EXEC = the range's lanes (2 vector instructions per row instead of 11, but
+// 4 global loads per row and no LDS window): 2.7 ms -- a wave64 load costs the memory pipe the same whatever its EXEC mask.
+#ifdef AGX_PGS_NO_ADDR
+#define AGX_PGS_ADDR0 "s_mov_b32 s84, 0\n"
+#define AGX_PGS_ADDR1 ""
+#define AGX_PGS_ADDR2 ""
+#define AGX_PGS_ADDR3 "v_mov_b32_e32 v85, 0\n"
+#define AGX_PGS_ADDR4 "s_bitcmp1_b32 s84, 31\n"
+#else
+#define AGX_PGS_ADDR0 "v_readlane_b32 s84, %[off], s80\n" "v_readlane_b32 s82, %[mlo], s80\n"
+#define AGX_PGS_ADDR1 "v_readlane_b32 s83, %[mhi], s80\n" "s_bitcmp1_b32 s84, 31\n"
+#define AGX_PGS_ADDR2 "v_mbcnt_lo_u32_b32 v81, s82, 0\n"
+#define AGX_PGS_ADDR3 "v_mbcnt_hi_u32_b32 v81, s83, v81\n" "v_add_lshl_u32 v85, v81, s84, 3\n"
+#define AGX_PGS_ADDR4 "v_cndmask_b32_e64 v85, 0, v85, s[82:83]\n"
+#endif
 #define AGX_PGS_DPP(CTRL) "v_add_f32_dpp v80, v80, v80 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 // One row: the dependent chain (dot product, 6-step DPP reduction, impulse update, broadcast) with the
 // address arithmetic of the prefetch for row r+3 woven into its wait states.
@@ -116,19 +134,16 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
   WAIT("4") \
   "v_mul_f32_e32 v80, " XJ0 ", %[dv0]\n" \
   "v_fmac_f32_e32 v80, " XJ1 ", %[dv1]\n" \
-  "v_readlane_b32 s84, %[off], s80\n" \
-  "v_readlane_b32 s82, %[mlo], s80\n" \
+  AGX_PGS_ADDR0 \
   AGX_PGS_DPP("quad_perm:[1,0,3,2]") \
-  "v_readlane_b32 s83, %[mhi], s80\n" \
-  "s_bitcmp1_b32 s84, 31\n" \
+  AGX_PGS_ADDR1 \
   AGX_PGS_DPP("quad_perm:[2,3,0,1]") \
-  "v_mbcnt_lo_u32_b32 v81, s82, 0\n" \
+  AGX_PGS_ADDR2 \
   "v_cmp_eq_u32_e32 vcc, s94, %[lane]\n" \
   AGX_PGS_DPP("row_shr:4") \
-  "v_mbcnt_hi_u32_b32 v81, s83, v81\n" \
-  "v_add_lshl_u32 v85, v81, s84, 3\n" \
+  AGX_PGS_ADDR3 \
   AGX_PGS_DPP("row_shr:8") \
-  "v_cndmask_b32_e64 v85, 0, v85, s[82:83]\n" \
+  AGX_PGS_ADDR4 \
   LOAD(Z0, "v85") \
   AGX_PGS_DPP("row_bcast:15") \
   "s_nop 1\n" \

@@ -24,6 +24,6 @@ done = torch.zeros(n, dtype=torch.uint8, device=dev); info = torch.zeros((n, 8),
 ms = np.zeros(3)
 for k in range(6):
     st.set_state(states)
-    t = st.step_timed(act, obs, rew, done, info)
-    if k > 0: ms += np.array(t)
+    t, cnt = st.step_timed(act, obs, rew, done, info)
+    if k > 0: ms += np.array(t) / np.maximum(np.array(cnt), 1)
 print(os.environ.get('AGX_LIB', 'default').split('/')[-1], 'build %.3f solve %.3f finish %.3f ms per substep' % tuple(ms / 5))
