@@ -134,10 +134,11 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   }
   const float vscale = dt / (1.0f - kDP);
   for (int k = tid; k < 3 * NN; k += T) { const float xv = gcloth[k]; S.x[k] = xv; S.q[k] = xv - gcloth[3 * NN + k] * vscale; }
-  // ownership: slot tid + j T of the Morton-ordered node list (-1: none); the 64 nodes of a wave and a j lie close together
+  // ownership: a wave owns 64 NPT consecutive nodes of the Morton-ordered list (-1: none), lane l its l-th, (64 + l)-th, ...: the nodes
+  // of a wave are one patch of the garment
   int own[NPT]; bool attached[NPT];
 #pragma unroll
-  for (int j = 0; j < NPT; j++) { const int i = cl[cl[AGX_CL_OFF_PERM] + tid + j * T]; own[j] = i; attached[j] = false; for (int a = 0; a < NA; a++) if (anci[4 * a] == i) attached[j] = true; }
+  for (int j = 0; j < NPT; j++) { const int i = cl[cl[AGX_CL_OFF_PERM] + wave * (64 * NPT) + j * 64 + lane]; own[j] = i; attached[j] = false; for (int a = 0; a < NA; a++) if (anci[4 * a] == i) attached[j] = true; }
   Contact con[NPT][NODE_CONTACTS]; int ncon[NPT];
   __syncthreads();
   for (int sub = 0; sub < nsub; sub++) {
@@ -233,11 +234,14 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
         whi[j][a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, h3[a])));
       }
     }
+    float ulo[3], uhi[3];
+    for (int a = 0; a < 3; a++) { ulo[a] = wlo[0][a]; uhi[a] = whi[0][a]; for (int j = 1; j < NPT; j++) { ulo[a] = fminf(ulo[a], wlo[j][a]); uhi[a] = fmaxf(uhi[a], whi[j][a]); } }
     int shn = ncand > 0 ? S.cand[0] : 0;
     float nb[6]; for (int a = 0; a < 6; a++) nb[a] = S.box[6 * shn + a];
     for (int k = 0; k < ncand; k++) {
       const int sh = shn; float bx[6]; for (int a = 0; a < 6; a++) bx[a] = nb[a];
       if (k + 1 < ncand) { shn = S.cand[k + 1]; for (int a = 0; a < 6; a++) nb[a] = S.box[6 * shn + a]; }
+      if (ulo[0] > bx[3] || ulo[1] > bx[4] || ulo[2] > bx[5] || uhi[0] < bx[0] || uhi[1] < bx[1] || uhi[2] < bx[2]) continue;   // the whole patch misses the shape
 #ifdef AGXC_NO_HULLS
       if (((const int*)S.shape)[SHAPE_WORDS * sh + 1] > 0) continue;
 #endif
@@ -247,6 +251,9 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
         const f3 xi = xs[j];
         if (!mine[j] || ncon[j] >= NODE_CONTACTS) continue;
         if (xi.x < bx[0] || xi.y < bx[1] || xi.z < bx[2] || xi.x > bx[3] || xi.y > bx[4] || xi.z > bx[5]) continue;
+#ifdef AGXC_NO_EVAL
+        continue;
+#endif
         f3 nw; const float dst = shape_distance(clf, cl, S, sh, xi, nw) - mrg;
         if (dst >= 0.f) continue;
         Contact c;
