@@ -18,7 +18,8 @@ except Exception:
         def __init__(self, observation_space, action_space, num_envs):
             self.observation_space, self.action_space, self.num_envs = observation_space, action_space, num_envs
 
-MODELS = {'FeedingJaco-v1': 'feeding_jaco', 'BedBathingSawyer-v1': 'bed_bathing_sawyer', 'ScratchItchPR2-v1': 'scratch_itch_pr2'}
+MODELS = {'FeedingJaco-v1': 'feeding_jaco', 'BedBathingSawyer-v1': 'bed_bathing_sawyer', 'ScratchItchPR2-v1': 'scratch_itch_pr2',
+          'DressingBaxter-v1': 'dressing_baxter'}
 
 
 class AgxVectorEnv(_VectorEnv):
@@ -31,6 +32,8 @@ class AgxVectorEnv(_VectorEnv):
         super().__init__(proto.observation_space, proto.action_space, num_envs)
         self._info_static = {'action_robot_len': proto.action_robot_len, 'action_human_len': proto.action_human_len,
                              'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
+        if name != 'FeedingJaco-v1':
+            vec_kwargs.setdefault('reset', 'pool')         # only FeedingJaco has a device-side reset generator
         self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=MODELS[name], **vec_kwargs)
         self._obs = None
 
