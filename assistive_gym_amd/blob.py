@@ -49,7 +49,7 @@ class ModelBlob:
         n_h = sum(1 for d in range(self.nrobot, self.ndof) if self.robot_i(d, 'ACT') >= 0)
         wi[L.H['ACT_DIM']] = self.act_dim_robot + n_h
         # obs_human_len: 19 + joints in feeding.py:10, 18 + joints in bed_bathing.py:10
-        wi[L.H['OBS_DIM']] = self.obs_dim_robot + {L.TASK_BED_BATHING: 18, L.TASK_SCRATCH_ITCH: 24, L.TASK_DRESSING: 18}.get(self.task_kind, 19) + n_h    # scratch_itch.py:8, dressing.py:9
+        wi[L.H['OBS_DIM']] = self.obs_dim_robot + {L.TASK_BED_BATHING: 18, L.TASK_SCRATCH_ITCH: 24, L.TASK_DRESSING: 18, L.TASK_ARM_MANIPULATION: 32}.get(self.task_kind, 19) + n_h    # scratch_itch.py:8, dressing.py:9, arm_manipulation.py:11
         wi[self.h['OFF_TASK'] + L.T['COOP']] = 1
         # pose-dependent arm limits (human.py:134-152) run when a shoulder joint is controllable (human.py:136-137)
         if self.h['OFF_MLP'] and any(self.robot_i(d, 'ACT') >= 0 for d in self.task_i_n('ARM_LIMIT_DOF', 1)):
@@ -62,11 +62,12 @@ class ModelBlob:
 
     @property
     def act_dim_robot(self):
-        return sum(1 for d in range(self.nrobot) if self.robot_i(d, 'ACT') >= 0)
+        # a single-arm robot driven with robot_arm = 'both' lists its arm joints twice (robot.py:16): DUP_ACT more actions
+        return sum(1 for d in range(self.nrobot) if self.robot_i(d, 'ACT') >= 0) + (self.task_i('DUP_ACT') if self.task_kind == L.TASK_ARM_MANIPULATION else 0)
 
     @property
     def obs_dim_robot(self):
-        return {L.TASK_BED_BATHING: 17, L.TASK_SCRATCH_ITCH: 23, L.TASK_DRESSING: 17}.get(self.task_kind, 18) + self.act_dim_robot       # bed_bathing.py:10 / scratch_itch.py:8 / dressing.py:9 / feeding.py:10
+        return {L.TASK_BED_BATHING: 17, L.TASK_SCRATCH_ITCH: 23, L.TASK_DRESSING: 17, L.TASK_ARM_MANIPULATION: 31}.get(self.task_kind, 18) + self.act_dim_robot       # bed_bathing.py:10 / scratch_itch.py:8 / dressing.py:9 / feeding.py:10
 
     def rec(self, d, gender=0):
         """link record index of DoF d (human DoFs have one record per gender)"""

@@ -160,6 +160,38 @@ AGX_DEV void observe_bed(const Ctx& c, float tool_force, float total_force, floa
     }
   }
 }
+// ArmManipulationEnv._get_obs (arm_manipulation.py:71-110) for a single-arm robot: the one tool is tool_right AND tool_left (:12-14) and
+// the arm joints are listed twice (robot_arm = 'both', robot.py:16); every lane computes, lane 0 writes.
+// tool_force = all contacts of the tool, total_force = total_force_on_human, th_force = tool_force_on_human
+AGX_DEV void observe_arm(const Ctx& c, float tool_force, float total_force, float th_force, float* gobs) {
+  const float* L = c.lds;
+  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
+  v3 jp[5], jpr[5];
+  for (int k = 0; k < 3; k++) jp[k] = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + k));        // shoulder, elbow, wrist
+  jp[3] = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_STOMACH_BODY)); jp[4] = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_WAIST_BODY));
+  for (int k = 0; k < 5; k++) jpr[k] = tmul(BR, jp[k] - bp);
+  if (c.lane == 0) {
+    int o = 0;
+    for (int rep = 0; rep < 2; rep++) { gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z; gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w; }
+    for (int rep = 0; rep < 2; rep++)
+      for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+        float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
+        gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
+      }
+    for (int k = 0; k < 5; k++) { gobs[o++] = jpr[k].x; gobs[o++] = jpr[k].y; gobs[o++] = jpr[k].z; }
+    gobs[o++] = tool_force; gobs[o++] = tool_force;
+    if (c.coop) {   // human_obs (:98-107), in the frame of the human's base (collision body 0)
+      const v3 hb = ld3(L + L_HUMAN); const m3 HR = ldm3(L + L_HUMAN + 3);
+      const v3 sph = tmul(HR, sp - hb); const q4 sqh = m3_to_quat(mul_at(HR, sR));
+      for (int rep = 0; rep < 2; rep++) { gobs[o++] = sph.x; gobs[o++] = sph.y; gobs[o++] = sph.z; gobs[o++] = sqh.x; gobs[o++] = sqh.y; gobs[o++] = sqh.z; gobs[o++] = sqh.w; }
+      for (int d = c.nrobot; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) gobs[o++] = L[L_ST + c.s_q + d];
+      for (int k = 0; k < 5; k++) { const v3 h = tmul(HR, jp[k] - hb); gobs[o++] = h.x; gobs[o++] = h.y; gobs[o++] = h.z; }
+      gobs[o++] = total_force; gobs[o++] = th_force; gobs[o++] = th_force;
+    }
+  }
+}
 // world position of the scratch-itch target: limb frame o target_on_arm (scratch_itch.py:148-152)
 AGX_DEV v3 scratch_target(const Ctx& c) {
   const float* L = c.lds; const int s_task = c.bi[AGX_H_S_TASK];
@@ -361,6 +393,7 @@ AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float
   if constexpr (TASK == AGX_TASK_BED_BATHING) observe_bed(c, 0.f, 0.f, 0.f, gobs);
   else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) observe_scratch(c, 0.f, 0.f, 0.f, gobs);
   else if constexpr (TASK == AGX_TASK_DRESSING) observe_dressing(c, c.lds[L_ST + c.bi[AGX_H_S_TASK] + AGX_DR_FORCE_SUM], 0.f, gobs);
+  else if constexpr (TASK == AGX_TASK_ARM_MANIPULATION) observe_arm(c, 0.f, 0.f, 0.f, gobs);
   else observe(c, 0.f, 0.f, gobs);
 }
 
@@ -480,6 +513,95 @@ AGX_DEV void env_finish_bed(const uint32_t* blob, float* gstate, const float* ga
       ginfo[AGX_INFO_TOTAL_FORCE] = total_f;
       ginfo[AGX_INFO_TASK_SUCCESS] = (float)(success >= Li[L_ST + c.s_env + AGX_E_TOTAL_FOOD] * TKF(c, AGX_T_SUCCESS_FRAC));
       ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = pad_f; ginfo[AGX_INFO_FOOD_REWARD] = (float)new_points;
+      ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
+    }
+  }
+  store_env(c, gstate, sw);
+}
+
+// finish, arm manipulation: everything ArmManipulationEnv.step does after take_step (arm_manipulation.py:18-60), single-arm robot
+AGX_DEV void env_finish_arm(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
+                            float* ginfo, float* lds, int lane) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  float* L = c.lds; int* Li = c.ldsi;
+  const int sw = c.bi[AGX_H_STATE_WORDS], act_dim = c.bi[AGX_H_ACT_DIM];
+  Scratch scr = scratch_of(gscratch);
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nqpt = 0;
+  load_env(c, gstate, sw);
+  float an2 = 0.f;
+  for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
+  wave_sync();
+  kinematics(c);
+  // get_total_force (:62-69): the one tool is counted as tool_right and as tool_left
+  float rf = 0.f, tf = 0.f, thf = 0.f;
+  if (lane < c.ncon) {
+    const float* k = scr.con + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const int ta = CLI(c, ki[C_CA], AGX_C_TAG), tb = CLI(c, ki[C_CB], AGX_C_TAG);
+    const float f = k[C_LAM] / c.dt;
+    const bool human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
+    if (tool) tf = f;
+    if (human && robot) rf = f;
+    if (human && tool) thf = f;
+  }
+  const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), th_f = wave_sum(thf), total_f = robot_f + 2.f * th_f;
+  observe_arm(c, tool_f, total_f, th_f, gobs);
+  // tool.get_closest_points(human, distance=0.01) (env.py:264-265): one point per (hull of the tool, shape of the human) pair that close,
+  // at the poses after the last substep: lane = pair
+  int near_pts = 0;
+  {
+    int t0 = -1, t1 = -1, h0 = -1, h1 = -1;
+    for (int g = 0; g < c.ngroup; g++) {
+      const int a0 = GRI(c, g, AGX_G_A0), b0 = GRI(c, g, AGX_G_B0);
+      if (CLI(c, a0, AGX_C_TAG) == AGX_TAG_TOOL && CLI(c, b0, AGX_C_TAG) == AGX_TAG_HUMAN) {
+        t0 = a0; t1 = GRI(c, g, AGX_G_A1); h0 = b0; h1 = GRI(c, g, AGX_G_B1);
+        if (c.gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { h0 = GRI(c, g, AGX_G_B0F); h1 = GRI(c, g, AGX_G_B1F); }
+        break;
+      }
+    }
+    float* AB = L + L_ARENA;
+    for (int col = t0 + lane; col < t1; col += 64) {   // world AABBs of the tool colliders (narrowphase centres its arithmetic there)
+      m3 R; v3 p; body_xf(c, CLI(c, col, AGX_C_BODY), R, p);
+      v3 cl = mk3(CLF(c, col, AGX_C_AABB_C), CLF(c, col, AGX_C_AABB_C + 1), CLF(c, col, AGX_C_AABB_C + 2));
+      v3 hl = mk3(CLF(c, col, AGX_C_AABB_H), CLF(c, col, AGX_C_AABB_H + 1), CLF(c, col, AGX_C_AABB_H + 2));
+      v3 cw = mul(R, cl) + p; float r = CLF(c, col, AGX_C_RADIUS);
+      for (int k = 0; k < 3; k++) {
+        float hh = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
+        AB[ABS * col + k] = comp(cw, k) - hh; AB[ABS * col + 3 + k] = comp(cw, k) + hh;
+      }
+    }
+    wave_sync();
+    const int nh = h1 - h0, np = (t1 - t0) * nh;
+    const float lim = TKF(c, AGX_T_PRESSURE_DIST);
+    for (int base = 0; base < np; base += 64) {
+      const int p = base + lane; const bool has = p < np;
+      const int ti = has ? p / nh : 0, hi = has ? p - ti * nh : 0;
+      Cand k; k.dist = lim; k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.gap = 0.f;
+      const bool hit = narrowphase(c, t0 + ti, h0 + hi, lim, k, has);
+      near_pts += popc64(wave_ballot(hit && k.dist < lim));
+    }
+  }
+  const float ee_speed = 2.f * ee_speed_of(c);                 // right + left end effector: the same link (:26-27)
+  const float pressure = near_pts <= 0 ? 0.f : th_f / (float)near_pts;
+  // human_preferences (env.py:237-274): reward_force_nontarget = -(total - (right + left)), tool_force_at_target = 0
+  const float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-(total_f - 2.f * th_f)) + TKF(c, AGX_T_C_P) * (-(2.f * pressure));
+  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  const v3 elbow = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + 1)), wrist = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + 2));
+  const v3 stomach = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_STOMACH_BODY)), waist = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_WAIST_BODY));
+  const v3 d0 = sp - elbow, d1 = elbow - stomach, d2 = wrist - waist;
+  const float rd_left = -sqrtf(dot(d0, d0)), rd_human = -sqrtf(dot(d1, d1)) - sqrtf(dot(d2, d2));      // :36-38
+  const float reward = TKF(c, AGX_T_W_DISTANCE) * rd_human + 2.f * TKF(c, AGX_T_W_WIPE) * rd_left + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + pref;   // :42
+  const int s_task = c.bi[AGX_H_S_TASK];
+  const float best0 = L[L_ST + s_task + AGX_AM_BEST], best = (best0 == 0.f || rd_human > best0) ? rd_human : best0;   // :47-48
+  const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];
+  wave_sync();
+  if (lane == 0) {
+    L[L_ST + s_task + AGX_AM_BEST] = best;
+    *greward = reward;
+    *gdone = (uint8_t)(iteration >= (int)TKF(c, AGX_T_EPISODE_LEN));
+    if (ginfo) {
+      ginfo[AGX_INFO_TOTAL_FORCE] = total_f;
+      ginfo[AGX_INFO_TASK_SUCCESS] = (float)(best >= TKF(c, AGX_T_SUCCESS_FRAC));
+      ginfo[AGX_INFO_ROBOT_FORCE] = robot_f; ginfo[AGX_INFO_TOOL_FORCE] = th_f; ginfo[AGX_INFO_FOOD_REWARD] = (float)near_pts;
       ginfo[AGX_INFO_PREF] = pref; ginfo[AGX_INFO_NCONTACT] = (float)c.ncon; ginfo[AGX_INFO_NROWS] = (float)c.nrows;
     }
   }
@@ -797,6 +919,7 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
   if constexpr (TASK == AGX_TASK_DRESSING) env_finish_dressing(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane, greport);
   else if constexpr (TASK == AGX_TASK_BED_BATHING) env_finish_bed(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) env_finish_scratch(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
+  else if constexpr (TASK == AGX_TASK_ARM_MANIPULATION) env_finish_arm(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else env_finish_feeding(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
 }
 

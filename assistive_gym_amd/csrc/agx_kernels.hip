@@ -41,11 +41,20 @@
 #define AGX_TASK 3
 #define AGX_VNAME dressing
 #define AGX_K(name) name##_dr
+#elif defined(AGX_VARIANT_ARM_MANIPULATION)
+// ArmManipulationSawyer: 10 Sawyer DoFs + the 10 joints of the human's right arm (always dynamic: it hangs limp beside the bed), one free
+// body (the scooper, 12 hulls)
+#define AGX_MAX_DOF 20
+#define AGX_MAX_FREE 2
+#define AGX_MAX_BLOCK 10
+#define AGX_TASK 4
+#define AGX_VNAME arm_manipulation
+#define AGX_K(name) name##_am
 #elif defined(AGX_VARIANT_FEEDING)
 #define AGX_VNAME feeding
 #define AGX_K(name) name
 #else
-#error "build with -DAGX_VARIANT_FEEDING, -DAGX_VARIANT_BED_BATHING or -DAGX_VARIANT_SCRATCH_ITCH"
+#error "build with -DAGX_VARIANT_<name>, see assistive_gym_amd/build.py"
 #endif
 
 #include "agx_wave.h"

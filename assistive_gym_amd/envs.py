@@ -93,6 +93,8 @@ class AssistiveEnv(_Base):
         self.total_force_on_human = 0.0
         self._stepper = None
         arm_pb = [base.robot_i(d, 'PB_INDEX') for d in sorted((d for d in range(base.nrobot) if base.robot_i(d, 'ACT') >= 0), key=lambda d: base.robot_i(d, 'ACT'))]
+        if base.act_dim_robot == 2 * len(arm_pb):                                     # a single-arm robot with robot_arm = 'both' (robot.py:16)
+            arm_pb = arm_pb + arm_pb
         hum_pb = [self.blob.robot_i(d, 'PB_INDEX') for d in range(base.nrobot, base.ndof)] if self.coop else []
         self.robot = _Agent(controllable_joint_indices=arm_pb, mobile=False, motor_gains=base.robot_f(0, 'KP'), motor_forces=base.robot_f(0, 'MAXF'))
         self.human = _Agent(controllable_joint_indices=hum_pb, controllable=self.coop)
@@ -272,7 +274,32 @@ class DressingBaxterHumanEnv(DressingBaxterEnv):
     coop = True
 
 
-ENV_IDS = {'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
+class ArmManipulationSawyerEnv(AssistiveEnv):
+    """ArmManipulationSawyer-v1 (arm_manipulation_envs.py:23-25): Sawyer lifts the limp right arm of a human lying on a bed back onto
+    the body with a scooper.  robot_arm = 'both' on a single-arm robot: 14 actions (the arm joints twice, robot.py:16)."""
+    model, task = 'arm_manipulation_sawyer', 'arm_manipulation'
+
+    def reset(self):
+        """ArmManipulationEnv.reset (arm_manipulation.py:110-182): host/reset_arm.py around the two settles on the device."""
+        from .host.reset_arm import make_states, ArmFallSettler
+        from .host.reset_bed import RagdollSettler
+        st = self._ensure_stepper()
+        if not hasattr(self, '_settler'):
+            self._settler, self._arm_settler = RagdollSettler(1, self.device), ArmFallSettler(self.blob, 1, self.device)
+        self.reset_seed = self._draw_seed()
+        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler, arm_settler=self._arm_settler)
+        st.set_state(rec)
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+
+class ArmManipulationSawyerHumanEnv(ArmManipulationSawyerEnv):
+    """ArmManipulationSawyerHuman-v1 (arm_manipulation_envs.py:57-61): the human's right arm (10 joints) is controllable;
+    actions {'robot': a[14], 'human': a[10]}, observations 45 + 42."""
+    coop = True
+
+
+ENV_IDS = {'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
            'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
 
 

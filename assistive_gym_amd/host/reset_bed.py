@@ -240,6 +240,8 @@ class BedBathingSawyerReset:
             M = np.einsum('bij,bj,bkj->bik', J, W, J)
             det = np.maximum(np.linalg.det(M), 0)
             jl[:, g] = np.power(det, 1.0 / 6) / (np.trace(M, axis1=1, axis2=2) / 6)                          # robot.py:189-191
+            if g == 0 and getattr(self, 'self_guard', False):
+                ok &= ~self._arm_in_pedestal(base_pos, base_R, orig, pe)
             reached[:, g] = ok
             qsol[:, g] = q
         valid = reached[:, 0]                                   # the start goal must be reachable (robot.py:196-200)
@@ -249,6 +251,17 @@ class BedBathingSawyerReset:
         if ngoal[best] <= 0:
             return None
         return base_pos[best], X.mat_to_quat(base_R[best]), qsol[best, 0], int(ngoal[best]), float(manip[best])
+
+    def _arm_in_pedestal(self, base_pos, base_R, orig, pe, margin=0.09):
+        """start poses whose arm folds into the robot's own pedestal (boxes of the base colliders grown by a link radius): Bullet's
+        null-space IK with rest poses does not produce those elbow-down solutions, the damped least squares here can"""
+        if not hasattr(self, '_ped'):
+            r = self.blob.meta['ranges']['robot_base']
+            self._ped = np.array([[self.blob.collider(c)['verts'].min(0) - margin, self.blob.collider(c)['verts'].max(0) + margin] for c in range(*r)])
+        pts = np.concatenate([orig[:, 2:], 0.5 * (orig[:, 2:-1] + orig[:, 3:]), pe[:, None]], axis=1)          # joint origins past the shoulder, midpoints, ee
+        loc = np.einsum('bji,bkj->bki', base_R, pts - base_pos[:, None])
+        inside = (loc[:, :, None, :] >= self._ped[None, None, :, 0]) & (loc[:, :, None, :] <= self._ped[None, None, :, 1])
+        return inside.all(-1).any(-1).any(-1)
 
     def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None):
         """Fill one state record (float32 view of length state_words) in place, with the 'drop' stand-in for the settle."""

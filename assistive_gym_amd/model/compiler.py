@@ -45,7 +45,7 @@ T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV
          SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
          TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, TOOL_OBS_POS=36, TOOL_OBS_QUAT=39, W_WIPE=43, TARGET_RADIUS=44,
          CLOSEST_DIST=45, PAD_LINK=46, ARM_LINK=47, OBS_LINK=49, NT=52, NT_MAX=56, ARM_LIMIT_ON=57, ARM_LIMIT_DOF=58, ARM_LIMIT_SIGN=62, C_D=64,
-         ARM_RADIUS=65, COUNT=72)
+         ARM_RADIUS=65, C_P=67, STOMACH_BODY=68, WAIST_BODY=69, DUP_ACT=70, PRESSURE_DIST=71, COUNT=72)
 # reset section (sampling ranges of FeedingEnv.reset + the posed-human kinematic tree), see agx_blob.h
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
@@ -58,7 +58,8 @@ BODY_WORLD, BODY_ROBOT_BASE, BODY_FREE0, BODY_HUMAN0 = -1, 100, 200, 300
 PARENT_ROBOT_BASE, PARENT_HUMAN_BASE = -1, -2
 HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.py:9): dynamic when the impairment is tremor
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8, BED=9)
-TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH, TASK_DRESSING = 0, 1, 2, 3
+TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH, TASK_DRESSING, TASK_ARM_MANIPULATION = 0, 1, 2, 3, 4
+AM = dict(BEST=0, WORDS=12)   # arm manipulation task words (AGX_AM_*)
 DR = dict(CLOTH_GRAVITY=0, FORCE_SUM=1, BEST=2, WORDS=12)   # dressing task words (AGX_DR_*)
 # cloth section (AGX_CL_*, AGX_CP_*)
 CL = dict(NN=0, NL=1, NCOLOR=2, NANCHOR=3, NSHAPE=4, OFF_COLOR=5, OFF_LINK=6, OFF_NODE=7, OFF_FACE=8, OFF_X0=9, OFF_ANCHOR=10, OFF_SHAPE=11,
@@ -1114,8 +1115,99 @@ def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
                 meta_extra=dict(arm_joints=arm, gripper_joints=grip, cloth=cmeta, cloth_orig_pos=cloth_orig_pos.tolist()))
 
 
+def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
+    """ArmManipulationSawyer-v1 (arm_manipulation_envs.py:23-25): Sawyer (a single-arm robot: tool_left IS tool_right,
+    arm_manipulation.py:12-16) holds the scooper (assets/arm_manipulation/arm_manipulation_scooper_vhacd.obj, 12 hulls, 1 kg,
+    tool.py:26-34) next to a human lying on the bed whose right arm hangs limp beside the body (arm_manipulation.py:141-149: a reactive
+    hold of 0.01 N m only) under full gravity (arm_manipulation.py:176); the task is to lift that arm back onto the body.
+    robot_arm = 'both' (arm_manipulation_envs.py:13) makes a single-arm robot list its seven arm joints TWICE (robot.py:16): 14 actions,
+    the second copy's motor targets win (setJointMotorControlArray takes them in order), 14 joint angles in the observation."""
+    sc = Scene()
+    arm = [3, 8, 9, 10, 11, 13, 16]
+    grip = [20, 22]
+    rob = compile_robot(os.path.join(assets, 'sawyer', 'sawyer.urdf'), arm, grip, gripper_target=[0.01, -0.01],           # sawyer.py:24
+                        motor_gain=0.05, motor_force=20.0, max_hull_verts=0)                                              # robot.py:37, arm_manipulation.py:114
+    nrobot = len(rob['dof_links'])
+    for d in range(nrobot):                           # the second copy of the arm joints drives the motors
+        if rob['rec_int'][d]['ACT'] >= 0:
+            rob['rec_int'][d]['ACT'] += len(arm)
+    gripper_collision = {18, 20, 21, 22, 23}
+    add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
+    add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
+    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+    sc.begin('robot_base')
+    for verts, radius, fr, pb in rob['base_colliders']:
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    sc.end('robot_base')
+    scoop = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'arm_manipulation', 'arm_manipulation_scooper_vhacd.obj'), 0.001)]   # arm_manipulation.py:159
+    allv = np.concatenate(scoop)
+    free = [dict(mass=1.0, inertia=box_inertia(1.0, allv.min(0) - HULL_MARGIN, allv.max(0) + HULL_MARGIN), gravity=0.0,                             # tool.py:10 mass=1; gravity 0: :177
+                 refpos=np.zeros(3), refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0)]
+    sc.begin('tool')
+    for hv in scoop:
+        sc.add(BODY_FREE0 + 0, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['TOOL'])
+    sc.end('tool')
+    hd = list(range(10))                                # human.right_arm_joints (arm_manipulation_envs.py:14)
+
+    def split(link):
+        return 'pecs' if link == 2 else ('arm' if 3 <= link <= 9 else 'rest')
+    human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.05, maxf=2.0, act0=2 * len(arm), split=split)     # human.motor_forces = 2 (:115)
+    sc.begin('bed')     # friction 0.3 once the human has settled (arm_manipulation.py:138)
+    bq = X.quat_from_rpy([np.pi / 2, 0, 0])
+    for g in load_obj_groups(os.path.join(assets, 'bed', 'bed_single_reduced_vhacd.obj'), 1.1):
+        sc.add(BODY_WORLD, X.apply(np.array([-0.1, 0, 0.0]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), bq, convex_hull_vertices(g))), HULL_MARGIN, 0.3, TAG['BED'])
+    sc.end('bed')
+    sc.begin('plane')
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    G_ = Groups(sc.ranges)
+    grp = G_.add
+    G_.rg['robot_arm'] = (G_.rg['robot_lower'][0], G_.rg['robot_upper'][1])
+    G_.rg['robot_links'] = (G_.rg['robot_lower'][0], G_.rg['robot_gripper'][1])
+    G_.rg['robot_top'] = (G_.rg['robot_upper'][0], G_.rg['robot_gripper'][1])
+    grp('tool', 'human_male', alt='human_female')     # (get_closest_points(human, 0.01), env.py:264, is a sweep of its own in the finish kernel)
+    grp('robot_links', 'human_male', alt='human_female', keep=2)
+    grp('robot_base', 'human_male', alt='human_female', keep=2, flags=GF_HUMAN_DYNAMIC)
+    grp('tool', 'bed', keep=2)
+    grp('robot_links', 'bed', keep=2)
+    grp('robot_arm', 'tool')
+    grp('robot_base', 'tool')
+    grp('robot_base', 'robot_top')
+    grp('robot_links', 'plane')
+    grp('tool', 'plane')
+    for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
+        G_.rg['harm_' + gender] = (G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][1])
+        grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)
+        grp('harm_' + gender, 'bed', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
+    groups = G_.rows
+    ee_pb, tool_pb = 19, 18
+    ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, [0.075, 0.235, 0], [0, 0, np.pi / 2.0])                       # sawyer.py:29,34
+    task_f = dict(W_DISTANCE=0.5, W_WIPE=0.25, W_ACTION=0.01, SUCCESS_FRAC=-0.7,         # config.ini:33-37: distance_human / distance_end_effector / action weights, threshold
+                  C_V=0.25, C_F=0.01, C_HF=0.05, C_P=0.01, PRESSURE_DIST=0.01,                                             # config.ini:40-42,46; env.py:262
+                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=tpos, TOOL_QUAT=tquat,
+                  TOOL_OBS_POS=[0, 0, 0], TOOL_OBS_QUAT=[0, 0, 0, 1.0], TOOL_MAXF=500.0, EPISODE_LEN=200, ARM_LIMIT_SIGN=-1.0)
+    task_i = dict(EE_LINK=ee_link, PAD_LINK=0, ARM_LINK=[nrobot + 5, nrobot + 7], OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], HEAD_LINK=-1,
+                  ARM_LIMIT_DOF=[nrobot + 3, nrobot + 4, nrobot + 5, nrobot + 6], ARM_LIMIT_ON=0,
+                  STOMACH_BODY=human_bodies.index(24), WAIST_BODY=human_bodies.index(27), DUP_ACT=len(arm))               # human.py:31-32
+    from .h5lite import load_keras_dense_stack
+    mlp = load_keras_dense_stack(os.path.join(assets, 'realistic_arm_limits_model.h5'))
+    params = default_params(n_iter)
+    params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-9.81)                                                               # arm_manipulation.py:120-121,176
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT']
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        pass        # the pool comes from assistive_gym_amd/host/reset_arm.py
+    return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
+                dict(NFOOD=0, ACT_DIM=2 * len(arm), OBS_DIM=31 + 2 * len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_ARM_MANIPULATION), reset_fill, reset_words,
+                task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip))
+
+
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
-                 bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter)
+                 bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
+                 arm_manipulation_sawyer=compile_arm_manipulation_sawyer)
 
 
 def main(names=None):

@@ -25,6 +25,12 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         from .host.reset_bed import make_states as make_bed_states, RagdollSettler
         # the rag-doll settle of BedBathingEnv.reset runs on the device (bed_settle kernel variant), the rest on the host
         return make_bed_states(blob, pool_size, seed=seed, impairment=impairment, settler=RagdollSettler(pool_size, device))[0]
+    if blob.task_kind == L.TASK_ARM_MANIPULATION:
+        # ArmManipulationEnv.reset (host/reset_arm.py) around its two settles on the device: the rag doll, then the fall of the right arm
+        from .host.reset_arm import make_states as make_arm_states, ArmFallSettler
+        from .host.reset_bed import RagdollSettler
+        return make_arm_states(blob, pool_size, seed=seed, impairment='no_tremor' if impairment == 'random' else impairment,
+                               settler=RagdollSettler(pool_size, device), arm_settler=ArmFallSettler(blob, pool_size, device))[0]
     if blob.task_kind == L.TASK_SCRATCH_ITCH:
         from .host.reset_scratch import make_states as make_scratch_states
         return make_scratch_states(blob, pool_size, seed=seed, impairment=impairment)[0]
@@ -169,6 +175,20 @@ class ScratchItchPR2VecEnv(AssistiveVecEnv):
 
 
 class ScratchItchPR2HumanVecEnv(ScratchItchPR2VecEnv):
+    coop = True
+
+
+class ArmManipulationSawyerVecEnv(AssistiveVecEnv):
+    """ArmManipulationSawyer-v1 (arm_manipulation_envs.py:23-25): 14 actions per env (the arm joints twice, robot.py:16), 45 observations."""
+    model = 'arm_manipulation_sawyer'
+
+    def __init__(self, n_envs, **kw):
+        kw.setdefault('reset', 'pool')
+        assert kw['reset'] != 'device', 'no device-side reset generator for ArmManipulationSawyer: use a pool'
+        super().__init__(n_envs, **kw)
+
+
+class ArmManipulationSawyerHumanVecEnv(ArmManipulationSawyerVecEnv):
     coop = True
 
 

@@ -65,7 +65,8 @@ enum {
 enum { AGX_TASK_FEEDING = 0,      /* assistive_gym/envs/feeding.py      */
        AGX_TASK_BED_BATHING = 1,  /* assistive_gym/envs/bed_bathing.py  */
        AGX_TASK_SCRATCH_ITCH = 2, /* assistive_gym/envs/scratch_itch.py */
-       AGX_TASK_DRESSING = 3 };   /* assistive_gym/envs/dressing.py     */
+       AGX_TASK_DRESSING = 3,     /* assistive_gym/envs/dressing.py     */
+       AGX_TASK_ARM_MANIPULATION = 4 };   /* assistive_gym/envs/arm_manipulation.py (single-arm robots) */
 
 /* ---- PARAMS: float[AGX_P_COUNT] ----------------------------------------------------------- */
 enum {
@@ -203,6 +204,14 @@ enum {
   /* ---- dressing (assistive_gym/envs/dressing.py, config.ini:28-31; W_WIPE = dressing_reward_weight, SUCCESS_FRAC = task_success_threshold) ---- */
   AGX_T_C_D = 64,           /* dressing_force_weight (config.ini:45)                                                 */
   AGX_T_ARM_RADIUS = 65,    /* float[2 genders]: hand_radius = elbow_radius = shoulder_radius (human_creation.py:89,140; util.py:134-138) */
+  /* ---- arm manipulation (assistive_gym/envs/arm_manipulation.py, config.ini:33-37; W_DISTANCE = distance_human_weight, W_WIPE =
+   * distance_end_effector_weight, SUCCESS_FRAC = task_success_threshold) ---- */
+  AGX_T_C_P = 67,           /* high_pressures_weight (config.ini:46)                                                  */
+  AGX_T_STOMACH_BODY = 68,  /* int: static human collision body whose frame is human.stomach (link 24)                */
+  AGX_T_WAIST_BODY = 69,    /* int: ... human.waist (link 27)                                                         */
+  AGX_T_DUP_ACT = 70,       /* int: a single-arm robot driven as 'both' arms (arm_manipulation_envs.py:13, robot.py:16) lists its arm joints
+                             * twice: ACT_DIM counts both copies, the second copy's targets win, the observation reports the angles twice */
+  AGX_T_PRESSURE_DIST = 71, /* float: range of tool.get_closest_points(human) that counts contact points for the pressure term (env.py:262) */
   AGX_T_COUNT = 72
 };
 
@@ -287,6 +296,9 @@ enum { AGX_SI_TARGET = 0,       /* float[3] target_on_arm, in the frame of its l
        AGX_SI_LIMB = 3,         /* int: 0 upper arm (human.right_shoulder), 1 forearm (human.right_elbow)                  */
        AGX_SI_PREV_CONTACT = 12,/* float[3]                                                                                */
        AGX_SI_WORDS = 16 };
+/* arm manipulation (offset AGX_H_S_TASK): float task_success = best reward_distance_human so far, 0 = none yet (arm_manipulation.py:46-47);
+ * the arm-limit words at AGX_BB_PREV / AGX_BB_HAS_PREV */
+enum { AGX_AM_BEST = 0, AGX_AM_WORDS = 12 };
 /* dressing (offset AGX_H_S_TASK): at AGX_BB_PREV / AGX_BB_HAS_PREV the arm-limit classifier's remembered pose, like the others */
 enum { AGX_DR_CLOTH_GRAVITY = 0, /* float: world gravity z acting on the cloth: -9.81 / 2 while it settles in reset, then -9.81 (dressing.py:178,195) */
        AGX_DR_FORCE_SUM = 1,     /* float: cloth_force_sum of the last step (dressing.py:96), an observation input                                */

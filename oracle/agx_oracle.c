@@ -216,6 +216,7 @@ typedef struct {
   row_t* rows; int nrows;
   /* dressing: the cloth (node positions / velocities live with the caller), its attachment point and the contacts of the last substep */
   double dr_gravity, dr_force_sum, dr_best;
+  double am_best;                                          /* arm manipulation: task_success = best reward_distance_human so far (arm_manipulation.py:48-49) */
   double* cx; double* cv; double* cq;                      /* [NN][3] each; NULL = no cloth attached to this call */
   double anchor[3]; int anchor_set;
   double* ccon; int nccon;                                 /* {x, y, z, fx, fy, fz} per node-vs-rigid contact */
@@ -255,6 +256,7 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
       for (int k = 0; k < 3; k++) { s->si_target[k] = st[m->s_task + AGX_SI_TARGET + k]; s->si_prev[k] = st[m->s_task + AGX_SI_PREV_CONTACT + k]; }
       s->si_limb = ((const int32_t*)st)[m->s_task + AGX_SI_LIMB];
     }
+    if (m->task_kind == AGX_TASK_ARM_MANIPULATION) s->am_best = st[m->s_task + AGX_AM_BEST];
     if (m->task_kind == AGX_TASK_DRESSING) { s->dr_gravity = st[m->s_task + AGX_DR_CLOTH_GRAVITY]; s->dr_force_sum = st[m->s_task + AGX_DR_FORCE_SUM]; s->dr_best = st[m->s_task + AGX_DR_BEST]; }
   }
 }
@@ -276,6 +278,7 @@ static void sim_store(const sim_t* s, float* st) {
     for (int k = 0; k < 4; k++) st[m->s_task + AGX_BB_PREV + k] = (float)s->arm_prev[k];
     ((int32_t*)st)[m->s_task + AGX_BB_HAS_PREV] = s->arm_has_prev;
     if (m->task_kind == AGX_TASK_SCRATCH_ITCH) for (int k = 0; k < 3; k++) st[m->s_task + AGX_SI_PREV_CONTACT + k] = (float)s->si_prev[k];
+    if (m->task_kind == AGX_TASK_ARM_MANIPULATION) st[m->s_task + AGX_AM_BEST] = (float)s->am_best;
     if (m->task_kind == AGX_TASK_DRESSING) { st[m->s_task + AGX_DR_FORCE_SUM] = (float)s->dr_force_sum; st[m->s_task + AGX_DR_BEST] = (float)s->dr_best; }
   }
 }
@@ -1371,6 +1374,91 @@ static void finish_bed(sim_t* s, const float* action, float* obs, float* reward,
     info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
   }
 }
+/* ArmManipulationEnv._get_obs (arm_manipulation.py:71-110) for a single-arm robot: tool_left IS tool_right (:12-14), so the tool pose
+ * and the tool forces appear twice; the arm joints are listed twice as well (robot_arm = 'both', robot.py:16) */
+static void observe_arm(sim_t* s, double tool_force, double total_force, double tool_human_force, float* obs) {
+  const agxo_model* m = s->m;
+  double sp[3], sR[9], spr[3], sqr[4];
+  tool_base_pose(s, sp, sR);                 /* tool.get_base_pos_orient() */
+  to_base_frame(s, sp, sR, spr, sqr);
+  const double* pts[5] = {s->link[TI(m, AGX_T_OBS_LINK)].p, s->link[TI(m, AGX_T_OBS_LINK + 1)].p, s->link[TI(m, AGX_T_OBS_LINK + 2)].p,
+                          s->human[TI(m, AGX_T_STOMACH_BODY)].p, s->human[TI(m, AGX_T_WAIST_BODY)].p};     /* :85-89 */
+  int o = 0;
+  for (int rep = 0; rep < 2; rep++) { for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k]; for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k]; }
+  for (int rep = 0; rep < 2; rep++)
+    for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+      double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
+    }
+  for (int j = 0; j < 5; j++) { double pr[3]; to_base_frame(s, pts[j], NULL, pr, NULL); for (int k = 0; k < 3; k++) obs[o++] = (float)pr[k]; }
+  obs[o++] = (float)tool_force; obs[o++] = (float)tool_force;
+  if (s->coop) {                             /* human_obs, :98-107 */
+    double sph[3], sqh[4];
+    to_human_frame(s, sp, sR, sph, sqh);
+    for (int rep = 0; rep < 2; rep++) { for (int k = 0; k < 3; k++) obs[o++] = (float)sph[k]; for (int k = 0; k < 4; k++) obs[o++] = (float)sqh[k]; }
+    for (int d = m->nrobot; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) obs[o++] = (float)s->q[d];
+    for (int j = 0; j < 5; j++) { double ph[3]; to_human_frame(s, pts[j], NULL, ph, NULL); for (int k = 0; k < 3; k++) obs[o++] = (float)ph[k]; }
+    obs[o++] = (float)total_force; obs[o++] = (float)tool_human_force; obs[o++] = (float)tool_human_force;
+  }
+}
+/* everything ArmManipulationEnv.step does after take_step (arm_manipulation.py:18-60), single-arm robot */
+static void finish_arm(sim_t* s, const float* action, float* obs, float* reward, int* done, float* info) {
+  const agxo_model* m = s->m; double dt = m->dt;
+  /* get_total_force (:62-69); the one tool is counted as tool_right and as tool_left */
+  double robot_f = 0, tool_f = 0, tool_human_f = 0;
+  for (int c = 0; c < s->ncon; c++) {
+    const contact_t* k = &s->con[c];
+    int ta = CI(m, k->ca, AGX_C_TAG), tb = CI(m, k->cb, AGX_C_TAG);
+    int human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
+    double f = k->lambda_n / dt;
+    if (tool) tool_f += f;
+    if (human && robot) robot_f += f;
+    if (human && tool) tool_human_f += f;
+  }
+  double total_f = robot_f + 2 * tool_human_f;               /* :68 */
+  observe_arm(s, tool_f, total_f, tool_human_f, obs);
+  /* tool.get_closest_points(human, distance=0.01): one point per (hull of the tool, shape of the human) pair that close, at the
+   * poses after the last substep (env.py:264-265) */
+  int near_pts = 0;
+  {
+    int t0 = -1, t1 = -1, h0 = -1, h1 = -1;
+    for (int gg = 0; gg < m->ngroup; gg++) {
+      int a0 = GI(m, gg, AGX_G_A0), b0 = GI(m, gg, AGX_G_B0);
+      if (CI(m, a0, AGX_C_TAG) == AGX_TAG_TOOL && CI(m, b0, AGX_C_TAG) == AGX_TAG_HUMAN) {
+        t0 = a0; t1 = GI(m, gg, AGX_G_A1); h0 = b0; h1 = GI(m, gg, AGX_G_B1);
+        if (s->gender == 1 && GI(m, gg, AGX_G_B0F) >= 0) { h0 = GI(m, gg, AGX_G_B0F); h1 = GI(m, gg, AGX_G_B1F); }
+        break;
+      }
+    }
+    const double lim = TF(m, AGX_T_PRESSURE_DIST);
+    for (int a = t0; a < t1; a++) for (int b = h0; b < h1; b++) { contact_t k; if (narrowphase(s, a, b, lim, &k) && k.dist < lim) near_pts++; }
+  }
+  double act_norm2 = 0; for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
+  xf_t ee; ee_frame(s, &ee);
+  int L = TI(m, AGX_T_EE_LINK); double wxp[3], vee[3];
+  cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
+  double ee_speed = 2 * sqrt(dot3(vee, vee));                /* right + left end effector: the same link (:26-27) */
+  double pressure = near_pts <= 0 ? 0.0 : tool_human_f / near_pts;      /* env.py:266-267 */
+  /* human_preferences (env.py:237-274): reward_force_nontarget = -(total - (right + left)) = -robot_f, tool_force_at_target = 0 */
+  double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_F) * (-(total_f - 2 * tool_human_f)) + TF(m, AGX_T_C_P) * (-(2 * pressure));
+  double sp[3], sR[9], d[3];
+  tool_base_pose(s, sp, sR);
+  const double *elbow = s->link[TI(m, AGX_T_OBS_LINK + 1)].p, *wrist = s->link[TI(m, AGX_T_OBS_LINK + 2)].p;
+  const double *stomach = s->human[TI(m, AGX_T_STOMACH_BODY)].p, *waist = s->human[TI(m, AGX_T_WAIST_BODY)].p;
+  sub3(sp, elbow, d); double rd_left = -sqrt(dot3(d, d));                                       /* :36 */
+  sub3(elbow, stomach, d); double rd_human = -sqrt(dot3(d, d));
+  sub3(wrist, waist, d); rd_human -= sqrt(dot3(d, d));                                          /* :38 */
+  double r = TF(m, AGX_T_W_DISTANCE) * rd_human + 2 * TF(m, AGX_T_W_WIPE) * rd_left + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + pref;   /* :42 */
+  if (s->am_best == 0 || rd_human > s->am_best) s->am_best = rd_human;                          /* :47-48 */
+  *reward = (float)r;
+  *done = s->iteration >= (int)TF(m, AGX_T_EPISODE_LEN);
+  if (info) {
+    info[AGX_INFO_TOTAL_FORCE] = (float)total_f;
+    info[AGX_INFO_TASK_SUCCESS] = (float)((float)s->am_best >= TF(m, AGX_T_SUCCESS_FRAC));
+    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)tool_human_f;
+    info[AGX_INFO_FOOD_REWARD] = (float)near_pts; info[AGX_INFO_PREF] = (float)pref;
+    info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
+  }
+}
 /* scratch itch: world position of the target, limb frame o target_on_arm (scratch_itch.py:148-152) */
 static void scratch_target(const sim_t* s, double* t) {
   const agxo_model* m = s->m; xf_apply(&s->link[TI(m, AGX_T_ARM_LINK + s->si_limb)], s->si_target, t);
@@ -1591,6 +1679,7 @@ void agxo_observe(const agxo_model* m, const float* state, float* obs) {
   if (m->task_kind == AGX_TASK_BED_BATHING) observe_bed(s, 0, 0, 0, obs);
   else if (m->task_kind == AGX_TASK_SCRATCH_ITCH) observe_scratch(s, 0, 0, 0, obs);
   else if (m->task_kind == AGX_TASK_DRESSING) observe_dressing(s, s->dr_force_sum, 0, obs);
+  else if (m->task_kind == AGX_TASK_ARM_MANIPULATION) observe_arm(s, 0, 0, 0, obs);
   else observe(s, 0, 0, obs);
   free(s);
 }
@@ -1668,6 +1757,7 @@ void agxo_step_cloth(const agxo_model* m, float* state, float* cloth, const floa
   }
   if (m->task_kind == AGX_TASK_BED_BATHING) { finish_bed(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   if (m->task_kind == AGX_TASK_SCRATCH_ITCH) { finish_scratch(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
+  if (m->task_kind == AGX_TASK_ARM_MANIPULATION) { finish_arm(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   update_target(s); /* FeedingEnv.update_targets (feeding.py:192-196) */
   double robot_f, tool_f; int hit_mask;
   contact_forces(s, &robot_f, &tool_f, &hit_mask);

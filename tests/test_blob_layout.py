@@ -34,7 +34,7 @@ def parse_enums():
 def test_layout_tables_match_header():
     v = parse_enums()
     for prefix, table in (('AGX_H_', L.H), ('AGX_P_', L.P), ('AGX_R_', L.R), ('AGX_F_', L.F), ('AGX_C_', L.C), ('AGX_G_', L.G),
-                          ('AGX_T_', L.T), ('AGX_E_', L.E), ('AGX_X_', L.X_), ('AGX_XJ_', L.XJ), ('AGX_CL_', L.CL), ('AGX_CP_', L.CP), ('AGX_DR_', L.DR)):
+                          ('AGX_T_', L.T), ('AGX_E_', L.E), ('AGX_X_', L.X_), ('AGX_XJ_', L.XJ), ('AGX_CL_', L.CL), ('AGX_CP_', L.CP), ('AGX_DR_', L.DR), ('AGX_AM_', L.AM)):
         for k, val in table.items():
             assert v[prefix + k] == val, (prefix + k, v[prefix + k], val)
     assert v['AGX_BLOB_MAGIC'] == L.MAGIC and v['AGX_BLOB_VERSION'] == L.VERSION

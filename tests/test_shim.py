@@ -80,18 +80,19 @@ def _reference_make_env(gym):
     return ns['make_env']
 
 
-@pytest.mark.parametrize('env_name', ['FeedingJaco-v1', 'BedBathingSawyer-v1', 'ScratchItchPR2-v1', 'DressingBaxter-v1'])
+@pytest.mark.parametrize('env_name', ['FeedingJaco-v1', 'BedBathingSawyer-v1', 'ScratchItchPR2-v1', 'DressingBaxter-v1', 'ArmManipulationSawyer-v1'])
 def test_reference_make_env_single_agent(shimmed, env_name):
     gym, _ = shimmed
     make_env = _reference_make_env(gym)
     env = make_env(env_name, coop=False, seed=7)
     assert type(env.env).__name__ == env_name.split('-')[0] + 'Env' and env._max_episode_steps == 200
-    assert env.action_space.shape == (7,) and env.observation_space.shape[0] in (24, 25, 30)
-    assert env.action_robot_len == 7 and len(env.robot.controllable_joint_indices) == 7      # what learn.py / env_viewer.py read
+    n_act = 14 if env_name.startswith('ArmManipulation') else 7         # robot_arm = 'both' on the single-arm Sawyer (robot.py:16)
+    assert env.action_space.shape == (n_act,) and env.observation_space.shape[0] in (24, 25, 30, 45)
+    assert env.action_robot_len == n_act and len(env.robot.controllable_joint_indices) == n_act      # what learn.py / env_viewer.py read
     env.disconnect()
 
 
-@pytest.mark.parametrize('env_name', ['FeedingJacoHuman-v1', 'BedBathingSawyerHuman-v1', 'ScratchItchPR2Human-v1', 'DressingBaxterHuman-v1'])
+@pytest.mark.parametrize('env_name', ['FeedingJacoHuman-v1', 'BedBathingSawyerHuman-v1', 'ScratchItchPR2Human-v1', 'DressingBaxterHuman-v1', 'ArmManipulationSawyerHuman-v1'])
 def test_reference_make_env_coop(shimmed, env_name):
     gym, creators = shimmed
     make_env = _reference_make_env(gym)
