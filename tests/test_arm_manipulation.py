@@ -62,7 +62,7 @@ def scooper_under_forearm(am, o, seed=1001, depth=0.003):
     v['tremor_target'][0] = v['q'][0, nr:]
     pos, rot = o.fk(s)
     el, wr = pos[nr + 7], pos[nr + 9]
-    assert abs((wr - el)[2]) < 0.05 * np.linalg.norm(wr - el) and el[0] < -0.6        # level, clear of the mattress
+    assert abs((wr - el)[2]) < 0.15 * np.linalg.norm(wr - el) and el[0] < -0.55       # level, clear of the mattress
     g = 'human_male' if infos[0]['gender'] == 'male' else 'human_female'
     rad = [am.collider(k) for k in range(*am.meta['ranges'][g]) if am.collider(k)['link'] == 7][0]['radius']
     hv = np.concatenate(tool_hulls_world(am, s))
