@@ -12,6 +12,7 @@ STEPS=${BENCH_STEPS:-2000}
 timeout 400 python bench.py --steps $STEPS > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
 timeout 300 python bench.py --task bedbathing --steps $STEPS > $O/bench_bedbathing.json 2> $O/bench_bedbathing.err; cut -c1-200 $O/bench_bedbathing.json
 timeout 300 python bench.py --task scratchitch --steps 600 > $O/bench_scratchitch.json 2> $O/bench_scratchitch.err; cut -c1-200 $O/bench_scratchitch.json
+timeout 300 python bench.py --task armmanipulation --steps $STEPS > $O/bench_armmanipulation.json 2> $O/bench_armmanipulation.err; cut -c1-200 $O/bench_armmanipulation.json
 timeout 400 python bench.py --task dressing --steps 100 --warmup 5 > $O/bench_dressing.json 2> $O/bench_dressing.err; cut -c1-200 $O/bench_dressing.json
 [ "${1:-}" = quick ] && exit 0
 cd /tmp && export TMPDIR=/tmp
