@@ -199,6 +199,16 @@ class FeedingJacoHumanEnv(FeedingJacoEnv):
     coop = True
 
 
+class FeedingPandaEnv(FeedingJacoEnv):
+    """FeedingPanda-v1 (feeding_envs.py:35-37): the same task with the wheelchair-mounted Franka Panda (agents/panda.py)."""
+    model = 'feeding_panda'
+
+
+class FeedingPandaHumanEnv(FeedingPandaEnv):
+    """FeedingPandaHuman-v1 (feeding_envs.py:69-73)"""
+    coop = True
+
+
 class BedBathingSawyerEnv(AssistiveEnv):
     """BedBathingSawyer-v1 (bed_bathing_envs.py:23-25): Sawyer wipes the right arm of a human lying on a bed."""
     model, task = 'bed_bathing_sawyer', 'bed_bathing'
@@ -299,7 +309,7 @@ class ArmManipulationSawyerHumanEnv(ArmManipulationSawyerEnv):
     coop = True
 
 
-ENV_IDS = {'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
+ENV_IDS = {'FeedingPanda-v1': FeedingPandaEnv, 'FeedingPandaHuman-v1': FeedingPandaHumanEnv, 'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
            'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
 
 

@@ -491,16 +491,38 @@ class Groups:
             self.rows.append([a0, a1, b0, b1, b0f, b1f, (GF_SAME if same else 0) | (GF_MANIFOLD if manifold else 0) | (GF_NO_ADJACENT if no_adjacent else 0) | flags, keep])
 
 
+# the wheelchair-mounted arms of the feeding task (Robot tables: agents/jaco.py:8-48, agents/panda.py:8-50); base = wheelchair position
+# [0, 0, 0.06] (furniture.py:16) + toc_base_pos_offset['feeding'] (feeding.py:117-119)
+FEEDING_ROBOTS = dict(
+    jaco=dict(urdf=('jaco', 'j2s7s300_gym.urdf'), arm=[1, 2, 3, 4, 5, 6, 7], grip=[9, 11, 13], gripper_target=1.33,            # jaco.py:8,13,20
+              gripper_collision=set(range(7, 15)), ee_pb=8,                                                                    # jaco.py:17,11
+              tool_pos=[0.1, -0.0225, 0.03], tool_rpy=[-0.1, -np.pi / 2.0, 0],                                                 # jaco.py:26,31
+              base_pos=[-0.35, -0.3, 0.36], ee_rpy=[np.pi / 2.0, 0, np.pi / 2.0]),                                             # jaco.py:47,43
+    panda=dict(urdf=('panda', 'panda.urdf'), arm=[0, 1, 2, 3, 4, 5, 6], grip=[9, 10], gripper_target=[0.001, 0.001],            # panda.py:8,13,20
+               gripper_collision={7, 8, 9, 10, 11}, ee_pb=11,                                                                  # panda.py:17,11
+               tool_pos=[-0.11, 0.0175, 0], tool_rpy=[-0.1, -np.pi / 2.0, np.pi],                                              # panda.py:26,31
+               base_pos=[-0.4, -0.35, 0.26], ee_rpy=[-np.pi / 2.0, 0, -np.pi / 2.0]))                                          # panda.py:36,43
+
+
 def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
     """FeedingJaco-v1 (feeding_envs.py:29-31).  Returns (blob uint32 array, meta dict)."""
+    return compile_feeding('jaco', assets, robot_hull_max_verts, n_iter)
+
+
+def compile_feeding_panda(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
+    """FeedingPanda-v1 (feeding_envs.py:35-37): the same scene with the wheelchair-mounted Franka arm."""
+    return compile_feeding('panda', assets, robot_hull_max_verts, n_iter)
+
+
+def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
     sc = Scene()
-    # ------------------------------------------------------------------ robot (agents/jaco.py)
-    arm = [1, 2, 3, 4, 5, 6, 7]
-    grip = [9, 11, 13]
-    rob = compile_robot(os.path.join(assets, 'jaco', 'j2s7s300_gym.urdf'), arm, grip, gripper_target=1.33,
+    # ------------------------------------------------------------------ robot (agents/jaco.py, agents/panda.py)
+    RB = FEEDING_ROBOTS[robot]
+    arm, grip = RB['arm'], RB['grip']
+    rob = compile_robot(os.path.join(assets, *RB['urdf']), arm, grip, gripper_target=RB['gripper_target'],
                         motor_gain=0.025, motor_force=1.0, max_hull_verts=robot_hull_max_verts)
     nrobot = len(rob['dof_links'])
-    gripper_collision = set(range(7, 15))          # jaco.py:17 -> no collision with the tool (tool.py:42-44)
+    gripper_collision = RB['gripper_collision']    # no collision with the tool (tool.py:42-44)
     add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)     # links that DO collide with the tool
     add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
     sc.begin('robot_base')
@@ -602,9 +624,9 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
         xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
-        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = [-0.35, -0.3, 0.36]                          # jaco.py:47 toc_base_pos_offset
+        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['base_pos']                               # toc_base_pos_offset
         xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])      # feeding.py:136
-        xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0])  # jaco.py:43 toc_ee_orient_rpy
+        xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])                  # toc_ee_orient_rpy
         xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.15, -0.65, 1.15], 0.05   # feeding.py:139
         xf[X_['BOWL_POS']:X_['BOWL_POS'] + 3], xf[X_['BOWL_RANGE']] = [-0.15, -0.65, 0.75], 0.05    # furniture.py:33
         xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [0, 0.03, 0.89], [0, 0.03, 0.86]   # human.py:102
@@ -638,8 +660,8 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
                 xi[b0 + XJ['DRAW']] = draw.get(j, -1)
         xi[ob:ob + nhuman] = human_bodies
         xi[od:od + nhdof] = hd
-    # end effector = PyBullet link 8 (jaco.py:11), carried by the moving link of joint 7
-    ee_pb = 8
+    # end effector = PyBullet link 8 (jaco.py:11), carried by the moving link of joint 7; link 11 of the Panda (panda.py:11)
+    ee_pb = RB['ee_pb']
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
     assert ee_link < nrobot
     task_f = dict(W_DISTANCE=1.0, W_ACTION=0.01, W_FOOD=1.0,                               # config.ini:15-18
@@ -647,13 +669,13 @@ def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=
                   SUCCESS_FRAC=0.75, MOUTH_DIST=0.03, SPILL_DIST=0.1,
                   MOUTH_M=[0, -0.11, 0.03], MOUTH_F=[0, -0.1, 0.03],                        # feeding.py:186
                   EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1],
-                  TOOL_POS=[0.1, -0.0225, 0.03], TOOL_QUAT=X.quat_from_rpy([-0.1, -np.pi / 2.0, 0]),   # jaco.py:26,31
+                  TOOL_POS=RB['tool_pos'], TOOL_QUAT=X.quat_from_rpy(RB['tool_rpy']),
                   TOOL_MAXF=500.0, EPISODE_LEN=200)                                        # tool.py:47
     task_i = dict(HEAD_LINK=head_link, EE_LINK=ee_link)
     params = default_params(n_iter)                                                        # robot / human gravity 0: feeding.py:150-152
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=25, FOOD0=2, TOOL_BODY=0, TASK_KIND=TASK_FEEDING), reset_fill, reset_words,
-                meta_extra=dict(head_link=int(head_link), robot_base_pos=[-0.35, -0.3, 0.36],
+                meta_extra=dict(head_link=int(head_link), robot_base_pos=list(RB['base_pos']),
                                 robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist()))
 
 
@@ -1205,7 +1227,7 @@ def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
                 task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip))
 
 
-COMPILERS = dict(feeding_jaco=compile_feeding_jaco, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
+COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
                  arm_manipulation_sawyer=compile_arm_manipulation_sawyer)
 

@@ -154,6 +154,11 @@ class FeedingJacoVecEnv(AssistiveVecEnv):
     model = 'feeding_jaco'
 
 
+class FeedingPandaVecEnv(AssistiveVecEnv):
+    """FeedingPanda-v1: the feeding kernels, oracle and device-side reset generator driven by the Panda's model blob."""
+    model = 'feeding_panda'
+
+
 class BedBathingSawyerVecEnv(AssistiveVecEnv):
     """BASELINE config 3.  Resets come from a pool of host-sampled post-reset states (reset='pool' / 'host')."""
     model = 'bed_bathing_sawyer'

@@ -28,6 +28,7 @@ SHADER_CLOCK_HZ = 2.4e9   # same guide: max clock 2400 MHz; 256 CUs x 4 SIMD-32,
 N_SIMD = 1024
 TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the compiled variant, workload description)
     'feeding': ('feeding_jaco', 'FeedingJacoVecEnv', '', 'FeedingJaco-v1'),
+    'feedingpanda': ('feeding_panda', 'FeedingPandaVecEnv', '', 'FeedingPanda-v1'),
     'bedbathing': ('bed_bathing_sawyer', 'BedBathingSawyerVecEnv', '_bb', 'BedBathingSawyer-v1'),
     'scratchitch': ('scratch_itch_pr2', 'ScratchItchPR2HumanVecEnv', '_si', 'ScratchItchPR2Human-v1 (co-op: 7 robot + 10 human actions)'),
     'armmanipulation': ('arm_manipulation_sawyer', 'ArmManipulationSawyerVecEnv', '_am', 'ArmManipulationSawyer-v1 (14 actions: the single arm listed twice)'),
