@@ -399,6 +399,20 @@ int agx_set_cloth_pool(agx_handle h, const float* pool_cloth_dev) {
   h->cloth_pool_dev = pool_cloth_dev; return AGX_OK;
 }
 
+int agx_check_collisions(agx_handle h, uint8_t* flags_host, void* stream) {
+  if (!h || !flags_host) return fail(AGX_E_ARG, "agx_check_collisions: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  // the stepper's own collision pass on the states as they are (no motor targets, nothing is integrated: the states do not change)
+  h->V->build(st, h->n_envs, h->blob_dev, h->state_dev, nullptr, h->scratch_dev, nullptr, 0, h->n_envs, h->sw, h->act_dim, nullptr, h->overflow_dev, nullptr, 0, 0);
+  HIPCHK(hipGetLastError());
+  h->V->collision_flags(st, h->n_envs, h->blob_dev, h->scratch_dev, h->work_dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(flags_host, h->work_dev, (size_t)h->n_envs, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return AGX_OK;
+}
+
 int agx_set_env_offset(agx_handle h, long long env_offset) {
   if (!h || env_offset < 0) return fail(AGX_E_ARG, "agx_set_env_offset: bad argument");
   h->env_offset = env_offset; return AGX_OK;

@@ -355,6 +355,29 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   return c.overflow;
 }
 
+// Collision flags of a state whose contacts the build kernel has just written to the per-env scratch record (agx_check_collisions):
+//   AGX_COLLIDE_ENV  -- a robot link or the tool touches (distance <= 0) the human or the furniture: what init_robot_pose and
+//                       ik_random_restarts reject (env.py:299-308, robot.py:103-108: get_closest_points(obj, distance=0));
+//   AGX_COLLIDE_SELF -- two robot links, or a robot link and the tool, interpenetrate by more than 1 cm (not checked by the reference,
+//                       whose null-space IK keeps away from folded arms; the host-side least-squares IK needs it).
+// Wave-uniform result.
+AGX_DEV int collision_flags(const uint32_t* __restrict__ blob, const float* __restrict__ gscratch, int lane) {
+  const int* bi = (const int*)blob;
+  const int* meta = (const int*)(gscratch + SCR_O_META);
+  const int ncon = meta[META_NCON];
+  bool env = false, self = false;
+  if (lane < ncon) {
+    const float* k = gscratch + SCR_O_CON + CON_STRIDE * lane; const int* ki = (const int*)k;
+    const int ta = bi[bi[AGX_H_OFF_COLL] + ki[C_CA] * AGX_C_STRIDE + AGX_C_TAG], tb = bi[bi[AGX_H_OFF_COLL] + ki[C_CB] * AGX_C_STRIDE + AGX_C_TAG];
+    const bool ra = ta == AGX_TAG_ROBOT || ta == AGX_TAG_TOOL, rb = tb == AGX_TAG_ROBOT || tb == AGX_TAG_TOOL;
+    const bool oa = ta == AGX_TAG_HUMAN || ta == AGX_TAG_TABLE || ta == AGX_TAG_WHEELCHAIR || ta == AGX_TAG_BED;
+    const bool ob = tb == AGX_TAG_HUMAN || tb == AGX_TAG_TABLE || tb == AGX_TAG_WHEELCHAIR || tb == AGX_TAG_BED;
+    env = ((ra && ob) || (rb && oa)) && k[C_DIST] <= 0.f;
+    self = ra && rb && k[C_DIST] < -0.01f;
+  }
+  return (wave_any(env) ? AGX_COLLIDE_ENV : 0) | (wave_any(self) ? AGX_COLLIDE_SELF : 0);
+}
+
 // solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
 AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane, int phase = 0) {
   Ctx c; ctx_init(c, blob, lds, lane);

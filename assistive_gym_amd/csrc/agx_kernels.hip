@@ -115,6 +115,14 @@ AGX_K(agx_observe_kernel)(const uint32_t* __restrict__ blob, float* state, float
   if (env >= n_envs) return;
   agx::env_observe(blob, state + (size_t)env * sw, obs + (size_t)env * obs_dim, lds, (int)threadIdx.x);
 }
+// after a build-kernel pass: the collision flags of every environment's state (agx_check_collisions)
+extern "C" __global__ void __launch_bounds__(64)
+AGX_K(agx_collision_flags_kernel)(const uint32_t* __restrict__ blob, const float* __restrict__ scratch, uint8_t* flags, int n_envs) {
+  const int env = blockIdx.x;
+  if (env >= n_envs) return;
+  const int f = agx::collision_flags(blob, scratch + (size_t)env * agx::SCR_WORDS, (int)threadIdx.x);
+  if (threadIdx.x == 0) flags[env] = (uint8_t)f;
+}
 #if AGX_HAS_SAMPLER
 // reset generator: FeedingEnv.reset's sampling incl. the IK restarts (64 per round, one per lane), float64
 extern "C" __global__ void __launch_bounds__(64)
@@ -184,6 +192,10 @@ void v_verdict(hipStream_t st, int n_envs, const uint32_t* blob, const float* sc
 }
 #endif
 
+void v_collision_flags(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, uint8_t* flags) {
+  hipLaunchKernelGGL(AGX_K(agx_collision_flags_kernel), dim3(n_envs), dim3(64), 0, st, blob, scratch, flags, n_envs);
+}
+
 #define AGX_STR2_(x) #x
 #define AGX_STR_(x) AGX_STR2_(x)
 const agx_variant g_variant = {
@@ -208,10 +220,11 @@ const agx_variant g_variant = {
   nullptr,
 #endif
 #if AGX_HAS_SAMPLER
-  v_verdict
+  v_verdict,
 #else
-  nullptr
+  nullptr,
 #endif
+  v_collision_flags
 };
 
 }  // namespace

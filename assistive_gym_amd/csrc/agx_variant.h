@@ -29,6 +29,8 @@ struct agx_variant {
                 int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* active, int lds_bytes);
   // collision verdict on freshly sampled states after a build pass (see agx_reset.h reset_collides)
   void (*verdict)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, const uint8_t* active, uint8_t* work, int* first_restart, const int* chosen);
+  // collision flags (AGX_COLLIDE_*) of every environment's state after a build pass (agx_check_collisions)
+  void (*collision_flags)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, uint8_t* flags);
 };
 
 extern "C" const agx_variant* agx_variant_feeding(void);

@@ -217,12 +217,12 @@ class BedBathingSawyerEnv(AssistiveEnv):
         """BedBathingEnv.reset (bed_bathing.py:112-171): the draws, the TOC base pose search and the IK restated on the host
         (host/reset_bed.py) around the rag-doll settle of the human, which runs on the device (bed_settle model); the result is
         injected into the stepper."""
-        from .host.reset_bed import make_states, RagdollSettler
+        from .host.reset_bed import make_states, RagdollSettler, DeviceCollisionChecker
         st = self._ensure_stepper()
         if not hasattr(self, '_settler'):
-            self._settler = RagdollSettler(1, self.device)
+            self._settler, self._checker = RagdollSettler(1, self.device), DeviceCollisionChecker(self.blob, 1, self.device)
         self.reset_seed = self._draw_seed()
-        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler)
+        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler, checker=self._checker)
         st.set_state(rec)
         self.iteration, self.task_success = 0, 0
         return self._split_obs(st.observe_host()[0].astype(np.float64))
@@ -240,13 +240,13 @@ class ScratchItchPR2Env(AssistiveEnv):
 
     def reset(self):
         """ScratchItchEnv.reset (scratch_itch.py:93-132), restated on the host (host/reset_scratch.py); its result is injected."""
-        from .host.reset_scratch import ScratchItchPR2Reset
+        from .host.reset_scratch import make_states
+        from .host.reset_bed import DeviceCollisionChecker
         st = self._ensure_stepper()
-        if not hasattr(self, '_sampler'):
-            self._sampler = ScratchItchPR2Reset(self.blob)
+        if not hasattr(self, '_checker'):
+            self._checker = DeviceCollisionChecker(self.blob, 1, self.device)
         self.reset_seed = self._draw_seed()
-        rec = self.blob.new_state(1)
-        self._sampler.sample(np.random.RandomState(self.reset_seed % (2 ** 32)), rec, env_seed=self.reset_seed % (2 ** 31))
+        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), checker=self._checker)
         st.set_state(rec)
         self.iteration, self.task_success = 0, 0
         return self._split_obs(st.observe_host()[0].astype(np.float64))
@@ -255,6 +255,34 @@ class ScratchItchPR2Env(AssistiveEnv):
 class ScratchItchPR2HumanEnv(ScratchItchPR2Env):
     """ScratchItchPR2Human-v1 (scratch_itch_envs.py:41-44; BASELINE config 4): the human's right arm (10 joints) is controllable,
     the pose-dependent arm limits run after every substep; actions {'robot': a[7], 'human': a[10]}, observations 30 + 34."""
+    coop = True
+
+
+class ScratchItchJacoEnv(ScratchItchPR2Env):
+    """ScratchItchJaco-v1 (scratch_itch_envs.py:29-31; the default environment of the reference's env_viewer.py / learn.py): the
+    wheelchair-mounted Jaco holds the scratcher."""
+    model = 'scratch_itch_jaco'
+
+
+class ScratchItchJacoHumanEnv(ScratchItchJacoEnv):
+    coop = True
+
+
+class ScratchItchPandaEnv(ScratchItchPR2Env):
+    """ScratchItchPanda-v1 (scratch_itch_envs.py:37-39)"""
+    model = 'scratch_itch_panda'
+
+
+class ScratchItchPandaHumanEnv(ScratchItchPandaEnv):
+    coop = True
+
+
+class ScratchItchSawyerEnv(ScratchItchPR2Env):
+    """ScratchItchSawyer-v1 (scratch_itch_envs.py:25-27)"""
+    model = 'scratch_itch_sawyer'
+
+
+class ScratchItchSawyerHumanEnv(ScratchItchSawyerEnv):
     coop = True
 
 
@@ -292,12 +320,13 @@ class ArmManipulationSawyerEnv(AssistiveEnv):
     def reset(self):
         """ArmManipulationEnv.reset (arm_manipulation.py:110-182): host/reset_arm.py around the two settles on the device."""
         from .host.reset_arm import make_states, ArmFallSettler
-        from .host.reset_bed import RagdollSettler
+        from .host.reset_bed import RagdollSettler, DeviceCollisionChecker
         st = self._ensure_stepper()
         if not hasattr(self, '_settler'):
             self._settler, self._arm_settler = RagdollSettler(1, self.device), ArmFallSettler(self.blob, 1, self.device)
+            self._checker = DeviceCollisionChecker(self.blob, 1, self.device)
         self.reset_seed = self._draw_seed()
-        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler, arm_settler=self._arm_settler)
+        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler, arm_settler=self._arm_settler, checker=self._checker)
         st.set_state(rec)
         self.iteration, self.task_success = 0, 0
         return self._split_obs(st.observe_host()[0].astype(np.float64))
@@ -309,7 +338,9 @@ class ArmManipulationSawyerHumanEnv(ArmManipulationSawyerEnv):
     coop = True
 
 
-ENV_IDS = {'FeedingPanda-v1': FeedingPandaEnv, 'FeedingPandaHuman-v1': FeedingPandaHumanEnv, 'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
+ENV_IDS = {'ScratchItchJaco-v1': ScratchItchJacoEnv, 'ScratchItchJacoHuman-v1': ScratchItchJacoHumanEnv, 'ScratchItchPanda-v1': ScratchItchPandaEnv,
+           'ScratchItchPandaHuman-v1': ScratchItchPandaHumanEnv, 'ScratchItchSawyer-v1': ScratchItchSawyerEnv, 'ScratchItchSawyerHuman-v1': ScratchItchSawyerHumanEnv,
+           'FeedingPanda-v1': FeedingPandaEnv, 'FeedingPandaHuman-v1': FeedingPandaHumanEnv, 'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
            'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
 
 

@@ -17,7 +17,7 @@ import numpy as np
 
 from ..model import compiler as L
 from ..model import xform as X
-from .reset_bed import ArmChain, BedBathingSawyerReset, settle_record, settled_pose
+from .reset_bed import ArmChain, BedBathingSawyerReset, settle_record, settled_pose, placement_rng, reject_collisions
 
 D = np.deg2rad
 PARKED = np.array([20.0, 20.0, 0.975])          # where the robot stands while the arm falls (it is not yet placed then, :162)
@@ -102,7 +102,7 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
         v['rng'][0, 1] = (env_seed ^ 0x5bd1e995) & 0x7FFFFFFF
         return state_row
 
-    def post_fall(self, rng, state_row, pre, env_seed=0, info=None):
+    def post_fall(self, rng, state_row, pre, env_seed=0, info=None, attempt=0):
         """everything after the arm has fallen (:148-179); the record keeps the arm's joint angles AND velocities"""
         b = self.blob
         v = b.view(state_row)
@@ -112,11 +112,14 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
             hq[j] = v['q'][0, nr + k]
         hpos, _ = hm.fk(pre['base_pos'], pre['base_quat'], hq)
         elbow, wrist, stomach, waist = hpos[7], hpos[9], hpos[24], hpos[27]        # :148-151
-        target_ee_pos = np.array([-1, 0.4, 0.8]) + rng.uniform(-0.05, 0.05, size=3)    # :158 (single arm)
-        rng.uniform(-0.05, 0.05, size=3)                                           # :159 target_ee_left_pos is drawn as well
+        if attempt == 0:
+            pre['target_ee_pos'] = np.array([-1, 0.4, 0.8]) + rng.uniform(-0.05, 0.05, size=3)    # :158 (single arm)
+            rng.uniform(-0.05, 0.05, size=3)                                       # :159 target_ee_left_pos is drawn as well
+        target_ee_pos = pre['target_ee_pos']
+        prng = placement_rng(rng, env_seed, attempt)
         toc = None
         for _ in range(4):
-            toc = self._toc(rng, target_ee_pos, [wrist, waist, elbow, stomach])    # :162
+            toc = self._toc(prng, target_ee_pos, [wrist, waist, elbow, stomach])   # :162
             if toc is not None:
                 break
         assert toc is not None, 'no reachable base pose found'
@@ -153,10 +156,11 @@ class ArmFallSettler:
         return self.ctx.get_state()[:n]
 
 
-def make_states(blob, n, seed=1001, impairment='no_tremor', settler=None, arm_settler=None, fall_steps=100, **kw):
+def make_states(blob, n, seed=1001, impairment='no_tremor', settler=None, arm_settler=None, fall_steps=100, checker=None, **kw):
     """n independent post-reset states; env i uses RandomState(seed + i).  settler: bed_settle records -> records after the 100-step
     rag-doll settle (host/reset_bed.RagdollSettler; None = the rigid 'drop' stand-in); arm_settler(states, n_sim_steps): the arm's fall
-    (ArmFallSettler; None = the arm stays as posed)."""
+    (ArmFallSettler; None = the arm stays as posed); checker(states) -> AGX_COLLIDE_* flags (reset_bed.DeviceCollisionChecker) turns on
+    init_robot_pose's collision rejection (env.py:281-308)."""
     rs = ArmManipulationSawyerReset(blob)
     st = blob.new_state(n)
     infos = [{} for _ in range(n)]
@@ -183,4 +187,8 @@ def make_states(blob, n, seed=1001, impairment='no_tremor', settler=None, arm_se
         st = np.ascontiguousarray(arm_settler(st, fall_steps))
     for i, p in enumerate(pres):
         rs.post_fall(rngs[i], st[i:i + 1], p, env_seed=seed + i, info=infos[i])
+    if checker is not None:
+        flags = reject_collisions(st, checker, lambda i, attempt: rs.post_fall(rngs[i], st[i:i + 1], pres[i], env_seed=seed + i, info=infos[i], attempt=attempt))
+        for i in range(n):
+            infos[i]['collision_flags'] = int(flags[i])
     return st, infos

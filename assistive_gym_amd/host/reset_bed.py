@@ -160,6 +160,49 @@ class RagdollSettler:
         return self.ctx.get_state()[:n]
 
 
+class DeviceCollisionChecker:
+    """states -> AGX_COLLIDE_* flags per state, from the stepper's own collision pass on the device (agx_check_collisions): the
+    collision rejection of init_robot_pose / ik_random_restarts (env.py:299-308, robot.py:103-108) for resets sampled on the host.
+    Fails loudly without a GPU."""
+
+    def __init__(self, blob, n_envs, device=0):
+        from ..libagx import Stepper
+        self.blob, self.n = blob, n_envs
+        self.ctx = Stepper(blob, n_envs, device)
+
+    def __call__(self, states):
+        out = np.zeros(len(states), dtype=np.uint8)
+        for i0 in range(0, len(states), self.n):
+            chunk = states[i0:i0 + self.n]
+            buf = self.blob.new_state(self.n)
+            buf[:len(chunk)] = chunk
+            buf[len(chunk):] = chunk[:1]
+            self.ctx.set_state(buf)
+            out[i0:i0 + len(chunk)] = self.ctx.check_collisions()[:len(chunk)]
+        return out
+
+
+def placement_rng(rng, env_seed, attempt):
+    """the random stream of the robot's placement: the sampler's own stream on the first attempt, a stream of its own on the re-draws
+    of init_robot_pose's rejection loop (env.py:281), so that nothing else of the episode changes"""
+    return rng if attempt == 0 else np.random.RandomState((env_seed * 7919 + 104729 * attempt) & 0x7FFFFFFF)
+
+
+def reject_collisions(states, flags_of, resample, max_iterations=3):
+    """init_robot_pose's loop (env.py:281-308): states whose robot or tool touches the human / the furniture (or whose arm is folded into
+    itself) are placed again, at most max_iterations placements in total; resample(i, attempt) rewrites states[i].  Returns the final
+    flags (a state still colliding after the last attempt is kept, as in the reference)."""
+    flags = flags_of(states)
+    for attempt in range(1, max_iterations):
+        bad = np.flatnonzero(flags)
+        if not len(bad):
+            break
+        for i in bad:
+            resample(int(i), attempt)
+        flags[bad] = flags_of(states[bad])
+    return flags
+
+
 class BedBathingSawyerReset:
     def __init__(self, blob, settle='drop'):
         assert blob.task_kind == L.TASK_BED_BATHING
@@ -297,7 +340,7 @@ class BedBathingSawyerReset:
         return dict(plane_friction=plane_friction, gender=gender, impairment=impairment, limit_scale=limit_scale, strength=strength,
                     tremors=tremors, hm=hm, hq=hq, base_pos=np.array([-0.15, 0.2, 0.95]), base_rpy=base_rpy, base_quat=X.quat_from_rpy(base_rpy))
 
-    def post_settle(self, rng, state_row, pre, env_seed=0, info=None):
+    def post_settle(self, rng, state_row, pre, env_seed=0, info=None, attempt=0):
         """everything after the settle (bed_bathing.py:133-171), from the resting pose in `pre`"""
         b = self.blob
         v = b.view(state_row)
@@ -311,10 +354,13 @@ class BedBathingSawyerReset:
             else:
                 v['human'][0, k, :3], v['human'][0, k, 3:] = hpos[link], hquat[link]
         shoulder, elbow, wrist = hpos[5], hpos[7], hpos[9]                         # bed_bathing.py:139-141
-        target_ee_pos = np.array([-0.6, 0.2, 1]) + rng.uniform(-0.05, 0.05, size=3)    # bed_bathing.py:147
+        if attempt == 0:
+            pre['target_ee_pos'] = np.array([-0.6, 0.2, 1]) + rng.uniform(-0.05, 0.05, size=3)    # bed_bathing.py:147
+        target_ee_pos = pre['target_ee_pos']
+        prng = placement_rng(rng, env_seed, attempt)
         toc = None
         for _ in range(4):
-            toc = self._toc(rng, target_ee_pos, [shoulder, elbow, wrist])
+            toc = self._toc(prng, target_ee_pos, [shoulder, elbow, wrist])
             if toc is not None:
                 break
         assert toc is not None, 'no reachable base pose found'
@@ -364,10 +410,11 @@ class BedBathingSawyerReset:
         return state_row
 
 
-def make_states(blob, n, seed=1001, impairment='random', settler=None, **kw):
+def make_states(blob, n, seed=1001, impairment='random', settler=None, checker=None, **kw):
     """n independent post-reset states; env i uses RandomState(seed + i).  With a `settler` (a callable advancing bed_settle
     state records by the 100 simulation steps of bed_bathing.py:130-131, e.g. RagdollSettler) the human is settled as a rag
-    doll, all environments in one batch; without one the rigid 'drop' stand-in is used."""
+    doll, all environments in one batch; without one the rigid 'drop' stand-in is used.  checker(states) -> AGX_COLLIDE_* flags
+    (DeviceCollisionChecker) turns on init_robot_pose's collision rejection (needs the settler path)."""
     rs = BedBathingSawyerReset(blob, settle='drop' if settler is None else 'ragdoll')
     st = blob.new_state(n)
     infos = [{} for _ in range(n)]
@@ -386,4 +433,8 @@ def make_states(blob, n, seed=1001, impairment='random', settler=None, **kw):
     for i, p in enumerate(pres):
         p['base_pos'], p['base_quat'], p['hq'] = settled_pose(sblob, ss[i:i + 1], p['hm'])
         rs.post_settle(rngs[i], st[i:i + 1], p, env_seed=seed + i, info=infos[i])
+    if checker is not None:
+        flags = reject_collisions(st, checker, lambda i, attempt: rs.post_settle(rngs[i], st[i:i + 1], pres[i], env_seed=seed + i, info=infos[i], attempt=attempt))
+        for i in range(n):
+            infos[i]['collision_flags'] = int(flags[i])
     return st, infos

@@ -1,10 +1,12 @@
-"""Host-side reset for ScratchItchPR2-v1 / ScratchItchPR2Human-v1: produces post-reset state records (the stepper's input).
+"""Host-side reset for ScratchItch<Robot>-v1 / ScratchItch<Robot>Human-v1 (PR2, Sawyer: base pose search; Jaco, Panda: mounted on the
+wheelchair): produces post-reset state records (the stepper's input).
 
 Follows the order of ScratchItchEnv.reset (assistive_gym/envs/scratch_itch.py:93-132): build_assistive_env('wheelchair')
 (envs/env.py:114-134: plane friction, Human.init draws, agents/human.py:72-102), the seated human with its joint presets
 (scratch_itch.py:104-105; Human.setup_joints, human.py:104-127: the right arm stays dynamic -- held by a reactive PD of gain 0.01
 and force 1 x strength when the human is not controllable), the target end-effector pose (:115-116), init_robot_pose ->
-Robot.position_robot_toc (env.py:276-310, robot.py:123-215) for the PR2's base and left arm, the gripper (:120), generate_target
+Robot.position_robot_toc (env.py:276-310, robot.py:123-215) for the base and arm of a free-standing robot, or Robot.ik_random_restarts
+(env.py:295-297, robot.py:84-121) from the fixed base of a wheelchair-mounted one (scratch_itch.py:97-99), the gripper (:120), generate_target
 (:134-146: limb draw + Util.point_on_capsule, util.py:58-78).
 
 As in host/reset_bed.py (whose TOC search and batched IK this reuses): Bullet's IK is replaced by damped least squares and the
@@ -15,23 +17,76 @@ import numpy as np
 from ..model import compiler as L
 from ..model import xform as X
 from ..model.human import HumanModel
-from .reset_bed import ArmChain, BedBathingSawyerReset
+from .reset_bed import ArmChain, BedBathingSawyerReset, mat_to_quat_batch, placement_rng, reject_collisions
 
 D = np.deg2rad
 
 
-class ScratchItchPR2Reset(BedBathingSawyerReset):
+class ScratchItchReset(BedBathingSawyerReset):
     def __init__(self, blob):
         assert blob.task_kind == L.TASK_SCRATCH_ITCH
         self.blob = blob
         self.arm = ArmChain(blob)
         self.human_bodies = blob.meta['human_bodies']
         self.human_dyn = blob.meta['human_dynamic_joints']
-        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array([0.1, 0, 0])                  # robot.py:142 + pr2.py:35
-        self.ee_R = X.quat_to_mat(X.quat_from_rpy([0, 0, 0]))                                # pr2.py:41 toc_ee_orient_rpy
+        m = blob.meta
+        self.mount = m.get('mount', 'toc')
+        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m.get('toc_base', [0.1, 0, 0]))       # robot.py:142 + toc_base_pos_offset (pr2.py:35)
+        self.fixed_base = np.array([0, 0, 0.06]) + np.array(m.get('toc_base', [0, 0, 0]))          # wheelchair position + offset (scratch_itch.py:97-99)
+        self.ee_R = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy', [0, 0, 0])))                      # toc_ee_orient_rpy (pr2.py:41)
+        self.self_guard = m.get('robot') == 'sawyer'                                                 # see reset_bed._arm_in_pedestal
         self._hm = {}
 
-    def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None):
+    def _near_human(self, hm, hpos, hquat, hbase, pts, margin=0.07):
+        """pts (B, K, 3): is any point closer than `margin` (an arm link's radius + clearance) to a capsule / sphere of the human?  The
+        stand-in for `get_closest_points(human, distance=0)` inside ik_random_restarts (robot.py:103-108) on the host."""
+        hit = np.zeros(pts.shape[0], dtype=bool)
+        for link, kind, data in hm.colliders():
+            lp, lq = (hbase, np.array([0, 0, 0, 1.0])) if link < 0 else (hpos[link], hquat[link])
+            if kind == 'capsule':
+                a, b = X.apply(lp, lq, np.stack([data[0], data[1]]))
+                r = data[2]
+            elif kind == 'sphere':
+                a = b = X.apply(lp, lq, data[0][None])[0]
+                r = data[1]
+            else:
+                continue
+            ab = b - a
+            t = np.clip(((pts - a) @ ab) / max(float(ab @ ab), 1e-12), 0, 1)
+            d = np.linalg.norm(pts - (a + t[..., None] * ab), axis=-1) - r
+            hit |= (d < margin).any(axis=1)
+        return hit
+
+    def _mounted_ik(self, rng, target_pos, human=None, restarts=64, rounds=4):
+        """Robot.ik_random_restarts (robot.py:84-121) from the fixed base: random rest poses until the end effector is within 0.01 of the
+        target pose and the arm is clear of the human; `restarts` of them are solved at once, the first that qualifies is taken; when
+        none does, the closest one (robot.py:117-121)"""
+        arm = self.arm
+        bp = np.repeat(self.fixed_base[None], restarts, axis=0)
+        bR = np.repeat(X.quat_to_mat(X.quat_from_rpy([0, 0, -np.pi / 2.0]))[None], restarts, axis=0)
+        lo = np.where(arm.lower < -1e9, -2 * np.pi, arm.lower)
+        hi = np.where(arm.upper > 1e9, 2 * np.pi, arm.upper)
+        tp, tR = np.repeat(target_pos[None], restarts, axis=0), np.repeat(self.ee_R[None], restarts, axis=0)
+        qt = X.mat_to_quat(self.ee_R)
+        best = None
+        for _ in range(rounds):
+            q = arm.ik(bp, bR, rng.uniform(lo, hi, size=(restarts, arm.n)), tp, tR, iters=200)
+            pe, Re, orig, _ = arm.fk(bp, bR, q)
+            qe = mat_to_quat_batch(Re)
+            err = np.linalg.norm(tp - pe, axis=1) + np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1))
+            ok = (np.linalg.norm(tp - pe, axis=1) < 0.01) & (np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1)) < 0.01)
+            if human is not None and ok.any():
+                pts = np.concatenate([orig[:, 1:], 0.5 * (orig[:, 1:-1] + orig[:, 2:]), pe[:, None], 0.5 * (orig[:, -1:] + pe[:, None])], axis=1)
+                ok &= ~self._near_human(*human, pts)
+            k = int(np.argmax(ok)) if ok.any() else int(np.argmin(err))
+            if best is None or err[k] < best[0]:
+                best = (float(err[k]), q[k].copy(), bool(ok[k]))
+            if ok.any():
+                break
+        return self.fixed_base.copy(), X.quat_from_rpy([0, 0, -np.pi / 2.0]), best[1], 1 if best[2] else 0, 0.0
+
+    def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None, attempt=0):
+        """attempt > 0: a re-draw of the robot's placement only (init_robot_pose's rejection loop), everything else as on attempt 0"""
         b = self.blob
         v = b.view(state_row)
         nr, nh = b.nrobot, b.nhdof
@@ -65,10 +120,14 @@ class ScratchItchPR2Reset(BedBathingSawyerReset):
         shoulder, elbow, wrist = hpos[5], hpos[7], hpos[9]                         # scratch_itch.py:107-109
         target_ee_pos = np.array([-0.6, 0, 0.8]) + rng.uniform(-0.05, 0.05, size=3)    # scratch_itch.py:115
         toc = None
-        for _ in range(4):
-            toc = self._toc(rng, target_ee_pos, [shoulder, elbow, wrist])
-            if toc is not None:
-                break
+        prng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)     # one draw of the main stream, whatever the attempt
+        if self.mount == 'wheelchair':
+            toc = self._mounted_ik(prng, target_ee_pos, human=(hm, hpos, hquat, hbase))
+        else:
+            for _ in range(4):
+                toc = self._toc(prng, target_ee_pos, [shoulder, elbow, wrist])
+                if toc is not None:
+                    break
         assert toc is not None, 'no reachable base pose found'
         rb_pos, rb_quat, q_arm, ngoal, manip = toc
         q = np.zeros(nr)
@@ -123,13 +182,22 @@ class ScratchItchPR2Reset(BedBathingSawyerReset):
         return state_row
 
 
-def make_states(blob, n, seed=1001, impairment='random', **kw):
-    """n independent post-reset states; env i uses RandomState(seed + i)."""
-    rs = ScratchItchPR2Reset(blob)
+def make_states(blob, n, seed=1001, impairment='random', checker=None, **kw):
+    """n independent post-reset states; env i uses RandomState(seed + i).  checker(states) -> AGX_COLLIDE_* flags
+    (reset_bed.DeviceCollisionChecker) turns on init_robot_pose's collision rejection (env.py:281-308)."""
+    rs = ScratchItchReset(blob)
     st = blob.new_state(n)
-    infos = []
+    infos = [{} for _ in range(n)]
+
+    def draw(i, attempt=0):
+        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], env_seed=seed + i, impairment=impairment, info=infos[i], attempt=attempt, **kw)
     for i in range(n):
-        info = {}
-        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], env_seed=seed + i, impairment=impairment, info=info, **kw)
-        infos.append(info)
+        draw(i)
+    if checker is not None:
+        flags = reject_collisions(st, checker, draw)
+        for i in range(n):
+            infos[i]['collision_flags'] = int(flags[i])
     return st, infos
+
+
+ScratchItchPR2Reset = ScratchItchReset

@@ -14,7 +14,7 @@ _LIB = None
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_cloth_nodes', 'agx_set_cloth', 'agx_get_cloth', 'agx_cloth_dev', 'agx_set_cloth_pool', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
-           'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset',
+           'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset', 'agx_check_collisions',
            'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather']
 
 
@@ -94,6 +94,12 @@ class Stepper:
         out = C.c_int()
         check(self.L.agx_overflow_count(self.h, C.byref(out)), 'agx_overflow_count')
         return out.value
+
+    def check_collisions(self):
+        """AGX_COLLIDE_* flags of every environment's current state (uint8 [n_envs]); the states are not advanced"""
+        out = np.zeros(self.n_envs, dtype=np.uint8)
+        check(self.L.agx_check_collisions(self.h, out.ctypes.data_as(C.c_void_p), None), 'agx_check_collisions')
+        return out
 
     def set_env_offset(self, env_offset):
         """global index of this stepper's first env (multi-GPU sharding): keeps agx_reset_done's pool draw placement independent"""

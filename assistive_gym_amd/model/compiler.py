@@ -969,29 +969,63 @@ def compile_bed_settle(assets=DEFAULT_ASSETS, n_iter=50):
                 task_words=BB['WORDS'], meta_extra=dict(settle_joints=joints, virtual_dofs=VR))
 
 
+# the robots of the scratch-itch task (robot_arm = 'left', scratch_itch_envs.py:15; on the single-arm robots left IS right).
+# mount 'toc': the base pose comes from Robot.position_robot_toc around [-0.85, -0.4, 0] + toc_base (robot.py:142);
+# mount 'wheelchair': the base is fixed at the wheelchair position [0, 0, 0.06] + toc_base, rpy [0, 0, -pi/2] (scratch_itch.py:97-99)
+# selfcol: 'none' (no URDF_USE_SELF_COLLISION, pr2.py:52), 'all' (every non-adjacent link pair, jaco.py:53 / panda.py:53),
+#          'sawyer' (the pairs Sawyer.init leaves enabled, sawyer.py:53-61)
+SCRATCH_ROBOTS = dict(
+    pr2=dict(urdf=('PR2', 'pr2_no_torso_lift_tall.urdf'), arm=[64, 65, 66, 68, 69, 71, 72], grip=[79, 80, 81, 82], gripper_target=[0.25] * 4,   # pr2.py:9,14,17
+             gripper_collision=set(range(71, 86)), ee_pb=76, tool_pb=76, tool_pos=[0, 0, 0], tool_rpy=[0, 0, 0],                              # pr2.py:16,12,15,26,32
+             toc_base=[0.1, 0, 0], ee_rpy=[0, 0, 0], mount='toc', selfcol='none', file_inertia=True,                                           # pr2.py:35,41,52
+             frozen_rest=dict(zip([42, 43, 44, 46, 47, 49, 50], [-1.75, 1.25, -1.5, -0.5, -1, 0, -1]))),                                       # right arm tucked, pr2.py:64
+    jaco=dict(urdf=('jaco', 'j2s7s300_gym.urdf'), arm=[1, 2, 3, 4, 5, 6, 7], grip=[9, 11, 13], gripper_target=[1.0] * 3,                        # jaco.py:8,13,19
+              gripper_collision=set(range(7, 15)), ee_pb=8, tool_pb=8, tool_pos=[0, 0, 0.02], tool_rpy=[0, -np.pi / 2.0, 0],                    # jaco.py:17,11,15,25,30
+              toc_base=[-0.35, -0.3, 0.3], ee_rpy=[0, np.pi / 2.0, 0], mount='wheelchair', selfcol='all'),                                     # jaco.py:35-36,42,53
+    panda=dict(urdf=('panda', 'panda.urdf'), arm=[0, 1, 2, 3, 4, 5, 6], grip=[9, 10], gripper_target=[0.02] * 2,                               # panda.py:8,13,19
+               gripper_collision={7, 8, 9, 10, 11}, ee_pb=11, tool_pb=11, tool_pos=[0, 0, 0], tool_rpy=[0, -np.pi / 2.0, 0],                   # panda.py:17,11,15,25,30
+               toc_base=[-0.4, -0.35, 0.2], ee_rpy=[0, np.pi / 2.0, 0], mount='wheelchair', selfcol='all'),                                    # panda.py:35-36,42,53
+    sawyer=dict(urdf=('sawyer', 'sawyer.urdf'), arm=[3, 8, 9, 10, 11, 13, 16], grip=[20, 22], gripper_target=[0.015, -0.015],                  # sawyer.py:8,13,19
+                gripper_collision={18, 20, 21, 22, 23}, ee_pb=19, tool_pb=18, tool_pos=[0, 0.125, 0], tool_rpy=[0, 0, np.pi / 2.0],            # sawyer.py:17,11,15,25,30
+                toc_base=[-0.1, 0, 0.975], ee_rpy=[0, np.pi / 2.0, 0], mount='toc', selfcol='sawyer', hull_verts=0))                           # sawyer.py:35,41
+
+
 def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
-    """ScratchItchPR2-v1 / ScratchItchPR2Human-v1 (scratch_itch_envs.py:17-19,41-44; BASELINE config 4 is the co-op flavour, `blob.coop()`):
-    the PR2's left arm (agents/pr2.py) holding the scratcher (assets/scratcher/tool_scratch.urdf) next to a human in the wheelchair
-    whose right arm joints 0..9 are the controllable joints.
+    """ScratchItchPR2-v1 / ScratchItchPR2Human-v1 (scratch_itch_envs.py:17-19,41-44; BASELINE config 4 is the co-op flavour, `blob.coop()`)."""
+    return compile_scratch_itch('pr2', assets, n_iter, robot_hull_max_verts)
+
+
+def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
+    """ScratchItch<Robot>-v1 / ScratchItch<Robot>Human-v1 (scratch_itch_envs.py:17-62): the robot's (left) arm holding the scratcher
+    (assets/scratcher/tool_scratch.urdf) next to a human in the wheelchair whose right arm joints 0..9 are the controllable joints.
     PR2: 44 movable joints behind a fixed base.  With the base fixed every branch off the base is dynamically independent; the
     branches that are not the left arm (casters, head, lasers, right arm) start at rest (Robot.reset_joints, pr2.py:62-66), carry
     no gravity (scratch_itch.py:122) and are only held by their default motors, so nothing but a collision could move them: they
     are compiled as STATIC geometry at those joint positions [deviation, DESIGN.md].  So are three passive joints of the left
     gripper mechanism (77 motor slider, 78 motor screw, 83 l_gripper_joint: 1..10 g, no collision shape).  What remains dynamic:
-    the 7 arm joints + the 4 finger joints."""
+    the 7 arm joints + the 4 finger joints.  Jaco / Panda / Sawyer: every movable joint is an arm or gripper joint (Sawyer's head pan
+    stays a dynamic joint held by its default motor, as in BedBathingSawyer)."""
     sc = Scene()
-    arm = [64, 65, 66, 68, 69, 71, 72]                  # pr2.py:9
-    grip = [79, 80, 81, 82]                             # pr2.py:14
-    urdf_path = os.path.join(assets, 'PR2', 'pr2_no_torso_lift_tall.urdf')
-    u0 = Urdf(urdf_path)
-    frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
-    frozen.update(dict(zip([42, 43, 44, 46, 47, 49, 50], [-1.75, 1.25, -1.5, -0.5, -1, 0, -1])))    # right arm tucked, pr2.py:64
-    rob = compile_robot(urdf_path, arm, grip, gripper_target=[0.25] * 4, motor_gain=0.05, motor_force=1.0,                # pr2.py:17, robot.py:36-37
-                        max_hull_verts=robot_hull_max_verts, frozen=frozen, use_file_inertia=True)                       # pr2.py:52
+    RB = SCRATCH_ROBOTS[robot]
+    arm, grip = RB['arm'], RB['grip']
+    urdf_path = os.path.join(assets, *RB['urdf'])
+    frozen = None
+    if 'frozen_rest' in RB:
+        u0 = Urdf(urdf_path)
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen.update(RB['frozen_rest'])
+    rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.05, motor_force=1.0,             # robot.py:36-37
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False))
     nrobot = len(rob['dof_links'])
-    gripper_collision = set(range(71, 86))              # pr2.py:16 -> no collision with the tool (tool.py:42-44)
-    add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)
-    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+    gripper_collision = RB['gripper_collision']         # no collision with the tool (tool.py:42-44)
+    if RB['selfcol'] == 'sawyer':                       # ranges as in compile_bed_bathing_sawyer
+        add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
+        add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
+        add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+        sc.ranges['robot_arm'] = (sc.ranges['robot_lower'][0], sc.ranges['robot_upper'][1])
+    else:
+        add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)
+        add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
     sc.begin('robot_base')                              # the base and every static branch
     for verts, radius, fr, pb in rob['base_colliders']:
         sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
@@ -1018,19 +1052,24 @@ def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ve
     grp('robot_links', 'human_male', alt='human_female', keep=2)
     grp('tool', 'wheelchair', keep=2)
     grp('robot_links', 'wheelchair', keep=2)
-    grp('robot_arm', 'tool')                                          # no URDF_USE_SELF_COLLISION for the PR2 (pr2.py:52): no robot x robot pairs
+    grp('robot_arm', 'tool')
     grp('robot_base', 'tool')
+    if RB['selfcol'] == 'all':                                        # URDF_USE_SELF_COLLISION: every robot link pair except same link / parent-child
+        grp('robot_links', 'robot_links', same=True, no_adjacent=True)
+    elif RB['selfcol'] == 'sawyer':
+        G_.rg['robot_top'] = (G_.rg['robot_upper'][0], G_.rg['robot_gripper'][1])
+        grp('robot_base', 'robot_top')
     grp('robot_links', 'plane')
     grp('tool', 'plane')
     for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
         G_.rg['harm_' + gender] = (G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][1])
-        grp('robot_base', 'harm_' + gender, keep=2, flags=gf | GF_HUMAN_DYNAMIC)       # the static PR2 parts only matter to the moving arm
+        grp('robot_base', 'harm_' + gender, keep=2, flags=gf | GF_HUMAN_DYNAMIC)       # the static robot parts only matter to the moving arm
         grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)     # human_creation.py:288-290
         grp('harm_' + gender, 'wheelchair', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
     groups = G_.rows
-    ee_pb = tool_pb = 76                                # pr2.py:12,15
+    ee_pb, tool_pb = RB['ee_pb'], RB['tool_pb']
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
-    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, [0, 0, 0], [0, 0, 0])       # pr2.py:26,32
+    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, RB['tool_pos'], RB['tool_rpy'])
     task_f = dict(W_DISTANCE=1.0, W_ACTION=0.01, W_WIPE=1.0, SUCCESS_FRAC=25.0,            # config.ini:3-7 (scratch_reward_weight; the 5 of scratch_itch.py:30 is in the task layer)
                   C_V=0.25, C_F=0.01, C_HF=0.05,                                           # config.ini:40-42
                   TARGET_RADIUS=0.025,                                                     # scratch_itch.py:54
@@ -1051,7 +1090,8 @@ def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ve
         pass        # the pool comes from assistive_gym_amd/host/reset_scratch.py
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=23 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_SCRATCH_ITCH), reset_fill, reset_words,
-                task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
+                task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot, mount=RB['mount'],
+                                                                 toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
 
 
 def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
@@ -1227,7 +1267,9 @@ def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
                 task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip))
 
 
-COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda, bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
+COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda,
+                 scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
+                 scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
                  arm_manipulation_sawyer=compile_arm_manipulation_sawyer)
 

@@ -24,16 +24,20 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     if blob.task_kind == L.TASK_BED_BATHING:
         from .host.reset_bed import make_states as make_bed_states, RagdollSettler
         # the rag-doll settle of BedBathingEnv.reset runs on the device (bed_settle kernel variant), the rest on the host
-        return make_bed_states(blob, pool_size, seed=seed, impairment=impairment, settler=RagdollSettler(pool_size, device))[0]
+        from .host.reset_bed import DeviceCollisionChecker
+        return make_bed_states(blob, pool_size, seed=seed, impairment=impairment, settler=RagdollSettler(pool_size, device),
+                               checker=DeviceCollisionChecker(blob, pool_size, device))[0]
     if blob.task_kind == L.TASK_ARM_MANIPULATION:
         # ArmManipulationEnv.reset (host/reset_arm.py) around its two settles on the device: the rag doll, then the fall of the right arm
         from .host.reset_arm import make_states as make_arm_states, ArmFallSettler
-        from .host.reset_bed import RagdollSettler
+        from .host.reset_bed import RagdollSettler, DeviceCollisionChecker
         return make_arm_states(blob, pool_size, seed=seed, impairment='no_tremor' if impairment == 'random' else impairment,
-                               settler=RagdollSettler(pool_size, device), arm_settler=ArmFallSettler(blob, pool_size, device))[0]
+                               settler=RagdollSettler(pool_size, device), arm_settler=ArmFallSettler(blob, pool_size, device),
+                               checker=DeviceCollisionChecker(blob, pool_size, device))[0]
     if blob.task_kind == L.TASK_SCRATCH_ITCH:
         from .host.reset_scratch import make_states as make_scratch_states
-        return make_scratch_states(blob, pool_size, seed=seed, impairment=impairment)[0]
+        from .host.reset_bed import DeviceCollisionChecker
+        return make_scratch_states(blob, pool_size, seed=seed, impairment=impairment, checker=DeviceCollisionChecker(blob, pool_size, device))[0]
     if blob.task_kind == L.TASK_DRESSING:
         # DressingEnv.reset restated on the host (host/reset_dressing.py) around the 50-step cloth settle on the device;
         # returns (states, garments): the garment of a pool entry travels with its state record
@@ -181,6 +185,19 @@ class ScratchItchPR2VecEnv(AssistiveVecEnv):
 
 class ScratchItchPR2HumanVecEnv(ScratchItchPR2VecEnv):
     coop = True
+
+
+class ScratchItchJacoVecEnv(ScratchItchPR2VecEnv):
+    """ScratchItchJaco-v1 (the reference's default environment): the same kernels with the wheelchair-mounted Jaco's model blob"""
+    model = 'scratch_itch_jaco'
+
+
+class ScratchItchPandaVecEnv(ScratchItchPR2VecEnv):
+    model = 'scratch_itch_panda'
+
+
+class ScratchItchSawyerVecEnv(ScratchItchPR2VecEnv):
+    model = 'scratch_itch_sawyer'
 
 
 class ArmManipulationSawyerVecEnv(AssistiveVecEnv):

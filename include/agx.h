@@ -113,6 +113,15 @@ int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, 
  * (env_offset + env_index + 977 * episode_count) mod pool_n with env_offset = the global index of this handle's first env
  * (agx_set_env_offset, default 0), so results do not depend on how the envs are spread over GPUs */
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream);
+/* Collision rejection for resets sampled on the host (env.py:276-310 init_robot_pose, robot.py:103-108): runs the stepper's collision
+ * pass on the states as they are (they are not advanced) and writes one byte of AGX_COLLIDE_* flags per environment to the HOST buffer
+ * flags_host[n_envs].  Synchronises the stream. */
+#ifndef AGX_COLLIDE_FLAGS
+#define AGX_COLLIDE_FLAGS
+enum { AGX_COLLIDE_ENV = 1,    /* a robot link or the tool touches (distance <= 0) the human or the furniture               */
+       AGX_COLLIDE_SELF = 2 }; /* two robot links, or a robot link and the tool, interpenetrate by more than 1 cm           */
+#endif
+int agx_check_collisions(agx_handle h, uint8_t* flags_host, void* stream);
 int agx_set_env_offset(agx_handle h, long long env_offset);
 
 /* ---- whole-batch observation collation across GPUs: environments are sharded by contiguous index ranges, one

@@ -146,6 +146,11 @@ enum {
 #define AGX_BODY_ROBOT_BASE 100
 #define AGX_BODY_FREE0 200
 #define AGX_BODY_HUMAN0 300
+/* flags of agx_check_collisions (agx.h) */
+#ifndef AGX_COLLIDE_FLAGS
+#define AGX_COLLIDE_FLAGS
+enum { AGX_COLLIDE_ENV = 1, AGX_COLLIDE_SELF = 2 };
+#endif
 enum { AGX_TAG_ROBOT = 1, AGX_TAG_TOOL = 2, AGX_TAG_HUMAN = 3, AGX_TAG_FOOD = 4, AGX_TAG_BOWL = 5,
        AGX_TAG_TABLE = 6, AGX_TAG_PLANE = 7, AGX_TAG_WHEELCHAIR = 8, AGX_TAG_BED = 9 };
 

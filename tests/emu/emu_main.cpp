@@ -79,6 +79,15 @@ extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed,
   return rc;
 }
 #endif
+// agx_check_collisions: the build pass on the state as it is, then the flags (returns them, -1 on divergent control flow)
+extern "C" int agx_emu_check_collisions(const uint32_t* blob, float* state) {
+  static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
+  static float scratch[agx::SCR_WORDS];
+  int flags = 0;
+  int rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, nullptr, scratch, nullptr, lds, lane); });
+  if (!rc) rc = run_wave(lds, 64, [&](int lane) { int f = agx::collision_flags(blob, scratch, lane); if (lane == 0) flags = f; });
+  return rc ? -1 : flags;
+}
 extern "C" int agx_emu_lds_bytes() { return agx::LDS_BYTES; }
 // debug record layout of this variant (same order as agx_debug_layout of the product library)
 extern "C" void agx_emu_debug_layout(int* out8) {

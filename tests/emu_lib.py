@@ -71,5 +71,13 @@ class Emu:
         assert rc == 0, 'wave emulator reported divergent control flow'
         return st, info
 
+    def check_collisions(self, state):
+        """agx_check_collisions for one env: AGX_COLLIDE_* flags (the state is not advanced)"""
+        st = np.ascontiguousarray(state, dtype=np.float32).copy()
+        f = self.L.agx_emu_check_collisions(_p(self.words), _p(st))
+        assert f >= 0, 'wave emulator reported divergent control flow'
+        assert np.array_equal(st, state), 'the collision pass must not change the state'
+        return f
+
     def observe(self, state):
         return self._run(state, None, 2, 0)[0]

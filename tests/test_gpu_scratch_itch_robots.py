@@ -1,0 +1,100 @@
+"""-m gpu: ScratchItchJaco-v1 (the reference's default environment), ScratchItchPanda-v1 and ScratchItchSawyer-v1 on the HIP stepper
+(scratch_itch kernel variant, through the C ABI) against the CPU oracle; agx_check_collisions against the oracle's contact list and the
+host reset's collision rejection driven by it.  PARITY UNPINNED vs PyBullet."""
+import numpy as np
+import pytest
+
+from test_scratch_itch_robots import _states, flags_from_oracle, scratching_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', params=['jaco', 'panda', 'sawyer'])
+def rb(request):
+    from assistive_gym_amd import libagx
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    if libagx.load().agx_device_count() <= 0:
+        pytest.skip('no GPU visible')
+    b = ModelBlob.load('scratch_itch_' + request.param)
+    return request.param, b, Oracle(b)
+
+
+def test_check_collisions_and_rejection(rb):
+    from assistive_gym_amd.host.reset_bed import DeviceCollisionChecker
+    name, b, o = rb
+    n = 48
+    chk = DeviceCollisionChecker(b, 32)                      # smaller than the batch: chunked
+    assert chk.ctx.variant() == 'scratch_itch'
+    raw, _ = _states(b, n, 3001)
+    got = chk(raw)
+    want = np.array([flags_from_oracle(b, o, s) for s in raw])
+    assert np.array_equal(got, want), (got, want)
+    st, infos = _states(b, n, 3001, checker=chk)
+    after = np.array([flags_from_oracle(b, o, s) for s in st])
+    assert np.array_equal(after, [i['collision_flags'] for i in infos])
+    assert (after != 0).sum() <= max(1, (want != 0).sum() // 2), (want, after)
+    assert np.array_equal(st[want == 0], raw[want == 0])
+
+
+def test_step_matches_oracle(rb):
+    from assistive_gym_amd.host.reset_bed import DeviceCollisionChecker
+    from assistive_gym_amd.libagx import Stepper
+    name, b, o = rb
+    chk = DeviceCollisionChecker(b, 16)
+    a, _ = _states(b, 12, 6001, checker=chk)
+    w = [scratching_state(b, o, seed=6201 + k, depth=0.002 + 0.001 * k, checker=chk) for k in range(4)]
+    states = np.concatenate([a, np.array(w)])
+    n = len(states)
+    st = Stepper(b, n)
+    st.set_state(states)
+    worst = np.zeros(n)
+    touched = 0
+    f = b.obs_dim_robot - 1
+    for k in range(4):
+        act = np.random.RandomState(100 + k).uniform(-1, 1, (n, 7)).astype(np.float32)
+        act[12:] *= 0.1
+        ref = st.get_state()                                   # single-step comparison from the device's own state
+        obs, rew, done, info = st.step_host(act)
+        for i in range(n):
+            o_obs, o_rew, o_done, o_info = o.step(ref[i], act[i])
+            assert info[i, 6] == o_info[6] and abs(info[i, 7] - o_info[7]) <= 4, (i, info[i], o_info)
+            dev = np.abs(obs[i] - o_obs)
+            assert dev[f] <= 1e-3 * max(1.0, abs(o_obs[f]))
+            dev[f] = 0
+            worst[i] = max(worst[i], float(dev.max()), abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
+            assert info[i, 4] == o_info[4] and info[i, 1] == o_info[1] and bool(done[i]) == o_done
+            for c in (0, 2, 3):
+                assert abs(info[i, c] - o_info[c]) <= 1e-3 * max(1.0, abs(o_info[c])), (i, c, info[i], o_info)
+        touched += int((info[12:, 3] > 0).sum())
+    st.close()
+    assert worst[:12].max() < 1e-4 and worst[12:].max() < 1e-3, worst
+    assert touched >= 3
+
+
+def test_default_environment_of_the_reference_runs_end_to_end():
+    """`python -m assistive_gym --env ScratchItchJaco-v1` (env_viewer.py:36): the scalar env and a batched rollout"""
+    import torch
+    from assistive_gym_amd import libagx
+    from assistive_gym_amd.envs import make
+    from assistive_gym_amd.vec_env import ScratchItchJacoVecEnv
+    if libagx.load().agx_device_count() <= 0:
+        pytest.skip('no GPU visible')
+    e = make('assistive_gym:ScratchItchJaco-v1')
+    o = e.reset()
+    assert o.shape == (30,) and e.action_space.shape == (7,)
+    total = 0.0
+    for k in range(20):
+        o, r, d, info = e.step(e.action_space.sample())
+        total += r
+    assert np.isfinite(total) and not d and set(info) >= {'total_force_on_human', 'task_success'}
+    e.disconnect()
+    n = 64
+    env = ScratchItchJacoVecEnv(n, pool_size=16, seed=3)
+    obs = env.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for k in range(200):
+        obs, rew, done, info = env.step(torch.rand((n, 7), device='cuda', generator=g) * 2 - 1)
+        assert bool(done.all()) == (k == 199)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and env.stepper.overflow_count() == 0
+    env.close()
