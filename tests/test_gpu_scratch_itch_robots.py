@@ -66,7 +66,7 @@ def test_step_matches_oracle(rb):
             assert info[i, 4] == o_info[4] and info[i, 1] == o_info[1] and bool(done[i]) == o_done
             for c in (0, 2, 3):
                 assert abs(info[i, c] - o_info[c]) <= 1e-3 * max(1.0, abs(o_info[c])), (i, c, info[i], o_info)
-        touched += int((info[12:, 3] > 0).sum())
+        touched += int((info[12:, 0] > 0).sum())            # total force on the human: the scratcher (or the arm behind it) presses on the limb
     st.close()
     assert worst[:12].max() < 1e-4 and worst[12:].max() < 1e-3, worst
     assert touched >= 3
