@@ -11,6 +11,15 @@
 #define AGX_TASK 1
 #define AGX_VNAME bed_bathing
 #define AGX_K(name) name##_bb
+#elif defined(AGX_VARIANT_BED_BATHING_L)
+// bed bathing with a robot of up to 12 dynamic joints (PR2: 7 arm + 4 finger joints): the limits of the scratch_itch variant
+#define AGX_MAX_DOF 24
+#define AGX_MAX_FREE 2
+#define AGX_MAX_BLOCK 12
+#define AGX_ARENA_WORDS 4096
+#define AGX_TASK 1
+#define AGX_VNAME bed_bathing_l
+#define AGX_K(name) name##_bbl
 #elif defined(AGX_VARIANT_BED_SETTLE)
 // the rag-doll settle of BedBathingEnv.reset (bed_bathing.py:119-137): the whole human as ONE articulated body of 47 DoFs (6 for the
 // floating base + 41 joints) falling onto the bed; reset time only (one wave per SIMD at most: 97 KB of LDS per environment)

@@ -39,3 +39,4 @@ extern "C" const agx_variant* agx_variant_scratch_itch(void);
 extern "C" const agx_variant* agx_variant_bed_settle(void);
 extern "C" const agx_variant* agx_variant_dressing(void);
 extern "C" const agx_variant* agx_variant_arm_manipulation(void);
+extern "C" const agx_variant* agx_variant_bed_bathing_l(void);

@@ -343,6 +343,21 @@ ENV_IDS = {'ScratchItchJaco-v1': ScratchItchJacoEnv, 'ScratchItchJacoHuman-v1': 
            'FeedingPanda-v1': FeedingPandaEnv, 'FeedingPandaHuman-v1': FeedingPandaHumanEnv, 'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
            'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
 
+# ---- further robots of a task: the same env code with another model blob (model/compiler.py ROBOT_BASE / ROBOT_TASK) -----------------------
+def _robot_flavours(base_cls, task_name, robots, ref):
+    for robot, model in robots:
+        cls = type('%s%sEnv' % (task_name, robot), (base_cls,), {'model': model, '__doc__': '%s%s-v1 (%s): %s with the %s' % (task_name, robot, ref, base_cls.__name__, robot)})
+        coop_cls = type('%s%sHumanEnv' % (task_name, robot), (cls,), {'coop': True, '__doc__': '%s%sHuman-v1 (%s): the human is controllable too' % (task_name, robot, ref)})
+        globals()[cls.__name__], globals()[coop_cls.__name__] = cls, coop_cls
+        ENV_IDS['%s%s-v1' % (task_name, robot)] = cls
+        ENV_IDS['%s%sHuman-v1' % (task_name, robot)] = coop_cls
+
+
+_robot_flavours(BedBathingSawyerEnv, 'BedBathing', [('Jaco', 'bed_bathing_jaco'), ('Panda', 'bed_bathing_panda'), ('PR2', 'bed_bathing_pr2'), ('Baxter', 'bed_bathing_baxter')],
+                'bed_bathing_envs.py:15-37,45-79')
+_robot_flavours(ScratchItchPR2Env, 'ScratchItch', [('Baxter', 'scratch_itch_baxter')], 'scratch_itch_envs.py:21-23,46-50')
+
+
 
 def make(env_id):
     """`gym.make('assistive_gym:FeedingJaco-v1')` equivalent, with the TimeLimit of 200 steps folded

@@ -211,8 +211,9 @@ class BedBathingSawyerReset:
         self.human_bodies = blob.meta['human_bodies']
         self.human_dyn = blob.meta['human_dynamic_joints']
         self.settle = settle
-        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array([-0.2, 0, 0.975])          # robot.py:142 + sawyer.py:37
-        self.ee_R = X.quat_to_mat(X.quat_from_rpy([0, np.pi / 2.0, 0]))                     # sawyer.py:43 toc_ee_orient_rpy
+        m = blob.meta
+        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m.get('toc_base', [-0.2, 0, 0.975]))      # robot.py:142 + toc_base_pos_offset (sawyer.py:37)
+        self.ee_R = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy', [0, np.pi / 2.0, 0])))                # toc_ee_orient_rpy (sawyer.py:43)
         r = blob.meta['ranges']
         self._bed = [blob.collider(c)['verts'] for c in range(*r['bed'])]
         self._bed_box = np.array([[v.min(0), v.max(0)] for v in self._bed])

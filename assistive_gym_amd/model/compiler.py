@@ -747,26 +747,48 @@ def tool_offset_in_ee_frame(rob, ee_pb, tool_pb, pos_offset, rpy_offset):
 
 
 def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
-    """BedBathingSawyer-v1 (bed_bathing_envs.py:23-25): Sawyer (agents/sawyer.py), the wiper (assets/bed_bathing/wiper.urdf,
-    tool.py:22-23), the human lying on the bed (bed_bathing.py:112-137; its right arm joints 0..9 are the controllable joints,
-    bed_bathing_envs.py:12 -- dynamic when the impairment is tremor, human.py:108), the bed (furniture.py:17-18, friction 5,
-    bed_bathing.py:116) and the ground."""
+    """BedBathingSawyer-v1 (bed_bathing_envs.py:23-25; BASELINE config 3)"""
+    return compile_bed_bathing('sawyer', assets, n_iter)
+
+
+def compile_bed_bathing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
+    """BedBathing<Robot>-v1 (bed_bathing_envs.py:15-37): the robot's (left) arm (agents/<robot>.py via ROBOT_BASE / ROBOT_TASK), the wiper
+    (assets/bed_bathing/wiper.urdf, tool.py:22-23), the human lying on the bed (bed_bathing.py:112-137; its right arm joints 0..9 are the
+    controllable joints, bed_bathing_envs.py:12 -- dynamic when the impairment is tremor, human.py:108), the bed (furniture.py:17-18,
+    friction 5, bed_bathing.py:116) and the ground.  A wheelchair-mounted arm (Jaco, Panda) stands on a nightstand that is loaded under
+    the base the TOC search found (bed_bathing.py:148-155, wheelchair_enabled=False): its hull is carried by the robot's base body
+    (it turns with the base's yaw of up to 30 degrees [deviation]: in the reference it keeps the world's orientation)."""
     sc = Scene()
-    # ------------------------------------------------------------------ robot (agents/sawyer.py:8-17)
-    arm = [3, 8, 9, 10, 11, 13, 16]
-    grip = [20, 22]
-    rob = compile_robot(os.path.join(assets, 'sawyer', 'sawyer.urdf'), arm, grip, gripper_target=[0.0125, -0.0125],    # sawyer.py:21
-                        motor_gain=0.05, motor_force=1.0, max_hull_verts=0)                                            # robot.py:36-37
+    RB = robot_table('bed_bathing', robot)
+    arm, grip = RB['arm'], RB['grip']
+    urdf_path = os.path.join(assets, *RB['urdf'])
+    frozen = None
+    if 'frozen_rest' in RB:
+        u0 = Urdf(urdf_path)
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen.update(RB['frozen_rest'])
+    rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.05, motor_force=1.0,          # robot.py:36-37
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False))
     nrobot = len(rob['dof_links'])
-    gripper_collision = {18, 20, 21, 22, 23}           # sawyer.py:17 -> no collision with the tool (tool.py:42-44)
-    # Sawyer.init (sawyer.py:52-61): URDF_USE_SELF_COLLISION, then every pair among links 3..23 and every pair of links
-    # 0..2 with links 0..8 is switched off: what remains is {base, 0, 1, 2} x {9..23}
-    add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
-    add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
-    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
-    sc.begin('robot_base')                              # base link and the links fixed to it (torso, pedestal, arm mount: links -1..2)
+    gripper_collision = RB['gripper_collision']         # no collision with the tool (tool.py:42-44)
+    if RB['selfcol'] == 'sawyer':
+        # Sawyer.init (sawyer.py:52-61): URDF_USE_SELF_COLLISION, then every pair among links 3..23 and every pair of links
+        # 0..2 with links 0..8 is switched off: what remains is {base, 0, 1, 2} x {9..23}
+        add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
+        add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
+        add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+    else:
+        add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb not in gripper_collision)
+        sc.begin('robot_upper'); sc.end('robot_upper')
+        add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+    sc.begin('robot_base')                              # base link and the links fixed to it (Sawyer: torso, pedestal, arm mount: links -1..2); static branches
     for verts, radius, fr, pb in rob['base_colliders']:
         sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    if RB['wheelchair_mounted']:                        # furniture.py:35-36 nightstand.urdf (one mesh = one hull), placed at [-0.9, 0.7, 0] + base_position
+        nv = load_obj_groups(os.path.join(assets, 'nightstand', 'nightstand.obj'), 0.275)
+        nv = X.apply(np.zeros(3), X.quat_from_rpy([np.pi / 2, 0, 0]), convex_hull_vertices(np.concatenate(nv)))
+        off = np.array([-0.9, 0.7, 0]) - (np.array([-0.85, -0.4, 0]) + np.array(RB['toc_base']))      # relative to the robot's base (robot.py:142)
+        sc.add(BODY_ROBOT_BASE, reduce_hull(nv + off, 64), HULL_MARGIN, DEFAULT_FRICTION, TAG['ROBOT'], link=-1)
     sc.end('robot_base')
     # ------------------------------------------------------------------ tool: wiper.urdf, three links welded by fixed joints = one rigid body
     free, frames, com = add_welded_tool(sc, os.path.join(assets, 'bed_bathing', 'wiper.urdf'))       # tool.py:22-23; gravity 0: bed_bathing.py:165
@@ -799,7 +821,10 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
     grp('robot_links', 'bed', keep=2)
     grp('robot_arm', 'tool')
     grp('robot_base', 'tool')
-    grp('robot_base', 'robot_top')                                    # the self-collision pairs Sawyer.init leaves enabled
+    if RB['selfcol'] == 'sawyer':
+        grp('robot_base', 'robot_top')                                # the self-collision pairs Sawyer.init leaves enabled
+    elif RB['selfcol'] == 'all':
+        grp('robot_links', 'robot_links', same=True, no_adjacent=True)
     grp('robot_links', 'plane')
     grp('tool', 'plane')
     # the human's own right arm (dynamic when the impairment is tremor): arm links 3..9 against the base and links 10.. of the
@@ -810,9 +835,9 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
         grp('harm_' + gender, 'bed', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
     groups = G_.rows
     # ------------------------------------------------------------------ task
-    ee_pb, tool_pb = 19, 18                             # sawyer.py:11,15
+    ee_pb, tool_pb = RB['ee_pb'], RB['tool_pb']
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
-    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, [0, 0.1175, 0], [np.pi / 2.0, 0, np.pi / 2.0])    # sawyer.py:27,33
+    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, RB['tool_pos'], RB['tool_rpy'])
     targets, nts = {}, []
     for gender in ('male', 'female'):
         hm = HumanModel(gender)
@@ -845,7 +870,8 @@ def compile_bed_bathing_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
         pass        # no device-side reset generator for this scene: the pool comes from assistive_gym_amd/host/reset_bed.py
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_BED_BATHING), reset_fill, reset_words,
-                targets=targets, task_words=BB['WORDS'], mlp=mlp, meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist()))
+                targets=targets, task_words=BB['WORDS'], mlp=mlp, meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot,
+                                                                                   toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
 
 
 RAGDOLL_PARTS = (('base', -1, -1), ('rpec', 0, 2), ('rarm', 3, 9), ('lpec', 10, 12), ('larm', 13, 19), ('head', 20, 23), ('waist', 24, 27),
@@ -969,25 +995,51 @@ def compile_bed_settle(assets=DEFAULT_ASSETS, n_iter=50):
                 task_words=BB['WORDS'], meta_extra=dict(settle_joints=joints, virtual_dofs=VR))
 
 
-# the robots of the scratch-itch task (robot_arm = 'left', scratch_itch_envs.py:15; on the single-arm robots left IS right).
-# mount 'toc': the base pose comes from Robot.position_robot_toc around [-0.85, -0.4, 0] + toc_base (robot.py:142);
-# mount 'wheelchair': the base is fixed at the wheelchair position [0, 0, 0.06] + toc_base, rpy [0, 0, -pi/2] (scratch_itch.py:97-99)
-# selfcol: 'none' (no URDF_USE_SELF_COLLISION, pr2.py:52), 'all' (every non-adjacent link pair, jaco.py:53 / panda.py:53),
-#          'sawyer' (the pairs Sawyer.init leaves enabled, sawyer.py:53-61)
-SCRATCH_ROBOTS = dict(
-    pr2=dict(urdf=('PR2', 'pr2_no_torso_lift_tall.urdf'), arm=[64, 65, 66, 68, 69, 71, 72], grip=[79, 80, 81, 82], gripper_target=[0.25] * 4,   # pr2.py:9,14,17
-             gripper_collision=set(range(71, 86)), ee_pb=76, tool_pb=76, tool_pos=[0, 0, 0], tool_rpy=[0, 0, 0],                              # pr2.py:16,12,15,26,32
-             toc_base=[0.1, 0, 0], ee_rpy=[0, 0, 0], mount='toc', selfcol='none', file_inertia=True,                                           # pr2.py:35,41,52
-             frozen_rest=dict(zip([42, 43, 44, 46, 47, 49, 50], [-1.75, 1.25, -1.5, -0.5, -1, 0, -1]))),                                       # right arm tucked, pr2.py:64
-    jaco=dict(urdf=('jaco', 'j2s7s300_gym.urdf'), arm=[1, 2, 3, 4, 5, 6, 7], grip=[9, 11, 13], gripper_target=[1.0] * 3,                        # jaco.py:8,13,19
-              gripper_collision=set(range(7, 15)), ee_pb=8, tool_pb=8, tool_pos=[0, 0, 0.02], tool_rpy=[0, -np.pi / 2.0, 0],                    # jaco.py:17,11,15,25,30
-              toc_base=[-0.35, -0.3, 0.3], ee_rpy=[0, np.pi / 2.0, 0], mount='wheelchair', selfcol='all'),                                     # jaco.py:35-36,42,53
-    panda=dict(urdf=('panda', 'panda.urdf'), arm=[0, 1, 2, 3, 4, 5, 6], grip=[9, 10], gripper_target=[0.02] * 2,                               # panda.py:8,13,19
-               gripper_collision={7, 8, 9, 10, 11}, ee_pb=11, tool_pb=11, tool_pos=[0, 0, 0], tool_rpy=[0, -np.pi / 2.0, 0],                   # panda.py:17,11,15,25,30
-               toc_base=[-0.4, -0.35, 0.2], ee_rpy=[0, np.pi / 2.0, 0], mount='wheelchair', selfcol='all'),                                    # panda.py:35-36,42,53
-    sawyer=dict(urdf=('sawyer', 'sawyer.urdf'), arm=[3, 8, 9, 10, 11, 13, 16], grip=[20, 22], gripper_target=[0.015, -0.015],                  # sawyer.py:8,13,19
-                gripper_collision={18, 20, 21, 22, 23}, ee_pb=19, tool_pb=18, tool_pos=[0, 0.125, 0], tool_rpy=[0, 0, np.pi / 2.0],            # sawyer.py:17,11,15,25,30
-                toc_base=[-0.1, 0, 0.975], ee_rpy=[0, np.pi / 2.0, 0], mount='toc', selfcol='sawyer', hull_verts=0))                           # sawyer.py:35,41
+# ---- robots as data: what the reference's robot classes hold (agents/<robot>.py), for the LEFT arm where a robot has two (the tasks below
+# use robot_arm = 'left', scratch_itch_envs.py:15 / bed_bathing_envs.py:13; on the single-arm robots left IS right) -----------------------
+# selfcol: 'none' (no URDF_USE_SELF_COLLISION: pr2.py:52, baxter.py:52), 'all' (every non-adjacent link pair, jaco.py:53 / panda.py:53; the
+#          Panda's base link 0 against links 2.. is left out [deviation]), 'sawyer' (the pairs Sawyer.init leaves enabled, sawyer.py:53-61)
+# frozen_rest: joints of the OTHER arm at their tucked pose (reset_joints); every joint that is neither an arm nor a gripper joint of the
+#          controlled arm is compiled as static geometry (see compile_scratch_itch)
+ROBOT_BASE = dict(
+    pr2=dict(urdf=('PR2', 'pr2_no_torso_lift_tall.urdf'), arm=[64, 65, 66, 68, 69, 71, 72], grip=[79, 80, 81, 82],                     # pr2.py:9,14
+             gripper_collision=set(range(71, 86)), ee_pb=76, tool_pb=76, selfcol='none', file_inertia=True, wheelchair_mounted=False,  # pr2.py:16,12,15,52
+             frozen_rest=dict(zip([42, 43, 44, 46, 47, 49, 50], [-1.75, 1.25, -1.5, -0.5, -1, 0, -1]))),                               # right arm tucked, pr2.py:64
+    baxter=dict(urdf=('baxter', 'baxter_custom.urdf'), arm=[34, 35, 36, 37, 38, 40, 41], grip=[49, 51],                                # baxter.py:9,14
+                gripper_collision={47, 49, 50, 51, 52}, ee_pb=48, tool_pb=47, selfcol='none', wheelchair_mounted=False,                # baxter.py:18,12,16,52
+                frozen_rest=dict(zip([12, 13, 14, 15, 16, 18, 19], [-0.75, 1, -0.5, 0.5, -1, -0.5, 0]))),                              # baxter.py:66
+    jaco=dict(urdf=('jaco', 'j2s7s300_gym.urdf'), arm=[1, 2, 3, 4, 5, 6, 7], grip=[9, 11, 13],                                         # jaco.py:8,13
+              gripper_collision=set(range(7, 15)), ee_pb=8, tool_pb=8, selfcol='all', wheelchair_mounted=True),                        # jaco.py:17,11,15,53
+    panda=dict(urdf=('panda', 'panda.urdf'), arm=[0, 1, 2, 3, 4, 5, 6], grip=[9, 10],                                                  # panda.py:8,13
+               gripper_collision={7, 8, 9, 10, 11}, ee_pb=11, tool_pb=11, selfcol='all', wheelchair_mounted=True),                     # panda.py:17,11,15,53
+    sawyer=dict(urdf=('sawyer', 'sawyer.urdf'), arm=[3, 8, 9, 10, 11, 13, 16], grip=[20, 22],                                          # sawyer.py:8,13
+                gripper_collision={18, 20, 21, 22, 23}, ee_pb=19, tool_pb=18, selfcol='sawyer', hull_verts=0, wheelchair_mounted=False))   # sawyer.py:17,11,15
+H_PI = np.pi / 2.0
+# per task: gripper_pos, tool_pos_offset, tool_orient_offset, toc_base_pos_offset, toc_ee_orient_rpy (agents/<robot>.py:19-47)
+ROBOT_TASK = dict(
+    scratch_itch=dict(
+        pr2=dict(gripper_target=[0.25] * 4, tool_pos=[0, 0, 0], tool_rpy=[0, 0, 0], toc_base=[0.1, 0, 0], ee_rpy=[0, 0, 0]),
+        baxter=dict(gripper_target=[0.015, -0.015], tool_pos=[0, 0.125, 0], tool_rpy=[0, 0, H_PI], toc_base=[0, 0, 0.925], ee_rpy=[0, H_PI, 0]),
+        jaco=dict(gripper_target=[1.0] * 3, tool_pos=[0, 0, 0.02], tool_rpy=[0, -H_PI, 0], toc_base=[-0.35, -0.3, 0.3], ee_rpy=[0, H_PI, 0]),
+        panda=dict(gripper_target=[0.02] * 2, tool_pos=[0, 0, 0], tool_rpy=[0, -H_PI, 0], toc_base=[-0.4, -0.35, 0.2], ee_rpy=[0, H_PI, 0]),
+        sawyer=dict(gripper_target=[0.015, -0.015], tool_pos=[0, 0.125, 0], tool_rpy=[0, 0, H_PI], toc_base=[-0.1, 0, 0.975], ee_rpy=[0, H_PI, 0])),
+    bed_bathing=dict(
+        pr2=dict(gripper_target=[0.2] * 4, tool_pos=[0, 0, 0], tool_rpy=[0, 0, 0], toc_base=[-0.1, 0, 0], ee_rpy=[0, 0, 0]),
+        baxter=dict(gripper_target=[0.0125, -0.0125], tool_pos=[0, 0.1175, 0], tool_rpy=[H_PI, 0, H_PI], toc_base=[-0.2, 0, 0.925], ee_rpy=[0, H_PI, 0]),
+        jaco=dict(gripper_target=[1.1] * 3, tool_pos=[-0.01, 0, 0.03], tool_rpy=[0, -H_PI, 0], toc_base=[-0.05, 1.05, 0.6], ee_rpy=[0, H_PI, 0]),
+        panda=dict(gripper_target=[0.02] * 2, tool_pos=[0, 0, 0], tool_rpy=[0, -H_PI, 0], toc_base=[-0.05, 1.05, 0.67], ee_rpy=[0, H_PI, 0]),
+        sawyer=dict(gripper_target=[0.0125, -0.0125], tool_pos=[0, 0.1175, 0], tool_rpy=[H_PI, 0, H_PI], toc_base=[-0.2, 0, 0.975], ee_rpy=[0, H_PI, 0])))
+
+
+def robot_table(task, robot):
+    RB = dict(ROBOT_BASE[robot])
+    RB.update(ROBOT_TASK[task][robot])
+    return RB
+
+
+# scratch itch: a wheelchair-mounted robot stays at the wheelchair position [0, 0, 0.06] + toc_base, rpy [0, 0, -pi/2] (scratch_itch.py:97-99,
+# mount 'wheelchair'); the others get their base pose from Robot.position_robot_toc around [-0.85, -0.4, 0] + toc_base (robot.py:142, 'toc')
+SCRATCH_ROBOTS = {r: dict(robot_table('scratch_itch', r), mount='wheelchair' if ROBOT_BASE[r]['wheelchair_mounted'] else 'toc') for r in ROBOT_TASK['scratch_itch']}
 
 
 def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
@@ -1268,8 +1320,10 @@ def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
 
 
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda,
+                 bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
+                 bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
-                 scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
+                 scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
                  arm_manipulation_sawyer=compile_arm_manipulation_sawyer)
 

@@ -214,6 +214,17 @@ class ArmManipulationSawyerHumanVecEnv(ArmManipulationSawyerVecEnv):
     coop = True
 
 
+def _vec_flavour(base_cls, name, model_name):
+    cls = type(name, (base_cls,), {'model': model_name, '__doc__': '%s: %s with another robot\'s model blob' % (name, base_cls.__name__)})
+    globals()[name] = cls
+    return cls
+
+
+for _r in ('jaco', 'panda', 'pr2', 'baxter'):
+    _vec_flavour(BedBathingSawyerVecEnv, 'BedBathing%sVecEnv' % {'pr2': 'PR2'}.get(_r, _r.capitalize()), 'bed_bathing_' + _r)
+_vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchBaxterVecEnv', 'scratch_itch_baxter')
+
+
 class DressingBaxterVecEnv(AssistiveVecEnv):
     """BASELINE config 5: DressingBaxter-v1 (dressing_envs.py:19-21).  Every environment carries a garment of 3,966 nodes next to its
     state record; resets come from a pool of (state, settled garment) pairs built once (host/reset_dressing.py + the device settle)."""

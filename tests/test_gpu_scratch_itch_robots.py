@@ -9,7 +9,7 @@ from test_scratch_itch_robots import _states, flags_from_oracle, scratching_stat
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['jaco', 'panda', 'sawyer'])
+@pytest.fixture(scope='module', params=['jaco', 'panda', 'sawyer', 'baxter'])
 def rb(request):
     from assistive_gym_amd import libagx
     from assistive_gym_amd.blob import ModelBlob

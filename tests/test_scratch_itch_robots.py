@@ -8,7 +8,7 @@ import pytest
 from assistive_gym_amd.model import xform as X
 from test_scratch_itch import target_world, tip_pose
 
-ROBOTS = ['jaco', 'panda', 'sawyer']
+ROBOTS = ['jaco', 'panda', 'sawyer', 'baxter']
 
 
 @pytest.fixture(scope='module', params=ROBOTS)
@@ -80,7 +80,7 @@ def test_model_tables(rb):
     grip_dofs = [d for d in range(b.nrobot) if b.robot_i(d, 'PB_INDEX') in T['grip']]
     assert np.allclose([b.robot_f(d, 'QT0') for d in grip_dofs], T['gripper_target'])                          # gripper_pos['scratch_itch']
     assert np.isclose(b.robot_f(arm_dofs[0], 'KP'), 0.05) and np.isclose(b.robot_f(arm_dofs[0], 'MAXF'), 1.0)  # robot.py:36-37
-    assert b.meta['mount'] == ('toc' if name == 'sawyer' else 'wheelchair')
+    assert b.meta['mount'] == ('toc' if name in ('sawyer', 'baxter') else 'wheelchair')
     c = b.coop()
     assert (c.act_dim, c.obs_dim) == (17, 64)
 
