@@ -80,8 +80,12 @@ def _reference_make_env(gym):
     return ns['make_env']
 
 
-@pytest.mark.parametrize('env_name', ['FeedingJaco-v1', 'FeedingPanda-v1', 'BedBathingSawyer-v1', 'ScratchItchPR2-v1', 'ScratchItchJaco-v1', 'ScratchItchPanda-v1', 'ScratchItchSawyer-v1',
-                                      'DressingBaxter-v1', 'ArmManipulationSawyer-v1'])
+def _built_ids(coop):
+    from assistive_gym_amd.envs import ENV_IDS
+    return sorted(k for k in ENV_IDS if k.endswith('Human-v1') == coop)
+
+
+@pytest.mark.parametrize('env_name', _built_ids(False))
 def test_reference_make_env_single_agent(shimmed, env_name):
     gym, _ = shimmed
     make_env = _reference_make_env(gym)
@@ -93,8 +97,7 @@ def test_reference_make_env_single_agent(shimmed, env_name):
     env.disconnect()
 
 
-@pytest.mark.parametrize('env_name', ['FeedingJacoHuman-v1', 'FeedingPandaHuman-v1', 'BedBathingSawyerHuman-v1', 'ScratchItchPR2Human-v1', 'ScratchItchJacoHuman-v1', 'DressingBaxterHuman-v1',
-                                      'ArmManipulationSawyerHuman-v1'])
+@pytest.mark.parametrize('env_name', _built_ids(True))
 def test_reference_make_env_coop(shimmed, env_name):
     gym, creators = shimmed
     make_env = _reference_make_env(gym)
