@@ -30,7 +30,7 @@ def test_pool_states_and_single_steps_match_the_oracle(rb):
     st = Stepper(b, n)
     assert st.variant() == ('bed_bathing_l' if name == 'pr2' else 'bed_bathing')
     st.set_state(states)
-    worst = 0.0
+    worst, touching = np.zeros(n), np.zeros(n, dtype=bool)
     for k in range(4):
         act = np.random.RandomState(100 + k).uniform(-1, 1, (n, 7)).astype(np.float32)
         ref = st.get_state()                                   # single-step comparison from the device's own state
@@ -41,12 +41,14 @@ def test_pool_states_and_single_steps_match_the_oracle(rb):
             dev = np.abs(obs[i] - o_obs)
             assert dev[-1] <= 1e-3 * max(1.0, abs(o_obs[-1]))
             dev[-1] = 0
-            worst = max(worst, float(dev.max()), abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
+            worst[i] = max(worst[i], float(dev.max()), abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
+            touching[i] |= o_info[6] > 0
             assert info[i, 4] == o_info[4] and info[i, 1] == o_info[1] and bool(done[i]) == o_done
             for c in (0, 2, 3):
                 assert abs(info[i, c] - o_info[c]) <= 1e-3 * max(1.0, abs(o_info[c])), (i, c, info[i], o_info)
     st.close()
-    assert worst < 2e-4, worst
+    # the bounds of tests/test_gpu_bed_bathing.py: 1e-4 in free space, 1e-3 for environments with contacts (forces agree to 1e-3 relative)
+    assert worst[~touching].max(initial=0) < 1e-4 and worst[touching].max(initial=0) < 1e-3, (worst, touching)
 
 
 def test_vec_env_rollout(rb):
