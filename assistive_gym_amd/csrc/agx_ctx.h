@@ -91,7 +91,10 @@ constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_
 constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_BLOCK * 6 + MAX_DOF * MAX_BLOCK;
 static_assert(A_DYN_END <= ARENA_WORDS, "dynamics workspace exceeds the arena");
 // arena, collision phase: world AABBs [ncoll][6]
-constexpr int MAX_COLL = 256;
+#ifndef AGX_MAX_COLL
+#define AGX_MAX_COLL 256
+#endif
+constexpr int MAX_COLL = AGX_MAX_COLL;
 static_assert(MAX_COLL * 6 <= ARENA_WORDS, "AABB table exceeds the arena");
 // misc words
 constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;

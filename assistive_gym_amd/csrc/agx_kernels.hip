@@ -59,6 +59,12 @@
 #define AGX_TASK 4
 #define AGX_VNAME arm_manipulation
 #define AGX_K(name) name##_am
+#elif defined(AGX_VARIANT_FEEDING_L)
+// the feeding scene with a free-standing robot (FeedingSawyer, FeedingBaxter): the pedestal / torso / other arm add up to 320 colliders
+#define AGX_MAX_COLL 320
+#define AGX_ARENA_WORDS 4040
+#define AGX_VNAME feeding_l
+#define AGX_K(name) name##_fl
 #elif defined(AGX_VARIANT_FEEDING)
 #define AGX_VNAME feeding
 #define AGX_K(name) name

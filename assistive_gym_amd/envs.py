@@ -199,6 +199,40 @@ class FeedingJacoHumanEnv(FeedingJacoEnv):
     coop = True
 
 
+class FeedingSawyerEnv(FeedingJacoEnv):
+    """FeedingSawyer-v1 (feeding_envs.py:25-27): a free-standing robot; its base pose comes from the base pose search on the host
+    (host/reset.py + host/reset_bed.py) with the device's collision pass rejecting colliding placements, then the 25 settle steps."""
+    model = 'feeding_sawyer'
+
+    def reset(self):
+        from .host.reset import make_states
+        from .host.reset_bed import DeviceCollisionChecker
+        st = self._ensure_stepper()
+        if not hasattr(self, '_checker'):
+            self._checker = DeviceCollisionChecker(self.blob, 1, self.device)
+        self.reset_seed = self._draw_seed()
+        rec, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), checker=self._checker)
+        st.set_state(rec)
+        st.settle(SETTLE_STEPS)
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+
+class FeedingSawyerHumanEnv(FeedingSawyerEnv):
+    """FeedingSawyerHuman-v1 (feeding_envs.py:51-54)"""
+    coop = True
+
+
+class FeedingBaxterEnv(FeedingSawyerEnv):
+    """FeedingBaxter-v1 (feeding_envs.py:21-23): Baxter's right arm"""
+    model = 'feeding_baxter'
+
+
+class FeedingBaxterHumanEnv(FeedingBaxterEnv):
+    """FeedingBaxterHuman-v1 (feeding_envs.py:46-49)"""
+    coop = True
+
+
 class FeedingPandaEnv(FeedingJacoEnv):
     """FeedingPanda-v1 (feeding_envs.py:35-37): the same task with the wheelchair-mounted Franka Panda (agents/panda.py)."""
     model = 'feeding_panda'
@@ -338,7 +372,8 @@ class ArmManipulationSawyerHumanEnv(ArmManipulationSawyerEnv):
     coop = True
 
 
-ENV_IDS = {'ScratchItchJaco-v1': ScratchItchJacoEnv, 'ScratchItchJacoHuman-v1': ScratchItchJacoHumanEnv, 'ScratchItchPanda-v1': ScratchItchPandaEnv,
+ENV_IDS = {'FeedingSawyer-v1': FeedingSawyerEnv, 'FeedingSawyerHuman-v1': FeedingSawyerHumanEnv, 'FeedingBaxter-v1': FeedingBaxterEnv, 'FeedingBaxterHuman-v1': FeedingBaxterHumanEnv,
+           'ScratchItchJaco-v1': ScratchItchJacoEnv, 'ScratchItchJacoHuman-v1': ScratchItchJacoHumanEnv, 'ScratchItchPanda-v1': ScratchItchPandaEnv,
            'ScratchItchPandaHuman-v1': ScratchItchPandaHumanEnv, 'ScratchItchSawyer-v1': ScratchItchSawyerEnv, 'ScratchItchSawyerHuman-v1': ScratchItchSawyerHumanEnv,
            'FeedingPanda-v1': FeedingPandaEnv, 'FeedingPandaHuman-v1': FeedingPandaHumanEnv, 'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
            'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}

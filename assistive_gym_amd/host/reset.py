@@ -1,4 +1,7 @@
-"""Host-side reset for FeedingJaco-v1: produces the pre-settle state record of one environment.
+"""Host-side reset for the feeding task (FeedingJaco-v1 and the other robots of model/compiler.py FEEDING_ROBOTS): produces the
+pre-settle state record of one environment.  Wheelchair-mounted robots (Jaco, Panda) get Robot.ik_random_restarts from their fixed base;
+free-standing ones (Sawyer, Baxter) the base pose search of Robot.position_robot_toc (host/reset_bed.py) with the goals
+[(target_ee_pos, target_ee_orient)] + [(mouth, None)] (feeding.py:141).
 
 Follows the order of FeedingEnv.reset (assistive_gym/envs/feeding.py:114-182) and what it calls:
 build_assistive_env (envs/env.py:114-134: plane friction U(0.025,0.5)), Human.init
@@ -35,7 +38,11 @@ class FeedingJacoReset:
         self.base_quat = np.array(blob.meta.get('robot_base_quat', X.quat_from_rpy([0, 0, -np.pi / 2]).tolist()))
         self.human_bodies = blob.meta.get('human_bodies')
         self.human_dyn = blob.meta.get('human_dynamic_joints', [20, 21, 22, 23])
-        self.toc_ee_orient = X.quat_from_rpy([np.pi / 2.0, 0, np.pi / 2.0])     # jaco.py:43
+        self.toc_ee_orient = X.quat_from_rpy(blob.meta.get('ee_rpy', [np.pi / 2.0, 0, np.pi / 2.0]))     # toc_ee_orient_rpy (jaco.py:43)
+        self.toc = None
+        if blob.meta.get('mount', 'wheelchair') == 'toc':
+            from .reset_bed import toc_search
+            self.toc = toc_search(blob)
         self._hm_cache = {}
 
     def _human(self, gender, limit_scale):
@@ -46,8 +53,9 @@ class FeedingJacoReset:
             self._hm_cache[key] = HumanModel(gender, limit_scale)
         return self._hm_cache[key]
 
-    def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', max_restarts=1000, info=None):
-        """Fill one state record (float32 view of length state_words) in place."""
+    def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', max_restarts=1000, info=None, attempt=0):
+        """Fill one state record (float32 view of length state_words) in place.  attempt > 0 (free-standing robots): a re-draw of the
+        robot's placement only (init_robot_pose's rejection loop, env.py:281-308)."""
         b, kin = self.blob, self.kin
         v = b.view(state_row)
         plane_friction = rng.uniform(0.025, 0.5)                                   # env.py:120
@@ -85,6 +93,22 @@ class FeedingJacoReset:
         ik_lo = np.where(kin.lower < -1e9, -2 * np.pi, kin.lower)                  # agent.py:223-231
         ik_hi = np.where(kin.upper > 1e9, 2 * np.pi, kin.upper)
         best, best_d, ok, restarts = None, np.inf, False, 0
+        base_pos, base_quat = self.base_pos, self.base_quat
+        if self.toc is not None:
+            from .reset_bed import placement_rng
+            prng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)
+            res = None
+            for _ in range(4):
+                res = self.toc._toc(prng, target_ee_pos, [target])
+                if res is not None:
+                    break
+            assert res is not None, 'no reachable base pose found'
+            base_pos, base_quat, q_arm, ngoal, manip = res
+            best = q.copy()
+            for k_, d_ in enumerate(self.toc.arm.chain):
+                best[d_] = q_arm[k_]
+            p, o = kin.ee_pose(base_pos, base_quat, best)
+            best_d, ok, max_restarts = float(np.linalg.norm(target_ee_pos - p)), True, 0
         for r in range(max_restarts):
             restarts = r + 1
             lo, hi = ik_lo, ik_hi
@@ -120,9 +144,9 @@ class FeedingJacoReset:
         # a controllable human keeps its controllable joints dynamic (human.py:108)
         v['frozen'][0] = 0 if (impairment == 'tremor' or b.is_coop) else (((1 << b.nhdof) - 1) << nr)
         v['limit_scale'][0] = limit_scale
-        v['base'][0, :3], v['base'][0, 3:] = self.base_pos, self.base_quat
+        v['base'][0, :3], v['base'][0, 3:] = base_pos, base_quat
         # tool in the gripper (tool.py:49-62)
-        tp, tq = kin.tool_pose(self.base_pos, self.base_quat, q)
+        tp, tq = kin.tool_pose(base_pos, base_quat, q)
         free = v['free'][0]
         free[:] = 0
         free[:, 6] = 1.0
@@ -156,13 +180,23 @@ class FeedingJacoReset:
         return state_row
 
 
-def make_states(blob, n, seed=1001, impairment='random', **kw):
-    """n independent post-reset (pre-settle) states; env i uses RandomState(seed + i)."""
+FeedingReset = FeedingJacoReset
+
+
+def make_states(blob, n, seed=1001, impairment='random', checker=None, **kw):
+    """n independent post-reset (pre-settle) states; env i uses RandomState(seed + i).  checker(states) -> AGX_COLLIDE_* flags
+    (reset_bed.DeviceCollisionChecker): init_robot_pose's collision rejection for the free-standing robots (env.py:281-308)."""
     rs = FeedingJacoReset(blob)
     st = blob.new_state(n)
-    infos = []
+    infos = [{} for _ in range(n)]
+
+    def draw(i, attempt=0):
+        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], env_seed=seed + i, impairment=impairment, info=infos[i], attempt=attempt, **kw)
     for i in range(n):
-        info = {}
-        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], env_seed=seed + i, impairment=impairment, info=info, **kw)
-        infos.append(info)
+        draw(i)
+    if checker is not None and rs.toc is not None:
+        from .reset_bed import reject_collisions
+        flags = reject_collisions(st, checker, draw)
+        for i in range(n):
+            infos[i]['collision_flags'] = int(flags[i])
     return st, infos

@@ -411,6 +411,17 @@ class BedBathingSawyerReset:
         return state_row
 
 
+def toc_search(blob):
+    """the base pose search of reset_bed (BedBathingSawyerReset._toc) for another task's model: an object with ._toc(rng, start, goals)"""
+    h = BedBathingSawyerReset.__new__(BedBathingSawyerReset)
+    m = blob.meta
+    h.blob, h.arm = blob, ArmChain(blob)
+    h.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m['toc_base'])          # robot.py:142 + toc_base_pos_offset
+    h.ee_R = X.quat_to_mat(X.quat_from_rpy(m['ee_rpy']))                         # toc_ee_orient_rpy
+    h.self_guard = m.get('robot') == 'sawyer'
+    return h
+
+
 def make_states(blob, n, seed=1001, impairment='random', settler=None, checker=None, **kw):
     """n independent post-reset states; env i uses RandomState(seed + i).  With a `settler` (a callable advancing bed_settle
     state records by the 100 simulation steps of bed_bathing.py:130-131, e.g. RagdollSettler) the human is settled as a rag

@@ -501,7 +501,18 @@ FEEDING_ROBOTS = dict(
     panda=dict(urdf=('panda', 'panda.urdf'), arm=[0, 1, 2, 3, 4, 5, 6], grip=[9, 10], gripper_target=[0.001, 0.001],            # panda.py:8,13,20
                gripper_collision={7, 8, 9, 10, 11}, ee_pb=11,                                                                  # panda.py:17,11
                tool_pos=[-0.11, 0.0175, 0], tool_rpy=[-0.1, -np.pi / 2.0, np.pi],                                              # panda.py:26,31
-               base_pos=[-0.4, -0.35, 0.26], ee_rpy=[-np.pi / 2.0, 0, -np.pi / 2.0]))                                          # panda.py:36,43
+               base_pos=[-0.4, -0.35, 0.26], ee_rpy=[-np.pi / 2.0, 0, -np.pi / 2.0]),                                          # panda.py:36,43
+    # free-standing robots (robot_arm = 'right', feeding_envs.py:15): the base pose comes from Robot.position_robot_toc around
+    # [-0.85, -0.4, 0] + toc_base (robot.py:142); no device-side reset generator (host/reset.py FeedingReset + the device's collision pass)
+    sawyer=dict(urdf=('sawyer', 'sawyer.urdf'), arm=[3, 8, 9, 10, 11, 13, 16], grip=[20, 22], gripper_target=[0.0, 0.0],         # sawyer.py:8,13,20
+                gripper_collision={18, 20, 21, 22, 23}, ee_pb=19, tool_pb=18, hull_verts=0, selfcol='sawyer',                   # sawyer.py:17,11,15
+                tool_pos=[-0.1, 0.12, -0.02], tool_rpy=[np.pi / 2.0 - 0.1, 0, np.pi / 2.0],                                     # sawyer.py:26,31
+                toc_base=[-0.1, 0.2, 0.975], ee_rpy=[np.pi / 2.0, 0, np.pi / 2.0]),                                             # sawyer.py:36,42
+    baxter=dict(urdf=('baxter', 'baxter_custom.urdf'), arm=[12, 13, 14, 15, 16, 18, 19], grip=[27, 29], gripper_target=[0.0, 0.0],   # baxter.py:8,13,20 (right arm)
+                gripper_collision={25, 27, 28, 29, 30}, ee_pb=26, tool_pb=25, selfcol='none',                                   # baxter.py:17,11,15
+                frozen_rest=dict(zip([34, 35, 36, 37, 38, 40, 41], [0.75, 1, 0.5, 0.5, 1, -0.5, 0])),                           # left arm tucked, baxter.py:67
+                tool_pos=[-0.1, 0.12, -0.02], tool_rpy=[np.pi / 2.0 - 0.1, 0, np.pi / 2.0],                                     # baxter.py:26,31
+                toc_base=[0, 0.2, 0.925], ee_rpy=[np.pi / 2.0, 0, np.pi / 2.0]))                                                # baxter.py:36,42
 
 
 def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
@@ -519,11 +530,23 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
     # ------------------------------------------------------------------ robot (agents/jaco.py, agents/panda.py)
     RB = FEEDING_ROBOTS[robot]
     arm, grip = RB['arm'], RB['grip']
-    rob = compile_robot(os.path.join(assets, *RB['urdf']), arm, grip, gripper_target=RB['gripper_target'],
-                        motor_gain=0.025, motor_force=1.0, max_hull_verts=robot_hull_max_verts)
+    mounted = 'base_pos' in RB                      # on the wheelchair (jaco.py:48, panda.py:49); else placed by the base pose search
+    urdf_path = os.path.join(assets, *RB['urdf'])
+    frozen = None
+    if 'frozen_rest' in RB:                         # the other arm, head, ...: static geometry at their rest pose (see compile_scratch_itch)
+        u0 = Urdf(urdf_path)
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen.update(RB['frozen_rest'])
+    rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'],
+                        motor_gain=0.025, motor_force=1.0, max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen)
     nrobot = len(rob['dof_links'])
     gripper_collision = RB['gripper_collision']    # no collision with the tool (tool.py:42-44)
-    add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)     # links that DO collide with the tool
+    if RB.get('selfcol') == 'sawyer':              # ranges as in compile_bed_bathing: links <= 8, links 9.. outside the gripper, gripper
+        add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
+        add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
+        sc.ranges['robot_arm'] = (sc.ranges['robot_lower'][0], sc.ranges['robot_upper'][1])
+    else:
+        add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)     # links that DO collide with the tool
     add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
     sc.begin('robot_base')
     for verts, radius, fr, pb in rob['base_colliders']:
@@ -605,9 +628,15 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
     grp('robot_gripper', 'bowl')
     grp('bowl', 'table')
     grp('bowl', 'plane')
-    # URDF_USE_SELF_COLLISION (jaco.py:53): every robot link pair except same link / parent-child
     G_.rg['robot_links'] = (G_.rg['robot_arm'][0], G_.rg['robot_gripper'][1])
-    grp('robot_links', 'robot_links', same=True, no_adjacent=True)
+    if RB.get('selfcol', 'all') == 'all':           # URDF_USE_SELF_COLLISION (jaco.py:53): every robot link pair except same link / parent-child
+        grp('robot_links', 'robot_links', same=True, no_adjacent=True)
+    elif RB['selfcol'] == 'sawyer':                 # the pairs Sawyer.init leaves enabled (sawyer.py:53-61): {base, 0, 1, 2} x {9..23}
+        G_.rg['robot_top'] = (G_.rg['robot_upper'][0], G_.rg['robot_gripper'][1])
+        grp('robot_base', 'robot_top')
+    if not mounted:                                 # the static pedestal / torso / other arm of a free-standing robot
+        grp('robot_base', 'tool')
+        grp('food', 'robot_base', keep=2)
     grp('robot_arm', 'wheelchair')
     grp('robot_gripper', 'wheelchair')
     grp('robot_arm', 'plane')
@@ -623,8 +652,8 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
         return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
-        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['base_pos']                               # toc_base_pos_offset
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm) if mounted else 0                    # NARM 0: no device-side reset generator for this blob
+        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['base_pos'] if mounted else np.array([-0.85, -0.4, 0]) + RB['toc_base']   # toc_base_pos_offset
         xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])      # feeding.py:136
         xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])                  # toc_ee_orient_rpy
         xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.15, -0.65, 1.15], 0.05   # feeding.py:139
@@ -669,13 +698,15 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
                   SUCCESS_FRAC=0.75, MOUTH_DIST=0.03, SPILL_DIST=0.1,
                   MOUTH_M=[0, -0.11, 0.03], MOUTH_F=[0, -0.1, 0.03],                        # feeding.py:186
                   EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1],
-                  TOOL_POS=RB['tool_pos'], TOOL_QUAT=X.quat_from_rpy(RB['tool_rpy']),
+                  TOOL_POS=RB['tool_pos'] if RB.get('tool_pb', ee_pb) == ee_pb else tool_offset_in_ee_frame(rob, ee_pb, RB['tool_pb'], RB['tool_pos'], RB['tool_rpy'])[0],
+                  TOOL_QUAT=X.quat_from_rpy(RB['tool_rpy']) if RB.get('tool_pb', ee_pb) == ee_pb else tool_offset_in_ee_frame(rob, ee_pb, RB['tool_pb'], RB['tool_pos'], RB['tool_rpy'])[1],
                   TOOL_MAXF=500.0, EPISODE_LEN=200)                                        # tool.py:47
     task_i = dict(HEAD_LINK=head_link, EE_LINK=ee_link)
     params = default_params(n_iter)                                                        # robot / human gravity 0: feeding.py:150-152
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=25, FOOD0=2, TOOL_BODY=0, TASK_KIND=TASK_FEEDING), reset_fill, reset_words,
-                meta_extra=dict(head_link=int(head_link), robot_base_pos=list(RB['base_pos']),
+                meta_extra=dict(head_link=int(head_link), robot=robot, mount='wheelchair' if mounted else 'toc', toc_base=list(RB.get('toc_base', [0, 0, 0])),
+                                ee_rpy=list(RB['ee_rpy']), robot_base_pos=list(RB['base_pos']) if mounted else (np.array([-0.85, -0.4, 0]) + RB['toc_base']).tolist(),
                                 robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist()))
 
 
@@ -1320,6 +1351,7 @@ def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
 
 
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda,
+                 feeding_sawyer=lambda *a, **k: compile_feeding('sawyer', *a, **k), feeding_baxter=lambda *a, **k: compile_feeding('baxter', *a, **k),
                  bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
                  bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),

@@ -45,10 +45,16 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         st, cloth, _ = make_dressing_states(blob, pool_size, seed=seed, impairment=impairment, settler=ClothSettler(blob, pool_size, device))
         return st, cloth
     st = Stepper(blob, pool_size, device)
+    if blob.meta.get('mount') == 'toc':      # a free-standing robot in the feeding scene (FeedingSawyer, FeedingBaxter): base pose search on the host
+        sampler = 'host'
     if sampler == 'device':
         st.sample_reset(seed, impairment=impairment)
     elif sampler == 'host':
-        states, _ = make_states(blob, pool_size, seed=seed, impairment=impairment)
+        checker = None
+        if blob.meta.get('mount') == 'toc':
+            from .host.reset_bed import DeviceCollisionChecker
+            checker = DeviceCollisionChecker(blob, pool_size, device)
+        states, _ = make_states(blob, pool_size, seed=seed, impairment=impairment, checker=checker)
         st.set_state(states)
     else:
         raise ValueError("sampler must be 'device' or 'host'")
@@ -156,6 +162,21 @@ class AssistiveVecEnv:
 
 class FeedingJacoVecEnv(AssistiveVecEnv):
     model = 'feeding_jaco'
+
+
+class FeedingSawyerVecEnv(AssistiveVecEnv):
+    """FeedingSawyer-v1 (feeding_envs.py:25-27): a free-standing robot -- resets from a pool built with the host sampler (base pose search)"""
+    model = 'feeding_sawyer'
+
+    def __init__(self, n_envs, **kw):
+        kw.setdefault('reset', 'pool')
+        assert kw['reset'] != 'device', 'the device-side reset generator places wheelchair-mounted robots only: use a pool'
+        super().__init__(n_envs, **kw)
+
+
+class FeedingBaxterVecEnv(FeedingSawyerVecEnv):
+    """FeedingBaxter-v1 (feeding_envs.py:21-23): Baxter's right arm"""
+    model = 'feeding_baxter'
 
 
 class FeedingPandaVecEnv(AssistiveVecEnv):
