@@ -30,9 +30,10 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
         self.arm = ArmChain(blob)
         self.human_bodies = blob.meta['human_bodies']
         self.human_dyn = blob.meta['human_dynamic_joints']
-        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array([-0.3, 0.6, 0.975])          # robot.py:142 + sawyer.py:40
-        self.ee_R = X.quat_to_mat(X.quat_from_rpy([0, -np.pi / 2.0, np.pi]))                 # sawyer.py:46 toc_ee_orient_rpy
-        self.self_guard = True                                                               # see _arm_in_pedestal
+        m = blob.meta
+        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m.get('toc_base', [-0.3, 0.6, 0.975]))     # robot.py:142 + toc_base_pos_offset (sawyer.py:40)
+        self.ee_R = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy', [0, -np.pi / 2.0, np.pi])))            # toc_ee_orient_rpy (sawyer.py:46)
+        self.self_guard = m.get('robot', 'sawyer') == 'sawyer'                                            # see _arm_in_pedestal
         self._hm = {}
 
     def pre_settle(self, rng, impairment='no_tremor', gender='random', human_q_override=None):
@@ -83,7 +84,8 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
         hq = hm.clamp(hq)                                                          # enforce_joint_limits (human.py:121)
         pre['hq'] = hq
         self._fill_human(v, pre)
-        self._place(v, PARKED, np.array([0, 0, 0, 1.0]), np.zeros(self.arm.n))
+        lo, hi = self.arm.lower, self.arm.upper                                     # parked at the middle of its joint ranges (the Jaco's zero pose violates its limits)
+        self._place(v, PARKED, np.array([0, 0, 0, 1.0]), np.where((lo > -1e9) & (hi < 1e9), 0.5 * (lo + hi), 0.0))
         hq_dyn = np.array([hq[j] for j in self.human_dyn])
         v['q'][0, nr:] = hq_dyn
         v['qt'][0, nr:] = hq_dyn

@@ -1059,7 +1059,11 @@ ROBOT_TASK = dict(
         baxter=dict(gripper_target=[0.0125, -0.0125], tool_pos=[0, 0.1175, 0], tool_rpy=[H_PI, 0, H_PI], toc_base=[-0.2, 0, 0.925], ee_rpy=[0, H_PI, 0]),
         jaco=dict(gripper_target=[1.1] * 3, tool_pos=[-0.01, 0, 0.03], tool_rpy=[0, -H_PI, 0], toc_base=[-0.05, 1.05, 0.6], ee_rpy=[0, H_PI, 0]),
         panda=dict(gripper_target=[0.02] * 2, tool_pos=[0, 0, 0], tool_rpy=[0, -H_PI, 0], toc_base=[-0.05, 1.05, 0.67], ee_rpy=[0, H_PI, 0]),
-        sawyer=dict(gripper_target=[0.0125, -0.0125], tool_pos=[0, 0.1175, 0], tool_rpy=[H_PI, 0, H_PI], toc_base=[-0.2, 0, 0.975], ee_rpy=[0, H_PI, 0])))
+        sawyer=dict(gripper_target=[0.0125, -0.0125], tool_pos=[0, 0.1175, 0], tool_rpy=[H_PI, 0, H_PI], toc_base=[-0.2, 0, 0.975], ee_rpy=[0, H_PI, 0])),
+    arm_manipulation=dict(      # the single-arm robots only: PR2 / Baxter hold a second tool in their other arm (arm_manipulation.py:15-16)
+        jaco=dict(gripper_target=[1.05] * 3, tool_pos=[0.075, 0, 0.14], tool_rpy=[H_PI, -H_PI, 0], toc_base=[-0.25, 1.15, 0.6], ee_rpy=[0, H_PI, 0]),
+        panda=dict(gripper_target=[0.02] * 2, tool_pos=[0.075, 0, 0.12], tool_rpy=[H_PI, -H_PI, 0], toc_base=[-0.25, 1.15, 0.67], ee_rpy=[0, H_PI, 0]),
+        sawyer=dict(gripper_target=[0.01, -0.01], tool_pos=[0.075, 0.235, 0], tool_rpy=[0, 0, H_PI], toc_base=[-0.3, 0.6, 0.975], ee_rpy=[0, -H_PI, np.pi])))
 
 
 def robot_table(task, robot):
@@ -1261,28 +1265,44 @@ def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
 
 
 def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
-    """ArmManipulationSawyer-v1 (arm_manipulation_envs.py:23-25): Sawyer (a single-arm robot: tool_left IS tool_right,
-    arm_manipulation.py:12-16) holds the scooper (assets/arm_manipulation/arm_manipulation_scooper_vhacd.obj, 12 hulls, 1 kg,
-    tool.py:26-34) next to a human lying on the bed whose right arm hangs limp beside the body (arm_manipulation.py:141-149: a reactive
-    hold of 0.01 N m only) under full gravity (arm_manipulation.py:176); the task is to lift that arm back onto the body.
+    """ArmManipulationSawyer-v1 (arm_manipulation_envs.py:23-25)"""
+    return compile_arm_manipulation('sawyer', assets, n_iter)
+
+
+def compile_arm_manipulation(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
+    """ArmManipulation<Robot>-v1 for a single-arm robot (Sawyer, Jaco, Panda: tool_left IS tool_right, arm_manipulation.py:12-16): the
+    robot holds the scooper (assets/arm_manipulation/arm_manipulation_scooper_vhacd.obj, 12 hulls, 1 kg, tool.py:26-34) next to a human
+    lying on the bed whose right arm hangs limp beside the body (arm_manipulation.py:141-149: a reactive hold of 0.01 N m only) under full
+    gravity (arm_manipulation.py:176); the task is to lift that arm back onto the body.
     robot_arm = 'both' (arm_manipulation_envs.py:13) makes a single-arm robot list its seven arm joints TWICE (robot.py:16): 14 actions,
-    the second copy's motor targets win (setJointMotorControlArray takes them in order), 14 joint angles in the observation."""
+    the second copy's motor targets win (setJointMotorControlArray takes them in order), 14 joint angles in the observation.  A
+    wheelchair-mounted arm stands on a nightstand at [-1.2, 0.7, 0] + base_position (arm_manipulation.py:163-167), carried here by the
+    robot's base body as in compile_bed_bathing."""
     sc = Scene()
-    arm = [3, 8, 9, 10, 11, 13, 16]
-    grip = [20, 22]
-    rob = compile_robot(os.path.join(assets, 'sawyer', 'sawyer.urdf'), arm, grip, gripper_target=[0.01, -0.01],           # sawyer.py:24
-                        motor_gain=0.05, motor_force=20.0, max_hull_verts=0)                                              # robot.py:37, arm_manipulation.py:114
+    RB = robot_table('arm_manipulation', robot)
+    arm, grip = RB['arm'], RB['grip']
+    rob = compile_robot(os.path.join(assets, *RB['urdf']), arm, grip, gripper_target=RB['gripper_target'],
+                        motor_gain=0.05, motor_force=20.0, max_hull_verts=RB.get('hull_verts', robot_hull_max_verts))             # robot.py:37, arm_manipulation.py:114
     nrobot = len(rob['dof_links'])
     for d in range(nrobot):                           # the second copy of the arm joints drives the motors
         if rob['rec_int'][d]['ACT'] >= 0:
             rob['rec_int'][d]['ACT'] += len(arm)
-    gripper_collision = {18, 20, 21, 22, 23}
-    add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
-    add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
+    gripper_collision = RB['gripper_collision']
+    if RB['selfcol'] == 'sawyer':
+        add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
+        add_robot_colliders(sc, rob, 'robot_upper', lambda pb: pb >= 9 and pb not in gripper_collision)
+    else:
+        add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb not in gripper_collision)
+        sc.begin('robot_upper'); sc.end('robot_upper')
     add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
     sc.begin('robot_base')
     for verts, radius, fr, pb in rob['base_colliders']:
         sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    if RB['wheelchair_mounted']:
+        nv = load_obj_groups(os.path.join(assets, 'nightstand', 'nightstand.obj'), 0.275)
+        nv = X.apply(np.zeros(3), X.quat_from_rpy([np.pi / 2, 0, 0]), convex_hull_vertices(np.concatenate(nv)))
+        off = np.array([-1.2, 0.7, 0]) - (np.array([-0.85, -0.4, 0]) + np.array(RB['toc_base']))      # arm_manipulation.py:166, robot.py:142
+        sc.add(BODY_ROBOT_BASE, reduce_hull(nv + off, 64), HULL_MARGIN, DEFAULT_FRICTION, TAG['ROBOT'], link=-1)
     sc.end('robot_base')
     scoop = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'arm_manipulation', 'arm_manipulation_scooper_vhacd.obj'), 0.001)]   # arm_manipulation.py:159
     allv = np.concatenate(scoop)
@@ -1317,7 +1337,10 @@ def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
     grp('robot_links', 'bed', keep=2)
     grp('robot_arm', 'tool')
     grp('robot_base', 'tool')
-    grp('robot_base', 'robot_top')
+    if RB['selfcol'] == 'sawyer':
+        grp('robot_base', 'robot_top')
+    elif RB['selfcol'] == 'all':
+        grp('robot_links', 'robot_links', same=True, no_adjacent=True)
     grp('robot_links', 'plane')
     grp('tool', 'plane')
     for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
@@ -1325,9 +1348,9 @@ def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
         grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)
         grp('harm_' + gender, 'bed', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
     groups = G_.rows
-    ee_pb, tool_pb = 19, 18
+    ee_pb, tool_pb = RB['ee_pb'], RB['tool_pb']
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
-    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, [0.075, 0.235, 0], [0, 0, np.pi / 2.0])                       # sawyer.py:29,34
+    tpos, tquat = tool_offset_in_ee_frame(rob, ee_pb, tool_pb, RB['tool_pos'], RB['tool_rpy'])
     task_f = dict(W_DISTANCE=0.5, W_WIPE=0.25, W_ACTION=0.01, SUCCESS_FRAC=-0.7,         # config.ini:33-37: distance_human / distance_end_effector / action weights, threshold
                   C_V=0.25, C_F=0.01, C_HF=0.05, C_P=0.01, PRESSURE_DIST=0.01,                                             # config.ini:40-42,46; env.py:262
                   EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=tpos, TOOL_QUAT=tquat,
@@ -1347,7 +1370,7 @@ def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
         pass        # the pool comes from assistive_gym_amd/host/reset_arm.py
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=2 * len(arm), OBS_DIM=31 + 2 * len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_ARM_MANIPULATION), reset_fill, reset_words,
-                task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip))
+                task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, robot=robot, toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
 
 
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda,
@@ -1357,7 +1380,8 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
                  scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
-                 arm_manipulation_sawyer=compile_arm_manipulation_sawyer)
+                 arm_manipulation_sawyer=compile_arm_manipulation_sawyer, arm_manipulation_jaco=lambda *a, **k: compile_arm_manipulation('jaco', *a, **k),
+                 arm_manipulation_panda=lambda *a, **k: compile_arm_manipulation('panda', *a, **k))
 
 
 def main(names=None):

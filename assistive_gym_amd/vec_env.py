@@ -246,6 +246,10 @@ for _r in ('jaco', 'panda', 'pr2', 'baxter'):
 _vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchBaxterVecEnv', 'scratch_itch_baxter')
 
 
+_vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationJacoVecEnv', 'arm_manipulation_jaco')
+_vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationPandaVecEnv', 'arm_manipulation_panda')
+
+
 class DressingBaxterVecEnv(AssistiveVecEnv):
     """BASELINE config 5: DressingBaxter-v1 (dressing_envs.py:19-21).  Every environment carries a garment of 3,966 nodes next to its
     state record; resets come from a pool of (state, settled garment) pairs built once (host/reset_dressing.py + the device settle)."""

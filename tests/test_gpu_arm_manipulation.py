@@ -136,3 +136,38 @@ def test_vec_env_rollout_and_scalar_env(am):
     o = e.reset()
     assert o.shape == (45,)
     e.disconnect()
+
+
+@pytest.mark.parametrize('robot', ['jaco', 'panda'])
+def test_other_single_arm_robots(robot):
+    """ArmManipulationJaco-v1 / ArmManipulationPanda-v1: pool states built the product way (both settles + collision rejection on the
+    device), single steps against the oracle, a batched rollout"""
+    import torch
+    from assistive_gym_amd import libagx, vec_env
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.libagx import Stepper
+    from oracle_lib import Oracle
+    if libagx.load().agx_device_count() <= 0:
+        pytest.skip('no GPU visible')
+    b = ModelBlob.load('arm_manipulation_' + robot)
+    o = Oracle(b)
+    n = 12
+    states = vec_env.build_reset_pool(b, n, 9001)
+    assert np.isfinite(states).all()
+    st = Stepper(b, n)
+    assert st.variant() == 'arm_manipulation'
+    st.set_state(states)
+    worst = np.zeros(n)
+    for k in range(3):
+        act = np.random.RandomState(300 + k).uniform(-1, 1, (n, 14)).astype(np.float32)
+        ref = st.get_state()
+        _check_step(b, o, st, ref, act, worst)
+    st.close()
+    assert worst.max() < 1e-3, worst
+    env = getattr(vec_env, 'ArmManipulation%sVecEnv' % robot.capitalize())(32, pool_size=8, seed=3)
+    obs = env.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for k in range(200):
+        obs, rew, done, info = env.step(torch.rand((32, 14), device='cuda', generator=g) * 2 - 1)
+    assert bool(done.all()) and torch.isfinite(obs).all() and torch.isfinite(rew).all() and env.stepper.overflow_count() == 0
+    env.close()
