@@ -329,11 +329,12 @@ class DressingBaxterEnv(AssistiveEnv):
         """DressingEnv.reset (dressing.py:112-198): the draws, the TOC base pose search and the IK restated on the host
         (host/reset_dressing.py); the garment is loaded relative to the end effector and settles for 50 steps on the device."""
         from .host.reset_dressing import make_states, ClothSettler
+        from .host.reset_bed import DeviceCollisionChecker
         st = self._ensure_stepper()
         if not hasattr(self, '_settler'):
-            self._settler = ClothSettler(self.blob, 1, self.device)
+            self._settler, self._checker = ClothSettler(self.blob, 1, self.device), DeviceCollisionChecker(self.blob, 1, self.device)
         self.reset_seed = self._draw_seed()
-        rec, cloth, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler)
+        rec, cloth, _ = make_states(self.blob, 1, seed=self.reset_seed % (2 ** 31), settler=self._settler, checker=self._checker)
         st.set_state(rec)
         st.set_cloth(cloth)
         self.iteration, self.task_success = 0, 0
@@ -390,6 +391,7 @@ def _robot_flavours(base_cls, task_name, robots, ref):
 
 _robot_flavours(BedBathingSawyerEnv, 'BedBathing', [('Jaco', 'bed_bathing_jaco'), ('Panda', 'bed_bathing_panda'), ('PR2', 'bed_bathing_pr2'), ('Baxter', 'bed_bathing_baxter')],
                 'bed_bathing_envs.py:15-37,45-79')
+_robot_flavours(DressingBaxterEnv, 'Dressing', [('Sawyer', 'dressing_sawyer'), ('Jaco', 'dressing_jaco'), ('Panda', 'dressing_panda')], 'dressing_envs.py:23-37,56-79')
 _robot_flavours(ArmManipulationSawyerEnv, 'ArmManipulation', [('Jaco', 'arm_manipulation_jaco'), ('Panda', 'arm_manipulation_panda')], 'arm_manipulation_envs.py:27-37,63-79')
 _robot_flavours(ScratchItchPR2Env, 'ScratchItch', [('Baxter', 'scratch_itch_baxter')], 'scratch_itch_envs.py:21-23,46-50')
 

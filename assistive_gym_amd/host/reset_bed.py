@@ -307,6 +307,55 @@ class BedBathingSawyerReset:
         inside = (loc[:, :, None, :] >= self._ped[None, None, :, 0]) & (loc[:, :, None, :] <= self._ped[None, None, :, 1])
         return inside.all(-1).any(-1).any(-1)
 
+    # ---- wheelchair-mounted robots: IK with random restarts from a fixed base (robot.py:84-121) ------------------------------------
+    def _near_human(self, hm, hpos, hquat, hbase, pts, margin=0.07):
+        """pts (B, K, 3): is any point closer than `margin` (an arm link's radius + clearance) to a capsule / sphere of the human?  The
+        stand-in for `get_closest_points(human, distance=0)` inside ik_random_restarts (robot.py:103-108) on the host."""
+        hit = np.zeros(pts.shape[0], dtype=bool)
+        for link, kind, data in hm.colliders():
+            lp, lq = (hbase, np.array([0, 0, 0, 1.0])) if link < 0 else (hpos[link], hquat[link])
+            if kind == 'capsule':
+                a, b = X.apply(lp, lq, np.stack([data[0], data[1]]))
+                r = data[2]
+            elif kind == 'sphere':
+                a = b = X.apply(lp, lq, data[0][None])[0]
+                r = data[1]
+            else:
+                continue
+            ab = b - a
+            t = np.clip(((pts - a) @ ab) / max(float(ab @ ab), 1e-12), 0, 1)
+            d = np.linalg.norm(pts - (a + t[..., None] * ab), axis=-1) - r
+            hit |= (d < margin).any(axis=1)
+        return hit
+
+    def _mounted_ik(self, rng, target_pos, base_pos, base_quat, human=None, restarts=64, rounds=4):
+        """Robot.ik_random_restarts (robot.py:84-121) from the fixed base: random rest poses until the end effector is within 0.01 of the
+        target pose and the arm is clear of the human; `restarts` of them are solved at once, the first that qualifies is taken; when
+        none does, the closest one (robot.py:117-121)"""
+        arm = self.arm
+        bp = np.repeat(np.asarray(base_pos, dtype=np.float64)[None], restarts, axis=0)
+        bR = np.repeat(X.quat_to_mat(base_quat)[None], restarts, axis=0)
+        lo = np.where(arm.lower < -1e9, -2 * np.pi, arm.lower)
+        hi = np.where(arm.upper > 1e9, 2 * np.pi, arm.upper)
+        tp, tR = np.repeat(target_pos[None], restarts, axis=0), np.repeat(self.ee_R[None], restarts, axis=0)
+        qt = X.mat_to_quat(self.ee_R)
+        best = None
+        for _ in range(rounds):
+            q = arm.ik(bp, bR, rng.uniform(lo, hi, size=(restarts, arm.n)), tp, tR, iters=200)
+            pe, Re, orig, _ = arm.fk(bp, bR, q)
+            qe = mat_to_quat_batch(Re)
+            err = np.linalg.norm(tp - pe, axis=1) + np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1))
+            ok = (np.linalg.norm(tp - pe, axis=1) < 0.01) & (np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1)) < 0.01)
+            if human is not None and ok.any():
+                pts = np.concatenate([orig[:, 1:], 0.5 * (orig[:, 1:-1] + orig[:, 2:]), pe[:, None], 0.5 * (orig[:, -1:] + pe[:, None])], axis=1)
+                ok &= ~self._near_human(*human, pts)
+            k = int(np.argmax(ok)) if ok.any() else int(np.argmin(err))
+            if best is None or err[k] < best[0]:
+                best = (float(err[k]), q[k].copy(), bool(ok[k]))
+            if ok.any():
+                break
+        return np.asarray(base_pos, dtype=np.float64).copy(), np.asarray(base_quat, dtype=np.float64), best[1], 1 if best[2] else 0, 0.0
+
     def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None):
         """Fill one state record (float32 view of length state_words) in place, with the 'drop' stand-in for the settle."""
         pre = self.pre_settle(rng, impairment, gender, human_q_override)

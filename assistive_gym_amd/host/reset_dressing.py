@@ -17,7 +17,7 @@ import numpy as np
 
 from ..model import compiler as L
 from ..model import xform as X
-from .reset_bed import ArmChain, BedBathingSawyerReset
+from .reset_bed import ArmChain, BedBathingSawyerReset, placement_rng, reject_collisions
 
 D = np.deg2rad
 
@@ -34,16 +34,20 @@ def cloth_nodes(blob):
     return int(blob.i[blob.h['OFF_CLOTH'] + L.CL['NN']])
 
 
-class DressingBaxterReset(BedBathingSawyerReset):
+class DressingReset(BedBathingSawyerReset):
     def __init__(self, blob):
         assert blob.task_kind == L.TASK_DRESSING
         self.blob = blob
         self.arm = ArmChain(blob)
         self.human_bodies = blob.meta['human_bodies']
         self.human_dyn = blob.meta['human_dynamic_joints']
-        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array([1.7, 0.7, 0.925])             # robot.py:142 + baxter.py:39
-        self.ee_R = X.quat_to_mat(X.quat_from_rpy([0, -np.pi / 2.0, 0]))                      # baxter.py:45 toc_ee_orient_rpy['dressing'][0]
-        self.ee_R_shoulder = X.quat_to_mat(X.quat_from_rpy([np.pi / 2.0, -np.pi / 2.0, 0]))   # [-1]
+        m = blob.meta
+        self.mount = m.get('mount', 'toc')
+        self.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m.get('toc_base', [1.7, 0.7, 0.925]))      # robot.py:142 + toc_base_pos_offset (baxter.py:39)
+        self.fixed_base = np.array([0, 0, 0.06]) + np.array(m.get('toc_base', [0, 0, 0]))                # wheelchair position + offset, rpy (0, 0, pi/2) (dressing.py:116-118)
+        self.ee_R = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy', [0, -np.pi / 2.0, 0])))                # toc_ee_orient_rpy['dressing'][0] (baxter.py:45)
+        self.ee_R_shoulder = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy_shoulder', [np.pi / 2.0, -np.pi / 2.0, 0])))   # [-1]
+        self.self_guard = m.get('robot') == 'sawyer'
         self.x0 = cloth_x0(blob)
         self.cloth_orig_pos = np.array(blob.meta['cloth_orig_pos'])
         self._hm = {}
@@ -57,7 +61,7 @@ class DressingBaxterReset(BedBathingSawyerReset):
             self._hm[key] = HumanModel(gender, limit_scale, cloth=True)
         return self._hm[key]
 
-    def sample(self, rng, state_row, cloth_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None):
+    def sample(self, rng, state_row, cloth_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None, attempt=0):
         """Fill one state record and one garment (float32 [2, NN, 3]: positions, velocities) in place -- BEFORE the cloth has settled;
         the record's cloth gravity is the settle value -9.81 / 2 (dressing.py:178)."""
         b = self.blob
@@ -94,10 +98,14 @@ class DressingBaxterReset(BedBathingSawyerReset):
         target_ee_pos = np.array([0.45, -0.3, 1]) + rng.uniform(-0.05, 0.05, size=3)    # dressing.py:130
         off = np.array([0, 0, 0.1])
         toc = None
-        for _ in range(4):
-            toc = self._toc(rng, target_ee_pos, [shoulder + off, elbow + off, wrist + off], goal_Rs=[self.ee_R_shoulder, self.ee_R, self.ee_R], right_side=False)
-            if toc is not None:
-                break
+        rng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)     # attempt > 0: a re-draw of the placement only (env.py:281)
+        if self.mount == 'wheelchair':       # Robot.ik_random_restarts from the fixed base on the human's left (env.py:295-297)
+            toc = self._mounted_ik(rng, target_ee_pos, self.fixed_base, X.quat_from_rpy([0, 0, np.pi / 2.0]), human=(hm, hpos, hquat, hbase))
+        else:
+            for _ in range(4):
+                toc = self._toc(rng, target_ee_pos, [shoulder + off, elbow + off, wrist + off], goal_Rs=[self.ee_R_shoulder, self.ee_R, self.ee_R], right_side=False)
+                if toc is not None:
+                    break
         assert toc is not None, 'no reachable base pose found'
         rb_pos, rb_quat, q_arm, ngoal, manip = toc
         q = np.zeros(nr)
@@ -171,17 +179,25 @@ class ClothSettler:
         return self.ctx.get_state()[:n], self.ctx.get_cloth()[:n]
 
 
-def make_states(blob, n, seed=1001, impairment='random', settler=None, settle_steps=50, **kw):
+def make_states(blob, n, seed=1001, impairment='random', settler=None, settle_steps=50, checker=None, **kw):
     """n independent post-reset (state record, garment) pairs; env i uses RandomState(seed + i).  settler(states, cloth, n_sim_steps)
     -> (states, cloth) runs the cloth settle (ClothSettler: on the device); without one the garment is left as loaded."""
-    rs = DressingBaxterReset(blob)
+    rs = DressingReset(blob)
     st = blob.new_state(n)
     cloth = np.zeros((n, 2, cloth_nodes(blob), 3), dtype=np.float32)
-    infos = []
+    infos = [{} for _ in range(n)]
+
+    def draw(i, attempt=0):
+        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], cloth[i], env_seed=seed + i, impairment=impairment, info=infos[i], attempt=attempt, **kw)
     for i in range(n):
-        info = {}
-        rs.sample(np.random.RandomState(seed + i), st[i:i + 1], cloth[i], env_seed=seed + i, impairment=impairment, info=info, **kw)
-        infos.append(info)
+        draw(i)
+    if checker is not None:          # init_robot_pose's collision rejection (env.py:281-308), before the garment is loaded
+        flags = reject_collisions(st, checker, draw)
+        for i in range(n):
+            infos[i]['collision_flags'] = int(flags[i])
     if settler is not None:
         st, cloth = settler(st, cloth, settle_steps)
     return finish_settle(blob, st), cloth, infos
+
+
+DressingBaxterReset = DressingReset

@@ -37,54 +37,6 @@ class ScratchItchReset(BedBathingSawyerReset):
         self.self_guard = m.get('robot') == 'sawyer'                                                 # see reset_bed._arm_in_pedestal
         self._hm = {}
 
-    def _near_human(self, hm, hpos, hquat, hbase, pts, margin=0.07):
-        """pts (B, K, 3): is any point closer than `margin` (an arm link's radius + clearance) to a capsule / sphere of the human?  The
-        stand-in for `get_closest_points(human, distance=0)` inside ik_random_restarts (robot.py:103-108) on the host."""
-        hit = np.zeros(pts.shape[0], dtype=bool)
-        for link, kind, data in hm.colliders():
-            lp, lq = (hbase, np.array([0, 0, 0, 1.0])) if link < 0 else (hpos[link], hquat[link])
-            if kind == 'capsule':
-                a, b = X.apply(lp, lq, np.stack([data[0], data[1]]))
-                r = data[2]
-            elif kind == 'sphere':
-                a = b = X.apply(lp, lq, data[0][None])[0]
-                r = data[1]
-            else:
-                continue
-            ab = b - a
-            t = np.clip(((pts - a) @ ab) / max(float(ab @ ab), 1e-12), 0, 1)
-            d = np.linalg.norm(pts - (a + t[..., None] * ab), axis=-1) - r
-            hit |= (d < margin).any(axis=1)
-        return hit
-
-    def _mounted_ik(self, rng, target_pos, human=None, restarts=64, rounds=4):
-        """Robot.ik_random_restarts (robot.py:84-121) from the fixed base: random rest poses until the end effector is within 0.01 of the
-        target pose and the arm is clear of the human; `restarts` of them are solved at once, the first that qualifies is taken; when
-        none does, the closest one (robot.py:117-121)"""
-        arm = self.arm
-        bp = np.repeat(self.fixed_base[None], restarts, axis=0)
-        bR = np.repeat(X.quat_to_mat(X.quat_from_rpy([0, 0, -np.pi / 2.0]))[None], restarts, axis=0)
-        lo = np.where(arm.lower < -1e9, -2 * np.pi, arm.lower)
-        hi = np.where(arm.upper > 1e9, 2 * np.pi, arm.upper)
-        tp, tR = np.repeat(target_pos[None], restarts, axis=0), np.repeat(self.ee_R[None], restarts, axis=0)
-        qt = X.mat_to_quat(self.ee_R)
-        best = None
-        for _ in range(rounds):
-            q = arm.ik(bp, bR, rng.uniform(lo, hi, size=(restarts, arm.n)), tp, tR, iters=200)
-            pe, Re, orig, _ = arm.fk(bp, bR, q)
-            qe = mat_to_quat_batch(Re)
-            err = np.linalg.norm(tp - pe, axis=1) + np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1))
-            ok = (np.linalg.norm(tp - pe, axis=1) < 0.01) & (np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1)) < 0.01)
-            if human is not None and ok.any():
-                pts = np.concatenate([orig[:, 1:], 0.5 * (orig[:, 1:-1] + orig[:, 2:]), pe[:, None], 0.5 * (orig[:, -1:] + pe[:, None])], axis=1)
-                ok &= ~self._near_human(*human, pts)
-            k = int(np.argmax(ok)) if ok.any() else int(np.argmin(err))
-            if best is None or err[k] < best[0]:
-                best = (float(err[k]), q[k].copy(), bool(ok[k]))
-            if ok.any():
-                break
-        return self.fixed_base.copy(), X.quat_from_rpy([0, 0, -np.pi / 2.0]), best[1], 1 if best[2] else 0, 0.0
-
     def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None, attempt=0):
         """attempt > 0: a re-draw of the robot's placement only (init_robot_pose's rejection loop), everything else as on attempt 0"""
         b = self.blob
@@ -122,7 +74,7 @@ class ScratchItchReset(BedBathingSawyerReset):
         toc = None
         prng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)     # one draw of the main stream, whatever the attempt
         if self.mount == 'wheelchair':
-            toc = self._mounted_ik(prng, target_ee_pos, human=(hm, hpos, hquat, hbase))
+            toc = self._mounted_ik(prng, target_ee_pos, self.fixed_base, X.quat_from_rpy([0, 0, -np.pi / 2.0]), human=(hm, hpos, hquat, hbase))   # scratch_itch.py:99
         else:
             for _ in range(4):
                 toc = self._toc(prng, target_ee_pos, [shoulder, elbow, wrist])

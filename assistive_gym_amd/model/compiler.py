@@ -1060,6 +1060,11 @@ ROBOT_TASK = dict(
         jaco=dict(gripper_target=[1.1] * 3, tool_pos=[-0.01, 0, 0.03], tool_rpy=[0, -H_PI, 0], toc_base=[-0.05, 1.05, 0.6], ee_rpy=[0, H_PI, 0]),
         panda=dict(gripper_target=[0.02] * 2, tool_pos=[0, 0, 0], tool_rpy=[0, -H_PI, 0], toc_base=[-0.05, 1.05, 0.67], ee_rpy=[0, H_PI, 0]),
         sawyer=dict(gripper_target=[0.0125, -0.0125], tool_pos=[0, 0.1175, 0], tool_rpy=[H_PI, 0, H_PI], toc_base=[-0.2, 0, 0.975], ee_rpy=[0, H_PI, 0])),
+    dressing=dict(              # no tool: the garment hangs from the end effector; ee_rpy = toc_ee_orient_rpy[0] (start), ee_rpy_shoulder = [-1]
+        baxter=dict(gripper_target=[0.0, 0.0], toc_base=[1.7, 0.7, 0.925], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[H_PI, -H_PI, 0]),
+        sawyer=dict(gripper_target=[0.0, 0.0], toc_base=[1.8, 0.7, 0.975], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[H_PI, -H_PI, 0]),
+        jaco=dict(gripper_target=[1.33] * 3, toc_base=[0.35, -0.3, 0.3], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[0, -H_PI, 0]),
+        panda=dict(gripper_target=[0.001] * 2, toc_base=[0.35, -0.35, 0.2], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[0, -H_PI, 0])),
     arm_manipulation=dict(      # the single-arm robots only: PR2 / Baxter hold a second tool in their other arm (arm_manipulation.py:15-16)
         jaco=dict(gripper_target=[1.05] * 3, tool_pos=[0.075, 0, 0.14], tool_rpy=[H_PI, -H_PI, 0], toc_base=[-0.25, 1.15, 0.6], ee_rpy=[0, H_PI, 0]),
         panda=dict(gripper_target=[0.02] * 2, tool_pos=[0.075, 0, 0.12], tool_rpy=[H_PI, -H_PI, 0], toc_base=[-0.25, 1.15, 0.67], ee_rpy=[0, H_PI, 0]),
@@ -1182,24 +1187,36 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
 
 
 def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
-    """DressingBaxter-v1 (dressing_envs.py:19-21; BASELINE config 5): Baxter's left arm (agents/baxter.py) pulls the sleeve of a
-    hospital gown (assets/clothing/hospitalgown_reduced.obj, the cloth section, model/cloth.py) over the left arm of a human
+    """DressingBaxter-v1 (dressing_envs.py:19-21; BASELINE config 5)"""
+    return compile_dressing('baxter', assets, n_iter, robot_hull_max_verts)
+
+
+def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
+    """Dressing<Robot>-v1 (dressing_envs.py:15-37): the robot's (left) arm (agents/<robot>.py via ROBOT_BASE / ROBOT_TASK) pulls the sleeve
+    of a hospital gown (assets/clothing/hospitalgown_reduced.obj, the cloth section, model/cloth.py) over the left arm of a human
     sitting in the wheelchair (dressing.py:112-198).  numSubSteps = 8 (dressing.py:184): a stepSimulation is eight internal
     substeps of 2.5 ms.  Baxter's other joints (head pan, right arm, right gripper) start at rest without gravity and are held by
     their default motors: static geometry at the poses of Robot.reset_joints / Baxter.reset_joints (baxter.py:63-67), as for the
     PR2 [deviation, DESIGN.md]."""
     from .cloth import compile_cloth
     sc = Scene()
-    arm = [34, 35, 36, 37, 38, 40, 41]                  # baxter.py:9 left_arm_joint_indices
-    grip = [49, 51]                                     # baxter.py:14
-    urdf_path = os.path.join(assets, 'baxter', 'baxter_custom.urdf')
-    u0 = Urdf(urdf_path)
-    frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
-    frozen.update(dict(zip([12, 13, 14, 15, 16, 18, 19], [-0.75, 1, -0.5, 0.5, -1, -0.5, 0])))      # baxter.py:66
-    rob = compile_robot(urdf_path, arm, grip, gripper_target=[0.0, 0.0], motor_gain=0.01, motor_force=1.0,          # baxter.py:20, dressing.py:121
-                        max_hull_verts=robot_hull_max_verts, frozen=frozen)
+    RB = robot_table('dressing', robot)
+    arm, grip = RB['arm'], RB['grip']
+    urdf_path = os.path.join(assets, *RB['urdf'])
+    frozen = None
+    if 'frozen_rest' in RB:
+        u0 = Urdf(urdf_path)
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen.update(RB['frozen_rest'])
+    rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.01, motor_force=1.0,          # dressing.py:121
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen)
     nrobot = len(rob['dof_links'])
-    add_robot_colliders(sc, rob, 'robot_links', lambda pb: True)
+    if RB['selfcol'] == 'sawyer':
+        add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
+        add_robot_colliders(sc, rob, 'robot_top', lambda pb: pb >= 9)
+        sc.ranges['robot_links'] = (sc.ranges['robot_lower'][0], sc.ranges['robot_top'][1])
+    else:
+        add_robot_colliders(sc, rob, 'robot_links', lambda pb: True)
     sc.begin('robot_base')
     for verts, radius, fr, pb in rob['base_colliders']:
         sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
@@ -1223,13 +1240,17 @@ def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
     grp('robot_links', 'human_male', alt='human_female', keep=2)
     grp('robot_links', 'wheelchair', keep=2)
     grp('robot_links', 'plane')
+    if RB['selfcol'] == 'all':
+        grp('robot_links', 'robot_links', same=True, no_adjacent=True)
+    elif RB['selfcol'] == 'sawyer':
+        grp('robot_base', 'robot_top')
     for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
         G_.rg['harm_' + gender] = (min(G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][0]), max(G_.rg['human_%s_pecs' % gender][1], G_.rg['human_%s_arm' % gender][1]))
         grp('robot_base', 'harm_' + gender, keep=2, flags=gf | GF_HUMAN_DYNAMIC)
         grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)     # human_creation.py:291-293
         grp('harm_' + gender, 'wheelchair', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
     groups = G_.rows
-    ee_pb = 48                                          # baxter.py:12 left_end_effector
+    ee_pb = RB['ee_pb']
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
     radii = [0.043, 0.0355]                             # hand_radius = elbow_radius = shoulder_radius, male / female (human_creation.py:89,140)
     task_f = dict(W_WIPE=1.0, W_ACTION=0.01, SUCCESS_FRAC=0.4,                             # config.ini:28-31
@@ -1261,7 +1282,9 @@ def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, [], params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRESSING), reset_fill, reset_words,
                 task_words=DR['WORDS'], mlp=mlp, cloth=cloth, sim_substeps=8,
-                meta_extra=dict(arm_joints=arm, gripper_joints=grip, cloth=cmeta, cloth_orig_pos=cloth_orig_pos.tolist()))
+                meta_extra=dict(arm_joints=arm, gripper_joints=grip, cloth=cmeta, cloth_orig_pos=cloth_orig_pos.tolist(), robot=robot,
+                                mount='wheelchair' if RB['wheelchair_mounted'] else 'toc', toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy']),
+                                ee_rpy_shoulder=list(RB['ee_rpy_shoulder'])))
 
 
 def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
@@ -1380,6 +1403,8 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
                  scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
+                 dressing_sawyer=lambda *a, **k: compile_dressing('sawyer', *a, **k), dressing_jaco=lambda *a, **k: compile_dressing('jaco', *a, **k),
+                 dressing_panda=lambda *a, **k: compile_dressing('panda', *a, **k),
                  arm_manipulation_sawyer=compile_arm_manipulation_sawyer, arm_manipulation_jaco=lambda *a, **k: compile_arm_manipulation('jaco', *a, **k),
                  arm_manipulation_panda=lambda *a, **k: compile_arm_manipulation('panda', *a, **k))
 

@@ -42,7 +42,9 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         # DressingEnv.reset restated on the host (host/reset_dressing.py) around the 50-step cloth settle on the device;
         # returns (states, garments): the garment of a pool entry travels with its state record
         from .host.reset_dressing import make_states as make_dressing_states, ClothSettler
-        st, cloth, _ = make_dressing_states(blob, pool_size, seed=seed, impairment=impairment, settler=ClothSettler(blob, pool_size, device))
+        from .host.reset_bed import DeviceCollisionChecker
+        st, cloth, _ = make_dressing_states(blob, pool_size, seed=seed, impairment=impairment, settler=ClothSettler(blob, pool_size, device),
+                                            checker=DeviceCollisionChecker(blob, pool_size, device))
         return st, cloth
     st = Stepper(blob, pool_size, device)
     if blob.meta.get('mount') == 'toc':      # a free-standing robot in the feeding scene (FeedingSawyer, FeedingBaxter): base pose search on the host
@@ -264,3 +266,7 @@ class DressingBaxterVecEnv(AssistiveVecEnv):
 
 class DressingBaxterHumanVecEnv(DressingBaxterVecEnv):
     coop = True
+
+
+for _r in ('sawyer', 'jaco', 'panda'):
+    _vec_flavour(DressingBaxterVecEnv, 'Dressing%sVecEnv' % _r.capitalize(), 'dressing_' + _r)

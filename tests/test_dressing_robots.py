@@ -1,0 +1,82 @@
+"""Dressing<Robot>-v1 for Sawyer (base pose search), Jaco and Panda (mounted on the wheelchair's left, dressing.py:116-118) without a GPU:
+blobs against the reference's robot tables, the host reset (the garment hangs from the end effector), a short cloth settle on the oracle
+and the rigid scene of the `dressing` kernel variant on the wave emulator.  The cloth kernel itself is compared on the GPU
+(tests/test_gpu_dressing.py).  PARITY UNPINNED vs PyBullet / the fork's cloth API."""
+import numpy as np
+import pytest
+
+from assistive_gym_amd.model import compiler as L
+from assistive_gym_amd.model import xform as X
+from test_dressing import cloth_tables
+
+
+@pytest.fixture(scope='module', params=['sawyer', 'jaco', 'panda'])
+def rb(request):
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    b = ModelBlob.load('dressing_' + request.param)
+    return request.param, b, Oracle(b)
+
+
+def _states(blob, n, seed, **kw):
+    from assistive_gym_amd.host.reset_dressing import make_states
+    return make_states(blob, n, seed=seed, **kw)
+
+
+def test_model_tables(rb):
+    name, b, o = rb
+    T = L.robot_table('dressing', name)
+    assert b.task_kind == L.TASK_DRESSING and (b.act_dim, b.obs_dim, b.nhdof, b.nfree) == (7, 24, 10, 0) and b.h['SIM_SUBSTEPS'] == 8
+    arm_dofs = sorted((d for d in range(b.nrobot) if b.robot_i(d, 'ACT') >= 0), key=lambda d: b.robot_i(d, 'ACT'))
+    assert [b.robot_i(d, 'PB_INDEX') for d in arm_dofs] == T['arm']
+    assert np.isclose(b.robot_f(arm_dofs[0], 'KP'), 0.01)                                                    # dressing.py:121
+    grip_dofs = [d for d in range(b.nrobot) if b.robot_i(d, 'PB_INDEX') in T['grip']]
+    assert np.allclose([b.robot_f(d, 'QT0') for d in grip_dofs], T['gripper_target'])
+    t = cloth_tables(b)
+    assert (t['nn'], t['nl']) == (3966, 11640) and b.meta['cloth']['shapes'] <= 192
+    assert b.meta['mount'] == ('toc' if name == 'sawyer' else 'wheelchair')
+
+
+def test_reset_hangs_the_garment_from_the_end_effector(rb):
+    name, b, o = rb
+    st, cloth, infos = _states(b, 3, 41)
+    t = cloth_tables(b)
+    want_q = X.quat_from_rpy(b.meta['ee_rpy'])
+    for i in range(3):
+        ee, q = o.ee_pose(st[i])
+        assert np.allclose(ee, infos[i]['start_ee_pos'], atol=1e-5)
+        if infos[i]['toc_goals'] > 0:
+            assert np.linalg.norm(ee - infos[i]['target_ee_pos']) < 0.031 and min(np.linalg.norm(q - want_q), np.linalg.norm(q + want_q)) < 0.031
+        assert np.allclose(cloth[i, 0] - t['x0'], ee - np.array(b.meta['cloth_orig_pos']), atol=1e-5)          # dressing.py:148-153
+        v = b.view(st[i:i + 1])
+        if b.meta['mount'] == 'wheelchair':      # dressing.py:116-118: wheelchair position + toc_base_pos_offset, rpy (0, 0, +pi/2)
+            assert np.allclose(v['base'][0, :3], np.array([0, 0, 0.06]) + b.meta['toc_base'], atol=1e-6)
+            assert np.allclose(v['base'][0, 3:], X.quat_from_rpy([0, 0, np.pi / 2.0]), atol=1e-6)
+    assert sum(1 for i in infos if i['toc_goals'] > 0) >= 2
+
+
+def test_short_cloth_settle_on_the_oracle_and_rigid_emulator_parity(rb):
+    from emu_lib import Emu
+    from test_scratch_itch_robots import emu_checker
+    name, b, o = rb
+    e = Emu(b)
+    st, cloth, infos = _states(b, 1, 43, checker=emu_checker(e))       # init_robot_pose's rejection: the least-squares IK can fold the Panda onto itself
+    assert infos[0]['collision_flags'] == 0
+    t = cloth_tables(b)
+    s, c = st[0].copy(), cloth[0].copy()
+    v = b.view(s.reshape(1, -1))
+    v['task'][0, L.DR['CLOTH_GRAVITY']] = np.array([-9.81 / 2], dtype=np.float32).view(np.int32)[0]
+    o.settle_cloth(s, c, 3)
+    ee, _ = o.ee_pose(s)
+    assert np.isfinite(c).all() and np.abs(c[0, t['anchors']].mean(0) - ee).max() < 0.02                  # the anchors stay at the end effector
+    stretch = np.sqrt(np.sum((c[0, t['a']] - c[0, t['b']]) ** 2, axis=1) / t['rest2'])
+    # a cloth, not loose points; the nodes the garment is loaded INSIDE the gripper with (Jaco's hand is wide) are pushed out to the 4 cm margin in the first steps
+    assert np.median(stretch) < 1.05 and np.percentile(stretch, 95) < 1.6 and stretch.max() < 12
+    so, se = st[0].copy(), st[0].copy()
+    rng = np.random.RandomState(2)
+    for k in range(2):
+        a = rng.uniform(-1, 1, 7).astype(np.float32)
+        o_obs, o_rew, o_done, o_info = o.step(so, a)
+        e_obs, e_rew, e_done, e_info, _ = e.step(se, a)
+        assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4 and o_done == e_done
+        assert np.abs(b.view(so.reshape(1, -1))['q'] - b.view(se.reshape(1, -1))['q']).max() < 2e-5

@@ -142,3 +142,38 @@ def test_scalar_env_and_coop(dr):
     assert ob['robot'].shape == (24,) and ob['human'].shape == (28,)
     ob, rw, dn, inf = co.step({'robot': np.zeros(7), 'human': np.ones(10) * 0.5})
     assert np.isfinite(ob['human']).all() and rw['robot'] == rw['human'] and not dn['__all__']
+
+
+@pytest.mark.parametrize('robot', ['sawyer', 'jaco', 'panda'])
+def test_other_robots(robot):
+    """DressingSawyer-v1 / DressingJaco-v1 / DressingPanda-v1: the pool built the product way (collision rejection, then the 50-step cloth
+    settle on the device), one env.step of the device against the oracle from a pool entry, a short batched rollout"""
+    import torch
+    from assistive_gym_amd import libagx, vec_env
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    if libagx.load().agx_device_count() <= 0:
+        pytest.skip('no GPU visible')
+    b = ModelBlob.load('dressing_' + robot)
+    o = Oracle(b)
+    env = getattr(vec_env, 'Dressing%sVecEnv' % robot.capitalize())(4, pool_size=4, seed=321)
+    obs = env.reset()
+    assert obs.shape == (4, 24) and torch.isfinite(obs).all()
+    s0, c0 = env.stepper.get_state(), env.stepper.get_cloth()
+    assert np.isfinite(c0).all() and np.percentile(np.linalg.norm(c0[:, 1], axis=2), 90) < 1.5        # settled
+    act = np.random.RandomState(5).uniform(-1, 1, (4, 7)).astype(np.float32)
+    obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+    obs, rew, info = obs.cpu().numpy(), rew.cpu().numpy(), info.cpu().numpy() if hasattr(info, 'cpu') else info
+    gc = env.stepper.get_cloth()
+    for i in range(2):
+        rs, rc = s0[i].copy(), c0[i].copy()
+        o_obs, o_rew, o_done, o_info = o.step_cloth(rs, rc, act[i])
+        assert np.abs(obs[i, :23] - o_obs[:23]).max() < 1e-4, (i, np.abs(obs[i, :23] - o_obs[:23]).max())
+        assert abs(rew[i] - o_rew) < 5e-3 + 0.01 * abs(obs[i, 23] - o_obs[23])
+        dx = np.abs(gc[i, 0] - rc[0])
+        assert np.median(dx) < 2e-5 and np.percentile(dx, 99) < 3e-3, (np.median(dx), np.percentile(dx, 99))
+    a = torch.zeros(4, 7, device='cuda')
+    for _ in range(5):
+        ob, rw, dn, inf = env.step(a)
+    assert torch.isfinite(ob).all() and torch.isfinite(rw).all() and env.stepper.overflow_count() == 0
+    env.close()
