@@ -60,8 +60,9 @@
 #define AGX_VNAME arm_manipulation
 #define AGX_K(name) name##_am
 #elif defined(AGX_VARIANT_FEEDING_L)
-// the feeding scene with a free-standing robot (FeedingSawyer, FeedingBaxter): the pedestal / torso / other arm add up to 320 colliders
+// the feeding scene with a free-standing robot (FeedingSawyer, FeedingBaxter, FeedingPR2): the pedestal / torso / other arm add up to 320 colliders
 #define AGX_MAX_COLL 320
+#define AGX_MAX_BLOCK 12      // the PR2's arm: 7 arm + 4 finger joints
 #define AGX_ARENA_WORDS 4040
 #define AGX_VNAME feeding_l
 #define AGX_K(name) name##_fl

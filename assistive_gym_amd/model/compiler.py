@@ -512,7 +512,12 @@ FEEDING_ROBOTS = dict(
                 gripper_collision={25, 27, 28, 29, 30}, ee_pb=26, tool_pb=25, selfcol='none',                                   # baxter.py:17,11,15
                 frozen_rest=dict(zip([34, 35, 36, 37, 38, 40, 41], [0.75, 1, 0.5, 0.5, 1, -0.5, 0])),                           # left arm tucked, baxter.py:67
                 tool_pos=[-0.1, 0.12, -0.02], tool_rpy=[np.pi / 2.0 - 0.1, 0, np.pi / 2.0],                                     # baxter.py:26,31
-                toc_base=[0, 0.2, 0.925], ee_rpy=[np.pi / 2.0, 0, np.pi / 2.0]))                                                # baxter.py:36,42
+                toc_base=[0, 0.2, 0.925], ee_rpy=[np.pi / 2.0, 0, np.pi / 2.0]),                                                # baxter.py:36,42
+    pr2=dict(urdf=('PR2', 'pr2_no_torso_lift_tall.urdf'), arm=[42, 43, 44, 46, 47, 49, 50], grip=[57, 58, 59, 60], gripper_target=[0.03] * 4,   # pr2.py:8,13,20 (right arm)
+             gripper_collision=set(range(49, 64)), ee_pb=54, tool_pb=54, selfcol='none', file_inertia=True,                    # pr2.py:17,11,15,52
+             frozen_rest=dict(zip([64, 65, 66, 68, 69, 71, 72], [1.75, 1.25, 1.5, -0.5, 1, 0, 1])),                             # left arm tucked, pr2.py:65
+             tool_pos=[0, -0.03, -0.11], tool_rpy=[-0.2, 0, 0],                                                                # pr2.py:26,31
+             toc_base=[0.1, 0.2, 0], ee_rpy=[np.pi / 2.0, 0, 0]))                                                              # pr2.py:36,42
 
 
 def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
@@ -538,7 +543,8 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
         frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
         frozen.update(RB['frozen_rest'])
     rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'],
-                        motor_gain=0.025, motor_force=1.0, max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen)
+                        motor_gain=0.025, motor_force=1.0, max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen,
+                        use_file_inertia=RB.get('file_inertia', False))
     nrobot = len(rob['dof_links'])
     gripper_collision = RB['gripper_collision']    # no collision with the tool (tool.py:42-44)
     if RB.get('selfcol') == 'sawyer':              # ranges as in compile_bed_bathing: links <= 8, links 9.. outside the gripper, gripper
@@ -1397,7 +1403,7 @@ def compile_arm_manipulation(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull
 
 
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda,
-                 feeding_sawyer=lambda *a, **k: compile_feeding('sawyer', *a, **k), feeding_baxter=lambda *a, **k: compile_feeding('baxter', *a, **k),
+                 feeding_sawyer=lambda *a, **k: compile_feeding('sawyer', *a, **k), feeding_baxter=lambda *a, **k: compile_feeding('baxter', *a, **k), feeding_pr2=lambda *a, **k: compile_feeding('pr2', *a, **k),
                  bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
                  bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),

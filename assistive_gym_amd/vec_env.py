@@ -246,6 +246,7 @@ def _vec_flavour(base_cls, name, model_name):
 for _r in ('jaco', 'panda', 'pr2', 'baxter'):
     _vec_flavour(BedBathingSawyerVecEnv, 'BedBathing%sVecEnv' % {'pr2': 'PR2'}.get(_r, _r.capitalize()), 'bed_bathing_' + _r)
 _vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchBaxterVecEnv', 'scratch_itch_baxter')
+_vec_flavour(FeedingSawyerVecEnv, 'FeedingPR2VecEnv', 'feeding_pr2')
 
 
 _vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationJacoVecEnv', 'arm_manipulation_jaco')

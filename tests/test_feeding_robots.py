@@ -8,7 +8,7 @@ from assistive_gym_amd.model import xform as X
 from test_scratch_itch_robots import emu_checker, flags_from_oracle
 
 
-@pytest.fixture(scope='module', params=['sawyer', 'baxter'])
+@pytest.fixture(scope='module', params=['sawyer', 'baxter', 'pr2'])
 def rb(request):
     from assistive_gym_amd.blob import ModelBlob
     from emu_lib import Emu

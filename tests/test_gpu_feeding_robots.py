@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['sawyer', 'baxter'])
+@pytest.fixture(scope='module', params=['sawyer', 'baxter', 'pr2'])
 def rb(request):
     from assistive_gym_amd import libagx
     from assistive_gym_amd.blob import ModelBlob
@@ -54,7 +54,7 @@ def test_vec_env_rollout_and_scalar_env(rb):
     from assistive_gym_amd.envs import make
     name, b, oracle = rb
     n = 64
-    env = getattr(vec_env, 'Feeding%sVecEnv' % name.capitalize())(n, pool_size=8, seed=3)
+    env = getattr(vec_env, 'Feeding%sVecEnv' % {'pr2': 'PR2'}.get(name, name.capitalize()))(n, pool_size=8, seed=3)
     obs = env.reset()
     assert obs.shape == (n, 25)
     g = torch.Generator(device='cuda'); g.manual_seed(5)
@@ -64,7 +64,7 @@ def test_vec_env_rollout_and_scalar_env(rb):
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
     assert env.stepper.overflow_count() < 0.03 * n * 200 * 5
     env.close()
-    e = make('assistive_gym:Feeding%s-v1' % name.capitalize())
+    e = make('assistive_gym:Feeding%s-v1' % {'pr2': 'PR2'}.get(name, name.capitalize()))
     o = e.reset()
     assert o.shape == (25,)
     o, r, d, info = e.step(e.action_space.sample())
