@@ -266,9 +266,12 @@ def test_golden_trajectory_replay(blob):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'feeding_jaco_oracle_traj.npz'))
     e = Emu(blob)
     s = g['state0'].copy()
-    for k in range(len(g['actions'])):
+    full = bool(os.environ.get('AGX_FULL_TESTS'))             # the emulator takes ~2 s per step: 8 of the 20 steps by default (the GPU suite replays all)
+    for k in range(len(g['actions']) if full else 8):
         obs, rew, done, info, _ = e.step(s, g['actions'][k])
         assert np.abs(obs - g['obs'][k]).max() < 2e-4 and abs(rew - float(g['reward'][k])) < 2e-4, k
+    if not full:
+        return
     v, w = blob.view(s[None]), blob.view(g['state_end'][None].copy())
     assert np.abs(v['q'] - w['q']).max() < 1e-4 and np.abs(v['free'][0, :, :3] - w['free'][0, :, :3]).max() < 3e-3   # the particles jostle on the spoon: mm-level after 20 free-running steps
     assert v['food_alive'][0] == w['food_alive'][0] and v['iteration'][0] == w['iteration'][0]
