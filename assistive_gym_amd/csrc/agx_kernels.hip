@@ -41,6 +41,15 @@
 #define AGX_TASK 2
 #define AGX_VNAME scratch_itch
 #define AGX_K(name) name##_si
+#elif defined(AGX_VARIANT_DRESSING_L)
+// DressingPR2: 7 arm + 4 finger joints + the 10 joints of the human's left arm; plus the cloth kernel
+#define AGX_MAX_DOF 24
+#define AGX_MAX_FREE 1
+#define AGX_MAX_BLOCK 12
+#define AGX_ARENA_WORDS 4096
+#define AGX_TASK 3
+#define AGX_VNAME dressing_l
+#define AGX_K(name) name##_drl
 #elif defined(AGX_VARIANT_DRESSING)
 // DressingBaxter: Baxter's left arm (7 arm joints + 2 finger joints; the rest of the robot static) + the 10 joints of the human's left
 // arm, no free body; plus the cloth kernel (agx_cloth.h)

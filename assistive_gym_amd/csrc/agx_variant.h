@@ -41,3 +41,4 @@ extern "C" const agx_variant* agx_variant_dressing(void);
 extern "C" const agx_variant* agx_variant_arm_manipulation(void);
 extern "C" const agx_variant* agx_variant_bed_bathing_l(void);
 extern "C" const agx_variant* agx_variant_feeding_l(void);
+extern "C" const agx_variant* agx_variant_dressing_l(void);

@@ -1070,7 +1070,8 @@ ROBOT_TASK = dict(
         baxter=dict(gripper_target=[0.0, 0.0], toc_base=[1.7, 0.7, 0.925], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[H_PI, -H_PI, 0]),
         sawyer=dict(gripper_target=[0.0, 0.0], toc_base=[1.8, 0.7, 0.975], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[H_PI, -H_PI, 0]),
         jaco=dict(gripper_target=[1.33] * 3, toc_base=[0.35, -0.3, 0.3], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[0, -H_PI, 0]),
-        panda=dict(gripper_target=[0.001] * 2, toc_base=[0.35, -0.35, 0.2], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[0, -H_PI, 0])),
+        panda=dict(gripper_target=[0.001] * 2, toc_base=[0.35, -0.35, 0.2], ee_rpy=[0, -H_PI, 0], ee_rpy_shoulder=[0, -H_PI, 0]),
+        pr2=dict(gripper_target=[0.0] * 4, toc_base=[1.7, 0.7, 0], ee_rpy=[0, 0, np.pi], ee_rpy_shoulder=[0, 0, 1.5 * np.pi])),      # pr2.py:23,39,45
     arm_manipulation=dict(      # the single-arm robots only: PR2 / Baxter hold a second tool in their other arm (arm_manipulation.py:15-16)
         jaco=dict(gripper_target=[1.05] * 3, tool_pos=[0.075, 0, 0.14], tool_rpy=[H_PI, -H_PI, 0], toc_base=[-0.25, 1.15, 0.6], ee_rpy=[0, H_PI, 0]),
         panda=dict(gripper_target=[0.02] * 2, tool_pos=[0.075, 0, 0.12], tool_rpy=[H_PI, -H_PI, 0], toc_base=[-0.25, 1.15, 0.67], ee_rpy=[0, H_PI, 0]),
@@ -1215,7 +1216,7 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
         frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
         frozen.update(RB['frozen_rest'])
     rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.01, motor_force=1.0,          # dressing.py:121
-                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen)
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False))
     nrobot = len(rob['dof_links'])
     if RB['selfcol'] == 'sawyer':
         add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
@@ -1410,7 +1411,7 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
                  dressing_sawyer=lambda *a, **k: compile_dressing('sawyer', *a, **k), dressing_jaco=lambda *a, **k: compile_dressing('jaco', *a, **k),
-                 dressing_panda=lambda *a, **k: compile_dressing('panda', *a, **k),
+                 dressing_panda=lambda *a, **k: compile_dressing('panda', *a, **k), dressing_pr2=lambda *a, **k: compile_dressing('pr2', *a, **k),
                  arm_manipulation_sawyer=compile_arm_manipulation_sawyer, arm_manipulation_jaco=lambda *a, **k: compile_arm_manipulation('jaco', *a, **k),
                  arm_manipulation_panda=lambda *a, **k: compile_arm_manipulation('panda', *a, **k))
 

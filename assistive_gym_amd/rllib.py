@@ -21,7 +21,7 @@ except Exception:
 MODELS = {'FeedingJaco-v1': 'feeding_jaco', 'FeedingPanda-v1': 'feeding_panda', 'FeedingSawyer-v1': 'feeding_sawyer', 'FeedingBaxter-v1': 'feeding_baxter', 'FeedingPR2-v1': 'feeding_pr2', 'BedBathingSawyer-v1': 'bed_bathing_sawyer', 'ScratchItchPR2-v1': 'scratch_itch_pr2', 'ScratchItchJaco-v1': 'scratch_itch_jaco', 'ScratchItchPanda-v1': 'scratch_itch_panda',
           'ScratchItchSawyer-v1': 'scratch_itch_sawyer', 'ScratchItchBaxter-v1': 'scratch_itch_baxter', 'BedBathingJaco-v1': 'bed_bathing_jaco',
           'BedBathingPanda-v1': 'bed_bathing_panda', 'BedBathingPR2-v1': 'bed_bathing_pr2', 'BedBathingBaxter-v1': 'bed_bathing_baxter',
-          'DressingBaxter-v1': 'dressing_baxter', 'DressingSawyer-v1': 'dressing_sawyer', 'DressingJaco-v1': 'dressing_jaco', 'DressingPanda-v1': 'dressing_panda', 'ArmManipulationSawyer-v1': 'arm_manipulation_sawyer', 'ArmManipulationJaco-v1': 'arm_manipulation_jaco',
+          'DressingBaxter-v1': 'dressing_baxter', 'DressingSawyer-v1': 'dressing_sawyer', 'DressingJaco-v1': 'dressing_jaco', 'DressingPanda-v1': 'dressing_panda', 'DressingPR2-v1': 'dressing_pr2', 'ArmManipulationSawyer-v1': 'arm_manipulation_sawyer', 'ArmManipulationJaco-v1': 'arm_manipulation_jaco',
           'ArmManipulationPanda-v1': 'arm_manipulation_panda'}
 
 

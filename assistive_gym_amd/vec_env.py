@@ -269,5 +269,5 @@ class DressingBaxterHumanVecEnv(DressingBaxterVecEnv):
     coop = True
 
 
-for _r in ('sawyer', 'jaco', 'panda'):
-    _vec_flavour(DressingBaxterVecEnv, 'Dressing%sVecEnv' % _r.capitalize(), 'dressing_' + _r)
+for _r in ('sawyer', 'jaco', 'panda', 'pr2'):
+    _vec_flavour(DressingBaxterVecEnv, 'Dressing%sVecEnv' % {'pr2': 'PR2'}.get(_r, _r.capitalize()), 'dressing_' + _r)

@@ -10,7 +10,7 @@ from assistive_gym_amd.model import xform as X
 from test_dressing import cloth_tables
 
 
-@pytest.fixture(scope='module', params=['sawyer', 'jaco', 'panda'])
+@pytest.fixture(scope='module', params=['sawyer', 'jaco', 'panda', 'pr2'])
 def rb(request):
     from assistive_gym_amd.blob import ModelBlob
     from oracle_lib import Oracle
@@ -34,7 +34,7 @@ def test_model_tables(rb):
     assert np.allclose([b.robot_f(d, 'QT0') for d in grip_dofs], T['gripper_target'])
     t = cloth_tables(b)
     assert (t['nn'], t['nl']) == (3966, 11640) and b.meta['cloth']['shapes'] <= 192
-    assert b.meta['mount'] == ('toc' if name == 'sawyer' else 'wheelchair')
+    assert b.meta['mount'] == ('toc' if name in ('sawyer', 'pr2') else 'wheelchair')
 
 
 def test_reset_hangs_the_garment_from_the_end_effector(rb):

@@ -144,7 +144,7 @@ def test_scalar_env_and_coop(dr):
     assert np.isfinite(ob['human']).all() and rw['robot'] == rw['human'] and not dn['__all__']
 
 
-@pytest.mark.parametrize('robot', ['sawyer', 'jaco', 'panda'])
+@pytest.mark.parametrize('robot', ['sawyer', 'jaco', 'panda', 'pr2'])
 def test_other_robots(robot):
     """DressingSawyer-v1 / DressingJaco-v1 / DressingPanda-v1: the pool built the product way (collision rejection, then the 50-step cloth
     settle on the device), one env.step of the device against the oracle from a pool entry, a short batched rollout"""
@@ -156,7 +156,8 @@ def test_other_robots(robot):
         pytest.skip('no GPU visible')
     b = ModelBlob.load('dressing_' + robot)
     o = Oracle(b)
-    env = getattr(vec_env, 'Dressing%sVecEnv' % robot.capitalize())(4, pool_size=4, seed=321)
+    env = getattr(vec_env, 'Dressing%sVecEnv' % {'pr2': 'PR2'}.get(robot, robot.capitalize()))(4, pool_size=4, seed=321)
+    assert env.stepper.variant() == ('dressing_l' if robot == 'pr2' else 'dressing')
     obs = env.reset()
     assert obs.shape == (4, 24) and torch.isfinite(obs).all()
     s0, c0 = env.stepper.get_state(), env.stepper.get_cloth()
