@@ -98,7 +98,7 @@ class DressingReset(BedBathingSawyerReset):
         target_ee_pos = np.array([0.45, -0.3, 1]) + rng.uniform(-0.05, 0.05, size=3)    # dressing.py:130
         off = np.array([0, 0, 0.1])
         toc = None
-        rng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)     # attempt > 0: a re-draw of the placement only (env.py:281)
+        rng = placement_rng(rng, env_seed, attempt)     # attempt > 0: a re-draw of the placement only (env.py:281); nothing else is drawn after it
         if self.mount == 'wheelchair':       # Robot.ik_random_restarts from the fixed base on the human's left (env.py:295-297)
             toc = self._mounted_ik(rng, target_ee_pos, self.fixed_base, X.quat_from_rpy([0, 0, np.pi / 2.0]), human=(hm, hpos, hquat, hbase))
         else:
