@@ -32,6 +32,8 @@ TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the com
     'bedbathing': ('bed_bathing_sawyer', 'BedBathingSawyerVecEnv', '_bb', 'BedBathingSawyer-v1'),
     'scratchitch': ('scratch_itch_pr2', 'ScratchItchPR2HumanVecEnv', '_si', 'ScratchItchPR2Human-v1 (co-op: 7 robot + 10 human actions)'),
     'armmanipulation': ('arm_manipulation_sawyer', 'ArmManipulationSawyerVecEnv', '_am', 'ArmManipulationSawyer-v1 (14 actions: the single arm listed twice)'),
+    'feedingsawyer': ('feeding_sawyer', 'FeedingSawyerVecEnv', '_fl', 'FeedingSawyer-v1 (free-standing robot: feeding_l kernel variant, 320 colliders)'),
+    'bedbathingpr2': ('bed_bathing_pr2', 'BedBathingPR2VecEnv', '_bbl', 'BedBathingPR2-v1 (bed_bathing_l kernel variant: 24 DoF)'),
     'scratchitchjaco': ('scratch_itch_jaco', 'ScratchItchJacoVecEnv', '_si', "ScratchItchJaco-v1 (the reference's default environment)"),
     'dressing': ('dressing_baxter', 'DressingBaxterVecEnv', '_dr', 'DressingBaxter-v1 (cloth of 3,966 nodes per env, numSubSteps 8: 40 internal substeps per step)'),
 }
