@@ -18,11 +18,10 @@ except Exception:
         def __init__(self, observation_space, action_space, num_envs):
             self.observation_space, self.action_space, self.num_envs = observation_space, action_space, num_envs
 
-MODELS = {'FeedingJaco-v1': 'feeding_jaco', 'FeedingPanda-v1': 'feeding_panda', 'FeedingSawyer-v1': 'feeding_sawyer', 'FeedingBaxter-v1': 'feeding_baxter', 'FeedingPR2-v1': 'feeding_pr2', 'BedBathingSawyer-v1': 'bed_bathing_sawyer', 'ScratchItchPR2-v1': 'scratch_itch_pr2', 'ScratchItchJaco-v1': 'scratch_itch_jaco', 'ScratchItchPanda-v1': 'scratch_itch_panda',
-          'ScratchItchSawyer-v1': 'scratch_itch_sawyer', 'ScratchItchBaxter-v1': 'scratch_itch_baxter', 'BedBathingJaco-v1': 'bed_bathing_jaco',
-          'BedBathingPanda-v1': 'bed_bathing_panda', 'BedBathingPR2-v1': 'bed_bathing_pr2', 'BedBathingBaxter-v1': 'bed_bathing_baxter',
-          'DressingBaxter-v1': 'dressing_baxter', 'DressingSawyer-v1': 'dressing_sawyer', 'DressingJaco-v1': 'dressing_jaco', 'DressingPanda-v1': 'dressing_panda', 'DressingPR2-v1': 'dressing_pr2', 'ArmManipulationSawyer-v1': 'arm_manipulation_sawyer', 'ArmManipulationJaco-v1': 'arm_manipulation_jaco',
-          'ArmManipulationPanda-v1': 'arm_manipulation_panda'}
+def _models():
+    """env id -> model blob of every single-agent environment that is built (assistive_gym_amd.envs.ENV_IDS)"""
+    from . import envs
+    return {k: c.model for k, c in envs.ENV_IDS.items() if not c.coop}
 
 
 class AgxVectorEnv(_VectorEnv):
@@ -35,9 +34,9 @@ class AgxVectorEnv(_VectorEnv):
         super().__init__(proto.observation_space, proto.action_space, num_envs)
         self._info_static = {'action_robot_len': proto.action_robot_len, 'action_human_len': proto.action_human_len,
                              'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
-        if name != 'FeedingJaco-v1':
-            vec_kwargs.setdefault('reset', 'pool')         # only FeedingJaco has a device-side reset generator
-        self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=MODELS[name], **vec_kwargs)
+        if name not in ('FeedingJaco-v1', 'FeedingPanda-v1'):
+            vec_kwargs.setdefault('reset', 'pool')         # only the wheelchair-mounted feeding robots have a device-side reset generator
+        self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=_models()[name], **vec_kwargs)
         self._obs = None
 
     def vector_reset(self):
