@@ -27,9 +27,17 @@ def lib(task_kind=0):
         so = os.path.join(EMU, 'libagx_emu_%s.so' % task_kind)
         deps = [os.path.join(EMU, f) for f in ('emu_main.cpp', 'agx_wave.h')] + \
                [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'agx_blob.h')]
-        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-I' + EMU, '-I' + CSRC] + VARIANT_DEFS[task_kind] +
-                                  ['-o', so, os.path.join(EMU, 'emu_main.cpp')])
+        def stale():
+            return not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+        if stale():
+            import fcntl
+            with open(so + '.lock', 'w') as lock:          # pytest-xdist workers / campaign processes build the same variant at the same time
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if stale():
+                    tmp = '%s.%d.tmp' % (so, os.getpid())
+                    subprocess.check_call(['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-I' + EMU, '-I' + CSRC] + VARIANT_DEFS[task_kind] +
+                                          ['-o', tmp, os.path.join(EMU, 'emu_main.cpp')])
+                    os.replace(tmp, so)
         L = C.CDLL(so)
         L.agx_emu_run.restype = C.c_int
         _LIBS[task_kind] = L
