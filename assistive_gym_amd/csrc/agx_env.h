@@ -120,8 +120,10 @@ AGX_DEV uint32_t rng_next(uint32_t& s0, uint32_t& s1) {
   return (uint32_t)(x >> 33) ^ (uint32_t)(x >> 11);
 }
 // pose of the tool frame the task reads: the base frame of the spoon (feeding.py:86), link 1 of the wiper (bed_bathing.py:81)
-AGX_DEV void tool_base_pose(const Ctx& c, v3& p, m3& R) {
-  const float* L = c.lds; const int tb = c.bi[AGX_H_TOOL_BODY];
+AGX_DEV void tool_base_pose_of(const Ctx& c, int tb, v3& p, m3& R);
+AGX_DEV void tool_base_pose(const Ctx& c, v3& p, m3& R) { tool_base_pose_of(c, c.bi[AGX_H_TOOL_BODY], p, R); }
+AGX_DEV void tool_base_pose_of(const Ctx& c, int tb, v3& p, m3& R) {
+  const float* L = c.lds;
   m3 FR = ldm3(L + L_FREER + 9 * tb); v3 fp = ld3(L + L_ST + c.s_free + 13 * tb);
   p = mul(FR, mk3(FBF(c, tb, AGX_F_REFPOS), FBF(c, tb, AGX_F_REFPOS + 1), FBF(c, tb, AGX_F_REFPOS + 2))) + fp;
   R = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
@@ -160,35 +162,43 @@ AGX_DEV void observe_bed(const Ctx& c, float tool_force, float total_force, floa
     }
   }
 }
-// ArmManipulationEnv._get_obs (arm_manipulation.py:71-110) for a single-arm robot: the one tool is tool_right AND tool_left (:12-14) and
-// the arm joints are listed twice (robot_arm = 'both', robot.py:16); every lane computes, lane 0 writes.
-// tool_force = all contacts of the tool, total_force = total_force_on_human, th_force = tool_force_on_human
-AGX_DEV void observe_arm(const Ctx& c, float tool_force, float total_force, float th_force, float* gobs) {
+// ArmManipulationEnv._get_obs (arm_manipulation.py:71-110).  Single-arm robot: the one tool is tool_right AND tool_left (:12-14) and the arm
+// joints are listed twice (robot_arm = 'both', robot.py:16).  Two-armed robot (AGX_T_TOOL2_BODY > 0): tool 0 = tool_right, the second tool
+// = tool_left, 14 joint angles = right arm then left arm.  Every lane computes, lane 0 writes.
+// tf_r / tf_l = all contacts of the right / left tool, thf_r / thf_l = the same on the human, total_force = total_force_on_human
+AGX_DEV void observe_arm(const Ctx& c, float tf_r, float tf_l, float total_force, float thf_r, float thf_l, float* gobs) {
   const float* L = c.lds;
+  const int tb2 = TKI(c, AGX_T_TOOL2_BODY); const bool dual = tb2 > 0;
   v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
-  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
-  v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
+  v3 sp[2]; m3 sR[2];
+  tool_base_pose(c, sp[0], sR[0]);
+  if (dual) tool_base_pose_of(c, tb2, sp[1], sR[1]); else { sp[1] = sp[0]; sR[1] = sR[0]; }
   v3 jp[5], jpr[5];
   for (int k = 0; k < 3; k++) jp[k] = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + k));        // shoulder, elbow, wrist
   jp[3] = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_STOMACH_BODY)); jp[4] = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_WAIST_BODY));
   for (int k = 0; k < 5; k++) jpr[k] = tmul(BR, jp[k] - bp);
   if (c.lane == 0) {
     int o = 0;
-    for (int rep = 0; rep < 2; rep++) { gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z; gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w; }
-    for (int rep = 0; rep < 2; rep++)
+    for (int t = 0; t < 2; t++) {
+      const v3 spr = tmul(BR, sp[t] - bp); const q4 sq = m3_to_quat(mul_at(BR, sR[t]));
+      gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z; gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
+    }
+    for (int rep = 0; rep < (dual ? 1 : 2); rep++)
       for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
         float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
         gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
       }
     for (int k = 0; k < 5; k++) { gobs[o++] = jpr[k].x; gobs[o++] = jpr[k].y; gobs[o++] = jpr[k].z; }
-    gobs[o++] = tool_force; gobs[o++] = tool_force;
+    gobs[o++] = tf_l; gobs[o++] = tf_r;                 // [tool_left_force, tool_right_force] (:92)
     if (c.coop) {   // human_obs (:98-107), in the frame of the human's base (collision body 0)
       const v3 hb = ld3(L + L_HUMAN); const m3 HR = ldm3(L + L_HUMAN + 3);
-      const v3 sph = tmul(HR, sp - hb); const q4 sqh = m3_to_quat(mul_at(HR, sR));
-      for (int rep = 0; rep < 2; rep++) { gobs[o++] = sph.x; gobs[o++] = sph.y; gobs[o++] = sph.z; gobs[o++] = sqh.x; gobs[o++] = sqh.y; gobs[o++] = sqh.z; gobs[o++] = sqh.w; }
+      for (int t = 0; t < 2; t++) {
+        const v3 sph = tmul(HR, sp[t] - hb); const q4 sqh = m3_to_quat(mul_at(HR, sR[t]));
+        gobs[o++] = sph.x; gobs[o++] = sph.y; gobs[o++] = sph.z; gobs[o++] = sqh.x; gobs[o++] = sqh.y; gobs[o++] = sqh.z; gobs[o++] = sqh.w;
+      }
       for (int d = c.nrobot; d < c.ndof; d++) if (RBI(c, d, AGX_R_ACT) >= 0) gobs[o++] = L[L_ST + c.s_q + d];
       for (int k = 0; k < 5; k++) { const v3 h = tmul(HR, jp[k] - hb); gobs[o++] = h.x; gobs[o++] = h.y; gobs[o++] = h.z; }
-      gobs[o++] = total_force; gobs[o++] = th_force; gobs[o++] = th_force;
+      gobs[o++] = total_force; gobs[o++] = thf_l; gobs[o++] = thf_r;
     }
   }
 }
@@ -416,19 +426,20 @@ AGX_DEV void env_observe(const uint32_t* blob, float* gstate, float* gobs, float
   if constexpr (TASK == AGX_TASK_BED_BATHING) observe_bed(c, 0.f, 0.f, 0.f, gobs);
   else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) observe_scratch(c, 0.f, 0.f, 0.f, gobs);
   else if constexpr (TASK == AGX_TASK_DRESSING) observe_dressing(c, c.lds[L_ST + c.bi[AGX_H_S_TASK] + AGX_DR_FORCE_SUM], 0.f, gobs);
-  else if constexpr (TASK == AGX_TASK_ARM_MANIPULATION) observe_arm(c, 0.f, 0.f, 0.f, gobs);
+  else if constexpr (TASK == AGX_TASK_ARM_MANIPULATION) observe_arm(c, 0.f, 0.f, 0.f, 0.f, 0.f, gobs);
   else observe(c, 0.f, 0.f, gobs);
 }
 
 // end-effector speed: norm of getLinkState(ee, computeLinkVelocity)[6] (feeding.py:22, bed_bathing.py:19)
-AGX_DEV float ee_speed_of(const Ctx& c) {
-  const float* L = c.lds; const int ee = TKI(c, AGX_T_EE_LINK);
+AGX_DEV float frame_speed(const Ctx& c, int link, v3 p) {
+  const float* L = c.lds;
   float sv[6] = {0, 0, 0, 0, 0, 0};
-  for (int d = ee; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { float qd = L[L_ST + c.s_qd + d]; for (int j = 0; j < 6; j++) sv[j] += L[L_S + 6 * d + j] * qd; }
-  v3 xr = ld3(L + L_MISC + M_EEP) - ld3(L + L_MISC + M_REF);
+  for (int d = link; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { float qd = L[L_ST + c.s_qd + d]; for (int j = 0; j < 6; j++) sv[j] += L[L_S + 6 * d + j] * qd; }
+  v3 xr = p - ld3(L + L_MISC + M_REF);
   v3 v = mk3(sv[3], sv[4], sv[5]) + cross(mk3(sv[0], sv[1], sv[2]), xr);
   return sqrtf(dot(v, v));
 }
+AGX_DEV float ee_speed_of(const Ctx& c) { return frame_speed(c, TKI(c, AGX_T_EE_LINK), ld3(c.lds + L_MISC + M_EEP)); }
 
 // finish, bed bathing: everything BedBathingEnv.step does after take_step (bed_bathing.py:15-39)
 AGX_DEV void env_finish_bed(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
@@ -555,22 +566,28 @@ AGX_DEV void env_finish_arm(const uint32_t* blob, float* gstate, const float* ga
   for (int k = 0; k < act_dim; k++) an2 += gaction[k] * gaction[k];
   wave_sync();
   kinematics(c);
-  // get_total_force (:62-69): the one tool is counted as tool_right and as tool_left
-  float rf = 0.f, tf = 0.f, thf = 0.f;
+  // get_total_force (:62-69): the one tool of a single-arm robot is counted as tool_right and as tool_left
+  const int tb2 = TKI(c, AGX_T_TOOL2_BODY); const bool dual = tb2 > 0; const int code2 = AGX_BODY_FREE0 + tb2;
+  float rf = 0.f, tf0 = 0.f, tf1 = 0.f, thf0 = 0.f, thf1 = 0.f;
   if (lane < c.ncon) {
     const float* k = scr.con + CON_STRIDE * lane; const int* ki = (const int*)k;
     const int ta = CLI(c, ki[C_CA], AGX_C_TAG), tb = CLI(c, ki[C_CB], AGX_C_TAG);
     const float f = k[C_LAM] / c.dt;
-    const bool human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
-    if (tool) tf = f;
+    const bool human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
     if (human && robot) rf = f;
-    if (human && tool) thf = f;
+    for (int side = 0; side < 2; side++) {              // a contact between the two tools counts for both
+      const int tag = side ? tb : ta, body = side ? ki[C_BB] : ki[C_BA];
+      if (tag != AGX_TAG_TOOL) continue;
+      if (dual && body == code2) { tf1 += f; if (human) thf1 += f; } else { tf0 += f; if (human) thf0 += f; }
+    }
   }
-  const float robot_f = wave_sum(rf), tool_f = wave_sum(tf), th_f = wave_sum(thf), total_f = robot_f + 2.f * th_f;
-  observe_arm(c, tool_f, total_f, th_f, gobs);
+  const float robot_f = wave_sum(rf); float tf_r = wave_sum(tf0), tf_l = wave_sum(tf1), thf_r = wave_sum(thf0), thf_l = wave_sum(thf1);
+  if (!dual) { tf_l = tf_r; thf_l = thf_r; }
+  const float total_f = robot_f + thf_r + thf_l;
+  observe_arm(c, tf_r, tf_l, total_f, thf_r, thf_l, gobs);
   // tool.get_closest_points(human, distance=0.01) (env.py:264-265): one point per (hull of the tool, shape of the human) pair that close,
   // at the poses after the last substep: lane = pair
-  int near_pts = 0;
+  int near_r = 0, near_l = 0;
   {
     int t0 = -1, t1 = -1, h0 = -1, h1 = -1;
     for (int g = 0; g < c.ngroup; g++) {
@@ -599,20 +616,31 @@ AGX_DEV void env_finish_arm(const uint32_t* blob, float* gstate, const float* ga
       const int p = base + lane; const bool has = p < np;
       const int ti = has ? p / nh : 0, hi = has ? p - ti * nh : 0;
       Cand k; k.dist = lim; k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.gap = 0.f;
-      const bool hit = narrowphase(c, t0 + ti, h0 + hi, lim, k, has);
-      near_pts += popc64(wave_ballot(hit && k.dist < lim));
+      const bool hit = narrowphase(c, t0 + ti, h0 + hi, lim, k, has) && k.dist < lim;
+      const bool second = dual && CLI(c, t0 + ti, AGX_C_BODY) == code2;
+      near_r += popc64(wave_ballot(hit && !second)); near_l += popc64(wave_ballot(hit && second));
     }
+    if (!dual) near_l = near_r;
   }
-  const float ee_speed = 2.f * ee_speed_of(c);                 // right + left end effector: the same link (:26-27)
-  const float pressure = near_pts <= 0 ? 0.f : th_f / (float)near_pts;
+  // right + left end effector (:26-27): the same link on a single-arm robot
+  float ee_speed = ee_speed_of(c);
+  if (dual) {
+    const int l2 = TKI(c, AGX_T_EE2_LINK);
+    const v3 e2 = mul(ldm3(L + L_LINKR + 9 * l2), mk3(TKF(c, AGX_T_EE2_POS), TKF(c, AGX_T_EE2_POS + 1), TKF(c, AGX_T_EE2_POS + 2))) + ld3(L + L_LINKP + 3 * l2);
+    ee_speed += frame_speed(c, l2, e2);
+  } else ee_speed *= 2.f;
+  const float pressure = (near_r <= 0 ? 0.f : thf_r / (float)near_r) + (near_l <= 0 ? 0.f : thf_l / (float)near_l);     // env.py:266-269
   // human_preferences (env.py:237-274): reward_force_nontarget = -(total - (right + left)), tool_force_at_target = 0
-  const float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-(total_f - 2.f * th_f)) + TKF(c, AGX_T_C_P) * (-(2.f * pressure));
-  v3 sp; m3 sR; tool_base_pose(c, sp, sR);
+  const float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-(total_f - thf_r - thf_l)) + TKF(c, AGX_T_C_P) * (-pressure);
+  v3 spr; m3 sRr; tool_base_pose(c, spr, sRr);
+  v3 spl = spr; if (dual) { m3 sRl; tool_base_pose_of(c, tb2, spl, sRl); }
   const v3 elbow = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + 1)), wrist = ld3(L + L_LINKP + 3 * TKI(c, AGX_T_OBS_LINK + 2));
   const v3 stomach = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_STOMACH_BODY)), waist = ld3(L + L_HUMAN + 12 * TKI(c, AGX_T_WAIST_BODY));
-  const v3 d0 = sp - elbow, d1 = elbow - stomach, d2 = wrist - waist;
-  const float rd_left = -sqrtf(dot(d0, d0)), rd_human = -sqrtf(dot(d1, d1)) - sqrtf(dot(d2, d2));      // :36-38
-  const float reward = TKF(c, AGX_T_W_DISTANCE) * rd_human + 2.f * TKF(c, AGX_T_W_WIPE) * rd_left + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + pref;   // :42
+  const v3 d0 = spl - elbow, d3 = spr - wrist, d1 = elbow - stomach, d2 = wrist - waist;
+  const float rd_left = -sqrtf(dot(d0, d0)), rd_right = -sqrtf(dot(d3, d3)), rd_human = -sqrtf(dot(d1, d1)) - sqrtf(dot(d2, d2));      // :36-38
+  const float we = TKF(c, AGX_T_W_WIPE);                                                                   // distance_end_effector_weight
+  const float reward = TKF(c, AGX_T_W_DISTANCE) * rd_human + (dual ? we * rd_left + we * rd_right : 2.f * we * rd_left) + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + pref;   // :41-44
+  const float th_f = dual ? thf_r + thf_l : thf_r; const int near_pts = dual ? near_r + near_l : near_r;
   const int s_task = c.bi[AGX_H_S_TASK];
   const float best0 = L[L_ST + s_task + AGX_AM_BEST], best = (best0 == 0.f || rd_human > best0) ? rd_human : best0;   // :47-48
   const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];

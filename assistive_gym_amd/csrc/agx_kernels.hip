@@ -68,6 +68,16 @@
 #define AGX_TASK 4
 #define AGX_VNAME arm_manipulation
 #define AGX_K(name) name##_am
+#elif defined(AGX_VARIANT_ARM_MANIPULATION_L)
+// arm manipulation with a two-armed robot (PR2: 2 x (7 arm + 4 finger joints); Baxter: 2 x 9): both arms are ONE articulated body of up to
+// 22 DoFs, plus the 10 joints of the human's arm and two free bodies (tool_right, tool_left).  40 KB of LDS per environment in the build kernel.
+#define AGX_MAX_DOF 32
+#define AGX_MAX_FREE 2
+#define AGX_MAX_BLOCK 22
+#define AGX_ARENA_WORDS 7552
+#define AGX_TASK 4
+#define AGX_VNAME arm_manipulation_l
+#define AGX_K(name) name##_aml
 #elif defined(AGX_VARIANT_FEEDING_L)
 // the feeding scene with a free-standing robot (FeedingSawyer, FeedingBaxter, FeedingPR2): the pedestal / torso / other arm add up to 320 colliders
 #define AGX_MAX_COLL 320

@@ -102,7 +102,8 @@ AGX_DEV void m3_to_euler_xyz(const m3& M, float* e) {
 
 // Non-contact row slots, in row order (the oracle builds them in the same order): motors of DoF 0..MAX_DOF-1, joint limits
 // (DoF, side), the 6 rows of the tool constraint.  One lane per slot, NC_PASSES passes of 64 slots.
-constexpr int NC_SLOTS = 3 * MAX_DOF + 6, NC_PASSES = (NC_SLOTS + 63) / 64;
+constexpr int NC_TOOLS = TASK == AGX_TASK_ARM_MANIPULATION ? 2 : 1;            // fixed constraints of tools (two-armed robots hold a second one, AGX_T_TOOL2_BODY)
+constexpr int NC_SLOTS = 3 * MAX_DOF + 6 * NC_TOOLS, NC_PASSES = (NC_SLOTS + 63) / 64;
 AGX_DEV void build_rows(Ctx& c) {
   float* L = c.lds; const int lane = c.lane, n = c.ndof; const float dt = c.dt;
   const float erp = PRM(c, AGX_P_ERP), cerp = PRM(c, AGX_P_CONTACT_ERP);
@@ -150,16 +151,22 @@ AGX_DEV void build_rows(Ctx& c) {
       } else if (slot < NC_SLOTS && c.nfree > 0) {
         // tool fixed constraint (tool.py:46-47): parent frame = end-effector frame o tool offset, child frame = the tool's
         // base (URDF root link) frame
-        const int k = slot - 3 * MAX_DOF; go = true;
+        const int kk = slot - 3 * MAX_DOF, second = kk >= 6, k = second ? kk - 6 : kk;
+        go = !second || TKI(c, AGX_T_TOOL2_BODY) > 0;
         v3 eep = ld3(L + L_MISC + M_EEP); m3 eeR = ldm3(L + L_MISC + M_EER);
-        v3 pivA = mul(eeR, mk3(TKF(c, AGX_T_TOOL_POS), TKF(c, AGX_T_TOOL_POS + 1), TKF(c, AGX_T_TOOL_POS + 2))) + eep;
-        m3 frameA = mul(eeR, quat_to_m3(TKF(c, AGX_T_TOOL_QUAT), TKF(c, AGX_T_TOOL_QUAT + 1), TKF(c, AGX_T_TOOL_QUAT + 2), TKF(c, AGX_T_TOOL_QUAT + 3)));
-        const int tb = c.bi[AGX_H_TOOL_BODY];
+        int o_tp = AGX_T_TOOL_POS, o_tq = AGX_T_TOOL_QUAT, tb = c.bi[AGX_H_TOOL_BODY], link = TKI(c, AGX_T_EE_LINK);
+        if (second && go) {   // the second tool hangs from the other end effector
+          link = TKI(c, AGX_T_EE2_LINK); tb = TKI(c, AGX_T_TOOL2_BODY); o_tp = AGX_T_TOOL2_POS; o_tq = AGX_T_TOOL2_QUAT;
+          const v3 lp = ld3(L + L_LINKP + 3 * link); const m3 LR = ldm3(L + L_LINKR + 9 * link);
+          eep = mul(LR, mk3(TKF(c, AGX_T_EE2_POS), TKF(c, AGX_T_EE2_POS + 1), TKF(c, AGX_T_EE2_POS + 2))) + lp;
+          eeR = mul(LR, quat_to_m3(TKF(c, AGX_T_EE2_QUAT), TKF(c, AGX_T_EE2_QUAT + 1), TKF(c, AGX_T_EE2_QUAT + 2), TKF(c, AGX_T_EE2_QUAT + 3)));
+        }
+        v3 pivA = mul(eeR, mk3(TKF(c, o_tp), TKF(c, o_tp + 1), TKF(c, o_tp + 2))) + eep;
+        m3 frameA = mul(eeR, quat_to_m3(TKF(c, o_tq), TKF(c, o_tq + 1), TKF(c, o_tq + 2), TKF(c, o_tq + 3)));
         const m3 FR = ldm3(L + L_FREER + 9 * tb);
         v3 pivB = mul(FR, mk3(FBF(c, tb, AGX_F_REFPOS), FBF(c, tb, AGX_F_REFPOS + 1), FBF(c, tb, AGX_F_REFPOS + 2))) + ld3(L + L_ST + c.s_free + 13 * tb);
         m3 frameB = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
         float lim = TKF(c, AGX_T_TOOL_MAXF) * dt; rlo = -lim; rhi = lim;
-        const int link = TKI(c, AGX_T_EE_LINK);
         if (k < 3) {
           v3 nrm = mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f);
           row_pair(c, R, link, pivA, AGX_BODY_FREE0 + tb, pivB, nrm, mk3(0, 0, 0));

@@ -42,3 +42,4 @@ extern "C" const agx_variant* agx_variant_arm_manipulation(void);
 extern "C" const agx_variant* agx_variant_bed_bathing_l(void);
 extern "C" const agx_variant* agx_variant_feeding_l(void);
 extern "C" const agx_variant* agx_variant_dressing_l(void);
+extern "C" const agx_variant* agx_variant_arm_manipulation_l(void);

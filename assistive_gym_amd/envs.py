@@ -393,7 +393,8 @@ _robot_flavours(BedBathingSawyerEnv, 'BedBathing', [('Jaco', 'bed_bathing_jaco')
                 'bed_bathing_envs.py:15-37,45-79')
 _robot_flavours(FeedingSawyerEnv, 'Feeding', [('PR2', 'feeding_pr2')], 'feeding_envs.py:17-19,41-44')
 _robot_flavours(DressingBaxterEnv, 'Dressing', [('Sawyer', 'dressing_sawyer'), ('Jaco', 'dressing_jaco'), ('Panda', 'dressing_panda'), ('PR2', 'dressing_pr2')], 'dressing_envs.py:23-37,56-79')
-_robot_flavours(ArmManipulationSawyerEnv, 'ArmManipulation', [('Jaco', 'arm_manipulation_jaco'), ('Panda', 'arm_manipulation_panda')], 'arm_manipulation_envs.py:27-37,63-79')
+_robot_flavours(ArmManipulationSawyerEnv, 'ArmManipulation', [('Jaco', 'arm_manipulation_jaco'), ('Panda', 'arm_manipulation_panda'), ('PR2', 'arm_manipulation_pr2'),
+                                                              ('Baxter', 'arm_manipulation_baxter')], 'arm_manipulation_envs.py:15-37,41-79')
 _robot_flavours(ScratchItchPR2Env, 'ScratchItch', [('Baxter', 'scratch_itch_baxter')], 'scratch_itch_envs.py:21-23,46-50')
 
 

@@ -28,6 +28,8 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
         assert blob.task_kind == L.TASK_ARM_MANIPULATION
         self.blob = blob
         self.arm = ArmChain(blob)
+        self.dual = bool(blob.meta.get('dual'))          # a two-armed robot: tool_right in the right hand (self.arm), tool_left in the left (self.arm2)
+        self.arm2 = ArmChain(blob, second=True) if self.dual else None
         self.human_bodies = blob.meta['human_bodies']
         self.human_dyn = blob.meta['human_dynamic_joints']
         m = blob.meta
@@ -51,12 +53,15 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
                 v['human'][0, k, :3], v['human'][0, k, 3:] = hpos[link], hquat[link]
         return hpos
 
-    def _place(self, v, rb_pos, rb_quat, q_arm):
-        """robot joints, base and the tool in the gripper (tool.py:49-62)"""
+    def _place(self, v, rb_pos, rb_quat, q_arm, q_arm2=None):
+        """robot joints, base and the tool(s) in the gripper(s) (tool.py:49-62)"""
         b, nr = self.blob, self.blob.nrobot
         q = np.zeros(nr)
         for k, d in enumerate(self.arm.chain):
             q[d] = q_arm[k]
+        if self.dual:
+            for k, d in enumerate(self.arm2.chain):
+                q[d] = q_arm2[k]
         for d in range(nr):                                                        # gripper open position, set instantly (:170)
             if b.robot_i(d, 'ACT') < 0:
                 q[d] = min(max(b.robot_f(d, 'QT0'), b.robot_f(d, 'LOWER')), b.robot_f(d, 'UPPER'))
@@ -71,6 +76,11 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
         free = v['free'][0]
         free[:] = 0
         free[0, :3], free[0, 3:7] = cp, cq
+        if self.dual:
+            pe, Re, _, _ = self.arm2.fk(np.asarray(rb_pos)[None], X.quat_to_mat(rb_quat)[None], q_arm2[None])
+            tp, tq = X.compose(pe[0], X.mat_to_quat(Re[0]), b.task_f('TOOL2_POS', 3), b.task_f('TOOL2_QUAT', 4))
+            ip, iq = X.invert(b.free_f(1, 'REFPOS', 3), b.free_f(1, 'REFQUAT', 4))
+            free[1, :3], free[1, 3:7] = X.compose(tp, tq, ip, iq)
 
     def arm_fall_record(self, state_row, pre, env_seed=0):
         """the record the second settle starts from (:136-142): the human resting, its right arm posed, the robot parked"""
@@ -85,7 +95,11 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
         pre['hq'] = hq
         self._fill_human(v, pre)
         lo, hi = self.arm.lower, self.arm.upper                                     # parked at the middle of its joint ranges (the Jaco's zero pose violates its limits)
-        self._place(v, PARKED, np.array([0, 0, 0, 1.0]), np.where((lo > -1e9) & (hi < 1e9), 0.5 * (lo + hi), 0.0))
+        mid2 = None
+        if self.dual:
+            lo2, hi2 = self.arm2.lower, self.arm2.upper
+            mid2 = np.where((lo2 > -1e9) & (hi2 < 1e9), 0.5 * (lo2 + hi2), 0.0)
+        self._place(v, PARKED, np.array([0, 0, 0, 1.0]), np.where((lo > -1e9) & (hi < 1e9), 0.5 * (lo + hi), 0.0), mid2)
         hq_dyn = np.array([hq[j] for j in self.human_dyn])
         v['q'][0, nr:] = hq_dyn
         v['qt'][0, nr:] = hq_dyn
@@ -115,18 +129,23 @@ class ArmManipulationSawyerReset(BedBathingSawyerReset):
         hpos, _ = hm.fk(pre['base_pos'], pre['base_quat'], hq)
         elbow, wrist, stomach, waist = hpos[7], hpos[9], hpos[24], hpos[27]        # :148-151
         if attempt == 0:
-            pre['target_ee_pos'] = np.array([-1, 0.4, 0.8]) + rng.uniform(-0.05, 0.05, size=3)    # :158 (single arm)
-            rng.uniform(-0.05, 0.05, size=3)                                       # :159 target_ee_left_pos is drawn as well
+            pre['target_ee_pos'] = np.array([-1, -0.3 if self.dual else 0.4, 0.8]) + rng.uniform(-0.05, 0.05, size=3)    # :158
+            pre['target_ee_left_pos'] = np.array([-1, 0.7, 0.8]) + rng.uniform(-0.05, 0.05, size=3)                    # :159 (drawn for a single arm as well)
         target_ee_pos = pre['target_ee_pos']
         prng = placement_rng(rng, env_seed, attempt)
-        toc = None
+        toc, q_arm2 = None, None
         for _ in range(4):
-            toc = self._toc(prng, target_ee_pos, [wrist, waist, elbow, stomach])   # :162
+            if self.dual:     # :165: the right arm's goals are wrist and waist, the left arm's elbow and stomach
+                toc = self._toc_dual(prng, [self.arm, self.arm2], [target_ee_pos, pre['target_ee_left_pos']], [[wrist, waist], [elbow, stomach]])
+            else:
+                toc = self._toc(prng, target_ee_pos, [wrist, waist, elbow, stomach])   # :162
             if toc is not None:
                 break
         assert toc is not None, 'no reachable base pose found'
         rb_pos, rb_quat, q_arm, ngoal, manip = toc
-        self._place(v, rb_pos, rb_quat, q_arm)
+        if self.dual:
+            q_arm, q_arm2 = q_arm
+        self._place(v, rb_pos, rb_quat, q_arm, q_arm2)
         v['iteration'][0] = 0
         v['task_success'][0] = 0
         v['task'][0] = 0                                                           # AM_BEST: task_success = 0 (init_env_variables)

@@ -31,9 +31,10 @@ D = np.deg2rad
 class ArmChain:
     """Batched (numpy) kinematics of the serial chain base -> end-effector link of the compiled robot."""
 
-    def __init__(self, blob):
+    def __init__(self, blob, second=False):
+        """second: the chain to the second end effector (AGX_T_EE2_*: the left arm of a two-armed robot holding tool_left)"""
         self.blob = blob
-        ee = blob.task_i('EE_LINK')
+        ee = blob.task_i('EE2_LINK' if second else 'EE_LINK')
         chain = []
         d = ee
         while d >= 0:
@@ -48,8 +49,8 @@ class ArmChain:
         self.upper = np.array([blob.robot_f(d, 'UPPER') for d in self.chain])
         self.act = [blob.robot_i(d, 'ACT') for d in self.chain]
         assert all(a >= 0 for a in self.act), 'every joint between the base and the end effector is an arm joint'
-        self.ee_pos = blob.task_f('EE_POS', 3)
-        self.ee_R = X.quat_to_mat(blob.task_f('EE_QUAT', 4))
+        self.ee_pos = blob.task_f('EE2_POS' if second else 'EE_POS', 3)
+        self.ee_R = X.quat_to_mat(blob.task_f('EE2_QUAT' if second else 'EE_QUAT', 4))
         self.n = len(self.chain)
 
     @staticmethod
@@ -355,6 +356,49 @@ class BedBathingSawyerReset:
             if ok.any():
                 break
         return np.asarray(base_pos, dtype=np.float64).copy(), np.asarray(base_quat, dtype=np.float64), best[1], 1 if best[2] else 0, 0.0
+
+    def _toc_dual(self, rng, arms, starts, goals, attempts=50):
+        """Robot.position_robot_toc with arms = ['right', 'left'] (robot.py:123-215): one base pose for both arms; the goals an arm reaches
+        and its manipulability add up over the arms, both start poses must be reachable.  arms: [ArmChain, ArmChain]; starts[i]: start
+        position of arm i (orientation self.ee_R); goals[i]: position-only goals of arm i.  Returns (base_pos, base_quat, [q_arm_i], goals
+        reached, manipulability) or None."""
+        A = attempts
+        rp = np.stack([rng.uniform(-0.5, 0, size=A), rng.uniform(-0.5, 0.5, size=A), np.zeros(A)], axis=1)
+        yaw = D(rng.uniform(-30, 30, size=A))
+        base_pos = self.toc_base[None] + rp
+        base_R = np.array([X.quat_to_mat(X.quat_from_rpy([0, 0, y])) for y in yaw])
+        ngoal, manip, valid = np.zeros(A), np.zeros(A), np.ones(A, dtype=bool)
+        qstart = []
+        for arm, start, gl in zip(arms, starts, goals):
+            lo = np.where(arm.lower < -1e9, -2 * np.pi, arm.lower)
+            hi = np.where(arm.upper > 1e9, 2 * np.pi, arm.upper)
+            ng = 1 + len(gl)
+            q0 = rng.uniform(lo, hi, size=(A, ng, arm.n))
+            for g in range(ng):
+                tp = np.repeat((start if g == 0 else gl[g - 1])[None], A, axis=0)
+                tR = np.repeat(self.ee_R[None], A, axis=0) if g == 0 else None
+                q = arm.ik(base_pos, base_R, q0[:, g], tp, tR, iters=100)
+                pe, Re, orig, axw = arm.fk(base_pos, base_R, q)
+                ok = np.linalg.norm(tp - pe, axis=1) < 0.03
+                if tR is not None:
+                    qe, qt = mat_to_quat_batch(Re), X.mat_to_quat(self.ee_R)
+                    ok &= np.minimum(np.linalg.norm(qe - qt[None], axis=1), np.linalg.norm(qe + qt[None], axis=1)) < 0.03
+                J = arm.jacobian(pe, orig, axw)
+                W = joint_limited_weighting(q, arm.lower, arm.upper)
+                M = np.einsum('bij,bj,bkj->bik', J, W, J)
+                det = np.maximum(np.linalg.det(M), 0)
+                jl = np.power(det, 1.0 / 6) / (np.trace(M, axis1=1, axis2=2) / 6)
+                ngoal += ok
+                manip += np.where(ok, jl, 0.0)
+                if g == 0:
+                    valid &= ok
+                    qstart.append(q)
+        ngoal = np.where(valid, ngoal, -1)
+        manip = np.where(valid, manip, -np.inf)
+        best = max(range(A), key=lambda a: (ngoal[a], manip[a]))
+        if ngoal[best] <= 0:
+            return None
+        return base_pos[best], X.mat_to_quat(base_R[best]), [q[best] for q in qstart], int(ngoal[best]), float(manip[best])
 
     def sample(self, rng, state_row, env_seed=0, impairment='random', gender='random', info=None, human_q_override=None):
         """Fill one state record (float32 view of length state_words) in place, with the 'drop' stand-in for the settle."""

@@ -45,7 +45,8 @@ T = dict(W_DISTANCE=0, W_ACTION=1, W_FOOD=2, C_V=3, C_F=4, C_HF=5, C_FD=6, C_FDV
          SPILL_DIST=10, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26,
          TOOL_QUAT=29, TOOL_MAXF=33, EPISODE_LEN=34, COOP=35, TOOL_OBS_POS=36, TOOL_OBS_QUAT=39, W_WIPE=43, TARGET_RADIUS=44,
          CLOSEST_DIST=45, PAD_LINK=46, ARM_LINK=47, OBS_LINK=49, NT=52, NT_MAX=56, ARM_LIMIT_ON=57, ARM_LIMIT_DOF=58, ARM_LIMIT_SIGN=62, C_D=64,
-         ARM_RADIUS=65, C_P=67, STOMACH_BODY=68, WAIST_BODY=69, DUP_ACT=70, PRESSURE_DIST=71, COUNT=72)
+         ARM_RADIUS=65, C_P=67, STOMACH_BODY=68, WAIST_BODY=69, DUP_ACT=70, PRESSURE_DIST=71,
+         TOOL2_BODY=72, EE2_LINK=73, EE2_POS=74, EE2_QUAT=77, TOOL2_POS=81, TOOL2_QUAT=84, COUNT=88)
 # reset section (sampling ranges of FeedingEnv.reset + the posed-human kinematic tree), see agx_blob.h
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
@@ -73,7 +74,7 @@ MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathin
 # pair-group flags (AGX_G_FLAGS)
 GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC = 1, 2, 4, 8, 16, 32
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 9
+MAGIC, VERSION = 0x31584741, 10
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -1084,6 +1085,16 @@ def robot_table(task, robot):
     return RB
 
 
+# the RIGHT arms of the two-armed robots (feeding: robot_arm = 'right'; arm manipulation: 'both')
+ROBOT_RIGHT = dict(
+    pr2=dict(arm=[42, 43, 44, 46, 47, 49, 50], grip=[57, 58, 59, 60], gripper_collision=set(range(49, 64)), ee_pb=54, tool_pb=54),      # pr2.py:8,13,17,11,15
+    baxter=dict(arm=[12, 13, 14, 15, 16, 18, 19], grip=[27, 29], gripper_collision={25, 27, 28, 29, 30}, ee_pb=26, tool_pb=25))         # baxter.py:8,13,17,11,15
+# arm manipulation with two tools (arm_manipulation.py:15-16): per-task numbers of the two-armed robots (pr2.py:24-46, baxter.py:24-46)
+ARM_MANIPULATION_DUAL = dict(
+    pr2=dict(gripper_target=[0.15] * 4, tool_pos=[0.125, 0, -0.075], tool_rpy=[H_PI, 0, 0], toc_base=[-0.3, 0.7, 0], ee_rpy=[0, 0, 0]),
+    baxter=dict(gripper_target=[0.01, -0.01], tool_pos=[0.075, 0.235, 0], tool_rpy=[0, 0, H_PI], toc_base=[-0.3, 0.6, 0.925], ee_rpy=[0, -H_PI, np.pi]))
+
+
 # scratch itch: a wheelchair-mounted robot stays at the wheelchair position [0, 0, 0.06] + toc_base, rpy [0, 0, -pi/2] (scratch_itch.py:97-99,
 # mount 'wheelchair'); the others get their base pose from Robot.position_robot_toc around [-0.85, -0.4, 0] + toc_base (robot.py:142, 'toc')
 SCRATCH_ROBOTS = {r: dict(robot_table('scratch_itch', r), mount='wheelchair' if ROBOT_BASE[r]['wheelchair_mounted'] else 'toc') for r in ROBOT_TASK['scratch_itch']}
@@ -1403,6 +1414,102 @@ def compile_arm_manipulation(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull
                 task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, robot=robot, toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
 
 
+def compile_arm_manipulation_dual(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
+    """ArmManipulationPR2-v1 / ArmManipulationBaxter-v1 (arm_manipulation_envs.py:15-21): robot_arm = 'both' on a two-armed robot -- the
+    right arm holds tool_right (the scooper whose distance to the WRIST is rewarded), the left arm tool_left (distance to the ELBOW)
+    (arm_manipulation.py:15-16,36-37,44); 14 actions (right arm, then left arm), both arms dynamic, two free bodies, two fixed
+    constraints (AGX_T_TOOL2_BODY, AGX_T_EE2_*).  Everything that is neither an arm nor a gripper joint (head, torso, casters) is static
+    geometry at its rest pose [deviation, as in compile_scratch_itch]."""
+    sc = Scene()
+    LB, RBR, TK = ROBOT_BASE[robot], ROBOT_RIGHT[robot], ARM_MANIPULATION_DUAL[robot]
+    arm = RBR['arm'] + LB['arm']                        # controllable_joint_indices: right arm, then left arm (robot.py:16)
+    grip = RBR['grip'] + LB['grip']
+    urdf_path = os.path.join(assets, *LB['urdf'])
+    u0 = Urdf(urdf_path)
+    frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+    rob = compile_robot(urdf_path, arm, grip, gripper_target=TK['gripper_target'] + TK['gripper_target'], motor_gain=0.05, motor_force=20.0,   # robot.py:37, arm_manipulation.py:114
+                        max_hull_verts=robot_hull_max_verts, frozen=frozen, use_file_inertia=LB.get('file_inertia', False))
+    nrobot = len(rob['dof_links'])
+    gcr, gcl = RBR['gripper_collision'], LB['gripper_collision']
+    add_robot_colliders(sc, rob, 'robot_grip_r', lambda pb: pb in gcr)          # no collision with tool_right (tool.py:42-44)
+    add_robot_colliders(sc, rob, 'robot_rest', lambda pb: pb not in gcr and pb not in gcl)
+    add_robot_colliders(sc, rob, 'robot_grip_l', lambda pb: pb in gcl)          # no collision with tool_left
+    sc.begin('robot_base')
+    for verts, radius, fr, pb in rob['base_colliders']:
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    sc.end('robot_base')
+    scoop = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'arm_manipulation', 'arm_manipulation_scooper_vhacd.obj'), 0.001)]   # arm_manipulation.py:159-161
+    allv = np.concatenate(scoop)
+    free = [dict(mass=1.0, inertia=box_inertia(1.0, allv.min(0) - HULL_MARGIN, allv.max(0) + HULL_MARGIN), gravity=0.0,                             # tool.py:10; gravity 0: :177-179
+                 refpos=np.zeros(3), refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0) for _ in range(2)]
+    for t, name in enumerate(('tool_r', 'tool_l')):
+        sc.begin(name)
+        for hv in scoop:
+            sc.add(BODY_FREE0 + t, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['TOOL'])
+        sc.end(name)
+    sc.ranges['tool'] = (sc.ranges['tool_r'][0], sc.ranges['tool_l'][1])
+    hd = list(range(10))                                # human.right_arm_joints (arm_manipulation_envs.py:14)
+
+    def split(link):
+        return 'pecs' if link == 2 else ('arm' if 3 <= link <= 9 else 'rest')
+    human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.05, maxf=2.0, act0=len(arm), split=split)     # human.motor_forces = 2 (:115)
+    sc.begin('bed')     # friction 0.3 once the human has settled (arm_manipulation.py:138)
+    bq = X.quat_from_rpy([np.pi / 2, 0, 0])
+    for g in load_obj_groups(os.path.join(assets, 'bed', 'bed_single_reduced_vhacd.obj'), 1.1):
+        sc.add(BODY_WORLD, X.apply(np.array([-0.1, 0, 0.0]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), bq, convex_hull_vertices(g))), HULL_MARGIN, 0.3, TAG['BED'])
+    sc.end('bed')
+    sc.begin('plane')
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    G_ = Groups(sc.ranges)
+    grp = G_.add
+    G_.rg['robot_links'] = (G_.rg['robot_grip_r'][0], G_.rg['robot_grip_l'][1])
+    G_.rg['robot_not_grip_r'] = (G_.rg['robot_rest'][0], G_.rg['robot_grip_l'][1])
+    G_.rg['robot_not_grip_l'] = (G_.rg['robot_grip_r'][0], G_.rg['robot_rest'][1])
+    grp('tool', 'human_male', alt='human_female')       # both tools: the finish kernel's near-point sweep tells them apart by their body
+    grp('robot_links', 'human_male', alt='human_female', keep=2)
+    grp('robot_base', 'human_male', alt='human_female', keep=2, flags=GF_HUMAN_DYNAMIC)
+    grp('tool', 'bed', keep=2)
+    grp('robot_links', 'bed', keep=2)
+    grp('robot_not_grip_r', 'tool_r')
+    grp('robot_not_grip_l', 'tool_l')
+    grp('robot_base', 'tool')
+    grp('tool_r', 'tool_l')
+    grp('robot_links', 'plane')
+    grp('tool', 'plane')
+    for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
+        G_.rg['harm_' + gender] = (G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][1])
+        grp('human_%s_arm' % gender, 'human_%s_rest' % gender, flags=gf | GF_HUMAN_DYNAMIC)
+        grp('harm_' + gender, 'bed', keep=2, flags=gf | GF_HUMAN_DYNAMIC)
+    groups = G_.rows
+    ee_r, ee_l = RBR['ee_pb'], LB['ee_pb']
+    link_r, link_l = rob['dof_of_pb'][rob['carrier'][ee_r]], rob['dof_of_pb'][rob['carrier'][ee_l]]
+    tpos_r, tquat_r = tool_offset_in_ee_frame(rob, ee_r, RBR['tool_pb'], TK['tool_pos'], TK['tool_rpy'])
+    tpos_l, tquat_l = tool_offset_in_ee_frame(rob, ee_l, LB['tool_pb'], TK['tool_pos'], TK['tool_rpy'])
+    task_f = dict(W_DISTANCE=0.5, W_WIPE=0.25, W_ACTION=0.01, SUCCESS_FRAC=-0.7,         # config.ini:33-37
+                  C_V=0.25, C_F=0.01, C_HF=0.05, C_P=0.01, PRESSURE_DIST=0.01,             # config.ini:40-42,46; env.py:262
+                  EE_POS=rob['rel'][ee_r][0], EE_QUAT=rob['rel'][ee_r][1], TOOL_POS=tpos_r, TOOL_QUAT=tquat_r,
+                  EE2_POS=rob['rel'][ee_l][0], EE2_QUAT=rob['rel'][ee_l][1], TOOL2_POS=tpos_l, TOOL2_QUAT=tquat_l,
+                  TOOL_OBS_POS=[0, 0, 0], TOOL_OBS_QUAT=[0, 0, 0, 1.0], TOOL_MAXF=500.0, EPISODE_LEN=200, ARM_LIMIT_SIGN=-1.0)
+    task_i = dict(EE_LINK=link_r, EE2_LINK=link_l, TOOL2_BODY=1, PAD_LINK=0, ARM_LINK=[nrobot + 5, nrobot + 7], OBS_LINK=[nrobot + 5, nrobot + 7, nrobot + 9], HEAD_LINK=-1,
+                  ARM_LIMIT_DOF=[nrobot + 3, nrobot + 4, nrobot + 5, nrobot + 6], ARM_LIMIT_ON=0,
+                  STOMACH_BODY=human_bodies.index(24), WAIST_BODY=human_bodies.index(27), DUP_ACT=0)
+    from .h5lite import load_keras_dense_stack
+    mlp = load_keras_dense_stack(os.path.join(assets, 'realistic_arm_limits_model.h5'))
+    params = default_params(n_iter)
+    params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-9.81)                               # arm_manipulation.py:120-121,176
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT']
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        pass        # the pool comes from assistive_gym_amd/host/reset_arm.py
+    return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=31 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_ARM_MANIPULATION), reset_fill, reset_words,
+                task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, robot=robot, dual=True, toc_base=list(TK['toc_base']), ee_rpy=list(TK['ee_rpy']),
+                                                                 right_arm_joints=RBR['arm'], left_arm_joints=LB['arm']))
+
+
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda,
                  feeding_sawyer=lambda *a, **k: compile_feeding('sawyer', *a, **k), feeding_baxter=lambda *a, **k: compile_feeding('baxter', *a, **k), feeding_pr2=lambda *a, **k: compile_feeding('pr2', *a, **k),
                  bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
@@ -1413,7 +1520,8 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  dressing_sawyer=lambda *a, **k: compile_dressing('sawyer', *a, **k), dressing_jaco=lambda *a, **k: compile_dressing('jaco', *a, **k),
                  dressing_panda=lambda *a, **k: compile_dressing('panda', *a, **k), dressing_pr2=lambda *a, **k: compile_dressing('pr2', *a, **k),
                  arm_manipulation_sawyer=compile_arm_manipulation_sawyer, arm_manipulation_jaco=lambda *a, **k: compile_arm_manipulation('jaco', *a, **k),
-                 arm_manipulation_panda=lambda *a, **k: compile_arm_manipulation('panda', *a, **k))
+                 arm_manipulation_panda=lambda *a, **k: compile_arm_manipulation('panda', *a, **k),
+                 arm_manipulation_baxter=lambda *a, **k: compile_arm_manipulation_dual('baxter', *a, **k), arm_manipulation_pr2=lambda *a, **k: compile_arm_manipulation_dual('pr2', *a, **k))
 
 
 def main(names=None):

@@ -251,6 +251,8 @@ _vec_flavour(FeedingSawyerVecEnv, 'FeedingPR2VecEnv', 'feeding_pr2')
 
 _vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationJacoVecEnv', 'arm_manipulation_jaco')
 _vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationPandaVecEnv', 'arm_manipulation_panda')
+_vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationPR2VecEnv', 'arm_manipulation_pr2')          # two arms, two tools
+_vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationBaxterVecEnv', 'arm_manipulation_baxter')
 
 
 class DressingBaxterVecEnv(AssistiveVecEnv):

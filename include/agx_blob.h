@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 9
+#define AGX_BLOB_VERSION 10
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -217,7 +217,15 @@ enum {
   AGX_T_DUP_ACT = 70,       /* int: a single-arm robot driven as 'both' arms (arm_manipulation_envs.py:13, robot.py:16) lists its arm joints
                              * twice: ACT_DIM counts both copies, the second copy's targets win, the observation reports the angles twice */
   AGX_T_PRESSURE_DIST = 71, /* float: range of tool.get_closest_points(human) that counts contact points for the pressure term (env.py:262) */
-  AGX_T_COUNT = 72
+  /* a second tool in the robot's other hand (two-armed robots in arm manipulation: tool_left, arm_manipulation.py:15-16; the first
+   * tool -- AGX_H_TOOL_BODY, AGX_T_EE_LINK ... -- is tool_right) */
+  AGX_T_TOOL2_BODY = 72,    /* int: free-body index of the second tool, 0 = there is none                                            */
+  AGX_T_EE2_LINK = 73,      /* int: moving link carrying the second end-effector frame (robot.left_end_effector)                     */
+  AGX_T_EE2_POS = 74,       /* float[3] that frame in the link frame                                                                 */
+  AGX_T_EE2_QUAT = 77,      /* float[4]                                                                                              */
+  AGX_T_TOOL2_POS = 81,     /* float[3] pivot of the second tool in its end-effector frame                                           */
+  AGX_T_TOOL2_QUAT = 84,    /* float[4]                                                                                              */
+  AGX_T_COUNT = 88
 };
 
 /* ---- RESET section (offset AGX_H_OFF_RESET): what FeedingEnv.reset samples (feeding.py:114-172, human.py:72-102,

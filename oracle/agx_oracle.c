@@ -798,12 +798,15 @@ static void plane_space(const double* n, double* p) { /* first tangent of btPlan
   if (fabs(n[2]) > 0.7071067811865475244) { double a = n[1] * n[1] + n[2] * n[2], k = 1.0 / sqrt(a); p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k; }
   else { double a = n[0] * n[0] + n[1] * n[1], k = 1.0 / sqrt(a); p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0; }
 }
-static void ee_frame(const sim_t* s, xf_t* ee) {
-  const agxo_model* m = s->m; int L = TI(m, AGX_T_EE_LINK);
-  double p[3] = {TF(m, AGX_T_EE_POS), TF(m, AGX_T_EE_POS + 1), TF(m, AGX_T_EE_POS + 2)};
-  double q[4] = {TF(m, AGX_T_EE_QUAT), TF(m, AGX_T_EE_QUAT + 1), TF(m, AGX_T_EE_QUAT + 2), TF(m, AGX_T_EE_QUAT + 3)}, Rq[9];
+/* end-effector frame of tool t: 0 = robot.right_end_effector (AGX_T_EE_*), 1 = the second tool's (AGX_T_EE2_*) */
+static void ee_frame_of(const sim_t* s, int t, xf_t* ee) {
+  const agxo_model* m = s->m; int L = TI(m, t ? AGX_T_EE2_LINK : AGX_T_EE_LINK), op = t ? AGX_T_EE2_POS : AGX_T_EE_POS, oq = t ? AGX_T_EE2_QUAT : AGX_T_EE_QUAT;
+  double p[3] = {TF(m, op), TF(m, op + 1), TF(m, op + 2)};
+  double q[4] = {TF(m, oq), TF(m, oq + 1), TF(m, oq + 2), TF(m, oq + 3)}, Rq[9];
   quat_to_mat(q, Rq); xf_apply(&s->link[L], p, ee->p); mm3(s->link[L].R, Rq, ee->R);
 }
+static void ee_frame(const sim_t* s, xf_t* ee) { ee_frame_of(s, 0, ee); }
+static int n_tools(const agxo_model* m) { return m->nfree > 0 ? (TI(m, AGX_T_TOOL2_BODY) > 0 ? 2 : 1) : 0; }
 
 /* number of articulated DoF entries a row stores: the robot block, the human block, or both */
 static int art_entries_of(const sim_t* s, int has_robot, int has_human) {
@@ -852,12 +855,13 @@ static void build_rows(sim_t* s) {
   }
   /* tool fixed constraint (tool.py:46-47): 3 linear rows along world axes at the pivots,
    * 3 angular rows about the parent frame axes; impulse clamp maxForce*dt */
-  const int has_tool = m->nfree > 0;
-  if (has_tool) {
-    xf_t ee; ee_frame(s, &ee);
-    int L = TI(m, AGX_T_EE_LINK), tb = m->tool_body, code_b = AGX_BODY_FREE0 + tb;
-    double tp[3] = {TF(m, AGX_T_TOOL_POS), TF(m, AGX_T_TOOL_POS + 1), TF(m, AGX_T_TOOL_POS + 2)};
-    double tq[4] = {TF(m, AGX_T_TOOL_QUAT), TF(m, AGX_T_TOOL_QUAT + 1), TF(m, AGX_T_TOOL_QUAT + 2), TF(m, AGX_T_TOOL_QUAT + 3)};
+  const int ntool = n_tools(m), has_tool = ntool > 0;
+  for (int t = 0; t < ntool; t++) {
+    xf_t ee; ee_frame_of(s, t, &ee);
+    int L = TI(m, t ? AGX_T_EE2_LINK : AGX_T_EE_LINK), tb = t ? TI(m, AGX_T_TOOL2_BODY) : m->tool_body, code_b = AGX_BODY_FREE0 + tb;
+    const int otp = t ? AGX_T_TOOL2_POS : AGX_T_TOOL_POS, otq = t ? AGX_T_TOOL2_QUAT : AGX_T_TOOL_QUAT;
+    double tp[3] = {TF(m, otp), TF(m, otp + 1), TF(m, otp + 2)};
+    double tq[4] = {TF(m, otq), TF(m, otq + 1), TF(m, otq + 2), TF(m, otq + 3)};
     double pivA[3], Rt[9], frameA[9];
     xf_apply(&ee, tp, pivA); quat_to_mat(tq, Rt); mm3(ee.R, Rt, frameA);
     /* child frame = the tool's base (URDF root link) frame: COM frame o REF */
@@ -893,7 +897,7 @@ static void build_rows(sim_t* s) {
   {
     int ent = 1, maxent = (int)PARAM(m, AGX_P_MAX_ENTRIES);
     /* non-contact rows: motors and limits address the robot; the 6 tool rows (last) robot + tool */
-    for (int r0 = 0; r0 < first_normal; r0++) ent += row_art_entries(s, &s->rows[r0]) + (has_tool && r0 >= first_normal - 6 ? 6 : 0);
+    for (int r0 = 0; r0 < first_normal; r0++) ent += row_art_entries(s, &s->rows[r0]) + (has_tool && r0 >= first_normal - 6 * ntool ? 6 : 0);
     int acc = 0;
     for (int c = 0; c < s->ncon; c++) {
       const contact_t* k = &s->con[c];
@@ -1223,8 +1227,10 @@ static void to_base_frame(const sim_t* s, const double* p, const double* R, doub
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Bt[3 * r + c] = s->base.R[3 * c + r];
     mm3(Bt, R, Rr); mat_to_quat(Rr, qo); }
 }
-static void tool_base_pose(const sim_t* s, double* p, double* R) {
-  const agxo_model* m = s->m; int tb = m->tool_body;
+static void tool_base_pose_of(const sim_t* s, int tb, double* p, double* R);
+static void tool_base_pose(const sim_t* s, double* p, double* R) { tool_base_pose_of(s, s->m->tool_body, p, R); }
+static void tool_base_pose_of(const sim_t* s, int tb, double* p, double* R) {
+  const agxo_model* m = s->m;
   double rp[3] = {FF(m, tb, AGX_F_REFPOS), FF(m, tb, AGX_F_REFPOS + 1), FF(m, tb, AGX_F_REFPOS + 2)};
   double rq[4] = {FF(m, tb, AGX_F_REFQUAT), FF(m, tb, AGX_F_REFQUAT + 1), FF(m, tb, AGX_F_REFQUAT + 2), FF(m, tb, AGX_F_REFQUAT + 3)}, Rr[9];
   quat_to_mat(rq, Rr); xf_apply(&s->freex[tb], rp, p); mm3(s->freex[tb].R, Rr, R);
@@ -1374,51 +1380,66 @@ static void finish_bed(sim_t* s, const float* action, float* obs, float* reward,
     info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
   }
 }
-/* ArmManipulationEnv._get_obs (arm_manipulation.py:71-110) for a single-arm robot: tool_left IS tool_right (:12-14), so the tool pose
- * and the tool forces appear twice; the arm joints are listed twice as well (robot_arm = 'both', robot.py:16) */
-static void observe_arm(sim_t* s, double tool_force, double total_force, double tool_human_force, float* obs) {
+/* ArmManipulationEnv._get_obs (arm_manipulation.py:71-110).  Single-arm robot: tool_left IS tool_right (:12-14), so the tool pose and
+ * the tool forces appear twice, and the arm joints are listed twice (robot_arm = 'both', robot.py:16).  Two-armed robot: tool 0 is
+ * tool_right, AGX_T_TOOL2_BODY is tool_left; the 14 joint angles are the right arm's, then the left arm's.
+ * tf[2] = {tool_right_force, tool_left_force} (all contacts of the tool), thf[2] = the same on the human */
+static void observe_arm(sim_t* s, const double* tf, double total_force, const double* thf, float* obs) {
   const agxo_model* m = s->m;
-  double sp[3], sR[9], spr[3], sqr[4];
-  tool_base_pose(s, sp, sR);                 /* tool.get_base_pos_orient() */
-  to_base_frame(s, sp, sR, spr, sqr);
+  const int dual = TI(m, AGX_T_TOOL2_BODY) > 0;
+  double sp[2][3], sR[2][9], spr[2][3], sqr[2][4];
+  for (int t = 0; t < 2; t++) {
+    tool_base_pose_of(s, (t && dual) ? TI(m, AGX_T_TOOL2_BODY) : m->tool_body, sp[t], sR[t]);   /* tool.get_base_pos_orient() */
+    to_base_frame(s, sp[t], sR[t], spr[t], sqr[t]);
+  }
   const double* pts[5] = {s->link[TI(m, AGX_T_OBS_LINK)].p, s->link[TI(m, AGX_T_OBS_LINK + 1)].p, s->link[TI(m, AGX_T_OBS_LINK + 2)].p,
                           s->human[TI(m, AGX_T_STOMACH_BODY)].p, s->human[TI(m, AGX_T_WAIST_BODY)].p};     /* :85-89 */
   int o = 0;
-  for (int rep = 0; rep < 2; rep++) { for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k]; for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k]; }
-  for (int rep = 0; rep < 2; rep++)
+  for (int t = 0; t < 2; t++) { for (int k = 0; k < 3; k++) obs[o++] = (float)spr[t][k]; for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[t][k]; }   /* right, then left (:92) */
+  for (int rep = 0; rep < (dual ? 1 : 2); rep++)
     for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
       double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
     }
   for (int j = 0; j < 5; j++) { double pr[3]; to_base_frame(s, pts[j], NULL, pr, NULL); for (int k = 0; k < 3; k++) obs[o++] = (float)pr[k]; }
-  obs[o++] = (float)tool_force; obs[o++] = (float)tool_force;
+  obs[o++] = (float)tf[1]; obs[o++] = (float)tf[0];                     /* [tool_left_force, tool_right_force] (:92) */
   if (s->coop) {                             /* human_obs, :98-107 */
-    double sph[3], sqh[4];
-    to_human_frame(s, sp, sR, sph, sqh);
-    for (int rep = 0; rep < 2; rep++) { for (int k = 0; k < 3; k++) obs[o++] = (float)sph[k]; for (int k = 0; k < 4; k++) obs[o++] = (float)sqh[k]; }
+    for (int t = 0; t < 2; t++) {
+      double sph[3], sqh[4];
+      to_human_frame(s, sp[t], sR[t], sph, sqh);
+      for (int k = 0; k < 3; k++) obs[o++] = (float)sph[k];
+      for (int k = 0; k < 4; k++) obs[o++] = (float)sqh[k];
+    }
     for (int d = m->nrobot; d < s->ndof; d++) if (RI(m, d, AGX_R_ACT) >= 0) obs[o++] = (float)s->q[d];
     for (int j = 0; j < 5; j++) { double ph[3]; to_human_frame(s, pts[j], NULL, ph, NULL); for (int k = 0; k < 3; k++) obs[o++] = (float)ph[k]; }
-    obs[o++] = (float)total_force; obs[o++] = (float)tool_human_force; obs[o++] = (float)tool_human_force;
+    obs[o++] = (float)total_force; obs[o++] = (float)thf[1]; obs[o++] = (float)thf[0];      /* total, tool_left_on_human, tool_right_on_human (:107) */
   }
 }
-/* everything ArmManipulationEnv.step does after take_step (arm_manipulation.py:18-60), single-arm robot */
+/* everything ArmManipulationEnv.step does after take_step (arm_manipulation.py:18-60) */
 static void finish_arm(sim_t* s, const float* action, float* obs, float* reward, int* done, float* info) {
   const agxo_model* m = s->m; double dt = m->dt;
-  /* get_total_force (:62-69); the one tool is counted as tool_right and as tool_left */
-  double robot_f = 0, tool_f = 0, tool_human_f = 0;
+  const int dual = TI(m, AGX_T_TOOL2_BODY) > 0, tb2 = AGX_BODY_FREE0 + TI(m, AGX_T_TOOL2_BODY);
+  /* get_total_force (:62-69); the one tool of a single-arm robot is counted as tool_right and as tool_left */
+  double robot_f = 0, tf[2] = {0, 0}, thf[2] = {0, 0};
   for (int c = 0; c < s->ncon; c++) {
     const contact_t* k = &s->con[c];
     int ta = CI(m, k->ca, AGX_C_TAG), tb = CI(m, k->cb, AGX_C_TAG);
-    int human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, tool = ta == AGX_TAG_TOOL || tb == AGX_TAG_TOOL, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
+    int human = ta == AGX_TAG_HUMAN || tb == AGX_TAG_HUMAN, robot = ta == AGX_TAG_ROBOT || tb == AGX_TAG_ROBOT;
     double f = k->lambda_n / dt;
-    if (tool) tool_f += f;
     if (human && robot) robot_f += f;
-    if (human && tool) tool_human_f += f;
+    for (int side = 0; side < 2; side++) {                    /* a contact between the two tools counts for both */
+      int tag = side ? tb : ta, body = side ? k->bb : k->ba;
+      if (tag != AGX_TAG_TOOL) continue;
+      int t = (dual && body == tb2) ? 1 : 0;
+      tf[t] += f;
+      if (human) thf[t] += f;
+    }
   }
-  double total_f = robot_f + 2 * tool_human_f;               /* :68 */
-  observe_arm(s, tool_f, total_f, tool_human_f, obs);
+  if (!dual) { tf[1] = tf[0]; thf[1] = thf[0]; }
+  double total_f = robot_f + thf[0] + thf[1];                 /* :68 */
+  observe_arm(s, tf, total_f, thf, obs);
   /* tool.get_closest_points(human, distance=0.01): one point per (hull of the tool, shape of the human) pair that close, at the
    * poses after the last substep (env.py:264-265) */
-  int near_pts = 0;
+  int near_pts[2] = {0, 0};
   {
     int t0 = -1, t1 = -1, h0 = -1, h1 = -1;
     for (int gg = 0; gg < m->ngroup; gg++) {
@@ -1430,32 +1451,42 @@ static void finish_arm(sim_t* s, const float* action, float* obs, float* reward,
       }
     }
     const double lim = TF(m, AGX_T_PRESSURE_DIST);
-    for (int a = t0; a < t1; a++) for (int b = h0; b < h1; b++) { contact_t k; if (narrowphase(s, a, b, lim, &k) && k.dist < lim) near_pts++; }
+    for (int a = t0; a < t1; a++) for (int b = h0; b < h1; b++) {
+      contact_t k; if (narrowphase(s, a, b, lim, &k) && k.dist < lim) near_pts[(dual && CI(m, a, AGX_C_BODY) == tb2) ? 1 : 0]++;
+    }
+    if (!dual) near_pts[1] = near_pts[0];
   }
   double act_norm2 = 0; for (int k = 0; k < m->act_dim; k++) act_norm2 += (double)action[k] * action[k];
-  xf_t ee; ee_frame(s, &ee);
-  int L = TI(m, AGX_T_EE_LINK); double wxp[3], vee[3];
-  cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
-  double ee_speed = 2 * sqrt(dot3(vee, vee));                /* right + left end effector: the same link (:26-27) */
-  double pressure = near_pts <= 0 ? 0.0 : tool_human_f / near_pts;      /* env.py:266-267 */
+  double ee_speed = 0;                                        /* right + left end effector (:26-27): the same link on a single-arm robot */
+  for (int t = 0; t < 2; t++) {
+    xf_t ee; ee_frame_of(s, dual ? t : 0, &ee);
+    int L = TI(m, (dual && t) ? AGX_T_EE2_LINK : AGX_T_EE_LINK); double wxp[3], vee[3];
+    cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
+    ee_speed += sqrt(dot3(vee, vee));
+  }
+  double pressure = 0;                                        /* env.py:266-269 */
+  for (int t = 0; t < 2; t++) pressure += near_pts[t] <= 0 ? 0.0 : thf[t] / near_pts[t];
   /* human_preferences (env.py:237-274): reward_force_nontarget = -(total - (right + left)) = -robot_f, tool_force_at_target = 0 */
-  double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_F) * (-(total_f - 2 * tool_human_f)) + TF(m, AGX_T_C_P) * (-(2 * pressure));
-  double sp[3], sR[9], d[3];
-  tool_base_pose(s, sp, sR);
+  double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_F) * (-(total_f - thf[0] - thf[1])) + TF(m, AGX_T_C_P) * (-pressure);
+  double spr[3], spl[3], sR[9], d[3];
+  tool_base_pose_of(s, m->tool_body, spr, sR);
+  tool_base_pose_of(s, dual ? TI(m, AGX_T_TOOL2_BODY) : m->tool_body, spl, sR);
   const double *elbow = s->link[TI(m, AGX_T_OBS_LINK + 1)].p, *wrist = s->link[TI(m, AGX_T_OBS_LINK + 2)].p;
   const double *stomach = s->human[TI(m, AGX_T_STOMACH_BODY)].p, *waist = s->human[TI(m, AGX_T_WAIST_BODY)].p;
-  sub3(sp, elbow, d); double rd_left = -sqrt(dot3(d, d));                                       /* :36 */
+  sub3(spl, elbow, d); double rd_left = -sqrt(dot3(d, d));                                      /* :36 */
+  sub3(spr, wrist, d); double rd_right = -sqrt(dot3(d, d));                                     /* :37 */
   sub3(elbow, stomach, d); double rd_human = -sqrt(dot3(d, d));
   sub3(wrist, waist, d); rd_human -= sqrt(dot3(d, d));                                          /* :38 */
-  double r = TF(m, AGX_T_W_DISTANCE) * rd_human + 2 * TF(m, AGX_T_W_WIPE) * rd_left + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + pref;   /* :42 */
+  double we = TF(m, AGX_T_W_WIPE);                                                              /* distance_end_effector_weight */
+  double r = TF(m, AGX_T_W_DISTANCE) * rd_human + (dual ? we * rd_left + we * rd_right : 2 * we * rd_left) + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + pref;   /* :41-44 */
   if (s->am_best == 0 || rd_human > s->am_best) s->am_best = rd_human;                          /* :47-48 */
   *reward = (float)r;
   *done = s->iteration >= (int)TF(m, AGX_T_EPISODE_LEN);
   if (info) {
     info[AGX_INFO_TOTAL_FORCE] = (float)total_f;
     info[AGX_INFO_TASK_SUCCESS] = (float)((float)s->am_best >= TF(m, AGX_T_SUCCESS_FRAC));
-    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)tool_human_f;
-    info[AGX_INFO_FOOD_REWARD] = (float)near_pts; info[AGX_INFO_PREF] = (float)pref;
+    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)(dual ? thf[0] + thf[1] : thf[0]);
+    info[AGX_INFO_FOOD_REWARD] = (float)(dual ? near_pts[0] + near_pts[1] : near_pts[0]); info[AGX_INFO_PREF] = (float)pref;
     info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
   }
 }
@@ -1679,7 +1710,7 @@ void agxo_observe(const agxo_model* m, const float* state, float* obs) {
   if (m->task_kind == AGX_TASK_BED_BATHING) observe_bed(s, 0, 0, 0, obs);
   else if (m->task_kind == AGX_TASK_SCRATCH_ITCH) observe_scratch(s, 0, 0, 0, obs);
   else if (m->task_kind == AGX_TASK_DRESSING) observe_dressing(s, s->dr_force_sum, 0, obs);
-  else if (m->task_kind == AGX_TASK_ARM_MANIPULATION) observe_arm(s, 0, 0, 0, obs);
+  else if (m->task_kind == AGX_TASK_ARM_MANIPULATION) { const double z[2] = {0, 0}; observe_arm(s, z, 0, z, obs); }
   else observe(s, 0, 0, obs);
   free(s);
 }

@@ -138,7 +138,7 @@ def test_vec_env_rollout_and_scalar_env(am):
     e.disconnect()
 
 
-@pytest.mark.parametrize('robot', ['jaco', 'panda'])
+@pytest.mark.parametrize('robot', ['jaco', 'panda', 'baxter', 'pr2'])
 def test_other_single_arm_robots(robot):
     """ArmManipulationJaco-v1 / ArmManipulationPanda-v1: pool states built the product way (both settles + collision rejection on the
     device), single steps against the oracle, a batched rollout"""
@@ -155,7 +155,7 @@ def test_other_single_arm_robots(robot):
     states = vec_env.build_reset_pool(b, n, 9001)
     assert np.isfinite(states).all()
     st = Stepper(b, n)
-    assert st.variant() == 'arm_manipulation'
+    assert st.variant() == ('arm_manipulation_l' if robot in ('baxter', 'pr2') else 'arm_manipulation')      # two-armed robots: both arms dynamic, two tools
     st.set_state(states)
     worst = np.zeros(n)
     for k in range(3):
@@ -164,7 +164,7 @@ def test_other_single_arm_robots(robot):
         _check_step(b, o, st, ref, act, worst)
     st.close()
     assert worst.max() < 1e-3, worst
-    env = getattr(vec_env, 'ArmManipulation%sVecEnv' % robot.capitalize())(32, pool_size=8, seed=3)
+    env = getattr(vec_env, 'ArmManipulation%sVecEnv' % {'pr2': 'PR2'}.get(robot, robot.capitalize()))(32, pool_size=8, seed=3)
     obs = env.reset()
     g = torch.Generator(device='cuda'); g.manual_seed(5)
     for k in range(200):
