@@ -130,8 +130,14 @@ def main():
                     help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--task', choices=sorted(TASKS), default='feeding', help="'feeding' = the BASELINE metric (config 2); 'bedbathing' = config 3; 'scratchitch' = config 4's env (co-op) on one GPU")
+    ap.add_argument('--env', default=None, help="any built env id instead of --task, e.g. 'ScratchItchJaco-v1' or 'FeedingSawyerHuman-v1' (assistive_gym_amd.envs.ENV_IDS)")
     args = ap.parse_args()
     model, env_cls, ksuffix, env_id = TASKS[args.task]
+    if args.env is not None:             # the kernel-name suffix is that of the variant agx_create picks: taken from the stepper below
+        from assistive_gym_amd.envs import ENV_IDS
+        cls = ENV_IDS[args.env.split(':')[-1]]
+        model, env_cls, ksuffix, env_id = cls.model, None, None, args.env.split(':')[-1]
+        args.task = 'dressing' if model.startswith('dressing') else args.env
     if args.pool is None:
         args.pool = 64 if args.task == 'dressing' else 256
 
@@ -151,7 +157,12 @@ def main():
     if distributed:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     n = args.envs_per_gpu
-    env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset)
+    if env_cls is None:
+        env = vec_env.AssistiveVecEnv(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset, model=model, coop=env_id.endswith('Human-v1'))
+        ksuffix = {'feeding': '', 'feeding_l': '_fl', 'bed_bathing': '_bb', 'bed_bathing_l': '_bbl', 'scratch_itch': '_si', 'dressing': '_dr', 'dressing_l': '_drl',
+                   'arm_manipulation': '_am', 'arm_manipulation_l': '_aml'}[env.stepper.variant()]
+    else:
+        env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset)
     blob = env.blob                      # the co-op flavour where the task's BASELINE config is co-op
     env.reset(env_offset=rank * n)
     K, W = args.steps, args.warmup
