@@ -4,10 +4,11 @@ the arm_manipulation kernel variant on the emulator against the oracle.  PARITY 
 import numpy as np
 import pytest
 
+from conftest import full
 from test_scratch_itch_robots import emu_checker, flags_from_oracle
 
 
-@pytest.fixture(scope='module', params=['jaco', 'panda'])
+@pytest.fixture(scope='module', params=['jaco', pytest.param('panda', marks=full)])
 def rb(request):
     from assistive_gym_amd.blob import ModelBlob
     from emu_lib import Emu

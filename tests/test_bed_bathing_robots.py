@@ -9,7 +9,9 @@ from assistive_gym_amd.model import xform as X
 from bed_util import arm_points, move_pad_to
 from test_scratch_itch_robots import emu_checker, flags_from_oracle
 
-ROBOTS = ['jaco', 'panda', 'pr2', 'baxter']
+from conftest import full
+
+ROBOTS = ['jaco', pytest.param('panda', marks=full), 'pr2', pytest.param('baxter', marks=full)]
 
 
 @pytest.fixture(scope='module', params=ROBOTS)

@@ -7,10 +7,11 @@ import pytest
 
 from assistive_gym_amd.model import compiler as L
 from assistive_gym_amd.model import xform as X
+from conftest import full
 from test_dressing import cloth_tables
 
 
-@pytest.fixture(scope='module', params=['sawyer', 'jaco', 'panda', 'pr2'])
+@pytest.fixture(scope='module', params=[pytest.param('sawyer', marks=full), 'jaco', pytest.param('panda', marks=full), 'pr2'])
 def rb(request):
     from assistive_gym_amd.blob import ModelBlob
     from oracle_lib import Oracle

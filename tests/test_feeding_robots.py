@@ -5,10 +5,11 @@ import numpy as np
 import pytest
 
 from assistive_gym_amd.model import xform as X
+from conftest import full
 from test_scratch_itch_robots import emu_checker, flags_from_oracle
 
 
-@pytest.fixture(scope='module', params=['sawyer', 'baxter', 'pr2'])
+@pytest.fixture(scope='module', params=['sawyer', pytest.param('baxter', marks=full), pytest.param('pr2', marks=full)])
 def rb(request):
     from assistive_gym_amd.blob import ModelBlob
     from emu_lib import Emu

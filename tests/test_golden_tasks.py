@@ -57,7 +57,7 @@ def test_emulator_replays_the_first_steps(name):
     b, g = _load(name)
     e = Emu(b)
     s = g['state0'].copy()
-    for k in range(3):
+    for k in range(2):
         obs, rew, done, info, _ = e.step(s, g['actions'][k])
         _check(b, obs, rew, g, k, 2e-4)
 

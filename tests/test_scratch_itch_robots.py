@@ -8,7 +8,9 @@ import pytest
 from assistive_gym_amd.model import xform as X
 from test_scratch_itch import target_world, tip_pose
 
-ROBOTS = ['jaco', 'panda', 'sawyer', 'baxter']
+from conftest import full
+
+ROBOTS = ['jaco', pytest.param('panda', marks=full), 'sawyer', pytest.param('baxter', marks=full)]
 
 
 @pytest.fixture(scope='module', params=ROBOTS)
