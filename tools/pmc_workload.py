@@ -1,7 +1,7 @@
 """Workload for the PMC passes: 6 observation-only launches (known traffic: one state record read,
 one observation written per env) followed by 6 full env.step launches, 4096 envs, unchunked
 (AGX_CHUNKS=1: every launch covers all environments, so per-launch counters are per 4096 environments).
-  python tools/pmc_workload.py [feeding|bedbathing]"""
+  python tools/pmc_workload.py [feeding|bedbathing|scratchitch|armmanipulation]"""
 import os, sys
 os.environ.setdefault('AGX_CHUNKS', '1')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +9,9 @@ sys.path.insert(0, ROOT)
 import torch
 from assistive_gym_amd import vec_env
 task = sys.argv[1] if len(sys.argv) > 1 else 'feeding'
-cls = {'feeding': 'FeedingJacoVecEnv', 'bedbathing': 'BedBathingSawyerVecEnv'}[task]
+cls = {'feeding': 'FeedingJacoVecEnv', 'bedbathing': 'BedBathingSawyerVecEnv', 'scratchitch': 'ScratchItchPR2HumanVecEnv', 'armmanipulation': 'ArmManipulationSawyerVecEnv'}[task]
 n = 4096
-env = getattr(vec_env, cls)(n, pool_size=64, seed=1001, auto_reset=False)
+env = getattr(vec_env, cls)(n, pool_size=32 if task in ('scratchitch', 'armmanipulation') else 64, seed=1001, auto_reset=False)
 env.reset()
 torch.cuda.synchronize()
 for _ in range(6):
