@@ -80,7 +80,7 @@ AGX_DEV double rs_u01(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t slot) 
 }
 // stream 0 slots, restart-stream slots (+ DoF)
 enum { RS_FRICTION = 0, RS_GENDER = 1, RS_IMPAIRMENT = 2, RS_LIMIT = 3, RS_STRENGTH = 4, RS_HEAD = 8, RS_EE = 12, RS_BOWL = 16,
-       RS_TREMOR = 32, RS_R_REST = 0, RS_R_LO = 16, RS_R_HI = 32 };
+       RS_TREMOR = 32, RS_LIMB = 48, RS_TARGET_LEN = 49, RS_TARGET_TH = 50, RS_R_REST = 0, RS_R_LO = 16, RS_R_HI = 32 };
 enum { RS_IMP_NONE = 0, RS_IMP_LIMITS = 1, RS_IMP_WEAKNESS = 2, RS_IMP_TREMOR = 3, RS_MODE_RANDOM = -1, RS_MODE_NO_TREMOR = -2 };
 constexpr int RS_NARM = 7;   // arm DoFs solved by the IK; agx_create checks the blob (a serial chain 0..6 carrying the end effector)
 
@@ -239,14 +239,17 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   }
   c.ls = imp != RS_IMP_LIMITS ? 1.0 : XF(c, AGX_X_LIMIT_LO) + (1.0 - XF(c, AGX_X_LIMIT_LO)) * rs_u01(seed_lo, seed_hi, 0, RS_LIMIT);   // human.py:85
   for (int k = 0; k < 3; k++) c.head[k] = (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_HEAD + k) - 1.0) * XF(c, AGX_X_HEAD_RANGE);          // feeding.py:125
+  const double strength = imp != RS_IMP_WEAKNESS ? 1.0 : XF(c, AGX_X_STRENGTH_LO) + (1.0 - XF(c, AGX_X_STRENGTH_LO)) * rs_u01(seed_lo, seed_hi, 0, RS_STRENGTH);   // human.py:86
+  const int xflags = XI(c, AGX_X_FLAGS);
 
   for (int w = lane; w < state_words; w += AGX_WAVE) gstate[w] = 0.f;
   wave_sync();
 
   // ---- posed human: one static collision body per lane, lane NHUMAN the head (mouth target) --------
-  if (lane <= nhuman) {
+  const int head_link = ((const int*)c.task)[AGX_T_HEAD_LINK];       // -1: the task has no mouth target (scratch itch)
+  if (lane < nhuman || (lane == nhuman && head_link >= 0)) {
     const int link = lane < nhuman ? c.xi[XI(c, AGX_X_OFF_BODIES) + lane]
-                                   : c.xi[XI(c, AGX_X_OFF_DYN) + ((const int*)c.task)[AGX_T_HEAD_LINK] - nrobot];
+                                   : c.xi[XI(c, AGX_X_OFF_DYN) + head_link - nrobot];
     d3 p; dq q;
     rs_link_pose(c, link, p, q);
     if (lane < nhuman) {
@@ -353,7 +356,16 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     float* o = gstate + sFREE + 13 * lane;
     const int tool_body = c.bi[AGX_H_TOOL_BODY], bowl_body = XI(c, AGX_X_BOWL_BODY), food0 = c.bi[AGX_H_FOOD0];
     d3 p = dmk(0, 0, 0); dq q = dq_ident();
-    if (lane == tool_body) { p = tp; q = tq; }
+    if (lane == tool_body) {
+      p = tp; q = tq;
+      const float* fb = c.bf + c.bi[AGX_H_OFF_FREE] + lane * AGX_F_STRIDE;
+      if (fb[AGX_F_REFPOS] != 0.f || fb[AGX_F_REFPOS + 1] != 0.f || fb[AGX_F_REFPOS + 2] != 0.f || fb[AGX_F_REFQUAT + 3] != 1.f) {
+        // a tool whose URDF base frame is not its centre-of-mass frame (wiper, scratcher): the record holds the COM frame
+        dq qi = dld4(fb + AGX_F_REFQUAT); qi.x = -qi.x; qi.y = -qi.y; qi.z = -qi.z;
+        const d3 ip = dqrot(qi, dld3(fb + AGX_F_REFPOS));
+        dcompose(tp, tq, dmk(-ip.x, -ip.y, -ip.z), qi, p, q);
+      }
+    }
     else if (lane == bowl_body) {                                                                            // furniture.py:32-34
       const double br = XF(c, AGX_X_BOWL_RANGE);
       d3 b = dld3(c.xf + AGX_X_BOWL_POS);
@@ -380,10 +392,24 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     ei[AGX_E_ITERATION] = 0; ei[AGX_E_TASK_SUCCESS] = 0;
     ei[AGX_E_RNG] = (int)((seed * 2654435761ull + 12345ull) & 0x7FFFFFFFull);
     ei[AGX_E_RNG + 1] = (int)((seed ^ 0x5bd1e995ull) & 0x7FFFFFFFull);
-    ei[AGX_E_TOTAL_FOOD] = nfood;
+    ei[AGX_E_TOTAL_FOOD] = (xflags & 2) ? 1 : nfood;               // scratch itch: task_success >= 1 x task_success_threshold (scratch_itch.py:37)
     const bool coop = ((const int*)c.task)[AGX_T_COOP] == 1;
-    ei[AGX_E_FROZEN] = (imp == RS_IMP_TREMOR || coop) ? 0 : (((1 << nhdof) - 1) << nrobot);                  // human.py:104-110
+    const bool agent = imp == RS_IMP_TREMOR || coop;                // then take_step drives the human's motors (env.py:130-131)
+    ei[AGX_E_FROZEN] = (agent || (xflags & 1)) ? 0 : (((1 << nhdof) - 1) << nrobot);                          // human.py:104-110
     e[AGX_E_LIMIT_SCALE] = (float)c.ls;
+    if (!agent && XF(c, AGX_X_REACTIVE_KP) > 0.0) {                 // the reactive hold of setup_joints (human.py:124-127)
+      e[AGX_E_HUMAN_KP] = c.xf[AGX_X_REACTIVE_KP]; e[AGX_E_HUMAN_MAXF] = (float)(XF(c, AGX_X_REACTIVE_MAXF) * strength);
+    }
+    if (xflags & 2) {   // generate_target (scratch_itch.py:134-146): limb, then Util.point_on_capsule (util.py:58-78) along (0, 0, -length)
+      const int limb = rs_u01(seed_lo, seed_hi, 0, RS_LIMB) < 0.5 ? 0 : 1;
+      const double length = (double)c.task[AGX_T_SI_LIMB_DIMS + 4 * c.gender + 2 * limb], radius = (double)c.task[AGX_T_SI_LIMB_DIMS + 4 * c.gender + 2 * limb + 1];
+      const double rl = radius + (length - radius) * rs_u01(seed_lo, seed_hi, 0, RS_TARGET_LEN);
+      const double th = 6.283185307179586 * rs_u01(seed_lo, seed_hi, 0, RS_TARGET_TH);
+      // axis (0, 0, -1), Util.orthogonal_vector -> (0, -1, 0), normal = axis x ortho = (-1, 0, 0)
+      float* tw = gstate + c.bi[AGX_H_S_TASK];
+      tw[AGX_SI_TARGET] = (float)(-radius * sin(th)); tw[AGX_SI_TARGET + 1] = (float)(-radius * cos(th)); tw[AGX_SI_TARGET + 2] = (float)(-rl);
+      ((int*)tw)[AGX_SI_LIMB] = limb;
+    }
     if (ginfo) { ginfo[0] = (float)ok; ginfo[1] = (float)restarts; ginfo[2] = (float)best_d; ginfo[3] = (float)imp; }
   }
   return ok ? restarts - 1 : -1;

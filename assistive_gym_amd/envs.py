@@ -294,16 +294,24 @@ class ScratchItchPR2HumanEnv(ScratchItchPR2Env):
 
 class ScratchItchJacoEnv(ScratchItchPR2Env):
     """ScratchItchJaco-v1 (scratch_itch_envs.py:29-31; the default environment of the reference's env_viewer.py / learn.py): the
-    wheelchair-mounted Jaco holds the scratcher."""
+    wheelchair-mounted Jaco holds the scratcher.  reset() is sampled on the device (agx_sample_reset: human, IK with random restarts and
+    collision rejection, tool, target on the arm), as FeedingJacoEnv's."""
     model = 'scratch_itch_jaco'
+
+    def reset(self):
+        st = self._ensure_stepper()
+        self.reset_seed = self._draw_seed()
+        st.sample_reset(self.reset_seed, impairment='random')
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
 
 
 class ScratchItchJacoHumanEnv(ScratchItchJacoEnv):
     coop = True
 
 
-class ScratchItchPandaEnv(ScratchItchPR2Env):
-    """ScratchItchPanda-v1 (scratch_itch_envs.py:37-39)"""
+class ScratchItchPandaEnv(ScratchItchJacoEnv):
+    """ScratchItchPanda-v1 (scratch_itch_envs.py:37-39): as ScratchItchJaco, with the wheelchair-mounted Panda"""
     model = 'scratch_itch_panda'
 
 

@@ -34,6 +34,14 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         return make_arm_states(blob, pool_size, seed=seed, impairment='no_tremor' if impairment == 'random' else impairment,
                                settler=RagdollSettler(pool_size, device), arm_settler=ArmFallSettler(blob, pool_size, device),
                                checker=DeviceCollisionChecker(blob, pool_size, device))[0]
+    if blob.task_kind == L.TASK_SCRATCH_ITCH and blob.meta.get('mount') == 'wheelchair' and sampler == 'device':
+        # a wheelchair-mounted arm (Jaco, Panda): ScratchItchEnv.reset sampled by the device-side reset generator, as for the feeding scenes
+        st = Stepper(blob, pool_size, device)
+        st.sample_reset(seed, impairment=impairment)
+        st.synchronize()
+        out = st.get_state()
+        st.close()
+        return out
     if blob.task_kind == L.TASK_SCRATCH_ITCH:
         from .host.reset_scratch import make_states as make_scratch_states
         from .host.reset_bed import DeviceCollisionChecker
@@ -107,8 +115,10 @@ class AssistiveVecEnv:
         """FeedingEnv.reset for the envs selected by mask (None = all), in place on the device: env i of episode e is
         sampled from episode_seed(seed, e, env_offset) + i -- a function of the GLOBAL env index and the episode only,
         i.e. independent of the number of GPUs the batch is spread over -- and settled for 25 substeps"""
+        from .model import compiler as L
+        settle = SETTLE_STEPS if self.blob.task_kind == L.TASK_FEEDING else 0      # ScratchItchEnv.reset has no settle loop
         self.stepper.reset(mask, None, episode_seed(self.seed, self._episode, self.env_offset), impairment=self.impairment,
-                           settle_substeps=SETTLE_STEPS, stream=s)
+                           settle_substeps=settle, stream=s)
         self._episode += 1
 
     def reset(self, env_offset=0):
@@ -210,12 +220,14 @@ class ScratchItchPR2HumanVecEnv(ScratchItchPR2VecEnv):
     coop = True
 
 
-class ScratchItchJacoVecEnv(ScratchItchPR2VecEnv):
-    """ScratchItchJaco-v1 (the reference's default environment): the same kernels with the wheelchair-mounted Jaco's model blob"""
+class ScratchItchJacoVecEnv(AssistiveVecEnv):
+    """ScratchItchJaco-v1 (the reference's default environment): the scratch-itch kernels with the wheelchair-mounted Jaco's model blob;
+    its resets come from the device-side reset generator (reset='pool': a pool sampled once; reset='device': fresh states every episode;
+    reset='host': the numpy sampler of host/reset_scratch.py)"""
     model = 'scratch_itch_jaco'
 
 
-class ScratchItchPandaVecEnv(ScratchItchPR2VecEnv):
+class ScratchItchPandaVecEnv(ScratchItchJacoVecEnv):
     model = 'scratch_itch_panda'
 
 

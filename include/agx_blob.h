@@ -177,6 +177,8 @@ enum {
   AGX_T_C_V, AGX_T_C_F, AGX_T_C_HF, AGX_T_C_FD, AGX_T_C_FDV,   /* config.ini:40-44           */
   AGX_T_SUCCESS_FRAC,                                           /* config.ini:19              */
   AGX_T_MOUTH_DIST, AGX_T_SPILL_DIST,                           /* feeding.py:61,71           */
+  AGX_T_SI_LIMB_DIMS = 9, /* scratch itch blobs reuse the feeding-only words 9..16: float[2 genders][2 limbs][length, radius] of the upper arm and
+                          * the forearm (scratch_itch.py:136-139), read by the device-side reset generator                                          */
   AGX_T_MOUTH_M = 11,    /* float[3] mouth offset in the head frame, male (feeding.py:186)    */
   AGX_T_MOUTH_F = 14,    /* float[3] female                                                   */
   AGX_T_HEAD_LINK = 17,  /* int: moving link that is the human head (human.head = 23)         */
@@ -263,6 +265,10 @@ enum {
   AGX_X_FOOD_OFF = 45,   /* float[3] offset of the food grid from the tool position (feeding.py:162) */
   AGX_X_COLLISION_TRIES = 48, /* int: how many successful IK restarts may be rejected because the robot / tool touches the human,
                           * the table or the wheelchair (robot.py:105-112, env.py:299-308) before one is accepted unchecked */
+  AGX_X_REACTIVE_KP = 49,   /* gain of the reactive hold of a human that is not an agent (setup_joints reactive_gain, scratch_itch.py:105); 0 = none (Feeding) */
+  AGX_X_REACTIVE_MAXF = 50, /* its force limit before the strength factor (reactive_force, human.py:126)                                                    */
+  AGX_X_FLAGS = 51,         /* int: bit 0 = the human's controllable joints stay dynamic whatever the impairment (human.py:108 with a reactive force);
+                             * bit 1 = scratch itch: draw the limb and the target on it (scratch_itch.py:134-146; dimensions in AGX_T_SI_LIMB_DIMS) */
   AGX_X_COUNT = 52
 };
 enum {

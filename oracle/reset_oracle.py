@@ -26,6 +26,7 @@ M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
 MASK = 0xFFFFFFFF
 # stream 0 slots
 S_FRICTION, S_GENDER, S_IMPAIRMENT, S_LIMIT, S_STRENGTH, S_HEAD, S_EE, S_BOWL, S_TREMOR = 0, 1, 2, 3, 4, 8, 12, 16, 32
+S_LIMB, S_TARGET_LEN, S_TARGET_TH = 48, 49, 50          # scratch itch: generate_target (scratch_itch.py:134-146)
 # restart stream slots (+ DoF index)
 R_REST, R_LO, R_HI = 0, 16, 32
 IMPAIRMENTS = ('none', 'limits', 'weakness', 'tremor')       # human.py:80
@@ -36,12 +37,13 @@ MODE_RANDOM, MODE_NO_TREMOR = -1, -2
 X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE_RANGE=16, BOWL_POS=17, BOWL_RANGE=20,
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
           IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
-          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48, COUNT=52)
+          BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
+          REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, COUNT=52)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
-H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK = 31, 13, 14, 18
+H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, STRIDE=36)
 F = dict(REFPOS=5, REFQUAT=8, STRIDE=16)
-T = dict(MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35)
+T = dict(SI_LIMB_DIMS=9, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35)
 
 
 def contacts_collide(blob_words, contacts):
@@ -290,8 +292,10 @@ class ResetOracle:
         for k, link in enumerate(bodies):
             p, q = self.link_pose(g, link, ls, head)
             st[S['HUMAN'] + 7 * k:S['HUMAN'] + 7 * k + 3], st[S['HUMAN'] + 7 * k + 3:S['HUMAN'] + 7 * k + 7] = p, q
-        hp, hq = self.link_pose(g, dyn[self.ti('HEAD_LINK') - self.nrobot], ls, head)
-        target, _ = compose(hp, hq, self.tf('MOUTH_F' if g else 'MOUTH_M', 3), np.array([0, 0, 0, 1.0]))
+        target = np.zeros(3)
+        if self.ti('HEAD_LINK') >= 0:                                      # tasks with a mouth target (feeding.py:184-196)
+            hp, hq = self.link_pose(g, dyn[self.ti('HEAD_LINK') - self.nrobot], ls, head)
+            target, _ = compose(hp, hq, self.tf('MOUTH_F' if g else 'MOUTH_M', 3), np.array([0, 0, 0, 1.0]))
 
         er = self.xf('EE_RANGE')
         target_ee = self.xf('EE_TARGET', 3) + np.array([(2 * u(S_EE + k) - 1) * er for k in range(3)])
@@ -328,23 +332,31 @@ class ResetOracle:
         fr = lambda b: S['FREE'] + 13 * b
         for b in range(self.nfree):
             st[fr(b) + 6] = 1.0
-        st[fr(self.tool_body):fr(self.tool_body) + 3], st[fr(self.tool_body) + 3:fr(self.tool_body) + 7] = tp, tq
+        fo = int(self.i[H_OFF_FREE]) + self.tool_body * F['STRIDE']
+        refp, refq = self.f[fo + F['REFPOS']:fo + F['REFPOS'] + 3].astype(np.float64), self.f[fo + F['REFQUAT']:fo + F['REFQUAT'] + 4].astype(np.float64)
+        cp, cq = tp, tq
+        if np.any(refp != 0) or refq[3] != 1:                              # a welded tool (scratcher): the record holds the COM frame
+            qi = np.array([-refq[0], -refq[1], -refq[2], refq[3]])
+            cp, cq = compose(tp, tq, -qrot(qi, refp), qi)
+        st[fr(self.tool_body):fr(self.tool_body) + 3], st[fr(self.tool_body) + 3:fr(self.tool_body) + 7] = cp, cq
         # bowl (furniture.py:32-34): base frame -> COM frame
         bb = self.xi('BOWL_BODY')
-        br = self.xf('BOWL_RANGE')
-        bowl = self.xf('BOWL_POS', 3) + np.array([(2 * u(S_BOWL) - 1) * br, (2 * u(S_BOWL + 1) - 1) * br, 0.0])
-        fo = int(self.i[H_OFF_FREE]) + bb * F['STRIDE']
-        refp, refq = self.f[fo + F['REFPOS']:fo + F['REFPOS'] + 3], self.f[fo + F['REFQUAT']:fo + F['REFQUAT'] + 4]
-        qi = np.array([-refq[0], -refq[1], -refq[2], refq[3]])
-        cp, cq = compose(bowl, np.array([0, 0, 0, 1.0]), -qrot(qi, refp), qi)
-        st[fr(bb):fr(bb) + 3], st[fr(bb) + 3:fr(bb) + 7] = cp, cq
+        if bb >= 0:
+            br = self.xf('BOWL_RANGE')
+            bowl = self.xf('BOWL_POS', 3) + np.array([(2 * u(S_BOWL) - 1) * br, (2 * u(S_BOWL + 1) - 1) * br, 0.0])
+            fo = int(self.i[H_OFF_FREE]) + bb * F['STRIDE']
+            refp, refq = self.f[fo + F['REFPOS']:fo + F['REFPOS'] + 3], self.f[fo + F['REFQUAT']:fo + F['REFQUAT'] + 4]
+            qi = np.array([-refq[0], -refq[1], -refq[2], refq[3]])
+            cp, cq = compose(bowl, np.array([0, 0, 0, 1.0]), -qrot(qi, refp), qi)
+            st[fr(bb):fr(bb) + 3], st[fr(bb) + 3:fr(bb) + 7] = cp, cq
         # food grid above the spoon (feeding.py:158-166)
         rf_, fo3 = self.xf('FOOD_R'), self.xf('FOOD_OFF', 3)
         k = 0
         for a in range(2):
             for b in range(2):
                 for c in range(2):
-                    st[fr(self.food0 + k):fr(self.food0 + k) + 3] = np.array([a * 2 * rf_, b * 2 * rf_, c * 2 * rf_]) + fo3 + tp
+                    if k < self.nfood:
+                        st[fr(self.food0 + k):fr(self.food0 + k) + 3] = np.array([a * 2 * rf_, b * 2 * rf_, c * 2 * rf_]) + fo3 + tp
                     k += 1
         e = S['ENV']
         st[e + 0] = friction
@@ -354,9 +366,25 @@ class ResetOracle:
         si[e + 7] = si[e + 8] = 0
         si[e + 9] = (seed * 2654435761 + 12345) & 0x7FFFFFFF
         si[e + 10] = (seed ^ 0x5bd1e995) & 0x7FFFFFFF
-        si[e + 11] = self.nfood
+        xflags = self.xi('FLAGS')
+        si[e + 11] = 1 if xflags & 2 else self.nfood
         coop = self.ti('COOP') == 1
-        si[e + 12] = 0 if (imp == 3 or coop) else (((1 << self.nhdof) - 1) << nr)     # human.py:104-110
+        agent = imp == 3 or coop
+        si[e + 12] = 0 if (agent or xflags & 1) else (((1 << self.nhdof) - 1) << nr)     # human.py:104-110
         st[e + 13] = ls
+        if not agent and self.xf('REACTIVE_KP') > 0:                       # the reactive hold of setup_joints (human.py:124-127)
+            st[e + 14], st[e + 15] = self.xf('REACTIVE_KP'), self.xf('REACTIVE_MAXF') * strength
+        limb, target_on_arm = None, None
+        if xflags & 2:                                                     # generate_target (scratch_itch.py:134-146, util.py:58-78)
+            limb = 0 if u(S_LIMB) < 0.5 else 1
+            dims = self.tf('SI_LIMB_DIMS', 8).astype(np.float64)
+            length, radius = dims[4 * g + 2 * limb], dims[4 * g + 2 * limb + 1]
+            rl = radius + (length - radius) * u(S_TARGET_LEN)
+            th = 2 * np.pi * u(S_TARGET_TH)
+            axis, ortho, normal = np.array([0, 0, -1.0]), np.array([0, -1.0, 0]), np.array([-1.0, 0, 0])
+            target_on_arm = rl * axis + radius * np.cos(th) * ortho + radius * np.sin(th) * normal
+            ts = int(self.i[H_S_TASK])
+            st[ts:ts + 3] = target_on_arm
+            si[ts + 3] = limb
         return st, dict(gender=g, impairment=imp, limit_scale=ls, strength=strength, tremors=tremors, ik_ok=ok,
-                        ik_restarts=restarts, ik_pos_err=best_d, target_ee=target_ee, head=head)
+                        ik_restarts=restarts, ik_pos_err=best_d, target_ee=target_ee, head=head, limb=limb, target_on_arm=target_on_arm)

@@ -98,3 +98,43 @@ def test_default_environment_of_the_reference_runs_end_to_end():
         assert bool(done.all()) == (k == 199)
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and env.stepper.overflow_count() == 0
     env.close()
+
+
+@pytest.mark.parametrize('robot', ['jaco', 'panda'])
+def test_device_reset_generator(robot):
+    """ScratchItchEnv.reset on the device for the wheelchair-mounted arms: agx_sample_reset against its numpy restatement, then a VecEnv
+    whose every episode starts from newly sampled states (reset='device')"""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import reset_oracle as ro
+    from assistive_gym_amd import libagx, vec_env
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.libagx import Stepper
+    from test_reset_generator import assert_same_record
+    if libagx.load().agx_device_count() <= 0:
+        pytest.skip('no GPU visible')
+    b = ModelBlob.load('scratch_itch_' + robot)
+    n, seed0 = 24, (1 << 33) + 99
+    st = Stepper(b, n)
+    info = torch.zeros((n, 4), dtype=torch.float32, device='cuda')
+    st.sample_reset(seed0, ik_info=info)
+    st.synchronize()
+    got, gi = st.get_state(), info.cpu().numpy()
+    R = ro.with_collision_check(b.words)
+    for i in list(range(6)) + [n - 1]:
+        want, winfo = R.sample(seed0 + i)
+        assert_same_record(b, want, got[i], 'env %d' % i)
+        assert bool(gi[i, 0]) == winfo['ik_ok'] and int(gi[i, 1]) == winfo['ik_restarts'] and int(gi[i, 3]) == winfo['impairment']
+    st.close()
+    env = getattr(vec_env, 'ScratchItch%sVecEnv' % robot.capitalize())(64, reset='device', seed=5)
+    obs = env.reset()
+    first = obs.clone()
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for k in range(200):
+        obs, rew, done, inf = env.step(torch.rand((64, 7), device='cuda', generator=g) * 2 - 1)
+        assert bool(done.all()) == (k == 199)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and env.stepper.overflow_count() == 0
+    assert (obs[:, 10:13] != first[:, 10:13]).any(dim=1).all()          # every env starts its next episode with a NEW target on the arm
+    env.close()

@@ -146,3 +146,56 @@ def test_emulator_matches_oracle_in_free_space_and_scratching(rb):
             assert abs(oi[c] - ei[c]) <= 1e-3 * max(1.0, abs(oi[c]))
         hits += int(oi[3] > 0)
     assert hits >= 1, 'the scratcher presses on the arm'
+
+
+# ---- the device-side reset generator for the wheelchair-mounted arms (csrc/agx_reset.h on the wave emulator vs oracle/reset_oracle.py) --------
+@pytest.mark.parametrize('robot', ['jaco', pytest.param('panda', marks=full)])
+def test_device_reset_generator_matches_its_restatement(robot):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import reset_oracle as ro
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.model import compiler as L
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    from test_reset_generator import assert_same_record
+    b = ModelBlob.load('scratch_itch_' + robot)
+    e, o = Emu(b), Oracle(b)
+    R = ro.with_collision_check(b.words)
+    oks = 0
+    for seed, imp in ((1001, -1), (1002, -1), (31, 3), (32, 2)):
+        st, info = R.sample(seed, imp)
+        se, ie = e.sample(seed, imp)
+        assert_same_record(b, st, se, 'seed %d' % seed)
+        assert bool(ie[0]) == info['ik_ok'] and int(ie[1]) == info['ik_restarts'] and int(ie[3]) == info['impairment']
+        oks += info['ik_ok']
+        v = b.view(se[None])
+        # ScratchItchEnv.reset (scratch_itch.py:93-132): base on the wheelchair, the arm dynamic, the reactive hold unless the human is an agent
+        assert np.allclose(v['base'][0, :3], np.array([0, 0, 0.06]) + b.meta['toc_base'], atol=1e-6) and v['frozen'][0] == 0 and v['total_food'][0] == 1
+        if info['impairment'] == 3:
+            assert v['human_kp'][0] == 0 and np.any(v['tremor'][0] != 0) and np.all(np.abs(v['tremor'][0]) <= np.deg2rad(10) + 1e-6)
+        else:
+            assert np.isclose(v['human_kp'][0], 0.01) and np.isclose(v['human_maxf'][0], info['strength'])
+        # generate_target (:134-146): a point on the cylinder surface of the drawn limb
+        limb = int(v['task'][0, L.SI['LIMB']])
+        t = v['task'][0, L.SI['TARGET']:L.SI['TARGET'] + 3].view(np.float32).astype(np.float64)
+        dims = b.task_f('SI_LIMB_DIMS', 8)
+        length, radius = dims[4 * int(v['gender'][0]) + 2 * limb], dims[4 * int(v['gender'][0]) + 2 * limb + 1]
+        assert limb in (0, 1) and np.isclose(np.hypot(t[0], t[1]), radius, atol=1e-6) and -length - 1e-6 <= t[2] <= -radius + 1e-6
+        if info['ik_ok']:
+            assert not flags_from_oracle(b, o, se) & 1                       # accepted restarts do not touch the human / the wheelchair
+            ee, _ = o.ee_pose(se)
+            assert np.linalg.norm(ee - info['target_ee']) < 0.011
+        # the sampled state steps: emulator vs oracle
+        s1, s2 = se.copy(), se.copy()
+        a = np.random.RandomState(seed).uniform(-1, 1, 7).astype(np.float32)
+        oo, orr, od, oi = o.step(s1, a)
+        eo, er, ed, ei, _ = e.step(s2, a)
+        assert oi[6] == ei[6] and np.abs(oo[:-1] - eo[:-1]).max() < 1e-4 and abs(orr - er) < 1e-4 * max(1.0, abs(orr))
+    assert oks >= 3
+    # the limb dimensions are those of the capsules of the compiled human (human_creation.py)
+    from assistive_gym_amd.model.human import HumanModel
+    hm = HumanModel('male')
+    assert np.allclose(b.task_f('SI_LIMB_DIMS', 8)[:4], [hm.dims['upperarm'][1], hm.dims['upperarm'][0], hm.dims['forearm'][1], hm.dims['forearm'][0]])
+    assert np.allclose(b.task_f('SI_LIMB_DIMS', 8)[:4], [0.279, 0.043, 0.257, 0.033], atol=1e-6)         # scratch_itch.py:136
