@@ -24,15 +24,21 @@ def _check(name, got, ref):
 
 def _load(path, blob):
     d = np.load(path, allow_pickle=False)
+    if 'model' in d.files and str(d['model']) != 'feeding_jaco':          # a dump of another Feeding<Robot>-v1 (tools/pybullet_dump.py --env)
+        from assistive_gym_amd.blob import ModelBlob
+        blob = ModelBlob.load(str(d['model']))
     assert int(d['blob_version']) == blob.h['VERSION'], 'dump was recorded for another blob version'
     assert d['states'].shape[1] == blob.state_words and len(d['states']) == len(d['actions']) + 1
-    return d
+    return d, blob
 
 
 @pytest.mark.skipif(not DUMPS, reason='no PyBullet reference dump committed (tools/pybullet_dump.py needs the reference stack)')
 @pytest.mark.parametrize('path', DUMPS)
 def test_oracle_matches_reference_dump(path, blob, oracle):
-    d = _load(path, blob)
+    d, blob = _load(path, blob)
+    if blob.words is not oracle.blob.words:
+        from oracle_lib import Oracle
+        oracle = Oracle(blob)
     for k in range(len(d['actions'])):
         s = d['states'][k].copy()
         obs, rew, done, info = oracle.step(s, d['actions'][k])
@@ -46,7 +52,7 @@ def test_oracle_matches_reference_dump(path, blob, oracle):
 @pytest.mark.parametrize('path', DUMPS)
 def test_stepper_matches_reference_dump(path, blob):
     from assistive_gym_amd.libagx import Stepper
-    d = _load(path, blob)
+    d, blob = _load(path, blob)
     T = len(d['actions'])
     st = Stepper(blob, T)                     # step k of the episode runs in environment slot k
     st.set_state(d['states'][:T])

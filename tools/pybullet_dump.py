@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """Oracle-dump tool of the parity protocol: run the REFERENCE (assistive_gym on the
 Zackory/bullet3 PyBullet fork it pins, setup.py:21) and record, for every step of a seeded random-action
-episode of FeedingJaco-v1, the complete physics state in THIS repo's state-record layout together with
-the reference's observation, reward, done and `total_force_on_human`.
+episode of a Feeding<Robot>-v1 environment (FeedingJaco-v1 by default; --env FeedingPanda-v1 / FeedingSawyer-v1 / FeedingBaxter-v1 /
+FeedingPR2-v1: the same state-record layout, driven by the blob's metadata), the complete physics state in THIS repo's state-record
+layout together with the reference's observation, reward, done and `total_force_on_human`.
 
     python tools/pybullet_dump.py --seed 1001 --steps 200 --out tests/golden/pybullet_dump_seed1001.npz
+    python tools/pybullet_dump.py --env FeedingSawyer-v1 --out tests/golden/pybullet_dump_feeding_sawyer_seed1001.npz
+
+The other tasks (bed bathing, scratch itch, dressing, arm manipulation) need a capture_state of their own (task words, tool link
+frames, the garment) and are not covered yet.
 
 The result is consumed by tests/test_reference_dump.py: each recorded state is injected
 (`agx_set_state` / the oracle), the recorded action is applied, and observation, reward and force are
@@ -107,16 +112,20 @@ def main():
     ap.add_argument('--seed', type=int, default=1001)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden', 'pybullet_dump_seed1001.npz'))
+    ap.add_argument('--env', default='FeedingJaco-v1', help='a Feeding<Robot>-v1 id that assistive_gym_amd builds')
     args = ap.parse_args()
 
+    import importlib
     import json
     import pybullet as p                                    # the fork pinned by the reference's setup.py:21
-    from assistive_gym.envs.feeding_envs import FeedingJacoEnv
     from assistive_gym_amd.blob import ModelBlob, DATA_DIR
-    blob = ModelBlob.load('feeding_jaco')
-    meta = json.load(open(os.path.join(DATA_DIR, 'feeding_jaco.meta.json')))
+    from assistive_gym_amd.envs import ENV_IDS
+    assert args.env.startswith('Feeding') and not args.env.endswith('Human-v1') and args.env in ENV_IDS, 'a single-agent Feeding<Robot>-v1 id'
+    model = ENV_IDS[args.env].model
+    blob = ModelBlob.load(model)
+    meta = json.load(open(os.path.join(DATA_DIR, model + '.meta.json')))
 
-    env = FeedingJacoEnv()
+    env = getattr(importlib.import_module('assistive_gym.envs.feeding_envs'), args.env.split('-')[0] + 'Env')()     # feeding_envs.py:17-39
     env.seed(args.seed)                                     # env.py:78-80
     obs0 = env.reset()
     foods = list(env.foods)                                 # creation order, feeding.py:154-159
@@ -131,7 +140,7 @@ def main():
         obs.append(np.asarray(o, dtype=np.float64)); rew.append(float(r)); done.append(bool(d))
         force.append(float(info['total_force_on_human'])); success.append(int(info['task_success']))
     states.append(capture_state(env, blob, meta, foods, p))
-    np.savez_compressed(args.out, blob_version=blob.h['VERSION'], seed=args.seed, obs0=np.asarray(obs0, dtype=np.float64),
+    np.savez_compressed(args.out, blob_version=blob.h['VERSION'], model=model, seed=args.seed, obs0=np.asarray(obs0, dtype=np.float64),
                         states=np.asarray(states, dtype=np.float32), actions=actions, obs=np.asarray(obs), reward=np.asarray(rew),
                         done=np.asarray(done), total_force_on_human=np.asarray(force), task_success=np.asarray(success),
                         gender=env.human.gender, impairment=env.human.impairment,
