@@ -227,10 +227,10 @@ int agx_get_state(agx_handle h, float* host_states) {
 int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fail(AGX_E_ARG, "agx_state_dev: bad argument"); *out_dev = h->state_dev; return AGX_OK; }
 
 // one p.stepSimulation() for the environments [e0, e0+ne): build + solve
-static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st, int phase) {
+static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st, int phase, bool settle) {
   h->V->build(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active, h->overflow_dev, h->trace_dev, h->trace_words, phase);
   HIPCHK(hipGetLastError());
-  h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active, phase);
+  h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active, settle ? (phase | AGX_PHASE_SETTLE) : phase);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -250,7 +250,7 @@ static int launch_chunked(agx_handle h, int n_substeps, const float* act, float*
     // calls run first (leaving their link frames in the trace), then one cloth launch replays them (one-way coupling, agx_cloth.h).
     for (int g0 = 0; g0 < n_substeps; g0 += h->frame_skip) {
       const int gs = n_substeps - g0 < h->frame_skip ? n_substeps - g0 : h->frame_skip, nsub = gs * h->sim_sub;
-      for (int k = 0; k < nsub; k++) { const bool first = g0 == 0 && k == 0; int rc = launch_substep(h, first ? act : nullptr, first ? dbg : nullptr, e0, ne, st, k); if (rc) return rc; }
+      for (int k = 0; k < nsub; k++) { const bool first = g0 == 0 && k == 0; int rc = launch_substep(h, first ? act : nullptr, first ? dbg : nullptr, e0, ne, st, k, !finish); if (rc) return rc; }
       if (h->cloth_dev) {
         h->V->cloth(st, ne, h->blob_dev, h->state_dev, h->trace_dev, h->cloth_dev, h->report_dev, e0, h->n_envs, h->sw, h->trace_words, h->cloth_words, h->report_words, nsub,
                     h->active, h->cloth_lds);

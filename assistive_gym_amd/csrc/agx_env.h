@@ -391,7 +391,6 @@ AGX_DEV int collision_flags(const uint32_t* __restrict__ blob, const float* __re
 // solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
 AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane, int phase = 0) {
   Ctx c; ctx_init(c, blob, lds, lane);
-  { const int S = c.bi[AGX_H_SIM_SUBSTEPS]; c.hooks = S <= 1 || (phase + 1) % S == 0; }   // phase: index of this substep within the env step
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
   c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
@@ -408,6 +407,13 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
   { const float ls = c.lds[L_ST + c.s_env + AGX_E_LIMIT_SCALE]; c.limit_scale = ls > 0.f ? ls : 1.f; }   // records written before v6 carry 0
   c.coop = TKI(c, AGX_T_COOP) == 1;
+  // hooks (env.py:227-231) run after the last internal substep of a p.stepSimulation() call of take_step -- not in the reset-time settle
+  // loops, which are plain engine steps (AGX_PHASE_SETTLE), and only while the human is in env.agents: controllable or tremor
+  // (env.py:130-131).  A human arm that is dynamic because of a reactive hold only (scratch itch, arm manipulation, dressing;
+  // human.py:108,124-127) is never limit-reset by the reference.
+  { const int S = c.bi[AGX_H_SIM_SUBSTEPS], ph = phase & ~AGX_PHASE_SETTLE;
+    const bool tremor_on = wave_any(lane < c.nhdof && lds[L_ST + c.s_tremor + lane] != 0.f);
+    c.hooks = (S <= 1 || (ph + 1) % S == 0) && !(phase & AGX_PHASE_SETTLE) && (c.coop || tremor_on); }
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0, dv1;
   if (!(rowspace && pgs_rowspace(c, lds + L_SOLVE_ENT, dv0, dv1))) pgs(c, dv0, dv1);

@@ -22,6 +22,15 @@ from .reset_bed import ArmChain, BedBathingSawyerReset, mat_to_quat_batch, place
 D = np.deg2rad
 
 
+def point_on_limb(rng, radius, length):
+    """Util.point_on_capsule (util.py:58-78) for p1 = 0, p2 = (0, 0, -length), theta_range = (0, 2 pi), as generate_target calls it
+    (scratch_itch.py:140): two draws, a length along the axis in [radius, length] and an angle."""
+    rl = rng.uniform(radius, length)
+    th = rng.uniform(0, 2 * np.pi)
+    axis, ortho, normal = np.array([0, 0, -1.0]), np.array([0, -1.0, 0]), np.array([-1.0, 0, 0])     # Util.orthogonal_vector of (0, 0, -1)
+    return rl * axis + radius * np.cos(th) * ortho + radius * np.sin(th) * normal
+
+
 class ScratchItchReset(BedBathingSawyerReset):
     def __init__(self, blob):
         assert blob.task_kind == L.TASK_SCRATCH_ITCH
@@ -113,10 +122,7 @@ class ScratchItchReset(BedBathingSawyerReset):
         # generate_target (scratch_itch.py:134-146): limb, then a point on its capsule (util.py:58-78)
         limb = int(rng.randint(2))
         radius, length = hm.dims['upperarm' if limb == 0 else 'forearm']
-        rl = rng.uniform(radius, length)
-        th = rng.uniform(0, 2 * np.pi)
-        axis, ortho, normal = np.array([0, 0, -1.0]), np.array([0, -1.0, 0]), np.array([-1.0, 0, 0])     # Util.orthogonal_vector of (0, 0, -1)
-        target_on_arm = rl * axis + radius * np.cos(th) * ortho + radius * np.sin(th) * normal
+        target_on_arm = point_on_limb(rng, radius, length)
         task = v['task'][0]
         task[:] = 0
         task[L.SI['TARGET']:L.SI['TARGET'] + 3] = target_on_arm.astype(np.float32).view(np.int32)

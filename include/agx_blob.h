@@ -19,6 +19,10 @@
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
 #define AGX_LIMIT_EPS 1e-6f
+/* launch flag OR-ed into the `phase` argument of the solve kernel: this substep belongs to a reset-time settle loop (plain
+ * p.stepSimulation() calls: feeding.py:178-179, bed_bathing.py:130-131, arm_manipulation.py:145-146, dressing.py:190-193), so none of
+ * the hooks take_step runs between its stepSimulation calls (env.py:227-231) apply */
+#define AGX_PHASE_SETTLE 0x40000000
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
 /* face manifold on static world boxes (table top, ground): besides the closest point, up to AGX_FACE_EXTRA more
  * vertices of the other collider become contact candidates -- those within AGX_FACE_BAND of its lowest vertex,

@@ -26,6 +26,7 @@
 #define MAXV 80 /* max vertices of one collider core */
 #define MAXCOLL 512
 #define MAXQPT 16
+#define MAXMAN 192
 
 typedef struct { double p[3]; double R[9]; } xf_t;
 
@@ -198,6 +199,11 @@ typedef struct {
   double limit_scale;    /* scale of the human joint limits (impairment 'limits') */
   double human_kp, human_maxf;   /* per-env motor gain / force of the human's joints, 0 = the blob's (AGX_E_HUMAN_KP) */
   int coop;              /* the human is controllable (TASK.COOP) */
+  int human_agent;       /* the human is in env.agents: controllable or tremor (env.py:130-131).  Only then does take_step's loop reach
+                          * Agent.enforce_joint_limits / enforce_realistic_joint_limits (env.py:227-231): a human whose arm is dynamic only
+                          * because of a reactive hold (scratch itch, arm manipulation, dressing; human.py:108,124-127) is never limit-reset */
+  int settling;          /* reset-time stepSimulation loops (feeding.py:178-179, bed_bathing.py:130-131, arm_manipulation.py:145-146,
+                          * dressing.py:190-193) are plain engine steps: no hooks */
   uint32_t rng[2];
   /* derived, per substep */
   xf_t link[MAXDOF], freex[MAXFREE];
@@ -213,6 +219,7 @@ typedef struct {
   double arm_prev[4]; int arm_has_prev;                    /* arm_previous_valid_pose (human.py:147-149) */
   double si_target[3], si_prev[3]; int si_limb;            /* scratch itch: target_on_arm, prev_target_contact_pos, limb (scratch_itch.py:134-146,96) */
   int contact_overflow;
+  contact_t man[MAXMAN]; int nman;                         /* every narrowphase hit (separation < CONTACT_BREAK) of the groups whose manifold the task reads (flag bit 1), in collide order: what getContactPoints lists for them, with or without force (world API below) */
   row_t* rows; int nrows;
   /* dressing: the cloth (node positions / velocities live with the caller), its attachment point and the contacts of the last substep */
   double dr_gravity, dr_force_sum, dr_best;
@@ -242,6 +249,8 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
   s->frozen = ei[AGX_E_FROZEN];
   s->limit_scale = e[AGX_E_LIMIT_SCALE] > 0 ? e[AGX_E_LIMIT_SCALE] : 1.0;   /* records written before v6 carry 0 */
   s->coop = TI(m, AGX_T_COOP) == 1;
+  s->human_agent = s->coop;
+  for (int k = 0; k < m->nhdof; k++) if (st[m->s_tremor + k] != 0) s->human_agent = 1;          /* impairment == 'tremor' */
   s->human_kp = e[AGX_E_HUMAN_KP]; s->human_maxf = e[AGX_E_HUMAN_MAXF];
   for (int k = 0; k < m->nhdof; k++) { s->tremor[k] = st[m->s_tremor + k]; s->tremor_target[k] = st[m->s_tremor + m->nhdof + k]; }
   for (int k = 0; k < 3; k++) s->target[k] = e[AGX_E_TARGET + k];
@@ -696,7 +705,7 @@ static void collide(sim_t* s) {
     double g = collider_speed(s, c) * dt0;
     for (int k = 0; k < 3; k++) { lo[c][k] -= g; hi[c][k] += g; }
   }
-  s->ncon = 0; s->food_near_human = 0; s->contact_overflow = 0; s->nqpt = 0;
+  s->ncon = 0; s->food_near_human = 0; s->contact_overflow = 0; s->nqpt = 0; s->nman = 0;
   double dt = m->dt, slack = PARAM(m, AGX_P_CONTACT_SLACK);
   for (int g = 0; g < m->ngroup; g++) {
     int a0 = GI(m, g, AGX_G_A0), a1 = GI(m, g, AGX_G_A1), b0 = GI(m, g, AGX_G_B0), b1 = GI(m, g, AGX_G_B1);
@@ -720,6 +729,7 @@ static void collide(sim_t* s) {
         if (sep) continue;
         contact_t k;
         if (!narrowphase_ab(s, a, b, brk, &k, lo[a], hi[a])) continue;
+        if ((GI(m, g, AGX_G_FLAGS) & 2) && s->nman < MAXMAN) s->man[s->nman++] = k;
         /* a manifold point exists (what getContactPoints reports, agent.py:100-116) */
         if (m->task_kind == AGX_TASK_FEEDING && CI(m, a, AGX_C_TAG) == AGX_TAG_FOOD && CI(m, b, AGX_C_TAG) == AGX_TAG_HUMAN)
           s->food_near_human |= 1 << (CI(m, a, AGX_C_BODY) - AGX_BODY_FREE0 - m->food0);
@@ -1205,11 +1215,11 @@ static void substep_h(sim_t* s, int hooks) {
   }
   if (hooks) arm_limits(s);   /* env.py:230-231, after the limit reset above */
 }
-static void substep(sim_t* s) { substep_h(s, 1); }
+static void substep(sim_t* s) { substep_h(s, s->human_agent && !s->settling); }
 /* one p.stepSimulation(): sim_sub internal substeps (numSubSteps, dressing.py:184), the hooks after the last one */
 static void sim_step(sim_t* s) {
   s->anchor_set = 0;   /* DressingEnv.update_targets after the previous call moved the cloth's attachment to the end effector (dressing.py:200-210) */
-  for (int k = 0; k < s->m->sim_sub; k++) substep_h(s, k == s->m->sim_sub - 1);
+  for (int k = 0; k < s->m->sim_sub; k++) substep_h(s, k == s->m->sim_sub - 1 && s->human_agent && !s->settling);
 }
 
 /* ------------------------------------------------------------------------------------ task layer */
@@ -1734,6 +1744,7 @@ void agxo_settle_cloth(const agxo_model* m, float* state, float* cloth, int n_si
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
   s->rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
   cloth_attach(s, cloth);
+  s->settling = 1;
   for (int k = 0; k < n_sim_steps; k++) sim_step(s);
   kinematics(s); update_target(s);
   cloth_detach(s, cloth);
@@ -1921,4 +1932,148 @@ int agxo_substep_debug(const agxo_model* m, float* state, double* out, int max_o
   for (int c = 0; c < n; c++) { double* o = out + 13 * c; const contact_t* k = &s->con[c];
     o[0] = k->ca; o[1] = k->cb; memcpy(o + 2, k->pa, 24); memcpy(o + 5, k->pb, 24); memcpy(o + 8, k->n, 24); o[11] = k->dist; o[12] = k->lambda_n; }
   sim_store(s, state); free(s->rows); free(s); return n;
+}
+
+/* ------------------------------------------------------------------------------------ world API
+ * A persistent double-precision simulation that a PyBullet-shaped facade (tests/refbridge/) drives call by call, so that the
+ * REFERENCE'S OWN Python (AssistiveEnv.take_step, <Task>Env.step / _get_obs / get_total_force / get_food_rewards,
+ * human_preferences, Agent.enforce_joint_limits, Human.enforce_realistic_joint_limits) runs on top of this oracle's physics:
+ * one agxo_world_step() is one p.stepSimulation() and nothing else -- no action processing, no limit reset, no arm-limit
+ * classifier, no task layer; those stay with the caller.  Test infrastructure, like the rest of this file. */
+struct agxo_world { sim_t s; int fresh; int anchor_given; double anchor[3]; };
+
+static void world_refresh(agxo_world* w) { if (!w->fresh) { kinematics(&w->s); w->fresh = 1; } }
+
+agxo_world* agxo_world_create(const agxo_model* m, const float* state, const float* cloth) {
+  agxo_world* w = (agxo_world*)calloc(1, sizeof *w);
+  sim_load(&w->s, m, state);
+  w->s.rows = (row_t*)malloc(sizeof(row_t) * MAXROWS);
+  cloth_attach(&w->s, cloth);
+  w->fresh = 0; w->anchor_given = 0;
+  return w;
+}
+void agxo_world_store(agxo_world* w, float* state, float* cloth) {
+  sim_store(&w->s, state);
+  if (cloth && w->s.cx) { const int n3 = 3 * agxo_cloth_nodes(w->s.m); for (int k = 0; k < n3; k++) { cloth[k] = (float)w->s.cx[k]; cloth[n3 + k] = (float)w->s.cv[k]; } }
+}
+void agxo_world_free(agxo_world* w) {
+  if (!w) return;
+  if (w->s.cx) { free(w->s.cx); free(w->s.cv); free(w->s.cq); free(w->s.ccon); }
+  free(w->s.rows); free(w);
+}
+/* getJointStates / resetJointState / setJointMotorControlArray(targetPositions) by DoF */
+void agxo_world_joints(agxo_world* w, double* q, double* qd, double* qt) {
+  for (int d = 0; d < w->s.ndof; d++) { if (q) q[d] = w->s.q[d]; if (qd) qd[d] = w->s.qd[d]; if (qt) qt[d] = w->s.qt[d]; }
+}
+void agxo_world_reset_joint(agxo_world* w, int d, double q, double qd) { w->s.q[d] = q; w->s.qd[d] = qd; w->fresh = 0; }
+void agxo_world_set_target(agxo_world* w, int d, double qt) { w->s.qt[d] = qt; }
+/* resetBasePositionAndOrientation of a free body given its BASE (URDF root link) frame; velocities kept (as Bullet does) */
+void agxo_world_set_free_base(agxo_world* w, int b, const double* pos, const double* quat) {
+  sim_t* s = &w->s; const agxo_model* m = s->m;
+  double rp[3] = {FF(m, b, AGX_F_REFPOS), FF(m, b, AGX_F_REFPOS + 1), FF(m, b, AGX_F_REFPOS + 2)};
+  double rq[4] = {FF(m, b, AGX_F_REFQUAT), FF(m, b, AGX_F_REFQUAT + 1), FF(m, b, AGX_F_REFQUAT + 2), FF(m, b, AGX_F_REFQUAT + 3)};
+  /* base = com o ref  =>  com = base o ref^-1 */
+  double Rb[9], Rr[9], Rc[9], t[3]; quat_to_mat(quat, Rb); quat_to_mat(rq, Rr); mmt3(Rb, Rr, Rc);
+  mv3(Rc, rp, t); for (int k = 0; k < 3; k++) s->fpos[b][k] = pos[k] - t[k];
+  mat_to_quat(Rc, s->fquat[b]); w->fresh = 0;
+}
+/* the cloth's attachment body (dressing.py:200-210: teleported to the end effector by update_targets); until it is given the
+ * oracle's own rule applies (the end effector where the stepSimulation call began) */
+void agxo_world_set_anchor(agxo_world* w, const double* pos) { memcpy(w->anchor, pos, 24); w->anchor_given = 1; }
+/* one p.stepSimulation(): SIM_SUBSTEPS internal substeps, no hooks */
+void agxo_world_step(agxo_world* w) {
+  sim_t* s = &w->s;
+  if (w->anchor_given) { memcpy(s->anchor, w->anchor, 24); s->anchor_set = 1; } else s->anchor_set = 0;
+  for (int k = 0; k < s->m->sim_sub; k++) substep_h(s, 0);
+  w->fresh = 0;
+}
+/* world frames and velocities (getLinkState(computeForwardKinematics, computeLinkVelocity) / getBasePositionAndOrientation / getBaseVelocity).
+ * kind 0: URDF link frame of moving link `index`; 1: base frame of free body `index`; 2: static human collision body `index`;
+ * 3: robot base; 4: end-effector frame of tool `index` (robot.right/left_end_effector); 5: the frame of the tool the task observes
+ * (AGX_T_TOOL_OBS_*, e.g. link 1 of the wiper) for free body `index`.  lin = velocity of the frame origin.  Returns 0 on a bad kind */
+int agxo_world_frame(agxo_world* w, int kind, int index, double* pos, double* quat, double* lin, double* ang) {
+  world_refresh(w);
+  sim_t* s = &w->s; const agxo_model* m = s->m;
+  double p[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, v[3] = {0, 0, 0}, om[3] = {0, 0, 0};
+  if (kind == 0 || kind == 4) {
+    int L = kind == 0 ? index : TI(m, index ? AGX_T_EE2_LINK : AGX_T_EE_LINK);
+    if (L < 0 || L >= s->ndof) return 0;
+    if (kind == 0) { memcpy(p, s->link[L].p, 24); memcpy(R, s->link[L].R, 72); }
+    else { xf_t ee; ee_frame_of(s, index, &ee); memcpy(p, ee.p, 24); memcpy(R, ee.R, 72); }
+    double wxp[3]; cross3(s->vsp[L], p, wxp); add3(s->vsp[L] + 3, wxp, v); memcpy(om, s->vsp[L], 24);
+  } else if (kind == 1 || kind == 5) {
+    if (index < 0 || index >= s->nfree) return 0;
+    if (kind == 5) tool_base_pose_of(s, index, p, R);
+    else { double rp[3] = {FF(m, index, AGX_F_REFPOS), FF(m, index, AGX_F_REFPOS + 1), FF(m, index, AGX_F_REFPOS + 2)};
+      double rq[4] = {FF(m, index, AGX_F_REFQUAT), FF(m, index, AGX_F_REFQUAT + 1), FF(m, index, AGX_F_REFQUAT + 2), FF(m, index, AGX_F_REFQUAT + 3)}, Rr[9];
+      quat_to_mat(rq, Rr); xf_apply(&s->freex[index], rp, p); mm3(s->freex[index].R, Rr, R); }
+    double r[3], wr[3]; sub3(p, s->fpos[index], r); cross3(s->fw[index], r, wr); add3(s->fv[index], wr, v); memcpy(om, s->fw[index], 24);
+  } else if (kind == 2) { if (index < 0 || index >= m->nhuman) return 0; memcpy(p, s->human[index].p, 24); memcpy(R, s->human[index].R, 72); }
+  else if (kind == 3) { memcpy(p, s->base.p, 24); memcpy(R, s->base.R, 72); }
+  else return 0;
+  if (pos) memcpy(pos, p, 24); if (quat) mat_to_quat(R, quat); if (lin) memcpy(lin, v, 24); if (ang) memcpy(ang, om, 24);
+  return 1;
+}
+/* getContactPoints after the last agxo_world_step: rows of 16 doubles {colliderA, colliderB, pA(3), pB(3), n(3) from B to A,
+ * distance, normal force, 1 = solver contact / 0 = manifold point without a solver row}.  First the manifold points of the groups
+ * whose manifold the task reads (collide order; force of the solver contact of the same pair, if any), then the remaining solver
+ * contacts.  Returns the count */
+int agxo_world_contacts(agxo_world* w, double* out, int max_out) {
+  sim_t* s = &w->s; const double dt = s->m->dt; int n = 0;
+  unsigned char used[MAXC]; memset(used, 0, sizeof used);
+  for (int q = 0; q < s->nman; q++) {
+    const contact_t* k = &s->man[q]; double f = 0; int solver = 0;
+    for (int c = 0; c < s->ncon; c++) if (!used[c] && s->con[c].ca == k->ca && s->con[c].cb == k->cb) { f = s->con[c].lambda_n / dt; solver = 1; used[c] = 1; break; }
+    if (n < max_out) { double* o = out + 16 * n; o[0] = k->ca; o[1] = k->cb; memcpy(o + 2, k->pa, 24); memcpy(o + 5, k->pb, 24); memcpy(o + 8, k->n, 24); o[11] = k->dist; o[12] = f; o[13] = solver; o[14] = o[15] = 0; }
+    n++;
+  }
+  for (int c = 0; c < s->ncon; c++) {
+    if (used[c]) continue;
+    const contact_t* k = &s->con[c];
+    if (n < max_out) { double* o = out + 16 * n; o[0] = k->ca; o[1] = k->cb; memcpy(o + 2, k->pa, 24); memcpy(o + 5, k->pb, 24); memcpy(o + 8, k->n, 24); o[11] = k->dist; o[12] = k->lambda_n / dt; o[13] = 1; o[14] = o[15] = 0; }
+    n++;
+  }
+  return n;
+}
+/* getClosestPoints(distance): one row {colliderA, colliderB, pA(3), pB(3), distance} per collider pair closer than `dist`, at the current poses */
+int agxo_world_closest(agxo_world* w, const int* ca, int na, const int* cb, int nb, double dist, double* out, int max_out) {
+  world_refresh(w);
+  sim_t* s = &w->s; int n = 0;
+  for (int a = 0; a < na; a++) for (int b = 0; b < nb; b++) {
+    contact_t k; if (!narrowphase(s, ca[a], cb[b], dist, &k) || k.dist >= dist) continue;
+    if (n < max_out) { double* o = out + 9 * n; o[0] = ca[a]; o[1] = cb[b]; memcpy(o + 2, k.pa, 24); memcpy(o + 5, k.pb, 24); o[8] = k.dist; }
+    n++;
+  }
+  return n;
+}
+/* getSoftBodyData: node positions x[NN][3] and the contacts of the last internal substep {x, y, z, fx, fy, fz}; returns the contact count */
+int agxo_world_cloth(agxo_world* w, double* x, double* contacts, int max_contacts) {
+  sim_t* s = &w->s; if (!s->cx) return -1;
+  const int n3 = 3 * agxo_cloth_nodes(s->m);
+  if (x) memcpy(x, s->cx, sizeof(double) * n3);
+  int n = s->nccon < max_contacts ? s->nccon : max_contacts;
+  if (contacts) memcpy(contacts, s->ccon, sizeof(double) * 6 * n);
+  return s->nccon;
+}
+void agxo_world_set_cloth_gravity(agxo_world* w, double gz) { w->s.dr_gravity = gz; }
+/* Util.sleeve_on_arm_reward as finish_dressing evaluates it (util.py:134-202), for direct comparison with the reference's function:
+ * pts[6][3], shoulder / elbow / wrist, the common radius -> out[9] = {forearm_in_sleeve, upperarm_in_sleeve, distance_along_forearm,
+ * distance_along_upperarm, distance_to_hand, distance_to_elbow, distance_to_shoulder, forearm_length, upperarm_length} */
+void agxo_sleeve_reward(const double* pts6, const double* shoulder, const double* elbow, const double* wrist, double rad, double* out) {
+  const double (*pts)[3] = (const double (*)[3])pts6;
+  double we[3], es[3]; sub3(wrist, elbow, we); sub3(shoulder, elbow, es);
+  const double lwe = sqrt(dot3(we, we)), les = sqrt(dot3(es, es));
+  double hand_end[3], elbow_end[3], shoulder_end[3];
+  for (int k = 0; k < 3; k++) { hand_end[k] = wrist[k] + we[k] / lwe * rad * 2; elbow_end[k] = elbow[k] - we[k] / lwe * rad; shoulder_end[k] = shoulder[k] + es[k] / les * rad; }
+  const int around_fore = points_around_axis(pts, 6, elbow_end, hand_end, hand_end), around_upper = points_around_axis(pts, 6, shoulder_end, elbow_end, shoulder_end);
+  const int f1 = line_intersects_triangle(pts[0], pts[1], pts[2], hand_end, elbow_end), f2 = line_intersects_triangle(pts[3], pts[4], pts[5], hand_end, elbow_end);
+  const int u1 = line_intersects_triangle(pts[0], pts[1], pts[2], elbow_end, shoulder_end), u2 = line_intersects_triangle(pts[3], pts[4], pts[5], elbow_end, shoulder_end);
+  double centre[3] = {0, 0, 0}, d[3]; for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) centre[k] += pts[i][k] / 6.0;
+  out[0] = around_fore && (f1 || f2); out[1] = around_upper && (u1 || u2);
+  sub3(hand_end, centre, d); out[2] = out[4] = sqrt(dot3(d, d));
+  sub3(centre, elbow, d); out[3] = sqrt(dot3(d, d));
+  sub3(elbow_end, centre, d); out[5] = sqrt(dot3(d, d));
+  sub3(shoulder_end, centre, d); out[6] = sqrt(dot3(d, d));
+  sub3(hand_end, elbow_end, d); out[7] = sqrt(dot3(d, d));
+  out[8] = les;
 }

@@ -69,6 +69,25 @@ int agxo_collide(const agxo_model* m, const float* state, double* out, int max_o
 int agxo_rows_debug(const agxo_model* m, float* state, double* out, int max_out);
 int agxo_substep_debug(const agxo_model* m, float* state, double* contacts_out, int max_out);
 
+/* ---- world API (tests/refbridge): a persistent f64 simulation driven call by call through a PyBullet-shaped facade, so that the
+ * reference's own Python half runs on this oracle's physics.  One agxo_world_step = one p.stepSimulation(), nothing else. */
+typedef struct agxo_world agxo_world;
+agxo_world* agxo_world_create(const agxo_model* m, const float* state, const float* cloth);
+void agxo_world_store(agxo_world* w, float* state, float* cloth);
+void agxo_world_free(agxo_world* w);
+void agxo_world_joints(agxo_world* w, double* q, double* qd, double* qt);
+void agxo_world_reset_joint(agxo_world* w, int dof, double q, double qd);
+void agxo_world_set_target(agxo_world* w, int dof, double qt);
+void agxo_world_set_free_base(agxo_world* w, int body, const double* pos3, const double* quat4);
+void agxo_world_set_anchor(agxo_world* w, const double* pos3);
+void agxo_world_set_cloth_gravity(agxo_world* w, double gz);
+void agxo_world_step(agxo_world* w);
+int agxo_world_frame(agxo_world* w, int kind, int index, double* pos3, double* quat4, double* lin3, double* ang3);
+int agxo_world_contacts(agxo_world* w, double* out16, int max_out);
+int agxo_world_closest(agxo_world* w, const int* ca, int na, const int* cb, int nb, double dist, double* out9, int max_out);
+int agxo_world_cloth(agxo_world* w, double* x, double* contacts6, int max_contacts);
+void agxo_sleeve_reward(const double* pts6, const double* shoulder, const double* elbow, const double* wrist, double rad, double* out9);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,7 +55,7 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
   for (int k = 0; k < nsub && !rc; k++) {
     const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (k == 0) ? debug : nullptr;
     rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, dbg, lds, lane); });
-    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, k); });
+    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, mode == 1 ? (k | AGX_PHASE_SETTLE) : k); });
   }
   if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
   return rc;
