@@ -57,6 +57,10 @@ AGX_DEV void pgs_row(PgsSet& S, const float& lam_normal, const PgsBuf& X, int la
   wave_opaque(dv0);       // keeps the two updates scalar: a packed FMA would need (c0, c1) in adjacent registers
   dv1 += X.c1 * dl;
 }
+AGX_DEV uint64_t pgs_range_mask(int l0, int l1) {
+  const uint64_t hi = l1 >= 64 ? ~0ull : ((1ull << l1) - 1ull), lo = l0 >= 64 ? ~0ull : ((1ull << l0) - 1ull);
+  return hi & ~lo;
+}
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_PGS_CPP)
 // ---- the Gauss-Seidel sweep in gfx950 assembly ------------------------------------------------------
 // The compiler's schedule of the loop above is poor in exactly the places that matter: it rotates
@@ -205,10 +209,6 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
 // lo/hi are the per-lane bounds of this sweep (for friction sets already scaled by the normal
 // impulses).  `rows` has one bit per row slot to visit; rows below slot `ls` have all their pairs inside
 // the LDS window, the others stream from global.
-AGX_DEV uint64_t pgs_range_mask(int l0, int l1) {
-  const uint64_t hi = l1 >= 64 ? ~0ull : ((1ull << l1) - 1ull), lo = l0 >= 64 ? ~0ull : ((1ull << l0) - 1ull);
-  return hi & ~lo;
-}
 AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int lane, uint64_t rows, int ls, float& dv0, float& dv1) {
   const uint64_t in_lds = rows & pgs_range_mask(0, ls), in_glb = rows & ~pgs_range_mask(0, ls);
   if (in_lds) {
@@ -221,37 +221,27 @@ AGX_DEV void pgs_sweep_asm(PgsSet& S, float lo, float hi, const float* E, int la
   }
 }
 #endif
+// `skip`: row slots of [l0, l1) that are not visited in this sweep (the no-op re-test rule of pgs(), AGX_P_NOOP_RETEST)
 template <bool FRICTION>
-AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int lane, int l0, int ls, int l1, float& dv0, float& dv1) {
+AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int lane, int l0, int ls, int l1, float& dv0, float& dv1, uint64_t skip = 0ull) {
   if (l1 <= l0) return;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_PGS_CPP)
-  const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
-  uint64_t rows = pgs_range_mask(l0, l1);
+  uint64_t rows = pgs_range_mask(l0, l1) & ~skip;
   // A friction row whose normal impulse is zero has the bounds [0, 0]; if its own impulse is zero as
   // well its update is exactly "no change", so the visit is skipped.  The normal impulses do not
   // change during a friction sweep and a friction impulse only changes at its own visit, so the set
   // of rows to visit is known up front.  (More than half of the contacts are speculative and inactive.)
   if (FRICTION) rows &= wave_ballot(lam_normal != 0.f || S.lam != 0.f);
+  if (!rows) return;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_PGS_CPP)
+  const float hi = FRICTION ? S.hi * lam_normal : S.hi, lo = FRICTION ? -hi : S.lo;
   pgs_sweep_asm(S, lo, hi, E, lane, rows, ls, dv0, dv1);
 #else
   (void)ls;
-  PgsBuf A, B, C;
-  const int last = l1 - 1;
-#define AGX_PGS_FETCH_C(X, r) { const int rr_ = (r) < last ? (r) : last; pgs_fetch(E, lane, wave_bcast_i(S.pack, rr_), wave_bcast_i(S.off, rr_) & 0x7fffffff, X); }
-  AGX_PGS_FETCH_C(A, l0);
-  AGX_PGS_FETCH_C(B, l0 + 1);
-  for (int rl = l0;; rl += 3) {
-    AGX_PGS_FETCH_C(C, rl + 2);
-    pgs_row<FRICTION>(S, lam_normal, A, lane, rl, dv0, dv1);
-    if (rl + 1 >= l1) break;
-    AGX_PGS_FETCH_C(A, rl + 3);
-    pgs_row<FRICTION>(S, lam_normal, B, lane, rl + 1, dv0, dv1);
-    if (rl + 2 >= l1) break;
-    AGX_PGS_FETCH_C(B, rl + 4);
-    pgs_row<FRICTION>(S, lam_normal, C, lane, rl + 2, dv0, dv1);
-    if (rl + 3 >= l1) break;
+  while (rows) {
+    const int rl = ffs64(rows); rows &= rows - 1ull;
+    PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(S.pack, rl), wave_bcast_i(S.off, rl) & 0x7fffffff, X);
+    pgs_row<FRICTION>(S, lam_normal, X, lane, rl, dv0, dv1);
   }
-#undef AGX_PGS_FETCH_C
 #endif
 }
 AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet& S) {
@@ -311,14 +301,21 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
     wave_sync();
     float w = 0.f;                                                  // J_r . dv of this lane's row
     const int fn = lane - nc;                                       // normal row of this lane's friction row
+    const int K = (int)PRM(c, AGX_P_NOOP_RETEST);                   // the no-op re-test rule, see pgs()
+    uint64_t skip = 0ull;
     for (int it = 0; it < iters; it++) {
-      for (int r = 0; r < nA; r++) {                                // non-contact rows and contact normals
+      const bool retest = K > 0 && it % K == 0;
+      const float before = S.lam;
+      uint64_t rowsA = pgs_range_mask(0, nA) & ~((K > 0 && !retest) ? skip : 0ull);
+      while (rowsA) {                                               // non-contact rows and contact normals
+        const int r = ffs64(rowsA); rowsA &= rowsA - 1ull;
         const float arow = A[RS_MAX_ROWS * r + lane];
         const float nl = wave_clamp(S.lam + (S.b - w) * S.invD, S.lo, S.hi);
         const float dl = wave_bcast(nl - S.lam, r);
         if (lane == r) S.lam = nl;
         w += arow * dl;
       }
+      if (retest) skip = wave_ballot(S.lam == before) & pgs_range_mask(0, nA);
       if (nc > 0) {
         wave_sync(); LAM[lane] = S.lam; wave_sync();
         const float ln = (lane >= nA && lane < R) ? LAM[fn] : 0.f;  // the normal impulses do not change during the friction pass
@@ -364,9 +361,18 @@ AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   // this is a prefix of its lane range)
   const int s0 = pgs_lds_split(A0, lane, 0, a0n), s1 = pgs_lds_split(A1, lane, 0, a1n);
   const int t0 = pgs_lds_split(B0, lane, f0a, f0b), t1 = pgs_lds_split(B1, lane, f1a, f1b);
+  // AGX_P_NOOP_RETEST = K > 0: a row of the non-friction block (motors, limits, tool rows, contact normals) whose visit in a re-test
+  // sweep (sweep index divisible by K) changed nothing -- an inactive contact or limit (0 -> 0), a motor sitting on its force bound --
+  // is not visited in the K - 1 sweeps that follow (42 % of these visits are no-ops in FeedingJaco; the oracle applies the same
+  // rule, pgs() in oracle/agx_oracle.c; sensitivity: profiles/r03/noop_retest_sensitivity.json).  K = 0: every row in every sweep.
+  const int K = (int)PRM(c, AGX_P_NOOP_RETEST);
+  uint64_t skip0 = 0ull, skip1 = 0ull;
   for (int it = 0; it < iters; it++) {
-    pgs_sweep<false>(A0, A0.lam, E, lane, 0, s0, a0n, dv0, dv1);
-    pgs_sweep<false>(A1, A1.lam, E, lane, 0, s1, a1n, dv0, dv1);
+    const bool retest = K > 0 && it % K == 0, use = K > 0 && !retest;
+    const float b0 = A0.lam, b1 = A1.lam;
+    pgs_sweep<false>(A0, A0.lam, E, lane, 0, s0, a0n, dv0, dv1, use ? skip0 : 0ull);
+    pgs_sweep<false>(A1, A1.lam, E, lane, 0, s1, a1n, dv0, dv1, use ? skip1 : 0ull);
+    if (retest) { skip0 = wave_ballot(A0.lam == b0); skip1 = wave_ballot(A1.lam == b1); }
     pgs_sweep<true>(B0, A0.lam, E, lane, f0a, t0, f0b, dv0, dv1);
     pgs_sweep<true>(B1, A1.lam, E, lane, f1a, t1, f1b, dv0, dv1);
   }

@@ -92,6 +92,8 @@ enum {
   AGX_P_CONTACT_SLACK,   /* solver rows only for contacts that could close within one substep:
                             dist + v_n*dt < slack (rows that stay inactive have no effect)         */
   AGX_P_MAX_ENTRIES,     /* cap on the summed (J,B) coefficient pairs of all rows of a substep    */
+  AGX_P_NOOP_RETEST,     /* K > 0: rows of the non-friction block whose visit in a re-test sweep (every K-th) was a no-op are skipped until
+                            the next re-test sweep; 0 = every row in every sweep (agx_pgs.h, oracle pgs())                 */
   AGX_P_COUNT = 24
 };
 

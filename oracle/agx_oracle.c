@@ -949,18 +949,33 @@ static void build_rows(sim_t* s) {
 }
 
 /* K6: projected Gauss-Seidel, fixed number of sweeps, rows in construction order */
+double g_pgs_stats[8];
+/* AGX_P_NOOP_RETEST = K > 0: a row of the non-friction block (motors, limits, tool rows, contact normals) whose visit in a re-test
+ * sweep (sweep index divisible by K) changed nothing -- an inactive contact or limit (0 -> 0), a motor sitting on its force bound --
+ * is not visited in the K - 1 sweeps that follow.  Skipped visits that would have been no-ops too change nothing; the others (a row
+ * that would have woken up between two re-tests) are the approximation, quantified in profiles/r03/noop_retest_sensitivity.json.
+ * K = 0: plain projected Gauss-Seidel, every row in every sweep.  Friction rows: a row whose bound is zero and whose impulse is zero
+ * is an exact no-op and is skipped by the device in any case. */
 static void pgs(sim_t* s, double* dv) {
   int iters = (int)PARAM(s->m, AGX_P_NITER);
+  const int K = (int)PARAM(s->m, AGX_P_NOOP_RETEST);
+  unsigned char skip[MAXROWS]; memset(skip, 0, sizeof skip);
   memset(dv, 0, sizeof(double) * NVMAX);
+  g_pgs_stats[5] += 1;
   for (int it = 0; it < iters; it++) for (int i = 0; i < s->nrows; i++) {
     row_t* r = &s->rows[i];
     if (r->invD == 0) continue;
+    const int retest = K > 0 && it % K == 0;
+    if (K > 0 && !retest && r->fric_of < 0 && skip[i]) continue;
     double lo = r->lo, hi = r->hi;
     if (r->fric_of >= 0) { double ln = s->rows[r->fric_of].lambda; hi = r->mu * ln; lo = -hi; }
     double jdv = 0; for (int k = 0; k < s->nv; k++) jdv += r->J[k] * dv[k];
     double nl = r->lambda + (r->b - jdv) * r->invD;
     if (nl < lo) nl = lo; if (nl > hi) nl = hi;
     double dl = nl - r->lambda; r->lambda = nl;
+    if (retest && r->fric_of < 0) skip[i] = dl == 0;
+    if (r->fric_of < 0) { g_pgs_stats[0] += 1; if (dl == 0) g_pgs_stats[1] += 1; }
+    else { g_pgs_stats[2] += 1; if (dl == 0) g_pgs_stats[3] += 1; if (hi == 0 && nl == 0 && dl == 0) g_pgs_stats[4] += 1; }
     if (dl != 0) for (int k = 0; k < s->nv; k++) dv[k] += r->B[k] * dl;
   }
 }
