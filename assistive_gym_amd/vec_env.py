@@ -121,6 +121,17 @@ class AssistiveVecEnv:
                            settle_substeps=settle, stream=s)
         self._episode += 1
 
+    def set_pool(self, states, cloth=None):
+        """Use the given post-reset states (float32 [pool_size, state_words]; with a garment each for models with a cloth) as the reset
+        pool instead of generating one -- e.g. a workload-specific pool (bench.py --workload wiping) or states sampled elsewhere."""
+        assert states.dtype == np.float32 and states.shape == (self.pool_size, self.blob.state_words)
+        self.pool_host = np.ascontiguousarray(states)
+        self.pool = torch.from_numpy(self.pool_host).to(self.device)
+        if cloth is not None:
+            self.cloth_pool_host = np.ascontiguousarray(cloth)
+            self.cloth_pool = torch.from_numpy(self.cloth_pool_host).to(self.device)
+            self.stepper.set_cloth_pool(self.cloth_pool)
+
     def reset(self, env_offset=0):
         """env_offset: global index of this shard's first env (multi-GPU sharding keeps the
         env -> initial state mapping independent of the GPU count)."""

@@ -117,57 +117,76 @@ def cpu_baseline(blob, states, envs_per_core, n_steps, model='feeding_jaco', wor
                        'per process %.0f env-steps/s; wall incl. start-up %.1f s' % (cores, envs_per_core, n_steps, workload, single, wall))
 
 
-def main():
-    if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
-        return _cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), *(sys.argv[5:6]))
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=50)
-    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
-    ap.add_argument('--pool', type=int, default=None, help='reset pool size (default 256; 64 for dressing, whose pool entries carry a garment and a 50-step device settle)')
-    ap.add_argument('--reset', choices=['pool', 'device', 'host'], default='pool',
-                    help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--task', choices=sorted(TASKS), default='feeding', help="'feeding' = the BASELINE metric (config 2); 'bedbathing' = config 3; 'scratchitch' = config 4's env (co-op) on one GPU")
-    ap.add_argument('--env', default=None, help="any built env id instead of --task, e.g. 'ScratchItchJaco-v1' or 'FeedingSawyerHuman-v1' (assistive_gym_amd.envs.ENV_IDS)")
-    args = ap.parse_args()
-    model, env_cls, ksuffix, env_id = TASKS[args.task]
-    if args.env is not None:             # the kernel-name suffix is that of the variant agx_create picks: taken from the stepper below
-        from assistive_gym_amd.envs import ENV_IDS
-        cls = ENV_IDS[args.env.split(':')[-1]]
-        model, env_cls, ksuffix, env_id = cls.model, None, None, args.env.split(':')[-1]
-        args.task = 'dressing' if model.startswith('dressing') else args.env
-    if args.pool is None:
-        args.pool = 64 if args.task == 'dressing' else 256
+def wiping_pool(blob, n, seed):
+    """BASELINE config 3 asks for 'dense tool-skin contact': post-reset states of BedBathingSawyer with the arm abducted and the wiping pad
+    pressed 4 mm into the forearm / the upper arm at a random place (the robot base is translated so that the pad lands there; the
+    reference's reset would have to be followed by a trained policy to get there).  Host code, pool generation only."""
+    from assistive_gym_amd.host.reset_bed import make_states
+    from assistive_gym_amd.model import xform as X
+    st, infos = make_states(blob, n, seed=seed, human_q_override={3: np.deg2rad(70)})
+    rng = np.random.RandomState(seed)
+    from assistive_gym_amd.model.human import HumanModel
+    for i in range(n):
+        s = st[i]
+        v = blob.view(s.reshape(1, -1))
+        g = int(v['gender'][0])
+        hm = HumanModel('male' if g == 0 else 'female')
+        nr = blob.nrobot
+        # world frames of the right arm links from the state's static / dynamic human records: joint chain 0..9 hangs off the chest
+        q = np.zeros(hm.n); q[:10] = v['q'][0, nr:nr + 10]
+        base = v['human'][0, 0]
+        pos, quat = hm.fk(base[:3].astype(np.float64), base[3:7].astype(np.float64), q)
+        sh, el, wr = pos[5], pos[7], pos[9]
+        fore = rng.rand() < 0.6
+        p0, p1 = (el, wr) if fore else (sh, el)
+        rad = hm.dims['forearm' if fore else 'upperarm'][0]
+        want = p0 + rng.uniform(0.25, 0.75) * (p1 - p0) + np.array([0, 0, rad + 0.0025 - 0.004])
+        fp, fq = v['free'][0, 0, :3].astype(np.float64), v['free'][0, 0, 3:7].astype(np.float64)
+        bp, bq = X.compose(fp, fq, blob.free_f(0, 'REFPOS', 3), blob.free_f(0, 'REFQUAT', 4))
+        pad, _ = X.compose(bp, bq, blob.task_f('TOOL_OBS_POS', 3), blob.task_f('TOOL_OBS_QUAT', 4))
+        d = (want - pad).astype(np.float32)
+        v['base'][0, :3] += d; v['free'][0, 0, :3] += d; v['free'][0, 0, 7:] = 0
+    return st
 
+
+def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, cpu=True, workload=None, env_id_override=None):
+    """one timed run of one configuration on this rank's GPU; returns the JSON-able dict on rank 0 (None elsewhere)"""
     import torch
     import torch.distributed as dist
-    from assistive_gym_amd.blob import ModelBlob
     from assistive_gym_amd import vec_env
     from assistive_gym_amd.shard import ObsGatherer
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: libagx has no CPU path')
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    model, env_cls, ksuffix, env_id = TASKS[task]
+    pool = args.pool
+    if env_id_override is not None:             # the kernel-name suffix is that of the variant agx_create picks: taken from the stepper below
+        from assistive_gym_amd.envs import ENV_IDS
+        cls = ENV_IDS[env_id_override.split(':')[-1]]
+        model, env_cls, ksuffix, env_id = cls.model, None, None, env_id_override.split(':')[-1]
+        task = 'dressing' if model.startswith('dressing') else env_id_override
+    if pool is None:
+        pool = 64 if task == 'dressing' else 256
     n = args.envs_per_gpu
+    blob_override = None
+    if args.param:
+        from assistive_gym_amd.blob import ModelBlob
+        blob_override = ModelBlob.load(model)
+        for kv in args.param:
+            k, v = kv.split('=')
+            blob_override = blob_override.set_param(k, float(v))
     if env_cls is None:
-        env = vec_env.AssistiveVecEnv(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset, model=model, coop=env_id.endswith('Human-v1'))
+        env = vec_env.AssistiveVecEnv(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, model=model, coop=env_id.endswith('Human-v1'), blob=blob_override)
         ksuffix = {'feeding': '', 'feeding_l': '_fl', 'bed_bathing': '_bb', 'bed_bathing_l': '_bbl', 'scratch_itch': '_si', 'dressing': '_dr', 'dressing_l': '_drl',
                    'arm_manipulation': '_am', 'arm_manipulation_l': '_aml'}[env.stepper.variant()]
     else:
-        env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=args.pool, reset=args.reset)
+        env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, blob=blob_override)
     blob = env.blob                      # the co-op flavour where the task's BASELINE config is co-op
+    action_scale = 1.0
+    if workload == 'wiping':
+        env.set_pool(wiping_pool(blob, pool, 1001))
+        action_scale = 0.15
     env.reset(env_offset=rank * n)
-    K, W = args.steps, args.warmup
+    K, W = steps, warmup
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
-    tape = torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1
+    tape = (torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1) * action_scale
     # whole-batch observation collation: RCCL all-gather on a side stream, overlapped with the next step (two buffers alternate)
     gatherer = ObsGatherer(n, blob.obs_dim, world, device=torch.device('cuda', local_rank)) if distributed else None
 
@@ -186,10 +205,14 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    overflow0 = env.stepper.overflow_count()
     env.stepper.profile_begin(stream)
     t0 = time.perf_counter()
+    ncon_sum, ncon_n = torch.zeros((), device='cuda', dtype=torch.float64), 0
     for k in range(W, W + K):
         one(k)
+        if (k - W) % 16 == 0:            # contacts of the last substep, sampled (device-side sum, no host sync)
+            ncon_sum += (env.info[:, 6] % 1000).double().mean(); ncon_n += 1
     kernel_ms = env.stepper.profile_end(stream)
     if distributed:
         gatherer.wait()                  # the last gathers are inside the timed region
@@ -200,6 +223,8 @@ def main():
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    overflow = env.stepper.overflow_count() - overflow0
+    contacts = float(ncon_sum.item()) / max(1, ncon_n)
     # per-kernel launch durations (HIP events after every launch, on the chunk stream it is launched on),
     # measured after the timed region so that `value` is not perturbed by the extra events / host syncs.
     # The step is issued as a few independent chunks of environments on internal streams, so launches of
@@ -217,19 +242,21 @@ def main():
             ms, cnt = env.stepper.step_timed(tape[(W + k) % (W + K)], env.obs, env.reward, env.done, env.info, stream)
             kms += np.array(ms); kcnt += np.array(cnt)
         kms /= NT; kcnt /= NT
+    out = None
     if rank == 0:
         total_steps = world * n * K
         value = total_steps / elapsed
         sw = blob.state_words
-        fs = int(blob.param('FRAME_SKIP'))
         # algorithmic HBM bytes per env-step: state record read + written once, action read, obs /
         # reward / done / info written (DESIGN.md "bytes per env-step")
         bytes_per_env_step = 2 * sw * 4 + blob.act_dim * 4 + blob.obs_dim * 4 + 4 + 1 + 8 * 4
         if has_cloth:                        # + the garment read and written once per env step: node positions and velocities
             bytes_per_env_step += 2 * env.cloth_pool_host[0].size * 4
         names = [k + ksuffix for k in ('agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel')]
+        traffic_key = None
         if has_cloth:
             names[2] = 'whole step (40 x [agx_build_kernel%s, agx_solve_kernel%s] + agx_cloth_kernel%s + agx_finish_kernel%s)' % ((ksuffix,) * 4)
+            traffic_key = 'agx_cloth_kernel' + ksuffix
         dom = int(np.argmax(kms))
         # one launch of the dominant kernel advances the environments of one chunk by 1/frame_skip of an env-step
         launches = [int(round(x)) for x in kcnt]
@@ -240,26 +267,32 @@ def main():
         achieved = bytes_per_env_step * units / (launch_ms * 1e-3) / 1e9
         # HBM traffic and VALU instruction counts of the same kernel from separate rocprofv3 --pmc passes (tools/pmc_workload.py,
         # reduced by tools/pmc_traffic.py to per-environment figures), scaled to the SAME launch size as the algorithmic bytes
-        traffic, traffic_src, valu_frac = None, None, None
-        for cand in ('r02_traffic_%s.json' % args.task, 'r01_traffic.json' if args.task == 'feeding' else None):
+        traffic, traffic_src, valu_frac, cloth_kernel = None, None, None, None
+        tname = task if workload is None else task + '_' + workload
+        for cand in ('r03_traffic_%s.json' % tname, 'r02_traffic_%s.json' % tname, 'r01_traffic.json' if task == 'feeding' else None):
             tpath = cand and os.path.join(ROOT, 'profiles', cand)
             if tpath and os.path.exists(tpath):
                 tj = json.load(open(tpath))
-                kj = tj.get('kernels', {}).get(names[dom])
+                kj = tj.get('kernels', {}).get(traffic_key or names[dom])
                 if kj:
                     traffic = kj['hbm_bytes_per_env_launch'] * envs_per_launch
                     traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s), per environment x %d environments per launch' % (cand, tj.get('correction', ''), envs_per_launch)
                     if 'valu_insts_per_env_launch' in kj:
                         # wave64 VALU instruction = 2 issue cycles on a SIMD-32 (guide, "Wave scheduling"); 1024 SIMDs
-                        valu_frac = kj['valu_insts_per_env_launch'] * envs_per_launch * 2.0 / (launch_ms * 1e-3 * SHADER_CLOCK_HZ * N_SIMD)
+                        ms_for = kj.get('ms_per_launch', launch_ms) if traffic_key else launch_ms
+                        valu_frac = kj['valu_insts_per_env_launch'] * envs_per_launch * 2.0 / (ms_for * 1e-3 * SHADER_CLOCK_HZ * N_SIMD)
+                    if traffic_key:
+                        cloth_kernel = dict(kernel=traffic_key, **{k: kj[k] for k in kj if k != 'hbm_bytes_per_env_launch'}, hbm_bytes_per_env_launch=kj['hbm_bytes_per_env_launch'])
                     break
         out = {
             'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s, %d lockstep envs per MI355X, random-policy rollout, 5 simulation steps per env step, 50 PGS sweeps' % (env_id, n),
-                       'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': args.pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
-                       'obs_allgather': bool(distributed)},
+            'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, 50 PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else 'pad pressed onto the arm at reset, small random actions (x%.2f)' % action_scale),
+                       'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
+                       'obs_allgather': bool(distributed), 'noop_retest': blob.param('NOOP_RETEST')},
+            'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps
+            'overflow_count': int(overflow),       # substeps (summed over environments) in which a contact was dropped by the contact / row / coefficient budgets
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': names[dom], 'kernel_ms_per_launch': launch_ms, 'launches_per_step': launches[dom],
@@ -271,13 +304,65 @@ def main():
                          'kernels_ms_per_step_summed_over_overlapping_launches': dict(zip(names, [float(x) for x in kms])),
                          'stream_ms_per_step': kernel_ms / K,
                          'step_level_achieved': bytes_per_env_step * n / (elapsed / K) / 1e9,
-                         'note': 'dependent-chain latency bound solver (VALU issue ~0.3 of peak); HBM fraction reported as the contract requires (SURVEY 8d)'},
+                         'note': 'solver bound by VALU / cross-lane issue per row visit, not by HBM; HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if cloth_kernel:
+            out['roofline']['cloth_kernel'] = cloth_kernel
+        if world == 1 and cpu:
             out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8 if not has_cloth else 2, 1000 if not has_cloth else 40,
                                                model + ('+coop' if blob.is_coop else ''), env_id, cloth=env.cloth_pool_host if has_cloth else None)
-        print(json.dumps(out))
     env.close()
+    return out
+
+
+def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
+        return _cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), *(sys.argv[5:6]))
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--pool', type=int, default=None, help='reset pool size (default 256; 64 for dressing, whose pool entries carry a garment and a 50-step device settle)')
+    ap.add_argument('--reset', choices=['pool', 'device', 'host'], default='pool',
+                    help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--task', choices=sorted(TASKS), default=None, help="'feeding' = the BASELINE metric (config 2, the default); 'bedbathing' = config 3; 'scratchitch' = config 4's env (co-op) on one GPU; 'dressing' = config 5's")
+    ap.add_argument('--workload', choices=['wiping'], default=None, help="bedbathing only: 'wiping' = the contact-rich variant of config 3 (pad pressed onto the arm)")
+    ap.add_argument('--env', default=None, help="any built env id instead of --task, e.g. 'ScratchItchJaco-v1' or 'FeedingSawyerHuman-v1' (assistive_gym_amd.envs.ENV_IDS)")
+    ap.add_argument('--param', action='append', default=[], help='override a PARAMS entry of the model blob, e.g. --param NOOP_RETEST=0 (same-box A/B runs)')
+    ap.add_argument('--no-configs', action='store_true', help='the default 1-GPU run also times short runs of BASELINE configs 3, 4 (1 GPU), 5 (1 GPU) into "configs"; this skips them')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('gloo' is for the CPU-side test of the launch path only; the stepper needs a GPU)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: libagx has no CPU path')
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        dist.init_process_group(args.backend, device_id=torch.device('cuda', local_rank))
+    headline = args.task is None and args.env is None
+    task = args.task or 'feeding'
+    out = run_config(args, task, args.steps, args.warmup, rank, world, local_rank, distributed, cpu=not args.no_cpu_baseline, workload=args.workload, env_id_override=args.env)
+    if headline and world == 1 and not args.no_configs:
+        # the other single-GPU BASELINE configurations on the same clock: short runs (a few seconds each), the headline value above is config 2
+        extra = {}
+        for key, t, wl, st in (('config3_BedBathingSawyer-v1', 'bedbathing', None, 300), ('config3_BedBathingSawyer-v1_wiping_contact', 'bedbathing', 'wiping', 300),
+                               ('config4_ScratchItchPR2Human-v1_1gpu', 'scratchitch', None, 300), ('config5_DressingBaxter-v1_1gpu', 'dressing', None, 30)):
+            r = run_config(args, t, st, 10, rank, world, local_rank, distributed, cpu=False, workload=wl)
+            extra[key] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'contacts_per_substep', 'overflow_count')}
+            extra[key]['workload'] = r['config']['workload']
+            extra[key]['roofline'] = {k: r['roofline'][k] for k in ('achieved', 'peak', 'frac', 'traffic', 'kernel', 'kernel_ms_per_launch', 'algorithmic_bytes_per_env_step', 'valu_issue_frac') if k in r['roofline']}
+            if 'cloth_kernel' in r['roofline']:
+                extra[key]['roofline']['cloth_kernel'] = r['roofline']['cloth_kernel']
+        out['configs'] = extra
+    if rank == 0:
+        print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
 

@@ -4,6 +4,9 @@ HBM bytes per kernel -> profiles/r02_traffic_<task>.json (read by bench.py for r
 roofline.valu_issue_frac).
 
   python tools/pmc_traffic.py <task> <fetch_counter_collection.csv> <write_counter_collection.csv> [<valu_counter_collection.csv>] [envs]
+      [--more <counter_collection.csv> ...] [--stats <kernel_stats.csv>] [--out profiles/r03_traffic_<task>.json]
+  --more: further PMC passes; every counter found is reported per environment and launch (`counters_per_env_launch`)
+  --stats: a rocprofv3 --kernel-trace --stats summary of the same workload -> `ms_per_launch`
 
 Units / corrections: both counters are in KiB.  On gfx950 FETCH_SIZE tallies 128-B requests at
 64 B, so it is doubled (guide); WRITE_SIZE is used as reported.  The observation-only launches of
@@ -40,13 +43,21 @@ def per_kernel_count(path, counter):
 
 
 def main():
+    argv = sys.argv
+    more, stats, outp = [], None, None
+    if '--out' in argv:
+        k = argv.index('--out'); outp = argv[k + 1]; del argv[k:k + 2]
+    if '--stats' in argv:
+        k = argv.index('--stats'); stats = argv[k + 1]; del argv[k:k + 2]
+    if '--more' in argv:
+        k = argv.index('--more'); more = argv[k + 1:]; del argv[k:]
     task = sys.argv[1]
     fetch, write = per_kernel(sys.argv[2], 'FETCH_SIZE'), per_kernel(sys.argv[3], 'WRITE_SIZE')
     valu = per_kernel_count(sys.argv[4], 'SQ_INSTS_VALU') if len(sys.argv) > 4 and sys.argv[4].endswith('.csv') else {}
     envs = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 4096
     sys.path.insert(0, ROOT)
     from assistive_gym_amd.blob import ModelBlob
-    blob = ModelBlob.load({'feeding': 'feeding_jaco', 'bedbathing': 'bed_bathing_sawyer', 'scratchitch': 'scratch_itch_pr2', 'armmanipulation': 'arm_manipulation_sawyer'}[task])
+    blob = ModelBlob.load({'feeding': 'feeding_jaco', 'bedbathing': 'bed_bathing_sawyer', 'scratchitch': 'scratch_itch_pr2', 'armmanipulation': 'arm_manipulation_sawyer', 'dressing': 'dressing_baxter'}[task])
     if task == 'scratchitch':
         blob = blob.coop()
     out = {'envs': envs, 'note': 'hbm_bytes_per_launch is for a launch over all `envs` environments; a step issues chunks of them', 'correction': 'FETCH_SIZE x2 (gfx950, guide), WRITE_SIZE as reported', 'kernels': {}}
@@ -57,13 +68,24 @@ def main():
                              'hbm_bytes_per_env_launch': 2.0 * f + w, 'hbm_bytes_per_launch': (2.0 * f + w) * envs}
         if k in valu and valu[k][1]:
             out['kernels'][k]['valu_insts_per_env_launch'] = valu[k][0] / valu[k][1]     # wave-level VALU instructions per environment (= per wave) and launch
+    for path in more:                        # every counter of the extra passes, per environment (= workgroup) and launch
+        names = {r['Counter_Name'] for r in csv.DictReader(open(path))}
+        for cname in sorted(names):
+            for k, a in per_kernel_count(path, cname).items():
+                if k in out['kernels'] and a[1]:
+                    out['kernels'][k].setdefault('counters_per_env_launch', {})[cname] = a[0] / a[1]
+    if stats:
+        for r in csv.DictReader(open(stats)):
+            k = r['Name'].split('(')[0]
+            if k in out['kernels']:
+                out['kernels'][k]['ms_per_launch'] = float(r['AverageNs']) * 1e-6; out['kernels'][k]['launches_in_trace'] = int(r['Calls'])
     obs_k = [k for k in out['kernels'] if k.startswith('agx_observe_kernel')]
     if obs_k:
         o = out['kernels'][obs_k[0]]
         known_r, known_w = blob.state_words * 4, blob.obs_dim * 4
         out['calibration'] = {'kernel': obs_k[0], 'known_read_bytes_per_env': known_r, 'known_write_bytes_per_env': known_w,
                               'fetch_x2_over_known': 2.0 * o['fetch_raw_bytes_per_env'] / known_r, 'write_over_known': o['write_raw_bytes_per_env'] / known_w}
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r02_traffic_%s.json' % task), 'w'), indent=1)
+    json.dump(out, open(outp or os.path.join(ROOT, 'profiles', 'r03_traffic_%s.json' % task), 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
 
