@@ -978,6 +978,20 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
   else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) env_finish_scratch(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else if constexpr (TASK == AGX_TASK_ARM_MANIPULATION) env_finish_arm(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else env_finish_feeding(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
+  // Non-finite guard (the reference's nearest analogue is the forced reconnect of env.py:93-97): an environment whose joint or
+  // free-body state has become NaN / Inf must not poison a training batch.  Its observation and reward are zeroed, it is reported done
+  // -- so the auto-reset (agx_reset_done / the masked agx_reset) replaces its state -- and AGX_INFO_NCONTACT carries AGX_INFO_NONFINITE.
+  {
+    const int* bi = (const int*)blob; const float* st = lds + L_ST;    // the state copy of the task layer above
+    const int ndof = bi[AGX_H_NDOF], nfree = bi[AGX_H_NFREE], s_q = bi[AGX_H_S_Q], s_free = bi[AGX_H_S_FREE], od = bi[AGX_H_OBS_DIM];
+    bool bad = false;
+    for (int k = lane; k < 2 * ndof; k += 64) { const float v = st[(k < ndof ? s_q : bi[AGX_H_S_QD] - ndof) + k]; bad = bad || !(fabsf(v) < 3.0e38f); }
+    for (int k = lane; k < 13 * nfree; k += 64) { const float v = st[s_free + k]; bad = bad || !(fabsf(v) < 3.0e38f); }
+    if (wave_any(bad)) {
+      for (int k = lane; k < od; k += 64) gobs[k] = 0.f;
+      if (lane == 0) { *greward = 0.f; *gdone = 1; if (ginfo) { ginfo[AGX_INFO_TOTAL_FORCE] = 0.f; ginfo[AGX_INFO_TASK_SUCCESS] = 0.f; ginfo[AGX_INFO_NCONTACT] = AGX_INFO_NONFINITE; } }
+    }
+  }
 }
 
 }  // namespace agx

@@ -337,12 +337,12 @@ enum { AGX_DR_CLOTH_GRAVITY = 0, /* float: world gravity z acting on the cloth: 
  * int32 header [AGX_CL_HDR], then the arrays at the section-relative word offsets it names. ------------------------ */
 enum {
   AGX_CL_NN = 0,         /* nodes: the OBJ's vertices in order of first appearance in its face list (tinyobj re-indexing)   */
-  AGX_CL_NL = 1,         /* links = unique mesh edges, sorted by colour                                                     */
+  AGX_CL_NL = 1,         /* link SLOTS = unique mesh edges sorted by colour, plus empty slots (-1) of the bank schedule          */
   AGX_CL_NCOLOR = 2,     /* colour classes: links of one class share no node and are relaxed in parallel; classes in order   */
   AGX_CL_NANCHOR = 3,
   AGX_CL_NSHAPE = 4,     /* rigid colliders the cloth is tested against                                                      */
   AGX_CL_OFF_COLOR = 5,  /* int[NCOLOR + 1] first link of every class                                                        */
-  AGX_CL_OFF_LINK = 6,   /* {int a | b << 16, float rest length squared}[NL]                                                  */
+  AGX_CL_OFF_LINK = 6,   /* {int a | b << 16 (-1: empty slot), float rest length squared}[NL]                                 */
   AGX_CL_OFF_NODE = 7,   /* {int first incident face entry, float area}[NN] (+ one terminating entry): node area = mean rest
                             area of the incident faces (btSoftBody::updateArea)                                             */
   AGX_CL_OFF_FACE = 8,   /* int[entries] j | k << 16: the other two vertices of each incident face, in the face's winding      */
@@ -390,5 +390,7 @@ enum { AGX_INFO_TOTAL_FORCE = 0, AGX_INFO_TASK_SUCCESS = 1, AGX_INFO_ROBOT_FORCE
        AGX_INFO_PREF = 5,
        AGX_INFO_NCONTACT = 6,    /* solver contacts of the last substep + 1000 * contacts dropped by a budget (overflow) */
        AGX_INFO_NROWS = 7, AGX_INFO_COUNT = 8 };
+/* AGX_INFO_NCONTACT of an environment whose state was found non-finite after the step: observation and reward zeroed, done set */
+#define AGX_INFO_NONFINITE 1.0e6f
 
 #endif

@@ -1161,6 +1161,7 @@ static void cloth_substep(sim_t* s) {
       }
     }
     for (int c = 0; c < NCOL; c++) for (int l = color[c]; l < color[c + 1]; l++) {   /* PSolve_Links */
+      if (linki[2 * l] < 0) continue;                                  /* an empty slot of the kernel's bank schedule (model/cloth.py) */
       const int a = linki[2 * l] & 0xffff, b = (linki[2 * l] >> 16) & 0xffff; const double c1 = linkf[2 * l + 1];
       double del[3]; sub3(x[b], x[a], del); const double len = dot3(del, del);
       if (c1 + len > 1.1920929e-7) {

@@ -60,7 +60,9 @@ def tables(blob):
     anc = ci[ci[L.CL['OFF_ANCHOR']]:ci[L.CL['OFF_ANCHOR']] + 4 * int(ci[L.CL['NANCHOR']])].reshape(-1, 4)
     ancf = cf[ci[L.CL['OFF_ANCHOR']]:ci[L.CL['OFF_ANCHOR']] + 4 * int(ci[L.CL['NANCHOR']])].reshape(-1, 4)[:, 1:].astype(np.float64)
     par = cf[ci[L.CL['OFF_PARAM']]:ci[L.CL['OFF_PARAM']] + L.CP['COUNT']].astype(np.float64)
-    return dict(nn=nn, a=lk & 0xffff, b=(lk >> 16) & 0xffff, rest2=cf[ci[L.CL['OFF_LINK']]:ci[L.CL['OFF_LINK']] + 2 * nl].reshape(nl, 2)[:, 1].astype(np.float64),
+    real = lk >= 0                                   # -1: an empty slot of the kernel's bank schedule
+    rest2 = cf[ci[L.CL['OFF_LINK']]:ci[L.CL['OFF_LINK']] + 2 * nl].reshape(nl, 2)[:, 1].astype(np.float64)
+    return dict(nn=nn, a=(lk & 0xffff)[real], b=((lk >> 16) & 0xffff)[real], rest2=rest2[real],
                 node=node, face=face, area=area, anchors=anc[:, 0], anchor_off=ancf, par=par,
                 x0=cf[ci[L.CL['OFF_X0']]:ci[L.CL['OFF_X0']] + 3 * nn].reshape(nn, 3).astype(np.float64))
 

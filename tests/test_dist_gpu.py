@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
 
 def test_two_ranks_match_one_rank_bit_for_bit():
     if not torch.cuda.is_available():
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     obs1, rew1, final1 = _rollout(N_GLOBAL, 0, 0)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -70,7 +70,7 @@ def test_two_ranks_match_one_rank_bit_for_bit():
 def test_gatherer_overlaps_on_a_side_stream(monkeypatch):
     """the double-buffer / event protocol on the GPU with a stand-in collective (two copies of the local shard)"""
     if not torch.cuda.is_available():
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     from assistive_gym_amd.shard import ObsGatherer
     from assistive_gym_amd.vec_env import FeedingJacoVecEnv
     calls = []
@@ -101,7 +101,7 @@ def test_gatherer_overlaps_on_a_side_stream(monkeypatch):
 
 def test_c_abi_allgather_single_rank():
     if not torch.cuda.is_available():
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     from assistive_gym_amd.blob import ModelBlob
     from assistive_gym_amd.libagx import Stepper
     st = Stepper(ModelBlob.load('feeding_jaco'), 4)

@@ -33,7 +33,8 @@ def cloth_tables(blob):
     color = ci[ci[L.CL['OFF_COLOR']]:ci[L.CL['OFF_COLOR']] + ncol + 1]
     lk = ci[ci[L.CL['OFF_LINK']]:ci[L.CL['OFF_LINK']] + 2 * nl].reshape(nl, 2)[:, 0]
     rest2 = cf[ci[L.CL['OFF_LINK']]:ci[L.CL['OFF_LINK']] + 2 * nl].reshape(nl, 2)[:, 1]
-    a, b = lk & 0xffff, (lk >> 16) & 0xffff
+    real = lk >= 0                                   # -1: an empty slot of the kernel's bank schedule (model/cloth.py bank_schedule)
+    a, b = np.where(real, lk & 0xffff, -1), np.where(real, (lk >> 16) & 0xffff, -1)
     x0 = cf[ci[L.CL['OFF_X0']]:ci[L.CL['OFF_X0']] + 3 * nn].reshape(nn, 3).astype(np.float64)
     anc = ci[ci[L.CL['OFF_ANCHOR']]:ci[L.CL['OFF_ANCHOR']] + 4 * int(ci[L.CL['NANCHOR']])].reshape(-1, 4)[:, 0]
     return dict(nn=nn, nl=nl, ncol=ncol, color=color, a=a, b=b, rest2=rest2, x0=x0, anchors=anc, tri=ci[L.CL['TRI']:L.CL['TRI'] + 6],

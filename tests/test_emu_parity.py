@@ -305,3 +305,17 @@ def test_pushed_bowl_and_particles(blob, oracle, case):
     assert np.abs(vo['q'] - ve['q']).max() < 1e-5
     assert np.abs(vo['free'][0, :, :3] - ve['free'][0, :, :3]).max() < 5e-5
     assert oo[3][6] == eo[3][6] and oo[3][7] == eo[3][7]                        # same contacts and rows in the last substep
+
+
+def test_nonfinite_state_is_flagged_and_masked(blob, emu):
+    """SURVEY 5 robustness: an environment whose state has gone NaN reports done with a zeroed observation / reward and the
+    AGX_INFO_NONFINITE marker, so that the auto-reset replaces it and a training batch is not poisoned (kernel sources on the emulator)"""
+    st, _ = make_states(blob, 1, seed=3401)
+    s = st[0].copy()
+    v = blob.view(s)
+    v['q'][0, 2] = np.nan
+    obs, rew, done, info, _ = emu.step(s, np.zeros(blob.act_dim, dtype=np.float32))
+    assert done and rew == 0.0 and np.all(obs == 0.0) and info[6] == 1.0e6
+    s = st[0].copy()                                             # a healthy state is left alone
+    obs, rew, done, info, _ = emu.step(s, np.zeros(blob.act_dim, dtype=np.float32))
+    assert not done and np.isfinite(obs).all() and info[6] < 1.0e6

@@ -14,7 +14,7 @@ def am():
     from assistive_gym_amd import libagx
     from assistive_gym_amd.blob import ModelBlob
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     return ModelBlob.load('arm_manipulation_sawyer')
 
 
@@ -148,7 +148,7 @@ def test_other_single_arm_robots(robot):
     from assistive_gym_amd.libagx import Stepper
     from oracle_lib import Oracle
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     b = ModelBlob.load('arm_manipulation_' + robot)
     o = Oracle(b)
     n = 12

@@ -15,7 +15,7 @@ def bed():
     from assistive_gym_amd.blob import ModelBlob
     from assistive_gym_amd import libagx
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     return ModelBlob.load('bed_bathing_sawyer')
 
 

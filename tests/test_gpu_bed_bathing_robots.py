@@ -13,7 +13,7 @@ def rb(request):
     from assistive_gym_amd.blob import ModelBlob
     from oracle_lib import Oracle
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     b = ModelBlob.load('bed_bathing_' + request.param)
     return request.param, b, Oracle(b)
 

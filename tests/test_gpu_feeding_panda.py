@@ -19,7 +19,7 @@ def panda():
     from assistive_gym_amd import libagx
     from assistive_gym_amd.blob import ModelBlob
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     return ModelBlob.load('feeding_panda')
 
 

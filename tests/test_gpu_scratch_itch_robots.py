@@ -15,7 +15,7 @@ def rb(request):
     from assistive_gym_amd.blob import ModelBlob
     from oracle_lib import Oracle
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     b = ModelBlob.load('scratch_itch_' + request.param)
     return request.param, b, Oracle(b)
 
@@ -79,7 +79,7 @@ def test_default_environment_of_the_reference_runs_end_to_end():
     from assistive_gym_amd.envs import make
     from assistive_gym_amd.vec_env import ScratchItchJacoVecEnv
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     e = make('assistive_gym:ScratchItchJaco-v1')
     o = e.reset()
     assert o.shape == (30,) and e.action_space.shape == (7,)
@@ -114,7 +114,7 @@ def test_device_reset_generator(robot):
     from assistive_gym_amd.libagx import Stepper
     from test_reset_generator import assert_same_record, with_reset_params
     if libagx.load().agx_device_count() <= 0:
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     # 100 restarts instead of 1,000 for the comparison: an unreachable target runs through all of them, 70 ms each in the numpy restatement
     b = with_reset_params(ModelBlob.load('scratch_itch_' + robot), IK_RESTARTS=100)
     n, seed0 = 24, (1 << 33) + 99

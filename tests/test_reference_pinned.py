@@ -331,7 +331,7 @@ def _groups():
 def test_gpu_step_matches_the_reference(key, names):
     import torch
     if not torch.cuda.is_available():
-        pytest.fail('-m gpu run without a visible GPU') if os.environ.get('AGX_REQUIRE_GPU', '1') == '1' else pytest.skip('no GPU')
+        __import__('conftest').no_gpu()
     from assistive_gym_amd import libagx
     from refcases import variant_blob
     model, coop, variant = key

@@ -131,7 +131,7 @@ def test_vector_env_adapter_steps_on_the_gpu(env_id):
     import numpy as np
     import torch
     if not torch.cuda.is_available():
-        pytest.skip('no GPU visible')
+        __import__('conftest').no_gpu()
     from assistive_gym_amd.rllib import AgxVectorEnv
     n = 32
     env = AgxVectorEnv(env_id, n, pool_size=8)
