@@ -90,6 +90,7 @@ struct agx_handle_s {
   // (environments with many rows finish last) overlaps with the next kernel of another chunk and the
   // lean solve kernel shares the CUs with the LDS-heavy build kernel.
   int n_chunks; hipStream_t cs[8]; hipEvent_t fork_ev, join_ev[8];
+  bool packed_solve;    // solve with the packed kernel (four environments per wavefront) when the variant has one; AGX_SOLVE=old turns it off
 };
 
 extern "C" {
@@ -188,6 +189,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     HIPCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     for (int k = 0; k < nc; k++) { HIPCHK(hipStreamCreateWithFlags(&h->cs[k], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming)); }
   }
+  { const char* e = getenv("AGX_SOLVE"); h->packed_solve = !(e && !strcmp(e, "old")); }
   HIPCHK(V->init());
   *out = h;
   return AGX_OK;
@@ -230,7 +232,11 @@ int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fa
 static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st, int phase, bool settle) {
   h->V->build(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active, h->overflow_dev, h->trace_dev, h->trace_words, phase);
   HIPCHK(hipGetLastError());
-  h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active, settle ? (phase | AGX_PHASE_SETTLE) : phase);
+  const int ph = settle ? (phase | AGX_PHASE_SETTLE) : phase;
+  // the packed kernel (four environments per wavefront) where the variant has one; the debug path keeps the single-environment kernel
+  // (its per-phase cycle counters); AGX_SOLVE=old selects it for same-box A/B runs
+  if (h->V->solve4 && h->packed_solve && !dbg) h->V->solve4(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, e0, h->sw, h->active, ph);
+  else h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active, ph);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -303,7 +309,8 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
     for (int k = 0; k < h->frame_skip; k++) {
       h->V->build(st, ne, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr, h->overflow_dev, nullptr, 0, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
-      h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr, k);
+      if (h->V->solve4 && h->packed_solve) h->V->solve4(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, e0, h->sw, (const uint8_t*)nullptr, k);
+      else h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
     }
     h->V->finish(st, ne, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, nullptr, 0);

@@ -112,7 +112,19 @@ constexpr int QPT_STRIDE = 4;                            // manifold query point
 constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
 constexpr int SCR_O_QPT = SCR_O_META + SCR_META;
-constexpr int SCR_WORDS = SCR_O_QPT + SCR_QPT;
+// ---- block rows: the same constraint rows in the layout the packed solve kernel (agx_pgs4.h) reads.  The generalised velocity is cut
+// into blocks of 6: the articulated DoFs first (NB_ART blocks, the last one padded), then one block per free body; a row keeps one
+// ENTRY of 12 floats (J[6], B[6]) per block it touches, in block order, and a header {1/D, b, lo, hi | mu, 64-bit map (nibble k =
+// 1 + entry index of block k, 0 = untouched), index of its first entry, entry count}.  One lane of a 16-lane group owns one block.
+constexpr int NB_ART = (MAX_DOF + 5) / 6, NB = NB_ART + MAX_FREE;
+static_assert(NB <= 16, "one lane of a 16-lane group per velocity block");
+constexpr int BRH_WORDS = 8, BRE_WORDS = 12;
+constexpr int BRH_INVD = 0, BRH_B = 1, BRH_LO = 2, BRH_HI = 3, BRH_MAPLO = 4, BRH_MAPHI = 5, BRH_EOFF = 6, BRH_NENT = 7;
+constexpr int SCR_BRH = MAX_ROWS * BRH_WORDS, SCR_BRE = 2 * SCR_ENT, BR_MAX_ENT = SCR_BRE / BRE_WORDS;
+constexpr int SCR_O_BRH = SCR_O_QPT + SCR_QPT, SCR_O_BRE = SCR_O_BRH + SCR_BRH;
+static_assert(SCR_O_BRH % 4 == 0 && SCR_O_BRE % 4 == 0, "block rows are read as 16-byte words");
+constexpr int SCR_WORDS = SCR_O_BRE + SCR_BRE;
+constexpr int META_NBENT = 7;
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
 constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)
@@ -133,6 +145,7 @@ struct Ctx {
   float* gqpt; int nqpt;   // bed bathing: manifold points of the (wiping pad, human) pairs (bed_bathing.py:47-58), per-env scratch
   float* dbg;   // optional debug sink (parity tests)
   float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
+  float* BH; float* BE; // the same rows as block rows (headers, entries) for the packed solve kernel
   int nent;             // (J,B) pairs written by build_rows (entry 0 is the zero pair)
   float* gcon;          // contact records handed from the build kernel to the solve / finish kernels
   long long tm[16]; bool timing;   // per-phase shader-clock totals (debug path only)
@@ -166,7 +179,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
   c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
   c.dt = PRM(c, AGX_P_DT) / (float)(h[AGX_H_SIM_SUBSTEPS] > 1 ? h[AGX_H_SIM_SUBSTEPS] : 1); c.hooks = true;
-  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.BH = nullptr; c.BE = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 

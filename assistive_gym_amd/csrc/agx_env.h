@@ -288,9 +288,9 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
 //          from L2, integration, mouth-target update -> state
 //   finish (once per step): forces, observation, food state machine, preferences, reward, done.
 // ============================================================================================
-struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; };
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; };
 AGX_DEV Scratch scratch_of(float* base) {
-  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT;
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE;
   return s;
 }
 
@@ -302,7 +302,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   float* L = c.lds; int* Li = c.ldsi;
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
-  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.gqpt = scr.qpt;
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.gqpt = scr.qpt; c.BH = scr.brh; c.BE = scr.bre;
   load_env(c, gstate, sw);
   if (gaction) {
     const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP);
@@ -388,21 +388,10 @@ AGX_DEV int collision_flags(const uint32_t* __restrict__ blob, const float* __re
   return (wave_any(env) ? AGX_COLLIDE_ENV : 0) | (wave_any(self) ? AGX_COLLIDE_SELF : 0);
 }
 
-// solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
-AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane, int phase = 0) {
-  Ctx c; ctx_init(c, blob, lds, lane);
-  const int sw = c.bi[AGX_H_STATE_WORDS];
-  Scratch scr = scratch_of(gscratch);
-  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
-  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nent = scr.meta[META_NENT];
-  // state copy only (the frame tables of load_env are not needed here and their LDS is the row window)
+// the part of the solve kernels after the Gauss-Seidel sweeps: state copy, hooks decision, integration, arm limits, store
+AGX_DEV void solve_tail(Ctx& c, float* gstate, Scratch& scr, int sw, int phase, float dv0, float dv1) {
+  float* lds = c.lds; const int lane = c.lane;
   for (int k = lane; k < sw; k += 64) lds[L_ST + k] = gstate[k];
-  // environments with few rows take the row-space sweep (its work area replaces the (J,B) window)
-  // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)
-  const bool rowspace = RS_MAX_ROWS > 0 && c.nrows <= RS_MAX_ROWS && c.nv <= 64 && c.nv <= RS_NVP && c.nrows > 0 && c.nent <= SOLVE_LDS_PAIRS;
-  { const int np = c.nent < SOLVE_LDS_PAIRS ? c.nent : SOLVE_LDS_PAIRS;
-    const f2* src = (const f2*)scr.ent; f2* dst = (f2*)(lds + L_SOLVE_ENT);
-    for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
   wave_sync();
   c.gender = c.ldsi[L_ST + c.s_env + AGX_E_GENDER]; c.frozen = c.ldsi[L_ST + c.s_env + AGX_E_FROZEN];
   { const float ls = c.lds[L_ST + c.s_env + AGX_E_LIMIT_SCALE]; c.limit_scale = ls > 0.f ? ls : 1.f; }   // records written before v6 carry 0
@@ -414,13 +403,28 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   { const int S = c.bi[AGX_H_SIM_SUBSTEPS], ph = phase & ~AGX_PHASE_SETTLE;
     const bool tremor_on = wave_any(lane < c.nhdof && lds[L_ST + c.s_tremor + lane] != 0.f);
     c.hooks = (S <= 1 || (ph + 1) % S == 0) && !(phase & AGX_PHASE_SETTLE) && (c.coop || tremor_on); }
+  integrate(c, scr.vel, dv0, dv1);
+  if constexpr (TASK != AGX_TASK_FEEDING) arm_limits(c, lds + L_VEL);   // the velocity vector is dead after the integration
+  store_env(c, gstate, sw);
+}
+// solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
+AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane, int phase = 0) {
+  Ctx c; ctx_init(c, blob, lds, lane);
+  const int sw = c.bi[AGX_H_STATE_WORDS];
+  Scratch scr = scratch_of(gscratch);
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
+  c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nent = scr.meta[META_NENT];
+  // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)
+  const bool rowspace = RS_MAX_ROWS > 0 && c.nrows <= RS_MAX_ROWS && c.nv <= 64 && c.nv <= RS_NVP && c.nrows > 0 && c.nent <= SOLVE_LDS_PAIRS;
+  { const int np = c.nent < SOLVE_LDS_PAIRS ? c.nent : SOLVE_LDS_PAIRS;
+    const f2* src = (const f2*)scr.ent; f2* dst = (f2*)(lds + L_SOLVE_ENT);
+    for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
+  wave_sync();
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0, dv1;
   if (!(rowspace && pgs_rowspace(c, lds + L_SOLVE_ENT, dv0, dv1))) pgs(c, dv0, dv1);
   const long long t1 = gdebug ? wave_clock() : 0;
-  integrate(c, scr.vel, dv0, dv1);
-  if constexpr (TASK != AGX_TASK_FEEDING) arm_limits(c, lds + L_VEL);   // the velocity vector is dead after the integration
-  store_env(c, gstate, sw);
+  solve_tail(c, gstate, scr, sw, phase, dv0, dv1);
   if (gdebug && lane == 0) { gdebug[DBG_TIME + 5] = (float)(t1 - t0); gdebug[DBG_TIME + 6] = (float)(wave_clock() - t1); }
 }
 

@@ -47,20 +47,28 @@ AGX_DEV void row_art_range(const Ctx& c, const RowGeom& r, int& lo, int& n) {
   n = (r.robot && r.human) ? c.ndof : (r.robot ? c.nrobot : (r.human ? c.nhdof : 0));
 }
 AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return n + (r.fa >= 0 ? 6 : 0) + (r.fb >= 0 ? 6 : 0); }
+// block-row entries of a row (agx_ctx.h: one per velocity block of 6 it touches)
+AGX_DEV int row_block_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return (n > 0 ? (lo + n - 1) / 6 - lo / 6 + 1 : 0) + (r.fa >= 0 ? 1 : 0) + (r.fb >= 0 ? 1 : 0); }
 // B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
 // A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
-AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float bterm, float lo, float hi, int fric_of, float mu) {
+AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int boff, float bterm, float lo, float hi, int fric_of, float mu) {
   float* L = c.lds; float* E = c.E + 2 * off; const int n = c.ndof;
+  float* BEr = c.BE + BRE_WORDS * boff;                      // this row's block entries: articulated blocks k0..k1, then its free bodies in block order
   float D = 0.f; int e = 0;
   int a0 = 0, na = 0, b0 = 0, nb = 0;
   int alo, an; row_art_range(c, r, alo, an);
   const bool art = an > 0;
+  const int k0 = alo / 6, nartb = art ? (alo + an - 1) / 6 - k0 + 1 : 0;
+  uint64_t bmap = 0ull; int be = 0;
   if (art) {
     a0 = alo; na = an;
+    for (int k = 0; k < nartb; k++) { bmap |= (uint64_t)(k + 1) << (4 * (k0 + k)); for (int q = 0; q < BRE_WORDS; q++) BEr[BRE_WORDS * k + q] = 0.f; }   // padding slots of the touched blocks
+    be = nartb;
     _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i >= alo && i < alo + an) {
       float acc = 0.f;
       _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
       E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
+      float* o = BEr + BRE_WORDS * (i / 6 - k0) + i % 6; o[0] = r.Jr[i]; o[6] = acc;
     }
   }
   // free bodies in ascending DoF order, so that the pairs of a row are stored in lane order (the
@@ -76,6 +84,8 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
     int base = n + 6 * fb;
     if (na == 0 && nb == 0 && !art) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
+    for (int k = 0; k < 6; k++) { BEr[BRE_WORDS * be + k] = J[k]; BEr[BRE_WORDS * be + 6 + k] = B[k]; }
+    bmap |= (uint64_t)(be + 1) << (4 * (NB_ART + fb)); be++;
   }
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
   float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
@@ -87,7 +97,9 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
   if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
   Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
   Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
-  (void)fric_of;
+  { float* BH = c.BH + BRH_WORDS * row; int* BHi = (int*)BH;
+    BH[BRH_INVD] = H[H_INVD]; BH[BRH_B] = bterm; BH[BRH_LO] = lo; BH[BRH_HI] = fric_of >= 0 ? mu : hi;
+    BHi[BRH_MAPLO] = (int)(uint32_t)bmap; BHi[BRH_MAPHI] = (int)(uint32_t)(bmap >> 32); BHi[BRH_EOFF] = boff; BHi[BRH_NENT] = be; }
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
   if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
@@ -110,16 +122,16 @@ AGX_DEV void build_rows(Ctx& c) {
   int maxrows = (int)PRM(c, AGX_P_MAX_ROWS); if (maxrows > MAX_ROWS) maxrows = MAX_ROWS;
   int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > SCR_ENT / 2) maxent = SCR_ENT / 2;
   if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }               // entry 0 of the arena is the zero pair
-  int nnc = 0, ent = 1;                                         // non-contact rows / coefficient pairs so far
+  int nnc = 0, ent = 1, bent = 0;                               // non-contact rows / coefficient pairs / block-row entries so far
   // contact rows: lane = contact; normal rows first, then one friction row per contact
-  int nc = c.ncon, ccnt = 0, cincl = 0, tot = 0, entN = 0, entF = 0;
+  int nc = c.ncon, ccnt = 0, cincl = 0, tot = 0, entN = 0, entF = 0, bcnt = 0, bincl = 0, btot = 0, bentN = 0, bentF = 0;
   int ba = 0, bb = 0; v3 pa = mk3(0, 0, 0), pb = pa, nn = pa; float dist = 0.f, mu = 0.f;
   RowGeom rn; row_clear(rn);
   // the row kinds go through ONE row_store call site (its M^-1 J^T product is the bulk of this phase's code):
   // phases [0, NC_PASSES) non-contact slots, NC_PASSES contact normals, NC_PASSES + 1 contact friction
   _Pragma("nounroll") for (int ph = 0; ph < NC_PASSES + 2; ph++) {
     RowGeom R; row_clear(R);
-    int rrow = 0, roff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
+    int rrow = 0, roff = 0, rboff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
     if (ph < NC_PASSES) {
       const int slot = 64 * ph + lane;
       if (slot < MAX_DOF) {
@@ -181,8 +193,9 @@ AGX_DEV void build_rows(Ctx& c) {
       }
       const int cnt = go ? row_entries(c, R) : 0;
       const uint64_t am = wave_ballot(go);
-      rrow = nnc + wave_rank(am); roff = ent + wave_scan_excl(cnt);
-      nnc += popc64(am); ent += wave_sum_i(cnt);
+      const int bc = go ? row_block_entries(c, R) : 0;
+      rrow = nnc + wave_rank(am); roff = ent + wave_scan_excl(cnt); rboff = bent + wave_scan_excl(bc);
+      nnc += popc64(am); ent += wave_sum_i(cnt); bent += wave_sum_i(bc);
     } else if (ph == NC_PASSES) {
       const bool has = lane < nc;
       if (has) {
@@ -192,17 +205,19 @@ AGX_DEV void build_rows(Ctx& c) {
       }
       ccnt = has ? row_entries(c, rn) : 0;
       cincl = wave_scan_excl(ccnt) + ccnt;
+      bcnt = has ? row_block_entries(c, rn) : 0;
+      bincl = wave_scan_excl(bcnt) + bcnt;
       // largest prefix of the contact list that fits the row and coefficient budgets; the contacts beyond it are
       // dropped and counted as overflow
-      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent);
+      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent) && (bent + 2 * bincl <= BR_MAX_ENT);
       const int kept = popc64(wave_ballot(fits));
       c.overflow += nc - kept; nc = kept;
-      tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0);
-      entN = ent; entF = ent + (nc > 0 ? tot : 0);
-      R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rlo = 0.f; rhi = 1e30f;
+      tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0); btot = wave_bcast_i(bincl, nc > 0 ? nc - 1 : 0);
+      entN = ent; entF = ent + (nc > 0 ? tot : 0); bentN = bent; bentF = bent + (nc > 0 ? btot : 0);
+      R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rboff = bentN + bincl - bcnt; rlo = 0.f; rhi = 1e30f;
       if (go) { const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv); }
     } else {
-      go = lane < nc; rrow = nnc + nc + lane; roff = entF + cincl - ccnt; rfric = nnc + lane; rmu = mu;
+      go = lane < nc; rrow = nnc + nc + lane; roff = entF + cincl - ccnt; rboff = bentF + bincl - bcnt; rfric = nnc + lane; rmu = mu;
       if (go) {
         // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
         v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);
@@ -213,7 +228,7 @@ AGX_DEV void build_rows(Ctx& c) {
         rb = -row_velocity(c, R);
       }
     }
-    if (go) row_store(c, R, rrow, roff, rb, rlo, rhi, rfric, rmu);
+    if (go) row_store(c, R, rrow, roff, rboff, rb, rlo, rhi, rfric, rmu);
   }
   c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0);
   wave_sync();

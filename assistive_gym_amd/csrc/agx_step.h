@@ -30,6 +30,7 @@
 #include "agx_rows.h"
 #include "agx_pgs.h"
 #include "agx_env.h"
+#include "agx_pgs4.h"
 #if AGX_HAS_SAMPLER
 #include "agx_reset.h"
 #endif

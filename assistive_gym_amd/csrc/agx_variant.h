@@ -31,6 +31,9 @@ struct agx_variant {
   void (*verdict)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, const uint8_t* active, uint8_t* work, int* first_restart, const int* chosen);
   // collision flags (AGX_COLLIDE_*) of every environment's state after a build pass (agx_check_collisions)
   void (*collision_flags)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, uint8_t* flags);
+  // the packed solve kernel (agx_pgs4.h: four environments per wavefront) over the environments [e0, e0 + ne); null in variants that
+  // keep the one-wave-per-environment sweeps
+  void (*solve4)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, int e0, int sw, const uint8_t* active, int phase);
 };
 
 extern "C" const agx_variant* agx_variant_feeding(void);

@@ -146,6 +146,9 @@ def wiping_pool(blob, n, seed):
         pad, _ = X.compose(bp, bq, blob.task_f('TOOL_OBS_POS', 3), blob.task_f('TOOL_OBS_QUAT', 4))
         d = (want - pad).astype(np.float32)
         v['base'][0, :3] += d; v['free'][0, 0, :3] += d; v['free'][0, 0, 7:] = 0
+        # the pad stays on the skin for a handful of steps under small random actions (no policy presses it down): episodes of this
+        # workload are 8 steps long, i.e. every environment is put back onto the arm from the pool every 8 steps
+        v['iteration'][0] = int(blob.task_f('EPISODE_LEN')) - 8
     return st
 
 
@@ -288,7 +291,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, 50 PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else 'pad pressed onto the arm at reset, small random actions (x%.2f)' % action_scale),
+            'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, 50 PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed), 'noop_retest': blob.param('NOOP_RETEST')},
             'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps

@@ -64,3 +64,15 @@ AGX_DEV long long wave_clock() { return 0; }
 AGX_DEV float wave_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 AGX_DEV void wave_opaque(float&) {}
 AGX_DEV int wave_uniform(int x) { return x; }
+
+// ---- 16-lane group primitives of the packed solve kernel (csrc/agx_pgs4.h) ----
+// same association as the DPP butterfly of the device code: pairs, quads, halves of the 16-lane row, the row
+AGX_DEV float g16_sum(float x) {
+  const uint32_t* s = emu::exchange(emu::f2u(x));
+  const int b = emu::W->cur & ~15;
+  float q[4]; for (int i = 0; i < 4; i++) q[i] = (emu::u2f(s[b + 4 * i]) + emu::u2f(s[b + 4 * i + 1])) + (emu::u2f(s[b + 4 * i + 2]) + emu::u2f(s[b + 4 * i + 3]));
+  return (q[0] + q[1]) + (q[2] + q[3]);
+}
+AGX_DEV uint32_t g16_ballot(bool p, int group) { return (uint32_t)(wave_ballot(p) >> (16 * group)) & 0xffffu; }
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };

@@ -45,8 +45,11 @@ static int run_wave(float* lds, size_t lds_words, std::function<void(int)> body)
 
 extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
                            float* info, float* debug, int mode, int nsettle) {
-  static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
+  static float lds[(agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS) + agx::LDS_SOLVE4_WORDS];
   static float scratch[agx::SCR_WORDS];
+  // AGX_EMU_SOLVE=old: the one-wave-per-environment sweep; default: the packed kernel (groups 1..3 of the wave idle: one environment here)
+  static const bool packed = !(getenv("AGX_EMU_SOLVE") && !strcmp(getenv("AGX_EMU_SOLVE"), "old")) && agx::USE_SOLVE4;
+  const int sw = ((const int*)blob)[AGX_H_STATE_WORDS];
   const int frame_skip = (int)((const float*)blob)[((const int*)blob)[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   int rc = 0;
   if (mode == 2) return run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_observe(blob, state, obs, lds, lane); });
@@ -55,7 +58,9 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
   for (int k = 0; k < nsub && !rc; k++) {
     const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (k == 0) ? debug : nullptr;
     rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, dbg, lds, lane); });
-    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, mode == 1 ? (k | AGX_PHASE_SETTLE) : k); });
+    const int ph = mode == 1 ? (k | AGX_PHASE_SETTLE) : k;
+    if (!rc && packed) rc = run_wave(lds, agx::LDS_SOLVE4_WORDS, [&](int lane) { agx::env_solve4(blob, state, scratch, 0, 1, sw, nullptr, lds, lane, ph); });
+    else if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, ph); });
   }
   if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
   return rc;
