@@ -101,6 +101,8 @@ int agx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess)
 int agx_lds_bytes_per_env(void) { return agx_variant_feeding()->lds_bytes; }
 int agx_debug_words(void) { return agx_variant_feeding()->dbg_words; }   // FeedingJaco variant; agx_debug_layout(h) for a handle
 
+static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_envs, int device);
+void agx_destroy(agx_handle h);
 int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_handle* out) {
   if (!blob || !out || n_envs <= 0 || blob_bytes < sizeof(uint32_t) * AGX_H_COUNT) return fail(AGX_E_ARG, "agx_create: bad argument");
   const uint32_t* w = (const uint32_t*)blob; const int32_t* hi = (const int32_t*)blob;
@@ -145,6 +147,15 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   agx_handle h = new agx_handle_s();
   memset(h, 0, sizeof *h);
   h->can_sample = can_sample; h->V = V;
+  const int rc = create_fill(h, blob, blob_bytes, n_envs, device);
+  if (rc != AGX_OK) { const std::string keep = g_err; agx_destroy(h); g_err = keep; return rc; }   // every error exit releases what was allocated
+  *out = h;
+  return AGX_OK;
+}
+
+// the allocations of agx_create; on failure the caller destroys the partly filled handle
+static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_envs, int device) {
+  const int32_t* hi = (const int32_t*)blob; const agx_variant* V = h->V; const bool can_sample = h->can_sample;
   h->device = device; h->n_envs = n_envs; h->act_dim = hi[AGX_H_ACT_DIM]; h->obs_dim = hi[AGX_H_OBS_DIM]; h->sw = hi[AGX_H_STATE_WORDS];
   HIPCHK(hipMalloc(&h->blob_dev, blob_bytes));
   HIPCHK(hipMemcpy(h->blob_dev, blob, blob_bytes, hipMemcpyHostToDevice));
@@ -159,14 +170,14 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   h->frame_skip = (int)((const float*)blob)[hi[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   h->sim_sub = hi[AGX_H_SIM_SUBSTEPS] > 1 ? hi[AGX_H_SIM_SUBSTEPS] : 1;
   if (hi[AGX_H_OFF_CLOTH]) {
-    if (!V->cloth) { delete h; return fail(AGX_E_LIMIT, "agx_create: the model has a cloth but the kernel variant of its task has no cloth kernel"); }
+    if (!V->cloth || !V->cloth_lds_bytes) return fail(AGX_E_LIMIT, "agx_create: the model has a cloth but the kernel variant of its task has no cloth kernel");
     const int32_t* cl = hi + hi[AGX_H_OFF_CLOTH];
     h->cloth_nn = cl[AGX_CL_NN];
     h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn);
     h->trace_words = h->frame_skip * h->sim_sub * hi[AGX_H_NDOF] * 12;
-    h->cloth_lds = 4 * (6 * h->cloth_nn + 12 * 64 + 6 * 192 + 192 + 4 + 6 * (AGX_CLOTH_THREADS / 64) + 4 + 12 * 192 + 3 * 3584 + 4);   // agxc::lds_words
+    h->cloth_lds = V->cloth_lds_bytes(h->cloth_nn);          // agxc::lds_words of the variant's own cloth kernel
     if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4096 || cl[AGX_CL_NCOLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_MAX_LINKS_PER_COLOR] > 1024 ||
-        cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + 2 > 64 || cl[AGX_CL_NN] > 65535 || hi[AGX_H_NFREE] != 0) { delete h; return fail(AGX_E_LIMIT, "agx_create: cloth exceeds the limits of the cloth kernel"); }
+        cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + 2 > 64 || cl[AGX_CL_NN] > 65535 || hi[AGX_H_NFREE] != 0) return fail(AGX_E_LIMIT, "agx_create: cloth exceeds the limits of the cloth kernel");
     HIPCHK(hipMalloc(&h->cloth_dev, (size_t)n_envs * h->cloth_words * 4)); HIPCHK(hipMemset(h->cloth_dev, 0, (size_t)n_envs * h->cloth_words * 4));
     HIPCHK(hipMalloc(&h->trace_dev, (size_t)n_envs * h->trace_words * 4)); HIPCHK(hipMemset(h->trace_dev, 0, (size_t)n_envs * h->trace_words * 4));
     HIPCHK(hipMalloc(&h->report_dev, (size_t)n_envs * h->report_words * 4)); HIPCHK(hipMemset(h->report_dev, 0, (size_t)n_envs * h->report_words * 4));
@@ -191,7 +202,6 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   }
   { const char* e = getenv("AGX_SOLVE"); h->packed_solve = !(e && !strcmp(e, "old")); }
   HIPCHK(V->init());
-  *out = h;
   return AGX_OK;
 }
 
@@ -201,9 +211,10 @@ void agx_destroy(agx_handle h) {
   hipFree(h->scratch_dev); hipFree(h->overflow_dev); hipFree(h->first_restart_dev); hipFree(h->chosen_dev); hipFree(h->work_dev); hipFree(h->blob_dev); hipFree(h->state_dev); hipFree(h->episode_dev); hipFree(h->act_dev); hipFree(h->obs_dev);
   hipFree(h->rew_dev); hipFree(h->info_dev); hipFree(h->done_dev);
   if (h->cloth_dev) { hipFree(h->cloth_dev); hipFree(h->trace_dev); hipFree(h->report_dev); }
-  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
-  for (int c = 0; c < 8; c++) for (int k = 0; k < 16; k++) hipEventDestroy(h->kev[c][k]);
-  hipEventDestroy(h->fork_ev); for (int k = 0; k < h->n_chunks; k++) { hipStreamDestroy(h->cs[k]); hipEventDestroy(h->join_ev[k]); }
+  if (h->ev0) hipEventDestroy(h->ev0); if (h->ev1) hipEventDestroy(h->ev1);      // a handle whose creation failed half way holds nulls
+  for (int c = 0; c < 8; c++) for (int k = 0; k < 16; k++) if (h->kev[c][k]) hipEventDestroy(h->kev[c][k]);
+  if (h->fork_ev) hipEventDestroy(h->fork_ev);
+  for (int k = 0; k < h->n_chunks; k++) { if (h->cs[k]) hipStreamDestroy(h->cs[k]); if (h->join_ev[k]) hipEventDestroy(h->join_ev[k]); }
   delete h;
 }
 

@@ -239,6 +239,9 @@ void v_verdict(hipStream_t st, int n_envs, const uint32_t* blob, const float* sc
 }
 #endif
 
+#if AGX_TASK == 3
+int v_cloth_lds_bytes(int nn) { return 4 * agxc::lds_words(nn); }
+#endif
 void v_collision_flags(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, uint8_t* flags) {
   hipLaunchKernelGGL(AGX_K(agx_collision_flags_kernel), dim3(n_envs), dim3(64), 0, st, blob, scratch, flags, n_envs);
 }
@@ -272,7 +275,12 @@ const agx_variant g_variant = {
   nullptr,
 #endif
   v_collision_flags,
-  agx::USE_SOLVE4 ? v_solve4 : nullptr
+  agx::USE_SOLVE4 ? v_solve4 : nullptr,
+#if AGX_TASK == 3
+  v_cloth_lds_bytes
+#else
+  nullptr
+#endif
 };
 
 }  // namespace

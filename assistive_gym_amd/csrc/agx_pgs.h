@@ -296,7 +296,7 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
       wave_sync(); ROW[lane] = X.c0; wave_sync();
       float a = 0.f;
       if (lane < R) for (int d = 0; d < nv; d++) a += LJ[RS_NVP * lane + d] * ROW[d];
-      A[RS_MAX_ROWS * i + lane] = a;
+      if (lane < RS_MAX_ROWS) A[RS_MAX_ROWS * i + lane] = a;      // a row of A has RS_MAX_ROWS entries: lanes beyond it must not spill into the next row / the ROW buffer
     }
     wave_sync();
     float w = 0.f;                                                  // J_r . dv of this lane's row

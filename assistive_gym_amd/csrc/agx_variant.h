@@ -34,6 +34,8 @@ struct agx_variant {
   // the packed solve kernel (agx_pgs4.h: four environments per wavefront) over the environments [e0, e0 + ne); null in variants that
   // keep the one-wave-per-environment sweeps
   void (*solve4)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, int e0, int sw, const uint8_t* active, int phase);
+  // dynamic LDS bytes of the cloth kernel for a garment of nn nodes (agxc::lds_words); null without a cloth kernel
+  int (*cloth_lds_bytes)(int nn);
 };
 
 extern "C" const agx_variant* agx_variant_feeding(void);

@@ -348,6 +348,18 @@ class DressingBaxterEnv(AssistiveEnv):
         self.iteration, self.task_success = 0, 0
         return self._split_obs(st.observe_host()[0].astype(np.float64))
 
+    # the garment lives outside the state record: a state is the pair (record, garment[2][NN][3])
+    def get_state(self):
+        st = self._ensure_stepper()
+        return st.get_state()[0], st.get_cloth()[0]
+
+    def set_state(self, state):
+        if not (isinstance(state, (tuple, list)) and len(state) == 2):
+            raise ValueError('a dressing state is the pair (state record, garment): pass what get_state() returned')
+        st = self._ensure_stepper()
+        st.set_state(np.asarray(state[0], dtype=np.float32).reshape(1, -1))
+        st.set_cloth(np.ascontiguousarray(state[1], dtype=np.float32)[None])
+
 
 class DressingBaxterHumanEnv(DressingBaxterEnv):
     """DressingBaxterHuman-v1 (dressing_envs.py:51-55): the human's left arm (10 joints) is controllable, the pose-dependent arm limits

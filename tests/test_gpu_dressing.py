@@ -136,6 +136,17 @@ def test_scalar_env_and_coop(dr):
     assert o.shape == (24,) and np.isfinite(o).all() and o[23] == 0
     o, r, d, info = env.step(env.action_space.sample())
     assert o.shape == (24,) and np.isfinite(r) and not d and 'task_success' in info
+    # get_state / set_state carry the garment with the record: stepping twice from the same saved state gives the same result
+    saved = env.get_state()
+    assert isinstance(saved, tuple) and saved[1].shape[0] == 2
+    a = env.action_space.sample()
+    o1, r1, _, _ = env.step(a)
+    env.step(env.action_space.sample())
+    env.set_state(saved)
+    o2, r2, _, _ = env.step(a)
+    assert np.array_equal(o1, o2) and r1 == r2
+    with pytest.raises(ValueError):
+        env.set_state(saved[0])
     co = make('assistive_gym:DressingBaxterHuman-v1')
     co.seed(6)
     ob = co.reset()
