@@ -113,16 +113,22 @@ constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
 constexpr int SCR_O_QPT = SCR_O_META + SCR_META;
 // ---- block rows: the same constraint rows in the layout the packed solve kernel (agx_pgs4.h) reads.  The generalised velocity is cut
-// into blocks of 6: the articulated DoFs first (NB_ART blocks, the last one padded), then one block per free body; a row keeps one
-// ENTRY of 12 floats (J[6], B[6]) per block it touches, in block order, and a header {1/D, b, lo, hi | mu, 64-bit map (nibble k =
-// 1 + entry index of block k, 0 = untouched), index of its first entry, entry count}.  One lane of a 16-lane group owns one block.
+// into blocks of 6: the articulated DoFs first (NB_ART blocks, the last one padded), then one block per free body.  A row keeps, in
+// UNITS of 6 floats: for every articulated block it touches J[6] and B[6] (2 units, blocks in order), then J[6] of each free body it
+// touches (1 unit each, bodies in ascending order; B = M^-1 J is recomputed from the body's inverse mass and world inverse inertia,
+// BRF_*).  Header (4 words): 1/D, b, bound, descriptor = k0 | nart << 4 | (fa + 1) << 8 | (fb + 1) << 12 | class << 16 | first unit << 18
+// with k0 / nart the articulated blocks, fa / fb the free bodies (0 = none) and class 0: -bound <= lambda <= bound (motors, tool rows),
+// 1: 0 <= lambda (limits, contact normals), 2: |lambda| <= bound x lambda of the contact's normal row (friction, bound = mu).
 constexpr int NB_ART = (MAX_DOF + 5) / 6, NB = NB_ART + MAX_FREE;
-static_assert(NB <= 16, "one lane of a 16-lane group per velocity block");
-constexpr int BRH_WORDS = 8, BRE_WORDS = 12;
-constexpr int BRH_INVD = 0, BRH_B = 1, BRH_LO = 2, BRH_HI = 3, BRH_MAPLO = 4, BRH_MAPHI = 5, BRH_EOFF = 6, BRH_NENT = 7;
-constexpr int SCR_BRH = MAX_ROWS * BRH_WORDS, SCR_BRE = 2 * SCR_ENT, BR_MAX_ENT = SCR_BRE / BRE_WORDS;
-constexpr int SCR_O_BRH = SCR_O_QPT + SCR_QPT, SCR_O_BRE = SCR_O_BRH + SCR_BRH;
-static_assert(SCR_O_BRH % 4 == 0 && SCR_O_BRE % 4 == 0, "block rows are read as 16-byte words");
+static_assert(NB <= 16 && MAX_FREE < 15, "one lane of a 16-lane group per velocity block; free bodies are 4-bit codes");
+constexpr int BRH_WORDS = 4, BRU_WORDS = 6;
+constexpr int BRH_INVD = 0, BRH_B = 1, BRH_BOUND = 2, BRH_DESC = 3;
+constexpr int BR_CLASS_SYM = 0, BR_CLASS_POS = 1, BR_CLASS_FRIC = 2;
+constexpr int BRF_WORDS = 8;                             // per free body: 1/m, world inverse inertia xx, xy, xz, yy, yz, zz, unused
+constexpr int SCR_BRH = MAX_ROWS * BRH_WORDS, SCR_BRE = 2 * SCR_ENT, BR_MAX_UNITS = SCR_BRE / BRU_WORDS, SCR_BRF = MAX_FREE * BRF_WORDS;
+static_assert(BR_MAX_UNITS < (1 << 14), "first unit of a row: 14 bits of the descriptor");
+constexpr int SCR_O_BRH = SCR_O_QPT + SCR_QPT, SCR_O_BRF = SCR_O_BRH + SCR_BRH, SCR_O_BRE = SCR_O_BRF + SCR_BRF;
+static_assert(SCR_O_BRH % 4 == 0 && SCR_O_BRE % 2 == 0 && SCR_O_BRF % 4 == 0, "block rows are read as 16- and 8-byte words");
 constexpr int SCR_WORDS = SCR_O_BRE + SCR_BRE;
 constexpr int META_NBENT = 7;
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
@@ -147,6 +153,7 @@ struct Ctx {
   float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
   float* BH; float* BE; // the same rows as block rows (headers, entries) for the packed solve kernel
   int nent;             // (J,B) pairs written by build_rows (entry 0 is the zero pair)
+  int nbunits;          // block-row units written by build_rows
   float* gcon;          // contact records handed from the build kernel to the solve / finish kernels
   long long tm[16]; bool timing;   // per-phase shader-clock totals (debug path only)
 };
@@ -179,7 +186,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
   c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
   c.dt = PRM(c, AGX_P_DT) / (float)(h[AGX_H_SIM_SUBSTEPS] > 1 ? h[AGX_H_SIM_SUBSTEPS] : 1); c.hooks = true;
-  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.BH = nullptr; c.BE = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.nbunits = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.BH = nullptr; c.BE = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 

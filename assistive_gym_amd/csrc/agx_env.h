@@ -288,9 +288,9 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
 //          from L2, integration, mouth-target update -> state
 //   finish (once per step): forces, observation, food state machine, preferences, reward, done.
 // ============================================================================================
-struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; };
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; float* brf; };
 AGX_DEV Scratch scratch_of(float* base) {
-  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE;
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE; s.brf = base + SCR_O_BRF;
   return s;
 }
 
@@ -350,10 +350,14 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
   build_rows(c); AGX_TICK(4)
+  if (lane < c.nfree) {      // what the packed solve kernel needs to form B = M^-1 J of a free body from J: 1/m and the world inverse inertia
+    float* o = gscratch + SCR_O_BRF + BRF_WORDS * lane; const float* Ii = L + L_FIINV + 9 * lane; const float mass = FBF(c, lane, AGX_F_MASS);
+    o[0] = mass > 0.f ? 1.0f / mass : 0.f; o[1] = Ii[0]; o[2] = Ii[1]; o[3] = Ii[2]; o[4] = Ii[4]; o[5] = Ii[5]; o[6] = Ii[8]; o[7] = 0.f;
+  }
 #undef AGX_TICK
   // hand-over to the solve kernel
   for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
-  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; scr.meta[META_NQPT] = c.nqpt; }
+  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; scr.meta[META_NQPT] = c.nqpt; scr.meta[META_NBENT] = c.nbunits; }
   if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
     if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // qdd at DBG_QDD
     for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[DBG_CON + q] = scr.con[q];

@@ -47,28 +47,27 @@ AGX_DEV void row_art_range(const Ctx& c, const RowGeom& r, int& lo, int& n) {
   n = (r.robot && r.human) ? c.ndof : (r.robot ? c.nrobot : (r.human ? c.nhdof : 0));
 }
 AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return n + (r.fa >= 0 ? 6 : 0) + (r.fb >= 0 ? 6 : 0); }
-// block-row entries of a row (agx_ctx.h: one per velocity block of 6 it touches)
-AGX_DEV int row_block_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return (n > 0 ? (lo + n - 1) / 6 - lo / 6 + 1 : 0) + (r.fa >= 0 ? 1 : 0) + (r.fb >= 0 ? 1 : 0); }
+// block-row units of a row (agx_ctx.h): 2 per articulated velocity block it touches, 1 per free body
+AGX_DEV int row_block_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return (n > 0 ? 2 * ((lo + n - 1) / 6 - lo / 6 + 1) : 0) + (r.fa >= 0 ? 1 : 0) + (r.fb >= 0 ? 1 : 0); }
 // B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
 // A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
 AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int boff, float bterm, float lo, float hi, int fric_of, float mu) {
   float* L = c.lds; float* E = c.E + 2 * off; const int n = c.ndof;
-  float* BEr = c.BE + BRE_WORDS * boff;                      // this row's block entries: articulated blocks k0..k1, then its free bodies in block order
+  float* BEr = c.BE + BRU_WORDS * boff;                      // this row's units: articulated blocks k0..k1 (J, B), then its free bodies' J in ascending order
   float D = 0.f; int e = 0;
   int a0 = 0, na = 0, b0 = 0, nb = 0;
   int alo, an; row_art_range(c, r, alo, an);
   const bool art = an > 0;
   const int k0 = alo / 6, nartb = art ? (alo + an - 1) / 6 - k0 + 1 : 0;
-  uint64_t bmap = 0ull; int be = 0;
+  int be = 2 * nartb, f1 = 0, f2 = 0;                        // units so far; codes (index + 1) of the free bodies in ascending order
   if (art) {
     a0 = alo; na = an;
-    for (int k = 0; k < nartb; k++) { bmap |= (uint64_t)(k + 1) << (4 * (k0 + k)); for (int q = 0; q < BRE_WORDS; q++) BEr[BRE_WORDS * k + q] = 0.f; }   // padding slots of the touched blocks
-    be = nartb;
+    for (int q = 0; q < 2 * BRU_WORDS * nartb; q++) BEr[q] = 0.f;                     // padding slots of the touched blocks
     _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i >= alo && i < alo + an) {
       float acc = 0.f;
       _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
       E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
-      float* o = BEr + BRE_WORDS * (i / 6 - k0) + i % 6; o[0] = r.Jr[i]; o[6] = acc;
+      float* o = BEr + 2 * BRU_WORDS * (i / 6 - k0) + i % 6; o[0] = r.Jr[i]; o[6] = acc;
     }
   }
   // free bodies in ascending DoF order, so that the pairs of a row are stored in lane order (the
@@ -84,8 +83,9 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
     int base = n + 6 * fb;
     if (na == 0 && nb == 0 && !art) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
-    for (int k = 0; k < 6; k++) { BEr[BRE_WORDS * be + k] = J[k]; BEr[BRE_WORDS * be + 6 + k] = B[k]; }
-    bmap |= (uint64_t)(be + 1) << (4 * (NB_ART + fb)); be++;
+    for (int k = 0; k < 6; k++) BEr[BRU_WORDS * be + k] = J[k];
+    if (f1 == 0) f1 = fb + 1; else f2 = fb + 1;
+    be++;
   }
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
   float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
@@ -98,8 +98,9 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
   Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
   Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
   { float* BH = c.BH + BRH_WORDS * row; int* BHi = (int*)BH;
-    BH[BRH_INVD] = H[H_INVD]; BH[BRH_B] = bterm; BH[BRH_LO] = lo; BH[BRH_HI] = fric_of >= 0 ? mu : hi;
-    BHi[BRH_MAPLO] = (int)(uint32_t)bmap; BHi[BRH_MAPHI] = (int)(uint32_t)(bmap >> 32); BHi[BRH_EOFF] = boff; BHi[BRH_NENT] = be; }
+    const int cls = fric_of >= 0 ? BR_CLASS_FRIC : (lo == 0.f ? BR_CLASS_POS : BR_CLASS_SYM);      // every row kind of build_rows is one of the three
+    BH[BRH_INVD] = H[H_INVD]; BH[BRH_B] = bterm; BH[BRH_BOUND] = fric_of >= 0 ? mu : hi;
+    BHi[BRH_DESC] = k0 | (nartb << 4) | (f1 << 8) | (f2 << 12) | (cls << 16) | (boff << 18); }
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
   if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
@@ -209,7 +210,7 @@ AGX_DEV void build_rows(Ctx& c) {
       bincl = wave_scan_excl(bcnt) + bcnt;
       // largest prefix of the contact list that fits the row and coefficient budgets; the contacts beyond it are
       // dropped and counted as overflow
-      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent) && (bent + 2 * bincl <= BR_MAX_ENT);
+      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent) && (bent + 2 * bincl <= BR_MAX_UNITS);
       const int kept = popc64(wave_ballot(fits));
       c.overflow += nc - kept; nc = kept;
       tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0); btot = wave_bcast_i(bincl, nc > 0 ? nc - 1 : 0);
@@ -230,7 +231,7 @@ AGX_DEV void build_rows(Ctx& c) {
     }
     if (go) row_store(c, R, rrow, roff, rboff, rb, rlo, rhi, rfric, rmu);
   }
-  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0);
+  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0); c.nbunits = bentF + (nc > 0 ? btot : 0);
   wave_sync();
 }
 

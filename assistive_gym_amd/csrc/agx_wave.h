@@ -13,6 +13,8 @@
 
 AGX_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
 AGX_DEV void wave_sync() { __syncthreads(); }
+// orders this wavefront's own LDS accesses in the compiler; the hardware executes a wavefront's LDS instructions in order, so no wait
+AGX_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // DPP controls (cdna4 ISA: DPP_CTRL)
 #define AGX_DPP_QUAD_1032 0xb1

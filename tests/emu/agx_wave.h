@@ -40,6 +40,7 @@ inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 AGX_DEV int wave_lane() { return emu::W->cur; }
 AGX_DEV void wave_sync() { emu::exchange(0); }
+AGX_DEV void wave_fence() { emu::exchange(0); }
 AGX_DEV float wave_sum(float x) {
   const uint32_t* s = emu::exchange(emu::f2u(x));
   // same association as the DPP tree of csrc/agx_wave.h: quads, rows of 16, then rows combined
