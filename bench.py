@@ -152,6 +152,65 @@ def wiping_pool(blob, n, seed):
     return st
 
 
+class _DryEnv:
+    """--dry-run: a stand-in for the batched environment on CPU tensors, so that the launch path of `bench.py --gpus N` -- rendezvous from the
+    torchrun environment, sharding by rank, the per-step observation all-gather (shard.ObsGatherer), barrier, max-over-ranks timing, the one
+    JSON line on rank 0 -- can be exercised without a GPU (tests/test_dist_gloo.py, backend gloo).  It steps nothing: libagx has no CPU path."""
+
+    def __init__(self, n, act_dim, obs_dim, rank):
+        import torch
+        self.n_envs, self.act_dim, self.obs_dim, self.rank = n, act_dim, obs_dim, rank
+        self.obs = torch.zeros((n, obs_dim)); self.info = torch.zeros((n, 8)); self.env_offset = 0
+
+    def reset(self, env_offset=0):
+        self.env_offset = env_offset
+
+    def step(self, actions, obs_out=None):
+        import torch
+        o = self.obs if obs_out is None else obs_out
+        o.zero_(); o[:, :self.act_dim] = actions; o[:, -1] = torch.arange(self.n_envs, dtype=torch.float32) + self.env_offset     # global env index: checked by the test
+        self.obs = o
+        return o, None, None, self.info
+
+
+def dry_run(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.shard import ObsGatherer
+    model, _, _, env_id = TASKS[args.task or 'feeding']
+    blob = ModelBlob.load(model)
+    if env_id.split()[0].endswith('Human-v1'):
+        blob = blob.coop()
+    n, K, W = args.envs_per_gpu, args.steps, args.warmup
+    env = _DryEnv(n, blob.act_dim, blob.obs_dim, rank)
+    env.reset(env_offset=rank * n)
+    g = torch.Generator(); g.manual_seed(1001 + rank)
+    tape = torch.rand((W + K, n, blob.act_dim), generator=g) * 2 - 1
+    gatherer = ObsGatherer(n, blob.obs_dim, world, device=None) if world > 1 else None
+    full = None
+    for k in range(W + K):
+        if k == W:
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        if gatherer is not None:
+            env.step(tape[k], obs_out=gatherer.buffer(k & 1)); full = gatherer.submit(k & 1)
+        else:
+            full = env.step(tape[k])[0]
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = bool(torch.equal(full[:, -1], torch.arange(world * n, dtype=torch.float32)))     # every rank holds the whole batch in global env order
+    return {'metric': 'env_steps_per_sec', 'value': world * n * K / float(t.item()), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': float(t.item()) / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'DRY RUN of the launch path of %s (no stepping: libagx has no CPU path)' % env_id, 'envs_per_gpu': n, 'global_envs': world * n,
+                       'parallelism': 'env-sharded x%d' % world, 'obs_allgather': world > 1, 'gathered_in_global_order': ok, 'obs_dim': blob.obs_dim, 'act_dim': blob.act_dim},
+            'dry_run': True}
+
+
 def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, cpu=True, workload=None, env_id_override=None):
     """one timed run of one configuration on this rank's GPU; returns the JSON-able dict on rank 0 (None elsewhere)"""
     import torch
@@ -335,8 +394,21 @@ def main():
     ap.add_argument('--env', default=None, help="any built env id instead of --task, e.g. 'ScratchItchJaco-v1' or 'FeedingSawyerHuman-v1' (assistive_gym_amd.envs.ENV_IDS)")
     ap.add_argument('--param', action='append', default=[], help='override a PARAMS entry of the model blob, e.g. --param NOOP_RETEST=0 (same-box A/B runs)')
     ap.add_argument('--no-configs', action='store_true', help='the default 1-GPU run also times short runs of BASELINE configs 3, 4 (1 GPU), 5 (1 GPU) into "configs"; this skips them')
-    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('gloo' is for the CPU-side test of the launch path only; the stepper needs a GPU)")
+    ap.add_argument('--backend', default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --dry-run)")
+    ap.add_argument('--dry-run', action='store_true', help='exercise the launch / sharding / all-gather / timing path on CPU tensors without stepping (no GPU needed; backend gloo)')
     args = ap.parse_args()
+    if args.dry_run:
+        import torch.distributed as dist
+        world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+        if world > 1:
+            dist.init_process_group(args.backend or 'gloo')
+        out = dry_run(args, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    args.backend = args.backend or 'nccl'
 
     import torch
     import torch.distributed as dist

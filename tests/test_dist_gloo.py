@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -93,3 +94,27 @@ def test_obs_gatherer_double_buffer_protocol():
     for rank, outs in res:
         for k, full in enumerate(outs):
             np.testing.assert_array_equal(full, np.concatenate([base + 1000 * k, base + 1000 * k + 100]))
+
+
+@pytest.mark.parametrize('task', ['feeding', 'scratchitch', 'dressing'])
+def test_bench_launch_path_on_gloo(task):
+    """`bench.py --gpus 2` exactly as the driver launches it (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1),
+    with --dry-run: no stepping (libagx has no CPU path), but the rank / world handling, the sharding by global env index, the per-step
+    observation all-gather, the barrier + max-over-ranks timing and the single JSON line of rank 0 are the real code -- for the
+    multi-GPU BASELINE configs too (ScratchItchPR2 co-op: 64 observations, 17 actions; DressingBaxter)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--task', task, '--envs-per-gpu', '32', '--dry-run'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout                     # one JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 6 and j['warmup'] == 2 and j['scaling'] == 'weak' and j['dry_run'] and j['config']['global_envs'] == 64
+    assert j['config']['gathered_in_global_order'] and j['config']['obs_allgather']
+    assert (j['config']['obs_dim'], j['config']['act_dim']) == {'feeding': (25, 7), 'scratchitch': (64, 17), 'dressing': (24, 7)}[task]

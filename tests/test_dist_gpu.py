@@ -12,34 +12,40 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-N_GLOBAL, STEPS, POOL, SEED = 48, 204, 5, 4242
+STEPS, SEED = 204, 4242
+# BASELINE config 2's env and the two multi-GPU configs (4: ScratchItchPR2 co-op, 17 actions, 30 + 34 observations; 5: DressingBaxter, whose
+# pool entries carry a garment each): (VecEnv class, global envs, pool size)
+CASES = {'feeding': ('FeedingJacoVecEnv', 48, 5), 'scratchitch_coop': ('ScratchItchPR2HumanVecEnv', 16, 3), 'dressing': ('DressingBaxterVecEnv', 8, 3)}
 
 
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rollout(n, env_offset, device):
-    from assistive_gym_amd.vec_env import FeedingJacoVecEnv
-    env = FeedingJacoVecEnv(n, device=device, seed=SEED, pool_size=POOL)
+def _rollout(case, n, env_offset, device):
+    from assistive_gym_amd import vec_env
+    cls, n_global, pool = CASES[case]
+    env = getattr(vec_env, cls)(n, device=device, seed=SEED, pool_size=pool)
     env.reset(env_offset=env_offset)
-    tape = torch.from_numpy(np.random.RandomState(7).uniform(-1, 1, (STEPS, N_GLOBAL, 7)).astype(np.float32))
+    tape = torch.from_numpy(np.random.RandomState(7).uniform(-1, 1, (STEPS, n_global, env.act_dim)).astype(np.float32))
     obs_log, rew_log = [], []
     for k in range(STEPS):
         obs, rew, done, info = env.step(tape[k, env_offset:env_offset + n].contiguous().cuda(device))
         if k % 17 == 0 or k >= STEPS - 5:
             obs_log.append(obs.cpu().clone()); rew_log.append(rew.cpu().clone())
     final = torch.from_numpy(env.stepper.get_state())
+    if getattr(env, 'cloth_pool_host', None) is not None:          # the garments are part of the state: appended, one row per environment
+        final = torch.cat([final, torch.from_numpy(env.stepper.get_cloth()).reshape(n, -1)], dim=1)
     env.close()
     return torch.stack(obs_log), torch.stack(rew_log), final
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, case):
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = rank % torch.cuda.device_count()
-    n = N_GLOBAL // world
-    obs, rew, final = _rollout(n, rank * n, dev)
+    n = CASES[case][1] // world
+    obs, rew, final = _rollout(case, n, rank * n, dev)
     outs = []
     for t in (obs.transpose(0, 1).contiguous(), rew.transpose(0, 1).contiguous(), final):      # env-major, so that shards concatenate
         full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
@@ -51,14 +57,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_one_rank_bit_for_bit():
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_two_ranks_match_one_rank_bit_for_bit(case):
     if not torch.cuda.is_available():
         __import__('conftest').no_gpu()
-    obs1, rew1, final1 = _rollout(N_GLOBAL, 0, 0)
+    obs1, rew1, final1 = _rollout(case, CASES[case][1], 0, 0)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, case)) for r in range(2)]
     [p.start() for p in ps]
     obs2, rew2, final2 = q.get(timeout=600)
     [p.join(timeout=120) for p in ps]
