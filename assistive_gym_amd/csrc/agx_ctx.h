@@ -112,23 +112,30 @@ constexpr int QPT_STRIDE = 4;                            // manifold query point
 constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
 constexpr int SCR_O_QPT = SCR_O_META + SCR_META;
-// ---- block rows: the same constraint rows in the layout the packed solve kernel (agx_pgs4.h) reads.  The generalised velocity is cut
-// into blocks of 6: the articulated DoFs first (NB_ART blocks, the last one padded), then one block per free body.  A row keeps, in
-// UNITS of 6 floats: for every articulated block it touches J[6] and B[6] (2 units, blocks in order), then J[6] of each free body it
-// touches (1 unit each, bodies in ascending order; B = M^-1 J is recomputed from the body's inverse mass and world inverse inertia,
-// BRF_*).  Header (4 words): 1/D, b, bound, descriptor = k0 | nart << 4 | (fa + 1) << 8 | (fb + 1) << 12 | class << 16 | first unit << 18
-// with k0 / nart the articulated blocks, fa / fb the free bodies (0 = none) and class 0: -bound <= lambda <= bound (motors, tool rows),
-// 1: 0 <= lambda (limits, contact normals), 2: |lambda| <= bound x lambda of the contact's normal row (friction, bound = mu).
+// ---- block rows: the same constraint rows in the layout the packed solve kernel (agx_pgs4.h) reads; only the variants that solve
+// with it emit them.  The generalised velocity is cut into blocks of 6: the articulated DoFs first (NB_ART blocks, the last one
+// padded), then one block per free body; block k is lane k of a 16-lane group.  A row keeps, in UNITS of 6 floats: for every
+// articulated block it touches J[6] and B[6] (2 units, blocks in order), then J[6] of each free body it touches (1 unit each, bodies in
+// ascending order; B = M^-1 J is recomputed from the body's inverse mass and world inverse inertia, BRF_*).  Header (6 words):
+//   nibbles of lanes 0..7, first unit | class << 16, nibbles of lanes 8..15, bound, 1/D, b
+// nibble of a lane = 1 + the offset, inside the row, of the unit(s) of the lane's block, or 0 if the row does not touch it -- so a lane
+// finds its coefficients with a shift and an add; lanes 0..7 read words (0, 1), lanes 8..15 words (1, 2).  Class 0: -bound <= lambda <=
+// bound (motors, tool rows), 1: 0 <= lambda (limits, contact normals), 2: |lambda| <= bound x lambda of the contact's normal row
+// (friction, bound = mu).
+#ifndef AGX_USE_SOLVE4
+#define AGX_USE_SOLVE4 (AGX_TASK == 0)
+#endif
+constexpr bool USE_SOLVE4 = AGX_USE_SOLVE4;
 constexpr int NB_ART = (MAX_DOF + 5) / 6, NB = NB_ART + MAX_FREE;
-static_assert(NB <= 16 && MAX_FREE < 15, "one lane of a 16-lane group per velocity block; free bodies are 4-bit codes");
-constexpr int BRH_WORDS = 4, BRU_WORDS = 6;
-constexpr int BRH_INVD = 0, BRH_B = 1, BRH_BOUND = 2, BRH_DESC = 3;
+static_assert(!USE_SOLVE4 || (NB <= 16 && 2 * NB_ART + 2 <= 15), "one lane of a 16-lane group per velocity block; unit offsets inside a row are nibbles");
+constexpr int BRH_WORDS = 6, BRU_WORDS = 6;
+constexpr int BRH_NIBLO = 0, BRH_EOFF = 1, BRH_NIBHI = 2, BRH_BOUND = 3, BRH_INVD = 4, BRH_B = 5;
 constexpr int BR_CLASS_SYM = 0, BR_CLASS_POS = 1, BR_CLASS_FRIC = 2;
 constexpr int BRF_WORDS = 8;                             // per free body: 1/m, world inverse inertia xx, xy, xz, yy, yz, zz, unused
-constexpr int SCR_BRH = MAX_ROWS * BRH_WORDS, SCR_BRE = 2 * SCR_ENT, BR_MAX_UNITS = SCR_BRE / BRU_WORDS, SCR_BRF = MAX_FREE * BRF_WORDS;
-static_assert(BR_MAX_UNITS < (1 << 14), "first unit of a row: 14 bits of the descriptor");
+constexpr int SCR_BRH = USE_SOLVE4 ? MAX_ROWS * BRH_WORDS : 0, SCR_BRE = USE_SOLVE4 ? 2 * SCR_ENT : 0, BR_MAX_UNITS = SCR_BRE / BRU_WORDS, SCR_BRF = USE_SOLVE4 ? MAX_FREE * BRF_WORDS : 0;
+static_assert(BR_MAX_UNITS < (1 << 16), "first unit of a row: 16 bits of the header word");
 constexpr int SCR_O_BRH = SCR_O_QPT + SCR_QPT, SCR_O_BRF = SCR_O_BRH + SCR_BRH, SCR_O_BRE = SCR_O_BRF + SCR_BRF;
-static_assert(SCR_O_BRH % 4 == 0 && SCR_O_BRE % 2 == 0 && SCR_O_BRF % 4 == 0, "block rows are read as 16- and 8-byte words");
+static_assert(SCR_O_BRH % 2 == 0 && SCR_O_BRE % 2 == 0 && SCR_O_BRF % 4 == 0, "block rows are read as 8-byte words");
 constexpr int SCR_WORDS = SCR_O_BRE + SCR_BRE;
 constexpr int META_NBENT = 7;
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;

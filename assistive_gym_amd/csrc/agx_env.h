@@ -350,7 +350,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
   build_rows(c); AGX_TICK(4)
-  if (lane < c.nfree) {      // what the packed solve kernel needs to form B = M^-1 J of a free body from J: 1/m and the world inverse inertia
+  if (USE_SOLVE4 && lane < c.nfree) {      // what the packed solve kernel needs to form B = M^-1 J of a free body from J: 1/m and the world inverse inertia
     float* o = gscratch + SCR_O_BRF + BRF_WORDS * lane; const float* Ii = L + L_FIINV + 9 * lane; const float mass = FBF(c, lane, AGX_F_MASS);
     o[0] = mass > 0.f ? 1.0f / mass : 0.f; o[1] = Ii[0]; o[2] = Ii[1]; o[3] = Ii[2]; o[4] = Ii[4]; o[5] = Ii[5]; o[6] = Ii[8]; o[7] = 0.f;
   }

@@ -32,49 +32,68 @@ AGX_DEV float g16_sum(float x) {
 AGX_DEV uint32_t g16_ballot(bool p, int group) { return (uint32_t)(__ballot(p) >> (16 * group)) & 0xffffu; }
 #endif
 
-// which variants solve with the packed kernel (the others keep the one-wave-per-environment sweeps of agx_pgs.h)
-#ifndef AGX_USE_SOLVE4
-#define AGX_USE_SOLVE4 (AGX_TASK == 0)
-#endif
-constexpr bool USE_SOLVE4 = AGX_USE_SOLVE4;
-// LDS of the packed kernel (float words): the per-environment epilogue reuses [L_ST, L_VEL + 128) of the single-environment layout; each
-// of the four groups has its impulses, its visit list and skip flags (bytes) and P4_ROWMEM words of row memory: the headers of all its
-// rows (4 words each), then a window of the first units of its rows -- units beyond the window are read from the scratch record (L2).
-// 4 x 40 KB = the CU's 160 KB: one wavefront per SIMD, every environment of a 4096-environment batch resident at once.
-constexpr int P4_BASE = L_VEL + 128;
-constexpr int P4_LAM = 0, P4_LIST = P4_LAM + MAX_ROWS, P4_SKIP = P4_LIST + MAX_ROWS / 4, P4_ROWS = P4_SKIP + MAX_ROWS / 4;
-constexpr int P4_ROWMEM = (10240 - 64 - P4_BASE - 4 * 128) / 4 - P4_ROWS;
-constexpr int P4_GROUP_WORDS = P4_ROWS + P4_ROWMEM;
-constexpr int P4_DV = P4_BASE + 4 * P4_GROUP_WORDS;      // [4][128] velocity deltas in DoF order for the epilogue
-constexpr int LDS_SOLVE4_WORDS = P4_DV + 4 * 128;
-constexpr int LDS_SOLVE4_BYTES = LDS_SOLVE4_WORDS * 4;
-static_assert(LDS_SOLVE4_BYTES <= 40 * 1024 && P4_ROWMEM >= MAX_ROWS * BRH_WORDS && P4_ROWS % 2 == 0 && P4_BASE % 2 == 0 && P4_GROUP_WORDS % 2 == 0, "four wavefronts per CU; 8-byte aligned row memory");
+// LDS of the packed kernel (float words), 40 KB = a quarter of the CU's 160 KB: one wavefront per SIMD, every environment of a
+// 4096-environment batch resident at once.  16 zero words (what a lane reads for a row that does not touch its block), then per group:
+// its impulses, its visit list (16-bit entries: row | class << 8; 8 entries of slack for the look-ahead reads), its skip flags (bytes) and
+// the row memory: the headers of all its rows (BRH_WORDS each), then a window of the first units of its rows -- a FeedingJaco scene at
+// rest (53 contacts, 122 rows, 260 units) fits entirely; units beyond the window are read from the scratch record (L2).  When the sweeps are over, the per-environment epilogue reuses the bottom
+// of this memory as [L_ST, L_VEL + 128) of the single-environment layout, and the top 4 x 128 words as the velocity deltas in DoF order.
+constexpr int LDS_SOLVE4_WORDS = 10240, LDS_SOLVE4_BYTES = LDS_SOLVE4_WORDS * 4;
+constexpr int P4_ZERO = 0, P4_G0 = 16, P4_GROUP_WORDS = (LDS_SOLVE4_WORDS - P4_G0) / 4;
+constexpr int P4_LIST_PAD = 8;
+// a group's memory is cut to its row count R8 (R rounded up to 8): impulses [R8], list [R8 + pad] (16 bit), skip flags [R8] (bytes), row memory
+AGX_DEV constexpr int p4_rows_words(int r8) { return r8 + (r8 + P4_LIST_PAD) / 2 + r8 / 4; }
+constexpr int P4_DV = LDS_SOLVE4_WORDS - 4 * 128;        // [4][128]
+static_assert(P4_GROUP_WORDS - p4_rows_words(MAX_ROWS) >= MAX_ROWS * BRH_WORDS + 4 * BRU_WORDS && P4_G0 % 2 == 0 && P4_GROUP_WORDS % 2 == 0 && MAX_ROWS % 8 == 0 && P4_LIST_PAD % 8 == 0, "8-byte aligned row memory");
+static_assert(L_VEL + 128 <= P4_DV && MAX_ROWS <= 255, "the epilogue's single-environment region stays below the velocity deltas; rows fit the list's low byte");
 
 AGX_DEV void solve_tail(Ctx& c, float* gstate, Scratch& scr, int sw, int phase, float dv0, float dv1);
 
-struct P4Ent { f2 j0, j1, j2, b0, b1, b2; };      // J[6] of this lane's block, B[6] for articulated blocks
-// this lane's part of the row described by `desc`: issues the loads (window in LDS or scratch in L2); lanes the row does not touch get zeros
-AGX_DEV void p4_fetch(uint32_t desc, bool on, int j, int wunits, const float* ENT, const float* BE, P4Ent& E) {
-  const f2 z = {0.f, 0.f};
-  E.j0 = z; E.j1 = z; E.j2 = z; E.b0 = z; E.b1 = z; E.b2 = z;
-  const int k0 = desc & 15, nart = (desc >> 4) & 15, fa = (desc >> 8) & 15, fb = (desc >> 12) & 15; const int eoff = (int)(desc >> 18);
-  const bool isart = j < NB_ART; const int f1 = j - NB_ART + 1;
-  const bool has = on && (isart ? (unsigned)(j - k0) < (unsigned)nart : (f1 == fa || f1 == fb));
-  const int unit = isart ? eoff + 2 * (j - k0) : eoff + 2 * nart + ((f1 == fb && fa != 0) ? 1 : 0);
-  if (has) {
-    if (unit + (isart ? 1 : 0) < wunits) {
-      const f2* p = (const f2*)(ENT + BRU_WORDS * unit);
-      E.j0 = p[0]; E.j1 = p[1]; E.j2 = p[2];
-      if (isart) { E.b0 = p[3]; E.b1 = p[4]; E.b2 = p[5]; }
-    } else {
-      const f2* p = (const f2*)(BE + BRU_WORDS * unit);
-      E.j0 = p[0]; E.j1 = p[1]; E.j2 = p[2];
-      if (isart) { E.b0 = p[3]; E.b1 = p[4]; E.b2 = p[5]; }
+// One look-ahead slot of the pipeline: J[6] of this lane's block and B[6] (articulated blocks; zero for a free body, whose B is formed
+// from J); `far`: the units lie beyond the LDS window (then at unit index `unit` of the scratch record)
+struct P4Ent { f2 j0, j1, j2, b0, b1, b2; int unit; bool far; };
+// what a lane needs to find its units of a row: its nibble word and the first-unit word of the row's header (agx_ctx.h)
+struct P4Na { uint32_t x, y; };
+AGX_DEV P4Na p4_na(const float* HDR, int row, int j) {
+  const uint32_t* h = (const uint32_t*)HDR + BRH_WORDS * row + (j >> 3);       // lanes 0..7: words (0, 1); lanes 8..15: words (1, 2)
+  P4Na n; n.x = h[0]; n.y = h[1]; return n;
+}
+// Requests this lane's units of the row behind `na` into E.  LDS pointers (the window or the zero unit) and unconditional ds_reads, so
+// that the loads stay in flight across the arithmetic of the steps before their use: LDS answers in order and the compiler can wait
+// for "all but the youngest n" (a flat pointer covering LDS and L2 would count against lgkmcnt AND vmcnt: every LDS wait would then
+// wait for memory too).
+AGX_DEV void p4_load(P4Na na, bool on, int j, int wunits, const float* ENT, const float* ZERO, P4Ent& E) {
+  const bool lo8 = j < 8, isart = j < NB_ART;
+  const uint32_t nibw = lo8 ? na.x : na.y, eoffw = lo8 ? na.y : na.x;
+  const int nib = (int)((nibw >> (4 * (j & 7))) & 15u);
+  const int unit = (int)(eoffw & 0xffffu) + nib - 1;
+  const bool has = on & (nib != 0), inwin = unit + (isart ? 1 : 0) < wunits;
+  const float* pj = (has & inwin) ? ENT + BRU_WORDS * unit : ZERO;
+  const float* pb = (has & inwin & isart) ? ENT + BRU_WORDS * unit + BRU_WORDS : ZERO;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float p4_v2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) p4_v2* p4_lp;
+  const p4_lp qj = (p4_lp)pj, qb = (p4_lp)pb;
+  const p4_v2 u0 = qj[0], u1 = qj[1], u2 = qj[2], u3 = qb[0], u4 = qb[1], u5 = qb[2];
+  E.j0 = {u0.x, u0.y}; E.j1 = {u1.x, u1.y}; E.j2 = {u2.x, u2.y}; E.b0 = {u3.x, u3.y}; E.b1 = {u4.x, u4.y}; E.b2 = {u5.x, u5.y};
+#else
+  const f2* qj = (const f2*)pj; const f2* qb = (const f2*)pb;
+  E.j0 = qj[0]; E.j1 = qj[1]; E.j2 = qj[2]; E.b0 = qb[0]; E.b1 = qb[1]; E.b2 = qb[2];
+#endif
+  E.unit = unit; E.far = has & !inwin;
+}
+// just before the slot is used, in the (rare) parts whose lists hold rows beyond the window: those units from L2, waited for on the spot
+AGX_DEV void p4_fix(P4Ent& E, const float* BE, int j) {
+  if (wave_any(E.far)) {
+    if (E.far) {
+      const f2* q = (const f2*)(BE + BRU_WORDS * E.unit);
+      E.j0 = q[0]; E.j1 = q[1]; E.j2 = q[2];
+      if (j < NB_ART) { E.b0 = q[3]; E.b1 = q[4]; E.b2 = q[5]; }
     }
   }
 }
 
-// env_first: environment of group 0; env_end: end of the launch's environment range; active as in the single-environment kernels
+// env_first: environment of group 0; n_envs: end of the launch's environment range; active as in the single-environment kernels
 AGX_DEV void env_solve4(const uint32_t* blob, float* gstate_all, float* gscratch_all, int env_first, int n_envs, int sw, const uint8_t* active, float* lds, int lane, int phase) {
   const int g = lane >> 4, j = lane & 15;
   const int env = env_first + g;
@@ -84,42 +103,56 @@ AGX_DEV void env_solve4(const uint32_t* blob, float* gstate_all, float* gscratch
   const int* meta = (const int*)(scrb + SCR_O_META);
   const int nnc = valid ? meta[META_NNC] : 0, nc = valid ? meta[META_NCON] : 0, nA = nnc + nc, R = nA + nc, nunits = valid ? meta[META_NBENT] : 0;
   const float* BH = scrb + SCR_O_BRH; const float* BE = scrb + SCR_O_BRE;
-  float* G = lds + P4_BASE + g * P4_GROUP_WORDS;
-  float* LAM = G + P4_LAM; uint8_t* LIST = (uint8_t*)(G + P4_LIST); uint8_t* SKIP = (uint8_t*)(G + P4_SKIP);
-  float* HDR = G + P4_ROWS; float* ENT = HDR + BRH_WORDS * ((R + 1) & ~1);       // headers, then the window of units (8-byte aligned)
-  const int wunits = (P4_ROWMEM - BRH_WORDS * ((R + 1) & ~1)) / BRU_WORDS;
-  static_assert(MAX_ROWS <= 255, "visit lists are bytes");
-  for (int r = j; r < MAX_ROWS; r += 16) { LAM[r] = 0.f; SKIP[r] = 0; LIST[r] = 0; }
-  for (int r = j; r < R; r += 16) *(float4*)(HDR + BRH_WORDS * r) = *(const float4*)(BH + BRH_WORDS * r);
-  { const int nw = (nunits < wunits ? nunits : wunits) * (BRU_WORDS / 2);
-    for (int k = j; k < nw; k += 16) ((f2*)ENT)[k] = ((const f2*)BE)[k]; }
-  // inverse mass and world inverse inertia of this lane's free body (B = M^-1 J of its rows is formed from J)
+  float* G = lds + P4_G0 + g * P4_GROUP_WORDS;
+  const int R8 = (R + 7) & ~7;
+  float* LAM = G; uint16_t* LIST = (uint16_t*)(G + R8); uint8_t* SKIP = (uint8_t*)(G + R8 + (R8 + P4_LIST_PAD) / 2);
+  float* HDR = G + p4_rows_words(R8); float* ENT = HDR + BRH_WORDS * R;       // headers, then the window of units (8-byte aligned: BRH_WORDS is even)
+#ifdef AGX_P4_WINDOW_CAP          // tests: a small window, so that the path for units beyond it runs on ordinary scenes
+  const int wunits = AGX_P4_WINDOW_CAP;
+#else
+  const int wunits = (P4_GROUP_WORDS - p4_rows_words(R8) - BRH_WORDS * R) / BRU_WORDS;
+#endif
+  for (int r = j; r < R8; r += 16) { LAM[r] = 0.f; SKIP[r] = 0; }
+  for (int r = j; r < R8 + P4_LIST_PAD; r += 16) LIST[r] = 0;
+  if (lane < 16) lds[P4_ZERO + lane] = 0.f;
+  if (R == 0 && j < BRH_WORDS) HDR[j] = 0.f;                         // the look-ahead reads of an empty list land on row 0
+  { const int nw = R * (BRH_WORDS / 2); for (int k = j; k < nw; k += 16) ((f2*)HDR)[k] = ((const f2*)BH)[k]; }
+  { const int nw = (nunits < wunits ? nunits : wunits) * (BRU_WORDS / 2); for (int k = j; k < nw; k += 16) ((f2*)ENT)[k] = ((const f2*)BE)[k]; }
+  // the first row with units beyond the window (rows are stored in unit order)
+  int rfar = R;
+  for (int base = 0; wave_any(base < R); base += 16) {
+    const int r = base + j;
+    const int end = r + 1 < R ? (int)(((const uint32_t*)BH)[BRH_WORDS * (r + 1) + BRH_EOFF] & 0xffffu) : nunits;
+    const uint32_t m = g16_ballot(r < R && end > wunits, g);
+    if (m && rfar == R) rfar = base + __builtin_ctz(m);
+  }
+  // inverse mass and world inverse inertia of this lane's free body (B = M^-1 J of its rows is formed from J); zero in the other lanes
   float im = 0.f, ixx = 0.f, ixy = 0.f, ixz = 0.f, iyy = 0.f, iyz = 0.f, izz = 0.f;
-  const bool isart = j < NB_ART;
-  if (!isart && j - NB_ART < bi[AGX_H_NFREE]) {
+  if (j >= NB_ART && j - NB_ART < bi[AGX_H_NFREE]) {
     const float* F = scrb + SCR_O_BRF + BRF_WORDS * (j - NB_ART);
     im = F[0]; ixx = F[1]; ixy = F[2]; ixz = F[3]; iyy = F[4]; iyz = F[5]; izz = F[6];
   }
   float dv0 = 0.f, dv1 = 0.f, dv2 = 0.f, dv3 = 0.f, dv4 = 0.f, dv5 = 0.f;
   const int iters = (int)bf[bi[AGX_H_OFF_PARAMS] + AGX_P_NITER], K = (int)bf[bi[AGX_H_OFF_PARAMS] + AGX_P_NOOP_RETEST];
-  int lenA = 0;
+  const float* ZERO = lds + P4_ZERO;
+  int lenA = 0; bool farA = false;
   wave_sync();
   for (int it = 0; it < iters; it++) {
     const bool retest = K > 0 && it % K == 0;
     // the non-friction part of the visit list changes only around a re-test sweep (every row / the rows that are not skipped)
     if (it == 0 || (K > 0 && (it % K == 0 || it % K == 1))) {
-      lenA = 0;
+      lenA = 0; farA = rfar < nA;                  // (conservative on the sweeps that skip rows)
       for (int base = 0; wave_any(base < nA); base += 16) {
         const int r = base + j;
         const bool take = r < nA && (K <= 0 || retest || !SKIP[r]);
         const uint32_t m = g16_ballot(take, g);
-        if (take) LIST[lenA + __builtin_popcount(m & ((1u << j) - 1u))] = (uint8_t)r;
+        if (take) LIST[lenA + __builtin_popcount(m & ((1u << j) - 1u))] = (uint16_t)(r | ((((const uint32_t*)HDR)[BRH_WORDS * r + BRH_EOFF] >> 16) << 8));
         lenA += __builtin_popcount(m);
       }
       wave_sync();
     }
     for (int part = 0; part < 2; part++) {
-      int len = lenA, first = 0;
+      int len = lenA, first = 0; bool anyfar = farA;
       if (part == 1) {
         // friction rows: a row whose normal impulse (as this sweep's normal pass left it) and own impulse are both zero is an exact no-op
         wave_sync();
@@ -128,46 +161,70 @@ AGX_DEV void env_solve4(const uint32_t* blob, float* gstate_all, float* gscratch
           const int r = nA + base + j;
           const bool take = base + j < nc && (LAM[r - nc] != 0.f || LAM[r] != 0.f);
           const uint32_t m = g16_ballot(take, g);
-          if (take) LIST[first + len + __builtin_popcount(m & ((1u << j) - 1u))] = (uint8_t)r;
+          if (take) LIST[first + len + __builtin_popcount(m & ((1u << j) - 1u))] = (uint16_t)(r | (BR_CLASS_FRIC << 8));
           len += __builtin_popcount(m);
         }
+        anyfar = rfar < R;
         wave_sync();
       }
-      // software pipeline: step t computes with the header and units fetched during step t - 1; the header of step t + 2 and the units
-      // of step t + 1 are requested before the arithmetic of step t (a group's visit list is fixed for the part, so every address is known)
-      int r0 = 0 < len ? LIST[first] : 0, r1 = 1 < len ? LIST[first + 1] : 0;
-      float4 H0 = *(const float4*)(HDR + BRH_WORDS * r0), H1 = *(const float4*)(HDR + BRH_WORDS * r1);
-      P4Ent E0; p4_fetch(__builtin_bit_cast(uint32_t, H0.w), 0 < len, j, wunits, ENT, BE, E0);
-      for (int t = 0; wave_any(t < len); t++) {
-        const bool on = t < len;
-        const int r2 = t + 2 < len ? LIST[first + t + 2] : 0;
-        const float4 H2 = *(const float4*)(HDR + BRH_WORDS * r2);
-        P4Ent E1; p4_fetch(__builtin_bit_cast(uint32_t, H1.w), t + 1 < len, j, wunits, ENT, BE, E1);
-        const int r = r0;
-        const int cls = (int)((__builtin_bit_cast(uint32_t, H0.w) >> 16) & 3u);
-        const float J0 = E0.j0.x, J1 = E0.j0.y, J2 = E0.j1.x, J3 = E0.j1.y, J4 = E0.j2.x, J5 = E0.j2.y;
-        float B0, B1, B2, B3, B4, B5;
-        if (isart) { B0 = E0.b0.x; B1 = E0.b0.y; B2 = E0.b1.x; B3 = E0.b1.y; B4 = E0.b2.x; B5 = E0.b2.y; }
-        else { B0 = im * J0; B1 = im * J1; B2 = im * J2; B3 = ixx * J3 + ixy * J4 + ixz * J5; B4 = ixy * J3 + iyy * J4 + iyz * J5; B5 = ixz * J3 + iyz * J4 + izz * J5; }
-        const float x = ((J0 * dv0 + J1 * dv1) + (J2 * dv2 + J3 * dv3)) + (J4 * dv4 + J5 * dv5);
-        // every lane reads the impulses BEFORE the cross-lane sum: lane 0 of the group rewrites LAM[r] below (lock step on the GPU; on
-        // the fibre emulator the sum is the rendezvous that orders these reads before that write)
-        const float lam = LAM[r];
-        const float lamn = LAM[(cls == BR_CLASS_FRIC && on) ? r - nc : r];
-        const float jdv = g16_sum(x);
-        const float hi = cls == BR_CLASS_SYM ? H0.z : (cls == BR_CLASS_POS ? 1e30f : H0.z * lamn), lo = cls == BR_CLASS_POS ? 0.f : -hi;
-        const float nl = wave_clamp(lam + (H0.y - jdv) * H0.x, lo, hi);
-        const float dl = on ? nl - lam : 0.f;
-        if (on && j == 0) { LAM[r] = nl; if (retest && part == 0) SKIP[r] = dl == 0.f ? 1 : 0; }
-        dv0 += B0 * dl; dv1 += B1 * dl; dv2 += B2 * dl; dv3 += B3 * dl; dv4 += B4 * dl; dv5 += B5 * dl;
-        wave_fence();     // the next visit of this group reads the impulse written above: program order inside one wavefront, no wait
-        r0 = r1; r1 = r2; H0 = H1; H1 = H2; E0 = E1;
+      const bool mark = retest && part == 0;
+      // Software pipeline over the group's visit list (fixed for the part, so every address is known ahead): at step t the list entry
+      // of step t + 4, the nibble / first-unit words of step t + 3, the units of step t + 2 and the header of step t + 1 are requested
+      // before the arithmetic of step t.  Three unit slots rotate through "in use / next / being fetched" (the loop body is three steps).
+      // List entries past the end are stale but valid rows; `on` keeps them from having any effect.
+      const uint16_t* LP = LIST + first;
+      int rq0 = LP[0], rq1 = LP[1], rq2 = LP[2], rq3 = LP[3];
+      P4Ent EA, EB, EC;
+      p4_load(p4_na(HDR, rq0 & 255, j), 0 < len, j, wunits, ENT, ZERO, EA);
+      p4_load(p4_na(HDR, rq1 & 255, j), 1 < len, j, wunits, ENT, ZERO, EB);
+      P4Na na2 = p4_na(HDR, rq2 & 255, j);
+      f2 Hc01 = *(const f2*)(HDR + BRH_WORDS * (rq0 & 255) + BRH_INVD); float Hcb = HDR[BRH_WORDS * (rq0 & 255) + BRH_BOUND];      // (1/D, b), bound
+      int t = 0;
+#define P4_STEP(ECUR, ENEW, FIX) { \
+        const bool on = t < len; \
+        const int r = rq0 & 255, cls = rq0 >> 8; \
+        if (FIX) p4_fix(ECUR, BE, j); \
+        /* the impulses first: LDS answers in order, so the look-ahead reads below may still be in flight when these two are waited for. */ \
+        /* Every lane reads them BEFORE the cross-lane sum: lane 0 of the group rewrites LAM[r] below (lock step on the GPU; on the fibre */ \
+        /* emulator the sum is the rendezvous that orders these reads before that write) */ \
+        const float lam = LAM[r]; \
+        const float lamn = LAM[cls == BR_CLASS_FRIC ? r - nc : r]; \
+        wave_fence(); \
+        const int rn = LP[t + 4]; \
+        const P4Na na3 = p4_na(HDR, rq3 & 255, j); \
+        p4_load(na2, t + 2 < len, j, wunits, ENT, ZERO, ENEW); \
+        const f2 Hn01 = *(const f2*)(HDR + BRH_WORDS * (rq1 & 255) + BRH_INVD); const float Hnb = HDR[BRH_WORDS * (rq1 & 255) + BRH_BOUND]; \
+        const float J0 = ECUR.j0.x, J1 = ECUR.j0.y, J2 = ECUR.j1.x, J3 = ECUR.j1.y, J4 = ECUR.j2.x, J5 = ECUR.j2.y; \
+        /* B = the stored M^-1 J of an articulated block (im = I = 0 in those lanes) or M^-1 J of this lane's free body (stored part 0) */ \
+        const float B0 = im * J0 + ECUR.b0.x, B1 = im * J1 + ECUR.b0.y, B2 = im * J2 + ECUR.b1.x; \
+        const float B3 = ixx * J3 + (ixy * J4 + (ixz * J5 + ECUR.b1.y)), B4 = ixy * J3 + (iyy * J4 + (iyz * J5 + ECUR.b2.x)), B5 = ixz * J3 + (iyz * J4 + (izz * J5 + ECUR.b2.y)); \
+        const float x = ((J0 * dv0 + J1 * dv1) + (J2 * dv2 + J3 * dv3)) + (J4 * dv4 + J5 * dv5); \
+        const float jdv = g16_sum(x); \
+        const float hi = cls == BR_CLASS_SYM ? Hcb : (cls == BR_CLASS_POS ? 1e30f : Hcb * lamn), lo = cls == BR_CLASS_POS ? 0.f : -hi; \
+        const float nl = wave_clamp(lam + (Hc01.y - jdv) * Hc01.x, lo, hi); \
+        const float dl = on ? nl - lam : 0.f; \
+        if (on && j == 0) { LAM[r] = nl; if (mark) SKIP[r] = dl == 0.f ? 1 : 0; } \
+        dv0 += B0 * dl; dv1 += B1 * dl; dv2 += B2 * dl; dv3 += B3 * dl; dv4 += B4 * dl; dv5 += B5 * dl; \
+        wave_fence();     /* the next visit of this group reads the impulse written above: program order inside one wavefront, no wait */ \
+        rq0 = rq1; rq1 = rq2; rq2 = rq3; rq3 = rn; na2 = na3; Hc01 = Hn01; Hcb = Hnb; t++; \
+        if (!wave_any(t < len)) break; }
+      if (!wave_any(0 < len)) continue;
+      if (!wave_any(anyfar)) for (;;) {             // every unit of every group's list in its LDS window: the common case
+        P4_STEP(EA, EC, false)
+        P4_STEP(EB, EA, false)
+        P4_STEP(EC, EB, false)
+      } else for (;;) {
+        P4_STEP(EA, EC, true)
+        P4_STEP(EB, EA, true)
+        P4_STEP(EC, EB, true)
       }
+#undef P4_STEP
     }
   }
   wave_sync();
   // solved normal impulses -> contact records (what getContactPoints reports until the next step)
   if (valid) { float* gcon = scrb + SCR_O_CON; for (int r = nnc + j; r < nA; r += 16) gcon[CON_STRIDE * (r - nnc) + C_LAM] = LAM[r]; }
+  wave_sync();                 // the velocity deltas of group 3 land in (what was) its own row memory
   // velocity deltas in DoF order, then integration + hooks one environment at a time with the whole wave (the single-environment code)
   {
     const int ndof = bi[AGX_H_NDOF], nfree = bi[AGX_H_NFREE];

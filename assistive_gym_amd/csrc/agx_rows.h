@@ -59,19 +59,21 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
   int alo, an; row_art_range(c, r, alo, an);
   const bool art = an > 0;
   const int k0 = alo / 6, nartb = art ? (alo + an - 1) / 6 - k0 + 1 : 0;
-  int be = 2 * nartb, f1 = 0, f2 = 0;                        // units so far; codes (index + 1) of the free bodies in ascending order
+  int be = 2 * nartb;                                        // units so far
+  uint64_t nib = 0ull;                                       // per lane of the packed solver: 1 + offset of its unit(s) inside the row
+  for (int i = 0; i < nartb; i++) nib |= (uint64_t)(2 * i + 1) << (4 * (k0 + i));
   if (art) {
     a0 = alo; na = an;
-    for (int q = 0; q < 2 * BRU_WORDS * nartb; q++) BEr[q] = 0.f;                     // padding slots of the touched blocks
+    if (USE_SOLVE4) for (int q = 0; q < 2 * BRU_WORDS * nartb; q++) BEr[q] = 0.f;     // padding slots of the touched blocks
     _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i >= alo && i < alo + an) {
       float acc = 0.f;
       _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
       E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
-      float* o = BEr + 2 * BRU_WORDS * (i / 6 - k0) + i % 6; o[0] = r.Jr[i]; o[6] = acc;
+      if (USE_SOLVE4) { float* o = BEr + 2 * BRU_WORDS * (i / 6 - k0) + i % 6; o[0] = r.Jr[i]; o[6] = acc; }
     }
   }
   // free bodies in ascending DoF order, so that the pairs of a row are stored in lane order (the
-  // solver addresses them by the rank of the lane inside the row's lane mask)
+  // solver addresses them by the rank of the lane inside the row's lane mask); the packed solver's units likewise
   const int first = (r.fa >= 0 && r.fb >= 0 && r.fb < r.fa) ? 1 : 0;
   for (int s2 = 0; s2 < 2; s2++) {
     const int side = s2 ^ first;
@@ -83,9 +85,11 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
     int base = n + 6 * fb;
     if (na == 0 && nb == 0 && !art) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
-    for (int k = 0; k < 6; k++) BEr[BRU_WORDS * be + k] = J[k];
-    if (f1 == 0) f1 = fb + 1; else f2 = fb + 1;
-    be++;
+    if (USE_SOLVE4) {
+      for (int k = 0; k < 6; k++) BEr[BRU_WORDS * be + k] = J[k];
+      nib |= (uint64_t)(be + 1) << (4 * (NB_ART + fb));
+      be++;
+    }
   }
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
   float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
@@ -97,10 +101,12 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
   if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
   Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
   Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
-  { float* BH = c.BH + BRH_WORDS * row; int* BHi = (int*)BH;
+  if (USE_SOLVE4) {
+    float* BH = c.BH + BRH_WORDS * row; int* BHi = (int*)BH;
     const int cls = fric_of >= 0 ? BR_CLASS_FRIC : (lo == 0.f ? BR_CLASS_POS : BR_CLASS_SYM);      // every row kind of build_rows is one of the three
     BH[BRH_INVD] = H[H_INVD]; BH[BRH_B] = bterm; BH[BRH_BOUND] = fric_of >= 0 ? mu : hi;
-    BHi[BRH_DESC] = k0 | (nartb << 4) | (f1 << 8) | (f2 << 12) | (cls << 16) | (boff << 18); }
+    BHi[BRH_NIBLO] = (int)(uint32_t)nib; BHi[BRH_NIBHI] = (int)(uint32_t)(nib >> 32); BHi[BRH_EOFF] = boff | (cls << 16);
+  }
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
   if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
@@ -210,7 +216,7 @@ AGX_DEV void build_rows(Ctx& c) {
       bincl = wave_scan_excl(bcnt) + bcnt;
       // largest prefix of the contact list that fits the row and coefficient budgets; the contacts beyond it are
       // dropped and counted as overflow
-      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent) && (bent + 2 * bincl <= BR_MAX_UNITS);
+      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent) && (!USE_SOLVE4 || bent + 2 * bincl <= BR_MAX_UNITS - 2);
       const int kept = popc64(wave_ballot(fits));
       c.overflow += nc - kept; nc = kept;
       tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0); btot = wave_bcast_i(bincl, nc > 0 ? nc - 1 : 0);

@@ -24,6 +24,25 @@ def _models():
     return {k: c.model for k, c in envs.ENV_IDS.items() if not c.coop}
 
 
+class _LazyInfos:
+    """the per-environment info dicts of a step (`info` of <Task>Env.step: total_force_on_human, task_success, the four length entries),
+    built only for the environments somebody indexes: a sampler that never looks at `info` does not pay for num_envs dictionaries per step"""
+
+    def __init__(self, static, force, success):
+        self._static, self._force, self._success = static, force, success
+
+    def __len__(self):
+        return len(self._force)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        return dict(self._static, total_force_on_human=float(self._force[i]), task_success=int(self._success[i]))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class AgxVectorEnv(_VectorEnv):
     def __init__(self, env_id, num_envs, device=0, seed=1001, **vec_kwargs):
         from . import envs
@@ -37,7 +56,7 @@ class AgxVectorEnv(_VectorEnv):
         if name not in ('FeedingJaco-v1', 'FeedingPanda-v1', 'ScratchItchJaco-v1', 'ScratchItchPanda-v1'):
             vec_kwargs.setdefault('reset', 'pool')         # only the wheelchair-mounted feeding robots have a device-side reset generator
         self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=_models()[name], **vec_kwargs)
-        self._obs = None
+        self._obs, self._host, self._pack = None, None, None
 
     def vector_reset(self):
         self._obs = self.vec.reset().cpu().numpy().astype(np.float64)
@@ -50,13 +69,21 @@ class AgxVectorEnv(_VectorEnv):
         import torch
         a = torch.as_tensor(np.asarray(actions, dtype=np.float32), device=self.vec.device).contiguous()
         obs, rew, done, info = self.vec.step(a)
-        boundary = bool(done[0].item())
-        # at the boundary vec.obs already holds the first observation of the new episode; RLlib wants the terminal one here
-        last = (self.vec.terminal_obs if boundary else obs).cpu().numpy().astype(np.float64)
-        self._obs = obs.cpu().numpy().astype(np.float64)
-        info_h = info.cpu().numpy()
-        infos = [dict(self._info_static, total_force_on_human=float(info_h[i, 0]), task_success=int(info_h[i, 1])) for i in range(self.num_envs)]
-        return list(last), list(rew.cpu().numpy().astype(np.float64)), [bool(d) for d in done.cpu().numpy()], infos
+        # ONE device-to-host transfer per step: observations (the terminal ones at an episode boundary, which RLlib wants here; vec.obs then
+        # already holds the first observation of the new episode), reward, done flags and the two info columns in a single pinned buffer
+        boundary = self.vec._t % self.vec.episode_len == 0
+        last = self.vec.terminal_obs if boundary else obs
+        n, od = self.num_envs, last.shape[1]
+        if self._host is None:
+            self._pack = torch.empty((n, od + 4), dtype=torch.float32, device=self.vec.device)
+            self._host = torch.empty((n, od + 4), dtype=torch.float32, pin_memory=True)
+        self._pack[:, :od] = last; self._pack[:, od] = rew; self._pack[:, od + 1] = done.float(); self._pack[:, od + 2:od + 4] = info[:, 0:2]
+        self._host.copy_(self._pack, non_blocking=True)
+        torch.cuda.current_stream(self.vec.device).synchronize()
+        h = self._host.numpy()
+        self._obs = obs.cpu().numpy().astype(np.float64) if boundary else h[:, :od].astype(np.float64)
+        obs64 = h[:, :od].astype(np.float64)
+        return list(obs64), h[:, od].astype(np.float64).tolist(), (h[:, od + 1] != 0).tolist(), _LazyInfos(self._info_static, h[:, od + 2].copy(), h[:, od + 3].copy())
 
     def get_unwrapped(self):
         return []

@@ -15,7 +15,7 @@ from .shard import episode_seed, pool_indices
 SETTLE_STEPS = 25   # feeding.py:178-179
 
 
-def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device'):
+def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device', _depth=0):
     """pool_size post-reset states: FeedingEnv.reset's sampling (sampler 'device': agx_sample_reset on the GPU;
     'host': the numpy path of host/reset.py), then the 25 settle steps of feeding.py:178-179 on the device.
     BedBathingSawyer: BedBathingEnv.reset restated on the host (host/reset_bed.py) around the rag-doll settle on the device.
@@ -72,6 +72,14 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     st.synchronize()
     out = st.get_state()
     st.close()
+    # A sampled start whose arm pose the IK restarts left deep inside the table or the bowl is pushed out by the contact rows with whatever
+    # velocity closes the gap in one substep (no penetration-recovery clamp as in Bullet's split impulse): a few in a thousand blow up during
+    # the settle.  Such entries never enter a pool: they are drawn again from the seeds after this batch's.
+    bad = ~np.isfinite(out).all(axis=1)
+    if bad.any() and _depth < 4:
+        out[bad] = build_reset_pool(blob, int(bad.sum()), seed + pool_size, device, impairment, sampler, _depth + 1)
+    elif bad.any():
+        raise RuntimeError('%d of %d sampled reset states are not finite after the settle (seed %d)' % (bad.sum(), pool_size, seed))
     return out
 
 

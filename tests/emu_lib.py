@@ -16,6 +16,7 @@ VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BL
 
 VARIANT_DEFS[3] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=3']      # dressing (rigid scene; the cloth kernel is a workgroup kernel)
 VARIANT_DEFS[4] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=4']      # arm manipulation
+VARIANT_DEFS['feeding_cap'] = ['-DAGX_P4_WINDOW_CAP=100']      # the packed solver with a small LDS window: its rows-beyond-the-window path on ordinary scenes
 VARIANT_DEFS['feeding_l'] = ['-DAGX_MAX_COLL=320', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040']
 VARIANT_DEFS['dressing_l'] = ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=3']
 VARIANT_DEFS['arm_l'] = ['-DAGX_MAX_DOF=32', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=22', '-DAGX_ARENA_WORDS=7552', '-DAGX_TASK=4']
@@ -50,9 +51,9 @@ def _p(a):
 
 
 class Emu:
-    def __init__(self, blob):
+    def __init__(self, blob, kind=None):
         self.blob = blob
-        self.L = lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
+        self.L = lib(kind) if kind is not None else lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
         self.words = np.ascontiguousarray(blob.words)
         lay = (C.c_int * 8)()
         self.L.agx_emu_debug_layout(lay)
@@ -74,6 +75,12 @@ class Emu:
 
     def settle(self, state, n, debug=False):
         return self._run(state, None, 1, n, debug)[4]
+
+    def settle_packed(self, states, n):
+        """the packed solve kernel (csrc/agx_pgs4.h) with up to four environments in one wavefront: `states` (k, state_words), in place"""
+        assert states.flags.c_contiguous and states.dtype == np.float32 and 1 <= len(states) <= 4
+        rc = self.L.agx_emu_settle_packed(_p(self.words), _p(states), C.c_int(len(states)), C.c_int(n))
+        assert rc == 0, 'wave emulator reported divergent control flow (or the variant has no packed kernel)'
 
     def sample(self, seed, impairment_mode=-1, gender_mode=-1):
         """device-side reset generator (csrc/agx_reset.h) for one env -> (state record, info[4])"""

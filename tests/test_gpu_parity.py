@@ -394,3 +394,38 @@ def test_nonfinite_environment_is_flagged_masked_and_replaced(gpu_lib, blob):
     torch.cuda.synchronize()
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and not (info[:, 6] >= 1.0e6).any() and np.isfinite(env.stepper.get_state()[:, :42]).all()
     env.close()
+
+
+def test_oracle_parity_at_bench_size(gpu_lib, blob, oracle):
+    """The BASELINE configuration itself (4096 environments in one handle: three chunks on internal streams, the packed solve kernel
+    with four environments per wavefront) against the oracle: after 40 random-policy steps, one more step from the states as they
+    are; 64 of the 4096 environments, spread over the chunks and over all four lane groups, are compared one by one"""
+    import torch
+    from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+    n = 4096
+    env = FeedingJacoVecEnv(n, pool_size=64, seed=2002)
+    env.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for k in range(40):
+        env.step(torch.rand((n, blob.act_dim), device='cuda', generator=g) * 2 - 1)
+    torch.cuda.synchronize()
+    before = env.stepper.get_state()
+    a = torch.rand((n, blob.act_dim), device='cuda', generator=g) * 2 - 1
+    obs, rew, done, info = env.step(a)
+    torch.cuda.synchronize()
+    obs, rew, info, a = obs.cpu().numpy(), rew.cpu().numpy(), info.cpu().numpy(), a.cpu().numpy()
+    worst = dict(obs=0.0, reward=0.0, force=0.0)
+    flips = 0
+    picks = [(i * 67 + (i % 4)) % n for i in range(64)]
+    assert len({p % 4 for p in picks}) == 4 and min(picks) < 1365 < max(picks)
+    for i in picks:
+        s = before[i].copy()
+        o_obs, o_rew, o_done, o_info = oracle.step(s, a[i])
+        if info[i, 6] != o_info[6]:
+            flips += 1; continue                          # a borderline contact candidate decided differently in f32 and f64
+        worst['obs'] = max(worst['obs'], float(np.abs(obs[i] - o_obs).max()))
+        worst['reward'] = max(worst['reward'], abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
+        worst['force'] = max(worst['force'], abs(float(info[i, 0]) - float(o_info[0])) / max(1.0, abs(float(o_info[0]))))
+    print('bench-size parity:', worst, 'contact-count flips', flips, 'of 64')
+    assert flips <= 4 and worst['obs'] < 1e-4 and worst['reward'] < 1e-4 and worst['force'] < 1e-3
+    env.close()
