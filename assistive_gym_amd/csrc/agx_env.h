@@ -350,9 +350,12 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
   build_rows(c); AGX_TICK(4)
-  if (USE_SOLVE4 && lane < c.nfree) {      // what the packed solve kernel needs to form B = M^-1 J of a free body from J: 1/m and the world inverse inertia
-    float* o = gscratch + SCR_O_BRF + BRF_WORDS * lane; const float* Ii = L + L_FIINV + 9 * lane; const float mass = FBF(c, lane, AGX_F_MASS);
-    o[0] = mass > 0.f ? 1.0f / mass : 0.f; o[1] = Ii[0]; o[2] = Ii[1]; o[3] = Ii[2]; o[4] = Ii[4]; o[5] = Ii[5]; o[6] = Ii[8]; o[7] = 0.f;
+  if (USE_SOLVE4 && lane < c.nfree) {      // S = (M^-1)^(1/2) of a free body, for the packed solve kernel's epilogue: sqrt(1/m), R sqrt(I_body^-1) R^T
+    float* o = gscratch + SCR_O_BRF + BRF_WORDS * lane; const float mass = FBF(c, lane, AGX_F_MASS);
+    m3 R = ldm3(L + L_FREER + 9 * lane), Ds; for (int k = 0; k < 9; k++) Ds.a[k] = 0;
+    for (int k = 0; k < 3; k++) { float I = FBF(c, lane, AGX_F_INERTIA + k); Ds.a[4 * k] = I > 0 ? sqrtf(1.0f / I) : 0.0f; }
+    m3 S = mul_bt(mul(R, Ds), R);
+    o[0] = mass > 0.f ? sqrtf(1.0f / mass) : 0.f; o[1] = S.a[0]; o[2] = S.a[1]; o[3] = S.a[2]; o[4] = S.a[4]; o[5] = S.a[5]; o[6] = S.a[8]; o[7] = 0.f;
   }
 #undef AGX_TICK
   // hand-over to the solve kernel

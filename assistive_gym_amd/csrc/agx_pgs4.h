@@ -49,8 +49,9 @@ static_assert(L_VEL + 128 <= P4_DV && MAX_ROWS <= 255, "the epilogue's single-en
 
 AGX_DEV void solve_tail(Ctx& c, float* gstate, Scratch& scr, int sw, int phase, float dv0, float dv1);
 
-// One look-ahead slot of the pipeline: J[6] of this lane's block and B[6] (articulated blocks; zero for a free body, whose B is formed
-// from J); `far`: the units lie beyond the LDS window (then at unit index `unit` of the scratch record)
+// One look-ahead slot of the pipeline: J[6] of this lane's block and B[6]; for a free body's lane both are its single unit S J (agx_ctx.h:
+// in the scaled velocity S^-1 v of a free body, S = (M^-1)^(1/2), the row's B IS its J).  `far`: the units lie beyond the LDS window
+// (then at unit index `unit` of the scratch record)
 struct P4Ent { f2 j0, j1, j2, b0, b1, b2; int unit; bool far; };
 // what a lane needs to find its units of a row: its nibble word and the first-unit word of the row's header (agx_ctx.h)
 struct P4Na { uint32_t x, y; };
@@ -69,7 +70,7 @@ AGX_DEV void p4_load(P4Na na, bool on, int j, int wunits, const float* ENT, cons
   const int unit = (int)(eoffw & 0xffffu) + nib - 1;
   const bool has = on & (nib != 0), inwin = unit + (isart ? 1 : 0) < wunits;
   const float* pj = (has & inwin) ? ENT + BRU_WORDS * unit : ZERO;
-  const float* pb = (has & inwin & isart) ? ENT + BRU_WORDS * unit + BRU_WORDS : ZERO;
+  const float* pb = isart ? pj + BRU_WORDS : pj;                     // (ZERO is two units long)
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef float p4_v2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(3))) p4_v2* p4_lp;
@@ -88,7 +89,8 @@ AGX_DEV void p4_fix(P4Ent& E, const float* BE, int j) {
     if (E.far) {
       const f2* q = (const f2*)(BE + BRU_WORDS * E.unit);
       E.j0 = q[0]; E.j1 = q[1]; E.j2 = q[2];
-      if (j < NB_ART) { E.b0 = q[3]; E.b1 = q[4]; E.b2 = q[5]; }
+      const f2* qb = j < NB_ART ? q + 3 : q;
+      E.b0 = qb[0]; E.b1 = qb[1]; E.b2 = qb[2];
     }
   }
 }
@@ -126,11 +128,11 @@ AGX_DEV void env_solve4(const uint32_t* blob, float* gstate_all, float* gscratch
     const uint32_t m = g16_ballot(r < R && end > wunits, g);
     if (m && rfar == R) rfar = base + __builtin_ctz(m);
   }
-  // inverse mass and world inverse inertia of this lane's free body (B = M^-1 J of its rows is formed from J); zero in the other lanes
-  float im = 0.f, ixx = 0.f, ixy = 0.f, ixz = 0.f, iyy = 0.f, iyz = 0.f, izz = 0.f;
+  // S = (M^-1)^(1/2) of this lane's free body: its velocity delta is kept as S^-1 dv until the epilogue
+  float sm = 0.f, sxx = 0.f, sxy = 0.f, sxz = 0.f, syy = 0.f, syz = 0.f, szz = 0.f;
   if (j >= NB_ART && j - NB_ART < bi[AGX_H_NFREE]) {
     const float* F = scrb + SCR_O_BRF + BRF_WORDS * (j - NB_ART);
-    im = F[0]; ixx = F[1]; ixy = F[2]; ixz = F[3]; iyy = F[4]; iyz = F[5]; izz = F[6];
+    sm = F[0]; sxx = F[1]; sxy = F[2]; sxz = F[3]; syy = F[4]; syz = F[5]; szz = F[6];
   }
   float dv0 = 0.f, dv1 = 0.f, dv2 = 0.f, dv3 = 0.f, dv4 = 0.f, dv5 = 0.f;
   const int iters = (int)bf[bi[AGX_H_OFF_PARAMS] + AGX_P_NITER], K = (int)bf[bi[AGX_H_OFF_PARAMS] + AGX_P_NOOP_RETEST];
@@ -179,25 +181,23 @@ AGX_DEV void env_solve4(const uint32_t* blob, float* gstate_all, float* gscratch
       p4_load(p4_na(HDR, rq1 & 255, j), 1 < len, j, wunits, ENT, ZERO, EB);
       P4Na na2 = p4_na(HDR, rq2 & 255, j);
       f2 Hc01 = *(const f2*)(HDR + BRH_WORDS * (rq0 & 255) + BRH_INVD); float Hcb = HDR[BRH_WORDS * (rq0 & 255) + BRH_BOUND];      // (1/D, b), bound
+      float lamP = LAM[rq0 & 255], lamnP = LAM[(rq0 >> 8) == BR_CLASS_FRIC ? (rq0 & 255) - nc : (rq0 & 255)];
       int t = 0;
 #define P4_STEP(ECUR, ENEW, FIX) { \
         const bool on = t < len; \
         const int r = rq0 & 255, cls = rq0 >> 8; \
         if (FIX) p4_fix(ECUR, BE, j); \
-        /* the impulses first: LDS answers in order, so the look-ahead reads below may still be in flight when these two are waited for. */ \
-        /* Every lane reads them BEFORE the cross-lane sum: lane 0 of the group rewrites LAM[r] below (lock step on the GPU; on the fibre */ \
-        /* emulator the sum is the rendezvous that orders these reads before that write) */ \
-        const float lam = LAM[r]; \
-        const float lamn = LAM[cls == BR_CLASS_FRIC ? r - nc : r]; \
+        /* the impulses of step t + 1 (never the row this step rewrites).  Every lane reads them BEFORE the cross-lane sum: lane 0 of the */ \
+        /* group writes LAM[r] below (lock step on the GPU; on the fibre emulator the sum is the rendezvous that orders reads and write) */ \
+        const float lam = lamP, lamn = lamnP; \
+        { const int r1 = rq1 & 255; lamP = LAM[r1]; lamnP = LAM[(rq1 >> 8) == BR_CLASS_FRIC ? r1 - nc : r1]; } \
         wave_fence(); \
         const int rn = LP[t + 4]; \
         const P4Na na3 = p4_na(HDR, rq3 & 255, j); \
         p4_load(na2, t + 2 < len, j, wunits, ENT, ZERO, ENEW); \
         const f2 Hn01 = *(const f2*)(HDR + BRH_WORDS * (rq1 & 255) + BRH_INVD); const float Hnb = HDR[BRH_WORDS * (rq1 & 255) + BRH_BOUND]; \
         const float J0 = ECUR.j0.x, J1 = ECUR.j0.y, J2 = ECUR.j1.x, J3 = ECUR.j1.y, J4 = ECUR.j2.x, J5 = ECUR.j2.y; \
-        /* B = the stored M^-1 J of an articulated block (im = I = 0 in those lanes) or M^-1 J of this lane's free body (stored part 0) */ \
-        const float B0 = im * J0 + ECUR.b0.x, B1 = im * J1 + ECUR.b0.y, B2 = im * J2 + ECUR.b1.x; \
-        const float B3 = ixx * J3 + (ixy * J4 + (ixz * J5 + ECUR.b1.y)), B4 = ixy * J3 + (iyy * J4 + (iyz * J5 + ECUR.b2.x)), B5 = ixz * J3 + (iyz * J4 + (izz * J5 + ECUR.b2.y)); \
+        const float B0 = ECUR.b0.x, B1 = ECUR.b0.y, B2 = ECUR.b1.x, B3 = ECUR.b1.y, B4 = ECUR.b2.x, B5 = ECUR.b2.y; \
         const float x = ((J0 * dv0 + J1 * dv1) + (J2 * dv2 + J3 * dv3)) + (J4 * dv4 + J5 * dv5); \
         const float jdv = g16_sum(x); \
         const float hi = cls == BR_CLASS_SYM ? Hcb : (cls == BR_CLASS_POS ? 1e30f : Hcb * lamn), lo = cls == BR_CLASS_POS ? 0.f : -hi; \
@@ -231,7 +231,11 @@ AGX_DEV void env_solve4(const uint32_t* blob, float* gstate_all, float* gscratch
     float* DV = lds + P4_DV + 128 * g;
     for (int k = j; k < 128; k += 16) DV[k] = 0.f;
     wave_sync();
-    const float dv[6] = {dv0, dv1, dv2, dv3, dv4, dv5};
+    float dv[6] = {dv0, dv1, dv2, dv3, dv4, dv5};
+    if (j >= NB_ART) {       // a free body: back from the scaled velocity
+      dv[0] = sm * dv0; dv[1] = sm * dv1; dv[2] = sm * dv2;
+      dv[3] = sxx * dv3 + sxy * dv4 + sxz * dv5; dv[4] = sxy * dv3 + syy * dv4 + syz * dv5; dv[5] = sxz * dv3 + syz * dv4 + szz * dv5;
+    }
     for (int s = 0; s < 6; s++) {
       int d = -1;
       if (j < NB_ART) { if (6 * j + s < ndof) d = 6 * j + s; }

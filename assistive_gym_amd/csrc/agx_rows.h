@@ -86,7 +86,13 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
     if (na == 0 && nb == 0 && !art) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
     if (USE_SOLVE4) {
-      for (int k = 0; k < 6; k++) BEr[BRU_WORDS * be + k] = J[k];
+      // the unit of a free body is S J with S = (M^-1)^(1/2) = (sqrt(1/m), R sqrt(I_body^-1) R^T): in the scaled velocity S^-1 v the row's
+      // B equals its J, so the packed solver reads one unit where it would need two (or nine multiply-adds per visit)
+      const m3 Rf = ldm3(L + L_FREER + 9 * fb); const float sm = sqrtf(im);
+      v3 jb = tmul(Rf, mk3(J[3], J[4], J[5]));
+      float si[3]; for (int k = 0; k < 3; k++) { const float I = FBF(c, fb, AGX_F_INERTIA + k); si[k] = I > 0 ? sqrtf(1.0f / I) : 0.0f; }
+      v3 ja = mul(Rf, mk3(si[0] * jb.x, si[1] * jb.y, si[2] * jb.z));
+      float* o = BEr + BRU_WORDS * be; o[0] = sm * J[0]; o[1] = sm * J[1]; o[2] = sm * J[2]; o[3] = ja.x; o[4] = ja.y; o[5] = ja.z;
       nib |= (uint64_t)(be + 1) << (4 * (NB_ART + fb));
       be++;
     }
