@@ -122,10 +122,13 @@ constexpr int SCR_O_QPT = SCR_O_META + SCR_META;
 // finds its coefficients with a shift and an add; lanes 0..7 read words (0, 1), lanes 8..15 words (1, 2).  Class 0: -bound <= lambda <=
 // bound (motors, tool rows), 1: 0 <= lambda (limits, contact normals), 2: |lambda| <= bound x lambda of the contact's normal row
 // (friction, bound = mu).
+// Opt-in build (-DAGX_USE_SOLVE4=1, feeding variants): measured on MI355X the packed kernel executes 0.6x the instructions of the
+// one-wave-per-environment kernel but, held to one wavefront per SIMD by its 40 KB of LDS, issues only 64 % of the time -- 1.24 ms
+// against 1.14 ms per 4096-environment launch (profiles/r03/solve_kernels_sq_counters.md).  The product solves with agx_pgs.h.
 #ifndef AGX_USE_SOLVE4
-#define AGX_USE_SOLVE4 (AGX_TASK == 0)
+#define AGX_USE_SOLVE4 0
 #endif
-constexpr bool USE_SOLVE4 = AGX_USE_SOLVE4;
+constexpr bool USE_SOLVE4 = AGX_USE_SOLVE4 && AGX_TASK == 0;
 constexpr int NB_ART = (MAX_DOF + 5) / 6, NB = NB_ART + MAX_FREE;
 static_assert(!USE_SOLVE4 || (NB <= 16 && 2 * NB_ART + 2 <= 15), "one lane of a 16-lane group per velocity block; unit offsets inside a row are nibbles");
 constexpr int BRH_WORDS = 6, BRU_WORDS = 6;

@@ -16,7 +16,8 @@ VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BL
 
 VARIANT_DEFS[3] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=3']      # dressing (rigid scene; the cloth kernel is a workgroup kernel)
 VARIANT_DEFS[4] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=4']      # arm manipulation
-VARIANT_DEFS['feeding_cap'] = ['-DAGX_P4_WINDOW_CAP=100']      # the packed solver with a small LDS window: its rows-beyond-the-window path on ordinary scenes
+VARIANT_DEFS['feeding_packed'] = ['-DAGX_USE_SOLVE4=1']       # the opt-in packed solve kernel (csrc/agx_pgs4.h)
+VARIANT_DEFS['feeding_cap'] = ['-DAGX_USE_SOLVE4=1', '-DAGX_P4_WINDOW_CAP=100']      # the packed solver with a small LDS window: its rows-beyond-the-window path on ordinary scenes
 VARIANT_DEFS['feeding_l'] = ['-DAGX_MAX_COLL=320', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040']
 VARIANT_DEFS['dressing_l'] = ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=3']
 VARIANT_DEFS['arm_l'] = ['-DAGX_MAX_DOF=32', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=22', '-DAGX_ARENA_WORDS=7552', '-DAGX_TASK=4']

@@ -322,10 +322,10 @@ def test_nonfinite_state_is_flagged_and_masked(blob, emu):
 
 
 def test_packed_solver_with_all_groups_at_work(blob, oracle):
-    """csrc/agx_pgs4.h: four environments share a wavefront, each on its own 16-lane group with its own visit list.  Three environments with
+    """csrc/agx_pgs4.h (opt-in build, -DAGX_USE_SOLVE4=1): four environments share a wavefront, each on its own 16-lane group with its own visit list.  Three environments with
     different row counts in one wave: bitwise what the same kernel gives for each of them alone (group 0), and the oracle's result."""
     from emu_lib import Emu
-    e = Emu(blob)
+    e = Emu(blob, kind='feeding_packed')
     st, _ = make_states(blob, 3, seed=4001)
     for i in range(3):
         oracle.settle(st[i], 8 * (i + 1))                       # the food has fallen further in each: different contact sets per group
@@ -344,7 +344,7 @@ def test_packed_solver_rows_beyond_the_lds_window(blob, oracle):
     """units that do not fit the group's LDS window are read from the scratch record: a build with a 100-unit window (an ordinary scene at
     rest has 260) against the oracle and, bitwise, against the full-window build"""
     from emu_lib import Emu
-    full, cap = Emu(blob), Emu(blob, kind='feeding_cap')
+    full, cap = Emu(blob, kind='feeding_packed'), Emu(blob, kind='feeding_cap')
     st, _ = make_states(blob, 1, seed=3001)
     s = st[0]
     oracle.settle(s, 20)

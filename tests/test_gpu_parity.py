@@ -397,9 +397,8 @@ def test_nonfinite_environment_is_flagged_masked_and_replaced(gpu_lib, blob):
 
 
 def test_oracle_parity_at_bench_size(gpu_lib, blob, oracle):
-    """The BASELINE configuration itself (4096 environments in one handle: three chunks on internal streams, the packed solve kernel
-    with four environments per wavefront) against the oracle: after 40 random-policy steps, one more step from the states as they
-    are; 64 of the 4096 environments, spread over the chunks and over all four lane groups, are compared one by one"""
+    """The BASELINE configuration itself (4096 environments in one handle: three chunks on internal streams) against the oracle: after 40 random-policy steps, one more step from the states as they
+    are; 64 of the 4096 environments, spread over the chunks, are compared one by one"""
     import torch
     from assistive_gym_amd.vec_env import FeedingJacoVecEnv
     n = 4096

@@ -1,4 +1,5 @@
-"""GPU diagnostic: the packed solve kernel (agx_pgs4.h) against the one-wave-per-environment kernel (AGX_SOLVE=old) on the same states.
+"""GPU diagnostic: the packed solve kernel (agx_pgs4.h; an opt-in build: python -m assistive_gym_amd.build --extra "-DAGX_USE_SOLVE4=1" --out
+assistive_gym_amd/lib/libagx_packed.so, then AGX_LIB=<that file>) against the one-wave-per-environment kernel (AGX_SOLVE=old) on the same states.
   python tools/gpu_p4_diag.py [model] [n] [steps]      -> prints deviations, saves offending input states under gpurun_out/p4_diag/"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 3: quick A/B of the packed solve kernel against the one-wave-per-environment kernel (AGX_SOLVE=old), feeding headline workload
 set -u
+# (the packed kernel is an opt-in build since: AGX_LIB=assistive_gym_amd/lib/libagx_packed.so, see tools/gpu_p4_diag.py)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-r03f}
 rm -rf $O && mkdir -p $O

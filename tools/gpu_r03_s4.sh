@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 3, GPU session 4: packed solve kernel v4 (nibble headers, LDS-only look-ahead): diagnostics against AGX_SOLVE=old, A/B, trace
 set -u
+# (the packed kernel is an opt-in build since: AGX_LIB=assistive_gym_amd/lib/libagx_packed.so, see tools/gpu_p4_diag.py)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03e
 rm -rf $O && mkdir -p $O
