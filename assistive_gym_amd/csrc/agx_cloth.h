@@ -6,7 +6,8 @@
 // bodies where each substep starts -- the build kernel leaves the world frames of the moving links of every substep in the
 // per-environment trace -- and the rigid bodies do not feel the cloth.  The rigid substeps of an env step therefore all run
 // first, then this kernel replays their poses: x and q are read from and written to HBM once per env step (95 KB each way)
-// instead of once per substep.
+// instead of once per substep.  In between, the record in HBM is scratch: during the last substep every contact sums its impulses
+// there (slot node x contact; only the thread that owns the node touches it) -- 43 KB that used to sit in LDS.
 //
 // Per substep: (a) body frames, shape boxes (world AABB grown by the margin) and the attachment point into LDS; the shapes whose
 // box meets the cloth's bounding box form the candidate list, in shape order; (b) per node: normal from the incident faces,
@@ -23,8 +24,8 @@ namespace agxc {
 constexpr int T = AGX_CLOTH_THREADS;
 constexpr int NPT = 4096 / T;              // nodes per thread (garments of up to 4,096 nodes)
 constexpr int LPT = 1024 / T;              // links per thread and colour class (classes hold at most 1,024 links)
-constexpr int IMP_SLOTS = 3584;           // contacts of the last substep whose impulses are summed for the report (LDS)
 constexpr int NODE_CONTACTS = 2;          // AGX_CLOTH_NODE_CONTACTS: contacts kept per node (the first ones in shape order)
+static_assert(NODE_CONTACTS == 2, "the impulse sums of the last substep use the garment record (2 x NN x 3 floats) as scratch");
 constexpr int MAX_BODIES = 64, MAX_SHAPES = 192;
 constexpr float EPS = 1.1920929e-7f;      // SIMD_EPSILON
 
@@ -55,11 +56,10 @@ struct Lds {
   int* cand; int* ncand;         // candidate shapes of this substep, in shape order
   float* red;                    // [16 waves][6] bounding-box reduction
   float* anchor;                 // [3]
-  float* imp; int* nimp;         // [IMP_SLOTS][3] summed contact impulses of the last substep, allocation counter
   float* shape;                  // [MAX_SHAPES][12]: body slot (int), face planes (int count, int first), radius, core vertex 0 (3), core vertex 1 (3), kDF x friction, unused
 };
 constexpr int SHAPE_WORDS = 12;
-constexpr int lds_words(int nn) { return 6 * nn + 12 * MAX_BODIES + 6 * MAX_SHAPES + MAX_SHAPES + 4 + 6 * (T / 64) + 4 + SHAPE_WORDS * MAX_SHAPES + 3 * IMP_SLOTS + 4; }
+constexpr int lds_words(int nn) { return 6 * nn + 12 * MAX_BODIES + 6 * MAX_SHAPES + MAX_SHAPES + 4 + 6 * (T / 64) + 4 + SHAPE_WORDS * MAX_SHAPES; }
 
 __device__ inline int body_slot(int code, int ndof, int nhuman) {
   if (code == AGX_BODY_WORLD) return ndof + 1 + nhuman;
@@ -92,7 +92,7 @@ __device__ inline float shape_distance(const float* clf, const int* cl, const Ld
   return dist;
 }
 
-struct Contact { f3 n; float offset, c3; int slot; };   // slot: impulse accumulator in LDS (last substep only), -1 = none
+struct Contact { f3 n; float offset, c3; bool rep; };   // rep: a contact of the last substep, whose impulses are summed for the report
 
 // one env step of the garment: `nsub` internal substeps, substep k reading the link frames of trace slot k.
 // gcloth: float[2][NN][3] positions then velocities (in/out); greport: see agx_blob.h AGX_CLOTH_REPORT (written after the last substep)
@@ -110,7 +110,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   const int gender = ((const int*)gstate)[s_env + AGX_E_GENDER];
   const float grav = gstate[s_task + AGX_DR_CLOTH_GRAVITY];
   Lds S; S.x = lds; S.q = S.x + 3 * NN; S.body = S.q + 3 * NN; S.box = S.body + 12 * MAX_BODIES; S.cand = (int*)(S.box + 6 * MAX_SHAPES);
-  S.ncand = S.cand + MAX_SHAPES; S.red = (float*)(S.ncand + 4); S.anchor = S.red + 6 * (T / 64); S.shape = S.anchor + 4; S.imp = S.shape + SHAPE_WORDS * MAX_SHAPES; S.nimp = (int*)(S.imp + 3 * IMP_SLOTS);
+  S.ncand = S.cand + MAX_SHAPES; S.red = (float*)(S.ncand + 4); S.anchor = S.red + 6 * (T / 64); S.shape = S.anchor + 4;
   const int* nodei = cl + cl[AGX_CL_OFF_NODE]; const float* nodef = clf + cl[AGX_CL_OFF_NODE];
   const int* face = cl + cl[AGX_CL_OFF_FACE];
   const int* anci = cl + cl[AGX_CL_OFF_ANCHOR]; const float* ancf = clf + cl[AGX_CL_OFF_ANCHOR];
@@ -146,7 +146,6 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     const float* tr = gtrace + (size_t)sub * ndof * 12;
     for (int k = tid; k < 12 * ndof; k += T) S.body[k] = tr[k];
     __syncthreads();
-    if (tid == 0) *S.nimp = 0;
     if (sub % S_ == 0 && tid == 0) {     // end-effector frame origin = link frame * EE_POS (dressing.py:200-210)
       const int ot = bi[AGX_H_OFF_TASK]; const float* B = S.body + 12 * bi[ot + AGX_T_EE_LINK];
       st(S.anchor, ld(B) + rot(B + 3, ld(bf + ot + AGX_T_EE_POS)));
@@ -257,8 +256,8 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
         f3 nw; const float dst = shape_distance(clf, cl, S, sh, xi, nw) - mrg;
         if (dst >= 0.f) continue;
         Contact c;
-        c.n = nw; c.offset = -dot(nw, xi) + dst; c.slot = -1;
-        if (sub == nsub - 1) { const int sl = atomicAdd(S.nimp, 1); if (sl < IMP_SLOTS) { c.slot = sl; st(S.imp + 3 * sl, mk(0.f, 0.f, 0.f)); } }
+        c.n = nw; c.offset = -dot(nw, xi) + dst; c.rep = sub == nsub - 1;
+        if (c.rep) st(gcloth + 3 * (NODE_CONTACTS * own[j] + ncon[j]), mk(0.f, 0.f, 0.f));
         const f3 vr = xi - qs[j]; const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
         const float fc = S.shape[SHAPE_WORDS * sh + 10];
         c.c3 = dot(fv, fv) < (dn * fc * dn * fc) ? 0.f : 1.f - fc;
@@ -286,7 +285,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
               float dp = dot(xi, c.n) + c.offset; if (dp > mrg) dp = mrg;
               const f3 fv = vr - dn * c.n, corr = vr - c.c3 * fv + (dp * kCHR) * c.n;
               xi = xi - corr;
-              if (c.slot >= 0) { float* o = S.imp + 3 * c.slot; const float w = 1.0f / (dt * im); o[0] += w * corr.x; o[1] += w * corr.y; o[2] += w * corr.z; }
+              if (c.rep) { float* o = gcloth + 3 * (NODE_CONTACTS * i + cc); const float w = 1.0f / (dt * im); o[0] += w * corr.x; o[1] += w * corr.y; o[2] += w * corr.z; }
             }
           }
           st(S.x + 3 * i, xi);
@@ -314,9 +313,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
       }
     }
   }
-  // write back: positions, velocities of the last substep; report for the finish kernel
-  const float vc = (1.0f - kDP) / dt;
-  for (int k = tid; k < 3 * NN; k += T) { gcloth[k] = S.x[k]; gcloth[3 * NN + k] = (S.x[k] - S.q[k]) * vc; }
+  // report for the finish kernel, then write back the positions and the velocities of the last substep (over the impulse sums)
   if (greport) {
     if (tid < 6) st(greport + 3 * tid, ld(S.x + 3 * cl[AGX_CL_TRI + tid]));
 #pragma unroll
@@ -326,10 +323,13 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
 #pragma unroll
       for (int cc = 0; cc < NODE_CONTACTS; cc++) {
         float* o = greport + 20 + 2 * (NODE_CONTACTS * i + cc);
-        if (nsub > 0 && cc < ncon[j] && con[j][cc].slot >= 0) { const f3 f = (1.0f / dt) * ld(S.imp + 3 * con[j][cc].slot); o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
+        if (nsub > 0 && cc < ncon[j] && con[j][cc].rep) { const f3 f = (1.0f / dt) * ld(gcloth + 3 * (NODE_CONTACTS * i + cc)); o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
       }
     }
   }
+  __syncthreads();
+  const float vc = (1.0f - kDP) / dt;
+  for (int k = tid; k < 3 * NN; k += T) { gcloth[k] = S.x[k]; gcloth[3 * NN + k] = (S.x[k] - S.q[k]) * vc; }
 }
 
 }  // namespace agxc
