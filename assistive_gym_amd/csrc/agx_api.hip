@@ -176,7 +176,7 @@ static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_
     h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn);
     h->trace_words = h->frame_skip * h->sim_sub * hi[AGX_H_NDOF] * 12;
     h->cloth_lds = V->cloth_lds_bytes(h->cloth_nn);          // agxc::lds_words of the variant's own cloth kernel
-    if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4096 || cl[AGX_CL_NCOLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_MAX_LINKS_PER_COLOR] > 1024 ||
+    if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4096 || cl[AGX_CL_NCOLOR] - (AGX_CLOTH_THREADS / 64) * cl[AGX_CL_NPATCH_COLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_NPATCH_COLOR] < 0 || cl[AGX_CL_MAX_LINKS_PER_COLOR] > 1024 ||
         cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + 2 > 64 || cl[AGX_CL_NN] > 65535 || hi[AGX_H_NFREE] != 0) return fail(AGX_E_LIMIT, "agx_create: cloth exceeds the limits of the cloth kernel");
     HIPCHK(hipMalloc(&h->cloth_dev, (size_t)n_envs * h->cloth_words * 4)); HIPCHK(hipMemset(h->cloth_dev, 0, (size_t)n_envs * h->cloth_words * 4));
     HIPCHK(hipMalloc(&h->trace_dev, (size_t)n_envs * h->trace_words * 4)); HIPCHK(hipMemset(h->trace_dev, 0, (size_t)n_envs * h->trace_words * 4));

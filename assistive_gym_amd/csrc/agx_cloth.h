@@ -13,9 +13,9 @@
 // box meets the cloth's bounding box form the candidate list, in shape order; (b) per node: normal from the incident faces,
 // gravity, clamped aerodynamic drag, q = x, x += v dt; (c) per node: contacts with the candidate shapes (capsule / sphere cores
 // exactly, hulls through their face planes), at most AGX_CLOTH_NODE_CONTACTS per node, kept in registers -- a node's contacts
-// only move that node; (d) piterations x [anchors, rigid contacts, links colour class by colour class] with a workgroup barrier
-// between phases.  A thread owns nodes tid, tid + T, tid + 2T, ... and, per colour class, link number tid of that class (its
-// two node indices and rest length squared stay in registers for the whole launch).
+// only move that node; (d) piterations x [anchors | rigid contacts, the links inside each wave's patch (256 neighbouring nodes: 8 of 9
+// links) colour by colour without a workgroup barrier | the links between patches, one workgroup-wide colour class at a time].
+// A wave owns the nodes of its patch (AGX_CL_OFF_PERM, Morton order), lane l its l-th, (64 + l)-th, ...
 #pragma once
 #include "../../include/agx_blob.h"
 
@@ -100,7 +100,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   const int* bi = (const int*)blob; const float* bf = (const float*)blob;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int oc = bi[AGX_H_OFF_CLOTH]; const int* cl = bi + oc; const float* clf = bf + oc;
-  const int NN = cl[AGX_CL_NN], NCOL = cl[AGX_CL_NCOLOR], NA = cl[AGX_CL_NANCHOR], NS = cl[AGX_CL_NSHAPE];
+  const int NN = cl[AGX_CL_NN], NCOL = cl[AGX_CL_NCOLOR], NA = cl[AGX_CL_NANCHOR], NS = cl[AGX_CL_NSHAPE], KP = cl[AGX_CL_NPATCH_COLOR];
   const int ndof = bi[AGX_H_NDOF], nhuman = bi[AGX_H_NHUMAN], S_ = bi[AGX_H_SIM_SUBSTEPS] > 1 ? bi[AGX_H_SIM_SUBSTEPS] : 1;
   const float* par = clf + cl[AGX_CL_OFF_PARAM];
   const float dt = bf[bi[AGX_H_OFF_PARAMS] + AGX_P_DT] / (float)S_;
@@ -291,18 +291,39 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
           st(S.x + 3 * i, xi);
         }
       }
+      // PSolve_Links.  (1) The links inside this wave's patch, colour by colour, no workgroup barrier: patches share no node, the LDS
+      // executes a wave's accesses in order, and nothing but this wave has touched the patch since the anchors' barrier (a node's contacts
+      // move that node only).  Link table: class w KP + c = 64 slots, lane l relaxes slot l; streamed one class ahead.
+      {
+        const int2* pl = links + (size_t)wave * KP * 64 + lane;
+        int2 nx = KP > 0 ? pl[0] : make_int2(-1, 0);
+        for (int c = 0; c < KP; c++) {
+#ifdef AGXC_NO_LINKS
+          break;
+#endif
+          const int2 cur = nx;
+          if (c + 1 < KP) nx = pl[(c + 1) * 64];
+          if (cur.x >= 0) {
+            const int a = cur.x & 0xffff, b = (cur.x >> 16) & 0xffff;
+            const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur.y);
+            if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next class reads what this one wrote (other lanes of this wave)
+        }
+      }
       __syncthreads();
-      // PSolve_Links, one colour class at a time
+      // (2) the links between patches, one colour class at a time across the workgroup
+      const int* xcolor = color + (T / 64) * KP; const int NX = NCOL - (T / 64) * KP;
       int2 nxt[LPT];
 #pragma unroll
-      for (int u = 0; u < LPT; u++) { const int l = color[0] + tid + u * T; nxt[u] = l < color[1] ? links[l] : make_int2(-1, 0); }
-      for (int c = 0; c < NCOL; c++) {
+      for (int u = 0; u < LPT; u++) { const int l = xcolor[0] + tid + u * T; nxt[u] = (NX > 0 && l < xcolor[1]) ? links[l] : make_int2(-1, 0); }
+      for (int c = 0; c < NX; c++) {
 #ifdef AGXC_NO_LINKS
         break;
 #endif
         int2 cur[LPT];
 #pragma unroll
-        for (int u = 0; u < LPT; u++) { cur[u] = nxt[u]; if (c + 1 < NCOL) { const int l = color[c + 1] + tid + u * T; nxt[u] = l < color[c + 2] ? links[l] : make_int2(-1, 0); } }
+        for (int u = 0; u < LPT; u++) { cur[u] = nxt[u]; if (c + 1 < NX) { const int l = xcolor[c + 1] + tid + u * T; nxt[u] = l < xcolor[c + 2] ? links[l] : make_int2(-1, 0); } }
 #pragma unroll
         for (int u = 0; u < LPT; u++) if (cur[u].x >= 0) {
           const int a = cur[u].x & 0xffff, b = (cur[u].x >> 16) & 0xffff;

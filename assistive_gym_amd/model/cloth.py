@@ -64,6 +64,34 @@ def colour_links(links, n_nodes, cap):
     return np.array(cls), len(used)
 
 
+def colour_links_balanced(links, cap):
+    """the links of one patch in as few classes of at most `cap` links as a greedy search finds: for K = ceil(n / cap), K + 1, ... every
+    link (longest-waiting first: by the degree of its nodes) goes to the feasible class with the fewest links; the first K that places
+    all of them wins.  Returns (class of every link, K)."""
+    n = len(links)
+    if n == 0:
+        return np.zeros(0, dtype=int), 0
+    deg = {}
+    for a, b in links:
+        deg[a] = deg.get(a, 0) + 1; deg[b] = deg.get(b, 0) + 1
+    order = sorted(range(n), key=lambda k: -(deg[links[k][0]] + deg[links[k][1]]))
+    for K in range((n + cap - 1) // cap, n + 1):
+        used, cnt, cls, ok = [set() for _ in range(K)], [0] * K, [0] * n, True
+        for k in order:
+            a, b = links[k]
+            best = None
+            for c in range(K):
+                if cnt[c] < cap and a not in used[c] and b not in used[c] and (best is None or cnt[c] < cnt[best]):
+                    best = c
+            if best is None:
+                ok = False
+                break
+            used[best].update((a, b)); cnt[best] += 1; cls[k] = best
+        if ok:
+            return np.array(cls), K
+    raise AssertionError('unreachable')
+
+
 def bank_schedule(class_links, lanes=32, seeds=3):
     """Order of the links of ONE colour class for the cloth kernel (thread t relaxes slot t): x lives in LDS as float[NN][3], so the
     lanes of a 32-lane bank group read / write without conflict exactly when their node indices are distinct mod 32 (bank =
@@ -127,20 +155,50 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
     R = X.quat_to_mat(X.quat_from_rpy(rpy))
     x0 = scale * (v @ R.T + np.asarray(position))                    # see module docstring
     nn = len(x0)
-    links = mesh_links(faces)
-    cls, ncolor = colour_links(links, nn, 1024)                  # the cloth kernel holds 1,024 links of a class (1024 / threads per thread)
-    assert ncolor <= CLOTH_MAX_COLORS, ncolor
-    # within a class the order is free (no two links share a node): a bank-conflict-free schedule for the cloth kernel, with empty
-    # slots (None -> -1 in the table) where a 32-lane group cannot be filled without a conflict
-    links = [(min(a, b), max(a, b)) for a, b in links]
+    links = [(min(a, b), max(a, b)) for a, b in mesh_links(faces)]
+    # ownership order of the cloth kernel: Morton order of the rest positions (10 bits per axis); wave w owns 256 consecutive nodes of it
+    g = np.floor((x0 - x0.min(0)) / (np.ptp(x0, axis=0).max() + 1e-9) * 1023).astype(np.int64)
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(10):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+    morton = spread(g[:, 0]) | (spread(g[:, 1]) << 1) | (spread(g[:, 2]) << 2)
+    perm = np.full(4096, -1, dtype=np.int64)
+    perm[:nn] = np.argsort(morton, kind='stable')
+    assert nn <= 4096
+    # Link schedule.  A link whose two nodes belong to the same patch (the 256 nodes of a wave) is relaxed by that wave, colour by colour,
+    # with no workgroup barrier: patches share no node.  Only the links BETWEEN patches (a ninth of them) keep workgroup-wide classes.
+    # Within a class the order is free (no two links share a node): a bank-conflict-aware order for the cloth kernel (bank_schedule).
+    W = CLOTH_THREADS // 64
+    patch_of = np.full(nn, -1)
+    for w in range(W):
+        own = perm[w * (4096 // W):(w + 1) * (4096 // W)]
+        patch_of[own[own >= 0]] = w
+    inner = [[l for l in links if patch_of[l[0]] == w and patch_of[l[1]] == w] for w in range(W)]
+    cross = [l for l in links if patch_of[l[0]] != patch_of[l[1]]]
+    inner_cls = [colour_links_balanced(li, 64) for li in inner]
+    npatch_color = max(k for _, k in inner_cls)
     sched, color_off, bank_extra = [], [0], 0
-    for c in range(ncolor):
-        order_c, extra_c = bank_schedule(sorted(l for l, k in zip(links, cls) if k == c))
+    for w in range(W):
+        cls_w, _ = inner_cls[w]
+        for c in range(npatch_color):
+            order_c, extra_c = bank_schedule(sorted(l for l, k in zip(inner[w], cls_w) if k == c))
+            assert len(order_c) <= 64
+            sched += order_c + [None] * (64 - len(order_c)); bank_extra += extra_c
+            color_off.append(len(sched))
+    cls, ncross = colour_links(cross, nn, 1024)                  # the cloth kernel relaxes one link of a class per thread
+    assert ncross <= CLOTH_MAX_COLORS, ncross
+    for c in range(ncross):
+        order_c, extra_c = bank_schedule(sorted(l for l, k in zip(cross, cls) if k == c))
         sched += order_c; bank_extra += extra_c
         color_off.append(len(sched))
+    ncolor = W * npatch_color + ncross
     links = sched
     n_real = sum(1 for l in links if l is not None)
-    max_per = max(color_off[c + 1] - color_off[c] for c in range(ncolor))
+    assert n_real == len(inner[0]) + sum(len(t) for t in inner[1:]) + len(cross)
+    max_per = max([color_off[c + 1] - color_off[c] for c in range(W * npatch_color, ncolor)] + [0])
     assert max_per <= 1024
     rest2 = np.array([np.sum((x0[l[0]] - x0[l[1]]) ** 2) if l is not None else 0.0 for l in links])
     # incident faces per node, in face order, rotated so that the node comes first (same cross product)
@@ -156,18 +214,6 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
     area = np.where(cnt > 0, area_sum / np.maximum(cnt, 1), 0.0)
     node_first = np.concatenate([[0], np.cumsum([len(t) for t in inc])]).astype(np.int64)
     face_entries = np.array([e for t in inc for e in t], dtype=np.int64)
-    # ownership order of the cloth kernel: Morton order of the rest positions (10 bits per axis)
-    g = np.floor((x0 - x0.min(0)) / (np.ptp(x0, axis=0).max() + 1e-9) * 1023).astype(np.int64)
-
-    def spread(v):
-        out = np.zeros_like(v)
-        for b in range(10):
-            out |= ((v >> b) & 1) << (3 * b)
-        return out
-    morton = spread(g[:, 0]) | (spread(g[:, 1]) << 1) | (spread(g[:, 2]) << 2)
-    perm = np.full(4096, -1, dtype=np.int64)
-    perm[:nn] = np.argsort(morton, kind='stable')
-    assert nn <= 4096
     # rigid shapes: capsule / sphere cores are evaluated exactly, hulls through their face planes
     planes, shapes = [], []
     for ci in shape_ids:
@@ -194,6 +240,7 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
         i[CL['OFF_' + name]] = off[name]
     i[CL['TRI']:CL['TRI'] + 6] = list(tri1) + list(tri2)
     i[CL['MAX_LINKS_PER_COLOR']] = max_per
+    i[CL['NPATCH_COLOR']] = npatch_color
     i[off['PERM']:off['PERM'] + 4096] = perm
     i[off['COLOR']:off['COLOR'] + ncolor + 1] = color_off
     for k, l in enumerate(links):
@@ -214,5 +261,5 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
         if k != 'MASS':
             pv[CP[k]] = val
     pv[CP['NODE_IM']] = nn / params['MASS']                          # setTotalMass(mass, fromfaces=false): equal node masses
-    meta = dict(nodes=nn, links=n_real, link_slots=len(links), link_bank_extra_cycles=int(bank_extra), colors=ncolor, faces=len(faces), shapes=len(shapes), planes=len(planes), max_links_per_color=max_per)
+    meta = dict(nodes=nn, links=n_real, link_slots=len(links), link_bank_extra_cycles=int(bank_extra), colors=ncolor, patch_colors=npatch_color, cross_colors=ncross, cross_links=len(cross), faces=len(faces), shapes=len(shapes), planes=len(planes), max_links_per_color=max_per)
     return f.view(np.uint32).copy(), meta

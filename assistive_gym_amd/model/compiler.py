@@ -65,7 +65,7 @@ AM = dict(BEST=0, WORDS=12)   # arm manipulation task words (AGX_AM_*)
 DR = dict(CLOTH_GRAVITY=0, FORCE_SUM=1, BEST=2, WORDS=12)   # dressing task words (AGX_DR_*)
 # cloth section (AGX_CL_*, AGX_CP_*)
 CL = dict(NN=0, NL=1, NCOLOR=2, NANCHOR=3, NSHAPE=4, OFF_COLOR=5, OFF_LINK=6, OFF_NODE=7, OFF_FACE=8, OFF_X0=9, OFF_ANCHOR=10, OFF_SHAPE=11,
-          OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, OFF_PERM=21, HDR=24)
+          OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, OFF_PERM=21, NPATCH_COLOR=22, HDR=24)
 CP = dict(KLST=0, KDP=1, KDG=2, KDF=3, KCHR=4, KKHR=5, KAHR=6, PITER=7, MARGIN=8, NODE_IM=9, AIR_DENSITY=10, FORCE_SCALE=11, FORCE_MAX=12,
           EE_BELOW=13, COUNT=16)
 CLOTH_MAX_COLORS, CLOTH_THREADS, CLOTH_NODE_CONTACTS = 16, 1024, 2

@@ -338,7 +338,8 @@ enum { AGX_DR_CLOTH_GRAVITY = 0, /* float: world gravity z acting on the cloth: 
 enum {
   AGX_CL_NN = 0,         /* nodes: the OBJ's vertices in order of first appearance in its face list (tinyobj re-indexing)   */
   AGX_CL_NL = 1,         /* link SLOTS = unique mesh edges sorted by colour, plus empty slots (-1) of the bank schedule          */
-  AGX_CL_NCOLOR = 2,     /* colour classes: links of one class share no node and are relaxed in parallel; classes in order   */
+  AGX_CL_NCOLOR = 2,     /* colour classes: links of one class share no node and are relaxed in parallel; classes in order.  The first
+                            16 x NPATCH_COLOR classes are patch classes (below), the others hold the links between patches       */
   AGX_CL_NANCHOR = 3,
   AGX_CL_NSHAPE = 4,     /* rigid colliders the cloth is tested against                                                      */
   AGX_CL_OFF_COLOR = 5,  /* int[NCOLOR + 1] first link of every class                                                        */
@@ -353,9 +354,12 @@ enum {
   AGX_CL_OFF_PLANE = 12, /* float[planes][4]: outward unit normal and offset of the hull's faces in the body frame             */
   AGX_CL_TRI = 13,       /* int[6]: the two vertex triples around the opening of the left sleeve (dressing.py:156-157)         */
   AGX_CL_OFF_PARAM = 19, /* float[AGX_CP_COUNT]                                                                                */
-  AGX_CL_MAX_LINKS_PER_COLOR = 20, /* int: size of the largest class (<= 1,024: the cloth kernel keeps 1024 / threads links per thread)   */
+  AGX_CL_MAX_LINKS_PER_COLOR = 20, /* int: size of the largest class between patches (<= 1,024: one link per thread of the cloth kernel)   */
   AGX_CL_OFF_PERM = 21,  /* int[4096]: node owned by slot t of the cloth kernel (thread t % threads, t / threads-th node of that thread), -1 = none:
                             the nodes in Morton order of their rest positions, so that the 64 nodes of a wave lie close together    */
+  AGX_CL_NPATCH_COLOR = 22, /* K: the link table starts with 16 x K classes of exactly 64 slots, class w K + c = colour c of the links whose
+                            two nodes both belong to patch w (the 256 nodes that wave w of the cloth kernel owns, OFF_PERM): patches
+                            share no node, so a wave relaxes its K classes in order without waiting for any other wave            */
   AGX_CL_HDR = 24
 };
 enum {

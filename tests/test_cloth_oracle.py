@@ -201,7 +201,7 @@ def test_patch_on_the_forearm_matches_numpy(small):
     assert len(rep) >= 5 and len(con) == len(rep)
     assert np.abs(cloth[0] - xr).max() < 5e-6 and np.abs(cloth[1] - vr).max() < 2e-3
     want = np.array([np.concatenate(rep[i]) for i in sorted(rep)])
-    assert np.allclose(con[:, :3], want[:, :3], atol=5e-6) and np.allclose(con[:, 3:], want[:, 3:], rtol=2e-3, atol=1e-6)
+    assert np.allclose(con[:, :3], want[:, :3], atol=5e-6) and np.allclose(con[:, 3:], want[:, 3:], rtol=2e-3, atol=3e-5)      # forces of 0.4 ... 3 mN on this 1.2 g patch: sums of nearly cancelling corrections
 
 
 def _advance_rigid_one_substep(blob, oracle, s):

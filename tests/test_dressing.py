@@ -55,12 +55,26 @@ def test_model_header_and_cloth_section(dr):
     assert np.allclose(dr.task_f('ARM_RADIUS', 2), [0.043, 0.0355])                                         # human_creation.py:89,140
     assert dr.param('HUMAN_GRAVITY_Z') == -1.0 and dr.param('ROBOT_GRAVITY_Z') == 0.0                       # dressing.py:179-181
     t = cloth_tables(dr)
-    assert (t['nn'], t['nl']) == (3966, 11640) and t['ncol'] <= 16                                          # SURVEY: 3,966 vertices / 7,673 faces -> 11,640 edges
-    # a colour class never uses a node twice (its links can be relaxed in parallel), and no class is larger than the cloth kernel's thread count
+    real = t['a'] >= 0
+    assert t['nn'] == 3966 and real.sum() == 11640                                                          # SURVEY: 3,966 vertices / 7,673 faces -> 11,640 edges
+    # Link schedule (model/cloth.py): 16 x K patch classes of 64 slots -- the links inside the 256-node patch of each wave of the cloth kernel --
+    # then at most 16 workgroup-wide classes of the links between patches.  A class never uses a node twice (its links are relaxed in parallel);
+    # the patch classes of wave w use nodes of patch w only (they are relaxed without waiting for the other waves).
+    ci = dr.i[dr.h['OFF_CLOTH']:]
+    K = int(ci[L.CL['NPATCH_COLOR']])
+    perm = ci[ci[L.CL['OFF_PERM']]:ci[L.CL['OFF_PERM']] + 4096]
+    assert 11 <= K <= 13 and 0 < t['ncol'] - 16 * K <= 16
     for c in range(t['ncol']):
         sl = slice(t['color'][c], t['color'][c + 1])
-        nodes = np.concatenate([t['a'][sl], t['b'][sl]])
-        assert len(np.unique(nodes)) == len(nodes) and len(nodes) // 2 <= 1024
+        nodes = np.concatenate([t['a'][sl], t['b'][sl]]); nodes = nodes[nodes >= 0]
+        assert len(np.unique(nodes)) == len(nodes)
+        if c < 16 * K:
+            assert t['color'][c + 1] - t['color'][c] == 64 and set(nodes) <= set(perm[256 * (c // K):256 * (c // K + 1)])
+        else:
+            assert len(nodes) // 2 <= 1024
+    cross = slice(t['color'][16 * K], t['color'][t['ncol']])
+    assert (t['a'][cross] >= 0).sum() < 0.15 * 11640                                                         # eight of nine links lie inside a patch
+    t = dict(t, a=t['a'][real], b=t['b'][real], rest2=t['rest2'][real])
     assert np.allclose(t['rest2'], np.sum((t['x0'][t['a']] - t['x0'][t['b']]) ** 2, axis=1), rtol=1e-5)
     # the four anchor nodes hang together at the attachment point (dressing.py:148,153): a check of the node order and of the load transform
     assert list(t['anchors']) == [2086, 2087, 2088, 2041]
@@ -99,7 +113,8 @@ def test_cloth_hangs_from_its_anchors_and_keeps_its_links(dr, dr_oracle):
     ee, _ = dr_oracle.ee_pose(s)
     assert np.abs(c[0, t['anchors']].mean(0) - ee).max() < 0.02                                             # PSolve_Anchors
     assert c[0, :, 2].mean() < z0 - 0.05                                                                    # it falls ...
-    stretch = np.sqrt(np.sum((c[0, t['a']] - c[0, t['b']]) ** 2, axis=1) / t['rest2'])
+    real = t['a'] >= 0                               # (-1: empty slots of the link schedule)
+    stretch = np.sqrt(np.sum((c[0, t['a'][real]] - c[0, t['b'][real]]) ** 2, axis=1) / t['rest2'][real])
     assert np.median(stretch) < 1.05 and np.percentile(stretch, 99) < 1.6                                   # ... as a cloth, not as loose points (kLST = 0.055 is soft)
     # the robot holds its pose during the settle (motors at their targets, no gravity on the robot)
     assert np.abs(dr.view(s.reshape(1, -1))['q'][0, :7] - dr.view(st[0:1])['q'][0, :7]).max() < 1e-3

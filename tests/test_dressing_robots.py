@@ -34,7 +34,7 @@ def test_model_tables(rb):
     grip_dofs = [d for d in range(b.nrobot) if b.robot_i(d, 'PB_INDEX') in T['grip']]
     assert np.allclose([b.robot_f(d, 'QT0') for d in grip_dofs], T['gripper_target'])
     t = cloth_tables(b)
-    assert (t['nn'], t['nl']) == (3966, 11640) and b.meta['cloth']['shapes'] <= 192
+    assert (t['nn'], int((t['a'] >= 0).sum())) == (3966, 11640) and b.meta['cloth']['shapes'] <= 192
     assert b.meta['mount'] == ('toc' if name in ('sawyer', 'pr2') else 'wheelchair')
 
 
@@ -70,7 +70,8 @@ def test_short_cloth_settle_on_the_oracle_and_rigid_emulator_parity(rb):
     o.settle_cloth(s, c, 3)
     ee, _ = o.ee_pose(s)
     assert np.isfinite(c).all() and np.abs(c[0, t['anchors']].mean(0) - ee).max() < 0.02                  # the anchors stay at the end effector
-    stretch = np.sqrt(np.sum((c[0, t['a']] - c[0, t['b']]) ** 2, axis=1) / t['rest2'])
+    real = t['a'] >= 0                               # (-1: empty slots of the link schedule)
+    stretch = np.sqrt(np.sum((c[0, t['a'][real]] - c[0, t['b'][real]]) ** 2, axis=1) / t['rest2'][real])
     # a cloth, not loose points; the nodes the garment is loaded INSIDE the gripper with (Jaco's hand is wide) are pushed out to the 4 cm margin in the first steps
     assert np.median(stretch) < 1.05 and np.percentile(stretch, 95) < 1.6 and stretch.max() < 12
     so, se = st[0].copy(), st[0].copy()
