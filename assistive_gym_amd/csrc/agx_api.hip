@@ -173,7 +173,7 @@ static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_
     if (!V->cloth || !V->cloth_lds_bytes) return fail(AGX_E_LIMIT, "agx_create: the model has a cloth but the kernel variant of its task has no cloth kernel");
     const int32_t* cl = hi + hi[AGX_H_OFF_CLOTH];
     h->cloth_nn = cl[AGX_CL_NN];
-    h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn);
+    h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn) + AGX_CLOTH_SCRATCH_WORDS(h->cloth_nn);
     h->trace_words = h->frame_skip * h->sim_sub * hi[AGX_H_NDOF] * 12;
     h->cloth_lds = V->cloth_lds_bytes(h->cloth_nn);          // agxc::lds_words of the variant's own cloth kernel
     if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4096 || cl[AGX_CL_NCOLOR] - (AGX_CLOTH_THREADS / 64) * cl[AGX_CL_NPATCH_COLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_NPATCH_COLOR] < 0 || cl[AGX_CL_MAX_LINKS_PER_COLOR] > 1024 ||

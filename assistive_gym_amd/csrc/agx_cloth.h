@@ -6,8 +6,7 @@
 // bodies where each substep starts -- the build kernel leaves the world frames of the moving links of every substep in the
 // per-environment trace -- and the rigid bodies do not feel the cloth.  The rigid substeps of an env step therefore all run
 // first, then this kernel replays their poses: x and q are read from and written to HBM once per env step (95 KB each way)
-// instead of once per substep.  In between, the record in HBM is scratch: during the last substep every contact sums its impulses
-// there (slot node x contact; only the thread that owns the node touches it) -- 43 KB that used to sit in LDS.
+// instead of once per substep.
 //
 // Per substep: (a) body frames, shape boxes (world AABB grown by the margin) and the attachment point into LDS; the shapes whose
 // box meets the cloth's bounding box form the candidate list, in shape order; (b) per node: normal from the incident faces,
@@ -25,7 +24,6 @@ constexpr int T = AGX_CLOTH_THREADS;
 constexpr int NPT = 4096 / T;              // nodes per thread (garments of up to 4,096 nodes)
 constexpr int LPT = 1024 / T;              // links per thread and colour class (classes hold at most 1,024 links)
 constexpr int NODE_CONTACTS = 2;          // AGX_CLOTH_NODE_CONTACTS: contacts kept per node (the first ones in shape order)
-static_assert(NODE_CONTACTS == 2, "the impulse sums of the last substep use the garment record (2 x NN x 3 floats) as scratch");
 constexpr int MAX_BODIES = 64, MAX_SHAPES = 192;
 constexpr float EPS = 1.1920929e-7f;      // SIMD_EPSILON
 
@@ -69,12 +67,15 @@ __device__ inline int body_slot(int code, int ndof, int nhuman) {
 }
 
 // signed distance of world point x to the surface of shape `sh` (negative inside) and the outward normal, world frame; the shape's
-// record comes from the LDS table filled once per launch, only the face planes of hulls are read from the blob (L2)
+// record comes from the LDS table filled once per launch, only the face planes of hulls are read from the blob.  `sh` is the same in
+// every lane of the wave (the candidate loop is workgroup-uniform): plane count and first plane go to scalar registers, so that the
+// planes arrive through the scalar cache (s_load) instead of as 64-lane vector loads of one address each -- the texture path, not the
+// arithmetic, was what the contact phase waited for.
 __device__ inline float shape_distance(const float* clf, const int* cl, const Lds& S, int sh, f3 x, f3& nw) {
   const float* rec = S.shape + SHAPE_WORDS * sh; const int* reci = (const int*)rec;
   const float* B = S.body + 12 * reci[0];
   const f3 xl = rot_t(B + 3, x - ld(B));
-  const int np = reci[1]; const float rad = rec[3];
+  const int np = __builtin_amdgcn_readfirstlane(reci[1]); const float rad = rec[3];
   f3 nl; float dist;
   if (np == 0) {
     const f3 a = ld(rec + 4), ab = ld(rec + 7) - a, ax = xl - a; const float l2 = dot(ab, ab);
@@ -83,16 +84,28 @@ __device__ inline float shape_distance(const float* clf, const int* cl, const Ld
     if (len > 1e-12f) nl = (1.0f / len) * nl; else nl = mk(0.f, 0.f, 1.f);
     dist = len - rad;
   } else {
-    const float4* P = (const float4*)(clf + cl[AGX_CL_OFF_PLANE]) + reci[2];   // 16-byte aligned by the model compiler
+    const float4* P = (const float4*)(clf + cl[AGX_CL_OFF_PLANE]) + __builtin_amdgcn_readfirstlane(reci[2]);   // 16-byte aligned by the model compiler
     float bd = -3.0e38f; nl = mk(0.f, 0.f, 1.f);
-    for (int k = 0; k < np; k++) { const float4 pl = P[k]; const float t = pl.x * xl.x + pl.y * xl.y + pl.z * xl.z - pl.w; if (t > bd) { bd = t; nl = mk(pl.x, pl.y, pl.z); } }
+    for (int k = 0; k < np; k += 4) {          // plane lists are padded to a multiple of four (model/cloth.py): one scalar load of 64 bytes
+      const float4 p0 = P[k], p1 = P[k + 1], p2 = P[k + 2], p3 = P[k + 3];
+      const float t0 = p0.x * xl.x + p0.y * xl.y + p0.z * xl.z - p0.w, t1 = p1.x * xl.x + p1.y * xl.y + p1.z * xl.z - p1.w;
+      const float t2 = p2.x * xl.x + p2.y * xl.y + p2.z * xl.z - p2.w, t3 = p3.x * xl.x + p3.y * xl.y + p3.z * xl.z - p3.w;
+      if (t0 > bd) { bd = t0; nl = mk(p0.x, p0.y, p0.z); }
+      if (t1 > bd) { bd = t1; nl = mk(p1.x, p1.y, p1.z); }
+      if (t2 > bd) { bd = t2; nl = mk(p2.x, p2.y, p2.z); }
+      if (t3 > bd) { bd = t3; nl = mk(p3.x, p3.y, p3.z); }
+    }
     dist = bd - rad;
   }
   nw = rot(B + 3, nl);
   return dist;
 }
 
-struct Contact { f3 n; float offset, c3; bool rep; };   // rep: a contact of the last substep, whose impulses are summed for the report
+// A node-vs-rigid contact of the current substep lives in the environment's contact scratch in HBM (behind its report, agx_blob.h
+// AGX_CLOTH_SCRATCH_WORDS), slot (node, k): normal (3), offset, c3 (friction factor), impulse sum (3; last substep only).  Only the
+// thread that owns the node touches the slot.  In registers the eight records of a thread cost 48 VGPRs that the compiler could not
+// find (121 spilled registers, spill traffic in every loop of the kernel); the thread keeps the contact COUNT of its nodes only.
+constexpr int CREC = 8;
 
 // one env step of the garment: `nsub` internal substeps, substep k reading the link frames of trace slot k.
 // gcloth: float[2][NN][3] positions then velocities (in/out); greport: see agx_blob.h AGX_CLOTH_REPORT (written after the last substep)
@@ -139,7 +152,8 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   int own[NPT]; bool attached[NPT];
 #pragma unroll
   for (int j = 0; j < NPT; j++) { const int i = cl[cl[AGX_CL_OFF_PERM] + wave * (64 * NPT) + j * 64 + lane]; own[j] = i; attached[j] = false; for (int a = 0; a < NA; a++) if (anci[4 * a] == i) attached[j] = true; }
-  Contact con[NPT][NODE_CONTACTS]; int ncon[NPT];
+  int ncon[NPT];
+  float* const grec = greport + AGX_CLOTH_REPORT_WORDS(NN);
   __syncthreads();
   for (int sub = 0; sub < nsub; sub++) {
     // (a) frames of the moving links at the start of this substep; attachment point at the start of the current stepSimulation call
@@ -220,13 +234,13 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     // candidates outermost (their boxes are read once per thread, the next one while the current one is tested), this thread's nodes
     // innermost.  A shape whose box misses the box of the wave's 64 nodes of slot j (wave uniform, kept in scalar registers) is skipped
     // for all of them with one test: the nodes of a wave are neighbours on the garment (Morton ownership order).
-    f3 xs[NPT], qs[NPT]; bool mine[NPT];
+    bool mine[NPT];
     float wlo[NPT][3], whi[NPT][3];
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
       const int i = own[j]; ncon[j] = 0; mine[j] = i >= 0 && !attached[j];
-      xs[j] = mine[j] ? ld(S.x + 3 * i) : mk(0.f, 0.f, 0.f); qs[j] = mine[j] ? ld(S.q + 3 * i) : mk(0.f, 0.f, 0.f);
-      float l3[3] = {mine[j] ? xs[j].x : 3.0e38f, mine[j] ? xs[j].y : 3.0e38f, mine[j] ? xs[j].z : 3.0e38f}, h3[3] = {mine[j] ? xs[j].x : -3.0e38f, mine[j] ? xs[j].y : -3.0e38f, mine[j] ? xs[j].z : -3.0e38f};
+      const f3 xj = mine[j] ? ld(S.x + 3 * i) : mk(0.f, 0.f, 0.f);
+      float l3[3] = {mine[j] ? xj.x : 3.0e38f, mine[j] ? xj.y : 3.0e38f, mine[j] ? xj.z : 3.0e38f}, h3[3] = {mine[j] ? xj.x : -3.0e38f, mine[j] ? xj.y : -3.0e38f, mine[j] ? xj.z : -3.0e38f};
       for (int a = 0; a < 3; a++) {
         for (int o = 32; o > 0; o >>= 1) { l3[a] = fminf(l3[a], __shfl_xor(l3[a], o)); h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], o)); }
         wlo[j][a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, l3[a])));
@@ -238,7 +252,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     int shn = ncand > 0 ? S.cand[0] : 0;
     float nb[6]; for (int a = 0; a < 6; a++) nb[a] = S.box[6 * shn + a];
     for (int k = 0; k < ncand; k++) {
-      const int sh = shn; float bx[6]; for (int a = 0; a < 6; a++) bx[a] = nb[a];
+      const int sh = __builtin_amdgcn_readfirstlane(shn); float bx[6]; for (int a = 0; a < 6; a++) bx[a] = nb[a];
       if (k + 1 < ncand) { shn = S.cand[k + 1]; for (int a = 0; a < 6; a++) nb[a] = S.box[6 * shn + a]; }
       if (ulo[0] > bx[3] || ulo[1] > bx[4] || ulo[2] > bx[5] || uhi[0] < bx[0] || uhi[1] < bx[1] || uhi[2] < bx[2]) continue;   // the whole patch misses the shape
 #ifdef AGXC_NO_HULLS
@@ -247,21 +261,19 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
 #pragma unroll
       for (int j = 0; j < NPT; j++) {
         if (wlo[j][0] > bx[3] || wlo[j][1] > bx[4] || wlo[j][2] > bx[5] || whi[j][0] < bx[0] || whi[j][1] < bx[1] || whi[j][2] < bx[2]) continue;   // wave uniform
-        const f3 xi = xs[j];
         if (!mine[j] || ncon[j] >= NODE_CONTACTS) continue;
+        const f3 xi = ld(S.x + 3 * own[j]);           // (positions do not move during this phase: re-read rather than kept in registers)
         if (xi.x < bx[0] || xi.y < bx[1] || xi.z < bx[2] || xi.x > bx[3] || xi.y > bx[4] || xi.z > bx[5]) continue;
 #ifdef AGXC_NO_EVAL
         continue;
 #endif
         f3 nw; const float dst = shape_distance(clf, cl, S, sh, xi, nw) - mrg;
         if (dst >= 0.f) continue;
-        Contact c;
-        c.n = nw; c.offset = -dot(nw, xi) + dst; c.rep = sub == nsub - 1;
-        if (c.rep) st(gcloth + 3 * (NODE_CONTACTS * own[j] + ncon[j]), mk(0.f, 0.f, 0.f));
-        const f3 vr = xi - qs[j]; const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
+        const f3 vr = xi - ld(S.q + 3 * own[j]); const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
         const float fc = S.shape[SHAPE_WORDS * sh + 10];
-        c.c3 = dot(fv, fv) < (dn * fc * dn * fc) ? 0.f : 1.f - fc;
-        if (ncon[j] == 0) con[j][0] = c; else con[j][1] = c;      // no dynamic index: the contacts stay in registers
+        float* rec = grec + CREC * (NODE_CONTACTS * own[j] + ncon[j]);
+        *(float4*)rec = make_float4(nw.x, nw.y, nw.z, -dot(nw, xi) + dst);
+        *(float4*)(rec + 4) = make_float4(dot(fv, fv) < (dn * fc * dn * fc) ? 0.f : 1.f - fc, 0.f, 0.f, 0.f);
         ncon[j]++;
       }
     }
@@ -279,13 +291,15 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
           f3 xi = ld(S.x + 3 * i); const f3 qi = ld(S.q + 3 * i);
 #pragma unroll
           for (int cc = 0; cc < NODE_CONTACTS; cc++) if (cc < ncon[j]) {
-            Contact& c = con[j][cc];
-            const f3 vr = xi - qi; const float dn = dot(vr, c.n);
+            float* rec = grec + CREC * (NODE_CONTACTS * i + cc);
+            const float4 r0 = *(const float4*)rec; const float c3 = rec[4];
+            const f3 cn = mk(r0.x, r0.y, r0.z);
+            const f3 vr = xi - qi; const float dn = dot(vr, cn);
             if (dn <= EPS) {
-              float dp = dot(xi, c.n) + c.offset; if (dp > mrg) dp = mrg;
-              const f3 fv = vr - dn * c.n, corr = vr - c.c3 * fv + (dp * kCHR) * c.n;
+              float dp = dot(xi, cn) + r0.w; if (dp > mrg) dp = mrg;
+              const f3 fv = vr - dn * cn, corr = vr - c3 * fv + (dp * kCHR) * cn;
               xi = xi - corr;
-              if (c.rep) { float* o = gcloth + 3 * (NODE_CONTACTS * i + cc); const float w = 1.0f / (dt * im); o[0] += w * corr.x; o[1] += w * corr.y; o[2] += w * corr.z; }
+              if (sub == nsub - 1) { const float w = 1.0f / (dt * im); rec[5] += w * corr.x; rec[6] += w * corr.y; rec[7] += w * corr.z; }
             }
           }
           st(S.x + 3 * i, xi);
@@ -334,7 +348,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
       }
     }
   }
-  // report for the finish kernel, then write back the positions and the velocities of the last substep (over the impulse sums)
+  // report for the finish kernel; write back the positions and the velocities of the last substep
   if (greport) {
     if (tid < 6) st(greport + 3 * tid, ld(S.x + 3 * cl[AGX_CL_TRI + tid]));
 #pragma unroll
@@ -344,7 +358,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
 #pragma unroll
       for (int cc = 0; cc < NODE_CONTACTS; cc++) {
         float* o = greport + 20 + 2 * (NODE_CONTACTS * i + cc);
-        if (nsub > 0 && cc < ncon[j] && con[j][cc].rep) { const f3 f = (1.0f / dt) * ld(gcloth + 3 * (NODE_CONTACTS * i + cc)); o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
+        if (nsub > 0 && cc < ncon[j]) { const f3 f = (1.0f / dt) * ld(grec + CREC * (NODE_CONTACTS * i + cc) + 5); o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
       }
     }
   }

@@ -221,9 +221,10 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
         if len(c['verts']) <= 2:
             shapes.append([ci, 0, 0, gender_of(ci)])
         else:
-            pl = hull_planes(c['verts'])
+            pl = hull_planes(c['verts']).tolist()
+            pl += [pl[-1]] * ((-len(pl)) % 4)      # the cloth kernel evaluates four planes per scalar load: the last plane repeated (ties keep the first)
             shapes.append([ci, len(planes), len(pl), gender_of(ci)])
-            planes.extend(pl.tolist())
+            planes.extend(pl)
     planes = np.array(planes, dtype=np.float64).reshape(-1, 4)
     off, cur = {}, CL['HDR']
     cur += (-cur) % 4      # (the PLANE array is read as 16-byte words: the section itself starts on a 16-byte boundary, see pack())

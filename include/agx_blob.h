@@ -351,7 +351,8 @@ enum {
   AGX_CL_OFF_ANCHOR = 10,/* {int node, float[3] offset from the attachment body}[NANCHOR]                                     */
   AGX_CL_OFF_SHAPE = 11, /* int[NSHAPE][4]: collider index, first plane, plane count (0: capsule / sphere core + radius), gender
                             (0 always present, 1 / 2: part of the male / female human only)                                    */
-  AGX_CL_OFF_PLANE = 12, /* float[planes][4]: outward unit normal and offset of the hull's faces in the body frame             */
+  AGX_CL_OFF_PLANE = 12, /* float[planes][4]: outward unit normal and offset of the hull's faces in the body frame; a hull's list is
+                            padded to a multiple of four planes with copies of its last one (the cloth kernel reads four at a time)    */
   AGX_CL_TRI = 13,       /* int[6]: the two vertex triples around the opening of the left sleeve (dressing.py:156-157)         */
   AGX_CL_OFF_PARAM = 19, /* float[AGX_CP_COUNT]                                                                                */
   AGX_CL_MAX_LINKS_PER_COLOR = 20, /* int: size of the largest class between patches (<= 1,024: one link per thread of the cloth kernel)   */
@@ -383,6 +384,9 @@ enum {
 /* per-environment cloth report written by the cloth kernel for the finish kernel: float[18] the six sleeve vertices, 2 unused,
  * then per node and contact slot {height of the node, |force|} of the last substep's contacts (|force| = -1: empty slot) */
 #define AGX_CLOTH_REPORT_WORDS(nn) (20 + 2 * AGX_CLOTH_NODE_CONTACTS * (nn))
+/* behind the report, per environment: the cloth kernel's contact records of the current substep, 8 floats per (node, contact slot):
+ * normal (3), offset, friction factor, impulse sum of the last substep (3) */
+#define AGX_CLOTH_SCRATCH_WORDS(nn) (8 * AGX_CLOTH_NODE_CONTACTS * (nn))
 
 #define AGX_MLP_HIDDEN 64
 #define AGX_MLP_WORDS (4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1)
