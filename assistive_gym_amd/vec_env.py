@@ -83,6 +83,57 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     return out
 
 
+def _refresh_worker(model, coop, seed, batch, device, impairment, sampler, queue):
+    """child process of PoolRefresher: post-reset states batch after batch, each from its own seeds (reset sampling on the host or the
+    device + the settles on the device, exactly as the first pool was built: build_reset_pool)"""
+    blob = ModelBlob.load(model)
+    if coop and not blob.is_coop:
+        blob = blob.coop()
+    g = 1
+    while True:
+        out = build_reset_pool(blob, batch, int(seed) + 1_000_003 * g, device, impairment, sampler)
+        queue.put((g, out))               # blocks while two batches are waiting: the worker never runs far ahead of the rollout
+        g += 1
+
+
+class PoolRefresher:
+    """Fresh start states for the tasks whose reset is sampled on the host (free-standing robots: base pose search; the rag-doll and
+    cloth settles): a child process keeps producing batches of post-reset states, the rollout swaps them into the pool at episode
+    boundaries.  The reference draws a new human / target / base pose at EVERY reset (bed_bathing.py:112-171); a fixed pool shows a run
+    the same 256 states forever -- this bounds the repetition by the host sampler's rate instead (a few states per second per process;
+    the on-device generator of the wheelchair-mounted scenes, reset='device', needs none of this).
+    sync=False: batches are taken when they are ready (the pool's content then depends on timing); sync=True: episode e waits for batch
+    e, so that a run is reproducible and ranks that shard a batch see the same pools."""
+
+    def __init__(self, model, coop, seed, batch, device, impairment, sampler, sync=False):
+        import multiprocessing as mp
+        ctx = mp.get_context('spawn')
+        self.queue = ctx.Queue(maxsize=2)
+        self.sync, self.batch, self.taken = sync, batch, 0
+        self.proc = ctx.Process(target=_refresh_worker, args=(model, coop, seed, batch, device, impairment, sampler, self.queue), daemon=True)
+        self.proc.start()
+
+    def poll(self):
+        """batches that are due: [states or (states, garments)]"""
+        import queue as _q
+        out = []
+        if self.sync:
+            out.append(self.queue.get(timeout=1800)[1])             # episode e waits for batch e
+        else:
+            while True:
+                try:
+                    out.append(self.queue.get_nowait()[1])
+                except _q.Empty:
+                    break
+        self.taken += len(out)
+        return out
+
+    def close(self):
+        if self.proc.is_alive():
+            self.proc.terminate()
+        self.proc.join(timeout=5)
+
+
 class AssistiveVecEnv:
     """N lock-stepped environments of one compiled model (`model` = blob name: 'feeding_jaco', 'bed_bathing_sawyer').
     reset modes (all sampled and settled on the GPU unless 'host'):
@@ -97,7 +148,8 @@ class AssistiveVecEnv:
 
     coop = False
 
-    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool', model=None, coop=None):
+    def __init__(self, n_envs, device=0, seed=1001, pool_size=256, blob=None, impairment='random', auto_reset=True, reset='pool', model=None, coop=None,
+                 pool_refresh=0, pool_refresh_sync=False):
         assert reset in ('pool', 'device', 'host')
         self.blob = blob or ModelBlob.load(model or self.model)
         if (self.coop if coop is None else coop) and not self.blob.is_coop:
@@ -115,6 +167,9 @@ class AssistiveVecEnv:
         self.episode_len = int(self.blob.task_f('EPISODE_LEN'))
         self.env_offset, self._t, self._episode = 0, 0, 0
         self.terminal_obs = None
+        # pool_refresh = k > 0: a child process samples k new start states at a time, swapped into the pool at episode boundaries (PoolRefresher)
+        self.pool_refresh, self.pool_refresh_sync, self._refresher, self._refresh_cursor, self.pool_refreshed = int(pool_refresh), pool_refresh_sync, None, 0, 0
+        self._model_name = model or self.model
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -156,6 +211,9 @@ class AssistiveVecEnv:
                     self.cloth_pool = torch.from_numpy(self.cloth_pool_host).to(self.device)
                     self.stepper.set_cloth_pool(self.cloth_pool)
                 self.pool = torch.from_numpy(self.pool_host).to(self.device)
+                if self.pool_refresh > 0 and self._refresher is None:
+                    self._refresher = PoolRefresher(self._model_name, self.blob.is_coop, self.seed, min(self.pool_refresh, self.pool_size), self.device_index, self.impairment,
+                                                    'host' if self.reset_mode == 'host' else 'device', sync=self.pool_refresh_sync)
             idx = pool_indices(env_offset, self.n_envs, self.pool_size)
             self.stepper.set_state(self.pool_host[idx])
             if getattr(self, 'cloth_pool_host', None) is not None:
@@ -177,6 +235,8 @@ class AssistiveVecEnv:
         if self.auto_reset:
             boundary = self._t % self.episode_len == 0      # lock-stepped batch: every env is done (feeding.py:37)
             if self.reset_mode != 'device':
+                if boundary and self._refresher is not None:
+                    self._swap_in_fresh_states()
                 self.stepper.reset_done(self.pool, self.pool_size, self.done, s)
             elif boundary:
                 self._fresh_reset(self.done, s)
@@ -187,7 +247,23 @@ class AssistiveVecEnv:
                 self.stepper.observe_dev(self.obs, s)
         return self.obs, self.reward, self.done, self.info
 
+    def _swap_in_fresh_states(self):
+        """batches the refresher has ready replace the oldest pool entries (round robin), states and -- for models with a cloth -- garments"""
+        for b in self._refresher.poll():
+            states, cloth = b if isinstance(b, tuple) else (b, None)
+            k = len(states)
+            idx = (self._refresh_cursor + np.arange(k)) % self.pool_size
+            self.pool_host[idx] = states
+            self.pool[torch.from_numpy(idx).to(self.device)] = torch.from_numpy(states).to(self.device)
+            if cloth is not None:
+                self.cloth_pool_host[idx] = cloth
+                self.cloth_pool[torch.from_numpy(idx).to(self.device)] = torch.from_numpy(cloth).to(self.device)
+            self._refresh_cursor = int((self._refresh_cursor + k) % self.pool_size)
+            self.pool_refreshed += k
+
     def close(self):
+        if self._refresher is not None:
+            self._refresher.close()
         self.stepper.close()
 
 

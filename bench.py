@@ -235,11 +235,12 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             k, v = kv.split('=')
             blob_override = blob_override.set_param(k, float(v))
     if env_cls is None:
-        env = vec_env.AssistiveVecEnv(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, model=model, coop=env_id.endswith('Human-v1'), blob=blob_override)
+        env = vec_env.AssistiveVecEnv(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, model=model, coop=env_id.endswith('Human-v1'), blob=blob_override,
+                                      pool_refresh=getattr(args, 'pool_refresh', 0))
         ksuffix = {'feeding': '', 'feeding_l': '_fl', 'bed_bathing': '_bb', 'bed_bathing_l': '_bbl', 'scratch_itch': '_si', 'dressing': '_dr', 'dressing_l': '_drl',
                    'arm_manipulation': '_am', 'arm_manipulation_l': '_aml'}[env.stepper.variant()]
     else:
-        env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, blob=blob_override)
+        env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, blob=blob_override, pool_refresh=getattr(args, 'pool_refresh', 0))
     blob = env.blob                      # the co-op flavour where the task's BASELINE config is co-op
     action_scale = 1.0
     if workload == 'wiping':
@@ -355,6 +356,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
                        'obs_allgather': bool(distributed), 'noop_retest': blob.param('NOOP_RETEST')},
             'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps
             'overflow_count': int(overflow),       # substeps (summed over environments) in which a contact was dropped by the contact / row / coefficient budgets
+            'pool_states_refreshed': int(getattr(env, 'pool_refreshed', 0)),      # --pool-refresh: start states a child process sampled during the run and the rollout swapped into the pool
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': names[dom], 'kernel_ms_per_launch': launch_ms, 'launches_per_step': launches[dom],
@@ -388,6 +390,7 @@ def main():
     ap.add_argument('--pool', type=int, default=None, help='reset pool size (default 256; 64 for dressing, whose pool entries carry a garment and a 50-step device settle)')
     ap.add_argument('--reset', choices=['pool', 'device', 'host'], default='pool',
                     help="'pool': auto-reset from a fixed device-generated pool (BASELINE config 2); 'device': new states sampled for every episode")
+    ap.add_argument('--pool-refresh', type=int, default=0, help='k > 0: a child process samples k new start states at a time and the rollout swaps them into the pool at episode boundaries (vec_env.PoolRefresher); the line then reports pool_states_refreshed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--task', choices=sorted(TASKS), default=None, help="'feeding' = the BASELINE metric (config 2, the default); 'bedbathing' = config 3; 'scratchitch' = config 4's env (co-op) on one GPU; 'dressing' = config 5's")
     ap.add_argument('--workload', choices=['wiping'], default=None, help="bedbathing only: 'wiping' = the contact-rich variant of config 3 (pad pressed onto the arm)")
