@@ -64,18 +64,15 @@ constexpr int L_SOLVE_ENT = L_VEL + 128;
 // Build-time knobs for same-box A/B runs (tools/ab_build.sh): -DAGX_SOLVE_LDS_PAIRS=n (size of the solve kernel's
 // LDS row window), -DAGX_NO_LDS_ROWS (all rows from global memory), -DAGX_PGS_CPP (the C++ twin of the assembly sweep).
 #ifndef AGX_SOLVE_LDS_PAIRS
-#define AGX_SOLVE_LDS_PAIRS (AGX_TASK == 0 || AGX_MAX_DOF > 32 ? 960 : 640)      // the row-space variants: 640 (environments of 21 ... 45 rows have 250 ... 520 pairs)
+#define AGX_SOLVE_LDS_PAIRS 960
 #endif
 constexpr int SOLVE_LDS_PAIRS = AGX_SOLVE_LDS_PAIRS;
 static_assert(L_SOLVE_ENT % 2 == 0, "(J,B) pairs are read as 8-byte words");
 // Row-space solve (agx_pgs.h pgs_rowspace; the variants other than FeedingJaco, whose environments have few solver rows): the dense
 // Jacobians of up to RS_MAX_ROWS rows and their coupling matrix A = J M^-1 J^T replace the (J,B) window in LDS
-constexpr int RS_MAX_ROWS = TASK != AGX_TASK_FEEDING && MAX_DOF <= 32 ? 48 : 0, RS_NVP = (MAX_DOF + 6 * MAX_FREE) | 1;     // row stride of the dense Jacobian: odd = conflict free
-// layout of the work area behind the (J,B) window, which the row-space path fills with ALL pairs of the environment (it bails out otherwise).
-// A is symmetric (M^-1 is): its lower triangle is kept, A(i, j) at i (i + 1) / 2 + j for j <= i.  With 48 rows and 640 pairs the work
-// area is 20 KB (30 KB with the full 56 x 56 matrix and 960 pairs): 8 environments per CU instead of 5 -- the kernel was occupancy bound.
-constexpr int RS_TRI = RS_MAX_ROWS * (RS_MAX_ROWS + 1) / 2;
-constexpr int RS_J = 2 * SOLVE_LDS_PAIRS, RS_A = RS_J + RS_MAX_ROWS * RS_NVP, RS_ROW = RS_A + RS_TRI, RS_LAM = RS_ROW + 64, RS_WORDS = RS_MAX_ROWS ? RS_LAM + 64 : 0;
+constexpr int RS_MAX_ROWS = TASK != AGX_TASK_FEEDING && MAX_DOF <= 32 ? 56 : 0, RS_NVP = (MAX_DOF + 6 * MAX_FREE) | 1;     // row stride of the dense Jacobian: odd = conflict free
+// layout of the work area behind the (J,B) window, which the row-space path fills with ALL pairs of the environment (it bails out otherwise)
+constexpr int RS_J = 2 * SOLVE_LDS_PAIRS, RS_A = RS_J + RS_MAX_ROWS * RS_NVP, RS_ROW = RS_A + RS_MAX_ROWS * RS_MAX_ROWS, RS_LAM = RS_ROW + 64, RS_WORDS = RS_MAX_ROWS ? RS_LAM + 64 : 0;
 constexpr int LDS_SOLVE_WORDS = L_SOLVE_ENT + (2 * SOLVE_LDS_PAIRS > RS_WORDS ? 2 * SOLVE_LDS_PAIRS : RS_WORDS);
 constexpr int LDS_SOLVE_BYTES = LDS_SOLVE_WORDS * 4;
 // arena, dynamics phase

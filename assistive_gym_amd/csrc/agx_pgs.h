@@ -296,11 +296,9 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
       wave_sync(); ROW[lane] = X.c0; wave_sync();
       float a = 0.f;
       if (lane < R) for (int d = 0; d < nv; d++) a += LJ[RS_NVP * lane + d] * ROW[d];
-      if (lane <= i) A[i * (i + 1) / 2 + lane] = a;                // lower triangle: A(i, j), j <= i
+      if (lane < RS_MAX_ROWS) A[RS_MAX_ROWS * i + lane] = a;      // a row of A has RS_MAX_ROWS entries: lanes beyond it must not spill into the next row / the ROW buffer
     }
     wave_sync();
-    const int tri_lane = lane * (lane + 1) / 2;                     // A(r, lane) = A(lane, r): row r of the symmetric matrix from its lower triangle
-#define AGX_RS_AROW(r) A[lane <= (r) ? (r) * ((r) + 1) / 2 + lane : tri_lane + (r)]
     float w = 0.f;                                                  // J_r . dv of this lane's row
     const int fn = lane - nc;                                       // normal row of this lane's friction row
     const int K = (int)PRM(c, AGX_P_NOOP_RETEST);                   // the no-op re-test rule, see pgs()
@@ -311,7 +309,7 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
       uint64_t rowsA = pgs_range_mask(0, nA) & ~((K > 0 && !retest) ? skip : 0ull);
       while (rowsA) {                                               // non-contact rows and contact normals
         const int r = ffs64(rowsA); rowsA &= rowsA - 1ull;
-        const float arow = lane < R ? AGX_RS_AROW(r) : 0.f;
+        const float arow = A[RS_MAX_ROWS * r + lane];
         const float nl = wave_clamp(S.lam + (S.b - w) * S.invD, S.lo, S.hi);
         const float dl = wave_bcast(nl - S.lam, r);
         if (lane == r) S.lam = nl;
@@ -326,7 +324,7 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
         uint64_t todo = wave_ballot(lane >= nA && lane < R && (ln != 0.f || S.lam != 0.f));
         while (todo) {
           const int r = ffs64(todo); todo &= todo - 1ull;
-          const float arow = lane < R ? AGX_RS_AROW(r) : 0.f;
+          const float arow = A[RS_MAX_ROWS * r + lane];
           const float nl = wave_clamp(S.lam + (S.b - w) * S.invD, lo, hi);
           const float dl = wave_bcast(nl - S.lam, r);
           if (lane == r) S.lam = nl;
@@ -341,7 +339,6 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
       dv0 += X.c0 * wave_bcast(S.lam, r);
     }
     if (lane >= nnc && lane < nA) c.gcon[CON_STRIDE * (lane - nnc) + C_LAM] = S.lam;
-#undef AGX_RS_AROW
     return true;
   }
 }
