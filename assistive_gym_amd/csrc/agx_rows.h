@@ -206,7 +206,7 @@ AGX_DEV void build_rows(Ctx& c) {
       }
       const int cnt = go ? row_entries(c, R) : 0;
       const uint64_t am = wave_ballot(go);
-      const int bc = go ? row_block_entries(c, R) : 0;
+      const int bc = (USE_SOLVE4 && go) ? row_block_entries(c, R) : 0;
       rrow = nnc + wave_rank(am); roff = ent + wave_scan_excl(cnt); rboff = bent + wave_scan_excl(bc);
       nnc += popc64(am); ent += wave_sum_i(cnt); bent += wave_sum_i(bc);
     } else if (ph == NC_PASSES) {
@@ -218,7 +218,7 @@ AGX_DEV void build_rows(Ctx& c) {
       }
       ccnt = has ? row_entries(c, rn) : 0;
       cincl = wave_scan_excl(ccnt) + ccnt;
-      bcnt = has ? row_block_entries(c, rn) : 0;
+      bcnt = (USE_SOLVE4 && has) ? row_block_entries(c, rn) : 0;
       bincl = wave_scan_excl(bcnt) + bcnt;
       // largest prefix of the contact list that fits the row and coefficient budgets; the contacts beyond it are
       // dropped and counted as overflow
