@@ -31,6 +31,16 @@ class ModelBlob:
         return cls(np.fromfile(path, dtype=np.uint32), meta)
 
     # ---- sections --------------------------------------------------------------------------
+    @property
+    def has_reset_generator(self):
+        """the blob carries a reset section the device-side reset generator (csrc/agx_reset.h, agx_sample_reset / agx_reset) can sample from:
+        the feeding and scratch-itch scenes with a wheelchair-mounted arm, and the scratch-itch scenes of the free-standing PR2 / Baxter
+        (base pose search on the device)"""
+        from .model import compiler as L
+        x0 = int(self.i[L.H['OFF_RESET']])
+        words = int(self.i[L.H['OFF_TARGETS']]) - x0 if 'OFF_TARGETS' in L.H else 0
+        return words > L.X_['COUNT'] and int(self.i[x0 + L.X_['NARM']]) > 0
+
     def param(self, key):
         return float(self.f[self.h['OFF_PARAMS'] + L.P[key]])
 

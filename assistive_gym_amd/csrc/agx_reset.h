@@ -80,7 +80,8 @@ AGX_DEV double rs_u01(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t slot) 
 }
 // stream 0 slots, restart-stream slots (+ DoF)
 enum { RS_FRICTION = 0, RS_GENDER = 1, RS_IMPAIRMENT = 2, RS_LIMIT = 3, RS_STRENGTH = 4, RS_HEAD = 8, RS_EE = 12, RS_BOWL = 16,
-       RS_TREMOR = 32, RS_LIMB = 48, RS_TARGET_LEN = 49, RS_TARGET_TH = 50, RS_R_REST = 0, RS_R_LO = 16, RS_R_HI = 32 };
+       RS_TREMOR = 32, RS_LIMB = 48, RS_TARGET_LEN = 49, RS_TARGET_TH = 50, RS_R_REST = 0, RS_R_LO = 16, RS_R_HI = 32,
+       RS_T_STREAM0 = 2000, RS_T_X = 0, RS_T_Y = 1, RS_T_YAW = 2, RS_T_REST = 16 };      // base pose search: stream RS_T_STREAM0 + 64 (try x rounds + round) + candidate; rest pose of goal g at RS_T_REST + 8 g + DoF
 enum { RS_IMP_NONE = 0, RS_IMP_LIMITS = 1, RS_IMP_WEAKNESS = 2, RS_IMP_TREMOR = 3, RS_MODE_RANDOM = -1, RS_MODE_NO_TREMOR = -2 };
 constexpr int RS_NARM = 7;   // arm DoFs solved by the IK; agx_create checks the blob (a serial chain 0..6 carrying the end effector)
 
@@ -91,6 +92,7 @@ struct ResetCtx {
   int nj, gender;
   double ls;                          // limit scale of the sampled human
   double head[3];                     // head joint angle draws
+  d3 base_p; dq base_q;               // robot base: the blob's fixed pose, or this lane's candidate of the base pose search
 };
 #define XF(c, k) ((double)(c).xf[(k)])
 #define XI(c, k) ((c).xi[(k)])
@@ -120,7 +122,7 @@ AGX_DEV void rs_link_pose(const ResetCtx& c, int link, d3& p, dq& q) {
 
 // arm forward kinematics: joint origins, world joint axes, end-effector pose
 AGX_DEV void rs_arm_fk(const ResetCtx& c, const double* q, d3* pos, d3* axw, d3& pe, dq& oe) {
-  d3 pp = dld3(c.xf + AGX_X_BASE_POS); dq pq = dld4(c.xf + AGX_X_BASE_QUAT);
+  d3 pp = c.base_p; dq pq = c.base_q;
 #pragma unroll
   for (int d = 0; d < RS_NARM; d++) {
     const float* r = c.rob + d * AGX_R_STRIDE;
@@ -134,30 +136,35 @@ AGX_DEV void rs_arm_fk(const ResetCtx& c, const double* q, d3* pos, d3* axw, d3&
   dcompose(pp, pq, dld3(c.task + AGX_T_EE_POS), dld4(c.task + AGX_T_EE_QUAT), pe, oe);
 }
 
-// damped least squares from q (in place), joint box [lo, hi]
-AGX_DEV void rs_ik(const ResetCtx& c, double* q, const double* lo, const double* hi, d3 tpos, dq tquat) {
+// damped least squares from q (in place), joint box [lo, hi]; ORIENT = false: position only (a 3 x 3 system)
+template <bool ORIENT>
+AGX_DEV void rs_ik(const ResetCtx& c, double* q, const double* lo, const double* hi, d3 tpos, dq tquat, int iters) {
   const double lam2 = XF(c, AGX_X_IK_DAMP) * XF(c, AGX_X_IK_DAMP), tol = XF(c, AGX_X_IK_TOL), maxstep = XF(c, AGX_X_IK_MAXSTEP);
-  const int iters = XI(c, AGX_X_IK_ITERS);
+  constexpr int NE = ORIENT ? 6 : 3;
   for (int it = 0; it < iters; it++) {
     d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
     rs_arm_fk(c, q, pos, axw, pe, oe);
     const d3 ep = tpos - pe;
-    dq oc; oc.x = -oe.x; oc.y = -oe.y; oc.z = -oe.z; oc.w = oe.w;
-    dq qe = dqmul(tquat, oc);
-    if (qe.w < 0) { qe.x = -qe.x; qe.y = -qe.y; qe.z = -qe.z; }
-    const d3 er = dmk(2.0 * qe.x, 2.0 * qe.y, 2.0 * qe.z);
+    d3 er = dmk(0, 0, 0);
+    if (ORIENT) {
+      dq oc; oc.x = -oe.x; oc.y = -oe.y; oc.z = -oe.z; oc.w = oe.w;
+      dq qe = dqmul(tquat, oc);
+      if (qe.w < 0) { qe.x = -qe.x; qe.y = -qe.y; qe.z = -qe.z; }
+      er = dmk(2.0 * qe.x, 2.0 * qe.y, 2.0 * qe.z);
+    }
     if (sqrt(ddot(ep, ep)) < tol && sqrt(ddot(er, er)) < tol) break;
     // columns of the 6 x NARM Jacobian: [axis x (pe - origin); axis]
-    double J[6][RS_NARM];
+    double J[NE][RS_NARM];
 #pragma unroll
     for (int d = 0; d < RS_NARM; d++) {
       const d3 l = dcross(axw[d], pe - pos[d]);
-      J[0][d] = l.x; J[1][d] = l.y; J[2][d] = l.z; J[3][d] = axw[d].x; J[4][d] = axw[d].y; J[5][d] = axw[d].z;
+      J[0][d] = l.x; J[1][d] = l.y; J[2][d] = l.z;
+      if (ORIENT) { J[NE - 3][d] = axw[d].x; J[NE - 2][d] = axw[d].y; J[NE - 1][d] = axw[d].z; }
     }
     // A = J J^T + lam^2 I, Cholesky A = L L^T, solve A y = e
-    double A[6][6];
+    double A[NE][NE];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < NE; i++) {
 #pragma unroll
       for (int j = 0; j <= i; j++) {
         double s = (i == j) ? lam2 : 0.0;
@@ -168,14 +175,14 @@ AGX_DEV void rs_ik(const ResetCtx& c, double* q, const double* lo, const double*
     }
     double y[6] = {ep.x, ep.y, ep.z, er.x, er.y, er.z};
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
+    for (int j = 0; j < NE; j++) {
       double s = A[j][j];
 #pragma unroll
       for (int k = 0; k < j; k++) s -= A[j][k] * A[j][k];
       const double ljj = sqrt(s), inv = 1.0 / ljj;
       A[j][j] = ljj;
 #pragma unroll
-      for (int i = j + 1; i < 6; i++) {
+      for (int i = j + 1; i < NE; i++) {
         double t = A[i][j];
 #pragma unroll
         for (int k = 0; k < j; k++) t -= A[i][k] * A[j][k];
@@ -183,17 +190,17 @@ AGX_DEV void rs_ik(const ResetCtx& c, double* q, const double* lo, const double*
       }
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < NE; i++) {
       double t = y[i];
 #pragma unroll
       for (int k = 0; k < i; k++) t -= A[i][k] * y[k];
       y[i] = t / A[i][i];
     }
 #pragma unroll
-    for (int i = 5; i >= 0; i--) {
+    for (int i = NE - 1; i >= 0; i--) {
       double t = y[i];
 #pragma unroll
-      for (int k = i + 1; k < 6; k++) t -= A[k][i] * y[k];
+      for (int k = i + 1; k < NE; k++) t -= A[k][i] * y[k];
       y[i] = t / A[i][i];
     }
     double dqv[RS_NARM], step = 0.0;
@@ -201,13 +208,60 @@ AGX_DEV void rs_ik(const ResetCtx& c, double* q, const double* lo, const double*
     for (int d = 0; d < RS_NARM; d++) {
       double s = 0.0;
 #pragma unroll
-      for (int i = 0; i < 6; i++) s += J[i][d] * y[i];
+      for (int i = 0; i < NE; i++) s += J[i][d] * y[i];
       dqv[d] = s; step = fmax(step, fabs(s));
     }
     const double scale = step > maxstep ? maxstep / step : 1.0;
 #pragma unroll
     for (int d = 0; d < RS_NARM; d++) q[d] = fmin(fmax(q[d] + (step > maxstep ? dqv[d] * scale : dqv[d]), lo[d]), hi[d]);
   }
+}
+
+// Robot.joint_limited_weighting (robot.py:217-228) and the joint-limit-weighted kinematic isotropy of a solution (robot.py:186-191):
+// M = J diag(w) J^T, JLWKI = det(M)^(1/6) / (trace(M) / 6); det through the Cholesky factor (0 when M is not positive definite)
+AGX_DEV double rs_jlwki(const ResetCtx& c, const double* q) {
+  d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
+  rs_arm_fk(c, q, pos, axw, pe, oe);
+  double J[6][RS_NARM], w[RS_NARM];
+#pragma unroll
+  for (int d = 0; d < RS_NARM; d++) {
+    const d3 l = dcross(axw[d], pe - pos[d]);
+    J[0][d] = l.x; J[1][d] = l.y; J[2][d] = l.z; J[3][d] = axw[d].x; J[4][d] = axw[d].y; J[5][d] = axw[d].z;
+    const double lower = (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER];
+    const double qr = 0.5 * (upper - lower);
+    const double wd = 1.0 - pow(0.5, (qr - fabs(qr - q[d] + lower)) / (0.05 * qr) + 1.0);
+    w[d] = fmax(wd, 0.001);
+  }
+  double M[6][6], tr = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < RS_NARM; d++) s += J[i][d] * w[d] * J[j][d];
+      M[i][j] = s;
+    }
+    tr += M[i][i];
+  }
+  double det = 1.0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double s = M[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= M[j][k] * M[j][k];
+    if (!(s > 0.0)) return 0.0;
+    const double ljj = sqrt(s), inv = 1.0 / ljj;
+    M[j][j] = ljj; det *= s;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double t = M[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= M[i][k] * M[j][k];
+      M[i][j] = t * inv;
+    }
+  }
+  return pow(det, 1.0 / 6.0) / (tr / 6.0);
 }
 
 // One environment.  gstate: this env's state record (fully overwritten).  ginfo (may be null): float[4] =
@@ -222,6 +276,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   c.xf = c.bf + c.bi[AGX_H_OFF_RESET]; c.xi = c.bi + c.bi[AGX_H_OFF_RESET];
   c.rob = c.bf + c.bi[AGX_H_OFF_ROBOT]; c.task = c.bf + c.bi[AGX_H_OFF_TASK];
   c.nj = XI(c, AGX_X_NJOINT);
+  c.base_p = dld3(c.xf + AGX_X_BASE_POS); c.base_q = dld4(c.xf + AGX_X_BASE_QUAT);
   const int ndof = c.bi[AGX_H_NDOF], nrobot = c.bi[AGX_H_NROBOT], nhdof = c.bi[AGX_H_NHDOF], nfree = c.bi[AGX_H_NFREE];
   const int nhuman = c.bi[AGX_H_NHUMAN], nfood = c.bi[AGX_H_NFOOD], state_words = c.bi[AGX_H_STATE_WORDS];
   const int sQ = c.bi[AGX_H_S_Q], sQT = c.bi[AGX_H_S_QT], sFREE = c.bi[AGX_H_S_FREE], sBASE = c.bi[AGX_H_S_BASE];
@@ -274,6 +329,72 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   int best_r = 0x7fffffff, restarts = max_restarts, ok = 0;
 #pragma unroll
   for (int d = 0; d < RS_NARM; d++) best_q[d] = 0.0;
+  const int toc_attempts = XI(c, AGX_X_TOC_ATTEMPTS);
+  if (toc_attempts > 0) {
+    // ---- a free-standing robot: Robot.position_robot_toc (robot.py:123-215), one candidate base pose per lane.  A candidate solves the
+    // IK for the start pose (position + orientation) and for the position goals on the human's arm from random rest poses; candidates that
+    // reach the start pose compete by (goals reached, summed JLWKI of the reached goals), the earliest one wins ties (robot.py:204: >).
+    // `first_restart` counts the placements that collided so far (env.py:281-308 re-draws the placement): every placement has its own streams.
+    const int rounds = XI(c, AGX_X_TOC_ROUNDS), titers = XI(c, AGX_X_TOC_IK_ITERS);
+    const double tthr = XF(c, AGX_X_TOC_THRESH), prange = XF(c, AGX_X_TOC_POS_RANGE), yrange = XF(c, AGX_X_TOC_YAW_RANGE);
+    d3 goals[3];
+    for (int k = 0; k < 3; k++) { dq gq; rs_link_pose(c, XI(c, AGX_X_TOC_GOAL_LINKS + k), goals[k], gq); }
+    const d3 base0 = dld3(c.xf + AGX_X_BASE_POS);
+    restarts = 0;
+    for (int round = 0; round < rounds && !ok; round++) {
+      const uint32_t stream = (uint32_t)RS_T_STREAM0 + 64u * (uint32_t)(first_restart * rounds + round) + (uint32_t)lane;
+      const bool active = lane < toc_attempts;
+      const double ux = rs_u01(seed_lo, seed_hi, stream, RS_T_X), uy = rs_u01(seed_lo, seed_hi, stream, RS_T_Y), uw = rs_u01(seed_lo, seed_hi, stream, RS_T_YAW);
+      const double yaw = XF(c, AGX_X_TOC_YAW0) + (2.0 * uw - 1.0) * yrange;
+      c.base_p = base0 + dmk(XF(c, AGX_X_TOC_X_SIGN) * prange * ux, (2.0 * uy - 1.0) * prange, 0.0);
+      c.base_q = dq_axis_angle(dmk(0, 0, 1), yaw);
+      int reached = 0; double manip = 0.0, qs[RS_NARM];
+#pragma unroll
+      for (int d = 0; d < RS_NARM; d++) qs[d] = 0.0;
+      if (active) {
+        double lo[RS_NARM], hi[RS_NARM];
+#pragma unroll
+        for (int d = 0; d < RS_NARM; d++) {
+          const double lower = (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER];
+          lo[d] = lower < -1e9 ? -6.283185307179586 : lower; hi[d] = upper > 1e9 ? 6.283185307179586 : upper;     // agent.py:223-231
+        }
+        for (int g = 0; g < 4; g++) {
+          double q[RS_NARM];
+#pragma unroll
+          for (int d = 0; d < RS_NARM; d++) q[d] = lo[d] + (hi[d] - lo[d]) * rs_u01(seed_lo, seed_hi, stream, RS_T_REST + 8 * g + d);     // agent.py:263
+          const d3 tp = g == 0 ? tpos : goals[g - 1];
+          if (g == 0) rs_ik<true>(c, q, lo, hi, tp, tquat, titers); else rs_ik<false>(c, q, lo, hi, tp, tquat, titers);
+          d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
+          rs_arm_fk(c, q, pos, axw, pe, oe);
+          bool hit = sqrt(ddot(tp - pe, tp - pe)) < tthr;                                                          // robot.py:97
+          if (g == 0) {
+            const double mx = tquat.x - oe.x, my = tquat.y - oe.y, mz = tquat.z - oe.z, mw = tquat.w - oe.w;
+            const double px = tquat.x + oe.x, py = tquat.y + oe.y, pz = tquat.z + oe.z, pw = tquat.w + oe.w;
+            hit = hit && fmin(sqrt(mx * mx + my * my + mz * mz + mw * mw), sqrt(px * px + py * py + pz * pz + pw * pw)) < tthr;
+#pragma unroll
+            for (int d = 0; d < RS_NARM; d++) qs[d] = q[d];
+          }
+          if (hit) { reached |= 1 << g; manip += rs_jlwki(c, q); }
+        }
+      }
+      const int ngoal = (active && (reached & 1)) ? __builtin_popcount(reached) : -1;            // the start pose must be reachable (robot.py:196-200)
+      int bl = 0, bn = -2; double bm = -1e300;
+      for (int l = 0; l < AGX_WAVE; l++) {
+        const int nl = wave_bcast_i(ngoal, l); const double ml = wave_bcast_d(manip, l);
+        if (nl > bn || (nl == bn && nl > 0 && ml > bm)) { bn = nl; bm = ml; bl = l; }
+      }
+      restarts++;
+      if (bn > 0) ok = 1;
+      if (bn > 0 || round == rounds - 1) {           // the winner (or, if nobody reaches the start pose in any round, candidate 0 of the last one)
+        const d3 bp = c.base_p; const dq bq = c.base_q;
+        c.base_p = dmk(wave_bcast_d(bp.x, bl), wave_bcast_d(bp.y, bl), wave_bcast_d(bp.z, bl));
+        c.base_q.x = wave_bcast_d(bq.x, bl); c.base_q.y = wave_bcast_d(bq.y, bl); c.base_q.z = wave_bcast_d(bq.z, bl); c.base_q.w = wave_bcast_d(bq.w, bl);
+#pragma unroll
+        for (int d = 0; d < RS_NARM; d++) best_q[d] = wave_bcast_d(qs[d], bl);
+        best_d = (double)bn; best_r = first_restart;
+      }
+    }
+  } else
   for (int r0 = 0; r0 < max_restarts && !ok; r0 += AGX_WAVE) {
     const int r = r0 + lane;
     const bool active = r < max_restarts;
@@ -293,7 +414,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
         q[d] = l + (h - l) * rs_u01(seed_lo, seed_hi, 1u + (uint32_t)r, RS_R_REST + d);                            // agent.py:263
         lo[d] = fmin(l, h); hi[d] = fmax(l, h);
       }
-      rs_ik(c, q, lo, hi, tpos, tquat);
+      rs_ik<true>(c, q, lo, hi, tpos, tquat, XI(c, AGX_X_IK_ITERS));
 #pragma unroll
       for (int d = 0; d < RS_NARM; d++)                                                                          // set_joint_angles(use_limits=True)
         q[d] = fmin(fmax(q[d], (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER]), (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER]);
@@ -319,7 +440,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
       for (int d = 0; d < RS_NARM; d++) best_q[d] = wave_bcast_d(q[d], l);
     }
   }
-  if (!ok) {   // no restart met the thresholds: the one with the smallest position error, earliest on ties (robot.py:100-103)
+  if (!ok && toc_attempts == 0) {   // no restart met the thresholds: the one with the smallest position error, earliest on ties (robot.py:100-103)
     double md = 1e300; int mr = 0x7fffffff, ml = 0;
     for (int l = 0; l < AGX_WAVE; l++) {
       const double dl = wave_bcast_d(best_d, l); const int rl = wave_bcast_i(best_r, l);
@@ -382,7 +503,10 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     }
     o[0] = (float)p.x; o[1] = (float)p.y; o[2] = (float)p.z; o[3] = (float)q.x; o[4] = (float)q.y; o[5] = (float)q.z; o[6] = (float)q.w;
   }
-  if (lane < 7) gstate[sBASE + lane] = c.xf[AGX_X_BASE_POS + lane];      // BASE_POS[3] and BASE_QUAT[4] are adjacent
+  if (lane == 0) {
+    float* o = gstate + sBASE;
+    o[0] = (float)c.base_p.x; o[1] = (float)c.base_p.y; o[2] = (float)c.base_p.z; o[3] = (float)c.base_q.x; o[4] = (float)c.base_q.y; o[5] = (float)c.base_q.z; o[6] = (float)c.base_q.w;
+  }
   if (lane == 0) {
     float* e = gstate + sENV; int* ei = gstate_i + sENV;
     const uint64_t seed = ((uint64_t)seed_hi << 32) | seed_lo;
@@ -412,6 +536,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     }
     if (ginfo) { ginfo[0] = (float)ok; ginfo[1] = (float)restarts; ginfo[2] = (float)best_d; ginfo[3] = (float)imp; }
   }
+  if (toc_attempts > 0) return ok ? first_restart : -1;         // the placement that was accepted (the next one, if it collides, is first_restart + 1)
   return ok ? restarts - 1 : -1;
 }
 

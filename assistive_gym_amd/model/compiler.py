@@ -52,7 +52,8 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
           IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
-          REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, COUNT=52)
+          REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
+          TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, COUNT=64)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
          TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, HUMAN_KP=14, HUMAN_MAXF=15, COUNT=16)
@@ -1202,16 +1203,29 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
         dims += [hmd['upperarm'][1], hmd['upperarm'][0], hmd['forearm'][1], hmd['forearm'][0]]
     task_f['SI_LIMB_DIMS'] = dims
 
+    # the device-side reset generator (csrc/agx_reset.h) samples ScratchItchEnv.reset (scratch_itch.py:93-132): a wheelchair-mounted arm by
+    # IK restarts, a free-standing robot by the base pose search of Robot.position_robot_toc (robot.py:123-215) -- the latter for the robots
+    # whose arm is a serial 7-joint chain and needs no pedestal guard (PR2, Baxter; the Sawyer keeps the host sampler, reset_bed._arm_in_pedestal)
+    generator = mounted or robot in ('pr2', 'baxter')
+
     def reset_words(nhuman, nhdof):
-        return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if mounted else 0)
+        return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if generator else 0)
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        if not mounted:
-            return      # a free-standing robot: the pool comes from assistive_gym_amd/host/reset_scratch.py (base pose search)
-        # a wheelchair-mounted arm: the device-side reset generator (csrc/agx_reset.h) samples ScratchItchEnv.reset (scratch_itch.py:93-132)
+        if not generator:
+            return      # the pool comes from assistive_gym_amd/host/reset_scratch.py
         xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
-        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([0, 0, 0.06]) + RB['toc_base']       # scratch_itch.py:97-99
-        xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])
+        if mounted:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([0, 0, 0.06]) + RB['toc_base']       # scratch_itch.py:97-99
+            xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])
+        else:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([-0.85, -0.4, 0]) + RB['toc_base']   # robot.py:142 + toc_base_pos_offset (pr2.py:35)
+            xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = [0, 0, 0, 1]
+            xi[X_['TOC_ATTEMPTS']], xi[X_['TOC_ROUNDS']] = 50, 4                                 # robot.py:123 attempts; reset_scratch.py's four tries
+            xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW_RANGE']] = 0.5, np.deg2rad(30.0)              # random_position, random_rotation (env.py:298)
+            xf[X_['TOC_YAW0']], xf[X_['TOC_X_SIGN']] = 0.0, -1.0                                 # the robot stands on the human's right: x in [-0.5, 0]
+            xi[X_['TOC_IK_ITERS']], xf[X_['TOC_THRESH']] = 100, 0.03                              # max_ik_iterations, success_threshold (robot.py:97)
+            xi[X_['TOC_GOAL_LINKS']:X_['TOC_GOAL_LINKS'] + 3] = [5, 7, 9]                         # shoulder, elbow, wrist (scratch_itch.py:107-109)
         xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])                    # toc_ee_orient_rpy
         xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.6, 0, 0.8], 0.05     # scratch_itch.py:115
         xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [0, 0.03, 0.89], [0, 0.03, 0.86]   # human.py:102

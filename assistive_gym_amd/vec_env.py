@@ -34,8 +34,9 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         return make_arm_states(blob, pool_size, seed=seed, impairment='no_tremor' if impairment == 'random' else impairment,
                                settler=RagdollSettler(pool_size, device), arm_settler=ArmFallSettler(blob, pool_size, device),
                                checker=DeviceCollisionChecker(blob, pool_size, device))[0]
-    if blob.task_kind == L.TASK_SCRATCH_ITCH and blob.meta.get('mount') == 'wheelchair' and sampler == 'device':
-        # a wheelchair-mounted arm (Jaco, Panda): ScratchItchEnv.reset sampled by the device-side reset generator, as for the feeding scenes
+    if blob.task_kind == L.TASK_SCRATCH_ITCH and blob.has_reset_generator and sampler == 'device':
+        # a wheelchair-mounted arm (Jaco, Panda) or a free-standing PR2 / Baxter (base pose search on the device): ScratchItchEnv.reset sampled by
+        # the device-side reset generator, as for the feeding scenes
         st = Stepper(blob, pool_size, device)
         st.sample_reset(seed, impairment=impairment)
         st.synchronize()
@@ -302,13 +303,15 @@ class BedBathingSawyerVecEnv(AssistiveVecEnv):
 
 
 class ScratchItchPR2VecEnv(AssistiveVecEnv):
-    """ScratchItchPR2-v1; coop=True = ScratchItchPR2Human-v1 (BASELINE config 4: 7 + 10 actions, 30 + 34 observations per env)."""
+    """ScratchItchPR2-v1; coop=True = ScratchItchPR2Human-v1 (BASELINE config 4: 7 + 10 actions, 30 + 34 observations per env).
+    reset='pool': a pool sampled once by the device-side reset generator (human, target, base pose search of position_robot_toc with its 50
+    candidate poses one per lane, collision rejection); reset='device': new states every episode; reset='host': the numpy sampler."""
     model = 'scratch_itch_pr2'
 
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
-        assert kw['reset'] != 'device', 'no device-side reset generator for ScratchItchPR2: use a pool'
         super().__init__(n_envs, **kw)
+        assert self.reset_mode != 'device' or self.blob.has_reset_generator, 'no device-side reset generator for this model (the Sawyer needs the pedestal guard of the host sampler): use a pool'
 
 
 class ScratchItchPR2HumanVecEnv(ScratchItchPR2VecEnv):

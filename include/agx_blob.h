@@ -275,7 +275,16 @@ enum {
   AGX_X_REACTIVE_MAXF = 50, /* its force limit before the strength factor (reactive_force, human.py:126)                                                    */
   AGX_X_FLAGS = 51,         /* int: bit 0 = the human's controllable joints stay dynamic whatever the impairment (human.py:108 with a reactive force);
                              * bit 1 = scratch itch: draw the limb and the target on it (scratch_itch.py:134-146; dimensions in AGX_T_SI_LIMB_DIMS) */
-  AGX_X_COUNT = 52
+  /* base pose search of a free-standing robot (Robot.position_robot_toc, robot.py:123-215); TOC_ATTEMPTS = 0: the base is fixed (BASE_POS / BASE_QUAT) */
+  AGX_X_TOC_ATTEMPTS = 52,  /* int: candidate base poses per round (<= 64: one per lane)                                                   */
+  AGX_X_TOC_ROUNDS = 53,    /* int: rounds of new candidates while no candidate reaches the start pose                                   */
+  AGX_X_TOC_POS_RANGE = 54, /* candidate position = BASE_POS + (x, y, 0), x ~ U(0, r) x TOC_X_SIGN, y ~ U(-r, r) (random_position)          */
+  AGX_X_TOC_YAW_RANGE = 55, /* candidate yaw = TOC_YAW0 + U(-r, r) (random_rotation)                                                      */
+  AGX_X_TOC_YAW0 = 56, AGX_X_TOC_X_SIGN = 57,
+  AGX_X_TOC_IK_ITERS = 58,  /* int: damped-least-squares iterations per goal (max_ik_iterations)                                          */
+  AGX_X_TOC_THRESH = 59,    /* a goal counts as reached below this position (start pose: and orientation) error (robot.py:97)             */
+  AGX_X_TOC_GOAL_LINKS = 60,/* int[3]: human tree links whose origins are the position goals besides the start pose (scratch_itch.py:107-109) */
+  AGX_X_COUNT = 64
 };
 enum {
   AGX_XJ_PARENT = 0,     /* int: parent joint (PyBullet link numbering), -1 = base              */

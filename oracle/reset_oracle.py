@@ -29,6 +29,8 @@ S_FRICTION, S_GENDER, S_IMPAIRMENT, S_LIMIT, S_STRENGTH, S_HEAD, S_EE, S_BOWL, S
 S_LIMB, S_TARGET_LEN, S_TARGET_TH = 48, 49, 50          # scratch itch: generate_target (scratch_itch.py:134-146)
 # restart stream slots (+ DoF index)
 R_REST, R_LO, R_HI = 0, 16, 32
+# base pose search (free-standing robots): stream T_STREAM0 + 64 (placement x rounds + round) + candidate
+T_STREAM0, T_X, T_Y, T_YAW, T_REST = 2000, 0, 1, 2, 16
 IMPAIRMENTS = ('none', 'limits', 'weakness', 'tremor')       # human.py:80
 MODE_RANDOM, MODE_NO_TREMOR = -1, -2
 
@@ -38,7 +40,8 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           HBASE_M=21, HBASE_F=24, FOOD_R=27, HEAD_RANGE=28, IK_ITERS=29, IK_DAMP=30, IK_MAXSTEP=31, IK_THRESH=32,
           IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
-          REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, COUNT=52)
+          REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
+          TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, COUNT=64)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, STRIDE=36)
@@ -191,9 +194,9 @@ class ResetOracle:
         return compose(self.xf('HBASE_F' if g else 'HBASE_M', 3), np.array([0, 0, 0, 1.0]), p, q)
 
     # -- robot --------------------------------------------------------------------------------------
-    def arm_fk(self, q):
+    def arm_fk(self, q, base=None):
         narm = self.xi('NARM')
-        pp, pq = self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4)
+        pp, pq = base if base is not None else (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
         pos, axw = [], []
         for d in range(narm):
             assert self.ri(d, 'PARENT') == d - 1 and self.ri(d, 'ACT') == d
@@ -207,31 +210,93 @@ class ResetOracle:
         pe, oe = compose(pp, pq, self.tf('EE_POS', 3), self.tf('EE_QUAT', 4))
         return pe, oe, pos, axw
 
-    def ik(self, q0, lo, hi, target_pos, target_quat):
+    def ik(self, q0, lo, hi, target_pos, target_quat, iters=None, base=None):
+        """damped least squares; target_quat None = position only"""
         narm = self.xi('NARM')
         q = np.array(q0, dtype=np.float64)
         lam2 = self.xf('IK_DAMP') ** 2
         tol, maxstep = self.xf('IK_TOL'), self.xf('IK_MAXSTEP')
-        for _ in range(self.xi('IK_ITERS')):
-            pe, oe, pos, axw = self.arm_fk(q)
+        for _ in range(self.xi('IK_ITERS') if iters is None else iters):
+            pe, oe, pos, axw = self.arm_fk(q, base)
             ep = target_pos - pe
-            qe = qmul(target_quat, np.array([-oe[0], -oe[1], -oe[2], oe[3]]))
-            if qe[3] < 0:
-                qe = -qe
-            er = 2.0 * qe[:3]
+            er = np.zeros(3)
+            if target_quat is not None:
+                qe = qmul(target_quat, np.array([-oe[0], -oe[1], -oe[2], oe[3]]))
+                if qe[3] < 0:
+                    qe = -qe
+                er = 2.0 * qe[:3]
             if np.sqrt(ep @ ep) < tol and np.sqrt(er @ er) < tol:
                 break
             J = np.zeros((6, narm))
             for d in range(narm):
                 J[:3, d] = np.cross(axw[d], pe - pos[d])
                 J[3:, d] = axw[d]
-            y = np.linalg.solve(J @ J.T + lam2 * np.eye(6), np.concatenate([ep, er]))
+            if target_quat is None:
+                J, e = J[:3], ep
+            else:
+                e = np.concatenate([ep, er])
+            y = np.linalg.solve(J @ J.T + lam2 * np.eye(len(e)), e)
             dq = J.T @ y
             step = np.max(np.abs(dq))
             if step > maxstep:
                 dq = dq * (maxstep / step)
             q = np.minimum(np.maximum(q + dq, lo), hi)
         return q
+
+    def jlwki(self, q, base):
+        """joint-limit-weighted kinematic isotropy of an arm pose (robot.py:186-191, 217-228)"""
+        narm = self.xi('NARM')
+        pe, oe, pos, axw = self.arm_fk(q, base)
+        J = np.zeros((6, narm))
+        for d in range(narm):
+            J[:3, d] = np.cross(axw[d], pe - pos[d])
+            J[3:, d] = axw[d]
+        lower = np.array([self.rf(d, 'LOWER') for d in range(narm)], dtype=np.float64)
+        upper = np.array([self.rf(d, 'UPPER') for d in range(narm)], dtype=np.float64)
+        qr = 0.5 * (upper - lower)
+        w = np.maximum(1.0 - np.power(0.5, (qr - np.abs(qr - q + lower)) / (0.05 * qr) + 1.0), 0.001)
+        M = (J * w[None]) @ J.T
+        det = max(np.linalg.det(M), 0.0)
+        return det ** (1.0 / 6.0) / (np.trace(M) / 6.0)
+
+    def toc(self, seed, placement, target_pos, target_quat, goals):
+        """Robot.position_robot_toc (robot.py:123-215) as the device runs it: TOC_ATTEMPTS candidate base poses per round, each solving
+        the start pose and the position goals from random rest poses; -> (ok, base (p, q), start solution, rounds used, goals reached)"""
+        narm, A, rounds = self.xi('NARM'), self.xi('TOC_ATTEMPTS'), self.xi('TOC_ROUNDS')
+        lower = np.array([self.rf(d, 'LOWER') for d in range(narm)], dtype=np.float64)
+        upper = np.array([self.rf(d, 'UPPER') for d in range(narm)], dtype=np.float64)
+        lo, hi = np.where(lower < -1e9, -2 * np.pi, lower), np.where(upper > 1e9, 2 * np.pi, upper)
+        thr, pr, yr = self.xf('TOC_THRESH'), self.xf('TOC_POS_RANGE'), self.xf('TOC_YAW_RANGE')
+        base0 = self.xf('BASE_POS', 3)
+        out = None
+        for rnd in range(rounds):
+            best = None
+            for a in range(A):
+                stream = T_STREAM0 + 64 * (placement * rounds + rnd) + a
+                yaw = self.xf('TOC_YAW0') + (2 * u01(seed, stream, T_YAW) - 1) * yr
+                base = (base0 + np.array([self.xf('TOC_X_SIGN') * pr * u01(seed, stream, T_X), (2 * u01(seed, stream, T_Y) - 1) * pr, 0.0]),
+                        q_axis_angle(np.array([0, 0, 1.0]), yaw))
+                reached, manip, qs = 0, 0.0, None
+                for g in range(4):
+                    q0 = lo + (hi - lo) * np.array([u01(seed, stream, T_REST + 8 * g + d) for d in range(narm)])
+                    tp = target_pos if g == 0 else goals[g - 1]
+                    q = self.ik(q0, lo, hi, tp, target_quat if g == 0 else None, iters=self.xi('TOC_IK_ITERS'), base=base)
+                    pe, oe, _, _ = self.arm_fk(q, base)
+                    hit = np.sqrt((tp - pe) @ (tp - pe)) < thr
+                    if g == 0:
+                        dm, dp = target_quat - oe, target_quat + oe
+                        hit = hit and min(np.sqrt(dm @ dm), np.sqrt(dp @ dp)) < thr
+                        qs = q
+                    if hit:
+                        reached |= 1 << g
+                        manip += self.jlwki(q, base)
+                ngoal = bin(reached).count('1') if reached & 1 else -1
+                if best is None or ngoal > best[0] or (ngoal == best[0] and ngoal > 0 and manip > best[1]):
+                    best = (ngoal, manip, base, qs)
+            out = (best[0] > 0, best[2], best[3], rnd + 1, best[0], best[1])
+            if best[0] > 0:
+                break
+        return out
 
     def restart(self, seed, r, target_pos, target_quat):
         """IK restart r (robot.py:88-99): returns (q, position error, orientation error)"""
@@ -263,8 +328,8 @@ class ResetOracle:
             st, info = self._sample_from(seed, impairment_mode, gender_mode, max_restarts, first)
             if t == tries or not info['ik_ok'] or not self.collides(st):
                 break
-            rejected.append(info['ik_restarts'] - 1)
-            first = info['ik_restarts']
+            rejected.append(first if self.xi('TOC_ATTEMPTS') > 0 else info['ik_restarts'] - 1)
+            first = first + 1 if self.xi('TOC_ATTEMPTS') > 0 else info['ik_restarts']        # base pose search: the next PLACEMENT (env.py:281-308)
         info['rejected_restarts'] = rejected
         return st, info
 
@@ -303,6 +368,13 @@ class ResetOracle:
         n_max = self.xi('IK_RESTARTS') if max_restarts is None else max_restarts
         thr = self.xf('IK_THRESH')
         best, best_d, ok, restarts = None, np.inf, False, 0
+        base = (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
+        toc_info = None
+        if self.xi('TOC_ATTEMPTS') > 0:                                    # a free-standing robot: base pose search instead of IK restarts
+            goals = [self.link_pose(g, int(self.i[self.x0 + X_['TOC_GOAL_LINKS'] + k]), ls, head)[0] for k in range(3)]
+            ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals)
+            best_d, n_max = float(ngoal), 0
+            toc_info = dict(goals_reached=ngoal, manipulability=manip, base_pos=base[0], base_quat=base[1])
         for r in range(n_max):
             restarts = r + 1
             q, dpos, dor = self.restart(seed, r, target_ee, toc)
@@ -325,9 +397,9 @@ class ResetOracle:
         st[S['QT']:S['QT'] + self.ndof] = qfull
         st[S['TREMOR']:S['TREMOR'] + self.nhdof] = tremors
         st[S['TREMOR'] + self.nhdof:S['TREMOR'] + 2 * self.nhdof] = qfull[nr:]
-        st[S['BASE']:S['BASE'] + 3], st[S['BASE'] + 3:S['BASE'] + 7] = self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4)
+        st[S['BASE']:S['BASE'] + 3], st[S['BASE'] + 3:S['BASE'] + 7] = base
         # tool in the hand (tool.py:49-62)
-        pe, oe, _, _ = self.arm_fk(best)
+        pe, oe, _, _ = self.arm_fk(best, base)
         tp, tq = compose(pe, oe, self.tf('TOOL_POS', 3), self.tf('TOOL_QUAT', 4))
         fr = lambda b: S['FREE'] + 13 * b
         for b in range(self.nfree):
@@ -387,4 +459,4 @@ class ResetOracle:
             st[ts:ts + 3] = target_on_arm
             si[ts + 3] = limb
         return st, dict(gender=g, impairment=imp, limit_scale=ls, strength=strength, tremors=tremors, ik_ok=ok,
-                        ik_restarts=restarts, ik_pos_err=best_d, target_ee=target_ee, head=head, limb=limb, target_on_arm=target_on_arm)
+                        ik_restarts=restarts, ik_pos_err=best_d, target_ee=target_ee, head=head, limb=limb, target_on_arm=target_on_arm, toc=toc_info)

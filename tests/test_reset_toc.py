@@ -1,0 +1,127 @@
+"""Device-side reset generator, base pose search: ScratchItchEnv.reset for the free-standing PR2 / Baxter (scratch_itch.py:93-132 with
+Robot.position_robot_toc, robot.py:123-228: 50 candidate base poses, one per lane; IK for the start pose and the three position goals on
+the human's arm per candidate; goals reached, then summed JLWKI decide) -- the kernel source (csrc/agx_reset.h) on the wave emulator and
+through the C ABI on the GPU against its numpy float64 restatement (oracle/reset_oracle.py: own Philox, numpy.linalg solve / det)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import reset_oracle as ro                      # noqa: E402  (test infrastructure)
+from assistive_gym_amd.blob import ModelBlob   # noqa: E402
+from assistive_gym_amd.model import compiler as L   # noqa: E402
+from test_reset_generator import assert_same_record   # noqa: E402
+
+
+@pytest.fixture(scope='module', params=['pr2', 'baxter'])
+def rb(request):
+    from emu_lib import Emu
+    b = ModelBlob.load('scratch_itch_' + request.param)
+    assert b.has_reset_generator and b.meta['mount'] == 'toc'
+    return request.param, b, Emu(b)
+
+
+def _x(blob, key, as_int=False):
+    o = blob.h['OFF_RESET'] + L.X_[key]
+    return int(blob.i[o]) if as_int else float(blob.f[o])
+
+
+@pytest.mark.parametrize('seed', [77, (1 << 33) + 5])
+def test_emulated_kernel_matches_oracle(rb, seed):
+    name, blob, emu = rb
+    o = ro.with_collision_check(blob.words)
+    st, info = o.sample(seed)
+    se, ie = emu.sample(seed)
+    assert_same_record(blob, st, se, '%s seed %d' % (name, seed))
+    assert info['ik_ok'] and bool(ie[0]) and int(ie[1]) == info['ik_restarts'] and int(ie[2]) == info['toc']['goals_reached'] >= 1
+    v = blob.view(st.reshape(1, -1))
+    # the chosen base lies in the sampled box on the human's right, turned by at most 30 degrees (robot.py:142-146, env.py:298)
+    base0 = blob.f[blob.h['OFF_RESET'] + L.X_['BASE_POS']:blob.h['OFF_RESET'] + L.X_['BASE_POS'] + 3].astype(np.float64)
+    d = v['base'][0, :3] - base0
+    assert -0.5 <= d[0] <= 1e-6 and abs(d[1]) <= 0.5 + 1e-6 and abs(d[2]) < 1e-6
+    assert abs(2 * np.arctan2(v['base'][0, 5], v['base'][0, 6])) <= np.deg2rad(30) + 1e-6 and v['base'][0, 3] == 0 and v['base'][0, 4] == 0
+    # the start pose is reached: the end effector sits within the threshold of the drawn start position
+    from oracle_lib import Oracle
+    ee, _ = Oracle(blob).ee_pose(st.copy())
+    assert np.linalg.norm(ee - info['target_ee']) < 0.03
+
+
+def test_nobody_reaches_the_start_pose(rb):
+    """a threshold no candidate can meet: all four rounds are spent, the record is still a valid world (candidate 0 of the last round)"""
+    from emu_lib import Emu
+    name, blob, _ = rb
+    w = blob.words.copy(); w.view(np.float32)[blob.h['OFF_RESET'] + L.X_['TOC_THRESH']] = 1e-12
+    w.view(np.int32)[blob.h['OFF_RESET'] + L.X_['TOC_ATTEMPTS']] = 6                 # (six candidates: keeps the numpy side quick)
+    b = ModelBlob(w, blob.meta)
+    st, info = ro.ResetOracle(b.words).sample(5)
+    se, ie = Emu(b).sample(5)
+    assert not info['ik_ok'] and info['ik_restarts'] == 4 and not bool(ie[0]) and int(ie[1]) == 4
+    assert_same_record(b, st, se)
+    assert np.isfinite(st).all()
+
+
+def test_a_colliding_placement_is_drawn_again(rb):
+    """with the collision verdict forced to "collides" once, the second placement uses its own streams: another base pose"""
+    name, blob, emu = rb
+    calls = []
+
+    def collides(st):
+        calls.append(1)
+        return len(calls) == 1
+    o = ro.ResetOracle(blob.words, collides)
+    st, info = o.sample(123)
+    plain, _ = ro.ResetOracle(blob.words).sample(123)
+    assert info['rejected_restarts'] == [0] and len(calls) == 2
+    v0, v1 = blob.view(plain.reshape(1, -1)), blob.view(st.reshape(1, -1))
+    assert not np.array_equal(v0['base'], v1['base']) and np.array_equal(v0['human'], v1['human'])
+
+
+@pytest.mark.gpu
+def test_gpu_base_pose_search_matches_oracle():
+    import torch
+    from assistive_gym_amd import libagx
+    from assistive_gym_amd.libagx import Stepper
+    if libagx.load().agx_device_count() <= 0:
+        __import__('conftest').no_gpu()
+    blob = ModelBlob.load('scratch_itch_pr2')
+    o = ro.with_collision_check(blob.words)
+    n = 6
+    st = Stepper(blob, n)
+    info = torch.zeros((n, 4), device='cuda')
+    st.sample_reset(9001, ik_info=info)
+    st.synchronize()
+    got, gi = st.get_state(), info.cpu().numpy()
+    for i in range(n):
+        so, io = o.sample(9001 + i)
+        assert_same_record(blob, so, got[i], 'env %d' % i)
+        assert bool(gi[i, 0]) == io['ik_ok'] and int(gi[i, 1]) == io['ik_restarts']
+    st.close()
+
+
+@pytest.mark.gpu
+def test_gpu_config4_resets_on_the_device():
+    """ScratchItchPR2Human-v1 (BASELINE config 4) with reset='device': every episode of every environment starts from a newly sampled human,
+    target and robot placement (VERDICT r2 item 5 for this config); the batch keeps stepping across the boundary"""
+    import torch
+    from assistive_gym_amd import libagx
+    from assistive_gym_amd.vec_env import ScratchItchPR2HumanVecEnv
+    if libagx.load().agx_device_count() <= 0:
+        __import__('conftest').no_gpu()
+    n = 64
+    env = ScratchItchPR2HumanVecEnv(n, reset='device', seed=21)
+    obs = env.reset()
+    first = env.stepper.get_state().copy()
+    v0 = env.blob.view(first)
+    assert torch.isfinite(obs).all() and len(np.unique(np.round(v0['base'][:, 0], 5))) > n // 2          # placements differ between environments
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    for k in range(200):
+        obs, rew, done, info = env.step(torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1)
+        assert bool(done.all()) == (k == 199)
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    v1 = env.blob.view(env.stepper.get_state())
+    assert (np.abs(v1['base'][:, :2] - v0['base'][:, :2]).max(axis=1) > 1e-4).all()                      # a NEW placement for every environment
+    assert (v1['iteration'] == 0).all()
+    env.close()
