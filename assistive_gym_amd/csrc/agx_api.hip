@@ -45,6 +45,28 @@ agx_reset_cloth_kernel(float* cloth, const float* pool, int pool_n, const uint8_
   for (int k = threadIdx.x; k < cw; k += 256) cloth[(size_t)env * cw + k] = src[k];
 }
 
+// models with a cloth, device-side reset: the garment of a freshly sampled environment is the loaded mesh shifted to the end effector
+// (dressing.py:146-153: x = X0 + offset; the reset generator left the offset in the task words, AGX_DR_CLOTH_OFF), at rest
+extern "C" __global__ void __launch_bounds__(256)
+agx_place_cloth_kernel(float* cloth, const float* state, const uint32_t* blob, const uint8_t* mask, int n_envs, int sw, int cw) {
+  const int env = blockIdx.x;
+  if (env >= n_envs || (mask && !mask[env])) return;
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  const int oc = bi[AGX_H_OFF_CLOTH]; const int nn = bi[oc + AGX_CL_NN];
+  const float* x0 = bf + oc + bi[oc + AGX_CL_OFF_X0];
+  const float* off = state + (size_t)env * sw + bi[AGX_H_S_TASK] + AGX_DR_CLOTH_OFF;
+  float* c = cloth + (size_t)env * cw;
+  for (int k = threadIdx.x; k < 3 * nn; k += 256) { c[k] = x0[k] + off[k % 3]; c[3 * nn + k] = 0.f; }
+}
+// ... and when the settle of reset() is over the garment feels full gravity (dressing.py:195)
+extern "C" __global__ void __launch_bounds__(64)
+agx_cloth_gravity_kernel(float* state, const uint32_t* blob, const uint8_t* mask, int n_envs, int sw) {
+  const int env = blockIdx.x * 64 + threadIdx.x;
+  if (env >= n_envs || (mask && !mask[env])) return;
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  state[(size_t)env * sw + bi[AGX_H_S_TASK] + AGX_DR_CLOTH_GRAVITY] = bf[bi[AGX_H_OFF_RESET] + AGX_X_CLOTH_GRAVITY];
+}
+
 extern "C" __global__ void __launch_bounds__(64) agx_selftest_kernel(float* out_f, int* out_i, unsigned long long* out_m) {
   const int lane = wave_lane();
   float x = (float)(lane * lane % 17) * 0.25f - 1.0f;
@@ -370,6 +392,10 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
                  gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev);
     HIPCHK(hipGetLastError());
   }
+  if (h->cloth_dev) {      // the garment goes where the sampled end effector is
+    hipLaunchKernelGGL(agx_place_cloth_kernel, dim3(h->n_envs), dim3(256), 0, st, h->cloth_dev, h->state_dev, h->blob_dev, mask_dev, h->n_envs, h->sw, h->cloth_words);
+    HIPCHK(hipGetLastError());
+  }
   return AGX_OK;
 }
 int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {
@@ -383,6 +409,10 @@ int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, 
   h->active = mask_dev;   // the settle substeps touch the masked environments only
   rc = launch_chunked(h, settle_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
   h->active = nullptr;
+  if (!rc && h->cloth_dev) {
+    hipLaunchKernelGGL(agx_cloth_gravity_kernel, dim3((h->n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->state_dev, h->blob_dev, mask_dev, h->n_envs, h->sw);
+    HIPCHK(hipGetLastError());
+  }
   return rc;
 }
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {

@@ -337,8 +337,8 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     // `first_restart` counts the placements that collided so far (env.py:281-308 re-draws the placement): every placement has its own streams.
     const int rounds = XI(c, AGX_X_TOC_ROUNDS), titers = XI(c, AGX_X_TOC_IK_ITERS);
     const double tthr = XF(c, AGX_X_TOC_THRESH), prange = XF(c, AGX_X_TOC_POS_RANGE), yrange = XF(c, AGX_X_TOC_YAW_RANGE);
-    d3 goals[3];
-    for (int k = 0; k < 3; k++) { dq gq; rs_link_pose(c, XI(c, AGX_X_TOC_GOAL_LINKS + k), goals[k], gq); }
+    d3 goals[3]; const bool goal_orient = XI(c, AGX_X_TOC_GOAL_ORIENT) != 0;
+    for (int k = 0; k < 3; k++) { dq gq; rs_link_pose(c, XI(c, AGX_X_TOC_GOAL_LINKS + k), goals[k], gq); goals[k] = goals[k] + dld3(c.xf + AGX_X_TOC_GOAL_OFF); }
     const d3 base0 = dld3(c.xf + AGX_X_BASE_POS);
     restarts = 0;
     for (int round = 0; round < rounds && !ok; round++) {
@@ -363,14 +363,18 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
 #pragma unroll
           for (int d = 0; d < RS_NARM; d++) q[d] = lo[d] + (hi[d] - lo[d]) * rs_u01(seed_lo, seed_hi, stream, RS_T_REST + 8 * g + d);     // agent.py:263
           const d3 tp = g == 0 ? tpos : goals[g - 1];
-          if (g == 0) rs_ik<true>(c, q, lo, hi, tp, tquat, titers); else rs_ik<false>(c, q, lo, hi, tp, tquat, titers);
+          const bool orient = g == 0 || goal_orient;
+          const dq tq = g == 0 ? tquat : dld4(c.xf + AGX_X_TOC_GOAL_QUAT + 4 * (g - 1));
+          if (orient) rs_ik<true>(c, q, lo, hi, tp, tq, titers); else rs_ik<false>(c, q, lo, hi, tp, tq, titers);
           d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
           rs_arm_fk(c, q, pos, axw, pe, oe);
           bool hit = sqrt(ddot(tp - pe, tp - pe)) < tthr;                                                          // robot.py:97
-          if (g == 0) {
-            const double mx = tquat.x - oe.x, my = tquat.y - oe.y, mz = tquat.z - oe.z, mw = tquat.w - oe.w;
-            const double px = tquat.x + oe.x, py = tquat.y + oe.y, pz = tquat.z + oe.z, pw = tquat.w + oe.w;
+          if (orient) {
+            const double mx = tq.x - oe.x, my = tq.y - oe.y, mz = tq.z - oe.z, mw = tq.w - oe.w;
+            const double px = tq.x + oe.x, py = tq.y + oe.y, pz = tq.z + oe.z, pw = tq.w + oe.w;
             hit = hit && fmin(sqrt(mx * mx + my * my + mz * mz + mw * mw), sqrt(px * px + py * py + pz * pz + pw * pw)) < tthr;
+          }
+          if (g == 0) {
 #pragma unroll
             for (int d = 0; d < RS_NARM; d++) qs[d] = q[d];
           }
@@ -516,7 +520,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     ei[AGX_E_ITERATION] = 0; ei[AGX_E_TASK_SUCCESS] = 0;
     ei[AGX_E_RNG] = (int)((seed * 2654435761ull + 12345ull) & 0x7FFFFFFFull);
     ei[AGX_E_RNG + 1] = (int)((seed ^ 0x5bd1e995ull) & 0x7FFFFFFFull);
-    ei[AGX_E_TOTAL_FOOD] = (xflags & 2) ? 1 : nfood;               // scratch itch: task_success >= 1 x task_success_threshold (scratch_itch.py:37)
+    ei[AGX_E_TOTAL_FOOD] = (xflags & 6) ? 1 : nfood;               // scratch itch, dressing: task_success >= 1 x task_success_threshold (scratch_itch.py:37)
     const bool coop = ((const int*)c.task)[AGX_T_COOP] == 1;
     const bool agent = imp == RS_IMP_TREMOR || coop;                // then take_step drives the human's motors (env.py:130-131)
     ei[AGX_E_FROZEN] = (agent || (xflags & 1)) ? 0 : (((1 << nhdof) - 1) << nrobot);                          // human.py:104-110
@@ -533,6 +537,12 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
       float* tw = gstate + c.bi[AGX_H_S_TASK];
       tw[AGX_SI_TARGET] = (float)(-radius * sin(th)); tw[AGX_SI_TARGET + 1] = (float)(-radius * cos(th)); tw[AGX_SI_TARGET + 2] = (float)(-rl);
       ((int*)tw)[AGX_SI_LIMB] = limb;
+    }
+    if (xflags & 4) {   // dressing: the garment is loaded shifted to the end effector and settles under half gravity (dressing.py:146-149,178)
+      float* tw = gstate + c.bi[AGX_H_S_TASK];
+      tw[AGX_DR_CLOTH_GRAVITY] = c.xf[AGX_X_CLOTH_GRAVITY_SETTLE];
+      tw[AGX_DR_CLOTH_OFF] = (float)(pe.x - XF(c, AGX_X_CLOTH_ORIG_POS)); tw[AGX_DR_CLOTH_OFF + 1] = (float)(pe.y - XF(c, AGX_X_CLOTH_ORIG_POS + 1));
+      tw[AGX_DR_CLOTH_OFF + 2] = (float)(pe.z - XF(c, AGX_X_CLOTH_ORIG_POS + 2));
     }
     if (ginfo) { ginfo[0] = (float)ok; ginfo[1] = (float)restarts; ginfo[2] = (float)best_d; ginfo[3] = (float)imp; }
   }

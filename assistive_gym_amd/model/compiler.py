@@ -53,7 +53,8 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
-          TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, COUNT=64)
+          TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, COUNT=84)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
          TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, HUMAN_KP=14, HUMAN_MAXF=15, COUNT=16)
@@ -63,7 +64,7 @@ HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.p
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8, BED=9)
 TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH, TASK_DRESSING, TASK_ARM_MANIPULATION = 0, 1, 2, 3, 4
 AM = dict(BEST=0, WORDS=12)   # arm manipulation task words (AGX_AM_*)
-DR = dict(CLOTH_GRAVITY=0, FORCE_SUM=1, BEST=2, WORDS=12)   # dressing task words (AGX_DR_*)
+DR = dict(CLOTH_GRAVITY=0, FORCE_SUM=1, BEST=2, CLOTH_OFF=3, WORDS=12)   # dressing task words (AGX_DR_*)
 # cloth section (AGX_CL_*, AGX_CP_*)
 CL = dict(NN=0, NL=1, NCOLOR=2, NANCHOR=3, NSHAPE=4, OFF_COLOR=5, OFF_LINK=6, OFF_NODE=7, OFF_FACE=8, OFF_X0=9, OFF_ANCHOR=10, OFF_SHAPE=11,
           OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, OFF_PERM=21, NPATCH_COLOR=22, HDR=24)
@@ -1237,29 +1238,34 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
         xi[X_['BOWL_BODY']] = -1
         xi[X_['COLLISION_TRIES']] = 3                                                        # env.py:276 max_iterations
         xf[X_['REACTIVE_KP']], xf[X_['REACTIVE_MAXF']], xi[X_['FLAGS']] = 0.01, 1.0, 3         # scratch_itch.py:105
-        oj = X_['COUNT']
-        ob = oj + 2 * 42 * XJ['STRIDE']
-        od = ob + nhuman
-        xi[X_['OFF_JOINTS']], xi[X_['OFF_BODIES']], xi[X_['OFF_DYN']] = oj, ob, od
-        preset = {3: 30, 6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}                  # scratch_itch.py:104
-        for g, gender in enumerate(('male', 'female')):
-            hm1, hm2 = HumanModel(gender, 1.0), HumanModel(gender, 0.5)
-            for j in range(42):
-                b0 = oj + (g * 42 + j) * XJ['STRIDE']
-                xi[b0 + XJ['PARENT']] = hm1.parent[j]
-                xf[b0 + XJ['OFF']:b0 + XJ['OFF'] + 3] = hm1.offset[j]
-                xf[b0 + XJ['AXIS']:b0 + XJ['AXIS'] + 3] = hm1.axis[j]
-                xf[b0 + XJ['LOWER']], xf[b0 + XJ['UPPER']] = hm1.lower[j], hm1.upper[j]
-                scaled = hm1.lower[j] != hm2.lower[j] or hm1.upper[j] != hm2.upper[j]
-                xi[b0 + XJ['FLAGS']] = (1 if hm1.jtype[j] == 'r' else 0) | (2 if scaled else 0)
-                xf[b0 + XJ['PRESET']] = np.deg2rad(preset.get(j, 0.0))
-                xi[b0 + XJ['DRAW']] = -1
-        xi[ob:ob + nhuman] = human_bodies
-        xi[od:od + nhdof] = hd
+        fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {3: 30, 6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80})   # scratch_itch.py:104
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=23 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_SCRATCH_ITCH), reset_fill, reset_words,
                 task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot, mount=RB['mount'],
                                                                  toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
+
+
+def fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, preset, cloth=False):
+    """the posed-human part of a reset section (AGX_X_OFF_JOINTS / OFF_BODIES / OFF_DYN): the 42-joint tree of both genders with the
+    task's preset angles (degrees), the links of the static collision bodies and the joints behind the human DoFs; no drawn joints"""
+    oj = X_['COUNT']
+    ob = oj + 2 * 42 * XJ['STRIDE']
+    od = ob + nhuman
+    xi[X_['OFF_JOINTS']], xi[X_['OFF_BODIES']], xi[X_['OFF_DYN']] = oj, ob, od
+    for g, gender in enumerate(('male', 'female')):
+        hm1, hm2 = HumanModel(gender, 1.0, cloth=cloth), HumanModel(gender, 0.5, cloth=cloth)
+        for j in range(42):
+            b0 = oj + (g * 42 + j) * XJ['STRIDE']
+            xi[b0 + XJ['PARENT']] = hm1.parent[j]
+            xf[b0 + XJ['OFF']:b0 + XJ['OFF'] + 3] = hm1.offset[j]
+            xf[b0 + XJ['AXIS']:b0 + XJ['AXIS'] + 3] = hm1.axis[j]
+            xf[b0 + XJ['LOWER']], xf[b0 + XJ['UPPER']] = hm1.lower[j], hm1.upper[j]
+            scaled = hm1.lower[j] != hm2.lower[j] or hm1.upper[j] != hm2.upper[j]
+            xi[b0 + XJ['FLAGS']] = (1 if hm1.jtype[j] == 'r' else 0) | (2 if scaled else 0)
+            xf[b0 + XJ['PRESET']] = np.deg2rad(preset.get(j, 0.0))
+            xi[b0 + XJ['DRAW']] = -1
+    xi[ob:ob + nhuman] = human_bodies
+    xi[od:od + nhdof] = hd
 
 
 def compile_dressing_baxter(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
@@ -1350,11 +1356,49 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
                                  sc.colliders, shape_ids,
                                  gender_of=lambda ci: 1 if r['human_male'][0] <= ci < r['human_male'][1] else (2 if r['human_female'][0] <= ci < r['human_female'][1] else 0))
 
+    # DressingEnv.reset on the device (csrc/agx_reset.h; dressing.py:112-198): seated human with the left arm raised, the robot on the
+    # human's LEFT -- a wheelchair-mounted arm by IK restarts, Baxter / PR2 by the base pose search with oriented goals 10 cm above
+    # shoulder / elbow / wrist (dressing.py:132) --, the garment shifted to the end effector, settle gravity on the cloth.  The Sawyer keeps
+    # the host sampler (pedestal guard).
+    mounted = RB['wheelchair_mounted']
+    generator = mounted or robot in ('baxter', 'pr2')
+
     def reset_words(nhuman, nhdof):
-        return X_['COUNT']
+        return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if generator else 0)
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        pass        # the pool comes from assistive_gym_amd/host/reset_dressing.py
+        if not generator:
+            return      # the pool comes from assistive_gym_amd/host/reset_dressing.py
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
+        if mounted:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([0, 0, 0.06]) + RB['toc_base']       # dressing.py:116-118
+            xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, np.pi / 2.0])
+        else:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([-0.85, -0.4, 0]) + RB['toc_base']   # robot.py:142 + toc_base_pos_offset (baxter.py:39)
+            xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = [0, 0, 0, 1]
+            xi[X_['TOC_ATTEMPTS']], xi[X_['TOC_ROUNDS']] = 50, 4
+            xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW_RANGE']] = 0.5, np.deg2rad(30.0)
+            xf[X_['TOC_YAW0']], xf[X_['TOC_X_SIGN']] = np.pi, 1.0                                # on the human's left, turned by pi (env.py:298, robot.py:143)
+            xi[X_['TOC_IK_ITERS']], xf[X_['TOC_THRESH']] = 100, 0.03
+            xi[X_['TOC_GOAL_LINKS']:X_['TOC_GOAL_LINKS'] + 3] = [15, 17, 19]                      # left shoulder, elbow, wrist (dressing.py:126-128)
+            xi[X_['TOC_GOAL_ORIENT']] = 1
+            xf[X_['TOC_GOAL_OFF']:X_['TOC_GOAL_OFF'] + 3] = [0, 0, 0.1]                           # dressing.py:132
+            for k, rpy in enumerate((RB['ee_rpy_shoulder'], RB['ee_rpy'], RB['ee_rpy'])):         # toc_ee_orient_rpy[-1] at the shoulder, [0] else
+                xf[X_['TOC_GOAL_QUAT'] + 4 * k:X_['TOC_GOAL_QUAT'] + 4 * k + 4] = X.quat_from_rpy(rpy)
+        xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])
+        xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [0.45, -0.3, 1], 0.05      # dressing.py:130
+        xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [0, 0.03, 0.89], [0, 0.03, 0.86]   # human.py:102
+        xf[X_['HEAD_RANGE']] = 0.0
+        xi[X_['IK_ITERS']], xf[X_['IK_DAMP']], xf[X_['IK_MAXSTEP']], xf[X_['IK_TOL']] = 200, 0.05, 0.5, 1e-4
+        xf[X_['IK_THRESH']], xi[X_['IK_RESTARTS']], xi[X_['IK_RANDLIM_FROM']] = 0.01, 1000, 10
+        xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5
+        xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(10.0)
+        xi[X_['BOWL_BODY']] = -1
+        xi[X_['COLLISION_TRIES']] = 3
+        xf[X_['REACTIVE_KP']], xf[X_['REACTIVE_MAXF']], xi[X_['FLAGS']] = 0.01, 1.0, 1 | 4       # dressing.py:124; bit 2: the garment words
+        xf[X_['CLOTH_GRAVITY_SETTLE']], xf[X_['CLOTH_GRAVITY']] = -9.81 / 2, -9.81               # dressing.py:178,195
+        xf[X_['CLOTH_ORIG_POS']:X_['CLOTH_ORIG_POS'] + 3] = cloth_orig_pos
+        fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {6: -90, 13: -45, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}, cloth=True)   # dressing.py:123
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, [], params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRESSING), reset_fill, reset_words,
                 task_words=DR['WORDS'], mlp=mlp, cloth=cloth, sim_substeps=8,

@@ -13,6 +13,7 @@ from .libagx import Stepper
 from .shard import episode_seed, pool_indices
 
 SETTLE_STEPS = 25   # feeding.py:178-179
+DRESSING_SETTLE_STEPS = 50   # dressing.py:186-187
 
 
 def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device', _depth=0):
@@ -47,6 +48,15 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         from .host.reset_scratch import make_states as make_scratch_states
         from .host.reset_bed import DeviceCollisionChecker
         return make_scratch_states(blob, pool_size, seed=seed, impairment=impairment, checker=DeviceCollisionChecker(blob, pool_size, device))[0]
+    if blob.task_kind == L.TASK_DRESSING and blob.has_reset_generator and sampler == 'device':
+        # DressingEnv.reset on the device: sampling (base pose search for Baxter / PR2), the garment at the end effector, the 50-step settle
+        # under half gravity, full gravity afterwards -- all inside agx_reset
+        st = Stepper(blob, pool_size, device)
+        st.reset(None, None, seed, impairment=impairment, settle_substeps=DRESSING_SETTLE_STEPS)
+        st.synchronize()
+        out = st.get_state(), st.get_cloth()
+        st.close()
+        return out
     if blob.task_kind == L.TASK_DRESSING:
         # DressingEnv.reset restated on the host (host/reset_dressing.py) around the 50-step cloth settle on the device;
         # returns (states, garments): the garment of a pool entry travels with its state record
@@ -180,7 +190,8 @@ class AssistiveVecEnv:
         sampled from episode_seed(seed, e, env_offset) + i -- a function of the GLOBAL env index and the episode only,
         i.e. independent of the number of GPUs the batch is spread over -- and settled for 25 substeps"""
         from .model import compiler as L
-        settle = SETTLE_STEPS if self.blob.task_kind == L.TASK_FEEDING else 0      # ScratchItchEnv.reset has no settle loop
+        # FeedingEnv.reset: 25 steps for the food to drop; DressingEnv.reset: 50 for the garment; ScratchItchEnv.reset has no settle loop
+        settle = {L.TASK_FEEDING: SETTLE_STEPS, L.TASK_DRESSING: DRESSING_SETTLE_STEPS}.get(self.blob.task_kind, 0)
         self.stepper.reset(mask, None, episode_seed(self.seed, self._episode, self.env_offset), impairment=self.impairment,
                            settle_substeps=settle, stream=s)
         self._episode += 1
@@ -367,14 +378,16 @@ _vec_flavour(ArmManipulationSawyerVecEnv, 'ArmManipulationBaxterVecEnv', 'arm_ma
 
 class DressingBaxterVecEnv(AssistiveVecEnv):
     """BASELINE config 5: DressingBaxter-v1 (dressing_envs.py:19-21).  Every environment carries a garment of 3,966 nodes next to its
-    state record; resets come from a pool of (state, settled garment) pairs built once (host/reset_dressing.py + the device settle)."""
+    state record.  reset='pool': (state, settled garment) pairs generated once on the device (sampling incl. the base pose search, the
+    garment at the end effector, the 50-step settle: agx_reset); reset='device': every episode of every environment starts from a newly
+    sampled and settled state; reset='host': the numpy sampler of host/reset_dressing.py around the device settle."""
     model = 'dressing_baxter'
 
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
         kw.setdefault('pool_size', 64)
-        assert kw['reset'] != 'device', 'no device-side reset generator for DressingBaxter: use a pool'
         super().__init__(n_envs, **kw)
+        assert self.reset_mode != 'device' or self.blob.has_reset_generator, 'no device-side reset generator for this model (the Sawyer needs the pedestal guard of the host sampler): use a pool'
 
 
 class DressingBaxterHumanVecEnv(DressingBaxterVecEnv):

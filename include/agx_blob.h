@@ -274,7 +274,8 @@ enum {
   AGX_X_REACTIVE_KP = 49,   /* gain of the reactive hold of a human that is not an agent (setup_joints reactive_gain, scratch_itch.py:105); 0 = none (Feeding) */
   AGX_X_REACTIVE_MAXF = 50, /* its force limit before the strength factor (reactive_force, human.py:126)                                                    */
   AGX_X_FLAGS = 51,         /* int: bit 0 = the human's controllable joints stay dynamic whatever the impairment (human.py:108 with a reactive force);
-                             * bit 1 = scratch itch: draw the limb and the target on it (scratch_itch.py:134-146; dimensions in AGX_T_SI_LIMB_DIMS) */
+                             * bit 1 = scratch itch: draw the limb and the target on it (scratch_itch.py:134-146; dimensions in AGX_T_SI_LIMB_DIMS);
+                             * bit 2 = dressing: settle gravity and garment offset into the task words (AGX_DR_CLOTH_GRAVITY, AGX_DR_CLOTH_OFF) */
   /* base pose search of a free-standing robot (Robot.position_robot_toc, robot.py:123-215); TOC_ATTEMPTS = 0: the base is fixed (BASE_POS / BASE_QUAT) */
   AGX_X_TOC_ATTEMPTS = 52,  /* int: candidate base poses per round (<= 64: one per lane)                                                   */
   AGX_X_TOC_ROUNDS = 53,    /* int: rounds of new candidates while no candidate reaches the start pose                                   */
@@ -283,8 +284,14 @@ enum {
   AGX_X_TOC_YAW0 = 56, AGX_X_TOC_X_SIGN = 57,
   AGX_X_TOC_IK_ITERS = 58,  /* int: damped-least-squares iterations per goal (max_ik_iterations)                                          */
   AGX_X_TOC_THRESH = 59,    /* a goal counts as reached below this position (start pose: and orientation) error (robot.py:97)             */
-  AGX_X_TOC_GOAL_LINKS = 60,/* int[3]: human tree links whose origins are the position goals besides the start pose (scratch_itch.py:107-109) */
-  AGX_X_COUNT = 64
+  AGX_X_TOC_GOAL_LINKS = 60,/* int[3]: human tree links whose origins (+ TOC_GOAL_OFF) are the goals besides the start pose (scratch_itch.py:107-109, dressing.py:126-132) */
+  AGX_X_TOC_GOAL_ORIENT = 63, /* int: 1 = the goals carry the end-effector orientations TOC_GOAL_QUAT (dressing.py:132), 0 = position only        */
+  AGX_X_TOC_GOAL_OFF = 64,  /* float[3] offset added to every goal position                                                                */
+  AGX_X_CLOTH_GRAVITY_SETTLE = 67, /* dressing (FLAGS bit 2): gravity on the garment during the settle of reset() (dressing.py:178) ...          */
+  AGX_X_CLOTH_GRAVITY = 68,        /* ... and afterwards (dressing.py:195): agx_reset writes it when its settle is over                       */
+  AGX_X_CLOTH_ORIG_POS = 69,/* float[3]: the garment is loaded shifted by (end effector position - this) (dressing.py:146-149)              */
+  AGX_X_TOC_GOAL_QUAT = 72, /* float[3][4]                                                                                                  */
+  AGX_X_COUNT = 84
 };
 enum {
   AGX_XJ_PARENT = 0,     /* int: parent joint (PyBullet link numbering), -1 = base              */
@@ -337,6 +344,8 @@ enum { AGX_AM_BEST = 0, AGX_AM_WORDS = 12 };
 enum { AGX_DR_CLOTH_GRAVITY = 0, /* float: world gravity z acting on the cloth: -9.81 / 2 while it settles in reset, then -9.81 (dressing.py:178,195) */
        AGX_DR_FORCE_SUM = 1,     /* float: cloth_force_sum of the last step (dressing.py:96), an observation input                                */
        AGX_DR_BEST = 2,          /* float: self.task_success, the best reward_dressing so far (dressing.py:62-63)                                 */
+       AGX_DR_CLOTH_OFF = 3,     /* float[3]: offset of the garment's load position, written by the device-side reset generator for the launch that
+                                    places the garment (x = X0 + offset); unused afterwards                                                      */
        AGX_DR_WORDS = 12 };
 
 /* ---- CLOTH section (offset AGX_H_OFF_CLOTH): the garment of DressingEnv.reset (dressing.py:153-154: p.loadCloth of

@@ -41,7 +41,8 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           IK_RESTARTS=33, IK_TOL=34, IK_RANDLIM_FROM=35, FRIC_LO=36, FRIC_HI=37, LIMIT_LO=38, TREMOR_RANGE=39,
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
-          TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, COUNT=64)
+          TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, COUNT=84)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, STRIDE=36)
@@ -259,7 +260,7 @@ class ResetOracle:
         det = max(np.linalg.det(M), 0.0)
         return det ** (1.0 / 6.0) / (np.trace(M) / 6.0)
 
-    def toc(self, seed, placement, target_pos, target_quat, goals):
+    def toc(self, seed, placement, target_pos, target_quat, goals, goal_quats=None):
         """Robot.position_robot_toc (robot.py:123-215) as the device runs it: TOC_ATTEMPTS candidate base poses per round, each solving
         the start pose and the position goals from random rest poses; -> (ok, base (p, q), start solution, rounds used, goals reached)"""
         narm, A, rounds = self.xi('NARM'), self.xi('TOC_ATTEMPTS'), self.xi('TOC_ROUNDS')
@@ -280,12 +281,14 @@ class ResetOracle:
                 for g in range(4):
                     q0 = lo + (hi - lo) * np.array([u01(seed, stream, T_REST + 8 * g + d) for d in range(narm)])
                     tp = target_pos if g == 0 else goals[g - 1]
-                    q = self.ik(q0, lo, hi, tp, target_quat if g == 0 else None, iters=self.xi('TOC_IK_ITERS'), base=base)
+                    tq = target_quat if g == 0 else (goal_quats[g - 1] if goal_quats is not None else None)
+                    q = self.ik(q0, lo, hi, tp, tq, iters=self.xi('TOC_IK_ITERS'), base=base)
                     pe, oe, _, _ = self.arm_fk(q, base)
                     hit = np.sqrt((tp - pe) @ (tp - pe)) < thr
-                    if g == 0:
-                        dm, dp = target_quat - oe, target_quat + oe
+                    if tq is not None:
+                        dm, dp = tq - oe, tq + oe
                         hit = hit and min(np.sqrt(dm @ dm), np.sqrt(dp @ dp)) < thr
+                    if g == 0:
                         qs = q
                     if hit:
                         reached |= 1 << g
@@ -371,8 +374,9 @@ class ResetOracle:
         base = (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
         toc_info = None
         if self.xi('TOC_ATTEMPTS') > 0:                                    # a free-standing robot: base pose search instead of IK restarts
-            goals = [self.link_pose(g, int(self.i[self.x0 + X_['TOC_GOAL_LINKS'] + k]), ls, head)[0] for k in range(3)]
-            ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals)
+            goals = [self.link_pose(g, int(self.i[self.x0 + X_['TOC_GOAL_LINKS'] + k]), ls, head)[0] + self.xf('TOC_GOAL_OFF', 3) for k in range(3)]
+            gq = [self.f[self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k:self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k + 4].astype(np.float64) for k in range(3)] if self.xi('TOC_GOAL_ORIENT') else None
+            ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals, gq)
             best_d, n_max = float(ngoal), 0
             toc_info = dict(goals_reached=ngoal, manipulability=manip, base_pos=base[0], base_quat=base[1])
         for r in range(n_max):
@@ -404,13 +408,16 @@ class ResetOracle:
         fr = lambda b: S['FREE'] + 13 * b
         for b in range(self.nfree):
             st[fr(b) + 6] = 1.0
-        fo = int(self.i[H_OFF_FREE]) + self.tool_body * F['STRIDE']
+        if self.nfree == 0:                                                # dressing: no tool, no free bodies
+            self.tool_body = -1
+        fo = int(self.i[H_OFF_FREE]) + max(self.tool_body, 0) * F['STRIDE']
         refp, refq = self.f[fo + F['REFPOS']:fo + F['REFPOS'] + 3].astype(np.float64), self.f[fo + F['REFQUAT']:fo + F['REFQUAT'] + 4].astype(np.float64)
         cp, cq = tp, tq
         if np.any(refp != 0) or refq[3] != 1:                              # a welded tool (scratcher): the record holds the COM frame
             qi = np.array([-refq[0], -refq[1], -refq[2], refq[3]])
             cp, cq = compose(tp, tq, -qrot(qi, refp), qi)
-        st[fr(self.tool_body):fr(self.tool_body) + 3], st[fr(self.tool_body) + 3:fr(self.tool_body) + 7] = cp, cq
+        if self.tool_body >= 0:
+            st[fr(self.tool_body):fr(self.tool_body) + 3], st[fr(self.tool_body) + 3:fr(self.tool_body) + 7] = cp, cq
         # bowl (furniture.py:32-34): base frame -> COM frame
         bb = self.xi('BOWL_BODY')
         if bb >= 0:
@@ -439,7 +446,7 @@ class ResetOracle:
         si[e + 9] = (seed * 2654435761 + 12345) & 0x7FFFFFFF
         si[e + 10] = (seed ^ 0x5bd1e995) & 0x7FFFFFFF
         xflags = self.xi('FLAGS')
-        si[e + 11] = 1 if xflags & 2 else self.nfood
+        si[e + 11] = 1 if xflags & 6 else self.nfood
         coop = self.ti('COOP') == 1
         agent = imp == 3 or coop
         si[e + 12] = 0 if (agent or xflags & 1) else (((1 << self.nhdof) - 1) << nr)     # human.py:104-110
@@ -458,5 +465,9 @@ class ResetOracle:
             ts = int(self.i[H_S_TASK])
             st[ts:ts + 3] = target_on_arm
             si[ts + 3] = limb
+        if xflags & 4:                                                     # dressing: settle gravity, garment offset (dressing.py:146-149,178)
+            ts = int(self.i[H_S_TASK])
+            st[ts + 0] = self.xf('CLOTH_GRAVITY_SETTLE')
+            st[ts + 3:ts + 6] = pe - self.xf('CLOTH_ORIG_POS', 3)
         return st, dict(gender=g, impairment=imp, limit_scale=ls, strength=strength, tremors=tremors, ik_ok=ok,
                         ik_restarts=restarts, ik_pos_err=best_d, target_ee=target_ee, head=head, limb=limb, target_on_arm=target_on_arm, toc=toc_info)

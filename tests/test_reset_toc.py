@@ -125,3 +125,81 @@ def test_gpu_config4_resets_on_the_device():
     assert (np.abs(v1['base'][:, :2] - v0['base'][:, :2]).max(axis=1) > 1e-4).all()                      # a NEW placement for every environment
     assert (v1['iteration'] == 0).all()
     env.close()
+
+
+# ---- DressingEnv.reset on the device (dressing.py:112-198): oriented goals above the human's left arm, the garment words ----------------
+@pytest.fixture(scope='module', params=['baxter', 'jaco'])
+def dr(request):
+    from emu_lib import Emu
+    b = ModelBlob.load('dressing_' + request.param)
+    assert b.has_reset_generator
+    return request.param, b, Emu(b)
+
+
+def test_dressing_emulated_kernel_matches_oracle(dr):
+    name, blob, emu = dr
+    st, info = ro.with_collision_check(blob.words).sample(31)
+    se, ie = emu.sample(31)
+    assert_same_record(blob, st, se, name)
+    assert info['ik_ok'] and bool(ie[0])
+    v = blob.view(st.reshape(1, -1))
+    tw = v['task'][0].view(np.float32)
+    assert tw[L.DR['CLOTH_GRAVITY']] == np.float32(-9.81 / 2)                                              # dressing.py:178
+    from oracle_lib import Oracle
+    ee, _ = Oracle(blob).ee_pose(st.copy())
+    assert np.abs(tw[L.DR['CLOTH_OFF']:L.DR['CLOTH_OFF'] + 3] - (ee - np.array(blob.meta['cloth_orig_pos']))).max() < 1e-5     # dressing.py:146-149
+    if name == 'baxter':      # the robot stands on the human's LEFT, turned by pi +- 30 degrees (env.py:298, robot.py:143)
+        base0 = blob.f[blob.h['OFF_RESET'] + L.X_['BASE_POS']:blob.h['OFF_RESET'] + L.X_['BASE_POS'] + 3]
+        d = v['base'][0, :3] - base0
+        assert -1e-6 <= d[0] <= 0.5 and abs(d[1]) <= 0.5 + 1e-6
+        yaw = 2 * np.arctan2(v['base'][0, 5], v['base'][0, 6])
+        assert abs(abs(yaw) - np.pi) <= np.deg2rad(30) + 1e-6
+        assert info['toc']['goals_reached'] >= 1
+
+
+@pytest.mark.gpu
+def test_gpu_dressing_resets_on_the_device():
+    """DressingBaxter-v1 (BASELINE config 5) with reset='device': agx_reset samples the scene, loads the garment at the end effector, settles it
+    for 50 steps under half gravity and switches to full gravity; the episode boundary does the same for every environment"""
+    import torch
+    from assistive_gym_amd import libagx
+    from assistive_gym_amd.libagx import Stepper
+    from assistive_gym_amd.vec_env import DressingBaxterVecEnv
+    if libagx.load().agx_device_count() <= 0:
+        __import__('conftest').no_gpu()
+    blob = ModelBlob.load('dressing_baxter')
+    oc = blob.h['OFF_CLOTH']
+    nn = int(blob.i[oc + L.CL['NN']])
+    x0 = blob.f[oc + int(blob.i[oc + L.CL['OFF_X0']]):oc + int(blob.i[oc + L.CL['OFF_X0']]) + 3 * nn].reshape(nn, 3)
+    # sampling alone: the record against the numpy restatement, the garment = X0 + offset at rest
+    o = ro.with_collision_check(blob.words)
+    st = Stepper(blob, 3)
+    st.sample_reset(500)
+    st.synchronize()
+    got, cloth = st.get_state(), st.get_cloth()
+    for i in range(3):
+        so, io = o.sample(500 + i)
+        assert_same_record(blob, so, got[i], 'env %d' % i)
+        off = blob.view(got[i:i + 1])['task'][0].view(np.float32)[L.DR['CLOTH_OFF']:L.DR['CLOTH_OFF'] + 3]
+        assert np.abs(cloth[i, 0] - (x0 + off)).max() < 1e-6 and not cloth[i, 1].any()
+    st.close()
+    # the whole reset in a VecEnv: settled garments hanging below the end effector, full gravity, fresh states at the boundary
+    n = 8
+    env = DressingBaxterVecEnv(n, reset='device', seed=77)
+    obs = env.reset()
+    s0, c0 = env.stepper.get_state(), env.stepper.get_cloth()
+    v = env.blob.view(s0)
+    assert torch.isfinite(obs).all() and np.isfinite(c0).all()
+    assert (v['task'][:, L.DR['CLOTH_GRAVITY']].view(np.float32) == np.float32(-9.81)).all() and (v['iteration'] == 0).all()
+    assert np.percentile(np.linalg.norm(c0[:, 1], axis=2), 90) < 1.5                                      # settled
+    assert (c0[:, 0, :, 2].min(axis=1) < c0[:, 0, :, 2].max(axis=1) - 0.5).all()                          # hanging: more than half a metre tall
+    a = torch.zeros(n, 7, device='cuda')
+    for k in range(200):
+        obs, rew, done, info = env.step(a)
+        assert bool(done.all()) == (k == 199)
+    s1, c1 = env.stepper.get_state(), env.stepper.get_cloth()
+    v1 = env.blob.view(s1)
+    assert torch.isfinite(obs).all() and np.isfinite(c1).all() and (v1['iteration'] == 0).all()
+    assert (np.abs(v1['base'][:, :2] - v['base'][:, :2]).max(axis=1) > 1e-4).all()                        # a NEW placement for every environment
+    assert (v1['task'][:, L.DR['CLOTH_GRAVITY']].view(np.float32) == np.float32(-9.81)).all()
+    env.close()
