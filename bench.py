@@ -295,7 +295,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     # kernel trace (rocprofv3 --kernel-trace) of this command reports.
     NT = 20
     kms, kcnt = np.zeros(3), np.zeros(3)
-    has_cloth = getattr(env, 'cloth_pool_host', None) is not None
+    has_cloth = env.stepper.cloth_nodes() > 0
     if has_cloth:
         # 40 build / solve pairs + the cloth kernel + finish per step: too many launches for the per-launch event table; the split by
         # kernel comes from the rocprofv3 kernel trace (profiles/); here the whole step is the unit
@@ -314,7 +314,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         # reward / done / info written (DESIGN.md "bytes per env-step")
         bytes_per_env_step = 2 * sw * 4 + blob.act_dim * 4 + blob.obs_dim * 4 + 4 + 1 + 8 * 4
         if has_cloth:                        # + the garment read and written once per env step: node positions and velocities
-            bytes_per_env_step += 2 * env.cloth_pool_host[0].size * 4
+            bytes_per_env_step += 2 * 6 * env.stepper.cloth_nodes() * 4
         names = [k + ksuffix for k in ('agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel')]
         traffic_key = None
         if has_cloth:
@@ -374,7 +374,8 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             out['roofline']['cloth_kernel'] = cloth_kernel
         if world == 1 and cpu:
             out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8 if not has_cloth else 2, 1000 if not has_cloth else 40,
-                                               model + ('+coop' if blob.is_coop else ''), env_id, cloth=env.cloth_pool_host if has_cloth else None)
+                                               model + ('+coop' if blob.is_coop else ''), env_id,
+                                               cloth=(env.cloth_pool_host if args.reset != 'device' else env.stepper.get_cloth()) if has_cloth else None)
     env.close()
     return out
 
