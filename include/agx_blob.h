@@ -94,6 +94,13 @@ enum {
   AGX_P_MAX_ENTRIES,     /* cap on the summed (J,B) coefficient pairs of all rows of a substep    */
   AGX_P_NOOP_RETEST,     /* K > 0: rows of the non-friction block whose visit in a re-test sweep (every K-th) was a no-op are skipped until
                             the next re-test sweep; 0 = every row in every sweep (agx_pgs.h, oracle pgs())                 */
+  /* [BULLET-UNVERIFIED] switches, evaluated by the CPU oracle only (the device solves with all three off; tests/diag/bullet_unknowns_sensitivity.py
+   * measures what each would change): */
+  AGX_P_ORACLE_RESIDUAL_EPS = 21, /* > 0: the sweeps stop once max_rows (delta lambda x D)^2 <= eps (btSequentialImpulseConstraintSolver's
+                                     m_leastSquaresResidualThreshold; PyBullet's default solverResidualThreshold is believed to be 1e-7)   */
+  AGX_P_ORACLE_FRICTION_DIRS = 22,/* 2: a second friction row per contact along n x t (SOLVER_USE_2_FRICTION_DIRECTIONS); 0 / 1: one        */
+  AGX_P_ORACLE_WARMSTART = 23,    /* > 0: contact normals start from this factor x the impulse of the same contact in the previous substep
+                                     (SOLVER_USE_WARMSTARTING, m_warmstartingFactor 0.85)                                                 */
   AGX_P_COUNT = 24
 };
 

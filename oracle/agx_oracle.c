@@ -835,6 +835,10 @@ static int row_art_entries(const sim_t* s, const row_t* r) {
   for (int d = m->nrobot; d < m->ndof; d++) if (r->J[d] != 0) hh = 1;
   return art_entries_of(s, rr, hh);
 }
+/* warm-start memory of the [BULLET-UNVERIFIED] switch AGX_P_ORACLE_WARMSTART: normal impulses of the last substep that was solved, by
+ * (collider a, collider b, ordinal inside the pair); one environment at a time (the sensitivity study), cleared by agxo_warm_clear() */
+static int g_warm_n = 0, g_warm_key[MAXC][3]; static double g_warm_lam[MAXC];
+void agxo_warm_clear(void) { g_warm_n = 0; }
 static void build_rows(sim_t* s) {
   const agxo_model* m = s->m; int n = s->ndof;
   double dt = m->dt, erp = PARAM(m, AGX_P_ERP), cerp = PARAM(m, AGX_P_CONTACT_ERP);
@@ -904,6 +908,8 @@ static void build_rows(sim_t* s) {
    * longest prefix that fits the row budget and the (J,B) coefficient budget: a row stores one
    * pair per DoF of each dynamic body it touches (all robot DoFs, 6 per free body). */
   int first_normal = s->nrows, nc = 0;
+  const int fdirs = (int)PARAM(m, AGX_P_ORACLE_FRICTION_DIRS) == 2 ? 2 : 1;   /* [BULLET-UNVERIFIED] switch, oracle only */
+  const double wsf = PARAM(m, AGX_P_ORACLE_WARMSTART);
   {
     int ent = 1, maxent = (int)PARAM(m, AGX_P_MAX_ENTRIES);
     /* non-contact rows: motors and limits address the robot; the 6 tool rows (last) robot + tool */
@@ -913,7 +919,7 @@ static void build_rows(sim_t* s) {
       const contact_t* k = &s->con[c];
       int e = art_range_entries(s, k->ba, k->bb) + ((k->ba >= AGX_BODY_FREE0 && k->ba < AGX_BODY_HUMAN0) ? 6 : 0) + ((k->bb >= AGX_BODY_FREE0 && k->bb < AGX_BODY_HUMAN0) ? 6 : 0);
       acc += e;
-      if (first_normal + 2 * (c + 1) > maxrows || ent + 2 * acc > maxent) break;
+      if (first_normal + (1 + fdirs) * (c + 1) > maxrows || ent + (1 + fdirs) * acc > maxent) break;
       nc = c + 1;
     }
   }
@@ -924,6 +930,10 @@ static void build_rows(sim_t* s) {
     double rv = row_vel(s, r);
     r->b = k->dist > 0 ? (-k->dist / dt - rv) : (-k->dist * cerp / dt - rv);
     r->lo = 0; r->hi = 1e30;
+    if (wsf > 0) {   /* warm start: the same contact (collider pair, ordinal inside the pair) of the previous substep */
+      int ord = 0; for (int c2 = 0; c2 < c; c2++) if (s->con[c2].ca == k->ca && s->con[c2].cb == k->cb) ord++;
+      for (int p = 0; p < g_warm_n; p++) if (g_warm_key[p][0] == k->ca && g_warm_key[p][1] == k->cb && g_warm_key[p][2] == ord) { r->lambda = wsf * g_warm_lam[p]; break; }
+    }
   }
   for (int c = 0; c < nc; c++) {
     contact_t* k = &s->con[c];
@@ -942,6 +952,13 @@ static void build_rows(sim_t* s) {
     body_jacobian(s, k->ba, k->pa, t, NULL, 1.0, r->J); body_jacobian(s, k->bb, k->pb, t, NULL, -1.0, r->J);
     finish_row(s, r);
     r->b = -row_vel(s, r); r->fric_of = first_normal + c; r->mu = k->mu; r->lo = 0; r->hi = 0;
+    if (fdirs == 2) {   /* the second direction of the friction pyramid */
+      double t2[3]; cross3(k->n, t, t2);
+      row_t* r2 = NEWROW();
+      body_jacobian(s, k->ba, k->pa, t2, NULL, 1.0, r2->J); body_jacobian(s, k->bb, k->pb, t2, NULL, -1.0, r2->J);
+      finish_row(s, r2);
+      r2->b = -row_vel(s, r2); r2->fric_of = first_normal + c; r2->mu = k->mu; r2->lo = 0; r2->hi = 0;
+    }
   }
   s->contact_overflow += s->ncon - nc;   /* dropped by the row / coefficient budgets */
   s->ncon = nc;
@@ -962,7 +979,11 @@ static void pgs(sim_t* s, double* dv) {
   unsigned char skip[MAXROWS]; memset(skip, 0, sizeof skip);
   memset(dv, 0, sizeof(double) * NVMAX);
   g_pgs_stats[5] += 1;
-  for (int it = 0; it < iters; it++) for (int i = 0; i < s->nrows; i++) {
+  const double reps = PARAM(s->m, AGX_P_ORACLE_RESIDUAL_EPS);
+  for (int i = 0; i < s->nrows; i++) if (s->rows[i].lambda != 0) for (int k = 0; k < s->nv; k++) dv[k] += s->rows[i].B[k] * s->rows[i].lambda;   /* warm-started rows */
+  for (int it = 0; it < iters; it++) {
+   double res = 0;
+   for (int i = 0; i < s->nrows; i++) {
     row_t* r = &s->rows[i];
     if (r->invD == 0) continue;
     const int retest = K > 0 && it % K == 0;
@@ -977,6 +998,10 @@ static void pgs(sim_t* s, double* dv) {
     if (r->fric_of < 0) { g_pgs_stats[0] += 1; if (dl == 0) g_pgs_stats[1] += 1; }
     else { g_pgs_stats[2] += 1; if (dl == 0) g_pgs_stats[3] += 1; if (hi == 0 && nl == 0 && dl == 0) g_pgs_stats[4] += 1; }
     if (dl != 0) for (int k = 0; k < s->nv; k++) dv[k] += r->B[k] * dl;
+    { const double e = dl / r->invD; if (e * e > res) res = e * e; }
+   }
+   g_pgs_stats[6] += 1;
+   if (reps > 0 && res <= reps) break;   /* [BULLET-UNVERIFIED] switch: residual early-out */
   }
 }
 
@@ -1206,10 +1231,18 @@ static void substep_h(sim_t* s, int hooks) {
   build_rows(s);
   double dv[NVMAX];
   pgs(s, dv);
-  for (int c = 0; c < s->ncon; c++) {
+  {
+    const int fdirs = (int)PARAM(m, AGX_P_ORACLE_FRICTION_DIRS) == 2 ? 2 : 1;
     /* normal rows follow the non-contact rows in construction order */
-    int first_normal = s->nrows - 2 * s->ncon;
-    s->con[c].lambda_n = s->rows[first_normal + c].lambda;
+    const int first_normal = s->nrows - (1 + fdirs) * s->ncon;
+    for (int c = 0; c < s->ncon; c++) s->con[c].lambda_n = s->rows[first_normal + c].lambda;
+    if (PARAM(m, AGX_P_ORACLE_WARMSTART) > 0) {
+      g_warm_n = s->ncon < MAXC ? s->ncon : MAXC;
+      for (int c = 0; c < g_warm_n; c++) {
+        int ord = 0; for (int c2 = 0; c2 < c; c2++) if (s->con[c2].ca == s->con[c].ca && s->con[c2].cb == s->con[c].cb) ord++;
+        g_warm_key[c][0] = s->con[c].ca; g_warm_key[c][1] = s->con[c].cb; g_warm_key[c][2] = ord; g_warm_lam[c] = s->con[c].lambda_n;
+      }
+    }
   }
   for (int d = 0; d < n; d++) {
     s->qd[d] = s->vel[d] + dv[d]; s->q[d] += dt * s->qd[d];
