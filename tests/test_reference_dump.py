@@ -8,6 +8,7 @@ No such dump can be produced in the build container (no pybullet): the tests SKI
 tests/golden/pybullet_dump_*.npz is committed -- until then parity is unpinned."""
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -24,7 +25,7 @@ def _check(name, got, ref):
 
 def _load(path, blob):
     d = np.load(path, allow_pickle=False)
-    if 'model' in d.files and str(d['model']) != 'feeding_jaco':          # a dump of another Feeding<Robot>-v1 (tools/pybullet_dump.py --env)
+    if 'model' in d.files and str(d['model']) != 'feeding_jaco':          # a dump of another environment (tools/pybullet_dump.py --env: any task, any robot)
         from assistive_gym_amd.blob import ModelBlob
         blob = ModelBlob.load(str(d['model']))
     assert int(d['blob_version']) == blob.h['VERSION'], 'dump was recorded for another blob version'
@@ -39,9 +40,13 @@ def test_oracle_matches_reference_dump(path, blob, oracle):
     if blob.words is not oracle.blob.words:
         from oracle_lib import Oracle
         oracle = Oracle(blob)
+    has_cloth = 'cloth' in d.files
     for k in range(len(d['actions'])):
         s = d['states'][k].copy()
-        obs, rew, done, info = oracle.step(s, d['actions'][k])
+        if has_cloth:                          # a Dressing dump carries the garment of every step (node velocities are not in the fork's API: zero)
+            obs, rew, done, info = oracle.step_cloth(s, d['cloth'][k].copy(), d['actions'][k])
+        else:
+            obs, rew, done, info = oracle.step(s, d['actions'][k])
         _check('oracle obs @%d' % k, obs, d['obs'][k]); _check('oracle reward @%d' % k, rew, d['reward'][k])
         _check('oracle force @%d' % k, info[0], d['total_force_on_human'][k])
         assert bool(done) == bool(d['done'][k])
@@ -56,9 +61,86 @@ def test_stepper_matches_reference_dump(path, blob):
     T = len(d['actions'])
     st = Stepper(blob, T)                     # step k of the episode runs in environment slot k
     st.set_state(d['states'][:T])
+    if 'cloth' in d.files:
+        st.set_cloth(d['cloth'][:T])
     obs, rew, done, info = st.step_host(d['actions'])
     for k in range(T):
         _check('obs @%d' % k, obs[k], d['obs'][k]); _check('reward @%d' % k, rew[k], d['reward'][k])
         _check('force @%d' % k, info[k, 0], d['total_force_on_human'][k])
         assert bool(done[k]) == bool(d['done'][k])
     st.close()
+
+
+# ---- the dump tool's state capture (tests/refbridge/capture.py, used by tools/pybullet_dump.py) against the bridge: capture(adopt(state))
+# must give `state` back -- for every task, through the same PyBullet calls the tool makes where the real PyBullet exists
+def _bridge_cases():
+    import refbridge
+    if not refbridge.available():
+        return []
+    import refcases
+    want = ('feeding_jaco_tremor', 'feeding_food_events', 'feeding_coop_tremor', 'bed_wiping', 'bed_coop_rollback', 'scratch_itch_pr2_coop_scratching',
+            'scratch_itch_jaco', 'arm_manipulation_sawyer_lifting', 'arm_manipulation_pr2', 'dressing_on_forearm', 'dressing_coop_sleeve')
+    out, seen = [], set()
+    for c in refcases.build_cases():
+        key = next((w for w in want if c['name'].startswith(w)), None)
+        if key and key not in seen:
+            seen.add(key); out.append(c)
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='needs the reference checkout (the build container has it, the GPU box does not)')
+def test_capture_inverts_adopt_on_the_bridge():
+    import refbridge
+    import refcases
+    from refbridge import capture as cap
+    from assistive_gym_amd.model import compiler as L
+    cases = _bridge_cases()
+    assert len(cases) >= 9
+    refbridge.install()
+    p = sys.modules['pybullet']
+    for c in cases:
+        blob = refcases.variant_blob(c['model'], c['coop'], c['variant'])
+        env, w = refbridge.adopt(blob, c['state'], c['cloth'])
+        task = cap.TASK_OF_KIND[blob.task_kind]
+        initial = {}
+        if task == 'feeding':                       # adopt() lists only the particles that are still alive: the creation order comes from the body ids
+            class _F:
+                def __init__(self, body): self.body = body
+                def __eq__(self, o): return getattr(o, 'body', None) == self.body
+                def __hash__(self): return hash(self.body)
+            initial['foods'] = [_F(refbridge.FOOD0 + k) for k in range(blob.nfood)]
+            env.foods = [_F(f.body) for f in env.foods]; env.foods_active = [_F(f.body) for f in env.foods_active]
+            env.bowl = _F(refbridge.BOWL)           # (created by reset() in the reference: furniture.py:32-34)
+        if task == 'bed_bathing':                   # likewise the wiping targets: marker ids in creation order
+            ids = sorted(m for m in w.markers if m >= w.first_target_marker)
+            nt = sum(int(x) for x in blob.task_i_n('NT', 4)[2 * w.gender:2 * w.gender + 2])
+            initial['targets'] = ids[:nt]
+        cl = None if c['cloth'] is None else np.zeros_like(c['cloth'])
+        got = cap.capture(env, blob, p, initial, cloth_out=cl)
+        a, b = blob.view(c['state'].reshape(1, -1).copy()), blob.view(got.reshape(1, -1))
+        def pose_dev(x, y):                          # [..., 7+]: position, quaternion (q and -q are the same rotation), the rest
+            x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+            dq = np.minimum(np.abs(x[..., 3:7] - y[..., 3:7]).max(axis=-1), np.abs(x[..., 3:7] + y[..., 3:7]).max(axis=-1))
+            rest = np.abs(np.delete(x, [3, 4, 5, 6], axis=-1) - np.delete(y, [3, 4, 5, 6], axis=-1)).max(axis=-1)
+            return float(np.maximum(dq, rest).max())
+        for k in ('q', 'qd', 'tremor', 'tremor_target'):
+            assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() < 2e-6, (c['name'], k)
+        assert pose_dev(a['base'][0], b['base'][0]) < 2e-6 and pose_dev(a['human'][0], b['human'][0]) < 2e-6, c['name']
+        near = np.abs(a['free'][0][:, :3]).max(axis=1) < 500 if blob.nfree else np.zeros(0, bool)          # eaten particles were teleported away
+        assert not near.any() or pose_dev(a['free'][0][near], b['free'][0][near]) < 2e-6, c['name']
+        for k in ('gender', 'iteration', 'food_alive', 'food_active', 'task_success', 'frozen'):
+            assert int(a[k][0]) == int(b[k][0]), (c['name'], k, int(a[k][0]), int(b[k][0]))
+        assert abs(float(a['limit_scale'][0]) - float(b['limit_scale'][0])) < 1e-6
+        nr = blob.nrobot
+        passive = [d for d in range(nr) if blob.robot_i(d, 'ACT') < 0]
+        assert np.abs(a['qt'][0, passive] - b['qt'][0, passive]).max() < 2e-6 if passive else True, c['name']
+        ta, tb = a['task'][0].view(np.float32), b['task'][0].view(np.float32)
+        if task == 'bed_bathing':
+            assert np.array_equal(a['task'][0][:6], b['task'][0][:6]), c['name']                               # the surviving targets
+        if task == 'scratch_itch':
+            assert np.abs(ta[:3] - tb[:3]).max() < 1e-6 and a['task'][0][3] == b['task'][0][3] and np.abs(ta[12:15] - tb[12:15]).max() < 1e-6
+        if task == 'dressing':
+            assert abs(ta[L.DR['BEST']] - tb[L.DR['BEST']]) < 1e-6 and np.abs(cl[0] - c['cloth'][0]).max() < 2e-6
+        if blob.task_i('ARM_LIMIT_ON'):
+            assert a['task'][0][10] == b['task'][0][10] and np.abs(ta[6:10] - tb[6:10]).max() < 1e-6
+        w.close()
