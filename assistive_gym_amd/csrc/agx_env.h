@@ -995,12 +995,19 @@ AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gactio
   {
     const int* bi = (const int*)blob; const float* st = lds + L_ST;    // the state copy of the task layer above
     const int ndof = bi[AGX_H_NDOF], nfree = bi[AGX_H_NFREE], s_q = bi[AGX_H_S_Q], s_free = bi[AGX_H_S_FREE], od = bi[AGX_H_OBS_DIM];
+    // "not finite" includes velocities nothing in these scenes can reach (1e3 rad/s, m/s): a deep start-up penetration pushed out in one
+    // substep (no recovery clamp) blows up over a few steps before it overflows -- it is ended as soon as it is implausible.
+    // The outputs themselves are checked too (a finite state can still give an overflowing reward term).
+    wave_sync();                       // (the observation was written by whichever lane computed an entry)
     bool bad = false;
-    for (int k = lane; k < 2 * ndof; k += 64) { const float v = st[(k < ndof ? s_q : bi[AGX_H_S_QD] - ndof) + k]; bad = bad || !(fabsf(v) < 3.0e38f); }
-    for (int k = lane; k < 13 * nfree; k += 64) { const float v = st[s_free + k]; bad = bad || !(fabsf(v) < 3.0e38f); }
+    for (int k = lane; k < 2 * ndof; k += 64) { const float v = st[(k < ndof ? s_q : bi[AGX_H_S_QD] - ndof) + k]; bad = bad || !(fabsf(v) < (k < ndof ? 3.0e38f : 1.0e3f)); }
+    for (int k = lane; k < 13 * nfree; k += 64) { const float v = st[s_free + k]; bad = bad || !(fabsf(v) < (k % 13 >= 7 ? 1.0e3f : 3.0e38f)); }
+    for (int k = lane; k < od; k += 64) bad = bad || !(fabsf(gobs[k]) < 3.0e38f);
+    if (lane == 0) bad = bad || !(fabsf(*greward) < 3.0e38f);
     if (wave_any(bad)) {
       for (int k = lane; k < od; k += 64) gobs[k] = 0.f;
-      if (lane == 0) { *greward = 0.f; *gdone = 1; if (ginfo) { ginfo[AGX_INFO_TOTAL_FORCE] = 0.f; ginfo[AGX_INFO_TASK_SUCCESS] = 0.f; ginfo[AGX_INFO_NCONTACT] = AGX_INFO_NONFINITE; } }
+      if (lane == 0) { *greward = 0.f; *gdone = 1; }
+      if (ginfo && lane < AGX_INFO_COUNT) ginfo[lane] = lane == AGX_INFO_NCONTACT ? AGX_INFO_NONFINITE : 0.f;
     }
   }
 }

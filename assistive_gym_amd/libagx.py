@@ -144,6 +144,16 @@ class Stepper:
         check(self.L.agx_state_dev(self.h, C.byref(p)), 'agx_state_dev')
         return p.value
 
+    def state_tensor(self):
+        """the state records as a torch tensor over the handle's own device memory (float32 [n_envs, state_words], no copy)"""
+        import torch
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = dict(shape=(self.n_envs, self.state_words), typestr='<f4', data=(self.state_dev(), False), version=2, strides=None)
+        return torch.as_tensor(v, device='cuda:%d' % self.device)
+
     def settle(self, n_substeps, stream=0):
         check(self.L.agx_settle(self.h, C.c_int(n_substeps), C.c_void_p(stream)), 'agx_settle')
 

@@ -181,6 +181,7 @@ class AssistiveVecEnv:
         # pool_refresh = k > 0: a child process samples k new start states at a time, swapped into the pool at episode boundaries (PoolRefresher)
         self.pool_refresh, self.pool_refresh_sync, self._refresher, self._refresh_cursor, self.pool_refreshed = int(pool_refresh), pool_refresh_sync, None, 0, 0
         self._model_name = model or self.model
+        self.start_states_redrawn = 0                 # reset='device': environments whose sampled start came out of the settle implausible and were drawn again
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -194,6 +195,17 @@ class AssistiveVecEnv:
         settle = {L.TASK_FEEDING: SETTLE_STEPS, L.TASK_DRESSING: DRESSING_SETTLE_STEPS}.get(self.blob.task_kind, 0)
         self.stepper.reset(mask, None, episode_seed(self.seed, self._episode, self.env_offset), impairment=self.impairment,
                            settle_substeps=settle, stream=s)
+        if settle > 0:
+            # a sampled start deep inside the table / the bowl comes out of the settle blown up (a few in a thousand for the Panda, DESIGN 2:
+            # no penetration-recovery clamp): such environments are drawn once more, from the seeds of a later "episode"
+            st = self.stepper.state_tensor()
+            bad = ~torch.isfinite(st).all(dim=1) | (st[:, self.blob.h['S_QD']:self.blob.h['S_QD'] + self.blob.ndof].abs().amax(dim=1) > 1.0e3)
+            if mask is not None:
+                bad &= mask.bool()
+            if bool(bad.any()):
+                self.stepper.reset(bad.to(torch.uint8), None, episode_seed(self.seed, self._episode + (1 << 20), self.env_offset), impairment=self.impairment,
+                                   settle_substeps=settle, stream=s)
+                self.start_states_redrawn += int(bad.sum())
         self._episode += 1
 
     def set_pool(self, states, cloth=None):
