@@ -86,7 +86,7 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     # A sampled start whose arm pose the IK restarts left deep inside the table or the bowl is pushed out by the contact rows with whatever
     # velocity closes the gap in one substep (no penetration-recovery clamp as in Bullet's split impulse): a few in a thousand blow up during
     # the settle.  Such entries never enter a pool: they are drawn again from the seeds after this batch's.
-    bad = ~np.isfinite(out).all(axis=1)
+    bad = ~np.isfinite(out[:, :blob.h['S_ENV']]).all(axis=1)          # (the float part of a record: the env / task words hold integers)
     if bad.any() and _depth < 4:
         out[bad] = build_reset_pool(blob, int(bad.sum()), seed + pool_size, device, impairment, sampler, _depth + 1)
     elif bad.any():
@@ -199,7 +199,8 @@ class AssistiveVecEnv:
             # a sampled start deep inside the table / the bowl comes out of the settle blown up (a few in a thousand for the Panda, DESIGN 2:
             # no penetration-recovery clamp): such environments are drawn once more, from the seeds of a later "episode"
             st = self.stepper.state_tensor()
-            bad = ~torch.isfinite(st).all(dim=1) | (st[:, self.blob.h['S_QD']:self.blob.h['S_QD'] + self.blob.ndof].abs().amax(dim=1) > 1.0e3)
+            fl = st[:, :self.blob.h['S_ENV']]                  # joint angles ... human frames, tremor words: the float part of a record (the env / task words hold integers)
+            bad = ~torch.isfinite(fl).all(dim=1) | (st[:, self.blob.h['S_QD']:self.blob.h['S_QD'] + self.blob.ndof].abs().amax(dim=1) > 1.0e3)
             if mask is not None:
                 bad &= mask.bool()
             if bool(bad.any()):
