@@ -128,8 +128,14 @@ class PoolRefresher:
         """batches that are due: [states or (states, garments)]"""
         import queue as _q
         out = []
-        if self.sync:
-            out.append(self.queue.get(timeout=1800)[1])             # episode e waits for batch e
+        if self.sync:                                               # episode e waits for batch e
+            while True:
+                try:
+                    out.append(self.queue.get(timeout=5)[1])
+                    break
+                except _q.Empty:
+                    if not self.proc.is_alive():
+                        raise RuntimeError('the pool refresher process has died (exit code %s)' % self.proc.exitcode)
         else:
             while True:
                 try:
