@@ -307,20 +307,13 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
       const bool retest = K > 0 && it % K == 0;
       const float before = S.lam;
       uint64_t rowsA = pgs_range_mask(0, nA) & ~((K > 0 && !retest) ? skip : 0ull);
-      // The row of A a visit needs does not depend on the visit before it: it is read two visits ahead, so that the LDS round trip (as
-      // long as the whole arithmetic of a visit) is off the chain  w -> impulse -> broadcast -> w.
-      int r0 = -1, r1 = -1; float a0 = 0.f, a1 = 0.f;
-      if (rowsA) { r0 = ffs64(rowsA); rowsA &= rowsA - 1ull; a0 = A[RS_MAX_ROWS * r0 + lane]; }
-      if (rowsA) { r1 = ffs64(rowsA); rowsA &= rowsA - 1ull; a1 = A[RS_MAX_ROWS * r1 + lane]; }
-      while (r0 >= 0) {                                             // non-contact rows and contact normals
-        int r2 = -1; float a2 = 0.f;
-        if (rowsA) { r2 = ffs64(rowsA); rowsA &= rowsA - 1ull; a2 = A[RS_MAX_ROWS * r2 + lane]; }
-        const int r = r0; const float arow = a0;
+      while (rowsA) {                                               // non-contact rows and contact normals
+        const int r = ffs64(rowsA); rowsA &= rowsA - 1ull;
+        const float arow = A[RS_MAX_ROWS * r + lane];
         const float nl = wave_clamp(S.lam + (S.b - w) * S.invD, S.lo, S.hi);
         const float dl = wave_bcast(nl - S.lam, r);
         if (lane == r) S.lam = nl;
         w += arow * dl;
-        r0 = r1; a0 = a1; r1 = r2; a1 = a2;
       }
       if (retest) skip = wave_ballot(S.lam == before) & pgs_range_mask(0, nA);
       if (nc > 0) {
@@ -329,18 +322,13 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
         const float hi = S.hi * ln, lo = -hi;
         // a friction row whose normal impulse and own impulse are both zero is an exact no-op (as in the velocity-space sweep)
         uint64_t todo = wave_ballot(lane >= nA && lane < R && (ln != 0.f || S.lam != 0.f));
-        int f0 = -1, f1 = -1; float b0 = 0.f, b1 = 0.f;
-        if (todo) { f0 = ffs64(todo); todo &= todo - 1ull; b0 = A[RS_MAX_ROWS * f0 + lane]; }
-        if (todo) { f1 = ffs64(todo); todo &= todo - 1ull; b1 = A[RS_MAX_ROWS * f1 + lane]; }
-        while (f0 >= 0) {
-          int f2 = -1; float b2 = 0.f;
-          if (todo) { f2 = ffs64(todo); todo &= todo - 1ull; b2 = A[RS_MAX_ROWS * f2 + lane]; }
-          const int r = f0; const float arow = b0;
+        while (todo) {
+          const int r = ffs64(todo); todo &= todo - 1ull;
+          const float arow = A[RS_MAX_ROWS * r + lane];
           const float nl = wave_clamp(S.lam + (S.b - w) * S.invD, lo, hi);
           const float dl = wave_bcast(nl - S.lam, r);
           if (lane == r) S.lam = nl;
           w += arow * dl;
-          f0 = f1; b0 = b1; f1 = f2; b1 = b2;
         }
       }
     }
