@@ -156,10 +156,16 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   if (can_sample) {
     const int32_t* X = hi + hi[AGX_H_OFF_RESET];
     const int32_t* T = hi + hi[AGX_H_OFF_TASK];
-    if (X[AGX_X_NARM] != V->rs_narm || T[AGX_T_EE_LINK] != V->rs_narm - 1 || hi[AGX_H_NROBOT] < V->rs_narm || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64) can_sample = false;
-    for (int d = 0; can_sample && d < V->rs_narm; d++) {
+    // the arm: rs_narm joints in a serial chain (AGX_X_CHAIN: each joint's parent is the one before, the first hangs off the base), the
+    // k-th one driven by action k, the last one carrying the end effector
+    if (X[AGX_X_NARM] != V->rs_narm || hi[AGX_H_NROBOT] < V->rs_narm || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64 || X[AGX_X_TOC_ATTEMPTS] > 64 ||
+        X[AGX_X_TOC_NGOALS] > 3 || X[AGX_X_PED_N] > 2) can_sample = false;
+    for (int k = 0; can_sample && k < V->rs_narm; k++) {
+      const int d = X[AGX_X_CHAIN + k];
+      if (d < 0 || d >= hi[AGX_H_NROBOT]) { can_sample = false; break; }
       const int32_t* R = hi + hi[AGX_H_OFF_ROBOT] + d * AGX_R_STRIDE;
-      if (R[AGX_R_PARENT] != d - 1 || R[AGX_R_ACT] != d) can_sample = false;
+      if (R[AGX_R_PARENT] != (k ? X[AGX_X_CHAIN + k - 1] : -1) || R[AGX_R_ACT] != k) can_sample = false;
+      if (k == V->rs_narm - 1 && T[AGX_T_EE_LINK] != d) can_sample = false;
     }
   }
   int ndev = 0;

@@ -93,6 +93,7 @@ struct ResetCtx {
   double ls;                          // limit scale of the sampled human
   double head[3];                     // head joint angle draws
   d3 base_p; dq base_q;               // robot base: the blob's fixed pose, or this lane's candidate of the base pose search
+  int chain[7];                       // DoF of the arm's k-th joint (AGX_X_CHAIN)
 };
 #define XF(c, k) ((double)(c).xf[(k)])
 #define XI(c, k) ((c).xi[(k)])
@@ -125,7 +126,7 @@ AGX_DEV void rs_arm_fk(const ResetCtx& c, const double* q, d3* pos, d3* axw, d3&
   d3 pp = c.base_p; dq pq = c.base_q;
 #pragma unroll
   for (int d = 0; d < RS_NARM; d++) {
-    const float* r = c.rob + d * AGX_R_STRIDE;
+    const float* r = c.rob + c.chain[d] * AGX_R_STRIDE;
     d3 jp; dq jq;
     dcompose(pp, pq, dld3(r + AGX_R_TPOS), dld4(r + AGX_R_TQUAT), jp, jq);
     const d3 ax = dld3(r + AGX_R_AXIS);
@@ -227,7 +228,7 @@ AGX_DEV double rs_jlwki(const ResetCtx& c, const double* q) {
   for (int d = 0; d < RS_NARM; d++) {
     const d3 l = dcross(axw[d], pe - pos[d]);
     J[0][d] = l.x; J[1][d] = l.y; J[2][d] = l.z; J[3][d] = axw[d].x; J[4][d] = axw[d].y; J[5][d] = axw[d].z;
-    const double lower = (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER];
+    const double lower = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_UPPER];
     const double qr = 0.5 * (upper - lower);
     const double wd = 1.0 - pow(0.5, (qr - fabs(qr - q[d] + lower)) / (0.05 * qr) + 1.0);
     w[d] = fmax(wd, 0.001);
@@ -277,6 +278,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   c.rob = c.bf + c.bi[AGX_H_OFF_ROBOT]; c.task = c.bf + c.bi[AGX_H_OFF_TASK];
   c.nj = XI(c, AGX_X_NJOINT);
   c.base_p = dld3(c.xf + AGX_X_BASE_POS); c.base_q = dld4(c.xf + AGX_X_BASE_QUAT);
+  for (int d = 0; d < RS_NARM; d++) c.chain[d] = XI(c, AGX_X_CHAIN + d);
   const int ndof = c.bi[AGX_H_NDOF], nrobot = c.bi[AGX_H_NROBOT], nhdof = c.bi[AGX_H_NHDOF], nfree = c.bi[AGX_H_NFREE];
   const int nhuman = c.bi[AGX_H_NHUMAN], nfood = c.bi[AGX_H_NFOOD], state_words = c.bi[AGX_H_STATE_WORDS];
   const int sQ = c.bi[AGX_H_S_Q], sQT = c.bi[AGX_H_S_QT], sFREE = c.bi[AGX_H_S_FREE], sBASE = c.bi[AGX_H_S_BASE];
@@ -338,7 +340,14 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     const int rounds = XI(c, AGX_X_TOC_ROUNDS), titers = XI(c, AGX_X_TOC_IK_ITERS);
     const double tthr = XF(c, AGX_X_TOC_THRESH), prange = XF(c, AGX_X_TOC_POS_RANGE), yrange = XF(c, AGX_X_TOC_YAW_RANGE);
     d3 goals[3]; const bool goal_orient = XI(c, AGX_X_TOC_GOAL_ORIENT) != 0;
-    for (int k = 0; k < 3; k++) { dq gq; rs_link_pose(c, XI(c, AGX_X_TOC_GOAL_LINKS + k), goals[k], gq); goals[k] = goals[k] + dld3(c.xf + AGX_X_TOC_GOAL_OFF); }
+    const int ngoals = XI(c, AGX_X_TOC_NGOALS);
+    for (int k = 0; k < 3; k++) goals[k] = dmk(0, 0, 0);
+    if (XI(c, AGX_X_TOC_GOAL_KIND) == 1) {       // feeding: the mouth (feeding.py:142, 184-196)
+      d3 hp; dq hq; rs_link_pose(c, c.xi[XI(c, AGX_X_OFF_DYN) + head_link - nrobot], hp, hq);
+      goals[0] = hp + dqrot(hq, dld3(c.task + (c.gender ? AGX_T_MOUTH_F : AGX_T_MOUTH_M)));
+    } else
+      for (int k = 0; k < ngoals; k++) { dq gq; rs_link_pose(c, XI(c, AGX_X_TOC_GOAL_LINKS + k), goals[k], gq); goals[k] = goals[k] + dld3(c.xf + AGX_X_TOC_GOAL_OFF); }
+    const int nped = XI(c, AGX_X_PED_N);
     const d3 base0 = dld3(c.xf + AGX_X_BASE_POS);
     restarts = 0;
     for (int round = 0; round < rounds && !ok; round++) {
@@ -355,10 +364,10 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
         double lo[RS_NARM], hi[RS_NARM];
 #pragma unroll
         for (int d = 0; d < RS_NARM; d++) {
-          const double lower = (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER];
+          const double lower = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_UPPER];
           lo[d] = lower < -1e9 ? -6.283185307179586 : lower; hi[d] = upper > 1e9 ? 6.283185307179586 : upper;     // agent.py:223-231
         }
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g <= ngoals; g++) {
           double q[RS_NARM];
 #pragma unroll
           for (int d = 0; d < RS_NARM; d++) q[d] = lo[d] + (hi[d] - lo[d]) * rs_u01(seed_lo, seed_hi, stream, RS_T_REST + 8 * g + d);     // agent.py:263
@@ -377,6 +386,16 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
           if (g == 0) {
 #pragma unroll
             for (int d = 0; d < RS_NARM; d++) qs[d] = q[d];
+            // the pedestal guard: joint origins past the shoulder, the midpoints between them and the end effector, in the base frame
+            for (int b = 0; b < nped && hit; b++) {
+              const float* bx = c.xf + AGX_X_PED_BOX + 6 * b;
+              dq bi_ = c.base_q; bi_.x = -bi_.x; bi_.y = -bi_.y; bi_.z = -bi_.z;
+              for (int k = 0; k < 10 && hit; k++) {
+                const d3 pt = k < 5 ? pos[2 + k] : (k < 9 ? dmk(0.5 * (pos[k - 3].x + pos[k - 2].x), 0.5 * (pos[k - 3].y + pos[k - 2].y), 0.5 * (pos[k - 3].z + pos[k - 2].z)) : pe);
+                const d3 l = dqrot(bi_, pt - c.base_p);
+                if (l.x >= bx[0] && l.y >= bx[1] && l.z >= bx[2] && l.x <= bx[3] && l.y <= bx[4] && l.z <= bx[5]) hit = false;
+              }
+            }
           }
           if (hit) { reached |= 1 << g; manip += rs_jlwki(c, q); }
         }
@@ -409,7 +428,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
       double lo[RS_NARM], hi[RS_NARM];
 #pragma unroll
       for (int d = 0; d < RS_NARM; d++) {
-        const double lower = (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER];
+        const double lower = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_UPPER];
         double l = lower < -1e9 ? -6.283185307179586 : lower, h = upper > 1e9 ? 6.283185307179586 : upper;       // agent.py:223-231
         if (r >= randlim_from) {                                                                                 // robot.py:91
           l *= rs_u01(seed_lo, seed_hi, 1u + (uint32_t)r, RS_R_LO + d);
@@ -421,7 +440,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
       rs_ik<true>(c, q, lo, hi, tpos, tquat, XI(c, AGX_X_IK_ITERS));
 #pragma unroll
       for (int d = 0; d < RS_NARM; d++)                                                                          // set_joint_angles(use_limits=True)
-        q[d] = fmin(fmax(q[d], (double)c.rob[d * AGX_R_STRIDE + AGX_R_LOWER]), (double)c.rob[d * AGX_R_STRIDE + AGX_R_UPPER]);
+        q[d] = fmin(fmax(q[d], (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_LOWER]), (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_UPPER]);
       d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
       rs_arm_fk(c, q, pos, axw, pe, oe);
       dpos = sqrt(ddot(tpos - pe, tpos - pe));
@@ -461,11 +480,14 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   dcompose(pe, oe, dld3(c.task + AGX_T_TOOL_POS), dld4(c.task + AGX_T_TOOL_QUAT), tp, tq);                   // tool.py:49-62
   if (lane < ndof) {
     double qv;
-    if (lane < RS_NARM) {
+    int ck = -1;
+#pragma unroll
+    for (int d = 0; d < RS_NARM; d++) ck = c.chain[d] == lane ? d : ck;
+    if (ck >= 0) {
       qv = best_q[0];
 #pragma unroll
-      for (int d = 1; d < RS_NARM; d++) qv = lane == d ? best_q[d] : qv;
-    } else if (lane < nrobot) {                                                                              // gripper, feeding.py:143-144
+      for (int d = 1; d < RS_NARM; d++) qv = ck == d ? best_q[d] : qv;
+    } else if (lane < nrobot) {                                                                              // gripper (and joints outside the arm), feeding.py:143-144
       const float* r = c.rob + lane * AGX_R_STRIDE;
       qv = fmin(fmax((double)r[AGX_R_QT0], (double)r[AGX_R_LOWER]), (double)r[AGX_R_UPPER]);
     } else {

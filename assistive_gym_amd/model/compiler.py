@@ -54,7 +54,7 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
           TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
-          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, COUNT=84)
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, PED_BOX=96, COUNT=108)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
          TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, HUMAN_KP=14, HUMAN_MAXF=15, COUNT=16)
@@ -663,9 +663,16 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
         return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm) if mounted else 0                    # NARM 0: no device-side reset generator for this blob
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
         xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['base_pos'] if mounted else np.array([-0.85, -0.4, 0]) + RB['toc_base']   # toc_base_pos_offset
-        xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])      # feeding.py:136
+        xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0]) if mounted else [0, 0, 0, 1]      # feeding.py:136; a free-standing robot: robot.py:142-146
+        if not mounted:     # base pose search (robot.py:123-215) with the mouth as the one goal besides the start pose (feeding.py:142)
+            xi[X_['TOC_ATTEMPTS']], xi[X_['TOC_ROUNDS']] = 50, 4
+            xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW_RANGE']] = 0.5, np.deg2rad(30.0)
+            xf[X_['TOC_YAW0']], xf[X_['TOC_X_SIGN']] = 0.0, -1.0
+            xi[X_['TOC_IK_ITERS']], xf[X_['TOC_THRESH']] = 100, 0.03
+            xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 1, 1
+        fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
         xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])                  # toc_ee_orient_rpy
         xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.15, -0.65, 1.15], 0.05   # feeding.py:139
         xf[X_['BOWL_POS']:X_['BOWL_POS'] + 3], xf[X_['BOWL_RANGE']] = [-0.15, -0.65, 0.75], 0.05    # furniture.py:33
@@ -1205,9 +1212,9 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
     task_f['SI_LIMB_DIMS'] = dims
 
     # the device-side reset generator (csrc/agx_reset.h) samples ScratchItchEnv.reset (scratch_itch.py:93-132): a wheelchair-mounted arm by
-    # IK restarts, a free-standing robot by the base pose search of Robot.position_robot_toc (robot.py:123-215) -- the latter for the robots
-    # whose arm is a serial 7-joint chain and needs no pedestal guard (PR2, Baxter; the Sawyer keeps the host sampler, reset_bed._arm_in_pedestal)
-    generator = mounted or robot in ('pr2', 'baxter')
+    # IK restarts, a free-standing robot by the base pose search of Robot.position_robot_toc (robot.py:123-215; the Sawyer with the pedestal
+    # guard of reset_bed._arm_in_pedestal as a candidate filter)
+    generator = True
 
     def reset_words(nhuman, nhdof):
         return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if generator else 0)
@@ -1216,6 +1223,8 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
         if not generator:
             return      # the pool comes from assistive_gym_amd/host/reset_scratch.py
         xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
+        fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
+        xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 3, 0
         if mounted:
             xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([0, 0, 0.06]) + RB['toc_base']       # scratch_itch.py:97-99
             xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0])
@@ -1243,6 +1252,20 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=23 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_SCRATCH_ITCH), reset_fill, reset_words,
                 task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot, mount=RB['mount'],
                                                                  toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
+
+
+def fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc_colliders=None, base_range=None, guard=False, margin=0.09):
+    """AGX_X_CHAIN: the DoFs of the arm's seven joints in chain order (the Sawyer's chain skips its head pan); AGX_X_PED_*: the boxes of
+    the robot's own pedestal grown by a link radius, in the base frame -- a start pose whose arm folds into them is not accepted by the
+    base pose search (host/reset_bed.py::_arm_in_pedestal: the damped least squares finds elbow-down solutions Bullet's IK does not)"""
+    dof_of = {j: d for d, j in enumerate(rob['dof_links'])}
+    xi[X_['CHAIN']:X_['CHAIN'] + 7] = [dof_of[j] for j in arm]
+    if guard:
+        boxes = [(sc_colliders[c]['verts'].min(0) - margin, sc_colliders[c]['verts'].max(0) + margin) for c in range(*base_range)]
+        assert len(boxes) <= 2
+        xi[X_['PED_N']] = len(boxes)
+        for k, (lo, hi) in enumerate(boxes):
+            xf[X_['PED_BOX'] + 6 * k:X_['PED_BOX'] + 6 * k + 3], xf[X_['PED_BOX'] + 6 * k + 3:X_['PED_BOX'] + 6 * k + 6] = lo, hi
 
 
 def fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, preset, cloth=False):
@@ -1358,10 +1381,10 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
 
     # DressingEnv.reset on the device (csrc/agx_reset.h; dressing.py:112-198): seated human with the left arm raised, the robot on the
     # human's LEFT -- a wheelchair-mounted arm by IK restarts, Baxter / PR2 by the base pose search with oriented goals 10 cm above
-    # shoulder / elbow / wrist (dressing.py:132) --, the garment shifted to the end effector, settle gravity on the cloth.  The Sawyer keeps
-    # the host sampler (pedestal guard).
+    # shoulder / elbow / wrist (dressing.py:132; the Sawyer with its pedestal guard) --, the garment shifted to the end effector, settle
+    # gravity on the cloth.
     mounted = RB['wheelchair_mounted']
-    generator = mounted or robot in ('baxter', 'pr2')
+    generator = True
 
     def reset_words(nhuman, nhdof):
         return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if generator else 0)
@@ -1370,6 +1393,8 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
         if not generator:
             return      # the pool comes from assistive_gym_amd/host/reset_dressing.py
         xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
+        fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
+        xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 3, 0
         if mounted:
             xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([0, 0, 0.06]) + RB['toc_base']       # dressing.py:116-118
             xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, np.pi / 2.0])

@@ -66,7 +66,7 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
                                             checker=DeviceCollisionChecker(blob, pool_size, device))
         return st, cloth
     st = Stepper(blob, pool_size, device)
-    if blob.meta.get('mount') == 'toc':      # a free-standing robot in the feeding scene (FeedingSawyer, FeedingBaxter): base pose search on the host
+    if blob.meta.get('mount') == 'toc' and not blob.has_reset_generator:      # (older blobs: base pose search on the host)
         sampler = 'host'
     if sampler == 'device':
         st.sample_reset(seed, impairment=impairment)
@@ -303,12 +303,12 @@ class FeedingJacoVecEnv(AssistiveVecEnv):
 
 
 class FeedingSawyerVecEnv(AssistiveVecEnv):
-    """FeedingSawyer-v1 (feeding_envs.py:25-27): a free-standing robot -- resets from a pool built with the host sampler (base pose search)"""
+    """FeedingSawyer-v1 (feeding_envs.py:25-27): a free-standing robot -- its base pose search runs in the device-side reset generator like
+    the IK restarts of the mounted arms (reset='pool' / 'device'); reset='host': the numpy sampler"""
     model = 'feeding_sawyer'
 
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
-        assert kw['reset'] != 'device', 'the device-side reset generator places wheelchair-mounted robots only: use a pool'
         super().__init__(n_envs, **kw)
 
 

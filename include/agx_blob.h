@@ -298,7 +298,13 @@ enum {
   AGX_X_CLOTH_GRAVITY = 68,        /* ... and afterwards (dressing.py:195): agx_reset writes it when its settle is over                       */
   AGX_X_CLOTH_ORIG_POS = 69,/* float[3]: the garment is loaded shifted by (end effector position - this) (dressing.py:146-149)              */
   AGX_X_TOC_GOAL_QUAT = 72, /* float[3][4]                                                                                                  */
-  AGX_X_COUNT = 84
+  AGX_X_CHAIN = 84,         /* int[7]: the DoFs of the arm's joints in chain order (each one's parent is the one before; the Sawyer's skip its head pan) */
+  AGX_X_TOC_NGOALS = 91,    /* int: goals besides the start pose (1 ... 3)                                                                 */
+  AGX_X_TOC_GOAL_KIND = 92, /* int: 0 = origins of TOC_GOAL_LINKS (+ TOC_GOAL_OFF); 1 = the mouth target (feeding.py:142)                  */
+  AGX_X_PED_N = 93,         /* int: boxes of the robot's own pedestal (0 ... 2), base frame, already grown by a link radius: a candidate whose
+                               start pose puts a joint origin past the shoulder, a link midpoint or the end effector inside one is rejected */
+  AGX_X_PED_BOX = 96,       /* float[PED_N][6]: min corner, max corner                                                                     */
+  AGX_X_COUNT = 108
 };
 enum {
   AGX_XJ_PARENT = 0,     /* int: parent joint (PyBullet link numbering), -1 = base              */

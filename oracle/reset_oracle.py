@@ -42,7 +42,7 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
           TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
-          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, COUNT=84)
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, PED_BOX=96, COUNT=108)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, STRIDE=36)
@@ -195,19 +195,29 @@ class ResetOracle:
         return compose(self.xf('HBASE_F' if g else 'HBASE_M', 3), np.array([0, 0, 0, 1.0]), p, q)
 
     # -- robot --------------------------------------------------------------------------------------
+    def chain(self):
+        """DoFs of the arm's joints in chain order (AGX_X_CHAIN)"""
+        return [int(self.i[self.x0 + X_['CHAIN'] + k]) for k in range(self.xi('NARM'))]
+
+    def arm_limits(self):
+        ch = self.chain()
+        return (np.array([self.rf(d, 'LOWER') for d in ch], dtype=np.float64), np.array([self.rf(d, 'UPPER') for d in ch], dtype=np.float64))
+
     def arm_fk(self, q, base=None):
         narm = self.xi('NARM')
         pp, pq = base if base is not None else (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
         pos, axw = [], []
-        for d in range(narm):
-            assert self.ri(d, 'PARENT') == d - 1 and self.ri(d, 'ACT') == d
+        ch = self.chain()
+        for k in range(narm):
+            d = ch[k]
+            assert self.ri(d, 'PARENT') == (ch[k - 1] if k else -1) and self.ri(d, 'ACT') == k
             jp, jq = compose(pp, pq, self.rf(d, 'TPOS', 3), self.rf(d, 'TQUAT', 4))
             ax = self.rf(d, 'AXIS', 3)
-            pq = qmul(jq, q_axis_angle(ax, q[d]))
+            pq = qmul(jq, q_axis_angle(ax, q[k]))
             pp = jp
             pos.append(jp)
             axw.append(qrot(pq, ax))
-        assert self.ti('EE_LINK') == narm - 1
+        assert self.ti('EE_LINK') == ch[narm - 1]
         pe, oe = compose(pp, pq, self.tf('EE_POS', 3), self.tf('EE_QUAT', 4))
         return pe, oe, pos, axw
 
@@ -252,8 +262,7 @@ class ResetOracle:
         for d in range(narm):
             J[:3, d] = np.cross(axw[d], pe - pos[d])
             J[3:, d] = axw[d]
-        lower = np.array([self.rf(d, 'LOWER') for d in range(narm)], dtype=np.float64)
-        upper = np.array([self.rf(d, 'UPPER') for d in range(narm)], dtype=np.float64)
+        lower, upper = self.arm_limits()
         qr = 0.5 * (upper - lower)
         w = np.maximum(1.0 - np.power(0.5, (qr - np.abs(qr - q + lower)) / (0.05 * qr) + 1.0), 0.001)
         M = (J * w[None]) @ J.T
@@ -264,8 +273,7 @@ class ResetOracle:
         """Robot.position_robot_toc (robot.py:123-215) as the device runs it: TOC_ATTEMPTS candidate base poses per round, each solving
         the start pose and the position goals from random rest poses; -> (ok, base (p, q), start solution, rounds used, goals reached)"""
         narm, A, rounds = self.xi('NARM'), self.xi('TOC_ATTEMPTS'), self.xi('TOC_ROUNDS')
-        lower = np.array([self.rf(d, 'LOWER') for d in range(narm)], dtype=np.float64)
-        upper = np.array([self.rf(d, 'UPPER') for d in range(narm)], dtype=np.float64)
+        lower, upper = self.arm_limits()
         lo, hi = np.where(lower < -1e9, -2 * np.pi, lower), np.where(upper > 1e9, 2 * np.pi, upper)
         thr, pr, yr = self.xf('TOC_THRESH'), self.xf('TOC_POS_RANGE'), self.xf('TOC_YAW_RANGE')
         base0 = self.xf('BASE_POS', 3)
@@ -278,13 +286,22 @@ class ResetOracle:
                 base = (base0 + np.array([self.xf('TOC_X_SIGN') * pr * u01(seed, stream, T_X), (2 * u01(seed, stream, T_Y) - 1) * pr, 0.0]),
                         q_axis_angle(np.array([0, 0, 1.0]), yaw))
                 reached, manip, qs = 0, 0.0, None
-                for g in range(4):
+                for g in range(1 + len(goals)):
                     q0 = lo + (hi - lo) * np.array([u01(seed, stream, T_REST + 8 * g + d) for d in range(narm)])
                     tp = target_pos if g == 0 else goals[g - 1]
                     tq = target_quat if g == 0 else (goal_quats[g - 1] if goal_quats is not None else None)
                     q = self.ik(q0, lo, hi, tp, tq, iters=self.xi('TOC_IK_ITERS'), base=base)
-                    pe, oe, _, _ = self.arm_fk(q, base)
+                    pe, oe, orig, _ = self.arm_fk(q, base)
                     hit = np.sqrt((tp - pe) @ (tp - pe)) < thr
+                    if g == 0 and hit and self.xi('PED_N') > 0:                    # the pedestal guard (host/reset_bed.py::_arm_in_pedestal)
+                        pts = orig[2:] + [0.5 * (orig[k] + orig[k + 1]) for k in range(2, narm - 1)] + [pe]
+                        bi = np.array([-base[1][0], -base[1][1], -base[1][2], base[1][3]])
+                        for b in range(self.xi('PED_N')):
+                            bx = self.f[self.x0 + X_['PED_BOX'] + 6 * b:self.x0 + X_['PED_BOX'] + 6 * b + 6].astype(np.float64)
+                            for pt in pts:
+                                l = qrot(bi, pt - base[0])
+                                if np.all(l >= bx[:3]) and np.all(l <= bx[3:]):
+                                    hit = False
                     if tq is not None:
                         dm, dp = tq - oe, tq + oe
                         hit = hit and min(np.sqrt(dm @ dm), np.sqrt(dp @ dp)) < thr
@@ -304,8 +321,7 @@ class ResetOracle:
     def restart(self, seed, r, target_pos, target_quat):
         """IK restart r (robot.py:88-99): returns (q, position error, orientation error)"""
         narm = self.xi('NARM')
-        lower = np.array([self.rf(d, 'LOWER') for d in range(narm)])
-        upper = np.array([self.rf(d, 'UPPER') for d in range(narm)])
+        lower, upper = self.arm_limits()
         ik_lo = np.where(lower < -1e9, -2 * np.pi, lower)                 # agent.py:223-231
         ik_hi = np.where(upper > 1e9, 2 * np.pi, upper)
         lo, hi = ik_lo, ik_hi
@@ -374,7 +390,10 @@ class ResetOracle:
         base = (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
         toc_info = None
         if self.xi('TOC_ATTEMPTS') > 0:                                    # a free-standing robot: base pose search instead of IK restarts
-            goals = [self.link_pose(g, int(self.i[self.x0 + X_['TOC_GOAL_LINKS'] + k]), ls, head)[0] + self.xf('TOC_GOAL_OFF', 3) for k in range(3)]
+            if self.xi('TOC_GOAL_KIND') == 1:                              # feeding: the mouth (feeding.py:142)
+                goals = [target]
+            else:
+                goals = [self.link_pose(g, int(self.i[self.x0 + X_['TOC_GOAL_LINKS'] + k]), ls, head)[0] + self.xf('TOC_GOAL_OFF', 3) for k in range(self.xi('TOC_NGOALS'))]
             gq = [self.f[self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k:self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k + 4].astype(np.float64) for k in range(3)] if self.xi('TOC_GOAL_ORIENT') else None
             ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals, gq)
             best_d, n_max = float(ngoal), 0
@@ -392,9 +411,11 @@ class ResetOracle:
                 break
         nr, narm = self.nrobot, self.xi('NARM')
         qfull = np.zeros(self.ndof)
-        qfull[:narm] = best
-        for d in range(narm, nr):                                          # gripper opened instantly, feeding.py:143-144
+        ch = self.chain()
+        for d in range(nr):                                                # gripper (and joints outside the arm) opened instantly, feeding.py:143-144
             qfull[d] = min(max(self.rf(d, 'QT0'), self.rf(d, 'LOWER')), self.rf(d, 'UPPER'))
+        for k, d in enumerate(ch):
+            qfull[d] = best[k]
         for k, j in enumerate(dyn):
             qfull[nr + k] = self.joint_angle(g, j, ls, head)
         st[S['Q']:S['Q'] + self.ndof] = qfull

@@ -32,7 +32,7 @@ def test_model_tables(rb):
     assert [b.robot_i(d, 'PB_INDEX') for d in arm_dofs] == T['arm']
     assert np.isclose(b.robot_f(arm_dofs[0], 'KP'), 0.025) and np.isclose(b.robot_f(arm_dofs[0], 'MAXF'), 1.0)     # feeding.py:122, robot.py:36
     assert b.meta['mount'] == 'toc' and b.h['NCOLL'] > 256                                                          # needs the feeding_l variant
-    assert b.i[b.h['OFF_RESET'] + L.X_['NARM']] == 0                                                               # no device-side reset generator
+    assert b.i[b.h['OFF_RESET'] + L.X_['NARM']] == 7 and b.i[b.h['OFF_RESET'] + L.X_['TOC_ATTEMPTS']] == 50        # the device-side reset generator searches the base pose (robot.py:123)
     c = b.coop()
     assert (c.act_dim, c.obs_dim) == (11, 25 + 23)
 
