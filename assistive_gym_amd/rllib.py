@@ -53,8 +53,7 @@ class AgxVectorEnv(_VectorEnv):
         super().__init__(proto.observation_space, proto.action_space, num_envs)
         self._info_static = {'action_robot_len': proto.action_robot_len, 'action_human_len': proto.action_human_len,
                              'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
-        if name not in ('FeedingJaco-v1', 'FeedingPanda-v1', 'ScratchItchJaco-v1', 'ScratchItchPanda-v1'):
-            vec_kwargs.setdefault('reset', 'pool')         # only the wheelchair-mounted feeding robots have a device-side reset generator
+        vec_kwargs.setdefault('reset', 'pool')             # (reset='device': fresh states every episode, for the models with a device-side reset generator)
         self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=_models()[name], **vec_kwargs)
         self._obs, self._host, self._pack = None, None, None
 
