@@ -100,7 +100,12 @@ int agx_observe(agx_handle h, float* obs_dev, void* stream);
  * how envs are spread over handles or GPUs).  impairment_mode: -1 = random over none/limits/weakness/tremor
  * (human.py:80), -2 = random without tremor, 0..3 = fixed; gender_mode: -1 random, 0 male, 1 female.
  * ik_info_dev (may be NULL): [n_envs][4] float = {IK met the thresholds, restarts used, position error,
- * impairment drawn}.  Follow with agx_settle(h, 25, stream) (feeding.py:178-179) and agx_observe.
+ * impairment drawn}; for a free-standing robot, whose base pose is searched as Robot.position_robot_toc does
+ * (robot.py:123-215: AGX_X_TOC_ATTEMPTS candidate poses per round, one per lane): {a candidate reached the start
+ * pose, rounds used, goals reached by the chosen candidate incl. the start pose, impairment drawn}.
+ * Models with a cloth: the garment is placed at the sampled end effector (dressing.py:146-153), at rest.
+ * Follow with agx_settle(h, 25, stream) (feeding.py:178-179) and agx_observe -- or use agx_reset, which also
+ * switches the garment of a dressing scene from its settle gravity to full gravity when the settle is over.
  * Also zeroes the handle's episode counters. */
 int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream);
 /* reset() of a SUBSET of the envs (gym semantics: the caller resets the envs that are done): envs with
