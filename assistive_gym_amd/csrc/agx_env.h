@@ -419,7 +419,7 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   Ctx c; ctx_init(c, blob, lds, lane);
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
-  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con;
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.dbg = gdebug;
   c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nent = scr.meta[META_NENT];
   // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)
   const bool rowspace = RS_MAX_ROWS > 0 && c.nrows <= RS_MAX_ROWS && c.nv <= 64 && c.nv <= RS_NVP && c.nrows > 0 && c.nent <= SOLVE_LDS_PAIRS;

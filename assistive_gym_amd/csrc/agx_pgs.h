@@ -284,21 +284,44 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
     const float* E = W;                                            // the (J,B) window holds every pair of this environment (env_solve copied them)
     PgsSet S; pgs_load_set(c, lane, lane < R, lane >= nA, S);      // lane r owns row r; friction rows: S.hi = mu
     float* LJ = W + RS_J; float* A = W + RS_A; float* ROW = W + RS_ROW; float* LAM = W + RS_LAM;
-    // dense Jacobians: J[r][d]
+    const long long tA0 = c.dbg ? wave_clock() : 0;                 // debug runs: cycles of forming the dense Jacobians and A (DBG_TIME + 7)
+    // dense Jacobians J[r][d] and response rows B[r][d] = (M^-1 J_r^T)[d]; B overlays the region of A until A is written
+    float* LB = A;
+    static_assert(RS_NVP <= RS_MAX_ROWS || RS_MAX_ROWS == 0, "the dense B rows fit the region of A");
     for (int r = 0; r < R; r++) {
       PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(S.pack, r), wave_bcast_i(S.off, r) & 0x7fffffff, X);
-      if (lane < nv) LJ[RS_NVP * r + lane] = X.j0;
+      if (lane < nv) { LJ[RS_NVP * r + lane] = X.j0; LB[RS_NVP * r + lane] = X.c0; }
     }
     wave_sync();
-    // A[i][j] = sum_d J_j[d] B_i[d]: row i's B goes through a one-row LDS buffer (every lane needs all of it)
-    for (int i = 0; i < R; i++) {
-      PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(S.pack, i), wave_bcast_i(S.off, i) & 0x7fffffff, X);
-      wave_sync(); ROW[lane] = X.c0; wave_sync();
-      float a = 0.f;
-      if (lane < R) for (int d = 0; d < nv; d++) a += LJ[RS_NVP * lane + d] * ROW[d];
-      if (lane < RS_MAX_ROWS) A[RS_MAX_ROWS * i + lane] = a;      // a row of A has RS_MAX_ROWS entries: lanes beyond it must not spill into the next row / the ROW buffer
+    // A = B J^T (A[i][j] = sum_d B_i[d] J_j[d], symmetric up to the rows' DoF ranges) on the matrix cores: 32 x 32 tiles of
+    // v_mfma_f32_32x32x2_f32 steps over d (exact f32), one tile for up to 32 rows, four for up to 56.  Formed by a per-lane loop over d
+    // this was a quarter to a third of the whole solve (measured: 29 ... 50 k of 119 ... 160 k cycles per environment and substep).
+    {
+      const int li = lane & 31, hb = lane >> 5;
+      const bool two = R > 32;
+      Acc16 c00, c01, c10, c11; acc16_zero(c00); acc16_zero(c01); acc16_zero(c10); acc16_zero(c11);
+      for (int d0 = 0; d0 < nv; d0 += 2) {
+        const int d = d0 + hb; const bool dk = d < nv;
+        const float b0 = (dk && li < R) ? LB[RS_NVP * li + d] : 0.f, j0 = (dk && li < R) ? LJ[RS_NVP * li + d] : 0.f;
+        wave_mfma_32x32x2(b0, j0, c00);
+        if (two) {
+          const float b1 = (dk && li + 32 < R) ? LB[RS_NVP * (li + 32) + d] : 0.f, j1 = (dk && li + 32 < R) ? LJ[RS_NVP * (li + 32) + d] : 0.f;
+          wave_mfma_32x32x2(b0, j1, c01); wave_mfma_32x32x2(b1, j0, c10); wave_mfma_32x32x2(b1, j1, c11);
+        }
+      }
+      wave_sync();                                                  // every lane has read B: its region becomes A
+      for (int v = 0; v < 16; v++) {
+        const int i = (v & 3) + 8 * (v >> 2) + 4 * hb;
+        if (i < R && li < R) A[RS_MAX_ROWS * i + li] = acc16_get(c00, v);
+        if (two) {
+          if (i < R && li + 32 < R) A[RS_MAX_ROWS * i + li + 32] = acc16_get(c01, v);
+          if (i + 32 < R && li < R) A[RS_MAX_ROWS * (i + 32) + li] = acc16_get(c10, v);
+          if (i + 32 < R && li + 32 < R) A[RS_MAX_ROWS * (i + 32) + li + 32] = acc16_get(c11, v);
+        }
+      }
     }
     wave_sync();
+    if (c.dbg && lane == 0) c.dbg[DBG_TIME + 7] = (float)(wave_clock() - tA0);
     float w = 0.f;                                                  // J_r . dv of this lane's row
     const int fn = lane - nc;                                       // normal row of this lane's friction row
     const int K = (int)PRM(c, AGX_P_NOOP_RETEST);                   // the no-op re-test rule, see pgs()

@@ -90,3 +90,11 @@ AGX_DEV float wave_clamp(float x, float lo, float hi) { return __builtin_amdgcn_
 AGX_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // optimisation barrier on one register value (no instruction is emitted)
 AGX_DEV void wave_opaque(float& x) { asm volatile("" : "+v"(x)); }
+// 32 x 32 x 2 f32 matrix-core step: c += a_mat (32 x 2) * b_mat (2 x 32), exact f32.  Lane l supplies a_mat[l & 31][l >> 5] and
+// b_mat[l >> 5][l & 31]; register v of lane l holds c[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31] (cdna_hip_programming.md, fragment layout)
+typedef float agx_f32x16 __attribute__((ext_vector_type(16)));
+struct Acc16 { agx_f32x16 v; };
+AGX_DEV void acc16_zero(Acc16& c) { for (int k = 0; k < 16; k++) c.v[k] = 0.f; }
+AGX_DEV float acc16_get(const Acc16& c, int k) { return c.v[k]; }
+AGX_DEV void wave_mfma_32x32x2(float a, float b, Acc16& c) { c.v = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c.v, 0, 0, 0); }
+

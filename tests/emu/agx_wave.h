@@ -66,6 +66,18 @@ AGX_DEV float wave_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo
 AGX_DEV void wave_opaque(float&) {}
 AGX_DEV int wave_uniform(int x) { return x; }
 
+// the 32 x 32 x 2 f32 matrix-core step of csrc/agx_wave.h: the same lane -> element maps, an fmaf chain over k = 0, 1
+struct Acc16 { float v[16]; };
+AGX_DEV void acc16_zero(Acc16& c) { for (int k = 0; k < 16; k++) c.v[k] = 0.f; }
+AGX_DEV float acc16_get(const Acc16& c, int k) { return c.v[k]; }
+AGX_DEV void wave_mfma_32x32x2(float a, float b, Acc16& c) {
+  float A[64], B[64];
+  { const uint32_t* s = emu::exchange(emu::f2u(a)); for (int i = 0; i < 64; i++) A[i] = emu::u2f(s[i]); }
+  { const uint32_t* s = emu::exchange(emu::f2u(b)); for (int i = 0; i < 64; i++) B[i] = emu::u2f(s[i]); }
+  const int l = emu::W->cur, j = l & 31, hb = l >> 5;
+  for (int v = 0; v < 16; v++) { const int i = (v & 3) + 8 * (v >> 2) + 4 * hb; c.v[v] = fmaf(A[i + 32], B[j + 32], fmaf(A[i], B[j], c.v[v])); }
+}
+
 // ---- 16-lane group primitives of the packed solve kernel (csrc/agx_pgs4.h) ----
 // same association as the DPP butterfly of the device code: pairs, quads, halves of the 16-lane row, the row
 AGX_DEV float g16_sum(float x) {
