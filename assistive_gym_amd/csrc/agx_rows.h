@@ -51,7 +51,7 @@ AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_ran
 AGX_DEV int row_block_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return (n > 0 ? 2 * ((lo + n - 1) / 6 - lo / 6 + 1) : 0) + (r.fa >= 0 ? 1 : 0) + (r.fb >= 0 ? 1 : 0); }
 // B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
 // A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
-AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int boff, float bterm, float lo, float hi, int fric_of, float mu) {
+AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int boff, float bterm, float lo, float hi, int fric_of, float mu, const float* Bd) {
   float* L = c.lds; float* E = c.E + 2 * off; const int n = c.ndof;
   float* BEr = c.BE + BRU_WORDS * boff;                      // this row's units: articulated blocks k0..k1 (J, B), then its free bodies' J in ascending order
   float D = 0.f; int e = 0;
@@ -67,7 +67,8 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
     if (USE_SOLVE4) for (int q = 0; q < 2 * BRU_WORDS * nartb; q++) BEr[q] = 0.f;     // padding slots of the touched blocks
     _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i >= alo && i < alo + an) {
       float acc = 0.f;
-      _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j];
+      if (Bd) acc = Bd[i];                 // (M^-1 J^T)[i] of this row, formed for the whole pass on the matrix cores (build_rows)
+      else { _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j]; }
       E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
       if (USE_SOLVE4) { float* o = BEr + 2 * BRU_WORDS * (i / 6 - k0) + i % 6; o[0] = r.Jr[i]; o[6] = acc; }
     }
@@ -241,7 +242,37 @@ AGX_DEV void build_rows(Ctx& c) {
         rb = -row_velocity(c, R);
       }
     }
-    if (go) row_store(c, R, rrow, roff, rboff, rb, rlo, rhi, rfric, rmu);
+    // B = J M^-1 of the articulated part of this pass's rows (lane = row) on the matrix cores: the rows' Jacobians go through LDS (the
+    // collision arena is dead by now), v_mfma_f32_32x32x2_f32 steps over the DoFs into one 32 x MAX_DOF tile per 32 rows, and every lane
+    // reads its row of the product back.  As a per-lane double loop over the DoFs this product was the bulk of this phase: 72 k of the
+    // build kernel's 255 k cycles for a BedBathingSawyer environment (tools/gpu_build_phases.py).
+    const float* Bd = nullptr;
+    if constexpr (MAX_DOF <= 32) {
+      if (wave_any(go && (R.robot || R.human))) {
+        constexpr int JS = MAX_DOF | 1;                              // odd stride: lane = row reads / writes without bank conflicts
+        static_assert(64 * JS <= ARENA_WORDS, "the dense Jacobians of a pass fit the arena");
+        float* JD = L + L_ARENA;
+        _Pragma("unroll") for (int q = 0; q < MAX_DOF; q++) JD[JS * lane + q] = go ? R.Jr[q] : 0.f;
+        wave_sync();
+        const bool two = (wave_ballot(go) >> 32) != 0ull;
+        const int li = lane & 31, hb = lane >> 5;
+        Acc16 t0, t1; acc16_zero(t0); acc16_zero(t1);
+        for (int k0 = 0; k0 < n; k0 += 2) {
+          const int k = k0 + hb; const bool kk = k < n;
+          const float mb = (kk && li < n) ? L[L_MINV + k * MAX_DOF + li] : 0.f;
+          wave_mfma_32x32x2(kk ? JD[JS * li + k] : 0.f, mb, t0);
+          if (two) wave_mfma_32x32x2(kk ? JD[JS * (li + 32) + k] : 0.f, mb, t1);
+        }
+        wave_sync();                                                  // every lane has read the Jacobians: their place takes the product
+        for (int v = 0; v < 16; v++) {
+          const int i = (v & 3) + 8 * (v >> 2) + 4 * hb;
+          if (li < n) { JD[JS * i + li] = acc16_get(t0, v); if (two) JD[JS * (i + 32) + li] = acc16_get(t1, v); }
+        }
+        wave_sync();
+        Bd = JD + JS * lane;
+      }
+    }
+    if (go) row_store(c, R, rrow, roff, rboff, rb, rlo, rhi, rfric, rmu, Bd);
   }
   c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0); c.nbunits = bentF + (nc > 0 ? btot : 0);
   wave_sync();
