@@ -73,11 +73,13 @@ class ModelBlob:
     @property
     def act_dim_robot(self):
         # a single-arm robot driven with robot_arm = 'both' lists its arm joints twice (robot.py:16): DUP_ACT more actions
-        return sum(1 for d in range(self.nrobot) if self.robot_i(d, 'ACT') >= 0) + (self.task_i('DUP_ACT') if self.task_kind == L.TASK_ARM_MANIPULATION else 0)
+        # (joints that share another joint's action -- Robot.action_duplication, AGX_R_ACT_SRC -- add none)
+        return sum(1 for d in range(self.nrobot) if self.robot_i(d, 'ACT') >= 0 and self.robot_i(d, 'ACT_SRC') == 0) + (self.task_i('DUP_ACT') if self.task_kind == L.TASK_ARM_MANIPULATION else 0)
 
     @property
     def obs_dim_robot(self):
-        return {L.TASK_BED_BATHING: 17, L.TASK_SCRATCH_ITCH: 23, L.TASK_DRESSING: 17, L.TASK_ARM_MANIPULATION: 31}.get(self.task_kind, 18) + self.act_dim_robot       # bed_bathing.py:10 / scratch_itch.py:8 / dressing.py:9 / feeding.py:10
+        skipped = sum(1 for d in range(self.nrobot) if self.robot_i(d, 'ACT') >= 0 and self.robot_i(d, 'ACT_SRC') == 0 and self.robot_i(d, 'OBS_SKIP'))     # a mobile robot's wheels (feeding.py:90-92)
+        return {L.TASK_BED_BATHING: 17, L.TASK_SCRATCH_ITCH: 23, L.TASK_DRESSING: 17, L.TASK_ARM_MANIPULATION: 31}.get(self.task_kind, 18) + self.act_dim_robot - skipped       # bed_bathing.py:10 / scratch_itch.py:8 / dressing.py:9 / feeding.py:10
 
     def rec(self, d, gender=0):
         """link record index of DoF d (human DoFs have one record per gender)"""

@@ -26,7 +26,10 @@ constexpr int TASK = AGX_TASK;
 constexpr int MAX_HUMAN = 20;
 constexpr int MAX_CON = 64;
 constexpr int MAX_ROWS = 160;
-constexpr int ST_WORDS = 336;
+#ifndef AGX_ST_WORDS
+#define AGX_ST_WORDS 336
+#endif
+constexpr int ST_WORDS = AGX_ST_WORDS;
 constexpr int CON_STRIDE = 16;
 constexpr int HDR_STRIDE = 10;
 #ifndef AGX_ARENA_WORDS   // LDS arena reused per phase: dynamics workspace, then collider AABB table + worklist + candidates

@@ -119,6 +119,12 @@ AGX_DEV uint32_t rng_next(uint32_t& s0, uint32_t& s1) {
   s0 = (uint32_t)x; s1 = (uint32_t)(x >> 32);
   return (uint32_t)(x >> 33) ^ (uint32_t)(x >> 11);
 }
+// Robot.get_base_pos_orient() (agent.py:142-150), the frame of convert_to_realworld: the pose of the state record, or the moving link
+// that is the base link of a robot on a floating base (AGX_H_BASE_LINK)
+AGX_DEV void robot_base_pose(const Ctx& c, v3& p, m3& R) {
+  const float* L = c.lds; const int bl = c.bi[AGX_H_BASE_LINK];
+  if (bl > 0) { p = ld3(L + L_LINKP + 3 * (bl - 1)); R = ldm3(L + L_LINKR + 9 * (bl - 1)); } else { p = ld3(L + L_BASE); R = ldm3(L + L_BASE + 3); }
+}
 // pose of the tool frame the task reads: the base frame of the spoon (feeding.py:86), link 1 of the wiper (bed_bathing.py:81)
 AGX_DEV void tool_base_pose_of(const Ctx& c, int tb, v3& p, m3& R);
 AGX_DEV void tool_base_pose(const Ctx& c, v3& p, m3& R) { tool_base_pose_of(c, c.bi[AGX_H_TOOL_BODY], p, R); }
@@ -136,7 +142,7 @@ AGX_DEV void tool_base_pose_of(const Ctx& c, int tb, v3& p, m3& R) {
 // tool_force = all contacts of the tool, total_force = total_force_on_human, pad_force = tool_force_on_human
 AGX_DEV void observe_bed(const Ctx& c, float tool_force, float total_force, float pad_force, float* gobs) {
   const float* L = c.lds;
-  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 bp; m3 BR; robot_base_pose(c, bp, BR);
   v3 sp; m3 sR; tool_base_pose(c, sp, sR);
   v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
   v3 jp[3], jpr[3];
@@ -145,7 +151,7 @@ AGX_DEV void observe_bed(const Ctx& c, float tool_force, float total_force, floa
     int o = 0;
     gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z;
     gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
-    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0 && !RBI(c, d, AGX_R_OBS_SKIP)) {
       float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
       gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
     }
@@ -169,7 +175,7 @@ AGX_DEV void observe_bed(const Ctx& c, float tool_force, float total_force, floa
 AGX_DEV void observe_arm(const Ctx& c, float tf_r, float tf_l, float total_force, float thf_r, float thf_l, float* gobs) {
   const float* L = c.lds;
   const int tb2 = TKI(c, AGX_T_TOOL2_BODY); const bool dual = tb2 > 0;
-  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 bp; m3 BR; robot_base_pose(c, bp, BR);
   v3 sp[2]; m3 sR[2];
   tool_base_pose(c, sp[0], sR[0]);
   if (dual) tool_base_pose_of(c, tb2, sp[1], sR[1]); else { sp[1] = sp[0]; sR[1] = sR[0]; }
@@ -184,7 +190,7 @@ AGX_DEV void observe_arm(const Ctx& c, float tf_r, float tf_l, float total_force
       gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z; gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
     }
     for (int rep = 0; rep < (dual ? 1 : 2); rep++)
-      for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+      for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0 && !RBI(c, d, AGX_R_OBS_SKIP)) {
         float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
         gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
       }
@@ -212,7 +218,7 @@ AGX_DEV v3 scratch_target(const Ctx& c) {
 // tool_force = all contacts of the tool, total_force = total_force_on_human, target_force = tool_force_at_target
 AGX_DEV void observe_scratch(const Ctx& c, float tool_force, float total_force, float target_force, float* gobs) {
   const float* L = c.lds;
-  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 bp; m3 BR; robot_base_pose(c, bp, BR);
   v3 sp; m3 sR; tool_base_pose(c, sp, sR);                       // tool.get_pos_orient(1)
   v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
   const v3 tg = scratch_target(c), tgr = tmul(BR, tg - bp);
@@ -224,7 +230,7 @@ AGX_DEV void observe_scratch(const Ctx& c, float tool_force, float total_force, 
     gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
     gobs[o++] = spr.x - tgr.x; gobs[o++] = spr.y - tgr.y; gobs[o++] = spr.z - tgr.z;
     gobs[o++] = tgr.x; gobs[o++] = tgr.y; gobs[o++] = tgr.z;
-    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0 && !RBI(c, d, AGX_R_OBS_SKIP)) {
       float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
       gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
     }
@@ -246,7 +252,7 @@ AGX_DEV void observe_scratch(const Ctx& c, float tool_force, float total_force, 
 // FeedingEnv._get_obs (feeding.py:85-112), robot part; every lane computes, lane 0 writes
 AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* gobs) {
   const float* L = c.lds;
-  v3 bp = ld3(L + L_BASE); m3 BR = ldm3(L + L_BASE + 3);
+  v3 bp; m3 BR; robot_base_pose(c, bp, BR);
   v3 sp; m3 sR; tool_base_pose(c, sp, sR);
   v3 spr = tmul(BR, sp - bp); q4 sq = m3_to_quat(mul_at(BR, sR));
   const int hl = TKI(c, AGX_T_HEAD_LINK);
@@ -257,7 +263,7 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
     gobs[o++] = spr.x; gobs[o++] = spr.y; gobs[o++] = spr.z;
     gobs[o++] = sq.x; gobs[o++] = sq.y; gobs[o++] = sq.z; gobs[o++] = sq.w;
     gobs[o++] = spr.x - tpr.x; gobs[o++] = spr.y - tpr.y; gobs[o++] = spr.z - tpr.z;
-    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0 && !RBI(c, d, AGX_R_OBS_SKIP)) {
       float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
       gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
     }
@@ -321,8 +327,12 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
         // the limit test of take_step is discontinuous (an action that would cross a limit is zeroed,
         // env.py:206-211); it is evaluated in double like the reference's numpy code so that a joint
         // resting exactly on a limit takes the same branch
-        const float a32 = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE);
-        double a = (double)a32, qa = (double)L[L_ST + c.s_q + d]; const double lo = (double)DLO(c, d), hi = (double)DHI(c, d);
+        // Robot.action_multiplier scales a joint's action (env.py:196-197), Robot.action_duplication hands one joint's new target to
+        // several (env.py:218-220): such a joint accumulates from the angle and the limits of its source joint (AGX_R_ACT_SRC)
+        const float mult = RBF(c, d, AGX_R_ACT_MULT);
+        const int ds = RBI(c, d, AGX_R_ACT_SRC) > 0 ? RBI(c, d, AGX_R_ACT_SRC) - 1 : d;
+        const float a32 = fminf(fmaxf(gaction[ai], -1.f), 1.f) * PRM(c, AGX_P_ACTION_SCALE) * (mult != 0.f ? mult : 1.f);
+        double a = (double)a32, qa = (double)L[L_ST + c.s_q + ds]; const double lo = (double)DLO(c, ds), hi = (double)DHI(c, ds);
         double tt = (double)L[L_ST + c.s_tremor + c.nhdof + k2];
         for (int k = 0; k < nsub; k++) {
           bool below = qa + a < lo, above = qa + a > hi;
@@ -752,7 +762,7 @@ AGX_DEV void env_finish_scratch(const uint32_t* blob, float* gstate, const float
 // DressingEnv._get_obs (dressing.py:78-110); every lane computes, lane 0 writes
 AGX_DEV void observe_dressing(const Ctx& c, float cloth_force_sum, float robot_force, float* gobs) {
   const float* L = c.lds;
-  const v3 bp = ld3(L + L_BASE); const m3 BR = ldm3(L + L_BASE + 3);
+  v3 bp; m3 BR; robot_base_pose(c, bp, BR);
   const v3 ep = ld3(L + L_MISC + M_EEP); const m3 eR = ldm3(L + L_MISC + M_EER);
   const v3 epr = tmul(BR, ep - bp); const q4 eq = m3_to_quat(mul_at(BR, eR));
   v3 jp[3], jpr[3];
@@ -761,7 +771,7 @@ AGX_DEV void observe_dressing(const Ctx& c, float cloth_force_sum, float robot_f
     int o = 0;
     gobs[o++] = epr.x; gobs[o++] = epr.y; gobs[o++] = epr.z;
     gobs[o++] = eq.x; gobs[o++] = eq.y; gobs[o++] = eq.z; gobs[o++] = eq.w;
-    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0) {
+    for (int d = 0; d < c.nrobot; d++) if (RBI(c, d, AGX_R_ACT) >= 0 && !RBI(c, d, AGX_R_OBS_SKIP)) {
       float a = L[L_ST + c.s_q + d] + 3.14159265358979f;
       gobs[o++] = (a - 6.28318530717959f * floorf(a / 6.28318530717959f)) - 3.14159265358979f;
     }

@@ -85,6 +85,16 @@
 #define AGX_ARENA_WORDS 4040
 #define AGX_VNAME feeding_l
 #define AGX_K(name) name##_fl
+#elif defined(AGX_VARIANT_FEEDING_M)
+// the feeding scene with a mobile manipulator (FeedingStretch): a floating base (6 virtual joints) + 2 wheels + lift + 4 telescoping joints +
+// wrist + 2 fingers = 16 DoFs in ONE articulated body, plus the 4 head joints
+#define AGX_MAX_DOF 20
+#define AGX_MAX_BLOCK 16
+#define AGX_MAX_COLL 320
+#define AGX_ST_WORDS 344
+#define AGX_ARENA_WORDS 4040
+#define AGX_VNAME feeding_m
+#define AGX_K(name) name##_fm
 #elif defined(AGX_VARIANT_FEEDING)
 #define AGX_VNAME feeding
 #define AGX_K(name) name

@@ -76,7 +76,11 @@ AGX_DEV uint64_t pgs_range_mask(int l0, int l1) {
 // Register map: v64..v79 buffers, v80..v88 temporaries, s80..s95 scalars.
 #define AGX_STR2(x) #x
 #define AGX_STR(x) AGX_STR2(x)
+#if AGX_ST_WORDS == 336          // a literal: the offset is pasted into the assembly text
 #define AGX_SOLVE_ENT_BYTES 1856
+#elif AGX_ST_WORDS == 344
+#define AGX_SOLVE_ENT_BYTES 1888
+#endif
 static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row window used by the assembly");
 // the two sources of a row's pairs: the global scratch (vmcnt) or the LDS window (lgkmcnt)
 #define AGX_LOAD_G(DST, ADDR) "global_load_dwordx2 " DST ", " ADDR ", %[E]\n"

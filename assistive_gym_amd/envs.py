@@ -92,11 +92,14 @@ class AssistiveEnv(_Base):
         self.task_success = 0
         self.total_force_on_human = 0.0
         self._stepper = None
-        arm_pb = [base.robot_i(d, 'PB_INDEX') for d in sorted((d for d in range(base.nrobot) if base.robot_i(d, 'ACT') >= 0), key=lambda d: base.robot_i(d, 'ACT'))]
+        arm_pb = [base.robot_i(d, 'PB_INDEX') for d in sorted((d for d in range(base.nrobot) if base.robot_i(d, 'ACT') >= 0 and base.robot_i(d, 'ACT_SRC') == 0), key=lambda d: base.robot_i(d, 'ACT'))]
         if base.act_dim_robot == 2 * len(arm_pb):                                     # a single-arm robot with robot_arm = 'both' (robot.py:16)
             arm_pb = arm_pb + arm_pb
         hum_pb = [self.blob.robot_i(d, 'PB_INDEX') for d in range(base.nrobot, base.ndof)] if self.coop else []
-        self.robot = _Agent(controllable_joint_indices=arm_pb, mobile=False, motor_gains=base.robot_f(0, 'KP'), motor_forces=base.robot_f(0, 'MAXF'))
+        mobile = base.h['BASE_LINK'] > 0                                              # robot.py:11: 'wheel' in controllable_joints
+        d0 = next(d for d in range(base.nrobot) if base.robot_i(d, 'ACT') >= 0)
+        self.robot = _Agent(controllable_joint_indices=arm_pb, mobile=mobile, motor_gains=base.robot_f(d0, 'KP'), motor_forces=base.robot_f(d0, 'MAXF'),
+                            wheel_joint_indices=[base.robot_i(d, 'PB_INDEX') for d in range(base.nrobot) if base.robot_i(d, 'OBS_SKIP') and base.robot_i(d, 'ACT_SRC') == 0 and base.robot_i(d, 'ACT') >= 0])
         self.human = _Agent(controllable_joint_indices=hum_pb, controllable=self.coop)
         self.tool = _Agent()
         self.camera_width, self.camera_height, self.view_matrix, self.projection_matrix = None, None, None, None
@@ -411,7 +414,7 @@ def _robot_flavours(base_cls, task_name, robots, ref):
 
 _robot_flavours(BedBathingSawyerEnv, 'BedBathing', [('Jaco', 'bed_bathing_jaco'), ('Panda', 'bed_bathing_panda'), ('PR2', 'bed_bathing_pr2'), ('Baxter', 'bed_bathing_baxter')],
                 'bed_bathing_envs.py:15-37,45-79')
-_robot_flavours(FeedingSawyerEnv, 'Feeding', [('PR2', 'feeding_pr2')], 'feeding_envs.py:17-19,41-44')
+_robot_flavours(FeedingSawyerEnv, 'Feeding', [('PR2', 'feeding_pr2'), ('Stretch', 'feeding_stretch')], 'feeding_envs.py:17-19,33-35,41-44,60-63')
 _robot_flavours(DressingBaxterEnv, 'Dressing', [('Sawyer', 'dressing_sawyer'), ('Jaco', 'dressing_jaco'), ('Panda', 'dressing_panda'), ('PR2', 'dressing_pr2')], 'dressing_envs.py:23-37,56-79')
 _robot_flavours(ArmManipulationSawyerEnv, 'ArmManipulation', [('Jaco', 'arm_manipulation_jaco'), ('Panda', 'arm_manipulation_panda'), ('PR2', 'arm_manipulation_pr2'),
                                                               ('Baxter', 'arm_manipulation_baxter')], 'arm_manipulation_envs.py:15-37,41-79')

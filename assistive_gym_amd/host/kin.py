@@ -20,6 +20,7 @@ class RobotKin:
         self.lower = np.array([blob.robot_f(d, 'LOWER') for d in range(n)])
         self.upper = np.array([blob.robot_f(d, 'UPPER') for d in range(n)])
         self.act = [blob.robot_i(d, 'ACT') for d in range(n)]
+        self.prismatic = [blob.robot_i(d, 'JTYPE') == 1 for d in range(n)]
         self.arm = [d for d in range(n) if self.act[d] >= 0]
         self.arm.sort(key=lambda d: self.act[d])
         self.ee_link = blob.task_i('EE_LINK')
@@ -33,7 +34,10 @@ class RobotKin:
         for d in range(self.n):
             pp, pq = (base_pos, base_quat) if self.parent[d] < 0 else (pos[self.parent[d]], quat[self.parent[d]])
             jp, jq = X.compose(pp, pq, self.tpos[d], self.tquat[d])
-            pos[d], quat[d] = jp, X.quat_mul(jq, X.quat_from_axis_angle(self.axis[d], q[d]))
+            if self.prismatic[d]:
+                pos[d], quat[d] = jp + X.quat_rotate(jq, self.axis[d] * q[d]), jq
+            else:
+                pos[d], quat[d] = jp, X.quat_mul(jq, X.quat_from_axis_angle(self.axis[d], q[d]))
         return np.array(pos), np.array(quat)
 
     def ee_pose(self, base_pos, base_quat, q):
@@ -52,8 +56,11 @@ class RobotKin:
         d = self.ee_link
         while d >= 0:
             a = X.quat_rotate(quat[d], self.axis[d])
-            J[:3, d] = np.cross(a, pe - pos[d])
-            J[3:, d] = a
+            if self.prismatic[d]:
+                J[:3, d] = a
+            else:
+                J[:3, d] = np.cross(a, pe - pos[d])
+                J[3:, d] = a
             d = self.parent[d]
         return J
 

@@ -94,7 +94,22 @@ class FeedingJacoReset:
         ik_hi = np.where(kin.upper > 1e9, 2 * np.pi, kin.upper)
         best, best_d, ok, restarts = None, np.inf, False, 0
         base_pos, base_quat = self.base_pos, self.base_quat
-        if self.toc is not None:
+        if b.meta.get('mount') == 'mobile':
+            # a robot on wheels (env.py:282-293): the base around toc_base_pos_offset, yaw around toc_ee_orient_rpy's, no IK;
+            # Stretch.randomize_init_joint_angles (stretch.py:58-62) draws the lift height.  The record's base pose is the anchor of the
+            # robot's six virtual joints, which start at zero.  attempt > 0: init_robot_pose's re-draw after a collision (env.py:299-308).
+            from .reset_bed import placement_rng
+            prng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)
+            pos = np.array(b.meta['mobile_base'], dtype=np.float64)
+            pos[:2] += prng.uniform(-0.1, 0.1, size=2)
+            rpy = np.array(b.meta['mobile_rpy'], dtype=np.float64)
+            rpy[2] += prng.uniform(-D(30), D(30))
+            base_pos, base_quat = pos, X.quat_from_rpy(rpy)
+            best = q.copy()
+            best[b.meta['lift_dof']] = b.meta['lift'] + prng.uniform(-0.1, 0.1)
+            p, o = kin.ee_pose(base_pos, base_quat, best)
+            best_d, ok, max_restarts = float(np.linalg.norm(target_ee_pos - p)), True, 0
+        elif self.toc is not None:
             from .reset_bed import placement_rng
             prng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)
             res = None
@@ -194,7 +209,7 @@ def make_states(blob, n, seed=1001, impairment='random', checker=None, **kw):
         rs.sample(np.random.RandomState(seed + i), st[i:i + 1], env_seed=seed + i, impairment=impairment, info=infos[i], attempt=attempt, **kw)
     for i in range(n):
         draw(i)
-    if checker is not None and rs.toc is not None:
+    if checker is not None and (rs.toc is not None or blob.meta.get('mount') == 'mobile'):
         from .reset_bed import reject_collisions
         flags = reject_collisions(st, checker, draw)
         for i in range(n):

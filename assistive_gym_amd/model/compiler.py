@@ -32,12 +32,12 @@ H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT
          OBS_DIM=11, OFF_PARAMS=12, OFF_ROBOT=13, OFF_FREE=14, OFF_COLL=15, OFF_VERT=16, OFF_GROUP=17, OFF_TASK=18,
          STATE_WORDS=19, S_Q=20, S_QD=21, S_QT=22, S_FREE=23, S_BASE=24, S_HUMAN=25, S_ENV=26, FOOD0=27, TOOL_BODY=28,
          NDIR=29, OFF_DIRS=30, OFF_RESET=31, NROBOT=32, NHDOF=33, S_TREMOR=34, TASK_KIND=35, S_TASK=36, TASK_WORDS=37,
-         OFF_TARGETS=38, OFF_MLP=39, OFF_CLOTH=40, SIM_SUBSTEPS=41, COUNT=48)
+         OFF_TARGETS=38, OFF_MLP=39, OFF_CLOTH=40, SIM_SUBSTEPS=41, BASE_LINK=42, COUNT=48)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
          HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, NOOP_RETEST=20, ORACLE_RESIDUAL_EPS=21, ORACLE_FRICTION_DIRS=22, ORACLE_WARMSTART=23, COUNT=24)
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, COM=11, MASS=14, INERTIA=15, LOWER=21, UPPER=22, HAS_LIMIT=23, KP=24, KD=25,
-         MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, JTYPE=32, STRIDE=36)
+         MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, JTYPE=32, ACT_MULT=33, ACT_SRC=34, OBS_SKIP=35, STRIDE=36)
 F = dict(MASS=0, INERTIA=1, GRAVITY=4, REFPOS=5, REFQUAT=8, KIND=12, RADIUS=13, STRIDE=16)
 C = dict(BODY=0, NVERT=1, VOFF=2, RADIUS=3, FRICTION=4, TAG=5, AABB_C=6, AABB_H=9, LINK=12, STRIDE=16)
 G = dict(A0=0, A1=1, B0=2, B1=3, B0F=4, B1F=5, FLAGS=6, KEEP=7, STRIDE=8)
@@ -182,12 +182,23 @@ def aabb_inertia_in_inertial_frame(link, hulls):
     return box_inertia(link.mass, lo, hi)
 
 
-def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_gain, motor_force, max_hull_verts, frozen=None, use_file_inertia=False):
+def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_gain, motor_force, max_hull_verts, frozen=None, use_file_inertia=False, mobile=None):
     """Returns (records[ndof][R.STRIDE], per-dof collider lists, base collider list, maps).
     frozen: {PyBullet joint index: position} -- movable joints compiled as fixed at that position (their links merge into the
-    carrier of their parent); use_file_inertia: URDF_USE_INERTIA_FROM_FILE (pr2.py:52)."""
+    carrier of their parent); use_file_inertia: URDF_USE_INERTIA_FROM_FILE (pr2.py:52).
+    mobile: a robot on a floating base (useFixedBase=False, stretch.py:68) -- dict(mass=f(pb link, urdf mass) -> mass (the overrides of
+    stretch.py:75-83), motors={pb joint: (gain, force)} (stretch.py:49-50), mult={pb joint: action multiplier} (stretch.py:52),
+    dup={pb joint: pb joint whose target it shares} (action_duplication, stretch.py:51 + env.py:218-220), obs_skip={pb joints left out of
+    the observation}, friction={pb link: lateral friction} (stretch.py:86)).  Six virtual joints (prismatic x, y, z, revolute z, y, x:
+    the convention of compile_bed_settle) are put in front of the URDF's; the last virtual link IS the base link."""
     u = Urdf(urdf_path)
     frozen = frozen or {}
+    if mobile:
+        for idx in range(-1, len(u.indexed_joints)):
+            link = u.link_by_index(idx)
+            link.mass = mobile['mass'](idx, link.mass)
+            if idx in mobile.get('friction', {}):
+                link.lateral_friction = mobile['friction'][idx]
     cache = {}
     n_pb = len(u.indexed_joints)
     # world-at-q0 transform of every PyBullet link frame relative to the robot base (root link) frame
@@ -221,6 +232,7 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
     frictions = {}
     # gather per-link inertial data into carriers
     acc = {d: [] for d in range(len(dof_links))}
+    acc_base = []
     for idx in range(-1, n_pb):
         link = u.link_by_index(idx)
         hulls = link_collision_hulls(link, max_hull_verts, cache)
@@ -229,6 +241,10 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
         if car == -1:
             for verts, radius in hulls:
                 base_colliders.append((X.apply(rp, rq, verts), radius, link.lateral_friction, idx))
+            if mobile and link.mass > 0:
+                cp, cq = X.compose(rp, rq, link.com_pos, link.com_quat)
+                Rm = X.quat_to_mat(cq)
+                acc_base.append((link.mass, cp, Rm @ np.diag(aabb_inertia_in_inertial_frame(link, hulls)) @ Rm.T))
             continue
         d = dof_of_pb[car]
         for verts, radius in hulls:
@@ -270,9 +286,52 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
         else:
             # [BULLET-UNVERIFIED] default URDF joint motor: velocity target 0, max force = URDF effort
             rec[d, R['KP']], rec[d, R['KD']], rec[d, R['MAXF']] = 0.0, 1.0, j.effort
+        if mobile:
+            if pb in mobile.get('motors', {}):
+                rec[d, R['KP']], rec[d, R['MAXF']] = mobile['motors'][pb]
+            if pb in mobile.get('dup', {}):
+                src = mobile['dup'][pb]
+                ints['ACT'] = arm_joints.index(src)
+                ints['ACT_SRC'] = 1 + 6 + dof_of_pb[src]
+                ints['OBS_SKIP'] = 1
+                rec[d, R['ACT_MULT']] = mobile['mult'].get(src, 1.0)
+            if pb in mobile.get('mult', {}):
+                rec[d, R['ACT_MULT']] = mobile['mult'][pb]
+            if pb in mobile.get('obs_skip', ()):
+                ints['OBS_SKIP'] = 1
         rec_int[d] = ints
+    if mobile:
+        VR = 6
+        n = len(dof_links)
+        vrec = np.zeros((VR, R['STRIDE']))
+        vint = {}
+        vaxes = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 0, 1], [0, 1, 0], [1, 0, 0]]
+        for k in range(VR):
+            vrec[k, R['TQUAT'] + 3] = 1.0
+            vrec[k, R['AXIS']:R['AXIS'] + 3] = vaxes[k]
+            vrec[k, R['LOWER']], vrec[k, R['UPPER']] = -1e10, 1e10
+            vint[k] = dict(PARENT=-1 if k == 0 else k - 1, HAS_LIMIT=0, ACT=-1, PB_INDEX=-1, JTYPE=1 if k < 3 else 0)
+        m = sum(a[0] for a in acc_base)
+        com = sum(a[0] * a[1] for a in acc_base) / m
+        I = np.zeros((3, 3))
+        for mi, ci, Ii in acc_base:
+            r = ci - com
+            I += Ii + mi * ((r @ r) * np.eye(3) - np.outer(r, r))
+        vrec[VR - 1, R['COM']:R['COM'] + 3] = com
+        vrec[VR - 1, R['MASS']] = m
+        vrec[VR - 1, R['INERTIA']:R['INERTIA'] + 6] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+        rec = np.concatenate([vrec, rec])
+        for d in range(n):
+            ints = rec_int[d]
+            ints['PARENT'] = VR - 1 if ints['PARENT'] == -1 else ints['PARENT'] + VR
+            vint[VR + d] = ints
+        rec_int = vint
+        dof_of_pb = {pb: d + VR for pb, d in dof_of_pb.items()}
+        dof_links = [-1] * VR + dof_links          # PyBullet link of each moving link; the virtual ones have none (the last one carries link -1)
+        dof_colliders = [[] for _ in range(VR - 1)] + [base_colliders] + dof_colliders
+        base_colliders = []
     return dict(urdf=u, rec=rec, rec_int=rec_int, dof_links=dof_links, dof_of_pb=dof_of_pb, carrier=carrier, rel=rel,
-                dof_colliders=dof_colliders, base_colliders=base_colliders)
+                dof_colliders=dof_colliders, base_colliders=base_colliders, base_link=(6 if mobile else 0))
 
 
 def add_robot_colliders(sc, rob, name, pb_pred):
@@ -525,6 +584,24 @@ FEEDING_ROBOTS = dict(
              toc_base=[0.1, 0.2, 0], ee_rpy=[np.pi / 2.0, 0, 0]))                                                              # pr2.py:36,42
 
 
+# The Stretch (agents/stretch.py): a mobile manipulator on a floating base (useFixedBase=False, :68), controlled as 'wheel_right'
+# (feeding_envs.py:33): actions = two wheels, the lift, the telescoping arm (one action for its four prismatic joints) and the wrist yaw.
+STRETCH = dict(urdf=('stretch', 'stretch_uncalibrated.urdf'),
+               arm=[0, 1, 3, 5, 9], grip=[11, 13],                                               # stretch.py:9-11,14 (wheels first: robot.py:44)
+               gripper_collision=set(range(36)), ee_pb=15, tool_pb=15, selfcol='none',           # stretch.py:19,12,16,68
+               frozen_rest={20: 0.0, 21: 0.0},                                                   # head pan / tilt: not controlled, static geometry
+               mobile=dict(mass=lambda idx, m: 10.0 if idx in (-1, 0, 1) else (0.1 if m > 0 else 0.0),   # stretch.py:75-83
+                           motors={0: (0.1, 10.0), 1: (0.1, 10.0), 3: (0.01, 20.0), 5: (0.025, 10.0), 6: (0.025, 10.0), 7: (0.025, 10.0),
+                                   8: (0.025, 10.0), 9: (0.025, 10.0)},                         # stretch.py:49-50 over all_controllable_joints (:53)
+                           mult={0: 3.0, 1: 3.0, 3: 2.0, 5: 1.0, 9: 2.0},                         # stretch.py:52
+                           dup={6: 5, 7: 5, 8: 5},                                               # stretch.py:51
+                           obs_skip={0, 1},                                                      # feeding.py:90-92
+                           friction={-1: 0.0}))                                                  # stretch.py:86
+FEEDING_ROBOTS['stretch'] = dict(STRETCH, gripper_target=[0.0, 0.0], tool_pos=[0.1, 0, -0.02], tool_rpy=[np.pi / 2.0 - 0.1, 0, -np.pi / 2.0],   # stretch.py:21,27,32
+                                 mobile_base=[-0.9, -0.3, 0.09], mobile_rpy=[0, 0, np.pi / 2.0], lift=0.75,                                      # stretch.py:37,43,58-62
+                                 ee_rpy=[0, 0, np.pi / 2.0])
+
+
 def compile_feeding_jaco(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
     """FeedingJaco-v1 (feeding_envs.py:29-31).  Returns (blob uint32 array, meta dict)."""
     return compile_feeding('jaco', assets, robot_hull_max_verts, n_iter)
@@ -541,15 +618,16 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
     RB = FEEDING_ROBOTS[robot]
     arm, grip = RB['arm'], RB['grip']
     mounted = 'base_pos' in RB                      # on the wheelchair (jaco.py:48, panda.py:49); else placed by the base pose search
+    mobile = RB.get('mobile')                       # or drawn around a fixed spot on its own wheels (env.py:282-293)
     urdf_path = os.path.join(assets, *RB['urdf'])
     frozen = None
     if 'frozen_rest' in RB:                         # the other arm, head, ...: static geometry at their rest pose (see compile_scratch_itch)
         u0 = Urdf(urdf_path)
-        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip + list((RB.get('mobile') or {}).get('dup', ()))}
         frozen.update(RB['frozen_rest'])
     rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'],
                         motor_gain=0.025, motor_force=1.0, max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen,
-                        use_file_inertia=RB.get('file_inertia', False))
+                        use_file_inertia=RB.get('file_inertia', False), mobile=mobile)
     nrobot = len(rob['dof_links'])
     gripper_collision = RB['gripper_collision']    # no collision with the tool (tool.py:42-44)
     if RB.get('selfcol') == 'sawyer':              # ranges as in compile_bed_bathing: links <= 8, links 9.. outside the gripper, gripper
@@ -663,16 +741,20 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
         return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
-        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['base_pos'] if mounted else np.array([-0.85, -0.4, 0]) + RB['toc_base']   # toc_base_pos_offset
-        xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0]) if mounted else [0, 0, 0, 1]      # feeding.py:136; a free-standing robot: robot.py:142-146
-        if not mounted:     # base pose search (robot.py:123-215) with the mouth as the one goal besides the start pose (feeding.py:142)
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, (0 if mobile else len(arm))      # a mobile robot: no device-side generator (no IK in its reset, env.py:282-293)
+        if mobile:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3], xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = RB['mobile_base'], X.quat_from_rpy(RB['mobile_rpy'])
+        else:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['base_pos'] if mounted else np.array([-0.85, -0.4, 0]) + RB['toc_base']   # toc_base_pos_offset
+            xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0]) if mounted else [0, 0, 0, 1]      # feeding.py:136; a free-standing robot: robot.py:142-146
+        if not mounted and not mobile:     # base pose search (robot.py:123-215) with the mouth as the one goal besides the start pose (feeding.py:142)
             xi[X_['TOC_ATTEMPTS']], xi[X_['TOC_ROUNDS']] = 50, 4
             xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW_RANGE']] = 0.5, np.deg2rad(30.0)
             xf[X_['TOC_YAW0']], xf[X_['TOC_X_SIGN']] = 0.0, -1.0
             xi[X_['TOC_IK_ITERS']], xf[X_['TOC_THRESH']] = 100, 0.03
             xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 1, 1
-        fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
+        if not mobile:
+            fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
         xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])                  # toc_ee_orient_rpy
         xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.15, -0.65, 1.15], 0.05   # feeding.py:139
         xf[X_['BOWL_POS']:X_['BOWL_POS'] + 3], xf[X_['BOWL_RANGE']] = [-0.15, -0.65, 0.75], 0.05    # furniture.py:33
@@ -721,11 +803,17 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
                   TOOL_MAXF=500.0, EPISODE_LEN=200)                                        # tool.py:47
     task_i = dict(HEAD_LINK=head_link, EE_LINK=ee_link)
     params = default_params(n_iter)                                                        # robot / human gravity 0: feeding.py:150-152
+    n_obs_joints = len(arm)
+    meta_mobile = {}
+    if mobile:
+        params.update(ROBOT_GRAVITY_Z=-9.81)                                               # a mobile robot keeps its gravity (feeding.py:150-151)
+        n_obs_joints -= len(mobile['obs_skip'])                                            # obs_robot_len, feeding.py:10
+        meta_mobile = dict(mobile_base=list(RB['mobile_base']), mobile_rpy=list(RB['mobile_rpy']), lift=RB['lift'], lift_dof=int(rob['dof_of_pb'][3]))
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
-                dict(NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=25, FOOD0=2, TOOL_BODY=0, TASK_KIND=TASK_FEEDING), reset_fill, reset_words,
-                meta_extra=dict(head_link=int(head_link), robot=robot, mount='wheelchair' if mounted else 'toc', toc_base=list(RB.get('toc_base', [0, 0, 0])),
-                                ee_rpy=list(RB['ee_rpy']), robot_base_pos=list(RB['base_pos']) if mounted else (np.array([-0.85, -0.4, 0]) + RB['toc_base']).tolist(),
-                                robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist()))
+                dict(NFOOD=n_food, ACT_DIM=len(arm), OBS_DIM=18 + n_obs_joints, FOOD0=2, TOOL_BODY=0, TASK_KIND=TASK_FEEDING, BASE_LINK=rob['base_link']), reset_fill, reset_words,
+                meta_extra=dict(head_link=int(head_link), robot=robot, mount='mobile' if mobile else 'wheelchair' if mounted else 'toc', toc_base=list(RB.get('toc_base', [0, 0, 0])),
+                                ee_rpy=list(RB['ee_rpy']), robot_base_pos=list(RB['base_pos']) if mounted else list(RB['mobile_base']) if mobile else (np.array([-0.85, -0.4, 0]) + RB['toc_base']).tolist(),
+                                robot_base_quat=(X.quat_from_rpy(RB['mobile_rpy']) if mobile else X.quat_from_rpy([0, 0, -np.pi / 2.0])).tolist(), **meta_mobile))
 
 
 def capsule_points(p1, p2, radius, distance_between_points):
@@ -1639,6 +1727,7 @@ def compile_arm_manipulation_dual(robot, assets=DEFAULT_ASSETS, n_iter=50, robot
 
 COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feeding_panda,
                  feeding_sawyer=lambda *a, **k: compile_feeding('sawyer', *a, **k), feeding_baxter=lambda *a, **k: compile_feeding('baxter', *a, **k), feeding_pr2=lambda *a, **k: compile_feeding('pr2', *a, **k),
+                 feeding_stretch=lambda *a, **k: compile_feeding('stretch', *a, **k),
                  bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
                  bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),

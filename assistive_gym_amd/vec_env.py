@@ -66,13 +66,13 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
                                             checker=DeviceCollisionChecker(blob, pool_size, device))
         return st, cloth
     st = Stepper(blob, pool_size, device)
-    if blob.meta.get('mount') == 'toc' and not blob.has_reset_generator:      # (older blobs: base pose search on the host)
+    if blob.meta.get('mount') in ('toc', 'mobile') and not blob.has_reset_generator:      # a mobile robot (Stretch): placed by the numpy sampler (older blobs: base pose search on the host)
         sampler = 'host'
     if sampler == 'device':
         st.sample_reset(seed, impairment=impairment)
     elif sampler == 'host':
         checker = None
-        if blob.meta.get('mount') == 'toc':
+        if blob.meta.get('mount') in ('toc', 'mobile'):
             from .host.reset_bed import DeviceCollisionChecker
             checker = DeviceCollisionChecker(blob, pool_size, device)
         states, _ = make_states(blob, pool_size, seed=seed, impairment=impairment, checker=checker)
@@ -309,6 +309,17 @@ class FeedingSawyerVecEnv(AssistiveVecEnv):
 
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
+        super().__init__(n_envs, **kw)
+
+
+class FeedingStretchVecEnv(FeedingSawyerVecEnv):
+    """FeedingStretch-v1 (feeding_envs.py:33-35): the mobile manipulator on its own wheels -- 5 actions (two wheels, lift, telescoping arm,
+    wrist yaw: stretch.py:9-11,51-53), 21 observations (the wheel angles are left out, feeding.py:90-92).  Start states come from the numpy
+    sampler (host/reset.py: env.py:282-293 has no IK for a mobile robot) + the device's collision pass and settle: reset='pool' / 'host'."""
+    model = 'feeding_stretch'
+
+    def __init__(self, n_envs, **kw):
+        assert kw.get('reset', 'pool') != 'device', 'no device-side reset generator for the Stretch: use a pool (pool_refresh > 0 keeps it fresh)'
         super().__init__(n_envs, **kw)
 
 

@@ -63,6 +63,9 @@ enum {
                          The stepper's substep is then DT / SIM_SUBSTEPS long, an env step has FRAME_SKIP * SIM_SUBSTEPS of them, and
                          what the reference does between two stepSimulation calls (limit reset, arm-limit classifier, env.py:226-232)
                          runs after every SIM_SUBSTEPS-th substep                                                                    */
+  AGX_H_BASE_LINK,    /* 1 + the moving link that IS the base link of a robot with a floating base (Stretch: the last of six virtual
+                         joints hanging off the anchor pose AGX_H_S_BASE): Robot.get_base_pos_orient() / convert_to_realworld
+                         (agent.py:142-150, 165-171) read this link's pose.  0 = fixed base, the pose of the state record            */
   AGX_H_COUNT = 48
 };
 
@@ -123,6 +126,12 @@ enum {
                           * by the impairment), bit1 limits NOT scaled (legs, waist: human_creation.py:249-278), bit2 no hard limit
                           * reset (the rag-doll settle of bed_bathing.py:129-131 is plain stepSimulation) */
   AGX_R_JTYPE = 32,      /* int: 0 revolute, 1 prismatic (Sawyer gripper fingers, assets/sawyer/sawyer.urdf)  */
+  AGX_R_ACT_MULT = 33,   /* float: Robot.action_multiplier of this joint's action (env.py:196-197; stretch.py:52); 0 = 1          */
+  AGX_R_ACT_SRC = 34,    /* int: 1 + the DoF whose angle and limits the motor target is accumulated from -- Robot.action_duplication
+                          * (env.py:218-220, stretch.py:51): the four telescoping joints of the Stretch's arm are all told to go where
+                          * the first one's action leads; 0 = the joint itself                                                       */
+  AGX_R_OBS_SKIP = 35,   /* int: 1 = an actuated joint whose angle the observation leaves out (the wheels of a mobile robot,
+                          * feeding.py:90-92, and the duplicates of ACT_SRC, which are not controllable_joint_indices)               */
   AGX_R_STRIDE = 36
 };
 

@@ -1281,9 +1281,12 @@ static uint32_t rng_next(uint32_t* st) { /* 64-bit LCG in two words, xorshifted 
 }
 static void to_base_frame(const sim_t* s, const double* p, const double* R, double* po, double* qo) {
   /* Agent.convert_to_realworld (agent.py:60-64): invertTransform(base) o (p, R) */
-  double d[3]; sub3(p, s->base.p, d); mtv3(s->base.R, d, po);
+  /* the base of a robot on a floating base is a moving link (AGX_H_BASE_LINK) */
+  const int bl = s->m->i[AGX_H_BASE_LINK];
+  const xf_t* B = bl > 0 ? &s->link[bl - 1] : &s->base;
+  double d[3]; sub3(p, B->p, d); mtv3(B->R, d, po);
   if (R && qo) { double Bt[9], Rr[9];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Bt[3 * r + c] = s->base.R[3 * c + r];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Bt[3 * r + c] = B->R[3 * c + r];
     mm3(Bt, R, Rr); mat_to_quat(Rr, qo); }
 }
 static void tool_base_pose_of(const sim_t* s, int tb, double* p, double* R);
@@ -1320,7 +1323,7 @@ static void observe(sim_t* s, double robot_force, double tool_force, float* obs)
   for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k];
   for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k];
   for (int k = 0; k < 3; k++) obs[o++] = (float)(spr[k] - tpr[k]);
-  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0 && !RI(m, d, AGX_R_OBS_SKIP)) {
     double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
   }
   for (int k = 0; k < 3; k++) obs[o++] = (float)hpr[k];
@@ -1349,7 +1352,7 @@ static void observe_bed(sim_t* s, double tool_force, double total_force, double 
   int o = 0;
   for (int k = 0; k < 3; k++) obs[o++] = (float)spr[k];
   for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k];
-  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0 && !RI(m, d, AGX_R_OBS_SKIP)) {
     double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
   }
   for (int j = 0; j < 3; j++) {              /* shoulder, elbow, wrist positions (bed_bathing.py:89-94) */
@@ -1456,7 +1459,7 @@ static void observe_arm(sim_t* s, const double* tf, double total_force, const do
   int o = 0;
   for (int t = 0; t < 2; t++) { for (int k = 0; k < 3; k++) obs[o++] = (float)spr[t][k]; for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[t][k]; }   /* right, then left (:92) */
   for (int rep = 0; rep < (dual ? 1 : 2); rep++)
-    for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+    for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0 && !RI(m, d, AGX_R_OBS_SKIP)) {
       double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
     }
   for (int j = 0; j < 5; j++) { double pr[3]; to_base_frame(s, pts[j], NULL, pr, NULL); for (int k = 0; k < 3; k++) obs[o++] = (float)pr[k]; }
@@ -1565,7 +1568,7 @@ static void observe_scratch(sim_t* s, double tool_force, double total_force, dou
   for (int k = 0; k < 4; k++) obs[o++] = (float)sqr[k];
   for (int k = 0; k < 3; k++) obs[o++] = (float)(spr[k] - tgr[k]);
   for (int k = 0; k < 3; k++) obs[o++] = (float)tgr[k];
-  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0 && !RI(m, d, AGX_R_OBS_SKIP)) {
     double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);
   }
   for (int j = 0; j < 3; j++) {
@@ -1647,7 +1650,7 @@ static void observe_dressing(sim_t* s, double cloth_force_sum, double robot_forc
   int o = 0;
   for (int k = 0; k < 3; k++) obs[o++] = (float)pr[k];
   for (int k = 0; k < 4; k++) obs[o++] = (float)qr[k];
-  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0) {
+  for (int d = 0; d < m->nrobot; d++) if (RI(m, d, AGX_R_ACT) >= 0 && !RI(m, d, AGX_R_OBS_SKIP)) {
     double a = s->q[d] + M_PI, w = a - 2 * M_PI * floor(a / (2 * M_PI)); obs[o++] = (float)(w - M_PI);   /* :84 */
   }
   for (int j = 0; j < 3; j++) {
@@ -1825,7 +1828,10 @@ void agxo_step_cloth(const agxo_model* m, float* state, float* cloth, const floa
     if (is_human && !s->coop) continue;                /* the human only takes actions when controllable */
     float a32 = action[ai]; if (a32 < -1.0f) a32 = -1.0f; if (a32 > 1.0f) a32 = 1.0f;
     a32 *= (float)PARAM(m, AGX_P_ACTION_SCALE);
-    double a = a32, qa = s->q[d], lo = dof_lower(s, d), hi = dof_upper(s, d);
+    /* Robot.action_multiplier (env.py:196-197) and Robot.action_duplication (env.py:218-220): see AGX_R_ACT_MULT / AGX_R_ACT_SRC */
+    const float mult = (float)RF(m, d, AGX_R_ACT_MULT); if (mult != 0.0f) a32 *= mult;
+    const int ds = RI(m, d, AGX_R_ACT_SRC) > 0 ? RI(m, d, AGX_R_ACT_SRC) - 1 : d;
+    double a = a32, qa = s->q[ds], lo = dof_lower(s, ds), hi = dof_upper(s, ds);
     const int k2 = d - m->nrobot;
     for (int k = 0; k < nsub; k++) {
       int below = qa + a < lo, above = qa + a > hi;
@@ -2058,7 +2064,7 @@ int agxo_world_frame(agxo_world* w, int kind, int index, double* pos, double* qu
       quat_to_mat(rq, Rr); xf_apply(&s->freex[index], rp, p); mm3(s->freex[index].R, Rr, R); }
     double r[3], wr[3]; sub3(p, s->fpos[index], r); cross3(s->fw[index], r, wr); add3(s->fv[index], wr, v); memcpy(om, s->fw[index], 24);
   } else if (kind == 2) { if (index < 0 || index >= m->nhuman) return 0; memcpy(p, s->human[index].p, 24); memcpy(R, s->human[index].R, 72); }
-  else if (kind == 3) { memcpy(p, s->base.p, 24); memcpy(R, s->base.R, 72); }
+  else if (kind == 3) { const int bl = m->i[AGX_H_BASE_LINK]; const xf_t* B = bl > 0 ? &s->link[bl - 1] : &s->base; memcpy(p, B->p, 24); memcpy(R, B->R, 72); }
   else return 0;
   if (pos) memcpy(pos, p, 24); if (quat) mat_to_quat(R, quat); if (lin) memcpy(lin, v, 24); if (ang) memcpy(ang, om, 24);
   return 1;
