@@ -696,6 +696,9 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
     # keep=K: a small sphere / hull touching a compound of many convex pieces produces one candidate
     # per piece inside the 2 cm manifold margin; only the K with the smallest predicted gap become
     # solver rows (a deliberate bound -- see DESIGN.md "contact budget")
+    if mobile:      # what the robot stands on comes first: the contact budget (MAX_CON) drops the LAST candidates of a crowded substep
+        grp('robot_arm', 'plane')
+        grp('robot_gripper', 'plane')
     grp('food', 'tool', keep=4)
     grp('food', 'food', same=True)
     grp('food', 'human_male', alt='human_female', keep=2, manifold=True)   # feeding.py:77 asks whether a manifold point exists
@@ -728,8 +731,9 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
         grp('food', 'robot_base', keep=2)
     grp('robot_arm', 'wheelchair')
     grp('robot_gripper', 'wheelchair')
-    grp('robot_arm', 'plane')
-    grp('robot_gripper', 'plane')
+    if not mobile:
+        grp('robot_arm', 'plane')
+        grp('robot_gripper', 'plane')
     grp('tool', 'wheelchair')
     grp('tool', 'plane')
     grp('bowl', 'human_male', alt='human_female', keep=1)
