@@ -85,6 +85,24 @@
 #define AGX_ARENA_WORDS 4040
 #define AGX_VNAME feeding_l
 #define AGX_K(name) name##_fl
+#elif defined(AGX_VARIANT_BED_BATHING_M)
+// bed bathing with the mobile manipulator (BedBathingStretch): 16 robot DoFs on a floating base + the 10 joints of the human's arm
+#define AGX_MAX_DOF 28
+#define AGX_MAX_FREE 2
+#define AGX_MAX_BLOCK 16
+#define AGX_ARENA_WORDS 5632
+#define AGX_TASK 1
+#define AGX_VNAME bed_bathing_m
+#define AGX_K(name) name##_bbm
+#elif defined(AGX_VARIANT_SCRATCH_ITCH_M)
+// ScratchItchStretch: as bed_bathing_m with the scratch-itch task layer
+#define AGX_MAX_DOF 28
+#define AGX_MAX_FREE 2
+#define AGX_MAX_BLOCK 16
+#define AGX_ARENA_WORDS 5632
+#define AGX_TASK 2
+#define AGX_VNAME scratch_itch_m
+#define AGX_K(name) name##_sim
 #elif defined(AGX_VARIANT_FEEDING_M)
 // the feeding scene with a mobile manipulator (FeedingStretch): a floating base (6 virtual joints) + 2 wheels + lift + 4 telescoping joints +
 // wrist + 2 fingers = 16 DoFs in ONE articulated body, plus the 4 head joints

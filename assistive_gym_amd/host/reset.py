@@ -30,6 +30,30 @@ from .kin import RobotKin
 D = np.deg2rad
 
 
+class MobilePlacement:
+    """init_robot_pose for a robot on wheels (env.py:282-293): the base around toc_base_pos_offset (x, y +- 0.1), its yaw around
+    toc_ee_orient_rpy's (+- 30 degrees; none of it in the dressing task), no IK; Stretch.randomize_init_joint_angles (stretch.py:58-62) draws the
+    lift height.  The record's base pose is the anchor of the robot's six virtual joints, which start at zero."""
+
+    def __init__(self, blob):
+        self.blob, self.kin = blob, RobotKin(blob)
+        m = blob.meta
+        self.base, self.rpy, self.lift, self.lift_dof = np.array(m['mobile_base'], dtype=np.float64), np.array(m['mobile_rpy'], dtype=np.float64), m['lift'], m['lift_dof']
+        self.yaw_range = D(30) if m.get('mobile_yaw', True) else 0.0
+
+    def draw(self, prng):
+        """-> base position, base quaternion, joint vector of the robot (virtual joints included)"""
+        kin = self.kin
+        pos = self.base.copy()
+        pos[:2] += prng.uniform(-0.1, 0.1, size=2)
+        rpy = self.rpy.copy()
+        if self.yaw_range > 0:
+            rpy[2] += prng.uniform(-self.yaw_range, self.yaw_range)
+        q = np.clip(np.zeros(kin.n), kin.lower, kin.upper)                         # Agent.init -> enforce_joint_limits
+        q[self.lift_dof] = self.lift + prng.uniform(-0.1, 0.1)
+        return pos, X.quat_from_rpy(rpy), q
+
+
 class FeedingJacoReset:
     def __init__(self, blob):
         self.blob = blob
@@ -43,6 +67,7 @@ class FeedingJacoReset:
         if blob.meta.get('mount', 'wheelchair') == 'toc':
             from .reset_bed import toc_search
             self.toc = toc_search(blob)
+        self.mobile = MobilePlacement(blob) if blob.meta.get('mount') == 'mobile' else None
         self._hm_cache = {}
 
     def _human(self, gender, limit_scale):
@@ -95,18 +120,10 @@ class FeedingJacoReset:
         best, best_d, ok, restarts = None, np.inf, False, 0
         base_pos, base_quat = self.base_pos, self.base_quat
         if b.meta.get('mount') == 'mobile':
-            # a robot on wheels (env.py:282-293): the base around toc_base_pos_offset, yaw around toc_ee_orient_rpy's, no IK;
-            # Stretch.randomize_init_joint_angles (stretch.py:58-62) draws the lift height.  The record's base pose is the anchor of the
-            # robot's six virtual joints, which start at zero.  attempt > 0: init_robot_pose's re-draw after a collision (env.py:299-308).
+            # a robot on wheels (MobilePlacement).  attempt > 0: init_robot_pose's re-draw after a collision (env.py:299-308)
             from .reset_bed import placement_rng
             prng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)
-            pos = np.array(b.meta['mobile_base'], dtype=np.float64)
-            pos[:2] += prng.uniform(-0.1, 0.1, size=2)
-            rpy = np.array(b.meta['mobile_rpy'], dtype=np.float64)
-            rpy[2] += prng.uniform(-D(30), D(30))
-            base_pos, base_quat = pos, X.quat_from_rpy(rpy)
-            best = q.copy()
-            best[b.meta['lift_dof']] = b.meta['lift'] + prng.uniform(-0.1, 0.1)
+            base_pos, base_quat, best = self.mobile.draw(prng)
             p, o = kin.ee_pose(base_pos, base_quat, best)
             best_d, ok, max_restarts = float(np.linalg.norm(target_ee_pos - p)), True, 0
         elif self.toc is not None:

@@ -208,11 +208,16 @@ class BedBathingSawyerReset:
     def __init__(self, blob, settle='drop'):
         assert blob.task_kind == L.TASK_BED_BATHING
         self.blob = blob
-        self.arm = ArmChain(blob)
+        m = blob.meta
+        self.mount = m.get('mount', 'toc')
+        if self.mount == 'mobile':                                  # the Stretch: no arm chain to solve (env.py:282-293)
+            from .reset import MobilePlacement
+            self.arm, self.mobile = None, MobilePlacement(blob)
+        else:
+            self.arm = ArmChain(blob)
         self.human_bodies = blob.meta['human_bodies']
         self.human_dyn = blob.meta['human_dynamic_joints']
         self.settle = settle
-        m = blob.meta
         self.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m.get('toc_base', [-0.2, 0, 0.975]))      # robot.py:142 + toc_base_pos_offset (sawyer.py:37)
         self.ee_R = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy', [0, np.pi / 2.0, 0])))                # toc_ee_orient_rpy (sawyer.py:43)
         r = blob.meta['ranges']
@@ -452,16 +457,19 @@ class BedBathingSawyerReset:
             pre['target_ee_pos'] = np.array([-0.6, 0.2, 1]) + rng.uniform(-0.05, 0.05, size=3)    # bed_bathing.py:147
         target_ee_pos = pre['target_ee_pos']
         prng = placement_rng(rng, env_seed, attempt)
-        toc = None
+        toc = self.mobile.draw(prng) + (0, 0.0) if self.mount == 'mobile' else None
         for _ in range(4):
-            toc = self._toc(prng, target_ee_pos, [shoulder, elbow, wrist])
             if toc is not None:
                 break
+            toc = self._toc(prng, target_ee_pos, [shoulder, elbow, wrist])
         assert toc is not None, 'no reachable base pose found'
         rb_pos, rb_quat, q_arm, ngoal, manip = toc
-        q = np.zeros(nr)
-        for k, d in enumerate(self.arm.chain):
-            q[d] = q_arm[k]
+        if self.mount == 'mobile':
+            q = q_arm.copy()
+        else:
+            q = np.zeros(nr)
+            for k, d in enumerate(self.arm.chain):
+                q[d] = q_arm[k]
         for d in range(nr):                                                        # gripper open position, set instantly (bed_bathing.py:156)
             if b.robot_i(d, 'ACT') < 0:
                 q[d] = min(max(b.robot_f(d, 'QT0'), b.robot_f(d, 'LOWER')), b.robot_f(d, 'UPPER'))
@@ -478,8 +486,11 @@ class BedBathingSawyerReset:
         v['limit_scale'][0] = limit_scale
         v['base'][0, :3], v['base'][0, 3:] = rb_pos, rb_quat
         # tool in the gripper (tool.py:49-62): base frame = end-effector frame o TOOL; the record holds the COM frame
-        pe, Re, _, _ = self.arm.fk(rb_pos[None], X.quat_to_mat(rb_quat)[None], q_arm[None])
-        tp, tq = X.compose(pe[0], X.mat_to_quat(Re[0]), b.task_f('TOOL_POS', 3), b.task_f('TOOL_QUAT', 4))
+        if self.mount == 'mobile':
+            tp, tq = self.mobile.kin.tool_pose(rb_pos, rb_quat, q)
+        else:
+            pe, Re, _, _ = self.arm.fk(rb_pos[None], X.quat_to_mat(rb_quat)[None], q_arm[None])
+            tp, tq = X.compose(pe[0], X.mat_to_quat(Re[0]), b.task_f('TOOL_POS', 3), b.task_f('TOOL_QUAT', 4))
         ip, iq = X.invert(b.free_f(0, 'REFPOS', 3), b.free_f(0, 'REFQUAT', 4))
         cp, cq = X.compose(tp, tq, ip, iq)
         free = v['free'][0]

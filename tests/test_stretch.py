@@ -1,6 +1,9 @@
-"""FeedingStretch-v1 (feeding_envs.py:33-35, agents/stretch.py) without a GPU: the mobile manipulator's model blob against the reference's
-robot table, the mobile branch of init_robot_pose on the host (env.py:282-293), the wheels against analytic rolling / turning cases in the
-oracle, and the feeding_m kernel variant on the wave emulator against the oracle.  PARITY UNPINNED vs PyBullet (the physics half)."""
+"""The Stretch (agents/stretch.py) without a GPU -- FeedingStretch-v1 (feeding_envs.py:33-35) in detail, ScratchItchStretch-v1 and
+BedBathingStretch-v1 (scratch_itch_envs.py:31-33, bed_bathing_envs.py:31-33) on the same machinery: the mobile manipulator's model blob
+against the reference's robot table, the mobile branch of init_robot_pose on the host (env.py:282-293), the wheels against analytic rolling /
+turning cases in the oracle, and the *_m kernel variants on the wave emulator against the oracle.  ArmManipulationStretch is not built: the
+reference's own take_step raises for it (Stretch('wheel_both') has 8 controllable joints, its action_multiplier 5 entries: env.py:197).
+PARITY UNPINNED vs PyBullet (the physics half)."""
 import numpy as np
 import pytest
 
@@ -172,3 +175,77 @@ def test_emulator_settle_and_step_match_the_oracle(rb, coop):
             assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4
             assert np.abs(b.view(s1[None])['q'] - b.view(s2[None])['q']).max() < 5e-5
             s = s1
+
+
+# ---- the other tasks of the Stretch ----------------------------------------------------------------------------------------------------
+def _task_states(blob, n, seed, **kw):
+    from assistive_gym_amd.host import reset_bed, reset_scratch
+    from assistive_gym_amd.model import compiler as L
+    if blob.task_kind == L.TASK_SCRATCH_ITCH:
+        return reset_scratch.make_states(blob, n, seed=seed, **kw)[0]
+    return reset_bed.make_states(blob, n, seed=seed, **kw)[0]
+
+
+@pytest.fixture(scope='module', params=['scratch_itch', 'bed_bathing'])
+def tb(request):
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    b = ModelBlob.load(request.param + '_stretch')
+    return request.param, b, Oracle(b)
+
+
+def test_other_tasks_model_tables(tb):
+    from assistive_gym_amd.model import compiler as L
+    task, b, o = tb
+    base_obs = {'scratch_itch': 23, 'bed_bathing': 17}[task]                                   # scratch_itch.py:8, bed_bathing.py:10
+    assert (b.act_dim, b.obs_dim, b.nrobot, b.nhdof) == (5, base_obs + 3, 16, 10) and b.h['BASE_LINK'] == 6
+    assert b.meta['mount'] == 'mobile' and not b.has_reset_generator
+    assert b.meta['mobile_base'] == {'scratch_itch': [-1.0, -0.1, 0.09], 'bed_bathing': [-1.1, -0.1, 0.09]}[task]        # stretch.py:37,39
+    assert b.meta['lift'] == {'scratch_itch': 0.75, 'bed_bathing': 0.95}[task]                                             # stretch.py:58-62
+    assert [b.robot_f(d, 'QT0') for d in (14, 15)] == [np.float32(0.1)] * 2                                                # gripper_pos, stretch.py:21,24
+    assert b.param('ROBOT_GRAVITY_Z') == np.float32(-9.81) and b.param('HUMAN_GRAVITY_Z') == (0.0 if task == 'scratch_itch' else -1.0)
+    c = b.coop()
+    assert (c.act_dim, c.obs_dim) == (15, 2 * base_obs + 3 + 1 + 10)
+
+
+def test_other_tasks_reset_stand_and_drive(tb):
+    task, b, o = tb
+    st = _task_states(b, 3, 4101)
+    for i in range(3):
+        s = st[i].copy()
+        v = b.view(s[None])
+        assert np.all(np.abs(v['base'][0, :2] - np.array(b.meta['mobile_base'][:2])) <= 0.1 + 1e-6) and v['base'][0, 2] == np.float32(0.09)
+        assert abs(v['q'][0, 8] - b.meta['lift']) <= 0.1 + 1e-6 and np.all(v['q'][0, :8] == 0)
+        v['plane_friction'][0] = 0.5
+        o.settle(s, 15)
+        q0 = b.view(s[None])['q'][0].copy()
+        assert abs(q0[2] + 0.09) < 2e-3 and np.all(np.abs(q0[3:6]) < 0.02)
+        a = np.zeros(b.act_dim, np.float32)
+        a[0] = a[1] = 1.0
+        for k in range(10):
+            obs, rew, done, info = o.step(s, a)
+        q1 = b.view(s[None])['q'][0].copy()
+        dist, want = np.linalg.norm(q1[:2] - q0[:2]), 0.0508 * (q1[6:8] - q0[6:8]).mean()
+        assert 0.9 * want <= dist <= 1.01 * want and np.isfinite(obs).all() and np.isfinite(rew)
+
+
+@pytest.mark.parametrize('coop', [False, pytest.param(True, marks=full)])
+def test_other_tasks_emulator_matches_the_oracle(tb, coop):
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    task, b, _ = tb
+    b12 = (b.coop() if coop else b).set_param('NITER', 12)
+    o12, e12 = Oracle(b12), Emu(b12)
+    st = _task_states(b12, 1, 4110)
+    rng = np.random.RandomState(5)
+    s = st[0].copy()
+    o12.settle(s, 8)                      # onto the ground
+    for k in range(3):
+        a = rng.uniform(-1, 1, b12.act_dim).astype(np.float32)
+        s1, s2 = s.copy(), s.copy()
+        o_obs, o_rew, o_done, o_info = o12.step(s1, a)
+        e_obs, e_rew, e_done, e_info, _ = e12.step(s2, a)
+        assert o_info[6] == e_info[6] and o_info[7] == e_info[7]
+        assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4
+        assert np.abs(b.view(s1[None])['q'] - b.view(s2[None])['q']).max() < 5e-5
+        s = s1
