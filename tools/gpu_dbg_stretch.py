@@ -2,29 +2,22 @@ import sys, numpy as np
 sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 from assistive_gym_amd.blob import ModelBlob
 from assistive_gym_amd.libagx import Stepper
-from assistive_gym_amd.vec_env import build_reset_pool
 from oracle_lib import Oracle
-np.set_printoptions(precision=4,suppress=True,linewidth=220)
-b=ModelBlob.load('feeding_stretch'); o=Oracle(b)
-n=16
-states=build_reset_pool(b,n,5001)
+np.set_printoptions(precision=5,suppress=True,linewidth=220)
+b=ModelBlob.load('bed_bathing_stretch'); o=Oracle(b)
+states=np.load(sys.argv[1])
+n=len(states)
 s=Stepper(b,n)
 rng=np.random.RandomState(7)
 ref=states.copy()
 for k in range(4):
-    s.set_state(ref)
     a=rng.uniform(-1,1,(n,b.act_dim)).astype(np.float32)
-    obs,rew,done,info=s.step_host(a)
-    got=s.get_state()
+    s.set_state(ref); obs,rew,done,info=s.step_host(a); g=s.get_state()
+    prev=ref.copy()
     for i in range(n):
-        r0=ref[i].copy()
         oo=o.step(ref[i],a[i])
-        bad = (not np.isfinite(rew[i])) or (not np.isfinite(oo[1])) or bool(done[i])!=oo[2] or np.abs(obs[i]-oo[0]).max()>1e-3
-        if bad:
-            print('step',k,'env',i,'dev rew',rew[i],'done',done[i],'info',info[i],'| ora rew',oo[1],oo[2],oo[3])
-            print(' q0 ',b.view(r0[None])['q'][0][:16]); print(' qd0',b.view(r0[None])['qd'][0][:16])
-            print(' dev q',b.view(got[i:i+1])['q'][0][:16]); print(' ora q',b.view(ref[i:i+1])['q'][0][:16])
-            print(' act',a[i])
-            np.save('gpurun_out/stretch_bad_state.npy', r0); np.save('gpurun_out/stretch_bad_action.npy', a[i])
-            sys.exit(0)
-print('all fine')
+        d=np.abs(b.view(g[i:i+1])['q'][0]-b.view(ref[i:i+1])['q'][0])
+        if d.max()>2e-4:
+            print('step',k,'env',i,'q diff',d.max(),'at',int(d.argmax()),'obs diff',np.abs(obs[i]-oo[0]).max(),'ncon',info[i,6],oo[3][6],'rows',info[i,7],oo[3][7], 'force',info[i,0],oo[3][0])
+            print(' diff',d)
+            np.save('gpurun_out/bed_bad_state_%d_%d.npy'%(k,i), prev[i]); np.save('gpurun_out/bed_bad_action_%d_%d.npy'%(k,i), a[i])
