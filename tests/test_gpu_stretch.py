@@ -29,8 +29,10 @@ def rb(request):
 
 def test_step_matches_oracle(rb):
     """single-step parity.  A dynamic human arm lying on the bed (bed bathing, co-op or tremor) is an ill-conditioned contact state: changing
-    one joint angle by 1e-6 moves the ORACLE's own next state by up to 4e-4.  An environment that misses the plain tolerances is therefore
-    re-run in the oracle from a start state perturbed by 1e-6 rad, and the device must stay within 20 x the oracle's own spread.
+    the joint angles by 1e-6 moves the ORACLE's own next state by up to 2e-3 (an elbow resting exactly on its limit, a trembling arm on the
+    mattress; the CPU emulator of the kernels deviates from the oracle by as much on such a state).  An environment that misses the plain
+    tolerances is therefore re-run in the oracle from start states perturbed by +-1e-6 rad, and the device must stay within 20 x the oracle's
+    own spread.
     Joint angles: 3e-4 instead of the 5e-5 of the fixed-base robots -- the step in which the 31 kg base lands on its wheels from the 9 cm it is
     spawned above the ground (stretch.py:37) carries 0.1 kg links on it (stretch.py:79-80): 50 sweeps leave that impact unconverged, and the
     f32 sweeps then differ from the oracle's f64 ones by up to 1.5e-4 (measured; the contact sets are identical)."""
@@ -63,12 +65,19 @@ def test_step_matches_oracle(rb):
                 for key in worst:
                     worst[key] = max(worst[key], dev[key])
                 continue
-            pert = start.copy()
-            b.view(pert[None])['q'][0] += np.float32(1e-6)
-            p_obs, p_rew, p_done, p_info = oracle.step(pert, actions[i])
-            spread = dict(obs=(np.abs(p_obs - o_obs) / scale).max(), reward=abs(p_rew - o_rew) / max(1.0, abs(o_rew)),
-                          force=abs(p_info[0] - o_info[0]) / max(1.0, abs(o_info[0])), q=np.abs(b.view(pert[None])['q'] - b.view(ref[i])['q']).max())
+            spread = dict(obs=0.0, reward=0.0, force=0.0, q=0.0)
+            for eps in (1e-6, -1e-6):                                                  # both sides: a joint resting exactly on a limit reacts to one of them only
+                pert = start.copy()
+                b.view(pert[None])['q'][0] += np.float32(eps)
+                p_obs, p_rew, p_done, p_info = oracle.step(pert, actions[i])
+                for key, val in dict(obs=(np.abs(p_obs - o_obs) / scale).max(), reward=abs(p_rew - o_rew) / max(1.0, abs(o_rew)),
+                                     force=abs(p_info[0] - o_info[0]) / max(1.0, abs(o_info[0])), q=np.abs(b.view(pert[None])['q'] - b.view(ref[i])['q']).max()).items():
+                    spread[key] = max(spread[key], val)
             conditioned += 1
+            if any(dev[key] > 20 * spread[key] + dict(obs=3e-4, reward=1e-4, force=1e-3, q=3e-4)[key] for key in dev):     # keep the case for a replay on the emulator
+                import os
+                os.makedirs('gpurun_out', exist_ok=True)
+                np.savez('gpurun_out/stretch_parity_case_%s_%d.npz' % (b.task_name, int(b.is_coop)), start=start, action=actions[i], dev_state=got[i], dev_obs=obs[i])
             for key in dev:
                 assert dev[key] <= 20 * spread[key] + dict(obs=3e-4, reward=1e-4, force=1e-3, q=3e-4)[key], (k, i, key, dev, spread)
     st.close()
