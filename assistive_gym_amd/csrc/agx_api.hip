@@ -133,9 +133,9 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   const agx_variant* V = nullptr;
   {
     // the first (smallest) variant with the model's task layer whose limits hold the model
-    const agx_variant* all[13] = {agx_variant_feeding(), agx_variant_feeding_l(), agx_variant_feeding_m(), agx_variant_bed_bathing(), agx_variant_bed_bathing_l(), agx_variant_bed_bathing_m(),
+    const agx_variant* all[14] = {agx_variant_feeding(), agx_variant_feeding_l(), agx_variant_feeding_m(), agx_variant_bed_bathing(), agx_variant_bed_bathing_l(), agx_variant_bed_bathing_m(),
                                  agx_variant_scratch_itch(), agx_variant_scratch_itch_m(), agx_variant_bed_settle(),
-                                 agx_variant_dressing(), agx_variant_dressing_l(), agx_variant_arm_manipulation(), agx_variant_arm_manipulation_l()};
+                                 agx_variant_dressing(), agx_variant_dressing_l(), agx_variant_dressing_m(), agx_variant_arm_manipulation(), agx_variant_arm_manipulation_l()};
     bool task_seen = false;
     for (const agx_variant* v : all) {
       if (v->task_kind != hi[AGX_H_TASK_KIND]) continue;

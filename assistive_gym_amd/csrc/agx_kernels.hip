@@ -103,6 +103,15 @@
 #define AGX_TASK 2
 #define AGX_VNAME scratch_itch_m
 #define AGX_K(name) name##_sim
+#elif defined(AGX_VARIANT_DRESSING_M)
+// DressingStretch: 16 robot DoFs on a floating base + the 10 joints of the human's left arm; plus the cloth kernel
+#define AGX_MAX_DOF 28
+#define AGX_MAX_FREE 1
+#define AGX_MAX_BLOCK 16
+#define AGX_ARENA_WORDS 5632
+#define AGX_TASK 3
+#define AGX_VNAME dressing_m
+#define AGX_K(name) name##_drm
 #elif defined(AGX_VARIANT_FEEDING_M)
 // the feeding scene with a mobile manipulator (FeedingStretch): a floating base (6 virtual joints) + 2 wheels + lift + 4 telescoping joints +
 // wrist + 2 fingers = 16 DoFs in ONE articulated body, plus the 4 head joints

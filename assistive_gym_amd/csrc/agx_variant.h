@@ -49,5 +49,6 @@ extern "C" const agx_variant* agx_variant_feeding_l(void);
 extern "C" const agx_variant* agx_variant_feeding_m(void);
 extern "C" const agx_variant* agx_variant_bed_bathing_m(void);
 extern "C" const agx_variant* agx_variant_scratch_itch_m(void);
+extern "C" const agx_variant* agx_variant_dressing_m(void);
 extern "C" const agx_variant* agx_variant_dressing_l(void);
 extern "C" const agx_variant* agx_variant_arm_manipulation_l(void);

@@ -415,7 +415,7 @@ def _robot_flavours(base_cls, task_name, robots, ref):
 _robot_flavours(BedBathingSawyerEnv, 'BedBathing', [('Jaco', 'bed_bathing_jaco'), ('Panda', 'bed_bathing_panda'), ('PR2', 'bed_bathing_pr2'), ('Baxter', 'bed_bathing_baxter'), ('Stretch', 'bed_bathing_stretch')],
                 'bed_bathing_envs.py:15-37,45-79')
 _robot_flavours(FeedingSawyerEnv, 'Feeding', [('PR2', 'feeding_pr2'), ('Stretch', 'feeding_stretch')], 'feeding_envs.py:17-19,33-35,41-44,60-63')
-_robot_flavours(DressingBaxterEnv, 'Dressing', [('Sawyer', 'dressing_sawyer'), ('Jaco', 'dressing_jaco'), ('Panda', 'dressing_panda'), ('PR2', 'dressing_pr2')], 'dressing_envs.py:23-37,56-79')
+_robot_flavours(DressingBaxterEnv, 'Dressing', [('Sawyer', 'dressing_sawyer'), ('Jaco', 'dressing_jaco'), ('Panda', 'dressing_panda'), ('PR2', 'dressing_pr2'), ('Stretch', 'dressing_stretch')], 'dressing_envs.py:23-37,56-79')
 _robot_flavours(ArmManipulationSawyerEnv, 'ArmManipulation', [('Jaco', 'arm_manipulation_jaco'), ('Panda', 'arm_manipulation_panda'), ('PR2', 'arm_manipulation_pr2'),
                                                               ('Baxter', 'arm_manipulation_baxter')], 'arm_manipulation_envs.py:15-37,41-79')
 _robot_flavours(ScratchItchPR2Env, 'ScratchItch', [('Baxter', 'scratch_itch_baxter'), ('Stretch', 'scratch_itch_stretch')], 'scratch_itch_envs.py:21-23,31-33,46-50,58-62')

@@ -38,11 +38,15 @@ class DressingReset(BedBathingSawyerReset):
     def __init__(self, blob):
         assert blob.task_kind == L.TASK_DRESSING
         self.blob = blob
-        self.arm = ArmChain(blob)
-        self.human_bodies = blob.meta['human_bodies']
-        self.human_dyn = blob.meta['human_dynamic_joints']
         m = blob.meta
         self.mount = m.get('mount', 'toc')
+        if self.mount == 'mobile':                                  # the Stretch: no arm chain to solve (env.py:282-293)
+            from .reset import MobilePlacement
+            self.arm, self.mobile = None, MobilePlacement(blob)
+        else:
+            self.arm = ArmChain(blob)
+        self.human_bodies = blob.meta['human_bodies']
+        self.human_dyn = blob.meta['human_dynamic_joints']
         self.toc_base = np.array([-0.85, -0.4, 0]) + np.array(m.get('toc_base', [1.7, 0.7, 0.925]))      # robot.py:142 + toc_base_pos_offset (baxter.py:39)
         self.fixed_base = np.array([0, 0, 0.06]) + np.array(m.get('toc_base', [0, 0, 0]))                # wheelchair position + offset, rpy (0, 0, pi/2) (dressing.py:116-118)
         self.ee_R = X.quat_to_mat(X.quat_from_rpy(m.get('ee_rpy', [0, -np.pi / 2.0, 0])))                # toc_ee_orient_rpy['dressing'][0] (baxter.py:45)
@@ -99,7 +103,9 @@ class DressingReset(BedBathingSawyerReset):
         off = np.array([0, 0, 0.1])
         toc = None
         rng = placement_rng(rng, env_seed, attempt)     # attempt > 0: a re-draw of the placement only (env.py:281); nothing else is drawn after it
-        if self.mount == 'wheelchair':       # Robot.ik_random_restarts from the fixed base on the human's left (env.py:295-297)
+        if self.mount == 'mobile':
+            toc = self.mobile.draw(rng) + (0, 0.0)
+        elif self.mount == 'wheelchair':     # Robot.ik_random_restarts from the fixed base on the human's left (env.py:295-297)
             toc = self._mounted_ik(rng, target_ee_pos, self.fixed_base, X.quat_from_rpy([0, 0, np.pi / 2.0]), human=(hm, hpos, hquat, hbase))
         else:
             for _ in range(4):
@@ -108,9 +114,12 @@ class DressingReset(BedBathingSawyerReset):
                     break
         assert toc is not None, 'no reachable base pose found'
         rb_pos, rb_quat, q_arm, ngoal, manip = toc
-        q = np.zeros(nr)
-        for k, d in enumerate(self.arm.chain):
-            q[d] = q_arm[k]
+        if self.mount == 'mobile':
+            q = q_arm.copy()
+        else:
+            q = np.zeros(nr)
+            for k, d in enumerate(self.arm.chain):
+                q[d] = q_arm[k]
         for d in range(nr):                                                        # gripper open position, set instantly (dressing.py:140)
             if b.robot_i(d, 'ACT') < 0:
                 q[d] = min(max(b.robot_f(d, 'QT0'), b.robot_f(d, 'LOWER')), b.robot_f(d, 'UPPER'))
@@ -128,8 +137,11 @@ class DressingReset(BedBathingSawyerReset):
         v['human_maxf'][0] = 0.0 if agent else 1.0 * strength
         v['limit_scale'][0] = limit_scale
         v['base'][0, :3], v['base'][0, 3:] = rb_pos, rb_quat
-        pe, Re, _, _ = self.arm.fk(rb_pos[None], X.quat_to_mat(rb_quat)[None], q_arm[None])
-        start_ee_pos = pe[0]                                                       # dressing.py:146
+        if self.mount == 'mobile':
+            start_ee_pos = self.mobile.kin.ee_pose(rb_pos, rb_quat, q)[0]
+        else:
+            pe, Re, _, _ = self.arm.fk(rb_pos[None], X.quat_to_mat(rb_quat)[None], q_arm[None])
+            start_ee_pos = pe[0]                                                   # dressing.py:146
         cloth_offset = start_ee_pos - self.cloth_orig_pos                          # :148-149
         cloth_row[0] = (self.x0 + cloth_offset).astype(np.float32)
         cloth_row[1] = 0

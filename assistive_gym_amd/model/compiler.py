@@ -1430,16 +1430,22 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
     PR2 [deviation, DESIGN.md]."""
     from .cloth import compile_cloth
     sc = Scene()
-    RB = robot_table('dressing', robot)
+    RB = robot_table('dressing', robot) if robot != 'stretch' else None
+    if robot == 'stretch':
+        # the Stretch as 'wheel_left' (dressing_envs.py:31-33): stretch.py:25,41,47,58-60; its base keeps the orientation of toc_ee_orient_rpy
+        # (no yaw draw in this task, env.py:288-291); its motor gains are divided by numSubSteps (dressing.py:135-137)
+        mob = dict(STRETCH['mobile'], motors={j: (g / 8.0, f) for j, (g, f) in STRETCH['mobile']['motors'].items()})
+        RB = dict(STRETCH, mobile=mob, gripper_target=[0.0, 0.0], mobile_base=[0.75, -0.4, 0.09], mobile_rpy=[0, 0, -H_PI], mobile_yaw=False, lift=0.95,
+                  ee_rpy=[0, 0, -H_PI], ee_rpy_shoulder=[0, 0, -H_PI], toc_base=[0, 0, 0], wheelchair_mounted=False)
     arm, grip = RB['arm'], RB['grip']
     urdf_path = os.path.join(assets, *RB['urdf'])
     frozen = None
     if 'frozen_rest' in RB:
         u0 = Urdf(urdf_path)
-        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip}
+        frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in kept_joints(RB, arm, grip)}
         frozen.update(RB['frozen_rest'])
     rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.01, motor_force=1.0,          # dressing.py:121
-                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False))
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen, use_file_inertia=RB.get('file_inertia', False), mobile=RB.get('mobile'))
     nrobot = len(rob['dof_links'])
     if RB['selfcol'] == 'sawyer':
         add_robot_colliders(sc, rob, 'robot_lower', lambda pb: pb <= 8)
@@ -1467,9 +1473,12 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
     sc.end('plane')
     G_ = Groups(sc.ranges)
     grp = G_.add
+    if RB.get('mobile'):                                # first: what a mobile robot stands on (contact budget, see compile_feeding)
+        grp('robot_links', 'plane')
     grp('robot_links', 'human_male', alt='human_female', keep=2)
     grp('robot_links', 'wheelchair', keep=2)
-    grp('robot_links', 'plane')
+    if not RB.get('mobile'):
+        grp('robot_links', 'plane')
     if RB['selfcol'] == 'all':
         grp('robot_links', 'robot_links', same=True, no_adjacent=True)
     elif RB['selfcol'] == 'sawyer':
@@ -1491,6 +1500,9 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
                   ARM_LIMIT_DOF=[nrobot + 3, nrobot + 4, nrobot + 5, nrobot + 6], ARM_LIMIT_ON=0)
     params = default_params(n_iter)
     params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-1.0)                               # dressing.py:179-181
+    n_obs_joints, hdr_mobile, meta_mobile = mobile_extras(RB, rob, arm, params)
+    if meta_mobile:
+        meta_mobile['mobile_yaw'] = False
     from .h5lite import load_keras_dense_stack
     mlp = load_keras_dense_stack(os.path.join(assets, 'realistic_arm_limits_model.h5'))
     # the cloth is tested against the human, the robot and the wheelchair (not the ground: the gown never reaches it in an episode)
@@ -1509,7 +1521,7 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
     # shoulder / elbow / wrist (dressing.py:132; the Sawyer with its pedestal guard) --, the garment shifted to the end effector, settle
     # gravity on the cloth.
     mounted = RB['wheelchair_mounted']
-    generator = True
+    generator = not RB.get('mobile')                    # a mobile robot is placed by the numpy sampler (env.py:282-293 has no IK)
 
     def reset_words(nhuman, nhdof):
         return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if generator else 0)
@@ -1550,11 +1562,11 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
         xf[X_['CLOTH_ORIG_POS']:X_['CLOTH_ORIG_POS'] + 3] = cloth_orig_pos
         fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {6: -90, 13: -45, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}, cloth=True)   # dressing.py:123
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, [], params, task_f, task_i,
-                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRESSING), reset_fill, reset_words,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + n_obs_joints, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRESSING, **hdr_mobile), reset_fill, reset_words,
                 task_words=DR['WORDS'], mlp=mlp, cloth=cloth, sim_substeps=8,
                 meta_extra=dict(arm_joints=arm, gripper_joints=grip, cloth=cmeta, cloth_orig_pos=cloth_orig_pos.tolist(), robot=robot,
-                                mount='wheelchair' if RB['wheelchair_mounted'] else 'toc', toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy']),
-                                ee_rpy_shoulder=list(RB['ee_rpy_shoulder'])))
+                                mount='mobile' if RB.get('mobile') else 'wheelchair' if RB['wheelchair_mounted'] else 'toc', toc_base=list(RB['toc_base']), ee_rpy=list(RB['ee_rpy']),
+                                ee_rpy_shoulder=list(RB['ee_rpy_shoulder']), **meta_mobile))
 
 
 def compile_arm_manipulation_sawyer(assets=DEFAULT_ASSETS, n_iter=50):
@@ -1768,6 +1780,7 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
                  bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
+                 dressing_stretch=lambda *a, **k: compile_dressing('stretch', *a, **k),
                  scratch_itch_stretch=lambda *a, **k: compile_scratch_itch('stretch', *a, **k), bed_bathing_stretch=lambda *a, **k: compile_bed_bathing('stretch', *a, **k),
                  scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,

@@ -426,5 +426,5 @@ class DressingBaxterHumanVecEnv(DressingBaxterVecEnv):
     coop = True
 
 
-for _r in ('sawyer', 'jaco', 'panda', 'pr2'):
+for _r in ('sawyer', 'jaco', 'panda', 'pr2', 'stretch'):      # (stretch: mobile, 5 actions, 20 observations; pool from the numpy sampler + the device's cloth settle)
     _vec_flavour(DressingBaxterVecEnv, 'Dressing%sVecEnv' % {'pr2': 'PR2'}.get(_r, _r.capitalize()), 'dressing_' + _r)

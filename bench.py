@@ -237,7 +237,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     if env_cls is None:
         env = vec_env.AssistiveVecEnv(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, model=model, coop=env_id.endswith('Human-v1'), blob=blob_override,
                                       pool_refresh=getattr(args, 'pool_refresh', 0))
-        ksuffix = {'feeding': '', 'feeding_l': '_fl', 'feeding_m': '_fm', 'bed_bathing': '_bb', 'bed_bathing_l': '_bbl', 'bed_bathing_m': '_bbm', 'scratch_itch': '_si', 'scratch_itch_m': '_sim', 'dressing': '_dr', 'dressing_l': '_drl',
+        ksuffix = {'feeding': '', 'feeding_l': '_fl', 'feeding_m': '_fm', 'bed_bathing': '_bb', 'bed_bathing_l': '_bbl', 'bed_bathing_m': '_bbm', 'scratch_itch': '_si', 'scratch_itch_m': '_sim', 'dressing': '_dr', 'dressing_l': '_drl', 'dressing_m': '_drm',
                    'arm_manipulation': '_am', 'arm_manipulation_l': '_aml'}[env.stepper.variant()]
     else:
         env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, blob=blob_override, pool_refresh=getattr(args, 'pool_refresh', 0))

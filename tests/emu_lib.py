@@ -22,6 +22,7 @@ VARIANT_DEFS['feeding_l'] = ['-DAGX_MAX_COLL=320', '-DAGX_MAX_BLOCK=12', '-DAGX_
 VARIANT_DEFS['feeding_m'] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_BLOCK=16', '-DAGX_MAX_COLL=320', '-DAGX_ST_WORDS=344', '-DAGX_ARENA_WORDS=4040']    # FeedingStretch
 VARIANT_DEFS['bed_m'] = ['-DAGX_MAX_DOF=28', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=16', '-DAGX_ARENA_WORDS=5632', '-DAGX_TASK=1']          # BedBathingStretch
 VARIANT_DEFS['scratch_m'] = ['-DAGX_MAX_DOF=28', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=16', '-DAGX_ARENA_WORDS=5632', '-DAGX_TASK=2']      # ScratchItchStretch
+VARIANT_DEFS['dressing_m'] = ['-DAGX_MAX_DOF=28', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=16', '-DAGX_ARENA_WORDS=5632', '-DAGX_TASK=3']     # DressingStretch (rigid scene)
 VARIANT_DEFS['dressing_l'] = ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=3']
 VARIANT_DEFS['arm_l'] = ['-DAGX_MAX_DOF=32', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=22', '-DAGX_ARENA_WORDS=7552', '-DAGX_TASK=4']
 VARIANT_DEFS['bed_l'] = ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=1']
@@ -57,7 +58,7 @@ def _p(a):
 class Emu:
     def __init__(self, blob, kind=None):
         self.blob = blob
-        self.L = lib(kind) if kind is not None else lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_m' if (blob.task_kind == 0 and blob.ndof > 16) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_m' if blob.task_kind == 1 and blob.nrobot > 12 else 'scratch_m' if blob.task_kind == 2 and blob.nrobot > 12 else 'bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
+        self.L = lib(kind) if kind is not None else lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_m' if (blob.task_kind == 0 and blob.ndof > 16) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_m' if blob.task_kind == 1 and blob.nrobot > 12 else 'scratch_m' if blob.task_kind == 2 and blob.nrobot > 12 else 'bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_m' if blob.task_kind == 3 and blob.nrobot > 12 else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
         self.words = np.ascontiguousarray(blob.words)
         lay = (C.c_int * 8)()
         self.L.agx_emu_debug_layout(lay)

@@ -37,4 +37,4 @@ def test_every_env_id_has_its_blob():
     from assistive_gym_amd.model.compiler import COMPILERS
     for env_id, cls in ENV_IDS.items():
         assert cls.model in COMPILERS and os.path.exists(os.path.join(DATA_DIR, cls.model + '.agxblob')), env_id
-    assert len(ENV_IDS) == 56
+    assert len(ENV_IDS) == 58

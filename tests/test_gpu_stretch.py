@@ -139,3 +139,43 @@ def test_vec_env_rollout_and_scalar_env(rb):
     else:
         assert o.shape == (b.obs_dim,)
     e.disconnect()
+
+
+def test_dressing_stretch():
+    """DressingStretch-v1 (dressing_envs.py:31-33): the pool built the product way (numpy mobile placement, collision rejection, the 50-step
+    cloth settle on the device during which the robot drops onto its wheels), one env.step of the device -- rigid scene + cloth kernel --
+    against the oracle from a pool entry, a short batched rollout"""
+    import torch
+    from assistive_gym_amd import libagx, vec_env
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    if libagx.load().agx_device_count() <= 0:
+        __import__('conftest').no_gpu()
+    b = ModelBlob.load('dressing_stretch')
+    o = Oracle(b)
+    env = vec_env.DressingStretchVecEnv(4, pool_size=4, seed=321)
+    assert env.stepper.variant() == 'dressing_m'
+    obs = env.reset()
+    assert obs.shape == (4, 20) and torch.isfinite(obs).all()
+    s0, c0 = env.stepper.get_state(), env.stepper.get_cloth()
+    assert np.isfinite(c0).all() and np.percentile(np.linalg.norm(c0[:, 1], axis=2), 90) < 1.5        # settled
+    for i in range(4):
+        q = b.view(s0[i:i + 1])['q'][0]
+        assert abs(q[2] + 0.09) < 3e-3 and np.all(np.abs(q[3:6]) < 0.05)                               # standing on the ground
+    act = np.random.RandomState(5).uniform(-1, 1, (4, 5)).astype(np.float32)
+    obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+    obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+    gc = env.stepper.get_cloth()
+    for i in range(2):
+        rs, rc = s0[i].copy(), c0[i].copy()
+        o_obs, o_rew, o_done, o_info = o.step_cloth(rs, rc, act[i])
+        assert np.abs(obs[i, :19] - o_obs[:19]).max() < 3e-4, (i, np.abs(obs[i, :19] - o_obs[:19]).max())
+        assert abs(rew[i] - o_rew) < 5e-3 + 0.01 * abs(obs[i, 19] - o_obs[19])
+        dx = np.abs(gc[i, 0] - rc[0])
+        assert np.median(dx) < 2e-4 and np.percentile(dx, 99) < 3e-3, (np.median(dx), np.percentile(dx, 99))
+    a = torch.zeros(4, 5, device='cuda')
+    a[:, 0] = a[:, 1] = 1.0
+    for _ in range(5):
+        ob, rw, dn, inf = env.step(a)
+    assert torch.isfinite(ob).all() and torch.isfinite(rw).all() and env.stepper.overflow_count() == 0
+    env.close()

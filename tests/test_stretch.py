@@ -249,3 +249,55 @@ def test_other_tasks_emulator_matches_the_oracle(tb, coop):
         assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4
         assert np.abs(b.view(s1[None])['q'] - b.view(s2[None])['q']).max() < 5e-5
         s = s1
+
+
+# ---- DressingStretch-v1 (dressing_envs.py:31-33): the rigid scene + the garment hanging from the gripper ------------------------------------
+@pytest.fixture(scope='module')
+def db():
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    b = ModelBlob.load('dressing_stretch')
+    return b, Oracle(b)
+
+
+def test_dressing_model_tables(db):
+    from assistive_gym_amd.model import compiler as L
+    b, o = db
+    assert b.task_kind == L.TASK_DRESSING and (b.act_dim, b.obs_dim, b.nrobot, b.nhdof, b.nfree) == (5, 17 + 3, 16, 10, 0) and b.h['SIM_SUBSTEPS'] == 8      # dressing.py:9,184
+    assert b.h['BASE_LINK'] == 6 and b.meta['mount'] == 'mobile' and not b.has_reset_generator and b.meta['mobile_yaw'] is False
+    assert b.meta['mobile_base'] == [0.75, -0.4, 0.09] and np.allclose(b.meta['mobile_rpy'], [0, 0, -np.pi / 2]) and b.meta['lift'] == 0.95                  # stretch.py:41,47,59-60
+    # the motor gains are divided by numSubSteps (dressing.py:135-137)
+    assert np.allclose([b.robot_f(d, 'KP') for d in range(6, 14)], np.array([0.1] * 2 + [0.01] + [0.025] * 5) / 8.0)
+    assert [b.robot_f(d, 'MAXF') for d in range(6, 14)] == [10] * 2 + [20] + [10] * 5
+    c = b.coop()
+    assert (c.act_dim, c.obs_dim) == (15, 20 + 28)
+
+
+def test_dressing_reset_garment_and_emulator_parity(db):
+    from emu_lib import Emu
+    from assistive_gym_amd.host.reset_dressing import make_states
+    from assistive_gym_amd.model import compiler as L
+    from test_dressing import cloth_tables
+    b, o = db
+    e = Emu(b)
+    st, cloth, infos = make_states(b, 2, seed=47)
+    t = cloth_tables(b)
+    for i in range(2):
+        v = b.view(st[i:i + 1])
+        assert np.all(np.abs(v['base'][0, :2] - np.array([0.75, -0.4])) <= 0.1 + 1e-6) and np.allclose(v['base'][0, 3:], X.quat_from_rpy([0, 0, -np.pi / 2]), atol=1e-6)   # no yaw draw
+        ee, q = o.ee_pose(st[i])
+        assert np.allclose(ee, infos[i]['start_ee_pos'], atol=1e-5)
+        assert np.allclose(cloth[i, 0] - t['x0'], ee - np.array(b.meta['cloth_orig_pos']), atol=1e-5)            # dressing.py:148-153
+    s, c = st[0].copy(), cloth[0].copy()
+    b.view(s.reshape(1, -1))['task'][0, L.DR['CLOTH_GRAVITY']] = np.array([-9.81 / 2], dtype=np.float32).view(np.int32)[0]
+    o.settle_cloth(s, c, 3)
+    ee, _ = o.ee_pose(s)
+    assert np.isfinite(c).all() and np.abs(c[0, t['anchors']].mean(0) - ee).max() < 0.03                        # the anchors follow the (falling) gripper
+    so, se = st[0].copy(), st[0].copy()
+    rng = np.random.RandomState(2)
+    for k in range(2):
+        a = rng.uniform(-1, 1, 5).astype(np.float32)
+        o_obs, o_rew, o_done, o_info = o.step(so, a)
+        e_obs, e_rew, e_done, e_info, _ = e.step(se, a)
+        assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4 and o_done == e_done
+        assert np.abs(b.view(so.reshape(1, -1))['q'] - b.view(se.reshape(1, -1))['q']).max() < 5e-5
