@@ -159,9 +159,11 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     const int32_t* T = hi + hi[AGX_H_OFF_TASK];
     // the arm: rs_narm joints in a serial chain (AGX_X_CHAIN: each joint's parent is the one before, the first hangs off the base), the
     // k-th one driven by action k, the last one carrying the end effector
+    const bool mobile = (X[AGX_X_FLAGS] & 8) != 0;    // a robot on wheels: no arm chain to solve (its NARM only says that the blob has a reset section)
     if (X[AGX_X_NARM] != V->rs_narm || hi[AGX_H_NROBOT] < V->rs_narm || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64 || X[AGX_X_TOC_ATTEMPTS] > 64 ||
         X[AGX_X_TOC_NGOALS] > 3 || X[AGX_X_PED_N] > 2) can_sample = false;
-    for (int k = 0; can_sample && k < V->rs_narm; k++) {
+    if (mobile && (X[AGX_X_MOBILE_LIFT_DOF] < 0 || X[AGX_X_MOBILE_LIFT_DOF] >= hi[AGX_H_NROBOT] || X[AGX_X_TOC_ATTEMPTS] != 0 || X[AGX_X_IK_RESTARTS] != 0)) can_sample = false;
+    for (int k = 0; can_sample && !mobile && k < V->rs_narm; k++) {
       const int d = X[AGX_X_CHAIN + k];
       if (d < 0 || d >= hi[AGX_H_NROBOT]) { can_sample = false; break; }
       const int32_t* R = hi + hi[AGX_H_OFF_ROBOT] + d * AGX_R_STRIDE;

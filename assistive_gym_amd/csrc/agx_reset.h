@@ -122,6 +122,24 @@ AGX_DEV void rs_link_pose(const ResetCtx& c, int link, d3& p, dq& q) {
 }
 
 // arm forward kinematics: joint origins, world joint axes, end-effector pose
+// end-effector pose of a robot on wheels (AGX_X_FLAGS bit 3): the chain from the link that carries the end effector up to the base
+// (virtual joints, lift, telescoping joints, wrist: any joint types), every joint at zero but the lift
+AGX_DEV void rs_mobile_fk(const ResetCtx& c, int lift_dof, double lift_q, d3& pe, dq& oe) {
+  int links[24], n = 0;
+  for (int d = ((const int*)c.task)[AGX_T_EE_LINK]; d >= 0 && n < 24; d = ((const int*)c.rob)[d * AGX_R_STRIDE + AGX_R_PARENT]) links[n++] = d;
+  d3 pp = c.base_p; dq pq = c.base_q;
+  for (int k = n - 1; k >= 0; k--) {
+    const int d = links[k];
+    const float* r = c.rob + d * AGX_R_STRIDE;
+    d3 jp; dq jq;
+    dcompose(pp, pq, dld3(r + AGX_R_TPOS), dld4(r + AGX_R_TQUAT), jp, jq);
+    const double qd = d == lift_dof ? lift_q : fmin(fmax((double)r[AGX_R_QT0], (double)r[AGX_R_LOWER]), (double)r[AGX_R_UPPER]);
+    const d3 ax = dld3(r + AGX_R_AXIS);
+    if (((const int*)r)[AGX_R_JTYPE] == 1) { pp = jp + dqrot(jq, dmk(ax.x * qd, ax.y * qd, ax.z * qd)); pq = jq; }
+    else { pp = jp; pq = dqmul(jq, dq_axis_angle(ax, qd)); }
+  }
+  dcompose(pp, pq, dld3(c.task + AGX_T_EE_POS), dld4(c.task + AGX_T_EE_QUAT), pe, oe);
+}
 AGX_DEV void rs_arm_fk(const ResetCtx& c, const double* q, d3* pos, d3* axw, d3& pe, dq& oe) {
   d3 pp = c.base_p; dq pq = c.base_q;
 #pragma unroll
@@ -332,7 +350,19 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
 #pragma unroll
   for (int d = 0; d < RS_NARM; d++) best_q[d] = 0.0;
   const int toc_attempts = XI(c, AGX_X_TOC_ATTEMPTS);
-  if (toc_attempts > 0) {
+  const bool mobile = (xflags & 8) != 0;
+  double lift_q = 0.0;
+  if (mobile) {
+    // ---- a robot on wheels (env.py:282-293): three draws for the base, one for the lift (stretch.py:58-62); placement `first_restart` has its
+    // own stream, as the placements of the base pose search have
+    const uint32_t stream = (uint32_t)RS_T_STREAM0 + (uint32_t)first_restart;
+    const double prange = XF(c, AGX_X_TOC_POS_RANGE), yrange = XF(c, AGX_X_TOC_YAW_RANGE);
+    c.base_p = dld3(c.xf + AGX_X_BASE_POS) + dmk((2.0 * rs_u01(seed_lo, seed_hi, stream, RS_T_X) - 1.0) * prange, (2.0 * rs_u01(seed_lo, seed_hi, stream, RS_T_Y) - 1.0) * prange, 0.0);
+    c.base_q = dq_axis_angle(dmk(0, 0, 1), XF(c, AGX_X_TOC_YAW0) + (2.0 * rs_u01(seed_lo, seed_hi, stream, RS_T_YAW) - 1.0) * yrange);
+    lift_q = XF(c, AGX_X_MOBILE_LIFT) + (2.0 * rs_u01(seed_lo, seed_hi, stream, RS_T_REST) - 1.0) * 0.1;
+    ok = 1; restarts = 0; best_d = 0.0;
+  }
+  else if (toc_attempts > 0) {
     // ---- a free-standing robot: Robot.position_robot_toc (robot.py:123-215), one candidate base pose per lane.  A candidate solves the
     // IK for the start pose (position + orientation) and for the position goals on the human's arm from random rest poses; candidates that
     // reach the start pose compete by (goals reached, summed JLWKI of the reached goals), the earliest one wins ties (robot.py:204: >).
@@ -476,14 +506,17 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
 
   // ---- write the record (every lane now holds the chosen arm pose) ---------------------------------
   d3 pos[RS_NARM], axw[RS_NARM], pe, tp; dq oe, tq;
-  rs_arm_fk(c, best_q, pos, axw, pe, oe);
+  const int lift_dof = mobile ? XI(c, AGX_X_MOBILE_LIFT_DOF) : -1;
+  if (mobile) rs_mobile_fk(c, lift_dof, lift_q, pe, oe);
+  else rs_arm_fk(c, best_q, pos, axw, pe, oe);
   dcompose(pe, oe, dld3(c.task + AGX_T_TOOL_POS), dld4(c.task + AGX_T_TOOL_QUAT), tp, tq);                   // tool.py:49-62
   if (lane < ndof) {
     double qv;
     int ck = -1;
 #pragma unroll
-    for (int d = 0; d < RS_NARM; d++) ck = c.chain[d] == lane ? d : ck;
-    if (ck >= 0) {
+    for (int d = 0; d < RS_NARM; d++) ck = (!mobile && c.chain[d] == lane) ? d : ck;
+    if (lane == lift_dof) qv = lift_q;
+    else if (ck >= 0) {
       qv = best_q[0];
 #pragma unroll
       for (int d = 1; d < RS_NARM; d++) qv = ck == d ? best_q[d] : qv;
@@ -568,7 +601,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     }
     if (ginfo) { ginfo[0] = (float)ok; ginfo[1] = (float)restarts; ginfo[2] = (float)best_d; ginfo[3] = (float)imp; }
   }
-  if (toc_attempts > 0) return ok ? first_restart : -1;         // the placement that was accepted (the next one, if it collides, is first_restart + 1)
+  if (toc_attempts > 0 || mobile) return ok ? first_restart : -1;   // the placement that was accepted (the next one, if it collides, is first_restart + 1)
   return ok ? restarts - 1 : -1;
 }
 

@@ -54,7 +54,7 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
           TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
-          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, PED_BOX=96, COUNT=108)
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, COUNT=108)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
          TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, HUMAN_KP=14, HUMAN_MAXF=15, COUNT=16)
@@ -350,6 +350,19 @@ def mobile_extras(RB, rob, arm, params):
     meta = dict(mobile_base=list(RB['mobile_base']), mobile_rpy=list(RB['mobile_rpy']), lift=RB['lift'], lift_dof=int(rob['dof_of_pb'][3]),
                 robot_base_pos=list(RB['mobile_base']), robot_base_quat=X.quat_from_rpy(RB['mobile_rpy']).tolist())
     return len(arm) - len(mobile['obs_skip']), dict(BASE_LINK=rob['base_link']), meta
+
+
+def fill_reset_mobile(xf, xi, RB, rob):
+    """the reset section of a robot on wheels (AGX_X_FLAGS bit 3; env.py:282-293, stretch.py:58-62): call after the scene's own fill"""
+    xi[X_['NARM']] = 7                                 # (the generator's arm chain is compiled for 7 joints; a mobile robot does not use it)
+    xi[X_['FLAGS']] |= 8
+    xi[X_['TOC_ATTEMPTS']], xi[X_['IK_RESTARTS']], xi[X_['PED_N']] = 0, 0, 0
+    xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['mobile_base']
+    xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy(RB['mobile_rpy'])
+    assert RB['mobile_rpy'][0] == 0 and RB['mobile_rpy'][1] == 0
+    xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW0']] = 0.1, RB['mobile_rpy'][2]
+    xf[X_['TOC_YAW_RANGE']] = np.deg2rad(30.0) if RB.get('mobile_yaw', True) else 0.0
+    xf[X_['MOBILE_LIFT']], xi[X_['MOBILE_LIFT_DOF']] = RB['lift'], rob['dof_of_pb'][3]
 
 
 def add_robot_colliders(sc, rob, name, pb_pred):
@@ -763,7 +776,7 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
         return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        xi[X_['NJOINT']], xi[X_['NARM']] = 42, (0 if mobile else len(arm))      # a mobile robot: no device-side generator (no IK in its reset, env.py:282-293)
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
         if mobile:
             xf[X_['BASE_POS']:X_['BASE_POS'] + 3], xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = RB['mobile_base'], X.quat_from_rpy(RB['mobile_rpy'])
         else:
@@ -811,6 +824,8 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
                 xi[b0 + XJ['DRAW']] = draw.get(j, -1)
         xi[ob:ob + nhuman] = human_bodies
         xi[od:od + nhdof] = hd
+        if mobile:
+            fill_reset_mobile(xf, xi, RB, rob)
     # end effector = PyBullet link 8 (jaco.py:11), carried by the moving link of joint 7; link 11 of the Panda (panda.py:11)
     ee_pb = RB['ee_pb']
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
@@ -1338,7 +1353,7 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
     # the device-side reset generator (csrc/agx_reset.h) samples ScratchItchEnv.reset (scratch_itch.py:93-132): a wheelchair-mounted arm by
     # IK restarts, a free-standing robot by the base pose search of Robot.position_robot_toc (robot.py:123-215; the Sawyer with the pedestal
     # guard of reset_bed._arm_in_pedestal as a candidate filter)
-    generator = not RB.get('mobile')                    # a mobile robot is placed by the numpy sampler (host/reset_scratch.py; env.py:282-293 has no IK)
+    generator = True
     n_obs_joints, hdr_mobile, meta_mobile = mobile_extras(RB, rob, arm, params)
 
     def reset_words(nhuman, nhdof):
@@ -1348,7 +1363,8 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
         if not generator:
             return      # the pool comes from assistive_gym_amd/host/reset_scratch.py
         xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
-        fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
+        if not RB.get('mobile'):
+            fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
         xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 3, 0
         if mounted:
             xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([0, 0, 0.06]) + RB['toc_base']       # scratch_itch.py:97-99
@@ -1373,6 +1389,8 @@ def compile_scratch_itch(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max
         xi[X_['COLLISION_TRIES']] = 3                                                        # env.py:276 max_iterations
         xf[X_['REACTIVE_KP']], xf[X_['REACTIVE_MAXF']], xi[X_['FLAGS']] = 0.01, 1.0, 3         # scratch_itch.py:105
         fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {3: 30, 6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80})   # scratch_itch.py:104
+        if RB.get('mobile'):
+            fill_reset_mobile(xf, xi, RB, rob)
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=23 + n_obs_joints, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_SCRATCH_ITCH, **hdr_mobile), reset_fill, reset_words,
                 task_words=SI['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot, mount=RB['mount'],
@@ -1521,7 +1539,7 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
     # shoulder / elbow / wrist (dressing.py:132; the Sawyer with its pedestal guard) --, the garment shifted to the end effector, settle
     # gravity on the cloth.
     mounted = RB['wheelchair_mounted']
-    generator = not RB.get('mobile')                    # a mobile robot is placed by the numpy sampler (env.py:282-293 has no IK)
+    generator = True
 
     def reset_words(nhuman, nhdof):
         return X_['COUNT'] + (2 * 42 * XJ['STRIDE'] + nhuman + nhdof if generator else 0)
@@ -1530,7 +1548,8 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
         if not generator:
             return      # the pool comes from assistive_gym_amd/host/reset_dressing.py
         xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
-        fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
+        if not RB.get('mobile'):
+            fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
         xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 3, 0
         if mounted:
             xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([0, 0, 0.06]) + RB['toc_base']       # dressing.py:116-118
@@ -1561,6 +1580,8 @@ def compile_dressing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_ver
         xf[X_['CLOTH_GRAVITY_SETTLE']], xf[X_['CLOTH_GRAVITY']] = -9.81 / 2, -9.81               # dressing.py:178,195
         xf[X_['CLOTH_ORIG_POS']:X_['CLOTH_ORIG_POS'] + 3] = cloth_orig_pos
         fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {6: -90, 13: -45, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}, cloth=True)   # dressing.py:123
+        if RB.get('mobile'):
+            fill_reset_mobile(xf, xi, RB, rob)
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, [], params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + n_obs_joints, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRESSING, **hdr_mobile), reset_fill, reset_words,
                 task_words=DR['WORDS'], mlp=mlp, cloth=cloth, sim_substeps=8,

@@ -314,13 +314,10 @@ class FeedingSawyerVecEnv(AssistiveVecEnv):
 
 class FeedingStretchVecEnv(FeedingSawyerVecEnv):
     """FeedingStretch-v1 (feeding_envs.py:33-35): the mobile manipulator on its own wheels -- 5 actions (two wheels, lift, telescoping arm,
-    wrist yaw: stretch.py:9-11,51-53), 21 observations (the wheel angles are left out, feeding.py:90-92).  Start states come from the numpy
-    sampler (host/reset.py: env.py:282-293 has no IK for a mobile robot) + the device's collision pass and settle: reset='pool' / 'host'."""
+    wrist yaw: stretch.py:9-11,51-53), 21 observations (the wheel angles are left out, feeding.py:90-92).  Start states come from the
+    device-side reset generator (its branch for a robot on wheels: env.py:282-293 has no IK) like those of the other feeding robots
+    (reset='pool' / 'device'); reset='host': the numpy sampler."""
     model = 'feeding_stretch'
-
-    def __init__(self, n_envs, **kw):
-        assert kw.get('reset', 'pool') != 'device', 'no device-side reset generator for the Stretch: use a pool (pool_refresh > 0 keeps it fresh)'
-        super().__init__(n_envs, **kw)
 
 
 class FeedingBaxterVecEnv(FeedingSawyerVecEnv):
@@ -397,7 +394,7 @@ def _vec_flavour(base_cls, name, model_name):
 for _r in ('jaco', 'panda', 'pr2', 'baxter'):
     _vec_flavour(BedBathingSawyerVecEnv, 'BedBathing%sVecEnv' % {'pr2': 'PR2'}.get(_r, _r.capitalize()), 'bed_bathing_' + _r)
 _vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchBaxterVecEnv', 'scratch_itch_baxter')
-_vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchStretchVecEnv', 'scratch_itch_stretch')      # mobile: 5 actions, 26 observations; pool from the numpy sampler
+_vec_flavour(ScratchItchPR2VecEnv, 'ScratchItchStretchVecEnv', 'scratch_itch_stretch')      # mobile: 5 actions, 26 observations
 _vec_flavour(BedBathingSawyerVecEnv, 'BedBathingStretchVecEnv', 'bed_bathing_stretch')      # mobile: 5 actions, 20 observations
 _vec_flavour(FeedingSawyerVecEnv, 'FeedingPR2VecEnv', 'feeding_pr2')
 
@@ -426,5 +423,5 @@ class DressingBaxterHumanVecEnv(DressingBaxterVecEnv):
     coop = True
 
 
-for _r in ('sawyer', 'jaco', 'panda', 'pr2', 'stretch'):      # (stretch: mobile, 5 actions, 20 observations; pool from the numpy sampler + the device's cloth settle)
+for _r in ('sawyer', 'jaco', 'panda', 'pr2', 'stretch'):      # (stretch: mobile, 5 actions, 20 observations)
     _vec_flavour(DressingBaxterVecEnv, 'Dressing%sVecEnv' % {'pr2': 'PR2'}.get(_r, _r.capitalize()), 'dressing_' + _r)

@@ -291,7 +291,10 @@ enum {
   AGX_X_REACTIVE_MAXF = 50, /* its force limit before the strength factor (reactive_force, human.py:126)                                                    */
   AGX_X_FLAGS = 51,         /* int: bit 0 = the human's controllable joints stay dynamic whatever the impairment (human.py:108 with a reactive force);
                              * bit 1 = scratch itch: draw the limb and the target on it (scratch_itch.py:134-146; dimensions in AGX_T_SI_LIMB_DIMS);
-                             * bit 2 = dressing: settle gravity and garment offset into the task words (AGX_DR_CLOTH_GRAVITY, AGX_DR_CLOTH_OFF) */
+                             * bit 2 = dressing: settle gravity and garment offset into the task words (AGX_DR_CLOTH_GRAVITY, AGX_DR_CLOTH_OFF);
+                             * bit 3 = a robot on wheels (env.py:282-293): no IK -- the base at BASE_POS + U(-r, r)^2 (r = TOC_POS_RANGE), yaw TOC_YAW0
+                             *         + U(-r, r) (r = TOC_YAW_RANGE; roll and pitch of BASE_QUAT's rpy are zero), joint MOBILE_LIFT_DOF at MOBILE_LIFT +
+                             *         U(-0.1, 0.1) (stretch.py:58-62), every other joint at its QT0; a colliding placement is drawn again (env.py:299-308) */
   /* base pose search of a free-standing robot (Robot.position_robot_toc, robot.py:123-215); TOC_ATTEMPTS = 0: the base is fixed (BASE_POS / BASE_QUAT) */
   AGX_X_TOC_ATTEMPTS = 52,  /* int: candidate base poses per round (<= 64: one per lane)                                                   */
   AGX_X_TOC_ROUNDS = 53,    /* int: rounds of new candidates while no candidate reaches the start pose                                   */
@@ -312,6 +315,8 @@ enum {
   AGX_X_TOC_GOAL_KIND = 92, /* int: 0 = origins of TOC_GOAL_LINKS (+ TOC_GOAL_OFF); 1 = the mouth target (feeding.py:142)                  */
   AGX_X_PED_N = 93,         /* int: boxes of the robot's own pedestal (0 ... 2), base frame, already grown by a link radius: a candidate whose
                                start pose puts a joint origin past the shoulder, a link midpoint or the end effector inside one is rejected */
+  AGX_X_MOBILE_LIFT = 94,   /* float: centre of the lift joint's start height (FLAGS bit 3)                                                 */
+  AGX_X_MOBILE_LIFT_DOF = 95, /* int: its DoF                                                                                              */
   AGX_X_PED_BOX = 96,       /* float[PED_N][6]: min corner, max corner                                                                     */
   AGX_X_COUNT = 108
 };

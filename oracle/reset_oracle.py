@@ -42,10 +42,10 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
           TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
-          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, PED_BOX=96, COUNT=108)
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, COUNT=108)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
-R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, STRIDE=36)
+R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, JTYPE=32, STRIDE=36)
 F = dict(REFPOS=5, REFQUAT=8, STRIDE=16)
 T = dict(SI_LIMB_DIMS=9, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35)
 
@@ -203,6 +203,24 @@ class ResetOracle:
         ch = self.chain()
         return (np.array([self.rf(d, 'LOWER') for d in ch], dtype=np.float64), np.array([self.rf(d, 'UPPER') for d in ch], dtype=np.float64))
 
+    def mobile_fk(self, lift_dof, lift_q, base):
+        """end-effector pose of a robot on wheels (FLAGS bit 3; csrc/agx_reset.h rs_mobile_fk): the chain from the link carrying the end
+        effector up to the base, every joint at its clamped QT0 but the lift"""
+        links, d = [], self.ti('EE_LINK')
+        while d >= 0:
+            links.append(d)
+            d = self.ri(d, 'PARENT')
+        pp, pq = base
+        for d in links[::-1]:
+            jp, jq = compose(pp, pq, self.rf(d, 'TPOS', 3), self.rf(d, 'TQUAT', 4))
+            qd = lift_q if d == lift_dof else min(max(self.rf(d, 'QT0'), self.rf(d, 'LOWER')), self.rf(d, 'UPPER'))
+            ax = self.rf(d, 'AXIS', 3).astype(np.float64)
+            if self.ri(d, 'JTYPE') == 1:
+                pp, pq = jp + qrot(jq, ax * qd), jq
+            else:
+                pp, pq = jp, qmul(jq, q_axis_angle(ax, qd))
+        return compose(pp, pq, self.tf('EE_POS', 3), self.tf('EE_QUAT', 4))
+
     def arm_fk(self, q, base=None):
         narm = self.xi('NARM')
         pp, pq = base if base is not None else (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
@@ -347,8 +365,9 @@ class ResetOracle:
             st, info = self._sample_from(seed, impairment_mode, gender_mode, max_restarts, first)
             if t == tries or not info['ik_ok'] or not self.collides(st):
                 break
-            rejected.append(first if self.xi('TOC_ATTEMPTS') > 0 else info['ik_restarts'] - 1)
-            first = first + 1 if self.xi('TOC_ATTEMPTS') > 0 else info['ik_restarts']        # base pose search: the next PLACEMENT (env.py:281-308)
+            placed = self.xi('TOC_ATTEMPTS') > 0 or bool(self.xi('FLAGS') & 8)             # base pose search / a robot on wheels: the next PLACEMENT (env.py:281-308)
+            rejected.append(first if placed else info['ik_restarts'] - 1)
+            first = first + 1 if placed else info['ik_restarts']
         info['rejected_restarts'] = rejected
         return st, info
 
@@ -389,7 +408,15 @@ class ResetOracle:
         best, best_d, ok, restarts = None, np.inf, False, 0
         base = (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
         toc_info = None
-        if self.xi('TOC_ATTEMPTS') > 0:                                    # a free-standing robot: base pose search instead of IK restarts
+        mobile, lift_dof, lift_q = bool(self.xi('FLAGS') & 8), -1, 0.0
+        if mobile:                                                         # a robot on wheels (env.py:282-293, stretch.py:58-62): no IK
+            stream = T_STREAM0 + first_restart
+            pr, yr = self.xf('TOC_POS_RANGE'), self.xf('TOC_YAW_RANGE')
+            bp = self.xf('BASE_POS', 3) + np.array([(2 * u01(seed, stream, T_X) - 1) * pr, (2 * u01(seed, stream, T_Y) - 1) * pr, 0.0])
+            base = (bp, q_axis_angle(np.array([0, 0, 1.0]), self.xf('TOC_YAW0') + (2 * u01(seed, stream, T_YAW) - 1) * yr))
+            lift_dof, lift_q = self.xi('MOBILE_LIFT_DOF'), self.xf('MOBILE_LIFT') + (2 * u01(seed, stream, T_REST) - 1) * 0.1
+            ok, restarts, best_d, n_max, best = True, 0, 0.0, 0, []
+        elif self.xi('TOC_ATTEMPTS') > 0:                                  # a free-standing robot: base pose search instead of IK restarts
             if self.xi('TOC_GOAL_KIND') == 1:                              # feeding: the mouth (feeding.py:142)
                 goals = [target]
             else:
@@ -411,11 +438,13 @@ class ResetOracle:
                 break
         nr, narm = self.nrobot, self.xi('NARM')
         qfull = np.zeros(self.ndof)
-        ch = self.chain()
+        ch = [] if mobile else self.chain()
         for d in range(nr):                                                # gripper (and joints outside the arm) opened instantly, feeding.py:143-144
             qfull[d] = min(max(self.rf(d, 'QT0'), self.rf(d, 'LOWER')), self.rf(d, 'UPPER'))
         for k, d in enumerate(ch):
             qfull[d] = best[k]
+        if mobile:
+            qfull[lift_dof] = lift_q
         for k, j in enumerate(dyn):
             qfull[nr + k] = self.joint_angle(g, j, ls, head)
         st[S['Q']:S['Q'] + self.ndof] = qfull
@@ -424,7 +453,7 @@ class ResetOracle:
         st[S['TREMOR'] + self.nhdof:S['TREMOR'] + 2 * self.nhdof] = qfull[nr:]
         st[S['BASE']:S['BASE'] + 3], st[S['BASE'] + 3:S['BASE'] + 7] = base
         # tool in the hand (tool.py:49-62)
-        pe, oe, _, _ = self.arm_fk(best, base)
+        pe, oe = self.mobile_fk(lift_dof, lift_q, base) if mobile else self.arm_fk(best, base)[:2]
         tp, tq = compose(pe, oe, self.tf('TOOL_POS', 3), self.tf('TOOL_QUAT', 4))
         fr = lambda b: S['FREE'] + 13 * b
         for b in range(self.nfree):

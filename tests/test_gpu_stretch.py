@@ -179,3 +179,45 @@ def test_dressing_stretch():
         ob, rw, dn, inf = env.step(a)
     assert torch.isfinite(ob).all() and torch.isfinite(rw).all() and env.stepper.overflow_count() == 0
     env.close()
+
+
+def test_reset_generator_on_the_device_matches_its_restatement_and_feeds_episodes():
+    """the branch of the reset kernel for a robot on wheels (env.py:282-293: base jitter, yaw, lift height; no IK) through the C ABI against
+    the numpy restatement, and FeedingStretch / ScratchItchStretch with reset='device': new placements at every episode boundary"""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import reset_oracle as ro
+    from assistive_gym_amd import libagx, vec_env
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.libagx import Stepper
+    from test_reset_generator import assert_same_record
+    if libagx.load().agx_device_count() <= 0:
+        __import__('conftest').no_gpu()
+    for model in ('feeding_stretch', 'scratch_itch_stretch', 'dressing_stretch'):
+        blob = ModelBlob.load(model)
+        o = ro.with_collision_check(blob.words)
+        n = 6
+        st = Stepper(blob, n)
+        st.sample_reset(9001)
+        st.synchronize()
+        got = st.get_state()
+        for i in range(n):
+            so, io = o.sample(9001 + i)
+            assert_same_record(blob, so, got[i], '%s env %d' % (model, i))
+        st.close()
+    for cls in (vec_env.FeedingStretchVecEnv, vec_env.ScratchItchStretchVecEnv):
+        n = 64
+        env = cls(n, reset='device', seed=21)
+        obs = env.reset()
+        v0 = env.blob.view(env.stepper.get_state().copy())
+        assert torch.isfinite(obs).all() and len(np.unique(np.round(v0['base'][:, 0], 5))) > n // 2
+        g = torch.Generator(device='cuda'); g.manual_seed(3)
+        for k in range(200):
+            obs, rew, done, info = env.step(torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1)
+            assert bool(done.all()) == (k == 199)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        v1 = env.blob.view(env.stepper.get_state())
+        assert (np.abs(v1['base'][:, :2] - v0['base'][:, :2]).max(axis=1) > 1e-5).all() and (v1['iteration'] == 0).all()      # a NEW placement for every environment
+        env.close()

@@ -199,7 +199,7 @@ def test_other_tasks_model_tables(tb):
     task, b, o = tb
     base_obs = {'scratch_itch': 23, 'bed_bathing': 17}[task]                                   # scratch_itch.py:8, bed_bathing.py:10
     assert (b.act_dim, b.obs_dim, b.nrobot, b.nhdof) == (5, base_obs + 3, 16, 10) and b.h['BASE_LINK'] == 6
-    assert b.meta['mount'] == 'mobile' and not b.has_reset_generator
+    assert b.meta['mount'] == 'mobile' and b.has_reset_generator == (task == 'scratch_itch')      # bed bathing: the lying human comes out of a settle (no generator, §8)
     assert b.meta['mobile_base'] == {'scratch_itch': [-1.0, -0.1, 0.09], 'bed_bathing': [-1.1, -0.1, 0.09]}[task]        # stretch.py:37,39
     assert b.meta['lift'] == {'scratch_itch': 0.75, 'bed_bathing': 0.95}[task]                                             # stretch.py:58-62
     assert [b.robot_f(d, 'QT0') for d in (14, 15)] == [np.float32(0.1)] * 2                                                # gripper_pos, stretch.py:21,24
@@ -264,7 +264,7 @@ def test_dressing_model_tables(db):
     from assistive_gym_amd.model import compiler as L
     b, o = db
     assert b.task_kind == L.TASK_DRESSING and (b.act_dim, b.obs_dim, b.nrobot, b.nhdof, b.nfree) == (5, 17 + 3, 16, 10, 0) and b.h['SIM_SUBSTEPS'] == 8      # dressing.py:9,184
-    assert b.h['BASE_LINK'] == 6 and b.meta['mount'] == 'mobile' and not b.has_reset_generator and b.meta['mobile_yaw'] is False
+    assert b.h['BASE_LINK'] == 6 and b.meta['mount'] == 'mobile' and b.has_reset_generator and b.meta['mobile_yaw'] is False
     assert b.meta['mobile_base'] == [0.75, -0.4, 0.09] and np.allclose(b.meta['mobile_rpy'], [0, 0, -np.pi / 2]) and b.meta['lift'] == 0.95                  # stretch.py:41,47,59-60
     # the motor gains are divided by numSubSteps (dressing.py:135-137)
     assert np.allclose([b.robot_f(d, 'KP') for d in range(6, 14)], np.array([0.1] * 2 + [0.01] + [0.025] * 5) / 8.0)
@@ -301,3 +301,59 @@ def test_dressing_reset_garment_and_emulator_parity(db):
         e_obs, e_rew, e_done, e_info, _ = e.step(se, a)
         assert np.abs(o_obs - e_obs).max() < 1e-4 and abs(o_rew - e_rew) < 1e-4 and o_done == e_done
         assert np.abs(b.view(so.reshape(1, -1))['q'] - b.view(se.reshape(1, -1))['q']).max() < 5e-5
+
+
+# ---- the reset of a robot on wheels on the device (csrc/agx_reset.h, AGX_X_FLAGS bit 3) against its numpy restatement ---------------------
+@pytest.mark.parametrize('model', ['feeding_stretch', 'scratch_itch_stretch', pytest.param('dressing_stretch', marks=full)])
+@pytest.mark.parametrize('seed', [77, (1 << 33) + 5])
+def test_device_reset_generator_matches_its_numpy_restatement(model, seed):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import reset_oracle as ro
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.model import compiler as L
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    from test_reset_generator import assert_same_record
+    b = ModelBlob.load(model)
+    assert b.has_reset_generator and b.i[b.h['OFF_RESET'] + L.X_['FLAGS']] & 8
+    st, info = ro.with_collision_check(b.words).sample(seed)
+    se, ie = Emu(b).sample(seed)
+    assert_same_record(b, st, se, '%s seed %d' % (model, seed))
+    assert info['ik_ok'] and bool(ie[0])
+    v = b.view(st.reshape(1, -1))
+    d = v['base'][0, :3] - np.array(b.meta['mobile_base'])
+    assert np.all(np.abs(d[:2]) <= 0.1 + 1e-6) and abs(d[2]) < 1e-6                                               # env.py:285-286
+    yaw = 2 * np.arctan2(v['base'][0, 5], v['base'][0, 6])
+    dyaw = (yaw - b.meta['mobile_rpy'][2] + np.pi) % (2 * np.pi) - np.pi
+    assert abs(dyaw) <= (np.deg2rad(30) if b.meta.get('mobile_yaw', True) else 0) + 1e-6                          # env.py:287-291
+    q = v['q'][0]
+    assert abs(q[8] - b.meta['lift']) <= 0.1 + 1e-6 and np.all(q[:8] == 0) and np.all(q[9:14] == 0)               # stretch.py:58-62
+    # the tool (or, dressing, the garment) sits at the end effector the oracle's kinematics find for that record
+    ee, _ = Oracle(b).ee_pose(st.copy())
+    if b.nfree:
+        from assistive_gym_amd.host.kin import RobotKin
+        tp, _ = RobotKin(b).tool_pose(v['base'][0, :3].astype(np.float64), v['base'][0, 3:].astype(np.float64), q[:b.nrobot].astype(np.float64))
+        assert np.linalg.norm(v['free'][0, b.h['TOOL_BODY'], :3] - tp) < 0.2                                       # (COM frame vs base frame of the tool: centimetres)
+    else:
+        assert np.allclose(v['task'][0, L.DR['CLOTH_OFF']:L.DR['CLOTH_OFF'] + 3].view(np.float32), ee - np.array(b.meta['cloth_orig_pos']), atol=1e-5)
+
+
+def test_device_reset_redraws_a_colliding_placement():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import reset_oracle as ro
+    from assistive_gym_amd.blob import ModelBlob
+    b = ModelBlob.load('scratch_itch_stretch')
+    calls = []
+
+    def collides(st):
+        calls.append(1)
+        return len(calls) == 1
+    st, info = ro.ResetOracle(b.words, collides).sample(123)
+    plain, _ = ro.ResetOracle(b.words).sample(123)
+    assert info['rejected_restarts'] == [0] and len(calls) == 2
+    v0, v1 = b.view(plain.reshape(1, -1)), b.view(st.reshape(1, -1))
+    assert not np.array_equal(v0['base'], v1['base']) and np.array_equal(v0['human'], v1['human']) and v0['q'][0, 8] != v1['q'][0, 8]
