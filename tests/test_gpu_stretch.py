@@ -130,9 +130,9 @@ def test_vec_env_rollout_and_scalar_env(rb):
         assert bool(done.all()) == (k == 199)
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
     assert int((info[:, 6] >= 1.0e6).sum()) == 0                                   # no environment tripped the non-finite guard (AGX_INFO_NONFINITE)
-    # contacts dropped by the 64-contact budget.  FeedingStretch lives at that budget: 12 ground contacts (base and two wheels, four manifold
-    # points each) + the 28 of the food pile in the spoon + the bowl's 4 leave 20 for everything else, and after the landing the lift slides
-    # down until the spoon (64 hulls) rests on the table in many episodes: such environments drop candidates in every substep
+    # contacts dropped by the 64-contact budget.  Every feeding scene lives near that budget (28 food-spoon + 13..15 food-food + 11 bowl-table
+    # candidates = 52..58 at rest); the Stretch adds its 3 ground contacts, and after the landing the lift slides down until the spoon (64
+    # hulls) rests on the table in many episodes: such environments drop candidates in every substep
     assert env.stepper.overflow_count() < (0.75 if b.task_name == 'feeding' else 0.03) * n * 200 * 5
     env.close()
     e = make('assistive_gym:%s%s-v1' % (IDS[b.task_name], 'Human' if b.is_coop else ''))
