@@ -113,6 +113,9 @@ struct agx_handle_s {
   // lean solve kernel shares the CUs with the LDS-heavy build kernel.
   int n_chunks; hipStream_t cs[8]; hipEvent_t fork_ev, join_ev[8];
   bool packed_solve;    // solve with the packed kernel (four environments per wavefront) when the variant has one; AGX_SOLVE=old turns it off
+  int reset_flags;      // AGX_X_FLAGS of the blob's reset section (0 without one)
+  agx_handle_s* settle; // bed bathing (AGX_X_FLAGS bit 4): the handle of the rag-doll model whose settled records the sampler reads (agx_attach_settle_model; not owned)
+  int settle_substeps;  // substeps of that settle (100 simulation steps: bed_bathing.py:130-131)
 };
 
 extern "C" {
@@ -159,10 +162,12 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     const int32_t* T = hi + hi[AGX_H_OFF_TASK];
     // the arm: rs_narm joints in a serial chain (AGX_X_CHAIN: each joint's parent is the one before, the first hangs off the base), the
     // k-th one driven by action k, the last one carrying the end effector
-    const bool mobile = (X[AGX_X_FLAGS] & 8) != 0;    // a robot on wheels: no arm chain to solve (its NARM only says that the blob has a reset section)
-    if (X[AGX_X_NARM] != V->rs_narm || hi[AGX_H_NROBOT] < V->rs_narm || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64 || X[AGX_X_TOC_ATTEMPTS] > 64 ||
+    const bool ragdoll = (X[AGX_X_FLAGS] & 32) != 0;  // the rag-doll model of bed bathing: its sampler writes the drop record, there is no robot
+    const bool mobile = (X[AGX_X_FLAGS] & 8) != 0 || ragdoll;    // a robot on wheels: no arm chain to solve (its NARM only says that the blob has a reset section)
+    if (X[AGX_X_NARM] != V->rs_narm || (!ragdoll && hi[AGX_H_NROBOT] < V->rs_narm) || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64 || X[AGX_X_TOC_ATTEMPTS] > 64 ||
         X[AGX_X_TOC_NGOALS] > 3 || X[AGX_X_PED_N] > 2) can_sample = false;
-    if (mobile && (X[AGX_X_MOBILE_LIFT_DOF] < 0 || X[AGX_X_MOBILE_LIFT_DOF] >= hi[AGX_H_NROBOT] || X[AGX_X_TOC_ATTEMPTS] != 0 || X[AGX_X_IK_RESTARTS] != 0)) can_sample = false;
+    if (ragdoll && hi[AGX_H_NDOF] != 6 + X[AGX_X_NJOINT] - 1) can_sample = false;    // virtual joints + every joint of the tree but the fixed waist
+    if (mobile && !ragdoll && (X[AGX_X_MOBILE_LIFT_DOF] < 0 || X[AGX_X_MOBILE_LIFT_DOF] >= hi[AGX_H_NROBOT] || X[AGX_X_TOC_ATTEMPTS] != 0 || X[AGX_X_IK_RESTARTS] != 0)) can_sample = false;
     for (int k = 0; can_sample && !mobile && k < V->rs_narm; k++) {
       const int d = X[AGX_X_CHAIN + k];
       if (d < 0 || d >= hi[AGX_H_NROBOT]) { can_sample = false; break; }
@@ -178,6 +183,8 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   agx_handle h = new agx_handle_s();
   memset(h, 0, sizeof *h);
   h->can_sample = can_sample; h->V = V;
+  h->settle = nullptr; h->settle_substeps = 0;
+  h->reset_flags = (hi[AGX_H_OFF_TARGETS] - hi[AGX_H_OFF_RESET] >= AGX_X_COUNT || hi[AGX_H_NWORDS] - hi[AGX_H_OFF_RESET] >= AGX_X_COUNT) ? hi[hi[AGX_H_OFF_RESET] + AGX_X_FLAGS] : 0;
   const int rc = create_fill(h, blob, blob_bytes, n_envs, device);
   if (rc != AGX_OK) { const std::string keep = g_err; agx_destroy(h); g_err = keep; return rc; }   // every error exit releases what was allocated
   *out = h;
@@ -385,8 +392,23 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
                                                "provide post-reset states with agx_set_state / a pool for agx_reset_done");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
+  const float* settled = nullptr; int settled_sw = 0;
+  if (h->reset_flags & 16) {
+    // bed bathing (bed_bathing.py:119-137): the human is a rag doll dropped onto the bed -- the attached model samples its drop record from the
+    // same seeds, settles for 100 simulation steps, and its state records tell this model's sampler where the human lies
+    agx_handle_s* hs = h->settle;
+    if (!hs) return fail(AGX_E_ARG, "reset: this model's human comes out of a rag-doll settle; attach that model first (agx_attach_settle_model)");
+    hs->V->sample(st, hs->n_envs, hs->blob_dev, hs->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
+                  gender_mode, nullptr, hs->episode_dev, hs->sw, nullptr, hs->chosen_dev, nullptr, 0);
+    HIPCHK(hipGetLastError());
+    hs->active = mask_dev;
+    const int rc = launch_chunked(hs, h->settle_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
+    hs->active = nullptr;
+    if (rc) return rc;
+    settled = hs->state_dev; settled_sw = hs->sw;
+  }
   h->V->sample(st, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
-               gender_mode, ik_info_dev, h->episode_dev, h->sw, nullptr, h->chosen_dev);
+               gender_mode, ik_info_dev, h->episode_dev, h->sw, nullptr, h->chosen_dev, settled, settled_sw);
   HIPCHK(hipGetLastError());
   // collision rejection (robot.py:105-112, env.py:299-308): the contacts of the sampled state come from the stepper's own build kernel;
   // a state whose arm / tool touches the human, the table or the wheelchair is re-sampled from the next IK restart.  Fixed schedule
@@ -398,13 +420,22 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
     h->V->verdict(st, h->n_envs, h->blob_dev, h->scratch_dev, active, h->work_dev, h->first_restart_dev, h->chosen_dev);
     HIPCHK(hipGetLastError());
     h->V->sample(st, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, h->work_dev, impairment_mode,
-                 gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev);
+                 gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev, settled, settled_sw);
     HIPCHK(hipGetLastError());
   }
   if (h->cloth_dev) {      // the garment goes where the sampled end effector is
     hipLaunchKernelGGL(agx_place_cloth_kernel, dim3(h->n_envs), dim3(256), 0, st, h->cloth_dev, h->state_dev, h->blob_dev, mask_dev, h->n_envs, h->sw, h->cloth_words);
     HIPCHK(hipGetLastError());
   }
+  return AGX_OK;
+}
+int agx_attach_settle_model(agx_handle h, agx_handle settle, int n_substeps) {
+  if (!h || n_substeps < 0) return fail(AGX_E_ARG, "agx_attach_settle_model: bad argument");
+  if (!settle) { h->settle = nullptr; return AGX_OK; }
+  if (!(h->reset_flags & 16)) return fail(AGX_E_ARG, "agx_attach_settle_model: this model's reset does not read a settle record");
+  if (!(settle->reset_flags & 32) || !settle->can_sample) return fail(AGX_E_ARG, "agx_attach_settle_model: the second handle is not a rag-doll model with a drop sampler");
+  if (settle->n_envs != h->n_envs || settle->device != h->device) return fail(AGX_E_ARG, "agx_attach_settle_model: both handles must hold the same number of environments on the same device");
+  h->settle = settle; h->settle_substeps = n_substeps;
   return AGX_OK;
 }
 int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gender_mode, float* ik_info_dev, void* stream) {

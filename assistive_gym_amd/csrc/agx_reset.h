@@ -94,7 +94,11 @@ struct ResetCtx {
   double head[3];                     // head joint angle draws
   d3 base_p; dq base_q;               // robot base: the blob's fixed pose, or this lane's candidate of the base pose search
   int chain[7];                       // DoF of the arm's k-th joint (AGX_X_CHAIN)
+  const float* settled;               // AGX_X_FLAGS bit 4: the joint angles (q) of the rag-doll record the human's pose is read from; else null
 };
+constexpr int RS_RAGDOLL = 64;        // stream 0 slots RS_RAGDOLL + k: the jitter of the rag doll's k-th joint (bed_bathing.py:126)
+constexpr int RS_SETTLE_VIRTUAL = 6;  // the rag-doll model's virtual root joints come first (x, y, z, yaw, pitch, roll), then its joints in PyBullet
+constexpr int RS_SETTLE_FIXED = 24;   // order without the fixed waist joint 24 (model/compiler.py compile_bed_settle)
 #define XF(c, k) ((double)(c).xf[(k)])
 #define XI(c, k) ((c).xi[(k)])
 
@@ -103,6 +107,7 @@ AGX_DEV double rs_joint_angle(const ResetCtx& c, int j) {
   const int base = XI(c, AGX_X_OFF_JOINTS) + (c.gender * c.nj + j) * AGX_XJ_STRIDE;
   const int flags = c.xi[base + AGX_XJ_FLAGS];
   if (!(flags & 1)) return 0.0;
+  if (c.settled) return (double)c.settled[RS_SETTLE_VIRTUAL + j - (j > RS_SETTLE_FIXED ? 1 : 0)];      // where the rag doll came to rest (bed_bathing.py:129-137)
   double a = (double)c.xf[base + AGX_XJ_PRESET];
   const int k = c.xi[base + AGX_XJ_DRAW];
   if (k >= 0) a += (k == 0 ? c.head[0] : (k == 1 ? c.head[1] : c.head[2]));
@@ -118,6 +123,10 @@ AGX_DEV void rs_link_pose(const ResetCtx& c, int link, d3& p, dq& q) {
     dcompose(dld3(c.xf + base + AGX_XJ_OFF), jq, p, q, p, q);
     j = c.xi[base + AGX_XJ_PARENT];
   }
+  if (c.settled) {      // the rag doll's base: position q[0..2], orientation Rz(q[3]) Ry(q[4]) Rx(q[5])
+    const dq bq = dqmul(dqmul(dq_axis_angle(dmk(0, 0, 1), (double)c.settled[3]), dq_axis_angle(dmk(0, 1, 0), (double)c.settled[4])), dq_axis_angle(dmk(1, 0, 0), (double)c.settled[5]));
+    dcompose(dmk((double)c.settled[0], (double)c.settled[1], (double)c.settled[2]), bq, p, q, p, q);
+  } else
   dcompose(dld3(c.xf + (c.gender ? AGX_X_HBASE_F : AGX_X_HBASE_M)), dq_ident(), p, q, p, q);
 }
 
@@ -288,8 +297,9 @@ AGX_DEV double rs_jlwki(const ResetCtx& c, const double* q) {
 // first_restart: successful IK restarts below this index were rejected because the arm / tool touched the human, the table or the
 // wheelchair there (robot.py:105-112 `continue`s to the next restart); they neither succeed again nor count as the closest attempt.
 // Returns the index of the accepted restart, -1 if no restart met the thresholds (the closest attempt is used, robot.py:114-117).
+// settled (may be null): the state record of this environment in the rag-doll model after its settle (AGX_X_FLAGS bit 4 of this blob)
 AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gstate, uint32_t seed_lo, uint32_t seed_hi,
-                       int impairment_mode, int gender_mode, float* __restrict__ ginfo, int lane, int first_restart = 0) {
+                       int impairment_mode, int gender_mode, float* __restrict__ ginfo, int lane, int first_restart = 0, const float* __restrict__ settled = nullptr) {
   ResetCtx c;
   c.bf = (const float*)blob; c.bi = (const int*)blob;
   c.xf = c.bf + c.bi[AGX_H_OFF_RESET]; c.xi = c.bi + c.bi[AGX_H_OFF_RESET];
@@ -316,9 +326,35 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   for (int k = 0; k < 3; k++) c.head[k] = (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_HEAD + k) - 1.0) * XF(c, AGX_X_HEAD_RANGE);          // feeding.py:125
   const double strength = imp != RS_IMP_WEAKNESS ? 1.0 : XF(c, AGX_X_STRENGTH_LO) + (1.0 - XF(c, AGX_X_STRENGTH_LO)) * rs_u01(seed_lo, seed_hi, 0, RS_STRENGTH);   // human.py:86
   const int xflags = XI(c, AGX_X_FLAGS);
+  c.settled = (xflags & 16) ? settled : nullptr;      // (agx_sample_reset refuses to run such a blob without its rag-doll model attached)
 
   for (int w = lane; w < state_words; w += AGX_WAVE) gstate[w] = 0.f;
   wave_sync();
+
+  if (xflags & 32) {
+    // ---- this blob IS the rag-doll model (bed_settle): the record it is dropped from (bed_bathing.py:119-127) -- base in the air, every
+    // joint U(-r, r) clamped to its limits (Agent.set_joint_angles + enforce_joint_limits), at rest; friction / gender / limit scale as the
+    // task blob's sampler draws them (same seed, same stream-0 slots).  One joint per lane.
+    if (lane < ndof) {
+      double qv;
+      if (lane < 3) qv = XF(c, (c.gender ? AGX_X_HBASE_F : AGX_X_HBASE_M) + lane);
+      else if (lane < RS_SETTLE_VIRTUAL) qv = XF(c, AGX_X_EE_TARGET + lane - 3);                      // yaw, pitch, roll of the drop pose
+      else {
+        const int k = lane - RS_SETTLE_VIRTUAL, j = k + (k >= RS_SETTLE_FIXED ? 1 : 0);
+        const int jb = XI(c, AGX_X_OFF_JOINTS) + (c.gender * c.nj + j) * AGX_XJ_STRIDE;
+        const double sc = (c.xi[jb + AGX_XJ_FLAGS] & 2) ? c.ls : 1.0;
+        qv = (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_RAGDOLL + k) - 1.0) * XF(c, AGX_X_EE_RANGE);
+        qv = fmin(fmax(qv, (double)c.xf[jb + AGX_XJ_LOWER] * sc), (double)c.xf[jb + AGX_XJ_UPPER] * sc);
+      }
+      gstate[sQ + lane] = (float)qv; gstate[sQT + lane] = (float)qv;
+    }
+    if (lane == 0) {
+      gstate[sHUMAN + 6] = 1.f; gstate[sBASE + 6] = 1.f;                                               // the world anchor of the virtual joints
+      gstate[sENV + AGX_E_PLANE_FRICTION] = (float)friction; gstate_i[sENV + AGX_E_GENDER] = c.gender; gstate[sENV + AGX_E_LIMIT_SCALE] = (float)c.ls;
+      if (ginfo) { ginfo[0] = 1.f; ginfo[1] = 0.f; ginfo[2] = 0.f; ginfo[3] = (float)imp; }
+    }
+    return 0;
+  }
 
   // ---- posed human: one static collision body per lane, lane NHUMAN the head (mouth target) --------
   const int head_link = ((const int*)c.task)[AGX_T_HEAD_LINK];       // -1: the task has no mouth target (scratch itch)
@@ -576,6 +612,13 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     ei[AGX_E_RNG] = (int)((seed * 2654435761ull + 12345ull) & 0x7FFFFFFFull);
     ei[AGX_E_RNG + 1] = (int)((seed ^ 0x5bd1e995ull) & 0x7FFFFFFFull);
     ei[AGX_E_TOTAL_FOOD] = (xflags & 6) ? 1 : nfood;               // scratch itch, dressing: task_success >= 1 x task_success_threshold (scratch_itch.py:37)
+    if (xflags & 64) {   // bed bathing: generate_targets (bed_bathing.py:173-188) -- every target of this gender's two tables is alive
+      const int* nt4 = (const int*)c.task + AGX_T_NT;
+      const int nt = nt4[2 * c.gender] + nt4[2 * c.gender + 1];
+      ei[AGX_E_TOTAL_FOOD] = nt;                                    // total_target_count (bed_bathing.py:187)
+      unsigned* alive = (unsigned*)(gstate + c.bi[AGX_H_S_TASK]) + AGX_BB_ALIVE;
+      for (int t = 0; t < AGX_BB_ALIVE_WORDS; t++) alive[t] = nt >= 32 * (t + 1) ? 0xffffffffu : (nt > 32 * t ? (1u << (nt - 32 * t)) - 1u : 0u);
+    }
     const bool coop = ((const int*)c.task)[AGX_T_COOP] == 1;
     const bool agent = imp == RS_IMP_TREMOR || coop;                // then take_step drives the human's motors (env.py:130-131)
     ei[AGX_E_FROZEN] = (agent || (xflags & 1)) ? 0 : (((1 << nhdof) - 1) << nrobot);                          // human.py:104-110

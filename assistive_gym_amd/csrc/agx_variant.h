@@ -23,7 +23,8 @@ struct agx_variant {
                  float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words);
   void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim);
   void (*sample)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
-                 int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen);   // null without a reset generator
+                 int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen,
+                 const float* settled, int settled_sw);   // null without a reset generator; settled: [n_envs][settled_sw] records of the attached rag-doll model (or null)
   // the garment (agx_cloth.h): nsub substeps replaying the trace; null in variants without a cloth
   void (*cloth)(hipStream_t st, int ne, const uint32_t* blob, const float* state, const float* trace, float* cloth, float* report, int e0, int n_envs, int sw,
                 int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* active, int lds_bytes);

@@ -13,7 +13,7 @@ _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_cloth_nodes', 'agx_set_cloth', 'agx_get_cloth', 'agx_cloth_dev', 'agx_set_cloth_pool', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
-           'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
+           'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_attach_settle_model', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset', 'agx_check_collisions',
            'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather']
 
@@ -188,6 +188,12 @@ class Stepper:
         `seeds` (uint64/int64 device tensor) or seed + env index, then the settle substeps on those envs only"""
         check(self.L.agx_reset(self.h, _ptr(mask), _ptr(seeds), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), C.c_int(self.IMPAIRMENT_MODES[impairment]),
                                C.c_int(self.GENDER_MODES[gender]), C.c_int(settle_substeps), C.c_void_p(stream)), 'agx_reset')
+
+    def attach_settle_model(self, other, n_substeps):
+        """bed bathing: `other` is a Stepper on the rag-doll model (bed_settle) with as many environments; sample_reset / reset of this stepper
+        then drop and settle that model's humans first (bed_bathing.py:119-137) and read their resting poses.  Keeps `other` alive."""
+        check(self.L.agx_attach_settle_model(self.h, other.h if other is not None else None, C.c_int(n_substeps)), 'agx_attach_settle_model')
+        self._settle_model = other
 
     def reset_done(self, pool, pool_n, done, stream=0):
         check(self.L.agx_reset_done(self.h, _ptr(pool), C.c_int(pool_n), _ptr(done), C.c_void_p(stream)), 'agx_reset_done')

@@ -1045,11 +1045,38 @@ def compile_bed_bathing(robot, assets=DEFAULT_ASSETS, n_iter=50, robot_hull_max_
     if meta_mobile:
         meta_mobile['mount'] = 'mobile'
 
+    # BedBathingEnv.reset on the device (csrc/agx_reset.h; bed_bathing.py:112-171): the human's resting pose comes out of the rag-doll settle of a
+    # second model (bed_settle, AGX_X_FLAGS bit 4; agx_attach_settle_model); from there on the reset is the scratch-itch one -- the robot on the
+    # human's right by the base pose search (wheelchair_enabled=False: the mounted arms too, bed_bathing.py:148) with shoulder / elbow / wrist as
+    # goals (:139-141), the tool, all targets alive (:173-188)
     def reset_words(nhuman, nhdof):
-        return X_['COUNT']
+        return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        pass        # no device-side reset generator for this scene: the pool comes from assistive_gym_amd/host/reset_bed.py
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
+        if not RB.get('mobile'):
+            fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(robot == 'sawyer'))
+        xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 3, 0
+        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([-0.85, -0.4, 0]) + RB['toc_base']       # robot.py:142 + toc_base_pos_offset
+        xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = [0, 0, 0, 1]
+        xi[X_['TOC_ATTEMPTS']], xi[X_['TOC_ROUNDS']] = 50, 4                                     # robot.py:123 attempts; four tries as host/reset_bed.py
+        xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW_RANGE']] = 0.5, np.deg2rad(30.0)
+        xf[X_['TOC_YAW0']], xf[X_['TOC_X_SIGN']] = 0.0, -1.0                                     # on the human's right
+        xi[X_['TOC_IK_ITERS']], xf[X_['TOC_THRESH']] = 100, 0.03
+        xi[X_['TOC_GOAL_LINKS']:X_['TOC_GOAL_LINKS'] + 3] = [5, 7, 9]                             # right shoulder, elbow, wrist (bed_bathing.py:139-141)
+        xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])
+        xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.6, 0.2, 1.0], 0.05      # bed_bathing.py:146
+        xf[X_['HEAD_RANGE']] = 0.0
+        xi[X_['IK_ITERS']], xf[X_['IK_DAMP']], xf[X_['IK_MAXSTEP']], xf[X_['IK_TOL']] = 200, 0.05, 0.5, 1e-4
+        xf[X_['IK_THRESH']], xi[X_['IK_RESTARTS']], xi[X_['IK_RANDLIM_FROM']] = 0.01, 1000, 10
+        xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5                                        # env.py:120
+        xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(10.0)   # human.py:85-92
+        xi[X_['BOWL_BODY']] = -1
+        xi[X_['COLLISION_TRIES']] = 3
+        xi[X_['FLAGS']] = 16 | 64
+        fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {})
+        if RB.get('mobile'):
+            fill_reset_mobile(xf, xi, RB, rob)
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=17 + n_obs_joints, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_BED_BATHING, **hdr_mobile), reset_fill, reset_words,
                 targets=targets, task_words=BB['WORDS'], mlp=mlp, meta_extra=dict(pad_link=pad_link, arm_joints=arm, gripper_joints=grip, tool_com=com.tolist(), robot=robot,
@@ -1165,11 +1192,20 @@ def compile_bed_settle(assets=DEFAULT_ASSETS, n_iter=50):
     task_f = dict(EE_QUAT=[0, 0, 0, 1.0], TOOL_QUAT=[0, 0, 0, 1.0], EPISODE_LEN=1 << 20)
     task_i = dict(EE_LINK=VR - 1, PAD_LINK=0, ARM_LINK=[VR - 1, VR - 1], OBS_LINK=[VR - 1, VR - 1, VR - 1], NT=[0, 0, 0, 0], HEAD_LINK=-1, ARM_LIMIT_ON=0)
 
+    # the drop record of the rag doll (AGX_X_FLAGS bit 5; bed_bathing.py:119-127): base at [-0.15, 0.2, 0.95] with rpy (-pi/2, 0, 0), every joint
+    # U(-0.1, 0.1) clamped to its limits; the tree carries the limits of both genders
     def reset_words(nhuman, nhdof):
-        return X_['COUNT']
+        return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        pass
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, 7          # (NARM: "this blob has a reset section the generator reads"; there is no arm)
+        xi[X_['FLAGS']] = 32
+        xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [-0.15, 0.2, 0.95], [-0.15, 0.2, 0.95]      # bed_bathing.py:121
+        xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [0.0, 0.0, -np.pi / 2.0], 0.1                           # yaw, pitch, roll of that pose; the joint jitter (:126)
+        xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5
+        xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(10.0)
+        xi[X_['BOWL_BODY']] = -1
+        fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {})
     rob_empty = dict(dof_links=[], rec=[], rec_int=[])
     # one "static human body": the world anchor the first virtual joint hangs off (identity pose in the state record)
     return pack(sc, G_.rows, rob_empty, [-1], human_link_rec, list(range(nhdof)), [], params, task_f, task_i,

@@ -14,6 +14,15 @@ from .shard import episode_seed, pool_indices
 
 SETTLE_STEPS = 25   # feeding.py:178-179
 DRESSING_SETTLE_STEPS = 50   # dressing.py:186-187
+RAGDOLL_SETTLE_STEPS = 100   # bed_bathing.py:130-131
+
+
+def attach_ragdoll_model(stepper, n_envs, device):
+    """bed bathing: the stepper's reset generator reads the human's resting pose from the settled records of a second model, the rag doll
+    (bed_bathing.py:119-137): a Stepper on `bed_settle` with as many environments, attached through agx_attach_settle_model"""
+    rag = Stepper(ModelBlob.load('bed_settle'), n_envs, device)
+    stepper.attach_settle_model(rag, RAGDOLL_SETTLE_STEPS)
+    return rag
 
 
 def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device', _depth=0):
@@ -22,6 +31,16 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
     BedBathingSawyer: BedBathingEnv.reset restated on the host (host/reset_bed.py) around the rag-doll settle on the device.
     Returns a float32 (pool_size, state_words) array."""
     from .model import compiler as L
+    if blob.task_kind == L.TASK_BED_BATHING and blob.has_reset_generator and sampler == 'device':
+        # BedBathingEnv.reset on the device: the rag doll's drop record, its 100-step settle, then the sampler of this model (base pose search,
+        # tool, targets) reading the resting pose -- agx_sample_reset with the rag-doll model attached
+        st = Stepper(blob, pool_size, device)
+        rag = attach_ragdoll_model(st, pool_size, device)
+        st.sample_reset(seed, impairment=impairment)
+        st.synchronize()
+        out = st.get_state()
+        st.close(); rag.close()
+        return out
     if blob.task_kind == L.TASK_BED_BATHING:
         from .host.reset_bed import make_states as make_bed_states, RagdollSettler
         # the rag-doll settle of BedBathingEnv.reset runs on the device (bed_settle kernel variant), the rest on the host
@@ -331,13 +350,21 @@ class FeedingPandaVecEnv(AssistiveVecEnv):
 
 
 class BedBathingSawyerVecEnv(AssistiveVecEnv):
-    """BASELINE config 3.  Resets come from a pool of host-sampled post-reset states (reset='pool' / 'host')."""
+    """BASELINE config 3.  reset='pool': a pool of post-reset states sampled once on the device -- the rag doll of a second model dropped onto
+    the bed and settled for 100 steps, then the base pose search and the targets (agx_sample_reset with the rag-doll model attached);
+    reset='device': every episode of every environment starts from a newly sampled and settled human (the settle of 4096 rag dolls takes
+    about 1.7 s: DESIGN 8); reset='host': the numpy sampler around the device settle."""
     model = 'bed_bathing_sawyer'
 
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
-        assert kw['reset'] != 'device', 'no device-side reset generator for BedBathingSawyer: use a pool'
         super().__init__(n_envs, **kw)
+        self._ragdoll = attach_ragdoll_model(self.stepper, n_envs, self.device_index) if self.reset_mode == 'device' else None
+
+    def close(self):
+        super().close()
+        if self._ragdoll is not None:
+            self._ragdoll.close()
 
 
 class ScratchItchPR2VecEnv(AssistiveVecEnv):

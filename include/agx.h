@@ -114,6 +114,14 @@ int agx_sample_reset(agx_handle h, uint64_t seed, int impairment_mode, int gende
  * other envs are left untouched.  Their episode counters restart at 0. */
 int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, uint64_t seed, int impairment_mode,
               int gender_mode, int settle_substeps, void* stream);
+/* Bed bathing (reference: BedBathingEnv.reset, assistive_gym/envs/bed_bathing.py:119-137): the human of such a model is a rag doll dropped
+ * onto the bed and left to settle for 100 simulation steps before the rest of the reset is sampled.  `settle` is a second handle, created
+ * by the caller on the rag-doll model blob (bed_settle) with the same number of environments on the same device; agx_sample_reset / agx_reset
+ * of `h` then sample that model's drop records from the same seeds, settle them for n_substeps substeps and read the human's resting pose
+ * from its state records.  The second handle is not owned (destroy it after `h`); a null `settle` detaches.  Without an attachment the
+ * sampler of such a model refuses to run. */
+int agx_attach_settle_model(agx_handle h, agx_handle settle, int n_substeps);
+
 /* envs with done != 0 get a fresh state from pool_dev ([pool_n][state_words]); the pool entry is
  * (env_offset + env_index + 977 * episode_count) mod pool_n with env_offset = the global index of this handle's first env
  * (agx_set_env_offset, default 0), so results do not depend on how the envs are spread over GPUs */

@@ -294,7 +294,13 @@ enum {
                              * bit 2 = dressing: settle gravity and garment offset into the task words (AGX_DR_CLOTH_GRAVITY, AGX_DR_CLOTH_OFF);
                              * bit 3 = a robot on wheels (env.py:282-293): no IK -- the base at BASE_POS + U(-r, r)^2 (r = TOC_POS_RANGE), yaw TOC_YAW0
                              *         + U(-r, r) (r = TOC_YAW_RANGE; roll and pitch of BASE_QUAT's rpy are zero), joint MOBILE_LIFT_DOF at MOBILE_LIFT +
-                             *         U(-0.1, 0.1) (stretch.py:58-62), every other joint at its QT0; a colliding placement is drawn again (env.py:299-308) */
+                             *         U(-0.1, 0.1) (stretch.py:58-62), every other joint at its QT0; a colliding placement is drawn again (env.py:299-308);
+                             * bit 4 = bed bathing: the human's pose (base + joint angles) is where the rag doll of a second model came to rest
+                             *         (bed_bathing.py:119-137): agx_sample_reset samples that model's drop record, settles it and hands its state
+                             *         record to this sampler (agx_attach_settle_model);
+                             * bit 5 = THIS blob is that rag-doll model: its sampler writes the drop record -- base at HBASE_M / HBASE_F with the virtual
+                             *         joint angles (yaw, pitch, roll) EE_TARGET, every joint U(-EE_RANGE, EE_RANGE) clamped to its limits;
+                             * bit 6 = bed bathing: all wiping targets alive, TOTAL_FOOD = their number (bed_bathing.py:173-188)                         */
   /* base pose search of a free-standing robot (Robot.position_robot_toc, robot.py:123-215); TOC_ATTEMPTS = 0: the base is fixed (BASE_POS / BASE_QUAT) */
   AGX_X_TOC_ATTEMPTS = 52,  /* int: candidate base poses per round (<= 64: one per lane)                                                   */
   AGX_X_TOC_ROUNDS = 53,    /* int: rounds of new candidates while no candidate reaches the start pose                                   */

@@ -27,6 +27,7 @@ MASK = 0xFFFFFFFF
 # stream 0 slots
 S_FRICTION, S_GENDER, S_IMPAIRMENT, S_LIMIT, S_STRENGTH, S_HEAD, S_EE, S_BOWL, S_TREMOR = 0, 1, 2, 3, 4, 8, 12, 16, 32
 S_LIMB, S_TARGET_LEN, S_TARGET_TH = 48, 49, 50          # scratch itch: generate_target (scratch_itch.py:134-146)
+S_RAGDOLL = 64                                           # + k: the jitter of the rag doll's k-th joint (bed_bathing.py:126)
 # restart stream slots (+ DoF index)
 R_REST, R_LO, R_HI = 0, 16, 32
 # base pose search (free-standing robots): stream T_STREAM0 + 64 (placement x rounds + round) + candidate
@@ -177,6 +178,8 @@ class ResetOracle:
         flags = self.ji(g, j, 'FLAGS')
         if not flags & 1:
             return 0.0
+        if getattr(self, 'settled', None) is not None:                     # where the rag doll came to rest (bed_bathing.py:129-137)
+            return float(self.settled[6 + j - (1 if j > 24 else 0)])
         a = self.jf(g, j, 'PRESET')
         k = self.ji(g, j, 'DRAW')
         if k >= 0:
@@ -192,6 +195,10 @@ class ResetOracle:
             jq = q_axis_angle(self.jf(g, j, 'AXIS', 3), self.joint_angle(g, j, ls, head))
             p, q = compose(self.jf(g, j, 'OFF', 3), jq, p, q)
             j = self.ji(g, j, 'PARENT')
+        if getattr(self, 'settled', None) is not None:                     # the rag doll's base: position q[0..2], orientation Rz(q[3]) Ry(q[4]) Rx(q[5])
+            t = self.settled
+            bq = qmul(qmul(q_axis_angle(np.array([0, 0, 1.0]), t[3]), q_axis_angle(np.array([0, 1.0, 0]), t[4])), q_axis_angle(np.array([1.0, 0, 0]), t[5]))
+            return compose(t[:3], bq, p, q)
         return compose(self.xf('HBASE_F' if g else 'HBASE_M', 3), np.array([0, 0, 0, 1.0]), p, q)
 
     # -- robot --------------------------------------------------------------------------------------
@@ -355,14 +362,47 @@ class ResetOracle:
         return q, dpos, min(np.sqrt(dm @ dm), np.sqrt(dp @ dp))
 
     # -- one reset ----------------------------------------------------------------------------------
-    def sample(self, seed, impairment_mode=MODE_RANDOM, gender_mode=-1, max_restarts=None):
+    def ragdoll_drop(self, seed, impairment_mode=MODE_RANDOM, gender_mode=-1):
+        """the sampler of the rag-doll model (FLAGS bit 5; bed_bathing.py:119-127): its drop record -- base in the air, every joint
+        U(-r, r) clamped to its limits, at rest; friction / gender / limit scale as the task blob's sampler draws them from the same seed"""
+        assert self.xi('FLAGS') & 32
+        u = lambda idx: u01(seed, 0, idx)
+        friction = self.xf('FRIC_LO') + (self.xf('FRIC_HI') - self.xf('FRIC_LO')) * u(S_FRICTION)
+        g = gender_mode if gender_mode >= 0 else (0 if u(S_GENDER) < 0.5 else 1)
+        if impairment_mode >= 0:
+            imp = impairment_mode
+        else:
+            nchoice = 4 if impairment_mode == MODE_RANDOM else 3
+            imp = min(int(u(S_IMPAIRMENT) * nchoice), nchoice - 1)
+        ls = 1.0 if imp != 1 else self.xf('LIMIT_LO') + (1.0 - self.xf('LIMIT_LO')) * u(S_LIMIT)
+        st = np.zeros(self.state_words, dtype=np.float32)
+        si = st.view(np.int32)
+        S = self.S
+        q = np.zeros(self.ndof)
+        q[:3] = self.xf('HBASE_F' if g else 'HBASE_M', 3)
+        q[3:6] = self.xf('EE_TARGET', 3)
+        r = self.xf('EE_RANGE')
+        for k in range(self.ndof - 6):
+            j = k + (1 if k >= 24 else 0)
+            b0 = self.x0 + self.xi('OFF_JOINTS') + (g * self.xi('NJOINT') + j) * XJ['STRIDE']
+            sc = ls if int(self.i[b0 + XJ['FLAGS']]) & 2 else 1.0
+            q[6 + k] = min(max((2 * u(S_RAGDOLL + k) - 1) * r, float(self.f[b0 + XJ['LOWER']]) * sc), float(self.f[b0 + XJ['UPPER']]) * sc)
+        st[S['Q']:S['Q'] + self.ndof] = q
+        st[S['QT']:S['QT'] + self.ndof] = q
+        st[S['HUMAN'] + 6] = 1.0
+        st[S['BASE'] + 6] = 1.0
+        e = S['ENV']
+        st[e + 0], si[e + 1], st[e + 13] = friction, g, ls
+        return st, dict(gender=g, impairment=imp, limit_scale=ls)
+
+    def sample(self, seed, impairment_mode=MODE_RANDOM, gender_mode=-1, max_restarts=None, settled=None):
         """-> (state record float32[state_words], info dict).  With a `collides` callback (state record -> bool: does the arm /
         tool touch the human, the table or the wheelchair?) a successful IK restart that collides is rejected and the search
         goes on from the next restart (robot.py:105-112, env.py:299-308), at most COLLISION_TRIES times."""
         first, rejected = 0, []
         tries = self.xi('COLLISION_TRIES') if self.collides is not None else 0
         for t in range(tries + 1):
-            st, info = self._sample_from(seed, impairment_mode, gender_mode, max_restarts, first)
+            st, info = self._sample_from(seed, impairment_mode, gender_mode, max_restarts, first, settled)
             if t == tries or not info['ik_ok'] or not self.collides(st):
                 break
             placed = self.xi('TOC_ATTEMPTS') > 0 or bool(self.xi('FLAGS') & 8)             # base pose search / a robot on wheels: the next PLACEMENT (env.py:281-308)
@@ -371,8 +411,11 @@ class ResetOracle:
         info['rejected_restarts'] = rejected
         return st, info
 
-    def _sample_from(self, seed, impairment_mode, gender_mode, max_restarts, first_restart):
+    def _sample_from(self, seed, impairment_mode, gender_mode, max_restarts, first_restart, settled=None):
         u = lambda idx: u01(seed, 0, idx)
+        # bed bathing (FLAGS bit 4): the human lies where the rag doll of the second model came to rest (its record's q, float32)
+        assert (settled is not None) == bool(self.xi('FLAGS') & 16)
+        self.settled = None if settled is None else np.asarray(settled, dtype=np.float32)[:6 + self.xi('NJOINT') - 1].astype(np.float64)
         friction = self.xf('FRIC_LO') + (self.xf('FRIC_HI') - self.xf('FRIC_LO')) * u(S_FRICTION)
         g = gender_mode if gender_mode >= 0 else (0 if u(S_GENDER) < 0.5 else 1)
         if impairment_mode >= 0:
@@ -497,6 +540,13 @@ class ResetOracle:
         si[e + 10] = (seed ^ 0x5bd1e995) & 0x7FFFFFFF
         xflags = self.xi('FLAGS')
         si[e + 11] = 1 if xflags & 6 else self.nfood
+        if xflags & 64:                                                    # bed bathing: every wiping target alive (bed_bathing.py:173-188)
+            to = int(self.i[H_OFF_TASK])
+            nt = int(self.i[to + 52 + 2 * g]) + int(self.i[to + 52 + 2 * g + 1])      # AGX_T_NT
+            si[e + 11] = nt
+            ts = int(self.i[H_S_TASK])
+            for t in range(6):
+                st.view(np.uint32)[ts + t] = 0xffffffff if nt >= 32 * (t + 1) else ((1 << (nt - 32 * t)) - 1 if nt > 32 * t else 0)
         coop = self.ti('COOP') == 1
         agent = imp == 3 or coop
         si[e + 12] = 0 if (agent or xflags & 1) else (((1 << self.nhdof) - 1) << nr)     # human.py:104-110

@@ -87,11 +87,13 @@ class Emu:
         rc = self.L.agx_emu_settle_packed(_p(self.words), _p(states), C.c_int(len(states)), C.c_int(n))
         assert rc == 0, 'wave emulator reported divergent control flow (or the variant has no packed kernel)'
 
-    def sample(self, seed, impairment_mode=-1, gender_mode=-1):
-        """device-side reset generator (csrc/agx_reset.h) for one env -> (state record, info[4])"""
+    def sample(self, seed, impairment_mode=-1, gender_mode=-1, settled=None):
+        """device-side reset generator (csrc/agx_reset.h) for one env -> (state record, info[4]); settled: the rag-doll model's settled
+        record of this environment (bed bathing)"""
         st = np.zeros(self.blob.state_words, dtype=np.float32)
         info = np.zeros(4, dtype=np.float32)
-        rc = self.L.agx_emu_sample(_p(self.words), _p(st), C.c_uint64(seed), C.c_int(impairment_mode), C.c_int(gender_mode), _p(info))
+        settled = None if settled is None else np.ascontiguousarray(settled, dtype=np.float32)
+        rc = self.L.agx_emu_sample(_p(self.words), _p(st), C.c_uint64(seed), C.c_int(impairment_mode), C.c_int(gender_mode), _p(info), _p(settled))
         assert rc == 0, 'wave emulator reported divergent control flow'
         return st, info
 

@@ -34,6 +34,8 @@ def with_reset_params(blob, **kw):
 def assert_same_record(blob, a, b, what=''):
     e = blob.h['S_ENV']
     ints = [e + L.E[k] for k in ('GENDER', 'FOOD_ALIVE', 'FOOD_ACTIVE', 'ITERATION', 'TASK_SUCCESS', 'RNG', 'TOTAL_FOOD', 'FROZEN')] + [e + L.E['RNG'] + 1]
+    if blob.task_kind == L.TASK_BED_BATHING and blob.h['TASK_WORDS']:        # the bitmask of the targets not wiped yet
+        ints += [blob.h['S_TASK'] + L.BB['ALIVE'] + k for k in range(L.BB['ALIVE_WORDS'])]
     ai, bi = a.view(np.int32), b.view(np.int32)
     for k in ints:
         assert ai[k] == bi[k], (what, 'int word', k - e, ai[k], bi[k])

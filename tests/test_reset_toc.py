@@ -227,8 +227,10 @@ def test_every_feeding_scratch_and_dressing_model_resets_on_the_device():
             assert b.has_reset_generator, (task, robot)
             mounted = b.meta['mount'] == 'wheelchair'
             assert (_x(b, 'TOC_ATTEMPTS', True) == 0) == mounted and _x(b, 'PED_N', True) == (2 if robot == 'sawyer' else 0)
-    for name in ('bed_bathing_sawyer', 'arm_manipulation_sawyer'):                    # the lying human comes out of the rag-doll settle: host-sampled pools
-        assert not ModelBlob.load(name).has_reset_generator
+    for robot in ('jaco', 'panda', 'sawyer', 'baxter', 'pr2', 'stretch'):             # bed bathing: with the rag-doll model attached (tests/test_reset_bed_device.py)
+        b = ModelBlob.load('bed_bathing_' + robot)
+        assert b.has_reset_generator and _x(b, 'FLAGS', True) & 16
+    assert not ModelBlob.load('arm_manipulation_sawyer').has_reset_generator           # two settles (rag doll, then the arm's fall): host-sampled pools
 
 
 def test_pedestal_guard_rejects_start_poses_inside_the_boxes():

@@ -199,7 +199,7 @@ def test_other_tasks_model_tables(tb):
     task, b, o = tb
     base_obs = {'scratch_itch': 23, 'bed_bathing': 17}[task]                                   # scratch_itch.py:8, bed_bathing.py:10
     assert (b.act_dim, b.obs_dim, b.nrobot, b.nhdof) == (5, base_obs + 3, 16, 10) and b.h['BASE_LINK'] == 6
-    assert b.meta['mount'] == 'mobile' and b.has_reset_generator == (task == 'scratch_itch')      # bed bathing: the lying human comes out of a settle (no generator, §8)
+    assert b.meta['mount'] == 'mobile' and b.has_reset_generator                                  # (bed bathing: with the rag-doll model attached)
     assert b.meta['mobile_base'] == {'scratch_itch': [-1.0, -0.1, 0.09], 'bed_bathing': [-1.1, -0.1, 0.09]}[task]        # stretch.py:37,39
     assert b.meta['lift'] == {'scratch_itch': 0.75, 'bed_bathing': 0.95}[task]                                             # stretch.py:58-62
     assert [b.robot_f(d, 'QT0') for d in (14, 15)] == [np.float32(0.1)] * 2                                                # gripper_pos, stretch.py:21,24
