@@ -510,7 +510,7 @@ def reference_envs():
 
 # ------------------------------------------------------------------------------------------------ adopting a state record
 TASK_OF_KIND = {0: 'feeding', 1: 'bed_bathing', 2: 'scratch_itch', 3: 'dressing', 4: 'arm_manipulation'}
-ROBOT_CLASS = {'jaco': 'Jaco', 'sawyer': 'Sawyer', 'pr2': 'PR2', 'baxter': 'Baxter', 'panda': 'Panda'}
+ROBOT_CLASS = {'jaco': 'Jaco', 'sawyer': 'Sawyer', 'pr2': 'PR2', 'baxter': 'Baxter', 'panda': 'Panda', 'stretch': 'Stretch'}
 TASK_CLASS = {'feeding': 'Feeding', 'bed_bathing': 'BedBathing', 'scratch_itch': 'ScratchItch', 'dressing': 'Dressing', 'arm_manipulation': 'ArmManipulation'}
 
 
@@ -608,6 +608,8 @@ def adopt(blob, state, cloth=None):
         env.task_success = float(w.state0[blob.h['S_TASK']])                   # AGX_AM_BEST
     elif task == 'dressing':
         R.motor_gains = H.motor_gains = 0.01                                   # dressing.py:118
+        if R.mobile:
+            R.gains = list(np.array(R.gains) / 8.0)                            # dressing.py:135-137: "Change robot gains since we use numSubSteps=8"
         env.cloth_forces = np.zeros((1, 1))                                    # dressing.py:113
         env.cloth = CLOTH
         env.triangle1_point_indices = [1180, 2819, 30]; env.triangle2_point_indices = [1322, 13, 696]   # dressing.py:156-157 (node numbering of the loaded mesh)

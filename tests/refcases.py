@@ -279,8 +279,56 @@ def dressing_cases():
     return out
 
 
-def build_cases(tasks=('feeding', 'bed', 'scratch', 'arm', 'dressing')):
-    fns = dict(feeding=feeding_cases, bed=bed_cases, scratch=scratch_cases, arm=arm_cases, dressing=dressing_cases)
+def stretch_cases():
+    """the Stretch (agents/stretch.py): take_step's branches for a mobile robot -- action_multiplier (env.py:196-197), action_duplication
+    (env.py:218-220: one target for the four telescoping joints, clamped at joint 5's limit), per-joint gains and forces (stretch.py:49-50),
+    the observation without the wheel angles and in the MOVING base frame (feeding.py:90-92, agent.py:60-64) -- for the four tasks it runs in"""
+    from assistive_gym_amd.host import reset, reset_bed, reset_dressing, reset_scratch
+    out = []
+    rng = np.random.RandomState(61)
+    b = ModelBlob.load('feeding_stretch'); o = _oracle(b)
+    st, _ = reset.make_states(b, 1, seed=6101, impairment='none')
+    s = st[0].copy(); o.settle(s, 25)
+    for k in range(2):
+        a = rng.uniform(-1, 1, b.act_dim).astype(np.float32)
+        out.append(dict(name='feeding_stretch_step%d' % k, model='feeding_stretch', coop=False, variant='', state=s.copy(), cloth=None, action=a))
+        o.step(s, a)
+    out.append(dict(name='feeding_stretch_clipped_action', model='feeding_stretch', coop=False, variant='', state=s.copy(), cloth=None,
+                    action=np.array([4.0, -3.0, 1.0, 2.5, -1.7], dtype=np.float32)))
+    s2 = s.copy(); v = b.view(s2.reshape(1, -1))
+    v['q'][0, 9:13] = 0.125; v['qt'][0, 9:13] = 0.125           # the telescoping joints next to their 0.13 m limit: the duplicated target takes the clamp branch
+    out.append(dict(name='feeding_stretch_arm_at_limit', model='feeding_stretch', coop=False, variant='', state=s2, cloth=None,
+                    action=np.array([0.3, -0.3, -0.5, 1.0, 0.2], dtype=np.float32)))
+    bc = b.coop(); oc_ = _oracle(bc)
+    st, _ = reset.make_states(bc, 1, seed=6102, impairment='tremor')
+    s = st[0].copy(); oc_.settle(s, 25)
+    out.append(dict(name='feeding_stretch_coop_tremor', model='feeding_stretch', coop=True, variant='', state=s.copy(), cloth=None,
+                    action=rng.uniform(-1, 1, bc.act_dim).astype(np.float32)))
+    for model, mod, seed in (('scratch_itch_stretch', reset_scratch, 6103), ('bed_bathing_stretch', reset_bed, 6104)):
+        b = ModelBlob.load(model); o = _oracle(b)
+        st = mod.make_states(b, 1, seed=seed, impairment='none')[0]
+        s = st[0].copy(); o.settle(s, 10)                       # onto the wheels
+        for k in range(2):
+            a = rng.uniform(-1, 1, b.act_dim).astype(np.float32)
+            out.append(dict(name='%s_step%d' % (model, k), model=model, coop=False, variant='', state=s.copy(), cloth=None, action=a))
+            o.step(s, a)
+    b = ModelBlob.load('scratch_itch_stretch').coop(); o = _oracle(b)
+    st = reset_scratch.make_states(b, 1, seed=6105, impairment='limits')[0]
+    s = st[0].copy(); o.settle(s, 10)
+    out.append(dict(name='scratch_itch_stretch_coop', model='scratch_itch_stretch', coop=True, variant='', state=s.copy(), cloth=None,
+                    action=rng.uniform(-1, 1, b.act_dim).astype(np.float32)))
+    b = ModelBlob.load('dressing_stretch'); o = _oracle(b)
+    st, cloth, _ = reset_dressing.make_states(b, 1, 6106)
+    s, c = st[0].copy(), cloth[0].copy()
+    o.settle_cloth(s, c, 6)
+    b.view(s.reshape(1, -1))['task'][0, L.DR['CLOTH_GRAVITY']] = np.float32(-9.81).view(np.int32)
+    out.append(dict(name='dressing_stretch_hanging', model='dressing_stretch', coop=False, variant='', state=s.copy(), cloth=c.copy(),
+                    action=rng.uniform(-1, 1, b.act_dim).astype(np.float32)))
+    return out
+
+
+def build_cases(tasks=('feeding', 'bed', 'scratch', 'arm', 'dressing', 'stretch')):
+    fns = dict(feeding=feeding_cases, bed=bed_cases, scratch=scratch_cases, arm=arm_cases, dressing=dressing_cases, stretch=stretch_cases)
     out = []
     for t in tasks:
         out += fns[t]()

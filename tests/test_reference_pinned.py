@@ -119,10 +119,21 @@ def test_the_cases_cover_the_branches():
     assert any(ex[n][0] > 1.0 for n in NAMES if n.startswith('dressing'))                                              # cloth_force_sum
     assert any(bool(STEPS[n + '/done']) for n in NAMES)
     assert any(int(STEPS[n + '/task_success']) == 1 for n in NAMES)
+    # the Stretch: action_duplication hands ONE clamped target to the four telescoping joints (env.py:203-220), the wheels' targets move
+    # by 5 x 0.05 x 3 x action (env.py:188,197), the observation has no wheel angles (feeding.py:90-92)
+    from assistive_gym_amd.blob import ModelBlob
+    b = ModelBlob.load('feeding_stretch')
+    c = case('feeding_stretch_arm_at_limit')
+    qt = b.view(c['state_out'].reshape(1, -1).copy())['qt'][0]
+    assert np.allclose(qt[9:13], 0.13, atol=1e-6)
+    c = case('feeding_stretch_step0')
+    q0, qt = b.view(c['state'].reshape(1, -1).copy())['q'][0], b.view(c['state_out'].reshape(1, -1).copy())['qt'][0]
+    assert np.allclose(qt[6:8] - q0[6:8], 5 * 0.05 * 3 * np.clip(c['action'][:2], -1, 1), atol=1e-5) and len(c['obs']) == 21 and list(c['lens']) == [5, 0, 21, 0]
 
 
 # ---------------------------------------------------------------------------------------------------------------- CPU: kernel sources on the wave emulator
-EMU_CASES = [n for n in NAMES if not n.startswith('dressing') and (n.endswith('step0') or 'food' in n or 'clamped' in n or 'rollback' in n or n.endswith('face_1'))]
+EMU_CASES = [n for n in NAMES if not n.startswith('dressing') and (n.endswith('step0') or 'food' in n or 'clamped' in n or 'rollback' in n or n.endswith('face_1') or
+                                                                   ('stretch' in n and ('limit' in n or 'coop' in n or 'clipped' in n)))]
 
 
 @pytest.mark.parametrize('name', EMU_CASES)
