@@ -34,8 +34,9 @@ class ModelBlob:
     @property
     def has_reset_generator(self):
         """the blob carries a reset section the device-side reset generator (csrc/agx_reset.h, agx_sample_reset / agx_reset) can sample from:
-        the feeding and scratch-itch scenes with a wheelchair-mounted arm, and the scratch-itch scenes of the free-standing PR2 / Baxter
-        (base pose search on the device)"""
+        every feeding, scratch-itch, dressing and bed-bathing scene (wheelchair-mounted arm: IK restarts; free-standing robot: base pose
+        search; robot on wheels: placement draws; bed bathing: with the rag-doll model attached, agx_attach_settle_model) and the rag-doll
+        model itself (its drop record); not the arm-manipulation scenes (two settles: host sampler around the device settles)"""
         from .model import compiler as L
         x0 = int(self.i[L.H['OFF_RESET']])
         words = int(self.i[L.H['OFF_TARGETS']]) - x0 if 'OFF_TARGETS' in L.H else 0
