@@ -2064,7 +2064,8 @@ int agxo_world_frame(agxo_world* w, int kind, int index, double* pos, double* qu
       quat_to_mat(rq, Rr); xf_apply(&s->freex[index], rp, p); mm3(s->freex[index].R, Rr, R); }
     double r[3], wr[3]; sub3(p, s->fpos[index], r); cross3(s->fw[index], r, wr); add3(s->fv[index], wr, v); memcpy(om, s->fw[index], 24);
   } else if (kind == 2) { if (index < 0 || index >= m->nhuman) return 0; memcpy(p, s->human[index].p, 24); memcpy(R, s->human[index].R, 72); }
-  else if (kind == 3) { const int bl = m->i[AGX_H_BASE_LINK]; const xf_t* B = bl > 0 ? &s->link[bl - 1] : &s->base; memcpy(p, B->p, 24); memcpy(R, B->R, 72); }
+  else if (kind == 3) { const int bl = m->i[AGX_H_BASE_LINK]; const xf_t* B = bl > 0 ? &s->link[bl - 1] : &s->base; memcpy(p, B->p, 24); memcpy(R, B->R, 72);
+    if (bl > 0) { double wxp[3]; cross3(s->vsp[bl - 1], p, wxp); add3(s->vsp[bl - 1] + 3, wxp, v); memcpy(om, s->vsp[bl - 1], 24); } }   /* the twist of a floating base */
   else return 0;
   if (pos) memcpy(pos, p, 24); if (quat) mat_to_quat(R, quat); if (lin) memcpy(lin, v, 24); if (ang) memcpy(ang, om, 24);
   return 1;

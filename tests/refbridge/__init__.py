@@ -134,6 +134,7 @@ class World:
         self.h = C.c_void_p(self.L.agxo_world_create(C.c_void_p(self.oracle.h), _p(self.state0), _p(self.cloth0)))
         v = blob.view(self.state0.reshape(1, -1))
         self.gender = int(v['gender'][0])
+        self.plane_friction = float(v['plane_friction'][0])
         self.limit_scale = float(v['limit_scale'][0]) or 1.0
         self.human_kp, self.human_maxf = float(v['human_kp'][0]), float(v['human_maxf'][0])
         self.frozen = int(v['frozen'][0])
@@ -306,6 +307,12 @@ def make_pybullet(get_world):
         if body in (TOOL, TOOL2): return w.n_tool_links
         return 0
     p.getNumJoints = getNumJoints
+
+    def getDynamicsInfo(body, link, physicsClientId=0):
+        # (mass, lateral friction, ...): only what the state capture reads -- the ground's friction drawn by build_assistive_env (env.py:120)
+        assert body == PLANE and link == -1, 'getDynamicsInfo: only the plane is backed'
+        return (0.0, W().plane_friction, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0), 0.0, 0.0, 0.0, -1.0, -1.0, 2, 0.001)
+    p.getDynamicsInfo = getDynamicsInfo
 
     def getJointInfo(body, j, physicsClientId=0):
         w = W()
@@ -541,6 +548,7 @@ def adopt(blob, state, cloth=None):
     w.ee_links = {(R.right_end_effector if arm_right else R.left_end_effector): 0}
     if task == 'arm_manipulation' and not R.has_single_arm:
         w.ee_links[R.left_end_effector] = 1
+    env.plane.body, env.plane.id = PLANE, env.id                                  # env.py:118
     R.body = ROBOT
     Robot.init(R, ROBOT, env.id, env.np_random)
     env.agents.append(R)

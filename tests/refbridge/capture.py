@@ -69,11 +69,21 @@ def capture(env, blob, p, initial, cloth_out=None):
     cid, R, H = env.id, env.robot, env.human
     g = 1 if H.gender == 'female' else 0
     nr, nd = blob.nrobot, blob.ndof
-    # ---- articulated DoFs
-    rj = [blob.robot_i(d, 'PB_INDEX', g) for d in range(nr)]
+    # ---- articulated DoFs.  A robot on a floating base (AGX_H_BASE_LINK; Stretch): its six virtual joints hang off the record's base pose -- the
+    # capture takes the CURRENT base pose as that anchor, so the virtual angles are zero and their rates are the base twist in the anchor's
+    # axes (at zero angles the z-y-x Euler rates are the angular velocity's z, y, x components)
+    nv = blob.h['BASE_LINK'] if blob.h.get('BASE_LINK', 0) > 0 else 0
+    rj = [blob.robot_i(d, 'PB_INDEX', g) for d in range(nv, nr)]
     hj = [blob.robot_i(d, 'PB_INDEX', g) for d in range(nr, nd)]
     js = p.getJointStates(R.body, rj, physicsClientId=cid)
-    v['q'][0, :nr], v['qd'][0, :nr] = [j[0] for j in js], [j[1] for j in js]
+    v['q'][0, nv:nr], v['qd'][0, nv:nr] = [j[0] for j in js], [j[1] for j in js]
+    if nv:
+        bpos, born = p.getBasePositionAndOrientation(R.body, physicsClientId=cid)
+        lin, ang = p.getBaseVelocity(R.body, physicsClientId=cid)
+        qi = np.array([-born[0], -born[1], -born[2], born[3]])
+        ll, la = _q_rot(qi, lin), _q_rot(qi, ang)
+        v['q'][0, :nv] = 0
+        v['qd'][0, :nv] = [ll[0], ll[1], ll[2], la[2], la[1], la[0]]
     if hj:
         hs = p.getJointStates(H.body, hj, physicsClientId=cid)
         v['q'][0, nr:], v['qd'][0, nr:] = [j[0] for j in hs], [j[1] for j in hs]
@@ -119,6 +129,7 @@ def capture(env, blob, p, initial, cloth_out=None):
         v['human'][0, k] = list(pos) + list(orn)
     # ---- per-environment words
     v['gender'][0] = g
+    v['plane_friction'][0] = p.getDynamicsInfo(env.plane.body, -1, physicsClientId=cid)[1]              # env.py:120
     v['iteration'][0] = env.iteration
     v['limit_scale'][0] = H.limit_scale
     v['rng'][0] = [12345, 6789]                                                # the device's own generator (teleport positions); not compared

@@ -79,7 +79,8 @@ def _bridge_cases():
         return []
     import refcases
     want = ('feeding_jaco_tremor', 'feeding_food_events', 'feeding_coop_tremor', 'bed_wiping', 'bed_coop_rollback', 'scratch_itch_pr2_coop_scratching',
-            'scratch_itch_jaco', 'arm_manipulation_sawyer_lifting', 'arm_manipulation_pr2', 'dressing_on_forearm', 'dressing_coop_sleeve')
+            'scratch_itch_jaco', 'arm_manipulation_sawyer_lifting', 'arm_manipulation_pr2', 'dressing_on_forearm', 'dressing_coop_sleeve',
+            'feeding_stretch_step1', 'bed_bathing_stretch_step1')
     out, seen = [], set()
     for c in refcases.build_cases():
         key = next((w for w in want if c['name'].startswith(w)), None)
@@ -95,7 +96,7 @@ def test_capture_inverts_adopt_on_the_bridge():
     from refbridge import capture as cap
     from assistive_gym_amd.model import compiler as L
     cases = _bridge_cases()
-    assert len(cases) >= 9
+    assert len(cases) >= 11
     refbridge.install()
     p = sys.modules['pybullet']
     for c in cases:
@@ -123,14 +124,29 @@ def test_capture_inverts_adopt_on_the_bridge():
             dq = np.minimum(np.abs(x[..., 3:7] - y[..., 3:7]).max(axis=-1), np.abs(x[..., 3:7] + y[..., 3:7]).max(axis=-1))
             rest = np.abs(np.delete(x, [3, 4, 5, 6], axis=-1) - np.delete(y, [3, 4, 5, 6], axis=-1)).max(axis=-1)
             return float(np.maximum(dq, rest).max())
+        nv = blob.h['BASE_LINK'] if blob.h['BASE_LINK'] > 0 else 0
+        if nv:
+            # a robot on a floating base (Stretch): the capture anchors the six virtual joints at the CURRENT base pose (angles zero, the base
+            # twist in their rates) -- another record of the same physical state: the link frames agree, and so does what one env.step()
+            # of the oracle makes of both
+            from oracle_lib import Oracle
+            o = Oracle(blob)
+            pa, Ra = o.fk(c['state'].copy()); pb, Rb = o.fk(got.copy())
+            assert np.abs(pa[nv - 1:] - pb[nv - 1:]).max() < 2e-6 and np.abs(Ra[nv - 1:] - Rb[nv - 1:]).max() < 2e-6, c['name']      # from the base link on (the virtual links before it are bookkeeping)
+            s1, s2 = c['state'].copy(), got.copy()
+            o1, o2 = o.step(s1, c['action']), o.step(s2, c['action'])
+            assert np.abs(o1[0] - o2[0]).max() < 2e-5 and abs(o1[1] - o2[1]) < 2e-5, c['name']
+            pa, _ = o.fk(s1); pb, _ = o.fk(s2)
+            assert np.abs(pa[nv - 1:] - pb[nv - 1:]).max() < 2e-5, c['name']
+            assert np.all(b['q'][0, :nv] == 0)
         for k in ('q', 'qd', 'tremor', 'tremor_target'):
-            assert np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() < 2e-6, (c['name'], k)
-        assert pose_dev(a['base'][0], b['base'][0]) < 2e-6 and pose_dev(a['human'][0], b['human'][0]) < 2e-6, c['name']
+            assert np.abs(a[k].astype(np.float64)[0, nv:] - b[k].astype(np.float64)[0, nv:]).max() < 2e-6 if k in ('q', 'qd') else np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() < 2e-6, (c['name'], k)
+        assert (nv or pose_dev(a['base'][0], b['base'][0]) < 2e-6) and pose_dev(a['human'][0], b['human'][0]) < 2e-6, c['name']
         near = np.abs(a['free'][0][:, :3]).max(axis=1) < 500 if blob.nfree else np.zeros(0, bool)          # eaten particles were teleported away
         assert not near.any() or pose_dev(a['free'][0][near], b['free'][0][near]) < 2e-6, c['name']
         for k in ('gender', 'iteration', 'food_alive', 'food_active', 'task_success', 'frozen'):
             assert int(a[k][0]) == int(b[k][0]), (c['name'], k, int(a[k][0]), int(b[k][0]))
-        assert abs(float(a['limit_scale'][0]) - float(b['limit_scale'][0])) < 1e-6
+        assert abs(float(a['limit_scale'][0]) - float(b['limit_scale'][0])) < 1e-6 and abs(float(a['plane_friction'][0]) - float(b['plane_friction'][0])) < 1e-6
         nr = blob.nrobot
         passive = [d for d in range(nr) if blob.robot_i(d, 'ACT') < 0]
         assert np.abs(a['qt'][0, passive] - b['qt'][0, passive]).max() < 2e-6 if passive else True, c['name']
