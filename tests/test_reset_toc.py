@@ -13,10 +13,11 @@ sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import reset_oracle as ro                      # noqa: E402  (test infrastructure)
 from assistive_gym_amd.blob import ModelBlob   # noqa: E402
 from assistive_gym_amd.model import compiler as L   # noqa: E402
+from conftest import full                      # noqa: E402
 from test_reset_generator import assert_same_record   # noqa: E402
 
 
-@pytest.fixture(scope='module', params=['pr2', 'baxter', 'sawyer'])
+@pytest.fixture(scope='module', params=['pr2', pytest.param('baxter', marks=full), 'sawyer'])
 def rb(request):
     from emu_lib import Emu
     b = ModelBlob.load('scratch_itch_' + request.param)
@@ -251,9 +252,11 @@ def test_pedestal_guard_rejects_start_poses_inside_the_boxes():
     w2.view(np.int32)[o0 + L.X_['TOC_ATTEMPTS']] = 12; w3 = blob.words.copy(); w3.view(np.int32)[o0 + L.X_['TOC_ATTEMPTS']] = 12
     off, on = ro.ResetOracle(ModelBlob(w2, blob.meta).words), ro.ResetOracle(ModelBlob(w3, blob.meta).words)
     differ = 0
-    for seed in range(40, 52):
+    for seed in range(40, 52):                       # (stops at the first seed that shows the difference: the numpy base pose search is slow)
         a, b = off.sample(seed)[0], on.sample(seed)[0]
         differ += int(not np.array_equal(a, b))
+        if differ:
+            break
     assert differ >= 1
 
 
