@@ -264,3 +264,48 @@ def compile_cloth(obj_path, scale, position, rpy, anchors, anchor_body_pos, tri1
     pv[CP['NODE_IM']] = nn / params['MASS']                          # setTotalMass(mass, fromfaces=false): equal node masses
     meta = dict(nodes=nn, links=n_real, link_slots=len(links), link_bank_extra_cycles=int(bank_extra), colors=ncolor, patch_colors=npatch_color, cross_colors=ncross, cross_links=len(cross), faces=len(faces), shapes=len(shapes), planes=len(planes), max_links_per_color=max_per)
     return f.view(np.uint32).copy(), meta
+
+
+def compile_particles(x0, radius, total_mass, params, colliders, shape_ids, gender_of=lambda ci: 0):
+    """uint32 words of a particle section in the garment's format (AGX_CL_PARTICLES = 1): the water of the drinking task (drinking.py:160-170) --
+    nodes without links, faces or anchors, spheres of `radius` (the section's MARGIN) tested against the same kind of shape table.
+    x0: rest offsets of the particles (the 4 x 4 x 4 grid relative to the cup, drinking.py:163-167)."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    nn = len(x0)
+    assert nn <= 64
+    planes, shapes = [], []
+    for ci in shape_ids:
+        c = colliders[ci]
+        if len(c['verts']) <= 2:
+            shapes.append([ci, 0, 0, gender_of(ci)])
+        else:
+            pl = hull_planes(c['verts']).tolist()
+            pl += [pl[-1]] * ((-len(pl)) % 4)
+            shapes.append([ci, len(planes), len(pl), gender_of(ci)])
+            planes.extend(pl)
+    planes = np.array(planes, dtype=np.float64).reshape(-1, 4)
+    off, cur = {}, CL['HDR']
+    cur += (-cur) % 4
+    for name, size in (('COLOR', 1), ('LINK', 0), ('NODE', 2 * (nn + 1)), ('FACE', 0), ('X0', 3 * nn), ('ANCHOR', 0), ('SHAPE', 4 * len(shapes)),
+                       ('PLANE', 4 * len(planes)), ('PARAM', CP['COUNT']), ('PERM', 4096)):
+        if name == 'PLANE':
+            cur += (-cur) % 4
+        off[name] = cur
+        cur += size
+    f = np.zeros(cur, dtype=np.float32)
+    i = f.view(np.int32)
+    i[CL['NN']], i[CL['NL']], i[CL['NCOLOR']], i[CL['NANCHOR']], i[CL['NSHAPE']], i[CL['PARTICLES']] = nn, 0, 0, 0, len(shapes), 1
+    for name in ('COLOR', 'LINK', 'NODE', 'FACE', 'X0', 'ANCHOR', 'SHAPE', 'PLANE', 'PARAM', 'PERM'):
+        i[CL['OFF_' + name]] = off[name]
+    perm = np.full(4096, -1, dtype=np.int64)
+    perm[:nn] = np.arange(nn)
+    i[off['PERM']:off['PERM'] + 4096] = perm
+    f[off['X0']:off['X0'] + 3 * nn] = x0.astype(np.float32).ravel()
+    i[off['SHAPE']:off['SHAPE'] + 4 * len(shapes)] = np.array(shapes, dtype=np.int64).ravel() if shapes else []
+    f[off['PLANE']:off['PLANE'] + 4 * len(planes)] = planes.astype(np.float32).ravel()
+    pv = f[off['PARAM']:off['PARAM'] + CP['COUNT']]
+    for k, val in params.items():
+        pv[CP[k]] = val
+    pv[CP['MARGIN']] = radius
+    pv[CP['NODE_IM']] = nn / total_mass
+    return f.view(np.uint32).copy(), dict(nodes=nn, links=0, shapes=len(shapes), planes=len(planes), particles=True)

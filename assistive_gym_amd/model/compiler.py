@@ -64,10 +64,12 @@ HUMAN_DYNAMIC_JOINTS = [20, 21, 22, 23]      # human.head_joints (agents/human.p
 TAG = dict(ROBOT=1, TOOL=2, HUMAN=3, FOOD=4, BOWL=5, TABLE=6, PLANE=7, WHEELCHAIR=8, BED=9)
 TASK_FEEDING, TASK_BED_BATHING, TASK_SCRATCH_ITCH, TASK_DRESSING, TASK_ARM_MANIPULATION = 0, 1, 2, 3, 4
 AM = dict(BEST=0, WORDS=12)   # arm manipulation task words (AGX_AM_*)
+DK = dict(ALIVE=0, ACTIVE=2, WORDS=12)   # drinking task words (AGX_DK_*)
+TASK_DRINKING = 5
 DR = dict(CLOTH_GRAVITY=0, FORCE_SUM=1, BEST=2, CLOTH_OFF=3, WORDS=12)   # dressing task words (AGX_DR_*)
 # cloth section (AGX_CL_*, AGX_CP_*)
 CL = dict(NN=0, NL=1, NCOLOR=2, NANCHOR=3, NSHAPE=4, OFF_COLOR=5, OFF_LINK=6, OFF_NODE=7, OFF_FACE=8, OFF_X0=9, OFF_ANCHOR=10, OFF_SHAPE=11,
-          OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, OFF_PERM=21, NPATCH_COLOR=22, HDR=24)
+          OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, OFF_PERM=21, NPATCH_COLOR=22, PARTICLES=23, HDR=24)
 CP = dict(KLST=0, KDP=1, KDG=2, KDF=3, KCHR=4, KKHR=5, KAHR=6, PITER=7, MARGIN=8, NODE_IM=9, AIR_DENSITY=10, FORCE_SCALE=11, FORCE_MAX=12,
           EE_BELOW=13, COUNT=16)
 CLOTH_MAX_COLORS, CLOTH_THREADS, CLOTH_NODE_CONTACTS = 16, 1024, 2
@@ -851,6 +853,98 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
                 meta_extra=dict(head_link=int(head_link), robot=robot, mount='mobile' if mobile else 'wheelchair' if mounted else 'toc', toc_base=list(RB.get('toc_base', [0, 0, 0])),
                                 ee_rpy=list(RB['ee_rpy']), robot_base_pos=list(RB['base_pos']) if mounted else list(RB['mobile_base']) if mobile else (np.array([-0.85, -0.4, 0]) + RB['toc_base']).tolist(),
                                 robot_base_quat=(X.quat_from_rpy(RB['mobile_rpy']) if mobile else X.quat_from_rpy([0, 0, -np.pi / 2.0])).tolist(), **meta_mobile))
+
+
+# ---- Drinking (drinking.py): MODEL + CPU ORACLE ONLY so far -- no kernel variant serves TASK_DRINKING yet -----------------------------
+# per robot: gripper_pos, tool_pos_offset, tool_orient_offset, toc_base_pos_offset, toc_ee_orient_rpy for 'drinking' (agents/jaco.py:21,27,32,38,44)
+DRINKING_ROBOTS = dict(
+    jaco=dict(FEEDING_ROBOTS['jaco'], gripper_target=0.63, tool_pos=[0.05, -0.005, 0], tool_rpy=[0, -np.pi / 2.0, np.pi / 2.0],
+              base_pos=[-0.35, -0.3, 0.36], ee_rpy=[0, np.pi / 2.0, 0]))
+
+
+def compile_drinking(robot='jaco', assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=10):
+    """Drinking<Robot>-v1 (drinking_envs.py): the feeding scene without bowl, table and food -- the robot holds a cup (68 convex pieces,
+    plastic_coffee_cup_vhacd.obj x 0.045, tool.py:23-25,33-35) with 64 water spheres in it (r = 5 mm, 1 g each: drinking.py:160-170);
+    numSubSteps = 4, numSolverIterations = 10 (:157).  The water is a PARTICLE SECTION in the garment's format (model/cloth.py
+    compile_particles): one-way coupled to the rigid scene like the garment [deviation: Bullet solves the spheres as rigid bodies]."""
+    from .cloth import compile_particles
+    sc = Scene()
+    RB = DRINKING_ROBOTS[robot]
+    arm, grip = RB['arm'], RB['grip']
+    rob = compile_robot(os.path.join(assets, *RB['urdf']), arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.005, motor_force=1.0,    # drinking.py:130
+                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), use_file_inertia=RB.get('file_inertia', False))
+    nrobot = len(rob['dof_links'])
+    gripper_collision = RB['gripper_collision']
+    add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)
+    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
+    sc.begin('robot_base')
+    for verts, radius, fr, pb in rob['base_colliders']:
+        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
+    sc.end('robot_base')
+    cup = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'dinnerware', 'plastic_coffee_cup_vhacd.obj'), 0.045)]
+    allv = np.concatenate(cup)
+    free = [dict(mass=1.0, inertia=box_inertia(1.0, allv.min(0) - HULL_MARGIN, allv.max(0) + HULL_MARGIN), gravity=0.0,                            # tool.py:34, drinking.py:152
+                 refpos=np.zeros(3), refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0)]
+    sc.begin('tool')
+    for hv in cup:
+        sc.add(BODY_FREE0 + 0, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['TOOL'])
+    sc.end('tool')
+    hd = HUMAN_DYNAMIC_JOINTS
+    human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.005, maxf=1.0, act0=len(arm))                                           # drinking.py:130
+    head_link = nrobot + hd.index(23)
+    sc.begin('plane')
+    sc.add(BODY_WORLD, box_verts([0, 0, -5.0], [15, 15, 5]), 0.0, 1.0, TAG['PLANE'])
+    sc.end('plane')
+    sc.begin('wheelchair')
+    wq = X.quat_from_rpy([np.pi / 2, 0, np.pi])
+    for g in load_obj_groups(os.path.join(assets, 'wheelchair', 'wheelchair_permobil_reduced_compressed_vhacd.obj'), 0.15):
+        sc.add(BODY_WORLD, X.apply(np.array([0, 0, 0.06]), np.array([0, 0, 0, 1.0]), X.apply(np.zeros(3), wq, convex_hull_vertices(g))), HULL_MARGIN, DEFAULT_FRICTION, TAG['WHEELCHAIR'])
+    sc.end('wheelchair')
+    G_ = Groups(sc.ranges)
+    grp = G_.add
+    grp('tool', 'human_male', alt='human_female', keep=1)
+    grp('robot_arm', 'human_male', alt='human_female', keep=2)
+    grp('robot_gripper', 'human_male', alt='human_female', keep=2)
+    grp('robot_arm', 'tool')
+    G_.rg['robot_links'] = (G_.rg['robot_arm'][0], G_.rg['robot_gripper'][1])
+    if RB.get('selfcol', 'all') == 'all':
+        grp('robot_links', 'robot_links', same=True, no_adjacent=True)
+    grp('robot_arm', 'wheelchair')
+    grp('robot_gripper', 'wheelchair')
+    grp('robot_arm', 'plane')
+    grp('robot_gripper', 'plane')
+    grp('tool', 'wheelchair')
+    grp('tool', 'plane')
+
+    def reset_words(nhuman, nhdof):
+        return X_['COUNT']
+
+    def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
+        pass        # no device-side reset generator yet: host/reset_drinking.py
+
+    ee_pb = RB['ee_pb']
+    ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    task_f = dict(W_DISTANCE=1.0, W_ACTION=0.01, W_FOOD=1.0, W_WIPE=0.1,                   # config.ini:22-25 (W_WIPE = AGX_T_W_TILT: cup_tilt_weight)
+                  C_V=0.25, C_F=0.01, C_HF=0.05, C_FD=1.0, C_FDV=1.0,                      # config.ini:40-44
+                  SUCCESS_FRAC=0.75, MOUTH_DIST=0.03, SPILL_DIST=0.1, TARGET_RADIUS=0.05,  # config.ini:26, drinking.py:66,77,64
+                  MOUTH_M=[0, -0.11, 0.03], MOUTH_F=[0, -0.1, 0.03],                        # drinking.py:191
+                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=RB['tool_pos'], TOOL_QUAT=X.quat_from_rpy(RB['tool_rpy']),
+                  TOOL_OBS_POS=[0, 0.06, 0], TOOL_OBS_QUAT=X.quat_from_rpy([np.pi / 2.0, 0, 0]),   # the frame the reward reads the cup in (drinking.py:24,56)
+                  EE2_POS=[0, 0, -0.055], TOOL2_POS=[0, 0, 0.07],                          # AGX_T_DK_TOP / _BOTTOM: cup_top_center_offset, cup_bottom_center_offset (drinking.py:138-139)
+                  TOOL_MAXF=500.0, EPISODE_LEN=200)
+    task_i = dict(HEAD_LINK=head_link, EE_LINK=ee_link)
+    params = default_params(n_iter)                                                        # numSolverIterations = 10 (drinking.py:157); robot / human / tool gravity 0 (:150-152)
+    r = sc.ranges
+    shape_ids = [c for name in ('tool', 'robot_gripper', 'human_male', 'human_female') for c in range(*r[name])]
+    wr = 0.005
+    grid = [np.array([i * 2 * wr - 0.02, j * 2 * wr - 0.02, k * 2 * wr + 0.075]) for i in range(4) for j in range(4) for k in range(4)]          # drinking.py:163-167, relative to the cup
+    water, wmeta = compile_particles(grid, wr, 64 * 0.001, dict(KDF=0.5, KCHR=1.0, KKHR=1.0, PITER=10, FORCE_SCALE=1.0, FORCE_MAX=1e9), sc.colliders, shape_ids,
+                                     gender_of=lambda ci: 1 if r['human_male'][0] <= ci < r['human_male'][1] else (2 if r['human_female'][0] <= ci < r['human_female'][1] else 0))
+    return pack(sc, G_.rows, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=18 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRINKING), reset_fill, reset_words,
+                task_words=DK['WORDS'], cloth=water, sim_substeps=4,
+                meta_extra=dict(head_link=int(head_link), robot=robot, mount='wheelchair', water=wmeta, ee_rpy=list(RB['ee_rpy']), robot_base_pos=list(RB['base_pos']),
+                                robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist(), device_path=False))
 
 
 def capsule_points(p1, p2, radius, distance_between_points):
@@ -1837,7 +1931,7 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  bed_bathing_jaco=lambda *a, **k: compile_bed_bathing('jaco', *a, **k), bed_bathing_panda=lambda *a, **k: compile_bed_bathing('panda', *a, **k),
                  bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
-                 dressing_stretch=lambda *a, **k: compile_dressing('stretch', *a, **k),
+                 dressing_stretch=lambda *a, **k: compile_dressing('stretch', *a, **k), drinking_jaco=lambda *a, **k: compile_drinking('jaco', *a, **k),
                  scratch_itch_stretch=lambda *a, **k: compile_scratch_itch('stretch', *a, **k), bed_bathing_stretch=lambda *a, **k: compile_bed_bathing('stretch', *a, **k),
                  scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,

@@ -73,7 +73,9 @@ enum { AGX_TASK_FEEDING = 0,      /* assistive_gym/envs/feeding.py      */
        AGX_TASK_BED_BATHING = 1,  /* assistive_gym/envs/bed_bathing.py  */
        AGX_TASK_SCRATCH_ITCH = 2, /* assistive_gym/envs/scratch_itch.py */
        AGX_TASK_DRESSING = 3,     /* assistive_gym/envs/dressing.py     */
-       AGX_TASK_ARM_MANIPULATION = 4 };   /* assistive_gym/envs/arm_manipulation.py (single-arm robots) */
+       AGX_TASK_ARM_MANIPULATION = 4,    /* assistive_gym/envs/arm_manipulation.py (single-arm robots) */
+       AGX_TASK_DRINKING = 5 };          /* assistive_gym/envs/drinking.py -- MODEL AND CPU ORACLE ONLY so far: no kernel variant serves it (agx_create
+                                          * refuses such a blob); the water is a particle section in the garment's format (AGX_CL_PARTICLES)        */
 
 /* ---- PARAMS: float[AGX_P_COUNT] ----------------------------------------------------------- */
 enum {
@@ -373,6 +375,15 @@ enum { AGX_SI_TARGET = 0,       /* float[3] target_on_arm, in the frame of its l
 /* arm manipulation (offset AGX_H_S_TASK): float task_success = best reward_distance_human so far, 0 = none yet (arm_manipulation.py:46-47);
  * the arm-limit words at AGX_BB_PREV / AGX_BB_HAS_PREV */
 enum { AGX_AM_BEST = 0, AGX_AM_WORDS = 12 };
+/* drinking (offset AGX_H_S_TASK): the water particles still in the scene (self.waters, drinking.py:52-91) and those that have not hit the
+ * person yet (self.waters_active), 64-bit masks; the task constants reuse words no drinking scene needs otherwise: AGX_T_W_WIPE = cup_tilt_weight
+ * (config.ini:24), AGX_T_TARGET_RADIUS = the radius of the cup's cylinder test (0.05, drinking.py:64), AGX_T_TOOL_OBS_POS / _QUAT = the frame
+ * the reward reads the cup in ([0, 0.06, 0], rpy (pi/2, 0, 0): drinking.py:24,56), AGX_T_EE2_POS / AGX_T_TOOL2_POS = cup_top_center_offset /
+ * cup_bottom_center_offset in that frame (drinking.py:138-139) */
+enum { AGX_DK_ALIVE = 0, AGX_DK_ACTIVE = 2, AGX_DK_WORDS = 12 };   /* (words 6 .. 10 stay what they are in every task: AGX_BB_PREV / AGX_BB_HAS_PREV) */
+#define AGX_T_W_TILT AGX_T_W_WIPE
+#define AGX_T_DK_TOP AGX_T_EE2_POS
+#define AGX_T_DK_BOTTOM AGX_T_TOOL2_POS
 /* dressing (offset AGX_H_S_TASK): at AGX_BB_PREV / AGX_BB_HAS_PREV the arm-limit classifier's remembered pose, like the others */
 enum { AGX_DR_CLOTH_GRAVITY = 0, /* float: world gravity z acting on the cloth: -9.81 / 2 while it settles in reset, then -9.81 (dressing.py:178,195) */
        AGX_DR_FORCE_SUM = 1,     /* float: cloth_force_sum of the last step (dressing.py:96), an observation input                                */
@@ -412,6 +423,9 @@ enum {
   AGX_CL_NPATCH_COLOR = 22, /* K: the link table starts with 16 x K classes of exactly 64 slots, class w K + c = colour c of the links whose
                             two nodes both belong to patch w (the 256 nodes that wave w of the cloth kernel owns, OFF_PERM): patches
                             share no node, so a wave relaxes its K classes in order without waiting for any other wave            */
+  AGX_CL_PARTICLES = 23,    /* 1 = the nodes are free particles (the water of the drinking task: no links, faces or anchors): spheres of radius MARGIN
+                             * that also collide with each other (a Jacobi pass per solver iteration, neighbours in ascending order), under the world's
+                             * gravity AGX_P_GRAVITY_Z                                                                                                  */
   AGX_CL_HDR = 24
 };
 enum {

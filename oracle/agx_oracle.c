@@ -223,6 +223,8 @@ typedef struct {
   row_t* rows; int nrows;
   /* dressing: the cloth (node positions / velocities live with the caller), its attachment point and the contacts of the last substep */
   double dr_gravity, dr_force_sum, dr_best;
+  uint64_t dk_alive, dk_active;                            /* drinking: the water particles still in the scene / that have not hit the person yet */
+  int* ccon_node; int* ccon_shape;                         /* node and shape-table entry of every contact of ccon */
   double am_best;                                          /* arm manipulation: task_success = best reward_distance_human so far (arm_manipulation.py:48-49) */
   double* cx; double* cv; double* cq;                      /* [NN][3] each; NULL = no cloth attached to this call */
   double anchor[3]; int anchor_set;
@@ -267,6 +269,11 @@ static void sim_load(sim_t* s, const agxo_model* m, const float* st) {
     }
     if (m->task_kind == AGX_TASK_ARM_MANIPULATION) s->am_best = st[m->s_task + AGX_AM_BEST];
     if (m->task_kind == AGX_TASK_DRESSING) { s->dr_gravity = st[m->s_task + AGX_DR_CLOTH_GRAVITY]; s->dr_force_sum = st[m->s_task + AGX_DR_FORCE_SUM]; s->dr_best = st[m->s_task + AGX_DR_BEST]; }
+    if (m->task_kind == AGX_TASK_DRINKING) {
+      const uint32_t* u = (const uint32_t*)st + m->s_task;
+      s->dk_alive = (uint64_t)u[AGX_DK_ALIVE] | ((uint64_t)u[AGX_DK_ALIVE + 1] << 32); s->dk_active = (uint64_t)u[AGX_DK_ACTIVE] | ((uint64_t)u[AGX_DK_ACTIVE + 1] << 32);
+      s->dr_gravity = PARAM(m, AGX_P_GRAVITY_Z);           /* the water falls under the world's gravity (env.py:104) */
+    }
   }
 }
 static void sim_store(const sim_t* s, float* st) {
@@ -289,6 +296,10 @@ static void sim_store(const sim_t* s, float* st) {
     if (m->task_kind == AGX_TASK_SCRATCH_ITCH) for (int k = 0; k < 3; k++) st[m->s_task + AGX_SI_PREV_CONTACT + k] = (float)s->si_prev[k];
     if (m->task_kind == AGX_TASK_ARM_MANIPULATION) st[m->s_task + AGX_AM_BEST] = (float)s->am_best;
     if (m->task_kind == AGX_TASK_DRESSING) { st[m->s_task + AGX_DR_FORCE_SUM] = (float)s->dr_force_sum; st[m->s_task + AGX_DR_BEST] = (float)s->dr_best; }
+    if (m->task_kind == AGX_TASK_DRINKING) {
+      uint32_t* u = (uint32_t*)st + m->s_task;
+      u[AGX_DK_ALIVE] = (uint32_t)s->dk_alive; u[AGX_DK_ALIVE + 1] = (uint32_t)(s->dk_alive >> 32); u[AGX_DK_ACTIVE] = (uint32_t)s->dk_active; u[AGX_DK_ACTIVE + 1] = (uint32_t)(s->dk_active >> 32);
+    }
   }
 }
 
@@ -1062,7 +1073,7 @@ static void arm_limits(sim_t* s) {
 #define CLH(m, k) ((m)->i[(m)->o_cloth + (k)])
 #define CLPAR(m, k) ((double)(m)->f[(m)->o_cloth + CLH(m, AGX_CL_OFF_PARAM) + (k)])
 #define CLOTH_NODE_CONTACTS AGX_CLOTH_NODE_CONTACTS
-typedef struct { double n[3], offset, c3, imp[3]; } ccontact_t;
+typedef struct { double n[3], offset, c3, imp[3]; int sh; } ccontact_t;
 
 /* signed distance of world point x to the surface of shape sh (negative inside) and the outward normal, world frame */
 static double cloth_shape_distance(const sim_t* s, int sh, const double* x, double* nw) {
@@ -1162,7 +1173,7 @@ static void cloth_substep(sim_t* s) {
       if (dst >= 0) continue;
       if (getenv("AGXO_TRACE_NODE") && atoi(getenv("AGXO_TRACE_NODE")) == i) fprintf(stderr, "node %d shape %d collider %d tag %d body %d dst %g n %g %g %g x %g %g %g\n", i, sh, c, CI(m, c, AGX_C_TAG), CI(m, c, AGX_C_BODY), dst, nw[0], nw[1], nw[2], x[i][0], x[i][1], x[i][2]);
       ccontact_t* k = &con[CLOTH_NODE_CONTACTS * i + ncon[i]++];
-      memcpy(k->n, nw, 24); k->offset = -dot3(nw, x[i]) + dst; k->imp[0] = k->imp[1] = k->imp[2] = 0;
+      memcpy(k->n, nw, 24); k->offset = -dot3(nw, x[i]) + dst; k->imp[0] = k->imp[1] = k->imp[2] = 0; k->sh = sh;
       double vr[3]; sub3(x[i], q[i], vr); const double dn = dot3(vr, nw); double fv[3] = {vr[0] - nw[0] * dn, vr[1] - nw[1] * dn, vr[2] - nw[2] * dn};
       const double fc = kDF * CF(m, c, AGX_C_FRICTION);
       k->c3 = dot3(fv, fv) < (dn * fc * dn * fc) ? 0 : 1 - fc;
@@ -1199,17 +1210,103 @@ static void cloth_substep(sim_t* s) {
   for (int i = 0; i < NN; i++) for (int k = 0; k < 3; k++) v[i][k] = (x[i][k] - q[i][k]) / dt * (1 - kDP);
   s->nccon = 0;
   for (int i = 0; i < NN; i++) for (int cc = 0; cc < ncon[i]; cc++) {
-    const ccontact_t* k = &con[CLOTH_NODE_CONTACTS * i + cc]; double* o = s->ccon + 6 * s->nccon++;
+    const ccontact_t* k = &con[CLOTH_NODE_CONTACTS * i + cc]; s->ccon_node[s->nccon] = i; s->ccon_shape[s->nccon] = k->sh; double* o = s->ccon + 6 * s->nccon++;
     for (int a = 0; a < 3; a++) { o[a] = x[i][a]; o[3 + a] = k->imp[a] / dt; }
   }
   free(slo); free(shi); free(attached); free(con); free(ncon);
+}
+/* The water of the drinking task (AGX_CL_PARTICLES; drinking.py:160-177): NN free spheres of radius r = MARGIN, one-way coupled to the rigid
+ * scene like the garment (they see the cup, the gripper and the person where this substep starts).  Position-based, every step local to a
+ * particle or a Jacobi pass, so that a device kernel with one lane per particle reproduces it:
+ *   1. v += g dt, x = q + v dt;
+ *   2. candidate shapes per particle (at most WATER_CONTACTS, in shape order): those within 2 r + |v| dt of where the substep starts; each
+ *      contributes the half space of the face (or tangent plane) the particle is in front of THERE;
+ *   3. PITER iterations: (a) particle <-> particle: every particle sums, over its overlapping neighbours in ascending index order and from
+ *      the positions the pass starts with, half of each overlap along the centre line, divides by their number and moves by that; (b) each
+ *      particle against the half spaces of its candidates in order (the shapes have the last word of an iteration: the pile cannot press a
+ *      particle through a wall);
+ *   4. v = (x - q) / dt (1 - KDP); a particle that touched a shape loses the share KDF x friction of its tangential velocity.
+ * [deviation: Bullet solves the spheres as rigid bodies inside its sequential-impulse solve, with rolling] */
+#define WATER_CONTACTS 12
+static void water_substep(sim_t* s) {
+  const agxo_model* m = s->m; const int oc = m->o_cloth;
+  const int NN = CLH(m, AGX_CL_NN), NS = CLH(m, AGX_CL_NSHAPE);
+  const double dt = m->dt, r = CLPAR(m, AGX_CP_MARGIN), kDP = CLPAR(m, AGX_CP_KDP), kDF = CLPAR(m, AGX_CP_KDF); const int piter = (int)CLPAR(m, AGX_CP_PITER);
+  double (*x)[3] = (double (*)[3])s->cx, (*v)[3] = (double (*)[3])s->cv, (*q)[3] = (double (*)[3])s->cq;
+  double (*slo)[3] = (double (*)[3])malloc(sizeof(double) * 3 * NS), (*shi)[3] = (double (*)[3])malloc(sizeof(double) * 3 * NS);
+  for (int sh = 0; sh < NS; sh++) {                         /* world boxes of the shapes (as cloth_substep builds them), grown per particle below */
+    const int c = m->i[oc + CLH(m, AGX_CL_OFF_SHAPE) + 4 * sh];
+    const xf_t* X = body_xf(s, CI(m, c, AGX_C_BODY));
+    double cl_[3] = {CF(m, c, AGX_C_AABB_C), CF(m, c, AGX_C_AABB_C + 1), CF(m, c, AGX_C_AABB_C + 2)}, cw[3];
+    xf_apply(X, cl_, cw);
+    const double g = (double)(float)((float)CF(m, c, AGX_C_RADIUS) + 1e-6f);
+    for (int k = 0; k < 3; k++) {
+      const double h = fabs(X->R[3 * k]) * CF(m, c, AGX_C_AABB_H) + fabs(X->R[3 * k + 1]) * CF(m, c, AGX_C_AABB_H + 1) + fabs(X->R[3 * k + 2]) * CF(m, c, AGX_C_AABB_H + 2) + g;
+      slo[sh][k] = cw[k] - h; shi[sh][k] = cw[k] + h;
+    }
+  }
+  typedef struct { double n[3], off; int sh, hit; } wplane_t;                  /* half space n . p >= off + r of a candidate shape */
+  wplane_t (*cand)[WATER_CONTACTS] = (wplane_t (*)[WATER_CONTACTS])malloc(sizeof(wplane_t) * WATER_CONTACTS * NN); int* ncand = (int*)calloc(NN, sizeof(int));
+  for (int i = 0; i < NN; i++) {
+    for (int k = 0; k < 3; k++) q[i][k] = x[i][k];
+    v[i][2] += s->dr_gravity * dt;
+    const double reach = 2 * r + sqrt(dot3(v[i], v[i])) * dt;
+    for (int sh = 0; sh < NS && ncand[i] < WATER_CONTACTS; sh++) {
+      const int only = m->i[oc + CLH(m, AGX_CL_OFF_SHAPE) + 4 * sh + 3];
+      if (only && only != s->gender + 1) continue;
+      int out = 0; for (int k = 0; k < 3; k++) if (q[i][k] < slo[sh][k] - reach || q[i][k] > shi[sh][k] + reach) out = 1;
+      if (out) continue;
+      /* the plane is taken where the substep STARTS (the face the particle is in front of there): re-evaluating the nearest face while the pile
+       * presses a particle into a thin piece would flip it to the far side */
+      double nw[3]; const double d = cloth_shape_distance(s, sh, q[i], nw);
+      if (d >= reach) continue;
+      wplane_t* c = &cand[i][ncand[i]++]; memcpy(c->n, nw, 24); c->off = dot3(nw, q[i]) - d; c->sh = sh; c->hit = 0;
+    }
+    for (int k = 0; k < 3; k++) x[i][k] = q[i][k] + v[i][k] * dt;
+  }
+  double (*dx)[3] = (double (*)[3])malloc(sizeof(double) * 3 * NN);
+  for (int it = 0; it < piter; it++) {
+    for (int i = 0; i < NN; i++) {
+      int cnt = 0; dx[i][0] = dx[i][1] = dx[i][2] = 0;
+      for (int j = 0; j < NN; j++) {
+        if (j == i) continue;
+        double del[3]; sub3(x[i], x[j], del); const double d2 = dot3(del, del);
+        if (d2 >= 4 * r * r) continue;
+        const double d = sqrt(d2);
+        if (d > 1.1920929e-7) { const double sc = 0.5 * (2 * r - d) / d; for (int t = 0; t < 3; t++) dx[i][t] += del[t] * sc; }
+        else dx[i][2] += (i > j ? 1.0 : -1.0) * r;          /* coincident centres: apart along z, the higher index up */
+        cnt++;
+      }
+      if (cnt > 1) for (int t = 0; t < 3; t++) dx[i][t] /= cnt;
+    }
+    for (int i = 0; i < NN; i++) for (int t = 0; t < 3; t++) x[i][t] += dx[i][t];
+    for (int i = 0; i < NN; i++) for (int cc = 0; cc < ncand[i]; cc++) {
+      wplane_t* c = &cand[i][cc]; const double d = dot3(c->n, x[i]) - c->off - r;
+      if (d < 0) { for (int k = 0; k < 3; k++) x[i][k] -= c->n[k] * d; c->hit = 1; }
+    }
+  }
+  s->nccon = 0;
+  for (int i = 0; i < NN; i++) {
+    for (int k = 0; k < 3; k++) v[i][k] = (x[i][k] - q[i][k]) / dt * (1 - kDP);
+    for (int cc = 0; cc < ncand[i]; cc++) {
+      const wplane_t* c = &cand[i][cc];
+      if (!c->hit) continue;
+      const int col = m->i[oc + CLH(m, AGX_CL_OFF_SHAPE) + 4 * c->sh];
+      const double vn = dot3(v[i], c->n), fc = kDF * CF(m, col, AGX_C_FRICTION);
+      for (int k = 0; k < 3; k++) v[i][k] -= (v[i][k] - c->n[k] * vn) * (fc < 1 ? fc : 1);
+      s->ccon_node[s->nccon] = i; s->ccon_shape[s->nccon] = c->sh; double* o = s->ccon + 6 * s->nccon++;
+      for (int k = 0; k < 3; k++) { o[k] = x[i][k]; o[3 + k] = 0; }
+    }
+  }
+  free(slo); free(shi); free(cand); free(ncand); free(dx);
 }
 /* one internal substep; `hooks`: this substep ends a p.stepSimulation() call, after which the reference enforces the human's joint
  * limits and the pose-dependent arm limits (env.py:226-232) */
 static void substep_h(sim_t* s, int hooks) {
   const agxo_model* m = s->m; int n = s->ndof; double dt = m->dt;
   kinematics(s);
-  if (s->cx) cloth_substep(s);   /* one-way coupling: the cloth sees the rigid bodies where this substep starts (btSoftBody::predictMotion precedes the rigid solve) */
+  if (s->cx && m->i[m->o_cloth + AGX_CL_PARTICLES]) water_substep(s);
+  else if (s->cx) cloth_substep(s);   /* one-way coupling: the cloth sees the rigid bodies where this substep starts (btSoftBody::predictMotion precedes the rigid solve) */
   double qdd[MAXDOF];
   aba(s, NULL, 1, qdd); minv_from_aba(s);
   for (int d = 0; d < n; d++) s->vel[d] = s->qd[d] + dt * qdd[d];
@@ -1296,7 +1393,7 @@ static void tool_base_pose_of(const sim_t* s, int tb, double* p, double* R) {
   double rp[3] = {FF(m, tb, AGX_F_REFPOS), FF(m, tb, AGX_F_REFPOS + 1), FF(m, tb, AGX_F_REFPOS + 2)};
   double rq[4] = {FF(m, tb, AGX_F_REFQUAT), FF(m, tb, AGX_F_REFQUAT + 1), FF(m, tb, AGX_F_REFQUAT + 2), FF(m, tb, AGX_F_REFQUAT + 3)}, Rr[9];
   quat_to_mat(rq, Rr); xf_apply(&s->freex[tb], rp, p); mm3(s->freex[tb].R, Rr, R);
-  if (m->task_kind != AGX_TASK_FEEDING) {   /* the frame the task reads: link 1 of the wiper (bed_bathing.py:81) */
+  if (m->task_kind != AGX_TASK_FEEDING && m->task_kind != AGX_TASK_DRINKING) {   /* the frame the task reads: link 1 of the wiper (bed_bathing.py:81); drinking observes the cup's base frame (drinking.py:94) and applies its offset in the reward */
     double op[3] = {TF(m, AGX_T_TOOL_OBS_POS), TF(m, AGX_T_TOOL_OBS_POS + 1), TF(m, AGX_T_TOOL_OBS_POS + 2)};
     double oq[4] = {TF(m, AGX_T_TOOL_OBS_QUAT), TF(m, AGX_T_TOOL_OBS_QUAT + 1), TF(m, AGX_T_TOOL_OBS_QUAT + 2), TF(m, AGX_T_TOOL_OBS_QUAT + 3)}, Ro[9], R2[9], t[3];
     mv3(R, op, t); add3(p, t, p); quat_to_mat(oq, Ro); mm3(R, Ro, R2); memcpy(R, R2, sizeof R2);
@@ -1767,6 +1864,78 @@ static void contact_forces(const sim_t* s, double* robot_f, double* tool_f, int*
   }
 }
 
+/* DrinkingEnv.step after take_step (drinking.py:12-50): observation, get_water_rewards (:52-91), the cup's distance / tilt terms, preferences */
+static void finish_drinking(sim_t* s, double act_norm2, float* obs, float* reward, int* done, float* info) {
+  const agxo_model* m = s->m;
+  update_target(s);
+  double robot_f, tool_f; int hm; contact_forces(s, &robot_f, &tool_f, &hm);
+  observe(s, robot_f, tool_f, obs);                       /* DrinkingEnv._get_obs = FeedingEnv._get_obs with the cup (drinking.py:93-121) */
+  const double total_f = robot_f + tool_f;
+  /* the frame the reward reads the cup in: base frame o ([0, 0.06, 0], rpy (pi/2, 0, 0)) (drinking.py:24,56), top and bottom centres in it */
+  double cp[3], cR[9], p2[3], R2[9], Ro[9], t[3], top[3], bot[3];
+  tool_base_pose(s, cp, cR);
+  const double op[3] = {TF(m, AGX_T_TOOL_OBS_POS), TF(m, AGX_T_TOOL_OBS_POS + 1), TF(m, AGX_T_TOOL_OBS_POS + 2)};
+  const double oq[4] = {TF(m, AGX_T_TOOL_OBS_QUAT), TF(m, AGX_T_TOOL_OBS_QUAT + 1), TF(m, AGX_T_TOOL_OBS_QUAT + 2), TF(m, AGX_T_TOOL_OBS_QUAT + 3)};
+  mv3(cR, op, t); add3(cp, t, p2); quat_to_mat(oq, Ro); mm3(cR, Ro, R2);
+  const double to[3] = {TF(m, AGX_T_DK_TOP), TF(m, AGX_T_DK_TOP + 1), TF(m, AGX_T_DK_TOP + 2)}, bo[3] = {TF(m, AGX_T_DK_BOTTOM), TF(m, AGX_T_DK_BOTTOM + 1), TF(m, AGX_T_DK_BOTTOM + 2)};
+  mv3(R2, to, t); add3(p2, t, top); mv3(R2, bo, t); add3(p2, t, bot);
+  double water_reward = 0, water_hit = 0, vel_sum = 0;
+  const int NN = s->cx ? agxo_cloth_nodes(m) : 0;
+  const uint64_t active_on_entry = s->dk_active;
+  double axis[3]; sub3(bot, top, axis); const double cyl = TF(m, AGX_T_TARGET_RADIUS) * sqrt(dot3(axis, axis));
+  for (int k = 0; k < NN; k++) {
+    if (!(s->dk_alive >> k & 1)) continue;
+    const double* x = s->cx + 3 * k; double a[3], b[3], cr[3];
+    sub3(x, top, a); sub3(x, bot, b); cross3(a, axis, cr);
+    const int inside = dot3(a, axis) >= 0 && dot3(b, axis) <= 0 && sqrt(dot3(cr, cr)) <= cyl;       /* Util.points_in_cylinder (util.py:53-56) */
+    if (inside) continue;
+    double d[3]; sub3(s->target, x, d);
+    if (sqrt(dot3(d, d)) < TF(m, AGX_T_MOUTH_DIST)) {                                               /* in the mouth (drinking.py:66-75) */
+      water_reward += 10; s->success += 1; vel_sum += sqrt(dot3(s->cv + 3 * k, s->cv + 3 * k));
+      s->dk_alive &= ~(1ull << k); s->dk_active &= ~(1ull << k);
+      for (int q = 0; q < 3; q++) s->cx[3 * k + q] = 1000.0 + 1000.0 * (rng_next(s->rng) >> 8) * (1.0 / 16777216.0);
+      continue;
+    }
+    /* w.get_closest_points(self.tool, distance=0.1) empty -> spilled (drinking.py:77-80): the particle against the cup's pieces */
+    int near = 0;
+    const int NS = m->i[m->o_cloth + AGX_CL_NSHAPE];
+    for (int sh = 0; sh < NS && !near; sh++) {
+      const int c = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * sh];
+      if (CI(m, c, AGX_C_TAG) != AGX_TAG_TOOL) continue;
+      double nw[3]; if (cloth_shape_distance(s, sh, x, nw) - CLPAR(m, AGX_CP_MARGIN) <= TF(m, AGX_T_SPILL_DIST)) near = 1;
+    }
+    if (!near) { water_reward -= 1; s->dk_alive &= ~(1ull << k); }
+  }
+  /* waters_active as it was on entry (drinking.py:81-85; the list is only filtered after both loops): a particle that touches the person */
+  uint64_t counted = 0;
+  for (int c = 0; c < s->nccon; c++) {
+    const int k = s->ccon_node[c], col = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * s->ccon_shape[c]];
+    if (CI(m, col, AGX_C_TAG) == AGX_TAG_HUMAN && (active_on_entry >> k & 1) && !(counted >> k & 1)) { water_hit -= 1; counted |= 1ull << k; s->dk_active &= ~(1ull << k); }
+  }
+  xf_t ee; ee_frame(s, &ee);
+  int L = TI(m, AGX_T_EE_LINK); double wxp[3], vee[3];
+  cross3(s->vsp[L], ee.p, wxp); add3(s->vsp[L] + 3, wxp, vee);
+  const double ee_speed = sqrt(dot3(vee, vee));
+  const double pref = TF(m, AGX_T_C_V) * (-ee_speed) + TF(m, AGX_T_C_F) * (-total_f) + TF(m, AGX_T_C_HF) * (tool_f < 10 ? 0.0 : -tool_f)
+                    + TF(m, AGX_T_C_FD) * water_hit + TF(m, AGX_T_C_FDV) * (-vel_sum);              /* env.py:249-256, the feeding / drinking branch */
+  double dd[3]; sub3(s->target, top, dd);
+  /* cup_euler[0]: roll of the offset frame, btQuaternion::getEulerZYX as p.getEulerFromQuaternion returns it (drinking.py:30-31) */
+  double q[4]; mat_to_quat(R2, q);
+  const double sarg = -2.0 * (q[0] * q[2] - q[3] * q[1]);
+  const double roll = (sarg <= -0.99999 || sarg >= 0.99999) ? 0.0 : atan2(2 * (q[1] * q[2] + q[3] * q[0]), q[3] * q[3] - q[0] * q[0] - q[1] * q[1] + q[2] * q[2]);
+  const double r = TF(m, AGX_T_W_DISTANCE) * (-sqrt(dot3(dd, dd))) + TF(m, AGX_T_W_ACTION) * (-sqrt(act_norm2)) + TF(m, AGX_T_W_TILT) * (-fabs(roll - M_PI / 2))
+                 + TF(m, AGX_T_W_FOOD) * water_reward + pref;
+  *reward = (float)r;
+  *done = s->iteration >= (int)TF(m, AGX_T_EPISODE_LEN);
+  if (info) {
+    info[AGX_INFO_TOTAL_FORCE] = (float)total_f;
+    info[AGX_INFO_TASK_SUCCESS] = (float)(s->success >= s->total_food * TF(m, AGX_T_SUCCESS_FRAC));
+    info[AGX_INFO_ROBOT_FORCE] = (float)robot_f; info[AGX_INFO_TOOL_FORCE] = (float)tool_f;
+    info[AGX_INFO_FOOD_REWARD] = (float)water_reward; info[AGX_INFO_PREF] = (float)pref;
+    info[AGX_INFO_NCONTACT] = (float)s->ncon; info[AGX_INFO_NROWS] = (float)s->nrows;
+  }
+}
+
 void agxo_observe(const agxo_model* m, const float* state, float* obs) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state); kinematics(s); update_target(s);
   if (m->task_kind == AGX_TASK_BED_BATHING) observe_bed(s, 0, 0, 0, obs);
@@ -1783,14 +1952,16 @@ static void cloth_attach(sim_t* s, const float* cloth) {
   if (!cloth || !s->m->o_cloth) return;
   const int n3 = 3 * agxo_cloth_nodes(s->m);
   s->cx = (double*)malloc(sizeof(double) * n3); s->cv = (double*)malloc(sizeof(double) * n3); s->cq = (double*)malloc(sizeof(double) * n3);
-  s->ccon = (double*)malloc(sizeof(double) * 6 * CLOTH_NODE_CONTACTS * (n3 / 3));
+  const int per = CLOTH_NODE_CONTACTS > 12 ? CLOTH_NODE_CONTACTS : 12;    /* (water: WATER_CONTACTS candidates per particle) */
+  s->ccon = (double*)malloc(sizeof(double) * 6 * per * (n3 / 3));
+  s->ccon_node = (int*)malloc(sizeof(int) * per * (n3 / 3)); s->ccon_shape = (int*)malloc(sizeof(int) * per * (n3 / 3));
   for (int k = 0; k < n3; k++) { s->cx[k] = cloth[k]; s->cv[k] = cloth[n3 + k]; }
 }
 static void cloth_detach(sim_t* s, float* cloth) {
   if (!s->cx) return;
   const int n3 = 3 * agxo_cloth_nodes(s->m);
   for (int k = 0; k < n3; k++) { cloth[k] = (float)s->cx[k]; cloth[n3 + k] = (float)s->cv[k]; }
-  free(s->cx); free(s->cv); free(s->cq); free(s->ccon); s->cx = NULL;
+  free(s->cx); free(s->cv); free(s->cq); free(s->ccon); free(s->ccon_node); free(s->ccon_shape); s->cx = NULL;
 }
 void agxo_settle_cloth(const agxo_model* m, float* state, float* cloth, int n_sim_steps) {
   sim_t* s = (sim_t*)malloc(sizeof *s); sim_load(s, m, state);
@@ -1852,6 +2023,7 @@ void agxo_step_cloth(const agxo_model* m, float* state, float* cloth, const floa
     g_nccon = s->cx ? (s->nccon < 4096 ? s->nccon : 4096) : 0; if (g_nccon) memcpy(g_ccon, s->ccon, sizeof(double) * 6 * g_nccon);
     cloth_detach(s, cloth); sim_store(s, state); free(s->rows); free(s); return;
   }
+  if (m->task_kind == AGX_TASK_DRINKING) { finish_drinking(s, act_norm2, obs, reward, done, info); cloth_detach(s, cloth); sim_store(s, state); free(s->rows); free(s); return; }
   if (m->task_kind == AGX_TASK_BED_BATHING) { finish_bed(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   if (m->task_kind == AGX_TASK_SCRATCH_ITCH) { finish_scratch(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
   if (m->task_kind == AGX_TASK_ARM_MANIPULATION) { finish_arm(s, action, obs, reward, done, info); sim_store(s, state); free(s->rows); free(s); return; }
@@ -2013,7 +2185,7 @@ void agxo_world_store(agxo_world* w, float* state, float* cloth) {
 }
 void agxo_world_free(agxo_world* w) {
   if (!w) return;
-  if (w->s.cx) { free(w->s.cx); free(w->s.cv); free(w->s.cq); free(w->s.ccon); }
+  if (w->s.cx) { free(w->s.cx); free(w->s.cv); free(w->s.cq); free(w->s.ccon); free(w->s.ccon_node); free(w->s.ccon_shape); }
   free(w->s.rows); free(w);
 }
 /* getJointStates / resetJointState / setJointMotorControlArray(targetPositions) by DoF */

@@ -6,7 +6,7 @@ import numpy as np
 from assistive_gym_amd.blob import ModelBlob
 from assistive_gym_amd.model import compiler as L
 from oracle_lib import Oracle
-names = sorted(f[:-8] for f in os.listdir(os.path.join(ROOT, 'assistive_gym_amd', 'data')) if f.endswith('.agxblob') and f != 'bed_settle.agxblob' and not f.startswith('dressing'))
+names = sorted(f[:-8] for f in os.listdir(os.path.join(ROOT, 'assistive_gym_amd', 'data')) if f.endswith('.agxblob') and f != 'bed_settle.agxblob' and not f.startswith('dressing') and not f.startswith('drinking'))
 w = int(sys.argv[1]); names = names[w::4]
 def states(b, seed):
     k = b.task_kind

@@ -1,0 +1,116 @@
+"""DrinkingJaco-v1 (assistive_gym/envs/drinking.py) -- MODEL AND CPU ORACLE ONLY so far (no kernel variant serves the task): the
+model blob against the reference's tables, the host reset, the water particles in the oracle (they come to rest in the cup, stay in it while
+it tilts a little, pour out when it tips over), and the task layer's terms against a numpy restatement.  The reference's own step() runs
+on this oracle through tests/refbridge (test_reference_pinned.py).  PARITY UNPINNED vs PyBullet (the physics half)."""
+import numpy as np
+import pytest
+
+from assistive_gym_amd.model import compiler as L
+from assistive_gym_amd.model import xform as X
+
+
+@pytest.fixture(scope='module')
+def dk():
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    b = ModelBlob.load('drinking_jaco')
+    return b, Oracle(b)
+
+
+@pytest.fixture(scope='module')
+def settled(dk):
+    from assistive_gym_amd.host.reset_drinking import make_states
+    b, o = dk
+    st, water, infos = make_states(b, 1, seed=3, impairment='none')
+    s, w = st[0].copy(), water[0].copy()
+    o.settle_cloth(s, w, 50)                                                                        # drinking.py:176-177
+    return s, w, infos[0]
+
+
+def _in_cup(b, s, w):
+    v = b.view(s[None])
+    tp, tq = v['free'][0, 0, :3].astype(np.float64), v['free'][0, 0, 3:7].astype(np.float64)
+    rel = np.array([X.quat_rotate(X.quat_conj(tq), p - tp) for p in w[0].astype(np.float64)])       # the cup's axis is its mesh y axis
+    return (np.hypot(rel[:, 0], rel[:, 2]) < 0.04) & (rel[:, 1] > 0) & (rel[:, 1] < 0.13), rel
+
+
+def test_model_tables(dk):
+    b, o = dk
+    assert b.task_kind == L.TASK_DRINKING and (b.act_dim, b.obs_dim, b.nhdof, b.nfree) == (7, 25, 4, 1) and b.h['SIM_SUBSTEPS'] == 4      # drinking.py:8,157
+    assert b.param('NITER') == 10                                                                                                      # numSolverIterations (:157)
+    arm = [d for d in range(b.nrobot) if b.robot_i(d, 'ACT') >= 0]
+    assert np.isclose(b.robot_f(arm[0], 'KP'), 0.005)                                                                                  # :130
+    assert np.allclose([b.robot_f(d, 'QT0') for d in range(b.nrobot) if b.robot_i(d, 'ACT') < 0], 0.63)                                # jaco.py:21
+    assert np.allclose(b.task_f('TOOL_POS', 3), [0.05, -0.005, 0]) and np.allclose(b.task_f('TOOL_QUAT', 4), X.quat_from_rpy([0, -np.pi / 2, np.pi / 2]))   # jaco.py:27,32
+    assert np.isclose(b.task_f('W_WIPE'), 0.1) and np.isclose(b.task_f('SUCCESS_FRAC'), 0.75) and np.isclose(b.task_f('TARGET_RADIUS'), 0.05)               # config.ini:24,26; drinking.py:64
+    oc = b.h['OFF_CLOTH']
+    assert b.i[oc + L.CL['NN']] == 64 and b.i[oc + L.CL['PARTICLES']] == 1 and b.i[oc + L.CL['NL']] == 0
+    r = b.meta['ranges']
+    assert r['tool'][1] - r['tool'][0] == 68                                                                                           # the cup's convex pieces
+    x0 = b.f[oc + int(b.i[oc + L.CL['OFF_X0']]):oc + int(b.i[oc + L.CL['OFF_X0']]) + 192].reshape(64, 3)
+    assert np.allclose(np.unique(np.round(x0[:, 0], 6)), [-0.02, -0.01, 0.0, 0.01]) and np.allclose(np.unique(np.round(x0[:, 2], 6)), [0.075, 0.085, 0.095, 0.105])   # :163-167
+
+
+def test_no_kernel_variant_serves_the_task_yet(dk):
+    """the product refuses the blob loudly (no CPU path, no silent fallback): only checked where a GPU library can be loaded at all"""
+    from assistive_gym_amd.envs import ENV_IDS
+    assert not any(k.startswith('Drinking') for k in ENV_IDS)
+
+
+def test_water_rests_in_the_cup(dk, settled):
+    b, o = dk
+    s, w, info = settled
+    assert info['ik_ok']
+    inside, rel = _in_cup(b, s, w)
+    assert inside.all() and np.linalg.norm(w[1], axis=1).max() < 0.02
+    assert 0.010 < rel[:, 1].min() < 0.014 and rel[:, 1].max() < 0.045                      # on the bottom (6.5 mm + the radius), three to four layers
+    d = np.linalg.norm(w[0][:, None] - w[0][None], axis=2) + np.eye(64)
+    assert d.min() > 0.0085                                                                 # spheres of 5 mm radius: the projection leaves them at most 15 % compressed
+    v = b.view(s[None])
+    assert v['total_food'][0] == 64 and v['task'][0][L.DK['ALIVE']] == -1 and v['task'][0][L.DK['ALIVE'] + 1] == -1
+
+
+def test_water_stays_when_tilted_a_little_and_pours_when_tipped_over(dk, settled):
+    b, o = dk
+    s, w, _ = settled
+    s, w = s.copy(), w.copy()
+    a = np.zeros(7, np.float32); a[4], a[5], a[6] = 0.5, 1.0, 1.0
+    water_reward = 0.0
+    for k in range(25):
+        obs, rew, done, info = o.step_cloth(s, w, a)
+        water_reward += info[4]
+    assert _in_cup(b, s, w)[0].all() and water_reward == 0                                   # tilted by about 25 degrees: nothing spilled
+    for k in range(60):
+        obs, rew, done, info = o.step_cloth(s, w, a)
+        water_reward += info[4]
+    inside, _ = _in_cup(b, s, w)
+    v = b.view(s[None])
+    alive = bin(int(v['task'][0][L.DK['ALIVE']]) & 0xffffffff).count('1') + bin(int(v['task'][0][L.DK['ALIVE'] + 1]) & 0xffffffff).count('1')
+    assert inside.sum() < 10 and alive < 10 and water_reward == -(64 - alive)               # upside down: each particle further than 0.1 m from the cup costs 1 (drinking.py:77-80)
+    assert np.isfinite(obs).all() and np.isfinite(rew)
+
+
+def test_reward_terms(dk, settled):
+    """distance of the cup's top centre to the mouth, the action norm, the tilt term and the preferences (drinking.py:19-33, env.py:249-256)"""
+    b, o = dk
+    s, w, _ = settled
+    s, w = s.copy(), w.copy()
+    a = np.array([0.3, -0.2, 0.1, 0.5, -0.4, 0.2, 0.1], np.float32)
+    obs, rew, done, info = o.step_cloth(s, w, a)
+    v = b.view(s[None])
+    tp, tq = v['free'][0, 0, :3].astype(np.float64), v['free'][0, 0, 3:7].astype(np.float64)
+    cp, cq = X.compose(tp, tq, np.array([0, 0.06, 0]), X.quat_from_rpy([np.pi / 2, 0, 0]))                # drinking.py:24
+    top, _ = X.compose(cp, cq, np.array([0, 0, -0.055]), np.array([0, 0, 0, 1.0]))                          # :25, 138
+    x, y, z, ww = cq
+    roll = np.arctan2(2 * (y * z + ww * x), ww * ww - x * x - y * y + z * z)                                # p.getEulerFromQuaternion
+    ee_v = np.linalg.norm(o.world_frame_velocity(s, b.task_i('EE_LINK'))) if hasattr(o, 'world_frame_velocity') else None
+    want_wo_pref = -np.linalg.norm(v['target'][0].astype(np.float64) - top) - 0.01 * np.linalg.norm(a) - 0.1 * abs(roll - np.pi / 2)
+    assert abs((rew - info[5]) - want_wo_pref) < 2e-5                                                       # info[5] = the preferences score
+    assert info[5] <= 0 and obs.shape == (25,) and not done
+    # the observation is the feeding one with the cup (drinking.py:93-106): cup pose in the robot's base frame, cup - mouth, joint angles, head pose, force
+    bp, bq = v['base'][0, :3].astype(np.float64), v['base'][0, 3:].astype(np.float64)
+    ip, iq = X.invert(bp, bq)
+    cup_real, _ = X.compose(ip, iq, tp, tq)
+    assert np.allclose(obs[:3], cup_real, atol=1e-5)
+    mouth_real, _ = X.compose(ip, iq, v['target'][0].astype(np.float64), np.array([0, 0, 0, 1.0]))
+    assert np.allclose(obs[7:10], cup_real - mouth_real, atol=1e-5)

@@ -200,7 +200,8 @@ def test_task_constants_are_the_reference_config():
     from assistive_gym_amd.blob import ModelBlob, DATA_DIR
     from assistive_gym_amd.model import compiler as L
     cfg = lambda sec, key: float(UNITS['config/%s/%s' % (sec, key)])
-    sec_of = {L.TASK_FEEDING: 'feeding', L.TASK_BED_BATHING: 'bed_bathing', L.TASK_SCRATCH_ITCH: 'scratch_itch', L.TASK_DRESSING: 'dressing', L.TASK_ARM_MANIPULATION: 'arm_manipulation'}
+    sec_of = {L.TASK_FEEDING: 'feeding', L.TASK_BED_BATHING: 'bed_bathing', L.TASK_SCRATCH_ITCH: 'scratch_itch', L.TASK_DRESSING: 'dressing', L.TASK_ARM_MANIPULATION: 'arm_manipulation',
+              L.TASK_DRINKING: 'drinking'}
     n = 0
     for path in sorted(glob.glob(os.path.join(DATA_DIR, '*.agxblob'))):
         b = ModelBlob.load(os.path.basename(path)[:-len('.agxblob')])
@@ -211,10 +212,12 @@ def test_task_constants_are_the_reference_config():
         assert b.task_f('W_ACTION') == f32(cfg(sec, 'action_weight')) and b.task_f('SUCCESS_FRAC') == f32(cfg(sec, 'task_success_threshold'))
         # the food terms exist in the feeding blobs only (the other tasks never pass food arguments to human_preferences)
         for key, tag in (('C_V', 'velocity_weight'), ('C_F', 'force_nontarget_weight'), ('C_HF', 'high_forces_weight')) + \
-                ((('C_FD', 'food_hit_weight'), ('C_FDV', 'food_velocities_weight')) if b.task_kind == L.TASK_FEEDING else ()):
+                ((('C_FD', 'food_hit_weight'), ('C_FDV', 'food_velocities_weight')) if b.task_kind in (L.TASK_FEEDING, L.TASK_DRINKING) else ()):
             assert b.task_f(key) == f32(cfg('human_preferences', tag)), (path, key)
         if b.task_kind == L.TASK_FEEDING:
             assert b.task_f('W_DISTANCE') == f32(cfg(sec, 'distance_weight')) and b.task_f('W_FOOD') == f32(cfg(sec, 'food_reward_weight'))
+        if b.task_kind == L.TASK_DRINKING:        # (model and oracle only so far)
+            assert b.task_f('W_DISTANCE') == f32(cfg(sec, 'distance_weight')) and b.task_f('W_FOOD') == f32(cfg(sec, 'drinking_reward_weight')) and b.task_f('W_WIPE') == f32(cfg(sec, 'cup_tilt_weight'))
         if b.task_kind == L.TASK_BED_BATHING:
             assert b.task_f('W_DISTANCE') == f32(cfg(sec, 'distance_weight')) and b.task_f('W_WIPE') == f32(cfg(sec, 'wiping_reward_weight'))
         if b.task_kind == L.TASK_SCRATCH_ITCH:
