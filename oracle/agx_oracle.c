@@ -1018,7 +1018,7 @@ static void pgs(sim_t* s, double* dv) {
 
 /* FeedingEnv.update_targets (feeding.py:192-196): mouth = head pose o mouth offset */
 static void update_target(sim_t* s) {
-  const agxo_model* m = s->m; if (m->task_kind != AGX_TASK_FEEDING) return;
+  const agxo_model* m = s->m; if (m->task_kind != AGX_TASK_FEEDING && m->task_kind != AGX_TASK_DRINKING) return;   /* feeding.py:192-196, drinking.py:192-196 */
   int hl = TI(m, AGX_T_HEAD_LINK), o = s->gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
   double mp[3] = {TF(m, o), TF(m, o + 1), TF(m, o + 2)};
   xf_apply(&s->link[hl], mp, s->target);   /* link frames of the CURRENT kinematics() call */
@@ -2284,6 +2284,36 @@ int agxo_world_cloth(agxo_world* w, double* x, double* contacts, int max_contact
   return s->nccon;
 }
 void agxo_world_set_cloth_gravity(agxo_world* w, double gz) { w->s.dr_gravity = gz; }
+/* a water particle as the body the reference holds it as (drinking.py:52-91): getBasePositionAndOrientation / getBaseVelocity,
+ * resetBasePositionAndOrientation (velocity kept, as Bullet does), and the two proximity queries of get_water_rewards --
+ * bit 0: getClosestPoints(water, tool, dist) is not empty (surface distance of the sphere to a piece of the cup <= dist),
+ * bit 1: getContactPoints(water, human) is not empty (a person's shape among the particle's contacts of the last internal substep) */
+int agxo_world_particle(agxo_world* w, int k, double* pos, double* vel) {
+  sim_t* s = &w->s; if (!s->cx || k < 0 || k >= agxo_cloth_nodes(s->m)) return 0;
+  if (pos) memcpy(pos, s->cx + 3 * k, 24);
+  if (vel) memcpy(vel, s->cv + 3 * k, 24);
+  return 1;
+}
+void agxo_world_set_particle(agxo_world* w, int k, const double* pos) {
+  sim_t* s = &w->s; if (!s->cx || k < 0 || k >= agxo_cloth_nodes(s->m)) return;
+  memcpy(s->cx + 3 * k, pos, 24);
+}
+int agxo_world_particle_query(agxo_world* w, int k, double dist) {
+  sim_t* s = &w->s; const agxo_model* m = s->m; if (!s->cx || k < 0 || k >= agxo_cloth_nodes(m)) return 0;
+  world_refresh(w);
+  int out = 0; const int NS = m->i[m->o_cloth + AGX_CL_NSHAPE];
+  for (int sh = 0; sh < NS && !out; sh++) {
+    const int c = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * sh];
+    if (CI(m, c, AGX_C_TAG) != AGX_TAG_TOOL) continue;
+    double nw[3]; if (cloth_shape_distance(s, sh, s->cx + 3 * k, nw) - CLPAR(m, AGX_CP_MARGIN) <= dist) out = 1;
+  }
+  for (int c = 0; c < s->nccon; c++) {
+    if (s->ccon_node[c] != k) continue;
+    const int col = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * s->ccon_shape[c]];
+    if (CI(m, col, AGX_C_TAG) == AGX_TAG_HUMAN) out |= 2;
+  }
+  return out;
+}
 /* Util.sleeve_on_arm_reward as finish_dressing evaluates it (util.py:134-202), for direct comparison with the reference's function:
  * pts[6][3], shoulder / elbow / wrist, the common radius -> out[9] = {forearm_in_sleeve, upperarm_in_sleeve, distance_along_forearm,
  * distance_along_upperarm, distance_to_hand, distance_to_elbow, distance_to_shoulder, forearm_length, upperarm_length} */

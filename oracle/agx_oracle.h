@@ -86,6 +86,11 @@ int agxo_world_frame(agxo_world* w, int kind, int index, double* pos3, double* q
 int agxo_world_contacts(agxo_world* w, double* out16, int max_out);
 int agxo_world_closest(agxo_world* w, const int* ca, int na, const int* cb, int nb, double dist, double* out9, int max_out);
 int agxo_world_cloth(agxo_world* w, double* x, double* contacts6, int max_contacts);
+/* a water particle as a body (DrinkingEnv.get_water_rewards, drinking.py:52-91): pose / velocity, teleport, and the two proximity
+ * queries (bit 0: within `dist` of the cup, bit 1: touched the person in the last internal substep) */
+int agxo_world_particle(agxo_world* w, int k, double* pos, double* vel);
+void agxo_world_set_particle(agxo_world* w, int k, const double* pos);
+int agxo_world_particle_query(agxo_world* w, int k, double dist);
 void agxo_sleeve_reward(const double* pts6, const double* shoulder, const double* elbow, const double* wrist, double rad, double* out9);
 
 #ifdef __cplusplus

@@ -31,6 +31,7 @@ def extras_of(env, task):
     if task == 'feeding': return g('robot_force_on_human', 'spoon_force_on_human')
     if task == 'bed_bathing': return g('tool_force', 'tool_force_on_human', 'total_force_on_human', 'new_contact_points')
     if task == 'scratch_itch': return g('total_force_on_human', 'tool_force', 'tool_force_at_target')
+    if task == 'drinking': return g('robot_force_on_human', 'cup_force_on_human')
     if task == 'arm_manipulation': return g('tool_right_force', 'tool_left_force', 'tool_right_force_on_human', 'tool_left_force_on_human', 'total_force_on_human')
     return g('cloth_force_sum', 'robot_force_on_human', 'forearm_in_sleeve', 'upperarm_in_sleeve')
 
@@ -53,6 +54,7 @@ def make_steps():
         out[n + '/lens'] = np.array([r['info'][k] for k in ('action_robot_len', 'action_human_len', 'obs_robot_len', 'obs_human_len')], dtype=np.int32)
         out[n + '/extras'] = extras_of(r['env'], rb.TASK_OF_KIND[b.task_kind])
         out[n + '/state_out'] = r['state']
+        if b.task_kind == 5: out[n + '/cloth_out'] = r['cloth']         # the water after the step (the garment's nodes are not kept: 2 x 3268 x 3 per case)
         out[n + '/meta'] = np.array([c['model'], '1' if c['coop'] else '0', c['variant']])
         w.close()
         print('%-46s reward %10.4f  force %9.3f  success %d' % (n, r['reward'], r['info']['total_force_on_human'], r['info']['task_success']))

@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 # body unique ids of the facade
 PLANE, ROBOT, HUMAN, FURNITURE, TOOL, TOOL2, TABLE, BOWL, ATTACH, CLOTH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-FOOD0, MARKER0 = 100, 1000
+FOOD0, WATER0, MARKER0 = 100, 200, 1000       # food / water particle k is body FOOD0 + k / WATER0 + k
 TAG_ROBOT, TAG_TOOL, TAG_HUMAN, TAG_FOOD, TAG_BOWL, TAG_TABLE, TAG_PLANE, TAG_WHEELCHAIR, TAG_BED = 1, 2, 3, 4, 5, 6, 7, 8, 9
 BODY_FREE0, BODY_HUMAN0 = 200, 300
 
@@ -112,8 +112,12 @@ def _lib():
         L.agxo_world_reset_joint.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.agxo_world_set_target.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.agxo_world_set_cloth_gravity.argtypes = [C.c_void_p, C.c_double]
-        for n in ('agxo_world_frame', 'agxo_world_contacts', 'agxo_world_closest', 'agxo_world_cloth'):
+        for n in ('agxo_world_frame', 'agxo_world_contacts', 'agxo_world_closest', 'agxo_world_cloth', 'agxo_world_particle', 'agxo_world_particle_query'):
             getattr(L, n).restype = C.c_int
+        L.agxo_world_set_particle.restype = None
+        L.agxo_world_particle.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.agxo_world_set_particle.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.agxo_world_particle_query.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L._world_ready = True
     return L
 
@@ -147,6 +151,8 @@ class World:
         self.tool_body = blob.h['TOOL_BODY']
         self.tool2_body = blob.task_i('TOOL2_BODY')
         self.food0, self.nfood = blob.h['FOOD0'], blob.nfood
+        oc = blob.h['OFF_CLOTH']
+        self.nwater = int(blob.i[oc + 0]) if (oc and blob.task_kind == 5) else 0      # AGX_CL_NN of a particle section (drinking)
         self.bowl_body = None
         for b in range(blob.nfree):
             if int(blob.i[blob.h['OFF_FREE'] + b * 16 + 12]) == 2:
@@ -213,6 +219,10 @@ class World:
             return self.frame(1, self.bowl_body, vel)
         elif FOOD0 <= body < FOOD0 + self.nfood and link == -1:
             return self.frame(1, self.food0 + body - FOOD0, vel)
+        elif WATER0 <= body < WATER0 + self.nwater and link == -1:
+            pos, lin = np.zeros(3), np.zeros(3)
+            assert self.L.agxo_world_particle(self.h, body - WATER0, _p(pos), _p(lin))
+            return (pos, np.array([0, 0, 0, 1.0]), lin, np.zeros(3)) if vel else (pos, np.array([0, 0, 0, 1.0]))
         elif body in self.markers and link == -1:
             z = np.zeros(3)
             return (self.markers[body], np.array([0, 0, 0, 1.0]), z, z) if vel else (self.markers[body], np.array([0, 0, 0, 1.0]))
@@ -391,6 +401,8 @@ def make_pybullet(get_world):
             w.markers[body] = np.asarray(pos, dtype=np.float64).copy()
             if body == getattr(w, 'attach_marker', None):
                 w.L.agxo_world_set_anchor(w.h, _p(np.ascontiguousarray(pos, dtype=np.float64)))
+        elif WATER0 <= body < WATER0 + w.nwater:
+            w.L.agxo_world_set_particle(w.h, body - WATER0, _p(np.ascontiguousarray(pos, dtype=np.float64)))
         elif FOOD0 <= body < FOOD0 + w.nfood:
             w.L.agxo_world_set_free_base(w.h, C.c_int(w.food0 + body - FOOD0), _p(np.ascontiguousarray(pos, dtype=np.float64)), _p(np.ascontiguousarray(orn, dtype=np.float64)))
         else:
@@ -404,8 +416,16 @@ def make_pybullet(get_world):
         if swap: ba, la, bb, lb, pa, pb, n = bb, lb, ba, la, pb, pa, -n
         return (0, ba, bb, la, lb, tuple(pa), tuple(pb), tuple(n), float(row[11]), float(row[12]), 0.0, (0, 0, 0), 0.0, (0, 0, 0))
 
+    def _water_tuple(w, body, other):
+        pos = tuple(w.link_frame(body, -1)[0])
+        return (0, body, other, -1, -1, pos, pos, (0.0, 0.0, 1.0), 0.0, 0.0, 0.0, (0, 0, 0), 0.0, (0, 0, 0))
+
     def getContactPoints(bodyA=None, bodyB=None, linkIndexA=None, linkIndexB=None, physicsClientId=0):
         w = W(); out = []
+        if bodyA is not None and WATER0 <= bodyA < WATER0 + w.nwater:
+            # a water particle: only WHETHER it touches the person is backed (drinking.py:85 reads the length of the list)
+            assert bodyB == HUMAN, 'contacts of a water particle: only against the person'
+            return (_water_tuple(w, bodyA, HUMAN),) if w.L.agxo_world_particle_query(w.h, bodyA - WATER0, 0.0) & 2 else ()
         for row in w.contacts():
             (ba, la), (bb, lb) = w.coll[int(row[0])], w.coll[int(row[1])]
             for swap in (False, True):
@@ -420,6 +440,9 @@ def make_pybullet(get_world):
 
     def getClosestPoints(bodyA, bodyB, distance, linkIndexA=None, linkIndexB=None, physicsClientId=0):
         w = W()
+        if WATER0 <= bodyA < WATER0 + w.nwater:
+            assert bodyB == TOOL, 'closest points of a water particle: only against the cup (drinking.py:77)'
+            return (_water_tuple(w, bodyA, TOOL),) if w.L.agxo_world_particle_query(w.h, bodyA - WATER0, float(distance)) & 1 else ()
         rows = w.closest(w.colliders_of(bodyA, linkIndexA), w.colliders_of(bodyB, linkIndexB), float(distance))
         out = []
         for r in rows:
@@ -510,15 +533,15 @@ def reference_envs():
     sub = types.ModuleType(name + '.envs'); sub.__path__ = [os.path.join(REF_ROOT, 'assistive_gym', 'envs')]
     sys.modules[name], sys.modules[name + '.envs'] = pkg, sub
     pkg.envs = sub
-    for m in ('feeding_envs', 'bed_bathing_envs', 'scratch_itch_envs', 'dressing_envs', 'arm_manipulation_envs'):
+    for m in ('feeding_envs', 'bed_bathing_envs', 'scratch_itch_envs', 'dressing_envs', 'arm_manipulation_envs', 'drinking_envs'):
         setattr(sub, m, importlib.import_module('%s.envs.%s' % (name, m)))
     return sub
 
 
 # ------------------------------------------------------------------------------------------------ adopting a state record
-TASK_OF_KIND = {0: 'feeding', 1: 'bed_bathing', 2: 'scratch_itch', 3: 'dressing', 4: 'arm_manipulation'}
+TASK_OF_KIND = {0: 'feeding', 1: 'bed_bathing', 2: 'scratch_itch', 3: 'dressing', 4: 'arm_manipulation', 5: 'drinking'}
 ROBOT_CLASS = {'jaco': 'Jaco', 'sawyer': 'Sawyer', 'pr2': 'PR2', 'baxter': 'Baxter', 'panda': 'Panda', 'stretch': 'Stretch'}
-TASK_CLASS = {'feeding': 'Feeding', 'bed_bathing': 'BedBathing', 'scratch_itch': 'ScratchItch', 'dressing': 'Dressing', 'arm_manipulation': 'ArmManipulation'}
+TASK_CLASS = {'feeding': 'Feeding', 'bed_bathing': 'BedBathing', 'scratch_itch': 'ScratchItch', 'dressing': 'Dressing', 'arm_manipulation': 'ArmManipulation', 'drinking': 'Drinking'}
 
 
 def adopt(blob, state, cloth=None):
@@ -543,8 +566,8 @@ def adopt(blob, state, cloth=None):
     links = [j for (b, j) in w.dof_of if b == ROBOT]
     ee = [R.right_end_effector, R.left_end_effector]
     w.n_robot_joints = max(links + ee + R.controllable_joint_indices) + 1
-    w.n_tool_links = 0 if task in ('feeding', 'arm_manipulation') else 2      # spoon / scooper: one body; wiper.urdf, tool_scratch.urdf: links 0, 1
-    arm_right = task in ('feeding', 'arm_manipulation')                        # feeding.py:142 arm='right'; bed_bathing.py:147, scratch_itch.py:116, dressing.py:134 arm='left'
+    w.n_tool_links = 0 if task in ('feeding', 'arm_manipulation', 'drinking') else 2      # spoon / scooper / cup: one body; wiper.urdf, tool_scratch.urdf: links 0, 1
+    arm_right = task in ('feeding', 'arm_manipulation', 'drinking')            # feeding.py:142, drinking.py:150 arm='right'; bed_bathing.py:147, scratch_itch.py:116, dressing.py:134 arm='left'
     w.ee_links = {(R.right_end_effector if arm_right else R.left_end_effector): 0}
     if task == 'arm_manipulation' and not R.has_single_arm:
         w.ee_links[R.left_end_effector] = 1
@@ -588,6 +611,19 @@ def adopt(blob, state, cloth=None):
             if alive >> k & 1: env.foods.append(f)
             if active >> k & 1: env.foods_active.append(f)
         env.total_food_count = int(v['total_food'][0])                         # feeding.py:169
+        env.task_success = int(v['task_success'][0])
+    elif task == 'drinking':
+        R.motor_gains = H.motor_gains = 0.005                                  # drinking.py:130
+        env.generate_target()                                                  # drinking.py:184-196
+        env.cup_top_center_offset, env.cup_bottom_center_offset = np.array([0, 0, -0.055]), np.array([0, 0, 0.07])      # drinking.py:142-143
+        tw = [int(x) & 0xffffffff for x in v['task'][0][:4]]                  # AGX_DK_ALIVE / AGX_DK_ACTIVE: 64-bit masks in two words each
+        alive, active = tw[0] | tw[1] << 32, tw[2] | tw[3] << 32
+        env.waters, env.waters_active = [], []
+        for k in range(w.nwater):
+            f = Agent(); f.init(WATER0 + k, env.id, env.np_random, indices=-1)
+            if alive >> k & 1: env.waters.append(f)
+            if active >> k & 1: env.waters_active.append(f)
+        env.total_water_count = int(v['total_food'][0])                        # drinking.py:171
         env.task_success = int(v['task_success'][0])
     elif task == 'bed_bathing':
         w.first_target_marker = w.next_marker + 1
@@ -678,6 +714,11 @@ def writeback(env, w, state):
         v['target'][0] = env.target_pos
         alive = sum(1 << (f.body - FOOD0) for f in env.foods); active = sum(1 << (f.body - FOOD0) for f in env.foods_active)
         v['food_alive'][0], v['food_active'][0], v['task_success'][0] = alive, active, env.task_success
+    elif task == 'drinking':
+        v['target'][0] = env.target_pos
+        alive = sum(1 << (f.body - WATER0) for f in env.waters); active = sum(1 << (f.body - WATER0) for f in env.waters_active)
+        state.view(np.uint32)[st:st + 4] = np.array([alive & 0xffffffff, alive >> 32, active & 0xffffffff, active >> 32], dtype=np.uint32)
+        v['task_success'][0] = env.task_success
     elif task == 'bed_bathing':
         v['task_success'][0] = env.task_success
         # the surviving targets by identity: the marker bodies were created upper arm first, in order (adopt -> generate_targets)

@@ -327,8 +327,80 @@ def stretch_cases():
     return out
 
 
-def build_cases(tasks=('feeding', 'bed', 'scratch', 'arm', 'dressing', 'stretch')):
-    fns = dict(feeding=feeding_cases, bed=bed_cases, scratch=scratch_cases, arm=arm_cases, dressing=dressing_cases, stretch=stretch_cases)
+def drinking_cases():
+    """DrinkingJaco (drinking.py): the water at rest in the cup under random actions, with tremor, the person co-acting; the cup tipping over
+    (spills: -1 each, drinking.py:77-80); particles put at the mouth (+10 each, teleported, :66-75) and onto the person's chest (the
+    water-hit count of the preferences, :84-88); the step that ends the episode."""
+    from assistive_gym_amd.host.reset_drinking import make_states
+    from assistive_gym_amd.model import compiler as L
+    out = []
+    b = variant_blob('drinking_jaco', False, '')
+    o = _oracle(b)
+    settled = {}
+    for imp, seed in (('none', 3), ('tremor', 5)):
+        st, water, _ = make_states(b, 1, seed=seed, impairment=imp)
+        s, w = st[0].copy(), water[0].copy()
+        o.settle_cloth(s, w, 50)                                                                    # drinking.py:176-177
+        settled[imp] = (s.copy(), w.copy())
+        rng = np.random.RandomState(seed)
+        for k in range(2):
+            a = rng.uniform(-1, 1, b.act_dim).astype(np.float32)
+            out.append(dict(name='drinking_%s_step%d' % (imp, k), model='drinking_jaco', coop=False, variant='', state=s.copy(), cloth=w.copy(), action=a))
+            o.step_cloth(s, w, a)
+    # tipping the cup over: the wrist joints driven for 40 steps, then the steps in which the first particles leave the 0.1 m shell
+    s, w = settled['none'][0].copy(), settled['none'][1].copy()
+    a = np.zeros(7, np.float32); a[4], a[5], a[6] = 0.5, 1.0, 1.0
+    taken = 0
+    for k in range(90):
+        s0, w0 = s.copy(), w.copy()
+        obs, rew, done, info = o.step_cloth(s, w, a)
+        if info[4] < 0 and taken < 3:
+            out.append(dict(name='drinking_spilling_%d' % taken, model='drinking_jaco', coop=False, variant='', state=s0, cloth=w0, action=a.copy()))
+            taken += 1
+    assert taken == 3
+    # at the mouth: three particles lifted out of the cup to within 0.03 m of the target, one of them moving
+    s, w = settled['none'][0].copy(), settled['none'][1].copy()
+    v = b.view(s[None])
+    target = v['target'][0].astype(np.float64)
+    top = np.argsort(-w[0][:, 2])[:4]
+    fall = np.array([0.0, -0.015, 0.049])                                                          # one step is 0.1 s of free fall; clear of the face
+    w[0][top[0]] = target + fall + [0.0, 0.0, 0.008]; w[0][top[1]] = target + fall + [0.013, 0.0, -0.004]; w[0][top[2]] = target + fall + [-0.012, 0.03, 0.0]
+    w[1][top[0]] = w[1][top[1]] = 0.0; w[1][top[2]] = [0.0, -0.3, 0.0]
+    b.view(s[None])['task_success'][0] = 46                                                         # 46 + 3 >= 0.75 x 64: info['task_success'] turns 1 (drinking.py:38)
+    w[0][top[3]] = target + [0.0, -0.07, 0.06]; w[1][top[3]] = 0.0                                  # near the mouth but outside the 0.03 m ball: not drunk
+    out.append(dict(name='drinking_at_the_mouth', model='drinking_jaco', coop=False, variant='', state=s.copy(), cloth=w.copy(), action=np.zeros(7, np.float32)))
+    _, _, _, info = o.step_cloth(s.copy(), w.copy(), np.zeros(7, np.float32))
+    assert info[4] == 29.0, info[4]                                                                 # three drunk, the fourth counted as spilled (0.1 m from the cup)
+    # onto the person: three particles that left the cup earlier (no longer in `waters`, still in `waters_active`) land on the lap in this step
+    s, w = settled['none'][0].copy(), settled['none'][1].copy()
+    u = s.view(np.uint32); st0 = b.h['S_TASK']
+    for j, i in enumerate(top[:3]):
+        w[0][i] = target + [0.1 + 0.02 * (j - 1), -0.2, -0.402]; w[1][i] = [0.0, 0.0, -0.98]
+        u[st0 + L.DK['ALIVE'] + (int(i) >> 5)] &= ~np.uint32(1 << (int(i) & 31))
+    out.append(dict(name='drinking_water_on_the_person', model='drinking_jaco', coop=False, variant='', state=s.copy(), cloth=w.copy(), action=np.zeros(7, np.float32)))
+    s1 = s.copy(); _, _, _, info = o.step_cloth(s1, w.copy(), np.zeros(7, np.float32))
+    u1 = s1.view(np.uint32)
+    assert info[4] == 0.0 and sum(bin(int(x)).count('1') for x in u1[st0 + L.DK['ACTIVE']:st0 + L.DK['ACTIVE'] + 2]) == 61
+    # the last step of the episode
+    s, w = settled['tremor'][0].copy(), settled['tremor'][1].copy()
+    b.view(s[None])['iteration'][0] = 199
+    out.append(dict(name='drinking_episode_end', model='drinking_jaco', coop=False, variant='', state=s, cloth=w, action=np.zeros(7, np.float32)))
+    # co-optimisation: the person's head joints act too
+    co = variant_blob('drinking_jaco', True, '')
+    st, water, _ = make_states(co, 1, seed=11, impairment='none')
+    s, w = st[0].copy(), water[0].copy()
+    oc = _oracle(co)
+    oc.settle_cloth(s, w, 50)
+    rng = np.random.RandomState(11)
+    for k in range(2):
+        a = rng.uniform(-1, 1, co.act_dim).astype(np.float32)
+        out.append(dict(name='drinking_coop_step%d' % k, model='drinking_jaco', coop=True, variant='', state=s.copy(), cloth=w.copy(), action=a))
+        oc.step_cloth(s, w, a)
+    return out
+
+
+def build_cases(tasks=('feeding', 'bed', 'scratch', 'arm', 'dressing', 'stretch', 'drinking')):
+    fns = dict(feeding=feeding_cases, bed=bed_cases, scratch=scratch_cases, arm=arm_cases, dressing=dressing_cases, stretch=stretch_cases, drinking=drinking_cases)
     out = []
     for t in tasks:
         out += fns[t]()

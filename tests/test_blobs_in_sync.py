@@ -9,7 +9,7 @@ import pytest
 from conftest import full
 
 ASSETS = '/root/reference/assistive_gym/envs/assets'
-LEAN = {'feeding_jaco', 'bed_bathing_sawyer', 'scratch_itch_jaco', 'arm_manipulation_pr2', 'feeding_sawyer', 'bed_settle'}
+LEAN = {'feeding_jaco', 'bed_bathing_sawyer', 'scratch_itch_jaco', 'arm_manipulation_pr2', 'feeding_sawyer', 'bed_settle', 'drinking_jaco'}
 
 
 def _names():

@@ -73,6 +73,8 @@ def check_state(b, c, s, tol):
         assert abs(float(ta[0:1].view(np.float32)[0]) - float(tb[0:1].view(np.float32)[0])) <= tol, (c['name'], 'task_success (best distance)')
     if b.task_kind == L.TASK_DRESSING:
         assert abs(float(ta[2:3].view(np.float32)[0]) - float(tb[2:3].view(np.float32)[0])) <= 20 * tol, (c['name'], 'task_success (best reward)')
+    if b.task_kind == L.TASK_DRINKING:
+        assert np.array_equal(ta[:4], tb[:4]), (c['name'], 'waters / waters_active', ta[:4], tb[:4])
     if b.task_i('ARM_LIMIT_ON'):
         assert int(ta[10]) == int(tb[10]) and np.abs(ta[6:10].view(np.float32) - tb[6:10].view(np.float32)).max() <= tol, (c['name'], 'arm_previous_valid_pose')
 
@@ -100,7 +102,12 @@ def test_oracle_step_matches_the_reference(name):
     if c['cloth'] is None:
         obs, rew, done, info = o.step(s, c['action'])
     else:
-        obs, rew, done, info = o.step_cloth(s, c['cloth'].copy(), c['action'])
+        cl = c['cloth'].copy()
+        obs, rew, done, info = o.step_cloth(s, cl, c['action'])
+        if name + '/cloth_out' in STEPS:                       # drinking: the water particles after the step (drunk ones are teleported to random far-away places)
+            ref = STEPS[name + '/cloth_out']
+            near = np.abs(ref[0]).max(axis=1) < 500
+            assert np.array_equal(near, np.abs(cl[0]).max(axis=1) < 500) and np.abs(cl[:, near].astype(np.float64) - ref[:, near]).max() <= 2e-6, name
     check_step(b, c, obs, rew, done, info, tol=2e-6, ftol=2e-6)
     check_state(b, c, s, tol=2e-6)
     assert list(c['lens']) == [b.act_dim_robot, b.act_dim - b.act_dim_robot, b.obs_dim_robot, b.obs_dim - b.obs_dim_robot]      # info's length entries (feeding.py:35)
@@ -119,9 +126,16 @@ def test_the_cases_cover_the_branches():
     assert any(ex[n][0] > 1.0 for n in NAMES if n.startswith('dressing'))                                              # cloth_force_sum
     assert any(bool(STEPS[n + '/done']) for n in NAMES)
     assert any(int(STEPS[n + '/task_success']) == 1 for n in NAMES)
+    # drinking: water drunk (+10 each, the count crossing the success threshold), spilled (-1 each), on the person (the preferences' hit count)
+    assert rew['drinking_at_the_mouth'] > 20 and int(STEPS['drinking_at_the_mouth/task_success']) == 1
+    assert all(-4.5 < rew['drinking_spilling_%d' % k] < -1.5 for k in range(3))
+    u0, u1 = case('drinking_water_on_the_person')['state'].view(np.uint32), case('drinking_water_on_the_person')['state_out'].view(np.uint32)
+    from assistive_gym_amd.blob import ModelBlob
+    st = ModelBlob.load('drinking_jaco').h['S_TASK']
+    assert sum(bin(int(x)).count('1') for x in u0[st + 2:st + 4]) == 64 and sum(bin(int(x)).count('1') for x in u1[st + 2:st + 4]) == 61
+    assert abs((rew['drinking_water_on_the_person'] - rew['drinking_none_step0']) + 3.0) < 0.5          # C_fd = 1 per particle (env.py:249-256)
     # the Stretch: action_duplication hands ONE clamped target to the four telescoping joints (env.py:203-220), the wheels' targets move
     # by 5 x 0.05 x 3 x action (env.py:188,197), the observation has no wheel angles (feeding.py:90-92)
-    from assistive_gym_amd.blob import ModelBlob
     b = ModelBlob.load('feeding_stretch')
     c = case('feeding_stretch_arm_at_limit')
     qt = b.view(c['state_out'].reshape(1, -1).copy())['qt'][0]
@@ -132,7 +146,8 @@ def test_the_cases_cover_the_branches():
 
 
 # ---------------------------------------------------------------------------------------------------------------- CPU: kernel sources on the wave emulator
-EMU_CASES = [n for n in NAMES if not n.startswith('dressing') and (n.endswith('step0') or 'food' in n or 'clamped' in n or 'rollback' in n or n.endswith('face_1') or
+NO_DEVICE_PATH = ('drinking_jaco',)       # models with an oracle and reference-pinned cases but no kernel variant yet
+EMU_CASES = [n for n in NAMES if not n.startswith('dressing') and not n.startswith('drinking') and (n.endswith('step0') or 'food' in n or 'clamped' in n or 'rollback' in n or n.endswith('face_1') or
                                                                    ('stretch' in n and ('limit' in n or 'coop' in n or 'clipped' in n)))]
 
 
@@ -341,7 +356,8 @@ def _groups():
     g = {}
     for n in NAMES:
         model, coop, variant = [str(x) for x in STEPS[n + '/meta']]
-        g.setdefault((model, coop, variant), []).append(n)
+        if model not in NO_DEVICE_PATH:
+            g.setdefault((model, coop, variant), []).append(n)
     return sorted(g.items())
 
 
