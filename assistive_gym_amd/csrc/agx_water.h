@@ -1,0 +1,180 @@
+// agx_water.h -- the water of DrinkingEnv (drinking.py:160-172: 64 spheres of 5 mm radius, 1 g each, in the cup): ONE WAVEFRONT per
+// environment, lane = particle.  Follows oracle/agx_oracle.c, water_substep, step for step (same order of operations, float32 here):
+// position-based, one-way coupled -- the water sees the cup, the robot and the person where each internal substep STARTS (the build
+// kernel leaves the world frames of the moving links and the free bodies of every substep in the per-environment trace), the rigid
+// bodies do not feel the water (64 g against a cup held by a 500 N constraint).  [deviation: Bullet solves the spheres as rigid bodies
+// inside its sequential-impulse solve, with rolling and friction]
+//
+// Per substep: (a) frames and shape boxes into LDS; (b) per particle: gravity, the candidate half spaces -- at most CONTACTS, in shape
+// order, of the shapes within 2 r + |v| dt of where the substep starts, each the face (or tangent plane) the particle is in front of
+// THERE --, prediction; (c) PITER iterations of [a Jacobi particle-particle pass over ascending neighbours, from the positions the
+// pass starts with | the half-space projections in candidate order]; (d) v = (x - q) / dt (1 - kDP), tangential damping where a shape
+// was touched.  The rigid substeps of an env step all run first, then this kernel replays their poses (as the garment's kernel does).
+#pragma once
+
+namespace agxw {
+constexpr int CONTACTS = 12;                 // WATER_CONTACTS of the oracle
+constexpr int MAX_BODIES = 64, MAX_SHAPES = 192, MAX_PARTICLES = 64, CAND_WORDS = 5;
+// LDS (floats): body frames [MAX_BODIES][p(3), R(9)], shape boxes [MAX_SHAPES][lo(3), hi(3)], particle positions [64][3], candidates
+// [64][CONTACTS][n(3), offset, shape | hit << 16]
+constexpr int L_BODY = 0, L_BOX = L_BODY + 12 * MAX_BODIES, L_X = L_BOX + 6 * MAX_SHAPES, L_CAND = L_X + 3 * MAX_PARTICLES;
+constexpr int LDS_WORDS = L_CAND + MAX_PARTICLES * CONTACTS * CAND_WORDS;
+constexpr int TRACE_BODY_WORDS = 12;         // per body and substep: p(3), R(9) row major
+constexpr int REPORT_WORDS = MAX_PARTICLES;  // per particle: 1 = touched a shape of the person in the last internal substep (drinking.py:84-88)
+
+// body slots: moving link d -> d, robot base -> ndof, human body h -> ndof + 1 + h, world -> ndof + 1 + nhuman, free body b -> ndof + 2 + nhuman + b
+AGX_DEV int body_slot(int code, int ndof, int nhuman) {
+  if (code == AGX_BODY_WORLD) return ndof + 1 + nhuman;
+  if (code >= AGX_BODY_HUMAN0) return ndof + 1 + (code - AGX_BODY_HUMAN0);
+  if (code >= AGX_BODY_FREE0) return ndof + 2 + nhuman + (code - AGX_BODY_FREE0);
+  if (code == AGX_BODY_ROBOT_BASE) return ndof;
+  return code;
+}
+AGX_DEV void quat_to_rows(const float* q, float* R) {
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+// robot base, the person's static bodies, the world and (from the state record: where the env step ENDS) the free bodies
+AGX_DEV void static_frames(const uint32_t* blob, const float* gstate, float* body, int lane, bool with_free) {
+  const int* bi = (const int*)blob;
+  const int ndof = bi[AGX_H_NDOF], nhuman = bi[AGX_H_NHUMAN], nfree = bi[AGX_H_NFREE];
+  for (int k = lane; k < 2 + nhuman + (with_free ? nfree : 0); k += 64) {
+    float* B = body + 12 * (ndof + k);
+    if (k == 1 + nhuman) { for (int t = 0; t < 12; t++) B[t] = (t == 3 || t == 7 || t == 11) ? 1.f : 0.f; continue; }
+    const float* r = k == 0 ? gstate + bi[AGX_H_S_BASE] : k <= nhuman ? gstate + bi[AGX_H_S_HUMAN] + 7 * (k - 1) : gstate + bi[AGX_H_S_FREE] + 13 * (k - 2 - nhuman);
+    B[0] = r[0]; B[1] = r[1]; B[2] = r[2]; quat_to_rows(r + 3, B + 3);
+  }
+}
+// signed distance of world point x to the surface of cloth shape `sh` (negative inside) and the outward normal nw (world frame): capsule /
+// sphere cores exactly, hulls through their face planes (the largest plane distance: exact inside and in front of a face)
+AGX_DEV float shape_distance(const uint32_t* blob, const float* body, int sh, const float* x, float* nw) {
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  const int* cl = bi + bi[AGX_H_OFF_CLOTH]; const float* clf = bf + bi[AGX_H_OFF_CLOTH];
+  const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * sh; const int c = rec[0], p0 = rec[1], np = rec[2];
+  const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
+  const float* B = body + 12 * body_slot(ci[AGX_C_BODY], bi[AGX_H_NDOF], bi[AGX_H_NHUMAN]); const float* R = B + 3;
+  const float d0 = x[0] - B[0], d1 = x[1] - B[1], d2 = x[2] - B[2];
+  const float xl0 = R[0] * d0 + R[3] * d1 + R[6] * d2, xl1 = R[1] * d0 + R[4] * d1 + R[7] * d2, xl2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+  const float rad = cf[AGX_C_RADIUS];
+  float n0, n1, n2, dist;
+  if (np == 0) {
+    const float* v = bf + bi[AGX_H_OFF_VERT] + 3 * ci[AGX_C_VOFF];
+    float c0 = v[0], c1 = v[1], c2 = v[2];
+    if (ci[AGX_C_NVERT] == 2) {
+      const float ab0 = v[3] - v[0], ab1 = v[4] - v[1], ab2 = v[5] - v[2], l2 = ab0 * ab0 + ab1 * ab1 + ab2 * ab2;
+      float t = l2 > 0.f ? ((xl0 - v[0]) * ab0 + (xl1 - v[1]) * ab1 + (xl2 - v[2]) * ab2) / l2 : 0.f; t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+      c0 += t * ab0; c1 += t * ab1; c2 += t * ab2;
+    }
+    n0 = xl0 - c0; n1 = xl1 - c1; n2 = xl2 - c2; const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+    if (len > 1e-12f) { n0 /= len; n1 /= len; n2 /= len; } else { n0 = 0.f; n1 = 0.f; n2 = 1.f; }
+    dist = len - rad;
+  } else {
+    const float* P = clf + cl[AGX_CL_OFF_PLANE] + 4 * p0;
+    float bd = -3.0e38f; n0 = 0.f; n1 = 0.f; n2 = 1.f;
+    for (int k = 0; k < np; k++) { const float t = P[4 * k] * xl0 + P[4 * k + 1] * xl1 + P[4 * k + 2] * xl2 - P[4 * k + 3]; if (t > bd) { bd = t; n0 = P[4 * k]; n1 = P[4 * k + 1]; n2 = P[4 * k + 2]; } }
+    dist = bd - rad;
+  }
+  nw[0] = R[0] * n0 + R[1] * n1 + R[2] * n2; nw[1] = R[3] * n0 + R[4] * n1 + R[5] * n2; nw[2] = R[6] * n0 + R[7] * n1 + R[8] * n2;
+  return dist;
+}
+
+// one env step of the water: `nsub` internal substeps, substep k reading the frames of trace slot k ([NDOF + NFREE][12]).
+// gwater: float[2][NN][3] positions then velocities (in/out); greport: REPORT_WORDS ints, written after the last substep
+AGX_DEV void water_env(const uint32_t* blob, const float* gstate, const float* gtrace, float* gwater, float* greport, int nsub, float* lds, int lane) {
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  const int* cl = bi + bi[AGX_H_OFF_CLOTH]; const float* clf = bf + bi[AGX_H_OFF_CLOTH];
+  const int NN = cl[AGX_CL_NN], NS = cl[AGX_CL_NSHAPE];
+  const int ndof = bi[AGX_H_NDOF], nhuman = bi[AGX_H_NHUMAN], nfree = bi[AGX_H_NFREE], S_ = bi[AGX_H_SIM_SUBSTEPS] > 1 ? bi[AGX_H_SIM_SUBSTEPS] : 1;
+  const float* par = clf + cl[AGX_CL_OFF_PARAM];
+  const float dt = bf[bi[AGX_H_OFF_PARAMS] + AGX_P_DT] / (float)S_, grav = bf[bi[AGX_H_OFF_PARAMS] + AGX_P_GRAVITY_Z];
+  const float r = par[AGX_CP_MARGIN], kDP = par[AGX_CP_KDP], kDF = par[AGX_CP_KDF]; const int piter = (int)par[AGX_CP_PITER];
+  const int gender = ((const int*)gstate)[bi[AGX_H_S_ENV] + AGX_E_GENDER];
+  float* body = lds + L_BODY; float* box = lds + L_BOX; float* X = lds + L_X; float* cand = lds + L_CAND + lane * CONTACTS * CAND_WORDS;
+  const bool mine = lane < NN;
+  float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f}, q[3];
+  if (mine) for (int k = 0; k < 3; k++) { x[k] = gwater[3 * lane + k]; v[k] = gwater[3 * NN + 3 * lane + k]; }
+  static_frames(blob, gstate, body, lane, false);
+  int human_hit = 0;
+  for (int sub = 0; sub < nsub; sub++) {
+    // (a) frames of the moving links and the free bodies at the start of this substep; world boxes of the shapes
+    const float* tr = gtrace + (size_t)sub * (ndof + nfree) * TRACE_BODY_WORDS;
+    wave_sync();
+    for (int k = lane; k < 12 * ndof; k += 64) body[k] = tr[k];
+    for (int k = lane; k < 12 * nfree; k += 64) body[12 * (ndof + 2 + nhuman) + k] = tr[12 * ndof + k];
+    wave_sync();
+    for (int sh = lane; sh < NS; sh += 64) {
+      const int c = cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh];
+      const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
+      const float* B = body + 12 * body_slot(ci[AGX_C_BODY], ndof, nhuman); const float* R = B + 3;
+      const float g = cf[AGX_C_RADIUS] + 1e-6f;
+      for (int k = 0; k < 3; k++) {
+        const float cw = B[k] + R[3 * k] * cf[AGX_C_AABB_C] + R[3 * k + 1] * cf[AGX_C_AABB_C + 1] + R[3 * k + 2] * cf[AGX_C_AABB_C + 2];
+        const float h = fabsf(R[3 * k]) * cf[AGX_C_AABB_H] + fabsf(R[3 * k + 1]) * cf[AGX_C_AABB_H + 1] + fabsf(R[3 * k + 2]) * cf[AGX_C_AABB_H + 2] + g;
+        box[6 * sh + k] = cw - h; box[6 * sh + 3 + k] = cw + h;
+      }
+    }
+    wave_sync();
+    // (b) gravity, candidates where the substep starts, prediction
+    int ncand = 0;
+    if (mine) {
+      for (int k = 0; k < 3; k++) q[k] = x[k];
+      v[2] += grav * dt;
+      const float reach = 2 * r + sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * dt;
+      for (int sh = 0; sh < NS && ncand < CONTACTS; sh++) {
+        const int only = cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh + 3];
+        if (only && only != gender + 1) continue;
+        const float* b6 = box + 6 * sh;
+        if (q[0] < b6[0] - reach || q[0] > b6[3] + reach || q[1] < b6[1] - reach || q[1] > b6[4] + reach || q[2] < b6[2] - reach || q[2] > b6[5] + reach) continue;
+        float nw[3]; const float d = shape_distance(blob, body, sh, q, nw);
+        if (d >= reach) continue;
+        float* c = cand + CAND_WORDS * ncand++;
+        c[0] = nw[0]; c[1] = nw[1]; c[2] = nw[2]; c[3] = (nw[0] * q[0] + nw[1] * q[1] + nw[2] * q[2]) - d; ((int*)c)[4] = sh;
+      }
+      for (int k = 0; k < 3; k++) x[k] = q[k] + v[k] * dt;
+    }
+    // (c) projection iterations
+    for (int it = 0; it < piter; it++) {
+      wave_sync();
+      if (mine) { X[3 * lane] = x[0]; X[3 * lane + 1] = x[1]; X[3 * lane + 2] = x[2]; }
+      wave_sync();
+      if (mine) {
+        float dx[3] = {0.f, 0.f, 0.f}; int cnt = 0;
+        for (int j = 0; j < NN; j++) {
+          if (j == lane) continue;
+          const float e0 = x[0] - X[3 * j], e1 = x[1] - X[3 * j + 1], e2 = x[2] - X[3 * j + 2], d2 = e0 * e0 + e1 * e1 + e2 * e2;
+          if (d2 >= 4 * r * r) continue;
+          const float d = sqrtf(d2);
+          if (d > 1.1920929e-7f) { const float sc = 0.5f * (2 * r - d) / d; dx[0] += e0 * sc; dx[1] += e1 * sc; dx[2] += e2 * sc; }
+          else dx[2] += (lane > j ? 1.0f : -1.0f) * r;        // coincident centres: apart along z, the higher index up
+          cnt++;
+        }
+        if (cnt > 1) for (int k = 0; k < 3; k++) dx[k] /= (float)cnt;
+        for (int k = 0; k < 3; k++) x[k] += dx[k];
+        for (int cc = 0; cc < ncand; cc++) {
+          float* c = cand + CAND_WORDS * cc;
+          const float d = (c[0] * x[0] + c[1] * x[1] + c[2] * x[2]) - c[3] - r;
+          if (d < 0.f) { x[0] -= c[0] * d; x[1] -= c[1] * d; x[2] -= c[2] * d; ((int*)c)[4] |= 1 << 16; }
+        }
+      }
+    }
+    // (d) velocities; a particle that touched a shape loses the share kDF x friction of its tangential velocity
+    human_hit = 0;
+    if (mine) {
+      for (int k = 0; k < 3; k++) v[k] = (x[k] - q[k]) / dt * (1 - kDP);
+      for (int cc = 0; cc < ncand; cc++) {
+        const float* c = cand + CAND_WORDS * cc; const int w = ((const int*)c)[4];
+        if (!(w >> 16)) continue;
+        const int col = cl[cl[AGX_CL_OFF_SHAPE] + 4 * (w & 0xffff)];
+        const float fr = kDF * bf[bi[AGX_H_OFF_COLL] + col * AGX_C_STRIDE + AGX_C_FRICTION], fc = fr < 1.f ? fr : 1.f;
+        const float vn = v[0] * c[0] + v[1] * c[1] + v[2] * c[2];
+        for (int k = 0; k < 3; k++) v[k] -= (v[k] - c[k] * vn) * fc;
+        if (bi[bi[AGX_H_OFF_COLL] + col * AGX_C_STRIDE + AGX_C_TAG] == AGX_TAG_HUMAN) human_hit = 1;
+      }
+    }
+  }
+  if (mine) for (int k = 0; k < 3; k++) { gwater[3 * lane + k] = x[k]; gwater[3 * NN + 3 * lane + k] = v[k]; }
+  if (greport && lane < REPORT_WORDS) ((int*)greport)[lane] = mine ? human_hit : 0;
+}
+}  // namespace agxw

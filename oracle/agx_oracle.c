@@ -1302,9 +1302,17 @@ static void water_substep(sim_t* s) {
 }
 /* one internal substep; `hooks`: this substep ends a p.stepSimulation() call, after which the reference enforces the human's joint
  * limits and the pose-dependent arm limits (env.py:226-232) */
+/* test hook: the world frames of the moving links and the free bodies where each internal substep starts, in the layout the build kernel
+ * leaves them in for the cloth / water kernels (agx_blob.h, trace: [substep][NDOF + NFREE][p(3), R(9)]); NULL switches it off */
+static float* g_trace_out = NULL; static int g_trace_k = 0;
+void agxo_trace_into(float* buf) { g_trace_out = buf; g_trace_k = 0; }
 static void substep_h(sim_t* s, int hooks) {
   const agxo_model* m = s->m; int n = s->ndof; double dt = m->dt;
   kinematics(s);
+  if (g_trace_out) {
+    float* o = g_trace_out + (size_t)12 * (n + m->nfree) * g_trace_k++;
+    for (int d = 0; d < n + m->nfree; d++) { const xf_t* X = d < n ? &s->link[d] : &s->freex[d - n]; for (int k = 0; k < 3; k++) o[12 * d + k] = (float)X->p[k]; for (int k = 0; k < 9; k++) o[12 * d + 3 + k] = (float)X->R[k]; }
+  }
   if (s->cx && m->i[m->o_cloth + AGX_CL_PARTICLES]) water_substep(s);
   else if (s->cx) cloth_substep(s);   /* one-way coupling: the cloth sees the rigid bodies where this substep starts (btSoftBody::predictMotion precedes the rigid solve) */
   double qdd[MAXDOF];

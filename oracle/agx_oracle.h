@@ -88,6 +88,9 @@ int agxo_world_closest(agxo_world* w, const int* ca, int na, const int* cb, int 
 int agxo_world_cloth(agxo_world* w, double* x, double* contacts6, int max_contacts);
 /* a water particle as a body (DrinkingEnv.get_water_rewards, drinking.py:52-91): pose / velocity, teleport, and the two proximity
  * queries (bit 0: within `dist` of the cup, bit 1: touched the person in the last internal substep) */
+/* test hook: record the frames of the moving links and the free bodies at the start of every internal substep of the following calls
+ * ([substep][NDOF + NFREE][12] floats: p, R row major); NULL stops */
+void agxo_trace_into(float* buf);
 int agxo_world_particle(agxo_world* w, int k, double* pos, double* vel);
 void agxo_world_set_particle(agxo_world* w, int k, const double* pos);
 int agxo_world_particle_query(agxo_world* w, int k, double dist);

@@ -112,6 +112,11 @@ extern "C" int agx_emu_check_collisions(const uint32_t* blob, float* state) {
   if (!rc) rc = run_wave(lds, 64, [&](int lane) { int f = agx::collision_flags(blob, scratch, lane); if (lane == 0) flags = f; });
   return rc ? -1 : flags;
 }
+// the water kernel body (csrc/agx_water.h) for one environment: `nsub` internal substeps over the given trace
+extern "C" int agx_emu_water(const uint32_t* blob, const float* state, const float* trace, float* water, float* report, int nsub) {
+  static float lds[agxw::LDS_WORDS];
+  return run_wave(lds, agxw::LDS_WORDS, [&](int lane) { agxw::water_env(blob, state, trace, water, report, nsub, lds, lane); });
+}
 extern "C" int agx_emu_lds_bytes() { return agx::LDS_BYTES; }
 // debug record layout of this variant (same order as agx_debug_layout of the product library)
 extern "C" void agx_emu_debug_layout(int* out8) {

@@ -114,3 +114,54 @@ def test_reward_terms(dk, settled):
     assert np.allclose(obs[:3], cup_real, atol=1e-5)
     mouth_real, _ = X.compose(ip, iq, v['target'][0].astype(np.float64), np.array([0, 0, 0, 1.0]))
     assert np.allclose(obs[7:10], cup_real - mouth_real, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ the water kernel source (csrc/agx_water.h) on the wave emulator
+def _water_on_emulator(b, o, s, w, action):
+    """one env step: the oracle steps the scene and records the frames of every internal substep; the kernel source replays the water over that
+    trace from the same start.  Returns (oracle water, kernel water, kernel report, oracle state after, info)"""
+    import ctypes as C
+    from emu_lib import lib, _p
+    L = lib(0)
+    nsub = int(b.param('FRAME_SKIP')) * b.h['SIM_SUBSTEPS']
+    trace = np.zeros((nsub, b.ndof + b.nfree, 12), np.float32)
+    s0, w_o = s.copy(), w.copy()
+    o.L.agxo_trace_into(_p(trace))
+    try:
+        obs, rew, done, info = o.step_cloth(s, w_o, action)
+    finally:
+        o.L.agxo_trace_into(None)
+    w_k = w.copy(); report = np.zeros(64, np.int32)
+    words = np.ascontiguousarray(b.words)
+    rc = L.agx_emu_water(_p(words), _p(s0), _p(trace), _p(w_k), _p(report), C.c_int(nsub))
+    assert rc == 0
+    return w_o, w_k, report, info
+
+
+def test_water_kernel_source_matches_the_oracle(dk, settled):
+    """at rest in the cup, while the cup is driven to tip over (particles sliding, leaving, falling), and landing on the person's lap"""
+    b, o = dk
+    s, w, _ = settled
+    s, w = s.copy(), w.copy()
+    a = np.zeros(7, np.float32); a[4], a[5], a[6] = 0.5, 1.0, 1.0
+    worst = 0.0
+    for k in range(60):
+        w_o, w_k, report, info = _water_on_emulator(b, o, s, w, a if k else np.array([0.3, -0.2, 0.1, 0.5, -0.4, 0.2, 0.1], np.float32))
+        near = np.abs(w_o[0]).max(axis=1) < 500
+        dp = np.abs(w_k[0, near].astype(np.float64) - w_o[0, near]).max(axis=1); dv = np.abs(w_k[1, near].astype(np.float64) - w_o[1, near]).max(axis=1)
+        worst = max(worst, dp.max())
+        # float32 against float64 over 20 substeps x 10 iterations of a jittering, contact-rich pile (the oracle's own particles move at up to
+        # 0.1 m/s "at rest").  The typical particle agrees to a few micrometres; a particle on the threshold of one more neighbour overlap
+        # (the contact set is discontinuous) ends up to half a millimetre away in single steps (measured: max 0.55 mm, median 3.6 um over
+        # the 70 steps of this trajectory).  Velocities are position differences over 5 ms: 200 x the position noise.
+        assert dp.max() < 2e-3 and np.median(dp) < 5e-5 and np.median(dv) < 2e-3, (k, dp.max(), np.median(dp), np.median(dv))
+        w = w_o                                           # follow the oracle: every step starts both from the same water
+    assert worst > 0                                      # (not the same arithmetic: a real comparison)
+    # onto the lap: the report is the person-hit flag of the last internal substep
+    v = b.view(s[None]); target = v['target'][0].astype(np.float64)
+    s2, w2 = settled[0].copy(), settled[1].copy()
+    top = np.argsort(-w2[0][:, 2])[:3]
+    for j, i in enumerate(top):
+        w2[0][i] = target + [0.1 + 0.02 * (j - 1), -0.2, -0.402]; w2[1][i] = [0.0, 0.0, -0.98]
+    w_o, w_k, report, info = _water_on_emulator(b, o, s2, w2, np.zeros(7, np.float32))
+    assert sorted(np.nonzero(report)[0]) == sorted(int(i) for i in top) and np.abs(w_k[0] - w_o[0]).max() < 2e-3
