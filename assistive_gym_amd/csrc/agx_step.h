@@ -31,7 +31,6 @@
 #include "agx_pgs.h"
 #include "agx_env.h"
 #include "agx_pgs4.h"
-#include "agx_water.h"
 #if AGX_HAS_SAMPLER
 #include "agx_reset.h"
 #endif

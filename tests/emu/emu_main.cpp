@@ -2,6 +2,7 @@
 // CPU wave emulator.  Built by tests/emu_lib.py into tests/emu/libagx_emu.so.  Test-only.
 #include "agx_wave.h"
 #include "agx_step.h"
+#include "agx_water.h"      // not yet part of a kernel variant: the source is checked here against the oracle first
 #include <functional>
 #include <cstdio>
 

@@ -165,3 +165,17 @@ def test_water_kernel_source_matches_the_oracle(dk, settled):
         w2[0][i] = target + [0.1 + 0.02 * (j - 1), -0.2, -0.402]; w2[1][i] = [0.0, 0.0, -0.98]
     w_o, w_k, report, info = _water_on_emulator(b, o, s2, w2, np.zeros(7, np.float32))
     assert sorted(np.nonzero(report)[0]) == sorted(int(i) for i in top) and np.abs(w_k[0] - w_o[0]).max() < 2e-3
+
+
+def test_water_kernel_source_compiles_for_gfx950(tmp_path):
+    """hipcc cross-compiles without a GPU: registers, scratch and LDS of the kernel body as the device would run it"""
+    import os, shutil, subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-c', '-I', os.path.join(root, 'assistive_gym_amd', 'csrc'), os.path.join(root, 'tests', 'diag', 'water_kernel_check.hip'),
+                        '-o', str(tmp_path / 'wk.o'), '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    usage = {ln.split('remark:')[1].split(':')[0].strip(): ln.split(':')[-1].split('[')[0].strip() for ln in r.stderr.splitlines() if 'remark:' in ln and ':' in ln.split('remark:')[1]}
+    assert int(usage['ScratchSize [bytes/lane]']) == 0 and int(usage['VGPRs']) <= 128 and int(usage['LDS Size [bytes/block]']) == 4 * (12 * 64 + 6 * 192 + 3 * 64 + 64 * 12 * 5)
