@@ -83,7 +83,7 @@ AGX_DEV void arm_limits(Ctx& c, float* X) {
 AGX_DEV void update_target(Ctx& c) {
   float* L = c.lds;
   wave_sync();
-  if (TASK == AGX_TASK_FEEDING && c.lane == 0) {
+  if ((TASK == AGX_TASK_FEEDING || TASK == AGX_TASK_DRINKING) && c.lane == 0) {      // (drinking.py:192-196: the same target, and the head moves there)
     const int hl = TKI(c, AGX_T_HEAD_LINK), o = c.gender == 1 ? AGX_T_MOUTH_F : AGX_T_MOUTH_M;
     st3(L + L_ST + c.s_env + AGX_E_TARGET, mul(ldm3(L + L_LINKR + 9 * hl), mk3(TKF(c, o), TKF(c, o + 1), TKF(c, o + 2))) + ld3(L + L_LINKP + 3 * hl));
   }
@@ -133,7 +133,7 @@ AGX_DEV void tool_base_pose_of(const Ctx& c, int tb, v3& p, m3& R) {
   m3 FR = ldm3(L + L_FREER + 9 * tb); v3 fp = ld3(L + L_ST + c.s_free + 13 * tb);
   p = mul(FR, mk3(FBF(c, tb, AGX_F_REFPOS), FBF(c, tb, AGX_F_REFPOS + 1), FBF(c, tb, AGX_F_REFPOS + 2))) + fp;
   R = mul(FR, quat_to_m3(FBF(c, tb, AGX_F_REFQUAT), FBF(c, tb, AGX_F_REFQUAT + 1), FBF(c, tb, AGX_F_REFQUAT + 2), FBF(c, tb, AGX_F_REFQUAT + 3)));
-  if constexpr (TASK != AGX_TASK_FEEDING) {
+  if constexpr (TASK != AGX_TASK_FEEDING && TASK != AGX_TASK_DRINKING) {      // (the cup is observed in its base frame; AGX_T_TOOL_OBS_* is the frame of its reward terms)
     p = mul(R, mk3(TKF(c, AGX_T_TOOL_OBS_POS), TKF(c, AGX_T_TOOL_OBS_POS + 1), TKF(c, AGX_T_TOOL_OBS_POS + 2))) + p;
     R = mul(R, quat_to_m3(TKF(c, AGX_T_TOOL_OBS_QUAT), TKF(c, AGX_T_TOOL_OBS_QUAT + 1), TKF(c, AGX_T_TOOL_OBS_QUAT + 2), TKF(c, AGX_T_TOOL_OBS_QUAT + 3)));
   }
@@ -355,7 +355,11 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
 #define AGX_TICK(k) if (c.timing) { t1 = wave_clock(); c.tm[k] += t1 - t0; t0 = t1; }
   kinematics(c); AGX_TICK(0)
   // models with a cloth: the world frames of the moving links where this substep starts, for the cloth kernel (one-way coupling)
-  if (gtrace) { for (int k = lane; k < 3 * c.ndof; k += 64) gtrace[12 * (k / 3) + k % 3] = L[L_LINKP + k]; for (int k = lane; k < 9 * c.ndof; k += 64) gtrace[12 * (k / 9) + 3 + k % 9] = L[L_LINKR + k]; }
+  if (gtrace) {
+    for (int k = lane; k < 3 * c.ndof; k += 64) gtrace[12 * (k / 3) + k % 3] = L[L_LINKP + k]; for (int k = lane; k < 9 * c.ndof; k += 64) gtrace[12 * (k / 9) + 3 + k % 9] = L[L_LINKR + k];
+    // ... and of the free bodies behind them (the water's cup; the garment's scene has none): a trace slot is 12 (NDOF + NFREE) words
+    for (int k = lane; k < 12 * c.nfree; k += 64) { const int b = k / 12, t = k % 12; gtrace[12 * (c.ndof + b) + t] = t < 3 ? L[L_ST + c.s_free + 13 * b + t] : L[L_FREER + 9 * b + t - 3]; }
+  }
   aba_and_minv(c); AGX_TICK(1)
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
@@ -883,7 +887,7 @@ AGX_DEV void env_finish_dressing(const uint32_t* blob, float* gstate, const floa
 
 // finish: everything FeedingEnv.step does after take_step (feeding.py:17-43)
 AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
-                        float* ginfo, float* lds, int lane) {
+                        float* ginfo, float* lds, int lane, const float* greport = nullptr, float* gwater = nullptr) {
   Ctx c; ctx_init(c, blob, lds, lane);
   float* L = c.lds; int* Li = c.ldsi;
   const int sw = c.bi[AGX_H_STATE_WORDS], act_dim = c.bi[AGX_H_ACT_DIM];
@@ -968,13 +972,87 @@ AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float
     if (!near) { food_reward -= 5.f; alive &= ~(1 << k); }
   }
   for (int k = 0; k < c.nfood; k++) if ((active_on_entry >> k & 1) && (hit_mask >> k & 1)) { food_hit -= 1.f; active &= ~(1 << k); }
+#if AGX_TASK == 5   /* AGX_TASK_DRINKING (an enum: not visible to the preprocessor) */
+  // DrinkingEnv.get_water_rewards (drinking.py:52-91), lane = particle: outside the cup's cylinder and within 0.03 m of the mouth -> drunk
+  // (+10, teleported), else further than 0.1 m from every piece of the cup -> spilled (-1); a particle of waters_active (as it was on
+  // entry) that touched the person in the last internal substep (the water kernel's report) counts for the preferences
+  float tilt_term = 0.f; v3 cup_top = mk3(0.f, 0.f, 0.f);
+  {
+    float* body = L + L_ARENA;                                   // frames in agx_water.h's slot layout, where this env step ends
+    for (int k = lane; k < 3 * c.ndof; k += 64) body[12 * (k / 3) + k % 3] = L[L_LINKP + k];
+    for (int k = lane; k < 9 * c.ndof; k += 64) body[12 * (k / 9) + 3 + k % 9] = L[L_LINKR + k];
+    agxw::static_frames(blob, L + L_ST, body, lane, true);
+    wave_sync();
+    v3 cp; m3 cR; tool_base_pose(c, cp, cR);
+    const v3 p2 = mul(cR, mk3(TKF(c, AGX_T_TOOL_OBS_POS), TKF(c, AGX_T_TOOL_OBS_POS + 1), TKF(c, AGX_T_TOOL_OBS_POS + 2))) + cp;
+    const m3 R2 = mul(cR, quat_to_m3(TKF(c, AGX_T_TOOL_OBS_QUAT), TKF(c, AGX_T_TOOL_OBS_QUAT + 1), TKF(c, AGX_T_TOOL_OBS_QUAT + 2), TKF(c, AGX_T_TOOL_OBS_QUAT + 3)));
+    const v3 top = mul(R2, mk3(TKF(c, AGX_T_DK_TOP), TKF(c, AGX_T_DK_TOP + 1), TKF(c, AGX_T_DK_TOP + 2))) + p2;
+    const v3 bot = mul(R2, mk3(TKF(c, AGX_T_DK_BOTTOM), TKF(c, AGX_T_DK_BOTTOM + 1), TKF(c, AGX_T_DK_BOTTOM + 2))) + p2;
+    cup_top = top;
+    const q4 q = m3_to_quat(R2);                                 // cup_euler[0] as p.getEulerFromQuaternion returns it (drinking.py:30-31)
+    const float sarg = -2.0f * (q.x * q.z - q.w * q.y);
+    const float roll = (sarg <= -0.99999f || sarg >= 0.99999f) ? 0.f : atan2f(2 * (q.y * q.z + q.w * q.x), q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z);
+    tilt_term = -fabsf(roll - 3.14159265358979f * 0.5f);
+    const int* cl = c.bi + c.bi[AGX_H_OFF_CLOTH]; const float* clf = c.bf + c.bi[AGX_H_OFF_CLOTH];
+    const int NN = cl[AGX_CL_NN], NS = cl[AGX_CL_NSHAPE]; const float margin = clf[cl[AGX_CL_OFF_PARAM] + AGX_CP_MARGIN];
+    const int s_task = c.bi[AGX_H_S_TASK];
+    const bool mine = lane < NN;
+    const bool is_alive = mine && ((uint32_t)Li[L_ST + s_task + AGX_DK_ALIVE + (lane >> 5)] >> (lane & 31) & 1u);
+    const bool is_active = mine && ((uint32_t)Li[L_ST + s_task + AGX_DK_ACTIVE + (lane >> 5)] >> (lane & 31) & 1u);
+    float x[3] = {0.f, 0.f, 0.f}; float speed = 0.f;
+    if (mine) { for (int k = 0; k < 3; k++) x[k] = gwater[3 * lane + k]; const float* vv = gwater + 3 * NN + 3 * lane; speed = sqrtf(vv[0] * vv[0] + vv[1] * vv[1] + vv[2] * vv[2]); }
+    bool drunk = false, spilled = false;
+    if (is_alive) {
+      const v3 xp = mk3(x[0], x[1], x[2]), axis = bot - top, a = xp - top, b = xp - bot, cr = cross(a, axis);
+      const float cyl = TKF(c, AGX_T_TARGET_RADIUS) * sqrtf(dot(axis, axis));
+      const bool inside = dot(a, axis) >= 0.f && dot(b, axis) <= 0.f && sqrtf(dot(cr, cr)) <= cyl;          // Util.points_in_cylinder (util.py:53-56)
+      if (!inside) {
+        const v3 d = target - xp;
+        if (sqrtf(dot(d, d)) < TKF(c, AGX_T_MOUTH_DIST)) drunk = true;
+        else {
+          bool near = false;
+          for (int sh = 0; sh < NS && !near; sh++) {
+            if (c.bi[c.bi[AGX_H_OFF_COLL] + cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh] * AGX_C_STRIDE + AGX_C_TAG] != AGX_TAG_TOOL) continue;
+            float nw[3]; if (agxw::shape_distance(blob, body, sh, x, nw) - margin <= spill) near = true;
+          }
+          spilled = !near;
+        }
+      }
+    }
+    const bool hit = is_active && greport && ((const int*)greport)[lane] != 0;
+    const uint64_t m_drunk = wave_ballot(drunk), m_spilled = wave_ballot(spilled), m_hit = wave_ballot(hit);
+    food_reward = 10.f * (float)popc64(m_drunk) - (float)popc64(m_spilled);
+    food_hit = -(float)popc64(m_hit);
+    vel_sum = wave_sum(drunk ? speed : 0.f);
+    success += popc64(m_drunk);
+    for (uint64_t m = m_drunk; m; m &= m - 1) {                   // teleported in ascending order, three draws each (drinking.py:74)
+      const int e = ffs64(m);
+      const float px = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      const float py = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      const float pz = 1000.0f + 1000.0f * (float)(rng_next(r0, r1) >> 8) * (1.0f / 16777216.0f);
+      if (lane == e) { gwater[3 * lane] = px; gwater[3 * lane + 1] = py; gwater[3 * lane + 2] = pz; }
+    }
+    wave_sync();
+    if (lane < 2) {
+      const uint32_t gone = (uint32_t)((m_drunk | m_spilled) >> (32 * lane)), off = (uint32_t)((m_drunk | m_hit) >> (32 * lane));
+      Li[L_ST + s_task + AGX_DK_ALIVE + lane] = (int)((uint32_t)Li[L_ST + s_task + AGX_DK_ALIVE + lane] & ~gone);
+      Li[L_ST + s_task + AGX_DK_ACTIVE + lane] = (int)((uint32_t)Li[L_ST + s_task + AGX_DK_ACTIVE + lane] & ~off);
+    }
+    wave_sync();
+  }
+#endif
   // end-effector speed (feeding.py:22), human_preferences (env.py:237-274, feeding branch), reward
   const float ee_speed = ee_speed_of(c);
   float pref = TKF(c, AGX_T_C_V) * (-ee_speed) + TKF(c, AGX_T_C_F) * (-total_f) + TKF(c, AGX_T_C_HF) * (tool_f < 10.f ? 0.f : -tool_f)
              + TKF(c, AGX_T_C_FD) * food_hit + TKF(c, AGX_T_C_FDV) * (-vel_sum);
   v3 sp; m3 sR; tool_base_pose(c, sp, sR);
   v3 dd = target - sp;
+#if AGX_TASK == 5   /* AGX_TASK_DRINKING (an enum: not visible to the preprocessor) */
+  dd = target - cup_top;                                           // the top centre of the cup against the mouth (drinking.py:25-26), and the tilt term (:30-31)
+  float reward = TKF(c, AGX_T_W_DISTANCE) * (-sqrtf(dot(dd, dd))) + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + TKF(c, AGX_T_W_TILT) * tilt_term + TKF(c, AGX_T_W_FOOD) * food_reward + pref;
+#else
   float reward = TKF(c, AGX_T_W_DISTANCE) * (-sqrtf(dot(dd, dd))) + TKF(c, AGX_T_W_ACTION) * (-sqrtf(an2)) + TKF(c, AGX_T_W_FOOD) * food_reward + pref;
+#endif
   const int iteration = Li[L_ST + c.s_env + AGX_E_ITERATION];
   wave_sync();
   if (lane == 0) {
@@ -993,12 +1071,12 @@ AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float
 }
 
 AGX_DEV void env_finish(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gobs, float* greward, uint8_t* gdone,
-                        float* ginfo, float* lds, int lane, const float* greport = nullptr) {
+                        float* ginfo, float* lds, int lane, const float* greport = nullptr, float* gwater = nullptr) {
   if constexpr (TASK == AGX_TASK_DRESSING) env_finish_dressing(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane, greport);
   else if constexpr (TASK == AGX_TASK_BED_BATHING) env_finish_bed(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else if constexpr (TASK == AGX_TASK_SCRATCH_ITCH) env_finish_scratch(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
   else if constexpr (TASK == AGX_TASK_ARM_MANIPULATION) env_finish_arm(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
-  else env_finish_feeding(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane);
+  else env_finish_feeding(blob, gstate, gaction, gscratch, gobs, greward, gdone, ginfo, lds, lane, greport, gwater);
   // Non-finite guard (the reference's nearest analogue is the forced reconnect of env.py:93-97): an environment whose joint or
   // free-body state has become NaN / Inf must not poison a training batch.  Its observation and reward are zeroed, it is reported done
   // -- so the auto-reset (agx_reset_done / the masked agx_reset) replaces its state -- and AGX_INFO_NCONTACT carries AGX_INFO_NONFINITE.

@@ -29,6 +29,9 @@
 #include "agx_collide.h"
 #include "agx_rows.h"
 #include "agx_pgs.h"
+#if AGX_TASK == 5   /* AGX_TASK_DRINKING (an enum: not visible to the preprocessor) */
+#include "agx_water.h"
+#endif
 #include "agx_env.h"
 #include "agx_pgs4.h"
 #if AGX_HAS_SAMPLER

@@ -113,6 +113,28 @@ extern "C" int agx_emu_check_collisions(const uint32_t* blob, float* state) {
   if (!rc) rc = run_wave(lds, 64, [&](int lane) { int f = agx::collision_flags(blob, scratch, lane); if (lane == 0) flags = f; });
   return rc ? -1 : flags;
 }
+#if AGX_TASK == 5
+// one env step of the drinking scene as libagx schedules it: frame_skip x sim_sub x [build (leaving the frames of the substep in the trace), solve],
+// the water kernel over the trace, the finish kernel with the water buffer and the water kernel's report
+extern "C" int agx_emu_step_water(const uint32_t* blob, float* state, float* water, const float* action, float* obs, float* reward, uint8_t* done, float* info) {
+  static float lds[(agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS) > agxw::LDS_WORDS ? (agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS) : agxw::LDS_WORDS];
+  static float scratch[agx::SCR_WORDS];
+  const int* bi = (const int*)blob;
+  const int frame_skip = (int)((const float*)blob)[bi[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP], sim_sub = bi[AGX_H_SIM_SUBSTEPS] > 1 ? bi[AGX_H_SIM_SUBSTEPS] : 1;
+  const int nsub = frame_skip * sim_sub, slot = 12 * (bi[AGX_H_NDOF] + bi[AGX_H_NFREE]);
+  float* trace = (float*)calloc((size_t)nsub * slot, 4); float report[agxw::REPORT_WORDS] = {0};
+  int rc = 0;
+  for (int k = 0; k < nsub && !rc; k++) {
+    const float* act = k == 0 ? action : nullptr;
+    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, nullptr, lds, lane, trace + (size_t)k * slot); });
+    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, nullptr, lds, lane, k); });
+  }
+  if (!rc) rc = run_wave(lds, agxw::LDS_WORDS, [&](int lane) { agxw::water_env(blob, state, trace, water, report, nsub, lds, lane); });
+  if (!rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane, report, water); });
+  free(trace);
+  return rc;
+}
+#endif
 // the water kernel body (csrc/agx_water.h) for one environment: `nsub` internal substeps over the given trace
 extern "C" int agx_emu_water(const uint32_t* blob, const float* state, const float* trace, float* water, float* report, int nsub) {
   static float lds[agxw::LDS_WORDS];

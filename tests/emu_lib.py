@@ -16,6 +16,7 @@ VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BL
 
 VARIANT_DEFS[3] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=3']      # dressing (rigid scene; the cloth kernel is a workgroup kernel)
 VARIANT_DEFS[4] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=4']      # arm manipulation
+VARIANT_DEFS['drinking'] = ['-DAGX_MAX_FREE=1', '-DAGX_TASK=5']      # the feeding limits, the drinking task layer, the water kernel (csrc/agx_water.h)
 VARIANT_DEFS['feeding_packed'] = ['-DAGX_USE_SOLVE4=1']       # the opt-in packed solve kernel (csrc/agx_pgs4.h)
 VARIANT_DEFS['feeding_cap'] = ['-DAGX_USE_SOLVE4=1', '-DAGX_P4_WINDOW_CAP=100']      # the packed solver with a small LDS window: its rows-beyond-the-window path on ordinary scenes
 VARIANT_DEFS['feeding_l'] = ['-DAGX_MAX_COLL=320', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040']
@@ -58,7 +59,7 @@ def _p(a):
 class Emu:
     def __init__(self, blob, kind=None):
         self.blob = blob
-        self.L = lib(kind) if kind is not None else lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_m' if (blob.task_kind == 0 and blob.ndof > 16) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_m' if blob.task_kind == 1 and blob.nrobot > 12 else 'scratch_m' if blob.task_kind == 2 and blob.nrobot > 12 else 'bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_m' if blob.task_kind == 3 and blob.nrobot > 12 else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
+        self.L = lib(kind) if kind is not None else lib('drinking') if blob.task_kind == 5 else lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_m' if (blob.task_kind == 0 and blob.ndof > 16) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_m' if blob.task_kind == 1 and blob.nrobot > 12 else 'scratch_m' if blob.task_kind == 2 and blob.nrobot > 12 else 'bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_m' if blob.task_kind == 3 and blob.nrobot > 12 else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
         self.words = np.ascontiguousarray(blob.words)
         lay = (C.c_int * 8)()
         self.L.agx_emu_debug_layout(lay)
@@ -77,6 +78,14 @@ class Emu:
 
     def step(self, state, action, debug=False):
         return self._run(state, action, 0, 0, debug)
+
+    def step_water(self, state, water, action):
+        """one env step of the drinking scene (state and water in place) -> (obs, reward, done, info)"""
+        assert state.dtype == np.float32 and water.dtype == np.float32 and water.flags.c_contiguous
+        obs = np.zeros(self.blob.obs_dim, dtype=np.float32); rew = np.zeros(1, dtype=np.float32); done = np.zeros(1, dtype=np.uint8); info = np.zeros(8, dtype=np.float32)
+        rc = self.L.agx_emu_step_water(_p(self.words), _p(state), _p(water), _p(np.ascontiguousarray(action, dtype=np.float32)), _p(obs), _p(rew), _p(done), _p(info))
+        assert rc == 0, 'wave emulator reported divergent control flow'
+        return obs, float(rew[0]), bool(done[0]), info
 
     def settle(self, state, n, debug=False):
         return self._run(state, None, 1, n, debug)[4]

@@ -384,7 +384,9 @@ def drinking_cases():
     # the last step of the episode
     s, w = settled['tremor'][0].copy(), settled['tremor'][1].copy()
     b.view(s[None])['iteration'][0] = 199
-    out.append(dict(name='drinking_episode_end', model='drinking_jaco', coop=False, variant='', state=s, cloth=w, action=np.zeros(7, np.float32)))
+    # (not a zero action: the cup then stays at the IK target whose roll is exactly pi, the branch cut of getEulerFromQuaternion in the tilt term
+    # -|roll - pi/2| (drinking.py:30-31) -- the reference's reward jumps by 0.1 pi between +pi and -pi there, and float32 lands on either side)
+    out.append(dict(name='drinking_episode_end', model='drinking_jaco', coop=False, variant='', state=s, cloth=w, action=np.full(7, -0.5, np.float32)))
     # co-optimisation: the person's head joints act too
     co = variant_blob('drinking_jaco', True, '')
     st, water, _ = make_states(co, 1, seed=11, impairment='none')

@@ -164,6 +164,31 @@ def test_emulator_step_matches_the_reference(name):
     check_state(b, c, s, tol=device_tol(name))
 
 
+def check_water(name, water, tol):
+    """the water after the step against the reference run's (drunk particles are teleported to random far-away places: only that they are gone)"""
+    ref = STEPS[name + '/cloth_out']
+    near = np.abs(ref[0]).max(axis=1) < 500
+    assert np.array_equal(near, np.abs(water[0]).max(axis=1) < 500), (name, 'the same particles are gone')
+    assert np.abs(water[0][near].astype(np.float64) - ref[0][near]).max() <= tol, (name, 'water positions')
+
+
+@pytest.mark.parametrize('name', [n for n in NAMES if n.startswith('drinking')])
+def test_emulator_drinking_step_matches_the_reference(name):
+    """the drinking step as libagx will schedule it -- build kernels leaving the cup's and the links' frames in the trace, solve kernels, the
+    water kernel (csrc/agx_water.h) over the trace, the finish kernel with the water's task layer -- from the kernel sources on the wave
+    emulator, against what the reference's DrinkingJacoEnv.step() returned (NO kernel variant ships it yet: DESIGN 8)"""
+    from emu_lib import Emu
+    from refcases import variant_blob
+    c = case(name)
+    b = variant_blob(c['model'], c['coop'], c['variant'])
+    e = Emu(b)
+    s, w = c['state'].copy(), c['cloth'].copy()
+    obs, rew, done, info = e.step_water(s, w, c['action'])
+    check_step(b, c, obs, rew, done, info, tol=1e-4, ftol=1e-3)
+    check_state(b, c, s, tol=1e-4)
+    check_water(name, w, tol=5e-4)
+
+
 # ---------------------------------------------------------------------------------------------------------------- CPU: direct calls of the reference's functions
 def test_sleeve_on_arm_reward_matches_the_reference():
     import ctypes as C
