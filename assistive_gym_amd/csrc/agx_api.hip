@@ -136,9 +136,9 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   const agx_variant* V = nullptr;
   {
     // the first (smallest) variant with the model's task layer whose limits hold the model
-    const agx_variant* all[14] = {agx_variant_feeding(), agx_variant_feeding_l(), agx_variant_feeding_m(), agx_variant_bed_bathing(), agx_variant_bed_bathing_l(), agx_variant_bed_bathing_m(),
+    const agx_variant* all[15] = {agx_variant_feeding(), agx_variant_feeding_l(), agx_variant_feeding_m(), agx_variant_bed_bathing(), agx_variant_bed_bathing_l(), agx_variant_bed_bathing_m(),
                                  agx_variant_scratch_itch(), agx_variant_scratch_itch_m(), agx_variant_bed_settle(),
-                                 agx_variant_dressing(), agx_variant_dressing_l(), agx_variant_dressing_m(), agx_variant_arm_manipulation(), agx_variant_arm_manipulation_l()};
+                                 agx_variant_dressing(), agx_variant_dressing_l(), agx_variant_dressing_m(), agx_variant_arm_manipulation(), agx_variant_arm_manipulation_l(), agx_variant_drinking()};
     bool task_seen = false;
     for (const agx_variant* v : all) {
       if (v->task_kind != hi[AGX_H_TASK_KIND]) continue;
@@ -212,9 +212,13 @@ static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_
     const int32_t* cl = hi + hi[AGX_H_OFF_CLOTH];
     h->cloth_nn = cl[AGX_CL_NN];
     h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn) + AGX_CLOTH_SCRATCH_WORDS(h->cloth_nn);
-    h->trace_words = h->frame_skip * h->sim_sub * hi[AGX_H_NDOF] * 12;
+    h->trace_words = h->frame_skip * h->sim_sub * (hi[AGX_H_NDOF] + hi[AGX_H_NFREE]) * 12;      // per substep: the frames of the moving links, then of the free bodies
     h->cloth_lds = V->cloth_lds_bytes(h->cloth_nn);          // agxc::lds_words of the variant's own cloth kernel
-    if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4096 || cl[AGX_CL_NCOLOR] - (AGX_CLOTH_THREADS / 64) * cl[AGX_CL_NPATCH_COLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_NPATCH_COLOR] < 0 || cl[AGX_CL_MAX_LINKS_PER_COLOR] > 1024 ||
+    if (cl[AGX_CL_PARTICLES]) {      // the water of the drinking scene (agx_water.h): one wavefront, lane = particle; report = one word per particle
+      h->report_words = 64;
+      if (h->cloth_nn > 64 || cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + hi[AGX_H_NFREE] + 2 > 64 || hi[AGX_H_TASK_KIND] != AGX_TASK_DRINKING)
+        return fail(AGX_E_LIMIT, "agx_create: particles exceed the limits of the water kernel");
+    } else if (h->cloth_lds > 160 * 1024 || h->cloth_nn > 4096 || cl[AGX_CL_NCOLOR] - (AGX_CLOTH_THREADS / 64) * cl[AGX_CL_NPATCH_COLOR] > AGX_CLOTH_MAX_COLORS || cl[AGX_CL_NPATCH_COLOR] < 0 || cl[AGX_CL_MAX_LINKS_PER_COLOR] > 1024 ||
         cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + 2 > 64 || cl[AGX_CL_NN] > 65535 || hi[AGX_H_NFREE] != 0) return fail(AGX_E_LIMIT, "agx_create: cloth exceeds the limits of the cloth kernel");
     HIPCHK(hipMalloc(&h->cloth_dev, (size_t)n_envs * h->cloth_words * 4)); HIPCHK(hipMemset(h->cloth_dev, 0, (size_t)n_envs * h->cloth_words * 4));
     HIPCHK(hipMalloc(&h->trace_dev, (size_t)n_envs * h->trace_words * 4)); HIPCHK(hipMemset(h->trace_dev, 0, (size_t)n_envs * h->trace_words * 4));
@@ -313,7 +317,8 @@ static int launch_chunked(agx_handle h, int n_substeps, const float* act, float*
       }
     }
     if (finish) {
-      h->V->finish(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, h->report_dev, h->report_words);
+      h->V->finish(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, h->report_dev, h->report_words,
+                   h->cloth_dev, h->cloth_words);
       HIPCHK(hipGetLastError());
     }
     if (nc > 1) { HIPCHK(hipEventRecord(h->join_ev[c], st)); HIPCHK(hipStreamWaitEvent(user, h->join_ev[c], 0)); }
@@ -362,7 +367,7 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
       else h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
     }
-    h->V->finish(st, ne, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, nullptr, 0);
+    h->V->finish(st, ne, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, nullptr, 0, nullptr, 0);
     HIPCHK(hipEventRecord(h->kev[c][e++], st));
     HIPCHK(hipGetLastError());
     nev[c] = e;

@@ -122,6 +122,12 @@
 #define AGX_ARENA_WORDS 4040
 #define AGX_VNAME feeding_m
 #define AGX_K(name) name##_fm
+#elif defined(AGX_VARIANT_DRINKING)
+// DrinkingJaco: the feeding scene's robot and person, the cup as the one free body (68 hulls), no food; plus the water kernel (agx_water.h)
+#define AGX_MAX_FREE 1
+#define AGX_TASK 5
+#define AGX_VNAME drinking
+#define AGX_K(name) name##_dk
 #elif defined(AGX_VARIANT_FEEDING)
 #define AGX_VNAME feeding
 #define AGX_K(name) name
@@ -147,7 +153,7 @@ AGX_K(agx_build_kernel)(const uint32_t* __restrict__ blob, float* state, const f
   if (env >= n_envs || (active && !active[env])) return;   // `active`: masked settle of agx_reset, null on the step path
   const int dropped = agx::env_build(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
                                      debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x,
-                                     trace ? trace + (size_t)env * trace_words + (size_t)phase * 12 * ((const int*)blob)[AGX_H_NDOF] : nullptr);
+                                     trace ? trace + (size_t)env * trace_words + (size_t)phase * 12 * (((const int*)blob)[AGX_H_NDOF] + ((const int*)blob)[AGX_H_NFREE]) : nullptr);
   if (dropped > 0 && threadIdx.x == 0) atomicAdd(overflow_total, dropped);   // contacts dropped by a budget (rare; agx_overflow_count)
 }
 // solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
@@ -169,14 +175,26 @@ AGX_K(agx_solve4_kernel)(const uint32_t* __restrict__ blob, float* state, float*
 // finish: forces, observation, task state machine, reward, done, info
 extern "C" __global__ void __launch_bounds__(64, 2)
 AGX_K(agx_finish_kernel)(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
-                         float* info, int env0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words) {
+                         float* info, int env0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words, float* cloth, int cloth_words) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = env0 + blockIdx.x;
   if (env >= n_envs) return;
   agx::env_finish(blob, state + (size_t)env * sw, actions + (size_t)env * act_dim, scratch + (size_t)env * agx::SCR_WORDS, obs + (size_t)env * obs_dim,
                   reward + env, done + env, info ? info + (size_t)env * AGX_INFO_COUNT : nullptr, lds, (int)threadIdx.x,
-                  report ? report + (size_t)env * report_words : nullptr);
+                  report ? report + (size_t)env * report_words : nullptr, cloth ? cloth + (size_t)env * cloth_words : nullptr);
 }
+#if AGX_TASK == 5
+// the water: one wavefront per environment, lane = particle (agx_water.h); replays the frames the build kernels left in the trace
+extern "C" __global__ void __launch_bounds__(64)
+AGX_K(agx_water_kernel)(const uint32_t* __restrict__ blob, const float* __restrict__ state, const float* __restrict__ trace, float* water, float* report, int env0, int n_envs,
+                        int sw, int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* __restrict__ active) {
+  __shared__ __attribute__((aligned(16))) float lds[agxw::LDS_WORDS];
+  const int env = env0 + blockIdx.x;
+  if (env >= n_envs || (active && !active[env])) return;
+  agxw::water_env(blob, state + (size_t)env * sw, trace + (size_t)env * trace_words, water + (size_t)env * cloth_words, report ? report + (size_t)env * report_words : nullptr, nsub,
+                  lds, (int)threadIdx.x);
+}
+#endif
 #if AGX_TASK == 3
 // the garment: one workgroup of AGX_CLOTH_THREADS threads per environment, positions resident in LDS for all substeps of the launch
 extern "C" __global__ void __launch_bounds__(AGX_CLOTH_THREADS)
@@ -253,10 +271,18 @@ void v_solve4(hipStream_t st, int ne, const uint32_t* blob, float* state, float*
   hipLaunchKernelGGL(AGX_K(agx_solve4_kernel), dim3((ne + 3) / 4), dim3(64), agx::LDS_SOLVE4_BYTES, st, blob, state, scratch, e0, e0 + ne, sw, active, phase);
 }
 void v_finish(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done, float* info,
-              int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words) {
+              int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words, float* cloth, int cloth_words) {
   hipLaunchKernelGGL(AGX_K(agx_finish_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, obs, reward, done, info, e0, n_envs, sw, act_dim, obs_dim,
-                     report, report_words);
+                     report, report_words, cloth, cloth_words);
 }
+#if AGX_TASK == 5
+void v_cloth(hipStream_t st, int ne, const uint32_t* blob, const float* state, const float* trace, float* cloth, float* report, int e0, int n_envs, int sw,
+             int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* active, int lds_bytes) {
+  (void)lds_bytes;
+  hipLaunchKernelGGL(AGX_K(agx_water_kernel), dim3(ne), dim3(64), 0, st, blob, state, trace, cloth, report, e0, n_envs, sw, trace_words, cloth_words, report_words, nsub, active);
+}
+int v_cloth_lds_bytes(int nn) { (void)nn; return 4 * agxw::LDS_WORDS; }
+#endif
 #if AGX_TASK == 3
 void v_cloth(hipStream_t st, int ne, const uint32_t* blob, const float* state, const float* trace, float* cloth, float* report, int e0, int n_envs, int sw,
              int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* active, int lds_bytes) {
@@ -303,7 +329,7 @@ const agx_variant g_variant = {
 #else
   nullptr,
 #endif
-#if AGX_TASK == 3
+#if AGX_TASK == 3 || AGX_TASK == 5
   v_cloth,
 #else
   nullptr,
@@ -315,7 +341,7 @@ const agx_variant g_variant = {
 #endif
   v_collision_flags,
   agx::USE_SOLVE4 ? v_solve4 : nullptr,
-#if AGX_TASK == 3
+#if AGX_TASK == 3 || AGX_TASK == 5
   v_cloth_lds_bytes
 #else
   nullptr

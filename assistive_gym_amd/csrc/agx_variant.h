@@ -20,7 +20,7 @@ struct agx_variant {
                 int act_dim, const uint8_t* active, int* overflow_total, float* trace, int trace_words, int phase);
   void (*solve)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase);
   void (*finish)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
-                 float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words);
+                 float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words, float* cloth, int cloth_words);   // cloth: the water buffer for the drinking task layer (teleports drunk particles), unused elsewhere
   void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim);
   void (*sample)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
                  int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen,
@@ -53,3 +53,4 @@ extern "C" const agx_variant* agx_variant_scratch_itch_m(void);
 extern "C" const agx_variant* agx_variant_dressing_m(void);
 extern "C" const agx_variant* agx_variant_dressing_l(void);
 extern "C" const agx_variant* agx_variant_arm_manipulation_l(void);
+extern "C" const agx_variant* agx_variant_drinking(void);

@@ -74,8 +74,9 @@ enum { AGX_TASK_FEEDING = 0,      /* assistive_gym/envs/feeding.py      */
        AGX_TASK_SCRATCH_ITCH = 2, /* assistive_gym/envs/scratch_itch.py */
        AGX_TASK_DRESSING = 3,     /* assistive_gym/envs/dressing.py     */
        AGX_TASK_ARM_MANIPULATION = 4,    /* assistive_gym/envs/arm_manipulation.py (single-arm robots) */
-       AGX_TASK_DRINKING = 5 };          /* assistive_gym/envs/drinking.py -- MODEL AND CPU ORACLE ONLY so far: no kernel variant serves it (agx_create
-                                          * refuses such a blob); the water is a particle section in the garment's format (AGX_CL_PARTICLES)        */
+       AGX_TASK_DRINKING = 5 };          /* assistive_gym/envs/drinking.py: the `drinking` kernel variant; the water is a particle section in the
+                                          * garment's format (AGX_CL_PARTICLES) stepped by agx_water.h.  Round 3: checked on the CPU wave emulator
+                                          * only, NOT YET RUN ON A GPU; no env ids are registered for it                                */
 
 /* ---- PARAMS: float[AGX_P_COUNT] ----------------------------------------------------------- */
 enum {

@@ -1,4 +1,5 @@
-"""DrinkingJaco-v1 (assistive_gym/envs/drinking.py) -- MODEL AND CPU ORACLE ONLY so far (no kernel variant serves the task): the
+"""DrinkingJaco-v1 (assistive_gym/envs/drinking.py) -- model, CPU oracle, and the kernel sources on the CPU wave emulator (the `drinking` kernel
+variant is compiled but has not run on a GPU yet): the
 model blob against the reference's tables, the host reset, the water particles in the oracle (they come to rest in the cup, stay in it while
 it tilts a little, pour out when it tips over), and the task layer's terms against a numpy restatement.  The reference's own step() runs
 on this oracle through tests/refbridge (test_reference_pinned.py).  PARITY UNPINNED vs PyBullet (the physics half)."""
@@ -51,8 +52,9 @@ def test_model_tables(dk):
     assert np.allclose(np.unique(np.round(x0[:, 0], 6)), [-0.02, -0.01, 0.0, 0.01]) and np.allclose(np.unique(np.round(x0[:, 2], 6)), [0.075, 0.085, 0.095, 0.105])   # :163-167
 
 
-def test_no_kernel_variant_serves_the_task_yet(dk):
-    """the product refuses the blob loudly (no CPU path, no silent fallback): only checked where a GPU library can be loaded at all"""
+def test_no_env_ids_yet(dk):
+    """the `drinking` kernel variant exists and agrees with the reference on the wave emulator, but it has not run on a GPU yet (round 3 ran out of
+    GPU time): no env id is registered for the task until tests/test_zz_gpu_drinking.py has passed on the device"""
     from assistive_gym_amd.envs import ENV_IDS
     assert not any(k.startswith('Drinking') for k in ENV_IDS)
 
