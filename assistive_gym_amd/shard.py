@@ -46,9 +46,10 @@ class ObsGatherer:
     On CPU tensors (gloo tests) there are no streams: submit() gathers synchronously.
     """
 
-    def __init__(self, n_local, obs_dim, world, device=None, dtype=None):
+    def __init__(self, n_local, obs_dim, world, device=None, dtype=None, force=False):
         import torch
         self.torch, self.world = torch, world
+        self.force = force            # a 1-rank group still runs the collective (bench.py --force-gather: the stream layout of N ranks on one GPU)
         self.cuda = device is not None and torch.device(device).type == 'cuda'
         dtype = dtype or torch.float32
         self.local = [torch.zeros((n_local, obs_dim), dtype=dtype, device=device) for _ in range(2)]
@@ -70,7 +71,7 @@ class ObsGatherer:
     def submit(self, slot):
         """enqueue the all-gather of local[slot] -> full[slot]"""
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self.full[slot] = self.local[slot]
             return self.full[slot]
         if not self.cuda:

@@ -17,6 +17,12 @@ import os
 import sys
 import time
 
+# The step is issued on 3 internal chunk streams + the caller's stream; with --gpus N the observation gather adds a side stream and RCCL its
+# own.  HIP maps streams onto 4 hardware queues by default: a 5th stream shares a queue with a chunk stream and serialises two chunks
+# (measured round 3: 4 chunks on 4 queues 324 k vs 466 k env-steps/s).  Must be in the environment before the HIP runtime initialises,
+# i.e. before `import torch`; an explicit setting by the caller wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,6 +32,7 @@ ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 SHADER_CLOCK_HZ = 2.4e9   # same guide: max clock 2400 MHz; 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles
 N_SIMD = 1024
+SURVEY_8D_BYTES = {'feeding_jaco': 4253}     # SURVEY.md 8(d) "Algorithmic bytes per env-step (FeedingJaco)"
 TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the compiled variant, workload description)
     'feeding': ('feeding_jaco', 'FeedingJacoVecEnv', '', 'FeedingJaco-v1'),
     'feedingpanda': ('feeding_panda', 'FeedingPandaVecEnv', '', 'FeedingPanda-v1'),
@@ -251,7 +258,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
     tape = (torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1) * action_scale
     # whole-batch observation collation: RCCL all-gather on a side stream, overlapped with the next step (two buffers alternate)
-    gatherer = ObsGatherer(n, blob.obs_dim, world, device=torch.device('cuda', local_rank)) if distributed else None
+    gatherer = ObsGatherer(n, blob.obs_dim, world, device=torch.device('cuda', local_rank), force=args.force_gather) if distributed else None
 
     def one(k):
         if distributed:
@@ -260,8 +267,20 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         else:
             env.step(tape[k])
 
+    # the contact sampling of the timed loop (torch remainder / cast / mean / add kernels and their allocations) runs in the warm-up too:
+    # the first call of each loads its code object (tens of ms each) -- inside a 20-step timed window that was half of the time
+    # (236 k in the driver's 20-step run vs 471 k over 2,000 steps)
+    ncon_sum, ncon_buf = torch.zeros((), device='cuda', dtype=torch.float64), torch.zeros((), device='cuda', dtype=torch.float64)
+
+    def sample_contacts():
+        torch.mean((env.info[:, 6] % 1000).double(), dim=0, out=ncon_buf)
+        ncon_sum.add_(ncon_buf)
+
     for k in range(W):
         one(k)
+        sample_contacts()
+    sample_contacts()
+    ncon_sum.zero_()
     if distributed:
         gatherer.wait()
     stream = torch.cuda.current_stream().cuda_stream
@@ -271,11 +290,11 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     overflow0 = env.stepper.overflow_count()
     env.stepper.profile_begin(stream)
     t0 = time.perf_counter()
-    ncon_sum, ncon_n = torch.zeros((), device='cuda', dtype=torch.float64), 0
+    ncon_n = 0
     for k in range(W, W + K):
         one(k)
         if (k - W) % 16 == 0:            # contacts of the last substep, sampled (device-side sum, no host sync)
-            ncon_sum += (env.info[:, 6] % 1000).double().mean(); ncon_n += 1
+            sample_contacts(); ncon_n += 1
     kernel_ms = env.stepper.profile_end(stream)
     if distributed:
         gatherer.wait()                  # the last gathers are inside the timed region
@@ -315,6 +334,12 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         bytes_per_env_step = 2 * sw * 4 + blob.act_dim * 4 + blob.obs_dim * 4 + 4 + 1 + 8 * 4
         if has_cloth:                        # + the garment read and written once per env step: node positions and velocities
             bytes_per_env_step += 2 * 6 * env.stepper.cloth_nodes() * 4
+        # `roofline.achieved` uses SURVEY 8d's per-unit figure where the survey gives one (FeedingJaco: 4,253 B per env-step, a 514-word
+        # state incl. a 256-word contact warm-start cache this design does not keep); the bytes of the record this design really moves
+        # (322 words: 2,741 B) stay beside it as `record_bytes_per_env_step`
+        record_bytes_per_env_step = bytes_per_env_step
+        if not blob.is_coop:
+            bytes_per_env_step = SURVEY_8D_BYTES.get(model, bytes_per_env_step)
         names = [k + ksuffix for k in ('agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel')]
         traffic_key = None
         if has_cloth:
@@ -361,7 +386,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': names[dom], 'kernel_ms_per_launch': launch_ms, 'launches_per_step': launches[dom],
                          'chunks': chunks, 'envs_per_launch': envs_per_launch,
-                         'algorithmic_bytes_per_env_step': bytes_per_env_step, 'algorithmic_bytes_per_launch': bytes_per_env_step * units,
+                         'algorithmic_bytes_per_env_step': bytes_per_env_step, 'record_bytes_per_env_step': record_bytes_per_env_step, 'algorithmic_bytes_per_launch': bytes_per_env_step * units,
                          'traffic_over_algorithmic': (traffic / (bytes_per_env_step * units)) if traffic else None,
                          'valu_issue_frac': valu_frac,      # of ONE launch (one chunk of environments); `chunks` such launches share the GPU
                          'valu_issue_frac_all_chunks': (valu_frac * chunks) if valu_frac else None,
@@ -399,8 +424,17 @@ def main():
     ap.add_argument('--param', action='append', default=[], help='override a PARAMS entry of the model blob, e.g. --param NOOP_RETEST=0 (same-box A/B runs)')
     ap.add_argument('--no-configs', action='store_true', help='the default 1-GPU run also times short runs of BASELINE configs 3, 4 (1 GPU), 5 (1 GPU) into "configs"; this skips them')
     ap.add_argument('--backend', default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --dry-run)")
+    ap.add_argument('--force-gather', action='store_true', help='1 GPU: run the multi-GPU code path anyway (a 1-rank RCCL process group, the per-step observation all-gather on its side stream) -- what the stream / hardware-queue layout of --gpus N looks like on one GPU')
     ap.add_argument('--dry-run', action='store_true', help='exercise the launch / sharding / all-gather / timing path on CPU tensors without stepping (no GPU needed; backend gloo)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1) -- the same command
+        # line the driver uses for N > 1; the ranks see WORLD_SIZE and take the branch below
+        import socket
+        import subprocess
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        raise SystemExit(subprocess.call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+                                          '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]))
     if args.dry_run:
         import torch.distributed as dist
         world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
@@ -419,7 +453,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
+    distributed = world > 1 or args.force_gather
+    if args.force_gather and world == 1:
+        import socket
+        sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+        for k, v in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', str(port)), ('RANK', '0'), ('WORLD_SIZE', '1'), ('LOCAL_RANK', '0')):
+            os.environ.setdefault(k, v)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: libagx has no CPU path')
     torch.cuda.set_device(local_rank)

@@ -118,3 +118,20 @@ def test_bench_launch_path_on_gloo(task):
     assert j['n_gpus'] == 2 and j['steps'] == 6 and j['warmup'] == 2 and j['scaling'] == 'weak' and j['dry_run'] and j['config']['global_envs'] == 64
     assert j['config']['gathered_in_global_order'] and j['config']['obs_allgather']
     assert (j['config']['obs_dim'], j['config']['act_dim']) == {'feeding': (25, 7), 'scratchitch': (64, 17), 'dressing': (24, 7)}[task]
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (no WORLD_SIZE in the environment): bench.py becomes the launcher itself, two ranks run
+    and rank 0 prints n_gpus == 2 (`--gpus` used to be parsed and ignored -> n_gpus 1 for every N)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run', '--backend', 'gloo', '--steps', '4', '--warmup', '1', '--envs-per-gpu', '16'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['global_envs'] == 32 and j['config']['gathered_in_global_order'] and j['config']['obs_allgather']
