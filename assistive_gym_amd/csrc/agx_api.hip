@@ -26,14 +26,18 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 // done envs take a fresh record from the pool; coalesced copy, one wave per env
 extern "C" __global__ void __launch_bounds__(64)
-agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* done, int* episode, int n_envs, int sw, long long env_offset) {
+agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* done, int* episode, int n_envs, int sw, long long env_offset, int iter_word, int iteration) {
   const int env = blockIdx.x;
   if (env >= n_envs || !done[env]) return;
   int ep = episode[env] + 1;
   // the pool entry is a function of the GLOBAL environment index: the same env draws the same states on any GPU count
   const float* src = pool + (size_t)((env_offset + env + 977 * (long long)ep) % pool_n) * sw;
   for (int k = threadIdx.x; k < sw; k += 64) state[(size_t)env * sw + k] = src[k];
-  if (threadIdx.x == 0) episode[env] = ep;
+  if (threadIdx.x == 0) {
+    episode[env] = ep;
+    // agx_reset_done_at: the replacement joins the lock-stepped batch at its current iteration (env.py:185), so that it ends with the batch
+    if (iteration >= 0) ((int*)state)[(size_t)env * sw + iter_word] = iteration;
+  }
 }
 
 // ... and, for models with a cloth, the garment that belongs to that pool record (launched after agx_reset_kernel: episode[] is already advanced)
@@ -91,6 +95,7 @@ struct agx_handle_s {
   int *first_restart_dev, *chosen_dev; uint8_t* work_dev;   // reset generator: per-env retry bookkeeping
   long long env_offset;   // global index of env 0 of this handle (multi-GPU sharding), see agx_set_env_offset
   int device, n_envs, act_dim, obs_dim, sw;
+  int iter_word;          // index of AGX_E_ITERATION in a state record (agx_reset_done_at)
   uint32_t* blob_dev;
   float* state_dev;
   float* scratch_dev;   // [n_envs][SCR_WORDS]: rows, predicted velocities, contacts handed between the kernels
@@ -100,6 +105,7 @@ struct agx_handle_s {
   // models with a cloth section (DressingBaxter): garments [n_envs][2][NN][3], the link frames of every substep of an env step for the
   // cloth kernel, its report to the finish kernel, and the garments of the reset pool (agx_set_cloth_pool)
   int cloth_nn, cloth_words, trace_words, report_words, cloth_lds;
+  bool particles;       // the "cloth" section holds the water particles of the drinking scene (AGX_CL_PARTICLES), not a garment
   float *cloth_dev, *trace_dev, *report_dev; const float* cloth_pool_dev;
   bool can_sample;      // the variant has a reset generator (agx_reset.h) and the blob fits it
   const uint8_t* active;// per-env mask honoured by the build / solve launches (agx_reset's masked settle), normally null
@@ -194,6 +200,7 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
 // the allocations of agx_create; on failure the caller destroys the partly filled handle
 static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_envs, int device) {
   const int32_t* hi = (const int32_t*)blob; const agx_variant* V = h->V; const bool can_sample = h->can_sample;
+  h->iter_word = hi[AGX_H_S_ENV] + AGX_E_ITERATION;
   h->device = device; h->n_envs = n_envs; h->act_dim = hi[AGX_H_ACT_DIM]; h->obs_dim = hi[AGX_H_OBS_DIM]; h->sw = hi[AGX_H_STATE_WORDS];
   HIPCHK(hipMalloc(&h->blob_dev, blob_bytes));
   HIPCHK(hipMemcpy(h->blob_dev, blob, blob_bytes, hipMemcpyHostToDevice));
@@ -214,6 +221,7 @@ static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_
     h->cloth_words = 6 * h->cloth_nn; h->report_words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn) + AGX_CLOTH_SCRATCH_WORDS(h->cloth_nn);
     h->trace_words = h->frame_skip * h->sim_sub * (hi[AGX_H_NDOF] + hi[AGX_H_NFREE]) * 12;      // per substep: the frames of the moving links, then of the free bodies
     h->cloth_lds = V->cloth_lds_bytes(h->cloth_nn);          // agxc::lds_words of the variant's own cloth kernel
+    h->particles = cl[AGX_CL_PARTICLES] != 0;
     if (cl[AGX_CL_PARTICLES]) {      // the water of the drinking scene (agx_water.h): one wavefront, lane = particle; report = one word per particle
       h->report_words = 64;
       if (h->cloth_nn > 64 || cl[AGX_CL_NSHAPE] > 192 || hi[AGX_H_NDOF] + hi[AGX_H_NHUMAN] + hi[AGX_H_NFREE] + 2 > 64 || hi[AGX_H_TASK_KIND] != AGX_TASK_DRINKING)
@@ -384,10 +392,11 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
   if (launches3) { launches3[0] = cnt[0]; launches3[1] = cnt[1]; launches3[2] = cnt[2]; }
   return AGX_OK;
 }
-int agx_observe(agx_handle h, float* obs, void* stream) {
+int agx_observe(agx_handle h, float* obs, void* stream) { return agx_observe_masked(h, obs, nullptr, stream); }
+int agx_observe_masked(agx_handle h, float* obs, const uint8_t* mask_dev, void* stream) {
   if (!h || !obs) return fail(AGX_E_ARG, "agx_observe: bad argument");
   HIPCHK(hipSetDevice(h->device));
-  h->V->observe((hipStream_t)stream, h->n_envs, h->blob_dev, h->state_dev, obs, h->sw, h->obs_dim);
+  h->V->observe((hipStream_t)stream, h->n_envs, h->blob_dev, h->state_dev, obs, h->sw, h->obs_dim, mask_dev);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -428,7 +437,7 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
                  gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev, settled, settled_sw);
     HIPCHK(hipGetLastError());
   }
-  if (h->cloth_dev) {      // the garment goes where the sampled end effector is
+  if (h->cloth_dev && !h->particles) {      // the garment goes where the sampled end effector is (dressing task words; the water has its own placement)
     hipLaunchKernelGGL(agx_place_cloth_kernel, dim3(h->n_envs), dim3(256), 0, st, h->cloth_dev, h->state_dev, h->blob_dev, mask_dev, h->n_envs, h->sw, h->cloth_words);
     HIPCHK(hipGetLastError());
   }
@@ -454,17 +463,19 @@ int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, 
   h->active = mask_dev;   // the settle substeps touch the masked environments only
   rc = launch_chunked(h, settle_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
   h->active = nullptr;
-  if (!rc && h->cloth_dev) {
+  if (!rc && h->cloth_dev && !h->particles) {
     hipLaunchKernelGGL(agx_cloth_gravity_kernel, dim3((h->n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->state_dev, h->blob_dev, mask_dev, h->n_envs, h->sw);
     HIPCHK(hipGetLastError());
   }
   return rc;
 }
-int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) {
+int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream) { return agx_reset_done_at(h, pool_dev, pool_n, done_dev, -1, stream); }
+int agx_reset_done_at(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, int iteration, void* stream) {
   if (!h || !pool_dev || pool_n <= 0 || !done_dev) return fail(AGX_E_ARG, "agx_reset_done: bad argument");
   HIPCHK(hipSetDevice(h->device));
   if (h->cloth_dev && !h->cloth_pool_dev) return fail(AGX_E_ARG, "agx_reset_done: the model has a cloth; give the garments of the pool with agx_set_cloth_pool first");
-  hipLaunchKernelGGL(agx_reset_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->state_dev, pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->sw, h->env_offset);
+  hipLaunchKernelGGL(agx_reset_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->state_dev, pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->sw, h->env_offset,
+                     h->iter_word, iteration);
   HIPCHK(hipGetLastError());
   if (h->cloth_dev) {
     hipLaunchKernelGGL(agx_reset_cloth_kernel, dim3(h->n_envs), dim3(256), 0, (hipStream_t)stream, h->cloth_dev, h->cloth_pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->cloth_words, h->env_offset);

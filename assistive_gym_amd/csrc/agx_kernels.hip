@@ -207,10 +207,10 @@ AGX_K(agx_cloth_kernel)(const uint32_t* __restrict__ blob, const float* __restri
 }
 #endif
 extern "C" __global__ void __launch_bounds__(64, 2)
-AGX_K(agx_observe_kernel)(const uint32_t* __restrict__ blob, float* state, float* obs, int n_envs, int sw, int obs_dim) {
+AGX_K(agx_observe_kernel)(const uint32_t* __restrict__ blob, float* state, float* obs, int n_envs, int sw, int obs_dim, const uint8_t* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = blockIdx.x;
-  if (env >= n_envs) return;
+  if (env >= n_envs || (mask && !mask[env])) return;
   agx::env_observe(blob, state + (size_t)env * sw, obs + (size_t)env * obs_dim, lds, (int)threadIdx.x);
 }
 // after a build-kernel pass: the collision flags of every environment's state (agx_check_collisions)
@@ -290,8 +290,8 @@ void v_cloth(hipStream_t st, int ne, const uint32_t* blob, const float* state, c
                      report_words, nsub, active);
 }
 #endif
-void v_observe(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim) {
-  hipLaunchKernelGGL(AGX_K(agx_observe_kernel), dim3(n_envs), dim3(64), agx::LDS_BYTES, st, blob, state, obs, n_envs, sw, obs_dim);
+void v_observe(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim, const uint8_t* mask) {
+  hipLaunchKernelGGL(AGX_K(agx_observe_kernel), dim3(n_envs), dim3(64), agx::LDS_BYTES, st, blob, state, obs, n_envs, sw, obs_dim, mask);
 }
 #if AGX_HAS_SAMPLER
 void v_sample(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,

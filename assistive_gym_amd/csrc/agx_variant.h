@@ -21,7 +21,7 @@ struct agx_variant {
   void (*solve)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase);
   void (*finish)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
                  float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words, float* cloth, int cloth_words);   // cloth: the water buffer for the drinking task layer (teleports drunk particles), unused elsewhere
-  void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim);
+  void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim, const uint8_t* mask);   // mask: null = every environment
   void (*sample)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
                  int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen,
                  const float* settled, int settled_sw);   // null without a reset generator; settled: [n_envs][settled_sw] records of the attached rag-doll model (or null)

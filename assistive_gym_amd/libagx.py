@@ -13,7 +13,7 @@ _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_cloth_nodes', 'agx_set_cloth', 'agx_get_cloth', 'agx_cloth_dev', 'agx_set_cloth_pool', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
-           'agx_observe', 'agx_sample_reset', 'agx_reset', 'agx_attach_settle_model', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
+           'agx_observe', 'agx_observe_masked', 'agx_reset_done_at', 'agx_sample_reset', 'agx_reset', 'agx_attach_settle_model', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset', 'agx_check_collisions',
            'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather']
 
@@ -154,6 +154,18 @@ class Stepper:
         v.__cuda_array_interface__ = dict(shape=(self.n_envs, self.state_words), typestr='<f4', data=(self.state_dev(), False), version=2, strides=None)
         return torch.as_tensor(v, device='cuda:%d' % self.device)
 
+    def cloth_tensor(self):
+        """the garments as a torch tensor over the handle's own device memory (float32 [n_envs, 2, nodes, 3], no copy)"""
+        import torch
+        p = C.c_void_p()
+        check(self.L.agx_cloth_dev(self.h, C.byref(p)), 'agx_cloth_dev')
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = dict(shape=(self.n_envs, 2, self.cloth_nodes(), 3), typestr='<f4', data=(p.value, False), version=2, strides=None)
+        return torch.as_tensor(v, device='cuda:%d' % self.device)
+
     def settle(self, n_substeps, stream=0):
         check(self.L.agx_settle(self.h, C.c_int(n_substeps), C.c_void_p(stream)), 'agx_settle')
 
@@ -172,8 +184,9 @@ class Stepper:
         check(self.L.agx_step_timed(self.h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), C.c_void_p(stream), ms, cnt), 'agx_step_timed')
         return [ms[0], ms[1], ms[2]], [cnt[0], cnt[1], cnt[2]]
 
-    def observe_dev(self, obs, stream=0):
-        check(self.L.agx_observe(self.h, _ptr(obs), C.c_void_p(stream)), 'agx_observe')
+    def observe_dev(self, obs, stream=0, mask=None):
+        """mask: uint8 device tensor, only those environments' rows are written (agx_observe_masked)"""
+        check(self.L.agx_observe_masked(self.h, _ptr(obs), _ptr(mask), C.c_void_p(stream)), 'agx_observe_masked')
 
     IMPAIRMENT_MODES = {'random': -1, 'no_tremor': -2, 'none': 0, 'limits': 1, 'weakness': 2, 'tremor': 3}
     GENDER_MODES = {'random': -1, 'male': 0, 'female': 1}
@@ -195,8 +208,9 @@ class Stepper:
         check(self.L.agx_attach_settle_model(self.h, other.h if other is not None else None, C.c_int(n_substeps)), 'agx_attach_settle_model')
         self._settle_model = other
 
-    def reset_done(self, pool, pool_n, done, stream=0):
-        check(self.L.agx_reset_done(self.h, _ptr(pool), C.c_int(pool_n), _ptr(done), C.c_void_p(stream)), 'agx_reset_done')
+    def reset_done(self, pool, pool_n, done, stream=0, iteration=-1):
+        """iteration >= 0: the replacement states join the batch at that iteration (agx_reset_done_at)"""
+        check(self.L.agx_reset_done_at(self.h, _ptr(pool), C.c_int(pool_n), _ptr(done), C.c_int(iteration), C.c_void_p(stream)), 'agx_reset_done_at')
 
     def step_host(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, self.act_dim)

@@ -252,6 +252,12 @@ class AssistiveVecEnv:
         s = self._stream()
         if self.reset_mode == 'device':
             self._fresh_reset(None, s)
+            # rescue pool for environments the non-finite guard ends mid-episode (step()): the first start states of this batch
+            k = min(self.n_envs, 64 if self.stepper.cloth_nodes() > 0 else 256)
+            self._rescue = self.stepper.state_tensor()[:k].clone()
+            if self.stepper.cloth_nodes() > 0:
+                self._rescue_cloth = self.stepper.cloth_tensor()[:k].clone()
+                self.stepper.set_cloth_pool(self._rescue_cloth)
         else:
             if self.pool is None:
                 self.pool_host = build_reset_pool(self.blob, self.pool_size, self.seed, self.device_index, self.impairment,
@@ -290,6 +296,16 @@ class AssistiveVecEnv:
                 self.stepper.reset_done(self.pool, self.pool_size, self.done, s)
             elif boundary:
                 self._fresh_reset(self.done, s)
+            else:
+                # an environment ended by the non-finite guard mid-episode (done = 1, zeroed outputs): replaced at once from the rescue pool
+                # (the first states this batch was started from), joining the batch at its current iteration so that it reaches the
+                # 200-step boundary -- where the masked agx_reset samples every environment anew -- together with the others.  No host
+                # round trip: the kernel does nothing for environments that are not done.
+                self.stepper.reset_done(self._rescue, len(self._rescue), self.done, s, iteration=self._t % self.episode_len)
+            if not boundary:
+                # ... and the row of such an environment becomes the first observation of its new episode, as at a boundary
+                # (also the short episodes of workload-specific pools, bench.py --workload wiping); other rows are untouched
+                self.stepper.observe_dev(self.obs, s, mask=self.done)
             if boundary:
                 # vector-env convention: the observation returned with done is the first one of the new episode
                 # (`return self._get_obs()` of reset(), feeding.py:182); the last one of the old episode is kept aside

@@ -95,6 +95,9 @@ int agx_overflow_count(agx_handle h, int* out);
 int agx_step_timed(agx_handle h, const float* actions_dev, float* obs_dev, float* reward_dev,
                    uint8_t* done_dev, float* info_dev, void* stream, float* ms3, int* launches3);
 int agx_observe(agx_handle h, float* obs_dev, void* stream);
+/* ... for the environments with mask_dev[i] != 0 only (the rows of the others are left as they are); mask_dev NULL = all.
+ * The first observation of environments replaced mid-batch by agx_reset_done / agx_reset */
+int agx_observe_masked(agx_handle h, float* obs_dev, const uint8_t* mask_dev, void* stream);
 /* Overwrites the state record of EVERY env of the handle with a freshly sampled pre-settle reset state; env i
  * is a pure function of (seed + i) (counter-based Philox4x32-10 draws, so the result does not depend on
  * how envs are spread over handles or GPUs).  impairment_mode: -1 = random over none/limits/weakness/tremor
@@ -126,6 +129,10 @@ int agx_attach_settle_model(agx_handle h, agx_handle settle, int n_substeps);
  * (env_offset + env_index + 977 * episode_count) mod pool_n with env_offset = the global index of this handle's first env
  * (agx_set_env_offset, default 0), so results do not depend on how the envs are spread over GPUs */
 int agx_reset_done(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, void* stream);
+/* the same for an environment that ends OUTSIDE the batch's episode boundary (the non-finite guard of agx_step reports done = 1 mid-episode;
+ * the reference's nearest analogue is the forced reconnect of env.py:93-97): the replacement state joins the lock-stepped batch at
+ * `iteration` (env.py:185; < 0: keep the pool record's own), so that it reaches `done` (feeding.py:37) together with the others */
+int agx_reset_done_at(agx_handle h, const float* pool_dev, int pool_n, const uint8_t* done_dev, int iteration, void* stream);
 /* Collision rejection for resets sampled on the host (env.py:276-310 init_robot_pose, robot.py:103-108): runs the stepper's collision
  * pass on the states as they are (they are not advanced) and writes one byte of AGX_COLLIDE_* flags per environment to the HOST buffer
  * flags_host[n_envs].  Synchronises the stream. */

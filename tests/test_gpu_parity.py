@@ -371,28 +371,43 @@ def test_golden_trajectory_replay(gpu_lib, blob):
     st.close()
 
 
-def test_nonfinite_environment_is_flagged_masked_and_replaced(gpu_lib, blob):
-    """one environment of the batch goes NaN -> it alone reports done with zeroed observation / reward and the
-    AGX_INFO_NONFINITE marker; the pool auto-reset replaces its state and the next step is finite everywhere"""
+@pytest.mark.parametrize('reset', ['pool', 'device'])
+def test_nonfinite_environment_is_flagged_masked_and_replaced(gpu_lib, blob, reset):
+    """one environment of the batch goes NaN mid-episode -> it alone reports done with a zero reward and the AGX_INFO_NONFINITE
+    marker; it is replaced AT ONCE (reset='pool': from the pool; reset='device': from the rescue pool, joining the batch at its current
+    iteration so that the masked re-sampling at the 200-step boundary finds the batch in lock step) and its row of the observations is
+    the first observation of its new episode -- what a vector-env consumer expects with done -- not a stream of zeroed 1-step episodes"""
     import torch
     from assistive_gym_amd.vec_env import FeedingJacoVecEnv
     n = 64
-    env = FeedingJacoVecEnv(n, pool_size=16, seed=4242)
+    env = FeedingJacoVecEnv(n, pool_size=16, seed=4242, reset=reset)
     env.reset()
+    a = torch.zeros((n, env.act_dim), device='cuda')
+    for _ in range(3):
+        env.step(a)
     st = env.stepper.get_state()
     blob.view(st)['q'][5, 1] = np.nan
     blob.view(st)['free'][9, 0, 0] = np.inf
     env.stepper.set_state(st)
-    a = torch.zeros((n, env.act_dim), device='cuda')
     obs, rew, done, info = env.step(a)
     torch.cuda.synchronize()
     bad = (info[:, 6] >= 1.0e6).cpu().numpy()
     assert list(np.nonzero(bad)[0]) == [5, 9]
     assert done.cpu().numpy()[bad].all() and not done.cpu().numpy()[~bad].any()
-    assert (obs[5] == 0).all() and (obs[9] == 0).all() and float(rew[5]) == 0.0 and torch.isfinite(obs).all() and torch.isfinite(rew).all()
-    obs, rew, done, info = env.step(a)                        # replaced from the pool by the auto-reset
+    assert float(rew[5]) == 0.0 and float(rew[9]) == 0.0 and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    now = env.stepper.get_state()
+    assert np.isfinite(now[:, :42]).all()
+    fresh = env.stepper.observe_host()
+    assert np.array_equal(obs.cpu().numpy()[bad], fresh[bad]) and np.abs(fresh[bad]).max() > 0     # first observation of the replacement
+    it = blob.view(now)['iteration']
+    if reset == 'device':
+        assert (it == 4).all()                                # the replacements joined the batch at its iteration
+    else:
+        assert (it[~bad] == 4).all() and (it[bad] == 0).all()   # pool records start their own 200-step episode
+    for _ in range(3):
+        obs, rew, done, info = env.step(a)
     torch.cuda.synchronize()
-    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and not (info[:, 6] >= 1.0e6).any() and np.isfinite(env.stepper.get_state()[:, :42]).all()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and not (info[:, 6] >= 1.0e6).any() and not done.any()
     env.close()
 
 
