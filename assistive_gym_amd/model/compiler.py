@@ -211,7 +211,14 @@ def compile_robot(urdf_path, arm_joints, gripper_joints, gripper_target, motor_g
             dof_of_pb[j.index] = len(dof_links)
             dof_links.append(j.index)
     # carrier (moving ancestor, or -1 for base) and transform link-frame-in-carrier-frame for every link
-    carrier, rel = {-1: -1}, {-1: (np.zeros(3), np.array([0, 0, 0, 1.0]))}
+    # The BASE FRAME of the model is the root link's INERTIAL frame: p.resetBasePositionAndOrientation / p.getBasePositionAndOrientation
+    # (agent.py:142-150, the frame of Robot.set_base_pos_orient, init_robot_pose's placements and convert_to_realworld) address the centre of
+    # mass of the base, not the URDF link frame (PyBullet quickstart guide: "the position is of the center of mass"; loadURDF's basePosition
+    # is the one that means the link frame) [BULLET-UNVERIFIED].  Only two of the reference's robots have a root link whose inertial origin is
+    # not zero: the Sawyer's base (-0.1, 0, 0.07) and the Stretch's base_link (-0.109, -0.0007, 0.0915: toc_base_pos_offset z = 0.09 is that
+    # height, i.e. the wheels start on the ground).
+    root = u.link_by_index(-1)
+    carrier, rel = {-1: -1}, {-1: X.invert(root.com_pos, root.com_quat)}
     for j in u.indexed_joints:
         pidx = u.links[j.parent].index
         if j.index in dof_of_pb:

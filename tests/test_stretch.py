@@ -89,7 +89,7 @@ def test_wheels_roll_and_turn_as_a_differential_drive(rb, friction):
         b.view(s[None])['plane_friction'][0] = friction
         o.settle(s, 25)
         q0 = b.view(s[None])['q'][0].copy()
-        assert abs(q0[2] + 0.09) < 2e-3                                                                          # dropped from z = 0.09 onto its wheels
+        assert abs(q0[2]) < 4e-3                                                                                 # placed with its centre of mass at z = 0.09 (stretch.py:37: PyBullet's base frame is the inertial frame), i.e. ON its wheels: it stays there
         a = np.zeros(5, np.float32)
         a[0], a[1] = aw
         for k in range(20):
@@ -99,7 +99,10 @@ def test_wheels_roll_and_turn_as_a_differential_drive(rb, friction):
         # the target of an env step is the wheel angle + 5 x 0.05 x 3 (env.py:188,197,201-216); the position motor with gain 0.1 (stretch.py:49)
         # closes a tenth of the remaining error per substep, well below its 10 N
         assert np.allclose(np.abs(dth), 20 * 0.75 * (1 - 0.9 ** 5) * np.abs(aw), rtol=0.02)
-        dist, yaw = np.linalg.norm(q1[:2] - q0[:2]), q1[3] - q0[3]
+        # q[:3] is the base's centre of mass (the model's base frame, PyBullet's); the point the drive turns about is the middle of the axle =
+        # the origin of base_link, at -inertial origin (stretch_uncalibrated.urdf: -0.1095, -0.0007) in that frame
+        axle = lambda q: q[:2] + np.array([[np.cos(q[3]), -np.sin(q[3])], [np.sin(q[3]), np.cos(q[3])]]) @ np.array([0.109461304328163, 0.000741018909047708])
+        dist, yaw = np.linalg.norm(axle(q1) - axle(q0)), q1[3] - q0[3]
         want_dist, want_yaw = r * dth.mean(), r * (dth[0] - dth[1]) / track
         assert abs(q1[2] - q0[2]) < 1e-3 and np.all(np.abs(q1[4:6]) < 5e-3), name
         if name == 'forward':
@@ -219,7 +222,7 @@ def test_other_tasks_reset_stand_and_drive(tb):
         v['plane_friction'][0] = 0.5
         o.settle(s, 15)
         q0 = b.view(s[None])['q'][0].copy()
-        assert abs(q0[2] + 0.09) < 2e-3 and np.all(np.abs(q0[3:6]) < 0.02)
+        assert abs(q0[2]) < 4e-3 and np.all(np.abs(q0[3:6]) < 0.02)
         a = np.zeros(b.act_dim, np.float32)
         a[0] = a[1] = 1.0
         for k in range(10):
