@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 DEPS = [os.path.join(CSRC, f) for f in sorted(f for f in os.listdir(CSRC) if f.endswith(('.h', '.hip')))] + \
        [os.path.join(os.path.dirname(HERE), 'include', f) for f in ('agx.h', 'agx_blob.h')]
 OUT = os.path.join(HERE, 'lib', 'libagx.so')
-VARIANTS = ['FEEDING', 'FEEDING_L', 'FEEDING_M', 'BED_BATHING', 'BED_BATHING_L', 'BED_BATHING_M', 'SCRATCH_ITCH', 'SCRATCH_ITCH_M', 'BED_SETTLE', 'DRESSING', 'DRESSING_L', 'DRESSING_M', 'ARM_MANIPULATION', 'ARM_MANIPULATION_L', 'DRINKING']
+VARIANTS = ['FEEDING', 'FEEDING_L', 'FEEDING_M', 'BED_BATHING', 'BED_BATHING_L', 'BED_BATHING_M', 'SCRATCH_ITCH', 'SCRATCH_ITCH_M', 'BED_SETTLE', 'DRESSING', 'DRESSING_L', 'DRESSING_M', 'ARM_MANIPULATION', 'ARM_MANIPULATION_L', 'DRINKING', 'DRINKING_L', 'DRINKING_M']
 
 
 def build(force=False, verbose=False, extra=(), out=None):

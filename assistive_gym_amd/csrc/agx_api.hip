@@ -49,6 +49,19 @@ agx_reset_cloth_kernel(float* cloth, const float* pool, int pool_n, const uint8_
   for (int k = threadIdx.x; k < cw; k += 256) cloth[(size_t)env * cw + k] = src[k];
 }
 
+// drinking, device-side reset: the 4 x 4 x 4 grid of water spheres above the cup's base frame position, world axes, at rest (drinking.py:160-167)
+extern "C" __global__ void __launch_bounds__(64)
+agx_place_water_kernel(float* water, const float* state, const uint32_t* blob, const uint8_t* mask, int n_envs, int sw, int cw) {
+  const int env = blockIdx.x;
+  if (env >= n_envs || (mask && !mask[env])) return;
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  const int oc = bi[AGX_H_OFF_CLOTH]; const int nn = bi[oc + AGX_CL_NN];
+  const float* x0 = bf + oc + bi[oc + AGX_CL_OFF_X0];
+  const float* cup = state + (size_t)env * sw + bi[AGX_H_S_FREE] + 13 * bi[AGX_H_TOOL_BODY];      // the cup's record holds its base frame (REFPOS = 0, compile_feeding)
+  float* c = water + (size_t)env * cw;
+  for (int k = threadIdx.x; k < 3 * nn; k += 64) { c[k] = x0[k] + cup[k % 3]; c[3 * nn + k] = 0.f; }
+}
+
 // models with a cloth, device-side reset: the garment of a freshly sampled environment is the loaded mesh shifted to the end effector
 // (dressing.py:146-153: x = X0 + offset; the reset generator left the offset in the task words, AGX_DR_CLOTH_OFF), at rest
 extern "C" __global__ void __launch_bounds__(256)
@@ -142,9 +155,9 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   const agx_variant* V = nullptr;
   {
     // the first (smallest) variant with the model's task layer whose limits hold the model
-    const agx_variant* all[15] = {agx_variant_feeding(), agx_variant_feeding_l(), agx_variant_feeding_m(), agx_variant_bed_bathing(), agx_variant_bed_bathing_l(), agx_variant_bed_bathing_m(),
+    const agx_variant* all[17] = {agx_variant_feeding(), agx_variant_feeding_l(), agx_variant_feeding_m(), agx_variant_bed_bathing(), agx_variant_bed_bathing_l(), agx_variant_bed_bathing_m(),
                                  agx_variant_scratch_itch(), agx_variant_scratch_itch_m(), agx_variant_bed_settle(),
-                                 agx_variant_dressing(), agx_variant_dressing_l(), agx_variant_dressing_m(), agx_variant_arm_manipulation(), agx_variant_arm_manipulation_l(), agx_variant_drinking()};
+                                 agx_variant_dressing(), agx_variant_dressing_l(), agx_variant_dressing_m(), agx_variant_arm_manipulation(), agx_variant_arm_manipulation_l(), agx_variant_drinking(), agx_variant_drinking_l(), agx_variant_drinking_m()};
     bool task_seen = false;
     for (const agx_variant* v : all) {
       if (v->task_kind != hi[AGX_H_TASK_KIND]) continue;
@@ -435,6 +448,10 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
     HIPCHK(hipGetLastError());
     h->V->sample(st, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, h->work_dev, impairment_mode,
                  gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev, settled, settled_sw);
+    HIPCHK(hipGetLastError());
+  }
+  if (h->cloth_dev && h->particles) {       // the water goes into the sampled cup
+    hipLaunchKernelGGL(agx_place_water_kernel, dim3(h->n_envs), dim3(64), 0, st, h->cloth_dev, h->state_dev, h->blob_dev, mask_dev, h->n_envs, h->sw, h->cloth_words);
     HIPCHK(hipGetLastError());
   }
   if (h->cloth_dev && !h->particles) {      // the garment goes where the sampled end effector is (dressing task words; the water has its own placement)

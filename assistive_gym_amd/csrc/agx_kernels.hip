@@ -122,6 +122,23 @@
 #define AGX_ARENA_WORDS 4040
 #define AGX_VNAME feeding_m
 #define AGX_K(name) name##_fm
+#elif defined(AGX_VARIANT_DRINKING_L)
+// the drinking scene with the PR2's arm: 7 arm + 4 finger joints in one articulated body
+#define AGX_MAX_FREE 1
+#define AGX_MAX_BLOCK 12
+#define AGX_ARENA_WORDS 4040
+#define AGX_TASK 5
+#define AGX_VNAME drinking_l
+#define AGX_K(name) name##_dkl
+#elif defined(AGX_VARIANT_DRINKING_M)
+// the drinking scene with the mobile manipulator (DrinkingStretch): as feeding_m -- 16 DoFs on a floating base + the 4 head joints
+#define AGX_MAX_FREE 1
+#define AGX_MAX_DOF 20
+#define AGX_MAX_BLOCK 16
+#define AGX_ARENA_WORDS 4040
+#define AGX_TASK 5
+#define AGX_VNAME drinking_m
+#define AGX_K(name) name##_dkm
 #elif defined(AGX_VARIANT_DRINKING)
 // DrinkingJaco: the feeding scene's robot and person, the cup as the one free body (68 hulls), no food; plus the water kernel (agx_water.h)
 #define AGX_MAX_FREE 1

@@ -408,9 +408,13 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     d3 goals[3]; const bool goal_orient = XI(c, AGX_X_TOC_GOAL_ORIENT) != 0;
     const int ngoals = XI(c, AGX_X_TOC_NGOALS);
     for (int k = 0; k < 3; k++) goals[k] = dmk(0, 0, 0);
-    if (XI(c, AGX_X_TOC_GOAL_KIND) == 1) {       // feeding: the mouth (feeding.py:142, 184-196)
+    const int goal_kind = XI(c, AGX_X_TOC_GOAL_KIND);
+    if (goal_kind == 1 || goal_kind == 2) {      // feeding: the mouth (feeding.py:142, 184-196)
       d3 hp; dq hq; rs_link_pose(c, c.xi[XI(c, AGX_X_OFF_DYN) + head_link - nrobot], hp, hq);
       goals[0] = hp + dqrot(hq, dld3(c.task + (c.gender ? AGX_T_MOUTH_F : AGX_T_MOUTH_M)));
+      // drinking (kind 2, drinking.py:143): start_pos_orient = [(start pose), (mouth, None)] -- BOTH must be reached for a base pose to count
+      // (robot.py:196-200) -- and the mouth with the start pose's end-effector orientation as the one further goal
+      goals[1] = goals[0];
     } else
       for (int k = 0; k < ngoals; k++) { dq gq; rs_link_pose(c, XI(c, AGX_X_TOC_GOAL_LINKS + k), goals[k], gq); goals[k] = goals[k] + dld3(c.xf + AGX_X_TOC_GOAL_OFF); }
     const int nped = XI(c, AGX_X_PED_N);
@@ -438,8 +442,8 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
 #pragma unroll
           for (int d = 0; d < RS_NARM; d++) q[d] = lo[d] + (hi[d] - lo[d]) * rs_u01(seed_lo, seed_hi, stream, RS_T_REST + 8 * g + d);     // agent.py:263
           const d3 tp = g == 0 ? tpos : goals[g - 1];
-          const bool orient = g == 0 || goal_orient;
-          const dq tq = g == 0 ? tquat : dld4(c.xf + AGX_X_TOC_GOAL_QUAT + 4 * (g - 1));
+          const bool orient = g == 0 || goal_orient || (goal_kind == 2 && g == 2);
+          const dq tq = (g == 0 || goal_kind == 2) ? tquat : dld4(c.xf + AGX_X_TOC_GOAL_QUAT + 4 * (g - 1));
           if (orient) rs_ik<true>(c, q, lo, hi, tp, tq, titers); else rs_ik<false>(c, q, lo, hi, tp, tq, titers);
           d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
           rs_arm_fk(c, q, pos, axw, pe, oe);
@@ -466,7 +470,8 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
           if (hit) { reached |= 1 << g; manip += rs_jlwki(c, q); }
         }
       }
-      const int ngoal = (active && (reached & 1)) ? __builtin_popcount(reached) : -1;            // the start pose must be reachable (robot.py:196-200)
+      const int must = goal_kind == 2 ? 3 : 1;                                                     // the start goals must be reachable (robot.py:196-200)
+      const int ngoal = (active && (reached & must) == must) ? __builtin_popcount(reached) : -1;
       int bl = 0, bn = -2; double bm = -1e300;
       for (int l = 0; l < AGX_WAVE; l++) {
         const int nl = wave_bcast_i(ngoal, l); const double ml = wave_bcast_d(manip, l);
@@ -612,6 +617,12 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     ei[AGX_E_RNG] = (int)((seed * 2654435761ull + 12345ull) & 0x7FFFFFFFull);
     ei[AGX_E_RNG + 1] = (int)((seed ^ 0x5bd1e995ull) & 0x7FFFFFFFull);
     ei[AGX_E_TOTAL_FOOD] = (xflags & 6) ? 1 : nfood;               // scratch itch, dressing: task_success >= 1 x task_success_threshold (scratch_itch.py:37)
+    if (c.bi[AGX_H_TASK_KIND] == AGX_TASK_DRINKING) {               // self.waters / self.waters_active: every particle (drinking.py:168-172)
+      const int nw = c.bi[c.bi[AGX_H_OFF_CLOTH] + AGX_CL_NN];
+      ei[AGX_E_TOTAL_FOOD] = nw;                                    // total_water_count
+      unsigned* tw = (unsigned*)(gstate + c.bi[AGX_H_S_TASK]);
+      for (int t = 0; t < 2; t++) { const unsigned m = nw >= 32 * (t + 1) ? 0xffffffffu : (nw > 32 * t ? (1u << (nw - 32 * t)) - 1u : 0u); tw[AGX_DK_ALIVE + t] = m; tw[AGX_DK_ACTIVE + t] = m; }
+    }
     if (xflags & 64) {   // bed bathing: generate_targets (bed_bathing.py:173-188) -- every target of this gender's two tables is alive
       const int* nt4 = (const int*)c.task + AGX_T_NT;
       const int nt = nt4[2 * c.gender] + nt4[2 * c.gender + 1];

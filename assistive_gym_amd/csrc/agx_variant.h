@@ -54,3 +54,5 @@ extern "C" const agx_variant* agx_variant_dressing_m(void);
 extern "C" const agx_variant* agx_variant_dressing_l(void);
 extern "C" const agx_variant* agx_variant_arm_manipulation_l(void);
 extern "C" const agx_variant* agx_variant_drinking(void);
+extern "C" const agx_variant* agx_variant_drinking_l(void);
+extern "C" const agx_variant* agx_variant_drinking_m(void);

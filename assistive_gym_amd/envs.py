@@ -246,6 +246,39 @@ class FeedingPandaHumanEnv(FeedingPandaEnv):
     coop = True
 
 
+class DrinkingJacoEnv(AssistiveEnv):
+    """DrinkingJaco-v1 (drinking_envs.py:29-31): the wheelchair-mounted Jaco tilts a cup with 64 water particles at the person's mouth.
+    The water lives next to the state record on the device (float32 [2, 64, 3]: positions, velocities)."""
+    model, task = 'drinking_jaco', 'drinking'
+
+    def reset(self):
+        """DrinkingEnv.reset (drinking.py:122-181) on the device: human, target, robot start pose (IK restarts / base pose search / placement
+        draws with collision rejection), cup, the 4 x 4 x 4 water grid above it, then the 50 steps in which the water drops into the cup"""
+        st = self._ensure_stepper()
+        self.reset_seed = self._draw_seed()
+        st.sample_reset(self.reset_seed, impairment='random')
+        st.settle(50)                                                                              # drinking.py:176-177
+        self.iteration, self.task_success = 0, 0
+        return self._split_obs(st.observe_host()[0].astype(np.float64))
+
+    # the water lives outside the state record: a state is the pair (record, water[2][64][3])
+    def get_state(self):
+        st = self._ensure_stepper()
+        return st.get_state()[0], st.get_cloth()[0]
+
+    def set_state(self, state):
+        if not (isinstance(state, (tuple, list)) and len(state) == 2):
+            raise ValueError('a drinking state is the pair (state record, water): pass what get_state() returned')
+        st = self._ensure_stepper()
+        st.set_state(np.asarray(state[0], dtype=np.float32).reshape(1, -1))
+        st.set_cloth(np.ascontiguousarray(state[1], dtype=np.float32)[None])
+
+
+class DrinkingJacoHumanEnv(DrinkingJacoEnv):
+    """DrinkingJacoHuman-v1 (drinking_envs.py:56-59): the human's head joints are controllable too"""
+    coop = True
+
+
 class BedBathingSawyerEnv(AssistiveEnv):
     """BedBathingSawyer-v1 (bed_bathing_envs.py:23-25): Sawyer wipes the right arm of a human lying on a bed."""
     model, task = 'bed_bathing_sawyer', 'bed_bathing'
@@ -400,7 +433,7 @@ ENV_IDS = {'FeedingSawyer-v1': FeedingSawyerEnv, 'FeedingSawyerHuman-v1': Feedin
            'ScratchItchJaco-v1': ScratchItchJacoEnv, 'ScratchItchJacoHuman-v1': ScratchItchJacoHumanEnv, 'ScratchItchPanda-v1': ScratchItchPandaEnv,
            'ScratchItchPandaHuman-v1': ScratchItchPandaHumanEnv, 'ScratchItchSawyer-v1': ScratchItchSawyerEnv, 'ScratchItchSawyerHuman-v1': ScratchItchSawyerHumanEnv,
            'FeedingPanda-v1': FeedingPandaEnv, 'FeedingPandaHuman-v1': FeedingPandaHumanEnv, 'ArmManipulationSawyer-v1': ArmManipulationSawyerEnv, 'ArmManipulationSawyerHuman-v1': ArmManipulationSawyerHumanEnv, 'DressingBaxter-v1': DressingBaxterEnv, 'DressingBaxterHuman-v1': DressingBaxterHumanEnv, 'ScratchItchPR2-v1': ScratchItchPR2Env, 'ScratchItchPR2Human-v1': ScratchItchPR2HumanEnv, 'FeedingJaco-v1': FeedingJacoEnv, 'FeedingJacoHuman-v1': FeedingJacoHumanEnv, 'BedBathingSawyer-v1': BedBathingSawyerEnv,
-           'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv}
+           'BedBathingSawyerHuman-v1': BedBathingSawyerHumanEnv, 'DrinkingJaco-v1': DrinkingJacoEnv, 'DrinkingJacoHuman-v1': DrinkingJacoHumanEnv}
 
 # ---- further robots of a task: the same env code with another model blob (model/compiler.py ROBOT_BASE / ROBOT_TASK) -----------------------
 def _robot_flavours(base_cls, task_name, robots, ref):
@@ -419,6 +452,8 @@ _robot_flavours(DressingBaxterEnv, 'Dressing', [('Sawyer', 'dressing_sawyer'), (
 _robot_flavours(ArmManipulationSawyerEnv, 'ArmManipulation', [('Jaco', 'arm_manipulation_jaco'), ('Panda', 'arm_manipulation_panda'), ('PR2', 'arm_manipulation_pr2'),
                                                               ('Baxter', 'arm_manipulation_baxter')], 'arm_manipulation_envs.py:15-37,41-79')
 _robot_flavours(ScratchItchPR2Env, 'ScratchItch', [('Baxter', 'scratch_itch_baxter'), ('Stretch', 'scratch_itch_stretch')], 'scratch_itch_envs.py:21-23,31-33,46-50,58-62')
+_robot_flavours(DrinkingJacoEnv, 'Drinking', [('PR2', 'drinking_pr2'), ('Baxter', 'drinking_baxter'), ('Sawyer', 'drinking_sawyer'), ('Stretch', 'drinking_stretch'), ('Panda', 'drinking_panda')],
+                'drinking_envs.py:15-27,33-55,61-67')
 
 
 

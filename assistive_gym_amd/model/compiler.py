@@ -652,10 +652,19 @@ def compile_feeding_panda(assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter
     return compile_feeding('panda', assets, robot_hull_max_verts, n_iter)
 
 
-def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=50):
+def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=None, task='feeding'):
+    """task='feeding': Feeding<Robot>-v1 (feeding_envs.py).  task='drinking': Drinking<Robot>-v1 (drinking_envs.py:15-67) -- the same robot
+    (right arm), person and wheelchair without table, bowl and food: the robot holds a cup (68 convex pieces, plastic_coffee_cup_vhacd.obj
+    x 0.045, tool.py:23-25,33-35) with 64 water spheres in it (r = 5 mm, 1 g each: drinking.py:160-170); numSubSteps = 4,
+    numSolverIterations = 10 (:157), motor gains 0.005 (:130).  The water is a PARTICLE SECTION in the garment's format (model/cloth.py
+    compile_particles): one-way coupled to the rigid scene like the garment [deviation: Bullet solves the spheres as rigid bodies]."""
     sc = Scene()
+    drink = task == 'drinking'
+    if n_iter is None:
+        n_iter = 10 if drink else 50
+    gain = 0.005 if drink else 0.025                # drinking.py:130 / feeding.py:122
     # ------------------------------------------------------------------ robot (agents/jaco.py, agents/panda.py)
-    RB = FEEDING_ROBOTS[robot]
+    RB = (DRINKING_ROBOTS if drink else FEEDING_ROBOTS)[robot]
     arm, grip = RB['arm'], RB['grip']
     mounted = 'base_pos' in RB                      # on the wheelchair (jaco.py:48, panda.py:49); else placed by the base pose search
     mobile = RB.get('mobile')                       # or drawn around a fixed spot on its own wheels (env.py:282-293)
@@ -666,7 +675,7 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
         frozen = {j.index: 0.0 for j in u0.indexed_joints if j.type != 'fixed' and j.index not in arm + grip + list((RB.get('mobile') or {}).get('dup', ()))}
         frozen.update(RB['frozen_rest'])
     rob = compile_robot(urdf_path, arm, grip, gripper_target=RB['gripper_target'],
-                        motor_gain=0.025, motor_force=1.0, max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen,
+                        motor_gain=gain, motor_force=1.0, max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), frozen=frozen,
                         use_file_inertia=RB.get('file_inertia', False), mobile=mobile)
     nrobot = len(rob['dof_links'])
     gripper_collision = RB['gripper_collision']    # no collision with the tool (tool.py:42-44)
@@ -683,8 +692,8 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
     sc.end('robot_base')
     # ------------------------------------------------------------------ free bodies
     free = []
-    # tool: spoon, createMultiBody(baseMass=1) with the 64-hull compound (tool.py:26-34, feeding.py:137)
-    spoon = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'dinnerware', 'spoon_vhacd.obj'), 0.08)]
+    # tool: spoon, createMultiBody(baseMass=1) with the 64-hull compound (tool.py:26-34, feeding.py:137); drinking: the cup (tool.py:23-25, drinking.py:137)
+    spoon = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'dinnerware', 'plastic_coffee_cup_vhacd.obj' if drink else 'spoon_vhacd.obj'), 0.045 if drink else 0.08)]
     allv = np.concatenate(spoon)
     free.append(dict(mass=1.0, inertia=box_inertia(1.0, allv.min(0) - HULL_MARGIN, allv.max(0) + HULL_MARGIN), gravity=0.0,
                      refpos=np.zeros(3), refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0))
@@ -692,6 +701,8 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
     for hv in spoon:
         sc.add(BODY_FREE0 + 0, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['TOOL'])
     sc.end('tool')
+    if drink:
+        return _finish_drinking(sc, RB, rob, robot, arm, grip, free, assets, n_iter, mounted, mobile)
     # bowl (furniture.py:32-34, assets/dinnerware/bowl.urdf)
     bu = Urdf(os.path.join(assets, 'dinnerware', 'bowl.urdf'))
     bl = bu.root
@@ -862,40 +873,33 @@ def compile_feeding(robot, assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_ite
                                 robot_base_quat=(X.quat_from_rpy(RB['mobile_rpy']) if mobile else X.quat_from_rpy([0, 0, -np.pi / 2.0])).tolist(), **meta_mobile))
 
 
-# ---- Drinking (drinking.py): MODEL + CPU ORACLE ONLY so far -- no kernel variant serves TASK_DRINKING yet -----------------------------
-# per robot: gripper_pos, tool_pos_offset, tool_orient_offset, toc_base_pos_offset, toc_ee_orient_rpy for 'drinking' (agents/jaco.py:21,27,32,38,44)
+# ---- Drinking (drinking.py, drinking_envs.py:15-67): the feeding scene's robots with the cup ---------------------------------------------------
+# per robot: gripper_pos, tool_pos_offset, tool_orient_offset, toc_base_pos_offset, toc_ee_orient_rpy for 'drinking' (agents/<robot>.py:19-47)
 DRINKING_ROBOTS = dict(
-    jaco=dict(FEEDING_ROBOTS['jaco'], gripper_target=0.63, tool_pos=[0.05, -0.005, 0], tool_rpy=[0, -np.pi / 2.0, np.pi / 2.0],
-              base_pos=[-0.35, -0.3, 0.36], ee_rpy=[0, np.pi / 2.0, 0]))
+    jaco=dict(FEEDING_ROBOTS['jaco'], gripper_target=0.63, tool_pos=[0.05, -0.005, 0], tool_rpy=[0, -np.pi / 2.0, np.pi / 2.0],                   # jaco.py:21,27,32
+              base_pos=[-0.35, -0.3, 0.36], ee_rpy=[0, np.pi / 2.0, 0]),                                                                        # jaco.py:38,44
+    panda=dict(FEEDING_ROBOTS['panda'], gripper_target=[0.035, 0.035], tool_pos=[0.05, 0, 0.01], tool_rpy=[0, -np.pi / 2.0, np.pi / 2.0],        # panda.py:21,27,32
+               base_pos=[-0.4, -0.35, 0.26], ee_rpy=[0, np.pi / 2.0, 0]),                                                                       # panda.py:38,44
+    sawyer=dict(FEEDING_ROBOTS['sawyer'], gripper_target=[0.025, -0.025], tool_pos=[0.05, 0.125, 0], tool_rpy=[0, 0, np.pi / 2.0],               # sawyer.py:21,27,32
+                toc_base=[-0.1, 0.2, 0.975], ee_rpy=[0, -np.pi / 2.0, np.pi]),                                                                  # sawyer.py:37,43
+    baxter=dict(FEEDING_ROBOTS['baxter'], gripper_target=[0.025, -0.025], tool_pos=[0.05, 0.125, 0], tool_rpy=[0, 0, np.pi / 2.0],               # baxter.py:21,27,32
+                toc_base=[0, 0.2, 0.925], ee_rpy=[0, -np.pi / 2.0, np.pi]),                                                                     # baxter.py:37,43
+    pr2=dict(FEEDING_ROBOTS['pr2'], gripper_target=[0.45] * 4, tool_pos=[-0.01, 0, -0.05], tool_rpy=[np.pi / 2.0, 0, 0],                         # pr2.py:21,27,32
+             toc_base=[0.2, 0.2, 0], ee_rpy=[0, 0, 0]),                                                                                         # pr2.py:37,43
+    stretch=dict(STRETCH, gripper_target=[0.2, 0.2], tool_pos=[0, 0, -0.05], tool_rpy=[np.pi / 2.0, 0, 0],                                      # stretch.py:23,29,34
+                 mobile_base=[-0.9, -0.3, 0.09], mobile_rpy=[0, 0, np.pi / 2.0], lift=0.75, ee_rpy=[0, 0, np.pi / 2.0]))                         # stretch.py:39,45,58-62
 
 
 def compile_drinking(robot='jaco', assets=DEFAULT_ASSETS, robot_hull_max_verts=64, n_iter=10):
-    """Drinking<Robot>-v1 (drinking_envs.py): the feeding scene without bowl, table and food -- the robot holds a cup (68 convex pieces,
-    plastic_coffee_cup_vhacd.obj x 0.045, tool.py:23-25,33-35) with 64 water spheres in it (r = 5 mm, 1 g each: drinking.py:160-170);
-    numSubSteps = 4, numSolverIterations = 10 (:157).  The water is a PARTICLE SECTION in the garment's format (model/cloth.py
-    compile_particles): one-way coupled to the rigid scene like the garment [deviation: Bullet solves the spheres as rigid bodies]."""
+    """Drinking<Robot>-v1 (drinking_envs.py:15-39); see compile_feeding(task='drinking')"""
+    return compile_feeding(robot, assets, robot_hull_max_verts, n_iter, task='drinking')
+
+
+def _finish_drinking(sc, RB, rob, robot, arm, grip, free, assets, n_iter, mounted, mobile):
+    """compile_feeding(task='drinking') after the robot and the cup: person, wheelchair, ground (build_assistive_env('wheelchair'),
+    drinking.py:125), pair groups, the reset section (drinking.py:122-181), the task constants and the water"""
     from .cloth import compile_particles
-    sc = Scene()
-    RB = DRINKING_ROBOTS[robot]
-    arm, grip = RB['arm'], RB['grip']
-    rob = compile_robot(os.path.join(assets, *RB['urdf']), arm, grip, gripper_target=RB['gripper_target'], motor_gain=0.005, motor_force=1.0,    # drinking.py:130
-                        max_hull_verts=RB.get('hull_verts', robot_hull_max_verts), use_file_inertia=RB.get('file_inertia', False))
     nrobot = len(rob['dof_links'])
-    gripper_collision = RB['gripper_collision']
-    add_robot_colliders(sc, rob, 'robot_arm', lambda pb: pb not in gripper_collision)
-    add_robot_colliders(sc, rob, 'robot_gripper', lambda pb: pb in gripper_collision)
-    sc.begin('robot_base')
-    for verts, radius, fr, pb in rob['base_colliders']:
-        sc.add(BODY_ROBOT_BASE, verts, radius, fr, TAG['ROBOT'], link=pb)
-    sc.end('robot_base')
-    cup = [convex_hull_vertices(g) for g in load_obj_groups(os.path.join(assets, 'dinnerware', 'plastic_coffee_cup_vhacd.obj'), 0.045)]
-    allv = np.concatenate(cup)
-    free = [dict(mass=1.0, inertia=box_inertia(1.0, allv.min(0) - HULL_MARGIN, allv.max(0) + HULL_MARGIN), gravity=0.0,                            # tool.py:34, drinking.py:152
-                 refpos=np.zeros(3), refquat=np.array([0, 0, 0, 1.0]), kind=KIND['TOOL'], radius=0.0)]
-    sc.begin('tool')
-    for hv in cup:
-        sc.add(BODY_FREE0 + 0, hv, HULL_MARGIN, DEFAULT_FRICTION, TAG['TOOL'])
-    sc.end('tool')
     hd = HUMAN_DYNAMIC_JOINTS
     human_bodies, human_link_rec = add_human(sc, assets, nrobot, hd, kp=0.005, maxf=1.0, act0=len(arm))                                           # drinking.py:130
     head_link = nrobot + hd.index(23)
@@ -909,6 +913,9 @@ def compile_drinking(robot='jaco', assets=DEFAULT_ASSETS, robot_hull_max_verts=6
     sc.end('wheelchair')
     G_ = Groups(sc.ranges)
     grp = G_.add
+    if mobile:      # what the robot stands on comes first (see compile_feeding)
+        grp('robot_arm', 'plane')
+        grp('robot_gripper', 'plane')
     grp('tool', 'human_male', alt='human_female', keep=1)
     grp('robot_arm', 'human_male', alt='human_female', keep=2)
     grp('robot_gripper', 'human_male', alt='human_female', keep=2)
@@ -916,42 +923,110 @@ def compile_drinking(robot='jaco', assets=DEFAULT_ASSETS, robot_hull_max_verts=6
     G_.rg['robot_links'] = (G_.rg['robot_arm'][0], G_.rg['robot_gripper'][1])
     if RB.get('selfcol', 'all') == 'all':
         grp('robot_links', 'robot_links', same=True, no_adjacent=True)
+    elif RB['selfcol'] == 'sawyer':
+        G_.rg['robot_top'] = (G_.rg['robot_upper'][0], G_.rg['robot_gripper'][1])
+        grp('robot_base', 'robot_top')
+    if not mounted:
+        grp('robot_base', 'tool')
     grp('robot_arm', 'wheelchair')
     grp('robot_gripper', 'wheelchair')
-    grp('robot_arm', 'plane')
-    grp('robot_gripper', 'plane')
+    if not mobile:
+        grp('robot_arm', 'plane')
+        grp('robot_gripper', 'plane')
     grp('tool', 'wheelchair')
     grp('tool', 'plane')
 
     def reset_words(nhuman, nhdof):
-        return X_['COUNT']
+        return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        pass        # no device-side reset generator yet: host/reset_drinking.py
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(arm)
+        if mobile:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3], xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = RB['mobile_base'], X.quat_from_rpy(RB['mobile_rpy'])
+        else:
+            xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = RB['base_pos'] if mounted else np.array([-0.85, -0.4, 0]) + RB['toc_base']   # drinking.py:126-128; robot.py:142
+            xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = X.quat_from_rpy([0, 0, -np.pi / 2.0]) if mounted else [0, 0, 0, 1]
+        if not mounted and not mobile:
+            # base pose search (robot.py:123-215) with start_pos_orient = [(start pose), (mouth, None)] and the mouth WITH the end-effector
+            # orientation as the one further goal (drinking.py:143): goal kind 2
+            xi[X_['TOC_ATTEMPTS']], xi[X_['TOC_ROUNDS']] = 50, 4
+            xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW_RANGE']] = 0.5, np.deg2rad(30.0)
+            xf[X_['TOC_YAW0']], xf[X_['TOC_X_SIGN']] = 0.0, -1.0
+            xi[X_['TOC_IK_ITERS']], xf[X_['TOC_THRESH']] = 100, 0.03
+            xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 2, 2
+        if not mobile:
+            fill_reset_chain_and_pedestal(xf, xi, rob, arm, sc.colliders, sc.ranges['robot_base'], guard=(not mounted and robot == 'sawyer'))
+        xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(RB['ee_rpy'])                  # toc_ee_orient_rpy
+        xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-0.2, -0.5, 1.1], 0.05   # drinking.py:141
+        xf[X_['HBASE_M']:X_['HBASE_M'] + 3], xf[X_['HBASE_F']:X_['HBASE_F'] + 3] = [0, 0.03, 0.89], [0, 0.03, 0.86]   # human.py:102
+        xf[X_['HEAD_RANGE']] = np.deg2rad(30.0)                                              # drinking.py:133
+        xi[X_['IK_ITERS']], xf[X_['IK_DAMP']], xf[X_['IK_MAXSTEP']], xf[X_['IK_TOL']] = 200, 0.05, 0.5, 1e-4   # host/kin.py (not Bullet's IK)
+        xf[X_['IK_THRESH']], xi[X_['IK_RESTARTS']], xi[X_['IK_RANDLIM_FROM']] = 0.01, 1000, 10   # robot.py:84-97
+        xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5                                    # env.py:120
+        xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(20.0)   # human.py:85-90
+        xi[X_['BOWL_BODY']] = -1
+        xi[X_['COLLISION_TRIES']] = 3                                                        # env.py:276 max_iterations
+        oj = X_['COUNT']
+        ob = oj + 2 * 42 * XJ['STRIDE']
+        od = ob + nhuman
+        xi[X_['OFF_JOINTS']], xi[X_['OFF_BODIES']], xi[X_['OFF_DYN']] = oj, ob, od
+        preset = {6: -90, 16: -90, 28: -90, 31: 80, 35: -90, 38: 80}                         # drinking.py:132
+        draw = {21: 0, 22: 1, 23: 2}                                                         # drinking.py:133
+        for g, gender in enumerate(('male', 'female')):
+            hm1, hm2 = HumanModel(gender, 1.0), HumanModel(gender, 0.5)
+            for j in range(42):
+                b0 = oj + (g * 42 + j) * XJ['STRIDE']
+                xi[b0 + XJ['PARENT']] = hm1.parent[j]
+                xf[b0 + XJ['OFF']:b0 + XJ['OFF'] + 3] = hm1.offset[j]
+                xf[b0 + XJ['AXIS']:b0 + XJ['AXIS'] + 3] = hm1.axis[j]
+                xf[b0 + XJ['LOWER']], xf[b0 + XJ['UPPER']] = hm1.lower[j], hm1.upper[j]
+                scaled = hm1.lower[j] != hm2.lower[j] or hm1.upper[j] != hm2.upper[j]
+                xi[b0 + XJ['FLAGS']] = (1 if hm1.jtype[j] == 'r' else 0) | (2 if scaled else 0)
+                xf[b0 + XJ['PRESET']] = np.deg2rad(preset.get(j, 0.0))
+                xi[b0 + XJ['DRAW']] = draw.get(j, -1)
+        xi[ob:ob + nhuman] = human_bodies
+        xi[od:od + nhdof] = hd
+        if mobile:
+            fill_reset_mobile(xf, xi, RB, rob)
 
     ee_pb = RB['ee_pb']
     ee_link = rob['dof_of_pb'][rob['carrier'][ee_pb]]
+    tool_pos, tool_quat = (RB['tool_pos'], X.quat_from_rpy(RB['tool_rpy'])) if RB.get('tool_pb', ee_pb) == ee_pb else tool_offset_in_ee_frame(rob, ee_pb, RB['tool_pb'], RB['tool_pos'], RB['tool_rpy'])
     task_f = dict(W_DISTANCE=1.0, W_ACTION=0.01, W_FOOD=1.0, W_WIPE=0.1,                   # config.ini:22-25 (W_WIPE = AGX_T_W_TILT: cup_tilt_weight)
                   C_V=0.25, C_F=0.01, C_HF=0.05, C_FD=1.0, C_FDV=1.0,                      # config.ini:40-44
                   SUCCESS_FRAC=0.75, MOUTH_DIST=0.03, SPILL_DIST=0.1, TARGET_RADIUS=0.05,  # config.ini:26, drinking.py:66,77,64
                   MOUTH_M=[0, -0.11, 0.03], MOUTH_F=[0, -0.1, 0.03],                        # drinking.py:191
-                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=RB['tool_pos'], TOOL_QUAT=X.quat_from_rpy(RB['tool_rpy']),
+                  EE_POS=rob['rel'][ee_pb][0], EE_QUAT=rob['rel'][ee_pb][1], TOOL_POS=tool_pos, TOOL_QUAT=tool_quat,
                   TOOL_OBS_POS=[0, 0.06, 0], TOOL_OBS_QUAT=X.quat_from_rpy([np.pi / 2.0, 0, 0]),   # the frame the reward reads the cup in (drinking.py:24,56)
                   EE2_POS=[0, 0, -0.055], TOOL2_POS=[0, 0, 0.07],                          # AGX_T_DK_TOP / _BOTTOM: cup_top_center_offset, cup_bottom_center_offset (drinking.py:138-139)
                   TOOL_MAXF=500.0, EPISODE_LEN=200)
     task_i = dict(HEAD_LINK=head_link, EE_LINK=ee_link)
     params = default_params(n_iter)                                                        # numSolverIterations = 10 (drinking.py:157); robot / human / tool gravity 0 (:150-152)
+    n_obs_joints = len(arm)
+    meta_mobile = {}
+    if mobile:
+        params.update(ROBOT_GRAVITY_Z=-9.81)                                               # a mobile robot keeps its gravity (drinking.py:149-150)
+        n_obs_joints -= len(mobile['obs_skip'])                                            # obs_robot_len, drinking.py:8
+        meta_mobile = dict(mobile_base=list(RB['mobile_base']), mobile_rpy=list(RB['mobile_rpy']), lift=RB['lift'], lift_dof=int(rob['dof_of_pb'][3]))
     r = sc.ranges
-    shape_ids = [c for name in ('tool', 'robot_gripper', 'human_male', 'human_female') for c in range(*r[name])]
+    # what the water can touch, in the order the water kernel keeps a particle's contacts: the cup, the person, the gripper that holds the cup;
+    # then -- while the kernel's shape table has room (192) -- the arm, the ground and the wheelchair spilled water lands on
+    # (drinking.py:84: water that touches the person counts; in Bullet the spheres collide with everything)
+    shape_ids = [c for name in ('tool', 'human_male', 'human_female', 'robot_gripper') for c in range(*r[name])]
+    for name in ('robot_arm', 'plane', 'wheelchair'):
+        extra = [c for c in range(*r[name]) if c not in shape_ids]
+        shape_ids += extra[:max(0, 192 - len(shape_ids))]
     wr = 0.005
     grid = [np.array([i * 2 * wr - 0.02, j * 2 * wr - 0.02, k * 2 * wr + 0.075]) for i in range(4) for j in range(4) for k in range(4)]          # drinking.py:163-167, relative to the cup
     water, wmeta = compile_particles(grid, wr, 64 * 0.001, dict(KDF=0.5, KCHR=1.0, KKHR=1.0, PITER=10, FORCE_SCALE=1.0, FORCE_MAX=1e9), sc.colliders, shape_ids,
                                      gender_of=lambda ci: 1 if r['human_male'][0] <= ci < r['human_male'][1] else (2 if r['human_female'][0] <= ci < r['human_female'][1] else 0))
     return pack(sc, G_.rows, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
-                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=18 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRINKING), reset_fill, reset_words,
+                dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=18 + n_obs_joints, FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_DRINKING, BASE_LINK=rob['base_link']), reset_fill, reset_words,
                 task_words=DK['WORDS'], cloth=water, sim_substeps=4,
-                meta_extra=dict(head_link=int(head_link), robot=robot, mount='wheelchair', water=wmeta, ee_rpy=list(RB['ee_rpy']), robot_base_pos=list(RB['base_pos']),
-                                robot_base_quat=X.quat_from_rpy([0, 0, -np.pi / 2.0]).tolist(), device_path=False))
+                meta_extra=dict(head_link=int(head_link), robot=robot, mount='mobile' if mobile else 'wheelchair' if mounted else 'toc', toc_base=list(RB.get('toc_base', [0, 0, 0])),
+                                water=wmeta, ee_rpy=list(RB['ee_rpy']),
+                                robot_base_pos=list(RB['base_pos']) if mounted else list(RB['mobile_base']) if mobile else (np.array([-0.85, -0.4, 0]) + RB['toc_base']).tolist(),
+                                robot_base_quat=(X.quat_from_rpy(RB['mobile_rpy']) if mobile else X.quat_from_rpy([0, 0, -np.pi / 2.0])).tolist(), **meta_mobile))
 
 
 def capsule_points(p1, p2, radius, distance_between_points):
@@ -1939,6 +2014,9 @@ COMPILERS = dict(feeding_jaco=compile_feeding_jaco, feeding_panda=compile_feedin
                  bed_bathing_pr2=lambda *a, **k: compile_bed_bathing('pr2', *a, **k), bed_bathing_baxter=lambda *a, **k: compile_bed_bathing('baxter', *a, **k),
                  scratch_itch_jaco=lambda *a, **k: compile_scratch_itch('jaco', *a, **k), scratch_itch_panda=lambda *a, **k: compile_scratch_itch('panda', *a, **k),
                  dressing_stretch=lambda *a, **k: compile_dressing('stretch', *a, **k), drinking_jaco=lambda *a, **k: compile_drinking('jaco', *a, **k),
+                 drinking_panda=lambda *a, **k: compile_drinking('panda', *a, **k), drinking_sawyer=lambda *a, **k: compile_drinking('sawyer', *a, **k),
+                 drinking_baxter=lambda *a, **k: compile_drinking('baxter', *a, **k), drinking_pr2=lambda *a, **k: compile_drinking('pr2', *a, **k),
+                 drinking_stretch=lambda *a, **k: compile_drinking('stretch', *a, **k),
                  scratch_itch_stretch=lambda *a, **k: compile_scratch_itch('stretch', *a, **k), bed_bathing_stretch=lambda *a, **k: compile_bed_bathing('stretch', *a, **k),
                  scratch_itch_sawyer=lambda *a, **k: compile_scratch_itch('sawyer', *a, **k), scratch_itch_baxter=lambda *a, **k: compile_scratch_itch('baxter', *a, **k), bed_bathing_sawyer=compile_bed_bathing_sawyer, scratch_itch_pr2=compile_scratch_itch_pr2,
                  bed_settle=compile_bed_settle, dressing_baxter=compile_dressing_baxter,

@@ -15,6 +15,7 @@ from .shard import episode_seed, pool_indices
 SETTLE_STEPS = 25   # feeding.py:178-179
 DRESSING_SETTLE_STEPS = 50   # dressing.py:186-187
 RAGDOLL_SETTLE_STEPS = 100   # bed_bathing.py:130-131
+DRINKING_SETTLE_STEPS = 50   # drinking.py:176-177: the water drops into the cup
 
 
 def attach_ragdoll_model(stepper, n_envs, device):
@@ -72,6 +73,28 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         # under half gravity, full gravity afterwards -- all inside agx_reset
         st = Stepper(blob, pool_size, device)
         st.reset(None, None, seed, impairment=impairment, settle_substeps=DRESSING_SETTLE_STEPS)
+        st.synchronize()
+        out = st.get_state(), st.get_cloth()
+        st.close()
+        return out
+    if blob.task_kind == L.TASK_DRINKING and sampler == 'device':
+        # DrinkingEnv.reset on the device (drinking.py:122-181): sampling (IK restarts / base pose search / placement draws), the water grid above
+        # the cup, the 50 steps in which it drops into the cup -- all inside agx_reset; returns (states, water): the particles of a pool
+        # entry travel with its state record like a garment
+        assert blob.has_reset_generator
+        st = Stepper(blob, pool_size, device)
+        st.reset(None, None, seed, impairment=impairment, settle_substeps=DRINKING_SETTLE_STEPS)
+        st.synchronize()
+        out = st.get_state(), st.get_cloth()
+        st.close()
+        return out
+    if blob.task_kind == L.TASK_DRINKING:
+        # the numpy sampler (host/reset_drinking.py: the wheelchair-mounted arms) around the device's 50-step settle
+        from .host.reset_drinking import make_states as make_drinking_states
+        states, water, _ = make_drinking_states(blob, pool_size, seed=seed, impairment=impairment)
+        st = Stepper(blob, pool_size, device)
+        st.set_state(states); st.set_cloth(water)
+        st.settle(DRINKING_SETTLE_STEPS)
         st.synchronize()
         out = st.get_state(), st.get_cloth()
         st.close()
@@ -217,7 +240,7 @@ class AssistiveVecEnv:
         i.e. independent of the number of GPUs the batch is spread over -- and settled for 25 substeps"""
         from .model import compiler as L
         # FeedingEnv.reset: 25 steps for the food to drop; DressingEnv.reset: 50 for the garment; ScratchItchEnv.reset has no settle loop
-        settle = {L.TASK_FEEDING: SETTLE_STEPS, L.TASK_DRESSING: DRESSING_SETTLE_STEPS}.get(self.blob.task_kind, 0)
+        settle = {L.TASK_FEEDING: SETTLE_STEPS, L.TASK_DRESSING: DRESSING_SETTLE_STEPS, L.TASK_DRINKING: DRINKING_SETTLE_STEPS}.get(self.blob.task_kind, 0)
         self.stepper.reset(mask, None, episode_seed(self.seed, self._episode, self.env_offset), impairment=self.impairment,
                            settle_substeps=settle, stream=s)
         if settle > 0:
@@ -358,6 +381,36 @@ class FeedingStretchVecEnv(FeedingSawyerVecEnv):
 class FeedingBaxterVecEnv(FeedingSawyerVecEnv):
     """FeedingBaxter-v1 (feeding_envs.py:21-23): Baxter's right arm"""
     model = 'feeding_baxter'
+
+
+class DrinkingJacoVecEnv(AssistiveVecEnv):
+    """DrinkingJaco-v1 (drinking_envs.py:29-31): the wheelchair-mounted Jaco brings a cup with 64 water particles to the person's mouth.
+    The water lives next to the state record like a garment (float32 [n, 2, 64, 3]); the pool holds (state, water) pairs sampled and settled
+    on the device (agx_reset: IK restarts, the grid above the cup, 50 settle steps); reset='device': new ones every episode."""
+    model = 'drinking_jaco'
+
+
+class DrinkingPandaVecEnv(DrinkingJacoVecEnv):
+    model = 'drinking_panda'
+
+
+class DrinkingSawyerVecEnv(DrinkingJacoVecEnv):
+    """DrinkingSawyer-v1 (drinking_envs.py:25-27): a free-standing robot, placed by the base pose search of the device-side reset generator
+    (start pose and the mouth must be reachable, the mouth with the start orientation is the further goal: drinking.py:143)"""
+    model = 'drinking_sawyer'
+
+
+class DrinkingBaxterVecEnv(DrinkingJacoVecEnv):
+    model = 'drinking_baxter'
+
+
+class DrinkingPR2VecEnv(DrinkingJacoVecEnv):
+    model = 'drinking_pr2'
+
+
+class DrinkingStretchVecEnv(DrinkingJacoVecEnv):
+    """DrinkingStretch-v1 (drinking_envs.py:33-35): the mobile manipulator, 5 actions, 21 observations"""
+    model = 'drinking_stretch'
 
 
 class FeedingPandaVecEnv(AssistiveVecEnv):

@@ -42,6 +42,7 @@ TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the com
     'feedingsawyer': ('feeding_sawyer', 'FeedingSawyerVecEnv', '_fl', 'FeedingSawyer-v1 (free-standing robot: feeding_l kernel variant, 320 colliders)'),
     'bedbathingpr2': ('bed_bathing_pr2', 'BedBathingPR2VecEnv', '_bbl', 'BedBathingPR2-v1 (bed_bathing_l kernel variant: 24 DoF)'),
     'scratchitchjaco': ('scratch_itch_jaco', 'ScratchItchJacoVecEnv', '_si', "ScratchItchJaco-v1 (the reference's default environment)"),
+    'drinking': ('drinking_jaco', 'DrinkingJacoVecEnv', '_dk', 'DrinkingJaco-v1 (64 water particles per env, numSubSteps 4 / 10 solver sweeps: 20 internal substeps per step)'),
     'dressing': ('dressing_baxter', 'DressingBaxterVecEnv', '_dr', 'DressingBaxter-v1 (cloth of 3,966 nodes per env, numSubSteps 8: 40 internal substeps per step)'),
 }
 
@@ -230,7 +231,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         from assistive_gym_amd.envs import ENV_IDS
         cls = ENV_IDS[env_id_override.split(':')[-1]]
         model, env_cls, ksuffix, env_id = cls.model, None, None, env_id_override.split(':')[-1]
-        task = 'dressing' if model.startswith('dressing') else env_id_override
+        task = 'dressing' if model.startswith('dressing') else 'drinking' if model.startswith('drinking') else env_id_override
     if pool is None:
         pool = 64 if task == 'dressing' else 256
     n = args.envs_per_gpu
@@ -245,7 +246,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         env = vec_env.AssistiveVecEnv(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, model=model, coop=env_id.endswith('Human-v1'), blob=blob_override,
                                       pool_refresh=getattr(args, 'pool_refresh', 0))
         ksuffix = {'feeding': '', 'feeding_l': '_fl', 'feeding_m': '_fm', 'bed_bathing': '_bb', 'bed_bathing_l': '_bbl', 'bed_bathing_m': '_bbm', 'scratch_itch': '_si', 'scratch_itch_m': '_sim', 'dressing': '_dr', 'dressing_l': '_drl', 'dressing_m': '_drm',
-                   'arm_manipulation': '_am', 'arm_manipulation_l': '_aml'}[env.stepper.variant()]
+                   'arm_manipulation': '_am', 'arm_manipulation_l': '_aml', 'drinking': '_dk', 'drinking_l': '_dkl', 'drinking_m': '_dkm'}[env.stepper.variant()]
     else:
         env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, blob=blob_override, pool_refresh=getattr(args, 'pool_refresh', 0))
     blob = env.blob                      # the co-op flavour where the task's BASELINE config is co-op
@@ -343,8 +344,10 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         names = [k + ksuffix for k in ('agx_build_kernel', 'agx_solve_kernel', 'agx_finish_kernel')]
         traffic_key = None
         if has_cloth:
-            names[2] = 'whole step (40 x [agx_build_kernel%s, agx_solve_kernel%s] + agx_cloth_kernel%s + agx_finish_kernel%s)' % ((ksuffix,) * 4)
-            traffic_key = 'agx_cloth_kernel' + ksuffix
+            nsub = int(blob.param('FRAME_SKIP')) * max(1, blob.h['SIM_SUBSTEPS'])
+            pk = 'agx_water_kernel' if task == 'drinking' else 'agx_cloth_kernel'
+            names[2] = 'whole step (%d x [agx_build_kernel%s, agx_solve_kernel%s] + %s%s + agx_finish_kernel%s)' % (nsub, ksuffix, ksuffix, pk, ksuffix, ksuffix)
+            traffic_key = pk + ksuffix
         dom = int(np.argmax(kms))
         # one launch of the dominant kernel advances the environments of one chunk by 1/frame_skip of an env-step
         launches = [int(round(x)) for x in kcnt]
@@ -357,7 +360,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         # reduced by tools/pmc_traffic.py to per-environment figures), scaled to the SAME launch size as the algorithmic bytes
         traffic, traffic_src, valu_frac, cloth_kernel = None, None, None, None
         tname = task if workload is None else task + '_' + workload
-        for cand in ('r03_traffic_%s.json' % tname, 'r02_traffic_%s.json' % tname, 'r01_traffic.json' if task == 'feeding' else None):
+        for cand in ('r04_traffic_%s.json' % tname, 'r03_traffic_%s.json' % tname, 'r02_traffic_%s.json' % tname, 'r01_traffic.json' if task == 'feeding' else None):
             tpath = cand and os.path.join(ROOT, 'profiles', cand)
             if tpath and os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -376,7 +379,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, 50 PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale),
+            'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, %d PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale, int(blob.param('NITER'))),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed), 'noop_retest': blob.param('NOOP_RETEST')},
             'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps
@@ -398,7 +401,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         if cloth_kernel:
             out['roofline']['cloth_kernel'] = cloth_kernel
         if world == 1 and cpu:
-            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8 if not has_cloth else 2, 1000 if not has_cloth else 40,
+            out['cpu_baseline'] = cpu_baseline(blob, env.pool_host if args.reset != 'device' else env.stepper.get_state(), 8 if (not has_cloth or task == 'drinking') else 2, 1000 if not has_cloth else (300 if task == 'drinking' else 40),
                                                model + ('+coop' if blob.is_coop else ''), env_id,
                                                cloth=(env.cloth_pool_host if args.reset != 'device' else env.stepper.get_cloth()) if has_cloth else None)
     env.close()

@@ -46,6 +46,7 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, COUNT=108)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
+H_TASK_KIND, H_OFF_CLOTH = 35, 40
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, JTYPE=32, STRIDE=36)
 F = dict(REFPOS=5, REFQUAT=8, STRIDE=16)
 T = dict(SI_LIMB_DIMS=9, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35)
@@ -294,7 +295,7 @@ class ResetOracle:
         det = max(np.linalg.det(M), 0.0)
         return det ** (1.0 / 6.0) / (np.trace(M) / 6.0)
 
-    def toc(self, seed, placement, target_pos, target_quat, goals, goal_quats=None):
+    def toc(self, seed, placement, target_pos, target_quat, goals, goal_quats=None, must=1):
         """Robot.position_robot_toc (robot.py:123-215) as the device runs it: TOC_ATTEMPTS candidate base poses per round, each solving
         the start pose and the position goals from random rest poses; -> (ok, base (p, q), start solution, rounds used, goals reached)"""
         narm, A, rounds = self.xi('NARM'), self.xi('TOC_ATTEMPTS'), self.xi('TOC_ROUNDS')
@@ -335,7 +336,7 @@ class ResetOracle:
                     if hit:
                         reached |= 1 << g
                         manip += self.jlwki(q, base)
-                ngoal = bin(reached).count('1') if reached & 1 else -1
+                ngoal = bin(reached).count('1') if (reached & must) == must else -1      # the start goals must be reachable (robot.py:196-200)
                 if best is None or ngoal > best[0] or (ngoal == best[0] and ngoal > 0 and manip > best[1]):
                     best = (ngoal, manip, base, qs)
             out = (best[0] > 0, best[2], best[3], rnd + 1, best[0], best[1])
@@ -465,7 +466,10 @@ class ResetOracle:
             else:
                 goals = [self.link_pose(g, int(self.i[self.x0 + X_['TOC_GOAL_LINKS'] + k]), ls, head)[0] + self.xf('TOC_GOAL_OFF', 3) for k in range(self.xi('TOC_NGOALS'))]
             gq = [self.f[self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k:self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k + 4].astype(np.float64) for k in range(3)] if self.xi('TOC_GOAL_ORIENT') else None
-            ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals, gq)
+            must = 1
+            if self.xi('TOC_GOAL_KIND') == 2:                              # drinking (drinking.py:143): the mouth (position) is a second START goal, the mouth with the
+                goals, gq, must = [target, target], [None, toc], 3         # start pose's end-effector orientation the one further goal
+            ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals, gq, must)
             best_d, n_max = float(ngoal), 0
             toc_info = dict(goals_reached=ngoal, manipulability=manip, base_pos=base[0], base_quat=base[1])
         for r in range(n_max):
@@ -547,6 +551,14 @@ class ResetOracle:
             ts = int(self.i[H_S_TASK])
             for t in range(6):
                 st.view(np.uint32)[ts + t] = 0xffffffff if nt >= 32 * (t + 1) else ((1 << (nt - 32 * t)) - 1 if nt > 32 * t else 0)
+        if int(self.i[H_TASK_KIND]) == 5:                                   # drinking: every water particle in self.waters / self.waters_active (drinking.py:168-172)
+            oc = int(self.i[H_OFF_CLOTH])
+            nw = int(self.i[oc + 0])                                       # AGX_CL_NN
+            si[e + 11] = nw
+            ts = int(self.i[H_S_TASK])
+            for t in range(2):
+                m = 0xffffffff if nw >= 32 * (t + 1) else ((1 << (nw - 32 * t)) - 1 if nw > 32 * t else 0)
+                st.view(np.uint32)[ts + 0 + t] = st.view(np.uint32)[ts + 2 + t] = m      # AGX_DK_ALIVE, AGX_DK_ACTIVE
         coop = self.ti('COOP') == 1
         agent = imp == 3 or coop
         si[e + 12] = 0 if (agent or xflags & 1) else (((1 << self.nhdof) - 1) << nr)     # human.py:104-110

@@ -17,6 +17,8 @@ VARIANT_DEFS = {0: [], 1: ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BL
 VARIANT_DEFS[3] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=3']      # dressing (rigid scene; the cloth kernel is a workgroup kernel)
 VARIANT_DEFS[4] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10', '-DAGX_TASK=4']      # arm manipulation
 VARIANT_DEFS['drinking'] = ['-DAGX_MAX_FREE=1', '-DAGX_TASK=5']      # the feeding limits, the drinking task layer, the water kernel (csrc/agx_water.h)
+VARIANT_DEFS['drinking_l'] = ['-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040', '-DAGX_TASK=5']      # DrinkingPR2
+VARIANT_DEFS['drinking_m'] = ['-DAGX_MAX_FREE=1', '-DAGX_MAX_DOF=20', '-DAGX_MAX_BLOCK=16', '-DAGX_ARENA_WORDS=4040', '-DAGX_TASK=5']      # DrinkingStretch
 VARIANT_DEFS['feeding_packed'] = ['-DAGX_USE_SOLVE4=1']       # the opt-in packed solve kernel (csrc/agx_pgs4.h)
 VARIANT_DEFS['feeding_cap'] = ['-DAGX_USE_SOLVE4=1', '-DAGX_P4_WINDOW_CAP=100']      # the packed solver with a small LDS window: its rows-beyond-the-window path on ordinary scenes
 VARIANT_DEFS['feeding_l'] = ['-DAGX_MAX_COLL=320', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040']
@@ -59,7 +61,7 @@ def _p(a):
 class Emu:
     def __init__(self, blob, kind=None):
         self.blob = blob
-        self.L = lib(kind) if kind is not None else lib('drinking') if blob.task_kind == 5 else lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_m' if (blob.task_kind == 0 and blob.ndof > 16) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_m' if blob.task_kind == 1 and blob.nrobot > 12 else 'scratch_m' if blob.task_kind == 2 and blob.nrobot > 12 else 'bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_m' if blob.task_kind == 3 and blob.nrobot > 12 else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
+        self.L = lib(kind) if kind is not None else lib('drinking_m' if blob.ndof > 16 else 'drinking_l' if blob.nrobot > 10 else 'drinking') if blob.task_kind == 5 else lib('settle' if blob.ndof > 32 else 'arm_l' if (blob.task_kind == 4 and blob.ndof > 20) else 'feeding_m' if (blob.task_kind == 0 and blob.ndof > 16) else 'feeding_l' if (blob.task_kind == 0 and blob.h['NCOLL'] > 256) else ('bed_m' if blob.task_kind == 1 and blob.nrobot > 12 else 'scratch_m' if blob.task_kind == 2 and blob.nrobot > 12 else 'bed_l' if blob.task_kind == 1 and (blob.ndof > 20 or blob.nrobot > 10) else 'dressing_m' if blob.task_kind == 3 and blob.nrobot > 12 else 'dressing_l' if blob.task_kind == 3 and (blob.ndof > 20 or blob.nrobot > 10) else blob.task_kind))
         self.words = np.ascontiguousarray(blob.words)
         lay = (C.c_int * 8)()
         self.L.agx_emu_debug_layout(lay)

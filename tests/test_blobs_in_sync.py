@@ -37,4 +37,4 @@ def test_every_env_id_has_its_blob():
     from assistive_gym_amd.model.compiler import COMPILERS
     for env_id, cls in ENV_IDS.items():
         assert cls.model in COMPILERS and os.path.exists(os.path.join(DATA_DIR, cls.model + '.agxblob')), env_id
-    assert len(ENV_IDS) == 58
+    assert len(ENV_IDS) == 70          # the reference's 6 tasks x 6 robots x {-, Human} = 72, minus ArmManipulationStretch(Human), which raises in the reference's first step

@@ -1,5 +1,5 @@
-"""DrinkingJaco-v1 (assistive_gym/envs/drinking.py) -- model, CPU oracle, and the kernel sources on the CPU wave emulator (the `drinking` kernel
-variant is compiled but has not run on a GPU yet): the
+"""Drinking<Robot>-v1 (assistive_gym/envs/drinking.py, drinking_envs.py) -- model, CPU oracle, and the kernel sources on the CPU wave emulator (the GPU
+tests are tests/test_zz_gpu_drinking.py): the
 model blob against the reference's tables, the host reset, the water particles in the oracle (they come to rest in the cup, stay in it while
 it tilts a little, pour out when it tips over), and the task layer's terms against a numpy restatement.  The reference's own step() runs
 on this oracle through tests/refbridge (test_reference_pinned.py).  PARITY UNPINNED vs PyBullet (the physics half)."""
@@ -52,11 +52,51 @@ def test_model_tables(dk):
     assert np.allclose(np.unique(np.round(x0[:, 0], 6)), [-0.02, -0.01, 0.0, 0.01]) and np.allclose(np.unique(np.round(x0[:, 2], 6)), [0.075, 0.085, 0.095, 0.105])   # :163-167
 
 
-def test_no_env_ids_yet(dk):
-    """the `drinking` kernel variant exists and agrees with the reference on the wave emulator, but it has not run on a GPU yet (round 3 ran out of
-    GPU time): no env id is registered for the task until tests/test_zz_gpu_drinking.py has passed on the device"""
+def test_env_ids_and_robot_tables():
+    """the 12 ids of drinking_envs.py:15-67 and the per-robot 'drinking' entries of agents/<robot>.py"""
     from assistive_gym_amd.envs import ENV_IDS
-    assert not any(k.startswith('Drinking') for k in ENV_IDS)
+    from assistive_gym_amd.blob import ModelBlob
+    ids = sorted(k for k in ENV_IDS if k.startswith('Drinking'))
+    assert ids == sorted('Drinking%s%s-v1' % (r, h) for r in ('PR2', 'Baxter', 'Sawyer', 'Jaco', 'Stretch', 'Panda') for h in ('', 'Human'))
+    want = dict(jaco=([0.05, -0.005, 0], [0, -np.pi / 2, np.pi / 2], [0, np.pi / 2, 0], 7, 25), panda=([0.05, 0, 0.01], [0, -np.pi / 2, np.pi / 2], [0, np.pi / 2, 0], 7, 25),
+                sawyer=([0.05, 0.125, 0], [0, 0, np.pi / 2], [0, -np.pi / 2, np.pi], 7, 25), baxter=([0.05, 0.125, 0], [0, 0, np.pi / 2], [0, -np.pi / 2, np.pi], 7, 25),
+                pr2=([-0.01, 0, -0.05], [np.pi / 2, 0, 0], [0, 0, 0], 7, 25), stretch=([0, 0, -0.05], [np.pi / 2, 0, 0], [0, 0, np.pi / 2], 5, 21))
+    for robot, (tool_pos, tool_rpy, ee_rpy, act, obs) in want.items():
+        b = ModelBlob.load('drinking_' + robot)
+        assert b.task_kind == L.TASK_DRINKING and (b.act_dim, b.obs_dim) == (act, obs) and b.h['SIM_SUBSTEPS'] == 4 and b.param('NITER') == 10, robot
+        assert np.allclose(b.meta['ee_rpy'], ee_rpy) and b.has_reset_generator, robot
+        if robot in ('jaco', 'panda', 'pr2', 'stretch'):             # the tool hangs off the end-effector link itself (TOOL_POS is then the table's entry)
+            assert np.allclose(b.task_f('TOOL_POS', 3), tool_pos, atol=1e-6) and np.allclose(b.task_f('TOOL_QUAT', 4), X.quat_from_rpy(tool_rpy), atol=1e-6), robot
+        d0 = next(d for d in range(b.nrobot) if b.robot_i(d, 'ACT') >= 0 and b.robot_i(d, 'PB_INDEX') not in (0, 1))
+        assert np.isclose(b.robot_f(d0, 'KP'), 0.005) or robot == 'stretch'                                                            # drinking.py:130 (the Stretch keeps its own gains, stretch.py:49)
+        cc = b.coop()
+        assert (cc.act_dim, cc.obs_dim) == (act + 4, obs + 23)                                                                          # drinking.py:8: 19 + the 4 head joints
+
+
+@pytest.mark.parametrize('robot', ['jaco', 'sawyer', 'pr2', 'stretch'])
+def test_device_reset_sampler_matches_its_restatement(robot):
+    """DrinkingEnv.reset's sampling on the device (csrc/agx_reset.h on the wave emulator) against the numpy restatement (oracle/reset_oracle.py):
+    the wheelchair-mounted arm by IK restarts, the free-standing robots by the base pose search with the mouth as a second START goal and the
+    mouth with the start orientation as the further goal (drinking.py:143: goal kind 2), the Stretch by its placement draws; every water
+    particle alive"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import reset_oracle as ro
+    from assistive_gym_amd.blob import ModelBlob
+    from emu_lib import Emu
+    b = ModelBlob.load('drinking_' + robot)
+    o, e = ro.with_collision_check(b.words), Emu(b)
+    for seed in (1005, 77):
+        st, info = o.sample(seed)
+        se, ie = e.sample(seed)
+        assert np.array_equal(st.view(np.uint32), se.view(np.uint32)) or np.abs(st - se).max() <= 1e-6, (robot, seed)
+        assert info['ik_ok'] and ie[0] == 1.0
+        if robot in ('sawyer', 'pr2'):
+            assert info['toc']['goals_reached'] >= 2                                                     # the start pose AND the mouth (robot.py:196-200)
+        v = b.view(st.reshape(1, -1))
+        assert v['total_food'][0] == 64 and v['task'][0][L.DK['ALIVE']] == -1 and v['task'][0][L.DK['ACTIVE'] + 1] == -1
+        assert np.linalg.norm(v['target'][0]) > 0.5 and v['free'][0, 0, 2] > (0.5 if robot == 'stretch' else 0.8)        # the mouth target; the cup in the hand (the Stretch's lift starts at 0.75 +- 0.1)
 
 
 def test_water_rests_in_the_cup(dk, settled):
@@ -149,7 +189,12 @@ def test_water_kernel_source_matches_the_oracle(dk, settled):
     worst = 0.0
     for k in range(60):
         w_o, w_k, report, info = _water_on_emulator(b, o, s, w, a if k else np.array([0.3, -0.2, 0.1, 0.5, -0.4, 0.2, 0.1], np.float32))
-        near = np.abs(w_o[0]).max(axis=1) < 500
+        # the particles that count: within SPILL_DIST + 5 cm of the cup (beyond 0.1 m a particle is spilled and leaves self.waters, drinking.py:77-80;
+        # what it bounces off on its way down -- the arm, the wheelchair's 44 pieces -- is a chaotic sequence of single contacts)
+        cup = b.view(s[None])['free'][0, 0, :3].astype(np.float64)
+        near = (np.abs(w_o[0]).max(axis=1) < 500) & (np.linalg.norm(w_o[0] - cup, axis=1) < 0.15)
+        if not near.any():
+            break
         dp = np.abs(w_k[0, near].astype(np.float64) - w_o[0, near]).max(axis=1); dv = np.abs(w_k[1, near].astype(np.float64) - w_o[1, near]).max(axis=1)
         worst = max(worst, dp.max())
         # float32 against float64 over 20 substeps x 10 iterations of a jittering, contact-rich pile (the oracle's own particles move at up to
