@@ -1013,7 +1013,7 @@ AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float
           bool near = false;
           for (int sh = 0; sh < NS && !near; sh++) {
             if (c.bi[c.bi[AGX_H_OFF_COLL] + cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh] * AGX_C_STRIDE + AGX_C_TAG] != AGX_TAG_TOOL) continue;
-            float nw[3]; if (agxw::shape_distance(blob, body, sh, x, nw) - margin <= spill) near = true;
+            float nw[3]; if (agxw::shape_distance_blob(blob, body, sh, x, nw) - margin <= spill) near = true;
           }
           spilled = !near;
         }

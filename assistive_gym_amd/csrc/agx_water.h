@@ -14,11 +14,14 @@
 
 namespace agxw {
 constexpr int CONTACTS = 12;                 // WATER_CONTACTS of the oracle
-constexpr int MAX_BODIES = 64, MAX_SHAPES = 192, MAX_PARTICLES = 64, CAND_WORDS = 5;
-// LDS (floats): body frames [MAX_BODIES][p(3), R(9)], shape boxes [MAX_SHAPES][lo(3), hi(3)], particle positions [64][3], candidates
-// [64][CONTACTS][n(3), offset, shape | hit << 16]
-constexpr int L_BODY = 0, L_BOX = L_BODY + 12 * MAX_BODIES, L_X = L_BOX + 6 * MAX_SHAPES, L_CAND = L_X + 3 * MAX_PARTICLES;
-constexpr int LDS_WORDS = L_CAND + MAX_PARTICLES * CONTACTS * CAND_WORDS;
+constexpr int MAX_BODIES = 64, MAX_SHAPES = 192, MAX_PARTICLES = 64;
+// LDS (floats): body frames [MAX_BODIES][p(3), R(9)], shape boxes [MAX_SHAPES][lo(3), hi(3)], particle positions [64][3], the shape table
+// [MAX_SHAPES][SHAPE_WORDS] (filled once per launch: what shape_distance and the boxes need of a shape's cloth-section and collider records --
+// read from the blob per particle and substep these were chains of four dependent L2 loads per shape, 17 ms per 4096-environment step), and
+// the list of the shapes whose box meets the water's (per substep, in shape order).  A particle's candidate half spaces live in registers.
+constexpr int SHAPE_WORDS = 14;              // body slot, plane count, first plane, radius, vertex offset, vertex count, min(kDF x friction, 1), only-gender | human << 8, AABB centre (3), half extents (3)
+constexpr int L_BODY = 0, L_BOX = L_BODY + 12 * MAX_BODIES, L_X = L_BOX + 6 * MAX_SHAPES, L_SHAPE = L_X + 3 * MAX_PARTICLES, L_LIST = L_SHAPE + SHAPE_WORDS * MAX_SHAPES;
+constexpr int LDS_WORDS = L_LIST + MAX_SHAPES;
 constexpr int TRACE_BODY_WORDS = 12;         // per body and substep: p(3), R(9) row major
 constexpr int REPORT_WORDS = MAX_PARTICLES;  // per particle: 1 = touched a shape of the person in the last internal substep (drinking.py:84-88)
 
@@ -47,9 +50,59 @@ AGX_DEV void static_frames(const uint32_t* blob, const float* gstate, float* bod
     B[0] = r[0]; B[1] = r[1]; B[2] = r[2]; quat_to_rows(r + 3, B + 3);
   }
 }
+// the shape table (lane = shape): everything the kernel reads of a shape per substep, once per launch
+AGX_DEV void shape_table(const uint32_t* blob, float* table, float kDF, int lane) {
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  const int* cl = bi + bi[AGX_H_OFF_CLOTH];
+  const int NS = cl[AGX_CL_NSHAPE], ndof = bi[AGX_H_NDOF], nhuman = bi[AGX_H_NHUMAN];
+  for (int sh = lane; sh < NS; sh += 64) {
+    const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * sh; const int c = rec[0];
+    const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
+    float* o = table + SHAPE_WORDS * sh; int* oi = (int*)o;
+    oi[0] = body_slot(ci[AGX_C_BODY], ndof, nhuman); oi[1] = rec[2]; oi[2] = rec[1]; o[3] = cf[AGX_C_RADIUS]; oi[4] = ci[AGX_C_VOFF]; oi[5] = ci[AGX_C_NVERT];
+    const float fr = kDF * cf[AGX_C_FRICTION]; o[6] = fr < 1.f ? fr : 1.f;
+    oi[7] = rec[3] | ((ci[AGX_C_TAG] == AGX_TAG_HUMAN ? 1 : 0) << 8);
+    for (int k = 0; k < 3; k++) { o[8 + k] = cf[AGX_C_AABB_C + k]; o[11 + k] = cf[AGX_C_AABB_H + k]; }
+  }
+}
 // signed distance of world point x to the surface of cloth shape `sh` (negative inside) and the outward normal nw (world frame): capsule /
-// sphere cores exactly, hulls through their face planes (the largest plane distance: exact inside and in front of a face)
-AGX_DEV float shape_distance(const uint32_t* blob, const float* body, int sh, const float* x, float* nw) {
+// sphere cores exactly, hulls through their face planes (the largest plane distance: exact inside and in front of a face).  `sh` is the same
+// in every lane (wave-uniform loop of the caller): the shape's record comes from the LDS table as broadcast reads, its planes / core vertices
+// from the blob at a wave-uniform address (scalar loads).
+AGX_DEV float shape_distance(const uint32_t* blob, const float* body, const float* table, int sh, const float* x, float* nw) {
+  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
+  const float* clf = bf + bi[AGX_H_OFF_CLOTH]; const int* cl = bi + bi[AGX_H_OFF_CLOTH];
+  const float* rec = table + SHAPE_WORDS * sh; const int* reci = (const int*)rec;
+  const int np = wave_uniform(reci[1]), p0 = wave_uniform(reci[2]);
+  const float* B = body + 12 * wave_uniform(reci[0]); const float* R = B + 3;
+  const float d0 = x[0] - B[0], d1 = x[1] - B[1], d2 = x[2] - B[2];
+  const float xl0 = R[0] * d0 + R[3] * d1 + R[6] * d2, xl1 = R[1] * d0 + R[4] * d1 + R[7] * d2, xl2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+  const float rad = rec[3];
+  float n0, n1, n2, dist;
+  if (np == 0) {
+    const float* v = bf + bi[AGX_H_OFF_VERT] + 3 * wave_uniform(reci[4]);
+    float c0 = v[0], c1 = v[1], c2 = v[2];
+    if (wave_uniform(reci[5]) == 2) {
+      const float ab0 = v[3] - v[0], ab1 = v[4] - v[1], ab2 = v[5] - v[2], l2 = ab0 * ab0 + ab1 * ab1 + ab2 * ab2;
+      float t = l2 > 0.f ? ((xl0 - v[0]) * ab0 + (xl1 - v[1]) * ab1 + (xl2 - v[2]) * ab2) / l2 : 0.f; t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
+      c0 += t * ab0; c1 += t * ab1; c2 += t * ab2;
+    }
+    n0 = xl0 - c0; n1 = xl1 - c1; n2 = xl2 - c2; const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+    if (len > 1e-12f) { n0 /= len; n1 /= len; n2 /= len; } else { n0 = 0.f; n1 = 0.f; n2 = 1.f; }
+    dist = len - rad;
+  } else {
+    const float* P = clf + cl[AGX_CL_OFF_PLANE] + 4 * p0;
+    float bd = -3.0e38f; n0 = 0.f; n1 = 0.f; n2 = 1.f;
+    for (int k = 0; k < np; k++) { const float t = P[4 * k] * xl0 + P[4 * k + 1] * xl1 + P[4 * k + 2] * xl2 - P[4 * k + 3]; if (t > bd) { bd = t; n0 = P[4 * k]; n1 = P[4 * k + 1]; n2 = P[4 * k + 2]; } }
+    dist = bd - rad;
+  }
+  nw[0] = R[0] * n0 + R[1] * n1 + R[2] * n2; nw[1] = R[3] * n0 + R[4] * n1 + R[5] * n2; nw[2] = R[6] * n0 + R[7] * n1 + R[8] * n2;
+  return dist;
+}
+
+// the same from the blob's own records, `sh` free to differ between lanes: the spill query of the task layer (drinking.py:77; only particles
+// that have left the cup's cylinder ask)
+AGX_DEV float shape_distance_blob(const uint32_t* blob, const float* body, int sh, const float* x, float* nw) {
   const int* bi = (const int*)blob; const float* bf = (const float*)blob;
   const int* cl = bi + bi[AGX_H_OFF_CLOTH]; const float* clf = bf + bi[AGX_H_OFF_CLOTH];
   const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * sh; const int c = rec[0], p0 = rec[1], np = rec[2];
@@ -91,11 +144,14 @@ AGX_DEV void water_env(const uint32_t* blob, const float* gstate, const float* g
   const float dt = bf[bi[AGX_H_OFF_PARAMS] + AGX_P_DT] / (float)S_, grav = bf[bi[AGX_H_OFF_PARAMS] + AGX_P_GRAVITY_Z];
   const float r = par[AGX_CP_MARGIN], kDP = par[AGX_CP_KDP], kDF = par[AGX_CP_KDF]; const int piter = (int)par[AGX_CP_PITER];
   const int gender = ((const int*)gstate)[bi[AGX_H_S_ENV] + AGX_E_GENDER];
-  float* body = lds + L_BODY; float* box = lds + L_BOX; float* X = lds + L_X; float* cand = lds + L_CAND + lane * CONTACTS * CAND_WORDS;
+  float* body = lds + L_BODY; float* box = lds + L_BOX; float* X = lds + L_X; float* table = lds + L_SHAPE; int* list = (int*)(lds + L_LIST);
   const bool mine = lane < NN;
   float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f}, q[3];
   if (mine) for (int k = 0; k < 3; k++) { x[k] = gwater[3 * lane + k]; v[k] = gwater[3 * NN + 3 * lane + k]; }
   static_frames(blob, gstate, body, lane, false);
+  shape_table(blob, table, kDF, lane);
+  // candidate half spaces of this lane's particle: normal (3), offset, shape | touched << 16 -- registers, walked by unrolled predicated loops
+  float cn0[CONTACTS], cn1[CONTACTS], cn2[CONTACTS], cof[CONTACTS]; int csh[CONTACTS];
   int human_hit = 0;
   for (int sub = 0; sub < nsub; sub++) {
     // (a) frames of the moving links and the free bodies at the start of this substep; world boxes of the shapes
@@ -105,35 +161,53 @@ AGX_DEV void water_env(const uint32_t* blob, const float* gstate, const float* g
     for (int k = lane; k < 12 * nfree; k += 64) body[12 * (ndof + 2 + nhuman) + k] = tr[12 * ndof + k];
     wave_sync();
     for (int sh = lane; sh < NS; sh += 64) {
-      const int c = cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh];
-      const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
-      const float* B = body + 12 * body_slot(ci[AGX_C_BODY], ndof, nhuman); const float* R = B + 3;
-      const float g = cf[AGX_C_RADIUS] + 1e-6f;
+      const float* rec = table + SHAPE_WORDS * sh;
+      const float* B = body + 12 * ((const int*)rec)[0]; const float* R = B + 3;
+      const float g = rec[3] + 1e-6f;
       for (int k = 0; k < 3; k++) {
-        const float cw = B[k] + R[3 * k] * cf[AGX_C_AABB_C] + R[3 * k + 1] * cf[AGX_C_AABB_C + 1] + R[3 * k + 2] * cf[AGX_C_AABB_C + 2];
-        const float h = fabsf(R[3 * k]) * cf[AGX_C_AABB_H] + fabsf(R[3 * k + 1]) * cf[AGX_C_AABB_H + 1] + fabsf(R[3 * k + 2]) * cf[AGX_C_AABB_H + 2] + g;
+        const float cw = B[k] + R[3 * k] * rec[8] + R[3 * k + 1] * rec[9] + R[3 * k + 2] * rec[10];
+        const float h = fabsf(R[3 * k]) * rec[11] + fabsf(R[3 * k + 1]) * rec[12] + fabsf(R[3 * k + 2]) * rec[13] + g;
         box[6 * sh + k] = cw - h; box[6 * sh + 3 + k] = cw + h;
       }
     }
-    wave_sync();
-    // (b) gravity, candidates where the substep starts, prediction
-    int ncand = 0;
+    // (b) gravity; the shapes whose box meets the box of the water (each particle grown by its own reach) in shape order; a particle's
+    // candidates where the substep starts; prediction
+    float reach = 0.f;
     if (mine) {
       for (int k = 0; k < 3; k++) q[k] = x[k];
       v[2] += grav * dt;
-      const float reach = 2 * r + sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * dt;
-      for (int sh = 0; sh < NS && ncand < CONTACTS; sh++) {
-        const int only = cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh + 3];
-        if (only && only != gender + 1) continue;
-        const float* b6 = box + 6 * sh;
-        if (q[0] < b6[0] - reach || q[0] > b6[3] + reach || q[1] < b6[1] - reach || q[1] > b6[4] + reach || q[2] < b6[2] - reach || q[2] > b6[5] + reach) continue;
-        float nw[3]; const float d = shape_distance(blob, body, sh, q, nw);
-        if (d >= reach) continue;
-        float* c = cand + CAND_WORDS * ncand++;
-        c[0] = nw[0]; c[1] = nw[1]; c[2] = nw[2]; c[3] = (nw[0] * q[0] + nw[1] * q[1] + nw[2] * q[2]) - d; ((int*)c)[4] = sh;
-      }
-      for (int k = 0; k < 3; k++) x[k] = q[k] + v[k] * dt;
+      reach = 2 * r + sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * dt;
     }
+    // (a drunk particle waits thousands of metres away, drinking.py:70: it meets no shape's box -- the ground box ends at 15 m -- and stays out of the water's)
+    const bool here = mine && fabsf(q[0]) < 500.f && fabsf(q[1]) < 500.f && fabsf(q[2]) < 500.f;
+    float wlo[3], whi[3];
+    for (int k = 0; k < 3; k++) { wlo[k] = wave_min(here ? q[k] - reach : 3.0e38f); whi[k] = wave_max(here ? q[k] + reach : -3.0e38f); }
+    wave_sync();
+    int nlist = 0;
+    for (int base = 0; base < NS; base += 64) {
+      const int sh = base + lane; bool ok = sh < NS;
+      if (ok) { const int only = ((const int*)table)[SHAPE_WORDS * sh + 7] & 0xff; if (only && only != gender + 1) ok = false; }
+      if (ok) { const float* b6 = box + 6 * sh; for (int k = 0; k < 3; k++) if (b6[k] > whi[k] || b6[3 + k] < wlo[k]) ok = false; }
+      const uint64_t m = wave_ballot(ok);
+      if (ok) list[nlist + wave_rank(m)] = sh;
+      nlist += popc64(m);
+    }
+    wave_sync();
+    int ncand = 0;
+    for (int e = 0; e < nlist; e++) {                       // wave-uniform loop; a lane takes part while it has room and its particle is within reach of the shape's box
+      const int sh = wave_uniform(list[e]);
+      const float* b6 = box + 6 * sh;
+      const bool near = here && ncand < CONTACTS && !(q[0] < b6[0] - reach || q[0] > b6[3] + reach || q[1] < b6[1] - reach || q[1] > b6[4] + reach || q[2] < b6[2] - reach || q[2] > b6[5] + reach);
+      if (!wave_any(near)) continue;
+      float nw[3]; const float d = shape_distance(blob, body, table, sh, q, nw);
+      if (near && d < reach) {
+        const float off = (nw[0] * q[0] + nw[1] * q[1] + nw[2] * q[2]) - d;
+#pragma unroll
+        for (int cc = 0; cc < CONTACTS; cc++) if (cc == ncand) { cn0[cc] = nw[0]; cn1[cc] = nw[1]; cn2[cc] = nw[2]; cof[cc] = off; csh[cc] = sh; }
+        ncand++;
+      }
+    }
+    if (mine) for (int k = 0; k < 3; k++) x[k] = q[k] + v[k] * dt;
     // (c) projection iterations
     for (int it = 0; it < piter; it++) {
       wave_sync();
@@ -152,10 +226,10 @@ AGX_DEV void water_env(const uint32_t* blob, const float* gstate, const float* g
         }
         if (cnt > 1) for (int k = 0; k < 3; k++) dx[k] /= (float)cnt;
         for (int k = 0; k < 3; k++) x[k] += dx[k];
-        for (int cc = 0; cc < ncand; cc++) {
-          float* c = cand + CAND_WORDS * cc;
-          const float d = (c[0] * x[0] + c[1] * x[1] + c[2] * x[2]) - c[3] - r;
-          if (d < 0.f) { x[0] -= c[0] * d; x[1] -= c[1] * d; x[2] -= c[2] * d; ((int*)c)[4] |= 1 << 16; }
+#pragma unroll
+        for (int cc = 0; cc < CONTACTS; cc++) if (cc < ncand) {
+          const float d = (cn0[cc] * x[0] + cn1[cc] * x[1] + cn2[cc] * x[2]) - cof[cc] - r;
+          if (d < 0.f) { x[0] -= cn0[cc] * d; x[1] -= cn1[cc] * d; x[2] -= cn2[cc] * d; csh[cc] |= 1 << 16; }
         }
       }
     }
@@ -163,14 +237,13 @@ AGX_DEV void water_env(const uint32_t* blob, const float* gstate, const float* g
     human_hit = 0;
     if (mine) {
       for (int k = 0; k < 3; k++) v[k] = (x[k] - q[k]) / dt * (1 - kDP);
-      for (int cc = 0; cc < ncand; cc++) {
-        const float* c = cand + CAND_WORDS * cc; const int w = ((const int*)c)[4];
-        if (!(w >> 16)) continue;
-        const int col = cl[cl[AGX_CL_OFF_SHAPE] + 4 * (w & 0xffff)];
-        const float fr = kDF * bf[bi[AGX_H_OFF_COLL] + col * AGX_C_STRIDE + AGX_C_FRICTION], fc = fr < 1.f ? fr : 1.f;
-        const float vn = v[0] * c[0] + v[1] * c[1] + v[2] * c[2];
-        for (int k = 0; k < 3; k++) v[k] -= (v[k] - c[k] * vn) * fc;
-        if (bi[bi[AGX_H_OFF_COLL] + col * AGX_C_STRIDE + AGX_C_TAG] == AGX_TAG_HUMAN) human_hit = 1;
+#pragma unroll
+      for (int cc = 0; cc < CONTACTS; cc++) if (cc < ncand && (csh[cc] >> 16)) {
+        const float* rec = table + SHAPE_WORDS * (csh[cc] & 0xffff);
+        const float fc = rec[6];
+        const float vn = v[0] * cn0[cc] + v[1] * cn1[cc] + v[2] * cn2[cc];
+        v[0] -= (v[0] - cn0[cc] * vn) * fc; v[1] -= (v[1] - cn1[cc] * vn) * fc; v[2] -= (v[2] - cn2[cc] * vn) * fc;
+        if (((const int*)rec)[7] >> 8) human_hit = 1;
       }
     }
   }

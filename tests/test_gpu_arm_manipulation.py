@@ -63,14 +63,21 @@ def test_variant(am):
 def test_arm_fall_on_the_device_matches_the_oracle(am, device_fall):
     """the second settle of the reset (100 stepSimulation calls at gravity -1): device vs oracle, from the same posed records"""
     from oracle_lib import Oracle
+    import conditioning as C
     posed, _ = _states(am, 4, 7001)
     o = Oracle(device_fall.blob)
     fell = device_fall(posed, 100)
+    fw = C.float_words(am)
     for i in range(4):
         ref = posed[i].copy()
         o.settle(ref, 100)
-        q, qo = am.view(fell[i:i + 1])['q'][0, 10:], am.view(ref.reshape(1, -1))['q'][0, 10:]
-        assert np.abs(q - qo).max() < 5e-3, (i, q, qo)
+        # 100 FREE-RUNNING substeps of a limp arm falling onto the body (not a single step): the yardstick is the oracle's own run from
+        # the same record moved by one float32 ulp per word (tests/conditioning.py)
+        twin = posed[i].copy(); twin[fw] = C._perturb_f32(twin[fw], np.random.RandomState(i)); o.settle(twin, 100)
+        q, qo, qt = am.view(fell[i:i + 1])['q'][0, 10:], am.view(ref.reshape(1, -1))['q'][0, 10:], am.view(twin.reshape(1, -1))['q'][0, 10:]
+        spread = float(np.abs(qt - qo).max())
+        print('arm fall env %d: device vs oracle %.3g rad, oracle vs its 1-ulp twin %.3g rad' % (i, np.abs(q - qo).max(), spread))
+        assert np.abs(q - qo).max() < max(3e-4, C.K * spread), (i, q, qo, spread)
         assert np.abs(q - am.view(posed[i:i + 1])['q'][0, 10:]).max() > 0.05
 
 

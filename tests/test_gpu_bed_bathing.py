@@ -116,16 +116,25 @@ def test_free_running_episode_stays_close(bed, bed_oracle):
     states, _ = _states(bed, 4, 5301)
     st = Stepper(bed, 4)
     st.set_state(states)
+    import conditioning as C
     ref = states.copy()
-    dev_max = 0.0
+    # a second oracle run from the same states moved by ONE float32 ulp per word: how far 30 free-running steps carry a perturbation the
+    # device cannot even represent (tests/conditioning.py) -- the yardstick for the device's own drift
+    twin = states.copy()
+    fw = C.float_words(bed)
+    twin[:, fw] = C._perturb_f32(twin[:, fw], np.random.RandomState(1))
+    dev_max, spread = 0.0, 0.0
     for k in range(30):
         act = np.random.RandomState(300 + k).uniform(-1, 1, (4, 7)).astype(np.float32)
         obs, rew, done, info = st.step_host(act)
         for i in range(4):
             o_obs, o_rew, _, _ = bed_oracle.step(ref[i], act[i])
+            t_obs, t_rew, _, _ = bed_oracle.step(twin[i], act[i])
             dev_max = max(dev_max, float(np.abs(obs[i] - o_obs).max()), abs(float(rew[i]) - o_rew))
+            spread = max(spread, float(np.abs(t_obs - o_obs).max()), abs(t_rew - o_rew))
     st.close()
-    assert dev_max < 2e-3, dev_max
+    print('free-running 30 steps: device vs oracle %.3g, oracle vs its 1-ulp twin %.3g' % (dev_max, spread))
+    assert dev_max < max(2e-3, C.K * spread), (dev_max, spread)
 
 
 def test_vec_env_rollout_and_auto_reset(bed):
@@ -202,7 +211,9 @@ def test_coop_with_arm_limit_classifier_matches_oracle(bed):
             for f in (23, 50, 51):                              # contact forces (tool_force; total / pad force of the human's part): 1e-3 relative
                 assert dev[f] <= 1e-3 * max(1.0, abs(o_obs[f])), (k, i, f, obs[i, f], o_obs[f])
                 dev[f] = 0
-            d = max(float(dev.max()), abs(float(rew[i]) - o_rew))
+            # the reward carries the force terms with weights <= 0.05 (env.py:249-256): their 1e-3 relative bound is part of its own
+            fscale = max(1.0, float(np.abs(o_obs[[23, 50, 51]]).max()))
+            d = max(float(dev.max()), max(0.0, abs(float(rew[i]) - o_rew) - 0.06 * 1e-3 * fscale) / max(1.0, abs(o_rew)))
             if d > worst:
                 worst, where = d, (k, i, int(dev.argmax()), float(rew[i]), o_rew)
             vg, vo = coop.view(got[i].reshape(1, -1)), coop.view(ref[i].reshape(1, -1))

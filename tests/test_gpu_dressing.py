@@ -79,14 +79,22 @@ def test_step_matches_oracle(dr, dr_oracle):
     st = Stepper(dr, n)
     st.set_state(s); st.set_cloth(c)
     ref_s, ref_c = s.copy(), c.copy()
-    rel_force = []
+    import conditioning as C
+    rel_force, rel_sens = [], []
     for k in range(3):
         act = np.random.RandomState(300 + k).uniform(-1, 1, (n, 7)).astype(np.float32)
         st.set_state(ref_s); st.set_cloth(ref_c)
         obs, rew, done, info = st.step_host(act)
         gs, gc = st.get_state(), st.get_cloth()
         for i in range(n):
+            # The cloth-force term (dressing.py:35-43) is a sum over hundreds of node contacts, each in or out by two thresholds and by whether
+            # the node is inside a margin shell in the LAST of 40 substeps -- where resting nodes sit exactly ON the shell (the contact
+            # projection puts them there).  How well is it determined at all?  The oracle repeats the step with the garment moved by
+            # U(-1e-6, 1e-6) m per coordinate -- the distance device and oracle nodes are apart after one env step (median 3e-7, p99 5e-6 m
+            # below) -- and its OWN sum moves by percent (measured on the CPU: 0.1-1.4 % for one float32 ulp, 2-5 % for 1e-6 m).
+            sens = C.ulp_sensitivity(dr, dr_oracle, ref_s[i], act[i], cloth=ref_c[i], trials=2, seed=17 * k + i, cloth_eps=1e-6)
             o_obs, o_rew, o_done, o_info = dr_oracle.step_cloth(ref_s[i], ref_c[i], act[i])
+            rel_sens.append(sens['obs'][23] / max(1.0, abs(o_obs[23])))
             assert np.abs(obs[i, :23] - o_obs[:23]).max() < 1e-4, (k, i)
             # cloth forces: a sum over hundreds of node contacts, each in or out by two thresholds (height below the end effector, |f| < 20,
             # dressing.py:42) and by whether the node is inside a margin shell in the last substep: single contacts flip between f32 and f64
@@ -97,8 +105,11 @@ def test_step_matches_oracle(dr, dr_oracle):
         assert np.abs(gs - ref_s)[:, :57].max() < 1e-4                                               # joint angles, velocities, targets
         dx = np.abs(gc[:, 0] - ref_c[:, 0])
         assert np.median(dx) < 2e-5 and np.percentile(dx, 99) < 3e-3, (k, np.median(dx), np.percentile(dx, 99))      # 40 substeps; contact nodes drift apart
-    print('cloth_force_sum relative differences:', np.round(rel_force, 4))
-    assert np.median(rel_force) < 0.06 and max(rel_force) < 0.3
+    print('cloth_force_sum relative differences, device vs oracle:', np.round(rel_force, 4))
+    print('                                     oracle vs itself after a 1e-6 m perturbation of the garment:', np.round(rel_sens, 4))
+    # the written bound: the device's deviation is of the size of the oracle's own indeterminacy -- as a distribution (single
+    # contacts flip on either side): median within 2 x, maximum within 2 x, and 1e-3 where the term IS determined to 1e-3
+    assert np.median(rel_force) <= max(1e-3, 2.0 * np.median(rel_sens)) and max(rel_force) <= max(1e-3, 2.0 * max(rel_sens)), (np.median(rel_force), np.median(rel_sens), max(rel_force), max(rel_sens))
     st.close()
 
 

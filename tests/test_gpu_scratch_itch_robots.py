@@ -38,6 +38,7 @@ def test_check_collisions_and_rejection(rb):
 
 
 def test_step_matches_oracle(rb):
+    import conditioning as C
     from assistive_gym_amd.host.reset_bed import DeviceCollisionChecker
     from assistive_gym_amd.libagx import Stepper
     name, b, o = rb
@@ -57,18 +58,27 @@ def test_step_matches_oracle(rb):
         ref = st.get_state()                                   # single-step comparison from the device's own state
         obs, rew, done, info = st.step_host(act)
         for i in range(n):
-            o_obs, o_rew, o_done, o_info = o.step(ref[i], act[i])
+            o_obs, o_rew, o_done, o_info = o.step(ref[i].copy(), act[i])
             assert info[i, 6] == o_info[6] and abs(info[i, 7] - o_info[7]) <= 4, (i, info[i], o_info)
             dev = np.abs(obs[i] - o_obs)
-            # the tool force of a pressed contact after 50 unconverged sweeps, f32 against f64: the worst crafted state (Baxter, step 2, env 14) sits at
-            # 1.0e-3 relative -- 0.91e-3 with the per-lane loops of rounds 1-2, 1.03e-3 since the row products run on the matrix cores (another
-            # summation order); the CPU emulator of the kernels reproduces the device's value
-            assert dev[f] <= 2e-3 * max(1.0, abs(o_obs[f]))
+            # the tool force of a pressed contact after 50 unconverged sweeps, f32 against f64: north_star's 1e-3 relative; a case beyond it is
+            # judged against the oracle's own response to a 1-ulp perturbation of its input (tests/conditioning.py: the worst crafted state --
+            # Baxter, step 2, env 14 -- sits at 1.03e-3 since the row products run on the matrix cores, 0.91e-3 with the per-lane loops before)
+            sens = []
+            def _sens():
+                if not sens:
+                    sens.append(C.ulp_sensitivity(b, o, ref[i], act[i], trials=4))
+                return sens[0]
+            ok, lim, sv = C.within(dev[f], o_obs[f], lambda: _sens()['obs'][f])
+            if sv is not None:
+                print('conditioned: %s step %d env %d tool force dev %.3g rel, 1-ulp sensitivity %.3g' % (name, k, i, dev[f] / max(1.0, abs(o_obs[f])), sv))
+            assert ok, (k, i, dev[f], lim, sv)
             dev[f] = 0
             worst[i] = max(worst[i], float(dev.max()), abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
             assert info[i, 4] == o_info[4] and info[i, 1] == o_info[1] and bool(done[i]) == o_done
             for c in (0, 2, 3):
-                assert abs(info[i, c] - o_info[c]) <= 2e-3 * max(1.0, abs(o_info[c])), (i, c, info[i], o_info)
+                ok, lim, sv = C.within(abs(info[i, c] - o_info[c]), o_info[c], lambda: _sens()['info'][c])
+                assert ok, (i, c, info[i], o_info, lim, sv)
         touched += int((info[12:, 0] > 0).sum())            # total force on the human: the scratcher (or the arm behind it) presses on the limb
     st.close()
     assert worst[:12].max() < 1e-4 and worst[12:].max() < 1e-3, worst
