@@ -353,3 +353,32 @@ def test_packed_solver_rows_beyond_the_lds_window(blob, oracle):
     assert np.array_equal(a, b)
     vo, ve = blob.view(r), blob.view(b)
     assert np.abs(vo['q'] - ve['q']).max() < 2e-6 and np.abs(vo['qd'] - ve['qd']).max() < 2e-5
+
+
+def test_noop_retest_rule_against_the_plain_solve(blob):
+    """The no-op re-test rule (AGX_P_NOOP_RETEST = 5) is an approximation the oracle shares; here the kernel sources WITH the rule (the full 50
+    sweeps) against the ORACLE WITHOUT it (NOOP_RETEST = 0, the plain solve): settled FeedingJaco states, three steps each, reward / forces /
+    observation to 1e-3 relative.  The same comparison on 64 environments x 20 steps of configs 2 and 3 (wiping) runs on the GPU
+    (tests/test_gpu_parity.py); the sensitivity study behind the rule is tests/diag/noop_retest_sensitivity.py."""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    assert blob.param('NOOP_RETEST') == 5 and blob.param('NITER') == 50
+    e, with_rule, plain = Emu(blob), Oracle(blob), Oracle(blob.set_param('NOOP_RETEST', 0.0))
+    st, _ = make_states(blob, 3, seed=3601)
+    rng = np.random.RandomState(6)
+    differs = 0
+    for i in range(3):
+        s = st[i].copy()
+        with_rule.settle(s, 25)
+        for k in range(3):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            s_e, s_p, s_r = s.copy(), s.copy(), s.copy()
+            obs, rew, done, info, _ = e.step(s_e, a)
+            o_obs, o_rew, o_done, o_info = plain.step(s_p, a)
+            r_obs, r_rew, _, _ = with_rule.step(s_r, a)
+            differs += int(not np.array_equal(s_p, s_r))
+            assert np.abs(obs - o_obs).max() < 1e-3 and abs(rew - o_rew) <= 1e-3 * max(1.0, abs(o_rew)) and abs(info[0] - o_info[0]) <= 1e-3 * max(1.0, abs(o_info[0])), (i, k)
+            vq, vp = blob.view(s_e[None])['q'][0], blob.view(s_p[None])['q'][0]
+            assert np.abs(vq - vp).max() < 1e-4
+            s = s_p
+    assert differs > 0                                     # (the rule does change the arithmetic: a real comparison)
