@@ -23,6 +23,10 @@ namespace agxc {
 constexpr int T = AGX_CLOTH_THREADS;
 constexpr int NPT = 4096 / T;              // nodes per thread (garments of up to 4,096 nodes)
 constexpr int LPT = 1024 / T;              // links per thread and colour class (classes hold at most 1,024 links)
+#ifndef AGXC_PF
+#define AGXC_PF 3
+#endif
+constexpr int PF = AGXC_PF;                // colour classes of link records in flight (see PSolve_Links)
 constexpr int NODE_CONTACTS = 2;          // AGX_CLOTH_NODE_CONTACTS: contacts kept per node (the first ones in shape order)
 constexpr int MAX_BODIES = 64, MAX_SHAPES = 192;
 constexpr float EPS = 1.1920929e-7f;      // SIMD_EPSILON
@@ -44,6 +48,20 @@ __device__ inline void quat_to_mat(const float* q, float* R) {
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
   R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
   R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// Workgroup barrier for phases that exchange data through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier: the fence makes
+// every wave wait for ALL its outstanding memory operations -- including the link records of the NEXT colour class, which are requested one
+// class ahead precisely so that their L2 latency overlaps this class's LDS work.  With 17 barriers per solver iteration and 200 iterations
+// per env step that wait (a full global-memory round trip per phase) was most of the kernel.  Here: wait for this wave's LDS operations only
+// (lgkmcnt), then the barrier; global loads stay in flight (the link table is read-only, and the contact records in the HBM scratch are only
+// ever touched by the thread that owns the node).  -DAGXC_FULL_BARRIERS restores __syncthreads() for same-box A/B runs.
+__device__ inline void lds_barrier() {
+#ifdef AGXC_FULL_BARRIERS
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // LDS layout (floats)
@@ -154,12 +172,12 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   for (int j = 0; j < NPT; j++) { const int i = cl[cl[AGX_CL_OFF_PERM] + wave * (64 * NPT) + j * 64 + lane]; own[j] = i; attached[j] = false; for (int a = 0; a < NA; a++) if (anci[4 * a] == i) attached[j] = true; }
   int ncon[NPT];
   float* const grec = greport + AGX_CLOTH_REPORT_WORDS(NN);
-  __syncthreads();
+  lds_barrier();
   for (int sub = 0; sub < nsub; sub++) {
     // (a) frames of the moving links at the start of this substep; attachment point at the start of the current stepSimulation call
     const float* tr = gtrace + (size_t)sub * ndof * 12;
     for (int k = tid; k < 12 * ndof; k += T) S.body[k] = tr[k];
-    __syncthreads();
+    lds_barrier();
     if (sub % S_ == 0 && tid == 0) {     // end-effector frame origin = link frame * EE_POS (dressing.py:200-210)
       const int ot = bi[AGX_H_OFF_TASK]; const float* B = S.body + 12 * bi[ot + AGX_T_EE_LINK];
       st(S.anchor, ld(B) + rot(B + 3, ld(bf + ot + AGX_T_EE_POS)));
@@ -181,7 +199,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
                   hz = fabsf(R[6]) * h.x + fabsf(R[7]) * h.y + fabsf(R[8]) * h.z + r;
       float* bx = S.box + 6 * tid; bx[0] = cw.x - hx; bx[1] = cw.y - hy; bx[2] = cw.z - hz; bx[3] = cw.x + hx; bx[4] = cw.y + hy; bx[5] = cw.z + hz;
     }
-    __syncthreads();
+    lds_barrier();
     if (wave == 0) {                     // candidate list: shapes of this gender whose box meets the cloth's, in shape order
       float clo[3], chi[3];
       for (int a = 0; a < 3; a++) { clo[a] = S.red[a]; chi[a] = S.red[3 + a]; for (int w = 1; w < T / 64; w++) { clo[a] = fminf(clo[a], S.red[6 * w + a]); chi[a] = fmaxf(chi[a], S.red[6 * w + 3 + a]); } }
@@ -221,10 +239,10 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
         vnew[j] = v;
       }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < NPT; j++) { const int i = own[j]; if (i >= 0) { const f3 xi = ld(S.x + 3 * i); st(S.q + 3 * i, xi); st(S.x + 3 * i, xi + dt * vnew[j]); } }
-    __syncthreads();
+    lds_barrier();
     // (c) contacts of this thread's nodes (CollideSDF_RS::DoNode)
 #ifdef AGXC_NO_CONTACTS
     const int ncand = 0;
@@ -283,7 +301,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
         const int i = anci[4 * tid]; const f3 wa = ld(S.anchor) + ld(ancf + 4 * tid + 1), xi = ld(S.x + 3 * i), qi = ld(S.q + 3 * i);
         st(S.x + 3 * i, xi + (-1.0f) * (xi - qi) + kAHR * (wa - xi));
       }
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int j = 0; j < NPT; j++) {     // PSolve_RContacts
         const int i = own[j];
@@ -309,42 +327,62 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
       // executes a wave's accesses in order, and nothing but this wave has touched the patch since the anchors' barrier (a node's contacts
       // move that node only).  Link table: class w KP + c = 64 slots, lane l relaxes slot l; streamed one class ahead.
       {
+        // link records are requested PF classes ahead of their use (a ring of PF registers, statically indexed: the loop is unrolled by PF):
+        // an L2 round trip is several classes long, one class ahead (round 3) still exposed most of it at every class
         const int2* pl = links + (size_t)wave * KP * 64 + lane;
-        int2 nx = KP > 0 ? pl[0] : make_int2(-1, 0);
-        for (int c = 0; c < KP; c++) {
+        int2 ring[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) ring[u] = u < KP ? pl[u * 64] : make_int2(-1, 0);
+        for (int c0 = 0; c0 < KP; c0 += PF) {
 #ifdef AGXC_NO_LINKS
           break;
 #endif
-          const int2 cur = nx;
-          if (c + 1 < KP) nx = pl[(c + 1) * 64];
-          if (cur.x >= 0) {
-            const int a = cur.x & 0xffff, b = (cur.x >> 16) & 0xffff;
-            const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur.y);
-            if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+#pragma unroll
+          for (int u = 0; u < PF; u++) {
+            const int c = c0 + u;
+            if (c >= KP) break;
+            const int2 cur = ring[u];
+            ring[u] = c + PF < KP ? pl[(c + PF) * 64] : make_int2(-1, 0);
+            if (cur.x >= 0) {
+              const int a = cur.x & 0xffff, b = (cur.x >> 16) & 0xffff;
+              const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur.y);
+              if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next class reads what this one wrote (other lanes of this wave)
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next class reads what this one wrote (other lanes of this wave)
         }
       }
-      __syncthreads();
+      lds_barrier();
       // (2) the links between patches, one colour class at a time across the workgroup
       const int* xcolor = color + (T / 64) * KP; const int NX = NCOL - (T / 64) * KP;
-      int2 nxt[LPT];
+      int2 nxt[PF][LPT];
 #pragma unroll
-      for (int u = 0; u < LPT; u++) { const int l = xcolor[0] + tid + u * T; nxt[u] = (NX > 0 && l < xcolor[1]) ? links[l] : make_int2(-1, 0); }
-      for (int c = 0; c < NX; c++) {
+      for (int p = 0; p < PF; p++)
+#pragma unroll
+        for (int u = 0; u < LPT; u++) { const int l = (p < NX ? xcolor[p] : 0) + tid + u * T; nxt[p][u] = (p < NX && l < xcolor[p + 1]) ? links[l] : make_int2(-1, 0); }
+      for (int c0 = 0; c0 < NX; c0 += PF) {
 #ifdef AGXC_NO_LINKS
         break;
 #endif
-        int2 cur[LPT];
 #pragma unroll
-        for (int u = 0; u < LPT; u++) { cur[u] = nxt[u]; if (c + 1 < NX) { const int l = xcolor[c + 1] + tid + u * T; nxt[u] = l < xcolor[c + 2] ? links[l] : make_int2(-1, 0); } }
+        for (int p = 0; p < PF; p++) {
+          const int c = c0 + p;
+          if (c >= NX) break;
+          int2 cur[LPT];
 #pragma unroll
-        for (int u = 0; u < LPT; u++) if (cur[u].x >= 0) {
-          const int a = cur[u].x & 0xffff, b = (cur[u].x >> 16) & 0xffff;
-          const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur[u].y);
-          if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+          for (int u = 0; u < LPT; u++) {
+            cur[u] = nxt[p][u];
+            const int l = (c + PF < NX ? xcolor[c + PF] : 0) + tid + u * T;
+            nxt[p][u] = (c + PF < NX && l < xcolor[c + PF + 1]) ? links[l] : make_int2(-1, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < LPT; u++) if (cur[u].x >= 0) {
+            const int a = cur[u].x & 0xffff, b = (cur[u].x >> 16) & 0xffff;
+            const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur[u].y);
+            if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+          }
+          lds_barrier();
         }
-        __syncthreads();
       }
     }
   }
@@ -362,7 +400,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   const float vc = (1.0f - kDP) / dt;
   for (int k = tid; k < 3 * NN; k += T) { gcloth[k] = S.x[k]; gcloth[3 * NN + k] = (S.x[k] - S.q[k]) * vc; }
 }

@@ -1,7 +1,7 @@
 """Workload for the PMC passes: 6 observation-only launches (known traffic: one state record read,
 one observation written per env) followed by 6 full env.step launches, 4096 envs, unchunked
 (AGX_CHUNKS=1: every launch covers all environments, so per-launch counters are per 4096 environments).
-  python tools/pmc_workload.py [feeding|bedbathing|scratchitch|armmanipulation|dressing] [envs]
+  python tools/pmc_workload.py [feeding|bedbathing|scratchitch|armmanipulation|dressing|drinking] [envs]
 (dressing: 1024 environments by default -- one 1,024-thread cloth workgroup each -- and 4 steps)"""
 import os, sys
 os.environ.setdefault('AGX_CHUNKS', '1')
@@ -11,7 +11,7 @@ import torch
 from assistive_gym_amd import vec_env
 task = sys.argv[1] if len(sys.argv) > 1 else 'feeding'
 cls = {'feeding': 'FeedingJacoVecEnv', 'bedbathing': 'BedBathingSawyerVecEnv', 'scratchitch': 'ScratchItchPR2HumanVecEnv', 'armmanipulation': 'ArmManipulationSawyerVecEnv',
-       'dressing': 'DressingBaxterVecEnv'}[task]
+       'dressing': 'DressingBaxterVecEnv', 'drinking': 'DrinkingJacoVecEnv'}[task]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else (1024 if task == 'dressing' else 4096)
 env = getattr(vec_env, cls)(n, pool_size=16 if task == 'dressing' else 32 if task in ('scratchitch', 'armmanipulation') else 64, seed=1001, auto_reset=False)
 env.reset()
