@@ -49,7 +49,7 @@ class AgxVectorEnv(_VectorEnv):
         from .vec_env import AssistiveVecEnv
         name = env_id.split(':')[-1]
         proto = envs.ENV_IDS[name]()                     # spaces and info keys of the scalar env
-        assert not proto.coop, 'co-op (multi-agent) envs go through RLlib MultiAgentEnv, not VectorEnv'
+        assert not proto.coop, 'co-op (multi-agent) ids are batched by AgxMultiAgentBatchEnv (RLlib BaseEnv), not by a VectorEnv'
         super().__init__(proto.observation_space, proto.action_space, num_envs)
         self._info_static = {'action_robot_len': proto.action_robot_len, 'action_human_len': proto.action_human_len,
                              'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
@@ -62,7 +62,9 @@ class AgxVectorEnv(_VectorEnv):
         return list(self._obs)
 
     def reset_at(self, index):
-        return self._obs[index]                          # the batch was reset on the device at the episode boundary
+        # the batch was reset on the device at the episode boundary; an environment the non-finite guard ended mid-episode was replaced at
+        # once (vec_env.step) and its row already holds the first observation of its new episode
+        return self._obs[index]
 
     def vector_step(self, actions):
         import torch
@@ -89,3 +91,97 @@ class AgxVectorEnv(_VectorEnv):
 
     def close(self):
         self.vec.close()
+
+
+try:
+    from ray.rllib.env.base_env import BaseEnv as _BaseEnv
+except Exception:
+    class _BaseEnv:
+        pass
+
+
+class AgxMultiAgentBatchEnv(_BaseEnv):
+    """The co-op ids (`<Task><Robot>Human-v1`: RLlib MultiAgentEnv in the reference, two policies 'robot' and 'human' --
+    assistive_gym/learn.py:33-36, e.g. scratch_itch_envs.py:41-44 = BASELINE config 4) as ONE RLlib BaseEnv over the batched stepper: what
+    `num_workers = cpu_count()` processes with one scalar multi-agent env each do in the reference.  RLlib's BaseEnv contract (ray 1.x):
+
+        poll() -> (obs, rewards, dones, infos, off_policy_actions), each {env_id: {agent_id: value}} (dones also carry '__all__')
+        send_actions({env_id: {agent_id: action}});   try_reset(env_id) -> {agent_id: obs};   get_unwrapped() -> []
+
+    One env.step() of all environments and ONE device-to-host transfer per poll/send round (a single pinned buffer: both agents'
+    observations, reward, done, two info columns).  Register it the way the reference registers its scalar multi-agent envs:
+
+        register_env('assistive_gym:ScratchItchPR2Human-v1', lambda cfg: AgxMultiAgentBatchEnv('ScratchItchPR2Human-v1', cfg.get('num_envs', 1024)))
+    """
+
+    def __init__(self, env_id, num_envs, device=0, seed=1001, **vec_kwargs):
+        from . import envs
+        from .vec_env import AssistiveVecEnv
+        name = env_id.split(':')[-1]
+        cls = envs.ENV_IDS[name]
+        assert cls.coop, 'single-agent ids go through AgxVectorEnv'
+        proto = cls()
+        self.num_envs = num_envs
+        self.observation_space_robot, self.observation_space_human = proto.observation_space_robot, proto.observation_space_human
+        self.action_space_robot, self.action_space_human = proto.action_space_robot, proto.action_space_human
+        self.observation_space, self.action_space = proto.observation_space, proto.action_space
+        self.nr, self.ar = proto.obs_robot_len, proto.action_robot_len
+        self._info_static = {'action_robot_len': proto.action_robot_len, 'action_human_len': proto.action_human_len,
+                             'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
+        vec_kwargs.setdefault('reset', 'pool')
+        self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=cls.model, coop=True, **vec_kwargs)
+        self._host = self._pack = None
+        self._pending = None             # what the next poll() returns
+        self._first = self._split(self.vec.reset().cpu().numpy().astype(np.float64))
+        self._pending = (dict(self._first), {}, {}, {})
+        self._new_obs = {}               # env_id -> first observation of the episode that began at the last boundary (try_reset)
+
+    def _split(self, obs):
+        return {i: {'robot': obs[i, :self.nr], 'human': obs[i, self.nr:]} for i in range(self.num_envs)}
+
+    def poll(self):
+        obs, rew, done, info = self._pending
+        self._pending = ({}, {}, {}, {})
+        return obs, rew, done, info, {}
+
+    def send_actions(self, action_dict):
+        import torch
+        n = self.num_envs
+        a = np.zeros((n, self.vec.act_dim), dtype=np.float32)
+        for i, d in action_dict.items():
+            a[i, :self.ar] = d['robot']; a[i, self.ar:] = d['human']
+        obs, rew, done, info = self.vec.step(torch.as_tensor(a, device=self.vec.device).contiguous())
+        boundary = self.vec._t % self.vec.episode_len == 0
+        last = self.vec.terminal_obs if boundary else obs
+        od = last.shape[1]
+        if self._host is None:
+            self._pack = torch.empty((n, od + 4), dtype=torch.float32, device=self.vec.device)
+            self._host = torch.empty((n, od + 4), dtype=torch.float32, pin_memory=True)
+        self._pack[:, :od] = last; self._pack[:, od] = rew; self._pack[:, od + 1] = done.float(); self._pack[:, od + 2:od + 4] = info[:, 0:2]
+        self._host.copy_(self._pack, non_blocking=True)
+        torch.cuda.current_stream(self.vec.device).synchronize()
+        h = self._host.numpy()
+        o = self._split(h[:, :od].astype(np.float64))
+        r = {i: {'robot': float(h[i, od]), 'human': float(h[i, od])} for i in range(n)}                       # both agents share the reward (feeding.py:41-43)
+        d = {i: {'robot': bool(h[i, od + 1]), 'human': bool(h[i, od + 1]), '__all__': bool(h[i, od + 1])} for i in range(n)}
+        inf = {i: {'robot': dict(self._info_static, total_force_on_human=float(h[i, od + 2]), task_success=int(h[i, od + 3]))} for i in range(n)}
+        for i in range(n):
+            inf[i]['human'] = inf[i]['robot']
+        if h[:, od + 1].any():           # environments that ended (all of them at the 200-step boundary): their next observation is the new episode's first
+            first = self._split(obs.cpu().numpy().astype(np.float64))
+            self._new_obs = {i: first[i] for i in range(n) if h[i, od + 1]}
+        self._pending = (o, r, d, inf)
+
+    def try_reset(self, env_id=None):
+        """RLlib calls this for an env whose '__all__' is done; the batch has already been reset on the device"""
+        if env_id is None:
+            return {i: self.try_reset(i) for i in range(self.num_envs)}
+        return self._new_obs.pop(env_id, None) or self._first[env_id]
+
+    def get_unwrapped(self):
+        return []
+
+    def stop(self):
+        self.vec.close()
+
+    close = stop

@@ -481,6 +481,16 @@ def main():
             extra[key]['roofline'] = {k: r['roofline'][k] for k in ('achieved', 'peak', 'frac', 'traffic', 'kernel', 'kernel_ms_per_launch', 'algorithmic_bytes_per_env_step', 'valu_issue_frac') if k in r['roofline']}
             if 'cloth_kernel' in r['roofline']:
                 extra[key]['roofline']['cloth_kernel'] = r['roofline']['cloth_kernel']
+        # config 3 with a NEW human / base pose for every episode of every environment (reset='device': 4096 rag dolls dropped and settled for
+        # 100 steps at each 200-step boundary -- the Amdahl term the pool avoids; two boundaries inside the timed window) beside the pool rate above
+        args_dev = argparse.Namespace(**dict(vars(args), reset='device', pool=None))
+        r = run_config(args_dev, 'bedbathing', 400, 10, rank, world, local_rank, distributed, cpu=False)
+        extra['config3_BedBathingSawyer-v1_reset_on_device_every_episode'] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'contacts_per_substep', 'overflow_count')}
+        extra['config3_BedBathingSawyer-v1_reset_on_device_every_episode']['workload'] = r['config']['workload'] + '; every episode starts from a newly sampled and settled state (agx_reset with the rag-doll model attached)'
+        # Drinking: the sixth task, 64 water particles per environment
+        r = run_config(args, 'drinking', 200, 10, rank, world, local_rank, distributed, cpu=False)
+        extra['DrinkingJaco-v1'] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'contacts_per_substep', 'overflow_count')}
+        extra['DrinkingJaco-v1']['workload'] = r['config']['workload']
         out['configs'] = extra
     if rank == 0:
         print(json.dumps(out))

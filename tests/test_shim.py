@@ -145,3 +145,42 @@ def test_vector_env_adapter_steps_on_the_gpu(env_id):
     first = env.reset_at(3)                               # first observation of the next episode, already on the host
     assert first.shape == env.observation_space.shape and np.isfinite(first).all() and not np.array_equal(first, obs[3])
     env.close()
+
+
+def test_multi_agent_batch_adapter_surface():
+    """the co-op batch adapter (RLlib BaseEnv contract) imports without ray"""
+    from assistive_gym_amd.rllib import AgxMultiAgentBatchEnv
+    for m in ('poll', 'send_actions', 'try_reset', 'get_unwrapped', 'stop'):
+        assert callable(getattr(AgxMultiAgentBatchEnv, m))
+
+
+@pytest.mark.gpu
+def test_multi_agent_batch_adapter_runs_config4_batched():
+    """BASELINE config 4's environment (ScratchItchPR2Human-v1: two policies, 7 + 10 actions, 30 + 34 observations) through the co-op batch
+    adapter: one poll / send_actions round = one env.step() of the whole batch; per-agent dictionaries as the reference's MultiAgentEnv
+    returns them (scratch_itch.py:38-40); the same numbers as the scalar multi-agent env from the same state"""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        __import__('conftest').no_gpu()
+    from assistive_gym_amd.rllib import AgxMultiAgentBatchEnv
+    from assistive_gym_amd.envs import ENV_IDS
+    n = 16
+    env = AgxMultiAgentBatchEnv('assistive_gym:ScratchItchPR2Human-v1', n, pool_size=8)
+    obs, rew, done, info, off = env.poll()
+    assert sorted(obs) == list(range(n)) and obs[0]['robot'].shape == (30,) and obs[0]['human'].shape == (34,) and rew == {} and off == {}
+    scalar = ENV_IDS['ScratchItchPR2Human-v1']()
+    scalar.set_state(env.vec.stepper.get_state()[5])
+    rng = np.random.RandomState(0)
+    for k in range(200):
+        acts = {i: {'robot': rng.uniform(-1, 1, 7), 'human': rng.uniform(-1, 1, 10)} for i in range(n)}
+        env.send_actions(acts)
+        obs, rew, done, info, _ = env.poll()
+        if k == 0:
+            so, sr, sd, si = scalar.step(acts[5])
+            assert np.abs(so['robot'] - obs[5]['robot']).max() < 1e-5 and np.abs(so['human'] - obs[5]['human']).max() < 1e-5 and abs(sr['robot'] - rew[5]['robot']) < 1e-5
+        assert all(done[i]['__all__'] == (k == 199) for i in range(n)) and rew[3]['robot'] == rew[3]['human']
+        assert set(info[0]['robot']) == {'total_force_on_human', 'task_success', 'action_robot_len', 'action_human_len', 'obs_robot_len', 'obs_human_len'}
+    first = env.try_reset(3)
+    assert first['robot'].shape == (30,) and np.isfinite(first['human']).all() and not np.array_equal(first['robot'], obs[3]['robot'])
+    scalar.disconnect(); env.stop()
