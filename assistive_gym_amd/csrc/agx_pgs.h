@@ -279,6 +279,14 @@ AGX_DEV int pgs_lds_split(const PgsSet& S, int lane, int l0, int l1) {
 // instead of 16, so the solve launch of BedBathingSawyer only went from 0.57 to 0.50 ms and its step rate from 890 k to 995 k.  Same rows, same order, same clamps as the velocity-space sweep; the results differ by rounding only
 // (sums are associated differently).  dv = sum_i B_i lambda_i is formed once at the end.
 // Returns false (nothing done) if the environment has more rows than fit or touches DoFs beyond lane 63.
+// K of the no-op re-test rule for this environment and substep (see pgs()): AGX_P_NOOP_RETEST, or 0 = plain sweeps when one of the
+// substep's contacts is pressed deeper than AGX_P_NOOP_PEN (include/agx_blob.h).  Wave-uniform; lane = contact (MAX_CON <= 64).
+AGX_DEV int noop_period(const Ctx& c) {
+  const int K = (int)PRM(c, AGX_P_NOOP_RETEST); const float pen = PRM(c, AGX_P_NOOP_PEN);
+  if (K <= 0 || !(pen > 0.f)) return K;
+  const bool pressed = c.lane < c.ncon && c.gcon[CON_STRIDE * c.lane + C_DIST] < -pen;
+  return wave_any(pressed) ? 0 : K;
+}
 AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
   if constexpr (RS_MAX_ROWS == 0) { (void)c; (void)W; (void)dv0; (void)dv1; return false; }
   else {
@@ -328,7 +336,7 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
     if (c.dbg && lane == 0) c.dbg[DBG_TIME + 7] = (float)(wave_clock() - tA0);
     float w = 0.f;                                                  // J_r . dv of this lane's row
     const int fn = lane - nc;                                       // normal row of this lane's friction row
-    const int K = (int)PRM(c, AGX_P_NOOP_RETEST);                   // the no-op re-test rule, see pgs()
+    const int K = noop_period(c);                                   // the no-op re-test rule, see pgs()
     uint64_t skip = 0ull;
     for (int it = 0; it < iters; it++) {
       const bool retest = K > 0 && it % K == 0;
@@ -392,7 +400,7 @@ AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   // sweep (sweep index divisible by K) changed nothing -- an inactive contact or limit (0 -> 0), a motor sitting on its force bound --
   // is not visited in the K - 1 sweeps that follow (42 % of these visits are no-ops in FeedingJaco; the oracle applies the same
   // rule, pgs() in oracle/agx_oracle.c; sensitivity: profiles/r03/noop_retest_sensitivity.json).  K = 0: every row in every sweep.
-  const int K = (int)PRM(c, AGX_P_NOOP_RETEST);
+  const int K = noop_period(c);
   uint64_t skip0 = 0ull, skip1 = 0ull;
   for (int it = 0; it < iters; it++) {
     const bool retest = K > 0 && it % K == 0, use = K > 0 && !retest;

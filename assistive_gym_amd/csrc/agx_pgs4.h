@@ -135,6 +135,7 @@ AGX_DEV void env_solve4(const uint32_t* blob, float* gstate_all, float* gscratch
     sm = F[0]; sxx = F[1]; sxy = F[2]; sxz = F[3]; syy = F[4]; syz = F[5]; szz = F[6];
   }
   float dv0 = 0.f, dv1 = 0.f, dv2 = 0.f, dv3 = 0.f, dv4 = 0.f, dv5 = 0.f;
+  // (one no-op period for the four environments of the wave: AGX_P_NOOP_PEN, the product kernel's per-environment switch to plain sweeps, is not implemented here)
   const int iters = (int)bf[bi[AGX_H_OFF_PARAMS] + AGX_P_NITER], K = (int)bf[bi[AGX_H_OFF_PARAMS] + AGX_P_NOOP_RETEST];
   const float* ZERO = lds + P4_ZERO;
   int lenA = 0; bool farA = false;

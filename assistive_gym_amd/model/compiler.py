@@ -35,7 +35,7 @@ H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT
          OFF_TARGETS=38, OFF_MLP=39, OFF_CLOTH=40, SIM_SUBSTEPS=41, BASE_LINK=42, COUNT=48)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
-         HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, NOOP_RETEST=20, ORACLE_RESIDUAL_EPS=21, ORACLE_FRICTION_DIRS=22, ORACLE_WARMSTART=23, COUNT=24)
+         HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, NOOP_RETEST=20, ORACLE_RESIDUAL_EPS=21, ORACLE_FRICTION_DIRS=22, ORACLE_WARMSTART=23, NOOP_PEN=24, COUNT=25)
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, COM=11, MASS=14, INERTIA=15, LOWER=21, UPPER=22, HAS_LIMIT=23, KP=24, KD=25,
          MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, JTYPE=32, ACT_MULT=33, ACT_SRC=34, OBS_SKIP=35, STRIDE=36)
 F = dict(MASS=0, INERTIA=1, GRAVITY=4, REFPOS=5, REFQUAT=8, KIND=12, RADIUS=13, STRIDE=16)
@@ -79,7 +79,7 @@ MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathin
 # pair-group flags (AGX_G_FLAGS)
 GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC = 1, 2, 4, 8, 16, 32
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 10
+MAGIC, VERSION = 0x31584741, 11
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -155,7 +155,14 @@ def link_collision_hulls(link, max_verts, assets_cache):
         elif c.kind == 'box':
             if np.all(np.asarray(c.size) <= 0):
                 continue  # zero-size end-effector marker box (j2s7s300_gym.urdf:389-393): no volume
-            out.append((X.apply(c.pos, c.quat, box_verts(np.zeros(3), np.asarray(c.size) / 2)), 0.0))
+            # btBoxShape with the URDF importer's collision margin (gUrdfDefaultCollisionMargin = 1 mm, as for the meshes): the core is the box
+            # SHRUNK by the margin, the margin is added back as a radius -- the faces stay where they are, edges are rounded by 1 mm
+            # [BULLET-UNVERIFIED].  It is also what keeps the contact normal of two primitives resting on each other (the Sawyer's arm on its
+            # pedestal) defined in float32: with zero-radius cores the normal is (pa - pb) / d at d ~ 1e-6 m -- 5 % noise at float32 pose
+            # accuracy, a free-running BedBathingSawyer episode drifted 5e-3 rad from the f64 oracle through ONE such contact (round 4).
+            half = np.asarray(c.size, dtype=np.float64) / 2
+            m = min(HULL_MARGIN, 0.5 * float(half.min()))
+            out.append((X.apply(c.pos, c.quat, box_verts(np.zeros(3), half - m)), m))
         elif c.kind == 'sphere':
             out.append((np.asarray(c.pos)[None], c.radius))
         elif c.kind == 'capsule':
@@ -166,7 +173,7 @@ def link_collision_hulls(link, max_verts, assets_cache):
             a = np.linspace(0, 2 * np.pi, 16, endpoint=False)
             ring = np.stack([c.radius * np.cos(a), c.radius * np.sin(a)], axis=1)
             pts = np.concatenate([np.c_[ring, np.full(16, -c.length / 2)], np.c_[ring, np.full(16, c.length / 2)]])
-            out.append((X.apply(c.pos, c.quat, pts), 0.0))
+            out.append((X.apply(c.pos, c.quat, pts), HULL_MARGIN))      # a convex hull of ring points with the importer's margin outside, like a mesh [BULLET-UNVERIFIED]
     return out
 
 
@@ -455,6 +462,7 @@ def default_params(n_iter):
     return dict(DT=0.02, FRAME_SKIP=5, NITER=n_iter, ERP=0.2, CONTACT_ERP=0.2, CONTACT_BREAK=0.02, LIN_DAMP=0.04, ANG_DAMP=0.04,
                 FRIC_EPS=1e-7, LIMIT_ACT=0.25, ACTION_SCALE=0.05, GRAVITY_Z=-9.81, GJK_TOL=1e-6, GJK_MAXIT=24, MAX_CONTACTS=64,
                 MAX_ROWS=160, ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=0.0, CONTACT_SLACK=0.001, MAX_ENTRIES=2040,
+                NOOP_PEN=0.0002,   # ... but not in a substep with a contact pressed deeper than 0.2 mm (agx_blob.h AGX_P_NOOP_PEN)
                 NOOP_RETEST=5)     # rows whose visit was a no-op are re-tested every 5th sweep (agx_blob.h AGX_P_NOOP_RETEST; 0 = plain PGS)
 
 

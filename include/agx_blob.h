@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 10
+#define AGX_BLOB_VERSION 11
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -107,7 +107,14 @@ enum {
   AGX_P_ORACLE_FRICTION_DIRS = 22,/* 2: a second friction row per contact along n x t (SOLVER_USE_2_FRICTION_DIRECTIONS); 0 / 1: one        */
   AGX_P_ORACLE_WARMSTART = 23,    /* > 0: contact normals start from this factor x the impulse of the same contact in the previous substep
                                      (SOLVER_USE_WARMSTARTING, m_warmstartingFactor 0.85)                                                 */
-  AGX_P_COUNT = 24
+  AGX_P_NOOP_PEN = 24,   /* > 0: the no-op re-test rule is switched OFF (plain sweeps) for an environment in every substep that has a contact
+                            penetrating deeper than this (metres).  The rule delays the wake-up of a skipped row by up to K - 1 sweeps; with a tool
+                            PRESSED onto skin -- where the force terms of the rewards come from -- that moved total_force_on_human by up to 5e-2 N
+                            and single steps' rewards through flipped wiping events against the plain 50-sweep solve (f64 oracle with the rule vs
+                            without, BedBathingSawyer wiping workload: 5 of 96 steps beyond 1e-3).  With 0.2 mm the same 96 steps are identical to
+                            the plain solve, and FeedingJaco's resting food pile (penetrations of ~0.05 mm) keeps the rule: 75.5 -> 76.5 row
+                            visits per sweep.  0 = the rule applies regardless (round 3) */
+  AGX_P_COUNT = 25
 };
 
 /* ---- ROBOT: one record per moving link, stride AGX_R_STRIDE ------------------------------- */

@@ -986,7 +986,9 @@ double g_pgs_stats[8];
  * is an exact no-op and is skipped by the device in any case. */
 static void pgs(sim_t* s, double* dv) {
   int iters = (int)PARAM(s->m, AGX_P_NITER);
-  const int K = (int)PARAM(s->m, AGX_P_NOOP_RETEST);
+  int K = (int)PARAM(s->m, AGX_P_NOOP_RETEST);
+  { const double pen = PARAM(s->m, AGX_P_NOOP_PEN);          /* a pressed contact (deeper than AGX_P_NOOP_PEN): plain sweeps in this substep */
+    if (K > 0 && pen > 0) for (int c = 0; c < s->ncon; c++) if (s->con[c].dist < -pen) K = 0; }
   unsigned char skip[MAXROWS]; memset(skip, 0, sizeof skip);
   memset(dv, 0, sizeof(double) * NVMAX);
   g_pgs_stats[5] += 1;

@@ -167,24 +167,27 @@ def scratch_cases():
         if b.meta.get('mount') == 'wheelchair':
             continue         # the crafted contact below moves the robot base, which a wheelchair-mounted arm cannot do without hitting the chair
         # the tip pressed into the skin at the target: scratches count when the tip moved > 1 cm (scratch_itch.py:28-32,46-57)
-        st, _ = make_states(b, 1, seed=6201, impairment='none')
-        s = st[0].copy()
-        v = b.view(s.reshape(1, -1))
-        pos, rot = o.fk(s)
-        limb = b.task_i_n('ARM_LINK', 2)[int(v['task'][0][L.SI['LIMB']])]
-        lp, lR = pos[limb], rot[limb]
-        tgt = lR @ s[b.h['S_TASK']:b.h['S_TASK'] + 3].astype(np.float64) + lp
-        axis = lR @ np.array([0, 0, -1.0])
-        radial = (tgt - lp) - np.dot(tgt - lp, axis) * axis; radial /= np.linalg.norm(radial)
-        fp, fq = v['free'][0, 0, :3].astype(np.float64), v['free'][0, 0, 3:7].astype(np.float64)
-        bp, bq = X.compose(fp, fq, b.free_f(0, 'REFPOS', 3), b.free_f(0, 'REFQUAT', 4))
-        tip, _ = X.compose(bp, bq, b.task_f('TOOL_OBS_POS', 3), b.task_f('TOOL_OBS_QUAT', 4))
-        _shift_robot(b, s, tgt + radial * (0.01 - 0.003) - tip)
-        v['free'][0, 0, 7:] = 0
-        for k in range(3):
-            a = (rng.uniform(-1, 1, b.act_dim) * 0.4).astype(np.float32)
-            out.append(dict(name='%s%s_scratching_step%d' % (model, '_coop' if coop else '', k), model=model, coop=coop, variant='', state=s.copy(), cloth=None, action=a))
-            o.step(s, a)
+        # (seed 6201: the tip leaves the skin within the step -- a scratch counts with zero force at the target, scratch_itch.py:28-32; seed 6213:
+        # the tip stays pressed on the target through all three steps: tool_force_at_target > 0 in the observation and the preferences)
+        for tag, cseed in (('scratching', 6201), ('scratchingb', 6213)):
+          st, _ = make_states(b, 1, seed=cseed, impairment='none')
+          s = st[0].copy()
+          v = b.view(s.reshape(1, -1))
+          pos, rot = o.fk(s)
+          limb = b.task_i_n('ARM_LINK', 2)[int(v['task'][0][L.SI['LIMB']])]
+          lp, lR = pos[limb], rot[limb]
+          tgt = lR @ s[b.h['S_TASK']:b.h['S_TASK'] + 3].astype(np.float64) + lp
+          axis = lR @ np.array([0, 0, -1.0])
+          radial = (tgt - lp) - np.dot(tgt - lp, axis) * axis; radial /= np.linalg.norm(radial)
+          fp, fq = v['free'][0, 0, :3].astype(np.float64), v['free'][0, 0, 3:7].astype(np.float64)
+          bp, bq = X.compose(fp, fq, b.free_f(0, 'REFPOS', 3), b.free_f(0, 'REFQUAT', 4))
+          tip, _ = X.compose(bp, bq, b.task_f('TOOL_OBS_POS', 3), b.task_f('TOOL_OBS_QUAT', 4))
+          _shift_robot(b, s, tgt + radial * (0.01 - 0.003) - tip)
+          v['free'][0, 0, 7:] = 0
+          for k in range(3):
+              a = (rng.uniform(-1, 1, b.act_dim) * 0.4).astype(np.float32)
+              out.append(dict(name='%s%s_%s_step%d' % (model, '_coop' if coop else '', tag, k), model=model, coop=coop, variant='', state=s.copy(), cloth=None, action=a))
+              o.step(s, a)
     return out
 
 

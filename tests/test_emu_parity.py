@@ -325,6 +325,11 @@ def test_packed_solver_with_all_groups_at_work(blob, oracle):
     """csrc/agx_pgs4.h (opt-in build, -DAGX_USE_SOLVE4=1): four environments share a wavefront, each on its own 16-lane group with its own visit list.  Three environments with
     different row counts in one wave: bitwise what the same kernel gives for each of them alone (group 0), and the oracle's result."""
     from emu_lib import Emu
+    from oracle_lib import Oracle
+    # (the opt-in packed kernel sweeps its four environments with ONE no-op period: the per-environment switch AGX_P_NOOP_PEN of the product
+    # kernel -- plain sweeps in a substep with a pressed contact -- does not exist in it; compared with that switch off on both sides)
+    blob = blob.set_param('NOOP_PEN', 0.0)
+    oracle = Oracle(blob)
     e = Emu(blob, kind='feeding_packed')
     st, _ = make_states(blob, 3, seed=4001)
     for i in range(3):

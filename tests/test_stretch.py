@@ -83,7 +83,7 @@ def test_wheels_roll_and_turn_as_a_differential_drive(rb, friction):
     b, o = rb
     st, _ = _states(b, 1, 4005, impairment='none')
     r, track = 0.0508, 2 * 0.15765                                                                              # stretch_uncalibrated.urdf: wheel mesh radius, joint offsets
-    slip = 0.08 if friction >= 0.5 else 0.3
+    slip = 0.09 if friction >= 0.5 else 0.3
     for name, aw in (('forward', (1, 1)), ('spin', (1, -1)), ('arc', (1, 0.5))):
         s = st[0].copy()
         b.view(s[None])['plane_friction'][0] = friction
