@@ -24,7 +24,7 @@ constexpr int T = AGX_CLOTH_THREADS;
 constexpr int NPT = 4096 / T;              // nodes per thread (garments of up to 4,096 nodes)
 constexpr int LPT = 1024 / T;              // links per thread and colour class (classes hold at most 1,024 links)
 #ifndef AGXC_PF
-#define AGXC_PF 3
+#define AGXC_PF 1
 #endif
 constexpr int PF = AGXC_PF;                // colour classes of link records in flight (see PSolve_Links)
 constexpr int NODE_CONTACTS = 2;          // AGX_CLOTH_NODE_CONTACTS: contacts kept per node (the first ones in shape order)
@@ -327,8 +327,9 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
       // executes a wave's accesses in order, and nothing but this wave has touched the patch since the anchors' barrier (a node's contacts
       // move that node only).  Link table: class w KP + c = 64 slots, lane l relaxes slot l; streamed one class ahead.
       {
-        // link records are requested PF classes ahead of their use (a ring of PF registers, statically indexed: the loop is unrolled by PF):
-        // an L2 round trip is several classes long, one class ahead (round 3) still exposed most of it at every class
+        // link records are requested PF classes ahead of their use (a ring of PF registers, statically indexed: the loop is unrolled by PF).
+        // Measured (round 4, same box, DressingBaxter 30 steps): PF = 1 with __syncthreads 53.04 k, PF = 1 with the LDS-only barrier 52.97 k,
+        // PF = 3 with it 51.69 k env-steps/s -- neither the barriers' global-memory waits nor the prefetch distance is what the kernel waits for
         const int2* pl = links + (size_t)wave * KP * 64 + lane;
         int2 ring[PF];
 #pragma unroll

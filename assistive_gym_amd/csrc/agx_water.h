@@ -22,6 +22,7 @@ constexpr int MAX_BODIES = 64, MAX_SHAPES = 192, MAX_PARTICLES = 64;
 constexpr int SHAPE_WORDS = 14;              // body slot, plane count, first plane, radius, vertex offset, vertex count, min(kDF x friction, 1), only-gender | human << 8, AABB centre (3), half extents (3)
 constexpr int L_BODY = 0, L_BOX = L_BODY + 12 * MAX_BODIES, L_X = L_BOX + 6 * MAX_SHAPES, L_SHAPE = L_X + 3 * MAX_PARTICLES, L_LIST = L_SHAPE + SHAPE_WORDS * MAX_SHAPES;
 constexpr int LDS_WORDS = L_LIST + MAX_SHAPES;
+struct P4 { float x, y, z, w; };            // a face plane: unit normal, offset
 constexpr int TRACE_BODY_WORDS = 12;         // per body and substep: p(3), R(9) row major
 constexpr int REPORT_WORDS = MAX_PARTICLES;  // per particle: 1 = touched a shape of the person in the last internal substep (drinking.py:84-88)
 
@@ -91,9 +92,22 @@ AGX_DEV float shape_distance(const uint32_t* blob, const float* body, const floa
     if (len > 1e-12f) { n0 /= len; n1 /= len; n2 /= len; } else { n0 = 0.f; n1 = 0.f; n2 = 1.f; }
     dist = len - rad;
   } else {
-    const float* P = clf + cl[AGX_CL_OFF_PLANE] + 4 * p0;
+    // Plane lists are padded to a multiple of four and start at a multiple of four (model/cloth.py): FOUR planes = 64 bytes per scalar load
+    // at a wave-uniform address, the next four requested before these are evaluated.  One plane per load and iteration left the loop waiting
+    // for a scalar-cache round trip per plane: ~23 planes x 68 cup pieces x 20 substeps = most of the kernel's 10.6 ms (round 4, second pass).
+    const P4* P = (const P4*)(clf + cl[AGX_CL_OFF_PLANE] + 4 * p0);
     float bd = -3.0e38f; n0 = 0.f; n1 = 0.f; n2 = 1.f;
-    for (int k = 0; k < np; k++) { const float t = P[4 * k] * xl0 + P[4 * k + 1] * xl1 + P[4 * k + 2] * xl2 - P[4 * k + 3]; if (t > bd) { bd = t; n0 = P[4 * k]; n1 = P[4 * k + 1]; n2 = P[4 * k + 2]; } }
+    P4 a0 = P[0], a1 = P[1], a2 = P[2], a3 = P[3];
+    for (int k = 0; k < np; k += 4) {
+      const P4 c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+      if (k + 4 < np) { a0 = P[k + 4]; a1 = P[k + 5]; a2 = P[k + 6]; a3 = P[k + 7]; }
+      const float t0 = c0.x * xl0 + c0.y * xl1 + c0.z * xl2 - c0.w, t1 = c1.x * xl0 + c1.y * xl1 + c1.z * xl2 - c1.w;
+      const float t2 = c2.x * xl0 + c2.y * xl1 + c2.z * xl2 - c2.w, t3 = c3.x * xl0 + c3.y * xl1 + c3.z * xl2 - c3.w;
+      if (t0 > bd) { bd = t0; n0 = c0.x; n1 = c0.y; n2 = c0.z; }
+      if (t1 > bd) { bd = t1; n0 = c1.x; n1 = c1.y; n2 = c1.z; }
+      if (t2 > bd) { bd = t2; n0 = c2.x; n1 = c2.y; n2 = c2.z; }
+      if (t3 > bd) { bd = t3; n0 = c3.x; n1 = c3.y; n2 = c3.z; }
+    }
     dist = bd - rad;
   }
   nw[0] = R[0] * n0 + R[1] * n1 + R[2] * n2; nw[1] = R[3] * n0 + R[4] * n1 + R[5] * n2; nw[2] = R[6] * n0 + R[7] * n1 + R[8] * n2;

@@ -57,7 +57,7 @@ def main():
     envs = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 4096
     sys.path.insert(0, ROOT)
     from assistive_gym_amd.blob import ModelBlob
-    blob = ModelBlob.load({'feeding': 'feeding_jaco', 'bedbathing': 'bed_bathing_sawyer', 'scratchitch': 'scratch_itch_pr2', 'armmanipulation': 'arm_manipulation_sawyer', 'dressing': 'dressing_baxter'}[task])
+    blob = ModelBlob.load({'feeding': 'feeding_jaco', 'bedbathing': 'bed_bathing_sawyer', 'scratchitch': 'scratch_itch_pr2', 'armmanipulation': 'arm_manipulation_sawyer', 'dressing': 'dressing_baxter', 'drinking': 'drinking_jaco'}[task])
     if task == 'scratchitch':
         blob = blob.coop()
     out = {'envs': envs, 'note': 'hbm_bytes_per_launch is for a launch over all `envs` environments; a step issues chunks of them', 'correction': 'FETCH_SIZE x2 (gfx950, guide), WRITE_SIZE as reported', 'kernels': {}}
