@@ -24,6 +24,14 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(AGX_E_HIP, #x, e_); } while (0)
 
+// the warm-start memory (AGX_P_WARMSTART) of the environments whose state is replaced from outside is forgotten: their scratch record's
+// entry count is zeroed (mask null = every environment)
+extern "C" __global__ void __launch_bounds__(256)
+agx_forget_warm_kernel(float* scratch, int scr_words, int word, const uint8_t* mask, int n_envs) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env < n_envs && (!mask || mask[env])) ((int*)scratch)[(size_t)env * scr_words + word] = 0;
+}
+
 // done envs take a fresh record from the pool; coalesced copy, one wave per env
 extern "C" __global__ void __launch_bounds__(64)
 agx_reset_kernel(float* state, const float* pool, int pool_n, const uint8_t* done, int* episode, int n_envs, int sw, long long env_offset, int iter_word, int iteration) {
@@ -136,6 +144,10 @@ struct agx_handle_s {
   agx_handle_s* settle; // bed bathing (AGX_X_FLAGS bit 4): the handle of the rag-doll model whose settled records the sampler reads (agx_attach_settle_model; not owned)
   int settle_substeps;  // substeps of that settle (100 simulation steps: bed_bathing.py:130-131)
 };
+
+static void forget_warm(agx_handle_s* h, const uint8_t* mask_dev, hipStream_t st) {
+  hipLaunchKernelGGL(agx_forget_warm_kernel, dim3((h->n_envs + 255) / 256), dim3(256), 0, st, h->scratch_dev, h->V->scr_words, h->V->scr_warm_word, mask_dev, h->n_envs);
+}
 
 extern "C" {
 
@@ -292,6 +304,7 @@ int agx_set_state(agx_handle h, const float* host_states) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemcpy(h->state_dev, host_states, (size_t)h->n_envs * h->sw * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemset(h->episode_dev, 0, (size_t)h->n_envs * 4));
+  forget_warm(h, nullptr, nullptr); HIPCHK(hipGetLastError()); HIPCHK(hipDeviceSynchronize());
   return AGX_OK;
 }
 int agx_get_state(agx_handle h, float* host_states) {
@@ -419,6 +432,7 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
                                                "provide post-reset states with agx_set_state / a pool for agx_reset_done");
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
+  forget_warm(h, mask_dev, st);          // the sampled environments start without a warm-start memory
   const float* settled = nullptr; int settled_sw = 0;
   if (h->reset_flags & 16) {
     // bed bathing (bed_bathing.py:119-137): the human is a rag doll dropped onto the bed -- the attached model samples its drop record from the
@@ -493,6 +507,7 @@ int agx_reset_done_at(agx_handle h, const float* pool_dev, int pool_n, const uin
   if (h->cloth_dev && !h->cloth_pool_dev) return fail(AGX_E_ARG, "agx_reset_done: the model has a cloth; give the garments of the pool with agx_set_cloth_pool first");
   hipLaunchKernelGGL(agx_reset_kernel, dim3(h->n_envs), dim3(64), 0, (hipStream_t)stream, h->state_dev, pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->sw, h->env_offset,
                      h->iter_word, iteration);
+  forget_warm(h, done_dev, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   if (h->cloth_dev) {
     hipLaunchKernelGGL(agx_reset_cloth_kernel, dim3(h->n_envs), dim3(256), 0, (hipStream_t)stream, h->cloth_dev, h->cloth_pool_dev, pool_n, done_dev, h->episode_dev, h->n_envs, h->cloth_words, h->env_offset);

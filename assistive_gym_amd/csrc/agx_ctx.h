@@ -140,10 +140,13 @@ constexpr int BR_CLASS_SYM = 0, BR_CLASS_POS = 1, BR_CLASS_FRIC = 2;
 constexpr int BRF_WORDS = 8;                             // per free body: 1/m, world inverse inertia xx, xy, xz, yy, yz, zz, unused
 constexpr int SCR_BRH = USE_SOLVE4 ? MAX_ROWS * BRH_WORDS : 0, SCR_BRE = USE_SOLVE4 ? 2 * SCR_ENT : 0, BR_MAX_UNITS = SCR_BRE / BRU_WORDS, SCR_BRF = USE_SOLVE4 ? MAX_FREE * BRF_WORDS : 0;
 static_assert(BR_MAX_UNITS < (1 << 16), "first unit of a row: 16 bits of the header word");
-constexpr int SCR_O_BRH = SCR_O_QPT + SCR_QPT, SCR_O_BRF = SCR_O_BRH + SCR_BRH, SCR_O_BRE = SCR_O_BRF + SCR_BRF;
+// warm-start memory (AGX_P_WARMSTART): per contact of the last solved substep its key -- collider a | collider b << 9 | ordinal inside the
+// pair << 18 -- and its solved normal impulse; META_NWARM entries, 0 = none / invalidated
+constexpr int SCR_WARM = 2 * MAX_CON, SCR_O_WARM = SCR_O_QPT + SCR_QPT;
+constexpr int SCR_O_BRH = SCR_O_WARM + SCR_WARM, SCR_O_BRF = SCR_O_BRH + SCR_BRH, SCR_O_BRE = SCR_O_BRF + SCR_BRF;
 static_assert(SCR_O_BRH % 2 == 0 && SCR_O_BRE % 2 == 0 && SCR_O_BRF % 4 == 0, "block rows are read as 8-byte words");
 constexpr int SCR_WORDS = SCR_O_BRE + SCR_BRE;
-constexpr int META_NBENT = 7;
+constexpr int META_NBENT = 7, META_NWARM = 8;
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
 constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)

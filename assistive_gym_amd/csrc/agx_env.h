@@ -294,10 +294,39 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
 //          from L2, integration, mouth-target update -> state
 //   finish (once per step): forces, observation, food state machine, preferences, reward, done.
 // ============================================================================================
-struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; float* brf; };
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; float* brf; float* warm; };
 AGX_DEV Scratch scratch_of(float* base) {
-  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE; s.brf = base + SCR_O_BRF;
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE; s.brf = base + SCR_O_BRF; s.warm = base + SCR_O_WARM;
   return s;
+}
+
+// ---- warm starting (AGX_P_WARMSTART, a [BULLET-UNVERIFIED] switch, default off) -------------------------------------------------------
+// key of this lane's contact: collider a | collider b << 9 | ordinal among the contacts of the same pair << 18 (the face manifold gives a pair
+// up to four); lanes >= ncon return -1.  Wave-uniform call.
+AGX_DEV int warm_key(const Ctx& c, int lane) {
+  const bool has = lane < c.ncon;
+  const int* ki = (const int*)(c.gcon + CON_STRIDE * (has ? lane : 0));
+  const int pair = has ? (ki[C_CA] | (ki[C_CB] << 9)) : -1;
+  int ord = 0;
+  for (int j = 0; j < c.ncon; j++) { const int pj = wave_bcast_i(pair, j); if (has && j < lane && pj == pair) ord++; }
+  return has ? (pair | (ord << 18)) : -1;
+}
+// build kernel, after the contacts of the substep are in the scratch record: C_LAM := factor x the impulse of the same contact in the memory
+AGX_DEV void warm_seed(const Ctx& c, const Scratch& scr, int lane) {
+  const float wsf = PRM(c, AGX_P_WARMSTART);
+  if (!(wsf > 0.f)) return;
+  const int nw = scr.meta[META_NWARM];
+  const int key = warm_key(c, lane);
+  float lam = 0.f;
+  for (int p = 0; p < nw && p < MAX_CON; p++) if (((const int*)scr.warm)[p] == key) { lam = wsf * scr.warm[MAX_CON + p]; break; }
+  if (lane < c.ncon) c.gcon[CON_STRIDE * lane + C_LAM] = lam;
+}
+// solve kernel, after the sweeps: this substep's contacts and their solved impulses become the memory
+AGX_DEV void warm_remember(const Ctx& c, const Scratch& scr, int lane) {
+  if (!(PRM(c, AGX_P_WARMSTART) > 0.f)) return;
+  const int key = warm_key(c, lane);
+  if (lane < c.ncon) { ((int*)scr.warm)[lane] = key; scr.warm[MAX_CON + lane] = c.gcon[CON_STRIDE * lane + C_LAM]; }
+  if (lane == 0) scr.meta[META_NWARM] = c.ncon;
 }
 
 // build: `gaction` non-null on the first substep of an env.step() (take_step, env.py:174-222)
@@ -363,6 +392,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   aba_and_minv(c); AGX_TICK(1)
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
+  warm_seed(c, scr, lane);
   build_rows(c); AGX_TICK(4)
   if (USE_SOLVE4 && lane < c.nfree) {      // S = (M^-1)^(1/2) of a free body, for the packed solve kernel's epilogue: sqrt(1/m), R sqrt(I_body^-1) R^T
     float* o = gscratch + SCR_O_BRF + BRF_WORDS * lane; const float mass = FBF(c, lane, AGX_F_MASS);
@@ -444,6 +474,7 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0, dv1;
   if (!(rowspace && pgs_rowspace(c, lds + L_SOLVE_ENT, dv0, dv1))) pgs(c, dv0, dv1);
+  warm_remember(c, scr, lane);
   const long long t1 = gdebug ? wave_clock() : 0;
   solve_tail(c, gstate, scr, sw, phase, dv0, dv1);
   if (gdebug && lane == 0) { gdebug[DBG_TIME + 5] = (float)(t1 - t0); gdebug[DBG_TIME + 6] = (float)(wave_clock() - t1); }

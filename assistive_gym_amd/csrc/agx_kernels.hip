@@ -359,10 +359,11 @@ const agx_variant g_variant = {
   v_collision_flags,
   agx::USE_SOLVE4 ? v_solve4 : nullptr,
 #if AGX_TASK == 3 || AGX_TASK == 5
-  v_cloth_lds_bytes
+  v_cloth_lds_bytes,
 #else
-  nullptr
+  nullptr,
 #endif
+  agx::SCR_O_META + agx::META_NWARM
 };
 
 }  // namespace

@@ -335,6 +335,11 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
     wave_sync();
     if (c.dbg && lane == 0) c.dbg[DBG_TIME + 7] = (float)(wave_clock() - tA0);
     float w = 0.f;                                                  // J_r . dv of this lane's row
+    if (PRM(c, AGX_P_WARMSTART) > 0.f) {                            // warm start: the normals begin at the impulses the build kernel seeded (warm_seed)
+      const float l0 = (lane >= nnc && lane < nA) ? c.gcon[CON_STRIDE * (lane - nnc) + C_LAM] : 0.f;
+      S.lam = l0;
+      for (uint64_t m = wave_ballot(l0 != 0.f); m; m &= m - 1ull) { const int r = ffs64(m); w += A[RS_MAX_ROWS * r + lane] * wave_bcast(l0, r); }
+    }
     const int fn = lane - nc;                                       // normal row of this lane's friction row
     const int K = noop_period(c);                                   // the no-op re-test rule, see pgs()
     uint64_t skip = 0ull;
@@ -400,6 +405,19 @@ AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   // sweep (sweep index divisible by K) changed nothing -- an inactive contact or limit (0 -> 0), a motor sitting on its force bound --
   // is not visited in the K - 1 sweeps that follow (42 % of these visits are no-ops in FeedingJaco; the oracle applies the same
   // rule, pgs() in oracle/agx_oracle.c; sensitivity: profiles/r03/noop_retest_sensitivity.json).  K = 0: every row in every sweep.
+  if (PRM(c, AGX_P_WARMSTART) > 0.f) {                              // warm start (see pgs_rowspace): impulses of the memory, dv = sum_r B_r lambda_r in row order
+    const int r0 = lane, r1 = 64 + lane;
+    const float l0 = (r0 >= nnc && r0 < nA) ? c.gcon[CON_STRIDE * (r0 - nnc) + C_LAM] : 0.f, l1 = (r1 >= nnc && r1 < nA) ? c.gcon[CON_STRIDE * (r1 - nnc) + C_LAM] : 0.f;
+    A0.lam = l0; A1.lam = l1;
+    for (uint64_t m = wave_ballot(l0 != 0.f); m; m &= m - 1ull) {
+      const int r = ffs64(m); PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(A0.pack, r), wave_bcast_i(A0.off, r) & 0x7fffffff, X);
+      const float dl = wave_bcast(l0, r); dv0 += X.c0 * dl; dv1 += X.c1 * dl;
+    }
+    for (uint64_t m = wave_ballot(l1 != 0.f); m; m &= m - 1ull) {
+      const int r = ffs64(m); PgsBuf X; pgs_fetch(E, lane, wave_bcast_i(A1.pack, r), wave_bcast_i(A1.off, r) & 0x7fffffff, X);
+      const float dl = wave_bcast(l1, r); dv0 += X.c0 * dl; dv1 += X.c1 * dl;
+    }
+  }
   const int K = noop_period(c);
   uint64_t skip0 = 0ull, skip1 = 0ull;
   for (int it = 0; it < iters; it++) {

@@ -37,6 +37,9 @@ struct agx_variant {
   void (*solve4)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, int e0, int sw, const uint8_t* active, int phase);
   // dynamic LDS bytes of the cloth kernel for a garment of nn nodes (agxc::lds_words); null without a cloth kernel
   int (*cloth_lds_bytes)(int nn);
+  // word of the per-environment scratch record that counts the entries of the warm-start memory (AGX_P_WARMSTART): agx_api.hip zeroes it
+  // for every environment whose state is replaced from outside (set_state, resets)
+  int scr_warm_word;
 };
 
 extern "C" const agx_variant* agx_variant_feeding(void);

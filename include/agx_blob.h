@@ -100,13 +100,18 @@ enum {
   AGX_P_MAX_ENTRIES,     /* cap on the summed (J,B) coefficient pairs of all rows of a substep    */
   AGX_P_NOOP_RETEST,     /* K > 0: rows of the non-friction block whose visit in a re-test sweep (every K-th) was a no-op are skipped until
                             the next re-test sweep; 0 = every row in every sweep (agx_pgs.h, oracle pgs())                 */
-  /* [BULLET-UNVERIFIED] switches, evaluated by the CPU oracle only (the device solves with all three off; tests/diag/bullet_unknowns_sensitivity.py
-   * measures what each would change): */
+  /* [BULLET-UNVERIFIED] switches (all off = the default conventions; tests/diag/bullet_unknowns_sensitivity.py measures what each would change).
+   * RESIDUAL_EPS and FRICTION_DIRS are evaluated by the CPU oracle only; WARMSTART by the oracle AND the device (round 4): */
   AGX_P_ORACLE_RESIDUAL_EPS = 21, /* > 0: the sweeps stop once max_rows (delta lambda x D)^2 <= eps (btSequentialImpulseConstraintSolver's
                                      m_leastSquaresResidualThreshold; PyBullet's default solverResidualThreshold is believed to be 1e-7)   */
   AGX_P_ORACLE_FRICTION_DIRS = 22,/* 2: a second friction row per contact along n x t (SOLVER_USE_2_FRICTION_DIRECTIONS); 0 / 1: one        */
-  AGX_P_ORACLE_WARMSTART = 23,    /* > 0: contact normals start from this factor x the impulse of the same contact in the previous substep
-                                     (SOLVER_USE_WARMSTARTING, m_warmstartingFactor 0.85)                                                 */
+  AGX_P_WARMSTART = 23,           /* > 0: contact normals start from this factor x the impulse the SAME contact -- (collider a, collider b,
+                                     ordinal inside the pair) -- was solved to in the previous substep (SOLVER_USE_WARMSTARTING,
+                                     m_warmstartingFactor 0.85).  Device: the solve kernel leaves (key, impulse) of its contacts in the
+                                     environment's scratch record, the next build kernel seeds C_LAM from it, the solve starts its sweeps
+                                     from those impulses (agx_env.h warm_*); the memory is per environment and is cleared whenever the
+                                     environment's state is replaced (agx_set_state, agx_reset*, agx_sample_reset).                        */
+  AGX_P_ORACLE_WARMSTART = AGX_P_WARMSTART,
   AGX_P_NOOP_PEN = 24,   /* > 0: the no-op re-test rule is switched OFF (plain sweeps) for an environment in every substep that has a contact
                             penetrating deeper than this (metres).  The rule delays the wake-up of a skipped row by up to K - 1 sweeps; with a tool
                             PRESSED onto skin -- where the force terms of the rewards come from -- that moved total_force_on_human by up to 5e-2 N

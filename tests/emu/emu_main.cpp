@@ -45,10 +45,14 @@ static int run_wave(float* lds, size_t lds_words, std::function<void(int)> body)
   return rc;
 }
 
+// the scratch record of agx_emu_run's environment persists between calls, like the device's (the warm-start memory of AGX_P_WARMSTART
+// lives in it); agx_emu_forget_warm() = what agx_set_state / the resets do to it
+static float g_scratch[agx::SCR_WORDS];
+extern "C" void agx_emu_forget_warm() { ((int*)g_scratch)[agx::SCR_O_META + agx::META_NWARM] = 0; }
 extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
                            float* info, float* debug, int mode, int nsettle) {
   static float lds[(agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS) + agx::LDS_SOLVE4_WORDS];
-  static float scratch[agx::SCR_WORDS];
+  float* const scratch = g_scratch;
   // AGX_EMU_SOLVE=old: the one-wave-per-environment sweep; default: the packed kernel (groups 1..3 of the wave idle: one environment here)
   static const bool packed = !(getenv("AGX_EMU_SOLVE") && !strcmp(getenv("AGX_EMU_SOLVE"), "old")) && agx::USE_SOLVE4;
   const int sw = ((const int*)blob)[AGX_H_STATE_WORDS];

@@ -78,6 +78,10 @@ class Emu:
         assert rc == 0, 'wave emulator reported divergent control flow'
         return obs, float(rew[0]), bool(done[0]), info, dbg
 
+    def forget_warm(self):
+        """the warm-start memory (AGX_P_WARMSTART) of the emulated environment's scratch record: cleared, as agx_set_state / the resets do"""
+        self.L.agx_emu_forget_warm()
+
     def step(self, state, action, debug=False):
         return self._run(state, action, 0, 0, debug)
 

@@ -88,6 +88,10 @@ class Oracle:
         n = self.L.agxo_cloth_contacts(_p(out), C.c_int(max_out))
         return out[:min(n, max_out)]
 
+    def forget_warm(self):
+        """the process-wide warm-start memory of the AGX_P_WARMSTART switch (one environment at a time): cleared"""
+        self.L.agxo_warm_clear()
+
     def settle(self, state, n):
         self.L.agxo_settle(C.c_void_p(self.h), _p(state), C.c_int(n))
 
