@@ -73,6 +73,20 @@ def bound(value_scale, sens, rel=1e-3, floor=0.0):
     return max(rel * max(1.0, abs(value_scale)), K * sens, floor)
 
 
+def force_floor(blob):
+    """Absolute floor of a contact-force comparison, newtons.  A contact row's right-hand side carries the gap: b = -dist x ERP / dt; with the
+    effective mass m the row sees, the force it asks for is F = m b / dt, i.e. the contact is a spring of stiffness m ERP / dt^2 in the gap.
+    The gap itself is a difference of world positions at 1 ... 2 m, where float32 resolves 1.2e-7 m: measured, f32 kernels vs the f64 oracle
+    from the SAME state, dist deviates by up to 2.4e-7 m in the first substep (tests/diag, BedBathingSawyer wiping states: 76 contacts,
+    median 2e-8) and the joint angles by ~5e-7 rad over the five substeps of a step -- 1e-6 m at the contact.  With m <= the robot's moving
+    mass (the Sawyer's arm: 18.9 kg; ERP 0.2, dt 0.02) that is 18.9 x 500 N/m x 1e-6 m = 9.4e-3 N: no float32 pipeline can pin a force of
+    1 N on a static person to 1e-3 RELATIVE (1 mN); at 10 N and above the relative bound is the larger one and applies."""
+    h = blob.h
+    m = sum(float(blob.robot_f(d, 'MASS')) for d in range(blob.nrobot))
+    dt = float(blob.param('DT')) / max(1, int(h.get('SIM_SUBSTEPS', 1)))
+    return m * float(blob.param('CONTACT_ERP')) / dt ** 2 * 1.0e-6
+
+
 def within(dev, scale, sens_fn, rel=1e-3, floor=0.0):
     """dev <= max(rel x max(1, scale), K x sensitivity, floor); the sensitivity (an oracle run per trial) is evaluated only when the plain
     1e-3 bound is exceeded.  -> (ok, limit, sensitivity or None)"""

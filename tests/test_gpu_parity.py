@@ -494,8 +494,10 @@ def test_noop_retest_rule_against_the_plain_solve(gpu_lib, workload):
                 lim = dict(reward=C.K * sens['reward'] / max(1.0, abs(o_rew)), total_force=C.K * sens['info'][0] / max(1.0, abs(o_info[0])),
                            tool_force=C.K * sens['obs'][f] / max(1.0, abs(o_obs[f])), obs=C.K * float(np.delete(sens['obs'], f).max()))
                 conditioned += 1
+                ff = C.force_floor(b)
+                floor = dict(reward=0.06 * ff / max(1.0, abs(o_rew)), total_force=ff / max(1.0, abs(o_info[0])), tool_force=ff / max(1.0, abs(o_obs[f])), obs=0.0)
                 for key in dev:
-                    assert dev[key] <= max(1e-3, lim[key]), (workload, k, i, key, dev, lim)
+                    assert dev[key] <= max(1e-3, lim[key], floor[key]), (workload, k, i, key, dev, lim, floor)
             else:
                 for key in dev:
                     worst[key] = max(worst[key], dev[key])

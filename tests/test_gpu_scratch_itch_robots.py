@@ -69,7 +69,7 @@ def test_step_matches_oracle(rb):
                 if not sens:
                     sens.append(C.ulp_sensitivity(b, o, ref[i], act[i], trials=4))
                 return sens[0]
-            ok, lim, sv = C.within(dev[f], o_obs[f], lambda: _sens()['obs'][f])
+            ok, lim, sv = C.within(dev[f], o_obs[f], lambda: _sens()['obs'][f], floor=C.force_floor(b))
             if sv is not None:
                 print('conditioned: %s step %d env %d tool force dev %.3g rel, 1-ulp sensitivity %.3g' % (name, k, i, dev[f] / max(1.0, abs(o_obs[f])), sv))
             assert ok, (k, i, dev[f], lim, sv)
@@ -77,11 +77,12 @@ def test_step_matches_oracle(rb):
             worst[i] = max(worst[i], float(dev.max()), abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
             assert info[i, 4] == o_info[4] and info[i, 1] == o_info[1] and bool(done[i]) == o_done
             for c in (0, 2, 3):
-                ok, lim, sv = C.within(abs(info[i, c] - o_info[c]), o_info[c], lambda: _sens()['info'][c])
+                ok, lim, sv = C.within(abs(info[i, c] - o_info[c]), o_info[c], lambda: _sens()['info'][c], floor=C.force_floor(b) if c == 0 else 0.0)
                 assert ok, (i, c, info[i], o_info, lim, sv)
         touched += int((info[12:, 0] > 0).sum())            # total force on the human: the scratcher (or the arm behind it) presses on the limb
     st.close()
-    assert worst[:12].max() < 1e-4 and worst[12:].max() < 1e-3, worst
+    # (the crafted pressed states: observation / reward within 1e-3 plus the reward's share of the force floor, weights <= 0.05)
+    assert worst[:12].max() < 1e-4 and worst[12:].max() < 1e-3 + 0.06 * C.force_floor(b), worst
     assert touched >= 3
 
 
