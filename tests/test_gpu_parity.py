@@ -506,3 +506,54 @@ def test_noop_retest_rule_against_the_plain_solve(gpu_lib, workload):
           % (workload, {k: float('%.3g' % v) for k, v in worst.items()}, conditioned, n * steps, touching))
     assert conditioned <= 0.02 * n * steps
     assert workload == 'feeding' or touching > 0.2 * n * steps
+
+
+@pytest.mark.parametrize('workload', ['feeding', 'wiping'])
+def test_warm_start_switch_on_the_device(gpu_lib, workload):
+    """AGX_P_WARMSTART through the C ABI against the oracle's switch.  (a) 16 environments, three steps, every step from an injected state
+    (agx_set_state forgets the memory; the oracle's is cleared per environment): substeps 2-5 of each step start warm on both sides.
+    (b) ONE environment stepped four times without injection: the memory persists from step to step on both sides."""
+    import sys, os
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.libagx import Stepper
+    from assistive_gym_amd.vec_env import build_reset_pool
+    from oracle_lib import Oracle
+    n = 16
+    if workload == 'feeding':
+        b0 = ModelBlob.load('feeding_jaco'); states = build_reset_pool(b0, n, seed=7007); scale = 1.0
+    else:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import wiping_pool
+        b0 = ModelBlob.load('bed_bathing_sawyer'); states = wiping_pool(b0, n, 7007); b0.view(states)['iteration'][:] = 0; scale = 0.15
+    b = b0.set_param('WARMSTART', 0.85)
+    o, cold = Oracle(b), Oracle(b0)
+    st = Stepper(b, n)
+    rng = np.random.RandomState(3)
+    ref = states.copy()
+    differs = 0.0
+    for k in range(3):
+        st.set_state(ref)
+        act = (rng.uniform(-1, 1, (n, b.act_dim)) * scale).astype(np.float32)
+        obs, rew, done, info = st.step_host(act)
+        got = st.get_state()
+        for i in range(n):
+            o.forget_warm()
+            sc = ref[i].copy()
+            o_obs, o_rew, _, o_info = o.step(ref[i], act[i])
+            cold.step(sc, act[i])
+            differs = max(differs, float(np.abs(ref[i] - sc)[:b.h['S_ENV']].max()))
+            assert np.abs(obs[i] - o_obs).max() < 1e-4 and abs(rew[i] - o_rew) < 1e-4 * max(1.0, abs(o_rew)), (workload, k, i)
+            assert abs(info[i, 0] - o_info[0]) <= max(1e-3 * max(1.0, abs(o_info[0])), 1e-2), (workload, k, i, info[i, 0], o_info[0])
+            assert np.abs(b.view(got[i:i + 1])['q'][0] - b.view(ref[i:i + 1])['q'][0]).max() < 2e-5
+    assert differs > 1e-6 or workload == 'wiping'           # the switch changes the food pile's unconverged solve (the pad's small system converges either way)
+    st.close()
+    one = Stepper(b, 1)
+    s = states[:1].copy()
+    one.set_state(s); o.forget_warm()
+    so = s[0].copy()
+    for k in range(4):
+        a = (rng.uniform(-1, 1, (1, b.act_dim)) * scale).astype(np.float32)
+        obs, rew, done, info = one.step_host(a)
+        o_obs, o_rew, _, o_info = o.step(so, a[0])
+        assert np.abs(obs[0] - o_obs).max() < 3e-4 * (k + 1), (workload, 'persistent', k)      # free running: deviations compound
+    o.forget_warm(); one.close()
