@@ -229,14 +229,18 @@ AGX_DEV void water_env(const uint32_t* blob, const float* gstate, const float* g
       wave_sync();
       if (mine) {
         float dx[3] = {0.f, 0.f, 0.f}; int cnt = 0;
+        // branch-free over the 64 neighbours (selects instead of divergent skips; the positions come as LDS broadcasts): this loop is 640 passes
+        // per substep and was 40 % of the kernel's vector instructions with a branch, an IEEE square root and a division in each
+        const float rr4 = 4 * r * r;
         for (int j = 0; j < NN; j++) {
-          if (j == lane) continue;
           const float e0 = x[0] - X[3 * j], e1 = x[1] - X[3 * j + 1], e2 = x[2] - X[3 * j + 2], d2 = e0 * e0 + e1 * e1 + e2 * e2;
-          if (d2 >= 4 * r * r) continue;
-          const float d = sqrtf(d2);
-          if (d > 1.1920929e-7f) { const float sc = 0.5f * (2 * r - d) / d; dx[0] += e0 * sc; dx[1] += e1 * sc; dx[2] += e2 * sc; }
-          else dx[2] += (lane > j ? 1.0f : -1.0f) * r;        // coincident centres: apart along z, the higher index up
-          cnt++;
+          const bool in = d2 < rr4 && j != lane;
+          const bool apart = d2 > 1.1920929e-7f * 1.1920929e-7f;
+          // 0.5 (2 r - d) / d = r / d - 0.5 with 1 / d from the hardware reciprocal square root (1 ulp; the oracle's arithmetic is float64 anyway)
+          const float sc = (in && apart) ? r * wave_rsqrt(d2) - 0.5f : 0.f;
+          dx[0] += e0 * sc; dx[1] += e1 * sc; dx[2] += e2 * sc;
+          dx[2] += (in && !apart) ? (lane > j ? r : -r) : 0.f;   // coincident centres: apart along z, the higher index up
+          cnt += in ? 1 : 0;
         }
         if (cnt > 1) for (int k = 0; k < 3; k++) dx[k] /= (float)cnt;
         for (int k = 0; k < 3; k++) x[k] += dx[k];

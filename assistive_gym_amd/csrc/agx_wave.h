@@ -82,6 +82,8 @@ AGX_DEV int wave_scan_excl(int x) {
   for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
   return incl - x;
 }
+// 1 / sqrt(x), v_rsq_f32 (1 ulp)
+AGX_DEV float wave_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 // shader clock (s_memtime), for the per-phase cycle counters of the debug path
 AGX_DEV long long wave_clock() { return (long long)__builtin_readcyclecounter(); }
 // clamp to [lo, hi] (lo <= hi) in one v_med3_f32

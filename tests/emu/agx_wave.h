@@ -65,6 +65,7 @@ AGX_DEV long long wave_clock() { return 0; }
 AGX_DEV float wave_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 AGX_DEV void wave_opaque(float&) {}
 AGX_DEV int wave_uniform(int x) { return x; }
+AGX_DEV float wave_rsqrt(float x) { return 1.0f / sqrtf(x); }
 
 // the 32 x 32 x 2 f32 matrix-core step of csrc/agx_wave.h: the same lane -> element maps, an fmaf chain over k = 0, 1
 struct Acc16 { float v[16]; };
