@@ -270,7 +270,9 @@ static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_
     const char* e = getenv("AGX_CHUNKS");
     // default: 3 chunks for large batches (3 chunk streams + the caller's stream = the 4 hardware queues HIP uses
     // by default; measured 335 k -> 386 k env-steps/s at 4096 envs, 4 chunks need GPU_MAX_HW_QUEUES=8), 1 otherwise
-    int nc = e ? atoi(e) : (n_envs >= 2048 ? 3 : 1); if (nc < 1) nc = 1; if (nc > 8) nc = 8; if (n_envs < 64 * nc) nc = 1;
+    // (the drinking scenes run unchunked: 20 light build / solve pairs and one long water launch per step -- measured 295 k env-steps/s in one chunk
+    // under the profiler against 244 k in three)
+    int nc = e ? atoi(e) : (h->particles ? 1 : (n_envs >= 2048 ? 3 : 1)); if (nc < 1) nc = 1; if (nc > 8) nc = 8; if (n_envs < 64 * nc) nc = 1;
     h->n_chunks = nc;
     HIPCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     for (int k = 0; k < nc; k++) { HIPCHK(hipStreamCreateWithFlags(&h->cs[k], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming)); }

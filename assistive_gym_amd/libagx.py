@@ -76,7 +76,9 @@ class Stepper:
     def n_chunks(self):
         """independent chunks of environments a step is issued as (AGX_CHUNKS, default 3 from 2048 environments on)"""
         e = os.environ.get('AGX_CHUNKS')
-        nc = int(e) if e else (3 if self.n_envs >= 2048 else 1)
+        from .model import compiler as L
+        particles = self.blob.h.get('OFF_CLOTH', 0) and int(self.blob.i[self.blob.h['OFF_CLOTH'] + L.CL['PARTICLES']])     # the drinking scenes run unchunked (agx_api.hip)
+        nc = int(e) if e else (1 if particles else (3 if self.n_envs >= 2048 else 1))
         nc = min(max(nc, 1), 8)
         return 1 if self.n_envs < 64 * nc else nc
 

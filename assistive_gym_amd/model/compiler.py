@@ -72,7 +72,7 @@ CL = dict(NN=0, NL=1, NCOLOR=2, NANCHOR=3, NSHAPE=4, OFF_COLOR=5, OFF_LINK=6, OF
           OFF_PLANE=12, TRI=13, OFF_PARAM=19, MAX_LINKS_PER_COLOR=20, OFF_PERM=21, NPATCH_COLOR=22, PARTICLES=23, HDR=24)
 CP = dict(KLST=0, KDP=1, KDG=2, KDF=3, KCHR=4, KKHR=5, KAHR=6, PITER=7, MARGIN=8, NODE_IM=9, AIR_DENSITY=10, FORCE_SCALE=11, FORCE_MAX=12,
           EE_BELOW=13, COUNT=16)
-CLOTH_MAX_COLORS, CLOTH_THREADS, CLOTH_NODE_CONTACTS = 16, 1024, 2
+CLOTH_MAX_COLORS, CLOTH_THREADS, CLOTH_NODE_CONTACTS = 16, int(os.environ.get('AGX_CLOTH_THREADS', '1024')), 2      # (the environment variable: A/B blobs for a library built with -DAGX_CLOTH_THREADS)
 SI = dict(TARGET=0, LIMB=3, PREV_CONTACT=12, WORDS=16)   # scratch itch task words (AGX_SI_*); the arm-limit words sit where BB has them
 BB = dict(ALIVE=0, ALIVE_WORDS=6, PREV=6, HAS_PREV=10, WORDS=12)
 MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathing task words of the state record (AGX_BB_*)

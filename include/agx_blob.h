@@ -111,7 +111,6 @@ enum {
                                      environment's scratch record, the next build kernel seeds C_LAM from it, the solve starts its sweeps
                                      from those impulses (agx_env.h warm_*); the memory is per environment and is cleared whenever the
                                      environment's state is replaced (agx_set_state, agx_reset*, agx_sample_reset).                        */
-  AGX_P_ORACLE_WARMSTART = AGX_P_WARMSTART,
   AGX_P_NOOP_PEN = 24,   /* > 0: the no-op re-test rule is switched OFF (plain sweeps) for an environment in every substep that has a contact
                             penetrating deeper than this (metres).  The rule delays the wake-up of a skipped row by up to K - 1 sweeps; with a tool
                             PRESSED onto skin -- where the force terms of the rewards come from -- that moved total_force_on_human by up to 5e-2 N
@@ -457,7 +456,9 @@ enum {
   AGX_CP_COUNT = 16
 };
 #define AGX_CLOTH_MAX_COLORS 16
+#ifndef AGX_CLOTH_THREADS      /* -DAGX_CLOTH_THREADS=512 with a blob compiled for it (AGX_CLOTH_THREADS=512 python -m ...compiler): same-box A/B builds */
 #define AGX_CLOTH_THREADS 1024
+#endif
 #define AGX_CLOTH_NODE_CONTACTS 2   /* node-vs-rigid contacts kept per node and substep: the first ones in shape order */
 /* per-environment cloth report written by the cloth kernel for the finish kernel: float[18] the six sleeve vertices, 2 unused,
  * then per node and contact slot {height of the node, |force|} of the last substep's contacts (|force| = -1: empty slot) */

@@ -846,7 +846,7 @@ static int row_art_entries(const sim_t* s, const row_t* r) {
   for (int d = m->nrobot; d < m->ndof; d++) if (r->J[d] != 0) hh = 1;
   return art_entries_of(s, rr, hh);
 }
-/* warm-start memory of the [BULLET-UNVERIFIED] switch AGX_P_ORACLE_WARMSTART: normal impulses of the last substep that was solved, by
+/* warm-start memory of the [BULLET-UNVERIFIED] switch AGX_P_WARMSTART: normal impulses of the last substep that was solved, by
  * (collider a, collider b, ordinal inside the pair); one environment at a time (the sensitivity study), cleared by agxo_warm_clear() */
 static int g_warm_n = 0, g_warm_key[MAXC][3]; static double g_warm_lam[MAXC];
 void agxo_warm_clear(void) { g_warm_n = 0; }
@@ -920,7 +920,7 @@ static void build_rows(sim_t* s) {
    * pair per DoF of each dynamic body it touches (all robot DoFs, 6 per free body). */
   int first_normal = s->nrows, nc = 0;
   const int fdirs = (int)PARAM(m, AGX_P_ORACLE_FRICTION_DIRS) == 2 ? 2 : 1;   /* [BULLET-UNVERIFIED] switch, oracle only */
-  const double wsf = PARAM(m, AGX_P_ORACLE_WARMSTART);
+  const double wsf = PARAM(m, AGX_P_WARMSTART);
   {
     int ent = 1, maxent = (int)PARAM(m, AGX_P_MAX_ENTRIES);
     /* non-contact rows: motors and limits address the robot; the 6 tool rows (last) robot + tool */
@@ -1343,7 +1343,7 @@ static void substep_h(sim_t* s, int hooks) {
     /* normal rows follow the non-contact rows in construction order */
     const int first_normal = s->nrows - (1 + fdirs) * s->ncon;
     for (int c = 0; c < s->ncon; c++) s->con[c].lambda_n = s->rows[first_normal + c].lambda;
-    if (PARAM(m, AGX_P_ORACLE_WARMSTART) > 0) {
+    if (PARAM(m, AGX_P_WARMSTART) > 0) {
       g_warm_n = s->ncon < MAXC ? s->ncon : MAXC;
       for (int c = 0; c < g_warm_n; c++) {
         int ord = 0; for (int c2 = 0; c2 < c; c2++) if (s->con[c2].ca == s->con[c].ca && s->con[c2].cb == s->con[c].cb) ord++;

@@ -8,8 +8,8 @@ from assistive_gym_amd.libagx import Stepper
 from assistive_gym_amd.host import reset_dressing as rd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-b = ModelBlob.load('dressing_baxter')
-cache = os.path.join(ROOT, 'gpurun_out', 'cloth_bench_states.npz')
+b = ModelBlob.load(os.environ.get('AGX_CLOTH_BLOB', 'dressing_baxter'))     # AGX_CLOTH_BLOB=dressing_baxter_t512 with a -DAGX_CLOTH_THREADS=512 library
+cache = os.path.join(ROOT, 'gpurun_out', 'cloth_bench_states_%s.npz' % os.environ.get('AGX_CLOTH_BLOB', 'dressing_baxter'))
 if os.path.exists(cache):
     z = np.load(cache); st, cl = z['st'], z['cl']
 else:
