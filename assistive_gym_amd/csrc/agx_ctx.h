@@ -90,8 +90,12 @@ constexpr int A_ACC = A_PA + MAX_DOF * 6;
 constexpr int A_DINV = A_ACC + MAX_DOF * 6;              // [MAX_DOF]
 constexpr int A_UU = A_DINV + MAX_DOF;
 constexpr int A_QDD = A_UU + MAX_DOF;
-constexpr int A_COLS = A_QDD + MAX_DOF;                  // [MAX_DOF lanes][MAX_BLOCK][6] M^-1 column workspace (links of the lane's own articulated body)
-constexpr int A_DYN_END = A_COLS + MAX_DOF * MAX_BLOCK * 6 + MAX_DOF * MAX_BLOCK;
+// M^-1 column workspace: [COLS_LANES lanes][MAX_BLOCK][6] + [COLS_LANES][MAX_BLOCK] (links of the lane's own articulated body).  A lane computes
+// the columns lane, lane + COLS_LANES, ...: one batch for the task models; the 47-DoF rag doll of the bed-bathing reset takes two batches of
+// 24 lanes, which halves its 64 KB workspace -- 97 -> 65 KB of LDS per environment, two environments per CU instead of one
+constexpr int COLS_LANES = MAX_DOF > 32 ? (MAX_DOF + 1) / 2 : MAX_DOF;
+constexpr int A_COLS = A_QDD + MAX_DOF;
+constexpr int A_DYN_END = A_COLS + COLS_LANES * MAX_BLOCK * 6 + COLS_LANES * MAX_BLOCK;
 static_assert(A_DYN_END <= ARENA_WORDS, "dynamics workspace exceeds the arena");
 // arena, collision phase: world AABBs [ncoll][6]
 #ifndef AGX_MAX_COLL

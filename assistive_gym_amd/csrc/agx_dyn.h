@@ -145,11 +145,11 @@ AGX_DEV void aba_and_minv(Ctx& c) {
   }
   // M^-1: lane j = response to a unit force on joint j (Bullet: calcAccelerationDeltasMultiDof).  M^-1 is block diagonal
   // (robot, human chain): a lane walks the links of its own articulated body only; cross-block entries are zero.
-  if (lane < n) {
-    const int j = lane, b0 = j < c.nrobot ? 0 : c.nrobot, b1 = j < c.nrobot ? c.nrobot : n;
-    float* P = A + A_COLS + j * (MAX_BLOCK * 6);
+  if (lane < COLS_LANES) for (int j = lane; j < n; j += COLS_LANES) {
+    const int b0 = j < c.nrobot ? 0 : c.nrobot, b1 = j < c.nrobot ? c.nrobot : n;
+    float* P = A + A_COLS + lane * (MAX_BLOCK * 6);
     for (int k = 0; k < (b1 - b0) * 6; k++) P[k] = 0.f;
-    float* UU = A + A_COLS + MAX_DOF * MAX_BLOCK * 6 + j * MAX_BLOCK;   // per-lane u[] next to the column workspaces
+    float* UU = A + A_COLS + COLS_LANES * MAX_BLOCK * 6 + lane * MAX_BLOCK;   // per-lane u[] next to the column workspaces
     for (int d = b1 - 1; d >= b0; d--) {
       float u = (d == j ? 1.f : 0.f) - dot6p(L + L_S + 6 * d, P + 6 * (d - b0));
       UU[d - b0] = u;

@@ -22,11 +22,12 @@
 #define AGX_K(name) name##_bbl
 #elif defined(AGX_VARIANT_BED_SETTLE)
 // the rag-doll settle of BedBathingEnv.reset (bed_bathing.py:119-137): the whole human as ONE articulated body of 47 DoFs (6 for the
-// floating base + 41 joints) falling onto the bed; reset time only (one wave per SIMD at most: 97 KB of LDS per environment)
+// floating base + 41 joints) falling onto the bed; reset time only (65 KB of LDS per environment -- two per CU -- since the M^-1 columns are computed
+// in two batches of 24 lanes, agx_ctx.h COLS_LANES; 97 KB and one per CU before round 4)
 #define AGX_MAX_DOF 48
 #define AGX_MAX_FREE 1
 #define AGX_MAX_BLOCK 48
-#define AGX_ARENA_WORDS 20224
+#define AGX_ARENA_WORDS 11968
 #define AGX_SCR_ENT 16384
 #define AGX_TASK 1
 #define AGX_VNAME bed_settle

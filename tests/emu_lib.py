@@ -29,7 +29,7 @@ VARIANT_DEFS['dressing_m'] = ['-DAGX_MAX_DOF=28', '-DAGX_MAX_FREE=1', '-DAGX_MAX
 VARIANT_DEFS['dressing_l'] = ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=3']
 VARIANT_DEFS['arm_l'] = ['-DAGX_MAX_DOF=32', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=22', '-DAGX_ARENA_WORDS=7552', '-DAGX_TASK=4']
 VARIANT_DEFS['bed_l'] = ['-DAGX_MAX_DOF=24', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4096', '-DAGX_TASK=1']
-VARIANT_DEFS['settle'] = ['-DAGX_MAX_DOF=48', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=48', '-DAGX_ARENA_WORDS=20224', '-DAGX_SCR_ENT=16384', '-DAGX_TASK=1']
+VARIANT_DEFS['settle'] = ['-DAGX_MAX_DOF=48', '-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=48', '-DAGX_ARENA_WORDS=11968', '-DAGX_SCR_ENT=16384', '-DAGX_TASK=1']
 
 
 def lib(task_kind=0):
