@@ -1041,12 +1041,26 @@ AGX_DEV void env_finish_feeding(const uint32_t* blob, float* gstate, const float
         const v3 d = target - xp;
         if (sqrtf(dot(d, d)) < TKF(c, AGX_T_MOUTH_DIST)) drunk = true;
         else {
-          bool near = false;
-          for (int sh = 0; sh < NS && !near; sh++) {
-            if (c.bi[c.bi[AGX_H_OFF_COLL] + cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh] * AGX_C_STRIDE + AGX_C_TAG] != AGX_TAG_TOOL) continue;
-            float nw[3]; if (agxw::shape_distance_blob(blob, body, sh, x, nw) - margin <= spill) near = true;
-          }
-          spilled = !near;
+          spilled = true;      // decided below: the 0.1 m query against the cup's vertices (every lane takes part in the wave-uniform loops)
+        }
+      }
+    }
+    // w.get_closest_points(self.tool, distance=0.1) (drinking.py:77): a candidate is near when one of the cup's VERTICES is within the limit
+    // of the particle (the oracle's particle_near_tool: accurate to ~0.5 mm at this range, where the face-plane bound ran 10-30 % low).
+    // The shape and vertex loops are wave uniform (scalar / broadcast loads); lanes without a candidate idle.
+    if (wave_any(spilled)) {
+      for (int sh = 0; sh < NS; sh++) {
+        const int col = cl[cl[AGX_CL_OFF_SHAPE] + 4 * sh];
+        const int* ci = c.bi + c.bi[AGX_H_OFF_COLL] + col * AGX_C_STRIDE; const float* cf = c.bf + c.bi[AGX_H_OFF_COLL] + col * AGX_C_STRIDE;
+        if (ci[AGX_C_TAG] != AGX_TAG_TOOL) continue;
+        const float* B = body + 12 * agxw::body_slot(ci[AGX_C_BODY], c.ndof, c.nhuman); const float* R = B + 3;
+        const float d0 = x[0] - B[0], d1 = x[1] - B[1], d2 = x[2] - B[2];
+        const float xl0 = R[0] * d0 + R[3] * d1 + R[6] * d2, xl1 = R[1] * d0 + R[4] * d1 + R[7] * d2, xl2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
+        const float lim = spill + margin + cf[AGX_C_RADIUS], lim2 = lim * lim;
+        const float* v = c.bf + c.bi[AGX_H_OFF_VERT] + 3 * ci[AGX_C_VOFF];
+        for (int k = 0; k < ci[AGX_C_NVERT]; k++) {
+          const float e0 = xl0 - v[3 * k], e1 = xl1 - v[3 * k + 1], e2 = xl2 - v[3 * k + 2];
+          if (e0 * e0 + e1 * e1 + e2 * e2 <= lim2) spilled = false;
         }
       }
     }

@@ -114,39 +114,6 @@ AGX_DEV float shape_distance(const uint32_t* blob, const float* body, const floa
   return dist;
 }
 
-// the same from the blob's own records, `sh` free to differ between lanes: the spill query of the task layer (drinking.py:77; only particles
-// that have left the cup's cylinder ask)
-AGX_DEV float shape_distance_blob(const uint32_t* blob, const float* body, int sh, const float* x, float* nw) {
-  const int* bi = (const int*)blob; const float* bf = (const float*)blob;
-  const int* cl = bi + bi[AGX_H_OFF_CLOTH]; const float* clf = bf + bi[AGX_H_OFF_CLOTH];
-  const int* rec = cl + cl[AGX_CL_OFF_SHAPE] + 4 * sh; const int c = rec[0], p0 = rec[1], np = rec[2];
-  const int* ci = bi + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE; const float* cf = bf + bi[AGX_H_OFF_COLL] + c * AGX_C_STRIDE;
-  const float* B = body + 12 * body_slot(ci[AGX_C_BODY], bi[AGX_H_NDOF], bi[AGX_H_NHUMAN]); const float* R = B + 3;
-  const float d0 = x[0] - B[0], d1 = x[1] - B[1], d2 = x[2] - B[2];
-  const float xl0 = R[0] * d0 + R[3] * d1 + R[6] * d2, xl1 = R[1] * d0 + R[4] * d1 + R[7] * d2, xl2 = R[2] * d0 + R[5] * d1 + R[8] * d2;
-  const float rad = cf[AGX_C_RADIUS];
-  float n0, n1, n2, dist;
-  if (np == 0) {
-    const float* v = bf + bi[AGX_H_OFF_VERT] + 3 * ci[AGX_C_VOFF];
-    float c0 = v[0], c1 = v[1], c2 = v[2];
-    if (ci[AGX_C_NVERT] == 2) {
-      const float ab0 = v[3] - v[0], ab1 = v[4] - v[1], ab2 = v[5] - v[2], l2 = ab0 * ab0 + ab1 * ab1 + ab2 * ab2;
-      float t = l2 > 0.f ? ((xl0 - v[0]) * ab0 + (xl1 - v[1]) * ab1 + (xl2 - v[2]) * ab2) / l2 : 0.f; t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
-      c0 += t * ab0; c1 += t * ab1; c2 += t * ab2;
-    }
-    n0 = xl0 - c0; n1 = xl1 - c1; n2 = xl2 - c2; const float len = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
-    if (len > 1e-12f) { n0 /= len; n1 /= len; n2 /= len; } else { n0 = 0.f; n1 = 0.f; n2 = 1.f; }
-    dist = len - rad;
-  } else {
-    const float* P = clf + cl[AGX_CL_OFF_PLANE] + 4 * p0;
-    float bd = -3.0e38f; n0 = 0.f; n1 = 0.f; n2 = 1.f;
-    for (int k = 0; k < np; k++) { const float t = P[4 * k] * xl0 + P[4 * k + 1] * xl1 + P[4 * k + 2] * xl2 - P[4 * k + 3]; if (t > bd) { bd = t; n0 = P[4 * k]; n1 = P[4 * k + 1]; n2 = P[4 * k + 2]; } }
-    dist = bd - rad;
-  }
-  nw[0] = R[0] * n0 + R[1] * n1 + R[2] * n2; nw[1] = R[3] * n0 + R[4] * n1 + R[5] * n2; nw[2] = R[6] * n0 + R[7] * n1 + R[8] * n2;
-  return dist;
-}
-
 // one env step of the water: `nsub` internal substeps, substep k reading the frames of trace slot k ([NDOF + NFREE][12]).
 // gwater: float[2][NN][3] positions then velocities (in/out); greport: REPORT_WORDS ints, written after the last substep
 AGX_DEV void water_env(const uint32_t* blob, const float* gstate, const float* gtrace, float* gwater, float* greport, int nsub, float* lds, int lane) {

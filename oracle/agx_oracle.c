@@ -1107,6 +1107,28 @@ static double cloth_shape_distance(const sim_t* s, int sh, const double* x, doub
   return dist;
 }
 
+/* the 0.1 m closest-point query of a water particle against the cup (drinking.py:77: w.get_closest_points(self.tool, distance=0.1) empty
+ * -> spilled): is the particle's surface within `dist` of a piece of the tool?  At that range the distance of a point to a centimetre-sized
+ * convex piece is its distance to the piece's nearest VERTEX to within (piece size)^2 / (8 d) ~ 0.5 mm, whereas the face-plane value of
+ * cloth_shape_distance is a lower bound that runs up to ~10-30 % low off edges (the penalty fired late).  Vertices it is. */
+static int particle_near_tool(const sim_t* s, const double* x, double dist) {
+  const agxo_model* m = s->m; const int NS = m->i[m->o_cloth + AGX_CL_NSHAPE];
+  const double rw = CLPAR(m, AGX_CP_MARGIN);
+  for (int sh = 0; sh < NS; sh++) {
+    const int c = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * sh];
+    if (CI(m, c, AGX_C_TAG) != AGX_TAG_TOOL) continue;
+    const xf_t* X = body_xf(s, CI(m, c, AGX_C_BODY));
+    double d[3], xl[3]; sub3(x, X->p, d); mtv3(X->R, d, xl);
+    const double lim = dist + rw + CF(m, c, AGX_C_RADIUS);
+    const float* v = m->f + m->o_vert + 3 * CI(m, c, AGX_C_VOFF);
+    for (int k = 0; k < CI(m, c, AGX_C_NVERT); k++) {
+      const double e0 = xl[0] - v[3 * k], e1 = xl[1] - v[3 * k + 1], e2 = xl[2] - v[3 * k + 2];
+      if (e0 * e0 + e1 * e1 + e2 * e2 <= lim * lim) return 1;
+    }
+  }
+  return 0;
+}
+
 static void cloth_substep(sim_t* s) {
   const agxo_model* m = s->m; const int oc = m->o_cloth;
   const int NN = CLH(m, AGX_CL_NN), NCOL = CLH(m, AGX_CL_NCOLOR), NA = CLH(m, AGX_CL_NANCHOR), NS = CLH(m, AGX_CL_NSHAPE);
@@ -1907,13 +1929,7 @@ static void finish_drinking(sim_t* s, double act_norm2, float* obs, float* rewar
       continue;
     }
     /* w.get_closest_points(self.tool, distance=0.1) empty -> spilled (drinking.py:77-80): the particle against the cup's pieces */
-    int near = 0;
-    const int NS = m->i[m->o_cloth + AGX_CL_NSHAPE];
-    for (int sh = 0; sh < NS && !near; sh++) {
-      const int c = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * sh];
-      if (CI(m, c, AGX_C_TAG) != AGX_TAG_TOOL) continue;
-      double nw[3]; if (cloth_shape_distance(s, sh, x, nw) - CLPAR(m, AGX_CP_MARGIN) <= TF(m, AGX_T_SPILL_DIST)) near = 1;
-    }
+    const int near = particle_near_tool(s, x, TF(m, AGX_T_SPILL_DIST));
     if (!near) { water_reward -= 1; s->dk_alive &= ~(1ull << k); }
   }
   /* waters_active as it was on entry (drinking.py:81-85; the list is only filtered after both loops): a particle that touches the person */
@@ -2311,12 +2327,7 @@ void agxo_world_set_particle(agxo_world* w, int k, const double* pos) {
 int agxo_world_particle_query(agxo_world* w, int k, double dist) {
   sim_t* s = &w->s; const agxo_model* m = s->m; if (!s->cx || k < 0 || k >= agxo_cloth_nodes(m)) return 0;
   world_refresh(w);
-  int out = 0; const int NS = m->i[m->o_cloth + AGX_CL_NSHAPE];
-  for (int sh = 0; sh < NS && !out; sh++) {
-    const int c = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * sh];
-    if (CI(m, c, AGX_C_TAG) != AGX_TAG_TOOL) continue;
-    double nw[3]; if (cloth_shape_distance(s, sh, s->cx + 3 * k, nw) - CLPAR(m, AGX_CP_MARGIN) <= dist) out = 1;
-  }
+  int out = particle_near_tool(s, s->cx + 3 * k, dist);
   for (int c = 0; c < s->nccon; c++) {
     if (s->ccon_node[c] != k) continue;
     const int col = m->i[m->o_cloth + m->i[m->o_cloth + AGX_CL_OFF_SHAPE] + 4 * s->ccon_shape[c]];
