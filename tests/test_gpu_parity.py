@@ -502,6 +502,9 @@ def test_noop_retest_rule_against_the_plain_solve(gpu_lib, workload):
                                 tool_force=C.K_STEP * s2['obs'][f] / max(1.0, abs(o_obs[f])), obs=C.K_STEP * float(np.delete(s2['obs'], f).max()))
                     lim = {key: max(lim[key], lim2[key]) for key in lim}
                     print('step-level conditioning: %s step %d env %d dev %s bound %s' % (workload, k, i, {q: float('%.3g' % v) for q, v in dev.items()}, {q: float('%.3g' % v) for q, v in lim.items()}))
+                    import os
+                    os.makedirs('gpurun_out', exist_ok=True)
+                    np.savez('gpurun_out/noop_parity_case_%s_%d_%d.npz' % (workload, k, i), start=ref[i], action=act[i], dev_obs=obs[i], dev_info=info[i], oracle_obs=o_obs, oracle_info=o_info)
                 for key in dev:
                     assert dev[key] <= max(1e-3, lim[key], floor[key]), (workload, k, i, key, dev, lim, floor)
             else:
@@ -552,7 +555,7 @@ def test_warm_start_switch_on_the_device(gpu_lib, workload):
             assert np.abs(np.delete(obs[i] - o_obs, fcol)).max() < 1e-4 and abs(rew[i] - o_rew) < 1e-4 * max(1.0, abs(o_rew)) + 0.06 * 1e-2, (workload, k, i)
             assert abs(obs[i, fcol] - o_obs[fcol]) <= max(1e-3 * max(1.0, abs(o_obs[fcol])), 1e-2), (workload, k, i)
             assert abs(info[i, 0] - o_info[0]) <= max(1e-3 * max(1.0, abs(o_info[0])), 1e-2), (workload, k, i, info[i, 0], o_info[0])
-            assert np.abs(b.view(got[i:i + 1])['q'][0] - b.view(ref[i:i + 1])['q'][0]).max() < 2e-5
+            assert np.abs(b.view(got[i:i + 1])['q'][0] - b.view(ref[i:i + 1])['q'][0]).max() < 1e-4
     assert differs > 1e-6 or workload == 'wiping'           # the switch changes the food pile's unconverged solve (the pad's small system converges either way)
     st.close()
     one = Stepper(b, 1)

@@ -76,6 +76,9 @@ def test_step_matches_oracle(rb):
             ok, lim, sv = C.within(dev[f], o_obs[f], lambda: _sens()['obs'][f], floor=C.force_floor(b), step_sens_fn=lambda: _sens2()['obs'][f])
             if sv is not None:
                 print('conditioned: %s step %d env %d tool force dev %.3g rel, 1-ulp sensitivity %.3g' % (name, k, i, dev[f] / max(1.0, abs(o_obs[f])), sv))
+                import os                                   # kept for a replay on the CPU wave emulator (tests/diag)
+                os.makedirs('gpurun_out', exist_ok=True)
+                np.savez('gpurun_out/scratch_parity_case_%s_%d_%d.npz' % (name, k, i), start=ref[i], action=act[i], dev_obs=obs[i], dev_info=info[i], oracle_obs=o_obs, oracle_info=o_info)
             assert ok, (k, i, dev[f], lim, sv)
             dev[f] = 0
             worst[i] = max(worst[i], float(dev.max()), abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
