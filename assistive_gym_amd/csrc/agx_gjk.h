@@ -96,6 +96,11 @@ AGX_DEV v3 gjk_support_wave(const gjk_shape& s, v3 d, bool active) {
   return out;
 }
 
+// iteration statistics of the narrowphase on the CPU wave emulator (tests/diag/narrowphase_passes.py); nothing on the device
+#ifndef AGX_TRACE_GJK
+#define AGX_TRACE_GJK(has, iters, na, nb, box)
+#endif
+
 // closest point to the origin on triangle (a,b,c): barycentric weights
 AGX_DEV void gjk_closest_tri(v3 a, v3 b, v3 c, float& wa, float& wb, float& wc) {
   v3 ab = b - a, ac = c - a, ap = -a, bp = -b, cp = -c;
@@ -215,12 +220,14 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
   pa = a0; pb = b0;
   bool pen = false, far_out = false, active = has;
   float lb = 0.f;
+  int my_iters = 0; (void)my_iters;
   { const float vw0 = dot(d0, v); if (has && vw0 > 0.f && vw0 * vw0 > far * far * dd) { far_out = true; lb = vw0 / sqrtf(dd); active = false; } }
   for (int it = 0; it < maxit; it++) {
     if (active && vv < 1e-12f) { pen = true; active = false; }   /* cores closer than 1 micron: treat as overlapping */
     if (!wave_any(active)) break;
     const v3 wa = gjk_support_wave(sa, -v, active), wb = gjk_support_wave(sb, v, active);
     if (active) {
+      my_iters++;
       const v3 w = wa - wb;
       const float vw = dot(v, w);
       const bool e0 = s.p0.w.x == w.x && s.p0.w.y == w.y && s.p0.w.z == w.z;
@@ -252,6 +259,7 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
       }
     }
   }
+  AGX_TRACE_GJK(has, my_iters, sa.n, sb.n, sb.box)
   if (pen) { dist = 0; return true; }
   dist = far_out ? lb : sqrtf(vv);
   return false;

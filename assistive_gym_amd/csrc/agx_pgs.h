@@ -280,11 +280,16 @@ AGX_DEV int pgs_lds_split(const PgsSet& S, int lane, int l0, int l1) {
 // (sums are associated differently).  dv = sum_i B_i lambda_i is formed once at the end.
 // Returns false (nothing done) if the environment has more rows than fit or touches DoFs beyond lane 63.
 // K of the no-op re-test rule for this environment and substep (see pgs()): AGX_P_NOOP_RETEST, or 0 = plain sweeps when one of the
-// substep's contacts is pressed deeper than AGX_P_NOOP_PEN (include/agx_blob.h).  Wave-uniform; lane = contact (MAX_CON <= 64).
+// substep's contacts is pressed deeper than AGX_P_NOOP_PEN or is a contact of the robot / its tool with the person (include/agx_blob.h).  Wave-uniform; lane = contact (MAX_CON <= 64).
 AGX_DEV int noop_period(const Ctx& c) {
   const int K = (int)PRM(c, AGX_P_NOOP_RETEST); const float pen = PRM(c, AGX_P_NOOP_PEN);
   if (K <= 0 || !(pen > 0.f)) return K;
-  const bool pressed = c.lane < c.ncon && c.gcon[CON_STRIDE * c.lane + C_DIST] < -pen;
+  bool pressed = false;
+  if (c.lane < c.ncon) {                                            // ... or is one of the robot / its tool with the person: the forces the task reports come from plain sweeps
+    const float* o = c.gcon + CON_STRIDE * c.lane; const int* oi = (const int*)o;
+    const int ta = CLI(c, oi[C_CA], AGX_C_TAG), tb = CLI(c, oi[C_CB], AGX_C_TAG);
+    pressed = o[C_DIST] < -pen || (ta == AGX_TAG_HUMAN && (tb == AGX_TAG_ROBOT || tb == AGX_TAG_TOOL)) || (tb == AGX_TAG_HUMAN && (ta == AGX_TAG_ROBOT || ta == AGX_TAG_TOOL));
+  }
   return wave_any(pressed) ? 0 : K;
 }
 AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {

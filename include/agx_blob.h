@@ -117,7 +117,10 @@ enum {
                             and single steps' rewards through flipped wiping events against the plain 50-sweep solve (f64 oracle with the rule vs
                             without, BedBathingSawyer wiping workload: 5 of 96 steps beyond 1e-3).  With 0.2 mm the same 96 steps are identical to
                             the plain solve, and FeedingJaco's resting food pile (penetrations of ~0.05 mm) keeps the rule: 75.5 -> 76.5 row
-                            visits per sweep.  0 = the rule applies regardless (round 3) */
+                            visits per sweep.  With the switch on (> 0) a contact of the robot or its tool with the person switches the rule off as well:
+                            a robot link RESTING on the person sits at dist ~ 0 and carries newtons (wiping workload, f64: total_force_on_human
+                            5.1404 N with the rule vs 5.1480 N plain, 1.5e-3 relative) -- every force the tasks report is a force on the person,
+                            so all of them come from plain sweeps.  0 = the rule applies regardless (round 3) */
   AGX_P_COUNT = 25
 };
 

@@ -988,7 +988,13 @@ static void pgs(sim_t* s, double* dv) {
   int iters = (int)PARAM(s->m, AGX_P_NITER);
   int K = (int)PARAM(s->m, AGX_P_NOOP_RETEST);
   { const double pen = PARAM(s->m, AGX_P_NOOP_PEN);          /* a pressed contact (deeper than AGX_P_NOOP_PEN): plain sweeps in this substep */
-    if (K > 0 && pen > 0) for (int c = 0; c < s->ncon; c++) if (s->con[c].dist < -pen) K = 0; }
+    if (K > 0 && pen > 0) for (int c = 0; c < s->ncon; c++) if (s->con[c].dist < -pen) K = 0;
+    /* ... and so does any contact of the robot or its tool with the person (resting contacts sit at dist ~ 0 and still carry the forces the
+     * task reports) */
+    if (K > 0 && pen > 0) for (int c = 0; c < s->ncon; c++) {
+      const int ta = CI(s->m, s->con[c].ca, AGX_C_TAG), tb = CI(s->m, s->con[c].cb, AGX_C_TAG);
+      if ((ta == AGX_TAG_HUMAN && (tb == AGX_TAG_ROBOT || tb == AGX_TAG_TOOL)) || (tb == AGX_TAG_HUMAN && (ta == AGX_TAG_ROBOT || ta == AGX_TAG_TOOL))) K = 0;
+    } }
   unsigned char skip[MAXROWS]; memset(skip, 0, sizeof skip);
   memset(dv, 0, sizeof(double) * NVMAX);
   g_pgs_stats[5] += 1;

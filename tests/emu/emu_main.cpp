@@ -1,6 +1,11 @@
 // Host harness that runs the product kernel sources (csrc/agx_step.h) for ONE environment on the
 // CPU wave emulator.  Built by tests/emu_lib.py into tests/emu/libagx_emu.so.  Test-only.
 #include "agx_wave.h"
+#ifdef AGX_EMU_TRACE_GJK      // tests/diag/narrowphase_passes.py: per gjk_distance call and lane (call, lane, iterations, |A|, |B|, box)
+extern "C" { int g_gjk_trace[1 << 22]; int g_gjk_n = 0, g_gjk_call = 0; }
+#define AGX_TRACE_GJK(has, iters, na, nb, box) { if (wave_lane() == 0) g_gjk_call++; wave_sync(); \
+  if ((has) && g_gjk_n + 6 <= (1 << 22)) { int* t = g_gjk_trace + g_gjk_n; g_gjk_n += 6; t[0] = g_gjk_call; t[1] = wave_lane(); t[2] = (iters); t[3] = (na); t[4] = (nb); t[5] = (box) ? 1 : 0; } }
+#endif
 #include "agx_step.h"
 #include "agx_water.h"      // not yet part of a kernel variant: the source is checked here against the oracle first
 #include <functional>

@@ -321,3 +321,27 @@ def test_emulator_coop_episode(bed, bed_oracle, bed_emu):
         assert np.abs(vo['q'] - ve['q']).max() < 2e-5 and np.array_equal(vo['task'][0, 10], ve['task'][0, 10])
     # the human part of the observation: joint angles of the 10 arm joints, then shoulder / elbow / wrist in the human's frame
     assert np.abs(oo[24 + 7:24 + 17] - vo['q'][0, coop.nrobot:]).max() < 1e-6
+
+
+def test_noop_rule_is_off_where_the_robot_rests_on_the_person():
+    """tests/golden/wiping_resting_arm_case.npz (written by the GPU test of the no-op re-test rule, session r04f): a Sawyer link RESTS on the
+    person -- two contacts at dist = +1 um carrying 5.1 N.  The rule applied regardless (AGX_P_NOOP_PEN = 0) moves total_force_on_human by
+    1.5e-3 relative against the plain 50-sweep solve in float64; with the switch (the default) every substep that has a robot / tool contact
+    with the person is solved with plain sweeps and the step is IDENTICAL to the plain solve; the kernel sources (wave emulator) follow."""
+    import os
+    from assistive_gym_amd.blob import ModelBlob
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    import conditioning as C
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'wiping_resting_arm_case.npz'))
+    b = ModelBlob.load('bed_bathing_sawyer')
+    plain = Oracle(b.set_param('NOOP_RETEST', 0.0)).step(d['start'].copy(), d['action'])
+    rule = Oracle(b).step(d['start'].copy(), d['action'])
+    regardless = Oracle(b.set_param('NOOP_PEN', 0.0)).step(d['start'].copy(), d['action'])
+    assert plain[3][0] > 5.0
+    assert abs(regardless[3][0] - plain[3][0]) > 1e-3 * plain[3][0]
+    assert rule[3][0] == plain[3][0] and np.array_equal(rule[0], plain[0]) and rule[1] == plain[1]
+    emu = Emu(b).step(d['start'].copy(), d['action'])
+    assert abs(emu[3][0] - plain[3][0]) <= max(1e-3 * plain[3][0], C.force_floor(b))
+    old = Emu(b.set_param('NOOP_PEN', 0.0)).step(d['start'].copy(), d['action'])
+    assert abs(float(d['dev_info'][0]) - old[3][0]) < 2e-3      # the device of that session still applied the rule here (5.1385 N): what the emulator gives without the switch

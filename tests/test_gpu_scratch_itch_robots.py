@@ -64,7 +64,7 @@ def test_step_matches_oracle(rb):
             # the tool force of a pressed contact after 50 unconverged sweeps, f32 against f64: north_star's 1e-3 relative; a case beyond it is
             # judged against the oracle's own response to a 1-ulp perturbation of its input (tests/conditioning.py: the worst crafted state --
             # Baxter, step 2, env 14 -- sits at 1.03e-3 since the row products run on the matrix cores, 0.91e-3 with the per-lane loops before)
-            sens, sens2 = [], []
+            sens, sens2, sens3 = [], [], []
             def _sens():
                 if not sens:
                     sens.append(C.ulp_sensitivity(b, o, ref[i], act[i], trials=4))
@@ -73,7 +73,11 @@ def test_step_matches_oracle(rb):
                 if not sens2:
                     sens2.append(C.ulp_sensitivity(b, o, ref[i], act[i], trials=6, rel_eps=C.STEP_EPS))
                 return sens2[0]
-            ok, lim, sv = C.within(dev[f], o_obs[f], lambda: _sens()['obs'][f], floor=C.force_floor(b), step_sens_fn=lambda: _sens2()['obs'][f])
+            def _sens3():
+                if not sens3:
+                    sens3.append(C.ulp_sensitivity(b, o, ref[i], act[i], trials=6, rel_eps=C.GEOM_EPS))
+                return sens3[0]
+            ok, lim, sv = C.within(dev[f], o_obs[f], lambda: _sens()['obs'][f], floor=C.force_floor(b), step_sens_fn=lambda: _sens2()['obs'][f], geom_sens_fn=lambda: _sens3()['obs'][f])
             if sv is not None:
                 print('conditioned: %s step %d env %d tool force dev %.3g rel, 1-ulp sensitivity %.3g' % (name, k, i, dev[f] / max(1.0, abs(o_obs[f])), sv))
                 import os                                   # kept for a replay on the CPU wave emulator (tests/diag)
@@ -84,7 +88,7 @@ def test_step_matches_oracle(rb):
             worst[i] = max(worst[i], float(dev.max()), abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
             assert info[i, 4] == o_info[4] and info[i, 1] == o_info[1] and bool(done[i]) == o_done
             for c in (0, 2, 3):
-                ok, lim, sv = C.within(abs(info[i, c] - o_info[c]), o_info[c], lambda: _sens()['info'][c], floor=C.force_floor(b) if c == 0 else 0.0, step_sens_fn=lambda: _sens2()['info'][c])
+                ok, lim, sv = C.within(abs(info[i, c] - o_info[c]), o_info[c], lambda: _sens()['info'][c], floor=C.force_floor(b) if c == 0 else 0.0, step_sens_fn=lambda: _sens2()['info'][c], geom_sens_fn=lambda: _sens3()['info'][c])
                 assert ok, (i, c, info[i], o_info, lim, sv)
         touched += int((info[12:, 0] > 0).sum())            # total force on the human: the scratcher (or the arm behind it) presses on the limb
     st.close()

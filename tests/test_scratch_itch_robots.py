@@ -201,3 +201,32 @@ def test_device_reset_generator_matches_its_restatement(robot):
     hm = HumanModel('male')
     assert np.allclose(b.task_f('SI_LIMB_DIMS', 8)[:4], [hm.dims['upperarm'][1], hm.dims['upperarm'][0], hm.dims['forearm'][1], hm.dims['forearm'][0]])
     assert np.allclose(b.task_f('SI_LIMB_DIMS', 8)[:4], [0.279, 0.043, 0.257, 0.033], atol=1e-6)         # scratch_itch.py:136
+
+
+def test_witness_point_of_a_parallel_edge_contact_is_what_the_geometry_level_bounds():
+    """tests/golden/scratch_sawyer_parallel_edge_case.npz: the state / action of the one GPU parity case of the suite beyond north_star's 1e-3
+    AND beyond the step-level conditioning (ScratchItchSawyer, crafted pressed state, session r04f: device tool force 0.98798 N, oracle
+    1.01162 N), written by the GPU test and replayed here on the CPU wave emulator.  What it shows: (1) the emulator reproduces the device
+    (2e-5 N), so the deviation is float32 arithmetic of the kernel sources and nothing the hardware adds; (2) the oracle's force responds
+    LINEARLY to input perturbations here (3.5e-3 N per 1e-6), i.e. no threshold is crossed -- the witness point of the single contact slides
+    along an edge of the scratcher that lies parallel to the forearm; (3) the device's deviation is inside the oracle's response at
+    conditioning.GEOM_EPS, the level derived from float32's rounding of world-space vertices over a 1 cm feature."""
+    import os
+    import conditioning as C
+    from assistive_gym_amd.blob import ModelBlob
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'scratch_sawyer_parallel_edge_case.npz'))
+    b = ModelBlob.load('scratch_itch_sawyer'); f = b.obs_dim_robot - 1
+    o, e = Oracle(b), Emu(b)
+    o_obs = o.step(d['start'].copy(), d['action'])[0]
+    e_obs = e.step(d['start'].copy(), d['action'])[0]
+    assert abs(e_obs[f] - d['dev_obs'][f]) < 1e-4                                   # (1) emulator == device
+    dev = abs(float(d['dev_obs'][f]) - float(o_obs[f]))
+    assert dev > 1e-3 * max(1.0, abs(o_obs[f]))                                     # the case IS beyond north_star's bound
+    s1 = C.ulp_sensitivity(b, o, d['start'], d['action'], trials=6, rel_eps=1e-6)['obs'][f]
+    s3 = C.ulp_sensitivity(b, o, d['start'], d['action'], trials=6, rel_eps=3e-6)['obs'][f]
+    sg = C.ulp_sensitivity(b, o, d['start'], d['action'], trials=6, rel_eps=C.GEOM_EPS)['obs'][f]
+    assert 2.0 < s3 / s1 < 4.5                                                      # (2) linear response: x3 in, ~x3 out
+    assert dev <= C.K_GEOM * sg                                                     # (3)
+    assert C.within(dev, o_obs[f], lambda: 0.0, floor=C.force_floor(b), step_sens_fn=lambda: s1, geom_sens_fn=lambda: sg)[0]
