@@ -72,13 +72,18 @@ AGX_DEV void emit_contact(Ctx& c, int slot, int ca, int cb, const Cand& k) {
 //      them, in order) become contacts.
 // The contact order (group, a, selection order) is what the oracle produces, so the solver rows
 // are identical.
-constexpr int WL_MAX = 200, CAND_STRIDE = 8;
+constexpr int CAND_STRIDE = 8;
+constexpr int TW_WORDS = 6 * (MAX_DOF + MAX_FREE);        // twist (w, v at the reference point M_REF) of every moving body, see rel_travel()
+constexpr int WL_FIT = (ARENA_WORDS - ABS * MAX_COLL - TW_WORDS) / (1 + CAND_STRIDE);
+constexpr int WL_MAX = WL_FIT < 200 ? WL_FIT : 200;      // worklist entries the arena has room for
 constexpr int A_WL = ABS * MAX_COLL;                      // int[WL_MAX]: a | b << 9 | group << 18 | face-manifold point << 24
 constexpr int WL_KEY_MASK = ~((511 << 9) | (3 << 24));    // (group, A collider) of a worklist entry
 constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_STRIDE]: gap, pa, n, dist (pb = pa - dist n)
-static_assert(A_CAND + WL_MAX * CAND_STRIDE <= ARENA_WORDS, "collision workspace exceeds the arena");
+constexpr int A_TW = A_CAND + WL_MAX * CAND_STRIDE;     // float[MAX_DOF + MAX_FREE][6]
+static_assert(A_TW + TW_WORDS <= ARENA_WORDS, "collision workspace exceeds the arena");
 static_assert(MAX_COLL <= 512, "collider indices are packed in 9 bits");
 constexpr int WL_CAP = WL_MAX - 16;   // the candidate words of the last 16 entries (128 ints) hold the A-collider list of a sweep
+static_assert(WL_CAP >= 128, "a flush of at least two full passes");
 
 AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
   const float* L = c.lds; const int pr = c.ldsi[L_ARENA + A_WL + idx]; const float* cd = L + L_ARENA + A_CAND + CAND_STRIDE * idx;
@@ -149,6 +154,41 @@ AGX_DEV float body_wmag(const Ctx& c, int code) {
   if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) return c.lds[L_WMAG + MAX_DOF + (code - AGX_BODY_FREE0)];
   return 0.f;
 }
+// twist of the body a collider is attached to, about the common reference point M_REF: velocity field u(x) = v + w x (x - ref); zero for
+// the static bodies.  Filled at the start of collide().
+AGX_DEV void body_twist(const Ctx& c, int code, v3& w, v3& v) {
+  int slot = -1;
+  if (code >= 0 && code < AGX_BODY_ROBOT_BASE) slot = code;
+  else if (code >= AGX_BODY_FREE0 && code < AGX_BODY_HUMAN0) slot = MAX_DOF + (code - AGX_BODY_FREE0);
+  if (slot < 0) { w = mk3(0.f, 0.f, 0.f); v = w; return; }
+  const float* T = c.lds + L_ARENA + A_TW + 6 * slot;
+  w = ld3(T); v = ld3(T + 3);
+}
+// Upper bound on |v_n| dt of a contact of the pair (a, b) from the RELATIVE motion of the two bodies.  With the relative velocity field
+// u(x) = v_A(x) - v_B(x) = dv + dw x (x - ref) the contact's normal velocity is v_n = n . (v_A(pa) - v_B(pb)) = n . u(pa), because
+// pa - pb is parallel to n (closest points, or the penetration direction).  pa lies within ext_a (half the diagonal of a's world box) of
+// the box centre ca:  |v_n| <= |u(ca)| + |dw| ext_a.  For a sphere (one-vertex core) pa - ca = -r n and the rotation term has no normal
+// component at all: |v_n| <= |u(c)| at the sphere's centre, whichever side the sphere is on.
+// The per-collider travel distances (AB[.][6], absolute speeds) bound the same quantity by |v_A| + |v_B|: for bodies that move TOGETHER
+// -- the food riding on the spoon while the arm swings it, 180 of the ~225 narrowphase pairs of a FeedingJaco substep -- that is the speed
+// of the arm, this is ~0.  Used wherever a pair is dropped because it cannot produce a solver row (predicted gap = dist + v_n dt >=
+// slack): the set of contacts is unchanged, only the work is.
+AGX_DEV float rel_travel(const Ctx& c, int a, int b) {
+  const float* AB = c.lds + L_ARENA;
+#ifdef AGX_NO_REL_TRAVEL   // build-time knob for same-box A/B runs and the bit-identity check of tests/test_emu_parity.py
+  return AB[ABS * a + 6] + AB[ABS * b + 6];
+#endif
+  v3 wa, va, wb, vb;
+  body_twist(c, CLI(c, a, AGX_C_BODY), wa, va); body_twist(c, CLI(c, b, AGX_C_BODY), wb, vb);
+  const bool sa = CLI(c, a, AGX_C_NVERT) == 1, sb = CLI(c, b, AGX_C_NVERT) == 1;
+  const int e = (!sa && sb) ? b : a;                               // evaluate at the sphere's centre if there is one
+  const v3 lo = ld3(AB + ABS * e), hi = ld3(AB + ABS * e + 3);
+  const v3 ce = 0.5f * (lo + hi), d = hi - lo;
+  const v3 dw = wa - wb;
+  const v3 u = (va - vb) + cross(dw, ce - ld3(c.lds + L_MISC + M_REF));
+  const float rot = (sa || sb) ? 0.f : sqrtf(dot(dw, dw)) * 0.5f * sqrtf(dot(d, d));
+  return fminf(1.001f * (sqrtf(dot(u, u)) + rot) * c.dt + 1e-6f, AB[ABS * a + 6] + AB[ABS * b + 6]);
+}
 // conservative separation test: every point of collider x lies within |half extents| + radius of
 // the centre of its box; collider y lies within its body-frame box inflated by its radius.  True if
 // the two are certainly further apart than `reach`.
@@ -188,7 +228,7 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
       // the AABBs were grown by.  Unless the task asks whether a manifold point exists (group flag bit 1), a pair
       // further apart than that is of no interest and its GJK may stop at the first separating axis that proves it
       // (pairs such as two idle fingers 4 mm apart otherwise run to full convergence every substep).
-      if (!(GRI(c, g, AGX_G_FLAGS) & 2)) lim = fminf(brk, slack + AB[ABS * a + 6] + AB[ABS * b + 6] + 1e-5f);
+      if (!(GRI(c, g, AGX_G_FLAGS) & 2)) lim = fminf(brk, slack + rel_travel(c, a, b) + 1e-5f);
     }
     k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.dist = 0.f;
     bool hit = narrowphase(c, a, b, lim, k, has && sub == 0);
@@ -320,7 +360,7 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gfl
     }
     if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * a + q] > AB[ABS * b + 3 + q] + mg || AB[ABS * b + q] > AB[ABS * a + 3 + q] + mg) ok = false;
     // level 3: bounding sphere of one collider against the body-frame box of the other, both ways
-    if (ok) { const float reach = mg + AB[ABS * a + 6] + AB[ABS * b + 6] + 1e-5f; ok = !sphere_box_apart(c, a, b, reach) && !sphere_box_apart(c, b, a, reach); }
+    if (ok) { const float reach = mg + rel_travel(c, a, b) + 1e-5f; ok = !sphere_box_apart(c, a, b, reach) && !sphere_box_apart(c, b, a, reach); }
     const uint64_t m = wave_ballot(ok);
     const int slot = wn + wave_rank(m);
     if (ok && slot < WL_CAP) WL[slot] = a | (b << 9) | (g << 18) | (sub << 24);
@@ -339,11 +379,16 @@ AGX_DEV void collide(Ctx& c) {
 #define AGX_CTICK(k) if (c.timing) { ct1 = wave_clock(); c.tm[k] += ct1 - ct0; ct0 = ct1; }
   // 1. world AABBs, grown by the distance the collider can travel in this substep (speculative):
   //    the broadphase margin then only has to cover the solver slack
-  if (lane < MAX_DOF + MAX_FREE) {     // angular speed of every moving body, once (the chain walk is per body, not per collider)
-    v3 w = mk3(0, 0, 0);
-    if (lane < MAX_DOF) { if (lane < c.ndof) for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) w = w + L[L_VEL + d] * ld3(L + L_S + 6 * d); }
-    else if (lane - MAX_DOF < c.nfree) w = ld3(L + L_VEL + c.ndof + 6 * (lane - MAX_DOF) + 3);
+  if (lane < MAX_DOF + MAX_FREE) {     // twist and angular speed of every moving body, once (the chain walk is per body, not per collider)
+    v3 w = mk3(0, 0, 0), v = w;
+    if (lane < MAX_DOF) { if (lane < c.ndof) for (int d = lane; d >= 0; d = RBI(c, d, AGX_R_PARENT)) { const float qd = L[L_VEL + d]; w = w + qd * ld3(L + L_S + 6 * d); v = v + qd * ld3(L + L_S + 6 * d + 3); } }
+    else if (lane - MAX_DOF < c.nfree) {
+      const int fb = lane - MAX_DOF, o = c.ndof + 6 * fb;
+      w = ld3(L + L_VEL + o + 3);
+      v = ld3(L + L_VEL + o) + cross(w, ld3(L + L_MISC + M_REF) - ld3(L + L_ST + c.s_free + 13 * fb));
+    }
     L[L_WMAG + lane] = sqrtf(dot(w, w));
+    st3(AB + A_TW + 6 * lane, w); st3(AB + A_TW + 6 * lane + 3, v);
   }
   wave_sync();
   for (int col = lane; col < c.ncoll; col += 64) {

@@ -98,7 +98,7 @@ AGX_DEV v3 gjk_support_wave(const gjk_shape& s, v3 d, bool active) {
 
 // iteration statistics of the narrowphase on the CPU wave emulator (tests/diag/narrowphase_passes.py); nothing on the device
 #ifndef AGX_TRACE_GJK
-#define AGX_TRACE_GJK(has, iters, na, nb, box)
+#define AGX_TRACE_GJK(has, iters, na, nb, box, far_out, dist, far)
 #endif
 
 // closest point to the origin on triangle (a,b,c): barycentric weights
@@ -259,7 +259,7 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
       }
     }
   }
-  AGX_TRACE_GJK(has, my_iters, sa.n, sb.n, sb.box)
+  AGX_TRACE_GJK(has, my_iters, sa.n, sb.n, sb.box, far_out, far_out ? lb : sqrtf(vv), far)
   if (pen) { dist = 0; return true; }
   dist = far_out ? lb : sqrtf(vv);
   return false;

@@ -31,7 +31,7 @@ def main(n_states=6, steps=3):
         for k in range(steps):
             n.value = 0
             e.step(s, rng.uniform(-1, 1, b.act_dim).astype(np.float32))
-            t = np.frombuffer(tr, dtype=np.int32, count=n.value).reshape(-1, 6).copy()
+            t = np.frombuffer(tr, dtype=np.int32, count=n.value).reshape(-1, 9).copy()
             rows.append(t)
             calls = np.unique(t[:, 0])
             per = []
@@ -50,6 +50,7 @@ def main(n_states=6, steps=3):
     print('pairs with a one-vertex core (spheres): %d of %d, iterations histogram' % (len(pt), len(t)), np.bincount(pt[:, 2]))
     ot = t[(t[:, 3] != 1) & (t[:, 4] != 1)]
     print('other pairs: iterations histogram', np.bincount(ot[:, 2]), 'hull sizes |A|+|B| median', np.median(ot[:, 3] + ot[:, 4]))
+    print('sphere pairs: stopped by the separating-axis early-out %d of %d; limit (um) median %d; core distance of the others (um): median %d, share beyond the limit %.2f' % ((pt[:, 6] == 1).sum(), len(pt), np.median(pt[:, 8]), np.median(pt[pt[:, 6] == 0][:, 7]), (pt[pt[:, 6] == 0][:, 7] > pt[pt[:, 6] == 0][:, 8]).mean()))
     print('sphere pairs: partner hull size median %d max %d' % (np.median(pt[:, 3] + pt[:, 4] - 1), (pt[:, 3] + pt[:, 4] - 1).max()))
 
 

@@ -3,8 +3,9 @@
 #include "agx_wave.h"
 #ifdef AGX_EMU_TRACE_GJK      // tests/diag/narrowphase_passes.py: per gjk_distance call and lane (call, lane, iterations, |A|, |B|, box)
 extern "C" { int g_gjk_trace[1 << 22]; int g_gjk_n = 0, g_gjk_call = 0; }
-#define AGX_TRACE_GJK(has, iters, na, nb, box) { if (wave_lane() == 0) g_gjk_call++; wave_sync(); \
-  if ((has) && g_gjk_n + 6 <= (1 << 22)) { int* t = g_gjk_trace + g_gjk_n; g_gjk_n += 6; t[0] = g_gjk_call; t[1] = wave_lane(); t[2] = (iters); t[3] = (na); t[4] = (nb); t[5] = (box) ? 1 : 0; } }
+#define AGX_TRACE_GJK(has, iters, na, nb, box, far_out, dist, far) { if (wave_lane() == 0) g_gjk_call++; wave_sync(); \
+  if ((has) && g_gjk_n + 9 <= (1 << 22)) { int* t = g_gjk_trace + g_gjk_n; g_gjk_n += 9; t[0] = g_gjk_call; t[1] = wave_lane(); t[2] = (iters); t[3] = (na); t[4] = (nb); t[5] = (box) ? 1 : 0; \
+    t[6] = (far_out) ? 1 : 0; t[7] = (int)((dist) * 1e6f); t[8] = (int)((far) * 1e6f); } }
 #endif
 #include "agx_step.h"
 #include "agx_water.h"      // not yet part of a kernel variant: the source is checked here against the oracle first

@@ -19,6 +19,7 @@ VARIANT_DEFS[4] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=10',
 VARIANT_DEFS['drinking'] = ['-DAGX_MAX_FREE=1', '-DAGX_TASK=5']      # the feeding limits, the drinking task layer, the water kernel (csrc/agx_water.h)
 VARIANT_DEFS['drinking_l'] = ['-DAGX_MAX_FREE=1', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040', '-DAGX_TASK=5']      # DrinkingPR2
 VARIANT_DEFS['drinking_m'] = ['-DAGX_MAX_FREE=1', '-DAGX_MAX_DOF=20', '-DAGX_MAX_BLOCK=16', '-DAGX_ARENA_WORDS=4040', '-DAGX_TASK=5']      # DrinkingStretch
+VARIANT_DEFS['feeding_abs_travel'] = ['-DAGX_NO_REL_TRAVEL']      # narrowphase limits from the per-collider (absolute) travel distances only
 VARIANT_DEFS['feeding_trace'] = ['-DAGX_EMU_TRACE_GJK']      # tests/diag/narrowphase_passes.py
 VARIANT_DEFS['feeding_packed'] = ['-DAGX_USE_SOLVE4=1']       # the opt-in packed solve kernel (csrc/agx_pgs4.h)
 VARIANT_DEFS['feeding_cap'] = ['-DAGX_USE_SOLVE4=1', '-DAGX_P4_WINDOW_CAP=100']      # the packed solver with a small LDS window: its rows-beyond-the-window path on ordinary scenes

@@ -429,3 +429,22 @@ def test_warm_start_switch_matches_the_oracle(blob, path):
     # (the food pile's 50 sweeps are not converged: the start matters; the pad's small system is converged to the last bit in 50 sweeps either way)
     assert differs > 1e-6 or path == 'row_space'
     o.forget_warm()
+
+
+def test_relative_travel_bound_leaves_the_contacts_unchanged(blob):
+    """rel_travel() (csrc/agx_collide.h) only drops pairs that cannot produce a solver row: the kernel sources with and without it
+    (-DAGX_NO_REL_TRAVEL) produce bit-identical state records over random-policy steps of settled FeedingJaco states."""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    st, _ = make_states(blob, 3, seed=5151)
+    new, old = Emu(blob), Emu(blob, kind='feeding_abs_travel')
+    o = Oracle(blob)
+    rng = np.random.RandomState(9)
+    for i in range(len(st)):
+        o.settle(st[i], 25)
+        s1, s2 = st[i].copy(), st[i].copy()
+        for k in range(6):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            r1 = new.step(s1, a); r2 = old.step(s2, a)
+            assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32)), (i, k)
+            assert np.array_equal(r1[0], r2[0]) and r1[1] == r2[1]
