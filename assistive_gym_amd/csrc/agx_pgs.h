@@ -296,7 +296,7 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
   if constexpr (RS_MAX_ROWS == 0) { (void)c; (void)W; (void)dv0; (void)dv1; return false; }
   else {
     const int lane = c.lane, iters = (int)PRM(c, AGX_P_NITER);
-    const int nnc = c.first_normal, nc = c.ncon, nA = nnc + nc, R = nA + nc, nv = c.nv;
+    const int nnc = c.first_normal, nc = c.ncon, nA = nnc + nc, R = c.nrows, nv = c.nv;       // R = nA + nc friction rows (AGX_P_FRICTION_DIRS = 2: + nc more)
     if (R > RS_MAX_ROWS || nv > 64 || nv > RS_NVP || R == 0 || c.nent > SOLVE_LDS_PAIRS) return false;
     const float* E = W;                                            // the (J,B) window holds every pair of this environment (env_solve copied them)
     PgsSet S; pgs_load_set(c, lane, lane < R, lane >= nA, S);      // lane r owns row r; friction rows: S.hi = mu
@@ -345,7 +345,7 @@ AGX_DEV bool pgs_rowspace(Ctx& c, float* W, float& dv0, float& dv1) {
       S.lam = l0;
       for (uint64_t m = wave_ballot(l0 != 0.f); m; m &= m - 1ull) { const int r = ffs64(m); w += A[RS_MAX_ROWS * r + lane] * wave_bcast(l0, r); }
     }
-    const int fn = lane - nc;                                       // normal row of this lane's friction row
+    const int fn = lane - (lane >= nA + nc ? 2 * nc : nc);          // normal row of this lane's friction row (first / second direction block)
     const int K = noop_period(c);                                   // the no-op re-test rule, see pgs()
     uint64_t skip = 0ull;
     for (int it = 0; it < iters; it++) {
@@ -425,6 +425,8 @@ AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
   }
   const int K = noop_period(c);
   uint64_t skip0 = 0ull, skip1 = 0ull;
+  const bool two_dirs = c.nrows > nA + nc;
+  float lamC0 = 0.f, lamC1 = 0.f;
   for (int it = 0; it < iters; it++) {
     const bool retest = K > 0 && it % K == 0, use = K > 0 && !retest;
     const float b0 = A0.lam, b1 = A1.lam;
@@ -433,6 +435,20 @@ AGX_DEV void pgs(Ctx& c, float& dv0, float& dv1) {
     if (retest) { skip0 = wave_ballot(A0.lam == b0); skip1 = wave_ballot(A1.lam == b1); }
     pgs_sweep<true>(B0, A0.lam, E, lane, f0a, t0, f0b, dv0, dv1);
     pgs_sweep<true>(B1, A1.lam, E, lane, f1a, t1, f1b, dv0, dv1);
+    if (two_dirs) {
+      // AGX_P_FRICTION_DIRS = 2: the block of second directions, one row per contact again in the lane of its normal row.  Its row sets are
+      // re-read from the headers in every sweep (only the impulses stay in registers): the switch is for parity studies, the default path
+      // pays two registers for it
+      PgsSet C0, C1;
+      { const int c0 = lane - nnc, c1 = 64 + lane - nnc;
+        pgs_load_set(c, nA + nc + c0, c0 >= 0 && c0 < nc, true, C0);
+        pgs_load_set(c, nA + nc + c1, c1 >= 0 && c1 < nc, true, C1); }
+      C0.lam = lamC0; C1.lam = lamC1;
+      const int u0 = pgs_lds_split(C0, lane, f0a, f0b), u1 = pgs_lds_split(C1, lane, f1a, f1b);
+      pgs_sweep<true>(C0, A0.lam, E, lane, f0a, u0, f0b, dv0, dv1);
+      pgs_sweep<true>(C1, A1.lam, E, lane, f1a, u1, f1b, dv0, dv1);
+      lamC0 = C0.lam; lamC1 = C1.lam;
+    }
   }
   // solved normal impulses -> contact records (what getContactPoints reports until the next step)
   { const int r0 = lane, r1 = 64 + lane;

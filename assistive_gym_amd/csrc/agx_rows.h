@@ -137,13 +137,16 @@ AGX_DEV void build_rows(Ctx& c) {
   int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > SCR_ENT / 2) maxent = SCR_ENT / 2;
   if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }               // entry 0 of the arena is the zero pair
   int nnc = 0, ent = 1, bent = 0;                               // non-contact rows / coefficient pairs / block-row entries so far
-  // contact rows: lane = contact; normal rows first, then one friction row per contact
+  // contact rows: lane = contact; normal rows first, then one friction row per contact (AGX_P_FRICTION_DIRS = 2: a second block of
+  // friction rows along n x t behind the first)
+  const int fd = (!USE_SOLVE4 && (int)PRM(c, AGX_P_FRICTION_DIRS) == 2) ? 2 : 1;
+  v3 tdir = mk3(0, 0, 0);
   int nc = c.ncon, ccnt = 0, cincl = 0, tot = 0, entN = 0, entF = 0, bcnt = 0, bincl = 0, btot = 0, bentN = 0, bentF = 0;
   int ba = 0, bb = 0; v3 pa = mk3(0, 0, 0), pb = pa, nn = pa; float dist = 0.f, mu = 0.f;
   RowGeom rn; row_clear(rn);
   // the row kinds go through ONE row_store call site (its M^-1 J^T product is the bulk of this phase's code):
   // phases [0, NC_PASSES) non-contact slots, NC_PASSES contact normals, NC_PASSES + 1 contact friction
-  _Pragma("nounroll") for (int ph = 0; ph < NC_PASSES + 2; ph++) {
+  _Pragma("nounroll") for (int ph = 0; ph < NC_PASSES + 1 + fd; ph++) {
     RowGeom R; row_clear(R);
     int rrow = 0, roff = 0, rboff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
     if (ph < NC_PASSES) {
@@ -223,7 +226,7 @@ AGX_DEV void build_rows(Ctx& c) {
       bincl = wave_scan_excl(bcnt) + bcnt;
       // largest prefix of the contact list that fits the row and coefficient budgets; the contacts beyond it are
       // dropped and counted as overflow
-      const bool fits = has && (nnc + 2 * (lane + 1) <= maxrows) && (ent + 2 * cincl <= maxent) && (!USE_SOLVE4 || bent + 2 * bincl <= BR_MAX_UNITS - 2);
+      const bool fits = has && (nnc + (1 + fd) * (lane + 1) <= maxrows) && (ent + (1 + fd) * cincl <= maxent) && (!USE_SOLVE4 || bent + 2 * bincl <= BR_MAX_UNITS - 2);
       const int kept = popc64(wave_ballot(fits));
       c.overflow += nc - kept; nc = kept;
       tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0); btot = wave_bcast_i(bincl, nc > 0 ? nc - 1 : 0);
@@ -231,13 +234,18 @@ AGX_DEV void build_rows(Ctx& c) {
       R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rboff = bentN + bincl - bcnt; rlo = 0.f; rhi = 1e30f;
       if (go) { const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv); }
     } else {
-      go = lane < nc; rrow = nnc + nc + lane; roff = entF + cincl - ccnt; rboff = bentF + bincl - bcnt; rfric = nnc + lane; rmu = mu;
+      const int k2 = ph - NC_PASSES - 1;                            // 0: first friction direction, 1: the second (n x t)
+      go = lane < nc; rrow = nnc + (1 + k2) * nc + lane; roff = entF + k2 * tot + cincl - ccnt; rboff = bentF + bincl - bcnt; rfric = nnc + lane; rmu = mu;
       if (go) {
         // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
-        v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);
-        v3 t = vr - dot(vr, nn) * nn;
-        float l2 = dot(t, t);
-        if (l2 > PRM(c, AGX_P_FRIC_EPS)) t = (1.0f / sqrtf(l2)) * t; else plane_space(nn, t);
+        v3 t;
+        if (k2 == 0) {
+          v3 vr = point_velocity(c, ba, pa) - point_velocity(c, bb, pb);
+          t = vr - dot(vr, nn) * nn;
+          float l2 = dot(t, t);
+          if (l2 > PRM(c, AGX_P_FRIC_EPS)) t = (1.0f / sqrtf(l2)) * t; else plane_space(nn, t);
+          tdir = t;
+        } else t = cross(nn, tdir);
         row_pair(c, R, ba, pa, bb, pb, t, mk3(0, 0, 0));
         rb = -row_velocity(c, R);
       }
@@ -274,7 +282,7 @@ AGX_DEV void build_rows(Ctx& c) {
     }
     if (go) row_store(c, R, rrow, roff, rboff, rb, rlo, rhi, rfric, rmu, Bd);
   }
-  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + 2 * nc; c.nent = entF + (nc > 0 ? tot : 0); c.nbunits = bentF + (nc > 0 ? btot : 0);
+  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + (1 + fd) * nc; c.nent = entF + (nc > 0 ? fd * tot : 0); c.nbunits = bentF + (nc > 0 ? btot : 0);
   wave_sync();
 }
 

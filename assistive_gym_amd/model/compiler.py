@@ -35,7 +35,7 @@ H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT
          OFF_TARGETS=38, OFF_MLP=39, OFF_CLOTH=40, SIM_SUBSTEPS=41, BASE_LINK=42, COUNT=48)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
-         HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, NOOP_RETEST=20, ORACLE_RESIDUAL_EPS=21, ORACLE_FRICTION_DIRS=22, WARMSTART=23, NOOP_PEN=24, COUNT=25)
+         HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, NOOP_RETEST=20, ORACLE_RESIDUAL_EPS=21, FRICTION_DIRS=22, WARMSTART=23, NOOP_PEN=24, COUNT=25)
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, COM=11, MASS=14, INERTIA=15, LOWER=21, UPPER=22, HAS_LIMIT=23, KP=24, KD=25,
          MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, JTYPE=32, ACT_MULT=33, ACT_SRC=34, OBS_SKIP=35, STRIDE=36)
 F = dict(MASS=0, INERTIA=1, GRAVITY=4, REFPOS=5, REFQUAT=8, KIND=12, RADIUS=13, STRIDE=16)

@@ -101,10 +101,14 @@ enum {
   AGX_P_NOOP_RETEST,     /* K > 0: rows of the non-friction block whose visit in a re-test sweep (every K-th) was a no-op are skipped until
                             the next re-test sweep; 0 = every row in every sweep (agx_pgs.h, oracle pgs())                 */
   /* [BULLET-UNVERIFIED] switches (all off = the default conventions; tests/diag/bullet_unknowns_sensitivity.py measures what each would change).
-   * RESIDUAL_EPS and FRICTION_DIRS are evaluated by the CPU oracle only; WARMSTART by the oracle AND the device (round 4): */
+   * RESIDUAL_EPS is evaluated by the CPU oracle only; FRICTION_DIRS and WARMSTART by the oracle AND the device (round 4): */
   AGX_P_ORACLE_RESIDUAL_EPS = 21, /* > 0: the sweeps stop once max_rows (delta lambda x D)^2 <= eps (btSequentialImpulseConstraintSolver's
                                      m_leastSquaresResidualThreshold; PyBullet's default solverResidualThreshold is believed to be 1e-7)   */
-  AGX_P_ORACLE_FRICTION_DIRS = 22,/* 2: a second friction row per contact along n x t (SOLVER_USE_2_FRICTION_DIRECTIONS); 0 / 1: one        */
+  AGX_P_FRICTION_DIRS = 22,       /* 2: a second friction row per contact along n x t (SOLVER_USE_2_FRICTION_DIRECTIONS), each bounded by
+                                     mu x the normal impulse (the friction pyramid); 0 / 1: one.  Row order: ... normals, the first directions of all
+                                     contacts, the second directions of all contacts (Bullet interleaves the two per contact; with the blocked
+                                     order the device sweeps one register set after the other).  Costs a third row per contact in the row and
+                                     coefficient budgets (AGX_P_MAX_ROWS: 47 instead of 71 contacts next to FeedingJaco's 17 other rows)     */
   AGX_P_WARMSTART = 23,           /* > 0: contact normals start from this factor x the impulse the SAME contact -- (collider a, collider b,
                                      ordinal inside the pair) -- was solved to in the previous substep (SOLVER_USE_WARMSTARTING,
                                      m_warmstartingFactor 0.85).  Device: the solve kernel leaves (key, impulse) of its contacts in the

@@ -178,6 +178,7 @@ typedef struct {
   int ba, bb;          /* body codes */
   double pa[3], pb[3], n[3], dist, mu;
   double lambda_n;     /* solved normal impulse */
+  double t1[3];        /* first friction direction of the substep's row (build_rows) */
 } contact_t;
 
 typedef struct {
@@ -919,7 +920,7 @@ static void build_rows(sim_t* s) {
    * longest prefix that fits the row budget and the (J,B) coefficient budget: a row stores one
    * pair per DoF of each dynamic body it touches (all robot DoFs, 6 per free body). */
   int first_normal = s->nrows, nc = 0;
-  const int fdirs = (int)PARAM(m, AGX_P_ORACLE_FRICTION_DIRS) == 2 ? 2 : 1;   /* [BULLET-UNVERIFIED] switch, oracle only */
+  const int fdirs = (int)PARAM(m, AGX_P_FRICTION_DIRS) == 2 ? 2 : 1;   /* [BULLET-UNVERIFIED] switch, oracle and device */
   const double wsf = PARAM(m, AGX_P_WARMSTART);
   {
     int ent = 1, maxent = (int)PARAM(m, AGX_P_MAX_ENTRIES);
@@ -963,13 +964,15 @@ static void build_rows(sim_t* s) {
     body_jacobian(s, k->ba, k->pa, t, NULL, 1.0, r->J); body_jacobian(s, k->bb, k->pb, t, NULL, -1.0, r->J);
     finish_row(s, r);
     r->b = -row_vel(s, r); r->fric_of = first_normal + c; r->mu = k->mu; r->lo = 0; r->hi = 0;
-    if (fdirs == 2) {   /* the second direction of the friction pyramid */
-      double t2[3]; cross3(k->n, t, t2);
-      row_t* r2 = NEWROW();
-      body_jacobian(s, k->ba, k->pa, t2, NULL, 1.0, r2->J); body_jacobian(s, k->bb, k->pb, t2, NULL, -1.0, r2->J);
-      finish_row(s, r2);
-      r2->b = -row_vel(s, r2); r2->fric_of = first_normal + c; r2->mu = k->mu; r2->lo = 0; r2->hi = 0;
-    }
+    memcpy(k->t1, t, sizeof t);
+  }
+  if (fdirs == 2) for (int c = 0; c < nc; c++) {   /* the second direction of the friction pyramid: a block of its own behind the first directions */
+    contact_t* k = &s->con[c];
+    double t2[3]; cross3(k->n, k->t1, t2);
+    row_t* r2 = NEWROW();
+    body_jacobian(s, k->ba, k->pa, t2, NULL, 1.0, r2->J); body_jacobian(s, k->bb, k->pb, t2, NULL, -1.0, r2->J);
+    finish_row(s, r2);
+    r2->b = -row_vel(s, r2); r2->fric_of = first_normal + c; r2->mu = k->mu; r2->lo = 0; r2->hi = 0;
   }
   s->contact_overflow += s->ncon - nc;   /* dropped by the row / coefficient budgets */
   s->ncon = nc;
@@ -1367,7 +1370,7 @@ static void substep_h(sim_t* s, int hooks) {
   double dv[NVMAX];
   pgs(s, dv);
   {
-    const int fdirs = (int)PARAM(m, AGX_P_ORACLE_FRICTION_DIRS) == 2 ? 2 : 1;
+    const int fdirs = (int)PARAM(m, AGX_P_FRICTION_DIRS) == 2 ? 2 : 1;
     /* normal rows follow the non-contact rows in construction order */
     const int first_normal = s->nrows - (1 + fdirs) * s->ncon;
     for (int c = 0; c < s->ncon; c++) s->con[c].lambda_n = s->rows[first_normal + c].lambda;

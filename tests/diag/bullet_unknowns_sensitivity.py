@@ -19,8 +19,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from assistive_gym_amd.blob import ModelBlob       # noqa: E402
 from oracle_lib import Oracle                       # noqa: E402
 
-SWITCHES = {'residual early-out 1e-7': dict(ORACLE_RESIDUAL_EPS=1e-7), 'two friction directions': dict(ORACLE_FRICTION_DIRS=2),
-            'warm start 0.85': dict(WARMSTART=0.85), 'all three': dict(ORACLE_RESIDUAL_EPS=1e-7, ORACLE_FRICTION_DIRS=2, WARMSTART=0.85)}
+SWITCHES = {'residual early-out 1e-7': dict(ORACLE_RESIDUAL_EPS=1e-7), 'two friction directions': dict(FRICTION_DIRS=2),
+            'warm start 0.85': dict(WARMSTART=0.85), 'all three': dict(ORACLE_RESIDUAL_EPS=1e-7, FRICTION_DIRS=2, WARMSTART=0.85)}
 
 
 def variant(blob, **kw):

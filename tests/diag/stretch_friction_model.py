@@ -18,8 +18,8 @@ from assistive_gym_amd.blob import ModelBlob       # noqa: E402
 from assistive_gym_amd.host.reset import make_states   # noqa: E402
 from oracle_lib import Oracle                       # noqa: E402
 
-SWITCHES = {'device conventions': {}, 'two friction directions': dict(ORACLE_FRICTION_DIRS=2), 'warm start 0.85': dict(WARMSTART=0.85),
-            'residual early-out 1e-7': dict(ORACLE_RESIDUAL_EPS=1e-7), 'all three': dict(ORACLE_RESIDUAL_EPS=1e-7, ORACLE_FRICTION_DIRS=2, WARMSTART=0.85)}
+SWITCHES = {'device conventions': {}, 'two friction directions': dict(FRICTION_DIRS=2), 'warm start 0.85': dict(WARMSTART=0.85),
+            'residual early-out 1e-7': dict(ORACLE_RESIDUAL_EPS=1e-7), 'all three': dict(ORACLE_RESIDUAL_EPS=1e-7, FRICTION_DIRS=2, WARMSTART=0.85)}
 DRIVES = {'straight': (1.0, 1.0), 'spin': (1.0, -1.0), 'arc': (1.0, 0.5)}
 R_WHEEL, TRACK = 0.0508, 2 * 0.15765
 

@@ -448,3 +448,46 @@ def test_relative_travel_bound_leaves_the_contacts_unchanged(blob):
             r1 = new.step(s1, a); r2 = old.step(s2, a)
             assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32)), (i, k)
             assert np.array_equal(r1[0], r2[0]) and r1[1] == r2[1]
+
+
+@pytest.mark.parametrize('path', ['velocity_space', 'row_space'])
+def test_second_friction_direction_matches_the_oracle(blob, path):
+    """AGX_P_FRICTION_DIRS = 2 (a [BULLET-UNVERIFIED] convention: SOLVER_USE_2_FRICTION_DIRECTIONS; default off) on the kernel sources: a
+    second block of friction rows along n x t behind the first, each bounded by mu x the normal impulse.  The velocity-space sweep of
+    FeedingJaco re-reads the block's row sets per sweep, the row-space sweep of BedBathingSawyer just has more rows (an environment whose
+    rows no longer fit its 56-row work area falls back to the velocity-space sweep, as always).  Against the oracle's switch over four
+    steps; the switch must change the result."""
+    import os, sys
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    from assistive_gym_amd.blob import ModelBlob
+    if path == 'velocity_space':
+        b0 = blob
+        st, _ = make_states(b0, 1, seed=3001)
+        s = st[0].copy(); Oracle(b0).settle(s, 25)
+        scale = 1.0
+    else:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import wiping_pool
+        b0 = ModelBlob.load('bed_bathing_sawyer')
+        s = wiping_pool(b0, 2, 6006)[1].copy(); b0.view(s[None])['iteration'][0] = 0
+        scale = 0.15
+    b = b0.set_param('FRICTION_DIRS', 2.0)
+    o, e, one = Oracle(b), Emu(b), Oracle(b0)
+    so, se, sc = s.copy(), s.copy(), s.copy()
+    rng = np.random.RandomState(5)
+    differs, rows = 0.0, []
+    for k in range(4):
+        a = (rng.uniform(-1, 1, b.act_dim) * scale).astype(np.float32)
+        o_obs, o_rew, _, o_info = o.step(so, a)
+        obs, rew, _, info, _ = e.step(se, a)
+        c_obs, c_rew, _, c_info = one.step(sc, a)
+        assert info[7] == o_info[7] and info[6] == o_info[6], (path, k, info, o_info)            # rows and contacts of the last substep
+        rows.append((int(o_info[7]), int(o_info[6]), int(c_info[7]), int(c_info[6])))
+        assert np.abs(obs - o_obs).max() < 2e-5 and abs(rew - o_rew) < 2e-5 * max(1.0, abs(o_rew)) and abs(info[0] - o_info[0]) <= 1e-3 * max(1.0, abs(o_info[0])), (path, k)
+        assert np.abs(b.view(se[None])['q'][0] - b.view(so[None])['q'][0]).max() < 5e-6
+        differs = max(differs, float(np.abs(so - sc)[:b.h['S_ENV']].max()))
+        se[:] = so; sc[:] = so
+    # three rows per contact instead of two next to the same non-contact rows (FeedingJaco's 160-row budget then holds 47 contacts, not 53)
+    assert all(r2 - 3 * n2 == r1 - 2 * n1 for r2, n2, r1, n1 in rows[:1]) and any(n2 > 0 for _, n2, _, _ in rows), rows
+    assert differs > 1e-7, differs

@@ -568,3 +568,49 @@ def test_warm_start_switch_on_the_device(gpu_lib, workload):
         o_obs, o_rew, _, o_info = o.step(so, a[0])
         assert np.abs(obs[0] - o_obs).max() < 3e-4 * (k + 1), (workload, 'persistent', k)      # free running: deviations compound
     o.forget_warm(); one.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload', ['feeding', 'wiping'])
+def test_second_friction_direction_on_the_device(gpu_lib, workload):
+    """AGX_P_FRICTION_DIRS = 2 through the C ABI against the oracle's switch: 16 environments, three steps, every step from an injected state.
+    FeedingJaco takes the velocity-space sweep (the second block's row sets re-read per sweep, 47 contacts in the 160-row budget), the
+    wiping workload of BedBathingSawyer the row-space sweep (or the velocity-space one where an environment's rows exceed its work area)."""
+    import sys, os
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.libagx import Stepper
+    from assistive_gym_amd.vec_env import build_reset_pool
+    from oracle_lib import Oracle
+    import conditioning as C
+    n = 16
+    if workload == 'feeding':
+        b0 = ModelBlob.load('feeding_jaco'); states = build_reset_pool(b0, n, seed=7107); scale = 1.0
+    else:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import wiping_pool
+        b0 = ModelBlob.load('bed_bathing_sawyer'); states = wiping_pool(b0, n, 7107); b0.view(states)['iteration'][:] = 0; scale = 0.15
+    b = b0.set_param('FRICTION_DIRS', 2.0)
+    o, one = Oracle(b), Oracle(b0)
+    st = Stepper(b, n)
+    rng = np.random.RandomState(4)
+    ref = states.copy()
+    differs, three = 0.0, 0
+    fcol = b.obs_dim_robot - 1
+    for k in range(3):
+        st.set_state(ref)
+        act = (rng.uniform(-1, 1, (n, b.act_dim)) * scale).astype(np.float32)
+        obs, rew, done, info = st.step_host(act)
+        got = st.get_state()
+        for i in range(n):
+            sc = ref[i].copy()
+            o_obs, o_rew, _, o_info = o.step(ref[i], act[i])
+            c_info = one.step(sc, act[i])[3]
+            differs = max(differs, float(np.abs(ref[i] - sc)[:b.h['S_ENV']].max()))
+            assert info[i, 6] == o_info[6] and info[i, 7] == o_info[7], (workload, k, i, info[i], o_info)
+            three += int(o_info[6] > 0 and o_info[7] - 3 * o_info[6] == c_info[7] - 2 * c_info[6])
+            assert np.abs(np.delete(obs[i] - o_obs, fcol)).max() < 1e-4 and abs(rew[i] - o_rew) < 1e-4 * max(1.0, abs(o_rew)) + 0.06 * C.force_floor(b), (workload, k, i)
+            assert abs(obs[i, fcol] - o_obs[fcol]) <= max(1e-3 * max(1.0, abs(o_obs[fcol])), C.force_floor(b)), (workload, k, i)
+            assert abs(info[i, 0] - o_info[0]) <= max(1e-3 * max(1.0, abs(o_info[0])), C.force_floor(b)), (workload, k, i, info[i, 0], o_info[0])
+            assert np.abs(b.view(got[i:i + 1])['q'][0] - b.view(ref[i:i + 1])['q'][0]).max() < 1e-4
+    assert three > 0 and differs > 1e-7, (three, differs)
+    st.close()
