@@ -35,8 +35,9 @@ class ModelBlob:
     def has_reset_generator(self):
         """the blob carries a reset section the device-side reset generator (csrc/agx_reset.h, agx_sample_reset / agx_reset) can sample from:
         every feeding, scratch-itch, dressing and bed-bathing scene (wheelchair-mounted arm: IK restarts; free-standing robot: base pose
-        search; robot on wheels: placement draws; bed bathing: with the rag-doll model attached, agx_attach_settle_model) and the rag-doll
-        model itself (its drop record); not the arm-manipulation scenes (two settles: host sampler around the device settles)"""
+        search; robot on wheels: placement draws; bed bathing: with the rag-doll model attached, agx_attach_settle_model), the rag-doll
+        model itself (its drop record) and the single-arm arm-manipulation scenes (with their fall model -- fall_model() -- and the
+        rag-doll model behind it); not the two-armed arm-manipulation scenes (host sampler around the device settles)"""
         from .model import compiler as L
         x0 = int(self.i[L.H['OFF_RESET']])
         words = int(self.i[L.H['OFF_TARGETS']]) - x0 if 'OFF_TARGETS' in L.H else 0
@@ -49,6 +50,26 @@ class ModelBlob:
         """Returns a copy of the blob with one PARAMS entry changed (tests, ablations)."""
         w = self.words.copy()
         w.view(np.float32)[self.h['OFF_PARAMS'] + L.P[key]] = value
+        return ModelBlob(w, self.meta)
+
+    def fall_model(self):
+        """The model the arm of ArmManipulationEnv.reset falls in (arm_manipulation.py:139-146): this blob at the reset's gravity of -1 on the
+        human, its sampler switched to the record the arm falls from (AGX_X_FLAGS bit 8).  A second handle on it is attached to the task's
+        handle, the rag-doll handle to that one (agx_attach_settle_model twice)."""
+        assert self.task_kind == L.TASK_ARM_MANIPULATION and self.has_reset_generator
+        w = self.words.copy()
+        w.view(np.float32)[self.h['OFF_PARAMS'] + L.P['HUMAN_GRAVITY_Z']] = -1.0
+        w.view(np.int32)[int(self.i[L.H['OFF_RESET']]) + L.X_['FLAGS']] |= 256
+        return ModelBlob(w, self.meta)
+
+    def with_drop_base(self, pos):
+        """The rag-doll model (bed_settle) dropping the human from another spot: ArmManipulationEnv.reset drops it from [-0.25, 0.2, 0.95]
+        (arm_manipulation.py:123), BedBathingEnv.reset from [-0.15, 0.2, 0.95] (bed_bathing.py:121, the compiled value)."""
+        x0 = int(self.i[L.H['OFF_RESET']])
+        assert int(self.i[x0 + L.X_['FLAGS']]) & 32
+        w = self.words.copy()
+        for key in ('HBASE_M', 'HBASE_F'):
+            w.view(np.float32)[x0 + L.X_[key]:x0 + L.X_[key] + 3] = pos
         return ModelBlob(w, self.meta)
 
     def coop(self):

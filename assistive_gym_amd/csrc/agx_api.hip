@@ -196,14 +196,15 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
     const bool ragdoll = (X[AGX_X_FLAGS] & 32) != 0;  // the rag-doll model of bed bathing: its sampler writes the drop record, there is no robot
     const bool mobile = (X[AGX_X_FLAGS] & 8) != 0 || ragdoll;    // a robot on wheels: no arm chain to solve (its NARM only says that the blob has a reset section)
     if (X[AGX_X_NARM] != V->rs_narm || (!ragdoll && hi[AGX_H_NROBOT] < V->rs_narm) || hi[AGX_H_NHUMAN] >= 64 || hi[AGX_H_NDOF] > 64 || X[AGX_X_TOC_ATTEMPTS] > 64 ||
-        X[AGX_X_TOC_NGOALS] > 3 || X[AGX_X_PED_N] > 2) can_sample = false;
+        X[AGX_X_TOC_NGOALS] > 4 || X[AGX_X_PED_N] > 2) can_sample = false;
     if (ragdoll && hi[AGX_H_NDOF] != 6 + X[AGX_X_NJOINT] - 1) can_sample = false;    // virtual joints + every joint of the tree but the fixed waist
     if (mobile && !ragdoll && (X[AGX_X_MOBILE_LIFT_DOF] < 0 || X[AGX_X_MOBILE_LIFT_DOF] >= hi[AGX_H_NROBOT] || X[AGX_X_TOC_ATTEMPTS] != 0 || X[AGX_X_IK_RESTARTS] != 0)) can_sample = false;
     for (int k = 0; can_sample && !mobile && k < V->rs_narm; k++) {
       const int d = X[AGX_X_CHAIN + k];
       if (d < 0 || d >= hi[AGX_H_NROBOT]) { can_sample = false; break; }
       const int32_t* R = hi + hi[AGX_H_OFF_ROBOT] + d * AGX_R_STRIDE;
-      if (R[AGX_R_PARENT] != (k ? X[AGX_X_CHAIN + k - 1] : -1) || R[AGX_R_ACT] != k) can_sample = false;
+      const int dup = hi[AGX_H_TASK_KIND] == AGX_TASK_ARM_MANIPULATION ? T[AGX_T_DUP_ACT] : 0;     // robot_arm = 'both' lists a single arm twice: the second copy's actions drive it (robot.py:16)
+      if (R[AGX_R_PARENT] != (k ? X[AGX_X_CHAIN + k - 1] : -1) || R[AGX_R_ACT] != k + dup) can_sample = false;
       if (k == V->rs_narm - 1 && T[AGX_T_EE_LINK] != d) can_sample = false;
     }
   }
@@ -435,23 +436,40 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
   HIPCHK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
   forget_warm(h, mask_dev, st);          // the sampled environments start without a warm-start memory
-  const float* settled = nullptr; int settled_sw = 0;
+  const float* settled = nullptr; int settled_sw = 0; const float* fell = nullptr;
   if (h->reset_flags & 16) {
     // bed bathing (bed_bathing.py:119-137): the human is a rag doll dropped onto the bed -- the attached model samples its drop record from the
-    // same seeds, settles for 100 simulation steps, and its state records tell this model's sampler where the human lies
+    // same seeds, settles for 100 simulation steps, and its state records tell this model's sampler where the human lies.
+    // Arm manipulation (arm_manipulation.py:117-146; FLAGS bit 7): the attached model is the FALL model -- this blob at gravity -1, its
+    // sampler writing the record the posed arm falls from -- and the rag-doll model is attached to that one: rag doll, then the fall, then here.
     agx_handle_s* hs = h->settle;
     if (!hs) return fail(AGX_E_ARG, "reset: this model's human comes out of a rag-doll settle; attach that model first (agx_attach_settle_model)");
-    hs->V->sample(st, hs->n_envs, hs->blob_dev, hs->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
-                  gender_mode, nullptr, hs->episode_dev, hs->sw, nullptr, hs->chosen_dev, nullptr, 0);
+    const bool two = (h->reset_flags & 128) && !(h->reset_flags & 256);
+    if (two && !(hs->reset_flags & 256)) return fail(AGX_E_ARG, "reset: this model's reset lets the arm fall in a second handle (ModelBlob.fall_model()); attach that one, and the rag-doll model to it");
+    agx_handle_s* hr = two ? hs->settle : hs;
+    if (!hr) return fail(AGX_E_ARG, "reset: the fall model has no rag-doll model attached (agx_attach_settle_model)");
+    hr->V->sample(st, hr->n_envs, hr->blob_dev, hr->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
+                  gender_mode, nullptr, hr->episode_dev, hr->sw, nullptr, hr->chosen_dev, nullptr, 0, nullptr);
     HIPCHK(hipGetLastError());
-    hs->active = mask_dev;
-    const int rc = launch_chunked(hs, h->settle_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
-    hs->active = nullptr;
+    hr->active = mask_dev;
+    int rc = launch_chunked(hr, two ? hs->settle_substeps : h->settle_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
+    hr->active = nullptr;
     if (rc) return rc;
-    settled = hs->state_dev; settled_sw = hs->sw;
+    settled = hr->state_dev; settled_sw = hr->sw;
+    if (two) {
+      forget_warm(hs, mask_dev, st);
+      hs->V->sample(st, hs->n_envs, hs->blob_dev, hs->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
+                    gender_mode, nullptr, hs->episode_dev, hs->sw, nullptr, hs->chosen_dev, settled, settled_sw, nullptr);
+      HIPCHK(hipGetLastError());
+      hs->active = mask_dev;
+      rc = launch_chunked(hs, h->settle_substeps, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, stream);
+      hs->active = nullptr;
+      if (rc) return rc;
+      fell = hs->state_dev;
+    }
   }
   h->V->sample(st, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, mask_dev, impairment_mode,
-               gender_mode, ik_info_dev, h->episode_dev, h->sw, nullptr, h->chosen_dev, settled, settled_sw);
+               gender_mode, ik_info_dev, h->episode_dev, h->sw, nullptr, h->chosen_dev, settled, settled_sw, fell);
   HIPCHK(hipGetLastError());
   // collision rejection (robot.py:105-112, env.py:299-308): the contacts of the sampled state come from the stepper's own build kernel;
   // a state whose arm / tool touches the human, the table or the wheelchair is re-sampled from the next IK restart.  Fixed schedule
@@ -463,7 +481,7 @@ static int launch_sample(agx_handle h, uint64_t seed, const uint64_t* seeds_dev,
     h->V->verdict(st, h->n_envs, h->blob_dev, h->scratch_dev, active, h->work_dev, h->first_restart_dev, h->chosen_dev);
     HIPCHK(hipGetLastError());
     h->V->sample(st, h->n_envs, h->blob_dev, h->state_dev, (unsigned long long)seed, (const unsigned long long*)seeds_dev, h->work_dev, impairment_mode,
-                 gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev, settled, settled_sw);
+                 gender_mode, ik_info_dev, h->episode_dev, h->sw, h->first_restart_dev, h->chosen_dev, settled, settled_sw, fell);
     HIPCHK(hipGetLastError());
   }
   if (h->cloth_dev && h->particles) {       // the water goes into the sampled cup
@@ -480,7 +498,9 @@ int agx_attach_settle_model(agx_handle h, agx_handle settle, int n_substeps) {
   if (!h || n_substeps < 0) return fail(AGX_E_ARG, "agx_attach_settle_model: bad argument");
   if (!settle) { h->settle = nullptr; return AGX_OK; }
   if (!(h->reset_flags & 16)) return fail(AGX_E_ARG, "agx_attach_settle_model: this model's reset does not read a settle record");
-  if (!(settle->reset_flags & 32) || !settle->can_sample) return fail(AGX_E_ARG, "agx_attach_settle_model: the second handle is not a rag-doll model with a drop sampler");
+  const bool wants_fall = (h->reset_flags & 128) && !(h->reset_flags & 256);      // arm manipulation: the fall model goes here, the rag doll behind it
+  if (wants_fall ? !(settle->reset_flags & 256) : !(settle->reset_flags & 32)) return fail(AGX_E_ARG, wants_fall ? "agx_attach_settle_model: this model takes its fall model (the same blob with AGX_X_FLAGS bit 8)" : "agx_attach_settle_model: the second handle is not a rag-doll model with a drop sampler");
+  if (!settle->can_sample) return fail(AGX_E_ARG, "agx_attach_settle_model: the second handle has no sampler");
   if (settle->n_envs != h->n_envs || settle->device != h->device) return fail(AGX_E_ARG, "agx_attach_settle_model: both handles must hold the same number of environments on the same device");
   h->settle = settle; h->settle_substeps = n_substeps;
   return AGX_OK;

@@ -18,7 +18,7 @@ namespace agx {
 #ifndef AGX_TASK           // AGX_TASK_* of include/agx_blob.h: the task layer compiled into the finish / observe kernels
 #define AGX_TASK 0
 #endif
-#define AGX_HAS_SAMPLER (AGX_TASK == 0 || AGX_TASK == 1 || AGX_TASK == 2 || AGX_TASK == 3 || AGX_TASK == 5)   // the device-side reset generator (agx_reset.h): feeding, bed-bathing (incl. its rag-doll model), scratch-itch, dressing and drinking scenes
+#define AGX_HAS_SAMPLER 1   // the device-side reset generator (agx_reset.h): every task (arm manipulation: the single-arm robots)
 constexpr int MAX_DOF = AGX_MAX_DOF;
 constexpr int MAX_FREE = AGX_MAX_FREE;
 constexpr int MAX_BLOCK = AGX_MAX_BLOCK;

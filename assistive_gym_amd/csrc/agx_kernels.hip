@@ -244,14 +244,14 @@ AGX_K(agx_collision_flags_kernel)(const uint32_t* __restrict__ blob, const float
 extern "C" __global__ void __launch_bounds__(64)
 AGX_K(agx_sample_kernel)(const uint32_t* __restrict__ blob, float* state, unsigned long long seed0, const unsigned long long* __restrict__ seeds, const uint8_t* __restrict__ mask,
                          int impairment_mode, int gender_mode, float* info4, int* episode, int n_envs, int sw, const int* __restrict__ first_restart, int* chosen,
-                         const float* __restrict__ settled, int settled_sw) {
+                         const float* __restrict__ settled, int settled_sw, const float* __restrict__ fell) {
   const int env = blockIdx.x;
   if (env >= n_envs || (mask && !mask[env])) return;
   const unsigned long long seed = seeds ? seeds[env] : seed0 + (unsigned long long)env;
   if (threadIdx.x == 0) episode[env] = 0;
   const int r = agx::env_sample(blob, state + (size_t)env * sw, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode,
                                 info4 ? info4 + (size_t)env * 4 : nullptr, (int)threadIdx.x, first_restart ? first_restart[env] : 0,
-                                settled ? settled + (size_t)env * settled_sw : nullptr);
+                                settled ? settled + (size_t)env * settled_sw : nullptr, fell ? fell + (size_t)env * sw : nullptr);
   if (chosen && threadIdx.x == 0) chosen[env] = r;
 }
 // after a build-kernel pass over the freshly sampled states: which of them start in collision (and have a restart left to try)?
@@ -313,9 +313,9 @@ void v_observe(hipStream_t st, int n_envs, const uint32_t* blob, float* state, f
 }
 #if AGX_HAS_SAMPLER
 void v_sample(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
-              int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen, const float* settled, int settled_sw) {
+              int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen, const float* settled, int settled_sw, const float* fell) {
   hipLaunchKernelGGL(AGX_K(agx_sample_kernel), dim3(n_envs), dim3(64), 0, st, blob, state, seed0, seeds, mask, impairment_mode, gender_mode, info4, episode, n_envs, sw,
-                     first_restart, chosen, settled, settled_sw);
+                     first_restart, chosen, settled, settled_sw, fell);
 }
 void v_verdict(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, const uint8_t* active, uint8_t* work, int* first_restart, const int* chosen) {
   hipLaunchKernelGGL(AGX_K(agx_reset_verdict_kernel), dim3(n_envs), dim3(64), 0, st, blob, scratch, active, work, first_restart, chosen, n_envs);

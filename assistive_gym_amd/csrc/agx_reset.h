@@ -95,6 +95,10 @@ struct ResetCtx {
   d3 base_p; dq base_q;               // robot base: the blob's fixed pose, or this lane's candidate of the base pose search
   int chain[7];                       // DoF of the arm's k-th joint (AGX_X_CHAIN)
   const float* settled;               // AGX_X_FLAGS bit 4: the joint angles (q) of the rag-doll record the human's pose is read from; else null
+  const float* fell;                  // AGX_X_FLAGS bit 7: the fall model's record after the arm's fall (same layout as this blob's records); else null
+  bool fall_stage;                    // AGX_X_FLAGS bit 8: this blob is the fall model
+  int fell_q;                         // offset of the human DoFs' joint angles inside `fell`
+  int nhdof;
 };
 constexpr int RS_RAGDOLL = 64;        // stream 0 slots RS_RAGDOLL + k: the jitter of the rag doll's k-th joint (bed_bathing.py:126)
 constexpr int RS_SETTLE_VIRTUAL = 6;  // the rag-doll model's virtual root joints come first (x, y, z, yaw, pitch, roll), then its joints in PyBullet
@@ -107,11 +111,17 @@ AGX_DEV double rs_joint_angle(const ResetCtx& c, int j) {
   const int base = XI(c, AGX_X_OFF_JOINTS) + (c.gender * c.nj + j) * AGX_XJ_STRIDE;
   const int flags = c.xi[base + AGX_XJ_FLAGS];
   if (!(flags & 1)) return 0.0;
-  if (c.settled) return (double)c.settled[RS_SETTLE_VIRTUAL + j - (j > RS_SETTLE_FIXED ? 1 : 0)];      // where the rag doll came to rest (bed_bathing.py:129-137)
+  if (c.fell)                                                              // a joint of the arm that fell: where it came to rest (arm_manipulation.py:145-151)
+    for (int k = 0; k < c.nhdof; k++) if (c.xi[XI(c, AGX_X_OFF_DYN) + k] == j) return (double)c.fell[c.fell_q + k];
+  const double s = (flags & 2) ? c.ls : 1.0;
+  if (c.settled && !(c.fall_stage && (flags & 4))) {                       // where the rag doll came to rest (bed_bathing.py:129-137)
+    const double a = (double)c.settled[RS_SETTLE_VIRTUAL + j - (j > RS_SETTLE_FIXED ? 1 : 0)];
+    // the fall model: setup_joints -> enforce_joint_limits clamps every joint once more (arm_manipulation.py:139-140, human.py:121)
+    return c.fall_stage ? fmin(fmax(a, (double)c.xf[base + AGX_XJ_LOWER] * s), (double)c.xf[base + AGX_XJ_UPPER] * s) : a;
+  }
   double a = (double)c.xf[base + AGX_XJ_PRESET];
   const int k = c.xi[base + AGX_XJ_DRAW];
   if (k >= 0) a += (k == 0 ? c.head[0] : (k == 1 ? c.head[1] : c.head[2]));
-  const double s = (flags & 2) ? c.ls : 1.0;
   return fmin(fmax(a, (double)c.xf[base + AGX_XJ_LOWER] * s), (double)c.xf[base + AGX_XJ_UPPER] * s);
 }
 // world pose of a human link frame (-1 = base): from the link up to the base, then the base transform
@@ -299,7 +309,8 @@ AGX_DEV double rs_jlwki(const ResetCtx& c, const double* q) {
 // Returns the index of the accepted restart, -1 if no restart met the thresholds (the closest attempt is used, robot.py:114-117).
 // settled (may be null): the state record of this environment in the rag-doll model after its settle (AGX_X_FLAGS bit 4 of this blob)
 AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gstate, uint32_t seed_lo, uint32_t seed_hi,
-                       int impairment_mode, int gender_mode, float* __restrict__ ginfo, int lane, int first_restart = 0, const float* __restrict__ settled = nullptr) {
+                       int impairment_mode, int gender_mode, float* __restrict__ ginfo, int lane, int first_restart = 0, const float* __restrict__ settled = nullptr,
+                       const float* __restrict__ fell = nullptr) {
   ResetCtx c;
   c.bf = (const float*)blob; c.bi = (const int*)blob;
   c.xf = c.bf + c.bi[AGX_H_OFF_RESET]; c.xi = c.bi + c.bi[AGX_H_OFF_RESET];
@@ -327,6 +338,10 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   const double strength = imp != RS_IMP_WEAKNESS ? 1.0 : XF(c, AGX_X_STRENGTH_LO) + (1.0 - XF(c, AGX_X_STRENGTH_LO)) * rs_u01(seed_lo, seed_hi, 0, RS_STRENGTH);   // human.py:86
   const int xflags = XI(c, AGX_X_FLAGS);
   c.settled = (xflags & 16) ? settled : nullptr;      // (agx_sample_reset refuses to run such a blob without its rag-doll model attached)
+  c.fall_stage = (xflags & 256) != 0;
+  c.fell = ((xflags & 128) && !c.fall_stage) ? fell : nullptr;
+  c.fell_q = sQ + nrobot; c.nhdof = nhdof;
+  const int sQD = c.bi[AGX_H_S_QD];
 
   for (int w = lane; w < state_words; w += AGX_WAVE) gstate[w] = 0.f;
   wave_sync();
@@ -363,7 +378,9 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
                                    : c.xi[XI(c, AGX_X_OFF_DYN) + head_link - nrobot];
     d3 p; dq q;
     rs_link_pose(c, link, p, q);
-    if (lane < nhuman) {
+    if (lane < nhuman && c.fell) {                      // the bodies did not move while the arm fell: the fall model's record has them
+      for (int k = 0; k < 7; k++) gstate[sHUMAN + 7 * lane + k] = c.fell[sHUMAN + 7 * lane + k];
+    } else if (lane < nhuman) {
       float* o = gstate + sHUMAN + 7 * lane;
       o[0] = (float)p.x; o[1] = (float)p.y; o[2] = (float)p.z; o[3] = (float)q.x; o[4] = (float)q.y; o[5] = (float)q.z; o[6] = (float)q.w;
     } else {                                                                                                 // feeding.py:184-196
@@ -388,7 +405,18 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   const int toc_attempts = XI(c, AGX_X_TOC_ATTEMPTS);
   const bool mobile = (xflags & 8) != 0;
   double lift_q = 0.0;
-  if (mobile) {
+  if (c.fall_stage) {
+    // ---- the fall model: the robot is not placed yet (arm_manipulation.py:162 comes after the fall) -- parked out of reach, its arm at the
+    // middle of its joint ranges (host/reset_arm.py arm_fall_record)
+    c.base_p = dld3(c.xf + AGX_X_FALL_PARK); c.base_q = dq_ident();
+#pragma unroll
+    for (int d = 0; d < RS_NARM; d++) {
+      const double lower = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_UPPER];
+      best_q[d] = (lower > -1e9 && upper < 1e9) ? 0.5 * (lower + upper) : 0.0;
+    }
+    ok = 1; restarts = 0; best_d = 0.0;
+  }
+  else if (mobile) {
     // ---- a robot on wheels (env.py:282-293): three draws for the base, one for the lift (stretch.py:58-62); placement `first_restart` has its
     // own stream, as the placements of the base pose search have
     const uint32_t stream = (uint32_t)RS_T_STREAM0 + (uint32_t)first_restart;
@@ -405,9 +433,9 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     // `first_restart` counts the placements that collided so far (env.py:281-308 re-draws the placement): every placement has its own streams.
     const int rounds = XI(c, AGX_X_TOC_ROUNDS), titers = XI(c, AGX_X_TOC_IK_ITERS);
     const double tthr = XF(c, AGX_X_TOC_THRESH), prange = XF(c, AGX_X_TOC_POS_RANGE), yrange = XF(c, AGX_X_TOC_YAW_RANGE);
-    d3 goals[3]; const bool goal_orient = XI(c, AGX_X_TOC_GOAL_ORIENT) != 0;
+    d3 goals[4]; const bool goal_orient = XI(c, AGX_X_TOC_GOAL_ORIENT) != 0;
     const int ngoals = XI(c, AGX_X_TOC_NGOALS);
-    for (int k = 0; k < 3; k++) goals[k] = dmk(0, 0, 0);
+    for (int k = 0; k < 4; k++) goals[k] = dmk(0, 0, 0);
     const int goal_kind = XI(c, AGX_X_TOC_GOAL_KIND);
     if (goal_kind == 1 || goal_kind == 2) {      // feeding: the mouth (feeding.py:142, 184-196)
       d3 hp; dq hq; rs_link_pose(c, c.xi[XI(c, AGX_X_OFF_DYN) + head_link - nrobot], hp, hq);
@@ -416,7 +444,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
       // (robot.py:196-200) -- and the mouth with the start pose's end-effector orientation as the one further goal
       goals[1] = goals[0];
     } else
-      for (int k = 0; k < ngoals; k++) { dq gq; rs_link_pose(c, XI(c, AGX_X_TOC_GOAL_LINKS + k), goals[k], gq); goals[k] = goals[k] + dld3(c.xf + AGX_X_TOC_GOAL_OFF); }
+      for (int k = 0; k < ngoals; k++) { dq gq; rs_link_pose(c, k < 3 ? XI(c, AGX_X_TOC_GOAL_LINKS + k) : XI(c, AGX_X_TOC_GOAL_LINK3), goals[k], gq); goals[k] = goals[k] + dld3(c.xf + AGX_X_TOC_GOAL_OFF); }
     const int nped = XI(c, AGX_X_PED_N);
     const d3 base0 = dld3(c.xf + AGX_X_BASE_POS);
     restarts = 0;
@@ -443,7 +471,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
           for (int d = 0; d < RS_NARM; d++) q[d] = lo[d] + (hi[d] - lo[d]) * rs_u01(seed_lo, seed_hi, stream, RS_T_REST + 8 * g + d);     // agent.py:263
           const d3 tp = g == 0 ? tpos : goals[g - 1];
           const bool orient = g == 0 || goal_orient || (goal_kind == 2 && g == 2);
-          const dq tq = (g == 0 || goal_kind == 2) ? tquat : dld4(c.xf + AGX_X_TOC_GOAL_QUAT + 4 * (g - 1));
+          const dq tq = (g == 0 || goal_kind == 2 || !goal_orient) ? tquat : dld4(c.xf + AGX_X_TOC_GOAL_QUAT + 4 * (g - 1));       // (position-only goals do not read it)
           if (orient) rs_ik<true>(c, q, lo, hi, tp, tq, titers); else rs_ik<false>(c, q, lo, hi, tp, tq, titers);
           d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
           rs_arm_fk(c, q, pos, axw, pe, oe);
@@ -572,6 +600,10 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     }
     gstate[sQ + lane] = (float)qv;
     gstate[sQT + lane] = (float)qv;
+    if (c.fell && lane >= nrobot) {     // the arm keeps the velocity it fell with, its hold the pose it was given before the fall (host/reset_arm.py post_fall)
+      gstate[sQD + lane] = c.fell[sQD + lane]; gstate[sQT + lane] = c.fell[sQT + lane];
+      gstate[sTREMOR + nhdof + lane - nrobot] = c.fell[sTREMOR + nhdof + lane - nrobot];
+    }
   }
   if (lane < nfree) {
     float* o = gstate + sFREE + 13 * lane;
@@ -616,7 +648,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     ei[AGX_E_ITERATION] = 0; ei[AGX_E_TASK_SUCCESS] = 0;
     ei[AGX_E_RNG] = (int)((seed * 2654435761ull + 12345ull) & 0x7FFFFFFFull);
     ei[AGX_E_RNG + 1] = (int)((seed ^ 0x5bd1e995ull) & 0x7FFFFFFFull);
-    ei[AGX_E_TOTAL_FOOD] = (xflags & 6) ? 1 : nfood;               // scratch itch, dressing: task_success >= 1 x task_success_threshold (scratch_itch.py:37)
+    ei[AGX_E_TOTAL_FOOD] = (xflags & (6 | 128)) ? 1 : nfood;       // scratch itch, dressing, arm manipulation: task_success >= 1 x task_success_threshold (scratch_itch.py:37)
     if (c.bi[AGX_H_TASK_KIND] == AGX_TASK_DRINKING) {               // self.waters / self.waters_active: every particle (drinking.py:168-172)
       const int nw = c.bi[c.bi[AGX_H_OFF_CLOTH] + AGX_CL_NN];
       ei[AGX_E_TOTAL_FOOD] = nw;                                    // total_water_count

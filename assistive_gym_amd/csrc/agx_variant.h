@@ -24,7 +24,7 @@ struct agx_variant {
   void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim, const uint8_t* mask);   // mask: null = every environment
   void (*sample)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, unsigned long long seed0, const unsigned long long* seeds, const uint8_t* mask,
                  int impairment_mode, int gender_mode, float* info4, int* episode, int sw, const int* first_restart, int* chosen,
-                 const float* settled, int settled_sw);   // null without a reset generator; settled: [n_envs][settled_sw] records of the attached rag-doll model (or null)
+                 const float* settled, int settled_sw, const float* fell);   // null without a reset generator; settled: [n_envs][settled_sw] records of the attached rag-doll model (or null); fell: [n_envs][sw] records of the attached fall model (arm manipulation, or null)
   // the garment (agx_cloth.h): nsub substeps replaying the trace; null in variants without a cloth
   void (*cloth)(hipStream_t st, int ne, const uint32_t* blob, const float* state, const float* trace, float* cloth, float* report, int e0, int n_envs, int sw,
                 int trace_words, int cloth_words, int report_words, int nsub, const uint8_t* active, int lds_bytes);

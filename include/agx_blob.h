@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 11
+#define AGX_BLOB_VERSION 12
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -321,7 +321,16 @@ enum {
                              *         record to this sampler (agx_attach_settle_model);
                              * bit 5 = THIS blob is that rag-doll model: its sampler writes the drop record -- base at HBASE_M / HBASE_F with the virtual
                              *         joint angles (yaw, pitch, roll) EE_TARGET, every joint U(-EE_RANGE, EE_RANGE) clamped to its limits;
-                             * bit 6 = bed bathing: all wiping targets alive, TOTAL_FOOD = their number (bed_bathing.py:173-188)                         */
+                             * bit 6 = bed bathing: all wiping targets alive, TOTAL_FOOD = their number (bed_bathing.py:173-188);
+                             * bit 7 = arm manipulation (arm_manipulation.py:110-180; with bit 4): between the rag doll's settle and the base pose search the
+                             *         human's right arm is posed (the joints with AGX_XJ_FLAGS bit 2 at their PRESET) and FALLS for 100 simulation steps
+                             *         at gravity -1 while everything else of the human is static (:139-146) -- in a THIRD handle on the same model
+                             *         ("fall model": this blob with HUMAN_GRAVITY_Z = -1 and bit 8 set, ModelBlob.fall_model()), attached to this one;
+                             *         the rag-doll model is attached to the fall model.  This sampler reads the human's bodies, the arm's joint angles
+                             *         and velocities from the fall model's settled record and the four goals of the base pose search (wrist, waist,
+                             *         elbow, stomach: TOC_GOAL_LINKS[0..2], TOC_GOAL_LINK3) from the tree with those angles;
+                             * bit 8 = THIS blob is the fall model: its sampler writes the record the arm falls from -- the human where the rag doll lies
+                             *         with the preset arm, the robot parked at FALL_PARK with its arm at the middle of its joint ranges               */
   /* base pose search of a free-standing robot (Robot.position_robot_toc, robot.py:123-215); TOC_ATTEMPTS = 0: the base is fixed (BASE_POS / BASE_QUAT) */
   AGX_X_TOC_ATTEMPTS = 52,  /* int: candidate base poses per round (<= 64: one per lane)                                                   */
   AGX_X_TOC_ROUNDS = 53,    /* int: rounds of new candidates while no candidate reaches the start pose                                   */
@@ -345,14 +354,17 @@ enum {
   AGX_X_MOBILE_LIFT = 94,   /* float: centre of the lift joint's start height (FLAGS bit 3)                                                 */
   AGX_X_MOBILE_LIFT_DOF = 95, /* int: its DoF                                                                                              */
   AGX_X_PED_BOX = 96,       /* float[PED_N][6]: min corner, max corner                                                                     */
-  AGX_X_COUNT = 108
+  AGX_X_TOC_GOAL_LINK3 = 108, /* int: a fourth goal link (arm manipulation: wrist, waist, elbow, stomach, arm_manipulation.py:162)                 */
+  AGX_X_FALL_PARK = 109,    /* float[3]: where the robot stands while the arm falls (FLAGS bit 8; it is placed afterwards, :162)                    */
+  AGX_X_COUNT = 112
 };
 enum {
   AGX_XJ_PARENT = 0,     /* int: parent joint (PyBullet link numbering), -1 = base              */
   AGX_XJ_OFF = 1,        /* float[3] joint frame in the parent link frame                       */
   AGX_XJ_AXIS = 4,       /* float[3]                                                            */
   AGX_XJ_LOWER = 7, AGX_XJ_UPPER = 8,  /* limits at limit_scale 1                                */
-  AGX_XJ_FLAGS = 9,      /* int: bit0 revolute (else fixed), bit1 limits scale with the impairment */
+  AGX_XJ_FLAGS = 9,      /* int: bit0 revolute (else fixed), bit1 limits scale with the impairment, bit2 the fall model poses this joint at its
+                            PRESET instead of where the rag doll left it (arm_manipulation.py:139) */
   AGX_XJ_PRESET = 10,    /* joint angle set by the task at reset (feeding.py:124), radians      */
   AGX_XJ_DRAW = 11,      /* int: index of the head-angle draw added to the preset, -1 = none    */
   AGX_XJ_STRIDE = 12

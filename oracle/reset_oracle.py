@@ -43,7 +43,7 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
           TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
-          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, COUNT=108)
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, TOC_GOAL_LINK3=108, FALL_PARK=109, COUNT=112)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
 H_TASK_KIND, H_OFF_CLOTH = 35, 40
@@ -179,8 +179,17 @@ class ResetOracle:
         flags = self.ji(g, j, 'FLAGS')
         if not flags & 1:
             return 0.0
-        if getattr(self, 'settled', None) is not None:                     # where the rag doll came to rest (bed_bathing.py:129-137)
-            return float(self.settled[6 + j - (1 if j > 24 else 0)])
+        if getattr(self, 'fell', None) is not None:                        # a joint of the arm that fell: where it came to rest (arm_manipulation.py:145-151)
+            dyn = [int(self.i[self.x0 + self.xi('OFF_DYN') + k]) for k in range(self.nhdof)]
+            if j in dyn:
+                return float(self.fell[self.S['Q'] + self.nrobot + dyn.index(j)])
+        fall_stage = bool(self.xi('FLAGS') & 256)
+        if getattr(self, 'settled', None) is not None and not (fall_stage and flags & 4):     # where the rag doll came to rest (bed_bathing.py:129-137)
+            a = float(self.settled[6 + j - (1 if j > 24 else 0)])
+            if fall_stage:                                                 # setup_joints -> enforce_joint_limits (arm_manipulation.py:139-140, human.py:121)
+                s = ls if flags & 2 else 1.0
+                a = min(max(a, self.jf(g, j, 'LOWER') * s), self.jf(g, j, 'UPPER') * s)
+            return a
         a = self.jf(g, j, 'PRESET')
         k = self.ji(g, j, 'DRAW')
         if k >= 0:
@@ -236,7 +245,8 @@ class ResetOracle:
         ch = self.chain()
         for k in range(narm):
             d = ch[k]
-            assert self.ri(d, 'PARENT') == (ch[k - 1] if k else -1) and self.ri(d, 'ACT') == k
+            dup = int(self.i[int(self.i[H_OFF_TASK]) + 70]) if int(self.i[H_TASK_KIND]) == 4 else 0     # AGX_T_DUP_ACT: robot_arm = 'both' lists a single arm twice, the second copy's actions drive it (robot.py:16)
+            assert self.ri(d, 'PARENT') == (ch[k - 1] if k else -1) and self.ri(d, 'ACT') == k + dup
             jp, jq = compose(pp, pq, self.rf(d, 'TPOS', 3), self.rf(d, 'TQUAT', 4))
             ax = self.rf(d, 'AXIS', 3)
             pq = qmul(jq, q_axis_angle(ax, q[k]))
@@ -396,14 +406,14 @@ class ResetOracle:
         st[e + 0], si[e + 1], st[e + 13] = friction, g, ls
         return st, dict(gender=g, impairment=imp, limit_scale=ls)
 
-    def sample(self, seed, impairment_mode=MODE_RANDOM, gender_mode=-1, max_restarts=None, settled=None):
+    def sample(self, seed, impairment_mode=MODE_RANDOM, gender_mode=-1, max_restarts=None, settled=None, fell=None):
         """-> (state record float32[state_words], info dict).  With a `collides` callback (state record -> bool: does the arm /
         tool touch the human, the table or the wheelchair?) a successful IK restart that collides is rejected and the search
         goes on from the next restart (robot.py:105-112, env.py:299-308), at most COLLISION_TRIES times."""
         first, rejected = 0, []
         tries = self.xi('COLLISION_TRIES') if self.collides is not None else 0
         for t in range(tries + 1):
-            st, info = self._sample_from(seed, impairment_mode, gender_mode, max_restarts, first, settled)
+            st, info = self._sample_from(seed, impairment_mode, gender_mode, max_restarts, first, settled, fell)
             if t == tries or not info['ik_ok'] or not self.collides(st):
                 break
             placed = self.xi('TOC_ATTEMPTS') > 0 or bool(self.xi('FLAGS') & 8)             # base pose search / a robot on wheels: the next PLACEMENT (env.py:281-308)
@@ -412,11 +422,16 @@ class ResetOracle:
         info['rejected_restarts'] = rejected
         return st, info
 
-    def _sample_from(self, seed, impairment_mode, gender_mode, max_restarts, first_restart, settled=None):
+    def _sample_from(self, seed, impairment_mode, gender_mode, max_restarts, first_restart, settled=None, fell=None):
         u = lambda idx: u01(seed, 0, idx)
         # bed bathing (FLAGS bit 4): the human lies where the rag doll of the second model came to rest (its record's q, float32)
         assert (settled is not None) == bool(self.xi('FLAGS') & 16)
         self.settled = None if settled is None else np.asarray(settled, dtype=np.float32)[:6 + self.xi('NJOINT') - 1].astype(np.float64)
+        # arm manipulation (FLAGS bit 7; arm_manipulation.py:139-151): the arm's joint angles / velocities and the human's bodies after the fall, from the
+        # fall model's record (this blob's layout); the fall model itself (bit 8) writes the record the arm falls from
+        fall_stage = bool(self.xi('FLAGS') & 256)
+        assert (fell is not None) == (bool(self.xi('FLAGS') & 128) and not fall_stage)
+        self.fell = None if fell is None else np.asarray(fell, dtype=np.float32).astype(np.float64)
         friction = self.xf('FRIC_LO') + (self.xf('FRIC_HI') - self.xf('FRIC_LO')) * u(S_FRICTION)
         g = gender_mode if gender_mode >= 0 else (0 if u(S_GENDER) < 0.5 else 1)
         if impairment_mode >= 0:
@@ -437,6 +452,9 @@ class ResetOracle:
         bodies = [int(self.i[self.x0 + self.xi('OFF_BODIES') + k]) for k in range(self.nhuman)]
         dyn = [int(self.i[self.x0 + self.xi('OFF_DYN') + k]) for k in range(self.nhdof)]
         for k, link in enumerate(bodies):
+            if self.fell is not None:                                      # the bodies did not move while the arm fell
+                st[S['HUMAN'] + 7 * k:S['HUMAN'] + 7 * k + 7] = self.fell[S['HUMAN'] + 7 * k:S['HUMAN'] + 7 * k + 7]
+                continue
             p, q = self.link_pose(g, link, ls, head)
             st[S['HUMAN'] + 7 * k:S['HUMAN'] + 7 * k + 3], st[S['HUMAN'] + 7 * k + 3:S['HUMAN'] + 7 * k + 7] = p, q
         target = np.zeros(3)
@@ -453,7 +471,12 @@ class ResetOracle:
         base = (self.xf('BASE_POS', 3), self.xf('BASE_QUAT', 4))
         toc_info = None
         mobile, lift_dof, lift_q = bool(self.xi('FLAGS') & 8), -1, 0.0
-        if mobile:                                                         # a robot on wheels (env.py:282-293, stretch.py:58-62): no IK
+        if fall_stage:                                                     # the robot is placed after the fall (arm_manipulation.py:162): parked, arm at mid range
+            lower, upper = self.arm_limits()
+            base = (self.xf('FALL_PARK', 3), np.array([0, 0, 0, 1.0]))
+            best = np.where((lower > -1e9) & (upper < 1e9), 0.5 * (lower + upper), 0.0)
+            ok, restarts, best_d, n_max = True, 0, 0.0, 0
+        elif mobile:                                                       # a robot on wheels (env.py:282-293, stretch.py:58-62): no IK
             stream = T_STREAM0 + first_restart
             pr, yr = self.xf('TOC_POS_RANGE'), self.xf('TOC_YAW_RANGE')
             bp = self.xf('BASE_POS', 3) + np.array([(2 * u01(seed, stream, T_X) - 1) * pr, (2 * u01(seed, stream, T_Y) - 1) * pr, 0.0])
@@ -464,7 +487,7 @@ class ResetOracle:
             if self.xi('TOC_GOAL_KIND') == 1:                              # feeding: the mouth (feeding.py:142)
                 goals = [target]
             else:
-                goals = [self.link_pose(g, int(self.i[self.x0 + X_['TOC_GOAL_LINKS'] + k]), ls, head)[0] + self.xf('TOC_GOAL_OFF', 3) for k in range(self.xi('TOC_NGOALS'))]
+                goals = [self.link_pose(g, int(self.i[self.x0 + (X_['TOC_GOAL_LINKS'] + k if k < 3 else X_['TOC_GOAL_LINK3'])]), ls, head)[0] + self.xf('TOC_GOAL_OFF', 3) for k in range(self.xi('TOC_NGOALS'))]
             gq = [self.f[self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k:self.x0 + X_['TOC_GOAL_QUAT'] + 4 * k + 4].astype(np.float64) for k in range(3)] if self.xi('TOC_GOAL_ORIENT') else None
             must = 1
             if self.xi('TOC_GOAL_KIND') == 2:                              # drinking (drinking.py:143): the mouth (position) is a second START goal, the mouth with the
@@ -498,6 +521,10 @@ class ResetOracle:
         st[S['QT']:S['QT'] + self.ndof] = qfull
         st[S['TREMOR']:S['TREMOR'] + self.nhdof] = tremors
         st[S['TREMOR'] + self.nhdof:S['TREMOR'] + 2 * self.nhdof] = qfull[nr:]
+        if self.fell is not None:                                          # the arm keeps its velocity, its hold the pose it was given before the fall
+            for key in ('QD', 'QT'):
+                st[S[key] + nr:S[key] + self.ndof] = self.fell[S[key] + nr:S[key] + self.ndof]
+            st[S['TREMOR'] + self.nhdof:S['TREMOR'] + 2 * self.nhdof] = self.fell[S['TREMOR'] + self.nhdof:S['TREMOR'] + 2 * self.nhdof]
         st[S['BASE']:S['BASE'] + 3], st[S['BASE'] + 3:S['BASE'] + 7] = base
         # tool in the hand (tool.py:49-62)
         pe, oe = self.mobile_fk(lift_dof, lift_q, base) if mobile else self.arm_fk(best, base)[:2]
@@ -543,7 +570,7 @@ class ResetOracle:
         si[e + 9] = (seed * 2654435761 + 12345) & 0x7FFFFFFF
         si[e + 10] = (seed ^ 0x5bd1e995) & 0x7FFFFFFF
         xflags = self.xi('FLAGS')
-        si[e + 11] = 1 if xflags & 6 else self.nfood
+        si[e + 11] = 1 if xflags & (6 | 128) else self.nfood
         if xflags & 64:                                                    # bed bathing: every wiping target alive (bed_bathing.py:173-188)
             to = int(self.i[H_OFF_TASK])
             nt = int(self.i[to + 52 + 2 * g]) + int(self.i[to + 52 + 2 * g + 1])      # AGX_T_NT

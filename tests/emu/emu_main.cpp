@@ -96,12 +96,13 @@ extern "C" int agx_emu_settle_packed(const uint32_t* blob, float* states, int n,
 }
 #if AGX_HAS_SAMPLER
 // settled (may be null): the rag-doll model's settled state record of this environment (bed bathing, AGX_X_FLAGS bit 4)
-extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed, int impairment_mode, int gender_mode, float* info4, const float* settled) {
+// fell (may be null): the fall model's record of this environment after the arm's fall (arm manipulation, AGX_X_FLAGS bit 7)
+extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed, int impairment_mode, int gender_mode, float* info4, const float* settled, const float* fell) {
   // the same schedule as libagx's launch_sample: sample, then AGX_X_COLLISION_TRIES rounds of [build, verdict, re-sample from the next restart]
   static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
   static float scratch[agx::SCR_WORDS];
   int chosen = -1, first = 0;
-  int rc = run_wave(lds, 64, [&](int lane) { int r = agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane, 0, settled); if (lane == 0) chosen = r; });
+  int rc = run_wave(lds, 64, [&](int lane) { int r = agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane, 0, settled, fell); if (lane == 0) chosen = r; });
   const int tries = ((const int*)blob)[((const int*)blob)[AGX_H_OFF_RESET] + AGX_X_COLLISION_TRIES];
   for (int t = 0; t < tries && !rc && chosen >= 0; t++) {
     rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, nullptr, scratch, nullptr, lds, lane); });
@@ -109,7 +110,7 @@ extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed,
     if (!rc) rc = run_wave(lds, 64, [&](int lane) { bool a = agx::reset_collides(blob, scratch, lane); if (lane == 0) again = a; });
     if (!again) break;
     first = chosen + 1;
-    if (!rc) rc = run_wave(lds, 64, [&](int lane) { int r = agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane, first, settled); if (lane == 0) chosen = r; });
+    if (!rc) rc = run_wave(lds, 64, [&](int lane) { int r = agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane, first, settled, fell); if (lane == 0) chosen = r; });
   }
   return rc;
 }

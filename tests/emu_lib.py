@@ -104,13 +104,14 @@ class Emu:
         rc = self.L.agx_emu_settle_packed(_p(self.words), _p(states), C.c_int(len(states)), C.c_int(n))
         assert rc == 0, 'wave emulator reported divergent control flow (or the variant has no packed kernel)'
 
-    def sample(self, seed, impairment_mode=-1, gender_mode=-1, settled=None):
+    def sample(self, seed, impairment_mode=-1, gender_mode=-1, settled=None, fell=None):
         """device-side reset generator (csrc/agx_reset.h) for one env -> (state record, info[4]); settled: the rag-doll model's settled
         record of this environment (bed bathing)"""
         st = np.zeros(self.blob.state_words, dtype=np.float32)
         info = np.zeros(4, dtype=np.float32)
         settled = None if settled is None else np.ascontiguousarray(settled, dtype=np.float32)
-        rc = self.L.agx_emu_sample(_p(self.words), _p(st), C.c_uint64(seed), C.c_int(impairment_mode), C.c_int(gender_mode), _p(info), _p(settled))
+        fell = None if fell is None else np.ascontiguousarray(fell, dtype=np.float32)
+        rc = self.L.agx_emu_sample(_p(self.words), _p(st), C.c_uint64(seed), C.c_int(impairment_mode), C.c_int(gender_mode), _p(info), _p(settled), _p(fell))
         assert rc == 0, 'wave emulator reported divergent control flow'
         return st, info
 
