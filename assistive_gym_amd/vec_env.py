@@ -26,6 +26,21 @@ def attach_ragdoll_model(stepper, n_envs, device):
     return rag
 
 
+ARM_FALL_STEPS = 100         # arm_manipulation.py:145-146
+ARM_DROP_BASE = (-0.25, 0.2, 0.95)   # arm_manipulation.py:123
+
+
+def attach_arm_fall_models(stepper, blob, n_envs, device):
+    """arm manipulation (single-arm robots): ArmManipulationEnv.reset has TWO settles (arm_manipulation.py:117-146) -- the rag doll (bed_settle,
+    dropped from its own spot) and the fall of the posed right arm, which runs on the task's own model at the reset's gravity of -1
+    (ModelBlob.fall_model()).  The fall handle is attached to the task's, the rag doll to the fall handle.  -> (fall, ragdoll) steppers"""
+    rag = Stepper(ModelBlob.load('bed_settle').with_drop_base(ARM_DROP_BASE), n_envs, device)
+    fall = Stepper(blob.fall_model(), n_envs, device)
+    fall.attach_settle_model(rag, RAGDOLL_SETTLE_STEPS)
+    stepper.attach_settle_model(fall, ARM_FALL_STEPS)
+    return fall, rag
+
+
 def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampler='device', _depth=0):
     """pool_size post-reset states: FeedingEnv.reset's sampling (sampler 'device': agx_sample_reset on the GPU;
     'host': the numpy path of host/reset.py), then the 25 settle steps of feeding.py:178-179 on the device.
@@ -48,6 +63,15 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         from .host.reset_bed import DeviceCollisionChecker
         return make_bed_states(blob, pool_size, seed=seed, impairment=impairment, settler=RagdollSettler(pool_size, device),
                                checker=DeviceCollisionChecker(blob, pool_size, device))[0]
+    if blob.task_kind == L.TASK_ARM_MANIPULATION and blob.has_reset_generator and sampler == 'device':
+        # ArmManipulationEnv.reset on the device (the single-arm robots): rag doll, the arm's fall in the fall model, then this model's sampler
+        st = Stepper(blob, pool_size, device)
+        fall, rag = attach_arm_fall_models(st, blob, pool_size, device)
+        st.sample_reset(seed, impairment='no_tremor' if impairment == 'random' else impairment)
+        st.synchronize()
+        out = st.get_state()
+        st.close(); fall.close(); rag.close()
+        return out
     if blob.task_kind == L.TASK_ARM_MANIPULATION:
         # ArmManipulationEnv.reset (host/reset_arm.py) around its two settles on the device: the rag doll, then the fall of the right arm
         from .host.reset_arm import make_states as make_arm_states, ArmFallSettler
@@ -473,8 +497,15 @@ class ArmManipulationSawyerVecEnv(AssistiveVecEnv):
 
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
-        assert kw['reset'] != 'device', 'no device-side reset generator for ArmManipulationSawyer: use a pool'
+        kw.setdefault('impairment', 'no_tremor')           # build_assistive_env(human_impairment='no_tremor'), arm_manipulation.py:112
         super().__init__(n_envs, **kw)
+        assert self.reset_mode != 'device' or self.blob.has_reset_generator, 'no device-side reset generator for the two-armed robots (two arm chains in the base pose search): use a pool'
+        self._fall = attach_arm_fall_models(self.stepper, self.blob, n_envs, self.device_index) if self.reset_mode == 'device' else None
+
+    def close(self):
+        super().close()
+        for st in self._fall or ():
+            st.close()
 
 
 class ArmManipulationSawyerHumanVecEnv(ArmManipulationSawyerVecEnv):
