@@ -36,8 +36,8 @@ class ModelBlob:
         """the blob carries a reset section the device-side reset generator (csrc/agx_reset.h, agx_sample_reset / agx_reset) can sample from:
         every feeding, scratch-itch, dressing and bed-bathing scene (wheelchair-mounted arm: IK restarts; free-standing robot: base pose
         search; robot on wheels: placement draws; bed bathing: with the rag-doll model attached, agx_attach_settle_model), the rag-doll
-        model itself (its drop record) and the single-arm arm-manipulation scenes (with their fall model -- fall_model() -- and the
-        rag-doll model behind it); not the two-armed arm-manipulation scenes (host sampler around the device settles)"""
+        model itself (its drop record) and the arm-manipulation scenes (with their fall model -- fall_model() -- and the rag-doll model
+        behind it; PR2 / Baxter: one base pose for two arm chains)"""
         from .model import compiler as L
         x0 = int(self.i[L.H['OFF_RESET']])
         words = int(self.i[L.H['OFF_TARGETS']]) - x0 if 'OFF_TARGETS' in L.H else 0

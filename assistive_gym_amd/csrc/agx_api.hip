@@ -207,6 +207,13 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
       if (R[AGX_R_PARENT] != (k ? X[AGX_X_CHAIN + k - 1] : -1) || R[AGX_R_ACT] != k + dup) can_sample = false;
       if (k == V->rs_narm - 1 && T[AGX_T_EE_LINK] != d) can_sample = false;
     }
+    for (int k = 0; can_sample && (X[AGX_X_FLAGS] & 512) && k < V->rs_narm; k++) {     // a two-armed robot: the second chain, driven by the actions behind the first arm's
+      const int d = X[AGX_X_CHAIN2 + k];
+      if (d < 0 || d >= hi[AGX_H_NROBOT]) { can_sample = false; break; }
+      const int32_t* R = hi + hi[AGX_H_OFF_ROBOT] + d * AGX_R_STRIDE;
+      if (R[AGX_R_PARENT] != (k ? X[AGX_X_CHAIN2 + k - 1] : -1) || R[AGX_R_ACT] != V->rs_narm + k) can_sample = false;
+      if (k == V->rs_narm - 1 && (T[AGX_T_EE2_LINK] != d || T[AGX_T_TOOL2_BODY] <= 0 || T[AGX_T_TOOL2_BODY] >= hi[AGX_H_NFREE])) can_sample = false;
+    }
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AGX_E_NOGPU, "agx_create: no HIP device (libagx has no CPU path)");

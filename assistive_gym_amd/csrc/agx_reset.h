@@ -79,7 +79,7 @@ AGX_DEV double rs_u01(uint32_t k0, uint32_t k1, uint32_t stream, uint32_t slot) 
   return (double)((((uint64_t)(c0 >> 5)) << 26) | (uint64_t)(c1 >> 6)) * (1.0 / 9007199254740992.0);
 }
 // stream 0 slots, restart-stream slots (+ DoF)
-enum { RS_FRICTION = 0, RS_GENDER = 1, RS_IMPAIRMENT = 2, RS_LIMIT = 3, RS_STRENGTH = 4, RS_HEAD = 8, RS_EE = 12, RS_BOWL = 16,
+enum { RS_FRICTION = 0, RS_GENDER = 1, RS_IMPAIRMENT = 2, RS_LIMIT = 3, RS_STRENGTH = 4, RS_HEAD = 8, RS_EE = 12, RS_BOWL = 16, RS_EE2 = 20,
        RS_TREMOR = 32, RS_LIMB = 48, RS_TARGET_LEN = 49, RS_TARGET_TH = 50, RS_R_REST = 0, RS_R_LO = 16, RS_R_HI = 32,
        RS_T_STREAM0 = 2000, RS_T_X = 0, RS_T_Y = 1, RS_T_YAW = 2, RS_T_REST = 16 };      // base pose search: stream RS_T_STREAM0 + 64 (try x rounds + round) + candidate; rest pose of goal g at RS_T_REST + 8 g + DoF
 enum { RS_IMP_NONE = 0, RS_IMP_LIMITS = 1, RS_IMP_WEAKNESS = 2, RS_IMP_TREMOR = 3, RS_MODE_RANDOM = -1, RS_MODE_NO_TREMOR = -2 };
@@ -93,7 +93,8 @@ struct ResetCtx {
   double ls;                          // limit scale of the sampled human
   double head[3];                     // head joint angle draws
   d3 base_p; dq base_q;               // robot base: the blob's fixed pose, or this lane's candidate of the base pose search
-  int chain[7];                       // DoF of the arm's k-th joint (AGX_X_CHAIN)
+  int chain[7];                       // DoF of the arm's k-th joint (AGX_X_CHAIN; the second arm of a two-armed robot: AGX_X_CHAIN2, see rs_second_arm)
+  int ee_pos, ee_quat;                // task words of that arm's end-effector frame (AGX_T_EE_POS / _QUAT, or AGX_T_EE2_*)
   const float* settled;               // AGX_X_FLAGS bit 4: the joint angles (q) of the rag-doll record the human's pose is read from; else null
   const float* fell;                  // AGX_X_FLAGS bit 7: the fall model's record after the arm's fall (same layout as this blob's records); else null
   bool fall_stage;                    // AGX_X_FLAGS bit 8: this blob is the fall model
@@ -157,7 +158,7 @@ AGX_DEV void rs_mobile_fk(const ResetCtx& c, int lift_dof, double lift_q, d3& pe
     if (((const int*)r)[AGX_R_JTYPE] == 1) { pp = jp + dqrot(jq, dmk(ax.x * qd, ax.y * qd, ax.z * qd)); pq = jq; }
     else { pp = jp; pq = dqmul(jq, dq_axis_angle(ax, qd)); }
   }
-  dcompose(pp, pq, dld3(c.task + AGX_T_EE_POS), dld4(c.task + AGX_T_EE_QUAT), pe, oe);
+  dcompose(pp, pq, dld3(c.task + c.ee_pos), dld4(c.task + c.ee_quat), pe, oe);
 }
 AGX_DEV void rs_arm_fk(const ResetCtx& c, const double* q, d3* pos, d3* axw, d3& pe, dq& oe) {
   d3 pp = c.base_p; dq pq = c.base_q;
@@ -171,7 +172,14 @@ AGX_DEV void rs_arm_fk(const ResetCtx& c, const double* q, d3* pos, d3* axw, d3&
     pp = jp;
     pos[d] = jp; axw[d] = dqrot(pq, ax);
   }
-  dcompose(pp, pq, dld3(c.task + AGX_T_EE_POS), dld4(c.task + AGX_T_EE_QUAT), pe, oe);
+  dcompose(pp, pq, dld3(c.task + c.ee_pos), dld4(c.task + c.ee_quat), pe, oe);
+}
+// the context of the SECOND arm of a two-armed robot (AGX_X_FLAGS bit 9): its chain and its end-effector frame, the same base
+AGX_DEV ResetCtx rs_second_arm(const ResetCtx& c) {
+  ResetCtx c2 = c;
+  for (int d = 0; d < RS_NARM; d++) c2.chain[d] = c.xi[AGX_X_CHAIN2 + d];
+  c2.ee_pos = AGX_T_EE2_POS; c2.ee_quat = AGX_T_EE2_QUAT;
+  return c2;
 }
 
 // damped least squares from q (in place), joint box [lo, hi]; ORIENT = false: position only (a 3 x 3 system)
@@ -318,6 +326,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   c.nj = XI(c, AGX_X_NJOINT);
   c.base_p = dld3(c.xf + AGX_X_BASE_POS); c.base_q = dld4(c.xf + AGX_X_BASE_QUAT);
   for (int d = 0; d < RS_NARM; d++) c.chain[d] = XI(c, AGX_X_CHAIN + d);
+  c.ee_pos = AGX_T_EE_POS; c.ee_quat = AGX_T_EE_QUAT;
   const int ndof = c.bi[AGX_H_NDOF], nrobot = c.bi[AGX_H_NROBOT], nhdof = c.bi[AGX_H_NHDOF], nfree = c.bi[AGX_H_NFREE];
   const int nhuman = c.bi[AGX_H_NHUMAN], nfood = c.bi[AGX_H_NFOOD], state_words = c.bi[AGX_H_STATE_WORDS];
   const int sQ = c.bi[AGX_H_S_Q], sQT = c.bi[AGX_H_S_QT], sFREE = c.bi[AGX_H_S_FREE], sBASE = c.bi[AGX_H_S_BASE];
@@ -398,10 +407,15 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   const dq tquat = dld4(c.xf + AGX_X_EE_QUAT);
   const int max_restarts = XI(c, AGX_X_IK_RESTARTS), randlim_from = XI(c, AGX_X_IK_RANDLIM_FROM);
   const double thresh = XF(c, AGX_X_IK_THRESH);
-  double best_q[RS_NARM], best_d = 1e300;
+  double best_q[RS_NARM], best_q2[RS_NARM], best_d = 1e300;                                                   // best_q2: the second arm of a two-armed robot
   int best_r = 0x7fffffff, restarts = max_restarts, ok = 0;
 #pragma unroll
-  for (int d = 0; d < RS_NARM; d++) best_q[d] = 0.0;
+  for (int d = 0; d < RS_NARM; d++) { best_q[d] = 0.0; best_q2[d] = 0.0; }
+  const bool two_arms = (xflags & 512) != 0;
+  d3 tpos2 = dld3(c.xf + AGX_X_EE_TARGET2);                                                                  // arm_manipulation.py:159
+  tpos2.x += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_EE2 + 0) - 1.0) * XF(c, AGX_X_EE_RANGE);
+  tpos2.y += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_EE2 + 1) - 1.0) * XF(c, AGX_X_EE_RANGE);
+  tpos2.z += (2.0 * rs_u01(seed_lo, seed_hi, 0, RS_EE2 + 2) - 1.0) * XF(c, AGX_X_EE_RANGE);
   const int toc_attempts = XI(c, AGX_X_TOC_ATTEMPTS);
   const bool mobile = (xflags & 8) != 0;
   double lift_q = 0.0;
@@ -413,6 +427,11 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     for (int d = 0; d < RS_NARM; d++) {
       const double lower = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_UPPER];
       best_q[d] = (lower > -1e9 && upper < 1e9) ? 0.5 * (lower + upper) : 0.0;
+      if (two_arms) {
+        const int d2 = c.xi[AGX_X_CHAIN2 + d];
+        const double lower2 = (double)c.rob[d2 * AGX_R_STRIDE + AGX_R_LOWER], upper2 = (double)c.rob[d2 * AGX_R_STRIDE + AGX_R_UPPER];
+        best_q2[d] = (lower2 > -1e9 && upper2 < 1e9) ? 0.5 * (lower2 + upper2) : 0.0;
+      }
     }
     ok = 1; restarts = 0; best_d = 0.0;
   }
@@ -455,26 +474,32 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
       const double yaw = XF(c, AGX_X_TOC_YAW0) + (2.0 * uw - 1.0) * yrange;
       c.base_p = base0 + dmk(XF(c, AGX_X_TOC_X_SIGN) * prange * ux, (2.0 * uy - 1.0) * prange, 0.0);
       c.base_q = dq_axis_angle(dmk(0, 0, 1), yaw);
-      int reached = 0; double manip = 0.0, qs[RS_NARM];
+      int reached = 0; double manip = 0.0, qs[RS_NARM], qs2[RS_NARM];
 #pragma unroll
-      for (int d = 0; d < RS_NARM; d++) qs[d] = 0.0;
-      if (active) {
+      for (int d = 0; d < RS_NARM; d++) { qs[d] = 0.0; qs2[d] = 0.0; }
+      // a two-armed robot (arm_manipulation.py:165): arm 0 = the right arm with the start pose and the first half of the goals, arm 1 = the left arm
+      // (CHAIN2, EE2) with its own start pose tpos2 and the second half; bit 3 arm + g of `reached`, rest-pose draws at RS_T_REST + 8 (3 arm + g)
+      const int narms = two_arms ? 2 : 1, gpa = two_arms ? ngoals / 2 : ngoals;      // goals per arm
+      if (active) for (int arm = 0; arm < narms; arm++) {
+        ResetCtx ca = arm ? rs_second_arm(c) : c;
+        ca.base_p = c.base_p; ca.base_q = c.base_q;
         double lo[RS_NARM], hi[RS_NARM];
 #pragma unroll
         for (int d = 0; d < RS_NARM; d++) {
-          const double lower = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[c.chain[d] * AGX_R_STRIDE + AGX_R_UPPER];
+          const double lower = (double)c.rob[ca.chain[d] * AGX_R_STRIDE + AGX_R_LOWER], upper = (double)c.rob[ca.chain[d] * AGX_R_STRIDE + AGX_R_UPPER];
           lo[d] = lower < -1e9 ? -6.283185307179586 : lower; hi[d] = upper > 1e9 ? 6.283185307179586 : upper;     // agent.py:223-231
         }
-        for (int g = 0; g <= ngoals; g++) {
+        for (int g = 0; g <= gpa; g++) {
+          const int slot = (two_arms ? 3 * arm : 0) + g;
           double q[RS_NARM];
 #pragma unroll
-          for (int d = 0; d < RS_NARM; d++) q[d] = lo[d] + (hi[d] - lo[d]) * rs_u01(seed_lo, seed_hi, stream, RS_T_REST + 8 * g + d);     // agent.py:263
-          const d3 tp = g == 0 ? tpos : goals[g - 1];
+          for (int d = 0; d < RS_NARM; d++) q[d] = lo[d] + (hi[d] - lo[d]) * rs_u01(seed_lo, seed_hi, stream, RS_T_REST + 8 * slot + d);     // agent.py:263
+          const d3 tp = g == 0 ? (arm ? tpos2 : tpos) : goals[arm * gpa + g - 1];
           const bool orient = g == 0 || goal_orient || (goal_kind == 2 && g == 2);
           const dq tq = (g == 0 || goal_kind == 2 || !goal_orient) ? tquat : dld4(c.xf + AGX_X_TOC_GOAL_QUAT + 4 * (g - 1));       // (position-only goals do not read it)
-          if (orient) rs_ik<true>(c, q, lo, hi, tp, tq, titers); else rs_ik<false>(c, q, lo, hi, tp, tq, titers);
+          if (orient) rs_ik<true>(ca, q, lo, hi, tp, tq, titers); else rs_ik<false>(ca, q, lo, hi, tp, tq, titers);
           d3 pos[RS_NARM], axw[RS_NARM], pe; dq oe;
-          rs_arm_fk(c, q, pos, axw, pe, oe);
+          rs_arm_fk(ca, q, pos, axw, pe, oe);
           bool hit = sqrt(ddot(tp - pe, tp - pe)) < tthr;                                                          // robot.py:97
           if (orient) {
             const double mx = tq.x - oe.x, my = tq.y - oe.y, mz = tq.z - oe.z, mw = tq.w - oe.w;
@@ -483,7 +508,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
           }
           if (g == 0) {
 #pragma unroll
-            for (int d = 0; d < RS_NARM; d++) qs[d] = q[d];
+            for (int d = 0; d < RS_NARM; d++) { if (arm) qs2[d] = q[d]; else qs[d] = q[d]; }
             // the pedestal guard: joint origins past the shoulder, the midpoints between them and the end effector, in the base frame
             for (int b = 0; b < nped && hit; b++) {
               const float* bx = c.xf + AGX_X_PED_BOX + 6 * b;
@@ -495,10 +520,10 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
               }
             }
           }
-          if (hit) { reached |= 1 << g; manip += rs_jlwki(c, q); }
+          if (hit) { reached |= 1 << slot; manip += rs_jlwki(ca, q); }
         }
       }
-      const int must = goal_kind == 2 ? 3 : 1;                                                     // the start goals must be reachable (robot.py:196-200)
+      const int must = goal_kind == 2 ? 3 : (two_arms ? 9 : 1);                                    // the start goals must be reachable (robot.py:196-200; both arms': bits 0 and 3)
       const int ngoal = (active && (reached & must) == must) ? __builtin_popcount(reached) : -1;
       int bl = 0, bn = -2; double bm = -1e300;
       for (int l = 0; l < AGX_WAVE; l++) {
@@ -512,7 +537,7 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
         c.base_p = dmk(wave_bcast_d(bp.x, bl), wave_bcast_d(bp.y, bl), wave_bcast_d(bp.z, bl));
         c.base_q.x = wave_bcast_d(bq.x, bl); c.base_q.y = wave_bcast_d(bq.y, bl); c.base_q.z = wave_bcast_d(bq.z, bl); c.base_q.w = wave_bcast_d(bq.w, bl);
 #pragma unroll
-        for (int d = 0; d < RS_NARM; d++) best_q[d] = wave_bcast_d(qs[d], bl);
+        for (int d = 0; d < RS_NARM; d++) { best_q[d] = wave_bcast_d(qs[d], bl); best_q2[d] = wave_bcast_d(qs2[d], bl); }
         best_d = (double)bn; best_r = first_restart;
       }
     }
@@ -579,16 +604,27 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
   if (mobile) rs_mobile_fk(c, lift_dof, lift_q, pe, oe);
   else rs_arm_fk(c, best_q, pos, axw, pe, oe);
   dcompose(pe, oe, dld3(c.task + AGX_T_TOOL_POS), dld4(c.task + AGX_T_TOOL_QUAT), tp, tq);                   // tool.py:49-62
+  d3 tp2 = tp; dq tq2 = tq;                                                                                  // tool_left in the left hand (arm_manipulation.py:156)
+  if (two_arms) {
+    ResetCtx c2 = rs_second_arm(c);
+    d3 pos2[RS_NARM], axw2[RS_NARM], pe2; dq oe2;
+    rs_arm_fk(c2, best_q2, pos2, axw2, pe2, oe2);
+    dcompose(pe2, oe2, dld3(c.task + AGX_T_TOOL2_POS), dld4(c.task + AGX_T_TOOL2_QUAT), tp2, tq2);
+  }
   if (lane < ndof) {
     double qv;
-    int ck = -1;
+    int ck = -1, ck2 = -1;
 #pragma unroll
-    for (int d = 0; d < RS_NARM; d++) ck = (!mobile && c.chain[d] == lane) ? d : ck;
+    for (int d = 0; d < RS_NARM; d++) { ck = (!mobile && c.chain[d] == lane) ? d : ck; ck2 = (two_arms && c.xi[AGX_X_CHAIN2 + d] == lane) ? d : ck2; }
     if (lane == lift_dof) qv = lift_q;
     else if (ck >= 0) {
       qv = best_q[0];
 #pragma unroll
       for (int d = 1; d < RS_NARM; d++) qv = ck == d ? best_q[d] : qv;
+    } else if (ck2 >= 0) {
+      qv = best_q2[0];
+#pragma unroll
+      for (int d = 1; d < RS_NARM; d++) qv = ck2 == d ? best_q2[d] : qv;
     } else if (lane < nrobot) {                                                                              // gripper (and joints outside the arm), feeding.py:143-144
       const float* r = c.rob + lane * AGX_R_STRIDE;
       qv = fmin(fmax((double)r[AGX_R_QT0], (double)r[AGX_R_LOWER]), (double)r[AGX_R_UPPER]);
@@ -609,14 +645,16 @@ AGX_DEV int env_sample(const uint32_t* __restrict__ blob, float* __restrict__ gs
     float* o = gstate + sFREE + 13 * lane;
     const int tool_body = c.bi[AGX_H_TOOL_BODY], bowl_body = XI(c, AGX_X_BOWL_BODY), food0 = c.bi[AGX_H_FOOD0];
     d3 p = dmk(0, 0, 0); dq q = dq_ident();
-    if (lane == tool_body) {
-      p = tp; q = tq;
+    const int tool2_body = two_arms ? ((const int*)c.task)[AGX_T_TOOL2_BODY] : -1;
+    if (lane == tool_body || lane == tool2_body) {
+      const d3 tpx = lane == tool2_body ? tp2 : tp; const dq tqx = lane == tool2_body ? tq2 : tq;
+      p = tpx; q = tqx;
       const float* fb = c.bf + c.bi[AGX_H_OFF_FREE] + lane * AGX_F_STRIDE;
       if (fb[AGX_F_REFPOS] != 0.f || fb[AGX_F_REFPOS + 1] != 0.f || fb[AGX_F_REFPOS + 2] != 0.f || fb[AGX_F_REFQUAT + 3] != 1.f) {
         // a tool whose URDF base frame is not its centre-of-mass frame (wiper, scratcher): the record holds the COM frame
         dq qi = dld4(fb + AGX_F_REFQUAT); qi.x = -qi.x; qi.y = -qi.y; qi.z = -qi.z;
         const d3 ip = dqrot(qi, dld3(fb + AGX_F_REFPOS));
-        dcompose(tp, tq, dmk(-ip.x, -ip.y, -ip.z), qi, p, q);
+        dcompose(tpx, tqx, dmk(-ip.x, -ip.y, -ip.z), qi, p, q);
       }
     }
     else if (lane == bowl_body) {                                                                            // furniture.py:32-34

@@ -54,7 +54,7 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
           TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
-          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, TOC_GOAL_LINK3=108, FALL_PARK=109, COUNT=112)
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, TOC_GOAL_LINK3=108, FALL_PARK=109, CHAIN2=112, EE_TARGET2=119, COUNT=124)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 E = dict(PLANE_FRICTION=0, GENDER=1, TARGET=2, FOOD_ALIVE=5, FOOD_ACTIVE=6, ITERATION=7, TASK_SUCCESS=8, RNG=9,
          TOTAL_FOOD=11, FROZEN=12, LIMIT_SCALE=13, HUMAN_KP=14, HUMAN_MAXF=15, COUNT=16)
@@ -79,7 +79,7 @@ MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathin
 # pair-group flags (AGX_G_FLAGS)
 GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC = 1, 2, 4, 8, 16, 32
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 12
+MAGIC, VERSION = 0x31584741, 13
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -2030,11 +2030,40 @@ def compile_arm_manipulation_dual(robot, assets=DEFAULT_ASSETS, n_iter=50, robot
     params = default_params(n_iter)
     params.update(ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=-9.81)                               # arm_manipulation.py:120-121,176
 
+    # ArmManipulationEnv.reset on the device for a two-armed robot (AGX_X_FLAGS bits 4, 7 and 9): as for the single arm (compile_arm_manipulation),
+    # with ONE base pose for both arms (arm_manipulation.py:165) -- the right arm's start pose and goals wrist / waist, the left arm's start pose
+    # and goals elbow / stomach
     def reset_words(nhuman, nhdof):
-        return X_['COUNT']
+        return X_['COUNT'] + 2 * 42 * XJ['STRIDE'] + nhuman + nhdof
 
     def reset_fill(xf, xi, nhuman, nhdof, human_bodies, hd):
-        pass        # the pool comes from assistive_gym_amd/host/reset_arm.py
+        xi[X_['NJOINT']], xi[X_['NARM']] = 42, len(RBR['arm'])
+        fill_reset_chain_and_pedestal(xf, xi, rob, RBR['arm'])
+        dof_of = {j: d for d, j in enumerate(rob['dof_links'])}
+        xi[X_['CHAIN2']:X_['CHAIN2'] + 7] = [dof_of[j] for j in LB['arm']]
+        xi[X_['TOC_NGOALS']], xi[X_['TOC_GOAL_KIND']] = 4, 0
+        xf[X_['BASE_POS']:X_['BASE_POS'] + 3] = np.array([-0.85, -0.4, 0]) + TK['toc_base']       # robot.py:142 + toc_base_pos_offset
+        xf[X_['BASE_QUAT']:X_['BASE_QUAT'] + 4] = [0, 0, 0, 1]
+        xi[X_['TOC_ATTEMPTS']], xi[X_['TOC_ROUNDS']] = 50, 4
+        xf[X_['TOC_POS_RANGE']], xf[X_['TOC_YAW_RANGE']] = 0.5, np.deg2rad(30.0)
+        xf[X_['TOC_YAW0']], xf[X_['TOC_X_SIGN']] = 0.0, -1.0
+        xi[X_['TOC_IK_ITERS']], xf[X_['TOC_THRESH']] = 100, 0.03
+        xi[X_['TOC_GOAL_LINKS']:X_['TOC_GOAL_LINKS'] + 3] = [9, 27, 7]                            # right arm: wrist, waist; left arm: elbow ... (arm_manipulation.py:165)
+        xi[X_['TOC_GOAL_LINK3']] = 24                                                            # ... stomach
+        xf[X_['EE_QUAT']:X_['EE_QUAT'] + 4] = X.quat_from_rpy(TK['ee_rpy'])
+        xf[X_['EE_TARGET']:X_['EE_TARGET'] + 3], xf[X_['EE_RANGE']] = [-1.0, -0.3, 0.8], 0.05     # arm_manipulation.py:158 (two arms)
+        xf[X_['EE_TARGET2']:X_['EE_TARGET2'] + 3] = [-1.0, 0.7, 0.8]                             # :159
+        xf[X_['FALL_PARK']:X_['FALL_PARK'] + 3] = [20.0, 20.0, 0.975]
+        xf[X_['HEAD_RANGE']] = 0.0
+        xi[X_['IK_ITERS']], xf[X_['IK_DAMP']], xf[X_['IK_MAXSTEP']], xf[X_['IK_TOL']] = 200, 0.05, 0.5, 1e-4
+        xf[X_['IK_THRESH']], xi[X_['IK_RESTARTS']], xi[X_['IK_RANDLIM_FROM']] = 0.01, 1000, 10
+        xf[X_['FRIC_LO']], xf[X_['FRIC_HI']] = 0.025, 0.5
+        xf[X_['LIMIT_LO']], xf[X_['STRENGTH_LO']], xf[X_['TREMOR_RANGE']] = 0.5, 0.25, np.deg2rad(10.0)
+        xf[X_['REACTIVE_KP']], xf[X_['REACTIVE_MAXF']] = 0.05, 0.01
+        xi[X_['BOWL_BODY']] = -1
+        xi[X_['COLLISION_TRIES']] = 3
+        xi[X_['FLAGS']] = 1 | 16 | 128 | 512
+        fill_reset_human_tree(xf, xi, nhuman, nhdof, human_bodies, hd, {3: 60.0, 4: -60.0, 6: 0.0}, fall_preset=(3, 4, 6))
     return pack(sc, groups, rob, human_bodies, human_link_rec, hd, free, params, task_f, task_i,
                 dict(NFOOD=0, ACT_DIM=len(arm), OBS_DIM=31 + len(arm), FOOD0=0, TOOL_BODY=0, TASK_KIND=TASK_ARM_MANIPULATION), reset_fill, reset_words,
                 task_words=AM['WORDS'], mlp=mlp, meta_extra=dict(arm_joints=arm, gripper_joints=grip, robot=robot, dual=True, toc_base=list(TK['toc_base']), ee_rpy=list(TK['ee_rpy']),

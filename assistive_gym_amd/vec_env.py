@@ -31,7 +31,7 @@ ARM_DROP_BASE = (-0.25, 0.2, 0.95)   # arm_manipulation.py:123
 
 
 def attach_arm_fall_models(stepper, blob, n_envs, device):
-    """arm manipulation (single-arm robots): ArmManipulationEnv.reset has TWO settles (arm_manipulation.py:117-146) -- the rag doll (bed_settle,
+    """arm manipulation: ArmManipulationEnv.reset has TWO settles (arm_manipulation.py:117-146) -- the rag doll (bed_settle,
     dropped from its own spot) and the fall of the posed right arm, which runs on the task's own model at the reset's gravity of -1
     (ModelBlob.fall_model()).  The fall handle is attached to the task's, the rag doll to the fall handle.  -> (fall, ragdoll) steppers"""
     rag = Stepper(ModelBlob.load('bed_settle').with_drop_base(ARM_DROP_BASE), n_envs, device)
@@ -64,7 +64,7 @@ def build_reset_pool(blob, pool_size, seed, device=0, impairment='random', sampl
         return make_bed_states(blob, pool_size, seed=seed, impairment=impairment, settler=RagdollSettler(pool_size, device),
                                checker=DeviceCollisionChecker(blob, pool_size, device))[0]
     if blob.task_kind == L.TASK_ARM_MANIPULATION and blob.has_reset_generator and sampler == 'device':
-        # ArmManipulationEnv.reset on the device (the single-arm robots): rag doll, the arm's fall in the fall model, then this model's sampler
+        # ArmManipulationEnv.reset on the device: rag doll, the arm's fall in the fall model, then this model's sampler (one base pose for both arms of PR2 / Baxter)
         st = Stepper(blob, pool_size, device)
         fall, rag = attach_arm_fall_models(st, blob, pool_size, device)
         st.sample_reset(seed, impairment='no_tremor' if impairment == 'random' else impairment)
@@ -499,7 +499,7 @@ class ArmManipulationSawyerVecEnv(AssistiveVecEnv):
         kw.setdefault('reset', 'pool')
         kw.setdefault('impairment', 'no_tremor')           # build_assistive_env(human_impairment='no_tremor'), arm_manipulation.py:112
         super().__init__(n_envs, **kw)
-        assert self.reset_mode != 'device' or self.blob.has_reset_generator, 'no device-side reset generator for the two-armed robots (two arm chains in the base pose search): use a pool'
+        assert self.reset_mode != 'device' or self.blob.has_reset_generator
         self._fall = attach_arm_fall_models(self.stepper, self.blob, n_envs, self.device_index) if self.reset_mode == 'device' else None
 
     def close(self):

@@ -123,7 +123,7 @@ int agx_reset(agx_handle h, const uint8_t* mask_dev, const uint64_t* seeds_dev, 
  * of `h` then sample that model's drop records from the same seeds, settle them for n_substeps substeps and read the human's resting pose
  * from its state records.  The second handle is not owned (destroy it after `h`); a null `settle` detaches.  Without an attachment the
  * sampler of such a model refuses to run.
- * Arm manipulation (ArmManipulationEnv.reset, assistive_gym/envs/arm_manipulation.py:117-162; single-arm robots): two settles.  `settle` is
+ * Arm manipulation (ArmManipulationEnv.reset, assistive_gym/envs/arm_manipulation.py:117-165): two settles.  `settle` is
  * then a handle on the task's FALL model (the same blob with HUMAN_GRAVITY_Z = -1 and AGX_X_FLAGS bit 8: its sampler writes the record the
  * posed arm falls from), n_substeps the length of the fall (100); the rag-doll handle is attached to the fall handle by a second call.
  * agx_sample_reset / agx_reset of `h` run rag doll, fall and the task's sampler in that order. */

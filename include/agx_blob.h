@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 12
+#define AGX_BLOB_VERSION 13
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -329,6 +329,10 @@ enum {
                              *         the rag-doll model is attached to the fall model.  This sampler reads the human's bodies, the arm's joint angles
                              *         and velocities from the fall model's settled record and the four goals of the base pose search (wrist, waist,
                              *         elbow, stomach: TOC_GOAL_LINKS[0..2], TOC_GOAL_LINK3) from the tree with those angles;
+                             * bit 9 = a two-armed robot (arm_manipulation.py:165; Robot.position_robot_toc with arm = ['right', 'left']): ONE base pose for both
+                             *         arms -- each arm solves its own start pose (EE_TARGET / EE_TARGET2, orientation EE_QUAT) and two of the four goals
+                             *         (right: TOC_GOAL_LINKS[0..1] = wrist, waist; left: TOC_GOAL_LINKS[2], TOC_GOAL_LINK3 = elbow, stomach); both start
+                             *         poses must be reached, goals and manipulability add up over the arms; the second tool goes into the second hand;
                              * bit 8 = THIS blob is the fall model: its sampler writes the record the arm falls from -- the human where the rag doll lies
                              *         with the preset arm, the robot parked at FALL_PARK with its arm at the middle of its joint ranges               */
   /* base pose search of a free-standing robot (Robot.position_robot_toc, robot.py:123-215); TOC_ATTEMPTS = 0: the base is fixed (BASE_POS / BASE_QUAT) */
@@ -356,7 +360,10 @@ enum {
   AGX_X_PED_BOX = 96,       /* float[PED_N][6]: min corner, max corner                                                                     */
   AGX_X_TOC_GOAL_LINK3 = 108, /* int: a fourth goal link (arm manipulation: wrist, waist, elbow, stomach, arm_manipulation.py:162)                 */
   AGX_X_FALL_PARK = 109,    /* float[3]: where the robot stands while the arm falls (FLAGS bit 8; it is placed afterwards, :162)                    */
-  AGX_X_COUNT = 112
+  AGX_X_CHAIN2 = 112,       /* int[7]: FLAGS bit 9 -- the DoFs of the SECOND arm's joints in chain order (arm manipulation with a two-armed robot: CHAIN is
+                               the right arm holding tool_right, CHAIN2 the left arm holding tool_left: AGX_T_EE2_*, AGX_T_TOOL2_*)                   */
+  AGX_X_EE_TARGET2 = 119,   /* float[3]: centre of the second arm's end-effector start position (arm_manipulation.py:159), +- EE_RANGE                */
+  AGX_X_COUNT = 124
 };
 enum {
   AGX_XJ_PARENT = 0,     /* int: parent joint (PyBullet link numbering), -1 = base              */

@@ -43,13 +43,15 @@ X_ = dict(NJOINT=0, NARM=1, BASE_POS=2, BASE_QUAT=5, EE_QUAT=9, EE_TARGET=13, EE
           BOWL_BODY=40, OFF_JOINTS=41, OFF_BODIES=42, OFF_DYN=43, STRENGTH_LO=44, FOOD_OFF=45, COLLISION_TRIES=48,
           REACTIVE_KP=49, REACTIVE_MAXF=50, FLAGS=51, TOC_ATTEMPTS=52, TOC_ROUNDS=53, TOC_POS_RANGE=54, TOC_YAW_RANGE=55, TOC_YAW0=56, TOC_X_SIGN=57,
           TOC_IK_ITERS=58, TOC_THRESH=59, TOC_GOAL_LINKS=60, TOC_GOAL_ORIENT=63, TOC_GOAL_OFF=64, CLOTH_GRAVITY_SETTLE=67, CLOTH_GRAVITY=68,
-          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, TOC_GOAL_LINK3=108, FALL_PARK=109, COUNT=112)
+          CLOTH_ORIG_POS=69, TOC_GOAL_QUAT=72, CHAIN=84, TOC_NGOALS=91, TOC_GOAL_KIND=92, PED_N=93, MOBILE_LIFT=94, MOBILE_LIFT_DOF=95, PED_BOX=96, TOC_GOAL_LINK3=108, FALL_PARK=109, CHAIN2=112, EE_TARGET2=119, COUNT=124)
 XJ = dict(PARENT=0, OFF=1, AXIS=4, LOWER=7, UPPER=8, FLAGS=9, PRESET=10, DRAW=11, STRIDE=12)
 H_OFF_RESET, H_OFF_ROBOT, H_OFF_FREE, H_OFF_TASK, H_S_TASK = 31, 13, 14, 18, 36
 H_TASK_KIND, H_OFF_CLOTH = 35, 40
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, LOWER=21, UPPER=22, ACT=27, QT0=28, JTYPE=32, STRIDE=36)
 F = dict(REFPOS=5, REFQUAT=8, STRIDE=16)
-T = dict(SI_LIMB_DIMS=9, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35)
+T = dict(SI_LIMB_DIMS=9, MOUTH_M=11, MOUTH_F=14, HEAD_LINK=17, EE_LINK=18, EE_POS=19, EE_QUAT=22, TOOL_POS=26, TOOL_QUAT=29, COOP=35,
+         TOOL2_BODY=72, EE2_LINK=73, EE2_POS=74, EE2_QUAT=77, TOOL2_POS=81, TOOL2_QUAT=84)
+S_EE2 = 20                                               # stream 0: the second arm's start position (arm_manipulation.py:159)
 
 
 def contacts_collide(blob_words, contacts):
@@ -213,8 +215,8 @@ class ResetOracle:
 
     # -- robot --------------------------------------------------------------------------------------
     def chain(self):
-        """DoFs of the arm's joints in chain order (AGX_X_CHAIN)"""
-        return [int(self.i[self.x0 + X_['CHAIN'] + k]) for k in range(self.xi('NARM'))]
+        """DoFs of the arm's joints in chain order (AGX_X_CHAIN; self.arm = 1: the second arm of a two-armed robot, AGX_X_CHAIN2)"""
+        return [int(self.i[self.x0 + X_['CHAIN2' if getattr(self, 'arm', 0) else 'CHAIN'] + k]) for k in range(self.xi('NARM'))]
 
     def arm_limits(self):
         ch = self.chain()
@@ -246,15 +248,16 @@ class ResetOracle:
         for k in range(narm):
             d = ch[k]
             dup = int(self.i[int(self.i[H_OFF_TASK]) + 70]) if int(self.i[H_TASK_KIND]) == 4 else 0     # AGX_T_DUP_ACT: robot_arm = 'both' lists a single arm twice, the second copy's actions drive it (robot.py:16)
-            assert self.ri(d, 'PARENT') == (ch[k - 1] if k else -1) and self.ri(d, 'ACT') == k + dup
+            assert self.ri(d, 'PARENT') == (ch[k - 1] if k else -1) and self.ri(d, 'ACT') == k + dup + (narm if getattr(self, 'arm', 0) else 0)
             jp, jq = compose(pp, pq, self.rf(d, 'TPOS', 3), self.rf(d, 'TQUAT', 4))
             ax = self.rf(d, 'AXIS', 3)
             pq = qmul(jq, q_axis_angle(ax, q[k]))
             pp = jp
             pos.append(jp)
             axw.append(qrot(pq, ax))
-        assert self.ti('EE_LINK') == ch[narm - 1]
-        pe, oe = compose(pp, pq, self.tf('EE_POS', 3), self.tf('EE_QUAT', 4))
+        second = getattr(self, 'arm', 0)
+        assert self.ti('EE2_LINK' if second else 'EE_LINK') == ch[narm - 1]
+        pe, oe = compose(pp, pq, self.tf('EE2_POS' if second else 'EE_POS', 3), self.tf('EE2_QUAT' if second else 'EE_QUAT', 4))
         return pe, oe, pos, axw
 
     def ik(self, q0, lo, hi, target_pos, target_quat, iters=None, base=None):
@@ -305,14 +308,19 @@ class ResetOracle:
         det = max(np.linalg.det(M), 0.0)
         return det ** (1.0 / 6.0) / (np.trace(M) / 6.0)
 
-    def toc(self, seed, placement, target_pos, target_quat, goals, goal_quats=None, must=1):
+    def toc(self, seed, placement, target_pos, target_quat, goals, goal_quats=None, must=1, target_pos2=None):
         """Robot.position_robot_toc (robot.py:123-215) as the device runs it: TOC_ATTEMPTS candidate base poses per round, each solving
-        the start pose and the position goals from random rest poses; -> (ok, base (p, q), start solution, rounds used, goals reached)"""
+        the start pose and the position goals from random rest poses; -> (ok, base (p, q), start solution, rounds used, goals reached).
+        target_pos2 (a two-armed robot, FLAGS bit 9; arm_manipulation.py:165): the second arm's start position -- arm 0 takes target_pos and
+        the first half of the goals, arm 1 (CHAIN2, EE2) target_pos2 and the second half; both start poses must be reached; the start
+        solution is then the pair (q of arm 0, q of arm 1)"""
         narm, A, rounds = self.xi('NARM'), self.xi('TOC_ATTEMPTS'), self.xi('TOC_ROUNDS')
-        lower, upper = self.arm_limits()
-        lo, hi = np.where(lower < -1e9, -2 * np.pi, lower), np.where(upper > 1e9, 2 * np.pi, upper)
         thr, pr, yr = self.xf('TOC_THRESH'), self.xf('TOC_POS_RANGE'), self.xf('TOC_YAW_RANGE')
         base0 = self.xf('BASE_POS', 3)
+        two = target_pos2 is not None
+        narms, gpa = (2, len(goals) // 2) if two else (1, len(goals))
+        if two:
+            must = 9
         out = None
         for rnd in range(rounds):
             best = None
@@ -321,34 +329,40 @@ class ResetOracle:
                 yaw = self.xf('TOC_YAW0') + (2 * u01(seed, stream, T_YAW) - 1) * yr
                 base = (base0 + np.array([self.xf('TOC_X_SIGN') * pr * u01(seed, stream, T_X), (2 * u01(seed, stream, T_Y) - 1) * pr, 0.0]),
                         q_axis_angle(np.array([0, 0, 1.0]), yaw))
-                reached, manip, qs = 0, 0.0, None
-                for g in range(1 + len(goals)):
-                    q0 = lo + (hi - lo) * np.array([u01(seed, stream, T_REST + 8 * g + d) for d in range(narm)])
-                    tp = target_pos if g == 0 else goals[g - 1]
-                    tq = target_quat if g == 0 else (goal_quats[g - 1] if goal_quats is not None else None)
-                    q = self.ik(q0, lo, hi, tp, tq, iters=self.xi('TOC_IK_ITERS'), base=base)
-                    pe, oe, orig, _ = self.arm_fk(q, base)
-                    hit = np.sqrt((tp - pe) @ (tp - pe)) < thr
-                    if g == 0 and hit and self.xi('PED_N') > 0:                    # the pedestal guard (host/reset_bed.py::_arm_in_pedestal)
-                        pts = orig[2:] + [0.5 * (orig[k] + orig[k + 1]) for k in range(2, narm - 1)] + [pe]
-                        bi = np.array([-base[1][0], -base[1][1], -base[1][2], base[1][3]])
-                        for b in range(self.xi('PED_N')):
-                            bx = self.f[self.x0 + X_['PED_BOX'] + 6 * b:self.x0 + X_['PED_BOX'] + 6 * b + 6].astype(np.float64)
-                            for pt in pts:
-                                l = qrot(bi, pt - base[0])
-                                if np.all(l >= bx[:3]) and np.all(l <= bx[3:]):
-                                    hit = False
-                    if tq is not None:
-                        dm, dp = tq - oe, tq + oe
-                        hit = hit and min(np.sqrt(dm @ dm), np.sqrt(dp @ dp)) < thr
-                    if g == 0:
-                        qs = q
-                    if hit:
-                        reached |= 1 << g
-                        manip += self.jlwki(q, base)
+                reached, manip, qs = 0, 0.0, [None, None]
+                for arm in range(narms):
+                    self.arm = arm
+                    lower, upper = self.arm_limits()
+                    lo, hi = np.where(lower < -1e9, -2 * np.pi, lower), np.where(upper > 1e9, 2 * np.pi, upper)
+                    for g in range(1 + gpa):
+                        slot = (3 * arm if two else 0) + g
+                        q0 = lo + (hi - lo) * np.array([u01(seed, stream, T_REST + 8 * slot + d) for d in range(narm)])
+                        tp = (target_pos2 if arm else target_pos) if g == 0 else goals[arm * gpa + g - 1]
+                        tq = target_quat if g == 0 else (goal_quats[g - 1] if goal_quats is not None else None)
+                        q = self.ik(q0, lo, hi, tp, tq, iters=self.xi('TOC_IK_ITERS'), base=base)
+                        pe, oe, orig, _ = self.arm_fk(q, base)
+                        hit = np.sqrt((tp - pe) @ (tp - pe)) < thr
+                        if g == 0 and hit and self.xi('PED_N') > 0:                # the pedestal guard (host/reset_bed.py::_arm_in_pedestal)
+                            pts = orig[2:] + [0.5 * (orig[k] + orig[k + 1]) for k in range(2, narm - 1)] + [pe]
+                            bi = np.array([-base[1][0], -base[1][1], -base[1][2], base[1][3]])
+                            for b in range(self.xi('PED_N')):
+                                bx = self.f[self.x0 + X_['PED_BOX'] + 6 * b:self.x0 + X_['PED_BOX'] + 6 * b + 6].astype(np.float64)
+                                for pt in pts:
+                                    l = qrot(bi, pt - base[0])
+                                    if np.all(l >= bx[:3]) and np.all(l <= bx[3:]):
+                                        hit = False
+                        if tq is not None:
+                            dm, dp = tq - oe, tq + oe
+                            hit = hit and min(np.sqrt(dm @ dm), np.sqrt(dp @ dp)) < thr
+                        if g == 0:
+                            qs[arm] = q
+                        if hit:
+                            reached |= 1 << slot
+                            manip += self.jlwki(q, base)
+                self.arm = 0
                 ngoal = bin(reached).count('1') if (reached & must) == must else -1      # the start goals must be reachable (robot.py:196-200)
                 if best is None or ngoal > best[0] or (ngoal == best[0] and ngoal > 0 and manip > best[1]):
-                    best = (ngoal, manip, base, qs)
+                    best = (ngoal, manip, base, (qs[0], qs[1]) if two else qs[0])
             out = (best[0] > 0, best[2], best[3], rnd + 1, best[0], best[1])
             if best[0] > 0:
                 break
@@ -465,6 +479,9 @@ class ResetOracle:
         er = self.xf('EE_RANGE')
         target_ee = self.xf('EE_TARGET', 3) + np.array([(2 * u(S_EE + k) - 1) * er for k in range(3)])
         toc = self.xf('EE_QUAT', 4)
+        two_arms, best2 = bool(self.xi('FLAGS') & 512), None               # a two-armed robot (arm_manipulation.py:159,165)
+        target_ee2 = self.xf('EE_TARGET2', 3) + np.array([(2 * u(S_EE2 + k) - 1) * er for k in range(3)])
+        self.arm = 0
         n_max = self.xi('IK_RESTARTS') if max_restarts is None else max_restarts
         thr = self.xf('IK_THRESH')
         best, best_d, ok, restarts = None, np.inf, False, 0
@@ -475,6 +492,11 @@ class ResetOracle:
             lower, upper = self.arm_limits()
             base = (self.xf('FALL_PARK', 3), np.array([0, 0, 0, 1.0]))
             best = np.where((lower > -1e9) & (upper < 1e9), 0.5 * (lower + upper), 0.0)
+            if two_arms:
+                self.arm = 1
+                lower, upper = self.arm_limits()
+                best2 = np.where((lower > -1e9) & (upper < 1e9), 0.5 * (lower + upper), 0.0)
+                self.arm = 0
             ok, restarts, best_d, n_max = True, 0, 0.0, 0
         elif mobile:                                                       # a robot on wheels (env.py:282-293, stretch.py:58-62): no IK
             stream = T_STREAM0 + first_restart
@@ -492,7 +514,9 @@ class ResetOracle:
             must = 1
             if self.xi('TOC_GOAL_KIND') == 2:                              # drinking (drinking.py:143): the mouth (position) is a second START goal, the mouth with the
                 goals, gq, must = [target, target], [None, toc], 3         # start pose's end-effector orientation the one further goal
-            ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals, gq, must)
+            ok, base, best, restarts, ngoal, manip = self.toc(seed, first_restart, target_ee, toc, goals, gq, must, target_pos2=target_ee2 if two_arms else None)
+            if two_arms:
+                best, best2 = best
             best_d, n_max = float(ngoal), 0
             toc_info = dict(goals_reached=ngoal, manipulability=manip, base_pos=base[0], base_quat=base[1])
         for r in range(n_max):
@@ -513,6 +537,11 @@ class ResetOracle:
             qfull[d] = min(max(self.rf(d, 'QT0'), self.rf(d, 'LOWER')), self.rf(d, 'UPPER'))
         for k, d in enumerate(ch):
             qfull[d] = best[k]
+        if two_arms:
+            self.arm = 1
+            for k, d in enumerate(self.chain()):
+                qfull[d] = best2[k]
+            self.arm = 0
         if mobile:
             qfull[lift_dof] = lift_q
         for k, j in enumerate(dyn):
@@ -542,6 +571,18 @@ class ResetOracle:
             cp, cq = compose(tp, tq, -qrot(qi, refp), qi)
         if self.tool_body >= 0:
             st[fr(self.tool_body):fr(self.tool_body) + 3], st[fr(self.tool_body) + 3:fr(self.tool_body) + 7] = cp, cq
+        if two_arms:                                                       # tool_left in the left hand (arm_manipulation.py:156)
+            self.arm = 1
+            pe2, oe2 = self.arm_fk(best2, base)[:2]
+            self.arm = 0
+            t2 = self.ti('TOOL2_BODY')
+            tp2, tq2 = compose(pe2, oe2, self.tf('TOOL2_POS', 3), self.tf('TOOL2_QUAT', 4))
+            fo2 = int(self.i[H_OFF_FREE]) + t2 * F['STRIDE']
+            refp2, refq2 = self.f[fo2 + F['REFPOS']:fo2 + F['REFPOS'] + 3].astype(np.float64), self.f[fo2 + F['REFQUAT']:fo2 + F['REFQUAT'] + 4].astype(np.float64)
+            if np.any(refp2 != 0) or refq2[3] != 1:
+                qi2 = np.array([-refq2[0], -refq2[1], -refq2[2], refq2[3]])
+                tp2, tq2 = compose(tp2, tq2, -qrot(qi2, refp2), qi2)
+            st[fr(t2):fr(t2) + 3], st[fr(t2) + 3:fr(t2) + 7] = tp2, tq2
         # bowl (furniture.py:32-34): base frame -> COM frame
         bb = self.xi('BOWL_BODY')
         if bb >= 0:

@@ -196,7 +196,7 @@ def test_other_single_arm_robots(robot):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('robot', ['sawyer', 'jaco', 'panda'])
+@pytest.mark.parametrize('robot', ['sawyer', 'jaco', 'panda', 'pr2', 'baxter'])
 def test_reset_on_the_device_three_models_in_a_row(robot):
     """ArmManipulationEnv.reset through the C ABI (arm_manipulation.py:110-180): agx_sample_reset on the task's handle runs the rag doll's drop
     and 100-step settle (bed_settle), the fall model's sampler and the arm's 100-step fall, then the task's sampler with collision rejection.

@@ -31,12 +31,13 @@ def chain(robot, seed, rag_steps=12, fall_steps=10):
     return sblob, b, fb, rag, dinfo
 
 
-@pytest.mark.parametrize('robot', ['sawyer', pytest.param('jaco', marks=full), pytest.param('panda', marks=full)])
+@pytest.mark.parametrize('robot', ['sawyer', 'pr2', pytest.param('jaco', marks=full), pytest.param('panda', marks=full), pytest.param('baxter', marks=full)])
 def test_fall_record_matches_restatement(robot):
     from emu_lib import Emu
     seed = 7301
     sblob, b, fb, rag, dinfo = chain(robot, seed)
-    assert b.has_reset_generator and b.i[b.h['OFF_RESET'] + L.X_['FLAGS']] == 1 | 16 | 128
+    dual = robot in ('pr2', 'baxter')
+    assert b.has_reset_generator and b.i[b.h['OFF_RESET'] + L.X_['FLAGS']] == 1 | 16 | 128 | (512 if dual else 0)
     assert fb.i[fb.h['OFF_RESET'] + L.X_['FLAGS']] & 256 and fb.param('HUMAN_GRAVITY_Z') == -1.0 and b.param('HUMAN_GRAVITY_Z') == pytest.approx(-9.81)
     st, info = ro.ResetOracle(fb.words).sample(seed, impairment_mode=ro.MODE_NO_TREMOR, settled=rag)
     se, ie = Emu(fb).sample(seed, impairment_mode=ro.MODE_NO_TREMOR, settled=rag)
@@ -61,11 +62,13 @@ def test_fall_record_matches_restatement(robot):
     assert abs(v['q'][0, nr + dyn.index(3)] - min(np.deg2rad(60), hm.upper[3])) < 1e-6 and v['q'][0, nr + dyn.index(6)] == pytest.approx(max(0.0, hm.lower[6]), abs=1e-6)
     assert np.allclose(v['base'][0, :3], PARKED) and np.allclose(v['free'][0, 0, :3], hv['free'][0, 0, :3], atol=2e-5)
     assert abs(abs(float(v['free'][0, 0, 3:7] @ hv['free'][0, 0, 3:7])) - 1.0) < 1e-6                 # the same orientation (q and -q)
+    if dual:                                                                                         # the second scooper in the left hand
+        assert np.allclose(v['free'][0, 1, :3], hv['free'][0, 1, :3], atol=2e-5) and abs(abs(float(v['free'][0, 1, 3:7] @ hv['free'][0, 1, 3:7])) - 1.0) < 1e-6
     assert v['frozen'][0] == 0 and v['human_kp'][0] == pytest.approx(0.05) and v['human_maxf'][0] == pytest.approx(0.01 * info['strength']) and v['total_food'][0] == 1
     assert np.allclose(v['tremor_target'][0], v['q'][0, nr:])
 
 
-@pytest.mark.parametrize('robot', ['sawyer', pytest.param('jaco', marks=full), pytest.param('panda', marks=full)])
+@pytest.mark.parametrize('robot', ['sawyer', 'pr2', pytest.param('jaco', marks=full), pytest.param('panda', marks=full), pytest.param('baxter', marks=full)])
 def test_post_fall_sampler_reads_both_records(robot):
     from emu_lib import Emu
     from oracle_lib import Oracle
@@ -103,3 +106,5 @@ def test_post_fall_sampler_reads_both_records(robot):
     assert list(b.i[x0 + L.X_['TOC_GOAL_LINKS']:x0 + L.X_['TOC_GOAL_LINKS'] + 3]) + [int(b.i[x0 + L.X_['TOC_GOAL_LINK3']])] == [9, 27, 7, 24]
     # the tool sits in the gripper of the placed arm; the end effector reached its start target
     assert np.linalg.norm(v['free'][0, 0, :3] - v['base'][0, :3]) < 1.6
+    if robot in ('pr2', 'baxter'):                      # both start poses reached: the two scoopers near their targets (arm_manipulation.py:158-159)
+        assert np.linalg.norm(v['free'][0, 0, :3] - np.array([-1, -0.3, 0.8])) < 0.35 and np.linalg.norm(v['free'][0, 1, :3] - np.array([-1, 0.7, 0.8])) < 0.35

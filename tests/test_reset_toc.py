@@ -231,10 +231,9 @@ def test_every_feeding_scratch_and_dressing_model_resets_on_the_device():
     for robot in ('jaco', 'panda', 'sawyer', 'baxter', 'pr2', 'stretch'):             # bed bathing: with the rag-doll model attached (tests/test_reset_bed_device.py)
         b = ModelBlob.load('bed_bathing_' + robot)
         assert b.has_reset_generator and _x(b, 'FLAGS', True) & 16
-    for robot in ('sawyer', 'jaco', 'panda'):                                            # two settles (rag doll, then the arm's fall): bits 4 and 7, tests/test_reset_arm_device.py
+    for robot in ('sawyer', 'jaco', 'panda', 'pr2', 'baxter'):                           # two settles (rag doll, then the arm's fall): bits 4 and 7, tests/test_reset_arm_device.py
         b = ModelBlob.load('arm_manipulation_' + robot)
-        assert b.has_reset_generator and _x(b, 'FLAGS', True) == 1 | 16 | 128 and _x(b, 'TOC_NGOALS', True) == 4
-    assert not ModelBlob.load('arm_manipulation_pr2').has_reset_generator               # two arm chains in the base pose search: host-sampled pools
+        assert b.has_reset_generator and _x(b, 'FLAGS', True) == 1 | 16 | 128 | (512 if robot in ('pr2', 'baxter') else 0) and _x(b, 'TOC_NGOALS', True) == 4
 
 
 def test_pedestal_guard_rejects_start_poses_inside_the_boxes():
