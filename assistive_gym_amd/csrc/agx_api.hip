@@ -29,7 +29,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 extern "C" __global__ void __launch_bounds__(256)
 agx_forget_warm_kernel(float* scratch, int scr_words, int word, const uint8_t* mask, int n_envs) {
   const int env = blockIdx.x * 256 + threadIdx.x;
-  if (env < n_envs && (!mask || mask[env])) ((int*)scratch)[(size_t)env * scr_words + word] = 0;
+  if (env < n_envs && (!mask || mask[env])) { int* m = (int*)scratch + (size_t)env * scr_words + word; m[0] = 0; m[1] = 0; }      // META_NWARM, META_NMAN
 }
 
 // done envs take a fresh record from the pool; coalesced copy, one wave per env

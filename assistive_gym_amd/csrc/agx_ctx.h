@@ -147,10 +147,14 @@ static_assert(BR_MAX_UNITS < (1 << 16), "first unit of a row: 16 bits of the hea
 // warm-start memory (AGX_P_WARMSTART): per contact of the last solved substep its key -- collider a | collider b << 9 | ordinal inside the
 // pair << 18 -- and its solved normal impulse; META_NWARM entries, 0 = none / invalidated
 constexpr int SCR_WARM = 2 * MAX_CON, SCR_O_WARM = SCR_O_QPT + SCR_QPT;
-constexpr int SCR_O_BRH = SCR_O_WARM + SCR_WARM, SCR_O_BRF = SCR_O_BRH + SCR_BRH, SCR_O_BRE = SCR_O_BRF + SCR_BRF;
+// persistent manifold (AGX_P_MANIFOLD, agx_env.h manifold_update): META_NMAN cached points of MP_STRIDE words -- key (collider a | collider b << 9),
+// local point on A (3), on B (3), world normal (3), distance, friction -- in cache order
+constexpr int MP_STRIDE = 12, MP_KEY = 0, MP_LA = 1, MP_LB = 4, MP_N = 7, MP_DIST = 10, MP_MU = 11;
+constexpr int SCR_MAN = MP_STRIDE * MAX_CON, SCR_O_MAN = SCR_O_WARM + SCR_WARM;
+constexpr int SCR_O_BRH = SCR_O_MAN + SCR_MAN, SCR_O_BRF = SCR_O_BRH + SCR_BRH, SCR_O_BRE = SCR_O_BRF + SCR_BRF;
 static_assert(SCR_O_BRH % 2 == 0 && SCR_O_BRE % 2 == 0 && SCR_O_BRF % 4 == 0, "block rows are read as 8-byte words");
 constexpr int SCR_WORDS = SCR_O_BRE + SCR_BRE;
-constexpr int META_NBENT = 7, META_NWARM = 8;
+constexpr int META_NBENT = 7, META_NWARM = 8, META_NMAN = 9;      // (NWARM and NMAN are cleared together: agx_forget_warm_kernel)
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
 constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)

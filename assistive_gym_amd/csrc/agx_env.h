@@ -294,9 +294,9 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
 //          from L2, integration, mouth-target update -> state
 //   finish (once per step): forces, observation, food state machine, preferences, reward, done.
 // ============================================================================================
-struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; float* brf; float* warm; };
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; float* brf; float* warm; float* man; };
 AGX_DEV Scratch scratch_of(float* base) {
-  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE; s.brf = base + SCR_O_BRF; s.warm = base + SCR_O_WARM;
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE; s.brf = base + SCR_O_BRF; s.warm = base + SCR_O_WARM; s.man = base + SCR_O_MAN;
   return s;
 }
 
@@ -327,6 +327,120 @@ AGX_DEV void warm_remember(const Ctx& c, const Scratch& scr, int lane) {
   const int key = warm_key(c, lane);
   if (lane < c.ncon) { ((int*)scr.warm)[lane] = key; scr.warm[MAX_CON + lane] = c.gcon[CON_STRIDE * lane + C_LAM]; }
   if (lane == 0) scr.meta[META_NWARM] = c.ncon;
+}
+
+// ---- persistent contact manifold (AGX_P_MANIFOLD, a [BULLET-UNVERIFIED] switch, default off; include/agx_blob.h) ---------------------------
+// Build kernel, after collide(): the substep's GJK contacts (c.gcon[0 .. c.ncon)) update the cached points of the environment (scratch record,
+// lane = cached point while they are in registers) and the contact list is rebuilt from the cache.  Contacts on a static world box keep their
+// face manifold and pass through.  Mirrors manifold_update() of oracle/agx_oracle.c step by step (same order, same tie breaks).
+struct MPoint { int key; v3 la, lb, n; float dist, mu; };
+AGX_DEV MPoint mp_bcast(const MPoint& e, int src) {
+  MPoint r; r.key = wave_bcast_i(e.key, src);
+  r.la = mk3(wave_bcast(e.la.x, src), wave_bcast(e.la.y, src), wave_bcast(e.la.z, src)); r.lb = mk3(wave_bcast(e.lb.x, src), wave_bcast(e.lb.y, src), wave_bcast(e.lb.z, src));
+  r.n = mk3(wave_bcast(e.n.x, src), wave_bcast(e.n.y, src), wave_bcast(e.n.z, src)); r.dist = wave_bcast(e.dist, src); r.mu = wave_bcast(e.mu, src);
+  return r;
+}
+AGX_DEV_NOINLINE void manifold_update(Ctx& c, const Scratch& scr) {
+  const int lane = c.lane;
+  const float brk = PRM(c, AGX_P_CONTACT_BREAK), slack = PRM(c, AGX_P_CONTACT_SLACK);
+  int maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (maxc > MAX_CON) maxc = MAX_CON;
+  float* MP = scr.man;
+  int nm = scr.meta[META_NMAN]; if (nm > MAX_CON) nm = MAX_CON;
+  // (1) refresh (lane = cached point), order-preserving compaction through the scratch record
+  MPoint e; e.key = -1; e.la = mk3(0, 0, 0); e.lb = e.la; e.n = e.la; e.dist = 0.f; e.mu = 0.f;
+  bool keep = false;
+  if (lane < nm) {
+    const float* q = MP + MP_STRIDE * lane;
+    e.key = ((const int*)q)[MP_KEY]; e.la = ld3(q + MP_LA); e.lb = ld3(q + MP_LB); e.n = ld3(q + MP_N); e.mu = q[MP_MU];
+    m3 Ra, Rb; v3 oa, ob; body_xf(c, CLI(c, e.key & 511, AGX_C_BODY), Ra, oa); body_xf(c, CLI(c, (e.key >> 9) & 511, AGX_C_BODY), Rb, ob);
+    const v3 pa = mul(Ra, e.la) + oa, pb = mul(Rb, e.lb) + ob;
+    e.dist = dot(pa - pb, e.n);
+    const v3 drift = pb - (pa - e.dist * e.n);
+    keep = e.dist <= brk && dot(drift, drift) <= brk * brk;
+  }
+  wave_sync();
+  {
+    const uint64_t km = wave_ballot(keep);
+    if (keep) { float* q = MP + MP_STRIDE * wave_rank(km); ((int*)q)[MP_KEY] = e.key; st3(q + MP_LA, e.la); st3(q + MP_LB, e.lb); st3(q + MP_N, e.n); q[MP_DIST] = e.dist; q[MP_MU] = e.mu; }
+    nm = popc64(km);
+  }
+  wave_sync();
+  e.key = -1;
+  if (lane < nm) { const float* q = MP + MP_STRIDE * lane; e.key = ((const int*)q)[MP_KEY]; e.la = ld3(q + MP_LA); e.lb = ld3(q + MP_LB); e.n = ld3(q + MP_N); e.dist = q[MP_DIST]; e.mu = q[MP_MU]; }
+  // (2) merge the substep's contacts, one after the other (every lane reads the same record)
+  const int nnew = c.ncon;
+  for (int i = 0; i < nnew; i++) {
+    const float* k = c.gcon + CON_STRIDE * i; const int* ki = (const int*)k;
+    const int ca = ki[C_CA], cb = ki[C_CB];
+    if (face_box(c, cb)) continue;
+    MPoint q; q.key = ca | (cb << 9); q.n = ld3(k + C_N); q.dist = k[C_DIST]; q.mu = k[C_MU];
+    { m3 Ra, Rb; v3 oa, ob; body_xf(c, ki[C_BA], Ra, oa); body_xf(c, ki[C_BB], Rb, ob); q.la = tmul(Ra, ld3(k + C_PA) - oa); q.lb = tmul(Rb, ld3(k + C_PB) - ob); }
+    const bool match = lane < nm && e.key == q.key;
+    const v3 dl = e.la - q.la; const float d2 = dot(dl, dl);
+    const bool close = match && d2 < brk * brk;
+    const float dmin = wave_min(close ? d2 : 3.0e38f);
+    int target = -1;
+    const uint64_t mm = wave_ballot(match);
+    if (dmin < 3.0e38f) target = ffs64(wave_ballot(close && d2 == dmin));      // getCacheEntry: the nearest cached point (lowest index on ties)
+    else if (popc64(mm) < 4) { if (nm < MAX_CON) { target = nm; nm++; } }       // append
+    else {
+      // four cached (sortCachedPoints): the deepest of the five stays, the replacement leaves the largest area
+      int idx[4]; uint64_t t = mm; for (int j = 0; j < 4; j++) { idx[j] = ffs64(t); t &= t - 1ull; }
+      const MPoint p0 = mp_bcast(e, idx[0]), p1 = mp_bcast(e, idx[1]), p2 = mp_bcast(e, idx[2]), p3 = mp_bcast(e, idx[3]);
+      int deepest = -1; float pen = q.dist;
+      if (p0.dist < pen) { deepest = 0; pen = p0.dist; }
+      if (p1.dist < pen) { deepest = 1; pen = p1.dist; }
+      if (p2.dist < pen) { deepest = 2; pen = p2.dist; }
+      if (p3.dist < pen) { deepest = 3; pen = p3.dist; }
+      float res[4] = {0.f, 0.f, 0.f, 0.f};
+      if (deepest != 0) { const v3 x = cross(q.la - p1.la, p3.la - p2.la); res[0] = dot(x, x); }
+      if (deepest != 1) { const v3 x = cross(q.la - p0.la, p3.la - p2.la); res[1] = dot(x, x); }
+      if (deepest != 2) { const v3 x = cross(q.la - p0.la, p3.la - p1.la); res[2] = dot(x, x); }
+      if (deepest != 3) { const v3 x = cross(q.la - p0.la, p2.la - p1.la); res[3] = dot(x, x); }
+      int bi = -1; float bv = -3.0e38f;
+      for (int j = 0; j < 4; j++) if (fabsf(res[j]) > bv) { bv = fabsf(res[j]); bi = j; }
+      target = idx[bi];
+    }
+    if (lane == target) e = q;
+  }
+  // (3) the contact list: face-manifold contacts in place, every pair of the substep's contacts with its cached points in cache order, then the
+  // cached pairs without a new point; a cached point becomes a contact when its predicted gap is below the slack
+  bool live = false; v3 wpa = mk3(0, 0, 0), wpb = wpa; int eba = 0, ebb = 0;
+  if (lane < nm) {
+    eba = CLI(c, e.key & 511, AGX_C_BODY); ebb = CLI(c, (e.key >> 9) & 511, AGX_C_BODY);
+    m3 Ra, Rb; v3 oa, ob; body_xf(c, eba, Ra, oa); body_xf(c, ebb, Rb, ob);
+    wpa = mul(Ra, e.la) + oa; wpb = mul(Rb, e.lb) + ob;
+    const v3 vr = point_velocity(c, eba, wpa) - point_velocity(c, ebb, wpb);
+    live = e.dist + dot(vr, e.n) * c.dt < slack;
+  }
+  float rec[CON_STRIDE];                                       // lane i < nnew: the i-th contact of the substep, kept while the list is rewritten
+  for (int w = 0; w < CON_STRIDE; w++) rec[w] = lane < nnew ? c.gcon[CON_STRIDE * lane + w] : 0.f;
+  int my_face_slot = -1, out_slot = -1, no = 0, overflow = 0;
+  bool used = false;
+  for (int i = 0; i <= nnew; i++) {
+    int key_i = -1; bool face = false;
+    if (i < nnew) { const int* ki = (const int*)(c.gcon + CON_STRIDE * i); key_i = ki[C_CA] | (ki[C_CB] << 9); face = face_box(c, ki[C_CB]); }
+    if (face) { if (no < maxc) { if (lane == i) my_face_slot = no; no++; } else overflow++; continue; }
+    const bool sel = lane < nm && !used && (i == nnew || e.key == key_i);
+    used = used || sel;
+    const bool em = sel && live;
+    const uint64_t m = wave_ballot(em);
+    const int slot = no + wave_rank(m), cnt = popc64(m);
+    if (em && slot < maxc) out_slot = slot;
+    const int room = maxc - no;
+    if (cnt > room) { overflow += cnt - room; no = maxc; } else no += cnt;
+  }
+  wave_sync();
+  if (my_face_slot >= 0) for (int w = 0; w < CON_STRIDE; w++) c.gcon[CON_STRIDE * my_face_slot + w] = rec[w];
+  if (out_slot >= 0) {
+    float* o = c.gcon + CON_STRIDE * out_slot; int* oi = (int*)o;
+    oi[C_CA] = e.key & 511; oi[C_CB] = (e.key >> 9) & 511; oi[C_BA] = eba; oi[C_BB] = ebb;
+    st3(o + C_PA, wpa); st3(o + C_PB, wpb); st3(o + C_N, e.n); o[C_DIST] = e.dist; o[C_MU] = e.mu; o[C_LAM] = 0.f;
+  }
+  if (lane < nm) { float* q = MP + MP_STRIDE * lane; ((int*)q)[MP_KEY] = e.key; st3(q + MP_LA, e.la); st3(q + MP_LB, e.lb); st3(q + MP_N, e.n); q[MP_DIST] = e.dist; q[MP_MU] = e.mu; }
+  if (lane == 0) scr.meta[META_NMAN] = nm;
+  c.ncon = no; c.overflow += overflow;
+  wave_sync();
 }
 
 // build: `gaction` non-null on the first substep of an env.step() (take_step, env.py:174-222)
@@ -392,6 +506,9 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   aba_and_minv(c); AGX_TICK(1)
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
+#ifndef AGX_NO_MANIFOLD     // build-time knob for same-box A/B runs: the default path with and without the (not inlined) manifold stage in the kernel
+  if (PRM(c, AGX_P_MANIFOLD) > 0.f) manifold_update(c, scr);
+#endif
   warm_seed(c, scr, lane);
   build_rows(c); AGX_TICK(4)
   if (USE_SOLVE4 && lane < c.nfree) {      // S = (M^-1)^(1/2) of a free body, for the packed solve kernel's epilogue: sqrt(1/m), R sqrt(I_body^-1) R^T

@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 13
+#define AGX_BLOB_VERSION 14
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -125,7 +125,18 @@ enum {
                             a robot link RESTING on the person sits at dist ~ 0 and carries newtons (wiping workload, f64: total_force_on_human
                             5.1404 N with the rule vs 5.1480 N plain, 1.5e-3 relative) -- every force the tasks report is a force on the person,
                             so all of them come from plain sweeps.  0 = the rule applies regardless (round 3) */
-  AGX_P_COUNT = 25
+  AGX_P_MANIFOLD = 25,   /* > 0: persistent contact manifold for the hull pairs that are not resting on a static world box (those have the face
+                            manifold): up to 4 points per collider pair live across substeps and steps (btPersistentManifold [BULLET-UNVERIFIED],
+                            default off).  Per substep: (1) every cached point is refreshed -- world positions from its two body-local points,
+                            distance along its stored world normal -- and dropped when that distance or its lateral drift exceeds the
+                            contact-break distance (refreshContactPoints); (2) the substep's GJK contact of a pair replaces the cached point
+                            whose local point on A is nearest within the break distance (getCacheEntry / replaceContactPoint), else it is
+                            appended, else -- four cached -- it replaces the point whose removal keeps the largest area while the deepest point
+                            stays (sortCachedPoints); (3) every cached point whose predicted gap is below the slack becomes a contact: the
+                            pairs of the substep's own contacts in their order, each with its cached points in cache order, then the cached
+                            pairs without a new point.  The memory (64 points per environment) lives with the warm-start memory in the
+                            scratch record and is cleared with it.  Oracle and device; agx_env.h manifold_*                               */
+  AGX_P_COUNT = 26
 };
 
 /* ---- ROBOT: one record per moving link, stride AGX_R_STRIDE ------------------------------- */

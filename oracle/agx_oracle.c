@@ -777,6 +777,102 @@ static void collide(sim_t* s) {
   }
 }
 
+/* persistent manifold of the [BULLET-UNVERIFIED] switch AGX_P_MANIFOLD (include/agx_blob.h): cached contact points of one environment, in
+ * cache order; cleared together with the warm-start memory */
+#define MAXMP 64
+typedef struct { int ca, cb; double la[3], lb[3], n[3], dist, mu; } mpoint_t;
+static int g_mp_n = 0; static mpoint_t g_mp[MAXMP];
+static int g_mp_stats[4];      /* replaced (nearest), appended, replaced by the area rule, dropped at the refresh -- since the last agxo_manifold_stats() */
+/* test hooks: the cache as rows of 12 doubles {collider a, collider b, local point on A (3), on B (3), world normal (3), friction} */
+int agxo_manifold_get(double* out, int max_out) {
+  int n = g_mp_n < max_out ? g_mp_n : max_out;
+  for (int p = 0; p < n; p++) { double* o = out + 12 * p; o[0] = g_mp[p].ca; o[1] = g_mp[p].cb; memcpy(o + 2, g_mp[p].la, 24); memcpy(o + 5, g_mp[p].lb, 24); memcpy(o + 8, g_mp[p].n, 24); o[11] = g_mp[p].mu; }
+  return n;
+}
+void agxo_manifold_set(const double* in, int n) {
+  g_mp_n = n < MAXMP ? n : MAXMP;
+  for (int p = 0; p < g_mp_n; p++) { const double* o = in + 12 * p; g_mp[p].ca = (int)o[0]; g_mp[p].cb = (int)o[1]; memcpy(g_mp[p].la, o + 2, 24); memcpy(g_mp[p].lb, o + 5, 24); memcpy(g_mp[p].n, o + 8, 24); g_mp[p].mu = o[11]; g_mp[p].dist = 0; }
+}
+void agxo_manifold_stats(int* out4) { memcpy(out4, g_mp_stats, sizeof g_mp_stats); memset(g_mp_stats, 0, sizeof g_mp_stats); }
+/* AGX_P_MANIFOLD: refresh the cached points, merge the substep's GJK contacts into them, rebuild the contact list (see include/agx_blob.h) */
+static int mp_face_pair(const agxo_model* m, int cb) {
+  return CI(m, cb, AGX_C_BODY) == AGX_BODY_WORLD && CI(m, cb, AGX_C_NVERT) == 8 && (CI(m, cb, AGX_C_TAG) == AGX_TAG_TABLE || CI(m, cb, AGX_C_TAG) == AGX_TAG_PLANE);
+}
+static void xf_apply_inv(const xf_t* X, const double* w, double* o) {
+  double d[3]; sub3(w, X->p, d);
+  for (int k = 0; k < 3; k++) o[k] = X->R[k] * d[0] + X->R[3 + k] * d[1] + X->R[6 + k] * d[2];
+}
+static void manifold_update(sim_t* s) {
+  const agxo_model* m = s->m;
+  const double brk = PARAM(m, AGX_P_CONTACT_BREAK), slack = PARAM(m, AGX_P_CONTACT_SLACK), dt = m->dt;
+  int maxc = (int)PARAM(m, AGX_P_MAX_CONTACTS); if (maxc > MAXC) maxc = MAXC;
+  /* (1) refresh */
+  int n = 0;
+  for (int p = 0; p < g_mp_n; p++) {
+    mpoint_t q = g_mp[p];
+    double pa[3], pb[3], d[3];
+    xf_apply(body_xf(s, CI(m, q.ca, AGX_C_BODY)), q.la, pa); xf_apply(body_xf(s, CI(m, q.cb, AGX_C_BODY)), q.lb, pb);
+    sub3(pa, pb, d);
+    q.dist = dot3(d, q.n);
+    if (q.dist > brk) { g_mp_stats[3]++; continue; }
+    double drift[3]; for (int k = 0; k < 3; k++) drift[k] = pb[k] - (pa[k] - q.n[k] * q.dist);
+    if (dot3(drift, drift) > brk * brk) { g_mp_stats[3]++; continue; }
+    g_mp[n++] = q;
+  }
+  g_mp_n = n;
+  /* (2) merge the substep's contacts (not those of the face manifold) */
+  for (int c = 0; c < s->ncon; c++) {
+    const contact_t* k = &s->con[c];
+    if (mp_face_pair(m, k->cb)) continue;
+    mpoint_t q; q.ca = k->ca; q.cb = k->cb; memcpy(q.n, k->n, 24); q.dist = k->dist; q.mu = k->mu;
+    xf_apply_inv(body_xf(s, k->ba), k->pa, q.la); xf_apply_inv(body_xf(s, k->bb), k->pb, q.lb);
+    int idx[4], cnt = 0, nearest = -1; double shortest = brk * brk;
+    for (int p = 0; p < g_mp_n; p++) {
+      if (g_mp[p].ca != q.ca || g_mp[p].cb != q.cb) continue;
+      double d[3]; sub3(g_mp[p].la, q.la, d); const double d2 = dot3(d, d);
+      if (d2 < shortest) { shortest = d2; nearest = p; }
+      if (cnt < 4) idx[cnt] = p;
+      cnt++;
+    }
+    if (nearest >= 0) { g_mp[nearest] = q; g_mp_stats[0]++; continue; }
+    if (cnt < 4) { if (g_mp_n < MAXMP) g_mp[g_mp_n++] = q; g_mp_stats[1]++; continue; }
+    g_mp_stats[2]++;
+    /* four cached: sortCachedPoints -- the deepest of the five stays, the replacement leaves the largest area */
+    int deepest = -1; double pen = q.dist;
+    for (int i = 0; i < 4; i++) if (g_mp[idx[i]].dist < pen) { deepest = i; pen = g_mp[idx[i]].dist; }
+    double res[4] = {0, 0, 0, 0};
+    static const int other[4][3] = {{1, 3, 2}, {0, 3, 2}, {0, 3, 1}, {0, 2, 1}};     /* res_i = |(new - p[o0]) x (p[o1] - p[o2])|^2 */
+    for (int i = 0; i < 4; i++) {
+      if (deepest == i) continue;
+      double a[3], b[3], x[3];
+      sub3(q.la, g_mp[idx[other[i][0]]].la, a); sub3(g_mp[idx[other[i][1]]].la, g_mp[idx[other[i][2]]].la, b); cross3(a, b, x);
+      res[i] = dot3(x, x);
+    }
+    int bi = -1; double bv = -1e300;
+    for (int i = 0; i < 4; i++) if (fabs(res[i]) > bv) { bv = fabs(res[i]); bi = i; }
+    g_mp[idx[bi]] = q;
+  }
+  /* (3) the contact list */
+  contact_t out[MAXC]; int no = 0, overflow = 0;
+  unsigned char used[MAXMP]; memset(used, 0, sizeof used);
+  for (int c = 0; c <= s->ncon; c++) {
+    const contact_t* k = c < s->ncon ? &s->con[c] : NULL;
+    if (k && mp_face_pair(m, k->cb)) { if (no < maxc) out[no++] = *k; else overflow++; continue; }
+    for (int p = 0; p < g_mp_n; p++) {
+      if (used[p] || (k && (g_mp[p].ca != k->ca || g_mp[p].cb != k->cb))) continue;      /* k == NULL: the cached pairs without a new point */
+      used[p] = 1;
+      const mpoint_t* q = &g_mp[p];
+      contact_t e; e.ca = q->ca; e.cb = q->cb; e.ba = CI(m, q->ca, AGX_C_BODY); e.bb = CI(m, q->cb, AGX_C_BODY);
+      xf_apply(body_xf(s, e.ba), q->la, e.pa); xf_apply(body_xf(s, e.bb), q->lb, e.pb);
+      memcpy(e.n, q->n, 24); e.dist = q->dist; e.mu = q->mu; e.lambda_n = 0; memset(e.t1, 0, sizeof e.t1);
+      double va[3], vb[3], vr[3]; point_velocity(s, e.ba, e.pa, va); point_velocity(s, e.bb, e.pb, vb); sub3(va, vb, vr);
+      if (!(e.dist + dot3(vr, e.n) * dt < slack)) continue;
+      if (no < maxc) out[no++] = e; else overflow++;
+    }
+  }
+  memcpy(s->con, out, sizeof(contact_t) * no); s->ncon = no; s->contact_overflow += overflow;
+}
+
 /* ------------------------------------------------------------------------------------ rows */
 /* Jacobian contribution of a unit force `f` (and unit torque `t`) applied on body `code` at world
  * point x (lever arms about the world origin for links, about the COM for free bodies). */
@@ -850,7 +946,7 @@ static int row_art_entries(const sim_t* s, const row_t* r) {
 /* warm-start memory of the [BULLET-UNVERIFIED] switch AGX_P_WARMSTART: normal impulses of the last substep that was solved, by
  * (collider a, collider b, ordinal inside the pair); one environment at a time (the sensitivity study), cleared by agxo_warm_clear() */
 static int g_warm_n = 0, g_warm_key[MAXC][3]; static double g_warm_lam[MAXC];
-void agxo_warm_clear(void) { g_warm_n = 0; }
+void agxo_warm_clear(void) { g_warm_n = 0; g_mp_n = 0; }
 static void build_rows(sim_t* s) {
   const agxo_model* m = s->m; int n = s->ndof;
   double dt = m->dt, erp = PARAM(m, AGX_P_ERP), cerp = PARAM(m, AGX_P_CONTACT_ERP);
@@ -1366,6 +1462,7 @@ static void substep_h(sim_t* s, int hooks) {
     for (int k = 0; k < 3; k++) s->vel[o + 3 + k] = w[k] + dt * (acc[k] - sa * w[k]);
   }
   collide(s);
+  if (PARAM(m, AGX_P_MANIFOLD) > 0) manifold_update(s);
   build_rows(s);
   double dv[NVMAX];
   pgs(s, dv);

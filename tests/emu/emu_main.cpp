@@ -54,7 +54,20 @@ static int run_wave(float* lds, size_t lds_words, std::function<void(int)> body)
 // the scratch record of agx_emu_run's environment persists between calls, like the device's (the warm-start memory of AGX_P_WARMSTART
 // lives in it); agx_emu_forget_warm() = what agx_set_state / the resets do to it
 static float g_scratch[agx::SCR_WORDS];
-extern "C" void agx_emu_forget_warm() { ((int*)g_scratch)[agx::SCR_O_META + agx::META_NWARM] = 0; }
+extern "C" void agx_emu_forget_warm() { ((int*)g_scratch)[agx::SCR_O_META + agx::META_NWARM] = 0; ((int*)g_scratch)[agx::SCR_O_META + agx::META_NMAN] = 0; }
+// test hooks of the persistent manifold: the cache of the emulated environment's scratch record, rows as in oracle_lib.Oracle.manifold_get
+extern "C" int agx_emu_manifold_get(double* out, int max_out) {
+  int n = ((int*)g_scratch)[agx::SCR_O_META + agx::META_NMAN]; if (n > max_out) n = max_out;
+  for (int p = 0; p < n; p++) { const float* q = g_scratch + agx::SCR_O_MAN + agx::MP_STRIDE * p; double* o = out + 12 * p; const int key = ((const int*)q)[agx::MP_KEY];
+    o[0] = key & 511; o[1] = (key >> 9) & 511; for (int k = 0; k < 3; k++) { o[2 + k] = q[agx::MP_LA + k]; o[5 + k] = q[agx::MP_LB + k]; o[8 + k] = q[agx::MP_N + k]; } o[11] = q[agx::MP_MU]; }
+  return n;
+}
+extern "C" void agx_emu_manifold_set(const double* in, int n) {
+  if (n > agx::MAX_CON) n = agx::MAX_CON;
+  ((int*)g_scratch)[agx::SCR_O_META + agx::META_NMAN] = n;
+  for (int p = 0; p < n; p++) { float* q = g_scratch + agx::SCR_O_MAN + agx::MP_STRIDE * p; const double* o = in + 12 * p;
+    ((int*)q)[agx::MP_KEY] = (int)o[0] | ((int)o[1] << 9); for (int k = 0; k < 3; k++) { q[agx::MP_LA + k] = (float)o[2 + k]; q[agx::MP_LB + k] = (float)o[5 + k]; q[agx::MP_N + k] = (float)o[8 + k]; } q[agx::MP_DIST] = 0.f; q[agx::MP_MU] = (float)o[11]; }
+}
 extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
                            float* info, float* debug, int mode, int nsettle) {
   static float lds[(agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS) + agx::LDS_SOLVE4_WORDS];

@@ -80,6 +80,15 @@ class Emu:
         assert rc == 0, 'wave emulator reported divergent control flow'
         return obs, float(rew[0]), bool(done[0]), info, dbg
 
+    def manifold_get(self):
+        out = np.zeros((64, 12))
+        self.L.agx_emu_manifold_get.restype = C.c_int
+        return out[:self.L.agx_emu_manifold_get(_p(out), C.c_int(64))].copy()
+
+    def manifold_set(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        self.L.agx_emu_manifold_set(_p(rows), C.c_int(len(rows)))
+
     def forget_warm(self):
         """the warm-start memory (AGX_P_WARMSTART) of the emulated environment's scratch record: cleared, as agx_set_state / the resets do"""
         self.L.agx_emu_forget_warm()

@@ -88,6 +88,22 @@ class Oracle:
         n = self.L.agxo_cloth_contacts(_p(out), C.c_int(max_out))
         return out[:min(n, max_out)]
 
+    def manifold_get(self):
+        """the cached points: rows {collider a, collider b, local point on A (3), on B (3), world normal (3), friction}"""
+        out = np.zeros((64, 12))
+        self.L.agxo_manifold_get.restype = C.c_int
+        return out[:self.L.agxo_manifold_get(_p(out), C.c_int(64))].copy()
+
+    def manifold_set(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        self.L.agxo_manifold_set(_p(rows), C.c_int(len(rows)))
+
+    def manifold_stats(self):
+        """AGX_P_MANIFOLD: [replaced (nearest), appended, replaced by the area rule, dropped at the refresh] since the last call"""
+        out = np.zeros(4, dtype=np.int32)
+        self.L.agxo_manifold_stats(_p(out))
+        return out
+
     def forget_warm(self):
         """the process-wide warm-start memory of the AGX_P_WARMSTART switch (one environment at a time): cleared"""
         self.L.agxo_warm_clear()

@@ -491,3 +491,107 @@ def test_second_friction_direction_matches_the_oracle(blob, path):
     # three rows per contact instead of two next to the same non-contact rows (FeedingJaco's 160-row budget then holds 47 contacts, not 53)
     assert all(r2 - 3 * n2 == r1 - 2 * n1 for r2, n2, r1, n1 in rows[:1]) and any(n2 > 0 for _, n2, _, _ in rows), rows
     assert differs > 1e-7, differs
+
+
+@pytest.mark.parametrize('scene', ['feeding', 'wiping', 'scratching'])
+def test_persistent_manifold_matches_the_oracle(blob, scene):
+    """AGX_P_MANIFOLD (a [BULLET-UNVERIFIED] convention: btPersistentManifold, default off) on the kernel sources: cached contact points of the
+    hull pairs live across substeps and steps in the scratch record -- refreshed, merged with the substep's GJK contacts (nearest replaces,
+    append, or the area rule when four are cached), and the contact list is rebuilt from them.  Against the oracle's switch over consecutive
+    steps (the memory persists on both sides); contact and row counts must agree exactly, and the switch must change the result."""
+    import os, sys
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    from assistive_gym_amd.blob import ModelBlob
+    steps = 4
+    if scene == 'feeding':
+        b0 = blob
+        st, _ = make_states(b0, 1, seed=3001)
+        s = st[0].copy(); Oracle(b0).settle(s, 25)
+        scale = 1.0
+    elif scene == 'wiping':
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import wiping_pool
+        b0 = ModelBlob.load('bed_bathing_sawyer')
+        s = wiping_pool(b0, 4, 6006)[3].copy(); b0.view(s[None])['iteration'][0] = 0
+        scale = 0.15
+    else:
+        d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'scratch_sawyer_parallel_edge_case.npz'))
+        b0 = ModelBlob.load('scratch_itch_sawyer'); s = d['start'].copy(); scale = 0.1
+    b = b0.set_param('MANIFOLD', 1.0)
+    o, e, plain = Oracle(b), Emu(b), Oracle(b0)
+    o.forget_warm(); e.forget_warm(); o.manifold_stats()
+    so, se, sp = s.copy(), s.copy(), s.copy()
+    rng = np.random.RandomState(5)
+    differs, more = 0.0, 0
+    f = b.obs_dim_robot - 1
+    for k in range(steps):
+        a = (rng.uniform(-1, 1, b.act_dim) * scale).astype(np.float32)
+        o_obs, o_rew, _, o_info = o.step(so, a)
+        obs, rew, _, info, _ = e.step(se, a)
+        p_info = plain.step(sp, a)[3]
+        assert info[6] == o_info[6] and info[7] == o_info[7], (scene, k, info, o_info)
+        more += int(o_info[6] > p_info[6])
+        tol = 2e-5 if scene != 'feeding' else 1e-4
+        assert np.abs(np.delete(obs - o_obs, f)).max() < tol and abs(rew - o_rew) < tol * max(1.0, abs(o_rew)) + 0.06 * 1e-2, (scene, k, np.abs(obs - o_obs).max())
+        assert abs(obs[f] - o_obs[f]) <= max(1e-3 * max(1.0, abs(o_obs[f])), 1e-2) and abs(info[0] - o_info[0]) <= max(1e-3 * max(1.0, abs(o_info[0])), 1e-2), (scene, k, obs[f], o_obs[f])
+        differs = max(differs, float(np.abs(so - sp)[:b.h['S_ENV']].max()))
+        se[:] = so; sp[:] = so
+    assert differs > 1e-7 and (more > 0 or scene == 'wiping'), (differs, more)      # (the wiping steps end with as many contacts, at other points)
+    stats = o.manifold_stats()
+    print('%s: manifold points replaced %d, appended %d, replaced by the area rule %d, dropped at the refresh %d' % ((scene,) + tuple(int(x) for x in stats)))
+    assert stats[0] > 0 and stats[1] > 0 and (scene != 'wiping' or stats[3] > 0), stats          # (the pad slides: points drift out and are dropped)
+    o.forget_warm()
+
+
+def test_persistent_manifold_area_rule():
+    """The fifth point of a pair (sortCachedPoints): colliders of the scenes here are smaller than the 2 cm within which a new point REPLACES its
+    nearest cached neighbour, so the rule is reached through the test hooks -- four cached points of the scratcher-on-forearm pair placed 3 cm
+    around the real contact, at its distance and normal (they pass the refresh: no drift), then one step.  Oracle and kernel sources must
+    end with the same five-minus-one points, and the rule must have fired."""
+    import os
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    from assistive_gym_amd.blob import ModelBlob
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'scratch_sawyer_parallel_edge_case.npz'))
+    b = ModelBlob.load('scratch_itch_sawyer').set_param('MANIFOLD', 1.0).set_param('FRAME_SKIP', 1.0)
+    o, e = Oracle(b), Emu(b)
+    zero = np.zeros(b.act_dim, dtype=np.float32)
+    o.forget_warm(); e.forget_warm(); o.manifold_stats()
+    s0 = d['start'].copy()
+    so = s0.copy(); o.step(so, zero)
+    real = o.manifold_get()
+    assert len(real) >= 1
+    p = real[0]
+    # four more points of the pair: 3 cm from the real one along the local x / y axes of A, each with the point of B that lies at the real
+    # contact's distance along its normal (no drift at the refresh) -- B's frame (a link of the human's arm) from the oracle's kinematics, A's
+    # (the tool, a free body) from the record, both AFTER the step: the refresh of the next substep sees those poses
+    from assistive_gym_amd.model import xform as X
+    from assistive_gym_amd.model import compiler as L
+    ca, cb = int(p[0]), int(p[1])
+    ba, bb = b.collider(ca)['body'], b.collider(cb)['body']
+    assert L.BODY_FREE0 <= ba < L.BODY_HUMAN0 and 0 <= bb < L.BODY_ROBOT_BASE
+    vo = b.view(so.reshape(1, -1))
+    pa_, qa_ = vo['free'][0, ba - L.BODY_FREE0, :3].astype(np.float64), vo['free'][0, ba - L.BODY_FREE0, 3:7].astype(np.float64)
+    Ra = X.quat_to_mat(qa_)
+    lpos, lrot = o.fk(so)
+    pb_, Rb = lpos[bb], lrot[bb]
+    n = p[8:11]
+    dist0 = float((Ra @ p[2:5] + pa_ - (Rb @ p[5:8] + pb_)) @ n)
+    rows = []
+    for off in ([0.03, 0, 0], [-0.03, 0, 0], [0, 0.03, 0], [0, -0.03, 0]):
+        q = p.copy(); q[2:5] += off
+        wa = Ra @ q[2:5] + pa_
+        q[5:8] = Rb.T @ (wa - n * dist0 - pb_)
+        rows.append(q)
+    rows = np.array(rows)
+    o.manifold_set(rows); e.manifold_set(rows); o.manifold_stats()
+    s1, s2 = so.copy(), so.copy()
+    o_out = o.step(s1, zero); e_out = e.step(s2, zero)
+    stats = o.manifold_stats()
+    assert stats[2] == 1, stats                                     # the area rule fired once
+    mo, me = o.manifold_get(), e.manifold_get()
+    assert len(mo) == len(me) == 4 and np.array_equal(mo[:, :2], me[:, :2])
+    assert np.abs(mo[:, 2:] - me[:, 2:]).max() < 2e-5, np.abs(mo - me).max()
+    assert e_out[3][6] == o_out[3][6] and np.abs(e_out[0] - o_out[0]).max() < 1e-3
+    o.forget_warm()

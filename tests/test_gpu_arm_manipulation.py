@@ -30,6 +30,10 @@ def device_fall(am):
     return ArmFallSettler(am, 16)
 
 
+def _start_of(state):
+    return state.copy()
+
+
 def _check_step(blob, o, st, ref, act, worst):
     obs, rew, done, info = st.step_host(act)
     got = st.get_state()
@@ -54,6 +58,16 @@ def _check_step(blob, o, st, ref, act, worst):
                                    geom_sens_fn=lambda: sens(C.GEOM_EPS)['obs'][k])
             if sv is not None:
                 print('conditioned: env %d force entry %d: device %.5g oracle %.5g, bound %.3g' % (i, k, obs[i, k], o_obs[k], lim))
+            if not ok:
+                # a VIOLENT step (tests/test_reference_pinned.py): a sampled start that PENETRATES (the scooper more than a millimetre inside the
+                # mattress: the re-draws of the reset reject contacts with the person and the furniture COLLISION_TRIES times, then accept) is
+                # pushed out within one substep -- no penetration-recovery clamp, DESIGN 2 -- with tens of newtons; judged against the oracle
+                # under a 1e-5 relative perturbation of its input (session r04j: ArmManipulationJaco, 21.01 N vs 20.88 N)
+                con = o.collide(_start_of(start))
+                assert len(con) and con[:, 11].min() < -1e-3, (i, k, obs[i, k], o_obs[k], lim, sv)
+                lim = max(lim, C.K * sens(1e-5)['obs'][k])
+                print('VIOLENT STEP: env %d starts %.2f mm inside a collider: force entry %d device %.5g oracle %.5g, bound %.3g' % (i, -1e3 * con[:, 11].min(), k, obs[i, k], o_obs[k], lim))
+                ok = dev[k] <= lim
             assert ok, (i, k, obs[i, k], o_obs[k], lim, sv)
             dev[k] = 0
         # the reward carries 0.01 * pressure and 0.01 * forces: compare it at the forces' tolerance

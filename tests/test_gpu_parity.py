@@ -626,3 +626,50 @@ def test_second_friction_direction_on_the_device(gpu_lib, workload):
             assert np.abs(b.view(got[i:i + 1])['q'][0] - b.view(ref[i:i + 1])['q'][0]).max() < pose_tol
     assert three > 0 and differs > 1e-7 and violent <= 2, (three, differs, violent)
     st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload', ['feeding', 'wiping'])
+def test_persistent_manifold_on_the_device(gpu_lib, workload):
+    """AGX_P_MANIFOLD through the C ABI against the oracle's switch: ONE environment stepped six times without injection (the cached points
+    live in the environment's scratch record from step to step; the oracle's memory is process-wide, hence one environment at a time), for
+    six different start states.  Contact and row counts of every step must agree exactly."""
+    import sys, os
+    from assistive_gym_amd.blob import ModelBlob
+    from assistive_gym_amd.libagx import Stepper
+    from assistive_gym_amd.vec_env import build_reset_pool
+    from oracle_lib import Oracle
+    import conditioning as C
+    n = 6
+    if workload == 'feeding':
+        b0 = ModelBlob.load('feeding_jaco'); states = build_reset_pool(b0, n, seed=7207); scale = 1.0
+    else:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import wiping_pool
+        b0 = ModelBlob.load('bed_bathing_sawyer'); states = wiping_pool(b0, n, 7207); b0.view(states)['iteration'][:] = 0; scale = 0.15
+    b = b0.set_param('MANIFOLD', 1.0)
+    o, plain = Oracle(b), Oracle(b0)
+    fcol = b.obs_dim_robot - 1
+    differs, more = 0.0, 0
+    for i in range(n):
+        one = Stepper(b, 1)
+        one.set_state(states[i:i + 1]); o.forget_warm()
+        so, sp = states[i].copy(), states[i].copy()
+        rng = np.random.RandomState(40 + i)
+        for k in range(6):
+            a = (rng.uniform(-1, 1, (1, b.act_dim)) * scale).astype(np.float32)
+            obs, rew, done, info = one.step_host(a)
+            o_obs, o_rew, _, o_info = o.step(so, a[0])
+            p_info = plain.step(sp, a[0])[3]
+            assert info[0, 6] == o_info[6] and info[0, 7] == o_info[7], (workload, i, k, info[0], o_info)
+            more += int(o_info[6] > p_info[6])
+            # free running: deviations compound over the steps of an episode (the food pile's contact set is sensitive, DESIGN 2)
+            tol = (3e-4 if workload == 'feeding' else 1e-4) * (k + 1)
+            assert np.abs(np.delete(obs[0] - o_obs, fcol)).max() < tol, (workload, i, k, np.abs(obs[0] - o_obs).max())
+            assert abs(obs[0, fcol] - o_obs[fcol]) <= max(1e-3 * max(1.0, abs(o_obs[fcol])), C.force_floor(b)) * (k + 1), (workload, i, k)
+            differs = max(differs, float(np.abs(so - sp)[:b.h['S_ENV']].max()))
+            sp[:] = so
+            one.set_state(so[None]) if False else None
+        one.close()
+    o.forget_warm()
+    assert differs > 1e-7 and (more > 0 or workload == 'wiping'), (differs, more)
