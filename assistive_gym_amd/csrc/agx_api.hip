@@ -129,6 +129,7 @@ struct agx_handle_s {
   bool particles;       // the "cloth" section holds the water particles of the drinking scene (AGX_CL_PARTICLES), not a garment
   float *cloth_dev, *trace_dev, *report_dev; const float* cloth_pool_dev;
   bool can_sample;      // the variant has a reset generator (agx_reset.h) and the blob fits it
+  bool manifold;        // AGX_P_MANIFOLD > 0 in the blob: the step path launches the variant's build kernel with the manifold stage
   const uint8_t* active;// per-env mask honoured by the build / solve launches (agx_reset's masked settle), normally null
   // staging for the *_host convenience calls
   float *act_dev, *obs_dev, *rew_dev, *info_dev; uint8_t* done_dev;
@@ -222,6 +223,8 @@ int agx_create(const void* blob, size_t blob_bytes, int n_envs, int device, agx_
   agx_handle h = new agx_handle_s();
   memset(h, 0, sizeof *h);
   h->can_sample = can_sample; h->V = V;
+  h->manifold = ((const float*)blob)[hi[AGX_H_OFF_PARAMS] + AGX_P_MANIFOLD] > 0.f;
+  if (h->manifold && !V->build_mf) { delete h; return fail(AGX_E_LIMIT, "agx_create: AGX_P_MANIFOLD is set, but this kernel variant is compiled without the manifold stage (feeding, bed_bathing, scratch_itch, arm_manipulation have it)"); }
   h->settle = nullptr; h->settle_substeps = 0;
   h->reset_flags = (hi[AGX_H_OFF_TARGETS] - hi[AGX_H_OFF_RESET] >= AGX_X_COUNT || hi[AGX_H_NWORDS] - hi[AGX_H_OFF_RESET] >= AGX_X_COUNT) ? hi[hi[AGX_H_OFF_RESET] + AGX_X_FLAGS] : 0;
   const int rc = create_fill(h, blob, blob_bytes, n_envs, device);
@@ -327,7 +330,7 @@ int agx_state_dev(agx_handle h, float** out_dev) { if (!h || !out_dev) return fa
 
 // one p.stepSimulation() for the environments [e0, e0+ne): build + solve
 static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, int ne, hipStream_t st, int phase, bool settle) {
-  h->V->build(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active, h->overflow_dev, h->trace_dev, h->trace_words, phase);
+  (h->manifold ? h->V->build_mf : h->V->build)(st, ne, h->blob_dev, h->state_dev, act, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->act_dim, h->active, h->overflow_dev, h->trace_dev, h->trace_words, phase);
   HIPCHK(hipGetLastError());
   const int ph = settle ? (phase | AGX_PHASE_SETTLE) : phase;
   // the packed kernel (four environments per wavefront) where the variant has one; the debug path keeps the single-environment kernel
@@ -405,7 +408,7 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
     int e = 0;
     HIPCHK(hipEventRecord(h->kev[c][e++], st));
     for (int k = 0; k < h->frame_skip; k++) {
-      h->V->build(st, ne, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr, h->overflow_dev, nullptr, 0, k);
+      (h->manifold ? h->V->build_mf : h->V->build)(st, ne, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr, h->overflow_dev, nullptr, 0, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
       if (h->V->solve4 && h->packed_solve) h->V->solve4(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, e0, h->sw, (const uint8_t*)nullptr, k);
       else h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr, k);

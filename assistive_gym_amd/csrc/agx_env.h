@@ -340,7 +340,7 @@ AGX_DEV MPoint mp_bcast(const MPoint& e, int src) {
   r.n = mk3(wave_bcast(e.n.x, src), wave_bcast(e.n.y, src), wave_bcast(e.n.z, src)); r.dist = wave_bcast(e.dist, src); r.mu = wave_bcast(e.mu, src);
   return r;
 }
-AGX_DEV_NOINLINE void manifold_update(Ctx& c, const Scratch& scr) {
+AGX_DEV void manifold_update(Ctx& c, const Scratch& scr) {
   const int lane = c.lane;
   const float brk = PRM(c, AGX_P_CONTACT_BREAK), slack = PRM(c, AGX_P_CONTACT_SLACK);
   int maxc = (int)PRM(c, AGX_P_MAX_CONTACTS); if (maxc > MAX_CON) maxc = MAX_CON;
@@ -445,6 +445,10 @@ AGX_DEV_NOINLINE void manifold_update(Ctx& c, const Scratch& scr) {
 
 // build: `gaction` non-null on the first substep of an env.step() (take_step, env.py:174-222)
 // returns the number of contacts dropped by a budget (contact, row or coefficient cap)
+// MANIFOLD: the build kernel with the persistent-manifold stage (AGX_P_MANIFOLD).  A second kernel, not a branch: compiled into the default build
+// kernel -- even as a function that is never called -- the stage costs the DEFAULT path 9.5 % (same-box A/B, session r04k: 467 -> 423 k
+// env-steps/s, build kernel 8.2 -> 10.8 ms per step; scratch 176 -> 736 bytes per lane).  libagx launches it for blobs with the switch on.
+template <bool MANIFOLD = false>
 AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction, float* gscratch, float* gdebug, float* lds, int lane, float* gtrace = nullptr) {
   Ctx c; ctx_init(c, blob, lds, lane);
   c.timing = gdebug != nullptr; c.dbg = gdebug;
@@ -506,9 +510,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   aba_and_minv(c); AGX_TICK(1)
   predict_velocities(c); AGX_TICK(2)
   collide(c); AGX_TICK(3)
-#ifndef AGX_NO_MANIFOLD     // build-time knob for same-box A/B runs: the default path with and without the (not inlined) manifold stage in the kernel
-  if (PRM(c, AGX_P_MANIFOLD) > 0.f) manifold_update(c, scr);
-#endif
+  if constexpr (MANIFOLD) { if (PRM(c, AGX_P_MANIFOLD) > 0.f) manifold_update(c, scr); }
   warm_seed(c, scr, lane);
   build_rows(c); AGX_TICK(4)
   if (USE_SOLVE4 && lane < c.nfree) {      // S = (M^-1)^(1/2) of a free body, for the packed solve kernel's epilogue: sqrt(1/m), R sqrt(I_body^-1) R^T

@@ -152,6 +152,13 @@
 #else
 #error "build with -DAGX_VARIANT_<name>, see assistive_gym_amd/build.py"
 #endif
+// the variants that also carry the build kernel with the persistent-manifold stage (AGX_P_MANIFOLD; agx_env.h env_build<true>): the four
+// tasks whose rewards read contact forces, with their default robots
+#if defined(AGX_VARIANT_FEEDING) || defined(AGX_VARIANT_BED_BATHING) || defined(AGX_VARIANT_SCRATCH_ITCH) || defined(AGX_VARIANT_ARM_MANIPULATION)
+#define AGX_HAS_MANIFOLD 1
+#else
+#define AGX_HAS_MANIFOLD 0
+#endif
 
 #include "agx_wave.h"
 #include "agx_step.h"
@@ -174,6 +181,20 @@ AGX_K(agx_build_kernel)(const uint32_t* __restrict__ blob, float* state, const f
                                      trace ? trace + (size_t)env * trace_words + (size_t)phase * 12 * (((const int*)blob)[AGX_H_NDOF] + ((const int*)blob)[AGX_H_NFREE]) : nullptr);
   if (dropped > 0 && threadIdx.x == 0) atomicAdd(overflow_total, dropped);   // contacts dropped by a budget (rare; agx_overflow_count)
 }
+#if AGX_HAS_MANIFOLD
+// build with the persistent-manifold stage between collision and rows (blobs with AGX_P_MANIFOLD > 0 only)
+extern "C" __global__ void __launch_bounds__(64, 2)
+AGX_K(agx_build_mf_kernel)(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* debug, int env0, int n_envs, int sw, int act_dim,
+                           const uint8_t* __restrict__ active, int* overflow_total, float* trace, int trace_words, int phase) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int env = env0 + blockIdx.x;
+  if (env >= n_envs || (active && !active[env])) return;
+  const int dropped = agx::env_build<true>(blob, state + (size_t)env * sw, actions ? actions + (size_t)env * act_dim : nullptr, scratch + (size_t)env * agx::SCR_WORDS,
+                                           debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x,
+                                           trace ? trace + (size_t)env * trace_words + (size_t)phase * 12 * (((const int*)blob)[AGX_H_NDOF] + ((const int*)blob)[AGX_H_NFREE]) : nullptr);
+  if (dropped > 0 && threadIdx.x == 0) atomicAdd(overflow_total, dropped);
+}
+#endif
 // solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
 extern "C" __global__ void __launch_bounds__(64, 4)
 AGX_K(agx_solve_kernel)(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active, int phase) {
@@ -269,6 +290,9 @@ AGX_K(agx_reset_verdict_kernel)(const uint32_t* __restrict__ blob, const float* 
 
 hipError_t v_init(void) {
   hipError_t e = hipFuncSetAttribute((const void*)AGX_K(agx_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
+#if AGX_HAS_MANIFOLD
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_build_mf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
+#endif
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_solve4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_SOLVE4_BYTES);
@@ -282,6 +306,13 @@ void v_build(hipStream_t st, int ne, const uint32_t* blob, float* state, const f
   hipLaunchKernelGGL(AGX_K(agx_build_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, debug, e0, n_envs, sw, act_dim, active, overflow_total,
                      trace, trace_words, phase);
 }
+#if AGX_HAS_MANIFOLD
+void v_build_mf(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* debug, int e0, int n_envs, int sw, int act_dim,
+                const uint8_t* active, int* overflow_total, float* trace, int trace_words, int phase) {
+  hipLaunchKernelGGL(AGX_K(agx_build_mf_kernel), dim3(ne), dim3(64), agx::LDS_BYTES, st, blob, state, actions, scratch, debug, e0, n_envs, sw, act_dim, active, overflow_total,
+                     trace, trace_words, phase);
+}
+#endif
 void v_solve(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase) {
   hipLaunchKernelGGL(AGX_K(agx_solve_kernel), dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, blob, state, scratch, debug, e0, n_envs, sw, active, phase);
 }
@@ -341,7 +372,13 @@ const agx_variant g_variant = {
 #else
   0,
 #endif
-  v_init, v_build, v_solve, v_finish, v_observe,
+  v_init, v_build, v_solve,
+#if AGX_HAS_MANIFOLD
+  v_build_mf,
+#else
+  nullptr,
+#endif
+  v_finish, v_observe,
 #if AGX_HAS_SAMPLER
   v_sample,
 #else

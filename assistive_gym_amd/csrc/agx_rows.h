@@ -232,7 +232,10 @@ AGX_DEV void build_rows(Ctx& c) {
       tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0); btot = wave_bcast_i(bincl, nc > 0 ? nc - 1 : 0);
       entN = ent; entF = ent + (nc > 0 ? tot : 0); bentN = bent; bentF = bent + (nc > 0 ? btot : 0);
       R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rboff = bentN + bincl - bcnt; rlo = 0.f; rhi = 1e30f;
-      if (go) { const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv); }
+      if (go) {
+        const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv);
+        const float sp = PRM(c, AGX_P_SPLIT_PEN); if (sp > 0.f && dist < -sp) rb = -rv;      // split impulse: no positional term below the threshold (agx_blob.h)
+      }
     } else {
       const int k2 = ph - NC_PASSES - 1;                            // 0: first friction direction, 1: the second (n x t)
       go = lane < nc; rrow = nnc + (1 + k2) * nc + lane; roff = entF + k2 * tot + cincl - ccnt; rboff = bentF + bincl - bcnt; rfric = nnc + lane; rmu = mu;

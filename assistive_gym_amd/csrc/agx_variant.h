@@ -19,6 +19,9 @@ struct agx_variant {
   void (*build)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* debug, int e0, int n_envs, int sw,
                 int act_dim, const uint8_t* active, int* overflow_total, float* trace, int trace_words, int phase);
   void (*solve)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase);
+  // the build kernel with the persistent-manifold stage (blobs with AGX_P_MANIFOLD > 0); null in variants compiled without it
+  void (*build_mf)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* debug, int e0, int n_envs, int sw, int act_dim,
+                   const uint8_t* active, int* overflow_total, float* trace, int trace_words, int phase);
   void (*finish)(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
                  float* info, int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words, float* cloth, int cloth_words);   // cloth: the water buffer for the drinking task layer (teleports drunk particles), unused elsewhere
   void (*observe)(hipStream_t st, int n_envs, const uint32_t* blob, float* state, float* obs, int sw, int obs_dim, const uint8_t* mask);   // mask: null = every environment

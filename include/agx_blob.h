@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 14
+#define AGX_BLOB_VERSION 15
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -136,7 +136,14 @@ enum {
                             pairs of the substep's own contacts in their order, each with its cached points in cache order, then the cached
                             pairs without a new point.  The memory (64 points per environment) lives with the warm-start memory in the
                             scratch record and is cleared with it.  Oracle and device; agx_env.h manifold_*                               */
-  AGX_P_COUNT = 26
+  AGX_P_SPLIT_PEN = 26,  /* > 0: a contact penetrating deeper than this (metres) gets NO positional term in its row (b = -v_rel.n only).  Bullet's
+                            split impulse ([BULLET-UNVERIFIED]; m_splitImpulse = true, m_splitImpulsePenetrationThreshold = -0.04): below the
+                            threshold the penetration recovery leaves the velocity solve (m_rhs = velocity impulse, m_rhsPenetration = the rest) and
+                            is applied to the POSITIONS of rigid bodies by a separate push solve; for multibodies -- what PyBullet makes of every
+                            URDF and of createMultiBody -- btMultiBodyConstraintSolver sets up the same split and never solves the push part, i.e.
+                            such a contact only stops the approach.  0 = off: the Baumgarte term on the full depth (deeply penetrating
+                            START poses are pushed out within one substep); 0.04 = Bullet's value.  Oracle and device (agx_rows.h)            */
+  AGX_P_COUNT = 27
 };
 
 /* ---- ROBOT: one record per moving link, stride AGX_R_STRIDE ------------------------------- */

@@ -1037,6 +1037,7 @@ static void build_rows(sim_t* s) {
     finish_row(s, r);
     double rv = row_vel(s, r);
     r->b = k->dist > 0 ? (-k->dist / dt - rv) : (-k->dist * cerp / dt - rv);
+    { const double sp = PARAM(m, AGX_P_SPLIT_PEN); if (sp > 0 && k->dist < -sp) r->b = -rv; }   /* split impulse: no positional term below the threshold */
     r->lo = 0; r->hi = 1e30;
     if (wsf > 0) {   /* warm start: the same contact (collider pair, ordinal inside the pair) of the previous substep */
       int ord = 0; for (int c2 = 0; c2 < c; c2++) if (s->con[c2].ca == k->ca && s->con[c2].cb == k->cb) ord++;

@@ -82,7 +82,7 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
   const int nsub = (mode == 1 ? nsettle : frame_skip) * sim_sub;
   for (int k = 0; k < nsub && !rc; k++) {
     const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (k == 0) ? debug : nullptr;
-    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, dbg, lds, lane); });
+    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, state, act, scratch, dbg, lds, lane); });
     const int ph = mode == 1 ? (k | AGX_PHASE_SETTLE) : k;
     if (!rc && getenv("AGX_EMU_PRINT_META")) { const int* m = (const int*)(scratch + agx::SCR_O_META); fprintf(stderr, "meta: rows %d nnc %d contacts %d pairs %d block units %d\n", m[agx::META_NROWS], m[agx::META_NNC], m[agx::META_NCON], m[agx::META_NENT], m[agx::META_NBENT]); }
     if (!rc && packed) rc = run_wave(lds, agx::LDS_SOLVE4_WORDS, [&](int lane) { agx::env_solve4(blob, state, scratch, 0, 1, sw, nullptr, lds, lane, ph); });
@@ -102,7 +102,7 @@ extern "C" int agx_emu_settle_packed(const uint32_t* blob, float* states, int n,
   int rc = 0;
   for (int k = 0; k < nsettle * sim_sub && !rc; k++) {
     for (int e = 0; e < n && !rc; e++)
-      rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, states + (size_t)e * sw, nullptr, scratch + (size_t)e * agx::SCR_WORDS, nullptr, lds, lane); });
+      rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, states + (size_t)e * sw, nullptr, scratch + (size_t)e * agx::SCR_WORDS, nullptr, lds, lane); });
     if (!rc) rc = run_wave(lds, agx::LDS_SOLVE4_WORDS, [&](int lane) { agx::env_solve4(blob, states, scratch, 0, n, sw, nullptr, lds, lane, k | AGX_PHASE_SETTLE); });
   }
   return rc;
@@ -118,7 +118,7 @@ extern "C" int agx_emu_sample(const uint32_t* blob, float* state, uint64_t seed,
   int rc = run_wave(lds, 64, [&](int lane) { int r = agx::env_sample(blob, state, (uint32_t)seed, (uint32_t)(seed >> 32), impairment_mode, gender_mode, info4, lane, 0, settled, fell); if (lane == 0) chosen = r; });
   const int tries = ((const int*)blob)[((const int*)blob)[AGX_H_OFF_RESET] + AGX_X_COLLISION_TRIES];
   for (int t = 0; t < tries && !rc && chosen >= 0; t++) {
-    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, nullptr, scratch, nullptr, lds, lane); });
+    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, state, nullptr, scratch, nullptr, lds, lane); });
     bool again = false;
     if (!rc) rc = run_wave(lds, 64, [&](int lane) { bool a = agx::reset_collides(blob, scratch, lane); if (lane == 0) again = a; });
     if (!again) break;
@@ -133,7 +133,7 @@ extern "C" int agx_emu_check_collisions(const uint32_t* blob, float* state) {
   static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
   static float scratch[agx::SCR_WORDS];
   int flags = 0;
-  int rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, nullptr, scratch, nullptr, lds, lane); });
+  int rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, state, nullptr, scratch, nullptr, lds, lane); });
   if (!rc) rc = run_wave(lds, 64, [&](int lane) { int f = agx::collision_flags(blob, scratch, lane); if (lane == 0) flags = f; });
   return rc ? -1 : flags;
 }
@@ -150,7 +150,7 @@ extern "C" int agx_emu_step_water(const uint32_t* blob, float* state, float* wat
   int rc = 0;
   for (int k = 0; k < nsub && !rc; k++) {
     const float* act = k == 0 ? action : nullptr;
-    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build(blob, state, act, scratch, nullptr, lds, lane, trace + (size_t)k * slot); });
+    rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, state, act, scratch, nullptr, lds, lane, trace + (size_t)k * slot); });
     if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, nullptr, lds, lane, k); });
   }
   if (!rc) rc = run_wave(lds, agxw::LDS_WORDS, [&](int lane) { agxw::water_env(blob, state, trace, water, report, nsub, lds, lane); });

@@ -595,3 +595,25 @@ def test_persistent_manifold_area_rule():
     assert np.abs(mo[:, 2:] - me[:, 2:]).max() < 2e-5, np.abs(mo - me).max()
     assert e_out[3][6] == o_out[3][6] and np.abs(e_out[0] - o_out[0]).max() < 1e-3
     o.forget_warm()
+
+
+def test_split_impulse_threshold_matches_the_oracle():
+    """AGX_P_SPLIT_PEN (a [BULLET-UNVERIFIED] convention, default off; Bullet: 4 cm): a contact deeper than the threshold gets no positional
+    term in its row.  The pressed scratcher of the committed fixture (0.3 mm inside the forearm) with a threshold of 0.2 mm: the kernel
+    sources against the oracle's switch, and the contact force must drop against the default (the push-out term is gone)."""
+    import os
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    from assistive_gym_amd.blob import ModelBlob
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'scratch_sawyer_parallel_edge_case.npz'))
+    b0 = ModelBlob.load('scratch_itch_sawyer').set_param('FRAME_SKIP', 1.0)
+    b = b0.set_param('SPLIT_PEN', 0.0002)
+    f = b.obs_dim_robot - 1
+    zero = np.zeros(b.act_dim, dtype=np.float32)
+    s1, s2, s3 = d['start'].copy(), d['start'].copy(), d['start'].copy()
+    o_obs = Oracle(b).step(s1, zero)[0]
+    e_obs = Emu(b).step(s2, zero)[0]
+    p_obs = Oracle(b0).step(s3, zero)[0]
+    assert p_obs[f] > 1.0 and o_obs[f] < 0.8 * p_obs[f], (p_obs[f], o_obs[f])          # 2.25 N with the positional term, 1.60 N without
+    assert np.abs(np.delete(e_obs - o_obs, f)).max() < 2e-5 and abs(e_obs[f] - o_obs[f]) <= 1e-3 * max(1.0, abs(o_obs[f]))
+    assert np.abs(b.view(s1[None])['q'][0] - b.view(s2[None])['q'][0]).max() < 5e-6
