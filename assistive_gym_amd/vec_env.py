@@ -239,6 +239,9 @@ class AssistiveVecEnv:
             self.blob = self.blob.coop()
         self.n_envs, self.device_index, self.seed = n_envs, device, seed
         self.device = torch.device('cuda', device)
+        from .model import compiler as _L
+        if self.blob.task_kind == _L.TASK_ARM_MANIPULATION and impairment == 'random':
+            impairment = 'no_tremor'                      # build_assistive_env(human_impairment='no_tremor'), arm_manipulation.py:112
         self.pool_size, self.impairment, self.auto_reset, self.reset_mode = pool_size, impairment, auto_reset, reset
         self.stepper = Stepper(self.blob, n_envs, device)
         self.act_dim, self.obs_dim = self.blob.act_dim, self.blob.obs_dim
@@ -254,6 +257,16 @@ class AssistiveVecEnv:
         self.pool_refresh, self.pool_refresh_sync, self._refresher, self._refresh_cursor, self.pool_refreshed = int(pool_refresh), pool_refresh_sync, None, 0, 0
         self._model_name = model or self.model
         self.start_states_redrawn = 0                 # reset='device': environments whose sampled start came out of the settle implausible and were drawn again
+        # reset='device' of the models whose reset has settles of its own before the sampling: further handles attached to the stepper
+        # (bed bathing: the rag doll; arm manipulation: the arm's fall, and the rag doll behind it) -- for whichever class or model name built this env
+        self._aux_steppers = ()
+        if self.reset_mode == 'device' and self.blob.has_reset_generator:
+            from .model import compiler as L
+            flags = int(self.blob.i[int(self.blob.i[L.H['OFF_RESET']]) + L.X_['FLAGS']])
+            if self.blob.task_kind == L.TASK_ARM_MANIPULATION and flags & 128:
+                self._aux_steppers = attach_arm_fall_models(self.stepper, self.blob, n_envs, self.device_index)
+            elif flags & 16:
+                self._aux_steppers = (attach_ragdoll_model(self.stepper, n_envs, self.device_index),)
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -378,6 +391,9 @@ class AssistiveVecEnv:
         if self._refresher is not None:
             self._refresher.close()
         self.stepper.close()
+        for st in self._aux_steppers:
+            st.close()
+        self._aux_steppers = ()
 
 
 class FeedingJacoVecEnv(AssistiveVecEnv):
@@ -452,12 +468,6 @@ class BedBathingSawyerVecEnv(AssistiveVecEnv):
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
         super().__init__(n_envs, **kw)
-        self._ragdoll = attach_ragdoll_model(self.stepper, n_envs, self.device_index) if self.reset_mode == 'device' else None
-
-    def close(self):
-        super().close()
-        if self._ragdoll is not None:
-            self._ragdoll.close()
 
 
 class ScratchItchPR2VecEnv(AssistiveVecEnv):
@@ -497,15 +507,8 @@ class ArmManipulationSawyerVecEnv(AssistiveVecEnv):
 
     def __init__(self, n_envs, **kw):
         kw.setdefault('reset', 'pool')
-        kw.setdefault('impairment', 'no_tremor')           # build_assistive_env(human_impairment='no_tremor'), arm_manipulation.py:112
         super().__init__(n_envs, **kw)
         assert self.reset_mode != 'device' or self.blob.has_reset_generator
-        self._fall = attach_arm_fall_models(self.stepper, self.blob, n_envs, self.device_index) if self.reset_mode == 'device' else None
-
-    def close(self):
-        super().close()
-        for st in self._fall or ():
-            st.close()
 
 
 class ArmManipulationSawyerHumanVecEnv(ArmManipulationSawyerVecEnv):

@@ -73,7 +73,7 @@ def test_env_ids_and_robot_tables():
         assert (cc.act_dim, cc.obs_dim) == (act + 4, obs + 23)                                                                          # drinking.py:8: 19 + the 4 head joints
 
 
-@pytest.mark.parametrize('robot', ['jaco', 'sawyer', 'pr2', 'stretch'])
+@pytest.mark.parametrize('robot', ['jaco', 'sawyer', pytest.param('pr2', marks=__import__('conftest').full), 'stretch'])
 def test_device_reset_sampler_matches_its_restatement(robot):
     """DrinkingEnv.reset's sampling on the device (csrc/agx_reset.h on the wave emulator) against the numpy restatement (oracle/reset_oracle.py):
     the wheelchair-mounted arm by IK restarts, the free-standing robots by the base pose search with the mouth as a second START goal and the

@@ -436,14 +436,14 @@ def test_relative_travel_bound_leaves_the_contacts_unchanged(blob):
     (-DAGX_NO_REL_TRAVEL) produce bit-identical state records over random-policy steps of settled FeedingJaco states."""
     from emu_lib import Emu
     from oracle_lib import Oracle
-    st, _ = make_states(blob, 3, seed=5151)
+    st, _ = make_states(blob, 2, seed=5151)
     new, old = Emu(blob), Emu(blob, kind='feeding_abs_travel')
     o = Oracle(blob)
     rng = np.random.RandomState(9)
     for i in range(len(st)):
         o.settle(st[i], 25)
         s1, s2 = st[i].copy(), st[i].copy()
-        for k in range(6):
+        for k in range(3):
             a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
             r1 = new.step(s1, a); r2 = old.step(s2, a)
             assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32)), (i, k)

@@ -31,7 +31,7 @@ def chain(robot, seed, rag_steps=12, fall_steps=10):
     return sblob, b, fb, rag, dinfo
 
 
-@pytest.mark.parametrize('robot', ['sawyer', 'pr2', pytest.param('jaco', marks=full), pytest.param('panda', marks=full), pytest.param('baxter', marks=full)])
+@pytest.mark.parametrize('robot', ['sawyer', pytest.param('pr2', marks=full), pytest.param('jaco', marks=full), pytest.param('panda', marks=full), pytest.param('baxter', marks=full)])
 def test_fall_record_matches_restatement(robot):
     from emu_lib import Emu
     seed = 7301

@@ -17,7 +17,7 @@ from conftest import full                      # noqa: E402
 from test_reset_generator import assert_same_record   # noqa: E402
 
 
-@pytest.fixture(scope='module', params=['pr2', pytest.param('baxter', marks=full), 'sawyer'])
+@pytest.fixture(scope='module', params=[pytest.param('pr2', marks=full), pytest.param('baxter', marks=full), 'sawyer'])
 def rb(request):
     from emu_lib import Emu
     b = ModelBlob.load('scratch_itch_' + request.param)
