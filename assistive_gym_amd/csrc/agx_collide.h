@@ -189,6 +189,11 @@ AGX_DEV float rel_travel(const Ctx& c, int a, int b) {
   const float rot = (sa || sb) ? 0.f : sqrtf(dot(dw, dw)) * 0.5f * sqrtf(dot(d, d));
   return fminf(1.001f * (sqrtf(dot(u, u)) + rot) * c.dt + 1e-6f, AB[ABS * a + 6] + AB[ABS * b + 6]);
 }
+#ifdef AGX_SWEEP_TWO_SIDED
+#define AGX_SWEEP_ONE_SIDED_COND false
+#else
+#define AGX_SWEEP_ONE_SIDED_COND (CLI(c, a, AGX_C_NVERT) == 1)
+#endif
 // conservative separation test: every point of collider x lies within |half extents| + radius of
 // the centre of its box; collider y lies within its body-frame box inflated by its radius.  True if
 // the two are certainly further apart than `reach`.
@@ -360,7 +365,9 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gfl
     }
     if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * a + q] > AB[ABS * b + 3 + q] + mg || AB[ABS * b + q] > AB[ABS * a + 3 + q] + mg) ok = false;
     // level 3: bounding sphere of one collider against the body-frame box of the other, both ways
-    if (ok) { const float reach = mg + rel_travel(c, a, b) + 1e-5f; ok = !sphere_box_apart(c, a, b, reach) && !sphere_box_apart(c, b, a, reach); }
+    // (the second test -- b's bounding sphere against a's body-frame box -- cannot reject what the first one passed when a is a sphere: its
+    // box is the point itself, so the test degenerates to two bounding spheres; skipped then: AGX_SWEEP_ONE_SIDED)
+    if (ok) { const float reach = mg + rel_travel(c, a, b) + 1e-5f; ok = !sphere_box_apart(c, a, b, reach) && (AGX_SWEEP_ONE_SIDED_COND || !sphere_box_apart(c, b, a, reach)); }
     const uint64_t m = wave_ballot(ok);
     const int slot = wn + wave_rank(m);
     if (ok && slot < WL_CAP) WL[slot] = a | (b << 9) | (g << 18) | (sub << 24);
