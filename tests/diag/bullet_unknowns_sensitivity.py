@@ -1,11 +1,11 @@
-"""What the [BULLET-UNVERIFIED] solver conventions are worth, measured in the CPU oracle: the oracle has three
-switches the device does not (include/agx_blob.h AGX_P_ORACLE_*): the residual early-out of the sweeps, a second friction direction,
-warm-started contact normals.  For each task workload, random-policy episodes are run with the conventions the device implements; from
+"""What the [BULLET-UNVERIFIED] solver conventions are worth, measured in the CPU oracle: the switches of
+include/agx_blob.h -- the residual early-out of the sweeps (oracle only), a second friction direction, warm-started contact normals, the
+persistent 4-point manifold, the split-impulse threshold (oracle and device since round 4).  For each task workload, random-policy episodes are run with the conventions the device implements; from
 every pre-step state the SAME step is repeated with one switch on, and the deviations of what the step returns are recorded:
 reward, total_force_on_human, the tool's force, the largest observation entry.  Free-running 200-step episodes per switch give the
 difference of the episode return beside it (dominated by how chaotic the scene is: the food pile).
 
-    python tests/diag/bullet_unknowns_sensitivity.py [episodes] -> profiles/r03/bullet_unknowns_sensitivity.json (+ a markdown table on stdout)
+    python tests/diag/bullet_unknowns_sensitivity.py [episodes] -> profiles/r04/bullet_unknowns_sensitivity.json (+ a markdown table on stdout)
 """
 import ctypes as C
 import json
@@ -20,7 +20,8 @@ from assistive_gym_amd.blob import ModelBlob       # noqa: E402
 from oracle_lib import Oracle                       # noqa: E402
 
 SWITCHES = {'residual early-out 1e-7': dict(ORACLE_RESIDUAL_EPS=1e-7), 'two friction directions': dict(FRICTION_DIRS=2),
-            'warm start 0.85': dict(WARMSTART=0.85), 'all three': dict(ORACLE_RESIDUAL_EPS=1e-7, FRICTION_DIRS=2, WARMSTART=0.85)}
+            'warm start 0.85': dict(WARMSTART=0.85), 'persistent manifold': dict(MANIFOLD=1.0), 'split impulse below 4 cm': dict(SPLIT_PEN=0.04),
+            'all five': dict(ORACLE_RESIDUAL_EPS=1e-7, FRICTION_DIRS=2, WARMSTART=0.85, MANIFOLD=1.0, SPLIT_PEN=0.04)}
 
 
 def variant(blob, **kw):
@@ -100,7 +101,7 @@ def main():
             print('| %s | %.2e / %.2e / %.2e | %.2e / %.2e | %.2e / %.2e | %.2e | %+.3f |' % (k, x['reward']['median'], x['reward']['p99'], x['reward']['max'], x['force']['p99'], x['force']['max'],
                                                                                      x['tool']['p99'], x['tool']['max'], x['obs']['max'], x['episode_return_diff_mean']))
     os.makedirs(os.path.join(ROOT, 'profiles', 'r03'), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r03', 'bullet_unknowns_sensitivity.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r04', 'bullet_unknowns_sensitivity.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -617,3 +617,26 @@ def test_split_impulse_threshold_matches_the_oracle():
     assert p_obs[f] > 1.0 and o_obs[f] < 0.8 * p_obs[f], (p_obs[f], o_obs[f])          # 2.25 N with the positional term, 1.60 N without
     assert np.abs(np.delete(e_obs - o_obs, f)).max() < 2e-5 and abs(e_obs[f] - o_obs[f]) <= 1e-3 * max(1.0, abs(o_obs[f]))
     assert np.abs(b.view(s1[None])['q'][0] - b.view(s2[None])['q'][0]).max() < 5e-6
+
+
+def test_all_solver_switches_together_match_the_oracle(blob):
+    """warm start + second friction direction + persistent manifold + split-impulse threshold at once (the combination a comparison with a
+    PyBullet dump would start from): the kernel sources against the oracle over consecutive FeedingJaco steps, the memories of both sides
+    (impulses, cached points) built up step by step."""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    st, _ = make_states(blob, 1, seed=3001)
+    s = st[0].copy(); Oracle(blob).settle(s, 25)
+    b = blob.set_param('WARMSTART', 0.85).set_param('FRICTION_DIRS', 2.0).set_param('MANIFOLD', 1.0).set_param('SPLIT_PEN', 0.04)
+    o, e = Oracle(b), Emu(b)
+    o.forget_warm(); e.forget_warm()
+    so, se = s.copy(), s.copy()
+    rng = np.random.RandomState(11)
+    for k in range(3):
+        a = rng.uniform(-1, 1, b.act_dim).astype(np.float32)
+        o_obs, o_rew, _, o_info = o.step(so, a)
+        obs, rew, _, info, _ = e.step(se, a)
+        assert info[6] == o_info[6] and info[7] == o_info[7], (k, info, o_info)
+        assert np.abs(obs - o_obs).max() < 1e-4 and abs(rew - o_rew) < 1e-4 * max(1.0, abs(o_rew)), (k, np.abs(obs - o_obs).max())
+        se[:] = so
+    o.forget_warm()
