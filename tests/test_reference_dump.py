@@ -160,3 +160,35 @@ def test_capture_inverts_adopt_on_the_bridge():
         if blob.task_i('ARM_LIMIT_ON'):
             assert a['task'][0][10] == b['task'][0][10] and np.abs(ta[6:10] - tb[6:10]).max() < 1e-6
         w.close()
+
+
+def test_convention_search_recovers_the_conventions_of_a_synthetic_dump(tmp_path):
+    """tools/convention_search.py on a dump whose "reference" is the oracle itself under a HIDDEN pair of conventions (warm start + second
+    friction direction) -- the pad of BedBathingSawyer pressed on the arm, 10 steps with every state recorded: the search must rank exactly that
+    combination first with zero deviation, and the default conventions must be told apart from it."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import convention_search as cs
+    from bench import wiping_pool
+    from assistive_gym_amd.blob import ModelBlob
+    from oracle_lib import Oracle
+    b0 = ModelBlob.load('bed_bathing_sawyer')
+    hidden = b0.set_param('WARMSTART', 0.85).set_param('FRICTION_DIRS', 2.0)
+    o = Oracle(hidden); o.forget_warm()
+    s = wiping_pool(b0, 4, 6006)[3].copy(); b0.view(s[None])['iteration'][0] = 0
+    rng = np.random.RandomState(2)
+    states, acts, obs, rew, done, force = [s.copy()], [], [], [], [], []
+    for k in range(10):
+        a = (rng.uniform(-1, 1, b0.act_dim) * 0.15).astype(np.float32)
+        ob, r, dn, info = o.step(s, a)
+        acts.append(a); obs.append(ob); rew.append(r); done.append(dn); force.append(info[0]); states.append(s.copy())
+    o.forget_warm()
+    path = str(tmp_path / 'pybullet_dump_synthetic.npz')
+    np.savez(path, model='bed_bathing_sawyer', blob_version=b0.h['VERSION'], states=np.array(states), actions=np.array(acts), obs=np.array(obs),
+             reward=np.array(rew), done=np.array(done), total_force_on_human=np.array(force))
+    res = cs.search(path)
+    best, r = res[0]
+    assert best == (True, True, False, False, False), best
+    assert max(r['obs'], r['reward'], r['force']) < 1e-9 and r['done_mismatches'] == 0
+    default = [x for c, x in res if not any(c)][0]
+    assert max(default['obs'], default['reward'], default['force']) > 1e-4, default
