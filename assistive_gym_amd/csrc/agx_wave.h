@@ -12,7 +12,13 @@
 #define AGX_WAVE 64
 
 AGX_DEV int wave_lane() { return (int)(threadIdx.x & 63u); }
+#ifdef AGX_WAVE_SYNC_LDS_ONLY   // timing experiment only (NOT safe: some sync points order global scratch traffic between lanes): how much of the
+                                // kernels' time is the workgroup fence of __syncthreads() waiting for outstanding global loads / stores?
+                                // Measured (same box, profiles/r04/r04t_ab_feeding_lds_only_wave_sync.txt): none -- 473.3 vs 473.2 k env-steps/s.
+AGX_DEV void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 AGX_DEV void wave_sync() { __syncthreads(); }
+#endif
 // orders this wavefront's own LDS accesses in the compiler; the hardware executes a wavefront's LDS instructions in order, so no wait
 AGX_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
