@@ -237,6 +237,11 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
     }
     k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.dist = 0.f;
     bool hit = narrowphase(c, a, b, lim, k, has && sub == 0);
+#ifdef AGX_NARROWPHASE_TWICE   // timing experiment: the narrowphase of every pass a second time (same result) -- the slowdown of the step is what ONE
+    { Cand k2; k2.gap = 3.0e38f; k2.n = mk3(0.f, 0.f, 0.f); k2.pa = k2.n; k2.pb = k2.n; k2.dist = 0.f;     // narrowphase costs under the chunk overlap,
+      const bool h2 = narrowphase(c, a, b, lim + 1e-9f, k2, has && sub == 0);                               // i.e. the ceiling of any gain there
+      if (h2 && k2.dist == 12345.678f) k.gap = 0.f; }
+#endif
     // on a face GJK's closest point is an arbitrary point of the face: the first contact of a pair resting on a static
     // world box is re-anchored at a vertex as well (oracle: face_manifold)
     if (has && sub == 0 && hit && k.n.z > 0.999f && face_box(c, b) && CLI(c, a, AGX_C_NVERT) >= 2) { Cand k0; k0.gap = k.gap; if (face_point(c, a, b, 0, k.pa, k0)) k = k0; }
