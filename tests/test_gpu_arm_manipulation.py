@@ -30,10 +30,6 @@ def device_fall(am):
     return ArmFallSettler(am, 16)
 
 
-def _start_of(state):
-    return state.copy()
-
-
 def _check_step(blob, o, st, ref, act, worst):
     obs, rew, done, info = st.step_host(act)
     got = st.get_state()
@@ -63,7 +59,7 @@ def _check_step(blob, o, st, ref, act, worst):
                 # mattress: the re-draws of the reset reject contacts with the person and the furniture COLLISION_TRIES times, then accept) is
                 # pushed out within one substep -- no penetration-recovery clamp, DESIGN 2 -- with tens of newtons; judged against the oracle
                 # under a 1e-5 relative perturbation of its input (session r04j: ArmManipulationJaco, 21.01 N vs 20.88 N)
-                con = o.collide(_start_of(start))
+                con = o.collide(start.copy())
                 assert len(con) and con[:, 11].min() < -1e-3, (i, k, obs[i, k], o_obs[k], lim, sv)
                 lim = max(lim, C.K * sens(1e-5)['obs'][k])
                 print('VIOLENT STEP: env %d starts %.2f mm inside a collider: force entry %d device %.5g oracle %.5g, bound %.3g' % (i, -1e3 * con[:, 11].min(), k, obs[i, k], o_obs[k], lim))
