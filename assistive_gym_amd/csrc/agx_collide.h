@@ -187,7 +187,9 @@ AGX_DEV float rel_travel(const Ctx& c, int a, int b) {
   const v3 dw = wa - wb;
   const v3 u = (va - vb) + cross(dw, ce - ld3(c.lds + L_MISC + M_REF));
   const float rot = (sa || sb) ? 0.f : sqrtf(dot(dw, dw)) * 0.5f * sqrtf(dot(d, d));
-  return fminf(1.001f * (sqrtf(dot(u, u)) + rot) * c.dt + 1e-6f, AB[ABS * a + 6] + AB[ABS * b + 6]);
+  const float t = 1.001f * (sqrtf(dot(u, u)) + rot) * c.dt + 1e-6f;
+  if constexpr (ABS == 7) return fminf(t, AB[ABS * a + 6] + AB[ABS * b + 6]);       // (the old layout: never above the sum of the absolute travels)
+  else return t;
 }
 #ifdef AGX_SWEEP_TWO_SIDED
 #define AGX_SWEEP_ONE_SIDED_COND false
@@ -416,7 +418,7 @@ AGX_DEV void collide(Ctx& c) {
       float h = fabsf(R.a[3 * k]) * hl.x + fabsf(R.a[3 * k + 1]) * hl.y + fabsf(R.a[3 * k + 2]) * hl.z + r;
       AB[ABS * col + k] = comp(cw, k) - h - grow; AB[ABS * col + 3 + k] = comp(cw, k) + h + grow;
     }
-    AB[ABS * col + 6] = grow;
+    if constexpr (ABS == 7) AB[ABS * col + 6] = grow;
   }
   wave_sync();
   AGX_CTICK(8)

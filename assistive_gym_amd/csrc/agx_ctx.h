@@ -37,7 +37,16 @@ constexpr int HDR_STRIDE = 10;
 #endif
 constexpr int ARENA_WORDS = AGX_ARENA_WORDS;
 constexpr int MAX_QPT = 16;                              // manifold points of the (wiping pad, human) pairs handed to the finish kernel
-constexpr int ABS = 7;                                   // collider table stride: world AABB (6) + speculative growth (1)
+// collider table stride: world AABB (6) + the collider's own travel distance (1).  -DAGX_AABB_WITHOUT_TRAVEL (A/B knob): without the seventh word
+// -- rel_travel() (agx_collide.h) then bounds the narrowphase limit alone -- the worklist gets 256 words of the arena back: 200 entries instead
+// of 182, one flush instead of two for a FeedingJaco substep (23 instead of 28 passes per step on the emulator, bit-identical contacts).  Measured
+// on the last GPU seconds of round 4 (profiles/r04/r04v_ab_feeding_worklist_200.txt): 469.5 / 468.2 k against 468.8 k -- no difference, so the
+// layout the GPU suite ran on stays the default.
+#if defined(AGX_AABB_WITHOUT_TRAVEL) && !defined(AGX_NO_REL_TRAVEL)
+constexpr int ABS = 6;
+#else
+constexpr int ABS = 7;
+#endif
 
 // ---- LDS layout (float words) -------------------------------------------------------------
 constexpr int L_ST = 0;
