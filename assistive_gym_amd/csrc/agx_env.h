@@ -578,21 +578,26 @@ AGX_DEV void solve_tail(Ctx& c, float* gstate, Scratch& scr, int sw, int phase, 
   store_env(c, gstate, sw);
 }
 // solve: PGS + integration + post-substep hooks of one p.stepSimulation() (env.py:226-232)
-AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane, int phase = 0) {
+// lds_words: the solve kernel's LDS (LDS_SOLVE_WORDS, or more / less when libagx was told so: the row-local sweep sizes its window from it)
+AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, float* gdebug, float* lds, int lane, int phase = 0, int lds_words = LDS_SOLVE_WORDS) {
   Ctx c; ctx_init(c, blob, lds, lane);
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
   c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.dbg = gdebug;
   c.ncon = scr.meta[META_NCON]; c.nrows = scr.meta[META_NROWS]; c.first_normal = scr.meta[META_NNC]; c.nent = scr.meta[META_NENT];
-  // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)
-  const bool rowspace = RS_MAX_ROWS > 0 && c.nrows <= RS_MAX_ROWS && c.nv <= 64 && c.nv <= RS_NVP && c.nrows > 0 && c.nent <= SOLVE_LDS_PAIRS;
-  { const int np = c.nent < SOLVE_LDS_PAIRS ? c.nent : SOLVE_LDS_PAIRS;
-    const f2* src = (const f2*)scr.ent; f2* dst = (f2*)(lds + L_SOLVE_ENT);
-    for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
-  wave_sync();
   const long long t0 = gdebug ? wave_clock() : 0;
-  float dv0, dv1;
-  if (!(rowspace && pgs_rowspace(c, lds + L_SOLVE_ENT, dv0, dv1))) pgs(c, dv0, dv1);
+  float dv0 = 0.f, dv1 = 0.f;
+  bool solved = false;
+  if constexpr (LV_COMPILED) { if (lv_eligible(c)) { pgs_lv(c, lds, lds_words, dv0, dv1); solved = true; } }      // the row-local sweep (agx_pgs_lv.h)
+  if (!solved) {
+    // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)
+    const bool rowspace = RS_MAX_ROWS > 0 && c.nrows <= RS_MAX_ROWS && c.nv <= 64 && c.nv <= RS_NVP && c.nrows > 0 && c.nent <= SOLVE_LDS_PAIRS;
+    { const int np = c.nent < SOLVE_LDS_PAIRS ? c.nent : SOLVE_LDS_PAIRS;
+      const f2* src = (const f2*)scr.ent; f2* dst = (f2*)(lds + L_SOLVE_ENT);
+      for (int k = lane; k < np; k += 64) dst[k] = src[k]; }
+    wave_sync();
+    if (!(rowspace && pgs_rowspace(c, lds + L_SOLVE_ENT, dv0, dv1))) pgs(c, dv0, dv1);
+  }
   warm_remember(c, scr, lane);
   const long long t1 = gdebug ? wave_clock() : 0;
   solve_tail(c, gstate, scr, sw, phase, dv0, dv1);

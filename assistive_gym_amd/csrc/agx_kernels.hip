@@ -197,11 +197,13 @@ AGX_K(agx_build_mf_kernel)(const uint32_t* __restrict__ blob, float* state, cons
 #endif
 // solve: 50 PGS sweeps streaming the rows from the scratch record (L2), integration.  Lean.
 extern "C" __global__ void __launch_bounds__(64, 4)
-AGX_K(agx_solve_kernel)(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active, int phase) {
+AGX_K(agx_solve_kernel)(const uint32_t* __restrict__ blob, float* state, float* scratch, float* debug, int env0, int n_envs, int sw, const uint8_t* __restrict__ active, int phase,
+                        int lds_words) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int env = env0 + blockIdx.x;
   if (env >= n_envs || (active && !active[env])) return;
-  agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x, phase);
+  agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x, phase,
+                 lds_words);
 }
 // solve, packed: FOUR environments per wavefront (agx_pgs4.h); the grid covers the environments [env0, env_end) four at a time
 extern "C" __global__ void __launch_bounds__(64, 1)
@@ -288,8 +290,13 @@ AGX_K(agx_reset_verdict_kernel)(const uint32_t* __restrict__ blob, const float* 
 }
 #endif
 
+// LDS of a solve launch.  AGX_SOLVE_LDS_BYTES (tuning knob, read once): the row-local sweep (agx_pgs_lv.h) sizes its window of resident rows
+// from it -- more LDS = fewer rows streamed from L2, fewer wavefronts per CU; never below what the other sweeps and solve_tail() need
+int g_solve_lds_bytes = agx::LDS_SOLVE_BYTES;
 hipError_t v_init(void) {
-  hipError_t e = hipFuncSetAttribute((const void*)AGX_K(agx_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
+  if (const char* e = getenv("AGX_SOLVE_LDS_BYTES")) { int b = atoi(e) & ~15; if (b > agx::LDS_SOLVE_BYTES && b <= 64 * 1024) g_solve_lds_bytes = b; }
+  hipError_t e = hipFuncSetAttribute((const void*)AGX_K(agx_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g_solve_lds_bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
 #if AGX_HAS_MANIFOLD
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_build_mf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
 #endif
@@ -314,7 +321,7 @@ void v_build_mf(hipStream_t st, int ne, const uint32_t* blob, float* state, cons
 }
 #endif
 void v_solve(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase) {
-  hipLaunchKernelGGL(AGX_K(agx_solve_kernel), dim3(ne), dim3(64), agx::LDS_SOLVE_BYTES, st, blob, state, scratch, debug, e0, n_envs, sw, active, phase);
+  hipLaunchKernelGGL(AGX_K(agx_solve_kernel), dim3(ne), dim3(64), g_solve_lds_bytes, st, blob, state, scratch, debug, e0, n_envs, sw, active, phase, g_solve_lds_bytes / 4);
 }
 void v_solve4(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, int e0, int sw, const uint8_t* active, int phase) {
   hipLaunchKernelGGL(AGX_K(agx_solve4_kernel), dim3((ne + 3) / 4), dim3(64), agx::LDS_SOLVE4_BYTES, st, blob, state, scratch, e0, e0 + ne, sw, active, phase);

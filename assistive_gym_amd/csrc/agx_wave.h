@@ -67,6 +67,17 @@ AGX_DEV int wave_sum_i(int x) {
   x += dpp_mov_i<AGX_DPP_ROW_BCAST31>(0, x);
   return __builtin_amdgcn_readlane(x, 63);
 }
+// sum over the 16 lanes of this lane's DPP row as an xor butterfly (1, 2, half mirror, mirror): every lane adds the same two numbers at
+// every step, so the result is bitwise the same in all 16 lanes -- no broadcast afterwards (the row-local sweep, agx_pgs_lv.h)
+#define AGX_DPP_ROW_HALF_MIRROR 0x141
+#define AGX_DPP_ROW_MIRROR 0x140
+AGX_DEV float wave_sum16(float x) {
+  x += dpp_mov<AGX_DPP_QUAD_1032>(0.f, x);
+  x += dpp_mov<AGX_DPP_QUAD_2301>(0.f, x);
+  x += dpp_mov<AGX_DPP_ROW_HALF_MIRROR>(0.f, x);
+  x += dpp_mov<AGX_DPP_ROW_MIRROR>(0.f, x);
+  return x;
+}
 AGX_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
 AGX_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // value of lane `src` (src may differ per lane)

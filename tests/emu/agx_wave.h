@@ -87,6 +87,7 @@ AGX_DEV float g16_sum(float x) {
   float q[4]; for (int i = 0; i < 4; i++) q[i] = (emu::u2f(s[b + 4 * i]) + emu::u2f(s[b + 4 * i + 1])) + (emu::u2f(s[b + 4 * i + 2]) + emu::u2f(s[b + 4 * i + 3]));
   return (q[0] + q[1]) + (q[2] + q[3]);
 }
+AGX_DEV float wave_sum16(float x) { return g16_sum(x); }
 AGX_DEV uint32_t g16_ballot(bool p, int group) { return (uint32_t)(wave_ballot(p) >> (16 * group)) & 0xffffu; }
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(16) int4 { int x, y, z, w; };

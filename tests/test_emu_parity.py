@@ -640,3 +640,36 @@ def test_all_solver_switches_together_match_the_oracle(blob):
         assert np.abs(obs - o_obs).max() < 1e-4 and abs(rew - o_rew) < 1e-4 * max(1.0, abs(o_rew)), (k, np.abs(obs - o_obs).max())
         se[:] = so
     o.forget_warm()
+
+
+def test_row_local_sweep_against_the_register_sweep(blob):
+    """The row-local sweep (csrc/agx_pgs_lv.h: velocity deltas in LDS, lane = entry of the visited row; the default solve path of the feeding
+    scenes) against the register sweep (csrc/agx_pgs.h, variant built with -DAGX_PGS_LV=0) and against itself with a 300-pair LDS window
+    (most rows stream their pairs from the scratch record): same rows, same order, same clamps -- the dot products are associated
+    differently, so the three agree to rounding, not bit for bit, and the window size must not change a bit."""
+    from emu_lib import Emu
+    from oracle_lib import Oracle
+    lv, reg, cap, oracle = Emu(blob, 0), Emu(blob, 'feeding_reg'), Emu(blob, 'feeding_lv_cap'), Oracle(blob)
+    st, _ = make_states(blob, 2, seed=3701)
+    rng = np.random.RandomState(8)
+    differs = 0
+    for i in range(2):
+        s = st[i].copy()
+        oracle.settle(s, 20)
+        for k in range(2):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            s_l, s_r, s_c, s_o = s.copy(), s.copy(), s.copy(), s.copy()
+            l_obs, l_rew, _, l_info, _ = lv.step(s_l, a)
+            r_obs, r_rew, _, r_info, _ = reg.step(s_r, a)
+            c_obs, c_rew, _, c_info, _ = cap.step(s_c, a)
+            o_obs, o_rew, _, o_info = oracle.step(s_o, a)
+            assert np.array_equal(s_l, s_c) and np.array_equal(l_obs, c_obs) and l_rew == c_rew          # the window is a cache, not arithmetic
+            differs += int(not np.array_equal(s_l, s_r))
+            assert l_info[6] == r_info[6] == o_info[6] and l_info[7] == r_info[7] == o_info[7]         # same contacts, same rows
+            vl, vr, vo = blob.view(s_l[None]), blob.view(s_r[None]), blob.view(s_o[None])
+            for key, tol in (('q', 2e-6), ('qd', 2e-5)):
+                assert np.abs(vl[key] - vr[key]).max() < tol and np.abs(vl[key] - vo[key]).max() < 5 * tol, (i, k, key)
+            assert np.abs(vl['free'][0, :, :3] - vr['free'][0, :, :3]).max() < 2e-6
+            assert np.abs(l_obs - o_obs).max() < 1e-4 and abs(l_rew - o_rew) < 1e-4 and abs(l_info[0] - o_info[0]) <= 1e-3 * max(1.0, abs(o_info[0]))
+            s = s_o
+    assert differs > 0                                     # (two different sweeps: a real comparison)
