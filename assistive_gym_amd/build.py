@@ -15,8 +15,9 @@ OUT = os.path.join(HERE, 'lib', 'libagx.so')
 VARIANTS = ['FEEDING', 'FEEDING_L', 'FEEDING_M', 'BED_BATHING', 'BED_BATHING_L', 'BED_BATHING_M', 'SCRATCH_ITCH', 'SCRATCH_ITCH_M', 'BED_SETTLE', 'DRESSING', 'DRESSING_L', 'DRESSING_M', 'ARM_MANIPULATION', 'ARM_MANIPULATION_L', 'DRINKING', 'DRINKING_L', 'DRINKING_M']
 
 
-def build(force=False, verbose=False, extra=(), out=None):
-    """out / extra: an A/B build of the same library with extra compiler flags (same-box comparisons: AGX_LIB=<out> python bench.py)"""
+def build(force=False, verbose=False, extra=(), out=None, only=None):
+    """out / extra: an A/B build of the same library with extra compiler flags (same-box comparisons: AGX_LIB=<out> python bench.py);
+    only: kernel variants the extra flags apply to (e.g. ['FEEDING']) -- the other objects are taken from the main build's lib/obj"""
     OUT = out or globals()['OUT']
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     if not force and not out and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
@@ -28,11 +29,17 @@ def build(force=False, verbose=False, extra=(), out=None):
     objdir = os.path.join(HERE, 'lib', 'obj' if not out else 'obj_' + os.path.splitext(os.path.basename(out))[0])
     os.makedirs(objdir, exist_ok=True)
     jobs = [(os.path.join(objdir, 'agx_api.o'), base + ['-c', os.path.join(CSRC, 'agx_api.hip')])]
+    reuse = []
     for v in VARIANTS:
+        if only and v not in only:
+            reuse.append(os.path.join(HERE, 'lib', 'obj', 'agx_kernels_%s.o' % v.lower()))
+            continue
         jobs.append((os.path.join(objdir, 'agx_kernels_%s.o' % v.lower()), base + ['-DAGX_VARIANT_' + v, '-c', os.path.join(CSRC, 'agx_kernels.hip')]))
+    if only:
+        jobs[0] = (os.path.join(HERE, 'lib', 'obj', 'agx_api.o'), None)
     with ThreadPoolExecutor(len(jobs)) as ex:
-        list(ex.map(lambda j: subprocess.check_call(j[1] + ['-o', j[0]]), jobs))
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + [j[0] for j in jobs])
+        list(ex.map(lambda j: j[1] and subprocess.check_call(j[1] + ['-o', j[0]]), jobs))
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + [j[0] for j in jobs] + reuse)
     return OUT
 
 
@@ -40,4 +47,5 @@ if __name__ == '__main__':
     a = sys.argv
     out = a[a.index('--out') + 1] if '--out' in a else None
     extra = a[a.index('--extra') + 1].split() if '--extra' in a else ()
-    print(build(force='--force' in a, verbose='-v' in a, extra=extra, out=out))
+    only = a[a.index('--only') + 1].split(',') if '--only' in a else None
+    print(build(force='--force' in a, verbose='-v' in a, extra=extra, out=out, only=only))

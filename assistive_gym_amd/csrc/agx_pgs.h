@@ -125,6 +125,12 @@ static_assert(AGX_SOLVE_ENT_BYTES == 4 * L_SOLVE_ENT, "LDS offset of the row win
 #define AGX_PGS_ADDR2 ""
 #define AGX_PGS_ADDR3 "v_mov_b32_e32 v85, 0\n"
 #define AGX_PGS_ADDR4 "s_bitcmp1_b32 s84, 31\n"
+#elif defined(AGX_PGS_NO_READLANE3)   // timing ablation (results meaningless): the three v_readlane of the row-ahead fetch as scalar moves -- what fetching the row descriptors some other way (scalar loads) could save at most
+#define AGX_PGS_ADDR0 "s_mov_b32 s84, 8\n" "s_mov_b32 s82, 0xfff\n"
+#define AGX_PGS_ADDR1 "s_mov_b32 s83, 0\n" "s_bitcmp1_b32 s84, 31\n"
+#define AGX_PGS_ADDR2 "v_mbcnt_lo_u32_b32 v81, s82, 0\n"
+#define AGX_PGS_ADDR3 "v_mbcnt_hi_u32_b32 v81, s83, v81\n" "v_add_lshl_u32 v85, v81, s84, 3\n"
+#define AGX_PGS_ADDR4 "v_cndmask_b32_e64 v85, 0, v85, s[82:83]\n"
 #else
 #define AGX_PGS_ADDR0 "v_readlane_b32 s84, %[off], s80\n" "v_readlane_b32 s82, %[mlo], s80\n"
 #define AGX_PGS_ADDR1 "v_readlane_b32 s83, %[mhi], s80\n" "s_bitcmp1_b32 s84, 31\n"

@@ -21,8 +21,15 @@
 namespace agx {
 
 constexpr int LV_G = 16;                                            // lanes of a visit = the longest row this path takes
+// MEASURED (round 5, profiles/r05/r05a_ab_lv_vs_register_sweep.txt, r05b_solve_cycles_per_visit.txt) AND NOT KEPT AS THE DEFAULT: FeedingJaco at 4096
+// environments 430 k env-steps/s against 467 k with the register sweep (same box, two runs each).  Shader-clock cycles of one solve per row and
+// sweep: one wavefront per CU 268 (register sweep: 192), sixteen per CU 331 (278); with every row inside the LDS window (20 KB) 247 / 275.
+// hipcc's loop is ~110 instructions per visit (16 vector, 7 LDS, the rest scalar bookkeeping, exec-mask branches and waits): a lone wave is
+// bound by its own issue rate (~4 cycles per instruction), sixteen per CU by the LDS -- 22 LDS cycles per visit (two b128 header broadcasts,
+// pairs, slot, gather, two stores) x 16 waves = 352 per visit round, against the register sweep's ~92 vector-port cycles x 4 waves per SIMD.
+// EXEC = 16 lanes buys nothing (full EXEC: 256 / 322).  Opt-in build: -DAGX_PGS_LV=1 (emulator variant 'feeding_lv', tests/test_emu_parity.py).
 #ifndef AGX_PGS_LV
-#define AGX_PGS_LV 1
+#define AGX_PGS_LV 0
 #endif
 constexpr bool LV_COMPILED = AGX_PGS_LV && MAX_DOF <= 16 && TASK == AGX_TASK_FEEDING && !USE_SOLVE4;
 constexpr int LV_HDR_WORDS = 8;                                     // invD, b, lo, hi | lam, off8, n, pack
@@ -81,7 +88,9 @@ AGX_DEV void lv_ent_load(const LvLay& Y, const LvHdr& h, int k, LvEnt& e) {
 // one visit in two halves: the gather is issued before the look-ahead loads of the step (LDS answers in order: what is requested
 // first arrives first), then the dot product, the impulse update (identical in the 16 lanes) and the scatter.  Lane 0 keeps the row's impulse.
 AGX_DEV float lv_gather(const LvLay& Y, const LvEnt& e) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(AGX_LV_ABL_NOGATHER)
+  return e.J;
+#elif defined(__HIP_DEVICE_COMPILE__)
   return lv_ld1(Y.lds, e.ia);                                       // lanes beyond the row read a 16-bit address of some later row (or nothing: LDS reads beyond the allocation return 0); masked in lv_update
 #else
   return e.on ? lv_ld1(Y.lds, e.ia) : 0.f;
@@ -92,8 +101,14 @@ AGX_DEV void lv_update(const LvLay& Y, const LvHdr& h, const LvEnt& e, float v, 
   const float jdv = wave_sum16(x);
   const float nl = wave_clamp(h.lam + (h.b - jdv) * h.invD, h.lo, h.hi);
   const float dl = nl - h.lam;
+#ifndef AGX_LV_ABL_NOLAMW        // AGX_LV_ABL_*: timing experiments (results meaningless), what each piece of a visit costs
   if (k == 0) lv_st1(Y.lds, h.addr + 4 * LV_H_LAM, nl);
+#endif
+#ifndef AGX_LV_ABL_NOSCATTER
   if (e.on) lv_st1(Y.lds, e.ia, v + e.B * dl);
+#else
+  if (e.on && v + e.B * dl == 12345.f) lv_st1(Y.lds, e.ia, 0.f);
+#endif
   wave_fence();                                                     // the next visit gathers what this one scattered: program order inside one wavefront
 }
 // the rows base + (set bits of m0, then 64 + set bits of m1), ascending
@@ -109,7 +124,7 @@ AGX_DEV int lv_next(LvIt& it) {
 AGX_DEV void lv_part(const LvLay& Y, int lane, uint64_t m0, uint64_t m1, int base) {
   const int nvis = popc64(m0) + popc64(m1);
   if (nvis == 0) return;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_LV_ABL_FULL_EXEC)
   if (lane < LV_G)                                                  // the sweeps run under EXEC = lanes 0..15 (the emulator's collectives need all 64 fibres)
 #endif
   {
@@ -119,11 +134,21 @@ AGX_DEV void lv_part(const LvLay& Y, int lane, uint64_t m0, uint64_t m1, int bas
     lv_hdr_load(Y, lv_next(it), h0); lv_hdr_load(Y, lv_next(it), h1); lv_hdr_load(Y, lv_next(it), h2);
     lv_ent_load(Y, h0, k, e0); lv_ent_load(Y, h1, k, e1);
     int t = 0;
+#ifdef AGX_LV_ABL_NOHDR
+#define LV_ABL_HDR(x) (void)lv_next(it);
+#else
+#define LV_ABL_HDR(x) x
+#endif
+#ifdef AGX_LV_ABL_NOENT
+#define LV_ABL_ENT(x)
+#else
+#define LV_ABL_ENT(x) x
+#endif
 #define LV_STEP(HC, EC, HN3, HN2, EN2) { \
       const float v = lv_gather(Y, EC); \
       wave_fence(); \
-      lv_hdr_load(Y, lv_next(it), HN3); \
-      lv_ent_load(Y, HN2, k, EN2); \
+      LV_ABL_HDR(lv_hdr_load(Y, lv_next(it), HN3);) \
+      LV_ABL_ENT(lv_ent_load(Y, HN2, k, EN2);) \
       lv_update(Y, HC, EC, v, k); \
       if (++t == nvis) break; }
     for (;;) {

@@ -11,12 +11,46 @@ given (state, action) is, with nothing but the oracle; the parity tests then bou
 
 K: the device is not one rounding away from the oracle but a random walk of them.  Measured on the emulator (the device's arithmetic on the
 CPU) over the reference-pinned cases, device deviation / 1-ulp sensitivity has median ~1 and stays below 8 wherever the sensitivity itself is
-above 1e-6 (tests/test_conditioning.py prints the table); 16 is twice that.  A case whose bound exceeds 1e-3 is therefore one whose reference
+above 1e-6 (tests/test_conditioning.py measures it on a sample of the reference-pinned cases); 16 is twice that.  A case whose bound exceeds 1e-3 is therefore one whose reference
 value is itself undetermined at that level -- not one where the device is allowed to be sloppy.
 Test infrastructure (CPU oracle only)."""
+import atexit
+import json
+import os
+
 import numpy as np
 
 K = 16.0
+# No escalated bound may exceed CAP x the base tolerance (rel x max(1, scale), or the floor where that is larger): a device result that is wrong
+# by percents must not pass because the oracle is locally sensitive (ADVICE r4).  25 = the largest ratio any case of the suite needed on the GPU
+# (profiles/r05/conditioning_tally_gpu.json), rounded up.
+CAP = 25.0
+
+# ---- the tally: which level did the comparisons of this run need?  (VERDICT r4 weak 2: a green suite says nothing about that.)
+# 'steps' = env steps the oracle computed for a test (tests/oracle_lib.py counts them; its own sensitivity runs excluded): the unit of the
+# denominator.  Judgments beyond the contract tolerance, one per QUANTITY (reward, a force, the pose block ...) that needed it:
+# 'floor' = within the absolute force floor; 'ulp' = within K x the oracle's 1-ulp sensitivity; 'step' = within K_STEP x its 1e-6 sensitivity;
+# 'geom' = within K_GEOM x its 1.2e-5 sensitivity; 'skipped' = a step that was computed and NOT compared.  'plain' = quantities that went through
+# within() / check() and passed at the contract tolerance (a subset of what the tests compare with bare asserts).
+# tests/conftest.py prints the totals in the terminal summary and FAILS the run when the judgments beyond 'plain' exceed MAX_NON_PLAIN x steps.
+LEVELS = ('steps', 'plain', 'floor', 'ulp', 'step', 'geom', 'skipped')
+IN_SENSITIVITY = [False]
+MAX_NON_PLAIN = 0.01
+TALLY = {k: 0 for k in LEVELS}
+_TALLY_FILE = os.environ.get('AGX_CONDITIONING_TALLY')              # xdist workers / the session: one JSON line per process at exit
+
+
+def tally(level, n=1):
+    TALLY[level] += int(n)
+
+
+def _dump_tally():
+    if _TALLY_FILE and any(TALLY.values()):
+        with open(_TALLY_FILE, 'a') as f:
+            f.write(json.dumps(TALLY) + '\n')
+
+
+atexit.register(_dump_tally)
 
 
 def _perturb_f32(x, rng):
@@ -50,6 +84,14 @@ def ulp_sensitivity(blob, oracle, state, action, cloth=None, trials=3, seed=0, c
             c = c.copy()
             o, r, d, i = oracle.step_cloth(s, c, action)
         return np.asarray(o, dtype=np.float64), float(r), np.asarray(i, dtype=np.float64), s.astype(np.float64)
+    IN_SENSITIVITY[0] = True
+    try:
+        return _ulp_sensitivity(blob, run, state, cloth, trials, seed, cloth_eps, rel_eps)
+    finally:
+        IN_SENSITIVITY[0] = False
+
+
+def _ulp_sensitivity(blob, run, state, cloth, trials, seed, cloth_eps, rel_eps):
     o0, r0, i0, s0 = run(state, cloth)
     rng = np.random.RandomState(seed)
     fw = float_words(blob)
@@ -69,8 +111,9 @@ def ulp_sensitivity(blob, oracle, state, action, cloth=None, trials=3, seed=0, c
 
 
 def bound(value_scale, sens, rel=1e-3, floor=0.0):
-    """the parity bound of a quantity of size `value_scale` whose 1-ulp sensitivity is `sens`"""
-    return max(rel * max(1.0, abs(value_scale)), K * sens, floor)
+    """the parity bound of a quantity of size `value_scale` whose 1-ulp sensitivity is `sens` (capped, see CAP)"""
+    base = max(rel * max(1.0, abs(value_scale)), floor)
+    return min(CAP * base, max(base, K * sens))
 
 
 def force_floor(blob):
@@ -113,16 +156,45 @@ def within(dev, scale, sens_fn, rel=1e-3, floor=0.0, step_sens_fn=None, geom_sen
     distance (-0.22171 vs -0.22189 mm) and normal; tool force 0.988 N vs 1.0116 N, while the oracle's own force moves by 3.5e-3 N per 1e-6 of
     input perturbation, linearly up to 3e-5: the device's deviation equals an input perturbation of 6.7e-6.  The persistent 4-point
     manifold of Bullet (DESIGN §2 deviations) removes the sliding point; until the device has it, this level stands.  K_GEOM = 1."""
-    lim = max(rel * max(1.0, abs(scale)), floor)
+    base = rel * max(1.0, abs(scale))
+    lim = max(base, floor)
+    cap = CAP * lim
     if dev <= lim:
+        tally('plain' if dev <= base else 'floor')
         return True, lim, None
     sens = float(sens_fn())
-    lim = max(lim, K * sens)
+    lim = min(cap, max(lim, K * sens))
     if dev <= lim or step_sens_fn is None:
+        if dev <= lim:
+            tally('ulp')
         return dev <= lim, lim, sens
     sens2 = float(step_sens_fn())
-    lim = max(lim, K_STEP * sens2)
+    lim = min(cap, max(lim, K_STEP * sens2))
     if dev <= lim or geom_sens_fn is None:
+        if dev <= lim:
+            tally('step')
         return dev <= lim, lim, sens2
     sens3 = float(geom_sens_fn())
-    return dev <= max(lim, K_GEOM * sens3), max(lim, K_GEOM * sens3), sens3
+    lim = min(cap, max(lim, K_GEOM * sens3))
+    if dev <= lim:
+        tally('geom')
+    return dev <= lim, lim, sens3
+
+
+def check(dev, base, floor=0.0, ulp=None, step=None, geom=None):
+    """The tests that scale their bounds themselves: is `dev` within `base` (the contract tolerance, already scaled), else within `floor`, else
+    within the limits the callables `ulp` / `step` / `geom` return (evaluated in that order, only when needed; each already multiplied by its
+    K), every limit capped at CAP x max(base, floor)?  Tallies the level that passed.  -> (ok, limit)"""
+    if dev <= base:
+        tally('plain'); return True, base
+    lim = max(base, floor)
+    if dev <= lim:
+        tally('floor'); return True, lim
+    cap = CAP * lim
+    for name, fn in (('ulp', ulp), ('step', step), ('geom', geom)):
+        if fn is None:
+            continue
+        lim = min(cap, max(lim, float(fn())))
+        if dev <= lim:
+            tally(name); return True, lim
+    return False, lim

@@ -29,6 +29,60 @@ def pytest_configure(config):
     m = config.getoption('-m') or ''
     _GPU_SELECTED[0] = 'gpu' in m and 'not gpu' not in m
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the conditioning tally (tests/conditioning.py): every process of the run -- this one, xdist workers -- appends its counts to one file
+    if not hasattr(config, 'workerinput') and 'AGX_CONDITIONING_TALLY' not in os.environ:
+        import tempfile
+        fd, path = tempfile.mkstemp(prefix='agx_conditioning_', suffix='.jsonl')
+        os.close(fd)
+        os.environ['AGX_CONDITIONING_TALLY'] = path
+        config._agx_tally_owner = path
+
+
+def _conditioning_totals(config):
+    import json
+    import conditioning as C
+    tot = {k: 0 for k in C.LEVELS}
+    path = os.environ.get('AGX_CONDITIONING_TALLY')
+    if path and os.path.exists(path):
+        for line in open(path):
+            for k, v in json.loads(line).items():
+                tot[k] += v
+    for k, v in C.TALLY.items():                    # this process has not exited yet
+        tot[k] += v
+    return tot
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How many oracle comparisons of this run passed at the contract tolerance, and how many needed which conditioning level
+    (VERDICT r4 weak 2).  More than 1 % beyond 'plain' fails the run (pytest_sessionfinish)."""
+    if hasattr(config, 'workerinput'):
+        return
+    import conditioning as C
+    tot = _conditioning_totals(config)
+    n = tot['steps']
+    non_plain = sum(tot[k] for k in C.LEVELS if k not in ('steps', 'plain'))
+    if n or non_plain:
+        terminalreporter.write_line('oracle comparisons: %d env steps compared; quantities judged beyond the contract tolerance: ' % n +
+                                    ', '.join('%s %d' % (k, tot[k]) for k in C.LEVELS if k not in ('steps', 'plain')) +
+                                    ' (checked plain through the same helpers: %d) -- beyond plain per compared step: %.2f %% (limit %.0f %%)'
+                                    % (tot['plain'], 100.0 * non_plain / max(n, 1), 100.0 * C.MAX_NON_PLAIN))
+        out = os.environ.get('AGX_CONDITIONING_REPORT')
+        if out:
+            import json
+            with open(out, 'w') as f:
+                json.dump(dict(steps_compared=n, levels=tot, beyond_plain_per_step=non_plain / max(n, 1), limit=C.MAX_NON_PLAIN), f)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    config = session.config
+    if hasattr(config, 'workerinput'):
+        return
+    import conditioning as C
+    tot = _conditioning_totals(config)
+    n = tot['steps']
+    non_plain = sum(tot[k] for k in C.LEVELS if k not in ('steps', 'plain'))
+    if n >= 1000 and non_plain > C.MAX_NON_PLAIN * n and session.exitstatus == 0:
+        session.exitstatus = 1                      # a green suite in which more than 1 % of the comparisons needed a conditioning level is not green
 
 
 @pytest.fixture(scope='session')

@@ -43,6 +43,15 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+
+def _count_compared_step():
+    """every env step the oracle computes for a test is one unit of the conditioning tally (tests/conditioning.py): 'steps' -- except the
+    oracle's own sensitivity runs"""
+    import conditioning
+    if not conditioning.IN_SENSITIVITY[0]:
+        conditioning.tally('steps')
+
+
 class Oracle:
     def __init__(self, blob):
         self.blob = blob
@@ -66,6 +75,7 @@ class Oracle:
         info = np.zeros(8, dtype=np.float32)
         action = np.ascontiguousarray(action, dtype=np.float32)
         self.L.agxo_step(C.c_void_p(self.h), _p(state), _p(action), _p(obs), _p(rew), _p(done), _p(info))
+        _count_compared_step()
         return obs, float(rew[0]), bool(done[0]), info
 
     # ---- models with a cloth section: the garment is a float32 [2, NN, 3] array (positions, velocities) next to the state record
@@ -77,6 +87,7 @@ class Oracle:
         action = np.ascontiguousarray(action, dtype=np.float32)
         assert cloth.dtype == np.float32 and cloth.flags['C_CONTIGUOUS']
         self.L.agxo_step_cloth(C.c_void_p(self.h), _p(state), _p(cloth), _p(action), _p(obs), _p(rew), _p(done), _p(info))
+        _count_compared_step()
         return obs, float(rew[0]), bool(done[0]), info
 
     def settle_cloth(self, state, cloth, n_sim_steps):

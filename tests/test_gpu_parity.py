@@ -435,13 +435,13 @@ def test_oracle_parity_at_bench_size(gpu_lib, blob, oracle):
     for i in picks:
         s = before[i].copy()
         o_obs, o_rew, o_done, o_info = oracle.step(s, a[i])
-        if info[i, 6] != o_info[6]:
-            flips += 1; continue                          # a borderline contact candidate decided differently in f32 and f64
+        flips += int(info[i, 6] != o_info[6])             # a borderline (speculative) contact candidate decided differently in f32 and f64: compared like every other
         worst['obs'] = max(worst['obs'], float(np.abs(obs[i] - o_obs).max()))
         worst['reward'] = max(worst['reward'], abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)))
         worst['force'] = max(worst['force'], abs(float(info[i, 0]) - float(o_info[0])) / max(1.0, abs(float(o_info[0]))))
-    print('bench-size parity:', worst, 'contact-count flips', flips, 'of 64')
+    print('bench-size parity:', worst, 'contact-count flips', flips, 'of 64 (compared too)')
     assert flips <= 4 and worst['obs'] < 1e-4 and worst['reward'] < 1e-4 and worst['force'] < 1e-3
+    __import__('conditioning').tally('plain', 3 * len(picks))
     env.close()
 
 
@@ -489,24 +489,26 @@ def test_noop_retest_rule_against_the_plain_solve(gpu_lib, workload):
             dev = dict(reward=abs(float(rew[i]) - o_rew) / max(1.0, abs(o_rew)), total_force=abs(info[i, 0] - o_info[0]) / max(1.0, abs(o_info[0])),
                        tool_force=abs(obs[i, f] - o_obs[f]) / max(1.0, abs(o_obs[f])), obs=float(np.abs(np.delete(obs[i] - o_obs, f)).max()))
             touching += int(o_info[0] > 0 or o_obs[f] > 0)
-            if max(dev['reward'], dev['total_force'], dev['tool_force']) > 1e-3 or dev['obs'] > 1e-3:
-                sens = C.ulp_sensitivity(b.set_param('NOOP_RETEST', 0.0), plain, ref[i], act[i], trials=4)
-                lim = dict(reward=C.K * sens['reward'] / max(1.0, abs(o_rew)), total_force=C.K * sens['info'][0] / max(1.0, abs(o_info[0])),
-                           tool_force=C.K * sens['obs'][f] / max(1.0, abs(o_obs[f])), obs=C.K * float(np.delete(sens['obs'], f).max()))
+            ff = C.force_floor(b)
+            floor = dict(reward=0.06 * ff / max(1.0, abs(o_rew)), total_force=ff / max(1.0, abs(o_info[0])), tool_force=ff / max(1.0, abs(o_obs[f])), obs=0.0)
+            cache = {}
+
+            def level(eps, kk, _i=i, _ref=ref, _act=act, _cache=cache, _o=(o_obs, o_rew, o_info)):
+                # the plain oracle's own response to a 1-ulp (eps None) / 1e-6 relative perturbation of its input, scaled like `dev`
+                if eps not in _cache:
+                    sn = C.ulp_sensitivity(b.set_param('NOOP_RETEST', 0.0), plain, _ref[_i], _act[_i], trials=4 if eps is None else 6, rel_eps=eps)
+                    _cache[eps] = dict(reward=kk * sn['reward'] / max(1.0, abs(_o[1])), total_force=kk * sn['info'][0] / max(1.0, abs(_o[2][0])),
+                                       tool_force=kk * sn['obs'][f] / max(1.0, abs(_o[0][f])), obs=kk * float(np.delete(sn['obs'], f).max()))
+                return _cache[eps]
+            for key in dev:
+                ok, lim = C.check(dev[key], 1e-3, floor[key], ulp=lambda: level(None, C.K)[key], step=lambda: level(C.STEP_EPS, C.K_STEP)[key])
+                assert ok, (workload, k, i, key, dev, lim, floor)
+            if cache:
                 conditioned += 1
-                ff = C.force_floor(b)
-                floor = dict(reward=0.06 * ff / max(1.0, abs(o_rew)), total_force=ff / max(1.0, abs(o_info[0])), tool_force=ff / max(1.0, abs(o_obs[f])), obs=0.0)
-                if any(dev[key] > max(1e-3, lim[key], floor[key]) for key in dev):      # step-level noise (conditioning.within): the oracle under a 1e-6 relative perturbation
-                    s2 = C.ulp_sensitivity(b.set_param('NOOP_RETEST', 0.0), plain, ref[i], act[i], trials=6, rel_eps=C.STEP_EPS)
-                    lim2 = dict(reward=C.K_STEP * s2['reward'] / max(1.0, abs(o_rew)), total_force=C.K_STEP * s2['info'][0] / max(1.0, abs(o_info[0])),
-                                tool_force=C.K_STEP * s2['obs'][f] / max(1.0, abs(o_obs[f])), obs=C.K_STEP * float(np.delete(s2['obs'], f).max()))
-                    lim = {key: max(lim[key], lim2[key]) for key in lim}
-                    print('step-level conditioning: %s step %d env %d dev %s bound %s' % (workload, k, i, {q: float('%.3g' % v) for q, v in dev.items()}, {q: float('%.3g' % v) for q, v in lim.items()}))
-                    import os
+                if C.STEP_EPS in cache:
+                    print('step-level conditioning: %s step %d env %d dev %s' % (workload, k, i, {q: float('%.3g' % v) for q, v in dev.items()}))
                     os.makedirs('gpurun_out', exist_ok=True)
                     np.savez('gpurun_out/noop_parity_case_%s_%d_%d.npz' % (workload, k, i), start=ref[i], action=act[i], dev_obs=obs[i], dev_info=info[i], oracle_obs=o_obs, oracle_info=o_info)
-                for key in dev:
-                    assert dev[key] <= max(1e-3, lim[key], floor[key]), (workload, k, i, key, dev, lim, floor)
             else:
                 for key in dev:
                     worst[key] = max(worst[key], dev[key])
