@@ -235,7 +235,7 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
       // the AABBs were grown by.  Unless the task asks whether a manifold point exists (group flag bit 1), a pair
       // further apart than that is of no interest and its GJK may stop at the first separating axis that proves it
       // (pairs such as two idle fingers 4 mm apart otherwise run to full convergence every substep).
-      if (!(GRI(c, g, AGX_G_FLAGS) & 2)) lim = fminf(brk, slack + rel_travel(c, a, b) + 1e-5f);
+      if (!(GRI(c, g, AGX_G_FLAGS) & (2 | 64))) lim = fminf(brk, slack + rel_travel(c, a, b) + 1e-5f);
     }
     k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.dist = 0.f;
     bool hit = narrowphase(c, a, b, lim, k, has && sub == 0);
@@ -260,7 +260,7 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
         near = true;
         v3 vr = point_velocity(c, CLI(c, a, AGX_C_BODY), k.pa) - point_velocity(c, CLI(c, b, AGX_C_BODY), k.pb);
         float pg = k.dist + dot(vr, k.n) * c.dt;
-        if (pg < slack) k.gap = pg;
+        if (pg < ((GRI(c, g, AGX_G_FLAGS) & 64) ? brk : slack)) k.gap = pg;      // bit6: a row for every contact of the group inside the break distance (agx_blob.h)
       }
       float* cd = CD + CAND_STRIDE * i;
       cd[0] = k.gap; st3(cd + 1, k.pa); st3(cd + 4, k.n); cd[7] = k.dist;
@@ -434,7 +434,7 @@ AGX_DEV void collide(Ctx& c) {
       if (gender == 1 && GRI(c, g, AGX_G_B0F) >= 0) { G.b0 = GRI(c, g, AGX_G_B0F); G.b1 = GRI(c, g, AGX_G_B1F); }
       G.flags = GRI(c, g, AGX_G_FLAGS); G.keep = GRI(c, g, AGX_G_KEEP);
       const int a0 = G.a0, a1 = G.a1, b0 = G.b0, b1 = G.b1;
-      const float mg = (G.flags & 2) ? brk : slack;
+      const float mg = (G.flags & (2 | 64)) ? brk : slack;
       // bit3 / bit4: male / female only; bit5: only while some human DoF is dynamic
       const bool wanted = !((G.flags & 8) && gender != 0) && !((G.flags & 16) && gender != 1) &&
                           !((G.flags & 32) && c.nrobot + c.nhdof <= 32 && ((~c.frozen >> c.nrobot) & ((1u << c.nhdof) - 1u)) == 0);
@@ -463,7 +463,7 @@ AGX_DEV void collide(Ctx& c) {
     } else {
       const int a0 = wave_bcast_i(G.a0, g), a1 = wave_bcast_i(G.a1, g), b0 = wave_bcast_i(G.b0, g), b1 = wave_bcast_i(G.b1, g);
       const int gflags = wave_bcast_i(G.flags, g);
-      const float mg = (gflags & 2) ? brk : slack;   // bit1: getContactPoints-style existence query
+      const float mg = (gflags & (2 | 64)) ? brk : slack;   // bit1: getContactPoints-style existence query; bit6: every contact inside the break distance is solved
       const int rep = face_box(c, b0) ? 1 + AGX_FACE_EXTRA : 1;   // B ranges are homogeneous (table boxes, the ground plane, ...)
       const int nb = (b1 - b0) * rep;
       if (ab < 0) { ab = a0; abatch = a1 - a0; }

@@ -77,7 +77,7 @@ SI = dict(TARGET=0, LIMB=3, PREV_CONTACT=12, WORDS=16)   # scratch itch task wor
 BB = dict(ALIVE=0, ALIVE_WORDS=6, PREV=6, HAS_PREV=10, WORDS=12)
 MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathing task words of the state record (AGX_BB_*)
 # pair-group flags (AGX_G_FLAGS)
-GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC = 1, 2, 4, 8, 16, 32
+GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC, GF_SOLVE_ALL = 1, 2, 4, 8, 16, 32, 64
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
 MAGIC, VERSION = 0x31584741, 15
 
@@ -601,6 +601,10 @@ class Groups:
         b0, b1 = self.rg[b]
         b0f, b1f = self.rg[alt] if alt else (-1, -1)
         assert b1 - b0 <= 128 and (b1f - b0f) <= 128 and a1 - a0 <= 128, 'a collider range must fit two wave-wide passes'
+        # the groups whose forces the tasks report (robot / tool against the person): every contact inside the break distance gets a row and
+        # none is dropped by a KEEP budget (include/agx_blob.h, group flag bit 6; round 5: the approximation study against the PLAIN oracle)
+        if a in ('tool', 'robot_arm', 'robot_gripper', 'robot_base', 'robot_links', 'robot_upper', 'robot_top') and (b.startswith('human') or b.startswith('harm')):
+            flags |= GF_SOLVE_ALL; keep = 0
         if a1 > a0 and b1 > b0:
             self.rows.append([a0, a1, b0, b1, b0f, b1f, (GF_SAME if same else 0) | (GF_MANIFOLD if manifold else 0) | (GF_NO_ADJACENT if no_adjacent else 0) | flags, keep])
 

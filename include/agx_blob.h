@@ -226,7 +226,13 @@ enum {
                                    (URDF_USE_SELF_COLLISION semantics, jaco.py:53);
                                    bit3 / bit4: the group exists for a male / female human only (both collider ranges
                                    are gender specific, e.g. the human's arm against the rest of its body);
-                                   bit5: the group is skipped while every human DoF is frozen (both sides static)   */
+                                   bit5: the group is skipped while every human DoF is frozen (both sides static);
+                                   bit6: a solver row for EVERY contact of the group inside CONTACT_BREAK, not only those whose
+                                   predicted gap is below CONTACT_SLACK (the prediction knows nothing of the motor rows: a tool
+                                   driven onto the person closes gaps it calls open).  Set on the groups whose forces the tasks
+                                   report -- robot / tool against the person -- together with KEEP = 0: against the oracle without
+                                   any budget these two were worth up to 0.5 relative on total_force_on_human in 1-2 % of the
+                                   contact-rich steps (round 5, profiles/r05/approximation_budget.json)                     */
   AGX_G_KEEP = 7,               /* per A collider keep only the KEEP contacts with the smallest
                                    predicted gap (0 = keep all)                               */
   AGX_G_STRIDE = 8

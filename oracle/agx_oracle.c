@@ -21,12 +21,29 @@
 #define MAXFREE 16
 #define MAXHUMAN 24
 #define NVMAX (MAXDOF + 6 * MAXFREE)
+/* limits; the PLAIN build of the approximation study (oracle/Makefile `plain`, tests/diag/approximation_budget.py) raises them: full hulls,
+ * every candidate contact kept, every contact inside the break distance solved */
+#ifndef MAXC
 #define MAXC 96
+#endif
+#ifndef MAXROWS
 #define MAXROWS 320
+#endif
+#ifndef MAXV
 #define MAXV 80 /* max vertices of one collider core */
+#endif
+#ifndef MAXCAND
+#define MAXCAND 128 /* candidate contacts of one collider against one pair group */
+#endif
 #define MAXCOLL 512
 #define MAXQPT 16
+#ifndef MAXMAN
 #define MAXMAN 192
+#endif
+/* narrowphase calls whose CORES overlapped since the last agxo_stat_core_overlaps(): the 42-direction penetration sampling ran instead of
+ * the exact GJK distance (how often does the approximate depth matter at all?) */
+static long g_stat_core_overlap = 0, g_stat_narrowphase = 0;
+void agxo_stat_core_overlaps(long* out2) { out2[0] = g_stat_core_overlap; out2[1] = g_stat_narrowphase; g_stat_core_overlap = 0; g_stat_narrowphase = 0; }
 
 typedef struct { double p[3]; double R[9]; } xf_t;
 
@@ -600,6 +617,7 @@ static int narrowphase_ab(const sim_t* s, int ca, int cb, double limit, contact_
   if (clipped) for (int k = 0; k < 3; k++) cen[1][k] = 0.5 * (vb[k] + vb[3 * 7 + k]);
   sub3(cen[0], cen[1], d0);
   int pen = gjk_core(va, na, vb, nb, PARAM(m, AGX_P_GJK_TOL), (int)PARAM(m, AGX_P_GJK_MAXIT), d0, &d, pa, pb, NULL);
+  g_stat_narrowphase++; if (pen) g_stat_core_overlap++;
   if (!pen) {
     if (d - ra - rb >= limit) return 0;
     sub3(pa, pb, n); for (int k = 0; k < 3; k++) n[k] /= d;
@@ -728,9 +746,13 @@ static void collide(sim_t* s) {
       if (((fl & 8) && s->gender != 0) || ((fl & 16) && s->gender != 1)) continue;
       if ((fl & 32) && m->ndof <= 32 && ((~s->frozen >> m->nrobot) & ((1u << m->nhdof) - 1u)) == 0) continue;
     }
-    const double mg = (GI(m, g, AGX_G_FLAGS) & 2) ? brk : slack;   /* bit1: getContactPoints-style existence query */
+    /* bit6: a solver row for EVERY contact of the group inside the break distance, not only those that can close within the substep by
+     * their predicted velocity (the groups whose forces the task reports: robot / tool against the person).  The predicted velocity knows
+     * nothing of the motor rows: a pad driven onto the arm closes gaps the prediction calls open (profiles/r05/approximation_budget.json) */
+    const double gslack = (GI(m, g, AGX_G_FLAGS) & 64) ? brk : slack;
+    const double mg = (GI(m, g, AGX_G_FLAGS) & (2 | 64)) ? brk : slack;   /* bit1: getContactPoints-style existence query */
     for (int a = a0; a < a1; a++) {
-      contact_t cand[128]; double gap[128]; int nc = 0;
+      contact_t cand[MAXCAND]; double gap[MAXCAND]; int nc = 0;
       for (int b = (same ? a + 1 : b0); b < b1; b++) {
         if (GI(m, g, AGX_G_FLAGS) & 4) {   /* self-collision: not the same link, not parent and child */
           int la = CI(m, a, AGX_C_BODY), lb = CI(m, b, AGX_C_BODY);
@@ -756,12 +778,12 @@ static void collide(sim_t* s) {
         /* solver row only if the gap can close within this substep */
         double va[3], vb[3], vr[3]; point_velocity(s, k.ba, k.pa, va); point_velocity(s, k.bb, k.pb, vb); sub3(va, vb, vr);
         double pg = k.dist + dot3(vr, k.n) * dt;
-        if (pg < slack) { cand[nc] = k; gap[nc] = pg; nc++; }
+        if (pg < gslack && nc < MAXCAND) { cand[nc] = k; gap[nc] = pg; nc++; }
         for (int e = 0; e < ne; e++) {
           if (extra[e].dist >= brk) continue;
           point_velocity(s, extra[e].ba, extra[e].pa, va); point_velocity(s, extra[e].bb, extra[e].pb, vb); sub3(va, vb, vr);
           double pg2 = extra[e].dist + dot3(vr, extra[e].n) * dt;
-          if (pg2 < slack && nc < 128) { cand[nc] = extra[e]; gap[nc] = pg2; nc++; }
+          if (pg2 < gslack && nc < MAXCAND) { cand[nc] = extra[e]; gap[nc] = pg2; nc++; }
         }
       }
       /* keep the `keep` candidates with the smallest predicted gap (ties: lower B index), emitted in

@@ -1,0 +1,196 @@
+"""What do the throughput-motivated approximations that oracle and device SHARE cost?  (VERDICT r4 missing 2.)
+
+The product conventions -- robot hulls decimated to <= 64 vertices (model/meshio.py reduce_hull), per-pair-group KEEP budgets and the 1 mm solver
+slack (speculative contacts beyond it get no row), the 64-contact / 160-row / 2,040-pair budgets, the no-op re-test rule -- are applied by the
+oracle exactly as by the device, so every device-vs-oracle test is blind to them.  Here the DEFAULT oracle is compared with a PLAIN one:
+
+    full collision hulls (the compiler run with robot_hull_max_verts=None), KEEP = 0 in every pair group (every candidate kept),
+    CONTACT_SLACK = CONTACT_BREAK (a row for every contact inside the 2 cm break distance), contact / row / pair budgets of 1024 / 4096 / 10^6
+    (oracle/Makefile `plain`: the same source with larger arrays), NOOP_RETEST = 0 (plain 50 sweeps)
+
+step by step from the SAME state: the default oracle free-runs 3 x 200 random-policy steps per BASELINE config ('random_policy'), and 8 steps of
+small actions from every start state in which the robot or its tool touches the person ('contact_rich': the reference-pinned cases of
+tests/refcases.py and the bench's wiping pool); at every step the PLAIN oracle steps from the default's state with the same action, and reward,
+total_force_on_human and the tool force are compared (relative to max(1, |x|), north_star's 1e-3).  The one shared approximation PLAIN does not remove is the 42-direction penetration sampling for colliders whose CORES
+overlap (a contact pressed deeper than the sum of the two margins): the script counts how often that path ran at all.
+Needs /root/reference (the compiler reads the reference's assets): run here, result committed as profiles/r05/approximation_budget.json.
+usage: python tests/diag/approximation_budget.py [config ...] [--steps 200] [--seeds 3]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from assistive_gym_amd.blob import ModelBlob            # noqa: E402
+from assistive_gym_amd.model import compiler as L        # noqa: E402
+import oracle_lib                                        # noqa: E402
+
+
+PROPOSED = [None]  # --proposed KEEP: instead of the default conventions, the default blob with group flag bit 6 (a row for every contact inside the
+                   # break distance) and KEEP = the given value on the groups robot / tool x person -- what would that leave of the deviation?
+
+
+def proposed_blob(b):
+    keep = PROPOSED[0]
+    w = b.words.copy(); wi = w.view(np.int32)
+    g0, c0 = b.h['OFF_GROUP'], b.h['OFF_COLL']
+    n = 0
+    for g in range(b.h['NGROUP']):
+        r = g0 + L.G['STRIDE'] * g
+        ta = wi[c0 + wi[r + L.G['A0']] * L.C['STRIDE'] + L.C['TAG']]; tb = wi[c0 + wi[r + L.G['B0']] * L.C['STRIDE'] + L.C['TAG']]
+        if (ta in (L.TAG['ROBOT'], L.TAG['TOOL']) and tb == L.TAG['HUMAN']) or (ta == L.TAG['TOOL'] and tb in (L.TAG['BED'], L.TAG['TABLE'], L.TAG['WHEELCHAIR'], L.TAG['PLANE'], L.TAG['BOWL'])):
+            wi[r + L.G['FLAGS']] |= 64; wi[r + L.G['KEEP']] = keep; n += 1
+    assert n > 0
+    return ModelBlob(w, b.meta)
+
+
+ONLY = [None]      # --only hulls|keep|slack|noop|budgets: ONE of PLAIN's changes at a time (attribution runs)
+
+
+def plain_blob(name):
+    only = ONLY[0]
+    if only and only != 'hulls':
+        b = ModelBlob.load(name)
+        w = b.words.copy(); wi = w.view(np.int32)
+        if only == 'keep':
+            for g in range(b.h['NGROUP']):
+                wi[b.h['OFF_GROUP'] + L.G['STRIDE'] * g + L.G['KEEP']] = 0
+        b = ModelBlob(w, b.meta)
+        for k, v in (('MAX_CONTACTS', 1024.0), ('MAX_ROWS', 4096.0), ('MAX_ENTRIES', 1.0e6)):
+            b = b.set_param(k, v)
+        if only == 'slack':
+            b = b.set_param('CONTACT_SLACK', b.param('CONTACT_BREAK'))
+        if only == 'noop':
+            b = b.set_param('NOOP_RETEST', 0.0)
+        return b
+    words, meta = {'feeding_jaco': lambda: L.compile_feeding('jaco', robot_hull_max_verts=None),
+                   'bed_bathing_sawyer': lambda: L.compile_bed_bathing('sawyer', robot_hull_max_verts=None),
+                   'scratch_itch_pr2': lambda: L.compile_scratch_itch('pr2', robot_hull_max_verts=None),
+                   'dressing_baxter': lambda: L.compile_dressing('baxter', robot_hull_max_verts=None)}[name]()
+    b = ModelBlob(words, meta)
+    if only == 'hulls':
+        return b
+    w = b.words.copy(); wi = w.view(np.int32)
+    g0 = b.h['OFF_GROUP']
+    for g in range(b.h['NGROUP']):
+        wi[g0 + L.G['STRIDE'] * g + L.G['KEEP']] = 0
+    b = ModelBlob(w, meta)
+    for k, v in (('CONTACT_SLACK', b.param('CONTACT_BREAK')), ('MAX_CONTACTS', 1024.0), ('MAX_ROWS', 4096.0), ('MAX_ENTRIES', 1.0e6), ('NOOP_RETEST', 0.0)):
+        b = b.set_param(k, v)
+    return b
+
+
+def states_for(config, blob, n, seed):
+    if config == 'config2_feeding':
+        from assistive_gym_amd.host.reset import make_states
+        st, _ = make_states(blob, n, seed=seed)
+        return st, None
+    if config == 'config3_bedbathing':
+        from assistive_gym_amd.host.reset_bed import make_states
+        return make_states(blob, n, seed=seed)[0], None
+    if config == 'config4_scratchitch_coop':
+        from assistive_gym_amd.host.reset_scratch import make_states
+        return make_states(blob, n, seed=seed)[0], None
+    from assistive_gym_amd.host.reset_dressing import make_states
+    s, c, _ = make_states(blob, n, seed=seed)
+    return s, c
+
+
+CONFIGS = {'config2_feeding': ('feeding_jaco', False, 1.0), 'config3_bedbathing': ('bed_bathing_sawyer', False, 1.0), 'config4_scratchitch_coop': ('scratch_itch_pr2', True, 1.0),
+           'config5_dressing': ('dressing_baxter', False, 1.0)}
+
+
+def contact_rich_starts(config, d):
+    """start states in which the robot / its tool touches the person: the reference-pinned cases of the model (tests/refcases.py: spoon pushed
+    against the face, pad wiping, scratcher on the skin, arm lifting, sleeve on the forearm) and, for config 3, the bench's wiping pool"""
+    import refcases
+    name, coop, _ = CONFIGS[config]
+    task = {'feeding_jaco': 'feeding', 'bed_bathing_sawyer': 'bed', 'scratch_itch_pr2': 'scratch', 'dressing_baxter': 'dressing'}[name]
+    out = [(c['state'].copy(), None if c['cloth'] is None else c['cloth'].copy()) for c in refcases.build_cases(tasks=(task,))
+           if c['model'] == name and bool(c['coop']) == coop and not c['variant']]
+    if name == 'bed_bathing_sawyer':
+        from bench import wiping_pool
+        st = wiping_pool(d, 48, 977); d.view(st)['iteration'][:] = 0
+        out += [(x.copy(), None) for x in st]
+    for s, c in out:
+        d.view(s.reshape(1, -1))['iteration'][0] = 0
+    return out
+
+
+def compare(d, od, op, starts, steps, scale, seed, settle=0, cloth_settle=0):
+    f = d.obs_dim_robot - 1
+    rel = dict(reward=[], total_force=[], tool_force=[]); absd = dict(reward=[], total_force=[], tool_force=[])
+    ncon = dict(default=[], plain=[]); touching = 0
+    fl = slice(0, d.h['S_ENV'])                              # the float part of a record (the env / task words hold integers)
+    for k0, (s, c) in enumerate(starts):
+        if settle:
+            od.settle(s, settle)
+        if c is not None and cloth_settle:
+            od.settle_cloth(s, c, cloth_settle)
+        rng = np.random.RandomState(seed + k0)
+        for k in range(steps):
+            a = (rng.uniform(-1, 1, d.act_dim) * scale).astype(np.float32)
+            sp = s.copy(); cp = None if c is None else c.copy()
+            if c is None:
+                o, r, dn, i = od.step(s, a); po, pr, _, pi = op.step(sp, a)
+            else:
+                o, r, dn, i = od.step_cloth(s, c, a); po, pr, _, pi = op.step_cloth(sp, cp, a)
+            for key, x, y in (('reward', r, pr), ('total_force', i[0], pi[0]), ('tool_force', o[f], po[f])):
+                absd[key].append(abs(float(x) - float(y))); rel[key].append(abs(float(x) - float(y)) / max(1.0, abs(float(y))))
+            ncon['default'].append(float(i[6])); ncon['plain'].append(float(pi[6])); touching += int(pi[0] > 0 or po[f] > 0)
+            if dn or not np.isfinite(s[fl]).all():
+                break
+    out = dict(steps_compared=len(rel['reward']), steps_with_a_force_on_the_person_or_the_tool=touching,
+               contacts_last_substep=dict(default=float(np.mean(ncon['default'])), plain=float(np.mean(ncon['plain']))))
+    for key in rel:
+        r = np.array(rel[key]); a = np.array(absd[key])
+        out[key] = dict(rel_p50=float(np.percentile(r, 50)), rel_p99=float(np.percentile(r, 99)), rel_max=float(r.max()), abs_p99=float(np.percentile(a, 99)), abs_max=float(a.max()),
+                        frac_above_1e_3=float((r > 1e-3).mean()))
+    return out
+
+
+def run(config, steps, seeds):
+    name, coop, scale = CONFIGS[config]
+    d, p = ModelBlob.load(name), plain_blob(name)
+    if PROPOSED[0] is not None:
+        d = proposed_blob(d)
+    if coop:
+        d, p = d.coop(), p.coop()
+    assert d.state_words == p.state_words and d.obs_dim == p.obs_dim
+    od, op = oracle_lib.Oracle(d), oracle_lib.Oracle(p, plain=True)
+    stat = (C.c_long * 2)()
+    op.L.agxo_stat_core_overlaps(stat)
+    t0 = time.time()
+    starts = []
+    for sd in range(seeds):
+        st, cl = states_for(config, d, 1, 4100 + 17 * sd)
+        starts.append((st[0].copy(), None if cl is None else cl[0].copy()))
+    out = dict(config=config, model=name, hull_vertices=dict(default=int(d.h['NVERT']), plain=int(p.h['NVERT'])))
+    out['random_policy'] = compare(d, od, op, starts, steps, scale, 500, settle=25 if name == 'feeding_jaco' else 0, cloth_settle=20)
+    out['contact_rich'] = compare(d, od, op, contact_rich_starts(config, d), 8, 0.15, 900)
+    op.L.agxo_stat_core_overlaps(stat)
+    out.update(seconds=round(time.time() - t0, 1), plain_narrowphase_calls=int(stat[1]), plain_core_overlaps_sampled_in_42_directions=int(stat[0]))
+    return out
+
+
+if __name__ == '__main__':
+    args = sys.argv[1:]
+    steps = int(args[args.index('--steps') + 1]) if '--steps' in args else 200
+    seeds = int(args[args.index('--seeds') + 1]) if '--seeds' in args else 3
+    names = [a for a in args if a in CONFIGS] or list(CONFIGS)
+    if '--proposed' in args:
+        PROPOSED[0] = int(args[args.index('--proposed') + 1])
+    if '--only' in args:
+        ONLY[0] = args[args.index('--only') + 1]
+    res = []
+    for cfg in names:
+        r = run(cfg, steps if cfg != 'config5_dressing' else min(steps, 40), seeds)
+        print(json.dumps(r)); sys.stdout.flush()
+        res.append(r)
+    out = args[args.index('--out') + 1] if '--out' in args else None
+    if out:
+        json.dump(dict(what=__doc__.split('\n\n')[0], configs=res), open(out, 'w'), indent=1)

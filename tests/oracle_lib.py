@@ -7,6 +7,22 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = None
+_PLAIN = None
+
+
+def plain_lib():
+    """the same oracle source built with room for full hulls and unbudgeted contact lists (oracle/Makefile `plain`; tests/diag/approximation_budget.py)"""
+    global _PLAIN
+    if _PLAIN is None:
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'plain'], stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(ROOT, 'oracle', 'libagx_oracle_plain.so'))
+        L.agxo_load.restype = C.c_void_p
+        L.agxo_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.agxo_free.argtypes = [C.c_void_p]
+        for name in ('agxo_step', 'agxo_settle', 'agxo_step_cloth', 'agxo_settle_cloth'):
+            getattr(L, name).restype = None
+        _PLAIN = L
+    return _PLAIN
 
 
 def lib():
@@ -53,9 +69,9 @@ def _count_compared_step():
 
 
 class Oracle:
-    def __init__(self, blob):
+    def __init__(self, blob, plain=False):
         self.blob = blob
-        self.L = lib()
+        self.L = plain_lib() if plain else lib()
         self.words = np.ascontiguousarray(blob.words)
         self.h = self.L.agxo_load(_p(self.words), C.c_size_t(len(self.words)))
         assert self.h, 'oracle rejected the model blob'

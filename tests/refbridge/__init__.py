@@ -583,6 +583,8 @@ def adopt(blob, state, cloth=None):
     trem = v['tremor'][0].astype(np.float64)
     H.impairment = 'tremor' if np.any(trem != 0) else ('limits' if w.limit_scale != 1.0 else 'none')
     H.limit_scale, H.strength = w.limit_scale, 1.0
+    if float(v['human_kp'][0]) > 0:                                           # impairment 'weakness': the reactive hold's force is reactive_force x strength (human.py:126)
+        H.strength = float(v['human_maxf'][0]) / {'scratch_itch': 1.0, 'dressing': 1.0, 'arm_manipulation': 0.01}.get(task, 1.0)
     hdofs = [d for d in range(blob.nrobot, blob.ndof)]
     pb_of = {blob.robot_i(d, 'PB_INDEX', w.gender): d for d in hdofs}
     assert all(j in pb_of for j in H.controllable_joint_indices), 'the model does not simulate every controllable joint of the human'

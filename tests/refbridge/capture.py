@@ -152,8 +152,11 @@ def capture(env, blob, p, initial, cloth_out=None):
         # (bed_bathing.py:139, human.py:108-112); the other tasks keep the arm dynamic behind a reactive hold (human.py:124-127)
         v['frozen'][0] = (((1 << blob.nhdof) - 1) << nr) if (task == 'bed_bathing' and not agent) else 0
         if not agent and task != 'bed_bathing':                                                          # the reactive hold of setup_joints (human.py:124-127)
-            gain = {'bed_bathing': 0.01, 'scratch_itch': 0.01, 'dressing': 0.01, 'arm_manipulation': 0.01}[task]
-            v['human_kp'][0], v['human_maxf'][0] = gain, 1.0 * getattr(H, 'strength', 1.0)
+            # (gain, force) as the task's reset() hands them to setup_joints: scratch_itch.py:105 and dressing.py:124 reactive_force=1, reactive_gain=0.01;
+            # arm_manipulation.py:141 reactive_force=0.01 with setup_joints' default gain of 0.05 (human.py:104).  [found by the bridge rehearsal of
+            # tools/pybullet_dump.py, round 5: the arm-manipulation pair was recorded as (0.01, 1.0)]
+            gain, force = {'scratch_itch': (0.01, 1.0), 'dressing': (0.01, 1.0), 'arm_manipulation': (0.05, 0.01)}[task]
+            v['human_kp'][0], v['human_maxf'][0] = gain, force * getattr(H, 'strength', 1.0)
         if task == 'bed_bathing':
             v['task_success'][0] = env.task_success
             alive = [0] * 6

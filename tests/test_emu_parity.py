@@ -537,7 +537,8 @@ def test_persistent_manifold_matches_the_oracle(blob, scene):
         assert abs(obs[f] - o_obs[f]) <= max(1e-3 * max(1.0, abs(o_obs[f])), 1e-2) and abs(info[0] - o_info[0]) <= max(1e-3 * max(1.0, abs(o_info[0])), 1e-2), (scene, k, obs[f], o_obs[f])
         differs = max(differs, float(np.abs(so - sp)[:b.h['S_ENV']].max()))
         se[:] = so; sp[:] = so
-    assert differs > 1e-7 and (more > 0 or scene == 'wiping'), (differs, more)      # (the wiping steps end with as many contacts, at other points)
+    # (the wiping and scratching steps end with as many contacts, at other points: tool x person keeps every contact inside the break distance since round 5, group flag bit 6)
+    assert differs > 1e-7 and (more > 0 or scene != 'feeding'), (differs, more)
     stats = o.manifold_stats()
     print('%s: manifold points replaced %d, appended %d, replaced by the area rule %d, dropped at the refresh %d' % ((scene,) + tuple(int(x) for x in stats)))
     assert stats[0] > 0 and stats[1] > 0 and (scene != 'wiping' or stats[3] > 0), stats          # (the pad slides: points drift out and are dropped)
@@ -591,7 +592,8 @@ def test_persistent_manifold_area_rule():
     stats = o.manifold_stats()
     assert stats[2] == 1, stats                                     # the area rule fired once
     mo, me = o.manifold_get(), e.manifold_get()
-    assert len(mo) == len(me) == 4 and np.array_equal(mo[:, :2], me[:, :2])
+    # (other pairs of the tool with the arm lie inside the break distance and have cached points of their own since round 5: group flag bit 6)
+    assert len(mo) == len(me) and np.array_equal(mo[:, :2], me[:, :2]) and int(((mo[:, 0] == ca) & (mo[:, 1] == cb)).sum()) == 4
     assert np.abs(mo[:, 2:] - me[:, 2:]).max() < 2e-5, np.abs(mo - me).max()
     assert e_out[3][6] == o_out[3][6] and np.abs(e_out[0] - o_out[0]).max() < 1e-3
     o.forget_warm()

@@ -1,0 +1,160 @@
+"""-m gpu: oracle parity AT THE BENCH SIZE for every BASELINE configuration (VERDICT r4 missing 3).  4096 environments in one handle -- the
+chunk streams, the pool draws, the occupancy the bench line is measured at -- are rolled forward under a random policy; then ONE more step from
+the states as they are, and a spread of the 4096 environments is compared with the CPU oracle one by one: observation, reward, the forces the
+reward is made of.  Environments whose borderline contact candidates come out differently in float32 and float64 ("flips") are compared like all
+others.  Quantities beyond the contract tolerance (north_star: 1e-3 relative on forces and rewards) go through tests/conditioning.py and are
+counted in the run's tally.  PARITY UNPINNED vs PyBullet: the oracle is this repository's restatement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    from assistive_gym_amd import libagx
+    if libagx.load().agx_device_count() <= 0:
+        __import__('conftest').no_gpu()
+
+
+def _compare(blob, oracle, before, act, obs, rew, info, picks, label, cloth=None, pose_tol=1e-4):
+    """picked environments one by one.  Force entries of the observation (the tool force; co-op: the two force entries of the human's half),
+    total_force_on_human, the robot's and the tool's force on the person (info 0, 2, 3) and the reward: 1e-3 relative, then the force floor, then the oracle's own 1-ulp
+    and 1e-6 sensitivities (counted); everything else of the observation: pose_tol absolute."""
+    import conditioning as C
+    f = blob.obs_dim_robot - 1
+    fcols = [f] + ([blob.obs_dim - 2, blob.obs_dim - 1] if blob.is_coop else [])
+    ff = C.force_floor(blob)
+    worst = dict(pose=0.0, reward=0.0, force=0.0)
+    flips, judged = 0, 0
+    for i in picks:
+        s = before[i].copy()
+        c = None if cloth is None else cloth[i].copy()
+        o_obs, o_rew, o_done, o_info = oracle.step(s, act[i]) if c is None else oracle.step_cloth(s, c, act[i])
+        flips += int(info[i, 6] != o_info[6])
+        cache = {}
+
+        def sens(eps, _i=i):
+            if eps not in cache:
+                cache[eps] = C.ulp_sensitivity(blob, oracle, before[_i], act[_i], cloth=None if cloth is None else cloth[_i], trials=4 if eps is None else 6, rel_eps=eps,
+                                               cloth_eps=1e-6 if cloth is not None else None)
+            return cache[eps]
+        dev = np.abs(obs[i] - o_obs)
+        pose = float(np.delete(dev, fcols).max())
+        ok, lim = C.check(pose, pose_tol, ulp=lambda: C.K * float(np.delete(sens(None)['obs'], fcols).max()), step=lambda: C.K_STEP * float(np.delete(sens(C.STEP_EPS)['obs'], fcols).max()))
+        assert ok, (label, i, 'pose', pose, lim)
+        worst['pose'] = max(worst['pose'], pose)
+        for k in fcols:
+            ok, lim = C.check(dev[k], 1e-3 * max(1.0, abs(o_obs[k])), ff, ulp=lambda: C.K * sens(None)['obs'][k], step=lambda: C.K_STEP * sens(C.STEP_EPS)['obs'][k])
+            assert ok, (label, i, 'obs force', k, obs[i, k], o_obs[k], lim)
+            worst['force'] = max(worst['force'], dev[k] / max(1.0, abs(o_obs[k])))
+        for q in (0, 2, 3):                           # total_force_on_human, the robot's force on the person, the tool's
+            d = abs(float(info[i, q]) - float(o_info[q]))
+            ok, lim = C.check(d, 1e-3 * max(1.0, abs(o_info[q])), ff, ulp=lambda: C.K * sens(None)['info'][q], step=lambda: C.K_STEP * sens(C.STEP_EPS)['info'][q])
+            assert ok, (label, i, 'info', q, info[i, q], o_info[q], lim)
+            worst['force'] = max(worst['force'], d / max(1.0, abs(o_info[q])))
+        d = abs(float(rew[i]) - o_rew)
+        # the reward carries the forces with the task's weights (at most 0.06 per newton, config.ini): its floor is that share of the force floor
+        ok, lim = C.check(d, 1e-3 * max(1.0, abs(o_rew)), 0.06 * ff, ulp=lambda: C.K * sens(None)['reward'], step=lambda: C.K_STEP * sens(C.STEP_EPS)['reward'])
+        assert ok, (label, i, 'reward', rew[i], o_rew, lim)
+        worst['reward'] = max(worst['reward'], d / max(1.0, abs(o_rew)))
+        assert info[i, 1] == o_info[1], (label, i, 'task_success', info[i, 1], o_info[1])
+        judged += int(bool(cache))
+    print('%s: bench-size parity over %d of 4096 environments: worst pose %.2e, reward %.2e (relative), force %.2e (relative); contact-count flips %d (compared too); '
+          'environments that needed a conditioning level %d' % (label, len(picks), worst['pose'], worst['reward'], worst['force'], flips, judged))
+    return worst, flips, judged
+
+
+def _rollout(env, steps, seed, scale=1.0):
+    import torch
+    n = env.n_envs
+    g = torch.Generator(device='cuda'); g.manual_seed(seed)
+    contacts = 0.0
+    for k in range(steps):
+        env.step((torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1) * scale)
+        contacts += float(env.info[:, 6].mean())
+    torch.cuda.synchronize()
+    before = env.stepper.get_state()
+    a = (torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1) * scale
+    return before, a, contacts / max(steps, 1)
+
+
+PICKS = [(i * 67) % 4096 for i in range(64)]
+
+
+@pytest.mark.parametrize('config', ['config3_random', 'config3_wiping', 'config4_coop'])
+def test_oracle_parity_at_bench_size(config):
+    """BedBathingSawyer-v1 (random policy; the contact-rich wiping pool of bench.py) and ScratchItchPR2Human-v1 (co-op) at 4096 environments"""
+    _gpu()
+    import torch
+    from assistive_gym_amd import vec_env
+    from oracle_lib import Oracle
+    n = 4096
+    if config.startswith('config3'):
+        env = vec_env.BedBathingSawyerVecEnv(n, pool_size=64, seed=2303)
+        if config == 'config3_wiping':
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import wiping_pool
+            env.set_pool(wiping_pool(env.blob, 64, 2303))
+        steps, scale = (20, 1.0) if config == 'config3_random' else (5, 0.15)      # the wiping pool's episodes are 8 steps long: compare inside one
+    else:
+        env = vec_env.ScratchItchPR2HumanVecEnv(n, pool_size=64, seed=2404)
+        steps, scale = 20, 1.0
+    blob = env.blob
+    oracle = Oracle(blob)
+    env.reset()
+    before, a, contacts = _rollout(env, steps, 7, scale)
+    obs, rew, done, info = env.step(a)
+    torch.cuda.synchronize()
+    obs, rew, info, a = obs.cpu().numpy(), rew.cpu().numpy(), info.cpu().numpy(), a.cpu().numpy()
+    worst, flips, judged = _compare(blob, oracle, before, a, obs, rew, info, PICKS, config)
+    print('%s: contacts per env step during the rollout %.2f' % (config, contacts))
+    assert flips <= 6 and judged <= 6
+    env.close()
+
+
+def test_oracle_parity_at_bench_size_dressing():
+    """DressingBaxter-v1 at 4096 environments (4096 garments of 3,966 nodes): 16 environments against the oracle's 40 substeps + cloth solve.  The rigid
+    part and the sleeve geometry at the contract tolerance; the cloth-force term (a sum over hundreds of node contacts that switch on and off
+    at the margin shell) against the oracle's own spread under a 1e-6 m perturbation of the garment, as tests/test_gpu_dressing.py does."""
+    _gpu()
+    import torch
+    import conditioning as C
+    from assistive_gym_amd import vec_env
+    from oracle_lib import Oracle
+    n = 4096
+    env = vec_env.DressingBaxterVecEnv(n, pool_size=32, seed=2505)
+    blob = env.blob
+    oracle = Oracle(blob)
+    env.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(9)
+    for k in range(6):
+        env.step(torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1)
+    torch.cuda.synchronize()
+    picks = [(i * 67) % n for i in range(16)]
+    before = env.stepper.get_state()
+    cloth_t = env.stepper.cloth_tensor()
+    before_c = {i: cloth_t[i].cpu().numpy().copy() for i in picks}
+    a = torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1
+    obs, rew, done, info = env.step(a)
+    torch.cuda.synchronize()
+    obs, rew, info, a = obs.cpu().numpy(), rew.cpu().numpy(), info.cpu().numpy(), a.cpu().numpy()
+    rel_force, rel_sens = [], []
+    for i in picks:
+        s, c = before[i].copy(), before_c[i].copy()
+        sens = C.ulp_sensitivity(blob, oracle, before[i], a[i], cloth=before_c[i], trials=2, seed=i, cloth_eps=1e-6)
+        o_obs, o_rew, o_done, o_info = oracle.step_cloth(s, c, a[i])
+        pose = float(np.abs(obs[i, :23] - o_obs[:23]).max())
+        ok, lim = C.check(pose, 1e-4, ulp=lambda: C.K * float(sens['obs'][:23].max()))
+        assert ok, (i, 'pose', pose, lim)
+        rel_force.append(abs(obs[i, 23] - o_obs[23]) / max(1.0, abs(o_obs[23]))); rel_sens.append(sens['obs'][23] / max(1.0, abs(o_obs[23])))
+        ok, lim = C.check(abs(info[i, 4] - o_info[4]), 1e-3 * max(1.0, abs(o_info[4])), ulp=lambda: C.K * sens['info'][4])      # reward_dressing
+        assert ok, (i, 'reward_dressing', info[i, 4], o_info[4], lim)
+        # reward = reward_dressing + C_d x cloth forces + preferences: beyond the cloth-force share (0.01 per newton of the difference) it is determined
+        ok, lim = C.check(max(0.0, abs(rew[i] - o_rew) - 0.01 * abs(obs[i, 23] - o_obs[23])), 1e-3 * max(1.0, abs(o_rew)), ulp=lambda: C.K * sens['reward'])
+        assert ok, (i, 'reward', rew[i], o_rew, lim)
+    print('DressingBaxter at 4096: cloth_force_sum relative deviation, device vs oracle %s; oracle vs itself under 1e-6 m %s' % (np.round(rel_force, 4), np.round(rel_sens, 4)))
+    assert np.median(rel_force) <= max(1e-3, 2.0 * np.median(rel_sens)) and max(rel_force) <= max(1e-3, 2.0 * max(rel_sens))
+    env.close()
