@@ -55,36 +55,52 @@ class AgxVectorEnv(_VectorEnv):
                              'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
         vec_kwargs.setdefault('reset', 'pool')             # (reset='device': fresh states every episode, for the models with a device-side reset generator)
         self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=_models()[name], **vec_kwargs)
+        self.vec.keep_terminal_obs = True                 # the last observation of every row that ends, boundary or not (vec_env.step)
         self._obs, self._host, self._pack = None, None, None
 
     def vector_reset(self):
-        self._obs = self.vec.reset().cpu().numpy().astype(np.float64)
+        self._obs = list(self.vec.reset().cpu().numpy())
         return list(self._obs)
 
     def reset_at(self, index):
         # the batch was reset on the device at the episode boundary; an environment the non-finite guard ended mid-episode was replaced at
-        # once (vec_env.step) and its row already holds the first observation of its new episode
+        # once (vec_env.step) and the first observation of its new episode was kept for this call
         return self._obs[index]
 
     def vector_step(self, actions):
+        """Host cost per step at 4096 environments (round 5, tools/gpu_rllib_overhead.py): the actions arrive as a list of arrays (one
+        np.concatenate, 0.5 ms; an [n, act_dim] array is taken as it is), ONE device-to-host transfer brings back terminal observations,
+        rewards, done flags, two info columns and -- for the rows that ended -- the first observations of the new episodes, into one of two
+        pinned buffers used in turn (the rows handed out stay valid for one more step, no copy), as float32 like the observation space."""
         import torch
-        a = torch.as_tensor(np.asarray(actions, dtype=np.float32), device=self.vec.device).contiguous()
+        n = self.num_envs
+        if not isinstance(actions, np.ndarray):
+            actions = np.concatenate(actions).reshape(n, -1)
+        a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float32), device=self.vec.device)
         obs, rew, done, info = self.vec.step(a)
-        # ONE device-to-host transfer per step: observations (the terminal ones at an episode boundary, which RLlib wants here; vec.obs then
-        # already holds the first observation of the new episode), reward, done flags and the two info columns in a single pinned buffer
-        boundary = self.vec._t % self.vec.episode_len == 0
-        last = self.vec.terminal_obs if boundary else obs
-        n, od = self.num_envs, last.shape[1]
+        # rows whose episode ended: RLlib wants the LAST observation of the old episode here and the first of the new one from reset_at(); the
+        # stepper has already put the new first observation into `obs` for those rows and kept the old one in vec.terminal_obs
+        last = self.vec.terminal_obs
+        od = obs.shape[1]
         if self._host is None:
-            self._pack = torch.empty((n, od + 4), dtype=torch.float32, device=self.vec.device)
-            self._host = torch.empty((n, od + 4), dtype=torch.float32, pin_memory=True)
-        self._pack[:, :od] = last; self._pack[:, od] = rew; self._pack[:, od + 1] = done.float(); self._pack[:, od + 2:od + 4] = info[:, 0:2]
-        self._host.copy_(self._pack, non_blocking=True)
+            self._pack = torch.empty((n, 2 * od + 4), dtype=torch.float32, device=self.vec.device)
+            self._host = [torch.empty((n, 2 * od + 4), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self._flip = 0
+        pk = self._pack
+        pk[:, :od] = last; pk[:, od] = rew; pk[:, od + 1] = done; pk[:, od + 2:od + 4] = info[:, 0:2]; pk[:, od + 4:] = obs
+        self._flip ^= 1
+        host = self._host[self._flip]
+        host.copy_(pk, non_blocking=True)
         torch.cuda.current_stream(self.vec.device).synchronize()
-        h = self._host.numpy()
-        self._obs = obs.cpu().numpy().astype(np.float64) if boundary else h[:, :od].astype(np.float64)
-        obs64 = h[:, :od].astype(np.float64)
-        return list(obs64), h[:, od].astype(np.float64).tolist(), (h[:, od + 1] != 0).tolist(), _LazyInfos(self._info_static, h[:, od + 2].copy(), h[:, od + 3].copy())
+        h = host.numpy()
+        dn = h[:, od + 1] != 0
+        rows = list(h[:, :od])
+        self._obs = rows
+        if dn.any():
+            self._obs = list(rows)
+            for i in np.nonzero(dn)[0]:
+                self._obs[i] = h[i, od + 4:]
+        return rows, h[:, od].tolist(), dn.tolist(), _LazyInfos(self._info_static, h[:, od + 2], h[:, od + 3])
 
     def get_unwrapped(self):
         return []
@@ -132,9 +148,18 @@ class AgxMultiAgentBatchEnv(_BaseEnv):
         self.vec = AssistiveVecEnv(num_envs, device=device, seed=seed, model=cls.model, coop=True, **vec_kwargs)
         self._host = self._pack = None
         self._pending = None             # what the next poll() returns
+        self.vec.keep_terminal_obs = True
         self._first = self._split(self.vec.reset().cpu().numpy().astype(np.float64))
-        self._pending = (dict(self._first), {}, {}, {})
+        self._pending = self._after_reset(self._first)
         self._new_obs = {}               # env_id -> first observation of the episode that began at the last boundary (try_reset)
+
+    @staticmethod
+    def _after_reset(first):
+        """what poll() returns for environments that have just been reset: as ray 1.x's _MultiAgentEnvState.reset leaves them -- a reward of None
+        per agent, done False for both agents and '__all__', an empty info per agent (RLlib's sampler indexes dones[env_id]['__all__'] and
+        infos[env_id] for every env_id that has an observation)"""
+        return (dict(first), {i: {'robot': None, 'human': None} for i in first}, {i: {'robot': False, 'human': False, '__all__': False} for i in first},
+                {i: {'robot': {}, 'human': {}} for i in first})
 
     def _split(self, obs):
         return {i: {'robot': obs[i, :self.nr], 'human': obs[i, self.nr:]} for i in range(self.num_envs)}
@@ -151,8 +176,7 @@ class AgxMultiAgentBatchEnv(_BaseEnv):
         for i, d in action_dict.items():
             a[i, :self.ar] = d['robot']; a[i, self.ar:] = d['human']
         obs, rew, done, info = self.vec.step(torch.as_tensor(a, device=self.vec.device).contiguous())
-        boundary = self.vec._t % self.vec.episode_len == 0
-        last = self.vec.terminal_obs if boundary else obs
+        last = self.vec.terminal_obs                    # the last observation of every row that ended (boundary or not), the current one elsewhere
         od = last.shape[1]
         if self._host is None:
             self._pack = torch.empty((n, od + 4), dtype=torch.float32, device=self.vec.device)

@@ -253,6 +253,8 @@ class AssistiveVecEnv:
         self.episode_len = int(self.blob.task_f('EPISODE_LEN'))
         self.env_offset, self._t, self._episode = 0, 0, 0
         self.terminal_obs = None
+        self.keep_terminal_obs = False                # adapters (rllib.py): terminal_obs after EVERY step = the step's observation with the rows that ended
+                                                      # holding their LAST observation, self.obs holding the first one of their new episode
         # pool_refresh = k > 0: a child process samples k new start states at a time, swapped into the pool at episode boundaries (PoolRefresher)
         self.pool_refresh, self.pool_refresh_sync, self._refresher, self._refresh_cursor, self.pool_refreshed = int(pool_refresh), pool_refresh_sync, None, 0, 0
         self._model_name = model or self.model
@@ -365,12 +367,16 @@ class AssistiveVecEnv:
             if not boundary:
                 # ... and the row of such an environment becomes the first observation of its new episode, as at a boundary
                 # (also the short episodes of workload-specific pools, bench.py --workload wiping); other rows are untouched
+                if self.keep_terminal_obs:
+                    self.terminal_obs = self.obs.clone()     # (before the masked re-observe overwrites the rows that ended: guard-ended environments, short-episode pools)
                 self.stepper.observe_dev(self.obs, s, mask=self.done)
             if boundary:
                 # vector-env convention: the observation returned with done is the first one of the new episode
                 # (`return self._get_obs()` of reset(), feeding.py:182); the last one of the old episode is kept aside
                 self.terminal_obs = self.obs.clone()
                 self.stepper.observe_dev(self.obs, s)
+        elif self.keep_terminal_obs:
+            self.terminal_obs = self.obs
         return self.obs, self.reward, self.done, self.info
 
     def _swap_in_fresh_states(self):

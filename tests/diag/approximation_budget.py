@@ -121,12 +121,21 @@ def contact_rich_starts(config, d):
     return out
 
 
-def compare(d, od, op, starts, steps, scale, seed, settle=0, cloth_settle=0):
+def compare(d, od, op, starts, steps, scale, seed, settle=0, cloth_settle=0, max_pen=None):
     f = d.obs_dim_robot - 1
     rel = dict(reward=[], total_force=[], tool_force=[]); absd = dict(reward=[], total_force=[], tool_force=[])
     ncon = dict(default=[], plain=[]); touching = 0
     fl = slice(0, d.h['S_ENV'])                              # the float part of a record (the env / task words hold integers)
+    violent = 0
     for k0, (s, c) in enumerate(starts):
+        # crafted starts with the robot or its tool more than 1 cm INSIDE the person (a translated base can do that) are not contact, they are an
+        # explosion in both oracles: counted, not compared
+        if max_pen is not None:
+            con = od.collide(s.copy())
+            wi = d.words.view(np.int32); c0 = d.h['OFF_COLL']
+            human = [c for c in con if L.TAG['HUMAN'] in (wi[c0 + int(c[0]) * L.C['STRIDE'] + L.C['TAG']], wi[c0 + int(c[1]) * L.C['STRIDE'] + L.C['TAG']])]
+            if human and min(float(c[11]) for c in human) < -max_pen:
+                violent += 1; continue
         if settle:
             od.settle(s, settle)
         if c is not None and cloth_settle:
@@ -144,7 +153,7 @@ def compare(d, od, op, starts, steps, scale, seed, settle=0, cloth_settle=0):
             ncon['default'].append(float(i[6])); ncon['plain'].append(float(pi[6])); touching += int(pi[0] > 0 or po[f] > 0)
             if dn or not np.isfinite(s[fl]).all():
                 break
-    out = dict(steps_compared=len(rel['reward']), steps_with_a_force_on_the_person_or_the_tool=touching,
+    out = dict(steps_compared=len(rel['reward']), starts_skipped_as_interpenetrating=violent, steps_with_a_force_on_the_person_or_the_tool=touching,
                contacts_last_substep=dict(default=float(np.mean(ncon['default'])), plain=float(np.mean(ncon['plain']))))
     for key in rel:
         r = np.array(rel[key]); a = np.array(absd[key])
@@ -171,7 +180,7 @@ def run(config, steps, seeds):
         starts.append((st[0].copy(), None if cl is None else cl[0].copy()))
     out = dict(config=config, model=name, hull_vertices=dict(default=int(d.h['NVERT']), plain=int(p.h['NVERT'])))
     out['random_policy'] = compare(d, od, op, starts, steps, scale, 500, settle=25 if name == 'feeding_jaco' else 0, cloth_settle=20)
-    out['contact_rich'] = compare(d, od, op, contact_rich_starts(config, d), 8, 0.15, 900)
+    out['contact_rich'] = compare(d, od, op, contact_rich_starts(config, d), 8, 0.15, 900, max_pen=0.01)
     op.L.agxo_stat_core_overlaps(stat)
     out.update(seconds=round(time.time() - t0, 1), plain_narrowphase_calls=int(stat[1]), plain_core_overlaps_sampled_in_42_directions=int(stat[0]))
     return out
