@@ -635,6 +635,24 @@ int rccl_fail(const char* what, int rc) {
 }
 }  // namespace
 
+// [n_envs][obs_dim + 4] = observation | reward | done (0 / 1) | info[0] (total_force_on_human) | info[1] (task_success): what one consumer of the
+// whole batch reads per step (learn.py:26,72: the sampler's obs, reward, done, info) as ONE record per environment -- one all-gather per step
+__global__ void agx_pack_kernel(const float* __restrict__ obs, const float* __restrict__ rew, const uint8_t* __restrict__ done, const float* __restrict__ info,
+                                float* __restrict__ out, int n, int od) {
+  const int w = od + 4, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * w) return;
+  const int e = i / w, c = i - e * w;
+  out[i] = c < od ? obs[(size_t)e * od + c] : c == od ? rew[e] : c == od + 1 ? (done[e] ? 1.f : 0.f) : info[(size_t)e * AGX_INFO_DIM + (c - od - 2)];
+}
+int agx_pack_step(agx_handle h, const float* obs_dev, const float* reward_dev, const uint8_t* done_dev, const float* info_dev, float* packed_dev, void* stream) {
+  if (!h || !obs_dev || !reward_dev || !done_dev || !info_dev || !packed_dev) return fail(AGX_E_ARG, "agx_pack_step: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  const int total = h->n_envs * (h->obs_dim + 4);
+  hipLaunchKernelGGL(agx_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs_dev, reward_dev, done_dev, info_dev, packed_dev, h->n_envs, h->obs_dim);
+  HIPCHK(hipGetLastError());
+  return AGX_OK;
+}
+
 int agx_comm_unique_id(void* out128) {
   if (!out128) return fail(AGX_E_ARG, "agx_comm_unique_id: null");
   int rc = rccl_load(); if (rc) return rc;

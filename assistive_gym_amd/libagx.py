@@ -15,7 +15,7 @@ EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_p
            'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_cloth_nodes', 'agx_set_cloth', 'agx_get_cloth', 'agx_cloth_dev', 'agx_set_cloth_pool', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_observe_masked', 'agx_reset_done_at', 'agx_sample_reset', 'agx_reset', 'agx_attach_settle_model', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset', 'agx_check_collisions',
-           'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather']
+           'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather', 'agx_pack_step']
 
 
 class AgxError(RuntimeError):
@@ -38,6 +38,26 @@ def load():
 def check(rc, what=''):
     if rc != 0:
         raise AgxError('%s failed (%d): %s' % (what, rc, load().agx_last_error().decode()))
+
+
+def comm_unique_id():
+    """agx_comm_unique_id: the 128-byte RCCL id rank 0 obtains and hands to the other ranks (by the host's own means)"""
+    buf = C.create_string_buffer(128)
+    check(load().agx_comm_unique_id(buf), 'agx_comm_unique_id')
+    return bytes(buf.raw)
+
+
+def comm_init_rank(device, rank, world, unique_id):
+    """agx_comm_init_rank (collective over all ranks) -> communicator handle for Stepper.allgather"""
+    assert len(unique_id) == 128
+    comm = C.c_void_p()
+    check(load().agx_comm_init_rank(C.c_int(device), C.c_int(rank), C.c_int(world), C.c_char_p(unique_id), C.byref(comm)), 'agx_comm_init_rank')
+    return comm.value
+
+
+def comm_destroy(comm):
+    if comm:
+        check(load().agx_comm_destroy(C.c_void_p(comm)), 'agx_comm_destroy')
 
 
 def _ptr(x):
@@ -106,6 +126,11 @@ class Stepper:
     def set_env_offset(self, env_offset):
         """global index of this stepper's first env (multi-GPU sharding): keeps agx_reset_done's pool draw placement independent"""
         check(self.L.agx_set_env_offset(self.h, C.c_longlong(int(env_offset))), 'agx_set_env_offset')
+
+    def pack_step(self, obs, reward, done, info, packed, stream=0):
+        """agx_pack_step: [n_envs, obs_dim + 4] = observation | reward | done | total_force_on_human | task_success (float32 device tensors; done uint8)"""
+        assert packed.shape == (self.n_envs, obs.shape[1] + 4) and packed.is_contiguous() and obs.is_contiguous()
+        check(self.L.agx_pack_step(self.h, _ptr(obs), _ptr(reward), _ptr(done), _ptr(info), _ptr(packed), C.c_void_p(stream)), 'agx_pack_step')
 
     def allgather(self, local, gathered, comm=None, stream=0):
         """agx_allgather of a float32 device tensor (comm None = single rank)"""

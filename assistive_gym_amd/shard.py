@@ -35,25 +35,29 @@ def gather_observations(obs_local, world, out=None):
     return out
 
 
-class ObsGatherer:
-    """Whole-batch observation collation overlapped with the next env.step().
+class BatchGatherer:
+    """Whole-batch collation overlapped with the next env.step().  What is gathered per step is ONE record per environment:
+    observation | reward | done | total_force_on_human | task_success ([n, obs_dim + 4] float32, `pack()`; SURVEY 8e: what the single consumer
+    of the whole batch -- the sampler of learn.py:26,72 -- reads), or any [n, width] buffer the caller fills.
 
-    The all-gather of step k runs on a SIDE stream: it waits (event) for the kernels that produced the observations of step k
-    and then proceeds concurrently with the kernels of step k + 1 on the compute stream.  Two observation buffers and two
-    gathered buffers alternate, so step k + 1 never writes what the gather of step k is still reading; before a buffer is
-    reused (step k + 2) the compute stream waits for the gather that read it.  `wait(slot)` makes the current stream wait for
-    the gathered batch of that slot (what a learner consuming the whole batch calls).
-    On CPU tensors (gloo tests) there are no streams: submit() gathers synchronously.
+    The all-gather of step k runs on a SIDE stream: it waits (event) for the kernels that produced the records of step k and then proceeds
+    concurrently with the kernels of step k + 1 on the compute stream.  Two local and two gathered buffers alternate, so step k + 1 never
+    writes what the gather of step k is still reading; before a buffer is reused (step k + 2) the compute stream waits for the gather that
+    read it.  `wait(slot)` makes the current stream wait for the gathered batch of that slot (what a learner consuming it calls).
+    The collective: torch.distributed (backend nccl = RCCL; gloo on CPU tensors in the tests, synchronously -- no streams there), or
+    `comm` = a communicator of the C ABI (libagx.comm_init_rank) together with `stepper`: agx_allgather, RCCL bound by libagx itself.
     """
 
-    def __init__(self, n_local, obs_dim, world, device=None, dtype=None, force=False):
+    def __init__(self, n_local, width, world, device=None, dtype=None, force=False, stepper=None, comm=None):
         import torch
         self.torch, self.world = torch, world
         self.force = force            # a 1-rank group still runs the collective (bench.py --force-gather: the stream layout of N ranks on one GPU)
         self.cuda = device is not None and torch.device(device).type == 'cuda'
+        self.stepper, self.comm = stepper, comm
+        assert comm is None or (stepper is not None and self.cuda), 'the C ABI collective gathers device buffers of a stepper handle'
         dtype = dtype or torch.float32
-        self.local = [torch.zeros((n_local, obs_dim), dtype=dtype, device=device) for _ in range(2)]
-        self.full = [torch.zeros((world * n_local, obs_dim), dtype=dtype, device=device) for _ in range(2)]
+        self.local = [torch.zeros((n_local, width), dtype=dtype, device=device) for _ in range(2)]
+        self.full = [torch.zeros((world * n_local, width), dtype=dtype, device=device) for _ in range(2)]
         if self.cuda:
             self.stream = torch.cuda.Stream(device=device)
             self.produced = [torch.cuda.Event() for _ in range(2)]
@@ -61,12 +65,24 @@ class ObsGatherer:
             self.pending = [False, False]
 
     def buffer(self, slot):
-        """the observation buffer step `slot` (= step index mod 2) writes into; on the GPU the compute stream first waits for
-        the gather that last read this buffer"""
+        """the local buffer step `slot` (= step index mod 2) writes into; on the GPU the compute stream first waits for the gather that
+        last read this buffer"""
         if self.cuda and self.pending[slot]:
             self.torch.cuda.current_stream().wait_event(self.gathered[slot])
             self.pending[slot] = False
         return self.local[slot]
+
+    def pack(self, slot, obs, reward, done, info):
+        """local[slot] = observation | reward | done | info[:, 0:2] of this step, on the current stream (agx_pack_step on the device; the same
+        layout with tensor ops on CPU tensors)"""
+        out = self.buffer(slot)
+        od = obs.shape[1]
+        assert out.shape[1] == od + 4
+        if self.cuda and self.stepper is not None:
+            self.stepper.pack_step(obs, reward, done, info, out, self.torch.cuda.current_stream().cuda_stream)
+        else:
+            out[:, :od] = obs; out[:, od] = reward; out[:, od + 1] = done.to(out.dtype); out[:, od + 2:od + 4] = info[:, 0:2]
+        return out
 
     def submit(self, slot):
         """enqueue the all-gather of local[slot] -> full[slot]"""
@@ -81,7 +97,10 @@ class ObsGatherer:
         self.produced[slot].record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(self.produced[slot])
-            dist.all_gather_into_tensor(self.full[slot], self.local[slot])
+            if self.comm is not None:
+                self.stepper.allgather(self.local[slot], self.full[slot], self.comm, self.stream.cuda_stream)
+            else:
+                dist.all_gather_into_tensor(self.full[slot], self.local[slot])
             self.gathered[slot].record(self.stream)
         self.pending[slot] = True
         return self.full[slot]
@@ -94,3 +113,6 @@ class ObsGatherer:
             if self.pending[s]:
                 self.torch.cuda.current_stream().wait_event(self.gathered[s])
                 self.pending[s] = False
+
+
+ObsGatherer = BatchGatherer      # (rounds 2-4: observations only)

@@ -169,6 +169,7 @@ class _DryEnv:
         import torch
         self.n_envs, self.act_dim, self.obs_dim, self.rank = n, act_dim, obs_dim, rank
         self.obs = torch.zeros((n, obs_dim)); self.info = torch.zeros((n, 8)); self.env_offset = 0
+        self.reward = torch.zeros(n); self.done = torch.zeros(n, dtype=torch.uint8)
 
     def reset(self, env_offset=0):
         self.env_offset = env_offset
@@ -178,14 +179,16 @@ class _DryEnv:
         o = self.obs if obs_out is None else obs_out
         o.zero_(); o[:, :self.act_dim] = actions; o[:, -1] = torch.arange(self.n_envs, dtype=torch.float32) + self.env_offset     # global env index: checked by the test
         self.obs = o
-        return o, None, None, self.info
+        g = torch.arange(self.n_envs, dtype=torch.float32) + self.env_offset
+        self.reward = -g; self.done = (g.long() % 2).to(torch.uint8); self.info[:, 0] = 0.5 * g; self.info[:, 1] = 2.0 * g      # functions of the global index: the packed record is checked column by column
+        return o, self.reward, self.done, self.info
 
 
 def dry_run(args, rank, world):
     import torch
     import torch.distributed as dist
     from assistive_gym_amd.blob import ModelBlob
-    from assistive_gym_amd.shard import ObsGatherer
+    from assistive_gym_amd.shard import BatchGatherer
     model, _, _, env_id = TASKS[args.task or 'feeding']
     blob = ModelBlob.load(model)
     if env_id.split()[0].endswith('Human-v1'):
@@ -195,27 +198,29 @@ def dry_run(args, rank, world):
     env.reset(env_offset=rank * n)
     g = torch.Generator(); g.manual_seed(1001 + rank)
     tape = torch.rand((W + K, n, blob.act_dim), generator=g) * 2 - 1
-    gatherer = ObsGatherer(n, blob.obs_dim, world, device=None) if world > 1 else None
+    # the whole-batch record of a step: observation | reward | done | total_force_on_human | task_success, one all-gather
+    gatherer = BatchGatherer(n, blob.obs_dim + 4, world, device=None)
     full = None
     for k in range(W + K):
         if k == W:
             if world > 1:
                 dist.barrier()
             t0 = time.perf_counter()
-        if gatherer is not None:
-            env.step(tape[k], obs_out=gatherer.buffer(k & 1)); full = gatherer.submit(k & 1)
-        else:
-            full = env.step(tape[k])[0]
+        o, r, d, i = env.step(tape[k])
+        gatherer.pack(k & 1, o, r, d, i); full = gatherer.submit(k & 1)
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ok = bool(torch.equal(full[:, -1], torch.arange(world * n, dtype=torch.float32)))     # every rank holds the whole batch in global env order
+    gi, od = torch.arange(world * n, dtype=torch.float32), blob.obs_dim
+    # every rank holds the whole batch in global env order, every column of the record where it belongs
+    ok = bool(torch.equal(full[:, od - 1], gi) and torch.equal(full[:, od], -gi) and torch.equal(full[:, od + 1], (gi.long() % 2).float()) and
+              torch.equal(full[:, od + 2], 0.5 * gi) and torch.equal(full[:, od + 3], 2.0 * gi))
     return {'metric': 'env_steps_per_sec', 'value': world * n * K / float(t.item()), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': float(t.item()) / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'DRY RUN of the launch path of %s (no stepping: libagx has no CPU path)' % env_id, 'envs_per_gpu': n, 'global_envs': world * n,
-                       'parallelism': 'env-sharded x%d' % world, 'obs_allgather': world > 1, 'gathered_in_global_order': ok, 'obs_dim': blob.obs_dim, 'act_dim': blob.act_dim},
+                       'parallelism': 'env-sharded x%d' % world, 'obs_allgather': world > 1, 'gathered_record': 'obs | reward | done | total_force_on_human | task_success', 'gathered_in_global_order': ok, 'obs_dim': blob.obs_dim, 'act_dim': blob.act_dim},
             'dry_run': True}
 
 
@@ -224,7 +229,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     import torch
     import torch.distributed as dist
     from assistive_gym_amd import vec_env
-    from assistive_gym_amd.shard import ObsGatherer
+    from assistive_gym_amd.shard import BatchGatherer
     model, env_cls, ksuffix, env_id = TASKS[task]
     pool = args.pool
     if env_id_override is not None:             # the kernel-name suffix is that of the variant agx_create picks: taken from the stepper below
@@ -258,15 +263,28 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     K, W = steps, warmup
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
     tape = (torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1) * action_scale
-    # whole-batch observation collation: RCCL all-gather on a side stream, overlapped with the next step (two buffers alternate)
-    gatherer = ObsGatherer(n, blob.obs_dim, world, device=torch.device('cuda', local_rank), force=args.force_gather) if distributed else None
+    # whole-batch collation: per step ONE record per environment -- observation | reward | done | total_force_on_human | task_success (SURVEY
+    # 8e; packed on the device by agx_pack_step) -- all-gathered over RCCL on a side stream, overlapped with the next step (two buffers alternate).
+    # --gather abi (the default): the collective of the C ABI (agx_comm_init_rank / agx_allgather, RCCL bound by libagx itself; the 128-byte id
+    # travels over the torch.distributed group that the launcher's rendezvous set up); --gather torch: torch.distributed's all-gather.
+    gatherer, gather_how, comm = None, None, None
+    if distributed:
+        gather_how = args.gather
+        if gather_how == 'abi':
+            try:
+                from assistive_gym_amd import libagx
+                box = [libagx.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = libagx.comm_init_rank(local_rank, rank, world, box[0])
+            except Exception as e:                       # (a node whose RCCL the C ABI cannot bind: the line says so)
+                gather_how, comm = 'torch (agx_comm_init_rank failed: %s)' % str(e)[:120], None
+        gatherer = BatchGatherer(n, blob.obs_dim + 4, world, device=torch.device('cuda', local_rank), force=args.force_gather, stepper=env.stepper, comm=comm)
 
     def one(k):
+        env.step(tape[k])
         if distributed:
-            env.step(tape[k], obs_out=gatherer.buffer(k & 1))
+            gatherer.pack(k & 1, env.obs, env.reward, env.done, env.info)
             gatherer.submit(k & 1)
-        else:
-            env.step(tape[k])
 
     # the contact sampling of the timed loop (torch remainder / cast / mean / add kernels and their allocations) runs in the warm-up too:
     # the first call of each loads its code object (tens of ms each) -- inside a 20-step timed window that was half of the time
@@ -307,6 +325,9 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     overflow = env.stepper.overflow_count() - overflow0
+    if comm is not None:
+        from assistive_gym_amd import libagx
+        torch.cuda.synchronize(); libagx.comm_destroy(comm)
     contacts = float(ncon_sum.item()) / max(1, ncon_n)
     # per-kernel launch durations (HIP events after every launch, on the chunk stream it is launched on),
     # measured after the timed region so that `value` is not perturbed by the extra events / host syncs.
@@ -381,7 +402,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             'data': 'synthetic',
             'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, %d PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale, int(blob.param('NITER'))),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
-                       'obs_allgather': bool(distributed), 'noop_retest': blob.param('NOOP_RETEST')},
+                       'obs_allgather': bool(distributed), 'gather': gather_how, 'gathered_record': 'obs | reward | done | total_force_on_human | task_success' if distributed else None, 'noop_retest': blob.param('NOOP_RETEST')},
             'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps
             'overflow_count': int(overflow),       # substeps (summed over environments) in which a contact was dropped by the contact / row / coefficient budgets
             'pool_states_refreshed': int(getattr(env, 'pool_refreshed', 0)),      # --pool-refresh: start states a child process sampled during the run and the rollout swapped into the pool
@@ -428,6 +449,7 @@ def main():
     ap.add_argument('--no-configs', action='store_true', help='the default 1-GPU run also times short runs of BASELINE configs 3, 4 (1 GPU), 5 (1 GPU) into "configs"; this skips them')
     ap.add_argument('--backend', default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --dry-run)")
     ap.add_argument('--force-gather', action='store_true', help='1 GPU: run the multi-GPU code path anyway (a 1-rank RCCL process group, the per-step observation all-gather on its side stream) -- what the stream / hardware-queue layout of --gpus N looks like on one GPU')
+    ap.add_argument('--gather', choices=['abi', 'torch'], default='abi', help="the collective of the per-step whole-batch gather with --gpus N: 'abi' = agx_comm_init_rank / agx_allgather of the C ABI (RCCL bound by libagx), 'torch' = torch.distributed")
     ap.add_argument('--dry-run', action='store_true', help='exercise the launch / sharding / all-gather / timing path on CPU tensors without stepping (no GPU needed; backend gloo)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

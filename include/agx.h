@@ -155,6 +155,10 @@ int agx_set_env_offset(agx_handle h, long long env_offset);
  * agx_comm_init_rank: collective over all ranks; agx_allgather: gathered_dev[rank * floats_per_rank ...] = the shard of `rank`,
  * enqueued on `stream` (use a side stream and an event after agx_step to overlap it with the next step); comm == NULL = one rank. */
 int agx_comm_unique_id(void* out128);
+/* What is gathered: agx_pack_step writes packed_dev[n_envs][obs_dim + 4] = observation | reward | done (0 / 1) | total_force_on_human |
+ * task_success per environment (the sampler's obs, reward, done, info: assistive_gym/learn.py:26,72), enqueued on `stream` after the agx_step
+ * that produced them; agx_allgather of n_envs * (obs_dim + 4) floats then collates the whole batch in ONE collective per step. */
+int agx_pack_step(agx_handle h, const float* obs_dev, const float* reward_dev, const uint8_t* done_dev, const float* info_dev, float* packed_dev, void* stream);
 int agx_comm_init_rank(int device, int rank, int world, const void* unique_id128, void** comm_out);
 int agx_comm_destroy(void* comm);
 int agx_allgather(agx_handle h, const float* local_dev, float* gathered_dev, size_t floats_per_rank, void* comm, void* stream);

@@ -117,3 +117,31 @@ def test_c_abi_allgather_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     st.close()
+
+
+def test_c_abi_packed_gather_through_a_communicator():
+    """The whole-batch record of a step packed on the device (agx_pack_step) and gathered by the C ABI's own collective (agx_comm_unique_id /
+    agx_comm_init_rank / agx_allgather: RCCL bound by libagx) on the gatherer's side stream -- a one-rank communicator here (RCCL takes one rank
+    per device; the N-rank run is bench.py --gpus N, whose default is this path) -- against the same record packed with tensor ops."""
+    if not torch.cuda.is_available():
+        __import__('conftest').no_gpu()
+    from assistive_gym_amd import libagx
+    from assistive_gym_amd.shard import BatchGatherer
+    from assistive_gym_amd.vec_env import FeedingJacoVecEnv
+    n = 64
+    env = FeedingJacoVecEnv(n, pool_size=8, seed=5)
+    env.reset()
+    comm = libagx.comm_init_rank(0, 0, 1, libagx.comm_unique_id())
+    assert comm
+    g = BatchGatherer(n, env.obs_dim + 4, 1, device=torch.device('cuda', 0), force=True, stepper=env.stepper, comm=comm)
+    gen = torch.Generator(device='cuda'); gen.manual_seed(3)
+    for k in range(4):
+        obs, rew, done, info = env.step(torch.rand((n, env.act_dim), device='cuda', generator=gen) * 2 - 1)
+        g.pack(k & 1, obs, rew, done, info)
+        full = g.submit(k & 1)
+        g.wait(k & 1)
+        torch.cuda.synchronize()
+        want = torch.cat([obs, rew[:, None], done.float()[:, None], info[:, 0:2]], dim=1)
+        assert full.shape == (n, env.obs_dim + 4) and torch.equal(full, want)
+    libagx.comm_destroy(comm)
+    env.close()

@@ -168,7 +168,9 @@ def test_multi_agent_batch_adapter_runs_config4_batched():
     n = 16
     env = AgxMultiAgentBatchEnv('assistive_gym:ScratchItchPR2Human-v1', n, pool_size=8)
     obs, rew, done, info, off = env.poll()
-    assert sorted(obs) == list(range(n)) and obs[0]['robot'].shape == (30,) and obs[0]['human'].shape == (34,) and rew == {} and off == {}
+    assert sorted(obs) == list(range(n)) and obs[0]['robot'].shape == (30,) and obs[0]['human'].shape == (34,) and off == {}
+    # after a reset: what ray 1.x's _MultiAgentEnvState.reset leaves (the sampler indexes dones[env_id]['__all__'] and infos[env_id] for every observed env)
+    assert all(rew[i] == {'robot': None, 'human': None} and done[i] == {'robot': False, 'human': False, '__all__': False} and info[i] == {'robot': {}, 'human': {}} for i in range(n))
     scalar = ENV_IDS['ScratchItchPR2Human-v1']()
     scalar.set_state(env.vec.stepper.get_state()[5])
     rng = np.random.RandomState(0)
@@ -184,3 +186,40 @@ def test_multi_agent_batch_adapter_runs_config4_batched():
     first = env.try_reset(3)
     assert first['robot'].shape == (30,) and np.isfinite(first['human']).all() and not np.array_equal(first['robot'], obs[3]['robot'])
     scalar.disconnect(); env.stop()
+
+
+@pytest.mark.gpu
+def test_multi_agent_batch_adapter_under_a_sampler_loop():
+    """A stand-in for RLlib's sampler (ray 1.x _env_runner / _process_observations; ray itself is not installed): poll(), for every env_id with
+    an observation read dones[env_id]['__all__'], the per-agent rewards and infos[env_id][agent]; an env whose '__all__' is set is reset with
+    try_reset(env_id) and its first observation joins the round; actions for every observed agent go back through send_actions.  Runs over
+    an episode boundary.  (The first poll of the adapter used to return empty reward / done / info dictionaries: KeyError in this loop.)"""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        __import__('conftest').no_gpu()
+    from assistive_gym_amd.rllib import AgxMultiAgentBatchEnv
+    n = 8
+    env = AgxMultiAgentBatchEnv('assistive_gym:ScratchItchPR2Human-v1', n, pool_size=8)
+    rng = np.random.RandomState(1)
+    episodes, steps, ret = 0, 0, {i: 0.0 for i in range(n)}
+    for rnd in range(203):
+        obs, rewards, dones, infos, off = env.poll()
+        to_eval = {}
+        for env_id, agent_obs in obs.items():
+            all_done = dones[env_id]['__all__']
+            for agent, o in agent_obs.items():
+                r = rewards[env_id][agent]
+                assert (r is None) == (rnd == 0) and isinstance(infos[env_id][agent], dict)
+                if r is not None and agent == 'robot':
+                    ret[env_id] += r
+            if all_done:
+                episodes += 1
+                first = env.try_reset(env_id)
+                assert first is not None and set(first) == {'robot', 'human'} and np.isfinite(first['robot']).all()
+                agent_obs = first
+            to_eval[env_id] = agent_obs
+        env.send_actions({i: {'robot': rng.uniform(-1, 1, 7), 'human': rng.uniform(-1, 1, 10)} for i in to_eval})
+        steps += 1
+    assert episodes == n and all(np.isfinite(v) and v < 0 for v in ret.values())
+    env.stop()
