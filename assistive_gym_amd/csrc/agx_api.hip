@@ -140,7 +140,6 @@ struct agx_handle_s {
   // (environments with many rows finish last) overlaps with the next kernel of another chunk and the
   // lean solve kernel shares the CUs with the LDS-heavy build kernel.
   int n_chunks; hipStream_t cs[8]; hipEvent_t fork_ev, join_ev[8];
-  bool packed_solve;    // solve with the packed kernel (four environments per wavefront) when the variant has one; AGX_SOLVE=old turns it off
   int reset_flags;      // AGX_X_FLAGS of the blob's reset section (0 without one)
   agx_handle_s* settle; // bed bathing (AGX_X_FLAGS bit 4): the handle of the rag-doll model whose settled records the sampler reads (agx_attach_settle_model; not owned)
   int settle_substeps;  // substeps of that settle (100 simulation steps: bed_bathing.py:130-131)
@@ -288,7 +287,6 @@ static int create_fill(agx_handle h, const void* blob, size_t blob_bytes, int n_
     HIPCHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
     for (int k = 0; k < nc; k++) { HIPCHK(hipStreamCreateWithFlags(&h->cs[k], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming)); }
   }
-  { const char* e = getenv("AGX_SOLVE"); h->packed_solve = !(e && !strcmp(e, "old")); }
   HIPCHK(V->init());
   return AGX_OK;
 }
@@ -335,8 +333,7 @@ static int launch_substep(agx_handle h, const float* act, float* dbg, int e0, in
   const int ph = settle ? (phase | AGX_PHASE_SETTLE) : phase;
   // the packed kernel (four environments per wavefront) where the variant has one; the debug path keeps the single-environment kernel
   // (its per-phase cycle counters); AGX_SOLVE=old selects it for same-box A/B runs
-  if (h->V->solve4 && h->packed_solve && !dbg) h->V->solve4(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, e0, h->sw, h->active, ph);
-  else h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active, ph);
+  h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, dbg, e0, h->n_envs, h->sw, h->active, ph);
   HIPCHK(hipGetLastError());
   return AGX_OK;
 }
@@ -410,8 +407,7 @@ int agx_step_timed(agx_handle h, const float* a, float* obs, float* rew, uint8_t
     for (int k = 0; k < h->frame_skip; k++) {
       (h->manifold ? h->V->build_mf : h->V->build)(st, ne, h->blob_dev, h->state_dev, k == 0 ? a : nullptr, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, h->act_dim, (const uint8_t*)nullptr, h->overflow_dev, nullptr, 0, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
-      if (h->V->solve4 && h->packed_solve) h->V->solve4(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, e0, h->sw, (const uint8_t*)nullptr, k);
-      else h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr, k);
+      h->V->solve(st, ne, h->blob_dev, h->state_dev, h->scratch_dev, nullptr, e0, h->n_envs, h->sw, (const uint8_t*)nullptr, k);
       HIPCHK(hipEventRecord(h->kev[c][e++], st));
     }
     h->V->finish(st, ne, h->blob_dev, h->state_dev, a, h->scratch_dev, obs, rew, done, info, e0, h->n_envs, h->sw, h->act_dim, h->obs_dim, nullptr, 0, nullptr, 0);

@@ -128,31 +128,6 @@ constexpr int QPT_STRIDE = 4;                            // manifold query point
 constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
 constexpr int SCR_O_QPT = SCR_O_META + SCR_META;
-// ---- block rows: the same constraint rows in the layout the packed solve kernel (agx_pgs4.h) reads; only the variants that solve
-// with it emit them.  The generalised velocity is cut into blocks of 6: the articulated DoFs first (NB_ART blocks, the last one
-// padded), then one block per free body; block k is lane k of a 16-lane group.  A row keeps, in UNITS of 6 floats: for every
-// articulated block it touches J[6] and B[6] (2 units, blocks in order), then J[6] of each free body it touches (1 unit each, bodies in
-// ascending order; B = M^-1 J is recomputed from the body's inverse mass and world inverse inertia, BRF_*).  Header (6 words):
-//   nibbles of lanes 0..7, first unit | class << 16, nibbles of lanes 8..15, bound, 1/D, b
-// nibble of a lane = 1 + the offset, inside the row, of the unit(s) of the lane's block, or 0 if the row does not touch it -- so a lane
-// finds its coefficients with a shift and an add; lanes 0..7 read words (0, 1), lanes 8..15 words (1, 2).  Class 0: -bound <= lambda <=
-// bound (motors, tool rows), 1: 0 <= lambda (limits, contact normals), 2: |lambda| <= bound x lambda of the contact's normal row
-// (friction, bound = mu).
-// Opt-in build (-DAGX_USE_SOLVE4=1, feeding variants): measured on MI355X the packed kernel executes 0.6x the instructions of the
-// one-wave-per-environment kernel but, held to one wavefront per SIMD by its 40 KB of LDS, issues only 64 % of the time -- 1.24 ms
-// against 1.14 ms per 4096-environment launch (profiles/r03/solve_kernels_sq_counters.md).  The product solves with agx_pgs.h.
-#ifndef AGX_USE_SOLVE4
-#define AGX_USE_SOLVE4 0
-#endif
-constexpr bool USE_SOLVE4 = AGX_USE_SOLVE4 && AGX_TASK == 0;
-constexpr int NB_ART = (MAX_DOF + 5) / 6, NB = NB_ART + MAX_FREE;
-static_assert(!USE_SOLVE4 || (NB <= 16 && 2 * NB_ART + 2 <= 15), "one lane of a 16-lane group per velocity block; unit offsets inside a row are nibbles");
-constexpr int BRH_WORDS = 6, BRU_WORDS = 6;
-constexpr int BRH_NIBLO = 0, BRH_EOFF = 1, BRH_NIBHI = 2, BRH_BOUND = 3, BRH_INVD = 4, BRH_B = 5;
-constexpr int BR_CLASS_SYM = 0, BR_CLASS_POS = 1, BR_CLASS_FRIC = 2;
-constexpr int BRF_WORDS = 8;                             // per free body: 1/m, world inverse inertia xx, xy, xz, yy, yz, zz, unused
-constexpr int SCR_BRH = USE_SOLVE4 ? MAX_ROWS * BRH_WORDS : 0, SCR_BRE = USE_SOLVE4 ? 2 * SCR_ENT : 0, BR_MAX_UNITS = SCR_BRE / BRU_WORDS, SCR_BRF = USE_SOLVE4 ? MAX_FREE * BRF_WORDS : 0;
-static_assert(BR_MAX_UNITS < (1 << 16), "first unit of a row: 16 bits of the header word");
 // warm-start memory (AGX_P_WARMSTART): per contact of the last solved substep its key -- collider a | collider b << 9 | ordinal inside the
 // pair << 18 -- and its solved normal impulse; META_NWARM entries, 0 = none / invalidated
 constexpr int SCR_WARM = 2 * MAX_CON, SCR_O_WARM = SCR_O_QPT + SCR_QPT;
@@ -160,10 +135,8 @@ constexpr int SCR_WARM = 2 * MAX_CON, SCR_O_WARM = SCR_O_QPT + SCR_QPT;
 // local point on A (3), on B (3), world normal (3), distance, friction -- in cache order
 constexpr int MP_STRIDE = 12, MP_KEY = 0, MP_LA = 1, MP_LB = 4, MP_N = 7, MP_DIST = 10, MP_MU = 11;
 constexpr int SCR_MAN = MP_STRIDE * MAX_CON, SCR_O_MAN = SCR_O_WARM + SCR_WARM;
-constexpr int SCR_O_BRH = SCR_O_MAN + SCR_MAN, SCR_O_BRF = SCR_O_BRH + SCR_BRH, SCR_O_BRE = SCR_O_BRF + SCR_BRF;
-static_assert(SCR_O_BRH % 2 == 0 && SCR_O_BRE % 2 == 0 && SCR_O_BRF % 4 == 0, "block rows are read as 8-byte words");
-constexpr int SCR_WORDS = SCR_O_BRE + SCR_BRE;
-constexpr int META_NBENT = 7, META_NWARM = 8, META_NMAN = 9;      // (NWARM and NMAN are cleared together: agx_forget_warm_kernel)
+constexpr int SCR_WORDS = SCR_O_MAN + SCR_MAN;
+constexpr int META_NWARM = 8, META_NMAN = 9;      // (NWARM and NMAN are cleared together: agx_forget_warm_kernel)
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
 constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
 constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)
@@ -184,9 +157,7 @@ struct Ctx {
   float* gqpt; int nqpt;   // bed bathing: manifold points of the (wiping pad, human) pairs (bed_bathing.py:47-58), per-env scratch
   float* dbg;   // optional debug sink (parity tests)
   float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
-  float* BH; float* BE; // the same rows as block rows (headers, entries) for the packed solve kernel
   int nent;             // (J,B) pairs written by build_rows (entry 0 is the zero pair)
-  int nbunits;          // block-row units written by build_rows
   float* gcon;          // contact records handed from the build kernel to the solve / finish kernels
   long long tm[16]; bool timing;   // per-phase shader-clock totals (debug path only)
 };
@@ -219,7 +190,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
   c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
   c.dt = PRM(c, AGX_P_DT) / (float)(h[AGX_H_SIM_SUBSTEPS] > 1 ? h[AGX_H_SIM_SUBSTEPS] : 1); c.hooks = true;
-  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.nbunits = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.BH = nullptr; c.BE = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 

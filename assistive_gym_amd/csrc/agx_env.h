@@ -294,9 +294,9 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
 //          from L2, integration, mouth-target update -> state
 //   finish (once per step): forces, observation, food state machine, preferences, reward, done.
 // ============================================================================================
-struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* brh; float* bre; float* brf; float* warm; float* man; };
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* warm; float* man; };
 AGX_DEV Scratch scratch_of(float* base) {
-  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.brh = base + SCR_O_BRH; s.bre = base + SCR_O_BRE; s.brf = base + SCR_O_BRF; s.warm = base + SCR_O_WARM; s.man = base + SCR_O_MAN;
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.warm = base + SCR_O_WARM; s.man = base + SCR_O_MAN;
   return s;
 }
 
@@ -455,7 +455,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   float* L = c.lds; int* Li = c.ldsi;
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
-  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.gqpt = scr.qpt; c.BH = scr.brh; c.BE = scr.bre;
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.gqpt = scr.qpt;
   load_env(c, gstate, sw);
   if (gaction) {
     const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP);
@@ -513,17 +513,10 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   if constexpr (MANIFOLD) { if (PRM(c, AGX_P_MANIFOLD) > 0.f) manifold_update(c, scr); }
   warm_seed(c, scr, lane);
   build_rows(c); AGX_TICK(4)
-  if (USE_SOLVE4 && lane < c.nfree) {      // S = (M^-1)^(1/2) of a free body, for the packed solve kernel's epilogue: sqrt(1/m), R sqrt(I_body^-1) R^T
-    float* o = gscratch + SCR_O_BRF + BRF_WORDS * lane; const float mass = FBF(c, lane, AGX_F_MASS);
-    m3 R = ldm3(L + L_FREER + 9 * lane), Ds; for (int k = 0; k < 9; k++) Ds.a[k] = 0;
-    for (int k = 0; k < 3; k++) { float I = FBF(c, lane, AGX_F_INERTIA + k); Ds.a[4 * k] = I > 0 ? sqrtf(1.0f / I) : 0.0f; }
-    m3 S = mul_bt(mul(R, Ds), R);
-    o[0] = mass > 0.f ? sqrtf(1.0f / mass) : 0.f; o[1] = S.a[0]; o[2] = S.a[1]; o[3] = S.a[2]; o[4] = S.a[4]; o[5] = S.a[5]; o[6] = S.a[8]; o[7] = 0.f;
-  }
 #undef AGX_TICK
   // hand-over to the solve kernel
   for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
-  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; scr.meta[META_NQPT] = c.nqpt; scr.meta[META_NBENT] = c.nbunits; }
+  if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; scr.meta[META_NQPT] = c.nqpt; }
   if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
     if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // qdd at DBG_QDD
     for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[DBG_CON + q] = scr.con[q];

@@ -205,14 +205,6 @@ AGX_K(agx_solve_kernel)(const uint32_t* __restrict__ blob, float* state, float* 
   agx::env_solve(blob, state + (size_t)env * sw, scratch + (size_t)env * agx::SCR_WORDS, debug ? debug + (size_t)env * agx::DBG_WORDS : nullptr, lds, (int)threadIdx.x, phase,
                  lds_words);
 }
-// solve, packed: FOUR environments per wavefront (agx_pgs4.h); the grid covers the environments [env0, env_end) four at a time
-extern "C" __global__ void __launch_bounds__(64, 1)
-AGX_K(agx_solve4_kernel)(const uint32_t* __restrict__ blob, float* state, float* scratch, int env0, int env_end, int sw, const uint8_t* __restrict__ active, int phase) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int first = env0 + 4 * (int)blockIdx.x;
-  if (first >= env_end) return;
-  agx::env_solve4(blob, state, scratch, first, env_end, sw, active, lds, (int)threadIdx.x, phase);
-}
 // finish: forces, observation, task state machine, reward, done, info
 extern "C" __global__ void __launch_bounds__(64, 2)
 AGX_K(agx_finish_kernel)(const uint32_t* __restrict__ blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done,
@@ -302,7 +294,6 @@ hipError_t v_init(void) {
 #endif
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_solve4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, agx::LDS_SOLVE4_BYTES);
 #if AGX_TASK == 3
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)AGX_K(agx_cloth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #endif
@@ -322,9 +313,6 @@ void v_build_mf(hipStream_t st, int ne, const uint32_t* blob, float* state, cons
 #endif
 void v_solve(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, float* debug, int e0, int n_envs, int sw, const uint8_t* active, int phase) {
   hipLaunchKernelGGL(AGX_K(agx_solve_kernel), dim3(ne), dim3(64), g_solve_lds_bytes, st, blob, state, scratch, debug, e0, n_envs, sw, active, phase, g_solve_lds_bytes / 4);
-}
-void v_solve4(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, int e0, int sw, const uint8_t* active, int phase) {
-  hipLaunchKernelGGL(AGX_K(agx_solve4_kernel), dim3((ne + 3) / 4), dim3(64), agx::LDS_SOLVE4_BYTES, st, blob, state, scratch, e0, e0 + ne, sw, active, phase);
 }
 void v_finish(hipStream_t st, int ne, const uint32_t* blob, float* state, const float* actions, float* scratch, float* obs, float* reward, uint8_t* done, float* info,
               int e0, int n_envs, int sw, int act_dim, int obs_dim, const float* report, int report_words, float* cloth, int cloth_words) {
@@ -402,7 +390,6 @@ const agx_variant g_variant = {
   nullptr,
 #endif
   v_collision_flags,
-  agx::USE_SOLVE4 ? v_solve4 : nullptr,
 #if AGX_TASK == 3 || AGX_TASK == 5
   v_cloth_lds_bytes,
 #else

@@ -31,7 +31,7 @@ constexpr int LV_G = 16;                                            // lanes of 
 #ifndef AGX_PGS_LV
 #define AGX_PGS_LV 0
 #endif
-constexpr bool LV_COMPILED = AGX_PGS_LV && MAX_DOF <= 16 && TASK == AGX_TASK_FEEDING && !USE_SOLVE4;
+constexpr bool LV_COMPILED = AGX_PGS_LV && MAX_DOF <= 16 && TASK == AGX_TASK_FEEDING;
 constexpr int LV_HDR_WORDS = 8;                                     // invD, b, lo, hi | lam, off8, n, pack
 constexpr int LV_H_LAM = 4, LV_H_LO = 2, LV_H_HI = 3;
 constexpr int LV_DV = 0, LV_HDR = 128;                              // LDS words: dv[128], headers[8 R8], pairs[2 (win + 16)], dv slot addresses[(win + 16) / 2] (16 bit)

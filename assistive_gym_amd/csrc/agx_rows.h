@@ -47,34 +47,25 @@ AGX_DEV void row_art_range(const Ctx& c, const RowGeom& r, int& lo, int& n) {
   n = (r.robot && r.human) ? c.ndof : (r.robot ? c.nrobot : (r.human ? c.nhdof : 0));
 }
 AGX_DEV int row_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return n + (r.fa >= 0 ? 6 : 0) + (r.fb >= 0 ? 6 : 0); }
-// block-row units of a row (agx_ctx.h): 2 per articulated velocity block it touches, 1 per free body
-AGX_DEV int row_block_entries(const Ctx& c, const RowGeom& r) { int lo, n; row_art_range(c, r, lo, n); return (n > 0 ? 2 * ((lo + n - 1) / 6 - lo / 6 + 1) : 0) + (r.fa >= 0 ? 1 : 0) + (r.fb >= 0 ? 1 : 0); }
 // B = M^-1 J^T, D = J B; stores the (J,B) pairs and the header of row `row` at entry offset `off`.
 // A row addresses at most two contiguous DoF ranges: [a0,a0+na) and [b0,b0+nb).
-AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int boff, float bterm, float lo, float hi, int fric_of, float mu, const float* Bd) {
+AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float bterm, float lo, float hi, int fric_of, float mu, const float* Bd) {
   float* L = c.lds; float* E = c.E + 2 * off; const int n = c.ndof;
-  float* BEr = c.BE + BRU_WORDS * boff;                      // this row's units: articulated blocks k0..k1 (J, B), then its free bodies' J in ascending order
   float D = 0.f; int e = 0;
   int a0 = 0, na = 0, b0 = 0, nb = 0;
   int alo, an; row_art_range(c, r, alo, an);
   const bool art = an > 0;
-  const int k0 = alo / 6, nartb = art ? (alo + an - 1) / 6 - k0 + 1 : 0;
-  int be = 2 * nartb;                                        // units so far
-  uint64_t nib = 0ull;                                       // per lane of the packed solver: 1 + offset of its unit(s) inside the row
-  for (int i = 0; i < nartb; i++) nib |= (uint64_t)(2 * i + 1) << (4 * (k0 + i));
   if (art) {
     a0 = alo; na = an;
-    if (USE_SOLVE4) for (int q = 0; q < 2 * BRU_WORDS * nartb; q++) BEr[q] = 0.f;     // padding slots of the touched blocks
     _Pragma("unroll") for (int i = 0; i < MAX_DOF; i++) if (i >= alo && i < alo + an) {
       float acc = 0.f;
       if (Bd) acc = Bd[i];                 // (M^-1 J^T)[i] of this row, formed for the whole pass on the matrix cores (build_rows)
       else { _Pragma("unroll") for (int j = 0; j < MAX_DOF; j++) if (j >= alo && j < alo + an) acc += L[L_MINV + i * MAX_DOF + j] * r.Jr[j]; }
       E[2 * e] = r.Jr[i]; E[2 * e + 1] = acc; D += r.Jr[i] * acc; e++;
-      if (USE_SOLVE4) { float* o = BEr + 2 * BRU_WORDS * (i / 6 - k0) + i % 6; o[0] = r.Jr[i]; o[6] = acc; }
     }
   }
   // free bodies in ascending DoF order, so that the pairs of a row are stored in lane order (the
-  // solver addresses them by the rank of the lane inside the row's lane mask); the packed solver's units likewise
+  // solver addresses them by the rank of the lane inside the row's lane mask)
   const int first = (r.fa >= 0 && r.fb >= 0 && r.fb < r.fa) ? 1 : 0;
   for (int s2 = 0; s2 < 2; s2++) {
     const int side = s2 ^ first;
@@ -86,17 +77,6 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
     int base = n + 6 * fb;
     if (na == 0 && nb == 0 && !art) { a0 = base; na = 6; } else if (nb == 0) { b0 = base; nb = 6; } else { /* third range cannot occur */ }
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
-    if (USE_SOLVE4) {
-      // the unit of a free body is S J with S = (M^-1)^(1/2) = (sqrt(1/m), R sqrt(I_body^-1) R^T): in the scaled velocity S^-1 v the row's
-      // B equals its J, so the packed solver reads one unit where it would need two (or nine multiply-adds per visit)
-      const m3 Rf = ldm3(L + L_FREER + 9 * fb); const float sm = sqrtf(im);
-      v3 jb = tmul(Rf, mk3(J[3], J[4], J[5]));
-      float si[3]; for (int k = 0; k < 3; k++) { const float I = FBF(c, fb, AGX_F_INERTIA + k); si[k] = I > 0 ? sqrtf(1.0f / I) : 0.0f; }
-      v3 ja = mul(Rf, mk3(si[0] * jb.x, si[1] * jb.y, si[2] * jb.z));
-      float* o = BEr + BRU_WORDS * be; o[0] = sm * J[0]; o[1] = sm * J[1]; o[2] = sm * J[2]; o[3] = ja.x; o[4] = ja.y; o[5] = ja.z;
-      nib |= (uint64_t)(be + 1) << (4 * (NB_ART + fb));
-      be++;
-    }
   }
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
   float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
@@ -108,12 +88,6 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, int bof
   if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
   Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
   Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
-  if (USE_SOLVE4) {
-    float* BH = c.BH + BRH_WORDS * row; int* BHi = (int*)BH;
-    const int cls = fric_of >= 0 ? BR_CLASS_FRIC : (lo == 0.f ? BR_CLASS_POS : BR_CLASS_SYM);      // every row kind of build_rows is one of the three
-    BH[BRH_INVD] = H[H_INVD]; BH[BRH_B] = bterm; BH[BRH_BOUND] = fric_of >= 0 ? mu : hi;
-    BHi[BRH_NIBLO] = (int)(uint32_t)nib; BHi[BRH_NIBHI] = (int)(uint32_t)(nib >> 32); BHi[BRH_EOFF] = boff | (cls << 16);
-  }
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
   if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
@@ -136,19 +110,19 @@ AGX_DEV void build_rows(Ctx& c) {
   int maxrows = (int)PRM(c, AGX_P_MAX_ROWS); if (maxrows > MAX_ROWS) maxrows = MAX_ROWS;
   int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > SCR_ENT / 2) maxent = SCR_ENT / 2;
   if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }               // entry 0 of the arena is the zero pair
-  int nnc = 0, ent = 1, bent = 0;                               // non-contact rows / coefficient pairs / block-row entries so far
+  int nnc = 0, ent = 1;                                         // non-contact rows / coefficient pairs so far
   // contact rows: lane = contact; normal rows first, then one friction row per contact (AGX_P_FRICTION_DIRS = 2: a second block of
   // friction rows along n x t behind the first)
-  const int fd = (!USE_SOLVE4 && (int)PRM(c, AGX_P_FRICTION_DIRS) == 2) ? 2 : 1;
+  const int fd = (int)PRM(c, AGX_P_FRICTION_DIRS) == 2 ? 2 : 1;
   v3 tdir = mk3(0, 0, 0);
-  int nc = c.ncon, ccnt = 0, cincl = 0, tot = 0, entN = 0, entF = 0, bcnt = 0, bincl = 0, btot = 0, bentN = 0, bentF = 0;
+  int nc = c.ncon, ccnt = 0, cincl = 0, tot = 0, entN = 0, entF = 0;
   int ba = 0, bb = 0; v3 pa = mk3(0, 0, 0), pb = pa, nn = pa; float dist = 0.f, mu = 0.f;
   RowGeom rn; row_clear(rn);
   // the row kinds go through ONE row_store call site (its M^-1 J^T product is the bulk of this phase's code):
   // phases [0, NC_PASSES) non-contact slots, NC_PASSES contact normals, NC_PASSES + 1 contact friction
   _Pragma("nounroll") for (int ph = 0; ph < NC_PASSES + 1 + fd; ph++) {
     RowGeom R; row_clear(R);
-    int rrow = 0, roff = 0, rboff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
+    int rrow = 0, roff = 0, rfric = -1; float rb = 0.f, rlo = 0.f, rhi = 0.f, rmu = 0.f; bool go = false;
     if (ph < NC_PASSES) {
       const int slot = 64 * ph + lane;
       if (slot < MAX_DOF) {
@@ -210,9 +184,8 @@ AGX_DEV void build_rows(Ctx& c) {
       }
       const int cnt = go ? row_entries(c, R) : 0;
       const uint64_t am = wave_ballot(go);
-      const int bc = (USE_SOLVE4 && go) ? row_block_entries(c, R) : 0;
-      rrow = nnc + wave_rank(am); roff = ent + wave_scan_excl(cnt); rboff = bent + wave_scan_excl(bc);
-      nnc += popc64(am); ent += wave_sum_i(cnt); bent += wave_sum_i(bc);
+      rrow = nnc + wave_rank(am); roff = ent + wave_scan_excl(cnt);
+      nnc += popc64(am); ent += wave_sum_i(cnt);
     } else if (ph == NC_PASSES) {
       const bool has = lane < nc;
       if (has) {
@@ -222,23 +195,21 @@ AGX_DEV void build_rows(Ctx& c) {
       }
       ccnt = has ? row_entries(c, rn) : 0;
       cincl = wave_scan_excl(ccnt) + ccnt;
-      bcnt = (USE_SOLVE4 && has) ? row_block_entries(c, rn) : 0;
-      bincl = wave_scan_excl(bcnt) + bcnt;
       // largest prefix of the contact list that fits the row and coefficient budgets; the contacts beyond it are
       // dropped and counted as overflow
-      const bool fits = has && (nnc + (1 + fd) * (lane + 1) <= maxrows) && (ent + (1 + fd) * cincl <= maxent) && (!USE_SOLVE4 || bent + 2 * bincl <= BR_MAX_UNITS - 2);
+      const bool fits = has && (nnc + (1 + fd) * (lane + 1) <= maxrows) && (ent + (1 + fd) * cincl <= maxent);
       const int kept = popc64(wave_ballot(fits));
       c.overflow += nc - kept; nc = kept;
-      tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0); btot = wave_bcast_i(bincl, nc > 0 ? nc - 1 : 0);
-      entN = ent; entF = ent + (nc > 0 ? tot : 0); bentN = bent; bentF = bent + (nc > 0 ? btot : 0);
-      R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rboff = bentN + bincl - bcnt; rlo = 0.f; rhi = 1e30f;
+      tot = wave_bcast_i(cincl, nc > 0 ? nc - 1 : 0);
+      entN = ent; entF = ent + (nc > 0 ? tot : 0);
+      R = rn; go = lane < nc; rrow = nnc + lane; roff = entN + cincl - ccnt; rlo = 0.f; rhi = 1e30f;
       if (go) {
         const float rv = row_velocity(c, rn); rb = dist > 0 ? (-dist / dt - rv) : (-dist * cerp / dt - rv);
         const float sp = PRM(c, AGX_P_SPLIT_PEN); if (sp > 0.f && dist < -sp) rb = -rv;      // split impulse: no positional term below the threshold (agx_blob.h)
       }
     } else {
       const int k2 = ph - NC_PASSES - 1;                            // 0: first friction direction, 1: the second (n x t)
-      go = lane < nc; rrow = nnc + (1 + k2) * nc + lane; roff = entF + k2 * tot + cincl - ccnt; rboff = bentF + bincl - bcnt; rfric = nnc + lane; rmu = mu;
+      go = lane < nc; rrow = nnc + (1 + k2) * nc + lane; roff = entF + k2 * tot + cincl - ccnt; rfric = nnc + lane; rmu = mu;
       if (go) {
         // friction direction: lateral slip direction if it is resolvable, else the first plane-space tangent
         v3 t;
@@ -283,9 +254,9 @@ AGX_DEV void build_rows(Ctx& c) {
         Bd = JD + JS * lane;
       }
     }
-    if (go) row_store(c, R, rrow, roff, rboff, rb, rlo, rhi, rfric, rmu, Bd);
+    if (go) row_store(c, R, rrow, roff, rb, rlo, rhi, rfric, rmu, Bd);
   }
-  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + (1 + fd) * nc; c.nent = entF + (nc > 0 ? fd * tot : 0); c.nbunits = bentF + (nc > 0 ? btot : 0);
+  c.ncon = nc; c.first_normal = nnc; c.nrows = nnc + (1 + fd) * nc; c.nent = entF + (nc > 0 ? fd * tot : 0);
   wave_sync();
 }
 

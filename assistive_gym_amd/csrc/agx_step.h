@@ -34,7 +34,6 @@
 #include "agx_water.h"
 #endif
 #include "agx_env.h"
-#include "agx_pgs4.h"
 #if AGX_HAS_SAMPLER
 #include "agx_reset.h"
 #endif

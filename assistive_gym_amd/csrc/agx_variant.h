@@ -35,9 +35,6 @@ struct agx_variant {
   void (*verdict)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, const uint8_t* active, uint8_t* work, int* first_restart, const int* chosen);
   // collision flags (AGX_COLLIDE_*) of every environment's state after a build pass (agx_check_collisions)
   void (*collision_flags)(hipStream_t st, int n_envs, const uint32_t* blob, const float* scratch, uint8_t* flags);
-  // the packed solve kernel (agx_pgs4.h: four environments per wavefront) over the environments [e0, e0 + ne); null in variants that
-  // keep the one-wave-per-environment sweeps
-  void (*solve4)(hipStream_t st, int ne, const uint32_t* blob, float* state, float* scratch, int e0, int sw, const uint8_t* active, int phase);
   // dynamic LDS bytes of the cloth kernel for a garment of nn nodes (agxc::lds_words); null without a cloth kernel
   int (*cloth_lds_bytes)(int nn);
   // word of the per-environment scratch record that counts the entries of the warm-start memory (AGX_P_WARMSTART): agx_api.hip zeroes it

@@ -70,11 +70,8 @@ extern "C" void agx_emu_manifold_set(const double* in, int n) {
 }
 extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
                            float* info, float* debug, int mode, int nsettle) {
-  static float lds[(agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS) + agx::LDS_SOLVE4_WORDS];
+  static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
   float* const scratch = g_scratch;
-  // AGX_EMU_SOLVE=old: the one-wave-per-environment sweep; default: the packed kernel (groups 1..3 of the wave idle: one environment here)
-  static const bool packed = !(getenv("AGX_EMU_SOLVE") && !strcmp(getenv("AGX_EMU_SOLVE"), "old")) && agx::USE_SOLVE4;
-  const int sw = ((const int*)blob)[AGX_H_STATE_WORDS];
   const int frame_skip = (int)((const float*)blob)[((const int*)blob)[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   int rc = 0;
   if (mode == 2) return run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_observe(blob, state, obs, lds, lane); });
@@ -84,27 +81,10 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
     const float* act = (mode == 0 && k == 0) ? action : nullptr; float* dbg = (k == 0) ? debug : nullptr;
     rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, state, act, scratch, dbg, lds, lane); });
     const int ph = mode == 1 ? (k | AGX_PHASE_SETTLE) : k;
-    if (!rc && getenv("AGX_EMU_PRINT_META")) { const int* m = (const int*)(scratch + agx::SCR_O_META); fprintf(stderr, "meta: rows %d nnc %d contacts %d pairs %d block units %d\n", m[agx::META_NROWS], m[agx::META_NNC], m[agx::META_NCON], m[agx::META_NENT], m[agx::META_NBENT]); }
-    if (!rc && packed) rc = run_wave(lds, agx::LDS_SOLVE4_WORDS, [&](int lane) { agx::env_solve4(blob, state, scratch, 0, 1, sw, nullptr, lds, lane, ph); });
-    else if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, ph); });
+    if (!rc && getenv("AGX_EMU_PRINT_META")) { const int* m = (const int*)(scratch + agx::SCR_O_META); fprintf(stderr, "meta: rows %d nnc %d contacts %d pairs %d\n", m[agx::META_NROWS], m[agx::META_NNC], m[agx::META_NCON], m[agx::META_NENT]); }
+    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, ph); });
   }
   if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
-  return rc;
-}
-// The packed solve kernel with ALL FOUR groups of the wavefront at work: n (1..4) environments, consecutive state records; `settle`
-// stepSimulation calls.  Each environment's build runs as its own wave (as on the device), then one packed wave solves the n of them.
-extern "C" int agx_emu_settle_packed(const uint32_t* blob, float* states, int n, int nsettle) {
-  static float lds[(agx::LDS_WORDS > agx::LDS_SOLVE4_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE4_WORDS)];
-  static float scratch[4 * agx::SCR_WORDS];
-  if (!agx::USE_SOLVE4 || n < 1 || n > 4) return -1;
-  const int sw = ((const int*)blob)[AGX_H_STATE_WORDS];
-  const int sim_sub = ((const int*)blob)[AGX_H_SIM_SUBSTEPS] > 1 ? ((const int*)blob)[AGX_H_SIM_SUBSTEPS] : 1;
-  int rc = 0;
-  for (int k = 0; k < nsettle * sim_sub && !rc; k++) {
-    for (int e = 0; e < n && !rc; e++)
-      rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, states + (size_t)e * sw, nullptr, scratch + (size_t)e * agx::SCR_WORDS, nullptr, lds, lane); });
-    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE4_WORDS, [&](int lane) { agx::env_solve4(blob, states, scratch, 0, n, sw, nullptr, lds, lane, k | AGX_PHASE_SETTLE); });
-  }
   return rc;
 }
 #if AGX_HAS_SAMPLER

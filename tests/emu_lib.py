@@ -23,8 +23,6 @@ VARIANT_DEFS['feeding_abs_travel'] = ['-DAGX_NO_REL_TRAVEL']      # narrowphase 
 VARIANT_DEFS['feeding_trace'] = ['-DAGX_EMU_TRACE_GJK']      # tests/diag/narrowphase_passes.py
 VARIANT_DEFS['feeding_lv'] = ['-DAGX_PGS_LV=1']       # the opt-in row-local sweep (csrc/agx_pgs_lv.h: velocity deltas in LDS, lane = entry of the visited row)
 VARIANT_DEFS['feeding_lv_cap'] = ['-DAGX_PGS_LV=1', '-DAGX_LV_WINDOW_CAP=300']       # the row-local sweep with a small LDS window: its rows-beyond-the-window path on ordinary scenes
-VARIANT_DEFS['feeding_packed'] = ['-DAGX_USE_SOLVE4=1']       # the opt-in packed solve kernel (csrc/agx_pgs4.h)
-VARIANT_DEFS['feeding_cap'] = ['-DAGX_USE_SOLVE4=1', '-DAGX_P4_WINDOW_CAP=100']      # the packed solver with a small LDS window: its rows-beyond-the-window path on ordinary scenes
 VARIANT_DEFS['feeding_l'] = ['-DAGX_MAX_COLL=320', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040']
 VARIANT_DEFS['feeding_m'] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_BLOCK=16', '-DAGX_MAX_COLL=320', '-DAGX_ST_WORDS=344', '-DAGX_ARENA_WORDS=4040']    # FeedingStretch
 VARIANT_DEFS['bed_m'] = ['-DAGX_MAX_DOF=28', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=16', '-DAGX_ARENA_WORDS=5632', '-DAGX_TASK=1']          # BedBathingStretch
@@ -108,12 +106,6 @@ class Emu:
 
     def settle(self, state, n, debug=False):
         return self._run(state, None, 1, n, debug)[4]
-
-    def settle_packed(self, states, n):
-        """the packed solve kernel (csrc/agx_pgs4.h) with up to four environments in one wavefront: `states` (k, state_words), in place"""
-        assert states.flags.c_contiguous and states.dtype == np.float32 and 1 <= len(states) <= 4
-        rc = self.L.agx_emu_settle_packed(_p(self.words), _p(states), C.c_int(len(states)), C.c_int(n))
-        assert rc == 0, 'wave emulator reported divergent control flow (or the variant has no packed kernel)'
 
     def sample(self, seed, impairment_mode=-1, gender_mode=-1, settled=None, fell=None):
         """device-side reset generator (csrc/agx_reset.h) for one env -> (state record, info[4]); settled: the rag-doll model's settled

@@ -321,45 +321,6 @@ def test_nonfinite_state_is_flagged_and_masked(blob, emu):
     assert not done and np.isfinite(obs).all() and info[6] < 1.0e6
 
 
-def test_packed_solver_with_all_groups_at_work(blob, oracle):
-    """csrc/agx_pgs4.h (opt-in build, -DAGX_USE_SOLVE4=1): four environments share a wavefront, each on its own 16-lane group with its own visit list.  Three environments with
-    different row counts in one wave: bitwise what the same kernel gives for each of them alone (group 0), and the oracle's result."""
-    from emu_lib import Emu
-    from oracle_lib import Oracle
-    # (the opt-in packed kernel sweeps its four environments with ONE no-op period: the per-environment switch AGX_P_NOOP_PEN of the product
-    # kernel -- plain sweeps in a substep with a pressed contact -- does not exist in it; compared with that switch off on both sides)
-    blob = blob.set_param('NOOP_PEN', 0.0)
-    oracle = Oracle(blob)
-    e = Emu(blob, kind='feeding_packed')
-    st, _ = make_states(blob, 3, seed=4001)
-    for i in range(3):
-        oracle.settle(st[i], 8 * (i + 1))                       # the food has fallen further in each: different contact sets per group
-    ref, got, one = st.copy(), st.copy(), st.copy()
-    e.settle_packed(got, 2)
-    for i in range(3):
-        e.settle(one[i], 2)
-        oracle.settle(ref[i], 2)
-        vo, ve = blob.view(ref[i]), blob.view(got[i])
-        assert np.abs(vo['q'] - ve['q']).max() < 2e-6 and np.abs(vo['qd'] - ve['qd']).max() < 2e-5
-        assert np.abs(vo['free'][0, :, :3] - ve['free'][0, :, :3]).max() < 2e-5          # free-body positions
-    assert np.array_equal(one, got)
-
-
-def test_packed_solver_rows_beyond_the_lds_window(blob, oracle):
-    """units that do not fit the group's LDS window are read from the scratch record: a build with a 100-unit window (an ordinary scene at
-    rest has 260) against the oracle and, bitwise, against the full-window build"""
-    from emu_lib import Emu
-    full, cap = Emu(blob, kind='feeding_packed'), Emu(blob, kind='feeding_cap')
-    st, _ = make_states(blob, 1, seed=3001)
-    s = st[0]
-    oracle.settle(s, 20)
-    a, b, r = s.copy(), s.copy(), s.copy()
-    full.settle(a, 2); cap.settle(b, 2); oracle.settle(r, 2)
-    assert np.array_equal(a, b)
-    vo, ve = blob.view(r), blob.view(b)
-    assert np.abs(vo['q'] - ve['q']).max() < 2e-6 and np.abs(vo['qd'] - ve['qd']).max() < 2e-5
-
-
 def test_noop_retest_rule_against_the_plain_solve(blob):
     """The no-op re-test rule (AGX_P_NOOP_RETEST = 5) is an approximation the oracle shares; here the kernel sources WITH the rule (the full 50
     sweeps) against the ORACLE WITHOUT it (NOOP_RETEST = 0, the plain solve): settled FeedingJaco states, three steps each, reward / forces /

@@ -11,7 +11,7 @@ import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(j['value']), j['ms_per_step'], {k[4:-7]: round(x,2) for k,x in j['roofline']['kernels_ms_per_step_summed_over_overlapping_launches'].items()})"; }
 for rep in 1 2; do
 timeout 300 $B > $O/bench_default_$rep.json 2>/dev/null; line default_$rep < $O/bench_default_$rep.json | tee -a $O/ab.txt
-for v in nolds noaddr norl3; do AGX_LIB=$R/assistive_gym_amd/lib/variants/$v.so timeout 300 $B > $O/bench_$v_$rep.json 2>/dev/null; line ${v}_$rep < $O/bench_$v_$rep.json | tee -a $O/ab.txt; done
+for v in nolds noaddr norl3; do AGX_LIB=$R/assistive_gym_amd/lib/variants/$v.so timeout 300 $B > $O/bench_${v}_${rep}.json 2>/dev/null; line ${v}_$rep < $O/bench_${v}_${rep}.json | tee -a $O/ab.txt; done
 done
 for t in bedbathing scratchitch; do timeout 300 python bench.py --task $t --steps 300 --warmup 20 --no-cpu-baseline > $O/bench_$t.json 2>/dev/null; line $t < $O/bench_$t.json | tee -a $O/ab.txt; done
 timeout 300 python bench.py --task bedbathing --workload wiping --steps 300 --warmup 20 --no-cpu-baseline > $O/bench_wiping.json 2>/dev/null; line wiping < $O/bench_wiping.json | tee -a $O/ab.txt
