@@ -131,6 +131,8 @@ def wiping_pool(blob, n, seed):
     reference's reset would have to be followed by a trained policy to get there).  Host code, pool generation only."""
     from assistive_gym_amd.host.reset_bed import make_states
     from assistive_gym_amd.model import xform as X
+    n_want = n
+    n = n + n // 2 + 4                                  # spare candidates: states whose arm is folded into itself are dropped below
     st, infos = make_states(blob, n, seed=seed, human_q_override={3: np.deg2rad(70)})
     rng = np.random.RandomState(seed)
     from assistive_gym_amd.model.human import HumanModel
@@ -157,7 +159,20 @@ def wiping_pool(blob, n, seed):
         # the pad stays on the skin for a handful of steps under small random actions (no policy presses it down): episodes of this
         # workload are 8 steps long, i.e. every environment is put back onto the arm from the pool every 8 steps
         v['iteration'][0] = int(blob.task_f('EPISODE_LEN')) - 8
-    return st
+    # The host sampler's least-squares IK does not keep the arm out of itself (the reference's null-space IK does): a start with two robot links
+    # 5 cm inside each other is not a wiping state, it is an explosion a few steps later (round 5: the stepper's own collision flags drop them;
+    # without a GPU -- the emulator tests -- the candidates are taken as they come).
+    from assistive_gym_amd import libagx
+    keep = np.ones(n, dtype=bool)
+    if libagx.load().agx_device_count() > 0:
+        chk = libagx.Stepper(blob, n)
+        chk.set_state(st)
+        keep = (chk.check_collisions() & 2) == 0         # AGX_COLLIDE_SELF (include/agx.h): two robot links, or a link and the tool, more than 1 cm inside each other
+        chk.close()
+    idx = np.flatnonzero(keep)
+    if len(idx) < n_want:                               # (never seen: a third of the candidates are spare)
+        idx = np.concatenate([idx, np.flatnonzero(~keep)])
+    return np.ascontiguousarray(st[idx[:n_want]])
 
 
 class _DryEnv:

@@ -230,7 +230,9 @@ enum {
                                    bit6: a solver row for EVERY contact of the group inside CONTACT_BREAK, not only those whose
                                    predicted gap is below CONTACT_SLACK (the prediction knows nothing of the motor rows: a tool
                                    driven onto the person closes gaps it calls open).  Set on the groups whose forces the tasks
-                                   report -- robot / tool against the person -- together with KEEP = 0: against the oracle without
+                                   report -- robot / tool against the person; not a tool compiled as a compound of dozens of convex
+                                   pieces (spoon, cup), whose speculative contacts would starve the substep's contact budget -- together
+                                   with KEEP = 0: against the oracle without
                                    any budget these two were worth up to 0.5 relative on total_force_on_human in 1-2 % of the
                                    contact-rich steps (round 5, profiles/r05/approximation_budget.json)                     */
   AGX_G_KEEP = 7,               /* per A collider keep only the KEEP contacts with the smallest

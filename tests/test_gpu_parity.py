@@ -678,7 +678,9 @@ def test_persistent_manifold_on_the_device(gpu_lib, workload):
             torch.cuda.synchronize()
         one.close()
     o.forget_warm()
-    assert differs > 1e-7 and (more > 0 or workload == 'wiping') and flips <= 2, (differs, more, flips)
+    # (wiping: since round 5 every contact of the pad with the person inside the break distance is solved anyway -- group flag bit 6 --, the cached
+    # points can coincide with them)
+    assert (differs > 1e-7 or workload == 'wiping') and (more > 0 or workload == 'wiping') and flips <= 2, (differs, more, flips)
 
 
 @pytest.mark.gpu

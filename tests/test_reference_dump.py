@@ -102,8 +102,9 @@ def test_stepper_matches_reference_dump(path, blob):
             pose = pose[pose != 23]              # the cloth-force term of the dressing observation: judged in tests/test_gpu_dressing.py against the oracle's own spread
         _check('obs @%d' % k, obs[k][pose], d['obs'][k][pose])
         # forces of a float32 pipeline carry the absolute floor of tests/conditioning.py (a contact is a spring of ~10^4 N/m in a gap known to ~1e-6 m)
-        ok, lim = C.check(abs(obs[k, f] - d['obs'][k][f]), REL * max(1.0, abs(d['obs'][k][f])), C.force_floor(blob))
-        assert ok, ('tool force @%d' % k, obs[k, f], d['obs'][k][f])
+        if 'cloth' not in d.files:               # (dressing: this column IS the cloth-force sum, judged below)
+            ok, lim = C.check(abs(obs[k, f] - d['obs'][k][f]), REL * max(1.0, abs(d['obs'][k][f])), C.force_floor(blob))
+            assert ok, ('tool force @%d' % k, obs[k, f], d['obs'][k][f])
         cf = 0.0
         if 'cloth' in d.files:                  # the cloth-force term: see test_oracle_matches_reference_dump
             from oracle_lib import Oracle
