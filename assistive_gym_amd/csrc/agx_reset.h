@@ -118,7 +118,9 @@ AGX_DEV double rs_joint_angle(const ResetCtx& c, int j) {
   if (c.settled && !(c.fall_stage && (flags & 4))) {                       // where the rag doll came to rest (bed_bathing.py:129-137)
     const double a = (double)c.settled[RS_SETTLE_VIRTUAL + j - (j > RS_SETTLE_FIXED ? 1 : 0)];
     // the fall model: setup_joints -> enforce_joint_limits clamps every joint once more (arm_manipulation.py:139-140, human.py:121)
-    return c.fall_stage ? fmin(fmax(a, (double)c.xf[base + AGX_XJ_LOWER] * s), (double)c.xf[base + AGX_XJ_UPPER] * s) : a;
+    // ... and the task's own sampler (c.fell: the stage after the fall) reads the same clamped pose: its goal poses (wrist, elbow, waist, stomach) must come
+    // from the tree the fall model wrote the human bodies from, not from the rag doll's unclamped angles (arm_manipulation.py:139-151)
+    return (c.fall_stage || c.fell) ? fmin(fmax(a, (double)c.xf[base + AGX_XJ_LOWER] * s), (double)c.xf[base + AGX_XJ_UPPER] * s) : a;
   }
   double a = (double)c.xf[base + AGX_XJ_PRESET];
   const int k = c.xi[base + AGX_XJ_DRAW];

@@ -43,6 +43,23 @@ class _LazyInfos:
         return (self[i] for i in range(len(self)))
 
 
+class _Rows:
+    """the rows of an [n, d] array as a sequence (what RLlib's sampler iterates: `dict(enumerate(obs))`), without building n array views up
+    front -- 1.1 ms of host time per step at 4096 environments"""
+
+    def __init__(self, a):
+        self._a = a
+
+    def __len__(self):
+        return len(self._a)
+
+    def __getitem__(self, i):
+        return self._a[i]
+
+    def __iter__(self):
+        return iter(self._a)
+
+
 class AgxVectorEnv(_VectorEnv):
     def __init__(self, env_id, num_envs, device=0, seed=1001, **vec_kwargs):
         from . import envs
@@ -59,8 +76,8 @@ class AgxVectorEnv(_VectorEnv):
         self._obs, self._host, self._pack = None, None, None
 
     def vector_reset(self):
-        self._obs = list(self.vec.reset().cpu().numpy())
-        return list(self._obs)
+        self._obs = _Rows(self.vec.reset().cpu().numpy())
+        return self._obs
 
     def reset_at(self, index):
         # the batch was reset on the device at the episode boundary; an environment the non-finite guard ended mid-episode was replaced at
@@ -94,12 +111,9 @@ class AgxVectorEnv(_VectorEnv):
         torch.cuda.current_stream(self.vec.device).synchronize()
         h = host.numpy()
         dn = h[:, od + 1] != 0
-        rows = list(h[:, :od])
-        self._obs = rows
-        if dn.any():
-            self._obs = list(rows)
-            for i in np.nonzero(dn)[0]:
-                self._obs[i] = h[i, od + 4:]
+        rows = _Rows(h[:, :od])
+        # reset_at(i): the first observation of the new episode for the rows that ended, the current observation elsewhere
+        self._obs = _Rows(np.where(dn[:, None], h[:, od + 4:], h[:, :od])) if dn.any() else rows
         return rows, h[:, od].tolist(), dn.tolist(), _LazyInfos(self._info_static, h[:, od + 2], h[:, od + 3])
 
     def get_unwrapped(self):

@@ -175,6 +175,99 @@ def wiping_pool(blob, n, seed):
     return np.ascontiguousarray(st[idx[:n_want]])
 
 
+def wiping_tape_vectors(blob, states):
+    """A scripted press-and-wipe policy for the 'dense' workload of config 3 (BASELINE: "dense tool-skin contact, PGS-heavy"):
+    per start state two joint-space directions -- `along`: the arm joints' motion that moves the pad along the limb it lies on, `press`: the one
+    that pushes it into the skin -- from the numeric Jacobian of the pad position at the start pose (host/kin.py), damped least squares.
+    The action of step t is g(F) x press + wipe_gain x along x square_wave(t) (WipingPolicy below): no learned policy.  The reference's take_step
+    re-anchors the motor targets at the CURRENT angles every step (env.py:201-215), so a constant press does not wind up."""
+    from assistive_gym_amd.host.kin import RobotKin
+    from assistive_gym_amd.model import xform as X
+    from assistive_gym_amd.model.human import HumanModel
+    kin = RobotKin(blob)
+    arm = kin.arm
+    n = len(states)
+    along, press = np.zeros((n, blob.act_dim), dtype=np.float32), np.zeros((n, blob.act_dim), dtype=np.float32)
+    for i in range(n):
+        v = blob.view(states[i].reshape(1, -1))
+        q = v['q'][0, :blob.nrobot].astype(np.float64)
+        bp, bq = v['base'][0, :3].astype(np.float64), v['base'][0, 3:7].astype(np.float64)
+
+        def pad(qq):
+            tp, tq = kin.tool_pose(bp, bq, qq)
+            return X.compose(tp, tq, blob.task_f('TOOL_OBS_POS', 3), blob.task_f('TOOL_OBS_QUAT', 4))[0]
+        p0 = pad(q)
+        J = np.zeros((3, len(arm)))
+        for k, d in enumerate(arm):
+            dq = q.copy(); dq[d] += 1e-5
+            J[:, k] = (pad(dq) - p0) / 1e-5
+        hm = HumanModel('male' if int(v['gender'][0]) == 0 else 'female')
+        hq = np.zeros(hm.n); hq[:10] = v['q'][0, blob.nrobot:blob.nrobot + 10]
+        base = v['human'][0, 0]
+        pos, _ = hm.fk(base[:3].astype(np.float64), base[3:7].astype(np.float64), hq)
+        sh, el, wr = pos[5], pos[7], pos[9]
+        # the limb the pad is nearest to, its axis, and the direction from the pad to the axis (= into the skin)
+        best = None
+        for a0, a1 in ((el, wr), (sh, el)):
+            ax = (a1 - a0) / np.linalg.norm(a1 - a0)
+            t = float(np.clip(np.dot(p0 - a0, ax), 0.0, np.linalg.norm(a1 - a0)))
+            foot = a0 + t * ax
+            dist = np.linalg.norm(p0 - foot)
+            if best is None or dist < best[0]:
+                best = (dist, ax, (foot - p0) / max(dist, 1e-9))
+        Jp = J.T @ np.linalg.inv(J @ J.T + 1e-4 * np.eye(3))                      # damped pseudo-inverse
+        for vec, out in ((best[1], along), (best[2], press)):
+            dq = Jp @ vec
+            dq = dq / max(np.abs(dq).max(), 1e-9)
+            for k, d in enumerate(arm):
+                out[i, kin.act[d]] = dq[k]
+    return along, press
+
+
+class WipingPolicy:
+    """The scripted press-and-wipe policy on the device: action = press x g(F) + along x wipe_gain x square_wave(t), g(F) = clip(0.05 + kf (F_target - F),
+    -0.05, 0.3) with F the tool force of the last observation -- press harder while the pad carries less than F_target newtons, ease off above.
+    Five tensor operations per step on the observations that are already on the device."""
+
+    def __init__(self, along, press, idx, fcol, episode_len, device, kf=0.1, f_target=2.0, wipe_gain=0.25, period=40):
+        import torch
+        self.torch = torch
+        self.al = torch.from_numpy(along[idx]).to(device) * wipe_gain
+        self.pr = torch.from_numpy(press[idx]).to(device)
+        self.fcol, self.T, self.kf, self.ft, self.period, self.t = fcol, episode_len, kf, f_target, period, 0
+
+    def __call__(self, obs):
+        torch = self.torch
+        wave = 1.0 if (self.t % self.T) % self.period < self.period // 2 else -1.0
+        self.t += 1
+        g = torch.clamp(0.05 + self.kf * (self.ft - obs[:, self.fcol]), -0.05, 0.3)
+        return torch.clamp(self.pr * g[:, None] + self.al * wave, -1.0, 1.0).contiguous()
+
+
+def dense_wiping_pool(blob, pool, device_index, seed=1001):
+    """Start states for the dense workload: twice `pool` candidates of the wiping pool, every one rolled for a whole 200-step episode under the
+    scripted policy on the device; the `pool` states on which the policy keeps the pad on the skin longest are kept (the rest slide off the limb
+    within a few steps -- an open-loop direction computed at the start pose is all the policy knows about the arm).  -> (states, along, press)"""
+    import torch
+    from assistive_gym_amd import vec_env
+    cand = wiping_pool(blob, 2 * pool, seed)
+    blob.view(cand)['iteration'][:] = 0                      # whole episodes
+    along, press = wiping_tape_vectors(blob, cand)
+    m = len(cand)
+    sel = vec_env.BedBathingSawyerVecEnv(m, device=device_index, seed=seed, pool_size=m, blob=blob)
+    sel.set_pool(cand)
+    obs = sel.reset()
+    f = blob.obs_dim_robot - 1
+    pol = WipingPolicy(along, press, np.arange(m), f, sel.episode_len, sel.device)
+    touching = torch.zeros(m, device=sel.device)
+    for k in range(sel.episode_len - 1):
+        obs, _, _, _ = sel.step(pol(obs))
+        touching += (obs[:, f] > 0).float()
+    order = torch.argsort(touching, descending=True).cpu().numpy()[:pool]
+    sel.close()
+    return np.ascontiguousarray(cand[order]), along[order], press[order], float(touching[torch.from_numpy(order).to(touching.device)].mean().item()) / (sel.episode_len - 1)
+
+
 class _DryEnv:
     """--dry-run: a stand-in for the batched environment on CPU tensors, so that the launch path of `bench.py --gpus N` -- rendezvous from the
     torchrun environment, sharding by rank, the per-step observation all-gather (shard.ObsGatherer), barrier, max-over-ranks timing, the one
@@ -253,7 +346,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         model, env_cls, ksuffix, env_id = cls.model, None, None, env_id_override.split(':')[-1]
         task = 'dressing' if model.startswith('dressing') else 'drinking' if model.startswith('drinking') else env_id_override
     if pool is None:
-        pool = 64 if task == 'dressing' else 256
+        pool = 64 if task == 'dressing' or workload == 'dense' else 256       # (dense: every candidate start is rolled for an episode on the device first)
     n = args.envs_per_gpu
     blob_override = None
     if args.param:
@@ -271,13 +364,19 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         env = getattr(vec_env, env_cls)(n, device=local_rank, seed=1001, pool_size=pool, reset=args.reset, blob=blob_override, pool_refresh=getattr(args, 'pool_refresh', 0))
     blob = env.blob                      # the co-op flavour where the task's BASELINE config is co-op
     action_scale = 1.0
+    policy, dense_touching = None, None
     if workload == 'wiping':
         env.set_pool(wiping_pool(blob, pool, 1001))
         action_scale = 0.15
+    if workload == 'dense':
+        from assistive_gym_amd.shard import pool_indices
+        st_d, al_d, pr_d, dense_touching = dense_wiping_pool(blob, pool, local_rank)
+        env.set_pool(st_d)
+        policy = WipingPolicy(al_d, pr_d, pool_indices(rank * n, n, pool), blob.obs_dim_robot - 1, env.episode_len, env.device)
     env.reset(env_offset=rank * n)
     K, W = steps, warmup
     g = torch.Generator(device='cuda'); g.manual_seed(1001 + rank)
-    tape = (torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1) * action_scale
+    tape = (torch.rand((W + K, n, blob.act_dim), device='cuda', generator=g) * 2 - 1) * action_scale if policy is None else None
     # whole-batch collation: per step ONE record per environment -- observation | reward | done | total_force_on_human | task_success (SURVEY
     # 8e; packed on the device by agx_pack_step) -- all-gathered over RCCL on a side stream, overlapped with the next step (two buffers alternate).
     # --gather abi (the default): the collective of the C ABI (agx_comm_init_rank / agx_allgather, RCCL bound by libagx itself; the 128-byte id
@@ -296,7 +395,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         gatherer = BatchGatherer(n, blob.obs_dim + 4, world, device=torch.device('cuda', local_rank), force=args.force_gather, stepper=env.stepper, comm=comm)
 
     def one(k):
-        env.step(tape[k])
+        env.step(tape[k] if policy is None else policy(env.obs))
         if distributed:
             gatherer.pack(k & 1, env.obs, env.reward, env.done, env.info)
             gatherer.submit(k & 1)
@@ -415,7 +514,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             'metric': 'env_steps_per_sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, %d PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale, int(blob.param('NITER'))),
+            'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, %d PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else ('scripted press-and-wipe policy on the device (tool force feedback), whole 200-step episodes from starts with the pad on the arm; the pad carries force in %.0f %% of the selection rollout' % (100 * dense_touching)) if workload == 'dense' else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale, int(blob.param('NITER'))),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed), 'gather': gather_how, 'gathered_record': 'obs | reward | done | total_force_on_human | task_success' if distributed else None, 'noop_retest': blob.param('NOOP_RETEST')},
             'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps
@@ -458,7 +557,7 @@ def main():
     ap.add_argument('--pool-refresh', type=int, default=0, help='k > 0: a child process samples k new start states at a time and the rollout swaps them into the pool at episode boundaries (vec_env.PoolRefresher); the line then reports pool_states_refreshed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--task', choices=sorted(TASKS), default=None, help="'feeding' = the BASELINE metric (config 2, the default); 'bedbathing' = config 3; 'scratchitch' = config 4's env (co-op) on one GPU; 'dressing' = config 5's")
-    ap.add_argument('--workload', choices=['wiping'], default=None, help="bedbathing only: 'wiping' = the contact-rich variant of config 3 (pad pressed onto the arm)")
+    ap.add_argument('--workload', choices=['wiping', 'dense'], default=None, help="bedbathing only: 'wiping' = pad pressed onto the arm at every reset, 8-step episodes, small random actions; 'dense' = whole 200-step episodes under a scripted press-and-wipe policy (BASELINE config 3: dense tool-skin contact)")
     ap.add_argument('--env', default=None, help="any built env id instead of --task, e.g. 'ScratchItchJaco-v1' or 'FeedingSawyerHuman-v1' (assistive_gym_amd.envs.ENV_IDS)")
     ap.add_argument('--param', action='append', default=[], help='override a PARAMS entry of the model blob, e.g. --param NOOP_RETEST=0 (same-box A/B runs)')
     ap.add_argument('--no-configs', action='store_true', help='the default 1-GPU run also times short runs of BASELINE configs 3, 4 (1 GPU), 5 (1 GPU) into "configs"; this skips them')
@@ -511,6 +610,7 @@ def main():
         # the other single-GPU BASELINE configurations on the same clock: short runs (a few seconds each), the headline value above is config 2
         extra = {}
         for key, t, wl, st in (('config3_BedBathingSawyer-v1', 'bedbathing', None, 300), ('config3_BedBathingSawyer-v1_wiping_contact', 'bedbathing', 'wiping', 300),
+                               ('config3_BedBathingSawyer-v1_dense', 'bedbathing', 'dense', 400),
                                ('config4_ScratchItchPR2Human-v1_1gpu', 'scratchitch', None, 300), ('config5_DressingBaxter-v1_1gpu', 'dressing', None, 30)):
             r = run_config(args, t, st, 10, rank, world, local_rank, distributed, cpu=False, workload=wl)
             extra[key] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'contacts_per_substep', 'overflow_count')}

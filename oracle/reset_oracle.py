@@ -188,7 +188,7 @@ class ResetOracle:
         fall_stage = bool(self.xi('FLAGS') & 256)
         if getattr(self, 'settled', None) is not None and not (fall_stage and flags & 4):     # where the rag doll came to rest (bed_bathing.py:129-137)
             a = float(self.settled[6 + j - (1 if j > 24 else 0)])
-            if fall_stage:                                                 # setup_joints -> enforce_joint_limits (arm_manipulation.py:139-140, human.py:121)
+            if fall_stage or getattr(self, 'fell', None) is not None:      # setup_joints -> enforce_joint_limits (arm_manipulation.py:139-140, human.py:121); the task stage reads the SAME clamped pose the fall model wrote its bodies from
                 s = ls if flags & 2 else 1.0
                 a = min(max(a, self.jf(g, j, 'LOWER') * s), self.jf(g, j, 'UPPER') * s)
             return a

@@ -160,3 +160,39 @@ def test_oracle_parity_at_bench_size_dressing():
     print('DressingBaxter at 4096: cloth_force_sum relative deviation, device vs oracle %s; oracle vs itself under 1e-6 m %s' % (np.round(rel_force, 4), np.round(rel_sens, 4)))
     assert np.median(rel_force) <= max(1e-3, 2.0 * np.median(rel_sens)) and max(rel_force) <= max(1e-3, 2.0 * max(rel_sens))
     env.close()
+
+
+def test_oracle_parity_at_bench_size_dense_wiping():
+    """BASELINE config 3 as BASELINE describes it ("dense tool-skin contact, PGS-heavy"): the scripted press-and-wipe policy of bench.py --workload
+    dense (whole episodes with the pad on the arm, several contacts per substep) at 4096 environments; after 30 policy steps one more step from the
+    states as they are, 64 environments against the oracle."""
+    _gpu()
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import dense_wiping_pool, WipingPolicy
+    from assistive_gym_amd import vec_env
+    from assistive_gym_amd.shard import pool_indices
+    from oracle_lib import Oracle
+    n, pool = 4096, 32
+    env = vec_env.BedBathingSawyerVecEnv(n, pool_size=pool, seed=2606)
+    blob = env.blob
+    st, al, pr, touching = dense_wiping_pool(blob, pool, 0, seed=2606)
+    env.set_pool(st)
+    obs = env.reset()
+    pol = WipingPolicy(al, pr, pool_indices(0, n, pool), blob.obs_dim_robot - 1, env.episode_len, env.device)
+    contacts, forced = 0.0, 0.0
+    for k in range(30):
+        obs, _, _, info = env.step(pol(obs))
+        contacts += float((info[:, 6] % 1000).mean()); forced += float((obs[:, blob.obs_dim_robot - 1] > 0).float().mean())
+    torch.cuda.synchronize()
+    before = env.stepper.get_state()
+    a = pol(obs)
+    obs, rew, done, info = env.step(a)
+    torch.cuda.synchronize()
+    obs, rew, info, a = obs.cpu().numpy(), rew.cpu().numpy(), info.cpu().numpy(), a.cpu().numpy()
+    worst, flips, judged = _compare(blob, Oracle(blob), before, a, obs, rew, info, PICKS, 'config3_dense')
+    print('config3_dense: contacts per substep (last substep of a step, mean over 30 steps) %.2f; environments with a force on the pad %.0f %%; selection rollout %.0f %%'
+          % (contacts / 30, 100 * forced / 30, 100 * touching))
+    assert contacts / 30 >= 3.0 and forced / 30 > 0.5
+    assert flips <= 8 and judged <= 16
+    env.close()
