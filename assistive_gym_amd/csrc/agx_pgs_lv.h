@@ -111,6 +111,9 @@ AGX_DEV void lv_update(const LvLay& Y, const LvHdr& h, const LvEnt& e, float v, 
 #endif
   wave_fence();                                                     // the next visit gathers what this one scattered: program order inside one wavefront
 }
+#if defined(__HIP_DEVICE_COMPILE__) && AGX_PGS_LV == 2
+AGX_DEV void lv_part_asm(const LvLay& Y, int lane, uint64_t mask, int base);
+#endif
 // the rows base + (set bits of m0, then 64 + set bits of m1), ascending
 struct LvIt { uint64_t m0, m1; int base, last; };
 AGX_DEV int lv_next(LvIt& it) {
@@ -122,12 +125,24 @@ AGX_DEV int lv_next(LvIt& it) {
 // header of visit t + 3 and the entry of visit t + 2 are requested before the arithmetic of visit t.  A row is visited once per part, so a
 // header (with its impulse) read three visits early is current.
 AGX_DEV void lv_part(const LvLay& Y, int lane, uint64_t m0, uint64_t m1, int base) {
-  const int nvis = popc64(m0) + popc64(m1);
+  int nvis = popc64(m0) + popc64(m1);
   if (nvis == 0) return;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_LV_ABL_FULL_EXEC)
   if (lane < LV_G)                                                  // the sweeps run under EXEC = lanes 0..15 (the emulator's collectives need all 64 fibres)
 #endif
   {
+#if defined(__HIP_DEVICE_COMPILE__) && AGX_PGS_LV == 2
+    // the assembly loop takes a 64-bit mask of rows inside the LDS window; rows beyond it (a suffix, Y.rfar) go through the C++ loop below
+    { const uint64_t n0 = base >= Y.rfar ? 0ull : (base + 64 <= Y.rfar ? ~0ull : pgs_range_mask(0, Y.rfar - base));
+      const uint64_t n1 = base + 64 >= Y.rfar ? 0ull : (base + 128 <= Y.rfar ? ~0ull : pgs_range_mask(0, Y.rfar - base - 64));
+      if ((m0 & ~n0) == 0ull && (m1 & ~n1) == 0ull) {
+        if (m0) lv_part_asm(Y, lane, m0, base);
+        if (m1) lv_part_asm(Y, lane, m1, base + 64);
+        m0 = 0ull; m1 = 0ull;
+      } }
+    nvis = popc64(m0) + popc64(m1);
+#endif
+    if (nvis > 0) {
     const int k = lane & (LV_G - 1);
     LvIt it; it.m0 = m0; it.m1 = m1; it.base = base; it.last = base;
     LvHdr h0, h1, h2, h3; LvEnt e0, e1, e2, e3;
@@ -158,9 +173,112 @@ AGX_DEV void lv_part(const LvLay& Y, int lane, uint64_t m0, uint64_t m1, int bas
       LV_STEP(h3, e3, h2, h1, e1)
     }
 #undef LV_STEP
+    }
   }
   wave_fence();
 }
+
+#if defined(__HIP_DEVICE_COMPILE__) && AGX_PGS_LV == 2
+// ---- the visit loop in gfx950 assembly (-DAGX_PGS_LV=2): the same visit as lv_gather / lv_update on the same LDS tables, 45 instructions instead of
+// the compiler's ~110.  One 64-bit mask of rows whose pairs all lie inside the LDS window (the caller checks).  Header ring of three
+// (visit t, t + 1, t + 2 in flight), entry ring of two; the body is written out six visits long so that both rings rotate without moves.
+// LDS answers in order, so the waits are exact: at the top of a visit the two stores of the previous one may still be in flight (lgkmcnt 2),
+// after the look-ahead loads the gather must be in (lgkmcnt 4).  Registers: v64..v87 headers, v88..v93 entries, v94..v99 temporaries,
+// v100..v102 header addresses; s80..s91.
+#define LVA_H0 "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v[64:67]", "v[68:71]", "v100"
+// step(HC: invD,b,lo,hi,lam of the current visit + its header address | HN1: pa, n, xa of the next | HN2: two b128 targets + address register
+//      of the one after | EC: J, B, ia, on-mask of the current | EN: pair target, ia, on-mask of the next)
+#define LVA_STEP(C_INVD, C_B, C_LO, C_HI, C_LAM, C_HA, N1_PA, N1_N, N1_XA, N2_LO4, N2_HI4, N2_HA, EC_J, EC_B, EC_IA, EC_ON, EN_JB, EN_IA, EN_ON) \
+  "s_waitcnt lgkmcnt(2)\n" \
+  "ds_read_b32 v94, " EC_IA "\n" \
+  "s_ff1_i32_b64 s82, s[80:81]\n" \
+  "s_bitset0_b64 s[80:81], s82\n" \
+  "s_lshl_b32 s83, s82, 5\n" \
+  "s_add_u32 s83, s83, %[hdr]\n" \
+  "v_mov_b32_e32 " N2_HA ", s83\n" \
+  "v_add_u32_e32 v98, " N1_PA ", %[k8]\n" \
+  "v_add_u32_e32 v99, " N1_XA ", %[k2]\n" \
+  "ds_read_b64 " EN_JB ", v98\n" \
+  "ds_read_u16 " EN_IA ", v99\n" \
+  "v_cmp_lt_u32_e64 " EN_ON ", %[k], " N1_N "\n" \
+  "ds_read_b128 " N2_LO4 ", " N2_HA "\n" \
+  "ds_read_b128 " N2_HI4 ", " N2_HA " offset:16\n" \
+  "s_waitcnt lgkmcnt(4)\n" \
+  "v_mul_f32_e32 v95, " EC_J ", v94\n" \
+  "v_cndmask_b32_e64 v95, 0, v95, " EC_ON "\n" \
+  "s_nop 1\n" \
+  "v_add_f32_dpp v95, v95, v95 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+  "s_nop 1\n" \
+  "v_add_f32_dpp v95, v95, v95 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+  "s_nop 1\n" \
+  "v_add_f32_dpp v95, v95, v95 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+  "s_nop 1\n" \
+  "v_add_f32_dpp v95, v95, v95 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+  "v_sub_f32_e32 v96, " C_B ", v95\n" \
+  "v_fma_f32 v96, " C_INVD ", v96, " C_LAM "\n" \
+  "v_med3_f32 v96, v96, " C_LO ", " C_HI "\n" \
+  "v_sub_f32_e32 v97, v96, " C_LAM "\n" \
+  "v_fmac_f32_e32 v94, " EC_B ", v97\n" \
+  "s_mov_b64 exec, 1\n" \
+  "ds_write_b32 " C_HA ", v96 offset:16\n" \
+  "s_mov_b64 exec, " EC_ON "\n" \
+  "ds_write_b32 " EC_IA ", v94\n" \
+  "s_mov_b64 exec, 0xffff\n" \
+  "s_sub_u32 s84, s84, 1\n" \
+  "s_cbranch_scc1 9f\n" \
+  "s_cmp_eq_u32 s84, 0\n" \
+  "s_cbranch_scc1 9f\n"
+// header slots: A = v64..v71 (address v100), B = v72..v79 (v101), C = v80..v87 (v102); entry slots: P = v[88:89] + v90 (mask s[86:87]), Q = v[91:92] + v93 (s[88:89])
+#define LVA_HCUR_A "v64", "v65", "v66", "v67", "v68", "v100"
+#define LVA_HCUR_B "v72", "v73", "v74", "v75", "v76", "v101"
+#define LVA_HCUR_C "v80", "v81", "v82", "v83", "v84", "v102"
+#define LVA_HN1_A "v69", "v70", "v71"
+#define LVA_HN1_B "v77", "v78", "v79"
+#define LVA_HN1_C "v85", "v86", "v87"
+#define LVA_HN2_A "v[64:67]", "v[68:71]", "v100"
+#define LVA_HN2_B "v[72:75]", "v[76:79]", "v101"
+#define LVA_HN2_C "v[80:83]", "v[84:87]", "v102"
+#define LVA_EC_P "v88", "v89", "v90", "s[86:87]"
+#define LVA_EC_Q "v91", "v92", "v93", "s[88:89]"
+#define LVA_EN_P "v[88:89]", "v90", "s[86:87]"
+#define LVA_EN_Q "v[91:92]", "v93", "s[88:89]"
+#define LVA_S2(a, b, c, d, e) LVA_STEP a, b, c, d, e)
+#define LVA_CALL(HC, HN1, HN2, EC, EN) LVA_APPLY(LVA_STEP, HC, HN1, HN2, EC, EN)
+#define LVA_APPLY(M, ...) M(__VA_ARGS__)
+AGX_DEV void lv_part_asm(const LvLay& Y, int lane, uint64_t mask, int base) {
+  const int k = lane, k8 = 8 * lane, k2 = 2 * lane;
+  const int hdr = Y.hdr_addr + 4 * LV_HDR_WORDS * base;
+  const int nvis = popc64(mask);
+  asm volatile(
+    "s_mov_b64 s[80:81], %[mask]\n"
+    "s_mov_b32 s84, %[nvis]\n"
+    // prime: headers of visits 0 and 1, entry of visit 0
+    "s_ff1_i32_b64 s82, s[80:81]\n" "s_bitset0_b64 s[80:81], s82\n" "s_lshl_b32 s83, s82, 5\n" "s_add_u32 s83, s83, %[hdr]\n" "v_mov_b32_e32 v100, s83\n"
+    "ds_read_b128 v[64:67], v100\n" "ds_read_b128 v[68:71], v100 offset:16\n"
+    "s_ff1_i32_b64 s82, s[80:81]\n" "s_bitset0_b64 s[80:81], s82\n" "s_lshl_b32 s83, s82, 5\n" "s_add_u32 s83, s83, %[hdr]\n" "v_mov_b32_e32 v101, s83\n"
+    "ds_read_b128 v[72:75], v101\n" "ds_read_b128 v[76:79], v101 offset:16\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "v_add_u32_e32 v98, v69, %[k8]\n" "v_add_u32_e32 v99, v71, %[k2]\n"
+    "ds_read_b64 v[88:89], v98\n" "ds_read_u16 v90, v99\n"
+    "v_cmp_lt_u32_e64 s[86:87], %[k], v70\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    "8:\n"
+    LVA_CALL(LVA_HCUR_A, LVA_HN1_B, LVA_HN2_C, LVA_EC_P, LVA_EN_Q)
+    LVA_CALL(LVA_HCUR_B, LVA_HN1_C, LVA_HN2_A, LVA_EC_Q, LVA_EN_P)
+    LVA_CALL(LVA_HCUR_C, LVA_HN1_A, LVA_HN2_B, LVA_EC_P, LVA_EN_Q)
+    LVA_CALL(LVA_HCUR_A, LVA_HN1_B, LVA_HN2_C, LVA_EC_Q, LVA_EN_P)
+    LVA_CALL(LVA_HCUR_B, LVA_HN1_C, LVA_HN2_A, LVA_EC_P, LVA_EN_Q)
+    LVA_CALL(LVA_HCUR_C, LVA_HN1_A, LVA_HN2_B, LVA_EC_Q, LVA_EN_P)
+    "s_branch 8b\n"
+    "9:\n"
+    "s_waitcnt lgkmcnt(0)\n"
+    :
+    : [mask] "s"(mask), [nvis] "s"(nvis), [hdr] "s"(hdr), [k] "v"(k), [k8] "v"(k8), [k2] "v"(k2)
+    : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",
+      "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102",
+      "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "vcc", "scc", "memory");
+}
+#endif
 
 // may this environment take the row-local sweep?  (wave uniform)
 AGX_DEV bool lv_eligible(const Ctx& c) {
