@@ -228,7 +228,7 @@ AGX_DEV void lv_part(const LvLay& Y, int lane, uint64_t m0, uint64_t m1, int bas
   "s_cbranch_scc1 9f\n" \
   "s_cmp_eq_u32 s84, 0\n" \
   "s_cbranch_scc1 9f\n"
-// header slots: A = v64..v71 (address v100), B = v72..v79 (v101), C = v80..v87 (v102); entry slots: P = v[88:89] + v90 (mask s[86:87]), Q = v[91:92] + v93 (s[88:89])
+// header slots: A = v64..v71 (address v100), B = v72..v79 (v101), C = v80..v87 (v102); entry slots: P = v[88:89] + v90 (mask s[86:87]), Q = v[92:93] + v91 (s[88:89]); register tuples must be even aligned on gfx950
 #define LVA_HCUR_A "v64", "v65", "v66", "v67", "v68", "v100"
 #define LVA_HCUR_B "v72", "v73", "v74", "v75", "v76", "v101"
 #define LVA_HCUR_C "v80", "v81", "v82", "v83", "v84", "v102"
@@ -239,9 +239,9 @@ AGX_DEV void lv_part(const LvLay& Y, int lane, uint64_t m0, uint64_t m1, int bas
 #define LVA_HN2_B "v[72:75]", "v[76:79]", "v101"
 #define LVA_HN2_C "v[80:83]", "v[84:87]", "v102"
 #define LVA_EC_P "v88", "v89", "v90", "s[86:87]"
-#define LVA_EC_Q "v91", "v92", "v93", "s[88:89]"
+#define LVA_EC_Q "v92", "v93", "v91", "s[88:89]"
 #define LVA_EN_P "v[88:89]", "v90", "s[86:87]"
-#define LVA_EN_Q "v[91:92]", "v93", "s[88:89]"
+#define LVA_EN_Q "v[92:93]", "v91", "s[88:89]"
 #define LVA_S2(a, b, c, d, e) LVA_STEP a, b, c, d, e)
 #define LVA_CALL(HC, HN1, HN2, EC, EN) LVA_APPLY(LVA_STEP, HC, HN1, HN2, EC, EN)
 #define LVA_APPLY(M, ...) M(__VA_ARGS__)

@@ -9,12 +9,12 @@ done
 for L in 9536 12288 16384 20480; do
 AGX_SOLVE_LDS_BYTES=$L AGX_LIB=$R/assistive_gym_amd/lib/variants/lv2.so timeout 200 python tools/gpu_lv_cycles.py 256 4096 2>&1 | grep -v "Warn\|amdgpu.ids" | tee -a $O/cycles.txt
 done
-AGX_SOLVE_LDS_BYTES=20480 AGX_LIB=$R/assistive_gym_amd/lib/variants/lv1.so timeout 200 python tools/gpu_lv_cycles.py 256 4096 2>&1 | grep -v "Warn\|amdgpu.ids" | tee -a $O/cycles.txt
-timeout 200 python tools/gpu_lv_cycles.py 256 4096 2>&1 | grep -v "Warn\|amdgpu.ids" | tee -a $O/cycles.txt
+
+
 B="python bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-configs"
 line() { python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(j['value']), j['ms_per_step'], {k[4:-7]: round(x,2) for k,x in j['roofline']['kernels_ms_per_step_summed_over_overlapping_launches'].items()})"; }
-timeout 300 $B > $O/bench_default.json 2>/dev/null; line default < $O/bench_default.json | tee -a $O/ab.txt
+
 for L in 9536 12288 16384 20480; do AGX_SOLVE_LDS_BYTES=$L AGX_LIB=$R/assistive_gym_amd/lib/variants/lv2.so timeout 300 $B > $O/bench_lv2_$L.json 2>/dev/null; line lv2_lds$L < $O/bench_lv2_$L.json | tee -a $O/ab.txt; done
 for C in 2 4 6; do AGX_CHUNKS=$C AGX_SOLVE_LDS_BYTES=20480 AGX_LIB=$R/assistive_gym_amd/lib/variants/lv2.so timeout 300 $B > $O/bench_lv2_20480_c$C.json 2>/dev/null; line lv2_lds20480_chunks$C < $O/bench_lv2_20480_c$C.json | tee -a $O/ab.txt; done
