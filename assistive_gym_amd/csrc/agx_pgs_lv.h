@@ -21,17 +21,18 @@
 namespace agx {
 
 constexpr int LV_G = 16;                                            // lanes of a visit = the longest row this path takes
-// MEASURED (round 5, profiles/r05/r05a_ab_lv_vs_register_sweep.txt, r05b_solve_cycles_per_visit.txt) AND NOT KEPT AS THE DEFAULT: FeedingJaco at 4096
-// environments 430 k env-steps/s against 467 k with the register sweep (same box, two runs each).  Shader-clock cycles of one solve per row and
-// sweep: one wavefront per CU 268 (register sweep: 192), sixteen per CU 331 (278); with every row inside the LDS window (20 KB) 247 / 275.
-// hipcc's loop is ~110 instructions per visit (16 vector, 7 LDS, the rest scalar bookkeeping, exec-mask branches and waits): a lone wave is
-// bound by its own issue rate (~4 cycles per instruction), sixteen per CU by the LDS -- 22 LDS cycles per visit (two b128 header broadcasts,
-// pairs, slot, gather, two stores) x 16 waves = 352 per visit round, against the register sweep's ~92 vector-port cycles x 4 waves per SIMD.
-// EXEC = 16 lanes buys nothing (full EXEC: 256 / 322).  Opt-in build: -DAGX_PGS_LV=1 (emulator variant 'feeding_lv', tests/test_emu_parity.py).
+// MEASURED (round 5; profiles/r05/).  AGX_PGS_LV = 1, the visit loop as hipcc compiles it from the C++ below: 430 k env-steps/s against 467 k with the
+// register sweep -- ~110 instructions per visit (16 vector, 7 LDS, the rest scalar bookkeeping, exec-mask branches, waits): 268 / 331 shader
+// cycles per row and sweep with one / sixteen wavefronts per CU (register sweep 192 / 278).  AGX_PGS_LV = 2 (the DEFAULT of the feeding
+// variant), the same visit on the same LDS tables written out in gfx950 assembly (lv_part_asm, 45 instructions): 155 / 168 cycles with every
+// row inside the window, FeedingJaco 524 k env-steps/s (r05f_*).  Rows beyond the window still go through the C++ loop, so the solve launch
+// of this variant takes 20 KB of LDS (agx_kernels.hip) -- with the register sweep's 9.5 KB a third of the visits are such rows: 437 k.
+// -DAGX_PGS_LV=0: the register sweep of agx_pgs.h (emulator variant 'feeding_reg' keeps its C++ twin tested).
 #ifndef AGX_PGS_LV
-#define AGX_PGS_LV 0
+#define AGX_PGS_LV 2
 #endif
-constexpr bool LV_COMPILED = AGX_PGS_LV && MAX_DOF <= 16 && TASK == AGX_TASK_FEEDING;
+constexpr bool LV_COMPILED = AGX_PGS_LV && MAX_DOF <= 16 && MAX_BLOCK <= 10 && TASK == AGX_TASK_FEEDING;       // the `feeding` variant (Jaco, Panda); rows of at most 16 pairs are checked per environment (lv_eligible)
+constexpr int LV_SOLVE_LDS_BYTES = 20480;                           // LDS of a solve launch of that variant: every row of an ordinary substep inside the window
 constexpr int LV_HDR_WORDS = 8;                                     // invD, b, lo, hi | lam, off8, n, pack
 constexpr int LV_H_LAM = 4, LV_H_LO = 2, LV_H_HI = 3;
 constexpr int LV_DV = 0, LV_HDR = 128;                              // LDS words: dv[128], headers[8 R8], pairs[2 (win + 16)], dv slot addresses[(win + 16) / 2] (16 bit)

@@ -606,13 +606,13 @@ def test_all_solver_switches_together_match_the_oracle(blob):
 
 
 def test_row_local_sweep_against_the_register_sweep(blob):
-    """The opt-in row-local sweep (csrc/agx_pgs_lv.h: velocity deltas in LDS, lane = entry of the visited row; built with -DAGX_PGS_LV=1,
-    measured slower than the register sweep on the MI355X and therefore not the default) against the register sweep (csrc/agx_pgs.h) and against itself with a 300-pair LDS window
+    """The row-local sweep (csrc/agx_pgs_lv.h: velocity deltas in LDS, lane = entry of the visited row; the default solve path of the feeding
+    variant -- on the device its visit loop is the assembly twin of the C++ run here) against the register sweep (csrc/agx_pgs.h, built with -DAGX_PGS_LV=0) and against itself with a 300-pair LDS window
     (most rows stream their pairs from the scratch record): same rows, same order, same clamps -- the dot products are associated
     differently, so the three agree to rounding, not bit for bit, and the window size must not change a bit."""
     from emu_lib import Emu
     from oracle_lib import Oracle
-    lv, reg, cap, oracle = Emu(blob, 'feeding_lv'), Emu(blob, 0), Emu(blob, 'feeding_lv_cap'), Oracle(blob)
+    lv, reg, cap, oracle = Emu(blob, 0), Emu(blob, 'feeding_reg'), Emu(blob, 'feeding_lv_cap'), Oracle(blob)
     st, _ = make_states(blob, 2, seed=3701)
     rng = np.random.RandomState(8)
     differs = 0
