@@ -31,7 +31,7 @@ constexpr int MAX_ROWS = 160;
 #endif
 constexpr int ST_WORDS = AGX_ST_WORDS;
 constexpr int CON_STRIDE = 16;
-constexpr int HDR_STRIDE = 10;
+constexpr int HDR_STRIDE = 16;   // 64 bytes: words 0..7 are what a visit of the row-local sweep needs (one 8-word scalar load, agx_pgs_lvs.h)
 #ifndef AGX_ARENA_WORDS   // LDS arena reused per phase: dynamics workspace, then collider AABB table + worklist + candidates
 #define AGX_ARENA_WORDS 3592
 #endif
@@ -138,7 +138,10 @@ constexpr int SCR_MAN = MP_STRIDE * MAX_CON, SCR_O_MAN = SCR_O_WARM + SCR_WARM;
 constexpr int SCR_WORDS = SCR_O_MAN + SCR_MAN;
 constexpr int META_NWARM = 8, META_NMAN = 9;      // (NWARM and NMAN are cleared together: agx_forget_warm_kernel)
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
-constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_PACK = 4, H_OFF = 5, H_M2 = 6, H_MU = 7, H_MLO = 8, H_MHI = 9;
+constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_OFF = 4, H_N = 5, H_NA = 6, H_AB = 7, H_PACK = 8, H_M2 = 9, H_MU = 10, H_MLO = 11, H_MHI = 12;
+// H_N: pairs of the row, H_NA: of its first DoF range; H_AB: byte offsets of the velocity slots of the two ranges relative to the pair index,
+// (4 a0 + H_AB_BIAS) | (4 (b0 - na) + H_AB_BIAS) << 16 -- the slot of pair k is 4 k + (k < na ? A : B) - H_AB_BIAS
+constexpr int H_AB_BIAS = 64;
 constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)
 
 struct Ctx {

@@ -518,7 +518,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   for (int k = lane; k < SCR_VEL; k += 64) scr.vel[k] = L[L_VEL + k];
   if (lane == 0) { scr.meta[META_NCON] = c.ncon; scr.meta[META_NROWS] = c.nrows; scr.meta[META_NNC] = c.first_normal; scr.meta[META_NEAR] = c.near_mask; scr.meta[META_OVERFLOW] = c.overflow; scr.meta[META_NENT] = c.nent; scr.meta[META_NQPT] = c.nqpt; }
   if (gdebug) {   // first-substep internals for the parity tests and the phase cycle counters
-    if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; }   // qdd at DBG_QDD
+    if (lane == 0) { gdebug[0] = (float)c.ncon; gdebug[1] = (float)c.nrows; gdebug[2] = (float)c.overflow; gdebug[3] = (float)c.first_normal; gdebug[4] = (float)c.nent; }   // qdd at DBG_QDD
     for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[DBG_CON + q] = scr.con[q];
     for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[DBG_MINV + q] = L[L_MINV + q];
     wave_sync();
@@ -581,7 +581,8 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0 = 0.f, dv1 = 0.f;
   bool solved = false;
-  if constexpr (LV_COMPILED) { if (lv_eligible(c)) { pgs_lv(c, lds, lds_words, dv0, dv1); solved = true; } }      // the row-local sweep (agx_pgs_lv.h)
+  if constexpr (LVS_COMPILED) { if (lvs_eligible(c, lds_words)) { pgs_lvs(c, lds, lds_words, dv0, dv1); solved = true; } }   // the row-local sweep, pairs and velocities in LDS (agx_pgs_lvs.h)
+  else if constexpr (LV_COMPILED) { if (lv_eligible(c)) { pgs_lv(c, lds, lds_words, dv0, dv1); solved = true; } }      // the row-local sweep, headers in LDS too (agx_pgs_lv.h)
   if (!solved) {
     // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)
     const bool rowspace = RS_MAX_ROWS > 0 && c.nrows <= RS_MAX_ROWS && c.nv <= 64 && c.nv <= RS_NVP && c.nrows > 0 && c.nent <= SOLVE_LDS_PAIRS;

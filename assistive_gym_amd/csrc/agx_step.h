@@ -30,6 +30,7 @@
 #include "agx_rows.h"
 #include "agx_pgs.h"
 #include "agx_pgs_lv.h"
+#include "agx_pgs_lvs.h"
 #if AGX_TASK == 5   /* AGX_TASK_DRINKING (an enum: not visible to the preprocessor) */
 #include "agx_water.h"
 #endif

@@ -457,7 +457,8 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         kms[:] = [0, 0, kernel_ms / K]; kcnt[:] = [0, 0, env.stepper.n_chunks() if hasattr(env.stepper, 'n_chunks') else 1]
     else:
         for k in range(NT):
-            ms, cnt = env.stepper.step_timed(tape[(W + k) % (W + K)], env.obs, env.reward, env.done, env.info, stream)
+            act = tape[(W + k) % (W + K)] if policy is None else policy(env.obs)
+            ms, cnt = env.stepper.step_timed(act, env.obs, env.reward, env.done, env.info, stream)
             kms += np.array(ms); kcnt += np.array(cnt)
         kms /= NT; kcnt /= NT
     out = None

@@ -68,9 +68,11 @@ extern "C" void agx_emu_manifold_set(const double* in, int n) {
   for (int p = 0; p < n; p++) { float* q = g_scratch + agx::SCR_O_MAN + agx::MP_STRIDE * p; const double* o = in + 12 * p;
     ((int*)q)[agx::MP_KEY] = (int)o[0] | ((int)o[1] << 9); for (int k = 0; k < 3; k++) { q[agx::MP_LA + k] = (float)o[2 + k]; q[agx::MP_LB + k] = (float)o[5 + k]; q[agx::MP_N + k] = (float)o[8 + k]; } q[agx::MP_DIST] = 0.f; q[agx::MP_MU] = (float)o[11]; }
 }
+// LDS of a solve launch, as libagx sizes it (agx_kernels.hip, g_solve_lds_bytes)
+constexpr int EMU_SOLVE_WORDS = agx::LVS_COMPILED && agx::LVS_SOLVE_LDS_BYTES / 4 > agx::LDS_SOLVE_WORDS ? agx::LVS_SOLVE_LDS_BYTES / 4 : agx::LDS_SOLVE_WORDS;
 extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* action, float* obs, float* reward, uint8_t* done,
                            float* info, float* debug, int mode, int nsettle) {
-  static float lds[agx::LDS_WORDS > agx::LDS_SOLVE_WORDS ? agx::LDS_WORDS : agx::LDS_SOLVE_WORDS];
+  static float lds[agx::LDS_WORDS > EMU_SOLVE_WORDS ? agx::LDS_WORDS : EMU_SOLVE_WORDS];
   float* const scratch = g_scratch;
   const int frame_skip = (int)((const float*)blob)[((const int*)blob)[AGX_H_OFF_PARAMS] + AGX_P_FRAME_SKIP];
   int rc = 0;
@@ -82,7 +84,7 @@ extern "C" int agx_emu_run(const uint32_t* blob, float* state, const float* acti
     rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_build<true>(blob, state, act, scratch, dbg, lds, lane); });
     const int ph = mode == 1 ? (k | AGX_PHASE_SETTLE) : k;
     if (!rc && getenv("AGX_EMU_PRINT_META")) { const int* m = (const int*)(scratch + agx::SCR_O_META); fprintf(stderr, "meta: rows %d nnc %d contacts %d pairs %d\n", m[agx::META_NROWS], m[agx::META_NNC], m[agx::META_NCON], m[agx::META_NENT]); }
-    if (!rc) rc = run_wave(lds, agx::LDS_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, ph); });
+    if (!rc) rc = run_wave(lds, EMU_SOLVE_WORDS, [&](int lane) { agx::env_solve(blob, state, scratch, dbg, lds, lane, ph, EMU_SOLVE_WORDS); });
   }
   if (mode == 0 && !rc) rc = run_wave(lds, agx::LDS_WORDS, [&](int lane) { agx::env_finish(blob, state, action, scratch, obs, reward, done, info, lds, lane); });
   return rc;

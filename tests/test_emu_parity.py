@@ -636,3 +636,30 @@ def test_row_local_sweep_against_the_register_sweep(blob):
             assert np.abs(l_obs - o_obs).max() < 1e-4 and abs(l_rew - o_rew) < 1e-4 and abs(l_info[0] - o_info[0]) <= 1e-3 * max(1.0, abs(o_info[0]))
             s = s_o
     assert differs > 0                                     # (two different sweeps: a real comparison)
+
+
+def test_row_local_sweep_with_scalar_headers(blob):
+    """csrc/agx_pgs_lvs.h (-DAGX_PGS_LV=3: row headers through scalar loads from the scratch record, impulses in a vector register, velocity
+    slots by arithmetic on the header) does the arithmetic of csrc/agx_pgs_lv.h visit by visit: the two agree BIT FOR BIT, and so does a build whose LDS
+    window holds 300 pairs only (most rows read their pairs from the scratch record: the window is a cache, not arithmetic); the register sweep
+    (-DAGX_PGS_LV=0) associates the dot products differently and agrees to rounding."""
+    from emu_lib import Emu
+    lv, lvs, cap, reg = Emu(blob, 0), Emu(blob, 'feeding_lvs'), Emu(blob, 'feeding_lvs_cap'), Emu(blob, 'feeding_reg')
+    st, _ = make_states(blob, 2, seed=3702)
+    rng = np.random.RandomState(9)
+    differs = 0
+    for i in range(2):
+        s = st[i].copy()
+        for k in range(3):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            outs = []
+            for e in (lv, lvs, cap, reg):
+                se = s.copy()
+                obs, rew, done, info, _ = e.step(se, a)
+                outs.append((se, obs, rew, info))
+            (s_l, o_l, r_l, i_l), (s_s, o_s, r_s, i_s), (s_c, o_c, r_c, i_c), (s_r, o_r, r_r, i_r) = outs
+            assert np.array_equal(s_l, s_s) and np.array_equal(o_l, o_s) and r_l == r_s and np.array_equal(i_l, i_s), (i, k)
+            assert np.array_equal(s_c, s_s) and np.array_equal(o_c, o_s) and r_c == r_s, (i, k)
+            differs += int(not np.array_equal(s_s, s_r))
+            s = s_s
+    assert differs > 0                                     # (a row-local sweep ran, not the register sweep)

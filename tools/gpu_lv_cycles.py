@@ -19,8 +19,9 @@ for n in [int(a) for a in sys.argv[1:]] or [256, 4096]:
     env.stepper.step_dev(a, env.obs, env.reward, env.done, env.info, torch.cuda.current_stream().cuda_stream, debug=dbg)
     torch.cuda.synchronize()
     D = dbg.cpu().numpy()
-    rows, cyc, tail = D[:, 1], D[:, lay[6] + 5], D[:, lay[6] + 6]
+    rows, cyc, tail, nent = D[:, 1], D[:, lay[6] + 5], D[:, lay[6] + 6], D[:, 4]
     print('%s lds=%s n=%d: rows median %.0f, solve cycles median %.0f (p10 %.0f, p90 %.0f), per row and sweep %.0f; tail (integration, store) median %.0f'
           % (os.path.basename(os.environ.get('AGX_LIB', 'libagx.so')), os.environ.get('AGX_SOLVE_LDS_BYTES', 'default'), n, np.median(rows), np.median(cyc), np.percentile(cyc, 10),
              np.percentile(cyc, 90), np.median(cyc / (50 * np.maximum(rows, 1))), np.median(tail)))
+    print('   pairs per environment: median %.0f, p75 %.0f, p90 %.0f, p99 %.0f, max %.0f' % (np.median(nent), np.percentile(nent, 75), np.percentile(nent, 90), np.percentile(nent, 99), nent.max()))
     env.close()
