@@ -19,7 +19,8 @@ namespace agx {
 
 constexpr bool LVS_COMPILED = AGX_PGS_LV == 3 && LV_COMPILED;
 constexpr int LVS_SOLVE_LDS_BYTES = LDS_SOLVE_BYTES;                // LDS of a solve launch of that variant: 16 waves per CU; the window holds the non-contact and normal rows of an ordinary substep and the first friction rows
-constexpr int LVS_DV = 0, LVS_PAIRS = 128;                           // LDS words: dv[128], pairs[2 x window]
+constexpr int LVS_DV = 0, LVS_LAM = 128, LVS_HI = LVS_LAM + MAX_ROWS, LVS_PAIRS = LVS_HI + MAX_ROWS;   // LDS words: dv[128], impulses[MAX_ROWS], friction bounds[MAX_ROWS], pairs[2 x window]
+static_assert(LVS_PAIRS % 2 == 0, "pairs are read as 8-byte words");
 static_assert(HDR_STRIDE == 16 && H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && H_OFF == 4 && H_N == 5 && H_NA == 6 && H_AB == 7, "the scalar load of a visit is words 0..7 of a 64-byte header");
 
 // pairs that fit a solve launch with lds_words of LDS
@@ -35,13 +36,13 @@ AGX_DEV bool lvs_eligible(const Ctx& c, int lds_words) {
   return lv_eligible(c) && c.first_normal + c.ncon <= 128 && c.ncon <= 64;
 }
 
-struct LvsLay { float* lds; const float* H; const float* E; int dv_addr, pairs_addr, rfar; };   // rfar: first row whose pairs are not (all) inside the LDS window
+struct LvsLay { float* lds; const float* H; const float* E; int dv_addr, lam_addr, pairs_addr, rfar; };   // rfar: first row whose pairs are not (all) inside the LDS window
 
 #if !defined(__HIP_DEVICE_COMPILE__) || defined(AGX_PGS_LV_CPP)
 // One visit, the C++ statement of what the assembly loop does (the emulator runs this; on the device it is the -DAGX_PGS_LV_CPP build).
 // lam: this lane's impulse register (lane = row - base); hiv: friction parts, mu x the normal impulse of the lane's contact (else unused).
-AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam, bool fric, bool far, float hiv) {
-  const float* H = Y.H + HDR_STRIDE * (base + bit); const int* Hi = (const int*)H;
+AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int row, bool fric, bool far) {
+  const float* H = Y.H + HDR_STRIDE * row; const int* Hi = (const int*)H;
   const int k = lane & (LV_G - 1);                                  // (the four 16-lane groups of the wave do the same visit)
   const int n = Hi[H_N], na = Hi[H_NA], ab = Hi[H_AB], off = Hi[H_OFF] & 0x0fffffff;
   const bool on = k < n;
@@ -49,14 +50,13 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
   float J = 0.f, B = 0.f, v = 0.f;
   if (on) { if (far) lv_ld2g(Y.E + 2 * (off + k), J, B); else lv_ld2(Y.lds, Y.pairs_addr + 8 * (off + k), J, B); v = lv_ld1(Y.lds, Y.dv_addr + slot); }
   const float jdv = wave_sum16(on ? J * v : 0.f);
-  const float l0 = wave_bcast(lam, bit);
+  const float l0 = lv_ld1(Y.lds, Y.lam_addr + 4 * row);
   float lo = H[H_LO], hi = H[H_HI];
-  if (fric) { hi = wave_bcast(hiv, bit); lo = -hi; }
+  if (fric) { hi = lv_ld1(Y.lds, Y.lam_addr + 4 * (MAX_ROWS + row)); lo = -hi; }
   const float nl = wave_clamp(l0 + (H[H_B] - jdv) * H[H_INVD], lo, hi);
   const float dl = nl - l0;
-  if (lane == bit) lam = nl;
-  wave_fence();                                                     // (emulator: the four groups have gathered before any of them scatters)
-  if (on) lv_st1(Y.lds, Y.dv_addr + slot, v + B * dl);
+  wave_fence();                                                     // (emulator: the four groups have read before any of them writes)
+  if (on) { lv_st1(Y.lds, Y.lam_addr + 4 * row, nl); lv_st1(Y.lds, Y.dv_addr + slot, v + B * dl); }
   wave_fence();                                                     // the next visit gathers what this one scattered
 }
 #else
@@ -73,7 +73,7 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
 #define LVS_NO(x)
 #define LVS_NOT_LVS_YES(x)
 #define LVS_NOT_LVS_NO(x) x
-#define LVS_ENTRY(FRIC, FAR, N_OFF, N_N, N_NA, N_AB, N_BIT, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LAM, EN_HI) \
+#define LVS_ENTRY(FRIC, FAR, N_OFF, N_N, N_NA, N_AB, N_BIT, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LA, EN_LAM, EN_HI) \
   "s_bfm_b32 " EN_ONLO ", " N_N ", 0\n" \
   "s_bfm_b32 vcc_lo, " N_NA ", 0\n" \
   "v_lshl_add_u32 v98, " N_OFF ", 3, %[k8p]\n" \
@@ -81,44 +81,34 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
   FAR("global_load_dwordx2 " EN_JB ", v98, %[E]\n") LVS_NOT_##FAR("ds_read_b64 " EN_JB ", v98\n") \
   "v_bfe_u32 v99, " N_AB ", v99, 10\n" \
   "v_add_u32_e32 " EN_IA ", v99, %[k4dv]\n" \
-  "v_readlane_b32 " EN_LAM ", %[lam], " N_BIT "\n" \
-  FRIC("v_readlane_b32 " EN_HI ", %[hiv], " N_BIT "\n")
+  "v_add_u32_e32 " EN_LA ", " N_BIT ", %[lamm]\n" \
+  "ds_read_b32 " EN_LAM ", " EN_LA "\n" \
+  FRIC("ds_read_b32 " EN_HI ", " EN_LA " offset:%c[hioff]\n")
 #define LVS_HEADER(N_OCT, N_BIT) \
-  "s_ff1_i32_b64 " N_BIT ", s[88:89]\n" \
-  "s_bitset0_b64 s[88:89], " N_BIT "\n" \
-  "s_lshl_b32 s99, " N_BIT ", 6\n" \
+  "s_ff1_i32_b64 s99, s[88:89]\n" \
+  "s_bitset0_b64 s[88:89], s99\n" \
+  "s_lshl_b32 s99, s99, 6\n" \
   "s_add_u32 s99, s99, %[base64]\n" \
-  "s_load_dwordx8 " N_OCT ", %[Hm], s99\n"
+  "s_load_dwordx8 " N_OCT ", %[Hm], s99\n" \
+  "s_lshr_b32 " N_BIT ", s99, 4\n"
 #define LVS_WAIT(FAR) FAR("s_waitcnt vmcnt(0) lgkmcnt(0)\n") LVS_NOT_##FAR("s_waitcnt lgkmcnt(0)\n")
-#define LVS_STEP(FRIC, FAR, C_INVD, C_B, C_LO, C_HI, C_BIT, N1_OFF, N1_N, N1_NA, N1_AB, N1_BIT, N3_OCT, N3_BIT, EC_J, EC_B, EC_IA, EC_ON, EC_LAM, EC_HI, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LAM, EN_HI) \
+#define LVS_STEP(FRIC, FAR, C_INVD, C_B, C_LO, C_HI, C_BIT, N1_OFF, N1_N, N1_NA, N1_AB, N1_BIT, N3_OCT, N3_BIT, EC_J, EC_B, EC_IA, EC_ON, EC_LA, EC_LAM, EC_HI, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LA, EN_LAM, EN_HI) \
   "ds_read_b32 v94, " EC_IA "\n" \
-  LVS_ENTRY(FRIC, FAR, N1_OFF, N1_N, N1_NA, N1_AB, N1_BIT, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LAM, EN_HI) \
+  LVS_ENTRY(FRIC, FAR, N1_OFF, N1_N, N1_NA, N1_AB, N1_BIT, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LA, EN_LAM, EN_HI) \
   LVS_WAIT(FAR) \
+  LVS_HEADER(N3_OCT, N3_BIT) \
   "v_mul_f32_e32 v95, " EC_J ", v94\n" \
   "v_cndmask_b32_e64 v95, 0, v95, " EC_ON "\n" \
-  /* the header request of visit t + 3 and two moves fill the wait states a DPP read of a fresh register needs (2 each) */ \
-  "s_ff1_i32_b64 " N3_BIT ", s[88:89]\n" \
-  "s_bitset0_b64 s[88:89], " N3_BIT "\n" \
-  LVS_DPP("quad_perm:[1,0,3,2]") \
-  "s_lshl_b32 s99, " N3_BIT ", 6\n" \
-  "s_add_u32 s99, s99, %[base64]\n" \
-  LVS_DPP("quad_perm:[2,3,0,1]") \
-  "s_load_dwordx8 " N3_OCT ", %[Hm], s99\n" \
-  "v_mov_b32_e32 v99, " EC_LAM "\n" \
-  LVS_DPP("row_half_mirror") \
-  FRIC("v_mov_b32_e32 v98, " EC_HI "\n") LVS_NOT_##FRIC("v_mov_b32_e32 v98, " C_LO "\n") \
-  "s_nop 0\n" \
-  LVS_DPP("row_mirror") \
+  FRIC("s_nop 1\n") LVS_NOT_##FRIC("v_mov_b32_e32 v98, " C_LO "\n" "s_nop 0\n") \
+  LVS_DPP("quad_perm:[1,0,3,2]") "s_nop 1\n" LVS_DPP("quad_perm:[2,3,0,1]") "s_nop 1\n" LVS_DPP("row_half_mirror") "s_nop 1\n" LVS_DPP("row_mirror") \
   "v_sub_f32_e32 v96, " C_B ", v95\n" \
-  "v_fma_f32 v97, " C_INVD ", v96, v99\n" \
-  FRIC("v_med3_f32 v96, v97, -v98, v98\n") LVS_NOT_##FRIC("v_med3_f32 v96, v97, v98, " C_HI "\n") \
-  "v_sub_f32_e32 v97, v96, v99\n" \
+  "v_fma_f32 v97, " C_INVD ", v96, " EC_LAM "\n" \
+  FRIC("v_med3_f32 v96, v97, -" EC_HI ", " EC_HI "\n") LVS_NOT_##FRIC("v_med3_f32 v96, v97, v98, " C_HI "\n") \
+  "v_sub_f32_e32 v97, v96, " EC_LAM "\n" \
   "v_fmac_f32_e32 v94, " EC_B ", v97\n" \
   "s_mov_b64 exec, " EC_ON "\n" \
   "ds_write_b32 " EC_IA ", v94\n" \
-  "v_readfirstlane_b32 s99, v96\n" \
-  "s_lshl_b64 exec, 1, " C_BIT "\n" \
-  "v_mov_b32_e32 %[lam], s99\n" \
+  "ds_write_b32 " EC_LA ", v96\n" \
   "s_mov_b64 exec, 0xffff\n" \
   "s_sub_u32 s98, s98, 1\n" \
   "s_cbranch_scc1 9f\n"
@@ -135,10 +125,10 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
 #define LVS_N3_C "s[68:75]", "s86"
 #define LVS_N3_D "s[76:83]", "s87"
 // entry slots: J, B, slot address, on-mask, impulse, friction bound / as targets: pair, slot address, on-mask (pair, low word), impulse, bound
-#define LVS_EC_P "v88", "v89", "v90", "s[90:91]", "s94", "s96"
-#define LVS_EC_Q "v92", "v93", "v91", "s[92:93]", "s95", "s97"
-#define LVS_EN_P "v[88:89]", "v90", "s[90:91]", "s90", "s94", "s96"
-#define LVS_EN_Q "v[92:93]", "v91", "s[92:93]", "s92", "s95", "s97"
+#define LVS_EC_P "v88", "v89", "v90", "s[90:91]", "v100", "v101", "v102"
+#define LVS_EC_Q "v92", "v93", "v91", "s[92:93]", "v103", "v104", "v105"
+#define LVS_EN_P "v[88:89]", "v90", "s[90:91]", "s90", "v100", "v101", "v102"
+#define LVS_EN_Q "v[92:93]", "v91", "s[92:93]", "s92", "v103", "v104", "v105"
 #define LVS_APPLY(M, ...) M(__VA_ARGS__)
 #define LVS_CALL(FRIC, FAR, C, N1, N3, EC, EN) LVS_APPLY(LVS_STEP, FRIC, FAR, C, N1, N3, EC, EN)
 #define LVS_BODY(FRIC, FAR) \
@@ -161,18 +151,19 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
     LVS_WAIT(FAR) \
     "s_mov_b64 exec, s[50:51]\n"
 #define LVS_CLOBBERS \
-      "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", \
+      "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", \
       "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", \
       "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "scc", "memory"
 // an exhausted cursor gives bit -1: the header address is then base64 - 64 with base64 = 64 (base + 1) against Hm = H - 64 bytes, i.e. the row
 // before `base` (or, for base 0, the last 64 bytes of the pair arena in front of the headers): loaded, never visited
 #define LVS_ASM(FRIC, FAR, K8) \
   asm volatile(LVS_BODY(FRIC, FAR) \
-    : [lam] "+v"(lam) \
-    : [mask] "s"(mask), [nvis1] "s"(nvis1), [base64] "s"(base64), [Hm] "s"(Hm), [E] "s"(Y.E), [k8p] "v"(K8), [k4dv] "v"(4 * lane + Y.dv_addr - H_AB_BIAS), [hiv] "v"(hiv) \
+    : \
+    : [mask] "s"(mask), [nvis1] "s"(nvis1), [base64] "s"(base64), [Hm] "s"(Hm), [E] "s"(Y.E), [k8p] "v"(K8), [k4dv] "v"(4 * lane + Y.dv_addr - H_AB_BIAS), \
+      [lamm] "v"(Y.lam_addr - 4), [hioff] "n"(4 * MAX_ROWS) \
     : LVS_CLOBBERS)
 // far: the rows' pairs lie beyond the LDS window: loaded from the scratch record (vmcnt) instead
-AGX_DEV void lvs_part_asm(const LvsLay& Y, int lane, uint64_t mask, int base, float& lam, bool fric, bool far, float hiv) {
+AGX_DEV void lvs_part_asm(const LvsLay& Y, int lane, uint64_t mask, int base, bool fric, bool far) {
   const int nvis1 = popc64(mask) - 1, base64 = 64 * (base + 1);
   const float* Hm = Y.H - HDR_STRIDE;
   if (!far) { if (fric) LVS_ASM(LVS_YES, LVS_NO, 8 * lane + Y.pairs_addr); else LVS_ASM(LVS_NO, LVS_NO, 8 * lane + Y.pairs_addr); }
@@ -180,19 +171,19 @@ AGX_DEV void lvs_part_asm(const LvsLay& Y, int lane, uint64_t mask, int base, fl
 }
 #endif
 
-// the rows base + (set bits of mask), ascending.  lam: impulses, lane = row - base; fric: friction rows, bounds -+ hiv (lane = row - base).
+// the rows base + (set bits of mask), ascending; fric: friction rows, bounds -+ the row's entry of the bound array.
 // Pair offsets grow with the row index: the rows whose pairs lie beyond the LDS window are a suffix [Y.rfar, ...), visited after the others.
-AGX_DEV void lvs_part(const LvsLay& Y, int lane, uint64_t mask, int base, float& lam, bool fric, float hiv) {
+AGX_DEV void lvs_part(const LvsLay& Y, int lane, uint64_t mask, int base, bool fric) {
   if (!mask) return;
   const int nn = Y.rfar - base;
   const uint64_t near = nn >= 64 ? mask : (nn <= 0 ? 0ull : mask & pgs_range_mask(0, nn)), far = mask & ~near;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(AGX_PGS_LV_CPP)
-  // (the loop narrows EXEC to lanes 0..15 itself and restores it; the impulse register is read and written by lane index, whatever EXEC)
-  if (near) lvs_part_asm(Y, lane, near, base, lam, fric, false, hiv);
-  if (far) lvs_part_asm(Y, lane, far, base, lam, fric, true, hiv);
+  // (the loop narrows EXEC to lanes 0..15 itself and restores it)
+  if (near) lvs_part_asm(Y, lane, near, base, fric, false);
+  if (far) lvs_part_asm(Y, lane, far, base, fric, true);
 #else
-  for (uint64_t m = near; m; m &= m - 1ull) lvs_visit(Y, lane, base, ffs64(m), lam, fric, false, hiv);
-  for (uint64_t m = far; m; m &= m - 1ull) lvs_visit(Y, lane, base, ffs64(m), lam, fric, true, hiv);
+  for (uint64_t m = near; m; m &= m - 1ull) lvs_visit(Y, lane, base + ffs64(m), fric, false);
+  for (uint64_t m = far; m; m &= m - 1ull) lvs_visit(Y, lane, base + ffs64(m), fric, true);
 #endif
   wave_fence();
 }
@@ -200,10 +191,11 @@ AGX_DEV void lvs_part(const LvsLay& Y, int lane, uint64_t mask, int base, float&
 AGX_DEV void pgs_lvs(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) {
   const int lane = c.lane, iters = (int)PRM(c, AGX_P_NITER);
   const int nnc = c.first_normal, nc = c.ncon, nA = nnc + nc, R = c.nrows;       // rows: [0,nnc) non-contact, [nnc,nA) normals, then nc friction rows per direction
-  LvsLay Y; Y.lds = lds; Y.H = c.H; Y.E = c.E; Y.dv_addr = lv_addr(lds, lds + LVS_DV); Y.pairs_addr = lv_addr(lds, lds + LVS_PAIRS);
-  // ---- prologue (all 64 lanes): velocity deltas, the window of pairs, the first row beyond it
+  LvsLay Y; Y.lds = lds; Y.H = c.H; Y.E = c.E; Y.dv_addr = lv_addr(lds, lds + LVS_DV); Y.lam_addr = lv_addr(lds, lds + LVS_LAM); Y.pairs_addr = lv_addr(lds, lds + LVS_PAIRS);
+  // ---- prologue (all 64 lanes): velocity deltas, impulses, the window of pairs, the first row beyond it
   const int win = lvs_window(lds_words);
   lds[LVS_DV + lane] = 0.f; lds[LVS_DV + 64 + lane] = 0.f;
+  for (int r = lane; r < 2 * MAX_ROWS; r += 64) lds[LVS_LAM + r] = 0.f;
   { const f2* src = (const f2*)c.E; f2* dst = (f2*)(lds + LVS_PAIRS); const int np = c.nent < win ? c.nent : win; for (int q = lane; q < np; q += 64) dst[q] = src[q]; }
   { int far_first = R;
     for (int r = lane; r < R; r += 64) { const int* Hi = (const int*)(c.H + HDR_STRIDE * r); if ((Hi[H_OFF] & 0x0fffffff) + Hi[H_N] > win && r < far_first) far_first = r; }
@@ -218,31 +210,33 @@ AGX_DEV void pgs_lvs(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
   wave_sync();
   const uint64_t rowsA0 = pgs_range_mask(0, nA < 64 ? nA : 64), rowsA1 = nA > 64 ? pgs_range_mask(0, nA - 64) : 0ull;
   const int K = noop_period(c);                                     // the no-op re-test rule: see pgs()
-  // impulses: rows 0..63 and 64..127 of the non-contact + normal block (lane = row, row - 64); friction rows of either direction (lane = contact)
-  float lamA0 = 0.f, lamA1 = 0.f, lamF1 = 0.f, lamF2 = 0.f;
   uint64_t skip0 = 0ull, skip1 = 0ull;
-  const int nsrc = (nnc + lane) & 63; const bool nhi = nnc + lane >= 64;           // where the normal impulse of this lane's contact lives
-  float ln = 0.f;
+  float* LAM = lds + LVS_LAM; float* HI = lds + LVS_HI;
   for (int it = 0; it < iters; it++) {
     const bool retest = K > 0 && it % K == 0, use = K > 0 && !retest;
-    const float bef0 = lamA0, bef1 = lamA1;
-    lvs_part(Y, lane, rowsA0 & ~(use ? skip0 : 0ull), 0, lamA0, false, 0.f);
-    lvs_part(Y, lane, rowsA1 & ~(use ? skip1 : 0ull), 64, lamA1, false, 0.f);
-    if (retest) { skip0 = wave_ballot(lamA0 == bef0); skip1 = wave_ballot(lamA1 == bef1); }
-    { const float s0 = wave_shfl(lamA0, nsrc), s1 = wave_shfl(lamA1, nsrc); ln = lane < nc ? (nhi ? s1 : s0) : 0.f; }
-    // friction rows (lane = contact): bounds from the normal impulses as this sweep's normal pass left them; a row whose normal impulse
-    // and own impulse are both zero is an exact no-op and is not visited
-    { const uint64_t todo = wave_ballot(lane < nc && (ln != 0.f || lamF1 != 0.f));
-      lvs_part(Y, lane, todo, nA, lamF1, true, mu1 * ln); }
-    if (two_dirs) {
-      const uint64_t todo = wave_ballot(lane < nc && (ln != 0.f || lamF2 != 0.f));
-      lvs_part(Y, lane, todo, nA + nc, lamF2, true, mu2 * ln);
+    float bef0 = 0.f, bef1 = 0.f;
+    if (retest) { if (lane < nA) bef0 = LAM[lane]; if (64 + lane < nA) bef1 = LAM[64 + lane]; }
+    lvs_part(Y, lane, rowsA0 & ~(use ? skip0 : 0ull), 0, false);
+    lvs_part(Y, lane, rowsA1 & ~(use ? skip1 : 0ull), 64, false);
+    if (retest) {
+      const float af0 = lane < nA ? LAM[lane] : 0.f, af1 = 64 + lane < nA ? LAM[64 + lane] : 0.f;
+      skip0 = wave_ballot(af0 == bef0); skip1 = wave_ballot(af1 == bef1);
+    }
+    for (int dir = 0; dir < (two_dirs ? 2 : 1); dir++) {
+      // friction rows (lane = contact): bounds from the normal impulses as this sweep's normal pass left them; a row whose normal
+      // impulse and own impulse are both zero is an exact no-op and is not visited
+      const int f0 = nA + dir * nc;
+      float ln = 0.f, lf = 0.f;
+      if (lane < nc) { ln = LAM[nnc + lane]; lf = LAM[f0 + lane]; HI[f0 + lane] = (dir ? mu2 : mu1) * ln; }
+      const uint64_t todo = wave_ballot(lane < nc && (ln != 0.f || lf != 0.f));
+      wave_sync();
+      lvs_part(Y, lane, todo, f0, true);
     }
   }
   wave_sync();
   // velocity deltas back to their DoF lanes; solved normal impulses -> contact records (what getContactPoints reports until the next step)
   dv0 = lds[LVS_DV + lane]; dv1 = lds[LVS_DV + 64 + lane];
-  if (lane < nc) c.gcon[CON_STRIDE * lane + C_LAM] = ln;
+  if (lane < nc) c.gcon[CON_STRIDE * lane + C_LAM] = LAM[nnc + lane];
   wave_sync();
 }
 
