@@ -282,9 +282,10 @@ AGX_K(agx_reset_verdict_kernel)(const uint32_t* __restrict__ blob, const float* 
 }
 #endif
 
-// LDS of a solve launch.  AGX_SOLVE_LDS_BYTES (tuning knob, read once): the row-local sweep (agx_pgs_lv.h) sizes its window of resident rows
+// LDS of a solve launch.  AGX_SOLVE_LDS_BYTES (tuning knob, read once): the row-local sweep (agx_pgs_lvs.h, agx_pgs_lv.h) sizes its window of resident rows
 // from it -- more LDS = fewer rows streamed from L2, fewer wavefronts per CU; never below what the other sweeps and solve_tail() need
-int g_solve_lds_bytes = agx::LV_COMPILED && !agx::LVS_COMPILED && agx::LV_SOLVE_LDS_BYTES > agx::LDS_SOLVE_BYTES ? agx::LV_SOLVE_LDS_BYTES : (agx::LVS_COMPILED && agx::LVS_SOLVE_LDS_BYTES > agx::LDS_SOLVE_BYTES ? agx::LVS_SOLVE_LDS_BYTES : agx::LDS_SOLVE_BYTES);
+constexpr int SWEEP_LDS_BYTES = agx::LVS_COMPILED ? agx::LVS_SOLVE_LDS_BYTES : (agx::LV_COMPILED ? agx::LV_SOLVE_LDS_BYTES : 0);      // what the row-local sweep of this variant wants (agx_pgs_lvs.h / agx_pgs_lv.h)
+int g_solve_lds_bytes = SWEEP_LDS_BYTES > agx::LDS_SOLVE_BYTES ? SWEEP_LDS_BYTES : agx::LDS_SOLVE_BYTES;
 hipError_t v_init(void) {
   if (const char* e = getenv("AGX_SOLVE_LDS_BYTES")) { int b = atoi(e) & ~15; if (b >= agx::LDS_SOLVE_BYTES && b <= 64 * 1024) g_solve_lds_bytes = b; }
   hipError_t e = hipFuncSetAttribute((const void*)AGX_K(agx_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g_solve_lds_bytes);

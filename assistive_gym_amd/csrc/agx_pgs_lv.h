@@ -23,13 +23,14 @@ namespace agx {
 constexpr int LV_G = 16;                                            // lanes of a visit = the longest row this path takes
 // MEASURED (round 5; profiles/r05/).  AGX_PGS_LV = 1, the visit loop as hipcc compiles it from the C++ below: 430 k env-steps/s against 467 k with the
 // register sweep -- ~110 instructions per visit (16 vector, 7 LDS, the rest scalar bookkeeping, exec-mask branches, waits): 268 / 331 shader
-// cycles per row and sweep with one / sixteen wavefronts per CU (register sweep 192 / 278).  AGX_PGS_LV = 2 (the DEFAULT of the feeding
-// variant), the same visit on the same LDS tables written out in gfx950 assembly (lv_part_asm, 45 instructions): 155 / 168 cycles with every
-// row inside the window, FeedingJaco 524 k env-steps/s (r05f_*).  Rows beyond the window still go through the C++ loop, so the solve launch
-// of this variant takes 20 KB of LDS (agx_kernels.hip) -- with the register sweep's 9.5 KB a third of the visits are such rows: 437 k.
-// -DAGX_PGS_LV=0: the register sweep of agx_pgs.h (emulator variant 'feeding_reg' keeps its C++ twin tested).
+// cycles per row and sweep with one / sixteen wavefronts per CU (register sweep 192 / 278).  AGX_PGS_LV = 2, the same visit on the same
+// LDS tables written out in gfx950 assembly (lv_part_asm, 45 instructions): 155 / 168 cycles with every row inside the window, FeedingJaco
+// 522 k env-steps/s (r05f_*).  Rows beyond the window still go through the C++ loop, so the solve launch of that build takes 20 KB of LDS
+// (agx_kernels.hip: 8 solve waves per CU) -- with the register sweep's 9.5 KB a third of the visits are such rows: 437 k.
+// AGX_PGS_LV = 3 (the DEFAULT of the feeding variant): agx_pgs_lvs.h, the same visit with the row headers in scalar registers and 10 KB
+// of LDS: 552 k.  -DAGX_PGS_LV=0: the register sweep of agx_pgs.h.  Emulator variants 'feeding_lv2' / 'feeding_reg' keep the C++ twins tested.
 #ifndef AGX_PGS_LV
-#define AGX_PGS_LV 2
+#define AGX_PGS_LV 3
 #endif
 constexpr bool LV_COMPILED = AGX_PGS_LV && MAX_DOF <= 16 && MAX_BLOCK <= 10 && TASK == AGX_TASK_FEEDING;       // the `feeding` variant (Jaco, Panda); rows of at most 16 pairs are checked per environment (lv_eligible)
 constexpr int LV_SOLVE_LDS_BYTES = 20480;                           // LDS of a solve launch of that variant: every row of an ordinary substep inside the window

@@ -1,24 +1,36 @@
-// agx_pgs_lvs.h -- K6, the row-local sweep with nothing but velocities and pairs in LDS (AGX_PGS_LV == 3).
+// agx_pgs_lvs.h -- K6, the row-local sweep with nothing but velocities and pairs in LDS (AGX_PGS_LV == 3, the default of the feeding variant).
 // Part of the stepper (see agx_step.h); included by agx_step.h only, after agx_pgs_lv.h (whose visit it restates on a leaner layout).
 //
 // agx_pgs_lv.h keeps an 8-word header per row and a 16-bit velocity slot per pair in LDS beside the pairs: 17.6 KB for an ordinary FeedingJaco
-// substep, 8 solve waves per CU, and the sweep is a dependent chain per visit (260 cycles alone on a CU, 283 with 8 waves): latency bound.
-// Here a visit gets
+// substep (1,350 pairs, 123 rows), i.e. 8 solve waves per CU.  Here a visit gets
 //   * the row's header -- 1/D, b, lo, hi, pair offset, pair counts, velocity slot offsets: words 0..7 of the 64-byte header build_rows()
 //     leaves in the scratch record -- through the SCALAR cache: one s_load_dwordx8 three visits ahead, the values are used straight from
 //     scalar registers;
-//   * the row's impulse from a vector register (lane = row: v_readlane before, v_writelane after), so the no-op re-test and the friction
-//     bounds are ordinary per-lane arithmetic between the parts;
-//   * the velocity slot of a pair by arithmetic on two header words.
-// LDS holds the velocity deltas (128 words) and the pairs: 10.5 KB for the ordinary substep, and per visit three LDS instructions (pairs,
-// gather, scatter) instead of seven.  An environment whose pairs do not fit takes the register sweep (agx_pgs.h): wave uniform.
-// Same rows, same order, same clamps, same no-op re-test rule and friction skipping as pgs() and pgs_lv().
+//   * the row's impulse from a vector register (lane = row: v_readlane before, a one-lane v_mov after), so the no-op re-test and the
+//     friction bounds are ordinary per-lane arithmetic between the parts;
+//   * the velocity slot of a pair by arithmetic on one header word;
+//   * its pairs from the LDS window, or -- the rows beyond it: the tail of the friction rows, most of which the no-op rule skips -- from the
+//     scratch record (global_load, vmcnt).
+// LDS holds the velocity deltas (128 words) and the window: 10 KB per solve wave (16 per CU), three LDS instructions per visit instead of
+// seven.  Same rows, same order, same clamps, same arithmetic as pgs_lv(): the two are BIT-IDENTICAL on the GPU (tools/gpu_lv_bits.py,
+// profiles/r05/r05i_bits_*) and in the emulator, whatever the window.
+//
+// MEASURED (round 5, same box, 4096 FeedingJaco environments, 300 steps; profiles/r05/r05h..r05m).  env-steps/s: pgs_lv() at 20 KB 522 k;
+// this file at 9.5 / 10 / 11 / 12 KB of LDS 544 / 552 / 546 / 540 k.  Shader cycles per row and sweep with one / sixteen waves per CU:
+// 159 / 266 at 10 KB (pgs_lv: 155 / 168 with eight).  What did NOT help: impulses and friction bounds in LDS arrays instead of the register
+// (three fewer vector instructions, three more LDS instructions: 521 k; tools/experiments/agx_pgs_lvs_impulses_in_lds.h); the write-back of
+// the impulse and the loop test moved into the shadow of the next gather (546 k).  What did: the scalar instructions of the header request
+// in the wait states the DPP butterfly needs anyway (538 -> 552 k).
+// Marginal cost of ONE more instruction per visit, measured with redundant instructions (AGX_LVS_PROBE_*, r05m_*), one / sixteen waves
+// per CU: vector 5.9 / 3.8 cycles, scalar 5.5 / 5.9, s_nop 5.5 / 4.2, LDS read 21 / 6, LDS write 11 / 9 -- of a visit of 268 / 448 cycles and
+// 38 instructions.  A wave pays 4..6 cycles for every instruction it issues, of whatever kind, in both regimes: the sweep is bound by the
+// per-wave issue rate of a dependent chain, not by a pipe; what is left is the instruction count per visit.
 #pragma once
 
 namespace agx {
 
 constexpr bool LVS_COMPILED = AGX_PGS_LV == 3 && LV_COMPILED;
-constexpr int LVS_SOLVE_LDS_BYTES = LDS_SOLVE_BYTES;                // LDS of a solve launch of that variant: 16 waves per CU; the window holds the non-contact and normal rows of an ordinary substep and the first friction rows
+constexpr int LVS_SOLVE_LDS_BYTES = 10240;                          // LDS of a solve launch of that variant: 16 waves per CU; the window (1,216 pairs) holds the non-contact and normal rows of an ordinary substep and most friction rows
 constexpr int LVS_DV = 0, LVS_PAIRS = 128;                           // LDS words: dv[128], pairs[2 x window]
 static_assert(HDR_STRIDE == 16 && H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && H_OFF == 4 && H_N == 5 && H_NA == 6 && H_AB == 7, "the scalar load of a visit is words 0..7 of a 64-byte header");
 
@@ -69,6 +81,29 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
 // s[52:83] headers, s84..s87 their bit indices, s[88:89] cursor, s[90:93] on-masks, s94..s97 impulses / friction bounds,
 // s98 visits left, s99 scratch, vcc; v88..v93 entries (pair, slot address), v94..v99 temporaries.
 #define LVS_DPP(CTRL) "v_add_f32_dpp v95, v95, v95 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// AGX_LVS_PROBE_*: marginal cost of one more instruction of a kind inside a visit -- redundant instructions that change no result
+// (tools/gpu_r05_s13.sh; profiles/r05/r05m_*): n extra instructions per visit
+#define LVS_REP0(x)
+#define LVS_REP1(x) x
+#define LVS_REP2(x) x x
+#define LVS_REP4(x) x x x x
+#define LVS_REPN(n, x) LVS_REPN_(n, x)
+#define LVS_REPN_(n, x) LVS_REP##n(x)
+#ifndef AGX_LVS_PROBE_VALU
+#define AGX_LVS_PROBE_VALU 0
+#endif
+#ifndef AGX_LVS_PROBE_SALU
+#define AGX_LVS_PROBE_SALU 0
+#endif
+#ifndef AGX_LVS_PROBE_NOP
+#define AGX_LVS_PROBE_NOP 0
+#endif
+#ifndef AGX_LVS_PROBE_LDSR
+#define AGX_LVS_PROBE_LDSR 0
+#endif
+#ifndef AGX_LVS_PROBE_LDSW
+#define AGX_LVS_PROBE_LDSW 0
+#endif
 #define LVS_YES(x) x
 #define LVS_NO(x)
 #define LVS_NOT_LVS_YES(x)
@@ -93,7 +128,9 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
 #define LVS_STEP(FRIC, FAR, C_INVD, C_B, C_LO, C_HI, C_BIT, N1_OFF, N1_N, N1_NA, N1_AB, N1_BIT, N3_OCT, N3_BIT, EC_J, EC_B, EC_IA, EC_ON, EC_LAM, EC_HI, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LAM, EN_HI) \
   "ds_read_b32 v94, " EC_IA "\n" \
   LVS_ENTRY(FRIC, FAR, N1_OFF, N1_N, N1_NA, N1_AB, N1_BIT, EN_JB, EN_IA, EN_ON, EN_ONLO, EN_LAM, EN_HI) \
+  LVS_REPN(AGX_LVS_PROBE_LDSR, "ds_read_b32 v97, " EC_IA "\n") \
   LVS_WAIT(FAR) \
+  LVS_REPN(AGX_LVS_PROBE_VALU, "v_mov_b32_e32 v97, 0\n") LVS_REPN(AGX_LVS_PROBE_SALU, "s_mov_b32 s99, 0\n") LVS_REPN(AGX_LVS_PROBE_NOP, "s_nop 0\n") \
   "v_mul_f32_e32 v95, " EC_J ", v94\n" \
   "v_cndmask_b32_e64 v95, 0, v95, " EC_ON "\n" \
   /* the header request of visit t + 3 and two moves fill the wait states a DPP read of a fresh register needs (2 each) */ \
@@ -116,6 +153,7 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
   "v_fmac_f32_e32 v94, " EC_B ", v97\n" \
   "s_mov_b64 exec, " EC_ON "\n" \
   "ds_write_b32 " EC_IA ", v94\n" \
+  LVS_REPN(AGX_LVS_PROBE_LDSW, "ds_write_b32 " EC_IA ", v94\n") \
   "v_readfirstlane_b32 s99, v96\n" \
   "s_lshl_b64 exec, 1, " C_BIT "\n" \
   "v_mov_b32_e32 %[lam], s99\n" \

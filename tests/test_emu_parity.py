@@ -606,13 +606,13 @@ def test_all_solver_switches_together_match_the_oracle(blob):
 
 
 def test_row_local_sweep_against_the_register_sweep(blob):
-    """The row-local sweep (csrc/agx_pgs_lv.h: velocity deltas in LDS, lane = entry of the visited row; the default solve path of the feeding
-    variant -- on the device its visit loop is the assembly twin of the C++ run here) against the register sweep (csrc/agx_pgs.h, built with -DAGX_PGS_LV=0) and against itself with a 300-pair LDS window
+    """The row-local sweep (csrc/agx_pgs_lv.h, -DAGX_PGS_LV=2: velocity deltas in LDS, lane = entry of the visited row -- on the device its
+    visit loop is the assembly twin of the C++ run here) against the register sweep (csrc/agx_pgs.h, built with -DAGX_PGS_LV=0) and against itself with a 300-pair LDS window
     (most rows stream their pairs from the scratch record): same rows, same order, same clamps -- the dot products are associated
     differently, so the three agree to rounding, not bit for bit, and the window size must not change a bit."""
     from emu_lib import Emu
     from oracle_lib import Oracle
-    lv, reg, cap, oracle = Emu(blob, 0), Emu(blob, 'feeding_reg'), Emu(blob, 'feeding_lv_cap'), Oracle(blob)
+    lv, reg, cap, oracle = Emu(blob, 'feeding_lv2'), Emu(blob, 'feeding_reg'), Emu(blob, 'feeding_lv_cap'), Oracle(blob)
     st, _ = make_states(blob, 2, seed=3701)
     rng = np.random.RandomState(8)
     differs = 0
@@ -639,12 +639,12 @@ def test_row_local_sweep_against_the_register_sweep(blob):
 
 
 def test_row_local_sweep_with_scalar_headers(blob):
-    """csrc/agx_pgs_lvs.h (-DAGX_PGS_LV=3: row headers through scalar loads from the scratch record, impulses in a vector register, velocity
+    """csrc/agx_pgs_lvs.h (the default solve path of the feeding variant: row headers through scalar loads from the scratch record, impulses in a vector register, velocity
     slots by arithmetic on the header) does the arithmetic of csrc/agx_pgs_lv.h visit by visit: the two agree BIT FOR BIT, and so does a build whose LDS
     window holds 300 pairs only (most rows read their pairs from the scratch record: the window is a cache, not arithmetic); the register sweep
     (-DAGX_PGS_LV=0) associates the dot products differently and agrees to rounding."""
     from emu_lib import Emu
-    lv, lvs, cap, reg = Emu(blob, 0), Emu(blob, 'feeding_lvs'), Emu(blob, 'feeding_lvs_cap'), Emu(blob, 'feeding_reg')
+    lv, lvs, cap, reg = Emu(blob, 'feeding_lv2'), Emu(blob, 0), Emu(blob, 'feeding_lvs_cap'), Emu(blob, 'feeding_reg')
     st, _ = make_states(blob, 2, seed=3702)
     rng = np.random.RandomState(9)
     differs = 0

@@ -3,7 +3,7 @@
 # default 9.5 KB): bit-for-bit states against the default build (window as large as the scene, default window, 300-pair window), step rate over
 # LDS size and chunk count, cycles per visit
 set -u
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05k; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05l; mkdir -p $O; cd $R
 export TMPDIR=/tmp
 V=$R/assistive_gym_amd/lib/variants/lvs.so; VC=$R/assistive_gym_amd/lib/variants/lvs_cap.so
 AGX_SOLVE_LDS_BYTES=20480 timeout 200 python tools/gpu_lv_bits.py $O/bits_lv.npz 1024 40 2>&1 | tail -1
