@@ -17,8 +17,7 @@ AGX_DEV void make_shape(const Ctx& c, int col, v3 shift, gjk_shape& s) {
 }
 // closest features of colliders (ca, cb); true if the separation (radii included) is below limit.
 // Wave-uniform: every lane calls it, lanes without a pair pass has = false.
-// iters: GJK iterations this lane's pair took (the effort memory of collide_flush), if asked for
-AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, bool has, int* iters = nullptr) {
+AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, bool has) {
   const float* AB = c.lds + L_ARENA;
   gjk_shape sa, sb;
   sa.v = nullptr; sa.n = 0; sa.box = false; sa.c = mk3(0.f, 0.f, 0.f); sb.v = nullptr; sb.n = 0; sb.box = false; sb.c = sa.c;
@@ -41,9 +40,7 @@ AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, b
     ra = CLF(c, ca, AGX_C_RADIUS); rb = CLF(c, cb, AGX_C_RADIUS);
   }
   float d; v3 pa, pb, n;
-  int its = 0;
-  const bool pen = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), limit + ra + rb + GJK_FAR_MARGIN, ok, d, pa, pb, its);
-  if (iters) *iters = its;
+  const bool pen = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), limit + ra + rb + GJK_FAR_MARGIN, ok, d, pa, pb);
   if (!ok) return false;
   if (!pen) {
     if (d - ra - rb >= limit) return false;
@@ -217,10 +214,6 @@ AGX_DEV bool sphere_box_apart(const Ctx& c, int x, int y, float reach) {
 
 // narrowphase + selection over the current worklist (entries of one or several whole groups, in
 // enumeration order); appends the resulting contacts
-#ifndef AGX_NARROWPHASE_BY_EFFORT   // -DAGX_NARROWPHASE_BY_EFFORT=0: worklist order (A/B runs)
-#define AGX_NARROWPHASE_BY_EFFORT 1
-#endif
-AGX_DEV int iter_slot(int a, int b) { return (a + 37 * b) & (ITER_SLOTS - 1); }
 AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float slack, const GroupRegs& G) {
   float* L = c.lds; int* WL = c.ldsi + L_ARENA + A_WL; float* CD = L + L_ARENA + A_CAND; const int lane = c.lane;
   const float* AB = L + L_ARENA;
@@ -229,34 +222,10 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
   wave_sync();
   long long ct0 = c.timing ? wave_clock() : 0;
   if (c.timing) { c.tm[13] += wn; c.tm[14] += (wn + 63) / 64; }   // debug: narrowphase pairs / passes
-  // 3. narrowphase, 64 pairs per pass.  A pass runs until its slowest lane has converged (4-6 GJK iterations) while the mean pair needs 1.75
-  // (most pairs are proven apart by the first separating axis), so the entries are taken in the order of the effort they took the LAST
-  // time they were tested (a byte per pair in the scratch record, hashed): the pairs in contact share passes, the rest run short ones.
-  // The order decides nothing but which pairs wait for each other -- every entry's result goes to its own candidate record.  Feeding
-  // only: elsewhere the ORDER of the manifold query points (nqpt) follows the order of the passes.
-  constexpr bool BY_EFFORT = TASK == AGX_TASK_FEEDING && AGX_NARROWPHASE_BY_EFFORT;
-  uint8_t* PERM = (uint8_t*)(c.ldsi + L_ARENA + A_CAND + CAND_STRIDE * WL_CAP);      // (the A-collider list of the sweep is dead; SEL takes the place afterwards)
-  static_assert(WL_MAX <= 256 && WL_CAP <= 4 * 64, "worklist indices fit a byte, the worklist four chunks of 64");
-  if constexpr (BY_EFFORT) {
-    int key[4];
-    for (int q = 0; q < 4; q++) {
-      const int i = 64 * q + lane; key[q] = -2;
-      if (i < wn) { const int pr = WL[i]; key[q] = ((pr >> 24) & 3) ? -1 : (c.giter ? (c.giter[iter_slot(pr & 511, (pr >> 9) & 511)] & 7) : 0); }   // face-manifold entries last: they read their pair's GJK contact
-    }
-    int pos = 0;
-    for (int bin = 7; bin >= -1; bin--)
-      for (int q = 0; q < 4; q++) {
-        if (64 * q >= wn) break;
-        const uint64_t m = wave_ballot(key[q] == bin);
-        if (key[q] == bin) PERM[pos + wave_rank(m)] = (uint8_t)(64 * q + lane);
-        pos += popc64(m);
-      }
-    wave_sync();
-  }
+  // 3. narrowphase, 64 pairs per pass
   bool any_manifold_query = false;
   for (int base = 0; base < wn; base += 64) {
-    const bool has = base + lane < wn;
-    const int i = BY_EFFORT ? (has ? (int)PERM[base + lane] : wn) : base + lane;
+    const int i = base + lane; const bool has = i < wn;
     Cand k; k.gap = 3.0e38f; bool near = false; int a = 0, g = 0;
     int b = 0, sub = 0;
     float lim = brk;
@@ -269,9 +238,7 @@ AGX_DEV void collide_flush(Ctx& c, int wn, CollideState& cs, float brk, float sl
       if (!(GRI(c, g, AGX_G_FLAGS) & (2 | 64))) lim = fminf(brk, slack + rel_travel(c, a, b) + 1e-5f);
     }
     k.n = mk3(0.f, 0.f, 0.f); k.pa = k.n; k.pb = k.n; k.dist = 0.f;
-    int its = 0;
-    bool hit = narrowphase(c, a, b, lim, k, has && sub == 0, &its);
-    if (BY_EFFORT && c.giter && has && sub == 0) c.giter[iter_slot(a, b)] = (uint8_t)(its < 7 ? its : 7);
+    bool hit = narrowphase(c, a, b, lim, k, has && sub == 0);
 #ifdef AGX_NARROWPHASE_TWICE   // timing experiment: the narrowphase of every pass a second time (same result) -- the slowdown of the step is what ONE
     { Cand k2; k2.gap = 3.0e38f; k2.n = mk3(0.f, 0.f, 0.f); k2.pa = k2.n; k2.pb = k2.n; k2.dist = 0.f;     // narrowphase costs under the chunk overlap,
       const bool h2 = narrowphase(c, a, b, lim + 1e-9f, k2, has && sub == 0);                               // i.e. the ceiling of any gain there

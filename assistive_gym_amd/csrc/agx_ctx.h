@@ -31,7 +31,10 @@ constexpr int MAX_ROWS = 160;
 #endif
 constexpr int ST_WORDS = AGX_ST_WORDS;
 constexpr int CON_STRIDE = 16;
-constexpr int HDR_STRIDE = 16;   // 64 bytes: words 0..7 are what a visit of the row-local sweep needs (one 8-word scalar load, agx_pgs_lvs.h)
+// row header of the scratch record.  Variants whose solve kernel has the row-local sweep (agx_pgs_lv.h: LV_COMPILED -- the same condition) keep 64 bytes
+// per row, words 0..7 what a visit needs (one 8-word scalar load, agx_pgs_lvs.h); the others the 10 words of the register sweep
+constexpr bool HDR_WIDE = AGX_MAX_DOF <= 16 && AGX_MAX_BLOCK <= 10 && AGX_TASK == AGX_TASK_FEEDING;
+constexpr int HDR_STRIDE = HDR_WIDE ? 16 : 10;
 #ifndef AGX_ARENA_WORDS   // LDS arena reused per phase: dynamics workspace, then collider AABB table + worklist + candidates
 #define AGX_ARENA_WORDS 3592
 #endif
@@ -135,13 +138,11 @@ constexpr int SCR_WARM = 2 * MAX_CON, SCR_O_WARM = SCR_O_QPT + SCR_QPT;
 // local point on A (3), on B (3), world normal (3), distance, friction -- in cache order
 constexpr int MP_STRIDE = 12, MP_KEY = 0, MP_LA = 1, MP_LB = 4, MP_N = 7, MP_DIST = 10, MP_MU = 11;
 constexpr int SCR_MAN = MP_STRIDE * MAX_CON, SCR_O_MAN = SCR_O_WARM + SCR_WARM;
-// narrowphase effort memory (agx_collide.h, collide_flush): GJK iterations the pair (a, b) took when it was last tested, one byte per hash slot.
-// A scheduling hint only -- it decides which pairs share a pass, never what a pair's result is
-constexpr int ITER_SLOTS = 2048, SCR_ITER = ITER_SLOTS / 4, SCR_O_ITER = SCR_O_MAN + SCR_MAN;
-constexpr int SCR_WORDS = SCR_O_ITER + SCR_ITER;
+constexpr int SCR_WORDS = SCR_O_MAN + SCR_MAN;
 constexpr int META_NWARM = 8, META_NMAN = 9;      // (NWARM and NMAN are cleared together: agx_forget_warm_kernel)
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
-constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_OFF = 4, H_N = 5, H_NA = 6, H_AB = 7, H_PACK = 8, H_M2 = 9, H_MU = 10, H_MLO = 11, H_MHI = 12;
+constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_OFF = HDR_WIDE ? 4 : 5, H_N = 5, H_NA = 6, H_AB = 7, H_PACK = HDR_WIDE ? 8 : 4, H_M2 = HDR_WIDE ? 9 : 6, H_MU = HDR_WIDE ? 10 : 7,
+              H_MLO = HDR_WIDE ? 11 : 8, H_MHI = HDR_WIDE ? 12 : 9;      // (H_N, H_NA, H_AB: wide headers only)
 // H_N: pairs of the row, H_NA: of its first DoF range; H_AB: byte offsets of the velocity slots of the two ranges relative to the pair index,
 // (4 a0 + H_AB_BIAS) | (4 (b0 - na) + H_AB_BIAS) << 16 -- the slot of pair k is 4 k + (k < na ? A : B) - H_AB_BIAS
 constexpr int H_AB_BIAS = 64;
@@ -160,7 +161,6 @@ struct Ctx {
   float dt;             // one internal substep: DT / SIM_SUBSTEPS
   bool hooks;           // this substep ends a p.stepSimulation() call: the limit reset and the arm-limit classifier run (env.py:226-232)
   int ncon, nrows, first_normal, near_mask, overflow;
-  uint8_t* giter;          // narrowphase effort memory (scratch record), or nullptr
   float* gqpt; int nqpt;   // bed bathing: manifold points of the (wiping pad, human) pairs (bed_bathing.py:47-58), per-env scratch
   float* dbg;   // optional debug sink (parity tests)
   float* E; float* H;   // constraint rows: (J,B) coefficient pairs and row headers (per-env scratch in HBM/L2)
@@ -197,7 +197,7 @@ AGX_DEV void ctx_init(Ctx& c, const uint32_t* blob, float* lds, int lane) {
   c.s_human = h[AGX_H_S_HUMAN]; c.s_env = h[AGX_H_S_ENV]; c.s_tremor = h[AGX_H_S_TREMOR];
   c.nrobot = h[AGX_H_NROBOT]; c.nhdof = h[AGX_H_NHDOF]; c.gender = 0; c.frozen = 0; c.limit_scale = 1.f; c.coop = false;
   c.dt = PRM(c, AGX_P_DT) / (float)(h[AGX_H_SIM_SUBSTEPS] > 1 ? h[AGX_H_SIM_SUBSTEPS] : 1); c.hooks = true;
-  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0; c.giter = nullptr;
+  c.ncon = 0; c.nrows = 0; c.first_normal = 0; c.near_mask = 0; c.overflow = 0; c.nent = 0; c.dbg = nullptr; c.E = nullptr; c.H = nullptr; c.gcon = nullptr; c.gqpt = nullptr; c.nqpt = 0;
   c.timing = false; for (int k = 0; k < 16; k++) c.tm[k] = 0;
 }
 

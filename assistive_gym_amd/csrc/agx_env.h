@@ -294,9 +294,9 @@ AGX_DEV void observe(const Ctx& c, float robot_force, float tool_force, float* g
 //          from L2, integration, mouth-target update -> state
 //   finish (once per step): forces, observation, food state machine, preferences, reward, done.
 // ============================================================================================
-struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* warm; float* man; float* iter; };
+struct Scratch { float* ent; float* hdr; float* vel; float* con; int* meta; float* qpt; float* warm; float* man; };
 AGX_DEV Scratch scratch_of(float* base) {
-  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.warm = base + SCR_O_WARM; s.man = base + SCR_O_MAN; s.iter = base + SCR_O_ITER;
+  Scratch s; s.ent = base + SCR_O_ENT; s.hdr = base + SCR_O_HDR; s.vel = base + SCR_O_VEL; s.con = base + SCR_O_CON; s.meta = (int*)(base + SCR_O_META); s.qpt = base + SCR_O_QPT; s.warm = base + SCR_O_WARM; s.man = base + SCR_O_MAN;
   return s;
 }
 
@@ -455,7 +455,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
   float* L = c.lds; int* Li = c.ldsi;
   const int sw = c.bi[AGX_H_STATE_WORDS];
   Scratch scr = scratch_of(gscratch);
-  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.gqpt = scr.qpt; c.giter = (uint8_t*)scr.iter;
+  c.E = scr.ent; c.H = scr.hdr; c.gcon = scr.con; c.gqpt = scr.qpt;
   load_env(c, gstate, sw);
   if (gaction) {
     const int nsub = (int)PRM(c, AGX_P_FRAME_SKIP);

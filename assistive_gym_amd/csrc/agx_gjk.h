@@ -204,7 +204,7 @@ AGX_DEV bool gjk_solve(gjk_simplex& s, v3& v) {
 // v.w / |v| on the distance (w is the extreme point of A - B along -v); once that bound exceeds `far` the iteration
 // stops and the bound is returned as dist (> far, witness points meaningless).  The caller adds a margin to `far` that
 // dwarfs the rounding error of the bound, so accept / reject decisions are those of the converged distance.
-AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, int maxit, float far, bool has, float& dist, v3& pa, v3& pb, int& iters) {
+AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, int maxit, float far, bool has, float& dist, v3& pa, v3& pb) {
   gjk_simplex s;
   // first simplex point: the support point of A - B along -(centre(A) - centre(B)), a point of the Minkowski
   // difference that already faces the origin (about one iteration fewer per pair than starting from two arbitrary
@@ -220,7 +220,7 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
   pa = a0; pb = b0;
   bool pen = false, far_out = false, active = has;
   float lb = 0.f;
-  int my_iters = 0;
+  int my_iters = 0; (void)my_iters;
   { const float vw0 = dot(d0, v); if (has && vw0 > 0.f && vw0 * vw0 > far * far * dd) { far_out = true; lb = vw0 / sqrtf(dd); active = false; } }
   for (int it = 0; it < maxit; it++) {
     if (active && vv < 1e-12f) { pen = true; active = false; }   /* cores closer than 1 micron: treat as overlapping */
@@ -260,7 +260,6 @@ AGX_DEV bool gjk_distance(const gjk_shape& sa, const gjk_shape& sb, float tol, i
     }
   }
   AGX_TRACE_GJK(has, my_iters, sa.n, sb.n, sb.box, far_out, far_out ? lb : sqrtf(vv), far)
-  iters = my_iters;
   if (pen) { dist = 0; return true; }
   dist = far_out ? lb : sqrtf(vv);
   return false;

@@ -32,7 +32,7 @@ constexpr int LV_G = 16;                                            // lanes of 
 #ifndef AGX_PGS_LV
 #define AGX_PGS_LV 3
 #endif
-constexpr bool LV_COMPILED = AGX_PGS_LV && MAX_DOF <= 16 && MAX_BLOCK <= 10 && TASK == AGX_TASK_FEEDING;       // the `feeding` variant (Jaco, Panda); rows of at most 16 pairs are checked per environment (lv_eligible)
+constexpr bool LV_COMPILED = AGX_PGS_LV && HDR_WIDE;       // the `feeding` variant (Jaco, Panda); rows of at most 16 pairs are checked per environment (lv_eligible)
 constexpr int LV_SOLVE_LDS_BYTES = 20480;                           // LDS of a solve launch of that variant: every row of an ordinary substep inside the window
 constexpr int LV_HDR_WORDS = 8;                                     // invD, b, lo, hi | lam, off8, n, pack
 constexpr int LV_H_LAM = 4, LV_H_LO = 2, LV_H_HI = 3;

@@ -32,7 +32,8 @@ namespace agx {
 constexpr bool LVS_COMPILED = AGX_PGS_LV == 3 && LV_COMPILED;
 constexpr int LVS_SOLVE_LDS_BYTES = 10240;                          // LDS of a solve launch of that variant: 16 waves per CU; the window (1,216 pairs) holds the non-contact and normal rows of an ordinary substep and most friction rows
 constexpr int LVS_DV = 0, LVS_PAIRS = 128;                           // LDS words: dv[128], pairs[2 x window]
-static_assert(HDR_STRIDE == 16 && H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && H_OFF == 4 && H_N == 5 && H_NA == 6 && H_AB == 7, "the scalar load of a visit is words 0..7 of a 64-byte header");
+static_assert(!LVS_COMPILED || HDR_STRIDE == 16, "the row-local sweep reads 64-byte headers");
+static_assert(!HDR_WIDE || H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && H_OFF == 4 && H_N == 5 && H_NA == 6 && H_AB == 7, "the scalar load of a visit is words 0..7 of a 64-byte header");
 
 // pairs that fit a solve launch with lds_words of LDS
 AGX_DEV int lvs_window(int lds_words) {

@@ -87,7 +87,7 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
   if (na > 0) { if (a0 < 64) mlo |= ra << a0; if (a0 + na > 64) mhi |= a0 >= 64 ? ra << (a0 - 64) : ra >> (64 - a0); }
   if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
   Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
-  Hi[H_N] = na + nb; Hi[H_NA] = na; Hi[H_AB] = (4 * a0 + H_AB_BIAS) | ((4 * (b0 - na) + H_AB_BIAS) << 16);
+  if constexpr (HDR_WIDE) { Hi[H_N] = na + nb; Hi[H_NA] = na; Hi[H_AB] = (4 * a0 + H_AB_BIAS) | ((4 * (b0 - na) + H_AB_BIAS) << 16); }
   Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
