@@ -31,10 +31,11 @@ constexpr int MAX_ROWS = 160;
 #endif
 constexpr int ST_WORDS = AGX_ST_WORDS;
 constexpr int CON_STRIDE = 16;
-// row header of the scratch record.  Variants whose solve kernel has the row-local sweep (agx_pgs_lv.h: LV_COMPILED -- the same condition) keep 64 bytes
-// per row, words 0..7 what a visit needs (one 8-word scalar load, agx_pgs_lvs.h); the others the 10 words of the register sweep
+// row headers of the scratch record.  Variants whose solve kernel has the row-local sweep (agx_pgs_lv.h: LV_COMPILED -- the same condition) keep TWO
+// tables: 32 bytes per row with exactly what a visit of that sweep needs (one 8-word scalar load, agx_pgs_lvs.h; two rows per cache line), and
+// behind it 8 words per row for the register sweep (DoF lane masks, mu).  The others keep the one 10-word table of rounds 1-4.
 constexpr bool HDR_WIDE = AGX_MAX_DOF <= 16 && AGX_MAX_BLOCK <= 10 && AGX_TASK == AGX_TASK_FEEDING;
-constexpr int HDR_STRIDE = HDR_WIDE ? 16 : 10;
+constexpr int HDR_STRIDE = HDR_WIDE ? 8 : 10;                              // words per row of the (first) table
 #ifndef AGX_ARENA_WORDS   // LDS arena reused per phase: dynamics workspace, then collider AABB table + worklist + candidates
 #define AGX_ARENA_WORDS 3592
 #endif
@@ -120,13 +121,13 @@ constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
 // contact record
 constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 10, C_DIST = 13, C_MU = 14, C_LAM = 15;
 // row header
-constexpr int DBG_CON = 16, DBG_MINV = DBG_CON + MAX_CON * CON_STRIDE, DBG_HDR = DBG_MINV + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * HDR_STRIDE,
+constexpr int DBG_CON = 16, DBG_MINV = DBG_CON + MAX_CON * CON_STRIDE, DBG_HDR = DBG_MINV + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * (HDR_WIDE ? 16 : 10),
               DBG_TIME = DBG_LAM + MAX_ROWS, DBG_QDD = DBG_TIME + 16, DBG_WORDS = DBG_QDD + MAX_DOF;
 // per-environment scratch record in HBM (L2-resident while its environment is being solved)
 #ifndef AGX_SCR_ENT        // floats of the per-env (J,B) coefficient store: a row keeps one pair per DoF of each articulated block it touches
 #define AGX_SCR_ENT 4096
 #endif
-constexpr int SCR_ENT = AGX_SCR_ENT, SCR_HDR = MAX_ROWS * HDR_STRIDE, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
+constexpr int SCR_ENT = AGX_SCR_ENT, SCR_HDR = MAX_ROWS * (HDR_WIDE ? 16 : 10), SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
 constexpr int QPT_STRIDE = 4;                            // manifold query point: position on the human (3), PyBullet link of the human collider (int)
 constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;
@@ -141,11 +142,15 @@ constexpr int SCR_MAN = MP_STRIDE * MAX_CON, SCR_O_MAN = SCR_O_WARM + SCR_WARM;
 constexpr int SCR_WORDS = SCR_O_MAN + SCR_MAN;
 constexpr int META_NWARM = 8, META_NMAN = 9;      // (NWARM and NMAN are cleared together: agx_forget_warm_kernel)
 constexpr int META_NCON = 0, META_NROWS = 1, META_NNC = 2, META_NEAR = 3, META_OVERFLOW = 4, META_NENT = 5, META_NQPT = 6;
-constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_OFF = HDR_WIDE ? 4 : 5, H_N = 5, H_NA = 6, H_AB = 7, H_PACK = HDR_WIDE ? 8 : 4, H_M2 = HDR_WIDE ? 9 : 6, H_MU = HDR_WIDE ? 10 : 7,
-              H_MLO = HDR_WIDE ? 11 : 8, H_MHI = HDR_WIDE ? 12 : 9;      // (H_N, H_NA, H_AB: wide headers only)
+constexpr int H_INVD = 0, H_B = 1, H_LO = 2, H_HI = 3, H_OFF = HDR_WIDE ? 4 : 5, H_N = 5, H_NA = 6, H_AB = 7;      // (H_N, H_NA, H_AB: two-table layout only)
+// words of the second table (two-table layout) / of the same row (one table): hx_row()
+constexpr int HX_STRIDE = HDR_WIDE ? 8 : 10, HX_BASE = HDR_WIDE ? MAX_ROWS * HDR_STRIDE : 0;
+constexpr int H_PACK = HDR_WIDE ? 0 : 4, H_M2 = HDR_WIDE ? 1 : 6, H_MU = HDR_WIDE ? 2 : 7, H_MLO = HDR_WIDE ? 3 : 8, H_MHI = HDR_WIDE ? 4 : 9;
 // H_N: pairs of the row, H_NA: of its first DoF range; H_AB: byte offsets of the velocity slots of the two ranges relative to the pair index,
 // (4 a0 + H_AB_BIAS) | (4 (b0 - na) + H_AB_BIAS) << 16 -- the slot of pair k is 4 k + (k < na ? A : B) - H_AB_BIAS
 constexpr int H_AB_BIAS = 64;
+AGX_DEV float* hx_row(float* H, int row) { return H + HX_BASE + HX_STRIDE * row; }
+AGX_DEV const float* hx_row(const float* H, int row) { return H + HX_BASE + HX_STRIDE * row; }
 constexpr int OFF_TWO_BIT = 31;   // H_OFF bit 31: the row also touches DoFs 64.. (second lane slot)
 
 struct Ctx {

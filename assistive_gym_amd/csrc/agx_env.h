@@ -522,7 +522,7 @@ AGX_DEV int env_build(const uint32_t* blob, float* gstate, const float* gaction,
     for (int q = lane; q < MAX_CON * CON_STRIDE; q += 64) gdebug[DBG_CON + q] = scr.con[q];
     for (int q = lane; q < MAX_DOF * MAX_DOF; q += 64) gdebug[DBG_MINV + q] = L[L_MINV + q];
     wave_sync();
-    for (int q = lane; q < MAX_ROWS * HDR_STRIDE; q += 64) gdebug[DBG_HDR + q] = scr.hdr[q];
+    for (int q = lane; q < SCR_HDR; q += 64) gdebug[DBG_HDR + q] = scr.hdr[q];
     if (lane == 0) { for (int k = 0; k < 16; k++) if (k != 5 && k != 6 && k != 7) gdebug[DBG_TIME + k] = (float)c.tm[k]; }
   }
   return c.overflow;

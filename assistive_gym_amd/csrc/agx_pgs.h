@@ -256,14 +256,14 @@ AGX_DEV void pgs_sweep(PgsSet& S, const float& lam_normal, const float* E, int l
 }
 AGX_DEV void pgs_load_set(const Ctx& c, int row, bool ok, bool friction, PgsSet& S) {
   ok = ok && row < MAX_ROWS;
-  const float* H = c.H + HDR_STRIDE * (ok ? row : 0); const int* Hi = (const int*)H;
+  const float* H = c.H + HDR_STRIDE * (ok ? row : 0); const int* Hi = (const int*)H; const float* X = hx_row(c.H, ok ? row : 0); const int* Xi = (const int*)X;
   const float invD = ok ? H[H_INVD] : 0.f;
   // a row without effective mass (static-static, degenerate) is kept but pinned at zero impulse
   const bool live = ok && invD != 0.f;
   S.invD = invD; S.b = ok ? H[H_B] : 0.f; S.lam = 0.f;
-  S.lo = live ? H[H_LO] : 0.f; S.hi = live ? (friction ? H[H_MU] : H[H_HI]) : 0.f;
-  S.pack = ok ? Hi[H_PACK] : 0; S.off = ok ? Hi[H_OFF] : 0;
-  S.mlo = ok ? Hi[H_MLO] : 0; S.mhi = ok ? Hi[H_MHI] : 0; S.m2 = ok ? Hi[H_M2] : 0;
+  S.lo = live ? H[H_LO] : 0.f; S.hi = live ? (friction ? X[H_MU] : H[H_HI]) : 0.f;
+  S.pack = ok ? Xi[H_PACK] : 0; S.off = ok ? Hi[H_OFF] : 0;
+  S.mlo = ok ? Xi[H_MLO] : 0; S.mhi = ok ? Xi[H_MHI] : 0; S.m2 = ok ? Xi[H_M2] : 0;
 }
 // first lane of [l0, l1) whose row reaches beyond the LDS window of (J,B) pairs (l1 if none)
 AGX_DEV int pgs_lds_split(const PgsSet& S, int lane, int l0, int l1) {

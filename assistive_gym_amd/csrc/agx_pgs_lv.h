@@ -28,7 +28,7 @@ constexpr int LV_G = 16;                                            // lanes of 
 // 522 k env-steps/s (r05f_*).  Rows beyond the window still go through the C++ loop, so the solve launch of that build takes 20 KB of LDS
 // (agx_kernels.hip: 8 solve waves per CU) -- with the register sweep's 9.5 KB a third of the visits are such rows: 437 k.
 // AGX_PGS_LV = 3 (the DEFAULT of the feeding variant): agx_pgs_lvs.h, the same visit with the row headers in scalar registers and 10 KB
-// of LDS: 552 k.  -DAGX_PGS_LV=0: the register sweep of agx_pgs.h.  Emulator variants 'feeding_lv2' / 'feeding_reg' keep the C++ twins tested.
+// of LDS: 566 k.  -DAGX_PGS_LV=0: the register sweep of agx_pgs.h.  Emulator variants 'feeding_lv2' / 'feeding_reg' keep the C++ twins tested.
 #ifndef AGX_PGS_LV
 #define AGX_PGS_LV 3
 #endif
@@ -308,7 +308,7 @@ AGX_DEV void pgs_lv(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) {
     const float* H = c.H + HDR_STRIDE * (ok ? r : 0); const int* Hi = (const int*)H;
     const float invD = ok ? H[H_INVD] : 0.f;
     const bool live = ok && invD != 0.f, fric = r >= nA;          // friction bounds are rewritten before every friction part
-    const int pack = ok ? Hi[H_PACK] : 0, off = ok ? (Hi[H_OFF] & 0x7fffffff) : 0;
+    const int pack = ok ? ((const int*)hx_row(c.H, r))[H_PACK] : 0, off = ok ? (Hi[H_OFF] & 0x7fffffff) : 0;
     const int na = (pack >> 8) & 255, nb = (int)((unsigned)pack >> 24), n = na + nb;
     const bool near = ok && off + n <= win;
     float* o = HDR + LV_HDR_WORDS * r; int* oi = (int*)o;
@@ -327,8 +327,8 @@ AGX_DEV void pgs_lv(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) {
   const bool two_dirs = R > nA + nc;
   float mu1 = 0.f, mu2 = 0.f;
   if (lane < nc) {
-    const float* H = c.H + HDR_STRIDE * (nA + lane); mu1 = H[H_INVD] != 0.f ? H[H_MU] : 0.f;
-    if (two_dirs) { const float* H2 = c.H + HDR_STRIDE * (nA + nc + lane); mu2 = H2[H_INVD] != 0.f ? H2[H_MU] : 0.f; }
+    const float* H = c.H + HDR_STRIDE * (nA + lane); mu1 = H[H_INVD] != 0.f ? hx_row(c.H, nA + lane)[H_MU] : 0.f;
+    if (two_dirs) { const float* H2 = c.H + HDR_STRIDE * (nA + nc + lane); mu2 = H2[H_INVD] != 0.f ? hx_row(c.H, nA + nc + lane)[H_MU] : 0.f; }
   }
   wave_sync();
   const int a0n = nA < 64 ? nA : 64, a1n = nA - 64;

@@ -3,7 +3,7 @@
 //
 // agx_pgs_lv.h keeps an 8-word header per row and a 16-bit velocity slot per pair in LDS beside the pairs: 17.6 KB for an ordinary FeedingJaco
 // substep (1,350 pairs, 123 rows), i.e. 8 solve waves per CU.  Here a visit gets
-//   * the row's header -- 1/D, b, lo, hi, pair offset, pair counts, velocity slot offsets: words 0..7 of the 64-byte header build_rows()
+//   * the row's header -- 1/D, b, lo, hi, pair offset, pair counts, velocity slot offsets: the 32-byte row of the first header table build_rows()
 //     leaves in the scratch record -- through the SCALAR cache: one s_load_dwordx8 three visits ahead, the values are used straight from
 //     scalar registers;
 //   * the row's impulse from a vector register (lane = row: v_readlane before, a one-lane v_mov after), so the no-op re-test and the
@@ -15,12 +15,14 @@
 // seven.  Same rows, same order, same clamps, same arithmetic as pgs_lv(): the two are BIT-IDENTICAL on the GPU (tools/gpu_lv_bits.py,
 // profiles/r05/r05i_bits_*) and in the emulator, whatever the window.
 //
-// MEASURED (round 5, same box, 4096 FeedingJaco environments, 300 steps; profiles/r05/r05h..r05m).  env-steps/s: pgs_lv() at 20 KB 522 k;
-// this file at 9.5 / 10 / 11 / 12 KB of LDS 544 / 552 / 546 / 540 k.  Shader cycles per row and sweep with one / sixteen waves per CU:
-// 159 / 266 at 10 KB (pgs_lv: 155 / 168 with eight).  What did NOT help: impulses and friction bounds in LDS arrays instead of the register
+// MEASURED (round 5, same box, 4096 FeedingJaco environments, 300 steps; profiles/r05/r05h..r05s).  env-steps/s: pgs_lv() at 20 KB 522 k;
+// this file at 9.5 / 10 / 11 / 12 KB of LDS 561 / 566 / 555 / 547 k (with the headers as 64-byte rows of one table: 544 / 552 / 546 / 540 k --
+// the 32-byte table halves the lines a sweep pulls through the scalar cache and lets the live headers of an XCD fit its L2: HBM-side
+// traffic of a solve launch 70 -> 31 KB per environment).  Shader cycles per row and sweep with one / sixteen waves per CU: 159 / 213 at
+// 10 KB (64-byte rows: 159 / 266; pgs_lv: 155 / 168 with eight).  What did NOT help: impulses and friction bounds in LDS arrays instead of the register
 // (three fewer vector instructions, three more LDS instructions: 521 k; tools/experiments/agx_pgs_lvs_impulses_in_lds.h); the write-back of
 // the impulse and the loop test moved into the shadow of the next gather (546 k).  What did: the scalar instructions of the header request
-// in the wait states the DPP butterfly needs anyway (538 -> 552 k).
+// in the wait states the DPP butterfly needs anyway (538 -> 552 k, measured on the 64-byte rows like the probes below).
 // Marginal cost of ONE more instruction per visit, measured with redundant instructions (AGX_LVS_PROBE_*, r05m_*), one / sixteen waves
 // per CU: vector 5.9 / 3.8 cycles, scalar 5.5 / 5.9, s_nop 5.5 / 4.2, LDS read 21 / 6, LDS write 11 / 9 -- of a visit of 268 / 448 cycles and
 // 38 instructions.  A wave pays 4..6 cycles for every instruction it issues, of whatever kind, in both regimes: the sweep is bound by the
@@ -32,8 +34,8 @@ namespace agx {
 constexpr bool LVS_COMPILED = AGX_PGS_LV == 3 && LV_COMPILED;
 constexpr int LVS_SOLVE_LDS_BYTES = 10240;                          // LDS of a solve launch of that variant: 16 waves per CU; the window (1,216 pairs) holds the non-contact and normal rows of an ordinary substep and most friction rows
 constexpr int LVS_DV = 0, LVS_PAIRS = 128;                           // LDS words: dv[128], pairs[2 x window]
-static_assert(!LVS_COMPILED || HDR_STRIDE == 16, "the row-local sweep reads 64-byte headers");
-static_assert(!HDR_WIDE || H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && H_OFF == 4 && H_N == 5 && H_NA == 6 && H_AB == 7, "the scalar load of a visit is words 0..7 of a 64-byte header");
+static_assert(!LVS_COMPILED || HDR_STRIDE == 8, "the row-local sweep reads 32-byte headers");
+static_assert(!HDR_WIDE || H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && H_OFF == 4 && H_N == 5 && H_NA == 6 && H_AB == 7, "the scalar load of a visit is the 8 words of a row of the first header table");
 
 // pairs that fit a solve launch with lds_words of LDS
 AGX_DEV int lvs_window(int lds_words) {
@@ -122,7 +124,7 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
 #define LVS_HEADER(N_OCT, N_BIT) \
   "s_ff1_i32_b64 " N_BIT ", s[88:89]\n" \
   "s_bitset0_b64 s[88:89], " N_BIT "\n" \
-  "s_lshl_b32 s99, " N_BIT ", 6\n" \
+  "s_lshl_b32 s99, " N_BIT ", 5\n" \
   "s_add_u32 s99, s99, %[base64]\n" \
   "s_load_dwordx8 " N_OCT ", %[Hm], s99\n"
 #define LVS_WAIT(FAR) FAR("s_waitcnt vmcnt(0) lgkmcnt(0)\n") LVS_NOT_##FAR("s_waitcnt lgkmcnt(0)\n")
@@ -138,7 +140,7 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
   "s_ff1_i32_b64 " N3_BIT ", s[88:89]\n" \
   "s_bitset0_b64 s[88:89], " N3_BIT "\n" \
   LVS_DPP("quad_perm:[1,0,3,2]") \
-  "s_lshl_b32 s99, " N3_BIT ", 6\n" \
+  "s_lshl_b32 s99, " N3_BIT ", 5\n" \
   "s_add_u32 s99, s99, %[base64]\n" \
   LVS_DPP("quad_perm:[2,3,0,1]") \
   "s_load_dwordx8 " N3_OCT ", %[Hm], s99\n" \
@@ -203,8 +205,8 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
       "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", \
       "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", \
       "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "vcc", "scc", "memory"
-// an exhausted cursor gives bit -1: the header address is then base64 - 64 with base64 = 64 (base + 1) against Hm = H - 64 bytes, i.e. the row
-// before `base` (or, for base 0, the last 64 bytes of the pair arena in front of the headers): loaded, never visited
+// an exhausted cursor gives bit -1: the header address is then base64 - 32 with base64 = 32 (base + 1) against Hm = H - 32 bytes, i.e. the row
+// before `base` (or, for base 0, the last 32 bytes of the pair arena in front of the headers): loaded, never visited
 #define LVS_ASM(FRIC, FAR, K8) \
   asm volatile(LVS_BODY(FRIC, FAR) \
     : [lam] "+v"(lam) \
@@ -212,7 +214,7 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
     : LVS_CLOBBERS)
 // far: the rows' pairs lie beyond the LDS window: loaded from the scratch record (vmcnt) instead
 AGX_DEV void lvs_part_asm(const LvsLay& Y, int lane, uint64_t mask, int base, float& lam, bool fric, bool far, float hiv) {
-  const int nvis1 = popc64(mask) - 1, base64 = 64 * (base + 1);
+  const int nvis1 = popc64(mask) - 1, base64 = 4 * HDR_STRIDE * (base + 1);
   const float* Hm = Y.H - HDR_STRIDE;
   if (!far) { if (fric) LVS_ASM(LVS_YES, LVS_NO, 8 * lane + Y.pairs_addr); else LVS_ASM(LVS_NO, LVS_NO, 8 * lane + Y.pairs_addr); }
   else { if (fric) LVS_ASM(LVS_YES, LVS_YES, 8 * lane); else LVS_ASM(LVS_NO, LVS_YES, 8 * lane); }
@@ -251,8 +253,8 @@ AGX_DEV void pgs_lvs(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
   const bool two_dirs = R > nA + nc;
   float mu1 = 0.f, mu2 = 0.f;
   if (lane < nc) {
-    const float* H = c.H + HDR_STRIDE * (nA + lane); mu1 = H[H_INVD] != 0.f ? H[H_MU] : 0.f;
-    if (two_dirs) { const float* H2 = c.H + HDR_STRIDE * (nA + nc + lane); mu2 = H2[H_INVD] != 0.f ? H2[H_MU] : 0.f; }
+    const float* H = c.H + HDR_STRIDE * (nA + lane); mu1 = H[H_INVD] != 0.f ? hx_row(c.H, nA + lane)[H_MU] : 0.f;
+    if (two_dirs) { const float* H2 = c.H + HDR_STRIDE * (nA + nc + lane); mu2 = H2[H_INVD] != 0.f ? hx_row(c.H, nA + nc + lane)[H_MU] : 0.f; }
   }
   wave_sync();
   const uint64_t rowsA0 = pgs_range_mask(0, nA < 64 ? nA : 64), rowsA1 = nA > 64 ? pgs_range_mask(0, nA - 64) : 0ull;

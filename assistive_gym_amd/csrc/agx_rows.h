@@ -79,16 +79,16 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
     for (int k = 0; k < 6; k++) { E[2 * e] = J[k]; E[2 * e + 1] = B[k]; D += J[k] * B[k]; e++; }
   }
   // a robot + two free bodies would need three ranges; the scene has no such row (checked at build time)
-  float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H;
+  float* H = c.H + HDR_STRIDE * row; int* Hi = (int*)H; float* X = hx_row(c.H, row); int* Xi = (int*)X;
   H[H_INVD] = D > 1e-12f ? 1.0f / D : 0.f; H[H_B] = bterm; H[H_LO] = lo; H[H_HI] = hi;
   // lane masks of the two DoF ranges: bits 0..63 (first lane slot) and 64.. (second slot)
   const uint64_t ra = na > 0 ? ((~0ull >> (64 - na)) ) : 0ull, rb = nb > 0 ? ((~0ull >> (64 - nb))) : 0ull;
   uint64_t mlo = 0ull, mhi = 0ull;
   if (na > 0) { if (a0 < 64) mlo |= ra << a0; if (a0 + na > 64) mhi |= a0 >= 64 ? ra << (a0 - 64) : ra >> (64 - a0); }
   if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
-  Hi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
+  Xi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
   if constexpr (HDR_WIDE) { Hi[H_N] = na + nb; Hi[H_NA] = na; Hi[H_AB] = (4 * a0 + H_AB_BIAS) | ((4 * (b0 - na) + H_AB_BIAS) << 16); }
-  Hi[H_M2] = (int)(uint32_t)mhi; H[H_MU] = mu; Hi[H_MLO] = (int)(uint32_t)mlo; Hi[H_MHI] = (int)(uint32_t)(mlo >> 32);
+  Xi[H_M2] = (int)(uint32_t)mhi; X[H_MU] = mu; Xi[H_MLO] = (int)(uint32_t)mlo; Xi[H_MHI] = (int)(uint32_t)(mlo >> 32);
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
   if (fabsf(n.z) > 0.70710678f) { float a = n.y * n.y + n.z * n.z, k = 1.0f / sqrtf(a); p = mk3(0, -n.z * k, n.y * k); }
