@@ -22,7 +22,9 @@
 // 10 KB (64-byte rows: 159 / 266; pgs_lv: 155 / 168 with eight).  What did NOT help: impulses and friction bounds in LDS arrays instead of the register
 // (three fewer vector instructions, three more LDS instructions: 521 k; tools/experiments/agx_pgs_lvs_impulses_in_lds.h); the write-back of
 // the impulse and the loop test moved into the shadow of the next gather (546 k).  What did: the scalar instructions of the header request
-// in the wait states the DPP butterfly needs anyway (538 -> 552 k, measured on the 64-byte rows like the probes below).
+// in the wait states the DPP butterfly needs anyway (538 -> 552 k, measured on the 64-byte rows like the probes below); rows beyond the
+// window waiting for their OWN pair only (vmcnt 1): 566 -> 569 k, and the 9.5 KB launch as fast as the 10 KB one.  Warming the scalar cache
+// with the next part's first header lines at the start of a part: no difference (568 / 569 k, r05u_*).
 // Marginal cost of ONE more instruction per visit, measured with redundant instructions (AGX_LVS_PROBE_*, r05m_*), one / sixteen waves
 // per CU: vector 5.9 / 3.8 cycles, scalar 5.5 / 5.9, s_nop 5.5 / 4.2, LDS read 21 / 6, LDS write 11 / 9 -- of a visit of 268 / 448 cycles and
 // 38 instructions.  A wave pays 4..6 cycles for every instruction it issues, of whatever kind, in both regimes: the sweep is bound by the
@@ -50,7 +52,7 @@ AGX_DEV bool lvs_eligible(const Ctx& c, int lds_words) {
   return lv_eligible(c) && c.first_normal + c.ncon <= 128 && c.ncon <= 64;
 }
 
-struct LvsLay { float* lds; const float* H; const float* E; int dv_addr, pairs_addr, rfar, pf; };   // rfar: first row whose pairs are not (all) inside the LDS window; pf: a row the NEXT part will probably start at (scalar-cache warm-up), or -1
+struct LvsLay { float* lds; const float* H; const float* E; int dv_addr, pairs_addr, rfar; };   // rfar: first row whose pairs are not (all) inside the LDS window
 
 #if !defined(__HIP_DEVICE_COMPILE__) || defined(AGX_PGS_LV_CPP)
 // One visit, the C++ statement of what the assembly loop does (the emulator runs this; on the device it is the -DAGX_PGS_LV_CPP build).
@@ -185,19 +187,12 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
 #define LVS_EN_Q "v[92:93]", "v91", "s[92:93]", "s92", "s95", "s97"
 #define LVS_APPLY(M, ...) M(__VA_ARGS__)
 #define LVS_CALL(FRIC, FAR, C, N1, N3, EC, EN) LVS_APPLY(LVS_STEP, FRIC, FAR, C, N1, N3, EC, EN)
-#ifdef AGX_LVS_NO_PREFETCH   // A/B knob
-#define LVS_PREFETCH
-#else
-#define LVS_PREFETCH "s_load_dwordx8 s[76:83], %[Hm], %[pf]\n" "s_add_u32 s99, %[pf], 64\n" "s_load_dwordx8 s[76:83], %[Hm], s99\n"
-#endif
 #define LVS_BODY(FRIC, FAR) \
     "s_mov_b64 s[50:51], exec\n" \
     "s_mov_b64 exec, 0xffff\n" \
     "s_mov_b64 s[88:89], %[mask]\n" \
     "s_mov_b32 s98, %[nvis1]\n" \
     "s_mov_b32 s91, 0\n" "s_mov_b32 s93, 0\n" "s_mov_b32 vcc_hi, 0\n" \
-    /* warm the scalar cache for the NEXT part (its likely first header lines; the caller's guess): two loads into the octet this part requests last */ \
-    LVS_PREFETCH \
     /* prime: headers of visits 0, 1, 2; entry of visit 0 */ \
     LVS_HEADER("s[52:59]", "s84") LVS_HEADER("s[60:67]", "s85") LVS_HEADER("s[68:75]", "s86") \
     "s_waitcnt lgkmcnt(0)\n" \
@@ -220,11 +215,11 @@ AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam,
 #define LVS_ASM(FRIC, FAR, K8) \
   asm volatile(LVS_BODY(FRIC, FAR) \
     : [lam] "+v"(lam) \
-    : [mask] "s"(mask), [nvis1] "s"(nvis1), [base64] "s"(base64), [Hm] "s"(Hm), [pf] "s"(pf), [E] "s"(Y.E), [k8p] "v"(K8), [k4dv] "v"(4 * lane + Y.dv_addr - H_AB_BIAS), [hiv] "v"(hiv) \
+    : [mask] "s"(mask), [nvis1] "s"(nvis1), [base64] "s"(base64), [Hm] "s"(Hm), [E] "s"(Y.E), [k8p] "v"(K8), [k4dv] "v"(4 * lane + Y.dv_addr - H_AB_BIAS), [hiv] "v"(hiv) \
     : LVS_CLOBBERS)
 // far: the rows' pairs lie beyond the LDS window: loaded from the scratch record (vmcnt) instead
 AGX_DEV void lvs_part_asm(const LvsLay& Y, int lane, uint64_t mask, int base, float& lam, bool fric, bool far, float hiv) {
-  const int nvis1 = popc64(mask) - 1, base64 = 4 * HDR_STRIDE * (base + 1), pf = 4 * HDR_STRIDE * (Y.pf + 1);
+  const int nvis1 = popc64(mask) - 1, base64 = 4 * HDR_STRIDE * (base + 1);
   const float* Hm = Y.H - HDR_STRIDE;
   if (!far) { if (fric) LVS_ASM(LVS_YES, LVS_NO, 8 * lane + Y.pairs_addr); else LVS_ASM(LVS_NO, LVS_NO, 8 * lane + Y.pairs_addr); }
   else { if (fric) LVS_ASM(LVS_YES, LVS_YES, 8 * lane); else LVS_ASM(LVS_NO, LVS_YES, 8 * lane); }
@@ -274,12 +269,9 @@ AGX_DEV void pgs_lvs(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
   uint64_t skip0 = 0ull, skip1 = 0ull;
   const int nsrc = (nnc + lane) & 63; const bool nhi = nnc + lane >= 64;           // where the normal impulse of this lane's contact lives
   float ln = 0.f;
-  uint64_t todo1 = 0ull;                                            // friction rows of the first direction visited in the previous sweep
-  Y.pf = -1;
   for (int it = 0; it < iters; it++) {
     const bool retest = K > 0 && it % K == 0, use = K > 0 && !retest;
     const float bef0 = lamA0, bef1 = lamA1;
-    Y.pf = todo1 ? nA + ffs64(todo1) : -1;                           // (what the friction part will probably start with)
     lvs_part(Y, lane, rowsA0 & ~(use ? skip0 : 0ull), 0, lamA0, false, 0.f);
     lvs_part(Y, lane, rowsA1 & ~(use ? skip1 : 0ull), 64, lamA1, false, 0.f);
     if (retest) { skip0 = wave_ballot(lamA0 == bef0); skip1 = wave_ballot(lamA1 == bef1); }
@@ -287,10 +279,7 @@ AGX_DEV void pgs_lvs(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
     // friction rows (lane = contact): bounds from the normal impulses as this sweep's normal pass left them; a row whose normal impulse
     // and own impulse are both zero is an exact no-op and is not visited
     { const uint64_t todo = wave_ballot(lane < nc && (ln != 0.f || lamF1 != 0.f));
-      const bool use_next = K > 0 && (it + 1) % K != 0;
-      const uint64_t nextA0 = rowsA0 & ~(use_next ? skip0 : 0ull);
-      Y.pf = nextA0 ? ffs64(nextA0) : -1;                            // (the first row of the next sweep)
-      lvs_part(Y, lane, todo, nA, lamF1, true, mu1 * ln); todo1 = todo; }
+      lvs_part(Y, lane, todo, nA, lamF1, true, mu1 * ln); }
     if (two_dirs) {
       const uint64_t todo = wave_ballot(lane < nc && (ln != 0.f || lamF2 != 0.f));
       lvs_part(Y, lane, todo, nA + nc, lamF2, true, mu2 * ln);
