@@ -82,7 +82,16 @@ constexpr int A_CAND = A_WL + WL_MAX;                   // float[WL_MAX][CAND_ST
 constexpr int A_TW = A_CAND + WL_MAX * CAND_STRIDE;     // float[MAX_DOF + MAX_FREE][6]
 static_assert(A_TW + TW_WORDS <= ARENA_WORDS, "collision workspace exceeds the arena");
 static_assert(MAX_COLL <= 512, "collider indices are packed in 9 bits");
-constexpr int WL_CAP = WL_MAX - 16;   // the candidate words of the last 16 entries (128 ints) hold the A-collider list of a sweep
+// the candidate words of the last entries hold the two collider lists of a sweep (128 + 128 indices; afterwards the selection's slot list, 64 ints):
+// bytes where collider indices fit a byte -- 8 entries instead of 16.  For the feeding variant that is 174 usable entries instead of 166, and an
+// ordinary FeedingJaco substep has ~170 candidate pairs (150 of them food x spoon pieces): one flush of three narrowphase passes instead of
+// 163 + 6 = four (profiles/r05/r05x_*)
+constexpr bool LIST_BYTES = MAX_COLL <= 256;
+constexpr int LIST_TAIL = LIST_BYTES ? 8 : 16;
+constexpr int WL_CAP = WL_MAX - LIST_TAIL;
+template <bool B> struct ListIndex { typedef unsigned short type; };
+template <> struct ListIndex<true> { typedef uint8_t type; };
+typedef ListIndex<LIST_BYTES>::type list_t;
 static_assert(WL_CAP >= 128, "a flush of at least two full passes");
 
 AGX_DEV void emit_from_cand(Ctx& c, int slot, int idx) {
@@ -338,11 +347,11 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gfl
   const bool same = gflags & 1, no_adjacent = gflags & 4;   // bit2, self-collision: not the same link, not parent and child
   // level 1: the A colliders whose box reaches the union box of the B range and vice versa (the union
   // boxes were computed by the group cull, lane g holds them), compacted in ascending order into two
-  // 16-bit lists in the tail of the candidate area (unused until the flush).  Filtering both sides
+  // index lists (list_t) in the tail of the candidate area (unused until the flush).  Filtering both sides
   // matters for pairs of compounds (64 spoon pieces x 44 wheelchair pieces: a handful of each are close).
   float ulo[2][3], uhi[2][3];
   for (int q = 0; q < 3; q++) { ulo[0][q] = wave_bcast(G.blo[q], g); uhi[0][q] = wave_bcast(G.bhi[q], g); ulo[1][q] = wave_bcast(G.alo[q], g); uhi[1][q] = wave_bcast(G.ahi[q], g); }
-  unsigned short* LIST = (unsigned short*)(c.ldsi + L_ARENA + A_CAND + CAND_STRIDE * WL_CAP);   // [0,128): A side, [128,256): B side
+  list_t* LIST = (list_t*)(c.ldsi + L_ARENA + A_CAND + CAND_STRIDE * WL_CAP);   // [0,128): A side, [128,256): B side
   int nlive[2] = {0, 0};
   for (int side = 0; side < 2; side++) {
     const int r0 = side == 0 ? aa : b0, r1 = side == 0 ? ab : b1;
@@ -350,7 +359,7 @@ AGX_DEV int collide_sweep(Ctx& c, int g, int aa, int ab, int b0, int b1, int gfl
       const int x = base + lane; bool ok = x < r1;
       if (ok) for (int q = 0; q < 3; q++) if (AB[ABS * x + q] > uhi[side][q] + mg || ulo[side][q] > AB[ABS * x + 3 + q] + mg) ok = false;
       const uint64_t m = wave_ballot(ok);
-      if (ok) LIST[128 * side + nlive[side] + wave_rank(m)] = (unsigned short)x;
+      if (ok) LIST[128 * side + nlive[side] + wave_rank(m)] = (list_t)x;
       nlive[side] += popc64(m);
     }
   }
