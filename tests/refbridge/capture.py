@@ -1,5 +1,5 @@
 """State capture for the parity protocol: the physics state of a REFERENCE environment object (an `assistive_gym` env of
-any of the five built tasks, after reset() or between steps), read through the PyBullet API and the env's own attributes, written in this
+any of the six built tasks, after reset() or between steps), read through the PyBullet API and the env's own attributes, written in this
 repository's state-record layout (include/agx_blob.h) -- the inverse of `refbridge.adopt`.  `p` is the pybullet module the env runs on: the
 real one where the reference's fork is installed (tools/pybullet_dump.py), or the facade of tests/refbridge, on which
 tests/test_reference_dump.py checks that capture(adopt(state)) reproduces `state` for every task.
@@ -13,10 +13,10 @@ Conventions (asserted where they can be):
   * motor targets: an actuated joint's target is recomputed by take_step from the current angle (env.py:201-215), so it is recorded as the
     angle; a joint without an action (gripper) keeps the blob's QT0; a human joint that is not an agent's keeps setup_joints' target.
 `initial`: what has to be remembered from right after reset(), because the reference drops it later: the food particles in creation order
-(feeding.py:154-159), the wiping targets in creation order (bed_bathing.py:173-188)."""
+(feeding.py:154-159), the wiping targets in creation order (bed_bathing.py:173-188), the water particles in creation order (drinking.py:160-171)."""
 import numpy as np
 
-TASK_OF_KIND = {0: 'feeding', 1: 'bed_bathing', 2: 'scratch_itch', 3: 'dressing', 4: 'arm_manipulation'}
+TASK_OF_KIND = {0: 'feeding', 1: 'bed_bathing', 2: 'scratch_itch', 3: 'dressing', 4: 'arm_manipulation', 5: 'drinking'}
 
 
 def remember(env, blob):
@@ -27,6 +27,8 @@ def remember(env, blob):
         out['foods'] = list(env.foods)
     if task == 'bed_bathing':
         out['targets'] = [t.body for t in list(env.targets_upperarm) + list(env.targets_forearm)]
+    if task == 'drinking':
+        out['waters'] = list(env.waters)
     return out
 
 
@@ -61,7 +63,8 @@ def _base(p, body, cid, blob=None, fb=None):
 
 def capture(env, blob, p, initial, cloth_out=None):
     """-> state record float32[state_words]; dressing: cloth_out (float32 [2, NN, 3]) receives the node positions (velocities are not part
-    of the fork's getSoftBodyData and stay zero)"""
+    of the fork's getSoftBodyData and stay zero); drinking: cloth_out (float32 [2, 64, 3]) receives the water particles' positions and
+    velocities (Bullet bases: getBasePositionAndOrientation / getBaseVelocity), in creation order"""
     from assistive_gym_amd.model import compiler as L
     task = TASK_OF_KIND[blob.task_kind]
     s = blob.new_state(1)
@@ -146,6 +149,19 @@ def capture(env, blob, p, initial, cloth_out=None):
         v['food_active'][0] = sum(1 << k for k, f in enumerate(foods) if f in env.foods_active)
         v['task_success'][0], v['total_food'][0] = env.task_success, env.total_food_count
         v['frozen'][0] = 0 if H.impairment == 'tremor' or H.controllable else (((1 << blob.nhdof) - 1) << nr)     # human.py:108-112
+    elif task == 'drinking':
+        v['target'][0] = env.target_pos                                                            # drinking.py:184-196
+        waters = initial['waters']
+        alive = sum(1 << k for k, f in enumerate(waters) if f in env.waters)
+        active = sum(1 << k for k, f in enumerate(waters) if f in env.waters_active)
+        s[0].view(np.uint32)[st:st + 4] = np.array([alive & 0xffffffff, alive >> 32, active & 0xffffffff, active >> 32], dtype=np.uint32)     # AGX_DK_ALIVE / AGX_DK_ACTIVE
+        v['task_success'][0], v['total_food'][0] = env.task_success, env.total_water_count
+        v['frozen'][0] = 0 if H.impairment == 'tremor' or H.controllable else (((1 << blob.nhdof) - 1) << nr)     # drinking.py:132, human.py:108-112
+        if cloth_out is not None:
+            for k, f in enumerate(waters):
+                pos, _ = p.getBasePositionAndOrientation(f.body, physicsClientId=cid)
+                lin, _ = p.getBaseVelocity(f.body, physicsClientId=cid)
+                cloth_out[0, k], cloth_out[1, k] = np.asarray(pos, dtype=np.float32), np.asarray(lin, dtype=np.float32)
     else:
         v['total_food'][0] = 1
         # bed bathing: setup_joints(use_static_joints=True) without a reactive force freezes the arm of a human that is not an agent

@@ -54,11 +54,17 @@ def test_oracle_matches_reference_dump(path, blob, oracle):
     if blob.words is not oracle.blob.words:
         from oracle_lib import Oracle
         oracle = Oracle(blob)
-    has_cloth = 'cloth' in d.files
+    has_cloth = 'cloth' in d.files and blob.task_kind == 3
+    has_water = 'cloth' in d.files and blob.task_kind == 5
     import conditioning as C
     for k in range(len(d['actions'])):
         s = d['states'][k].copy()
-        if has_cloth:                          # a Dressing dump carries the garment of every step (node velocities are not in the fork's API: zero)
+        if has_water:                          # a Drinking dump carries the 64 water particles of every step (positions and velocities)
+            obs, rew, done, info = oracle.step_cloth(s, d['cloth'][k].copy(), d['actions'][k])
+            _check('oracle obs @%d' % k, obs, d['obs'][k]); _check('oracle reward @%d' % k, rew, d['reward'][k])
+            _check('oracle force @%d' % k, info[0], d['total_force_on_human'][k])
+            assert int(info[1]) == int(d['task_success'][k])
+        elif has_cloth:                        # a Dressing dump carries the garment of every step (node velocities are not in the fork's API: zero)
             obs, rew, done, info = oracle.step_cloth(s, d['cloth'][k].copy(), d['actions'][k])
             # The cloth-force term (dressing.py:35-43; observation word 23, total_force_on_human, and reward through C_d = 0.01 per newton) is a
             # sum over hundreds of node contacts that switch on and off at a margin shell: the float32 rounding of the recorded garment alone
@@ -96,17 +102,18 @@ def test_stepper_matches_reference_dump(path, blob):
     obs, rew, done, info = st.step_host(d['actions'])
     import conditioning as C
     f = blob.obs_dim_robot - 1
+    garment = 'cloth' in d.files and blob.task_kind == 3      # (a Drinking dump's `cloth` is the water: no cloth-force term)
     for k in range(T):
         pose = np.delete(np.arange(blob.obs_dim), f)
-        if 'cloth' in d.files:
+        if garment:
             pose = pose[pose != 23]              # the cloth-force term of the dressing observation: judged in tests/test_gpu_dressing.py against the oracle's own spread
         _check('obs @%d' % k, obs[k][pose], d['obs'][k][pose])
         # forces of a float32 pipeline carry the absolute floor of tests/conditioning.py (a contact is a spring of ~10^4 N/m in a gap known to ~1e-6 m)
-        if 'cloth' not in d.files:               # (dressing: this column IS the cloth-force sum, judged below)
+        if not garment:                          # (dressing: this column IS the cloth-force sum, judged below)
             ok, lim = C.check(abs(obs[k, f] - d['obs'][k][f]), REL * max(1.0, abs(d['obs'][k][f])), C.force_floor(blob))
             assert ok, ('tool force @%d' % k, obs[k, f], d['obs'][k][f])
         cf = 0.0
-        if 'cloth' in d.files:                  # the cloth-force term: see test_oracle_matches_reference_dump
+        if garment:                             # the cloth-force term: see test_oracle_matches_reference_dump
             from oracle_lib import Oracle
             sens = C.ulp_sensitivity(blob, Oracle(blob), d['states'][k], d['actions'][k], cloth=d['cloth'][k], trials=3, seed=k, cloth_eps=1e-6)
             cf = abs(float(obs[k, 23]) - float(d['obs'][k][23]))
@@ -129,7 +136,7 @@ def _bridge_cases():
     import refcases
     want = ('feeding_jaco_tremor', 'feeding_food_events', 'feeding_coop_tremor', 'bed_wiping', 'bed_coop_rollback', 'scratch_itch_pr2_coop_scratching',
             'scratch_itch_jaco', 'arm_manipulation_sawyer_lifting', 'arm_manipulation_pr2', 'dressing_on_forearm', 'dressing_coop_sleeve',
-            'feeding_stretch_step1', 'bed_bathing_stretch_step1')
+            'feeding_stretch_step1', 'bed_bathing_stretch_step1', 'drinking_none_step0', 'drinking_spilling', 'drinking_at_the_mouth')
     out, seen = [], set()
     for c in refcases.build_cases():
         key = next((w for w in want if c['name'].startswith(w)), None)
@@ -145,7 +152,7 @@ def test_capture_inverts_adopt_on_the_bridge():
     from refbridge import capture as cap
     from assistive_gym_amd.model import compiler as L
     cases = _bridge_cases()
-    assert len(cases) >= 11
+    assert len(cases) >= 13 and any(c['model'].startswith('drinking') for c in cases)
     refbridge.install()
     p = sys.modules['pybullet']
     for c in cases:
@@ -161,6 +168,13 @@ def test_capture_inverts_adopt_on_the_bridge():
             initial['foods'] = [_F(refbridge.FOOD0 + k) for k in range(blob.nfood)]
             env.foods = [_F(f.body) for f in env.foods]; env.foods_active = [_F(f.body) for f in env.foods_active]
             env.bowl = _F(refbridge.BOWL)           # (created by reset() in the reference: furniture.py:32-34)
+        if task == 'drinking':                      # likewise the water particles (drinking.py:160-171)
+            class _W:
+                def __init__(self, body): self.body = body
+                def __eq__(self, o): return getattr(o, 'body', None) == self.body
+                def __hash__(self): return hash(self.body)
+            initial['waters'] = [_W(refbridge.WATER0 + k) for k in range(w.nwater)]
+            env.waters = [_W(f.body) for f in env.waters]; env.waters_active = [_W(f.body) for f in env.waters_active]
         if task == 'bed_bathing':                   # likewise the wiping targets: marker ids in creation order
             ids = sorted(m for m in w.markers if m >= w.first_target_marker)
             nt = sum(int(x) for x in blob.task_i_n('NT', 4)[2 * w.gender:2 * w.gender + 2])
@@ -206,6 +220,11 @@ def test_capture_inverts_adopt_on_the_bridge():
             assert np.abs(ta[:3] - tb[:3]).max() < 1e-6 and a['task'][0][3] == b['task'][0][3] and np.abs(ta[12:15] - tb[12:15]).max() < 1e-6
         if task == 'dressing':
             assert abs(ta[L.DR['BEST']] - tb[L.DR['BEST']]) < 1e-6 and np.abs(cl[0] - c['cloth'][0]).max() < 2e-6
+        if task == 'drinking':
+            assert np.array_equal(a['task'][0][:4], b['task'][0][:4]), c['name']                               # alive / active particle masks
+            assert np.abs(a['target'][0] - b['target'][0]).max() < 1e-6 and int(a['total_food'][0]) == int(b['total_food'][0])
+            here = np.abs(c['cloth'][0]).max(axis=1) < 500                                                  # (drunk particles were teleported away)
+            assert np.abs(cl[0][here] - c['cloth'][0][here]).max() < 2e-6 and np.abs(cl[1][here] - c['cloth'][1][here]).max() < 2e-6, c['name']
         if blob.task_i('ARM_LIMIT_ON'):
             assert a['task'][0][10] == b['task'][0][10] and np.abs(ta[6:10] - tb[6:10]).max() < 1e-6
         w.close()

@@ -1,11 +1,12 @@
 """Oracle-dump tool of the parity protocol: run the REFERENCE (assistive_gym on the Zackory/bullet3 PyBullet fork it
 pins, setup.py:21) and record, for every step of a seeded random-action episode of ANY built single-agent environment (Feeding, BedBathing,
-ScratchItch, Dressing, ArmManipulation on every robot of assistive_gym_amd.envs.ENV_IDS; FeedingJaco-v1 by default), the complete
+ScratchItch, Dressing, ArmManipulation, Drinking on every robot of assistive_gym_amd.envs.ENV_IDS; FeedingJaco-v1 by default), the complete
 physics state in THIS repo's state-record layout together with the reference's observation, reward, done and `total_force_on_human`.
 
     python tools/pybullet_dump.py --seed 1001 --steps 200 --out tests/golden/pybullet_dump_seed1001.npz
     python tools/pybullet_dump.py --env BedBathingSawyer-v1 --out tests/golden/pybullet_dump_bed_bathing_sawyer_seed1001.npz
     python tools/pybullet_dump.py --env DressingBaxter-v1 ...          (also records the garment's node positions per step)
+    python tools/pybullet_dump.py --env DrinkingJaco-v1 ...            (also records the 64 water particles per step)
 
 The result is consumed by tests/test_reference_dump.py: each recorded state is injected (`agx_set_state` / the oracle), the recorded
 action is applied, and observation, reward and force are compared with what the reference produced (1e-3 relative).  Committing such a
@@ -29,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-TASK_MODULE = {0: 'feeding_envs', 1: 'bed_bathing_envs', 2: 'scratch_itch_envs', 3: 'dressing_envs', 4: 'arm_manipulation_envs'}
+TASK_MODULE = {0: 'feeding_envs', 1: 'bed_bathing_envs', 2: 'scratch_itch_envs', 3: 'dressing_envs', 4: 'arm_manipulation_envs', 5: 'drinking_envs'}
 
 
 def main():
@@ -100,7 +101,7 @@ def bridge_main(args):
     blob = ModelBlob.load(model)
     task = cap.TASK_OF_KIND[blob.task_kind]
     # the episode starts from one of the start states of the reference-pinned cases (tests/refcases.py: this repository's reset, settled)
-    start = next(c for c in refcases.build_cases(tasks=({'feeding': 'feeding', 'bed_bathing': 'bed', 'scratch_itch': 'scratch', 'dressing': 'dressing', 'arm_manipulation': 'arm'}[task],))
+    start = next(c for c in refcases.build_cases(tasks=({'feeding': 'feeding', 'bed_bathing': 'bed', 'scratch_itch': 'scratch', 'dressing': 'dressing', 'arm_manipulation': 'arm', 'drinking': 'drinking'}[task],))
                  if c['model'] == model and not c['coop'] and not c['variant'])
     refbridge.install()
     p = sys.modules['pybullet']
@@ -113,6 +114,12 @@ def bridge_main(args):
             def __hash__(self): return hash(self.body)
         initial['foods'] = [_F(refbridge.FOOD0 + k) for k in range(blob.nfood)]
         env.bowl = _F(refbridge.BOWL)                   # (step() never touches the bowl; the capture reads its body id)
+    if task == 'drinking':
+        class _W:
+            def __init__(self, body): self.body = body
+            def __eq__(self, o): return getattr(o, 'body', None) == self.body
+            def __hash__(self): return hash(self.body)
+        initial['waters'] = [_W(refbridge.WATER0 + k) for k in range(w.nwater)]
     if task == 'bed_bathing':
         ids = sorted(m for m in w.markers if m >= w.first_target_marker)
         nt = sum(int(x) for x in blob.task_i_n('NT', 4)[2 * w.gender:2 * w.gender + 2])
@@ -125,7 +132,7 @@ def bridge_main(args):
     def snap():
         cl = np.zeros((2, nn, 3), dtype=np.float32) if has_cloth else None
         s = cap.capture(env, blob, p, initial, cloth_out=cl)
-        if has_cloth:
+        if has_cloth and task != 'drinking':
             cl[1] = w.store()[1][1]                     # node velocities: not in the fork's API (a real dump has zeros there); the bridge knows them
         return s, cl
     states, cloths, obs, rew, done, force, success = [], [], [], [], [], [], []
