@@ -14,7 +14,7 @@ file turns "PARITY UNPINNED" into a pinned parity statement for the physics half
 
 THIS SCRIPT CANNOT RUN IN THE BUILD CONTAINER (no pybullet, no gym, no network) and has never been executed against the real PyBullet.
 What has been executed is its state capture (tests/refbridge/capture.py): on the fake `pybullet` of tests/refbridge, whose bodies are the
-CPU oracle's, capture(adopt(state)) gives `state` back for all five tasks (tests/test_reference_dump.py::test_capture_inverts_adopt_on_the_bridge).
+CPU oracle's, capture(adopt(state)) gives `state` back for all six tasks (tests/test_reference_dump.py::test_capture_inverts_adopt_on_the_bridge).
 Requirements where it is run: the reference checkout importable as `assistive_gym`, its PyBullet fork (per-body gravity,
 agent.py:196-197; the cloth API for Dressing), numpy; this repository (incl. tests/) on PYTHONPATH.  The conventions the capture relies on
 are listed at the top of tests/refbridge/capture.py; the one most likely to need a flip on the real engine is which frame
