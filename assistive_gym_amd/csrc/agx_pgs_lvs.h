@@ -12,8 +12,8 @@
 //   * its pairs from the LDS window, or -- the rows beyond it: the tail of the friction rows, most of which the no-op rule skips -- from the
 //     scratch record (global_load, vmcnt).
 // LDS holds the velocity deltas (128 words) and the window: 10 KB per solve wave (16 per CU), three LDS instructions per visit instead of
-// seven.  Same rows, same order, same clamps, same arithmetic as pgs_lv(): the two are BIT-IDENTICAL on the GPU (tools/gpu_lv_bits.py,
-// profiles/r05/r05i_bits_*) and in the emulator, whatever the window.
+// seven.  Same rows, same order, same clamps, same arithmetic as pgs_lv(): the two are BIT-IDENTICAL on the GPU (tests/test_gpu_solve_variants.py,
+// tools/gpu_lv_bits.py, profiles/r05/r05i_bits_*) and in the emulator, whatever the window.
 //
 // MEASURED (round 5, same box, 4096 FeedingJaco environments, 300 steps; profiles/r05/r05h..r05s).  env-steps/s: pgs_lv() at 20 KB 522 k;
 // this file at 9.5 / 10 / 11 / 12 KB of LDS 561 / 566 / 555 / 547 k (with the headers as 64-byte rows of one table: 544 / 552 / 546 / 540 k --
@@ -42,7 +42,7 @@ static_assert(!HDR_WIDE || H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && 
 // pairs that fit a solve launch with lds_words of LDS
 AGX_DEV int lvs_window(int lds_words) {
   int w = (lds_words - LVS_PAIRS) / 2;
-#ifdef AGX_LV_WINDOW_CAP            // tests: a small window, so that ordinary scenes take the fallback
+#ifdef AGX_LV_WINDOW_CAP            // tests: a small window, so that most rows of an ordinary scene read their pairs from the scratch record
   if (w > AGX_LV_WINDOW_CAP) w = AGX_LV_WINDOW_CAP;
 #endif
   return w;
@@ -55,7 +55,8 @@ AGX_DEV bool lvs_eligible(const Ctx& c, int lds_words) {
 struct LvsLay { float* lds; const float* H; const float* E; int dv_addr, pairs_addr, rfar; };   // rfar: first row whose pairs are not (all) inside the LDS window
 
 #if !defined(__HIP_DEVICE_COMPILE__) || defined(AGX_PGS_LV_CPP)
-// One visit, the C++ statement of what the assembly loop does (the emulator runs this; on the device it is the -DAGX_PGS_LV_CPP build).
+// One visit, the C++ statement of what the assembly loop does: what the emulator runs (tests/test_emu_parity.py holds it bit-identical with
+// pgs_lv()'s twin).  -DAGX_PGS_LV_CPP compiles it for the device as well (a debugging aid, never run on hardware).
 // lam: this lane's impulse register (lane = row - base); hiv: friction parts, mu x the normal impulse of the lane's contact (else unused).
 AGX_DEV void lvs_visit(const LvsLay& Y, int lane, int base, int bit, float& lam, bool fric, bool far, float hiv) {
   const float* H = Y.H + HDR_STRIDE * (base + bit); const int* Hi = (const int*)H;
