@@ -270,9 +270,17 @@ AGX_DEV void pgs_lvs(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
   uint64_t skip0 = 0ull, skip1 = 0ull;
   const int nsrc = (nnc + lane) & 63; const bool nhi = nnc + lane >= 64;           // where the normal impulse of this lane's contact lives
   float ln = 0.f;
+#ifdef AGX_EMU_TRACE_SCHED     // tests/diag/solve_schedule_study.py: the DoF masks of the rows, then per sweep the rows visited
+  if (lane == 0) { g_sched_trace[g_sched_n++] = -1; g_sched_trace[g_sched_n++] = R; g_sched_trace[g_sched_n++] = nnc; g_sched_trace[g_sched_n++] = nc;
+    for (int r = 0; r < R; r++) { const int* Xi = (const int*)hx_row(c.H, r); g_sched_trace[g_sched_n++] = Xi[H_MLO]; g_sched_trace[g_sched_n++] = Xi[H_MHI]; g_sched_trace[g_sched_n++] = Xi[H_M2]; } }
+#define AGX_TRACE_SCHED(kind, m) if (lane == 0 && g_sched_n + 3 < (1 << 24)) { g_sched_trace[g_sched_n++] = kind; g_sched_trace[g_sched_n++] = (int)(uint32_t)(m); g_sched_trace[g_sched_n++] = (int)(uint32_t)((m) >> 32); }
+#else
+#define AGX_TRACE_SCHED(kind, m)
+#endif
   for (int it = 0; it < iters; it++) {
     const bool retest = K > 0 && it % K == 0, use = K > 0 && !retest;
     const float bef0 = lamA0, bef1 = lamA1;
+    AGX_TRACE_SCHED(-2, rowsA0 & ~(use ? skip0 : 0ull)) AGX_TRACE_SCHED(-3, rowsA1 & ~(use ? skip1 : 0ull))
     lvs_part(Y, lane, rowsA0 & ~(use ? skip0 : 0ull), 0, lamA0, false, 0.f);
     lvs_part(Y, lane, rowsA1 & ~(use ? skip1 : 0ull), 64, lamA1, false, 0.f);
     if (retest) { skip0 = wave_ballot(lamA0 == bef0); skip1 = wave_ballot(lamA1 == bef1); }
@@ -280,6 +288,7 @@ AGX_DEV void pgs_lvs(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
     // friction rows (lane = contact): bounds from the normal impulses as this sweep's normal pass left them; a row whose normal impulse
     // and own impulse are both zero is an exact no-op and is not visited
     { const uint64_t todo = wave_ballot(lane < nc && (ln != 0.f || lamF1 != 0.f));
+      AGX_TRACE_SCHED(-4, todo)
       lvs_part(Y, lane, todo, nA, lamF1, true, mu1 * ln); }
     if (two_dirs) {
       const uint64_t todo = wave_ballot(lane < nc && (ln != 0.f || lamF2 != 0.f));

@@ -61,9 +61,14 @@ class _Rows:
 
 
 class AgxVectorEnv(_VectorEnv):
-    def __init__(self, env_id, num_envs, device=0, seed=1001, **vec_kwargs):
+    def __init__(self, env_id, num_envs, device=0, seed=1001, reuse_host_buffers=False, **vec_kwargs):
+        """reuse_host_buffers (opt-in, default off): hand out VIEWS into two pinned host buffers used in turn instead of a fresh copy per step.
+        The views are overwritten two steps later, so this is only for a consumer that is done with a step's observations / infos before
+        the step after next -- NOT RLlib's collectors, which keep the ndarray references of a whole rollout fragment and stack them when
+        the SampleBatch is built.  With the default every step's rows live in memory of their own, valid for ever."""
         from . import envs
         from .vec_env import AssistiveVecEnv
+        self._reuse = bool(reuse_host_buffers)
         name = env_id.split(':')[-1]
         proto = envs.ENV_IDS[name]()                     # spaces and info keys of the scalar env
         assert not proto.coop, 'co-op (multi-agent) ids are batched by AgxMultiAgentBatchEnv (RLlib BaseEnv), not by a VectorEnv'
@@ -87,8 +92,10 @@ class AgxVectorEnv(_VectorEnv):
     def vector_step(self, actions):
         """Host cost per step at 4096 environments (round 5, tools/gpu_rllib_overhead.py): the actions arrive as a list of arrays (one
         np.concatenate, 0.5 ms; an [n, act_dim] array is taken as it is), ONE device-to-host transfer brings back terminal observations,
-        rewards, done flags, two info columns and -- for the rows that ended -- the first observations of the new episodes, into one of two
-        pinned buffers used in turn (the rows handed out stay valid for one more step, no copy), as float32 like the observation space."""
+        rewards, done flags, two info columns and -- for the rows that ended -- the first observations of the new episodes, into a pinned
+        buffer; what is handed out is ONE contiguous copy of it per step (0.1 ms at 4096 x 54 floats), float32 like the observation space:
+        RLlib's collectors keep the row references until the SampleBatch is built, so the rows must never be overwritten
+        (reuse_host_buffers=True hands out views into two alternating pinned buffers instead: see __init__)."""
         import torch
         n = self.num_envs
         if not isinstance(actions, np.ndarray):
@@ -110,6 +117,8 @@ class AgxVectorEnv(_VectorEnv):
         host.copy_(pk, non_blocking=True)
         torch.cuda.current_stream(self.vec.device).synchronize()
         h = host.numpy()
+        if not self._reuse:
+            h = h.copy()                                  # memory of this step's own: rows, info columns and reset_at() observations are views of it
         dn = h[:, od + 1] != 0
         rows = _Rows(h[:, :od])
         # reset_at(i): the first observation of the new episode for the rows that ended, the current observation elsewhere

@@ -47,6 +47,12 @@ TASKS = {   # --task -> (model blob, VecEnv class, kernel-name suffix of the com
 }
 
 
+MULTI_GPU_CONFIGS = {      # world size -> (key in "configs", --task, timed steps): BASELINE.json configs[3] and configs[4]
+    4: ('config4_ScratchItchPR2Human-v1_16384_envs_4gpu', 'scratchitch', 300),
+    8: ('config5_DressingBaxter-v1_32768_envs_8gpu', 'dressing', 30),
+}
+
+
 def _cpu_worker(path, seed, n_steps, model='feeding_jaco'):
     """`bench.py --cpu-worker`: one host process stepping its share of the sample with the C oracle;
     prints "<env-steps> <seconds>"."""
@@ -329,7 +335,7 @@ def dry_run(args, rank, world):
     return {'metric': 'env_steps_per_sec', 'value': world * n * K / float(t.item()), 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': float(t.item()) / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'DRY RUN of the launch path of %s (no stepping: libagx has no CPU path)' % env_id, 'envs_per_gpu': n, 'global_envs': world * n,
-                       'parallelism': 'env-sharded x%d' % world, 'obs_allgather': world > 1, 'gathered_record': 'obs | reward | done | total_force_on_human | task_success', 'gathered_in_global_order': ok, 'obs_dim': blob.obs_dim, 'act_dim': blob.act_dim},
+                       'parallelism': 'env-sharded x%d' % world, 'obs_allgather': world > 1, 'gather': 'torch.distributed (%s; the dry run has no device buffers for the C ABI collective)' % (args.backend or 'gloo'), 'gathered_record': 'obs | reward | done | total_force_on_human | task_success', 'gathered_in_global_order': ok, 'obs_dim': blob.obs_dim, 'act_dim': blob.act_dim},
             'dry_run': True}
 
 
@@ -386,13 +392,31 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     if distributed:
         gather_how = args.gather
         if gather_how == 'abi':
+            # agx_comm_init_rank is a COLLECTIVE: a rank that cannot take part (RCCL not bindable by libagx, ...) must keep the others from
+            # entering it, and a rank whose own init failed must take the others with it into the fallback -- otherwise some ranks sit in
+            # ncclCommInitRank / agx_allgather while the rest call dist.all_gather: a hang, not a fallback.  Two votes over the
+            # launcher's torch.distributed group: before the collective (can every rank bind RCCL and did rank 0 get an id?) and after it.
+            from assistive_gym_amd import libagx
+            err = None
             try:
-                from assistive_gym_amd import libagx
-                box = [libagx.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm = libagx.comm_init_rank(local_rank, rank, world, box[0])
-            except Exception as e:                       # (a node whose RCCL the C ABI cannot bind: the line says so)
-                gather_how, comm = 'torch (agx_comm_init_rank failed: %s)' % str(e)[:120], None
+                uid = libagx.comm_unique_id()            # (every rank: binds RCCL or raises; rank 0's id is the one that travels)
+                box = [uid if rank == 0 else None]
+            except Exception as e:
+                err, box = str(e), [None]
+            dist.broadcast_object_list(box, src=0)
+            ok = torch.tensor([0 if (err or box[0] is None) else 1], device='cuda', dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()):
+                try:
+                    comm = libagx.comm_init_rank(local_rank, rank, world, box[0])
+                except Exception as e:
+                    err, comm = str(e), None
+                ok = torch.tensor([0 if comm is None else 1], device='cuda', dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if not int(ok.item()) and comm is not None:
+                    libagx.comm_destroy(comm); comm = None
+            if comm is None:                             # (on every rank alike; the line says so)
+                gather_how = 'torch (agx_comm_init_rank failed on %s: %s)' % ('this rank' if err else 'another rank', str(err)[:120])
         gatherer = BatchGatherer(n, blob.obs_dim + 4, world, device=torch.device('cuda', local_rank), force=args.force_gather, stepper=env.stepper, comm=comm)
 
     def one(k):
@@ -439,6 +463,21 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    in_order = None
+    if distributed:
+        # after the timed region: is the whole batch every rank holds in GLOBAL env order?  Rank r's own shard must sit bit for bit at rows
+        # [r n, (r + 1) n) of its gathered buffer, and the per-shard checksums every rank computed of its OWN records must be the ones found
+        # at the shards' places in this rank's gathered buffer (all ranks vote)
+        last = (W + K - 1) & 1
+        full, mine = gatherer.full[last], gatherer.local[last]
+        sums = torch.zeros(world, device='cuda', dtype=torch.float64)
+        sums[rank] = mine.double().sum()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        found = full.double().reshape(world, -1).sum(dim=1)
+        ok = torch.equal(full[rank * n:(rank + 1) * n], mine) and bool(((found - sums).abs() <= 1e-9 * sums.abs().clamp(min=1.0)).all())
+        okt = torch.tensor([1 if ok else 0], device='cuda', dtype=torch.int32)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        in_order = bool(okt.item())
     overflow = env.stepper.overflow_count() - overflow0
     if comm is not None:
         from assistive_gym_amd import libagx
@@ -518,7 +557,8 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             'data': 'synthetic',
             'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, %d PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else ('scripted press-and-wipe policy on the device (tool force feedback), whole 200-step episodes from starts with the pad on the arm; the pad carries force in %.0f %% of the selection rollout' % (100 * dense_touching)) if workload == 'dense' else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale, int(blob.param('NITER'))),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
-                       'obs_allgather': bool(distributed), 'gather': gather_how, 'gathered_record': 'obs | reward | done | total_force_on_human | task_success' if distributed else None, 'noop_retest': blob.param('NOOP_RETEST')},
+                       'obs_allgather': bool(distributed), 'gather': gather_how, 'gathered_record': 'obs | reward | done | total_force_on_human | task_success' if distributed else None,
+                       'gathered_in_global_order': in_order, 'noop_retest': blob.param('NOOP_RETEST')},
             'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps
             'overflow_count': int(overflow),       # substeps (summed over environments) in which a contact was dropped by the contact / row / coefficient budgets
             'pool_states_refreshed': int(getattr(env, 'pool_refreshed', 0)),      # --pool-refresh: start states a child process sampled during the run and the rollout swapped into the pool
@@ -582,6 +622,11 @@ def main():
         if world > 1:
             dist.init_process_group(args.backend or 'gloo')
         out = dry_run(args, rank, world)
+        if args.task is None and args.env is None and world in MULTI_GPU_CONFIGS and not args.no_configs:
+            key, t, _ = MULTI_GPU_CONFIGS[world]
+            r = dry_run(argparse.Namespace(**dict(vars(args), task=t)), rank, world)
+            out.setdefault('configs', {})[key] = dict({k: r[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'ms_per_step')}, workload=r['config']['workload'], global_envs=r['config']['global_envs'],
+                                                       gather=r['config']['gather'], gathered_in_global_order=r['config']['gathered_in_global_order'])
         if rank == 0:
             print(json.dumps(out))
         if world > 1:
@@ -608,6 +653,25 @@ def main():
     headline = args.task is None and args.env is None
     task = args.task or 'feeding'
     out = run_config(args, task, args.steps, args.warmup, rank, world, local_rank, distributed, cpu=not args.no_cpu_baseline, workload=args.workload, env_id_override=args.env)
+    if headline and world == 1 and not args.no_configs:
+        # beside the headline: the same workload over 2,000 steps (ten episode boundaries inside the window) when the timed
+        # window was short, and with the EXACT solver -- NOOP_RETEST = 0: every row visited in every sweep, no re-test rule -- over 300 steps
+        if args.steps < 200:
+            r = run_config(args, task, 2000, 50, rank, world, local_rank, distributed, cpu=False)
+            out['value_2000_steps'] = r['value']
+        args0 = argparse.Namespace(**dict(vars(args), param=list(args.param) + ['NOOP_RETEST=0']))
+        r = run_config(args0, task, 300, 20, rank, world, local_rank, distributed, cpu=False)
+        out['value_noop_retest_0'] = r['value']
+        out['value_noop_retest_0_note'] = 'same process, 300 steps, --param NOOP_RETEST=0: plain projected Gauss-Seidel, every row visited in all %d sweeps' % int(r['config']['workload'].split(',')[-1].split()[0])
+    if headline and world in MULTI_GPU_CONFIGS and not args.no_configs:
+        # the driver's 4- and 8-rank commands also run BASELINE config 4 (ScratchItchPR2 co-op, 16,384 environments over 4 GPUs) / config 5
+        # (DressingBaxter, 32,768 over 8) as written: same sharding, same per-step whole-batch gather (every rank takes part: collectives)
+        key, t, st = MULTI_GPU_CONFIGS[world]
+        r = run_config(args, t, st, 10, rank, world, local_rank, distributed, cpu=False)
+        if rank == 0:
+            out.setdefault('configs', {})[key] = dict({k: r[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'ms_per_step', 'contacts_per_substep', 'overflow_count')},
+                                                       workload=r['config']['workload'], global_envs=r['config']['global_envs'], gather=r['config']['gather'],
+                                                       gathered_in_global_order=r['config']['gathered_in_global_order'])
     if headline and world == 1 and not args.no_configs:
         # the other single-GPU BASELINE configurations on the same clock: short runs (a few seconds each), the headline value above is config 2
         extra = {}

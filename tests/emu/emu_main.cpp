@@ -7,6 +7,9 @@ extern "C" { int g_gjk_trace[1 << 22]; int g_gjk_n = 0, g_gjk_call = 0; }
   if ((has) && g_gjk_n + 9 <= (1 << 22)) { int* t = g_gjk_trace + g_gjk_n; g_gjk_n += 9; t[0] = g_gjk_call; t[1] = wave_lane(); t[2] = (iters); t[3] = (na); t[4] = (nb); t[5] = (box) ? 1 : 0; \
     t[6] = (far_out) ? 1 : 0; t[7] = (int)((dist) * 1e6f); t[8] = (int)((far) * 1e6f); } }
 #endif
+#ifdef AGX_EMU_TRACE_SCHED    // tests/diag/solve_schedule_study.py: row DoF masks and per-sweep visit masks of the row-local sweep
+extern "C" { int g_sched_trace[1 << 24]; int g_sched_n = 0; }
+#endif
 #include "agx_step.h"
 #include "agx_water.h"      // not yet part of a kernel variant: the source is checked here against the oracle first
 #include <functional>

@@ -172,3 +172,42 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['config']['global_envs'] == 32 and j['config']['gathered_in_global_order'] and j['config']['obs_allgather']
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_driver_n_rank_command_line_fields(world):
+    """The driver's N-rank command (`bench.py --gpus N --steps K --warmup W`, no --task, default 4096 environments per GPU) on the dry-run
+    path: the one JSON line carries n_gpus = N, global_envs = N x 4096, how the gather was done and that the whole batch arrived in global
+    env order; the 4- and 8-rank commands ALSO run BASELINE config 4 (ScratchItchPR2 co-op, 16,384 environments over 4 GPUs) / config 5
+    (DressingBaxter, 32,768 over 8) under "configs" (VERDICT r5 next 8)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--dry-run', '--backend', 'gloo', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    c = j['config']
+    assert j['n_gpus'] == world and c['global_envs'] == world * 4096 and c['envs_per_gpu'] == 4096 and j['scaling'] == 'weak'
+    assert c['obs_allgather'] and c['gathered_in_global_order'] and c['gather'] and 'FeedingJaco-v1' in c['workload']
+    want = {4: ('config4_ScratchItchPR2Human-v1_16384_envs_4gpu', 16384, 'ScratchItchPR2Human-v1'), 8: ('config5_DressingBaxter-v1_32768_envs_8gpu', 32768, 'DressingBaxter-v1')}.get(world)
+    if want is None:
+        assert 'configs' not in j
+    else:
+        e = j['configs'][want[0]]
+        assert e['n_gpus'] == world and e['global_envs'] == want[1] and want[2] in e['workload'] and e['gathered_in_global_order'] and e['gather']
+
+
+def test_real_bench_path_votes_on_the_collective_and_checks_the_order():
+    """the GPU path of bench.py (not runnable here) must not let ranks disagree about which collective they are in (a per-rank
+    try/except around agx_comm_init_rank is a hang when one rank fails), and must report the gathered order: both are all-rank reductions in
+    the source"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'bench.py')).read()
+    body = src[src.index("if gather_how == 'abi':"):src.index('gatherer = BatchGatherer(n, blob.obs_dim + 4, world, device=torch.device')]
+    assert body.count('dist.all_reduce(ok, op=dist.ReduceOp.MIN)') == 2 and 'libagx.comm_destroy(comm); comm = None' in body
+    assert "'gathered_in_global_order': in_order" in src and 'dist.all_reduce(okt, op=dist.ReduceOp.MIN)' in src
