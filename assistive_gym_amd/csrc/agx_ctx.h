@@ -121,13 +121,23 @@ constexpr int M_REF = 0, M_EEP = 3, M_EER = 6, M_ANC = 15;
 // contact record
 constexpr int C_CA = 0, C_CB = 1, C_BA = 2, C_BB = 3, C_PA = 4, C_PB = 7, C_N = 10, C_DIST = 13, C_MU = 14, C_LAM = 15;
 // row header
-constexpr int DBG_CON = 16, DBG_MINV = DBG_CON + MAX_CON * CON_STRIDE, DBG_HDR = DBG_MINV + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + MAX_ROWS * (HDR_WIDE ? 16 : 10),
-              DBG_TIME = DBG_LAM + MAX_ROWS, DBG_QDD = DBG_TIME + 16, DBG_WORDS = DBG_QDD + MAX_DOF;
+// ... and, for the wide row-local sweep (agx_pgs_lvw.h: up to four rows with disjoint velocity slots per visit, one per 16-lane group, so every
+// lane fetches the header of ITS group's row), two compact tables behind them -- what a visit of that sweep reads per row is 24 bytes:
+//   Q, 4 words: 1/D, b, lo, hi (friction rows: 1/D, b, 4 x the row of the contact's normal impulse, mu -- 0 without effective mass); a lane reads
+//      word (lane & 3) and takes the others from its quad by DPP;
+//   P, 2 words: 8 off | n << 16 | na << 24, and the H_AB word; read whole by every lane, fields picked by SDWA byte / word selects.
+// Row HW_DUMMY of both is the idle row (n = 0, 1/D = 0) a lane group without work visits.
+constexpr int HW_ROWS = MAX_ROWS + 8, HW_DUMMY = MAX_ROWS, HQ_STRIDE = 4, HP_STRIDE = 2;
+constexpr int HDR_TABLE_WORDS = MAX_ROWS * (HDR_WIDE ? 16 : 10);
+constexpr int HQ_BASE = HDR_TABLE_WORDS, HP_BASE = HQ_BASE + (HDR_WIDE ? HQ_STRIDE * HW_ROWS : 0), SCR_HDR_WORDS = HP_BASE + (HDR_WIDE ? HP_STRIDE * HW_ROWS : 0);
+constexpr int DBG_CON = 16, DBG_MINV = DBG_CON + MAX_CON * CON_STRIDE, DBG_HDR = DBG_MINV + MAX_DOF * MAX_DOF, DBG_LAM = DBG_HDR + SCR_HDR_WORDS,
+              DBG_TIME = DBG_LAM + MAX_ROWS, DBG_QDD = DBG_TIME + 24,      // (timers: 16 words of the build kernel's phases, 5..7 the solve kernel's; 16..19: steps / rows / scheduled steps / rows per sweep of the wide sweep)
+              DBG_WORDS = DBG_QDD + MAX_DOF;
 // per-environment scratch record in HBM (L2-resident while its environment is being solved)
 #ifndef AGX_SCR_ENT        // floats of the per-env (J,B) coefficient store: a row keeps one pair per DoF of each articulated block it touches
 #define AGX_SCR_ENT 4096
 #endif
-constexpr int SCR_ENT = AGX_SCR_ENT, SCR_HDR = MAX_ROWS * (HDR_WIDE ? 16 : 10), SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
+constexpr int SCR_ENT = AGX_SCR_ENT, SCR_HDR = SCR_HDR_WORDS, SCR_VEL = 128, SCR_CON = MAX_CON * CON_STRIDE, SCR_META = 16;
 constexpr int QPT_STRIDE = 4;                            // manifold query point: position on the human (3), PyBullet link of the human collider (int)
 constexpr int SCR_QPT = TASK != AGX_TASK_FEEDING ? MAX_QPT * QPT_STRIDE : 0;
 constexpr int SCR_O_ENT = 0, SCR_O_HDR = SCR_O_ENT + SCR_ENT, SCR_O_VEL = SCR_O_HDR + SCR_HDR, SCR_O_CON = SCR_O_VEL + SCR_VEL, SCR_O_META = SCR_O_CON + SCR_CON;

@@ -581,7 +581,8 @@ AGX_DEV void env_solve(const uint32_t* blob, float* gstate, float* gscratch, flo
   const long long t0 = gdebug ? wave_clock() : 0;
   float dv0 = 0.f, dv1 = 0.f;
   bool solved = false;
-  if constexpr (LVS_COMPILED) { if (lvs_eligible(c, lds_words)) { pgs_lvs(c, lds, lds_words, dv0, dv1); solved = true; } }   // the row-local sweep, pairs and velocities in LDS (agx_pgs_lvs.h)
+  if constexpr (LVW_COMPILED) { if (lvw_eligible(c, lds_words)) solved = pgs_lvw(c, lds, lds_words, dv0, dv1); }              // the wide row-local sweep: up to four rows per visit (agx_pgs_lvw.h)
+  if constexpr (LVS_COMPILED) { if (!solved && lvs_eligible(c, lds_words)) { pgs_lvs(c, lds, lds_words, dv0, dv1); solved = true; } }   // the row-local sweep, pairs and velocities in LDS (agx_pgs_lvs.h)
   else if constexpr (LV_COMPILED) { if (lv_eligible(c)) { pgs_lv(c, lds, lds_words, dv0, dv1); solved = true; } }      // the row-local sweep, headers in LDS too (agx_pgs_lv.h)
   if (!solved) {
     // environments with few rows take the row-space sweep (pgs_rowspace; it needs all pairs inside the window)

@@ -27,10 +27,11 @@ constexpr int LV_G = 16;                                            // lanes of 
 // LDS tables written out in gfx950 assembly (lv_part_asm, 45 instructions): 155 / 168 cycles with every row inside the window, FeedingJaco
 // 522 k env-steps/s (r05f_*).  Rows beyond the window still go through the C++ loop, so the solve launch of that build takes 20 KB of LDS
 // (agx_kernels.hip: 8 solve waves per CU) -- with the register sweep's 9.5 KB a third of the visits are such rows: 437 k.
-// AGX_PGS_LV = 3 (the DEFAULT of the feeding variant): agx_pgs_lvs.h, the same visit with the row headers in scalar registers and 10 KB
-// of LDS: 566 k.  -DAGX_PGS_LV=0: the register sweep of agx_pgs.h.  Emulator variants 'feeding_lv2' / 'feeding_reg' keep the C++ twins tested.
+// AGX_PGS_LV = 3 (the default of round 5): agx_pgs_lvs.h, the same visit with the row headers in scalar registers and 10 KB
+// of LDS: 566 k.  AGX_PGS_LV = 4 (the DEFAULT since round 6): agx_pgs_lvw.h, up to four rows with disjoint velocity slots per visit, one per 16-lane
+// group (same bits); agx_pgs_lvs.h stays compiled in as its fallback and A/B partner (AGX_P_SOLVE_WIDE = 0).  -DAGX_PGS_LV=0: the register sweep of agx_pgs.h.  Emulator variants 'feeding_lv2' / 'feeding_reg' keep the C++ twins tested.
 #ifndef AGX_PGS_LV
-#define AGX_PGS_LV 3
+#define AGX_PGS_LV 4
 #endif
 constexpr bool LV_COMPILED = AGX_PGS_LV && HDR_WIDE;       // the `feeding` variant (Jaco, Panda); rows of at most 16 pairs are checked per environment (lv_eligible)
 constexpr int LV_SOLVE_LDS_BYTES = 20480;                           // LDS of a solve launch of that variant: every row of an ordinary substep inside the window

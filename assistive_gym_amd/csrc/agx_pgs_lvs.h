@@ -33,7 +33,7 @@
 
 namespace agx {
 
-constexpr bool LVS_COMPILED = AGX_PGS_LV == 3 && LV_COMPILED;
+constexpr bool LVS_COMPILED = (AGX_PGS_LV == 3 || AGX_PGS_LV == 4) && LV_COMPILED;      // (4: the wide sweep of agx_pgs_lvw.h, with this one as its fallback)
 constexpr int LVS_SOLVE_LDS_BYTES = 10240;                          // LDS of a solve launch of that variant: 16 waves per CU; the window (1,216 pairs) holds the non-contact and normal rows of an ordinary substep and most friction rows
 constexpr int LVS_DV = 0, LVS_PAIRS = 128;                           // LDS words: dv[128], pairs[2 x window]
 static_assert(!LVS_COMPILED || HDR_STRIDE == 8, "the row-local sweep reads 32-byte headers");

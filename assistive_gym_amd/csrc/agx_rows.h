@@ -87,7 +87,14 @@ AGX_DEV void row_store(const Ctx& c, const RowGeom& r, int row, int off, float b
   if (na > 0) { if (a0 < 64) mlo |= ra << a0; if (a0 + na > 64) mhi |= a0 >= 64 ? ra << (a0 - 64) : ra >> (64 - a0); }
   if (nb > 0) { if (b0 < 64) mlo |= rb << b0; if (b0 + nb > 64) mhi |= b0 >= 64 ? rb << (b0 - 64) : rb >> (64 - b0); }
   Xi[H_PACK] = a0 | (na << 8) | (b0 << 16) | (nb << 24); Hi[H_OFF] = off | (mhi ? (int)(1u << OFF_TWO_BIT) : 0);
-  if constexpr (HDR_WIDE) { Hi[H_N] = na + nb; Hi[H_NA] = na; Hi[H_AB] = (4 * a0 + H_AB_BIAS) | ((4 * (b0 - na) + H_AB_BIAS) << 16); }
+  if constexpr (HDR_WIDE) {
+    Hi[H_N] = na + nb; Hi[H_NA] = na; Hi[H_AB] = (4 * a0 + H_AB_BIAS) | ((4 * (b0 - na) + H_AB_BIAS) << 16);
+    // the two compact tables of the wide row-local sweep (agx_ctx.h, agx_pgs_lvw.h)
+    float* Q = c.H + HQ_BASE + HQ_STRIDE * row; int* Qi = (int*)Q; int* P = (int*)(c.H + HP_BASE + HP_STRIDE * row);
+    Q[0] = H[H_INVD]; Q[1] = bterm;
+    if (fric_of >= 0) { Qi[2] = 4 * fric_of; Q[3] = H[H_INVD] != 0.f ? mu : 0.f; } else { Q[2] = lo; Q[3] = hi; }
+    P[0] = (8 * off) | ((na + nb) << 16) | (na << 24); P[1] = Hi[H_AB];
+  }
   Xi[H_M2] = (int)(uint32_t)mhi; X[H_MU] = mu; Xi[H_MLO] = (int)(uint32_t)mlo; Xi[H_MHI] = (int)(uint32_t)(mlo >> 32);
 }
 AGX_DEV void plane_space(v3 n, v3& p) {
@@ -111,6 +118,9 @@ AGX_DEV void build_rows(Ctx& c) {
   int maxrows = (int)PRM(c, AGX_P_MAX_ROWS); if (maxrows > MAX_ROWS) maxrows = MAX_ROWS;
   int maxent = (int)PRM(c, AGX_P_MAX_ENTRIES); if (maxent > SCR_ENT / 2) maxent = SCR_ENT / 2;
   if (lane == 0) { c.E[0] = 0.f; c.E[1] = 0.f; }               // entry 0 of the arena is the zero pair
+  if constexpr (HDR_WIDE) { if (lane < HQ_STRIDE + HP_STRIDE) {                   // the idle row of the wide sweep's tables: no pairs, no effective mass
+    if (lane < HQ_STRIDE) c.H[HQ_BASE + HQ_STRIDE * HW_DUMMY + lane] = 0.f;
+    else ((int*)c.H)[HP_BASE + HP_STRIDE * HW_DUMMY + lane - HQ_STRIDE] = lane == HQ_STRIDE ? 0 : (H_AB_BIAS | (H_AB_BIAS << 16)); } }
   int nnc = 0, ent = 1;                                         // non-contact rows / coefficient pairs so far
   // contact rows: lane = contact; normal rows first, then one friction row per contact (AGX_P_FRICTION_DIRS = 2: a second block of
   // friction rows along n x t behind the first)

@@ -31,6 +31,7 @@
 #include "agx_pgs.h"
 #include "agx_pgs_lv.h"
 #include "agx_pgs_lvs.h"
+#include "agx_pgs_lvw.h"
 #if AGX_TASK == 5   /* AGX_TASK_DRINKING (an enum: not visible to the preprocessor) */
 #include "agx_water.h"
 #endif

@@ -92,6 +92,7 @@ AGX_DEV int wave_rank(uint64_t mask) {
 }
 AGX_DEV int popc64(uint64_t m) { return __popcll(m); }
 AGX_DEV int ffs64(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+AGX_DEV int clz64(uint64_t m) { return __clzll((long long)m); }      // leading zero bits (m != 0)
 // exclusive prefix sum over lanes (Hillis-Steele on ds_bpermute; used a few times per substep only)
 AGX_DEV int wave_scan_excl(int x) {
   const int lane = wave_lane();

@@ -232,3 +232,148 @@ class AgxMultiAgentBatchEnv(_BaseEnv):
         self.vec.close()
 
     close = stop
+
+
+_AGENT = 'agent0'          # RLlib's _DUMMY_AGENT_ID: the agent key of a single-agent env behind the BaseEnv interface
+
+
+class AgxPipelinedBatchEnv(_BaseEnv):
+    """The single-agent ids as an RLlib BaseEnv with TWO half-batches in flight.
+
+    `vector_step` of a VectorEnv is synchronous: every step starts on an idle GPU and the sampler's own work (policy forward, collectors)
+    starts on an idle host -- 334 k of the 554 k env-steps/s the device-resident loop reaches (profiles/r05).  RLlib's BaseEnv contract is
+    asynchronous by design (`poll()` returns whichever sub-environments have something to report, `send_actions()` takes actions for exactly
+    those; the sampler loop of ray 1.x, _env_runner, alternates the two), so this adapter splits the batch into halves A = [0, n/2) and
+    B = [n/2, n): poll() hands out the finished step of one half while the kernels of the other half run, send_actions() enqueues that
+    half's next step and returns without waiting.  Each half is a handle of its own (same pool, global env indices: the trajectories are those
+    of one n-environment batch), stepped on its own stream, with its own pinned host buffer; what poll() returns is a copy (RLlib keeps the
+    references until the SampleBatch is built).  Episode ends: as AgxVectorEnv -- the observation returned with done is the LAST one of the
+    old episode, try_reset(env_id) the first one of the new episode.
+
+        register_env('assistive_gym:FeedingJaco-v1', lambda cfg: AgxPipelinedBatchEnv('FeedingJaco-v1', cfg.get('num_envs', 4096)))
+    """
+
+    def __init__(self, env_id, num_envs, device=0, seed=1001, **vec_kwargs):
+        import torch
+        from . import envs
+        from .vec_env import AssistiveVecEnv
+        name = env_id.split(':')[-1]
+        proto = envs.ENV_IDS[name]()
+        assert not proto.coop and num_envs % 2 == 0
+        self.num_envs, self.observation_space, self.action_space = num_envs, proto.observation_space, proto.action_space
+        self._info_static = {'action_robot_len': proto.action_robot_len, 'action_human_len': proto.action_human_len,
+                             'obs_robot_len': proto.obs_robot_len, 'obs_human_len': proto.obs_human_len}
+        vec_kwargs.setdefault('reset', 'pool')
+        n2 = num_envs // 2
+        self.n2, self.torch = n2, torch
+        self.halves, self.streams, self.events, self.host, self.pack, self.act = [], [], [], [], [], []
+        for h in range(2):
+            v = AssistiveVecEnv(n2, device=device, seed=seed, model=_models()[name], **vec_kwargs)
+            v.keep_terminal_obs = True
+            self.halves.append(v); self.streams.append(torch.cuda.Stream(device=v.device)); self.events.append(torch.cuda.Event())
+        od = self.halves[0].obs_dim
+        self.od = od
+        for h in range(2):
+            v = self.halves[h]
+            if h == 1:
+                v.pool, v.pool_host = self.halves[0].pool, self.halves[0].pool_host          # one pool for both halves (drawn by GLOBAL env index)
+            with torch.cuda.stream(self.streams[h]):
+                first = v.reset(env_offset=h * n2)
+                self.pack.append(torch.empty((n2, 2 * od + 4), dtype=torch.float32, device=v.device))
+                self.host.append(torch.empty((n2, 2 * od + 4), dtype=torch.float32, pin_memory=True))
+                self.act.append(torch.empty((n2, v.act_dim), dtype=torch.float32, device=v.device))
+                self.host[h][:, :od].copy_(first, non_blocking=True)
+                self.events[h].record(self.streams[h])
+        self._state = ['reset', 'reset']      # what the next poll of a half returns: its reset observations, or a step's results
+        self._turn = 0
+        self._new_obs = {}
+        self._ids = [np.arange(0, n2), np.arange(n2, num_envs)]
+
+    def poll(self):
+        h = self._turn
+        self.events[h].synchronize()
+        a = self.host[h].numpy().copy()
+        od, ids = self.od, self._ids[h].tolist()
+        if self._state[h] == 'reset':
+            obs = {i: {_AGENT: row} for i, row in zip(ids, a[:, :od])}
+            return (obs, {i: {_AGENT: None} for i in ids}, {i: {_AGENT: False, '__all__': False} for i in ids}, {i: {_AGENT: {}} for i in ids}, {})
+        dn = (a[:, od + 1] != 0).tolist()
+        obs = {i: {_AGENT: row} for i, row in zip(ids, a[:, :od])}
+        rew = {i: {_AGENT: r} for i, r in zip(ids, a[:, od].tolist())}
+        done = {i: {_AGENT: d, '__all__': d} for i, d in zip(ids, dn)}
+        info = _LazyAgentInfos(ids[0], self._info_static, a[:, od + 2], a[:, od + 3])
+        if any(dn):
+            first = a[:, od + 4:]
+            for k, d in enumerate(dn):
+                if d:
+                    self._new_obs[ids[k]] = {_AGENT: first[k]}
+        return obs, rew, done, info, {}
+
+    def send_actions(self, action_dict):
+        """actions for the environments of the half the last poll() reported; enqueues that half's next step and returns"""
+        torch = self.torch
+        h = self._turn
+        v, n2, od = self.halves[h], self.n2, self.od
+        lo = h * n2
+        a = np.empty((n2, v.act_dim), dtype=np.float32)
+        if len(action_dict) == n2:
+            for k in range(n2):
+                a[k] = action_dict[lo + k][_AGENT]
+        else:                                  # (a sampler that skipped some environments: they repeat a zero action)
+            a[:] = 0
+            for i, d in action_dict.items():
+                a[i - lo] = d[_AGENT]
+        with torch.cuda.stream(self.streams[h]):
+            self.act[h].copy_(torch.from_numpy(a), non_blocking=True)
+            obs, rew, done, info = v.step(self.act[h])
+            pk = self.pack[h]
+            pk[:, :od] = v.terminal_obs; pk[:, od] = rew; pk[:, od + 1] = done; pk[:, od + 2:od + 4] = info[:, 0:2]; pk[:, od + 4:] = obs
+            self.host[h].copy_(pk, non_blocking=True)
+            self.events[h].record(self.streams[h])
+        self._state[h] = 'step'
+        self._turn ^= 1
+
+    def try_reset(self, env_id=None):
+        if env_id is None:
+            return {i: self.try_reset(i) for i in range(self.num_envs)}
+        return self._new_obs.pop(env_id, None)
+
+    def get_unwrapped(self):
+        return []
+
+    def stop(self):
+        for v in self.halves:
+            v.close()
+
+    close = stop
+
+
+class _LazyAgentInfos:
+    """{env_id: {'agent0': info}} of a half-batch, built per environment on access (a sampler that never reads `info` pays nothing)"""
+
+    def __init__(self, first_id, static, force, success):
+        self._lo, self._static, self._force, self._success = first_id, static, force, success
+
+    def __len__(self):
+        return len(self._force)
+
+    def __contains__(self, i):
+        return self._lo <= i < self._lo + len(self._force)
+
+    def __getitem__(self, i):
+        k = i - self._lo
+        if not 0 <= k < len(self._force):
+            raise KeyError(i)
+        return {_AGENT: dict(self._static, total_force_on_human=float(self._force[k]), task_success=int(self._success[k]))}
+
+    def get(self, i, default=None):
+        return self[i] if i in self else default
+
+    def keys(self):
+        return range(self._lo, self._lo + len(self._force))
+
+    def items(self):
+        return ((i, self[i]) for i in self.keys())
+
+    def __iter__(self):
+        return iter(self.keys())

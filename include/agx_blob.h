@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 15
+#define AGX_BLOB_VERSION 16
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -143,7 +143,10 @@ enum {
                             URDF and of createMultiBody -- btMultiBodyConstraintSolver sets up the same split and never solves the push part, i.e.
                             such a contact only stops the approach.  0 = off: the Baumgarte term on the full depth (deeply penetrating
                             START poses are pushed out within one substep); 0.04 = Bullet's value.  Oracle and device (agx_rows.h)            */
-  AGX_P_COUNT = 27
+  AGX_P_SOLVE_WIDE = 27, /* != 0 (the default, 1): the feeding variant's solve kernel visits up to four rows with disjoint velocity slots at once, one per
+                            16-lane group (csrc/agx_pgs_lvw.h); 0: one row per visit (csrc/agx_pgs_lvs.h).  The two compute the same bits (rows that share no
+                            slot commute exactly): a device-only switch for same-process A/B runs and the bit-for-bit test; the oracle ignores it          */
+  AGX_P_COUNT = 28
 };
 
 /* ---- ROBOT: one record per moving link, stride AGX_R_STRIDE ------------------------------- */

@@ -60,6 +60,7 @@ AGX_DEV int wave_bcast_i(int x, int src) { return wave_shfl_i(x, src); }
 AGX_DEV int wave_rank(uint64_t mask) { return __builtin_popcountll(mask & ((1ull << emu::W->cur) - 1ull)); }
 AGX_DEV int popc64(uint64_t m) { return __builtin_popcountll(m); }
 AGX_DEV int ffs64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
+AGX_DEV int clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 AGX_DEV int wave_scan_excl(int x) { const uint32_t* s = emu::exchange((uint32_t)x); int t = 0; for (int i = 0; i < emu::W->cur; i++) t += (int)s[i]; return t; }
 AGX_DEV long long wave_clock() { return 0; }
 AGX_DEV float wave_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }

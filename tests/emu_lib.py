@@ -24,8 +24,11 @@ VARIANT_DEFS['feeding_trace'] = ['-DAGX_EMU_TRACE_GJK']      # tests/diag/narrow
 VARIANT_DEFS['feeding_trace_sched'] = ['-DAGX_EMU_TRACE_SCHED']      # tests/diag/solve_schedule_study.py
 VARIANT_DEFS['feeding_reg'] = ['-DAGX_PGS_LV=0']       # the register sweep of csrc/agx_pgs.h (its C++ twin) for the scenes that take the row-local sweep (csrc/agx_pgs_lv.h) by default
 VARIANT_DEFS['feeding_lv_cap'] = ['-DAGX_PGS_LV=2', '-DAGX_LV_WINDOW_CAP=300']       # the row-local sweep with a small LDS window: its rows-beyond-the-window path on ordinary scenes
-VARIANT_DEFS['feeding_lv2'] = ['-DAGX_PGS_LV=2']       # the row-local sweep with row headers, impulses and velocity slots in LDS (csrc/agx_pgs_lv.h); the default (0) is csrc/agx_pgs_lvs.h
-VARIANT_DEFS['feeding_lvs_cap'] = ['-DAGX_LV_WINDOW_CAP=300']       # ... with a small LDS window: most rows read their pairs from the scratch record
+VARIANT_DEFS['feeding_lv2'] = ['-DAGX_PGS_LV=2']       # the row-local sweep with row headers, impulses and velocity slots in LDS (csrc/agx_pgs_lv.h); the default (0) is csrc/agx_pgs_lvw.h
+VARIANT_DEFS['feeding_lvs'] = ['-DAGX_PGS_LV=3']       # the row-local sweep with scalar row headers (csrc/agx_pgs_lvs.h), one row per visit: the default of round 5, now the fallback of ...
+VARIANT_DEFS['feeding_lvs_cap'] = ['-DAGX_PGS_LV=3', '-DAGX_LV_WINDOW_CAP=300']       # ... with a small LDS window: most rows read their pairs from the scratch record
+VARIANT_DEFS['feeding_lvw_cap'] = ['-DAGX_LV_WINDOW_CAP=300']       # the wide row-local sweep (csrc/agx_pgs_lvw.h, the default: variant 0) with a small LDS window
+VARIANT_DEFS['feeding_lvw_8steps'] = ['-DAGX_LVW_MAX_STEPS=8']       # ... whose scheduler gives up beyond 8 steps per part: every ordinary substep falls back to the narrow sweep
 VARIANT_DEFS['feeding_l'] = ['-DAGX_MAX_COLL=320', '-DAGX_MAX_BLOCK=12', '-DAGX_ARENA_WORDS=4040']
 VARIANT_DEFS['feeding_m'] = ['-DAGX_MAX_DOF=20', '-DAGX_MAX_BLOCK=16', '-DAGX_MAX_COLL=320', '-DAGX_ST_WORDS=344', '-DAGX_ARENA_WORDS=4040']    # FeedingStretch
 VARIANT_DEFS['bed_m'] = ['-DAGX_MAX_DOF=28', '-DAGX_MAX_FREE=2', '-DAGX_MAX_BLOCK=16', '-DAGX_ARENA_WORDS=5632', '-DAGX_TASK=1']          # BedBathingStretch

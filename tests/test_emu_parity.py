@@ -638,13 +638,44 @@ def test_row_local_sweep_against_the_register_sweep(blob):
     assert differs > 0                                     # (two different sweeps: a real comparison)
 
 
+def test_wide_row_local_sweep_is_bit_identical(blob):
+    """csrc/agx_pgs_lvw.h (the default solve path of the feeding variant since round 6: up to four rows with disjoint velocity slots per visit, one per
+    16-lane group, list-scheduled per substep) against csrc/agx_pgs_lvs.h (one row per visit, the default of round 5): rows that share no slot
+    commute exactly and rows that do keep their order, so states, observations, rewards and info agree BIT FOR BIT -- over settling (the bowl
+    lands, food falls onto the spoon) and steps; also with a 300-pair LDS window (steps with a row beyond it read every pair from the scratch
+    record), with the blob switch AGX_P_SOLVE_WIDE = 0 (the narrow sweep inside the wide build), and in a build whose scheduler gives up at 8
+    steps per part (the fallback to the narrow sweep, substep by substep)."""
+    from emu_lib import Emu
+    wide, narrow, cap, few = Emu(blob), Emu(blob, 'feeding_lvs'), Emu(blob, 'feeding_lvw_cap'), Emu(blob, 'feeding_lvw_8steps')
+    off = Emu(blob.set_param('SOLVE_WIDE', 0))
+    st, _ = make_states(blob, 3, seed=3703)
+    rng = np.random.RandomState(10)
+    for i in range(3):
+        s = st[i].copy()
+        if i < 2:
+            sw, sn = s.copy(), s.copy()
+            wide.settle(sw, 6); narrow.settle(sn, 6)
+            assert np.array_equal(sw.view(np.uint32), sn.view(np.uint32)), i
+            s = sw
+        for k in range(3):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            outs = []
+            for e in (wide, narrow, cap, few, off):
+                se = s.copy()
+                obs, rew, done, info, _ = e.step(se, a)
+                outs.append((se, obs, rew, info))
+            for name, (se, obs, rew, info) in zip(('narrow', 'window of 300 pairs', 'scheduler limited to 8 steps', 'SOLVE_WIDE = 0'), outs[1:]):
+                assert np.array_equal(se.view(np.uint32), outs[0][0].view(np.uint32)) and np.array_equal(obs, outs[0][1]) and rew == outs[0][2] and np.array_equal(info, outs[0][3]), (i, k, name)
+            s = outs[0][0]
+
+
 def test_row_local_sweep_with_scalar_headers(blob):
-    """csrc/agx_pgs_lvs.h (the default solve path of the feeding variant: row headers through scalar loads from the scratch record, impulses in a vector register, velocity
+    """csrc/agx_pgs_lvs.h (the fallback of the wide sweep; the default of round 5: row headers through scalar loads from the scratch record, impulses in a vector register, velocity
     slots by arithmetic on the header) does the arithmetic of csrc/agx_pgs_lv.h visit by visit: the two agree BIT FOR BIT, and so does a build whose LDS
     window holds 300 pairs only (most rows read their pairs from the scratch record: the window is a cache, not arithmetic); the register sweep
     (-DAGX_PGS_LV=0) associates the dot products differently and agrees to rounding."""
     from emu_lib import Emu
-    lv, lvs, cap, reg = Emu(blob, 'feeding_lv2'), Emu(blob, 0), Emu(blob, 'feeding_lvs_cap'), Emu(blob, 'feeding_reg')
+    lv, lvs, cap, reg = Emu(blob, 'feeding_lv2'), Emu(blob, 'feeding_lvs'), Emu(blob, 'feeding_lvs_cap'), Emu(blob, 'feeding_reg')
     st, _ = make_states(blob, 2, seed=3702)
     rng = np.random.RandomState(9)
     differs = 0

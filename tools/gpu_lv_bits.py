@@ -20,7 +20,13 @@ import torch
 from assistive_gym_amd import vec_env
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-env = vec_env.FeedingJacoVecEnv(n, pool_size=64, seed=1001)
+blob = None
+if os.environ.get('AGX_BITS_PARAM'):            # e.g. SOLVE_WIDE=0: the narrow sweep inside the default build (same-process A/B switch of the blob)
+    from assistive_gym_amd.blob import ModelBlob
+    blob = ModelBlob.load('feeding_jaco')
+    for kv in os.environ['AGX_BITS_PARAM'].split(','):
+        k, v = kv.split('='); blob = blob.set_param(k, float(v))
+env = vec_env.FeedingJacoVecEnv(n, pool_size=64, seed=1001, blob=blob)
 env.reset()
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 rew = []
@@ -30,4 +36,4 @@ for k in range(steps):
 torch.cuda.synchronize()
 np.savez(sys.argv[1], state=env.stepper.get_state().view(np.uint32), obs=env.obs.cpu().numpy(),
          reward=torch.stack(rew).cpu().numpy(), info=env.info.cpu().numpy())
-print('wrote', sys.argv[1], os.environ.get('AGX_LIB', 'libagx.so'), os.environ.get('AGX_SOLVE_LDS_BYTES', 'default'))
+print('wrote', sys.argv[1], os.environ.get('AGX_LIB', 'libagx.so'), os.environ.get('AGX_SOLVE_LDS_BYTES', 'default'), os.environ.get('AGX_BITS_PARAM', ''))

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from assistive_gym_amd.rllib import AgxVectorEnv, AgxMultiAgentBatchEnv
+from assistive_gym_amd.rllib import AgxVectorEnv, AgxMultiAgentBatchEnv, AgxPipelinedBatchEnv
 from assistive_gym_amd.vec_env import FeedingJacoVecEnv
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -28,6 +28,27 @@ for k in range(10): v.vector_step(al)
 t0 = time.perf_counter()
 for k in range(K): v.vector_step(al)
 out['rllib_vector_env'] = n * K / (time.perf_counter() - t0); v.close()
+
+# (d) the same ids behind the asynchronous BaseEnv contract, two half-batches in flight: poll() hands out one half's finished step while the other
+# half's kernels run.  `adapter only`: prebuilt action dictionaries, results not looked at (as (b)); `with a sampler stand-in`: every
+# observation, reward and done flag is read and an action dictionary is built per round, as ray 1.x's _env_runner does
+p2 = AgxPipelinedBatchEnv('FeedingJaco-v1', n, pool_size=64)
+half = [{i: {'agent0': acts[i]} for i in range(0, n // 2)}, {i: {'agent0': acts[i]} for i in range(n // 2, n)}]
+for k in range(24): p2.poll(); p2.send_actions(half[k & 1])
+t0 = time.perf_counter()
+for k in range(2 * K): p2.poll(); p2.send_actions(half[k & 1])
+torch.cuda.synchronize(); out['rllib_pipelined_base_env_adapter_only'] = n * K / (time.perf_counter() - t0)
+t0 = time.perf_counter(); tot = 0.0
+for k in range(2 * K):
+    obs, rew, done, info, _ = p2.poll()
+    to_send = {}
+    for i, ao in obs.items():
+        r = rew[i]['agent0']; tot += r if r is not None else 0.0
+        if done[i]['__all__']:
+            ao = p2.try_reset(i)
+        to_send[i] = {'agent0': acts[i]}
+    p2.send_actions(to_send)
+torch.cuda.synchronize(); out['rllib_pipelined_base_env_with_sampler_stand_in'] = n * K / (time.perf_counter() - t0); p2.stop()
 
 m = AgxMultiAgentBatchEnv('ScratchItchPR2Human-v1', n, pool_size=64); m.poll()
 ad = {i: {'robot': acts[i], 'human': np.zeros(10, np.float32)} for i in range(n)}

@@ -15,6 +15,7 @@
 #   pmc:<task>       the separate --pmc passes over tools/pmc_workload.py <task>, reduced by tools/pmc_traffic.py -> traffic_<task>.json
 #   rllib            tools/gpu_rllib_overhead.py -> rllib_overhead.json
 #   py:<script>[,args]  python <script> args -> <script basename>.log
+#   env:VAR=VAL / unset:VAR   environment for the actions that follow (e.g. env:AGX_SOLVE_LDS_BYTES=12288)
 #   ab:<name>        AGX_LIB=assistive_gym_amd/lib/variants/<name>.so bench.py --steps 300 (x2, interleaved with the default build) -> ab_<name>.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -40,7 +41,7 @@ for A in "$@"; do
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log ;;
     driver) timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_cmd.json 2>$O/driver_cmd.err; line $O/driver_cmd.json ;;
     default) timeout 1200 python bench.py > $O/bench_default_all_configs.json 2>$O/bench_default.err; line $O/bench_default_all_configs.json ;;
-    bench) N=$(echo "$V" | tr -c 'A-Za-z0-9=' '_'); timeout 900 python bench.py $(echo "$V" | tr ',' ' ') --no-cpu-baseline --no-configs > $O/bench_$N.json 2>$O/bench_$N.err; line $O/bench_$N.json ;;
+    bench) N=$(echo "$V" | tr -c 'A-Za-z0-9=' '_')${AGX_SOLVE_LDS_BYTES:+_lds$AGX_SOLVE_LDS_BYTES}; timeout 900 python bench.py $(echo "$V" | tr ',' ' ') --no-cpu-baseline --no-configs > $O/bench_$N.json 2>$O/bench_$N.err; line $O/bench_$N.json ;;
     prof|prof1) T=${V:-feeding}; S=""; [ $K = prof1 ] && S="unchunked_"
       ( cd /tmp && AGX_CHUNKS=$([ $K = prof1 ] && echo 1 || echo "${AGX_CHUNKS:-}") timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tmp -- python $R/bench.py --task $T --steps 50 --warmup 5 --no-cpu-baseline --no-configs > $O/bench_${S}under_rocprof_$T.json 2>$O/rocprof_$T.err )
       find $O/prof_tmp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_${S}$T.csv; head -6 $O/kernel_stats_${S}$T.csv; rm -rf $O/prof_tmp ;;
@@ -59,6 +60,8 @@ for A in "$@"; do
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(j['value']), round(j['ms_per_step'], 3), {k.split('_')[1]: round(v, 2) for k, v in j['roofline']['kernels_ms_per_step_summed_over_overlapping_launches'].items()})" | tee -a $O/ab_$V.txt
       done; done; unset AGX_LIB ;;
+    env) export "$V"; echo "exported $V" ;;
+    unset) unset "$V" ;;
     *) echo "unknown action $A" ;;
   esac
 done
