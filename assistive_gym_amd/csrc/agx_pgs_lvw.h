@@ -58,20 +58,25 @@ struct LvwLay { float* lds; const float* H; const float* E; int dv_addr, lam_add
 // ---- the static schedule of the rows [r0, r0 + nr), in that order: lane = step.  ss: the (up to four) rows of this lane's step, a byte each,
 // idle slots = HW_DUMMY.  Returns the number of steps, -1 when they do not fit LVW_MAX_STEPS.
 AGX_DEV int lvw_schedule(const Ctx& c, int lane, int r0, int nr, uint32_t& ss) {
+  // the slot masks of the rows r0 + lane and r0 + 64 + lane, read once (lane = row); the loop below takes a row's from its lane
+  uint32_t a0 = 0u, a1 = 0u, a2 = 0u, b0 = 0u, b1 = 0u, b2 = 0u;
+  if (lane < nr) { const int* Xi = (const int*)hx_row(c.H, r0 + lane); a0 = (uint32_t)Xi[H_MLO]; a1 = (uint32_t)Xi[H_MHI]; a2 = (uint32_t)Xi[H_M2]; }
+  if (64 + lane < nr) { const int* Xi = (const int*)hx_row(c.H, r0 + 64 + lane); b0 = (uint32_t)Xi[H_MLO]; b1 = (uint32_t)Xi[H_MHI]; b2 = (uint32_t)Xi[H_M2]; }
   uint32_t u0 = 0u, u1 = 0u, u2 = 0u; int fill = 0; ss = LVW_IDLE;
-  bool ok = true;
-  for (int r = r0; r < r0 + nr; r++) {
-    const int* Xi = (const int*)hx_row(c.H, r);
-    const uint32_t m0 = (uint32_t)Xi[H_MLO], m1 = (uint32_t)Xi[H_MHI], m2 = (uint32_t)Xi[H_M2];
+  bool fits = true;
+  auto place = [&](uint32_t m0, uint32_t m1, uint32_t m2, int r) {
     const uint64_t conflicts = wave_ballot(((u0 & m0) | (u1 & m1) | (u2 & m2)) != 0u);         // steps that hold a row sharing a slot with r
     const int e = conflicts ? 64 - clz64(conflicts) : 0;                                         // r goes behind the last of them
     const uint64_t room = wave_ballot(fill < LVW_NG && lane < LVW_MAX_STEPS);
     const uint64_t cand = e >= 64 ? 0ull : (room >> e) << e;
-    if (!cand) { ok = false; break; }                                                            // (wave uniform)
-    const int s = ffs64(cand);
+    if (!cand) fits = false;                                                                     // (wave uniform; the rows that follow are placed for nothing)
+    const int s = cand ? ffs64(cand) : -1;
     if (lane == s) { const int sh = 8 * fill; ss = (ss & ~(0xffu << sh)) | ((uint32_t)r << sh); fill++; u0 |= m0; u1 |= m1; u2 |= m2; }
-  }
-  if (!ok) return -1;
+  };
+  const int n0 = nr < 64 ? nr : 64;
+  _Pragma("nounroll") for (int r = 0; r < n0; r++) place((uint32_t)wave_bcast_i((int)a0, r), (uint32_t)wave_bcast_i((int)a1, r), (uint32_t)wave_bcast_i((int)a2, r), r0 + r);
+  _Pragma("nounroll") for (int r = 64; r < nr; r++) place((uint32_t)wave_bcast_i((int)b0, r - 64), (uint32_t)wave_bcast_i((int)b1, r - 64), (uint32_t)wave_bcast_i((int)b2, r - 64), r0 + r);
+  if (!fits) return -1;
   const uint64_t used = wave_ballot(fill > 0);
   return used ? 64 - clz64(used) : 0;
 }
@@ -132,7 +137,13 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
 #define LVW_SL3 "v110", "v111", "v[110:111]", "v112", "v113", "v[112:113]", "v114", "v115", "v116", "v117", "v118", "v119", "s[58:59]"
 #define LVW_QP(i) " quad_perm:[" #i "," #i "," #i "," #i "] row_mask:0xf bank_mask:0xf\n"
 #define LVW_DPP(CTRL) "v_add_f32_dpp v120, v120, v120 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+// S1, the row index of this lane's group for step t + 4: one byte of the step list in LDS.  (Tried, r06b: the list in a vector register, lane = step,
+// a step's word through v_readlane + v_bfe -- one LDS instruction less, two VALU / SALU more: 588 k against 607 k env-steps/s, same box.  Not kept.)
 #define LVW_S1(RID, OFF) "ds_read_u8 " RID ", %[sa] offset:" OFF "\n"
+#define LVW_S1B(RID)
+#define LVW_TAIL_STEP "s_nop 0\n"
+#define LVW_TAIL_LAST "v_add_u32_e32 %[sa], 16, %[sa]\n"
+#define LVW_PRIME LVW_S1("v88", "0") LVW_S1("v98", "4") LVW_S1("v108", "8") LVW_S1("v118", "12") "s_waitcnt lgkmcnt(0)\n"
 #define LVW_S2(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
   "v_lshl_add_u32 v126, " RID ", 4, %[hbk]\n" \
   "v_lshlrev_b32_e32 v127, 3, " RID "\n" \
@@ -161,7 +172,7 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
   "s_branch " LBL "2b\n"
 #define LVW_GATHER(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) "ds_read_b32 v123, " IA "\n"
 // S4 with the S2 of step t + 3 and the S1 of step t + 4 in the wait states the butterfly needs (two between a write and a DPP read of it)
-#define LVW_S4(FRIC, S2TEXT_A, S2TEXT_B, S2TEXT_C, S1TEXT, TAIL, P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
+#define LVW_S4(FRIC, S2TEXT_A, S2TEXT_B, S2TEXT_C, S1TEXT, S1B, TAIL, P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
   "v_mul_f32_e32 v120, " J ", v123\n" \
   "v_cndmask_b32_e64 v120, 0, v120, " SON "\n" \
   S2TEXT_A \
@@ -173,6 +184,7 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
   "v_mov_b32_e32 v122, " L0 "\n" \
   TAIL \
   LVW_DPP("row_mirror") \
+  S1B \
   "v_sub_f32_dpp v121, " HWA ", v120" LVW_QP(1) \
   "v_fmac_f32_dpp v122, " HWA ", v121" LVW_QP(0) \
   FRIC("v_mul_f32_dpp v121, " HWA ", " LN LVW_QP(3)) \
@@ -197,23 +209,22 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
   "s_waitcnt vmcnt(2)\n" \
   LVS_APPLY(LVW_S3, FRIC, LBL, N1) \
   "s_waitcnt lgkmcnt(1)\n" \
-  LVS_APPLY(LVW_S4, FRIC, LVS_APPLY(LVW_S2_A, N3), LVS_APPLY(LVW_S2_B, N3), LVS_APPLY(LVW_S2_C, N3), LVW_S1(LVS_APPLY(LVW_RID, C), OFF), TAIL, C)
+  LVS_APPLY(LVW_S4, FRIC, LVS_APPLY(LVW_S2_A, N3), LVS_APPLY(LVW_S2_B, N3), LVS_APPLY(LVW_S2_C, N3), LVW_S1(LVS_APPLY(LVW_RID, C), OFF), LVW_S1B(LVS_APPLY(LVW_RID, C)), TAIL, C)
 #define LVW_BODY(FRIC) \
     "s_mov_b64 s[50:51], exec\n" \
     "s_mov_b64 exec, -1\n" \
     "s_mov_b32 s60, %[nst1]\n" \
     /* prime: row indices of steps 0..3, headers of 0..2, the S3 of step 0 before the S2 of step 2 (so that a far pair of step 0 is older than the two loads the first vmcnt(2) leaves in flight) */ \
-    LVW_S1("v88", "0") LVW_S1("v98", "4") LVW_S1("v108", "8") LVW_S1("v118", "12") \
-    "s_waitcnt lgkmcnt(0)\n" \
+    LVW_PRIME \
     LVS_APPLY(LVW_S2, LVW_SL0) LVS_APPLY(LVW_S2, LVW_SL1) \
     "s_waitcnt vmcnt(2)\n" \
     LVS_APPLY(LVW_S3, FRIC, "7", LVW_SL0) \
     LVS_APPLY(LVW_S2, LVW_SL2) \
     "8:\n" \
-    LVW_ITER(FRIC, "1", "16", "s_nop 0\n", LVW_SL0, LVW_SL1, LVW_SL3) \
-    LVW_ITER(FRIC, "2", "20", "s_nop 0\n", LVW_SL1, LVW_SL2, LVW_SL0) \
-    LVW_ITER(FRIC, "3", "24", "s_nop 0\n", LVW_SL2, LVW_SL3, LVW_SL1) \
-    LVW_ITER(FRIC, "4", "28", "v_add_u32_e32 %[sa], 16, %[sa]\n", LVW_SL3, LVW_SL0, LVW_SL2) \
+    LVW_ITER(FRIC, "1", "16", LVW_TAIL_STEP, LVW_SL0, LVW_SL1, LVW_SL3) \
+    LVW_ITER(FRIC, "2", "20", LVW_TAIL_STEP, LVW_SL1, LVW_SL2, LVW_SL0) \
+    LVW_ITER(FRIC, "3", "24", LVW_TAIL_STEP, LVW_SL2, LVW_SL3, LVW_SL1) \
+    LVW_ITER(FRIC, "4", "28", LVW_TAIL_LAST, LVW_SL3, LVW_SL0, LVW_SL2) \
     "s_branch 8b\n" \
     "9:\n" \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
@@ -274,7 +285,7 @@ AGX_DEV bool pgs_lvw(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
   wave_sync();
   const int rowsA4 = lane < nsA ? lvw_rows4(ssA) : 0, rowsF4 = lane < nsF ? lvw_rows4(ssF) : 0;
   const int nFull = lvw_compact(lds, LIST_FULL, lane, ssA, rowsA4);
-  int nRed = 0;
+  int nRed = 0, nF = 0, actF = -1;
   int stat_steps = 0, stat_rows = 0;                                // debug launches only: steps executed, rows visited (tools/gpu_solve_streams.py)
   const bool stats = c.dbg != nullptr;
   const int K = noop_period(c);                                     // the no-op re-test rule: see pgs()
@@ -301,9 +312,10 @@ AGX_DEV bool pgs_lvw(Ctx& c, float* lds, int lds_words, float& dv0, float& dv1) 
       }
       uint32_t ssd = ss;
       if (dir) for (int j = 0; j < LVW_NG; j++) if (lvw_row(ss, j) != HW_DUMMY) ssd += (uint32_t)nc << (8 * j);      // the same steps, the rows of the second direction
-      const int nF = lvw_compact(lds, LIST_F, lane, ssd, act & rowsF4);
+      act &= rowsF4;
+      if (two_dirs || wave_any(act != actF)) { nF = lvw_compact(lds, LIST_F, lane, ssd, act); actF = act; }      // (the list of the last sweep serves while the same rows are due)
       lvw_part(Y, lane, LIST_F, nF, true);
-      if (stats) { stat_steps += nF; stat_rows += wave_sum_i(__builtin_popcount(act & rowsF4)); }
+      if (stats) { stat_steps += nF; stat_rows += wave_sum_i(__builtin_popcount(act)); }
     }
   }
   wave_sync();

@@ -969,6 +969,16 @@ static int row_art_entries(const sim_t* s, const row_t* r) {
  * (collider a, collider b, ordinal inside the pair); one environment at a time (the sensitivity study), cleared by agxo_warm_clear() */
 static int g_warm_n = 0, g_warm_key[MAXC][3]; static double g_warm_lam[MAXC];
 void agxo_warm_clear(void) { g_warm_n = 0; g_mp_n = 0; }
+/* test hooks (tests/diag/resting_contact_sensitivity.py): the warm-start memory as rows of 4 doubles {collider a, collider b, ordinal, impulse} */
+int agxo_warm_get(double* out, int max_out) {
+  int n = g_warm_n < max_out ? g_warm_n : max_out;
+  for (int p = 0; p < n; p++) { out[4 * p] = g_warm_key[p][0]; out[4 * p + 1] = g_warm_key[p][1]; out[4 * p + 2] = g_warm_key[p][2]; out[4 * p + 3] = g_warm_lam[p]; }
+  return n;
+}
+void agxo_warm_set(const double* in, int n) {
+  g_warm_n = n < MAXC ? n : MAXC;
+  for (int p = 0; p < g_warm_n; p++) { g_warm_key[p][0] = (int)in[4 * p]; g_warm_key[p][1] = (int)in[4 * p + 1]; g_warm_key[p][2] = (int)in[4 * p + 2]; g_warm_lam[p] = in[4 * p + 3]; }
+}
 static void build_rows(sim_t* s) {
   const agxo_model* m = s->m; int n = s->ndof;
   double dt = m->dt, erp = PARAM(m, AGX_P_ERP), cerp = PARAM(m, AGX_P_CONTACT_ERP);

@@ -131,6 +131,16 @@ class Oracle:
         self.L.agxo_manifold_stats(_p(out))
         return out
 
+    def warm_get(self):
+        """the warm-start memory (AGX_P_WARMSTART): rows {collider a, collider b, ordinal inside the pair, impulse}"""
+        out = np.zeros((96, 4))
+        self.L.agxo_warm_get.restype = C.c_int
+        return out[:self.L.agxo_warm_get(_p(out), C.c_int(96))].copy()
+
+    def warm_set(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        self.L.agxo_warm_set(_p(rows), C.c_int(len(rows)))
+
     def forget_warm(self):
         """the process-wide warm-start memory of the AGX_P_WARMSTART switch (one environment at a time): cleared"""
         self.L.agxo_warm_clear()

@@ -62,6 +62,10 @@ def _compare(blob, oracle, before, act, obs, rew, info, picks, label, cloth=None
         worst['reward'] = max(worst['reward'], d / max(1.0, abs(o_rew)))
         assert info[i, 1] == o_info[1], (label, i, 'task_success', info[i, 1], o_info[1])
         judged += int(bool(cache))
+    if os.environ.get('AGX_DUMP_BENCH_STATES'):        # the compared states for a CPU study (tests/diag/resting_contact_sensitivity.py --from <file>)
+        os.makedirs(os.environ['AGX_DUMP_BENCH_STATES'], exist_ok=True)
+        np.savez(os.path.join(os.environ['AGX_DUMP_BENCH_STATES'], 'bench_size_%s.npz' % label), picks=np.array(picks), state=before[picks], action=act[picks],
+                 obs=obs[picks], reward=rew[picks], info=info[picks])
     print('%s: bench-size parity over %d of 4096 environments: worst pose %.2e, reward %.2e (relative), force %.2e (relative); contact-count flips %d (compared too); '
           'environments that needed a conditioning level %d' % (label, len(picks), worst['pose'], worst['reward'], worst['force'], flips, judged))
     return worst, flips, judged

@@ -24,7 +24,7 @@ line() { python - "$1" <<'PY'
 import json, sys
 try:
     j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print('  %s: %.0f env-steps/s, %.3f ms/step' % (sys.argv[1].split('/')[-1], j['value'], j['ms_per_step']), {k: round(v) for k, v in j.items() if k.startswith('value_')},
+    print('  %s: %.0f env-steps/s, %.3f ms/step' % (sys.argv[1].split('/')[-1], j['value'], j['ms_per_step']), {k: round(v) for k, v in j.items() if k.startswith('value_') and not isinstance(v, str)},
           'solve ms/launch %.4f' % j['roofline']['kernel_ms_per_launch'] if 'roofline' in j else '')
     for k, v in j.get('configs', {}).items(): print('     ', k, round(v['value']), v.get('contacts_per_substep'))
 except Exception as e:
@@ -35,7 +35,7 @@ for A in "$@"; do
   K=${A%%:*}; V=${A#*:}; [ "$K" = "$A" ] && V=""
   echo "== $A"
   case $K in
-    suite) AGX_CONDITIONING_REPORT=$O/conditioning_tally_gpu.json timeout 2700 python -m pytest tests -m gpu -q -rs > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log; grep -E "^FAILED|^ERROR|passed|failed|oracle comparisons" $O/pytest_gpu.log | tail -16 ;;
+    suite) AGX_DUMP_BENCH_STATES=$O/bench_states AGX_CONDITIONING_REPORT=$O/conditioning_tally_gpu.json timeout 2700 python -m pytest tests -m gpu -q -rs > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log; grep -E "^FAILED|^ERROR|passed|failed|oracle comparisons" $O/pytest_gpu.log | tail -16 ;;
     tests) N=$(echo "$V" | tr -c 'A-Za-z0-9' '_'); timeout 1800 python -m pytest tests -m gpu -q -rs -k "$V" > $O/pytest_$N.log 2>&1; echo "rc=$?"; grep -E "^FAILED|^ERROR|passed|failed" $O/pytest_$N.log | tail -12 ;;
     file) N=$(basename "$V" .py); timeout 1800 python -m pytest "$V" -m gpu -q -rs -x > $O/pytest_$N.log 2>&1; echo "rc=$?"; grep -E "^FAILED|^ERROR|passed|failed|Error" $O/pytest_$N.log | tail -12 ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log ;;
