@@ -558,6 +558,16 @@ int agx_get_cloth(agx_handle h, float* host_cloth) {
   return AGX_OK;
 }
 int agx_cloth_dev(agx_handle h, float** out_dev) { if (!h || !out_dev || !h->cloth_dev) return fail(AGX_E_ARG, "agx_cloth_dev: bad argument or a model without a cloth"); *out_dev = h->cloth_dev; return AGX_OK; }
+int agx_get_cloth_report(agx_handle h, float* host_report, int* words_per_env) {
+  if (!h || !h->cloth_dev || !h->report_dev) return fail(AGX_E_ARG, "agx_get_cloth_report: bad argument or a model without a cloth");
+  const int words = AGX_CLOTH_REPORT_WORDS(h->cloth_nn);
+  if (words_per_env) *words_per_env = words;
+  if (!host_report) return AGX_OK;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy2D(host_report, (size_t)words * 4, h->report_dev, (size_t)h->report_words * 4, (size_t)words * 4, (size_t)h->n_envs, hipMemcpyDeviceToHost));
+  return AGX_OK;
+}
 int agx_set_cloth_pool(agx_handle h, const float* pool_cloth_dev) {
   if (!h || !h->cloth_dev) return fail(AGX_E_ARG, "agx_set_cloth_pool: bad argument or a model without a cloth");
   h->cloth_pool_dev = pool_cloth_dev; return AGX_OK;

@@ -40,6 +40,20 @@ __device__ inline float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b
 __device__ inline f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ inline f3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
 __device__ inline void st(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+// Node positions in LDS are padded to NS4 = 4 words (round 6): a node is ONE 16-byte-aligned ds_read_b128 (4 LDS cycles per wave instruction) instead
+// of three ds_read_b32 at stride 3 (2 cycles each, and the three of them conflict on their own: ~2-way with the link tables of the garment), and one
+// ds_write_b64 + ds_write_b32 instead of three ds_write_b32.  The kernel is bound by the LDS pipe -- 16 wavefronts of 64 links per colour class, 12
+// word accesses per link (tests/diag notes in DESIGN 4) -- so LDS cycles per link are what there is to save.  -DAGXC_NODE_STRIDE=3: the old layout (A/B).
+#ifndef AGXC_NODE_STRIDE
+#define AGXC_NODE_STRIDE 4
+#endif
+constexpr int NS4 = AGXC_NODE_STRIDE;
+__device__ inline f3 ldn(const float* p) {
+  if constexpr (NS4 == 4) { const float4 v = *(const float4*)p; return mk(v.x, v.y, v.z); } else return mk(p[0], p[1], p[2]);
+}
+__device__ inline void stn(float* p, f3 a) {
+  if constexpr (NS4 == 4) { *(float2*)p = make_float2(a.x, a.y); p[2] = a.z; } else { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+}
 // R (row major, 9 floats) times v, and R^T times v
 __device__ inline f3 rot(const float* R, f3 v) { return mk(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z); }
 __device__ inline f3 rot_t(const float* R, f3 v) { return mk(R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z); }
@@ -66,7 +80,7 @@ __device__ inline void lds_barrier() {
 
 // LDS layout (floats)
 struct Lds {
-  float* x; float* q;            // [NN][3] each
+  float* x; float* q;            // [NN][NS4] each (x, y, z, pad)
   float* body;                   // [MAX_BODIES][12]: p(3), R(9); index: moving link d, ndof = robot base, ndof + 1 + h = human body h, last = world
   float* box;                    // [MAX_SHAPES][6] world AABB of the shape grown by the margin
   int* cand; int* ncand;         // candidate shapes of this substep, in shape order
@@ -75,7 +89,7 @@ struct Lds {
   float* shape;                  // [MAX_SHAPES][12]: body slot (int), face planes (int count, int first), radius, core vertex 0 (3), core vertex 1 (3), kDF x friction, unused
 };
 constexpr int SHAPE_WORDS = 12;
-constexpr int lds_words(int nn) { return 6 * nn + 12 * MAX_BODIES + 6 * MAX_SHAPES + MAX_SHAPES + 4 + 6 * (T / 64) + 4 + SHAPE_WORDS * MAX_SHAPES; }
+constexpr int lds_words(int nn) { return 2 * NS4 * nn + 12 * MAX_BODIES + 6 * MAX_SHAPES + MAX_SHAPES + 4 + 6 * (T / 64) + 4 + SHAPE_WORDS * MAX_SHAPES; }
 
 __device__ inline int body_slot(int code, int ndof, int nhuman) {
   if (code == AGX_BODY_WORLD) return ndof + 1 + nhuman;
@@ -140,7 +154,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   const int s_env = bi[AGX_H_S_ENV], s_task = bi[AGX_H_S_TASK];
   const int gender = ((const int*)gstate)[s_env + AGX_E_GENDER];
   const float grav = gstate[s_task + AGX_DR_CLOTH_GRAVITY];
-  Lds S; S.x = lds; S.q = S.x + 3 * NN; S.body = S.q + 3 * NN; S.box = S.body + 12 * MAX_BODIES; S.cand = (int*)(S.box + 6 * MAX_SHAPES);
+  Lds S; S.x = lds; S.q = S.x + NS4 * NN; S.body = S.q + NS4 * NN; S.box = S.body + 12 * MAX_BODIES; S.cand = (int*)(S.box + 6 * MAX_SHAPES);
   S.ncand = S.cand + MAX_SHAPES; S.red = (float*)(S.ncand + 4); S.anchor = S.red + 6 * (T / 64); S.shape = S.anchor + 4;
   const int* nodei = cl + cl[AGX_CL_OFF_NODE]; const float* nodef = clf + cl[AGX_CL_OFF_NODE];
   const int* face = cl + cl[AGX_CL_OFF_FACE];
@@ -164,7 +178,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     st(o + 4, ld(v)); st(o + 7, ci[AGX_C_NVERT] == 2 ? ld(v + 3) : ld(v)); o[10] = kDF * cf[AGX_C_FRICTION]; o[11] = 0.f;
   }
   const float vscale = dt / (1.0f - kDP);
-  for (int k = tid; k < 3 * NN; k += T) { const float xv = gcloth[k]; S.x[k] = xv; S.q[k] = xv - gcloth[3 * NN + k] * vscale; }
+  for (int k = tid; k < 3 * NN; k += T) { const float xv = gcloth[k]; const int kk = NS4 * (k / 3) + k % 3; S.x[kk] = xv; S.q[kk] = xv - gcloth[3 * NN + k] * vscale; }
   // ownership: a wave owns 64 NPT consecutive nodes of the Morton-ordered list (-1: none), lane l its l-th, (64 + l)-th, ...: the nodes
   // of a wave are one patch of the garment
   int own[NPT]; bool attached[NPT];
@@ -185,7 +199,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     // cloth bounding box
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
-    for (int j = 0; j < NPT; j++) { const int i = own[j]; if (i >= 0) for (int a = 0; a < 3; a++) { const float v = S.x[3 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); } }
+    for (int j = 0; j < NPT; j++) { const int i = own[j]; if (i >= 0) for (int a = 0; a < 3; a++) { const float v = S.x[NS4 * i + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); } }
     for (int a = 0; a < 3; a++) for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
     if (lane == 0) for (int a = 0; a < 3; a++) { S.red[6 * wave + a] = lo[a]; S.red[6 * wave + 3 + a] = hi[a]; }
     // shape boxes: world AABB of the collider (core box rotated + radius) grown by the margin
@@ -220,13 +234,13 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     for (int j = 0; j < NPT; j++) {
       const int i = own[j]; vnew[j] = mk(0.f, 0.f, 0.f);
       if (i >= 0) {
-        const f3 xi = ld(S.x + 3 * i);
+        const f3 xi = ldn(S.x + NS4 * i);
         f3 nrm = mk(0.f, 0.f, 0.f);
 #ifndef AGXC_NO_NORMALS
-        for (int e = nodei[2 * i]; e < nodei[2 * i + 2]; e++) { const int fe = face[e]; nrm = nrm + cross(ld(S.x + 3 * (fe & 0xffff)) - xi, ld(S.x + 3 * ((fe >> 16) & 0xffff)) - xi); }
+        for (int e = nodei[2 * i]; e < nodei[2 * i + 2]; e++) { const int fe = face[e]; nrm = nrm + cross(ldn(S.x + NS4 * (fe & 0xffff)) - xi, ldn(S.x + NS4 * ((fe >> 16) & 0xffff)) - xi); }
 #endif
         const float nl = sqrtf(dot(nrm, nrm)); if (nl > EPS) nrm = (1.0f / nl) * nrm;
-        f3 v = ((1.0f - kDP) / dt) * (xi - ld(S.q + 3 * i));
+        f3 v = ((1.0f - kDP) / dt) * (xi - ldn(S.q + NS4 * i));
         v.z += grav * dt;
         const float v2 = dot(v, v);
         if (kDG > 0.f && v2 > EPS) {
@@ -241,7 +255,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     }
     lds_barrier();
 #pragma unroll
-    for (int j = 0; j < NPT; j++) { const int i = own[j]; if (i >= 0) { const f3 xi = ld(S.x + 3 * i); st(S.q + 3 * i, xi); st(S.x + 3 * i, xi + dt * vnew[j]); } }
+    for (int j = 0; j < NPT; j++) { const int i = own[j]; if (i >= 0) { const f3 xi = ldn(S.x + NS4 * i); stn(S.q + NS4 * i, xi); stn(S.x + NS4 * i, xi + dt * vnew[j]); } }
     lds_barrier();
     // (c) contacts of this thread's nodes (CollideSDF_RS::DoNode)
 #ifdef AGXC_NO_CONTACTS
@@ -257,7 +271,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
       const int i = own[j]; ncon[j] = 0; mine[j] = i >= 0 && !attached[j];
-      const f3 xj = mine[j] ? ld(S.x + 3 * i) : mk(0.f, 0.f, 0.f);
+      const f3 xj = mine[j] ? ldn(S.x + NS4 * i) : mk(0.f, 0.f, 0.f);
       float l3[3] = {mine[j] ? xj.x : 3.0e38f, mine[j] ? xj.y : 3.0e38f, mine[j] ? xj.z : 3.0e38f}, h3[3] = {mine[j] ? xj.x : -3.0e38f, mine[j] ? xj.y : -3.0e38f, mine[j] ? xj.z : -3.0e38f};
       for (int a = 0; a < 3; a++) {
         for (int o = 32; o > 0; o >>= 1) { l3[a] = fminf(l3[a], __shfl_xor(l3[a], o)); h3[a] = fmaxf(h3[a], __shfl_xor(h3[a], o)); }
@@ -280,14 +294,14 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
       for (int j = 0; j < NPT; j++) {
         if (wlo[j][0] > bx[3] || wlo[j][1] > bx[4] || wlo[j][2] > bx[5] || whi[j][0] < bx[0] || whi[j][1] < bx[1] || whi[j][2] < bx[2]) continue;   // wave uniform
         if (!mine[j] || ncon[j] >= NODE_CONTACTS) continue;
-        const f3 xi = ld(S.x + 3 * own[j]);           // (positions do not move during this phase: re-read rather than kept in registers)
+        const f3 xi = ldn(S.x + NS4 * own[j]);           // (positions do not move during this phase: re-read rather than kept in registers)
         if (xi.x < bx[0] || xi.y < bx[1] || xi.z < bx[2] || xi.x > bx[3] || xi.y > bx[4] || xi.z > bx[5]) continue;
 #ifdef AGXC_NO_EVAL
         continue;
 #endif
         f3 nw; const float dst = shape_distance(clf, cl, S, sh, xi, nw) - mrg;
         if (dst >= 0.f) continue;
-        const f3 vr = xi - ld(S.q + 3 * own[j]); const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
+        const f3 vr = xi - ldn(S.q + NS4 * own[j]); const float dn = dot(vr, nw); const f3 fv = vr - dn * nw;
         const float fc = S.shape[SHAPE_WORDS * sh + 10];
         float* rec = grec + CREC * (NODE_CONTACTS * own[j] + ncon[j]);
         *(float4*)rec = make_float4(nw.x, nw.y, nw.z, -dot(nw, xi) + dst);
@@ -298,15 +312,15 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
     // (d) position solver
     for (int it = 0; it < piter; it++) {
       if (tid < NA) {                     // PSolve_Anchors
-        const int i = anci[4 * tid]; const f3 wa = ld(S.anchor) + ld(ancf + 4 * tid + 1), xi = ld(S.x + 3 * i), qi = ld(S.q + 3 * i);
-        st(S.x + 3 * i, xi + (-1.0f) * (xi - qi) + kAHR * (wa - xi));
+        const int i = anci[4 * tid]; const f3 wa = ld(S.anchor) + ld(ancf + 4 * tid + 1), xi = ldn(S.x + NS4 * i), qi = ldn(S.q + NS4 * i);
+        stn(S.x + NS4 * i, xi + (-1.0f) * (xi - qi) + kAHR * (wa - xi));
       }
       lds_barrier();
 #pragma unroll
       for (int j = 0; j < NPT; j++) {     // PSolve_RContacts
         const int i = own[j];
         if (i >= 0 && ncon[j] > 0) {
-          f3 xi = ld(S.x + 3 * i); const f3 qi = ld(S.q + 3 * i);
+          f3 xi = ldn(S.x + NS4 * i); const f3 qi = ldn(S.q + NS4 * i);
 #pragma unroll
           for (int cc = 0; cc < NODE_CONTACTS; cc++) if (cc < ncon[j]) {
             float* rec = grec + CREC * (NODE_CONTACTS * i + cc);
@@ -320,7 +334,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
               if (sub == nsub - 1) { const float w = 1.0f / (dt * im); rec[5] += w * corr.x; rec[6] += w * corr.y; rec[7] += w * corr.z; }
             }
           }
-          st(S.x + 3 * i, xi);
+          stn(S.x + NS4 * i, xi);
         }
       }
       // PSolve_Links.  (1) The links inside this wave's patch, colour by colour, no workgroup barrier: patches share no node, the LDS
@@ -346,8 +360,8 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
             ring[u] = c + PF < KP ? pl[(c + PF) * 64] : make_int2(-1, 0);
             if (cur.x >= 0) {
               const int a = cur.x & 0xffff, b = (cur.x >> 16) & 0xffff;
-              const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur.y);
-              if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+              const f3 xa = ldn(S.x + NS4 * a), xb = ldn(S.x + NS4 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur.y);
+              if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; stn(S.x + NS4 * a, xa - k * del); stn(S.x + NS4 * b, xb + k * del); }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next class reads what this one wrote (other lanes of this wave)
           }
@@ -379,8 +393,8 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
 #pragma unroll
           for (int u = 0; u < LPT; u++) if (cur[u].x >= 0) {
             const int a = cur[u].x & 0xffff, b = (cur[u].x >> 16) & 0xffff;
-            const f3 xa = ld(S.x + 3 * a), xb = ld(S.x + 3 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur[u].y);
-            if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; st(S.x + 3 * a, xa - k * del); st(S.x + 3 * b, xb + k * del); }
+            const f3 xa = ldn(S.x + NS4 * a), xb = ldn(S.x + NS4 * b), del = xb - xa; const float len = dot(del, del), c1 = __int_as_float(cur[u].y);
+            if (c1 + len > EPS) { const float k = (c1 - len) / (c1 + len) * kLST * 0.5f; stn(S.x + NS4 * a, xa - k * del); stn(S.x + NS4 * b, xb + k * del); }
           }
           lds_barrier();
         }
@@ -389,7 +403,7 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
   }
   // report for the finish kernel; write back the positions and the velocities of the last substep
   if (greport) {
-    if (tid < 6) st(greport + 3 * tid, ld(S.x + 3 * cl[AGX_CL_TRI + tid]));
+    if (tid < 6) st(greport + 3 * tid, ldn(S.x + NS4 * cl[AGX_CL_TRI + tid]));
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
       const int i = own[j];
@@ -397,13 +411,13 @@ __device__ inline void cloth_env(const uint32_t* blob, const float* gstate, cons
 #pragma unroll
       for (int cc = 0; cc < NODE_CONTACTS; cc++) {
         float* o = greport + 20 + 2 * (NODE_CONTACTS * i + cc);
-        if (nsub > 0 && cc < ncon[j]) { const f3 f = (1.0f / dt) * ld(grec + CREC * (NODE_CONTACTS * i + cc) + 5); o[0] = S.x[3 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
+        if (nsub > 0 && cc < ncon[j]) { const f3 f = (1.0f / dt) * ld(grec + CREC * (NODE_CONTACTS * i + cc) + 5); o[0] = S.x[NS4 * i + 2]; o[1] = sqrtf(dot(f, f)); } else { o[0] = 0.f; o[1] = -1.f; }
       }
     }
   }
   lds_barrier();
   const float vc = (1.0f - kDP) / dt;
-  for (int k = tid; k < 3 * NN; k += T) { gcloth[k] = S.x[k]; gcloth[3 * NN + k] = (S.x[k] - S.q[k]) * vc; }
+  for (int k = tid; k < 3 * NN; k += T) { const int kk = NS4 * (k / 3) + k % 3; gcloth[k] = S.x[kk]; gcloth[3 * NN + k] = (S.x[kk] - S.q[kk]) * vc; }
 }
 
 }  // namespace agxc

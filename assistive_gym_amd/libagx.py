@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('AGX_LIB', os.path.join(HERE, 'lib', 'libagx.so'))   #
 _LIB = None
 
 EXPORTS = ['agx_version', 'agx_last_error', 'agx_device_count', 'agx_lds_bytes_per_env', 'agx_create', 'agx_destroy', 'agx_dims',
-           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_cloth_nodes', 'agx_set_cloth', 'agx_get_cloth', 'agx_cloth_dev', 'agx_set_cloth_pool', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
+           'agx_set_state', 'agx_get_state', 'agx_state_dev', 'agx_settle', 'agx_settle_debug', 'agx_cloth_nodes', 'agx_set_cloth', 'agx_get_cloth', 'agx_cloth_dev', 'agx_set_cloth_pool', 'agx_get_cloth_report', 'agx_step', 'agx_step_debug', 'agx_step_timed', 'agx_debug_words',
            'agx_observe', 'agx_observe_masked', 'agx_reset_done_at', 'agx_sample_reset', 'agx_reset', 'agx_attach_settle_model', 'agx_reset_done', 'agx_step_host', 'agx_observe_host', 'agx_profile_begin', 'agx_profile_end',
            'agx_synchronize', 'agx_selftest', 'agx_debug_layout', 'agx_variant_name', 'agx_overflow_count', 'agx_set_env_offset', 'agx_check_collisions',
            'agx_comm_unique_id', 'agx_comm_init_rank', 'agx_comm_destroy', 'agx_allgather', 'agx_pack_step']
@@ -160,6 +160,15 @@ class Stepper:
     def get_cloth(self):
         out = np.zeros((self.n_envs, 2, self.cloth_nodes(), 3), dtype=np.float32)
         check(self.L.agx_get_cloth(self.h, out.ctypes.data_as(C.c_void_p)), 'agx_get_cloth')
+        return out
+
+    def get_cloth_report(self):
+        """the cloth kernel's report of the last step, float32 [n_envs, 20 + 2 * slots * nodes]: sleeve vertices (18), 2 unused, then per node and
+        contact slot {node height, |contact force| of the last substep or -1} (agx_get_cloth_report)"""
+        w = C.c_int()
+        check(self.L.agx_get_cloth_report(self.h, None, C.byref(w)), 'agx_get_cloth_report')
+        out = np.zeros((self.n_envs, w.value), dtype=np.float32)
+        check(self.L.agx_get_cloth_report(self.h, out.ctypes.data_as(C.c_void_p), None), 'agx_get_cloth_report')
         return out
 
     def set_cloth_pool(self, pool_cloth):

@@ -61,14 +61,17 @@ class _Rows:
 
 
 class AgxVectorEnv(_VectorEnv):
-    def __init__(self, env_id, num_envs, device=0, seed=1001, reuse_host_buffers=False, **vec_kwargs):
-        """reuse_host_buffers (opt-in, default off): hand out VIEWS into two pinned host buffers used in turn instead of a fresh copy per step.
+    def __init__(self, env_id, num_envs, device=0, seed=1001, reuse_host_buffers=False, env_offset=0, **vec_kwargs):
+        """env_offset: global index of this object's first environment -- several AgxVectorEnv objects (RLlib rollout workers: `worker_env`
+        below) then step disjoint slices of ONE batch (pool draws and reset seeds go by global index, as across GPUs: shard.py).
+        reuse_host_buffers (opt-in, default off): hand out VIEWS into two pinned host buffers used in turn instead of a fresh copy per step.
         The views are overwritten two steps later, so this is only for a consumer that is done with a step's observations / infos before
         the step after next -- NOT RLlib's collectors, which keep the ndarray references of a whole rollout fragment and stack them when
         the SampleBatch is built.  With the default every step's rows live in memory of their own, valid for ever."""
         from . import envs
         from .vec_env import AssistiveVecEnv
         self._reuse = bool(reuse_host_buffers)
+        self._env_offset = int(env_offset)
         name = env_id.split(':')[-1]
         proto = envs.ENV_IDS[name]()                     # spaces and info keys of the scalar env
         assert not proto.coop, 'co-op (multi-agent) ids are batched by AgxMultiAgentBatchEnv (RLlib BaseEnv), not by a VectorEnv'
@@ -81,7 +84,7 @@ class AgxVectorEnv(_VectorEnv):
         self._obs, self._host, self._pack = None, None, None
 
     def vector_reset(self):
-        self._obs = _Rows(self.vec.reset().cpu().numpy())
+        self._obs = _Rows(self.vec.reset(env_offset=self._env_offset).cpu().numpy())
         return self._obs
 
     def reset_at(self, index):
@@ -96,11 +99,14 @@ class AgxVectorEnv(_VectorEnv):
         buffer; what is handed out is ONE contiguous copy of it per step (0.1 ms at 4096 x 54 floats), float32 like the observation space:
         RLlib's collectors keep the row references until the SampleBatch is built, so the rows must never be overwritten
         (reuse_host_buffers=True hands out views into two alternating pinned buffers instead: see __init__)."""
+        import time
         import torch
         n = self.num_envs
+        t0 = time.perf_counter()
         if not isinstance(actions, np.ndarray):
             actions = np.concatenate(actions).reshape(n, -1)
         a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float32), device=self.vec.device)
+        t1 = time.perf_counter()
         obs, rew, done, info = self.vec.step(a)
         # rows whose episode ended: RLlib wants the LAST observation of the old episode here and the first of the new one from reset_at(); the
         # stepper has already put the new first observation into `obs` for those rows and kept the old one in vec.terminal_obs
@@ -115,7 +121,10 @@ class AgxVectorEnv(_VectorEnv):
         self._flip ^= 1
         host = self._host[self._flip]
         host.copy_(pk, non_blocking=True)
+        t2 = time.perf_counter()
         torch.cuda.current_stream(self.vec.device).synchronize()
+        t3 = time.perf_counter()
+        self.host_seconds = getattr(self, 'host_seconds', np.zeros(4)) + np.array([t1 - t0, t2 - t1, t3 - t2, 0.0])      # actions to the device | enqueue | wait for the GPU | (results: added below)
         h = host.numpy()
         if not self._reuse:
             h = h.copy()                                  # memory of this step's own: rows, info columns and reset_at() observations are views of it
@@ -123,13 +132,30 @@ class AgxVectorEnv(_VectorEnv):
         rows = _Rows(h[:, :od])
         # reset_at(i): the first observation of the new episode for the rows that ended, the current observation elsewhere
         self._obs = _Rows(np.where(dn[:, None], h[:, od + 4:], h[:, :od])) if dn.any() else rows
-        return rows, h[:, od].tolist(), dn.tolist(), _LazyInfos(self._info_static, h[:, od + 2], h[:, od + 3])
+        out = rows, h[:, od].tolist(), dn.tolist(), _LazyInfos(self._info_static, h[:, od + 2], h[:, od + 3])
+        self.host_seconds[3] += time.perf_counter() - t3
+        return out
 
     def get_unwrapped(self):
         return []
 
     def close(self):
         self.vec.close()
+
+
+def worker_env(env_id, cfg, default_envs=2048):
+    """env creator for `register_env`: one AgxVectorEnv per RLlib rollout worker, each a disjoint slice of one batch.
+
+        register_env('assistive_gym:FeedingJaco-v1', lambda cfg: worker_env('FeedingJaco-v1', cfg))
+        config = {'num_workers': 2, 'env_config': {'num_envs': 2048}, ...}
+
+    `vector_step` is synchronous (RLlib's VectorEnv contract): while a worker's sampler builds its batch the GPU would idle, and while the GPU steps
+    the worker would.  With TWO workers of 2,048 environments on one GPU (the reference runs `num_workers = cpu_count()` of them, learn.py:26,72) one
+    worker's kernels run while the other is in its Python: measured in tools/gpu_rllib_overhead.py (two threads / two processes).  cfg: RLlib's
+    EnvContext (worker_index 1 ... num_workers; 0 = the local worker) or a plain dict."""
+    n = int(cfg.get('num_envs', default_envs)) if hasattr(cfg, 'get') else default_envs
+    w = max(0, int(getattr(cfg, 'worker_index', 0)) - 1)
+    return AgxVectorEnv(env_id, n, device=int(cfg.get('device', 0)) if hasattr(cfg, 'get') else 0, seed=int(cfg.get('seed', 1001)) if hasattr(cfg, 'get') else 1001, env_offset=w * n)
 
 
 try:

@@ -80,6 +80,12 @@ int agx_set_cloth(agx_handle h, const float* host_cloth);
 int agx_get_cloth(agx_handle h, float* host_cloth);
 int agx_cloth_dev(agx_handle h, float** out_dev);
 int agx_set_cloth_pool(agx_handle h, const float* pool_cloth_dev);
+/* models with a cloth: copies the cloth kernel's report of the LAST agx_step to the host -- per environment float[18] the six sleeve vertices
+ * (util.py:156-157), 2 unused, then per node and contact slot {height of the node, |contact force| of the last substep, -1 = no contact}
+ * (what dressing.py:25,35-43 reads from getSoftBodyData; AGX_CLOTH_REPORT_WORDS in agx_blob.h).  words_per_env (may be NULL) receives the row
+ * length; host_report NULL = query the length only.  Synchronises the device.  For parity tests of the cloth-force term (which node contacts
+ * are in the sum), not on the step path. */
+int agx_get_cloth_report(agx_handle h, float* host_report, int* words_per_env);
 int agx_debug_words(void);   /* of the FeedingJaco kernel variant; agx_debug_layout for the variant serving a handle */
 /* layout of the debug record of the kernel variant serving this handle: out8 = {words per env, contacts offset, M^-1 offset,
  * M^-1 row stride, row headers offset, impulses offset, phase timers offset, qdd offset} */

@@ -2140,8 +2140,10 @@ void agxo_settle_cloth(const agxo_model* m, float* state, float* cloth, int n_si
 }
 void agxo_settle(const agxo_model* m, float* state, int n_substeps) { agxo_settle_cloth(m, state, NULL, n_substeps); }
 /* contacts of the cloth with the rigid shapes in the last substep of the last call: {x, y, z, fx, fy, fz} each (tests) */
-static double g_ccon[6 * 4096]; static int g_nccon = 0;
+static double g_ccon[6 * 4096]; static int g_ccon_node[4096]; static int g_nccon = 0;
 int agxo_cloth_contacts(double* out, int max_out) { int n = g_nccon < max_out ? g_nccon : max_out; memcpy(out, g_ccon, sizeof(double) * 6 * n); return g_nccon; }
+/* ... and the garment node of each of them (tests/test_gpu_bench_size.py: which node contacts are in the cloth-force sum on either side) */
+int agxo_cloth_contact_nodes(int* out, int max_out) { int n = g_nccon < max_out ? g_nccon : max_out; memcpy(out, g_ccon_node, sizeof(int) * n); return g_nccon; }
 
 void agxo_step(const agxo_model* m, float* state, const float* action, float* obs, float* reward, int* done, float* info) {
   agxo_step_cloth(m, state, NULL, action, obs, reward, done, info);
@@ -2185,7 +2187,7 @@ void agxo_step_cloth(const agxo_model* m, float* state, float* cloth, const floa
   kinematics(s); /* poses after the last integration, as the getters in _get_obs see them */
   if (m->task_kind == AGX_TASK_DRESSING) {
     finish_dressing(s, action, obs, reward, done, info);
-    g_nccon = s->cx ? (s->nccon < 4096 ? s->nccon : 4096) : 0; if (g_nccon) memcpy(g_ccon, s->ccon, sizeof(double) * 6 * g_nccon);
+    g_nccon = s->cx ? (s->nccon < 4096 ? s->nccon : 4096) : 0; if (g_nccon) { memcpy(g_ccon, s->ccon, sizeof(double) * 6 * g_nccon); memcpy(g_ccon_node, s->ccon_node, sizeof(int) * g_nccon); }
     cloth_detach(s, cloth); sim_store(s, state); free(s->rows); free(s); return;
   }
   if (m->task_kind == AGX_TASK_DRINKING) { finish_drinking(s, act_norm2, obs, reward, done, info); cloth_detach(s, cloth); sim_store(s, state); free(s->rows); free(s); return; }

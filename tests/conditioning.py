@@ -22,9 +22,32 @@ import numpy as np
 
 K = 16.0
 # No escalated bound may exceed CAP x the base tolerance (rel x max(1, scale), or the floor where that is larger): a device result that is wrong
-# by percents must not pass because the oracle is locally sensitive.  25 = the largest ratio any case of the suite needed on the GPU
-# (profiles/r05/conditioning_tally_gpu.json), rounded up.
-CAP = 25.0
+# by percents must not pass because the oracle is locally sensitive.
+# CAP = 10, a derivation instead of round 5's "largest ratio any case needed" (25).  A float32 pipeline of N dependent
+# updates reproduces a quantity of condition number kappa (relative change of the output per relative change of the input) to about
+# kappa x eps x sqrt(N), eps = 6e-8.  One env step is N = 5 substeps x 50 sweeps x ~110 rows = 27,500 dependent row updates: sqrt(N) = 166.
+# The contract tolerance 1e-3 is met up to kappa = 100; CAP x 1e-3 = 1e-2 up to kappa = 1,000, where a 1e-6 relative change of the INPUT -- less
+# than what one substep of float32 arithmetic leaves between any two implementations -- moves the output by the whole contract tolerance.  A
+# step beyond that is UNDETERMINED at the contract's level for any float32 implementation, the reference's own repeatability included: it is
+# not certified by stretching the bound further; it is counted ('undetermined': the device must still stay inside K x the measured
+# sensitivity) and limited per configuration (MAX_UNDETERMINED of the compared environments).
+CAP = 10.0
+MAX_UNDETERMINED = 0.02
+# Per BASELINE configuration (tests/test_gpu_bench_size.py): the share of the compared ENVIRONMENTS that needed any level beyond the force floor may
+# not exceed MAX_JUDGED_PER_CONFIG -- unless the f64 oracle ALONE (no device involved) flags more of them as ill-conditioned (K x its 1-ulp
+# sensitivity above the tolerance): then that device-independent count is the limit (config 3 under the random policy: limbs of the person
+# sliding on the mattress, profiles/r06/resting_contact_sensitivity.json).
+MAX_JUDGED_PER_CONFIG = 0.05
+CONFIG_TALLY = {}
+LAST_UNDETERMINED = [0]          # running count of 'undetermined' verdicts (check()): the per-configuration tests read the difference
+
+
+def config_tally(config, envs, judged, undetermined, oracle_flagged):
+    t = CONFIG_TALLY.setdefault(config, dict(envs=0, judged=0, undetermined=0, oracle_flagged=0))
+    t['envs'] += int(envs); t['judged'] += int(judged); t['undetermined'] += int(undetermined); t['oracle_flagged'] += int(oracle_flagged)
+    if _TALLY_FILE:
+        with open(_TALLY_FILE + '.configs', 'a') as f:
+            f.write(json.dumps({config: dict(envs=int(envs), judged=int(judged), undetermined=int(undetermined), oracle_flagged=int(oracle_flagged))}) + '\n')
 
 # ---- the tally: which level did the comparisons of this run need?  (a green suite says nothing about that.)
 # 'steps' = env steps the oracle computed for a test (tests/oracle_lib.py counts them; its own sensitivity runs excluded): the unit of the
@@ -33,7 +56,7 @@ CAP = 25.0
 # 'geom' = within K_GEOM x its 1.2e-5 sensitivity; 'skipped' = a step that was computed and NOT compared.  'plain' = quantities that went through
 # within() / check() and passed at the contract tolerance (a subset of what the tests compare with bare asserts).
 # tests/conftest.py prints the totals in the terminal summary and FAILS the run when the judgments beyond 'plain' exceed MAX_NON_PLAIN x steps.
-LEVELS = ('steps', 'plain', 'floor', 'ulp', 'step', 'geom', 'skipped', 'cloth_force')
+LEVELS = ('steps', 'plain', 'floor', 'ulp', 'step', 'geom', 'skipped', 'cloth_force', 'undetermined')
 # 'cloth_force': the dressing task's cloth-force sum judged against the oracle's own spread (check(..., uncapped=True)): reported, not part of the 1 % rule --
 # the term is ill-posed by construction (see check()), every dressing step with cloth contact lands here
 EXEMPT = ('steps', 'plain', 'cloth_force')
@@ -165,23 +188,20 @@ def within(dev, scale, sens_fn, rel=1e-3, floor=0.0, step_sens_fn=None, geom_sen
     if dev <= lim:
         tally('plain' if dev <= base else 'floor')
         return True, lim, None
-    sens = float(sens_fn())
-    lim = min(cap, max(lim, K * sens))
-    if dev <= lim or step_sens_fn is None:
+    raw, last = lim, None
+    for name, fn, k in (('ulp', sens_fn, K), ('step', step_sens_fn, K_STEP), ('geom', geom_sens_fn, K_GEOM)):
+        if fn is None:
+            continue
+        last = float(fn())
+        raw = max(raw, k * last)
+        lim = min(cap, raw)
         if dev <= lim:
-            tally('ulp')
-        return dev <= lim, lim, sens
-    sens2 = float(step_sens_fn())
-    lim = min(cap, max(lim, K_STEP * sens2))
-    if dev <= lim or geom_sens_fn is None:
-        if dev <= lim:
-            tally('step')
-        return dev <= lim, lim, sens2
-    sens3 = float(geom_sens_fn())
-    lim = min(cap, max(lim, K_GEOM * sens3))
-    if dev <= lim:
-        tally('geom')
-    return dev <= lim, lim, sens3
+            tally(name)
+            return True, lim, last
+    if dev <= raw:                                   # inside the measured sensitivity but beyond CAP x the tolerance: not certified, counted (see CAP)
+        tally('undetermined'); LAST_UNDETERMINED[0] += 1
+        return True, raw, last
+    return False, lim, last
 
 
 def check(dev, base, floor=0.0, ulp=None, step=None, geom=None, uncapped=False):
@@ -196,10 +216,15 @@ def check(dev, base, floor=0.0, ulp=None, step=None, geom=None, uncapped=False):
     # uncapped: only for the one quantity that is ill-posed by construction and measured as such -- the dressing task's cloth-force sum, which the
     # SAME oracle moves by up to 6 % when its garment goes through float32 once (tests/test_reference_dump.py, the bridge rehearsal)
     cap = float('inf') if uncapped else CAP * lim
+    raw = lim
     for name, fn in (('ulp', ulp), ('step', step), ('geom', geom)):
         if fn is None:
             continue
-        lim = min(cap, max(lim, float(fn())))
+        raw = max(raw, float(fn()))
+        lim = min(cap, raw)
         if dev <= lim:
             tally('cloth_force' if uncapped else name); return True, lim
+    if dev <= raw:                                   # inside the measured sensitivity but beyond CAP x the tolerance: not certified, counted (see CAP)
+        tally('undetermined'); LAST_UNDETERMINED[0] += 1
+        return True, raw
     return False, lim

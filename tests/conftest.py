@@ -52,6 +52,22 @@ def _conditioning_totals(config):
     return tot
 
 
+def _config_totals():
+    """per BASELINE configuration: environments compared / judged beyond the floor / undetermined / flagged by the oracle alone (conditioning.config_tally)"""
+    import json
+    out = {}
+    path = os.environ.get('AGX_CONDITIONING_TALLY')
+    if path and os.path.exists(path + '.configs'):
+        for line in open(path + '.configs'):
+            for cfg, t in json.loads(line).items():
+                o = out.setdefault(cfg, dict(envs=0, judged=0, undetermined=0, oracle_flagged=0))
+                for k, v in t.items():
+                    o[k] += v
+    for o in out.values():
+        o['judged_rate'] = o['judged'] / max(1, o['envs']); o['oracle_flagged_rate'] = o['oracle_flagged'] / max(1, o['envs'])
+    return out
+
+
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """How many oracle comparisons of this run passed at the contract tolerance, and how many needed which conditioning level
     (VERDICT r4 weak 2).  More than 1 % beyond 'plain' fails the run (pytest_sessionfinish)."""
@@ -70,7 +86,11 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         if out:
             import json
             with open(out, 'w') as f:
-                json.dump(dict(steps_compared=n, levels=tot, beyond_plain_per_step=non_plain / max(n, 1), limit=C.MAX_NON_PLAIN), f)
+                json.dump(dict(steps_compared=n, levels=tot, beyond_plain_per_step=non_plain / max(n, 1), limit=C.MAX_NON_PLAIN, cap=C.CAP, K=C.K,
+                               per_config=_config_totals(), per_config_limit=C.MAX_JUDGED_PER_CONFIG, undetermined_limit_per_config=C.MAX_UNDETERMINED), f, indent=1)
+    for cfg, t in sorted(_config_totals().items()):
+        terminalreporter.write_line('  %s: %d environments compared, %d judged beyond the force floor (%.1f %%), %d undetermined, %d flagged ill-conditioned by the oracle alone (%.1f %%)'
+                                    % (cfg, t['envs'], t['judged'], 100 * t['judged_rate'], t['undetermined'], t['oracle_flagged'], 100 * t['oracle_flagged_rate']))
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -28,7 +28,8 @@ def _compare(blob, oracle, before, act, obs, rew, info, picks, label, cloth=None
     fcols = [f] + ([blob.obs_dim - 2, blob.obs_dim - 1] if blob.is_coop else [])
     ff = C.force_floor(blob)
     worst = dict(pose=0.0, reward=0.0, force=0.0)
-    flips, judged = 0, 0
+    flips, judged, flagged = 0, 0, 0
+    und0 = C.LAST_UNDETERMINED[0]
     for i in picks:
         s = before[i].copy()
         c = None if cloth is None else cloth[i].copy()
@@ -62,12 +63,25 @@ def _compare(blob, oracle, before, act, obs, rew, info, picks, label, cloth=None
         worst['reward'] = max(worst['reward'], d / max(1.0, abs(o_rew)))
         assert info[i, 1] == o_info[1], (label, i, 'task_success', info[i, 1], o_info[1])
         judged += int(bool(cache))
+        # device-independent: does the f64 oracle ALONE call this step ill-conditioned (K x its 1-ulp sensitivity above a compared quantity's tolerance)?
+        if cloth is None:
+            sn = sens(None)
+            flagged += int(C.K * float(np.delete(sn['obs'], fcols).max()) > pose_tol or C.K * sn['reward'] > max(1e-3 * max(1.0, abs(o_rew)), 0.06 * ff) or
+                           any(C.K * sn['info'][q] > max(1e-3 * max(1.0, abs(o_info[q])), ff) for q in (0, 2, 3)))
+    undetermined = C.LAST_UNDETERMINED[0] - und0
+    C.config_tally(label, len(picks), judged, undetermined, flagged)
     if os.environ.get('AGX_DUMP_BENCH_STATES'):        # the compared states for a CPU study (tests/diag/resting_contact_sensitivity.py --from <file>)
         os.makedirs(os.environ['AGX_DUMP_BENCH_STATES'], exist_ok=True)
         np.savez(os.path.join(os.environ['AGX_DUMP_BENCH_STATES'], 'bench_size_%s.npz' % label), picks=np.array(picks), state=before[picks], action=act[picks],
                  obs=obs[picks], reward=rew[picks], info=info[picks])
     print('%s: bench-size parity over %d of 4096 environments: worst pose %.2e, reward %.2e (relative), force %.2e (relative); contact-count flips %d (compared too); '
-          'environments that needed a conditioning level %d' % (label, len(picks), worst['pose'], worst['reward'], worst['force'], flips, judged))
+          'environments that needed a conditioning level %d (flagged ill-conditioned by the oracle alone: %d; beyond CAP x the tolerance, counted as undetermined: %d quantities)'
+          % (label, len(picks), worst['pose'], worst['reward'], worst['force'], flips, judged, flagged, undetermined))
+    # per configuration: at most 5 % of the compared environments may need a level -- or as many as the oracle alone flags, where that is more
+    # (a property of the scene, not of the device); at most 2 % of the environments (at least one) may hold an undetermined quantity
+    if cloth is None:
+        assert judged <= max(int(C.MAX_JUDGED_PER_CONFIG * len(picks)), flagged), (label, judged, flagged)
+        assert undetermined <= max(3, int(3 * C.MAX_UNDETERMINED * len(picks))), (label, undetermined)        # (quantities: one ill-conditioned environment holds up to three of them)
     return worst, flips, judged
 
 
@@ -117,7 +131,7 @@ def test_oracle_parity_at_bench_size(config):
     print('%s: contacts per env step during the rollout %.2f' % (config, contacts))
     # (BedBathingSawyer under the random policy: an eighth of the compared environments has the arm on the mattress or the person at that step, where
     # one float32 ulp of the state moves the joint angles by 1e-3: judged against the oracle's own sensitivity and counted in the run's tally)
-    assert flips <= 6 and judged <= (12 if config == 'config3_random' else 6)
+    assert flips <= 6
     env.close()
 
 
@@ -166,6 +180,84 @@ def test_oracle_parity_at_bench_size_dressing():
     env.close()
 
 
+def _worker_init(paths):
+    import sys
+    for p in paths:
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.pop('AGX_CONDITIONING_TALLY', None)
+
+
+def test_cloth_force_distribution_at_bench_size():
+    """The dressing task's cloth-force term (dressing.py:25,35-43: a sum over hundreds of node contacts, each in or out by thresholds) as a DISTRIBUTION
+    (VERDICT r5 next 4a): environment by environment the device's sum deviates from the oracle's by 0.5 ... 9 %, the size of the oracle's own spread under a 1e-6 m
+    perturbation of the garment -- which says nothing about a systematic error hiding inside that spread.  Here 1,024 of the 4,096 environments of a
+    bench-size handle are compared over 5 consecutive steps (5,120 oracle steps, one process per host core):
+      * the MEAN of the device's sums is within 1e-2 of the mean of the oracle's (a bias of the contact rule or of the force filter would show here);
+      * the signed deviations are symmetric: a two-sided sign test does not reject P(device > oracle) = 1/2 at p = 0.01;
+      * reported: the per-environment relative deviation (median, 90 %, max) and the rate at which a garment node is in contact on one side only."""
+    _gpu()
+    import multiprocessing as mp
+    import torch
+    from assistive_gym_amd import vec_env
+    n, npick, nsteps = 4096, 1024, 5
+    env = vec_env.DressingBaxterVecEnv(n, pool_size=32, seed=2707)
+    blob = env.blob
+    env.reset()
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    for k in range(6):
+        env.step(torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1)
+    picks = np.arange(npick) * (n // npick)
+    pk = torch.from_numpy(picks).to(env.device)
+    f = blob.obs_dim_robot - 1
+    nn = env.stepper.cloth_nodes()
+    jobs, dev_sum, dev_nodes, dev_rew = [], [], [], []
+    for k in range(nsteps):
+        torch.cuda.synchronize()
+        st = env.stepper.state_tensor()[pk].cpu().numpy(); cl = env.stepper.cloth_tensor()[pk].cpu().numpy()
+        a = torch.rand((n, env.act_dim), device='cuda', generator=g) * 2 - 1
+        obs, rew, done, info = env.step(a)
+        torch.cuda.synchronize()
+        an = a[pk].cpu().numpy()
+        rep = env.stepper.get_cloth_report()[picks][:, 20:].reshape(npick, nn, -1, 2)           # [env, node, slot, {height, |force|}]
+        for j in range(npick):
+            jobs.append(('dressing_baxter', st[j], cl[j], an[j]))
+            dev_nodes.append(np.flatnonzero((rep[j, :, :, 1] >= 0).any(axis=1)).astype(np.int32))
+        dev_sum += obs[pk, f].cpu().numpy().astype(np.float64).tolist(); dev_rew += rew[pk].cpu().numpy().astype(np.float64).tolist()
+    env.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    import oracle_lib
+    oracle_lib.lib()                                    # (built once, before the workers race for it)
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(min(16, os.cpu_count() or 1), initializer=_worker_init, initargs=([here, os.path.dirname(here)],)) as pool:
+        res = pool.map(oracle_lib.dressing_step_job, jobs, chunksize=8)
+    dev = np.array(dev_sum); orc = np.array([r[0] for r in res]); orew = np.array([r[2] for r in res])
+    d = dev - orc
+    rel = np.abs(d) / np.maximum(1.0, np.abs(orc))
+    pos, neg = int((d > 0).sum()), int((d < 0).sum())
+    from scipy.stats import binomtest
+    p_sign = float(binomtest(pos, pos + neg, 0.5).pvalue) if pos + neg else 1.0
+    bias = float((dev.mean() - orc.mean()) / max(1.0, abs(orc.mean())))
+    only_one, both = 0, 0
+    for dn, r in zip(dev_nodes, res):
+        a_, b_ = set(dn.tolist()), set(r[1].tolist())
+        only_one += len(a_ ^ b_); both += len(a_ | b_)
+    rew_beyond_share = np.maximum(0.0, np.abs(np.array(dev_rew) - orew) - 0.01 * np.abs(d))
+    summary = dict(compared=len(dev), mean_device=float(dev.mean()), mean_oracle=float(orc.mean()), relative_bias_of_the_mean=bias, device_above=pos, device_below=neg, sign_test_p=p_sign,
+                   relative_deviation_median=float(np.median(rel)), relative_deviation_p90=float(np.percentile(rel, 90)), relative_deviation_max=float(rel.max()),
+                   node_contacts_on_one_side_only=only_one, node_contacts_on_either_side=both, node_contact_disagreement_rate=only_one / max(1, both),
+                   environments_with_cloth_contact=int((orc > 0).sum()), reward_beyond_the_cloth_force_share_max=float(rew_beyond_share.max()))
+    print('DressingBaxter cloth-force distribution at the bench size:', summary)
+    if os.environ.get('AGX_DUMP_BENCH_STATES'):
+        import json
+        os.makedirs(os.environ['AGX_DUMP_BENCH_STATES'], exist_ok=True)
+        json.dump(summary, open(os.path.join(os.environ['AGX_DUMP_BENCH_STATES'], 'cloth_force_distribution.json'), 'w'), indent=1)
+    assert (orc > 0).sum() > 0.5 * len(orc), 'the workload has no cloth contact to speak of'
+    assert abs(bias) <= 1e-2, summary
+    assert p_sign >= 0.01, summary
+    assert only_one / max(1, both) < 0.1, summary
+
+
 def test_oracle_parity_at_bench_size_dense_wiping():
     """BASELINE config 3 as BASELINE describes it ("dense tool-skin contact, PGS-heavy"): the scripted press-and-wipe policy of bench.py --workload
     dense (whole episodes with the pad on the arm, several contacts per substep) at 4096 environments; after 30 policy steps one more step from the
@@ -198,5 +290,5 @@ def test_oracle_parity_at_bench_size_dense_wiping():
     print('config3_dense: contacts per substep (last substep of a step, mean over 30 steps) %.2f; environments with a force on the pad %.0f %%; selection rollout %.0f %%'
           % (contacts / 30, 100 * forced / 30, 100 * touching))
     assert contacts / 30 >= 3.0 and forced / 30 > 0.5
-    assert flips <= 8 and judged <= 16
+    assert flips <= 8
     env.close()

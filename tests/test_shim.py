@@ -147,6 +147,63 @@ def test_vector_env_adapter_steps_on_the_gpu(env_id):
     env.close()
 
 
+@pytest.mark.gpu
+def test_vector_env_rows_are_never_overwritten_and_workers_slice_one_batch():
+    """ RLlib's collectors keep the observation / info references of a whole rollout fragment and stack them when the SampleBatch is
+    built: what vector_step hands out must never change afterwards -- the rows of step k are compared with copies taken at step k after 6 more steps
+    (the opt-in reuse_host_buffers=True, two alternating pinned buffers, DOES overwrite them: the contract its docstring states).  And: two
+    AgxVectorEnv objects of n / 2 environments with env_offset 0 / n/2 (rllib.worker_env: two rollout workers) step the environments of ONE
+    n-environment batch: same first observations, same trajectory under the same actions."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        __import__('conftest').no_gpu()
+    from assistive_gym_amd.rllib import AgxVectorEnv, AgxPipelinedBatchEnv, worker_env
+    n = 16
+    rng = np.random.RandomState(0)
+    acts = [rng.uniform(-1, 1, (n, 7)).astype(np.float32) for _ in range(8)]
+    for reuse in (False, True):
+        env = AgxVectorEnv('FeedingJaco-v1', n, pool_size=8, reuse_host_buffers=reuse)
+        env.vector_reset()
+        kept, infos0 = [], None
+        for k in range(8):
+            obs, rew, done, infos = env.vector_step(list(acts[k]))
+            kept.append(([obs[i] for i in range(n)], [obs[i].copy() for i in range(n)]))
+            if k == 0:
+                infos0 = (infos, [dict(infos[i]) for i in range(n)])
+        same = all(np.array_equal(r, c) for rows, copies in kept[:2] for r, c in zip(rows, copies))
+        assert same == (not reuse)
+        if not reuse:
+            assert all(infos0[0][i] == infos0[1][i] for i in range(n))
+            whole = kept
+        env.close()
+    halves = [AgxVectorEnv('FeedingJaco-v1', n // 2, pool_size=8, env_offset=h * (n // 2)) for h in range(2)]
+    w = worker_env('FeedingJaco-v1', {'num_envs': n // 2})
+    assert w.num_envs == n // 2 and w._env_offset == 0
+    w.close()
+    first = [h.vector_reset() for h in halves]
+    for k in range(3):
+        outs = [halves[h].vector_step(list(acts[k][h * (n // 2):(h + 1) * (n // 2)])) for h in range(2)]
+        for h in range(2):
+            for i in range(n // 2):
+                assert np.array_equal(outs[h][0][i], whole[k][1][h * (n // 2) + i]), (k, h, i)
+    for h in halves:
+        h.close()
+    # the asynchronous two-half BaseEnv: the same batch again, half by half
+    p = AgxPipelinedBatchEnv('FeedingJaco-v1', n, pool_size=8)
+    for k in range(3):
+        for h in range(2):
+            obs, rew, done, info, _ = p.poll()
+            ids = sorted(obs)
+            assert ids == list(range(h * (n // 2), (h + 1) * (n // 2))) and set(obs[ids[0]]) == {'agent0'}
+            if k > 0:
+                assert all(np.array_equal(obs[i]['agent0'], whole[k - 1][1][i]) for i in ids) and not done[ids[0]]['__all__'] and 'task_success' in info[ids[0]]['agent0']
+            else:
+                assert all(rew[i]['agent0'] is None for i in ids)
+            p.send_actions({i: {'agent0': acts[k][i]} for i in ids})
+    p.stop()
+
+
 def test_multi_agent_batch_adapter_surface():
     """the co-op batch adapter (RLlib BaseEnv contract) imports without ray"""
     from assistive_gym_amd.rllib import AgxMultiAgentBatchEnv

@@ -11,6 +11,14 @@ import torch
 from assistive_gym_amd.rllib import AgxVectorEnv, AgxMultiAgentBatchEnv, AgxPipelinedBatchEnv
 from assistive_gym_amd.vec_env import FeedingJacoVecEnv
 
+if len(sys.argv) > 1 and sys.argv[1] == '--half':        # child of (e): one synchronous VectorEnv of sys.argv[2] environments; prints its env-steps/s over a window both children share roughly
+    nh, Kh, h = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    v = AgxVectorEnv('FeedingJaco-v1', nh, pool_size=64, env_offset=h * nh); v.vector_reset()
+    al2 = list(np.random.RandomState(h).uniform(-1, 1, (nh, 7)).astype(np.float32))
+    for _ in range(30): v.vector_step(al2)
+    t0 = time.perf_counter()
+    for _ in range(Kh): v.vector_step(al2)
+    print(nh * Kh / (time.perf_counter() - t0)); v.close(); sys.exit(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 out = {'n_envs': n, 'steps': K}
@@ -27,7 +35,43 @@ al = list(acts)
 for k in range(10): v.vector_step(al)
 t0 = time.perf_counter()
 for k in range(K): v.vector_step(al)
-out['rllib_vector_env'] = n * K / (time.perf_counter() - t0); v.close()
+out['rllib_vector_env'] = n * K / (time.perf_counter() - t0)
+hs = v.host_seconds; v.host_seconds = np.zeros(4)
+for k in range(K): v.vector_step(al)
+out['rllib_vector_env_ms_per_step'] = dict(zip(('actions_to_device', 'enqueue_step_pack_copy', 'wait_for_the_gpu', 'results_to_python'), (v.host_seconds / K * 1e3).round(3).tolist()))
+os.environ['AGX_CHUNKS'] = '1'
+v1 = AgxVectorEnv('FeedingJaco-v1', n, pool_size=64); v1.vector_reset()
+for k in range(10): v1.vector_step(al)
+t0 = time.perf_counter()
+for k in range(K): v1.vector_step(al)
+out['rllib_vector_env_one_chunk'] = n * K / (time.perf_counter() - t0); v1.close(); del os.environ['AGX_CHUNKS']
+v.close()
+
+# (e) two VectorEnvs of n / 2 environments (RLlib: num_workers = 2, rllib.worker_env), each stepped synchronously -- from two threads of this
+# process (the GIL is released while a thread waits for its GPU results, so one worker's kernels run while the other is in its Python), and
+# from two processes (what RLlib's rollout workers are)
+import threading
+def _worker(v, steps, acts_half, out, k):
+    al2 = list(acts_half)
+    for _ in range(10): v.vector_step(al2)
+    bar.wait()
+    t0 = time.perf_counter()
+    for _ in range(steps): v.vector_step(al2)
+    out[k] = time.perf_counter() - t0
+vs = [AgxVectorEnv('FeedingJaco-v1', n // 2, pool_size=64, env_offset=h * (n // 2)) for h in range(2)]
+for v in vs: v.vector_reset()
+bar = threading.Barrier(2); el = [0.0, 0.0]
+th = [threading.Thread(target=_worker, args=(vs[h], K, acts[h * (n // 2):(h + 1) * (n // 2)], el, h)) for h in range(2)]
+for t in th: t.start()
+for t in th: t.join()
+out['rllib_two_vector_envs_two_threads'] = n * K / max(el)
+for v in vs: v.close()
+import subprocess
+cmd = [sys.executable, os.path.abspath(__file__), '--half', str(n // 2), str(K)]
+t0 = time.perf_counter()
+ps = [subprocess.Popen(cmd + [str(h)], stdout=subprocess.PIPE, text=True) for h in range(2)]
+rates = [float(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
+out['rllib_two_vector_envs_two_processes'] = sum(rates)
 
 # (d) the same ids behind the asynchronous BaseEnv contract, two half-batches in flight: poll() hands out one half's finished step while the other
 # half's kernels run.  `adapter only`: prebuilt action dictionaries, results not looked at (as (b)); `with a sampler stand-in`: every

@@ -43,7 +43,9 @@ for A in "$@"; do
     default) timeout 1200 python bench.py > $O/bench_default_all_configs.json 2>$O/bench_default.err; line $O/bench_default_all_configs.json ;;
     bench) N=$(echo "$V" | tr -c 'A-Za-z0-9=' '_')${AGX_SOLVE_LDS_BYTES:+_lds$AGX_SOLVE_LDS_BYTES}; timeout 900 python bench.py $(echo "$V" | tr ',' ' ') --no-cpu-baseline --no-configs > $O/bench_$N.json 2>$O/bench_$N.err; line $O/bench_$N.json ;;
     prof|prof1) T=${V:-feeding}; S=""; [ $K = prof1 ] && S="unchunked_"
-      ( cd /tmp && AGX_CHUNKS=$([ $K = prof1 ] && echo 1 || echo "${AGX_CHUNKS:-}") timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tmp -- python $R/bench.py --task $T --steps 50 --warmup 5 --no-cpu-baseline --no-configs > $O/bench_${S}under_rocprof_$T.json 2>$O/rocprof_$T.err )
+      if [ $K = prof1 ]; then export AGX_CHUNKS=1; fi
+      ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tmp -- python $R/bench.py --task $T --steps 50 --warmup 5 --no-cpu-baseline --no-configs > $O/bench_${S}under_rocprof_$T.json 2>$O/rocprof_$T.err )
+      [ $K = prof1 ] && unset AGX_CHUNKS
       find $O/prof_tmp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_${S}$T.csv; head -6 $O/kernel_stats_${S}$T.csv; rm -rf $O/prof_tmp ;;
     pmc) T=${V:-feeding}; mkdir -p $O/pmc
       for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
