@@ -40,12 +40,14 @@ __device__ inline float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b
 __device__ inline f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ inline f3 ld(const float* p) { return mk(p[0], p[1], p[2]); }
 __device__ inline void st(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
-// Node positions in LDS are padded to NS4 = 4 words (round 6): a node is ONE 16-byte-aligned ds_read_b128 (4 LDS cycles per wave instruction) instead
-// of three ds_read_b32 at stride 3 (2 cycles each, and the three of them conflict on their own: ~2-way with the link tables of the garment), and one
-// ds_write_b64 + ds_write_b32 instead of three ds_write_b32.  The kernel is bound by the LDS pipe -- 16 wavefronts of 64 links per colour class, 12
-// word accesses per link (tests/diag notes in DESIGN 4) -- so LDS cycles per link are what there is to save.  -DAGXC_NODE_STRIDE=3: the old layout (A/B).
+// Node positions in LDS: NS4 words per node.  3 (the default): x, y, z packed, three ds_read_b32 / ds_write_b32 per node.  -DAGXC_NODE_STRIDE=4 (round 6, A/B):
+// padded to 16 bytes, ONE ds_read_b128 and a ds_write_b64 + ds_write_b32 per node -- fewer LDS instructions, and by the guide's table fewer LDS cycles per
+// link (28 against 36 + conflicts; the link tables of the garment give ~2.1-way conflicts on the packed layout, measured on the blob).  MEASURED, same box,
+// DressingBaxter 4096 x 30 steps: padded 50.4 / 51.6 k env-steps/s against packed 54.1 k (profiles/r06/r06d_ab_cloth_node_stride.txt) -- slower: the kernel
+// is not bound by LDS array cycles (as the counters of round 5 already said: 63 % of the wave cycles at s_waitcnt, i.e. latency between 17 barriers per
+// solver iteration).  Results are bit-identical either way (tests/test_gpu_dressing.py passes with both).  Not kept as the default.
 #ifndef AGXC_NODE_STRIDE
-#define AGXC_NODE_STRIDE 4
+#define AGXC_NODE_STRIDE 3
 #endif
 constexpr int NS4 = AGXC_NODE_STRIDE;
 __device__ inline f3 ldn(const float* p) {
