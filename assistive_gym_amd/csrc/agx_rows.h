@@ -188,9 +188,10 @@ AGX_DEV void build_rows(Ctx& c) {
         } else {
           float ang[3]; m3_to_euler_xyz(mul_at(frameA, frameB), ang);
           const int q = k - 3;
-          v3 axw = mk3(frameA.a[q], frameA.a[3 + q], frameA.a[6 + q]);
+          // (column q of frameA by selects: a dynamically indexed private array would live in scratch memory)
+          v3 axw = q == 0 ? mk3(frameA.a[0], frameA.a[3], frameA.a[6]) : (q == 1 ? mk3(frameA.a[1], frameA.a[4], frameA.a[7]) : mk3(frameA.a[2], frameA.a[5], frameA.a[8]));
           row_pair(c, R, link, pivA, AGX_BODY_FREE0 + tb, pivB, mk3(0, 0, 0), axw);
-          rb = ang[q] * erp / dt - row_velocity(c, R);
+          rb = (q == 0 ? ang[0] : (q == 1 ? ang[1] : ang[2])) * erp / dt - row_velocity(c, R);
         }
       }
       const int cnt = go ? row_entries(c, R) : 0;

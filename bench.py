@@ -536,7 +536,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
         # reduced by tools/pmc_traffic.py to per-environment figures), scaled to the SAME launch size as the algorithmic bytes
         traffic, traffic_src, valu_frac, cloth_kernel = None, None, None, None
         tname = task if workload is None else task + '_' + workload
-        for cand in ('r05_traffic_%s.json' % tname, 'r04_traffic_%s.json' % tname, 'r03_traffic_%s.json' % tname, 'r02_traffic_%s.json' % tname, 'r01_traffic.json' if task == 'feeding' else None):
+        for cand in ('r06_traffic_%s.json' % tname, 'r05_traffic_%s.json' % tname, 'r04_traffic_%s.json' % tname, 'r03_traffic_%s.json' % tname, 'r02_traffic_%s.json' % tname, 'r01_traffic.json' if task == 'feeding' else None):
             tpath = cand and os.path.join(ROOT, 'profiles', cand)
             if tpath and os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -573,7 +573,7 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
                          'kernels_ms_per_step_summed_over_overlapping_launches': dict(zip(names, [float(x) for x in kms])),
                          'stream_ms_per_step': kernel_ms / K,
                          'step_level_achieved': bytes_per_env_step * n / (elapsed / K) / 1e9,
-                         'note': 'solver bound by the per-wave issue rate of the dependent chain of a row visit (38 instructions, 4-6 cycles each whatever their kind: DESIGN 5), not by HBM; HBM fraction reported as the contract requires (SURVEY 8d)'},
+                         'note': 'solver bound by the latency of the dependent chain through the rows that share a body (wide row-local sweep: 1.38 rows per 38-instruction step, 56 % of the wave cycles at s_waitcnt: DESIGN 5), not by HBM; HBM fraction reported as the contract requires (SURVEY 8d)'},
         }
         if cloth_kernel:
             out['roofline']['cloth_kernel'] = cloth_kernel
