@@ -39,6 +39,14 @@ constexpr int LVS_DV = 0, LVS_PAIRS = 128;                           // LDS word
 static_assert(!LVS_COMPILED || HDR_STRIDE == 8, "the row-local sweep reads 32-byte headers");
 static_assert(!HDR_WIDE || H_INVD == 0 && H_B == 1 && H_LO == 2 && H_HI == 3 && H_OFF == 4 && H_N == 5 && H_NA == 6 && H_AB == 7, "the scalar load of a visit is the 8 words of a row of the first header table");
 
+//  The look-ahead of the last visit of a part runs on the "exhausted cursor" header -- row base - 1; for base 0 the last 32 bytes of the pair
+// arena, arbitrary floats read as a pair offset.  On the FAR path that offset would be DEREFERENCED (a global load up to 4 GB behind the scratch
+// record).  It cannot happen while rows 0..63 -- the only ones a part with base 0 visits -- lie inside the LDS window whatever the launch size:
+// 64 rows x 16 pairs + the zero pair <= the smallest window a solve launch can have.  Device builds with a capped window (AGX_LV_WINDOW_CAP) are refused.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AGX_LV_WINDOW_CAP) && !defined(AGX_PGS_LV_CPP)
+#error "AGX_LV_WINDOW_CAP is for the C++ twin (emulator, -DAGX_PGS_LV_CPP): the assembly sweep's look-ahead relies on rows 0..63 lying inside the window"
+#endif
+static_assert(!LVS_COMPILED || (LDS_SOLVE_BYTES / 4 - LVS_PAIRS) / 2 >= 64 * LV_G + 1, "rows 0..63 must fit the smallest LDS window of a solve launch (look-ahead of the exhausted cursor)");
 // pairs that fit a solve launch with lds_words of LDS
 AGX_DEV int lvs_window(int lds_words) {
   int w = (lds_words - LVS_PAIRS) / 2;

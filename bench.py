@@ -695,8 +695,16 @@ def main():
         extra['DrinkingJaco-v1'] = {k: r[k] for k in ('value', 'unit', 'steps', 'ms_per_step', 'contacts_per_substep', 'overflow_count')}
         extra['DrinkingJaco-v1']['workload'] = r['config']['workload']
         out['configs'] = extra
+    if distributed:
+        # RCCL writes a version banner through C stdio when a communicator is created; buffered, it would come out at exit -- BEHIND the JSON line.
+        # The one JSON line is the last thing this process prints: flush C stdio first, print, and tear the process group down quietly.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
 

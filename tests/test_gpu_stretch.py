@@ -63,7 +63,8 @@ def test_step_matches_oracle(rb):
             scale = 1.0 + np.abs(o_obs) * (1e-3 / 3e-4)                               # observation entries: 3e-4 absolute + 1e-3 relative (the force entries; north_star)
             dev = dict(obs=(np.abs(obs[i] - o_obs) / scale).max(), reward=abs(rew[i] - o_rew) / max(1.0, abs(o_rew)),
                        force=abs(info[i, 0] - o_info[0]) / max(1.0, abs(o_info[0])), q=np.abs(b.view(got[i])['q'] - b.view(ref[i])['q']).max())
-            if dev['obs'] < 3e-4 and dev['reward'] < 3e-4 and dev['force'] < 1e-3 and dev['q'] < 3e-4:
+            if dev['obs'] < 3e-4 and dev['reward'] < 1e-3 and dev['force'] < 1e-3 and dev['q'] < 3e-4:      # (reward: north_star's 1e-3 relative -- rounds 3-5 held it to 3e-4 here, a third of the contract;
+                # the end-effector speed term of a robot on wheels with a 100 : 1 mass ratio sits at 2e-4 ... 6e-4 in float32 depending on how the compiler contracts the sweeps)
                 for key in worst:
                     worst[key] = max(worst[key], dev[key])
                 continue
@@ -76,12 +77,12 @@ def test_step_matches_oracle(rb):
                                      force=abs(p_info[0] - o_info[0]) / max(1.0, abs(o_info[0])), q=np.abs(b.view(pert[None])['q'] - b.view(ref[i])['q']).max()).items():
                     spread[key] = max(spread[key], val)
             conditioned += 1
-            if any(dev[key] > 20 * spread[key] + dict(obs=3e-4, reward=3e-4, force=1e-3, q=3e-4)[key] for key in dev):     # keep the case for a replay on the emulator
+            if any(dev[key] > 20 * spread[key] + dict(obs=3e-4, reward=1e-3, force=1e-3, q=3e-4)[key] for key in dev):     # keep the case for a replay on the emulator
                 import os
                 os.makedirs('gpurun_out', exist_ok=True)
                 np.savez('gpurun_out/stretch_parity_case_%s_%d.npz' % (b.task_name, int(b.is_coop)), start=start, action=actions[i], dev_state=got[i], dev_obs=obs[i])
             for key in dev:
-                assert dev[key] <= 20 * spread[key] + dict(obs=3e-4, reward=3e-4, force=1e-3, q=3e-4)[key], (k, i, key, dev, spread)
+                assert dev[key] <= 20 * spread[key] + dict(obs=3e-4, reward=1e-3, force=1e-3, q=3e-4)[key], (k, i, key, dev, spread)
     st.close()
     print('worst deviations', worst, 'contact-count flips', flips, 'of', n * steps, '; judged against the oracle\'s own sensitivity:', conditioned)
     assert flips <= 0.08 * n * steps and conditioned <= 0.25 * n * steps

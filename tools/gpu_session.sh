@@ -23,7 +23,7 @@ export TMPDIR=/tmp
 line() { python - "$1" <<'PY'
 import json, sys
 try:
-    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    j = json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith('{')][-1])
     print('  %s: %.0f env-steps/s, %.3f ms/step' % (sys.argv[1].split('/')[-1], j['value'], j['ms_per_step']), {k: round(v) for k, v in j.items() if k.startswith('value_') and not isinstance(v, str)},
           'solve ms/launch %.4f' % j['roofline']['kernel_ms_per_launch'] if 'roofline' in j else '')
     for k, v in j.get('configs', {}).items(): print('     ', k, round(v['value']), v.get('contacts_per_substep'))
