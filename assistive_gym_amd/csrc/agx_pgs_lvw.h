@@ -141,7 +141,6 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
 // a step's word through v_readlane + v_bfe -- one LDS instruction less, two VALU / SALU more: 588 k against 607 k env-steps/s, same box.  Not kept.)
 #define LVW_S1(RID, OFF) "ds_read_u8 " RID ", %[sa] offset:" OFF "\n"
 #define LVW_S1B(RID)
-#define LVW_TAIL_STEP "s_nop 0\n"
 #define LVW_TAIL_LAST "v_add_u32_e32 %[sa], 16, %[sa]\n"
 #define LVW_PRIME LVW_S1("v88", "0") LVW_S1("v98", "4") LVW_S1("v108", "8") LVW_S1("v118", "12") "s_waitcnt lgkmcnt(0)\n"
 #define LVW_S2(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
@@ -171,8 +170,41 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
   "global_load_dwordx2 " JB ", v124, %[E]\n" \
   "s_branch " LBL "2b\n"
 #define LVW_GATHER(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) "ds_read_b32 v123, " IA "\n"
+// The end of a step.  Default (AGX_LVW_EARLY_GATHER, round 6): the scatter, then the GATHER OF THE NEXT STEP -- it only has to follow the scatter (LDS executes a
+// wave's accesses in order) -- and only then the impulse store; the loop counter is decremented in a wait state of the butterfly (nothing between there and the
+// branch touches SCC).  -DAGX_LVW_EARLY_GATHER=0: the first version (impulse store, scatter, counter, branch; the gather opens the next step).
+#ifndef AGX_LVW_EARLY_GATHER
+#define AGX_LVW_EARLY_GATHER 1
+#endif
+#if AGX_LVW_EARLY_GATHER
+#define LVW_END(LA, SON, IA, GNEXT, SUBEND) \
+  "s_mov_b64 exec, " SON "\n" \
+  "ds_write_b32 " IA ", v123\n" \
+  "s_mov_b64 exec, -1\n" \
+  GNEXT \
+  "ds_write_b32 " LA ", v122\n" \
+  SUBEND \
+  "s_cbranch_scc1 9f\n"
+#define LVW_TOP_GATHER(...)
+#define LVW_PRIME_GATHER(...) LVS_APPLY(LVW_GATHER, __VA_ARGS__)
+#define LVW_TAIL_STEP "s_sub_u32 s60, s60, 1\n"
+#define LVW_SUBEND_STEP
+#else
+#define LVW_END(LA, SON, IA, GNEXT, SUBEND) \
+  "ds_write_b32 " LA ", v122\n" \
+  "s_mov_b64 exec, " SON "\n" \
+  "ds_write_b32 " IA ", v123\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_sub_u32 s60, s60, 1\n" \
+  "s_cbranch_scc1 9f\n"
+#define LVW_TOP_GATHER(...) LVS_APPLY(LVW_GATHER, __VA_ARGS__)
+#define LVW_PRIME_GATHER(...)
+#define LVW_TAIL_STEP "s_nop 0\n"
+#define LVW_SUBEND_STEP
+#endif
+#define LVW_SUBEND_LAST "s_sub_u32 s60, s60, 1\n"
 // S4 with the S2 of step t + 3 and the S1 of step t + 4 in the wait states the butterfly needs (two between a write and a DPP read of it)
-#define LVW_S4(FRIC, S2TEXT_A, S2TEXT_B, S2TEXT_C, S1TEXT, S1B, TAIL, P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
+#define LVW_S4(FRIC, S2TEXT_A, S2TEXT_B, S2TEXT_C, S1TEXT, S1B, TAIL, GNEXT, SUBEND, P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
   "v_mul_f32_e32 v120, " J ", v123\n" \
   "v_cndmask_b32_e64 v120, 0, v120, " SON "\n" \
   S2TEXT_A \
@@ -193,23 +225,23 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
   LVS_NOT_##FRIC("v_min_f32_dpp v122, " HWA ", v121" LVW_QP(3)) \
   "v_sub_f32_e32 v121, v122, " L0 "\n" \
   "v_fmac_f32_e32 v123, " B ", v121\n" \
-  "ds_write_b32 " LA ", v122\n" \
-  "s_mov_b64 exec, " SON "\n" \
-  "ds_write_b32 " IA ", v123\n" \
-  "s_mov_b64 exec, -1\n" \
-  "s_sub_u32 s60, s60, 1\n" \
-  "s_cbranch_scc1 9f\n"
+  LVW_END(LA, SON, IA, GNEXT, SUBEND)
 #define LVW_S2_A(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) "v_lshl_add_u32 v126, " RID ", 4, %[hbk]\n" "v_lshlrev_b32_e32 v127, 3, " RID "\n"
 #define LVW_S2_B(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) "global_load_dword " HWA ", v126, %[hq]\n" "v_lshl_add_u32 " LA ", " RID ", 2, %[lamb]\n"
 #define LVW_S2_C(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) "global_load_dwordx2 " PP ", v127, %[hp]\n"
 #define LVW_RID(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) RID
 // one step: C the slot of step t, N1 of t + 1, N3 of t + 3 (S1 of t + 4 re-uses C's row index register: its step has long passed S2)
-#define LVW_ITER(FRIC, LBL, OFF, TAIL, C, N1, N3) \
-  LVS_APPLY(LVW_GATHER, C) \
+#define LVW_ITER(FRIC, LBL, OFF, TAIL, SUBEND, C, N1, N3) \
+  LVW_TOP_GATHER(C) \
   "s_waitcnt vmcnt(2)\n" \
   LVS_APPLY(LVW_S3, FRIC, LBL, N1) \
   "s_waitcnt lgkmcnt(1)\n" \
-  LVS_APPLY(LVW_S4, FRIC, LVS_APPLY(LVW_S2_A, N3), LVS_APPLY(LVW_S2_B, N3), LVS_APPLY(LVW_S2_C, N3), LVW_S1(LVS_APPLY(LVW_RID, C), OFF), LVW_S1B(LVS_APPLY(LVW_RID, C)), TAIL, C)
+  LVS_APPLY(LVW_S4, FRIC, LVS_APPLY(LVW_S2_A, N3), LVS_APPLY(LVW_S2_B, N3), LVS_APPLY(LVW_S2_C, N3), LVW_S1(LVS_APPLY(LVW_RID, C), OFF), LVW_S1B(LVS_APPLY(LVW_RID, C)), TAIL, LVW_GNEXT(N1), SUBEND, C)
+#if AGX_LVW_EARLY_GATHER
+#define LVW_GNEXT(...) LVS_APPLY(LVW_GATHER, __VA_ARGS__)
+#else
+#define LVW_GNEXT(...)
+#endif
 #define LVW_BODY(FRIC) \
     "s_mov_b64 s[50:51], exec\n" \
     "s_mov_b64 exec, -1\n" \
@@ -219,12 +251,13 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
     LVS_APPLY(LVW_S2, LVW_SL0) LVS_APPLY(LVW_S2, LVW_SL1) \
     "s_waitcnt vmcnt(2)\n" \
     LVS_APPLY(LVW_S3, FRIC, "7", LVW_SL0) \
+    LVW_PRIME_GATHER(LVW_SL0) \
     LVS_APPLY(LVW_S2, LVW_SL2) \
     "8:\n" \
-    LVW_ITER(FRIC, "1", "16", LVW_TAIL_STEP, LVW_SL0, LVW_SL1, LVW_SL3) \
-    LVW_ITER(FRIC, "2", "20", LVW_TAIL_STEP, LVW_SL1, LVW_SL2, LVW_SL0) \
-    LVW_ITER(FRIC, "3", "24", LVW_TAIL_STEP, LVW_SL2, LVW_SL3, LVW_SL1) \
-    LVW_ITER(FRIC, "4", "28", LVW_TAIL_LAST, LVW_SL3, LVW_SL0, LVW_SL2) \
+    LVW_ITER(FRIC, "1", "16", LVW_TAIL_STEP, LVW_SUBEND_STEP, LVW_SL0, LVW_SL1, LVW_SL3) \
+    LVW_ITER(FRIC, "2", "20", LVW_TAIL_STEP, LVW_SUBEND_STEP, LVW_SL1, LVW_SL2, LVW_SL0) \
+    LVW_ITER(FRIC, "3", "24", LVW_TAIL_STEP, LVW_SUBEND_STEP, LVW_SL2, LVW_SL3, LVW_SL1) \
+    LVW_ITER(FRIC, "4", "28", LVW_TAIL_LAST, LVW_SUBEND_LAST, LVW_SL3, LVW_SL0, LVW_SL2) \
     "s_branch 8b\n" \
     "9:\n" \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n" \
