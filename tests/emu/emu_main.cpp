@@ -149,6 +149,22 @@ extern "C" int agx_emu_water(const uint32_t* blob, const float* state, const flo
   static float lds[agxw::LDS_WORDS];
   return run_wave(lds, agxw::LDS_WORDS, [&](int lane) { agxw::water_env(blob, state, trace, water, report, nsub, lds, lane); });
 }
+#if AGX_PGS_LV == 4
+// the list scheduler of the wide row-local sweep (csrc/agx_pgs_lvw.h lvw_schedule) on given slot masks: masks3[3 r ...] = the 96-bit mask of row r;
+// ss64[step] = the (up to four) rows of a step, a byte each (agx::HW_DUMMY = idle); returns the number of steps, -1 when they do not fit
+extern "C" int agx_emu_lvw_schedule(const uint32_t* masks3, int nr, uint32_t* ss64) {
+  if constexpr (!agx::LVW_COMPILED) { (void)masks3; (void)nr; (void)ss64; return -2; }
+  else {
+    static float hdr[agx::SCR_HDR_WORDS];
+    for (int r = 0; r < nr && r < agx::MAX_ROWS; r++) { int* Xi = (int*)agx::hx_row(hdr, r); Xi[agx::H_MLO] = (int)masks3[3 * r]; Xi[agx::H_MHI] = (int)masks3[3 * r + 1]; Xi[agx::H_M2] = (int)masks3[3 * r + 2]; }
+    static float lds[64];
+    int ns = 0;
+    const int rc = run_wave(lds, 64, [&](int lane) { agx::Ctx c; c.H = hdr; c.lane = lane; uint32_t ss; const int n = agx::lvw_schedule(c, lane, 0, nr, ss); ss64[lane] = ss; if (lane == 0) ns = n; });
+    return rc ? -3 : ns;
+  }
+}
+extern "C" int agx_emu_lvw_dummy_row() { return agx::HW_DUMMY; }
+#endif
 extern "C" int agx_emu_lds_bytes() { return agx::LDS_BYTES; }
 // debug record layout of this variant (same order as agx_debug_layout of the product library)
 extern "C" void agx_emu_debug_layout(int* out8) {
