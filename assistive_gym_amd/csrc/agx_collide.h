@@ -39,7 +39,6 @@ AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, b
     }
     ra = CLF(c, ca, AGX_C_RADIUS); rb = CLF(c, cb, AGX_C_RADIUS);
   }
-#ifdef AGX_NO_PEN_REFINE      // (same-box A/B of the kernel's speed only: the refinement of AGX_P_PEN_REFINE compiled out -- results differ from the oracle where cores overlap)
   float d; v3 pa, pb, n;
   const bool pen = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), limit + ra + rb + GJK_FAR_MARGIN, ok, d, pa, pb);
   if (!ok) return false;
@@ -50,36 +49,6 @@ AGX_DEV bool narrowphase(const Ctx& c, int ca, int cb, float limit, Cand& out, b
     float depth; gjk_penetration(sa, sb, c.bf + c.o_dirs, c.bi[AGX_H_NDIR], depth, n, pa, pb);
     d = -depth;
   }
-#else
-  float d = 0.f; v3 pa = mk3(0.f, 0.f, 0.f), pb = pa, n = pa;
-  // Two rounds through ONE call site of the (wave-uniform) GJK iteration.  Round 0: the distance of the pair; lanes whose cores overlap take the depth
-  // from the 42-direction sampling and -- AGX_P_PEN_REFINE (include/agx_blob.h) -- displace A by that depth (+ AGX_PEN_EXTRA) along the sampled
-  // normal.  Round 1 (only when a lane of the wave asked for it: rare): GJK on the displaced pairs; depth = displacement - distance found, the
-  // witness point on B that run's, the one on A that point moved back by the depth; the normal stays the sampled direction.
-  bool pen = false, refine = false; float disp = 0.f;
-  const bool want_refine = PRM(c, AGX_P_PEN_REFINE) != 0.f;
-  _Pragma("nounroll") for (int round = 0; round < 2; round++) {
-    float d2; v3 pa2, pb2;
-    const bool pen2 = gjk_distance(sa, sb, PRM(c, AGX_P_GJK_TOL), (int)PRM(c, AGX_P_GJK_MAXIT), round == 0 ? limit + ra + rb + GJK_FAR_MARGIN : 3.0e38f, round == 0 ? ok : refine, d2, pa2, pb2);
-    if (round == 0) {
-      pen = pen2; d = d2; pa = pa2; pb = pb2;
-      if (ok && pen) {
-        float depth; gjk_penetration(sa, sb, c.bf + c.o_dirs, c.bi[AGX_H_NDIR], depth, n, pa, pb);
-        d = -depth;
-        if (want_refine) { refine = true; disp = depth + AGX_PEN_EXTRA; sa.p = sa.p + disp * n; sa.c = sa.c + disp * n; }
-      }
-      if (!wave_any(refine)) break;
-    } else if (refine && !pen2) {
-      float depth = disp - d2; depth = depth < 0.f ? 0.f : (depth > disp - AGX_PEN_EXTRA ? disp - AGX_PEN_EXTRA : depth);
-      pb = pb2; pa = pb2 - depth * n; d = -depth;
-    }
-  }
-  if (!ok) return false;
-  if (!pen) {
-    if (d - ra - rb >= limit) return false;
-    n = (1.0f / d) * (pa - pb);
-  }
-#endif
   out.pa = pa - ra * n + shift; out.pb = pb + rb * n + shift; out.n = n; out.dist = d - ra - rb;
   return true;
 }

@@ -35,7 +35,7 @@ H = dict(MAGIC=0, VERSION=1, NWORDS=2, NDOF=3, NFREE=4, NHUMAN=5, NCOLL=6, NVERT
          OFF_TARGETS=38, OFF_MLP=39, OFF_CLOTH=40, SIM_SUBSTEPS=41, BASE_LINK=42, COUNT=48)
 P = dict(DT=0, FRAME_SKIP=1, NITER=2, ERP=3, CONTACT_ERP=4, CONTACT_BREAK=5, LIN_DAMP=6, ANG_DAMP=7, FRIC_EPS=8,
          LIMIT_ACT=9, ACTION_SCALE=10, GRAVITY_Z=11, GJK_TOL=12, GJK_MAXIT=13, MAX_CONTACTS=14, MAX_ROWS=15, ROBOT_GRAVITY_Z=16,
-         HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, NOOP_RETEST=20, ORACLE_RESIDUAL_EPS=21, FRICTION_DIRS=22, WARMSTART=23, NOOP_PEN=24, MANIFOLD=25, SPLIT_PEN=26, SOLVE_WIDE=27, PEN_REFINE=28, COUNT=29)
+         HUMAN_GRAVITY_Z=17, CONTACT_SLACK=18, MAX_ENTRIES=19, NOOP_RETEST=20, ORACLE_RESIDUAL_EPS=21, FRICTION_DIRS=22, WARMSTART=23, NOOP_PEN=24, MANIFOLD=25, SPLIT_PEN=26, SOLVE_WIDE=27, COUNT=28)
 R = dict(PARENT=0, TPOS=1, TQUAT=4, AXIS=8, COM=11, MASS=14, INERTIA=15, LOWER=21, UPPER=22, HAS_LIMIT=23, KP=24, KD=25,
          MAXF=26, ACT=27, QT0=28, JDAMP=29, PB_INDEX=30, KIND=31, JTYPE=32, ACT_MULT=33, ACT_SRC=34, OBS_SKIP=35, STRIDE=36)
 F = dict(MASS=0, INERTIA=1, GRAVITY=4, REFPOS=5, REFQUAT=8, KIND=12, RADIUS=13, STRIDE=16)
@@ -79,7 +79,7 @@ MLP_WORDS = 4 * 64 + 64 + 64 * 64 + 64 + 64 * 64 + 64 + 64 + 1      # bed bathin
 # pair-group flags (AGX_G_FLAGS)
 GF_SAME, GF_MANIFOLD, GF_NO_ADJACENT, GF_MALE, GF_FEMALE, GF_HUMAN_DYNAMIC, GF_SOLVE_ALL = 1, 2, 4, 8, 16, 32, 64
 KIND = dict(TOOL=1, BOWL=2, FOOD=3)
-MAGIC, VERSION = 0x31584741, 17
+MAGIC, VERSION = 0x31584741, 16
 
 HULL_MARGIN = 0.001          # [BULLET-UNVERIFIED] gUrdfDefaultCollisionMargin
 DEFAULT_FRICTION = 0.5       # [BULLET-UNVERIFIED]
@@ -462,7 +462,6 @@ def default_params(n_iter):
     return dict(DT=0.02, FRAME_SKIP=5, NITER=n_iter, ERP=0.2, CONTACT_ERP=0.2, CONTACT_BREAK=0.02, LIN_DAMP=0.04, ANG_DAMP=0.04,
                 FRIC_EPS=1e-7, LIMIT_ACT=0.25, ACTION_SCALE=0.05, GRAVITY_Z=-9.81, GJK_TOL=1e-6, GJK_MAXIT=24, MAX_CONTACTS=64,
                 MAX_ROWS=160, ROBOT_GRAVITY_Z=0.0, HUMAN_GRAVITY_Z=0.0, CONTACT_SLACK=0.001, MAX_ENTRIES=2040,
-                PEN_REFINE=1.0,    # overlapping cores: the sampled penetration depth refined by a GJK run on the displaced pair (agx_blob.h AGX_P_PEN_REFINE)
                 SOLVE_WIDE=1.0,    # the wide row-local sweep of the feeding variant's solve kernel (agx_blob.h AGX_P_SOLVE_WIDE; same bits either way)
                 SPLIT_PEN=0.0,     # Bullet's split impulse threshold: off (agx_blob.h AGX_P_SPLIT_PEN)
                 MANIFOLD=0.0,      # persistent 4-point manifold of the moving hull pairs: off (agx_blob.h AGX_P_MANIFOLD)

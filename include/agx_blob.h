@@ -14,7 +14,7 @@
 #define AGX_BLOB_H
 
 #define AGX_BLOB_MAGIC 0x31584741 /* "AGX1" */
-#define AGX_BLOB_VERSION 17
+#define AGX_BLOB_VERSION 16
 /* Agent.enforce_joint_limits (agent.py:240-250) resets a human joint found beyond a limit (q = limit, qd = 0).  A joint
  * stopped by its limit row arrives EXACTLY on the limit up to rounding, where `q < lower` is a coin flip of the arithmetic
  * (f32 here, f64 in the oracle / in Bullet); the reset is therefore applied only beyond this tolerance (radians). */
@@ -24,7 +24,6 @@
  * the hooks take_step runs between its stepSimulation calls (env.py:227-231) apply */
 #define AGX_PHASE_SETTLE 0x40000000
 #define AGX_BOX_CLIP 0.05f /* static world boxes are clipped to the other collider's AABB grown by this */
-#define AGX_PEN_EXTRA 0.002f /* AGX_P_PEN_REFINE: extra displacement beyond the sampled depth, so that the displaced pair is clearly separated */
 /* face manifold on static world boxes (table top, ground): besides the closest point, up to AGX_FACE_EXTRA more
  * vertices of the other collider become contact candidates -- those within AGX_FACE_BAND of its lowest vertex,
  * each at least AGX_FACE_SPREAD (horizontally) away from the points already chosen, farthest first */
@@ -147,13 +146,7 @@ enum {
   AGX_P_SOLVE_WIDE = 27, /* != 0 (the default, 1): the feeding variant's solve kernel visits up to four rows with disjoint velocity slots at once, one per
                             16-lane group (csrc/agx_pgs_lvw.h); 0: one row per visit (csrc/agx_pgs_lvs.h).  The two compute the same bits (rows that share no
                             slot commute exactly): a device-only switch for same-process A/B runs and the bit-for-bit test; the oracle ignores it          */
-  AGX_P_PEN_REFINE = 28, /* != 0 (the default, 1): when the CORES of two colliders overlap, the depth found by the 42-direction sampling is REFINED the way Bullet's
-                            btMinkowskiPenetrationDepthSolver does it ([BULLET-UNVERIFIED], from memory: its fallback when EPA fails): A is displaced by the sampled
-                            depth (+ AGX_PEN_EXTRA) along the sampled normal, GJK runs on the displaced pair, and the depth becomes (displacement - the distance
-                            found), the witness point on B the one of that run; the normal stays the sampled direction.  The raw sampling over-estimates the depth
-                            of a graze: round 6's PLAIN-oracle test on the hardware found a Jaco link cutting the table's corner by ~1 mm reported as 2.2 cm (a row
-                            that pushes the arm away at 1.1 m/s).  0: the raw sampling of rounds 1-5.  Oracle and device (agx_collide.h narrowphase)        */
-  AGX_P_COUNT = 29
+  AGX_P_COUNT = 28
 };
 
 /* ---- ROBOT: one record per moving link, stride AGX_R_STRIDE ------------------------------- */

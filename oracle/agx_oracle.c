@@ -636,20 +636,6 @@ static int narrowphase_ab(const sim_t* s, int ca, int cb, double limit, contact_
     int ia = support(va, na, nd);
     memcpy(pa, va + 3 * ia, 24); memcpy(pb, pa, 24); axpy3(best, n, pb);
     d = -best;
-    if (PARAM(m, AGX_P_PEN_REFINE) != 0) {
-      /* AGX_P_PEN_REFINE (include/agx_blob.h): A displaced by the sampled depth (+ AGX_PEN_EXTRA) along n, GJK on the displaced pair; the depth becomes
-       * displacement - distance, the witness point on B that run's, the point on A that point moved back by the depth along n; the normal stays n */
-      const double disp = best + (double)AGX_PEN_EXTRA;
-      static double vd[3 * MAXV];
-      for (int q = 0; q < na; q++) for (int k = 0; k < 3; k++) vd[3 * q + k] = va[3 * q + k] + disp * n[k];
-      double d2, pa2[3], pb2[3], dn[3] = {d0[0] + disp * n[0], d0[1] + disp * n[1], d0[2] + disp * n[2]};      /* (start direction: centre of the displaced A - centre of B, as the device) */
-      const int pen2 = gjk_core(vd, na, vb, nb, PARAM(m, AGX_P_GJK_TOL), (int)PARAM(m, AGX_P_GJK_MAXIT), dn, &d2, pa2, pb2, NULL);
-      if (!pen2) {
-        double depth = disp - d2; if (depth < 0) depth = 0; if (depth > best) depth = best;
-        memcpy(pb, pb2, 24); memcpy(pa, pb2, 24); axpy3(-depth, n, pa);
-        d = -depth;
-      }
-    }
   }
   for (int k = 0; k < 3; k++) { out->pa[k] = pa[k] - ra * n[k] + shift[k]; out->pb[k] = pb[k] + rb * n[k] + shift[k]; out->n[k] = n[k]; }
   out->dist = d - ra - rb; out->ca = ca; out->cb = cb;

@@ -43,8 +43,8 @@ def _load(path, blob):
         from assistive_gym_amd.blob import ModelBlob
         blob = ModelBlob.load(str(d['model']))
     # what a dump depends on is the STATE RECORD layout.  Blob versions with the same record layout as the current one: 16 = 15 + one PARAMS entry
-    # (AGX_P_SOLVE_WIDE), 17 = 16 + AGX_P_PEN_REFINE (include/agx_blob.h) -- the committed bridge rehearsals were recorded at 15
-    assert int(d['blob_version']) in (blob.h['VERSION'], 15, 16), 'dump was recorded for another blob version'
+    # (AGX_P_SOLVE_WIDE, a device-only switch; include/agx_blob.h) -- the committed bridge rehearsals were recorded at 15
+    assert int(d['blob_version']) in (blob.h['VERSION'], 15), 'dump was recorded for another blob version'
     assert d['states'].shape[1] == blob.state_words and len(d['states']) == len(d['actions']) + 1
     return d, blob
 
