@@ -164,11 +164,29 @@ AGX_DEV void lvw_step(const LvwLay& Y, int lane, uint32_t w, bool fric) {
   "s_cbranch_vccnz " LBL "1f\n" \
   "ds_read_b64 " JB ", v124\n" \
   LBL "2:\n"
+// (AGX_LVW_FAR_ALL_LANES=1: the first version -- every lane of a far step took its pair from the scratch record, 64 loads of which two thirds fetched pairs the
+// window holds, or nothing a row owns (k >= n).  Now: the lanes of rows inside the window read LDS as in a near step -- the LDS count of the step is the same --
+// and only the on-lanes of the rows beyond it load from the record.  Same values either way.)
+#ifndef AGX_LVW_FAR_ALL_LANES
+#define AGX_LVW_FAR_ALL_LANES 0
+#endif
+#if AGX_LVW_FAR_ALL_LANES
 #define LVW_FAR(LBL, P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
   LBL "1:\n" \
   "v_add_u32_sdwa v124, " P0 ", %[k8] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n" \
   "global_load_dwordx2 " JB ", v124, %[E]\n" \
   "s_branch " LBL "2b\n"
+#else
+#define LVW_FAR(LBL, P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) \
+  LBL "1:\n" \
+  "s_andn2_b64 exec, exec, vcc\n" \
+  "ds_read_b64 " JB ", v124\n" \
+  "s_and_b64 exec, vcc, " SON "\n" \
+  "v_add_u32_sdwa v124, " P0 ", %[k8] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n" \
+  "global_load_dwordx2 " JB ", v124, %[E]\n" \
+  "s_mov_b64 exec, -1\n" \
+  "s_branch " LBL "2b\n"
+#endif
 #define LVW_GATHER(P0, P1, PP, J, B, JB, HWA, L0, IA, LA, RID, LN, SON) "ds_read_b32 v123, " IA "\n"
 // The end of a step.  Default (AGX_LVW_EARLY_GATHER, round 6): the scatter, then the GATHER OF THE NEXT STEP -- it only has to follow the scatter (LDS executes a
 // wave's accesses in order) -- and only then the impulse store; the loop counter is decremented in a wait state of the butterfly (nothing between there and the

@@ -16,6 +16,7 @@
 #   rllib            tools/gpu_rllib_overhead.py -> rllib_overhead.json
 #   py:<script>[,args]  python <script> args -> <script basename>.log
 #   env:VAR=VAL / unset:VAR   environment for the actions that follow (e.g. env:AGX_SOLVE_LDS_BYTES=12288)
+#   bits:<name>      tools/gpu_lv_bits.py: 40 steps of 1,024 FeedingJaco environments, default build against lib/variants/<name>.so, bit by bit -> bits_<name>.txt
 #   ab:<name>        AGX_LIB=assistive_gym_amd/lib/variants/<name>.so bench.py --steps 300 (x2, interleaved with the default build) -> ab_<name>.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -62,6 +63,8 @@ for A in "$@"; do
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(j['value']), round(j['ms_per_step'], 3), {k.split('_')[1]: round(v, 2) for k, v in j['roofline']['kernels_ms_per_step_summed_over_overlapping_launches'].items()})" | tee -a $O/ab_$V.txt
       done; done; unset AGX_LIB ;;
+    bits) timeout 600 python tools/gpu_lv_bits.py /tmp/bits_default.npz 1024 40 > /dev/null 2>$O/bits_$V.err; AGX_LIB=$R/assistive_gym_amd/lib/variants/$V.so timeout 600 python tools/gpu_lv_bits.py /tmp/bits_$V.npz 1024 40 > /dev/null 2>>$O/bits_$V.err
+      python tools/gpu_lv_bits.py --compare /tmp/bits_default.npz /tmp/bits_$V.npz | tail -2 | tee $O/bits_$V.txt ;;
     env) export "$V"; echo "exported $V" ;;
     unset) unset "$V" ;;
     *) echo "unknown action $A" ;;
