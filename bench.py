@@ -558,7 +558,8 @@ def run_config(args, task, steps, warmup, rank, world, local_rank, distributed, 
             'config': {'workload': '%s, %d lockstep envs per MI355X, %s, 5 simulation steps per env step, %d PGS sweeps' % (env_id, n, 'random-policy rollout' if workload is None else ('scripted press-and-wipe policy on the device (tool force feedback), whole 200-step episodes from starts with the pad on the arm; the pad carries force in %.0f %% of the selection rollout' % (100 * dense_touching)) if workload == 'dense' else 'pad pressed onto the arm at every reset, 8-step episodes, small random actions (x%.2f)' % action_scale, int(blob.param('NITER'))),
                        'envs_per_gpu': n, 'global_envs': world * n, 'reset_pool': pool, 'reset': args.reset, 'parallelism': 'env-sharded x%d' % world,
                        'obs_allgather': bool(distributed), 'gather': gather_how, 'gathered_record': 'obs | reward | done | total_force_on_human | task_success' if distributed else None,
-                       'gathered_in_global_order': in_order, 'noop_retest': blob.param('NOOP_RETEST')},
+                       'gathered_in_global_order': in_order, 'noop_retest': blob.param('NOOP_RETEST'),
+                       **({'ranks_share_gpus': '%d ranks on %d device(s): a rehearsal of the N-rank command (--share-gpus), not a scaling point' % (world, torch.cuda.device_count())} if getattr(args, 'share_gpus', False) else {})},
             'contacts_per_substep': contacts,      # solver contacts of the last substep of a step, mean over environments and sampled steps
             'overflow_count': int(overflow),       # substeps (summed over environments) in which a contact was dropped by the contact / row / coefficient budgets
             'pool_states_refreshed': int(getattr(env, 'pool_refreshed', 0)),      # --pool-refresh: start states a child process sampled during the run and the rollout swapped into the pool
@@ -606,6 +607,7 @@ def main():
     ap.add_argument('--backend', default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --dry-run)")
     ap.add_argument('--force-gather', action='store_true', help='1 GPU: run the multi-GPU code path anyway (a 1-rank RCCL process group, the per-step observation all-gather on its side stream) -- what the stream / hardware-queue layout of --gpus N looks like on one GPU')
     ap.add_argument('--gather', choices=['abi', 'torch'], default='abi', help="the collective of the per-step whole-batch gather with --gpus N: 'abi' = agx_comm_init_rank / agx_allgather of the C ABI (RCCL bound by libagx), 'torch' = torch.distributed")
+    ap.add_argument('--share-gpus', action='store_true', help='REHEARSAL of the N-rank command on a box with fewer GPUs than ranks: rank r steps on device r %% device_count (several ranks share a GPU; RCCL refuses two ranks on one device, so use --backend gloo: the C-ABI collective then fails its vote and the gather falls back to torch.distributed, loudly).  The line says so; its value is not a scaling point')
     ap.add_argument('--dry-run', action='store_true', help='exercise the launch / sharding / all-gather / timing path on CPU tensors without stepping (no GPU needed; backend gloo)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -647,9 +649,14 @@ def main():
             os.environ.setdefault(k, v)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: libagx has no CPU path')
+    if args.share_gpus:
+        local_rank %= torch.cuda.device_count()       # (local_rank is only ever used as the device index below)
     torch.cuda.set_device(local_rank)
     if distributed:
-        dist.init_process_group(args.backend, device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group(args.backend, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
     headline = args.task is None and args.env is None
     task = args.task or 'feeding'
     out = run_config(args, task, args.steps, args.warmup, rank, world, local_rank, distributed, cpu=not args.no_cpu_baseline, workload=args.workload, env_id_override=args.env)

@@ -17,6 +17,7 @@
 #   py:<script>[,args]  python <script> args -> <script basename>.log
 #   env:VAR=VAL / unset:VAR   environment for the actions that follow (e.g. env:AGX_SOLVE_LDS_BYTES=12288)
 #   bits:<name>      tools/gpu_lv_bits.py: 40 steps of 1,024 FeedingJaco environments, default build against lib/variants/<name>.so, bit by bit -> bits_<name>.txt
+#   share[:N]        the driver's N-rank command (default 2) with all ranks on this box's one GPU: bench.py --gpus N --backend gloo --share-gpus -> share_gpus_N.json
 #   ab:<name>        AGX_LIB=assistive_gym_amd/lib/variants/<name>.so bench.py --steps 300 (x2, interleaved with the default build) -> ab_<name>.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -65,6 +66,7 @@ j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(j['
       done; done; unset AGX_LIB ;;
     bits) timeout 600 python tools/gpu_lv_bits.py /tmp/bits_default.npz 1024 40 > /dev/null 2>$O/bits_$V.err; AGX_LIB=$R/assistive_gym_amd/lib/variants/$V.so timeout 600 python tools/gpu_lv_bits.py /tmp/bits_$V.npz 1024 40 > /dev/null 2>>$O/bits_$V.err
       python tools/gpu_lv_bits.py --compare /tmp/bits_default.npz /tmp/bits_$V.npz | tail -2 | tee $O/bits_$V.txt ;;
+    share) N=${V:-2}; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus $N --steps 50 --warmup 5 --backend gloo --share-gpus --no-cpu-baseline > $O/share_gpus_$N.json 2>$O/share_gpus_$N.err; echo "rc=$?"; line $O/share_gpus_$N.json; tail -3 $O/share_gpus_$N.err ;;
     env) export "$V"; echo "exported $V" ;;
     unset) unset "$V" ;;
     *) echo "unknown action $A" ;;
