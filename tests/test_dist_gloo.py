@@ -211,3 +211,19 @@ def test_real_bench_path_votes_on_the_collective_and_checks_the_order():
     body = src[src.index("if gather_how == 'abi':"):src.index('gatherer = BatchGatherer(n, blob.obs_dim + 4, world, device=torch.device')]
     assert body.count('dist.all_reduce(ok, op=dist.ReduceOp.MIN)') == 2 and 'libagx.comm_destroy(comm); comm = None' in body
     assert "'gathered_in_global_order': in_order" in src and 'dist.all_reduce(okt, op=dist.ReduceOp.MIN)' in src
+
+
+def test_share_gpus_rehearsal_is_explicit_and_labelled():
+    """several ranks on one device only with --share-gpus (a misconfigured production launch must still fail at set_device), and the line then says
+    that it is a rehearsal; the committed lines of the 2- and 4-rank rehearsals on the MI355X box (profiles/r06/r06p_*) show the voted fallback:
+    RCCL refused the communicator, every rank gathered through torch.distributed, records in global order"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'bench.py')).read()
+    assert "if args.share_gpus:\n        local_rank %= torch.cuda.device_count()" in src and "'ranks_share_gpus'" in src
+    for n in (2, 4):
+        p = os.path.join(root, 'profiles', 'r06', 'r06p_share_gpus_%d_ranks_one_gpu.json' % n)
+        j = json.loads([l for l in open(p).read().splitlines() if l.startswith('{')][-1])
+        assert j['n_gpus'] == n and j['config']['global_envs'] == 4096 * n and j['config']['gathered_in_global_order'] is True
+        assert j['config']['gather'].startswith('torch (agx_comm_init_rank failed') and 'rehearsal' in j['config']['ranks_share_gpus']
+    assert j['configs']['config4_ScratchItchPR2Human-v1_16384_envs_4gpu']['gathered_in_global_order'] is True
