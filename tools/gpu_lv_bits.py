@@ -14,6 +14,10 @@ if sys.argv[1] == '--compare':
             x, y = a[k].reshape(a[k].shape[0], -1), b[k].reshape(b[k].shape[0], -1)
             rows = np.where((x.view(np.uint32) != y.view(np.uint32)).any(axis=1))[0] if x.dtype == np.float32 else np.where((x != y).any(axis=1))[0]
             print('%s: %d of %d environments differ (first %s)' % (k, len(rows), x.shape[0], rows[:8])); bad += 1
+            if a[k].ndim >= 2:            # which trailing columns, and by how much
+                xs, ys = a[k].reshape(-1, a[k].shape[-1]), b[k].reshape(-1, b[k].shape[-1])
+                cols = np.where((xs != ys).any(axis=0))[0]
+                print('   columns', cols[:16], 'max |difference| per column', [float(np.nanmax(np.abs(xs[:, c].astype(np.float64) - ys[:, c]))) for c in cols[:16]], 'shape', a[k].shape)
     print('IDENTICAL' if not bad else 'DIFFERENT', sys.argv[2], sys.argv[3])
     sys.exit(1 if bad else 0)
 import torch
