@@ -27,16 +27,19 @@ AGX_DEV v3 gjk_vertex0(const gjk_shape& s) {
   if (s.box) return s.lo;
   return mul(s.R, mk3(s.v[0], s.v[1], s.v[2])) + s.p;
 }
-// AGX_GJK_SCAN_WIDE (round 6, an A/B knob, OFF): the scan below with vertex 0 inside the first round, eight vertices per round and the winner's coordinates
-// carried along -- two memory round trips for a 16-vertex spoon piece instead of five.  Measured, same box, interleaved: 614.9 / 613.9 k against 609.6 / 609.1 k
-// env-steps/s (first version 620-621 k; build kernel 0.609 against 0.621 ms per launch).  NOT the default: the winner then sits in three separate registers, and
-// `R v + p` -- which the compiler rounds differently at every inlined call site of the 4-per-round scan (packed products, partly fused chains) -- comes out with
-// other last bits whatever sequence is pinned (gjk_xf).  Two pinned sequences were run through the GPU suite: 203 of 205 tests passed each time, and each time
-// two OTHER tests on ill-conditioned states (a threshold contact of a crafted pressed state; the co-op arm one step after a classifier roll-back; a wiping
-// force) missed margins that were met by the rounding the suite grew up with.  1 % is not worth re-basing those margins in the last round
-// (profiles/r06/r06u_ab_gjk_scan_wide.txt).
+// AGX_GJK_SCAN_WIDE (round 6).  The vertex scan of gjk_support is a chain of memory round trips, not of arithmetic: no address depends on a comparison,
+// but each round of the loop waits for its own loads (the compiler keeps the rounds of a loop with a per-lane trip count apart, and un-does a source-level
+// software pipeline).  0: the scan of rounds 3-5 -- vertex 0, then four vertices per round, then the winner loaded by index: five round trips for a
+// 16-vertex spoon piece.  2 (the DEFAULT): vertex 0 inside the first round and EIGHT vertices per round while more than four are left -- three round trips.
+// Same comparisons in the same order, and `R v + p` still works on a fresh 12-byte load: BIT-IDENTICAL with 0 on 13 task / robot combinations
+// (512-1,024 environments x 30-40 steps each, profiles/r06/r06w_*), 615.2 / 615.7 k against 610.6 / 610.5 k env-steps/s, same box, interleaved.
+// 1 (an A/B knob): the winner's coordinates carried along instead of re-loaded -- one round trip less, 614-621 k -- but the winner then sits in three
+// separate registers, and `R v + p`, which the compiler rounds differently at every inlined call site (packed products, partly fused chains), comes out with
+// other last bits whatever sequence is pinned (gjk_xf).  Two pinned sequences were run through the GPU suite: 203 of 205 tests passed each time, and each
+// time two OTHER tests on ill-conditioned states (a threshold contact of a crafted pressed state; the co-op arm one step after a classifier roll-back; a
+// wiping force) missed margins the suite's own rounding meets.  Not worth re-basing those margins (profiles/r06/r06u_ab_gjk_scan_wide.txt).
 #ifndef AGX_GJK_SCAN_WIDE
-#define AGX_GJK_SCAN_WIDE 0
+#define AGX_GJK_SCAN_WIDE 2
 #endif
 // R v + p of the scan's winner with ONE rounding sequence, p + fma(R2, z, fma(R1, y, [R0 x])), written with a product and a sum the compiler may not
 // contract or re-associate.  (Left to the compiler, `mul(R, v) + p` came out differently at every inlined call site -- packed products, partly fused
@@ -65,17 +68,18 @@ AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
     return best;
   }
   const v3 dl = gjk_local_dir(s.R, d);
-  // The scan is a chain of memory round trips, not of arithmetic: the address of no load depends on a comparison, but each round of a loop waits
-  // for its own loads.  Round 6 (AGX_GJK_SCAN_WIDE): vertex 0 is part of the first round (no separate first load), rounds hold EIGHT vertices
-  // while more than four are left (a 16-vertex spoon piece: two round trips instead of five), and the winner's coordinates are carried along
-  // instead of being loaded again at the end (one more round trip).  Indices are clamped to n-1: a repeated vertex never wins the strict
-  // comparison, so the first maximum is still the one returned -- the same vertex as the 4-per-round scan of rounds 3-5, to the bit.
+  // (AGX_GJK_SCAN_WIDE above.)  Indices are clamped to n-1: a repeated vertex never wins the strict comparison, so the first maximum is still the one
+  // returned -- the same vertex as the 4-per-round scan, to the bit.
   const float* V = s.v;
 #if AGX_GJK_SCAN_WIDE
   const int last = s.n - 1;
-  float bd = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f;
+  float bd = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f; int best = 0;
 #define GJK_LDV(j, kk) const int i##j = (kk) < last ? (kk) : last; const float x##j = V[3 * i##j], y##j = V[3 * i##j + 1], z##j = V[3 * i##j + 2];
+#if AGX_GJK_SCAN_WIDE == 2     // the winner by INDEX, loaded again at the end (one round trip more): `R v + p` keeps the operands -- a fresh 12-byte load -- it has in the 4-per-round scan
+#define GJK_CMP(j) { const float t = gjk_dot3(x##j, y##j, z##j, dl); if (t > bd) { bd = t; best = i##j; } }
+#else
 #define GJK_CMP(j) { const float t = gjk_dot3(x##j, y##j, z##j, dl); if (t > bd) { bd = t; bx = x##j; by = y##j; bz = z##j; } }
+#endif
   int k = 0;
   for (; s.n - k > 4; k += 8) {
     GJK_LDV(0, k) GJK_LDV(1, k + 1) GJK_LDV(2, k + 2) GJK_LDV(3, k + 3) GJK_LDV(4, k + 4) GJK_LDV(5, k + 5) GJK_LDV(6, k + 6) GJK_LDV(7, k + 7)
@@ -87,7 +91,13 @@ AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
   }
 #undef GJK_LDV
 #undef GJK_CMP
+#if AGX_GJK_SCAN_WIDE == 2
+  (void)bx; (void)by; (void)bz;
+  return mul(s.R, mk3(V[3 * best], V[3 * best + 1], V[3 * best + 2])) + s.p;
+#else
+  (void)best;
   return gjk_xf(s.R, s.p, bx, by, bz);
+#endif
 #else
   int best = 0;
   float bd = gjk_dot3(V[0], V[1], V[2], dl);

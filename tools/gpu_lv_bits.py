@@ -30,7 +30,7 @@ if os.environ.get('AGX_BITS_PARAM'):            # e.g. SOLVE_WIDE=0: the narrow 
     blob = ModelBlob.load('feeding_jaco')
     for kv in os.environ['AGX_BITS_PARAM'].split(','):
         k, v = kv.split('='); blob = blob.set_param(k, float(v))
-env = vec_env.FeedingJacoVecEnv(n, pool_size=64, seed=1001, blob=blob)
+env = getattr(vec_env, os.environ.get('AGX_BITS_ENV', 'FeedingJacoVecEnv'))(n, pool_size=64, seed=1001, **({'blob': blob} if blob is not None else {}))      # AGX_BITS_ENV: another task's VecEnv class
 env.reset()
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 rew = []

@@ -18,6 +18,7 @@
 #   env:VAR=VAL / unset:VAR   environment for the actions that follow (e.g. env:AGX_SOLVE_LDS_BYTES=12288)
 #   bits:<name>      tools/gpu_lv_bits.py: 40 steps of 1,024 FeedingJaco environments, default build against lib/variants/<name>.so, bit by bit -> bits_<name>.txt
 #   share[:N]        the driver's N-rank command (default 2) with all ranks on this box's one GPU: bench.py --gpus N --backend gloo --share-gpus -> share_gpus_N.json
+#   bitsenv:<name>,<VecEnv class>[,<class> ...]   the same for other tasks' environments (512 x 30 steps) -> bitsenv_<name>.txt
 #   ab:<name>        AGX_LIB=assistive_gym_amd/lib/variants/<name>.so bench.py --steps 300 (x2, interleaved with the default build) -> ab_<name>.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -64,6 +65,9 @@ for A in "$@"; do
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L', round(j['value']), round(j['ms_per_step'], 3), {k.split('_')[1]: round(v, 2) for k, v in j['roofline']['kernels_ms_per_step_summed_over_overlapping_launches'].items()})" | tee -a $O/ab_$V.txt
       done; done; unset AGX_LIB ;;
+    bitsenv) for E in $(echo "${V#*,}" | tr ',' ' '); do L=${V%%,*}
+        AGX_BITS_ENV=$E timeout 600 python tools/gpu_lv_bits.py /tmp/be_default.npz 512 30 > /dev/null 2>$O/bitsenv_$E.err; AGX_BITS_ENV=$E AGX_LIB=$R/assistive_gym_amd/lib/variants/$L.so timeout 600 python tools/gpu_lv_bits.py /tmp/be_$L.npz 512 30 > /dev/null 2>>$O/bitsenv_$E.err
+        echo "$E: $(python tools/gpu_lv_bits.py --compare /tmp/be_default.npz /tmp/be_$L.npz | tail -1)" | tee -a $O/bitsenv_$L.txt; done ;;
     bits) timeout 600 python tools/gpu_lv_bits.py /tmp/bits_default.npz 1024 40 > /dev/null 2>$O/bits_$V.err; AGX_LIB=$R/assistive_gym_amd/lib/variants/$V.so timeout 600 python tools/gpu_lv_bits.py /tmp/bits_$V.npz 1024 40 > /dev/null 2>>$O/bits_$V.err
       python tools/gpu_lv_bits.py --compare /tmp/bits_default.npz /tmp/bits_$V.npz | tail -2 | tee $O/bits_$V.txt ;;
     share) N=${V:-2}; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus $N --steps 50 --warmup 5 --backend gloo --share-gpus --no-cpu-baseline > $O/share_gpus_$N.json 2>$O/share_gpus_$N.err; echo "rc=$?"; line $O/share_gpus_$N.json; tail -3 $O/share_gpus_$N.err ;;
