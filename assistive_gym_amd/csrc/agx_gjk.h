@@ -41,6 +41,10 @@ AGX_DEV v3 gjk_vertex0(const gjk_shape& s) {
 #ifndef AGX_GJK_SCAN_WIDE
 #define AGX_GJK_SCAN_WIDE 2
 #endif
+#ifndef AGX_GJK_SCAN_ONE
+#define AGX_GJK_SCAN_ONE 1
+#endif
+
 // R v + p of the scan's winner with ONE rounding sequence, p + fma(R2, z, fma(R1, y, [R0 x])), written with a product and a sum the compiler may not
 // contract or re-associate.  (Left to the compiler, `mul(R, v) + p` came out differently at every inlined call site -- packed products, partly fused
 // chains, another pattern for the third component -- so the support points of A and of B were rounded by different rules, and neither like the CPU wave
@@ -81,6 +85,10 @@ AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
 #define GJK_CMP(j) { const float t = gjk_dot3(x##j, y##j, z##j, dl); if (t > bd) { bd = t; bx = x##j; by = y##j; bz = z##j; } }
 #endif
   int k = 0;
+#if AGX_GJK_SCAN_ONE
+  if (s.n > 1)       // a one-vertex core (a food particle, a bead of the tool) has nothing to scan: its support point is one round trip, not two
+#endif
+  {
   for (; s.n - k > 4; k += 8) {
     GJK_LDV(0, k) GJK_LDV(1, k + 1) GJK_LDV(2, k + 2) GJK_LDV(3, k + 3) GJK_LDV(4, k + 4) GJK_LDV(5, k + 5) GJK_LDV(6, k + 6) GJK_LDV(7, k + 7)
     GJK_CMP(0) GJK_CMP(1) GJK_CMP(2) GJK_CMP(3) GJK_CMP(4) GJK_CMP(5) GJK_CMP(6) GJK_CMP(7)
@@ -88,6 +96,7 @@ AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
   if (k < s.n) {
     GJK_LDV(0, k) GJK_LDV(1, k + 1) GJK_LDV(2, k + 2) GJK_LDV(3, k + 3)
     GJK_CMP(0) GJK_CMP(1) GJK_CMP(2) GJK_CMP(3)
+  }
   }
 #undef GJK_LDV
 #undef GJK_CMP
@@ -121,6 +130,9 @@ AGX_DEV v3 gjk_support(const gjk_shape& s, v3 d) {
 // scan, so -- when there are only a few of them -- the wave serves those lanes one at a time: 64 vertices per
 // step, one per lane, argmax by wave_max + ballot.  The lowest index among equal maxima wins, like the
 // sequential scan's strict comparison, so both paths return the same vertex.
+// (Tried at the end of round 6: two served lanes per turn and the winners loaded by their own lanes in one load behind the loop -- 618.0 / 618.4 k against
+// 616.8 / 616.6 k, and NOT bit-identical: `R v + p` moved out of the loop is rounded by another pattern.  The served scans are coalesced loads; they are
+// not where a pass waits.  Dropped: profiles/r06/r06z_ab_coop_scan_batched.txt.)
 #ifdef AGX_GJK_NO_COOP   // build-time knob for A/B runs: every lane scans its own hull
 constexpr int GJK_COOP_MIN = 32, GJK_COOP_MAX_LANES = 0;
 #else
