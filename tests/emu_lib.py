@@ -22,6 +22,7 @@ VARIANT_DEFS['drinking_m'] = ['-DAGX_MAX_FREE=1', '-DAGX_MAX_DOF=20', '-DAGX_MAX
 VARIANT_DEFS['feeding_abs_travel'] = ['-DAGX_NO_REL_TRAVEL']      # narrowphase limits from the per-collider (absolute) travel distances only
 VARIANT_DEFS['feeding_trace'] = ['-DAGX_EMU_TRACE_GJK']      # tests/diag/narrowphase_passes.py
 VARIANT_DEFS['feeding_trace_sched'] = ['-DAGX_EMU_TRACE_SCHED', '-DAGX_PGS_LV=3']      # tests/diag/solve_schedule_study.py
+VARIANT_DEFS['feeding_scan4'] = ['-DAGX_GJK_SCAN_WIDE=0', '-DAGX_GJK_SCAN_ONE=0']      # the 4-per-round support scan of rounds 3-5 (csrc/agx_gjk.h)
 VARIANT_DEFS['feeding_reg'] = ['-DAGX_PGS_LV=0']       # the register sweep of csrc/agx_pgs.h (its C++ twin) for the scenes that take the row-local sweep (csrc/agx_pgs_lv.h) by default
 VARIANT_DEFS['feeding_lv_cap'] = ['-DAGX_PGS_LV=2', '-DAGX_LV_WINDOW_CAP=300']       # the row-local sweep with a small LDS window: its rows-beyond-the-window path on ordinary scenes
 VARIANT_DEFS['feeding_lv2'] = ['-DAGX_PGS_LV=2']       # the row-local sweep with row headers, impulses and velocity slots in LDS (csrc/agx_pgs_lv.h); the default (0) is csrc/agx_pgs_lvw.h

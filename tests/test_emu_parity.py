@@ -694,3 +694,26 @@ def test_row_local_sweep_with_scalar_headers(blob):
             differs += int(not np.array_equal(s_s, s_r))
             s = s_s
     assert differs > 0                                     # (a row-local sweep ran, not the register sweep)
+
+
+def test_support_scan_rounds_are_bit_identical(blob):
+    """csrc/agx_gjk.h gjk_support: vertex 0 inside the first round, eight vertices per round, one-vertex cores not scanned (AGX_GJK_SCAN_WIDE 2,
+    AGX_GJK_SCAN_ONE 1: the default since the end of round 6) against the scan of rounds 3-5 (vertex 0, then four per round): the same comparisons in the
+    same order, the winner re-loaded by index -- states, observations, rewards and info agree BIT FOR BIT over settling and steps (on the GPU:
+    tests/test_gpu_solve_variants.py, and 13 task / robot combinations in profiles/r06/r06w_*, r06za_*)."""
+    from emu_lib import Emu
+    new, old = Emu(blob), Emu(blob, 'feeding_scan4')
+    st, _ = make_states(blob, 3, seed=3811)
+    rng = np.random.RandomState(12)
+    for i in range(3):
+        s = st[i].copy()
+        sn, so = s.copy(), s.copy()
+        new.settle(sn, 5); old.settle(so, 5)
+        assert np.array_equal(sn.view(np.uint32), so.view(np.uint32)), i
+        s = sn
+        for k in range(3):
+            a = rng.uniform(-1, 1, blob.act_dim).astype(np.float32)
+            s1, s0 = s.copy(), s.copy()
+            o1, r1, d1, i1, _ = new.step(s1, a); o0, r0, d0, i0, _ = old.step(s0, a)
+            assert np.array_equal(s1.view(np.uint32), s0.view(np.uint32)) and np.array_equal(o1, o0) and r1 == r0 and np.array_equal(i1, i0), (i, k)
+            s = s1

@@ -1,4 +1,5 @@
-"""-m gpu: the row-local Gauss-Seidel sweeps of the feeding variant compute the same bits.
+"""-m gpu: the row-local Gauss-Seidel sweeps of the feeding variant compute the same bits (and so do the two vertex scans of the GJK support function:
+lib/variants/scan4.so is the build with the 4-per-round scan of rounds 3-5, csrc/agx_gjk.h AGX_GJK_SCAN_WIDE).
   * csrc/agx_pgs_lvw.h (the default since round 6): up to four rows with disjoint velocity slots per visit, one per 16-lane group, list-scheduled
     per substep -- rows that share no slot commute exactly, rows that do keep their order;
   * csrc/agx_pgs_lvs.h (the default of round 5, now the fallback): one row per visit, row headers through scalar loads -- built by
@@ -17,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, 'tools', 'gpu_lv_bits.py')
 LV2 = os.path.join(ROOT, 'assistive_gym_amd', 'lib', 'variants', 'lv2.so')
 LVS = os.path.join(ROOT, 'assistive_gym_amd', 'lib', 'variants', 'lvs.so')
+SCAN4 = os.path.join(ROOT, 'assistive_gym_amd', 'lib', 'variants', 'scan4.so')
 
 
 def _rollout(out, env):
@@ -26,10 +28,11 @@ def _rollout(out, env):
 
 
 def test_row_local_sweeps_bit_identical(tmp_path):
-    assert os.path.exists(LV2) and os.path.exists(LVS), 'lib/variants/{lv2,lvs}.so are missing: run __graft_entry__.build()'
+    assert os.path.exists(LV2) and os.path.exists(LVS) and os.path.exists(SCAN4), 'lib/variants/{lv2,lvs,scan4}.so are missing: run __graft_entry__.build()'
     runs = {'wide (default)': {}, 'narrow build (lvs.so)': {'AGX_LIB': LVS}, 'headers in LDS (lv2.so)': {'AGX_LIB': LV2},
             'wide, smallest window': {'AGX_SOLVE_LDS_BYTES': '9536'},          # (the smallest solve launch: most friction rows lie beyond the window)
-            'wide build, SOLVE_WIDE = 0': {'AGX_BITS_PARAM': 'SOLVE_WIDE=0'}, 'wide, 12 KB': {'AGX_SOLVE_LDS_BYTES': '12288'}}
+            'wide build, SOLVE_WIDE = 0': {'AGX_BITS_PARAM': 'SOLVE_WIDE=0'}, 'wide, 12 KB': {'AGX_SOLVE_LDS_BYTES': '12288'},
+            'support scan of rounds 3-5 (scan4.so)': {'AGX_LIB': SCAN4}}
     paths = {}
     for k, (name, env) in enumerate(runs.items()):
         paths[name] = str(tmp_path / ('run%d.npz' % k))
