@@ -33,6 +33,7 @@ AGX_DEV v3 gjk_vertex0(const gjk_shape& s) {
 // 16-vertex spoon piece.  2 (the DEFAULT): vertex 0 inside the first round and EIGHT vertices per round while more than four are left -- three round trips.
 // Same comparisons in the same order, and `R v + p` still works on a fresh 12-byte load: BIT-IDENTICAL with 0 on 13 task / robot combinations
 // (512-1,024 environments x 30-40 steps each, profiles/r06/r06w_*), 615.2 / 615.7 k against 610.6 / 610.5 k env-steps/s, same box, interleaved.
+// (Sixteen per round: bit-identical too, 66 instead of 62 spilled registers, 609.7 / 610.0 k against 616.5 / 615.3 k -- eight it is.)
 // 1 (an A/B knob): the winner's coordinates carried along instead of re-loaded -- one round trip less, 614-621 k -- but the winner then sits in three
 // separate registers, and `R v + p`, which the compiler rounds differently at every inlined call site (packed products, partly fused chains), comes out with
 // other last bits whatever sequence is pinned (gjk_xf).  Two pinned sequences were run through the GPU suite: 203 of 205 tests passed each time, and each
